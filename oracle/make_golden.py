@@ -1,0 +1,394 @@
+"""Generate tests/golden/*.npz from the REFERENCE implementation (build container only).
+
+TEST INFRASTRUCTURE.  Run as ``python -m oracle.make_golden`` from the repo root.  Imports the
+reference from /root/reference through oracle/ref_import.py, feeds it seeded inputs and stores inputs +
+the reference's outputs.  Inputs that can be regenerated deterministically (synthetic weights through
+oracle/synth.py, one-hot tensors from base codes) are stored in their compact form.
+
+Fixture list:
+  G1  encode_*.npz        seq_digit_encoder / seq_ohe_encoder on strings with N runs, lowercase, IUPAC,
+                          both strands, chromosome-edge sites, clustered sites (merged windows)
+  G2  windowing.npz       bed_reader segment order + get_seqs_to_digitalized tuples
+  G3  snv_pretrained_*.npz  shipped checkpoints (weights included) -> log-probs
+  G4/5 snv_synth_*.npz    synthetic-weight S (10/1000) / T (5/100) / P (7/1000) configs, Network0/1/2
+  G6  snv_taps.npz        per-layer module outputs (forward hooks) for 2 windows
+  G7  snv_train_*.npz     one CE-sum training step: loss, every grad, BN running stats, grad-norm
+  G8  indel_*.npz         UNet_Small shipped checkpoints + a synthetic 2-class L=4000 model
+  G9  predict_m.npz       model_predict_m on 3 uneven batches
+  G10 batching.npz        generate_data_batches row order incl. tail carry-over
+"""
+import contextlib
+import io
+import os
+import sys
+from collections import namedtuple
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+
+from oracle import encode_ref, ref_import, synth  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden")
+REF = ref_import.REFERENCE_ROOT
+Row = namedtuple("Row", "chrom start stop name score strand")
+Row.end = property(lambda self: self.stop)
+
+
+def quiet(fn, *a, **k):
+    with contextlib.redirect_stdout(io.StringIO()):
+        return fn(*a, **k)
+
+
+def save(name, **arrays):
+    path = os.path.join(OUT, name)
+    np.savez_compressed(path, **arrays)
+    print(f"  wrote {name}  ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def unique_state(sd):
+    """Drop the ResBlock duplicate registrations (`.layer.N.`) -- restored on load."""
+    return {k: v.numpy() for k, v in sd.items() if ".layer." not in k}
+
+
+# ------------------------------------------------------------------------------------------ G1 / G2
+def make_chrom(rng, n):
+    seq = rng.choice(list("ACGT"), size=n)
+    seq[300:340] = "N"                       # N run
+    seq[1200:1203] = "N"
+    for pos, c in [(50, "R"), (51, "Y"), (700, "M"), (701, "S"), (702, "W"), (1500, "K"),
+                   (1501, "B"), (1502, "D"), (2000, "H"), (2001, "V")]:
+        seq[pos] = c
+    s = "".join(seq)
+    s = s[:2500] + s[2500:2600].lower() + s[2600:]     # soft-masked stretch
+    return s
+
+
+def make_sites(rng, n_chrom, n_sites, radius_hint):
+    starts = set(rng.integers(0, n_chrom, size=n_sites).tolist())
+    starts |= {0, 1, 2, 5, n_chrom - 1, n_chrom - 2, n_chrom - 6}          # chromosome edges
+    starts |= set(range(1000, 1012))                                        # clustered -> merged window
+    starts |= {295, 299, 300, 320, 339, 340, 345, 49, 52, 699, 703, 1499, 1503, 2003}  # around N/IUPAC
+    starts = sorted(starts)
+    strands = rng.choice(["+", "-"], size=len(starts)).tolist()
+    return starts, strands
+
+
+def ref_encode(prep, seq, rows, strand, radius, order, model_type, kind):
+    """Run the reference per merged segment for one strand group; rows must be sorted."""
+    outs = []
+    for start0, stop0, chrom, st, index, impute in prep.get_seqs_to_digitalized(seq, rows, radius, strand, model_type):
+        if kind == "kmer":
+            outs.append(prep.seq_digit_encoder(seq, start0, stop0, chrom, st, radius, index, order, impute, model_type))
+        else:
+            outs.append(np.stack(prep.seq_ohe_encoder(seq, start0, stop0, chrom, st, radius, index, impute, model_type)))
+    return np.concatenate(outs, axis=0)
+
+
+def g1_encode(ref):
+    prep = ref.preprocessing
+    rng = np.random.default_rng(101)
+    n_chrom = 5000
+    seq = make_chrom(rng, n_chrom)
+    starts, strands = make_sites(rng, n_chrom, 160, 10)
+    arrays = dict(seq=np.frombuffer(seq.encode(), dtype=np.uint8), starts=np.array(starts, np.int64),
+                  strands=np.array([s == "-" for s in strands], np.uint8))
+    for model_type in ("snv", "indel"):
+        for strand in "+-":
+            rows = [Row("chrT", s, s + 1, ".", 0, st) for s, st in zip(starts, strands) if st == strand]
+            tag = "pos" if strand == "+" else "neg"
+            for r, k in [(5, 3), (7, 3), (10, 3), (7, 1), (6, 2)]:
+                arrays[f"kmer_{model_type}_{tag}_r{r}_k{k}"] = ref_encode(prep, seq, rows, strand, r, k, model_type, "kmer")
+            for R in (100, 1000):
+                ohe = ref_encode(prep, seq, rows, strand, R, 1, model_type, "ohe")
+                # store compactly: the tensor takes only 15 distinct column patterns
+                arrays[f"ohe_{model_type}_{tag}_R{R}"] = ohe.astype(np.float32) if R == 100 else np.zeros(0, np.float32)
+                arrays[f"ohesum_{model_type}_{tag}_R{R}"] = np.array(
+                    [ohe.shape[0], ohe.shape[1], ohe.shape[2]], np.int64)
+                # position-weighted checksums pin the R=1000 tensor without storing 32 KB per row
+                w = (np.arange(ohe.shape[2], dtype=np.float64) % 97 + 1.0)
+                arrays[f"ohechk_{model_type}_{tag}_R{R}"] = (ohe.astype(np.float64) * w[None, None, :]).sum(axis=2)
+    save("encode.npz", **arrays)
+
+
+class FakeBed:
+    """Iterable of rows that passes the reference's isinstance(BedTool) check (BedTool is a placeholder)."""
+
+    def __init__(self, rows):
+        self.rows = rows
+
+    def __iter__(self):
+        return iter(self.rows)
+
+    def __len__(self):
+        return len(self.rows)
+
+
+def g2_windowing(ref):
+    prep = ref.preprocessing
+    rng = np.random.default_rng(202)
+    rows = []
+    for chrom, n in (("chrA", 40000), ("chrB", 25000)):
+        st = np.unique(rng.integers(0, n, size=120))
+        for s in st.tolist():
+            rows.append(Row(chrom, s, s + 1, ".", int(rng.integers(0, 4)), "+" if rng.random() < 0.5 else "-"))
+    FakeBedT = type("FakeBedT", (prep.BedTool, FakeBed), {})
+    bed = FakeBedT.__new__(FakeBedT)
+    FakeBed.__init__(bed, rows)
+    central = 10000
+    order_chrom, order_start, order_strand, seg_id = [], [], [], []
+    win = []
+    for g, (batch, strand) in enumerate(prep.bed_reader(bed, central)):
+        for row in batch:
+            order_chrom.append(0 if row.chrom == "chrA" else 1)
+            order_start.append(row.start)
+            order_strand.append(strand == "-")
+            seg_id.append(g)
+        n = 40000 if batch[0].chrom == "chrA" else 25000
+        for start0, stop0, chrom, st, index, impute in prep.get_seqs_to_digitalized("N" * n, batch, 1000, strand, "snv"):
+            win.append([g, start0, stop0, len(index), int(impute)])
+    save("windowing.npz",
+         in_chrom=np.array([0 if r.chrom == "chrA" else 1 for r in rows], np.int64),
+         in_start=np.array([r.start for r in rows], np.int64),
+         in_strand=np.array([r.strand == "-" for r in rows], np.uint8),
+         in_score=np.array([r.score for r in rows], np.int64),
+         chrom_len=np.array([40000, 25000], np.int64), central=np.array(central),
+         out_chrom=np.array(order_chrom, np.int64), out_start=np.array(order_start, np.int64),
+         out_strand=np.array(order_strand, np.uint8), out_group=np.array(seg_id, np.int64),
+         merged=np.array(win, np.int64))
+
+
+# ------------------------------------------------------------------------------------------ SNV models
+def snv_cfg(r, R, order=3, h1=150, h2=75, C=32, k=3, n_class=4, drops=(0.1, 0.1, 0.25)):
+    cfg = dict(local_radius=r, local_order=order, local_hidden1_size=h1, local_hidden2_size=h2, distal_radius=R,
+               emb_dropout=drops[0], local_dropout=drops[1], CNN_kernel_size=k, CNN_out_channels=C,
+               distal_fc_dropout=drops[2])
+    ncol = 2 * r + 1 - (order - 1)
+    common = dict(emb_dims=[(4 ** order + 1, 2)] * ncol, n_cont=0, n_class=n_class, distal_order=1, in_channels=4)
+    return cfg, common
+
+
+def snv_inputs(rng, B, r, R, order=3, with_amb=True):
+    """Random windows as base codes; a few rows get N runs / IUPAC codes (generic path)."""
+    L = 2 * R + 1
+    codes = rng.integers(0, 4, size=(B, L)).astype(np.uint8)
+    if with_amb and B >= 8:
+        codes[1, 5:40] = 4
+        codes[2, L // 2 - 3: L // 2 + 3] = 4
+        codes[3, 0] = 4
+        codes[3, L - 1] = 4
+        codes[4, L // 2 + 50] = 7          # 'M'
+        codes[4, 17] = 11                  # 'B'
+        codes[5, L // 2 - 100] = 4         # first column of the mid crop
+        codes[5, L // 2 + 100] = 4
+    # local k-mer ids derived from the same window (centre +-r), like the reference pipeline would
+    centre = codes[:, R - r: R + r + 1].astype(np.int64)
+    ncol = 2 * r + 1 - (order - 1)
+    cat = np.zeros((B, ncol), np.int64)
+    bad = np.zeros((B, ncol), bool)
+    for d in range(order):
+        col = centre[:, d: d + ncol]
+        bad |= col > 3
+        cat = cat * 4 + np.where(col > 3, 0, col)
+    cat = np.where(bad, 4 ** order, cat)
+    return codes, cat
+
+
+def codes_to_onehot(codes):
+    return torch.from_numpy(np.ascontiguousarray(encode_ref._OHE[codes].transpose(0, 2, 1)))
+
+
+def run_ref_snv(ref, model_no, cfg, common, sd, codes, cat, train=False):
+    model = quiet(ref.nn_utils.model_choice, model_no, cfg, common, "snv")
+    model.load_state_dict(sd)
+    model.train(train)
+    x = codes_to_onehot(codes)
+    cont = torch.zeros(len(cat), 1, dtype=torch.float64)
+    with torch.no_grad():
+        out = quiet(model.forward, (cont, torch.from_numpy(cat)), x)
+    return model, out.numpy()
+
+
+def g3_pretrained(ref):
+    rng = np.random.default_rng(303)
+    for tag, path, r, R, B in [("human_AT", "models/Homo_sapiens/SNV/AT", 7, 1000, 48),
+                               ("example_ckpt6", "examples/snv/models/checkpoint_6", 7, 200, 48)]:
+        sd = torch.load(os.path.join(REF, path, "model"), map_location="cpu")
+        cfg, common = snv_cfg(r, R)
+        codes, cat = snv_inputs(rng, B, r, R)
+        _, out = run_ref_snv(ref, 2, cfg, common, sd, codes, cat)
+        arrays = {"w::" + k: v for k, v in unique_state(sd).items()}
+        save(f"snv_pretrained_{tag}.npz", codes=codes, cat=cat, logp=out,
+             hp=np.array([r, 3, R, 150, 75, 32, 3, 4], np.int64), **arrays)
+
+
+def g45_synth(ref):
+    rng = np.random.default_rng(404)
+    # (tag, model_no, r, R, n_class, B, seed)
+    cases = [("S_net2", 2, 10, 1000, 4, 40, 11), ("T_net2", 2, 5, 100, 4, 40, 12), ("P_net2", 2, 7, 1000, 4, 24, 13),
+             ("S_net1", 1, 10, 1000, 4, 24, 14), ("S_net0", 0, 10, 1000, 4, 40, 15), ("R300_net2_c3", 2, 4, 300, 3, 24, 16),
+             ("R128_net2", 2, 7, 128, 4, 24, 17)]
+    for tag, model_no, r, R, n_class, B, seed in cases:
+        cfg, common = snv_cfg(r, R, n_class=n_class)
+        model = quiet(ref.nn_utils.model_choice, model_no, cfg, common, "snv")
+        sd = synth.synth_state_dict(model.state_dict(), seed)
+        codes, cat = snv_inputs(rng, B, r, R)
+        _, out = run_ref_snv(ref, model_no, cfg, common, sd, codes, cat)
+        save(f"snv_synth_{tag}.npz", codes=codes, cat=cat, out=out, seed=np.array(seed),
+             hp=np.array([r, 3, R, 150, 75, 32, 3, n_class, model_no], np.int64))
+
+
+def g6_taps(ref):
+    rng = np.random.default_rng(606)
+    r, R = 7, 1000
+    cfg, common = snv_cfg(r, R)
+    model = quiet(ref.nn_utils.model_choice, 2, cfg, common, "snv")
+    sd = synth.synth_state_dict(model.state_dict(), 21)
+    model.load_state_dict(sd)
+    model.eval()
+    codes, cat = snv_inputs(rng, 2, r, R, with_amb=False)
+    taps = {}
+    names = ["maxpool1", "RBs1", "maxpool2", "conv2", "RBs2", "maxpool3", "conv3", "distal_fc1",
+             "maxpool1_2", "RBs1_2", "maxpool2_2", "conv2_2", "RBs2_2", "maxpool3_2", "conv3_2", "distal_fc2",
+             "local_fc"]
+    hooks = [getattr(model, n).register_forward_hook(lambda m, i, o, n=n: taps.__setitem__(n, o.detach().numpy().copy()))
+             for n in names]
+    x = codes_to_onehot(codes)
+    with torch.no_grad():
+        out = quiet(model.forward, (torch.zeros(2, 1, dtype=torch.float64), torch.from_numpy(cat)), x)
+    for h in hooks:
+        h.remove()
+    save("snv_taps.npz", codes=codes, cat=cat, out=out.numpy(), seed=np.array(21),
+         hp=np.array([r, 3, R, 150, 75, 32, 3, 4, 2], np.int64), **{"tap::" + k: v for k, v in taps.items()})
+
+
+def g7_train(ref):
+    rng = np.random.default_rng(707)
+    for tag, r, R, B, seed in [("T", 5, 100, 32, 31), ("S", 10, 1000, 12, 32)]:
+        cfg, common = snv_cfg(r, R, drops=(0.0, 0.0, 0.0))
+        model = quiet(ref.nn_utils.model_choice, 2, cfg, common, "snv")
+        sd = synth.synth_state_dict(model.state_dict(), seed)
+        model.load_state_dict(sd)
+        model.train()
+        codes, cat = snv_inputs(rng, B, r, R, with_amb=False)
+        y = rng.choice(4, size=B, p=[0.85, 0.05, 0.05, 0.05]).astype(np.int64)
+        x = codes_to_onehot(codes)
+        crit = nn.CrossEntropyLoss(reduction="sum")
+        preds = quiet(model.forward, (torch.zeros(B, 1, dtype=torch.float64), torch.from_numpy(cat)), x)
+        loss = crit(preds, torch.from_numpy(y))
+        model.zero_grad()
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9)
+        arrays = {}
+        for k, p in model.named_parameters():
+            if ".layer." in k:
+                continue
+            arrays["g::" + k] = p.grad.numpy() if p.grad is not None else np.zeros(0, np.float32)
+        for k, b in model.named_buffers():
+            if ".layer." in k or k.endswith("num_batches_tracked"):
+                continue
+            arrays["b::" + k] = b.numpy()
+        save(f"snv_train_{tag}.npz", codes=codes, cat=cat, y=y, seed=np.array(seed), loss=np.array(loss.item()),
+             preds=preds.detach().numpy(), gnorm=np.array(float(gnorm)),
+             hp=np.array([r, 3, R, 150, 75, 32, 3, 4, 2], np.int64), **arrays)
+
+
+# ------------------------------------------------------------------------------------------ INDEL
+def g8_indel(ref):
+    rng = np.random.default_rng(808)
+    for tag, path, R, n_class, rev, B in [("human_insertion", "models/Homo_sapiens/INDEL/insertion", 4000, 8, True, 6),
+                                          ("human_deletion_start", "models/Homo_sapiens/INDEL/deletion_start", 4000, 8, False, 6)]:
+        sd = torch.load(os.path.join(REF, path, "model"), map_location="cpu")
+        cfg = dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=[1, 4, 5, 5, 5, 2], use_reverse=rev)
+        common = dict(n_class=n_class)
+        model = quiet(ref.nn_utils.model_choice, 0, cfg, common, "indel")
+        model.load_state_dict(sd)
+        model.eval()
+        codes = rng.integers(0, 4, size=(B, 2 * R)).astype(np.uint8)
+        codes[1, 100:160] = 4
+        codes[2, 4000] = 9
+        with torch.no_grad():
+            out = model(codes_to_onehot(codes)).numpy()
+        save(f"indel_pretrained_{tag}.npz", codes=codes, out=out, hp=np.array([R, 8, 7, n_class, int(rev)], np.int64),
+             down=np.array([1, 4, 5, 5, 5, 2], np.int64), **{"w::" + k: v.numpy() for k, v in sd.items()})
+    for tag, R, n_class, rev, seed, B in [("synth_c2_rev", 2000, 2, True, 41, 6), ("synth_c2", 2000, 2, False, 42, 6),
+                                          ("synth_small", 500, 8, True, 43, 10)]:
+        cfg = dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=[1, 4, 5, 5, 5, 2], use_reverse=rev)
+        model = quiet(ref.nn_utils.model_choice, 0, cfg, dict(n_class=n_class), "indel")
+        sd = synth.synth_state_dict(model.state_dict(), seed)
+        model.load_state_dict(sd)
+        model.eval()
+        codes = rng.integers(0, 4, size=(B, 2 * R)).astype(np.uint8)
+        codes[1, 10:60] = 4
+        with torch.no_grad():
+            out = model(codes_to_onehot(codes)).numpy()
+        save(f"indel_{tag}.npz", codes=codes, out=out, seed=np.array(seed),
+             hp=np.array([R, 8, 7, n_class, int(rev)], np.int64), down=np.array([1, 4, 5, 5, 5, 2], np.int64))
+
+
+# ------------------------------------------------------------------------------------------ G9 / G10
+def g9_predict_m(ref):
+    rng = np.random.default_rng(909)
+    r, R = 5, 100
+    cfg, common = snv_cfg(r, R)
+    model = quiet(ref.nn_utils.model_choice, 2, cfg, common, "snv")
+    sd = synth.synth_state_dict(model.state_dict(), 51)
+    model.load_state_dict(sd)
+    sizes = [16, 16, 5]
+    codes, cat = snv_inputs(rng, sum(sizes), r, R)
+    y = rng.integers(0, 4, size=(sum(sizes), 1)).astype(np.float32)
+    x = codes_to_onehot(codes)
+    batches, o = [], 0
+    for n in sizes:
+        batches.append((torch.from_numpy(y[o:o + n]), torch.zeros(n, 1, dtype=torch.float64),
+                        torch.from_numpy(cat[o:o + n]), x[o:o + n]))
+        o += n
+    pred, total = quiet(ref.nn_utils.model_predict_m, model, batches, nn.CrossEntropyLoss(reduction="sum"),
+                        torch.device("cpu"), 4, True, "snv")
+    save("predict_m.npz", codes=codes, cat=cat, y=y, sizes=np.array(sizes), pred=pred.numpy(), total_loss=np.array(total),
+         seed=np.array(51), hp=np.array([r, 3, R, 150, 75, 32, 3, 4, 2], np.int64))
+
+
+def g10_batching(ref):
+    prep = ref.preprocessing
+    out = {}
+    for case, (seg_sizes, bs, nseg) in {"a": ([5, 7, 3], 4, 1), "b": ([5, 7, 3], 4, 2), "c": ([9, 2, 2, 6], 5, 3),
+                                        "d": ([3, 3], 8, 1)}.items():
+        segs, o = [], 0
+        for n in seg_sizes:
+            ids = torch.arange(o, o + n, dtype=torch.float32).reshape(1, n, 1)
+            segs.append((ids, torch.zeros(1, n, 1), ids.long().reshape(1, n, 1).repeat(1, 1, 3),
+                         ids.reshape(1, n, 1, 1).repeat(1, 1, 4, 6)))
+            o += n
+        rows, cuts = [], []
+        for y, cont, cat, dist in prep.generate_data_batches(segs, nseg, bs, shuffle=False):
+            rows.extend(y[:, 0].long().tolist())
+            cuts.append(y.shape[0])
+            assert cont.dtype == torch.float64 and cont.shape == (y.shape[0], 1)
+        out[f"{case}_sizes"] = np.array(seg_sizes)
+        out[f"{case}_bs_nseg"] = np.array([bs, nseg])
+        out[f"{case}_rows"] = np.array(rows)
+        out[f"{case}_cuts"] = np.array(cuts)
+    save("batching.npz", **out)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    ref = ref_import.load()
+    only = set(sys.argv[1:])
+    steps = dict(g1=g1_encode, g2=g2_windowing, g3=g3_pretrained, g45=g45_synth, g6=g6_taps, g7=g7_train,
+                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching)
+    for name, fn in steps.items():
+        if only and name not in only:
+            continue
+        print(name)
+        fn(ref)
+
+
+if __name__ == "__main__":
+    main()
