@@ -1,0 +1,152 @@
+/*
+ * mural_hip.h -- C ABI of libmural_hip.so, the MI355X (gfx950) hot path for MuRaL models.
+ *
+ * The reference (CaiLiLab/MuRaL) has no FFI layer: its seam is the Python nn.Module protocol of the
+ * classes returned by MuRaL/model/nn_utils.py:186 (model_choice).  Each entry point below names the
+ * reference interface it replaces (file:line relative to the reference tree).  The binding that a
+ * maintainer would add on the reference side is a ctypes stub; see INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain C types only; device pointers are raw HIP device addresses the caller owns ("dev"),
+ *     host pointers are marked "host".  The library borrows every pointer for the duration of one call.
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, nothing synchronises.
+ *   - return value: 0 = ok, otherwise a MURAL_E_* code; mural_last_error() gives the message of the
+ *     last failure on the calling thread.
+ *   - fp32 everywhere; integer outputs are bit-exact w.r.t. the reference.
+ */
+#ifndef MURAL_HIP_H
+#define MURAL_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+  MURAL_OK = 0,
+  MURAL_E_INVALID = 1,     /* bad argument / unsupported configuration (maps to ValueError)        */
+  MURAL_E_RUNTIME = 2,     /* HIP runtime failure (maps to RuntimeError)                            */
+  MURAL_E_WORKSPACE = 3,   /* workspace too small                                                   */
+  MURAL_E_ENCODING = 4     /* dense distal input holds a column that is not a MuRaL one-hot/IUPAC
+                              column (reported asynchronously through the status word, see below)   */
+};
+
+const char* mural_last_error(void);
+int mural_abi_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Genome in packed form (product input format):
+ *   packed2 : 16 bases per uint32, base i in bits [2*(i%16), +2)  (A0 C1 G2 T3; 0 where masked)
+ *   nmask   : 32 bases per uint32, bit (i%32) set when the base is not one of ACGT
+ * Bases outside [0, length) read as 'N' (the reference imputes chromosome ends with 'N',
+ * MuRaL/data/preprocessing.py:682-695, :791-804).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {
+  const uint32_t* packed2;   /* dev */
+  const uint32_t* nmask;     /* dev */
+  int64_t length;            /* bases in this chromosome */
+} MuralGenome;
+
+/* Replaces seq_digit_encoder (MuRaL/data/preprocessing.py:636-723) for one site per row.
+ * out: dev int64 [n][2*radius + (indel?0:1) - (order-1)], values in [0, 4^order].
+ * strand: dev uint8 [n], 0 = '+', 1 = '-'.  indel != 0 selects the indel window (:564-566).      */
+int mural_encode_kmer(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
+                      int32_t radius, int32_t order, int32_t indel, int64_t* out, void* stream);
+
+/* Replaces seq_ohe_encoder (MuRaL/data/preprocessing.py:756-816) for packed (ACGT/N) genomes.
+ * out: dev float [n][4][2*radius + (indel?0:1)].                                                   */
+int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
+                        int32_t radius, int32_t indel, float* out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SNV model family (Network0 / Network1 / Network2, MuRaL/model/model_snv.py:19-525), eval mode.
+ * Raw parameters are handed over as HOST pointers in the reference's state_dict naming; the library
+ * folds BatchNorm running statistics, builds the first-layer 3-mer lookup tables and the MFMA weight
+ * fragments, and keeps device copies inside the opaque handle.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { const float *weight, *bias, *running_mean, *running_var; } MuralBN;   /* host, [C] each */
+typedef struct { const float *weight, *bias; } MuralAffine;                             /* host */
+
+typedef struct {            /* ResBlock, model_snv.py:794-812 */
+  MuralBN bn1; MuralAffine conv1;   /* conv weight [C][C][3] */
+  MuralBN bn2; MuralAffine conv2;
+} MuralResBlock;
+
+typedef struct {            /* one conv tower, model_snv.py:350-388 (mid) / :392-430 (large) */
+  MuralBN bn_in;  MuralAffine conv_in;     /* conv1.0 / conv1.1   weight [C][4][K] */
+  MuralResBlock rbs1[2];                    /* RBs1.{0,1} */
+  MuralBN bn_mid; MuralAffine conv_mid;    /* conv2.0 / conv2.1   weight [C][C][K] */
+  MuralResBlock rbs2[2];                    /* RBs2.{0,1} */
+  MuralBN bn_out; MuralAffine conv_out;    /* conv3.0 / conv3.1 (+ReLU) */
+  MuralBN fc_bn;  MuralAffine fc;          /* distal_fc.0 / distal_fc.2  weight [n_class][C] */
+} MuralTower;
+
+typedef struct {            /* local branch, model_snv.py:322-339 */
+  const float* emb;                         /* emb_layer.weight [emb_rows][5] */
+  MuralAffine lin[2];                       /* lin_layers.{0,1}: [h1][5*cols], [h2][h1] */
+  MuralBN bn[2];                            /* bn_layers.{0,1} */
+  MuralAffine out;                          /* local_fc.0 (Network2) / model.output_layer (Network0) */
+} MuralLocal;
+
+typedef struct {
+  int32_t model_no;        /* 0 local-only, 1 towers only, 2 both (nn_utils.py:213-216)            */
+  int32_t n_class;
+  int32_t local_cols;      /* number of k-mer columns = len(emb_dims)                              */
+  int32_t emb_rows;        /* 4^local_order + 1                                                    */
+  int32_t hidden1, hidden2;
+  int32_t channels;        /* CNN_out_channels (this build: 32)                                    */
+  int32_t ksize;           /* CNN_kernel_size  (this build: 3)                                     */
+  int32_t distal_len;      /* 2*distal_radius + 1                                                  */
+  float bn_eps;            /* 1e-5 */
+} MuralSnvShape;
+
+typedef struct { MuralLocal local; MuralTower mid, large; } MuralSnvParams;
+
+typedef struct MuralSnvModel MuralSnvModel;
+
+int  mural_snv_model_create(const MuralSnvShape* shape, const MuralSnvParams* host_params, MuralSnvModel** out);
+void mural_snv_model_destroy(MuralSnvModel* m);
+
+/* scratch the forward calls need for a batch of n rows (bytes; allocate once, reuse).
+ * dense != 0: for mural_snv_forward_dense (adds n*distal_len symbol bytes); 0: for mural_snv_forward_packed */
+size_t mural_snv_workspace_bytes(const MuralSnvModel* m, int64_t n, int32_t dense);
+
+/* Replaces Network{0,1,2}.forward((cont_x, cat_x), distal_x) (model_snv.py:104-108, :226-287, :439-525)
+ * for already-encoded tensors.  cat_x: dev int64 [n][local_cols] (ignored for model_no 1);
+ * distal_x: dev float [n][4][distal_len] contiguous (ignored for model_no 0).
+ * out: dev float [n][n_class] -- log-probabilities (Network1/2) or raw logits (Network0).
+ * status: dev int32[1], set to MURAL_E_ENCODING by the kernels if a distal column is not a MuRaL
+ * encoding (caller checks after synchronising); may be NULL.                                       */
+int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
+                            float* out, void* workspace, size_t workspace_bytes, int32_t* status, void* stream);
+
+/* Fused encode + forward straight from the packed genome: the path `mural_snv predict` takes
+ * (replaces preprocessing.py:636-723 + :756-816 + model_snv.py:439-525 for n sites).
+ * local_radius / local_order describe the k-mer window of the local branch.                        */
+int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenome* g, const int64_t* pos,
+                             const uint8_t* strand, int64_t n, int32_t local_radius, int32_t local_order,
+                             float* out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* Debug/validation hook used by the parity tests: same as forward_dense for the first tile, and dumps
+ * the LDS-resident stage outputs of that tile to `taps` (dev float, see mural_snv_tap_layout).      */
+int mural_snv_debug_taps(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
+                         float* out, void* workspace, size_t workspace_bytes, float* taps, size_t taps_floats,
+                         void* stream);
+/* geometry of the fused kernel for this model: fills out[0..15] =
+ * {P, NBUF_floats, L2_large, L3_large, L4_large, L2_mid, L3_mid, L4_mid, n_tap_slots, ...}          */
+int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* out16);
+
+/* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
+const char* mural_snv_kernel_name(void);
+
+/* Live timing of the dominant kernel: between begin and end every launch of it is bracketed by HIP events
+ * on the launch stream; end() synchronises those events and returns the summed duration and the count.  */
+int mural_profile_begin(void);
+int mural_profile_end(double* total_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MURAL_HIP_H */

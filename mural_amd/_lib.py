@@ -1,0 +1,115 @@
+"""ctypes binding of libmural_hip.so (the C ABI declared in include/mural_hip.h).
+
+The product has NO CPU fallback: if the shared library is missing or a tensor is not on a HIP device the
+call fails loudly.  Build with ``python -c "import __graft_entry__ as g; g.build()"`` (or ``make -C
+mural_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+import torch  # noqa: F401  -- must be loaded BEFORE the extension so both share torch's HIP runtime (libamdhip64)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmural_hip.so")
+
+MURAL_OK, MURAL_E_INVALID, MURAL_E_RUNTIME, MURAL_E_WORKSPACE, MURAL_E_ENCODING = 0, 1, 2, 3, 4
+
+_f32p = C.POINTER(C.c_float)
+
+
+class MuralGenome(C.Structure):
+    _fields_ = [("packed2", C.c_void_p), ("nmask", C.c_void_p), ("length", C.c_int64)]
+
+
+class MuralBN(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p)]
+
+
+class MuralAffine(C.Structure):
+    _fields_ = [("weight", C.c_void_p), ("bias", C.c_void_p)]
+
+
+class MuralResBlock(C.Structure):
+    _fields_ = [("bn1", MuralBN), ("conv1", MuralAffine), ("bn2", MuralBN), ("conv2", MuralAffine)]
+
+
+class MuralTower(C.Structure):
+    _fields_ = [("bn_in", MuralBN), ("conv_in", MuralAffine), ("rbs1", MuralResBlock * 2),
+                ("bn_mid", MuralBN), ("conv_mid", MuralAffine), ("rbs2", MuralResBlock * 2),
+                ("bn_out", MuralBN), ("conv_out", MuralAffine), ("fc_bn", MuralBN), ("fc", MuralAffine)]
+
+
+class MuralLocal(C.Structure):
+    _fields_ = [("emb", C.c_void_p), ("lin", MuralAffine * 2), ("bn", MuralBN * 2), ("out", MuralAffine)]
+
+
+class MuralSnvShape(C.Structure):
+    _fields_ = [("model_no", C.c_int32), ("n_class", C.c_int32), ("local_cols", C.c_int32), ("emb_rows", C.c_int32),
+                ("hidden1", C.c_int32), ("hidden2", C.c_int32), ("channels", C.c_int32), ("ksize", C.c_int32),
+                ("distal_len", C.c_int32), ("bn_eps", C.c_float)]
+
+
+class MuralSnvParams(C.Structure):
+    _fields_ = [("local", MuralLocal), ("mid", MuralTower), ("large", MuralTower)]
+
+
+# every symbol include/mural_hip.h declares: name -> (restype, argtypes)
+PROTOTYPES = {
+    "mural_last_error": (C.c_char_p, []),
+    "mural_abi_version": (C.c_int, []),
+    "mural_encode_kmer": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p, C.c_void_p]),
+    "mural_encode_onehot": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                      C.c_void_p, C.c_void_p]),
+    "mural_snv_model_create": (C.c_int, [C.POINTER(MuralSnvShape), C.POINTER(MuralSnvParams), C.POINTER(C.c_void_p)]),
+    "mural_snv_model_destroy": (None, [C.c_void_p]),
+    "mural_snv_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
+    "mural_snv_forward_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                          C.c_size_t, C.c_void_p, C.c_void_p]),
+    "mural_snv_forward_packed": (C.c_int, [C.c_void_p, C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64,
+                                           C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mural_snv_debug_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mural_snv_tap_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mural_snv_kernel_name": (C.c_char_p, []),
+    "mural_profile_begin": (C.c_int, []),
+    "mural_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the shared library with typed prototypes; raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                "Run `make -C mural_amd/csrc` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback.")
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc):
+    if rc == MURAL_OK:
+        return
+    msg = lib().mural_last_error().decode("utf-8", "replace")
+    if rc == MURAL_E_INVALID:
+        raise ValueError(msg)
+    raise RuntimeError(f"libmural_hip error {rc}: {msg}")
+
+
+def require_cuda(t, name):
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must live on a HIP device (got {t.device}); mural_amd has no CPU path")
+    return t
+
+
+def current_stream_ptr(device):
+    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)

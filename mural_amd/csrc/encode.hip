@@ -1,0 +1,167 @@
+// Window encoders on the GPU: k-mer index, one-hot, and dense-tensor -> symbol classification.
+// Reference semantics: MuRaL/data/preprocessing.py:636-723 (k-mer), :756-816 (one-hot), :559-567 (windows).
+#include "common.h"
+
+namespace mural {
+
+static thread_local std::string g_err;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_err = buf;
+}
+
+const char* last_error_cstr() { return g_err.c_str(); }
+
+// one thread per (row, column): order-k index over the strand-oriented window
+__global__ void encode_kmer_kernel(MuralGenome g, const int64_t* __restrict__ pos, const uint8_t* __restrict__ strand,
+                                   int64_t n, int off, int width, int order, int ncol, int64_t* __restrict__ out) {
+  const int64_t total = n * ncol;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / ncol;
+    const int col = (int)(i - row * ncol);
+    const int64_t ws = pos[row] + off;
+    const bool neg = strand[row] != 0;
+    int64_t val = 0;
+    bool bad = false;
+    for (int d = 0; d < order; ++d) {
+      const int j = col + d;  // index in the strand-oriented window
+      uint32_t s = neg ? genome_sym(g.packed2, g.nmask, g.length, ws + (width - 1 - j))
+                       : genome_sym(g.packed2, g.nmask, g.length, ws + j);
+      if (s > 3u) bad = true;
+      if (neg) s = 3u - (s & 3u);
+      val = val * 4 + (int64_t)(s & 3u);
+    }
+    int64_t sentinel = 1;
+    for (int d = 0; d < order; ++d) sentinel *= 4;
+    out[i] = bad ? sentinel : val;
+  }
+}
+
+// one thread per (row, column): writes the 4 channel values (coalesced along the column axis per channel)
+__global__ void encode_onehot_kernel(MuralGenome g, const int64_t* __restrict__ pos, const uint8_t* __restrict__ strand,
+                                     int64_t n, int off, int width, float* __restrict__ out) {
+  const int64_t total = n * width;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / width;
+    const int j = (int)(i - row * width);
+    const int64_t ws = pos[row] + off;
+    const bool neg = strand[row] != 0;
+    uint32_t s = neg ? genome_sym(g.packed2, g.nmask, g.length, ws + (width - 1 - j))
+                     : genome_sym(g.packed2, g.nmask, g.length, ws + j);
+    if (neg) s = sym_complement(s);
+    float* o = out + row * 4 * (int64_t)width + j;
+#pragma unroll
+    for (int ch = 0; ch < 4; ++ch) o[(int64_t)ch * width] = (s > 3u) ? 0.25f : (s == (uint32_t)ch ? 1.0f : 0.0f);
+  }
+}
+
+__device__ __forceinline__ int frac_digit(float v) {
+  if (v == 0.0f) return 0;
+  if (v == 1.0f) return 1;
+  if (v == 0.5f) return 2;
+  if (v == 0.25f) return 3;
+  if (v == (float)(1.0 / 3.0)) return 4;
+  return -1;
+}
+
+// dense (n,4,L) one-hot / IUPAC-fraction tensor -> 1 symbol per column (what the fused kernel consumes)
+__global__ void dense_to_symbols_kernel(const float* __restrict__ x, int64_t n, int L, uint8_t* __restrict__ sym,
+                                        int32_t* __restrict__ status) {
+  const int64_t total = n * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / L;
+    const int j = (int)(i - row * L);
+    const float* p = x + row * 4 * (int64_t)L + j;
+    const int d0 = frac_digit(p[0]), d1 = frac_digit(p[L]), d2 = frac_digit(p[2 * (int64_t)L]), d3 = frac_digit(p[3 * (int64_t)L]);
+    int s = -1;
+    if ((d0 | d1 | d2 | d3) >= 0) {
+      switch (d0 + 5 * d1 + 25 * d2 + 125 * d3) {
+        case 1: s = 0; break;      // A
+        case 5: s = 1; break;      // C
+        case 25: s = 2; break;     // G
+        case 125: s = 3; break;    // T
+        case 468: s = 4; break;    // N
+        case 52: s = 5; break;     // R
+        case 260: s = 6; break;    // Y
+        case 12: s = 7; break;     // M
+        case 60: s = 8; break;     // S
+        case 252: s = 9; break;    // W
+        case 300: s = 10; break;   // K
+        case 620: s = 11; break;   // B
+        case 604: s = 12; break;   // D
+        case 524: s = 13; break;   // H
+        case 124: s = 14; break;   // V
+        default: break;
+      }
+    }
+    if (s < 0) {
+      s = SYM_N;
+      if (status) atomicOr(status, (int)MURAL_E_ENCODING);
+    }
+    sym[i] = (uint8_t)s;
+  }
+}
+
+int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream) {
+  const int64_t total = n * L;
+  if (total == 0) return MURAL_OK;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block < 8192 ? (total + block - 1) / block : 8192);
+  hipLaunchKernelGGL(dense_to_symbols_kernel, dim3(grid), dim3(block), 0, stream, x, n, L, sym, status);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural
+
+using namespace mural;
+
+extern "C" const char* mural_last_error(void) { return mural::last_error_cstr(); }
+extern "C" int mural_abi_version(void) { return 1; }
+
+static int window_geometry(int radius, int indel, int* off, int* width) {
+  MURAL_REQUIRE(radius >= 1, "radius must be >= 1, got %d", radius);
+  *off = indel ? -radius + 1 : -radius;
+  *width = indel ? 2 * radius : 2 * radius + 1;
+  return MURAL_OK;
+}
+
+extern "C" int mural_encode_kmer(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
+                                 int32_t radius, int32_t order, int32_t indel, int64_t* out, void* stream) {
+  MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
+  MURAL_REQUIRE(order >= 1 && order <= 12, "local_order must be in [1,12], got %d", order);
+  int off, width;
+  if (int rc = window_geometry(radius, indel, &off, &width)) return rc;
+  const int ncol = width - (order - 1);
+  MURAL_REQUIRE(ncol >= 1, "window too short for order %d", order);
+  if (n == 0) return MURAL_OK;
+  MURAL_REQUIRE(pos && strand && out, "pos/strand/out must not be NULL");
+  const int64_t total = n * ncol;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block < 8192 ? (total + block - 1) / block : 8192);
+  hipLaunchKernelGGL(encode_kmer_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *g, pos, strand, n, off, width,
+                     order, ncol, out);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+extern "C" int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
+                                   int32_t radius, int32_t indel, float* out, void* stream) {
+  MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
+  int off, width;
+  if (int rc = window_geometry(radius, indel, &off, &width)) return rc;
+  if (n == 0) return MURAL_OK;
+  MURAL_REQUIRE(pos && strand && out, "pos/strand/out must not be NULL");
+  const int64_t total = n * width;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block < 16384 ? (total + block - 1) / block : 16384);
+  hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *g, pos, strand, n, off,
+                     width, out);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}

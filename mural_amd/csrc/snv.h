@@ -1,0 +1,92 @@
+// Device-side data model of the fused SNV forward (shared by the host folder and the kernels).
+#pragma once
+#include "common.h"
+
+namespace mural {
+
+constexpr int SNV_C = 32;          // conv channels handled by the MFMA path
+constexpr int SNV_K = 3;           // conv taps
+constexpr int SNV_NLAYER = 10;     // C->C convs per tower: 4 (RBs1) + conv2 + 4 (RBs2) + conv3
+constexpr int SNV_KSTEPS = 24;     // 96 / 4 k-steps of v_mfma_f32_16x16x4_f32
+constexpr int SNV_WFRAG = 2 * SNV_KSTEPS * 64;   // floats per layer: [mblock][kstep][lane]
+constexpr int SNV_LUT = 125 * SNV_C;             // 3-mer lookup table (A,C,G,T,N)^3 x channels
+constexpr int SNV_TAPS = 3 * N_SYM * SNV_C;      // per-tap, per-symbol contributions (generic path)
+constexpr int SNV_MAXCLASS = 16;
+constexpr int SNV_NBMAX = 6;       // max 16-column blocks a wave owns in one stage
+constexpr int SNV_THREADS = 256;
+constexpr int SNV_WAVES = SNV_THREADS / 64;
+constexpr int SNV_MID_HALF = 100;  // model_snv.py:473
+
+// layer roles inside a tower (index into wfrag / bias / post_s / post_t)
+enum { L_RB1A_C1 = 0, L_RB1A_C2, L_RB1B_C1, L_RB1B_C2, L_CONV2, L_RB2A_C1, L_RB2A_C2, L_RB2B_C1, L_RB2B_C2, L_CONV3 };
+// standalone BN affine maps (index into ex_s / ex_t)
+enum { EX_RB1_ENTRY = 0, EX_BN_MID = 1, EX_BN_OUT = 2, EX_FC_BN = 3, EX_COUNT = 4 };
+
+struct TowerGeom {
+  int L1;          // columns of the tower input (2R+1 for large, 201 for mid)
+  int col0;        // first column of the tower input inside the window (crop start)
+  int L[3];        // lengths after maxpool1/2/3  (L2, L3, L4)
+  int pk[3], ps[3], pp[3];   // pool kernel / stride / pad
+  int Sc[3];       // column stride per position in the flattened geometry (= L + 1 separator)
+  int NC[3];       // logical columns: 1 + P*Sc
+  int nb[3];       // 16-column MFMA blocks covering [0, NC)
+  FastDiv dL[3];   // divide by L[i]
+  FastDiv dSc[3];  // divide by Sc[i]
+};
+
+struct TowerDev {                 // all device pointers into one blob
+  const float* lut;               // [125][32]
+  const float* taps;              // [3][16][32]
+  const float* bias0;             // [32] first-layer conv bias
+  const float* wfrag;             // [10][SNV_WFRAG]
+  const float* bias;              // [10][32]
+  const float* post_s;            // [10][32] BN scale applied to relu(layer output) for the next conv
+  const float* post_t;            // [10][32]
+  const float* ex_s;              // [4][32]
+  const float* ex_t;              // [4][32]
+  const float* fc_w;              // [n_class][32]
+  const float* fc_b;              // [n_class]
+};
+
+struct LocalDev {
+  const float* emb;               // [emb_rows][5]
+  const float* w1t;               // [in1][h1]  (transposed lin_layers.0.weight), in1 = 5*cols
+  const float* b1;                // [h1]
+  const float* w2t;               // [h1][h2]   BN0 folded in
+  const float* b2;                // [h2]
+  const float* w3t;               // [h2][n_class]  BN1 folded in
+  const float* b3;                // [n_class]
+  int cols, emb_rows, in1, h1, h2, n_class;
+};
+
+struct SnvFwdArgs {
+  TowerGeom geom[2];              // 0 = large, 1 = mid
+  TowerDev tw[2];
+  int P;                          // positions per tile
+  int nbuf;                       // floats per activation buffer
+  int Lwin;                       // window length (2R+1)
+  int n_class;
+  int has_local;                  // Network2: mix with local softmax
+  int64_t n;                      // rows
+  // input: either symbol rows or the packed genome
+  const uint8_t* codes;           // [n][Lwin] symbols, already strand-oriented (dense path)
+  MuralGenome genome;             // packed path
+  const int64_t* pos;
+  const uint8_t* strand;
+  int radius;                     // distal radius (packed path)
+  const float* local_logits;      // [n][n_class]
+  float* out;                     // [n][n_class]
+  float* taps;                    // debug dump (tile 0) or nullptr
+  int tap_stride;                 // floats per dumped buffer
+};
+
+}  // namespace mural
+
+struct MuralSnvModel {
+  MuralSnvShape shape;
+  mural::SnvFwdArgs args;         // geometry + device pointers (input/output fields filled per call)
+  mural::LocalDev local;
+  float* blob;                    // device allocation holding every folded tensor
+  size_t blob_floats;
+  size_t lds_bytes;               // dynamic LDS of the fused kernel
+};

@@ -1,0 +1,101 @@
+// Local branch of the SNV models: shared k-mer embedding -> Linear/ReLU/BN x2 -> Linear (eval mode).
+// Reference semantics: MuRaL/model/model_snv.py:451-468, :492 (Network2) and :74-93 (Network0).
+// 0.6 % of the model's FLOPs: plain fp32 VALU with the activations of a 32-position tile in LDS and the
+// (BN-folded, transposed) weights streamed from L2, coalesced along the output-feature axis.
+#include "snv.h"
+
+namespace mural {
+
+constexpr int LOC_TP = 32;        // positions per workgroup tile
+constexpr int LOC_PG = 8;         // positions per thread task
+constexpr int LOC_THREADS = 256;
+
+__device__ __forceinline__ void dense_layer(const float* __restrict__ X, int xs, const float* __restrict__ wt,
+                                            const float* __restrict__ bias, int K4, int H, float* __restrict__ Y, int ys,
+                                            bool relu) {
+  // Y[p][h] = act(bias[h] + sum_k X[p][k] * wt[k][h]) for the LOC_TP positions of the tile
+  const int tasks = H * (LOC_TP / LOC_PG);
+  for (int task = threadIdx.x; task < tasks; task += LOC_THREADS) {
+    const int pg = task / H;
+    const int h = task - pg * H;
+    float acc[LOC_PG];
+    const float b = bias[h];
+#pragma unroll
+    for (int i = 0; i < LOC_PG; ++i) acc[i] = b;
+    for (int k4 = 0; k4 < K4; ++k4) {
+      const float w0 = wt[(4 * k4 + 0) * H + h], w1 = wt[(4 * k4 + 1) * H + h];
+      const float w2 = wt[(4 * k4 + 2) * H + h], w3 = wt[(4 * k4 + 3) * H + h];
+#pragma unroll
+      for (int i = 0; i < LOC_PG; ++i) {
+        const float4 x = *reinterpret_cast<const float4*>(X + (pg * LOC_PG + i) * xs + 4 * k4);
+        acc[i] = fmaf(x.x, w0, acc[i]);
+        acc[i] = fmaf(x.y, w1, acc[i]);
+        acc[i] = fmaf(x.z, w2, acc[i]);
+        acc[i] = fmaf(x.w, w3, acc[i]);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < LOC_PG; ++i) Y[(pg * LOC_PG + i) * ys + h] = relu ? fmaxf(acc[i], 0.f) : acc[i];
+  }
+}
+
+__global__ __launch_bounds__(LOC_THREADS) void snv_local_mlp(LocalDev L, const int64_t* __restrict__ cat, int64_t n,
+                                                             float* __restrict__ out, int xs, int h1s, int h2s) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  float* X = lsm;                 // [LOC_TP][xs]
+  float* H1 = X + LOC_TP * xs;    // [LOC_TP][h1s]
+  float* H2 = H1 + LOC_TP * h1s;  // [LOC_TP][h2s]
+  float* O = H2 + LOC_TP * h2s;   // [LOC_TP][SNV_MAXCLASS]
+  const int64_t n_tiles = (n + LOC_TP - 1) / LOC_TP;
+  for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
+    const int64_t row0 = tile * LOC_TP;
+    // gather embeddings (zero-padded to xs columns)
+    for (int i = threadIdx.x; i < LOC_TP * xs; i += LOC_THREADS) {
+      const int p = i / xs, k = i - p * xs;
+      float v = 0.f;
+      const int64_t row = row0 + p;
+      if (k < L.in1 && row < n) {
+        const int col = k / 5, d = k - 5 * col;
+        int64_t id = cat[row * L.cols + col];
+        id = id < 0 ? 0 : (id >= L.emb_rows ? L.emb_rows - 1 : id);
+        v = L.emb[id * 5 + d];
+      }
+      X[i] = v;
+    }
+    // zero the K padding of the hidden buffers once per tile (cheap, keeps the k4 loops branch-free)
+    for (int i = threadIdx.x; i < LOC_TP * (h1s - L.h1); i += LOC_THREADS) {
+      const int p = i / (h1s - L.h1), k = L.h1 + i % (h1s - L.h1);
+      H1[p * h1s + k] = 0.f;
+    }
+    for (int i = threadIdx.x; i < LOC_TP * (h2s - L.h2); i += LOC_THREADS) {
+      const int p = i / (h2s - L.h2), k = L.h2 + i % (h2s - L.h2);
+      H2[p * h2s + k] = 0.f;
+    }
+    __syncthreads();
+    dense_layer(X, xs, L.w1t, L.b1, xs / 4, L.h1, H1, h1s, true);
+    __syncthreads();
+    dense_layer(H1, h1s, L.w2t, L.b2, h1s / 4, L.h2, H2, h2s, true);
+    __syncthreads();
+    dense_layer(H2, h2s, L.w3t, L.b3, h2s / 4, L.n_class, O, SNV_MAXCLASS, false);
+    __syncthreads();
+    for (int i = threadIdx.x; i < LOC_TP * L.n_class; i += LOC_THREADS) {
+      const int p = i / L.n_class, k = i - p * L.n_class;
+      if (row0 + p < n) out[(row0 + p) * L.n_class + k] = O[p * SNV_MAXCLASS + k];
+    }
+    __syncthreads();
+  }
+}
+
+int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream) {
+  if (n == 0) return MURAL_OK;
+  const int xs = (L.in1 + 3) & ~3, h1s = (L.h1 + 3) & ~3, h2s = (L.h2 + 3) & ~3;
+  const size_t lds = (size_t)LOC_TP * (xs + h1s + h2s + SNV_MAXCLASS) * sizeof(float);
+  MURAL_REQUIRE(lds <= 64 * 1024, "local branch too wide for the LDS tile (%zu bytes)", lds);
+  const int64_t n_tiles = (n + LOC_TP - 1) / LOC_TP;
+  const int grid = (int)(n_tiles < 4096 ? n_tiles : 4096);
+  hipLaunchKernelGGL(snv_local_mlp, dim3(grid), dim3(LOC_THREADS), lds, stream, L, cat, n, out, xs, h1s, h2s);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural

@@ -1,0 +1,447 @@
+// Host side of the SNV path: eval-mode folding of the reference parameters into the device layout of
+// snv.h, tile geometry, workspace carving, and the extern "C" forward entry points.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "snv.h"
+
+namespace mural {
+int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, bool packed, hipStream_t stream);
+int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
+int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream);
+
+namespace {
+
+// forward-strand channel values (A,C,G,T) of the 15 IUPAC symbols, MuRaL/data/preprocessing.py:758-772
+const double kSymVec[15][4] = {
+    {1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}, {.25, .25, .25, .25},
+    {.5, 0, .5, 0}, {0, .5, 0, .5}, {.5, .5, 0, 0}, {0, .5, .5, 0}, {.5, 0, 0, .5}, {0, 0, .5, .5},
+    {0, 1. / 3, 1. / 3, 1. / 3}, {1. / 3, 0, 1. / 3, 1. / 3}, {1. / 3, 1. / 3, 0, 1. / 3}, {1. / 3, 1. / 3, 1. / 3, 0}};
+
+struct Blob {
+  std::vector<float> host;
+  size_t alloc(size_t n) {
+    size_t off = (host.size() + 63) & ~size_t(63);  // 256-byte aligned sections
+    host.resize(off + n, 0.f);
+    return off;
+  }
+};
+
+void bn_affine(const MuralBN& bn, int C, float eps, double* s, double* t) {
+  for (int c = 0; c < C; ++c) {
+    // the one-hot symbol table is fp32 on the reference side: BN eval is (x-mean)/sqrt(var+eps)*w+b
+    const double inv = 1.0 / std::sqrt((double)bn.running_var[c] + (double)eps);
+    s[c] = (double)bn.weight[c] * inv;
+    t[c] = (double)bn.bias[c] - (double)bn.running_mean[c] * s[c];
+  }
+}
+
+bool bn_ok(const MuralBN& b) { return b.weight && b.bias && b.running_mean && b.running_var; }
+bool aff_ok(const MuralAffine& a) { return a.weight && a.bias; }
+
+// W[co][ci][t] (PyTorch Conv1d layout) -> MFMA A fragments [mblock][kstep][lane]
+// kstep s = 8t + 4h + q feeds input channel ci = 16h + 4*(lane>>4) + q, output channel 16*mb + (lane&15)
+void pack_wfrag(const float* W, float* dst) {
+  for (int mb = 0; mb < 2; ++mb)
+    for (int s = 0; s < SNV_KSTEPS; ++s)
+      for (int lane = 0; lane < 64; ++lane) {
+        const int t = s / 8, h = (s % 8) / 4, q = s % 4;
+        const int ci = 16 * h + 4 * (lane >> 4) + q;
+        const int co = 16 * mb + (lane & 15);
+        dst[(mb * SNV_KSTEPS + s) * 64 + lane] = W[(co * SNV_C + ci) * SNV_K + t];
+      }
+}
+
+struct TowerOff { size_t lut, taps, bias0, wfrag, bias, post_s, post_t, ex_s, ex_t, fc_w, fc_b; };
+
+int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& o) {
+  const int C = SNV_C;
+  MURAL_REQUIRE(bn_ok(T.bn_in) && aff_ok(T.conv_in) && bn_ok(T.bn_mid) && aff_ok(T.conv_mid) && bn_ok(T.bn_out) &&
+                    aff_ok(T.conv_out) && bn_ok(T.fc_bn) && aff_ok(T.fc),
+                "tower parameter pointer is NULL");
+  for (int i = 0; i < 2; ++i) {
+    MURAL_REQUIRE(bn_ok(T.rbs1[i].bn1) && aff_ok(T.rbs1[i].conv1) && bn_ok(T.rbs1[i].bn2) && aff_ok(T.rbs1[i].conv2) &&
+                      bn_ok(T.rbs2[i].bn1) && aff_ok(T.rbs2[i].conv1) && bn_ok(T.rbs2[i].bn2) && aff_ok(T.rbs2[i].conv2),
+                  "residual block parameter pointer is NULL");
+  }
+  o.lut = B.alloc(SNV_LUT);
+  o.taps = B.alloc(SNV_TAPS);
+  o.bias0 = B.alloc(C);
+  o.wfrag = B.alloc((size_t)SNV_NLAYER * SNV_WFRAG);
+  o.bias = B.alloc(SNV_NLAYER * C);
+  o.post_s = B.alloc(SNV_NLAYER * C);
+  o.post_t = B.alloc(SNV_NLAYER * C);
+  o.ex_s = B.alloc(EX_COUNT * C);
+  o.ex_t = B.alloc(EX_COUNT * C);
+  o.fc_w = B.alloc((size_t)sh.n_class * C);
+  o.fc_b = B.alloc(sh.n_class);
+
+  // ---- first layer: BN(4) -> Conv1d(4->32,k3,pad 1) as per-tap symbol tables and a 3-mer table.
+  // zero padding is applied AFTER the BN (model_snv.py:350-353), so the PAD symbol contributes exactly 0.
+  double s4[4], t4[4];
+  bn_affine(T.bn_in, 4, sh.bn_eps, s4, t4);
+  std::vector<double> tap(3 * N_SYM * C, 0.0);
+  for (int t = 0; t < 3; ++t)
+    for (int sym = 0; sym < 15; ++sym)
+      for (int co = 0; co < C; ++co) {
+        double acc = 0.0;
+        for (int ci = 0; ci < 4; ++ci) {
+          // BN output as the reference computes it in fp32, then the conv product
+          const float bnv = (float)(s4[ci] * kSymVec[sym][ci] + t4[ci]);
+          acc += (double)T.conv_in.weight[(co * 4 + ci) * 3 + t] * (double)bnv;
+        }
+        tap[(t * N_SYM + sym) * C + co] = acc;
+      }
+  for (size_t i = 0; i < tap.size(); ++i) B.host[o.taps + i] = (float)tap[i];
+  for (int co = 0; co < C; ++co) B.host[o.bias0 + co] = T.conv_in.bias[co];
+  for (int l = 0; l < 5; ++l)
+    for (int c = 0; c < 5; ++c)
+      for (int r = 0; r < 5; ++r)
+        for (int co = 0; co < C; ++co)
+          B.host[o.lut + ((l * 25 + c * 5 + r) * C + co)] =
+              (float)((double)T.conv_in.bias[co] + tap[(0 * N_SYM + l) * C + co] + tap[(1 * N_SYM + c) * C + co] +
+                      tap[(2 * N_SYM + r) * C + co]);
+
+  // ---- 32->32 convs
+  const MuralAffine* convs[SNV_NLAYER] = {&T.rbs1[0].conv1, &T.rbs1[0].conv2, &T.rbs1[1].conv1, &T.rbs1[1].conv2, &T.conv_mid,
+                                          &T.rbs2[0].conv1, &T.rbs2[0].conv2, &T.rbs2[1].conv1, &T.rbs2[1].conv2, &T.conv_out};
+  // BN applied to relu(output of layer i) to form the next conv's input (nullptr: output kept raw)
+  const MuralBN* post[SNV_NLAYER] = {&T.rbs1[0].bn2, &T.rbs1[1].bn1, &T.rbs1[1].bn2, nullptr, &T.rbs2[0].bn1,
+                                     &T.rbs2[0].bn2, &T.rbs2[1].bn1, &T.rbs2[1].bn2, nullptr, nullptr};
+  double s[SNV_C], t[SNV_C];
+  for (int l = 0; l < SNV_NLAYER; ++l) {
+    pack_wfrag(convs[l]->weight, &B.host[o.wfrag + (size_t)l * SNV_WFRAG]);
+    for (int c = 0; c < C; ++c) B.host[o.bias + l * C + c] = convs[l]->bias[c];
+    if (post[l]) {
+      bn_affine(*post[l], C, sh.bn_eps, s, t);
+      for (int c = 0; c < C; ++c) {
+        B.host[o.post_s + l * C + c] = (float)s[c];
+        B.host[o.post_t + l * C + c] = (float)t[c];
+      }
+    } else {
+      for (int c = 0; c < C; ++c) B.host[o.post_s + l * C + c] = 1.f;
+    }
+  }
+  const MuralBN* ex[EX_COUNT] = {&T.rbs1[0].bn1, &T.bn_mid, &T.bn_out, &T.fc_bn};
+  for (int e = 0; e < EX_COUNT; ++e) {
+    bn_affine(*ex[e], C, sh.bn_eps, s, t);
+    for (int c = 0; c < C; ++c) {
+      B.host[o.ex_s + e * C + c] = (float)s[c];
+      B.host[o.ex_t + e * C + c] = (float)t[c];
+    }
+  }
+  for (int i = 0; i < sh.n_class * C; ++i) B.host[o.fc_w + i] = T.fc.weight[i];
+  for (int i = 0; i < sh.n_class; ++i) B.host[o.fc_b + i] = T.fc.bias[i];
+  return MURAL_OK;
+}
+
+struct LocalOff { size_t emb, w1t, b1, w2t, b2, w3t, b3; };
+
+int fold_local(const MuralLocal& Lc, const MuralSnvShape& sh, Blob& B, LocalOff& o) {
+  MURAL_REQUIRE(Lc.emb && aff_ok(Lc.lin[0]) && aff_ok(Lc.lin[1]) && bn_ok(Lc.bn[0]) && bn_ok(Lc.bn[1]) && aff_ok(Lc.out),
+                "local-branch parameter pointer is NULL");
+  const int in1 = 5 * sh.local_cols, h1 = sh.hidden1, h2 = sh.hidden2, nc = sh.n_class;
+  const int xs = (in1 + 3) & ~3, h1s = (h1 + 3) & ~3, h2s = (h2 + 3) & ~3;
+  o.emb = B.alloc((size_t)sh.emb_rows * 5);
+  o.w1t = B.alloc((size_t)xs * h1);
+  o.b1 = B.alloc(h1);
+  o.w2t = B.alloc((size_t)h1s * h2);
+  o.b2 = B.alloc(h2);
+  o.w3t = B.alloc((size_t)h2s * nc);
+  o.b3 = B.alloc(nc);
+  for (int i = 0; i < sh.emb_rows * 5; ++i) B.host[o.emb + i] = Lc.emb[i];
+  for (int h = 0; h < h1; ++h) {
+    for (int k = 0; k < in1; ++k) B.host[o.w1t + (size_t)k * h1 + h] = Lc.lin[0].weight[(size_t)h * in1 + k];
+    B.host[o.b1 + h] = Lc.lin[0].bias[h];
+  }
+  // order is Linear -> ReLU -> BN (model_snv.py:466-467): BN_i folds exactly into the next Linear
+  std::vector<double> s(std::max(h1, h2)), t(std::max(h1, h2));
+  bn_affine(Lc.bn[0], h1, sh.bn_eps, s.data(), t.data());
+  for (int j = 0; j < h2; ++j) {
+    double b = Lc.lin[1].bias[j];
+    for (int h = 0; h < h1; ++h) {
+      const double w = Lc.lin[1].weight[(size_t)j * h1 + h];
+      B.host[o.w2t + (size_t)h * h2 + j] = (float)(w * s[h]);
+      b += w * t[h];
+    }
+    B.host[o.b2 + j] = (float)b;
+  }
+  bn_affine(Lc.bn[1], h2, sh.bn_eps, s.data(), t.data());
+  for (int k = 0; k < nc; ++k) {
+    double b = Lc.out.bias[k];
+    for (int j = 0; j < h2; ++j) {
+      const double w = Lc.out.weight[(size_t)k * h2 + j];
+      B.host[o.w3t + (size_t)j * nc + k] = (float)(w * s[j]);
+      b += w * t[j];
+    }
+    B.host[o.b3 + k] = (float)b;
+  }
+  return MURAL_OK;
+}
+
+int pool_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
+
+// tile geometry for P positions per workgroup; returns LDS bytes (0 if a stage needs too many blocks per wave)
+size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P) {
+  static const int pools[2][3][3] = {{{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}, {{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}};
+  int maxcols = 0;
+  for (int tw = 0; tw < 2; ++tw) {
+    TowerGeom& g = a.geom[tw];
+    g.L1 = tw == 0 ? Lwin : 2 * SNV_MID_HALF + 1;
+    g.col0 = tw == 0 ? 0 : Lwin / 2 - SNV_MID_HALF;
+    int L = g.L1;
+    for (int i = 0; i < 3; ++i) {
+      g.pk[i] = pools[tw][i][0];
+      g.ps[i] = pools[tw][i][1];
+      g.pp[i] = pools[tw][i][2];
+      L = pool_len(L, g.pk[i], g.ps[i], g.pp[i]);
+      if (L < 1) return 0;
+      g.L[i] = L;
+      g.Sc[i] = L + 1;
+      g.NC[i] = 1 + P * g.Sc[i];
+      g.nb[i] = (g.NC[i] + 15) / 16;
+      g.dL[i] = FastDiv::make((uint32_t)L);
+      g.dSc[i] = FastDiv::make((uint32_t)g.Sc[i]);
+      if ((g.nb[i] + SNV_WAVES - 1) / SNV_WAVES > SNV_NBMAX) return 0;
+      maxcols = std::max(maxcols, 16 * g.nb[i] + 2);
+    }
+  }
+  a.P = P;
+  a.Lwin = Lwin;
+  a.nbuf = std::max(maxcols * SNV_C, SNV_LUT + SNV_TAPS + SNV_C);
+  const int CW = (Lwin + 2 + 15) & ~15, KW = (Lwin + 15) & ~15;
+  return (size_t)2 * a.nbuf * 4 + (size_t)P * (CW + KW) + (size_t)(2 * P * SNV_C + 2 * P * SNV_MAXCLASS) * 4;
+}
+
+constexpr size_t kLdsTwoPerCu = 80 * 1024;
+constexpr size_t kLdsMax = 160 * 1024;
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; };
+
+size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
+  size_t off = 0;
+  auto take = [&](size_t bytes) {
+    size_t o = off;
+    off = align_up(off + bytes, 256);
+    return o;
+  };
+  const size_t o_ll = take((size_t)n * m->shape.n_class * 4);
+  const size_t o_cat = take((size_t)n * std::max(m->shape.local_cols, 1) * 8);
+  const size_t o_sym = take(dense ? (size_t)n * m->shape.distal_len : 16);
+  if (w) {
+    char* b = static_cast<char*>(base);
+    w->local_logits = reinterpret_cast<float*>(b + o_ll);
+    w->cat = reinterpret_cast<int64_t*>(b + o_cat);
+    w->symbols = reinterpret_cast<uint8_t*>(b + o_sym);
+  }
+  return off;
+}
+
+}  // namespace
+}  // namespace mural
+
+using namespace mural;
+
+extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnvParams* hp, MuralSnvModel** out) {
+  MURAL_REQUIRE(shape && hp && out, "NULL argument");
+  const MuralSnvShape& sh = *shape;
+  MURAL_REQUIRE(sh.model_no >= 0 && sh.model_no <= 2, "model_no for snv must be one of [0, 1, 2], got %d", sh.model_no);
+  MURAL_REQUIRE(sh.n_class >= 1 && sh.n_class <= SNV_MAXCLASS, "n_class must be in [1,%d], got %d", SNV_MAXCLASS, sh.n_class);
+  const bool has_local = sh.model_no != 1, has_towers = sh.model_no != 0;
+  if (has_towers) {
+    MURAL_REQUIRE(sh.channels == SNV_C && sh.ksize == SNV_K,
+                  "the gfx950 tower kernel is built for CNN_out_channels=32, CNN_kernel_size=3 (got %d, %d)", sh.channels,
+                  sh.ksize);
+    MURAL_REQUIRE(sh.distal_len > 200, "Error: distal seq len must be >200");   // model_snv.py:470
+  }
+  if (has_local) {
+    MURAL_REQUIRE(sh.local_cols >= 1 && sh.emb_rows >= 2 && sh.hidden1 >= 1 && sh.hidden2 >= 1, "bad local-branch shape");
+  }
+  MuralSnvModel* m = new MuralSnvModel();
+  std::memset(m, 0, sizeof(*m));
+  m->shape = sh;
+  Blob B;
+  TowerOff toff[2];
+  LocalOff loff;
+  int rc = MURAL_OK;
+  if (has_towers) {
+    rc = fold_tower(hp->large, sh, B, toff[0]);
+    if (!rc) rc = fold_tower(hp->mid, sh, B, toff[1]);
+    if (!rc) {
+      // largest P that keeps two workgroups per CU; fall back to one workgroup per CU for long windows
+      size_t lds = 0;
+      int P = 0;
+      for (int cand = 16; cand >= 1 && !P; --cand) {
+        SnvFwdArgs tmp;
+        const size_t need = plan_geometry(tmp, sh.distal_len, cand);
+        if (need && need <= kLdsTwoPerCu) { P = cand; lds = need; }
+      }
+      for (int cand = 16; cand >= 1 && !P; --cand) {
+        SnvFwdArgs tmp;
+        const size_t need = plan_geometry(tmp, sh.distal_len, cand);
+        if (need && need <= kLdsMax) { P = cand; lds = need; }
+      }
+      if (!P) {
+        set_error("distal_radius %d is too long for the LDS-resident tower kernel", (sh.distal_len - 1) / 2);
+        rc = MURAL_E_INVALID;
+      } else {
+        plan_geometry(m->args, sh.distal_len, P);
+        m->lds_bytes = lds;
+      }
+    }
+  }
+  if (!rc && has_local) rc = fold_local(hp->local, sh, B, loff);
+  if (rc) { delete m; return rc; }
+  m->blob_floats = B.host.size();
+  if (hipError_t e = hipMalloc(&m->blob, std::max<size_t>(m->blob_floats, 64) * 4); e != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the folded weights failed: %s", m->blob_floats * 4, hipGetErrorString(e));
+    delete m;
+    return MURAL_E_RUNTIME;
+  }
+  if (m->blob_floats && hipMemcpy(m->blob, B.host.data(), m->blob_floats * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("hipMemcpy of the folded weights failed");
+    (void)hipFree(m->blob);
+    delete m;
+    return MURAL_E_RUNTIME;
+  }
+  if (has_towers) {
+    for (int tw = 0; tw < 2; ++tw) {
+      TowerDev& d = m->args.tw[tw];
+      const TowerOff& o = toff[tw];
+      d.lut = m->blob + o.lut; d.taps = m->blob + o.taps; d.bias0 = m->blob + o.bias0; d.wfrag = m->blob + o.wfrag;
+      d.bias = m->blob + o.bias; d.post_s = m->blob + o.post_s; d.post_t = m->blob + o.post_t;
+      d.ex_s = m->blob + o.ex_s; d.ex_t = m->blob + o.ex_t; d.fc_w = m->blob + o.fc_w; d.fc_b = m->blob + o.fc_b;
+    }
+    m->args.n_class = sh.n_class;
+    m->args.has_local = sh.model_no == 2;
+  }
+  if (has_local) {
+    LocalDev& L = m->local;
+    L.emb = m->blob + loff.emb; L.w1t = m->blob + loff.w1t; L.b1 = m->blob + loff.b1; L.w2t = m->blob + loff.w2t;
+    L.b2 = m->blob + loff.b2; L.w3t = m->blob + loff.w3t; L.b3 = m->blob + loff.b3;
+    L.cols = sh.local_cols; L.emb_rows = sh.emb_rows; L.in1 = 5 * sh.local_cols; L.h1 = sh.hidden1; L.h2 = sh.hidden2;
+    L.n_class = sh.n_class;
+  }
+  *out = m;
+  return MURAL_OK;
+}
+
+extern "C" void mural_snv_model_destroy(MuralSnvModel* m) {
+  if (!m) return;
+  if (m->blob) (void)hipFree(m->blob);
+  delete m;
+}
+
+extern "C" size_t mural_snv_workspace_bytes(const MuralSnvModel* m, int64_t n, int32_t dense) {
+  if (!m || n <= 0) return 256;
+  return carve(m, n, dense != 0, nullptr, nullptr);
+}
+
+extern "C" int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* o) {
+  MURAL_REQUIRE(m && o, "NULL argument");
+  std::memset(o, 0, 16 * sizeof(int32_t));
+  o[0] = m->args.P;
+  o[1] = m->args.nbuf;
+  for (int i = 0; i < 3; ++i) { o[2 + i] = m->args.geom[0].L[i]; o[5 + i] = m->args.geom[1].L[i]; }
+  o[8] = 13;
+  o[9] = (int32_t)m->lds_bytes;
+  return MURAL_OK;
+}
+
+extern "C" const char* mural_snv_kernel_name(void) { return "snv_towers_fused"; }
+
+namespace mural { int profile_begin(); int profile_end(double*, int64_t*); }
+extern "C" int mural_profile_begin(void) { return mural::profile_begin(); }
+extern "C" int mural_profile_end(double* total_ms, int64_t* launches) { return mural::profile_end(total_ms, launches); }
+
+static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n, float* out,
+                              void* workspace, size_t ws_bytes, int32_t* status, float* taps, size_t taps_floats,
+                              void* stream_) {
+  MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(n >= 0, "negative batch");
+  if (n == 0) return MURAL_OK;
+  hipStream_t stream = (hipStream_t)stream_;
+  const MuralSnvShape& sh = m->shape;
+  MURAL_REQUIRE(out, "out is NULL");
+  if (ws_bytes < carve(m, n, true, nullptr, nullptr) || !workspace) {
+    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, true, nullptr, nullptr), ws_bytes);
+    return MURAL_E_WORKSPACE;
+  }
+  Workspace w;
+  carve(m, n, true, workspace, &w);
+  if (sh.model_no == 0) {
+    MURAL_REQUIRE(cat_x, "cat_x is NULL");
+    return launch_snv_local(m->local, cat_x, n, out, stream);   // raw logits, model_snv.py:93
+  }
+  MURAL_REQUIRE(distal_x, "distal_x is NULL");
+  if (sh.model_no == 2) {
+    MURAL_REQUIRE(cat_x, "cat_x is NULL");
+    if (int rc = launch_snv_local(m->local, cat_x, n, w.local_logits, stream)) return rc;
+  }
+  if (int rc = launch_dense_to_symbols(distal_x, n, sh.distal_len, w.symbols, status, stream)) return rc;
+  SnvFwdArgs a = m->args;
+  a.n = n;
+  a.codes = w.symbols;
+  a.local_logits = w.local_logits;
+  a.out = out;
+  a.taps = taps;
+  a.tap_stride = a.nbuf;
+  if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * a.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * a.nbuf);
+  return launch_snv_towers(m, a, /*packed=*/false, stream);
+}
+
+extern "C" int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
+                                       float* out, void* workspace, size_t workspace_bytes, int32_t* status, void* stream) {
+  return forward_dense_impl(m, cat_x, distal_x, n, out, workspace, workspace_bytes, status, nullptr, 0, stream);
+}
+
+extern "C" int mural_snv_debug_taps(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
+                                    float* out, void* workspace, size_t workspace_bytes, float* taps, size_t taps_floats,
+                                    void* stream) {
+  MURAL_REQUIRE(taps, "taps is NULL");
+  return forward_dense_impl(m, cat_x, distal_x, n, out, workspace, workspace_bytes, nullptr, taps, taps_floats, stream);
+}
+
+extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenome* g, const int64_t* pos,
+                                        const uint8_t* strand, int64_t n, int32_t local_radius, int32_t local_order,
+                                        float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
+  MURAL_REQUIRE(n >= 0, "negative batch");
+  if (n == 0) return MURAL_OK;
+  MURAL_REQUIRE(pos && strand && out, "pos/strand/out must not be NULL");
+  hipStream_t stream = (hipStream_t)stream_;
+  const MuralSnvShape& sh = m->shape;
+  if (workspace_bytes < carve(m, n, false, nullptr, nullptr) || !workspace) {
+    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, false, nullptr, nullptr), workspace_bytes);
+    return MURAL_E_WORKSPACE;
+  }
+  Workspace w;
+  carve(m, n, false, workspace, &w);
+  if (sh.model_no != 1) {
+    const int ncol = 2 * local_radius + 1 - (local_order - 1);
+    MURAL_REQUIRE(ncol == sh.local_cols, "local_radius/local_order give %d k-mer columns, model has %d", ncol, sh.local_cols);
+    int64_t sentinel = 1;
+    for (int i = 0; i < local_order; ++i) sentinel *= 4;
+    MURAL_REQUIRE(sentinel + 1 == sh.emb_rows, "local_order %d does not match the embedding table (%d rows)", local_order,
+                  sh.emb_rows);
+    if (int rc = mural_encode_kmer(g, pos, strand, n, local_radius, local_order, 0, w.cat, stream_)) return rc;
+    float* dst = sh.model_no == 0 ? out : w.local_logits;
+    if (int rc = launch_snv_local(m->local, w.cat, n, dst, stream)) return rc;
+    if (sh.model_no == 0) return MURAL_OK;
+  }
+  SnvFwdArgs a = m->args;
+  a.n = n;
+  a.genome = *g;
+  a.pos = pos;
+  a.strand = strand;
+  a.radius = (sh.distal_len - 1) / 2;
+  a.local_logits = w.local_logits;
+  a.out = out;
+  a.taps = nullptr;
+  return launch_snv_towers(m, a, /*packed=*/true, stream);
+}

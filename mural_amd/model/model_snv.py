@@ -1,0 +1,336 @@
+"""Drop-in SNV model classes backed by the gfx950 HIP library.
+
+Mirror of the reference's MuRaL/model/model_snv.py API surface: ``Network0`` (:97-108), ``Network1`` (:111-287),
+``Network2`` (:290-525) with the same constructor signatures, sub-module names and therefore the same
+``state_dict()`` keys/order (incl. the double registration inside ``ResBlock``, :794-812), so the shipped
+checkpoints load with ``load_state_dict(strict=True)``.
+
+The torch sub-modules here are *parameter containers only*: ``forward`` never runs them.  In eval mode it hands
+the raw parameters to ``libmural_hip.so`` (which folds BN statistics, builds the first-layer 3-mer tables and the
+MFMA weight fragments) and launches the fused kernels on the current HIP stream.  There is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .. import _lib
+
+POOLS_MID = ((3, 3, 1), (3, 3, 1), (3, 3, 1))          # model_snv.py:356,361,371
+POOLS_LARGE = ((15, 15, 7), (7, 7, 3), (3, 3, 1))      # model_snv.py:399,404,414
+
+
+class ResBlock(nn.Module):
+    """Parameter holder for the pre-activation residual unit (model_snv.py:794-812)."""
+
+    def __init__(self, in_channels=32, kernel_size=3, stride=1, padding=0, dilation=1):
+        super().__init__()
+        mk = lambda: nn.Conv1d(in_channels, in_channels, kernel_size=kernel_size, stride=stride, padding=padding,
+                               dilation=dilation)
+        self.bn1 = nn.BatchNorm1d(in_channels)
+        self.conv1 = mk()
+        self.bn2 = nn.BatchNorm1d(in_channels)
+        self.conv2 = mk()
+        self.layer = nn.Sequential(nn.ReLU(), self.bn1, self.conv1, nn.ReLU(), self.bn2, self.conv2)
+
+
+def _add_local(mod, emb_dims, no_of_cont, lin_layer_sizes, emb_dropout, lin_layer_dropouts, emb_padding_idx):
+    if no_of_cont != 0:
+        raise ValueError("continuous (bigWig) local features are not supported by the HIP path (n_cont must be 0)")
+    mod.no_of_cat = len(emb_dims)
+    mod.emb_layer = nn.Embedding(emb_padding_idx + 1, 5)
+    mod.no_of_embs = len(emb_dims) * 5
+    mod.no_of_cont = no_of_cont
+    sizes = [mod.no_of_embs + no_of_cont] + list(lin_layer_sizes)
+    mod.lin_layers = nn.ModuleList([nn.Linear(sizes[i], sizes[i + 1]) for i in range(len(sizes) - 1)])
+    mod.first_bn_layer = nn.BatchNorm1d(no_of_cont)
+    mod.bn_layers = nn.ModuleList([nn.BatchNorm1d(s) for s in lin_layer_sizes])
+    mod.emb_dropout_layer = nn.Dropout(emb_dropout)
+    mod.droput_layers = nn.ModuleList([nn.Dropout(p) for p in lin_layer_dropouts])
+    if len(lin_layer_sizes) != 2:
+        raise ValueError("the HIP local branch is built for two hidden layers (local_hidden1_size, local_hidden2_size)")
+
+
+def _add_tower(mod, sfx, in_channels, out_channels, kernel_size, pools, dropout, n_class):
+    pad = (kernel_size - 1) // 2
+    bn_conv = lambda cin, relu=False: nn.Sequential(*([nn.BatchNorm1d(cin), nn.Conv1d(cin, out_channels, kernel_size, 1, pad)]
+                                                      + ([nn.ReLU()] if relu else [])))
+    rbs = lambda: nn.Sequential(*[ResBlock(out_channels, kernel_size=3, stride=1, padding=1, dilation=1) for _ in range(2)])
+    setattr(mod, "conv1" + sfx, bn_conv(in_channels))
+    setattr(mod, "maxpool1" + sfx, nn.MaxPool1d(*pools[0]))
+    setattr(mod, "RBs1" + sfx, rbs())
+    setattr(mod, "maxpool2" + sfx, nn.MaxPool1d(*pools[1]))
+    setattr(mod, "conv2" + sfx, bn_conv(out_channels))
+    setattr(mod, "RBs2" + sfx, rbs())
+    setattr(mod, "maxpool3" + sfx, nn.MaxPool1d(*pools[2]))
+    setattr(mod, "conv3" + sfx, bn_conv(out_channels, relu=True))
+    setattr(mod, "distal_fc1" if sfx == "" else "distal_fc2",
+            nn.Sequential(nn.BatchNorm1d(out_channels), nn.Dropout(dropout), nn.Linear(out_channels, n_class)))
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# parameter hand-over to the C ABI
+# ---------------------------------------------------------------------------------------------------------------
+class _HostParams:
+    """Keeps contiguous fp32 host copies alive while the C side reads them."""
+
+    def __init__(self):
+        self.keep = []
+
+    def ptr(self, t):
+        a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+        self.keep.append(a)
+        return a.ctypes.data_as(C.c_void_p)
+
+    def bn(self, m):
+        return _lib.MuralBN(self.ptr(m.weight), self.ptr(m.bias), self.ptr(m.running_mean), self.ptr(m.running_var))
+
+    def affine(self, m):
+        return _lib.MuralAffine(self.ptr(m.weight), self.ptr(m.bias))
+
+    def resblock(self, rb):
+        return _lib.MuralResBlock(self.bn(rb.bn1), self.affine(rb.conv1), self.bn(rb.bn2), self.affine(rb.conv2))
+
+    def tower(self, mod, sfx):
+        g = lambda n: getattr(mod, n + sfx)
+        fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
+        t = _lib.MuralTower()
+        t.bn_in, t.conv_in = self.bn(g("conv1")[0]), self.affine(g("conv1")[1])
+        t.rbs1[0], t.rbs1[1] = self.resblock(g("RBs1")[0]), self.resblock(g("RBs1")[1])
+        t.bn_mid, t.conv_mid = self.bn(g("conv2")[0]), self.affine(g("conv2")[1])
+        t.rbs2[0], t.rbs2[1] = self.resblock(g("RBs2")[0]), self.resblock(g("RBs2")[1])
+        t.bn_out, t.conv_out = self.bn(g("conv3")[0]), self.affine(g("conv3")[1])
+        t.fc_bn, t.fc = self.bn(fc[0]), self.affine(fc[2])
+        return t
+
+    def local(self, mod, out_layer):
+        l = _lib.MuralLocal()
+        l.emb = self.ptr(mod.emb_layer.weight)
+        l.lin[0], l.lin[1] = self.affine(mod.lin_layers[0]), self.affine(mod.lin_layers[1])
+        l.bn[0], l.bn[1] = self.bn(mod.bn_layers[0]), self.bn(mod.bn_layers[1])
+        l.out = self.affine(out_layer)
+        return l
+
+
+class _HipSnvBase(nn.Module):
+    """Shared machinery: handle cache keyed on parameter versions, workspace, launches."""
+
+    model_no = -1
+
+    def _hip_init(self):
+        self._handle = None
+        self._handle_key = None
+        self._ws = None
+        self._status = None
+
+    # -- description of this model for the C side ------------------------------------------------------------
+    def _shape_and_params(self):
+        raise NotImplementedError
+
+    def _state_key(self):
+        key = []
+        for t in list(self.parameters()) + list(self.buffers()):
+            key.append((t.data_ptr(), t._version))
+        return tuple(key)
+
+    def _get_handle(self):
+        key = self._state_key()
+        if self._handle is None or key != self._handle_key:
+            self._release()
+            shape, params, keep = self._shape_and_params()
+            h = C.c_void_p()
+            _lib.check(_lib.lib().mural_snv_model_create(C.byref(shape), C.byref(params), C.byref(h)))
+            del keep
+            self._handle, self._handle_key = h, key
+        return self._handle
+
+    def _release(self):
+        if getattr(self, "_handle", None) is not None:
+            _lib.lib().mural_snv_model_destroy(self._handle)
+            self._handle = None
+
+    def __del__(self):
+        try:
+            self._release()
+        except Exception:
+            pass
+
+    def _workspace(self, n, device, dense=True):
+        need = int(_lib.lib().mural_snv_workspace_bytes(self._get_handle(), n, int(dense)))
+        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
+        return self._ws
+
+    def _device(self):
+        return next(self.parameters()).device
+
+    def _check_eval(self):
+        if self.training:
+            raise NotImplementedError(
+                "mural_amd: the training-mode forward/backward (batch-stat BN, dropout) is not built yet in this "
+                "round; call model.eval() for the HIP inference path")
+
+    # -- dense entry (drop-in forward) ------------------------------------------------------------------------
+    def _forward_dense(self, cat_x, distal_x, taps=None):
+        self._check_eval()
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("mural_amd models run on a HIP device only: call model.to('cuda') first")
+        n = None
+        cat_ptr = dist_ptr = None
+        if cat_x is not None:
+            cat_x = _lib.require_cuda(cat_x, "cat_x").to(torch.int64).contiguous()
+            n = cat_x.shape[0]
+            cat_ptr = cat_x.data_ptr()
+        if distal_x is not None:
+            distal_x = _lib.require_cuda(distal_x, "distal_x").to(torch.float32).contiguous()
+            n = distal_x.shape[0]
+            dist_ptr = distal_x.data_ptr()
+        with torch.cuda.device(dev):
+            handle = self._get_handle()
+            out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
+            ws = self._workspace(max(n, 1), dev)
+            stream = _lib.current_stream_ptr(dev)
+            if taps is None:
+                if self._status is None or self._status.device != dev:
+                    self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+                _lib.check(_lib.lib().mural_snv_forward_dense(handle, cat_ptr, dist_ptr, n, out.data_ptr(), ws.data_ptr(),
+                                                             ws.numel(), self._status.data_ptr(), stream))
+                if self.model_no != 0 and int(self._status.item()) != 0:
+                    self._status.zero_()
+                    raise ValueError("distal_input holds a column that is not a MuRaL one-hot / IUPAC-fraction encoding "
+                                     "(preprocessing.py:758-772); the HIP path consumes sequence encodings only")
+            else:
+                _lib.check(_lib.lib().mural_snv_debug_taps(handle, cat_ptr, dist_ptr, n, out.data_ptr(), ws.data_ptr(),
+                                                          ws.numel(), taps.data_ptr(), taps.numel(), stream))
+        return out
+
+    # -- fused encode + forward from the packed genome --------------------------------------------------------
+    def forward_packed(self, genome, pos, strand, local_radius=None, local_order=3):
+        """log-probabilities for sites `pos` (int64, 0-based) / `strand` (uint8, 1 = '-') of a PackedGenome."""
+        self._check_eval()
+        dev = self._device()
+        pos = _lib.require_cuda(pos, "pos").to(torch.int64).contiguous()
+        strand = _lib.require_cuda(strand, "strand").to(torch.uint8).contiguous()
+        n = pos.shape[0]
+        if local_radius is None:
+            local_radius = (getattr(self, "no_of_cat", 1) + local_order - 2) // 2
+        with torch.cuda.device(dev):
+            handle = self._get_handle()
+            out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
+            ws = self._workspace(max(n, 1), dev, dense=False)
+            g = genome.as_struct(dev)
+            _lib.check(_lib.lib().mural_snv_forward_packed(handle, C.byref(g), pos.data_ptr(), strand.data_ptr(), n,
+                                                          int(local_radius), int(local_order), out.data_ptr(),
+                                                          ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
+        return out
+
+    def tap_layout(self):
+        arr = (C.c_int32 * 16)()
+        _lib.check(_lib.lib().mural_snv_tap_layout(self._get_handle(), arr))
+        return list(arr)
+
+
+def _shape(model_no, n_class, local_cols=0, emb_rows=0, h1=0, h2=0, channels=32, ksize=3, distal_len=0):
+    return _lib.MuralSnvShape(model_no, n_class, local_cols, emb_rows, h1, h2, channels, ksize, distal_len, 1e-5)
+
+
+class FeedForwardNN(_HipSnvBase):
+    """Local-only network body (model_snv.py:19-95)."""
+    model_no = 0
+
+    def __init__(self, emb_dims, no_of_cont, lin_layer_sizes, emb_dropout, lin_layer_dropouts, n_class, emb_padding_idx=None):
+        super().__init__()
+        self.n_class = n_class
+        _add_local(self, emb_dims, no_of_cont, lin_layer_sizes, emb_dropout, lin_layer_dropouts, emb_padding_idx)
+        self.output_layer = nn.Linear(lin_layer_sizes[-1], n_class)
+        self._hip_init()
+
+    def _shape_and_params(self):
+        hp = _HostParams()
+        params = _lib.MuralSnvParams()
+        params.local = hp.local(self, self.output_layer)
+        shape = _shape(0, self.n_class, self.no_of_cat, self.emb_layer.num_embeddings, self.lin_layers[0].out_features,
+                       self.lin_layers[1].out_features)
+        return shape, params, hp
+
+    def forward(self, cont_data, cat_data):
+        return self._forward_dense(cat_data, None)
+
+
+class Network0(nn.Module):
+    """Wrapper with the common ((cont, cat), distal) call signature (model_snv.py:97-108)."""
+
+    def __init__(self, emb_dims, no_of_cont, lin_layer_sizes, emb_dropout, lin_layer_dropouts, n_class, emb_padding_idx=None):
+        super().__init__()
+        self.model = FeedForwardNN(emb_dims, no_of_cont, lin_layer_sizes, emb_dropout, lin_layer_dropouts, n_class,
+                                   emb_padding_idx)
+        self.n_class = n_class
+
+    def forward(self, local_input, distal_input=None):
+        cont_data, cat_data = local_input
+        return self.model.forward(cont_data, cat_data)
+
+    def forward_packed(self, genome, pos, strand, local_radius=None, local_order=3):
+        return self.model.forward_packed(genome, pos, strand, local_radius, local_order)
+
+
+class Network1(_HipSnvBase):
+    """Expanded-only model (model_snv.py:111-287)."""
+    model_no = 1
+
+    def __init__(self, in_channels, out_channels, kernel_size, distal_radius, distal_order, distal_fc_dropout, n_class):
+        super().__init__()
+        self.n_class, self.in_channels, self.kernel_size = n_class, in_channels, kernel_size
+        self.out_channels = out_channels
+        self.seq_len = distal_radius * 2 + 1 - (distal_order - 1)
+        _add_tower(self, "", in_channels, out_channels, kernel_size, POOLS_MID, distal_fc_dropout, n_class)
+        _add_tower(self, "_2", in_channels, out_channels, kernel_size, POOLS_LARGE, distal_fc_dropout, n_class)
+        self._hip_init()
+
+    def _shape_and_params(self):
+        hp = _HostParams()
+        params = _lib.MuralSnvParams()
+        params.mid, params.large = hp.tower(self, ""), hp.tower(self, "_2")
+        shape = _shape(1, self.n_class, channels=self.out_channels, ksize=self.kernel_size, distal_len=self.seq_len)
+        return shape, params, hp
+
+    def forward(self, local_input, distal_input):
+        assert distal_input.shape[2] > 200, "Error: distal seq len must be >200bp"
+        if distal_input.shape[2] != self.seq_len:
+            raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")
+        return self._forward_dense(None, distal_input[:, 0:self.in_channels, :])
+
+
+class Network2(_HipSnvBase):
+    """Combined local + expanded model (model_snv.py:290-525)."""
+    model_no = 2
+
+    def __init__(self, emb_dims, no_of_cont, lin_layer_sizes, emb_dropout, lin_layer_dropouts, in_channels, out_channels,
+                 kernel_size, distal_radius, distal_order, distal_fc_dropout, n_class, emb_padding_idx=None):
+        super().__init__()
+        self.n_class, self.in_channels, self.kernel_size = n_class, in_channels, kernel_size
+        self.out_channels = out_channels
+        _add_local(self, emb_dims, no_of_cont, lin_layer_sizes, emb_dropout, lin_layer_dropouts, emb_padding_idx)
+        self.seq_len = distal_radius * 2 + 1 - (distal_order - 1)
+        _add_tower(self, "", in_channels, out_channels, kernel_size, POOLS_MID, distal_fc_dropout, n_class)
+        _add_tower(self, "_2", in_channels, out_channels, kernel_size, POOLS_LARGE, distal_fc_dropout, n_class)
+        self.local_fc = nn.Sequential(nn.Linear(lin_layer_sizes[-1], n_class))
+        self._hip_init()
+
+    def _shape_and_params(self):
+        hp = _HostParams()
+        params = _lib.MuralSnvParams()
+        params.local = hp.local(self, self.local_fc[0])
+        params.mid, params.large = hp.tower(self, ""), hp.tower(self, "_2")
+        shape = _shape(2, self.n_class, self.no_of_cat, self.emb_layer.num_embeddings, self.lin_layers[0].out_features,
+                       self.lin_layers[1].out_features, self.out_channels, self.kernel_size, self.seq_len)
+        return shape, params, hp
+
+    def forward(self, local_input, distal_input, _taps=None):
+        cont_data, cat_data = local_input
+        assert distal_input.shape[2] > 200, "Error: distal seq len must be >200"
+        if distal_input.shape[2] != self.seq_len:
+            raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")
+        return self._forward_dense(cat_data, distal_input[:, 0:self.in_channels, :], taps=_taps)

@@ -1,0 +1,93 @@
+"""Model factory / initialiser / batched inference loop with the reference's contracts.
+
+  * ``model_choice``    -- MuRaL/model/nn_utils.py:186-231: same 4 positional arguments, same config keys, same
+                           registry ({'snv': {0,1,2}, 'indel': {0}}) and the same ValueError texts.
+  * ``weights_init``    -- nn_utils.py:14-35 (xavier-uniform convs, kaiming-normal linears, zero biases), applied with
+                           ``model.apply`` like training.py:324.
+  * ``model_predict_m`` -- nn_utils.py:37-76: returns ``(pred_y (N, n_class) on device, total_loss float)``; the loss
+                           is accumulated on the device and read back ONCE (the reference syncs per batch, :65) and the
+                           outputs are concatenated once (the reference re-copies the growing tensor per batch, :62).
+"""
+import inspect
+
+import torch
+import torch.nn as nn
+
+from .model_snv import Network0, Network1, Network2
+
+MODEL_REGISTRY = {"snv": {0: Network0, 1: Network1, 2: Network2}, "indel": {}}
+
+try:  # the INDEL model lands in its own module
+    from .model_indel import UNet_Small
+    MODEL_REGISTRY["indel"][0] = UNet_Small
+except ImportError:  # pragma: no cover
+    pass
+
+
+def weights_init(m):
+    """Initialise network layers by class name, as the reference does."""
+    classname = m.__class__.__name__
+    if classname.find("Conv1d") != -1 or classname.find("Conv2d") != -1:
+        nn.init.xavier_uniform_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+    elif classname.find("Linear") != -1:
+        nn.init.kaiming_normal_(m.weight)
+        if m.bias is not None:
+            nn.init.constant_(m.bias, 0)
+
+
+def model_choice(model_no, config, common_model_config, model_type):
+    """Build the model the config describes; kwargs are matched against the constructor signature."""
+    model_config = {**config, **common_model_config}
+
+    def adapt(para):
+        if model_type == "snv":
+            rules = {
+                "lin_layer_sizes": lambda: [config["local_hidden1_size"], config["local_hidden2_size"]],
+                "lin_layer_dropouts": lambda: [config["local_dropout"], config["local_dropout"]],
+                "emb_padding_idx": lambda: 4 ** config["local_order"],
+                "out_channels": lambda: config["CNN_out_channels"],
+                "kernel_size": lambda: config["CNN_kernel_size"],
+                "no_of_cont": lambda: common_model_config["n_cont"],
+            }
+        else:
+            rules = {
+                "out_channels": lambda: config["CNN_out_channels"],
+                "kernel_size": lambda: config["CNN_kernel_size"],
+                "downsize": lambda: config["down_list"],
+                "use_reverse": lambda: config.get("use_reverse", False),
+            }
+        return rules[para]() if para in rules else model_config[para]
+
+    if model_type not in MODEL_REGISTRY:
+        raise ValueError(f"model_type must be one of {list(MODEL_REGISTRY.keys())}, got {model_type}")
+    model_map = MODEL_REGISTRY[model_type]
+    model = model_map.get(model_no)
+    if model is None:
+        raise ValueError(f"model_no for {model_type} must be one of {list(model_map.keys())}, got {model_no}")
+    names = [p for p in inspect.signature(model.__init__).parameters.keys() if p != "self"]
+    return model(**{p: adapt(p) for p in names})
+
+
+def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, model_type="snv"):
+    """Run the model over an iterable of (y, cont_x, cat_x, distal_x) batches."""
+    device = torch.device(device)
+    model.to(device)
+    model.eval()
+    outs = []
+    loss_acc = torch.zeros((), dtype=torch.float64, device=device)
+    with torch.no_grad():
+        for y, cont_x, cat_x, distal_x in dataloader:
+            cat_x = cat_x.to(device, non_blocking=True)
+            cont_x = cont_x.to(device, non_blocking=True)
+            distal_x = distal_x.to(device, non_blocking=True)
+            y = y.to(device, non_blocking=True)
+            if model_type == "snv":
+                preds = model.forward((cont_x, cat_x), distal_x) if distal else model.forward(cont_x, cat_x)
+            else:
+                preds = model.forward(distal_x)
+            outs.append(preds)
+            loss_acc += criterion(preds, y.long().squeeze(1)).double()
+    pred_y = torch.cat(outs, dim=0) if outs else torch.empty(0, n_class, device=device)
+    return pred_y, float(loss_acc.item())

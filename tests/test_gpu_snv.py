@@ -1,0 +1,175 @@
+"""GPU parity: HIP SNV forward (through the C ABI) vs the reference's golden vectors and the CPU oracle.
+
+Tolerance (BASELINE.json north_star): per-class probabilities within 1e-5 abs of the reference CPU fp32 path.
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from oracle import encode_ref, snv_ref, synth
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-5
+SNV_FORWARD = sorted(os.path.basename(p) for p in glob.glob(os.path.join(U.GOLDEN, "snv_synth_*.npz"))
+                     + glob.glob(os.path.join(U.GOLDEN, "snv_pretrained_*.npz")))
+
+
+def product_from_hp(hp):
+    from mural_amd.model import model_choice
+    r, order, R, h1, h2, C, k, n_class = [int(v) for v in hp[:8]]
+    model_no = int(hp[8]) if len(hp) > 8 else 2
+    ncol = 2 * r + 1 - (order - 1)
+    cfg = dict(local_radius=r, local_order=order, local_hidden1_size=h1, local_hidden2_size=h2, distal_radius=R,
+               emb_dropout=0.1, local_dropout=0.1, CNN_kernel_size=k, CNN_out_channels=C, distal_fc_dropout=0.25)
+    common = dict(emb_dims=[(4 ** order + 1, 2)] * ncol, n_cont=0, n_class=n_class, distal_order=1, in_channels=4)
+    return model_choice(model_no, cfg, common, "snv"), model_no
+
+
+def assert_probs_close(got_logp, want_logp, model_no, name=""):
+    if model_no == 0:   # raw logits
+        assert np.abs(got_logp - want_logp).max() <= 2e-5 * max(1.0, np.abs(want_logp).max()), name
+        return
+    err = np.abs(np.exp(got_logp.astype(np.float64)) - np.exp(want_logp.astype(np.float64))).max()
+    assert err <= PROB_TOL, f"{name}: max prob err {err:.3e}"
+    big = want_logp > -12
+    assert np.abs(got_logp - want_logp)[big].max() <= 2e-3, name
+
+
+@pytest.mark.parametrize("name", SNV_FORWARD)
+def test_forward_dense_matches_reference(name):
+    fx = U.load(name)
+    model, model_no = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    model = model.cuda().eval()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    cont = torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        out = model((cont, cat), x)
+    assert out.shape == (len(cat), int(fx["hp"][7])) and out.dtype == torch.float32 and out.is_cuda
+    want = fx["logp"] if "logp" in fx.files else fx["out"]
+    assert_probs_close(out.cpu().numpy(), want, model_no, name)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 3, 7, 64, 257])
+def test_ragged_batches(batch):
+    fx = U.load("snv_synth_T_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    sd = U.snv_state_for(fx, orc)
+    model.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    model = model.cuda().eval()
+    orc.eval()
+    rng = np.random.default_rng(batch)
+    codes = rng.integers(0, 4, size=(batch, 201)).astype(np.uint8)
+    cat = rng.integers(0, 65, size=(batch, 9)).astype(np.int64)
+    with torch.no_grad():
+        want = orc((torch.zeros(batch, 1, dtype=torch.float64), torch.from_numpy(cat)), U.onehot(codes)).numpy()
+        got = model((torch.zeros(batch, 1, dtype=torch.float64).cuda(), torch.from_numpy(cat).cuda()),
+                    U.onehot(codes).cuda()).cpu().numpy()
+    assert_probs_close(got, want, 2, f"batch {batch}")
+
+
+def test_empty_batch():
+    fx = U.load("snv_synth_T_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    model = model.cuda().eval()
+    out = model((torch.zeros(0, 1).cuda(), torch.zeros(0, 9, dtype=torch.long).cuda()), torch.zeros(0, 4, 201).cuda())
+    assert out.shape == (0, 4)
+
+
+@pytest.mark.parametrize("cfg", [(10, 1000, 2, 301), (7, 1000, 2, 64), (5, 100, 2, 500), (10, 1000, 1, 40), (10, 1000, 0, 100)])
+def test_forward_packed_matches_oracle(cfg):
+    """fused decode+forward from the 2-bit genome == oracle(encoders(oracle)) on the same sites, both strands,
+    chromosome edges and N runs included."""
+    from mural_amd.data import PackedGenome
+    r, R, model_no, n_sites = cfg
+    rng = np.random.default_rng(1000 + r + R + model_no)
+    n = 60_000
+    raw = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=n, p=[.248, .248, .248, .248, .008])
+    raw[30000:30050] = ord("N")
+    seq = raw.tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = rng.integers(0, n, size=n_sites)
+    pos[:6] = [0, 1, 3, n - 1, n - 2, 30010]
+    strand = rng.integers(0, 2, size=n_sites).astype(np.uint8)
+    sym = ["-" if s else "+" for s in strand]
+    orc = snv_ref.build(model_no, local_radius=r, distal_radius=R)
+    sd = synth.synth_state_dict(orc.state_dict(), 77)
+    orc.load_state_dict(sd)
+    orc.eval()
+    hp = np.array([r, 3, R, 150, 75, 32, 3, 4, model_no])
+    model, _ = product_from_hp(hp)
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    cat = torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, r, 3))
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R))
+    with torch.no_grad():
+        want = orc((torch.zeros(n_sites, 1, dtype=torch.float64), cat), x).numpy()
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    got = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r,
+                               local_order=3).cpu().numpy()
+    assert_probs_close(got, want, model_no, str(cfg))
+
+
+def test_rejects_non_encoding_input():
+    fx = U.load("snv_synth_T_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    model = model.cuda().eval()
+    x = torch.rand(4, 4, 201, device="cuda")
+    with pytest.raises(ValueError):
+        model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), x)
+    with pytest.raises(AssertionError):
+        model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), torch.zeros(4, 4, 199).cuda())
+
+
+def test_cpu_tensors_fail_loudly():
+    fx = U.load("snv_synth_T_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    model = model.cuda().eval()
+    with pytest.raises(RuntimeError):
+        model((torch.zeros(4, 1), torch.zeros(4, 9, dtype=torch.long)), torch.zeros(4, 4, 201))
+
+
+def test_reload_weights_invalidates_folded_copy():
+    fx = U.load("snv_synth_T_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    model = model.cuda().eval()
+    orc.eval()
+    cat = torch.from_numpy(fx["cat"])
+    x = U.onehot(fx["codes"])
+    for seed in (5, 6):
+        sd = synth.synth_state_dict(orc.state_dict(), seed)
+        orc.load_state_dict(sd)
+        model.load_state_dict(sd)
+        with torch.no_grad():
+            want = orc((torch.zeros(len(cat), 1, dtype=torch.float64), cat), x).numpy()
+            got = model((torch.zeros(len(cat), 1).cuda(), cat.cuda()), x.cuda()).cpu().numpy()
+        assert_probs_close(got, want, 2, f"seed {seed}")
+
+
+def test_model_predict_m_contract():
+    from mural_amd.model import model_predict_m
+    fx = U.load("predict_m.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    x = U.onehot(fx["codes"])
+    batches, o = [], 0
+    for n in fx["sizes"].tolist():
+        batches.append((torch.from_numpy(fx["y"][o:o + n]), torch.zeros(n, 1, dtype=torch.float64),
+                        torch.from_numpy(fx["cat"][o:o + n]), x[o:o + n]))
+        o += n
+    pred, total = model_predict_m(model, batches, nn.CrossEntropyLoss(reduction="sum"), torch.device("cuda"), 4, True, "snv")
+    assert pred.is_cuda and pred.shape == fx["pred"].shape
+    assert_probs_close(pred.cpu().numpy(), fx["pred"], 2, "predict_m")
+    assert abs(total - float(fx["total_loss"])) <= 1e-4 * abs(float(fx["total_loss"]))
