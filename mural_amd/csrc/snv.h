@@ -12,7 +12,7 @@ constexpr int SNV_WFRAG = 2 * SNV_KSTEPS * 64;   // floats per layer: [mblock][k
 constexpr int SNV_LUT = 125 * SNV_C;             // 3-mer lookup table (A,C,G,T,N)^3 x channels
 constexpr int SNV_TAPS = 3 * N_SYM * SNV_C;      // per-tap, per-symbol contributions (generic path)
 constexpr int SNV_MAXCLASS = 16;
-constexpr int SNV_NBMAX = 6;       // max 16-column blocks a wave owns in one stage
+constexpr int SNV_NB2MAX = 9;      // max 16-column blocks a wave owns in one stage (waves split M x column parity)
 constexpr int SNV_THREADS = 256;
 constexpr int SNV_WAVES = SNV_THREADS / 64;
 constexpr int SNV_MID_HALF = 100;  // model_snv.py:473
@@ -74,6 +74,8 @@ struct SnvFwdArgs {
   const int64_t* pos;
   const uint8_t* strand;
   int radius;                     // distal radius (packed path)
+  int nwords;                     // 16-base genome words that can overlap one window
+  FastDiv dNW;                    // divide by nwords
   const float* local_logits;      // [n][n_class]
   float* out;                     // [n][n_class]
   float* taps;                    // debug dump (tile 0) or nullptr

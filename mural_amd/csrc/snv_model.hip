@@ -132,8 +132,17 @@ int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& 
       B.host[o.ex_t + e * C + c] = (float)t[c];
     }
   }
-  for (int i = 0; i < sh.n_class * C; ++i) B.host[o.fc_w + i] = T.fc.weight[i];
-  for (int i = 0; i < sh.n_class; ++i) B.host[o.fc_b + i] = T.fc.bias[i];
+  // distal_fc = BN -> Dropout -> Linear on the global-max features: the BN folds exactly into the Linear
+  bn_affine(T.fc_bn, C, sh.bn_eps, s, t);
+  for (int k = 0; k < sh.n_class; ++k) {
+    double b = T.fc.bias[k];
+    for (int c = 0; c < C; ++c) {
+      const double w = T.fc.weight[k * C + c];
+      B.host[o.fc_w + k * C + c] = (float)(w * s[c]);
+      b += w * t[c];
+    }
+    B.host[o.fc_b + k] = (float)b;
+  }
   return MURAL_OK;
 }
 
@@ -204,12 +213,14 @@ size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P) {
       g.nb[i] = (g.NC[i] + 15) / 16;
       g.dL[i] = FastDiv::make((uint32_t)L);
       g.dSc[i] = FastDiv::make((uint32_t)g.Sc[i]);
-      if ((g.nb[i] + SNV_WAVES - 1) / SNV_WAVES > SNV_NBMAX) return 0;
+      if ((g.nb[i] + 1) / 2 > SNV_NB2MAX) return 0;
       maxcols = std::max(maxcols, 16 * g.nb[i] + 2);
     }
   }
   a.P = P;
   a.Lwin = Lwin;
+  a.nwords = (Lwin + 15) / 16 + 1;
+  a.dNW = FastDiv::make((uint32_t)a.nwords);
   a.nbuf = std::max(maxcols * SNV_C, SNV_LUT + SNV_TAPS + SNV_C);
   const int CW = (Lwin + 2 + 15) & ~15, KW = (Lwin + 15) & ~15;
   return (size_t)2 * a.nbuf * 4 + (size_t)P * (CW + KW) + (size_t)(2 * P * SNV_C + 2 * P * SNV_MAXCLASS) * 4;

@@ -57,12 +57,118 @@ __device__ __forceinline__ int layer_mode(int layer) {
   return (int)((tbl >> (3 * layer)) & 7u);
 }
 
+// Per-wave addressing of one stage.  A wave owns M-block `mb` (16 output channels) of the 16-column blocks
+// b = cgp + 2i; block i of the wave sits 32 columns = 4096 bytes after block 0, which the swizzle leaves intact,
+// so every LDS address of the conv loop is one of these VGPRs plus a compile-time immediate.
+struct StageAddr {
+  uint32_t rd[6];   // byte offset of B-operand chunk (tap t, half h) for block 0: rd[2t+h]
+  uint32_t wr;      // byte offset of this lane's output chunk for block 0
+  uint32_t vmask;   // bit i: column of block i held by this lane carries data (not separator / padding)
+};
+
+__device__ __forceinline__ StageAddr stage_setup(const TowerGeom& g, int st, int P, int n16, int kk, int mb, int cgp) {
+  StageAddr a;
+  const int c0 = 16 * cgp + n16;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a.rd[2 * t + h] = 4u * (uint32_t)lds_off(c0 + t, 4 * h + kk);
+  a.wr = 4u * (uint32_t)lds_off(c0 + 1, 4 * mb + kk);
+  a.vmask = 0;
+#pragma unroll
+  for (int i = 0; i < SNV_NB2MAX; ++i)
+    a.vmask |= col_is_data(c0 + 32 * i, g.dSc[st], g.Sc[st], g.L[st], P) ? (1u << i) : 0u;
+  return a;
+}
+
+__device__ __forceinline__ f32x4 lds_ld4(const char* base, uint32_t off) {
+  return *reinterpret_cast<const f32x4*>(base + off);
+}
+__device__ __forceinline__ void lds_st4(char* base, uint32_t off, f32x4 v) { *reinterpret_cast<f32x4*>(base + off) = v; }
+
+// 24 k-steps of v_mfma_f32_16x16x4_f32 for one (DUAL: two) 16-column block(s) against this wave's M-block.
+// Operand reads of tap t+1/t+2 are in flight while tap t is multiplied (sched_barrier pins that order).
+template <bool DUAL>
+__device__ __forceinline__ void mfma_tap(const float (&a)[SNV_KSTEPS], int t, const f32x4 (&b0)[2], const f32x4 (&b1)[2],
+                                         f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * t + 4 * h + q], b0[h][q], acc0, 0, 0, 0);
+      if (DUAL) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * t + 4 * h + q], b1[h][q], acc1, 0, 0, 0);
+    }
+  }
+}
+
+template <bool DUAL>
+__device__ __forceinline__ void mfma_blocks(const char* in, const StageAddr& sa, uint32_t imm0, uint32_t imm1,
+                                            const float (&a)[SNV_KSTEPS], f32x4& acc0, f32x4& acc1) {
+  f32x4 x0[2], x1[2], y0[2], y1[2], z0[2], z1[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    x0[h] = lds_ld4(in, sa.rd[0 + h] + imm0);
+    if (DUAL) x1[h] = lds_ld4(in, sa.rd[0 + h] + imm1);
+  }
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    y0[h] = lds_ld4(in, sa.rd[2 + h] + imm0);
+    if (DUAL) y1[h] = lds_ld4(in, sa.rd[2 + h] + imm1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tap<DUAL>(a, 0, x0, x1, acc0, acc1);
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    z0[h] = lds_ld4(in, sa.rd[4 + h] + imm0);
+    if (DUAL) z1[h] = lds_ld4(in, sa.rd[4 + h] + imm1);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tap<DUAL>(a, 1, y0, y1, acc0, acc1);
+  __builtin_amdgcn_sched_barrier(0);
+  mfma_tap<DUAL>(a, 2, z0, z1, acc0, acc1);
+}
+
+__device__ __forceinline__ void epilogue(int mode, f32x4 acc, f32x4& xr, bool valid, f32x4 ps, f32x4 pt, char* out,
+                                         uint32_t off) {
+  f32x4 o;
+  if (mode == MODE_RES_LAST) {
+    o = acc;
+  } else if (mode == MODE_FINAL) {
+    o = max4(acc, splat(0.f));
+  } else {
+    o = relu_bn(acc, ps, pt);
+  }
+  if (mode == MODE_RES_FIRST) xr += acc;       // z = x1 + x0 carries the outer skip (model_snv.py:477-479)
+  else if (mode == MODE_ENTRY) xr = acc;
+  lds_st4(out, off, valid ? o : splat(0.f));
+}
+
+template <int PK>
+__device__ __forceinline__ f32x4 lut_window_fast(const float* lutS, const uint8_t* kx, int jlo, int cg, bool& ok) {
+  uint32_t idx[PK];
+  uint32_t any = 0;
+#pragma unroll
+  for (int w = 0; w < PK; ++w) {
+    idx[w] = kx[jlo + w];
+    any |= (idx[w] == 255u) ? 1u : 0u;
+  }
+  ok = any == 0;
+  f32x4 m = splat(-INFINITY);
+  if (ok) {
+#pragma unroll
+    for (int w = 0; w < PK; ++w) m = max4(m, ld4(lutS + idx[w] * 32u + 4u * cg));
+  }
+  return m;
+}
+
 template <int SRC>  // 0: symbol rows in HBM, 1: packed genome
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mb = wave & 1, cgp = wave >> 1;
+  const int n16 = lane & 15, kk = lane >> 4;
   const int P = args.P;
   const int Lwin = args.Lwin;
   const int CW = (Lwin + 2 + 15) & ~15;  // symbol row stride (bytes), PAD at both ends
@@ -71,37 +177,63 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   float* bufB = smem + args.nbuf;
   uint8_t* cbuf = reinterpret_cast<uint8_t*>(smem + 2 * args.nbuf);
   uint8_t* kidx = cbuf + P * CW;
-  float* feat = reinterpret_cast<float*>(kidx + P * KW);  // [2][P][32]
+  float* feat = reinterpret_cast<float*>(kidx + P * KW);  // [2][P][32] global max per tower
   float* logit = feat + 2 * P * SNV_C;                    // [2][P][SNV_MAXCLASS]
 
   const int64_t n_tiles = (args.n + P - 1) / P;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
     // ------------------------------------------------------------------ symbols of the P windows -> LDS
-    for (int p = 0; p < P; ++p) {
-      const int64_t row = row0 + p;
-      uint8_t* cb = cbuf + p * CW;
-      int64_t ws = 0;
-      bool neg = false;
-      if (SRC == 1 && row < args.n) {
-        ws = args.pos[row] - args.radius;
-        neg = args.strand[row] != 0;
-      }
-      for (int jj = tid; jj < Lwin + 2; jj += SNV_THREADS) {
-        uint32_t sym = SYM_PAD;
-        const int j = jj - 1;
-        if (j >= 0 && j < Lwin) {
-          if (row >= args.n) {
-            sym = SYM_N;
-          } else if (SRC == 0) {
-            sym = args.codes[row * Lwin + j];
-          } else {
-            const int64_t g = neg ? (ws + (Lwin - 1 - j)) : (ws + j);
-            sym = genome_sym(args.genome.packed2, args.genome.nmask, args.genome.length, g);
-            if (neg) sym = sym_complement(sym);
+    if (SRC == 1) {
+      // one thread per 16-base word of the packed genome that overlaps the window
+      const int nw = args.nwords;
+      for (int item = tid; item < P * nw; item += SNV_THREADS) {
+        const int p = (int)args.dNW.div((uint32_t)item);
+        const int wi = item - p * nw;
+        const int64_t row = row0 + p;
+        uint8_t* cb = cbuf + p * CW;
+        if (wi == 0) {
+          cb[0] = SYM_PAD;
+          cb[Lwin + 1] = SYM_PAD;
+        }
+        if (row >= args.n) {
+          for (int k = 0; k < 16; ++k) {
+            const int j = 16 * wi + k;
+            if (j < Lwin) cb[j + 1] = SYM_N;
+          }
+          continue;
+        }
+        const int64_t ws = args.pos[row] - args.radius;
+        const bool neg = args.strand[row] != 0;
+        const int64_t w = (ws >> 4) + wi;
+        const int64_t glen = args.genome.length;
+        uint32_t word = 0, mword = 0;
+        if (w >= 0 && 16 * w < glen) {
+          word = args.genome.packed2[w];
+          mword = args.genome.nmask[w >> 1] >> (16u * (uint32_t)(w & 1));
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int64_t gpos = 16 * w + k;
+          const int64_t j64 = neg ? (ws + Lwin - 1 - gpos) : (gpos - ws);
+          if (j64 >= 0 && j64 < Lwin) {
+            uint32_t sym = (word >> (2 * k)) & 3u;
+            if (neg) sym = 3u - sym;
+            if (gpos < 0 || gpos >= glen || ((mword >> k) & 1u)) sym = SYM_N;
+            cb[(int)j64 + 1] = (uint8_t)sym;
           }
         }
-        cb[jj] = (uint8_t)sym;
+      }
+    } else {
+      for (int p = 0; p < P; ++p) {
+        const int64_t row = row0 + p;
+        uint8_t* cb = cbuf + p * CW;
+        for (int jj = tid; jj < Lwin + 2; jj += SNV_THREADS) {
+          uint32_t sym = SYM_PAD;
+          const int j = jj - 1;
+          if (j >= 0 && j < Lwin) sym = (row < args.n) ? (uint32_t)args.codes[row * Lwin + j] : (uint32_t)SYM_N;
+          cb[jj] = (uint8_t)sym;
+        }
       }
     }
     __syncthreads();
@@ -118,6 +250,18 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
     for (int tw_i = 0; tw_i < 2; ++tw_i) {
       const TowerGeom& g = args.geom[tw_i];
       const TowerDev& tw = args.tw[tw_i];
+
+      // weights of the first conv + entry BN: issued now, consumed after stage 1
+      float a_cur[SNV_KSTEPS];
+      {
+        const float* wf = tw.wfrag + (size_t)mb * SNV_KSTEPS * 64 + lane;
+#pragma unroll
+        for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
+      }
+      const int chv = 16 * mb + 4 * kk;  // first of this lane's 4 output channels
+      f32x4 pb_cur = ld4(tw.bias + chv), ps_cur = ld4(tw.post_s + chv), pt_cur = ld4(tw.post_t + chv);
+      const f32x4 es = ld4(tw.ex_s + EX_RB1_ENTRY * 32 + chv), et = ld4(tw.ex_t + EX_RB1_ENTRY * 32 + chv);
+
       // -------------------------------------------------------------- stage 1: LUT conv + maxpool1 -> bufA
       {
         float* lutS = bufB;  // [125][32] | taps [3][16][32] | bias0 [32]
@@ -130,41 +274,52 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         const int L1 = g.L1, L2 = g.L[0], Sc = g.Sc[0];
         const int pk = g.pk[0], ps = g.ps[0], pp = g.pp[0];
         const int total = P * L2 * 8;
+        const int cg = tid & 7;
         for (int task = tid; task < total; task += SNV_THREADS) {
-          const int cg = task & 7;
           const uint32_t pj = (uint32_t)task >> 3;
           const uint32_t p = g.dL[0].div(pj);
           const int j2 = (int)(pj - p * (uint32_t)L2);
           const uint8_t* cb = cbuf + p * CW + g.col0;  // cb[j+1] is the symbol of tower column j
           const uint8_t* kx = kidx + p * KW + g.col0;
-          f32x4 m = splat(-INFINITY);
           const int jlo = j2 * ps - pp;
-          for (int w = 0; w < pk; ++w) {
-            const int j = jlo + w;
-            if (j < 0 || j >= L1) continue;
-            const uint32_t idx = kx[j];
-            f32x4 v;
-            if (idx != 255u && j > 0 && j < L1 - 1) {
-              v = ld4(lutS + idx * 32u + 4u * cg);
-            } else {
-              const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
-              const uint32_t sc = cb[j + 1];
-              const uint32_t sr = (j == L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
-              v = ld4(b0S + 4 * cg);
-              v += ld4(tapS + (0 * N_SYM + sl) * 32 + 4 * cg);
-              v += ld4(tapS + (1 * N_SYM + sc) * 32 + 4 * cg);
-              v += ld4(tapS + (2 * N_SYM + sr) * 32 + 4 * cg);
+          f32x4 m;
+          bool done = false;
+          if (jlo >= 1 && jlo + pk <= L1 - 1) {      // window strictly inside: table lookups only
+            if (pk == 15) m = lut_window_fast<15>(lutS, kx, jlo, cg, done);
+            else if (pk == 3) m = lut_window_fast<3>(lutS, kx, jlo, cg, done);
+          }
+          if (!done) {
+            m = splat(-INFINITY);
+            for (int w = 0; w < pk; ++w) {
+              const int j = jlo + w;
+              if (j < 0 || j >= L1) continue;
+              const uint32_t idx = kx[j];
+              f32x4 v;
+              if (idx != 255u && j > 0 && j < L1 - 1) {
+                v = ld4(lutS + idx * 32u + 4u * cg);
+              } else {
+                const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
+                const uint32_t sc = cb[j + 1];
+                const uint32_t sr = (j == L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
+                v = ld4(b0S + 4 * cg);
+                v += ld4(tapS + (0 * N_SYM + sl) * 32 + 4 * cg);
+                v += ld4(tapS + (1 * N_SYM + sc) * 32 + 4 * cg);
+                v += ld4(tapS + (2 * N_SYM + sr) * 32 + 4 * cg);
+              }
+              m = max4(m, v);
             }
-            m = max4(m, v);
           }
           const int c = 1 + (int)p * Sc + j2;
           st4(bufA + lds_off(c + 1, cg), m);
         }
-        // zero separators / tail padding of the stage-2 geometry
-        const int ncol = 16 * g.nb[0];
-        for (int task = tid; task < ncol * 8; task += SNV_THREADS) {
-          const int c = task >> 3, cg = task & 7;
-          if (!col_is_data(c, g.dSc[0], Sc, L2, P)) st4(bufA + lds_off(c + 1, cg), splat(0.f));
+        // zero the separator columns and the tail padding of the stage-2 geometry
+        {
+          const int nz = 1 + P + (16 * g.nb[0] - g.NC[0]);
+          for (int task = tid; task < nz * 8; task += SNV_THREADS) {
+            const int k = task >> 3;
+            const int c = (k <= P) ? k * Sc : g.NC[0] + (k - P - 1);
+            st4(bufA + lds_off(c + 1, task & 7), splat(0.f));
+          }
         }
         __syncthreads();
         if (args.taps != nullptr && tile == 0) {
@@ -174,43 +329,34 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
 
       // -------------------------------------------------------------- residual stream -> registers, BN-ReLU in place
-      float xres[SNV_NBMAX][8];
-      const int n16 = lane & 15, kk = lane >> 4;
+      f32x4 xres[SNV_NB2MAX];
+      StageAddr sa = stage_setup(g, 0, P, n16, kk, mb, cgp);
       {
-        const f32x4 s0 = ld4(tw.ex_s + EX_RB1_ENTRY * 32 + 4 * kk), s1 = ld4(tw.ex_s + EX_RB1_ENTRY * 32 + 16 + 4 * kk);
-        const f32x4 t0 = ld4(tw.ex_t + EX_RB1_ENTRY * 32 + 4 * kk), t1 = ld4(tw.ex_t + EX_RB1_ENTRY * 32 + 16 + 4 * kk);
+        char* A = reinterpret_cast<char*>(bufA);
 #pragma unroll
-        for (int i = 0; i < SNV_NBMAX; ++i) {
-          const int b = wave + SNV_WAVES * i;
-          if (b < g.nb[0]) {
-            const int c = 16 * b + n16;
-            const f32x4 v0 = ld4(bufA + lds_off(c + 1, kk));
-            const f32x4 v1 = ld4(bufA + lds_off(c + 1, 4 + kk));
-            xres[i][0] = v0.x; xres[i][1] = v0.y; xres[i][2] = v0.z; xres[i][3] = v0.w;
-            xres[i][4] = v1.x; xres[i][5] = v1.y; xres[i][6] = v1.z; xres[i][7] = v1.w;
-            const bool valid = col_is_data(c, g.dSc[0], g.Sc[0], g.L[0], P);
-            st4(bufA + lds_off(c + 1, kk), valid ? relu_bn(v0, s0, t0) : splat(0.f));
-            st4(bufA + lds_off(c + 1, 4 + kk), valid ? relu_bn(v1, s1, t1) : splat(0.f));
-          } else {
-#pragma unroll
-            for (int r = 0; r < 8; ++r) xres[i][r] = 0.f;
+        for (int i = 0; i < SNV_NB2MAX; ++i) {
+          xres[i] = splat(0.f);
+          if (cgp + 2 * i < g.nb[0]) {
+            const f32x4 v = lds_ld4(A, sa.wr + 4096u * i);
+            xres[i] = v;
+            lds_st4(A, sa.wr + 4096u * i, ((sa.vmask >> i) & 1u) ? relu_bn(v, es, et) : splat(0.f));
           }
         }
       }
       __syncthreads();
 
       // -------------------------------------------------------------- the ten 32->32 convs
+      f32x4 pool_s = splat(1.f), pool_t = splat(0.f);
       for (int layer = 0; layer < SNV_NLAYER; ++layer) {
         const int st = layer < 4 ? 0 : (layer < 9 ? 1 : 2);
         if (layer == 4 || layer == 9) {
           // max-pool (raw y in bufA) + BN (no ReLU) -> bufB in the next stage's geometry
           const int si = st - 1;  // input stage
-          const int ex = (layer == 4) ? EX_BN_MID : EX_BN_OUT;
           const int Lin = g.L[si], Lout = g.L[st], ScI = g.Sc[si], ScO = g.Sc[st];
           const int pk = g.pk[st], ps = g.ps[st], pp = g.pp[st];
           const int total = P * Lout * 8;
+          const int cg = tid & 7;
           for (int task = tid; task < total; task += SNV_THREADS) {
-            const int cg = task & 7;
             const uint32_t pj = (uint32_t)task >> 3;
             const uint32_t p = g.dL[st].div(pj);
             const int jo = (int)(pj - p * (uint32_t)Lout);
@@ -221,15 +367,19 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
               if (j < 0 || j >= Lin) continue;
               m = max4(m, ld4(bufA + lds_off(1 + (int)p * ScI + j + 1, cg)));
             }
-            const f32x4 s = ld4(tw.ex_s + ex * 32 + 4 * cg), t = ld4(tw.ex_t + ex * 32 + 4 * cg);
-            m = f32x4{fmaf(s.x, m.x, t.x), fmaf(s.y, m.y, t.y), fmaf(s.z, m.z, t.z), fmaf(s.w, m.w, t.w)};
+            m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
+                      fmaf(pool_s.w, m.w, pool_t.w)};
             st4(bufB + lds_off(1 + (int)p * ScO + jo + 1, cg), m);
           }
-          const int ncol = 16 * g.nb[st];
-          for (int task = tid; task < ncol * 8; task += SNV_THREADS) {
-            const int c = task >> 3, cg = task & 7;
-            if (!col_is_data(c, g.dSc[st], ScO, Lout, P)) st4(bufB + lds_off(c + 1, cg), splat(0.f));
+          {
+            const int nz = 1 + P + (16 * g.nb[st] - g.NC[st]);
+            for (int task = tid; task < nz * 8; task += SNV_THREADS) {
+              const int k = task >> 3;
+              const int c = (k <= P) ? k * ScO : g.NC[st] + (k - P - 1);
+              st4(bufB + lds_off(c + 1, task & 7), splat(0.f));
+            }
           }
+          sa = stage_setup(g, st, P, n16, kk, mb, cgp);
           __syncthreads();
           if (args.taps != nullptr && tile == 0) {
             float* dst = args.taps + (size_t)(tw_i * 6 + (layer == 4 ? 2 : 4)) * args.tap_stride;
@@ -239,77 +389,61 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
 
         const int mode = layer_mode(layer);
         const bool in_is_a = ((0xA5u >> layer) & 1u) != 0;
-        const float* in = in_is_a ? bufA : bufB;
-        float* out = in_is_a ? bufB : bufA;
-        const int nb = g.nb[st], Sc = g.Sc[st], Lv = g.L[st];
-        const FastDiv dSc = g.dSc[st];
+        const char* in = reinterpret_cast<const char*>(in_is_a ? bufA : bufB);
+        char* out = reinterpret_cast<char*>(in_is_a ? bufB : bufA);
+        const int nb = g.nb[st];
 
-        const float* wf = tw.wfrag + (size_t)layer * SNV_WFRAG;
-        float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
+        // prefetch the next layer's A fragments and affine maps (consumed after this layer's barrier)
+        float a_nxt[SNV_KSTEPS];
+        const int ln = layer < SNV_NLAYER - 1 ? layer + 1 : layer;
+        {
+          const float* wf = tw.wfrag + (size_t)ln * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
-        for (int s = 0; s < SNV_KSTEPS; ++s) {
-          a0[s] = wf[s * 64 + lane];
-          a1[s] = wf[(SNV_KSTEPS + s) * 64 + lane];
+          for (int s = 0; s < SNV_KSTEPS; ++s) a_nxt[s] = wf[s * 64];
         }
-        const f32x4 bias0 = ld4(tw.bias + layer * 32 + 4 * kk), bias1 = ld4(tw.bias + layer * 32 + 16 + 4 * kk);
-        const f32x4 ps0 = ld4(tw.post_s + layer * 32 + 4 * kk), ps1 = ld4(tw.post_s + layer * 32 + 16 + 4 * kk);
-        const f32x4 pt0 = ld4(tw.post_t + layer * 32 + 4 * kk), pt1 = ld4(tw.post_t + layer * 32 + 16 + 4 * kk);
+        const f32x4 pb_nxt = ld4(tw.bias + ln * 32 + chv), ps_nxt = ld4(tw.post_s + ln * 32 + chv),
+                    pt_nxt = ld4(tw.post_t + ln * 32 + chv);
+        if (layer == 3 || layer == 8) {
+          const int ex = layer == 3 ? EX_BN_MID : EX_BN_OUT;
+          pool_s = ld4(tw.ex_s + ex * 32 + 4 * (tid & 7));
+          pool_t = ld4(tw.ex_t + ex * 32 + 4 * (tid & 7));
+        }
 
+        const bool use_res = (mode == MODE_RES_FIRST || mode == MODE_RES_LAST);
 #pragma unroll
-        for (int i = 0; i < SNV_NBMAX; ++i) {
-          const int b = wave + SNV_WAVES * i;
-          if (b < nb) {
-            const int c = 16 * b + n16;
-            f32x4 acc0 = bias0, acc1 = bias1;
-            if (mode == MODE_RES_FIRST || mode == MODE_RES_LAST) {
-              acc0 += f32x4{xres[i][0], xres[i][1], xres[i][2], xres[i][3]};
-              acc1 += f32x4{xres[i][4], xres[i][5], xres[i][6], xres[i][7]};
+        for (int ip = 0; ip < (SNV_NB2MAX + 1) / 2; ++ip) {
+          const int i0 = 2 * ip, i1 = 2 * ip + 1;
+          const bool has0 = cgp + 2 * i0 < nb;
+          const bool has1 = (i1 < SNV_NB2MAX) && (cgp + 2 * i1 < nb);
+          if (has0) {
+            f32x4 acc0 = pb_cur, acc1 = pb_cur;
+            if (use_res) {
+              acc0 += xres[i0];
+              if (i1 < SNV_NB2MAX) acc1 += xres[i1];
             }
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-              const int pc = c + t;  // logical column c + t - 1, physical +1
-#pragma unroll
-              for (int h = 0; h < 2; ++h) {
-                const f32x4 bv = ld4(in + lds_off(pc, 4 * h + kk));
-                const int s = 8 * t + 4 * h;
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s + 0], bv.x, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s + 0], bv.x, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s + 1], bv.y, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s + 1], bv.y, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s + 2], bv.z, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s + 2], bv.z, acc1, 0, 0, 0);
-                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s + 3], bv.w, acc0, 0, 0, 0);
-                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s + 3], bv.w, acc1, 0, 0, 0);
-              }
-            }
-            const bool valid = col_is_data(c, dSc, Sc, Lv, P);
-            f32x4 o0, o1;
-            if (mode == MODE_RES_LAST) {
-              o0 = acc0; o1 = acc1;
-            } else if (mode == MODE_FINAL) {
-              o0 = max4(acc0, splat(0.f)); o1 = max4(acc1, splat(0.f));
+            if (has1) {
+              mfma_blocks<true>(in, sa, 4096u * i0, 4096u * i1, a_cur, acc0, acc1);
+              epilogue(mode, acc0, xres[i0], (sa.vmask >> i0) & 1u, ps_cur, pt_cur, out, sa.wr + 4096u * i0);
+              if (i1 < SNV_NB2MAX)
+                epilogue(mode, acc1, xres[i1], (sa.vmask >> i1) & 1u, ps_cur, pt_cur, out, sa.wr + 4096u * i1);
             } else {
-              o0 = relu_bn(acc0, ps0, pt0); o1 = relu_bn(acc1, ps1, pt1);
+              mfma_blocks<false>(in, sa, 4096u * i0, 0u, a_cur, acc0, acc1);
+              epilogue(mode, acc0, xres[i0], (sa.vmask >> i0) & 1u, ps_cur, pt_cur, out, sa.wr + 4096u * i0);
             }
-            if (mode == MODE_RES_FIRST) {        // z = x1 + x0 carries the outer skip (model_snv.py:477-479)
-              xres[i][0] += acc0.x; xres[i][1] += acc0.y; xres[i][2] += acc0.z; xres[i][3] += acc0.w;
-              xres[i][4] += acc1.x; xres[i][5] += acc1.y; xres[i][6] += acc1.z; xres[i][7] += acc1.w;
-            } else if (mode == MODE_ENTRY) {
-              xres[i][0] = acc0.x; xres[i][1] = acc0.y; xres[i][2] = acc0.z; xres[i][3] = acc0.w;
-              xres[i][4] = acc1.x; xres[i][5] = acc1.y; xres[i][6] = acc1.z; xres[i][7] = acc1.w;
-            }
-            st4(out + lds_off(c + 1, kk), valid ? o0 : splat(0.f));
-            st4(out + lds_off(c + 1, 4 + kk), valid ? o1 : splat(0.f));
           }
         }
         __syncthreads();
+#pragma unroll
+        for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = a_nxt[s];
+        pb_cur = pb_nxt; ps_cur = ps_nxt; pt_cur = pt_nxt;
         if (args.taps != nullptr && tile == 0 && (layer == 3 || layer == 8 || layer == 9)) {
           float* dst = args.taps + (size_t)(tw_i * 6 + (layer == 3 ? 1 : (layer == 8 ? 3 : 5))) * args.tap_stride;
-          for (int i = tid; i < args.nbuf; i += SNV_THREADS) dst[i] = out[i];
+          const float* o = reinterpret_cast<const float*>(out);
+          for (int i = tid; i < args.nbuf; i += SNV_THREADS) dst[i] = o[i];
         }
       }
 
-      // -------------------------------------------------------------- global max -> BN -> Linear (per tower)
+      // -------------------------------------------------------------- global max per (position, channel)
       {
         const int L4 = g.L[2], Sc4 = g.Sc[2];
         float* ft = feat + tw_i * P * SNV_C;
@@ -320,19 +454,35 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
             const int pc = 1 + p * Sc4 + j + 1;
             m = fmaxf(m, bufA[lds_off(pc, ch >> 2) + (ch & 3)]);
           }
-          ft[t] = fmaf(tw.ex_s[EX_FC_BN * 32 + ch], m, tw.ex_t[EX_FC_BN * 32 + ch]);
+          ft[t] = m;
         }
-        __syncthreads();
-        float* lg = logit + tw_i * P * SNV_MAXCLASS;
-        for (int t = tid; t < P * args.n_class; t += SNV_THREADS) {
-          const int p = t / args.n_class, k = t - p * args.n_class;
-          float acc = tw.fc_b[k];
-          for (int ch = 0; ch < SNV_C; ++ch) acc = fmaf(tw.fc_w[k * SNV_C + ch], ft[p * SNV_C + ch], acc);
-          lg[p * SNV_MAXCLASS + k] = acc;
-        }
-        __syncthreads();
+        // next tower's LUT staging overwrites bufB only; bufA is rewritten after the following barrier
       }
     }  // towers
+    __syncthreads();
+
+    // ------------------------------------------------------------------ BN+Linear per tower (BN folded on the host)
+    for (int t = tid; t < 2 * P * args.n_class; t += SNV_THREADS) {
+      const int k = t % args.n_class;
+      const int tp = t / args.n_class;  // tower * P + p
+      const int tw_i = tp / P;
+      const float* w = args.tw[tw_i].fc_w + k * SNV_C;
+      const float* f = feat + tp * SNV_C;
+      f32x4 wv[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) wv[q] = ld4(w + 4 * q);
+      float acc = args.tw[tw_i].fc_b[k];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 fv = ld4(f + 4 * q);
+        acc = fmaf(wv[q].x, fv.x, acc);
+        acc = fmaf(wv[q].y, fv.y, acc);
+        acc = fmaf(wv[q].z, fv.z, acc);
+        acc = fmaf(wv[q].w, fv.w, acc);
+      }
+      logit[tp * SNV_MAXCLASS + k] = acc;
+    }
+    __syncthreads();
 
     // ------------------------------------------------------------------ head (model_snv.py:515-523 / :284)
     if (tid < P && row0 + tid < args.n) {

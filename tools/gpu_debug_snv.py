@@ -94,7 +94,7 @@ def main(r=7, R=1000, seed=21, B=6):
     logit = small[2 * P * 32: 2 * P * 32 + 2 * P * 16].reshape(2, P, 16)
     for tw, sfx in ((0, "_2"), (1, "")):
         fcname = "distal_fc2" if tw == 0 else "distal_fc1"
-        ref_feat = bn_eval(fcname + ".0", taps_o["gmax" + sfx].numpy()[:P][:, :, None])[:, :, 0]
+        ref_feat = taps_o["gmax" + sfx].numpy()[:P]
         print(f"tower {tw} feat err {np.abs(feat[tw] - ref_feat).max():.3e}  logits err "
               f"{np.abs(logit[tw][:, :4] - taps_o['fc' + sfx].numpy()[:P]).max():.3e}")
     print("final logp err", np.abs(got - want).max(), " prob err", np.abs(np.exp(got) - np.exp(want)).max())
