@@ -101,46 +101,122 @@ __device__ __forceinline__ void mfma_tap(const float (&a)[SNV_KSTEPS], int t, co
   }
 }
 
-template <bool DUAL>
-__device__ __forceinline__ void mfma_blocks(const char* in, const StageAddr& sa, uint32_t imm0, uint32_t imm1,
-                                            const float (&a)[SNV_KSTEPS], f32x4& acc0, f32x4& acc1) {
-  f32x4 x0[2], x1[2], y0[2], y1[2], z0[2], z1[2];
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    x0[h] = lds_ld4(in, sa.rd[0 + h] + imm0);
-    if (DUAL) x1[h] = lds_ld4(in, sa.rd[0 + h] + imm1);
-  }
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    y0[h] = lds_ld4(in, sa.rd[2 + h] + imm0);
-    if (DUAL) y1[h] = lds_ld4(in, sa.rd[2 + h] + imm1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tap<DUAL>(a, 0, x0, x1, acc0, acc1);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    z0[h] = lds_ld4(in, sa.rd[4 + h] + imm0);
-    if (DUAL) z1[h] = lds_ld4(in, sa.rd[4 + h] + imm1);
-  }
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tap<DUAL>(a, 1, y0, y1, acc0, acc1);
-  __builtin_amdgcn_sched_barrier(0);
-  mfma_tap<DUAL>(a, 2, z0, z1, acc0, acc1);
+// Branch-free epilogue.  Per-layer scalars select the role of the layer (see layer_mode):
+//   out  = valid ? ps * max(acc, lo) + pt : 0      lo = 0 (ReLU) or -inf (raw); raw layers carry ps = 1, pt = 0
+//   xres = ku * acc + kx * xres                    (1,1) first conv2 of a group: z = x1 + x0 keeps the outer skip
+//                                                  (model_snv.py:477-479); (1,0) entry conv; (0,1) otherwise
+struct LayerK { float lo, ku, kx, kr; };
+
+__device__ __forceinline__ LayerK layer_consts(int mode) {
+  LayerK k;
+  k.lo = (mode == MODE_RES_LAST) ? -INFINITY : 0.f;
+  k.ku = (mode == MODE_RES_FIRST || mode == MODE_ENTRY) ? 1.f : 0.f;
+  k.kx = (mode == MODE_ENTRY) ? 0.f : 1.f;
+  k.kr = (mode == MODE_RES_FIRST || mode == MODE_RES_LAST) ? 1.f : 0.f;   // accumulator starts from bias + kr * xres
+  return k;
 }
 
-__device__ __forceinline__ void epilogue(int mode, f32x4 acc, f32x4& xr, bool valid, f32x4 ps, f32x4 pt, char* out,
+__device__ __forceinline__ void epilogue(const LayerK& k, f32x4 acc, f32x4& xr, bool valid, f32x4 ps, f32x4 pt, char* out,
                                          uint32_t off) {
   f32x4 o;
-  if (mode == MODE_RES_LAST) {
-    o = acc;
-  } else if (mode == MODE_FINAL) {
-    o = max4(acc, splat(0.f));
-  } else {
-    o = relu_bn(acc, ps, pt);
-  }
-  if (mode == MODE_RES_FIRST) xr += acc;       // z = x1 + x0 carries the outer skip (model_snv.py:477-479)
-  else if (mode == MODE_ENTRY) xr = acc;
+  o.x = fmaf(ps.x, fmaxf(acc.x, k.lo), pt.x);
+  o.y = fmaf(ps.y, fmaxf(acc.y, k.lo), pt.y);
+  o.z = fmaf(ps.z, fmaxf(acc.z, k.lo), pt.z);
+  o.w = fmaf(ps.w, fmaxf(acc.w, k.lo), pt.w);
+  xr.x = fmaf(acc.x, k.ku, xr.x * k.kx);
+  xr.y = fmaf(acc.y, k.ku, xr.y * k.kx);
+  xr.z = fmaf(acc.z, k.ku, xr.z * k.kx);
+  xr.w = fmaf(acc.w, k.ku, xr.w * k.kx);
   lds_st4(out, off, valid ? o : splat(0.f));
+}
+
+__device__ __forceinline__ f32x4 acc_init(const LayerK& k, f32x4 pb, f32x4 xr) {
+  return f32x4{fmaf(xr.x, k.kr, pb.x), fmaf(xr.y, k.kr, pb.y), fmaf(xr.z, k.kr, pb.z), fmaf(xr.w, k.kr, pb.w)};
+}
+
+// One 32->32 k=3 conv layer for this wave: its M-block against the 16-column blocks it owns.  Full pairs of blocks
+// run as two independent accumulator chains, software-pipelined: tap-0 operands were read during the previous
+// pair, tap-1/2 reads are in flight under the tap-0/1 MFMAs, and the previous pair's epilogue issues between this
+// pair's MFMA groups.  An odd last block runs as a single chain.
+__device__ __forceinline__ void conv_layer(const char* in, char* out, const StageAddr& sa, int nbw, const LayerK& k,
+                                           const float (&a)[SNV_KSTEPS], f32x4 pb, f32x4 ps, f32x4 pt,
+                                           f32x4 (&xres)[SNV_NB2MAX]) {
+  constexpr int NPF = SNV_NB2MAX / 2;   // full pairs that fit the register file
+  const int nfull = nbw >> 1;
+  f32x4 X0[2], X1[2];
+  f32x4 pa0 = splat(0.f), pa1 = splat(0.f);
+  if (nfull > 0) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      X0[h] = lds_ld4(in, sa.rd[h]);
+      X1[h] = lds_ld4(in, sa.rd[h] + 4096u);
+    }
+  }
+#pragma unroll
+  for (int ip = 0; ip < NPF; ++ip) {
+    const int i0 = 2 * ip, i1 = 2 * ip + 1;
+    if (ip < nfull) {
+      f32x4 Y0[2], Y1[2], Z0[2], Z1[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        Y0[h] = lds_ld4(in, sa.rd[2 + h] + 4096u * i0);
+        Y1[h] = lds_ld4(in, sa.rd[2 + h] + 4096u * i1);
+      }
+      f32x4 acc0 = acc_init(k, pb, xres[i0]), acc1 = acc_init(k, pb, xres[i1]);
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tap<true>(a, 0, X0, X1, acc0, acc1);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        Z0[h] = lds_ld4(in, sa.rd[4 + h] + 4096u * i0);
+        Z1[h] = lds_ld4(in, sa.rd[4 + h] + 4096u * i1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (ip > 0) {   // epilogue of the previous pair rides under this pair's tap-1 MFMAs
+        epilogue(k, pa0, xres[i0 - 2], (sa.vmask >> (i0 - 2)) & 1u, ps, pt, out, sa.wr + 4096u * (i0 - 2));
+        epilogue(k, pa1, xres[i0 - 1], (sa.vmask >> (i0 - 1)) & 1u, ps, pt, out, sa.wr + 4096u * (i0 - 1));
+      }
+      mfma_tap<true>(a, 1, Y0, Y1, acc0, acc1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (ip + 1 < nfull) {   // tap-0 operands of the next pair
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          X0[h] = lds_ld4(in, sa.rd[h] + 4096u * (i0 + 2));
+          X1[h] = lds_ld4(in, sa.rd[h] + 4096u * (i0 + 3));
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      mfma_tap<true>(a, 2, Z0, Z1, acc0, acc1);
+      pa0 = acc0;
+      pa1 = acc1;
+    } else if (ip > 0 && ip == nfull) {   // the previous pair was the last full one
+      epilogue(k, pa0, xres[i0 - 2], (sa.vmask >> (i0 - 2)) & 1u, ps, pt, out, sa.wr + 4096u * (i0 - 2));
+      epilogue(k, pa1, xres[i0 - 1], (sa.vmask >> (i0 - 1)) & 1u, ps, pt, out, sa.wr + 4096u * (i0 - 1));
+    }
+  }
+  if (nfull == NPF) {
+    epilogue(k, pa0, xres[2 * NPF - 2], (sa.vmask >> (2 * NPF - 2)) & 1u, ps, pt, out, sa.wr + 4096u * (2 * NPF - 2));
+    epilogue(k, pa1, xres[2 * NPF - 1], (sa.vmask >> (2 * NPF - 1)) & 1u, ps, pt, out, sa.wr + 4096u * (2 * NPF - 1));
+  }
+  if (nbw & 1) {   // odd last block: a single accumulator chain
+#pragma unroll
+    for (int i0 = 0; i0 < SNV_NB2MAX; i0 += 2) {
+      if (nbw - 1 == i0) {
+        f32x4 S0[2], S1[2], S2[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          S0[h] = lds_ld4(in, sa.rd[0 + h] + 4096u * i0);
+          S1[h] = lds_ld4(in, sa.rd[2 + h] + 4096u * i0);
+          S2[h] = lds_ld4(in, sa.rd[4 + h] + 4096u * i0);
+        }
+        f32x4 acc0 = acc_init(k, pb, xres[i0]), acc1 = acc0;
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_tap<false>(a, 0, S0, S0, acc0, acc1);
+        mfma_tap<false>(a, 1, S1, S1, acc0, acc1);
+        mfma_tap<false>(a, 2, S2, S2, acc0, acc1);
+        epilogue(k, acc0, xres[i0], (sa.vmask >> i0) & 1u, ps, pt, out, sa.wr + 4096u * i0);
+      }
+    }
+  }
 }
 
 template <int PK>
@@ -259,7 +335,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
       }
       const int chv = 16 * mb + 4 * kk;  // first of this lane's 4 output channels
-      f32x4 pb_cur = ld4(tw.bias + chv), ps_cur = ld4(tw.post_s + chv), pt_cur = ld4(tw.post_t + chv);
       const f32x4 es = ld4(tw.ex_s + EX_RB1_ENTRY * 32 + chv), et = ld4(tw.ex_t + EX_RB1_ENTRY * 32 + chv);
 
       // -------------------------------------------------------------- stage 1: LUT conv + maxpool1 -> bufA
@@ -346,7 +421,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       __syncthreads();
 
       // -------------------------------------------------------------- the ten 32->32 convs
-      f32x4 pool_s = splat(1.f), pool_t = splat(0.f);
       for (int layer = 0; layer < SNV_NLAYER; ++layer) {
         const int st = layer < 4 ? 0 : (layer < 9 ? 1 : 2);
         if (layer == 4 || layer == 9) {
@@ -356,6 +430,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           const int pk = g.pk[st], ps = g.ps[st], pp = g.pp[st];
           const int total = P * Lout * 8;
           const int cg = tid & 7;
+          const int ex = layer == 4 ? EX_BN_MID : EX_BN_OUT;
+          const f32x4 pool_s = ld4(tw.ex_s + ex * 32 + 4 * cg), pool_t = ld4(tw.ex_t + ex * 32 + 4 * cg);
           for (int task = tid; task < total; task += SNV_THREADS) {
             const uint32_t pj = (uint32_t)task >> 3;
             const uint32_t p = g.dL[st].div(pj);
@@ -387,55 +463,28 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           }
         }
 
-        const int mode = layer_mode(layer);
+        const LayerK lk = layer_consts(layer_mode(layer));
         const bool in_is_a = ((0xA5u >> layer) & 1u) != 0;
         const char* in = reinterpret_cast<const char*>(in_is_a ? bufA : bufB);
         char* out = reinterpret_cast<char*>(in_is_a ? bufB : bufA);
         const int nb = g.nb[st];
+        const int nbw = nb > cgp ? (nb - cgp + 1) / 2 : 0;   // blocks cgp, cgp+2, ... < nb
 
-        // prefetch the next layer's A fragments and affine maps (consumed after this layer's barrier)
+        // prefetch the next layer's A fragments (consumed after this layer's barrier)
         float a_nxt[SNV_KSTEPS];
         const int ln = layer < SNV_NLAYER - 1 ? layer + 1 : layer;
         {
-          const float* wf = tw.wfrag + (size_t)ln * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
+          const float* wfn = tw.wfrag + (size_t)ln * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
-          for (int s = 0; s < SNV_KSTEPS; ++s) a_nxt[s] = wf[s * 64];
+          for (int s = 0; s < SNV_KSTEPS; ++s) a_nxt[s] = wfn[s * 64];
         }
-        const f32x4 pb_nxt = ld4(tw.bias + ln * 32 + chv), ps_nxt = ld4(tw.post_s + ln * 32 + chv),
-                    pt_nxt = ld4(tw.post_t + ln * 32 + chv);
-        if (layer == 3 || layer == 8) {
-          const int ex = layer == 3 ? EX_BN_MID : EX_BN_OUT;
-          pool_s = ld4(tw.ex_s + ex * 32 + 4 * (tid & 7));
-          pool_t = ld4(tw.ex_t + ex * 32 + 4 * (tid & 7));
-        }
-
-        const bool use_res = (mode == MODE_RES_FIRST || mode == MODE_RES_LAST);
-#pragma unroll
-        for (int ip = 0; ip < (SNV_NB2MAX + 1) / 2; ++ip) {
-          const int i0 = 2 * ip, i1 = 2 * ip + 1;
-          const bool has0 = cgp + 2 * i0 < nb;
-          const bool has1 = (i1 < SNV_NB2MAX) && (cgp + 2 * i1 < nb);
-          if (has0) {
-            f32x4 acc0 = pb_cur, acc1 = pb_cur;
-            if (use_res) {
-              acc0 += xres[i0];
-              if (i1 < SNV_NB2MAX) acc1 += xres[i1];
-            }
-            if (has1) {
-              mfma_blocks<true>(in, sa, 4096u * i0, 4096u * i1, a_cur, acc0, acc1);
-              epilogue(mode, acc0, xres[i0], (sa.vmask >> i0) & 1u, ps_cur, pt_cur, out, sa.wr + 4096u * i0);
-              if (i1 < SNV_NB2MAX)
-                epilogue(mode, acc1, xres[i1], (sa.vmask >> i1) & 1u, ps_cur, pt_cur, out, sa.wr + 4096u * i1);
-            } else {
-              mfma_blocks<false>(in, sa, 4096u * i0, 0u, a_cur, acc0, acc1);
-              epilogue(mode, acc0, xres[i0], (sa.vmask >> i0) & 1u, ps_cur, pt_cur, out, sa.wr + 4096u * i0);
-            }
-          }
-        }
+        // affine maps of THIS layer: needed only in the epilogues, a full MFMA group later
+        const f32x4 pb = ld4(tw.bias + layer * 32 + chv), ps = ld4(tw.post_s + layer * 32 + chv),
+                    pt = ld4(tw.post_t + layer * 32 + chv);
+        conv_layer(in, out, sa, nbw, lk, a_cur, pb, ps, pt, xres);
         __syncthreads();
 #pragma unroll
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = a_nxt[s];
-        pb_cur = pb_nxt; ps_cur = ps_nxt; pt_cur = pt_nxt;
         if (args.taps != nullptr && tile == 0 && (layer == 3 || layer == 8 || layer == 9)) {
           float* dst = args.taps + (size_t)(tw_i * 6 + (layer == 3 ? 1 : (layer == 8 ? 3 : 5))) * args.tap_stride;
           const float* o = reinterpret_cast<const float*>(out);
