@@ -176,6 +176,14 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
         epilogue(k, pa1, xres[i0 - 1], (sa.vmask >> (i0 - 1)) & 1u, ps, pt, out, sa.wr + 4096u * (i0 - 1));
       }
       mfma_tap<true>(a, 1, Y0, Y1, acc0, acc1);
+      if (ip > 0) {   // spread the epilogue's VALU work into the MFMA issue gaps
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);   // 1 MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);   // 3 VALU
+        }
+        __builtin_amdgcn_sched_group_barrier(0x200, 2, 0);     // the two ds_write_b128
+      }
       __builtin_amdgcn_sched_barrier(0);
       if (ip + 1 < nfull) {   // tap-0 operands of the next pair
 #pragma unroll
@@ -470,6 +478,11 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         const int nb = g.nb[st];
         const int nbw = nb > cgp ? (nb - cgp + 1) / 2 : 0;   // blocks cgp, cgp+2, ... < nb
 
+        // affine maps of THIS layer (needed only in the epilogues, a full MFMA group later) are requested BEFORE the
+        // prefetch so that their counted vmcnt wait does not drain the prefetch
+        const f32x4 pb = ld4(tw.bias + layer * 32 + chv), ps = ld4(tw.post_s + layer * 32 + chv),
+                    pt = ld4(tw.post_t + layer * 32 + chv);
+        __builtin_amdgcn_sched_barrier(0);
         // prefetch the next layer's A fragments (consumed after this layer's barrier)
         float a_nxt[SNV_KSTEPS];
         const int ln = layer < SNV_NLAYER - 1 ? layer + 1 : layer;
@@ -478,9 +491,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
 #pragma unroll
           for (int s = 0; s < SNV_KSTEPS; ++s) a_nxt[s] = wfn[s * 64];
         }
-        // affine maps of THIS layer: needed only in the epilogues, a full MFMA group later
-        const f32x4 pb = ld4(tw.bias + layer * 32 + chv), ps = ld4(tw.post_s + layer * 32 + chv),
-                    pt = ld4(tw.post_t + layer * 32 + chv);
         conv_layer(in, out, sa, nbw, lk, a_cur, pb, ps, pt, xres);
         __syncthreads();
 #pragma unroll
