@@ -143,6 +143,9 @@ const char* mural_snv_kernel_name(void);
 
 /* Live timing of the dominant kernel: between begin and end every launch of it is bracketed by HIP events
  * on the launch stream; end() synchronises those events and returns the summed duration and the count.  */
+/* Diagnostic only: while a device buffer of 2048*32 uint64 is set, the packed-path tower kernel adds wave 0's
+ * cycles per phase into it (see tools/phase_stamps.py); pass NULL to switch off.                          */
+int mural_debug_set_stamps(void* dev_ptr);
 int mural_profile_begin(void);
 int mural_profile_end(double* total_ms, int64_t* launches);
 

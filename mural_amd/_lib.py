@@ -72,6 +72,7 @@ PROTOTYPES = {
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mural_snv_tap_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "mural_snv_kernel_name": (C.c_char_p, []),
+    "mural_debug_set_stamps": (C.c_int, [C.c_void_p]),
     "mural_profile_begin": (C.c_int, []),
     "mural_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }

@@ -11,7 +11,9 @@ constexpr int SNV_KSTEPS = 24;     // 96 / 4 k-steps of v_mfma_f32_16x16x4_f32
 constexpr int SNV_WFRAG = 2 * SNV_KSTEPS * 64;   // floats per layer: [mblock][kstep][lane]
 constexpr int SNV_LUT = 125 * SNV_C;             // 3-mer lookup table (A,C,G,T,N)^3 x channels
 constexpr int SNV_TAPS = 3 * N_SYM * SNV_C;      // per-tap, per-symbol contributions (generic path)
+constexpr int SNV_LUTBLK = SNV_LUT + SNV_TAPS + SNV_C;   // lut | taps | bias0, contiguous in the blob
 constexpr int SNV_MAXCLASS = 16;
+constexpr int SNV_CHUNK = 32768;   // sites per stage-1 / tower launch pair (bounds the x0 scratch)
 constexpr int SNV_NB2MAX = 9;      // max 16-column blocks a wave owns in one stage (waves split M x column parity)
 constexpr int SNV_THREADS = 256;
 constexpr int SNV_WAVES = SNV_THREADS / 64;
@@ -59,6 +61,20 @@ struct LocalDev {
   int cols, emb_rows, in1, h1, h2, n_class;
 };
 
+struct Stage1Tower { int L1, col0, L2, pk, ps, pp; };
+
+struct Stage1Args {               // snv_stage1_kernel: window decode + first conv layer + maxpool1
+  Stage1Tower tw[2];              // 0 = large, 1 = mid
+  const float* lut[2];            // lut | taps | bias0 blocks of the two towers
+  int Lwin, cw, wave_bytes, x0_cols, nwords, radius;
+  int64_t n;
+  const uint8_t* codes;           // [n][Lwin] symbols (dense path)
+  MuralGenome genome;             // packed path
+  const int64_t* pos;
+  const uint8_t* strand;
+  float* x0;                      // [n][x0_cols][32] pooled first-layer activations (large columns, then mid)
+};
+
 struct SnvFwdArgs {
   TowerGeom geom[2];              // 0 = large, 1 = mid
   TowerDev tw[2];
@@ -68,18 +84,13 @@ struct SnvFwdArgs {
   int n_class;
   int has_local;                  // Network2: mix with local softmax
   int64_t n;                      // rows
-  // input: either symbol rows or the packed genome
-  const uint8_t* codes;           // [n][Lwin] symbols, already strand-oriented (dense path)
-  MuralGenome genome;             // packed path
-  const int64_t* pos;
-  const uint8_t* strand;
-  int radius;                     // distal radius (packed path)
-  int nwords;                     // 16-base genome words that can overlap one window
-  FastDiv dNW;                    // divide by nwords
+  const float* x0;                // [n][x0_cols][32] stage-1 output (snv_stage1_kernel)
+  int x0_cols;                    // L2 large + L2 mid
   const float* local_logits;      // [n][n_class]
   float* out;                     // [n][n_class]
   float* taps;                    // debug dump (tile 0) or nullptr
   int tap_stride;                 // floats per dumped buffer
+  unsigned long long* stamps;     // diagnostic per-phase cycle sums [grid][32] or nullptr
 };
 
 }  // namespace mural
@@ -90,5 +101,7 @@ struct MuralSnvModel {
   mural::LocalDev local;
   float* blob;                    // device allocation holding every folded tensor
   size_t blob_floats;
-  size_t lds_bytes;               // dynamic LDS of the fused kernel
+  size_t lds_bytes;               // dynamic LDS of the tower kernel
+  mural::Stage1Args s1;           // stage-1 kernel arguments (input/output fields filled per call)
+  size_t s1_lds_bytes;
 };

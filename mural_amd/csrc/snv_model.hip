@@ -8,7 +8,8 @@
 #include "snv.h"
 
 namespace mural {
-int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, bool packed, hipStream_t stream);
+int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, hipStream_t stream);
+int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream);
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream);
 
@@ -66,9 +67,9 @@ int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& 
                       bn_ok(T.rbs2[i].bn1) && aff_ok(T.rbs2[i].conv1) && bn_ok(T.rbs2[i].bn2) && aff_ok(T.rbs2[i].conv2),
                   "residual block parameter pointer is NULL");
   }
-  o.lut = B.alloc(SNV_LUT);
-  o.taps = B.alloc(SNV_TAPS);
-  o.bias0 = B.alloc(C);
+  o.lut = B.alloc(SNV_LUTBLK);          // lut | taps | bias0 in one block: the stage-1 kernel stages it with one copy
+  o.taps = o.lut + SNV_LUT;
+  o.bias0 = o.taps + SNV_TAPS;
   o.wfrag = B.alloc((size_t)SNV_NLAYER * SNV_WFRAG);
   o.bias = B.alloc(SNV_NLAYER * C);
   o.post_s = B.alloc(SNV_NLAYER * C);
@@ -219,11 +220,9 @@ size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P) {
   }
   a.P = P;
   a.Lwin = Lwin;
-  a.nwords = (Lwin + 15) / 16 + 1;
-  a.dNW = FastDiv::make((uint32_t)a.nwords);
-  a.nbuf = std::max(maxcols * SNV_C, SNV_LUT + SNV_TAPS + SNV_C);
-  const int CW = (Lwin + 2 + 15) & ~15, KW = (Lwin + 15) & ~15;
-  return (size_t)2 * a.nbuf * 4 + (size_t)P * (CW + KW) + (size_t)(2 * P * SNV_C + 2 * P * SNV_MAXCLASS) * 4;
+  a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
+  a.nbuf = maxcols * SNV_C;
+  return (size_t)2 * a.nbuf * 4 + (size_t)(2 * P * SNV_C + 3 * P * SNV_MAXCLASS) * 4;
 }
 
 constexpr size_t kLdsTwoPerCu = 80 * 1024;
@@ -231,7 +230,7 @@ constexpr size_t kLdsMax = 160 * 1024;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; };
+struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; };
 
 size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
   size_t off = 0;
@@ -243,11 +242,13 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
   const size_t o_ll = take((size_t)n * m->shape.n_class * 4);
   const size_t o_cat = take((size_t)n * std::max(m->shape.local_cols, 1) * 8);
   const size_t o_sym = take(dense ? (size_t)n * m->shape.distal_len : 16);
+  const size_t o_x0 = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.x0_cols, 1) * SNV_C * 4);
   if (w) {
     char* b = static_cast<char*>(base);
     w->local_logits = reinterpret_cast<float*>(b + o_ll);
     w->cat = reinterpret_cast<int64_t*>(b + o_cat);
     w->symbols = reinterpret_cast<uint8_t*>(b + o_sym);
+    w->x0 = reinterpret_cast<float*>(b + o_x0);
   }
   return off;
 }
@@ -302,6 +303,22 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
       } else {
         plan_geometry(m->args, sh.distal_len, P);
         m->lds_bytes = lds;
+        Stage1Args& s1 = m->s1;
+        for (int tw = 0; tw < 2; ++tw) {
+          const TowerGeom& g = m->args.geom[tw];
+          s1.tw[tw] = Stage1Tower{g.L1, g.col0, g.L[0], g.pk[0], g.ps[0], g.pp[0]};
+        }
+        s1.Lwin = sh.distal_len;
+        s1.cw = (sh.distal_len + 2 + 15) & ~15;
+        s1.wave_bytes = (s1.cw + s1.tw[0].L2 * 16 + s1.tw[1].L2 * 4 + 15) & ~15;
+        s1.x0_cols = m->args.x0_cols;
+        s1.nwords = (sh.distal_len + 15) / 16 + 1;
+        s1.radius = (sh.distal_len - 1) / 2;
+        m->s1_lds_bytes = (size_t)2 * SNV_LUTBLK * 4 + (size_t)16 * s1.wave_bytes;
+        if (m->s1_lds_bytes > kLdsMax || s1.tw[0].pk > 16 || s1.tw[1].pk > 4) {
+          set_error("distal_radius %d is too long for the stage-1 kernel's LDS window", (sh.distal_len - 1) / 2);
+          rc = MURAL_E_INVALID;
+        }
       }
     }
   }
@@ -329,6 +346,8 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     }
     m->args.n_class = sh.n_class;
     m->args.has_local = sh.model_no == 2;
+    m->s1.lut[0] = m->args.tw[0].lut;
+    m->s1.lut[1] = m->args.tw[1].lut;
   }
   if (has_local) {
     LocalDev& L = m->local;
@@ -369,6 +388,34 @@ namespace mural { int profile_begin(); int profile_end(double*, int64_t*); }
 extern "C" int mural_profile_begin(void) { return mural::profile_begin(); }
 extern "C" int mural_profile_end(double* total_ms, int64_t* launches) { return mural::profile_end(total_ms, launches); }
 
+static unsigned long long* g_stamps = nullptr;
+extern "C" int mural_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; return MURAL_OK; }
+
+// stage-1 kernel + tower kernel over chunks of SNV_CHUNK sites (the x0 scratch holds one chunk)
+static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool packed, int64_t n, const Workspace& w,
+                      float* out, float* taps, hipStream_t stream) {
+  const int nc = m->shape.n_class;
+  for (int64_t c0 = 0; c0 < n; c0 += SNV_CHUNK) {
+    const int64_t cn = std::min<int64_t>(SNV_CHUNK, n - c0);
+    Stage1Args s = s1;
+    s.n = cn;
+    s.x0 = w.x0;
+    if (packed) { s.pos = s1.pos + c0; s.strand = s1.strand + c0; }
+    else s.codes = s1.codes + c0 * m->shape.distal_len;
+    if (int rc = launch_snv_stage1(s, packed, m->s1_lds_bytes, stream)) return rc;
+    SnvFwdArgs t = a;
+    t.n = cn;
+    t.x0 = w.x0;
+    t.local_logits = w.local_logits + c0 * nc;
+    t.out = out + c0 * nc;
+    t.taps = c0 == 0 ? taps : nullptr;
+    t.tap_stride = a.nbuf;
+    t.stamps = packed ? g_stamps : nullptr;
+    if (int rc = launch_snv_towers(m, t, stream)) return rc;
+  }
+  return MURAL_OK;
+}
+
 static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n, float* out,
                               void* workspace, size_t ws_bytes, int32_t* status, float* taps, size_t taps_floats,
                               void* stream_) {
@@ -394,15 +441,10 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
     if (int rc = launch_snv_local(m->local, cat_x, n, w.local_logits, stream)) return rc;
   }
   if (int rc = launch_dense_to_symbols(distal_x, n, sh.distal_len, w.symbols, status, stream)) return rc;
-  SnvFwdArgs a = m->args;
-  a.n = n;
-  a.codes = w.symbols;
-  a.local_logits = w.local_logits;
-  a.out = out;
-  a.taps = taps;
-  a.tap_stride = a.nbuf;
-  if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * a.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * a.nbuf);
-  return launch_snv_towers(m, a, /*packed=*/false, stream);
+  if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * m->args.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * m->args.nbuf);
+  Stage1Args s1 = m->s1;
+  s1.codes = w.symbols;
+  return run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, stream);
 }
 
 extern "C" int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
@@ -445,14 +487,9 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
     if (int rc = launch_snv_local(m->local, w.cat, n, dst, stream)) return rc;
     if (sh.model_no == 0) return MURAL_OK;
   }
-  SnvFwdArgs a = m->args;
-  a.n = n;
-  a.genome = *g;
-  a.pos = pos;
-  a.strand = strand;
-  a.radius = (sh.distal_len - 1) / 2;
-  a.local_logits = w.local_logits;
-  a.out = out;
-  a.taps = nullptr;
-  return launch_snv_towers(m, a, /*packed=*/true, stream);
+  Stage1Args s1 = m->s1;
+  s1.genome = *g;
+  s1.pos = pos;
+  s1.strand = strand;
+  return run_towers(m, s1, m->args, /*packed=*/true, n, w, out, nullptr, stream);
 }

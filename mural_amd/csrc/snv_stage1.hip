@@ -1,0 +1,208 @@
+// Stage 1 of both SNV towers: window decode -> BN(4)+Conv1d(4->32,k3) -> MaxPool1d, as 3-mer table lookups.
+//
+// Reference semantics: MuRaL/model/model_snv.py:473-475 (mid tower: centre crop, conv1, maxpool1) and :496-497
+// (large tower), fed by the encoders of MuRaL/data/preprocessing.py:756-816.  On a one-hot input the first layer at
+// column j depends only on the 3-mer (j-1, j, j+1): a 125 x 32 table per tower (A,C,G,T,N)^3; columns that touch an
+// IUPAC code, the conv zero padding or the crop edge take per-tap tables instead.  The (32 x 2001) first-layer
+// activation is never materialised: each lane owns 4 channels of one pooled column and maxes its 15 (large) or 3
+// (mid) lookups in registers.  Output: pooled activations x0[row][134 + 67 columns][32] (25.7 KB per site at R=1000).
+//
+// Mapping: ONE WAVE PER SITE, 16 waves per workgroup sharing the two towers' tables in LDS (staged once per
+// workgroup, persistent grid).  No workgroup barrier in the site loop: a wave's LDS writes are consumed only by
+// itself, so four waves per SIMD hide each other's LDS latency.  Bound: LDS reads (256 KB of table rows per site).
+#include "snv.h"
+
+namespace mural {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+__device__ __forceinline__ f32x4 s1_ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 s1_max4(f32x4 a, f32x4 b) {
+  return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+}
+
+constexpr int S1_WAVES = 16;
+constexpr int S1_THREADS = 64 * S1_WAVES;
+
+// all LDS traffic of this wave issued so far is complete and visible to its other lanes
+__device__ __forceinline__ void wave_lds_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+// 3-mer index of tower column j (255 = needs the per-tap path: IUPAC code, zero padding or crop edge)
+__device__ __forceinline__ uint32_t kmer_index(const uint8_t* cb, int j, int L1) {
+  if (j <= 0 || j >= L1 - 1) return 255u;           // cb[j + 1] is the symbol of tower column j
+  const uint32_t l = cb[j], c = cb[j + 1], r = cb[j + 2];
+  return (l <= 4u && c <= 4u && r <= 4u) ? (25u * l + 5u * c + r) : 255u;
+}
+
+// window-major 3-mer indices: kw[j2][SLOT], entry w = index of tower column ps*j2 - pp + w (255 beyond pk / range)
+template <int SLOT>
+__device__ __forceinline__ void build_kwin(const Stage1Tower& g, int lane, const uint8_t* cb0, uint8_t* kw) {
+  const uint8_t* cb = cb0 + g.col0;
+  const int ndw = g.L2 * (SLOT / 4);
+  for (int t = lane; t < ndw; t += 64) {
+    const int j2 = t / (SLOT / 4);
+    const int w0 = 4 * (t % (SLOT / 4));
+    uint32_t packed = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int w = w0 + q;
+      const uint32_t idx = (w < g.pk) ? kmer_index(cb, j2 * g.ps - g.pp + w, g.L1) : 255u;
+      packed |= idx << (8 * q);
+    }
+    *reinterpret_cast<uint32_t*>(kw + (size_t)t * 4) = packed;
+  }
+}
+
+template <int SLOT>
+__device__ __forceinline__ void pooled_lookup(const Stage1Tower& g, int lane, const float* lutS, const uint8_t* cb0,
+                                              const uint8_t* kw, float* __restrict__ out /* [L2][32] */) {
+  const float* tapS = lutS + SNV_LUT;
+  const float* b0S = tapS + SNV_TAPS;
+  const uint8_t* cb = cb0 + g.col0;
+  const int cg = lane & 7;
+  const int total = g.L2 * 8;
+  for (int task = lane; task < total; task += 64) {
+    const int j2 = task >> 3;
+    uint32_t d[SLOT / 4];
+    if (SLOT == 16) {
+      const uint4 q = *reinterpret_cast<const uint4*>(kw + (size_t)j2 * 16);
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[SLOT / 4 - 1] = q.w;
+    } else {
+      d[0] = *reinterpret_cast<const uint32_t*>(kw + (size_t)j2 * 4);
+    }
+    // bytes 0 .. SLOT-2 are table indices (< 128) unless a column needs the per-tap path (255)
+    uint32_t hi = d[SLOT / 4 - 1] & 0x00FFFFFFu;
+#pragma unroll
+    for (int r = 0; r + 1 < SLOT / 4; ++r) hi |= d[r];
+    const bool fast = ((hi & 0x80808080u) == 0u) && (g.pk == SLOT - 1);
+    f32x4 m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    if (fast) {
+#pragma unroll
+      for (int w = 0; w < SLOT - 1; ++w) {
+        const uint32_t idx = (d[w >> 2] >> (8 * (w & 3))) & 0xFFu;
+        m = s1_max4(m, s1_ld4(lutS + idx * 32u + 4u * cg));
+      }
+    } else {
+      const int jlo = j2 * g.ps - g.pp;
+      for (int w = 0; w < g.pk; ++w) {
+        const int j = jlo + w;
+        if (j < 0 || j >= g.L1) continue;      // MaxPool1d pads with -inf
+        const uint32_t idx = kmer_index(cb, j, g.L1);
+        f32x4 v;
+        if (idx != 255u) {
+          v = s1_ld4(lutS + idx * 32u + 4u * cg);
+        } else {                               // zero padding is applied after the BN: PAD rows are exactly 0
+          const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
+          const uint32_t sc = cb[j + 1];
+          const uint32_t sr = (j == g.L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
+          v = s1_ld4(b0S + 4 * cg);
+          v += s1_ld4(tapS + (0 * N_SYM + sl) * 32 + 4 * cg);
+          v += s1_ld4(tapS + (1 * N_SYM + sc) * 32 + 4 * cg);
+          v += s1_ld4(tapS + (2 * N_SYM + sr) * 32 + 4 * cg);
+        }
+        m = s1_max4(m, v);
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)j2 * 32 + 4 * cg) = m;   // 8 lanes write one 128-byte column
+  }
+}
+
+template <int SRC>  // 0: symbol rows in HBM (dense path), 1: packed genome
+__global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args args) {
+  extern __shared__ __attribute__((aligned(16))) float s1mem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* lutL = s1mem;
+  float* lutM = s1mem + SNV_LUTBLK;
+  uint8_t* wbase = reinterpret_cast<uint8_t*>(s1mem + 2 * SNV_LUTBLK) + (size_t)wave * args.wave_bytes;
+  uint8_t* cb = wbase;                        // [CW] symbols, PAD at both ends
+  uint8_t* kwL = cb + args.cw;                // [L2 large][16]
+  uint8_t* kwM = kwL + args.tw[0].L2 * 16;    // [L2 mid][4]
+
+  for (int i = tid * 4; i < SNV_LUTBLK; i += S1_THREADS * 4) {
+    *reinterpret_cast<f32x4*>(lutL + i) = s1_ld4(args.lut[0] + i);
+    *reinterpret_cast<f32x4*>(lutM + i) = s1_ld4(args.lut[1] + i);
+  }
+  __syncthreads();
+
+  const int Lwin = args.Lwin;
+  const int64_t stride = (int64_t)gridDim.x * S1_WAVES;
+  int64_t row = (int64_t)blockIdx.x * S1_WAVES + wave;
+  int64_t pos_pre = 0;
+  uint32_t neg_pre = 0;
+  if (SRC == 1 && row < args.n) {
+    pos_pre = args.pos[row];
+    neg_pre = args.strand[row];
+  }
+  for (; row < args.n; row += stride) {
+    // ------------------------------------------------------------------ symbols of the window -> LDS
+    if (SRC == 1) {
+      const int64_t ws = pos_pre - args.radius;
+      const bool neg = neg_pre != 0;
+      const int64_t glen = args.genome.length;
+      if (row + stride < args.n) {            // site of the next iteration: requested a whole iteration ahead
+        pos_pre = args.pos[row + stride];
+        neg_pre = args.strand[row + stride];
+      }
+      if (lane == 0) {
+        cb[0] = SYM_PAD;
+        cb[Lwin + 1] = SYM_PAD;
+      }
+      for (int wi = lane; wi < args.nwords; wi += 64) {   // one lane per 16-base word of the packed genome
+        const int64_t w = (ws >> 4) + wi;
+        uint32_t word = 0, mword = 0;
+        if (w >= 0 && 16 * w < glen) {
+          word = args.genome.packed2[w];
+          mword = args.genome.nmask[w >> 1] >> (16u * (uint32_t)(w & 1));
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+          const int64_t gpos = 16 * w + k;
+          const int64_t j64 = neg ? (ws + Lwin - 1 - gpos) : (gpos - ws);
+          if (j64 >= 0 && j64 < Lwin) {
+            uint32_t sym = (word >> (2 * k)) & 3u;
+            if (neg) sym = 3u - sym;
+            if (gpos < 0 || gpos >= glen || ((mword >> k) & 1u)) sym = SYM_N;
+            cb[(int)j64 + 1] = (uint8_t)sym;
+          }
+        }
+      }
+    } else {
+      const uint8_t* src = args.codes + row * Lwin;
+      for (int jj = lane; jj < Lwin + 2; jj += 64) {
+        const int j = jj - 1;
+        cb[jj] = (j >= 0 && j < Lwin) ? src[j] : (uint8_t)SYM_PAD;
+      }
+    }
+    wave_lds_fence();
+    build_kwin<16>(args.tw[0], lane, cb, kwL);
+    build_kwin<4>(args.tw[1], lane, cb, kwM);
+    wave_lds_fence();
+    float* out = args.x0 + (size_t)row * args.x0_cols * 32;
+    pooled_lookup<16>(args.tw[0], lane, lutL, cb, kwL, out);
+    pooled_lookup<4>(args.tw[1], lane, lutM, cb, kwM, out + (size_t)args.tw[0].L2 * 32);
+    wave_lds_fence();   // the next iteration overwrites cb / kw
+  }
+}
+
+int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream) {
+  if (a.n == 0) return MURAL_OK;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_stage1_kernel<0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_stage1_kernel<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  const int64_t want = (a.n + S1_WAVES - 1) / S1_WAVES;
+  const int grid = (int)(want < 256 ? want : 256);   // one 16-wave workgroup per CU, persistent
+  if (packed)
+    hipLaunchKernelGGL(snv_stage1_kernel<1>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
+  else
+    hipLaunchKernelGGL(snv_stage1_kernel<0>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural

@@ -1,13 +1,10 @@
-// Fused eval-mode forward of the two SNV conv towers + softmax-mixing head (gfx950 / CDNA4).
+// Eval-mode forward of the two SNV conv towers after their first layer + softmax-mixing head (gfx950 / CDNA4).
 //
-// Reference semantics: MuRaL/model/model_snv.py:473-523 (Network2.forward, tower part and head),
-// :794-812 (ResBlock).  One workgroup (4 waves) carries a tile of P positions through EVERY layer with the
-// activations resident in LDS; nothing but the symbols of the window (2-bit packed genome or 1 byte per
-// base) is read from HBM and only the (n_class) log-probabilities are written.
+// Reference semantics: MuRaL/model/model_snv.py:477-523 (Network2.forward, tower part and head),
+// :794-812 (ResBlock).  One workgroup (4 waves) carries a tile of P positions through EVERY remaining layer with
+// the activations resident in LDS: it reads the pooled first-layer activations written by snv_stage1_kernel
+// (25.7 KB per site at R=1000) and writes only the (n_class) log-probabilities.
 //
-//   stage 1   BN(4)+Conv1d(4->32,k3) on a one-hot input is a table lookup on the 3-mer (125 x 32 floats in
-//             LDS, fused with the first max-pool; columns touching IUPAC codes or the zero padding take a
-//             per-tap table instead), so the (32 x 2001) first-layer activation never exists.
 //   stage 2-4 every 32->32 k=3 conv is an implicit GEMM on v_mfma_f32_16x16x4_f32 (exact fp32):
 //             D[cout 16][col 16] += W[cout][k] * act[k][col], K = 3 taps x 32 channels = 24 k-steps,
 //             two M-blocks per 16-column block.  All positions of the tile share one flattened column axis
@@ -227,115 +224,46 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
   }
 }
 
-template <int PK>
-__device__ __forceinline__ f32x4 lut_window_fast(const float* lutS, const uint8_t* kx, int jlo, int cg, bool& ok) {
-  uint32_t idx[PK];
-  uint32_t any = 0;
-#pragma unroll
-  for (int w = 0; w < PK; ++w) {
-    idx[w] = kx[jlo + w];
-    any |= (idx[w] == 255u) ? 1u : 0u;
-  }
-  ok = any == 0;
-  f32x4 m = splat(-INFINITY);
-  if (ok) {
-#pragma unroll
-    for (int w = 0; w < PK; ++w) m = max4(m, ld4(lutS + idx[w] * 32u + 4u * cg));
-  }
-  return m;
-}
+// diagnostic: accumulate wave 0's cycles per phase into args.stamps[block][phase] (only when stamps != nullptr)
+#define SNV_STAMP(id)                                                              \
+  do {                                                                             \
+    if (args.stamps != nullptr && tid == 0) {                                      \
+      const unsigned long long _t = __builtin_amdgcn_s_memtime();                  \
+      args.stamps[(size_t)blockIdx.x * 32 + (id)] += _t - t_prev;                  \
+      t_prev = _t;                                                                 \
+    }                                                                              \
+  } while (0)
 
-template <int SRC>  // 0: symbol rows in HBM, 1: packed genome
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
+  unsigned long long t_prev = args.stamps != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mb = wave & 1, cgp = wave >> 1;
   const int n16 = lane & 15, kk = lane >> 4;
   const int P = args.P;
-  const int Lwin = args.Lwin;
-  const int CW = (Lwin + 2 + 15) & ~15;  // symbol row stride (bytes), PAD at both ends
-  const int KW = (Lwin + 15) & ~15;      // 3-mer index row stride
   float* bufA = smem;
   float* bufB = smem + args.nbuf;
-  uint8_t* cbuf = reinterpret_cast<uint8_t*>(smem + 2 * args.nbuf);
-  uint8_t* kidx = cbuf + P * CW;
-  float* feat = reinterpret_cast<float*>(kidx + P * KW);  // [2][P][32] global max per tower
-  float* logit = feat + 2 * P * SNV_C;                    // [2][P][SNV_MAXCLASS]
+  float* feat = smem + 2 * args.nbuf;          // [2][P][32] global max per tower
+  float* logit = feat + 2 * P * SNV_C;         // [3][P][SNV_MAXCLASS]: large, mid, local
 
   const int64_t n_tiles = (args.n + P - 1) / P;
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
-    // ------------------------------------------------------------------ symbols of the P windows -> LDS
-    if (SRC == 1) {
-      // one thread per 16-base word of the packed genome that overlaps the window
-      const int nw = args.nwords;
-      for (int item = tid; item < P * nw; item += SNV_THREADS) {
-        const int p = (int)args.dNW.div((uint32_t)item);
-        const int wi = item - p * nw;
-        const int64_t row = row0 + p;
-        uint8_t* cb = cbuf + p * CW;
-        if (wi == 0) {
-          cb[0] = SYM_PAD;
-          cb[Lwin + 1] = SYM_PAD;
-        }
-        if (row >= args.n) {
-          for (int k = 0; k < 16; ++k) {
-            const int j = 16 * wi + k;
-            if (j < Lwin) cb[j + 1] = SYM_N;
-          }
-          continue;
-        }
-        const int64_t ws = args.pos[row] - args.radius;
-        const bool neg = args.strand[row] != 0;
-        const int64_t w = (ws >> 4) + wi;
-        const int64_t glen = args.genome.length;
-        uint32_t word = 0, mword = 0;
-        if (w >= 0 && 16 * w < glen) {
-          word = args.genome.packed2[w];
-          mword = args.genome.nmask[w >> 1] >> (16u * (uint32_t)(w & 1));
-        }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int64_t gpos = 16 * w + k;
-          const int64_t j64 = neg ? (ws + Lwin - 1 - gpos) : (gpos - ws);
-          if (j64 >= 0 && j64 < Lwin) {
-            uint32_t sym = (word >> (2 * k)) & 3u;
-            if (neg) sym = 3u - sym;
-            if (gpos < 0 || gpos >= glen || ((mword >> k) & 1u)) sym = SYM_N;
-            cb[(int)j64 + 1] = (uint8_t)sym;
-          }
-        }
-      }
-    } else {
-      for (int p = 0; p < P; ++p) {
-        const int64_t row = row0 + p;
-        uint8_t* cb = cbuf + p * CW;
-        for (int jj = tid; jj < Lwin + 2; jj += SNV_THREADS) {
-          uint32_t sym = SYM_PAD;
-          const int j = jj - 1;
-          if (j >= 0 && j < Lwin) sym = (row < args.n) ? (uint32_t)args.codes[row * Lwin + j] : (uint32_t)SYM_N;
-          cb[jj] = (uint8_t)sym;
-        }
-      }
+    if (tid < P * args.n_class) {   // local-branch logits of this tile -> LDS (third logit vector)
+      const int p = tid / args.n_class, k = tid - p * args.n_class;
+      float v = 0.f;
+      if (args.has_local && row0 + p < args.n) v = args.local_logits[(row0 + p) * args.n_class + k];
+      logit[(2 * P + p) * SNV_MAXCLASS + k] = v;
     }
-    __syncthreads();
-    for (int p = 0; p < P; ++p) {
-      const uint8_t* cb = cbuf + p * CW;
-      uint8_t* kx = kidx + p * KW;
-      for (int j = tid; j < Lwin; j += SNV_THREADS) {
-        const uint32_t l = cb[j], c = cb[j + 1], r = cb[j + 2];
-        kx[j] = (l <= 4u && c <= 4u && r <= 4u) ? (uint8_t)(25u * l + 5u * c + r) : (uint8_t)255;
-      }
-    }
-    // (barrier below, after the LUT staging)
 
+    int x0_col0 = 0;   // first column of this tower inside a row of x0
     for (int tw_i = 0; tw_i < 2; ++tw_i) {
       const TowerGeom& g = args.geom[tw_i];
       const TowerDev& tw = args.tw[tw_i];
 
-      // weights of the first conv + entry BN: issued now, consumed after stage 1
+      // weights of the first conv + entry BN: issued now, consumed after the stage-1 activations have landed
       float a_cur[SNV_KSTEPS];
       {
         const float* wf = tw.wfrag + (size_t)mb * SNV_KSTEPS * 64 + lane;
@@ -345,66 +273,46 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       const int chv = 16 * mb + 4 * kk;  // first of this lane's 4 output channels
       const f32x4 es = ld4(tw.ex_s + EX_RB1_ENTRY * 32 + chv), et = ld4(tw.ex_t + EX_RB1_ENTRY * 32 + chv);
 
-      // -------------------------------------------------------------- stage 1: LUT conv + maxpool1 -> bufA
+      // -------------------------------------------------------------- pooled first-layer activations -> bufA
       {
-        float* lutS = bufB;  // [125][32] | taps [3][16][32] | bias0 [32]
-        for (int i = tid * 4; i < SNV_LUT; i += SNV_THREADS * 4) st4(lutS + i, ld4(tw.lut + i));
-        for (int i = tid * 4; i < SNV_TAPS; i += SNV_THREADS * 4) st4(lutS + SNV_LUT + i, ld4(tw.taps + i));
-        if (tid < SNV_C) lutS[SNV_LUT + SNV_TAPS + tid] = tw.bias0[tid];
-        __syncthreads();
-        const float* tapS = lutS + SNV_LUT;
-        const float* b0S = tapS + SNV_TAPS;
-        const int L1 = g.L1, L2 = g.L[0], Sc = g.Sc[0];
-        const int pk = g.pk[0], ps = g.ps[0], pp = g.pp[0];
-        const int total = P * L2 * 8;
+        const int L2 = g.L[0], Sc = g.Sc[0];
+        const int total = P * L2 * 8;      // 16-byte chunks: (position, column, 4-channel group)
         const int cg = tid & 7;
-        for (int task = tid; task < total; task += SNV_THREADS) {
-          const uint32_t pj = (uint32_t)task >> 3;
-          const uint32_t p = g.dL[0].div(pj);
-          const int j2 = (int)(pj - p * (uint32_t)L2);
-          const uint8_t* cb = cbuf + p * CW + g.col0;  // cb[j+1] is the symbol of tower column j
-          const uint8_t* kx = kidx + p * KW + g.col0;
-          const int jlo = j2 * ps - pp;
-          f32x4 m;
-          bool done = false;
-          if (jlo >= 1 && jlo + pk <= L1 - 1) {      // window strictly inside: table lookups only
-            if (pk == 15) m = lut_window_fast<15>(lutS, kx, jlo, cg, done);
-            else if (pk == 3) m = lut_window_fast<3>(lutS, kx, jlo, cg, done);
-          }
-          if (!done) {
-            m = splat(-INFINITY);
-            for (int w = 0; w < pk; ++w) {
-              const int j = jlo + w;
-              if (j < 0 || j >= L1) continue;
-              const uint32_t idx = kx[j];
-              f32x4 v;
-              if (idx != 255u && j > 0 && j < L1 - 1) {
-                v = ld4(lutS + idx * 32u + 4u * cg);
-              } else {
-                const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
-                const uint32_t sc = cb[j + 1];
-                const uint32_t sr = (j == L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
-                v = ld4(b0S + 4 * cg);
-                v += ld4(tapS + (0 * N_SYM + sl) * 32 + 4 * cg);
-                v += ld4(tapS + (1 * N_SYM + sc) * 32 + 4 * cg);
-                v += ld4(tapS + (2 * N_SYM + sr) * 32 + 4 * cg);
-              }
-              m = max4(m, v);
+        for (int task0 = 0; task0 < total; task0 += 4 * SNV_THREADS) {
+          f32x4 v[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {    // four independent 16-byte loads in flight per lane
+            const int task = task0 + u * SNV_THREADS + tid;
+            v[u] = splat(0.f);
+            if (task < total) {
+              const uint32_t pj = (uint32_t)task >> 3;
+              const uint32_t p = g.dL[0].div(pj);
+              const int j2 = (int)(pj - p * (uint32_t)L2);
+              if (row0 + p < args.n)
+                v[u] = ld4(args.x0 + ((size_t)(row0 + p) * args.x0_cols + x0_col0 + j2) * 32 + 4 * cg);
             }
           }
-          const int c = 1 + (int)p * Sc + j2;
-          st4(bufA + lds_off(c + 1, cg), m);
-        }
-        // zero the separator columns and the tail padding of the stage-2 geometry
-        {
-          const int nz = 1 + P + (16 * g.nb[0] - g.NC[0]);
-          for (int task = tid; task < nz * 8; task += SNV_THREADS) {
-            const int k = task >> 3;
-            const int c = (k <= P) ? k * Sc : g.NC[0] + (k - P - 1);
-            st4(bufA + lds_off(c + 1, task & 7), splat(0.f));
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const int task = task0 + u * SNV_THREADS + tid;
+            if (task < total) {
+              const uint32_t pj = (uint32_t)task >> 3;
+              const uint32_t p = g.dL[0].div(pj);
+              const int j2 = (int)(pj - p * (uint32_t)L2);
+              st4(bufA + lds_off(1 + (int)p * Sc + j2 + 1, cg), v[u]);
+            }
           }
         }
+        // zero the separator columns and the tail padding of the stage-2 geometry
+        const int nz = 1 + P + (16 * g.nb[0] - g.NC[0]);
+        for (int task = tid; task < nz * 8; task += SNV_THREADS) {
+          const int k = task >> 3;
+          const int c = (k <= P) ? k * Sc : g.NC[0] + (k - P - 1);
+          st4(bufA + lds_off(c + 1, task & 7), splat(0.f));
+        }
+        x0_col0 += L2;
         __syncthreads();
+        SNV_STAMP(2 + 12 * tw_i);   // stage-1 activations HBM -> LDS
         if (args.taps != nullptr && tile == 0) {
           float* dst = args.taps + (size_t)(tw_i * 6 + 0) * args.tap_stride;
           for (int i = tid; i < args.nbuf; i += SNV_THREADS) dst[i] = bufA[i];
@@ -416,17 +324,15 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       StageAddr sa = stage_setup(g, 0, P, n16, kk, mb, cgp);
       {
         char* A = reinterpret_cast<char*>(bufA);
+        const int nbw0 = g.nb[0] > cgp ? (g.nb[0] - cgp + 1) / 2 : 0;
 #pragma unroll
-        for (int i = 0; i < SNV_NB2MAX; ++i) {
-          xres[i] = splat(0.f);
-          if (cgp + 2 * i < g.nb[0]) {
-            const f32x4 v = lds_ld4(A, sa.wr + 4096u * i);
-            xres[i] = v;
-            lds_st4(A, sa.wr + 4096u * i, ((sa.vmask >> i) & 1u) ? relu_bn(v, es, et) : splat(0.f));
-          }
-        }
+        for (int i = 0; i < SNV_NB2MAX; ++i) xres[i] = (i < nbw0) ? lds_ld4(A, sa.wr + 4096u * i) : splat(0.f);
+#pragma unroll
+        for (int i = 0; i < SNV_NB2MAX; ++i)
+          if (i < nbw0) lds_st4(A, sa.wr + 4096u * i, ((sa.vmask >> i) & 1u) ? relu_bn(xres[i], es, et) : splat(0.f));
       }
       __syncthreads();
+      SNV_STAMP(3 + 12 * tw_i);   // residual stream to registers + BN/ReLU in place
 
       // -------------------------------------------------------------- the ten 32->32 convs
       for (int layer = 0; layer < SNV_NLAYER; ++layer) {
@@ -444,9 +350,17 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
             const uint32_t pj = (uint32_t)task >> 3;
             const uint32_t p = g.dL[st].div(pj);
             const int jo = (int)(pj - p * (uint32_t)Lout);
-            f32x4 m = splat(-INFINITY);
             const int jlo = jo * ps - pp;
-            for (int w = 0; w < pk; ++w) {
+            f32x4 v[7];
+#pragma unroll
+            for (int w = 0; w < 7; ++w) {   // the model's pools are 7- and 3-wide: all reads in flight together
+              const int j = jlo + w;
+              const bool in = (w < pk) && j >= 0 && j < Lin;
+              v[w] = ld4(bufA + lds_off(1 + (int)p * ScI + (in ? j : 0) + 1, cg));
+              if (!in) v[w] = splat(-INFINITY);
+            }
+            f32x4 m = max4(max4(max4(v[0], v[1]), max4(v[2], v[3])), max4(max4(v[4], v[5]), v[6]));
+            for (int w = 7; w < pk; ++w) {
               const int j = jlo + w;
               if (j < 0 || j >= Lin) continue;
               m = max4(m, ld4(bufA + lds_off(1 + (int)p * ScI + j + 1, cg)));
@@ -465,6 +379,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           }
           sa = stage_setup(g, st, P, n16, kk, mb, cgp);
           __syncthreads();
+          SNV_STAMP((layer == 4 ? 5 : 7) + 12 * tw_i);   // max-pool 2 / 3
           if (args.taps != nullptr && tile == 0) {
             float* dst = args.taps + (size_t)(tw_i * 6 + (layer == 4 ? 2 : 4)) * args.tap_stride;
             for (int i = tid; i < args.nbuf; i += SNV_THREADS) dst[i] = bufB[i];
@@ -492,7 +407,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           for (int s = 0; s < SNV_KSTEPS; ++s) a_nxt[s] = wfn[s * 64];
         }
         conv_layer(in, out, sa, nbw, lk, a_cur, pb, ps, pt, xres);
+        SNV_STAMP(9 + 12 * tw_i);   // conv phases of wave 0 (all layers)
         __syncthreads();
+        SNV_STAMP((layer < 4 ? 4 : (layer < 9 ? 6 : 8)) + 12 * tw_i);   // barrier wait after the convs of stage 2 / 3 / 4
 #pragma unroll
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = a_nxt[s];
         if (args.taps != nullptr && tile == 0 && (layer == 3 || layer == 8 || layer == 9)) {
@@ -515,6 +432,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           }
           ft[t] = m;
         }
+        SNV_STAMP(10 + 12 * tw_i);   // global max
         // next tower's LUT staging overwrites bufB only; bufA is rewritten after the following barrier
       }
     }  // towers
@@ -542,37 +460,32 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       logit[tp * SNV_MAXCLASS + k] = acc;
     }
     __syncthreads();
+    SNV_STAMP(25);   // fc
 
     // ------------------------------------------------------------------ head (model_snv.py:515-523 / :284)
-    if (tid < P && row0 + tid < args.n) {
-      const int p = tid;
+    if (tid < P * args.n_class) {
       const int nc = args.n_class;
-      const float* lgL = logit + p * SNV_MAXCLASS;
-      const float* lgM = logit + (P + p) * SNV_MAXCLASS;
-      const float* lgC = args.has_local ? (args.local_logits + (row0 + p) * nc) : nullptr;
-      float mL = -INFINITY, mM = -INFINITY, mC = -INFINITY;
-      for (int k = 0; k < nc; ++k) {
-        mL = fmaxf(mL, lgL[k]);
-        mM = fmaxf(mM, lgM[k]);
-        if (lgC) mC = fmaxf(mC, lgC[k]);
+      const int p = tid / nc, k = tid - p * nc;
+      float pr[3];
+#pragma unroll
+      for (int v = 0; v < 3; ++v) {   // softmax of the large / mid / local logits, this thread's class
+        const float* lg = logit + (v * P + p) * SNV_MAXCLASS;
+        float mx = -INFINITY;
+        for (int q = 0; q < nc; ++q) mx = fmaxf(mx, lg[q]);
+        float sum = 0.f;
+        for (int q = 0; q < nc; ++q) sum += expf(lg[q] - mx);
+        pr[v] = expf(lg[k] - mx) / sum;
       }
-      float sL = 0.f, sM = 0.f, sC = 0.f;
-      for (int k = 0; k < nc; ++k) {
-        sL += expf(lgL[k] - mL);
-        sM += expf(lgM[k] - mM);
-        if (lgC) sC += expf(lgC[k] - mC);
-      }
-      for (int k = 0; k < nc; ++k) {
-        float pr = (expf(lgM[k] - mM) / sM + expf(lgL[k] - mL) / sL) / 2.f;
-        if (lgC) pr = (expf(lgC[k] - mC) / sC + pr) / 2.f;
-        args.out[(row0 + p) * nc + k] = logf(fmaxf(pr, 1e-9f));
-      }
+      float prob = (pr[1] + pr[0]) / 2.f;
+      if (args.has_local) prob = (pr[2] + prob) / 2.f;
+      if (row0 + p < args.n) args.out[(row0 + p) * nc + k] = logf(fmaxf(prob, 1e-9f));
     }
     if (args.taps != nullptr && tile == 0) {
       float* dst = args.taps + (size_t)12 * args.tap_stride;
-      for (int i = tid; i < 2 * P * SNV_C + 2 * P * SNV_MAXCLASS; i += SNV_THREADS) dst[i] = feat[i];
+      for (int i = tid; i < 2 * P * SNV_C + 3 * P * SNV_MAXCLASS; i += SNV_THREADS) dst[i] = feat[i];
     }
     __syncthreads();
+    SNV_STAMP(26);   // head
   }
 }
 
@@ -608,15 +521,13 @@ int profile_end(double* total_ms, int64_t* launches) {
   return MURAL_OK;
 }
 
-int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, bool packed, hipStream_t stream) {
+int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, hipStream_t stream) {
   const int64_t n_tiles = (a.n + a.P - 1) / a.P;
   if (n_tiles == 0) return MURAL_OK;
   int grid = (int)(n_tiles < 2048 ? n_tiles : 2048);
   static bool attr_set = false;
   if (!attr_set) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<1>),
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -632,10 +543,7 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, bool packed, 
     g_prof.used += 2;
     MURAL_HIP_CHECK(hipEventRecord(e0, stream));
   }
-  if (packed)
-    hipLaunchKernelGGL(snv_towers_fused<1>, dim3(grid), dim3(SNV_THREADS), m->lds_bytes, stream, a);
-  else
-    hipLaunchKernelGGL(snv_towers_fused<0>, dim3(grid), dim3(SNV_THREADS), m->lds_bytes, stream, a);
+  hipLaunchKernelGGL(snv_towers_fused, dim3(grid), dim3(SNV_THREADS), m->lds_bytes, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   if (e1) MURAL_HIP_CHECK(hipEventRecord(e1, stream));
   return MURAL_OK;
