@@ -8,13 +8,14 @@ Workload (BASELINE.json configs[1]): a synthetic chromosom
 uniform ACGT bases (numpy default_rng(20251121)), stored 2-bit packed and resident in HBM when the timed region
 starts; sites = consecutive bases from 1000 on, '+' strand for even / '-' for odd index; weights = S-config
 ``weights_init`` with torch.manual_seed(0), eval mode.  One *step* = the hot path (k-mer encode + local MLP + fused
-window decode / conv towers / head) over one batch of ``--batch`` sites per rank; with the default flags 20 steps x
+window decode + first-layer lookup kernel / conv-tower kernel with head) over one batch of ``--batch`` sites per rank; with the default flags 20 steps x
 500,000 sites = the 10M positions of the config.  Every site's full +-1 kb window is evaluated independently -- no
 cross-position reuse.  N>1: ranks take disjoint site shards (weak scaling) and each step ends with one RCCL
 all_gather of the (batch, 4) fp32 log-probabilities.
 
-Extra objects on the JSON line: ``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch /
-HIP-event duration of that kernel measured live in the timed region, vs the 157.3 TFLOP/s fp32 MFMA peak) and
+Extra objects on the JSON line: ``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch of the
+layers it evaluates / HIP-event duration of that kernel measured live in the timed region, vs the 157.3 TFLOP/s fp32
+MFMA peak) and
 ``cpu_baseline`` (oracle = PyTorch-CPU restatement of the reference, timed on this box's host cores on a bounded
 sample of the same workload; rank 0, N=1 only).
 """
@@ -34,8 +35,9 @@ sys.path.insert(0, ROOT)
 LOCAL_RADIUS, LOCAL_ORDER, DISTAL_RADIUS, N_CLASS = 10, 3, 1000, 4
 GENOME_SITES = 10_000_000
 # algorithmic forward FLOP per position, SURVEY.md section 8d (2*Cin*Cout*K*Lout per conv, 2*in*out per linear)
-FLOP_TOWERS = 2_556_928 + 5_487_616        # mid + large tower = work of the fused kernel
-FLOP_TOTAL = 8_096_144
+FLOP_TOTAL = 8_096_144                     # local MLP 51,600 + mid tower 2,556,928 + large tower 5,487,616
+FLOP_FIRST_LAYERS = 154_368 + 1_536_768    # BN(4)+Conv(4->32): evaluated as 3-mer table lookups by snv_stage1_kernel
+FLOP_TOWERS = 2_556_928 + 5_487_616 - FLOP_FIRST_LAYERS   # the 32->32 convs + fc: work of the dominant kernel
 PEAK_FP32_MFMA_TFLOPS = 157.3              # /opt/skills/guides/MI355X_MICROARCH.md
 
 
@@ -189,7 +191,8 @@ def main():
     if rank == 0:
         bases = args.steps * B * world
         kernel_ms = k_ms.value / max(k_n.value, 1)
-        achieved = FLOP_TOWERS * B / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        sites_per_launch = args.steps * B / max(k_n.value, 1)      # the library launches the kernel per 32768-site chunk
+        achieved = FLOP_TOWERS * sites_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         line = {
             "metric": "predicted bases/s (SNV local=10/distal=1000, 4-class, predict)",
             "value": bases / elapsed, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -203,9 +206,12 @@ def main():
             "roofline": {"bound": "mfma", "kernel": _lib.lib().mural_snv_kernel_name().decode(),
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
-                         "flop_per_launch": FLOP_TOWERS * B, "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
-                         "note": "algorithmic FLOP counts the first conv layers (1.69 MFLOP/site) that the kernel "
-                                 "evaluates as a 3-mer table lookup"},
+                         "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
+                         "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
+                         "note": "algorithmic FLOP of the layers this kernel evaluates (6,353,408 per site: every 32->32 "
+                                 "conv + fc of both towers); the 1,691,136 FLOP/site of the two first conv layers are table "
+                                 "lookups in snv_stage1_kernel and the 51,600 FLOP/site local MLP is snv_local_mlp; "
+                                 "end-to-end model FLOP rate = 8,096,144 x value"},
         }
         if world == 1 and not args.no_cpu_baseline:
             state = {k: v.detach().cpu() for k, v in model.state_dict().items()}

@@ -194,7 +194,7 @@ int fold_local(const MuralLocal& Lc, const MuralSnvShape& sh, Blob& B, LocalOff&
 int pool_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
 
 // tile geometry for P positions per workgroup; returns LDS bytes (0 if a stage needs too many blocks per wave)
-size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P) {
+size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P, int n_class) {
   static const int pools[2][3][3] = {{{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}, {{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}};
   int maxcols = 0;
   for (int tw = 0; tw < 2; ++tw) {
@@ -222,7 +222,8 @@ size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P) {
   a.Lwin = Lwin;
   a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
   a.nbuf = maxcols * SNV_C;
-  return (size_t)2 * a.nbuf * 4 + (size_t)(2 * P * SNV_C + 3 * P * SNV_MAXCLASS) * 4;
+  const size_t par = (size_t)2 * (2 * EX_COUNT * SNV_C + n_class * SNV_C + SNV_MAXCLASS);   // resident small parameters
+  return (size_t)2 * a.nbuf * 4 + (size_t)(2 * P * SNV_C + 3 * P * SNV_MAXCLASS) * 4 + par * 4;
 }
 
 constexpr size_t kLdsTwoPerCu = 80 * 1024;
@@ -289,19 +290,19 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
       int P = 0;
       for (int cand = 16; cand >= 1 && !P; --cand) {
         SnvFwdArgs tmp;
-        const size_t need = plan_geometry(tmp, sh.distal_len, cand);
+        const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class);
         if (need && need <= kLdsTwoPerCu) { P = cand; lds = need; }
       }
       for (int cand = 16; cand >= 1 && !P; --cand) {
         SnvFwdArgs tmp;
-        const size_t need = plan_geometry(tmp, sh.distal_len, cand);
+        const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class);
         if (need && need <= kLdsMax) { P = cand; lds = need; }
       }
       if (!P) {
         set_error("distal_radius %d is too long for the LDS-resident tower kernel", (sh.distal_len - 1) / 2);
         rc = MURAL_E_INVALID;
       } else {
-        plan_geometry(m->args, sh.distal_len, P);
+        plan_geometry(m->args, sh.distal_len, P, sh.n_class);
         m->lds_bytes = lds;
         Stage1Args& s1 = m->s1;
         for (int tw = 0; tw < 2; ++tw) {

@@ -234,6 +234,29 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
     }                                                                              \
   } while (0)
 
+// Stage-1 activations of (tile, tower) straight into the residual registers, in MFMA accumulator layout
+// (lane = column n16 of each owned block, 4 channels starting at chv); separator / padding columns read as 0.
+__device__ __forceinline__ void request_x0(const SnvFwdArgs& args, f32x4 (&xres)[SNV_NB2MAX], int64_t tile, int tw_i,
+                                           int64_t n_tiles, int cgp, int n16, int chv) {
+  const TowerGeom& g = args.geom[tw_i];
+  const int x0c = tw_i == 0 ? 0 : args.geom[0].L[0];
+  const int nbw0 = g.nb[0] > cgp ? (g.nb[0] - cgp + 1) / 2 : 0;
+  const float* base = args.x0 + (size_t)x0c * 32 + chv;
+#pragma unroll
+  for (int i = 0; i < SNV_NB2MAX; ++i) {
+    xres[i] = splat(0.f);
+    const int c = 16 * (cgp + 2 * i) + n16;
+    if (i < nbw0 && c >= 1 && tile < n_tiles) {
+      const uint32_t u = (uint32_t)(c - 1);
+      const uint32_t p = g.dSc[0].div(u);
+      const uint32_t j2 = u - p * (uint32_t)g.Sc[0];
+      const int64_t row = tile * args.P + p;
+      if (p < (uint32_t)args.P && j2 < (uint32_t)g.L[0] && row < args.n)
+        xres[i] = ld4(base + ((size_t)row * args.x0_cols + j2) * 32);
+    }
+  }
+}
+
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -247,8 +270,28 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   float* bufB = smem + args.nbuf;
   float* feat = smem + 2 * args.nbuf;          // [2][P][32] global max per tower
   float* logit = feat + 2 * P * SNV_C;         // [3][P][SNV_MAXCLASS]: large, mid, local
+  float* par = logit + 3 * P * SNV_MAXCLASS;   // per tower: ex_s[4][32] | ex_t[4][32] | fc_w[nc][32] | fc_b[nc..]
+  const int par_stride = 2 * EX_COUNT * SNV_C + args.n_class * SNV_C + SNV_MAXCLASS;
+  for (int t2 = 0; t2 < 2; ++t2) {             // small per-channel parameters: resident for the whole launch
+    float* d = par + t2 * par_stride;
+    const TowerDev& tw = args.tw[t2];
+    for (int i = tid; i < EX_COUNT * SNV_C; i += SNV_THREADS) {
+      d[i] = tw.ex_s[i];
+      d[EX_COUNT * SNV_C + i] = tw.ex_t[i];
+    }
+    for (int i = tid; i < args.n_class * SNV_C; i += SNV_THREADS) d[2 * EX_COUNT * SNV_C + i] = tw.fc_w[i];
+    if (tid < args.n_class) d[2 * EX_COUNT * SNV_C + args.n_class * SNV_C + tid] = tw.fc_b[tid];
+  }
+  __syncthreads();
 
+  const int chv = 16 * mb + 4 * kk;  // first of this lane's 4 output channels
   const int64_t n_tiles = (args.n + P - 1) / P;
+
+  // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator
+  // layout, one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
+  f32x4 xres[SNV_NB2MAX];
+  request_x0(args, xres, blockIdx.x, 0, n_tiles, cgp, n16, chv);
+
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
     if (tid < P * args.n_class) {   // local-branch logits of this tile -> LDS (third logit vector)
@@ -258,81 +301,31 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       logit[(2 * P + p) * SNV_MAXCLASS + k] = v;
     }
 
-    int x0_col0 = 0;   // first column of this tower inside a row of x0
     for (int tw_i = 0; tw_i < 2; ++tw_i) {
       const TowerGeom& g = args.geom[tw_i];
       const TowerDev& tw = args.tw[tw_i];
+      const float* tpar = par + tw_i * par_stride;
 
-      // weights of the first conv + entry BN: issued now, consumed after the stage-1 activations have landed
+      // weights of the first conv: issued now, consumed after the entry barrier
       float a_cur[SNV_KSTEPS];
       {
         const float* wf = tw.wfrag + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
       }
-      const int chv = 16 * mb + 4 * kk;  // first of this lane's 4 output channels
-      const f32x4 es = ld4(tw.ex_s + EX_RB1_ENTRY * 32 + chv), et = ld4(tw.ex_t + EX_RB1_ENTRY * 32 + chv);
 
-      // -------------------------------------------------------------- pooled first-layer activations -> bufA
-      {
-        const int L2 = g.L[0], Sc = g.Sc[0];
-        const int total = P * L2 * 8;      // 16-byte chunks: (position, column, 4-channel group)
-        const int cg = tid & 7;
-        for (int task0 = 0; task0 < total; task0 += 4 * SNV_THREADS) {
-          f32x4 v[4];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {    // four independent 16-byte loads in flight per lane
-            const int task = task0 + u * SNV_THREADS + tid;
-            v[u] = splat(0.f);
-            if (task < total) {
-              const uint32_t pj = (uint32_t)task >> 3;
-              const uint32_t p = g.dL[0].div(pj);
-              const int j2 = (int)(pj - p * (uint32_t)L2);
-              if (row0 + p < args.n)
-                v[u] = ld4(args.x0 + ((size_t)(row0 + p) * args.x0_cols + x0_col0 + j2) * 32 + 4 * cg);
-            }
-          }
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            const int task = task0 + u * SNV_THREADS + tid;
-            if (task < total) {
-              const uint32_t pj = (uint32_t)task >> 3;
-              const uint32_t p = g.dL[0].div(pj);
-              const int j2 = (int)(pj - p * (uint32_t)L2);
-              st4(bufA + lds_off(1 + (int)p * Sc + j2 + 1, cg), v[u]);
-            }
-          }
-        }
-        // zero the separator columns and the tail padding of the stage-2 geometry
-        const int nz = 1 + P + (16 * g.nb[0] - g.NC[0]);
-        for (int task = tid; task < nz * 8; task += SNV_THREADS) {
-          const int k = task >> 3;
-          const int c = (k <= P) ? k * Sc : g.NC[0] + (k - P - 1);
-          st4(bufA + lds_off(c + 1, task & 7), splat(0.f));
-        }
-        x0_col0 += L2;
-        __syncthreads();
-        SNV_STAMP(2 + 12 * tw_i);   // stage-1 activations HBM -> LDS
-        if (args.taps != nullptr && tile == 0) {
-          float* dst = args.taps + (size_t)(tw_i * 6 + 0) * args.tap_stride;
-          for (int i = tid; i < args.nbuf; i += SNV_THREADS) dst[i] = bufA[i];
-        }
-      }
-
-      // -------------------------------------------------------------- residual stream -> registers, BN-ReLU in place
-      f32x4 xres[SNV_NB2MAX];
+      // -------------------------------------------------------------- entry: BN(ReLU(x0)) -> bufA, x0 stays in xres
       StageAddr sa = stage_setup(g, 0, P, n16, kk, mb, cgp);
       {
+        const f32x4 es = ld4(tpar + EX_RB1_ENTRY * 32 + chv), et = ld4(tpar + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv);
         char* A = reinterpret_cast<char*>(bufA);
         const int nbw0 = g.nb[0] > cgp ? (g.nb[0] - cgp + 1) / 2 : 0;
-#pragma unroll
-        for (int i = 0; i < SNV_NB2MAX; ++i) xres[i] = (i < nbw0) ? lds_ld4(A, sa.wr + 4096u * i) : splat(0.f);
 #pragma unroll
         for (int i = 0; i < SNV_NB2MAX; ++i)
           if (i < nbw0) lds_st4(A, sa.wr + 4096u * i, ((sa.vmask >> i) & 1u) ? relu_bn(xres[i], es, et) : splat(0.f));
       }
       __syncthreads();
-      SNV_STAMP(3 + 12 * tw_i);   // residual stream to registers + BN/ReLU in place
+      SNV_STAMP(3 + 12 * tw_i);   // stage-1 activations landed + BN/ReLU image written
 
       // -------------------------------------------------------------- the ten 32->32 convs
       for (int layer = 0; layer < SNV_NLAYER; ++layer) {
@@ -345,7 +338,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           const int total = P * Lout * 8;
           const int cg = tid & 7;
           const int ex = layer == 4 ? EX_BN_MID : EX_BN_OUT;
-          const f32x4 pool_s = ld4(tw.ex_s + ex * 32 + 4 * cg), pool_t = ld4(tw.ex_t + ex * 32 + 4 * cg);
+          const f32x4 pool_s = ld4(tpar + ex * 32 + 4 * cg), pool_t = ld4(tpar + (EX_COUNT + ex) * 32 + 4 * cg);
           for (int task = tid; task < total; task += SNV_THREADS) {
             const uint32_t pj = (uint32_t)task >> 3;
             const uint32_t p = g.dL[st].div(pj);
@@ -420,42 +413,44 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
 
       // -------------------------------------------------------------- global max per (position, channel)
+      // (the residual registers are dead after the last conv: request the next tower's stage-1 activations now)
+      request_x0(args, xres, tw_i == 0 ? tile : tile + gridDim.x, tw_i == 0 ? 1 : 0, n_tiles, cgp, n16, chv);
       {
         const int L4 = g.L[2], Sc4 = g.Sc[2];
         float* ft = feat + tw_i * P * SNV_C;
         for (int t = tid; t < P * SNV_C; t += SNV_THREADS) {
           const int p = t >> 5, ch = t & 31;
-          float m = -INFINITY;
-          for (int j = 0; j < L4; ++j) {
-            const int pc = 1 + p * Sc4 + j + 1;
-            m = fmaxf(m, bufA[lds_off(pc, ch >> 2) + (ch & 3)]);
+          float v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {   // all reads in flight together (L4 is 7 / 8 at R = 1000)
+            const int pc = 1 + p * Sc4 + (j < L4 ? j : 0) + 1;
+            v[j] = bufA[lds_off(pc, ch >> 2) + (ch & 3)];
+            if (j >= L4) v[j] = -INFINITY;
           }
+          float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+          for (int j = 8; j < L4; ++j) m = fmaxf(m, bufA[lds_off(1 + p * Sc4 + j + 1, ch >> 2) + (ch & 3)]);
           ft[t] = m;
         }
+        __syncthreads();   // bufA may be overwritten by the next tower's entry step; feat visible to the fc
         SNV_STAMP(10 + 12 * tw_i);   // global max
-        // next tower's LUT staging overwrites bufB only; bufA is rewritten after the following barrier
       }
     }  // towers
-    __syncthreads();
 
     // ------------------------------------------------------------------ BN+Linear per tower (BN folded on the host)
     for (int t = tid; t < 2 * P * args.n_class; t += SNV_THREADS) {
       const int k = t % args.n_class;
       const int tp = t / args.n_class;  // tower * P + p
       const int tw_i = tp / P;
-      const float* w = args.tw[tw_i].fc_w + k * SNV_C;
+      const float* w = par + tw_i * par_stride + 2 * EX_COUNT * SNV_C + k * SNV_C;
       const float* f = feat + tp * SNV_C;
-      f32x4 wv[8];
-#pragma unroll
-      for (int q = 0; q < 8; ++q) wv[q] = ld4(w + 4 * q);
-      float acc = args.tw[tw_i].fc_b[k];
+      float acc = par[tw_i * par_stride + 2 * EX_COUNT * SNV_C + args.n_class * SNV_C + k];
 #pragma unroll
       for (int q = 0; q < 8; ++q) {
-        const f32x4 fv = ld4(f + 4 * q);
-        acc = fmaf(wv[q].x, fv.x, acc);
-        acc = fmaf(wv[q].y, fv.y, acc);
-        acc = fmaf(wv[q].z, fv.z, acc);
-        acc = fmaf(wv[q].w, fv.w, acc);
+        const f32x4 wv = ld4(w + 4 * q), fv = ld4(f + 4 * q);
+        acc = fmaf(wv.x, fv.x, acc);
+        acc = fmaf(wv.y, fv.y, acc);
+        acc = fmaf(wv.z, fv.z, acc);
+        acc = fmaf(wv.w, fv.w, acc);
       }
       logit[tp * SNV_MAXCLASS + k] = acc;
     }
@@ -467,18 +462,29 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       const int nc = args.n_class;
       const int p = tid / nc, k = tid - p * nc;
       float pr[3];
-#pragma unroll
+#pragma unroll 1
       for (int v = 0; v < 3; ++v) {   // softmax of the large / mid / local logits, this thread's class
-        const float* lg = logit + (v * P + p) * SNV_MAXCLASS;
-        float mx = -INFINITY;
-        for (int q = 0; q < nc; ++q) mx = fmaxf(mx, lg[q]);
+        float lg[SNV_MAXCLASS];
+#pragma unroll
+        for (int q = 0; q < SNV_MAXCLASS; ++q)   // every logit read is in flight before the first use
+          lg[q] = logit[(v * P + p) * SNV_MAXCLASS + (q < nc ? q : 0)];
+        float mx = -INFINITY, own = 0.f;
+#pragma unroll
+        for (int q = 0; q < SNV_MAXCLASS; ++q)
+          if (q < nc) mx = fmaxf(mx, lg[q]);
         float sum = 0.f;
-        for (int q = 0; q < nc; ++q) sum += expf(lg[q] - mx);
-        pr[v] = expf(lg[k] - mx) / sum;
+#pragma unroll
+        for (int q = 0; q < SNV_MAXCLASS; ++q)
+          if (q < nc) {
+            const float e = __expf(lg[q] - mx);
+            sum += e;
+            own = (q == k) ? e : own;
+          }
+        pr[v] = own / sum;
       }
       float prob = (pr[1] + pr[0]) / 2.f;
       if (args.has_local) prob = (pr[2] + prob) / 2.f;
-      if (row0 + p < args.n) args.out[(row0 + p) * nc + k] = logf(fmaxf(prob, 1e-9f));
+      if (row0 + p < args.n) args.out[(row0 + p) * nc + k] = __logf(fmaxf(prob, 1e-9f));
     }
     if (args.taps != nullptr && tile == 0) {
       float* dst = args.taps + (size_t)12 * args.tap_stride;

@@ -77,7 +77,7 @@ def main(r=7, R=1000, seed=21, B=6):
 
     for tw, sfx in ((0, "_2"), (1, "")):
         Ls = lay[2:5] if tw == 0 else lay[5:8]
-        pairs = [(0, "pool1", Ls[0], None), (1, "rbs1", Ls[0], None), (2, "pool2", Ls[1], "conv2" + sfx + ".0"),
+        pairs = [(1, "rbs1", Ls[0], None), (2, "pool2", Ls[1], "conv2" + sfx + ".0"),
                  (3, "rbs2", Ls[1], None), (4, "pool3", Ls[2], "conv3" + sfx + ".0"), (5, "conv3", Ls[2], None)]
         for slot, name, L, bn in pairs:
             mine = stage_view(t[tw * 6 + slot], P, L, nbuf)
