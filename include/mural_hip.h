@@ -138,6 +138,42 @@ int mural_snv_debug_taps(const MuralSnvModel* m, const int64_t* cat_x, const flo
  * {P, NBUF_floats, L2_large, L3_large, L4_large, L2_mid, L3_mid, L4_mid, n_tap_slots, ...}          */
 int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* out16);
 
+/* ------------------------------------------------------------------------------------------------
+ * INDEL model (UNet_Small, MuRaL/model/model_indel.py:21-176), eval mode.  Parameters are HOST pointers in the
+ * reference's state_dict naming; conv weights are [Cout][Cin][K].
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct { MuralAffine conv; MuralBN bn; } MuralConvBN;            /* Sequential(Conv1d, BatchNorm1d) */
+typedef struct { const float* conv5_w; MuralBN bn1; const float* conv1_w; MuralBN bn2; } MuralConvBlock;   /* :6-19 */
+
+typedef struct {
+  int32_t n_class;
+  int32_t channels;        /* CNN_out_channels (8 in every shipped model)                          */
+  int32_t ksize;           /* CNN_kernel_size (7)                                                  */
+  int32_t down[6];         /* down_list                                                            */
+  int32_t use_reverse;     /* strand-symmetrising input conv present (insertion models)            */
+  int32_t length;          /* input length 2*distal_radius                                         */
+  float bn_eps;
+} MuralIndelShape;
+
+typedef struct {
+  MuralConvBN sym;                 /* conv.{0,1} (only when use_reverse)                           */
+  MuralConvBN up_l[6];             /* uplblocks.i.{0,1}                                            */
+  MuralConvBlock up_b[6];          /* upblocks.i.0.conv.{0,1,3,4}                                  */
+  MuralConvBN down_l[5];           /* downlblocks.j.{1,2}                                          */
+  MuralConvBlock down_b[5];        /* downblocks.j.0.conv.{0,1,3,4}                                */
+  MuralAffine out1; MuralBN out_bn; MuralAffine out2;   /* out_conv.{0,1,3}                        */
+  MuralBN fc_bn; MuralAffine fc;   /* out_fc.{0,2}                                                 */
+} MuralIndelParams;
+
+typedef struct MuralIndelModel MuralIndelModel;
+int  mural_indel_model_create(const MuralIndelShape* shape, const MuralIndelParams* host_params, MuralIndelModel** out);
+void mural_indel_model_destroy(MuralIndelModel* m);
+size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n);
+/* Replaces UNet_Small.forward(distal_input) (model_indel.py:151-176).  distal_x: dev float [n][4][length];
+ * out: dev float [n][n_class] positive Softplus scores (callers apply softmax, run_predict.py:214).      */
+int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

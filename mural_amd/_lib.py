@@ -43,6 +43,25 @@ class MuralLocal(C.Structure):
     _fields_ = [("emb", C.c_void_p), ("lin", MuralAffine * 2), ("bn", MuralBN * 2), ("out", MuralAffine)]
 
 
+class MuralConvBN(C.Structure):
+    _fields_ = [("conv", MuralAffine), ("bn", MuralBN)]
+
+
+class MuralConvBlock(C.Structure):
+    _fields_ = [("conv5_w", C.c_void_p), ("bn1", MuralBN), ("conv1_w", C.c_void_p), ("bn2", MuralBN)]
+
+
+class MuralIndelShape(C.Structure):
+    _fields_ = [("n_class", C.c_int32), ("channels", C.c_int32), ("ksize", C.c_int32), ("down", C.c_int32 * 6),
+                ("use_reverse", C.c_int32), ("length", C.c_int32), ("bn_eps", C.c_float)]
+
+
+class MuralIndelParams(C.Structure):
+    _fields_ = [("sym", MuralConvBN), ("up_l", MuralConvBN * 6), ("up_b", MuralConvBlock * 6),
+                ("down_l", MuralConvBN * 5), ("down_b", MuralConvBlock * 5), ("out1", MuralAffine), ("out_bn", MuralBN),
+                ("out2", MuralAffine), ("fc_bn", MuralBN), ("fc", MuralAffine)]
+
+
 class MuralSnvShape(C.Structure):
     _fields_ = [("model_no", C.c_int32), ("n_class", C.c_int32), ("local_cols", C.c_int32), ("emb_rows", C.c_int32),
                 ("hidden1", C.c_int32), ("hidden2", C.c_int32), ("channels", C.c_int32), ("ksize", C.c_int32),
@@ -71,6 +90,11 @@ PROTOTYPES = {
     "mural_snv_debug_taps": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mural_snv_tap_layout": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "mural_indel_model_create": (C.c_int, [C.POINTER(MuralIndelShape), C.POINTER(MuralIndelParams), C.POINTER(C.c_void_p)]),
+    "mural_indel_model_destroy": (None, [C.c_void_p]),
+    "mural_indel_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "mural_indel_forward_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
+                                            C.c_void_p]),
     "mural_snv_kernel_name": (C.c_char_p, []),
     "mural_debug_set_stamps": (C.c_int, [C.c_void_p]),
     "mural_profile_begin": (C.c_int, []),

@@ -1,0 +1,33 @@
+// Generic fp32 Conv1d building block (direct convolution on the vector ALU) used by the INDEL U-Net and by the
+// per-layer (training-mode) SNV path.  Tensors are [B][C][L] fp32 contiguous, like the reference's NCL layout.
+#pragma once
+#include "common.h"
+
+namespace mural {
+
+enum ConvAct { ACT_NONE = 0, ACT_RELU = 1, ACT_SILU = 2, ACT_SOFTPLUS = 3 };
+
+struct Conv1dArgs {
+  const float* in;       // [B][Cin][Lin]
+  const float* wt;       // weights re-laid-out as [Cin][K][Cout] (output channel contiguous)
+  const float* bias;     // [Cout] or nullptr
+  float* out;            // [B][Cout][Lout]
+  int B, Cin, Lin, Cout, Lout;
+  int K, stride, pad;
+  int up;                // nearest-neighbour upsampling of the input by `up` (virtual input length Lin * up)
+  // optional per-input-channel affine (+ReLU) applied to in-range input values BEFORE the zero padding:
+  //   x' = pre_s[ci] * (pre_relu ? max(x, 0) : x) + pre_t[ci]          (BatchNorm in front of a conv)
+  const float* pre_s;
+  const float* pre_t;
+  int pre_relu;
+  int act;               // ConvAct applied to (acc + bias)
+  const float* res1;     // optional residuals added AFTER the activation, [B][Cout][Lout]
+  const float* res2;
+};
+
+int launch_conv1d(const Conv1dArgs& a, hipStream_t stream);
+
+// y[b][c] = max_l x[b][c][l]
+int launch_rowmax(const float* x, int64_t rows, int L, float* y, hipStream_t stream);
+
+}  // namespace mural

@@ -1,0 +1,119 @@
+// Generic fp32 Conv1d (direct form, vector ALU): one workgroup = 64 output positions x all output channels of one
+// batch row.  The input span of the tile (all input channels) is staged once in LDS with the optional BN(+ReLU) pre-op
+// and nearest-neighbour upsampling applied; each wave then walks output-channel groups of COG channels, the weights of a
+// group arriving through wave-uniform (scalar) loads, so the inner loop is 1 LDS read + COG FMAs per (ci, tap).
+// Used by the INDEL U-Net (reference MuRaL/model/model_indel.py:6-176: k=7/5/1 convs, strides 1/4/5/2, Upsample,
+// SiLU / ReLU / Softplus, residual adds).
+#include "conv1d.h"
+
+namespace mural {
+
+__device__ __forceinline__ float apply_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SILU: return v / (1.f + expf(-v));
+    case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));   // torch.nn.Softplus(beta=1, threshold=20)
+    default: return v;
+  }
+}
+
+template <int COG>
+__global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a) {
+  extern __shared__ float tile[];   // [Cin][TWp]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int l0 = blockIdx.x * 64;
+  const int TW = 63 * a.stride + a.K;          // input span of 64 outputs
+  const int TWp = TW | 1;                      // odd row stride: channel rows start on different banks
+  const int in0 = l0 * a.stride - a.pad;       // first (virtual, upsampled) input index of the tile
+  const int Lv = a.Lin * a.up;
+  for (int ci = wave; ci < a.Cin; ci += 4) {
+    const float* src = a.in + ((size_t)b * a.Cin + ci) * a.Lin;
+    const float ps = a.pre_s ? a.pre_s[ci] : 1.f, pt = a.pre_t ? a.pre_t[ci] : 0.f;
+    for (int j = lane; j < TW; j += 64) {
+      const int v = in0 + j;
+      float x = 0.f;                           // zero padding (applied after the pre-op, like nn.Conv1d after a BN)
+      if (v >= 0 && v < Lv) {
+        x = src[a.up == 1 ? v : v / a.up];
+        if (a.pre_relu) x = fmaxf(x, 0.f);
+        x = fmaf(ps, x, pt);
+      }
+      tile[ci * TWp + j] = x;
+    }
+  }
+  __syncthreads();
+  const int l = l0 + lane;
+  const int ngroups = a.Cout / COG;
+  for (int cg = wave; cg < ngroups; cg += 4) {
+    float acc[COG];
+#pragma unroll
+    for (int c = 0; c < COG; ++c) acc[c] = a.bias ? a.bias[cg * COG + c] : 0.f;
+    const float* w = a.wt + cg * COG;
+    for (int ci = 0; ci < a.Cin; ++ci) {
+      const float* trow = tile + ci * TWp + lane * a.stride;
+      for (int k = 0; k < a.K; ++k) {
+        const float x = trow[k];
+        const float* wk = w + (size_t)(ci * a.K + k) * a.Cout;   // wave-uniform address: scalar loads
+#pragma unroll
+        for (int c = 0; c < COG; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
+      }
+    }
+    if (l < a.Lout) {
+#pragma unroll
+      for (int c = 0; c < COG; ++c) {
+        const size_t o = ((size_t)b * a.Cout + cg * COG + c) * a.Lout + l;
+        float v = apply_act(acc[c], a.act);
+        if (a.res1) v += a.res1[o];
+        if (a.res2) v += a.res2[o];
+        a.out[o] = v;
+      }
+    }
+  }
+}
+
+int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.Lout == 0) return MURAL_OK;
+  MURAL_REQUIRE(a.Cout % 4 == 0, "conv1d: Cout must be a multiple of 4 (got %d)", a.Cout);
+  MURAL_REQUIRE(a.up >= 1 && a.stride >= 1 && a.K >= 1, "conv1d: bad geometry");
+  const int TWp = (63 * a.stride + a.K) | 1;
+  const size_t lds = (size_t)a.Cin * TWp * sizeof(float);
+  MURAL_REQUIRE(lds <= 160 * 1024, "conv1d: input tile of %zu bytes exceeds LDS", lds);
+  const dim3 grid((a.Lout + 63) / 64, a.B);
+  static bool attr_set = false;
+  if (!attr_set) {
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_kernel<8>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_kernel<4>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  if (a.Cout % 8 == 0)
+    hipLaunchKernelGGL(conv1d_kernel<8>, grid, dim3(256), lds, stream, a);
+  else
+    hipLaunchKernelGGL(conv1d_kernel<4>, grid, dim3(256), lds, stream, a);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+// one wave per row: max over the row
+__global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int64_t rows, int L, float* __restrict__ y) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;
+  const float* p = x + row * L;
+  float m = -INFINITY;
+  for (int i = lane; i < L; i += 64) m = fmaxf(m, p[i]);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (lane == 0) y[row] = m;
+}
+
+int launch_rowmax(const float* x, int64_t rows, int L, float* y, hipStream_t stream) {
+  if (rows == 0) return MURAL_OK;
+  hipLaunchKernelGGL(rowmax_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, stream, x, rows, L, y);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural

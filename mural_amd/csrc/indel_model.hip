@@ -1,0 +1,286 @@
+// INDEL model (UNet_Small) eval-mode forward: host-side folding + layer program over the generic conv1d kernel.
+// Reference: MuRaL/model/model_indel.py:6-19 (ConvBlock), :21-176 (UNet_Small).
+//   * every BatchNorm follows its conv, so in eval mode it folds exactly into that conv's weights and bias;
+//   * the strand-symmetrising input layer conv(x) + flip_L(conv(flip_{C,L}(x))) (:154-155) is ONE conv with weights
+//     W[o][c][k] + W[o][3-c][K-1-k] (the second term's channel/length flips move onto the weights);
+//   * out_fc = BN -> Dropout -> Linear -> Softplus on the global max: the BN folds into the Linear.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "conv1d.h"
+
+namespace mural {
+namespace {
+
+static_assert(sizeof(MuralIndelShape) > 0, "header");
+constexpr int INDEL_LEVELS = 6;
+constexpr int INDEL_CHUNK = 64;   // positions per pass of the layer program (bounds the activation scratch)
+
+struct FoldedConv { size_t w, b; int Cin, Cout, K; };   // offsets into the blob; w laid out [Cin][K][Cout]
+
+struct Blob {
+  std::vector<float> host;
+  size_t alloc(size_t n) {
+    size_t off = (host.size() + 63) & ~size_t(63);
+    host.resize(off + n, 0.f);
+    return off;
+  }
+};
+
+void bn_scale_shift(const MuralBN& bn, int C, float eps, std::vector<double>& s, std::vector<double>& t) {
+  s.resize(C);
+  t.resize(C);
+  for (int c = 0; c < C; ++c) {
+    s[c] = (double)bn.weight[c] / std::sqrt((double)bn.running_var[c] + (double)eps);
+    t[c] = (double)bn.bias[c] - (double)bn.running_mean[c] * s[c];
+  }
+}
+
+// conv (weight [Cout][Cin][K], optional bias) followed by an optional BN -> [Cin][K][Cout] weights + bias
+FoldedConv fold_conv(Blob& B, const float* W, const float* bias, const MuralBN* bn, int Cout, int Cin, int K, float eps,
+                     bool symmetrise = false) {
+  FoldedConv f{B.alloc((size_t)Cin * K * Cout), B.alloc(Cout), Cin, Cout, K};
+  std::vector<double> s(Cout, 1.0), t(Cout, 0.0);
+  if (bn) bn_scale_shift(*bn, Cout, eps, s, t);
+  for (int co = 0; co < Cout; ++co) {
+    for (int ci = 0; ci < Cin; ++ci)
+      for (int k = 0; k < K; ++k) {
+        double w = W[((size_t)co * Cin + ci) * K + k];
+        if (symmetrise) w += W[((size_t)co * Cin + (Cin - 1 - ci)) * K + (K - 1 - k)];
+        B.host[f.w + ((size_t)ci * K + k) * Cout + co] = (float)(w * s[co]);
+      }
+    const double b = bias ? bias[co] : 0.0;
+    B.host[f.b + co] = (float)(symmetrise ? 2.0 * (b * s[co] + t[co]) : b * s[co] + t[co]);
+  }
+  return f;
+}
+
+bool bn_ok(const MuralBN& b) { return b.weight && b.bias && b.running_mean && b.running_var; }
+
+}  // namespace
+}  // namespace mural
+
+using namespace mural;
+
+struct MuralIndelModel {
+  MuralIndelShape shape;
+  int ch[INDEL_LEVELS], len[INDEL_LEVELS];
+  FoldedConv sym, up_l[INDEL_LEVELS], up5[INDEL_LEVELS], up1[INDEL_LEVELS];
+  FoldedConv dn_l[INDEL_LEVELS - 1], dn5[INDEL_LEVELS - 1], dn1[INDEL_LEVELS - 1], out1, out2;
+  size_t fc_w, fc_b;     // [n_class][C0] with the BN folded, [n_class]
+  float* blob;
+  size_t blob_floats;
+  size_t per_pos_floats;  // activation scratch per position
+};
+
+namespace mural {
+// softplus(fc(max features)) per (row, class)
+__global__ void indel_head_kernel(const float* __restrict__ feat, int64_t n, int C, int n_class,
+                                  const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= n * n_class) return;
+  const int64_t row = i / n_class;
+  const int k = (int)(i - row * n_class);
+  float acc = b[k];
+  for (int c = 0; c < C; ++c) acc = fmaf(w[k * C + c], feat[row * C + c], acc);
+  out[i] = acc > 20.f ? acc : log1pf(expf(acc));
+}
+}  // namespace mural
+
+extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const MuralIndelParams* hp, MuralIndelModel** out) {
+  MURAL_REQUIRE(shape && hp && out, "NULL argument");
+  const MuralIndelShape& sh = *shape;
+  MURAL_REQUIRE(sh.n_class >= 1 && sh.n_class <= 64, "n_class out of range: %d", sh.n_class);
+  MURAL_REQUIRE(sh.channels >= 4 && sh.channels % 4 == 0, "CNN_out_channels must be a positive multiple of 4, got %d", sh.channels);
+  MURAL_REQUIRE(sh.ksize >= 1 && (sh.ksize & 1), "CNN_kernel_size must be odd, got %d", sh.ksize);
+  MURAL_REQUIRE(sh.length >= 1, "bad input length %d", sh.length);
+  MuralIndelModel* m = new MuralIndelModel();
+  std::memset(m, 0, sizeof(*m));
+  m->shape = sh;
+  const int K = sh.ksize, pad = (K - 1) / 2;
+  int L = sh.length;
+  for (int i = 0; i < INDEL_LEVELS; ++i) {
+    MURAL_REQUIRE(sh.down[i] >= 1, "down_list entries must be >= 1");
+    m->ch[i] = sh.channels * (i + 1);
+    L = (L + 2 * pad - K) / sh.down[i] + 1;
+    m->len[i] = L;
+  }
+  for (int i = INDEL_LEVELS - 1; i >= 1; --i) {   // nn.Upsample(scale_factor=down[i]) must land on the skip's length
+    if (m->len[i] * sh.down[i] != m->len[i - 1]) {
+      set_error("input length %d is not compatible with down_list: level %d upsamples %d x %d != %d (the reference fails "
+                "at model_indel.py:170)", sh.length, i, m->len[i], sh.down[i], m->len[i - 1]);
+      delete m;
+      return MURAL_E_INVALID;
+    }
+  }
+  const float eps = sh.bn_eps;
+  Blob B;
+  bool ok = true;
+  if (sh.use_reverse) {
+    ok = ok && hp->sym.conv.weight && hp->sym.conv.bias && bn_ok(hp->sym.bn);
+    if (ok) m->sym = fold_conv(B, hp->sym.conv.weight, hp->sym.conv.bias, &hp->sym.bn, 4, 4, K, eps, /*symmetrise=*/true);
+  }
+  for (int i = 0; i < INDEL_LEVELS && ok; ++i) {
+    const int cin = i == 0 ? 4 : m->ch[i - 1], c = m->ch[i];
+    ok = hp->up_l[i].conv.weight && hp->up_l[i].conv.bias && bn_ok(hp->up_l[i].bn) && hp->up_b[i].conv5_w &&
+         bn_ok(hp->up_b[i].bn1) && hp->up_b[i].conv1_w && bn_ok(hp->up_b[i].bn2);
+    if (!ok) break;
+    m->up_l[i] = fold_conv(B, hp->up_l[i].conv.weight, hp->up_l[i].conv.bias, &hp->up_l[i].bn, c, cin, K, eps);
+    m->up5[i] = fold_conv(B, hp->up_b[i].conv5_w, nullptr, &hp->up_b[i].bn1, 2 * c, c, 5, eps);
+    m->up1[i] = fold_conv(B, hp->up_b[i].conv1_w, nullptr, &hp->up_b[i].bn2, c, 2 * c, 1, eps);
+  }
+  for (int j = 0; j < INDEL_LEVELS - 1 && ok; ++j) {
+    const int cin = m->ch[INDEL_LEVELS - 1 - j], c = m->ch[INDEL_LEVELS - 2 - j];
+    ok = hp->down_l[j].conv.weight && hp->down_l[j].conv.bias && bn_ok(hp->down_l[j].bn) && hp->down_b[j].conv5_w &&
+         bn_ok(hp->down_b[j].bn1) && hp->down_b[j].conv1_w && bn_ok(hp->down_b[j].bn2);
+    if (!ok) break;
+    m->dn_l[j] = fold_conv(B, hp->down_l[j].conv.weight, hp->down_l[j].conv.bias, &hp->down_l[j].bn, c, cin, K, eps);
+    m->dn5[j] = fold_conv(B, hp->down_b[j].conv5_w, nullptr, &hp->down_b[j].bn1, 2 * c, c, 5, eps);
+    m->dn1[j] = fold_conv(B, hp->down_b[j].conv1_w, nullptr, &hp->down_b[j].bn2, c, 2 * c, 1, eps);
+  }
+  const int C0 = m->ch[0];
+  ok = ok && hp->out1.weight && hp->out1.bias && bn_ok(hp->out_bn) && hp->out2.weight && hp->out2.bias && bn_ok(hp->fc_bn) &&
+       hp->fc.weight && hp->fc.bias;
+  if (!ok) {
+    set_error("INDEL parameter pointer is NULL");
+    delete m;
+    return MURAL_E_INVALID;
+  }
+  m->out1 = fold_conv(B, hp->out1.weight, hp->out1.bias, &hp->out_bn, C0, C0, 1, eps);
+  m->out2 = fold_conv(B, hp->out2.weight, hp->out2.bias, nullptr, C0, C0, 1, eps);
+  {
+    std::vector<double> s, t;
+    bn_scale_shift(hp->fc_bn, C0, eps, s, t);
+    m->fc_w = B.alloc((size_t)sh.n_class * C0);
+    m->fc_b = B.alloc(sh.n_class);
+    for (int k = 0; k < sh.n_class; ++k) {
+      double b = hp->fc.bias[k];
+      for (int c = 0; c < C0; ++c) {
+        const double w = hp->fc.weight[k * C0 + c];
+        B.host[m->fc_w + k * C0 + c] = (float)(w * s[c]);
+        b += w * t[c];
+      }
+      B.host[m->fc_b + k] = (float)b;
+    }
+  }
+  // activation scratch per position: S | E_0..E_5 | T1 | T2 | H | SP | M
+  size_t per = (size_t)4 * sh.length;
+  for (int i = 0; i < INDEL_LEVELS; ++i) per += (size_t)m->ch[i] * m->len[i];
+  const size_t big = (size_t)m->ch[0] * m->len[0];
+  size_t tmax = 0, hmax = 0;
+  for (int i = 0; i < INDEL_LEVELS; ++i) {
+    tmax = std::max(tmax, (size_t)m->ch[i] * m->len[i]);
+    hmax = std::max(hmax, (size_t)2 * m->ch[i] * m->len[i]);
+  }
+  per += 2 * tmax + hmax + big + C0;
+  m->per_pos_floats = per;
+  m->blob_floats = B.host.size();
+  if (hipError_t e = hipMalloc(&m->blob, m->blob_floats * 4); e != hipSuccess) {
+    set_error("hipMalloc of %zu bytes for the folded INDEL weights failed: %s", m->blob_floats * 4, hipGetErrorString(e));
+    delete m;
+    return MURAL_E_RUNTIME;
+  }
+  if (hipMemcpy(m->blob, B.host.data(), m->blob_floats * 4, hipMemcpyHostToDevice) != hipSuccess) {
+    set_error("hipMemcpy of the folded INDEL weights failed");
+    (void)hipFree(m->blob);
+    delete m;
+    return MURAL_E_RUNTIME;
+  }
+  *out = m;
+  return MURAL_OK;
+}
+
+extern "C" void mural_indel_model_destroy(MuralIndelModel* m) {
+  if (!m) return;
+  if (m->blob) (void)hipFree(m->blob);
+  delete m;
+}
+
+extern "C" size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n) {
+  if (!m || n <= 0) return 256;
+  return (size_t)std::min<int64_t>(n, INDEL_CHUNK) * m->per_pos_floats * 4 + 4096;
+}
+
+static int run_conv(const MuralIndelModel* m, const FoldedConv& f, const float* in, int B, int Lin, float* out, int Lout,
+                    int stride, int up, int act, const float* res1, const float* res2, hipStream_t stream) {
+  Conv1dArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = in; a.wt = m->blob + f.w; a.bias = m->blob + f.b; a.out = out;
+  a.B = B; a.Cin = f.Cin; a.Lin = Lin; a.Cout = f.Cout; a.Lout = Lout;
+  a.K = f.K; a.stride = stride; a.pad = (f.K - 1) / 2; a.up = up;
+  a.act = act; a.res1 = res1; a.res2 = res2;
+  return launch_conv1d(a, stream);
+}
+
+// Replaces UNet_Small.forward(distal_input) (model_indel.py:151-176): distal_x dev float [n][4][length] -> out
+// dev float [n][n_class] (positive Softplus scores; callers apply softmax / cross-entropy, run_predict.py:214).
+extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+  MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(n >= 0, "negative batch");
+  if (n == 0) return MURAL_OK;
+  MURAL_REQUIRE(distal_x && out, "distal_x/out is NULL");
+  if (!workspace || workspace_bytes < mural_indel_workspace_bytes(m, n)) {
+    set_error("workspace too small: need %zu bytes, got %zu", mural_indel_workspace_bytes(m, n), workspace_bytes);
+    return MURAL_E_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  const MuralIndelShape& sh = m->shape;
+  const int Lx = sh.length, C0 = m->ch[0];
+  for (int64_t c0 = 0; c0 < n; c0 += INDEL_CHUNK) {
+    const int B = (int)std::min<int64_t>(INDEL_CHUNK, n - c0);
+    float* p = static_cast<float*>(workspace);
+    auto take = [&](size_t per_pos) { float* r = p; p += per_pos * (size_t)B; return r; };
+    float* S = take((size_t)4 * Lx);
+    float* E[INDEL_LEVELS];
+    for (int i = 0; i < INDEL_LEVELS; ++i) E[i] = take((size_t)m->ch[i] * m->len[i]);
+    size_t tmax = 0, hmax = 0;
+    for (int i = 0; i < INDEL_LEVELS; ++i) {
+      tmax = std::max(tmax, (size_t)m->ch[i] * m->len[i]);
+      hmax = std::max(hmax, (size_t)2 * m->ch[i] * m->len[i]);
+    }
+    float* T1 = take(tmax);
+    float* T2 = take(tmax);
+    float* H = take(hmax);
+    float* SP = take((size_t)C0 * m->len[0]);
+    float* M = take(C0);
+    const float* x = distal_x + (size_t)c0 * 4 * Lx;
+    int rc = MURAL_OK;
+    const float* cur = x;
+    int Lcur = Lx;
+    if (sh.use_reverse) {
+      if ((rc = run_conv(m, m->sym, cur, B, Lcur, S, Lcur, 1, 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
+      cur = S;
+    }
+    for (int i = 0; i < INDEL_LEVELS; ++i) {     // encoder: strided conv+BN, then ConvBlock (x + BN(1x1(SiLU(BN(k5)))))
+      const int Li = m->len[i];
+      if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
+      if ((rc = run_conv(m, m->up5[i], T1, B, Li, H, Li, 1, 1, ACT_SILU, nullptr, nullptr, stream))) return rc;
+      if ((rc = run_conv(m, m->up1[i], H, B, Li, E[i], Li, 1, 1, ACT_NONE, T1, nullptr, stream))) return rc;
+      cur = E[i];
+      Lcur = Li;
+    }
+    float* dec = T2;
+    for (int j = 0; j < INDEL_LEVELS - 1; ++j) {   // decoder: upsample, conv+BN, ConvBlock, + encoder skip
+      const int lvl = INDEL_LEVELS - 2 - j;
+      const int Li = m->len[lvl];
+      if ((rc = run_conv(m, m->dn_l[j], cur, B, Lcur, T1, Li, 1, sh.down[lvl + 1], ACT_NONE, nullptr, nullptr, stream))) return rc;
+      if ((rc = run_conv(m, m->dn5[j], T1, B, Li, H, Li, 1, 1, ACT_SILU, nullptr, nullptr, stream))) return rc;
+      if ((rc = run_conv(m, m->dn1[j], H, B, Li, dec, Li, 1, 1, ACT_NONE, T1, E[lvl], stream))) return rc;
+      cur = dec;
+      Lcur = Li;
+      dec = (cur == T2) ? SP : T2;   // ping-pong between two level-0-sized buffers
+    }
+    if ((rc = run_conv(m, m->out1, cur, B, Lcur, H, Lcur, 1, 1, ACT_RELU, nullptr, nullptr, stream))) return rc;
+    float* sp = (cur == SP) ? T2 : SP;
+    if ((rc = run_conv(m, m->out2, H, B, Lcur, sp, Lcur, 1, 1, ACT_SOFTPLUS, nullptr, nullptr, stream))) return rc;
+    if ((rc = launch_rowmax(sp, (int64_t)B * C0, Lcur, M, stream))) return rc;
+    const int64_t total = (int64_t)B * sh.n_class;
+    hipLaunchKernelGGL(indel_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, M, (int64_t)B, C0,
+                       sh.n_class, m->blob + m->fc_w, m->blob + m->fc_b, out + c0 * sh.n_class);
+    MURAL_HIP_CHECK(hipGetLastError());
+  }
+  return MURAL_OK;
+}
