@@ -17,8 +17,9 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int COG>
-__global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a) {
+template <int COG, int KT>   // KT: compile-time tap count (0 = runtime a.K)
+__global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const float* __restrict__ wt,
+                                                      const float* __restrict__ bias) {
   extern __shared__ float tile[];   // [Cin][TWp]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -48,15 +49,28 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a) {
   for (int cg = wave; cg < ngroups; cg += 4) {
     float acc[COG];
 #pragma unroll
-    for (int c = 0; c < COG; ++c) acc[c] = a.bias ? a.bias[cg * COG + c] : 0.f;
-    const float* w = a.wt + cg * COG;
+    for (int c = 0; c < COG; ++c) acc[c] = bias ? bias[cg * COG + c] : 0.f;
+    const float* __restrict__ w = wt + cg * COG;
+    const int K = KT ? KT : a.K;
     for (int ci = 0; ci < a.Cin; ++ci) {
       const float* trow = tile + ci * TWp + lane * a.stride;
-      for (int k = 0; k < a.K; ++k) {
-        const float x = trow[k];
-        const float* wk = w + (size_t)(ci * a.K + k) * a.Cout;   // wave-uniform address: scalar loads
+      if (KT) {
+        float x[KT ? KT : 1];
 #pragma unroll
-        for (int c = 0; c < COG; ++c) acc[c] = fmaf(x, wk[c], acc[c]);
+        for (int k = 0; k < KT; ++k) x[k] = trow[k];      // all taps' LDS reads and scalar weight loads in flight together
+#pragma unroll
+        for (int k = 0; k < KT; ++k) {
+          const float* __restrict__ wk = w + (size_t)(ci * KT + k) * a.Cout;   // wave-uniform address: scalar loads
+#pragma unroll
+          for (int c = 0; c < COG; ++c) acc[c] = fmaf(x[k], wk[c], acc[c]);
+        }
+      } else {
+        for (int k = 0; k < K; ++k) {
+          const float xv = trow[k];
+          const float* __restrict__ wk = w + (size_t)(ci * K + k) * a.Cout;
+#pragma unroll
+          for (int c = 0; c < COG; ++c) acc[c] = fmaf(xv, wk[c], acc[c]);
+        }
       }
     }
     if (l < a.Lout) {
@@ -80,18 +94,20 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)a.Cin * TWp * sizeof(float);
   MURAL_REQUIRE(lds <= 160 * 1024, "conv1d: input tile of %zu bytes exceeds LDS", lds);
   const dim3 grid((a.Lout + 63) / 64, a.B);
-  static bool attr_set = false;
-  if (!attr_set) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_kernel<8>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&conv1d_kernel<4>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
+  using KernelFn = void (*)(const Conv1dArgs, const float*, const float*);
+  KernelFn fn = nullptr;
+  const bool c8 = a.Cout % 8 == 0;
+  switch (a.K) {
+    case 1: fn = c8 ? conv1d_kernel<8, 1> : conv1d_kernel<4, 1>; break;
+    case 3: fn = c8 ? conv1d_kernel<8, 3> : conv1d_kernel<4, 3>; break;
+    case 5: fn = c8 ? conv1d_kernel<8, 5> : conv1d_kernel<4, 5>; break;
+    case 7: fn = c8 ? conv1d_kernel<8, 7> : conv1d_kernel<4, 7>; break;
+    default: fn = c8 ? conv1d_kernel<8, 0> : conv1d_kernel<4, 0>; break;
   }
-  if (a.Cout % 8 == 0)
-    hipLaunchKernelGGL(conv1d_kernel<8>, grid, dim3(256), lds, stream, a);
-  else
-    hipLaunchKernelGGL(conv1d_kernel<4>, grid, dim3(256), lds, stream, a);
+  if (lds > 64 * 1024)
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        160 * 1024));
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, a, a.wt, a.bias);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
