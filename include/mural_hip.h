@@ -174,6 +174,53 @@ size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n);
 int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
                               void* workspace, size_t workspace_bytes, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training-mode building blocks (MuRaL/training.py:404-450 over model_snv.py:439-525): forward with
+ * batch-statistics BatchNorm and every backward, on [B][C][L] fp32 device tensors.  Composed by the
+ * autograd glue in mural_amd/model/train_ops.py.  "zeroed by the caller" marks accumulation targets.
+ * ---------------------------------------------------------------------------------------------- */
+int mural_op_relayout(const float* W, float* wt, int32_t Cout, int32_t Cin, int32_t K, int32_t dgrad, void* stream);
+int mural_op_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin,
+                    int32_t Cout, int32_t L, int32_t K, const float* pre_s, const float* pre_t, int32_t pre_relu,
+                    int32_t post_relu, const float* res1, const float* res2, void* stream);
+int mural_op_bn_stats(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, double* sum, double* sq, void* stream);
+int mural_op_bn_finalize(const double* sum, const double* sq, double n, int32_t C, const float* gamma,
+                         const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                         float* scale, float* shift, float* mean, float* invstd, void* stream);
+int mural_op_bn_apply(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, const float* scale,
+                      const float* shift, float* y, void* stream);
+int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, int32_t L, int32_t relu,
+                         const float* mean, const float* invstd, const float* gamma, double* s1, double* s2,
+                         float* dx, float* dgamma, float* dbeta, void* stream);
+int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, int32_t L, int32_t K,
+                        const float* scale, const float* shift, int32_t pre_relu, float* dW, float* db, void* stream);
+int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
+                         int32_t* arg, void* stream);
+int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,
+                         void* stream);
+int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
+                       int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
+                       const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                       unsigned long long* counts, float* tab, float* y, int32_t* arg, void* stream);
+int mural_op_first_bwd(const float* dy, const int32_t* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
+                       int32_t col0, int32_t L1, int32_t C, int32_t L2, const float* tab, const float* W,
+                       float* dtap, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream);
+int mural_op_linear_fwd(const float* x, const float* W, const float* b, int64_t B, int32_t I, int32_t O, float* y,
+                        void* stream);
+int mural_op_linear_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t I, int32_t O, float* dx,
+                        float* dW, float* db, void* stream);
+int mural_op_embedding_fwd(const int64_t* cat, const float* E, int64_t B, int32_t cols, int32_t rows, float* y,
+                           void* stream);
+int mural_op_embedding_bwd(const int64_t* cat, const float* dy, int64_t B, int32_t cols, int32_t rows, float* dE,
+                           void* stream);
+int mural_op_dropout(const float* x, int64_t total, float p, uint64_t seed, float* y, void* stream);
+int mural_op_relu_mask(const float* g, const float* ref, int64_t total, float* y, void* stream);
+int mural_op_head_fwd(const float* loc, const float* mid, const float* lar, int64_t B, int32_t nc, float* out,
+                      void* stream);
+int mural_op_head_bwd(const float* loc, const float* mid, const float* lar, const float* dout, int64_t B, int32_t nc,
+                      float* dloc, float* dmid, float* dlar, void* stream);
+int mural_op_dense_to_symbols(const float* x, int64_t n, int32_t L, uint8_t* sym, int32_t* status, void* stream);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

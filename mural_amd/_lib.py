@@ -72,8 +72,30 @@ class MuralSnvParams(C.Structure):
     _fields_ = [("local", MuralLocal), ("mid", MuralTower), ("large", MuralTower)]
 
 
+VP, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
+
 # every symbol include/mural_hip.h declares: name -> (restype, argtypes)
 PROTOTYPES = {
+    "mural_op_relayout": (C.c_int, [VP, VP, I32, I32, I32, I32, VP]),
+    "mural_op_conv1d": (C.c_int, [VP, VP, VP, VP, I64, I32, I32, I32, I32, VP, VP, I32, I32, VP, VP, VP]),
+    "mural_op_bn_stats": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, VP]),
+    "mural_op_bn_finalize": (C.c_int, [VP, VP, C.c_double, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, VP, VP]),
+    "mural_op_bn_apply": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, VP, VP]),
+    "mural_op_bn_backward": (C.c_int, [VP, VP, I64, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "mural_op_conv_wgrad": (C.c_int, [VP, VP, I64, I32, I32, I32, VP, VP, I32, VP, VP, VP]),
+    "mural_op_maxpool_fwd": (C.c_int, [VP, I64, I32, I32, I32, I32, VP, VP, VP]),
+    "mural_op_maxpool_bwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP]),
+    "mural_op_first_fwd": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, VP, VP]),
+    "mural_op_first_bwd": (C.c_int, [VP, VP, VP, I64, I32, I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP]),
+    "mural_op_linear_fwd": (C.c_int, [VP, VP, VP, I64, I32, I32, VP, VP]),
+    "mural_op_linear_bwd": (C.c_int, [VP, VP, VP, I64, I32, I32, VP, VP, VP, VP]),
+    "mural_op_embedding_fwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP]),
+    "mural_op_embedding_bwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP]),
+    "mural_op_dropout": (C.c_int, [VP, I64, C.c_float, C.c_uint64, VP, VP]),
+    "mural_op_relu_mask": (C.c_int, [VP, VP, I64, VP, VP]),
+    "mural_op_head_fwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP]),
+    "mural_op_head_bwd": (C.c_int, [VP, VP, VP, VP, I64, I32, VP, VP, VP, VP]),
+    "mural_op_dense_to_symbols": (C.c_int, [VP, I64, I32, VP, VP, VP]),
     "mural_last_error": (C.c_char_p, []),
     "mural_abi_version": (C.c_int, []),
     "mural_encode_kmer": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

@@ -1,0 +1,748 @@
+// Training-mode building blocks of the SNV models (forward with batch-statistics BatchNorm + every backward).
+// Reference semantics: MuRaL/training.py:404-450 (one step = forward, CE-sum loss, backward through every op) over
+// MuRaL/model/model_snv.py:439-525; torch defaults for BatchNorm1d (momentum 0.1, eps 1e-5, biased variance for the
+// normalisation, unbiased for running_var), MaxPool1d (-inf padding), Dropout (scale 1/(1-p)).
+// Layout: activations [B][C][L] fp32 (the reference's NCL).  Every entry point enqueues on the caller's stream.
+// Correctness-first kernels (vector ALU, atomics for cross-workgroup sums); the conv forward / input-gradient reuse the
+// generic conv1d kernel.  The Python autograd glue lives in mural_amd/model/train_ops.py.
+#include <cstring>
+
+#include "conv1d.h"
+#include "snv.h"
+
+namespace mural {
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------- weight re-layouts
+// W[Cout][Cin][K] -> wt[Cin][K][Cout]  (forward)         or -> wt[Cout][K][Cin] with taps flipped (input gradient)
+__global__ void relayout_kernel(const float* __restrict__ W, float* __restrict__ wt, int Cout, int Cin, int K, int dgrad) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Cout * Cin * K) return;
+  const int co = i / (Cin * K), r = i - co * Cin * K, ci = r / K, k = r - ci * K;
+  if (dgrad) wt[((size_t)co * K + (K - 1 - k)) * Cin + ci] = W[i];
+  else wt[((size_t)ci * K + k) * Cout + co] = W[i];
+}
+
+// ------------------------------------------------------------------------------------------- BatchNorm (train)
+// sums over (B, L) of a(x) and a(x)^2 per channel, a = relu or identity
+__global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int B, int C, int L, int relu,
+                                                       double* __restrict__ sum, double* __restrict__ sq) {
+  const int c = blockIdx.x;
+  double s = 0.0, q = 0.0;
+  const int64_t per = (int64_t)B * L;
+  for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.y * blockDim.x) {
+    const int64_t b = i / L;
+    const int l = (int)(i - b * L);
+    float v = x[(b * C + c) * L + l];
+    if (relu) v = fmaxf(v, 0.f);
+    s += v;
+    q += (double)v * v;
+  }
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = s;
+  sh[1][threadIdx.x] = q;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&sum[c], sh[0][0]);
+    atomicAdd(&sq[c], sh[1][0]);
+  }
+}
+
+// scale / shift of y = gamma * (a(x) - mean) * invstd + beta, running statistics update
+__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sq, double n, int C,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var,
+                                   float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
+                                   float* __restrict__ invstd_out) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double mean = sum[c] / n;
+  double var = sq[c] / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  scale[c] = (float)(gamma[c] * invstd);
+  shift[c] = (float)(beta[c] - mean * gamma[c] * invstd);
+  mean_out[c] = (float)mean;
+  invstd_out[c] = (float)invstd;
+  if (running_mean) {
+    const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+    running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+    running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+  }
+}
+
+// y = scale * a(x) + shift (materialised form, used on 2-D tensors)
+__global__ void bn_apply_kernel(const float* __restrict__ x, int64_t total, int C, int L, int relu,
+                                const float* __restrict__ scale, const float* __restrict__ shift, float* __restrict__ y) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / L) % C);
+    float v = x[i];
+    if (relu) v = fmaxf(v, 0.f);
+    y[i] = fmaf(scale[c], v, shift[c]);
+  }
+}
+
+// sums over (B, L) of dz and dz * xhat per channel
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ x, int B,
+                                                            int C, int L, int relu, const float* __restrict__ mean,
+                                                            const float* __restrict__ invstd, double* __restrict__ s1,
+                                                            double* __restrict__ s2) {
+  const int c = blockIdx.x;
+  const float mu = mean[c], is = invstd[c];
+  double a = 0.0, bq = 0.0;
+  const int64_t per = (int64_t)B * L;
+  for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.y * blockDim.x) {
+    const int64_t b = i / L;
+    const int l = (int)(i - b * L);
+    const size_t o = (size_t)(b * C + c) * L + l;
+    float v = x[o];
+    if (relu) v = fmaxf(v, 0.f);
+    const float g = dz[o];
+    a += g;
+    bq += (double)g * ((v - mu) * is);
+  }
+  __shared__ double sh[2][256];
+  sh[0][threadIdx.x] = a;
+  sh[1][threadIdx.x] = bq;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    atomicAdd(&s1[c], sh[0][0]);
+    atomicAdd(&s2[c], sh[1][0]);
+  }
+}
+
+// dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat));  dgamma = sum(dz*xhat), dbeta = sum(dz)
+__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x, int64_t total, int C, int L,
+                                    int relu, const float* __restrict__ mean, const float* __restrict__ invstd,
+                                    const float* __restrict__ gamma, const double* __restrict__ s1,
+                                    const double* __restrict__ s2, double n, float* __restrict__ dx) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)((i / L) % C);
+    const float raw = x[i];
+    const float v = relu ? fmaxf(raw, 0.f) : raw;
+    const float xh = (v - mean[c]) * invstd[c];
+    const float m1 = (float)(s1[c] / n), m2 = (float)(s2[c] / n);
+    float g = gamma[c] * invstd[c] * (dz[i] - m1 - xh * m2);
+    if (relu && raw <= 0.f) g = 0.f;
+    dx[i] = g;
+  }
+}
+
+__global__ void bn_param_grad_kernel(const double* __restrict__ s1, const double* __restrict__ s2, int C,
+                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  dgamma[c] = (float)s2[c];
+  dbeta[c] = (float)s1[c];
+}
+
+// ------------------------------------------------------------------------------------------- conv weight / bias gradients
+// dW[co][ci][k] = sum_{b,l} dy[b][co][l] * a[b][ci][l + k - pad], a = scale[ci] * act(x) + shift[ci] (zero outside [0, L))
+// db[co] = sum dy.  One workgroup walks (b, 64-column tile) items; thread t owns 4 (co, ci) pairs x K taps.
+template <int C, int K>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int L,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         int pre_relu, float* __restrict__ dW, float* __restrict__ db) {
+  constexpr int TL = 64, PAD = (K - 1) / 2, TW = TL + K - 1;
+  __shared__ float sdy[C][TL + 1];
+  __shared__ float sa[C][TW + 1];
+  const int tid = threadIdx.x;
+  float acc[(C * C) / 256][K];
+#pragma unroll
+  for (int p = 0; p < (C * C) / 256; ++p)
+#pragma unroll
+    for (int k = 0; k < K; ++k) acc[p][k] = 0.f;
+  float bacc = 0.f;
+  const int ntile = (L + TL - 1) / TL;
+  const int64_t items = (int64_t)B * ntile;
+  for (int64_t it = blockIdx.x; it < items; it += gridDim.x) {
+    const int b = (int)(it / ntile), l0 = (int)(it - (int64_t)b * ntile) * TL;
+    __syncthreads();
+    for (int i = tid; i < C * TL; i += 256) {
+      const int c = i / TL, j = i - c * TL;
+      sdy[c][j] = (l0 + j < L) ? dy[((size_t)b * C + c) * L + l0 + j] : 0.f;
+    }
+    for (int i = tid; i < C * TW; i += 256) {
+      const int c = i / TW, j = i - c * TW;
+      const int l = l0 + j - PAD;
+      float v = 0.f;
+      if (l >= 0 && l < L) {
+        v = x[((size_t)b * C + c) * L + l];
+        if (pre_relu) v = fmaxf(v, 0.f);
+        v = fmaf(scale[c], v, shift[c]);
+      }
+      sa[c][j] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < (C * C) / 256; ++p) {
+      const int pair = tid + 256 * p, co = pair / C, ci = pair - co * C;
+      for (int j = 0; j < TL; ++j) {
+        const float g = sdy[co][j];
+#pragma unroll
+        for (int k = 0; k < K; ++k) acc[p][k] = fmaf(g, sa[ci][j + k], acc[p][k]);
+      }
+    }
+    if (tid < C) {
+      float s = 0.f;
+      for (int j = 0; j < TL; ++j) s += sdy[tid][j];
+      bacc += s;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < (C * C) / 256; ++p) {
+    const int pair = tid + 256 * p;
+#pragma unroll
+    for (int k = 0; k < K; ++k) atomicAdd(&dW[(size_t)pair * K + k], acc[p][k]);
+  }
+  if (tid < C && db) atomicAdd(&db[tid], bacc);
+}
+
+// ------------------------------------------------------------------------------------------- pooling
+__global__ void maxpool_fwd_kernel(const float* __restrict__ x, int64_t rows, int L, int Lout, int k, int s, int p,
+                                   float* __restrict__ y, int32_t* __restrict__ arg) {
+  const int64_t total = rows * Lout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / Lout;
+    const int lo = (int)(i - r * Lout);
+    const float* xr = x + r * L;
+    float m = -INFINITY;
+    int am = -1;
+    for (int w = 0; w < k; ++w) {
+      const int l = lo * s - p + w;
+      if (l < 0 || l >= L) continue;
+      const float v = xr[l];
+      if (v > m || am < 0) { m = v; am = l; }    // first maximum wins, like torch
+    }
+    y[i] = m;
+    arg[i] = am;
+  }
+}
+
+__global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, int64_t rows, int L, int Lout,
+                                   float* __restrict__ dx) {
+  const int64_t total = rows * Lout;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / Lout;
+    atomicAdd(&dx[r * L + arg[i]], dy[i]);
+  }
+}
+
+// ------------------------------------------------------------------------------------------- first layer (one-hot input)
+// symbol histogram of the tower's input columns
+__global__ void sym_hist_kernel(const uint8_t* __restrict__ sym, int64_t B, int Lwin, int col0, int L1,
+                                unsigned long long* __restrict__ counts) {
+  __shared__ unsigned int h[N_SYM];
+  if (threadIdx.x < N_SYM) h[threadIdx.x] = 0;
+  __syncthreads();
+  const int64_t total = B * L1;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t b = i / L1;
+    const int j = (int)(i - b * L1);
+    atomicAdd(&h[sym[b * Lwin + col0 + j] & 15], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < N_SYM && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
+}
+
+__constant__ float kSymFrac[15][4] = {
+    {1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}, {.25f, .25f, .25f, .25f},
+    {.5f, 0, .5f, 0}, {0, .5f, 0, .5f}, {.5f, .5f, 0, 0}, {0, .5f, .5f, 0}, {.5f, 0, 0, .5f}, {0, 0, .5f, .5f},
+    {0, 1.f / 3, 1.f / 3, 1.f / 3}, {1.f / 3, 0, 1.f / 3, 1.f / 3}, {1.f / 3, 1.f / 3, 0, 1.f / 3}, {1.f / 3, 1.f / 3, 1.f / 3, 0}};
+
+// batch statistics of the one-hot tensor from the histogram -> BN output per (symbol, channel), per-tap tables
+// tab: [0..3*16*C) taps[t][sym][co] | bnval[16][4] | xhat[16][4] | mean[4] | invstd[4]
+__global__ void first_tables_kernel(const unsigned long long* __restrict__ counts, int C, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ W /*[C][4][3]*/, float eps,
+                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
+                                    float* __restrict__ tab) {
+  __shared__ float bnv[N_SYM][4], xh[N_SYM][4];
+  const int tid = threadIdx.x;
+  float* taps = tab;
+  float* bnval = tab + 3 * N_SYM * C;
+  float* xhat = bnval + N_SYM * 4;
+  float* stat = xhat + N_SYM * 4;
+  if (tid < 4) {
+    double n = 0, s = 0, q = 0;
+    for (int sym = 0; sym < 15; ++sym) {
+      const double cnt = (double)counts[sym];
+      n += cnt;
+      s += cnt * kSymFrac[sym][tid];
+      q += cnt * (double)kSymFrac[sym][tid] * kSymFrac[sym][tid];
+    }
+    const double mean = s / n;
+    double var = q / n - mean * mean;
+    if (var < 0) var = 0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    stat[tid] = (float)mean;
+    stat[4 + tid] = (float)invstd;
+    for (int sym = 0; sym < N_SYM; ++sym) {
+      const float h = sym < 15 ? (float)((kSymFrac[sym][tid] - mean) * invstd) : 0.f;
+      xh[sym][tid] = h;
+      bnv[sym][tid] = sym < 15 ? fmaf(gamma[tid], h, beta[tid]) : 0.f;   // PAD: zero padding after the BN
+    }
+    if (running_mean) {
+      const double unbiased = n > 1 ? var * n / (n - 1) : var;
+      running_mean[tid] = (float)((1.0 - momentum) * running_mean[tid] + momentum * mean);
+      running_var[tid] = (float)((1.0 - momentum) * running_var[tid] + momentum * unbiased);
+    }
+  }
+  __syncthreads();
+  for (int i = tid; i < N_SYM * 4; i += blockDim.x) {
+    bnval[i] = bnv[i / 4][i % 4];
+    xhat[i] = xh[i / 4][i % 4];
+  }
+  for (int i = tid; i < 3 * N_SYM * C; i += blockDim.x) {
+    const int t = i / (N_SYM * C), r = i - t * N_SYM * C, sym = r / C, co = r - sym * C;
+    float acc = 0.f;
+    for (int ci = 0; ci < 4; ++ci) acc = fmaf(W[(co * 4 + ci) * 3 + t], bnv[sym][ci], acc);
+    taps[i] = acc;
+  }
+}
+
+// conv1 (via per-tap tables) + maxpool1 with argmax: one thread per (b, co, pooled column)
+__global__ __launch_bounds__(256) void first_pool_fwd_kernel(const uint8_t* __restrict__ sym, int64_t B, int Lwin, int col0,
+                                                             int L1, int C, int L2, int pk, int ps, int pp,
+                                                             const float* __restrict__ tab, const float* __restrict__ bias,
+                                                             float* __restrict__ y, int32_t* __restrict__ arg) {
+  extern __shared__ float staps[];   // [3][16][C]
+  for (int i = threadIdx.x; i < 3 * N_SYM * C; i += blockDim.x) staps[i] = tab[i];
+  __syncthreads();
+  const int64_t total = B * C * L2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int l2 = (int)(i % L2);
+    const int co = (int)((i / L2) % C);
+    const int64_t b = i / ((int64_t)L2 * C);
+    const uint8_t* s = sym + b * Lwin + col0;
+    float m = -INFINITY;
+    int am = -1;
+    for (int w = 0; w < pk; ++w) {
+      const int j = l2 * ps - pp + w;
+      if (j < 0 || j >= L1) continue;
+      const int sl = j > 0 ? (s[j - 1] & 15) : SYM_PAD, sc = s[j] & 15, sr = j < L1 - 1 ? (s[j + 1] & 15) : SYM_PAD;
+      const float v = bias[co] + staps[(0 * N_SYM + sl) * C + co] + staps[(1 * N_SYM + sc) * C + co] +
+                      staps[(2 * N_SYM + sr) * C + co];
+      if (v > m || am < 0) { m = v; am = j; }
+    }
+    y[i] = m;
+    arg[i] = am;
+  }
+}
+
+// dTap[t][sym][co] += dy at the arg-max column's three taps; dbias[co] += dy
+__global__ __launch_bounds__(256) void first_pool_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg,
+                                                             const uint8_t* __restrict__ sym, int64_t B, int Lwin, int col0,
+                                                             int L1, int C, int L2, float* __restrict__ dtap,
+                                                             float* __restrict__ dbias) {
+  extern __shared__ float sd[];   // [3][16][C] + [C]
+  const int ntab = 3 * N_SYM * C;
+  for (int i = threadIdx.x; i < ntab + C; i += blockDim.x) sd[i] = 0.f;
+  __syncthreads();
+  const int64_t total = B * C * L2;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int co = (int)((i / L2) % C);
+    const int64_t b = i / ((int64_t)L2 * C);
+    const uint8_t* s = sym + b * Lwin + col0;
+    const int j = arg[i];
+    const float g = dy[i];
+    const int sl = j > 0 ? (s[j - 1] & 15) : SYM_PAD, sc = s[j] & 15, sr = j < L1 - 1 ? (s[j + 1] & 15) : SYM_PAD;
+    atomicAdd(&sd[(0 * N_SYM + sl) * C + co], g);
+    atomicAdd(&sd[(1 * N_SYM + sc) * C + co], g);
+    atomicAdd(&sd[(2 * N_SYM + sr) * C + co], g);
+    atomicAdd(&sd[ntab + co], g);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ntab; i += blockDim.x)
+    if (sd[i] != 0.f) atomicAdd(&dtap[i], sd[i]);
+  for (int i = threadIdx.x; i < C; i += blockDim.x)
+    if (sd[ntab + i] != 0.f) atomicAdd(&dbias[i], sd[ntab + i]);
+}
+
+// dW[co][ci][t] = sum_sym dTap[t][sym][co] * bnval[sym][ci];  dgamma / dbeta of the BN(4) through the BN outputs
+__global__ void first_param_grad_kernel(const float* __restrict__ dtap, const float* __restrict__ tab, int C,
+                                        const float* __restrict__ W, float* __restrict__ dW, float* __restrict__ dgamma,
+                                        float* __restrict__ dbeta) {
+  const float* bnval = tab + 3 * N_SYM * C;
+  const float* xhat = bnval + N_SYM * 4;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < C * 4 * 3; i += blockDim.x) {
+    const int co = i / 12, r = i - co * 12, ci = r / 3, t = r - ci * 3;
+    float acc = 0.f;
+    for (int sym = 0; sym < 15; ++sym) acc = fmaf(dtap[(t * N_SYM + sym) * C + co], bnval[sym * 4 + ci], acc);
+    dW[i] = acc;
+  }
+  if (tid < 4) {
+    const int ci = tid;
+    float dg = 0.f, dbt = 0.f;
+    for (int sym = 0; sym < 15; ++sym) {
+      float dbn = 0.f;   // gradient w.r.t. the BN output of (sym, ci)
+      for (int t = 0; t < 3; ++t)
+        for (int co = 0; co < C; ++co) dbn = fmaf(dtap[(t * N_SYM + sym) * C + co], W[(co * 4 + ci) * 3 + t], dbn);
+      dg = fmaf(dbn, xhat[sym * 4 + ci], dg);
+      dbt += dbn;
+    }
+    dgamma[ci] = dg;
+    dbeta[ci] = dbt;
+  }
+}
+
+// ------------------------------------------------------------------------------------------- small dense ops
+__global__ void linear_fwd_kernel(const float* __restrict__ x, const float* __restrict__ W, const float* __restrict__ b,
+                                  int64_t B, int I, int O, float* __restrict__ y) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B * O) return;
+  const int64_t r = i / O;
+  const int o = (int)(i - r * O);
+  float acc = b ? b[o] : 0.f;
+  const float* xr = x + r * I;
+  const float* w = W + (size_t)o * I;
+  for (int k = 0; k < I; ++k) acc = fmaf(xr[k], w[k], acc);
+  y[i] = acc;
+}
+
+__global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* __restrict__ W, int64_t B, int I, int O,
+                                    float* __restrict__ dx) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B * I) return;
+  const int64_t r = i / I;
+  const int k = (int)(i - r * I);
+  float acc = 0.f;
+  for (int o = 0; o < O; ++o) acc = fmaf(dy[r * O + o], W[(size_t)o * I + k], acc);
+  dx[i] = acc;
+}
+
+// dW[o][k] = sum_b dy[b][o] x[b][k]; db[o] = sum_b dy[b][o]: one wave per (o, k) strip
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t B,
+                                                           int I, int O, float* __restrict__ dW, float* __restrict__ db) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (o, k) or (o, I) for the bias
+  if (item >= (int64_t)O * (I + 1)) return;
+  const int o = (int)(item / (I + 1)), k = (int)(item - (int64_t)o * (I + 1));
+  float acc = 0.f;
+  for (int64_t b = lane; b < B; b += 64) acc = fmaf(dy[b * O + o], k < I ? x[b * I + k] : 1.f, acc);
+  acc = wave_sum(acc);
+  if (lane == 0) {
+    if (k < I) dW[(size_t)o * I + k] = acc;
+    else if (db) db[o] = acc;
+  }
+}
+
+__global__ void embedding_fwd_kernel(const int64_t* __restrict__ cat, const float* __restrict__ E, int64_t B, int cols, int rows,
+                                     float* __restrict__ y) {
+  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (i >= B * cols * 5) return;
+  const int d = (int)(i % 5);
+  const int64_t bc = i / 5;
+  int64_t id = cat[bc];
+  id = id < 0 ? 0 : (id >= rows ? rows - 1 : id);
+  y[i] = E[id * 5 + d];
+}
+
+__global__ __launch_bounds__(256) void embedding_bwd_kernel(const int64_t* __restrict__ cat, const float* __restrict__ dy,
+                                                            int64_t B, int cols, int rows, float* __restrict__ dE) {
+  extern __shared__ float se[];   // [rows][5]
+  for (int i = threadIdx.x; i < rows * 5; i += blockDim.x) se[i] = 0.f;
+  __syncthreads();
+  const int64_t total = B * cols * 5;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int d = (int)(i % 5);
+    int64_t id = cat[i / 5];
+    id = id < 0 ? 0 : (id >= rows ? rows - 1 : id);
+    atomicAdd(&se[id * 5 + d], dy[i]);
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < rows * 5; i += blockDim.x)
+    if (se[i] != 0.f) atomicAdd(&dE[i], se[i]);
+}
+
+__device__ __forceinline__ uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+// y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from a counter-based generator (seed, element index)
+__global__ void dropout_kernel(const float* __restrict__ x, int64_t total, float p, uint64_t seed, float* __restrict__ y) {
+  const float scale = 1.f / (1.f - p);
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const uint64_t r = mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
+    const float u = (float)(r >> 40) * (1.f / 16777216.f);
+    y[i] = u >= p ? x[i] * scale : 0.f;
+  }
+}
+
+__global__ void scale_mask_kernel(const float* __restrict__ x, const float* __restrict__ ref, int64_t total, int mode,
+                                  float* __restrict__ y) {
+  // mode 0: y = x where ref > 0 else 0 (ReLU backward on the saved output)
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    y[i] = ref[i] > 0.f ? x[i] : 0.f;
+}
+
+// head forward: out = log(clamp((sm(loc) + (sm(mid) + sm(large)) / 2) / 2, 1e-9)) ; Network1: without the local term
+__global__ void head_fwd_kernel(const float* __restrict__ loc, const float* __restrict__ mid, const float* __restrict__ lar,
+                                int64_t B, int nc, float* __restrict__ out) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* v[3] = {lar + b * nc, mid + b * nc, loc ? loc + b * nc : nullptr};
+  float mx[3], sm[3];
+  for (int t = 0; t < 3; ++t) {
+    mx[t] = -INFINITY;
+    sm[t] = 0.f;
+    if (!v[t]) continue;
+    for (int k = 0; k < nc; ++k) mx[t] = fmaxf(mx[t], v[t][k]);
+    for (int k = 0; k < nc; ++k) sm[t] += expf(v[t][k] - mx[t]);
+  }
+  for (int k = 0; k < nc; ++k) {
+    float p = (expf(v[1][k] - mx[1]) / sm[1] + expf(v[0][k] - mx[0]) / sm[0]) / 2.f;
+    if (v[2]) p = (expf(v[2][k] - mx[2]) / sm[2] + p) / 2.f;
+    out[b * nc + k] = logf(fmaxf(p, 1e-9f));
+  }
+}
+
+__global__ void head_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ mid, const float* __restrict__ lar,
+                                const float* __restrict__ dout, int64_t B, int nc, float* __restrict__ dloc,
+                                float* __restrict__ dmid, float* __restrict__ dlar) {
+  const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float* v[3] = {lar + b * nc, mid + b * nc, loc ? loc + b * nc : nullptr};
+  float* dv[3] = {dlar + b * nc, dmid + b * nc, dloc ? dloc + b * nc : nullptr};
+  const float wgt[3] = {loc ? 0.25f : 0.5f, loc ? 0.25f : 0.5f, 0.5f};
+  float s[3][SNV_MAXCLASS], dp[SNV_MAXCLASS];
+  for (int t = 0; t < 3; ++t) {
+    if (!v[t]) continue;
+    float mx = -INFINITY, sum = 0.f;
+    for (int k = 0; k < nc; ++k) mx = fmaxf(mx, v[t][k]);
+    for (int k = 0; k < nc; ++k) sum += expf(v[t][k] - mx);
+    for (int k = 0; k < nc; ++k) s[t][k] = expf(v[t][k] - mx) / sum;
+  }
+  for (int k = 0; k < nc; ++k) {
+    float p = (s[1][k] + s[0][k]) / 2.f;
+    if (v[2]) p = (s[2][k] + p) / 2.f;
+    dp[k] = p > 1e-9f ? dout[b * nc + k] / p : 0.f;      // clamp passes no gradient below its floor
+  }
+  for (int t = 0; t < 3; ++t) {
+    if (!v[t]) continue;
+    float dot = 0.f;
+    for (int k = 0; k < nc; ++k) dot += dp[k] * wgt[t] * s[t][k];
+    for (int k = 0; k < nc; ++k) dv[t][k] = s[t][k] * (dp[k] * wgt[t] - dot);
+  }
+}
+
+int grid_for(int64_t total, int block = 256, int cap = 16384) {
+  const int64_t g = (total + block - 1) / block;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace
+}  // namespace mural
+
+using namespace mural;
+#define STREAM ((hipStream_t)stream)
+#define CHECK_LAUNCH() MURAL_HIP_CHECK(hipGetLastError()); return MURAL_OK
+
+extern "C" int mural_op_relayout(const float* W, float* wt, int32_t Cout, int32_t Cin, int32_t K, int32_t dgrad, void* stream) {
+  const int total = Cout * Cin * K;
+  hipLaunchKernelGGL(relayout_kernel, dim3((total + 255) / 256), dim3(256), 0, STREAM, W, wt, Cout, Cin, K, dgrad);
+  CHECK_LAUNCH();
+}
+
+// generic conv on [B][Cin][L] with re-laid-out weights wt [Cin][K][Cout]; pre-op BN(+ReLU) per input channel; optional
+// bias / post ReLU / two residuals.  stride 1, pad (K-1)/2.
+extern "C" int mural_op_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin,
+                               int32_t Cout, int32_t L, int32_t K, const float* pre_s, const float* pre_t, int32_t pre_relu,
+                               int32_t post_relu, const float* res1, const float* res2, void* stream) {
+  Conv1dArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = in; a.wt = wt; a.bias = bias; a.out = out;
+  a.B = (int)B; a.Cin = Cin; a.Lin = L; a.Cout = Cout; a.Lout = L;
+  a.K = K; a.stride = 1; a.pad = (K - 1) / 2; a.up = 1;
+  a.pre_s = pre_s; a.pre_t = pre_t; a.pre_relu = pre_relu;
+  a.act = post_relu ? ACT_RELU : ACT_NONE; a.res1 = res1; a.res2 = res2;
+  return launch_conv1d(a, STREAM);
+}
+
+// sum / sumsq (double[C] each, zeroed by the caller) -> scale, shift, mean, invstd (+ running statistics update)
+extern "C" int mural_op_bn_stats(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, double* sum, double* sq,
+                                 void* stream) {
+  const int64_t per = B * L;
+  int gy = (int)((per + 256 * 8 - 1) / (256 * 8));
+  gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, gy), dim3(256), 0, STREAM, x, (int)B, C, L, relu, sum, sq);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_bn_finalize(const double* sum, const double* sq, double n, int32_t C, const float* gamma,
+                                    const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                    float* scale, float* shift, float* mean, float* invstd, void* stream) {
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM, sum, sq, n, C, gamma, beta, eps, momentum,
+                     running_mean, running_var, scale, shift, mean, invstd);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_bn_apply(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, const float* scale,
+                                 const float* shift, float* y, void* stream) {
+  const int64_t total = B * C * L;
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, x, total, C, L, relu, scale, shift, y);
+  CHECK_LAUNCH();
+}
+
+// s1/s2: double[C] scratch zeroed by the caller.  Writes dx, dgamma, dbeta.
+extern "C" int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, int32_t L, int32_t relu,
+                                    const float* mean, const float* invstd, const float* gamma, double* s1, double* s2,
+                                    float* dx, float* dgamma, float* dbeta, void* stream) {
+  const int64_t per = B * L, total = B * C * L;
+  if (total == 0) return MURAL_OK;
+  int gy = (int)((per + 256 * 8 - 1) / (256 * 8));
+  gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
+  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, gy), dim3(256), 0, STREAM, dz, x, (int)B, C, L, relu, mean, invstd, s1, s2);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, dz, x, total, C, L, relu, mean, invstd,
+                     gamma, s1, s2, (double)per, dx);
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM, s1, s2, C, dgamma, dbeta);
+  CHECK_LAUNCH();
+}
+
+// dW [32][32][3] and db [32] (zeroed by the caller) of a 32->32 k=3 conv whose input was scale*act(x)+shift
+extern "C" int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, int32_t L, int32_t K,
+                                   const float* scale, const float* shift, int32_t pre_relu, float* dW, float* db,
+                                   void* stream) {
+  MURAL_REQUIRE(C == 32 && K == 3, "conv_wgrad is built for 32 channels, 3 taps (got %d, %d)", C, K);
+  const int64_t items = B * ((L + 63) / 64);
+  const int grid = (int)(items < 1024 ? (items < 1 ? 1 : items) : 1024);
+  hipLaunchKernelGGL((conv_wgrad_kernel<32, 3>), dim3(grid), dim3(256), 0, STREAM, dy, x, (int)B, L, scale, shift, pre_relu, dW,
+                     db);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
+                                    int32_t* arg, void* stream) {
+  const int Lout = (L + 2 * p - k) / s + 1;
+  const int64_t total = rows * Lout;
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, x, rows, L, Lout, k, s, p, y, arg);
+  CHECK_LAUNCH();
+}
+
+// dx must be zeroed by the caller
+extern "C" int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,
+                                    void* stream) {
+  const int64_t total = rows * Lout;
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, dy, arg, rows, L, Lout, dx);
+  CHECK_LAUNCH();
+}
+
+// first layer of a tower in training mode.  counts: uint64[16] zeroed by the caller; tab: float[3*16*C + 16*4*2 + 8]
+extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
+                                  int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
+                                  const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                                  unsigned long long* counts, float* tab, float* y, int32_t* arg, void* stream) {
+  const int L2 = (L1 + 2 * pp - pk) / ps + 1;
+  hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(B * L1, 256, 2048)), dim3(256), 0, STREAM, sym, B, Lwin, col0, L1, counts);
+  hipLaunchKernelGGL(first_tables_kernel, dim3(1), dim3(256), 0, STREAM, counts, C, gamma, beta, W, eps, momentum, running_mean,
+                     running_var, tab);
+  const int64_t total = B * C * L2;
+  hipLaunchKernelGGL(first_pool_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), (size_t)3 * N_SYM * C * 4, STREAM, sym,
+                     B, Lwin, col0, L1, C, L2, pk, ps, pp, tab, bias, y, arg);
+  CHECK_LAUNCH();
+}
+
+// dtap: float[3*16*C] and dbias[C] zeroed by the caller; writes dW [C][4][3], dgamma[4], dbeta[4]
+extern "C" int mural_op_first_bwd(const float* dy, const int32_t* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
+                                  int32_t col0, int32_t L1, int32_t C, int32_t L2, const float* tab, const float* W,
+                                  float* dtap, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream) {
+  const int64_t total = B * C * L2;
+  hipLaunchKernelGGL(first_pool_bwd_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), (size_t)(3 * N_SYM * C + C) * 4, STREAM,
+                     dy, arg, sym, B, Lwin, col0, L1, C, L2, dtap, dbias);
+  hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), 0, STREAM, dtap, tab, C, W, dW, dgamma, dbeta);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_linear_fwd(const float* x, const float* W, const float* b, int64_t B, int32_t I, int32_t O, float* y,
+                                   void* stream) {
+  if (B == 0) return MURAL_OK;
+  hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((B * O + 255) / 256)), dim3(256), 0, STREAM, x, W, b, B, I, O, y);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_linear_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t I, int32_t O, float* dx,
+                                   float* dW, float* db, void* stream) {
+  if (B == 0) return MURAL_OK;
+  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((B * I + 255) / 256)), dim3(256), 0, STREAM, dy, W, B, I, O, dx);
+  const int64_t items = (int64_t)O * (I + 1);
+  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, STREAM, dy, x, B, I, O, dW, db);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_embedding_fwd(const int64_t* cat, const float* E, int64_t B, int32_t cols, int32_t rows, float* y,
+                                      void* stream) {
+  const int64_t total = B * cols * 5;
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(embedding_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, STREAM, cat, E, B, cols, rows, y);
+  CHECK_LAUNCH();
+}
+
+// dE [rows][5] zeroed by the caller
+extern "C" int mural_op_embedding_bwd(const int64_t* cat, const float* dy, int64_t B, int32_t cols, int32_t rows, float* dE,
+                                      void* stream) {
+  const int64_t total = B * cols * 5;
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(embedding_bwd_kernel, dim3(grid_for(total, 256, 256)), dim3(256), (size_t)rows * 5 * 4, STREAM, cat, dy, B,
+                     cols, rows, dE);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_dropout(const float* x, int64_t total, float p, uint64_t seed, float* y, void* stream) {
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, x, total, p, seed, y);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_relu_mask(const float* g, const float* ref, int64_t total, float* y, void* stream) {
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(scale_mask_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, g, ref, total, 0, y);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_head_fwd(const float* loc, const float* mid, const float* lar, int64_t B, int32_t nc, float* out,
+                                 void* stream) {
+  MURAL_REQUIRE(nc >= 1 && nc <= SNV_MAXCLASS, "n_class out of range");
+  if (B == 0) return MURAL_OK;
+  hipLaunchKernelGGL(head_fwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM, loc, mid, lar, B, nc, out);
+  CHECK_LAUNCH();
+}
+
+extern "C" int mural_op_head_bwd(const float* loc, const float* mid, const float* lar, const float* dout, int64_t B, int32_t nc,
+                                 float* dloc, float* dmid, float* dlar, void* stream) {
+  MURAL_REQUIRE(nc >= 1 && nc <= SNV_MAXCLASS, "n_class out of range");
+  if (B == 0) return MURAL_OK;
+  hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM, loc, mid, lar, dout, B, nc, dloc,
+                     dmid, dlar);
+  CHECK_LAUNCH();
+}
+
+namespace mural { int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream); }
+// dense (n,4,L) MuRaL encoding -> 1 symbol per column (status: see mural_snv_forward_dense)
+extern "C" int mural_op_dense_to_symbols(const float* x, int64_t n, int32_t L, uint8_t* sym, int32_t* status, void* stream) {
+  return mural::launch_dense_to_symbols(x, n, L, sym, status, STREAM);
+}

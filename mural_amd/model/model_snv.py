@@ -7,7 +7,9 @@ checkpoints load with ``load_state_dict(strict=True)``.
 
 The torch sub-modules here are *parameter containers only*: ``forward`` never runs them.  In eval mode it hands
 the raw parameters to ``libmural_hip.so`` (which folds BN statistics, builds the first-layer 3-mer tables and the
-MFMA weight fragments) and launches the fused kernels on the current HIP stream.  There is no CPU path.
+MFMA weight fragments) and launches the fused kernels on the current HIP stream; in training mode it composes the
+per-op HIP kernels of ``train_ops.py`` under autograd (batch-statistics BatchNorm, dropout, every backward).
+There is no CPU path.
 """
 import ctypes as C
 
@@ -167,9 +169,17 @@ class _HipSnvBase(nn.Module):
 
     def _check_eval(self):
         if self.training:
-            raise NotImplementedError(
-                "mural_amd: the training-mode forward/backward (batch-stat BN, dropout) is not built yet in this "
-                "round; call model.eval() for the HIP inference path")
+            raise RuntimeError("internal: the fused inference kernels serve eval mode only")
+
+    def _train_inputs(self, cat_x, distal_x):
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("mural_amd models run on a HIP device only: call model.to('cuda') first")
+        if cat_x is not None:
+            cat_x = _lib.require_cuda(cat_x, "cat_x").to(torch.int64).contiguous()
+        if distal_x is not None:
+            distal_x = _lib.require_cuda(distal_x, "distal_x")
+        return cat_x, distal_x
 
     # -- dense entry (drop-in forward) ------------------------------------------------------------------------
     def _forward_dense(self, cat_x, distal_x, taps=None):
@@ -256,6 +266,12 @@ class FeedForwardNN(_HipSnvBase):
         return shape, params, hp
 
     def forward(self, cont_data, cat_data):
+        if self.training:     # per-op HIP kernels under autograd (train_ops.py)
+            from . import train_ops as T
+            cat_data, _ = self._train_inputs(cat_data, None)
+            with torch.cuda.device(self._device()):
+                return T.local_forward(self, cat_data, self.output_layer, self.emb_dropout_layer.p,
+                                       [d.p for d in self.droput_layers])
         return self._forward_dense(cat_data, None)
 
 
@@ -300,6 +316,14 @@ class Network1(_HipSnvBase):
         assert distal_input.shape[2] > 200, "Error: distal seq len must be >200bp"
         if distal_input.shape[2] != self.seq_len:
             raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")
+        if self.training:
+            from . import train_ops as T
+            _, distal_input = self._train_inputs(None, distal_input)
+            with torch.cuda.device(self._device()):
+                sym = T.dense_to_symbols(distal_input[:, 0:self.in_channels, :])
+                mid = T.tower_forward(self, "", sym, self.seq_len // 2 - 100, 201, POOLS_MID, self.distal_fc1[1].p)
+                large = T.tower_forward(self, "_2", sym, 0, self.seq_len, POOLS_LARGE, self.distal_fc2[1].p)
+                return T.Head.apply(None, mid, large)
         return self._forward_dense(None, distal_input[:, 0:self.in_channels, :])
 
 
@@ -333,4 +357,14 @@ class Network2(_HipSnvBase):
         assert distal_input.shape[2] > 200, "Error: distal seq len must be >200"
         if distal_input.shape[2] != self.seq_len:
             raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")
+        if self.training:
+            from . import train_ops as T
+            cat_data, distal_input = self._train_inputs(cat_data, distal_input)
+            with torch.cuda.device(self._device()):
+                sym = T.dense_to_symbols(distal_input[:, 0:self.in_channels, :])
+                loc = T.local_forward(self, cat_data, self.local_fc[0], self.emb_dropout_layer.p,
+                                      [d.p for d in self.droput_layers])
+                mid = T.tower_forward(self, "", sym, self.seq_len // 2 - 100, 201, POOLS_MID, self.distal_fc1[1].p)
+                large = T.tower_forward(self, "_2", sym, 0, self.seq_len, POOLS_LARGE, self.distal_fc2[1].p)
+                return T.Head.apply(loc, mid, large)
         return self._forward_dense(cat_data, distal_input[:, 0:self.in_channels, :], taps=_taps)

@@ -1,0 +1,339 @@
+"""Autograd glue for the training-mode HIP building blocks (include/mural_hip.h, ``mural_op_*``).
+
+Each ``torch.autograd.Function`` below launches hand-written HIP kernels for its forward and backward; torch only
+provides the tensors, the stream and the autograd graph (the reference relies on stock autograd over ``torch.nn`` ops,
+MuRaL/training.py:424-427).  BatchNorm running statistics are updated in place by the forward kernels exactly like
+``nn.BatchNorm1d`` in training mode (momentum 0.1, unbiased running variance).
+"""
+import ctypes as C
+
+import torch
+
+from .. import _lib
+
+EPS, MOMENTUM = 1e-5, 0.1
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def _call(name, *args):
+    fn = getattr(_lib.lib(), name)
+    conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
+    _lib.check(fn(*conv))
+
+
+def _stream(t):
+    return _lib.current_stream_ptr(t.device)
+
+
+def _f32(t):
+    return t.detach().to(torch.float32).contiguous()
+
+
+class _BnState:
+    """Per-call batch statistics of one BatchNorm (scale/shift for the forward pre-op, mean/invstd for the backward)."""
+
+    def __init__(self, x, relu, bn, L):
+        B, Cn = x.shape[0], x.shape[1]
+        dev = x.device
+        acc = torch.zeros(2, Cn, dtype=torch.float64, device=dev)
+        st = _stream(x)
+        _call("mural_op_bn_stats", x, B, Cn, L, int(relu), acc[0], acc[1], st)
+        self.scale = torch.empty(Cn, device=dev)
+        self.shift = torch.empty(Cn, device=dev)
+        self.mean = torch.empty(Cn, device=dev)
+        self.invstd = torch.empty(Cn, device=dev)
+        _call("mural_op_bn_finalize", acc[0], acc[1], float(B * L), Cn, _f32(bn.weight), _f32(bn.bias), EPS, MOMENTUM,
+              bn.running_mean, bn.running_var, self.scale, self.shift, self.mean, self.invstd, st)
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+
+
+class BnConv(torch.autograd.Function):
+    """y = Conv1d(BN(act(x))) [+ ReLU] [+ res1 + res2], act = ReLU or identity, 32->32 channels, k=3, pad=1."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, weight, bias, res1, res2, bn, pre_relu, post_relu):
+        x = x.contiguous()
+        B, Cn, L = x.shape
+        st = _stream(x)
+        state = _BnState(x, pre_relu, bn, L)
+        wt = torch.empty_like(weight)
+        _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 0, st)
+        y = torch.empty((B, weight.shape[0], L), device=x.device)
+        _call("mural_op_conv1d", x, wt, _f32(bias), y, B, Cn, weight.shape[0], L, weight.shape[2], state.scale, state.shift,
+              int(pre_relu), int(post_relu), _p(res1), _p(res2), st)
+        ctx.save_for_backward(x, gamma, weight, y if post_relu else None, state.scale, state.shift, state.mean, state.invstd)
+        ctx.flags = (pre_relu, post_relu, res1 is not None, res2 is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, weight, y, scale, shift, mean, invstd = ctx.saved_tensors
+        pre_relu, post_relu, has_r1, has_r2 = ctx.flags
+        dy = dy.contiguous()
+        B, Cn, L = x.shape
+        st = _stream(x)
+        dres = dy
+        if post_relu:
+            g = torch.empty_like(dy)
+            _call("mural_op_relu_mask", dy, y, dy.numel(), g, st)
+            dy = g
+        dW = torch.zeros_like(weight)
+        db = torch.zeros(weight.shape[0], device=x.device)
+        _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, st)
+        wt = torch.empty_like(weight)
+        _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 1, st)
+        dz = torch.empty_like(x)
+        _call("mural_op_conv1d", dy, wt, None, dz, B, weight.shape[0], Cn, L, weight.shape[2], None, None, 0, 0, None, None, st)
+        acc = torch.zeros(2, Cn, dtype=torch.float64, device=x.device)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(Cn, device=x.device)
+        dbeta = torch.empty(Cn, device=x.device)
+        _call("mural_op_bn_backward", dz, x, B, Cn, L, int(pre_relu), mean, invstd, _f32(gamma), acc[0], acc[1], dx, dgamma,
+              dbeta, st)
+        return dx, dgamma, dbeta, dW, db, (dres if has_r1 else None), (dres if has_r2 else None), None, None, None
+
+
+class Bn2d(torch.autograd.Function):
+    """y = BN(act(x)) on (B, C) features (batch statistics over B)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn, pre_relu):
+        x = x.contiguous()
+        B, Cn = x.shape
+        state = _BnState(x, pre_relu, bn, 1)
+        y = torch.empty_like(x)
+        _call("mural_op_bn_apply", x, B, Cn, 1, int(pre_relu), state.scale, state.shift, y, _stream(x))
+        ctx.save_for_backward(x, gamma, state.mean, state.invstd)
+        ctx.pre_relu = pre_relu
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        B, Cn = x.shape
+        acc = torch.zeros(2, Cn, dtype=torch.float64, device=x.device)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(Cn, device=x.device)
+        dbeta = torch.empty(Cn, device=x.device)
+        _call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, 1, int(ctx.pre_relu), mean, invstd, _f32(gamma), acc[0], acc[1],
+              dx, dgamma, dbeta, _stream(x))
+        return dx, dgamma, dbeta, None, None
+
+
+class MaxPool(torch.autograd.Function):
+    """MaxPool1d(k, s, p) (floor mode, -inf padding); k = None -> global max over L (returns (B, C))."""
+
+    @staticmethod
+    def forward(ctx, x, k, s, p):
+        x = x.contiguous()
+        B, Cn, L = x.shape
+        glob = k is None
+        if glob:
+            k, s, p = L, 1, 0
+        Lout = (L + 2 * p - k) // s + 1
+        y = torch.empty((B, Cn, Lout), device=x.device)
+        arg = torch.empty((B, Cn, Lout), dtype=torch.int32, device=x.device)
+        _call("mural_op_maxpool_fwd", x, B * Cn, L, k, s, p, y, arg, _stream(x))
+        ctx.save_for_backward(arg)
+        ctx.dims = (B, Cn, L, Lout, glob)
+        return y.reshape(B, Cn) if glob else y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (arg,) = ctx.saved_tensors
+        B, Cn, L, Lout, glob = ctx.dims
+        dx = torch.zeros((B, Cn, L), device=dy.device)
+        _call("mural_op_maxpool_bwd", dy.contiguous(), arg, B * Cn, L, Lout, dx, _stream(dy))
+        return dx, None, None, None
+
+
+class FirstLayerPool(torch.autograd.Function):
+    """maxpool1(Conv1d(BN(one-hot))) of one tower from window symbols: per-tap symbol tables, arg-max saved."""
+
+    @staticmethod
+    def forward(ctx, sym, gamma, beta, weight, bias, bn, col0, L1, pool):
+        B, Lwin = sym.shape
+        Cn = weight.shape[0]
+        pk, ps, pp = pool
+        L2 = (L1 + 2 * pp - pk) // ps + 1
+        dev = sym.device
+        counts = torch.zeros(16, dtype=torch.int64, device=dev)
+        tab = torch.empty(3 * 16 * Cn + 16 * 4 * 2 + 8, device=dev)
+        y = torch.empty((B, Cn, L2), device=dev)
+        arg = torch.empty((B, Cn, L2), dtype=torch.int32, device=dev)
+        _call("mural_op_first_fwd", sym, B, Lwin, col0, L1, Cn, pk, ps, pp, _f32(gamma), _f32(beta), _f32(weight), _f32(bias),
+              EPS, MOMENTUM, bn.running_mean, bn.running_var, counts, tab, y, arg, _stream(sym))
+        with torch.no_grad():
+            bn.num_batches_tracked += 1
+        ctx.save_for_backward(sym, arg, tab, weight)
+        ctx.dims = (col0, L1, L2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        sym, arg, tab, weight = ctx.saved_tensors
+        col0, L1, L2 = ctx.dims
+        B, Lwin = sym.shape
+        Cn = weight.shape[0]
+        dev = sym.device
+        dtap = torch.zeros(3 * 16 * Cn, device=dev)
+        dW = torch.empty_like(weight)
+        db = torch.zeros(Cn, device=dev)
+        dgamma = torch.empty(4, device=dev)
+        dbeta = torch.empty(4, device=dev)
+        _call("mural_op_first_bwd", dy.contiguous(), arg, sym, B, Lwin, col0, L1, Cn, L2, tab, _f32(weight), dtap, dW, db, dgamma,
+              dbeta, _stream(sym))
+        return None, dgamma, dbeta, dW, db, None, None, None, None
+
+
+class Linear(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        x = x.contiguous()
+        B, I = x.shape
+        O = weight.shape[0]
+        y = torch.empty((B, O), device=x.device)
+        _call("mural_op_linear_fwd", x, _f32(weight), _f32(bias), B, I, O, y, _stream(x))
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        B, I = x.shape
+        O = weight.shape[0]
+        dx = torch.empty_like(x)
+        dW = torch.empty_like(weight)
+        db = torch.empty(O, device=x.device)
+        _call("mural_op_linear_bwd", dy.contiguous(), x, _f32(weight), B, I, O, dx, dW, db, _stream(x))
+        return dx, dW, db
+
+
+class Embedding(torch.autograd.Function):
+    """concat_i emb[cat[:, i]] with ONE shared (rows, 5) table (model_snv.py:322, :452-454)."""
+
+    @staticmethod
+    def forward(ctx, cat, table):
+        cat = cat.contiguous()
+        B, cols = cat.shape
+        y = torch.empty((B, cols * 5), device=table.device)
+        _call("mural_op_embedding_fwd", cat, _f32(table), B, cols, table.shape[0], y, _stream(table))
+        ctx.save_for_backward(cat)
+        ctx.rows = table.shape[0]
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cat,) = ctx.saved_tensors
+        B, cols = cat.shape
+        dE = torch.zeros((ctx.rows, 5), device=dy.device)
+        _call("mural_op_embedding_bwd", cat, dy.contiguous(), B, cols, ctx.rows, dE, _stream(dy))
+        return None, dE
+
+
+class Dropout(torch.autograd.Function):
+    """Inverted dropout with a counter-based generator; the mask is regenerated from the seed in the backward."""
+
+    @staticmethod
+    def forward(ctx, x, p, seed):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        _call("mural_op_dropout", x, x.numel(), float(p), C.c_uint64(seed), y, _stream(x))
+        ctx.p, ctx.seed = float(p), seed
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = dy.contiguous()
+        dx = torch.empty_like(dy)
+        _call("mural_op_dropout", dy, dy.numel(), ctx.p, C.c_uint64(ctx.seed), dx, _stream(dy))
+        return dx, None, None
+
+
+def dropout(x, p, training=True):
+    if not training or p <= 0.0:
+        return x
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # drawn from torch's CPU generator: torch.manual_seed applies
+    return Dropout.apply(x, p, seed)
+
+
+class Head(torch.autograd.Function):
+    """log(clamp((softmax(local) + (softmax(mid) + softmax(large)) / 2) / 2, 1e-9)); local=None for Network1."""
+
+    @staticmethod
+    def forward(ctx, loc, mid, lar):
+        B, nc = mid.shape
+        out = torch.empty((B, nc), device=mid.device)
+        loc_c = None if loc is None else loc.contiguous()
+        mid, lar = mid.contiguous(), lar.contiguous()
+        _call("mural_op_head_fwd", loc_c, mid, lar, B, nc, out, _stream(mid))
+        ctx.save_for_backward(mid, lar, *([] if loc_c is None else [loc_c]))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        saved = ctx.saved_tensors
+        mid, lar = saved[0], saved[1]
+        loc = saved[2] if len(saved) > 2 else None
+        B, nc = mid.shape
+        dmid, dlar = torch.empty_like(mid), torch.empty_like(lar)
+        dloc = None if loc is None else torch.empty_like(loc)
+        _call("mural_op_head_bwd", loc, mid, lar, dout.contiguous(), B, nc, dloc, dmid, dlar, _stream(mid))
+        return dloc, dmid, dlar
+
+
+def dense_to_symbols(distal_x):
+    """(B, 4, L) MuRaL one-hot / IUPAC-fraction tensor -> (B, L) uint8 symbols; raises on anything else."""
+    x = distal_x.to(torch.float32).contiguous()
+    B, _, L = x.shape
+    sym = torch.empty((B, L), dtype=torch.uint8, device=x.device)
+    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    _call("mural_op_dense_to_symbols", x, B, L, sym, status, _stream(x))
+    if int(status.item()) != 0:
+        raise ValueError("distal_input holds a column that is not a MuRaL one-hot / IUPAC-fraction encoding")
+    return sym
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# model composition (training mode)
+# ---------------------------------------------------------------------------------------------------------------
+def tower_forward(mod, sfx, sym, col0, L1, pools, dropout_p, training=True):
+    g = lambda n: getattr(mod, n + sfx)
+    bn_in, conv_in = g("conv1")[0], g("conv1")[1]
+    x0 = FirstLayerPool.apply(sym, bn_in.weight, bn_in.bias, conv_in.weight, conv_in.bias, bn_in, col0, L1, pools[0])
+
+    def res_blocks(rbs, x_in):
+        rb0, rb1 = rbs[0], rbs[1]
+        h = BnConv.apply(x_in, rb0.bn1.weight, rb0.bn1.bias, rb0.conv1.weight, rb0.conv1.bias, None, None, rb0.bn1, True, False)
+        x1 = BnConv.apply(h, rb0.bn2.weight, rb0.bn2.bias, rb0.conv2.weight, rb0.conv2.bias, x_in, None, rb0.bn2, True, False)
+        h = BnConv.apply(x1, rb1.bn1.weight, rb1.bn1.bias, rb1.conv1.weight, rb1.conv1.bias, None, None, rb1.bn1, True, False)
+        # second block's own residual (x1) plus the outer skip (x_in), model_snv.py:477-479
+        return BnConv.apply(h, rb1.bn2.weight, rb1.bn2.bias, rb1.conv2.weight, rb1.conv2.bias, x1, x_in, rb1.bn2, True, False)
+
+    y = res_blocks(g("RBs1"), x0)
+    p2 = MaxPool.apply(y, *pools[1])
+    bn_mid, conv_mid = g("conv2")[0], g("conv2")[1]
+    x0b = BnConv.apply(p2, bn_mid.weight, bn_mid.bias, conv_mid.weight, conv_mid.bias, None, None, bn_mid, False, False)
+    y = res_blocks(g("RBs2"), x0b)
+    p3 = MaxPool.apply(y, *pools[2])
+    bn_out, conv_out = g("conv3")[0], g("conv3")[1]
+    c3 = BnConv.apply(p3, bn_out.weight, bn_out.bias, conv_out.weight, conv_out.bias, None, None, bn_out, False, True)
+    feat = MaxPool.apply(c3, None, None, None)
+    fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
+    f = Bn2d.apply(feat, fc[0].weight, fc[0].bias, fc[0], False)
+    f = dropout(f, dropout_p, training)
+    return Linear.apply(f, fc[2].weight, fc[2].bias)
+
+
+def local_forward(mod, cat, out_layer, emb_p, lin_ps, training=True):
+    h = Embedding.apply(cat, mod.emb_layer.weight)
+    h = dropout(h, emb_p, training)
+    for lin, bn, p in zip(mod.lin_layers, mod.bn_layers, lin_ps):
+        h = Linear.apply(h, lin.weight, lin.bias)
+        h = Bn2d.apply(h, bn.weight, bn.bias, bn, True)          # order Linear -> ReLU -> BN (model_snv.py:466-467)
+        h = dropout(h, p, training)
+    return Linear.apply(h, out_layer.weight, out_layer.bias)

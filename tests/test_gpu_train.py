@@ -1,0 +1,93 @@
+"""GPU parity of the training step (forward with batch-stat BN, CE-sum loss, backward) against the reference's golden
+vectors: loss, every parameter gradient (relative 1e-4 of the tensor's max) and BN running statistics after the step."""
+import numpy as np
+import pytest
+import torch
+import torch.nn as nn
+
+from tests import _util as U
+from tests.test_gpu_snv import product_from_hp
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("tag", ["T", "S"])
+def test_train_step_matches_reference(tag):
+    fx = U.load(f"snv_train_{tag}.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    for m in model.modules():            # the fixture was generated with every dropout rate at 0
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    model = model.cuda().train()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    preds = model((torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda"), cat), x)
+    assert np.abs(preds.detach().cpu().numpy() - fx["preds"]).max() <= 2e-4
+    loss = nn.CrossEntropyLoss(reduction="sum")(preds, torch.from_numpy(fx["y"]).cuda())
+    model.zero_grad()
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-4 * abs(float(fx["loss"]))
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        if ".layer." in k or p.numel() == 0:
+            continue
+        want = fx["g::" + k]
+        assert p.grad is not None, k
+        # biases in front of a batch-statistics BN have a mathematically zero gradient (1e-7 rounding noise in the
+        # reference too): the absolute floor keeps those from being compared relative to noise
+        scale = float(np.abs(want).max()) + 1e-2
+        err = float(np.abs(p.grad.cpu().numpy() - want).max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= 2e-4, f"gradient of {worst[0]} off by {worst[1]:.2e} (relative to its max + 1e-2)"
+    gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9)
+    assert abs(float(gnorm) - float(fx["gnorm"])) <= 2e-4 * float(fx["gnorm"])
+    for k, b in model.named_buffers():
+        if ".layer." in k or k.endswith("num_batches_tracked") or b.numel() == 0:
+            continue
+        assert np.abs(b.cpu().numpy() - fx["b::" + k]).max() <= 2e-5, k
+
+
+def test_dropout_statistics_and_determinism():
+    from mural_amd.model import train_ops as T
+    x = torch.ones(1 << 20, device="cuda")
+    y = T.Dropout.apply(x, 0.25, 1234)
+    keep = float((y != 0).float().mean())
+    assert abs(keep - 0.75) < 5e-3
+    assert torch.allclose(y[y != 0], torch.full((1,), 1 / 0.75, device="cuda"))
+    assert torch.equal(y, T.Dropout.apply(x, 0.25, 1234)) and not torch.equal(y, T.Dropout.apply(x, 0.25, 1235))
+
+
+def test_optimizer_step_runs_and_eval_uses_updated_weights():
+    """one Adam step through the drop-in module, then the fused eval kernels see the new parameters/statistics"""
+    fx = U.load("snv_train_T.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    sd = U.snv_state_for(fx, orc)
+    model.load_state_dict(sd)
+    model = model.cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"]).cuda()
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    torch.manual_seed(0)
+    losses = []
+    for _ in range(3):
+        preds = model((torch.zeros(len(cat), 1, device="cuda"), cat), x)
+        loss = crit(preds, y)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses))
+    model.eval()
+    orc.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    orc.eval()
+    with torch.no_grad():
+        got = model((torch.zeros(len(cat), 1, device="cuda"), cat), x).cpu().numpy()
+        want = orc((torch.zeros(len(cat), 1, dtype=torch.float64), cat.cpu()), x.cpu()).numpy()
+    assert np.abs(np.exp(got) - np.exp(want)).max() <= 1e-5

@@ -80,7 +80,7 @@ def test_no_cpu_fallback():
     with pytest.raises(RuntimeError, match="HIP device"):
         model((torch.zeros(2, 1), torch.zeros(2, 9, dtype=torch.long)), torch.zeros(2, 4, 201))
     model.train()
-    with pytest.raises(NotImplementedError):
+    with pytest.raises(RuntimeError, match="HIP device"):
         model((torch.zeros(2, 1), torch.zeros(2, 9, dtype=torch.long)), torch.zeros(2, 4, 201))
 
 
