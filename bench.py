@@ -13,7 +13,8 @@ window decode + first-layer lookup kernel / conv-tower kernel with head) over on
 cross-position reuse.  N>1: ranks take disjoint site shards (weak scaling) and each step ends with one RCCL
 all_gather of the (batch, 4) fp32 log-probabilities.
 
-Extra objects on the JSON line: ``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch of the
+Extra objects on the JSON line: ``train`` (N=1: steps/s of the S-config training step at batch 4096, BASELINE.json
+configs[2], measured after the timed prediction region); ``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch of the
 layers it evaluates / HIP-event duration of that kernel measured live in the timed region, vs the 157.3 TFLOP/s fp32
 MFMA peak) and
 ``cpu_baseline`` (oracle = PyTorch-CPU restatement of the reference, timed on this box's host cores on a bounded
@@ -110,6 +111,36 @@ def cpu_baseline(model_state, codes, budget_s=12.0, batch=256):
                       f"{it} timed iterations after warm-up, best of 8/16/32/64 torch threads on {ncpu} host CPUs"}
 
 
+def train_steps_per_s(device, genome, B=4096, steps=8, warmup=3):
+    """BASELINE.json configs[2]: S-config from scratch, batch 4096, Adam lr 1e-3, CE-sum, clip 10, default dropouts."""
+    import torch.nn as nn
+    model = build_model(device).train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    rng = np.random.default_rng(1)
+    labels = torch.from_numpy(rng.choice(4, size=(steps + warmup) * B, p=[0.955, 0.015, 0.015, 0.015])).to(device)
+    cont = torch.zeros(B, 1, device=device)
+    times = []
+    for s in range(steps + warmup):
+        idx = torch.arange(s * B, (s + 1) * B, device=device)
+        pos, strand = idx + DISTAL_RADIUS, (idx & 1).to(torch.uint8)
+        cat = genome.encode_kmer(pos, strand, LOCAL_RADIUS, LOCAL_ORDER)
+        x = genome.encode_onehot(pos, strand, DISTAL_RADIUS)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        loss = crit(model((cont, cat), x), labels[s * B:(s + 1) * B])
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+        opt.step()
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[warmup:]))
+    return {"steps_per_s": 1.0 / t, "ms_per_step": t * 1e3, "batch": B, "sites_per_s": B / t, "optimizer": "Adam lr 1e-3",
+            "loss": "CrossEntropy(sum), clip_grad_norm 10", "note": "forward (batch-stat BN, dropout) + backward + update; "
+            "inputs already encoded on the device; median of %d steps after %d warm-up" % (steps, warmup)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -117,6 +148,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=500_000, help="sites per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train", action="store_true", help="skip the short train-steps/s measurement (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -213,6 +245,8 @@ def main():
                                  "lookups in snv_stage1_kernel and the 51,600 FLOP/site local MLP is snv_local_mlp; "
                                  "end-to-end model FLOP rate = 8,096,144 x value"},
         }
+        if world == 1 and not args.no_train:
+            line["train"] = train_steps_per_s(device, genome)
         if world == 1 and not args.no_cpu_baseline:
             state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(state, codes)

@@ -165,7 +165,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
                                                          int pre_relu, float* __restrict__ dW, float* __restrict__ db) {
   constexpr int TL = 64, PAD = (K - 1) / 2, TW = TL + K - 1;
   __shared__ float sdy[C][TL + 1];
-  __shared__ float sa[C][TW + 1];
+  __shared__ float sa[C][TW + 2];   // +1 column read by the two-column inner loop
   const int tid = threadIdx.x;
   float acc[(C * C) / 256][K];
 #pragma unroll
@@ -182,8 +182,8 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
       const int c = i / TL, j = i - c * TL;
       sdy[c][j] = (l0 + j < L) ? dy[((size_t)b * C + c) * L + l0 + j] : 0.f;
     }
-    for (int i = tid; i < C * TW; i += 256) {
-      const int c = i / TW, j = i - c * TW;
+    for (int i = tid; i < C * (TW + 1); i += 256) {
+      const int c = i / (TW + 1), j = i - c * (TW + 1);
       const int l = l0 + j - PAD;
       float v = 0.f;
       if (l >= 0 && l < L) {
@@ -194,13 +194,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
       sa[c][j] = v;
     }
     __syncthreads();
+    {
+      // thread = (input channel ci, group of (C*C)/256 consecutive output channels): the K+1 input values of two
+      // neighbouring columns are reused across the group's output channels
+      constexpr int G = (C * C) / 256;
+      const int ci = tid % C, co0 = (tid / C) * G;
+      for (int j = 0; j < TL; j += 2) {
+        float av[K + 1];
 #pragma unroll
-    for (int p = 0; p < (C * C) / 256; ++p) {
-      const int pair = tid + 256 * p, co = pair / C, ci = pair - co * C;
-      for (int j = 0; j < TL; ++j) {
-        const float g = sdy[co][j];
+        for (int k = 0; k < K + 1; ++k) av[k] = sa[ci][j + k];
 #pragma unroll
-        for (int k = 0; k < K; ++k) acc[p][k] = fmaf(g, sa[ci][j + k], acc[p][k]);
+        for (int p = 0; p < G; ++p) {
+          const float g0 = sdy[co0 + p][j], g1 = sdy[co0 + p][j + 1];
+#pragma unroll
+          for (int k = 0; k < K; ++k) acc[p][k] = fmaf(g1, av[k + 1], fmaf(g0, av[k], acc[p][k]));
+        }
       }
     }
     if (tid < C) {
@@ -211,9 +219,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
   }
 #pragma unroll
   for (int p = 0; p < (C * C) / 256; ++p) {
-    const int pair = tid + 256 * p;
+    const int ci = tid % C, co = (tid / C) * ((C * C) / 256) + p;
 #pragma unroll
-    for (int k = 0; k < K; ++k) atomicAdd(&dW[(size_t)pair * K + k], acc[p][k]);
+    for (int k = 0; k < K; ++k) atomicAdd(&dW[((size_t)co * C + ci) * K + k], acc[p][k]);
   }
   if (tid < C && db) atomicAdd(&db[tid], bacc);
 }
