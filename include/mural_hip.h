@@ -193,7 +193,8 @@ int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, 
                          const float* mean, const float* invstd, const float* gamma, double* s1, double* s2,
                          float* dx, float* dgamma, float* dbeta, void* stream);
 int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, int32_t L, int32_t K,
-                        const float* scale, const float* shift, int32_t pre_relu, float* dW, float* db, void* stream);
+                        const float* scale, const float* shift, int32_t pre_relu, float* dW, float* db,
+                        float* part, size_t part_floats, void* stream);
 int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
                          int32_t* arg, void* stream);
 int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,
@@ -207,6 +208,7 @@ int mural_op_first_bwd(const float* dy, const int32_t* arg, const uint8_t* sym, 
                        float* dtap, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream);
 int mural_op_linear_fwd(const float* x, const float* W, const float* b, int64_t B, int32_t I, int32_t O, float* y,
                         void* stream);
+/* dW / db are accumulated: zeroed by the caller */
 int mural_op_linear_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t I, int32_t O, float* dx,
                         float* dW, float* db, void* stream);
 int mural_op_embedding_fwd(const int64_t* cat, const float* E, int64_t B, int32_t cols, int32_t rows, float* y,

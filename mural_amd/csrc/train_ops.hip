@@ -162,10 +162,10 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ s1, const double
 template <int C, int K>
 __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x, int B, int L,
                                                          const float* __restrict__ scale, const float* __restrict__ shift,
-                                                         int pre_relu, float* __restrict__ dW, float* __restrict__ db) {
+                                                         int pre_relu, float* __restrict__ part /*[grid][C*C*K + C]*/) {
   constexpr int TL = 64, PAD = (K - 1) / 2, TW = TL + K - 1;
   __shared__ float sdy[C][TL + 1];
-  __shared__ float sa[C][TW + 2];   // +1 column read by the two-column inner loop
+  __shared__ float sa[C][TW + 3];   // +1 column read by the two-column inner loop; odd stride: conflict-free rows
   const int tid = threadIdx.x;
   float acc[(C * C) / 256][K];
 #pragma unroll
@@ -211,19 +211,47 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const float* __restrict
         }
       }
     }
-    if (tid < C) {
+    {   // bias gradient: thread = (output channel tid/8, 8-column slice tid%8)
+      const int co = tid >> 3, part8 = tid & 7;
       float s = 0.f;
-      for (int j = 0; j < TL; ++j) s += sdy[tid][j];
+#pragma unroll
+      for (int q = 0; q < TL / 8; ++q) s += sdy[co][part8 * (TL / 8) + q];
       bacc += s;
     }
   }
+  bacc += __shfl_xor(bacc, 1);
+  bacc += __shfl_xor(bacc, 2);
+  bacc += __shfl_xor(bacc, 4);
+  // per-workgroup partial sums (one plain store each); wgrad_reduce_kernel adds them up in a fixed order, so the
+  // gradient is bitwise reproducible and no float atomics contend on the 3 K-entry tensor
+  float* mine = part + (size_t)blockIdx.x * (C * C * K + C);
 #pragma unroll
   for (int p = 0; p < (C * C) / 256; ++p) {
     const int ci = tid % C, co = (tid / C) * ((C * C) / 256) + p;
 #pragma unroll
-    for (int k = 0; k < K; ++k) atomicAdd(&dW[((size_t)co * C + ci) * K + k], acc[p][k]);
+    for (int k = 0; k < K; ++k) mine[((size_t)co * C + ci) * K + k] = acc[p][k];
   }
-  if (tid < C && db) atomicAdd(&db[tid], bacc);
+  if ((tid & 7) == 0) mine[C * C * K + (tid >> 3)] = bacc;
+}
+
+// 64 outputs x 16 slices of the partial rows per workgroup; fixed summation order -> reproducible gradients
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restrict__ part, int nblk, int nW, int nB,
+                                                            float* __restrict__ dW, float* __restrict__ db) {
+  __shared__ float sh[16][64];
+  const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s = 0.f;
+  if (i < nW + nB)
+    for (int b = slice; b < nblk; b += 16) s += part[(size_t)b * (nW + nB) + i];
+  sh[slice][o] = s;
+  __syncthreads();
+  if (slice == 0 && i < nW + nB) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][o];
+    if (i < nW) dW[i] = t;
+    else if (db) db[i - nW] = t;
+  }
 }
 
 // ------------------------------------------------------------------------------------------- pooling
@@ -439,19 +467,18 @@ __global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* _
   dx[i] = acc;
 }
 
-// dW[o][k] = sum_b dy[b][o] x[b][k]; db[o] = sum_b dy[b][o]: one wave per (o, k) strip
+// dW[o][k] += sum_{b in chunk} dy[b][o] x[b][k]; db[o] likewise (k == I).  grid (O, chunks): thread = k, so the x row
+// reads are coalesced and dy[b][o] is a broadcast; chunks meet through float atomics (dW / db zeroed by the caller)
 __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t B,
                                                            int I, int O, float* __restrict__ dW, float* __restrict__ db) {
-  const int lane = threadIdx.x & 63;
-  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);   // (o, k) or (o, I) for the bias
-  if (item >= (int64_t)O * (I + 1)) return;
-  const int o = (int)(item / (I + 1)), k = (int)(item - (int64_t)o * (I + 1));
-  float acc = 0.f;
-  for (int64_t b = lane; b < B; b += 64) acc = fmaf(dy[b * O + o], k < I ? x[b * I + k] : 1.f, acc);
-  acc = wave_sum(acc);
-  if (lane == 0) {
-    if (k < I) dW[(size_t)o * I + k] = acc;
-    else if (db) db[o] = acc;
+  const int o = blockIdx.x;
+  const int64_t per = (B + gridDim.y - 1) / gridDim.y;
+  const int64_t b0 = (int64_t)blockIdx.y * per, b1 = (b0 + per < B) ? b0 + per : B;
+  for (int k = threadIdx.x; k <= I; k += blockDim.x) {
+    float acc = 0.f;
+    for (int64_t b = b0; b < b1; ++b) acc = fmaf(dy[b * O + o], k < I ? x[b * I + k] : 1.f, acc);
+    if (k < I) atomicAdd(&dW[(size_t)o * I + k], acc);
+    else if (db) atomicAdd(&db[o], acc);
   }
 }
 
@@ -630,15 +657,19 @@ extern "C" int mural_op_bn_backward(const float* dz, const float* x, int64_t B, 
   CHECK_LAUNCH();
 }
 
-// dW [32][32][3] and db [32] (zeroed by the caller) of a 32->32 k=3 conv whose input was scale*act(x)+shift
+// dW [32][32][3] and db [32] of a 32->32 k=3 conv whose input was scale*act(x)+shift; part: float scratch of
+// 1024 * 3104 floats for the per-workgroup partial sums
 extern "C" int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, int32_t L, int32_t K,
                                    const float* scale, const float* shift, int32_t pre_relu, float* dW, float* db,
-                                   void* stream) {
+                                   float* part, size_t part_floats, void* stream) {
   MURAL_REQUIRE(C == 32 && K == 3, "conv_wgrad is built for 32 channels, 3 taps (got %d, %d)", C, K);
   const int64_t items = B * ((L + 63) / 64);
   const int grid = (int)(items < 1024 ? (items < 1 ? 1 : items) : 1024);
-  hipLaunchKernelGGL((conv_wgrad_kernel<32, 3>), dim3(grid), dim3(256), 0, STREAM, dy, x, (int)B, L, scale, shift, pre_relu, dW,
-                     db);
+  MURAL_REQUIRE(part && part_floats >= (size_t)grid * (32 * 32 * 3 + 32), "conv_wgrad: partial-sum scratch too small");
+  hipLaunchKernelGGL((conv_wgrad_kernel<32, 3>), dim3(grid), dim3(256), 0, STREAM, dy, x, (int)B, L, scale, shift, pre_relu,
+                     part);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((32 * 32 * 3 + 32 + 63) / 64), dim3(1024), 0, STREAM, part, grid, 32 * 32 * 3, 32,
+                     dW, db);
   CHECK_LAUNCH();
 }
 
@@ -697,8 +728,9 @@ extern "C" int mural_op_linear_bwd(const float* dy, const float* x, const float*
                                    float* dW, float* db, void* stream) {
   if (B == 0) return MURAL_OK;
   if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((B * I + 255) / 256)), dim3(256), 0, STREAM, dy, W, B, I, O, dx);
-  const int64_t items = (int64_t)O * (I + 1);
-  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0, STREAM, dy, x, B, I, O, dW, db);
+  int chunks = (int)(B / 128);
+  chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
+  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(O, chunks), dim3(256), 0, STREAM, dy, x, B, I, O, dW, db);
   CHECK_LAUNCH();
 }
 

@@ -81,9 +81,11 @@ class BnConv(torch.autograd.Function):
             g = torch.empty_like(dy)
             _call("mural_op_relu_mask", dy, y, dy.numel(), g, st)
             dy = g
-        dW = torch.zeros_like(weight)
-        db = torch.zeros(weight.shape[0], device=x.device)
-        _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, st)
+        dW = torch.empty_like(weight)
+        db = torch.empty(weight.shape[0], device=x.device)
+        part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=x.device)
+        _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, part, part.numel(),
+              st)
         wt = torch.empty_like(weight)
         _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 1, st)
         dz = torch.empty_like(x)
@@ -207,8 +209,8 @@ class Linear(torch.autograd.Function):
         B, I = x.shape
         O = weight.shape[0]
         dx = torch.empty_like(x)
-        dW = torch.empty_like(weight)
-        db = torch.empty(O, device=x.device)
+        dW = torch.zeros_like(weight)
+        db = torch.zeros(O, device=x.device)
         _call("mural_op_linear_bwd", dy.contiguous(), x, _f32(weight), B, I, O, dx, dW, db, _stream(x))
         return dx, dW, db
 
