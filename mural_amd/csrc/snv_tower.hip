@@ -9,7 +9,7 @@
 //             D[cout 16][col 16] += W[cout][k] * act[k][col], K = 3 taps x 32 channels = 24 k-steps,
 //             two M-blocks per 16-column block.  All positions of the tile share one flattened column axis
 //             with a zero separator column between positions (that column IS the conv zero padding).
-//             LDS image: [column][32 channels] with a 16-byte-chunk XOR swizzle, read with ds_read_b128.
+//             LDS image: [column][32 channels] with a conflict-free 16-byte-chunk XOR swizzle, read with ds_read_b128.
 //             Weights live in 48 VGPRs per lane per layer (A fragments, fetched from L2 in fragment order).
 //             The residual stream stays in registers in MFMA accumulator layout across a whole stage.
 //   head      global max, BN, Linear(32->n_class) per tower, then log(clamp((sm(local)+(sm(mid)+sm(large))/2)/2)).
@@ -21,9 +21,14 @@ namespace mural {
 
 using f32x4 = __attribute__((ext_vector_type(4))) float;
 
-__device__ __forceinline__ int lds_off(int pc, int chunk) {
-  return pc * 32 + ((chunk ^ ((pc >> 1) & 7)) << 2);
+// LDS image [column][32 channels]: the eight 16-byte chunks of a column are XOR-permuted by a per-column key chosen
+// (exhaustive search over 16-entry tables, tools/lds_swizzle_search.py) so that the ds_read_b128 operand reads of all
+// three conv taps are bank-conflict-free for every 16-lane group of the instruction; the key depends on column mod 16,
+// so a wave's blocks, 32 columns apart, keep one base address + immediates.
+__device__ __forceinline__ int lds_key(int pc) {
+  return (int)((0x2e4c11ee4587ull >> (3 * (pc & 15))) & 7ull);
 }
+__device__ __forceinline__ int lds_off(int pc, int chunk) { return pc * 32 + ((chunk ^ lds_key(pc)) << 2); }
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }

@@ -18,7 +18,7 @@ def unswizzle(buf, ncols_phys):
     """physical LDS image -> [physical col][32]"""
     out = np.zeros((ncols_phys, 32), np.float32)
     for pc in range(ncols_phys):
-        key = (pc >> 1) & 7
+        key = (0x2e4c11ee4587 >> (3 * (pc & 15))) & 7
         for chunk in range(8):
             src = pc * 32 + 4 * (chunk ^ key)
             out[pc, 4 * chunk:4 * chunk + 4] = buf[src:src + 4]
