@@ -195,6 +195,15 @@ int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, 
 int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, int32_t L, int32_t K,
                         const float* scale, const float* shift, int32_t pre_relu, float* dW, float* db,
                         float* part, size_t part_floats, void* stream);
+/* fp32-MFMA path of the 32->32 k=3 convs on [B][32][L] tensors (L + 2 <= 288): forward / input gradient and weight +
+ * bias gradient.  W: PyTorch [32][32][3]; wfrag: float[3072] scratch; part: mural_op_conv32_wgrad_scratch() floats.    */
+int mural_op_conv32_supported(int32_t L);
+int mural_op_conv32(const float* x, const float* W, const float* bias, float* y, int64_t B, int32_t L, int32_t dgrad,
+                    const float* pre_s, const float* pre_t, int32_t pre_relu, int32_t post_relu, const float* res1,
+                    const float* res2, float* wfrag, void* stream);
+size_t mural_op_conv32_wgrad_scratch(void);
+int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B, int32_t L, const float* pre_s, const float* pre_t,
+                          int32_t pre_relu, float* dW, float* db, float* part, size_t part_floats, void* stream);
 int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
                          int32_t* arg, void* stream);
 int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,

@@ -1,0 +1,59 @@
+// Shared device helpers of the MFMA conv kernels: the swizzled LDS image [column][32 channels] of a flattened column
+// axis (zero separator columns between rows) and the v_mfma_f32_16x16x4_f32 operand conventions.
+#pragma once
+#include "common.h"
+
+namespace mural {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// LDS image [column][32 channels]: the eight 16-byte chunks of a column are XOR-permuted by a per-column key chosen
+// (exhaustive search over 16-entry tables, tools/lds_swizzle_search.py) so that the ds_read_b128 operand reads of all
+// three conv taps are bank-conflict-free for every 16-lane group of the instruction; the key depends on column mod 16,
+// so a wave's blocks, 32 columns apart, keep one base address + immediates.
+__device__ __forceinline__ int lds_key(int pc) {
+  return (int)((0x2e4c11ee4587ull >> (3 * (pc & 15))) & 7ull);
+}
+__device__ __forceinline__ int lds_off(int pc, int chunk) { return pc * 32 + ((chunk ^ lds_key(pc)) << 2); }
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
+__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
+  return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
+}
+__device__ __forceinline__ f32x4 relu_bn(f32x4 v, f32x4 s, f32x4 t) {
+  return f32x4{fmaf(s.x, fmaxf(v.x, 0.f), t.x), fmaf(s.y, fmaxf(v.y, 0.f), t.y), fmaf(s.z, fmaxf(v.z, 0.f), t.z),
+               fmaf(s.w, fmaxf(v.w, 0.f), t.w)};
+}
+
+// logical column c of a flattened stage geometry holds data (not separator / padding)?
+__device__ __forceinline__ bool col_is_data(int c, const FastDiv& dSc, int Sc, int Lv, int P) {
+  if (c < 1) return false;
+  uint32_t u = (uint32_t)(c - 1);
+  uint32_t p = dSc.div(u);
+  uint32_t j = u - p * (uint32_t)Sc;
+  return (p < (uint32_t)P) && (j < (uint32_t)Lv);
+}
+
+
+// 8 k-steps (one conv tap: 2 halves x 4) of v_mfma_f32_16x16x4_f32 for one (DUAL: two) 16-column block(s)
+template <bool DUAL, int NK>
+__device__ __forceinline__ void mfma_tap(const float (&a)[NK], int t, const f32x4 (&b0)[2], const f32x4 (&b1)[2],
+                                         f32x4& acc0, f32x4& acc1) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * t + 4 * h + q], b0[h][q], acc0, 0, 0, 0);
+      if (DUAL) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * t + 4 * h + q], b1[h][q], acc1, 0, 0, 0);
+    }
+  }
+}
+
+__device__ __forceinline__ f32x4 lds_ld4(const char* base, uint32_t off) {
+  return *reinterpret_cast<const f32x4*>(base + off);
+}
+__device__ __forceinline__ void lds_st4(char* base, uint32_t off, f32x4 v) { *reinterpret_cast<f32x4*>(base + off) = v; }
+
+}  // namespace mural

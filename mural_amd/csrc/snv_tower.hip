@@ -15,40 +15,10 @@
 //   head      global max, BN, Linear(32->n_class) per tower, then log(clamp((sm(local)+(sm(mid)+sm(large))/2)/2)).
 #include <vector>
 
+#include "mfma_tile.h"
 #include "snv.h"
 
 namespace mural {
-
-using f32x4 = __attribute__((ext_vector_type(4))) float;
-
-// LDS image [column][32 channels]: the eight 16-byte chunks of a column are XOR-permuted by a per-column key chosen
-// (exhaustive search over 16-entry tables, tools/lds_swizzle_search.py) so that the ds_read_b128 operand reads of all
-// three conv taps are bank-conflict-free for every 16-lane group of the instruction; the key depends on column mod 16,
-// so a wave's blocks, 32 columns apart, keep one base address + immediates.
-__device__ __forceinline__ int lds_key(int pc) {
-  return (int)((0x2e4c11ee4587ull >> (3 * (pc & 15))) & 7ull);
-}
-__device__ __forceinline__ int lds_off(int pc, int chunk) { return pc * 32 + ((chunk ^ lds_key(pc)) << 2); }
-
-__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
-__device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
-__device__ __forceinline__ f32x4 max4(f32x4 a, f32x4 b) {
-  return f32x4{fmaxf(a.x, b.x), fmaxf(a.y, b.y), fmaxf(a.z, b.z), fmaxf(a.w, b.w)};
-}
-__device__ __forceinline__ f32x4 relu_bn(f32x4 v, f32x4 s, f32x4 t) {
-  return f32x4{fmaf(s.x, fmaxf(v.x, 0.f), t.x), fmaf(s.y, fmaxf(v.y, 0.f), t.y), fmaf(s.z, fmaxf(v.z, 0.f), t.z),
-               fmaf(s.w, fmaxf(v.w, 0.f), t.w)};
-}
-
-// logical column c of a flattened stage geometry holds data (not separator / padding)?
-__device__ __forceinline__ bool col_is_data(int c, const FastDiv& dSc, int Sc, int Lv, int P) {
-  if (c < 1) return false;
-  uint32_t u = (uint32_t)(c - 1);
-  uint32_t p = dSc.div(u);
-  uint32_t j = u - p * (uint32_t)Sc;
-  return (p < (uint32_t)P) && (j < (uint32_t)Lv);
-}
 
 enum { MODE_PLAIN = 0, MODE_RES_FIRST = 1, MODE_RES_LAST = 2, MODE_ENTRY = 3, MODE_FINAL = 4 };
 
@@ -81,26 +51,6 @@ __device__ __forceinline__ StageAddr stage_setup(const TowerGeom& g, int st, int
   for (int i = 0; i < SNV_NB2MAX; ++i)
     a.vmask |= col_is_data(c0 + 32 * i, g.dSc[st], g.Sc[st], g.L[st], P) ? (1u << i) : 0u;
   return a;
-}
-
-__device__ __forceinline__ f32x4 lds_ld4(const char* base, uint32_t off) {
-  return *reinterpret_cast<const f32x4*>(base + off);
-}
-__device__ __forceinline__ void lds_st4(char* base, uint32_t off, f32x4 v) { *reinterpret_cast<f32x4*>(base + off) = v; }
-
-// 24 k-steps of v_mfma_f32_16x16x4_f32 for one (DUAL: two) 16-column block(s) against this wave's M-block.
-// Operand reads of tap t+1/t+2 are in flight while tap t is multiplied (sched_barrier pins that order).
-template <bool DUAL>
-__device__ __forceinline__ void mfma_tap(const float (&a)[SNV_KSTEPS], int t, const f32x4 (&b0)[2], const f32x4 (&b1)[2],
-                                         f32x4& acc0, f32x4& acc1) {
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * t + 4 * h + q], b0[h][q], acc0, 0, 0, 0);
-      if (DUAL) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a[8 * t + 4 * h + q], b1[h][q], acc1, 0, 0, 0);
-    }
-  }
 }
 
 // Branch-free epilogue.  Per-layer scalars select the role of the layer (see layer_mode):
@@ -166,7 +116,7 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
       }
       f32x4 acc0 = acc_init(k, pb, xres[i0]), acc1 = acc_init(k, pb, xres[i1]);
       __builtin_amdgcn_sched_barrier(0);
-      mfma_tap<true>(a, 0, X0, X1, acc0, acc1);
+      mfma_tap<true, SNV_KSTEPS>(a, 0, X0, X1, acc0, acc1);
 #pragma unroll
       for (int h = 0; h < 2; ++h) {
         Z0[h] = lds_ld4(in, sa.rd[4 + h] + 4096u * i0);
@@ -177,7 +127,7 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
         epilogue(k, pa0, xres[i0 - 2], (sa.vmask >> (i0 - 2)) & 1u, ps, pt, out, sa.wr + 4096u * (i0 - 2));
         epilogue(k, pa1, xres[i0 - 1], (sa.vmask >> (i0 - 1)) & 1u, ps, pt, out, sa.wr + 4096u * (i0 - 1));
       }
-      mfma_tap<true>(a, 1, Y0, Y1, acc0, acc1);
+      mfma_tap<true, SNV_KSTEPS>(a, 1, Y0, Y1, acc0, acc1);
       if (ip > 0) {   // spread the epilogue's VALU work into the MFMA issue gaps
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -195,7 +145,7 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_tap<true>(a, 2, Z0, Z1, acc0, acc1);
+      mfma_tap<true, SNV_KSTEPS>(a, 2, Z0, Z1, acc0, acc1);
       pa0 = acc0;
       pa1 = acc1;
     } else if (ip > 0 && ip == nfull) {   // the previous pair was the last full one
@@ -220,9 +170,9 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
         }
         f32x4 acc0 = acc_init(k, pb, xres[i0]), acc1 = acc0;
         __builtin_amdgcn_sched_barrier(0);
-        mfma_tap<false>(a, 0, S0, S0, acc0, acc1);
-        mfma_tap<false>(a, 1, S1, S1, acc0, acc1);
-        mfma_tap<false>(a, 2, S2, S2, acc0, acc1);
+        mfma_tap<false, SNV_KSTEPS>(a, 0, S0, S0, acc0, acc1);
+        mfma_tap<false, SNV_KSTEPS>(a, 1, S1, S1, acc0, acc1);
+        mfma_tap<false, SNV_KSTEPS>(a, 2, S2, S2, acc0, acc1);
         epilogue(k, acc0, xres[i0], (sa.vmask >> i0) & 1u, ps, pt, out, sa.wr + 4096u * i0);
       }
     }

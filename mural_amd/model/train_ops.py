@@ -61,18 +61,23 @@ class BnConv(torch.autograd.Function):
         st = _stream(x)
         state = _BnState(x, pre_relu, bn, L)
         wt = torch.empty_like(weight)
-        _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 0, st)
         y = torch.empty((B, weight.shape[0], L), device=x.device)
-        _call("mural_op_conv1d", x, wt, _f32(bias), y, B, Cn, weight.shape[0], L, weight.shape[2], state.scale, state.shift,
-              int(pre_relu), int(post_relu), _p(res1), _p(res2), st)
+        mfma = tuple(weight.shape) == (32, 32, 3) and bool(_lib.lib().mural_op_conv32_supported(L))
+        if mfma:      # fp32 MFMA implicit GEMM (csrc/conv32_mfma.hip)
+            _call("mural_op_conv32", x, _f32(weight), _f32(bias), y, B, L, 0, state.scale, state.shift, int(pre_relu),
+                  int(post_relu), _p(res1), _p(res2), wt, st)
+        else:         # generic direct conv (csrc/conv1d.hip)
+            _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 0, st)
+            _call("mural_op_conv1d", x, wt, _f32(bias), y, B, Cn, weight.shape[0], L, weight.shape[2], state.scale,
+                  state.shift, int(pre_relu), int(post_relu), _p(res1), _p(res2), st)
         ctx.save_for_backward(x, gamma, weight, y if post_relu else None, state.scale, state.shift, state.mean, state.invstd)
-        ctx.flags = (pre_relu, post_relu, res1 is not None, res2 is not None)
+        ctx.flags = (pre_relu, post_relu, res1 is not None, res2 is not None, mfma)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, gamma, weight, y, scale, shift, mean, invstd = ctx.saved_tensors
-        pre_relu, post_relu, has_r1, has_r2 = ctx.flags
+        pre_relu, post_relu, has_r1, has_r2, mfma = ctx.flags
         dy = dy.contiguous()
         B, Cn, L = x.shape
         st = _stream(x)
@@ -83,13 +88,19 @@ class BnConv(torch.autograd.Function):
             dy = g
         dW = torch.empty_like(weight)
         db = torch.empty(weight.shape[0], device=x.device)
-        part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=x.device)
-        _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, part, part.numel(),
-              st)
         wt = torch.empty_like(weight)
-        _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 1, st)
         dz = torch.empty_like(x)
-        _call("mural_op_conv1d", dy, wt, None, dz, B, weight.shape[0], Cn, L, weight.shape[2], None, None, 0, 0, None, None, st)
+        if mfma:
+            part = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), device=x.device)
+            _call("mural_op_conv32_wgrad", dy, x, B, L, scale, shift, int(pre_relu), dW, db, part, part.numel(), st)
+            _call("mural_op_conv32", dy, _f32(weight), None, dz, B, L, 1, None, None, 0, 0, None, None, wt, st)
+        else:
+            part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=x.device)
+            _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, part,
+                  part.numel(), st)
+            _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 1, st)
+            _call("mural_op_conv1d", dy, wt, None, dz, B, weight.shape[0], Cn, L, weight.shape[2], None, None, 0, 0, None, None,
+                  st)
         acc = torch.zeros(2, Cn, dtype=torch.float64, device=x.device)
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cn, device=x.device)
