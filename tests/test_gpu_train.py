@@ -91,3 +91,38 @@ def test_optimizer_step_runs_and_eval_uses_updated_weights():
         got = model((torch.zeros(len(cat), 1, device="cuda"), cat), x).cpu().numpy()
         want = orc((torch.zeros(len(cat), 1, dtype=torch.float64), cat.cpu()), x.cpu()).numpy()
     assert np.abs(np.exp(got) - np.exp(want)).max() <= 1e-5
+
+
+@pytest.mark.parametrize("model_no", [0, 1])
+def test_train_step_network0_network1_vs_oracle_autograd(model_no):
+    """sub-graphs of Network2: gradients against the CPU oracle's autograd (the oracle is pinned for training by G7)"""
+    hp = np.array([5, 3, 100, 150, 75, 32, 3, 4, model_no])
+    model, _ = product_from_hp(hp)
+    orc = U.snv_oracle_from_hp(hp, drops=(0.0, 0.0, 0.0))
+    from oracle import synth
+    sd = synth.synth_state_dict(orc.state_dict(), 99)
+    orc.load_state_dict(sd)
+    model.load_state_dict(sd)
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    model = model.cuda().train()
+    orc.train()
+    rng = np.random.default_rng(5)
+    B = 24
+    codes = rng.integers(0, 4, size=(B, 201)).astype(np.uint8)
+    cat = torch.from_numpy(rng.integers(0, 65, size=(B, 9)).astype(np.int64))
+    y = torch.from_numpy(rng.integers(0, 4, size=B))
+    x = U.onehot(codes)
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    want = crit(orc((torch.zeros(B, 1, dtype=torch.float64), cat), x), y)
+    want.backward()
+    got = crit(model((torch.zeros(B, 1, device="cuda"), cat.cuda()), x.cuda()), y.cuda())
+    got.backward()
+    assert abs(got.item() - want.item()) <= 1e-4 * abs(want.item())
+    ref = dict(orc.named_parameters())
+    for k, p in model.named_parameters():
+        if ".layer." in k or p.numel() == 0:
+            continue
+        w = ref[k].grad.numpy()
+        assert np.abs(p.grad.cpu().numpy() - w).max() <= 2e-4 * (np.abs(w).max() + 1e-2), k
