@@ -17,15 +17,19 @@ __device__ __forceinline__ float apply_act(float v, int act) {
   }
 }
 
-template <int COG, int KT>   // KT: compile-time tap count (0 = runtime a.K)
+template <int COG, int KT, bool WIDE>   // KT: compile-time tap count (0 = runtime a.K)
+// WIDE = false: workgroup = 64 output positions, the 4 waves share the output-channel groups;
+// WIDE = true : workgroup = 256 output positions, each wave takes 64 of them and walks every channel group (used when
+//               there are fewer than 4 groups, so that no wave idles on the 8/16-channel layers)
 __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const float* __restrict__ wt,
                                                       const float* __restrict__ bias) {
   extern __shared__ float tile[];   // [Cin][TWp]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b = blockIdx.y;
-  const int l0 = blockIdx.x * 64;
-  const int TW = 63 * a.stride + a.K;          // input span of 64 outputs
+  constexpr int TLB = WIDE ? 256 : 64;
+  const int l0 = blockIdx.x * TLB;
+  const int TW = (TLB - 1) * a.stride + a.K;   // input span of the tile's outputs
   const int TWp = TW | 1;                      // odd row stride: channel rows start on different banks
   const int in0 = l0 * a.stride - a.pad;       // first (virtual, upsampled) input index of the tile
   const int Lv = a.Lin * a.up;
@@ -44,16 +48,18 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
     }
   }
   __syncthreads();
-  const int l = l0 + lane;
+  const int lloc = WIDE ? 64 * wave + lane : lane;   // output position inside the tile
+  const int l = l0 + lloc;
   const int ngroups = a.Cout / COG;
-  for (int cg = wave; cg < ngroups; cg += 4) {
+  for (int cg = WIDE ? 0 : wave; cg < ngroups; cg += WIDE ? 1 : 4) {
     float acc[COG];
 #pragma unroll
     for (int c = 0; c < COG; ++c) acc[c] = bias ? bias[cg * COG + c] : 0.f;
     const float* __restrict__ w = wt + cg * COG;
     const int K = KT ? KT : a.K;
-    for (int ci = 0; ci < a.Cin; ++ci) {
-      const float* trow = tile + ci * TWp + lane * a.stride;
+#pragma unroll 4
+    for (int ci = 0; ci < a.Cin; ++ci) {   // unrolled: several input channels' scalar weight loads in flight together
+      const float* trow = tile + ci * TWp + lloc * a.stride;
       if (KT) {
         float x[KT ? KT : 1];
 #pragma unroll
@@ -86,24 +92,32 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
   }
 }
 
+template <bool WIDE>
+static void (*pick_kernel(int K, bool c8))(const Conv1dArgs, const float*, const float*) {
+  switch (K) {
+    case 1: return c8 ? conv1d_kernel<8, 1, WIDE> : conv1d_kernel<4, 1, WIDE>;
+    case 3: return c8 ? conv1d_kernel<8, 3, WIDE> : conv1d_kernel<4, 3, WIDE>;
+    case 5: return c8 ? conv1d_kernel<8, 5, WIDE> : conv1d_kernel<4, 5, WIDE>;
+    case 7: return c8 ? conv1d_kernel<8, 7, WIDE> : conv1d_kernel<4, 7, WIDE>;
+    default: return c8 ? conv1d_kernel<8, 0, WIDE> : conv1d_kernel<4, 0, WIDE>;
+  }
+}
+
 int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.Lout == 0) return MURAL_OK;
   MURAL_REQUIRE(a.Cout % 4 == 0, "conv1d: Cout must be a multiple of 4 (got %d)", a.Cout);
   MURAL_REQUIRE(a.up >= 1 && a.stride >= 1 && a.K >= 1, "conv1d: bad geometry");
-  const int TWp = (63 * a.stride + a.K) | 1;
+  const bool c8 = a.Cout % 8 == 0;
+  const int ngroups = a.Cout / (c8 ? 8 : 4);
+  const size_t lds_wide = (size_t)a.Cin * ((255 * a.stride + a.K) | 1) * sizeof(float);
+  const bool wide = ngroups < 4 && lds_wide <= 64 * 1024 && a.Lout > 64;
+  const int TWp = ((wide ? 255 : 63) * a.stride + a.K) | 1;
   const size_t lds = (size_t)a.Cin * TWp * sizeof(float);
   MURAL_REQUIRE(lds <= 160 * 1024, "conv1d: input tile of %zu bytes exceeds LDS", lds);
-  const dim3 grid((a.Lout + 63) / 64, a.B);
+  const int tlb = wide ? 256 : 64;
+  const dim3 grid((a.Lout + tlb - 1) / tlb, a.B);
   using KernelFn = void (*)(const Conv1dArgs, const float*, const float*);
-  KernelFn fn = nullptr;
-  const bool c8 = a.Cout % 8 == 0;
-  switch (a.K) {
-    case 1: fn = c8 ? conv1d_kernel<8, 1> : conv1d_kernel<4, 1>; break;
-    case 3: fn = c8 ? conv1d_kernel<8, 3> : conv1d_kernel<4, 3>; break;
-    case 5: fn = c8 ? conv1d_kernel<8, 5> : conv1d_kernel<4, 5>; break;
-    case 7: fn = c8 ? conv1d_kernel<8, 7> : conv1d_kernel<4, 7>; break;
-    default: fn = c8 ? conv1d_kernel<8, 0> : conv1d_kernel<4, 0>; break;
-  }
+  KernelFn fn = wide ? pick_kernel<true>(a.K, c8) : pick_kernel<false>(a.K, c8);
   if (lds > 64 * 1024)
     MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024));

@@ -16,7 +16,7 @@ namespace {
 
 static_assert(sizeof(MuralIndelShape) > 0, "header");
 constexpr int INDEL_LEVELS = 6;
-constexpr int INDEL_CHUNK = 64;   // positions per pass of the layer program (bounds the activation scratch)
+constexpr int INDEL_CHUNK = 256;   // positions per pass of the layer program (bounds the activation scratch)
 
 struct FoldedConv { size_t w, b; int Cin, Cout, K; };   // offsets into the blob; w laid out [Cin][K][Cout]
 

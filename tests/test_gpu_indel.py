@@ -51,9 +51,9 @@ def test_batch_larger_than_chunk_and_packed_path():
     rng = np.random.default_rng(3)
     seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=30000, p=[.247, .247, .247, .247, .012]).tobytes().decode()
     codes = encode_ref.seq_to_codes(seq)
-    pos = rng.integers(0, len(seq), size=150)
+    pos = rng.integers(0, len(seq), size=300)
     pos[:3] = [0, 2, len(seq) - 1]
-    strand = rng.integers(0, 2, size=150).astype(np.uint8)
+    strand = rng.integers(0, 2, size=300).astype(np.uint8)
     sym = ["-" if s else "+" for s in strand]
     R = int(fx["hp"][0])
     x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R, "indel"))
