@@ -225,6 +225,11 @@ def main():
         kernel_ms = k_ms.value / max(k_n.value, 1)
         sites_per_launch = args.steps * B / max(k_n.value, 1)      # the library launches the kernel per 32768-site chunk
         achieved = FLOP_TOWERS * sites_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
+        traffic = None     # HBM bytes per launch from the committed PMC passes (tools/profile_bench.sh), if present
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            with open(tpath) as fh:
+                traffic = json.load(fh)["hbm_bytes_per_site"] * sites_per_launch
         line = {
             "metric": "predicted bases/s (SNV local=10/distal=1000, 4-class, predict)",
             "value": bases / elapsed, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -237,7 +242,7 @@ def main():
                        "collective": "all_gather per step" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": _lib.lib().mural_snv_kernel_name().decode(),
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
                          "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
                          "note": "algorithmic FLOP of the layers this kernel evaluates (6,353,408 per site: every 32->32 "
