@@ -208,13 +208,17 @@ int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int
                          int32_t* arg, void* stream);
 int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,
                          void* stream);
+/* First layer of a tower in training mode: maxpool1(Conv1d(BN(one-hot))) from window symbols (model_snv.py:473-475,
+ * 496-497 under training.py:424), BN(4) batch statistics from the symbol histogram.  mural_op_first_plan gives the sizes of
+ * the caller-allocated buffers: tab (floats), arg (bytes per pooled output) and the backward scratch (floats).       */
+int mural_op_first_plan(int32_t C, int32_t pk, int64_t* tab_floats, int64_t* arg_bytes, int64_t* scratch_floats);
 int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
                        int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
                        const float* bias, float eps, float momentum, float* running_mean, float* running_var,
-                       unsigned long long* counts, float* tab, float* y, int32_t* arg, void* stream);
-int mural_op_first_bwd(const float* dy, const int32_t* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
-                       int32_t col0, int32_t L1, int32_t C, int32_t L2, const float* tab, const float* W,
-                       float* dtap, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream);
+                       unsigned long long* counts, float* tab, float* y, void* arg, void* stream);
+int mural_op_first_bwd(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
+                       int32_t col0, int32_t L1, int32_t C, int32_t pk, int32_t ps, int32_t pp, const float* tab,
+                       const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream);
 int mural_op_linear_fwd(const float* x, const float* W, const float* b, int64_t B, int32_t I, int32_t O, float* y,
                         void* stream);
 /* dW / db are accumulated: zeroed by the caller */

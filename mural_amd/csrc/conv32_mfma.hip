@@ -169,7 +169,7 @@ struct Wgrad32Args {
   int pre_relu;
   int B, L, R, Sc, NC, nb;
   FastDiv dL;
-  float* part;           // [grid * 4][32*32*3 + 32] per-wave partial sums
+  float* part;           // [grid][32*32*3 + 32] per-workgroup partial sums
   int img_floats;        // floats of one LDS image
 };
 
@@ -225,8 +225,11 @@ __global__ __launch_bounds__(256) void wgrad32_mfma_kernel(const Wgrad32Args a) 
   bacc += __shfl_xor(bacc, 1);
   bacc += __shfl_xor(bacc, 2);
   bacc += __shfl_xor(bacc, 4);
-  // D[row = cout 4kk+r][col = cin n16] of tile (m, t, h) -> dW[16m + 4kk + r][16h + n16][t]
-  float* mine = a.part + ((size_t)blockIdx.x * 4 + wave) * (C32 * C32 * 3 + C32);
+  // D[row = cout 4kk+r][col = cin n16] of tile (m, t, h) -> dW[16m + 4kk + r][16h + n16][t].  The four waves (column
+  // quarters) meet in LDS in a fixed order; one partial row per workgroup goes to HBM.
+  constexpr int NW = C32 * C32 * 3;
+  __syncthreads();                    // the images are dead: reuse them as [4][NW + 32]
+  float* mine = wimg + (size_t)wave * (NW + C32);
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -237,7 +240,11 @@ __global__ __launch_bounds__(256) void wgrad32_mfma_kernel(const Wgrad32Args a) 
         for (int r = 0; r < 4; ++r) mine[((16 * m + 4 * kk + r) * C32 + 16 * h + n16) * 3 + t] = acc[m][t][h][r];
   // each wave holds the bias sums of its own 8 output channels (in lanes 0, 8, ..); the other 24 entries of its row are 0
   const float sv = __shfl(bacc, (lane & 7) * 8);
-  if (lane < C32) mine[C32 * C32 * 3 + lane] = ((lane >> 3) == wave) ? sv : 0.f;
+  if (lane < C32) mine[NW + lane] = ((lane >> 3) == wave) ? sv : 0.f;
+  __syncthreads();
+  float* dst = a.part + (size_t)blockIdx.x * (NW + C32);
+  for (int i = tid; i < NW + C32; i += 256)
+    dst[i] = (wimg[i] + wimg[(NW + C32) + i]) + (wimg[2 * (NW + C32) + i] + wimg[3 * (NW + C32) + i]);
 }
 
 // 64 outputs x 16 slices of the partial rows per workgroup; fixed summation order -> reproducible gradients
@@ -301,7 +308,7 @@ extern "C" int mural_op_conv32(const float* x, const float* W, const float* bias
 }
 
 // dW [32][32][3], db [32] of y = conv32(pre(x)); part: float scratch of at least mural_op_conv32_wgrad_scratch() floats
-extern "C" size_t mural_op_conv32_wgrad_scratch(void) { return (size_t)512 * 4 * (C32 * C32 * 3 + C32); }
+extern "C" size_t mural_op_conv32_wgrad_scratch(void) { return (size_t)512 * (C32 * C32 * 3 + C32); }
 
 extern "C" int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B, int32_t L, const float* pre_s, const float* pre_t,
                                      int32_t pre_relu, float* dW, float* db, float* part, size_t part_floats, void* stream_) {
@@ -316,8 +323,10 @@ extern "C" int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B,
   a.img_floats = (16 * a.nb + 2) * C32;
   const int64_t ntiles = (B + a.R - 1) / a.R;
   const int grid = (int)(ntiles < 512 ? ntiles : 512);
-  MURAL_REQUIRE(part && part_floats >= (size_t)grid * 4 * (C32 * C32 * 3 + C32), "conv32_wgrad: partial-sum scratch too small");
-  const size_t lds = (size_t)2 * a.img_floats * 4 + 2 * C32 * 4;
+  MURAL_REQUIRE(part && part_floats >= (size_t)grid * (C32 * C32 * 3 + C32), "conv32_wgrad: partial-sum scratch too small");
+  size_t lds = (size_t)2 * a.img_floats * 4 + 2 * C32 * 4;
+  const size_t lds_red = (size_t)4 * (C32 * C32 * 3 + C32) * 4;     // the in-workgroup reduction reuses the image space
+  lds = lds > lds_red ? lds : lds_red;
   static bool attr_set = false;
   if (!attr_set) {
     MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad32_mfma_kernel),
@@ -325,7 +334,7 @@ extern "C" int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B,
     attr_set = true;
   }
   hipLaunchKernelGGL(wgrad32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);
-  hipLaunchKernelGGL(part_reduce_kernel, dim3((C32 * C32 * 3 + C32 + 63) / 64), dim3(1024), 0, stream, part, grid * 4,
+  hipLaunchKernelGGL(part_reduce_kernel, dim3((C32 * C32 * 3 + C32 + 63) / 64), dim3(1024), 0, stream, part, grid,
                      C32 * C32 * 3, C32, dW, db);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;

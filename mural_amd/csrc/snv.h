@@ -75,6 +75,23 @@ struct Stage1Args {               // snv_stage1_kernel: window decode + first co
   float* x0;                      // [n][x0_cols][32] pooled first-layer activations (large columns, then mid)
 };
 
+// training-mode first layer of ONE tower (snv_stage1.hip: first_train_kernel)
+constexpr int FIRST_TRAIN_MAXGRID = 256;
+struct FirstTrainArgs {
+  Stage1Tower tw;
+  int Lwin, cw, wave_bytes;
+  int64_t B;
+  const uint8_t* sym;             // [B][Lwin] window symbols
+  const float* lutblk;            // forward: lut | taps | bias of this step's batch statistics
+  float* y;                       // forward: [B][32][L2]
+  uint8_t* arg;                   // [B][L2][32] window offset of the pooled maximum (written forward, read backward)
+  const float* dy;                // backward: [B][32][L2]
+  float* dpart;                   // backward: [grid][SNV_LUTBLK] per-workgroup gradient tables
+};
+int first_train_grid(int64_t B);
+bool first_train_supported(int C, int pk);
+int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream);
+
 struct SnvFwdArgs {
   TowerGeom geom[2];              // 0 = large, 1 = mid
   TowerDev tw[2];

@@ -185,6 +185,187 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
   }
 }
 
+// ------------------------------------------------------------------------------------------------ training mode
+// The same table formulation serves the training step (MuRaL/training.py:424-433 through model_snv.py:473-475,496-497
+// with BatchNorm1d(4) on batch statistics): the tables are rebuilt on the device every step (train_ops.hip,
+// first_tables_kernel), the forward keeps the window offset of every pooled maximum (one byte per output, channel-last)
+// and the backward scatters the pooled gradient into a gradient TABLE (d lut | d taps | d bias) that the caller folds back
+// into conv weight / BN(4) gradients.  Activations leave in the training layout [B][32][L2] (NCL).
+
+template <int SLOT>
+__device__ __forceinline__ void pooled_lookup_train(const Stage1Tower& g, int lane, const float* lutS, const uint8_t* cb0,
+                                                    const uint8_t* kw, float* __restrict__ y /* [32][L2] */,
+                                                    uint8_t* __restrict__ arg /* [L2][32] */) {
+  const float* tapS = lutS + SNV_LUT;
+  const float* b0S = tapS + SNV_TAPS;
+  const uint8_t* cb = cb0 + g.col0;
+  const int cg = lane & 7;
+  const int total = g.L2 * 8;
+  for (int task = lane; task < total; task += 64) {
+    const int j2 = task >> 3;
+    uint32_t d[SLOT / 4];
+    if (SLOT == 16) {
+      const uint4 q = *reinterpret_cast<const uint4*>(kw + (size_t)j2 * 16);
+      d[0] = q.x; d[1] = q.y; d[2] = q.z; d[SLOT / 4 - 1] = q.w;
+    } else {
+      d[0] = *reinterpret_cast<const uint32_t*>(kw + (size_t)j2 * 4);
+    }
+    uint32_t hi = d[SLOT / 4 - 1] & 0x00FFFFFFu;
+#pragma unroll
+    for (int r = 0; r + 1 < SLOT / 4; ++r) hi |= d[r];
+    const bool fast = ((hi & 0x80808080u) == 0u) && (g.pk == SLOT - 1);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    uint32_t am[4] = {0u, 0u, 0u, 0u};                 // first maximum wins, like MaxPool1d(return_indices)
+    if (fast) {
+#pragma unroll
+      for (int w = 0; w < SLOT - 1; ++w) {
+        const uint32_t idx = (d[w >> 2] >> (8 * (w & 3))) & 0xFFu;
+        const f32x4 v = s1_ld4(lutS + idx * 32u + 4u * cg);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool gt = v[q] > m[q];
+          m[q] = gt ? v[q] : m[q];
+          am[q] = gt ? (uint32_t)w : am[q];
+        }
+      }
+    } else {
+      const int jlo = j2 * g.ps - g.pp;
+      for (int w = 0; w < g.pk; ++w) {
+        const int j = jlo + w;
+        if (j < 0 || j >= g.L1) continue;
+        const uint32_t idx = kmer_index(cb, j, g.L1);
+        f32x4 v;
+        if (idx != 255u) {
+          v = s1_ld4(lutS + idx * 32u + 4u * cg);
+        } else {
+          const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
+          const uint32_t sc = cb[j + 1];
+          const uint32_t sr = (j == g.L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
+          v = s1_ld4(b0S + 4 * cg);
+          v += s1_ld4(tapS + (0 * N_SYM + sl) * 32 + 4 * cg);
+          v += s1_ld4(tapS + (1 * N_SYM + sc) * 32 + 4 * cg);
+          v += s1_ld4(tapS + (2 * N_SYM + sr) * 32 + 4 * cg);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool gt = v[q] > m[q];
+          m[q] = gt ? v[q] : m[q];
+          am[q] = gt ? (uint32_t)w : am[q];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) y[(size_t)(4 * cg + q) * g.L2 + j2] = m[q];
+    *reinterpret_cast<uint32_t*>(arg + (size_t)j2 * 32 + 4 * cg) = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
+  }
+}
+
+// gradient scatter: acc = workgroup-private (d lut | d taps | d bias) block in LDS
+template <int SLOT>
+__device__ __forceinline__ void pooled_scatter(const Stage1Tower& g, int lane, float* acc, const uint8_t* cb0,
+                                               const uint8_t* kw, const float* __restrict__ dy /* [32][L2] */,
+                                               const uint8_t* __restrict__ arg /* [L2][32] */) {
+  float* tapA = acc + SNV_LUT;
+  float* b0A = tapA + SNV_TAPS;
+  const uint8_t* cb = cb0 + g.col0;
+  const int cg = lane & 7;
+  const int total = g.L2 * 8;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int task = lane; task < total; task += 64) {
+    const int j2 = task >> 3;
+    const uint32_t aw = *reinterpret_cast<const uint32_t*>(arg + (size_t)j2 * 32 + 4 * cg);
+    const int jlo = j2 * g.ps - g.pp;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int c = 4 * cg + q;
+      const float gq = dy[(size_t)c * g.L2 + j2];
+      const int w = (int)((aw >> (8 * q)) & 0xFFu);
+      const uint32_t idx = kw[(size_t)j2 * SLOT + w];
+      bsum[q] += gq;
+      if (idx != 255u) {
+        atomicAdd(&acc[idx * 32u + c], gq);
+      } else {
+        const int j = jlo + w;
+        const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
+        const uint32_t sc = cb[j + 1];
+        const uint32_t sr = (j == g.L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
+        atomicAdd(&tapA[(0 * N_SYM + sl) * 32 + c], gq);
+        atomicAdd(&tapA[(1 * N_SYM + sc) * 32 + c], gq);
+        atomicAdd(&tapA[(2 * N_SYM + sr) * 32 + c], gq);
+      }
+    }
+  }
+  // the table entries contain the conv bias; its gradient is the plain sum of the pooled gradients.  Lanes with the same
+  // channel group (lane & 7) meet through shuffles before one LDS atomic per channel.
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v = bsum[q];
+    v += __shfl_xor(v, 8);
+    v += __shfl_xor(v, 16);
+    v += __shfl_xor(v, 32);
+    if (lane < 8) atomicAdd(&b0A[4 * cg + q], v);
+  }
+}
+
+template <int SLOT, bool BWD>
+__global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s1mem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* blk = s1mem;                         // forward: lut | taps | bias; backward: their gradient accumulators
+  uint8_t* cb = reinterpret_cast<uint8_t*>(s1mem + SNV_LUTBLK) + (size_t)wave * a.wave_bytes;
+  uint8_t* kw = cb + a.cw;
+  for (int i = tid * 4; i < SNV_LUTBLK; i += S1_THREADS * 4)
+    *reinterpret_cast<f32x4*>(blk + i) = BWD ? f32x4{0.f, 0.f, 0.f, 0.f} : s1_ld4(a.lutblk + i);
+  __syncthreads();
+  const Stage1Tower g = a.tw;
+  const int Lwin = a.Lwin;
+  for (int64_t row = (int64_t)blockIdx.x * S1_WAVES + wave; row < a.B; row += (int64_t)gridDim.x * S1_WAVES) {
+    const uint8_t* src = a.sym + row * Lwin;
+    for (int jj = lane; jj < Lwin + 2; jj += 64) {
+      const int j = jj - 1;
+      cb[jj] = (j >= 0 && j < Lwin) ? src[j] : (uint8_t)SYM_PAD;
+    }
+    wave_lds_fence();
+    build_kwin<SLOT>(g, lane, cb, kw);
+    wave_lds_fence();
+    const size_t o = (size_t)row * 32 * g.L2;
+    if (BWD) pooled_scatter<SLOT>(g, lane, blk, cb, kw, a.dy + o, a.arg + o);
+    else pooled_lookup_train<SLOT>(g, lane, blk, cb, kw, a.y + o, a.arg + o);
+    wave_lds_fence();
+  }
+  if (BWD) {                                  // one partial block per workgroup; first_grad_fold_kernel sums them in order
+    __syncthreads();
+    float* dst = a.dpart + (size_t)blockIdx.x * SNV_LUTBLK;
+    for (int i = tid * 4; i < SNV_LUTBLK; i += S1_THREADS * 4) *reinterpret_cast<f32x4*>(dst + i) = s1_ld4(blk + i);
+  }
+}
+
+int first_train_grid(int64_t B) {
+  const int64_t want = (B + S1_WAVES - 1) / S1_WAVES;
+  return (int)(want < 1 ? 1 : (want < FIRST_TRAIN_MAXGRID ? want : FIRST_TRAIN_MAXGRID));
+}
+
+bool first_train_supported(int C, int pk) { return C == SNV_C && pk >= 1 && pk <= 15; }
+
+int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
+  if (a.B == 0) return MURAL_OK;
+  MURAL_REQUIRE(first_train_supported(SNV_C, a.tw.pk), "first layer: pool window %d not supported by the table kernel", a.tw.pk);
+  const int slot = a.tw.pk <= 3 ? 4 : 16;
+  a.cw = (a.Lwin + 2 + 15) & ~15;
+  a.wave_bytes = a.cw + ((a.tw.L2 * slot + 15) & ~15);
+  const size_t lds = (size_t)SNV_LUTBLK * 4 + (size_t)S1_WAVES * a.wave_bytes;
+  MURAL_REQUIRE(lds <= 160 * 1024, "first layer: window of %d columns does not fit the LDS working set", a.Lwin);
+  using KernelFn = void (*)(const FirstTrainArgs);
+  KernelFn fn = slot == 4 ? (bwd ? first_train_kernel<4, true> : first_train_kernel<4, false>)
+                          : (bwd ? first_train_kernel<16, true> : first_train_kernel<16, false>);
+  MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(fn, dim3(first_train_grid(a.B)), dim3(S1_THREADS), lds, stream, a);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream) {
   if (a.n == 0) return MURAL_OK;
   static bool attr_set = false;

@@ -306,12 +306,17 @@ __constant__ float kSymFrac[15][4] = {
     {.5f, 0, .5f, 0}, {0, .5f, 0, .5f}, {.5f, .5f, 0, 0}, {0, .5f, .5f, 0}, {.5f, 0, 0, .5f}, {0, 0, .5f, .5f},
     {0, 1.f / 3, 1.f / 3, 1.f / 3}, {1.f / 3, 0, 1.f / 3, 1.f / 3}, {1.f / 3, 1.f / 3, 0, 1.f / 3}, {1.f / 3, 1.f / 3, 1.f / 3, 0}};
 
+__host__ __device__ __forceinline__ int first_tab_floats(int C) { return 3 * N_SYM * C + 2 * N_SYM * 4 + 8; }
+__host__ __device__ __forceinline__ float* first_lutblk(float* tab, int C) { return tab + first_tab_floats(C); }
+
 // batch statistics of the one-hot tensor from the histogram -> BN output per (symbol, channel), per-tap tables
-// tab: [0..3*16*C) taps[t][sym][co] | bnval[16][4] | xhat[16][4] | mean[4] | invstd[4]
+// tab: [0..3*16*C) taps[t][sym][co] | bnval[16][4] | xhat[16][4] | mean[4] | invstd[4] | (with_lut: lut | taps | bias block
+// in the layout of the prediction path's stage-1 tables, snv.h SNV_LUTBLK)
 __global__ void first_tables_kernel(const unsigned long long* __restrict__ counts, int C, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ W /*[C][4][3]*/, float eps,
-                                    float momentum, float* __restrict__ running_mean, float* __restrict__ running_var,
-                                    float* __restrict__ tab) {
+                                    const float* __restrict__ beta, const float* __restrict__ W /*[C][4][3]*/,
+                                    const float* __restrict__ bias, float eps, float momentum,
+                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                    float* __restrict__ tab, int with_lut) {
   __shared__ float bnv[N_SYM][4], xh[N_SYM][4];
   const int tid = threadIdx.x;
   float* taps = tab;
@@ -354,6 +359,16 @@ __global__ void first_tables_kernel(const unsigned long long* __restrict__ count
     for (int ci = 0; ci < 4; ++ci) acc = fmaf(W[(co * 4 + ci) * 3 + t], bnv[sym][ci], acc);
     taps[i] = acc;
   }
+  if (!with_lut) return;
+  __syncthreads();                       // taps[] (global) written by this workgroup are visible to it
+  float* blk = first_lutblk(tab, C);
+  for (int i = tid; i < 125 * C; i += blockDim.x) {
+    const int e = i / C, co = i - e * C, l = e / 25, m = (e / 5) % 5, r = e % 5;
+    // same association as the per-tap path of the lookup kernels: ((bias + left) + centre) + right
+    blk[i] = ((bias[co] + taps[(0 * N_SYM + l) * C + co]) + taps[(1 * N_SYM + m) * C + co]) + taps[(2 * N_SYM + r) * C + co];
+  }
+  for (int i = tid; i < 3 * N_SYM * C; i += blockDim.x) blk[125 * C + i] = taps[i];
+  for (int i = tid; i < C; i += blockDim.x) blk[125 * C + 3 * N_SYM * C + i] = bias[i];
 }
 
 // conv1 (via per-tap tables) + maxpool1 with argmax: one thread per (b, co, pooled column)
@@ -414,31 +429,75 @@ __global__ __launch_bounds__(256) void first_pool_bwd_kernel(const float* __rest
     if (sd[ntab + i] != 0.f) atomicAdd(&dbias[i], sd[ntab + i]);
 }
 
-// dW[co][ci][t] = sum_sym dTap[t][sym][co] * bnval[sym][ci];  dgamma / dbeta of the BN(4) through the BN outputs
-__global__ void first_param_grad_kernel(const float* __restrict__ dtap, const float* __restrict__ tab, int C,
-                                        const float* __restrict__ W, float* __restrict__ dW, float* __restrict__ dgamma,
-                                        float* __restrict__ dbeta) {
+// ordered sum of the per-workgroup gradient tables of first_train_kernel<.., true>
+__global__ __launch_bounds__(256) void first_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
+                                                                float* __restrict__ red) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  int b = 0;
+  for (; b + 4 <= nblk; b += 4) {
+    a0 += part[(size_t)(b + 0) * n + i];
+    a1 += part[(size_t)(b + 1) * n + i];
+    a2 += part[(size_t)(b + 2) * n + i];
+    a3 += part[(size_t)(b + 3) * n + i];
+  }
+  for (; b < nblk; ++b) a0 += part[(size_t)b * n + i];
+  red[i] = (a0 + a1) + (a2 + a3);
+}
+
+// dW[co][ci][t] = sum_sym dTap[t][sym][co] * bnval[sym][ci];  dgamma / dbeta of the BN(4) through the BN outputs.
+// dlut (optional, [125][C] + taps [3][16][C] + bias [C] as one block): gradient of the 3-mer table of the lookup kernels,
+// folded into the per-tap gradients first (lut[l,m,r] = bias + tap0[l] + tap1[m] + tap2[r]); dbias is then written too.
+__global__ __launch_bounds__(256) void first_param_grad_kernel(const float* __restrict__ dtap, const float* __restrict__ dlutblk,
+                                                               const float* __restrict__ tab, int C,
+                                                               const float* __restrict__ W, float* __restrict__ dW,
+                                                               float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                               float* __restrict__ dbias) {
+  extern __shared__ float sg[];          // dtap [3][16][C] | dbn [16][4]
+  float* sdt = sg;
+  float* sdbn = sg + 3 * N_SYM * C;
   const float* bnval = tab + 3 * N_SYM * C;
   const float* xhat = bnval + N_SYM * 4;
   const int tid = threadIdx.x;
+  for (int i = tid; i < 3 * N_SYM * C; i += blockDim.x) {
+    float acc = dlutblk ? dlutblk[125 * C + i] : dtap[i];
+    if (dlutblk) {
+      const int t = i / (N_SYM * C), r = i - t * N_SYM * C, sym = r / C, co = r - sym * C;
+      if (sym < 5) {
+        for (int u = 0; u < 25; ++u) {     // the 25 table entries whose tap-t symbol is `sym`
+          const int e = t == 0 ? 25 * sym + u : (t == 1 ? 25 * (u / 5) + 5 * sym + (u % 5) : 5 * u + sym);
+          acc += dlutblk[e * C + co];
+        }
+      }
+    }
+    sdt[i] = acc;
+  }
+  if (dlutblk)
+    for (int i = tid; i < C; i += blockDim.x) dbias[i] = dlutblk[125 * C + 3 * N_SYM * C + i];
+  __syncthreads();
   for (int i = tid; i < C * 4 * 3; i += blockDim.x) {
     const int co = i / 12, r = i - co * 12, ci = r / 3, t = r - ci * 3;
     float acc = 0.f;
-    for (int sym = 0; sym < 15; ++sym) acc = fmaf(dtap[(t * N_SYM + sym) * C + co], bnval[sym * 4 + ci], acc);
+    for (int sym = 0; sym < 15; ++sym) acc = fmaf(sdt[(t * N_SYM + sym) * C + co], bnval[sym * 4 + ci], acc);
     dW[i] = acc;
   }
+  for (int i = tid; i < 15 * 4; i += blockDim.x) {   // gradient w.r.t. the BN output of (sym, ci)
+    const int sym = i / 4, ci = i - sym * 4;
+    float dbn = 0.f;
+    for (int t = 0; t < 3; ++t)
+      for (int co = 0; co < C; ++co) dbn = fmaf(sdt[(t * N_SYM + sym) * C + co], W[(co * 4 + ci) * 3 + t], dbn);
+    sdbn[i] = dbn;
+  }
+  __syncthreads();
   if (tid < 4) {
-    const int ci = tid;
     float dg = 0.f, dbt = 0.f;
     for (int sym = 0; sym < 15; ++sym) {
-      float dbn = 0.f;   // gradient w.r.t. the BN output of (sym, ci)
-      for (int t = 0; t < 3; ++t)
-        for (int co = 0; co < C; ++co) dbn = fmaf(dtap[(t * N_SYM + sym) * C + co], W[(co * 4 + ci) * 3 + t], dbn);
-      dg = fmaf(dbn, xhat[sym * 4 + ci], dg);
-      dbt += dbn;
+      dg = fmaf(sdbn[sym * 4 + tid], xhat[sym * 4 + tid], dg);
+      dbt += sdbn[sym * 4 + tid];
     }
-    dgamma[ci] = dg;
-    dbeta[ci] = dbt;
+    dgamma[tid] = dg;
+    dbeta[tid] = dbt;
   }
 }
 
@@ -480,6 +539,114 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
     if (k < I) atomicAdd(&dW[(size_t)o * I + k], acc);
     else if (db) atomicAdd(&db[o], acc);
   }
+}
+
+// Tiled dense layer: y[b][n] = bias[n] + sum_k x[b][k] * Wm(k, n) for 64 rows per workgroup.  The weight matrix is staged
+// in LDS as [k][N8] (any source strides: forward reads W[o][i] with n = o, the input gradient reads it with n = i), the
+// x tile as [64][K|1]; a lane owns one row and 8 outputs at a time, weights arrive as LDS broadcasts.
+__global__ __launch_bounds__(256) void linear_tile_kernel(const float* __restrict__ x, const float* __restrict__ W, int w_sn,
+                                                          int w_sk, const float* __restrict__ bias, int64_t B, int K, int N,
+                                                          float* __restrict__ y) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  const int N8 = (N + 7) & ~7, Kp = K | 1;
+  float* ws = lsm;                 // [K][N8]
+  float* xs = lsm + K * N8;        // [64][Kp]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t b0 = (int64_t)blockIdx.x * 64;
+  const bool k_fast = w_sk == 1;   // source contiguous along k (forward) or along n (input gradient)
+  for (int i = tid; i < K * N8; i += 256) {
+    int k, n;
+    if (k_fast) { n = i / K; k = i - n * K; } else { k = i / N8; n = i - k * N8; }
+    ws[k * N8 + n] = n < N ? W[(size_t)n * w_sn + (size_t)k * w_sk] : 0.f;   // padded output columns: 0
+  }
+  const int rows = (int)((B - b0) < 64 ? (B - b0) : 64);
+  for (int i = tid; i < rows * K; i += 256) {
+    const int r = i / K, k = i - r * K;
+    xs[r * Kp + k] = x[(size_t)b0 * K + i];
+  }
+  __syncthreads();
+  if (lane >= rows) return;
+  const float* xr = xs + lane * Kp;
+  for (int g = wave; g < N8 / 8; g += 4) {
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = (bias && 8 * g + c < N) ? bias[8 * g + c] : 0.f;
+    const float* wg = ws + 8 * g;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+      const float xv = xr[k];
+      const float4 w0 = *reinterpret_cast<const float4*>(wg + k * N8), w1 = *reinterpret_cast<const float4*>(wg + k * N8 + 4);
+      acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]); acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
+      acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]); acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
+    }
+    float* yr = y + (size_t)(b0 + lane) * N + 8 * g;
+#pragma unroll
+    for (int c = 0; c < 8; ++c)
+      if (8 * g + c < N) yr[c] = acc[c];
+  }
+}
+
+// dW[o][i] += sum_{b in 64-row chunk} dy[b][o] x[b][i]; db[o] likewise: both chunks staged in LDS, a thread owns an
+// 8 x 8 block of (o, i); chunks meet through hardware float atomics (dW / db zeroed by the caller)
+__global__ __launch_bounds__(256) void linear_wgrad_tile_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                int64_t B, int I, int O, int rows_per_wg,
+                                                                float* __restrict__ dW, float* __restrict__ db) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  const int O8 = (O + 7) & ~7, I8 = (I + 7) & ~7;
+  float* gs = lsm;                 // [64][O8]
+  float* xs = lsm + 64 * O8;       // [64][I8]
+  const int tid = threadIdx.x;
+  const int nbi = I8 / 8, nblk = (O8 / 8) * nbi;
+  const int ob = tid / nbi, ib = tid - ob * nbi;
+  float acc[8][8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u)
+#pragma unroll
+    for (int v = 0; v < 8; ++v) acc[u][v] = 0.f;
+  float bsum = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+  const int64_t r1 = r0 + rows_per_wg < B ? r0 + rows_per_wg : B;
+  for (int64_t b0 = r0; b0 < r1; b0 += 64) {
+    const int rows = (int)((r1 - b0) < 64 ? (r1 - b0) : 64);
+    __syncthreads();
+    for (int i = tid; i < 64 * O8; i += 256) {
+      const int r = i / O8, o = i - r * O8;
+      gs[i] = (r < rows && o < O) ? dy[(size_t)(b0 + r) * O + o] : 0.f;
+    }
+    for (int i = tid; i < 64 * I8; i += 256) {
+      const int r = i / I8, k = i - r * I8;
+      xs[i] = (r < rows && k < I) ? x[(size_t)(b0 + r) * I + k] : 0.f;
+    }
+    __syncthreads();
+    if (tid < nblk) {
+      for (int r = 0; r < 64; ++r) {
+        const float4 g0 = *reinterpret_cast<const float4*>(gs + r * O8 + 8 * ob), g1 = *reinterpret_cast<const float4*>(gs + r * O8 + 8 * ob + 4);
+        const float4 x0 = *reinterpret_cast<const float4*>(xs + r * I8 + 8 * ib), x1 = *reinterpret_cast<const float4*>(xs + r * I8 + 8 * ib + 4);
+        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+          for (int v = 0; v < 8; ++v) acc[u][v] = fmaf(gv[u], xv[v], acc[u][v]);
+      }
+    }
+    if (db && tid < O) {
+      float sacc = 0.f;
+      for (int r = 0; r < 64; ++r) sacc += gs[r * O8 + tid];
+      bsum += sacc;
+    }
+  }
+  if (tid < nblk) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+#pragma unroll
+      for (int v = 0; v < 8; ++v) {
+        const int o = 8 * ob + u, i = 8 * ib + v;
+        if (o < O && i < I) unsafeAtomicAdd(&dW[(size_t)o * I + i], acc[u][v]);
+      }
+  }
+  if (db && tid < O) unsafeAtomicAdd(&db[tid], bsum);
 }
 
 __global__ void embedding_fwd_kernel(const int64_t* __restrict__ cat, const float* __restrict__ E, int64_t B, int cols, int rows,
@@ -691,35 +858,97 @@ extern "C" int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t
   CHECK_LAUNCH();
 }
 
-// first layer of a tower in training mode.  counts: uint64[16] zeroed by the caller; tab: float[3*16*C + 16*4*2 + 8]
+// first layer of a tower in training mode: sizes of the caller-allocated buffers for (C, pool window).  The 3-mer table
+// kernels (snv_stage1.hip) serve C == 32 and windows up to 15; everything else takes the generic per-tap kernels.
+extern "C" int mural_op_first_plan(int32_t C, int32_t pk, int64_t* tab_floats, int64_t* arg_bytes, int64_t* scratch_floats) {
+  const bool fast = first_train_supported(C, pk);
+  *tab_floats = first_tab_floats(C) + (fast ? SNV_LUTBLK : 0);
+  *arg_bytes = fast ? 1 : 4;                       // per pooled output: window offset (uint8, [B][L2][C]) or column (int32, [B][C][L2])
+  *scratch_floats = fast ? (int64_t)(FIRST_TRAIN_MAXGRID + 1) * SNV_LUTBLK : 3 * N_SYM * C;
+  return MURAL_OK;
+}
+
+// counts: uint64[16] zeroed by the caller; tab / arg sized by mural_op_first_plan
 extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
                                   int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
                                   const float* bias, float eps, float momentum, float* running_mean, float* running_var,
-                                  unsigned long long* counts, float* tab, float* y, int32_t* arg, void* stream) {
+                                  unsigned long long* counts, float* tab, float* y, void* arg, void* stream) {
   const int L2 = (L1 + 2 * pp - pk) / ps + 1;
+  const bool fast = first_train_supported(C, pk);
   hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(B * L1, 256, 2048)), dim3(256), 0, STREAM, sym, B, Lwin, col0, L1, counts);
-  hipLaunchKernelGGL(first_tables_kernel, dim3(1), dim3(256), 0, STREAM, counts, C, gamma, beta, W, eps, momentum, running_mean,
-                     running_var, tab);
+  hipLaunchKernelGGL(first_tables_kernel, dim3(1), dim3(256), 0, STREAM, counts, C, gamma, beta, W, bias, eps, momentum,
+                     running_mean, running_var, tab, fast ? 1 : 0);
+  if (fast) {
+    FirstTrainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.tw = Stage1Tower{L1, col0, L2, pk, ps, pp};
+    a.Lwin = Lwin; a.B = B; a.sym = sym; a.lutblk = first_lutblk(tab, C); a.y = y; a.arg = static_cast<uint8_t*>(arg);
+    return launch_first_train(a, false, STREAM);
+  }
   const int64_t total = B * C * L2;
   hipLaunchKernelGGL(first_pool_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), (size_t)3 * N_SYM * C * 4, STREAM, sym,
-                     B, Lwin, col0, L1, C, L2, pk, ps, pp, tab, bias, y, arg);
+                     B, Lwin, col0, L1, C, L2, pk, ps, pp, tab, bias, y, static_cast<int32_t*>(arg));
   CHECK_LAUNCH();
 }
 
-// dtap: float[3*16*C] and dbias[C] zeroed by the caller; writes dW [C][4][3], dgamma[4], dbeta[4]
-extern "C" int mural_op_first_bwd(const float* dy, const int32_t* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
-                                  int32_t col0, int32_t L1, int32_t C, int32_t L2, const float* tab, const float* W,
-                                  float* dtap, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream) {
+// scratch sized by mural_op_first_plan (contents undefined on entry); writes dW [C][4][3], dbias[C], dgamma[4], dbeta[4]
+extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
+                                  int32_t col0, int32_t L1, int32_t C, int32_t pk, int32_t ps, int32_t pp, const float* tab,
+                                  const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
+                                  void* stream) {
+  const int L2 = (L1 + 2 * pp - pk) / ps + 1;
+  const size_t lds = (size_t)(3 * N_SYM * C + N_SYM * 4) * 4;
+  if (first_train_supported(C, pk)) {
+    FirstTrainArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.tw = Stage1Tower{L1, col0, L2, pk, ps, pp};
+    a.Lwin = Lwin; a.B = B; a.sym = sym; a.dy = dy; a.arg = const_cast<uint8_t*>(static_cast<const uint8_t*>(arg));
+    a.dpart = scratch;
+    const int nblk = first_train_grid(B);
+    float* red = scratch + (size_t)FIRST_TRAIN_MAXGRID * SNV_LUTBLK;
+    if (int rc = launch_first_train(a, true, STREAM)) return rc;
+    hipLaunchKernelGGL(first_part_reduce_kernel, dim3((SNV_LUTBLK + 255) / 256), dim3(256), 0, STREAM, scratch, B ? nblk : 0,
+                       SNV_LUTBLK, red);
+    hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), lds, STREAM, nullptr, red, tab, C, W, dW, dgamma, dbeta,
+                       dbias);
+    CHECK_LAUNCH();
+  }
+  float* dtap = scratch;
+  MURAL_HIP_CHECK(hipMemsetAsync(dtap, 0, (size_t)3 * N_SYM * C * 4, STREAM));
+  MURAL_HIP_CHECK(hipMemsetAsync(dbias, 0, (size_t)C * 4, STREAM));
   const int64_t total = B * C * L2;
   hipLaunchKernelGGL(first_pool_bwd_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), (size_t)(3 * N_SYM * C + C) * 4, STREAM,
-                     dy, arg, sym, B, Lwin, col0, L1, C, L2, dtap, dbias);
-  hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), 0, STREAM, dtap, tab, C, W, dW, dgamma, dbeta);
+                     dy, static_cast<const int32_t*>(arg), sym, B, Lwin, col0, L1, C, L2, dtap, dbias);
+  hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), lds, STREAM, dtap, nullptr, tab, C, W, dW, dgamma, dbeta,
+                     dbias);
   CHECK_LAUNCH();
+}
+
+static bool linear_tile_fits(int K, int N, size_t* lds) {
+  *lds = ((size_t)K * ((N + 7) & ~7) + (size_t)64 * (K | 1)) * sizeof(float);
+  return *lds <= 150 * 1024;
+}
+
+static int launch_linear_tile(const float* x, const float* W, int w_sn, int w_sk, const float* bias, int64_t B, int K, int N,
+                              float* y, size_t lds, hipStream_t stream) {
+  if (lds > 64 * 1024) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+  }
+  hipLaunchKernelGGL(linear_tile_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), lds, stream, x, W, w_sn, w_sk, bias, B, K, N, y);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
 }
 
 extern "C" int mural_op_linear_fwd(const float* x, const float* W, const float* b, int64_t B, int32_t I, int32_t O, float* y,
                                    void* stream) {
   if (B == 0) return MURAL_OK;
+  size_t lds;
+  if (linear_tile_fits(I, O, &lds)) return launch_linear_tile(x, W, I, 1, b, B, I, O, y, lds, STREAM);   // Wm(k, n) = W[n][k]
   hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((B * O + 255) / 256)), dim3(256), 0, STREAM, x, W, b, B, I, O, y);
   CHECK_LAUNCH();
 }
@@ -727,7 +956,27 @@ extern "C" int mural_op_linear_fwd(const float* x, const float* W, const float* 
 extern "C" int mural_op_linear_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t I, int32_t O, float* dx,
                                    float* dW, float* db, void* stream) {
   if (B == 0) return MURAL_OK;
-  if (dx) hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((B * I + 255) / 256)), dim3(256), 0, STREAM, dy, W, B, I, O, dx);
+  size_t lds;
+  if (dx) {
+    if (linear_tile_fits(O, I, &lds)) {                            // dx[b][i] = sum_o dy[b][o] W[o][i]: Wm(k = o, n = i)
+      if (int rc = launch_linear_tile(dy, W, 1, I, nullptr, B, O, I, dx, lds, STREAM)) return rc;
+    } else {
+      hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((B * I + 255) / 256)), dim3(256), 0, STREAM, dy, W, B, I, O, dx);
+    }
+  }
+  const int O8 = (O + 7) & ~7, I8 = (I + 7) & ~7;
+  if ((O8 / 8) * (I8 / 8) <= 256 && O <= 256) {
+    const size_t wl = (size_t)64 * (O8 + I8) * sizeof(float);
+    int64_t wgs = (B + 63) / 64;
+    wgs = wgs > 256 ? 256 : wgs;
+    const int rows_per_wg = (int)(((B + wgs - 1) / wgs + 63) / 64 * 64);
+    wgs = (B + rows_per_wg - 1) / rows_per_wg;
+    if (wl > 64 * 1024)
+      MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_tile_kernel),
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(linear_wgrad_tile_kernel, dim3((unsigned)wgs), dim3(256), wl, STREAM, dy, x, B, I, O, rows_per_wg, dW, db);
+    CHECK_LAUNCH();
+  }
   int chunks = (int)(B / 128);
   chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
   hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(O, chunks), dim3(256), 0, STREAM, dy, x, B, I, O, dW, db);

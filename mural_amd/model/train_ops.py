@@ -164,8 +164,17 @@ class MaxPool(torch.autograd.Function):
         return dx, None, None, None
 
 
+def _first_plan(Cn, pk):
+    """(tab floats, arg bytes per pooled output, backward scratch floats) of the first-layer kernels for this shape."""
+    import ctypes as C
+    t, a, s = C.c_int64(0), C.c_int64(0), C.c_int64(0)
+    _lib.check(_lib.lib().mural_op_first_plan(Cn, pk, C.byref(t), C.byref(a), C.byref(s)))
+    return t.value, a.value, s.value
+
+
 class FirstLayerPool(torch.autograd.Function):
-    """maxpool1(Conv1d(BN(one-hot))) of one tower from window symbols: per-tap symbol tables, arg-max saved."""
+    """maxpool1(Conv1d(BN(one-hot))) of one tower from window symbols: 3-mer / per-tap symbol tables rebuilt from the batch
+    statistics of this step, arg-max saved (one byte per pooled output on the table path)."""
 
     @staticmethod
     def forward(ctx, sym, gamma, beta, weight, bias, bn, col0, L1, pool):
@@ -174,32 +183,33 @@ class FirstLayerPool(torch.autograd.Function):
         pk, ps, pp = pool
         L2 = (L1 + 2 * pp - pk) // ps + 1
         dev = sym.device
+        tab_floats, arg_bytes, _ = _first_plan(Cn, pk)
         counts = torch.zeros(16, dtype=torch.int64, device=dev)
-        tab = torch.empty(3 * 16 * Cn + 16 * 4 * 2 + 8, device=dev)
+        tab = torch.empty(tab_floats, device=dev)
         y = torch.empty((B, Cn, L2), device=dev)
-        arg = torch.empty((B, Cn, L2), dtype=torch.int32, device=dev)
+        arg = torch.empty(B * Cn * L2 * arg_bytes, dtype=torch.uint8, device=dev)
         _call("mural_op_first_fwd", sym, B, Lwin, col0, L1, Cn, pk, ps, pp, _f32(gamma), _f32(beta), _f32(weight), _f32(bias),
               EPS, MOMENTUM, bn.running_mean, bn.running_var, counts, tab, y, arg, _stream(sym))
         with torch.no_grad():
             bn.num_batches_tracked += 1
         ctx.save_for_backward(sym, arg, tab, weight)
-        ctx.dims = (col0, L1, L2)
+        ctx.dims = (col0, L1, pool)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         sym, arg, tab, weight = ctx.saved_tensors
-        col0, L1, L2 = ctx.dims
+        col0, L1, (pk, ps, pp) = ctx.dims
         B, Lwin = sym.shape
         Cn = weight.shape[0]
         dev = sym.device
-        dtap = torch.zeros(3 * 16 * Cn, device=dev)
+        scratch = torch.empty(_first_plan(Cn, pk)[2], device=dev)
         dW = torch.empty_like(weight)
-        db = torch.zeros(Cn, device=dev)
+        db = torch.empty(Cn, device=dev)
         dgamma = torch.empty(4, device=dev)
         dbeta = torch.empty(4, device=dev)
-        _call("mural_op_first_bwd", dy.contiguous(), arg, sym, B, Lwin, col0, L1, Cn, L2, tab, _f32(weight), dtap, dW, db, dgamma,
-              dbeta, _stream(sym))
+        _call("mural_op_first_bwd", dy.contiguous(), arg, sym, B, Lwin, col0, L1, Cn, pk, ps, pp, tab, _f32(weight), scratch, dW,
+              db, dgamma, dbeta, _stream(sym))
         return None, dgamma, dbeta, dW, db, None, None, None, None
 
 
