@@ -191,16 +191,20 @@ int mural_op_bn_apply(const float* x, int64_t B, int32_t C, int32_t L, int32_t r
                       const float* shift, float* y, void* stream);
 int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, int32_t L, int32_t relu,
                          const float* mean, const float* invstd, const float* gamma, double* s1, double* s2,
-                         float* dx, float* dgamma, float* dbeta, void* stream);
+                         int32_t have_sums, const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta,
+                         void* stream);
 int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, int32_t L, int32_t K,
                         const float* scale, const float* shift, int32_t pre_relu, float* dW, float* db,
                         float* part, size_t part_floats, void* stream);
 /* fp32-MFMA path of the 32->32 k=3 convs on [B][32][L] tensors (L + 2 <= 288): forward / input gradient and weight +
- * bias gradient.  W: PyTorch [32][32][3]; wfrag: float[3072] scratch; part: mural_op_conv32_wgrad_scratch() floats.    */
+ * bias gradient.  W: PyTorch [32][32][3]; part: mural_op_conv32_wgrad_scratch() floats.  stat_mode 1 / 2: the epilogue
+ * also accumulates per-channel sums of the output into stat_out (double[2][32], zeroed by the caller): 1 = sum / sum of
+ * squares of act(y) (batch statistics for the next BatchNorm), 2 = sum(y), sum(y * xhat(stat_x)) (BatchNorm backward).  */
 int mural_op_conv32_supported(int32_t L);
 int mural_op_conv32(const float* x, const float* W, const float* bias, float* y, int64_t B, int32_t L, int32_t dgrad,
                     const float* pre_s, const float* pre_t, int32_t pre_relu, int32_t post_relu, const float* res1,
-                    const float* res2, float* wfrag, void* stream);
+                    const float* res2, int32_t stat_mode, int32_t stat_relu, const float* stat_x, const float* stat_mean,
+                    const float* stat_invstd, double* stat_out, void* stream);
 size_t mural_op_conv32_wgrad_scratch(void);
 int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B, int32_t L, const float* pre_s, const float* pre_t,
                           int32_t pre_relu, float* dW, float* db, float* part, size_t part_floats, void* stream);

@@ -22,7 +22,16 @@ constexpr int C32_MAXCOLS = 16 * 2 * C32_NB2MAX;
 struct Conv32Args {
   const float* x;        // [B][32][L]
   float* y;              // [B][32][L]
-  const float* wfrag;    // [2][24][64] MFMA A fragments
+  const float* W;        // PyTorch [32][32][3]; dgrad: use the transposed, tap-flipped filter
+  int dgrad;
+  // per-channel sums taken in the epilogue (the producer of a tensor knows its values: no extra pass over HBM)
+  int stat_mode;         // 0 none | 1: sum, sum of squares of act(y) (batch statistics of the NEXT BatchNorm)
+                         //        | 2: sum(y), sum(y * xhat), xhat = (act(stat_x) - mean) * invstd (BatchNorm backward of y = dz)
+  int stat_relu;         // act = relu
+  const float* stat_x;   // mode 2: [B][32][L]
+  const float* stat_mean;
+  const float* stat_invstd;
+  double* stat_out;      // [2][32], accumulated with atomics (zeroed by the caller)
   const float* bias;     // [32] or nullptr
   const float* pre_s;    // [32] or nullptr: x' = pre_s * act(x) + pre_t, act = relu if pre_relu
   const float* pre_t;
@@ -32,17 +41,6 @@ struct Conv32Args {
   int B, L, R, Sc, NC, nb;
   FastDiv dSc, dL;
 };
-
-// W[co][ci][k] (PyTorch) -> A fragments [mblock][kstep][lane]; dgrad: the transposed, tap-flipped filter
-__global__ void wfrag_kernel(const float* __restrict__ W, float* __restrict__ wfrag, int dgrad) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= 2 * C32_KSTEPS * 64) return;
-  const int lane = i & 63, s = (i >> 6) % C32_KSTEPS, mb = i / (64 * C32_KSTEPS);
-  const int t = s / 8, h = (s % 8) / 4, q = s % 4;
-  const int cin = 16 * h + 4 * (lane >> 4) + q;      // channel of the tensor being convolved
-  const int cout = 16 * mb + (lane & 15);            // channel of the tensor being produced
-  wfrag[i] = dgrad ? W[(cin * C32 + cout) * 3 + (2 - t)] : W[(cout * C32 + cin) * 3 + t];
-}
 
 // stage R rows of x (contiguous in memory) into the LDS image, applying the BN(+ReLU) affine; separators / tail = 0.
 // `aff` is an LDS copy of pre_s | pre_t (64 floats) or nullptr.
@@ -80,19 +78,23 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t 
   }
 }
 
-__global__ __launch_bounds__(256) void conv32_mfma_kernel(const Conv32Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv32_mfma_kernel(const Conv32Args a) {
   extern __shared__ __attribute__((aligned(16))) float img[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mb = wave & 1, cgp = wave >> 1;
   const int n16 = lane & 15, kk = lane >> 4;
-  float af[C32_KSTEPS];
-  {
-    const float* wf = a.wfrag + (size_t)mb * C32_KSTEPS * 64 + lane;
+  float af[C32_KSTEPS];   // A fragments: k-step s = 8 tap + 4 half + q holds W[cout = 16 mb + n16][cin = 16 half + 4 kk + q][tap]
 #pragma unroll
-    for (int s = 0; s < C32_KSTEPS; ++s) af[s] = wf[s * 64];
+  for (int s = 0; s < C32_KSTEPS; ++s) {
+    const int t = s / 8, h = (s % 8) / 4, q = s % 4;
+    const int cin = 16 * h + 4 * kk + q;               // channel of the tensor being convolved
+    const int cout = 16 * mb + n16;                    // channel of the tensor being produced
+    af[s] = a.dgrad ? a.W[(cin * C32 + cout) * 3 + (2 - t)] : a.W[(cout * C32 + cin) * 3 + t];
   }
   const int chv = 16 * mb + 4 * kk;
+  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
+
   const f32x4 bias = a.bias ? ld4(a.bias + chv) : splat(0.f);
   // per-lane LDS byte offsets of block 0 of this wave (block i: + 4096 i)
   uint32_t rd[6];
@@ -105,13 +107,15 @@ __global__ __launch_bounds__(256) void conv32_mfma_kernel(const Conv32Args a) {
   const char* in = reinterpret_cast<const char*>(img);
   float* aff = img + (16 * a.nb + 2) * C32;              // pre_s | pre_t
   if (a.pre_s && tid < 2 * C32) aff[tid] = tid < C32 ? a.pre_s[tid] : a.pre_t[tid - C32];
+  const float* sms = aff + 2 * C32;                      // stat_mean | stat_invstd (mode 2)
+  if (a.stat_mode == 2 && tid < 2 * C32) aff[2 * C32 + tid] = tid < C32 ? a.stat_mean[tid] : a.stat_invstd[tid - C32];
   const int64_t ntiles = ((int64_t)a.B + a.R - 1) / a.R;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t b0 = tile * a.R;
     __syncthreads();
     stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.NC, a.nb, a.dL, a.pre_s ? aff : nullptr, a.pre_relu, img, tid);
     __syncthreads();
-#pragma unroll
+#pragma unroll 1
     for (int ip = 0; ip < (C32_NB2MAX + 1) / 2; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
       if (i0 < nbw) {
@@ -153,9 +157,45 @@ __global__ __launch_bounds__(256) void conv32_mfma_kernel(const Conv32Args a) {
             if (a.res1) v += a.res1[oq];
             if (a.res2) v += a.res2[oq];
             a.y[oq] = v;
+            if (a.stat_mode == 1) {
+              const float t = a.stat_relu ? fmaxf(v, 0.f) : v;
+              st1[q] += t;
+              st2[q] += t * t;
+            } else if (a.stat_mode == 2) {
+              float r = a.stat_x[oq];
+              if (a.stat_relu) r = fmaxf(r, 0.f);
+              st1[q] += v;
+              st2[q] += v * ((r - sms[chv + q]) * sms[C32 + chv + q]);
+            }
           }
         }
       }
+    }
+  }
+  if (a.stat_mode) {
+    // lanes of one kk group hold the same 4 channels for 16 different columns; the two waves of an M-block meet in LDS
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) {
+        st1[q] += __shfl_xor(st1[q], off);
+        st2[q] += __shfl_xor(st2[q], off);
+      }
+    }
+    __syncthreads();                                   // the image is dead
+    float* red = img;                                  // [4 waves][2][16]
+    if (n16 == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        red[wave * 32 + 4 * kk + q] = st1[q];
+        red[wave * 32 + 16 + 4 * kk + q] = st2[q];
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      const int which = tid >> 5, ch = tid & 31, m = ch >> 4, j = ch & 15;
+      const float t = red[m * 32 + which * 16 + j] + red[(m + 2) * 32 + which * 16 + j];
+      atomicAdd(&a.stat_out[which * C32 + ch], (double)t);
     }
   }
 }
@@ -285,21 +325,26 @@ using namespace mural;
 extern "C" int mural_op_conv32_supported(int32_t L) { return (L + 2) <= C32_MAXCOLS ? 1 : 0; }
 
 // y = conv32(pre(x)) [+bias] [relu] [+res1 +res2]; W is the PyTorch [32][32][3] weight (dgrad != 0: input-gradient
-// filter, i.e. y = dL/dx for x = dL/dy); wfrag: float[3072] scratch for the fragment re-layout
+// filter, i.e. y = dL/dx for x = dL/dy).  stat_mode / stat_*: per-channel sums of the output taken in the epilogue
+// (see Conv32Args); stat_out: double[2][32] zeroed by the caller.
 extern "C" int mural_op_conv32(const float* x, const float* W, const float* bias, float* y, int64_t B, int32_t L, int32_t dgrad,
                                const float* pre_s, const float* pre_t, int32_t pre_relu, int32_t post_relu, const float* res1,
-                               const float* res2, float* wfrag, void* stream_) {
+                               const float* res2, int32_t stat_mode, int32_t stat_relu, const float* stat_x,
+                               const float* stat_mean, const float* stat_invstd, double* stat_out, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B == 0 || L == 0) return MURAL_OK;
   Conv32Args a;
   std::memset(&a, 0, sizeof(a));
   MURAL_REQUIRE(tile_geometry((int)B, L, &a.R, &a.Sc, &a.NC, &a.nb), "conv32: L = %d does not fit the LDS tile", L);
-  hipLaunchKernelGGL(wfrag_kernel, dim3((2 * C32_KSTEPS * 64 + 255) / 256), dim3(256), 0, stream, W, wfrag, dgrad);
-  a.x = x; a.y = y; a.wfrag = wfrag; a.bias = bias; a.pre_s = pre_s; a.pre_t = pre_t; a.res1 = res1; a.res2 = res2;
+  MURAL_REQUIRE(stat_mode == 0 || stat_out, "conv32: stat_mode %d needs stat_out", stat_mode);
+  MURAL_REQUIRE(stat_mode != 2 || (stat_x && stat_mean && stat_invstd), "conv32: stat_mode 2 needs stat_x / mean / invstd");
+  a.x = x; a.y = y; a.W = W; a.dgrad = dgrad; a.bias = bias; a.pre_s = pre_s; a.pre_t = pre_t; a.res1 = res1; a.res2 = res2;
   a.pre_relu = pre_relu; a.post_relu = post_relu; a.B = (int)B; a.L = L;
+  a.stat_mode = stat_mode; a.stat_relu = stat_relu; a.stat_x = stat_x; a.stat_mean = stat_mean; a.stat_invstd = stat_invstd;
+  a.stat_out = stat_out;
   a.dSc = FastDiv::make((uint32_t)a.Sc);
   a.dL = FastDiv::make((uint32_t)L);
-  const size_t lds = (size_t)(16 * a.nb + 2) * C32 * 4 + 2 * C32 * 4;
+  const size_t lds = (size_t)(16 * a.nb + 2) * C32 * 4 + 4 * C32 * 4;
   const int64_t ntiles = (B + a.R - 1) / a.R;
   const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
   hipLaunchKernelGGL(conv32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);

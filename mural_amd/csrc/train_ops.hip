@@ -131,29 +131,38 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
   }
 }
 
-// dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat));  dgamma = sum(dz*xhat), dbeta = sum(dz)
-__global__ void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x, int64_t total, int C, int L,
-                                    int relu, const float* __restrict__ mean, const float* __restrict__ invstd,
-                                    const float* __restrict__ gamma, const double* __restrict__ s1,
-                                    const double* __restrict__ s2, double n, float* __restrict__ dx) {
+// dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) [+ add1 + add2];  workgroup 0 also writes
+// dgamma = sum(dz * xhat), dbeta = sum(dz).  Per-channel constants are prepared once per workgroup in LDS.
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x, int64_t total,
+                                                           int C, int L, int relu, const float* __restrict__ mean,
+                                                           const float* __restrict__ invstd, const float* __restrict__ gamma,
+                                                           const double* __restrict__ s1, const double* __restrict__ s2, double n,
+                                                           const float* __restrict__ add1, const float* __restrict__ add2,
+                                                           float* __restrict__ dx, float* __restrict__ dgamma,
+                                                           float* __restrict__ dbeta) {
+  extern __shared__ float cst[];      // [C][4]: gamma * invstd, mean(dz), mean(dz * xhat), mean
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    cst[4 * c + 0] = gamma[c] * invstd[c];
+    cst[4 * c + 1] = (float)(s1[c] / n);
+    cst[4 * c + 2] = (float)(s2[c] / n);
+    cst[4 * c + 3] = mean[c];
+    if (blockIdx.x == 0) {
+      dgamma[c] = (float)s2[c];
+      dbeta[c] = (float)s1[c];
+    }
+  }
+  __syncthreads();
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)((i / L) % C);
     const float raw = x[i];
     const float v = relu ? fmaxf(raw, 0.f) : raw;
-    const float xh = (v - mean[c]) * invstd[c];
-    const float m1 = (float)(s1[c] / n), m2 = (float)(s2[c] / n);
-    float g = gamma[c] * invstd[c] * (dz[i] - m1 - xh * m2);
+    const float xh = (v - cst[4 * c + 3]) * invstd[c];
+    float g = cst[4 * c + 0] * (dz[i] - cst[4 * c + 1] - xh * cst[4 * c + 2]);
     if (relu && raw <= 0.f) g = 0.f;
+    if (add1) g += add1[i];
+    if (add2) g += add2[i];
     dx[i] = g;
   }
-}
-
-__global__ void bn_param_grad_kernel(const double* __restrict__ s1, const double* __restrict__ s2, int C,
-                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  dgamma[c] = (float)s2[c];
-  dbeta[c] = (float)s1[c];
 }
 
 // ------------------------------------------------------------------------------------------- conv weight / bias gradients
@@ -541,64 +550,79 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restri
   }
 }
 
-// Tiled dense layer: y[b][n] = bias[n] + sum_k x[b][k] * Wm(k, n) for 64 rows per workgroup.  The weight matrix is staged
-// in LDS as [k][N8] (any source strides: forward reads W[o][i] with n = o, the input gradient reads it with n = i), the
-// x tile as [64][K|1]; a lane owns one row and 8 outputs at a time, weights arrive as LDS broadcasts.
-__global__ __launch_bounds__(256) void linear_tile_kernel(const float* __restrict__ x, const float* __restrict__ W, int w_sn,
-                                                          int w_sk, const float* __restrict__ bias, int64_t B, int K, int N,
+// contiguous global -> LDS copy by a 256-thread workgroup (float4 when the source is 16-byte aligned), zero fill up to `pad`
+__device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n, int pad, int tid) {
+  if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+    const int n4 = n >> 2;
+    for (int i = tid; i < n4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (int i = 4 * n4 + tid; i < n; i += 256) dst[i] = src[i];
+  } else {
+    for (int i = tid; i < n; i += 256) dst[i] = src[i];
+  }
+  for (int i = n + tid; i < pad; i += 256) dst[i] = 0.f;
+}
+
+// Tiled dense layer for 64 rows per workgroup: y[b][n] = bias[n] + sum_k x[b][k] * Wm(k, n), with Wm(k, n) = W[n][k]
+// (trans = 0: forward, W is [N][K]) or W[k][n] (trans = 1: input gradient, W is [K][N]).  The whole weight matrix and the
+// x tile are copied linearly into LDS; a lane owns one row and 8 outputs at a time, weights arrive as LDS broadcasts.
+__global__ __launch_bounds__(256) void linear_tile_kernel(const float* __restrict__ x, const float* __restrict__ W, int trans,
+                                                          const float* __restrict__ bias, int64_t B, int K, int N,
                                                           float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
-  const int N8 = (N + 7) & ~7, Kp = K | 1;
-  float* ws = lsm;                 // [K][N8]
-  float* xs = lsm + K * N8;        // [64][Kp]
+  const int KN4 = (K * N + 3) & ~3;
+  float* ws = lsm;                 // W as stored
+  float* xs = lsm + KN4;           // [64][K] as stored; lanes read rows at stride K
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t b0 = (int64_t)blockIdx.x * 64;
-  const bool k_fast = w_sk == 1;   // source contiguous along k (forward) or along n (input gradient)
-  for (int i = tid; i < K * N8; i += 256) {
-    int k, n;
-    if (k_fast) { n = i / K; k = i - n * K; } else { k = i / N8; n = i - k * N8; }
-    ws[k * N8 + n] = n < N ? W[(size_t)n * w_sn + (size_t)k * w_sk] : 0.f;   // padded output columns: 0
-  }
   const int rows = (int)((B - b0) < 64 ? (B - b0) : 64);
-  for (int i = tid; i < rows * K; i += 256) {
-    const int r = i / K, k = i - r * K;
-    xs[r * Kp + k] = x[(size_t)b0 * K + i];
-  }
+  copy_to_lds(ws, W, K * N, K * N, tid);
+  copy_to_lds(xs, x + (size_t)b0 * K, rows * K, 64 * K, tid);
   __syncthreads();
-  if (lane >= rows) return;
-  const float* xr = xs + lane * Kp;
-  for (int g = wave; g < N8 / 8; g += 4) {
+  const float* xr = xs + lane * K;
+  for (int g = wave; g < (N + 7) / 8; g += 4) {
     float acc[8];
+    int off[8];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) acc[c] = (bias && 8 * g + c < N) ? bias[8 * g + c] : 0.f;
-    const float* wg = ws + 8 * g;
-#pragma unroll 4
+    for (int c = 0; c < 8; ++c) {
+      const int n = 8 * g + c < N ? 8 * g + c : N - 1;      // clamped: surplus columns are computed and dropped
+      acc[c] = bias ? bias[n] : 0.f;
+      off[c] = trans ? n : n * K;
+    }
+    const int kstep = trans ? N : 1;
+#pragma unroll 2
     for (int k = 0; k < K; ++k) {
       const float xv = xr[k];
-      const float4 w0 = *reinterpret_cast<const float4*>(wg + k * N8), w1 = *reinterpret_cast<const float4*>(wg + k * N8 + 4);
-      acc[0] = fmaf(xv, w0.x, acc[0]); acc[1] = fmaf(xv, w0.y, acc[1]); acc[2] = fmaf(xv, w0.z, acc[2]); acc[3] = fmaf(xv, w0.w, acc[3]);
-      acc[4] = fmaf(xv, w1.x, acc[4]); acc[5] = fmaf(xv, w1.y, acc[5]); acc[6] = fmaf(xv, w1.z, acc[6]); acc[7] = fmaf(xv, w1.w, acc[7]);
-    }
-    float* yr = y + (size_t)(b0 + lane) * N + 8 * g;
+      const float* wk = ws + k * kstep;
 #pragma unroll
-    for (int c = 0; c < 8; ++c)
-      if (8 * g + c < N) yr[c] = acc[c];
+      for (int c = 0; c < 8; ++c) acc[c] = fmaf(xv, wk[off[c]], acc[c]);
+    }
+    if (lane < rows) {
+      float* yr = y + (size_t)(b0 + lane) * N + 8 * g;
+#pragma unroll
+      for (int c = 0; c < 8; ++c)
+        if (8 * g + c < N) yr[c] = acc[c];
+    }
   }
 }
 
-// dW[o][i] += sum_{b in 64-row chunk} dy[b][o] x[b][i]; db[o] likewise: both chunks staged in LDS, a thread owns an
-// 8 x 8 block of (o, i); chunks meet through hardware float atomics (dW / db zeroed by the caller)
+// dW[o][i] += sum_{b in chunk} dy[b][o] x[b][i]; db[o] likewise: 64-row chunks of both operands copied linearly into LDS, a
+// thread owns an 8 x 8 block of (o, i); chunks meet through hardware float atomics (dW / db zeroed by the caller)
 __global__ __launch_bounds__(256) void linear_wgrad_tile_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 int64_t B, int I, int O, int rows_per_wg,
                                                                 float* __restrict__ dW, float* __restrict__ db) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
-  const int O8 = (O + 7) & ~7, I8 = (I + 7) & ~7;
-  float* gs = lsm;                 // [64][O8]
-  float* xs = lsm + 64 * O8;       // [64][I8]
+  float* gs = lsm;                                 // [64][O]
+  float* xs = lsm + ((64 * O + 3) & ~3);           // [64][I]
   const int tid = threadIdx.x;
-  const int nbi = I8 / 8, nblk = (O8 / 8) * nbi;
+  const int nbi = (I + 7) / 8, nblk = ((O + 7) / 8) * nbi;
   const int ob = tid / nbi, ib = tid - ob * nbi;
+  int go[8], xo[8];
+#pragma unroll
+  for (int u = 0; u < 8; ++u) {
+    go[u] = 8 * ob + u < O ? 8 * ob + u : O - 1;   // clamped: surplus entries are computed and dropped
+    xo[u] = 8 * ib + u < I ? 8 * ib + u : I - 1;
+  }
   float acc[8][8];
 #pragma unroll
   for (int u = 0; u < 8; ++u)
@@ -610,21 +634,15 @@ __global__ __launch_bounds__(256) void linear_wgrad_tile_kernel(const float* __r
   for (int64_t b0 = r0; b0 < r1; b0 += 64) {
     const int rows = (int)((r1 - b0) < 64 ? (r1 - b0) : 64);
     __syncthreads();
-    for (int i = tid; i < 64 * O8; i += 256) {
-      const int r = i / O8, o = i - r * O8;
-      gs[i] = (r < rows && o < O) ? dy[(size_t)(b0 + r) * O + o] : 0.f;
-    }
-    for (int i = tid; i < 64 * I8; i += 256) {
-      const int r = i / I8, k = i - r * I8;
-      xs[i] = (r < rows && k < I) ? x[(size_t)(b0 + r) * I + k] : 0.f;
-    }
+    copy_to_lds(gs, dy + (size_t)b0 * O, rows * O, 64 * O, tid);
+    copy_to_lds(xs, x + (size_t)b0 * I, rows * I, 64 * I, tid);
     __syncthreads();
     if (tid < nblk) {
+#pragma unroll 2
       for (int r = 0; r < 64; ++r) {
-        const float4 g0 = *reinterpret_cast<const float4*>(gs + r * O8 + 8 * ob), g1 = *reinterpret_cast<const float4*>(gs + r * O8 + 8 * ob + 4);
-        const float4 x0 = *reinterpret_cast<const float4*>(xs + r * I8 + 8 * ib), x1 = *reinterpret_cast<const float4*>(xs + r * I8 + 8 * ib + 4);
-        const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-        const float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+        float gv[8], xv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) { gv[u] = gs[r * O + go[u]]; xv[u] = xs[r * I + xo[u]]; }
 #pragma unroll
         for (int u = 0; u < 8; ++u)
 #pragma unroll
@@ -633,7 +651,7 @@ __global__ __launch_bounds__(256) void linear_wgrad_tile_kernel(const float* __r
     }
     if (db && tid < O) {
       float sacc = 0.f;
-      for (int r = 0; r < 64; ++r) sacc += gs[r * O8 + tid];
+      for (int r = 0; r < 64; ++r) sacc += gs[r * O + tid];
       bsum += sacc;
     }
   }
@@ -809,18 +827,22 @@ extern "C" int mural_op_bn_apply(const float* x, int64_t B, int32_t C, int32_t L
   CHECK_LAUNCH();
 }
 
-// s1/s2: double[C] scratch zeroed by the caller.  Writes dx, dgamma, dbeta.
+// BatchNorm (batch statistics) backward.  s1/s2: double[C]; have_sums == 0: zeroed by the caller and reduced here, != 0:
+// already hold sum(dz) / sum(dz * xhat) (taken by the producer of dz, mural_op_conv32 stat_mode 2).  Writes dx (+ the optional
+// add1 / add2 tensors: gradients arriving at x through residual connections), dgamma, dbeta.
 extern "C" int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, int32_t L, int32_t relu,
                                     const float* mean, const float* invstd, const float* gamma, double* s1, double* s2,
-                                    float* dx, float* dgamma, float* dbeta, void* stream) {
+                                    int32_t have_sums, const float* add1, const float* add2, float* dx, float* dgamma,
+                                    float* dbeta, void* stream) {
   const int64_t per = B * L, total = B * C * L;
   if (total == 0) return MURAL_OK;
-  int gy = (int)((per + 256 * 8 - 1) / (256 * 8));
-  gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
-  hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, gy), dim3(256), 0, STREAM, dz, x, (int)B, C, L, relu, mean, invstd, s1, s2);
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, dz, x, total, C, L, relu, mean, invstd,
-                     gamma, s1, s2, (double)per, dx);
-  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM, s1, s2, C, dgamma, dbeta);
+  if (!have_sums) {
+    int gy = (int)((per + 256 * 8 - 1) / (256 * 8));
+    gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, gy), dim3(256), 0, STREAM, dz, x, (int)B, C, L, relu, mean, invstd, s1, s2);
+  }
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), (size_t)C * 16, STREAM, dz, x, total, C, L, relu, mean,
+                     invstd, gamma, s1, s2, (double)per, add1, add2, dx, dgamma, dbeta);
   CHECK_LAUNCH();
 }
 
@@ -925,11 +947,11 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
 }
 
 static bool linear_tile_fits(int K, int N, size_t* lds) {
-  *lds = ((size_t)K * ((N + 7) & ~7) + (size_t)64 * (K | 1)) * sizeof(float);
+  *lds = ((size_t)((K * N + 3) & ~3) + (size_t)64 * K) * sizeof(float);
   return *lds <= 150 * 1024;
 }
 
-static int launch_linear_tile(const float* x, const float* W, int w_sn, int w_sk, const float* bias, int64_t B, int K, int N,
+static int launch_linear_tile(const float* x, const float* W, int trans, const float* bias, int64_t B, int K, int N,
                               float* y, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024) {
     static bool attr_set = false;
@@ -939,7 +961,7 @@ static int launch_linear_tile(const float* x, const float* W, int w_sn, int w_sk
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL(linear_tile_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), lds, stream, x, W, w_sn, w_sk, bias, B, K, N, y);
+  hipLaunchKernelGGL(linear_tile_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), lds, stream, x, W, trans, bias, B, K, N, y);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
@@ -948,7 +970,7 @@ extern "C" int mural_op_linear_fwd(const float* x, const float* W, const float* 
                                    void* stream) {
   if (B == 0) return MURAL_OK;
   size_t lds;
-  if (linear_tile_fits(I, O, &lds)) return launch_linear_tile(x, W, I, 1, b, B, I, O, y, lds, STREAM);   // Wm(k, n) = W[n][k]
+  if (linear_tile_fits(I, O, &lds)) return launch_linear_tile(x, W, 0, b, B, I, O, y, lds, STREAM);   // Wm(k, n) = W[n][k]
   hipLaunchKernelGGL(linear_fwd_kernel, dim3((unsigned)((B * O + 255) / 256)), dim3(256), 0, STREAM, x, W, b, B, I, O, y);
   CHECK_LAUNCH();
 }
@@ -959,14 +981,13 @@ extern "C" int mural_op_linear_bwd(const float* dy, const float* x, const float*
   size_t lds;
   if (dx) {
     if (linear_tile_fits(O, I, &lds)) {                            // dx[b][i] = sum_o dy[b][o] W[o][i]: Wm(k = o, n = i)
-      if (int rc = launch_linear_tile(dy, W, 1, I, nullptr, B, O, I, dx, lds, STREAM)) return rc;
+      if (int rc = launch_linear_tile(dy, W, 1, nullptr, B, O, I, dx, lds, STREAM)) return rc;
     } else {
       hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((B * I + 255) / 256)), dim3(256), 0, STREAM, dy, W, B, I, O, dx);
     }
   }
-  const int O8 = (O + 7) & ~7, I8 = (I + 7) & ~7;
-  if ((O8 / 8) * (I8 / 8) <= 256 && O <= 256) {
-    const size_t wl = (size_t)64 * (O8 + I8) * sizeof(float);
+  if (((O + 7) / 8) * ((I + 7) / 8) <= 256 && O <= 256) {
+    const size_t wl = ((size_t)((64 * O + 3) & ~3) + (size_t)64 * I) * sizeof(float);
     int64_t wgs = (B + 63) / 64;
     wgs = wgs > 256 ? 256 : wgs;
     const int rows_per_wg = (int)(((B + wgs - 1) / wgs + 63) / 64 * 64);

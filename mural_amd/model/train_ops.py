@@ -33,14 +33,16 @@ def _f32(t):
 
 
 class _BnState:
-    """Per-call batch statistics of one BatchNorm (scale/shift for the forward pre-op, mean/invstd for the backward)."""
+    """Per-call batch statistics of one BatchNorm (scale/shift for the forward pre-op, mean/invstd for the backward).
+    ``acc`` = float64 (2, C) sums of act(x) / act(x)^2 when the producer of x already took them in its epilogue."""
 
-    def __init__(self, x, relu, bn, L):
+    def __init__(self, x, relu, bn, L, acc=None):
         B, Cn = x.shape[0], x.shape[1]
         dev = x.device
-        acc = torch.zeros(2, Cn, dtype=torch.float64, device=dev)
         st = _stream(x)
-        _call("mural_op_bn_stats", x, B, Cn, L, int(relu), acc[0], acc[1], st)
+        if acc is None:
+            acc = torch.zeros(2, Cn, dtype=torch.float64, device=dev)
+            _call("mural_op_bn_stats", x, B, Cn, L, int(relu), acc[0], acc[1], st)
         self.scale = torch.empty(Cn, device=dev)
         self.shift = torch.empty(Cn, device=dev)
         self.mean = torch.empty(Cn, device=dev)
@@ -52,30 +54,40 @@ class _BnState:
 
 
 class BnConv(torch.autograd.Function):
-    """y = Conv1d(BN(act(x))) [+ ReLU] [+ res1 + res2], act = ReLU or identity, 32->32 channels, k=3, pad=1."""
+    """y = Conv1d(BN(act(x))) [+ ReLU] [+ res1 + res2], act = ReLU or identity, 32->32 channels, k=3, pad=1.
+
+    ``stats_in``: batch sums of act(x) taken by the producer of x (skips the statistics pass); ``stats_out`` (None / False /
+    True): also return the batch sums of y (True: of relu(y)) for the BatchNorm that consumes y, taken in the conv epilogue.
+    Returns (y, sums or an empty tensor)."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, weight, bias, res1, res2, bn, pre_relu, post_relu):
+    def forward(ctx, x, gamma, beta, weight, bias, res1, res2, bn, pre_relu, post_relu, stats_in=None, stats_out=None):
         x = x.contiguous()
         B, Cn, L = x.shape
         st = _stream(x)
-        state = _BnState(x, pre_relu, bn, L)
-        wt = torch.empty_like(weight)
+        state = _BnState(x, pre_relu, bn, L, stats_in)
         y = torch.empty((B, weight.shape[0], L), device=x.device)
         mfma = tuple(weight.shape) == (32, 32, 3) and bool(_lib.lib().mural_op_conv32_supported(L))
+        want = stats_out is not None
+        acc_out = torch.zeros(2, weight.shape[0], dtype=torch.float64, device=x.device) if want else torch.empty(0, device=x.device)
         if mfma:      # fp32 MFMA implicit GEMM (csrc/conv32_mfma.hip)
             _call("mural_op_conv32", x, _f32(weight), _f32(bias), y, B, L, 0, state.scale, state.shift, int(pre_relu),
-                  int(post_relu), _p(res1), _p(res2), wt, st)
+                  int(post_relu), _p(res1), _p(res2), 1 if want else 0, int(bool(stats_out)), None, None, None,
+                  acc_out if want else None, st)
         else:         # generic direct conv (csrc/conv1d.hip)
+            wt = torch.empty_like(weight)
             _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 0, st)
             _call("mural_op_conv1d", x, wt, _f32(bias), y, B, Cn, weight.shape[0], L, weight.shape[2], state.scale,
                   state.shift, int(pre_relu), int(post_relu), _p(res1), _p(res2), st)
+            if want:
+                _call("mural_op_bn_stats", y, B, weight.shape[0], L, int(bool(stats_out)), acc_out[0], acc_out[1], st)
         ctx.save_for_backward(x, gamma, weight, y if post_relu else None, state.scale, state.shift, state.mean, state.invstd)
         ctx.flags = (pre_relu, post_relu, res1 is not None, res2 is not None, mfma)
-        return y
+        ctx.mark_non_differentiable(acc_out)
+        return y, acc_out
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, _dacc):
         x, gamma, weight, y, scale, shift, mean, invstd = ctx.saved_tensors
         pre_relu, post_relu, has_r1, has_r2, mfma = ctx.flags
         dy = dy.contiguous()
@@ -88,26 +100,28 @@ class BnConv(torch.autograd.Function):
             dy = g
         dW = torch.empty_like(weight)
         db = torch.empty(weight.shape[0], device=x.device)
-        wt = torch.empty_like(weight)
         dz = torch.empty_like(x)
-        if mfma:
+        acc = torch.zeros(2, Cn, dtype=torch.float64, device=x.device)
+        if mfma:      # the input-gradient conv also takes the BatchNorm-backward sums of dz in its epilogue
             part = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), device=x.device)
             _call("mural_op_conv32_wgrad", dy, x, B, L, scale, shift, int(pre_relu), dW, db, part, part.numel(), st)
-            _call("mural_op_conv32", dy, _f32(weight), None, dz, B, L, 1, None, None, 0, 0, None, None, wt, st)
+            _call("mural_op_conv32", dy, _f32(weight), None, dz, B, L, 1, None, None, 0, 0, None, None, 2, int(pre_relu), x, mean,
+                  invstd, acc, st)
         else:
+            wt = torch.empty_like(weight)
             part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=x.device)
             _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, part,
                   part.numel(), st)
             _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 1, st)
             _call("mural_op_conv1d", dy, wt, None, dz, B, weight.shape[0], Cn, L, weight.shape[2], None, None, 0, 0, None, None,
                   st)
-        acc = torch.zeros(2, Cn, dtype=torch.float64, device=x.device)
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cn, device=x.device)
         dbeta = torch.empty(Cn, device=x.device)
-        _call("mural_op_bn_backward", dz, x, B, Cn, L, int(pre_relu), mean, invstd, _f32(gamma), acc[0], acc[1], dx, dgamma,
-              dbeta, st)
-        return dx, dgamma, dbeta, dW, db, (dres if has_r1 else None), (dres if has_r2 else None), None, None, None
+        _call("mural_op_bn_backward", dz, x, B, Cn, L, int(pre_relu), mean, invstd, _f32(gamma), acc[0], acc[1], int(mfma), None,
+              None, dx, dgamma, dbeta, st)
+        return (dx, dgamma, dbeta, dW, db, (dres if has_r1 else None), (dres if has_r2 else None), None, None, None, None,
+                None)
 
 
 class Bn2d(torch.autograd.Function):
@@ -133,7 +147,7 @@ class Bn2d(torch.autograd.Function):
         dgamma = torch.empty(Cn, device=x.device)
         dbeta = torch.empty(Cn, device=x.device)
         _call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, 1, int(ctx.pre_relu), mean, invstd, _f32(gamma), acc[0], acc[1],
-              dx, dgamma, dbeta, _stream(x))
+              0, None, None, dx, dgamma, dbeta, _stream(x))
         return dx, dgamma, dbeta, None, None
 
 
@@ -329,22 +343,26 @@ def tower_forward(mod, sfx, sym, col0, L1, pools, dropout_p, training=True):
     bn_in, conv_in = g("conv1")[0], g("conv1")[1]
     x0 = FirstLayerPool.apply(sym, bn_in.weight, bn_in.bias, conv_in.weight, conv_in.bias, bn_in, col0, L1, pools[0])
 
-    def res_blocks(rbs, x_in):
-        rb0, rb1 = rbs[0], rbs[1]
-        h = BnConv.apply(x_in, rb0.bn1.weight, rb0.bn1.bias, rb0.conv1.weight, rb0.conv1.bias, None, None, rb0.bn1, True, False)
-        x1 = BnConv.apply(h, rb0.bn2.weight, rb0.bn2.bias, rb0.conv2.weight, rb0.conv2.bias, x_in, None, rb0.bn2, True, False)
-        h = BnConv.apply(x1, rb1.bn1.weight, rb1.bn1.bias, rb1.conv1.weight, rb1.conv1.bias, None, None, rb1.bn1, True, False)
-        # second block's own residual (x1) plus the outer skip (x_in), model_snv.py:477-479
-        return BnConv.apply(h, rb1.bn2.weight, rb1.bn2.bias, rb1.conv2.weight, rb1.conv2.bias, x1, x_in, rb1.bn2, True, False)
+    def bnconv(x, bn, conv, res1=None, res2=None, pre_relu=True, post_relu=False, stats_in=None, stats_out=None):
+        y, acc = BnConv.apply(x, bn.weight, bn.bias, conv.weight, conv.bias, res1, res2, bn, pre_relu, post_relu, stats_in,
+                              stats_out)
+        return y, (acc if stats_out is not None else None)
 
-    y = res_blocks(g("RBs1"), x0)
+    def res_blocks(rbs, x_in, st_in):
+        # every conv takes the batch sums of relu(its output) in its epilogue for the BatchNorm of the next layer
+        rb0, rb1 = rbs[0], rbs[1]
+        h, st = bnconv(x_in, rb0.bn1, rb0.conv1, stats_in=st_in, stats_out=True)
+        x1, st = bnconv(h, rb0.bn2, rb0.conv2, res1=x_in, stats_in=st, stats_out=True)
+        h, st = bnconv(x1, rb1.bn1, rb1.conv1, stats_in=st, stats_out=True)
+        # second block's own residual (x1) plus the outer skip (x_in), model_snv.py:477-479
+        return bnconv(h, rb1.bn2, rb1.conv2, res1=x1, res2=x_in, stats_in=st)[0]
+
+    y = res_blocks(g("RBs1"), x0, None)
     p2 = MaxPool.apply(y, *pools[1])
-    bn_mid, conv_mid = g("conv2")[0], g("conv2")[1]
-    x0b = BnConv.apply(p2, bn_mid.weight, bn_mid.bias, conv_mid.weight, conv_mid.bias, None, None, bn_mid, False, False)
-    y = res_blocks(g("RBs2"), x0b)
+    x0b, st = bnconv(p2, g("conv2")[0], g("conv2")[1], pre_relu=False, stats_out=True)
+    y = res_blocks(g("RBs2"), x0b, st)
     p3 = MaxPool.apply(y, *pools[2])
-    bn_out, conv_out = g("conv3")[0], g("conv3")[1]
-    c3 = BnConv.apply(p3, bn_out.weight, bn_out.bias, conv_out.weight, conv_out.bias, None, None, bn_out, False, True)
+    c3 = bnconv(p3, g("conv3")[0], g("conv3")[1], pre_relu=False, post_relu=True)[0]
     feat = MaxPool.apply(c3, None, None, None)
     fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
     f = Bn2d.apply(feat, fc[0].weight, fc[0].bias, fc[0], False)
