@@ -183,14 +183,17 @@ int mural_op_relayout(const float* W, float* wt, int32_t Cout, int32_t Cin, int3
 int mural_op_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin,
                     int32_t Cout, int32_t L, int32_t K, const float* pre_s, const float* pre_t, int32_t pre_relu,
                     int32_t post_relu, const float* res1, const float* res2, void* stream);
-int mural_op_bn_stats(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, double* sum, double* sq, void* stream);
-int mural_op_bn_finalize(const double* sum, const double* sq, double n, int32_t C, const float* gamma,
+/* Batch sums of the training-mode BatchNorms live in accumulator blocks double[MURAL_BN_SLOTS][2][C], zeroed by the
+ * caller: producers add into the copy picked by their workgroup index (same-address atomics serialise), readers sum. */
+#define MURAL_BN_SLOTS 32
+int mural_op_bn_stats(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, double* acc, void* stream);
+int mural_op_bn_finalize(const double* acc, double n, int32_t C, const float* gamma,
                          const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                          float* scale, float* shift, float* mean, float* invstd, void* stream);
 int mural_op_bn_apply(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, const float* scale,
                       const float* shift, float* y, void* stream);
 int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, int32_t L, int32_t relu,
-                         const float* mean, const float* invstd, const float* gamma, double* s1, double* s2,
+                         const float* mean, const float* invstd, const float* gamma, double* acc,
                          int32_t have_sums, const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta,
                          void* stream);
 int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, int32_t L, int32_t K,
@@ -198,7 +201,7 @@ int mural_op_conv_wgrad(const float* dy, const float* x, int64_t B, int32_t C, i
                         float* part, size_t part_floats, void* stream);
 /* fp32-MFMA path of the 32->32 k=3 convs on [B][32][L] tensors (L + 2 <= 288): forward / input gradient and weight +
  * bias gradient.  W: PyTorch [32][32][3]; part: mural_op_conv32_wgrad_scratch() floats.  stat_mode 1 / 2: the epilogue
- * also accumulates per-channel sums of the output into stat_out (double[2][32], zeroed by the caller): 1 = sum / sum of
+ * also accumulates per-channel sums of the output into the accumulator block stat_out: 1 = sum / sum of
  * squares of act(y) (batch statistics for the next BatchNorm), 2 = sum(y), sum(y * xhat(stat_x)) (BatchNorm backward).  */
 int mural_op_conv32_supported(int32_t L);
 int mural_op_conv32(const float* x, const float* W, const float* bias, float* y, int64_t B, int32_t L, int32_t dgrad,
@@ -225,7 +228,7 @@ int mural_op_first_bwd(const float* dy, const void* arg, const uint8_t* sym, int
                        const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta, void* stream);
 int mural_op_linear_fwd(const float* x, const float* W, const float* b, int64_t B, int32_t I, int32_t O, float* y,
                         void* stream);
-/* dW / db are accumulated: zeroed by the caller */
+/* dx (optional), dW [O][I] and db [O] are fully written */
 int mural_op_linear_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t I, int32_t O, float* dx,
                         float* dW, float* db, void* stream);
 int mural_op_embedding_fwd(const int64_t* cat, const float* E, int64_t B, int32_t cols, int32_t rows, float* y,

@@ -78,10 +78,10 @@ VP, I32, I64 = C.c_void_p, C.c_int32, C.c_int64
 PROTOTYPES = {
     "mural_op_relayout": (C.c_int, [VP, VP, I32, I32, I32, I32, VP]),
     "mural_op_conv1d": (C.c_int, [VP, VP, VP, VP, I64, I32, I32, I32, I32, VP, VP, I32, I32, VP, VP, VP]),
-    "mural_op_bn_stats": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, VP]),
-    "mural_op_bn_finalize": (C.c_int, [VP, VP, C.c_double, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, VP, VP]),
+    "mural_op_bn_stats": (C.c_int, [VP, I64, I32, I32, I32, VP, VP]),
+    "mural_op_bn_finalize": (C.c_int, [VP, C.c_double, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, VP, VP]),
     "mural_op_bn_apply": (C.c_int, [VP, I64, I32, I32, I32, VP, VP, VP, VP]),
-    "mural_op_bn_backward": (C.c_int, [VP, VP, I64, I32, I32, I32, VP, VP, VP, VP, VP, I32, VP, VP, VP, VP, VP, VP]),
+    "mural_op_bn_backward": (C.c_int, [VP, VP, I64, I32, I32, I32, VP, VP, VP, VP, I32, VP, VP, VP, VP, VP, VP]),
     "mural_op_conv_wgrad": (C.c_int, [VP, VP, I64, I32, I32, I32, VP, VP, I32, VP, VP, VP, C.c_size_t, VP]),
     "mural_op_conv32_supported": (C.c_int, [I32]),
     "mural_op_conv32": (C.c_int, [VP, VP, VP, VP, I64, I32, I32, VP, VP, I32, I32, VP, VP, I32, I32, VP, VP, VP, VP, VP]),

@@ -31,7 +31,7 @@ struct Conv32Args {
   const float* stat_x;   // mode 2: [B][32][L]
   const float* stat_mean;
   const float* stat_invstd;
-  double* stat_out;      // [2][32], accumulated with atomics (zeroed by the caller)
+  double* stat_out;      // accumulator block [MURAL_BN_SLOTS][2][32] (zeroed by the caller), copy picked by workgroup index
   const float* bias;     // [32] or nullptr
   const float* pre_s;    // [32] or nullptr: x' = pre_s * act(x) + pre_t, act = relu if pre_relu
   const float* pre_t;
@@ -78,7 +78,8 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t 
   }
 }
 
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv32_mfma_kernel(const Conv32Args a) {
+template <int STAT>   // = Conv32Args::stat_mode, compile-time so that the plain forward does not carry the epilogue sums
+__global__ __launch_bounds__(256) void conv32_mfma_kernel(const Conv32Args a) {
   extern __shared__ __attribute__((aligned(16))) float img[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int t = s / 8, h = (s % 8) / 4, q = s % 4;
     const int cin = 16 * h + 4 * kk + q;               // channel of the tensor being convolved
     const int cout = 16 * mb + n16;                    // channel of the tensor being produced
-    af[s] = a.dgrad ? a.W[(cin * C32 + cout) * 3 + (2 - t)] : a.W[(cout * C32 + cin) * 3 + t];
+    af[s] = a.W[a.dgrad ? (cin * C32 + cout) * 3 + (2 - t) : (cout * C32 + cin) * 3 + t];
   }
   const int chv = 16 * mb + 4 * kk;
   float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
@@ -108,14 +109,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   float* aff = img + (16 * a.nb + 2) * C32;              // pre_s | pre_t
   if (a.pre_s && tid < 2 * C32) aff[tid] = tid < C32 ? a.pre_s[tid] : a.pre_t[tid - C32];
   const float* sms = aff + 2 * C32;                      // stat_mean | stat_invstd (mode 2)
-  if (a.stat_mode == 2 && tid < 2 * C32) aff[2 * C32 + tid] = tid < C32 ? a.stat_mean[tid] : a.stat_invstd[tid - C32];
+  if (STAT == 2 && tid < 2 * C32) aff[2 * C32 + tid] = tid < C32 ? a.stat_mean[tid] : a.stat_invstd[tid - C32];
   const int64_t ntiles = ((int64_t)a.B + a.R - 1) / a.R;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t b0 = tile * a.R;
     __syncthreads();
     stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.NC, a.nb, a.dL, a.pre_s ? aff : nullptr, a.pre_relu, img, tid);
     __syncthreads();
-#pragma unroll 1
+#pragma unroll
     for (int ip = 0; ip < (C32_NB2MAX + 1) / 2; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
       if (i0 < nbw) {
@@ -157,11 +158,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
             if (a.res1) v += a.res1[oq];
             if (a.res2) v += a.res2[oq];
             a.y[oq] = v;
-            if (a.stat_mode == 1) {
+            if (STAT == 1) {
               const float t = a.stat_relu ? fmaxf(v, 0.f) : v;
               st1[q] += t;
               st2[q] += t * t;
-            } else if (a.stat_mode == 2) {
+            } else if (STAT == 2) {
               float r = a.stat_x[oq];
               if (a.stat_relu) r = fmaxf(r, 0.f);
               st1[q] += v;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
       }
     }
   }
-  if (a.stat_mode) {
+  if (STAT) {
     // lanes of one kk group hold the same 4 channels for 16 different columns; the two waves of an M-block meet in LDS
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (tid < 64) {
       const int which = tid >> 5, ch = tid & 31, m = ch >> 4, j = ch & 15;
       const float t = red[m * 32 + which * 16 + j] + red[(m + 2) * 32 + which * 16 + j];
-      atomicAdd(&a.stat_out[which * C32 + ch], (double)t);
+      atomicAdd(&a.stat_out[((size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 + which) * C32 + ch], (double)t);
     }
   }
 }
@@ -326,7 +327,7 @@ extern "C" int mural_op_conv32_supported(int32_t L) { return (L + 2) <= C32_MAXC
 
 // y = conv32(pre(x)) [+bias] [relu] [+res1 +res2]; W is the PyTorch [32][32][3] weight (dgrad != 0: input-gradient
 // filter, i.e. y = dL/dx for x = dL/dy).  stat_mode / stat_*: per-channel sums of the output taken in the epilogue
-// (see Conv32Args); stat_out: double[2][32] zeroed by the caller.
+// (see Conv32Args); stat_out: accumulator block double[MURAL_BN_SLOTS][2][32] zeroed by the caller.
 extern "C" int mural_op_conv32(const float* x, const float* W, const float* bias, float* y, int64_t B, int32_t L, int32_t dgrad,
                                const float* pre_s, const float* pre_t, int32_t pre_relu, int32_t post_relu, const float* res1,
                                const float* res2, int32_t stat_mode, int32_t stat_relu, const float* stat_x,
@@ -347,7 +348,9 @@ extern "C" int mural_op_conv32(const float* x, const float* W, const float* bias
   const size_t lds = (size_t)(16 * a.nb + 2) * C32 * 4 + 4 * C32 * 4;
   const int64_t ntiles = (B + a.R - 1) / a.R;
   const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
-  hipLaunchKernelGGL(conv32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);
+  if (stat_mode == 0) hipLaunchKernelGGL(conv32_mfma_kernel<0>, dim3(grid), dim3(256), lds, stream, a);
+  else if (stat_mode == 1) hipLaunchKernelGGL(conv32_mfma_kernel<1>, dim3(grid), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL(conv32_mfma_kernel<2>, dim3(grid), dim3(256), lds, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

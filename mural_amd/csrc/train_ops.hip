@@ -13,6 +13,10 @@
 namespace mural {
 namespace {
 
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+
+constexpr int BN_SLOTS = MURAL_BN_SLOTS;
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -32,7 +36,7 @@ __global__ void relayout_kernel(const float* __restrict__ W, float* __restrict__
 // ------------------------------------------------------------------------------------------- BatchNorm (train)
 // sums over (B, L) of a(x) and a(x)^2 per channel, a = relu or identity
 __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__ x, int B, int C, int L, int relu,
-                                                       double* __restrict__ sum, double* __restrict__ sq) {
+                                                       double* __restrict__ acc) {
   const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
   const int64_t per = (int64_t)B * L;
@@ -55,22 +59,29 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
     }
     __syncthreads();
   }
-  if (threadIdx.x == 0) {
-    atomicAdd(&sum[c], sh[0][0]);
-    atomicAdd(&sq[c], sh[1][0]);
+  if (threadIdx.x == 0) {   // accumulator copy by workgroup: same-address atomics serialise in L2
+    double* slot = acc + (size_t)(blockIdx.y % BN_SLOTS) * 2 * C;
+    atomicAdd(&slot[c], sh[0][0]);
+    atomicAdd(&slot[C + c], sh[1][0]);
   }
 }
 
 // scale / shift of y = gamma * (a(x) - mean) * invstd + beta, running statistics update
-__global__ void bn_finalize_kernel(const double* __restrict__ sum, const double* __restrict__ sq, double n, int C,
+__device__ __forceinline__ double slot_sum(const double* __restrict__ acc, int C, int which, int c) {
+  double t = 0.0;
+  for (int k = 0; k < BN_SLOTS; ++k) t += acc[((size_t)k * 2 + which) * C + c];
+  return t;
+}
+
+__global__ void bn_finalize_kernel(const double* __restrict__ acc, double n, int C,
                                    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
                                    float* __restrict__ running_mean, float* __restrict__ running_var,
                                    float* __restrict__ scale, float* __restrict__ shift, float* __restrict__ mean_out,
                                    float* __restrict__ invstd_out) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  const double mean = sum[c] / n;
-  double var = sq[c] / n - mean * mean;
+  const double mean = slot_sum(acc, C, 0, c) / n;
+  double var = slot_sum(acc, C, 1, c) / n - mean * mean;
   if (var < 0.0) var = 0.0;
   const double invstd = 1.0 / sqrt(var + (double)eps);
   scale[c] = (float)(gamma[c] * invstd);
@@ -98,8 +109,7 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t total, int 
 // sums over (B, L) of dz and dz * xhat per channel
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ x, int B,
                                                             int C, int L, int relu, const float* __restrict__ mean,
-                                                            const float* __restrict__ invstd, double* __restrict__ s1,
-                                                            double* __restrict__ s2) {
+                                                            const float* __restrict__ invstd, double* __restrict__ acc) {
   const int c = blockIdx.x;
   const float mu = mean[c], is = invstd[c];
   double a = 0.0, bq = 0.0;
@@ -126,8 +136,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     __syncthreads();
   }
   if (threadIdx.x == 0) {
-    atomicAdd(&s1[c], sh[0][0]);
-    atomicAdd(&s2[c], sh[1][0]);
+    double* slot = acc + (size_t)(blockIdx.y % BN_SLOTS) * 2 * C;
+    atomicAdd(&slot[c], sh[0][0]);
+    atomicAdd(&slot[C + c], sh[1][0]);
   }
 }
 
@@ -136,19 +147,20 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ x, int64_t total,
                                                            int C, int L, int relu, const float* __restrict__ mean,
                                                            const float* __restrict__ invstd, const float* __restrict__ gamma,
-                                                           const double* __restrict__ s1, const double* __restrict__ s2, double n,
+                                                           const double* __restrict__ acc, double n,
                                                            const float* __restrict__ add1, const float* __restrict__ add2,
                                                            float* __restrict__ dx, float* __restrict__ dgamma,
                                                            float* __restrict__ dbeta) {
   extern __shared__ float cst[];      // [C][4]: gamma * invstd, mean(dz), mean(dz * xhat), mean
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const double s1 = slot_sum(acc, C, 0, c), s2 = slot_sum(acc, C, 1, c);
     cst[4 * c + 0] = gamma[c] * invstd[c];
-    cst[4 * c + 1] = (float)(s1[c] / n);
-    cst[4 * c + 2] = (float)(s2[c] / n);
+    cst[4 * c + 1] = (float)(s1 / n);
+    cst[4 * c + 2] = (float)(s2 / n);
     cst[4 * c + 3] = mean[c];
     if (blockIdx.x == 0) {
-      dgamma[c] = (float)s2[c];
-      dbeta[c] = (float)s1[c];
+      dgamma[c] = (float)s2;
+      dbeta[c] = (float)s1;
     }
   }
   __syncthreads();
@@ -535,21 +547,6 @@ __global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* _
   dx[i] = acc;
 }
 
-// dW[o][k] += sum_{b in chunk} dy[b][o] x[b][k]; db[o] likewise (k == I).  grid (O, chunks): thread = k, so the x row
-// reads are coalesced and dy[b][o] is a broadcast; chunks meet through float atomics (dW / db zeroed by the caller)
-__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t B,
-                                                           int I, int O, float* __restrict__ dW, float* __restrict__ db) {
-  const int o = blockIdx.x;
-  const int64_t per = (B + gridDim.y - 1) / gridDim.y;
-  const int64_t b0 = (int64_t)blockIdx.y * per, b1 = (b0 + per < B) ? b0 + per : B;
-  for (int k = threadIdx.x; k <= I; k += blockDim.x) {
-    float acc = 0.f;
-    for (int64_t b = b0; b < b1; ++b) acc = fmaf(dy[b * O + o], k < I ? x[b * I + k] : 1.f, acc);
-    if (k < I) atomicAdd(&dW[(size_t)o * I + k], acc);
-    else if (db) atomicAdd(&db[o], acc);
-  }
-}
-
 // contiguous global -> LDS copy by a 256-thread workgroup (float4 when the source is 16-byte aligned), zero fill up to `pad`
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n, int pad, int tid) {
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
@@ -562,109 +559,111 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict_
   for (int i = n + tid; i < pad; i += 256) dst[i] = 0.f;
 }
 
-// Tiled dense layer for 64 rows per workgroup: y[b][n] = bias[n] + sum_k x[b][k] * Wm(k, n), with Wm(k, n) = W[n][k]
-// (trans = 0: forward, W is [N][K]) or W[k][n] (trans = 1: input gradient, W is [K][N]).  The whole weight matrix and the
-// x tile are copied linearly into LDS; a lane owns one row and 8 outputs at a time, weights arrive as LDS broadcasts.
-__global__ __launch_bounds__(256) void linear_tile_kernel(const float* __restrict__ x, const float* __restrict__ W, int trans,
+// Dense layer on the fp32 matrix cores for 64 rows per workgroup: y[b][n] = bias[n] + sum_k x[b][k] * Wm(k, n), with
+// Wm(k, n) = W[n][k] (trans = 0: forward, W is [N][K]) or W[k][n] (trans = 1: input gradient, W is [K][N]).  The whole weight
+// matrix and the x tile are copied linearly into LDS; wave w owns rows 16w..16w+15 (A fragments in registers, K <= 256) and
+// walks the 16-column output blocks: D[16 rows][16 outputs] += x[16][4] * Wm[4][16] per v_mfma_f32_16x16x4_f32.
+constexpr int LIN_MAXK = 256;
+__global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W, int trans,
                                                           const float* __restrict__ bias, int64_t B, int K, int N,
                                                           float* __restrict__ y) {
   extern __shared__ __attribute__((aligned(16))) float lsm[];
   const int KN4 = (K * N + 3) & ~3;
   float* ws = lsm;                 // W as stored
-  float* xs = lsm + KN4;           // [64][K] as stored; lanes read rows at stride K
+  float* xs = lsm + KN4;           // [64][K] as stored
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
   const int64_t b0 = (int64_t)blockIdx.x * 64;
   const int rows = (int)((B - b0) < 64 ? (B - b0) : 64);
   copy_to_lds(ws, W, K * N, K * N, tid);
   copy_to_lds(xs, x + (size_t)b0 * K, rows * K, 64 * K, tid);
   __syncthreads();
-  const float* xr = xs + lane * K;
-  for (int g = wave; g < (N + 7) / 8; g += 4) {
-    float acc[8];
-    int off[8];
+  const int ksteps = (K + 3) / 4;
+  float af[LIN_MAXK / 4];
 #pragma unroll
-    for (int c = 0; c < 8; ++c) {
-      const int n = 8 * g + c < N ? 8 * g + c : N - 1;      // clamped: surplus columns are computed and dropped
-      acc[c] = bias ? bias[n] : 0.f;
-      off[c] = trans ? n : n * K;
+  for (int s = 0; s < LIN_MAXK / 4; ++s) {
+    const int k = 4 * s + kk;
+    af[s] = (s < ksteps && k < K) ? xs[(16 * wave + n16) * K + k] : 0.f;
+  }
+  for (int nt = 0; 16 * nt < N; ++nt) {
+    const int n = 16 * nt + n16;
+    const bool nv = n < N;
+    const float bv = (bias && nv) ? bias[n] : 0.f;
+    f32x4_t acc = {bv, bv, bv, bv};
+    const float* wcol = ws + (trans ? n : n * K);
+    const int kstride = trans ? N : 1;
+#pragma unroll
+    for (int s = 0; s < LIN_MAXK / 4; ++s) {
+      if (s < ksteps) {
+        const int k = 4 * s + kk;
+        const float bf = (nv && k < K) ? wcol[k * kstride] : 0.f;
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s], bf, acc, 0, 0, 0);
+      }
     }
-    const int kstep = trans ? N : 1;
-#pragma unroll 2
-    for (int k = 0; k < K; ++k) {
-      const float xv = xr[k];
-      const float* wk = ws + k * kstep;
+    if (nv) {
 #pragma unroll
-      for (int c = 0; c < 8; ++c) acc[c] = fmaf(xv, wk[off[c]], acc[c]);
-    }
-    if (lane < rows) {
-      float* yr = y + (size_t)(b0 + lane) * N + 8 * g;
-#pragma unroll
-      for (int c = 0; c < 8; ++c)
-        if (8 * g + c < N) yr[c] = acc[c];
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * wave + 4 * kk + r;
+        if (row < rows) y[(size_t)(b0 + row) * N + n] = acc[r];
+      }
     }
   }
 }
 
-// dW[o][i] += sum_{b in chunk} dy[b][o] x[b][i]; db[o] likewise: 64-row chunks of both operands copied linearly into LDS, a
-// thread owns an 8 x 8 block of (o, i); chunks meet through hardware float atomics (dW / db zeroed by the caller)
-__global__ __launch_bounds__(256) void linear_wgrad_tile_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                                int64_t B, int I, int O, int rows_per_wg,
-                                                                float* __restrict__ dW, float* __restrict__ db) {
-  extern __shared__ __attribute__((aligned(16))) float lsm[];
-  float* gs = lsm;                                 // [64][O]
-  float* xs = lsm + ((64 * O + 3) & ~3);           // [64][I]
-  const int tid = threadIdx.x;
-  const int nbi = (I + 7) / 8, nblk = ((O + 7) / 8) * nbi;
-  const int ob = tid / nbi, ib = tid - ob * nbi;
-  int go[8], xo[8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    go[u] = 8 * ob + u < O ? 8 * ob + u : O - 1;   // clamped: surplus entries are computed and dropped
-    xo[u] = 8 * ib + u < I ? 8 * ib + u : I - 1;
-  }
-  float acc[8][8];
-#pragma unroll
-  for (int u = 0; u < 8; ++u)
-#pragma unroll
-    for (int v = 0; v < 8; ++v) acc[u][v] = 0.f;
+// dW[o][i] = sum_b dy[b][o] x[b][i], db[o] = sum_b dy[b][o] on the fp32 matrix cores: one workgroup of 16 waves per 16 x 16
+// block of dW; wave w reduces rows [w B/16, (w+1) B/16) in k-steps of 4 rows with operands straight from HBM / L2
+// (each 16-column strip of dy and x is read by the workgroups of one block row / column only), the 16 partial tiles meet
+// in LDS in a fixed order: no atomics, reproducible.
+__global__ __launch_bounds__(1024) void linear_wgrad_mfma_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                 int64_t B, int I, int O, float* __restrict__ dW,
+                                                                 float* __restrict__ db) {
+  __shared__ float red[16][16 * 16 + 16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int nbi = (I + 15) / 16;
+  const int ob = blockIdx.x / nbi, ib = blockIdx.x - ob * nbi;
+  const int o = 16 * ob + n16, i = 16 * ib + n16;
+  const bool ov = o < O, iv = i < I;
+  const int64_t per = ((B + 15) / 16 + 3) & ~(int64_t)3;            // rows per wave, a multiple of 4
+  const int64_t r0 = wave * per, r1 = (r0 + per < B) ? r0 + per : B;
+  f32x4_t acc = {0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-  const int64_t r1 = r0 + rows_per_wg < B ? r0 + rows_per_wg : B;
-  for (int64_t b0 = r0; b0 < r1; b0 += 64) {
-    const int rows = (int)((r1 - b0) < 64 ? (r1 - b0) : 64);
-    __syncthreads();
-    copy_to_lds(gs, dy + (size_t)b0 * O, rows * O, 64 * O, tid);
-    copy_to_lds(xs, x + (size_t)b0 * I, rows * I, 64 * I, tid);
-    __syncthreads();
-    if (tid < nblk) {
-#pragma unroll 2
-      for (int r = 0; r < 64; ++r) {
-        float gv[8], xv[8];
+  for (int64_t r = r0; r < r1; r += 32) {
+    float a[8], b[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) { gv[u] = gs[r * O + go[u]]; xv[u] = xs[r * I + xo[u]]; }
-#pragma unroll
-        for (int u = 0; u < 8; ++u)
-#pragma unroll
-          for (int v = 0; v < 8; ++v) acc[u][v] = fmaf(gv[u], xv[v], acc[u][v]);
-      }
+    for (int u = 0; u < 8; ++u) {                                      // 16 loads in flight per lane
+      const int64_t row = r + 4 * u + kk;
+      const bool rv = row < r1;
+      a[u] = (rv && ov) ? dy[row * O + o] : 0.f;
+      b[u] = (rv && iv) ? x[row * I + i] : 0.f;
     }
-    if (db && tid < O) {
-      float sacc = 0.f;
-      for (int r = 0; r < 64; ++r) sacc += gs[r * O + tid];
-      bsum += sacc;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a[u], b[u], acc, 0, 0, 0);
+      bsum += a[u];
     }
   }
-  if (tid < nblk) {
+  // D[row = o 4kk+r][col = i n16]
 #pragma unroll
-    for (int u = 0; u < 8; ++u)
+  for (int r = 0; r < 4; ++r) red[wave][(4 * kk + r) * 16 + n16] = acc[r];
+  bsum += __shfl_xor(bsum, 16);
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 16) red[wave][256 + lane] = bsum;
+  __syncthreads();
+  if (tid < 256 + 16) {
+    float t = 0.f;
 #pragma unroll
-      for (int v = 0; v < 8; ++v) {
-        const int o = 8 * ob + u, i = 8 * ib + v;
-        if (o < O && i < I) unsafeAtomicAdd(&dW[(size_t)o * I + i], acc[u][v]);
-      }
+    for (int w = 0; w < 16; ++w) t += red[w][tid];
+    if (tid < 256) {
+      const int oo = 16 * ob + (tid >> 4), ii = 16 * ib + (tid & 15);
+      if (oo < O && ii < I) dW[(size_t)oo * I + ii] = t;
+    } else if (ib == 0 && db) {
+      const int oo = 16 * ob + (tid - 256);
+      if (oo < O) db[oo] = t;
+    }
   }
-  if (db && tid < O) unsafeAtomicAdd(&db[tid], bsum);
 }
 
 __global__ void embedding_fwd_kernel(const int64_t* __restrict__ cat, const float* __restrict__ E, int64_t B, int cols, int rows,
@@ -801,20 +800,21 @@ extern "C" int mural_op_conv1d(const float* in, const float* wt, const float* bi
   return launch_conv1d(a, STREAM);
 }
 
-// sum / sumsq (double[C] each, zeroed by the caller) -> scale, shift, mean, invstd (+ running statistics update)
-extern "C" int mural_op_bn_stats(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, double* sum, double* sq,
-                                 void* stream) {
+// Batch sums live in an accumulator block acc = double[MURAL_BN_SLOTS][2][C] (zeroed by the caller): workgroups add into
+// the copy picked by their index, readers sum the copies.  [k][0][c] = sum, [k][1][c] = sum of squares (forward) or
+// sum(dz), sum(dz * xhat) (backward).
+extern "C" int mural_op_bn_stats(const float* x, int64_t B, int32_t C, int32_t L, int32_t relu, double* acc, void* stream) {
   const int64_t per = B * L;
   int gy = (int)((per + 256 * 8 - 1) / (256 * 8));
   gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
-  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, gy), dim3(256), 0, STREAM, x, (int)B, C, L, relu, sum, sq);
+  hipLaunchKernelGGL(bn_stats_kernel, dim3(C, gy), dim3(256), 0, STREAM, x, (int)B, C, L, relu, acc);
   CHECK_LAUNCH();
 }
 
-extern "C" int mural_op_bn_finalize(const double* sum, const double* sq, double n, int32_t C, const float* gamma,
+extern "C" int mural_op_bn_finalize(const double* acc, double n, int32_t C, const float* gamma,
                                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
                                     float* scale, float* shift, float* mean, float* invstd, void* stream) {
-  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM, sum, sq, n, C, gamma, beta, eps, momentum,
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, STREAM, acc, n, C, gamma, beta, eps, momentum,
                      running_mean, running_var, scale, shift, mean, invstd);
   CHECK_LAUNCH();
 }
@@ -827,11 +827,11 @@ extern "C" int mural_op_bn_apply(const float* x, int64_t B, int32_t C, int32_t L
   CHECK_LAUNCH();
 }
 
-// BatchNorm (batch statistics) backward.  s1/s2: double[C]; have_sums == 0: zeroed by the caller and reduced here, != 0:
-// already hold sum(dz) / sum(dz * xhat) (taken by the producer of dz, mural_op_conv32 stat_mode 2).  Writes dx (+ the optional
+// BatchNorm (batch statistics) backward.  acc: accumulator block; have_sums == 0: zeroed by the caller and reduced here,
+// != 0: already holds sum(dz) / sum(dz * xhat) (taken by the producer of dz, mural_op_conv32 stat_mode 2).  Writes dx (+ the optional
 // add1 / add2 tensors: gradients arriving at x through residual connections), dgamma, dbeta.
 extern "C" int mural_op_bn_backward(const float* dz, const float* x, int64_t B, int32_t C, int32_t L, int32_t relu,
-                                    const float* mean, const float* invstd, const float* gamma, double* s1, double* s2,
+                                    const float* mean, const float* invstd, const float* gamma, double* acc,
                                     int32_t have_sums, const float* add1, const float* add2, float* dx, float* dgamma,
                                     float* dbeta, void* stream) {
   const int64_t per = B * L, total = B * C * L;
@@ -839,10 +839,10 @@ extern "C" int mural_op_bn_backward(const float* dz, const float* x, int64_t B, 
   if (!have_sums) {
     int gy = (int)((per + 256 * 8 - 1) / (256 * 8));
     gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
-    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, gy), dim3(256), 0, STREAM, dz, x, (int)B, C, L, relu, mean, invstd, s1, s2);
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3(C, gy), dim3(256), 0, STREAM, dz, x, (int)B, C, L, relu, mean, invstd, acc);
   }
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total)), dim3(256), (size_t)C * 16, STREAM, dz, x, total, C, L, relu, mean,
-                     invstd, gamma, s1, s2, (double)per, add1, add2, dx, dgamma, dbeta);
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(total, 256, 2048)), dim3(256), (size_t)C * 16, STREAM, dz, x, total, C, L, relu, mean,
+                     invstd, gamma, acc, (double)per, add1, add2, dx, dgamma, dbeta);
   CHECK_LAUNCH();
 }
 
@@ -948,7 +948,7 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
 
 static bool linear_tile_fits(int K, int N, size_t* lds) {
   *lds = ((size_t)((K * N + 3) & ~3) + (size_t)64 * K) * sizeof(float);
-  return *lds <= 150 * 1024;
+  return *lds <= 150 * 1024 && K <= LIN_MAXK;
 }
 
 static int launch_linear_tile(const float* x, const float* W, int trans, const float* bias, int64_t B, int K, int N,
@@ -956,12 +956,12 @@ static int launch_linear_tile(const float* x, const float* W, int trans, const f
   if (lds > 64 * 1024) {
     static bool attr_set = false;
     if (!attr_set) {
-      MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_tile_kernel),
+      MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel),
                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
       attr_set = true;
     }
   }
-  hipLaunchKernelGGL(linear_tile_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), lds, stream, x, W, trans, bias, B, K, N, y);
+  hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), lds, stream, x, W, trans, bias, B, K, N, y);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
@@ -986,21 +986,9 @@ extern "C" int mural_op_linear_bwd(const float* dy, const float* x, const float*
       hipLaunchKernelGGL(linear_bwd_x_kernel, dim3((unsigned)((B * I + 255) / 256)), dim3(256), 0, STREAM, dy, W, B, I, O, dx);
     }
   }
-  if (((O + 7) / 8) * ((I + 7) / 8) <= 256 && O <= 256) {
-    const size_t wl = ((size_t)((64 * O + 3) & ~3) + (size_t)64 * I) * sizeof(float);
-    int64_t wgs = (B + 63) / 64;
-    wgs = wgs > 256 ? 256 : wgs;
-    const int rows_per_wg = (int)(((B + wgs - 1) / wgs + 63) / 64 * 64);
-    wgs = (B + rows_per_wg - 1) / rows_per_wg;
-    if (wl > 64 * 1024)
-      MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_wgrad_tile_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(linear_wgrad_tile_kernel, dim3((unsigned)wgs), dim3(256), wl, STREAM, dy, x, B, I, O, rows_per_wg, dW, db);
-    CHECK_LAUNCH();
-  }
-  int chunks = (int)(B / 128);
-  chunks = chunks < 1 ? 1 : (chunks > 32 ? 32 : chunks);
-  hipLaunchKernelGGL(linear_bwd_w_kernel, dim3(O, chunks), dim3(256), 0, STREAM, dy, x, B, I, O, dW, db);
+  // dW / db are fully written (no accumulation into the caller's buffer)
+  hipLaunchKernelGGL(linear_wgrad_mfma_kernel, dim3((unsigned)(((O + 15) / 16) * ((I + 15) / 16))), dim3(1024), 0, STREAM, dy, x, B,
+                     I, O, dW, db);
   CHECK_LAUNCH();
 }
 

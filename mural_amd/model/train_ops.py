@@ -12,6 +12,32 @@ import torch
 from .. import _lib
 
 EPS, MOMENTUM = 1e-5, 0.1
+BN_SLOTS = 32          # include/mural_hip.h MURAL_BN_SLOTS
+
+
+class _ZeroArena:
+    """Zero-initialised float64 scratch handed out in slices: one fill kernel per chunk instead of one per accumulator.
+    Slices are never reused (a fresh chunk replaces an exhausted one; views keep old chunks alive as long as needed)."""
+
+    CHUNK = 1 << 17     # doubles (1 MiB)
+
+    def __init__(self):
+        self.buf, self.off = None, 0
+
+    def take(self, n, device):
+        if self.buf is None or self.buf.device != device or self.off + n > self.buf.numel():
+            self.buf, self.off = torch.zeros(max(self.CHUNK, n), dtype=torch.float64, device=device), 0
+        out = self.buf[self.off:self.off + n]
+        self.off += n
+        return out
+
+
+_arena = _ZeroArena()
+
+
+def _bn_acc(Cn, device):
+    """Zeroed accumulator block (BN_SLOTS, 2, C) for batch sums (see mural_op_bn_stats)."""
+    return _arena.take(BN_SLOTS * 2 * Cn, device).view(BN_SLOTS, 2, Cn)
 
 
 def _p(t):
@@ -34,20 +60,20 @@ def _f32(t):
 
 class _BnState:
     """Per-call batch statistics of one BatchNorm (scale/shift for the forward pre-op, mean/invstd for the backward).
-    ``acc`` = float64 (2, C) sums of act(x) / act(x)^2 when the producer of x already took them in its epilogue."""
+    ``acc`` = accumulator block with the sums of act(x) / act(x)^2 when the producer of x already took them in its epilogue."""
 
     def __init__(self, x, relu, bn, L, acc=None):
         B, Cn = x.shape[0], x.shape[1]
         dev = x.device
         st = _stream(x)
         if acc is None:
-            acc = torch.zeros(2, Cn, dtype=torch.float64, device=dev)
-            _call("mural_op_bn_stats", x, B, Cn, L, int(relu), acc[0], acc[1], st)
+            acc = _bn_acc(Cn, dev)
+            _call("mural_op_bn_stats", x, B, Cn, L, int(relu), acc, st)
         self.scale = torch.empty(Cn, device=dev)
         self.shift = torch.empty(Cn, device=dev)
         self.mean = torch.empty(Cn, device=dev)
         self.invstd = torch.empty(Cn, device=dev)
-        _call("mural_op_bn_finalize", acc[0], acc[1], float(B * L), Cn, _f32(bn.weight), _f32(bn.bias), EPS, MOMENTUM,
+        _call("mural_op_bn_finalize", acc, float(B * L), Cn, _f32(bn.weight), _f32(bn.bias), EPS, MOMENTUM,
               bn.running_mean, bn.running_var, self.scale, self.shift, self.mean, self.invstd, st)
         with torch.no_grad():
             bn.num_batches_tracked += 1
@@ -69,7 +95,7 @@ class BnConv(torch.autograd.Function):
         y = torch.empty((B, weight.shape[0], L), device=x.device)
         mfma = tuple(weight.shape) == (32, 32, 3) and bool(_lib.lib().mural_op_conv32_supported(L))
         want = stats_out is not None
-        acc_out = torch.zeros(2, weight.shape[0], dtype=torch.float64, device=x.device) if want else torch.empty(0, device=x.device)
+        acc_out = _bn_acc(weight.shape[0], x.device) if want else torch.empty(0, device=x.device)
         if mfma:      # fp32 MFMA implicit GEMM (csrc/conv32_mfma.hip)
             _call("mural_op_conv32", x, _f32(weight), _f32(bias), y, B, L, 0, state.scale, state.shift, int(pre_relu),
                   int(post_relu), _p(res1), _p(res2), 1 if want else 0, int(bool(stats_out)), None, None, None,
@@ -80,7 +106,7 @@ class BnConv(torch.autograd.Function):
             _call("mural_op_conv1d", x, wt, _f32(bias), y, B, Cn, weight.shape[0], L, weight.shape[2], state.scale,
                   state.shift, int(pre_relu), int(post_relu), _p(res1), _p(res2), st)
             if want:
-                _call("mural_op_bn_stats", y, B, weight.shape[0], L, int(bool(stats_out)), acc_out[0], acc_out[1], st)
+                _call("mural_op_bn_stats", y, B, weight.shape[0], L, int(bool(stats_out)), acc_out, st)
         ctx.save_for_backward(x, gamma, weight, y if post_relu else None, state.scale, state.shift, state.mean, state.invstd)
         ctx.flags = (pre_relu, post_relu, res1 is not None, res2 is not None, mfma)
         ctx.mark_non_differentiable(acc_out)
@@ -101,7 +127,7 @@ class BnConv(torch.autograd.Function):
         dW = torch.empty_like(weight)
         db = torch.empty(weight.shape[0], device=x.device)
         dz = torch.empty_like(x)
-        acc = torch.zeros(2, Cn, dtype=torch.float64, device=x.device)
+        acc = _bn_acc(Cn, x.device)
         if mfma:      # the input-gradient conv also takes the BatchNorm-backward sums of dz in its epilogue
             part = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), device=x.device)
             _call("mural_op_conv32_wgrad", dy, x, B, L, scale, shift, int(pre_relu), dW, db, part, part.numel(), st)
@@ -118,8 +144,8 @@ class BnConv(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cn, device=x.device)
         dbeta = torch.empty(Cn, device=x.device)
-        _call("mural_op_bn_backward", dz, x, B, Cn, L, int(pre_relu), mean, invstd, _f32(gamma), acc[0], acc[1], int(mfma), None,
-              None, dx, dgamma, dbeta, st)
+        _call("mural_op_bn_backward", dz, x, B, Cn, L, int(pre_relu), mean, invstd, _f32(gamma), acc, int(mfma), None, None, dx,
+              dgamma, dbeta, st)
         return (dx, dgamma, dbeta, dW, db, (dres if has_r1 else None), (dres if has_r2 else None), None, None, None, None,
                 None)
 
@@ -142,12 +168,12 @@ class Bn2d(torch.autograd.Function):
     def backward(ctx, dy):
         x, gamma, mean, invstd = ctx.saved_tensors
         B, Cn = x.shape
-        acc = torch.zeros(2, Cn, dtype=torch.float64, device=x.device)
+        acc = _bn_acc(Cn, x.device)
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cn, device=x.device)
         dbeta = torch.empty(Cn, device=x.device)
-        _call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, 1, int(ctx.pre_relu), mean, invstd, _f32(gamma), acc[0], acc[1],
-              0, None, None, dx, dgamma, dbeta, _stream(x))
+        _call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, 1, int(ctx.pre_relu), mean, invstd, _f32(gamma), acc, 0, None,
+              None, dx, dgamma, dbeta, _stream(x))
         return dx, dgamma, dbeta, None, None
 
 
@@ -244,8 +270,8 @@ class Linear(torch.autograd.Function):
         B, I = x.shape
         O = weight.shape[0]
         dx = torch.empty_like(x)
-        dW = torch.zeros_like(weight)
-        db = torch.zeros(O, device=x.device)
+        dW = torch.empty_like(weight)
+        db = torch.empty(O, device=x.device)
         _call("mural_op_linear_bwd", dy.contiguous(), x, _f32(weight), B, I, O, dx, dW, db, _stream(x))
         return dx, dW, db
 
