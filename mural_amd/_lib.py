@@ -164,4 +164,6 @@ def require_cuda(t, name):
 
 
 def current_stream_ptr(device):
-    return C.c_void_p(torch.cuda.current_stream(device).cuda_stream)
+    """Raw hipStream_t of torch's current stream on `device` (one C call: this sits on every kernel launch path)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    return C.c_void_p(torch._C._cuda_getCurrentRawStream(idx))

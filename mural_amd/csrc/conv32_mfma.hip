@@ -2,10 +2,16 @@
 // input gradient (same kernel, different weight fragments) and weight + bias gradient.  Used by the training step
 // (MuRaL/training.py:424-427 autograd over nn.Conv1d, here one explicit kernel per direction).
 //
-// As in snv_towers_fused, R batch rows share one flattened column axis with zero separator columns (= the conv's
-// zero padding); the tile is staged in LDS as [column][32 ch] with the conflict-free chunk permutation of mfma_tile.h,
-// with the optional BatchNorm(+ReLU) affine applied while staging.
-//   forward : D[16 cout][16 col] += W[cout][k] act[k][col], K = 3 taps x 32 ch; wave = (M-block, column parity)
+// These layers are HBM-bound at batch 4096 (3.4 GFLOP against 140-280 MB per layer), so the kernels are organised around
+// the memory streams: R batch rows (contiguous in memory) form one tile; every global access is a coalesced float4
+// stream over that contiguous block - the input, the residuals, the output - and the layout change happens in LDS.
+//   LDS image [32 ch][pitch]: the R rows share one flattened column axis with zero separator columns between them (= the
+//   conv's zero padding); pitch = 4 mod 32 makes every MFMA operand read conflict-free (v_mfma_f32_16x16x4_f32 operands
+//   are one float per lane: lanes = 16 columns x 4 channels or 16 channels x 4 columns).
+//   forward : D[16 cout][16 col] += W[cout][k] act[k][col], K = 3 taps x 32 ch; wave = (M-block, column parity).  The
+//             accumulators of all blocks stay in registers until every wave is done with the image, then overwrite it
+//             in place; the tile leaves through a streaming pass that adds the residuals and, on request, takes the
+//             per-channel sums the next BatchNorm (forward) or this BatchNorm's backward needs.
 //   wgrad   : dW[cout][(tap, cin)] += dy[cout][col] * act[cin][col + tap - 1]: M = cout, N = (tap, cin) = 6 blocks of 16,
 //             K = columns in steps of 4; each wave reduces a quarter of the tile's columns into 12 accumulator tiles
 #include <cstring>
@@ -18,13 +24,18 @@ constexpr int C32 = 32;
 constexpr int C32_KSTEPS = 24;
 constexpr int C32_NB2MAX = 9;          // <= 18 blocks of 16 columns per tile
 constexpr int C32_MAXCOLS = 16 * 2 * C32_NB2MAX;
+constexpr int C32_AUX = 128;           // floats after the image: pre_s | pre_t | stat_mean | stat_invstd
+
+// logical column c (0 = leading separator) lives at image index c + 1; index 0 is the guard read by tap 0 of column 0.
+// One compile-time pitch (>= 16 * 18 + 2, = 4 mod 32) for every geometry: operand addresses are one per-lane base + immediates.
+constexpr int C32_PITCH = 292;
 
 struct Conv32Args {
   const float* x;        // [B][32][L]
   float* y;              // [B][32][L]
   const float* W;        // PyTorch [32][32][3]; dgrad: use the transposed, tap-flipped filter
   int dgrad;
-  // per-channel sums taken in the epilogue (the producer of a tensor knows its values: no extra pass over HBM)
+  // per-channel sums taken while the tile streams out (the producer of a tensor knows its values: no extra pass over HBM)
   int stat_mode;         // 0 none | 1: sum, sum of squares of act(y) (batch statistics of the NEXT BatchNorm)
                          //        | 2: sum(y), sum(y * xhat), xhat = (act(stat_x) - mean) * invstd (BatchNorm backward of y = dz)
   int stat_relu;         // act = relu
@@ -42,13 +53,17 @@ struct Conv32Args {
   FastDiv dSc, dL;
 };
 
-// stage R rows of x (contiguous in memory) into the LDS image, applying the BN(+ReLU) affine; separators / tail = 0.
-// `aff` is an LDS copy of pre_s | pre_t (64 floats) or nullptr.
-__device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t b0, int B, int L, int R, int Sc, int NC, int nb,
-                                           const FastDiv& dL, const float* aff, int pre_relu, float* img, int tid) {
+// stage the tile's rows (contiguous in memory) into the image, applying the BN(+ReLU) affine; separator columns = 0.
+// `aff` is an LDS copy of pre_s | pre_t (64 floats) or nullptr.  zero_tail: also clear the guard and every column behind the
+// last staged row up to image index `ncols` (kernels that reduce over columns need exact zeros there).
+__device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t b0, int B, int L, int R, int Sc,
+                                           const FastDiv& dL, const float* aff, int pre_relu, float* img, int tid,
+                                           bool zero_tail, int ncols) {
+  constexpr int pitch = C32_PITCH;
   const int rows = (int)((B - b0) < R ? (B - b0) : R);
   const int total = rows * C32 * L;                      // a multiple of 4 (32 channels)
   const float* src = x + (size_t)b0 * C32 * L;           // 128-byte aligned: float4 loads
+#pragma unroll 2
   for (int i0 = tid * 4; i0 < total; i0 += 256 * 4) {
     const f32x4 v4 = ld4(src + i0);
     uint32_t rc = dL.div((uint32_t)i0);
@@ -60,31 +75,29 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t 
       float v = v4[e];
       if (pre_relu) v = fmaxf(v, 0.f);
       if (aff) v = fmaf(aff[ci], v, aff[C32 + ci]);
-      img[lds_off(1 + r * Sc + l + 1, ci >> 2) + (ci & 3)] = v;
+      img[ci * pitch + 2 + r * Sc + l] = v;
       ++l;
     }
   }
-  // zero: both guard columns (logical -1 and 16 nb), the separator columns, rows missing from a partial last tile, tail
-  const int nsep = R + 1, first_tail = 1 + rows * Sc;    // columns >= first_tail hold no data
-  const int nz = 2 + nsep + (16 * nb - first_tail > 0 ? 16 * nb - first_tail : 0);
-  for (int i = tid; i < nz * 8; i += 256) {
-    const int k = i >> 3, cg = i & 7;
-    int c;
-    if (k == 0) c = -1;
-    else if (k == 1) c = 16 * nb;
-    else if (k < 2 + nsep) c = (k - 2) * Sc;
-    else c = first_tail + (k - 2 - nsep);
-    if (c <= 16 * nb) st4(img + lds_off(c + 1, cg), splat(0.f));
+  for (int i = tid; i < (R + 1) * C32; i += 256) img[(i & 31) * pitch + 1 + (i >> 5) * Sc] = 0.f;   // separators
+  if (zero_tail) {
+    const int first = 2 + rows * Sc;                     // image index behind the closing separator of the last row
+    const int n = ncols - first + 2;                     // first .. ncols, + the guard
+    for (int i = tid; i < n * C32; i += 256) {
+      const int k = i >> 5;
+      img[(i & 31) * pitch + (k == 0 ? 0 : first + k - 1)] = 0.f;
+    }
   }
 }
 
-template <int STAT>   // = Conv32Args::stat_mode, compile-time so that the plain forward does not carry the epilogue sums
-__global__ __launch_bounds__(256) void conv32_mfma_kernel(const Conv32Args a) {
+template <int STAT>   // = Conv32Args::stat_mode, compile-time so that the plain forward does not carry the sums
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void conv32_mfma_kernel(const Conv32Args a) {
   extern __shared__ __attribute__((aligned(16))) float img[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int mb = wave & 1, cgp = wave >> 1;
   const int n16 = lane & 15, kk = lane >> 4;
+  constexpr int pitch = C32_PITCH;
   float af[C32_KSTEPS];   // A fragments: k-step s = 8 tap + 4 half + q holds W[cout = 16 mb + n16][cin = 16 half + 4 kk + q][tap]
 #pragma unroll
   for (int s = 0; s < C32_KSTEPS; ++s) {
@@ -94,109 +107,134 @@ __global__ __launch_bounds__(256) void conv32_mfma_kernel(const Conv32Args a) {
     af[s] = a.W[a.dgrad ? (cin * C32 + cout) * 3 + (2 - t) : (cout * C32 + cin) * 3 + t];
   }
   const int chv = 16 * mb + 4 * kk;
-  float st1[4] = {0.f, 0.f, 0.f, 0.f}, st2[4] = {0.f, 0.f, 0.f, 0.f};
-
   const f32x4 bias = a.bias ? ld4(a.bias + chv) : splat(0.f);
-  // per-lane LDS byte offsets of block 0 of this wave (block i: + 4096 i)
-  uint32_t rd[6];
-  const int c0 = 16 * cgp + n16;
-#pragma unroll
-  for (int t = 0; t < 3; ++t)
-#pragma unroll
-    for (int h = 0; h < 2; ++h) rd[2 * t + h] = 4u * (uint32_t)lds_off(c0 + t, 4 * h + kk);
+  float* aux = img + C32 * pitch;                        // pre_s | pre_t | stat_mean | stat_invstd
+  if (a.pre_s && tid < 2 * C32) aux[tid] = tid < C32 ? a.pre_s[tid] : a.pre_t[tid - C32];
+  if (STAT == 2 && tid < 2 * C32) aux[2 * C32 + tid] = tid < C32 ? a.stat_mean[tid] : a.stat_invstd[tid - C32];
   const int nbw = a.nb > cgp ? (a.nb - cgp + 1) / 2 : 0;
-  const char* in = reinterpret_cast<const char*>(img);
-  float* aff = img + (16 * a.nb + 2) * C32;              // pre_s | pre_t
-  if (a.pre_s && tid < 2 * C32) aff[tid] = tid < C32 ? a.pre_s[tid] : a.pre_t[tid - C32];
-  const float* sms = aff + 2 * C32;                      // stat_mean | stat_invstd (mode 2)
-  if (STAT == 2 && tid < 2 * C32) aff[2 * C32 + tid] = tid < C32 ? a.stat_mean[tid] : a.stat_invstd[tid - C32];
+  // operand reads: lane (n16, kk) takes act[cin = 16 h + 4 kk + q][column 16 blk + n16 + tap - 1] = image index (.. + tap)
+  const float* rd = img + 4 * kk * pitch + n16;
+  float sv[4] = {0.f, 0.f, 0.f, 0.f};                    // STAT 2: sum of the outputs, in accumulator layout
+  float racc1 = 0.f, racc2 = 0.f;                        // channel-major sums: thread = (channel tid / 8, column residue tid % 8)
   const int64_t ntiles = ((int64_t)a.B + a.R - 1) / a.R;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t b0 = tile * a.R;
+    const int rows = (int)((a.B - b0) < a.R ? (a.B - b0) : a.R);
     __syncthreads();
-    stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.NC, a.nb, a.dL, a.pre_s ? aff : nullptr, a.pre_relu, img, tid);
+    stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.dL, a.pre_s ? aux : nullptr, a.pre_relu, img, tid, false, 0);
     __syncthreads();
+    f32x4 acc[C32_NB2MAX + 1];
 #pragma unroll
     for (int ip = 0; ip < (C32_NB2MAX + 1) / 2; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
       if (i0 < nbw) {
         const bool dual = i1 < nbw;
-        f32x4 X0[2], X1[2], Y0[2], Y1[2], Z0[2], Z1[2];
+        const float* p0 = rd + 16 * (cgp + 2 * i0);
+        const float* p1 = rd + 16 * (cgp + 2 * (dual ? i1 : i0));
+        f32x4 a0 = bias, a1 = bias;                      // two independent accumulator chains (40-cycle dependent latency)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          X0[h] = lds_ld4(in, rd[0 + h] + 4096u * i0); X1[h] = lds_ld4(in, rd[0 + h] + 4096u * i1);
-          Y0[h] = lds_ld4(in, rd[2 + h] + 4096u * i0); Y1[h] = lds_ld4(in, rd[2 + h] + 4096u * i1);
-          Z0[h] = lds_ld4(in, rd[4 + h] + 4096u * i0); Z1[h] = lds_ld4(in, rd[4 + h] + 4096u * i1);
-        }
-        f32x4 acc0 = bias, acc1 = bias;
-        __builtin_amdgcn_sched_barrier(0);
-        if (dual) {
-          mfma_tap<true, C32_KSTEPS>(af, 0, X0, X1, acc0, acc1);
-          mfma_tap<true, C32_KSTEPS>(af, 1, Y0, Y1, acc0, acc1);
-          mfma_tap<true, C32_KSTEPS>(af, 2, Z0, Z1, acc0, acc1);
-        } else {
-          mfma_tap<false, C32_KSTEPS>(af, 0, X0, X1, acc0, acc1);
-          mfma_tap<false, C32_KSTEPS>(af, 1, Y0, Y1, acc0, acc1);
-          mfma_tap<false, C32_KSTEPS>(af, 2, Z0, Z1, acc0, acc1);
-        }
+        for (int t = 0; t < 3; ++t) {
+          float b0v[8], b1v[8];
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-          if (e == 1 && !dual) break;
-          const int c = 16 * (cgp + 2 * (e ? i1 : i0)) + n16;
-          if (c < 1 || c >= a.NC) continue;
+          for (int j = 0; j < 8; ++j) {
+            b0v[j] = p0[(16 * (j >> 2) + (j & 3)) * pitch + t];
+            b1v[j] = p1[(16 * (j >> 2) + (j & 3)) * pitch + t];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[8 * t + j], b0v[j], a0, 0, 0, 0);
+            if (dual) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[8 * t + j], b1v[j], a1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);             // one tap's operands in flight at a time: the layer is HBM-bound
+        }
+        acc[i0] = a0;
+        acc[i1] = a1;
+      }
+    }
+    __syncthreads();                                     // every wave is done reading the image: overwrite it with the outputs
+#pragma unroll
+    for (int i = 0; i < C32_NB2MAX; ++i) {
+      if (i < nbw) {
+        const int c = 16 * (cgp + 2 * i) + n16;          // logical column
+        f32x4 v = acc[i];
+        if (a.post_relu) v = max4(v, splat(0.f));
+#pragma unroll
+        for (int q = 0; q < 4; ++q) img[(chv + q) * pitch + 1 + c] = v[q];
+        if (STAT == 2 && c >= 1) {
           const uint32_t u = (uint32_t)(c - 1);
           const uint32_t r = a.dSc.div(u);
-          const int l = (int)(u - r * (uint32_t)a.Sc);
-          if (l >= a.L || b0 + r >= a.B) continue;
-          const f32x4 acc = e ? acc1 : acc0;
-          const size_t o = ((size_t)(b0 + r) * C32 + chv) * a.L + l;
+          if ((int)r < rows && (int)(u - r * (uint32_t)a.Sc) < a.L) {
 #pragma unroll
-          for (int q = 0; q < 4; ++q) {
-            float v = acc[q];
-            if (a.post_relu) v = fmaxf(v, 0.f);
-            const size_t oq = o + (size_t)q * a.L;
-            if (a.res1) v += a.res1[oq];
-            if (a.res2) v += a.res2[oq];
-            a.y[oq] = v;
-            if (STAT == 1) {
-              const float t = a.stat_relu ? fmaxf(v, 0.f) : v;
-              st1[q] += t;
-              st2[q] += t * t;
-            } else if (STAT == 2) {
-              float r = a.stat_x[oq];
-              if (a.stat_relu) r = fmaxf(r, 0.f);
-              st1[q] += v;
-              st2[q] += v * ((r - sms[chv + q]) * sms[C32 + chv + q]);
-            }
+            for (int q = 0; q < 4; ++q) sv[q] += v[q];
           }
         }
       }
     }
+    __syncthreads();
+    // the tile leaves as one contiguous float4 stream (+ residuals); values the sums need go back into the image
+    const int total = rows * C32 * a.L;
+    const size_t base = (size_t)b0 * C32 * a.L;
+#pragma unroll 1
+    for (int i0 = tid * 4; i0 < total; i0 += 256 * 4) {
+      const f32x4 r1 = a.res1 ? ld4(a.res1 + base + i0) : splat(0.f);
+      const f32x4 r2 = a.res2 ? ld4(a.res2 + base + i0) : splat(0.f);
+      f32x4 sx = splat(0.f);
+      if (STAT == 2) sx = ld4(a.stat_x + base + i0);
+      uint32_t rc = a.dL.div((uint32_t)i0);
+      int l = i0 - (int)rc * a.L;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (l >= a.L) { l -= a.L; ++rc; }
+        const int r = (int)rc >> 5, ci = (int)rc & 31;
+        const int idx = ci * pitch + 2 + r * a.Sc + l;
+        const float v = (img[idx] + r1[e]) + r2[e];
+        o[e] = v;
+        if (STAT == 1) img[idx] = a.stat_relu ? fmaxf(v, 0.f) : v;
+        if (STAT == 2) {
+          const float xr = a.stat_relu ? fmaxf(sx[e], 0.f) : sx[e];
+          img[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
+        }
+        ++l;
+      }
+      st4(a.y + base + i0, o);
+    }
+    if (STAT) {
+      __syncthreads();
+      const int ch = tid >> 3, p8 = tid & 7;
+      float s1 = 0.f, s2 = 0.f;
+      for (int r = 0; r < rows; ++r) {
+        const float* row = img + ch * pitch + 2 + r * a.Sc;
+        for (int l = p8; l < a.L; l += 8) {
+          const float t = row[l];
+          s1 += t;
+          if (STAT == 1) s2 += t * t;
+        }
+      }
+      racc1 += s1;
+      racc2 += s2;
+    }
   }
   if (STAT) {
-    // lanes of one kk group hold the same 4 channels for 16 different columns; the two waves of an M-block meet in LDS
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-#pragma unroll
-      for (int off = 1; off < 16; off <<= 1) {
-        st1[q] += __shfl_xor(st1[q], off);
-        st2[q] += __shfl_xor(st2[q], off);
+    double* slot = a.stat_out + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * C32;
+    racc1 += __shfl_xor(racc1, 1); racc1 += __shfl_xor(racc1, 2); racc1 += __shfl_xor(racc1, 4);
+    racc2 += __shfl_xor(racc2, 1); racc2 += __shfl_xor(racc2, 2); racc2 += __shfl_xor(racc2, 4);
+    if ((tid & 7) == 0) {
+      const int ch = tid >> 3;
+      if (STAT == 1) {
+        atomicAdd(&slot[ch], (double)racc1);
+        atomicAdd(&slot[C32 + ch], (double)racc2);
+      } else {
+        atomicAdd(&slot[C32 + ch], (double)racc1);      // sum(dz * xhat)
       }
     }
-    __syncthreads();                                   // the image is dead
-    float* red = img;                                  // [4 waves][2][16]
-    if (n16 == 0) {
+    if (STAT == 2) {                                     // sum(dz): lanes of one kk group hold 4 channels for 16 columns
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        red[wave * 32 + 4 * kk + q] = st1[q];
-        red[wave * 32 + 16 + 4 * kk + q] = st2[q];
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) sv[q] += __shfl_xor(sv[q], off);
+        if (n16 == 0) atomicAdd(&slot[chv + q], (double)sv[q]);
       }
-    }
-    __syncthreads();
-    if (tid < 64) {
-      const int which = tid >> 5, ch = tid & 31, m = ch >> 4, j = ch & 15;
-      const float t = red[m * 32 + which * 16 + j] + red[(m + 2) * 32 + which * 16 + j];
-      atomicAdd(&a.stat_out[((size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 + which) * C32 + ch], (double)t);
     }
   }
 }
@@ -211,19 +249,19 @@ struct Wgrad32Args {
   int B, L, R, Sc, NC, nb;
   FastDiv dL;
   float* part;           // [grid][32*32*3 + 32] per-workgroup partial sums
-  int img_floats;        // floats of one LDS image
 };
 
 __global__ __launch_bounds__(256) void wgrad32_mfma_kernel(const Wgrad32Args a) {
   extern __shared__ __attribute__((aligned(16))) float wimg[];
-  float* gimg = wimg;                 // dy tile
-  float* aimg = wimg + a.img_floats;  // BN(act(x)) tile
-  float* aff = aimg + a.img_floats;   // pre_s | pre_t
+  constexpr int pitch = C32_PITCH;
+  float* gimg = wimg;                       // dy tile
+  float* aimg = wimg + C32 * pitch;         // BN(act(x)) tile
+  float* aff = aimg + C32 * pitch;          // pre_s | pre_t
   if (a.pre_s && threadIdx.x < 2 * C32) aff[threadIdx.x] = threadIdx.x < C32 ? a.pre_s[threadIdx.x] : a.pre_t[threadIdx.x - C32];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kk = lane >> 4;
-  f32x4 acc[2][3][2];                 // [M-block][tap][cin half]
+  f32x4 acc[2][3][2];                       // [M-block][tap][cin half]
 #pragma unroll
   for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -231,24 +269,25 @@ __global__ __launch_bounds__(256) void wgrad32_mfma_kernel(const Wgrad32Args a) 
 #pragma unroll
       for (int h = 0; h < 2; ++h) acc[m][t][h] = splat(0.f);
   float bacc = 0.f;
-  const int nk = 4 * a.nb;            // k-steps of 4 columns
+  const int nk = 4 * a.nb;                  // k-steps of 4 columns
   const int k_lo = wave * nk / 4, k_hi = (wave + 1) * nk / 4;
+  const float* gp = gimg + n16 * pitch + 1 + kk;     // dy[cout = 16 m + n16][logical column 4 s + kk]
+  const float* ap = aimg + n16 * pitch + kk;         // act[cin = 16 h + n16][logical column 4 s + kk + tap - 1]
   const int64_t ntiles = ((int64_t)a.B + a.R - 1) / a.R;
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t b0 = tile * a.R;
     __syncthreads();
-    stage_rows(a.dy, b0, a.B, a.L, a.R, a.Sc, a.NC, a.nb, a.dL, nullptr, 0, gimg, tid);
-    stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.NC, a.nb, a.dL, a.pre_s ? aff : nullptr, a.pre_relu, aimg, tid);
+    stage_rows(a.dy, b0, a.B, a.L, a.R, a.Sc, a.dL, nullptr, 0, gimg, tid, true, 16 * a.nb + 1);
+    stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.dL, a.pre_s ? aff : nullptr, a.pre_relu, aimg, tid, true, 16 * a.nb + 1);
     __syncthreads();
     for (int s = k_lo; s < k_hi; ++s) {
-      const int c = 4 * s + kk;       // logical column of this lane's k element
       float g[2], bv[3][2];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) g[m] = gimg[lds_off(c + 1, (16 * m + n16) >> 2) + (n16 & 3)];
+      for (int m = 0; m < 2; ++m) g[m] = gp[16 * m * pitch + 4 * s];
 #pragma unroll
       for (int t = 0; t < 3; ++t)
 #pragma unroll
-        for (int h = 0; h < 2; ++h) bv[t][h] = aimg[lds_off(c + t, (16 * h + n16) >> 2) + (n16 & 3)];
+        for (int h = 0; h < 2; ++h) bv[t][h] = ap[16 * h * pitch + 4 * s + t];
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -258,8 +297,9 @@ __global__ __launch_bounds__(256) void wgrad32_mfma_kernel(const Wgrad32Args a) 
     }
     {   // bias gradient: thread = (cout tid/8, column residue tid%8)
       const int co = tid >> 3, p8 = tid & 7;
+      const float* row = gimg + co * pitch + 1;
       float sum = 0.f;
-      for (int c = p8; c < 16 * a.nb; c += 8) sum += gimg[lds_off(c + 1, co >> 2) + (co & 3)];
+      for (int c = p8; c < 16 * a.nb; c += 8) sum += row[c];
       bacc += sum;
     }
   }
@@ -326,7 +366,7 @@ using namespace mural;
 extern "C" int mural_op_conv32_supported(int32_t L) { return (L + 2) <= C32_MAXCOLS ? 1 : 0; }
 
 // y = conv32(pre(x)) [+bias] [relu] [+res1 +res2]; W is the PyTorch [32][32][3] weight (dgrad != 0: input-gradient
-// filter, i.e. y = dL/dx for x = dL/dy).  stat_mode / stat_*: per-channel sums of the output taken in the epilogue
+// filter, i.e. y = dL/dx for x = dL/dy).  stat_mode / stat_*: per-channel sums of the output taken while it streams out
 // (see Conv32Args); stat_out: accumulator block double[MURAL_BN_SLOTS][2][32] zeroed by the caller.
 extern "C" int mural_op_conv32(const float* x, const float* W, const float* bias, float* y, int64_t B, int32_t L, int32_t dgrad,
                                const float* pre_s, const float* pre_t, int32_t pre_relu, int32_t post_relu, const float* res1,
@@ -337,15 +377,16 @@ extern "C" int mural_op_conv32(const float* x, const float* W, const float* bias
   Conv32Args a;
   std::memset(&a, 0, sizeof(a));
   MURAL_REQUIRE(tile_geometry((int)B, L, &a.R, &a.Sc, &a.NC, &a.nb), "conv32: L = %d does not fit the LDS tile", L);
-  MURAL_REQUIRE(stat_mode == 0 || stat_out, "conv32: stat_mode %d needs stat_out", stat_mode);
-  MURAL_REQUIRE(stat_mode != 2 || (stat_x && stat_mean && stat_invstd), "conv32: stat_mode 2 needs stat_x / mean / invstd");
+  MURAL_REQUIRE(stat_mode >= 0 && stat_mode <= 2 && (stat_mode == 0 || stat_out), "conv32: stat_mode %d needs stat_out", stat_mode);
+  MURAL_REQUIRE(stat_mode != 2 || (stat_x && stat_mean && stat_invstd && !res1 && !res2 && !bias && !post_relu),
+                "conv32: stat_mode 2 needs stat_x / mean / invstd and a plain convolution");
   a.x = x; a.y = y; a.W = W; a.dgrad = dgrad; a.bias = bias; a.pre_s = pre_s; a.pre_t = pre_t; a.res1 = res1; a.res2 = res2;
   a.pre_relu = pre_relu; a.post_relu = post_relu; a.B = (int)B; a.L = L;
   a.stat_mode = stat_mode; a.stat_relu = stat_relu; a.stat_x = stat_x; a.stat_mean = stat_mean; a.stat_invstd = stat_invstd;
   a.stat_out = stat_out;
   a.dSc = FastDiv::make((uint32_t)a.Sc);
   a.dL = FastDiv::make((uint32_t)L);
-  const size_t lds = (size_t)(16 * a.nb + 2) * C32 * 4 + 4 * C32 * 4;
+  const size_t lds = (size_t)(C32 * C32_PITCH + C32_AUX) * 4;
   const int64_t ntiles = (B + a.R - 1) / a.R;
   const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
   if (stat_mode == 0) hipLaunchKernelGGL(conv32_mfma_kernel<0>, dim3(grid), dim3(256), lds, stream, a);
@@ -368,11 +409,10 @@ extern "C" int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B,
   a.dy = dy; a.x = x; a.pre_s = pre_s; a.pre_t = pre_t; a.pre_relu = pre_relu; a.B = (int)B; a.L = L;
   a.dL = FastDiv::make((uint32_t)L);
   a.part = part;
-  a.img_floats = (16 * a.nb + 2) * C32;
   const int64_t ntiles = (B + a.R - 1) / a.R;
   const int grid = (int)(ntiles < 512 ? ntiles : 512);
   MURAL_REQUIRE(part && part_floats >= (size_t)grid * (C32 * C32 * 3 + C32), "conv32_wgrad: partial-sum scratch too small");
-  size_t lds = (size_t)2 * a.img_floats * 4 + 2 * C32 * 4;
+  size_t lds = (size_t)(2 * C32 * C32_PITCH + 2 * C32) * 4;
   const size_t lds_red = (size_t)4 * (C32 * C32 * 3 + C32) * 4;     // the in-workgroup reduction reuses the image space
   lds = lds > lds_red ? lds : lds_red;
   static bool attr_set = false;

@@ -270,8 +270,10 @@ class FeedForwardNN(_HipSnvBase):
             from . import train_ops as T
             cat_data, _ = self._train_inputs(cat_data, None)
             with torch.cuda.device(self._device()):
-                return T.local_forward(self, cat_data, self.output_layer, self.emb_dropout_layer.p,
-                                       [d.p for d in self.droput_layers])
+                out = T.local_forward(self, cat_data, self.output_layer, self.emb_dropout_layer.p,
+                                      [d.p for d in self.droput_layers])
+                T.flush_bn_ticks()
+                return out
         return self._forward_dense(cat_data, None)
 
 
@@ -323,6 +325,7 @@ class Network1(_HipSnvBase):
                 sym = T.dense_to_symbols(distal_input[:, 0:self.in_channels, :])
                 mid = T.tower_forward(self, "", sym, self.seq_len // 2 - 100, 201, POOLS_MID, self.distal_fc1[1].p)
                 large = T.tower_forward(self, "_2", sym, 0, self.seq_len, POOLS_LARGE, self.distal_fc2[1].p)
+                T.flush_bn_ticks()
                 return T.Head.apply(None, mid, large)
         return self._forward_dense(None, distal_input[:, 0:self.in_channels, :])
 
@@ -366,5 +369,6 @@ class Network2(_HipSnvBase):
                                       [d.p for d in self.droput_layers])
                 mid = T.tower_forward(self, "", sym, self.seq_len // 2 - 100, 201, POOLS_MID, self.distal_fc1[1].p)
                 large = T.tower_forward(self, "_2", sym, 0, self.seq_len, POOLS_LARGE, self.distal_fc2[1].p)
+                T.flush_bn_ticks()
                 return T.Head.apply(loc, mid, large)
         return self._forward_dense(cat_data, distal_input[:, 0:self.in_channels, :], taps=_taps)

@@ -44,10 +44,17 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
+_fn_cache = {}
+_Tensor = torch.Tensor
+
+
 def _call(name, *args):
-    fn = getattr(_lib.lib(), name)
-    conv = [a.data_ptr() if isinstance(a, torch.Tensor) else a for a in args]
-    _lib.check(fn(*conv))
+    fn = _fn_cache.get(name)
+    if fn is None:
+        fn = _fn_cache[name] = getattr(_lib.lib(), name)
+    rc = fn(*[a.data_ptr() if isinstance(a, _Tensor) else a for a in args])
+    if rc:
+        _lib.check(rc)
 
 
 def _stream(t):
@@ -55,7 +62,26 @@ def _stream(t):
 
 
 def _f32(t):
+    if t.dtype is torch.float32 and t.is_contiguous():
+        return t                      # only its data pointer is used
     return t.detach().to(torch.float32).contiguous()
+
+
+_bn_touched = []
+
+
+def _bn_tick(bn):
+    """nn.BatchNorm1d increments num_batches_tracked per training forward; the increments of one model forward are applied
+    together (flush_bn_ticks) instead of one tiny kernel per layer."""
+    _bn_touched.append(bn.num_batches_tracked)
+
+
+def flush_bn_ticks():
+    flush_input_checks()
+    if _bn_touched:
+        with torch.no_grad():
+            torch._foreach_add_(_bn_touched, 1)
+        _bn_touched.clear()
 
 
 class _BnState:
@@ -69,14 +95,10 @@ class _BnState:
         if acc is None:
             acc = _bn_acc(Cn, dev)
             _call("mural_op_bn_stats", x, B, Cn, L, int(relu), acc, st)
-        self.scale = torch.empty(Cn, device=dev)
-        self.shift = torch.empty(Cn, device=dev)
-        self.mean = torch.empty(Cn, device=dev)
-        self.invstd = torch.empty(Cn, device=dev)
+        self.scale, self.shift, self.mean, self.invstd = torch.empty((4, Cn), device=dev).unbind(0)
         _call("mural_op_bn_finalize", acc, float(B * L), Cn, _f32(bn.weight), _f32(bn.bias), EPS, MOMENTUM,
               bn.running_mean, bn.running_var, self.scale, self.shift, self.mean, self.invstd, st)
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
+        _bn_tick(bn)
 
 
 class BnConv(torch.autograd.Function):
@@ -230,8 +252,7 @@ class FirstLayerPool(torch.autograd.Function):
         arg = torch.empty(B * Cn * L2 * arg_bytes, dtype=torch.uint8, device=dev)
         _call("mural_op_first_fwd", sym, B, Lwin, col0, L1, Cn, pk, ps, pp, _f32(gamma), _f32(beta), _f32(weight), _f32(bias),
               EPS, MOMENTUM, bn.running_mean, bn.running_var, counts, tab, y, arg, _stream(sym))
-        with torch.no_grad():
-            bn.num_batches_tracked += 1
+        _bn_tick(bn)
         ctx.save_for_backward(sym, arg, tab, weight)
         ctx.dims = (col0, L1, pool)
         return y
@@ -349,16 +370,36 @@ class Head(torch.autograd.Function):
         return dloc, dmid, dlar
 
 
+_pending_checks = []
+_status_host = {}
+
+
 def dense_to_symbols(distal_x):
-    """(B, 4, L) MuRaL one-hot / IUPAC-fraction tensor -> (B, L) uint8 symbols; raises on anything else."""
+    """(B, 4, L) MuRaL one-hot / IUPAC-fraction tensor -> (B, L) uint8 symbols.  Anything else raises ValueError from
+    ``flush_input_checks`` (called by the model forward after its launches are enqueued: the host then waits for this early
+    kernel only instead of draining the device before the forward starts)."""
     x = distal_x.to(torch.float32).contiguous()
     B, _, L = x.shape
-    sym = torch.empty((B, L), dtype=torch.uint8, device=x.device)
-    status = torch.zeros(1, dtype=torch.int32, device=x.device)
+    dev = x.device
+    sym = torch.empty((B, L), dtype=torch.uint8, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
     _call("mural_op_dense_to_symbols", x, B, L, sym, status, _stream(x))
-    if int(status.item()) != 0:
-        raise ValueError("distal_input holds a column that is not a MuRaL one-hot / IUPAC-fraction encoding")
+    host = _status_host.get(dev)
+    if host is None:
+        host = _status_host[dev] = torch.zeros(1, dtype=torch.int32).pin_memory()
+    host.copy_(status, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    _pending_checks.append((ev, host))
     return sym
+
+
+def flush_input_checks():
+    while _pending_checks:
+        ev, host = _pending_checks.pop()
+        ev.synchronize()
+        if int(host[0]) != 0:
+            raise ValueError("distal_input holds a column that is not a MuRaL one-hot / IUPAC-fraction encoding")
 
 
 # ---------------------------------------------------------------------------------------------------------------
