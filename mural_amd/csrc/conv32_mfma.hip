@@ -14,6 +14,7 @@
 //             per-channel sums the next BatchNorm (forward) or this BatchNorm's backward needs.
 //   wgrad   : dW[cout][(tap, cin)] += dy[cout][col] * act[cin][col + tap - 1]: M = cout, N = (tap, cin) = 6 blocks of 16,
 //             K = columns in steps of 4; each wave reduces a quarter of the tile's columns into 12 accumulator tiles
+#include <cstdlib>
 #include <cstring>
 
 #include "mfma_tile.h"
@@ -353,6 +354,14 @@ static bool tile_geometry(int B, int L, int* R, int* Sc, int* NC, int* nb) {
   int r = (C32_MAXCOLS - 1) / *Sc;
   if (r < 1) return false;
   if (r > B) r = B;
+  // large batches of short rows: prefer >= 1024 tiles (4 per CU) over the tallest tile.  (The tile height only regroups
+  // the fp32 partial sums of the fused BatchNorm statistics: results differ in the last bits, nothing else.)
+  const int balanced = (B + 1023) / 1024;
+  if (B >= 1024 && r > balanced) r = balanced;
+  if (const char* e = getenv("MURAL_DEBUG_CONV32_R")) {   // debugging aid (tools/gpu_debug_train_diff.py)
+    const int v = atoi(e);
+    if (v >= 1 && v <= r) r = v;
+  }
   *R = r;
   *NC = 1 + r * *Sc;
   *nb = (*NC + 15) / 16;
