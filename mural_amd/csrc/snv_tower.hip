@@ -13,6 +13,7 @@
 //             Weights live in 48 VGPRs per lane per layer (A fragments, fetched from L2 in fragment order).
 //             The residual stream stays in registers in MFMA accumulator layout across a whole stage.
 //   head      global max, BN, Linear(32->n_class) per tower, then log(clamp((sm(local)+(sm(mid)+sm(large))/2)/2)).
+#include <cstdlib>
 #include <vector>
 
 #include "mfma_tile.h"
@@ -486,6 +487,10 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, hipStream_t s
   const int64_t n_tiles = (a.n + a.P - 1) / a.P;
   if (n_tiles == 0) return MURAL_OK;
   int grid = (int)(n_tiles < 2048 ? n_tiles : 2048);
+  if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) {   // diagnostic: e.g. 256 = one workgroup per CU (tools/phase_stamps.py)
+    const int v = atoi(e);
+    if (v >= 1 && v < grid) grid = v;
+  }
   static bool attr_set = false;
   if (!attr_set) {
     MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused),

@@ -26,8 +26,9 @@ with torch.no_grad():
     model.forward_packed(genome, pos, strand, 10, 3)
     torch.cuda.synchronize()
     _lib.check(_lib.lib().mural_debug_set_stamps(None))
-s = stamps.view(2048, 32).double().cpu()
-tiles_per_block = (32768 / 2) / 2048 * (B / 32768)
+s = stamps.view(2048, 32).double().cpu()[:int(os.environ.get("MURAL_DEBUG_TOWER_GRID", "2048"))]
+grid = int(os.environ.get("MURAL_DEBUG_TOWER_GRID", "2048"))
+tiles_per_block = (32768 / 2) / grid * (B / 32768)
 mean = s.mean(dim=0) / tiles_per_block
 names = {0: "decode", 25: "fc", 26: "head"}
 for tw, nm in ((0, "L"), (1, "M")):
