@@ -8,14 +8,22 @@
 
 namespace mural {
 
+// Activations on the hardware transcendental units (v_exp_f32 / v_log_f32 / v_rcp_f32, ~1 ulp each): the accurate libm forms
+// cost as many instructions per output as the 8-channel convolutions themselves.  Relative error ~1e-6, far inside the
+// 1e-4 / 1e-5 parity budget of the INDEL scores (tests/test_gpu_indel.py).
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_SILU: return v / (1.f + expf(-v));
-    case ACT_SOFTPLUS: return v > 20.f ? v : log1pf(expf(v));   // torch.nn.Softplus(beta=1, threshold=20)
+    case ACT_SILU: return __fdividef(v, 1.f + __expf(-v));
+    case ACT_SOFTPLUS: {                                        // torch.nn.Softplus(beta=1, threshold=20)
+      const float e = __expf(v);
+      return v > 20.f ? v : (v < -15.f ? e : __logf(1.f + e));  // log(1 + e) = e to fp32 precision below -15
+    }
     default: return v;
   }
 }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 template <int COG, int KT, bool WIDE>   // KT: compile-time tap count (0 = runtime a.K)
 // WIDE = false: workgroup = 64 output positions, the 4 waves share the output-channel groups;
@@ -52,12 +60,14 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
   const int l = l0 + lloc;
   const int ngroups = a.Cout / COG;
   for (int cg = WIDE ? 0 : wave; cg < ngroups; cg += WIDE ? 1 : 4) {
-    float acc[COG];
+    // two output channels per v_pk_fma_f32: the input value is broadcast to both halves, the weight pair is a scalar pair
+    f32x2 acc[COG / 2];
 #pragma unroll
-    for (int c = 0; c < COG; ++c) acc[c] = bias ? bias[cg * COG + c] : 0.f;
+    for (int c = 0; c < COG / 2; ++c)
+      acc[c] = bias ? f32x2{bias[cg * COG + 2 * c], bias[cg * COG + 2 * c + 1]} : f32x2{0.f, 0.f};
     const float* __restrict__ w = wt + cg * COG;
     const int K = KT ? KT : a.K;
-#pragma unroll 4
+#pragma unroll 2
     for (int ci = 0; ci < a.Cin; ++ci) {   // unrolled: several input channels' scalar weight loads in flight together
       const float* trow = tile + ci * TWp + lloc * a.stride;
       if (KT) {
@@ -67,15 +77,17 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           const float* __restrict__ wk = w + (size_t)(ci * KT + k) * a.Cout;   // wave-uniform address: scalar loads
+          const f32x2 x2 = {x[k], x[k]};
 #pragma unroll
-          for (int c = 0; c < COG; ++c) acc[c] = fmaf(x[k], wk[c], acc[c]);
+          for (int c = 0; c < COG / 2; ++c) acc[c] = __builtin_elementwise_fma(x2, f32x2{wk[2 * c], wk[2 * c + 1]}, acc[c]);
         }
       } else {
         for (int k = 0; k < K; ++k) {
           const float xv = trow[k];
+          const f32x2 x2 = {xv, xv};
           const float* __restrict__ wk = w + (size_t)(ci * K + k) * a.Cout;
 #pragma unroll
-          for (int c = 0; c < COG; ++c) acc[c] = fmaf(xv, wk[c], acc[c]);
+          for (int c = 0; c < COG / 2; ++c) acc[c] = __builtin_elementwise_fma(x2, f32x2{wk[2 * c], wk[2 * c + 1]}, acc[c]);
         }
       }
     }
@@ -83,7 +95,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
 #pragma unroll
       for (int c = 0; c < COG; ++c) {
         const size_t o = ((size_t)b * a.Cout + cg * COG + c) * a.Lout + l;
-        float v = apply_act(acc[c], a.act);
+        float v = apply_act((c & 1) ? acc[c >> 1].y : acc[c >> 1].x, a.act);
         if (a.res1) v += a.res1[o];
         if (a.res2) v += a.res2[o];
         a.out[o] = v;
@@ -92,23 +104,31 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
   }
 }
 
-template <bool WIDE>
-static void (*pick_kernel(int K, bool c8))(const Conv1dArgs, const float*, const float*) {
+using Conv1dFn = void (*)(const Conv1dArgs, const float*, const float*);
+
+template <int COG, bool WIDE>
+static Conv1dFn pick_taps(int K) {
   switch (K) {
-    case 1: return c8 ? conv1d_kernel<8, 1, WIDE> : conv1d_kernel<4, 1, WIDE>;
-    case 3: return c8 ? conv1d_kernel<8, 3, WIDE> : conv1d_kernel<4, 3, WIDE>;
-    case 5: return c8 ? conv1d_kernel<8, 5, WIDE> : conv1d_kernel<4, 5, WIDE>;
-    case 7: return c8 ? conv1d_kernel<8, 7, WIDE> : conv1d_kernel<4, 7, WIDE>;
-    default: return c8 ? conv1d_kernel<8, 0, WIDE> : conv1d_kernel<4, 0, WIDE>;
+    case 1: return conv1d_kernel<COG, 1, WIDE>;
+    case 3: return conv1d_kernel<COG, 3, WIDE>;
+    case 5: return conv1d_kernel<COG, 5, WIDE>;
+    case 7: return conv1d_kernel<COG, 7, WIDE>;
+    default: return conv1d_kernel<COG, 0, WIDE>;
   }
+}
+
+template <bool WIDE>
+static Conv1dFn pick_kernel(int K, int cog) {
+  return cog == 16 ? pick_taps<16, WIDE>(K) : (cog == 8 ? pick_taps<8, WIDE>(K) : pick_taps<4, WIDE>(K));
 }
 
 int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.Lout == 0) return MURAL_OK;
   MURAL_REQUIRE(a.Cout % 4 == 0, "conv1d: Cout must be a multiple of 4 (got %d)", a.Cout);
   MURAL_REQUIRE(a.up >= 1 && a.stride >= 1 && a.K >= 1, "conv1d: bad geometry");
-  const bool c8 = a.Cout % 8 == 0;
-  const int ngroups = a.Cout / (c8 ? 8 : 4);
+  // output channels per accumulator group: 16 halves the LDS reads per FMA (used when a wave still gets a group)
+  const int cog = (a.Cout % 16 == 0) ? 16 : (a.Cout % 8 == 0 ? 8 : 4);
+  const int ngroups = a.Cout / cog;
   const size_t lds_wide = (size_t)a.Cin * ((255 * a.stride + a.K) | 1) * sizeof(float);
   const bool wide = ngroups < 4 && lds_wide <= 64 * 1024 && a.Lout > 64;
   const int TWp = ((wide ? 255 : 63) * a.stride + a.K) | 1;
@@ -116,8 +136,7 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   MURAL_REQUIRE(lds <= 160 * 1024, "conv1d: input tile of %zu bytes exceeds LDS", lds);
   const int tlb = wide ? 256 : 64;
   const dim3 grid((a.Lout + tlb - 1) / tlb, a.B);
-  using KernelFn = void (*)(const Conv1dArgs, const float*, const float*);
-  KernelFn fn = wide ? pick_kernel<true>(a.K, c8) : pick_kernel<false>(a.K, c8);
+  Conv1dFn fn = wide ? pick_kernel<true>(a.K, cog) : pick_kernel<false>(a.K, cog);
   if (lds > 64 * 1024)
     MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         160 * 1024));

@@ -16,7 +16,7 @@ namespace {
 
 static_assert(sizeof(MuralIndelShape) > 0, "header");
 constexpr int INDEL_LEVELS = 6;
-constexpr int INDEL_CHUNK = 256;   // positions per pass of the layer program (bounds the activation scratch)
+constexpr int INDEL_CHUNK = 2048;   // positions per pass of the layer program (1.8 MB of activation scratch each: 3.8 GB)
 
 struct FoldedConv { size_t w, b; int Cin, Cout, K; };   // offsets into the blob; w laid out [Cin][K][Cout]
 

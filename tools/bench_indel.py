@@ -15,7 +15,7 @@ torch.manual_seed(0)
 model = model_choice(0, cfg, dict(n_class=8), "indel")
 model.apply(weights_init)
 model = model.cuda().eval()
-B = 256
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 codes = torch.randint(0, 4, (B, 8000), device="cuda")
 x = torch.nn.functional.one_hot(codes, 4).permute(0, 2, 1).float().contiguous()
 with torch.no_grad():
