@@ -27,6 +27,22 @@ struct Conv1dArgs {
 
 int launch_conv1d(const Conv1dArgs& a, hipStream_t stream);
 
+// Fused ConvBlock of the INDEL U-Net (reference MuRaL/model/model_indel.py:6-19, eval mode, BatchNorms folded):
+//   out = x + W1 . SiLU(W5 * x + b5) + b1 [+ res2],  W5: k=5 conv C -> 2C, W1: 1x1 conv 2C -> C.
+// The 2C-channel intermediate lives in registers only.
+struct ConvBlockArgs {
+  const float* x;        // [B][C][L]
+  const float* w5;       // [C][5][2C]
+  const float* b5;       // [2C]
+  const float* w1;       // [2C][C]
+  const float* b1;       // [C]
+  const float* res2;     // optional [B][C][L] (decoder: encoder skip)
+  float* out;            // [B][C][L]
+  int B, C, L;
+};
+bool convblock_supported(int C);
+int launch_convblock(const ConvBlockArgs& a, hipStream_t stream);
+
 // y[b][c] = max_l x[b][c][l]
 int launch_rowmax(const float* x, int64_t rows, int L, float* y, hipStream_t stream);
 

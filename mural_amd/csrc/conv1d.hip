@@ -145,6 +145,87 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   return MURAL_OK;
 }
 
+// ------------------------------------------------------------------------------------------------ fused ConvBlock
+// One workgroup = 256 consecutive positions of one batch row; a lane owns one position and ALL channels of it: the k=5
+// conv fills 2C accumulators from the LDS tile (weights as scalar pairs, v_pk_fma_f32), SiLU runs on them in place, the
+// 1x1 conv contracts them to C outputs, the block input is added back from the tile.  HBM traffic: read x, write out
+// (+ read res2) instead of also writing and re-reading the 2C-channel intermediate.
+template <int C>
+__global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
+                                                        const float* __restrict__ b5, const float* __restrict__ w1,
+                                                        const float* __restrict__ b1) {
+  constexpr int C2 = 2 * C, TW = 256 + 4, TWp = TW | 1;
+  __shared__ float tile[C * TWp];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.y;
+  const int l0 = blockIdx.x * 256;
+  const float* src = a.x + (size_t)b * C * a.L;
+  for (int i = tid; i < C * TW; i += 256) {
+    const int ci = i / TW, j = i - ci * TW;
+    const int l = l0 - 2 + j;
+    tile[ci * TWp + j] = (l >= 0 && l < a.L) ? src[(size_t)ci * a.L + l] : 0.f;
+  }
+  __syncthreads();
+  const int l = l0 + tid;
+  f32x2 h[C];                                  // 2C accumulators as pairs
+#pragma unroll
+  for (int j = 0; j < C; ++j) h[j] = f32x2{b5[2 * j], b5[2 * j + 1]};
+#pragma unroll 1
+  for (int ci = 0; ci < C; ++ci) {
+    const float* trow = tile + ci * TWp + tid;
+    float x[5];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) x[k] = trow[k];
+#pragma unroll
+    for (int k = 0; k < 5; ++k) {
+      const float* __restrict__ wk = w5 + (size_t)(ci * 5 + k) * C2;      // wave-uniform: scalar loads
+      const f32x2 x2 = {x[k], x[k]};
+#pragma unroll
+      for (int j = 0; j < C; ++j) h[j] = __builtin_elementwise_fma(x2, f32x2{wk[2 * j], wk[2 * j + 1]}, h[j]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < C; ++j) h[j] = f32x2{apply_act(h[j].x, ACT_SILU), apply_act(h[j].y, ACT_SILU)};
+  f32x2 o[C / 2];
+#pragma unroll
+  for (int c = 0; c < C / 2; ++c) o[c] = f32x2{b1[2 * c], b1[2 * c + 1]};
+#pragma unroll
+  for (int j = 0; j < C2; ++j) {
+    const float* __restrict__ wj = w1 + (size_t)j * C;
+    const float hv = (j & 1) ? h[j >> 1].y : h[j >> 1].x;
+    const f32x2 h2 = {hv, hv};
+#pragma unroll
+    for (int c = 0; c < C / 2; ++c) o[c] = __builtin_elementwise_fma(h2, f32x2{wj[2 * c], wj[2 * c + 1]}, o[c]);
+  }
+  if (l < a.L) {
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+      const size_t oi = ((size_t)b * C + c) * a.L + l;
+      float v = ((c & 1) ? o[c >> 1].y : o[c >> 1].x) + tile[c * TWp + tid + 2];
+      if (a.res2) v += a.res2[oi];
+      a.out[oi] = v;
+    }
+  }
+}
+
+bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24 || C == 32 || C == 40 || C == 48; }
+
+int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.L == 0) return MURAL_OK;
+  MURAL_REQUIRE(convblock_supported(a.C), "convblock: %d channels not instantiated", a.C);
+  const dim3 grid((a.L + 255) / 256, a.B);
+  switch (a.C) {
+    case 8: hipLaunchKernelGGL(convblock_kernel<8>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+    case 16: hipLaunchKernelGGL(convblock_kernel<16>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+    case 24: hipLaunchKernelGGL(convblock_kernel<24>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+    case 32: hipLaunchKernelGGL(convblock_kernel<32>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+    case 40: hipLaunchKernelGGL(convblock_kernel<40>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+    default: hipLaunchKernelGGL(convblock_kernel<48>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+  }
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
 // one wave per row: max over the row
 __global__ __launch_bounds__(256) void rowmax_kernel(const float* __restrict__ x, int64_t rows, int L, float* __restrict__ y) {
   const int lane = threadIdx.x & 63;

@@ -214,6 +214,21 @@ static int run_conv(const MuralIndelModel* m, const FoldedConv& f, const float* 
   return launch_conv1d(a, stream);
 }
 
+// ConvBlock: x + BN(1x1(SiLU(BN(k5(x))))) [+ skip]; fused kernel when instantiated for the channel count
+static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
+                     float* H, float* out, const float* skip, hipStream_t stream) {
+  // (a lane of the fused kernel owns one position: rows shorter than half a workgroup keep the per-layer kernels)
+  if (L >= 128 && convblock_supported(f5.Cin) && f5.K == 5 && f1.K == 1 && f5.Cout == 2 * f5.Cin && f1.Cout == f5.Cin) {
+    ConvBlockArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = x; a.w5 = m->blob + f5.w; a.b5 = m->blob + f5.b; a.w1 = m->blob + f1.w; a.b1 = m->blob + f1.b;
+    a.res2 = skip; a.out = out; a.B = B; a.C = f5.Cin; a.L = L;
+    return launch_convblock(a, stream);
+  }
+  if (int rc = run_conv(m, f5, x, B, L, H, L, 1, 1, ACT_SILU, nullptr, nullptr, stream)) return rc;
+  return run_conv(m, f1, H, B, L, out, L, 1, 1, ACT_NONE, x, skip, stream);
+}
+
 // Replaces UNet_Small.forward(distal_input) (model_indel.py:151-176): distal_x dev float [n][4][length] -> out
 // dev float [n][n_class] (positive Softplus scores; callers apply softmax / cross-entropy, run_predict.py:214).
 extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
@@ -257,8 +272,7 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     for (int i = 0; i < INDEL_LEVELS; ++i) {     // encoder: strided conv+BN, then ConvBlock (x + BN(1x1(SiLU(BN(k5)))))
       const int Li = m->len[i];
       if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
-      if ((rc = run_conv(m, m->up5[i], T1, B, Li, H, Li, 1, 1, ACT_SILU, nullptr, nullptr, stream))) return rc;
-      if ((rc = run_conv(m, m->up1[i], H, B, Li, E[i], Li, 1, 1, ACT_NONE, T1, nullptr, stream))) return rc;
+      if ((rc = run_block(m, m->up5[i], m->up1[i], T1, B, Li, H, E[i], nullptr, stream))) return rc;
       cur = E[i];
       Lcur = Li;
     }
@@ -267,8 +281,7 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
       const int lvl = INDEL_LEVELS - 2 - j;
       const int Li = m->len[lvl];
       if ((rc = run_conv(m, m->dn_l[j], cur, B, Lcur, T1, Li, 1, sh.down[lvl + 1], ACT_NONE, nullptr, nullptr, stream))) return rc;
-      if ((rc = run_conv(m, m->dn5[j], T1, B, Li, H, Li, 1, 1, ACT_SILU, nullptr, nullptr, stream))) return rc;
-      if ((rc = run_conv(m, m->dn1[j], H, B, Li, dec, Li, 1, 1, ACT_NONE, T1, E[lvl], stream))) return rc;
+      if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream))) return rc;
       cur = dec;
       Lcur = Li;
       dec = (cur == T2) ? SP : T2;   // ping-pong between two level-0-sized buffers
