@@ -37,8 +37,15 @@ struct ConvBlockArgs {
   const float* w1;       // [2C][C]
   const float* b1;       // [C]
   const float* res2;     // optional [B][C][L] (decoder: encoder skip)
-  float* out;            // [B][C][L]
+  float* out;            // [B][C][L] (unused with a tail)
   int B, C, L;
+  // optional tail (model_indel.py:172-175): max over positions of Softplus(W_b . ReLU(W_a . out + b_a) + b_b), both 1x1 convs
+  // C -> C with weights [Cin][Cout]; tail_max: [B][C], zeroed by the caller (the scores are positive: integer atomic max)
+  const float* ta_w;
+  const float* ta_b;
+  const float* tb_w;
+  const float* tb_b;
+  float* tail_max;
 };
 bool convblock_supported(int C);
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream);

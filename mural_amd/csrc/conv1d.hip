@@ -150,10 +150,12 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
 // conv fills 2C accumulators from the LDS tile (weights as scalar pairs, v_pk_fma_f32), SiLU runs on them in place, the
 // 1x1 conv contracts them to C outputs, the block input is added back from the tile.  HBM traffic: read x, write out
 // (+ read res2) instead of also writing and re-reading the 2C-channel intermediate.
-template <int C>
+template <int C, bool TAIL>
 __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
                                                         const float* __restrict__ b5, const float* __restrict__ w1,
-                                                        const float* __restrict__ b1) {
+                                                        const float* __restrict__ b1, const float* __restrict__ ta_w,
+                                                        const float* __restrict__ ta_b, const float* __restrict__ tb_w,
+                                                        const float* __restrict__ tb_b) {
   constexpr int C2 = 2 * C, TW = 256 + 4, TWp = TW | 1;
   __shared__ float tile[C * TWp];
   const int tid = threadIdx.x;
@@ -197,30 +199,76 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
 #pragma unroll
     for (int c = 0; c < C / 2; ++c) o[c] = __builtin_elementwise_fma(h2, f32x2{wj[2 * c], wj[2 * c + 1]}, o[c]);
   }
-  if (l < a.L) {
+  float v[C];
 #pragma unroll
-    for (int c = 0; c < C; ++c) {
-      const size_t oi = ((size_t)b * C + c) * a.L + l;
-      float v = ((c & 1) ? o[c >> 1].y : o[c >> 1].x) + tile[c * TWp + tid + 2];
-      if (a.res2) v += a.res2[oi];
-      a.out[oi] = v;
+  for (int c = 0; c < C; ++c) {
+    v[c] = ((c & 1) ? o[c >> 1].y : o[c >> 1].x) + tile[c * TWp + tid + 2];
+    if (a.res2 && l < a.L) v[c] += a.res2[((size_t)b * C + c) * a.L + l];
+  }
+  if (!TAIL) {
+    if (l < a.L) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) a.out[((size_t)b * C + c) * a.L + l] = v[c];
     }
+    return;
+  }
+  // tail: two 1x1 convs on the lane's own position, then the maximum over the row's positions
+  f32x2 t[C / 2];
+#pragma unroll
+  for (int c = 0; c < C / 2; ++c) t[c] = f32x2{ta_b[2 * c], ta_b[2 * c + 1]};
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const f32x2 v2 = {v[j], v[j]};
+#pragma unroll
+    for (int c = 0; c < C / 2; ++c) t[c] = __builtin_elementwise_fma(v2, f32x2{ta_w[j * C + 2 * c], ta_w[j * C + 2 * c + 1]}, t[c]);
+  }
+  f32x2 u[C / 2];
+#pragma unroll
+  for (int c = 0; c < C / 2; ++c) u[c] = f32x2{tb_b[2 * c], tb_b[2 * c + 1]};
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    const float r = fmaxf((j & 1) ? t[j >> 1].y : t[j >> 1].x, 0.f);
+    const f32x2 r2 = {r, r};
+#pragma unroll
+    for (int c = 0; c < C / 2; ++c) u[c] = __builtin_elementwise_fma(r2, f32x2{tb_w[j * C + 2 * c], tb_w[j * C + 2 * c + 1]}, u[c]);
+  }
+#pragma unroll
+  for (int c = 0; c < C; ++c) {
+    float sp = apply_act((c & 1) ? u[c >> 1].y : u[c >> 1].x, ACT_SOFTPLUS);
+    if (l >= a.L) sp = 0.f;                    // Softplus > 0: 0 is the identity of the maximum
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sp = fmaxf(sp, __shfl_xor(sp, off));
+    if ((tid & 63) == 0) atomicMax(reinterpret_cast<int*>(a.tail_max + (size_t)b * C + c), __float_as_int(sp));
   }
 }
 
 bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24 || C == 32 || C == 40 || C == 48; }
 
+template <bool TAIL>
+static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
+  const dim3 grid((a.L + 255) / 256, a.B);
+#define MURAL_CB(CN)                                                                                                        \
+  hipLaunchKernelGGL((convblock_kernel<CN, TAIL>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, a.tb_w, \
+                     a.tb_b)
+  switch (a.C) {
+    case 8: MURAL_CB(8); break;
+    case 16: MURAL_CB(16); break;
+    case 24: MURAL_CB(24); break;
+    case 32: MURAL_CB(32); break;
+    case 40: MURAL_CB(40); break;
+    default: MURAL_CB(48); break;
+  }
+#undef MURAL_CB
+}
+
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.L == 0) return MURAL_OK;
   MURAL_REQUIRE(convblock_supported(a.C), "convblock: %d channels not instantiated", a.C);
-  const dim3 grid((a.L + 255) / 256, a.B);
-  switch (a.C) {
-    case 8: hipLaunchKernelGGL(convblock_kernel<8>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
-    case 16: hipLaunchKernelGGL(convblock_kernel<16>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
-    case 24: hipLaunchKernelGGL(convblock_kernel<24>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
-    case 32: hipLaunchKernelGGL(convblock_kernel<32>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
-    case 40: hipLaunchKernelGGL(convblock_kernel<40>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
-    default: hipLaunchKernelGGL(convblock_kernel<48>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+  if (a.tail_max) {
+    MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
+    launch_convblock_t<true>(a, stream);
+  } else {
+    launch_convblock_t<false>(a, stream);
   }
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;

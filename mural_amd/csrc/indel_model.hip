@@ -215,16 +215,25 @@ static int run_conv(const MuralIndelModel* m, const FoldedConv& f, const float* 
 }
 
 // ConvBlock: x + BN(1x1(SiLU(BN(k5(x))))) [+ skip]; fused kernel when instantiated for the channel count
-static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
-                     float* H, float* out, const float* skip, hipStream_t stream) {
+static bool block_fusable(const FoldedConv& f5, const FoldedConv& f1, int L) {
   // (a lane of the fused kernel owns one position: rows shorter than half a workgroup keep the per-layer kernels)
-  if (L >= 128 && convblock_supported(f5.Cin) && f5.K == 5 && f1.K == 1 && f5.Cout == 2 * f5.Cin && f1.Cout == f5.Cin) {
+  return L >= 128 && convblock_supported(f5.Cin) && f5.K == 5 && f1.K == 1 && f5.Cout == 2 * f5.Cin && f1.Cout == f5.Cin;
+}
+
+static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
+                     float* H, float* out, const float* skip, hipStream_t stream, float* tail_max = nullptr) {
+  if (block_fusable(f5, f1, L)) {
     ConvBlockArgs a;
     std::memset(&a, 0, sizeof(a));
     a.x = x; a.w5 = m->blob + f5.w; a.b5 = m->blob + f5.b; a.w1 = m->blob + f1.w; a.b1 = m->blob + f1.b;
     a.res2 = skip; a.out = out; a.B = B; a.C = f5.Cin; a.L = L;
+    if (tail_max) {   // out_conv (1x1, BN, ReLU, 1x1, Softplus) + max over positions ride on the last decoder block
+      a.ta_w = m->blob + m->out1.w; a.ta_b = m->blob + m->out1.b; a.tb_w = m->blob + m->out2.w; a.tb_b = m->blob + m->out2.b;
+      a.tail_max = tail_max;
+    }
     return launch_convblock(a, stream);
   }
+  MURAL_REQUIRE(!tail_max, "internal: tail fusion requested for an unfusable block");
   if (int rc = run_conv(m, f5, x, B, L, H, L, 1, 1, ACT_SILU, nullptr, nullptr, stream)) return rc;
   return run_conv(m, f1, H, B, L, out, L, 1, 1, ACT_NONE, x, skip, stream);
 }
@@ -277,19 +286,25 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
       Lcur = Li;
     }
     float* dec = T2;
+    bool tail_done = false;
     for (int j = 0; j < INDEL_LEVELS - 1; ++j) {   // decoder: upsample, conv+BN, ConvBlock, + encoder skip
       const int lvl = INDEL_LEVELS - 2 - j;
       const int Li = m->len[lvl];
       if ((rc = run_conv(m, m->dn_l[j], cur, B, Lcur, T1, Li, 1, sh.down[lvl + 1], ACT_NONE, nullptr, nullptr, stream))) return rc;
-      if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream))) return rc;
+      const bool fuse_tail = lvl == 0 && block_fusable(m->dn5[j], m->dn1[j], Li);
+      if (fuse_tail) MURAL_HIP_CHECK(hipMemsetAsync(M, 0, (size_t)B * C0 * sizeof(float), stream));
+      if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr))) return rc;
+      tail_done = fuse_tail;
       cur = dec;
       Lcur = Li;
       dec = (cur == T2) ? SP : T2;   // ping-pong between two level-0-sized buffers
     }
-    if ((rc = run_conv(m, m->out1, cur, B, Lcur, H, Lcur, 1, 1, ACT_RELU, nullptr, nullptr, stream))) return rc;
-    float* sp = (cur == SP) ? T2 : SP;
-    if ((rc = run_conv(m, m->out2, H, B, Lcur, sp, Lcur, 1, 1, ACT_SOFTPLUS, nullptr, nullptr, stream))) return rc;
-    if ((rc = launch_rowmax(sp, (int64_t)B * C0, Lcur, M, stream))) return rc;
+    if (!tail_done) {
+      if ((rc = run_conv(m, m->out1, cur, B, Lcur, H, Lcur, 1, 1, ACT_RELU, nullptr, nullptr, stream))) return rc;
+      float* sp = (cur == SP) ? T2 : SP;
+      if ((rc = run_conv(m, m->out2, H, B, Lcur, sp, Lcur, 1, 1, ACT_SOFTPLUS, nullptr, nullptr, stream))) return rc;
+      if ((rc = launch_rowmax(sp, (int64_t)B * C0, Lcur, M, stream))) return rc;
+    }
     const int64_t total = (int64_t)B * sh.n_class;
     hipLaunchKernelGGL(indel_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, M, (int64_t)B, C0,
                        sh.n_class, m->blob + m->fc_w, m->blob + m->fc_b, out + c0 * sh.n_class);
