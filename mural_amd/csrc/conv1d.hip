@@ -14,7 +14,7 @@ namespace mural {
 __device__ __forceinline__ float apply_act(float v, int act) {
   switch (act) {
     case ACT_RELU: return fmaxf(v, 0.f);
-    case ACT_SILU: return __fdividef(v, 1.f + __expf(-v));
+    case ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
     case ACT_SOFTPLUS: {                                        // torch.nn.Softplus(beta=1, threshold=20)
       const float e = __expf(v);
       return v > 20.f ? v : (v < -15.f ? e : __logf(1.f + e));  // log(1 + e) = e to fp32 precision below -15
