@@ -14,7 +14,7 @@ cross-position reuse.  N>1: ranks take disjoint site shards (weak scaling) and e
 all_gather of the (batch, 4) fp32 log-probabilities.
 
 Extra objects on the JSON line: ``train`` (N=1: steps/s of the S-config training step at batch 4096, BASELINE.json
-configs[2], measured after the timed prediction region); ``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch of the
+configs[2], measured after the timed prediction region); ``indel`` (N=1: UNet_Small positions/s, configs[3]); ``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch of the
 layers it evaluates / HIP-event duration of that kernel measured live in the timed region, vs the 157.3 TFLOP/s fp32
 MFMA peak) and
 ``cpu_baseline`` (oracle = PyTorch-CPU restatement of the reference, timed on this box's host cores on a bounded
@@ -111,7 +111,7 @@ def cpu_baseline(model_state, codes, budget_s=12.0, batch=256):
                       f"{it} timed iterations after warm-up, best of 8/16/32/64 torch threads on {ncpu} host CPUs"}
 
 
-def train_steps_per_s(device, genome, B=4096, steps=8, warmup=3):
+def train_steps_per_s(device, genome, B=4096, steps=30, warmup=5):
     """BASELINE.json configs[2]: S-config from scratch, batch 4096, Adam lr 1e-3, CE-sum, clip 10, default dropouts."""
     import torch.nn as nn
     model = build_model(device).train()
@@ -141,6 +141,28 @@ def train_steps_per_s(device, genome, B=4096, steps=8, warmup=3):
             "inputs already encoded on the device; median of %d steps after %d warm-up" % (steps, warmup)}
 
 
+def indel_positions_per_s(device, genome, n=4096):
+    """BASELINE.json configs[3]: UNet_Small, human-insertion geometry (L=8000, 8 classes, use_reverse), packed input."""
+    from mural_amd.model import model_choice, weights_init
+    cfg = dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=[1, 4, 5, 5, 5, 2], use_reverse=True)
+    torch.manual_seed(0)
+    model = model_choice(0, cfg, dict(n_class=8), "indel")
+    model.apply(weights_init)
+    model = model.to(device).eval()
+    idx = torch.arange(n, device=device, dtype=torch.int64)
+    pos, strand = idx * 100 + 4000, (idx & 1).to(torch.uint8)
+    with torch.no_grad():
+        model.forward_packed(genome, pos, strand, 4000)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            model.forward_packed(genome, pos, strand, 4000)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 3
+    return {"positions_per_s": n / dt, "positions": n, "window": 8000, "n_class": 8, "algorithmic_TFLOPs": n / dt * 113.4e6 / 1e12,
+            "note": "weights_init, window decode from the packed genome inside the timed region; 113.4 MFLOP/position"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -148,7 +170,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=500_000, help="sites per rank per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train", action="store_true", help="skip the short train-steps/s measurement (N=1 only)")
+    ap.add_argument("--no-train", action="store_true", help="skip the short train-steps/s and INDEL measurements (N=1 only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -252,6 +274,7 @@ def main():
         }
         if world == 1 and not args.no_train:
             line["train"] = train_steps_per_s(device, genome)
+            line["indel"] = indel_positions_per_s(device, genome)
         if world == 1 and not args.no_cpu_baseline:
             state = {k: v.detach().cpu() for k, v in model.state_dict().items()}
             line["cpu_baseline"] = cpu_baseline(state, codes)
