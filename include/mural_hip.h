@@ -254,6 +254,28 @@ int mural_debug_set_stamps(void* dev_ptr);
 int mural_profile_begin(void);
 int mural_profile_end(double* total_ms, int64_t* launches);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Host-side ingest (no device work): FASTA -> packed genome, BED -> site arrays, bed_reader row order.
+ * Replaces SeqIO.to_dict(SeqIO.parse(...)) (MuRaL/data/preprocessing.py:836), bed_reader (:39-106) and the base maps of
+ * the per-character encoders (:655-666, :762-772) for the packed-genome path.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* names: n_cap x name_cap chars (record id = text after '>' up to the first whitespace); lengths / offsets per record
+ * (offset = byte offset of the first sequence line).  n_records = records in the file (may exceed n_cap).           */
+int mural_fasta_scan(const char* path, int64_t n_cap, int32_t name_cap, char* names, int64_t* lengths,
+                     int64_t* offsets, int64_t* n_records);
+/* Pack one record into the MuralGenome format; amb_pos receives the positions of IUPAC codes other than N (n_amb
+ * counts all of them); any non-nucleotide character is MURAL_E_INVALID (the reference raises KeyError).             */
+int mural_fasta_pack(const char* path, int64_t offset, int64_t length, uint32_t* packed2, uint32_t* nmask,
+                     int64_t* amb_pos, int64_t amb_cap, int64_t* n_amb);
+/* Six-column BED (chrom start end name score strand); chrom_id indexes chrom_names (order of first appearance);
+ * strand: 0 '+', 1 '-'; score = class label.  cap = 0 counts rows / chromosomes.                                    */
+int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, int64_t* start, int64_t* end, float* score,
+                   uint8_t* strand, int32_t n_chrom_cap, int32_t name_cap, char* chrom_names, int64_t* n_rows,
+                   int32_t* n_chroms);
+/* order[k] = input row of output row k in bed_reader order (+ rows, then - rows of every central_bp-wide segment)    */
+int mural_bed_segment_order(const int32_t* chrom_id, const int64_t* start, const uint8_t* strand, int64_t n,
+                            int64_t central_bp, int64_t* order, int64_t* group, int64_t* n_groups);
+
 #ifdef __cplusplus
 }
 #endif

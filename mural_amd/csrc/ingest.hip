@@ -1,0 +1,304 @@
+// Host-side ingest for the packed-genome path: FASTA -> 2-bit + non-ACGT mask, BED -> site arrays, and the reference's
+// segment / strand row order.  Counterparts in the reference (pure Python, >99 % of its wall time on real inputs):
+//   SeqIO.to_dict(SeqIO.parse(ref_genome, 'fasta'))      MuRaL/data/preprocessing.py:836
+//   bed_reader                                            MuRaL/data/preprocessing.py:39-106
+//   the base maps of seq_digit_encoder / seq_ohe_encoder  MuRaL/data/preprocessing.py:655-666, :762-772
+// No device code here: the arrays produced feed mural_encode_* / mural_snv_forward_packed (include/mural_hip.h).
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <cctype>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "common.h"
+
+namespace {
+
+struct MappedFile {
+  const char* data = nullptr;
+  size_t size = 0;
+  int fd = -1;
+  bool open(const char* path) {
+    fd = ::open(path, O_RDONLY);
+    if (fd < 0) return false;
+    struct stat st;
+    if (fstat(fd, &st) != 0) return false;
+    size = (size_t)st.st_size;
+    if (size == 0) return true;
+    void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
+    if (p == MAP_FAILED) return false;
+    data = static_cast<const char*>(p);
+    madvise(p, size, MADV_SEQUENTIAL);
+    return true;
+  }
+  ~MappedFile() {
+    if (data) munmap(const_cast<char*>(data), size);
+    if (fd >= 0) ::close(fd);
+  }
+};
+
+// 0..3 = A C G T (either case), 4 = N, 5 = other IUPAC ambiguity code, 255 = not a nucleotide character
+struct BaseTable {
+  uint8_t t[256];
+  BaseTable() {
+    std::memset(t, 255, sizeof(t));
+    const char* acgt = "ACGT";
+    for (int i = 0; i < 4; ++i) {
+      t[(unsigned char)acgt[i]] = (uint8_t)i;
+      t[(unsigned char)std::tolower(acgt[i])] = (uint8_t)i;
+    }
+    const char* amb = "NRYMSWKBDHV";
+    for (const char* p = amb; *p; ++p) {
+      const uint8_t v = (*p == 'N') ? 4 : 5;
+      t[(unsigned char)*p] = v;
+      t[(unsigned char)std::tolower(*p)] = v;
+    }
+  }
+};
+const BaseTable kBase;
+
+inline const char* line_end(const char* p, const char* end) {
+  const void* q = std::memchr(p, '\n', (size_t)(end - p));
+  return q ? static_cast<const char*>(q) : end;
+}
+
+}  // namespace
+
+using namespace mural;
+
+// Scan a FASTA file: record names (text after '>' up to the first whitespace, like Bio.SeqIO ids), sequence lengths
+// (whitespace stripped) and the byte offset of each record's first sequence line.  names: n_cap x name_cap chars, NUL-terminated.
+extern "C" int mural_fasta_scan(const char* path, int64_t n_cap, int32_t name_cap, char* names, int64_t* lengths,
+                                int64_t* offsets, int64_t* n_records) {
+  MURAL_REQUIRE(path && n_records, "NULL argument");
+  MappedFile f;
+  if (!f.open(path)) {
+    set_error("cannot open FASTA file %s", path);
+    return MURAL_E_INVALID;
+  }
+  const char* p = f.data;
+  const char* end = f.data + f.size;
+  int64_t n = 0, cur_len = 0;
+  bool in_record = false;
+  while (p < end) {
+    const char* e = line_end(p, end);
+    if (*p == '>') {
+      if (in_record && n <= n_cap && lengths) lengths[n - 1] = cur_len;
+      ++n;
+      in_record = true;
+      cur_len = 0;
+      if (n <= n_cap) {
+        if (names) {
+          const char* q = p + 1;
+          int k = 0;
+          while (q < e && !std::isspace((unsigned char)*q) && k + 1 < name_cap) names[(n - 1) * (int64_t)name_cap + k++] = *q++;
+          names[(n - 1) * (int64_t)name_cap + k] = '\0';
+        }
+        if (offsets) offsets[n - 1] = (int64_t)((e < end ? e + 1 : end) - f.data);
+      }
+    } else if (in_record) {
+      for (const char* q = p; q < e; ++q)
+        if (!std::isspace((unsigned char)*q)) ++cur_len;
+    } else {
+      for (const char* q = p; q < e; ++q)
+        if (!std::isspace((unsigned char)*q)) {
+          set_error("%s: sequence data before the first '>' header", path);
+          return MURAL_E_INVALID;
+        }
+    }
+    p = e < end ? e + 1 : end;
+  }
+  if (in_record && n <= n_cap && lengths) lengths[n - 1] = cur_len;
+  *n_records = n;
+  return MURAL_OK;
+}
+
+// Pack one record (starting at byte `offset`, `length` bases) into the device format of include/mural_hip.h:
+// packed2: ceil(length/16) words (A0 C1 G2 T3, 2 bits per base), nmask: ceil(length/32) words (bit set = not ACGT).
+// Positions of IUPAC codes other than N are reported in amb_pos (up to amb_cap; n_amb counts all of them): windows that
+// overlap them need the dense encoders (fractional one-hot columns).  Any other character is an error, like the
+// reference's dict lookups (KeyError).
+extern "C" int mural_fasta_pack(const char* path, int64_t offset, int64_t length, uint32_t* packed2, uint32_t* nmask,
+                                int64_t* amb_pos, int64_t amb_cap, int64_t* n_amb) {
+  MURAL_REQUIRE(path && packed2 && nmask, "NULL argument");
+  MappedFile f;
+  if (!f.open(path)) {
+    set_error("cannot open FASTA file %s", path);
+    return MURAL_E_INVALID;
+  }
+  MURAL_REQUIRE(offset >= 0 && (size_t)offset <= f.size, "record offset outside the file");
+  std::memset(packed2, 0, (size_t)((length + 15) / 16) * 4);
+  std::memset(nmask, 0, (size_t)((length + 31) / 32) * 4);
+  const char* p = f.data + offset;
+  const char* end = f.data + f.size;
+  int64_t i = 0, amb = 0;
+  for (; p < end && *p != '>'; ++p) {
+    const unsigned char ch = (unsigned char)*p;
+    if (std::isspace(ch)) continue;
+    const uint8_t code = kBase.t[ch];
+    if (code == 255) {
+      set_error("%s: character '%c' at base %lld is not a nucleotide code", path, ch, (long long)i);
+      return MURAL_E_INVALID;
+    }
+    if (i >= length) {
+      set_error("%s: record holds more than the %lld bases announced by the scan", path, (long long)length);
+      return MURAL_E_INVALID;
+    }
+    if (code < 4) {
+      packed2[i >> 4] |= (uint32_t)code << (2 * (i & 15));
+    } else {
+      nmask[i >> 5] |= 1u << (i & 31);
+      if (code == 5) {
+        if (amb_pos && amb < amb_cap) amb_pos[amb] = i;
+        ++amb;
+      }
+    }
+    ++i;
+  }
+  if (i != length) {
+    set_error("%s: record holds %lld bases, the scan announced %lld", path, (long long)i, (long long)length);
+    return MURAL_E_INVALID;
+  }
+  if (n_amb) *n_amb = amb;
+  return MURAL_OK;
+}
+
+// Read a BED file with the reference's six columns (chrom, start, end, name, score = class label, strand).  Chromosome
+// names are interned in order of first appearance: chrom_id indexes `chrom_names` (n_chrom_cap x name_cap).  Call with
+// cap = 0 to count rows and chromosomes first.  Header / track / comment lines are skipped like pybedtools does.
+extern "C" int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, int64_t* start, int64_t* end_, float* score,
+                              uint8_t* strand, int32_t n_chrom_cap, int32_t name_cap, char* chrom_names, int64_t* n_rows,
+                              int32_t* n_chroms) {
+  MURAL_REQUIRE(path && n_rows && n_chroms, "NULL argument");
+  MappedFile f;
+  if (!f.open(path)) {
+    set_error("cannot open BED file %s", path);
+    return MURAL_E_INVALID;
+  }
+  std::vector<std::string> chroms;
+  const char* p = f.data;
+  const char* end = f.data + f.size;
+  int64_t n = 0, line_no = 0;
+  while (p < end) {
+    const char* e = line_end(p, end);
+    ++line_no;
+    const char* le = e;
+    while (le > p && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;
+    const size_t len = (size_t)(le - p);
+    const bool skip = len == 0 || *p == '#' || (len >= 5 && !std::strncmp(p, "track", 5)) || (len >= 7 && !std::strncmp(p, "browser", 7));
+    if (!skip) {
+      const char* fld[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+      size_t flen[6] = {0, 0, 0, 0, 0, 0};
+      int nf = 0;
+      const char* q = p;
+      while (q <= le && nf < 6) {
+        const char* t = q;
+        while (t < le && *t != '\t') ++t;
+        fld[nf] = q;
+        flen[nf] = (size_t)(t - q);
+        ++nf;
+        q = t + 1;
+      }
+      if (nf < 6) {
+        set_error("%s:%lld: expected 6 tab-separated BED columns (chrom start end name score strand), got %d", path,
+                  (long long)line_no, nf);
+        return MURAL_E_INVALID;
+      }
+      char* stop = nullptr;
+      const long long s = std::strtoll(fld[1], &stop, 10);
+      const bool s_ok = stop == fld[1] + flen[1] && flen[1] > 0;
+      const long long t2 = std::strtoll(fld[2], &stop, 10);
+      const bool e_ok = stop == fld[2] + flen[2] && flen[2] > 0;
+      const float sc = std::strtof(fld[4], &stop);
+      const bool c_ok = stop == fld[4] + flen[4] && flen[4] > 0;
+      const bool st_ok = flen[5] == 1 && (fld[5][0] == '+' || fld[5][0] == '-');
+      if (!s_ok || !e_ok || !c_ok || !st_ok || s < 0 || t2 < s) {
+        set_error("%s:%lld: malformed BED row", path, (long long)line_no);
+        return MURAL_E_INVALID;
+      }
+      const std::string name(fld[0], flen[0]);
+      int cid = -1;
+      if (!chroms.empty() && chroms.back() == name) cid = (int)chroms.size() - 1;   // sorted files: same as the previous row
+      for (int k = 0; cid < 0 && k < (int)chroms.size(); ++k)
+        if (chroms[k] == name) cid = k;
+      if (cid < 0) {
+        cid = (int)chroms.size();
+        chroms.push_back(name);
+      }
+      if (n < cap) {
+        if (chrom_id) chrom_id[n] = cid;
+        if (start) start[n] = s;
+        if (end_) end_[n] = t2;
+        if (score) score[n] = sc;
+        if (strand) strand[n] = fld[5][0] == '-' ? 1 : 0;
+      }
+      ++n;
+    }
+    p = e < end ? e + 1 : end;
+  }
+  *n_rows = n;
+  *n_chroms = (int32_t)chroms.size();
+  if (chrom_names)
+    for (int k = 0; k < (int)chroms.size() && k < n_chrom_cap; ++k) {
+      std::strncpy(chrom_names + (int64_t)k * name_cap, chroms[k].c_str(), (size_t)name_cap - 1);
+      chrom_names[(int64_t)k * name_cap + name_cap - 1] = '\0';
+    }
+  return MURAL_OK;
+}
+
+// Row order of bed_reader (preprocessing.py:39-106) for rows in file order: sites are cut into central_bp-wide segments
+// along each chromosome (the first chromosome's grid starts at its first site, later ones at 1), and every segment
+// yields its '+' rows, then its '-' rows.  order[k] = input row of output row k; group[k] = index of the yielded group.
+extern "C" int mural_bed_segment_order(const int32_t* chrom_id, const int64_t* start, const uint8_t* strand, int64_t n,
+                                       int64_t central_bp, int64_t* order, int64_t* group, int64_t* n_groups) {
+  MURAL_REQUIRE(n == 0 || (chrom_id && start && strand && order), "NULL argument");
+  MURAL_REQUIRE(central_bp >= 1, "central_bp must be positive");
+  std::vector<int64_t> pos_rows, neg_rows;
+  int64_t out = 0, g = 0;
+  auto flush = [&]() {
+    if (!pos_rows.empty()) {
+      for (int64_t r : pos_rows) {
+        order[out] = r;
+        if (group) group[out] = g;
+        ++out;
+      }
+      ++g;
+      pos_rows.clear();
+    }
+    if (!neg_rows.empty()) {
+      for (int64_t r : neg_rows) {
+        order[out] = r;
+        if (group) group[out] = g;
+        ++out;
+      }
+      ++g;
+      neg_rows.clear();
+    }
+  };
+  int32_t cur = -1;
+  int64_t end0 = 0;
+  for (int64_t i = 0; i < n; ++i) {
+    if (i == 0) {
+      cur = chrom_id[0];
+      end0 = start[0] + central_bp;
+    }
+    if (chrom_id[i] != cur) {
+      flush();
+      cur = chrom_id[i];
+      end0 = 1 + central_bp;
+    }
+    if (start[i] > end0) {
+      flush();
+      while (start[i] > end0) end0 += central_bp;
+    }
+    (strand[i] ? neg_rows : pos_rows).push_back(i);
+  }
+  flush();
+  if (n_groups) *n_groups = g;
+  return MURAL_OK;
+}

@@ -1,0 +1,159 @@
+"""FASTA / BED ingest for the packed-genome path (host side, C++ in csrc/ingest.hip) and a file-level predict helper.
+
+Counterparts in the reference: ``SeqIO.to_dict(SeqIO.parse(ref_genome, 'fasta'))`` (MuRaL/data/preprocessing.py:836),
+``bed_reader`` (:39-106), the per-batch focal-base consistency check (:479-484) and the prediction loop of
+MuRaL/scripts/run_predict.py:188-239.  The reference spends >99 % of its wall time in per-character Python encoders
+here; this path packs each chromosome once (2 bits per base + non-ACGT mask), keeps it in HBM and decodes windows inside
+the kernels.  Rows come out in ``bed_reader`` order (per ``segment_center``-wide segment: '+' rows, then '-' rows), which
+is the order the reference's DataLoader and its prediction table use before the final sort.
+"""
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+import torch
+
+from .. import _lib
+from .genome import PackedGenome
+
+_NAME = 256
+
+
+@dataclass
+class FastaRecord:
+    name: str
+    length: int
+    offset: int
+
+
+def scan_fasta(path):
+    """List the records of a FASTA file without decoding them."""
+    path = os.fspath(path)
+    n = C.c_int64(0)
+    _lib.check(_lib.lib().mural_fasta_scan(path.encode(), 0, _NAME, None, None, None, C.byref(n)))
+    cnt = n.value
+    names = C.create_string_buffer(max(cnt, 1) * _NAME)
+    lengths = np.zeros(max(cnt, 1), np.int64)
+    offsets = np.zeros(max(cnt, 1), np.int64)
+    _lib.check(_lib.lib().mural_fasta_scan(path.encode(), cnt, _NAME, names, lengths.ctypes.data, offsets.ctypes.data,
+                                          C.byref(n)))
+    out = []
+    for i in range(cnt):
+        raw = names.raw[i * _NAME:(i + 1) * _NAME]
+        out.append(FastaRecord(raw.split(b"\0", 1)[0].decode(), int(lengths[i]), int(offsets[i])))
+    return out
+
+
+def pack_fasta_record(path, rec):
+    """(packed2 uint32[], nmask uint32[], length, positions of non-N ambiguity codes) of one record -- the same
+    contract as ``genome.pack_sequence`` on the record's sequence string."""
+    path = os.fspath(path)
+    packed = np.zeros((rec.length + 15) // 16, np.uint32)
+    mask = np.zeros((rec.length + 31) // 32, np.uint32)
+    n_amb = C.c_int64(0)
+    cap = 1024
+    while True:
+        amb = np.zeros(cap, np.int64)
+        _lib.check(_lib.lib().mural_fasta_pack(path.encode(), rec.offset, rec.length, packed.ctypes.data, mask.ctypes.data,
+                                              amb.ctypes.data, cap, C.byref(n_amb)))
+        if n_amb.value <= cap:
+            return packed, mask, rec.length, amb[:n_amb.value].copy()
+        cap = int(n_amb.value)
+
+
+def read_fasta(path, device="cuda", names=None):
+    """{record id: PackedGenome on `device`} (only `names` if given), the packed counterpart of SeqIO.to_dict."""
+    out = {}
+    for rec in scan_fasta(path):
+        if names is not None and rec.name not in names:
+            continue
+        if rec.name in out:
+            raise ValueError(f"Duplicate key '{rec.name}'")        # SeqIO.to_dict raises ValueError on duplicate ids
+        packed, mask, n, amb = pack_fasta_record(path, rec)
+        out[rec.name] = PackedGenome(packed, mask, n, device, amb)
+    return out
+
+
+@dataclass
+class BedSites:
+    chrom_names: list
+    chrom_id: np.ndarray    # int32, index into chrom_names
+    start: np.ndarray       # int64, 0-based
+    end: np.ndarray
+    score: np.ndarray       # float32 class label (column 5)
+    strand: np.ndarray      # uint8, 0 '+', 1 '-'
+
+    def __len__(self):
+        return len(self.start)
+
+
+def read_bed(path):
+    """Six-column BED (chrom start end name score strand) -> arrays in file order."""
+    path = os.fspath(path)
+    n, nc = C.c_int64(0), C.c_int32(0)
+    lib = _lib.lib()
+    _lib.check(lib.mural_bed_read(path.encode(), 0, None, None, None, None, None, 0, _NAME, None, C.byref(n), C.byref(nc)))
+    rows, chroms = n.value, nc.value
+    cid = np.zeros(rows, np.int32)
+    start, end = np.zeros(rows, np.int64), np.zeros(rows, np.int64)
+    score = np.zeros(rows, np.float32)
+    strand = np.zeros(rows, np.uint8)
+    names = C.create_string_buffer(max(chroms, 1) * _NAME)
+    _lib.check(lib.mural_bed_read(path.encode(), rows, cid.ctypes.data, start.ctypes.data, end.ctypes.data, score.ctypes.data,
+                                 strand.ctypes.data, chroms, _NAME, names, C.byref(n), C.byref(nc)))
+    cn = [names.raw[i * _NAME:(i + 1) * _NAME].split(b"\0", 1)[0].decode() for i in range(chroms)]
+    return BedSites(cn, cid, start, end, score, strand)
+
+
+def bed_order(sites, central_bp):
+    """(order, group): bed_reader row order of `sites` (see batching.segment_order, here in C++)."""
+    n = len(sites)
+    order, group = np.zeros(n, np.int64), np.zeros(n, np.int64)
+    ng = C.c_int64(0)
+    _lib.check(_lib.lib().mural_bed_segment_order(sites.chrom_id.ctypes.data, sites.start.ctypes.data, sites.strand.ctypes.data,
+                                                 n, int(central_bp), order.ctypes.data, group.ctypes.data, C.byref(ng)))
+    return order, group
+
+
+def predict_bed(model, fasta_path, bed_path, local_radius, local_order=3, distal_radius=None, segment_center=300000,
+                device="cuda", batch_sites=1 << 20, model_type="snv"):
+    """Predict every BED site from a FASTA + BED pair.  Returns a dict of arrays in bed_reader order: ``chrom``, ``start``,
+    ``end``, ``strand`` ('+'/'-'), ``label`` and ``prob`` (n, n_class) = softmax of the model output (run_predict.py:214).
+
+    SNV sites must share one focal base after strand complement within every (segment, strand) group, as the reference
+    enforces (preprocessing.py:479-484; it exits, this raises ValueError)."""
+    sites = read_bed(bed_path)
+    order, group = bed_order(sites, segment_center)
+    used = {sites.chrom_names[c] for c in np.unique(sites.chrom_id)}
+    genomes = read_fasta(fasta_path, device, names=used)
+    missing = used - set(genomes)
+    if missing:
+        raise KeyError(sorted(missing)[0])      # the reference's seq_records[chrom] lookup
+    cid, start, strand = sites.chrom_id[order], sites.start[order], sites.strand[order]
+    probs = torch.empty((len(order), model.n_class), dtype=torch.float32, device=device)
+    focal = np.zeros(len(order), np.int64)
+    model = model.to(device).eval()
+    with torch.no_grad():
+        for c in np.unique(cid):             # every chromosome's rows are contiguous in bed_reader order
+            rows = np.nonzero(cid == c)[0]
+            g = genomes[sites.chrom_names[c]]
+            for r0 in range(0, len(rows), batch_sites):
+                sel = rows[r0:r0 + batch_sites]
+                pos = torch.from_numpy(start[sel]).to(device)
+                st = torch.from_numpy(strand[sel]).to(device)
+                if model_type == "snv":
+                    focal[sel] = g.encode_kmer(pos, st, 1, 1)[:, 1].cpu().numpy()     # strand-complemented focal base
+                    out = model.forward_packed(g, pos, st, local_radius=local_radius, local_order=local_order)
+                else:
+                    out = model.forward_packed(g, pos, st, distal_radius)
+                probs[torch.from_numpy(sel).to(device)] = torch.softmax(out, dim=1)
+    if model_type == "snv" and len(order):
+        first = np.r_[True, group[1:] != group[:-1]]                       # group ids are non-decreasing in this order
+        ref = focal[np.maximum.accumulate(np.where(first, np.arange(len(order)), 0))]
+        if (focal != ref).any():
+            raise ValueError("The positions in input BED file have different bases (A/T and C/G mixed)! The ref_genome or "
+                             "input BED file could be wrong.")
+    return {"chrom": np.asarray(sites.chrom_names, dtype=object)[cid], "start": start, "end": sites.end[order],
+            "strand": np.where(strand == 1, "-", "+"), "label": sites.score[order], "prob": probs.cpu().numpy(),
+            "order": order}

@@ -173,3 +173,63 @@ def test_model_predict_m_contract():
     assert pred.is_cuda and pred.shape == fx["pred"].shape
     assert_probs_close(pred.cpu().numpy(), fx["pred"], 2, "predict_m")
     assert abs(total - float(fx["total_loss"])) <= 1e-4 * abs(float(fx["total_loss"]))
+
+
+def test_predict_bed_from_fasta_matches_oracle(tmp_path):
+    """File-level path (C++ FASTA packer + BED reader + bed_reader row order + fused decode/forward) vs the oracle fed by
+    the oracle's own encoders on the same sites; mixed focal bases are rejected like the reference does."""
+    from mural_amd.data import ingest
+    r, R = 5, 100
+    rng = np.random.default_rng(4242)
+    seqs = {}
+    for name, n in (("chr2L", 4000), ("chrX", 2500)):
+        raw = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=n, p=[.248, .248, .248, .248, .008])
+        seqs[name] = raw.tobytes().decode()
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">{k} test\n" + "\n".join(s[i:i + 70] for i in range(0, len(s), 70)) + "\n" for k, s in seqs.items()))
+    rows = []
+    for name, s in seqs.items():                       # A sites on '+', T sites on '-': one focal base after complement
+        arr = np.frombuffer(s.encode(), np.uint8)
+        for p in np.sort(rng.choice(len(s), size=180, replace=False)):
+            if arr[p] == ord("A"):
+                rows.append((name, int(p), "+"))
+            elif arr[p] == ord("T"):
+                rows.append((name, int(p), "-"))
+    bed = tmp_path / "s.bed"
+    bed.write_text("".join(f"{c}\t{p}\t{p + 1}\t.\t{i % 4}\t{st}\n" for i, (c, p, st) in enumerate(rows)))
+    orc = snv_ref.build(2, local_radius=r, distal_radius=R)
+    sd = synth.synth_state_dict(orc.state_dict(), 78)
+    orc.load_state_dict(sd)
+    orc.eval()
+    model, _ = product_from_hp(np.array([r, 3, R, 150, 75, 32, 3, 4, 2]))
+    model.load_state_dict(sd)
+    res = ingest.predict_bed(model, fa, bed, local_radius=r, local_order=3, segment_center=500)
+    assert len(res["start"]) == len(rows)
+    # reference row order: per 500-bp segment, '+' rows then '-' rows (bed_reader); recompute it independently
+    from mural_amd.data.batching import segment_order
+    chrom = np.array([c for c, _, _ in rows])
+    start = np.array([p for _, p, _ in rows])
+    neg = np.array([st == "-" for _, _, st in rows])
+    order, _ = segment_order(chrom, start, neg, 500)
+    assert np.array_equal(res["start"], start[order]) and np.array_equal(res["chrom"], chrom[order])
+    assert np.array_equal(res["strand"] == "-", neg[order])
+    assert np.array_equal(res["label"], (np.arange(len(rows)) % 4)[order].astype(np.float32))
+    want = np.zeros((len(rows), 4))
+    for name, s in seqs.items():
+        sel = np.nonzero(chrom[order] == name)[0]
+        codes = encode_ref.seq_to_codes(s)
+        sym = ["-" if v else "+" for v in neg[order][sel]]
+        cat = torch.from_numpy(encode_ref.kmer_encode(codes, start[order][sel], sym, r, 3))
+        x = torch.from_numpy(encode_ref.onehot_encode(codes, start[order][sel], sym, R))
+        with torch.no_grad():
+            want[sel] = torch.softmax(orc((torch.zeros(len(sel), 1, dtype=torch.float64), cat), x), dim=1).numpy()
+    assert np.abs(res["prob"] - want).max() <= PROB_TOL
+    # a C site inside the first '+' group: the reference exits with "different bases", here ValueError
+    arr = np.frombuffer(seqs["chr2L"].encode(), np.uint8)
+    p0 = next(p for c, p, st in rows if c == "chr2L" and st == "+")
+    cpos = int(p0 + 1 + np.nonzero(arr[p0 + 1:p0 + 400] == ord("C"))[0][0])
+    rows2 = sorted(rows + [("chr2L", cpos, "+")], key=lambda t: (t[0] != "chr2L", t[1]))
+    bed2 = tmp_path / "mixed.bed"
+    bed2.write_text("".join(f"{c}\t{p}\t{p + 1}\t.\t0\t{st}\n" for c, p, st in rows2))
+    with pytest.raises(ValueError, match="different bases"):
+        ingest.predict_bed(model, fa, bed2, local_radius=r, local_order=3, segment_center=500)
