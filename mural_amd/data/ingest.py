@@ -157,3 +157,32 @@ def predict_bed(model, fasta_path, bed_path, local_radius, local_order=3, distal
     return {"chrom": np.asarray(sites.chrom_names, dtype=object)[cid], "start": start, "end": sites.end[order],
             "strand": np.where(strand == 1, "-", "+"), "label": sites.score[order], "prob": probs.cpu().numpy(),
             "order": order}
+
+
+def poisson_calibrate(prob):
+    """MuRaL/model/calibration.py:10-23 on an (n, n_class) array: lambda = -log(clip(prob0, 1e-10, 1)); the mutation
+    classes become lambda * prob_k / (1 - prob0) and class 0 becomes 1 - lambda (applied for INDEL models and with
+    --poisson_calib, run_predict.py:224-225)."""
+    prob = np.asarray(prob)
+    p0 = np.clip(prob[:, 0], 1e-10, 1.0)
+    lam = -np.log(p0)
+    out = prob.copy()
+    with np.errstate(divide="ignore", invalid="ignore"):
+        out[:, 1:] = lam[:, None] * prob[:, 1:] / (1 - p0)[:, None]
+    out[:, 0] = 1 - lam
+    return out
+
+
+def write_predictions(res, path, poisson=False):
+    """The prediction table of run_predict.py:230-239: columns chrom, start, end, strand, mut_type, prob0.., rows sorted
+    by (chrom, start), tab-separated, floats as '%.4g'.  `res` is the dict returned by ``predict_bed``."""
+    import pandas as pd
+    prob = poisson_calibrate(res["prob"]) if poisson else np.asarray(res["prob"])
+    names = ["prob%d" % i for i in range(prob.shape[1])]
+    df = pd.concat((pd.DataFrame({"chrom": res["chrom"], "start": res["start"], "end": res["end"], "strand": res["strand"]}),
+                    pd.DataFrame({"mut_type": np.asarray(res["label"]).astype(np.int64)}), pd.DataFrame(prob, columns=names)),
+                   axis=1)
+    df.sort_values(["chrom", "start"], inplace=True)
+    df.reset_index(drop=True, inplace=True)
+    df.to_csv(path, sep="\t", float_format="%.4g", index=False)
+    return df

@@ -8,6 +8,7 @@ oracle/synth.py, one-hot tensors from base codes) are stored in their compact fo
 Fixture list:
   G1  encode_*.npz        seq_digit_encoder / seq_ohe_encoder on strings with N runs, lowercase, IUPAC,
                           both strands, chromosome-edge sites, clustered sites (merged windows)
+  G11 output.npz          poisson_calibrate + the sorted '%.4g' prediction table
   G2  windowing.npz       bed_reader segment order + get_seqs_to_digitalized tuples
   G3  snv_pretrained_*.npz  shipped checkpoints (weights included) -> log-probs
   G4/5 snv_synth_*.npz    synthetic-weight S (10/1000) / T (5/100) / P (7/1000) configs, Network0/1/2
@@ -376,13 +377,42 @@ def g10_batching(ref):
     save("batching.npz", **out)
 
 
+def g11_output(ref):
+    """poisson_calibrate (MuRaL/model/calibration.py:10-23) and the prediction table written by run_predict.py:230-239
+    (sorted by chrom/start, '%.4g') on a small synthetic result."""
+    import importlib
+    import io
+    import pandas as pd
+    cal = importlib.import_module("MuRaL.model.calibration")
+    rng = np.random.default_rng(11)
+    p = rng.dirichlet([30, 1, 1, 1], size=40).astype(np.float32)
+    p[0] = [1.0, 0.0, 0.0, 0.0]                       # prob0 = 1: 0/0 in the reference
+    p[1] = [1e-12, 0.5, 0.25, 0.25]                   # clipped at 1e-10
+    names = ["prob%d" % i for i in range(4)]
+    with np.errstate(all="ignore"):
+        out = cal.poisson_calibrate(pd.DataFrame(p, columns=names))[names].to_numpy()
+    chrom = np.array(["chr2", "chr10", "chr2", "chr1"] * 10, dtype=object)
+    start = rng.integers(0, 1000, size=40)
+    strand = np.where(rng.integers(0, 2, size=40) == 1, "-", "+")
+    label = rng.integers(0, 4, size=40)
+    df = pd.concat((pd.DataFrame({"chrom": chrom, "start": start, "end": start + 1, "strand": strand}),
+                    pd.DataFrame({"mut_type": label}), pd.DataFrame(p, columns=names)), axis=1)
+    df.columns = ["chrom", "start", "end", "strand", "mut_type"] + names
+    df.sort_values(["chrom", "start"], inplace=True)
+    df.reset_index(drop=True, inplace=True)
+    buf = io.StringIO()
+    df.to_csv(buf, sep="\t", float_format="%.4g", index=False)
+    save("output.npz", prob=p, poisson=out, chrom=chrom.astype(str), start=start, strand=strand.astype(str), label=label,
+         table=np.array(buf.getvalue()))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_import.load()
     only = set(sys.argv[1:])
     steps = dict(g1=g1_encode, g2=g2_windowing, g3=g3_pretrained, g45=g45_synth, g6=g6_taps, g7=g7_train,
-                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching)
+                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output)
     for name, fn in steps.items():
         if only and name not in only:
             continue

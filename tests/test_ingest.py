@@ -91,3 +91,16 @@ def test_bed_reader_errors(tmp_path):
     assert len(I.read_bed(empty)) == 0
     order, group = I.bed_order(I.read_bed(empty), 1000)
     assert len(order) == 0
+
+
+def test_poisson_calibrate_and_prediction_table_match_reference(tmp_path):
+    fx = U.load("output.npz")
+    got = I.poisson_calibrate(fx["prob"])
+    assert np.array_equal(np.isnan(got), np.isnan(fx["poisson"]))
+    ok = ~np.isnan(got)
+    assert np.array_equal(got[ok], fx["poisson"][ok])
+    res = {"chrom": fx["chrom"].astype(object), "start": fx["start"], "end": fx["start"] + 1, "strand": fx["strand"].astype(object),
+           "label": fx["label"].astype(np.float32), "prob": fx["prob"]}
+    path = tmp_path / "pred.tsv"
+    I.write_predictions(res, path)
+    assert path.read_text() == str(fx["table"])
