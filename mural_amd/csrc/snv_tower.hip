@@ -180,6 +180,10 @@ __device__ __forceinline__ void conv_layer(const char* in, char* out, const Stag
   }
 }
 
+// Workgroup barrier for LDS-only hand-offs: __syncthreads() also drains vmcnt, i.e. it would wait for the stage-1
+// activations requested one tower ahead (request_x0) at the very next barrier and expose the full HBM latency per tower.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // diagnostic: accumulate wave 0's cycles per phase into args.stamps[block][phase] (only when stamps != nullptr)
 #define SNV_STAMP(id)                                                              \
   do {                                                                             \
@@ -387,7 +391,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           for (int j = 8; j < L4; ++j) m = fmaxf(m, bufA[lds_off(1 + p * Sc4 + j + 1, ch >> 2) + (ch & 3)]);
           ft[t] = m;
         }
-        __syncthreads();   // bufA may be overwritten by the next tower's entry step; feat visible to the fc
+        lds_barrier();   // bufA may be overwritten by the next tower's entry step; feat visible to the fc
         SNV_STAMP(10 + 12 * tw_i);   // global max
       }
     }  // towers
@@ -410,7 +414,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
       logit[tp * SNV_MAXCLASS + k] = acc;
     }
-    __syncthreads();
+    lds_barrier();
     SNV_STAMP(25);   // fc
 
     // ------------------------------------------------------------------ head (model_snv.py:515-523 / :284)
@@ -446,7 +450,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       float* dst = args.taps + (size_t)12 * args.tap_stride;
       for (int i = tid; i < 2 * P * SNV_C + 3 * P * SNV_MAXCLASS; i += SNV_THREADS) dst[i] = feat[i];
     }
-    __syncthreads();
+    lds_barrier();
     SNV_STAMP(26);   // head
   }
 }
