@@ -158,6 +158,7 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
                                                         const float* __restrict__ tb_b) {
   constexpr int C2 = 2 * C, TW = 256 + 4, TWp = TW | 1;
   __shared__ float tile[C * TWp];
+  __shared__ float hs[C2 * 256];               // SiLU outputs, [2C][256 lanes]
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   const int l0 = blockIdx.x * 256;
@@ -178,23 +179,35 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
     float x[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) x[k] = trow[k];
+    // at most ~64 weights in scalar registers at a time: more spills SGPRs into VGPR lanes (v_readlane per use)
+    constexpr int TG = (C2 <= 16) ? 4 : (C2 <= 32 ? 2 : 1);
 #pragma unroll
     for (int k = 0; k < 5; ++k) {
+      if (k % TG == 0) __builtin_amdgcn_sched_barrier(0);
       const float* __restrict__ wk = w5 + (size_t)(ci * 5 + k) * C2;      // wave-uniform: scalar loads
       const f32x2 x2 = {x[k], x[k]};
 #pragma unroll
       for (int j = 0; j < C; ++j) h[j] = __builtin_elementwise_fma(x2, f32x2{wk[2 * j], wk[2 * j + 1]}, h[j]);
     }
+    __builtin_amdgcn_sched_barrier(0);
   }
 #pragma unroll
   for (int j = 0; j < C; ++j) h[j] = f32x2{apply_act(h[j].x, ACT_SILU), apply_act(h[j].y, ACT_SILU)};
+  // 1x1 conv 2C -> C.  Its 2C x C weights do not fit the scalar register file if the loop over the 2C inputs is unrolled
+  // (and it must be, to index registers): the lane parks its 2C values in LDS (column tid: conflict-free) and walks them
+  // in a rolled loop, one scalar weight row in flight at a time.
+#pragma unroll
+  for (int j = 0; j < C; ++j) {
+    hs[(2 * j) * 256 + tid] = h[j].x;
+    hs[(2 * j + 1) * 256 + tid] = h[j].y;
+  }
   f32x2 o[C / 2];
 #pragma unroll
   for (int c = 0; c < C / 2; ++c) o[c] = f32x2{b1[2 * c], b1[2 * c + 1]};
-#pragma unroll
+#pragma unroll 2
   for (int j = 0; j < C2; ++j) {
     const float* __restrict__ wj = w1 + (size_t)j * C;
-    const float hv = (j & 1) ? h[j >> 1].y : h[j >> 1].x;
+    const float hv = hs[j * 256 + tid];
     const f32x2 h2 = {hv, hv};
 #pragma unroll
     for (int c = 0; c < C / 2; ++c) o[c] = __builtin_elementwise_fma(h2, f32x2{wj[2 * c], wj[2 * c + 1]}, o[c]);
@@ -242,7 +255,7 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
   }
 }
 
-bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24 || C == 32 || C == 40 || C == 48; }
+bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24; }   // LDS: tile + 2C x 256 floats
 
 template <bool TAIL>
 static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
@@ -253,10 +266,7 @@ static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
   switch (a.C) {
     case 8: MURAL_CB(8); break;
     case 16: MURAL_CB(16); break;
-    case 24: MURAL_CB(24); break;
-    case 32: MURAL_CB(32); break;
-    case 40: MURAL_CB(40); break;
-    default: MURAL_CB(48); break;
+    default: MURAL_CB(24); break;
   }
 #undef MURAL_CB
 }
