@@ -40,7 +40,7 @@ struct ConvBlockArgs {
   float* out;            // [B][C][L] (unused with a tail)
   int B, C, L;
   // optional tail (model_indel.py:172-175): max over positions of Softplus(W_b . ReLU(W_a . out + b_a) + b_b), both 1x1 convs
-  // C -> C with weights [Cin][Cout]; tail_max: [B][C], zeroed by the caller (the scores are positive: integer atomic max)
+  // C -> C with weights [Cin][Cout]; tail_max: [B][ceil(L / 256)][C] per-workgroup maxima, reduced by the consumer
   const float* ta_w;
   const float* ta_b;
   const float* tb_w;

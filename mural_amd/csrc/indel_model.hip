@@ -77,14 +77,19 @@ struct MuralIndelModel {
 
 namespace mural {
 // softplus(fc(max features)) per (row, class)
-__global__ void indel_head_kernel(const float* __restrict__ feat, int64_t n, int C, int n_class,
+// feat: [n][parts][C] partial maxima over positions (parts = 1: already the row maximum)
+__global__ void indel_head_kernel(const float* __restrict__ feat, int64_t n, int parts, int C, int n_class,
                                   const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out) {
   const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (i >= n * n_class) return;
   const int64_t row = i / n_class;
   const int k = (int)(i - row * n_class);
   float acc = b[k];
-  for (int c = 0; c < C; ++c) acc = fmaf(w[k * C + c], feat[row * C + c], acc);
+  for (int c = 0; c < C; ++c) {
+    float m = feat[(row * parts) * C + c];
+    for (int p = 1; p < parts; ++p) m = fmaxf(m, feat[(row * parts + p) * C + c]);
+    acc = fmaf(w[k * C + c], m, acc);
+  }
   out[i] = acc > 20.f ? acc : log1pf(expf(acc));
 }
 }  // namespace mural
@@ -174,7 +179,7 @@ extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const Mura
     tmax = std::max(tmax, (size_t)m->ch[i] * m->len[i]);
     hmax = std::max(hmax, (size_t)2 * m->ch[i] * m->len[i]);
   }
-  per += 2 * tmax + hmax + big + C0;
+  per += 2 * tmax + hmax + big + (size_t)C0 * ((m->len[0] + 255) / 256);   // M: per-tile maxima
   m->per_pos_floats = per;
   m->blob_floats = B.host.size();
   if (hipError_t e = hipMalloc(&m->blob, m->blob_floats * 4); e != hipSuccess) {
@@ -269,7 +274,8 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     float* T2 = take(tmax);
     float* H = take(hmax);
     float* SP = take((size_t)C0 * m->len[0]);
-    float* M = take(C0);
+    const int mparts = (m->len[0] + 255) / 256;
+    float* M = take((size_t)C0 * mparts);
     const float* x = distal_x + (size_t)c0 * 4 * Lx;
     int rc = MURAL_OK;
     const float* cur = x;
@@ -292,7 +298,6 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
       const int Li = m->len[lvl];
       if ((rc = run_conv(m, m->dn_l[j], cur, B, Lcur, T1, Li, 1, sh.down[lvl + 1], ACT_NONE, nullptr, nullptr, stream))) return rc;
       const bool fuse_tail = lvl == 0 && block_fusable(m->dn5[j], m->dn1[j], Li);
-      if (fuse_tail) MURAL_HIP_CHECK(hipMemsetAsync(M, 0, (size_t)B * C0 * sizeof(float), stream));
       if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr))) return rc;
       tail_done = fuse_tail;
       cur = dec;
@@ -306,7 +311,8 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
       if ((rc = launch_rowmax(sp, (int64_t)B * C0, Lcur, M, stream))) return rc;
     }
     const int64_t total = (int64_t)B * sh.n_class;
-    hipLaunchKernelGGL(indel_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, M, (int64_t)B, C0,
+    hipLaunchKernelGGL(indel_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, M, (int64_t)B,
+                       tail_done ? mparts : 1, C0,
                        sh.n_class, m->blob + m->fc_w, m->blob + m->fc_b, out + c0 * sh.n_class);
     MURAL_HIP_CHECK(hipGetLastError());
   }
