@@ -31,7 +31,7 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream);
 //   out = x + W1 . SiLU(W5 * x + b5) + b1 [+ res2],  W5: k=5 conv C -> 2C, W1: 1x1 conv 2C -> C.
 // The 2C-channel intermediate lives in registers only.
 struct ConvBlockArgs {
-  const float* x;        // [B][C][L]
+  const float* x;        // [B][C][L] (unused with a front)
   const float* w5;       // [C][5][2C]
   const float* b5;       // [2C]
   const float* w1;       // [2C][C]
@@ -40,7 +40,13 @@ struct ConvBlockArgs {
   float* out;            // [B][C][L] (unused with a tail)
   int B, C, L;
   // optional tail (model_indel.py:172-175): max over positions of Softplus(W_b . ReLU(W_a . out + b_a) + b_b), both 1x1 convs
-  // C -> C with weights [Cin][Cout]; tail_max: [B][ceil(L / 256)][C] per-workgroup maxima, reduced by the consumer
+  // C -> C with weights [Cin][Cout]; tail_max: [B][convblock_tiles()][C] per-workgroup maxima, reduced by the consumer
+  // optional front: x itself is not read but produced in LDS as conv_k7(upsample_u(f_in)) + f_b, a stride-1 k=7 conv
+  // Cf -> C with weights [Cf][7][C] (the decoder's Upsample + Conv1d + BN, model_indel.py:117-123, or the first encoder conv)
+  const float* f_in;     // [B][Cf][Lf], Lf * f_up == L
+  const float* f_w;
+  const float* f_b;
+  int Cf, Lf, f_up;
   const float* ta_w;
   const float* ta_b;
   const float* tb_w;
@@ -48,6 +54,7 @@ struct ConvBlockArgs {
   float* tail_max;
 };
 bool convblock_supported(int C);
+int convblock_tiles(int L, bool front);   // workgroups per row = entries per row of tail_max
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream);
 
 // y[b][c] = max_l x[b][c][l]

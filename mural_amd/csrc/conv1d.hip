@@ -150,32 +150,86 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
 // conv fills 2C accumulators from the LDS tile (weights as scalar pairs, v_pk_fma_f32), SiLU runs on them in place, the
 // 1x1 conv contracts them to C outputs, the block input is added back from the tile.  HBM traffic: read x, write out
 // (+ read res2) instead of also writing and re-reading the 2C-channel intermediate.
-template <int C, bool TAIL>
+constexpr int CB_FRONT_FLOATS = 2048;          // front input tile: Cf x (262 / up + 3) floats
+constexpr int CB_FRONT_OUT = 252;              // output positions per workgroup of the front variant
+
+template <int C, bool TAIL, bool FRONT>
 __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
                                                         const float* __restrict__ b5, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ ta_w,
                                                         const float* __restrict__ ta_b, const float* __restrict__ tb_w,
-                                                        const float* __restrict__ tb_b) {
+                                                        const float* __restrict__ tb_b, const float* __restrict__ f_w,
+                                                        const float* __restrict__ f_b) {
   constexpr int C2 = 2 * C, TW = 256 + 4, TWp = TW | 1;
   __shared__ float tile[C * TWp];
   __shared__ float hs[C2 * 256];               // SiLU outputs, [2C][256 lanes]
+  __shared__ float fin[FRONT ? CB_FRONT_FLOATS : 1];
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
-  const int l0 = blockIdx.x * 256;
-  const float* src = a.x + (size_t)b * C * a.L;
-  for (int i = tid; i < C * TW; i += 256) {
-    const int ci = i / TW, j = i - ci * TW;
-    const int l = l0 - 2 + j;
-    tile[ci * TWp + j] = (l >= 0 && l < a.L) ? src[(size_t)ci * a.L + l] : 0.f;
+  // without a front a workgroup covers 256 positions (tile = positions l0-2 .. l0+257); with one it covers CB_FRONT_OUT =
+  // 252: lane tid computes the block INPUT at position l0-2+tid (256 of them, no second pass for the halo) and, for
+  // 2 <= tid < 254, the block OUTPUT at that same position
+  constexpr int OUTW = FRONT ? CB_FRONT_OUT : 256;
+  const int l0 = blockIdx.x * OUTW;
+  if (!FRONT) {
+    const float* src = a.x + (size_t)b * C * a.L;
+    for (int i = tid; i < C * TW; i += 256) {
+      const int ci = i / TW, j = i - ci * TW;
+      const int l = l0 - 2 + j;
+      tile[ci * TWp + j] = (l >= 0 && l < a.L) ? src[(size_t)ci * a.L + l] : 0.f;
+    }
+  } else {
+    // the block input of positions l0-2 .. l0+253 needs the (virtual, upsampled) front input at l0-5 .. l0+256
+    const int up = a.f_up;
+    const int v0 = l0 - 5;                                   // first virtual index (may be negative)
+    const int r0 = v0 >= 0 ? v0 / up : -((-v0 + up - 1) / up);   // floor(v0 / up)
+    const int span = (l0 + 256) / up - r0 + 1;               // real columns staged per channel
+    const float* fsrc = a.f_in + (size_t)b * a.Cf * a.Lf;
+    for (int i = tid; i < a.Cf * span; i += 256) {
+      const int ci = i / span, rr = i - ci * span;
+      const int r = r0 + rr;
+      fin[i] = (r >= 0 && r < a.Lf) ? fsrc[(size_t)ci * a.Lf + r] : 0.f;   // zero padding of the upsampled tensor
+    }
+    __syncthreads();
+    {
+      const int j = tid;
+      const int l = l0 - 2 + j;
+      f32x2 t[C / 2];
+#pragma unroll
+      for (int c = 0; c < C / 2; ++c) t[c] = f32x2{f_b[2 * c], f_b[2 * c + 1]};
+      int ridx[7];
+#pragma unroll
+      for (int k = 0; k < 7; ++k) {
+        const int v = l - 3 + k;                             // virtual input index of tap k, >= v0
+        ridx[k] = (v >= 0 ? v / up : r0) - r0;               // v < 0 only if r0 < 0: column 0 then holds a zero
+      }
+#pragma unroll 1
+      for (int ci = 0; ci < a.Cf; ++ci) {
+        const float* frow = fin + ci * span;
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          const float* __restrict__ wk = f_w + (size_t)(ci * 7 + k) * C;   // wave-uniform: scalar loads
+          const float xv = frow[ridx[k]];
+          const f32x2 x2 = {xv, xv};
+#pragma unroll
+          for (int c = 0; c < C / 2; ++c) t[c] = __builtin_elementwise_fma(x2, f32x2{wk[2 * c], wk[2 * c + 1]}, t[c]);
+        }
+      }
+      const bool in = l >= 0 && l < a.L;                     // the k=5 conv zero-pads ITS input
+#pragma unroll
+      for (int c = 0; c < C; ++c) tile[c * TWp + j] = in ? ((c & 1) ? t[c >> 1].y : t[c >> 1].x) : 0.f;
+    }
   }
   __syncthreads();
-  const int l = l0 + tid;
+  const int toff = FRONT ? (tid >= 2 ? tid - 2 : 0) : tid;    // tile index of this lane's first k=5 tap
+  const int l = FRONT ? l0 - 2 + tid : l0 + tid;
+  const bool live = FRONT ? (tid >= 2 && tid < 2 + CB_FRONT_OUT && l < a.L) : (l < a.L);   // lane owns a real output
   f32x2 h[C];                                  // 2C accumulators as pairs
 #pragma unroll
   for (int j = 0; j < C; ++j) h[j] = f32x2{b5[2 * j], b5[2 * j + 1]};
 #pragma unroll 1
   for (int ci = 0; ci < C; ++ci) {
-    const float* trow = tile + ci * TWp + tid;
+    const float* trow = tile + ci * TWp + toff;
     float x[5];
 #pragma unroll
     for (int k = 0; k < 5; ++k) x[k] = trow[k];
@@ -215,11 +269,11 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
   float v[C];
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    v[c] = ((c & 1) ? o[c >> 1].y : o[c >> 1].x) + tile[c * TWp + tid + 2];
-    if (a.res2 && l < a.L) v[c] += a.res2[((size_t)b * C + c) * a.L + l];
+    v[c] = ((c & 1) ? o[c >> 1].y : o[c >> 1].x) + tile[c * TWp + toff + 2];
+    if (a.res2 && live) v[c] += a.res2[((size_t)b * C + c) * a.L + l];
   }
   if (!TAIL) {
-    if (l < a.L) {
+    if (live) {
 #pragma unroll
       for (int c = 0; c < C; ++c) a.out[((size_t)b * C + c) * a.L + l] = v[c];
     }
@@ -249,7 +303,7 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
 #pragma unroll
   for (int c = 0; c < C; ++c) {
     float sp = apply_act((c & 1) ? u[c >> 1].y : u[c >> 1].x, ACT_SOFTPLUS);
-    if (l >= a.L) sp = 0.f;                    // Softplus > 0: 0 is the identity of the maximum
+    if (!live) sp = 0.f;                       // Softplus > 0: 0 is the identity of the maximum
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sp = fmaxf(sp, __shfl_xor(sp, off));
     if ((tid & 63) == 0) hs[(tid >> 6) * C + c] = sp;
@@ -262,12 +316,14 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
 
 bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24; }   // LDS: tile + 2C x 256 floats
 
-template <bool TAIL>
+int convblock_tiles(int L, bool front) { return front ? (L + CB_FRONT_OUT - 1) / CB_FRONT_OUT : (L + 255) / 256; }
+
+template <bool TAIL, bool FRONT>
 static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
-  const dim3 grid((a.L + 255) / 256, a.B);
+  const dim3 grid(convblock_tiles(a.L, FRONT), a.B);
 #define MURAL_CB(CN)                                                                                                        \
-  hipLaunchKernelGGL((convblock_kernel<CN, TAIL>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, a.tb_w, \
-                     a.tb_b)
+  hipLaunchKernelGGL((convblock_kernel<CN, TAIL, FRONT>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, \
+                     a.tb_w, a.tb_b, a.f_w, a.f_b)
   switch (a.C) {
     case 8: MURAL_CB(8); break;
     case 16: MURAL_CB(16); break;
@@ -279,12 +335,15 @@ static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.L == 0) return MURAL_OK;
   MURAL_REQUIRE(convblock_supported(a.C), "convblock: %d channels not instantiated", a.C);
-  if (a.tail_max) {
-    MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
-    launch_convblock_t<true>(a, stream);
-  } else {
-    launch_convblock_t<false>(a, stream);
+  if (a.f_in) {
+    MURAL_REQUIRE(a.f_w && a.f_b && a.f_up >= 1 && a.Lf * a.f_up == a.L, "convblock: bad front geometry");
+    MURAL_REQUIRE(a.Cf * (262 / a.f_up + 3) <= CB_FRONT_FLOATS, "convblock: front input tile does not fit");
   }
+  if (a.tail_max) MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
+  if (a.tail_max && a.f_in) launch_convblock_t<true, true>(a, stream);
+  else if (a.tail_max) launch_convblock_t<true, false>(a, stream);
+  else if (a.f_in) launch_convblock_t<false, true>(a, stream);
+  else launch_convblock_t<false, false>(a, stream);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

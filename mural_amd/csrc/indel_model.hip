@@ -179,7 +179,7 @@ extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const Mura
     tmax = std::max(tmax, (size_t)m->ch[i] * m->len[i]);
     hmax = std::max(hmax, (size_t)2 * m->ch[i] * m->len[i]);
   }
-  per += 2 * tmax + hmax + big + (size_t)C0 * ((m->len[0] + 255) / 256);   // M: per-tile maxima
+  per += 2 * tmax + hmax + big + (size_t)C0 * convblock_tiles(m->len[0], true);   // M: per-tile maxima
   m->per_pos_floats = per;
   m->blob_floats = B.host.size();
   if (hipError_t e = hipMalloc(&m->blob, m->blob_floats * 4); e != hipSuccess) {
@@ -225,20 +225,32 @@ static bool block_fusable(const FoldedConv& f5, const FoldedConv& f1, int L) {
   return L >= 128 && convblock_supported(f5.Cin) && f5.K == 5 && f1.K == 1 && f5.Cout == 2 * f5.Cin && f1.Cout == f5.Cin;
 }
 
+// front: the stride-1 k=7 conv (with nearest-neighbour upsampling `up` of its input fin [B][ff->Cin][Lf]) that produces the
+// block input x; when fusable, x is never materialised (pass x = nullptr then)
+static bool front_fusable(const FoldedConv& ff, int up, int C) {
+  // measured (rocprofv3, 2048 positions): a win at 8 channels (594 us vs 491 + 450 us for the level-0 encoder), a loss at
+  // 16 / 24 channels where the block kernel's LDS footprint leaves too few waves to cover the front conv's latencies
+  return C == 8 && ff.K == 7 && ff.Cout == C && up >= 1 && ff.Cin * (262 / up + 3) <= 2048;
+}
+
 static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
-                     float* H, float* out, const float* skip, hipStream_t stream, float* tail_max = nullptr) {
+                     float* H, float* out, const float* skip, hipStream_t stream, float* tail_max = nullptr,
+                     const FoldedConv* ff = nullptr, const float* fin = nullptr, int up = 1) {
   if (block_fusable(f5, f1, L)) {
     ConvBlockArgs a;
     std::memset(&a, 0, sizeof(a));
     a.x = x; a.w5 = m->blob + f5.w; a.b5 = m->blob + f5.b; a.w1 = m->blob + f1.w; a.b1 = m->blob + f1.b;
     a.res2 = skip; a.out = out; a.B = B; a.C = f5.Cin; a.L = L;
+    if (ff) {
+      a.f_in = fin; a.f_w = m->blob + ff->w; a.f_b = m->blob + ff->b; a.Cf = ff->Cin; a.Lf = L / up; a.f_up = up;
+    }
     if (tail_max) {   // out_conv (1x1, BN, ReLU, 1x1, Softplus) + max over positions ride on the last decoder block
       a.ta_w = m->blob + m->out1.w; a.ta_b = m->blob + m->out1.b; a.tb_w = m->blob + m->out2.w; a.tb_b = m->blob + m->out2.b;
       a.tail_max = tail_max;
     }
     return launch_convblock(a, stream);
   }
-  MURAL_REQUIRE(!tail_max, "internal: tail fusion requested for an unfusable block");
+  MURAL_REQUIRE(!tail_max && !ff, "internal: front / tail fusion requested for an unfusable block");
   if (int rc = run_conv(m, f5, x, B, L, H, L, 1, 1, ACT_SILU, nullptr, nullptr, stream)) return rc;
   return run_conv(m, f1, H, B, L, out, L, 1, 1, ACT_NONE, x, skip, stream);
 }
@@ -274,8 +286,8 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     float* T2 = take(tmax);
     float* H = take(hmax);
     float* SP = take((size_t)C0 * m->len[0]);
-    const int mparts = (m->len[0] + 255) / 256;
-    float* M = take((size_t)C0 * mparts);
+    int mparts = 1;
+    float* M = take((size_t)C0 * convblock_tiles(m->len[0], true));
     const float* x = distal_x + (size_t)c0 * 4 * Lx;
     int rc = MURAL_OK;
     const float* cur = x;
@@ -286,8 +298,12 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     }
     for (int i = 0; i < INDEL_LEVELS; ++i) {     // encoder: strided conv+BN, then ConvBlock (x + BN(1x1(SiLU(BN(k5)))))
       const int Li = m->len[i];
-      if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
-      if ((rc = run_block(m, m->up5[i], m->up1[i], T1, B, Li, H, E[i], nullptr, stream))) return rc;
+      if (sh.down[i] == 1 && block_fusable(m->up5[i], m->up1[i], Li) && front_fusable(m->up_l[i], 1, m->ch[i])) {
+        if ((rc = run_block(m, m->up5[i], m->up1[i], nullptr, B, Li, H, E[i], nullptr, stream, nullptr, &m->up_l[i], cur, 1))) return rc;
+      } else {
+        if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
+        if ((rc = run_block(m, m->up5[i], m->up1[i], T1, B, Li, H, E[i], nullptr, stream))) return rc;
+      }
       cur = E[i];
       Lcur = Li;
     }
@@ -296,9 +312,18 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     for (int j = 0; j < INDEL_LEVELS - 1; ++j) {   // decoder: upsample, conv+BN, ConvBlock, + encoder skip
       const int lvl = INDEL_LEVELS - 2 - j;
       const int Li = m->len[lvl];
-      if ((rc = run_conv(m, m->dn_l[j], cur, B, Lcur, T1, Li, 1, sh.down[lvl + 1], ACT_NONE, nullptr, nullptr, stream))) return rc;
       const bool fuse_tail = lvl == 0 && block_fusable(m->dn5[j], m->dn1[j], Li);
-      if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr))) return rc;
+      const int up = sh.down[lvl + 1];
+      if (block_fusable(m->dn5[j], m->dn1[j], Li) && front_fusable(m->dn_l[j], up, m->ch[lvl]) && Lcur * up == Li) {
+        if ((rc = run_block(m, m->dn5[j], m->dn1[j], nullptr, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr, &m->dn_l[j], cur,
+                            up)))
+          return rc;
+        if (fuse_tail) mparts = convblock_tiles(Li, true);
+      } else {
+        if ((rc = run_conv(m, m->dn_l[j], cur, B, Lcur, T1, Li, 1, up, ACT_NONE, nullptr, nullptr, stream))) return rc;
+        if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr))) return rc;
+        if (fuse_tail) mparts = convblock_tiles(Li, false);
+      }
       tail_done = fuse_tail;
       cur = dec;
       Lcur = Li;
