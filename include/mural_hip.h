@@ -211,6 +211,11 @@ int mural_op_conv32(const float* x, const float* W, const float* bias, float* y,
 size_t mural_op_conv32_wgrad_scratch(void);
 int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B, int32_t L, const float* pre_s, const float* pre_t,
                           int32_t pre_relu, float* dW, float* db, float* part, size_t part_floats, void* stream);
+/* Whole backward of one BN -> conv32 layer in one pass over dy: dW, db, dz = dL/d(conv input) and the BatchNorm-backward
+ * sums of dz (accumulator block stat_out, zeroed by the caller; feed it to mural_op_bn_backward with have_sums = 1).      */
+int mural_op_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* pre_s,
+                        const float* pre_t, int32_t pre_relu, const float* mean, const float* invstd, float* dW, float* db,
+                        float* dz, double* stat_out, float* part, size_t part_floats, void* stream);
 int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
                          int32_t* arg, void* stream);
 int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,

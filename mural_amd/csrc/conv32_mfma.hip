@@ -329,6 +329,209 @@ __global__ __launch_bounds__(256) void wgrad32_mfma_kernel(const Wgrad32Args a) 
     dst[i] = (wimg[i] + wimg[(NW + C32) + i]) + (wimg[2 * (NW + C32) + i] + wimg[3 * (NW + C32) + i]);
 }
 
+// ------------------------------------------------------------------------------------------------- fused backward
+// One pass over a layer's backward: weight / bias gradient partials (as wgrad32_mfma_kernel), the input gradient dz = dgrad(dy)
+// and the BatchNorm-backward sums of dz (as conv32_mfma_kernel<2>) from ONE staging of the dy tile: dy is read once
+// instead of twice and a launch disappears.  LDS: dy image | BN(act(x)) image | aux.
+struct Bwd32Args {
+  const float* dy;       // [B][32][L]
+  const float* x;        // [B][32][L] pre-activation saved by the forward
+  const float* W;        // PyTorch [32][32][3]
+  const float* pre_s;    // conv input was pre_s * act(x) + pre_t
+  const float* pre_t;
+  const float* mean;     // batch statistics of act(x) (BatchNorm backward)
+  const float* invstd;
+  int pre_relu;
+  int B, L, R, Sc, NC, nb;
+  FastDiv dL, dSc;
+  float* part;           // [grid][32*32*3 + 32]
+  float* dz;             // [B][32][L]
+  double* stat_out;      // accumulator block: sum(dz), sum(dz * xhat)
+};
+
+__global__ __launch_bounds__(256) void bwd32_mfma_kernel(const Bwd32Args a) {
+  extern __shared__ __attribute__((aligned(16))) float wimg[];
+  constexpr int pitch = C32_PITCH;
+  float* gimg = wimg;                       // dy tile, later dz / dz * xhat
+  float* aimg = wimg + C32 * pitch;         // BN(act(x)) tile
+  float* aux = aimg + C32 * pitch;          // pre_s | pre_t | mean | invstd
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int mb = wave & 1, cgp = wave >> 1;
+  const int n16 = lane & 15, kk = lane >> 4;
+  if (tid < 2 * C32) {
+    aux[tid] = a.pre_s ? (tid < C32 ? a.pre_s[tid] : a.pre_t[tid - C32]) : (tid < C32 ? 1.f : 0.f);
+    aux[2 * C32 + tid] = tid < C32 ? a.mean[tid] : a.invstd[tid - C32];
+  }
+  float af[C32_KSTEPS];                     // input-gradient filter fragments (transposed, tap-flipped)
+#pragma unroll
+  for (int s = 0; s < C32_KSTEPS; ++s) {
+    const int t = s / 8, h = (s % 8) / 4, q = s % 4;
+    const int cin = 16 * h + 4 * kk + q, cout = 16 * mb + n16;
+    af[s] = a.W[(cin * C32 + cout) * 3 + (2 - t)];
+  }
+  const int chv = 16 * mb + 4 * kk;
+  f32x4 wacc[2][3][2];                      // weight gradient [M-block][tap][cin half]
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h) wacc[m][t][h] = splat(0.f);
+  float bacc = 0.f, racc = 0.f;
+  float sv[4] = {0.f, 0.f, 0.f, 0.f};
+  const int nk = 4 * a.nb;
+  const int k_lo = wave * nk / 4, k_hi = (wave + 1) * nk / 4;
+  const float* gp = gimg + n16 * pitch + 1 + kk;
+  const float* ap = aimg + n16 * pitch + kk;
+  const int nbw = a.nb > cgp ? (a.nb - cgp + 1) / 2 : 0;
+  const float* rd = gimg + 4 * kk * pitch + n16;
+  const int64_t ntiles = ((int64_t)a.B + a.R - 1) / a.R;
+  for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const int64_t b0 = tile * a.R;
+    const int rows = (int)((a.B - b0) < a.R ? (a.B - b0) : a.R);
+    __syncthreads();
+    stage_rows(a.dy, b0, a.B, a.L, a.R, a.Sc, a.dL, nullptr, 0, gimg, tid, true, 16 * a.nb + 1);
+    stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.dL, a.pre_s ? aux : nullptr, a.pre_relu, aimg, tid, true, 16 * a.nb + 1);
+    __syncthreads();
+    // ---- weight gradient: this wave's quarter of the columns
+    for (int s = k_lo; s < k_hi; ++s) {
+      float g[2], bv[3][2];
+#pragma unroll
+      for (int m = 0; m < 2; ++m) g[m] = gp[16 * m * pitch + 4 * s];
+#pragma unroll
+      for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bv[t][h] = ap[16 * h * pitch + 4 * s + t];
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) wacc[m][t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[m], bv[t][h], wacc[m][t][h], 0, 0, 0);
+    }
+    {   // bias gradient: thread = (cout tid/8, column residue tid%8)
+      const int co = tid >> 3, p8 = tid & 7;
+      const float* row = gimg + co * pitch + 1;
+      float sum = 0.f;
+      for (int c = p8; c < 16 * a.nb; c += 8) sum += row[c];
+      bacc += sum;
+    }
+    // ---- input gradient: this wave's M-block against every second column block of the dy image
+    f32x4 acc[C32_NB2MAX + 1];
+#pragma unroll
+    for (int ip = 0; ip < (C32_NB2MAX + 1) / 2; ++ip) {
+      const int i0 = 2 * ip, i1 = 2 * ip + 1;
+      if (i0 < nbw) {
+        const bool dual = i1 < nbw;
+        const float* p0 = rd + 16 * (cgp + 2 * i0);
+        const float* p1 = rd + 16 * (cgp + 2 * (dual ? i1 : i0));
+        f32x4 a0 = splat(0.f), a1 = splat(0.f);
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+          float b0v[8], b1v[8];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            b0v[j] = p0[(16 * (j >> 2) + (j & 3)) * pitch + t];
+            b1v[j] = p1[(16 * (j >> 2) + (j & 3)) * pitch + t];
+          }
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            a0 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[8 * t + j], b0v[j], a0, 0, 0, 0);
+            if (dual) a1 = __builtin_amdgcn_mfma_f32_16x16x4f32(af[8 * t + j], b1v[j], a1, 0, 0, 0);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        acc[i0] = a0;
+        acc[i1] = a1;
+      }
+    }
+    __syncthreads();                                     // every wave is done with the dy image: overwrite it with dz
+#pragma unroll
+    for (int i = 0; i < C32_NB2MAX; ++i) {
+      if (i < nbw) {
+        const int c = 16 * (cgp + 2 * i) + n16;
+        const f32x4 v = acc[i];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gimg[(chv + q) * pitch + 1 + c] = v[q];
+        if (c >= 1) {
+          const uint32_t u = (uint32_t)(c - 1);
+          const uint32_t r = a.dSc.div(u);
+          if ((int)r < rows && (int)(u - r * (uint32_t)a.Sc) < a.L) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sv[q] += v[q];
+          }
+        }
+      }
+    }
+    __syncthreads();
+    const int total = rows * C32 * a.L;
+    const size_t base = (size_t)b0 * C32 * a.L;
+#pragma unroll 1
+    for (int i0 = tid * 4; i0 < total; i0 += 256 * 4) {
+      const f32x4 sx = ld4(a.x + base + i0);
+      uint32_t rc = a.dL.div((uint32_t)i0);
+      int l = i0 - (int)rc * a.L;
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (l >= a.L) { l -= a.L; ++rc; }
+        const int r = (int)rc >> 5, ci = (int)rc & 31;
+        const int idx = ci * pitch + 2 + r * a.Sc + l;
+        const float v = gimg[idx];
+        o[e] = v;
+        const float xr = a.pre_relu ? fmaxf(sx[e], 0.f) : sx[e];
+        gimg[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
+        ++l;
+      }
+      st4(a.dz + base + i0, o);
+    }
+    __syncthreads();
+    {
+      const int ch = tid >> 3, p8 = tid & 7;
+      float s1 = 0.f;
+      for (int r = 0; r < rows; ++r) {
+        const float* row = gimg + ch * pitch + 2 + r * a.Sc;
+        for (int l = p8; l < a.L; l += 8) s1 += row[l];
+      }
+      racc += s1;
+    }
+  }
+  // BatchNorm-backward sums
+  {
+    double* slot = a.stat_out + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * C32;
+    racc += __shfl_xor(racc, 1); racc += __shfl_xor(racc, 2); racc += __shfl_xor(racc, 4);
+    if ((tid & 7) == 0) atomicAdd(&slot[C32 + (tid >> 3)], (double)racc);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+#pragma unroll
+      for (int off = 1; off < 16; off <<= 1) sv[q] += __shfl_xor(sv[q], off);
+      if (n16 == 0) atomicAdd(&slot[chv + q], (double)sv[q]);
+    }
+  }
+  // weight / bias gradient partial row of this workgroup
+  bacc += __shfl_xor(bacc, 1);
+  bacc += __shfl_xor(bacc, 2);
+  bacc += __shfl_xor(bacc, 4);
+  constexpr int NW = C32 * C32 * 3;
+  __syncthreads();
+  float* mine = wimg + (size_t)wave * (NW + C32);
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) mine[((16 * m + 4 * kk + r) * C32 + 16 * h + n16) * 3 + t] = wacc[m][t][h][r];
+  const float svb = __shfl(bacc, (lane & 7) * 8);
+  if (lane < C32) mine[NW + lane] = ((lane >> 3) == wave) ? svb : 0.f;
+  __syncthreads();
+  float* dst = a.part + (size_t)blockIdx.x * (NW + C32);
+  for (int i = tid; i < NW + C32; i += 256)
+    dst[i] = (wimg[i] + wimg[(NW + C32) + i]) + (wimg[2 * (NW + C32) + i] + wimg[3 * (NW + C32) + i]);
+}
+
 // 64 outputs x 16 slices of the partial rows per workgroup; fixed summation order -> reproducible gradients
 __global__ __launch_bounds__(1024) void part_reduce_kernel(const float* __restrict__ part, int nrow, int nW, int nB,
                                                            float* __restrict__ dW, float* __restrict__ db) {
@@ -431,6 +634,41 @@ extern "C" int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B,
     attr_set = true;
   }
   hipLaunchKernelGGL(wgrad32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);
+  hipLaunchKernelGGL(part_reduce_kernel, dim3((C32 * C32 * 3 + C32 + 63) / 64), dim3(1024), 0, stream, part, grid,
+                     C32 * C32 * 3, C32, dW, db);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+// Whole backward of y = conv32(pre_s * act(x) + pre_t) through the conv and its BatchNorm statistics in one pass over dy:
+// dW [32][32][3], db [32], dz = dL/d(conv input) [B][32][L] and the BatchNorm-backward sums of dz (accumulator block
+// stat_out, zeroed by the caller).  part: mural_op_conv32_wgrad_scratch() floats.
+extern "C" int mural_op_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* pre_s,
+                                   const float* pre_t, int32_t pre_relu, const float* mean, const float* invstd, float* dW,
+                                   float* db, float* dz, double* stat_out, float* part, size_t part_floats, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B == 0 || L == 0) return MURAL_OK;
+  Bwd32Args a;
+  std::memset(&a, 0, sizeof(a));
+  MURAL_REQUIRE(tile_geometry((int)B, L, &a.R, &a.Sc, &a.NC, &a.nb), "conv32_bwd: L = %d does not fit the LDS tile", L);
+  MURAL_REQUIRE(dy && x && W && mean && invstd && dW && db && dz && stat_out, "conv32_bwd: NULL argument");
+  a.dy = dy; a.x = x; a.W = W; a.pre_s = pre_s; a.pre_t = pre_t; a.pre_relu = pre_relu; a.mean = mean; a.invstd = invstd;
+  a.B = (int)B; a.L = L; a.part = part; a.dz = dz; a.stat_out = stat_out;
+  a.dL = FastDiv::make((uint32_t)L);
+  a.dSc = FastDiv::make((uint32_t)a.Sc);
+  const int64_t ntiles = (B + a.R - 1) / a.R;
+  const int grid = (int)(ntiles < 512 ? ntiles : 512);
+  MURAL_REQUIRE(part && part_floats >= (size_t)grid * (C32 * C32 * 3 + C32), "conv32_bwd: partial-sum scratch too small");
+  size_t lds = (size_t)(2 * C32 * C32_PITCH + C32_AUX) * 4;
+  const size_t lds_red = (size_t)4 * (C32 * C32 * 3 + C32) * 4;
+  lds = lds > lds_red ? lds : lds_red;
+  static bool attr_set = false;
+  if (!attr_set) {
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd32_mfma_kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(bwd32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);
   hipLaunchKernelGGL(part_reduce_kernel, dim3((C32 * C32 * 3 + C32 + 63) / 64), dim3(1024), 0, stream, part, grid,
                      C32 * C32 * 3, C32, dW, db);
   MURAL_HIP_CHECK(hipGetLastError());

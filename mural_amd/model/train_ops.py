@@ -150,11 +150,10 @@ class BnConv(torch.autograd.Function):
         db = torch.empty(weight.shape[0], device=x.device)
         dz = torch.empty_like(x)
         acc = _bn_acc(Cn, x.device)
-        if mfma:      # the input-gradient conv also takes the BatchNorm-backward sums of dz in its epilogue
+        if mfma:      # one pass over dy: weight / bias gradient, input gradient and the BatchNorm-backward sums of dz
             part = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), device=x.device)
-            _call("mural_op_conv32_wgrad", dy, x, B, L, scale, shift, int(pre_relu), dW, db, part, part.numel(), st)
-            _call("mural_op_conv32", dy, _f32(weight), None, dz, B, L, 1, None, None, 0, 0, None, None, 2, int(pre_relu), x, mean,
-                  invstd, acc, st)
+            _call("mural_op_conv32_bwd", dy, x, _f32(weight), B, L, scale, shift, int(pre_relu), mean, invstd, dW, db, dz, acc,
+                  part, part.numel(), st)
         else:
             wt = torch.empty_like(weight)
             part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=x.device)

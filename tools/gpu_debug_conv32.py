@@ -57,6 +57,21 @@ for B, L in [(32, 20), (32, 7), (32, 134), (5, 67), (300, 23), (4096, 20), (2050
     T._call("mural_op_conv32_wgrad", dy.to(dev), xg, B, L, sg, tg, 1, dW, db, part, part.numel(), st)
     e6 = ((dW.cpu().double() - Wd.grad).abs().max() / (Wd.grad.abs().max() + 1)).item()
     e7 = ((db.cpu().double() - bd.grad).abs().max() / (bd.grad.abs().max() + 1)).item()
+    # fused backward (one pass over dy)
+    dW2 = torch.empty(32, 32, 3, device=dev)
+    db2 = torch.empty(32, device=dev)
+    dz2 = torch.empty(B, 32, L, device=dev)
+    acc3 = torch.zeros(32, 2, 32, dtype=torch.float64, device=dev)
+    T._call("mural_op_conv32_bwd", dy.to(dev), xg, Wg, B, L, sg, tg, 1, mean.to(dev), invstd.to(dev), dW2, db2, dz2, acc3, part,
+            part.numel(), st)
+    a3 = acc3.sum(0).cpu()
+    e8 = max(((dW2.cpu().double() - Wd.grad).abs().max() / (Wd.grad.abs().max() + 1)).item(),
+             ((db2.cpu().double() - bd.grad).abs().max() / (bd.grad.abs().max() + 1)).item(),
+             (dz2.cpu().double() - dref).abs().max().item(),
+             ((a3[0] - dref.sum((0, 2))).abs().max() / (dref.sum((0, 2)).abs().max() + 1)).item(),
+             ((a3[1] - (dref * xh).sum((0, 2))).abs().max() / ((dref * xh).sum((0, 2)).abs().max() + 1)).item())
+    worst = max(worst, e8)
+    print("   fused backward worst %.1e" % e8)
     print("B=%5d L=%3d  fwd %.1e  sum %.1e sq %.1e | dgrad %.1e s1 %.1e s2 %.1e | dW %.1e db %.1e" % (B, L, e, e1, e2, e3, e4, e5, e6, e7))
     worst = max(worst, e, e1, e2, e3, e4, e5, e6, e7)
 print("worst", worst)
