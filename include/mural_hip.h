@@ -216,6 +216,16 @@ int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B, int32_t L,
 int mural_op_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* pre_s,
                         const float* pre_t, int32_t pre_relu, const float* mean, const float* invstd, float* dW, float* db,
                         float* dz, double* stat_out, float* part, size_t part_floats, void* stream);
+/* One call per BN -> conv32 layer and direction (composition of the kernels above).  state: float[4][32] = scale | shift |
+ * mean | invstd of this call's batch statistics, written by the forward and read by the backward.                          */
+int mural_op_bnconv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, double* acc, int32_t have_acc,
+                          const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                          float* running_var, float* state, const float* W, const float* bias, int32_t post_relu,
+                          const float* res1, const float* res2, double* acc_out, int32_t out_relu, float* y, void* stream);
+int mural_op_bnconv32_bwd(const float* dy, const float* x, int64_t B, int32_t L, int32_t pre_relu, const float* state,
+                          const float* gamma, const float* W, double* acc, float* part, size_t part_floats, float* dz,
+                          const float* add1, const float* add2, float* dW, float* db, float* dx, float* dgamma, float* dbeta,
+                          void* stream);
 int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
                          int32_t* arg, void* stream);
 int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "mural_bed_read": (C.c_int, [C.c_char_p, I64, VP, VP, VP, VP, VP, I32, I32, VP, VP, VP]),
     "mural_bed_segment_order": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP]),
     "mural_op_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]),
+    "mural_op_bnconv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP]),
+    "mural_op_bnconv32_bwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP, VP, VP, VP, VP, VP, VP]),
     "mural_op_first_plan": (C.c_int, [I32, I32, VP, VP, VP]),
     "mural_op_first_fwd": (C.c_int, [VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, VP, VP]),
     "mural_op_first_bwd": (C.c_int, [VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP]),

@@ -1044,3 +1044,43 @@ namespace mural { int launch_dense_to_symbols(const float* x, int64_t n, int L, 
 extern "C" int mural_op_dense_to_symbols(const float* x, int64_t n, int32_t L, uint8_t* sym, int32_t* status, void* stream) {
   return mural::launch_dense_to_symbols(x, n, L, sym, status, STREAM);
 }
+
+// ------------------------------------------------------------------------------------------- composed layer calls
+// One host call per BN -> conv32 layer and direction (the kernels are the ones above / in conv32_mfma.hip; composing them
+// here keeps the Python glue at one ctypes transition per layer, which matters once the step is launch-bound).
+extern "C" int mural_op_conv32(const float* x, const float* W, const float* bias, float* y, int64_t B, int32_t L, int32_t dgrad,
+                               const float* pre_s, const float* pre_t, int32_t pre_relu, int32_t post_relu, const float* res1,
+                               const float* res2, int32_t stat_mode, int32_t stat_relu, const float* stat_x,
+                               const float* stat_mean, const float* stat_invstd, double* stat_out, void* stream);
+extern "C" int mural_op_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* pre_s,
+                                   const float* pre_t, int32_t pre_relu, const float* mean, const float* invstd, float* dW,
+                                   float* db, float* dz, double* stat_out, float* part, size_t part_floats, void* stream);
+
+// forward: batch statistics (taken here unless acc already holds them) -> scale / shift / mean / invstd (state: float[4][32],
+// kept for the backward) + running statistics -> y = conv32(scale * act(x) + shift) [+ bias] [relu] [+ res1 + res2],
+// optionally with the batch sums of act'(y) for the next layer (acc_out)
+extern "C" int mural_op_bnconv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, double* acc, int32_t have_acc,
+                                     const float* gamma, const float* beta, float eps, float momentum, float* running_mean,
+                                     float* running_var, float* state, const float* W, const float* bias, int32_t post_relu,
+                                     const float* res1, const float* res2, double* acc_out, int32_t out_relu, float* y,
+                                     void* stream) {
+  if (!have_acc)
+    if (int rc = mural_op_bn_stats(x, B, 32, L, pre_relu, acc, stream)) return rc;
+  if (int rc = mural_op_bn_finalize(acc, (double)B * L, 32, gamma, beta, eps, momentum, running_mean, running_var, state,
+                                    state + 32, state + 64, state + 96, stream))
+    return rc;
+  return mural_op_conv32(x, W, bias, y, B, L, 0, state, state + 32, pre_relu, post_relu, res1, res2, acc_out ? 1 : 0, out_relu,
+                         nullptr, nullptr, nullptr, acc_out, stream);
+}
+
+// backward of the same layer: dW, db, then dx = BatchNorm backward of dz (+ add1 + add2), dgamma, dbeta.  dz: scratch [B][32][L]
+extern "C" int mural_op_bnconv32_bwd(const float* dy, const float* x, int64_t B, int32_t L, int32_t pre_relu, const float* state,
+                                     const float* gamma, const float* W, double* acc, float* part, size_t part_floats, float* dz,
+                                     const float* add1, const float* add2, float* dW, float* db, float* dx, float* dgamma,
+                                     float* dbeta, void* stream) {
+  if (int rc = mural_op_conv32_bwd(dy, x, W, B, L, state, state + 32, pre_relu, state + 64, state + 96, dW, db, dz, acc, part,
+                                   part_floats, stream))
+    return rc;
+  return mural_op_bn_backward(dz, x, B, 32, L, pre_relu, state + 64, state + 96, gamma, acc, 1, add1, add2, dx, dgamma, dbeta,
+                              stream);
+}

@@ -6,6 +6,7 @@ MuRaL/training.py:424-427).  BatchNorm running statistics are updated in place b
 ``nn.BatchNorm1d`` in training mode (momentum 0.1, unbiased running variance).
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -101,45 +102,62 @@ class _BnState:
         _bn_tick(bn)
 
 
+_part_cache = {}
+
+
+def _wgrad_part(device):
+    """Scratch for the per-workgroup weight-gradient partial rows (written and consumed inside one backward call)."""
+    t = _part_cache.get(device)
+    if t is None:
+        t = _part_cache[device] = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), device=device)
+    return t
+
+
 class BnConv(torch.autograd.Function):
     """y = Conv1d(BN(act(x))) [+ ReLU] [+ res1 + res2], act = ReLU or identity, 32->32 channels, k=3, pad=1.
 
     ``stats_in``: batch sums of act(x) taken by the producer of x (skips the statistics pass); ``stats_out`` (None / False /
     True): also return the batch sums of y (True: of relu(y)) for the BatchNorm that consumes y, taken in the conv epilogue.
-    Returns (y, sums or an empty tensor)."""
+    Returns (y, sums or an empty tensor).  The 32-channel MFMA path is one C call per direction."""
 
     @staticmethod
     def forward(ctx, x, gamma, beta, weight, bias, res1, res2, bn, pre_relu, post_relu, stats_in=None, stats_out=None):
         x = x.contiguous()
         B, Cn, L = x.shape
+        dev = x.device
         st = _stream(x)
-        state = _BnState(x, pre_relu, bn, L, stats_in)
-        y = torch.empty((B, weight.shape[0], L), device=x.device)
+        y = torch.empty((B, weight.shape[0], L), device=dev)
         mfma = tuple(weight.shape) == (32, 32, 3) and bool(_lib.lib().mural_op_conv32_supported(L))
         want = stats_out is not None
-        acc_out = _bn_acc(weight.shape[0], x.device) if want else torch.empty(0, device=x.device)
+        acc_out = _bn_acc(weight.shape[0], dev) if want else torch.empty(0, device=dev)
         if mfma:      # fp32 MFMA implicit GEMM (csrc/conv32_mfma.hip)
-            _call("mural_op_conv32", x, _f32(weight), _f32(bias), y, B, L, 0, state.scale, state.shift, int(pre_relu),
-                  int(post_relu), _p(res1), _p(res2), 1 if want else 0, int(bool(stats_out)), None, None, None,
-                  acc_out if want else None, st)
+            state = torch.empty((4, Cn), device=dev)
+            acc = stats_in if stats_in is not None else _bn_acc(Cn, dev)
+            _call("mural_op_bnconv32_fwd", x, B, L, int(pre_relu), acc, int(stats_in is not None), _f32(bn.weight), _f32(bn.bias),
+                  EPS, MOMENTUM, bn.running_mean, bn.running_var, state, _f32(weight), _f32(bias), int(post_relu), _p(res1),
+                  _p(res2), acc_out if want else None, int(bool(stats_out)), y, st)
+            _bn_tick(bn)
         else:         # generic direct conv (csrc/conv1d.hip)
+            bs = _BnState(x, pre_relu, bn, L, stats_in)
+            state = torch.stack([bs.scale, bs.shift, bs.mean, bs.invstd])
             wt = torch.empty_like(weight)
             _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 0, st)
-            _call("mural_op_conv1d", x, wt, _f32(bias), y, B, Cn, weight.shape[0], L, weight.shape[2], state.scale,
-                  state.shift, int(pre_relu), int(post_relu), _p(res1), _p(res2), st)
+            _call("mural_op_conv1d", x, wt, _f32(bias), y, B, Cn, weight.shape[0], L, weight.shape[2], state[0], state[1],
+                  int(pre_relu), int(post_relu), _p(res1), _p(res2), st)
             if want:
                 _call("mural_op_bn_stats", y, B, weight.shape[0], L, int(bool(stats_out)), acc_out, st)
-        ctx.save_for_backward(x, gamma, weight, y if post_relu else None, state.scale, state.shift, state.mean, state.invstd)
+        ctx.save_for_backward(x, gamma, weight, y if post_relu else None, state)
         ctx.flags = (pre_relu, post_relu, res1 is not None, res2 is not None, mfma)
         ctx.mark_non_differentiable(acc_out)
         return y, acc_out
 
     @staticmethod
     def backward(ctx, dy, _dacc):
-        x, gamma, weight, y, scale, shift, mean, invstd = ctx.saved_tensors
+        x, gamma, weight, y, state = ctx.saved_tensors
         pre_relu, post_relu, has_r1, has_r2, mfma = ctx.flags
         dy = dy.contiguous()
         B, Cn, L = x.shape
+        dev = x.device
         st = _stream(x)
         dres = dy
         if post_relu:
@@ -147,26 +165,26 @@ class BnConv(torch.autograd.Function):
             _call("mural_op_relu_mask", dy, y, dy.numel(), g, st)
             dy = g
         dW = torch.empty_like(weight)
-        db = torch.empty(weight.shape[0], device=x.device)
+        small = torch.empty((3, Cn), device=dev)          # db | dgamma | dbeta
+        db, dgamma, dbeta = small[0], small[1], small[2]
         dz = torch.empty_like(x)
-        acc = _bn_acc(Cn, x.device)
-        if mfma:      # one pass over dy: weight / bias gradient, input gradient and the BatchNorm-backward sums of dz
-            part = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), device=x.device)
-            _call("mural_op_conv32_bwd", dy, x, _f32(weight), B, L, scale, shift, int(pre_relu), mean, invstd, dW, db, dz, acc,
-                  part, part.numel(), st)
+        dx = torch.empty_like(x)
+        acc = _bn_acc(Cn, dev)
+        if mfma:      # one pass over dy: weight / bias gradient, input gradient, BatchNorm-backward sums; then the BN backward
+            part = _wgrad_part(dev)
+            _call("mural_op_bnconv32_bwd", dy, x, B, L, int(pre_relu), state, _f32(gamma), _f32(weight), acc, part, part.numel(),
+                  dz, None, None, dW, db, dx, dgamma, dbeta, st)
         else:
+            scale, shift, mean, invstd = state[0], state[1], state[2], state[3]
             wt = torch.empty_like(weight)
-            part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=x.device)
+            part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=dev)
             _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, part,
                   part.numel(), st)
             _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 1, st)
             _call("mural_op_conv1d", dy, wt, None, dz, B, weight.shape[0], Cn, L, weight.shape[2], None, None, 0, 0, None, None,
                   st)
-        dx = torch.empty_like(x)
-        dgamma = torch.empty(Cn, device=x.device)
-        dbeta = torch.empty(Cn, device=x.device)
-        _call("mural_op_bn_backward", dz, x, B, Cn, L, int(pre_relu), mean, invstd, _f32(gamma), acc, int(mfma), None, None, dx,
-              dgamma, dbeta, st)
+            _call("mural_op_bn_backward", dz, x, B, Cn, L, int(pre_relu), mean, invstd, _f32(gamma), acc, 0, None, None, dx,
+                  dgamma, dbeta, st)
         return (dx, dgamma, dbeta, dW, db, (dres if has_r1 else None), (dres if has_r2 else None), None, None, None, None,
                 None)
 
@@ -394,6 +412,8 @@ def dense_to_symbols(distal_x):
 
 
 def flush_input_checks():
+    if os.environ.get("MURAL_DEBUG_NO_INPUT_CHECK"):      # diagnostic (tools/host_vs_gpu_train.py): never wait for the device
+        _pending_checks.clear()
     while _pending_checks:
         ev, host = _pending_checks.pop()
         ev.synchronize()
