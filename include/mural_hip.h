@@ -250,7 +250,8 @@ int mural_op_embedding_fwd(const int64_t* cat, const float* E, int64_t B, int32_
                            void* stream);
 int mural_op_embedding_bwd(const int64_t* cat, const float* dy, int64_t B, int32_t cols, int32_t rows, float* dE,
                            void* stream);
-int mural_op_dropout(const float* x, int64_t total, float p, uint64_t seed, float* y, void* stream);
+int mural_op_dropout(const float* x, int64_t total, float p, uint64_t seed, const uint64_t* seed_dev, float* y,
+                     void* stream);
 int mural_op_relu_mask(const float* g, const float* ref, int64_t total, float* y, void* stream);
 int mural_op_head_fwd(const float* loc, const float* mid, const float* lar, int64_t B, int32_t nc, float* out,
                       void* stream);

@@ -103,7 +103,7 @@ PROTOTYPES = {
     "mural_op_linear_bwd": (C.c_int, [VP, VP, VP, I64, I32, I32, VP, VP, VP, VP]),
     "mural_op_embedding_fwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP]),
     "mural_op_embedding_bwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP]),
-    "mural_op_dropout": (C.c_int, [VP, I64, C.c_float, C.c_uint64, VP, VP]),
+    "mural_op_dropout": (C.c_int, [VP, I64, C.c_float, C.c_uint64, VP, VP, VP]),
     "mural_op_relu_mask": (C.c_int, [VP, VP, I64, VP, VP]),
     "mural_op_head_fwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP]),
     "mural_op_head_bwd": (C.c_int, [VP, VP, VP, VP, I64, I32, VP, VP, VP, VP]),

@@ -360,7 +360,12 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
   using KernelFn = void (*)(const FirstTrainArgs);
   KernelFn fn = slot == 4 ? (bwd ? first_train_kernel<4, true> : first_train_kernel<4, false>)
                           : (bwd ? first_train_kernel<16, true> : first_train_kernel<16, false>);
-  MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  static bool attr_set[4] = {false, false, false, false};   // once per instantiation (and never inside a graph capture)
+  const int which = (slot == 4 ? 0 : 2) + (bwd ? 1 : 0);
+  if (!attr_set[which]) {
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set[which] = true;
+  }
   hipLaunchKernelGGL(fn, dim3(first_train_grid(a.B)), dim3(S1_THREADS), lds, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;

@@ -701,7 +701,9 @@ __device__ __forceinline__ uint64_t mix64(uint64_t z) {
 }
 
 // y = x * keep / (1 - p), keep ~ Bernoulli(1 - p) from a counter-based generator (seed, element index)
-__global__ void dropout_kernel(const float* __restrict__ x, int64_t total, float p, uint64_t seed, float* __restrict__ y) {
+__global__ void dropout_kernel(const float* __restrict__ x, int64_t total, float p, uint64_t seed,
+                               const uint64_t* __restrict__ seed_dev, float* __restrict__ y) {
+  if (seed_dev) seed += *seed_dev;     // device-resident step counter: a captured graph draws a new mask on every replay
   const float scale = 1.f / (1.f - p);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const uint64_t r = mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
@@ -1010,9 +1012,10 @@ extern "C" int mural_op_embedding_bwd(const int64_t* cat, const float* dy, int64
   CHECK_LAUNCH();
 }
 
-extern "C" int mural_op_dropout(const float* x, int64_t total, float p, uint64_t seed, float* y, void* stream) {
+extern "C" int mural_op_dropout(const float* x, int64_t total, float p, uint64_t seed, const uint64_t* seed_dev, float* y,
+                                void* stream) {
   if (total == 0) return MURAL_OK;
-  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, x, total, p, seed, y);
+  hipLaunchKernelGGL(dropout_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, x, total, p, seed, seed_dev, y);
   CHECK_LAUNCH();
 }
 

@@ -36,6 +36,11 @@ class _ZeroArena:
 _arena = _ZeroArena()
 
 
+def reset_zero_arena():
+    """Drop the current chunk (graph capture: the fill of the chunks used inside the graph must be part of the graph)."""
+    _arena.buf, _arena.off = None, 0
+
+
 def _bn_acc(Cn, device):
     """Zeroed accumulator block (BN_SLOTS, 2, C) for batch sums (see mural_op_bn_stats)."""
     return _arena.take(BN_SLOTS * 2 * Cn, device).view(BN_SLOTS, 2, Cn)
@@ -340,26 +345,37 @@ class Dropout(torch.autograd.Function):
     """Inverted dropout with a counter-based generator; the mask is regenerated from the seed in the backward."""
 
     @staticmethod
-    def forward(ctx, x, p, seed):
+    def forward(ctx, x, p, seed, seed_dev=None):
         x = x.contiguous()
         y = torch.empty_like(x)
-        _call("mural_op_dropout", x, x.numel(), float(p), C.c_uint64(seed), y, _stream(x))
-        ctx.p, ctx.seed = float(p), seed
+        _call("mural_op_dropout", x, x.numel(), float(p), C.c_uint64(seed), seed_dev, y, _stream(x))
+        ctx.p, ctx.seed, ctx.seed_dev = float(p), seed, seed_dev
         return y
 
     @staticmethod
     def backward(ctx, dy):
         dy = dy.contiguous()
         dx = torch.empty_like(dy)
-        _call("mural_op_dropout", dy, dy.numel(), ctx.p, C.c_uint64(ctx.seed), dx, _stream(dy))
-        return dx, None, None
+        _call("mural_op_dropout", dy, dy.numel(), ctx.p, C.c_uint64(ctx.seed), ctx.seed_dev, dx, _stream(dy))
+        return dx, None, None, None
+
+
+_device_seed = None
+
+
+def set_device_seed(t):
+    """A device-resident uint64 step counter (int64 tensor of one element) added to every dropout seed, or None.  A captured
+    training step (mural_amd.train.GraphedTrainStep) bakes the host-drawn seeds into the graph and advances this counter
+    inside it, so every replay draws fresh masks."""
+    global _device_seed
+    _device_seed = t
 
 
 def dropout(x, p, training=True):
     if not training or p <= 0.0:
         return x
     seed = int(torch.randint(0, 2 ** 62, (1,)).item())     # drawn from torch's CPU generator: torch.manual_seed applies
-    return Dropout.apply(x, p, seed)
+    return Dropout.apply(x, p, seed, _device_seed)
 
 
 class Head(torch.autograd.Function):
@@ -389,6 +405,7 @@ class Head(torch.autograd.Function):
 
 _pending_checks = []
 _status_host = {}
+captured_status = []
 
 
 def dense_to_symbols(distal_x):
@@ -401,6 +418,9 @@ def dense_to_symbols(distal_x):
     sym = torch.empty((B, L), dtype=torch.uint8, device=dev)
     status = torch.zeros(1, dtype=torch.int32, device=dev)
     _call("mural_op_dense_to_symbols", x, B, L, sym, status, _stream(x))
+    if torch.cuda.is_current_stream_capturing():
+        captured_status.append(status)          # read by the owner of the graph after a replay (GraphedTrainStep)
+        return sym
     host = _status_host.get(dev)
     if host is None:
         host = _status_host[dev] = torch.zeros(1, dtype=torch.int32).pin_memory()
@@ -414,6 +434,8 @@ def dense_to_symbols(distal_x):
 def flush_input_checks():
     if os.environ.get("MURAL_DEBUG_NO_INPUT_CHECK"):      # diagnostic (tools/host_vs_gpu_train.py): never wait for the device
         _pending_checks.clear()
+    if _pending_checks and torch.cuda.is_current_stream_capturing():
+        return                                            # a captured step: the owner of the graph checks after the replay
     while _pending_checks:
         ev, host = _pending_checks.pop()
         ev.synchronize()

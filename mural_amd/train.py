@@ -1,0 +1,86 @@
+"""Whole-step hipGraph replay of the SNV training step.
+
+The eager step (MuRaL/training.py:424-436: forward, CE-sum loss, zero_grad, backward, clip_grad_norm_, optimizer.step) is
+about 300 kernel launches behind ~4 ms of Python; once the kernels are fast the host is the bottleneck.  ``GraphedTrainStep``
+captures one step into a HIP graph (``torch.cuda.CUDAGraph``) and replays it: the host then costs one launch per step.
+
+Differences from a plain loop, all of them the usual graph-capture contract:
+  * batch shapes are fixed at capture; inputs are copied into static tensors before every replay;
+  * the optimizer must be capturable (``torch.optim.Adam(..., capturable=True)``) and is stepped inside the graph;
+  * dropout masks: the host-drawn seeds are baked into the graph, a device-resident counter advanced inside the graph is
+    added to them, so every replay draws new masks (``train_ops.set_device_seed``);
+  * the encoding check of ``distal_x`` (ValueError on a non-MuRaL column) is read back after the replay, one step late.
+"""
+import torch
+
+from .model import train_ops as T
+
+
+class GraphedTrainStep:
+    def __init__(self, model, optimizer, criterion, cont_x, cat_x, distal_x, y, max_norm=10.0, warmup=3):
+        dev = distal_x.device
+        self.model, self.opt, self.crit, self.max_norm = model, optimizer, criterion, max_norm
+        self.cont, self.cat, self.x, self.y = (t.clone() for t in (cont_x, cat_x, distal_x, y))
+        self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
+        self.loss = None
+        self._status = []
+        self._pending = None
+        T.set_device_seed(self.seed)
+        try:
+            side = torch.cuda.Stream(device=dev)
+            side.wait_stream(torch.cuda.current_stream(dev))
+            with torch.cuda.stream(side):
+                for _ in range(warmup):        # allocator warm-up, lazy kernel attributes, optimizer state
+                    self._eager_step()
+            torch.cuda.current_stream(dev).wait_stream(side)
+            torch.cuda.synchronize(dev)
+            T.reset_zero_arena()
+            T.captured_status.clear()
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self._eager_step()
+            self._status = list(T.captured_status)
+            T.captured_status.clear()
+            T.reset_zero_arena()
+        finally:
+            T.set_device_seed(None)
+
+    def _eager_step(self):
+        self.seed += 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF       # new dropout masks every step (odd 63-bit increment)
+        out = self.model((self.cont, self.cat), self.x)
+        self.loss = self.crit(out, self.y)
+        self.opt.zero_grad(set_to_none=False)
+        self.loss.backward()
+        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
+        self.opt.step()
+
+    def __call__(self, cont_x, cat_x, distal_x, y):
+        """Run one training step on this batch; returns the (device) loss tensor of the step."""
+        self._check()
+        self.cont.copy_(cont_x, non_blocking=True)
+        self.cat.copy_(cat_x, non_blocking=True)
+        self.x.copy_(distal_x, non_blocking=True)
+        self.y.copy_(y, non_blocking=True)
+        self.graph.replay()
+        if self._status:
+            host = torch.empty(len(self._status), dtype=torch.int32, pin_memory=True)
+            for i, s in enumerate(self._status):
+                host[i:i + 1].copy_(s, non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record()
+            self._pending = (ev, host)
+        return self.loss
+
+    def _check(self):
+        if self._pending is not None:
+            ev, host = self._pending
+            ev.synchronize()
+            self._pending = None
+            if int(host.max()) != 0:
+                raise ValueError("distal_input of the previous step held a column that is not a MuRaL one-hot / IUPAC-fraction "
+                                 "encoding")
+
+    def finish(self):
+        """Wait for the last replay and raise its deferred input check, if any."""
+        torch.cuda.synchronize()
+        self._check()

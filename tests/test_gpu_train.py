@@ -58,6 +58,9 @@ def test_dropout_statistics_and_determinism():
     assert abs(keep - 0.75) < 5e-3
     assert torch.allclose(y[y != 0], torch.full((1,), 1 / 0.75, device="cuda"))
     assert torch.equal(y, T.Dropout.apply(x, 0.25, 1234)) and not torch.equal(y, T.Dropout.apply(x, 0.25, 1235))
+    # a device-resident counter is added to the seed (graph replay draws new masks from it)
+    ctr = torch.tensor([1], dtype=torch.int64, device="cuda")
+    assert torch.equal(T.Dropout.apply(x, 0.25, 1234, ctr), T.Dropout.apply(x, 0.25, 1235))
 
 
 def test_optimizer_step_runs_and_eval_uses_updated_weights():
@@ -126,3 +129,50 @@ def test_train_step_network0_network1_vs_oracle_autograd(model_no):
             continue
         w = ref[k].grad.numpy()
         assert np.abs(p.grad.cpu().numpy() - w).max() <= 2e-4 * (np.abs(w).max() + 1e-2), k
+
+
+def test_graphed_train_step_matches_eager():
+    """hipGraph replay of the whole step (mural_amd.train.GraphedTrainStep) == the eager step: same parameters after the
+    same batches (dropout off so both paths are deterministic), and a non-encoding input is reported one step late."""
+    from mural_amd.train import GraphedTrainStep
+    fx = U.load("snv_train_T.npz")
+    B = len(fx["cat"])
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"]).cuda()
+    cont = torch.zeros(B, 1, dtype=torch.float64, device="cuda")
+    crit = nn.CrossEntropyLoss(reduction="sum")
+
+    def make():
+        model, _ = product_from_hp(fx["hp"])
+        orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+        model.load_state_dict(U.snv_state_for(fx, orc))
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        model = model.cuda().train()
+        return model, torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True)
+
+    eager, opt_e = make()
+    n_steps = 3 + 2            # GraphedTrainStep: 3 eager warm-up steps + 2 replays (capturing executes nothing), same batch
+    for _ in range(n_steps):
+        loss = crit(eager((cont, cat), x), y)
+        opt_e.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(eager.parameters(), 10)
+        opt_e.step()
+    graphed, opt_g = make()
+    step = GraphedTrainStep(graphed, opt_g, crit, cont, cat, x, y)
+    for _ in range(2):
+        loss_g = step(cont, cat, x, y)
+    step.finish()
+    assert abs(loss_g.item() - loss.item()) <= 1e-3 * abs(loss.item())
+    for (k, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+        if not p.numel() or ("conv" in k and k.endswith(".bias")):
+            continue   # conv biases in front of a batch-statistics BN have ~1e-7 noise gradients: Adam turns them into +-lr steps
+        assert float((p.detach() - q.detach()).abs().max()) <= 1e-4 * (float(p.detach().abs().max()) + 1e-3), k
+    bad = x.clone()
+    bad[0, :, 5] = 0.3
+    step(cont, cat, bad, y)
+    with pytest.raises(ValueError, match="not a MuRaL"):
+        step.finish()
