@@ -1,0 +1,70 @@
+"""Post-head probability calibration of the prediction path (MuRaL/scripts/run_predict.py:217-225).
+
+  * ``dirichlet_calibrate``  -- the fitted full-Dirichlet map of ``model.fdiri_cal.pkl``:
+        softmax(W . [log(clip(p, tiny, 1 - tiny)); 1])            W: (n_class, n_class + 1), float64
+    (dirichlet_python/dirichletcal/calib/fulldirichlet.py:78-80, calib/multinomial.py:60-64, :235-244, utils.py:5-7).
+  * ``load_dirichlet_weights`` -- reads W out of the reference's pickles WITHOUT importing dirichletcal / jax: a restricted
+    unpickler maps the two calibrator classes to inert holders and ``jax._src.array._reconstruct_array`` (present in the
+    INDEL pickles) to its numpy equivalent; any other global is refused.
+  * ``poisson_calibrate`` lives in ``mural_amd.data.ingest`` (MuRaL/model/calibration.py:10-23).
+"""
+import pickle
+
+import numpy as np
+
+
+class _Holder:
+    """Stands in for FullDirichletCalibrator / MultinomialRegression: keeps the pickled attribute dict."""
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+
+
+def _reconstruct_jax_array(fun, args, arr_state, aval_state):
+    arr = fun(*args)
+    arr.__setstate__(arr_state)
+    return arr
+
+
+_ALLOWED = {
+    ("dirichletcal.calib.fulldirichlet", "FullDirichletCalibrator"): _Holder,
+    ("dirichletcal.calib.multinomial", "MultinomialRegression"): _Holder,
+    ("jax._src.array", "_reconstruct_array"): _reconstruct_jax_array,
+}
+_NUMPY_OK = {("numpy", "ndarray"), ("numpy", "dtype"), ("numpy.core.multiarray", "_reconstruct"),
+             ("numpy._core.multiarray", "_reconstruct"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar")}
+
+
+class _Restricted(pickle.Unpickler):
+    def find_class(self, module, name):
+        if (module, name) in _ALLOWED:
+            return _ALLOWED[(module, name)]
+        if (module, name) in _NUMPY_OK:
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f"calibrator pickle references {module}.{name}: refused")
+
+
+def load_dirichlet_weights(path):
+    """(n_class, n_class + 1) float64 weight matrix of a ``model.fdiri_cal.pkl`` written by the reference."""
+    with open(path, "rb") as fh:
+        obj = _Restricted(fh).load()
+    inner = getattr(obj, "calibrator_", None)
+    w = getattr(inner, "weights_", None)
+    if w is None:
+        raise ValueError(f"{path}: no fitted FullDirichletCalibrator inside (calibrator_.weights_ missing)")
+    w = np.asarray(w, dtype=np.float64)
+    if w.ndim != 2 or w.shape[1] != w.shape[0] + 1:
+        raise ValueError(f"{path}: unexpected weight shape {w.shape}")
+    return w
+
+
+def dirichlet_calibrate(prob, weights):
+    """Apply the full-Dirichlet calibration map to an (n, n_class) probability array; returns float64."""
+    prob = np.asarray(prob)
+    eps = np.finfo(prob.dtype).tiny                                    # clip_for_log uses the INPUT's dtype
+    s = np.log(np.clip(prob, eps, 1 - eps))
+    s1 = np.hstack((s, np.ones((len(s), 1))))
+    z = np.dot(s1, np.asarray(weights, dtype=np.float64).transpose())
+    z = z - np.max(z, axis=1).reshape(-1, 1)
+    e = np.exp(z)
+    return e / np.sum(e, axis=1).reshape(-1, 1)

@@ -173,11 +173,17 @@ def poisson_calibrate(prob):
     return out
 
 
-def write_predictions(res, path, poisson=False):
-    """The prediction table of run_predict.py:230-239: columns chrom, start, end, strand, mut_type, prob0.., rows sorted
-    by (chrom, start), tab-separated, floats as '%.4g'.  `res` is the dict returned by ``predict_bed``."""
+def write_predictions(res, path, poisson=False, dirichlet_weights=None):
+    """The prediction table of run_predict.py:217-239: optional Dirichlet calibration (``calibration.load_dirichlet_weights``
+    of the model's ``model.fdiri_cal.pkl``), optional Poisson calibration, then columns chrom, start, end, strand, mut_type,
+    prob0.., rows sorted by (chrom, start), tab-separated, floats as '%.4g'.  `res` is the dict returned by ``predict_bed``."""
     import pandas as pd
-    prob = poisson_calibrate(res["prob"]) if poisson else np.asarray(res["prob"])
+    prob = np.asarray(res["prob"])
+    if dirichlet_weights is not None:
+        from ..calibration import dirichlet_calibrate
+        prob = dirichlet_calibrate(prob, dirichlet_weights)
+    if poisson:
+        prob = poisson_calibrate(prob)
     names = ["prob%d" % i for i in range(prob.shape[1])]
     df = pd.concat((pd.DataFrame({"chrom": res["chrom"], "start": res["start"], "end": res["end"], "strand": res["strand"]}),
                     pd.DataFrame({"mut_type": np.asarray(res["label"]).astype(np.int64)}), pd.DataFrame(prob, columns=names)),

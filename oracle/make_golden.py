@@ -8,6 +8,7 @@ oracle/synth.py, one-hot tensors from base codes) are stored in their compact fo
 Fixture list:
   G1  encode_*.npz        seq_digit_encoder / seq_ohe_encoder on strings with N runs, lowercase, IUPAC,
                           both strands, chromosome-edge sites, clustered sites (merged windows)
+  G12 dirichlet.npz       FullDirichletCalibrator.predict_proba of two shipped calibrators
   G11 output.npz          poisson_calibrate + the sorted '%.4g' prediction table
   G2  windowing.npz       bed_reader segment order + get_seqs_to_digitalized tuples
   G3  snv_pretrained_*.npz  shipped checkpoints (weights included) -> log-probs
@@ -406,13 +407,75 @@ def g11_output(ref):
          table=np.array(buf.getvalue()))
 
 
+def g12_dirichlet(ref):
+    """FullDirichletCalibrator.predict_proba of two shipped calibrators (dirichlet_python/dirichletcal/calib/fulldirichlet.py
+    :78-80) run through the reference's own classes.  jax is absent in this image: ``jax.numpy`` is replaced by numpy for
+    the import (the predict path only uses hstack / dot / max / exp / sum, jax_enable_x64 float64), jax.grad & co by
+    placeholders (fitting is not exercised)."""
+    import pickle
+    import types
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "jax" or k.startswith("jax.") or k.startswith("dirichletcal")
+             or k == "autograd" or k.startswith("autograd.")}
+    for k in saved:
+        sys.modules.pop(k, None)
+
+    def mod(name, **kw):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for a, v in kw.items():
+            setattr(m, a, v)
+        sys.modules[name] = m
+        return m
+
+    def noop(f=None, **k):
+        return lambda *a, **kw: None
+
+    def recon(fun, args, arr_state, aval_state):
+        a = fun(*args)
+        a.__setstate__(arr_state)
+        return a
+
+    jax = mod("jax", numpy=np, grad=noop, hessian=noop, jit=lambda f, **k: f)
+    jax.config = mod("jax.config", config=types.SimpleNamespace(update=lambda *a, **k: None)).config
+    sys.modules["jax.numpy"] = np
+    mod("jax._src")
+    mod("jax._src.array", _reconstruct_array=recon)
+    mod("autograd", grad=noop, hessian=noop, numpy=np)
+    sys.modules["autograd.numpy"] = np
+    sys.path.insert(0, os.path.join(ref_import.REFERENCE_ROOT, "dirichlet_python"))
+    try:
+        importlib = __import__("importlib")
+        importlib.import_module("dirichletcal")
+        out = {}
+        rng = np.random.default_rng(12)
+        for tag, rel in (("snv", "models/Homo_sapiens/SNV/AT/model.fdiri_cal.pkl"),
+                         ("indel", "models/Homo_sapiens/INDEL/insertion/model.fdiri_cal.pkl")):
+            with open(os.path.join(ref_import.REFERENCE_ROOT, rel), "rb") as fh:
+                cal = pickle.load(fh)
+            w = np.asarray(cal.calibrator_.weights_, dtype=np.float64)
+            k = w.shape[0]
+            p = rng.dirichlet([30] + [1] * (k - 1), size=64).astype(np.float32)
+            p[0] = 0.0
+            p[0, 0] = 1.0                                  # exact 0 / 1 entries: clipped at finfo(float32).tiny
+            out[tag + "_w"] = w
+            out[tag + "_prob"] = p
+            out[tag + "_cal"] = np.asarray(cal.predict_proba(p))
+        save("dirichlet.npz", **out)
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == "jax" or k.startswith("jax.") or k.startswith("dirichletcal") or k == "autograd"
+                  or k.startswith("autograd.")]:
+            sys.modules.pop(k, None)
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_import.load()
     only = set(sys.argv[1:])
     steps = dict(g1=g1_encode, g2=g2_windowing, g3=g3_pretrained, g45=g45_synth, g6=g6_taps, g7=g7_train,
-                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output)
+                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet)
     for name, fn in steps.items():
         if only and name not in only:
             continue
