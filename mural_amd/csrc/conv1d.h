@@ -23,6 +23,7 @@ struct Conv1dArgs {
   int act;               // ConvAct applied to (acc + bias)
   const float* res1;     // optional residuals added AFTER the activation, [B][Cout][Lout]
   const float* res2;
+  int rt;                // set by launch_conv1d: batch rows packed into one 64-lane tile (short rows), 1 otherwise
 };
 
 int launch_conv1d(const Conv1dArgs& a, hipStream_t stream);

@@ -34,29 +34,43 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
   extern __shared__ float tile[];   // [Cin][TWp]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b = blockIdx.y;
+  // Short rows (Lout <= 32, the deep U-Net levels): RT = a.rt batch rows share one 64-lane tile, lane = (row, position);
+  // otherwise (RT = 1) a workgroup covers 64 / 256 positions of one row.
+  const int RT = WIDE ? 1 : a.rt;
+  const int b0 = blockIdx.y * RT;
   constexpr int TLB = WIDE ? 256 : 64;
   const int l0 = blockIdx.x * TLB;
-  const int TW = (TLB - 1) * a.stride + a.K;   // input span of the tile's outputs
+  const int TW = ((RT > 1 ? a.Lout : TLB) - 1) * a.stride + a.K;   // input span of one row of the tile
   const int TWp = TW | 1;                      // odd row stride: channel rows start on different banks
   const int in0 = l0 * a.stride - a.pad;       // first (virtual, upsampled) input index of the tile
   const int Lv = a.Lin * a.up;
-  for (int ci = wave; ci < a.Cin; ci += 4) {
-    const float* src = a.in + ((size_t)b * a.Cin + ci) * a.Lin;
+  for (int rc = wave; rc < RT * a.Cin; rc += 4) {
+    const int r = RT > 1 ? rc / a.Cin : 0, ci = rc - r * a.Cin;
+    const bool row_ok = b0 + r < a.B;
+    const float* src = a.in + ((size_t)(row_ok ? b0 + r : 0) * a.Cin + ci) * a.Lin;
     const float ps = a.pre_s ? a.pre_s[ci] : 1.f, pt = a.pre_t ? a.pre_t[ci] : 0.f;
     for (int j = lane; j < TW; j += 64) {
       const int v = in0 + j;
       float x = 0.f;                           // zero padding (applied after the pre-op, like nn.Conv1d after a BN)
-      if (v >= 0 && v < Lv) {
+      if (row_ok && v >= 0 && v < Lv) {
         x = src[a.up == 1 ? v : v / a.up];
         if (a.pre_relu) x = fmaxf(x, 0.f);
         x = fmaf(ps, x, pt);
       }
-      tile[ci * TWp + j] = x;
+      tile[rc * TWp + j] = x;
     }
   }
   __syncthreads();
-  const int lloc = WIDE ? 64 * wave + lane : lane;   // output position inside the tile
+  int lloc = WIDE ? 64 * wave + lane : lane;   // output position inside the tile
+  int b = b0, trow0 = 0;
+  bool live = true;
+  if (RT > 1) {
+    const int r = lane / a.Lout;
+    lloc = lane - r * a.Lout;
+    b = b0 + r;
+    live = r < RT && b < a.B;
+    trow0 = (live ? r : 0) * a.Cin * TWp;
+  }
   const int l = l0 + lloc;
   const int ngroups = a.Cout / COG;
   for (int cg = WIDE ? 0 : wave; cg < ngroups; cg += WIDE ? 1 : 4) {
@@ -69,7 +83,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
     const int K = KT ? KT : a.K;
 #pragma unroll 2
     for (int ci = 0; ci < a.Cin; ++ci) {   // unrolled: several input channels' scalar weight loads in flight together
-      const float* trow = tile + ci * TWp + lloc * a.stride;
+      const float* trow = tile + trow0 + ci * TWp + lloc * a.stride;
       if (KT) {
         float x[KT ? KT : 1];
 #pragma unroll
@@ -91,7 +105,7 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
         }
       }
     }
-    if (l < a.Lout) {
+    if (live && l < a.Lout) {
 #pragma unroll
       for (int c = 0; c < COG; ++c) {
         const size_t o = ((size_t)b * a.Cout + cg * COG + c) * a.Lout + l;
@@ -122,7 +136,8 @@ static Conv1dFn pick_kernel(int K, int cog) {
   return cog == 16 ? pick_taps<16, WIDE>(K) : (cog == 8 ? pick_taps<8, WIDE>(K) : pick_taps<4, WIDE>(K));
 }
 
-int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
+int launch_conv1d(const Conv1dArgs& a_in, hipStream_t stream) {
+  Conv1dArgs a = a_in;
   if (a.B == 0 || a.Lout == 0) return MURAL_OK;
   MURAL_REQUIRE(a.Cout % 4 == 0, "conv1d: Cout must be a multiple of 4 (got %d)", a.Cout);
   MURAL_REQUIRE(a.up >= 1 && a.stride >= 1 && a.K >= 1, "conv1d: bad geometry");
@@ -131,11 +146,16 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   const int ngroups = a.Cout / cog;
   const size_t lds_wide = (size_t)a.Cin * ((255 * a.stride + a.K) | 1) * sizeof(float);
   const bool wide = ngroups < 4 && lds_wide <= 64 * 1024 && a.Lout > 64;
-  const int TWp = ((wide ? 255 : 63) * a.stride + a.K) | 1;
-  const size_t lds = (size_t)a.Cin * TWp * sizeof(float);
+  a.rt = 1;
+  if (!wide && a.Lout <= 32) {                       // short rows: pack batch rows into the 64 lanes of a tile
+    a.rt = 64 / a.Lout;
+    while (a.rt > 1 && (size_t)a.rt * a.Cin * ((((size_t)a.Lout - 1) * a.stride + a.K) | 1) * sizeof(float) > 60 * 1024) --a.rt;
+  }
+  const int span = (a.rt > 1 ? a.Lout - 1 : (wide ? 255 : 63)) * a.stride + a.K;
+  const size_t lds = (size_t)a.rt * a.Cin * (span | 1) * sizeof(float);
   MURAL_REQUIRE(lds <= 160 * 1024, "conv1d: input tile of %zu bytes exceeds LDS", lds);
   const int tlb = wide ? 256 : 64;
-  const dim3 grid((a.Lout + tlb - 1) / tlb, a.B);
+  const dim3 grid(a.rt > 1 ? 1 : (a.Lout + tlb - 1) / tlb, (a.B + a.rt - 1) / a.rt);
   Conv1dFn fn = wide ? pick_kernel<true>(a.K, cog) : pick_kernel<false>(a.K, cog);
   if (lds > 64 * 1024)
     MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize,
