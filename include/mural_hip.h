@@ -228,8 +228,9 @@ int mural_op_bnconv32_bwd(const float* dy, const float* x, int64_t B, int32_t L,
                           void* stream);
 int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
                          int32_t* arg, void* stream);
-int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,
-                         void* stream);
+int mural_op_maxpool_bwd_needs_zero(int32_t k, int32_t s);   /* 1: dx must be zeroed by the caller (overlapping windows) */
+int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, int32_t k, int32_t s,
+                         int32_t p, float* dx, void* stream);
 /* First layer of a tower in training mode: maxpool1(Conv1d(BN(one-hot))) from window symbols (model_snv.py:473-475,
  * 496-497 under training.py:424), BN(4) batch statistics from the symbol histogram.  mural_op_first_plan gives the sizes of
  * the caller-allocated buffers: tab (floats), arg (bytes per pooled output) and the backward scratch (floats).       */

@@ -88,7 +88,8 @@ PROTOTYPES = {
     "mural_op_conv32_wgrad_scratch": (C.c_size_t, []),
     "mural_op_conv32_wgrad": (C.c_int, [VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, C.c_size_t, VP]),
     "mural_op_maxpool_fwd": (C.c_int, [VP, I64, I32, I32, I32, I32, VP, VP, VP]),
-    "mural_op_maxpool_bwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP]),
+    "mural_op_maxpool_bwd_needs_zero": (C.c_int, [I32, I32]),
+    "mural_op_maxpool_bwd": (C.c_int, [VP, VP, I64, I32, I32, I32, I32, I32, VP, VP]),
     "mural_fasta_scan": (C.c_int, [C.c_char_p, I64, I32, VP, VP, VP, VP]),
     "mural_fasta_pack": (C.c_int, [C.c_char_p, I64, I64, VP, VP, VP, I64, VP]),
     "mural_bed_read": (C.c_int, [C.c_char_p, I64, VP, VP, VP, VP, VP, I32, I32, VP, VP, VP]),

@@ -305,6 +305,21 @@ __global__ void maxpool_bwd_kernel(const float* __restrict__ dy, const int32_t* 
   }
 }
 
+// non-overlapping windows (stride >= kernel, the model's pools): every input column belongs to at most one window, so
+// the gradient is a gather - no atomics, and dx needs no zero fill
+__global__ void maxpool_bwd_gather_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, int64_t rows, int L,
+                                          int Lout, int k, int s, int p, float* __restrict__ dx) {
+  const int64_t total = rows * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / L;
+    const int j = (int)(i - r * L);
+    const int w = (j + p) / s;                       // the only window that can contain column j
+    float g = 0.f;
+    if (w < Lout && j + p - w * s < k && arg[r * Lout + w] == j) g = dy[r * Lout + w];
+    dx[i] = g;
+  }
+}
+
 // ------------------------------------------------------------------------------------------- first layer (one-hot input)
 // symbol histogram of the tower's input columns
 __global__ void sym_hist_kernel(const uint8_t* __restrict__ sym, int64_t B, int Lwin, int col0, int L1,
@@ -873,11 +888,19 @@ extern "C" int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int
   CHECK_LAUNCH();
 }
 
-// dx must be zeroed by the caller
-extern "C" int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, float* dx,
-                                    void* stream) {
+// k, s, p: the forward's window.  s >= k (disjoint windows): dx is fully written; otherwise dx must be zeroed by the caller
+// (mural_op_maxpool_bwd_needs_zero) and receives atomic adds
+extern "C" int mural_op_maxpool_bwd_needs_zero(int32_t k, int32_t s) { return s >= k ? 0 : 1; }
+
+extern "C" int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, int32_t k,
+                                    int32_t s, int32_t p, float* dx, void* stream) {
   const int64_t total = rows * Lout;
   if (total == 0) return MURAL_OK;
+  if (s >= k) {
+    hipLaunchKernelGGL(maxpool_bwd_gather_kernel, dim3(grid_for(rows * L)), dim3(256), 0, STREAM, dy, arg, rows, L, Lout, k, s, p,
+                       dx);
+    CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, dy, arg, rows, L, Lout, dx);
   CHECK_LAUNCH();
 }

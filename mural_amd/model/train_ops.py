@@ -236,15 +236,16 @@ class MaxPool(torch.autograd.Function):
         arg = torch.empty((B, Cn, Lout), dtype=torch.int32, device=x.device)
         _call("mural_op_maxpool_fwd", x, B * Cn, L, k, s, p, y, arg, _stream(x))
         ctx.save_for_backward(arg)
-        ctx.dims = (B, Cn, L, Lout, glob)
+        ctx.dims = (B, Cn, L, Lout, glob, k, s, p)
         return y.reshape(B, Cn) if glob else y
 
     @staticmethod
     def backward(ctx, dy):
         (arg,) = ctx.saved_tensors
-        B, Cn, L, Lout, glob = ctx.dims
-        dx = torch.zeros((B, Cn, L), device=dy.device)
-        _call("mural_op_maxpool_bwd", dy.contiguous(), arg, B * Cn, L, Lout, dx, _stream(dy))
+        B, Cn, L, Lout, glob, k, s, p = ctx.dims
+        # disjoint windows (stride >= kernel, every pool of the model): a gather writes all of dx, no zero fill / atomics
+        dx = (torch.zeros if s < k else torch.empty)((B, Cn, L), device=dy.device)
+        _call("mural_op_maxpool_bwd", dy.contiguous(), arg, B * Cn, L, Lout, k, s, p, dx, _stream(dy))
         return dx, None, None, None
 
 
