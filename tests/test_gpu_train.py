@@ -1,5 +1,7 @@
 """GPU parity of the training step (forward with batch-stat BN, CE-sum loss, backward) against the reference's golden
 vectors: loss, every parameter gradient (relative 1e-4 of the tensor's max) and BN running statistics after the step."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -176,3 +178,15 @@ def test_graphed_train_step_matches_eager():
     step(cont, cat, bad, y)
     with pytest.raises(ValueError, match="not a MuRaL"):
         step.finish()
+
+
+def test_conv32_kernels_match_torch_fp64():
+    """The MFMA conv kernels behind the training step (forward with pre-op / residuals / fused batch sums, input gradient
+    with BatchNorm-backward sums, weight gradient, fused backward) against torch ops in float64 on the CPU, over full,
+    partial and single-row tiles."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_debug_conv32.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "worst" in out.stdout
