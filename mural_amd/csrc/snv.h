@@ -108,13 +108,20 @@ struct SnvFwdArgs {
   float* taps;                    // debug dump (tile 0) or nullptr
   int tap_stride;                 // floats per dumped buffer
   unsigned long long* stamps;     // diagnostic per-phase cycle sums [grid][32] or nullptr
+  // Tower range of this launch.  {0, 1}: both towers and the head in one launch.  Split mode runs {0, 0} (large tower,
+  // its fc logits go to xlogit) and then {1, 1} (mid tower with its own, larger tile; reads xlogit and does the head).
+  int tw_first, tw_last;
+  float* xlogit;                  // [n][SNV_MAXCLASS] large-tower logits between the two launches of the split mode
 };
 
 }  // namespace mural
 
 struct MuralSnvModel {
   MuralSnvShape shape;
-  mural::SnvFwdArgs args;         // geometry + device pointers (input/output fields filled per call)
+  mural::SnvFwdArgs args;         // geometry + device pointers (input/output fields filled per call): both towers, one tile size
+  mural::SnvFwdArgs args_l, args_m;   // split mode: large tower alone / mid tower alone (each with its own tile size)
+  size_t lds_l, lds_m;
+  bool split;
   mural::LocalDev local;
   float* blob;                    // device allocation holding every folded tensor
   size_t blob_floats;

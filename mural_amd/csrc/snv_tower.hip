@@ -250,18 +250,24 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator
   // layout, one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
   f32x4 xres[SNV_NB2MAX];
-  request_x0(args, xres, blockIdx.x, 0, n_tiles, cgp, n16, chv);
+  request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
+  const bool do_head = args.tw_last == 1;
 
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
-    if (tid < P * args.n_class) {   // local-branch logits of this tile -> LDS (third logit vector)
+    if (do_head && tid < P * args.n_class) {   // local-branch logits of this tile -> LDS (third logit vector)
       const int p = tid / args.n_class, k = tid - p * args.n_class;
       float v = 0.f;
       if (args.has_local && row0 + p < args.n) v = args.local_logits[(row0 + p) * args.n_class + k];
       logit[(2 * P + p) * SNV_MAXCLASS + k] = v;
+      if (args.tw_first == 1) {               // split mode: the large tower's logits come from the previous launch
+        float u = 0.f;
+        if (row0 + p < args.n) u = args.xlogit[(row0 + p) * SNV_MAXCLASS + k];
+        logit[p * SNV_MAXCLASS + k] = u;
+      }
     }
 
-    for (int tw_i = 0; tw_i < 2; ++tw_i) {
+    for (int tw_i = args.tw_first; tw_i <= args.tw_last; ++tw_i) {
       const TowerGeom& g = args.geom[tw_i];
       const TowerDev& tw = args.tw[tw_i];
       const float* tpar = par + tw_i * par_stride;
@@ -374,7 +380,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
 
       // -------------------------------------------------------------- global max per (position, channel)
       // (the residual registers are dead after the last conv: request the next tower's stage-1 activations now)
-      request_x0(args, xres, tw_i == 0 ? tile : tile + gridDim.x, tw_i == 0 ? 1 : 0, n_tiles, cgp, n16, chv);
+      request_x0(args, xres, tw_i < args.tw_last ? tile : tile + gridDim.x, tw_i < args.tw_last ? tw_i + 1 : args.tw_first, n_tiles,
+                 cgp, n16, chv);
       {
         const int L4 = g.L[2], Sc4 = g.Sc[2];
         float* ft = feat + tw_i * P * SNV_C;
@@ -397,9 +404,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
     }  // towers
 
     // ------------------------------------------------------------------ BN+Linear per tower (BN folded on the host)
-    for (int t = tid; t < 2 * P * args.n_class; t += SNV_THREADS) {
+    for (int t = tid; t < (args.tw_last - args.tw_first + 1) * P * args.n_class; t += SNV_THREADS) {
       const int k = t % args.n_class;
-      const int tp = t / args.n_class;  // tower * P + p
+      const int tp = args.tw_first * P + t / args.n_class;  // tower * P + p
       const int tw_i = tp / P;
       const float* w = par + tw_i * par_stride + 2 * EX_COUNT * SNV_C + k * SNV_C;
       const float* f = feat + tp * SNV_C;
@@ -417,6 +424,14 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
     lds_barrier();
     SNV_STAMP(25);   // fc
 
+    if (!do_head) {   // split mode, large tower: hand the logits to the launch that runs the mid tower and the head
+      if (tid < P * args.n_class) {
+        const int p = tid / args.n_class, k = tid - p * args.n_class;
+        if (row0 + p < args.n) args.xlogit[(row0 + p) * SNV_MAXCLASS + k] = logit[p * SNV_MAXCLASS + k];
+      }
+      lds_barrier();
+      continue;
+    }
     // ------------------------------------------------------------------ head (model_snv.py:515-523 / :284)
     if (tid < P * args.n_class) {
       const int nc = args.n_class;
@@ -487,7 +502,7 @@ int profile_end(double* total_ms, int64_t* launches) {
   return MURAL_OK;
 }
 
-int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, hipStream_t stream) {
+int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_bytes, hipStream_t stream) {
   const int64_t n_tiles = (a.n + a.P - 1) / a.P;
   if (n_tiles == 0) return MURAL_OK;
   int grid = (int)(n_tiles < 2048 ? n_tiles : 2048);
@@ -513,7 +528,7 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, hipStream_t s
     g_prof.used += 2;
     MURAL_HIP_CHECK(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL(snv_towers_fused, dim3(grid), dim3(SNV_THREADS), m->lds_bytes, stream, a);
+  hipLaunchKernelGGL(snv_towers_fused, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   if (e1) MURAL_HIP_CHECK(hipEventRecord(e1, stream));
   return MURAL_OK;
