@@ -112,6 +112,11 @@ struct SnvFwdArgs {
   // its fc logits go to xlogit) and then {1, 1} (mid tower with its own, larger tile; reads xlogit and does the head).
   int tw_first, tw_last;
   float* xlogit;                  // [n][SNV_MAXCLASS] large-tower logits between the two launches of the split mode
+  // Stage range of this launch.  phase 0: everything.  phase 1: first conv stage only (entry + 4 residual convs + max-pool
+  // 2 + BN), the pooled tile goes to s3[tower].  phase 2: the two short stages (6 convs), global max, fc (+ head), reading
+  // s3[tower] - with a tile of many more positions, so that the short stages run full-width layers.
+  int phase;
+  float* s3[2];                   // [n][L3][32] per tower: input of the second conv stage, in the layout of x0
 };
 
 }  // namespace mural
@@ -119,8 +124,10 @@ struct SnvFwdArgs {
 struct MuralSnvModel {
   MuralSnvShape shape;
   mural::SnvFwdArgs args;         // geometry + device pointers (input/output fields filled per call): both towers, one tile size
-  mural::SnvFwdArgs args_l, args_m;   // split mode: large tower alone / mid tower alone (each with its own tile size)
-  size_t lds_l, lds_m;
+  // split mode: four launches per chunk - (tower, phase) = (large, 1), (mid, 1), (large, 2), (mid, 2 + head) - each with the
+  // largest tile that keeps two workgroups per CU
+  mural::SnvFwdArgs args_split[4];
+  size_t lds_split[4];
   bool split;
   mural::LocalDev local;
   float* blob;                    // device allocation holding every folded tensor

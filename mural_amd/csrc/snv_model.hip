@@ -195,8 +195,9 @@ int fold_local(const MuralLocal& Lc, const MuralSnvShape& sh, Blob& B, LocalOff&
 int pool_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
 
 // tile geometry for P positions per workgroup; returns LDS bytes (0 if a stage needs too many blocks per wave)
-// `towers`: bit mask of the towers the launch runs (their columns size the LDS buffers)
-size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P, int n_class, int towers = 3) {
+// `towers`: bit mask of the towers the launch runs; `phase`: 0 every stage, 1 first conv stage only, 2 the two short stages
+// only (see SnvFwdArgs): only the columns of the stages a launch runs size its LDS buffers
+size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P, int n_class, int towers = 3, int phase = 0) {
   static const int pools[2][3][3] = {{{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}, {{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}};
   int maxcols = 0;
   for (int tw = 0; tw < 2; ++tw) {
@@ -217,6 +218,7 @@ size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P, int n_class, int towers = 3
       g.dL[i] = FastDiv::make((uint32_t)L);
       g.dSc[i] = FastDiv::make((uint32_t)g.Sc[i]);
       if (!((towers >> tw) & 1)) continue;
+      if ((phase == 1 && i != 0) || (phase == 2 && i == 0)) continue;
       if ((g.nb[i] + 1) / 2 > SNV_NB2MAX) return 0;
       maxcols = std::max(maxcols, 16 * g.nb[i] + 2);
     }
@@ -225,6 +227,7 @@ size_t plan_geometry(SnvFwdArgs& a, int Lwin, int P, int n_class, int towers = 3
   a.Lwin = Lwin;
   a.tw_first = (towers & 1) ? 0 : 1;
   a.tw_last = (towers & 2) ? 1 : 0;
+  a.phase = phase;
   a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
   a.nbuf = maxcols * SNV_C;
   const size_t par = (size_t)2 * (2 * EX_COUNT * SNV_C + n_class * SNV_C + SNV_MAXCLASS);   // resident small parameters
@@ -236,7 +239,7 @@ constexpr size_t kLdsMax = 160 * 1024;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; };
+struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; float* s3[2]; };
 
 size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
   size_t off = 0;
@@ -250,6 +253,8 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
   const size_t o_sym = take(dense ? (size_t)n * m->shape.distal_len : 16);
   const size_t o_x0 = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.x0_cols, 1) * SNV_C * 4);
   const size_t o_xl = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * SNV_MAXCLASS * 4);
+  const size_t o_s3l = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
+  const size_t o_s3m = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
   if (w) {
     char* b = static_cast<char*>(base);
     w->local_logits = reinterpret_cast<float*>(b + o_ll);
@@ -257,6 +262,8 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
     w->symbols = reinterpret_cast<uint8_t*>(b + o_sym);
     w->x0 = reinterpret_cast<float*>(b + o_x0);
     w->xlogit = reinterpret_cast<float*>(b + o_xl);
+    w->s3[0] = reinterpret_cast<float*>(b + o_s3l);
+    w->s3[1] = reinterpret_cast<float*>(b + o_s3m);
   }
   return off;
 }
@@ -311,26 +318,23 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
       } else {
         plan_geometry(m->args, sh.distal_len, P, sh.n_class);
         m->lds_bytes = lds;
-        // split mode: each tower in its own launch with the largest tile that keeps two workgroups per CU (the short
-        // mid tower then amortises its per-layer fixed costs over more positions)
+        // split mode: (tower, phase) pairs in their own launches, each with the largest tile that keeps two workgroups per
+        // CU: the mid tower and above all the short stages then run layers that are many blocks wide
         m->split = false;
         if (lds <= kLdsTwoPerCu && !getenv("MURAL_DEBUG_NO_TOWER_SPLIT")) {
-          int Pl = 0, Pm = 0;
-          for (int cand = 16; cand >= 1 && !Pl; --cand) {
-            SnvFwdArgs tmp;
-            const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, 1);
-            if (need && need <= kLdsTwoPerCu) { Pl = cand; m->lds_l = need; }
+          bool ok = true;
+          for (int q = 0; q < 4 && ok; ++q) {
+            const int towers = (q & 1) ? 2 : 1, phase = q < 2 ? 1 : 2;
+            int Pq = 0;
+            for (int cand = 32; cand >= 1 && !Pq; --cand) {
+              SnvFwdArgs tmp;
+              const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, towers, phase);
+              if (need && need <= kLdsTwoPerCu) { Pq = cand; m->lds_split[q] = need; }
+            }
+            if (!Pq) { ok = false; break; }
+            plan_geometry(m->args_split[q], sh.distal_len, Pq, sh.n_class, towers, phase);
           }
-          for (int cand = 16; cand >= 1 && !Pm; --cand) {
-            SnvFwdArgs tmp;
-            const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, 2);
-            if (need && need <= kLdsTwoPerCu) { Pm = cand; m->lds_m = need; }
-          }
-          if (Pl && Pm && Pm > P) {
-            plan_geometry(m->args_l, sh.distal_len, Pl, sh.n_class, 1);
-            plan_geometry(m->args_m, sh.distal_len, Pm, sh.n_class, 2);
-            m->split = true;
-          }
+          m->split = ok;
         }
         Stage1Args& s1 = m->s1;
         for (int tw = 0; tw < 2; ++tw) {
@@ -375,11 +379,11 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     }
     m->args.n_class = sh.n_class;
     m->args.has_local = sh.model_no == 2;
-    for (SnvFwdArgs* a2 : {&m->args_l, &m->args_m}) {
-      a2->tw[0] = m->args.tw[0];
-      a2->tw[1] = m->args.tw[1];
-      a2->n_class = sh.n_class;
-      a2->has_local = m->args.has_local;
+    for (SnvFwdArgs& a2 : m->args_split) {
+      a2.tw[0] = m->args.tw[0];
+      a2.tw[1] = m->args.tw[1];
+      a2.n_class = sh.n_class;
+      a2.has_local = m->args.has_local;
     }
     m->s1.lut[0] = m->args.tw[0].lut;
     m->s1.lut[1] = m->args.tw[1].lut;
@@ -439,9 +443,10 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     else s.codes = s1.codes + c0 * m->shape.distal_len;
     if (int rc = launch_snv_stage1(s, packed, m->s1_lds_bytes, stream)) return rc;
     const bool split = m->split && taps == nullptr;       // the debug dump wants both towers in one tile geometry
-    for (int part = 0; part < (split ? 2 : 1); ++part) {
-      SnvFwdArgs t = split ? (part == 0 ? m->args_l : m->args_m) : a;
-      if (split) { t.Lwin = a.Lwin; }
+    for (int part = 0; part < (split ? 4 : 1); ++part) {
+      SnvFwdArgs t = split ? m->args_split[part] : a;
+      t.s3[0] = w.s3[0];
+      t.s3[1] = w.s3[1];
       t.n = cn;
       t.x0 = w.x0;
       t.xlogit = w.xlogit;
@@ -450,7 +455,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       t.taps = c0 == 0 ? taps : nullptr;
       t.tap_stride = a.nbuf;
       t.stamps = packed ? g_stamps : nullptr;
-      const size_t lds = split ? (part == 0 ? m->lds_l : m->lds_m) : m->lds_bytes;
+      const size_t lds = split ? m->lds_split[part] : m->lds_bytes;
       if (int rc = launch_snv_towers(m, t, lds, stream)) return rc;
     }
   }

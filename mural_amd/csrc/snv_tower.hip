@@ -250,8 +250,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator
   // layout, one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
   f32x4 xres[SNV_NB2MAX];
-  request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
-  const bool do_head = args.tw_last == 1;
+  if (args.phase != 2) request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
+  const bool do_head = args.tw_last == 1 && args.phase != 1;
 
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
@@ -275,14 +275,14 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       // weights of the first conv: issued now, consumed after the entry barrier
       float a_cur[SNV_KSTEPS];
       {
-        const float* wf = tw.wfrag + (size_t)mb * SNV_KSTEPS * 64 + lane;
+        const float* wf = tw.wfrag + (size_t)(args.phase == 2 ? 4 : 0) * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
       }
 
       // -------------------------------------------------------------- entry: BN(ReLU(x0)) -> bufA, x0 stays in xres
       StageAddr sa = stage_setup(g, 0, P, n16, kk, mb, cgp);
-      {
+      if (args.phase != 2) {
         const f32x4 es = ld4(tpar + EX_RB1_ENTRY * 32 + chv), et = ld4(tpar + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv);
         char* A = reinterpret_cast<char*>(bufA);
         const int nbw0 = g.nb[0] > cgp ? (g.nb[0] - cgp + 1) / 2 : 0;
@@ -294,9 +294,31 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       SNV_STAMP(3 + 12 * tw_i);   // stage-1 activations landed + BN/ReLU image written
 
       // -------------------------------------------------------------- the ten 32->32 convs
-      for (int layer = 0; layer < SNV_NLAYER; ++layer) {
+      for (int layer = args.phase == 2 ? 4 : 0; layer < SNV_NLAYER; ++layer) {
         const int st = layer < 4 ? 0 : (layer < 9 ? 1 : 2);
-        if (layer == 4 || layer == 9) {
+        if (layer == 4 && args.phase == 2) {
+          // second conv stage of a stage-split launch: its input was pooled by the phase-1 launch (s3, layout of x0)
+#pragma unroll
+          for (int i = 0; i < SNV_NB2MAX; ++i) xres[i] = splat(0.f);
+          const int Lout = g.L[1], ScO = g.Sc[1];
+          const int total = P * Lout * 8;
+          const float* src = args.s3[tw_i] + (size_t)row0 * Lout * 32;
+          for (int task = tid; task < total; task += SNV_THREADS) {
+            const uint32_t pj = (uint32_t)task >> 3;
+            const uint32_t p = g.dL[1].div(pj);
+            const int jo = (int)(pj - p * (uint32_t)Lout);
+            const f32x4 v = (row0 + p < args.n) ? ld4(src + (size_t)task * 4) : splat(0.f);
+            st4(bufB + lds_off(1 + (int)p * ScO + jo + 1, task & 7), v);
+          }
+          const int nz = 1 + P + (16 * g.nb[1] - g.NC[1]);
+          for (int task = tid; task < nz * 8; task += SNV_THREADS) {
+            const int k = task >> 3;
+            const int c = (k <= P) ? k * ScO : g.NC[1] + (k - P - 1);
+            st4(bufB + lds_off(c + 1, task & 7), splat(0.f));
+          }
+          sa = stage_setup(g, 1, P, n16, kk, mb, cgp);
+          __syncthreads();
+        } else if (layer == 4 || layer == 9) {
           // max-pool (raw y in bufA) + BN (no ReLU) -> bufB in the next stage's geometry
           const int si = st - 1;  // input stage
           const int Lin = g.L[si], Lout = g.L[st], ScI = g.Sc[si], ScO = g.Sc[st];
@@ -326,8 +348,13 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
             }
             m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
                       fmaf(pool_s.w, m.w, pool_t.w)};
-            st4(bufB + lds_off(1 + (int)p * ScO + jo + 1, cg), m);
+            if (args.phase == 1) {      // hand the pooled tile to the phase-2 launch: s3[row][jo][32], 128 bytes per 8 lanes
+              if (row0 + p < args.n) st4(args.s3[tw_i] + ((size_t)(row0 + p) * Lout + jo) * 32 + 4 * cg, m);
+            } else {
+              st4(bufB + lds_off(1 + (int)p * ScO + jo + 1, cg), m);
+            }
           }
+          if (args.phase == 1) break;   // the first conv stage is done
           {
             const int nz = 1 + P + (16 * g.nb[st] - g.NC[st]);
             for (int task = tid; task < nz * 8; task += SNV_THREADS) {
@@ -378,10 +405,17 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         }
       }
 
+      if (args.phase == 1) {   // stage-split launch: nothing after the pooling; bufA is free once every wave has pooled
+        request_x0(args, xres, tw_i < args.tw_last ? tile : tile + gridDim.x, tw_i < args.tw_last ? tw_i + 1 : args.tw_first,
+                   n_tiles, cgp, n16, chv);
+        lds_barrier();
+        continue;
+      }
       // -------------------------------------------------------------- global max per (position, channel)
       // (the residual registers are dead after the last conv: request the next tower's stage-1 activations now)
-      request_x0(args, xres, tw_i < args.tw_last ? tile : tile + gridDim.x, tw_i < args.tw_last ? tw_i + 1 : args.tw_first, n_tiles,
-                 cgp, n16, chv);
+      if (args.phase != 2)
+        request_x0(args, xres, tw_i < args.tw_last ? tile : tile + gridDim.x, tw_i < args.tw_last ? tw_i + 1 : args.tw_first, n_tiles,
+                   cgp, n16, chv);
       {
         const int L4 = g.L[2], Sc4 = g.Sc[2];
         float* ft = feat + tw_i * P * SNV_C;
@@ -403,6 +437,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
     }  // towers
 
+    if (args.phase == 1) continue;
     // ------------------------------------------------------------------ BN+Linear per tower (BN folded on the host)
     for (int t = tid; t < (args.tw_last - args.tw_first + 1) * P * args.n_class; t += SNV_THREADS) {
       const int k = t % args.n_class;
