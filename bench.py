@@ -267,7 +267,10 @@ def main():
     if rank == 0:
         bases = args.steps * B * world
         kernel_ms = k_ms.value / max(k_n.value, 1)
-        sites_per_launch = args.steps * B / max(k_n.value, 1)      # the library launches the kernel per 32768-site chunk
+        # the library launches the kernel four times per 32768-site chunk ((tower, stage-phase) pairs, each with its own tile
+        # size): sites_per_launch is the per-launch SHARE of the sites, so that FLOP_TOWERS x sites_per_launch / avg_launch_ms
+        # = (all tower FLOP of the timed region) / (all tower-kernel time of the timed region)
+        sites_per_launch = args.steps * B / max(k_n.value, 1)
         achieved = FLOP_TOWERS * sites_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
         traffic = None     # HBM bytes per launch from the committed PMC passes (tools/profile_bench.sh), if present
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
@@ -289,7 +292,9 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
                          "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
-                         "note": "algorithmic FLOP of the layers this kernel evaluates (6,353,408 per site: every 32->32 "
+                         "note": "four launches per 32768-site chunk: (large | mid tower) x (first conv stage | the two short "
+                                 "stages + fc + head); sites_per_launch / flop_per_launch / traffic are per-launch averages. "
+                                 "Algorithmic FLOP of the layers this kernel evaluates (6,353,408 per site: every 32->32 "
                                  "conv + fc of both towers); the 1,691,136 FLOP/site of the two first conv layers are table "
                                  "lookups in snv_stage1_kernel and the 51,600 FLOP/site local MLP is snv_local_mlp; "
                                  "end-to-end model FLOP rate = 8,096,144 x value"},
