@@ -2,6 +2,7 @@
 // snv.h, tile geometry, workspace carving, and the extern "C" forward entry points.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <vector>
@@ -325,13 +326,25 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
           bool ok = true;
           for (int q = 0; q < 4 && ok; ++q) {
             const int towers = (q & 1) ? 2 : 1, phase = q < 2 ? 1 : 2;
-            int Pq = 0;
-            for (int cand = 32; cand >= 1 && !Pq; --cand) {
+            int Pq = 0, Pmax = 32;
+            if (const char* e = getenv("MURAL_DEBUG_SPLIT_P")) {   // diagnostic: "P0,P1,P2,P3" caps the tile sizes
+              int v[4] = {32, 32, 32, 32};
+              sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+              if (v[q] >= 1) Pmax = v[q];
+            }
+            for (int cand = Pmax; cand >= 1 && !Pq; --cand) {
               SnvFwdArgs tmp;
               const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, towers, phase);
               if (need && need <= kLdsTwoPerCu) { Pq = cand; m->lds_split[q] = need; }
             }
             if (!Pq) { ok = false; break; }
+            if (phase == 2) {   // prefer a tile whose long stage splits into full block pairs for both waves (nb % 4 == 0)
+              for (int cand = Pq; cand >= Pq - 2 && cand >= 1; --cand) {
+                SnvFwdArgs tmp;
+                const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, towers, phase);
+                if (need && tmp.geom[q & 1].nb[1] % 4 == 0) { Pq = cand; m->lds_split[q] = need; break; }
+              }
+            }
             plan_geometry(m->args_split[q], sh.distal_len, Pq, sh.n_class, towers, phase);
           }
           m->split = ok;
