@@ -217,6 +217,8 @@ __device__ __forceinline__ void request_x0(const SnvFwdArgs& args, f32x4 (&xres)
   }
 }
 
+// PHASE = SnvFwdArgs::phase at compile time: the stage-split launches do not carry each other's code and registers
+template <int PHASE>
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
@@ -250,8 +252,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator
   // layout, one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
   f32x4 xres[SNV_NB2MAX];
-  if (args.phase != 2) request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
-  const bool do_head = args.tw_last == 1 && args.phase != 1;
+  if (PHASE != 2) request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
+  const bool do_head = args.tw_last == 1 && PHASE != 1;
 
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
@@ -275,14 +277,14 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       // weights of the first conv: issued now, consumed after the entry barrier
       float a_cur[SNV_KSTEPS];
       {
-        const float* wf = tw.wfrag + (size_t)(args.phase == 2 ? 4 : 0) * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
+        const float* wf = tw.wfrag + (size_t)(PHASE == 2 ? 4 : 0) * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
       }
 
       // -------------------------------------------------------------- entry: BN(ReLU(x0)) -> bufA, x0 stays in xres
       StageAddr sa = stage_setup(g, 0, P, n16, kk, mb, cgp);
-      if (args.phase != 2) {
+      if (PHASE != 2) {
         const f32x4 es = ld4(tpar + EX_RB1_ENTRY * 32 + chv), et = ld4(tpar + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv);
         char* A = reinterpret_cast<char*>(bufA);
         const int nbw0 = g.nb[0] > cgp ? (g.nb[0] - cgp + 1) / 2 : 0;
@@ -294,9 +296,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       SNV_STAMP(3 + 12 * tw_i);   // stage-1 activations landed + BN/ReLU image written
 
       // -------------------------------------------------------------- the ten 32->32 convs
-      for (int layer = args.phase == 2 ? 4 : 0; layer < SNV_NLAYER; ++layer) {
+      for (int layer = PHASE == 2 ? 4 : 0; layer < SNV_NLAYER; ++layer) {
         const int st = layer < 4 ? 0 : (layer < 9 ? 1 : 2);
-        if (layer == 4 && args.phase == 2) {
+        if (layer == 4 && PHASE == 2) {
           // second conv stage of a stage-split launch: its input was pooled by the phase-1 launch (s3, layout of x0)
 #pragma unroll
           for (int i = 0; i < SNV_NB2MAX; ++i) xres[i] = splat(0.f);
@@ -348,13 +350,13 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
             }
             m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
                       fmaf(pool_s.w, m.w, pool_t.w)};
-            if (args.phase == 1) {      // hand the pooled tile to the phase-2 launch: s3[row][jo][32], 128 bytes per 8 lanes
+            if (PHASE == 1) {      // hand the pooled tile to the phase-2 launch: s3[row][jo][32], 128 bytes per 8 lanes
               if (row0 + p < args.n) st4(args.s3[tw_i] + ((size_t)(row0 + p) * Lout + jo) * 32 + 4 * cg, m);
             } else {
               st4(bufB + lds_off(1 + (int)p * ScO + jo + 1, cg), m);
             }
           }
-          if (args.phase == 1) break;   // the first conv stage is done
+          if (PHASE == 1) break;   // the first conv stage is done
           {
             const int nz = 1 + P + (16 * g.nb[st] - g.NC[st]);
             for (int task = tid; task < nz * 8; task += SNV_THREADS) {
@@ -405,7 +407,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         }
       }
 
-      if (args.phase == 1) {   // stage-split launch: nothing after the pooling; bufA is free once every wave has pooled
+      if (PHASE == 1) {   // stage-split launch: nothing after the pooling; bufA is free once every wave has pooled
         request_x0(args, xres, tw_i < args.tw_last ? tile : tile + gridDim.x, tw_i < args.tw_last ? tw_i + 1 : args.tw_first,
                    n_tiles, cgp, n16, chv);
         lds_barrier();
@@ -413,7 +415,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
       // -------------------------------------------------------------- global max per (position, channel)
       // (the residual registers are dead after the last conv: request the next tower's stage-1 activations now)
-      if (args.phase != 2)
+      if (PHASE != 2)
         request_x0(args, xres, tw_i < args.tw_last ? tile : tile + gridDim.x, tw_i < args.tw_last ? tw_i + 1 : args.tw_first, n_tiles,
                    cgp, n16, chv);
       {
@@ -437,7 +439,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
     }  // towers
 
-    if (args.phase == 1) continue;
+    if (PHASE == 1) continue;
     // ------------------------------------------------------------------ BN+Linear per tower (BN folded on the host)
     for (int t = tid; t < (args.tw_last - args.tw_first + 1) * P * args.n_class; t += SNV_THREADS) {
       const int k = t % args.n_class;
@@ -547,7 +549,11 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
   }
   static bool attr_set = false;
   if (!attr_set) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused),
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<0>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<1>),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<2>),
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     attr_set = true;
   }
@@ -563,7 +569,9 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
     g_prof.used += 2;
     MURAL_HIP_CHECK(hipEventRecord(e0, stream));
   }
-  hipLaunchKernelGGL(snv_towers_fused, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
+  if (a.phase == 1) hipLaunchKernelGGL(snv_towers_fused<1>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
+  else if (a.phase == 2) hipLaunchKernelGGL(snv_towers_fused<2>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
+  else hipLaunchKernelGGL(snv_towers_fused<0>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   if (e1) MURAL_HIP_CHECK(hipEventRecord(e1, stream));
   return MURAL_OK;
