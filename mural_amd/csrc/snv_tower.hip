@@ -254,6 +254,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   f32x4 xres[SNV_NB2MAX];
   if (PHASE != 2) request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
   const bool do_head = args.tw_last == 1 && PHASE != 1;
+  // a first-stage launch runs one tower and one stage: its lane addressing / validity mask is tile-invariant
+  const StageAddr sa_first = stage_setup(args.geom[args.tw_first], 0, P, n16, kk, mb, cgp);
 
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
@@ -283,7 +285,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
 
       // -------------------------------------------------------------- entry: BN(ReLU(x0)) -> bufA, x0 stays in xres
-      StageAddr sa = stage_setup(g, 0, P, n16, kk, mb, cgp);
+      StageAddr sa = (PHASE == 1 || tw_i == args.tw_first) ? sa_first : stage_setup(g, 0, P, n16, kk, mb, cgp);
       if (PHASE != 2) {
         const f32x4 es = ld4(tpar + EX_RB1_ENTRY * 32 + chv), et = ld4(tpar + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv);
         char* A = reinterpret_cast<char*>(bufA);
