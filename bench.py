@@ -136,31 +136,11 @@ def train_steps_per_s(device, genome, B=4096, steps=30, warmup=5):
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
     t = float(np.median(times[warmup:]))
-    # the same loop without a host synchronisation between steps (a loop that does not read the loss every step)
-    batches = []
-    for s in range(steps):
-        idx = torch.arange(s * B, (s + 1) * B, device=device)
-        pos, strand = idx + DISTAL_RADIUS, (idx & 1).to(torch.uint8)
-        batches.append((genome.encode_kmer(pos, strand, LOCAL_RADIUS, LOCAL_ORDER), genome.encode_onehot(pos, strand, DISTAL_RADIUS),
-                        labels[s * B:(s + 1) * B]))
-        if len(batches) == 8:
-            break
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for s in range(steps):
-        cat, x, yb = batches[s % len(batches)]
-        loss = crit(model((cont, cat), x), yb)
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
-        opt.step()
-    torch.cuda.synchronize()
-    tp = (time.perf_counter() - t0) / steps
-    return {"steps_per_s": 1.0 / t, "ms_per_step": t * 1e3, "steps_per_s_pipelined": 1.0 / tp, "batch": B, "sites_per_s": B / t,
-            "optimizer": "Adam lr 1e-3", "loss": "CrossEntropy(sum), clip_grad_norm 10",
-            "note": "forward (batch-stat BN, dropout) + backward + update; inputs already encoded on the device; steps_per_s = "
-                    "median of %d individually synchronised steps after %d warm-up (the reference loop reads loss.item() every "
-                    "step); steps_per_s_pipelined = the same %d steps without a host sync in between" % (steps, warmup, steps)}
+    return {"steps_per_s": 1.0 / t, "ms_per_step": t * 1e3, "batch": B, "sites_per_s": B / t, "optimizer": "Adam lr 1e-3",
+            "loss": "CrossEntropy(sum), clip_grad_norm 10",
+            "note": "forward (batch-stat BN, dropout) + backward + update; inputs already encoded on the device; median of %d "
+                    "individually synchronised steps after %d warm-up (the reference loop reads loss.item() every step; "
+                    "tools/bench_variants.py train measures the un-synchronised loop)" % (steps, warmup)}
 
 
 def indel_positions_per_s(device, genome, n=4096):
