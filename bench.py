@@ -247,7 +247,7 @@ def main():
     if rank == 0:
         bases = args.steps * B * world
         kernel_ms = k_ms.value / max(k_n.value, 1)
-        # the library launches the kernel four times per 32768-site chunk ((tower, stage-phase) pairs, each with its own tile
+        # the library launches the kernel four times per chunk of <= 131072 sites ((tower, stage-phase) pairs, each with its own tile
         # size): sites_per_launch is the per-launch SHARE of the sites, so that FLOP_TOWERS x sites_per_launch / avg_launch_ms
         # = (all tower FLOP of the timed region) / (all tower-kernel time of the timed region)
         sites_per_launch = args.steps * B / max(k_n.value, 1)
@@ -272,7 +272,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                          "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
                          "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
-                         "note": "four launches per 32768-site chunk: (large | mid tower) x (first conv stage | the two short "
+                         "note": "four launches per chunk of <= 131072 sites: (large | mid tower) x (first conv stage | the two short "
                                  "stages + fc + head); sites_per_launch / flop_per_launch / traffic are per-launch averages. "
                                  "Algorithmic FLOP of the layers this kernel evaluates (6,353,408 per site: every 32->32 "
                                  "conv + fc of both towers); the 1,691,136 FLOP/site of the two first conv layers are table "

@@ -13,7 +13,7 @@ constexpr int SNV_LUT = 125 * SNV_C;             // 3-mer lookup table (A,C,G,T,
 constexpr int SNV_TAPS = 3 * N_SYM * SNV_C;      // per-tap, per-symbol contributions (generic path)
 constexpr int SNV_LUTBLK = SNV_LUT + SNV_TAPS + SNV_C;   // lut | taps | bias0, contiguous in the blob
 constexpr int SNV_MAXCLASS = 16;
-constexpr int SNV_CHUNK = 32768;   // sites per stage-1 / tower launch pair (bounds the x0 scratch)
+constexpr int SNV_CHUNK = 131072;  // sites per stage-1 / tower launch sequence (bounds the x0 scratch: 3.4 GB at R=1000)
 constexpr int SNV_NB2MAX = 9;      // max 16-column blocks a wave owns in one stage (waves split M x column parity)
 constexpr int SNV_THREADS = 256;
 constexpr int SNV_WAVES = SNV_THREADS / 64;
