@@ -293,6 +293,33 @@ int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, int64_t* st
 int mural_bed_segment_order(const int32_t* chrom_id, const int64_t* start, const uint8_t* strand, int64_t n,
                             int64_t central_bp, int64_t* order, int64_t* group, int64_t* n_groups);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Validation-epoch analytics (device-side segmented reductions into float64 tables; the correlation / Newton algebra
+ * on the tables is host work).  Replaces the pandas group-bys and per-row loops of MuRaL/evaluation/evaluation.py:
+ * freq_kmer_comp_multi (:48-67), corr_calc_sub (:124-193), Evaluator.evaluate_regional_score (:544-587), ECELoss /
+ * ClasswiseECELoss / BrierScore / mean CE (:209-290, :340-358) and the loss / gradient / Hessian sums of the full-Dirichlet
+ * fit (dirichlet_python/dirichletcal/calib/multinomial.py:153-172).  status: device int32, bit 0 = bad code / chrom /
+ * start, bit 1 = label or key out of range (such rows are skipped).  Tables must be zeroed by the caller.
+ * ------------------------------------------------------------------------------------------------------------- */
+/* keys[i] = base-5 number of codes[i][left0 .. left0+d) ++ codes[i][right0 .. right0+d) (order-1 codes 0..4);
+ * with region_size > 0: + (i / region_size) * 5^(2d), rows of regions >= n_regions get key -1                      */
+int mural_eval_kmer_keys(const int64_t* codes, int64_t n, int32_t ncols, int32_t left0, int32_t right0, int32_t d,
+                         int64_t region_size, int64_t n_regions, int32_t* keys, int32_t* status, void* stream);
+/* keys[i] = chrom_base[chrom_id[i]] + start[i] / window                                                           */
+int mural_eval_window_keys(const int32_t* chrom_id, const int64_t* start, int64_t n, int64_t window,
+                           const int64_t* chrom_base, int32_t n_chrom, int32_t* keys, int32_t* status, void* stream);
+/* table [n_groups][1 + 2 n_class] += { rows, rows with label c, sum of prob[:, c] } of the rows with key g >= 0     */
+int mural_eval_group_obs_pred(const int32_t* keys, const int32_t* label, const void* prob, int32_t prob_f64, int64_t n,
+                              int32_t n_class, int32_t n_groups, double* table, int32_t* status, void* stream);
+/* out [2 + 3 n_bins (1 + n_class)] += { NLL sum, Brier sum, top-label bins [n_bins][3], class bins [n_class][n_bins][3] }
+ * with bin b = (bounds[b], bounds[b+1]] and cells (rows, score sum, hits)                                           */
+int mural_eval_calib_metrics(const void* prob, int32_t prob_f64, const int32_t* label, int64_t n, int32_t n_class,
+                             int32_t n_bins, const float* bounds, double* out, int32_t* status, void* stream);
+/* out [1 + km + (km)^2] (km = n_class (n_class + 1)) += { loss sum, gradient, Hessian (if need_hessian) } of the
+ * multinomial regression on [log clip(prob); 1] at weights [n_class][n_class + 1] (float64, device); n_class <= 8    */
+int mural_eval_dirichlet_fit_terms(const void* prob, int32_t prob_f64, const int32_t* label, int64_t n, int32_t n_class,
+                                   const double* weights, int32_t need_hessian, double* out, int32_t* status, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -94,6 +94,11 @@ PROTOTYPES = {
     "mural_fasta_pack": (C.c_int, [C.c_char_p, I64, I64, VP, VP, VP, I64, VP]),
     "mural_bed_read": (C.c_int, [C.c_char_p, I64, VP, VP, VP, VP, VP, I32, I32, VP, VP, VP]),
     "mural_bed_segment_order": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP]),
+    "mural_eval_kmer_keys": (C.c_int, [VP, I64, I32, I32, I32, I32, I64, I64, VP, VP, VP]),
+    "mural_eval_window_keys": (C.c_int, [VP, VP, I64, I64, VP, I32, VP, VP, VP]),
+    "mural_eval_group_obs_pred": (C.c_int, [VP, VP, VP, I32, I64, I32, I32, VP, VP, VP]),
+    "mural_eval_calib_metrics": (C.c_int, [VP, I32, VP, I64, I32, I32, VP, VP, VP, VP]),
+    "mural_eval_dirichlet_fit_terms": (C.c_int, [VP, I32, VP, I64, I32, VP, I32, VP, VP, VP]),
     "mural_op_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]),
     "mural_op_bnconv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP]),
     "mural_op_bnconv32_bwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP, VP, VP, VP, VP, VP, VP]),

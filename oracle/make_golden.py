@@ -469,13 +469,151 @@ def g12_dirichlet(ref):
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
 
 
+def analytics_inputs(seed, n, n_class, radius, model_type, dtype=np.float32):
+    """Synthetic validation set: order-1 local codes, labels whose rate depends on the flanking bases, probabilities that
+    follow that rate with noise, three chromosomes of sorted starts."""
+    rng = np.random.default_rng(seed)
+    ncols = 2 * radius + (1 if model_type == "snv" else 0)
+    codes = rng.integers(0, 4, size=(n, ncols)).astype(np.int64)
+    codes[rng.random(codes.shape) < 0.01] = 4
+    ctx = codes[:, radius - 1] * 5 + codes[:, radius + (1 if model_type == "snv" else 0)]
+    rate = 0.02 + 0.01 * (ctx % 7)
+    pm = np.stack([rate * (c + 1) / n_class for c in range(n_class - 1)], axis=1)
+    p_true = np.concatenate([1 - pm.sum(axis=1, keepdims=True), pm], axis=1)
+    label = np.array([rng.choice(n_class, p=row) for row in p_true]).astype(np.int64)
+    noise = rng.dirichlet([40] + [2] * (n_class - 1), size=n)
+    prob = 0.7 * p_true + 0.3 * noise
+    prob = (prob / prob.sum(axis=1, keepdims=True)).astype(dtype)
+    chrom = np.sort(rng.choice(np.array(["chr1", "chr10", "chr2"]), size=n))
+    start = np.concatenate([np.sort(rng.integers(0, 60000, size=int((chrom == c).sum()))) for c in ("chr1", "chr10", "chr2")])
+    return codes, label, prob, chrom, start.astype(np.int64)
+
+
+def g13_analytics(ref):
+    """Validation analytics of MuRaL/evaluation/evaluation.py run through the reference's own functions:
+    freq_kmer_comp_multi, corr_calc_sub (pandas >= 2 dropped DataFrame.append, which it calls: shimmed with concat),
+    Evaluator.evaluate_regional_score, ECELoss / ClasswiseECELoss / BrierScore / CrossEntropyLoss, and the Newton driver of the
+    full-Dirichlet fit (dirichletcal/calib/multinomial.py:246-327) with its own objective on numpy and oracle/eval_ref.py's
+    analytic derivatives in place of jax.grad / jax.hessian (jax is absent; they are checked against finite differences of the
+    reference objective here)."""
+    import importlib
+    import types
+    import pandas as pd
+    from oracle import eval_ref
+    ev = importlib.import_module("MuRaL.evaluation.evaluation")
+    prep = ref.preprocessing
+    if not hasattr(pd.DataFrame, "append"):
+        pd.DataFrame.append = lambda self, other: pd.concat([self, other])
+    out = {}
+    for tag, model_type, n_class, radius, kmers, n in (("snv", "snv", 4, 5, (3, 5, 7), 6000), ("indel", "indel", 3, 4, (2, 4, 6), 3000)):
+        codes, label, prob, chrom, start = analytics_inputs(13 if tag == "snv" else 14, n, n_class, radius, model_type)
+        names = ["prob%d" % i for i in range(n_class)]
+        header = prep.get_local_header(radius, 1, model_type)
+        data_local = pd.concat([pd.DataFrame(codes, columns=header), pd.DataFrame({"mut_type": label.astype(np.float32)})], axis=1)
+        y_prob = pd.DataFrame(prob, columns=names)
+        dp = pd.concat([data_local, y_prob], axis=1)
+        for k in kmers:
+            out[f"{tag}_kmer{k}"] = np.array(quiet(ev.freq_kmer_comp_multi, dp, k, n_class), dtype=np.float64)
+        vp = pd.concat((pd.DataFrame({"chrom": chrom, "start": start, "end": start + 1, "strand": "+"}), dp[["mut_type"] + names]), axis=1)
+        vp.sort_values(["chrom", "start"], inplace=True)
+        vp.reset_index(drop=True, inplace=True)
+        for win in (1000, 5000):
+            out[f"{tag}_win{win}"] = np.array(quiet(ev.corr_calc_sub, vp, win, names), dtype=np.float64)
+        got = {}
+
+        def printer(*a, _got=got):
+            _got[a[0]] = a[1:]
+        e = ev.Evaluator(data_local, prob, n_class, printer=printer)
+        quiet(e.evaluate_regional_score, n, list(kmers[:2]))
+        out[f"{tag}_score"] = np.array([e.metrics["score"], got["n_regions:"][0]], dtype=np.float64)
+        out[f"{tag}_score_corr"] = np.array(got["corr_list: "][0], dtype=np.float64)
+        for dt in (np.float32, np.float64):
+            pr = prob.astype(dt)
+            if dt == np.float64:
+                pr = pr ** 0.9
+                pr = pr / pr.sum(axis=1, keepdims=True)
+            logits = torch.log(torch.from_numpy(pr))
+            lab = torch.from_numpy(label).long()
+            vals = [torch.nn.CrossEntropyLoss(reduction="mean")(logits, lab).item(), ev.ECELoss(n_bins=50)(logits, lab).item(),
+                    ev.ClasswiseECELoss(n_bins=50)(logits, lab).item(), ev.BrierScore()(logits, lab).item()]
+            out[f"{tag}_metrics_{np.dtype(dt).name}"] = np.array(vals, dtype=np.float64)
+            out[f"{tag}_metrics_prob_{np.dtype(dt).name}"] = pr
+        out[f"{tag}_codes"], out[f"{tag}_label"], out[f"{tag}_prob"] = codes, label, prob
+        out[f"{tag}_chrom"], out[f"{tag}_start"] = chrom.astype(str), start
+
+    # ---- the fit: reference Newton driver + objective on numpy, analytic derivatives
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "jax" or k.startswith("jax.") or k.startswith("dirichletcal")
+             or k == "autograd" or k.startswith("autograd.")}
+    for k in saved:
+        sys.modules.pop(k, None)
+
+    def raw_derivs(params, X, _xxt, target, k, *rest):
+        w = eval_ref.effective_weights(np.asarray(params), k)
+        label = np.argmax(np.asarray(target), axis=1)
+        _, g, h = eval_ref.fit_row_terms(np.asarray(X), label, w, True)
+        m = k + 1
+        g = g.reshape(k, m).copy()
+        g[-1] -= g.sum(axis=0)
+        h = h.reshape(k, m, k, m).copy()
+        h[-1] -= h.sum(axis=0)
+        h[:, :, -1] -= h.sum(axis=2)
+        return g.ravel(), h.reshape(k * m, k * m)
+
+    def mod(name, **kw):
+        mm = types.ModuleType(name)
+        mm.__path__ = []
+        for a, v in kw.items():
+            setattr(mm, a, v)
+        sys.modules[name] = mm
+        return mm
+
+    jax = mod("jax", numpy=np, grad=lambda f, argnums=0: (lambda *a: raw_derivs(*a)[0]),
+              hessian=lambda f, argnums=0: (lambda *a: raw_derivs(*a)[1]))
+    jax.config = mod("jax.config", config=types.SimpleNamespace(update=lambda *a, **k: None)).config
+    sys.modules["jax.numpy"] = np
+    mod("autograd", grad=lambda *a, **k: None, hessian=lambda *a, **k: None, numpy=np)
+    sys.modules["autograd.numpy"] = np
+    sys.path.insert(0, os.path.join(ref_import.REFERENCE_ROOT, "dirichlet_python"))
+    try:
+        mn = importlib.import_module("dirichletcal.calib.multinomial")
+        for tag, n_class in (("snv", 4), ("indel", 3)):
+            prob, label = out[f"{tag}_prob"], out[f"{tag}_label"]
+            X_ = eval_ref.fit_features(prob)
+            target = np.eye(n_class)[label]
+            w0 = np.asarray(mn._get_identity_weights(n_class, True, "Full"))
+            args = (X_, None, target, n_class, "Full", 0.0, None, True, "identity", None)
+            # finite-difference check of the stand-in derivatives against the reference objective
+            rng = np.random.default_rng(5)
+            wp = w0 + 0.1 * rng.standard_normal(w0.shape)
+            g, h = raw_derivs(wp, *args)
+            for idx in range(0, wp.shape[0], 3):
+                e = np.zeros_like(wp)
+                e[idx] = 1e-6
+                fd = (float(mn._objective(wp + e, *args)) - float(mn._objective(wp - e, *args))) / 2e-6
+                assert abs(fd - g[idx]) < 1e-7, (idx, fd, g[idx])
+                fdh = (raw_derivs(wp + e, *args)[0] - raw_derivs(wp - e, *args)[0]) / 2e-6
+                assert np.abs(fdh - h[idx]).max() < 1e-6
+            wts = mn._newton_update(w0, X_, None, target, n_class, "Full", reg_lambda=0.0, reg_mu=None, ref_row=True,
+                                    initializer="identity", reg_format=None)
+            full = np.asarray(mn._get_weights(wts, n_class, True, "Full"))
+            out[f"{tag}_fit_w"] = full
+            out[f"{tag}_fit_loss"] = np.array(float(mn._objective(wts, *args)))
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == "jax" or k.startswith("jax.") or k.startswith("dirichletcal") or k == "autograd"
+                  or k.startswith("autograd.")]:
+            sys.modules.pop(k, None)
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+    save("analytics.npz", **out)
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_import.load()
     only = set(sys.argv[1:])
     steps = dict(g1=g1_encode, g2=g2_windowing, g3=g3_pretrained, g45=g45_synth, g6=g6_taps, g7=g7_train,
-                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet)
+                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet, g13=g13_analytics)
     for name, fn in steps.items():
         if only and name not in only:
             continue
