@@ -320,6 +320,24 @@ int mural_eval_calib_metrics(const void* prob, int32_t prob_f64, const int32_t* 
 int mural_eval_dirichlet_fit_terms(const void* prob, int32_t prob_f64, const int32_t* label, int64_t n, int32_t n_class,
                                    const double* weights, int32_t need_hessian, double* out, int32_t* status, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Training-mode ops of the INDEL U-Net (MuRaL/model/model_indel.py:6-19, :151-176 under model.train()): a general
+ * Conv1d (stride, zero padding, input upsampled by `up` = nn.Upsample(scale_factor) in front of the conv) with its
+ * backward, and the element-wise activations.  x [B][Cin][Lin], W [Cout][Cin][K] (torch layout), y [B][Cout][Lout].
+ * ------------------------------------------------------------------------------------------------------------- */
+int mural_op_convg_out_length(int32_t Lin, int32_t K, int32_t stride, int32_t pad, int32_t up);   /* -1: bad geometry */
+/* wt: scratch of Cout*Cin*K floats */
+int mural_op_convg_fwd(const float* x, const float* W, const float* bias, float* wt, float* y, int64_t B, int32_t Cin,
+                       int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, void* stream);
+size_t mural_op_convg_bwd_scratch(int32_t Cin, int32_t Cout, int32_t K);                          /* floats */
+/* dx (optional), dW and db (optional) are fully written */
+int mural_op_convg_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout,
+                       int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
+                       size_t part_floats, void* stream);
+/* kind: 1 ReLU, 2 SiLU, 3 Softplus (beta 1, threshold 20); backward takes the forward INPUT x */
+int mural_op_act_fwd(const float* x, int64_t n, int32_t kind, float* y, void* stream);
+int mural_op_act_bwd(const float* dy, const float* x, int64_t n, int32_t kind, float* dx, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

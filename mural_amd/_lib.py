@@ -99,6 +99,12 @@ PROTOTYPES = {
     "mural_eval_group_obs_pred": (C.c_int, [VP, VP, VP, I32, I64, I32, I32, VP, VP, VP]),
     "mural_eval_calib_metrics": (C.c_int, [VP, I32, VP, I64, I32, I32, VP, VP, VP, VP]),
     "mural_eval_dirichlet_fit_terms": (C.c_int, [VP, I32, VP, I64, I32, VP, I32, VP, VP, VP]),
+    "mural_op_convg_out_length": (C.c_int, [I32, I32, I32, I32, I32]),
+    "mural_op_convg_fwd": (C.c_int, [VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP]),
+    "mural_op_convg_bwd_scratch": (C.c_size_t, [I32, I32, I32]),
+    "mural_op_convg_bwd": (C.c_int, [VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, C.c_size_t, VP]),
+    "mural_op_act_fwd": (C.c_int, [VP, I64, I32, VP, VP]),
+    "mural_op_act_bwd": (C.c_int, [VP, VP, I64, I32, VP, VP]),
     "mural_op_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]),
     "mural_op_bnconv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP]),
     "mural_op_bnconv32_bwd": (C.c_int, [VP, VP, I64, I32, I32, VP, VP, VP, VP, VP, C.c_size_t, VP, VP, VP, VP, VP, VP, VP, VP, VP]),

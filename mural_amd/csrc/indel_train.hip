@@ -1,0 +1,287 @@
+// Training-mode building blocks of the INDEL U-Net (reference MuRaL/model/model_indel.py:6-19, :151-176 run under
+// model.train(), MuRaL/training.py:404-450): a general Conv1d (any stride, nearest-neighbour upsampled input) with its
+// input- and weight-gradient kernels, and the SiLU / Softplus / ReLU element-wise pair.  BatchNorm (batch statistics),
+// Linear, Dropout and the global max come from train_ops.hip.  Tensors are [B][C][L] fp32, weights in torch's
+// [Cout][Cin][K] layout.  Direct convolutions on the vector ALU: at 4..48 channels the layers are HBM / latency bound.
+#include <cstring>
+
+#include "conv1d.h"
+
+namespace mural {
+namespace {
+
+constexpr int IT_THREADS = 256;
+
+// ------------------------------------------------------------------------------------------------ input gradient
+// dx[b][ci][j] = sum over the `up` positions l of the upsampled input that read x[j], taps k and output channels co of
+//   dy[b][co][(l + pad - k) / stride] * W[co][ci][k]        where (l + pad - k) is a non-negative multiple of stride.
+// A thread owns one (b, j) and CG input channels; weights sit in LDS as [co][k][ci] (a wave reads one address: broadcast).
+template <int CG>
+__global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                                float* __restrict__ dx, int64_t rows /* B * Lin */, int Cin,
+                                                                int Lin, int Cout, int Lout, int K, int stride, int pad, int up) {
+  extern __shared__ float wl[];                   // [Cout][K][CG]
+  const int ci0 = blockIdx.y * CG;
+  for (int i = threadIdx.x; i < Cout * K * CG; i += IT_THREADS) {
+    const int c = i % CG, r = i / CG, k = r % K, co = r / K;
+    wl[i] = (ci0 + c < Cin) ? W[((size_t)co * Cin + ci0 + c) * K + k] : 0.f;
+  }
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x;
+  if (row >= rows) return;
+  const int b = (int)(row / Lin), j = (int)(row - (int64_t)b * Lin);
+  float acc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+  const float* dyb = dy + (size_t)b * Cout * Lout;
+  for (int u = 0; u < up; ++u) {
+    const int l = j * up + u;
+    for (int k = 0; k < K; ++k) {
+      const int t = l + pad - k;
+      if (t < 0 || t % stride != 0) continue;
+      const int lo = t / stride;
+      if (lo >= Lout) continue;
+      for (int co = 0; co < Cout; ++co) {
+        const float g = dyb[(size_t)co * Lout + lo];
+        const float* w = wl + (co * K + k) * CG;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[c] = fmaf(g, w[c], acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CG; ++c)
+    if (ci0 + c < Cin) dx[((size_t)b * Cin + ci0 + c) * Lin + j] = acc[c];
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// part[chunk][co][ci * K + k] = sum over the chunk's (b, lo) of dy[b][co][lo] * xu[b][ci][lo * stride - pad + k], xu = x
+// upsampled by `up`; part[chunk][co][Cin * K] = sum of dy (bias gradient).  Workgroup = (chunk, group of 4 output channels).
+// With E = Cin * K <= 256 entries the 256 threads form 256 / E slices that split the 64 positions of a tile between them
+// (summed through LDS at the end); with more entries a thread owns two of them and all 64 positions.
+constexpr int WG_CO = 4, WG_TL = 64, WG_E = 2, WG_CHUNKS = 1024;
+
+__global__ __launch_bounds__(IT_THREADS) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                float* __restrict__ part, int B, int Cin, int Lin, int Cout,
+                                                                int Lout, int K, int stride, int pad, int up, int tiles_per_row,
+                                                                int64_t tiles, int chunks) {
+  extern __shared__ float lds[];
+  const int span = (WG_TL - 1) * stride + K, spanp = span | 1;
+  float* xs = lds;                               // [Cin][spanp]; reused for the slice reduction at the end
+  float* ds = lds + (size_t)Cin * spanp;         // [WG_CO][WG_TL]
+  const int chunk = blockIdx.x, co0 = blockIdx.y * WG_CO;
+  const int entries = Cin * K;
+  const int slices = entries <= IT_THREADS ? IT_THREADS / entries : 1;
+  float acc[WG_E][WG_CO];
+#pragma unroll
+  for (int e = 0; e < WG_E; ++e)
+#pragma unroll
+    for (int g = 0; g < WG_CO; ++g) acc[e][g] = 0.f;
+  float bacc = 0.f;
+  int eidx[WG_E], eci[WG_E], ek[WG_E];
+  const int sl = slices > 1 ? threadIdx.x / entries : 0;
+#pragma unroll
+  for (int e = 0; e < WG_E; ++e) {
+    int idx;
+    if (slices > 1) idx = (e == 0 && sl < slices) ? (int)threadIdx.x - sl * entries : -1;
+    else idx = (int)threadIdx.x + e * IT_THREADS < entries ? (int)threadIdx.x + e * IT_THREADS : -1;
+    eidx[e] = idx;
+    eci[e] = idx >= 0 ? idx / K : -1;
+    ek[e] = idx >= 0 ? idx % K : 0;
+  }
+  const int Lup = Lin * up;
+  for (int64_t tile = chunk; tile < tiles; tile += chunks) {
+    const int b = (int)(tile / tiles_per_row), lo0 = (int)(tile % tiles_per_row) * WG_TL;
+    __syncthreads();
+    const float* xb = x + (size_t)b * Cin * Lin;
+    const int base = lo0 * stride - pad;
+    for (int i = threadIdx.x; i < Cin * span; i += IT_THREADS) {
+      const int ci = i / span, p = i - ci * span;
+      const int l = base + p;
+      xs[ci * spanp + p] = (l >= 0 && l < Lup) ? xb[(size_t)ci * Lin + l / up] : 0.f;
+    }
+    for (int i = threadIdx.x; i < WG_CO * WG_TL; i += IT_THREADS) {
+      const int g = i / WG_TL, t = i - g * WG_TL;
+      const int lo = lo0 + t, co = co0 + g;
+      ds[i] = (lo < Lout && co < Cout) ? dy[((size_t)b * Cout + co) * Lout + lo] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < WG_E; ++e) {
+      if (eci[e] < 0) continue;
+      const float* xr = xs + eci[e] * spanp + ek[e];
+      for (int t = sl; t < WG_TL; t += slices) {
+        const float xv = xr[t * stride];
+#pragma unroll
+        for (int g = 0; g < WG_CO; ++g) acc[e][g] = fmaf(ds[g * WG_TL + t], xv, acc[e][g]);
+      }
+    }
+    if (threadIdx.x >= IT_THREADS - WG_CO) {       // the last threads are the least loaded ones
+      const int g = threadIdx.x - (IT_THREADS - WG_CO);
+      float sm = 0.f;
+      for (int t = 0; t < WG_TL; ++t) sm += ds[g * WG_TL + t];
+      bacc += sm;
+    }
+  }
+  const int rowlen = entries + 1;
+  if (slices > 1) {
+    __syncthreads();
+    if (eidx[0] >= 0)
+#pragma unroll
+      for (int g = 0; g < WG_CO; ++g) xs[(sl * entries + eidx[0]) * WG_CO + g] = acc[0][g];
+    __syncthreads();
+    if (sl == 0 && eidx[0] >= 0) {
+#pragma unroll
+      for (int g = 0; g < WG_CO; ++g) {
+        float sm = 0.f;
+        for (int q = 0; q < slices; ++q) sm += xs[(q * entries + eidx[0]) * WG_CO + g];
+        if (co0 + g < Cout) part[((size_t)chunk * Cout + co0 + g) * rowlen + eidx[0]] = sm;
+      }
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < WG_E; ++e) {
+      if (eidx[e] < 0) continue;
+#pragma unroll
+      for (int g = 0; g < WG_CO; ++g)
+        if (co0 + g < Cout) part[((size_t)chunk * Cout + co0 + g) * rowlen + eidx[e]] = acc[e][g];
+    }
+  }
+  if (threadIdx.x >= IT_THREADS - WG_CO) {
+    const int g = threadIdx.x - (IT_THREADS - WG_CO);
+    if (co0 + g < Cout) part[((size_t)chunk * Cout + co0 + g) * rowlen + entries] = bacc;
+  }
+}
+
+// one wave per output element: lanes stride over the chunks, float64 sum
+__global__ __launch_bounds__(IT_THREADS) void conv_wgrad_reduce_kernel(const float* __restrict__ part, int chunks, int Cout,
+                                                                       int entries, float* __restrict__ dW, float* __restrict__ db) {
+  const int i = blockIdx.x * (IT_THREADS / 64) + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const int rowlen = entries + 1;
+  if (i >= Cout * rowlen) return;
+  double s = 0.0;
+  for (int c = lane; c < chunks; c += 64) s += (double)part[(size_t)c * Cout * rowlen + i];
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+  if (lane != 0) return;
+  const int co = i / rowlen, r = i - co * rowlen;
+  if (r < entries) dW[(size_t)co * entries + r] = (float)s;
+  else if (db) db[co] = (float)s;
+}
+
+// ------------------------------------------------------------------------------------------------ activations
+// kind: 1 ReLU, 2 SiLU, 3 Softplus (beta 1, linear above 20, like torch.nn.Softplus)
+__device__ __forceinline__ float act_f(float v, int kind) {
+  if (kind == 1) return v > 0.f ? v : 0.f;
+  if (kind == 2) return v / (1.f + expf(-v));
+  return v > 20.f ? v : log1pf(expf(v));
+}
+__device__ __forceinline__ float act_d(float v, int kind) {
+  if (kind == 1) return v > 0.f ? 1.f : 0.f;
+  const float s = 1.f / (1.f + expf(-v));
+  if (kind == 2) return s * (1.f + v * (1.f - s));
+  return v > 20.f ? 1.f : s;
+}
+
+__global__ __launch_bounds__(IT_THREADS) void act_fwd_kernel(const float* __restrict__ x, int64_t n, int kind, float* __restrict__ y) {
+  const int64_t step = (int64_t)gridDim.x * IT_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < n; i += step) y[i] = act_f(x[i], kind);
+}
+__global__ __launch_bounds__(IT_THREADS) void act_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x, int64_t n,
+                                                             int kind, float* __restrict__ dx) {
+  const int64_t step = (int64_t)gridDim.x * IT_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < n; i += step) dx[i] = dy[i] * act_d(x[i], kind);
+}
+
+int out_length(int Lin, int K, int stride, int pad, int up) { return (Lin * up + 2 * pad - K) / stride + 1; }
+
+}  // namespace
+}  // namespace mural
+
+using namespace mural;
+
+extern "C" int mural_op_convg_out_length(int32_t Lin, int32_t K, int32_t stride, int32_t pad, int32_t up) {
+  if (K < 1 || stride < 1 || up < 1 || pad < 0 || Lin * up + 2 * pad < K) return -1;
+  return out_length(Lin, K, stride, pad, up);
+}
+
+// y = Conv1d(upsample_up(x)); wt = scratch of Cout * Cin * K floats (receives the [Cin][K][Cout] layout of W)
+extern "C" int mural_op_convg_fwd(const float* x, const float* W, const float* bias, float* wt, float* y, int64_t B, int32_t Cin,
+                                  int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, void* stream) {
+  MURAL_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && Lin >= 1, "convg_fwd: bad sizes");
+  MURAL_REQUIRE(mural_op_convg_out_length(Lin, K, stride, pad, up) >= 1, "convg_fwd: bad geometry");
+  if (B == 0) return MURAL_OK;
+  MURAL_REQUIRE(x && W && wt && y, "convg_fwd: null pointer");
+  int rc = mural_op_relayout(W, wt, Cout, Cin, K, 0, stream);
+  if (rc != MURAL_OK) return rc;
+  Conv1dArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = x; a.wt = wt; a.bias = bias; a.out = y;
+  a.B = (int)B; a.Cin = Cin; a.Lin = Lin; a.Cout = Cout; a.Lout = out_length(Lin, K, stride, pad, up);
+  a.K = K; a.stride = stride; a.pad = pad; a.up = up;
+  a.act = ACT_NONE;
+  return launch_conv1d(a, (hipStream_t)stream);
+}
+
+// dx (optional) [B][Cin][Lin], dW [Cout][Cin][K], db (optional) [Cout]; part = scratch of mural_op_convg_bwd_scratch floats
+extern "C" size_t mural_op_convg_bwd_scratch(int32_t Cin, int32_t Cout, int32_t K) {
+  return (size_t)WG_CHUNKS * Cout * ((size_t)Cin * K + 1);
+}
+
+extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout,
+                                  int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
+                                  size_t part_floats, void* stream) {
+  MURAL_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && Lin >= 1, "convg_bwd: bad sizes");
+  const int Lout = mural_op_convg_out_length(Lin, K, stride, pad, up);
+  MURAL_REQUIRE(Lout >= 1, "convg_bwd: bad geometry");
+  MURAL_REQUIRE(dy && x && W && dW && part, "convg_bwd: null pointer");
+  MURAL_REQUIRE(Cin * K <= WG_E * IT_THREADS, "convg_bwd: Cin * K = %d exceeds %d", Cin * K, WG_E * IT_THREADS);
+  hipStream_t st = (hipStream_t)stream;
+  if (dx) {
+    const int64_t rows = B * Lin;
+    const bool small = Cin <= 4;
+    const int cg = small ? 4 : 8;
+    const dim3 grid((unsigned)((rows + IT_THREADS - 1) / IT_THREADS), (Cin + cg - 1) / cg);
+    const size_t lds = (size_t)Cout * K * cg * sizeof(float);
+    if (small)
+      hipLaunchKernelGGL(conv_dgrad_kernel<4>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad, up);
+    else
+      hipLaunchKernelGGL(conv_dgrad_kernel<8>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad, up);
+    MURAL_HIP_CHECK(hipGetLastError());
+  }
+  const int tiles_per_row = (Lout + WG_TL - 1) / WG_TL;
+  const int64_t tiles = B * tiles_per_row;
+  const int chunks = (int)(tiles < WG_CHUNKS ? tiles : WG_CHUNKS);
+  const int entries = Cin * K;
+  MURAL_REQUIRE(part_floats >= (size_t)chunks * Cout * (entries + 1), "convg_bwd: scratch too small");
+  size_t lds_floats = (size_t)Cin * (((WG_TL - 1) * stride + K) | 1);
+  if (lds_floats < (size_t)IT_THREADS * WG_CO) lds_floats = (size_t)IT_THREADS * WG_CO;      // slice reduction scratch
+  const size_t lds = (lds_floats + WG_CO * WG_TL) * sizeof(float);
+  MURAL_REQUIRE(lds <= 64 * 1024, "convg_bwd: input tile of %zu bytes exceeds 64 KB of LDS", lds);
+  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(chunks, (Cout + WG_CO - 1) / WG_CO), dim3(IT_THREADS), lds, st, dy, x, part, (int)B, Cin,
+                     Lin, Cout, Lout, K, stride, pad, up, tiles_per_row, tiles, chunks);
+  MURAL_HIP_CHECK(hipGetLastError());
+  hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((Cout * (entries + 1) + 3) / 4), dim3(IT_THREADS), 0, st, part, chunks, Cout,
+                     entries, dW, db);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+extern "C" int mural_op_act_fwd(const float* x, int64_t n, int32_t kind, float* y, void* stream) {
+  MURAL_REQUIRE(kind >= 1 && kind <= 3, "act_fwd: kind must be 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
+  if (n <= 0) return MURAL_OK;
+  int64_t g = (n + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
+  hipLaunchKernelGGL(act_fwd_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(IT_THREADS), 0, (hipStream_t)stream, x, n, kind, y);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+extern "C" int mural_op_act_bwd(const float* dy, const float* x, int64_t n, int32_t kind, float* dx, void* stream) {
+  MURAL_REQUIRE(kind >= 1 && kind <= 3, "act_bwd: kind must be 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
+  if (n <= 0) return MURAL_OK;
+  int64_t g = (n + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(IT_THREADS), 0, (hipStream_t)stream, dy, x, n, kind, dx);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}

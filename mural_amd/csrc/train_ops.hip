@@ -5,6 +5,7 @@
 // Layout: activations [B][C][L] fp32 (the reference's NCL).  Every entry point enqueues on the caller's stream.
 // Correctness-first kernels (vector ALU, atomics for cross-workgroup sums); the conv forward / input-gradient reuse the
 // generic conv1d kernel.  The Python autograd glue lives in mural_amd/model/train_ops.py.
+#include <climits>
 #include <cstring>
 
 #include "conv1d.h"
@@ -293,6 +294,37 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int64_t rows, in
     }
     y[i] = m;
     arg[i] = am;
+  }
+}
+
+// wide windows (the global max over a long row): one wave per output, lanes stride over the window, then a shuffle reduction
+// that keeps the first maximum
+__global__ __launch_bounds__(256) void maxpool_fwd_wide_kernel(const float* __restrict__ x, int64_t rows, int L, int Lout, int k, int s,
+                                                               int p, float* __restrict__ y, int32_t* __restrict__ arg) {
+  const int64_t total = rows * Lout;
+  const int lane = threadIdx.x & 63;
+  for (int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6); i < total; i += (int64_t)gridDim.x * 4) {
+    const int64_t r = i / Lout;
+    const int lo = (int)(i - r * Lout);
+    const float* xr = x + r * L;
+    float m = -INFINITY;
+    int am = INT_MAX;
+    for (int w = lane; w < k; w += 64) {
+      const int l = lo * s - p + w;
+      if (l < 0 || l >= L) continue;
+      const float v = xr[l];
+      if (v > m || am == INT_MAX) { m = v; am = l; }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const float om = __shfl_xor(m, off, 64);
+      const int oa = __shfl_xor(am, off, 64);
+      if (oa != INT_MAX && (am == INT_MAX || om > m || (om == m && oa < am))) { m = om; am = oa; }
+    }
+    if (lane == 0) {
+      y[i] = m;
+      arg[i] = am == INT_MAX ? -1 : am;
+    }
   }
 }
 
@@ -884,6 +916,12 @@ extern "C" int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int
   const int Lout = (L + 2 * p - k) / s + 1;
   const int64_t total = rows * Lout;
   if (total == 0) return MURAL_OK;
+  if (k >= 256) {
+    const int64_t g = (total + 3) / 4;
+    hipLaunchKernelGGL(maxpool_fwd_wide_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, STREAM, x, rows, L, Lout, k, s,
+                       p, y, arg);
+    CHECK_LAUNCH();
+  }
   hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, STREAM, x, rows, L, Lout, k, s, p, y, arg);
   CHECK_LAUNCH();
 }

@@ -1,0 +1,148 @@
+"""Training-mode forward of ``UNet_Small`` on the HIP building blocks (``mural_op_convg_*``, ``mural_op_act_*`` of
+csrc/indel_train.hip; BatchNorm / Linear / Dropout / global max of csrc/train_ops.hip).
+
+The reference runs stock autograd over ``torch.nn`` modules (MuRaL/model/model_indel.py:151-176 under ``model.train()``,
+MuRaL/training.py:404-450).  Here each layer is a ``torch.autograd.Function`` whose forward and backward launch the
+hand-written kernels; torch supplies the tensors, the stream, the autograd graph and the residual adds / flips.
+BatchNorm uses batch statistics and updates ``running_mean`` / ``running_var`` / ``num_batches_tracked`` exactly like
+``nn.BatchNorm1d`` (the strand-symmetrising ``conv`` is applied twice per forward, so its BatchNorm is updated twice, as in
+the reference).
+"""
+import torch
+
+from .. import _lib
+from . import train_ops as T
+
+ACT_RELU, ACT_SILU, ACT_SOFTPLUS = 1, 2, 3
+
+_scratch = {}
+
+
+def _bwd_scratch(device, n):
+    t = _scratch.get(device)
+    if t is None or t.numel() < n:
+        t = _scratch[device] = torch.empty(n, device=device)
+    return t
+
+
+class Conv(torch.autograd.Function):
+    """y = Conv1d(Upsample(scale_factor=up)(x)) with torch-layout weight (Cout, Cin, K), optional bias, stride, zero padding."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, stride, pad, up):
+        x = x.contiguous()
+        B, Cin, Lin = x.shape
+        Cout, _, K = weight.shape
+        Lout = int(_lib.lib().mural_op_convg_out_length(Lin, K, stride, pad, up))
+        if Lout < 1:
+            raise ValueError(f"Conv1d: kernel {K} / padding {pad} do not fit an input of length {Lin * up}")
+        y = torch.empty((B, Cout, Lout), device=x.device)
+        wt = torch.empty(weight.numel(), device=x.device)
+        T._call("mural_op_convg_fwd", x, T._f32(weight), None if bias is None else T._f32(bias), wt, y, B, Cin, Lin, Cout, K, stride,
+                pad, up, T._stream(x))
+        ctx.save_for_backward(x, weight)
+        ctx.geom = (stride, pad, up, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        stride, pad, up, has_bias = ctx.geom
+        dy = dy.contiguous()
+        B, Cin, Lin = x.shape
+        Cout, _, K = weight.shape
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(Cout, device=dev) if has_bias else None
+        part = _bwd_scratch(dev, int(_lib.lib().mural_op_convg_bwd_scratch(Cin, Cout, K)))
+        T._call("mural_op_convg_bwd", dy, x, T._f32(weight), B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part.numel(),
+                T._stream(x))
+        return dx, dW, db, None, None, None
+
+
+class BatchNorm(torch.autograd.Function):
+    """y = BatchNorm1d(x) on (B, C, L) with batch statistics (running statistics updated in place)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, bn):
+        x = x.contiguous()
+        B, Cn, L = x.shape
+        state = T._BnState(x, False, bn, L)
+        y = torch.empty_like(x)
+        T._call("mural_op_bn_apply", x, B, Cn, L, 0, state.scale, state.shift, y, T._stream(x))
+        ctx.save_for_backward(x, gamma, state.mean, state.invstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, invstd = ctx.saved_tensors
+        B, Cn, L = x.shape
+        acc = T._bn_acc(Cn, x.device)
+        dx = torch.empty_like(x)
+        dgamma = torch.empty(Cn, device=x.device)
+        dbeta = torch.empty(Cn, device=x.device)
+        T._call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, L, 0, mean, invstd, T._f32(gamma), acc, 0, None, None, dx, dgamma,
+                dbeta, T._stream(x))
+        return dx, dgamma, dbeta, None
+
+
+class Act(torch.autograd.Function):
+    """ReLU / SiLU / Softplus; the backward re-derives the slope from the saved input."""
+
+    @staticmethod
+    def forward(ctx, x, kind):
+        x = x.contiguous()
+        y = torch.empty_like(x)
+        T._call("mural_op_act_fwd", x, x.numel(), kind, y, T._stream(x))
+        ctx.save_for_backward(x)
+        ctx.kind = kind
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dx = torch.empty_like(x)
+        T._call("mural_op_act_bwd", dy.contiguous(), x, x.numel(), ctx.kind, dx, T._stream(x))
+        return dx, None
+
+
+def _conv(x, conv, up=1):
+    return Conv.apply(x, conv.weight, conv.bias, int(conv.stride[0]), int(conv.padding[0]), int(up))
+
+
+def _bn(x, bn):
+    return BatchNorm.apply(x, bn.weight, bn.bias, bn)
+
+
+def _conv_block(x, cb):
+    """x + BN(Conv1x1(SiLU(BN(Conv5(x)))))   (model_indel.py:6-19)"""
+    seq = cb.conv
+    h = _bn(_conv(x, seq[0]), seq[1])
+    h = Act.apply(h, ACT_SILU)
+    return x + _bn(_conv(h, seq[3]), seq[4])
+
+
+def unet_forward_train(model, x):
+    """``UNet_Small.forward`` (model_indel.py:151-176) in training mode."""
+    out = x
+    if model.use_reverse:
+        sym = lambda t: _bn(_conv(t, model.conv[0]), model.conv[1])          # noqa: E731
+        out = sym(out) + sym(out.flip([1, 2])).flip([2])
+    encodings = []
+    for lconv, conv in zip(model.uplblocks, model.upblocks):
+        out = _conv_block(_bn(_conv(out, lconv[0]), lconv[1]), conv[0])
+        encodings.append(out)
+    for enc, lconv, conv in zip(reversed(encodings[:-1]), model.downlblocks, model.downblocks):
+        up = int(lconv[0].scale_factor)
+        out = enc + _conv_block(_bn(_conv(out, lconv[1], up), lconv[2]), conv[0])
+    oc = model.out_conv
+    out = Act.apply(_bn(_conv(out, oc[0]), oc[1]), ACT_RELU)
+    out = Act.apply(_conv(out, oc[3]), ACT_SOFTPLUS)
+    feat = T.MaxPool.apply(out, None, None, None)
+    fc = model.out_fc
+    f = T.Bn2d.apply(feat, fc[0].weight, fc[0].bias, fc[0], False)
+    f = T.dropout(f, float(fc[1].p), True)
+    res = Act.apply(T.Linear.apply(f, fc[2].weight, fc[2].bias), ACT_SOFTPLUS)
+    T.flush_bn_ticks()
+    return res

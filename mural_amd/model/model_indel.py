@@ -3,7 +3,8 @@
 Mirror of the reference's MuRaL/model/model_indel.py: ``ConvBlock`` (:6-19) and ``UNet_Small`` (:21-176) with the same
 constructor signature and sub-module names, hence the same ``state_dict()`` keys (232 keys / 178,036 parameters for the
 human insertion model, 225 / 177,912 without the strand-symmetrising ``conv``), so shipped checkpoints load strictly.
-The torch sub-modules are parameter containers; ``forward`` (eval mode) runs the HIP layer program.  No CPU path.
+The torch sub-modules are parameter containers; ``forward`` runs the fused HIP layer program in eval mode and the
+differentiable per-layer HIP ops of ``indel_train.py`` in training mode.  No CPU path.
 """
 import ctypes as C
 
@@ -108,14 +109,16 @@ class UNet_Small(nn.Module):
 
     def forward(self, distal_input):
         """Forward propagation of a batch: (B, 4, 2*distal_radius) fp32 one-hot -> (B, n_class) Softplus scores."""
-        if self.training:
-            raise NotImplementedError("mural_amd: UNet_Small training mode is not built yet; call model.eval()")
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("mural_amd models run on a HIP device only: call model.to('cuda') first")
         x = _lib.require_cuda(distal_input, "distal_input").to(torch.float32).contiguous()
         if x.dim() != 3 or x.shape[1] != 4:
             raise ValueError(f"distal_input must be (B, 4, L), got {tuple(x.shape)}")
+        if self.training:       # batch-statistics BatchNorm + dropout, differentiable (model/indel_train.py)
+            from .indel_train import unet_forward_train
+            with torch.cuda.device(dev):
+                return unet_forward_train(self, x)
         n, length = x.shape[0], x.shape[2]
         with torch.cuda.device(dev):
             handle = self._get_handle(length)

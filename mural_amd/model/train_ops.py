@@ -86,7 +86,11 @@ def flush_bn_ticks():
     flush_input_checks()
     if _bn_touched:
         with torch.no_grad():
-            torch._foreach_add_(_bn_touched, 1)
+            if len({id(t) for t in _bn_touched}) == len(_bn_touched):
+                torch._foreach_add_(_bn_touched, 1)
+            else:                         # a BatchNorm applied more than once per forward (UNet_Small's strand-symmetry conv)
+                for t in _bn_touched:
+                    t.add_(1)
         _bn_touched.clear()
 
 
@@ -230,7 +234,7 @@ class MaxPool(torch.autograd.Function):
         B, Cn, L = x.shape
         glob = k is None
         if glob:
-            k, s, p = L, 1, 0
+            k, s, p = L, L, 0          # one window per row: the backward is a gather (no zero fill, no atomics)
         Lout = (L + 2 * p - k) // s + 1
         y = torch.empty((B, Cn, Lout), device=x.device)
         arg = torch.empty((B, Cn, Lout), dtype=torch.int32, device=x.device)

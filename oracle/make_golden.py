@@ -469,6 +469,33 @@ def g12_dirichlet(ref):
         sys.modules.update({k: v for k, v in saved.items() if v is not None})
 
 
+def g14_indel_train(ref):
+    """One training step of the reference's UNet_Small (model.train(): batch-statistics BatchNorm; the hard-coded
+    Dropout(0.1) of out_fc set to p = 0 so the step is deterministic): scores, CE(sum) loss, every parameter gradient, BatchNorm
+    running statistics after the step."""
+    rng = np.random.default_rng(1414)
+    for tag, R, n_class, rev, seed, B in [("rev", 1000, 8, True, 51, 6), ("norev", 1000, 3, False, 52, 5)]:
+        cfg = dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=[1, 4, 5, 5, 5, 2], use_reverse=rev)
+        model = quiet(ref.nn_utils.model_choice, 0, cfg, dict(n_class=n_class), "indel")
+        sd = synth.synth_state_dict(model.state_dict(), seed)
+        model.load_state_dict(sd)
+        model.train()
+        model.out_fc[1].p = 0.0
+        codes = rng.integers(0, 4, size=(B, 2 * R)).astype(np.uint8)
+        codes[1, 10:60] = 4
+        y = rng.integers(0, n_class, size=B).astype(np.int64)
+        preds = model(codes_to_onehot(codes))
+        loss = nn.CrossEntropyLoss(reduction="sum")(preds, torch.from_numpy(y))
+        model.zero_grad()
+        loss.backward()
+        gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9)
+        arrays = {"g::" + k: p.grad.numpy() for k, p in model.named_parameters()}
+        arrays.update({"b::" + k: b.numpy() for k, b in model.named_buffers()})
+        save(f"indel_train_{tag}.npz", codes=codes, y=y, seed=np.array(seed), loss=np.array(loss.item()),
+             preds=preds.detach().numpy(), gnorm=np.array(float(gnorm)), hp=np.array([R, 8, 7, n_class, int(rev)], np.int64),
+             down=np.array([1, 4, 5, 5, 5, 2], np.int64), **arrays)
+
+
 def analytics_inputs(seed, n, n_class, radius, model_type, dtype=np.float32):
     """Synthetic validation set: order-1 local codes, labels whose rate depends on the flanking bases, probabilities that
     follow that rate with noise, three chromosomes of sorted starts."""
@@ -613,7 +640,7 @@ def main():
     ref = ref_import.load()
     only = set(sys.argv[1:])
     steps = dict(g1=g1_encode, g2=g2_windowing, g3=g3_pretrained, g45=g45_synth, g6=g6_taps, g7=g7_train,
-                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet, g13=g13_analytics)
+                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet, g13=g13_analytics, g14=g14_indel_train)
     for name, fn in steps.items():
         if only and name not in only:
             continue

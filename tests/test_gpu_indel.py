@@ -10,7 +10,8 @@ import torch
 from tests import _util as U
 
 pytestmark = pytest.mark.gpu
-INDEL_FORWARD = sorted(os.path.basename(p) for p in glob.glob(os.path.join(U.GOLDEN, "indel_*.npz")))
+INDEL_FORWARD = sorted(os.path.basename(p) for p in glob.glob(os.path.join(U.GOLDEN, "indel_*.npz"))
+                       if not os.path.basename(p).startswith("indel_train_"))
 
 
 def product_from(fx):
@@ -69,3 +70,98 @@ def test_incompatible_length_is_rejected():
     model = product_from(fx).cuda().eval()
     with pytest.raises(ValueError):
         model(torch.zeros(2, 4, 800, device="cuda"))
+
+
+# ------------------------------------------------------------------------------------------------ training mode
+def _train_step(model, x, y):
+    preds = model(x)
+    loss = torch.nn.CrossEntropyLoss(reduction="sum")(preds, y)
+    model.zero_grad()
+    loss.backward()
+    return preds, loss
+
+
+@pytest.mark.parametrize("tag", ["rev", "norev"])
+def test_train_step_matches_reference(tag):
+    """One training step (batch-statistics BatchNorm, CE(sum) loss, backward) against the reference's own step (G14):
+    scores 1e-5, loss 1e-5 relative, every gradient 1e-4 of (its tensor's max + 1e-2), running statistics 1e-5."""
+    fx = U.load(f"indel_train_{tag}.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc), strict=True)
+    model = model.cuda().train()
+    model.out_fc[1].p = 0.0
+    preds, loss = _train_step(model, U.onehot(fx["codes"]).cuda(), torch.from_numpy(fx["y"]).cuda())
+    assert np.abs(preds.detach().cpu().numpy() - fx["preds"]).max() <= 1e-5
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    grads = {k: p.grad.cpu().numpy() for k, p in model.named_parameters()}
+    for k, got in grads.items():
+        want = fx["g::" + k]
+        diff = np.abs(got - want).max()
+        tol = 1e-4 * (np.abs(want).max() + 1e-2)
+        if k.endswith(".bias") and k[:-4] + "weight" in grads and want.ndim == 1 and fx["g::" + k[:-4] + "weight"].ndim == 3:
+            # a conv bias gradient is the plain sum of the dy whose products with x form dW; in front of a batch-statistics
+            # BatchNorm it is mathematically zero, and behind the 5-row BatchNorm of out_fc it cancels to ~1e-3 of dW: its
+            # fp32 error follows the scale of dW (the reference's own fp32 value is 2e-5 away from a float64 evaluation)
+            tol = max(tol, 1e-5 * np.abs(fx["g::" + k[:-4] + "weight"]).max())
+        assert diff <= tol, (k, diff, tol)
+    for k, b in model.named_buffers():
+        assert np.abs(b.cpu().numpy().astype(np.float64) - fx["b::" + k]).max() <= 1e-5, k
+    gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9)
+    assert abs(float(gnorm) - float(fx["gnorm"])) <= 1e-4 * float(fx["gnorm"])
+
+
+def test_train_general_conv_against_torch():
+    """The general Conv1d op (stride, padding, upsampled input) and its backward against torch's conv1d on the shapes of the
+    U-Net and a few odd ones (ragged lengths, tiny rows)."""
+    from mural_amd.model.indel_train import Conv
+    rng = torch.Generator().manual_seed(5)
+    cases = [(3, 4, 8, 7, 1, 3, 1, 500), (2, 8, 16, 7, 4, 3, 1, 501), (2, 32, 40, 7, 5, 3, 1, 77), (5, 40, 48, 7, 2, 3, 1, 4),
+             (2, 48, 40, 7, 1, 3, 2, 9), (2, 16, 8, 7, 1, 3, 4, 130), (3, 48, 96, 5, 1, 2, 1, 70), (3, 96, 48, 1, 1, 0, 1, 70),
+             (1, 4, 4, 7, 1, 3, 1, 2000)]
+    for B, Cin, Cout, K, stride, pad, up, L in cases:
+        x = torch.randn((B, Cin, L), generator=rng)
+        w = torch.randn((Cout, Cin, K), generator=rng) / (Cin * K) ** 0.5
+        b = torch.randn(Cout, generator=rng)
+        xr, wr, br = x.clone().requires_grad_(), w.clone().requires_grad_(), b.clone().requires_grad_()
+        xu = xr.repeat_interleave(up, dim=2) if up > 1 else xr
+        yr = torch.nn.functional.conv1d(xu, wr, br, stride=stride, padding=pad)
+        g = torch.randn(yr.shape, generator=rng)
+        yr.backward(g)
+        xd, wd, bd = x.cuda().requires_grad_(), w.cuda().requires_grad_(), b.cuda().requires_grad_()
+        yd = Conv.apply(xd, wd, bd, stride, pad, up)
+        yd.backward(g.cuda())
+        case = (B, Cin, Cout, K, stride, pad, up, L)
+        assert yd.shape == yr.shape, case
+        assert (yd.detach().cpu() - yr.detach()).abs().max() <= 2e-5 * max(1.0, float(yr.abs().max())), case
+        for got, want, name in ((xd.grad, xr.grad, "dx"), (wd.grad, wr.grad, "dW"), (bd.grad, br.grad, "db")):
+            assert (got.cpu() - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max())), (case, name)
+
+
+def test_train_mode_updates_and_eval_after_training():
+    """A few Adam steps in training mode lower the loss, BatchNorm counters advance like nn.BatchNorm1d (the strand-symmetry
+    BatchNorm twice per forward), and the eval-mode fused program picks up the updated weights."""
+    fx = U.load("indel_train_rev.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    sd = U.indel_state_for(fx, orc)
+    model.load_state_dict(sd, strict=True)
+    model = model.cuda().train()
+    model.out_fc[1].p = 0.0
+    x, y = U.onehot(fx["codes"]).cuda(), torch.from_numpy(fx["y"]).cuda()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    losses = []
+    for _ in range(5):
+        _, loss = _train_step(model, x, y)
+        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+        opt.step()
+        losses.append(loss.item())
+    assert losses[-1] < losses[0]
+    assert int(model.conv[1].num_batches_tracked) == 7 + 10 and int(model.out_fc[0].num_batches_tracked) == 7 + 5
+    model.eval()
+    orc.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+    orc.eval()
+    with torch.no_grad():
+        got = model(x).cpu().numpy()
+        want = orc(U.onehot(fx["codes"])).numpy()
+    assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())

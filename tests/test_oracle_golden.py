@@ -16,7 +16,8 @@ from tests import _util as U
 
 SNV_FORWARD = sorted(os.path.basename(p) for p in glob.glob(os.path.join(U.GOLDEN, "snv_synth_*.npz"))
                      + glob.glob(os.path.join(U.GOLDEN, "snv_pretrained_*.npz")))
-INDEL_FORWARD = sorted(os.path.basename(p) for p in glob.glob(os.path.join(U.GOLDEN, "indel_*.npz")))
+INDEL_FORWARD = sorted(os.path.basename(p) for p in glob.glob(os.path.join(U.GOLDEN, "indel_*.npz"))
+                       if not os.path.basename(p).startswith("indel_train_"))
 
 
 # ------------------------------------------------------------------ G1: encoders, bit exact
@@ -132,6 +133,26 @@ def test_snv_train_step(tag):
         if ".layer." in k or k.endswith("num_batches_tracked") or b.numel() == 0:
             continue
         assert np.abs(b.numpy() - fx["b::" + k]).max() <= 1e-5, k
+
+
+# ------------------------------------------------------------------ G14: one INDEL training step
+@pytest.mark.parametrize("tag", ["rev", "norev"])
+def test_indel_train_step(tag):
+    fx = U.load(f"indel_train_{tag}.npz")
+    model = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, model))
+    model.train()
+    model.out_fc[1].p = 0.0
+    preds = model(U.onehot(fx["codes"]))
+    loss = nn.CrossEntropyLoss(reduction="sum")(preds, torch.from_numpy(fx["y"]))
+    loss.backward()
+    assert np.abs(preds.detach().numpy() - fx["preds"]).max() <= 1e-5
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-5 * abs(float(fx["loss"]))
+    for k, p in model.named_parameters():
+        want = fx["g::" + k]
+        assert np.abs(p.grad.numpy() - want).max() <= 1e-4 * (np.abs(want).max() + 1e-2), k
+    for k, b in model.named_buffers():
+        assert np.abs(b.numpy().astype(np.float64) - fx["b::" + k]).max() <= 1e-5, k
 
 
 # ------------------------------------------------------------------ G8: INDEL forward
