@@ -161,8 +161,34 @@ def indel_positions_per_s(device, genome, n=4096):
             model.forward_packed(genome, pos, strand, 4000)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / 3
-    return {"positions_per_s": n / dt, "positions": n, "window": 8000, "n_class": 8, "algorithmic_TFLOPs": n / dt * 113.4e6 / 1e12,
-            "note": "weights_init, window decode from the packed genome inside the timed region; 113.4 MFLOP/position"}
+    out = {"positions_per_s": n / dt, "positions": n, "window": 8000, "n_class": 8, "algorithmic_TFLOPs": n / dt * 113.4e6 / 1e12,
+           "note": "weights_init, window decode from the packed genome inside the timed region; 113.4 MFLOP/position"}
+    # one training configuration of the same model: batch 128 (the reference's default), CE(sum) + clip + Adam
+    tb = 128
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss(reduction="sum")
+    x = genome.encode_onehot(pos[:tb], strand[:tb], 4000, "indel")
+    y = (idx[:tb] % 8)
+
+    def step():
+        loss = crit(model(x), y)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, error_if_nonfinite=False)
+        opt.step()
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+    out["train"] = {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "batch": tb, "positions_per_s": tb / dt,
+                    "note": "forward (batch-statistics BatchNorm, dropout) + backward + clip + Adam on pre-encoded windows"}
+    return out
 
 
 def main():
