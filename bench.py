@@ -106,9 +106,29 @@ def cpu_baseline(model_state, codes, budget_s=12.0, batch=256):
             t_used += timed(4 + it)
             done += batch
             it += 1
+    # the training step of the same restatement beside it: batch 128 (the reference's default), CE(sum) + clip + Adam
+    orc.train()
+    tb = 128
+    opt = torch.optim.Adam(orc.parameters(), lr=1e-3)
+    crit = torch.nn.CrossEntropyLoss(reduction="sum")
+    cat, x = batch_inputs(0)
+    cat, x, y = cat[:tb], x[:tb], torch.from_numpy(np.arange(tb) % N_CLASS)
+
+    def train_step():
+        t0 = time.perf_counter()
+        loss = crit(orc((cont[:tb], cat), x), y)
+        opt.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(orc.parameters(), max_norm=10)
+        opt.step()
+        return time.perf_counter() - t0
+
+    train_step()
+    t_train = min(train_step(), train_step())
     return {"value": done / max(t_used, 1e-9), "unit": "bases/s", "cores": best_threads, "kind": "port",
             "sample": f"{done} sites of the same workload, model only (inputs pre-encoded), batch {batch}, "
-                      f"{it} timed iterations after warm-up, best of 8/16/32/64 torch threads on {ncpu} host CPUs"}
+                      f"{it} timed iterations after warm-up, best of 8/16/32/64 torch threads on {ncpu} host CPUs",
+            "train_steps_per_s": 1.0 / t_train, "train_batch": tb, "train_sites_per_s": tb / t_train}
 
 
 def train_steps_per_s(device, genome, B=4096, steps=30, warmup=5):
