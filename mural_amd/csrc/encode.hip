@@ -70,48 +70,82 @@ __device__ __forceinline__ int frac_digit(float v) {
 }
 
 // dense (n,4,L) one-hot / IUPAC-fraction tensor -> 1 symbol per column (what the fused kernel consumes)
-__global__ void dense_to_symbols_kernel(const float* __restrict__ x, int64_t n, int L, uint8_t* __restrict__ sym,
-                                        int32_t* __restrict__ status) {
+__device__ __forceinline__ int dense_symbol(float v0, float v1, float v2, float v3) {
+  const int d0 = frac_digit(v0), d1 = frac_digit(v1), d2 = frac_digit(v2), d3 = frac_digit(v3);
+  int s = -1;
+  if ((d0 | d1 | d2 | d3) >= 0) {
+    switch (d0 + 5 * d1 + 25 * d2 + 125 * d3) {
+      case 1: s = 0; break;      // A
+      case 5: s = 1; break;      // C
+      case 25: s = 2; break;     // G
+      case 125: s = 3; break;    // T
+      case 468: s = 4; break;    // N
+      case 52: s = 5; break;     // R
+      case 260: s = 6; break;    // Y
+      case 12: s = 7; break;     // M
+      case 60: s = 8; break;     // S
+      case 252: s = 9; break;    // W
+      case 300: s = 10; break;   // K
+      case 620: s = 11; break;   // B
+      case 604: s = 12; break;   // D
+      case 524: s = 13; break;   // H
+      case 124: s = 14; break;   // V
+      default: break;
+    }
+  }
+  return s;
+}
+
+// A thread converts 4 consecutive symbols of the flattened (row, column) index: 16 independent channel loads in flight and one
+// aligned 4-byte store (the symbol buffer is linear in that index, so a group may straddle two rows).  HBM-bound: 16 B in,
+// 1 B out per column.
+__global__ __launch_bounds__(256) void dense_to_symbols_kernel(const float* __restrict__ x, int64_t n, int L,
+                                                               uint8_t* __restrict__ sym, int32_t* __restrict__ status) {
   const int64_t total = n * L;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t row = i / L;
-    const int j = (int)(i - row * L);
-    const float* p = x + row * 4 * (int64_t)L + j;
-    const int d0 = frac_digit(p[0]), d1 = frac_digit(p[L]), d2 = frac_digit(p[2 * (int64_t)L]), d3 = frac_digit(p[3 * (int64_t)L]);
-    int s = -1;
-    if ((d0 | d1 | d2 | d3) >= 0) {
-      switch (d0 + 5 * d1 + 25 * d2 + 125 * d3) {
-        case 1: s = 0; break;      // A
-        case 5: s = 1; break;      // C
-        case 25: s = 2; break;     // G
-        case 125: s = 3; break;    // T
-        case 468: s = 4; break;    // N
-        case 52: s = 5; break;     // R
-        case 260: s = 6; break;    // Y
-        case 12: s = 7; break;     // M
-        case 60: s = 8; break;     // S
-        case 252: s = 9; break;    // W
-        case 300: s = 10; break;   // K
-        case 620: s = 11; break;   // B
-        case 604: s = 12; break;   // D
-        case 524: s = 13; break;   // H
-        case 124: s = 14; break;   // V
-        default: break;
+  const int64_t groups = (total + 3) >> 2;
+  for (int64_t gidx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i0 = gidx << 2;
+    int64_t row = i0 / L;
+    int j = (int)(i0 - row * L);
+    float v[4][4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const bool live = i0 + e < total;
+      const float* p = x + row * 4 * (int64_t)L + j;
+#pragma unroll
+      for (int ch = 0; ch < 4; ++ch) v[e][ch] = live ? p[(int64_t)ch * L] : 0.f;
+      if (++j == L) {
+        j = 0;
+        ++row;
       }
     }
-    if (s < 0) {
-      s = SYM_N;
-      if (status) atomicOr(status, (int)MURAL_E_ENCODING);
+    uint32_t packed = 0;
+    bool bad = false;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int s = dense_symbol(v[e][0], v[e][1], v[e][2], v[e][3]);
+      if (s < 0) {
+        s = SYM_N;
+        bad |= i0 + e < total;
+      }
+      packed |= (uint32_t)s << (8 * e);
     }
-    sym[i] = (uint8_t)s;
+    if (bad && status) atomicOr(status, (int)MURAL_E_ENCODING);
+    if (i0 + 3 < total) {
+      *reinterpret_cast<uint32_t*>(sym + i0) = packed;
+    } else {
+      for (int e = 0; i0 + e < total; ++e) sym[i0 + e] = (uint8_t)(packed >> (8 * e));
+    }
   }
 }
 
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream) {
   const int64_t total = n * L;
   if (total == 0) return MURAL_OK;
+  MURAL_REQUIRE((reinterpret_cast<uintptr_t>(sym) & 3u) == 0, "dense_to_symbols: the symbol buffer must be 4-byte aligned");
   const int block = 256;
-  const int grid = (int)((total + block - 1) / block < 8192 ? (total + block - 1) / block : 8192);
+  const int64_t groups = (total + 3) / 4;
+  const int grid = (int)((groups + block - 1) / block < 16384 ? (groups + block - 1) / block : 16384);
   hipLaunchKernelGGL(dense_to_symbols_kernel, dim3(grid), dim3(block), 0, stream, x, n, L, sym, status);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
