@@ -1,0 +1,121 @@
+"""Eval-mode forward of the SNV networks for shapes the fused tower kernel is not built for (``CNN_out_channels`` != 32,
+``CNN_kernel_size`` != 3, very long windows): the same layer sequence as MuRaL/model/model_snv.py:449-523 (Network2;
+:226-287 Network1), one HIP launch per layer (``mural_op_bn_apply`` with the running statistics as a per-channel affine,
+``mural_op_convg_fwd``, ``mural_op_maxpool_fwd``, ``mural_op_linear_fwd``, ``mural_op_embedding_fwd``, ``mural_op_head_fwd``).
+It exists for completeness of the drop-in (any ``model_choice`` configuration evaluates); every shipped checkpoint and the
+benchmark configuration take the fused path in ``model_snv.py``.  No CPU path here either.
+"""
+import torch
+
+from . import train_ops as T
+
+
+def _affine(bn):
+    """eval-mode BatchNorm as y = scale * x + shift"""
+    scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).to(torch.float32).contiguous()
+    shift = (bn.bias.detach() - bn.running_mean * scale).to(torch.float32).contiguous()
+    return scale, shift
+
+
+def _bn(x, bn, relu):
+    """BN(relu(x)) if relu else BN(x); x is (B, C, L) or (B, C)"""
+    x = x.contiguous()
+    B, Cn = x.shape[0], x.shape[1]
+    L = x.shape[2] if x.dim() == 3 else 1
+    scale, shift = _affine(bn)
+    y = torch.empty_like(x)
+    T._call("mural_op_bn_apply", x, B, Cn, L, int(relu), scale, shift, y, T._stream(x))
+    return y
+
+
+def _conv(x, conv):
+    x = x.contiguous()
+    B, Cin, L = x.shape
+    w = T._f32(conv.weight.detach())
+    Cout, _, K = w.shape
+    pad = int(conv.padding[0])
+    Lout = L + 2 * pad - K + 1
+    if Lout < 1:
+        raise ValueError(f"Conv1d: kernel {K} does not fit an input of length {L}")
+    y = torch.empty((B, Cout, Lout), device=x.device)
+    wt = torch.empty(w.numel(), device=x.device)
+    T._call("mural_op_convg_fwd", x, w, None if conv.bias is None else T._f32(conv.bias.detach()), wt, y, B, Cin, L, Cout, K, 1, pad, 1,
+            T._stream(x))
+    return y
+
+
+def _relu(x):
+    y = torch.empty_like(x)
+    T._call("mural_op_act_fwd", x, x.numel(), 1, y, T._stream(x))
+    return y
+
+
+def _pool(x, k, s, p):
+    x = x.contiguous()
+    B, Cn, L = x.shape
+    Lout = (L + 2 * p - k) // s + 1
+    y = torch.empty((B, Cn, Lout), device=x.device)
+    arg = torch.empty((B, Cn, Lout), dtype=torch.int32, device=x.device)
+    T._call("mural_op_maxpool_fwd", x, B * Cn, L, k, s, p, y, arg, T._stream(x))
+    return y
+
+
+def _linear(x, lin):
+    x = x.contiguous()
+    y = torch.empty((x.shape[0], lin.out_features), device=x.device)
+    T._call("mural_op_linear_fwd", x, T._f32(lin.weight.detach()), T._f32(lin.bias.detach()), x.shape[0], lin.in_features,
+            lin.out_features, y, T._stream(x))
+    return y
+
+
+def _res_blocks(rbs, x):
+    out = x
+    for rb in rbs:                       # ResBlock (model_snv.py:794-812): x + conv2(bn2(relu(conv1(bn1(relu(x))))))
+        h = _conv(_bn(out, rb.bn1, True), rb.conv1)
+        h = _conv(_bn(h, rb.bn2, True), rb.conv2)
+        out = out + h
+    return out + x                       # the outer skip (model_snv.py:477-479)
+
+
+def tower(mod, sfx, x, pools):
+    g = lambda n: getattr(mod, n + sfx)  # noqa: E731
+    out = _pool(_conv(_bn(x, g("conv1")[0], False), g("conv1")[1]), *pools[0])
+    out = _pool(_res_blocks(g("RBs1"), out), *pools[1])
+    out = _conv(_bn(out, g("conv2")[0], False), g("conv2")[1])
+    out = _pool(_res_blocks(g("RBs2"), out), *pools[2])
+    assert out.shape[2] >= 1, "Error: distal seq is too short for the pooling layers"
+    out = _relu(_conv(_bn(out, g("conv3")[0], False), g("conv3")[1]))
+    feat = _pool(out, out.shape[2], out.shape[2], 0).reshape(out.shape[0], out.shape[1])
+    fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
+    return _linear(_bn(feat, fc[0], False), fc[2])
+
+
+def local(mod, cat, out_layer):
+    cat = cat.contiguous()
+    table = T._f32(mod.emb_layer.weight.detach())
+    h = torch.empty((cat.shape[0], cat.shape[1] * table.shape[1]), device=table.device)
+    if table.shape[1] != 5:
+        raise ValueError("the embedding kernel is built for 5-dimensional k-mer embeddings")
+    T._call("mural_op_embedding_fwd", cat, table, cat.shape[0], cat.shape[1], table.shape[0], h, T._stream(table))
+    for lin, bn in zip(mod.lin_layers, mod.bn_layers):
+        h = _bn(_linear(h, lin), bn, True)          # Linear -> ReLU -> BN (model_snv.py:466-467)
+    return _linear(h, out_layer)
+
+
+def head(loc, mid, lar):
+    B, nc = mid.shape
+    out = torch.empty((B, nc), device=mid.device)
+    T._call("mural_op_head_fwd", None if loc is None else loc.contiguous(), mid.contiguous(), lar.contiguous(), B, nc, out,
+            T._stream(mid))
+    return out
+
+
+def forward(mod, cat_x, distal_x, pools_mid, pools_large):
+    """log-probabilities of Network1 (cat_x None) / Network2 from the reference's dense inputs"""
+    with torch.no_grad():
+        L = distal_x.shape[2]
+        x = distal_x.to(torch.float32)
+        mid = tower(mod, "", x[:, :, L // 2 - 100:L // 2 + 101].contiguous(), pools_mid)
+        lar = tower(mod, "_2", x.contiguous(), pools_large)
+        loc = None if cat_x is None else local(mod, cat_x, mod.local_fc[0])
+        return head(loc, mid, lar)

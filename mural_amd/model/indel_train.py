@@ -62,16 +62,18 @@ class Conv(torch.autograd.Function):
 
 
 class BatchNorm(torch.autograd.Function):
-    """y = BatchNorm1d(x) on (B, C, L) with batch statistics (running statistics updated in place)."""
+    """y = BatchNorm1d(act(x)) on (B, C, L) with batch statistics (running statistics updated in place); act = ReLU with
+    ``pre_relu`` (the SNV towers' ReLU -> BN order), identity otherwise."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, bn):
+    def forward(ctx, x, gamma, beta, bn, pre_relu=False):
         x = x.contiguous()
         B, Cn, L = x.shape
-        state = T._BnState(x, False, bn, L)
+        state = T._BnState(x, bool(pre_relu), bn, L)
         y = torch.empty_like(x)
-        T._call("mural_op_bn_apply", x, B, Cn, L, 0, state.scale, state.shift, y, T._stream(x))
+        T._call("mural_op_bn_apply", x, B, Cn, L, int(pre_relu), state.scale, state.shift, y, T._stream(x))
         ctx.save_for_backward(x, gamma, state.mean, state.invstd)
+        ctx.pre_relu = bool(pre_relu)
         return y
 
     @staticmethod
@@ -82,9 +84,9 @@ class BatchNorm(torch.autograd.Function):
         dx = torch.empty_like(x)
         dgamma = torch.empty(Cn, device=x.device)
         dbeta = torch.empty(Cn, device=x.device)
-        T._call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, L, 0, mean, invstd, T._f32(gamma), acc, 0, None, None, dx, dgamma,
-                dbeta, T._stream(x))
-        return dx, dgamma, dbeta, None
+        T._call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, L, int(ctx.pre_relu), mean, invstd, T._f32(gamma), acc, 0, None,
+                None, dx, dgamma, dbeta, T._stream(x))
+        return dx, dgamma, dbeta, None, None
 
 
 class Act(torch.autograd.Function):
@@ -112,7 +114,7 @@ def _conv(x, conv, up=1):
 
 
 def _bn(x, bn):
-    return BatchNorm.apply(x, bn.weight, bn.bias, bn)
+    return BatchNorm.apply(x, bn.weight, bn.bias, bn, False)
 
 
 def _conv_block(x, cb):
@@ -146,3 +148,34 @@ def unet_forward_train(model, x):
     res = Act.apply(T.Linear.apply(f, fc[2].weight, fc[2].bias), ACT_SOFTPLUS)
     T.flush_bn_ticks()
     return res
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SNV towers of any width / kernel size (the MFMA training kernels of train_ops.py serve the shipped 32-channel, k=3 shape)
+# ------------------------------------------------------------------------------------------------------------------
+def snv_tower_forward_train(mod, sfx, x, pools, dropout_p):
+    """One conv tower of Network1/2 (model_snv.py:473-493 / :496-513) in training mode from the dense (B, 4, L) window, on the
+    general per-layer ops.  Same layer order as ``train_ops.tower_forward``."""
+    g = lambda n: getattr(mod, n + sfx)          # noqa: E731
+
+    def bnconv(t, seq, pre_relu=False):
+        return _conv(BatchNorm.apply(t, seq[0].weight, seq[0].bias, seq[0], pre_relu), seq[1])
+
+    def res_blocks(rbs, t):
+        out = t
+        for rb in rbs:
+            h = _conv(BatchNorm.apply(out, rb.bn1.weight, rb.bn1.bias, rb.bn1, True), rb.conv1)
+            h = _conv(BatchNorm.apply(h, rb.bn2.weight, rb.bn2.bias, rb.bn2, True), rb.conv2)
+            out = out + h
+        return out + t
+
+    out = T.MaxPool.apply(bnconv(x.contiguous(), g("conv1")), *pools[0])
+    out = T.MaxPool.apply(res_blocks(g("RBs1"), out), *pools[1])
+    out = bnconv(out, g("conv2"))
+    out = T.MaxPool.apply(res_blocks(g("RBs2"), out), *pools[2])
+    out = Act.apply(bnconv(out, g("conv3")), ACT_RELU)
+    feat = T.MaxPool.apply(out, None, None, None)
+    fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
+    f = T.Bn2d.apply(feat, fc[0].weight, fc[0].bias, fc[0], False)
+    f = T.dropout(f, dropout_p, True)
+    return T.Linear.apply(f, fc[2].weight, fc[2].bias)

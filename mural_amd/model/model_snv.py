@@ -125,6 +125,7 @@ class _HipSnvBase(nn.Module):
         self._handle_key = None
         self._ws = None
         self._status = None
+        self._fused = None          # None: not probed yet; False: this shape takes the per-layer path (generic_eval.py)
 
     # -- description of this model for the C side ------------------------------------------------------------
     def _shape_and_params(self):
@@ -146,6 +147,17 @@ class _HipSnvBase(nn.Module):
             del keep
             self._handle, self._handle_key = h, key
         return self._handle
+
+    def _fused_ok(self):
+        """False when the fused kernels are not built for this shape (CNN_out_channels != 32, CNN_kernel_size != 3, a window
+        too long for LDS): the C side refuses the model and eval takes one HIP launch per layer instead."""
+        if self._fused is None:
+            try:
+                self._get_handle()
+                self._fused = True
+            except ValueError:
+                self._fused = False
+        return self._fused
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
@@ -197,6 +209,10 @@ class _HipSnvBase(nn.Module):
             distal_x = _lib.require_cuda(distal_x, "distal_x").to(torch.float32).contiguous()
             n = distal_x.shape[0]
             dist_ptr = distal_x.data_ptr()
+        if self.model_no != 0 and taps is None and not self._fused_ok():
+            from . import generic_eval
+            with torch.cuda.device(dev):
+                return generic_eval.forward(self, cat_x, distal_x, POOLS_MID, POOLS_LARGE)
         with torch.cuda.device(dev):
             handle = self._get_handle()
             out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
@@ -226,6 +242,12 @@ class _HipSnvBase(nn.Module):
         n = pos.shape[0]
         if local_radius is None:
             local_radius = (getattr(self, "no_of_cat", 1) + local_order - 2) // 2
+        if self.model_no != 0 and not self._fused_ok():
+            from . import generic_eval
+            with torch.cuda.device(dev):
+                x = genome.encode_onehot(pos, strand, (self.seq_len - 1) // 2)
+                cat = genome.encode_kmer(pos, strand, int(local_radius), int(local_order)) if self.model_no == 2 else None
+                return generic_eval.forward(self, cat, x, POOLS_MID, POOLS_LARGE)
         with torch.cuda.device(dev):
             handle = self._get_handle()
             out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
@@ -244,6 +266,23 @@ class _HipSnvBase(nn.Module):
 
 def _shape(model_no, n_class, local_cols=0, emb_rows=0, h1=0, h2=0, channels=32, ksize=3, distal_len=0):
     return _lib.MuralSnvShape(model_no, n_class, local_cols, emb_rows, h1, h2, channels, ksize, distal_len, 1e-5)
+
+
+def _train_towers(mod, distal_x):
+    """(mid, large) tower logits in training mode: the MFMA / table kernels for the shipped 32-channel k=3 shape, the general
+    per-layer ops (indel_train.py) for any other CNN_out_channels / CNN_kernel_size."""
+    from . import train_ops as T
+    if mod.out_channels == 32 and mod.kernel_size == 3:
+        sym = T.dense_to_symbols(distal_x)
+        mid = T.tower_forward(mod, "", sym, mod.seq_len // 2 - 100, 201, POOLS_MID, mod.distal_fc1[1].p)
+        large = T.tower_forward(mod, "_2", sym, 0, mod.seq_len, POOLS_LARGE, mod.distal_fc2[1].p)
+        return mid, large
+    from .indel_train import snv_tower_forward_train
+    x = distal_x.to(torch.float32)
+    L = x.shape[2]
+    mid = snv_tower_forward_train(mod, "", x[:, :, L // 2 - 100:L // 2 + 101], POOLS_MID, mod.distal_fc1[1].p)
+    large = snv_tower_forward_train(mod, "_2", x, POOLS_LARGE, mod.distal_fc2[1].p)
+    return mid, large
 
 
 class FeedForwardNN(_HipSnvBase):
@@ -322,9 +361,7 @@ class Network1(_HipSnvBase):
             from . import train_ops as T
             _, distal_input = self._train_inputs(None, distal_input)
             with torch.cuda.device(self._device()):
-                sym = T.dense_to_symbols(distal_input[:, 0:self.in_channels, :])
-                mid = T.tower_forward(self, "", sym, self.seq_len // 2 - 100, 201, POOLS_MID, self.distal_fc1[1].p)
-                large = T.tower_forward(self, "_2", sym, 0, self.seq_len, POOLS_LARGE, self.distal_fc2[1].p)
+                mid, large = _train_towers(self, distal_input[:, 0:self.in_channels, :])
                 T.flush_bn_ticks()
                 return T.Head.apply(None, mid, large)
         return self._forward_dense(None, distal_input[:, 0:self.in_channels, :])
@@ -364,11 +401,9 @@ class Network2(_HipSnvBase):
             from . import train_ops as T
             cat_data, distal_input = self._train_inputs(cat_data, distal_input)
             with torch.cuda.device(self._device()):
-                sym = T.dense_to_symbols(distal_input[:, 0:self.in_channels, :])
                 loc = T.local_forward(self, cat_data, self.local_fc[0], self.emb_dropout_layer.p,
                                       [d.p for d in self.droput_layers])
-                mid = T.tower_forward(self, "", sym, self.seq_len // 2 - 100, 201, POOLS_MID, self.distal_fc1[1].p)
-                large = T.tower_forward(self, "_2", sym, 0, self.seq_len, POOLS_LARGE, self.distal_fc2[1].p)
+                mid, large = _train_towers(self, distal_input[:, 0:self.in_channels, :])
                 T.flush_bn_ticks()
                 return T.Head.apply(loc, mid, large)
         return self._forward_dense(cat_data, distal_input[:, 0:self.in_channels, :], taps=_taps)

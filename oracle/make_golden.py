@@ -496,6 +496,23 @@ def g14_indel_train(ref):
              down=np.array([1, 4, 5, 5, 5, 2], np.int64), **arrays)
 
 
+def g15_generic_shapes(ref):
+    """Network1/2 with CNN_out_channels / CNN_kernel_size other than the shipped 32 / 3 (options of the reference's CLI,
+    commands/train.py:90-99), incl. an even kernel size (conv1/2/3 then shorten their rows by one column)."""
+    rng = np.random.default_rng(1515)
+    # (tag, model_no, r, R, n_class, B, seed, C, k)
+    cases = [("generic_c16k5_net2", 2, 5, 300, 4, 16, 18, 16, 5), ("generic_c64k3_net1", 1, 5, 300, 4, 16, 19, 64, 3),
+             ("generic_c24k4_net2", 2, 4, 300, 3, 16, 20, 24, 4)]
+    for tag, model_no, r, R, n_class, B, seed, C, k in cases:
+        cfg, common = snv_cfg(r, R, n_class=n_class, C=C, k=k)
+        model = quiet(ref.nn_utils.model_choice, model_no, cfg, common, "snv")
+        sd = synth.synth_state_dict(model.state_dict(), seed)
+        codes, cat = snv_inputs(rng, B, r, R)
+        _, out = run_ref_snv(ref, model_no, cfg, common, sd, codes, cat)
+        save(f"snv_synth_{tag}.npz", codes=codes, cat=cat, out=out, seed=np.array(seed),
+             hp=np.array([r, 3, R, 150, 75, C, k, n_class, model_no], np.int64))
+
+
 def analytics_inputs(seed, n, n_class, radius, model_type, dtype=np.float32):
     """Synthetic validation set: order-1 local codes, labels whose rate depends on the flanking bases, probabilities that
     follow that rate with noise, three chromosomes of sorted starts."""
@@ -640,7 +657,7 @@ def main():
     ref = ref_import.load()
     only = set(sys.argv[1:])
     steps = dict(g1=g1_encode, g2=g2_windowing, g3=g3_pretrained, g45=g45_synth, g6=g6_taps, g7=g7_train,
-                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet, g13=g13_analytics, g14=g14_indel_train)
+                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet, g13=g13_analytics, g14=g14_indel_train, g15=g15_generic_shapes)
     for name, fn in steps.items():
         if only and name not in only:
             continue

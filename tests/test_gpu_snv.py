@@ -233,3 +233,33 @@ def test_predict_bed_from_fasta_matches_oracle(tmp_path):
     bed2.write_text("".join(f"{c}\t{p}\t{p + 1}\t.\t0\t{st}\n" for c, p, st in rows2))
     with pytest.raises(ValueError, match="different bases"):
         ingest.predict_bed(model, fa, bed2, local_radius=r, local_order=3, segment_center=500)
+
+
+def test_packed_path_other_channel_and_kernel_sizes():
+    """Shapes outside the fused kernels (16 channels, k=5) take the per-layer path; packed-genome input equals dense input."""
+    from mural_amd.data import PackedGenome
+    from mural_amd.data.genome import pack_sequence
+    fx = U.load("snv_synth_generic_c16k5_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    sd = U.snv_state_for(fx, orc)
+    model.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    orc.eval()
+    model = model.cuda().eval()
+    assert model._fused_ok() is False
+    rng = np.random.default_rng(77)
+    seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=5000, p=[.245, .245, .245, .245, .02]).tobytes().decode()
+    packed, mask, n, amb = pack_sequence(seq)
+    genome = PackedGenome(packed, mask, n, "cuda", amb)
+    pos = torch.from_numpy(rng.integers(0, n, size=40)).cuda()
+    strand = torch.from_numpy(rng.integers(0, 2, size=40).astype(np.uint8)).cuda()
+    r, R = int(fx["hp"][0]), int(fx["hp"][2])
+    with torch.no_grad():
+        got = model.forward_packed(genome, pos, strand, local_radius=r, local_order=3)
+        x = genome.encode_onehot(pos, strand, R)
+        cat = genome.encode_kmer(pos, strand, r, 3)
+        want = model((torch.zeros(40, 1, dtype=torch.float64, device="cuda"), cat), x)
+        ref = orc((torch.zeros(40, 1, dtype=torch.float64), cat.cpu()), x.cpu())
+    assert torch.equal(got, want)
+    assert_probs_close(got.cpu().numpy(), ref.numpy(), 2, "generic packed")

@@ -190,3 +190,43 @@ def test_conv32_kernels_match_torch_fp64():
     out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "worst" in out.stdout
+
+
+@pytest.mark.parametrize("name", ["snv_synth_generic_c16k5_net2.npz", "snv_synth_generic_c24k4_net2.npz", "snv_synth_generic_c64k3_net1.npz"])
+def test_train_step_other_channel_and_kernel_sizes(name):
+    """CNN_out_channels / CNN_kernel_size other than 32 / 3 train on the general per-layer ops: one step (dropouts 0) against
+    the oracle's autograd on the same weights and inputs (the oracle reproduces the reference's forward for these shapes,
+    tests/test_oracle_golden.py)."""
+    from tests.test_gpu_snv import product_from_hp
+    fx = U.load(name)
+    model, model_no = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    sd = U.snv_state_for(fx, orc)
+    model.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    model = model.cuda().train()
+    orc.train()
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    cat, x = torch.from_numpy(fx["cat"]), U.onehot(fx["codes"])
+    y = torch.from_numpy(np.arange(len(cat)) % int(fx["hp"][7]))
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    want = orc((torch.zeros(len(cat), 1, dtype=torch.float64), cat), x)
+    crit(want, y).backward()
+    got = model((torch.zeros(len(cat), 1, dtype=torch.float64).cuda(), cat.cuda()), x.cuda())
+    loss = crit(got, y.cuda())
+    loss.backward()
+    assert np.abs(got.detach().cpu().numpy() - want.detach().numpy()).max() <= 2e-4
+    ref_grads = dict(orc.named_parameters())
+    for k, p in model.named_parameters():
+        if ".layer." in k or p.numel() == 0 or ref_grads[k].grad is None:
+            continue
+        w = ref_grads[k].grad.numpy()
+        err = float(np.abs(p.grad.cpu().numpy() - w).max()) / (float(np.abs(w).max()) + 1e-2)
+        assert err <= 2e-4, (k, err)
+    ref_buf = dict(orc.named_buffers())
+    for k, b in model.named_buffers():
+        if ".layer." in k or k.endswith("num_batches_tracked") or b.numel() == 0:
+            continue
+        assert np.abs(b.cpu().numpy() - ref_buf[k].numpy()).max() <= 2e-5, k
