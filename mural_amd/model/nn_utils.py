@@ -91,3 +91,45 @@ def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, 
             loss_acc += criterion(preds, y.long().squeeze(1)).double()
     pred_y = torch.cat(outs, dim=0) if outs else torch.empty(0, n_class, device=device)
     return pred_y, float(loss_acc.item())
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# model directories written by the reference's training run (`model`, `model.config.pkl`, `model.fdiri_cal.pkl`)
+# ------------------------------------------------------------------------------------------------------------------
+class _ConfigUnpickler(__import__("pickle").Unpickler):
+    """``model.config.pkl`` is a plain dict of Python / numpy scalars, lists and tuples: anything else is refused."""
+
+    _OK = {("numpy", "dtype"), ("numpy.core.multiarray", "scalar"), ("numpy._core.multiarray", "scalar"),
+           ("numpy.core.multiarray", "_reconstruct"), ("numpy._core.multiarray", "_reconstruct"), ("numpy", "ndarray"),
+           ("collections", "OrderedDict")}
+
+    def find_class(self, module, name):
+        if (module, name) in self._OK:
+            return super().find_class(module, name)
+        import pickle
+        raise pickle.UnpicklingError(f"model config references {module}.{name}: refused")
+
+
+def load_model_config(config_path):
+    """The hyper-parameter dict the reference pickles next to every checkpoint (scripts/run_predict.py:58-64)."""
+    with open(config_path, "rb") as fh:
+        config = _ConfigUnpickler(fh).load()
+    if not isinstance(config, dict):
+        raise ValueError(f"{config_path}: not a model config (expected a dict, got {type(config).__name__})")
+    return config
+
+
+def load_model(model_path, config_path=None, model_type="snv", device="cuda"):
+    """Build the network a checkpoint was trained with and load its weights, as scripts/run_predict.py:58-91, :163-189 does:
+    ``model_choice(config['model_no'], config, {'emb_dims', 'n_cont': 0, 'n_class', 'distal_order': 1, 'in_channels': 4})``
+    then ``load_state_dict``.  ``config_path`` defaults to ``<model_path>.config.pkl``.  Sequence-only models (every shipped
+    one: ``seq_only``) are supported; bigWig covariates are out of scope.  Returns (model in eval mode on `device`, config)."""
+    import torch
+    config = load_model_config(config_path or model_path + ".config.pkl")
+    if not config.get("seq_only", True):
+        raise ValueError("this checkpoint uses bigWig covariates (seq_only=False): not supported by the HIP path")
+    common = {"emb_dims": config["emb_dims"], "n_cont": 0, "n_class": config["n_class"], "distal_order": 1, "in_channels": 4}
+    model = model_choice(config["model_no"], config, common, model_type)
+    state = torch.load(model_path, map_location="cpu", weights_only=True)
+    model.load_state_dict(state)
+    return model.to(device).eval(), config

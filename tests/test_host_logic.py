@@ -137,3 +137,50 @@ def test_shard_bounds_partition():
             assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- model directories (model, model.config.pkl) -------------------------------------------------------------------------
+def test_load_model_from_reference_style_directory(tmp_path):
+    import pickle
+    from mural_amd.model import model_choice, nn_utils
+    r, order = 4, 3
+    ncol = 2 * r + 1 - (order - 1)
+    config = dict(local_radius=r, local_order=order, local_hidden1_size=150, local_hidden2_size=75, distal_radius=300, emb_dropout=0.1,
+                  local_dropout=0.1, CNN_kernel_size=3, CNN_out_channels=32, distal_fc_dropout=0.25, n_class=4, model_no=2,
+                  seq_only=True, emb_dims=[(np.int64(4 ** order + 1), 2)] * ncol, segment_center=300000)
+    common = dict(emb_dims=config["emb_dims"], n_cont=0, n_class=4, distal_order=1, in_channels=4)
+    torch.manual_seed(3)
+    src = model_choice(2, config, common, "snv")
+    torch.save(src.state_dict(), tmp_path / "model")
+    with open(tmp_path / "model.config.pkl", "wb") as fh:
+        pickle.dump(config, fh)
+    model, cfg = nn_utils.load_model(str(tmp_path / "model"), device="cpu")
+    assert cfg["local_radius"] == r and not model.training and type(model).__name__ == "Network2"
+    for (k, a), (k2, b) in zip(src.state_dict().items(), model.state_dict().items()):
+        assert k == k2 and torch.equal(a, b)
+    # anything but plain data in the config pickle is refused
+    class Evil:
+        def __reduce__(self):
+            import os
+            return (os.system, ("true",))
+    with open(tmp_path / "bad.pkl", "wb") as fh:
+        pickle.dump({"x": Evil()}, fh)
+    with pytest.raises(pickle.UnpicklingError):
+        nn_utils.load_model_config(str(tmp_path / "bad.pkl"))
+    config["seq_only"] = False
+    with open(tmp_path / "model.config.pkl", "wb") as fh:
+        pickle.dump(config, fh)
+    with pytest.raises(ValueError, match="bigWig"):
+        nn_utils.load_model(str(tmp_path / "model"), device="cpu")
+
+
+def test_load_shipped_checkpoints_if_present():
+    from oracle import ref_import
+    from mural_amd.model import nn_utils
+    root = os.path.join(ref_import.REFERENCE_ROOT, "models", "Homo_sapiens")
+    if not os.path.isdir(root):
+        pytest.skip("reference tree not mounted")
+    m, cfg = nn_utils.load_model(os.path.join(root, "SNV", "AT", "model"), device="cpu")
+    assert cfg["model_no"] == 2 and len(m.state_dict()) == 302
+    m, cfg = nn_utils.load_model(os.path.join(root, "INDEL", "insertion", "model"), model_type="indel", device="cpu")
+    assert cfg["use_reverse"] and len(m.state_dict()) == 232
