@@ -257,6 +257,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   // a first-stage launch runs one tower and one stage: its lane addressing / validity mask is tile-invariant
   const StageAddr sa_first = stage_setup(args.geom[args.tw_first], 0, P, n16, kk, mb, cgp);
 
+  float a_cur[SNV_KSTEPS];
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
     if (do_head && tid < P * args.n_class) {   // local-branch logits of this tile -> LDS (third logit vector)
@@ -276,9 +277,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       const TowerDev& tw = args.tw[tw_i];
       const float* tpar = par + tw_i * par_stride;
 
-      // weights of the first conv: issued now, consumed after the entry barrier
-      float a_cur[SNV_KSTEPS];
-      {
+      // weights of the first conv: issued now, consumed after the entry barrier.  A stage-split launch runs one tower, so
+      // from its second tile on they are already there: the last layer of a tile prefetches the first layer's fragments.
+      if (PHASE == 0 || tile == (int64_t)blockIdx.x) {
         const float* wf = tw.wfrag + (size_t)(PHASE == 2 ? 4 : 0) * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
@@ -323,6 +324,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           sa = stage_setup(g, 1, P, n16, kk, mb, cgp);
           __syncthreads();
         } else if (layer == 4 || layer == 9) {
+          // a first-stage launch ends with this pooling: the residual registers are dead, so the next tile's stage-1
+          // activations are requested now and their HBM latency hides under the pooling instead of stalling the next entry
+          if (PHASE == 1) request_x0(args, xres, tile + gridDim.x, tw_i, n_tiles, cgp, n16, chv);
           // max-pool (raw y in bufA) + BN (no ReLU) -> bufB in the next stage's geometry
           const int si = st - 1;  // input stage
           const int Lin = g.L[si], Lout = g.L[st], ScI = g.Sc[si], ScO = g.Sc[st];
@@ -390,7 +394,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         __builtin_amdgcn_sched_barrier(0);
         // prefetch the next layer's A fragments (consumed after this layer's barrier)
         float a_nxt[SNV_KSTEPS];
-        const int ln = layer < SNV_NLAYER - 1 ? layer + 1 : layer;
+        const int ln = PHASE == 1 ? (layer < 3 ? layer + 1 : 0) : (layer < SNV_NLAYER - 1 ? layer + 1 : (PHASE == 2 ? 4 : layer));
         {
           const float* wfn = tw.wfrag + (size_t)ln * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
@@ -410,8 +414,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
 
       if (PHASE == 1) {   // stage-split launch: nothing after the pooling; bufA is free once every wave has pooled
-        request_x0(args, xres, tw_i < args.tw_last ? tile : tile + gridDim.x, tw_i < args.tw_last ? tw_i + 1 : args.tw_first,
-                   n_tiles, cgp, n16, chv);
         lds_barrier();
         continue;
       }
@@ -548,6 +550,10 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
   if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) {   // diagnostic: e.g. 256 = one workgroup per CU (tools/phase_stamps.py)
     const int v = atoi(e);
     if (v >= 1 && v < grid) grid = v;
+  }
+  if (const char* e = getenv("MURAL_DEBUG_TOWER_LDS")) {    // diagnostic: inflate the first-stage launches' LDS request (occupancy study)
+    const size_t v = (size_t)atol(e);
+    if (a.phase == 1 && v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
   }
   static bool attr_set = false;
   if (!attr_set) {
