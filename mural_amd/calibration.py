@@ -7,6 +7,7 @@
     unpickler maps the two calibrator classes to inert holders and ``jax._src.array._reconstruct_array`` (present in the
     INDEL pickles) to its numpy equivalent; any other global is refused.
   * ``poisson_calibrate`` lives in ``mural_amd.data.ingest`` (MuRaL/model/calibration.py:10-23).
+  * ``mu_scaling_factor`` / ``apply_scaling`` -- the per-generation rate scaling of MuRaL/scripts/scaling.py:10-28, :76-93.
 """
 import pickle
 
@@ -68,3 +69,19 @@ def dirichlet_calibrate(prob, weights):
     z = z - np.max(z, axis=1).reshape(-1, 1)
     e = np.exp(z)
     return e / np.sum(e, axis=1).reshape(-1, 1)
+
+
+def mu_scaling_factor(prob, genomewide_mu, m_proportion, g_proportion=1.0):
+    """Factor that turns relative mutation probabilities into per-generation rates (MuRaL/scripts/scaling.py:76-93):
+    genomewide_mu * n_sites * m_proportion / g_proportion / sum over sites of (prob1 + ... + prob_{k-1}); `prob` holds the sites
+    used as the benchmark (all predicted sites, or those inside the benchmark regions)."""
+    prob = np.asarray(prob, dtype=np.float64)
+    return float(genomewide_mu * prob.shape[0] * m_proportion / g_proportion / prob[:, 1:].sum())
+
+
+def apply_scaling(prob, scale_factor):
+    """scripts/scaling.py:10-28: the mutation classes are multiplied by the factor, class 0 becomes 1 - their sum."""
+    out = np.asarray(prob, dtype=np.float64).copy()
+    out[:, 1:] *= scale_factor
+    out[:, 0] = 1.0 - out[:, 1:].sum(axis=1)
+    return out

@@ -403,8 +403,17 @@ def g11_output(ref):
     df.reset_index(drop=True, inplace=True)
     buf = io.StringIO()
     df.to_csv(buf, sep="\t", float_format="%.4g", index=False)
+    # scripts/scaling.py:10-28 on that table (file in, file out)
+    import tempfile
+    scaling = importlib.import_module("MuRaL.scripts.scaling")
+    with tempfile.TemporaryDirectory() as tmp:
+        src, dst = os.path.join(tmp, "pred.tsv"), os.path.join(tmp, "scaled.tsv")
+        with open(src, "w") as fh:
+            fh.write(buf.getvalue())
+        scaling.apply_scaling(src, 0.0123, 4, dst)
+        scaled = open(dst).read()
     save("output.npz", prob=p, poisson=out, chrom=chrom.astype(str), start=start, strand=strand.astype(str), label=label,
-         table=np.array(buf.getvalue()))
+         table=np.array(buf.getvalue()), scaled_table=np.array(scaled), scale_factor=np.array(0.0123))
 
 
 def g12_dirichlet(ref):

@@ -104,3 +104,23 @@ def test_poisson_calibrate_and_prediction_table_match_reference(tmp_path):
     path = tmp_path / "pred.tsv"
     I.write_predictions(res, path)
     assert path.read_text() == str(fx["table"])
+
+
+def test_mu_scaling_matches_reference_table(tmp_path):
+    """apply_scaling against the table the reference's scripts/scaling.py:10-28 wrote from the golden prediction table (it reads
+    the '%.4g' table back, scales, writes '%.4g' again); the factor formula of :76-93 on a hand example."""
+    import io
+    import pandas as pd
+    from mural_amd.calibration import apply_scaling, mu_scaling_factor
+    fx = U.load("output.npz")
+    src = pd.read_csv(io.StringIO(str(fx["table"])), sep="\t")
+    names = ["prob%d" % i for i in range(4)]
+    got = apply_scaling(src[names].to_numpy(), float(fx["scale_factor"]))
+    out = src.copy()
+    out[names[1:]] = got[:, 1:]
+    out["prob0"] = got[:, 0]
+    buf = io.StringIO()
+    out.to_csv(buf, sep="\t", index=False, float_format="%.4g")
+    assert buf.getvalue() == str(fx["scaled_table"])
+    prob = np.array([[0.9, 0.05, 0.03, 0.02], [0.8, 0.1, 0.05, 0.05]])
+    assert mu_scaling_factor(prob, 1.2e-8, 0.25, 0.5) == pytest.approx(1.2e-8 * 2 * 0.25 / 0.5 / 0.3)
