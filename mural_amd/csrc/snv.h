@@ -58,6 +58,8 @@ struct LocalDev {
   const float* b2;                // [h2]
   const float* w3t;               // [h2][n_class]  BN1 folded in
   const float* b3;                // [n_class]
+  const float* frag;              // the three weight matrices in MFMA A-fragment order (snv_local_mlp_mfma), frag_floats long
+  int frag_floats;
   int cols, emb_rows, in1, h1, h2, n_class;
 };
 

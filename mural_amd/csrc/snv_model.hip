@@ -149,7 +149,7 @@ int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& 
   return MURAL_OK;
 }
 
-struct LocalOff { size_t emb, w1t, b1, w2t, b2, w3t, b3; };
+struct LocalOff { size_t emb, w1t, b1, w2t, b2, w3t, b3, frag, frag_floats; };
 
 int fold_local(const MuralLocal& Lc, const MuralSnvShape& sh, Blob& B, LocalOff& o) {
   MURAL_REQUIRE(Lc.emb && aff_ok(Lc.lin[0]) && aff_ok(Lc.lin[1]) && bn_ok(Lc.bn[0]) && bn_ok(Lc.bn[1]) && aff_ok(Lc.out),
@@ -190,6 +190,25 @@ int fold_local(const MuralLocal& Lc, const MuralSnvShape& sh, Blob& B, LocalOff&
     }
     B.host[o.b3 + k] = (float)b;
   }
+  // the same three matrices in MFMA A-fragment order for snv_local_mlp_mfma (csrc/snv_local.hip):
+  //   frag[((nb * J + j) * 64 + lane) * 4 + t] = W[f = 16 nb + lane % 16][k = 16 j + 4 (lane / 16) + t], zero outside
+  const int K1p = (in1 + 15) & ~15, n1b = (h1 + 15) / 16, K2p = 16 * n1b, n2b = (h2 + 15) / 16, K3p = 16 * n2b;
+  o.frag_floats = (size_t)256 * (n1b * (K1p / 16) + n2b * (K2p / 16) + K3p / 16);
+  o.frag = B.alloc(o.frag_floats);
+  size_t at = o.frag;
+  auto emit = [&](size_t wt, int nb_count, int J, int K, int H) {
+    for (int nb = 0; nb < nb_count; ++nb)
+      for (int j = 0; j < J; ++j)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int t = 0; t < 4; ++t) {
+            const int f = 16 * nb + (lane & 15), k = 16 * j + 4 * (lane >> 4) + t;
+            const float v = (k < K && f < H) ? B.host[wt + (size_t)k * H + f] : 0.f;   // read before the blob may grow: alloc is done
+            B.host[at++] = v;
+          }
+  };
+  emit(o.w1t, n1b, K1p / 16, in1, h1);
+  emit(o.w2t, n2b, K2p / 16, h1, h2);
+  emit(o.w3t, 1, K3p / 16, h2, nc);
   return MURAL_OK;
 }
 
@@ -405,6 +424,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     LocalDev& L = m->local;
     L.emb = m->blob + loff.emb; L.w1t = m->blob + loff.w1t; L.b1 = m->blob + loff.b1; L.w2t = m->blob + loff.w2t;
     L.b2 = m->blob + loff.b2; L.w3t = m->blob + loff.w3t; L.b3 = m->blob + loff.b3;
+    L.frag = m->blob + loff.frag; L.frag_floats = (int)loff.frag_floats;
     L.cols = sh.local_cols; L.emb_rows = sh.emb_rows; L.in1 = 5 * sh.local_cols; L.h1 = sh.hidden1; L.h2 = sh.hidden2;
     L.n_class = sh.n_class;
   }
