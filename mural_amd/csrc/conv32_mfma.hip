@@ -539,8 +539,22 @@ __global__ __launch_bounds__(1024) void part_reduce_kernel(const float* __restri
   const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
   const int i = blockIdx.x * 64 + o;
   float s = 0.f;
-  if (i < nW + nB)
-    for (int b = slice; b < nrow; b += 16) s += part[(size_t)b * (nW + nB) + i];
+  if (i < nW + nB) {
+    // eight rows in flight per thread (the loop is latency-bound: 49 workgroups read 6 MB); the order of the adds is fixed
+    const size_t rs = (size_t)(nW + nB);
+    const float* p = part + i;
+    int b = slice;
+    float s0 = 0.f, s1 = 0.f;
+    for (; b + 7 * 16 < nrow; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + 16 * q) * rs];
+      s0 += (v[0] + v[1]) + (v[2] + v[3]);
+      s1 += (v[4] + v[5]) + (v[6] + v[7]);
+    }
+    for (; b < nrow; b += 16) s0 += p[(size_t)b * rs];
+    s = s0 + s1;
+  }
   sh[slice][o] = s;
   __syncthreads();
   if (slice == 0 && i < nW + nB) {
