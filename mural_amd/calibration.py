@@ -85,3 +85,43 @@ def apply_scaling(prob, scale_factor):
     out[:, 1:] *= scale_factor
     out[:, 0] = 1.0 - out[:, 1:].sum(axis=1)
     return out
+
+
+def save_dirichlet_calibrator(weights, path):
+    """Write a ``model.fdiri_cal.pkl`` the reference can load (MuRaL/training.py:574-575 pickles its fitted
+    ``FullDirichletCalibrator``; scripts/run_predict.py then calls ``predict_proba`` on it): the same two objects with the same
+    attribute dictionaries, pickled by class reference without importing dirichletcal / jax here.  `weights`: the (k, k + 1)
+    float64 matrix of ``evaluation.fit_full_dirichlet`` / ``load_dirichlet_weights``."""
+    import sys
+    import types
+    w = np.ascontiguousarray(weights, dtype=np.float64)
+    if w.ndim != 2 or w.shape[1] != w.shape[0] + 1:
+        raise ValueError(f"weights must be (k, k + 1), got {w.shape}")
+    k = w.shape[0]
+    names = {"dirichletcal.calib.fulldirichlet": "FullDirichletCalibrator", "dirichletcal.calib.multinomial": "MultinomialRegression"}
+    saved = {m: sys.modules.get(m) for m in list(names) + ["dirichletcal", "dirichletcal.calib"]}
+    classes = {}
+    try:
+        for mod, cls in names.items():            # look-alike modules so that pickle records the reference's global names
+            m = types.ModuleType(mod)
+            c = type(cls, (), {})
+            c.__module__ = mod
+            setattr(m, cls, c)
+            sys.modules[mod] = m
+            classes[cls] = c
+        for pkg in ("dirichletcal", "dirichletcal.calib"):
+            sys.modules[pkg] = types.ModuleType(pkg)
+        common = dict(reg_lambda=0.0, reg_mu=None, initializer="identity", reg_norm=False, ref_row=True, optimizer="auto")
+        inner = classes["MultinomialRegression"]()
+        inner.__dict__.update(dict(weights_0=None, method="Full", reg_format=None, classes=np.arange(k, dtype=np.int64), weights_=w,
+                                   weights_0_=np.hstack([np.eye(k), np.zeros((k, 1))]).ravel(), **common))
+        outer = classes["FullDirichletCalibrator"]()
+        outer.__dict__.update(dict(weights_init=None, weights_=None, calibrator_=inner, **common))
+        with open(path, "wb") as fh:
+            pickle.dump(outer, fh, protocol=4)
+    finally:
+        for m, old in saved.items():
+            if old is None:
+                sys.modules.pop(m, None)
+            else:
+                sys.modules[m] = old

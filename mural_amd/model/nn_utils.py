@@ -133,3 +133,18 @@ def load_model(model_path, config_path=None, model_type="snv", device="cuda"):
     state = torch.load(model_path, map_location="cpu", weights_only=True)
     model.load_state_dict(state)
     return model.to(device).eval(), config
+
+
+def save_model(model, dirichlet_weights, config, save_path):
+    """The three files of MuRaL/training.py:570-578: ``save_path`` (state dict), ``save_path + '.fdiri_cal.pkl'`` (skipped when
+    `dirichlet_weights` is None) and ``save_path + '.config.pkl'`` -- loadable by the reference and by ``load_model`` /
+    ``calibration.load_dirichlet_weights``."""
+    import pickle
+
+    import torch
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, save_path)
+    if dirichlet_weights is not None:
+        from ..calibration import save_dirichlet_calibrator
+        save_dirichlet_calibrator(dirichlet_weights, save_path + ".fdiri_cal.pkl")
+    with open(save_path + ".config.pkl", "wb") as fp:
+        pickle.dump(dict(config), fp)

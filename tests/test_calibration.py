@@ -77,3 +77,53 @@ def test_load_dirichlet_weights_without_dirichletcal_or_jax(tmp_path):
         pickle.dump(print, fh)
     with pytest.raises(pickle.UnpicklingError, match="refused"):
         K.load_dirichlet_weights(evil)
+
+
+def test_saved_calibrator_round_trips_and_loads_in_the_reference(tmp_path):
+    """save_dirichlet_calibrator -> our restricted reader; and, when the reference tree is mounted, -> the reference's own
+    classes (numpy standing in for jax, as in oracle/make_golden.py g12), whose predict_proba equals dirichlet_calibrate."""
+    import os
+    rng = np.random.default_rng(4)
+    k = 4
+    w = np.vstack([rng.normal(size=(k - 1, k + 1)), np.zeros((1, k + 1))])
+    path = str(tmp_path / "model.fdiri_cal.pkl")
+    K.save_dirichlet_calibrator(w, path)
+    assert np.array_equal(K.load_dirichlet_weights(path), w)
+    assert "dirichletcal.calib.fulldirichlet" not in sys.modules          # the look-alike modules are gone again
+    from oracle import ref_import
+    root = os.path.join(ref_import.REFERENCE_ROOT, "dirichlet_python")
+    if not os.path.isdir(root):
+        return
+    saved = {m: sys.modules.get(m) for m in list(sys.modules) if m == "jax" or m.startswith("jax.") or m.startswith("dirichletcal")
+             or m == "autograd" or m.startswith("autograd.")}
+    for m in saved:
+        sys.modules.pop(m, None)
+
+    def mod(name, **kw):
+        mm = types.ModuleType(name)
+        mm.__path__ = []
+        for a, v in kw.items():
+            setattr(mm, a, v)
+        sys.modules[name] = mm
+        return mm
+
+    noop = lambda *a, **kw: (lambda *b, **kb: None)      # noqa: E731
+    jax = mod("jax", numpy=np, grad=noop, hessian=noop)
+    jax.config = mod("jax.config", config=types.SimpleNamespace(update=lambda *a, **kw: None)).config
+    sys.modules["jax.numpy"] = np
+    mod("autograd", grad=noop, hessian=noop, numpy=np)
+    sys.modules["autograd.numpy"] = np
+    sys.path.insert(0, root)
+    try:
+        __import__("dirichletcal")
+        with open(path, "rb") as fh:
+            cal = pickle.load(fh)
+        assert type(cal).__module__ == "dirichletcal.calib.fulldirichlet"
+        prob = rng.dirichlet([20, 1, 1, 1], size=32).astype(np.float32)
+        assert np.abs(np.asarray(cal.predict_proba(prob)) - K.dirichlet_calibrate(prob, w)).max() <= 1e-14
+    finally:
+        sys.path.pop(0)
+        for m in [m for m in sys.modules if m == "jax" or m.startswith("jax.") or m.startswith("dirichletcal") or m == "autograd"
+                  or m.startswith("autograd.")]:
+            sys.modules.pop(m, None)
+        sys.modules.update({m: v for m, v in saved.items() if v is not None})

@@ -156,6 +156,13 @@ def test_load_model_from_reference_style_directory(tmp_path):
         pickle.dump(config, fh)
     model, cfg = nn_utils.load_model(str(tmp_path / "model"), device="cpu")
     assert cfg["local_radius"] == r and not model.training and type(model).__name__ == "Network2"
+    # save_model writes the reference's three files back (training.py:570-578)
+    from mural_amd.calibration import load_dirichlet_weights
+    w = np.hstack([np.eye(4), np.zeros((4, 1))])
+    nn_utils.save_model(model, w, cfg, str(tmp_path / "ckpt"))
+    again, cfg2 = nn_utils.load_model(str(tmp_path / "ckpt"), device="cpu")
+    assert cfg2 == cfg and np.array_equal(load_dirichlet_weights(str(tmp_path / "ckpt.fdiri_cal.pkl")), w)
+    assert all(torch.equal(a, b) for a, b in zip(model.state_dict().values(), again.state_dict().values()))
     for (k, a), (k2, b) in zip(src.state_dict().items(), model.state_dict().items()):
         assert k == k2 and torch.equal(a, b)
     # anything but plain data in the config pickle is refused
