@@ -84,3 +84,63 @@ class GraphedTrainStep:
         """Wait for the last replay and raise its deferred input check, if any."""
         torch.cuda.synchronize()
         self._check()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the reference's epoch loop (MuRaL/training.py:346-450) around the HIP models: optimiser / scheduler choice and the
+# per-batch policy (skip batches of one row, clip at 10, step the scheduler every batch, restart a learning rate that decayed
+# below min_lr).  Host logic only; the model does the device work.
+# ------------------------------------------------------------------------------------------------------------------
+def make_optimizer(config, params):
+    """training.py:346-360: Adam / AdamW / AdamW2 (both amsgrad) / SGD (momentum 0.98, nesterov) by ``config['optim']``."""
+    params = [p for p in params if p.requires_grad]
+    lr, wd = config["learning_rate"], config["weight_decay"]
+    name = config["optim"]
+    if name == "Adam":
+        return torch.optim.Adam(params, lr=lr, weight_decay=wd)
+    if name in ("AdamW", "AdamW2"):
+        return torch.optim.AdamW(params, lr=lr, weight_decay=wd, amsgrad=True)
+    if name == "SGD":
+        return torch.optim.SGD(params, lr=lr, weight_decay=wd, momentum=0.98, nesterov=True)
+    raise ValueError(f"Error: unsupported optimization method {name}")
+
+
+def make_scheduler(config, optimizer, train_size=None):
+    """training.py:364-373: 'StepLR' (step_size (5000 * 128) // batch_size, gamma LR_gamma), 'StepLR2' (per-step decay from
+    restart_lr to min_lr over one epoch), 'ROP' (ReduceLROnPlateau)."""
+    kind = config["lr_scheduler"]
+    if kind == "StepLR":
+        return torch.optim.lr_scheduler.StepLR(optimizer, step_size=(5000 * 128) // config["batch_size"], gamma=config["LR_gamma"])
+    if kind == "StepLR2":
+        gamma = (config["min_lr"] / config["restart_lr"]) ** (1 / (train_size // config["batch_size"]))
+        return torch.optim.lr_scheduler.StepLR(optimizer, step_size=1, gamma=gamma)
+    if kind == "ROP":
+        return torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, mode="min", factor=0.2, patience=1, threshold=0.0001, min_lr=1e-7)
+    raise ValueError(f"unknown lr_scheduler {kind}")
+
+
+def train_epoch(model, batches, criterion, optimizer, scheduler, config, device, model_type="snv", epoch=0):
+    """One epoch of training.py:392-450 over an iterable of ``(y, cont_x, cat_x, distal_x)`` batches (the order
+    ``generate_data_batches`` yields them).  Returns the summed loss."""
+    model.train()
+    if epoch > 0 and config["lr_scheduler"] == "StepLR2":
+        for g in optimizer.param_groups:
+            g["lr"] = config["restart_lr"]
+    total_loss = 0.0
+    for y, cont_x, cat_x, distal_x in batches:
+        if y.shape[0] == 1:                       # a single row cannot feed a batch-statistics BatchNorm (training.py:415)
+            continue
+        cat_x, cont_x, distal_x, y = cat_x.to(device), cont_x.to(device), distal_x.to(device), y.to(device)
+        preds = model.forward((cont_x, cat_x), distal_x) if model_type == "snv" else model.forward(distal_x)
+        loss = criterion(preds, y.long().squeeze())
+        optimizer.zero_grad()
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, error_if_nonfinite=False)
+        optimizer.step()
+        total_loss += loss.item()
+        if config["lr_scheduler"] != "ROP":
+            scheduler.step()
+            if optimizer.param_groups[0]["lr"] < config["min_lr"]:      # avoid very small learning rates
+                for g in optimizer.param_groups:
+                    g["lr"] = config["restart_lr"]
+    return total_loss

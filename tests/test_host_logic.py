@@ -191,3 +191,35 @@ def test_load_shipped_checkpoints_if_present():
     assert cfg["model_no"] == 2 and len(m.state_dict()) == 302
     m, cfg = nn_utils.load_model(os.path.join(root, "INDEL", "insertion", "model"), model_type="indel", device="cpu")
     assert cfg["use_reverse"] and len(m.state_dict()) == 232
+
+
+def test_train_epoch_policy_matches_reference_loop():
+    """Host policy of MuRaL/training.py:392-450 on a stand-in model: single-row batches are skipped, the scheduler steps every
+    batch, a learning rate below min_lr restarts at restart_lr, the loss is summed."""
+    from mural_amd import train as TR
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3, 4)
+
+        def forward(self, local, distal):
+            return self.lin(distal.mean(dim=2)[:, :3])
+
+    torch.manual_seed(0)
+    model = Toy()
+    config = dict(optim="Adam", learning_rate=1e-3, weight_decay=0.0, lr_scheduler="StepLR", batch_size=320000, LR_gamma=0.5,
+                  min_lr=3e-4, restart_lr=8e-4)
+    opt = TR.make_optimizer(config, model.parameters())
+    sch = TR.make_scheduler(config, opt)
+    assert sch.step_size == 2
+    mk = lambda b: (torch.zeros(b, 1), torch.zeros(b, 1, dtype=torch.float64), torch.zeros(b, 9, dtype=torch.int64), torch.rand(b, 4, 21))  # noqa: E731
+    batches = [mk(4), mk(1), mk(5), mk(4), mk(4), mk(4)]
+    before = model.lin.weight.detach().clone()
+    total = TR.train_epoch(model, batches, torch.nn.CrossEntropyLoss(reduction="sum"), opt, sch, config, "cpu")
+    assert total > 0 and not torch.equal(before, model.lin.weight)
+    # 5 batches trained (the single-row one skipped): lr 1e-3 -> 5e-4 after 2 steps -> 2.5e-4 < min_lr after 4 -> restart 8e-4
+    assert opt.param_groups[0]["lr"] == pytest.approx(8e-4)
+    with pytest.raises(ValueError):
+        TR.make_optimizer(dict(config, optim="LBFGS"), model.parameters())
+    assert isinstance(TR.make_optimizer(dict(config, optim="AdamW2"), model.parameters()), torch.optim.AdamW)
