@@ -159,6 +159,43 @@ def predict_bed(model, fasta_path, bed_path, local_radius, local_order=3, distal
             "order": order}
 
 
+
+def packed_segments(genomes, sites, order, group, local_radius, local_order=3, distal_radius=None, model_type="snv"):
+    """The dataset segments of the reference's ``CombinedDatasetNP`` (MuRaL/data/preprocessing.py:937-944: item i = the rows of
+    the i-th ``bed_reader`` group) encoded on the device from packed genomes: an iterator of
+    ``(y (1, n, 1) float32, cont_x (1, n, 1) float64 zeros, cat_x (1, n, cols) int64, distal_x (1, n, 4, L) float32)``, the
+    shapes its DataLoader(batch_size=1) hands to ``generate_data_batches``.  `genomes`: {chrom name: PackedGenome};
+    `order`, `group`: from ``bed_order``."""
+    cid, start, strand = sites.chrom_id[order], sites.start[order], sites.strand[order]
+    label = sites.score[order]
+    bounds = np.r_[0, np.nonzero(group[1:] != group[:-1])[0] + 1, len(group)] if len(group) else np.zeros(1, np.int64)
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        g = genomes[sites.chrom_names[cid[lo]]]
+        pos = torch.from_numpy(start[lo:hi]).to(g.device)
+        st = torch.from_numpy(strand[lo:hi]).to(g.device)
+        cat = g.encode_kmer(pos, st, local_radius, local_order, model_type)
+        distal = g.encode_onehot(pos, st, distal_radius, model_type)
+        y = torch.from_numpy(label[lo:hi].astype(np.float32)).reshape(1, -1, 1).to(g.device)
+        yield y, torch.zeros((1, hi - lo, 1), dtype=torch.float64), cat.unsqueeze(0), distal.unsqueeze(0)
+
+
+def train_batches_from_files(fasta_path, bed_path, batch_size, local_radius, local_order=3, distal_radius=None, segment_center=300000,
+                             sampled_segments=10, shuffle=True, generator=None, model_type="snv", device="cuda"):
+    """Training batches ``(y, cont_x, cat_x, distal_x)`` straight from a FASTA + BED pair in the order the reference's pipeline
+    produces them (bed_reader segments -> CombinedDatasetNP items -> ``generate_data_batches`` with `sampled_segments`
+    segments per group, preprocessing.py:1148-1226): C++ ingest, device-side window encoders, no per-base Python."""
+    from .batching import generate_data_batches
+    sites = read_bed(bed_path)
+    order, group = bed_order(sites, segment_center)
+    used = {sites.chrom_names[c] for c in np.unique(sites.chrom_id)}
+    genomes = read_fasta(fasta_path, device, names=used)
+    missing = used - set(genomes)
+    if missing:
+        raise KeyError(sorted(missing)[0])
+    segs = packed_segments(genomes, sites, order, group, local_radius, local_order, distal_radius, model_type)
+    return generate_data_batches(segs, sampled_segments, batch_size, shuffle=shuffle, generator=generator)
+
+
 def poisson_calibrate(prob):
     """MuRaL/model/calibration.py:10-23 on an (n, n_class) array: lambda = -log(clip(prob0, 1e-10, 1)); the mutation
     classes become lambda * prob_k / (1 - prob0) and class 0 becomes 1 - lambda (applied for INDEL models and with

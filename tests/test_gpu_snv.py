@@ -263,3 +263,45 @@ def test_packed_path_other_channel_and_kernel_sizes():
         ref = orc((torch.zeros(40, 1, dtype=torch.float64), cat.cpu()), x.cpu())
     assert torch.equal(got, want)
     assert_probs_close(got.cpu().numpy(), ref.numpy(), 2, "generic packed")
+
+
+def test_train_batches_from_files_match_reference_pipeline_order(tmp_path):
+    """FASTA + BED -> training batches: rows, labels, k-mer columns and one-hot windows equal the oracle encoders applied to the
+    sites in bed_reader order, cut by generate_data_batches (2 segments per group, batch 7, tail rows carried forward)."""
+    from mural_amd.data import ingest
+    from mural_amd.data.batching import segment_order
+    r, R = 4, 60
+    rng = np.random.default_rng(99)
+    seqs = {"chrA": rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=3000, p=[.24, .25, .25, .24, .02]).tobytes().decode(),
+            "chrB": rng.choice(np.frombuffer(b"ACGT", np.uint8), size=1500).tobytes().decode()}
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">{k}\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for k, s in seqs.items()))
+    rows = [(name, int(p), "+-"[int(rng.integers(0, 2))], int(rng.integers(0, 4))) for name, s in seqs.items()
+            for p in np.sort(rng.choice(len(s), size=45, replace=False))]
+    bed = tmp_path / "s.bed"
+    bed.write_text("".join(f"{c}\t{p}\t{p + 1}\t.\t{lab}\t{st}\n" for c, p, st, lab in rows))
+    chrom = np.array([c for c, _, _, _ in rows])
+    start = np.array([p for _, p, _, _ in rows])
+    neg = np.array([st == "-" for _, _, st, _ in rows])
+    lab = np.array([v for _, _, _, v in rows], dtype=np.float32)
+    order, _ = segment_order(chrom, start, neg, 400)
+    want_cat, want_x = [], []
+    for i in order:
+        codes = encode_ref.seq_to_codes(seqs[chrom[i]])
+        sym = ["-" if neg[i] else "+"]
+        want_cat.append(encode_ref.kmer_encode(codes, start[i:i + 1], sym, r, 3)[0])
+        want_x.append(encode_ref.onehot_encode(codes, start[i:i + 1], sym, R)[0])
+    want_cat, want_x, want_y = np.stack(want_cat), np.stack(want_x), lab[order]
+    got = list(ingest.train_batches_from_files(fa, bed, 7, r, 3, R, segment_center=400, sampled_segments=2, shuffle=False))
+    assert sum(b[0].shape[0] for b in got) == len(rows)
+    assert all(b[0].shape[0] == 7 for b in got[:-1]) and got[0][1].dtype == torch.float64 and got[0][1].shape == (7, 1)
+    # without shuffling the batches walk the bed_reader order (a carried tail goes first in its next group: still in order)
+    y = torch.cat([b[0] for b in got]).cpu().numpy().reshape(-1)
+    cat = torch.cat([b[2] for b in got]).cpu().numpy()
+    x = torch.cat([b[3] for b in got]).cpu().numpy()
+    assert np.array_equal(y, want_y) and np.array_equal(cat, want_cat) and np.array_equal(x, want_x)
+    # shuffled: the same multiset of rows
+    g = torch.Generator().manual_seed(1)
+    sh = list(ingest.train_batches_from_files(fa, bed, 7, r, 3, R, segment_center=400, sampled_segments=2, shuffle=True, generator=g))
+    cat2 = torch.cat([b[2] for b in sh]).cpu().numpy()
+    assert sorted(map(tuple, cat2.tolist())) == sorted(map(tuple, want_cat.tolist())) and not np.array_equal(cat2, want_cat)
