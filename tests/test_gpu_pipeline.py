@@ -82,3 +82,12 @@ def test_train_evaluate_save_reload_predict(tmp_path):
     table = ingest.write_predictions(res2, tmp_path / "pred.tsv", dirichlet_weights=load_dirichlet_weights(ckpt + ".fdiri_cal.pkl"))
     assert list(table.columns[:5]) == ["chrom", "start", "end", "strand", "mut_type"] and len(table) == len(rows)
     assert table["start"].is_monotonic_increasing
+    # the same through the command-line helper
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("predict_files", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                                                                                  "tools", "predict_files.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    mod.main([ckpt, str(fa), str(bed), str(tmp_path / "pred2.tsv")])
+    assert (tmp_path / "pred2.tsv").read_text() == (tmp_path / "pred.tsv").read_text()
