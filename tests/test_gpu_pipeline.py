@@ -91,3 +91,40 @@ def test_train_evaluate_save_reload_predict(tmp_path):
     spec.loader.exec_module(mod)
     mod.main([ckpt, str(fa), str(bed), str(tmp_path / "pred2.tsv")])
     assert (tmp_path / "pred2.tsv").read_text() == (tmp_path / "pred.tsv").read_text()
+
+
+def test_indel_train_from_files_and_predict(tmp_path):
+    """The INDEL model through the same chain: training batches from FASTA + BED (indel windows), two optimiser steps per
+    epoch policy, Poisson-calibrated prediction table (run_predict.py:224-225 applies it to every INDEL model)."""
+    from mural_amd import train as TR
+    from mural_amd.data import ingest
+    from mural_amd.model import model_choice, weights_init
+    rng = np.random.default_rng(7)
+    R, n_class = 1000, 3
+    seq = rng.choice(np.frombuffer(b"ACGT", np.uint8), size=12000).tobytes().decode()
+    fa = tmp_path / "g.fa"
+    fa.write_text(">chr1\n" + "\n".join(seq[i:i + 80] for i in range(0, len(seq), 80)) + "\n")
+    pos = np.sort(rng.choice(np.arange(10, len(seq) - 10), size=48, replace=False))
+    bed = tmp_path / "s.bed"
+    bed.write_text("".join(f"chr1\t{p}\t{p + 1}\t.\t{int(rng.integers(0, n_class))}\t{'+-'[int(rng.integers(0, 2))]}\n" for p in pos))
+    config = dict(local_radius=4, local_order=3, distal_radius=R, CNN_kernel_size=7, CNN_out_channels=8, down_list=[1, 4, 5, 5, 5, 2],
+                  use_reverse=True, n_class=n_class, model_no=0, optim="AdamW", learning_rate=1e-3, weight_decay=1e-6,
+                  lr_scheduler="StepLR", LR_gamma=0.9, batch_size=16, min_lr=1e-7, restart_lr=1e-4, segment_center=4000)
+    torch.manual_seed(1)
+    model = model_choice(0, config, dict(n_class=n_class), "indel")
+    model.apply(weights_init)
+    model = model.cuda()
+    opt = TR.make_optimizer(config, model.parameters())
+    sch = TR.make_scheduler(config, opt)
+    crit = torch.nn.CrossEntropyLoss(reduction="sum")
+    losses = []
+    for epoch in range(4):
+        batches = ingest.train_batches_from_files(fa, bed, 16, 4, 3, R, segment_center=4000, sampled_segments=2, shuffle=True,
+                                                  generator=torch.Generator().manual_seed(epoch), model_type="indel")
+        losses.append(TR.train_epoch(model, batches, crit, opt, sch, config, "cuda", model_type="indel", epoch=epoch))
+    assert np.isfinite(losses).all() and losses[-1] < losses[0], losses
+    model.eval()
+    res = ingest.predict_bed(model, fa, bed, 4, 3, distal_radius=R, segment_center=4000, model_type="indel")
+    assert res["prob"].shape == (48, n_class) and np.allclose(res["prob"].sum(axis=1), 1.0, atol=1e-5)
+    table = ingest.write_predictions(res, tmp_path / "indel.tsv", poisson=True)
+    assert len(table) == 48 and np.isfinite(table[["prob0", "prob1", "prob2"]].to_numpy()).all()
