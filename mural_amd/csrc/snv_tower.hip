@@ -217,6 +217,43 @@ __device__ __forceinline__ void request_x0(const SnvFwdArgs& args, f32x4 (&xres)
   }
 }
 
+// The same for a first-stage launch (one tower): the per-lane part of the address -- two divisions per block -- is computed
+// once per launch.  plan[i] = float offset of the lane's row inside the tile (a multiple of 32) | position p in the low
+// five bits, ~0u when the lane's column of block i holds no data.
+struct X0Plan { uint32_t off[SNV_NB2MAX]; };
+
+__device__ __forceinline__ X0Plan x0_plan(const SnvFwdArgs& args, int tw_i, int cgp, int n16) {
+  const TowerGeom& g = args.geom[tw_i];
+  const int nbw0 = g.nb[0] > cgp ? (g.nb[0] - cgp + 1) / 2 : 0;
+  X0Plan pl;
+#pragma unroll
+  for (int i = 0; i < SNV_NB2MAX; ++i) {
+    pl.off[i] = ~0u;
+    const int c = 16 * (cgp + 2 * i) + n16;
+    if (i < nbw0 && c >= 1) {
+      const uint32_t u = (uint32_t)(c - 1);
+      const uint32_t p = g.dSc[0].div(u);
+      const uint32_t j2 = u - p * (uint32_t)g.Sc[0];
+      if (p < (uint32_t)args.P && j2 < (uint32_t)g.L[0]) pl.off[i] = ((p * (uint32_t)args.x0_cols + j2) << 5) | p;
+    }
+  }
+  return pl;
+}
+
+__device__ __forceinline__ void request_x0_planned(const SnvFwdArgs& args, const X0Plan& pl, f32x4 (&xres)[SNV_NB2MAX], int64_t tile,
+                                                   int tw_i, int64_t n_tiles, int chv) {
+  const int x0c = tw_i == 0 ? 0 : args.geom[0].L[0];
+  const int64_t row0 = tile * args.P;
+  const float* base = args.x0 + ((size_t)row0 * args.x0_cols + x0c) * 32 + chv;
+  const bool whole = tile < n_tiles && row0 + args.P <= args.n;     // every position of the tile exists (all but the last tile)
+#pragma unroll
+  for (int i = 0; i < SNV_NB2MAX; ++i) {
+    xres[i] = splat(0.f);
+    const uint32_t o = pl.off[i];
+    if (o != ~0u && (whole || (tile < n_tiles && row0 + (int64_t)(o & 31u) < args.n))) xres[i] = ld4(base + (o & ~31u));
+  }
+}
+
 // PHASE = SnvFwdArgs::phase at compile time: the stage-split launches do not carry each other's code and registers
 template <int PHASE>
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdArgs args) {
@@ -252,7 +289,13 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator
   // layout, one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
   f32x4 xres[SNV_NB2MAX];
-  if (PHASE != 2) request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
+  X0Plan xplan;
+  if (PHASE == 1) {
+    xplan = x0_plan(args, args.tw_first, cgp, n16);
+    request_x0_planned(args, xplan, xres, blockIdx.x, args.tw_first, n_tiles, chv);
+  } else if (PHASE != 2) {
+    request_x0(args, xres, blockIdx.x, args.tw_first, n_tiles, cgp, n16, chv);
+  }
   const bool do_head = args.tw_last == 1 && PHASE != 1;
   // a first-stage launch runs one tower and one stage: its lane addressing / validity mask is tile-invariant
   const StageAddr sa_first = stage_setup(args.geom[args.tw_first], 0, P, n16, kk, mb, cgp);
@@ -326,7 +369,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         } else if (layer == 4 || layer == 9) {
           // a first-stage launch ends with this pooling: the residual registers are dead, so the next tile's stage-1
           // activations are requested now and their HBM latency hides under the pooling instead of stalling the next entry
-          if (PHASE == 1) request_x0(args, xres, tile + gridDim.x, tw_i, n_tiles, cgp, n16, chv);
+          if (PHASE == 1) request_x0_planned(args, xplan, xres, tile + gridDim.x, tw_i, n_tiles, chv);
           // max-pool (raw y in bufA) + BN (no ReLU) -> bufB in the next stage's geometry
           const int si = st - 1;  // input stage
           const int Lin = g.L[si], Lout = g.L[st], ScI = g.Sc[si], ScO = g.Sc[st];
