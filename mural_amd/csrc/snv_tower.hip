@@ -299,6 +299,12 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   const bool do_head = args.tw_last == 1 && PHASE != 1;
   // a first-stage launch runs one tower and one stage: its lane addressing / validity mask is tile-invariant
   const StageAddr sa_first = stage_setup(args.geom[args.tw_first], 0, P, n16, kk, mb, cgp);
+  // a short-stage launch runs one tower through stages 1 and 2: both lane maps are tile-invariant as well
+  StageAddr sa_s1 = sa_first, sa_s2 = sa_first;
+  if (PHASE == 2) {
+    sa_s1 = stage_setup(args.geom[args.tw_first], 1, P, n16, kk, mb, cgp);
+    sa_s2 = stage_setup(args.geom[args.tw_first], 2, P, n16, kk, mb, cgp);
+  }
 
   float a_cur[SNV_KSTEPS];
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
@@ -364,7 +370,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
             const int c = (k <= P) ? k * ScO : g.NC[1] + (k - P - 1);
             st4(bufB + lds_off(c + 1, task & 7), splat(0.f));
           }
-          sa = stage_setup(g, 1, P, n16, kk, mb, cgp);
+          sa = sa_s1;
           __syncthreads();
         } else if (layer == 4 || layer == 9) {
           // a first-stage launch ends with this pooling: the residual registers are dead, so the next tile's stage-1
@@ -383,13 +389,17 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
             const uint32_t p = g.dL[st].div(pj);
             const int jo = (int)(pj - p * (uint32_t)Lout);
             const int jlo = jo * ps - pp;
+            // window columns clamped into [lo, hi] = the in-range part of the window: a clamped read repeats a column that
+            // belongs to the window, so the maximum is unchanged and no -inf masking is needed (every window of the model
+            // overlaps its row: padding < kernel)
+            const int lo = jlo < 0 ? 0 : jlo;
+            const int hi = (jlo + pk - 1) < (Lin - 1) ? (jlo + pk - 1) : (Lin - 1);
             f32x4 v[7];
 #pragma unroll
             for (int w = 0; w < 7; ++w) {   // the model's pools are 7- and 3-wide: all reads in flight together
-              const int j = jlo + w;
-              const bool in = (w < pk) && j >= 0 && j < Lin;
-              v[w] = ld4(bufA + lds_off(1 + (int)p * ScI + (in ? j : 0) + 1, cg));
-              if (!in) v[w] = splat(-INFINITY);
+              int j = jlo + w;
+              j = j < lo ? lo : (j > hi ? hi : j);
+              v[w] = ld4(bufA + lds_off(1 + (int)p * ScI + j + 1, cg));
             }
             f32x4 m = max4(max4(max4(v[0], v[1]), max4(v[2], v[3])), max4(max4(v[4], v[5]), v[6]));
             for (int w = 7; w < pk; ++w) {
@@ -414,7 +424,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
               st4(bufB + lds_off(c + 1, task & 7), splat(0.f));
             }
           }
-          sa = stage_setup(g, st, P, n16, kk, mb, cgp);
+          sa = PHASE == 2 ? sa_s2 : stage_setup(g, st, P, n16, kk, mb, cgp);
           __syncthreads();
           SNV_STAMP((layer == 4 ? 5 : 7) + 12 * tw_i);   // max-pool 2 / 3
           if (args.taps != nullptr && tile == 0) {
