@@ -482,10 +482,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
           const int p = t >> 5, ch = t & 31;
           float v[8];
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {   // all reads in flight together (L4 is 7 / 8 at R = 1000)
-            const int pc = 1 + p * Sc4 + (j < L4 ? j : 0) + 1;
+          for (int j = 0; j < 8; ++j) {   // all reads in flight together (L4 is 7 / 8 at R = 1000); short rows repeat their last column
+            const int pc = 1 + p * Sc4 + (j < L4 ? j : L4 - 1) + 1;
             v[j] = bufA[lds_off(pc, ch >> 2) + (ch & 3)];
-            if (j >= L4) v[j] = -INFINITY;
           }
           float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
           for (int j = 8; j < L4; ++j) m = fmaxf(m, bufA[lds_off(1 + p * Sc4 + j + 1, ch >> 2) + (ch & 3)]);
