@@ -305,3 +305,35 @@ def test_train_batches_from_files_match_reference_pipeline_order(tmp_path):
     sh = list(ingest.train_batches_from_files(fa, bed, 7, r, 3, R, segment_center=400, sampled_segments=2, shuffle=True, generator=g))
     cat2 = torch.cat([b[2] for b in sh]).cpu().numpy()
     assert sorted(map(tuple, cat2.tolist())) == sorted(map(tuple, want_cat.tolist())) and not np.array_equal(cat2, want_cat)
+
+
+@pytest.mark.parametrize("name", ["snv_synth_S_net2.npz", "snv_synth_S_net0.npz", "snv_synth_R300_net2_c3.npz", "snv_pretrained_human_AT.npz"])
+def test_local_branch_mfma_kernel_on_golden_batches(name, monkeypatch):
+    """Batches under 4096 sites take the VALU kernel of the local branch; force the MFMA kernel on the same golden inputs
+    (ragged last tile, 3- and 4-class heads, the 13-column pretrained shape, Network0's raw logits)."""
+    if name not in SNV_FORWARD:
+        pytest.skip("fixture not present")
+    monkeypatch.setenv("MURAL_DEBUG_LOCAL_MFMA", "1")
+    test_forward_dense_matches_reference(name)
+
+
+def test_local_branch_kernels_agree_on_a_large_batch():
+    """>= 4096 sites: the MFMA kernel by default; it must agree with the VALU kernel (MURAL_DEBUG_LOCAL_VALU) to fp32 rounding."""
+    fx = U.load("snv_synth_S_net0.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    model = model.cuda().eval()
+    rng = np.random.default_rng(11)
+    n = 4096 * 3 + 17
+    cat = torch.from_numpy(rng.integers(0, 65, size=(n, int(fx["cat"].shape[1])))).cuda()
+    x = torch.zeros((n, 4, 2001), device="cuda")
+    cont = torch.zeros(n, 1, dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        a = model((cont, cat), x)
+        os.environ["MURAL_DEBUG_LOCAL_VALU"] = "1"
+        try:
+            b = model((cont, cat), x)
+        finally:
+            del os.environ["MURAL_DEBUG_LOCAL_VALU"]
+    assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
