@@ -337,3 +337,29 @@ def test_local_branch_kernels_agree_on_a_large_batch():
         finally:
             del os.environ["MURAL_DEBUG_LOCAL_VALU"]
     assert (a - b).abs().max().item() <= 2e-5 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("h1,h2,r,nc", [(40, 24, 7, 4), (16, 16, 3, 2), (200, 100, 10, 6)])
+def test_local_branch_other_widths_on_both_kernels(h1, h2, r, nc, monkeypatch):
+    """Local branch with other hidden widths / column counts / class counts (block grids 3x2, 1x1, 13x7) against the oracle, on
+    the VALU kernel (small batch) and on the MFMA kernel (forced)."""
+    hp = np.array([r, 3, 300, h1, h2, 32, 3, nc, 0])
+    model, _ = product_from_hp(hp)
+    orc = U.snv_oracle_from_hp(hp)
+    sd = synth.synth_state_dict(orc.state_dict(), 321)
+    model.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    model = model.cuda().eval()
+    orc.eval()
+    rng = np.random.default_rng(5)
+    n = 77
+    cat = rng.integers(0, 65, size=(n, 2 * r + 1 - 2)).astype(np.int64)
+    x = torch.zeros((n, 4, 601))
+    cont = torch.zeros(n, 1, dtype=torch.float64)
+    with torch.no_grad():
+        want = orc((cont, torch.from_numpy(cat)), x).numpy()
+        got_valu = model((cont.cuda(), torch.from_numpy(cat).cuda()), x.cuda()).cpu().numpy()
+        monkeypatch.setenv("MURAL_DEBUG_LOCAL_MFMA", "1")
+        got_mfma = model((cont.cuda(), torch.from_numpy(cat).cuda()), x.cuda()).cpu().numpy()
+    assert_probs_close(got_valu, want, 0, "valu")
+    assert_probs_close(got_mfma, want, 0, "mfma")
