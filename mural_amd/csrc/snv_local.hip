@@ -260,9 +260,8 @@ int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* ou
     d.dbg = getenv("MURAL_DEBUG_MLP") ? atoi(getenv("MURAL_DEBUG_MLP")) : 0;
     const size_t floats = (size_t)256 * (d.n1b * (d.K1p / 16) + d.n2b * (d.K2p / 16) + d.K3p / 16) + (size_t)LM_TP * (d.s1 + d.sx) +
                           (size_t)((L.emb_rows * 5 + 3) & ~3) + d.K2p + d.K3p + 16;
-    // small batches stay on the VALU kernel: the MFMA kernel stages 118 KB of fragments per workgroup before its first tile
-    const bool big = n >= 4096 || getenv("MURAL_DEBUG_LOCAL_MFMA");
-    if (big && L.n_class <= 16 && LM_TP * L.cols <= 4 * LOC_THREADS && floats * sizeof(float) <= 160 * 1024 && !getenv("MURAL_DEBUG_LOCAL_VALU")) {
+    // (the choice must not depend on the batch size: results are bitwise independent of how a site list is chunked)
+    if (L.n_class <= 16 && LM_TP * L.cols <= 4 * LOC_THREADS && floats * sizeof(float) <= 160 * 1024 && !getenv("MURAL_DEBUG_LOCAL_VALU")) {
       static bool attr_set = false;
       if (!attr_set) {
         MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_local_mlp_mfma),

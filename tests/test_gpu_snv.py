@@ -308,17 +308,18 @@ def test_train_batches_from_files_match_reference_pipeline_order(tmp_path):
 
 
 @pytest.mark.parametrize("name", ["snv_synth_S_net2.npz", "snv_synth_S_net0.npz", "snv_synth_R300_net2_c3.npz", "snv_pretrained_human_AT.npz"])
-def test_local_branch_mfma_kernel_on_golden_batches(name, monkeypatch):
-    """Batches under 4096 sites take the VALU kernel of the local branch; force the MFMA kernel on the same golden inputs
-    (ragged last tile, 3- and 4-class heads, the 13-column pretrained shape, Network0's raw logits)."""
+def test_local_branch_valu_kernel_on_golden_batches(name, monkeypatch):
+    """The local branch runs on the MFMA kernel whenever its weights fit LDS; the VALU kernel (the fallback for wider layers)
+    is forced here on the same golden inputs (ragged last tile, 3- and 4-class heads, the 13-column pretrained shape,
+    Network0's raw logits)."""
     if name not in SNV_FORWARD:
         pytest.skip("fixture not present")
-    monkeypatch.setenv("MURAL_DEBUG_LOCAL_MFMA", "1")
+    monkeypatch.setenv("MURAL_DEBUG_LOCAL_VALU", "1")
     test_forward_dense_matches_reference(name)
 
 
 def test_local_branch_kernels_agree_on_a_large_batch():
-    """>= 4096 sites: the MFMA kernel by default; it must agree with the VALU kernel (MURAL_DEBUG_LOCAL_VALU) to fp32 rounding."""
+    """The MFMA kernel (default) must agree with the VALU kernel (MURAL_DEBUG_LOCAL_VALU) to fp32 rounding on a large batch."""
     fx = U.load("snv_synth_S_net0.npz")
     model, _ = product_from_hp(fx["hp"])
     orc = U.snv_oracle_from_hp(fx["hp"])
@@ -341,8 +342,8 @@ def test_local_branch_kernels_agree_on_a_large_batch():
 
 @pytest.mark.parametrize("h1,h2,r,nc", [(40, 24, 7, 4), (16, 16, 3, 2), (200, 100, 10, 6)])
 def test_local_branch_other_widths_on_both_kernels(h1, h2, r, nc, monkeypatch):
-    """Local branch with other hidden widths / column counts / class counts (block grids 3x2, 1x1, 13x7) against the oracle, on
-    the VALU kernel (small batch) and on the MFMA kernel (forced)."""
+    """Local branch with other hidden widths / column counts / class counts (block grids 3x2, 1x1, 13x7: the last one does not
+    fit LDS and stays on the VALU kernel) against the oracle, on the default kernel and with the VALU kernel forced."""
     hp = np.array([r, 3, 300, h1, h2, 32, 3, nc, 0])
     model, _ = product_from_hp(hp)
     orc = U.snv_oracle_from_hp(hp)
@@ -358,8 +359,8 @@ def test_local_branch_other_widths_on_both_kernels(h1, h2, r, nc, monkeypatch):
     cont = torch.zeros(n, 1, dtype=torch.float64)
     with torch.no_grad():
         want = orc((cont, torch.from_numpy(cat)), x).numpy()
-        got_valu = model((cont.cuda(), torch.from_numpy(cat).cuda()), x.cuda()).cpu().numpy()
-        monkeypatch.setenv("MURAL_DEBUG_LOCAL_MFMA", "1")
         got_mfma = model((cont.cuda(), torch.from_numpy(cat).cuda()), x.cuda()).cpu().numpy()
+        monkeypatch.setenv("MURAL_DEBUG_LOCAL_VALU", "1")
+        got_valu = model((cont.cuda(), torch.from_numpy(cat).cuda()), x.cuda()).cpu().numpy()
     assert_probs_close(got_valu, want, 0, "valu")
     assert_probs_close(got_mfma, want, 0, "mfma")
