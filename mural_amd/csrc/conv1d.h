@@ -57,6 +57,9 @@ struct ConvBlockArgs {
 bool convblock_supported(int C);
 int convblock_tiles(int L, bool front);   // workgroups per row = entries per row of tail_max
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream);
+// fp32-MFMA version of the plain block (no front, no tail) for C = 16 / 24 (convblock_mfma.hip); launch_convblock routes to it
+bool convblock_mfma_supported(const ConvBlockArgs& a);
+int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream);
 
 // y[b][c] = max_l x[b][c][l]
 int launch_rowmax(const float* x, int64_t rows, int L, float* y, hipStream_t stream);

@@ -360,6 +360,7 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
     MURAL_REQUIRE(a.Cf * (262 / a.f_up + 3) <= CB_FRONT_FLOATS, "convblock: front input tile does not fit");
   }
   if (a.tail_max) MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
+  if (convblock_mfma_supported(a)) return launch_convblock_mfma(a, stream);
   if (a.tail_max && a.f_in) launch_convblock_t<true, true>(a, stream);
   else if (a.tail_max) launch_convblock_t<true, false>(a, stream);
   else if (a.f_in) launch_convblock_t<false, true>(a, stream);

@@ -1,0 +1,166 @@
+// Fused ConvBlock of the INDEL U-Net on fp32 MFMA (reference MuRaL/model/model_indel.py:6-19, eval mode, BatchNorms folded):
+//   out = x + W1 . SiLU(W5 * x + b5) + b1 [+ res2],   W5: k=5 conv C -> 2C, W1: 1x1 conv 2C -> C,   C = 16 or 24.
+// Same contract as convblock_kernel (conv1d.hip) for the blocks without front / tail; the packed-FMA version is bound by
+// vector-instruction issue (one v_pk_fma_f32 per 4 FLOP), here one v_mfma_f32_16x16x4_f32 does 2048 FLOP:
+//   GEMM 1  D1[hidden 16][position 16] += W5[hidden][(tap, ci)] * x[ci][position + tap - 2],  K = 5C in steps of 4 input channels
+//           of one tap; the B operand is one ds_read_b32 of the channel-major LDS tile (pitch = 16 mod 32) shared by the 2C/16
+//           hidden blocks.
+//   SiLU    on the accumulators.
+//   GEMM 2  D2[out 16][position 16] += W1[out][hidden] * h[hidden][position]: lane (position, kk) holds hidden channels
+//           16 mb + 4 kk + r in register r of block mb, which IS a B operand if k-step (mb, r) is defined to cover exactly those
+//           four channels (the order of the k-steps of a dot product is free) -- no shuffle, no LDS round trip.
+// Both weight matrices live in registers as A fragments for the whole workgroup lifetime (C = 24: 114 VGPRs).
+#include <cstdlib>
+
+#include "conv1d.h"
+#include "mfma_tile.h"
+
+namespace mural {
+namespace {
+
+constexpr int CM_TW = 256 + 8;     // tile: 256 positions + 4 columns each side (2 of them halo; 4 keeps float4 loads aligned)
+constexpr int CM_PITCH = 272;      // = 16 (mod 32) floats: the 16 positions x 4 channels of an operand read spread over all banks
+
+__device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
+template <int C>
+__global__ __launch_bounds__(256) void convblock_mfma_kernel(const ConvBlockArgs a) {
+  constexpr int C2 = 2 * C;
+  constexpr int MB1 = C2 / 16;           // hidden blocks
+  constexpr int CQ = C / 4;              // channel quads per tap
+  constexpr int KS1 = 5 * CQ;            // k-steps of GEMM 1
+  constexpr int MB2 = (C + 15) / 16;     // output blocks (C = 24: the second one is half empty)
+  constexpr int KS2 = 4 * MB1;           // k-steps of GEMM 2
+  __shared__ float tile[C * CM_PITCH];
+  __shared__ float otile[C * CM_PITCH];   // the block's outputs, streamed out as float4 rows once the tile is done
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
+
+  // A fragments: lane (m = n16, kk)
+  float a1[MB1][KS1], a2[MB2][KS2];
+#pragma unroll
+  for (int mb = 0; mb < MB1; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+      const int t = s / CQ, ci = 4 * (s % CQ) + kk;
+      a1[mb][s] = a.w5[(ci * 5 + t) * C2 + 16 * mb + n16];
+    }
+#pragma unroll
+  for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) {
+      const int h = 16 * (s >> 2) + 4 * kk + (s & 3), c = 16 * mb + n16;
+      a2[mb][s] = c < C ? a.w1[h * C + c] : 0.f;
+    }
+  // biases in accumulator layout: lane (position, kk), register r <-> row 16 mb + 4 kk + r
+  f32x4 bias1[MB1], bias2[MB2];
+#pragma unroll
+  for (int mb = 0; mb < MB1; ++mb) bias1[mb] = ld4(a.b5 + 16 * mb + 4 * kk);
+#pragma unroll
+  for (int mb = 0; mb < MB2; ++mb) {
+    const int c0 = 16 * mb + 4 * kk;
+    bias2[mb] = f32x4{c0 + 0 < C ? a.b1[c0 + 0] : 0.f, c0 + 1 < C ? a.b1[c0 + 1] : 0.f, c0 + 2 < C ? a.b1[c0 + 2] : 0.f,
+                      c0 + 3 < C ? a.b1[c0 + 3] : 0.f};
+  }
+
+  // persistent workgroup: the weight fragments are loaded once and serve every (row, tile) this workgroup walks
+  const int tiles_per_row = (a.L + 255) / 256;
+  const int64_t total_tiles = (int64_t)a.B * tiles_per_row;
+#pragma unroll 1
+  for (int64_t tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
+  const int b = (int)(tix / tiles_per_row);
+  const int l0 = (int)(tix - (int64_t)b * tiles_per_row) * 256;
+  __syncthreads();                                    // the previous tile is consumed
+  const float* src = a.x + (size_t)b * C * a.L;
+  if ((a.L & 3) == 0) {                               // rows start 16-byte aligned: float4 pieces of the tile, origin l0 - 4
+    constexpr int Q = CM_TW / 4;
+    for (int i = tid; i < C * Q; i += 256) {
+      const int ci = i / Q, q = i - ci * Q;
+      const int l = l0 - 4 + 4 * q;
+      const f32x4 v = (l >= 0 && l < a.L) ? ld4(src + (size_t)ci * a.L + l) : splat(0.f);
+      st4(tile + ci * CM_PITCH + 4 * q, v);
+    }
+  } else {
+    for (int i = tid; i < C * CM_TW; i += 256) {
+      const int ci = i / CM_TW, j = i - ci * CM_TW;
+      const int l = l0 - 4 + j;
+      tile[ci * CM_PITCH + j] = (l >= 0 && l < a.L) ? src[(size_t)ci * a.L + l] : 0.f;
+    }
+  }
+  __syncthreads();
+
+#pragma unroll 1
+  for (int pb = 0; pb < 4; ++pb) {
+    const int p = 64 * wave + 16 * pb + n16;          // tile-relative position of this lane's column
+    if (l0 + 64 * wave + 16 * pb >= a.L) break;       // wave-uniform: nothing of this block is inside the row
+    const float* xp = tile + kk * CM_PITCH + p + 2;   // x[ci = 4 cq + kk][p + t - 2] sits at xp[4 cq * pitch + t] (tile origin l0 - 4)
+    f32x4 acc1[MB1];
+#pragma unroll
+    for (int mb = 0; mb < MB1; ++mb) acc1[mb] = bias1[mb];
+#pragma unroll
+    for (int s = 0; s < KS1; ++s) {
+      const float bv = xp[4 * (s % CQ) * CM_PITCH + s / CQ];
+#pragma unroll
+      for (int mb = 0; mb < MB1; ++mb) acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mb][s], bv, acc1[mb], 0, 0, 0);
+    }
+    f32x4 acc2[MB2];
+#pragma unroll
+    for (int mb = 0; mb < MB2; ++mb) acc2[mb] = bias2[mb];
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) {
+      const float hv = silu_fast(acc1[s >> 2][s & 3]);
+#pragma unroll
+      for (int mb = 0; mb < MB2; ++mb) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb][s], hv, acc2[mb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int c = 16 * mb + 4 * kk + r;
+        if (c < C) otile[c * CM_PITCH + p] = tile[c * CM_PITCH + p + 4] + acc2[mb][r];
+      }
+  }
+  __syncthreads();
+  if ((a.L & 3) == 0) {
+    for (int i = tid; i < C * 64; i += 256) {
+      const int c = i >> 6, q = i & 63;
+      const int l = l0 + 4 * q;
+      if (l < a.L) {
+        const size_t o = ((size_t)b * C + c) * a.L + l;
+        f32x4 v = ld4(otile + c * CM_PITCH + 4 * q);
+        if (a.res2) v += ld4(a.res2 + o);
+        st4(a.out + o, v);
+      }
+    }
+  } else {
+    for (int i = tid; i < C * 256; i += 256) {
+      const int c = i >> 8, j = i & 255;
+      const int l = l0 + j;
+      if (l < a.L) {
+        const size_t o = ((size_t)b * C + c) * a.L + l;
+        float v = otile[c * CM_PITCH + j];
+        if (a.res2) v += a.res2[o];
+        a.out[o] = v;
+      }
+    }
+  }
+  }
+}
+
+}  // namespace
+
+bool convblock_mfma_supported(const ConvBlockArgs& a) {
+  return (a.C == 16 || a.C == 24) && !a.f_in && !a.tail_max && !getenv("MURAL_DEBUG_CONVBLOCK_VALU");
+}
+
+int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream) {
+  const int64_t tiles = (int64_t)a.B * ((a.L + 255) / 256);
+  const dim3 grid((unsigned)(tiles < 2048 ? tiles : 2048));
+  if (a.C == 16) hipLaunchKernelGGL(convblock_mfma_kernel<16>, grid, dim3(256), 0, stream, a);
+  else hipLaunchKernelGGL(convblock_mfma_kernel<24>, grid, dim3(256), 0, stream, a);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural
