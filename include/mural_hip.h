@@ -42,11 +42,20 @@ int mural_abi_version(void);
  *   nmask   : 32 bases per uint32, bit (i%32) set when the base is not one of ACGT
  * Bases outside [0, length) read as 'N' (the reference imputes chromosome ends with 'N',
  * MuRaL/data/preprocessing.py:682-695, :791-804).
+ * IUPAC ambiguity codes other than N (R Y M S W K B D H V; fractional one-hot columns in the reference,
+ * preprocessing.py:762-772) are rare and live in a sparse side table: their bit in nmask is set (the k-mer encoder
+ * treats them like N, :655-666) and (amb_pos, amb_sym) lists them in ascending position with their symbol
+ * MURAL_SYM_R .. MURAL_SYM_V.  The one-hot encoder and the fused forward resolve them through that table.
  * ---------------------------------------------------------------------------------------------- */
+enum { MURAL_SYM_A = 0, MURAL_SYM_C, MURAL_SYM_G, MURAL_SYM_T, MURAL_SYM_N, MURAL_SYM_R, MURAL_SYM_Y, MURAL_SYM_M,
+       MURAL_SYM_S, MURAL_SYM_W, MURAL_SYM_K, MURAL_SYM_B, MURAL_SYM_D, MURAL_SYM_H, MURAL_SYM_V };
 typedef struct {
   const uint32_t* packed2;   /* dev */
   const uint32_t* nmask;     /* dev */
   int64_t length;            /* bases in this chromosome */
+  const int64_t* amb_pos;    /* dev, ascending positions of non-N ambiguity codes (NULL when n_amb == 0) */
+  const uint8_t* amb_sym;    /* dev, MURAL_SYM_R .. MURAL_SYM_V per entry */
+  int64_t n_amb;
 } MuralGenome;
 
 /* Replaces seq_digit_encoder (MuRaL/data/preprocessing.py:636-723) for one site per row.
@@ -55,7 +64,8 @@ typedef struct {
 int mural_encode_kmer(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
                       int32_t radius, int32_t order, int32_t indel, int64_t* out, void* stream);
 
-/* Replaces seq_ohe_encoder (MuRaL/data/preprocessing.py:756-816) for packed (ACGT/N) genomes.
+/* Replaces seq_ohe_encoder (MuRaL/data/preprocessing.py:756-816): one-hot columns, 0.25 x 4 for N and the
+ * fractional columns of the other IUPAC codes (:762-772, complemented on the '-' strand :774-788).
  * out: dev float [n][4][2*radius + (indel?0:1)].                                                   */
 int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
                         int32_t radius, int32_t indel, float* out, void* stream);
@@ -118,7 +128,8 @@ size_t mural_snv_workspace_bytes(const MuralSnvModel* m, int64_t n, int32_t dens
  * distal_x: dev float [n][4][distal_len] contiguous (ignored for model_no 0).
  * out: dev float [n][n_class] -- log-probabilities (Network1/2) or raw logits (Network0).
  * status: dev int32[1], set to MURAL_E_ENCODING by the kernels if a distal column is not a MuRaL
- * encoding (caller checks after synchronising); may be NULL.                                       */
+ * encoding; while it is set the call's output is overwritten with NaN, so the failure is visible
+ * without a host round trip (the caller reads and clears the word whenever it synchronises); may be NULL. */
 int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
                             float* out, void* workspace, size_t workspace_bytes, int32_t* status, void* stream);
 
@@ -280,10 +291,11 @@ int mural_profile_end(double* total_ms, int64_t* launches);
  * (offset = byte offset of the first sequence line).  n_records = records in the file (may exceed n_cap).           */
 int mural_fasta_scan(const char* path, int64_t n_cap, int32_t name_cap, char* names, int64_t* lengths,
                      int64_t* offsets, int64_t* n_records);
-/* Pack one record into the MuralGenome format; amb_pos receives the positions of IUPAC codes other than N (n_amb
- * counts all of them); any non-nucleotide character is MURAL_E_INVALID (the reference raises KeyError).             */
+/* Pack one record into the MuralGenome format; amb_pos / amb_sym receive the positions and MURAL_SYM_* symbols of IUPAC
+ * codes other than N (up to amb_cap; n_amb counts all of them); any non-nucleotide character is MURAL_E_INVALID (the
+ * reference raises KeyError).                                                                                        */
 int mural_fasta_pack(const char* path, int64_t offset, int64_t length, uint32_t* packed2, uint32_t* nmask,
-                     int64_t* amb_pos, int64_t amb_cap, int64_t* n_amb);
+                     int64_t* amb_pos, uint8_t* amb_sym, int64_t amb_cap, int64_t* n_amb);
 /* Six-column BED (chrom start end name score strand); chrom_id indexes chrom_names (order of first appearance);
  * strand: 0 '+', 1 '-'; score = class label.  cap = 0 counts rows / chromosomes.                                    */
 int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, int64_t* start, int64_t* end, float* score,

@@ -18,7 +18,8 @@ _f32p = C.POINTER(C.c_float)
 
 
 class MuralGenome(C.Structure):
-    _fields_ = [("packed2", C.c_void_p), ("nmask", C.c_void_p), ("length", C.c_int64)]
+    _fields_ = [("packed2", C.c_void_p), ("nmask", C.c_void_p), ("length", C.c_int64), ("amb_pos", C.c_void_p),
+                ("amb_sym", C.c_void_p), ("n_amb", C.c_int64)]
 
 
 class MuralBN(C.Structure):
@@ -91,7 +92,7 @@ PROTOTYPES = {
     "mural_op_maxpool_bwd_needs_zero": (C.c_int, [I32, I32]),
     "mural_op_maxpool_bwd": (C.c_int, [VP, VP, I64, I32, I32, I32, I32, I32, VP, VP]),
     "mural_fasta_scan": (C.c_int, [C.c_char_p, I64, I32, VP, VP, VP, VP]),
-    "mural_fasta_pack": (C.c_int, [C.c_char_p, I64, I64, VP, VP, VP, I64, VP]),
+    "mural_fasta_pack": (C.c_int, [C.c_char_p, I64, I64, VP, VP, VP, VP, I64, VP]),
     "mural_bed_read": (C.c_int, [C.c_char_p, I64, VP, VP, VP, VP, VP, I32, I32, VP, VP, VP]),
     "mural_bed_segment_order": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP]),
     "mural_eval_kmer_keys": (C.c_int, [VP, I64, I32, I32, I32, I32, I64, I64, VP, VP, VP]),

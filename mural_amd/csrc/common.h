@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -30,6 +31,24 @@ void set_error(const char* fmt, ...);
     }                                       \
   } while (0)
 
+// hipFuncAttributeMaxDynamicSharedMemorySize belongs to (kernel, device): a launch site raises it once per device ordinal
+// (never inside a stream capture after the first call on that device).  Thread-safe; setting it twice is harmless.
+struct DynLdsOnce {
+  std::atomic<uint64_t> done{0};
+  template <typename... Fn>
+  int ensure(Fn... fns) {
+    int dev = 0;
+    MURAL_HIP_CHECK(hipGetDevice(&dev));
+    const uint64_t bit = dev < 64 ? (1ull << dev) : 0ull;
+    if (bit && (done.load(std::memory_order_acquire) & bit)) return MURAL_OK;
+    const void* list[] = {reinterpret_cast<const void*>(fns)...};
+    for (const void* f : list)
+      MURAL_HIP_CHECK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    done.fetch_or(bit, std::memory_order_release);
+    return MURAL_OK;
+  }
+};
+
 // symbols of the in-LDS base alphabet
 enum : uint8_t { SYM_A = 0, SYM_C = 1, SYM_G = 2, SYM_T = 3, SYM_N = 4, SYM_PAD = 15, SYM_BAD = 255 };
 constexpr int N_SYM = 16;
@@ -56,6 +75,48 @@ __device__ __forceinline__ uint32_t genome_sym(const uint32_t* __restrict__ pack
   uint32_t m = nmask[g >> 5];
   uint32_t two = (w >> (2u * (uint32_t)(g & 15))) & 3u;
   return ((m >> (uint32_t)(g & 31)) & 1u) ? (uint32_t)SYM_N : two;
+}
+
+// first index of the ascending side table with amb_pos[i] >= key (plain binary search, one thread)
+__device__ __forceinline__ int64_t amb_lower_bound(const int64_t* __restrict__ amb_pos, int64_t n, int64_t key) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t mid = (lo + hi) >> 1;
+    if (amb_pos[mid] < key) lo = mid + 1; else hi = mid;
+  }
+  return lo;
+}
+
+// the same bound found by a whole wave: 64 probes per round, wave-uniform result
+__device__ __forceinline__ int64_t amb_lower_bound_wave(const int64_t* __restrict__ amb_pos, int64_t n, int64_t key, int lane) {
+  int64_t lo = 0, hi = n;
+  while (lo < hi) {
+    const int64_t step = (hi - lo + 63) >> 6;
+    const int64_t idx = lo + (int64_t)lane * step;
+    const bool less = idx < hi && amb_pos[idx] < key;
+    const int cnt = __popcll(__ballot(less));          // the table ascends: `less` lanes form a prefix
+    if (cnt == 0) {
+      hi = lo;
+    } else {
+      const int64_t nhi = lo + (int64_t)cnt * step;
+      lo = lo + (int64_t)(cnt - 1) * step + 1;
+      hi = nhi < hi ? nhi : hi;
+    }
+  }
+  return lo;
+}
+
+// symbol of genome position g with IUPAC codes resolved through the side table (strand-agnostic, forward symbol)
+__device__ __forceinline__ uint32_t genome_sym_iupac(const MuralGenome& gn, int64_t g) {
+  if (g < 0 || g >= gn.length) return SYM_N;
+  const uint32_t w = gn.packed2[g >> 4];
+  const uint32_t m = gn.nmask[g >> 5];
+  if (((m >> (uint32_t)(g & 31)) & 1u) == 0u) return (w >> (2u * (uint32_t)(g & 15))) & 3u;
+  if (gn.n_amb > 0) {
+    const int64_t i = amb_lower_bound(gn.amb_pos, gn.n_amb, g);
+    if (i < gn.n_amb && gn.amb_pos[i] == g) return gn.amb_sym[i];
+  }
+  return SYM_N;
 }
 
 // complement within the 16-symbol alphabet (A<->T, C<->G, N, R<->Y, M<->K, S, W, B<->V, D<->H, PAD)

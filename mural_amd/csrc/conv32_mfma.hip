@@ -641,12 +641,8 @@ extern "C" int mural_op_conv32_wgrad(const float* dy, const float* x, int64_t B,
   size_t lds = (size_t)(2 * C32 * C32_PITCH + 2 * C32) * 4;
   const size_t lds_red = (size_t)4 * (C32 * C32 * 3 + C32) * 4;     // the in-workgroup reduction reuses the image space
   lds = lds > lds_red ? lds : lds_red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad32_mfma_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static DynLdsOnce big_lds;
+  if (int rc = big_lds.ensure(&wgrad32_mfma_kernel)) return rc;
   hipLaunchKernelGGL(wgrad32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);
   hipLaunchKernelGGL(part_reduce_kernel, dim3((C32 * C32 * 3 + C32 + 63) / 64), dim3(1024), 0, stream, part, grid,
                      C32 * C32 * 3, C32, dW, db);
@@ -676,12 +672,8 @@ extern "C" int mural_op_conv32_bwd(const float* dy, const float* x, const float*
   size_t lds = (size_t)(2 * C32 * C32_PITCH + C32_AUX) * 4;
   const size_t lds_red = (size_t)4 * (C32 * C32 * 3 + C32) * 4;
   lds = lds > lds_red ? lds : lds_red;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&bwd32_mfma_kernel),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static DynLdsOnce big_lds;
+  if (int rc = big_lds.ensure(&bwd32_mfma_kernel)) return rc;
   hipLaunchKernelGGL(bwd32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);
   hipLaunchKernelGGL(part_reduce_kernel, dim3((C32 * C32 * 3 + C32 + 63) / 64), dim3(1024), 0, stream, part, grid,
                      C32 * C32 * 3, C32, dW, db);

@@ -51,12 +51,15 @@ __global__ void encode_onehot_kernel(MuralGenome g, const int64_t* __restrict__ 
     const int j = (int)(i - row * width);
     const int64_t ws = pos[row] + off;
     const bool neg = strand[row] != 0;
-    uint32_t s = neg ? genome_sym(g.packed2, g.nmask, g.length, ws + (width - 1 - j))
-                     : genome_sym(g.packed2, g.nmask, g.length, ws + j);
+    uint32_t s = genome_sym_iupac(g, neg ? ws + (width - 1 - j) : ws + j);
     if (neg) s = sym_complement(s);
     float* o = out + row * 4 * (int64_t)width + j;
+    // channel set of the symbol (bit ch = base ch is possible): one-hot, pairs 0.5, triples 1/3, N 0.25 (preprocessing.py:758-772)
+    const uint32_t set = (0xF7BDEC963A5F8421ull >> (4u * s)) & 0xFu;
+    const int members = __popc(set);
+    const float v = members == 1 ? 1.0f : members == 2 ? 0.5f : members == 3 ? (float)(1.0 / 3.0) : 0.25f;
 #pragma unroll
-    for (int ch = 0; ch < 4; ++ch) o[(int64_t)ch * width] = (s > 3u) ? 0.25f : (s == (uint32_t)ch ? 1.0f : 0.0f);
+    for (int ch = 0; ch < 4; ++ch) o[(int64_t)ch * width] = ((set >> ch) & 1u) ? v : 0.0f;
   }
 }
 
@@ -139,6 +142,21 @@ __global__ __launch_bounds__(256) void dense_to_symbols_kernel(const float* __re
   }
 }
 
+// A flagged encoding error makes the call's output loud without a host round trip: every value becomes NaN.
+__global__ void poison_on_status_kernel(float* __restrict__ out, int64_t total, const int32_t* __restrict__ status) {
+  if (*status == 0) return;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
+    out[i] = __builtin_nanf("");
+}
+
+int launch_poison_on_status(float* out, int64_t total, const int32_t* status, hipStream_t stream) {
+  if (total == 0 || !status) return MURAL_OK;
+  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(poison_on_status_kernel, dim3(grid), dim3(256), 0, stream, out, total, status);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream) {
   const int64_t total = n * L;
   if (total == 0) return MURAL_OK;
@@ -156,7 +174,7 @@ int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int3
 using namespace mural;
 
 extern "C" const char* mural_last_error(void) { return mural::last_error_cstr(); }
-extern "C" int mural_abi_version(void) { return 1; }
+extern "C" int mural_abi_version(void) { return 2; }
 
 static int window_geometry(int radius, int indel, int* off, int* width) {
   MURAL_REQUIRE(radius >= 1, "radius must be >= 1, got %d", radius);
@@ -187,6 +205,7 @@ extern "C" int mural_encode_kmer(const MuralGenome* g, const int64_t* pos, const
 extern "C" int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
                                    int32_t radius, int32_t indel, float* out, void* stream) {
   MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
+  MURAL_REQUIRE(g->n_amb == 0 || (g->amb_pos && g->amb_sym), "genome: n_amb > 0 needs amb_pos and amb_sym");
   int off, width;
   if (int rc = window_geometry(radius, indel, &off, &width)) return rc;
   if (n == 0) return MURAL_OK;

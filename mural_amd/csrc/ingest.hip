@@ -42,21 +42,15 @@ struct MappedFile {
   }
 };
 
-// 0..3 = A C G T (either case), 4 = N, 5 = other IUPAC ambiguity code, 255 = not a nucleotide character
+// MURAL_SYM_* of a character (either case): 0..3 = A C G T, 4 = N, 5..14 = R Y M S W K B D H V; 255 = not a nucleotide code
 struct BaseTable {
   uint8_t t[256];
   BaseTable() {
     std::memset(t, 255, sizeof(t));
-    const char* acgt = "ACGT";
-    for (int i = 0; i < 4; ++i) {
-      t[(unsigned char)acgt[i]] = (uint8_t)i;
-      t[(unsigned char)std::tolower(acgt[i])] = (uint8_t)i;
-    }
-    const char* amb = "NRYMSWKBDHV";
-    for (const char* p = amb; *p; ++p) {
-      const uint8_t v = (*p == 'N') ? 4 : 5;
-      t[(unsigned char)*p] = v;
-      t[(unsigned char)std::tolower(*p)] = v;
+    const char* alphabet = "ACGTNRYMSWKBDHV";
+    for (int i = 0; alphabet[i]; ++i) {
+      t[(unsigned char)alphabet[i]] = (uint8_t)i;
+      t[(unsigned char)std::tolower(alphabet[i])] = (uint8_t)i;
     }
   }
 };
@@ -120,11 +114,11 @@ extern "C" int mural_fasta_scan(const char* path, int64_t n_cap, int32_t name_ca
 
 // Pack one record (starting at byte `offset`, `length` bases) into the device format of include/mural_hip.h:
 // packed2: ceil(length/16) words (A0 C1 G2 T3, 2 bits per base), nmask: ceil(length/32) words (bit set = not ACGT).
-// Positions of IUPAC codes other than N are reported in amb_pos (up to amb_cap; n_amb counts all of them): windows that
-// overlap them need the dense encoders (fractional one-hot columns).  Any other character is an error, like the
-// reference's dict lookups (KeyError).
+// Positions and symbols of IUPAC codes other than N are reported in amb_pos / amb_sym (up to amb_cap; n_amb counts all of
+// them): the side table of MuralGenome (fractional one-hot columns, preprocessing.py:762-772).  Any other character is an
+// error, like the reference's dict lookups (KeyError).
 extern "C" int mural_fasta_pack(const char* path, int64_t offset, int64_t length, uint32_t* packed2, uint32_t* nmask,
-                                int64_t* amb_pos, int64_t amb_cap, int64_t* n_amb) {
+                                int64_t* amb_pos, uint8_t* amb_sym, int64_t amb_cap, int64_t* n_amb) {
   MURAL_REQUIRE(path && packed2 && nmask, "NULL argument");
   MappedFile f;
   if (!f.open(path)) {
@@ -153,8 +147,11 @@ extern "C" int mural_fasta_pack(const char* path, int64_t offset, int64_t length
       packed2[i >> 4] |= (uint32_t)code << (2 * (i & 15));
     } else {
       nmask[i >> 5] |= 1u << (i & 31);
-      if (code == 5) {
-        if (amb_pos && amb < amb_cap) amb_pos[amb] = i;
+      if (code > 4) {
+        if (amb < amb_cap) {
+          if (amb_pos) amb_pos[amb] = i;
+          if (amb_sym) amb_sym[amb] = code;
+        }
         ++amb;
       }
     }

@@ -262,12 +262,8 @@ int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* ou
                           (size_t)((L.emb_rows * 5 + 3) & ~3) + d.K2p + d.K3p + 16;
     // (the choice must not depend on the batch size: results are bitwise independent of how a site list is chunked)
     if (L.n_class <= 16 && LM_TP * L.cols <= 4 * LOC_THREADS && floats * sizeof(float) <= 160 * 1024 && !getenv("MURAL_DEBUG_LOCAL_VALU")) {
-      static bool attr_set = false;
-      if (!attr_set) {
-        MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_local_mlp_mfma),
-                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        attr_set = true;
-      }
+      static DynLdsOnce big_lds;
+      if (int rc = big_lds.ensure(&snv_local_mlp_mfma)) return rc;
       const int64_t n_tiles = (n + LM_TP - 1) / LM_TP;
       const int grid = (int)(n_tiles < 256 ? n_tiles : 256);
       hipLaunchKernelGGL(snv_local_mlp_mfma, dim3(grid), dim3(LOC_THREADS), floats * sizeof(float), stream, L, cat, n, out, d);

@@ -14,6 +14,7 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream);
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream);
+int launch_poison_on_status(float* out, int64_t total, const int32_t* status, hipStream_t stream);
 
 namespace {
 
@@ -523,7 +524,8 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
   if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * m->args.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * m->args.nbuf);
   Stage1Args s1 = m->s1;
   s1.codes = w.symbols;
-  return run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, stream);
+  if (int rc = run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, stream)) return rc;
+  return launch_poison_on_status(out, n * sh.n_class, status, stream);
 }
 
 extern "C" int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
@@ -543,6 +545,7 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
                                         float* out, void* workspace, size_t workspace_bytes, void* stream_) {
   MURAL_REQUIRE(m, "model handle is NULL");
   MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
+  MURAL_REQUIRE(g->n_amb == 0 || (g->amb_pos && g->amb_sym), "genome: n_amb > 0 needs amb_pos and amb_sym");
   MURAL_REQUIRE(n >= 0, "negative batch");
   if (n == 0) return MURAL_OK;
   MURAL_REQUIRE(pos && strand && out, "pos/strand/out must not be NULL");

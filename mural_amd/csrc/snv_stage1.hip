@@ -167,6 +167,16 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
           }
         }
       }
+      if (args.genome.n_amb > 0) {            // IUPAC codes of the side table overwrite the N the mask produced
+        const int64_t e0 = amb_lower_bound_wave(args.genome.amb_pos, args.genome.n_amb, ws, lane);
+        for (int64_t e = e0 + lane; e < args.genome.n_amb; e += 64) {
+          const int64_t gpos = args.genome.amb_pos[e];
+          if (gpos >= ws + Lwin) break;
+          uint32_t sym = args.genome.amb_sym[e];
+          if (neg) sym = sym_complement(sym);
+          cb[(int)(neg ? (ws + Lwin - 1 - gpos) : (gpos - ws)) + 1] = (uint8_t)sym;
+        }
+      }
     } else {
       const uint8_t* src = args.codes + row * Lwin;
       for (int jj = lane; jj < Lwin + 2; jj += 64) {
@@ -360,12 +370,8 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
   using KernelFn = void (*)(const FirstTrainArgs);
   KernelFn fn = slot == 4 ? (bwd ? first_train_kernel<4, true> : first_train_kernel<4, false>)
                           : (bwd ? first_train_kernel<16, true> : first_train_kernel<16, false>);
-  static bool attr_set[4] = {false, false, false, false};   // once per instantiation (and never inside a graph capture)
-  const int which = (slot == 4 ? 0 : 2) + (bwd ? 1 : 0);
-  if (!attr_set[which]) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set[which] = true;
-  }
+  static DynLdsOnce big_lds[4];                             // once per instantiation and device (never inside a graph capture)
+  if (int rc = big_lds[(slot == 4 ? 0 : 2) + (bwd ? 1 : 0)].ensure(fn)) return rc;
   hipLaunchKernelGGL(fn, dim3(first_train_grid(a.B)), dim3(S1_THREADS), lds, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
@@ -373,14 +379,8 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
 
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream) {
   if (a.n == 0) return MURAL_OK;
-  static bool attr_set = false;
-  if (!attr_set) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_stage1_kernel<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_stage1_kernel<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static DynLdsOnce big_lds;
+  if (int rc = big_lds.ensure(&snv_stage1_kernel<0>, &snv_stage1_kernel<1>)) return rc;
   const int64_t want = (a.n + S1_WAVES - 1) / S1_WAVES;
   const int grid = (int)(want < 256 ? want : 256);   // one 16-wave workgroup per CU, persistent
   if (packed)

@@ -607,16 +607,8 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
     const size_t v = (size_t)atol(e);
     if (a.phase == 1 && v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<0>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<1>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&snv_towers_fused<2>),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    attr_set = true;
-  }
+  static DynLdsOnce big_lds;
+  if (int rc = big_lds.ensure(&snv_towers_fused<0>, &snv_towers_fused<1>, &snv_towers_fused<2>)) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof.on) {
     while (g_prof.ev.size() < g_prof.used + 2) {

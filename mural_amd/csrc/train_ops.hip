@@ -1017,12 +1017,8 @@ static bool linear_tile_fits(int K, int N, size_t* lds) {
 static int launch_linear_tile(const float* x, const float* W, int trans, const float* bias, int64_t B, int K, int N,
                               float* y, size_t lds, hipStream_t stream) {
   if (lds > 64 * 1024) {
-    static bool attr_set = false;
-    if (!attr_set) {
-      MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_mfma_kernel),
-                                          hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-      attr_set = true;
-    }
+    static DynLdsOnce big_lds;
+    if (int rc = big_lds.ensure(&linear_mfma_kernel)) return rc;
   }
   hipLaunchKernelGGL(linear_mfma_kernel, dim3((unsigned)((B + 63) / 64)), dim3(256), lds, stream, x, W, trans, bias, B, K, N, y);
   MURAL_HIP_CHECK(hipGetLastError());

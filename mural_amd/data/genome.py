@@ -6,8 +6,9 @@ resident in HBM; windows are decoded inside the kernels.
 
 Format (also documented in include/mural_hip.h): ``packed2`` holds 16 bases per uint32, base i in bits
 [2*(i%16), +2) with A0 C1 G2 T3; ``nmask`` holds 32 bases per uint32, bit (i%32) set when the base is not ACGT.
-IUPAC ambiguity codes other than N cannot be represented: ``pack_sequence`` reports their positions so that a caller
-can route windows that overlap them through the dense encoders (fractional one-hot columns, :762-772).
+IUPAC ambiguity codes other than N (fractional one-hot columns in the reference, :762-772) are rare: their mask bit is set
+(the k-mer encoder treats them like N, :655-666) and a sparse side table ``(amb_pos ascending, amb_sym)`` travels with the
+genome; the one-hot encoder and the fused forward resolve them through it.
 """
 import ctypes as C
 
@@ -16,17 +17,15 @@ import torch
 
 from .. import _lib
 
+SYMBOLS = "ACGTNRYMSWKBDHV"          # MURAL_SYM_* of include/mural_hip.h = index in this string
 _CODE = np.full(256, 255, dtype=np.uint8)
-for _i, _ch in enumerate("ACGT"):
+for _i, _ch in enumerate(SYMBOLS):
     _CODE[ord(_ch)] = _i
     _CODE[ord(_ch.lower())] = _i
-for _ch in "NRYMSWKBDHV":
-    _CODE[ord(_ch)] = 4 if _ch == "N" else 5
-    _CODE[ord(_ch.lower())] = 4 if _ch == "N" else 5
 
 
 def pack_sequence(seq):
-    """str/bytes -> (packed2 uint32[], nmask uint32[], length, positions of non-N ambiguity codes)."""
+    """str/bytes -> (packed2 uint32[], nmask uint32[], length, (positions, symbols) of non-N ambiguity codes)."""
     raw = np.frombuffer(seq.encode("ascii") if isinstance(seq, str) else bytes(seq), dtype=np.uint8)
     codes = _CODE[raw]
     if (codes == 255).any():
@@ -39,7 +38,8 @@ def pack_sequence(seq):
     m = (codes >= 4).astype(np.uint32)
     m = np.concatenate([m, np.zeros((-n) % 32, np.uint32)]).reshape(-1, 32)
     mask = np.bitwise_or.reduce(m << np.arange(32, dtype=np.uint32)[None, :], axis=1).astype(np.uint32)
-    return packed, mask, n, np.nonzero(codes == 5)[0].astype(np.int64)
+    amb = np.nonzero(codes > 4)[0].astype(np.int64)
+    return packed, mask, n, (amb, codes[amb].astype(np.uint8))
 
 
 class PackedGenome:
@@ -51,7 +51,16 @@ class PackedGenome:
         # int32 views: torch has no uint32 arithmetic, the kernels reinterpret the bits
         self.packed2 = torch.from_numpy(np.ascontiguousarray(packed2).view(np.int32)).to(self.device)
         self.nmask = torch.from_numpy(np.ascontiguousarray(nmask).view(np.int32)).to(self.device)
-        self.ambiguous = np.zeros(0, np.int64) if ambiguous is None else ambiguous
+        # side table of IUPAC codes other than N: (ascending positions int64, MURAL_SYM_* uint8)
+        amb_pos, amb_sym = (np.zeros(0, np.int64), np.zeros(0, np.uint8)) if ambiguous is None else ambiguous
+        amb_pos, amb_sym = np.asarray(amb_pos, np.int64), np.asarray(amb_sym, np.uint8)
+        if amb_pos.shape != amb_sym.shape or (len(amb_pos) > 1 and (np.diff(amb_pos) <= 0).any()):
+            raise ValueError("ambiguity table: positions must ascend strictly and match the symbols in length")
+        if len(amb_sym) and (amb_sym.min() < 5 or amb_sym.max() > 14):
+            raise ValueError("ambiguity table: symbols must be MURAL_SYM_R .. MURAL_SYM_V (5..14)")
+        self.ambiguous = (amb_pos, amb_sym)
+        self.amb_pos = torch.from_numpy(amb_pos).to(self.device) if len(amb_pos) else None
+        self.amb_sym = torch.from_numpy(amb_sym).to(self.device) if len(amb_pos) else None
 
     @classmethod
     def from_sequence(cls, seq, device="cuda"):
@@ -61,7 +70,10 @@ class PackedGenome:
     def as_struct(self, device=None):
         if device is not None and torch.device(device) != self.packed2.device:
             raise RuntimeError(f"genome lives on {self.packed2.device}, model on {device}")
-        return _lib.MuralGenome(self.packed2.data_ptr(), self.nmask.data_ptr(), self.length)
+        if self.amb_pos is None:
+            return _lib.MuralGenome(self.packed2.data_ptr(), self.nmask.data_ptr(), self.length, None, None, 0)
+        return _lib.MuralGenome(self.packed2.data_ptr(), self.nmask.data_ptr(), self.length, self.amb_pos.data_ptr(),
+                                self.amb_sym.data_ptr(), self.amb_pos.shape[0])
 
     # ------------------------------------------------------------------------------------------------
     def _prep(self, pos, strand):
@@ -86,7 +98,8 @@ class PackedGenome:
         return out
 
     def encode_onehot(self, pos, strand, radius, model_type="snv"):
-        """float32 (n, 4, W) one-hot windows (N -> 0.25 each), exact w.r.t. seq_ohe_encoder on ACGT/N genomes."""
+        """float32 (n, 4, W) one-hot windows (N -> 0.25 each, other IUPAC codes -> their fractional columns), exact w.r.t.
+        seq_ohe_encoder."""
         if model_type not in ("snv", "indel"):
             raise ValueError(f"model_type {model_type} not supported!")
         pos, strand = self._prep(pos, strand)

@@ -46,7 +46,7 @@ def scan_fasta(path):
 
 
 def pack_fasta_record(path, rec):
-    """(packed2 uint32[], nmask uint32[], length, positions of non-N ambiguity codes) of one record -- the same
+    """(packed2 uint32[], nmask uint32[], length, (positions, symbols) of non-N ambiguity codes) of one record -- the same
     contract as ``genome.pack_sequence`` on the record's sequence string."""
     path = os.fspath(path)
     packed = np.zeros((rec.length + 15) // 16, np.uint32)
@@ -54,11 +54,11 @@ def pack_fasta_record(path, rec):
     n_amb = C.c_int64(0)
     cap = 1024
     while True:
-        amb = np.zeros(cap, np.int64)
+        amb, sym = np.zeros(cap, np.int64), np.zeros(cap, np.uint8)
         _lib.check(_lib.lib().mural_fasta_pack(path.encode(), rec.offset, rec.length, packed.ctypes.data, mask.ctypes.data,
-                                              amb.ctypes.data, cap, C.byref(n_amb)))
+                                              amb.ctypes.data, sym.ctypes.data, cap, C.byref(n_amb)))
         if n_amb.value <= cap:
-            return packed, mask, rec.length, amb[:n_amb.value].copy()
+            return packed, mask, rec.length, (amb[:n_amb.value].copy(), sym[:n_amb.value].copy())
         cap = int(n_amb.value)
 
 
@@ -122,41 +122,12 @@ def predict_bed(model, fasta_path, bed_path, local_radius, local_order=3, distal
     ``end``, ``strand`` ('+'/'-'), ``label`` and ``prob`` (n, n_class) = softmax of the model output (run_predict.py:214).
 
     SNV sites must share one focal base after strand complement within every (segment, strand) group, as the reference
-    enforces (preprocessing.py:479-484; it exits, this raises ValueError)."""
-    sites = read_bed(bed_path)
-    order, group = bed_order(sites, segment_center)
-    used = {sites.chrom_names[c] for c in np.unique(sites.chrom_id)}
-    genomes = read_fasta(fasta_path, device, names=used)
-    missing = used - set(genomes)
-    if missing:
-        raise KeyError(sorted(missing)[0])      # the reference's seq_records[chrom] lookup
-    cid, start, strand = sites.chrom_id[order], sites.start[order], sites.strand[order]
-    probs = torch.empty((len(order), model.n_class), dtype=torch.float32, device=device)
-    focal = np.zeros(len(order), np.int64)
-    model = model.to(device).eval()
-    with torch.no_grad():
-        for c in np.unique(cid):             # every chromosome's rows are contiguous in bed_reader order
-            rows = np.nonzero(cid == c)[0]
-            g = genomes[sites.chrom_names[c]]
-            for r0 in range(0, len(rows), batch_sites):
-                sel = rows[r0:r0 + batch_sites]
-                pos = torch.from_numpy(start[sel]).to(device)
-                st = torch.from_numpy(strand[sel]).to(device)
-                if model_type == "snv":
-                    focal[sel] = g.encode_kmer(pos, st, 1, 1)[:, 1].cpu().numpy()     # strand-complemented focal base
-                    out = model.forward_packed(g, pos, st, local_radius=local_radius, local_order=local_order)
-                else:
-                    out = model.forward_packed(g, pos, st, distal_radius)
-                probs[torch.from_numpy(sel).to(device)] = torch.softmax(out, dim=1)
-    if model_type == "snv" and len(order):
-        first = np.r_[True, group[1:] != group[:-1]]                       # group ids are non-decreasing in this order
-        ref = focal[np.maximum.accumulate(np.where(first, np.arange(len(order)), 0))]
-        if (focal != ref).any():
-            raise ValueError("The positions in input BED file have different bases (A/T and C/G mixed)! The ref_genome or "
-                             "input BED file could be wrong.")
-    return {"chrom": np.asarray(sites.chrom_names, dtype=object)[cid], "start": start, "end": sites.end[order],
-            "strand": np.where(strand == 1, "-", "+"), "label": sites.score[order], "prob": probs.cpu().numpy(),
-            "order": order}
+    enforces for every SNV input (preprocessing.py:479-484 through the order-1 pass of prepare_local_data, :400; it exits,
+    this raises ValueError).  This is the one-process case of ``mural_amd.predict.predict_bed_sharded``: chromosomes are
+    streamed through the device one at a time."""
+    from ..predict import HipShardForward, predict_bed_sharded
+    fwd = HipShardForward(model, fasta_path, local_radius, local_order, distal_radius, device, batch_sites, model_type)
+    return predict_bed_sharded(fwd, bed_path, segment_center, model_type)
 
 
 

@@ -57,8 +57,29 @@ class UNet_Small(nn.Module):
         self._ws = None
 
     # ------------------------------------------------------------------------------------------------------
+    # The folded eval-mode copy is rebuilt when a parameter changed through torch and on every event that can change
+    # parameters or BatchNorm buffers behind torch's back (train()/eval() transitions: the training kernels and graph replays
+    # update running statistics without bumping tensor versions; load_state_dict; .to()) -- same policy as model_snv.py.
+    def invalidate_folded(self):
+        self._release()
+        self._plist = None
+
+    def train(self, mode=True):
+        self.invalidate_folded()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_folded()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_folded()
+        return super().load_state_dict(*args, **kwargs)
+
     def _state_key(self):
-        return tuple((t.data_ptr(), t._version) for t in list(self.parameters()) + list(self.buffers()))
+        if getattr(self, "_plist", None) is None:
+            self._plist = list(self.parameters())
+        return tuple([(t.data_ptr(), t._version) for t in self._plist])
 
     def _params(self, keep):
         def ptr(t):

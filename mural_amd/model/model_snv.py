@@ -125,27 +125,54 @@ class _HipSnvBase(nn.Module):
         self._handle_key = None
         self._ws = None
         self._status = None
+        self._status_host = None    # pinned copy of the encoding status of earlier calls (read one call late)
+        self._status_event = None
         self._fused = None          # None: not probed yet; False: this shape takes the per-layer path (generic_eval.py)
+        self._plist = None
 
     # -- description of this model for the C side ------------------------------------------------------------
     def _shape_and_params(self):
         raise NotImplementedError
 
+    # The folded eval-mode copy (BatchNorm statistics folded into weights, first-layer tables, MFMA fragments) is rebuilt
+    # when a parameter changed through torch (data_ptr / _version of the ~100 parameters) and on every event that can change
+    # parameters or BatchNorm buffers behind torch's back: a train()/eval() transition (the training kernels and a replayed
+    # HIP graph update weights and running statistics without bumping tensor versions), load_state_dict, .to()/_apply.
+    def invalidate_folded(self):
+        """Force the next eval-mode forward to rebuild the folded weights (call after changing buffers by hand)."""
+        self._handle_key = None
+        self._plist = None
+
+    def train(self, mode=True):
+        self.invalidate_folded()
+        return super().train(mode)
+
+    def _apply(self, fn, *args, **kwargs):
+        self.invalidate_folded()
+        return super()._apply(fn, *args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        self.invalidate_folded()
+        return super().load_state_dict(*args, **kwargs)
+
     def _state_key(self):
-        key = []
-        for t in list(self.parameters()) + list(self.buffers()):
-            key.append((t.data_ptr(), t._version))
-        return tuple(key)
+        if self._plist is None:
+            self._plist = list(self.parameters())
+        return tuple([(t.data_ptr(), t._version) for t in self._plist])
 
     def _get_handle(self):
+        """Folded device copy of the parameters; must be called under ``torch.cuda.device(model device)``."""
+        key = self._handle_key
+        if self._handle is not None and key is not None:
+            if key == self._state_key():
+                return self._handle
         key = self._state_key()
-        if self._handle is None or key != self._handle_key:
-            self._release()
-            shape, params, keep = self._shape_and_params()
-            h = C.c_void_p()
-            _lib.check(_lib.lib().mural_snv_model_create(C.byref(shape), C.byref(params), C.byref(h)))
-            del keep
-            self._handle, self._handle_key = h, key
+        self._release()
+        shape, params, keep = self._shape_and_params()
+        h = C.c_void_p()
+        _lib.check(_lib.lib().mural_snv_model_create(C.byref(shape), C.byref(params), C.byref(h)))
+        del keep
+        self._handle, self._handle_key = h, key
         return self._handle
 
     def _fused_ok(self):
@@ -153,7 +180,8 @@ class _HipSnvBase(nn.Module):
         too long for LDS): the C side refuses the model and eval takes one HIP launch per layer instead."""
         if self._fused is None:
             try:
-                self._get_handle()
+                with torch.cuda.device(self._device()):
+                    self._get_handle()
                 self._fused = True
             except ValueError:
                 self._fused = False
@@ -175,6 +203,31 @@ class _HipSnvBase(nn.Module):
         if self._ws is None or self._ws.numel() < need or self._ws.device != device:
             self._ws = torch.empty(need, dtype=torch.uint8, device=device)
         return self._ws
+
+    # -- encoding status of the dense entry, read without draining the device --------------------------------
+    _ENC_MSG = ("distal_input holds a column that is not a MuRaL one-hot / IUPAC-fraction encoding "
+                "(preprocessing.py:758-772); the HIP path consumes sequence encodings only")
+
+    def check_encoding(self, wait=True):
+        """Raise ValueError if an earlier dense forward saw a column that is not a sequence encoding.  The kernels flag it
+        in a device word and overwrite that call's output with NaN; the word travels to pinned host memory behind the launches
+        and is looked at here: without blocking at the start of the next forward, blocking when `wait` (model_predict_m does
+        that once at the end of its loop)."""
+        if self._status is None:
+            return
+        if wait:                               # authoritative: the device word itself (drains the stream)
+            bad = int(self._status.item()) != 0
+            self._status_event = None
+        else:
+            ev = self._status_event
+            if ev is None or not ev.query():
+                return
+            self._status_event = None
+            bad = int(self._status_host[0]) != 0
+        if bad:
+            self._status_host.zero_()
+            self._status.zero_()
+            raise ValueError(self._ENC_MSG)
 
     def _device(self):
         return next(self.parameters()).device
@@ -219,14 +272,16 @@ class _HipSnvBase(nn.Module):
             ws = self._workspace(max(n, 1), dev)
             stream = _lib.current_stream_ptr(dev)
             if taps is None:
+                self.check_encoding(wait=False)
                 if self._status is None or self._status.device != dev:
                     self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+                    self._status_host = torch.zeros(1, dtype=torch.int32).pin_memory()
                 _lib.check(_lib.lib().mural_snv_forward_dense(handle, cat_ptr, dist_ptr, n, out.data_ptr(), ws.data_ptr(),
                                                              ws.numel(), self._status.data_ptr(), stream))
-                if self.model_no != 0 and int(self._status.item()) != 0:
-                    self._status.zero_()
-                    raise ValueError("distal_input holds a column that is not a MuRaL one-hot / IUPAC-fraction encoding "
-                                     "(preprocessing.py:758-772); the HIP path consumes sequence encodings only")
+                if self.model_no != 0 and self._status_event is None and not torch.cuda.is_current_stream_capturing():
+                    self._status_host.copy_(self._status, non_blocking=True)
+                    self._status_event = torch.cuda.Event()
+                    self._status_event.record()
             else:
                 _lib.check(_lib.lib().mural_snv_debug_taps(handle, cat_ptr, dist_ptr, n, out.data_ptr(), ws.data_ptr(),
                                                           ws.numel(), taps.data_ptr(), taps.numel(), stream))

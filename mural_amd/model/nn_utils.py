@@ -5,8 +5,9 @@
   * ``weights_init``    -- nn_utils.py:14-35 (xavier-uniform convs, kaiming-normal linears, zero biases), applied with
                            ``model.apply`` like training.py:324.
   * ``model_predict_m`` -- nn_utils.py:37-76: returns ``(pred_y (N, n_class) on device, total_loss float)``; the loss
-                           is accumulated on the device and read back ONCE (the reference syncs per batch, :65) and the
-                           outputs are concatenated once (the reference re-copies the growing tensor per batch, :62).
+                           is accumulated on the device and read back ONCE (the reference syncs per batch, :65), the
+                           outputs are concatenated once (the reference re-copies the growing tensor per batch, :62) and
+                           small loader batches are fused into one launch.
 """
 import inspect
 
@@ -70,25 +71,54 @@ def model_choice(model_no, config, common_model_config, model_type):
     return model(**{p: adapt(p) for p in names})
 
 
-def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, model_type="snv"):
-    """Run the model over an iterable of (y, cont_x, cat_x, distal_x) batches."""
+def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, model_type="snv", fuse_rows=8192):
+    """Run the model over an iterable of (y, cont_x, cat_x, distal_x) batches.
+
+    The reference launches one forward per loader batch (default 16 rows, commands/predict.py:90); a 16-row launch leaves
+    the GPU idle, so consecutive loader batches are concatenated until `fuse_rows` rows are waiting and evaluated by ONE
+    forward.  Results are unchanged: rows keep their order, eval-mode outputs do not depend on the batch they are computed in,
+    and the loss is the sum of the per-batch criterion values (taken on the slices when the criterion does not sum)."""
     device = torch.device(device)
     model.to(device)
     model.eval()
     outs = []
     loss_acc = torch.zeros((), dtype=torch.float64, device=device)
+    additive = getattr(criterion, "reduction", None) == "sum"
+    pending, rows = [], 0
+
+    def flush():
+        nonlocal pending, rows
+        if not pending:
+            return
+        cat4 = lambda k: torch.cat([b[k] for b in pending], dim=0).to(device, non_blocking=True) if len(pending) > 1 \
+            else pending[0][k].to(device, non_blocking=True)
+        y, cont_x, cat_x, distal_x = cat4(0), cat4(1), cat4(2), cat4(3)
+        if model_type == "snv":
+            preds = model.forward((cont_x, cat_x), distal_x) if distal else model.forward(cont_x, cat_x)
+        else:
+            preds = model.forward(distal_x)
+        outs.append(preds)
+        target = y.long().squeeze(1)
+        if additive or len(pending) == 1:
+            loss_acc.add_(criterion(preds, target).double())
+        else:
+            o = 0
+            for b in pending:
+                n = b[0].shape[0]
+                loss_acc.add_(criterion(preds[o:o + n], target[o:o + n]).double())
+                o += n
+        pending, rows = [], 0
+
     with torch.no_grad():
-        for y, cont_x, cat_x, distal_x in dataloader:
-            cat_x = cat_x.to(device, non_blocking=True)
-            cont_x = cont_x.to(device, non_blocking=True)
-            distal_x = distal_x.to(device, non_blocking=True)
-            y = y.to(device, non_blocking=True)
-            if model_type == "snv":
-                preds = model.forward((cont_x, cat_x), distal_x) if distal else model.forward(cont_x, cat_x)
-            else:
-                preds = model.forward(distal_x)
-            outs.append(preds)
-            loss_acc += criterion(preds, y.long().squeeze(1)).double()
+        for batch in dataloader:
+            pending.append(batch)
+            rows += batch[0].shape[0]
+            if rows >= fuse_rows:
+                flush()
+        flush()
+    check = getattr(getattr(model, "model", model), "check_encoding", None)     # Network0 wraps its body in .model
+    if check is not None:
+        check(wait=True)
     pred_y = torch.cat(outs, dim=0) if outs else torch.empty(0, n_class, device=device)
     return pred_y, float(loss_acc.item())
 

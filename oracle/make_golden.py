@@ -226,6 +226,18 @@ def g3_pretrained(ref):
         arrays = {"w::" + k: v for k, v in unique_state(sd).items()}
         save(f"snv_pretrained_{tag}.npz", codes=codes, cat=cat, logp=out,
              hp=np.array([r, 3, R, 150, 75, 32, 3, 4], np.int64), **arrays)
+    # the other two shipped human SNV models (models/Homo_sapiens/SNV/README:3-16; BASELINE config 5 runs all three); their own
+    # generator keeps the two fixtures above byte-stable
+    rng = np.random.default_rng(3031)
+    for tag, path, r, R, B in [("human_CpG", "models/Homo_sapiens/SNV/CpG", 7, 1000, 32),
+                               ("human_nonCpG", "models/Homo_sapiens/SNV/nonCpG", 7, 1000, 32)]:
+        sd = torch.load(os.path.join(REF, path, "model"), map_location="cpu")
+        cfg, common = snv_cfg(r, R)
+        codes, cat = snv_inputs(rng, B, r, R)
+        _, out = run_ref_snv(ref, 2, cfg, common, sd, codes, cat)
+        arrays = {"w::" + k: v for k, v in unique_state(sd).items()}
+        save(f"snv_pretrained_{tag}.npz", codes=codes, cat=cat, logp=out,
+             hp=np.array([r, 3, R, 150, 75, 32, 3, 4], np.int64), **arrays)
 
 
 def g45_synth(ref):
@@ -330,6 +342,21 @@ def g8_indel(ref):
             out = model(codes_to_onehot(codes)).numpy()
         save(f"indel_{tag}.npz", codes=codes, out=out, seed=np.array(seed),
              hp=np.array([R, 8, 7, n_class, int(rev)], np.int64), down=np.array([1, 4, 5, 5, 5, 2], np.int64))
+    # the shipped 2-class, L = 4000 checkpoint (models/Arabidopsis_thaliana/INDEL/insertion); own generator, see g3
+    rng = np.random.default_rng(8081)
+    R, n_class, rev, B = 2000, 2, True, 6
+    sd = torch.load(os.path.join(REF, "models/Arabidopsis_thaliana/INDEL/insertion", "model"), map_location="cpu")
+    cfg = dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=[1, 4, 5, 5, 5, 2], use_reverse=rev)
+    model = quiet(ref.nn_utils.model_choice, 0, cfg, dict(n_class=n_class), "indel")
+    model.load_state_dict(sd)
+    model.eval()
+    codes = rng.integers(0, 4, size=(B, 2 * R)).astype(np.uint8)
+    codes[1, 100:160] = 4
+    codes[2, 2000] = 9
+    with torch.no_grad():
+        out = model(codes_to_onehot(codes)).numpy()
+    save("indel_pretrained_arabidopsis_insertion.npz", codes=codes, out=out, hp=np.array([R, 8, 7, n_class, int(rev)], np.int64),
+         down=np.array([1, 4, 5, 5, 5, 2], np.int64), **{"w::" + k: v.numpy() for k, v in sd.items()})
 
 
 # ------------------------------------------------------------------------------------------ G9 / G10

@@ -51,3 +51,110 @@ def test_sharded_predict_world2(n):
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
     assert all(shape == (n, 4) for _, _, shape in res)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# file-level sharded driver (mural_amd.predict.predict_bed_sharded): per-chromosome shards, per-rank blocks, one gather per
+# shard, rank-0 sink -- host logic on CPU with a stand-in for the HIP forward
+# ------------------------------------------------------------------------------------------------------------------
+def _write_bed(path, unsorted=False, mixed=False):
+    import numpy as np
+    rng = np.random.default_rng(5)
+    rows = []
+    for chrom, n in (("chr1", 157), ("chr10", 1), ("chr2", 64)):
+        for p in np.sort(rng.choice(20000, size=n, replace=False)):
+            rows.append((chrom, int(p), "+-"[int(p) % 2], int(p) % 4))
+    if unsorted:                                    # chr1 rows come back after chr10: its rows form two shards
+        rows = rows[:100] + rows[157:158] + rows[100:157] + rows[158:]
+    with open(path, "w") as fh:
+        for c, p, st, lab in rows:
+            fh.write(f"{c}\t{p}\t{p + 1}\t.\t{lab}\t{st}\n")
+    return rows
+
+
+def _fake_shard_forward(calls, mixed_at=None):
+    import numpy as np
+
+    def fwd(chrom, pos, strand):
+        calls.append((chrom, len(pos)))
+        h = (pos.astype(np.float64) * 0.001 + len(chrom) + strand.astype(np.float64) * 0.5)
+        logits = np.stack([np.sin(h), np.cos(h), np.sin(2 * h), np.cos(3 * h)], axis=1)
+        prob = np.exp(logits) / np.exp(logits).sum(axis=1, keepdims=True)
+        focal = np.zeros(len(pos))
+        if mixed_at is not None:
+            focal[pos == mixed_at] = 1
+        return torch.from_numpy(np.concatenate([prob, focal[:, None]], axis=1).astype(np.float32))
+    return fwd
+
+
+def _bed_worker(rank, world, port, bed, out_path, unsorted, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from mural_amd.predict import TsvSink, predict_bed_sharded, shard_bounds
+        calls = []
+        sink = TsvSink(out_path) if rank == 0 else None
+        res = predict_bed_sharded(_fake_shard_forward(calls), bed, segment_center=3000, sink=sink)
+        solo = []
+        want = _fake_shard_forward(solo)
+        ok = True
+        for chrom in np.unique(res["chrom"]):
+            sel = res["chrom"] == chrom
+            w = want(chrom, res["start"][sel], (res["strand"][sel] == "-").astype(np.uint8)).numpy()[:, :4]
+            ok &= bool(np.array_equal(res["prob"][sel], w))
+        # this rank evaluated only its block of every shard
+        n_shards = 4 if unsorted else 3
+        ok &= len(calls) == n_shards
+        sizes = [100, 1, 57, 64] if unsorted else [157, 1, 64]
+        for (c, n), total in zip(calls, sizes):
+            lo, hi = shard_bounds(total, rank, world)
+            ok &= n == hi - lo
+        q.put((rank, bool(ok), len(res["start"])))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("unsorted", [False, True])
+def test_predict_bed_sharded_world2(tmp_path, unsorted):
+    import numpy as np
+    import pandas as pd
+    from mural_amd.data.ingest import write_predictions
+    from mural_amd.predict import predict_bed_sharded
+    bed = str(tmp_path / "s.bed")
+    rows = _write_bed(bed, unsorted=unsorted)
+    out_path = str(tmp_path / "pred.tsv")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bed_worker, args=(r, 2, port, bed, out_path, unsorted, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(n == len(rows) for _, _, n in res)
+    # the streamed table of rank 0 == the single-process table written in one go
+    solo = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000)
+    want_path = str(tmp_path / "want.tsv")
+    write_predictions(solo, want_path)
+    got, want = pd.read_csv(out_path, sep="\t"), pd.read_csv(want_path, sep="\t")
+    assert list(got.columns) == list(want.columns) and len(got) == len(rows)
+    assert got.equals(want)
+    assert open(out_path).read() == open(want_path).read()
+
+
+def test_predict_bed_sharded_focal_check_and_empty(tmp_path):
+    from mural_amd.predict import TsvSink, predict_bed_sharded
+    bed = str(tmp_path / "s.bed")
+    rows = _write_bed(bed)
+    with pytest.raises(ValueError, match="different bases"):
+        predict_bed_sharded(_fake_shard_forward([], mixed_at=rows[30][1]), bed, segment_center=3000)
+    empty = str(tmp_path / "empty.bed")
+    open(empty, "w").close()
+    sink = TsvSink(str(tmp_path / "e.tsv"))
+    res = predict_bed_sharded(_fake_shard_forward([]), empty, sink=sink)
+    assert len(res["start"]) == 0
+    assert open(tmp_path / "e.tsv").read().startswith("chrom\tstart\tend\tstrand\tmut_type")

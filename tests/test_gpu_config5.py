@@ -1,0 +1,96 @@
+"""GPU parity for BASELINE config 5 (whole-genome SNV predict with the shipped Homo_sapiens weights, sharded): the same
+driver the 8-rank run uses, here at world size 1 with the REAL HIP forward -- site-level (ShardedPredictor / predict_sites)
+and file-level (predict_bed_sharded + HipShardForward + TsvSink) -- against the oracle model fed by the oracle encoders.
+The multi-rank host logic (block partition, one gather per shard, sink) is covered on CPU by tests/test_dist_gloo.py."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encode_ref
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-5
+HUMAN = ["snv_pretrained_human_AT.npz", "snv_pretrained_human_CpG.npz", "snv_pretrained_human_nonCpG.npz"]
+
+
+def _models(name):
+    from tests.test_gpu_snv import product_from_hp
+    fx = U.load(name)
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    sd = U.snv_state_for(fx, orc)
+    model.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    orc.eval()
+    return model.cuda().eval(), orc, int(fx["hp"][0]), int(fx["hp"][2])
+
+
+def _genome(rng, n, iupac=True):
+    alphabet = b"ACGTNRYKV" if iupac else b"ACGTN"
+    p = [.2465, .2465, .2465, .2465, .01, .001, .001, .001, .001] if iupac else [.2475, .2475, .2475, .2475, .01]
+    return rng.choice(np.frombuffer(alphabet, np.uint8), size=n, p=p).tobytes().decode()
+
+
+def _oracle_probs(orc, seq, pos, neg, r, R):
+    codes = encode_ref.seq_to_codes(seq)
+    sym = ["-" if v else "+" for v in neg]
+    cat = torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, r, 3))
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R))
+    with torch.no_grad():
+        return torch.softmax(orc((torch.zeros(len(pos), 1, dtype=torch.float64), cat), x), dim=1).numpy()
+
+
+@pytest.mark.parametrize("name", HUMAN)
+def test_sharded_predictor_real_forward_matches_oracle(name):
+    from mural_amd.data import PackedGenome
+    from mural_amd.predict import ShardedPredictor
+    model, orc, r, R = _models(name)
+    rng = np.random.default_rng(55)
+    seq = _genome(rng, 30_000)
+    pos = np.sort(rng.choice(len(seq), size=300, replace=False))
+    neg = rng.integers(0, 2, size=len(pos)).astype(np.uint8)
+    sp = ShardedPredictor(model, PackedGenome.from_sequence(seq, "cuda"), local_radius=r, local_order=3)
+    got = torch.softmax(sp(torch.from_numpy(pos).cuda(), torch.from_numpy(neg).cuda()), dim=1).cpu().numpy()
+    assert np.abs(got - _oracle_probs(orc, seq, pos, neg, r, R)).max() <= PROB_TOL
+
+
+def test_file_level_sharded_driver_streams_chromosomes(tmp_path):
+    """FASTA + BED -> per-chromosome shards -> sorted prediction table, with IUPAC codes in the genome."""
+    import pandas as pd
+    from mural_amd.data.ingest import write_predictions
+    from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
+    model, orc, r, R = _models(HUMAN[0])
+    rng = np.random.default_rng(56)
+    seqs = {"chr1": _genome(rng, 9000), "chr2": _genome(rng, 6000), "chrX": _genome(rng, 4000)}
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">{k}\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for k, s in seqs.items()))
+    rows = []
+    for name, s in seqs.items():                        # A on '+', T on '-': one focal base after complement
+        arr = np.frombuffer(s.encode(), np.uint8)
+        for p in np.sort(rng.choice(len(s), size=250, replace=False)):
+            if arr[p] == ord("A"):
+                rows.append((name, int(p), "+"))
+            elif arr[p] == ord("T"):
+                rows.append((name, int(p), "-"))
+    bed = tmp_path / "s.bed"
+    bed.write_text("".join(f"{c}\t{p}\t{p + 1}\t.\t{i % 4}\t{st}\n" for i, (c, p, st) in enumerate(rows)))
+    fwd = HipShardForward(model, fa, local_radius=r, local_order=3, batch_sites=64)
+    loaded = []
+    inner = fwd.genome
+    fwd.genome = lambda chrom: (loaded.append(chrom), inner(chrom))[1]
+    out = tmp_path / "pred.tsv"
+    res = predict_bed_sharded(fwd, bed, segment_center=2000, sink=TsvSink(out))
+    assert [c for i, c in enumerate(loaded) if i == 0 or loaded[i - 1] != c] == ["chr1", "chr2", "chrX"]
+    assert fwd._resident[0] == "chrX"                   # exactly one chromosome is resident at a time
+    assert len(res["start"]) == len(rows)
+    for name, s in seqs.items():
+        sel = res["chrom"] == name
+        want = _oracle_probs(orc, s, res["start"][sel], res["strand"][sel] == "-", r, R)
+        assert np.abs(res["prob"][sel] - want).max() <= PROB_TOL, name
+    want_path = tmp_path / "want.tsv"
+    write_predictions(res, want_path)
+    assert open(out).read() == open(want_path).read()
+    df = pd.read_csv(out, sep="\t")
+    assert df[["chrom", "start"]].equals(df[["chrom", "start"]].sort_values(["chrom", "start"]).reset_index(drop=True))

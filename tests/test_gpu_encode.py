@@ -34,21 +34,47 @@ def test_kmer_bit_exact_vs_reference_vectors(enc, model_type):
 
 @pytest.mark.parametrize("model_type", ["snv", "indel"])
 def test_onehot_exact(enc, model_type):
+    """Every row equals the reference's seq_ohe_encoder output, including the windows that hold the ten IUPAC codes other than
+    N of the G1 string (fractional columns, preprocessing.py:762-772; complemented on the '-' strand)."""
     fx, seq, genome = enc
+    assert len(genome.ambiguous[0]) == 10
     codes = encode_ref.seq_to_codes(seq)
-    codes_n = np.where(codes > 4, 4, codes)            # the packed format stores ambiguity codes as N
-    starts = fx["starts"]
-    strand = fx["strands"]
+    for neg in (False, True):
+        sel = fx["strands"].astype(bool) == neg
+        starts = fx["starts"][sel]
+        strand = np.full(len(starts), int(neg), np.uint8)
+        tag = "neg" if neg else "pos"
+        for R in (100, 1000):
+            got = genome.encode_onehot(starts, strand, R, model_type).cpu().numpy()
+            assert list(got.shape) == fx[f"ohesum_{model_type}_{tag}_R{R}"].tolist()
+            w = (np.arange(got.shape[2], dtype=np.float64) % 97 + 1.0)
+            assert np.array_equal((got.astype(np.float64) * w[None, None, :]).sum(axis=2), fx[f"ohechk_{model_type}_{tag}_R{R}"])
+            if R == 100:
+                want = fx[f"ohe_{model_type}_{tag}_R{R}"]
+                assert np.array_equal(got, want)
+                frac = ((want != 0) & (want != 1) & (want != 0.25)).any(axis=(1, 2))
+                assert frac.sum() >= 3           # the comparison does cover IUPAC windows
+            assert np.array_equal(got, encode_ref.onehot_encode(codes, starts, ["-" if neg else "+"] * len(starts), R, model_type))
+
+
+def test_iupac_side_table_dense_genome():
+    """Many ambiguity codes (beyond one 64-entry probe round of the wave search), both strands, chromosome edges."""
+    from mural_amd.data import PackedGenome
+    rng = np.random.default_rng(11)
+    n = 40_000
+    raw = rng.choice(np.frombuffer(b"ACGTNRYMSWKBDHVacgtnryk", np.uint8), size=n,
+                     p=[.2, .2, .2, .2, .02] + [.01] * 10 + [.02] * 4 + [.0] * 4)
+    seq = raw.tobytes().decode()
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    assert len(genome.ambiguous[0]) > 3000
+    codes = encode_ref.seq_to_codes(seq)
+    pos = np.r_[rng.integers(0, n, size=200), [0, 1, n - 1, n - 2]]
+    strand = rng.integers(0, 2, size=len(pos)).astype(np.uint8)
     sym = ["-" if s else "+" for s in strand]
-    for R in (100, 1000):
-        got = genome.encode_onehot(starts, strand, R, model_type).cpu().numpy()
-        want_n = encode_ref.onehot_encode(codes_n, starts, sym, R, model_type)
-        assert np.array_equal(got, want_n)
-        # rows whose window holds no ambiguity code other than N equal the reference's own output
-        want = encode_ref.onehot_encode(codes, starts, sym, R, model_type)
-        clean = (want == want_n).all(axis=(1, 2))
-        assert clean.sum() >= 3 or R == 1000
-        assert np.array_equal(got[clean], want[clean])
+    for R, mt in ((100, "snv"), (1000, "snv"), (300, "indel")):
+        got = genome.encode_onehot(pos, strand, R, mt).cpu().numpy()
+        assert np.array_equal(got, encode_ref.onehot_encode(codes, pos, sym, R, mt))
+    assert np.array_equal(genome.encode_kmer(pos, strand, 7, 3).cpu().numpy(), encode_ref.kmer_encode(codes, pos, sym, 7, 3))
 
 
 def test_large_random_genome_roundtrip():

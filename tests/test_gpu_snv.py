@@ -120,13 +120,91 @@ def test_forward_packed_matches_oracle(cfg):
     assert_probs_close(got, want, model_no, str(cfg))
 
 
+@pytest.mark.parametrize("R", [100, 1000])
+def test_forward_packed_iupac_windows_match_reference_encoding(R):
+    """The G1 string holds R Y M S W K B D H V: the packed path must evaluate them as the reference's fractional one-hot columns
+    (preprocessing.py:762-772), not as N.  Expected = oracle model on the reference's own encoder output (R = 100: the golden
+    tensors of seq_ohe_encoder themselves; R = 1000: the oracle encoder, which the golden check sums pin)."""
+    from mural_amd.data import PackedGenome
+    fx = U.load("encode.npz")
+    seq = fx["seq"].tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    r = 7
+    orc = snv_ref.build(2, local_radius=r, distal_radius=R)
+    sd = synth.synth_state_dict(orc.state_dict(), 91)
+    orc.load_state_dict(sd)
+    orc.eval()
+    model, _ = product_from_hp(np.array([r, 3, R, 150, 75, 32, 3, 4, 2]))
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    n_frac = 0
+    for neg in (False, True):
+        tag = "neg" if neg else "pos"
+        starts = fx["starts"][fx["strands"].astype(bool) == neg]
+        sym = ["-" if neg else "+"] * len(starts)
+        x = fx[f"ohe_snv_{tag}_R{R}"] if R == 100 else encode_ref.onehot_encode(codes, starts, sym, R)
+        cat = fx[f"kmer_snv_{tag}_r{r}_k3"]
+        with torch.no_grad():
+            want = orc((torch.zeros(len(starts), 1, dtype=torch.float64), torch.from_numpy(cat)), torch.from_numpy(x)).numpy()
+            as_n = orc((torch.zeros(len(starts), 1, dtype=torch.float64), torch.from_numpy(cat)),
+                       torch.from_numpy(encode_ref.onehot_encode(np.where(codes > 4, 4, codes), starts, sym, R))).numpy()
+        got = model.forward_packed(genome, torch.from_numpy(starts).cuda(),
+                                   torch.full((len(starts),), int(neg), dtype=torch.uint8).cuda(), local_radius=r,
+                                   local_order=3).cpu().numpy()
+        assert_probs_close(got, want, 2, f"iupac {tag} R{R}")
+        n_frac += int((np.abs(np.exp(want) - np.exp(as_n)).max(axis=1) > 1e-4).sum())
+    assert n_frac >= 3        # the fixture does distinguish "IUPAC as fractions" from "IUPAC as N"
+
+
+def test_forward_packed_many_ambiguity_codes():
+    """A genome with thousands of IUPAC codes: every window overlaps several side-table entries (multi-round wave search)."""
+    from mural_amd.data import PackedGenome
+    rng = np.random.default_rng(12)
+    n, r, R, n_sites = 50_000, 10, 1000, 150
+    raw = rng.choice(np.frombuffer(b"ACGTNRYMSWKBDHV", np.uint8), size=n, p=[.23, .23, .23, .23, .01] + [.007] * 10)
+    seq = raw.tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = rng.integers(0, n, size=n_sites)
+    pos[:4] = [0, 2, n - 1, n - 3]
+    strand = rng.integers(0, 2, size=n_sites).astype(np.uint8)
+    sym = ["-" if s else "+" for s in strand]
+    orc = snv_ref.build(2, local_radius=r, distal_radius=R)
+    sd = synth.synth_state_dict(orc.state_dict(), 92)
+    orc.load_state_dict(sd)
+    orc.eval()
+    model, _ = product_from_hp(np.array([r, 3, R, 150, 75, 32, 3, 4, 2]))
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    with torch.no_grad():
+        want = orc((torch.zeros(n_sites, 1, dtype=torch.float64), torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, r, 3))),
+                   torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R))).numpy()
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    got = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r,
+                               local_order=3).cpu().numpy()
+    assert_probs_close(got, want, 2, "dense ambiguity")
+
+
 def test_rejects_non_encoding_input():
     fx = U.load("snv_synth_T_net2.npz")
     model, _ = product_from_hp(fx["hp"])
     model = model.cuda().eval()
     x = torch.rand(4, 4, 201, device="cuda")
-    with pytest.raises(ValueError):
-        model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), x)
+    # the check does not drain the device: the call's output is NaN and the error surfaces at check_encoding() / a later call
+    out = model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), x)
+    assert torch.isnan(out).all()
+    with pytest.raises(ValueError, match="not a MuRaL"):
+        model.check_encoding()
+    good = U.onehot(np.zeros((4, 201), np.uint8)).cuda()
+    out = model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), good)
+    model.check_encoding()
+    assert torch.isfinite(out).all()
+    model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), x)
+    torch.cuda.synchronize()
+    with pytest.raises(ValueError, match="not a MuRaL"):      # picked up without blocking by the next forward
+        for _ in range(3):
+            model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), good)
+            torch.cuda.synchronize()
     with pytest.raises(AssertionError):
         model((torch.zeros(4, 1).cuda(), torch.zeros(4, 9, dtype=torch.long).cuda()), torch.zeros(4, 4, 199).cuda())
 

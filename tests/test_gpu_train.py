@@ -180,6 +180,45 @@ def test_graphed_train_step_matches_eager():
         step.finish()
 
 
+def test_eval_after_graph_replays_uses_current_weights():
+    """Graph replays update weights and BatchNorm running statistics without touching tensor versions: every train -> eval
+    transition must rebuild the folded eval-mode copy.  replay, eval, replay, eval -- each eval against the oracle loaded with
+    the model's state at that moment (and the two evals must differ)."""
+    from mural_amd.train import GraphedTrainStep
+    from tests.test_gpu_snv import assert_probs_close, product_from_hp
+    fx = U.load("snv_train_T.npz")
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"].astype(np.int64)).cuda()
+    cont = torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    model = model.cuda().train()
+    opt = torch.optim.Adam(model.parameters(), lr=5e-3, capturable=True)
+    step = GraphedTrainStep(model, opt, crit, cont, cat, x, y)
+    outs = []
+    for _ in range(2):
+        model.train()
+        for _ in range(3):
+            step(cont, cat, x, y)
+        step.finish()
+        model.eval()
+        with torch.no_grad():
+            got = model((cont, cat), x).cpu().numpy()
+        orc.load_state_dict({k: v.cpu() for k, v in model.state_dict().items()})
+        orc.eval()
+        with torch.no_grad():
+            want = orc((cont.cpu(), cat.cpu()), x.cpu()).numpy()
+        assert_probs_close(got, want, 2, "eval after replay")
+        outs.append(got)
+    assert np.abs(np.exp(outs[0]) - np.exp(outs[1])).max() > 1e-4
+
+
 def test_conv32_kernels_match_torch_fp64():
     """The MFMA conv kernels behind the training step (forward with pre-op / residuals / fused batch sums, input gradient
     with BatchNorm-backward sums, weight gradient, fused backward) against torch ops in float64 on the CPU, over full,

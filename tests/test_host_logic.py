@@ -123,7 +123,7 @@ def test_pack_sequence_matches_oracle_format():
     codes = encode_ref.seq_to_codes(seq)
     p2, m2 = encode_ref.pack_codes(codes)
     assert n == len(seq) and np.array_equal(packed, p2) and np.array_equal(mask, m2)
-    assert np.array_equal(amb, np.nonzero(codes > 4)[0])
+    assert np.array_equal(amb[0], np.nonzero(codes > 4)[0]) and np.array_equal(amb[1], codes[codes > 4])
     with pytest.raises(KeyError):
         pack_sequence("ACGTX")
 
