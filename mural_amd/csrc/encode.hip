@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void dense_to_symbols_kernel(const float* __re
 __global__ void poison_on_status_kernel(float* __restrict__ out, int64_t total, const int32_t* __restrict__ status) {
   if (*status == 0) return;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    out[i] = __builtin_nanf("");
+    reinterpret_cast<uint32_t*>(out)[i] = 0x7FC00000u;    // quiet NaN as a bit pattern: the library is built with -fno-honor-nans
 }
 
 int launch_poison_on_status(float* out, int64_t total, const int32_t* status, hipStream_t stream) {
