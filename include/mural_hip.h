@@ -271,6 +271,16 @@ int mural_op_head_bwd(const float* loc, const float* mid, const float* lar, cons
                       float* dloc, float* dmid, float* dlar, void* stream);
 int mural_op_dense_to_symbols(const float* x, int64_t n, int32_t L, uint8_t* sym, int32_t* status, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Post-head calibration of the prediction path in one pass over the (n, n_class) rows (run_predict.py:214-225):
+ * F.softmax of the model output (skipped when in_is_prob) -> full-Dirichlet map softmax(W . [log clip(p); 1]) when
+ * dirichlet_w != NULL (dev double [n_class][n_class + 1]; dirichletcal/calib/fulldirichlet.py:78-80, multinomial.py:60-64) ->
+ * poisson_calibrate (MuRaL/model/calibration.py:10-23) when poisson != 0 -> apply_scaling (MuRaL/scripts/scaling.py:10-28)
+ * when scale != 0.  out: dev double or float [n][n_class].  n_class <= 16.
+ * ------------------------------------------------------------------------------------------------------------- */
+int mural_calibrate_rows(const float* in, int64_t n, int32_t n_class, int32_t in_is_prob, const double* dirichlet_w,
+                         int32_t poisson, double scale, void* out, int32_t out_f64, void* stream);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

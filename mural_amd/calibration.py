@@ -6,6 +6,9 @@
   * ``load_dirichlet_weights`` -- reads W out of the reference's pickles WITHOUT importing dirichletcal / jax: a restricted
     unpickler maps the two calibrator classes to inert holders and ``jax._src.array._reconstruct_array`` (present in the
     INDEL pickles) to its numpy equivalent; any other global is refused.
+  * ``calibrate_device``     -- the whole chain (softmax -> Dirichlet map -> Poisson -> mu scaling) in one HIP kernel on the
+    (n, n_class) device tensor the model returned; the numpy functions here are the host-side counterparts for arrays that
+    already left the device.
   * ``poisson_calibrate`` lives in ``mural_amd.data.ingest`` (MuRaL/model/calibration.py:10-23).
   * ``mu_scaling_factor`` / ``apply_scaling`` -- the per-generation rate scaling of MuRaL/scripts/scaling.py:10-28, :76-93.
 """
@@ -69,6 +72,36 @@ def dirichlet_calibrate(prob, weights):
     z = z - np.max(z, axis=1).reshape(-1, 1)
     e = np.exp(z)
     return e / np.sum(e, axis=1).reshape(-1, 1)
+
+
+def calibrate_device(output, dirichlet_weights=None, poisson=False, scale_factor=None, input_is_prob=False, dtype=None):
+    """The post-head chain of run_predict.py:214-225 on the device in ONE kernel (csrc/calibrate.hip): softmax of the model
+    output (unless `input_is_prob`), the full-Dirichlet map, Poisson calibration and mu scaling, each optional.  `output`:
+    (n, n_class) float32 tensor on a HIP device.  Returns a device tensor (float64 by default, like the host functions)."""
+    import ctypes as C
+
+    import torch
+
+    from . import _lib
+    x = _lib.require_cuda(output, "output").to(torch.float32).contiguous()
+    if x.dim() != 2:
+        raise ValueError(f"output must be (n, n_class), got {tuple(x.shape)}")
+    n, k = x.shape
+    dtype = torch.float64 if dtype is None else dtype
+    if dtype not in (torch.float64, torch.float32):
+        raise ValueError("dtype must be float64 or float32")
+    w = None
+    if dirichlet_weights is not None:
+        wh = np.ascontiguousarray(dirichlet_weights, dtype=np.float64)
+        if wh.shape != (k, k + 1):
+            raise ValueError(f"dirichlet_weights must be ({k}, {k + 1}), got {wh.shape}")
+        w = torch.from_numpy(wh).to(x.device)
+    out = torch.empty((n, k), dtype=dtype, device=x.device)
+    with torch.cuda.device(x.device):
+        _lib.check(_lib.lib().mural_calibrate_rows(x.data_ptr(), n, k, int(bool(input_is_prob)), w.data_ptr() if w is not None else None,
+                                                  int(bool(poisson)), float(scale_factor or 0.0), out.data_ptr(),
+                                                  int(dtype == torch.float64), _lib.current_stream_ptr(x.device)))
+    return out
 
 
 def mu_scaling_factor(prob, genomewide_mu, m_proportion, g_proportion=1.0):

@@ -111,8 +111,13 @@ class HipShardForward:
     base appended as the last column."""
 
     def __init__(self, model, fasta_path, local_radius, local_order=3, distal_radius=None, device="cuda", batch_sites=1 << 20,
-                 model_type="snv"):
+                 model_type="snv", dirichlet_weights=None, poisson=False, scale_factor=None):
+        """`dirichlet_weights` / `poisson` / `scale_factor`: apply the post-head calibration chain of run_predict.py:217-225
+        (and scripts/scaling.py) on the device, fused behind the head (calibration.calibrate_device); the shard then carries
+        float64 calibrated probabilities and the sink must not calibrate again."""
         from .data import ingest
+        self.calibration = dict(dirichlet_weights=dirichlet_weights, poisson=poisson, scale_factor=scale_factor)
+        self.calibrated = dirichlet_weights is not None or bool(poisson) or bool(scale_factor)
         self._ingest = ingest
         self.model = model.to(device).eval()
         self.fasta_path, self.device = fasta_path, torch.device(device)
@@ -135,7 +140,8 @@ class HipShardForward:
     def __call__(self, chrom, pos, strand):
         g = self.genome(chrom)
         n = len(pos)
-        out = torch.empty((n, self.model.n_class + 1), dtype=torch.float32, device=self.device)
+        out = torch.empty((n, self.model.n_class + 1), dtype=torch.float64 if self.calibrated else torch.float32,
+                          device=self.device)
         for r0 in range(0, n, self.batch_sites):
             p = torch.from_numpy(pos[r0:r0 + self.batch_sites]).to(self.device)
             st = torch.from_numpy(strand[r0:r0 + self.batch_sites]).to(self.device)
@@ -145,7 +151,11 @@ class HipShardForward:
             else:
                 logp = self.model.forward_packed(g, p, st, self.distal_radius)
                 out[r0:r0 + len(p), -1] = 0.0
-            out[r0:r0 + len(p), :-1] = torch.softmax(logp, dim=1)
+            if self.calibrated:
+                from .calibration import calibrate_device
+                out[r0:r0 + len(p), :-1] = calibrate_device(logp, **self.calibration)
+            else:
+                out[r0:r0 + len(p), :-1] = torch.softmax(logp, dim=1)
         return out
 
 

@@ -94,3 +94,77 @@ def test_file_level_sharded_driver_streams_chromosomes(tmp_path):
     assert open(out).read() == open(want_path).read()
     df = pd.read_csv(out, sep="\t")
     assert df[["chrom", "start"]].equals(df[["chrom", "start"]].sort_values(["chrom", "start"]).reset_index(drop=True))
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# SURVEY.md section 8f-2 on the device: softmax -> full-Dirichlet map -> Poisson -> mu scaling in one kernel
+# ------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("tag", ["snv", "indel"])
+def test_device_dirichlet_map_matches_reference_calibrator(tag):
+    """G12: outputs of the reference's own FullDirichletCalibrator.predict_proba on two shipped calibrators."""
+    from mural_amd.calibration import calibrate_device
+    fx = U.load("dirichlet.npz")
+    prob = torch.from_numpy(fx[tag + "_prob"]).cuda()
+    got = calibrate_device(prob, dirichlet_weights=fx[tag + "_w"], input_is_prob=True)
+    assert got.dtype == torch.float64 and got.is_cuda
+    assert np.abs(got.cpu().numpy() - fx[tag + "_cal"]).max() <= 1e-6      # float32 log on the device vs numpy: last-bit differences
+    # from the model output (log-probabilities): softmax happens inside the kernel
+    got2 = calibrate_device(torch.log(prob), dirichlet_weights=fx[tag + "_w"]).cpu().numpy()
+    assert np.abs(got2 - fx[tag + "_cal"]).max() <= 1e-5
+
+
+def test_device_poisson_and_scaling_match_reference_tables(tmp_path):
+    """G11: poisson_calibrate and apply_scaling outputs written by the reference (prob -> poisson -> '%.4g' table -> scaled)."""
+    import io
+    import pandas as pd
+    from mural_amd.calibration import apply_scaling, calibrate_device
+    from mural_amd.data.ingest import poisson_calibrate
+    fx = U.load("output.npz")
+    prob = torch.from_numpy(fx["prob"]).cuda()
+    got = calibrate_device(prob, poisson=True, input_is_prob=True).cpu().numpy()
+    # (row 0 of the fixture has prob0 = 1: the reference's 0 / 0 = NaN for the mutation classes, reproduced)
+    assert np.isnan(fx["poisson"]).any() and np.array_equal(np.isnan(got), np.isnan(fx["poisson"]))
+    np.testing.assert_allclose(got, fx["poisson"], rtol=3e-7, atol=1e-9, equal_nan=True)
+    np.testing.assert_allclose(got, poisson_calibrate(fx["prob"].astype(np.float64)), rtol=1e-12, atol=1e-15, equal_nan=True)
+    factor = float(fx["scale_factor"])
+    scaled = calibrate_device(prob, poisson=True, scale_factor=factor, input_is_prob=True).cpu().numpy()
+    np.testing.assert_allclose(scaled, apply_scaling(poisson_calibrate(fx["prob"].astype(np.float64)), factor), rtol=1e-12,
+                               atol=1e-15, equal_nan=True)
+    # the reference's scaling script (scripts/scaling.py:10-28) read the '%.4g' table of the raw probabilities: same resolution
+    ref = pd.read_csv(io.StringIO(str(fx["scaled_table"])), sep="\t")
+    src = pd.read_csv(io.StringIO(str(fx["table"])), sep="\t")
+    cols = [c for c in ref.columns if c.startswith("prob")]
+    plain = calibrate_device(torch.from_numpy(src[cols].to_numpy().astype(np.float32)).cuda(), scale_factor=factor,
+                             input_is_prob=True).cpu().numpy()
+    assert np.allclose(plain, ref[cols].to_numpy(), rtol=1e-3, atol=1e-9)
+    # other class counts take the same kernel (2: template, 3: generic loop)
+    for k in (2, 3, 8):
+        p = torch.softmax(torch.randn(1000, k, generator=torch.Generator().manual_seed(k)), dim=1)
+        w = np.random.default_rng(k).normal(size=(k, k + 1))
+        from mural_amd.calibration import dirichlet_calibrate
+        want = poisson_calibrate(dirichlet_calibrate(p.numpy(), w))
+        got = calibrate_device(p.cuda(), dirichlet_weights=w, poisson=True, input_is_prob=True).cpu().numpy()
+        assert np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+    assert calibrate_device(torch.zeros(0, 4).cuda(), poisson=True).shape == (0, 4)
+
+
+def test_sharded_driver_with_device_calibration_writes_the_same_table(tmp_path):
+    """HipShardForward with the calibration fused behind the head + a plain sink == host-side calibration in the sink."""
+    from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
+    model, orc, r, R = _models(HUMAN[1])
+    rng = np.random.default_rng(57)
+    seq = _genome(rng, 8000, iupac=False)
+    fa = tmp_path / "g.fa"
+    fa.write_text(">chr7\n" + seq + "\n")
+    arr = np.frombuffer(seq.encode(), np.uint8)
+    sites = [int(p) for p in np.sort(rng.choice(len(seq), size=400, replace=False)) if arr[p] == ord("C")]
+    bed = tmp_path / "s.bed"
+    bed.write_text("".join(f"chr7\t{p}\t{p + 1}\t.\t0\t+\n" for p in sites))
+    w = np.random.default_rng(58).normal(size=(4, 5)) * 0.2 + np.hstack([np.eye(4), np.zeros((4, 1))])
+    a, b = tmp_path / "dev.tsv", tmp_path / "host.tsv"
+    predict_bed_sharded(HipShardForward(model, fa, r, 3, dirichlet_weights=w, poisson=True), bed, sink=TsvSink(a), collect=False)
+    predict_bed_sharded(HipShardForward(model, fa, r, 3), bed, sink=TsvSink(b, poisson=True, dirichlet_weights=w), collect=False)
+    ta, tb = open(a).read().split("\n"), open(b).read().split("\n")
+    assert len(ta) == len(tb) == len(sites) + 2
+    diff = sum(x != y for x, y in zip(ta, tb))
+    assert diff <= len(sites) // 100        # '%.4g' of float64 values that differ in the 7th digit: a rare rounding flip at most
