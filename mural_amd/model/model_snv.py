@@ -313,6 +313,54 @@ class _HipSnvBase(nn.Module):
                                                           ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
         return out
 
+    def forward_packed_reuse(self, genome, pos, strand, local_radius=None, local_order=3):
+        """``forward_packed`` with cross-position reuse (csrc/snv_reuse.hip): for site lists that are dense along a chromosome the
+        first conv stage of both towers is evaluated once per base and strand instead of once per window; per site only the
+        pooled columns next to its window edges are recomputed.  Same rows, same order, probabilities equal to the per-window
+        path within rounding (GPU tests: 1e-5).  Falls back to ``forward_packed`` for models the reuse kernels do not cover."""
+        self._check_eval()
+        dev = self._device()
+        pos = _lib.require_cuda(pos, "pos").to(torch.int64).contiguous()
+        strand = _lib.require_cuda(strand, "strand").to(torch.uint8).contiguous()
+        n = pos.shape[0]
+        lib = _lib.lib()
+        if local_radius is None:
+            local_radius = (getattr(self, "no_of_cat", 1) + local_order - 2) // 2
+        if self.model_no == 0 or n == 0 or not self._fused_ok():
+            return self.forward_packed(genome, pos, strand, local_radius, local_order)
+        with torch.cuda.device(dev):
+            handle = self._get_handle()
+            if not lib.mural_snv_reuse_supported(handle):
+                return self.forward_packed(genome, pos, strand, local_radius, local_order)
+            out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
+            span = int(lib.mural_snv_reuse_chunk_span())
+            g = genome.as_struct(dev)
+            stream = _lib.current_stream_ptr(dev)
+            for s in (0, 1):
+                idx = torch.nonzero(strand == s).squeeze(1)
+                if idx.numel() == 0:
+                    continue
+                p_sorted, perm = torch.sort(pos[idx])
+                p_min, p_max = int(p_sorted[0]), int(p_sorted[-1])
+                edges = torch.arange(p_min, p_max + span, span, device=dev, dtype=torch.int64)     # chunk k: [edges[k], edges[k+1])
+                cuts = torch.searchsorted(p_sorted, edges).tolist()
+                for k in range(len(cuts) - 1):
+                    lo, hi = cuts[k], cuts[k + 1]
+                    if hi == lo:
+                        continue
+                    c_lo = p_min + k * span
+                    c_hi = min(c_lo + span - 1, p_max)
+                    need = int(lib.mural_snv_reuse_workspace_bytes(handle, hi - lo, c_hi - c_lo + 1))
+                    if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                        self._ws = None
+                        self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    res = torch.empty((hi - lo, self.n_class), dtype=torch.float32, device=dev)
+                    _lib.check(lib.mural_snv_forward_packed_reuse(handle, C.byref(g), p_sorted[lo:hi].data_ptr(), hi - lo, s, c_lo,
+                                                                  c_hi, int(local_radius), int(local_order), res.data_ptr(),
+                                                                  self._ws.data_ptr(), self._ws.numel(), stream))
+                    out.index_copy_(0, idx[perm[lo:hi]], res)
+        return out
+
     def tap_layout(self):
         arr = (C.c_int32 * 16)()
         _lib.check(_lib.lib().mural_snv_tap_layout(self._get_handle(), arr))
@@ -386,6 +434,9 @@ class Network0(nn.Module):
 
     def forward_packed(self, genome, pos, strand, local_radius=None, local_order=3):
         return self.model.forward_packed(genome, pos, strand, local_radius, local_order)
+
+    def forward_packed_reuse(self, genome, pos, strand, local_radius=None, local_order=3):
+        return self.model.forward_packed(genome, pos, strand, local_radius, local_order)     # no conv towers: nothing to share
 
 
 class Network1(_HipSnvBase):

@@ -1,0 +1,110 @@
+"""GPU parity of the cross-position reuse path (csrc/snv_reuse.hip): for dense same-strand site lists it
+must return what the per-window path returns (which the other GPU tests hold to the reference's goldens / the oracle) within
+1e-5 on probabilities -- both strands, chromosome ends, N runs, IUPAC codes, several window radii, chunked spans."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import encode_ref, snv_ref, synth
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+PROB_TOL = 1e-5
+
+
+def _pair(r, R, model_no=2, seed=301, n_class=4):
+    from tests.test_gpu_snv import product_from_hp
+    orc = snv_ref.build(model_no, local_radius=r, distal_radius=R, n_class=n_class)
+    sd = synth.synth_state_dict(orc.state_dict(), seed)
+    orc.load_state_dict(sd)
+    orc.eval()
+    model, _ = product_from_hp(np.array([r, 3, R, 150, 75, 32, 3, n_class, model_no]))
+    model.load_state_dict(sd)
+    return model.cuda().eval(), orc
+
+
+def _genome(rng, n, iupac=True):
+    alphabet = b"ACGTNRYSWB" if iupac else b"ACGTN"
+    p = [.2465, .2465, .2465, .2465, .009, .001, .001, .001, .001, .001] if iupac else [.2475, .2475, .2475, .2475, .01]
+    raw = rng.choice(np.frombuffer(alphabet, np.uint8), size=n, p=p)
+    raw[n // 3:n // 3 + 70] = ord("N")
+    return raw.tobytes().decode()
+
+
+def _prob(logp):
+    return np.exp(logp.astype(np.float64))
+
+
+@pytest.mark.parametrize("cfg", [(10, 1000, 2), (7, 1000, 1), (7, 300, 2), (5, 128, 2), (7, 200, 2)])
+def test_reuse_equals_per_window_path_and_oracle(cfg):
+    from mural_amd.data import PackedGenome
+    r, R, model_no = cfg
+    model, orc = _pair(r, R, model_no)
+    rng = np.random.default_rng(500 + R)
+    n = 30_000
+    seq = _genome(rng, n)
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    # dense runs on both strands, both chromosome ends, a sparse tail
+    pos = np.r_[np.arange(0, 700), np.arange(9000, 12500), np.arange(n - 650, n), rng.integers(0, n, size=300)]
+    strand = (np.arange(len(pos)) % 2).astype(np.uint8)
+    strand[700:1400] = 1
+    perm = rng.permutation(len(pos))                    # the entry takes any order and both strands in one call
+    pos, strand = pos[perm], strand[perm]
+    tp, ts = torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda()
+    with torch.no_grad():
+        want = model.forward_packed(genome, tp, ts, local_radius=r, local_order=3).cpu().numpy()
+        got = model.forward_packed_reuse(genome, tp, ts, local_radius=r, local_order=3).cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(_prob(got) - _prob(want)).max()
+    assert err <= PROB_TOL, f"{cfg}: reuse vs per-window {err:.3e}"
+    sel = rng.choice(len(pos), size=96, replace=False)
+    codes = encode_ref.seq_to_codes(seq)
+    sym = ["-" if s else "+" for s in strand[sel]]
+    with torch.no_grad():
+        ref = orc((torch.zeros(len(sel), 1, dtype=torch.float64), torch.from_numpy(encode_ref.kmer_encode(codes, pos[sel], sym, r, 3))),
+                  torch.from_numpy(encode_ref.onehot_encode(codes, pos[sel], sym, R))).numpy()
+    assert np.abs(_prob(got[sel]) - _prob(ref)).max() <= PROB_TOL, f"{cfg}: reuse vs oracle"
+
+
+def test_reuse_one_million_dense_sites_both_strands():
+    """a 1 M-site dense list, both strands, reuse == per-window within 1e-5."""
+    from mural_amd.data import PackedGenome
+    model, _ = _pair(10, 1000)
+    rng = np.random.default_rng(77)
+    n = 1_010_000
+    genome = PackedGenome.from_sequence(_genome(rng, n, iupac=False), "cuda")
+    pos = torch.arange(2000, 2000 + 1_000_000, device="cuda")
+    strand = (pos & 1).to(torch.uint8)
+    with torch.no_grad():
+        want = model.forward_packed(genome, pos, strand, local_radius=10, local_order=3)
+        got = model.forward_packed_reuse(genome, pos, strand, local_radius=10, local_order=3)
+    err = float((got.double().exp() - want.double().exp()).abs().max())
+    assert err <= PROB_TOL, err
+    assert torch.isfinite(got).all()
+
+
+def test_reuse_chunks_long_spans_and_falls_back():
+    from mural_amd import _lib
+    from mural_amd.data import PackedGenome
+    model, _ = _pair(7, 1000, seed=302)
+    span = int(_lib.lib().mural_snv_reuse_chunk_span())
+    rng = np.random.default_rng(78)
+    n = 2 * span + 300_000
+    codes = rng.integers(0, 4, size=n).astype(np.uint8)
+    genome = PackedGenome.from_sequence(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode(), "cuda")
+    pos = np.r_[np.arange(5000, 9000), np.arange(span - 2000, span + 2000), np.arange(2 * span + 100_000, 2 * span + 104_000)]
+    strand = (rng.integers(0, 2, size=len(pos))).astype(np.uint8)
+    tp, ts = torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda()
+    with torch.no_grad():
+        want = model.forward_packed(genome, tp, ts, local_radius=7, local_order=3)
+        got = model.forward_packed_reuse(genome, tp, ts, local_radius=7, local_order=3)
+    assert float((got.double().exp() - want.double().exp()).abs().max()) <= PROB_TOL
+    # a window too short for the edge pyramids (R = 100: 14 pooled columns) and the local-only model take the per-window path
+    small, _ = _pair(5, 100, seed=303)
+    assert not _lib.lib().mural_snv_reuse_supported(small._get_handle())
+    with torch.no_grad():
+        a = small.forward_packed(genome, tp[:500], ts[:500], local_radius=5, local_order=3)
+        b = small.forward_packed_reuse(genome, tp[:500], ts[:500], local_radius=5, local_order=3)
+    assert torch.equal(a, b)
+    assert model.forward_packed_reuse(genome, tp[:0], ts[:0], local_radius=7, local_order=3).shape == (0, 4)
