@@ -142,17 +142,18 @@ int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenome* g, const
 
 /* Cross-position reuse for dense same-strand site lists (no reference counterpart beyond the window
  * sharing of its encoders, MuRaL/data/preprocessing.py:602-610, :808-814).  Same result as mural_snv_forward_packed (within
- * rounding of identical operation sequences; parity tests: 1e-5 on probabilities) for n sites that all lie on `strand`
- * (0 '+', 1 '-') of one chromosome inside [pos_min, pos_max] (host-known bounds, at most mural_snv_reuse_chunk_span() bases
- * apart; sites outside the bounds come back as NaN): the first conv stage of both towers is evaluated once per base of the span
- * as dilated convs over pooled rows, and per site only the pooled columns next to the window edges are recomputed.  Pays off
- * from a site density of a few percent of the bases.  Needs mural_snv_reuse_supported(m) (model_no 1 / 2, fused shape,
+ * rounding of identical operation sequences; parity tests: 1e-5 on probabilities) for n sites of one chromosome that lie inside
+ * [pos_min, pos_max] (host-known bounds, at most mural_snv_reuse_chunk_span() bases apart) on the strands named by `strands`
+ * (bit 0: '+' sites occur, bit 1: '-' sites occur; a site outside the bounds or on an unnamed strand comes back as NaN): the
+ * first conv stage of both towers is evaluated once per base of the span and strand as dilated convs over pooled rows, and per
+ * site only the pooled columns next to the window edges are recomputed.  Pays off from a site density of a few percent of the
+ * bases.  Needs mural_snv_reuse_supported(m) (model_no 1 / 2, fused shape,
  * at least 18 pooled columns per tower: distal_radius >= 135).                                                       */
 int     mural_snv_reuse_supported(const MuralSnvModel* m);
 int64_t mural_snv_reuse_chunk_span(void);
-size_t  mural_snv_reuse_workspace_bytes(const MuralSnvModel* m, int64_t n, int64_t span);
-int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const MuralGenome* g, const int64_t* pos, int64_t n,
-                                   int32_t strand, int64_t pos_min, int64_t pos_max, int32_t local_radius,
+size_t  mural_snv_reuse_workspace_bytes(const MuralSnvModel* m, int64_t n, int64_t span, int32_t strands);
+int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const MuralGenome* g, const int64_t* pos, const uint8_t* strand,
+                                   int64_t n, int32_t strands, int64_t pos_min, int64_t pos_max, int32_t local_radius,
                                    int32_t local_order, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Debug/validation hook used by the parity tests: same as forward_dense for the first tile, and dumps

@@ -243,25 +243,62 @@ struct EdgeArgs {
   int nbuf;                 // floats per LDS buffer
   int64_t n;                // sites of this launch
   const int64_t* pos;       // genome positions of the sites
+  const uint8_t* strand;    // 0 '+', 1 '-' per site: selects the row set
   int64_t glen;             // chromosome length
-  int neg;
-  int64_t t0, nb;           // rows: oriented coordinate of row 0, row count
+  int64_t t0[2], nb;        // rows per strand: oriented coordinate of row 0; row count
   int woff;                 // oriented offset of the tower's first input column from the site (-R large, -100 mid)
   int L1;                   // conv columns of the tower input (2R+1 / 201)
   int L2, L3;               // columns after maxpool1 / maxpool2
   int D;                    // stride of maxpool1 on the base axis (15 / 3)
   int pk2, ps2, pp2;        // maxpool2
+  int u_lo, u_hi;           // pooled columns whose window lies inside the shared rows (gathered from S)
   int right_pad;            // the last pooled column contains the right zero-padded conv column (large at R = 1000: yes)
-  const float* F;           // shared pooled first-layer rows
-  const float* El;          // first pooled column of a window starting at row b
-  const float* Er;          // last pooled column of a window ending at row b (used when right_pad)
-  const float* R;           // shared first-conv-stage output rows (raw)
-  const float* S;           // shared maxpool2 + BN rows
+  const float* F[2];        // per strand: shared pooled first-layer rows
+  const float* El[2];       // first pooled column of a window starting at row b
+  const float* Er[2];       // last pooled column of a window ending at row b (used when right_pad)
+  const float* R[2];        // shared first-conv-stage output rows (raw)
+  const float* S[2];        // shared maxpool2 + BN rows
   float* s3;                // [n][L3][32] out
 };
 
 // stage-2 column of edge-tile column j (0 .. 17): the 9 leftmost, then the 9 rightmost
 __device__ __forceinline__ int edge_q(int j, int L2) { return j < RU_EC ? j : L2 - RU_L + j; }
+
+// row index of a site's first input column | strand << 62, or -1 when the site lies outside the rows
+__device__ __forceinline__ int64_t edge_wstart(const EdgeArgs& args, int64_t row) {
+  if (row >= args.n) return -1;
+  const int64_t gp = args.pos[row];
+  const int neg = args.strand[row] != 0;
+  const int64_t t = neg ? args.glen - 1 - gp : gp;
+  const int64_t w = t + args.woff - args.t0[neg];
+  if (w < 0 || w + args.L1 > args.nb || args.F[neg] == nullptr) return -1;   // the caller's bounds / strand mask were wrong
+  return w | ((int64_t)neg << 62);
+}
+
+// x0 of the lane's edge columns of one tile, raw, in MFMA accumulator layout (requested one tile ahead)
+__device__ __forceinline__ void edge_request_x0(const EdgeArgs& args, const uint32_t (&plan)[SNV_NB2MAX], const int64_t* wst, int nbw,
+                                                int chv, f32x4 (&xres)[SNV_NB2MAX], uint32_t& live) {
+  live = 0;
+#pragma unroll
+  for (int i = 0; i < SNV_NB2MAX; ++i) {
+    xres[i] = splat(0.f);
+    if (i < nbw && plan[i] != ~0u) {
+      const int p = (int)(plan[i] >> 16), q = (int)(plan[i] & 0xFFFFu);
+      const int64_t ws = wst[p];
+      if (ws >= 0) {
+        const int set = (int)(ws >> 62);
+        const int64_t w = ws & ((1ll << 62) - 1);
+        const float* src = args.F[set] + (size_t)(w + (int64_t)args.D * q) * 32;
+        if (q == 0) src = args.El[set] + (size_t)w * 32;
+        else if (q == args.L2 - 1 && args.right_pad) src = args.Er[set] + (size_t)(w + args.L1 - 1) * 32;
+        xres[i] = ld4(src + chv);
+        live |= 1u << i;
+      }
+    }
+  }
+}
+
+constexpr int RU_POOL_SLOTS = 9;      // interior pooled (site, column, channel group) gathers per thread: P * n_int * 8 / 256 <= 9
 
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_edge_kernel(const EdgeArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -273,7 +310,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_edge_kernel(const EdgeArgs
   const int P = args.P;
   float* bufA = smem;
   float* bufB = smem + args.nbuf;
-  int64_t* wstart = reinterpret_cast<int64_t*>(smem + 2 * args.nbuf);   // [P] row index of each site's first input column (-1: bad)
+  int64_t* wbuf = reinterpret_cast<int64_t*>(smem + 2 * args.nbuf);     // [2][P]: this tile's and the next tile's window starts
   const TowerGeom& g = args.ge;
   const TowerDev& tw = args.tw;
   const int64_t n_tiles = (args.n + P - 1) / P;
@@ -303,42 +340,23 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_edge_kernel(const EdgeArgs
     for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
   }
   f32x4 xres[SNV_NB2MAX];
+  uint32_t live = 0;
+  int cur = 0;
+  if (tid < P) wbuf[tid] = edge_wstart(args, (int64_t)blockIdx.x * P + tid);
+  __syncthreads();
+  edge_request_x0(args, plan, wbuf, nbw, chv, xres, live);
   for (int64_t tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
     const int64_t row0 = tile * P;
-    if (tid < P) {
-      int64_t w = -1;
-      if (row0 + tid < args.n) {
-        const int64_t gp = args.pos[row0 + tid];
-        const int64_t t = args.neg ? args.glen - 1 - gp : gp;
-        w = t + args.woff - args.t0;
-        if (w < 0 || w + args.L1 > args.nb) w = -1;                    // outside the rows of this chunk: the caller's bounds were wrong
-      }
-      wstart[tid] = w;
-    }
-    __syncthreads();
-    // ---- entry: x0 of the 18 edge columns from the rows, raw into the residual registers, BN(ReLU) image into bufA
+    const int64_t* wst = wbuf + cur * P;
+    // ---- entry: BN(ReLU(x0)) image of the 18 edge columns into bufA; the raw values stay in the residual registers
     {
       char* A = reinterpret_cast<char*>(bufA);
 #pragma unroll
-      for (int i = 0; i < SNV_NB2MAX; ++i) {
-        xres[i] = splat(0.f);
-        if (i < nbw) {
-          bool valid = false;
-          if (plan[i] != ~0u) {
-            const int p = (int)(plan[i] >> 16), q = (int)(plan[i] & 0xFFFFu);
-            const int64_t w = wstart[p];
-            if (w >= 0) {
-              const float* src = args.F + (size_t)(w + (int64_t)args.D * q) * 32;
-              if (q == 0) src = args.El + (size_t)w * 32;
-              else if (q == args.L2 - 1 && args.right_pad) src = args.Er + (size_t)(w + args.L1 - 1) * 32;
-              xres[i] = ld4(src + chv);
-              valid = true;
-            }
-          }
-          lds_st4(A, sa.wr + 4096u * i, valid ? relu_bn(xres[i], es, et) : splat(0.f));
-        }
-      }
+      for (int i = 0; i < SNV_NB2MAX; ++i)
+        if (i < nbw) lds_st4(A, sa.wr + 4096u * i, ((live >> i) & 1u) ? relu_bn(xres[i], es, et) : splat(0.f));
     }
+    // window starts of the next tile: the position load hides under the convs
+    if (tid < P) wbuf[(cur ^ 1) * P + tid] = edge_wstart(args, (tile + gridDim.x) * P + tid);
     __syncthreads();
     // ---- the four ResBlock convs on the edge tile
     for (int layer = 0; layer < 4; ++layer) {
@@ -359,40 +377,81 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_edge_kernel(const EdgeArgs
 #pragma unroll
       for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = a_nxt[s];
     }
-    // ---- maxpool2 + BN -> s3: interior windows from S, windows touching the edge pyramids from bufA (+ R rows when mixed)
+    // the residual registers are dead: the next tile's x0 gathers fly under the pooling
+    if (tile + gridDim.x < n_tiles) edge_request_x0(args, plan, wbuf + (cur ^ 1) * P, nbw, chv, xres, live);
+    // ---- maxpool2 + BN -> s3.  Interior windows (columns u_lo .. u_hi) are gathers from S, all issued before the first store;
+    //      the few windows that touch the edge pyramids read bufA (+ R rows when mixed) and get the BN here.
     {
-      const int total = P * args.L3 * 8;
-      for (int task = tid; task < total; task += SNV_THREADS) {
-        const int pj = task >> 3, cg = task & 7;
-        const int p = pj / args.L3, u = pj - p * args.L3;
+      const int n_int = args.u_hi - args.u_lo + 1;
+      const int total = P * n_int * 8;
+      f32x4 sv[RU_POOL_SLOTS];
+#pragma unroll
+      for (int k = 0; k < RU_POOL_SLOTS; ++k) {
+        const int task = tid + k * SNV_THREADS;
+        sv[k] = splat(__uint_as_float(0x7FC00000u));
+        if (task < total) {
+          const int pj = task >> 3;
+          const int p = pj / n_int, u = args.u_lo + (pj - p * n_int);
+          const int64_t ws = wst[p];
+          if (ws >= 0) {
+            const int set = (int)(ws >> 62);
+            const int64_t w = ws & ((1ll << 62) - 1);
+            sv[k] = ld4(args.S[set] + (size_t)(w + (int64_t)args.D * args.ps2 * u) * 32 + 4 * cgq);
+          }
+        }
+      }
+      // edge / mixed windows while the gathers fly
+      const int n_edge = args.L3 - n_int;
+#pragma unroll 1
+      for (int task = tid; task < P * n_edge * 8; task += SNV_THREADS) {
+        const int pj = task >> 3;
+        const int p = pj / n_edge, e = pj - p * n_edge;
+        const int u = e < args.u_lo ? e : args.u_hi + 1 + (e - args.u_lo);
         if (row0 + p >= args.n) continue;
-        const int64_t w = wstart[p];
-        f32x4 m;
-        if (w < 0) {
-          m = splat(__uint_as_float(0x7FC00000u));
-        } else {
+        const int64_t ws = wst[p];
+        f32x4 m = splat(__uint_as_float(0x7FC00000u));
+        if (ws >= 0) {
+          const int set = (int)(ws >> 62);
+          const int64_t w = ws & ((1ll << 62) - 1);
           const int jlo = u * args.ps2 - args.pp2;
           const int lo = jlo < 0 ? 0 : jlo;
           const int hi = (jlo + args.pk2 - 1) < (args.L2 - 1) ? (jlo + args.pk2 - 1) : (args.L2 - 1);
-          if (lo >= RU_EV && hi <= args.L2 - 1 - RU_EV) {
-            m = ld4(args.S + (size_t)(w + (int64_t)args.D * (jlo + args.pp2)) * 32 + 4 * cg);
-          } else {
-            m = splat(-INFINITY);
-            for (int q = lo; q <= hi; ++q) {
-              f32x4 v;
-              if (q < RU_EV) v = ld4(bufA + lds_off(1 + p * RU_SC + q + 1, cg));
-              else if (q > args.L2 - 1 - RU_EV) v = ld4(bufA + lds_off(1 + p * RU_SC + (q - (args.L2 - RU_L)) + 1, cg));
-              else v = ld4(args.R + (size_t)(w + (int64_t)args.D * q) * 32 + 4 * cg);
-              m = max4(m, v);
+          f32x4 rv[7];
+#pragma unroll
+          for (int d = 0; d < 7; ++d) {           // the model's second pools are 7 / 3 wide: every row read in flight together
+            rv[d] = splat(-INFINITY);
+            const int q = lo + d;
+            if (q <= hi) {
+              if (q < RU_EV) rv[d] = ld4(bufA + lds_off(1 + p * RU_SC + q + 1, cgq));
+              else if (q > args.L2 - 1 - RU_EV) rv[d] = ld4(bufA + lds_off(1 + p * RU_SC + (q - (args.L2 - RU_L)) + 1, cgq));
+              else rv[d] = ld4(args.R[set] + (size_t)(w + (int64_t)args.D * q) * 32 + 4 * cgq);
             }
-            m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
-                      fmaf(pool_s.w, m.w, pool_t.w)};
           }
+          m = max4(max4(max4(rv[0], rv[1]), max4(rv[2], rv[3])), max4(max4(rv[4], rv[5]), rv[6]));
+          for (int q = lo + 7; q <= hi; ++q) {     // wider pools (not in the model): plain loop
+            f32x4 v;
+            if (q < RU_EV) v = ld4(bufA + lds_off(1 + p * RU_SC + q + 1, cgq));
+            else if (q > args.L2 - 1 - RU_EV) v = ld4(bufA + lds_off(1 + p * RU_SC + (q - (args.L2 - RU_L)) + 1, cgq));
+            else v = ld4(args.R[set] + (size_t)(w + (int64_t)args.D * q) * 32 + 4 * cgq);
+            m = max4(m, v);
+          }
+          m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
+                    fmaf(pool_s.w, m.w, pool_t.w)};
         }
-        st4(args.s3 + ((size_t)(row0 + p) * args.L3 + u) * 32 + 4 * cg, m);
+        st4(args.s3 + ((size_t)(row0 + p) * args.L3 + u) * 32 + 4 * cgq, m);
+      }
+#pragma unroll
+      for (int k = 0; k < RU_POOL_SLOTS; ++k) {
+        const int task = tid + k * SNV_THREADS;
+        if (task < total) {
+          const int pj = task >> 3;
+          const int p = pj / n_int, u = args.u_lo + (pj - p * n_int);
+          if (row0 + p < args.n) st4(args.s3 + ((size_t)(row0 + p) * args.L3 + u) * 32 + 4 * cgq, sv[k]);
+        }
       }
     }
-    __syncthreads();
+    lds_barrier();          // LDS-only hand-off: a full barrier would drain the x0 gathers of the next tile
+    cur ^= 1;
   }
 }
 
@@ -400,14 +459,14 @@ int pool_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct ReuseWs {
-  float* rows[11];          // FL FM ELl ELr EMl | T1 T2 T3 large | T1 T2 T3 mid
+  float* rows[2][11];       // per strand: FL FM ELl ELr EMl | T1 T2 T3 large | T1 T2 T3 mid
   int64_t* cat;
   float* local_logits;
   float* xlogit;
   float* s3[2];
 };
 
-size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, void* base, ReuseWs* w) {
+size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands, void* base, ReuseWs* w) {
   const int64_t nb = std::min<int64_t>(span, RU_CHUNK_SPAN) + m->shape.distal_len;
   size_t off = 0;
   auto take = [&](size_t bytes) {
@@ -415,8 +474,9 @@ size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, void* base, 
     off = align_up(off + bytes, 256);
     return o;
   };
-  size_t o_rows[11];
-  for (int i = 0; i < 11; ++i) o_rows[i] = take((size_t)nb * 32 * 4);
+  size_t o_rows[2][11];
+  for (int st = 0; st < 2; ++st)
+    for (int i = 0; i < 11; ++i) o_rows[st][i] = ((strands >> st) & 1) ? take((size_t)nb * 32 * 4) : 0;
   const int64_t ns = std::min<int64_t>(std::max<int64_t>(n, 1), SNV_CHUNK);
   const size_t o_cat = take((size_t)ns * std::max(m->shape.local_cols, 1) * 8);
   const size_t o_ll = take((size_t)ns * m->shape.n_class * 4);
@@ -425,7 +485,8 @@ size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, void* base, 
   const size_t o_s3m = take((size_t)ns * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
   if (w) {
     char* b = static_cast<char*>(base);
-    for (int i = 0; i < 11; ++i) w->rows[i] = reinterpret_cast<float*>(b + o_rows[i]);
+    for (int st = 0; st < 2; ++st)
+      for (int i = 0; i < 11; ++i) w->rows[st][i] = ((strands >> st) & 1) ? reinterpret_cast<float*>(b + o_rows[st][i]) : nullptr;
     w->cat = reinterpret_cast<int64_t*>(b + o_cat);
     w->local_logits = reinterpret_cast<float*>(b + o_ll);
     w->xlogit = reinterpret_cast<float*>(b + o_xl);
@@ -462,27 +523,27 @@ extern "C" int mural_snv_reuse_supported(const MuralSnvModel* m) { return m && r
 
 extern "C" int64_t mural_snv_reuse_chunk_span(void) { return RU_CHUNK_SPAN; }
 
-extern "C" size_t mural_snv_reuse_workspace_bytes(const MuralSnvModel* m, int64_t n, int64_t span) {
+extern "C" size_t mural_snv_reuse_workspace_bytes(const MuralSnvModel* m, int64_t n, int64_t span, int32_t strands) {
   if (!m || n <= 0 || span <= 0) return 256;
-  return carve_reuse(m, n, span, nullptr, nullptr);
+  return carve_reuse(m, n, span, strands & 3, nullptr, nullptr);
 }
 
-extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const MuralGenome* g, const int64_t* pos, int64_t n,
-                                              int32_t strand, int64_t pos_min, int64_t pos_max, int32_t local_radius,
-                                              int32_t local_order, float* out, void* workspace, size_t workspace_bytes,
-                                              void* stream_) {
+extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const MuralGenome* g, const int64_t* pos,
+                                              const uint8_t* strand, int64_t n, int32_t strands, int64_t pos_min, int64_t pos_max,
+                                              int32_t local_radius, int32_t local_order, float* out, void* workspace,
+                                              size_t workspace_bytes, void* stream_) {
   MURAL_REQUIRE(m, "model handle is NULL");
   MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
   MURAL_REQUIRE(g->n_amb == 0 || (g->amb_pos && g->amb_sym), "genome: n_amb > 0 needs amb_pos and amb_sym");
   MURAL_REQUIRE(reuse_supported(m), "cross-position reuse needs a tower model whose pooled rows hold at least %d columns", RU_L);
   MURAL_REQUIRE(n >= 0, "negative batch");
   if (n == 0) return MURAL_OK;
-  MURAL_REQUIRE(pos && out, "pos/out must not be NULL");
-  MURAL_REQUIRE(strand == 0 || strand == 1, "strand must be 0 ('+') or 1 ('-')");
+  MURAL_REQUIRE(pos && strand && out, "pos/strand/out must not be NULL");
+  MURAL_REQUIRE(strands >= 1 && strands <= 3, "strands must be 1 ('+' sites only), 2 ('-' only) or 3 (both)");
   MURAL_REQUIRE(pos_min <= pos_max && pos_max - pos_min + 1 <= RU_CHUNK_SPAN,
                 "reuse: sites must span at most %lld bases per call", (long long)RU_CHUNK_SPAN);
   const int64_t span = pos_max - pos_min + 1;
-  const size_t need = carve_reuse(m, n, span, nullptr, nullptr);
+  const size_t need = carve_reuse(m, n, span, strands, nullptr, nullptr);
   if (workspace_bytes < need || !workspace) {
     set_error("workspace too small: need %zu bytes, got %zu", need, workspace_bytes);
     return MURAL_E_WORKSPACE;
@@ -490,79 +551,83 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
   hipStream_t stream = (hipStream_t)stream_;
   const MuralSnvShape& sh = m->shape;
   ReuseWs w;
-  carve_reuse(m, n, span, workspace, &w);
+  carve_reuse(m, n, span, strands, workspace, &w);
   const int R = (sh.distal_len - 1) / 2;
-  const int neg = strand;
-  // oriented coordinates: t = g on '+', length - 1 - g on '-'; rows cover [c0 - R, c1 + R]
-  const int64_t c0 = neg ? g->length - 1 - pos_max : pos_min;
-  const int64_t t0 = c0 - R;
   const int64_t nb = span + 2 * (int64_t)R;
-  float *FL = w.rows[0], *FM = w.rows[1], *ELl = w.rows[2], *ELr = w.rows[3], *EMl = w.rows[4];
-
   const TowerGeom& gl = m->args.geom[0];
   const TowerGeom& gm = m->args.geom[1];
-  // ---- A: pooled first-layer rows
-  {
-    RowsS1Args a;
-    a.genome = *g;
-    a.neg = neg;
-    a.t0 = t0;
-    a.nb = nb;
-    a.lut[0] = m->args.tw[0].lut;
-    a.lut[1] = m->args.tw[1].lut;
-    const int last_lo = gl.ps[0] * (gl.L[0] - 1) - gl.pp[0];
-    const int last_hi = std::min(last_lo + gl.pk[0] - 1, gl.L1 - 1);
-    a.er_n = last_hi - last_lo;                     // interior columns in front of the zero-padded last conv column
-    MURAL_REQUIRE(gl.pk[0] == 15 && gl.ps[0] == 15 && gl.pp[0] == 7 && gm.pk[0] == 3 && gm.ps[0] == 3 && gm.pp[0] == 1,
-                  "reuse: unexpected maxpool1 geometry");
-    MURAL_REQUIRE(a.er_n >= 0 && a.er_n <= 14, "reuse: unexpected last pooled column");
-    a.FL = FL; a.FM = FM; a.ELl = ELl; a.ELr = ELr; a.EMl = EMl;
-    const size_t lds = (size_t)2 * SNV_LUTBLK * 4 + 2 * (RS1_TB + 2 * RS1_HALO);
-    static DynLdsOnce big_lds;
-    if (int rc = big_lds.ensure(&reuse_rows_stage1_kernel)) return rc;
-    const int64_t n_tiles = (nb + RS1_TB - 1) / RS1_TB;
-    hipLaunchKernelGGL(reuse_rows_stage1_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, 512)), dim3(RS1_THREADS), lds, stream, a);
-    MURAL_HIP_CHECK(hipGetLastError());
-  }
-  // ---- B + S per tower: the four ResBlock convs as dilated convs over the rows, then the sliding maxpool2
-  const float* Rrows[2];
-  const float* Srows[2];
-  for (int t = 0; t < 2; ++t) {
-    const TowerDev& tw = m->args.tw[t];
-    const TowerGeom& gg = m->args.geom[t];
-    const float* x0 = t == 0 ? FL : FM;
-    float *T1 = w.rows[5 + 3 * t], *T2 = w.rows[6 + 3 * t], *T3 = w.rows[7 + 3 * t];
-    const int D = gg.ps[0];
-    RowsConvArgs a{};
-    a.nb = nb;
-    a.D = D;
-    // RBs1[0].conv1 on BN(ReLU(x0))
-    a.x = x0; a.pre_s = tw.ex_s + EX_RB1_ENTRY * 32; a.pre_t = tw.ex_t + EX_RB1_ENTRY * 32;
-    a.wfrag = tw.wfrag + 0 * (size_t)SNV_WFRAG; a.bias = tw.bias + 0 * 32; a.res = nullptr; a.y = T1; a.z = nullptr; a.zadd = nullptr;
-    if (int rc = launch_rows_conv(a, stream)) return rc;
-    // RBs1[0].conv2: x1 = x0 + conv(...), z = x1 + x0 (outer skip, model_snv.py:477-479)
-    a.x = T1; a.pre_s = tw.post_s + 0 * 32; a.pre_t = tw.post_t + 0 * 32;
-    a.wfrag = tw.wfrag + 1 * (size_t)SNV_WFRAG; a.bias = tw.bias + 1 * 32; a.res = x0; a.y = T2; a.z = T3; a.zadd = x0;
-    if (int rc = launch_rows_conv(a, stream)) return rc;
-    // RBs1[1].conv1
-    a.x = T2; a.pre_s = tw.post_s + 1 * 32; a.pre_t = tw.post_t + 1 * 32;
-    a.wfrag = tw.wfrag + 2 * (size_t)SNV_WFRAG; a.bias = tw.bias + 2 * 32; a.res = nullptr; a.y = T1; a.z = nullptr; a.zadd = nullptr;
-    if (int rc = launch_rows_conv(a, stream)) return rc;
-    // RBs1[1].conv2 on top of z: RBs1(x0) + x0
-    a.x = T1; a.pre_s = tw.post_s + 2 * 32; a.pre_t = tw.post_t + 2 * 32;
-    a.wfrag = tw.wfrag + 3 * (size_t)SNV_WFRAG; a.bias = tw.bias + 3 * 32; a.res = T3; a.y = T2;
-    if (int rc = launch_rows_conv(a, stream)) return rc;
-    MURAL_REQUIRE(gg.pk[1] == 2 * gg.pp[1] + 1 && gg.ps[1] == gg.pk[1], "reuse: unexpected maxpool2 geometry");
-    const int64_t tasks = nb * 8;
-    hipLaunchKernelGGL(reuse_rows_pool_kernel, dim3((unsigned)std::min<int64_t>((tasks + 255) / 256, 8192)), dim3(256), 0, stream, T2, T3,
-                       nb, D, gg.pp[1], tw.ex_s + EX_BN_MID * 32, tw.ex_t + EX_BN_MID * 32);
-    MURAL_HIP_CHECK(hipGetLastError());
-    Rrows[t] = T2;
-    Srows[t] = T3;
+  MURAL_REQUIRE(gl.pk[0] == 15 && gl.ps[0] == 15 && gl.pp[0] == 7 && gm.pk[0] == 3 && gm.ps[0] == 3 && gm.pp[0] == 1,
+                "reuse: unexpected maxpool1 geometry");
+  int64_t t0s[2] = {0, 0};
+  const float* Rrows[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};   // [strand][tower]
+  const float* Srows[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}};
+  for (int neg = 0; neg < 2; ++neg) {
+    if (!((strands >> neg) & 1)) continue;
+    // oriented coordinates: t = g on '+', length - 1 - g on '-'; rows cover [c0 - R, c1 + R]
+    const int64_t c0 = neg ? g->length - 1 - pos_max : pos_min;
+    const int64_t t0 = c0 - R;
+    t0s[neg] = t0;
+    float* const* rows = w.rows[neg];
+    float *FL = rows[0], *FM = rows[1], *ELl = rows[2], *ELr = rows[3], *EMl = rows[4];
+    // ---- A: pooled first-layer rows
+    {
+      RowsS1Args a;
+      a.genome = *g;
+      a.neg = neg;
+      a.t0 = t0;
+      a.nb = nb;
+      a.lut[0] = m->args.tw[0].lut;
+      a.lut[1] = m->args.tw[1].lut;
+      const int last_lo = gl.ps[0] * (gl.L[0] - 1) - gl.pp[0];
+      const int last_hi = std::min(last_lo + gl.pk[0] - 1, gl.L1 - 1);
+      a.er_n = last_hi - last_lo;                     // interior columns in front of the zero-padded last conv column
+      MURAL_REQUIRE(a.er_n >= 0 && a.er_n <= 14, "reuse: unexpected last pooled column");
+      a.FL = FL; a.FM = FM; a.ELl = ELl; a.ELr = ELr; a.EMl = EMl;
+      const size_t lds = (size_t)2 * SNV_LUTBLK * 4 + 2 * (RS1_TB + 2 * RS1_HALO);
+      static DynLdsOnce big_lds;
+      if (int rc = big_lds.ensure(&reuse_rows_stage1_kernel)) return rc;
+      const int64_t n_tiles = (nb + RS1_TB - 1) / RS1_TB;
+      hipLaunchKernelGGL(reuse_rows_stage1_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, 512)), dim3(RS1_THREADS), lds, stream, a);
+      MURAL_HIP_CHECK(hipGetLastError());
+    }
+    // ---- B + S per tower: the four ResBlock convs as dilated convs over the rows, then the sliding maxpool2
+    for (int t = 0; t < 2; ++t) {
+      const TowerDev& tw = m->args.tw[t];
+      const TowerGeom& gg = m->args.geom[t];
+      const float* x0 = t == 0 ? FL : FM;
+      float *T1 = rows[5 + 3 * t], *T2 = rows[6 + 3 * t], *T3 = rows[7 + 3 * t];
+      const int D = gg.ps[0];
+      RowsConvArgs a{};
+      a.nb = nb;
+      a.D = D;
+      // RBs1[0].conv1 on BN(ReLU(x0))
+      a.x = x0; a.pre_s = tw.ex_s + EX_RB1_ENTRY * 32; a.pre_t = tw.ex_t + EX_RB1_ENTRY * 32;
+      a.wfrag = tw.wfrag + 0 * (size_t)SNV_WFRAG; a.bias = tw.bias + 0 * 32; a.res = nullptr; a.y = T1; a.z = nullptr; a.zadd = nullptr;
+      if (int rc = launch_rows_conv(a, stream)) return rc;
+      // RBs1[0].conv2: x1 = x0 + conv(...), z = x1 + x0 (outer skip, model_snv.py:477-479)
+      a.x = T1; a.pre_s = tw.post_s + 0 * 32; a.pre_t = tw.post_t + 0 * 32;
+      a.wfrag = tw.wfrag + 1 * (size_t)SNV_WFRAG; a.bias = tw.bias + 1 * 32; a.res = x0; a.y = T2; a.z = T3; a.zadd = x0;
+      if (int rc = launch_rows_conv(a, stream)) return rc;
+      // RBs1[1].conv1
+      a.x = T2; a.pre_s = tw.post_s + 1 * 32; a.pre_t = tw.post_t + 1 * 32;
+      a.wfrag = tw.wfrag + 2 * (size_t)SNV_WFRAG; a.bias = tw.bias + 2 * 32; a.res = nullptr; a.y = T1; a.z = nullptr; a.zadd = nullptr;
+      if (int rc = launch_rows_conv(a, stream)) return rc;
+      // RBs1[1].conv2 on top of z: RBs1(x0) + x0
+      a.x = T1; a.pre_s = tw.post_s + 2 * 32; a.pre_t = tw.post_t + 2 * 32;
+      a.wfrag = tw.wfrag + 3 * (size_t)SNV_WFRAG; a.bias = tw.bias + 3 * 32; a.res = T3; a.y = T2;
+      if (int rc = launch_rows_conv(a, stream)) return rc;
+      MURAL_REQUIRE(gg.pk[1] == 2 * gg.pp[1] + 1 && gg.ps[1] == gg.pk[1], "reuse: unexpected maxpool2 geometry");
+      const int64_t tasks = nb * 8;
+      hipLaunchKernelGGL(reuse_rows_pool_kernel, dim3((unsigned)std::min<int64_t>((tasks + 255) / 256, 8192)), dim3(256), 0, stream, T2,
+                         T3, nb, D, gg.pp[1], tw.ex_s + EX_BN_MID * 32, tw.ex_t + EX_BN_MID * 32);
+      MURAL_HIP_CHECK(hipGetLastError());
+      Rrows[neg][t] = T2;
+      Srows[neg][t] = T3;
+    }
   }
   // ---- per batch of sites: local branch, edge kernels, short-stage launches
   const int nc = sh.n_class;
-  // edge tile: as many sites as keep two workgroups per CU and <= SNV_NB2MAX blocks per wave
+  // edge tile: as many sites as keep <= SNV_NB2MAX blocks per wave (two workgroups per CU fit by far)
   int P = 1;
   for (int cand = 15; cand >= 1; --cand) {
     const int NC = 1 + cand * RU_SC, nbk = (NC + 15) / 16;
@@ -572,7 +637,8 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
   ge.L[0] = RU_L; ge.Sc[0] = RU_SC; ge.NC[0] = 1 + P * RU_SC; ge.nb[0] = (ge.NC[0] + 15) / 16;
   ge.dL[0] = FastDiv::make(RU_L); ge.dSc[0] = FastDiv::make(RU_SC);
   const int nbuf = (16 * ge.nb[0] + 2) * SNV_C;
-  const size_t lds_edge = (size_t)2 * nbuf * 4 + (size_t)P * 8 + 64;
+  const size_t lds_edge = (size_t)2 * nbuf * 4 + (size_t)2 * P * 8 + 64;
+
   static DynLdsOnce edge_lds;
   if (int rc = edge_lds.ensure(&snv_edge_kernel)) return rc;
   for (int64_t s0 = 0; s0 < n; s0 += SNV_CHUNK) {
@@ -583,10 +649,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       int64_t sentinel = 1;
       for (int i = 0; i < local_order; ++i) sentinel *= 4;
       MURAL_REQUIRE(sentinel + 1 == sh.emb_rows, "local_order %d does not match the embedding table (%d rows)", local_order, sh.emb_rows);
-      // strand array of the batch: the k-mer encoder takes one byte per site; a constant fill lives at the head of xlogit's block
-      uint8_t* st = reinterpret_cast<uint8_t*>(w.xlogit);
-      MURAL_HIP_CHECK(hipMemsetAsync(st, strand, (size_t)sn, stream));
-      if (int rc = mural_encode_kmer(g, pos + s0, st, sn, local_radius, local_order, 0, w.cat, stream_)) return rc;
+      if (int rc = mural_encode_kmer(g, pos + s0, strand + s0, sn, local_radius, local_order, 0, w.cat, stream_)) return rc;
       if (int rc = launch_snv_local(m->local, w.cat, sn, w.local_logits, stream)) return rc;
     }
     for (int t = 0; t < 2; ++t) {
@@ -598,9 +661,10 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       e.nbuf = nbuf;
       e.n = sn;
       e.pos = pos + s0;
+      e.strand = strand + s0;
       e.glen = g->length;
-      e.neg = neg;
-      e.t0 = t0;
+      e.t0[0] = t0s[0];
+      e.t0[1] = t0s[1];
       e.nb = nb;
       e.woff = -R + gg.col0;
       e.L1 = gg.L1;
@@ -610,12 +674,19 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       e.pk2 = gg.pk[1]; e.ps2 = gg.ps[1]; e.pp2 = gg.pp[1];
       const int last_lo = gg.ps[0] * (gg.L[0] - 1) - gg.pp[0];
       e.right_pad = (last_lo + gg.pk[0] - 1 >= gg.L1 - 1) ? 1 : 0;
-      e.F = t == 0 ? FL : FM;
-      e.El = t == 0 ? ELl : EMl;
-      e.Er = ELr;
       MURAL_REQUIRE(t == 0 || !e.right_pad, "reuse: the mid crop's last pooled column is expected to be interior");
-      e.R = Rrows[t];
-      e.S = Srows[t];
+      e.u_lo = (RU_EV + e.pp2 + e.ps2 - 1) / e.ps2;
+      e.u_hi = (e.L2 - 1 - RU_EV - (e.pk2 - 1) + e.pp2) / e.ps2;
+      if (e.u_hi > e.L3 - 1) e.u_hi = e.L3 - 1;
+      if (e.u_hi < e.u_lo) { e.u_lo = e.L3; e.u_hi = e.L3 - 1; }        // no interior window: every pooled column from the edge loop
+      MURAL_REQUIRE((int64_t)P * (e.u_hi - e.u_lo + 1) * 8 <= (int64_t)RU_POOL_SLOTS * SNV_THREADS, "reuse: pooled tile too large");
+      for (int neg = 0; neg < 2; ++neg) {
+        e.F[neg] = w.rows[neg][t == 0 ? 0 : 1];
+        e.El[neg] = w.rows[neg][t == 0 ? 2 : 4];
+        e.Er[neg] = w.rows[neg][3];
+        e.R[neg] = Rrows[neg][t];
+        e.S[neg] = Srows[neg][t];
+      }
       e.s3 = w.s3[t];
       const int64_t n_tiles = (sn + P - 1) / P;
       hipLaunchKernelGGL(snv_edge_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, 2048)), dim3(SNV_THREADS), lds_edge, stream, e);

@@ -336,12 +336,25 @@ class _HipSnvBase(nn.Module):
             span = int(lib.mural_snv_reuse_chunk_span())
             g = genome.as_struct(dev)
             stream = _lib.current_stream_ptr(dev)
-            for s in (0, 1):
-                idx = torch.nonzero(strand == s).squeeze(1)
-                if idx.numel() == 0:
-                    continue
-                p_sorted, perm = torch.sort(pos[idx])
-                p_min, p_max = int(p_sorted[0]), int(p_sorted[-1])
+            # one host round trip: bounds of the site list and which strands occur
+            p_min, p_max, s_min, s_max = torch.stack([pos.min(), pos.max(), strand.min().to(torch.int64),
+                                                      strand.max().to(torch.int64)]).tolist()
+
+            def run(p, st, lo, hi, strands, dst):
+                need = int(lib.mural_snv_reuse_workspace_bytes(handle, p.shape[0], hi - lo + 1, strands))
+                if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                    self._ws = None
+                    self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                _lib.check(lib.mural_snv_forward_packed_reuse(handle, C.byref(g), p.data_ptr(), st.data_ptr(), p.shape[0], strands, lo, hi,
+                                                              int(local_radius), int(local_order), dst.data_ptr(),
+                                                              self._ws.data_ptr(), self._ws.numel(), stream))
+
+            strands = (1 if s_min == 0 else 0) | (2 if s_max != 0 else 0)
+            if p_max - p_min + 1 <= span:              # the common case: one chunk, rows of both strands resident, sites in any order
+                run(pos, strand, p_min, p_max, strands, out)
+            else:                                      # long spans: sort once, one call per chunk of the position axis
+                p_sorted, perm = torch.sort(pos)
+                s_sorted = strand[perm].contiguous()
                 edges = torch.arange(p_min, p_max + span, span, device=dev, dtype=torch.int64)     # chunk k: [edges[k], edges[k+1])
                 cuts = torch.searchsorted(p_sorted, edges).tolist()
                 for k in range(len(cuts) - 1):
@@ -349,16 +362,9 @@ class _HipSnvBase(nn.Module):
                     if hi == lo:
                         continue
                     c_lo = p_min + k * span
-                    c_hi = min(c_lo + span - 1, p_max)
-                    need = int(lib.mural_snv_reuse_workspace_bytes(handle, hi - lo, c_hi - c_lo + 1))
-                    if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
-                        self._ws = None
-                        self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
                     res = torch.empty((hi - lo, self.n_class), dtype=torch.float32, device=dev)
-                    _lib.check(lib.mural_snv_forward_packed_reuse(handle, C.byref(g), p_sorted[lo:hi].data_ptr(), hi - lo, s, c_lo,
-                                                                  c_hi, int(local_radius), int(local_order), res.data_ptr(),
-                                                                  self._ws.data_ptr(), self._ws.numel(), stream))
-                    out.index_copy_(0, idx[perm[lo:hi]], res)
+                    run(p_sorted[lo:hi], s_sorted[lo:hi], c_lo, min(c_lo + span - 1, p_max), strands, res)
+                    out.index_copy_(0, perm[lo:hi], res)
         return out
 
     def tap_layout(self):
