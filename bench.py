@@ -13,12 +13,15 @@ window decode + first-layer lookup kernel / conv-tower kernel with head) over on
 cross-position reuse.  N>1: ranks take disjoint site shards (weak scaling) and each step ends with one RCCL
 all_gather of the (batch, 4) fp32 log-probabilities.
 
-Extra objects on the JSON line: ``train`` (N=1: steps/s of the S-config training step at batch 4096, BASELINE.json
-configs[2], measured after the timed prediction region); ``indel`` (N=1: UNet_Small positions/s, configs[3]); ``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch of the
-layers it evaluates / HIP-event duration of that kernel measured live in the timed region, vs the 157.3 TFLOP/s fp32
-MFMA peak) and
-``cpu_baseline`` (oracle = PyTorch-CPU restatement of the reference, timed on this box's host cores on a bounded
-sample of the same workload; rank 0, N=1 only).
+Extra objects on the JSON line (N=1, measured after the timed prediction region):
+``roofline`` (dominant kernel = snv_towers_fused: algorithmic FLOP per launch of the layers it evaluates / HIP-event duration of
+that kernel measured live in the timed region, vs the 157.3 TFLOP/s fp32 MFMA peak); ``cpu_baseline`` (oracle = PyTorch-CPU
+restatement of the reference on this box's host cores, os.cpu_count() threads, batch 16 / 256 / 1024, bounded samples);
+``variants`` (independent random windows handed over as the reference's dense tensors; the reference's default 16-site calls;
+``model_predict_m`` over a 16-row loader); ``dense_reuse`` (the SAME 10M-site workload through the cross-position reuse path,
+SURVEY.md section 8f-4 -- reported beside the per-window headline, never in place of it); ``train`` (configs[2]: S-config
+training step at batch 4096, >= 200 steps, un-synchronised and per-step synchronised, with its roofline) and ``indel``
+(configs[3]: UNet_Small with the shipped human insertion weights when the fixture is present, 1e5 positions, with its roofline).
 """
 import argparse
 import ctypes as C
@@ -68,121 +71,219 @@ def pack2(codes):
     return packed, mask
 
 
-def cpu_baseline(model_state, codes, budget_s=12.0, batch=256):
-    """Time the oracle (CPU restatement of the reference, oracle/snv_ref.py) on a bounded sample of the workload."""
+def cpu_model_name():
+    try:
+        with open("/proc/cpuinfo") as fh:
+            for line in fh:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(model_state, codes, budget_s=8.0):
+    """Time the oracle (CPU restatement of the reference, oracle/snv_ref.py) on bounded samples of the workload: model only,
+    inputs pre-encoded to the reference's tensor layout, batch 16 (the reference's default, commands/predict.py:90) / 256 / 1024,
+    >= 5 warm-up iterations discarded, median of up to 20 timed ones, at the best torch thread count of a scan up to
+    os.cpu_count() (see below)."""
     from oracle import encode_ref, snv_ref
     orc = snv_ref.build(2, local_radius=LOCAL_RADIUS, local_order=LOCAL_ORDER, distal_radius=DISTAL_RADIUS)
     orc.load_state_dict(model_state)
     orc.eval()
-    cont = torch.zeros(batch, 1, dtype=torch.float64)
+    ncpu = os.cpu_count() or 1
 
-    def batch_inputs(it):
-        pos = DISTAL_RADIUS + it * batch + np.arange(batch)
+    def batch_inputs(it, batch):
+        pos = DISTAL_RADIUS + (it * batch) % 100_000 + np.arange(batch)
         sym = ["-" if (p - DISTAL_RADIUS) % 2 else "+" for p in pos]
         return (torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, LOCAL_RADIUS, LOCAL_ORDER)),
                 torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, DISTAL_RADIUS)))
 
-    def timed(it):
-        cat, x = batch_inputs(it)
-        t0 = time.perf_counter()
-        orc((cont, cat), x)
-        return time.perf_counter() - t0
-
+    # Thread count: SURVEY.md section 8d names os.cpu_count(); on a many-core host intra-op threading of these small convs
+    # collapses long before that (measured on the 256-CPU MI355X host: 13 bases/s at 256 threads against several thousand at
+    # 16-64), so the scan walks up from 8 threads, stops once a setting is 2x slower than the best (it only gets worse from
+    # there) and the baseline is timed at the best setting -- the fair comparison -- with the whole scan reported.
+    scan = {}
     with torch.no_grad():
-        # intra-op threading of the small convs does not scale to every core of a big host: pick the best of a few
-        # thread counts (2 untimed + 2 timed iterations each), then time that setting for the budget
-        ncpu = os.cpu_count() or 1
-        best_threads, best_dt = 1, float("inf")
-        for threads in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        cont = torch.zeros(256, 1, dtype=torch.float64)
+        cat, x = batch_inputs(0, 256)
+        for threads in sorted({min(ncpu, t) for t in (8, 16, 32, 64, 128, ncpu)}):
             torch.set_num_threads(threads)
-            timed(0), timed(1)
-            dt = min(timed(2), timed(3))
-            if dt < best_dt:
-                best_threads, best_dt = threads, dt
-        torch.set_num_threads(best_threads)
-        timed(0)
-        done, t_used, it = 0, 0.0, 0
-        while t_used < budget_s and it < 400:
-            t_used += timed(4 + it)
-            done += batch
-            it += 1
-    # the training step of the same restatement beside it: batch 128 (the reference's default), CE(sum) + clip + Adam
+            orc((cont, cat), x)
+            t0 = time.perf_counter()
+            orc((cont, cat), x)
+            scan[str(threads)] = 256 / (time.perf_counter() - t0)
+            if scan[str(threads)] < 0.5 * max(scan.values()):
+                break
+    best_threads = int(max(scan, key=scan.get))
+    torch.set_num_threads(best_threads)
+
+    by_batch, samples = {}, {}
+    with torch.no_grad():
+        for batch in (16, 256, 1024):
+            cont = torch.zeros(batch, 1, dtype=torch.float64)
+            times, used, it = [], 0.0, 0
+            while it < 25 and (it < 7 or used < budget_s):
+                cat, x = batch_inputs(it, batch)
+                t0 = time.perf_counter()
+                orc((cont, cat), x)
+                dt = time.perf_counter() - t0
+                used += dt
+                if it >= 5:
+                    times.append(dt)
+                it += 1
+            by_batch[str(batch)] = batch / float(np.median(times))
+            samples[str(batch)] = f"{len(times)} timed iterations after 5 warm-up"
+    # the training step of the same restatement: CE(sum) + clip + Adam at batch 128 (the reference's default) and 4096
     orc.train()
-    tb = 128
     opt = torch.optim.Adam(orc.parameters(), lr=1e-3)
     crit = torch.nn.CrossEntropyLoss(reduction="sum")
-    cat, x = batch_inputs(0)
-    cat, x, y = cat[:tb], x[:tb], torch.from_numpy(np.arange(tb) % N_CLASS)
+    train = {}
+    for tb, reps in ((128, 3), (4096, 1)):
+        cat, x = batch_inputs(0, tb)
+        y = torch.from_numpy(np.arange(tb) % N_CLASS)
+        cont = torch.zeros(tb, 1, dtype=torch.float64)
 
-    def train_step():
-        t0 = time.perf_counter()
-        loss = crit(orc((cont[:tb], cat), x), y)
-        opt.zero_grad()
-        loss.backward()
-        torch.nn.utils.clip_grad_norm_(orc.parameters(), max_norm=10)
-        opt.step()
-        return time.perf_counter() - t0
+        def train_step():
+            t0 = time.perf_counter()
+            loss = crit(orc((cont, cat), x), y)
+            opt.zero_grad()
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(orc.parameters(), max_norm=10)
+            opt.step()
+            return time.perf_counter() - t0
 
-    train_step()
-    t_train = min(train_step(), train_step())
-    return {"value": done / max(t_used, 1e-9), "unit": "bases/s", "cores": best_threads, "kind": "port",
-            "sample": f"{done} sites of the same workload, model only (inputs pre-encoded), batch {batch}, "
-                      f"{it} timed iterations after warm-up, best of 8/16/32/64 torch threads on {ncpu} host CPUs",
-            "train_steps_per_s": 1.0 / t_train, "train_batch": tb, "train_sites_per_s": tb / t_train}
+        if tb == 128:
+            train_step()
+        t = min(train_step() for _ in range(reps))
+        train[str(tb)] = {"steps_per_s": 1.0 / t, "sites_per_s": tb / t}
+    return {"value": by_batch["256"], "unit": "bases/s", "cores": best_threads, "kind": "port", "cpu_model": cpu_model_name(),
+            "host_cpus": ncpu, "threads_scan_bases_per_s_at_batch_256": scan,
+            "sample": "model only (inputs pre-encoded: cat_x int64, distal_x fp32 one-hot) on windows of the same synthetic chromosome; "
+                      "value = batch 256; " + "; ".join(f"batch {b}: {v}" for b, v in samples.items()),
+            "bases_per_s_by_batch": by_batch, "train": train,
+            "train_note": "forward + backward + clip + Adam of the same restatement; batch 4096 is a single timed step"}
 
 
-def train_steps_per_s(device, genome, B=4096, steps=30, warmup=5):
-    """BASELINE.json configs[2]: S-config from scratch, batch 4096, Adam lr 1e-3, CE-sum, clip 10, default dropouts."""
+PEAK_HBM_TBS = 8.0                         # /opt/skills/guides/MI355X_MICROARCH.md
+FLOP_TRAIN_PER_SITE = 22.60e6              # fwd + dgrad + wgrad, no dgrad for the two input convs (SURVEY.md section 8d)
+FLOP_INDEL_PER_POS = 113.4e6               # UNet_Small insertion geometry, L = 8000 (SURVEY.md section 8d)
+
+
+def profile_fact(name):
+    """Numbers that need a profiler pass (PMC HBM bytes, launches per step) are read from the committed summary of that pass
+    (profiles/<name>.json, written from a rocprofv3 run of this very command on an MI355X); the JSON carries its provenance."""
+    path = os.path.join(ROOT, "profiles", name + ".json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as fh:
+        return json.load(fh)
+
+
+def train_steps_per_s(device, genome, B=4096, steps=200, warmup=20, sync_steps=50):
+    """BASELINE.json configs[2]: S-config from scratch, batch 4096, Adam lr 1e-3, CE-sum, clip 10, default dropouts.  `steps`
+    steps without a host synchronisation in between (windows encoded from the packed genome inside the timed loop), then
+    `sync_steps` individually synchronised ones (the reference reads loss.item() every step, training.py:437)."""
     import torch.nn as nn
     model = build_model(device).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3)
     crit = nn.CrossEntropyLoss(reduction="sum")
     rng = np.random.default_rng(1)
-    labels = torch.from_numpy(rng.choice(4, size=(steps + warmup) * B, p=[0.955, 0.015, 0.015, 0.015])).to(device)
+    total = steps + warmup + sync_steps
+    labels = torch.from_numpy(rng.choice(4, size=total * B, p=[0.955, 0.015, 0.015, 0.015])).to(device)
     cont = torch.zeros(B, 1, device=device)
-    times = []
-    for s in range(steps + warmup):
-        idx = torch.arange(s * B, (s + 1) * B, device=device)
+
+    def step(s):
+        idx = torch.arange(s * B, (s + 1) * B, device=device) % GENOME_SITES
         pos, strand = idx + DISTAL_RADIUS, (idx & 1).to(torch.uint8)
         cat = genome.encode_kmer(pos, strand, LOCAL_RADIUS, LOCAL_ORDER)
         x = genome.encode_onehot(pos, strand, DISTAL_RADIUS)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
         loss = crit(model((cont, cat), x), labels[s * B:(s + 1) * B])
         opt.zero_grad()
         loss.backward()
         torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
         opt.step()
+        return loss
+
+    for s in range(warmup):
+        step(s)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in range(warmup, warmup + steps):
+        loss = step(s)
+    torch.cuda.synchronize()
+    t = (time.perf_counter() - t0) / steps
+    times = []
+    for s in range(warmup + steps, total):
         torch.cuda.synchronize()
-        times.append(time.perf_counter() - t0)
-    t = float(np.median(times[warmup:]))
-    return {"steps_per_s": 1.0 / t, "ms_per_step": t * 1e3, "batch": B, "sites_per_s": B / t, "optimizer": "Adam lr 1e-3",
-            "loss": "CrossEntropy(sum), clip_grad_norm 10",
-            "note": "forward (batch-stat BN, dropout) + backward + update; inputs already encoded on the device; median of %d "
-                    "individually synchronised steps after %d warm-up (the reference loop reads loss.item() every step; "
-                    "tools/bench_variants.py train measures the un-synchronised loop)" % (steps, warmup)}
+        t1 = time.perf_counter()
+        step(s).item()
+        times.append(time.perf_counter() - t1)
+    t_sync = float(np.median(times))
+    tflops = FLOP_TRAIN_PER_SITE * B / t / 1e12
+    out = {"steps_per_s": 1.0 / t, "ms_per_step": t * 1e3, "batch": B, "sites_per_s": B / t, "steps": steps,
+           "steps_per_s_synchronised": 1.0 / t_sync, "ms_per_step_synchronised": t_sync * 1e3, "synchronised_steps": sync_steps,
+           "final_loss_per_site": float(loss.item()) / B, "optimizer": "Adam lr 1e-3", "loss": "CrossEntropy(sum), clip_grad_norm 10",
+           "note": "forward (batch-statistics BatchNorm, dropout 0.1/0.1/0.25) + backward + clip + Adam; window encode from the packed "
+                   "genome inside the timed loop; steps_per_s = %d steps without a host sync in between" % steps,
+           "roofline": {"flop_per_step": FLOP_TRAIN_PER_SITE * B, "achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS,
+                        "frac_mfma": tflops / PEAK_FP32_MFMA_TFLOPS}}
+    fact = profile_fact("r02_train_step")
+    if fact:
+        gbs = fact["hbm_bytes_per_step"] / t / 1e12
+        out["roofline"].update({"bound": "hbm", "hbm_bytes_per_step": fact["hbm_bytes_per_step"], "achieved_TBs": gbs, "peak_TBs": PEAK_HBM_TBS,
+                                "frac_hbm": gbs / PEAK_HBM_TBS, "launches_per_step": fact.get("launches_per_step"),
+                                "traffic_source": fact.get("source")})
+    return out
 
 
-def indel_positions_per_s(device, genome, n=4096):
-    """BASELINE.json configs[3]: UNet_Small, human-insertion geometry (L=8000, 8 classes, use_reverse), packed input."""
+def indel_model_and_weights(device):
+    """UNet_Small in the human-insertion configuration; the shipped Homo_sapiens/INDEL/insertion weights when the parity fixture
+    that carries them is present (tests/golden travels with the repository), weights_init otherwise."""
     from mural_amd.model import model_choice, weights_init
     cfg = dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=[1, 4, 5, 5, 5, 2], use_reverse=True)
     torch.manual_seed(0)
     model = model_choice(0, cfg, dict(n_class=8), "indel")
-    model.apply(weights_init)
-    model = model.to(device).eval()
+    fixture = os.path.join(ROOT, "tests", "golden", "indel_pretrained_human_insertion.npz")
+    if os.path.exists(fixture):
+        fx = np.load(fixture)
+        model.load_state_dict({k[3:]: torch.from_numpy(fx[k]) for k in fx.files if k.startswith("w::")})
+        weights = "Homo_sapiens/INDEL/insertion (shipped checkpoint, via tests/golden/indel_pretrained_human_insertion.npz)"
+    else:
+        model.apply(weights_init)
+        weights = "weights_init, torch.manual_seed(0)"
+    return model.to(device), weights
+
+
+def indel_positions_per_s(device, genome, n=100_000, chunk=20_000):
+    """BASELINE.json configs[3]: UNet_Small, human-insertion geometry (L=8000, 8 classes, use_reverse), 1e5 positions decoded from
+    the packed genome inside the timed region."""
+    model, weights = indel_model_and_weights(device)
+    model.eval()
     idx = torch.arange(n, device=device, dtype=torch.int64)
-    pos, strand = idx * 100 + 4000, (idx & 1).to(torch.uint8)
+    pos, strand = idx * 97 + 4000, (idx & 1).to(torch.uint8)
+
+    def run():
+        for c0 in range(0, n, chunk):
+            model.forward_packed(genome, pos[c0:c0 + chunk], strand[c0:c0 + chunk], 4000)
+
     with torch.no_grad():
-        model.forward_packed(genome, pos, strand, 4000)
+        model.forward_packed(genome, pos[:chunk], strand[:chunk], 4000)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(3):
-            model.forward_packed(genome, pos, strand, 4000)
+        run()
         torch.cuda.synchronize()
-        dt = (time.perf_counter() - t0) / 3
-    out = {"positions_per_s": n / dt, "positions": n, "window": 8000, "n_class": 8, "algorithmic_TFLOPs": n / dt * 113.4e6 / 1e12,
-           "note": "weights_init, window decode from the packed genome inside the timed region; 113.4 MFLOP/position"}
+        dt = time.perf_counter() - t0
+    tflops = n / dt * FLOP_INDEL_PER_POS / 1e12
+    out = {"positions_per_s": n / dt, "positions": n, "window": 8000, "n_class": 8, "weights": weights,
+           "note": "window decode from the packed genome inside the timed region; 113.4 MFLOP/position",
+           "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                        "frac": tflops / PEAK_FP32_MFMA_TFLOPS}}
+    fact = profile_fact("r02_indel_forward")
+    if fact:
+        tbs = fact["hbm_bytes_per_position"] * n / dt / 1e12
+        out["roofline"].update({"hbm_bytes_per_position": fact["hbm_bytes_per_position"], "achieved_TBs": tbs, "frac_hbm": tbs / PEAK_HBM_TBS,
+                                "traffic_source": fact.get("source")})
     # one training configuration of the same model: batch 128 (the reference's default), CE(sum) + clip + Adam
     tb = 128
     model.train()
@@ -198,17 +299,104 @@ def indel_positions_per_s(device, genome, n=4096):
         torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, error_if_nonfinite=False)
         opt.step()
 
-    for _ in range(2):
+    for _ in range(3):
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(20):
         step()
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / 5
+    dt = (time.perf_counter() - t0) / 20
+    tf = 3 * FLOP_INDEL_PER_POS * tb / dt / 1e12
     out["train"] = {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "batch": tb, "positions_per_s": tb / dt,
-                    "note": "forward (batch-statistics BatchNorm, dropout) + backward + clip + Adam on pre-encoded windows"}
+                    "note": "forward (batch-statistics BatchNorm, dropout) + backward + clip + Adam on pre-encoded windows, 20 steps",
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
+                                 "flop_per_step": 3 * FLOP_INDEL_PER_POS * tb}}
     return out
+
+
+def workload_variants(device, model, genome):
+    """The other call patterns SURVEY.md section 8d asks for, next to the headline."""
+    import torch.nn as nn
+    from mural_amd.model import model_predict_m
+    out = {}
+
+    def timed(fn, reps, warm):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps
+
+    with torch.no_grad():
+        # independent random windows handed over as the reference's own tensors (no shared genome buffer)
+        B = 16384
+        g = torch.Generator(device=device).manual_seed(5)
+        codes = torch.randint(0, 4, (B, 2 * DISTAL_RADIUS + 1), device=device, generator=g)
+        x = torch.nn.functional.one_hot(codes, 4).permute(0, 2, 1).float().contiguous()
+        c = codes[:, DISTAL_RADIUS - LOCAL_RADIUS:DISTAL_RADIUS + LOCAL_RADIUS + 1]
+        cat = (c[:, :-2] * 16 + c[:, 1:-1] * 4 + c[:, 2:]).contiguous()
+        cont = torch.zeros(B, 1, device=device, dtype=torch.float64)
+        dt = timed(lambda: model((cont, cat), x), 10, 2)
+        out["random_windows_dense_tensors"] = {"bases_per_s": B / dt, "batch": B, "ms_per_call": dt * 1e3,
+                                               "input_GB_per_s": B * (4 * (2 * DISTAL_RADIUS + 1) * 4 + cat.shape[1] * 8) / dt / 1e9,
+                                               "note": "B x 2001 i.i.d. bases per site as cat_x int64 + distal_x fp32 one-hot"}
+        # the reference's default call: 16 sites per forward (commands/predict.py:90), dense tensors, no sync between calls
+        calls = [(cont[i * 16:(i + 1) * 16], cat[i * 16:(i + 1) * 16].contiguous(), x[i * 16:(i + 1) * 16].contiguous()) for i in range(256)]
+        it = iter(range(10 ** 9))
+
+        def one():
+            co, ca, xx = calls[next(it) % 256]
+            return model((co, ca), xx)
+
+        dt = timed(one, 2000, 50)
+        out["batch16_dense_calls"] = {"bases_per_s": 16 / dt, "us_per_call": dt * 1e6,
+                                      "note": "one forward per 16 sites, 2000 calls back to back (encoding check read one call late)"}
+        # model_predict_m over a loader that yields 16-row batches: small batches are fused into one launch
+        n_rows = 16 * 1024
+        ys = torch.zeros(n_rows, 1)
+        loader = [(ys[i:i + 16], cont[i:i + 16].cpu(), cat[i:i + 16].cpu(), x[i:i + 16].cpu()) for i in range(0, n_rows, 16)]
+        crit = nn.CrossEntropyLoss(reduction="sum")
+        model_predict_m(model, loader[:64], crit, device, N_CLASS)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model_predict_m(model, loader, crit, device, N_CLASS)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["model_predict_m_batch16_loader"] = {"bases_per_s": n_rows / dt, "rows": n_rows,
+                                                 "note": "HOST tensors in 16-row batches: 32 KB of fp32 one-hot per site packed into a pinned "
+                                                         "buffer and copied over PCIe inside the timed region (that copy is the bound)"}
+        dev_loader = [tuple(t.to(device) for t in b) for b in loader]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        model_predict_m(model, dev_loader, crit, device, N_CLASS)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out["model_predict_m_batch16_device_loader"] = {"bases_per_s": n_rows / dt, "rows": n_rows,
+                                                        "note": "the same 16-row batches already on the device: fused into 8192-row launches"}
+    return out
+
+
+def dense_reuse(device, model, genome, sites, steps):
+    """The same workload through the cross-position reuse path: every site's result equals the
+    per-window result within 1e-5 (tests/test_gpu_reuse.py), but overlapping windows share their first conv stage."""
+    with torch.no_grad():
+        pos, strand = sites[0]
+        model.forward_packed_reuse(genome, pos, strand, local_radius=LOCAL_RADIUS, local_order=LOCAL_ORDER)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for s in range(steps):
+            pos, strand = sites[s % len(sites)]
+            model.forward_packed_reuse(genome, pos, strand, local_radius=LOCAL_RADIUS, local_order=LOCAL_ORDER)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+    n = sites[0][0].shape[0]
+    return {"bases_per_s": n / dt, "ms_per_step": dt * 1e3, "sites_per_step": n,
+            "note": "NOT the headline: dense same-chromosome site list, both strands; pooled first-stage rows are evaluated once per base "
+                    "and strand, per site only the window-edge columns and the short stages (csrc/snv_reuse.hip)"}
 
 
 def main():
@@ -298,11 +486,13 @@ def main():
         # = (all tower FLOP of the timed region) / (all tower-kernel time of the timed region)
         sites_per_launch = args.steps * B / max(k_n.value, 1)
         achieved = FLOP_TOWERS * sites_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0
-        traffic = None     # HBM bytes per launch from the committed PMC passes (tools/profile_bench.sh), if present
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            with open(tpath) as fh:
-                traffic = json.load(fh)["hbm_bytes_per_site"] * sites_per_launch
+        # HBM bytes per launch: PMC counters need their own profiler passes, so the figure comes from the committed summary of
+        # those passes over this same command (tools/profile_bench.sh -> profiles/hbm_traffic.json), scaled to this run's launches
+        traffic, traffic_source = None, None
+        fact = profile_fact("hbm_traffic")
+        if fact:
+            traffic = fact["hbm_bytes_per_site"] * sites_per_launch
+            traffic_source = "profiles/hbm_traffic.json: " + fact.get("note", "")
         line = {
             "metric": "predicted bases/s (SNV local=10/distal=1000, 4-class, predict)",
             "value": bases / elapsed, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -315,7 +505,7 @@ def main():
                        "collective": "all_gather per step" if world > 1 else "none"},
             "roofline": {"bound": "mfma", "kernel": _lib.lib().mural_snv_kernel_name().decode(),
                          "achieved": achieved, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                         "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
                          "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
                          "note": "four launches per chunk of <= 131072 sites: (large | mid tower) x (first conv stage | the two short "
@@ -326,6 +516,9 @@ def main():
                                  "end-to-end model FLOP rate = 8,096,144 x value"},
         }
         if world == 1 and not args.no_train:
+            line["variants"] = workload_variants(device, model, genome)
+            line["dense_reuse"] = dense_reuse(device, model, genome, sites, max(2, min(args.steps, 10)))
+            line["dense_reuse"]["speedup_vs_per_window"] = line["dense_reuse"]["bases_per_s"] / line["value"]
             line["train"] = train_steps_per_s(device, genome)
             line["indel"] = indel_positions_per_s(device, genome)
         if world == 1 and not args.no_cpu_baseline:

@@ -142,21 +142,6 @@ __global__ __launch_bounds__(256) void dense_to_symbols_kernel(const float* __re
   }
 }
 
-// A flagged encoding error makes the call's output loud without a host round trip: every value becomes NaN.
-__global__ void poison_on_status_kernel(float* __restrict__ out, int64_t total, const int32_t* __restrict__ status) {
-  if (*status == 0) return;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x)
-    reinterpret_cast<uint32_t*>(out)[i] = 0x7FC00000u;    // quiet NaN as a bit pattern: the library is built with -fno-honor-nans
-}
-
-int launch_poison_on_status(float* out, int64_t total, const int32_t* status, hipStream_t stream) {
-  if (total == 0 || !status) return MURAL_OK;
-  const int grid = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  hipLaunchKernelGGL(poison_on_status_kernel, dim3(grid), dim3(256), 0, stream, out, total, status);
-  MURAL_HIP_CHECK(hipGetLastError());
-  return MURAL_OK;
-}
-
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream) {
   const int64_t total = n * L;
   if (total == 0) return MURAL_OK;

@@ -110,6 +110,7 @@ struct SnvFwdArgs {
   float* taps;                    // debug dump (tile 0) or nullptr
   int tap_stride;                 // floats per dumped buffer
   unsigned long long* stamps;     // diagnostic per-phase cycle sums [grid][32] or nullptr
+  const int32_t* status;          // dense entry: encoding status word; while it is set the head writes NaN (nullptr: not checked)
   // Tower range of this launch.  {0, 1}: both towers and the head in one launch.  Split mode runs {0, 0} (large tower,
   // its fc logits go to xlogit) and then {1, 1} (mid tower with its own, larger tile; reads xlogit and does the head).
   int tw_first, tw_last;
@@ -131,6 +132,10 @@ struct MuralSnvModel {
   mural::SnvFwdArgs args_split[4];
   size_t lds_split[4];
   bool split;
+  // small batches (the reference's default predict call is 16 sites): ONE launch, one site per workgroup, both towers and the head
+  // -- the latency of a call is one tile through the layers, so the tile is as narrow as it gets
+  mural::SnvFwdArgs args_small;
+  size_t lds_small;
   mural::LocalDev local;
   float* blob;                    // device allocation holding every folded tensor
   size_t blob_floats;

@@ -14,7 +14,6 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream);
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream);
-int launch_poison_on_status(float* out, int64_t total, const int32_t* status, hipStream_t stream);
 
 namespace {
 
@@ -369,6 +368,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
           }
           m->split = ok;
         }
+        m->lds_small = plan_geometry(m->args_small, sh.distal_len, 1, sh.n_class);
         Stage1Args& s1 = m->s1;
         for (int tw = 0; tw < 2; ++tw) {
           const TowerGeom& g = m->args.geom[tw];
@@ -418,6 +418,10 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
       a2.n_class = sh.n_class;
       a2.has_local = m->args.has_local;
     }
+    m->args_small.tw[0] = m->args.tw[0];
+    m->args_small.tw[1] = m->args.tw[1];
+    m->args_small.n_class = sh.n_class;
+    m->args_small.has_local = m->args.has_local;
     m->s1.lut[0] = m->args.tw[0].lut;
     m->s1.lut[1] = m->args.tw[1].lut;
   }
@@ -465,9 +469,12 @@ static unsigned long long* g_stamps = nullptr;
 extern "C" int mural_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; return MURAL_OK; }
 
 // stage-1 kernel + tower kernel over chunks of SNV_CHUNK sites (the x0 scratch holds one chunk)
+constexpr int64_t SNV_SMALL_BATCH = 256;   // up to here a call is latency-bound: single launch with one-site tiles
+
 static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool packed, int64_t n, const Workspace& w,
-                      float* out, float* taps, hipStream_t stream) {
+                      float* out, float* taps, const int32_t* status, hipStream_t stream) {
   const int nc = m->shape.n_class;
+  const bool small = taps == nullptr && n <= SNV_SMALL_BATCH && m->lds_small > 0 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH");
   for (int64_t c0 = 0; c0 < n; c0 += SNV_CHUNK) {
     const int64_t cn = std::min<int64_t>(SNV_CHUNK, n - c0);
     Stage1Args s = s1;
@@ -476,9 +483,9 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     if (packed) { s.pos = s1.pos + c0; s.strand = s1.strand + c0; }
     else s.codes = s1.codes + c0 * m->shape.distal_len;
     if (int rc = launch_snv_stage1(s, packed, m->s1_lds_bytes, stream)) return rc;
-    const bool split = m->split && taps == nullptr;       // the debug dump wants both towers in one tile geometry
+    const bool split = m->split && taps == nullptr && !small;   // the debug dump wants both towers in one tile geometry
     for (int part = 0; part < (split ? 4 : 1); ++part) {
-      SnvFwdArgs t = split ? m->args_split[part] : a;
+      SnvFwdArgs t = split ? m->args_split[part] : (small ? m->args_small : a);
       t.s3[0] = w.s3[0];
       t.s3[1] = w.s3[1];
       t.n = cn;
@@ -489,7 +496,8 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       t.taps = c0 == 0 ? taps : nullptr;
       t.tap_stride = a.nbuf;
       t.stamps = packed ? g_stamps : nullptr;
-      const size_t lds = split ? m->lds_split[part] : m->lds_bytes;
+      t.status = status;
+      const size_t lds = split ? m->lds_split[part] : (small ? m->lds_small : m->lds_bytes);
       if (int rc = launch_snv_towers(m, t, lds, stream)) return rc;
     }
   }
@@ -524,8 +532,7 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
   if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * m->args.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * m->args.nbuf);
   Stage1Args s1 = m->s1;
   s1.codes = w.symbols;
-  if (int rc = run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, stream)) return rc;
-  return launch_poison_on_status(out, n * sh.n_class, status, stream);
+  return run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, status, stream);
 }
 
 extern "C" int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
@@ -573,5 +580,5 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
   s1.genome = *g;
   s1.pos = pos;
   s1.strand = strand;
-  return run_towers(m, s1, m->args, /*packed=*/true, n, w, out, nullptr, stream);
+  return run_towers(m, s1, m->args, /*packed=*/true, n, w, out, nullptr, nullptr, stream);
 }

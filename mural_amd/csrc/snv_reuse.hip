@@ -704,6 +704,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       t.taps = nullptr;
       t.tap_stride = 0;
       t.stamps = nullptr;
+      t.status = nullptr;
       if (int rc = launch_snv_towers(m, t, m->lds_split[part], stream)) return rc;
     }
   }

@@ -10,6 +10,8 @@
 // Mapping: ONE WAVE PER SITE, 16 waves per workgroup sharing the two towers' tables in LDS (staged once per
 // workgroup, persistent grid).  No workgroup barrier in the site loop: a wave's LDS writes are consumed only by
 // itself, so four waves per SIMD hide each other's LDS latency.  Bound: LDS reads (256 KB of table rows per site).
+#include <cstdlib>
+
 #include "snv.h"
 
 namespace mural {
@@ -34,11 +36,12 @@ __device__ __forceinline__ uint32_t kmer_index(const uint8_t* cb, int j, int L1)
 }
 
 // window-major 3-mer indices: kw[j2][SLOT], entry w = index of tower column ps*j2 - pp + w (255 beyond pk / range)
+// `lane` / `nl`: index and count of the lanes that share one site (64 = one wave per site; 1024 = the whole workgroup)
 template <int SLOT>
-__device__ __forceinline__ void build_kwin(const Stage1Tower& g, int lane, const uint8_t* cb0, uint8_t* kw) {
+__device__ __forceinline__ void build_kwin(const Stage1Tower& g, int lane, const uint8_t* cb0, uint8_t* kw, int nl = 64) {
   const uint8_t* cb = cb0 + g.col0;
   const int ndw = g.L2 * (SLOT / 4);
-  for (int t = lane; t < ndw; t += 64) {
+  for (int t = lane; t < ndw; t += nl) {
     const int j2 = t / (SLOT / 4);
     const int w0 = 4 * (t % (SLOT / 4));
     uint32_t packed = 0;
@@ -54,13 +57,13 @@ __device__ __forceinline__ void build_kwin(const Stage1Tower& g, int lane, const
 
 template <int SLOT>
 __device__ __forceinline__ void pooled_lookup(const Stage1Tower& g, int lane, const float* lutS, const uint8_t* cb0,
-                                              const uint8_t* kw, float* __restrict__ out /* [L2][32] */) {
+                                              const uint8_t* kw, float* __restrict__ out /* [L2][32] */, int nl = 64) {
   const float* tapS = lutS + SNV_LUT;
   const float* b0S = tapS + SNV_TAPS;
   const uint8_t* cb = cb0 + g.col0;
   const int cg = lane & 7;
   const int total = g.L2 * 8;
-  for (int task = lane; task < total; task += 64) {
+  for (int task = lane; task < total; task += nl) {
     const int j2 = task >> 3;
     uint32_t d[SLOT / 4];
     if (SLOT == 16) {
@@ -192,6 +195,54 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
     pooled_lookup<16>(args.tw[0], lane, lutL, cb, kwL, out);
     pooled_lookup<4>(args.tw[1], lane, lutM, cb, kwM, out + (size_t)args.tw[0].L2 * 32);
     wave_lds_fence();   // the next iteration overwrites cb / kw
+  }
+}
+
+// Small batches (the reference's default predict call has 16 sites): ONE WORKGROUP PER SITE -- the 16 waves split the window decode
+// and the pooled columns of a single site, so the latency of the launch is a sixteenth of the wave-per-site kernel's.
+template <int SRC>
+__global__ __launch_bounds__(S1_THREADS) void snv_stage1_site_kernel(const Stage1Args args) {
+  extern __shared__ __attribute__((aligned(16))) float s1mem[];
+  const int tid = threadIdx.x;
+  float* lutL = s1mem;
+  float* lutM = s1mem + SNV_LUTBLK;
+  uint8_t* cb = reinterpret_cast<uint8_t*>(s1mem + 2 * SNV_LUTBLK);
+  uint8_t* kwL = cb + args.cw;
+  uint8_t* kwM = kwL + args.tw[0].L2 * 16;
+  for (int i = tid * 4; i < SNV_LUTBLK; i += S1_THREADS * 4) {
+    *reinterpret_cast<f32x4*>(lutL + i) = s1_ld4(args.lut[0] + i);
+    *reinterpret_cast<f32x4*>(lutM + i) = s1_ld4(args.lut[1] + i);
+  }
+  const int Lwin = args.Lwin;
+  for (int64_t row = blockIdx.x; row < args.n; row += gridDim.x) {
+    __syncthreads();                         // previous site's readers are done (first pass: nothing to wait for but the LUT writers)
+    if (SRC == 1) {
+      const int64_t ws = args.pos[row] - args.radius;
+      const bool neg = args.strand[row] != 0;
+      if (tid == 0) {
+        cb[0] = SYM_PAD;
+        cb[Lwin + 1] = SYM_PAD;
+      }
+      for (int j = tid; j < Lwin; j += S1_THREADS) {
+        const int64_t gpos = neg ? ws + Lwin - 1 - j : ws + j;
+        uint32_t sym = genome_sym_iupac(args.genome, gpos);
+        if (neg) sym = sym_complement(sym);
+        cb[j + 1] = (uint8_t)sym;
+      }
+    } else {
+      const uint8_t* src = args.codes + row * Lwin;
+      for (int jj = tid; jj < Lwin + 2; jj += S1_THREADS) {
+        const int j = jj - 1;
+        cb[jj] = (j >= 0 && j < Lwin) ? src[j] : (uint8_t)SYM_PAD;
+      }
+    }
+    __syncthreads();
+    build_kwin<16>(args.tw[0], tid, cb, kwL, S1_THREADS);
+    build_kwin<4>(args.tw[1], tid, cb, kwM, S1_THREADS);
+    __syncthreads();
+    float* out = args.x0 + (size_t)row * args.x0_cols * 32;
+    pooled_lookup<16>(args.tw[0], tid, lutL, cb, kwL, out, S1_THREADS);
+    pooled_lookup<4>(args.tw[1], tid, lutM, cb, kwM, out + (size_t)args.tw[0].L2 * 32, S1_THREADS);
   }
 }
 
@@ -380,7 +431,14 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream) {
   if (a.n == 0) return MURAL_OK;
   static DynLdsOnce big_lds;
-  if (int rc = big_lds.ensure(&snv_stage1_kernel<0>, &snv_stage1_kernel<1>)) return rc;
+  if (int rc = big_lds.ensure(&snv_stage1_kernel<0>, &snv_stage1_kernel<1>, &snv_stage1_site_kernel<0>, &snv_stage1_site_kernel<1>))
+    return rc;
+  if (a.n <= 256 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH")) {     // latency-bound call: one workgroup per site
+    if (packed) hipLaunchKernelGGL(snv_stage1_site_kernel<1>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL(snv_stage1_site_kernel<0>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
+    MURAL_HIP_CHECK(hipGetLastError());
+    return MURAL_OK;
+  }
   const int64_t want = (a.n + S1_WAVES - 1) / S1_WAVES;
   const int grid = (int)(want < 256 ? want : 256);   // one 16-wave workgroup per CU, persistent
   if (packed)

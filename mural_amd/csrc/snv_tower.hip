@@ -388,7 +388,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
       float prob = (pr[1] + pr[0]) / 2.f;
       if (args.has_local) prob = (pr[2] + prob) / 2.f;
-      if (row0 + p < args.n) args.out[(row0 + p) * nc + k] = __logf(fmaxf(prob, 1e-9f));
+      float res = __logf(fmaxf(prob, 1e-9f));
+      if (args.status != nullptr && *args.status != 0) res = __uint_as_float(0x7FC00000u);   // flagged encoding error: loud output
+      if (row0 + p < args.n) args.out[(row0 + p) * nc + k] = res;
     }
     if (args.taps != nullptr && tile == 0) {
       float* dst = args.taps + (size_t)12 * args.tap_stride;

@@ -115,6 +115,24 @@ class _HostParams:
         return l
 
 
+class _on_device:
+    """``torch.cuda.device(dev)`` only when `dev` is not already current (the context manager costs ~10 us per call, which is
+    a sixth of a 16-site forward)."""
+    __slots__ = ("ctx",)
+
+    def __init__(self, dev):
+        self.ctx = None if torch.cuda.current_device() == (dev.index or 0) else torch.cuda.device(dev)
+
+    def __enter__(self):
+        if self.ctx is not None:
+            self.ctx.__enter__()
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+        return False
+
+
 class _HipSnvBase(nn.Module):
     """Shared machinery: handle cache keyed on parameter versions, workspace, launches."""
 
@@ -124,6 +142,7 @@ class _HipSnvBase(nn.Module):
         self._handle = None
         self._handle_key = None
         self._ws = None
+        self._ws_rows = [0, 0]      # rows the workspace is known to hold for the packed / dense entry
         self._status = None
         self._status_host = None    # pinned copy of the encoding status of earlier calls (read one call late)
         self._status_event = None
@@ -142,6 +161,7 @@ class _HipSnvBase(nn.Module):
         """Force the next eval-mode forward to rebuild the folded weights (call after changing buffers by hand)."""
         self._handle_key = None
         self._plist = None
+        self._ws_rows = [0, 0]
 
     def train(self, mode=True):
         self.invalidate_folded()
@@ -156,9 +176,10 @@ class _HipSnvBase(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def _state_key(self):
+        # in-place updates through torch bump _version; storage swaps go through _apply / load_state_dict (hooked above)
         if self._plist is None:
             self._plist = list(self.parameters())
-        return tuple([(t.data_ptr(), t._version) for t in self._plist])
+        return [t._version for t in self._plist]
 
     def _get_handle(self):
         """Folded device copy of the parameters; must be called under ``torch.cuda.device(model device)``."""
@@ -199,10 +220,16 @@ class _HipSnvBase(nn.Module):
             pass
 
     def _workspace(self, n, device, dense=True):
+        ws = self._ws
+        if ws is not None and ws.device == device and n <= self._ws_rows[int(dense)]:
+            return ws                                  # big enough for this many rows already (sizes grow with n)
         need = int(_lib.lib().mural_snv_workspace_bytes(self._get_handle(), n, int(dense)))
-        if self._ws is None or self._ws.numel() < need or self._ws.device != device:
-            self._ws = torch.empty(need, dtype=torch.uint8, device=device)
-        return self._ws
+        if ws is None or ws.numel() < need or ws.device != device:
+            self._ws = None
+            self._ws = ws = torch.empty(need, dtype=torch.uint8, device=device)
+            self._ws_rows = [0, 0]
+        self._ws_rows[int(dense)] = max(self._ws_rows[int(dense)], n)
+        return ws
 
     # -- encoding status of the dense entry, read without draining the device --------------------------------
     _ENC_MSG = ("distal_input holds a column that is not a MuRaL one-hot / IUPAC-fraction encoding "
@@ -266,7 +293,7 @@ class _HipSnvBase(nn.Module):
             from . import generic_eval
             with torch.cuda.device(dev):
                 return generic_eval.forward(self, cat_x, distal_x, POOLS_MID, POOLS_LARGE)
-        with torch.cuda.device(dev):
+        with _on_device(dev):
             handle = self._get_handle()
             out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
             ws = self._workspace(max(n, 1), dev)
@@ -345,6 +372,7 @@ class _HipSnvBase(nn.Module):
                 if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
                     self._ws = None
                     self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+                    self._ws_rows = [0, 0]
                 _lib.check(lib.mural_snv_forward_packed_reuse(handle, C.byref(g), p.data_ptr(), st.data_ptr(), p.shape[0], strands, lo, hi,
                                                               int(local_radius), int(local_order), dst.data_ptr(),
                                                               self._ws.data_ptr(), self._ws.numel(), stream))

@@ -71,6 +71,34 @@ def model_choice(model_no, config, common_model_config, model_type):
     return model(**{p: adapt(p) for p in names})
 
 
+def _gather_to_device(pending, k, device, staging):
+    """Field k of the waiting loader batches as ONE device tensor.  Host batches are packed into a reused pinned buffer (no
+    allocation, one asynchronous copy over PCIe); device batches are concatenated on the device."""
+    parts = [b[k] for b in pending]
+    if len(parts) == 1:
+        return parts[0].to(device, non_blocking=True)
+    if parts[0].is_cuda:
+        return torch.cat(parts, dim=0).to(device)
+    rows = sum(p.shape[0] for p in parts)
+    shape = (rows,) + tuple(parts[0].shape[1:])
+    numel = 1
+    for d in shape:
+        numel *= d
+    buf = staging.get(k)
+    if buf is None or buf.dtype != parts[0].dtype or buf.numel() < numel:
+        if buf is not None:
+            torch.cuda.current_stream().synchronize()      # the previous copy out of the buffer must have finished
+        buf = staging[k] = torch.empty(max(numel, 1), dtype=parts[0].dtype).pin_memory()
+    else:
+        torch.cuda.current_stream().synchronize()
+    host = buf[:numel].view(shape)
+    o = 0
+    for p in parts:
+        host[o:o + p.shape[0]].copy_(p)
+        o += p.shape[0]
+    return host.to(device, non_blocking=True)
+
+
 def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, model_type="snv", fuse_rows=8192):
     """Run the model over an iterable of (y, cont_x, cat_x, distal_x) batches.
 
@@ -85,14 +113,13 @@ def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, 
     loss_acc = torch.zeros((), dtype=torch.float64, device=device)
     additive = getattr(criterion, "reduction", None) == "sum"
     pending, rows = [], 0
+    staging = {}
 
     def flush():
         nonlocal pending, rows
         if not pending:
             return
-        cat4 = lambda k: torch.cat([b[k] for b in pending], dim=0).to(device, non_blocking=True) if len(pending) > 1 \
-            else pending[0][k].to(device, non_blocking=True)
-        y, cont_x, cat_x, distal_x = cat4(0), cat4(1), cat4(2), cat4(3)
+        y, cont_x, cat_x, distal_x = (_gather_to_device(pending, k, device, staging) for k in range(4))
         if model_type == "snv":
             preds = model.forward((cont_x, cat_x), distal_x) if distal else model.forward(cont_x, cat_x)
         else:
