@@ -297,6 +297,28 @@ int mural_op_dense_to_symbols(const float* x, int64_t n, int32_t L, uint8_t* sym
 int mural_calibrate_rows(const float* in, int64_t n, int32_t n_class, int32_t in_is_prob, const double* dirichlet_w,
                          int32_t poisson, double scale, void* out, int32_t out_f64, void* stream);
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * The SNV training step in one call per direction (MuRaL/training.py:424-427: preds = model.forward(...) under model.train(),
+ * loss.backward()), Network0 / 1 / 2 with CNN_out_channels = 32, CNN_kernel_size = 3.  `params`: DEVICE pointers in the
+ * state_dict naming of MuralSnvParams (running_mean / running_var are updated in place like nn.BatchNorm1d with `momentum`;
+ * num_batches_tracked is the caller's).  dropout_p[5] / seeds[5]: emb_dropout, the two local_dropout layers, distal_fc_dropout
+ * of the mid and of the large tower, with the seed of each mask (seed_dev: optional device-resident counter added to every
+ * seed).  Input: cat_x (dev int64 [B][local_cols]) and either distal_x (dev float [B][4][distal_len]; `status` as in
+ * mural_snv_forward_dense) or `symbols` (dev uint8 [B][distal_len] from mural_op_dense_to_symbols).  out: dev float [B][n_class]
+ * (log-probabilities; raw logits for Network0).  The workspace (mural_snv_train_workspace_bytes) carries every saved tensor
+ * from the forward to the backward of the same batch and must not be touched in between.
+ * mural_snv_train_backward: `grads` has the layout of `params`; every weight / bias / emb pointer receives the gradient of
+ * that tensor for d(loss)/d(out) = dout (fully written, no accumulation); running_* pointers are ignored.
+ * ------------------------------------------------------------------------------------------------------------- */
+size_t mural_snv_train_workspace_bytes(const MuralSnvShape* shape, int64_t B);
+int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSnvParams* params, const int64_t* cat_x, const float* distal_x,
+                            const uint8_t* symbols, int64_t B, const float* dropout_p, const uint64_t* seeds,
+                            const uint64_t* seed_dev, float momentum, float* out, void* workspace, size_t workspace_bytes,
+                            int32_t* status, void* stream);
+int mural_snv_train_backward(const MuralSnvShape* shape, const MuralSnvParams* params, const MuralSnvParams* grads,
+                             const int64_t* cat_x, const float* dout, int64_t B, const float* dropout_p, const uint64_t* seeds,
+                             const uint64_t* seed_dev, void* workspace, size_t workspace_bytes, void* stream);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

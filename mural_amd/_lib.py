@@ -122,6 +122,11 @@ PROTOTYPES = {
     "mural_op_head_bwd": (C.c_int, [VP, VP, VP, VP, I64, I32, VP, VP, VP, VP]),
     "mural_op_dense_to_symbols": (C.c_int, [VP, I64, I32, VP, VP, VP]),
     "mural_calibrate_rows": (C.c_int, [VP, I64, I32, I32, VP, I32, C.c_double, VP, I32, VP]),
+    "mural_snv_train_workspace_bytes": (C.c_size_t, [C.POINTER(MuralSnvShape), I64]),
+    "mural_snv_train_forward": (C.c_int, [C.POINTER(MuralSnvShape), C.POINTER(MuralSnvParams), VP, VP, VP, I64, VP, VP, VP, C.c_float,
+                                          VP, VP, C.c_size_t, VP, VP]),
+    "mural_snv_train_backward": (C.c_int, [C.POINTER(MuralSnvShape), C.POINTER(MuralSnvParams), C.POINTER(MuralSnvParams), VP, VP, I64,
+                                           VP, VP, VP, VP, C.c_size_t, VP]),
     "mural_last_error": (C.c_char_p, []),
     "mural_abi_version": (C.c_int, []),
     "mural_encode_kmer": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

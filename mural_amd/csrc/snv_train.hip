@@ -1,0 +1,459 @@
+// One C call per direction for the SNV training step (SURVEY.md section 8b "mural_snv_backward"; reference: the forward of
+// MuRaL/model/model_snv.py:439-525 under model.train() and loss.backward() of MuRaL/training.py:424-427).
+//
+// mural_snv_train_forward  : training-mode forward of Network0 / Network1 / Network2 (batch-statistics BatchNorm with running
+//                            statistics updated in place, dropout) -> (B, n_class) outputs; every tensor the backward needs stays in
+//                            the caller's workspace.
+// mural_snv_train_backward : gradient of every parameter tensor (written to the caller's buffers, laid out like the parameters)
+//                            from d(loss)/d(output) and that workspace.
+// The host composes the training kernels of train_ops.hip / conv32_mfma.hip / snv_stage1.hip here in C++, so a non-Python host needs
+// nothing but these two calls, an optimiser and a loss.  Parameters are DEVICE pointers in the reference's state_dict naming
+// (the MuralSnvParams structs of the eval path, here with device addresses).
+#include <algorithm>
+#include <cstring>
+
+#include "snv.h"
+
+using namespace mural;
+
+namespace {
+
+constexpr int TR_C = 32;
+constexpr size_t ACC_DOUBLES_32 = (size_t)MURAL_BN_SLOTS * 2 * TR_C;
+
+struct Arena {            // bump allocator over the caller's workspace; base == nullptr: dry run that only measures
+  char* base;
+  size_t off = 0;
+  explicit Arena(void* b) : base(static_cast<char*>(b)) {}
+  void* take(size_t bytes) {
+    const size_t o = off;
+    off = (off + bytes + 255) & ~size_t(255);
+    return base ? base + o : nullptr;
+  }
+  float* f(size_t n) { return static_cast<float*>(take(n * 4)); }
+  double* d(size_t n) { return static_cast<double*>(take(n * 8)); }
+  int32_t* i(size_t n) { return static_cast<int32_t*>(take(n * 4)); }
+  uint8_t* b(size_t n) { return static_cast<uint8_t*>(take(n)); }
+};
+
+struct TowerGeo { int L1, col0, L[3], pk[3], ps[3], pp[3]; };
+
+struct StageBufs {        // a run of two ResBlocks on [B][32][L]
+  float* t[4];            // h, x1, h2, xo
+  float* state[4];        // [4][32] scale | shift | mean | invstd per layer
+  double* acc_f[4];       // forward: sums feeding BN of layer i (acc_f[0] may be produced by the previous op)
+  double* acc_b[4];       // backward: BatchNorm-backward sums of layer i
+};
+
+struct TowerBufs {
+  unsigned long long* counts;
+  float* tab;
+  uint8_t* arg1;
+  float* x0;
+  StageBufs s2;
+  float* p2; int32_t* arg2;
+  float* x0b; float* state_c2; double* acc_c2_f; double* acc_c2_b;
+  StageBufs s3;
+  float* p3; int32_t* arg3;
+  float* c3; float* state_c3; double* acc_c3_f; double* acc_c3_b;
+  float* feat; int32_t* argg;
+  float* fc_state; double* acc_fc_f; double* acc_fc_b;
+  float* fb; float* fd; float* logits;
+};
+
+struct LocalBufs {
+  float* emb; float* emb_do;
+  float* lin[2]; float* bn_state[2]; double* acc_f[2]; double* acc_b[2];
+  float* bn_out[2]; float* dout[2];
+  float* logits;
+};
+
+struct Plan {
+  int B, nc, Lwin;
+  TowerGeo geo[2];          // 0 = mid ("" suffix), 1 = large ("_2")
+  uint8_t* sym;
+  TowerBufs tw[2];
+  LocalBufs loc;
+  // accumulator region (zeroed once per direction)
+  double* acc_begin; size_t acc_bytes;
+  // backward temporaries
+  float* g[4];              // gradient buffers of the largest activation shape
+  float* part; size_t part_floats;
+  float* dlogit[3];         // gradients of the local / mid / large logits
+  float* first_scratch;
+  size_t total;
+};
+
+int pool_len(int L, int k, int s, int p) { return (L + 2 * p - k) / s + 1; }
+
+void stage_bufs(Arena& A, StageBufs& s, size_t n) {
+  for (int i = 0; i < 4; ++i) {
+    s.t[i] = A.f(n);
+    s.state[i] = A.f(4 * TR_C);
+  }
+}
+
+// lay the workspace out; all accumulator blocks are carved from one contiguous region
+int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
+  static const int pools[2][3][3] = {{{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}, {{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}};
+  std::memset(P, 0, sizeof(*P));
+  P->B = (int)B;
+  P->nc = sh.n_class;
+  P->Lwin = sh.distal_len;
+  Arena A(ws);
+  const bool towers = sh.model_no != 0, local = sh.model_no != 1;
+  size_t max_act = 0;
+  if (towers) {
+    P->sym = A.b((size_t)B * sh.distal_len);
+    for (int t = 0; t < 2; ++t) {
+      TowerGeo& g = P->geo[t];
+      g.L1 = t == 0 ? 2 * SNV_MID_HALF + 1 : sh.distal_len;
+      g.col0 = t == 0 ? sh.distal_len / 2 - SNV_MID_HALF : 0;
+      int L = g.L1;
+      for (int i = 0; i < 3; ++i) {
+        g.pk[i] = pools[t][i][0]; g.ps[i] = pools[t][i][1]; g.pp[i] = pools[t][i][2];
+        L = pool_len(L, g.pk[i], g.ps[i], g.pp[i]);
+        MURAL_REQUIRE(L >= 1, "distal window too short for the pooling pyramid");
+        g.L[i] = L;
+      }
+      MURAL_REQUIRE(mural_op_conv32_supported(g.L[0]), "training: pooled rows of %d columns do not fit the MFMA conv tile", g.L[0]);
+      TowerBufs& b = P->tw[t];
+      int64_t tabf, argb, scr;
+      mural_op_first_plan(TR_C, g.pk[0], &tabf, &argb, &scr);
+      b.tab = A.f((size_t)tabf);
+      const size_t n2 = (size_t)B * TR_C * g.L[0], n3 = (size_t)B * TR_C * g.L[1], n4 = (size_t)B * TR_C * g.L[2];
+      max_act = std::max(max_act, n2);
+      b.arg1 = A.b(n2 * (size_t)argb);
+      b.x0 = A.f(n2);
+      stage_bufs(A, b.s2, n2);
+      b.p2 = A.f(n3); b.arg2 = A.i(n3);
+      b.x0b = A.f(n3); b.state_c2 = A.f(4 * TR_C);
+      stage_bufs(A, b.s3, n3);
+      b.p3 = A.f(n4); b.arg3 = A.i(n4);
+      b.c3 = A.f(n4); b.state_c3 = A.f(4 * TR_C);
+      b.feat = A.f((size_t)B * TR_C); b.argg = A.i((size_t)B * TR_C);
+      b.fc_state = A.f(4 * TR_C);
+      b.fb = A.f((size_t)B * TR_C); b.fd = A.f((size_t)B * TR_C);
+      b.logits = A.f((size_t)B * sh.n_class);
+    }
+  }
+  if (local) {
+    LocalBufs& l = P->loc;
+    const int in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
+    l.emb = A.f((size_t)B * in1); l.emb_do = A.f((size_t)B * in1);
+    for (int i = 0; i < 2; ++i) {
+      l.lin[i] = A.f((size_t)B * h[i]);
+      l.bn_state[i] = A.f(4 * (size_t)h[i]);
+      l.bn_out[i] = A.f((size_t)B * h[i]);
+      l.dout[i] = A.f((size_t)B * h[i]);
+    }
+    l.logits = A.f((size_t)B * sh.n_class);
+    max_act = std::max(max_act, (size_t)B * std::max(in1, std::max(h[0], h[1])));
+  }
+  // ---- accumulators
+  const size_t acc0 = A.off;
+  char* acc_base = static_cast<char*>(A.take(0));
+  if (towers) {
+    for (int t = 0; t < 2; ++t) {
+      TowerBufs& b = P->tw[t];
+      for (StageBufs* s : {&b.s2, &b.s3})
+        for (int i = 0; i < 4; ++i) { s->acc_f[i] = A.d(ACC_DOUBLES_32); s->acc_b[i] = A.d(ACC_DOUBLES_32); }
+      b.acc_c2_f = A.d(ACC_DOUBLES_32); b.acc_c2_b = A.d(ACC_DOUBLES_32);
+      b.acc_c3_f = A.d(ACC_DOUBLES_32); b.acc_c3_b = A.d(ACC_DOUBLES_32);
+      b.acc_fc_f = A.d(ACC_DOUBLES_32); b.acc_fc_b = A.d(ACC_DOUBLES_32);
+      b.counts = static_cast<unsigned long long*>(A.take(16 * 8));     // symbol histogram of the first layer (forward only)
+    }
+  }
+  if (local) {
+    const int h[2] = {sh.hidden1, sh.hidden2};
+    for (int i = 0; i < 2; ++i) {
+      P->loc.acc_f[i] = A.d((size_t)MURAL_BN_SLOTS * 2 * h[i]);
+      P->loc.acc_b[i] = A.d((size_t)MURAL_BN_SLOTS * 2 * h[i]);
+    }
+  }
+  P->acc_begin = reinterpret_cast<double*>(acc_base);
+  P->acc_bytes = A.off - acc0;
+  // ---- backward temporaries
+  for (int i = 0; i < 4; ++i) P->g[i] = A.f(max_act);
+  P->part_floats = mural_op_conv32_wgrad_scratch();
+  P->part = A.f(P->part_floats);
+  for (int i = 0; i < 3; ++i) P->dlogit[i] = A.f((size_t)B * sh.n_class);
+  if (towers) {
+    int64_t tabf, argb, scr = 0, m = 0;
+    for (int t = 0; t < 2; ++t) {
+      mural_op_first_plan(TR_C, P->geo[t].pk[0], &tabf, &argb, &scr);
+      m = std::max(m, scr);
+    }
+    P->first_scratch = A.f((size_t)m);
+  }
+  P->total = A.off;
+  return MURAL_OK;
+}
+
+const float EPS = 1e-5f;
+
+struct Ctx {
+  const MuralSnvShape* sh;
+  const MuralSnvParams* p;
+  const MuralSnvParams* gr;   // gradient destinations (backward)
+  Plan* P;
+  float momentum;
+  void* stream;
+};
+
+// ---- forward of one BN -> conv32 layer
+int bnconv_f(Ctx& c, const float* x, int L, int pre_relu, double* acc, bool have_acc, const MuralBN& bn, const MuralAffine& cv,
+             float* state, int post_relu, const float* r1, const float* r2, double* acc_out, int out_relu, float* y) {
+  return mural_op_bnconv32_fwd(x, c.P->B, L, pre_relu, acc, have_acc ? 1 : 0, bn.weight, bn.bias, EPS, c.momentum,
+                               const_cast<float*>(bn.running_mean), const_cast<float*>(bn.running_var), state, cv.weight, cv.bias,
+                               post_relu, r1, r2, acc_out, out_relu, y, c.stream);
+}
+
+int stage_f(Ctx& c, const MuralResBlock* rb, const float* x_in, int L, double* acc_in, bool have_in, StageBufs& s) {
+  // every conv takes the batch sums of relu(its output) in its epilogue for the BatchNorm of the next layer
+  if (int rc = bnconv_f(c, x_in, L, 1, have_in ? acc_in : s.acc_f[0], have_in, rb[0].bn1, rb[0].conv1, s.state[0], 0, nullptr, nullptr,
+                        s.acc_f[1], 1, s.t[0])) return rc;
+  if (int rc = bnconv_f(c, s.t[0], L, 1, s.acc_f[1], true, rb[0].bn2, rb[0].conv2, s.state[1], 0, x_in, nullptr, s.acc_f[2], 1, s.t[1]))
+    return rc;
+  if (int rc = bnconv_f(c, s.t[1], L, 1, s.acc_f[2], true, rb[1].bn1, rb[1].conv1, s.state[2], 0, nullptr, nullptr, s.acc_f[3], 1, s.t[2]))
+    return rc;
+  // the second block's own residual (x1) plus the outer skip (x_in), model_snv.py:477-479
+  return bnconv_f(c, s.t[2], L, 1, s.acc_f[3], true, rb[1].bn2, rb[1].conv2, s.state[3], 0, s.t[1], x_in, nullptr, 0, s.t[3]);
+}
+
+int dropout_f(Ctx& c, const float* x, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, float* y, const float** out) {
+  if (p <= 0.f) { *out = x; return MURAL_OK; }
+  *out = y;
+  return mural_op_dropout(x, n, p, seed, seed_dev, y, c.stream);
+}
+
+int tower_f(Ctx& c, int t, const MuralTower& T, float drop_p, uint64_t seed, const uint64_t* seed_dev) {
+  Plan& P = *c.P;
+  const TowerGeo& g = P.geo[t];
+  TowerBufs& b = P.tw[t];
+  const int B = P.B;
+  if (int rc = mural_op_first_fwd(P.sym, B, P.Lwin, g.col0, g.L1, TR_C, g.pk[0], g.ps[0], g.pp[0], T.bn_in.weight, T.bn_in.bias,
+                                  T.conv_in.weight, T.conv_in.bias, EPS, c.momentum, const_cast<float*>(T.bn_in.running_mean),
+                                  const_cast<float*>(T.bn_in.running_var), b.counts, b.tab, b.x0, b.arg1, c.stream)) return rc;
+  if (int rc = stage_f(c, T.rbs1, b.x0, g.L[0], nullptr, false, b.s2)) return rc;
+  if (int rc = mural_op_maxpool_fwd(b.s2.t[3], (int64_t)B * TR_C, g.L[0], g.pk[1], g.ps[1], g.pp[1], b.p2, b.arg2, c.stream)) return rc;
+  if (int rc = bnconv_f(c, b.p2, g.L[1], 0, b.acc_c2_f, false, T.bn_mid, T.conv_mid, b.state_c2, 0, nullptr, nullptr, b.s3.acc_f[0], 1,
+                        b.x0b)) return rc;
+  if (int rc = stage_f(c, T.rbs2, b.x0b, g.L[1], b.s3.acc_f[0], true, b.s3)) return rc;
+  if (int rc = mural_op_maxpool_fwd(b.s3.t[3], (int64_t)B * TR_C, g.L[1], g.pk[2], g.ps[2], g.pp[2], b.p3, b.arg3, c.stream)) return rc;
+  if (int rc = bnconv_f(c, b.p3, g.L[2], 0, b.acc_c3_f, false, T.bn_out, T.conv_out, b.state_c3, 1, nullptr, nullptr, nullptr, 0, b.c3))
+    return rc;
+  // global max over the columns = one pooling window per row
+  if (int rc = mural_op_maxpool_fwd(b.c3, (int64_t)B * TR_C, g.L[2], g.L[2], g.L[2], 0, b.feat, b.argg, c.stream)) return rc;
+  // distal_fc: BatchNorm1d -> Dropout -> Linear on (B, 32)
+  if (int rc = mural_op_bn_stats(b.feat, B, TR_C, 1, 0, b.acc_fc_f, c.stream)) return rc;
+  if (int rc = mural_op_bn_finalize(b.acc_fc_f, (double)B, TR_C, T.fc_bn.weight, T.fc_bn.bias, EPS, c.momentum,
+                                    const_cast<float*>(T.fc_bn.running_mean), const_cast<float*>(T.fc_bn.running_var), b.fc_state,
+                                    b.fc_state + TR_C, b.fc_state + 2 * TR_C, b.fc_state + 3 * TR_C, c.stream)) return rc;
+  if (int rc = mural_op_bn_apply(b.feat, B, TR_C, 1, 0, b.fc_state, b.fc_state + TR_C, b.fb, c.stream)) return rc;
+  const float* fin;
+  if (int rc = dropout_f(c, b.fb, (int64_t)B * TR_C, drop_p, seed, seed_dev, b.fd, &fin)) return rc;
+  return mural_op_linear_fwd(fin, T.fc.weight, T.fc.bias, B, TR_C, P.nc, b.logits, c.stream);
+}
+
+int local_f(Ctx& c, const int64_t* cat, const float* drop, const uint64_t* seeds, const uint64_t* seed_dev) {
+  Plan& P = *c.P;
+  const MuralSnvShape& sh = *c.sh;
+  const MuralLocal& L = c.p->local;
+  LocalBufs& l = P.loc;
+  const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
+  if (int rc = mural_op_embedding_fwd(cat, L.emb, B, sh.local_cols, sh.emb_rows, l.emb, c.stream)) return rc;
+  const float* x;
+  if (int rc = dropout_f(c, l.emb, (int64_t)B * in1, drop[0], seeds[0], seed_dev, l.emb_do, &x)) return rc;
+  int in = in1;
+  for (int i = 0; i < 2; ++i) {   // Linear -> ReLU -> BN -> Dropout (model_snv.py:466-467)
+    if (int rc = mural_op_linear_fwd(x, L.lin[i].weight, L.lin[i].bias, B, in, h[i], l.lin[i], c.stream)) return rc;
+    if (int rc = mural_op_bn_stats(l.lin[i], B, h[i], 1, 1, l.acc_f[i], c.stream)) return rc;
+    float* st = l.bn_state[i];
+    if (int rc = mural_op_bn_finalize(l.acc_f[i], (double)B, h[i], L.bn[i].weight, L.bn[i].bias, EPS, c.momentum,
+                                      const_cast<float*>(L.bn[i].running_mean), const_cast<float*>(L.bn[i].running_var), st, st + h[i],
+                                      st + 2 * h[i], st + 3 * h[i], c.stream)) return rc;
+    if (int rc = mural_op_bn_apply(l.lin[i], B, h[i], 1, 1, st, st + h[i], l.bn_out[i], c.stream)) return rc;
+    if (int rc = dropout_f(c, l.bn_out[i], (int64_t)B * h[i], drop[1 + i], seeds[1 + i], seed_dev, l.dout[i], &x)) return rc;
+    in = h[i];
+  }
+  return mural_op_linear_fwd(x, L.out.weight, L.out.bias, B, in, P.nc, l.logits, c.stream);
+}
+
+// ---- backward of one BN -> conv32 layer: dx (+ add1 + add2), parameter gradients to their destinations
+int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const float* state, const MuralBN& bn, const MuralAffine& cv,
+             double* acc, const float* add1, const float* add2, const MuralBN& gbn, const MuralAffine& gcv, float* dz, float* dx) {
+  return mural_op_bnconv32_bwd(dy, x, c.P->B, L, pre_relu, state, bn.weight, cv.weight, acc, c.P->part, c.P->part_floats, dz, add1, add2,
+                               const_cast<float*>(gcv.weight), const_cast<float*>(gcv.bias), dx, const_cast<float*>(gbn.weight),
+                               const_cast<float*>(gbn.bias), c.stream);
+}
+
+// d_out: gradient arriving at the stage output (kept intact); d_in: receives the gradient of the stage input; tmp: 3 buffers
+int stage_b(Ctx& c, const MuralResBlock* rb, const MuralResBlock* grb, const float* x_in, int L, StageBufs& s, const float* d_out,
+            float* d_in, float* const* tmp) {
+  float *dz = tmp[0], *ga = tmp[1], *gb = tmp[2];
+  // layer 3: y = conv(BN(relu(h2))) + x1 + x_in
+  if (int rc = bnconv_b(c, d_out, s.t[2], L, 1, s.state[3], rb[1].bn2, rb[1].conv2, s.acc_b[3], nullptr, nullptr, grb[1].bn2, grb[1].conv2,
+                        dz, ga)) return rc;                                       // ga = d h2
+  // layer 2: h2 = conv(BN(relu(x1))); x1 also feeds layer 3's residual
+  if (int rc = bnconv_b(c, ga, s.t[1], L, 1, s.state[2], rb[1].bn1, rb[1].conv1, s.acc_b[2], d_out, nullptr, grb[1].bn1, grb[1].conv1, dz,
+                        gb)) return rc;                                           // gb = d x1 (total)
+  // layer 1: x1 = conv(BN(relu(h))) + x_in
+  if (int rc = bnconv_b(c, gb, s.t[0], L, 1, s.state[1], rb[0].bn2, rb[0].conv2, s.acc_b[1], nullptr, nullptr, grb[0].bn2, grb[0].conv2, dz,
+                        ga)) return rc;                                           // ga = d h
+  // layer 0: h = conv(BN(relu(x_in))); x_in also feeds x1 (residual) and the stage output (outer skip)
+  return bnconv_b(c, ga, x_in, L, 1, s.state[0], rb[0].bn1, rb[0].conv1, s.acc_b[0], gb, d_out, grb[0].bn1, grb[0].conv1, dz, d_in);
+}
+
+int dropout_b(Ctx& c, const float* dy, int64_t n, float p, uint64_t seed, const uint64_t* seed_dev, float* dx, const float** out) {
+  if (p <= 0.f) { *out = dy; return MURAL_OK; }
+  *out = dx;
+  return mural_op_dropout(dy, n, p, seed, seed_dev, dx, c.stream);
+}
+
+int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float* dlogits, float drop_p, uint64_t seed,
+            const uint64_t* seed_dev) {
+  Plan& P = *c.P;
+  const TowerGeo& g = P.geo[t];
+  TowerBufs& b = P.tw[t];
+  const int B = P.B;
+  float *g0 = P.g[0], *g1 = P.g[1], *g2 = P.g[2], *g3 = P.g[3];
+  const float* fin = drop_p > 0.f ? b.fd : b.fb;
+  // Linear -> Dropout -> BatchNorm1d on (B, 32)
+  if (int rc = mural_op_linear_bwd(dlogits, fin, T.fc.weight, B, TR_C, P.nc, g0, const_cast<float*>(G.fc.weight),
+                                   const_cast<float*>(G.fc.bias), c.stream)) return rc;
+  const float* d;
+  if (int rc = dropout_b(c, g0, (int64_t)B * TR_C, drop_p, seed, seed_dev, g1, &d)) return rc;
+  if (int rc = mural_op_bn_backward(d, b.feat, B, TR_C, 1, 0, b.fc_state + 2 * TR_C, b.fc_state + 3 * TR_C, T.fc_bn.weight, b.acc_fc_b, 0,
+                                    nullptr, nullptr, g2, const_cast<float*>(G.fc_bn.weight), const_cast<float*>(G.fc_bn.bias), c.stream))
+    return rc;                                                                      // g2 = d feat
+  // global max, ReLU of conv3
+  if (int rc = mural_op_maxpool_bwd(g2, b.argg, (int64_t)B * TR_C, g.L[2], 1, g.L[2], g.L[2], 0, g0, c.stream)) return rc;
+  if (int rc = mural_op_relu_mask(g0, b.c3, (int64_t)B * TR_C * g.L[2], g1, c.stream)) return rc;
+  if (int rc = bnconv_b(c, g1, b.p3, g.L[2], 0, b.state_c3, T.bn_out, T.conv_out, b.acc_c3_b, nullptr, nullptr, G.bn_out, G.conv_out, g0,
+                        g2)) return rc;                                            // g2 = d p3
+  if (int rc = mural_op_maxpool_bwd(g2, b.arg3, (int64_t)B * TR_C, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, c.stream)) return rc;
+  float* tmp[3] = {g0, g1, g2};
+  // second ResBlock stage: the gradient of its output sits in g3, g0..g2 are the stage's temporaries; the gradient of its input
+  // lands in the forward's copy of the stage output, which no backward reads (the pooling behind it kept its arg-max)
+  float* d_in3 = b.s3.t[3];
+  if (int rc = stage_b(c, T.rbs2, G.rbs2, b.x0b, g.L[1], b.s3, g3, d_in3, tmp)) return rc;
+  if (int rc = bnconv_b(c, d_in3, b.p2, g.L[1], 0, b.state_c2, T.bn_mid, T.conv_mid, b.acc_c2_b, nullptr, nullptr, G.bn_mid, G.conv_mid, g0,
+                        g1)) return rc;                                            // g1 = d p2
+  if (int rc = mural_op_maxpool_bwd(g1, b.arg2, (int64_t)B * TR_C, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, c.stream)) return rc;
+  float* d_in2 = b.s2.t[3];
+  if (int rc = stage_b(c, T.rbs1, G.rbs1, b.x0, g.L[0], b.s2, g3, d_in2, tmp)) return rc;
+  return mural_op_first_bwd(d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, TR_C, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight,
+                            P.first_scratch, const_cast<float*>(G.conv_in.weight), const_cast<float*>(G.conv_in.bias),
+                            const_cast<float*>(G.bn_in.weight), const_cast<float*>(G.bn_in.bias), c.stream);
+}
+
+int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop, const uint64_t* seeds, const uint64_t* seed_dev) {
+  Plan& P = *c.P;
+  const MuralSnvShape& sh = *c.sh;
+  const MuralLocal& L = c.p->local;
+  const MuralLocal& G = c.gr->local;
+  LocalBufs& l = P.loc;
+  const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
+  float *g0 = P.g[0], *g1 = P.g[1], *g2 = P.g[2];
+  const float* x_last = drop[2] > 0.f ? l.dout[1] : l.bn_out[1];
+  if (int rc = mural_op_linear_bwd(dlogits, x_last, L.out.weight, B, h[1], P.nc, g0, const_cast<float*>(G.out.weight),
+                                   const_cast<float*>(G.out.bias), c.stream)) return rc;
+  const float* d = g0;
+  for (int i = 1; i >= 0; --i) {
+    const float* dd;
+    if (int rc = dropout_b(c, d, (int64_t)B * h[i], drop[1 + i], seeds[1 + i], seed_dev, g1, &dd)) return rc;
+    float* st = l.bn_state[i];
+    if (int rc = mural_op_bn_backward(dd, l.lin[i], B, h[i], 1, 1, st + 2 * h[i], st + 3 * h[i], L.bn[i].weight, l.acc_b[i], 0, nullptr,
+                                      nullptr, g2, const_cast<float*>(G.bn[i].weight), const_cast<float*>(G.bn[i].bias), c.stream)) return rc;
+    const int in = i == 0 ? in1 : h[0];
+    const float* xin = i == 0 ? (drop[0] > 0.f ? l.emb_do : l.emb) : (drop[1] > 0.f ? l.dout[0] : l.bn_out[0]);
+    if (int rc = mural_op_linear_bwd(g2, xin, L.lin[i].weight, B, in, h[i], g0, const_cast<float*>(G.lin[i].weight),
+                                     const_cast<float*>(G.lin[i].bias), c.stream)) return rc;
+    d = g0;
+  }
+  const float* de;
+  if (int rc = dropout_b(c, d, (int64_t)B * in1, drop[0], seeds[0], seed_dev, g1, &de)) return rc;
+  MURAL_HIP_CHECK(hipMemsetAsync(const_cast<float*>(G.emb), 0, (size_t)sh.emb_rows * 5 * 4, (hipStream_t)c.stream));
+  return mural_op_embedding_bwd(cat, de, B, sh.local_cols, sh.emb_rows, const_cast<float*>(G.emb), c.stream);
+}
+
+int check_shape(const MuralSnvShape* sh) {
+  MURAL_REQUIRE(sh, "shape is NULL");
+  MURAL_REQUIRE(sh->model_no >= 0 && sh->model_no <= 2, "model_no for snv must be one of [0, 1, 2], got %d", sh->model_no);
+  MURAL_REQUIRE(sh->n_class >= 1 && sh->n_class <= SNV_MAXCLASS, "n_class must be in [1,%d], got %d", SNV_MAXCLASS, sh->n_class);
+  if (sh->model_no != 0) {
+    MURAL_REQUIRE(sh->channels == SNV_C && sh->ksize == SNV_K,
+                  "the fused training step is built for CNN_out_channels=32, CNN_kernel_size=3 (got %d, %d)", sh->channels, sh->ksize);
+    MURAL_REQUIRE(sh->distal_len > 200, "Error: distal seq len must be >200");
+  }
+  if (sh->model_no != 1) MURAL_REQUIRE(sh->local_cols >= 1 && sh->emb_rows >= 2 && sh->hidden1 >= 1 && sh->hidden2 >= 1, "bad local-branch shape");
+  return MURAL_OK;
+}
+
+}  // namespace
+
+extern "C" size_t mural_snv_train_workspace_bytes(const MuralSnvShape* shape, int64_t B) {
+  if (check_shape(shape) || B <= 0) return 0;
+  Plan P;
+  if (make_plan(*shape, B, nullptr, &P)) return 0;
+  return P.total;
+}
+
+extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSnvParams* params, const int64_t* cat_x,
+                                       const float* distal_x, const uint8_t* symbols, int64_t B, const float* dropout_p, const uint64_t* seeds,
+                                       const uint64_t* seed_dev, float momentum, float* out, void* workspace, size_t workspace_bytes,
+                                       int32_t* status, void* stream) {
+  if (int rc = check_shape(shape)) return rc;
+  MURAL_REQUIRE(params && out && dropout_p && seeds, "NULL argument");
+  MURAL_REQUIRE(B >= 2, "a batch-statistics BatchNorm needs at least two rows (training.py:415 skips batches of one)");
+  Plan P;
+  if (int rc = make_plan(*shape, B, workspace, &P)) return rc;
+  if (!workspace || workspace_bytes < P.total) {
+    set_error("workspace too small: need %zu bytes, got %zu", P.total, workspace_bytes);
+    return MURAL_E_WORKSPACE;
+  }
+  Ctx c{shape, params, nullptr, &P, momentum, stream};
+  MURAL_HIP_CHECK(hipMemsetAsync(P.acc_begin, 0, P.acc_bytes, (hipStream_t)stream));
+  const int m = shape->model_no;
+  if (m != 1) {
+    MURAL_REQUIRE(cat_x, "cat_x is NULL");
+    if (int rc = local_f(c, cat_x, dropout_p, seeds, seed_dev)) return rc;
+    if (m == 0) {      // raw logits, model_snv.py:93
+      MURAL_HIP_CHECK(hipMemcpyAsync(out, P.loc.logits, (size_t)B * shape->n_class * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+      return MURAL_OK;
+    }
+  }
+  MURAL_REQUIRE(distal_x || symbols, "distal_x and symbols are both NULL");
+  if (symbols) {
+    MURAL_HIP_CHECK(hipMemcpyAsync(P.sym, symbols, (size_t)B * shape->distal_len, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  } else if (int rc = mural_op_dense_to_symbols(distal_x, B, shape->distal_len, P.sym, status, stream)) {
+    return rc;
+  }
+  if (int rc = tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev)) return rc;
+  if (int rc = tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev)) return rc;
+  return mural_op_head_fwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, B, shape->n_class, out, stream);
+}
+
+extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralSnvParams* params, const MuralSnvParams* grads,
+                                        const int64_t* cat_x, const float* dout, int64_t B, const float* dropout_p,
+                                        const uint64_t* seeds, const uint64_t* seed_dev, void* workspace, size_t workspace_bytes,
+                                        void* stream) {
+  if (int rc = check_shape(shape)) return rc;
+  MURAL_REQUIRE(params && grads && dout && dropout_p && seeds, "NULL argument");
+  Plan P;
+  if (int rc = make_plan(*shape, B, workspace, &P)) return rc;
+  if (!workspace || workspace_bytes < P.total) {
+    set_error("workspace too small: need %zu bytes, got %zu", P.total, workspace_bytes);
+    return MURAL_E_WORKSPACE;
+  }
+  Ctx c{shape, params, grads, &P, 0.f, stream};
+  const int m = shape->model_no, nc = shape->n_class;
+  if (m == 0) return local_b(c, cat_x, dout, dropout_p, seeds, seed_dev);
+  if (int rc = mural_op_head_bwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, dout, B, nc, m == 2 ? P.dlogit[0] : nullptr,
+                                 P.dlogit[1], P.dlogit[2], stream)) return rc;
+  if (m == 2)
+    if (int rc = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev)) return rc;
+  if (int rc = tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev)) return rc;
+  return tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);
+}

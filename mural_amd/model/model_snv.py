@@ -169,10 +169,12 @@ class _HipSnvBase(nn.Module):
 
     def _apply(self, fn, *args, **kwargs):
         self.invalidate_folded()
+        self._train_layout = None           # tensor objects / storages may be replaced
         return super()._apply(fn, *args, **kwargs)
 
     def load_state_dict(self, *args, **kwargs):
         self.invalidate_folded()
+        self._train_layout = None
         return super().load_state_dict(*args, **kwargs)
 
     def _state_key(self):
@@ -442,14 +444,11 @@ class FeedForwardNN(_HipSnvBase):
         return shape, params, hp
 
     def forward(self, cont_data, cat_data):
-        if self.training:     # per-op HIP kernels under autograd (train_ops.py)
-            from . import train_ops as T
+        if self.training:     # one autograd node over the C training step (train_step.py / csrc/snv_train.hip)
+            from . import train_step
             cat_data, _ = self._train_inputs(cat_data, None)
             with torch.cuda.device(self._device()):
-                out = T.local_forward(self, cat_data, self.output_layer, self.emb_dropout_layer.p,
-                                      [d.p for d in self.droput_layers])
-                T.flush_bn_ticks()
-                return out
+                return train_step.run(self, cat_data, None)
         return self._forward_dense(cat_data, None)
 
 
@@ -499,8 +498,11 @@ class Network1(_HipSnvBase):
             raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")
         if self.training:
             from . import train_ops as T
+            from . import train_step
             _, distal_input = self._train_inputs(None, distal_input)
             with torch.cuda.device(self._device()):
+                if train_step.supported(self):         # one autograd node over the C training step (csrc/snv_train.hip)
+                    return train_step.run(self, None, distal_input[:, 0:self.in_channels, :])
                 mid, large = _train_towers(self, distal_input[:, 0:self.in_channels, :])
                 T.flush_bn_ticks()
                 return T.Head.apply(None, mid, large)
@@ -539,8 +541,11 @@ class Network2(_HipSnvBase):
             raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")
         if self.training:
             from . import train_ops as T
+            from . import train_step
             cat_data, distal_input = self._train_inputs(cat_data, distal_input)
             with torch.cuda.device(self._device()):
+                if train_step.supported(self):         # one autograd node over the C training step (csrc/snv_train.hip)
+                    return train_step.run(self, cat_data, distal_input[:, 0:self.in_channels, :])
                 loc = T.local_forward(self, cat_data, self.local_fc[0], self.emb_dropout_layer.p,
                                       [d.p for d in self.droput_layers])
                 mid, large = _train_towers(self, distal_input[:, 0:self.in_channels, :])

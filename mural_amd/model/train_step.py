@@ -1,0 +1,166 @@
+"""The SNV training step as ONE autograd node over two C calls (include/mural_hip.h: mural_snv_train_forward / _backward).
+
+``loss.backward()`` of the reference (MuRaL/training.py:424-427) walks ~120 autograd nodes; here the whole model forward is one
+``torch.autograd.Function`` whose forward and backward are one library call each -- the composition of the ~100 kernels per
+direction lives in C++ (csrc/snv_train.hip), so the host costs two ctypes transitions per step instead of one per layer.
+Serves the shipped shape (32 channels, kernel 3); other shapes train on the per-layer ops of ``train_ops.py`` / ``indel_train.py``.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from .. import _lib
+
+MOMENTUM = 0.1
+_SLOTS = C.sizeof(_lib.MuralSnvParams) // 8          # the parameter struct is a flat run of pointers
+
+
+class _Layout:
+    """Which tensor sits in which pointer slot of MuralSnvParams, found by building the struct once with slot tokens."""
+
+    def __init__(self, model):
+        from .model_snv import _HostParams
+        tensors = []
+
+        class Tok(_HostParams):
+            def ptr(self, t):
+                tensors.append(t)
+                return C.c_void_p(len(tensors))            # token = 1-based index into `tensors`
+
+        tok = Tok()
+        params = _lib.MuralSnvParams()
+        if model.model_no != 1:
+            params.local = tok.local(model, model.output_layer if model.model_no == 0 else model.local_fc[0])
+        if model.model_no != 0:
+            params.mid, params.large = tok.tower(model, ""), tok.tower(model, "_2")
+        raw = np.frombuffer(bytes(params), dtype=np.int64)
+        assert raw.shape[0] == _SLOTS
+        self.slot_tensor = [tensors[v - 1] if v else None for v in raw.tolist()]
+        self.plist = [p for p in model.parameters() if p.numel()]
+        index = {id(p): i for i, p in enumerate(self.plist)}
+        # gradient slots: offset of each parameter in one flat float32 buffer (running statistics have none)
+        offs, o = [], 0
+        for p in self.plist:
+            offs.append(o)
+            o += (p.numel() + 63) // 64 * 64
+        self.total = o
+        self.poffs = offs
+        self.grad_off = np.full(_SLOTS, -1, np.int64)
+        for s, t in enumerate(self.slot_tensor):
+            if t is not None and id(t) in index:
+                self.grad_off[s] = offs[index[id(t)]] * 4
+        self.has_grad = self.grad_off >= 0
+        self.counters = [m.num_batches_tracked for m in model.modules()
+                         if isinstance(m, torch.nn.BatchNorm1d) and m.num_batches_tracked is not None and m.weight.numel()]
+        seen, uniq = set(), []
+        for t in self.counters:                       # ResBlock registers its BatchNorms twice
+            if id(t) not in seen:
+                seen.add(id(t))
+                uniq.append(t)
+        self.counters = uniq
+
+    def params_struct(self):
+        for t in self.slot_tensor:
+            if t is not None and (t.dtype is not torch.float32 or not t.is_contiguous()):
+                raise RuntimeError("the HIP training step needs contiguous float32 parameters and buffers")
+        raw = np.array([0 if t is None else t.data_ptr() for t in self.slot_tensor], dtype=np.int64)
+        s = _lib.MuralSnvParams()
+        C.memmove(C.byref(s), raw.ctypes.data, _SLOTS * 8)
+        return s
+
+    def grads_struct(self, base):
+        raw = np.where(self.has_grad, self.grad_off + base, 0)
+        s = _lib.MuralSnvParams()
+        C.memmove(C.byref(s), raw.ctypes.data, _SLOTS * 8)
+        return s
+
+
+def _layout(model):
+    lay = getattr(model, "_train_layout", None)
+    if lay is None:
+        lay = model._train_layout = _Layout(model)
+    return lay
+
+
+def supported(model):
+    return model.model_no == 0 or (model.out_channels == 32 and model.kernel_size == 3)
+
+
+def _make_shape(model):
+    sh = getattr(model, "_train_shape", None)
+    if sh is None:
+        local = model.model_no != 1
+        towers = model.model_no != 0
+        sh = model._train_shape = _lib.MuralSnvShape(
+            model.model_no, model.n_class, model.no_of_cat if local else 0, model.emb_layer.num_embeddings if local else 0,
+            model.lin_layers[0].out_features if local else 0, model.lin_layers[1].out_features if local else 0,
+            model.out_channels if towers else 32, model.kernel_size if towers else 3, model.seq_len if towers else 0, 1e-5)
+    return sh
+
+
+class ModelStep(torch.autograd.Function):
+    """out = model(cat_x, distal_x) in training mode; backward returns the gradient of every parameter."""
+
+    @staticmethod
+    def forward(ctx, model, shape, cat_x, symbols, drops, seeds, seed_dev, *params):
+        lay = _layout(model)
+        dev = params[0].device
+        B = (cat_x if cat_x is not None else symbols).shape[0]
+        lib = _lib.lib()
+        need = int(lib.mural_snv_train_workspace_bytes(C.byref(shape), B))
+        if need == 0:
+            _lib.check(_lib.MURAL_E_INVALID)
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        out = torch.empty((B, model.n_class), dtype=torch.float32, device=dev)
+        ps = lay.params_struct()
+        stream = _lib.current_stream_ptr(dev)
+        _lib.check(lib.mural_snv_train_forward(C.byref(shape), C.byref(ps), None if cat_x is None else cat_x.data_ptr(), None,
+                                               None if symbols is None else symbols.data_ptr(), B, drops.ctypes.data, seeds.ctypes.data,
+                                               None if seed_dev is None else seed_dev.data_ptr(), MOMENTUM, out.data_ptr(), ws.data_ptr(),
+                                               need, None, stream))
+        if lay.counters:
+            torch._foreach_add_(lay.counters, 1)
+        ctx.model, ctx.shape, ctx.ws, ctx.args, ctx.params = model, shape, ws, (cat_x, drops, seeds, seed_dev, B), params
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        model, shape, ws = ctx.model, ctx.shape, ctx.ws
+        cat_x, drops, seeds, seed_dev, B = ctx.args
+        lay = _layout(model)
+        dev = ws.device
+        flat = torch.empty(lay.total, dtype=torch.float32, device=dev)
+        ps, gs = lay.params_struct(), lay.grads_struct(flat.data_ptr())
+        dout = dout.contiguous()
+        _lib.check(_lib.lib().mural_snv_train_backward(C.byref(shape), C.byref(ps), C.byref(gs), None if cat_x is None else cat_x.data_ptr(),
+                                                       dout.data_ptr(), B, drops.ctypes.data, seeds.ctypes.data,
+                                                       None if seed_dev is None else seed_dev.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                       _lib.current_stream_ptr(dev)))
+        ctx.ws = None
+        grads = {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(lay.plist, lay.poffs)}
+        return (None,) * 7 + tuple(grads[id(p)] if p.numel() else torch.zeros_like(p) for p in ctx.params)
+
+
+def run(model, cat_x, distal_x):
+    """Training-mode forward of `model` on (cat_x int64 (B, cols) | None, distal_x float (B, 4, L) | None)."""
+    from . import train_ops as T
+    shape = _make_shape(model)
+    symbols = None
+    if distal_x is not None:
+        symbols = T.dense_to_symbols(distal_x)          # flags non-encodings; checked behind the launches (flush_input_checks)
+    ps = [model.emb_dropout_layer.p, model.droput_layers[0].p, model.droput_layers[1].p] if model.model_no != 1 else [0.0, 0.0, 0.0]
+    ps += [model.distal_fc1[1].p, model.distal_fc2[1].p] if model.model_no != 0 else [0.0, 0.0]
+    drops = np.asarray(ps, dtype=np.float32)
+    seeds = np.zeros(5, dtype=np.uint64)
+    for i, p in enumerate(ps):                          # one draw per active dropout, in the order of the reference's forward
+        if p > 0.0:
+            seeds[i] = int(torch.randint(0, 2 ** 62, (1,)).item())
+    params = list(model.parameters())
+    try:
+        out = ModelStep.apply(model, shape, cat_x, symbols, drops, seeds, T._device_seed, *params)
+        T.flush_input_checks()
+    except BaseException:
+        T._pending_checks.clear()                       # a failed forward must not leave its input check to the next one
+        raise
+    return out
