@@ -52,11 +52,23 @@ struct Conv32Args {
   int pre_relu, post_relu;
   int B, L, R, Sc, NC, nb;
   FastDiv dSc, dL;
+  // optional: finalize the BatchNorm of the conv input here instead of in its own launch.  fin_acc = accumulator block with the
+  // batch sums of act(x); every workgroup derives scale / shift from it, workgroup 0 also writes the state the backward reads
+  // (scale | shift | mean | invstd) and updates the running statistics (exactly what bn_finalize_kernel does, same arithmetic).
+  const double* fin_acc;
+  double fin_n;
+  const float* fin_gamma;
+  const float* fin_beta;
+  float fin_eps, fin_momentum;
+  float* fin_running_mean;
+  float* fin_running_var;
+  float* fin_state;      // [4][32]
 };
 
 // stage the tile's rows (contiguous in memory) into the image, applying the BN(+ReLU) affine; separator columns = 0.
 // `aff` is an LDS copy of pre_s | pre_t (64 floats) or nullptr.  zero_tail: also clear the guard and every column behind the
 // last staged row up to image index `ncols` (kernels that reduce over columns need exact zeros there).
+template <int STAGE_DEPTH = 8>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t b0, int B, int L, int R, int Sc,
                                            const FastDiv& dL, const float* aff, int pre_relu, float* img, int tid,
                                            bool zero_tail, int ncols) {
@@ -64,20 +76,31 @@ __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t 
   const int rows = (int)((B - b0) < R ? (B - b0) : R);
   const int total = rows * C32 * L;                      // a multiple of 4 (32 channels)
   const float* src = x + (size_t)b0 * C32 * L;           // 128-byte aligned: float4 loads
-#pragma unroll 2
-  for (int i0 = tid * 4; i0 < total; i0 += 256 * 4) {
-    const f32x4 v4 = ld4(src + i0);
-    uint32_t rc = dL.div((uint32_t)i0);
-    int l = i0 - (int)rc * L;
+  // The layer is HBM-bound and a workgroup is only 256 threads: keep STAGE_DEPTH 16-byte loads per thread in flight before the first
+  // LDS write (a dependent load-use pair per iteration leaves ~16 KB in flight per CU, a quarter of what the HBM pipe needs).
+  for (int base = tid * 4; base < total; base += 256 * 4 * STAGE_DEPTH) {
+    f32x4 v4[STAGE_DEPTH];
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (l >= L) { l -= L; ++rc; }                      // next (row, channel)
-      const int r = (int)rc >> 5, ci = (int)rc & 31;
-      float v = v4[e];
-      if (pre_relu) v = fmaxf(v, 0.f);
-      if (aff) v = fmaf(aff[ci], v, aff[C32 + ci]);
-      img[ci * pitch + 2 + r * Sc + l] = v;
-      ++l;
+    for (int q = 0; q < STAGE_DEPTH; ++q) {
+      const int i0 = base + q * 256 * 4;
+      v4[q] = i0 < total ? ld4(src + i0) : splat(0.f);
+    }
+#pragma unroll
+    for (int q = 0; q < STAGE_DEPTH; ++q) {
+      const int i0 = base + q * 256 * 4;
+      if (i0 >= total) break;
+      uint32_t rc = dL.div((uint32_t)i0);
+      int l = i0 - (int)rc * L;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (l >= L) { l -= L; ++rc; }                      // next (row, channel)
+        const int r = (int)rc >> 5, ci = (int)rc & 31;
+        float v = v4[q][e];
+        if (pre_relu) v = fmaxf(v, 0.f);
+        if (aff) v = fmaf(aff[ci], v, aff[C32 + ci]);
+        img[ci * pitch + 2 + r * Sc + l] = v;
+        ++l;
+      }
     }
   }
   for (int i = tid; i < (R + 1) * C32; i += 256) img[(i & 31) * pitch + 1 + (i >> 5) * Sc] = 0.f;   // separators
@@ -110,8 +133,38 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const int chv = 16 * mb + 4 * kk;
   const f32x4 bias = a.bias ? ld4(a.bias + chv) : splat(0.f);
   float* aux = img + C32 * pitch;                        // pre_s | pre_t | stat_mean | stat_invstd
-  if (a.pre_s && tid < 2 * C32) aux[tid] = tid < C32 ? a.pre_s[tid] : a.pre_t[tid - C32];
+  if (a.fin_acc) {
+    if (tid < C32) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < MURAL_BN_SLOTS; ++k) {
+        s1 += a.fin_acc[((size_t)k * 2 + 0) * C32 + tid];
+        s2 += a.fin_acc[((size_t)k * 2 + 1) * C32 + tid];
+      }
+      const double mean = s1 / a.fin_n;
+      double var = s2 / a.fin_n - mean * mean;
+      if (var < 0.0) var = 0.0;
+      const double invstd = 1.0 / sqrt(var + (double)a.fin_eps);
+      const float sc = (float)(a.fin_gamma[tid] * invstd);
+      const float sh = (float)(a.fin_beta[tid] - mean * a.fin_gamma[tid] * invstd);
+      aux[tid] = sc;
+      aux[C32 + tid] = sh;
+      if (blockIdx.x == 0) {
+        a.fin_state[tid] = sc;
+        a.fin_state[C32 + tid] = sh;
+        a.fin_state[2 * C32 + tid] = (float)mean;
+        a.fin_state[3 * C32 + tid] = (float)invstd;
+        if (a.fin_running_mean) {
+          const double unbiased = a.fin_n > 1.0 ? var * a.fin_n / (a.fin_n - 1.0) : var;
+          a.fin_running_mean[tid] = (float)((1.0 - a.fin_momentum) * a.fin_running_mean[tid] + a.fin_momentum * mean);
+          a.fin_running_var[tid] = (float)((1.0 - a.fin_momentum) * a.fin_running_var[tid] + a.fin_momentum * unbiased);
+        }
+      }
+    }
+  } else if (a.pre_s && tid < 2 * C32) {
+    aux[tid] = tid < C32 ? a.pre_s[tid] : a.pre_t[tid - C32];
+  }
   if (STAT == 2 && tid < 2 * C32) aux[2 * C32 + tid] = tid < C32 ? a.stat_mean[tid] : a.stat_invstd[tid - C32];
+  const bool has_pre = a.pre_s != nullptr || a.fin_acc != nullptr;
   const int nbw = a.nb > cgp ? (a.nb - cgp + 1) / 2 : 0;
   // operand reads: lane (n16, kk) takes act[cin = 16 h + 4 kk + q][column 16 blk + n16 + tap - 1] = image index (.. + tap)
   const float* rd = img + 4 * kk * pitch + n16;
@@ -122,7 +175,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int64_t b0 = tile * a.R;
     const int rows = (int)((a.B - b0) < a.R ? (a.B - b0) : a.R);
     __syncthreads();
-    stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.dL, a.pre_s ? aux : nullptr, a.pre_relu, img, tid, false, 0);
+    stage_rows<4>(a.x, b0, a.B, a.L, a.R, a.Sc, a.dL, has_pre ? aux : nullptr, a.pre_relu, img, tid, false, 0);
     __syncthreads();
     f32x4 acc[C32_NB2MAX + 1];
 #pragma unroll
@@ -175,30 +228,42 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     // the tile leaves as one contiguous float4 stream (+ residuals); values the sums need go back into the image
     const int total = rows * C32 * a.L;
     const size_t base = (size_t)b0 * C32 * a.L;
+    constexpr int OUT_DEPTH = 2;                          // residual / statistics loads of two float4 groups in flight together
 #pragma unroll 1
-    for (int i0 = tid * 4; i0 < total; i0 += 256 * 4) {
-      const f32x4 r1 = a.res1 ? ld4(a.res1 + base + i0) : splat(0.f);
-      const f32x4 r2 = a.res2 ? ld4(a.res2 + base + i0) : splat(0.f);
-      f32x4 sx = splat(0.f);
-      if (STAT == 2) sx = ld4(a.stat_x + base + i0);
-      uint32_t rc = a.dL.div((uint32_t)i0);
-      int l = i0 - (int)rc * a.L;
-      f32x4 o;
+    for (int ib = tid * 4; ib < total; ib += 256 * 4 * OUT_DEPTH) {
+      f32x4 r1v[OUT_DEPTH], r2v[OUT_DEPTH], sxv[OUT_DEPTH];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (l >= a.L) { l -= a.L; ++rc; }
-        const int r = (int)rc >> 5, ci = (int)rc & 31;
-        const int idx = ci * pitch + 2 + r * a.Sc + l;
-        const float v = (img[idx] + r1[e]) + r2[e];
-        o[e] = v;
-        if (STAT == 1) img[idx] = a.stat_relu ? fmaxf(v, 0.f) : v;
-        if (STAT == 2) {
-          const float xr = a.stat_relu ? fmaxf(sx[e], 0.f) : sx[e];
-          img[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
-        }
-        ++l;
+      for (int q = 0; q < OUT_DEPTH; ++q) {
+        const int i0 = ib + q * 256 * 4;
+        const bool live = i0 < total;
+        r1v[q] = (a.res1 && live) ? ld4(a.res1 + base + i0) : splat(0.f);
+        r2v[q] = (a.res2 && live) ? ld4(a.res2 + base + i0) : splat(0.f);
+        sxv[q] = (STAT == 2 && live) ? ld4(a.stat_x + base + i0) : splat(0.f);
       }
-      st4(a.y + base + i0, o);
+#pragma unroll
+      for (int q = 0; q < OUT_DEPTH; ++q) {
+        const int i0 = ib + q * 256 * 4;
+        if (i0 >= total) break;
+        const f32x4 r1 = r1v[q], r2 = r2v[q], sx = sxv[q];
+        uint32_t rc = a.dL.div((uint32_t)i0);
+        int l = i0 - (int)rc * a.L;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (l >= a.L) { l -= a.L; ++rc; }
+          const int r = (int)rc >> 5, ci = (int)rc & 31;
+          const int idx = ci * pitch + 2 + r * a.Sc + l;
+          const float v = (img[idx] + r1[e]) + r2[e];
+          o[e] = v;
+          if (STAT == 1) img[idx] = a.stat_relu ? fmaxf(v, 0.f) : v;
+          if (STAT == 2) {
+            const float xr = a.stat_relu ? fmaxf(sx[e], 0.f) : sx[e];
+            img[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
+          }
+          ++l;
+        }
+        st4(a.y + base + i0, o);
+      }
     }
     if (STAT) {
       __syncthreads();
@@ -467,24 +532,36 @@ __global__ __launch_bounds__(256) void bwd32_mfma_kernel(const Bwd32Args a) {
     __syncthreads();
     const int total = rows * C32 * a.L;
     const size_t base = (size_t)b0 * C32 * a.L;
+    constexpr int OUT_DEPTH = 4;
 #pragma unroll 1
-    for (int i0 = tid * 4; i0 < total; i0 += 256 * 4) {
-      const f32x4 sx = ld4(a.x + base + i0);
-      uint32_t rc = a.dL.div((uint32_t)i0);
-      int l = i0 - (int)rc * a.L;
-      f32x4 o;
+    for (int ib = tid * 4; ib < total; ib += 256 * 4 * OUT_DEPTH) {
+      f32x4 sxv[OUT_DEPTH];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (l >= a.L) { l -= a.L; ++rc; }
-        const int r = (int)rc >> 5, ci = (int)rc & 31;
-        const int idx = ci * pitch + 2 + r * a.Sc + l;
-        const float v = gimg[idx];
-        o[e] = v;
-        const float xr = a.pre_relu ? fmaxf(sx[e], 0.f) : sx[e];
-        gimg[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
-        ++l;
+      for (int q = 0; q < OUT_DEPTH; ++q) {
+        const int i0 = ib + q * 256 * 4;
+        sxv[q] = i0 < total ? ld4(a.x + base + i0) : splat(0.f);
       }
-      st4(a.dz + base + i0, o);
+#pragma unroll
+      for (int q = 0; q < OUT_DEPTH; ++q) {
+        const int i0 = ib + q * 256 * 4;
+        if (i0 >= total) break;
+        const f32x4 sx = sxv[q];
+        uint32_t rc = a.dL.div((uint32_t)i0);
+        int l = i0 - (int)rc * a.L;
+        f32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (l >= a.L) { l -= a.L; ++rc; }
+          const int r = (int)rc >> 5, ci = (int)rc & 31;
+          const int idx = ci * pitch + 2 + r * a.Sc + l;
+          const float v = gimg[idx];
+          o[e] = v;
+          const float xr = a.pre_relu ? fmaxf(sx[e], 0.f) : sx[e];
+          gimg[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
+          ++l;
+        }
+        st4(a.dz + base + i0, o);
+      }
     }
     __syncthreads();
     {
@@ -566,6 +643,50 @@ __global__ __launch_bounds__(1024) void part_reduce_kernel(const float* __restri
   }
 }
 
+// the same reduction for up to PR_MAXJOBS layers in one launch (blockIdx.y = layer): the backward kernels of a step leave their
+// partial rows in separate regions and one launch at the end of the backward turns them into dW / db
+constexpr int PR_MAXJOBS = 24;
+struct PartJobs {
+  const float* part[PR_MAXJOBS];
+  float* dW[PR_MAXJOBS];
+  float* db[PR_MAXJOBS];
+  int nrow[PR_MAXJOBS];
+};
+
+__global__ __launch_bounds__(1024) void part_reduce_multi_kernel(const PartJobs jobs, int nW, int nB) {
+  __shared__ float sh[16][64];
+  const int job = blockIdx.y;
+  const float* __restrict__ part = jobs.part[job];
+  const int nrow = jobs.nrow[job];
+  const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s = 0.f;
+  if (i < nW + nB) {
+    const size_t rs = (size_t)(nW + nB);
+    const float* p = part + i;
+    int b = slice;
+    float s0 = 0.f, s1 = 0.f;
+    for (; b + 7 * 16 < nrow; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + 16 * q) * rs];
+      s0 += (v[0] + v[1]) + (v[2] + v[3]);
+      s1 += (v[4] + v[5]) + (v[6] + v[7]);
+    }
+    for (; b < nrow; b += 16) s0 += p[(size_t)b * rs];
+    s = s0 + s1;
+  }
+  sh[slice][o] = s;
+  __syncthreads();
+  if (slice == 0 && i < nW + nB) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][o];
+    if (i < nW) jobs.dW[job][i] = t;
+    else if (jobs.db[job]) jobs.db[job][i - nW] = t;
+  }
+}
+
 static bool tile_geometry(int B, int L, int* R, int* Sc, int* NC, int* nb) {
   *Sc = L + 1;
   int r = (C32_MAXCOLS - 1) / *Sc;
@@ -583,6 +704,74 @@ static bool tile_geometry(int B, int L, int* R, int* Sc, int* NC, int* nb) {
   *NC = 1 + r * *Sc;
   *nb = (*NC + 15) / 16;
   return *nb <= 2 * C32_NB2MAX;
+}
+
+// ---- entry points of the composed training step (snv_train.hip) ----------------------------------------------------------
+// forward of BN(batch statistics) -> conv32 with the BatchNorm finalisation folded into the conv launch
+int train_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias,
+                     int post_relu, const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream) {
+  if (B == 0 || L == 0) return MURAL_OK;
+  Conv32Args a;
+  std::memset(&a, 0, sizeof(a));
+  MURAL_REQUIRE(tile_geometry((int)B, L, &a.R, &a.Sc, &a.NC, &a.nb), "conv32: L = %d does not fit the LDS tile", L);
+  a.x = x; a.y = y; a.W = W; a.bias = bias; a.res1 = res1; a.res2 = res2;
+  a.pre_relu = pre_relu; a.post_relu = post_relu; a.B = (int)B; a.L = L;
+  a.stat_mode = acc_out ? 1 : 0; a.stat_relu = out_relu; a.stat_out = acc_out;
+  a.fin_acc = acc; a.fin_n = (double)B * L; a.fin_gamma = gamma; a.fin_beta = beta; a.fin_eps = eps; a.fin_momentum = momentum;
+  a.fin_running_mean = running_mean; a.fin_running_var = running_var; a.fin_state = state;
+  a.dSc = FastDiv::make((uint32_t)a.Sc);
+  a.dL = FastDiv::make((uint32_t)L);
+  const size_t lds = (size_t)(C32 * C32_PITCH + C32_AUX) * 4;
+  const int64_t ntiles = (B + a.R - 1) / a.R;
+  const int grid = (int)(ntiles < 1024 ? ntiles : 1024);
+  if (a.stat_mode) hipLaunchKernelGGL(conv32_mfma_kernel<1>, dim3(grid), dim3(256), lds, stream, a);
+  else hipLaunchKernelGGL(conv32_mfma_kernel<0>, dim3(grid), dim3(256), lds, stream, a);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+size_t train_conv32_part_floats() { return (size_t)512 * (C32 * C32 * 3 + C32); }
+
+// backward kernel only: the partial rows stay in `part` (rows = workgroups launched, returned in *nrow) for reduce_parts()
+int train_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, int pre_relu, float* dz,
+                     double* stat_out, float* part, int* nrow, hipStream_t stream) {
+  Bwd32Args a;
+  std::memset(&a, 0, sizeof(a));
+  MURAL_REQUIRE(tile_geometry((int)B, L, &a.R, &a.Sc, &a.NC, &a.nb), "conv32_bwd: L = %d does not fit the LDS tile", L);
+  a.dy = dy; a.x = x; a.W = W; a.pre_s = state; a.pre_t = state + C32; a.pre_relu = pre_relu; a.mean = state + 2 * C32;
+  a.invstd = state + 3 * C32;
+  a.B = (int)B; a.L = L; a.part = part; a.dz = dz; a.stat_out = stat_out;
+  a.dL = FastDiv::make((uint32_t)L);
+  a.dSc = FastDiv::make((uint32_t)a.Sc);
+  const int64_t ntiles = (B + a.R - 1) / a.R;
+  const int grid = (int)(ntiles < 512 ? ntiles : 512);
+  size_t lds = (size_t)(2 * C32 * C32_PITCH + C32_AUX) * 4;
+  const size_t lds_red = (size_t)4 * (C32 * C32 * 3 + C32) * 4;
+  lds = lds > lds_red ? lds : lds_red;
+  static DynLdsOnce big_lds;
+  if (int rc = big_lds.ensure(&bwd32_mfma_kernel)) return rc;
+  hipLaunchKernelGGL(bwd32_mfma_kernel, dim3(grid), dim3(256), lds, stream, a);
+  MURAL_HIP_CHECK(hipGetLastError());
+  *nrow = grid;
+  return MURAL_OK;
+}
+
+int train_reduce_parts(const float* const* part, const int* nrow, float* const* dW, float* const* db, int njobs, hipStream_t stream) {
+  for (int j0 = 0; j0 < njobs; j0 += PR_MAXJOBS) {
+    PartJobs jobs;
+    std::memset(&jobs, 0, sizeof(jobs));
+    const int n = njobs - j0 < PR_MAXJOBS ? njobs - j0 : PR_MAXJOBS;
+    for (int j = 0; j < n; ++j) {
+      jobs.part[j] = part[j0 + j];
+      jobs.nrow[j] = nrow[j0 + j];
+      jobs.dW[j] = dW[j0 + j];
+      jobs.db[j] = db[j0 + j];
+    }
+    hipLaunchKernelGGL(part_reduce_multi_kernel, dim3((C32 * C32 * 3 + C32 + 63) / 64, n), dim3(1024), 0, stream, jobs, C32 * C32 * 3, C32);
+    MURAL_HIP_CHECK(hipGetLastError());
+  }
+  return MURAL_OK;
 }
 
 }  // namespace mural

@@ -16,6 +16,16 @@
 
 using namespace mural;
 
+namespace mural {   // conv32_mfma.hip
+int train_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
+                     float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias,
+                     int post_relu, const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream);
+size_t train_conv32_part_floats();
+int train_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, int pre_relu, float* dz,
+                     double* stat_out, float* part, int* nrow, hipStream_t stream);
+int train_reduce_parts(const float* const* part, const int* nrow, float* const* dW, float* const* db, int njobs, hipStream_t stream);
+}
+
 namespace {
 
 constexpr int TR_C = 32;
@@ -78,7 +88,7 @@ struct Plan {
   double* acc_begin; size_t acc_bytes;
   // backward temporaries
   float* g[4];              // gradient buffers of the largest activation shape
-  float* part; size_t part_floats;
+  float* part[24]; size_t part_floats;   // one partial-row region per conv32 layer (reduced by ONE launch at the end of the backward)
   float* dlogit[3];         // gradients of the local / mid / large logits
   float* first_scratch;
   size_t total;
@@ -175,8 +185,9 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
   P->acc_bytes = A.off - acc0;
   // ---- backward temporaries
   for (int i = 0; i < 4; ++i) P->g[i] = A.f(max_act);
-  P->part_floats = mural_op_conv32_wgrad_scratch();
-  P->part = A.f(P->part_floats);
+  P->part_floats = train_conv32_part_floats();
+  if (towers)
+    for (int i = 0; i < 20; ++i) P->part[i] = A.f(P->part_floats);
   for (int i = 0; i < 3; ++i) P->dlogit[i] = A.f((size_t)B * sh.n_class);
   if (towers) {
     int64_t tabf, argb, scr = 0, m = 0;
@@ -199,14 +210,22 @@ struct Ctx {
   Plan* P;
   float momentum;
   void* stream;
+  // weight-gradient partial rows waiting for the final reduction
+  int njobs = 0;
+  const float* job_part[24];
+  int job_nrow[24];
+  float* job_dW[24];
+  float* job_db[24];
 };
 
 // ---- forward of one BN -> conv32 layer
 int bnconv_f(Ctx& c, const float* x, int L, int pre_relu, double* acc, bool have_acc, const MuralBN& bn, const MuralAffine& cv,
              float* state, int post_relu, const float* r1, const float* r2, double* acc_out, int out_relu, float* y) {
-  return mural_op_bnconv32_fwd(x, c.P->B, L, pre_relu, acc, have_acc ? 1 : 0, bn.weight, bn.bias, EPS, c.momentum,
-                               const_cast<float*>(bn.running_mean), const_cast<float*>(bn.running_var), state, cv.weight, cv.bias,
-                               post_relu, r1, r2, acc_out, out_relu, y, c.stream);
+  if (!have_acc)
+    if (int rc = mural_op_bn_stats(x, c.P->B, TR_C, L, pre_relu, acc, c.stream)) return rc;
+  return train_conv32_fwd(x, c.P->B, L, pre_relu, acc, bn.weight, bn.bias, EPS, c.momentum, const_cast<float*>(bn.running_mean),
+                          const_cast<float*>(bn.running_var), state, cv.weight, cv.bias, post_relu, r1, r2, acc_out, out_relu, y,
+                          (hipStream_t)c.stream);
 }
 
 int stage_f(Ctx& c, const MuralResBlock* rb, const float* x_in, int L, double* acc_in, bool have_in, StageBufs& s) {
@@ -283,9 +302,15 @@ int local_f(Ctx& c, const int64_t* cat, const float* drop, const uint64_t* seeds
 // ---- backward of one BN -> conv32 layer: dx (+ add1 + add2), parameter gradients to their destinations
 int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const float* state, const MuralBN& bn, const MuralAffine& cv,
              double* acc, const float* add1, const float* add2, const MuralBN& gbn, const MuralAffine& gcv, float* dz, float* dx) {
-  return mural_op_bnconv32_bwd(dy, x, c.P->B, L, pre_relu, state, bn.weight, cv.weight, acc, c.P->part, c.P->part_floats, dz, add1, add2,
-                               const_cast<float*>(gcv.weight), const_cast<float*>(gcv.bias), dx, const_cast<float*>(gbn.weight),
-                               const_cast<float*>(gbn.bias), c.stream);
+  const int j = c.njobs++;
+  MURAL_REQUIRE(j < 20, "internal: more conv layers than partial-row regions");
+  if (int rc = train_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j], (hipStream_t)c.stream))
+    return rc;
+  c.job_part[j] = c.P->part[j];
+  c.job_dW[j] = const_cast<float*>(gcv.weight);
+  c.job_db[j] = const_cast<float*>(gcv.bias);
+  return mural_op_bn_backward(dz, x, c.P->B, TR_C, L, pre_relu, state + 2 * TR_C, state + 3 * TR_C, bn.weight, acc, 1, add1, add2, dx,
+                              const_cast<float*>(gbn.weight), const_cast<float*>(gbn.bias), c.stream);
 }
 
 // d_out: gradient arriving at the stage output (kept intact); d_in: receives the gradient of the stage input; tmp: 3 buffers
@@ -455,5 +480,6 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   if (m == 2)
     if (int rc = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev)) return rc;
   if (int rc = tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev)) return rc;
-  return tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);
+  if (int rc = tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev)) return rc;
+  return train_reduce_parts(c.job_part, c.job_nrow, c.job_dW, c.job_db, c.njobs, (hipStream_t)stream);
 }
