@@ -54,7 +54,7 @@ struct Conv32Args {
   FastDiv dSc, dL;
   // optional: finalize the BatchNorm of the conv input here instead of in its own launch.  fin_acc = accumulator block with the
   // batch sums of act(x); every workgroup derives scale / shift from it, workgroup 0 also writes the state the backward reads
-  // (scale | shift | mean | invstd) and updates the running statistics (exactly what bn_finalize_kernel does, same arithmetic).
+  // (scale | shift | mean | invstd) and updates the running statistics (what bn_finalize_kernel does).
   const double* fin_acc;
   double fin_n;
   const float* fin_gamma;
@@ -68,6 +68,51 @@ struct Conv32Args {
 // stage the tile's rows (contiguous in memory) into the image, applying the BN(+ReLU) affine; separator columns = 0.
 // `aff` is an LDS copy of pre_s | pre_t (64 floats) or nullptr.  zero_tail: also clear the guard and every column behind the
 // last staged row up to image index `ncols` (kernels that reduce over columns need exact zeros there).
+// The two halves of stage_rows for callers that keep a whole tile's loads in flight (issued one tile ahead): NV float4 per thread
+// cover the largest tile (32 channels x 288 columns / 256 threads).
+constexpr int C32_NV = 9;
+__device__ __forceinline__ void load_rows(const float* __restrict__ x, int64_t b0, int B, int L, int R, int tid, f32x4 (&v4)[C32_NV]) {
+  const int rows = (int)((B - b0) < R ? (B - b0) : R);
+  const int total = rows > 0 ? rows * C32 * L : 0;
+  const float* src = x + (size_t)b0 * C32 * L;
+#pragma unroll
+  for (int q = 0; q < C32_NV; ++q) {
+    const int i0 = tid * 4 + q * 256 * 4;
+    v4[q] = i0 < total ? ld4(src + i0) : splat(0.f);
+  }
+}
+
+__device__ __forceinline__ void scatter_rows(const f32x4 (&v4)[C32_NV], int64_t b0, int B, int L, int R, int Sc, const FastDiv& dL,
+                                             const float* aff, int pre_relu, float* img, int tid, int ncols) {
+  constexpr int pitch = C32_PITCH;
+  const int rows = (int)((B - b0) < R ? (B - b0) : R);
+  const int total = rows * C32 * L;
+#pragma unroll
+  for (int q = 0; q < C32_NV; ++q) {
+    const int i0 = tid * 4 + q * 256 * 4;
+    if (i0 >= total) break;
+    uint32_t rc = dL.div((uint32_t)i0);
+    int l = i0 - (int)rc * L;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (l >= L) { l -= L; ++rc; }
+      const int r = (int)rc >> 5, ci = (int)rc & 31;
+      float v = v4[q][e];
+      if (pre_relu) v = fmaxf(v, 0.f);
+      if (aff) v = fmaf(aff[ci], v, aff[C32 + ci]);
+      img[ci * pitch + 2 + r * Sc + l] = v;
+      ++l;
+    }
+  }
+  for (int i = tid; i < (R + 1) * C32; i += 256) img[(i & 31) * pitch + 1 + (i >> 5) * Sc] = 0.f;   // separators
+  const int first = 2 + rows * Sc;                       // exact zeros behind the last staged row (kernels that reduce over columns)
+  const int n = ncols - first + 2;
+  for (int i = tid; i < n * C32; i += 256) {
+    const int k = i >> 5;
+    img[(i & 31) * pitch + (k == 0 ? 0 : first + k - 1)] = 0.f;
+  }
+}
+
 template <int STAGE_DEPTH = 8>
 __device__ __forceinline__ void stage_rows(const float* __restrict__ x, int64_t b0, int B, int L, int R, int Sc,
                                            const FastDiv& dL, const float* aff, int pre_relu, float* img, int tid,
@@ -134,11 +179,27 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
   const f32x4 bias = a.bias ? ld4(a.bias + chv) : splat(0.f);
   float* aux = img + C32 * pitch;                        // pre_s | pre_t | stat_mean | stat_invstd
   if (a.fin_acc) {
+    // 64 sums over the 32 accumulator copies: all 256 threads take part (thread = channel x copy group, its eight loads in flight
+    // together) and meet in LDS -- 32 threads walking the copies one dependent load after the other cost 17 us per launch
+    double* red = reinterpret_cast<double*>(img);          // [8 groups][2][32] doubles, the image is not staged yet
+    {
+      const int c = tid & 31, grp = tid >> 5;
+      double v[8];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        v[2 * q] = a.fin_acc[((size_t)(4 * grp + q) * 2 + 0) * C32 + c];
+        v[2 * q + 1] = a.fin_acc[((size_t)(4 * grp + q) * 2 + 1) * C32 + c];
+      }
+      red[(grp * 2 + 0) * C32 + c] = (v[0] + v[2]) + (v[4] + v[6]);
+      red[(grp * 2 + 1) * C32 + c] = (v[1] + v[3]) + (v[5] + v[7]);
+    }
+    __syncthreads();
     if (tid < C32) {
       double s1 = 0.0, s2 = 0.0;
-      for (int k = 0; k < MURAL_BN_SLOTS; ++k) {
-        s1 += a.fin_acc[((size_t)k * 2 + 0) * C32 + tid];
-        s2 += a.fin_acc[((size_t)k * 2 + 1) * C32 + tid];
+#pragma unroll
+      for (int g = 0; g < MURAL_BN_SLOTS / 4; ++g) {
+        s1 += red[(g * 2 + 0) * C32 + tid];
+        s2 += red[(g * 2 + 1) * C32 + tid];
       }
       const double mean = s1 / a.fin_n;
       double var = s2 / a.fin_n - mean * mean;
@@ -412,13 +473,14 @@ struct Bwd32Args {
   float* part;           // [grid][32*32*3 + 32]
   float* dz;             // [B][32][L]
   double* stat_out;      // accumulator block: sum(dz), sum(dz * xhat)
+  int dbg;               // timing experiments only (MURAL_DEBUG_BWD32): 1 no x re-read, 2 no wgrad MFMA, 4 no dgrad MFMA, 8 no dz store
 };
 
-__global__ __launch_bounds__(256) void bwd32_mfma_kernel(const Bwd32Args a) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void bwd32_mfma_kernel(const Bwd32Args a) {
   extern __shared__ __attribute__((aligned(16))) float wimg[];
   constexpr int pitch = C32_PITCH;
-  float* gimg = wimg;                       // dy tile, later dz / dz * xhat
-  float* aimg = wimg + C32 * pitch;         // BN(act(x)) tile
+  float* gimg = wimg;                       // dy tile
+  float* aimg = wimg + C32 * pitch;         // BN(act(x)) tile, later dz / dz * xhat
   float* aux = aimg + C32 * pitch;          // pre_s | pre_t | mean | invstd
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -452,15 +514,26 @@ __global__ __launch_bounds__(256) void bwd32_mfma_kernel(const Bwd32Args a) {
   const int nbw = a.nb > cgp ? (a.nb - cgp + 1) / 2 : 0;
   const float* rd = gimg + 4 * kk * pitch + n16;
   const int64_t ntiles = ((int64_t)a.B + a.R - 1) / a.R;
+  // both tensors of a tile are requested as one batch of loads, one tile ahead: they fly under the MFMA and stream-out phases of
+  // the previous tile (four dependent load round trips per tile cost more than everything else in this kernel)
+  f32x4 pdy[C32_NV], px[C32_NV];
+  load_rows(a.dy, (int64_t)blockIdx.x * a.R, a.B, a.L, a.R, tid, pdy);
+  load_rows(a.x, (int64_t)blockIdx.x * a.R, a.B, a.L, a.R, tid, px);
   for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const int64_t b0 = tile * a.R;
     const int rows = (int)((a.B - b0) < a.R ? (a.B - b0) : a.R);
     __syncthreads();
-    stage_rows(a.dy, b0, a.B, a.L, a.R, a.Sc, a.dL, nullptr, 0, gimg, tid, true, 16 * a.nb + 1);
-    stage_rows(a.x, b0, a.B, a.L, a.R, a.Sc, a.dL, a.pre_s ? aux : nullptr, a.pre_relu, aimg, tid, true, 16 * a.nb + 1);
+    // (the LDS addresses of a thread's elements do not depend on the tile: without this opaque zero the compiler hoists all 72 of
+    // them out of the tile loop and spills the prefetched tile instead)
+    int tidv = tid;
+    asm volatile("" : "+v"(tidv));
+    if (!(a.dbg & 16)) {
+      scatter_rows(pdy, b0, a.B, a.L, a.R, a.Sc, a.dL, nullptr, 0, gimg, tidv, 16 * a.nb + 1);
+      scatter_rows(px, b0, a.B, a.L, a.R, a.Sc, a.dL, a.pre_s ? aux : nullptr, a.pre_relu, aimg, tidv, 16 * a.nb + 1);
+    } else if (pdy[0].x == 12345.f && px[1].y == 54321.f) gimg[tid] = pdy[3].z + px[5].w;
     __syncthreads();
     // ---- weight gradient: this wave's quarter of the columns
-    for (int s = k_lo; s < k_hi; ++s) {
+    for (int s = k_lo; s < ((a.dbg & 2) ? k_lo : k_hi); ++s) {
       float g[2], bv[3][2];
 #pragma unroll
       for (int m = 0; m < 2; ++m) g[m] = gp[16 * m * pitch + 4 * s];
@@ -475,19 +548,19 @@ __global__ __launch_bounds__(256) void bwd32_mfma_kernel(const Bwd32Args a) {
 #pragma unroll
           for (int h = 0; h < 2; ++h) wacc[m][t][h] = __builtin_amdgcn_mfma_f32_16x16x4f32(g[m], bv[t][h], wacc[m][t][h], 0, 0, 0);
     }
-    {   // bias gradient: thread = (cout tid/8, column residue tid%8)
+    if (!(a.dbg & 64)) {   // bias gradient: thread = (cout tid/8, column residue tid%8)
       const int co = tid >> 3, p8 = tid & 7;
       const float* row = gimg + co * pitch + 1;
       float sum = 0.f;
       for (int c = p8; c < 16 * a.nb; c += 8) sum += row[c];
       bacc += sum;
     }
-    // ---- input gradient: this wave's M-block against every second column block of the dy image
-    f32x4 acc[C32_NB2MAX + 1];
+    __syncthreads();                                     // the BN(act(x)) image is dead: the input gradient is written over it
+    // ---- input gradient: this wave's M-block against every second column block of the dy image, straight into the dead image
 #pragma unroll
     for (int ip = 0; ip < (C32_NB2MAX + 1) / 2; ++ip) {
       const int i0 = 2 * ip, i1 = 2 * ip + 1;
-      if (i0 < nbw) {
+      if (i0 < nbw && !(a.dbg & 4)) {
         const bool dual = i1 < nbw;
         const float* p0 = rd + 16 * (cgp + 2 * i0);
         const float* p1 = rd + 16 * (cgp + 2 * (dual ? i1 : i0));
@@ -507,39 +580,40 @@ __global__ __launch_bounds__(256) void bwd32_mfma_kernel(const Bwd32Args a) {
           }
           __builtin_amdgcn_sched_barrier(0);
         }
-        acc[i0] = a0;
-        acc[i1] = a1;
-      }
-    }
-    __syncthreads();                                     // every wave is done with the dy image: overwrite it with dz
 #pragma unroll
-    for (int i = 0; i < C32_NB2MAX; ++i) {
-      if (i < nbw) {
-        const int c = 16 * (cgp + 2 * i) + n16;
-        const f32x4 v = acc[i];
+        for (int u = 0; u < 2; ++u) {
+          if (u == 1 && !dual) break;
+          const f32x4 v = u == 0 ? a0 : a1;
+          const int c = 16 * (cgp + 2 * (i0 + u)) + n16;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) gimg[(chv + q) * pitch + 1 + c] = v[q];
-        if (c >= 1) {
-          const uint32_t u = (uint32_t)(c - 1);
-          const uint32_t r = a.dSc.div(u);
-          if ((int)r < rows && (int)(u - r * (uint32_t)a.Sc) < a.L) {
+          for (int q = 0; q < 4; ++q) aimg[(chv + q) * pitch + 1 + c] = v[q];
+          if (c >= 1) {
+            const uint32_t uu = (uint32_t)(c - 1);
+            const uint32_t r = a.dSc.div(uu);
+            if ((int)r < rows && (int)(uu - r * (uint32_t)a.Sc) < a.L) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) sv[q] += v[q];
+              for (int q = 0; q < 4; ++q) sv[q] += v[q];
+            }
           }
         }
       }
     }
     __syncthreads();
+    // the MFMA phases are over and their registers free: request the next tile now, it lands while this one streams out
+    if (tile + gridDim.x < ntiles) {
+      load_rows(a.dy, (tile + gridDim.x) * a.R, a.B, a.L, a.R, tid, pdy);
+      load_rows(a.x, (tile + gridDim.x) * a.R, a.B, a.L, a.R, tid, px);
+    }
     const int total = rows * C32 * a.L;
     const size_t base = (size_t)b0 * C32 * a.L;
-    constexpr int OUT_DEPTH = 4;
+    constexpr int OUT_DEPTH = 2;
 #pragma unroll 1
-    for (int ib = tid * 4; ib < total; ib += 256 * 4 * OUT_DEPTH) {
+    for (int ib = tid * 4; ib < ((a.dbg & 32) ? 0 : total); ib += 256 * 4 * OUT_DEPTH) {
       f32x4 sxv[OUT_DEPTH];
 #pragma unroll
       for (int q = 0; q < OUT_DEPTH; ++q) {
         const int i0 = ib + q * 256 * 4;
-        sxv[q] = i0 < total ? ld4(a.x + base + i0) : splat(0.f);
+        sxv[q] = (i0 < total && !(a.dbg & 1)) ? ld4(a.x + base + i0) : splat(0.f);
       }
 #pragma unroll
       for (int q = 0; q < OUT_DEPTH; ++q) {
@@ -554,21 +628,21 @@ __global__ __launch_bounds__(256) void bwd32_mfma_kernel(const Bwd32Args a) {
           if (l >= a.L) { l -= a.L; ++rc; }
           const int r = (int)rc >> 5, ci = (int)rc & 31;
           const int idx = ci * pitch + 2 + r * a.Sc + l;
-          const float v = gimg[idx];
+          const float v = aimg[idx];
           o[e] = v;
           const float xr = a.pre_relu ? fmaxf(sx[e], 0.f) : sx[e];
-          gimg[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
+          aimg[idx] = v * ((xr - aux[2 * C32 + ci]) * aux[3 * C32 + ci]);
           ++l;
         }
-        st4(a.dz + base + i0, o);
+        if (!(a.dbg & 8)) st4(a.dz + base + i0, o);
       }
     }
     __syncthreads();
     {
       const int ch = tid >> 3, p8 = tid & 7;
       float s1 = 0.f;
-      for (int r = 0; r < rows; ++r) {
-        const float* row = gimg + ch * pitch + 2 + r * a.Sc;
+      for (int r = 0; r < ((a.dbg & 64) ? 0 : rows); ++r) {
+        const float* row = aimg + ch * pitch + 2 + r * a.Sc;
         for (int l = p8; l < a.L; l += 8) s1 += row[l];
       }
       racc += s1;
@@ -742,6 +816,7 @@ int train_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B,
   a.dy = dy; a.x = x; a.W = W; a.pre_s = state; a.pre_t = state + C32; a.pre_relu = pre_relu; a.mean = state + 2 * C32;
   a.invstd = state + 3 * C32;
   a.B = (int)B; a.L = L; a.part = part; a.dz = dz; a.stat_out = stat_out;
+  if (const char* e = getenv("MURAL_DEBUG_BWD32")) a.dbg = atoi(e);
   a.dL = FastDiv::make((uint32_t)L);
   a.dSc = FastDiv::make((uint32_t)a.Sc);
   const int64_t ntiles = (B + a.R - 1) / a.R;
@@ -853,6 +928,7 @@ extern "C" int mural_op_conv32_bwd(const float* dy, const float* x, const float*
   MURAL_REQUIRE(dy && x && W && mean && invstd && dW && db && dz && stat_out, "conv32_bwd: NULL argument");
   a.dy = dy; a.x = x; a.W = W; a.pre_s = pre_s; a.pre_t = pre_t; a.pre_relu = pre_relu; a.mean = mean; a.invstd = invstd;
   a.B = (int)B; a.L = L; a.part = part; a.dz = dz; a.stat_out = stat_out;
+  if (const char* e = getenv("MURAL_DEBUG_BWD32")) a.dbg = atoi(e);
   a.dL = FastDiv::make((uint32_t)L);
   a.dSc = FastDiv::make((uint32_t)a.Sc);
   const int64_t ntiles = (B + a.R - 1) / a.R;
