@@ -186,7 +186,7 @@ def train_steps_per_s(device, genome, B=4096, steps=200, warmup=20, sync_steps=5
     `sync_steps` individually synchronised ones (the reference reads loss.item() every step, training.py:437)."""
     import torch.nn as nn
     model = build_model(device).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)       # one multi-tensor launch; same update rule
     crit = nn.CrossEntropyLoss(reduction="sum")
     rng = np.random.default_rng(1)
     total = steps + warmup + sync_steps
@@ -287,7 +287,7 @@ def indel_positions_per_s(device, genome, n=100_000, chunk=20_000):
     # one training configuration of the same model: batch 128 (the reference's default), CE(sum) + clip + Adam
     tb = 128
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)       # one multi-tensor launch; same update rule
     crit = torch.nn.CrossEntropyLoss(reduction="sum")
     x = genome.encode_onehot(pos[:tb], strand[:tb], 4000, "indel")
     y = (idx[:tb] % 8)

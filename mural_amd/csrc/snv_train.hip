@@ -24,6 +24,11 @@ size_t train_conv32_part_floats();
 int train_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, int pre_relu, float* dz,
                      double* stat_out, float* part, int* nrow, hipStream_t stream);
 int train_reduce_parts(const float* const* part, const int* nrow, float* const* dW, float* const* db, int njobs, hipStream_t stream);
+// train_ops.hip
+int train_bn2d_apply_dropout(const float* x, int64_t B, int C, int relu, const double* acc, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, float* state, float p, uint64_t seed,
+                             const uint64_t* seed_dev, float* y_bn, float* y, hipStream_t stream);
+int train_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t rows, int L, float* dx, hipStream_t stream);
 }
 
 namespace {
@@ -266,12 +271,10 @@ int tower_f(Ctx& c, int t, const MuralTower& T, float drop_p, uint64_t seed, con
   if (int rc = mural_op_maxpool_fwd(b.c3, (int64_t)B * TR_C, g.L[2], g.L[2], g.L[2], 0, b.feat, b.argg, c.stream)) return rc;
   // distal_fc: BatchNorm1d -> Dropout -> Linear on (B, 32)
   if (int rc = mural_op_bn_stats(b.feat, B, TR_C, 1, 0, b.acc_fc_f, c.stream)) return rc;
-  if (int rc = mural_op_bn_finalize(b.acc_fc_f, (double)B, TR_C, T.fc_bn.weight, T.fc_bn.bias, EPS, c.momentum,
-                                    const_cast<float*>(T.fc_bn.running_mean), const_cast<float*>(T.fc_bn.running_var), b.fc_state,
-                                    b.fc_state + TR_C, b.fc_state + 2 * TR_C, b.fc_state + 3 * TR_C, c.stream)) return rc;
-  if (int rc = mural_op_bn_apply(b.feat, B, TR_C, 1, 0, b.fc_state, b.fc_state + TR_C, b.fb, c.stream)) return rc;
-  const float* fin;
-  if (int rc = dropout_f(c, b.fb, (int64_t)B * TR_C, drop_p, seed, seed_dev, b.fd, &fin)) return rc;
+  if (int rc = train_bn2d_apply_dropout(b.feat, B, TR_C, 0, b.acc_fc_f, T.fc_bn.weight, T.fc_bn.bias, EPS, c.momentum,
+                                        const_cast<float*>(T.fc_bn.running_mean), const_cast<float*>(T.fc_bn.running_var), b.fc_state, drop_p,
+                                        seed, seed_dev, nullptr, b.fd, (hipStream_t)c.stream)) return rc;
+  const float* fin = b.fd;
   return mural_op_linear_fwd(fin, T.fc.weight, T.fc.bias, B, TR_C, P.nc, b.logits, c.stream);
 }
 
@@ -288,12 +291,10 @@ int local_f(Ctx& c, const int64_t* cat, const float* drop, const uint64_t* seeds
   for (int i = 0; i < 2; ++i) {   // Linear -> ReLU -> BN -> Dropout (model_snv.py:466-467)
     if (int rc = mural_op_linear_fwd(x, L.lin[i].weight, L.lin[i].bias, B, in, h[i], l.lin[i], c.stream)) return rc;
     if (int rc = mural_op_bn_stats(l.lin[i], B, h[i], 1, 1, l.acc_f[i], c.stream)) return rc;
-    float* st = l.bn_state[i];
-    if (int rc = mural_op_bn_finalize(l.acc_f[i], (double)B, h[i], L.bn[i].weight, L.bn[i].bias, EPS, c.momentum,
-                                      const_cast<float*>(L.bn[i].running_mean), const_cast<float*>(L.bn[i].running_var), st, st + h[i],
-                                      st + 2 * h[i], st + 3 * h[i], c.stream)) return rc;
-    if (int rc = mural_op_bn_apply(l.lin[i], B, h[i], 1, 1, st, st + h[i], l.bn_out[i], c.stream)) return rc;
-    if (int rc = dropout_f(c, l.bn_out[i], (int64_t)B * h[i], drop[1 + i], seeds[1 + i], seed_dev, l.dout[i], &x)) return rc;
+    if (int rc = train_bn2d_apply_dropout(l.lin[i], B, h[i], 1, l.acc_f[i], L.bn[i].weight, L.bn[i].bias, EPS, c.momentum,
+                                          const_cast<float*>(L.bn[i].running_mean), const_cast<float*>(L.bn[i].running_var), l.bn_state[i],
+                                          drop[1 + i], seeds[1 + i], seed_dev, nullptr, l.dout[i], (hipStream_t)c.stream)) return rc;
+    x = l.dout[i];
     in = h[i];
   }
   return mural_op_linear_fwd(x, L.out.weight, L.out.bias, B, in, P.nc, l.logits, c.stream);
@@ -343,7 +344,7 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   TowerBufs& b = P.tw[t];
   const int B = P.B;
   float *g0 = P.g[0], *g1 = P.g[1], *g2 = P.g[2], *g3 = P.g[3];
-  const float* fin = drop_p > 0.f ? b.fd : b.fb;
+  const float* fin = b.fd;
   // Linear -> Dropout -> BatchNorm1d on (B, 32)
   if (int rc = mural_op_linear_bwd(dlogits, fin, T.fc.weight, B, TR_C, P.nc, g0, const_cast<float*>(G.fc.weight),
                                    const_cast<float*>(G.fc.bias), c.stream)) return rc;
@@ -353,8 +354,7 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
                                     nullptr, nullptr, g2, const_cast<float*>(G.fc_bn.weight), const_cast<float*>(G.fc_bn.bias), c.stream))
     return rc;                                                                      // g2 = d feat
   // global max, ReLU of conv3
-  if (int rc = mural_op_maxpool_bwd(g2, b.argg, (int64_t)B * TR_C, g.L[2], 1, g.L[2], g.L[2], 0, g0, c.stream)) return rc;
-  if (int rc = mural_op_relu_mask(g0, b.c3, (int64_t)B * TR_C * g.L[2], g1, c.stream)) return rc;
+  if (int rc = train_gmax_relu_bwd(g2, b.argg, b.c3, (int64_t)B * TR_C, g.L[2], g1, (hipStream_t)c.stream)) return rc;
   if (int rc = bnconv_b(c, g1, b.p3, g.L[2], 0, b.state_c3, T.bn_out, T.conv_out, b.acc_c3_b, nullptr, nullptr, G.bn_out, G.conv_out, g0,
                         g2)) return rc;                                            // g2 = d p3
   if (int rc = mural_op_maxpool_bwd(g2, b.arg3, (int64_t)B * TR_C, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, c.stream)) return rc;
@@ -381,7 +381,7 @@ int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop,
   LocalBufs& l = P.loc;
   const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
   float *g0 = P.g[0], *g1 = P.g[1], *g2 = P.g[2];
-  const float* x_last = drop[2] > 0.f ? l.dout[1] : l.bn_out[1];
+  const float* x_last = l.dout[1];
   if (int rc = mural_op_linear_bwd(dlogits, x_last, L.out.weight, B, h[1], P.nc, g0, const_cast<float*>(G.out.weight),
                                    const_cast<float*>(G.out.bias), c.stream)) return rc;
   const float* d = g0;
@@ -392,7 +392,7 @@ int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop,
     if (int rc = mural_op_bn_backward(dd, l.lin[i], B, h[i], 1, 1, st + 2 * h[i], st + 3 * h[i], L.bn[i].weight, l.acc_b[i], 0, nullptr,
                                       nullptr, g2, const_cast<float*>(G.bn[i].weight), const_cast<float*>(G.bn[i].bias), c.stream)) return rc;
     const int in = i == 0 ? in1 : h[0];
-    const float* xin = i == 0 ? (drop[0] > 0.f ? l.emb_do : l.emb) : (drop[1] > 0.f ? l.dout[0] : l.bn_out[0]);
+    const float* xin = i == 0 ? (drop[0] > 0.f ? l.emb_do : l.emb) : l.dout[0];
     if (int rc = mural_op_linear_bwd(g2, xin, L.lin[i].weight, B, in, h[i], g0, const_cast<float*>(G.lin[i].weight),
                                      const_cast<float*>(G.lin[i].bias), c.stream)) return rc;
     d = g0;

@@ -18,6 +18,8 @@ using f32x4_t = __attribute__((ext_vector_type(4))) float;
 
 constexpr int BN_SLOTS = MURAL_BN_SLOTS;
 
+__device__ __forceinline__ uint64_t mix64(uint64_t z);
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
@@ -104,6 +106,82 @@ __global__ void bn_apply_kernel(const float* __restrict__ x, int64_t total, int 
     float v = x[i];
     if (relu) v = fmaxf(v, 0.f);
     y[i] = fmaf(scale[c], v, shift[c]);
+  }
+}
+
+// ---- small fused forms used by the composed training step (snv_train.hip) on (B, C) feature tensors ----------------------
+// y = dropout(scale * a(x) + shift) with scale / shift derived from the batch sums in `acc` by every workgroup; workgroup 0 also
+// writes the state (scale | shift | mean | invstd, [4][C]) and the running statistics: BatchNorm finalisation, affine map and
+// dropout of `Linear -> ReLU -> BatchNorm1d -> Dropout` (model_snv.py:466-467) and of distal_fc (:383-385) in one launch
+__global__ __launch_bounds__(256) void bn2d_apply_dropout_kernel(const float* __restrict__ x, int64_t B, int C, int relu,
+                                                                 const double* __restrict__ acc, const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, float eps, float momentum,
+                                                                 float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                                 float* __restrict__ state, float p, uint64_t seed,
+                                                                 const uint64_t* __restrict__ seed_dev, float* __restrict__ y_bn,
+                                                                 float* __restrict__ y) {
+  extern __shared__ float cst[];      // [C][2] scale, shift
+  const double n = (double)B;
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double s1 = 0.0, s2 = 0.0;
+    double v1[BN_SLOTS], v2[BN_SLOTS];
+#pragma unroll
+    for (int k = 0; k < BN_SLOTS; ++k) {
+      v1[k] = acc[((size_t)k * 2 + 0) * C + c];
+      v2[k] = acc[((size_t)k * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int k = 0; k < BN_SLOTS; ++k) {
+      s1 += v1[k];
+      s2 += v2[k];
+    }
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)(gamma[c] * invstd), sh = (float)(beta[c] - mean * gamma[c] * invstd);
+    cst[2 * c] = sc;
+    cst[2 * c + 1] = sh;
+    if (blockIdx.x == 0) {
+      state[c] = sc;
+      state[C + c] = sh;
+      state[2 * C + c] = (float)mean;
+      state[3 * C + c] = (float)invstd;
+      if (running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
+    }
+  }
+  __syncthreads();
+  if (seed_dev) seed += *seed_dev;
+  const float keep_scale = 1.f / (1.f - p);
+  const int64_t total = B * C;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    float v = x[i];
+    if (relu) v = fmaxf(v, 0.f);
+    v = fmaf(cst[2 * c], v, cst[2 * c + 1]);
+    if (y_bn) y_bn[i] = v;
+    if (p > 0.f) {
+      const uint64_t r = mix64(seed + 0x9E3779B97F4A7C15ull * (uint64_t)(i + 1));
+      const float u = (float)(r >> 40) * (1.f / 16777216.f);
+      v = u >= p ? v * keep_scale : 0.f;
+    }
+    y[i] = v;
+  }
+}
+
+// dc3[b][c][l] = (l == arg[b][c] && c3[b][c][l] > 0) ? dfeat[b][c] : 0: backward of the global max over columns and of the ReLU
+// in front of it (model_snv.py:487-489) in one pass
+__global__ void gmax_relu_bwd_kernel(const float* __restrict__ dfeat, const int32_t* __restrict__ arg, const float* __restrict__ c3,
+                                     int64_t rows, int L, float* __restrict__ dx) {
+  const int64_t total = rows * L;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / L;
+    const int l = (int)(i - r * L);
+    dx[i] = (arg[r] == l && c3[i] > 0.f) ? dfeat[r] : 0.f;
   }
 }
 
@@ -1098,6 +1176,26 @@ extern "C" int mural_op_head_bwd(const float* loc, const float* mid, const float
                      dmid, dlar);
   CHECK_LAUNCH();
 }
+
+namespace mural {
+int train_bn2d_apply_dropout(const float* x, int64_t B, int C, int relu, const double* acc, const float* gamma, const float* beta, float eps,
+                             float momentum, float* running_mean, float* running_var, float* state, float p, uint64_t seed,
+                             const uint64_t* seed_dev, float* y_bn, float* y, hipStream_t stream) {
+  const int64_t total = B * C;
+  if (total == 0) return MURAL_OK;
+  hipLaunchKernelGGL(bn2d_apply_dropout_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), (size_t)C * 8, stream, x, B, C, relu, acc, gamma,
+                     beta, eps, momentum, running_mean, running_var, state, p, seed, seed_dev, y_bn, y);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+int train_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t rows, int L, float* dx, hipStream_t stream) {
+  if (rows * L == 0) return MURAL_OK;
+  hipLaunchKernelGGL(gmax_relu_bwd_kernel, dim3(grid_for(rows * L)), dim3(256), 0, stream, dfeat, arg, c3, rows, L, dx);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+}  // namespace mural
 
 namespace mural { int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream); }
 // dense (n,4,L) MuRaL encoding -> 1 symbol per column (status: see mural_snv_forward_dense)
