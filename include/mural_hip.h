@@ -319,6 +319,17 @@ int mural_snv_train_backward(const MuralSnvShape* shape, const MuralSnvParams* p
                              const int64_t* cat_x, const float* dout, int64_t B, const float* dropout_p, const uint64_t* seeds,
                              const uint64_t* seed_dev, void* workspace, size_t workspace_bytes, void* stream);
 
+/* Validation hooks of the parity tests: the channel-last conv kernels of the composed training step on their own.  Tensors are
+ * [B][L][32]; acc blocks are double[MURAL_BN_SLOTS][2][32] (the forward reads the batch sums of act(x) from `acc` and finalises the
+ * BatchNorm itself; acc_out / stat_out zeroed by the caller); part: 512 * (32*32*3 + 32) floats of partial rows, *nrow of them written. */
+int mural_debug_cl_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
+                              const float* beta, float* running_mean, float* running_var, float* state, const float* W,
+                              const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,
+                              int32_t out_relu, float* y, void* stream);
+int mural_debug_cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* state,
+                              int32_t pre_relu, float* dz, double* stat_out, float* part, int32_t* nrow, void* stream);
+int mural_debug_cl_bn_stats(const float* x, int64_t rows, int32_t relu, double* acc, void* stream);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

@@ -89,6 +89,7 @@ struct FirstTrainArgs {
   uint8_t* arg;                   // [B][L2][32] window offset of the pooled maximum (written forward, read backward)
   const float* dy;                // backward: [B][32][L2]
   float* dpart;                   // backward: [grid][SNV_LUTBLK] per-workgroup gradient tables
+  int cl;                         // 1: y / dy are channel-last [B][L2][32] (the composed training step), 0: [B][32][L2]
 };
 int first_train_grid(int64_t B);
 bool first_train_supported(int C, int pk);

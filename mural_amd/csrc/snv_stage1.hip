@@ -255,8 +255,8 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_site_kernel(const Stage
 
 template <int SLOT>
 __device__ __forceinline__ void pooled_lookup_train(const Stage1Tower& g, int lane, const float* lutS, const uint8_t* cb0,
-                                                    const uint8_t* kw, float* __restrict__ y /* [32][L2] */,
-                                                    uint8_t* __restrict__ arg /* [L2][32] */) {
+                                                    const uint8_t* kw, float* __restrict__ y /* [32][L2] or [L2][32] */,
+                                                    uint8_t* __restrict__ arg /* [L2][32] */, int cl) {
   const float* tapS = lutS + SNV_LUT;
   const float* b0S = tapS + SNV_TAPS;
   const uint8_t* cb = cb0 + g.col0;
@@ -315,8 +315,12 @@ __device__ __forceinline__ void pooled_lookup_train(const Stage1Tower& g, int la
         }
       }
     }
+    if (cl) {
+      *reinterpret_cast<f32x4*>(y + (size_t)j2 * 32 + 4 * cg) = f32x4{m[0], m[1], m[2], m[3]};
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) y[(size_t)(4 * cg + q) * g.L2 + j2] = m[q];
+      for (int q = 0; q < 4; ++q) y[(size_t)(4 * cg + q) * g.L2 + j2] = m[q];
+    }
     *reinterpret_cast<uint32_t*>(arg + (size_t)j2 * 32 + 4 * cg) = am[0] | (am[1] << 8) | (am[2] << 16) | (am[3] << 24);
   }
 }
@@ -324,8 +328,8 @@ __device__ __forceinline__ void pooled_lookup_train(const Stage1Tower& g, int la
 // gradient scatter: acc = workgroup-private (d lut | d taps | d bias) block in LDS
 template <int SLOT>
 __device__ __forceinline__ void pooled_scatter(const Stage1Tower& g, int lane, float* acc, const uint8_t* cb0,
-                                               const uint8_t* kw, const float* __restrict__ dy /* [32][L2] */,
-                                               const uint8_t* __restrict__ arg /* [L2][32] */) {
+                                               const uint8_t* kw, const float* __restrict__ dy /* [32][L2] or [L2][32] */,
+                                               const uint8_t* __restrict__ arg /* [L2][32] */, int cl) {
   float* tapA = acc + SNV_LUT;
   float* b0A = tapA + SNV_TAPS;
   const uint8_t* cb = cb0 + g.col0;
@@ -339,7 +343,7 @@ __device__ __forceinline__ void pooled_scatter(const Stage1Tower& g, int lane, f
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int c = 4 * cg + q;
-      const float gq = dy[(size_t)c * g.L2 + j2];
+      const float gq = cl ? dy[(size_t)j2 * 32 + c] : dy[(size_t)c * g.L2 + j2];
       const int w = (int)((aw >> (8 * q)) & 0xFFu);
       const uint32_t idx = kw[(size_t)j2 * SLOT + w];
       bsum[q] += gq;
@@ -392,8 +396,8 @@ __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrai
     build_kwin<SLOT>(g, lane, cb, kw);
     wave_lds_fence();
     const size_t o = (size_t)row * 32 * g.L2;
-    if (BWD) pooled_scatter<SLOT>(g, lane, blk, cb, kw, a.dy + o, a.arg + o);
-    else pooled_lookup_train<SLOT>(g, lane, blk, cb, kw, a.y + o, a.arg + o);
+    if (BWD) pooled_scatter<SLOT>(g, lane, blk, cb, kw, a.dy + o, a.arg + o, a.cl);
+    else pooled_lookup_train<SLOT>(g, lane, blk, cb, kw, a.y + o, a.arg + o, a.cl);
     wave_lds_fence();
   }
   if (BWD) {                                  // one partial block per workgroup; first_grad_fold_kernel sums them in order

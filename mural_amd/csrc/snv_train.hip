@@ -16,19 +16,34 @@
 
 using namespace mural;
 
-namespace mural {   // conv32_mfma.hip
-int train_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
-                     float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias,
-                     int post_relu, const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream);
-size_t train_conv32_part_floats();
-int train_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, int pre_relu, float* dz,
-                     double* stat_out, float* part, int* nrow, hipStream_t stream);
+namespace mural {   // conv32_cl.hip: every activation of a tower is channel-last [B][L][32] inside the step
+int cl_conv32_supported(int L);
+int cl_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
+                  float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias, int post_relu,
+                  const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream);
+size_t cl_conv32_part_floats();
+int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, int pre_relu, float* dz,
+                  double* stat_out, float* part, int* nrow, hipStream_t stream);
+int cl_bn_stats(const float* x, int64_t rows, int relu, double* acc, hipStream_t stream);
+int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, const float* state, const float* gamma, const double* acc,
+                    const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
+int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, hipStream_t stream);
+int cl_maxpool_bwd(const float* dy, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream);
+int cl_gmax_fwd(const float* x, int64_t B, int L, float* feat, int32_t* arg, hipStream_t stream);
+int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t B, int L, float* dx, hipStream_t stream);
+// train_ops.hip / snv_stage1.hip: first layer with channel-last output
+int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
+                       const float* W, const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                       unsigned long long* counts, float* tab, float* y, void* arg, hipStream_t stream);
+int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp,
+                       const float* tab, const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
+                       hipStream_t stream);
+// conv32_mfma.hip
 int train_reduce_parts(const float* const* part, const int* nrow, float* const* dW, float* const* db, int njobs, hipStream_t stream);
 // train_ops.hip
 int train_bn2d_apply_dropout(const float* x, int64_t B, int C, int relu, const double* acc, const float* gamma, const float* beta, float eps,
                              float momentum, float* running_mean, float* running_var, float* state, float p, uint64_t seed,
                              const uint64_t* seed_dev, float* y_bn, float* y, hipStream_t stream);
-int train_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t rows, int L, float* dx, hipStream_t stream);
 }
 
 namespace {
@@ -131,7 +146,7 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
         MURAL_REQUIRE(L >= 1, "distal window too short for the pooling pyramid");
         g.L[i] = L;
       }
-      MURAL_REQUIRE(mural_op_conv32_supported(g.L[0]), "training: pooled rows of %d columns do not fit the MFMA conv tile", g.L[0]);
+      MURAL_REQUIRE(cl_conv32_supported(g.L[0]), "training: pooled rows of %d columns do not fit the MFMA conv tile", g.L[0]);
       TowerBufs& b = P->tw[t];
       int64_t tabf, argb, scr;
       mural_op_first_plan(TR_C, g.pk[0], &tabf, &argb, &scr);
@@ -190,7 +205,7 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
   P->acc_bytes = A.off - acc0;
   // ---- backward temporaries
   for (int i = 0; i < 4; ++i) P->g[i] = A.f(max_act);
-  P->part_floats = train_conv32_part_floats();
+  P->part_floats = cl_conv32_part_floats();
   if (towers)
     for (int i = 0; i < 20; ++i) P->part[i] = A.f(P->part_floats);
   for (int i = 0; i < 3; ++i) P->dlogit[i] = A.f((size_t)B * sh.n_class);
@@ -227,10 +242,10 @@ struct Ctx {
 int bnconv_f(Ctx& c, const float* x, int L, int pre_relu, double* acc, bool have_acc, const MuralBN& bn, const MuralAffine& cv,
              float* state, int post_relu, const float* r1, const float* r2, double* acc_out, int out_relu, float* y) {
   if (!have_acc)
-    if (int rc = mural_op_bn_stats(x, c.P->B, TR_C, L, pre_relu, acc, c.stream)) return rc;
-  return train_conv32_fwd(x, c.P->B, L, pre_relu, acc, bn.weight, bn.bias, EPS, c.momentum, const_cast<float*>(bn.running_mean),
-                          const_cast<float*>(bn.running_var), state, cv.weight, cv.bias, post_relu, r1, r2, acc_out, out_relu, y,
-                          (hipStream_t)c.stream);
+    if (int rc = cl_bn_stats(x, (int64_t)c.P->B * L, pre_relu, acc, (hipStream_t)c.stream)) return rc;
+  return cl_conv32_fwd(x, c.P->B, L, pre_relu, acc, bn.weight, bn.bias, EPS, c.momentum, const_cast<float*>(bn.running_mean),
+                       const_cast<float*>(bn.running_var), state, cv.weight, cv.bias, post_relu, r1, r2, acc_out, out_relu, y,
+                       (hipStream_t)c.stream);
 }
 
 int stage_f(Ctx& c, const MuralResBlock* rb, const float* x_in, int L, double* acc_in, bool have_in, StageBufs& s) {
@@ -256,19 +271,19 @@ int tower_f(Ctx& c, int t, const MuralTower& T, float drop_p, uint64_t seed, con
   const TowerGeo& g = P.geo[t];
   TowerBufs& b = P.tw[t];
   const int B = P.B;
-  if (int rc = mural_op_first_fwd(P.sym, B, P.Lwin, g.col0, g.L1, TR_C, g.pk[0], g.ps[0], g.pp[0], T.bn_in.weight, T.bn_in.bias,
-                                  T.conv_in.weight, T.conv_in.bias, EPS, c.momentum, const_cast<float*>(T.bn_in.running_mean),
-                                  const_cast<float*>(T.bn_in.running_var), b.counts, b.tab, b.x0, b.arg1, c.stream)) return rc;
+  hipStream_t st = (hipStream_t)c.stream;
+  if (int rc = train_first_fwd_cl(P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], T.bn_in.weight, T.bn_in.bias, T.conv_in.weight,
+                                  T.conv_in.bias, EPS, c.momentum, const_cast<float*>(T.bn_in.running_mean),
+                                  const_cast<float*>(T.bn_in.running_var), b.counts, b.tab, b.x0, b.arg1, st)) return rc;
   if (int rc = stage_f(c, T.rbs1, b.x0, g.L[0], nullptr, false, b.s2)) return rc;
-  if (int rc = mural_op_maxpool_fwd(b.s2.t[3], (int64_t)B * TR_C, g.L[0], g.pk[1], g.ps[1], g.pp[1], b.p2, b.arg2, c.stream)) return rc;
+  if (int rc = cl_maxpool_fwd(b.s2.t[3], B, g.L[0], g.pk[1], g.ps[1], g.pp[1], b.p2, b.arg2, st)) return rc;
   if (int rc = bnconv_f(c, b.p2, g.L[1], 0, b.acc_c2_f, false, T.bn_mid, T.conv_mid, b.state_c2, 0, nullptr, nullptr, b.s3.acc_f[0], 1,
                         b.x0b)) return rc;
   if (int rc = stage_f(c, T.rbs2, b.x0b, g.L[1], b.s3.acc_f[0], true, b.s3)) return rc;
-  if (int rc = mural_op_maxpool_fwd(b.s3.t[3], (int64_t)B * TR_C, g.L[1], g.pk[2], g.ps[2], g.pp[2], b.p3, b.arg3, c.stream)) return rc;
+  if (int rc = cl_maxpool_fwd(b.s3.t[3], B, g.L[1], g.pk[2], g.ps[2], g.pp[2], b.p3, b.arg3, st)) return rc;
   if (int rc = bnconv_f(c, b.p3, g.L[2], 0, b.acc_c3_f, false, T.bn_out, T.conv_out, b.state_c3, 1, nullptr, nullptr, nullptr, 0, b.c3))
     return rc;
-  // global max over the columns = one pooling window per row
-  if (int rc = mural_op_maxpool_fwd(b.c3, (int64_t)B * TR_C, g.L[2], g.L[2], g.L[2], 0, b.feat, b.argg, c.stream)) return rc;
+  if (int rc = cl_gmax_fwd(b.c3, B, g.L[2], b.feat, b.argg, st)) return rc;
   // distal_fc: BatchNorm1d -> Dropout -> Linear on (B, 32)
   if (int rc = mural_op_bn_stats(b.feat, B, TR_C, 1, 0, b.acc_fc_f, c.stream)) return rc;
   if (int rc = train_bn2d_apply_dropout(b.feat, B, TR_C, 0, b.acc_fc_f, T.fc_bn.weight, T.fc_bn.bias, EPS, c.momentum,
@@ -305,13 +320,13 @@ int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const
              double* acc, const float* add1, const float* add2, const MuralBN& gbn, const MuralAffine& gcv, float* dz, float* dx) {
   const int j = c.njobs++;
   MURAL_REQUIRE(j < 20, "internal: more conv layers than partial-row regions");
-  if (int rc = train_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j], (hipStream_t)c.stream))
+  if (int rc = cl_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j], (hipStream_t)c.stream))
     return rc;
   c.job_part[j] = c.P->part[j];
   c.job_dW[j] = const_cast<float*>(gcv.weight);
   c.job_db[j] = const_cast<float*>(gcv.bias);
-  return mural_op_bn_backward(dz, x, c.P->B, TR_C, L, pre_relu, state + 2 * TR_C, state + 3 * TR_C, bn.weight, acc, 1, add1, add2, dx,
-                              const_cast<float*>(gbn.weight), const_cast<float*>(gbn.bias), c.stream);
+  return cl_bn_bwd_apply(dz, x, (int64_t)c.P->B * L, pre_relu, state, bn.weight, acc, add1, add2, dx, const_cast<float*>(gbn.weight),
+                         const_cast<float*>(gbn.bias), (hipStream_t)c.stream);
 }
 
 // d_out: gradient arriving at the stage output (kept intact); d_in: receives the gradient of the stage input; tmp: 3 buffers
@@ -354,10 +369,11 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
                                     nullptr, nullptr, g2, const_cast<float*>(G.fc_bn.weight), const_cast<float*>(G.fc_bn.bias), c.stream))
     return rc;                                                                      // g2 = d feat
   // global max, ReLU of conv3
-  if (int rc = train_gmax_relu_bwd(g2, b.argg, b.c3, (int64_t)B * TR_C, g.L[2], g1, (hipStream_t)c.stream)) return rc;
+  hipStream_t st = (hipStream_t)c.stream;
+  if (int rc = cl_gmax_relu_bwd(g2, b.argg, b.c3, B, g.L[2], g1, st)) return rc;
   if (int rc = bnconv_b(c, g1, b.p3, g.L[2], 0, b.state_c3, T.bn_out, T.conv_out, b.acc_c3_b, nullptr, nullptr, G.bn_out, G.conv_out, g0,
                         g2)) return rc;                                            // g2 = d p3
-  if (int rc = mural_op_maxpool_bwd(g2, b.arg3, (int64_t)B * TR_C, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, c.stream)) return rc;
+  if (int rc = cl_maxpool_bwd(g2, b.arg3, B, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, st)) return rc;
   float* tmp[3] = {g0, g1, g2};
   // second ResBlock stage: the gradient of its output sits in g3, g0..g2 are the stage's temporaries; the gradient of its input
   // lands in the forward's copy of the stage output, which no backward reads (the pooling behind it kept its arg-max)
@@ -365,12 +381,12 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   if (int rc = stage_b(c, T.rbs2, G.rbs2, b.x0b, g.L[1], b.s3, g3, d_in3, tmp)) return rc;
   if (int rc = bnconv_b(c, d_in3, b.p2, g.L[1], 0, b.state_c2, T.bn_mid, T.conv_mid, b.acc_c2_b, nullptr, nullptr, G.bn_mid, G.conv_mid, g0,
                         g1)) return rc;                                            // g1 = d p2
-  if (int rc = mural_op_maxpool_bwd(g1, b.arg2, (int64_t)B * TR_C, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, c.stream)) return rc;
+  if (int rc = cl_maxpool_bwd(g1, b.arg2, B, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, st)) return rc;
   float* d_in2 = b.s2.t[3];
   if (int rc = stage_b(c, T.rbs1, G.rbs1, b.x0, g.L[0], b.s2, g3, d_in2, tmp)) return rc;
-  return mural_op_first_bwd(d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, TR_C, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight,
-                            P.first_scratch, const_cast<float*>(G.conv_in.weight), const_cast<float*>(G.conv_in.bias),
-                            const_cast<float*>(G.bn_in.weight), const_cast<float*>(G.bn_in.bias), c.stream);
+  return train_first_bwd_cl(d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight, P.first_scratch,
+                            const_cast<float*>(G.conv_in.weight), const_cast<float*>(G.conv_in.bias), const_cast<float*>(G.bn_in.weight),
+                            const_cast<float*>(G.bn_in.bias), st);
 }
 
 int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop, const uint64_t* seeds, const uint64_t* seed_dev) {

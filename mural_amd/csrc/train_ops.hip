@@ -1032,10 +1032,10 @@ extern "C" int mural_op_first_plan(int32_t C, int32_t pk, int64_t* tab_floats, i
 }
 
 // counts: uint64[16] zeroed by the caller; tab / arg sized by mural_op_first_plan
-extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
-                                  int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
-                                  const float* bias, float eps, float momentum, float* running_mean, float* running_var,
-                                  unsigned long long* counts, float* tab, float* y, void* arg, void* stream) {
+static int first_fwd_impl(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
+                          int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
+                          const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                          unsigned long long* counts, float* tab, float* y, void* arg, int cl, void* stream) {
   const int L2 = (L1 + 2 * pp - pk) / ps + 1;
   const bool fast = first_train_supported(C, pk);
   hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(B * L1, 256, 2048)), dim3(256), 0, STREAM, sym, B, Lwin, col0, L1, counts);
@@ -1046,8 +1046,10 @@ extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, i
     std::memset(&a, 0, sizeof(a));
     a.tw = Stage1Tower{L1, col0, L2, pk, ps, pp};
     a.Lwin = Lwin; a.B = B; a.sym = sym; a.lutblk = first_lutblk(tab, C); a.y = y; a.arg = static_cast<uint8_t*>(arg);
+    a.cl = cl;
     return launch_first_train(a, false, STREAM);
   }
+  MURAL_REQUIRE(!cl, "first layer: the channel-last layout is served by the table kernels only");
   const int64_t total = B * C * L2;
   hipLaunchKernelGGL(first_pool_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), (size_t)3 * N_SYM * C * 4, STREAM, sym,
                      B, Lwin, col0, L1, C, L2, pk, ps, pp, tab, bias, y, static_cast<int32_t*>(arg));
@@ -1055,10 +1057,18 @@ extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, i
 }
 
 // scratch sized by mural_op_first_plan (contents undefined on entry); writes dW [C][4][3], dbias[C], dgamma[4], dbeta[4]
-extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
-                                  int32_t col0, int32_t L1, int32_t C, int32_t pk, int32_t ps, int32_t pp, const float* tab,
-                                  const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
-                                  void* stream) {
+extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
+                                  int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
+                                  const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                                  unsigned long long* counts, float* tab, float* y, void* arg, void* stream) {
+  return first_fwd_impl(sym, B, Lwin, col0, L1, C, pk, ps, pp, gamma, beta, W, bias, eps, momentum, running_mean, running_var, counts, tab, y,
+                        arg, 0, stream);
+}
+
+static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
+                          int32_t col0, int32_t L1, int32_t C, int32_t pk, int32_t ps, int32_t pp, const float* tab,
+                          const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta, int cl,
+                          void* stream) {
   const int L2 = (L1 + 2 * pp - pk) / ps + 1;
   const size_t lds = (size_t)(3 * N_SYM * C + N_SYM * 4) * 4;
   if (first_train_supported(C, pk)) {
@@ -1067,6 +1077,7 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
     a.tw = Stage1Tower{L1, col0, L2, pk, ps, pp};
     a.Lwin = Lwin; a.B = B; a.sym = sym; a.dy = dy; a.arg = const_cast<uint8_t*>(static_cast<const uint8_t*>(arg));
     a.dpart = scratch;
+    a.cl = cl;
     const int nblk = first_train_grid(B);
     float* red = scratch + (size_t)FIRST_TRAIN_MAXGRID * SNV_LUTBLK;
     if (int rc = launch_first_train(a, true, STREAM)) return rc;
@@ -1076,6 +1087,7 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
                        dbias);
     CHECK_LAUNCH();
   }
+  MURAL_REQUIRE(!cl, "first layer: the channel-last layout is served by the table kernels only");
   float* dtap = scratch;
   MURAL_HIP_CHECK(hipMemsetAsync(dtap, 0, (size_t)3 * N_SYM * C * 4, STREAM));
   MURAL_HIP_CHECK(hipMemsetAsync(dbias, 0, (size_t)C * 4, STREAM));
@@ -1086,6 +1098,27 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
                      dbias);
   CHECK_LAUNCH();
 }
+
+extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
+                                  int32_t col0, int32_t L1, int32_t C, int32_t pk, int32_t ps, int32_t pp, const float* tab,
+                                  const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
+                                  void* stream) {
+  return first_bwd_impl(dy, arg, sym, B, Lwin, col0, L1, C, pk, ps, pp, tab, W, scratch, dW, dbias, dgamma, dbeta, 0, stream);
+}
+
+namespace mural {
+int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
+                       const float* W, const float* bias, float eps, float momentum, float* running_mean, float* running_var,
+                       unsigned long long* counts, float* tab, float* y, void* arg, hipStream_t stream) {
+  return first_fwd_impl(sym, B, Lwin, col0, L1, 32, pk, ps, pp, gamma, beta, W, bias, eps, momentum, running_mean, running_var, counts, tab, y,
+                        arg, 1, stream);
+}
+int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp,
+                       const float* tab, const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
+                       hipStream_t stream) {
+  return first_bwd_impl(dy, arg, sym, B, Lwin, col0, L1, 32, pk, ps, pp, tab, W, scratch, dW, dbias, dgamma, dbeta, 1, stream);
+}
+}  // namespace mural
 
 static bool linear_tile_fits(int K, int N, size_t* lds) {
   *lds = ((size_t)((K * N + 3) & ~3) + (size_t)64 * K) * sizeof(float);

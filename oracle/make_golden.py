@@ -280,19 +280,68 @@ def g6_taps(ref):
          hp=np.array([r, 3, R, 150, 75, 32, 3, 4, 2], np.int64), **{"tap::" + k: v for k, v in taps.items()})
 
 
+def pool_margins(model, margins):
+    """Forward hooks recording the smallest top-2 gap (relative to max(|top1|, 1)) over every max-pool window and global max.
+
+    The gradient of a max is discontinuous at a tie: where two window entries sit closer than float32 round-off accumulated through
+    the layers in front (a few 1e-6 relative), the reference's own backward picks one of them by the accident of its summation order,
+    and a correct implementation with another order picks the other.  g7 keeps only weight seeds without such a window.
+    """
+    def pool_hook(m, inp, out, first=False):
+        x = inp[0].detach()
+        k, s, p = (v if isinstance(v, int) else v[0] for v in (m.kernel_size, m.stride, m.padding))
+        w = torch.nn.functional.pad(x, (p, p), value=float("-inf")).unfold(2, k, s)
+        top = w.topk(2, dim=3).values
+        gap = (top[..., 0] - top[..., 1]) / top[..., 0].abs().clamp(min=1.0)
+        gap = gap[gap > 0]              # exact ties (the same 3-mer twice under pool1) go to the first entry in every implementation
+        if gap.numel():
+            # pool1 sits on the first conv of a one-hot input (three weights summed: exact to an ulp everywhere); deeper pools carry
+            # the round-off of the ResBlocks in front, so their gap is weighed 20 x stricter
+            margins.append(float(gap.min()) * (20.0 if first else 1.0))
+
+    def gmax_hook(m, inp, out):
+        if out.shape[2] < 2:
+            return
+        top = out.detach().topk(2, dim=2).values
+        gap = (top[..., 0] - top[..., 1]) / top[..., 0].abs().clamp(min=1.0)
+        gap = gap[(top[..., 0] > 0) & (gap > 0)]     # behind the ReLU an all-zero row has no gradient at all
+        if gap.numel():
+            margins.append(float(gap.min()))
+
+    hooks = [m.register_forward_hook(lambda m, i, o, f=n.startswith("maxpool1"): pool_hook(m, i, o, f))
+             for n, m in model.named_modules() if isinstance(m, nn.MaxPool1d)]
+    hooks += [getattr(model, n).register_forward_hook(gmax_hook) for n in ("conv3", "conv3_2")]
+    return hooks
+
+
+G7_MIN_MARGIN = 8e-6     # 4 x the largest relative difference seen between float32 implementations at the deepest pool (2e-6)
+
+
 def g7_train(ref):
     rng = np.random.default_rng(707)
-    for tag, r, R, B, seed in [("T", 5, 100, 32, 31), ("S", 10, 1000, 12, 32)]:
+    # weight seed of S: 32 has a pool3_2 window whose two best entries differ by 6e-7 relative (a float32 coin toss, see pool_margins);
+    # 33.. are tried in order and the first one clear of G7_MIN_MARGIN is kept
+    for tag, r, R, B, seeds in [("T", 5, 100, 32, (31,)), ("S", 10, 1000, 12, tuple(range(33, 64)))]:
         cfg, common = snv_cfg(r, R, drops=(0.0, 0.0, 0.0))
-        model = quiet(ref.nn_utils.model_choice, 2, cfg, common, "snv")
-        sd = synth.synth_state_dict(model.state_dict(), seed)
-        model.load_state_dict(sd)
-        model.train()
         codes, cat = snv_inputs(rng, B, r, R, with_amb=False)
         y = rng.choice(4, size=B, p=[0.85, 0.05, 0.05, 0.05]).astype(np.int64)
         x = codes_to_onehot(codes)
         crit = nn.CrossEntropyLoss(reduction="sum")
-        preds = quiet(model.forward, (torch.zeros(B, 1, dtype=torch.float64), torch.from_numpy(cat)), x)
+        for seed in seeds:
+            model = quiet(ref.nn_utils.model_choice, 2, cfg, common, "snv")
+            sd = synth.synth_state_dict(model.state_dict(), seed)
+            model.load_state_dict(sd)
+            model.train()
+            margins = []
+            hooks = pool_margins(model, margins)
+            preds = quiet(model.forward, (torch.zeros(B, 1, dtype=torch.float64), torch.from_numpy(cat)), x)
+            for h in hooks:
+                h.remove()
+            print(f"  G7 {tag}: weight seed {seed}, smallest max-pool margin {min(margins):.2e}")
+            if min(margins) >= G7_MIN_MARGIN:
+                break
+        else:
+            raise SystemExit("g7: no weight seed clear of max-pool near-ties")
         loss = crit(preds, torch.from_numpy(y))
         model.zero_grad()
         loss.backward()
@@ -307,6 +356,7 @@ def g7_train(ref):
                 continue
             arrays["b::" + k] = b.numpy()
         save(f"snv_train_{tag}.npz", codes=codes, cat=cat, y=y, seed=np.array(seed), loss=np.array(loss.item()),
+             pool_margin=np.array(min(margins)),
              preds=preds.detach().numpy(), gnorm=np.array(float(gnorm)),
              hp=np.array([r, 3, R, 150, 75, 32, 3, 4, 2], np.int64), **arrays)
 
