@@ -321,7 +321,7 @@ int mural_snv_train_backward(const MuralSnvShape* shape, const MuralSnvParams* p
 
 /* Validation hooks of the parity tests: the channel-last conv kernels of the composed training step on their own.  Tensors are
  * [B][L][32]; acc blocks are double[MURAL_BN_SLOTS][2][32] (the forward reads the batch sums of act(x) from `acc` and finalises the
- * BatchNorm itself; acc_out / stat_out zeroed by the caller); part: 512 * (32*32*3 + 32) floats of partial rows, *nrow of them written. */
+ * BatchNorm itself; acc_out / stat_out zeroed by the caller); part: 1024 * (32*32*3 + 32) floats of partial rows, *nrow of them written. */
 int mural_debug_cl_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float* state, const float* W,
                               const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,

@@ -32,7 +32,9 @@ struct ClTile {                    // tile of R rows on a flattened column axis 
 bool cl_tile(int B, int L, ClTile* t) {
   std::memset(t, 0, sizeof(*t));
   const int Sc = L + 1;
-  int r = (16 * 2 * SNV_NB2MAX - 1) / Sc;
+  static const int nbmax = getenv("MURAL_CL_NBMAX") ? atoi(getenv("MURAL_CL_NBMAX")) : 2 * SNV_NB2MAX;
+  int r = (16 * nbmax - 1) / Sc;
+  if (r < 1) r = (16 * 2 * SNV_NB2MAX - 1) / Sc;
   if (r < 1) return false;
   if (r > B) r = B;
   const int balanced = (B + 1023) / 1024;       // large batches of short rows: >= 1024 tiles rather than the tallest tile
@@ -157,6 +159,61 @@ __device__ __forceinline__ void cl_stage(const float* __restrict__ src, int rows
   }
 }
 
+// two per-channel sums of a 256-thread workgroup into its accumulator slot: lanes with the same chunk (tid & 7) hold the same four
+// channels; they meet through shuffles inside a wave and through `red` (64 floats per wave, dead LDS) across the four waves, so a
+// workgroup issues 64 double atomics instead of 256 -- at 1024 workgroups the atomics of one launch otherwise queue for ~10 us on
+// the few L2 channels the 16 KB accumulator block maps to
+__device__ __forceinline__ void cl_slot_add(f32x4 a1, f32x4 a2, double* slot, float* red, int tid) {
+  const int lane = tid & 63, wave = tid >> 6, chunk = tid & 7;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float v1 = a1[q], v2 = a2[q];
+#pragma unroll
+    for (int off = 8; off < 64; off <<= 1) {
+      v1 += __shfl_xor(v1, off);
+      v2 += __shfl_xor(v2, off);
+    }
+    if (lane < 8) {
+      red[wave * 64 + 4 * chunk + q] = v1;
+      red[wave * 64 + CL_C + 4 * chunk + q] = v2;
+    }
+  }
+  __syncthreads();
+  if (tid < 64) atomicAdd(&slot[tid], (double)((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid])));
+}
+
+// the same staging in two halves, so that the global loads of the NEXT tile are in flight while the current one is in its MFMA
+// phase: cl_fetch issues the (at most CL_PF) 16-byte loads of a thread, cl_put transforms and writes them to the image
+constexpr int CL_PF = (16 * 2 * SNV_NB2MAX * 8 + SNV_THREADS - 1) / SNV_THREADS;
+
+__device__ __forceinline__ void cl_fetch(const float* __restrict__ src, int total, int tid, f32x4 (&v)[CL_PF]) {
+#pragma unroll
+  for (int q = 0; q < CL_PF; ++q) {
+    const int task = tid + q * SNV_THREADS;
+    if (task < total) v[q] = ld4(src + (size_t)task * 4);
+  }
+}
+
+template <bool AFF, bool SUM>
+__device__ __forceinline__ void cl_put(const f32x4 (&v)[CL_PF], int total, const ClTile& t, f32x4 s4, f32x4 t4, f32x4 m4, int relu, float* img,
+                                       int tid, f32x4* colsum) {
+  const int Sc = t.g.Sc[0];
+  const int chunk = tid & 7;
+#pragma unroll
+  for (int q = 0; q < CL_PF; ++q) {
+    const int task = tid + q * SNV_THREADS;
+    if (task >= total) break;
+    const uint32_t col = (uint32_t)task >> 3;
+    const uint32_t r = t.g.dL[0].div(col);
+    const int l = (int)(col - r * (uint32_t)t.L);
+    f32x4 x = v[q];
+    if (SUM) *colsum += x;
+    if (relu) x = max4(x, splat(0.f));
+    if (AFF) x = f32x4{fmaf(s4.x, x.x - m4.x, t4.x), fmaf(s4.y, x.y - m4.y, t4.y), fmaf(s4.z, x.z - m4.z, t4.z), fmaf(s4.w, x.w - m4.w, t4.w)};
+    st4(img + lds_off(2 + (int)r * Sc + l, chunk), x);
+  }
+}
+
 // filter fragments in the order conv_layer / mfma_tap expect: k-step s = 8 tap + 4 half + q <-> input channel 16 half + 4 kk + q,
 // output channel 16 mb + n16; dgrad: the transposed, tap-flipped filter
 __device__ __forceinline__ void cl_frags(const float* __restrict__ W, int dgrad, int mb, int n16, int kk, float (&a)[SNV_KSTEPS]) {
@@ -181,6 +238,7 @@ struct ClFwdArgs {
   int pre_relu, post_relu;
   double* stat_out;       // nullptr: no sums
   int stat_relu;
+  int dbg;                // timing experiments (MURAL_DEBUG_CL): 1 no staging, 2 no MFMA phase, 4 no stream-out, 8 no residual loads
 };
 
 __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_fwd_kernel(const ClFwdArgs a) {
@@ -198,7 +256,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_fwd_kernel(const ClFw
   float af[SNV_KSTEPS];
   cl_frags(a.W, 0, mb, n16, kk, af);
   const f32x4 pb = a.bias ? ld4(a.bias + chv) : splat(0.f);
-  cl_finalize(a.fin, aux, reinterpret_cast<double*>(bufA), tid);
+  if (!(a.dbg & 32)) cl_finalize(a.fin, aux, reinterpret_cast<double*>(bufA), tid);
   const f32x4 s4 = ld4(aux + 4 * chunk), t4 = ld4(aux + CL_C + 4 * chunk), m4 = ld4(aux + 2 * CL_C + 4 * chunk);
   const TowerGeom& g = t.g;
   const StageAddr sa = stage_setup(g, 0, t.R, n16, kk, mb, cgp);
@@ -227,23 +285,34 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_fwd_kernel(const ClFw
     const int64_t b0 = tile * t.R;
     const int rows = (int)((t.B - b0) < t.R ? (t.B - b0) : t.R);
     const size_t base = (size_t)b0 * t.L * CL_C;
-    cl_stage<true, false>(a.x + base, rows, t, s4, t4, m4, a.pre_relu, bufA, tid, nullptr);
+    if (!(a.dbg & 1)) cl_stage<true, false>(a.x + base, rows, t, s4, t4, m4, a.pre_relu, bufA, tid, nullptr);
     cl_zero_gaps(bufA, t, rows, tid);
     f32x4 xres[SNV_NB2MAX];
+    // residual operands of the lane's columns: every load is issued (out-of-plan lanes re-read the tile's first element and drop
+    // it), so the nine round trips overlap instead of queueing behind one branch each
 #pragma unroll
-    for (int i = 0; i < SNV_NB2MAX; ++i) {
-      xres[i] = splat(0.f);
-      if (i < nbw && plan[i] != ~0u && (int)(plan[i] >> 16) < rows) {
-        const size_t o = base + ((size_t)(plan[i] >> 16) * t.L + (plan[i] & 0xFFFFu)) * CL_C + chv;
-        if (a.res1) xres[i] = ld4(a.res1 + o);
-        if (a.res2) xres[i] += ld4(a.res2 + o);
+    for (int i = 0; i < SNV_NB2MAX; ++i) xres[i] = splat(0.f);
+    if (a.res1 && !(a.dbg & 8)) {
+      const float* r2p = a.res2 ? a.res2 : a.res1;
+      f32x4 u[SNV_NB2MAX], w[SNV_NB2MAX];
+      bool ok[SNV_NB2MAX];
+#pragma unroll
+      for (int i = 0; i < SNV_NB2MAX; ++i) {
+        ok[i] = i < nbw && plan[i] != ~0u && (int)(plan[i] >> 16) < rows;
+        const size_t o = base + (ok[i] ? ((size_t)(plan[i] >> 16) * t.L + (plan[i] & 0xFFFFu)) * CL_C + chv : 0);
+        u[i] = ld4(a.res1 + o);
+        w[i] = ld4(r2p + o);
       }
+#pragma unroll
+      for (int i = 0; i < SNV_NB2MAX; ++i)
+        if (ok[i]) xres[i] = a.res2 ? u[i] + w[i] : u[i];
     }
     __syncthreads();
-    conv_layer(reinterpret_cast<const char*>(bufA), reinterpret_cast<char*>(bufB), sa, nbw, lk, af, pb, splat(1.f), splat(0.f), xres);
+    if (!(a.dbg & 2))
+      conv_layer(reinterpret_cast<const char*>(bufA), reinterpret_cast<char*>(bufB), sa, nbw, lk, af, pb, splat(1.f), splat(0.f), xres);
     __syncthreads();
     // the tile leaves as one contiguous stream of 16-byte pieces; the sums of act(y) ride along in registers
-    const int total = rows * t.L * 8;
+    const int total = (a.dbg & 4) ? 0 : rows * t.L * 8;
     for (int task = tid; task < total; task += SNV_THREADS) {
       const uint32_t col = (uint32_t)task >> 3;
       const uint32_t r = g.dL[0].div(col);
@@ -259,22 +328,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_fwd_kernel(const ClFw
     // (no barrier here: the next tile stages into bufA, and the barrier behind that staging separates this stream-out from the
     // next conv's writes to bufB)
   }
-  if (a.stat_out) {     // lanes with the same chunk (tid & 7) hold the same 4 channels: meet through shuffles, 8 lanes per wave add
-    double* slot = a.stat_out + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float v1 = sum1[q], v2 = sum2[q];
-#pragma unroll
-      for (int off = 8; off < 64; off <<= 1) {
-        v1 += __shfl_xor(v1, off);
-        v2 += __shfl_xor(v2, off);
-      }
-      if (lane < 8) {
-        atomicAdd(&slot[4 * chunk + q], (double)v1);
-        atomicAdd(&slot[CL_C + 4 * chunk + q], (double)v2);
-      }
-    }
-  }
+  if (a.stat_out && !(a.dbg & 16))     // bufA is dead: every wave is past the barrier in front of the last stream-out
+    cl_slot_add(sum1, sum2, a.stat_out + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, bufA, tid);
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
@@ -390,20 +445,14 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_bwd_kernel(const ClBw
   constexpr int NW = CL_C * CL_C * 3;
   __syncthreads();
   float* wred = smem;                                            // [4 waves][NW + 32] floats: the images are dead
+  cl_slot_add(sdz, sdzx, slot, wred, tid);
+  __syncthreads();
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
-    float v1 = sdz[q], v2 = sdzx[q], v3 = bsum[q];
+    float v3 = bsum[q];
 #pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-      v1 += __shfl_xor(v1, off);
-      v2 += __shfl_xor(v2, off);
-      v3 += __shfl_xor(v3, off);
-    }
-    if (lane < 8) {
-      atomicAdd(&slot[4 * chunk + q], (double)v1);
-      atomicAdd(&slot[CL_C + 4 * chunk + q], (double)v2);
-      wred[(size_t)wave * (NW + CL_C) + NW + 4 * chunk + q] = v3;    // every wave covers all 32 channels with its own columns
-    }
+    for (int off = 8; off < 64; off <<= 1) v3 += __shfl_xor(v3, off);
+    if (lane < 8) wred[(size_t)wave * (NW + CL_C) + NW + 4 * chunk + q] = v3;    // every wave covers all 32 channels with its own columns
   }
   // D[row = co 4 kk + r][col = ci n16] of tile (m, tap, h) -> dW[16 m + 4 kk + r][16 h + n16][tap]
   float* mine = wred + (size_t)wave * (NW + CL_C);
@@ -424,7 +473,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_bwd_kernel(const ClBw
 // ------------------------------------------------------------------------------------------------------------ streaming kernels
 // batch sums of act(x) and act(x)^2 per channel of a [rows][32] tensor (rows = B * L)
 __global__ __launch_bounds__(256) void bn_stats_cl_kernel(const float* __restrict__ x, int64_t rows, int relu, double* __restrict__ acc) {
-  const int chunk = threadIdx.x & 7;
   f32x4 s1 = splat(0.f), s2 = splat(0.f);
   const int64_t total = rows * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -433,21 +481,8 @@ __global__ __launch_bounds__(256) void bn_stats_cl_kernel(const float* __restric
     s1 += v;
     s2 += f32x4{v.x * v.x, v.y * v.y, v.z * v.z, v.w * v.w};
   }
-  double* slot = acc + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C;
-  const int lane = threadIdx.x & 63;
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float v1 = s1[q], v2 = s2[q];
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) {
-      v1 += __shfl_xor(v1, off);
-      v2 += __shfl_xor(v2, off);
-    }
-    if (lane < 8) {
-      atomicAdd(&slot[4 * chunk + q], (double)v1);
-      atomicAdd(&slot[CL_C + 4 * chunk + q], (double)v2);
-    }
-  }
+  __shared__ float red[256];
+  cl_slot_add(s1, s2, acc + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, red, threadIdx.x);
 }
 
 // dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) [+ add1 + add2]; workgroup 0 writes dgamma / dbeta
@@ -610,19 +645,25 @@ int cl_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* 
   ClFwdArgs a;
   std::memset(&a, 0, sizeof(a));
   MURAL_REQUIRE(cl_tile((int)B, L, &a.t), "conv32 (channel-last): L = %d does not fit the LDS tile", L);
+  if (!res1) { res1 = res2; res2 = nullptr; }
   a.x = x; a.y = y; a.W = W; a.bias = bias; a.res1 = res1; a.res2 = res2; a.pre_relu = pre_relu; a.post_relu = post_relu;
   a.stat_out = acc_out; a.stat_relu = out_relu;
   a.fin = ClFin{acc, (double)B * L, gamma, beta, eps, momentum, running_mean, running_var, state};
+  if (const char* e = getenv("MURAL_DEBUG_CL")) a.dbg = atoi(e);
   const size_t lds = (size_t)(2 * a.t.nbuf + 3 * CL_C) * 4;
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32cl_fwd_kernel)) return rc;
   const int64_t ntiles = (B + a.t.R - 1) / a.t.R;
-  hipLaunchKernelGGL(conv32cl_fwd_kernel, dim3((unsigned)(ntiles < 1024 ? ntiles : 1024)), dim3(SNV_THREADS), lds, stream, a);
+  int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+  per_cu = per_cu > 4 ? 4 : (per_cu < 2 ? 2 : per_cu);
+  static const int cus = getenv("MURAL_CL_CUS") ? atoi(getenv("MURAL_CL_CUS")) : 256;
+  const int64_t cap = (int64_t)cus * per_cu;
+  hipLaunchKernelGGL(conv32cl_fwd_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(SNV_THREADS), lds, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
-size_t cl_conv32_part_floats() { return (size_t)512 * (CL_C * CL_C * 3 + CL_C); }
+size_t cl_conv32_part_floats() { return (size_t)1024 * (CL_C * CL_C * 3 + CL_C); }
 
 int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, int pre_relu, float* dz,
                   double* stat_out, float* part, int* nrow, hipStream_t stream) {
@@ -631,10 +672,14 @@ int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, in
   MURAL_REQUIRE(cl_tile((int)B, L, &a.t), "conv32_bwd (channel-last): L = %d does not fit the LDS tile", L);
   a.dy = dy; a.x = x; a.W = W; a.state = state; a.pre_relu = pre_relu; a.part = part; a.dz = dz; a.stat_out = stat_out;
   const int64_t ntiles = (B + a.t.R - 1) / a.t.R;
-  const int grid = (int)(ntiles < 512 ? ntiles : 512);
   size_t lds = (size_t)2 * a.t.nbuf * 4;
   const size_t lds_red = (size_t)4 * (CL_C * CL_C * 3 + CL_C) * 4;
   lds = lds > lds_red ? lds : lds_red;
+  int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
+  per_cu = per_cu > 4 ? 4 : (per_cu < 2 ? 2 : per_cu);
+  static const int cus = getenv("MURAL_CL_CUS") ? atoi(getenv("MURAL_CL_CUS")) : 256;
+  const int64_t cap = (int64_t)cus * per_cu;
+  const int grid = (int)(ntiles < cap ? ntiles : cap);
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32cl_bwd_kernel)) return rc;
   hipLaunchKernelGGL(conv32cl_bwd_kernel, dim3(grid), dim3(SNV_THREADS), lds, stream, a);

@@ -76,7 +76,7 @@ for B, L, PRE in ((12, 20, 1), (12, 7, 0), (12, 134, 1), (32, 23, 0), (5, 67, 1)
               rel(state[2], mean), rel(state[3], invstd))
     dzd = torch.empty_like(xd)
     stat = torch.zeros(32 * 2 * 32, dtype=torch.float64, device=dev)
-    part = torch.empty(512 * 3104, device=dev)
+    part = torch.empty(1024 * 3104, device=dev)
     nrow = C.c_int32(0)
     _lib.check(lib.mural_debug_cl_conv32_bwd(dyd.data_ptr(), xd.data_ptr(), Wd.data_ptr(), B, L, state.data_ptr(), PRE, dzd.data_ptr(),
                                              stat.data_ptr(), part.data_ptr(), C.byref(nrow), st))
