@@ -274,6 +274,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_fwd_kernel(const ClFw
       if (r < (uint32_t)t.R && l < (uint32_t)t.L) plan[i] = (r << 16) | l;
     }
   }
+  if ((blockIdx.x >> ((a.dbg >> 12) & 15)) & 1)
+    for (int i = 0; i < (a.dbg >> 16); ++i) __builtin_amdgcn_s_sleep(127);
   LayerK lk;
   lk.lo = a.post_relu ? 0.f : -INFINITY;
   lk.ku = 0.f;
@@ -343,6 +345,7 @@ struct ClBwdArgs {
   float* part;            // [grid][32*32*3 + 32]
   float* dz;
   double* stat_out;       // sum(dz), sum(dz * xhat)
+  int dbg;                // timing experiments (MURAL_DEBUG_CL): 64 no staging, 128 no weight gradient, 256 no input gradient, 512 no stream-out
 };
 
 __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_bwd_kernel(const ClBwdArgs a) {
@@ -372,6 +375,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_bwd_kernel(const ClBw
   f32x4 bsum = splat(0.f), sdz = splat(0.f), sdzx = splat(0.f);
   const int nk = 4 * g.nb[0];
   const int k_lo = wave * nk / 4, k_hi = (wave + 1) * nk / 4;
+  if ((blockIdx.x >> ((a.dbg >> 12) & 15)) & 1)
+    for (int i = 0; i < (a.dbg >> 16); ++i) __builtin_amdgcn_s_sleep(127);
   LayerK lk;
   lk.lo = -INFINITY;
   lk.ku = 0.f;
@@ -382,14 +387,16 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_bwd_kernel(const ClBw
     const int64_t b0 = tile * t.R;
     const int rows = (int)((t.B - b0) < t.R ? (t.B - b0) : t.R);
     const size_t base = (size_t)b0 * t.L * CL_C;
-    cl_stage<false, true>(a.dy + base, rows, t, splat(1.f), splat(0.f), splat(0.f), 0, bufG, tid, &bsum);
-    cl_stage<true, false>(a.x + base, rows, t, s4, t4, mean4, a.pre_relu, bufA, tid, nullptr);
+    if (!(a.dbg & 64)) {
+      cl_stage<false, true>(a.dy + base, rows, t, splat(1.f), splat(0.f), splat(0.f), 0, bufG, tid, &bsum);
+      cl_stage<true, false>(a.x + base, rows, t, s4, t4, mean4, a.pre_relu, bufA, tid, nullptr);
+    }
     cl_zero_gaps(bufG, t, rows, tid);
     cl_zero_gaps(bufA, t, rows, tid);
     __syncthreads();
     // ---- weight gradient: dW[co][ci][tap] += dy[col][co] * act[col + tap - 1][ci]; M = co, N = ci, K = 4 columns per step, this
     //      wave's quarter of the columns.  Logical column c sits at image column c + 1, its tap-t neighbour at c + t.
-    for (int s = k_lo; s < k_hi; ++s) {
+    for (int s = k_lo; s < ((a.dbg & 128) ? k_lo : k_hi); ++s) {
       const int pc = 4 * s + kk;
       float gv[2], bv[3][2];
 #pragma unroll
@@ -410,11 +417,12 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_bwd_kernel(const ClBw
       f32x4 xres[SNV_NB2MAX];
 #pragma unroll
       for (int i = 0; i < SNV_NB2MAX; ++i) xres[i] = splat(0.f);
-      conv_layer(reinterpret_cast<const char*>(bufG), reinterpret_cast<char*>(bufA), sa, nbw, lk, af, splat(0.f), splat(1.f), splat(0.f), xres);
+      if (!(a.dbg & 256))
+        conv_layer(reinterpret_cast<const char*>(bufG), reinterpret_cast<char*>(bufA), sa, nbw, lk, af, splat(0.f), splat(1.f), splat(0.f), xres);
     }
     __syncthreads();
     // ---- stream dz out; sum dz and sum dz * xhat ride along (x is read again: an L2 hit a few microseconds after its staging)
-    const int total = rows * t.L * 8;
+    const int total = (a.dbg & 512) ? 0 : rows * t.L * 8;
     for (int bt = tid; bt < total; bt += SNV_THREADS * CL_DEPTH) {
       f32x4 xv[CL_DEPTH];
 #pragma unroll
@@ -671,6 +679,7 @@ int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, in
   std::memset(&a, 0, sizeof(a));
   MURAL_REQUIRE(cl_tile((int)B, L, &a.t), "conv32_bwd (channel-last): L = %d does not fit the LDS tile", L);
   a.dy = dy; a.x = x; a.W = W; a.state = state; a.pre_relu = pre_relu; a.part = part; a.dz = dz; a.stat_out = stat_out;
+  if (const char* e = getenv("MURAL_DEBUG_CL")) a.dbg = atoi(e);
   const int64_t ntiles = (B + a.t.R - 1) / a.t.R;
   size_t lds = (size_t)2 * a.t.nbuf * 4;
   const size_t lds_red = (size_t)4 * (CL_C * CL_C * 3 + CL_C) * 4;

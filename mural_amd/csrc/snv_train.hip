@@ -107,10 +107,11 @@ struct Plan {
   // accumulator region (zeroed once per direction)
   double* acc_begin; size_t acc_bytes;
   // backward temporaries
-  float* g[4];              // gradient buffers of the largest activation shape
+  float* g[4];              // gradient buffers of the largest activation shape (local branch, large tower)
+  float* g_mid[4];          // the mid tower's own set: the two towers run on two streams
   float* part[24]; size_t part_floats;   // one partial-row region per conv32 layer (reduced by ONE launch at the end of the backward)
   float* dlogit[3];         // gradients of the local / mid / large logits
-  float* first_scratch;
+  float* first_scratch[2];  // per tower
   size_t total;
 };
 
@@ -205,23 +206,60 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
   P->acc_bytes = A.off - acc0;
   // ---- backward temporaries
   for (int i = 0; i < 4; ++i) P->g[i] = A.f(max_act);
+  if (towers)
+    for (int i = 0; i < 4; ++i) P->g_mid[i] = A.f((size_t)B * TR_C * P->geo[0].L[0]);
   P->part_floats = cl_conv32_part_floats();
   if (towers)
     for (int i = 0; i < 20; ++i) P->part[i] = A.f(P->part_floats);
   for (int i = 0; i < 3; ++i) P->dlogit[i] = A.f((size_t)B * sh.n_class);
   if (towers) {
-    int64_t tabf, argb, scr = 0, m = 0;
+    int64_t tabf, argb, scr = 0;
     for (int t = 0; t < 2; ++t) {
       mural_op_first_plan(TR_C, P->geo[t].pk[0], &tabf, &argb, &scr);
-      m = std::max(m, scr);
+      P->first_scratch[t] = A.f((size_t)scr);
     }
-    P->first_scratch = A.f((size_t)m);
   }
   P->total = A.off;
   return MURAL_OK;
 }
 
 const float EPS = 1e-5f;
+
+// The two towers share nothing but the symbols, so the mid tower runs on a side stream next to the large one: its short rows
+// (67 / 23 / 8 columns) leave most of the chip idle, and the fixed cost of its ~60 launches per direction hides behind the large
+// tower's kernels.  Fork: the side stream waits for everything queued on the caller's stream; join: the caller's stream waits for
+// the side stream.  Both are legal inside a stream capture (the side stream joins the capture and leaves it at the join).
+struct SideStream {
+  hipStream_t side = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  int init() {
+    if (side) return MURAL_OK;
+    MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    MURAL_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
+    MURAL_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+    return MURAL_OK;
+  }
+  int fork(hipStream_t main) {
+    MURAL_HIP_CHECK(hipEventRecord(fork_ev, main));
+    MURAL_HIP_CHECK(hipStreamWaitEvent(side, fork_ev, 0));
+    return MURAL_OK;
+  }
+  int join(hipStream_t main) {
+    MURAL_HIP_CHECK(hipEventRecord(join_ev, side));
+    MURAL_HIP_CHECK(hipStreamWaitEvent(main, join_ev, 0));
+    return MURAL_OK;
+  }
+};
+
+int side_stream(SideStream** out) {
+  static SideStream per_device[64];
+  int dev = 0;
+  MURAL_HIP_CHECK(hipGetDevice(&dev));
+  MURAL_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+  if (int rc = per_device[dev].init()) return rc;
+  *out = &per_device[dev];
+  return MURAL_OK;
+}
 
 struct Ctx {
   const MuralSnvShape* sh;
@@ -358,7 +396,8 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   const TowerGeo& g = P.geo[t];
   TowerBufs& b = P.tw[t];
   const int B = P.B;
-  float *g0 = P.g[0], *g1 = P.g[1], *g2 = P.g[2], *g3 = P.g[3];
+  float* const* gs = t == 0 ? P.g_mid : P.g;
+  float *g0 = gs[0], *g1 = gs[1], *g2 = gs[2], *g3 = gs[3];
   const float* fin = b.fd;
   // Linear -> Dropout -> BatchNorm1d on (B, 32)
   if (int rc = mural_op_linear_bwd(dlogits, fin, T.fc.weight, B, TR_C, P.nc, g0, const_cast<float*>(G.fc.weight),
@@ -384,7 +423,7 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   if (int rc = cl_maxpool_bwd(g1, b.arg2, B, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, st)) return rc;
   float* d_in2 = b.s2.t[3];
   if (int rc = stage_b(c, T.rbs1, G.rbs1, b.x0, g.L[0], b.s2, g3, d_in2, tmp)) return rc;
-  return train_first_bwd_cl(d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight, P.first_scratch,
+  return train_first_bwd_cl(d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight, P.first_scratch[t],
                             const_cast<float*>(G.conv_in.weight), const_cast<float*>(G.conv_in.bias), const_cast<float*>(G.bn_in.weight),
                             const_cast<float*>(G.bn_in.bias), st);
 }
@@ -457,13 +496,11 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   Ctx c{shape, params, nullptr, &P, momentum, stream};
   MURAL_HIP_CHECK(hipMemsetAsync(P.acc_begin, 0, P.acc_bytes, (hipStream_t)stream));
   const int m = shape->model_no;
-  if (m != 1) {
-    MURAL_REQUIRE(cat_x, "cat_x is NULL");
+  if (m != 1) MURAL_REQUIRE(cat_x, "cat_x is NULL");
+  if (m == 0) {        // raw logits, model_snv.py:93
     if (int rc = local_f(c, cat_x, dropout_p, seeds, seed_dev)) return rc;
-    if (m == 0) {      // raw logits, model_snv.py:93
-      MURAL_HIP_CHECK(hipMemcpyAsync(out, P.loc.logits, (size_t)B * shape->n_class * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
-      return MURAL_OK;
-    }
+    MURAL_HIP_CHECK(hipMemcpyAsync(out, P.loc.logits, (size_t)B * shape->n_class * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MURAL_OK;
   }
   MURAL_REQUIRE(distal_x || symbols, "distal_x and symbols are both NULL");
   if (symbols) {
@@ -471,8 +508,17 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   } else if (int rc = mural_op_dense_to_symbols(distal_x, B, shape->distal_len, P.sym, status, stream)) {
     return rc;
   }
-  if (int rc = tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev)) return rc;
-  if (int rc = tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev)) return rc;
+  SideStream* ss;
+  if (int rc = side_stream(&ss)) return rc;
+  if (int rc = ss->fork((hipStream_t)stream)) return rc;
+  c.stream = ss->side;
+  int rc_mid = tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
+  c.stream = stream;
+  if (m == 2 && !rc_mid) rc_mid = local_f(c, cat_x, dropout_p, seeds, seed_dev);
+  int rc_large = rc_mid ? MURAL_OK : tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
+  if (int rc = ss->join((hipStream_t)stream)) return rc;     // also on an error: the side stream must not stay forked
+  if (rc_mid) return rc_mid;
+  if (rc_large) return rc_large;
   return mural_op_head_fwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, B, shape->n_class, out, stream);
 }
 
@@ -493,9 +539,16 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   if (m == 0) return local_b(c, cat_x, dout, dropout_p, seeds, seed_dev);
   if (int rc = mural_op_head_bwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, dout, B, nc, m == 2 ? P.dlogit[0] : nullptr,
                                  P.dlogit[1], P.dlogit[2], stream)) return rc;
-  if (m == 2)
-    if (int rc = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev)) return rc;
-  if (int rc = tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev)) return rc;
-  if (int rc = tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev)) return rc;
+  SideStream* ss;
+  if (int rc = side_stream(&ss)) return rc;
+  if (int rc = ss->fork((hipStream_t)stream)) return rc;
+  c.stream = ss->side;
+  int rc_mid = tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev);
+  c.stream = stream;
+  if (m == 2 && !rc_mid) rc_mid = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
+  int rc_large = rc_mid ? MURAL_OK : tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);
+  if (int rc = ss->join((hipStream_t)stream)) return rc;
+  if (rc_mid) return rc_mid;
+  if (rc_large) return rc_large;
   return train_reduce_parts(c.job_part, c.job_nrow, c.job_dW, c.job_db, c.njobs, (hipStream_t)stream);
 }
