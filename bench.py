@@ -185,6 +185,7 @@ def train_steps_per_s(device, genome, B=4096, steps=200, warmup=20, sync_steps=5
     steps without a host synchronisation in between (windows encoded from the packed genome inside the timed loop), then
     `sync_steps` individually synchronised ones (the reference reads loss.item() every step, training.py:437)."""
     import torch.nn as nn
+    from mural_amd.train import clip_grad_norm_
     model = build_model(device).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)       # one multi-tensor launch; same update rule
     crit = nn.CrossEntropyLoss(reduction="sum")
@@ -201,7 +202,7 @@ def train_steps_per_s(device, genome, B=4096, steps=200, warmup=20, sync_steps=5
         loss = crit(model((cont, cat), x), labels[s * B:(s + 1) * B])
         opt.zero_grad()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+        clip_grad_norm_(model, 10)            # mural_amd.train: torch.nn.utils.clip_grad_norm_ over the flat gradient buffer
         opt.step()
         return loss
 

@@ -542,7 +542,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cl_kernel(const float* __res
 // MaxPool1d(k, s, p) on [B][L][32] -> [B][Lout][32] with the arg-max column (first maximum wins); thread = (row, pooled column,
 // 4 channels)
 __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const float* __restrict__ x, int64_t B, int L, int Lout, int k, int s, int p,
-                                                             float* __restrict__ y, int32_t* __restrict__ arg) {
+                                                             float* __restrict__ y, int32_t* __restrict__ arg, double* __restrict__ acc) {
+  __shared__ float red[256];
+  f32x4 s1 = splat(0.f), s2 = splat(0.f);     // batch sums of the pooled values for the BatchNorm behind the pool (acc != nullptr)
   const int64_t total = B * Lout * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int chunk = (int)(i & 7);
@@ -566,7 +568,10 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const float* __rest
     st4(y + (size_t)bc * CL_C + 4 * chunk, m);
     int32_t* ap = arg + (size_t)bc * CL_C + 4 * chunk;
     ap[0] = am[0]; ap[1] = am[1]; ap[2] = am[2]; ap[3] = am[3];
+    s1 += m;
+    s2 += f32x4{m.x * m.x, m.y * m.y, m.z * m.z, m.w * m.w};
   }
+  if (acc) cl_slot_add(s1, s2, acc + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, red, threadIdx.x);
 }
 
 // gather backward for disjoint windows (stride >= kernel: every pool of the model): dx[b][l][c] = arg[b][lo][c] == l ? dy[b][lo][c] : 0
@@ -713,10 +718,11 @@ int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, con
   return MURAL_OK;
 }
 
-int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, hipStream_t stream) {
+int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, double* acc, hipStream_t stream) {
   const int Lout = (L + 2 * p - k) / s + 1;
   if (B * Lout == 0) return MURAL_OK;
-  hipLaunchKernelGGL(maxpool_cl_fwd_kernel, dim3(cl_grid(B * Lout * 8)), dim3(256), 0, stream, x, B, L, Lout, k, s, p, y, arg);
+  hipLaunchKernelGGL(maxpool_cl_fwd_kernel, dim3(cl_grid(B * Lout * 8, acc ? 1024 : 8192)), dim3(256), 0, stream, x, B, L, Lout, k, s, p, y, arg,
+                     acc);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

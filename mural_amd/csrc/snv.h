@@ -90,6 +90,7 @@ struct FirstTrainArgs {
   const float* dy;                // backward: [B][32][L2]
   float* dpart;                   // backward: [grid][SNV_LUTBLK] per-workgroup gradient tables
   int cl;                         // 1: y / dy are channel-last [B][L2][32] (the composed training step), 0: [B][32][L2]
+  double* stat;                   // forward, cl only: [MURAL_BN_SLOTS][2][32] batch sums of relu(y), relu(y)^2 (nullptr: none)
 };
 int first_train_grid(int64_t B);
 bool first_train_supported(int C, int pk);

@@ -256,7 +256,7 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_site_kernel(const Stage
 template <int SLOT>
 __device__ __forceinline__ void pooled_lookup_train(const Stage1Tower& g, int lane, const float* lutS, const uint8_t* cb0,
                                                     const uint8_t* kw, float* __restrict__ y /* [32][L2] or [L2][32] */,
-                                                    uint8_t* __restrict__ arg /* [L2][32] */, int cl) {
+                                                    uint8_t* __restrict__ arg /* [L2][32] */, int cl, f32x4& sum1, f32x4& sum2) {
   const float* tapS = lutS + SNV_LUT;
   const float* b0S = tapS + SNV_TAPS;
   const uint8_t* cb = cb0 + g.col0;
@@ -317,6 +317,10 @@ __device__ __forceinline__ void pooled_lookup_train(const Stage1Tower& g, int la
     }
     if (cl) {
       *reinterpret_cast<f32x4*>(y + (size_t)j2 * 32 + 4 * cg) = f32x4{m[0], m[1], m[2], m[3]};
+      // batch sums of relu(y) for the BatchNorm of the first ResBlock (lanes with the same lane & 7 own the same four channels)
+      const f32x4 r = f32x4{fmaxf(m[0], 0.f), fmaxf(m[1], 0.f), fmaxf(m[2], 0.f), fmaxf(m[3], 0.f)};
+      sum1 += r;
+      sum2 += f32x4{r.x * r.x, r.y * r.y, r.z * r.z, r.w * r.w};
     } else {
 #pragma unroll
       for (int q = 0; q < 4; ++q) y[(size_t)(4 * cg + q) * g.L2 + j2] = m[q];
@@ -386,6 +390,7 @@ __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrai
   __syncthreads();
   const Stage1Tower g = a.tw;
   const int Lwin = a.Lwin;
+  f32x4 sum1 = f32x4{0.f, 0.f, 0.f, 0.f}, sum2 = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int64_t row = (int64_t)blockIdx.x * S1_WAVES + wave; row < a.B; row += (int64_t)gridDim.x * S1_WAVES) {
     const uint8_t* src = a.sym + row * Lwin;
     for (int jj = lane; jj < Lwin + 2; jj += 64) {
@@ -397,8 +402,32 @@ __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrai
     wave_lds_fence();
     const size_t o = (size_t)row * 32 * g.L2;
     if (BWD) pooled_scatter<SLOT>(g, lane, blk, cb, kw, a.dy + o, a.arg + o, a.cl);
-    else pooled_lookup_train<SLOT>(g, lane, blk, cb, kw, a.y + o, a.arg + o, a.cl);
+    else pooled_lookup_train<SLOT>(g, lane, blk, cb, kw, a.y + o, a.arg + o, a.cl, sum1, sum2);
     wave_lds_fence();
+  }
+  if (!BWD && a.stat) {                       // 16 waves -> 64 sums through LDS -> one double atomic per sum and workgroup
+    __syncthreads();                          // every wave is done with the tables: their LDS carries the partial sums
+    float* red = blk;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      float v1 = sum1[q], v2 = sum2[q];
+#pragma unroll
+      for (int off = 8; off < 64; off <<= 1) {
+        v1 += __shfl_xor(v1, off);
+        v2 += __shfl_xor(v2, off);
+      }
+      if (lane < 8) {
+        red[wave * 64 + 4 * lane + q] = v1;
+        red[wave * 64 + 32 + 4 * lane + q] = v2;
+      }
+    }
+    __syncthreads();
+    if (tid < 64) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < S1_WAVES; ++w) v += red[w * 64 + tid];
+      atomicAdd(&a.stat[(size_t)(blockIdx.x % MURAL_BN_SLOTS) * 64 + tid], (double)v);
+    }
   }
   if (BWD) {                                  // one partial block per workgroup; first_grad_fold_kernel sums them in order
     __syncthreads();

@@ -27,14 +27,14 @@ int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, in
 int cl_bn_stats(const float* x, int64_t rows, int relu, double* acc, hipStream_t stream);
 int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, const float* state, const float* gamma, const double* acc,
                     const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
-int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, hipStream_t stream);
+int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, double* acc, hipStream_t stream);
 int cl_maxpool_bwd(const float* dy, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream);
 int cl_gmax_fwd(const float* x, int64_t B, int L, float* feat, int32_t* arg, hipStream_t stream);
 int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t B, int L, float* dx, hipStream_t stream);
 // train_ops.hip / snv_stage1.hip: first layer with channel-last output
 int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
                        const float* W, const float* bias, float eps, float momentum, float* running_mean, float* running_var,
-                       unsigned long long* counts, float* tab, float* y, void* arg, hipStream_t stream);
+                       unsigned long long* counts, float* tab, float* y, void* arg, double* stat, hipStream_t stream);
 int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp,
                        const float* tab, const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
                        hipStream_t stream);
@@ -109,6 +109,7 @@ struct Plan {
   // backward temporaries
   float* g[4];              // gradient buffers of the largest activation shape (local branch, large tower)
   float* g_mid[4];          // the mid tower's own set: the two towers run on two streams
+  float* g_loc[3];          // the local branch's (it shares the mid tower's stream, but not its buffers: no ordering to maintain)
   float* part[24]; size_t part_floats;   // one partial-row region per conv32 layer (reduced by ONE launch at the end of the backward)
   float* dlogit[3];         // gradients of the local / mid / large logits
   float* first_scratch[2];  // per tower
@@ -208,6 +209,8 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
   for (int i = 0; i < 4; ++i) P->g[i] = A.f(max_act);
   if (towers)
     for (int i = 0; i < 4; ++i) P->g_mid[i] = A.f((size_t)B * TR_C * P->geo[0].L[0]);
+  if (local)
+    for (int i = 0; i < 3; ++i) P->g_loc[i] = A.f((size_t)B * std::max(5 * sh.local_cols, std::max(sh.hidden1, sh.hidden2)));
   P->part_floats = cl_conv32_part_floats();
   if (towers)
     for (int i = 0; i < 20; ++i) P->part[i] = A.f(P->part_floats);
@@ -312,14 +315,14 @@ int tower_f(Ctx& c, int t, const MuralTower& T, float drop_p, uint64_t seed, con
   hipStream_t st = (hipStream_t)c.stream;
   if (int rc = train_first_fwd_cl(P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], T.bn_in.weight, T.bn_in.bias, T.conv_in.weight,
                                   T.conv_in.bias, EPS, c.momentum, const_cast<float*>(T.bn_in.running_mean),
-                                  const_cast<float*>(T.bn_in.running_var), b.counts, b.tab, b.x0, b.arg1, st)) return rc;
-  if (int rc = stage_f(c, T.rbs1, b.x0, g.L[0], nullptr, false, b.s2)) return rc;
-  if (int rc = cl_maxpool_fwd(b.s2.t[3], B, g.L[0], g.pk[1], g.ps[1], g.pp[1], b.p2, b.arg2, st)) return rc;
-  if (int rc = bnconv_f(c, b.p2, g.L[1], 0, b.acc_c2_f, false, T.bn_mid, T.conv_mid, b.state_c2, 0, nullptr, nullptr, b.s3.acc_f[0], 1,
+                                  const_cast<float*>(T.bn_in.running_var), b.counts, b.tab, b.x0, b.arg1, b.s2.acc_f[0], st)) return rc;
+  if (int rc = stage_f(c, T.rbs1, b.x0, g.L[0], b.s2.acc_f[0], true, b.s2)) return rc;
+  if (int rc = cl_maxpool_fwd(b.s2.t[3], B, g.L[0], g.pk[1], g.ps[1], g.pp[1], b.p2, b.arg2, b.acc_c2_f, st)) return rc;
+  if (int rc = bnconv_f(c, b.p2, g.L[1], 0, b.acc_c2_f, true, T.bn_mid, T.conv_mid, b.state_c2, 0, nullptr, nullptr, b.s3.acc_f[0], 1,
                         b.x0b)) return rc;
   if (int rc = stage_f(c, T.rbs2, b.x0b, g.L[1], b.s3.acc_f[0], true, b.s3)) return rc;
-  if (int rc = cl_maxpool_fwd(b.s3.t[3], B, g.L[1], g.pk[2], g.ps[2], g.pp[2], b.p3, b.arg3, st)) return rc;
-  if (int rc = bnconv_f(c, b.p3, g.L[2], 0, b.acc_c3_f, false, T.bn_out, T.conv_out, b.state_c3, 1, nullptr, nullptr, nullptr, 0, b.c3))
+  if (int rc = cl_maxpool_fwd(b.s3.t[3], B, g.L[1], g.pk[2], g.ps[2], g.pp[2], b.p3, b.arg3, b.acc_c3_f, st)) return rc;
+  if (int rc = bnconv_f(c, b.p3, g.L[2], 0, b.acc_c3_f, true, T.bn_out, T.conv_out, b.state_c3, 1, nullptr, nullptr, nullptr, 0, b.c3))
     return rc;
   if (int rc = cl_gmax_fwd(b.c3, B, g.L[2], b.feat, b.argg, st)) return rc;
   // distal_fc: BatchNorm1d -> Dropout -> Linear on (B, 32)
@@ -435,7 +438,7 @@ int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop,
   const MuralLocal& G = c.gr->local;
   LocalBufs& l = P.loc;
   const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
-  float *g0 = P.g[0], *g1 = P.g[1], *g2 = P.g[2];
+  float *g0 = P.g_loc[0], *g1 = P.g_loc[1], *g2 = P.g_loc[2];
   const float* x_last = l.dout[1];
   if (int rc = mural_op_linear_bwd(dlogits, x_last, L.out.weight, B, h[1], P.nc, g0, const_cast<float*>(G.out.weight),
                                    const_cast<float*>(G.out.bias), c.stream)) return rc;
@@ -511,10 +514,10 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   SideStream* ss;
   if (int rc = side_stream(&ss)) return rc;
   if (int rc = ss->fork((hipStream_t)stream)) return rc;
-  c.stream = ss->side;
-  int rc_mid = tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
+  c.stream = ss->side;                                       // side stream: local branch + mid tower; caller's stream: large tower
+  int rc_mid = m == 2 ? local_f(c, cat_x, dropout_p, seeds, seed_dev) : MURAL_OK;
+  if (!rc_mid) rc_mid = tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
   c.stream = stream;
-  if (m == 2 && !rc_mid) rc_mid = local_f(c, cat_x, dropout_p, seeds, seed_dev);
   int rc_large = rc_mid ? MURAL_OK : tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
   if (int rc = ss->join((hipStream_t)stream)) return rc;     // also on an error: the side stream must not stay forked
   if (rc_mid) return rc_mid;
@@ -544,8 +547,8 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   if (int rc = ss->fork((hipStream_t)stream)) return rc;
   c.stream = ss->side;
   int rc_mid = tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev);
-  c.stream = stream;
   if (m == 2 && !rc_mid) rc_mid = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
+  c.stream = stream;
   int rc_large = rc_mid ? MURAL_OK : tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);
   if (int rc = ss->join((hipStream_t)stream)) return rc;
   if (rc_mid) return rc_mid;

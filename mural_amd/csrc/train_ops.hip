@@ -431,17 +431,35 @@ __global__ void maxpool_bwd_gather_kernel(const float* __restrict__ dy, const in
 }
 
 // ------------------------------------------------------------------------------------------- first layer (one-hot input)
-// symbol histogram of the tower's input columns
-__global__ void sym_hist_kernel(const uint8_t* __restrict__ sym, int64_t B, int Lwin, int col0, int L1,
-                                unsigned long long* __restrict__ counts) {
+// symbol histogram of the tower's input columns.  A wave counts its 64 symbols per round with one ballot per base (A/C/G/T are all
+// but a handful of the symbols) into scalar counters; anything else takes the LDS-atomic path.  One global atomic per symbol and
+// workgroup at the end.
+__global__ __launch_bounds__(256) void sym_hist_kernel(const uint8_t* __restrict__ sym, int64_t B, int Lwin, int col0, int L1,
+                                                       unsigned long long* __restrict__ counts) {
   __shared__ unsigned int h[N_SYM];
   if (threadIdx.x < N_SYM) h[threadIdx.x] = 0;
   __syncthreads();
   const int64_t total = B * L1;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t b = i / L1;
-    const int j = (int)(i - b * L1);
-    atomicAdd(&h[sym[b * Lwin + col0 + j] & 15], 1u);
+  unsigned int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  const int64_t first = blockIdx.x * (int64_t)blockDim.x, stride = (int64_t)gridDim.x * blockDim.x;
+  for (int64_t base = first; base < total; base += stride) {       // uniform trip count per wave: the ballots see every lane
+    const int64_t i = base + threadIdx.x;
+    int v = -1;
+    if (i < total) {
+      const int64_t b = i / L1;
+      v = sym[b * Lwin + col0 + (int)(i - b * L1)] & 15;
+    }
+    c0 += __popcll(__ballot(v == 0));
+    c1 += __popcll(__ballot(v == 1));
+    c2 += __popcll(__ballot(v == 2));
+    c3 += __popcll(__ballot(v == 3));
+    if (v > 3) atomicAdd(&h[v], 1u);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    atomicAdd(&h[0], c0);
+    atomicAdd(&h[1], c1);
+    atomicAdd(&h[2], c2);
+    atomicAdd(&h[3], c3);
   }
   __syncthreads();
   if (threadIdx.x < N_SYM && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
@@ -1035,7 +1053,7 @@ extern "C" int mural_op_first_plan(int32_t C, int32_t pk, int64_t* tab_floats, i
 static int first_fwd_impl(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t col0, int32_t L1, int32_t C, int32_t pk,
                           int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
                           const float* bias, float eps, float momentum, float* running_mean, float* running_var,
-                          unsigned long long* counts, float* tab, float* y, void* arg, int cl, void* stream) {
+                          unsigned long long* counts, float* tab, float* y, void* arg, int cl, double* stat, void* stream) {
   const int L2 = (L1 + 2 * pp - pk) / ps + 1;
   const bool fast = first_train_supported(C, pk);
   hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(B * L1, 256, 2048)), dim3(256), 0, STREAM, sym, B, Lwin, col0, L1, counts);
@@ -1047,6 +1065,7 @@ static int first_fwd_impl(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t c
     a.tw = Stage1Tower{L1, col0, L2, pk, ps, pp};
     a.Lwin = Lwin; a.B = B; a.sym = sym; a.lutblk = first_lutblk(tab, C); a.y = y; a.arg = static_cast<uint8_t*>(arg);
     a.cl = cl;
+    a.stat = cl ? stat : nullptr;
     return launch_first_train(a, false, STREAM);
   }
   MURAL_REQUIRE(!cl, "first layer: the channel-last layout is served by the table kernels only");
@@ -1062,7 +1081,7 @@ extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, i
                                   const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                                   unsigned long long* counts, float* tab, float* y, void* arg, void* stream) {
   return first_fwd_impl(sym, B, Lwin, col0, L1, C, pk, ps, pp, gamma, beta, W, bias, eps, momentum, running_mean, running_var, counts, tab, y,
-                        arg, 0, stream);
+                        arg, 0, nullptr, stream);
 }
 
 static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
@@ -1109,9 +1128,9 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
 namespace mural {
 int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
                        const float* W, const float* bias, float eps, float momentum, float* running_mean, float* running_var,
-                       unsigned long long* counts, float* tab, float* y, void* arg, hipStream_t stream) {
+                       unsigned long long* counts, float* tab, float* y, void* arg, double* stat, hipStream_t stream) {
   return first_fwd_impl(sym, B, Lwin, col0, L1, 32, pk, ps, pp, gamma, beta, W, bias, eps, momentum, running_mean, running_var, counts, tab, y,
-                        arg, 1, stream);
+                        arg, 1, stat, stream);
 }
 int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp,
                        const float* tab, const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,

@@ -86,6 +86,26 @@ class GraphedTrainStep:
         self._check()
 
 
+def clip_grad_norm_(model, max_norm):
+    """``torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)`` (training.py:430) for a model whose gradients came out of
+    the one-call HIP backward: they are views of ONE flat buffer (zero between the slots), so the total 2-norm is one reduction
+    over it and the scaling one multiply -- three launches instead of a 150-tensor foreach.  Any other state (a gradient that
+    was replaced or accumulated elsewhere, a model without the flat buffer) falls through to torch's implementation."""
+    lay = getattr(model, "_train_layout", None)
+    flat = getattr(lay, "last_flat", None) if lay is not None else None
+    if flat is not None:
+        base = flat.data_ptr()
+        for p, off in zip(lay.plist, lay.poffs):        # every gradient still sits in its slot of the latest backward's buffer
+            g = p.grad
+            if g is None or g.data_ptr() != base + 4 * off:
+                break
+        else:
+            total = torch.linalg.vector_norm(flat, 2.0)
+            flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
+            return total
+    return torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm, error_if_nonfinite=False)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # the reference's epoch loop (MuRaL/training.py:346-450) around the HIP models: optimiser / scheduler choice and the
 # per-batch policy (skip batches of one row, clip at 10, step the scheduler every batch, restart a learning rate that decayed
@@ -135,7 +155,7 @@ def train_epoch(model, batches, criterion, optimizer, scheduler, config, device,
         loss = criterion(preds, y.long().squeeze())
         optimizer.zero_grad()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, error_if_nonfinite=False)
+        clip_grad_norm_(model, 10)
         optimizer.step()
         total_loss += loss.item()
         if config["lr_scheduler"] != "ROP":

@@ -389,3 +389,46 @@ def test_train_step_replicated_batch_equals_scaled_fixture():
         tol = 2e-4 * (float(np.abs(want).max()) + 1e-2 * reps)
         err = float(np.abs(p.grad.cpu().numpy() - want).max())
         assert err <= tol, f"gradient of {k}: off by {err:.3e} (allowed {tol:.3e})"
+
+
+def test_flat_clip_grad_norm_matches_torch():
+    """mural_amd.train.clip_grad_norm_ (one reduction over the flat gradient buffer of the one-call backward) against
+    torch.nn.utils.clip_grad_norm_ on the same gradients: same total norm, same clipped gradients; and the fall-back when a
+    gradient was replaced."""
+    from mural_amd.train import clip_grad_norm_
+    fx = U.load("snv_train_T.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    model = model.cuda().train()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"]).cuda()
+    crit = nn.CrossEntropyLoss(reduction="sum")
+
+    def grads():
+        model.zero_grad()
+        crit(model((torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda"), cat), x), y).backward()
+
+    for max_norm in (1e9, 0.5):
+        torch.manual_seed(5)
+        grads()
+        want_total = torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)
+        want = {k: p.grad.clone() for k, p in model.named_parameters() if p.numel()}
+        torch.manual_seed(5)
+        grads()
+        assert model._train_layout.last_flat is not None
+        total = clip_grad_norm_(model, max_norm)
+        assert abs(float(total) - float(want_total)) <= 1e-5 * float(want_total)
+        for k, p in model.named_parameters():
+            if p.numel():
+                # two separate backward passes: the float atomics of the first-layer gradient table land in a different order
+                assert float((p.grad - want[k]).abs().max()) <= 2e-5 * (float(want[k].abs().max()) + 1e-6), k
+    # a gradient that left the flat buffer: torch's path serves the call
+    torch.manual_seed(5)
+    grads()
+    first = next(p for p in model.parameters() if p.numel())
+    first.grad = first.grad.clone() * 2
+    ref_total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.numel()))
+    total = clip_grad_norm_(model, 1e9)
+    assert abs(float(total) - float(ref_total)) <= 1e-5 * float(ref_total)

@@ -19,7 +19,7 @@ codes = bench.synthetic_genome(200_000 + 2000)
 packed, mask = bench.pack2(codes)
 genome = PackedGenome(packed, mask, len(codes), dev)
 model = bench.build_model(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 crit = nn.CrossEntropyLoss(reduction="sum")
 labels = torch.zeros(B, dtype=torch.int64, device=dev)
 cont = torch.zeros(B, 1, device=dev)
@@ -42,7 +42,7 @@ for _ in range(3):
 torch.cuda.synchronize()
 pr = cProfile.Profile()
 pr.enable()
-for _ in range(10):
+for _ in range(30):
     step()
 pr.disable()
 torch.cuda.synchronize()

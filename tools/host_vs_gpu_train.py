@@ -17,7 +17,7 @@ codes = bench.synthetic_genome(200_000 + 2000)
 packed, mask = bench.pack2(codes)
 genome = PackedGenome(packed, mask, len(codes), dev)
 model = bench.build_model(dev).train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 crit = nn.CrossEntropyLoss(reduction="sum")
 labels = torch.zeros(B, dtype=torch.int64, device=dev)
 cont = torch.zeros(B, 1, device=dev)
