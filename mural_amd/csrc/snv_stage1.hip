@@ -340,27 +340,49 @@ __device__ __forceinline__ void pooled_scatter(const Stage1Tower& g, int lane, f
   const int cg = lane & 7;
   const int total = g.L2 * 8;
   float bsum[4] = {0.f, 0.f, 0.f, 0.f};
-  for (int task = lane; task < total; task += 64) {
-    const int j2 = task >> 3;
-    const uint32_t aw = *reinterpret_cast<const uint32_t*>(arg + (size_t)j2 * 32 + 4 * cg);
-    const int jlo = j2 * g.ps - g.pp;
+  // a wave owns one row: its ~17 rounds would each wait a full global round trip for their gradient, so the loads of NT rounds are
+  // issued together before any of them is scattered
+  constexpr int NT = 6;
+  for (int t0 = lane; t0 < total; t0 += 64 * NT) {
+    uint32_t awv[NT];
+    f32x4 gv[NT];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int c = 4 * cg + q;
-      const float gq = cl ? dy[(size_t)j2 * 32 + c] : dy[(size_t)c * g.L2 + j2];
-      const int w = (int)((aw >> (8 * q)) & 0xFFu);
-      const uint32_t idx = kw[(size_t)j2 * SLOT + w];
-      bsum[q] += gq;
-      if (idx != 255u) {
-        atomicAdd(&acc[idx * 32u + c], gq);
+    for (int u = 0; u < NT; ++u) {
+      const int task = t0 + 64 * u;
+      const int j2 = (task < total ? task : t0) >> 3;
+      awv[u] = *reinterpret_cast<const uint32_t*>(arg + (size_t)j2 * 32 + 4 * cg);
+      if (cl) {
+        gv[u] = *reinterpret_cast<const f32x4*>(dy + (size_t)j2 * 32 + 4 * cg);
       } else {
-        const int j = jlo + w;
-        const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
-        const uint32_t sc = cb[j + 1];
-        const uint32_t sr = (j == g.L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
-        atomicAdd(&tapA[(0 * N_SYM + sl) * 32 + c], gq);
-        atomicAdd(&tapA[(1 * N_SYM + sc) * 32 + c], gq);
-        atomicAdd(&tapA[(2 * N_SYM + sr) * 32 + c], gq);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) gv[u][q] = dy[(size_t)(4 * cg + q) * g.L2 + j2];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int task = t0 + 64 * u;
+      if (task >= total) break;
+      const int j2 = task >> 3;
+      const uint32_t aw = awv[u];
+      const int jlo = j2 * g.ps - g.pp;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int c = 4 * cg + q;
+        const float gq = gv[u][q];
+        const int w = (int)((aw >> (8 * q)) & 0xFFu);
+        const uint32_t idx = kw[(size_t)j2 * SLOT + w];
+        bsum[q] += gq;
+        if (idx != 255u) {
+          atomicAdd(&acc[idx * 32u + c], gq);
+        } else {
+          const int j = jlo + w;
+          const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
+          const uint32_t sc = cb[j + 1];
+          const uint32_t sr = (j == g.L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
+          atomicAdd(&tapA[(0 * N_SYM + sl) * 32 + c], gq);
+          atomicAdd(&tapA[(1 * N_SYM + sc) * 32 + c], gq);
+          atomicAdd(&tapA[(2 * N_SYM + sr) * 32 + c], gq);
+        }
       }
     }
   }
@@ -393,9 +415,17 @@ __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrai
   f32x4 sum1 = f32x4{0.f, 0.f, 0.f, 0.f}, sum2 = f32x4{0.f, 0.f, 0.f, 0.f};
   for (int64_t row = (int64_t)blockIdx.x * S1_WAVES + wave; row < a.B; row += (int64_t)gridDim.x * S1_WAVES) {
     const uint8_t* src = a.sym + row * Lwin;
-    for (int jj = lane; jj < Lwin + 2; jj += 64) {
-      const int j = jj - 1;
-      cb[jj] = (j >= 0 && j < Lwin) ? src[j] : (uint8_t)SYM_PAD;
+    constexpr int UN = 8;                     // byte loads in flight per lane (one wave loads the whole row)
+    for (int jj0 = lane; jj0 < Lwin + 2; jj0 += 64 * UN) {
+      uint8_t v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int j = jj0 + 64 * u - 1;
+        v[u] = (j >= 0 && j < Lwin) ? src[j] : (uint8_t)SYM_PAD;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (jj0 + 64 * u < Lwin + 2) cb[jj0 + 64 * u] = v[u];
     }
     wave_lds_fence();
     build_kwin<SLOT>(g, lane, cb, kw);
