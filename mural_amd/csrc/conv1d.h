@@ -26,7 +26,11 @@ struct Conv1dArgs {
   int rt;                // set by launch_conv1d: batch rows packed into one 64-lane tile (short rows), 1 otherwise
 };
 
-int launch_conv1d(const Conv1dArgs& a, hipStream_t stream);
+int launch_conv1d(const Conv1dArgs& a, hipStream_t stream);        // routes between the two kernels below
+int launch_conv1d_valu(const Conv1dArgs& a, hipStream_t stream);   // direct form on the vector ALU (conv1d.hip)
+// implicit-GEMM version on fp32 MFMA for layers with >= 16 output channels (conv1d_mfma.hip); launch_conv1d routes to it
+bool conv1d_mfma_supported(const Conv1dArgs& a);
+int launch_conv1d_mfma(const Conv1dArgs& a, hipStream_t stream);
 
 // Fused ConvBlock of the INDEL U-Net (reference MuRaL/model/model_indel.py:6-19, eval mode, BatchNorms folded):
 //   out = x + W1 . SiLU(W5 * x + b5) + b1 [+ res2],  W5: k=5 conv C -> 2C, W1: 1x1 conv 2C -> C.

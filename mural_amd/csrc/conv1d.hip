@@ -4,6 +4,8 @@
 // group arriving through wave-uniform (scalar) loads, so the inner loop is 1 LDS read + COG FMAs per (ci, tap).
 // Used by the INDEL U-Net (reference MuRaL/model/model_indel.py:6-176: k=7/5/1 convs, strides 1/4/5/2, Upsample,
 // SiLU / ReLU / Softplus, residual adds).
+#include <cstdlib>
+
 #include "conv1d.h"
 
 namespace mural {
@@ -136,7 +138,18 @@ static Conv1dFn pick_kernel(int K, int cog) {
   return cog == 16 ? pick_taps<16, WIDE>(K) : (cog == 8 ? pick_taps<8, WIDE>(K) : pick_taps<4, WIDE>(K));
 }
 
-int launch_conv1d(const Conv1dArgs& a_in, hipStream_t stream) {
+int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.Lout == 0) return MURAL_OK;
+  MURAL_REQUIRE(a.up >= 1 && a.stride >= 1 && a.K >= 1, "conv1d: bad geometry");
+  static const bool use_mfma = !(getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 0);   // A/B switch of the tools
+  // measured at 2048 rows (tools/gpu_debug_conv1d.py): the implicit GEMM wins on short rows (<= 128 columns: 2-4 x) and on long
+  // rows with a deep reduction (Cin * K >= 224); long rows with few input channels are bound by the output stream and the direct
+  // kernel's 64-column tiles keep more of them in flight
+  if (use_mfma && conv1d_mfma_supported(a) && (a.Lout <= 128 || a.Cin * a.K >= 224)) return launch_conv1d_mfma(a, stream);
+  return launch_conv1d_valu(a, stream);
+}
+
+int launch_conv1d_valu(const Conv1dArgs& a_in, hipStream_t stream) {
   Conv1dArgs a = a_in;
   if (a.B == 0 || a.Lout == 0) return MURAL_OK;
   MURAL_REQUIRE(a.Cout % 4 == 0, "conv1d: Cout must be a multiple of 4 (got %d)", a.Cout);

@@ -1,0 +1,258 @@
+// Generic fp32 Conv1d as an implicit GEMM on v_mfma_f32_16x16x4_f32 (gfx950): the same contract as conv1d.hip's vector-ALU
+// kernel (Conv1dArgs: stride, nearest-neighbour upsampling, per-channel pre-op, bias, activation, two residuals; [B][C][L]
+// tensors, weights [Cin][K][Cout]) for layers with at least 16 output channels.
+//
+// Why: the deep U-Net levels of the INDEL model (model_indel.py:21-176: 32..96 channels on rows of 80 / 16 / 8 columns) are
+// GEMMs with M = Cout, N = batch x columns, K = Cin x taps whose WEIGHTS outweigh a row's activations.  The direct kernel
+// gives a workgroup 64 output columns and streams every weight through the scalar cache once per workgroup -- 100-150 us per
+// launch for a few MFLOP per position.  Here the N axis is the flattened (row, column) index of TR whole rows (short rows) or a
+// 64-column segment of one row (long rows).  The four waves tile the (output-channel blocks) x (16-column blocks) grid 2 x 2
+// (4 x 1 over the columns when there is one channel block): per (4 input channels, tap) step a wave loads its <= 3 weight
+// fragments as coalesced 64-byte global loads (shared by the other waves through L1 / L2, one step ahead of their use) and its
+// <= 2 input fragments from LDS, and issues their outer product of MFMAs.
+//
+//   A (16 x 4)  = W[co = 16 mb + (lane & 15)][ci0 + (lane >> 4)][tap]      global, [Cin][K][Cout] layout: 16 lanes = 64 contiguous bytes
+//   B (4 x 16)  = X[ci0 + (lane >> 4)][column (lane & 15) of the block, tap] LDS tile [row][ci][span], pre-op / upsampling / zero
+//                                                                            padding applied while staging
+//   D (16 x 16) : lane holds rows 4 (lane >> 4) .. + 3 of column (lane & 15)
+#include "conv1d.h"
+
+namespace mural {
+namespace {
+
+typedef float g4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float cg_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    case ACT_SOFTPLUS: {
+      const float e = __expf(v);
+      return v > 20.f ? v : (v < -15.f ? e : __logf(1.f + e));
+    }
+    default: return v;
+  }
+}
+
+struct ConvGArgs {
+  Conv1dArgs a;
+  int TR;        // batch rows per tile (row regime), 1 in the segment regime
+  int seg;       // 1: a tile is a seg_cols()-column segment of one row (grid = segments x rows)
+  int span;      // staged input columns per (row, channel)
+  int span_p;    // LDS row stride (== 16 mod 32: the four channel rows of a fragment read land on disjoint bank halves)
+  FastDiv d_span, d_cin, d_up, d_lout;   // the staging loop's index arithmetic costs more than its loads with hardware division
+};
+
+constexpr int CG_NBW_SEG = 4;   // segment regime: 16-column blocks per wave (tile = 64 x (4 or 2) x ... columns, see seg_cols)
+
+// columns of a segment-regime tile: the column-block groups (4 with one channel block, else 2) x CG_NBW_SEG blocks x 16
+__host__ __device__ inline int seg_cols(int Cout) { return (Cout > 16 ? 2 : 4) * CG_NBW_SEG * 16; }
+
+template <int MW, int KT, int NBW>     // MW: output-channel blocks per wave (1..3); NBW: 16-column blocks per wave
+__global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, const float* __restrict__ wt, const float* __restrict__ bias) {
+  extern __shared__ float tile[];   // [TR][Cin][span_p]
+  const Conv1dArgs& a = g.a;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int b0 = g.seg ? blockIdx.y : blockIdx.x * g.TR;
+  const int SEG = seg_cols(a.Cout);
+  const int l0 = g.seg ? blockIdx.x * SEG : 0;
+  const int in0 = l0 * a.stride - a.pad;      // virtual (upsampled) input index of the first staged column
+  const int Lv = a.Lin * a.up;
+  // ---- stage: all 256 threads over the flattened (row, channel, column) index, UN independent loads in flight per thread (a
+  //      loop that waits for one load per round costs a global round trip per round: ~100 us on the deep levels)
+  {
+    const int total = g.TR * a.Cin * g.span;
+    constexpr int UN = 4;
+    for (int i0 = tid; i0 < total; i0 += 256 * UN) {
+      float x[UN];
+      int dsto[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        x[u] = 0.f;                           // zero padding, applied after the pre-op like nn.Conv1d behind a BatchNorm
+        dsto[u] = -1;
+        if (i < total) {
+          const int rc = (int)g.d_span.div((uint32_t)i), j = i - rc * g.span;
+          const int r = (int)g.d_cin.div((uint32_t)rc), ci = rc - r * a.Cin;
+          const int v = in0 + j;
+          dsto[u] = rc * g.span_p + j;
+          if (b0 + r < a.B && v >= 0 && v < Lv) {
+            float xv = a.in[((size_t)(b0 + r) * a.Cin + ci) * a.Lin + (int)g.d_up.div((uint32_t)v)];
+            if (a.pre_relu) xv = fmaxf(xv, 0.f);
+            x[u] = fmaf(a.pre_s ? a.pre_s[ci] : 1.f, xv, a.pre_t ? a.pre_t[ci] : 0.f);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (dsto[u] >= 0) tile[dsto[u]] = x[u];
+    }
+  }
+  __syncthreads();
+  const int ncols = g.seg ? (a.Lout - l0 < SEG ? a.Lout - l0 : SEG) : g.TR * a.Lout;
+  constexpr int K = KT;
+  // wave -> (channel-block group wm, column-block group wn)
+  const int mb_total = (a.Cout + 15) >> 4;
+  const int WM = mb_total >= 2 ? 2 : 1, WN = 4 / WM;
+  const int wm = wave % WM, wn = wave / WM;
+  const int m_first = wm * MW;                              // this wave's channel blocks: m_first .. m_first + MW - 1 (< mb_total)
+  const int nbw = g.seg ? NBW : 4 / WN;                     // row regime: 64 columns = 4 blocks over the WN groups
+  // per owned column block: LDS offset of the lane's column, validity
+  int boff[NBW], brow[NBW], bcol[NBW];
+  bool bval[NBW];
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    const int blk = wn * nbw + j;
+    const int col = 16 * blk + n16;
+    bval[j] = j < nbw && col < ncols;
+    int r = 0, l = bval[j] ? col : 0;
+    if (!g.seg) {
+      r = (int)g.d_lout.div((uint32_t)l);
+      l -= r * a.Lout;
+    }
+    brow[j] = r;
+    bcol[j] = l;
+    boff[j] = (r * a.Cin + kk) * g.span_p + l * a.stride;
+  }
+  // weight fragment addresses: channel blocks past Cout re-read block 0 and are zeroed by the select below
+  int woff[MW];
+  bool wok[MW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m) {
+    const int co = 16 * (m_first + m) + n16;
+    wok[m] = m_first + m < mb_total && co < a.Cout;
+    woff[m] = wok[m] ? co : n16;
+  }
+  g4 acc[MW][NBW];
+#pragma unroll
+  for (int m = 0; m < MW; ++m)
+#pragma unroll
+    for (int j = 0; j < NBW; ++j) acc[m][j] = g4{0.f, 0.f, 0.f, 0.f};
+  const float* wbase = wt + (size_t)kk * K * a.Cout;
+  float an[K][MW];                                          // next step's weight fragments, in flight during this step's MFMAs
+#pragma unroll
+  for (int t = 0; t < K; ++t)
+#pragma unroll
+    for (int m = 0; m < MW; ++m) an[t][m] = wbase[(size_t)t * a.Cout + woff[m]];
+  for (int ci0 = 0; ci0 < a.Cin; ci0 += 4) {
+    float ac[K][MW];
+#pragma unroll
+    for (int t = 0; t < K; ++t)
+#pragma unroll
+      for (int m = 0; m < MW; ++m) ac[t][m] = wok[m] ? an[t][m] : 0.f;
+    if (ci0 + 4 < a.Cin) {
+      const float* wnext = wbase + (size_t)(ci0 + 4) * K * a.Cout;
+#pragma unroll
+      for (int t = 0; t < K; ++t)
+#pragma unroll
+        for (int m = 0; m < MW; ++m) an[t][m] = wnext[(size_t)t * a.Cout + woff[m]];
+    }
+    const float* trow = tile + (size_t)ci0 * g.span_p;
+#pragma unroll
+    for (int t = 0; t < K; ++t) {
+      float bv[NBW];
+#pragma unroll
+      for (int j = 0; j < NBW; ++j) bv[j] = trow[boff[j] + t];
+#pragma unroll
+      for (int m = 0; m < MW; ++m)
+#pragma unroll
+        for (int j = 0; j < NBW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t][m], bv[j], acc[m][j], 0, 0, 0);
+    }
+  }
+  // ---- epilogue: bias, activation, residuals; 16 lanes write 16 consecutive columns of one output channel
+#pragma unroll
+  for (int j = 0; j < NBW; ++j) {
+    if (!bval[j] || b0 + brow[j] >= a.B) continue;
+#pragma unroll
+    for (int m = 0; m < MW; ++m)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = 16 * (m_first + m) + 4 * kk + q;
+        if (m_first + m < mb_total && co < a.Cout) {
+          const size_t o = ((size_t)(b0 + brow[j]) * a.Cout + co) * a.Lout + l0 + bcol[j];
+          float v = cg_act(acc[m][j][q] + (bias ? bias[co] : 0.f), a.act);
+          if (a.res1) v += a.res1[o];
+          if (a.res2) v += a.res2[o];
+          a.out[o] = v;
+        }
+      }
+  }
+}
+
+using ConvGFn = void (*)(const ConvGArgs, const float*, const float*);
+
+template <int MW, int NBW>
+ConvGFn pick_taps(int K) {
+  switch (K) {
+    case 1: return conv1d_mfma_kernel<MW, 1, NBW>;
+    case 5: return conv1d_mfma_kernel<MW, 5, NBW>;
+    case 7: return conv1d_mfma_kernel<MW, 7, NBW>;
+    default: return nullptr;
+  }
+}
+
+template <int NBW>
+ConvGFn pick_mw(int mb_total, int K) {
+  const int mw = mb_total >= 2 ? (mb_total + 1) / 2 : 1;
+  switch (mw) {
+    case 1: return pick_taps<1, NBW>(K);
+    case 2: return pick_taps<2, NBW>(K);
+    default: return pick_taps<3, NBW>(K);
+  }
+}
+
+ConvGFn pick(int mb_total, int K, int seg) { return seg ? pick_mw<CG_NBW_SEG>(mb_total, K) : pick_mw<2>(mb_total, K); }
+
+int pad_span(int span) {      // smallest stride >= span that is 16 mod 32
+  const int rem = span & 31;
+  return rem <= 16 ? span - rem + 16 : span - rem + 48;
+}
+
+bool plan(const Conv1dArgs& a, ConvGArgs* g) {
+  if (a.Cout < 16 || a.Cout > 96 || a.Cin % 4 != 0 || a.Cin < 4 || (a.K != 1 && a.K != 5 && a.K != 7)) return false;
+  g->a = a;
+  if (a.Lout > 64) {          // longer than the 64-column tile of the row regime
+    g->seg = 1;
+    g->TR = 1;
+    g->span = (seg_cols(a.Cout) - 1) * a.stride + a.K;
+  } else {
+    g->seg = 0;
+    g->span = (a.Lout - 1) * a.stride + a.K;
+    int tr = 64 / a.Lout;
+    if (tr < 1) tr = 1;
+    while (tr > 1 && (size_t)tr * a.Cin * pad_span(g->span) * 4 > 64 * 1024) --tr;
+    g->TR = tr;
+  }
+  g->span_p = pad_span(g->span);
+  g->d_span = FastDiv::make((uint32_t)g->span);
+  g->d_cin = FastDiv::make((uint32_t)a.Cin);
+  g->d_up = FastDiv::make((uint32_t)a.up);
+  g->d_lout = FastDiv::make((uint32_t)a.Lout);
+  return (size_t)g->TR * a.Cin * g->span_p * 4 <= 96 * 1024;
+}
+
+}  // namespace
+
+bool conv1d_mfma_supported(const Conv1dArgs& a) {
+  ConvGArgs g;
+  return plan(a, &g);
+}
+
+int launch_conv1d_mfma(const Conv1dArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.Lout == 0) return MURAL_OK;
+  ConvGArgs g;
+  MURAL_REQUIRE(plan(a, &g), "conv1d (MFMA): unsupported geometry");
+  const size_t lds = (size_t)g.TR * a.Cin * g.span_p * 4;
+  ConvGFn fn = pick((a.Cout + 15) / 16, a.K, g.seg);
+  if (lds > 64 * 1024)
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  const int segc = seg_cols(a.Cout);
+  const dim3 grid = g.seg ? dim3((a.Lout + segc - 1) / segc, a.B) : dim3((a.B + g.TR - 1) / g.TR);
+  hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, g, a.wt, a.bias);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural

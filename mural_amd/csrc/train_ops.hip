@@ -945,6 +945,24 @@ extern "C" int mural_op_conv1d(const float* in, const float* wt, const float* bi
   return launch_conv1d(a, STREAM);
 }
 
+// validation hook (tests/test_gpu_indel.py): the generic conv with every geometry knob of Conv1dArgs, on the vector-ALU kernel
+// (engine 0), the MFMA implicit-GEMM kernel (engine 1) or the router's choice (engine 2)
+extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin, int32_t Lin,
+                                  int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t up, int32_t act, const float* res1,
+                                  const float* res2, int32_t engine, void* stream) {
+  Conv1dArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.in = in; a.wt = wt; a.bias = bias; a.out = out;
+  a.B = (int)B; a.Cin = Cin; a.Lin = Lin; a.Cout = Cout; a.Lout = Lout;
+  a.K = K; a.stride = stride; a.pad = (K - 1) / 2; a.up = up;
+  a.act = act; a.res1 = res1; a.res2 = res2;
+  if (engine == 1) {
+    MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA): unsupported geometry");
+    return launch_conv1d_mfma(a, STREAM);
+  }
+  return engine == 0 ? launch_conv1d_valu(a, STREAM) : launch_conv1d(a, STREAM);
+}
+
 // Batch sums live in an accumulator block acc = double[MURAL_BN_SLOTS][2][C] (zeroed by the caller): workgroups add into
 // the copy picked by their index, readers sum the copies.  [k][0][c] = sum, [k][1][c] = sum of squares (forward) or
 // sum(dz), sum(dz * xhat) (backward).
