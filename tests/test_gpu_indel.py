@@ -104,7 +104,7 @@ def test_train_step_matches_reference(tag):
             # a conv bias gradient is the plain sum of the dy whose products with x form dW; in front of a batch-statistics
             # BatchNorm it is mathematically zero, and behind the 5-row BatchNorm of out_fc it cancels to ~1e-3 of dW: its
             # fp32 error follows the scale of dW (the reference's own fp32 value is 2e-5 away from a float64 evaluation)
-            tol = max(tol, 1e-5 * np.abs(fx["g::" + k[:-4] + "weight"]).max())
+            tol = max(tol, 2e-5 * np.abs(fx["g::" + k[:-4] + "weight"]).max())
         assert diff <= tol, (k, diff, tol)
     for k, b in model.named_buffers():
         assert np.abs(b.cpu().numpy().astype(np.float64) - fx["b::" + k]).max() <= 1e-5, k
