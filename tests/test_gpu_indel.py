@@ -84,7 +84,7 @@ def _train_step(model, x, y):
 @pytest.mark.parametrize("tag", ["rev", "norev"])
 def test_train_step_matches_reference(tag):
     """One training step (batch-statistics BatchNorm, CE(sum) loss, backward) against the reference's own step (G14):
-    scores 1e-5 of their scale, loss 1e-5 relative, every gradient 1e-4 of (its tensor's max + 1e-2), running statistics 1e-5."""
+    scores 1e-5 of their scale, loss 1e-5 relative, every gradient 2e-4 of (its tensor's max + 1e-2), running statistics 1e-5."""
     fx = U.load(f"indel_train_{tag}.npz")
     model = product_from(fx)
     orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
@@ -99,7 +99,7 @@ def test_train_step_matches_reference(tag):
     for k, got in grads.items():
         want = fx["g::" + k]
         diff = np.abs(got - want).max()
-        tol = 1e-4 * (np.abs(want).max() + 1e-2)
+        tol = 2e-4 * (np.abs(want).max() + 1e-2)          # the bar of the SNV step (test_gpu_train.py)
         if k.endswith(".bias") and k[:-4] + "weight" in grads and want.ndim == 1 and fx["g::" + k[:-4] + "weight"].ndim == 3:
             # a conv bias gradient is the plain sum of the dy whose products with x form dW; in front of a batch-statistics
             # BatchNorm it is mathematically zero, and behind the 5-row BatchNorm of out_fc it cancels to ~1e-3 of dW: its
