@@ -205,7 +205,9 @@ extern "C" void mural_indel_model_destroy(MuralIndelModel* m) {
 
 extern "C" size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n) {
   if (!m || n <= 0) return 256;
-  return (size_t)std::min<int64_t>(n, INDEL_CHUNK) * m->per_pos_floats * 4 + 4096;
+  // two chunks in flight (one per stream, see mural_indel_forward_dense) once there is more than one
+  const size_t lanes = n > INDEL_CHUNK ? 2 : 1;
+  return lanes * (size_t)std::min<int64_t>(n, INDEL_CHUNK) * m->per_pos_floats * 4 + 4096;
 }
 
 static int run_conv(const MuralIndelModel* m, const FoldedConv& f, const float* in, int B, int Lin, float* out, int Lout,
@@ -267,12 +269,26 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     set_error("workspace too small: need %zu bytes, got %zu", mural_indel_workspace_bytes(m, n), workspace_bytes);
     return MURAL_E_WORKSPACE;
   }
-  hipStream_t stream = (hipStream_t)stream_;
+  hipStream_t main_stream = (hipStream_t)stream_;
   const MuralIndelShape& sh = m->shape;
   const int Lx = sh.length, C0 = m->ch[0];
-  for (int64_t c0 = 0; c0 < n; c0 += INDEL_CHUNK) {
+  // Chunks are independent, and the ~45 launches of one chunk include a dozen on the deep levels (rows of 80 / 16 / 8 columns) that
+  // leave most of the chip idle: even chunks run on the caller's stream, odd ones on a side stream with their own half of the
+  // workspace, so the small kernels of one chunk fill the gaps of the other.
+  const int lanes = n > INDEL_CHUNK ? 2 : 1;
+  SideStream* ss = nullptr;
+  if (lanes == 2) {
+    if (int rc = side_stream(&ss)) return rc;
+    if (int rc = ss->fork(main_stream)) return rc;
+  }
+  int rc_all = MURAL_OK;
+  int64_t chunk_no = 0;
+  for (int64_t c0 = 0; c0 < n && rc_all == MURAL_OK; c0 += INDEL_CHUNK, ++chunk_no) {
     const int B = (int)std::min<int64_t>(INDEL_CHUNK, n - c0);
-    float* p = static_cast<float*>(workspace);
+    const int lane = (int)(chunk_no % lanes);
+    hipStream_t stream = lane == 0 ? main_stream : ss->side;
+    float* p = static_cast<float*>(workspace) + (size_t)lane * INDEL_CHUNK * m->per_pos_floats;
+    rc_all = [&]() -> int {
     auto take = [&](size_t per_pos) { float* r = p; p += per_pos * (size_t)B; return r; };
     float* S = take((size_t)4 * Lx);
     float* E[INDEL_LEVELS];
@@ -340,6 +356,10 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
                        tail_done ? mparts : 1, C0,
                        sh.n_class, m->blob + m->fc_w, m->blob + m->fc_b, out + c0 * sh.n_class);
     MURAL_HIP_CHECK(hipGetLastError());
+    return MURAL_OK;
+    }();
   }
-  return MURAL_OK;
+  if (lanes == 2)
+    if (int rc = ss->join(main_stream)) return rc;     // also on an error: the side stream must not stay forked
+  return rc_all;
 }

@@ -230,39 +230,7 @@ const float EPS = 1e-5f;
 
 // The two towers share nothing but the symbols, so the mid tower runs on a side stream next to the large one: its short rows
 // (67 / 23 / 8 columns) leave most of the chip idle, and the fixed cost of its ~60 launches per direction hides behind the large
-// tower's kernels.  Fork: the side stream waits for everything queued on the caller's stream; join: the caller's stream waits for
-// the side stream.  Both are legal inside a stream capture (the side stream joins the capture and leaves it at the join).
-struct SideStream {
-  hipStream_t side = nullptr;
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-  int init() {
-    if (side) return MURAL_OK;
-    MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    MURAL_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
-    MURAL_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
-    return MURAL_OK;
-  }
-  int fork(hipStream_t main) {
-    MURAL_HIP_CHECK(hipEventRecord(fork_ev, main));
-    MURAL_HIP_CHECK(hipStreamWaitEvent(side, fork_ev, 0));
-    return MURAL_OK;
-  }
-  int join(hipStream_t main) {
-    MURAL_HIP_CHECK(hipEventRecord(join_ev, side));
-    MURAL_HIP_CHECK(hipStreamWaitEvent(main, join_ev, 0));
-    return MURAL_OK;
-  }
-};
-
-int side_stream(SideStream** out) {
-  static SideStream per_device[64];
-  int dev = 0;
-  MURAL_HIP_CHECK(hipGetDevice(&dev));
-  MURAL_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
-  if (int rc = per_device[dev].init()) return rc;
-  *out = &per_device[dev];
-  return MURAL_OK;
-}
+// tower's kernels (SideStream, common.h).
 
 struct Ctx {
   const MuralSnvShape* sh;
