@@ -1,6 +1,8 @@
 // Generic fp32 Conv1d building block (direct convolution on the vector ALU) used by the INDEL U-Net and by the
 // per-layer (training-mode) SNV path.  Tensors are [B][C][L] fp32 contiguous, like the reference's NCL layout.
 #pragma once
+#include <vector>
+
 #include "common.h"
 
 namespace mural {
@@ -24,6 +26,10 @@ struct Conv1dArgs {
   const float* res1;     // optional residuals added AFTER the activation, [B][Cout][Lout]
   const float* res2;
   int rt;                // set by launch_conv1d: batch rows packed into one 64-lane tile (short rows), 1 otherwise
+  // phases > 1 (MFMA kernel only): the polyphase form of conv(upsample_phases(x)).  Output column phases * i + p only sees the source
+  // columns i + d for a few offsets d, so the K taps collapse to KJ = K summed taps per phase: wt is [Cin][KJ][Cout * phases] (row
+  // index co * phases + p), K = KJ, pad = -d_min, stride = up = 1, Lout = Lin * phases.  7 taps -> 3 at phases 4 / 5.
+  int phases;
 };
 
 int launch_conv1d(const Conv1dArgs& a, hipStream_t stream);        // routes between the two kernels below
@@ -31,6 +37,8 @@ int launch_conv1d_valu(const Conv1dArgs& a, hipStream_t stream);   // direct for
 // implicit-GEMM version on fp32 MFMA for layers with >= 16 output channels (conv1d_mfma.hip); launch_conv1d routes to it
 bool conv1d_mfma_supported(const Conv1dArgs& a);
 int launch_conv1d_mfma(const Conv1dArgs& a, hipStream_t stream);
+// host: weights [Cin][K][Cout] of conv_K(upsample_up(x)) -> polyphase weights [Cin][KJ][Cout * up] (Conv1dArgs::phases)
+void conv1d_phase_weights(const float* w, int Cin, int K, int Cout, int up, std::vector<float>* out, int* KJ, int* pad_out);
 
 // Fused ConvBlock of the INDEL U-Net (reference MuRaL/model/model_indel.py:6-19, eval mode, BatchNorms folded):
 //   out = x + W1 . SiLU(W5 * x + b5) + b1 [+ res2],  W5: k=5 conv C -> 2C, W1: 1x1 conv 2C -> C.

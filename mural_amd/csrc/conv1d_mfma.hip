@@ -15,6 +15,8 @@
 //   B (4 x 16)  = X[ci0 + (lane >> 4)][column (lane & 15) of the block, tap] LDS tile [row][ci][span], pre-op / upsampling / zero
 //                                                                            padding applied while staging
 //   D (16 x 16) : lane holds rows 4 (lane >> 4) .. + 3 of column (lane & 15)
+#include <vector>
+
 #include "conv1d.h"
 
 namespace mural {
@@ -41,7 +43,14 @@ struct ConvGArgs {
   int span;      // staged input columns per (row, channel)
   int span_p;    // LDS row stride (== 16 mod 32: the four channel rows of a fragment read land on disjoint bank halves)
   FastDiv d_span, d_cin, d_up, d_lout;   // the staging loop's index arithmetic costs more than its loads with hardware division
+  int Mrows;     // GEMM rows: Cout, or Cout * phases in the polyphase form
+  int Lcols;     // GEMM columns per batch row: Lout, or the source length Lin in the polyphase form
+  int ph;        // phases (1: plain)
+  FastDiv d_ph;
+  int mslice;    // 16-row blocks per workgroup
 };
+
+constexpr int CG_MSLICE = 6;    // at most this many 16-row blocks per workgroup; more rows go to further workgroups along grid.z
 
 constexpr int CG_NBW_SEG = 4;   // segment regime: 16-column blocks per wave (tile = 64 x (4 or 2) x ... columns, see seg_cols)
 
@@ -56,7 +65,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kk = lane >> 4;
   const int b0 = g.seg ? blockIdx.y : blockIdx.x * g.TR;
-  const int SEG = seg_cols(a.Cout);
+  const int SEG = seg_cols(g.Mrows);
   const int l0 = g.seg ? blockIdx.x * SEG : 0;
   const int in0 = l0 * a.stride - a.pad;      // virtual (upsampled) input index of the first staged column
   const int Lv = a.Lin * a.up;
@@ -91,11 +100,13 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
     }
   }
   __syncthreads();
-  const int ncols = g.seg ? (a.Lout - l0 < SEG ? a.Lout - l0 : SEG) : g.TR * a.Lout;
+  const int ncols = g.seg ? (g.Lcols - l0 < SEG ? g.Lcols - l0 : SEG) : g.TR * g.Lcols;
   constexpr int K = KT;
   // wave -> (channel-block group wm, column-block group wn)
-  const int mb_total = (a.Cout + 15) >> 4;
-  const int WM = mb_total >= 2 ? 2 : 1, WN = 4 / WM;
+  const int mb_all = (g.Mrows + 15) >> 4;
+  const int m_base = blockIdx.z * g.mslice;                 // this workgroup's slice of the channel blocks
+  const int mb_total = mb_all - m_base < g.mslice ? mb_all - m_base : g.mslice;
+  const int WM = mb_all >= 2 ? 2 : 1, WN = 4 / WM;
   const int wm = wave % WM, wn = wave / WM;
   const int m_first = wm * MW;                              // this wave's channel blocks: m_first .. m_first + MW - 1 (< mb_total)
   const int nbw = g.seg ? NBW : 4 / WN;                     // row regime: 64 columns = 4 blocks over the WN groups
@@ -110,7 +121,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
     int r = 0, l = bval[j] ? col : 0;
     if (!g.seg) {
       r = (int)g.d_lout.div((uint32_t)l);
-      l -= r * a.Lout;
+      l -= r * g.Lcols;
     }
     brow[j] = r;
     bcol[j] = l;
@@ -121,8 +132,8 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
   bool wok[MW];
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
-    const int co = 16 * (m_first + m) + n16;
-    wok[m] = m_first + m < mb_total && co < a.Cout;
+    const int co = 16 * (m_base + m_first + m) + n16;
+    wok[m] = m_first + m < mb_total && co < g.Mrows;
     woff[m] = wok[m] ? co : n16;
   }
   g4 acc[MW][NBW];
@@ -130,12 +141,12 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
   for (int m = 0; m < MW; ++m)
 #pragma unroll
     for (int j = 0; j < NBW; ++j) acc[m][j] = g4{0.f, 0.f, 0.f, 0.f};
-  const float* wbase = wt + (size_t)kk * K * a.Cout;
+  const float* wbase = wt + (size_t)kk * K * g.Mrows;
   float an[K][MW];                                          // next step's weight fragments, in flight during this step's MFMAs
 #pragma unroll
   for (int t = 0; t < K; ++t)
 #pragma unroll
-    for (int m = 0; m < MW; ++m) an[t][m] = wbase[(size_t)t * a.Cout + woff[m]];
+    for (int m = 0; m < MW; ++m) an[t][m] = wbase[(size_t)t * g.Mrows + woff[m]];
   for (int ci0 = 0; ci0 < a.Cin; ci0 += 4) {
     float ac[K][MW];
 #pragma unroll
@@ -143,11 +154,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
 #pragma unroll
       for (int m = 0; m < MW; ++m) ac[t][m] = wok[m] ? an[t][m] : 0.f;
     if (ci0 + 4 < a.Cin) {
-      const float* wnext = wbase + (size_t)(ci0 + 4) * K * a.Cout;
+      const float* wnext = wbase + (size_t)(ci0 + 4) * K * g.Mrows;
 #pragma unroll
       for (int t = 0; t < K; ++t)
 #pragma unroll
-        for (int m = 0; m < MW; ++m) an[t][m] = wnext[(size_t)t * a.Cout + woff[m]];
+        for (int m = 0; m < MW; ++m) an[t][m] = wnext[(size_t)t * g.Mrows + woff[m]];
     }
     const float* trow = tile + (size_t)ci0 * g.span_p;
 #pragma unroll
@@ -161,7 +172,11 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
         for (int j = 0; j < NBW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t][m], bv[j], acc[m][j], 0, 0, 0);
     }
   }
-  // ---- epilogue: bias, activation, residuals; 16 lanes write 16 consecutive columns of one output channel
+  // ---- epilogue: bias, activation, residuals, straight from the accumulators.  Plain: 16 lanes write 16 consecutive columns of
+  //      one output channel.  Polyphase: row co * ph + p of source column i is output column ph * i + p of channel co, so a lane's
+  //      four rows are (mostly) four consecutive output columns.  (Measured: routing the tile through LDS to store whole 16-byte
+  //      runs is no faster -- the kernel is bound by its serial stage / MFMA / store phases at 3 workgroups per CU, not by the
+  //      width of the stores.)
 #pragma unroll
   for (int j = 0; j < NBW; ++j) {
     if (!bval[j] || b0 + brow[j] >= a.B) continue;
@@ -169,9 +184,14 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
     for (int m = 0; m < MW; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int co = 16 * (m_first + m) + 4 * kk + q;
-        if (m_first + m < mb_total && co < a.Cout) {
-          const size_t o = ((size_t)(b0 + brow[j]) * a.Cout + co) * a.Lout + l0 + bcol[j];
+        const int row = 16 * (m_base + m_first + m) + 4 * kk + q;
+        if (m_first + m < mb_total && row < g.Mrows) {
+          int co = row, lo = l0 + bcol[j];
+          if (g.ph > 1) {
+            co = (int)g.d_ph.div((uint32_t)row);
+            lo = lo * g.ph + (row - co * g.ph);
+          }
+          const size_t o = ((size_t)(b0 + brow[j]) * a.Cout + co) * a.Lout + lo;
           float v = cg_act(acc[m][j][q] + (bias ? bias[co] : 0.f), a.act);
           if (a.res1) v += a.res1[o];
           if (a.res2) v += a.res2[o];
@@ -187,6 +207,7 @@ template <int MW, int NBW>
 ConvGFn pick_taps(int K) {
   switch (K) {
     case 1: return conv1d_mfma_kernel<MW, 1, NBW>;
+    case 3: return conv1d_mfma_kernel<MW, 3, NBW>;
     case 5: return conv1d_mfma_kernel<MW, 5, NBW>;
     case 7: return conv1d_mfma_kernel<MW, 7, NBW>;
     default: return nullptr;
@@ -194,8 +215,9 @@ ConvGFn pick_taps(int K) {
 }
 
 template <int NBW>
-ConvGFn pick_mw(int mb_total, int K) {
-  const int mw = mb_total >= 2 ? (mb_total + 1) / 2 : 1;
+ConvGFn pick_mw(int mb_total, int K, int mslice) {
+  const int slice = mb_total < mslice ? mb_total : mslice;
+  const int mw = mb_total >= 2 ? (slice + 1) / 2 : 1;
   switch (mw) {
     case 1: return pick_taps<1, NBW>(K);
     case 2: return pick_taps<2, NBW>(K);
@@ -203,7 +225,12 @@ ConvGFn pick_mw(int mb_total, int K) {
   }
 }
 
-ConvGFn pick(int mb_total, int K, int seg) { return seg ? pick_mw<CG_NBW_SEG>(mb_total, K) : pick_mw<2>(mb_total, K); }
+ConvGFn pick(int mb_total, int K, int seg, int mslice) {
+  return seg ? pick_mw<CG_NBW_SEG>(mb_total, K, mslice) : pick_mw<2>(mb_total, K, mslice);
+}
+
+struct ConvGArgs;
+size_t lds_bytes(const ConvGArgs& g);
 
 int pad_span(int span) {      // smallest stride >= span that is 16 mod 32
   const int rem = span & 31;
@@ -211,16 +238,22 @@ int pad_span(int span) {      // smallest stride >= span that is 16 mod 32
 }
 
 bool plan(const Conv1dArgs& a, ConvGArgs* g) {
-  if (a.Cout < 16 || a.Cout > 96 || a.Cin % 4 != 0 || a.Cin < 4 || (a.K != 1 && a.K != 5 && a.K != 7)) return false;
+  const int ph = a.phases > 1 ? a.phases : 1;
+  if (a.Cin % 4 != 0 || a.Cin < 4 || (a.K != 1 && a.K != 3 && a.K != 5 && a.K != 7)) return false;
+  if (ph > 1 && (a.stride != 1 || a.up != 1 || a.Lout != a.Lin * ph || a.pre_s || a.pre_t || a.pre_relu)) return false;
   g->a = a;
-  if (a.Lout > 64) {          // longer than the 64-column tile of the row regime
+  g->ph = ph;
+  g->Mrows = a.Cout * ph;
+  g->Lcols = ph > 1 ? a.Lin : a.Lout;
+  if (g->Mrows < 16 || (ph == 1 && g->Mrows > 16 * CG_MSLICE)) return false;
+  if (g->Lcols > 64) {          // longer than the 64-column tile of the row regime
     g->seg = 1;
     g->TR = 1;
-    g->span = (seg_cols(a.Cout) - 1) * a.stride + a.K;
+    g->span = (seg_cols(g->Mrows) - 1) * a.stride + a.K;
   } else {
     g->seg = 0;
-    g->span = (a.Lout - 1) * a.stride + a.K;
-    int tr = 64 / a.Lout;
+    g->span = (g->Lcols - 1) * a.stride + a.K;
+    int tr = 64 / g->Lcols;
     if (tr < 1) tr = 1;
     while (tr > 1 && (size_t)tr * a.Cin * pad_span(g->span) * 4 > 64 * 1024) --tr;
     g->TR = tr;
@@ -229,11 +262,35 @@ bool plan(const Conv1dArgs& a, ConvGArgs* g) {
   g->d_span = FastDiv::make((uint32_t)g->span);
   g->d_cin = FastDiv::make((uint32_t)a.Cin);
   g->d_up = FastDiv::make((uint32_t)a.up);
-  g->d_lout = FastDiv::make((uint32_t)a.Lout);
-  return (size_t)g->TR * a.Cin * g->span_p * 4 <= 96 * 1024;
+  g->d_lout = FastDiv::make((uint32_t)g->Lcols);
+  g->d_ph = FastDiv::make((uint32_t)ph);
+  g->mslice = CG_MSLICE;
+  return lds_bytes(*g) <= 96 * 1024;
 }
 
+size_t lds_bytes(const ConvGArgs& g) { return (size_t)g.TR * g.a.Cin * g.span_p * 4; }
+
 }  // namespace
+
+// Host: polyphase weights of conv_K(upsample_up(x)) with zero padding (K - 1) / 2 on the upsampled signal.  Output column up * i + p
+// reads the upsampled columns up * i + p + t - pad, i.e. the source columns i + floor((p + t - pad) / up): taps with the same
+// offset d are summed.  in: [Cin][K][Cout]; out: [Cin][KJ][Cout * up] with row co * up + p; *pad_out = -d_min.
+void conv1d_phase_weights(const float* w, int Cin, int K, int Cout, int up, std::vector<float>* out, int* KJ, int* pad_out) {
+  const int pad = (K - 1) / 2;
+  auto fl = [&](int v) { return v >= 0 ? v / up : -((-v + up - 1) / up); };
+  const int dmin = fl(-pad), dmax = fl(up - 1 + K - 1 - pad);
+  const int kj = dmax - dmin + 1;
+  out->assign((size_t)Cin * kj * Cout * up, 0.f);
+  for (int ci = 0; ci < Cin; ++ci)
+    for (int t = 0; t < K; ++t)
+      for (int p = 0; p < up; ++p) {
+        const int d = fl(p + t - pad) - dmin;
+        for (int co = 0; co < Cout; ++co)
+          (*out)[((size_t)ci * kj + d) * Cout * up + (size_t)co * up + p] += w[((size_t)ci * K + t) * Cout + co];
+      }
+  *KJ = kj;
+  *pad_out = -dmin;
+}
 
 bool conv1d_mfma_supported(const Conv1dArgs& a) {
   ConvGArgs g;
@@ -244,12 +301,15 @@ int launch_conv1d_mfma(const Conv1dArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.Lout == 0) return MURAL_OK;
   ConvGArgs g;
   MURAL_REQUIRE(plan(a, &g), "conv1d (MFMA): unsupported geometry");
-  const size_t lds = (size_t)g.TR * a.Cin * g.span_p * 4;
-  ConvGFn fn = pick((a.Cout + 15) / 16, a.K, g.seg);
+  const size_t lds = lds_bytes(g);
+  const int mb_all = (g.Mrows + 15) / 16;
+  ConvGFn fn = pick(mb_all, a.K, g.seg, g.mslice);
+  MURAL_REQUIRE(fn, "conv1d (MFMA): no kernel for %d taps", a.K);
   if (lds > 64 * 1024)
     MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  const int segc = seg_cols(a.Cout);
-  const dim3 grid = g.seg ? dim3((a.Lout + segc - 1) / segc, a.B) : dim3((a.B + g.TR - 1) / g.TR);
+  const int segc = seg_cols(g.Mrows);
+  const unsigned mz = (unsigned)((mb_all + g.mslice - 1) / g.mslice);
+  const dim3 grid = g.seg ? dim3((g.Lcols + segc - 1) / segc, a.B, mz) : dim3((a.B + g.TR - 1) / g.TR, 1, mz);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, g, a.wt, a.bias);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;

@@ -69,6 +69,8 @@ struct MuralIndelModel {
   int ch[INDEL_LEVELS], len[INDEL_LEVELS];
   FoldedConv sym, up_l[INDEL_LEVELS], up5[INDEL_LEVELS], up1[INDEL_LEVELS];
   FoldedConv dn_l[INDEL_LEVELS - 1], dn5[INDEL_LEVELS - 1], dn1[INDEL_LEVELS - 1], out1, out2;
+  FoldedConv dn_lp[INDEL_LEVELS - 1];     // polyphase form of dn_l (conv of the upsampled tensor), K = 0: not built
+  int dn_lp_pad[INDEL_LEVELS - 1];
   size_t fc_w, fc_b;     // [n_class][C0] with the BN folded, [n_class]
   float* blob;
   size_t blob_floats;
@@ -142,6 +144,18 @@ extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const Mura
          bn_ok(hp->down_b[j].bn1) && hp->down_b[j].conv1_w && bn_ok(hp->down_b[j].bn2);
     if (!ok) break;
     m->dn_l[j] = fold_conv(B, hp->down_l[j].conv.weight, hp->down_l[j].conv.bias, &hp->down_l[j].bn, c, cin, K, eps);
+    {   // Upsample(scale) + Conv1d(k): each output phase only sees 3 (scale 4 / 5) or 5 (scale 2) source columns -- the taps that
+        // share a source column are summed once here (conv1d_phase_weights) and the layer runs as a GEMM with Cout * scale rows
+      const int up = sh.down[INDEL_LEVELS - 1 - j];
+      if (up > 1) {
+        std::vector<float> pw;
+        int kj = 0, padj = 0;
+        conv1d_phase_weights(B.host.data() + m->dn_l[j].w, cin, K, c, up, &pw, &kj, &padj);
+        m->dn_lp[j] = FoldedConv{B.alloc(pw.size()), m->dn_l[j].b, cin, c, kj};
+        std::copy(pw.begin(), pw.end(), B.host.begin() + m->dn_lp[j].w);
+        m->dn_lp_pad[j] = padj;
+      }
+    }
     m->dn5[j] = fold_conv(B, hp->down_b[j].conv5_w, nullptr, &hp->down_b[j].bn1, 2 * c, c, 5, eps);
     m->dn1[j] = fold_conv(B, hp->down_b[j].conv1_w, nullptr, &hp->down_b[j].bn2, c, 2 * c, 1, eps);
   }
@@ -219,6 +233,21 @@ static int run_conv(const MuralIndelModel* m, const FoldedConv& f, const float* 
   a.K = f.K; a.stride = stride; a.pad = (f.K - 1) / 2; a.up = up;
   a.act = act; a.res1 = res1; a.res2 = res2;
   return launch_conv1d(a, stream);
+}
+
+// decoder front: Conv1d(k) of the nearest-neighbour upsampled tensor; polyphase GEMM when built and served by the MFMA kernel
+static int run_upconv(const MuralIndelModel* m, int j, const float* in, int B, int Lin, float* out, int Lout, int up, hipStream_t stream) {
+  const FoldedConv& fp = m->dn_lp[j];
+  if (fp.K > 0 && Lin * up == Lout) {
+    Conv1dArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = in; a.wt = m->blob + fp.w; a.bias = m->blob + fp.b; a.out = out;
+    a.B = B; a.Cin = fp.Cin; a.Lin = Lin; a.Cout = fp.Cout; a.Lout = Lout;
+    a.K = fp.K; a.stride = 1; a.pad = m->dn_lp_pad[j]; a.up = 1; a.phases = up;
+    a.act = ACT_NONE;
+    if (conv1d_mfma_supported(a)) return launch_conv1d_mfma(a, stream);
+  }
+  return run_conv(m, m->dn_l[j], in, B, Lin, out, Lout, 1, up, ACT_NONE, nullptr, nullptr, stream);
 }
 
 // ConvBlock: x + BN(1x1(SiLU(BN(k5(x))))) [+ skip]; fused kernel when instantiated for the channel count
@@ -336,7 +365,7 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
           return rc;
         if (fuse_tail) mparts = convblock_tiles(Li, true);
       } else {
-        if ((rc = run_conv(m, m->dn_l[j], cur, B, Lcur, T1, Li, 1, up, ACT_NONE, nullptr, nullptr, stream))) return rc;
+        if ((rc = run_upconv(m, j, cur, B, Lcur, T1, Li, up, stream))) return rc;
         if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr))) return rc;
         if (fuse_tail) mparts = convblock_tiles(Li, false);
       }

@@ -960,6 +960,24 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
     MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA): unsupported geometry");
     return launch_conv1d_mfma(a, STREAM);
   }
+  if (engine == 3) {     // polyphase form of the upsampled conv: weights expanded on the host once per weight tensor (kept for repeats)
+    MURAL_REQUIRE(up > 1 && stride == 1, "polyphase conv: needs up > 1, stride 1");
+    static const float* last_wt = nullptr;
+    static float* dw = nullptr;
+    static int kj = 0, padj = 0;
+    if (last_wt != wt) {
+      std::vector<float> hw((size_t)Cin * K * Cout), pw;
+      MURAL_HIP_CHECK(hipMemcpy(hw.data(), wt, hw.size() * 4, hipMemcpyDeviceToHost));
+      conv1d_phase_weights(hw.data(), Cin, K, Cout, up, &pw, &kj, &padj);
+      if (dw) (void)hipFree(dw);
+      MURAL_HIP_CHECK(hipMalloc(&dw, pw.size() * 4));
+      MURAL_HIP_CHECK(hipMemcpy(dw, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
+      last_wt = wt;
+    }
+    a.wt = dw; a.K = kj; a.pad = padj; a.up = 1; a.phases = up;
+    MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA, polyphase): unsupported geometry");
+    return launch_conv1d_mfma(a, STREAM);
+  }
   return engine == 0 ? launch_conv1d_valu(a, STREAM) : launch_conv1d(a, STREAM);
 }
 

@@ -21,7 +21,8 @@ cases = [(8, 16, 8000, 7, 4, 1, 0, 0), (16, 24, 2000, 7, 5, 1, 0, 0), (24, 32, 4
          (40, 48, 16, 7, 2, 1, 0, 0), (48, 40, 8, 7, 1, 2, 0, 0), (40, 32, 16, 7, 1, 5, 0, 0), (32, 24, 80, 7, 1, 5, 0, 0),
          (24, 16, 400, 7, 1, 5, 0, 0), (32, 64, 80, 5, 1, 1, 2, 0), (64, 32, 80, 1, 1, 1, 0, 2), (48, 96, 8, 5, 1, 1, 2, 0),
          (96, 48, 8, 1, 1, 1, 0, 2), (40, 80, 16, 5, 1, 1, 2, 0), (80, 40, 16, 1, 1, 1, 0, 1), (16, 32, 2000, 5, 1, 1, 2, 0),
-         (24, 48, 400, 5, 1, 1, 1, 1), (16, 16, 130, 7, 1, 1, 3, 0), (20, 24, 33, 5, 1, 1, 0, 0)]
+         (24, 48, 400, 5, 1, 1, 1, 1), (16, 16, 130, 7, 1, 1, 3, 0), (20, 24, 33, 5, 1, 1, 0, 0), (16, 8, 2000, 7, 1, 4, 0, 1),
+         (12, 20, 7, 5, 1, 3, 2, 0)]
 worst = 0.0
 for Cin, Cout, Lin, K, stride, up, act, nres in cases:
     B = B0 if Lin <= 2000 or not verbose else 512
@@ -43,14 +44,18 @@ for Cin, Cout, Lin, K, stride, up, act, nres in cases:
     rd = [f32(r) for r in res] + [None, None]
     st = _lib.current_stream_ptr(dev)
     line = f"Cin {Cin:3d} Cout {Cout:3d} Lin {Lin:5d} K {K} s {stride} up {up} act {act} res {nres}:"
-    for engine, name in ((0, "valu"), (1, "mfma")):
+    for engine, name in ((0, "valu"), (1, "mfma")) + (((3, "polyphase"),) if up > 1 else ()):
         out = torch.full((B, Cout, Lout), float("nan"), device=dev)
 
         def run():
             _lib.check(lib.mural_debug_conv1d(xd.data_ptr(), wt.data_ptr(), bd.data_ptr(), out.data_ptr(), B, Cin, Lin, Cout, Lout, K, stride,
                                               up, act, None if rd[0] is None else rd[0].data_ptr(),
                                               None if rd[1] is None else rd[1].data_ptr(), engine, st))
-        run()
+        try:
+            run()
+        except (RuntimeError, ValueError):        # geometry outside the engine (fewer than 16 GEMM rows)
+            line += f"  {name} n/a"
+            continue
         err = float((out.double().cpu() - y).abs().max() / (y.abs().max() + 1e-12))
         worst = max(worst, err if err == err else 1.0)
         line += f"  {name} {err:.1e}"
