@@ -12,6 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from mural_amd.data import PackedGenome  # noqa: E402
+from mural_amd.train import clip_grad_norm_  # noqa: E402
 
 
 def main(B=4096, steps=10, warmup=3):
@@ -37,7 +38,7 @@ def main(B=4096, steps=10, warmup=3):
         loss = crit(preds, labels[s * B:(s + 1) * B])
         opt.zero_grad()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), 10)
+        clip_grad_norm_(model, 10)
         opt.step()
         torch.cuda.synchronize()
         times.append(time.perf_counter() - t0)
