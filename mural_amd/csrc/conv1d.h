@@ -60,6 +60,7 @@ struct ConvBlockArgs {
   const float* f_w;
   const float* f_b;
   int Cf, Lf, f_up;
+  const float* f_pw;     // optional (f_up == 4): polyphase front weights [4 phases][Cf][3][C] (taps summed per source column)
   const float* ta_w;
   const float* ta_b;
   const float* tb_w;

@@ -224,7 +224,36 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
       fin[i] = (r >= 0 && r < a.Lf) ? fsrc[(size_t)ci * a.Lf + r] : 0.f;   // zero padding of the upsampled tensor
     }
     __syncthreads();
-    {
+    if (a.f_pw) {
+      // polyphase front (f_up == 4, workgroup origin l0 a multiple of 4): position l only sees the source columns l / 4 + d,
+      // d in {-1, 0, 1}, with the taps that share a column summed on the host per phase l % 4.  Wave w takes the tile entries
+      // j = 4 lane + w -- one phase per wave, so the phase's weights stay wave-uniform (scalar loads) -- and does 3 / 7 of the
+      // multiply-adds of the direct form below.
+      const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: scalar weight loads
+      const int j = 4 * (tid & 63) + wv;
+      const int l = l0 - 2 + j;
+      const int ph = (wv + 2) & 3;                           // l % 4 for every l >= 0 of the tile (l0 % 4 == 0)
+      const int i0 = (l >= 0 ? (l >> 2) : 0) - 1 - r0;       // fin column of source column l / 4 - 1
+      f32x2 t[C / 2];
+#pragma unroll
+      for (int c = 0; c < C / 2; ++c) t[c] = f32x2{f_b[2 * c], f_b[2 * c + 1]};
+      const float* __restrict__ pw = a.f_pw + (size_t)ph * a.Cf * 3 * C;
+#pragma unroll 2
+      for (int ci = 0; ci < a.Cf; ++ci) {
+        const float* frow = fin + ci * span + i0;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const float* __restrict__ wk = pw + (size_t)(ci * 3 + d) * C;    // wave-uniform: scalar loads
+          const float xv = frow[d];
+          const f32x2 x2 = {xv, xv};
+#pragma unroll
+          for (int c = 0; c < C / 2; ++c) t[c] = __builtin_elementwise_fma(x2, f32x2{wk[2 * c], wk[2 * c + 1]}, t[c]);
+        }
+      }
+      const bool in = l >= 0 && l < a.L;
+#pragma unroll
+      for (int c = 0; c < C; ++c) tile[c * TWp + j] = in ? ((c & 1) ? t[c >> 1].y : t[c >> 1].x) : 0.f;
+    } else {
       const int j = tid;
       const int l = l0 - 2 + j;
       f32x2 t[C / 2];
@@ -371,6 +400,7 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   if (a.f_in) {
     MURAL_REQUIRE(a.f_w && a.f_b && a.f_up >= 1 && a.Lf * a.f_up == a.L, "convblock: bad front geometry");
     MURAL_REQUIRE(a.Cf * (262 / a.f_up + 3) <= CB_FRONT_FLOATS, "convblock: front input tile does not fit");
+    MURAL_REQUIRE(!a.f_pw || a.f_up == 4, "convblock: the polyphase front serves an upsampling factor of 4");
   }
   if (a.tail_max) MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
   if (convblock_mfma_supported(a)) return launch_convblock_mfma(a, stream);

@@ -71,6 +71,7 @@ struct MuralIndelModel {
   FoldedConv dn_l[INDEL_LEVELS - 1], dn5[INDEL_LEVELS - 1], dn1[INDEL_LEVELS - 1], out1, out2;
   FoldedConv dn_lp[INDEL_LEVELS - 1];     // polyphase form of dn_l (conv of the upsampled tensor), K = 0: not built
   int dn_lp_pad[INDEL_LEVELS - 1];
+  size_t front_pw;                        // level-0 decoder front in the block kernel's polyphase layout [4][Cf][3][C]; 0: not built
   size_t fc_w, fc_b;     // [n_class][C0] with the BN folded, [n_class]
   float* blob;
   size_t blob_floats;
@@ -154,6 +155,14 @@ extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const Mura
         m->dn_lp[j] = FoldedConv{B.alloc(pw.size()), m->dn_l[j].b, cin, c, kj};
         std::copy(pw.begin(), pw.end(), B.host.begin() + m->dn_lp[j].w);
         m->dn_lp_pad[j] = padj;
+        if (j == INDEL_LEVELS - 2 && up == 4 && kj == 3 && padj == 1) {   // the fused front of the level-0 block kernel
+          m->front_pw = B.alloc((size_t)4 * cin * 3 * c);
+          for (int p = 0; p < 4; ++p)
+            for (int ci = 0; ci < cin; ++ci)
+              for (int d = 0; d < 3; ++d)
+                for (int co = 0; co < c; ++co)
+                  B.host[m->front_pw + (((size_t)p * cin + ci) * 3 + d) * c + co] = pw[((size_t)ci * 3 + d) * c * 4 + (size_t)co * 4 + p];
+        }
       }
     }
     m->dn5[j] = fold_conv(B, hp->down_b[j].conv5_w, nullptr, &hp->down_b[j].bn1, 2 * c, c, 5, eps);
@@ -274,6 +283,7 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
     a.res2 = skip; a.out = out; a.B = B; a.C = f5.Cin; a.L = L;
     if (ff) {
       a.f_in = fin; a.f_w = m->blob + ff->w; a.f_b = m->blob + ff->b; a.Cf = ff->Cin; a.Lf = L / up; a.f_up = up;
+      if (up == 4 && m->front_pw && ff == &m->dn_l[INDEL_LEVELS - 2]) a.f_pw = m->blob + m->front_pw;
     }
     if (tail_max) {   // out_conv (1x1, BN, ReLU, 1x1, Softplus) + max over positions ride on the last decoder block
       a.ta_w = m->blob + m->out1.w; a.ta_b = m->blob + m->out1.b; a.tb_w = m->blob + m->out2.w; a.tb_b = m->blob + m->out2.b;
