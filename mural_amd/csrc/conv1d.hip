@@ -51,15 +51,25 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
     const bool row_ok = b0 + r < a.B;
     const float* src = a.in + ((size_t)(row_ok ? b0 + r : 0) * a.Cin + ci) * a.Lin;
     const float ps = a.pre_s ? a.pre_s[ci] : 1.f, pt = a.pre_t ? a.pre_t[ci] : 0.f;
-    for (int j = lane; j < TW; j += 64) {
-      const int v = in0 + j;
-      float x = 0.f;                           // zero padding (applied after the pre-op, like nn.Conv1d after a BN)
-      if (row_ok && v >= 0 && v < Lv) {
-        x = src[a.up == 1 ? v : v / a.up];
-        if (a.pre_relu) x = fmaxf(x, 0.f);
-        x = fmaf(ps, x, pt);
+    // UN loads of a lane in flight before the first is used: a round that waits for its own load costs a global round trip, and
+    // a strided 256-column tile has 17 rounds per (row, channel)
+    constexpr int UN = 4;
+    for (int j0 = lane; j0 < TW; j0 += 64 * UN) {
+      float xv[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int v = in0 + j0 + 64 * u;
+        const bool ok = row_ok && j0 + 64 * u < TW && v >= 0 && v < Lv;
+        xv[u] = src[ok ? (a.up == 1 ? v : v / a.up) : 0];
+        if (!ok) xv[u] = 0.f;                  // zero padding (applied after the pre-op, like nn.Conv1d after a BN)
+        else {
+          if (a.pre_relu) xv[u] = fmaxf(xv[u], 0.f);
+          xv[u] = fmaf(ps, xv[u], pt);
+        }
       }
-      tile[rc * TWp + j] = x;
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (j0 + 64 * u < TW) tile[rc * TWp + j0 + 64 * u] = xv[u];
     }
   }
   __syncthreads();
