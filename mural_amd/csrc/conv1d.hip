@@ -216,10 +216,26 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
   const int l0 = blockIdx.x * OUTW;
   if (!FRONT) {
     const float* src = a.x + (size_t)b * C * a.L;
-    for (int i = tid; i < C * TW; i += 256) {
-      const int ci = i / TW, j = i - ci * TW;
-      const int l = l0 - 2 + j;
-      tile[ci * TWp + j] = (l >= 0 && l < a.L) ? src[(size_t)ci * a.L + l] : 0.f;
+    constexpr int UN = 4;                        // loads of a thread in flight (a round per load = a global round trip per round)
+    for (int i0 = tid; i0 < C * TW; i0 += 256 * UN) {
+      float v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        const int ci = i / TW, j = i - ci * TW;
+        const int l = l0 - 2 + j;
+        const bool ok = i < C * TW && l >= 0 && l < a.L;
+        v[u] = src[ok ? (size_t)ci * a.L + l : 0];
+        if (!ok) v[u] = 0.f;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < C * TW) {
+          const int ci = i / TW, j = i - ci * TW;
+          tile[ci * TWp + j] = v[u];
+        }
+      }
     }
   } else {
     // the block input of positions l0-2 .. l0+253 needs the (virtual, upsampled) front input at l0-5 .. l0+256
@@ -228,10 +244,21 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
     const int r0 = v0 >= 0 ? v0 / up : -((-v0 + up - 1) / up);   // floor(v0 / up)
     const int span = (l0 + 256) / up - r0 + 1;               // real columns staged per channel
     const float* fsrc = a.f_in + (size_t)b * a.Cf * a.Lf;
-    for (int i = tid; i < a.Cf * span; i += 256) {
-      const int ci = i / span, rr = i - ci * span;
-      const int r = r0 + rr;
-      fin[i] = (r >= 0 && r < a.Lf) ? fsrc[(size_t)ci * a.Lf + r] : 0.f;   // zero padding of the upsampled tensor
+    constexpr int UN = 5;                                    // 16 x 67 (decoder) and 4 x 262 (encoder) floats = 5 per thread
+    for (int i0 = tid; i0 < a.Cf * span; i0 += 256 * UN) {
+      float v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        const int ci = i / span, rr = i - ci * span;
+        const int r = r0 + rr;
+        const bool ok = i < a.Cf * span && r >= 0 && r < a.Lf;
+        v[u] = fsrc[ok ? (size_t)ci * a.Lf + r : 0];
+        if (!ok) v[u] = 0.f;                                 // zero padding of the upsampled tensor
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (i0 + 256 * u < a.Cf * span) fin[i0 + 256 * u] = v[u];
     }
     __syncthreads();
     if (a.f_pw) {

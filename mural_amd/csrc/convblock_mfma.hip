@@ -75,11 +75,26 @@ __global__ __launch_bounds__(256) void convblock_mfma_kernel(const ConvBlockArgs
   const float* src = a.x + (size_t)b * C * a.L;
   if ((a.L & 3) == 0) {                               // rows start 16-byte aligned: float4 pieces of the tile, origin l0 - 4
     constexpr int Q = CM_TW / 4;
-    for (int i = tid; i < C * Q; i += 256) {
-      const int ci = i / Q, q = i - ci * Q;
-      const int l = l0 - 4 + 4 * q;
-      const f32x4 v = (l >= 0 && l < a.L) ? ld4(src + (size_t)ci * a.L + l) : splat(0.f);
-      st4(tile + ci * CM_PITCH + 4 * q, v);
+    constexpr int UN = 4;                              // loads of a thread in flight: a round per load is a global round trip per round
+    for (int i0 = tid; i0 < C * Q; i0 += 256 * UN) {
+      f32x4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        const int ci = i / Q, q = i - ci * Q;
+        const int l = l0 - 4 + 4 * q;
+        const bool ok = i < C * Q && l >= 0 && l < a.L;
+        v[u] = ld4(src + (ok ? (size_t)ci * a.L + l : 0));
+        if (!ok) v[u] = splat(0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < C * Q) {
+          const int ci = i / Q, q = i - ci * Q;
+          st4(tile + ci * CM_PITCH + 4 * q, v[u]);
+        }
+      }
     }
   } else {
     for (int i = tid; i < C * CM_TW; i += 256) {
@@ -123,14 +138,23 @@ __global__ __launch_bounds__(256) void convblock_mfma_kernel(const ConvBlockArgs
   }
   __syncthreads();
   if ((a.L & 3) == 0) {
-    for (int i = tid; i < C * 64; i += 256) {
-      const int c = i >> 6, q = i & 63;
-      const int l = l0 + 4 * q;
-      if (l < a.L) {
-        const size_t o = ((size_t)b * C + c) * a.L + l;
-        f32x4 v = ld4(otile + c * CM_PITCH + 4 * q);
-        if (a.res2) v += ld4(a.res2 + o);
-        st4(a.out + o, v);
+    constexpr int UN = 4;
+    for (int i0 = tid; i0 < C * 64; i0 += 256 * UN) {
+      f32x4 r[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {                   // the skip tensor's pieces first, all in flight
+        const int i = i0 + 256 * u;
+        const int c = i >> 6, q = i & 63;
+        const int l = l0 + 4 * q;
+        const bool ok = a.res2 && i < C * 64 && l < a.L;
+        r[u] = ok ? ld4(a.res2 + ((size_t)b * C + c) * a.L + l) : splat(0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        const int c = i >> 6, q = i & 63;
+        const int l = l0 + 4 * q;
+        if (i < C * 64 && l < a.L) st4(a.out + ((size_t)b * C + c) * a.L + l, ld4(otile + c * CM_PITCH + 4 * q) + r[u]);
       }
     }
   } else {
