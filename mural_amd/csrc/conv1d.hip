@@ -206,7 +206,9 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
   constexpr int C2 = 2 * C, TW = 256 + 4, TWp = TW | 1;
   __shared__ float tile[C * TWp];
   __shared__ float hs[C2 * 256];               // SiLU outputs, [2C][256 lanes]
-  __shared__ float fin[FRONT ? CB_FRONT_FLOATS : 1];
+  static_assert(!FRONT || C2 * 256 >= CB_FRONT_FLOATS, "the front input tile borrows the SiLU buffer");
+  float* fin = hs;                             // front input tile: dead before the first SiLU output is parked (a barrier in between),
+                                               // and 8 KB less LDS is two more workgroups per CU to hide the scalar weight loads
   const int tid = threadIdx.x;
   const int b = blockIdx.y;
   // without a front a workgroup covers 256 positions (tile = positions l0-2 .. l0+257); with one it covers CB_FRONT_OUT =
