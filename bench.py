@@ -256,9 +256,9 @@ def indel_model_and_weights(device):
     return model.to(device), weights
 
 
-def indel_positions_per_s(device, genome, n=100_000, chunk=20_000):
+def indel_positions_per_s(device, genome, n=102_400, chunk=20_480):
     """BASELINE.json configs[3]: UNet_Small, human-insertion geometry (L=8000, 8 classes, use_reverse), 1e5 positions decoded from
-    the packed genome inside the timed region."""
+    the packed genome inside the timed region (calls of 20480 positions = 10 internal chunks of 2048, two in flight)."""
     model, weights = indel_model_and_weights(device)
     model.eval()
     idx = torch.arange(n, device=device, dtype=torch.int64)

@@ -41,11 +41,18 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __r
       if (t < 0 || t % stride != 0) continue;
       const int lo = t / stride;
       if (lo >= Lout) continue;
-      for (int co = 0; co < Cout; ++co) {
-        const float g = dyb[(size_t)co * Lout + lo];
-        const float* w = wl + (co * K + k) * CG;
+      // eight gradient loads in flight before the first is used (the channel counts are multiples of 8): a rolled loop waits a
+      // global round trip per output channel
+      for (int co0 = 0; co0 < Cout; co0 += 8) {
+        float g[8];
 #pragma unroll
-        for (int c = 0; c < CG; ++c) acc[c] = fmaf(g, w[c], acc[c]);
+        for (int q = 0; q < 8; ++q) g[q] = co0 + q < Cout ? dyb[(size_t)(co0 + q) * Lout + lo] : 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const float* w = wl + ((co0 + q < Cout ? co0 + q : 0) * K + k) * CG;
+#pragma unroll
+          for (int c = 0; c < CG; ++c) acc[c] = fmaf(g[q], w[c], acc[c]);
+        }
       }
     }
   }
@@ -95,15 +102,33 @@ __global__ __launch_bounds__(IT_THREADS) void conv_wgrad_kernel(const float* __r
     __syncthreads();
     const float* xb = x + (size_t)b * Cin * Lin;
     const int base = lo0 * stride - pad;
-    for (int i = threadIdx.x; i < Cin * span; i += IT_THREADS) {
-      const int ci = i / span, p = i - ci * span;
-      const int l = base + p;
-      xs[ci * spanp + p] = (l >= 0 && l < Lup) ? xb[(size_t)ci * Lin + l / up] : 0.f;
-    }
-    for (int i = threadIdx.x; i < WG_CO * WG_TL; i += IT_THREADS) {
+    {
+      const int i = threadIdx.x;                     // WG_CO * WG_TL == IT_THREADS: one gradient value per thread, requested first
       const int g = i / WG_TL, t = i - g * WG_TL;
       const int lo = lo0 + t, co = co0 + g;
-      ds[i] = (lo < Lout && co < Cout) ? dy[((size_t)b * Cout + co) * Lout + lo] : 0.f;
+      const float dv = (lo < Lout && co < Cout) ? dy[((size_t)b * Cout + co) * Lout + lo] : 0.f;
+      constexpr int UN = 4;                          // input loads of a thread in flight (a round per load = a global round trip)
+      for (int i0 = threadIdx.x; i0 < Cin * span; i0 += IT_THREADS * UN) {
+        float v[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int ii = i0 + IT_THREADS * u;
+          const int ci = ii / span, p = ii - ci * span;
+          const int l = base + p;
+          const bool ok = ii < Cin * span && l >= 0 && l < Lup;
+          v[u] = xb[ok ? (size_t)ci * Lin + l / up : 0];
+          if (!ok) v[u] = 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int ii = i0 + IT_THREADS * u;
+          if (ii < Cin * span) {
+            const int ci = ii / span, p = ii - ci * span;
+            xs[ci * spanp + p] = v[u];
+          }
+        }
+      }
+      ds[i] = dv;
     }
     __syncthreads();
 #pragma unroll
