@@ -22,6 +22,7 @@ namespace {
 
 constexpr int CL_C = 32;
 constexpr int CL_DEPTH = 4;        // 16-byte global loads a thread keeps in flight while staging / streaming
+constexpr int CL_CUS = 256;        // compute units of an MI355X: the grid is one resident set of workgroups walking the tiles
 
 struct ClTile {                    // tile of R rows on a flattened column axis with zero separators (stage 0 of a TowerGeom)
   TowerGeom g;
@@ -32,9 +33,7 @@ struct ClTile {                    // tile of R rows on a flattened column axis 
 bool cl_tile(int B, int L, ClTile* t) {
   std::memset(t, 0, sizeof(*t));
   const int Sc = L + 1;
-  static const int nbmax = getenv("MURAL_CL_NBMAX") ? atoi(getenv("MURAL_CL_NBMAX")) : 2 * SNV_NB2MAX;
-  int r = (16 * nbmax - 1) / Sc;
-  if (r < 1) r = (16 * 2 * SNV_NB2MAX - 1) / Sc;
+  int r = (16 * 2 * SNV_NB2MAX - 1) / Sc;      // the tallest tile wins (measured: 9 / 12-block tiles are 7 % slower over the step)
   if (r < 1) return false;
   if (r > B) r = B;
   const int balanced = (B + 1023) / 1024;       // large batches of short rows: >= 1024 tiles rather than the tallest tile
@@ -182,38 +181,6 @@ __device__ __forceinline__ void cl_slot_add(f32x4 a1, f32x4 a2, double* slot, fl
   if (tid < 64) atomicAdd(&slot[tid], (double)((red[tid] + red[64 + tid]) + (red[128 + tid] + red[192 + tid])));
 }
 
-// the same staging in two halves, so that the global loads of the NEXT tile are in flight while the current one is in its MFMA
-// phase: cl_fetch issues the (at most CL_PF) 16-byte loads of a thread, cl_put transforms and writes them to the image
-constexpr int CL_PF = (16 * 2 * SNV_NB2MAX * 8 + SNV_THREADS - 1) / SNV_THREADS;
-
-__device__ __forceinline__ void cl_fetch(const float* __restrict__ src, int total, int tid, f32x4 (&v)[CL_PF]) {
-#pragma unroll
-  for (int q = 0; q < CL_PF; ++q) {
-    const int task = tid + q * SNV_THREADS;
-    if (task < total) v[q] = ld4(src + (size_t)task * 4);
-  }
-}
-
-template <bool AFF, bool SUM>
-__device__ __forceinline__ void cl_put(const f32x4 (&v)[CL_PF], int total, const ClTile& t, f32x4 s4, f32x4 t4, f32x4 m4, int relu, float* img,
-                                       int tid, f32x4* colsum) {
-  const int Sc = t.g.Sc[0];
-  const int chunk = tid & 7;
-#pragma unroll
-  for (int q = 0; q < CL_PF; ++q) {
-    const int task = tid + q * SNV_THREADS;
-    if (task >= total) break;
-    const uint32_t col = (uint32_t)task >> 3;
-    const uint32_t r = t.g.dL[0].div(col);
-    const int l = (int)(col - r * (uint32_t)t.L);
-    f32x4 x = v[q];
-    if (SUM) *colsum += x;
-    if (relu) x = max4(x, splat(0.f));
-    if (AFF) x = f32x4{fmaf(s4.x, x.x - m4.x, t4.x), fmaf(s4.y, x.y - m4.y, t4.y), fmaf(s4.z, x.z - m4.z, t4.z), fmaf(s4.w, x.w - m4.w, t4.w)};
-    st4(img + lds_off(2 + (int)r * Sc + l, chunk), x);
-  }
-}
-
 // filter fragments in the order conv_layer / mfma_tap expect: k-step s = 8 tap + 4 half + q <-> input channel 16 half + 4 kk + q,
 // output channel 16 mb + n16; dgrad: the transposed, tap-flipped filter
 __device__ __forceinline__ void cl_frags(const float* __restrict__ W, int dgrad, int mb, int n16, int kk, float (&a)[SNV_KSTEPS]) {
@@ -274,8 +241,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_fwd_kernel(const ClFw
       if (r < (uint32_t)t.R && l < (uint32_t)t.L) plan[i] = (r << 16) | l;
     }
   }
-  if ((blockIdx.x >> ((a.dbg >> 12) & 15)) & 1)
-    for (int i = 0; i < (a.dbg >> 16); ++i) __builtin_amdgcn_s_sleep(127);
   LayerK lk;
   lk.lo = a.post_relu ? 0.f : -INFINITY;
   lk.ku = 0.f;
@@ -375,8 +340,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void conv32cl_bwd_kernel(const ClBw
   f32x4 bsum = splat(0.f), sdz = splat(0.f), sdzx = splat(0.f);
   const int nk = 4 * g.nb[0];
   const int k_lo = wave * nk / 4, k_hi = (wave + 1) * nk / 4;
-  if ((blockIdx.x >> ((a.dbg >> 12) & 15)) & 1)
-    for (int i = 0; i < (a.dbg >> 16); ++i) __builtin_amdgcn_s_sleep(127);
   LayerK lk;
   lk.lo = -INFINITY;
   lk.ku = 0.f;
@@ -638,6 +601,12 @@ __global__ __launch_bounds__(256) void gmax_relu_bwd_cl_kernel(const float* __re
   }
 }
 
+// phase-ablation switches of the timing tools (tools/time_conv32_cl.py), read once
+int debug_phases() {
+  static const int v = getenv("MURAL_DEBUG_CL") ? atoi(getenv("MURAL_DEBUG_CL")) : 0;
+  return v;
+}
+
 int cl_grid(int64_t total, int cap = 8192) {
   const int64_t g = (total + 255) / 256;
   return (int)(g < 1 ? 1 : (g > cap ? cap : g));
@@ -662,15 +631,14 @@ int cl_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* 
   a.x = x; a.y = y; a.W = W; a.bias = bias; a.res1 = res1; a.res2 = res2; a.pre_relu = pre_relu; a.post_relu = post_relu;
   a.stat_out = acc_out; a.stat_relu = out_relu;
   a.fin = ClFin{acc, (double)B * L, gamma, beta, eps, momentum, running_mean, running_var, state};
-  if (const char* e = getenv("MURAL_DEBUG_CL")) a.dbg = atoi(e);
+  a.dbg = debug_phases();
   const size_t lds = (size_t)(2 * a.t.nbuf + 3 * CL_C) * 4;
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32cl_fwd_kernel)) return rc;
   const int64_t ntiles = (B + a.t.R - 1) / a.t.R;
   int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
   per_cu = per_cu > 4 ? 4 : (per_cu < 2 ? 2 : per_cu);
-  static const int cus = getenv("MURAL_CL_CUS") ? atoi(getenv("MURAL_CL_CUS")) : 256;
-  const int64_t cap = (int64_t)cus * per_cu;
+  const int64_t cap = (int64_t)CL_CUS * per_cu;
   hipLaunchKernelGGL(conv32cl_fwd_kernel, dim3((unsigned)(ntiles < cap ? ntiles : cap)), dim3(SNV_THREADS), lds, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
@@ -684,15 +652,14 @@ int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, in
   std::memset(&a, 0, sizeof(a));
   MURAL_REQUIRE(cl_tile((int)B, L, &a.t), "conv32_bwd (channel-last): L = %d does not fit the LDS tile", L);
   a.dy = dy; a.x = x; a.W = W; a.state = state; a.pre_relu = pre_relu; a.part = part; a.dz = dz; a.stat_out = stat_out;
-  if (const char* e = getenv("MURAL_DEBUG_CL")) a.dbg = atoi(e);
+  a.dbg = debug_phases();
   const int64_t ntiles = (B + a.t.R - 1) / a.t.R;
   size_t lds = (size_t)2 * a.t.nbuf * 4;
   const size_t lds_red = (size_t)4 * (CL_C * CL_C * 3 + CL_C) * 4;
   lds = lds > lds_red ? lds : lds_red;
   int per_cu = (int)((size_t)160 * 1024 / (lds + 512));
   per_cu = per_cu > 4 ? 4 : (per_cu < 2 ? 2 : per_cu);
-  static const int cus = getenv("MURAL_CL_CUS") ? atoi(getenv("MURAL_CL_CUS")) : 256;
-  const int64_t cap = (int64_t)cus * per_cu;
+  const int64_t cap = (int64_t)CL_CUS * per_cu;
   const int grid = (int)(ntiles < cap ? ntiles : cap);
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32cl_bwd_kernel)) return rc;
