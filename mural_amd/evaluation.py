@@ -274,45 +274,86 @@ def fit_full_dirichlet(prob, label, reg_lambda=0.0, reg_mu=None, maxiter=1024, f
                                  ftol, gtol)
 
 
+# name -> (method, ref_row, reg_lambda, reg_mu, reg_norm): the calibrators `calibrate_prob` can be asked for (evaluation.py:303-316).
+# They are ONE multinomial regression on [log p; 1] (multinomial.py) under different linear parametrisations of its (k, k + 1) weight
+# matrix: 'Full' (every entry), 'Diag' (vector scaling: a diagonal and the intercepts), 'FixDiag' (temperature scaling: one scalar
+# on the diagonal), with or without subtracting the last raw row, with L2 / ODIR regularisation of the effective weights.
+CALIBRATORS = {
+    "FullDiri": ("Full", True, 0.0, None, False),
+    "FullDiriODIR": ("Full", True, 1e-2, 1e-2, False),
+    "FullDiri1": ("Full", True, 0.0, None, True),
+    "FullDiri2": ("Full", False, 0.0, None, False),
+    "VectS": ("Diag", True, 0.0, None, False),
+    "TempS": ("FixDiag", True, 0.0, None, False),
+}
+
+
+def _param_map(k, method, ref_row):
+    """(identity start, M) with effective weights.ravel() = M @ params (multinomial.py:186-232: raw matrix of the method, minus its
+    last row under ref_row)."""
+    m = k + 1
+    km = k * m
+    if method == "Full":
+        w0 = np.hstack([np.eye(k), np.zeros((k, 1))]).ravel()
+        P = np.eye(km)
+    elif method == "Diag":
+        w0 = np.hstack([np.ones(k), np.zeros(k)])
+        P = np.zeros((km, 2 * k))
+        for j in range(k):
+            P[j * m + j, j] = 1.0              # diagonal entry j
+            P[j * m + k, k + j] = 1.0          # intercept j
+    elif method == "FixDiag":
+        w0 = np.ones(1)
+        P = np.hstack([np.eye(k), np.zeros((k, 1))]).reshape(km, 1)
+    else:
+        raise ValueError(f"unknown calibration method {method}")
+    if ref_row:                                # W = raw - raw[-1]   (multinomial.py:207-211)
+        P = (np.eye(km) - np.kron(np.outer(np.ones(k), np.eye(k)[k - 1]), np.eye(m))) @ P
+    return w0, P
+
+
 def newton_full_dirichlet(row_terms, k, reg_lambda=0.0, reg_mu=None, maxiter=1024, ftol=1e-12, gtol=1e-8):
-    """Host side of the fit: ``row_terms(W (k, k+1), need_hessian) -> (mean loss, gradient (km,), Hessian (km, km))`` with
-    respect to the effective weights supplies the data terms (the device kernel in ``fit_full_dirichlet``)."""
+    """``newton_calibrator`` for the reference's default 'FullDiri' parametrisation."""
+    return newton_calibrator(row_terms, k, "Full", True, reg_lambda, reg_mu, maxiter, ftol, gtol)
+
+
+def newton_calibrator(row_terms, k, method="Full", ref_row=True, reg_lambda=0.0, reg_mu=None, maxiter=1024, ftol=1e-12, gtol=1e-8):
+    """Host side of the fit (multinomial.py:246-327): ``row_terms(W (k, k+1), need_hessian) -> (mean loss, gradient (km,), Hessian
+    (km, km))`` with respect to the EFFECTIVE weights supplies the data terms (the device kernel in ``fit_calibrator``); the
+    method's parametrisation, the reference row and the regulariser are linear / quadratic in them and applied here."""
     import scipy.linalg
     m = k + 1
     km = k * m
-    # raw (k, m) -> effective weights: W = raw - raw[-1]   (multinomial.py:207-211), as a (km, km) matrix T
-    T = np.eye(km) - np.kron(np.outer(np.ones(k), np.eye(k)[k - 1]), np.eye(m))
+    w0, M = _param_map(k, method, ref_row)
     offdiag = np.hstack([1.0 - np.eye(k), np.zeros((k, 1))]).ravel()
     icept = np.hstack([np.zeros((k, k)), np.ones((k, 1))]).ravel()
+    scale = np.full(km, reg_lambda) if reg_mu is None else reg_lambda * offdiag + reg_mu * icept     # multinomial.py:159-168
 
     def terms(params, need_hessian):
-        w = (T @ params).reshape(k, m)
+        w = (M @ params).reshape(k, m)
         loss, g, h = row_terms(w, need_hessian)
         wv = w.ravel()
-        if reg_mu is None:
-            loss += reg_lambda * np.sum(wv ** 2)
-            g = g + 2.0 * reg_lambda * wv
-            h = h + 2.0 * reg_lambda * np.eye(km)
-        else:
-            scale = reg_lambda * offdiag + reg_mu * icept
-            loss += np.sum(scale * wv ** 2)
-            g = g + 2.0 * scale * wv
-            h = h + 2.0 * np.diag(scale)
-        return float(loss), T.T @ g, T.T @ h @ T
+        loss += np.sum(scale * wv ** 2)
+        g = g + 2.0 * scale * wv
+        h = h + 2.0 * np.diag(scale)
+        return float(loss), M.T @ g, M.T @ h @ M
 
     steps = np.hstack((np.linspace(1, 0.1, 10), np.logspace(-2, -32, 31)))
-    weights = np.hstack([np.eye(k), np.zeros((k, 1))]).ravel()
+    weights = w0.copy()
     L_list = [terms(weights, False)[0]]
     for i in range(maxiter):
         _, gradient, hessian = terms(weights, True)
         if np.abs(gradient).sum() < gtol:
             break
-        try:
-            updates = scipy.linalg.pinv(hessian) @ gradient
-        except (np.linalg.LinAlgError, ValueError):
-            updates = gradient
+        if method == "FixDiag":
+            updates = gradient / hessian.ravel()              # multinomial.py:272-273
+        else:
+            try:
+                updates = scipy.linalg.pinv(hessian) @ gradient
+            except (np.linalg.LinAlgError, ValueError):
+                updates = gradient
         for step_size in steps:
-            tmp_w = weights - updates * step_size
+            tmp_w = weights - (updates * step_size).ravel()
             L = terms(tmp_w, False)[0]
             if (L - L_list[-1]) < 0:
                 break
@@ -328,7 +369,31 @@ def newton_full_dirichlet(row_terms, k, reg_lambda=0.0, reg_mu=None, maxiter=102
             break
         weights = tmp_w.copy()
     final = terms(weights, False)[0]
-    return (T @ weights).reshape(k, m), final
+    return (M @ weights).reshape(k, m), final
+
+
+def fit_calibrator(prob, label, name="FullDiri", maxiter=1024, ftol=1e-12, gtol=1e-8):
+    """Fit the calibrator ``calibrate_prob(..., calibr_name=name)`` builds (evaluation.py:303-316: 'FullDiri', 'FullDiriODIR',
+    'FullDiri1', 'FullDiri2', 'VectS', 'TempS') and return (weights (k, k + 1) float64, final objective).  Every one of them is
+    applied the same way afterwards: ``calibration.dirichlet_calibrate`` / ``mural_calibrate_rows`` with these weights."""
+    if name not in CALIBRATORS:
+        raise ValueError(f"unknown calibrator {name!r} (one of {sorted(CALIBRATORS)})")
+    method, ref_row, reg_lambda, reg_mu, reg_norm = CALIBRATORS[name]
+    prob = _prob(prob)
+    n, k = prob.shape
+    if k < 2 or k > _FIT_MAX_CLASSES:
+        raise ValueError(f"fit_calibrator supports 2..{_FIT_MAX_CLASSES} classes, got {k}")
+    lab = _label(label, n)
+    seen = torch.unique(lab).cpu().numpy()
+    if seen.shape[0] != k or seen.min() != 0 or seen.max() != k - 1:
+        raise ValueError("every class 0..n_class-1 must occur in the labels (the reference sizes the map by unique(y))")
+    if reg_norm:                                              # multinomial.py:81-86
+        if reg_mu is None:
+            reg_lambda = reg_lambda / (k * (k + 1))
+        else:
+            reg_lambda, reg_mu = reg_lambda / (k * (k - 1)), reg_mu / k
+    return newton_calibrator(lambda w, need_hessian: _fit_terms(prob, lab, w, need_hessian), k, method, ref_row, reg_lambda, reg_mu,
+                             maxiter, ftol, gtol)
 
 
 # ------------------------------------------------------------------------------------------------------------------
@@ -378,18 +443,19 @@ class Evaluator:
         return corr_list, score, n_regions
 
 
-def calibrate_prob(y_prob, y, printer=print):
-    """``calibrate_prob(..., calibr_name='FullDiri')`` (evaluation.py:297-365): fit the full-Dirichlet map on the validation
-    probabilities, report NLL / ECE / CwECE / Brier before and after.  Returns (weights, nll after calibration, prob_cal
-    (n, n_class) float64 on the device)."""
+def calibrate_prob(y_prob, y, printer=print, calibr_name="FullDiri"):
+    """``calibrate_prob(y_prob, y, device, calibr_name)`` (evaluation.py:297-365): fit the named calibrator on the validation
+    probabilities (the training loop asks for 'FullDiri'; 'FullDiriODIR', 'FullDiri1', 'FullDiri2', 'VectS', 'TempS' are the other
+    choices), report NLL / ECE / CwECE / Brier before and after.  Returns (weights, nll after calibration, prob_cal (n, n_class)
+    float64 on the device)."""
     y_prob = _prob(y_prob)
-    weights, _ = fit_full_dirichlet(y_prob, y)
+    weights, _ = fit_calibrator(y_prob, y, calibr_name)
     w = torch.from_numpy(weights).to(y_prob.device)
     tiny = torch.finfo(y_prob.dtype).tiny
     logp = torch.log(y_prob.clamp(tiny, 1 - tiny)).to(torch.float64)
     prob_cal = torch.softmax(logp @ w[:, :-1].T + w[:, -1], dim=1)
     before, after = calibration_metrics(y_prob, y), calibration_metrics(prob_cal, y)
     for tag, mtr in (("Before", before), ("After", after)):
-        printer("%s FullDiri scaling - NLL: %.8f, ECE: %.8f, CwECE: %.8f, Brier: %.8f" % (tag, mtr["nll"], mtr["ece"], mtr["c_ece"],
-                                                                                        mtr["brier"]))
+        printer("%s %s scaling - NLL: %.8f, ECE: %.8f, CwECE: %.8f, Brier: %.8f" % (tag, calibr_name, mtr["nll"], mtr["ece"], mtr["c_ece"],
+                                                                                   mtr["brier"]))
     return weights, after["nll"], prob_cal

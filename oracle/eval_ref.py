@@ -187,3 +187,110 @@ def fit_full_dirichlet(prob, label, maxiter=1024, ftol=1e-12, gtol=1e-8):
             break
         weights = tmp_w.copy()
     return effective_weights(weights, k), raw_terms(weights, False)[0]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the other calibrators of calibrate_prob (evaluation.py:297-320): one multinomial regression (multinomial.py) under
+# different linear parametrisations of the (k, k + 1) weight matrix, regularisers and with / without the reference row
+# ------------------------------------------------------------------------------------------------------------------
+CALIBRATORS = {
+    # name: (method, ref_row, reg_lambda, reg_mu, reg_norm)
+    "FullDiri": ("Full", True, 0.0, None, False),
+    "FullDiriODIR": ("Full", True, 1e-2, 1e-2, False),      # evaluation.py:309-311
+    "FullDiri1": ("Full", True, 0.0, None, True),           # reg_norm on reg_lambda = 0: the plain fit again
+    "FullDiri2": ("Full", False, 0.0, None, False),
+    "VectS": ("Diag", True, 0.0, None, False),              # vectorscaling.py:56-60 with logit_constant = 0: X = log p
+    "TempS": ("FixDiag", True, 0.0, None, False),           # tempscaling.py:57-61
+}
+
+
+def raw_weights(params, k, method):
+    """multinomial.py:186-205: the method's parameters as a raw (k, k + 1) matrix."""
+    params = np.asarray(params, np.float64)
+    if method == "Full":
+        return params.reshape(k, k + 1)
+    if method == "Diag":
+        return np.hstack([np.diag(params[:k]), params[k:].reshape(-1, 1)])
+    if method == "FixDiag":
+        return np.hstack([np.eye(k) * params[0], np.zeros((k, 1))])
+    raise ValueError(method)
+
+
+def method_weights(params, k, method, ref_row):
+    raw = raw_weights(params, k, method)
+    return raw - raw[-1:, :] if ref_row else raw           # multinomial.py:207-211
+
+
+def identity_params(k, method):
+    """multinomial.py:216-232."""
+    if method == "Full":
+        return np.hstack([np.eye(k), np.zeros((k, 1))]).ravel()
+    if method == "Diag":
+        return np.hstack([np.ones(k), np.zeros(k)])
+    return np.ones(1)
+
+
+def reg_terms(w, k, reg_lambda, reg_mu):
+    """multinomial.py:159-168 on the effective weights: value, gradient, (diagonal of the) Hessian."""
+    wv = w.ravel()
+    if reg_mu is None:
+        scale = np.full(k * (k + 1), reg_lambda)
+    else:
+        scale = reg_lambda * np.hstack([1.0 - np.eye(k), np.zeros((k, 1))]).ravel() + reg_mu * np.hstack([np.zeros((k, k)), np.ones((k, 1))]).ravel()
+    return float(np.sum(scale * wv ** 2)), 2.0 * scale * wv, 2.0 * scale
+
+
+def fit_calibrator(prob, label, name, maxiter=1024, ftol=1e-12, gtol=1e-8):
+    """calibrate_prob(..., calibr_name=name).fit: multinomial.py:69-130 + :246-327.  Returns (effective weights (k, k + 1), final
+    objective)."""
+    import scipy.linalg
+    method, ref_row, reg_lambda, reg_mu, reg_norm = CALIBRATORS[name]
+    X_ = fit_features(prob)
+    label = np.asarray(label).astype(np.int64)
+    k = prob.shape[1]
+    km = k * (k + 1)
+    if reg_norm:                                           # multinomial.py:81-86
+        if reg_mu is None:
+            reg_lambda = reg_lambda / (k * (k + 1))
+        else:
+            reg_lambda, reg_mu = reg_lambda / (k * (k - 1)), reg_mu / k
+    w0 = identity_params(k, method)
+    # the parametrisation is linear: column i of M is the effective weight matrix of the i-th unit parameter vector
+    M = np.stack([method_weights(e, k, method, ref_row).ravel() for e in np.eye(w0.shape[0])], axis=1)
+
+    def terms(params, need_hessian):
+        w = (M @ params).reshape(k, k + 1)
+        loss, g, h = fit_row_terms(X_, label, w, need_hessian)
+        r, rg, rh = reg_terms(w, k, reg_lambda, reg_mu)
+        g = g + rg
+        if need_hessian:
+            h = h + np.diag(rh)
+        return loss + r, M.T @ g, (M.T @ h @ M if need_hessian else np.zeros((w0.shape[0],) * 2))
+
+    weights = w0.copy()
+    L_list = [terms(weights, False)[0]]
+    for i in range(maxiter):
+        _, gradient, hessian = terms(weights, True)
+        if np.abs(gradient).sum() < gtol:
+            break
+        if method == "FixDiag":
+            updates = gradient / hessian.ravel()           # multinomial.py:272-273
+        else:
+            updates = scipy.linalg.pinv(hessian) @ gradient
+        for step_size in np.hstack((np.linspace(1, 0.1, 10), np.logspace(-2, -32, 31))):
+            tmp_w = weights - (updates * step_size).ravel()
+            L = terms(tmp_w, False)[0]
+            if (L - L_list[-1]) < 0:
+                break
+        L_list.append(float(L))
+        if np.isnan(L):
+            break
+        if i >= 5:
+            if (float(np.min(np.diff(L_list[-5:]))) > -ftol) & (float(np.sum(np.diff(L_list[-5:])) > 0) == 0):
+                weights = tmp_w.copy()
+                break
+        if (L_list[-1] - L_list[-2]) > 0:
+            break
+        weights = tmp_w.copy()
+    assert km == M.shape[0]
+    return (M @ weights).reshape(k, k + 1), terms(weights, False)[0]

@@ -728,6 +728,42 @@ def g13_analytics(ref):
             full = np.asarray(mn._get_weights(wts, n_class, True, "Full"))
             out[f"{tag}_fit_w"] = full
             out[f"{tag}_fit_loss"] = np.array(float(mn._objective(wts, *args)))
+            # the other calibrators of calibrate_prob (evaluation.py:303-316): the same reference driver and objective under the
+            # method's parametrisation; derivatives through the reference's own (linear) _get_weights, finite-difference checked
+            for name, (method, ref_row, lam, mu, reg_norm) in eval_ref.CALIBRATORS.items():
+                k = n_class
+                if reg_norm:
+                    lam, mu = (lam / (k * (k + 1)), mu) if mu is None else (lam / (k * (k - 1)), mu / k)
+                w0m = np.asarray(mn._get_identity_weights(k, ref_row, method), dtype=np.float64)
+                M = np.stack([np.asarray(mn._get_weights(e, k, ref_row, method)).ravel() for e in np.eye(w0m.shape[0])], axis=1)
+                margs = (X_, None, target, k, method, lam, mu, ref_row, "identity", None)
+
+                def method_derivs(params, X, _xxt, tgt, kk, *rest, M=M, lam=lam, mu=mu):
+                    w = (M @ np.asarray(params)).reshape(kk, kk + 1)
+                    _, g, h = eval_ref.fit_row_terms(np.asarray(X), np.argmax(np.asarray(tgt), axis=1), w, True)
+                    _, rg, rh = eval_ref.reg_terms(w, kk, lam, mu)
+                    return M.T @ (g + rg), M.T @ (h + np.diag(rh)) @ M
+
+                jax.grad = lambda f, argnums=0, d=method_derivs: (lambda *a: d(*a)[0])
+                jax.hessian = lambda f, argnums=0, d=method_derivs: (lambda *a: d(*a)[1])
+                mn._gradient = jax.grad(mn._objective)
+                mn._hessian = jax.hessian(mn._objective)
+                wp = w0m + 0.1 * rng.standard_normal(w0m.shape)
+                g, h = method_derivs(wp, *margs)
+                for idx in range(wp.shape[0]):
+                    e = np.zeros_like(wp)
+                    e[idx] = 1e-6
+                    fd = (float(mn._objective(wp + e, *margs)) - float(mn._objective(wp - e, *margs))) / 2e-6
+                    assert abs(fd - g[idx]) < 1e-6, (name, idx, fd, g[idx])
+                    fdh = (method_derivs(wp + e, *margs)[0] - method_derivs(wp - e, *margs)[0]) / 2e-6
+                    assert np.abs(fdh - h[idx]).max() < 1e-5, name
+                wm = mn._newton_update(w0m, X_, None, target, k, method, reg_lambda=lam, reg_mu=mu, ref_row=ref_row,
+                                       initializer="identity", reg_format=None)
+                out[f"{tag}_fit_{name}_w"] = np.asarray(mn._get_weights(np.asarray(wm), k, ref_row, method))
+                out[f"{tag}_fit_{name}_loss"] = np.array(float(mn._objective(np.asarray(wm), *margs)))
+                print(f"  G13 {tag} {name}: objective {float(out[f'{tag}_fit_{name}_loss']):.8f}")
+            mn._gradient = lambda *a: raw_derivs(*a)[0]
+            mn._hessian = lambda *a: raw_derivs(*a)[1]
     finally:
         sys.path.pop(0)
         for k in [k for k in sys.modules if k == "jax" or k.startswith("jax.") or k.startswith("dirichletcal") or k == "autograd"

@@ -71,6 +71,30 @@ def test_oracle_and_host_fit(tag, model_type, nc, kmers):
     assert np.all(w2[-1] == 0)
 
 
+@pytest.mark.parametrize("name", sorted(eval_ref.CALIBRATORS))
+@pytest.mark.parametrize("tag,model_type,nc,kmers", CASES)
+def test_oracle_and_host_fit_of_every_calibrator(tag, model_type, nc, kmers, name):
+    """The calibrators calibrate_prob can be asked for (evaluation.py:303-316: FullDiri, FullDiriODIR, FullDiri1, FullDiri2, VectS,
+    TempS) against the reference's own Newton driver and objective run under each parametrisation (G13; derivatives through the
+    reference's linear _get_weights, finite-difference checked in oracle/make_golden.py)."""
+    fx, codes, label, prob, chrom, start = _fx(tag)
+    want_w, want_loss = fx[f"{tag}_fit_{name}_w"], float(fx[f"{tag}_fit_{name}_loss"])
+    w, loss = eval_ref.fit_calibrator(prob, label, name)
+    assert np.abs(w - want_w).max() < 1e-8 and abs(loss - want_loss) < 1e-12
+    assert E.CALIBRATORS[name] == eval_ref.CALIBRATORS[name]
+    method, ref_row, lam, mu, reg_norm = E.CALIBRATORS[name]
+    if reg_norm:
+        lam, mu = (lam / (nc * (nc + 1)), mu) if mu is None else (lam / (nc * (nc - 1)), mu / nc)
+    X_ = eval_ref.fit_features(prob)
+    w2, loss2 = E.newton_calibrator(lambda wt, need: eval_ref.fit_row_terms(X_, label, wt, need), nc, method, ref_row, lam, mu)
+    assert np.abs(w2 - want_w).max() < 1e-8 and abs(loss2 - want_loss) < 1e-12
+    if name == "TempS":                        # one temperature: a scaled identity minus its last row, no intercepts
+        t = w2[0, 0]
+        assert np.allclose(w2[:-1, :-1], t * (np.eye(nc)[:-1] - np.eye(nc)[-1]), atol=1e-12) and np.all(w2[:, -1] == 0)
+    if name == "FullDiri2":
+        assert np.any(w2[-1] != 0)             # no reference row: the last row is fitted too
+
+
 def test_product_refuses_cpu_tensors():
     with pytest.raises(RuntimeError, match="HIP device"):
         E.freq_kmer_comp_multi(torch.zeros((4, 11), dtype=torch.int64), torch.zeros(4), torch.full((4, 4), 0.25), 3, 4)
@@ -160,6 +184,17 @@ def test_gpu_fit(tag, model_type, nc, kmers):
     assert np.abs(dirichlet_calibrate(prob, wts) - dirichlet_calibrate(prob, want)).max() < 1e-6
     weights, nll, prob_cal = E.calibrate_prob(d_prob, d_label, printer=lambda *a: None)
     assert abs(nll - final) < 1e-6 and prob_cal.shape == d_prob.shape
+    # the other calibrators through the same device kernel: the calibrated probabilities are what must agree
+    for name in ("FullDiriODIR", "FullDiri2", "VectS", "TempS"):
+        wn, fn = E.fit_calibrator(d_prob, d_label, name)
+        want_n = fx[f"{tag}_fit_{name}_w"]
+        assert abs(fn - float(fx[f"{tag}_fit_{name}_loss"])) < 1e-8, name
+        assert np.abs(dirichlet_calibrate(prob, wn) - dirichlet_calibrate(prob, want_n)).max() < 1e-6, name
+    lines = []
+    E.calibrate_prob(d_prob, d_label, printer=lambda *a: lines.append(a[0]), calibr_name="VectS")
+    assert lines[0].startswith("Before VectS scaling") and lines[1].startswith("After VectS scaling")
+    with pytest.raises(ValueError, match="unknown calibrator"):
+        E.fit_calibrator(d_prob, d_label, "Platt")
 
 
 @pytest.mark.gpu
