@@ -18,7 +18,7 @@ torch.manual_seed(0)
 model = model_choice(0, cfg, dict(n_class=8), "indel")
 model.apply(weights_init)
 model = model.cuda().train()
-opt = torch.optim.Adam(model.parameters(), lr=1e-3)
+opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
 crit = torch.nn.CrossEntropyLoss(reduction="sum")
 codes = torch.randint(0, 4, (B, 8000), device="cuda")
 x = torch.nn.functional.one_hot(codes, 4).permute(0, 2, 1).float().contiguous()
