@@ -21,7 +21,7 @@ _scratch = {}
 def _bwd_scratch(device, n):
     t = _scratch.get(device)
     if t is None or t.numel() < n:
-        t = _scratch[device] = torch.empty(n, device=device)
+        t = _scratch[device] = torch.empty(n, dtype=torch.float32, device=device)
     return t
 
 
@@ -36,8 +36,8 @@ class Conv(torch.autograd.Function):
         Lout = int(_lib.lib().mural_op_convg_out_length(Lin, K, stride, pad, up))
         if Lout < 1:
             raise ValueError(f"Conv1d: kernel {K} / padding {pad} do not fit an input of length {Lin * up}")
-        y = torch.empty((B, Cout, Lout), device=x.device)
-        wt = torch.empty(weight.numel(), device=x.device)
+        y = torch.empty((B, Cout, Lout), dtype=torch.float32, device=x.device)
+        wt = torch.empty(weight.numel(), dtype=torch.float32, device=x.device)
         T._call("mural_op_convg_fwd", x, T._f32(weight), None if bias is None else T._f32(bias), wt, y, B, Cin, Lin, Cout, K, stride,
                 pad, up, T._stream(x))
         ctx.save_for_backward(x, weight)
@@ -54,7 +54,7 @@ class Conv(torch.autograd.Function):
         dev = x.device
         dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         dW = torch.empty_like(weight)
-        db = torch.empty(Cout, device=dev) if has_bias else None
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_bias else None
         part = _bwd_scratch(dev, int(_lib.lib().mural_op_convg_bwd_scratch(Cin, Cout, K)))
         T._call("mural_op_convg_bwd", dy, x, T._f32(weight), B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part.numel(),
                 T._stream(x))
@@ -82,8 +82,8 @@ class BatchNorm(torch.autograd.Function):
         B, Cn, L = x.shape
         acc = T._bn_acc(Cn, x.device)
         dx = torch.empty_like(x)
-        dgamma = torch.empty(Cn, device=x.device)
-        dbeta = torch.empty(Cn, device=x.device)
+        dgamma = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(Cn, dtype=torch.float32, device=x.device)
         T._call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, L, int(ctx.pre_relu), mean, invstd, T._f32(gamma), acc, 0, None,
                 None, dx, dgamma, dbeta, T._stream(x))
         return dx, dgamma, dbeta, None, None

@@ -105,7 +105,7 @@ class _BnState:
         if acc is None:
             acc = _bn_acc(Cn, dev)
             _call("mural_op_bn_stats", x, B, Cn, L, int(relu), acc, st)
-        self.scale, self.shift, self.mean, self.invstd = torch.empty((4, Cn), device=dev).unbind(0)
+        self.scale, self.shift, self.mean, self.invstd = torch.empty((4, Cn), dtype=torch.float32, device=dev).unbind(0)
         _call("mural_op_bn_finalize", acc, float(B * L), Cn, _f32(bn.weight), _f32(bn.bias), EPS, MOMENTUM,
               bn.running_mean, bn.running_var, self.scale, self.shift, self.mean, self.invstd, st)
         _bn_tick(bn)
@@ -118,7 +118,7 @@ def _wgrad_part(device):
     """Scratch for the per-workgroup weight-gradient partial rows (written and consumed inside one backward call)."""
     t = _part_cache.get(device)
     if t is None:
-        t = _part_cache[device] = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), device=device)
+        t = _part_cache[device] = torch.empty(int(_lib.lib().mural_op_conv32_wgrad_scratch()), dtype=torch.float32, device=device)
     return t
 
 
@@ -135,12 +135,12 @@ class BnConv(torch.autograd.Function):
         B, Cn, L = x.shape
         dev = x.device
         st = _stream(x)
-        y = torch.empty((B, weight.shape[0], L), device=dev)
+        y = torch.empty((B, weight.shape[0], L), dtype=torch.float32, device=dev)
         mfma = tuple(weight.shape) == (32, 32, 3) and bool(_lib.lib().mural_op_conv32_supported(L))
         want = stats_out is not None
-        acc_out = _bn_acc(weight.shape[0], dev) if want else torch.empty(0, device=dev)
+        acc_out = _bn_acc(weight.shape[0], dev) if want else torch.empty(0, dtype=torch.float32, device=dev)
         if mfma:      # fp32 MFMA implicit GEMM (csrc/conv32_mfma.hip)
-            state = torch.empty((4, Cn), device=dev)
+            state = torch.empty((4, Cn), dtype=torch.float32, device=dev)
             acc = stats_in if stats_in is not None else _bn_acc(Cn, dev)
             _call("mural_op_bnconv32_fwd", x, B, L, int(pre_relu), acc, int(stats_in is not None), _f32(bn.weight), _f32(bn.bias),
                   EPS, MOMENTUM, bn.running_mean, bn.running_var, state, _f32(weight), _f32(bias), int(post_relu), _p(res1),
@@ -174,7 +174,7 @@ class BnConv(torch.autograd.Function):
             _call("mural_op_relu_mask", dy, y, dy.numel(), g, st)
             dy = g
         dW = torch.empty_like(weight)
-        small = torch.empty((3, Cn), device=dev)          # db | dgamma | dbeta
+        small = torch.empty((3, Cn), dtype=torch.float32, device=dev)          # db | dgamma | dbeta
         db, dgamma, dbeta = small[0], small[1], small[2]
         dz = torch.empty_like(x)
         dx = torch.empty_like(x)
@@ -186,7 +186,7 @@ class BnConv(torch.autograd.Function):
         else:
             scale, shift, mean, invstd = state[0], state[1], state[2], state[3]
             wt = torch.empty_like(weight)
-            part = torch.empty(1024 * (weight.numel() + weight.shape[0]), device=dev)
+            part = torch.empty(1024 * (weight.numel() + weight.shape[0]), dtype=torch.float32, device=dev)
             _call("mural_op_conv_wgrad", dy, x, B, Cn, L, weight.shape[2], scale, shift, int(pre_relu), dW, db, part,
                   part.numel(), st)
             _call("mural_op_relayout", _f32(weight), wt, weight.shape[0], weight.shape[1], weight.shape[2], 1, st)
@@ -218,8 +218,8 @@ class Bn2d(torch.autograd.Function):
         B, Cn = x.shape
         acc = _bn_acc(Cn, x.device)
         dx = torch.empty_like(x)
-        dgamma = torch.empty(Cn, device=x.device)
-        dbeta = torch.empty(Cn, device=x.device)
+        dgamma = torch.empty(Cn, dtype=torch.float32, device=x.device)
+        dbeta = torch.empty(Cn, dtype=torch.float32, device=x.device)
         _call("mural_op_bn_backward", dy.contiguous(), x, B, Cn, 1, int(ctx.pre_relu), mean, invstd, _f32(gamma), acc, 0, None,
               None, dx, dgamma, dbeta, _stream(x))
         return dx, dgamma, dbeta, None, None
@@ -236,7 +236,7 @@ class MaxPool(torch.autograd.Function):
         if glob:
             k, s, p = L, L, 0          # one window per row: the backward is a gather (no zero fill, no atomics)
         Lout = (L + 2 * p - k) // s + 1
-        y = torch.empty((B, Cn, Lout), device=x.device)
+        y = torch.empty((B, Cn, Lout), dtype=torch.float32, device=x.device)
         arg = torch.empty((B, Cn, Lout), dtype=torch.int32, device=x.device)
         _call("mural_op_maxpool_fwd", x, B * Cn, L, k, s, p, y, arg, _stream(x))
         ctx.save_for_backward(arg)
@@ -274,8 +274,8 @@ class FirstLayerPool(torch.autograd.Function):
         dev = sym.device
         tab_floats, arg_bytes, _ = _first_plan(Cn, pk)
         counts = torch.zeros(16, dtype=torch.int64, device=dev)
-        tab = torch.empty(tab_floats, device=dev)
-        y = torch.empty((B, Cn, L2), device=dev)
+        tab = torch.empty(tab_floats, dtype=torch.float32, device=dev)
+        y = torch.empty((B, Cn, L2), dtype=torch.float32, device=dev)
         arg = torch.empty(B * Cn * L2 * arg_bytes, dtype=torch.uint8, device=dev)
         _call("mural_op_first_fwd", sym, B, Lwin, col0, L1, Cn, pk, ps, pp, _f32(gamma), _f32(beta), _f32(weight), _f32(bias),
               EPS, MOMENTUM, bn.running_mean, bn.running_var, counts, tab, y, arg, _stream(sym))
@@ -291,11 +291,11 @@ class FirstLayerPool(torch.autograd.Function):
         B, Lwin = sym.shape
         Cn = weight.shape[0]
         dev = sym.device
-        scratch = torch.empty(_first_plan(Cn, pk)[2], device=dev)
+        scratch = torch.empty(_first_plan(Cn, pk)[2], dtype=torch.float32, device=dev)
         dW = torch.empty_like(weight)
-        db = torch.empty(Cn, device=dev)
-        dgamma = torch.empty(4, device=dev)
-        dbeta = torch.empty(4, device=dev)
+        db = torch.empty(Cn, dtype=torch.float32, device=dev)
+        dgamma = torch.empty(4, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(4, dtype=torch.float32, device=dev)
         _call("mural_op_first_bwd", dy.contiguous(), arg, sym, B, Lwin, col0, L1, Cn, pk, ps, pp, tab, _f32(weight), scratch, dW,
               db, dgamma, dbeta, _stream(sym))
         return None, dgamma, dbeta, dW, db, None, None, None, None
@@ -307,7 +307,7 @@ class Linear(torch.autograd.Function):
         x = x.contiguous()
         B, I = x.shape
         O = weight.shape[0]
-        y = torch.empty((B, O), device=x.device)
+        y = torch.empty((B, O), dtype=torch.float32, device=x.device)
         _call("mural_op_linear_fwd", x, _f32(weight), _f32(bias), B, I, O, y, _stream(x))
         ctx.save_for_backward(x, weight)
         return y
@@ -319,7 +319,7 @@ class Linear(torch.autograd.Function):
         O = weight.shape[0]
         dx = torch.empty_like(x)
         dW = torch.empty_like(weight)
-        db = torch.empty(O, device=x.device)
+        db = torch.empty(O, dtype=torch.float32, device=x.device)
         _call("mural_op_linear_bwd", dy.contiguous(), x, _f32(weight), B, I, O, dx, dW, db, _stream(x))
         return dx, dW, db
 
@@ -331,7 +331,7 @@ class Embedding(torch.autograd.Function):
     def forward(ctx, cat, table):
         cat = cat.contiguous()
         B, cols = cat.shape
-        y = torch.empty((B, cols * 5), device=table.device)
+        y = torch.empty((B, cols * 5), dtype=torch.float32, device=table.device)
         _call("mural_op_embedding_fwd", cat, _f32(table), B, cols, table.shape[0], y, _stream(table))
         ctx.save_for_backward(cat)
         ctx.rows = table.shape[0]
@@ -341,7 +341,7 @@ class Embedding(torch.autograd.Function):
     def backward(ctx, dy):
         (cat,) = ctx.saved_tensors
         B, cols = cat.shape
-        dE = torch.zeros((ctx.rows, 5), device=dy.device)
+        dE = torch.zeros((ctx.rows, 5), dtype=torch.float32, device=dy.device)
         _call("mural_op_embedding_bwd", cat, dy.contiguous(), B, cols, ctx.rows, dE, _stream(dy))
         return None, dE
 
@@ -389,7 +389,7 @@ class Head(torch.autograd.Function):
     @staticmethod
     def forward(ctx, loc, mid, lar):
         B, nc = mid.shape
-        out = torch.empty((B, nc), device=mid.device)
+        out = torch.empty((B, nc), dtype=torch.float32, device=mid.device)
         loc_c = None if loc is None else loc.contiguous()
         mid, lar = mid.contiguous(), lar.contiguous()
         _call("mural_op_head_fwd", loc_c, mid, lar, B, nc, out, _stream(mid))
