@@ -39,7 +39,8 @@ __device__ __forceinline__ float cg_act(float v, int act) {
 struct ConvGArgs {
   Conv1dArgs a;
   int TR;        // batch rows per tile (row regime), 1 in the segment regime
-  int seg;       // 1: a tile is a seg_cols()-column segment of one row (grid = segments x rows)
+  int seg;       // 1: a tile is a segc-column segment of one row (grid = segments x rows)
+  int segc;      // columns of a segment-regime tile (seg_cols)
   int span;      // staged input columns per (row, channel)
   int span_p;    // LDS row stride (== 16 mod 32: the four channel rows of a fragment read land on disjoint bank halves)
   FastDiv d_span, d_cin, d_up, d_lout;   // the staging loop's index arithmetic costs more than its loads with hardware division
@@ -52,10 +53,18 @@ struct ConvGArgs {
 
 constexpr int CG_MSLICE = 6;    // at most this many 16-row blocks per workgroup; more rows go to further workgroups along grid.z
 
-constexpr int CG_NBW_SEG = 4;   // segment regime: 16-column blocks per wave (tile = 64 x (4 or 2) x ... columns, see seg_cols)
+constexpr int CG_NBW_SEG = 4;   // segment regime: at most this many 16-column blocks per wave
 
-// columns of a segment-regime tile: the column-block groups (4 with one channel block, else 2) x CG_NBW_SEG blocks x 16
-__host__ __device__ inline int seg_cols(int Cout) { return (Cout > 16 ? 2 : 4) * CG_NBW_SEG * 16; }
+// 16-column blocks per wave of a segment-regime tile: CG_NBW_SEG for long rows, fewer when a whole row of 65..128 columns fits
+// (80-column rows on a 128 / 256-column tile would spend 40..70 % of their MFMAs on padding)
+inline int seg_nbw(int Mrows, int Lcols) {
+  const int wn = Mrows > 16 ? 2 : 4;
+  int nbw = (Lcols + 16 * wn - 1) / (16 * wn);
+  if (nbw < 2) nbw = 2;
+  return nbw < CG_NBW_SEG ? nbw : CG_NBW_SEG;
+}
+// columns of a segment-regime tile: the column-block groups (4 with one channel block, else 2) x blocks per wave x 16
+inline int seg_cols(int Mrows, int Lcols) { return (Mrows > 16 ? 2 : 4) * seg_nbw(Mrows, Lcols) * 16; }
 
 template <int MW, int KT, int NBW>     // MW: output-channel blocks per wave (1..3); NBW: 16-column blocks per wave
 __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, const float* __restrict__ wt, const float* __restrict__ bias) {
@@ -65,7 +74,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kk = lane >> 4;
   const int b0 = g.seg ? blockIdx.y : blockIdx.x * g.TR;
-  const int SEG = seg_cols(g.Mrows);
+  const int SEG = g.segc;
   const int l0 = g.seg ? blockIdx.x * SEG : 0;
   const int in0 = l0 * a.stride - a.pad;      // virtual (upsampled) input index of the first staged column
   const int Lv = a.Lin * a.up;
@@ -226,7 +235,8 @@ ConvGFn pick_mw(int mb_total, int K, int mslice) {
 }
 
 ConvGFn pick(int mb_total, int K, int seg, int mslice) {
-  return seg ? pick_mw<CG_NBW_SEG>(mb_total, K, mslice) : pick_mw<2>(mb_total, K, mslice);
+  if (!seg || seg == 2) return pick_mw<2>(mb_total, K, mslice);      // seg: 0 = row regime, else blocks per wave of the segment tile
+  return seg == 3 ? pick_mw<3>(mb_total, K, mslice) : pick_mw<CG_NBW_SEG>(mb_total, K, mslice);
 }
 
 struct ConvGArgs;
@@ -249,7 +259,8 @@ bool plan(const Conv1dArgs& a, ConvGArgs* g) {
   if (g->Lcols > 64) {          // longer than the 64-column tile of the row regime
     g->seg = 1;
     g->TR = 1;
-    g->span = (seg_cols(g->Mrows) - 1) * a.stride + a.K;
+    g->segc = seg_cols(g->Mrows, g->Lcols);
+    g->span = (g->segc - 1) * a.stride + a.K;
   } else {
     g->seg = 0;
     g->span = (g->Lcols - 1) * a.stride + a.K;
@@ -303,11 +314,11 @@ int launch_conv1d_mfma(const Conv1dArgs& a, hipStream_t stream) {
   MURAL_REQUIRE(plan(a, &g), "conv1d (MFMA): unsupported geometry");
   const size_t lds = lds_bytes(g);
   const int mb_all = (g.Mrows + 15) / 16;
-  ConvGFn fn = pick(mb_all, a.K, g.seg, g.mslice);
+  ConvGFn fn = pick(mb_all, a.K, g.seg ? seg_nbw(g.Mrows, g.Lcols) : 0, g.mslice);
   MURAL_REQUIRE(fn, "conv1d (MFMA): no kernel for %d taps", a.K);
   if (lds > 64 * 1024)
     MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(fn), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  const int segc = seg_cols(g.Mrows);
+  const int segc = g.segc;
   const unsigned mz = (unsigned)((mb_all + g.mslice - 1) / g.mslice);
   const dim3 grid = g.seg ? dim3((g.Lcols + segc - 1) / segc, a.B, mz) : dim3((a.B + g.TR - 1) / g.TR, 1, mz);
   hipLaunchKernelGGL(fn, grid, dim3(256), lds, stream, g, a.wt, a.bias);
