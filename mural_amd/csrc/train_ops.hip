@@ -439,21 +439,28 @@ __global__ __launch_bounds__(256) void sym_hist_kernel(const uint8_t* __restrict
   __shared__ unsigned int h[N_SYM];
   if (threadIdx.x < N_SYM) h[threadIdx.x] = 0;
   __syncthreads();
-  const int64_t total = B * L1;
   unsigned int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-  const int64_t first = blockIdx.x * (int64_t)blockDim.x, stride = (int64_t)gridDim.x * blockDim.x;
-  for (int64_t base = first; base < total; base += stride) {       // uniform trip count per wave: the ballots see every lane
-    const int64_t i = base + threadIdx.x;
-    int v = -1;
-    if (i < total) {
-      const int64_t b = i / L1;
-      v = sym[b * Lwin + col0 + (int)(i - b * L1)] & 15;
+  // a workgroup walks whole rows, its threads the row's columns, UN byte loads of a lane in flight; one workgroup per CU: the
+  // final global atomics all land on the same four addresses and serialise (8192 of them cost 28 us whatever the input size)
+  constexpr int UN = 4;
+  for (int64_t b = blockIdx.x; b < B; b += gridDim.x) {
+    const uint8_t* row = sym + b * Lwin + col0;
+    for (int j0 = 0; j0 < L1; j0 += 256 * UN) {                    // uniform trip count per wave: the ballots see every lane
+      int v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int j = j0 + 256 * u + (int)threadIdx.x;
+        v[u] = j < L1 ? (row[j] & 15) : -1;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        c0 += __popcll(__ballot(v[u] == 0));
+        c1 += __popcll(__ballot(v[u] == 1));
+        c2 += __popcll(__ballot(v[u] == 2));
+        c3 += __popcll(__ballot(v[u] == 3));
+        if (v[u] > 3) atomicAdd(&h[v[u]], 1u);
+      }
     }
-    c0 += __popcll(__ballot(v == 0));
-    c1 += __popcll(__ballot(v == 1));
-    c2 += __popcll(__ballot(v == 2));
-    c3 += __popcll(__ballot(v == 3));
-    if (v > 3) atomicAdd(&h[v], 1u);
   }
   if ((threadIdx.x & 63) == 0) {
     atomicAdd(&h[0], c0);
@@ -1092,7 +1099,7 @@ static int first_fwd_impl(const uint8_t* sym, int64_t B, int32_t Lwin, int32_t c
                           unsigned long long* counts, float* tab, float* y, void* arg, int cl, double* stat, void* stream) {
   const int L2 = (L1 + 2 * pp - pk) / ps + 1;
   const bool fast = first_train_supported(C, pk);
-  hipLaunchKernelGGL(sym_hist_kernel, dim3(grid_for(B * L1, 256, 2048)), dim3(256), 0, STREAM, sym, B, Lwin, col0, L1, counts);
+  hipLaunchKernelGGL(sym_hist_kernel, dim3((unsigned)(B < 1024 ? B : 1024)), dim3(256), 0, STREAM, sym, B, Lwin, col0, L1, counts);
   hipLaunchKernelGGL(first_tables_kernel, dim3(1), dim3(256), 0, STREAM, counts, C, gamma, beta, W, bias, eps, momentum,
                      running_mean, running_var, tab, fast ? 1 : 0);
   if (fast) {
