@@ -71,23 +71,30 @@ struct FastDiv {
 // stream joins the capture and leaves it at the join).
 // ---------------------------------------------------------------------------------------------
 struct SideStream {
-  hipStream_t side = nullptr;
-  hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+  hipStream_t side = nullptr, side2 = nullptr;
+  hipEvent_t fork_ev = nullptr, join_ev = nullptr, join2_ev = nullptr;
   int init() {
     if (side) return MURAL_OK;
     MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
+    MURAL_HIP_CHECK(hipEventCreateWithFlags(&join2_ev, hipEventDisableTiming));
     return MURAL_OK;
   }
-  int fork(hipStream_t main) {
+  int fork(hipStream_t main, bool both = false) {
     MURAL_HIP_CHECK(hipEventRecord(fork_ev, main));
     MURAL_HIP_CHECK(hipStreamWaitEvent(side, fork_ev, 0));
+    if (both) MURAL_HIP_CHECK(hipStreamWaitEvent(side2, fork_ev, 0));
     return MURAL_OK;
   }
-  int join(hipStream_t main) {
+  int join(hipStream_t main, bool both = false) {
     MURAL_HIP_CHECK(hipEventRecord(join_ev, side));
     MURAL_HIP_CHECK(hipStreamWaitEvent(main, join_ev, 0));
+    if (both) {
+      MURAL_HIP_CHECK(hipEventRecord(join2_ev, side2));
+      MURAL_HIP_CHECK(hipStreamWaitEvent(main, join2_ev, 0));
+    }
     return MURAL_OK;
   }
 };

@@ -481,13 +481,14 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   }
   SideStream* ss;
   if (int rc = side_stream(&ss)) return rc;
-  if (int rc = ss->fork((hipStream_t)stream)) return rc;
-  c.stream = ss->side;                                       // side stream: local branch + mid tower; caller's stream: large tower
+  if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
+  c.stream = ss->side2;                                      // three streams: local branch | mid tower | large tower (caller's)
   int rc_mid = m == 2 ? local_f(c, cat_x, dropout_p, seeds, seed_dev) : MURAL_OK;
+  c.stream = ss->side;
   if (!rc_mid) rc_mid = tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
   c.stream = stream;
   int rc_large = rc_mid ? MURAL_OK : tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
-  if (int rc = ss->join((hipStream_t)stream)) return rc;     // also on an error: the side stream must not stay forked
+  if (int rc = ss->join((hipStream_t)stream, true)) return rc;     // also on an error: the side streams must not stay forked
   if (rc_mid) return rc_mid;
   if (rc_large) return rc_large;
   return mural_op_head_fwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, B, shape->n_class, out, stream);
@@ -512,13 +513,14 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
                                  P.dlogit[1], P.dlogit[2], stream)) return rc;
   SideStream* ss;
   if (int rc = side_stream(&ss)) return rc;
-  if (int rc = ss->fork((hipStream_t)stream)) return rc;
+  if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
   c.stream = ss->side;
   int rc_mid = tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev);
+  c.stream = ss->side2;
   if (m == 2 && !rc_mid) rc_mid = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
   c.stream = stream;
   int rc_large = rc_mid ? MURAL_OK : tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);
-  if (int rc = ss->join((hipStream_t)stream)) return rc;
+  if (int rc = ss->join((hipStream_t)stream, true)) return rc;
   if (rc_mid) return rc_mid;
   if (rc_large) return rc_large;
   return train_reduce_parts(c.job_part, c.job_nrow, c.job_dW, c.job_db, c.njobs, (hipStream_t)stream);
