@@ -482,12 +482,14 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   SideStream* ss;
   if (int rc = side_stream(&ss)) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
-  c.stream = ss->side2;                                      // three streams: local branch | mid tower | large tower (caller's)
-  int rc_mid = m == 2 ? local_f(c, cat_x, dropout_p, seeds, seed_dev) : MURAL_OK;
+  // three streams: large tower (caller's) | mid tower | local branch.  The large tower is the critical path, so it is enqueued
+  // first: the ~70 launches of the other two would otherwise hold its first kernel back by their enqueue time
+  int rc_large = tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
   c.stream = ss->side;
-  if (!rc_mid) rc_mid = tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
+  int rc_mid = rc_large ? MURAL_OK : tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
+  c.stream = ss->side2;
+  if (m == 2 && !rc_mid && !rc_large) rc_mid = local_f(c, cat_x, dropout_p, seeds, seed_dev);
   c.stream = stream;
-  int rc_large = rc_mid ? MURAL_OK : tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
   if (int rc = ss->join((hipStream_t)stream, true)) return rc;     // also on an error: the side streams must not stay forked
   if (rc_mid) return rc_mid;
   if (rc_large) return rc_large;
@@ -514,12 +516,12 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   SideStream* ss;
   if (int rc = side_stream(&ss)) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
+  int rc_large = tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);   // critical path first
   c.stream = ss->side;
-  int rc_mid = tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev);
+  int rc_mid = rc_large ? MURAL_OK : tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev);
   c.stream = ss->side2;
-  if (m == 2 && !rc_mid) rc_mid = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
+  if (m == 2 && !rc_mid && !rc_large) rc_mid = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
   c.stream = stream;
-  int rc_large = rc_mid ? MURAL_OK : tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);
   if (int rc = ss->join((hipStream_t)stream, true)) return rc;
   if (rc_mid) return rc_mid;
   if (rc_large) return rc_large;
