@@ -205,8 +205,12 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
                                                         const float* __restrict__ f_b) {
   constexpr int C2 = 2 * C, TW = 256 + 4, TWp = TW | 1;
   __shared__ float tile[C * TWp];
-  __shared__ float hs[C2 * 256];               // SiLU outputs, [2C][256 lanes]
-  static_assert(!FRONT || C2 * 256 >= CB_FRONT_FLOATS, "the front input tile borrows the SiLU buffer");
+  // SiLU outputs parked for the rolled 1x1 loop, HP of the 2C rows at a time (a lane only ever touches its own column, so the
+  // passes need no barrier): at 8 channels two passes of 8 rows keep the buffer at 8 KB and the workgroup at 17 KB of LDS = 8
+  // workgroups per CU, which is what hides the scalar weight loads of the inner loops
+  constexpr int HP = C == 8 ? 8 : C2;
+  __shared__ float hs[HP * 256];
+  static_assert(!FRONT || HP * 256 >= CB_FRONT_FLOATS, "the front input tile borrows the SiLU buffer");
   float* fin = hs;                             // front input tile: dead before the first SiLU output is parked (a barrier in between),
                                                // and 8 KB less LDS is two more workgroups per CU to hide the scalar weight loads
   const int tid = threadIdx.x;
@@ -351,21 +355,24 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
   // 1x1 conv 2C -> C.  Its 2C x C weights do not fit the scalar register file if the loop over the 2C inputs is unrolled
   // (and it must be, to index registers): the lane parks its 2C values in LDS (column tid: conflict-free) and walks them
   // in a rolled loop, one scalar weight row in flight at a time.
-#pragma unroll
-  for (int j = 0; j < C; ++j) {
-    hs[(2 * j) * 256 + tid] = h[j].x;
-    hs[(2 * j + 1) * 256 + tid] = h[j].y;
-  }
   f32x2 o[C / 2];
 #pragma unroll
   for (int c = 0; c < C / 2; ++c) o[c] = f32x2{b1[2 * c], b1[2 * c + 1]};
-#pragma unroll 2
-  for (int j = 0; j < C2; ++j) {
-    const float* __restrict__ wj = w1 + (size_t)j * C;
-    const float hv = hs[j * 256 + tid];
-    const f32x2 h2 = {hv, hv};
 #pragma unroll
-    for (int c = 0; c < C / 2; ++c) o[c] = __builtin_elementwise_fma(h2, f32x2{wj[2 * c], wj[2 * c + 1]}, o[c]);
+  for (int j0 = 0; j0 < C2; j0 += HP) {
+#pragma unroll
+    for (int j = 0; j < HP / 2; ++j) {
+      hs[(2 * j) * 256 + tid] = h[j0 / 2 + j].x;
+      hs[(2 * j + 1) * 256 + tid] = h[j0 / 2 + j].y;
+    }
+#pragma unroll 2
+    for (int j = 0; j < HP; ++j) {
+      const float* __restrict__ wj = w1 + (size_t)(j0 + j) * C;
+      const float hv = hs[j * 256 + tid];
+      const f32x2 h2 = {hv, hv};
+#pragma unroll
+      for (int c = 0; c < C / 2; ++c) o[c] = __builtin_elementwise_fma(h2, f32x2{wj[2 * c], wj[2 * c + 1]}, o[c]);
+    }
   }
   float v[C];
 #pragma unroll
