@@ -53,7 +53,8 @@ struct ConvGArgs {
 
 constexpr int CG_MSLICE = 6;    // at most this many 16-row blocks per workgroup; more rows go to further workgroups along grid.z
 
-constexpr int CG_NBW_SEG = 4;   // segment regime: at most this many 16-column blocks per wave
+constexpr int CG_NBW_SEG = 3;   // segment regime: at most this many 16-column blocks per wave (2, 3 and 4 measure the same over the
+                                // U-Net forward, within the +-2 % run-to-run spread; 3 keeps the accumulators at 36 registers)
 
 // 16-column blocks per wave of a segment-regime tile: CG_NBW_SEG for long rows, fewer when a whole row of 65..128 columns fits
 // (80-column rows on a 128 / 256-column tile would spend 40..70 % of their MFMAs on padding)
@@ -236,7 +237,7 @@ ConvGFn pick_mw(int mb_total, int K, int mslice) {
 
 ConvGFn pick(int mb_total, int K, int seg, int mslice) {
   if (!seg || seg == 2) return pick_mw<2>(mb_total, K, mslice);      // seg: 0 = row regime, else blocks per wave of the segment tile
-  return seg == 3 ? pick_mw<3>(mb_total, K, mslice) : pick_mw<CG_NBW_SEG>(mb_total, K, mslice);
+  return pick_mw<CG_NBW_SEG>(mb_total, K, mslice);
 }
 
 struct ConvGArgs;
