@@ -75,6 +75,9 @@ struct Stage1Args {               // snv_stage1_kernel: window decode + first co
   const int64_t* pos;
   const uint8_t* strand;
   float* x0;                      // [n][x0_cols][32] pooled first-layer activations (large columns, then mid)
+  const float* dense;             // small-batch dense entry: [n][4][Lwin] one-hot / IUPAC fractions read directly (codes unused), or nullptr
+  int32_t* status;                // dense: MURAL_E_ENCODING is or-ed in for a column that is no valid encoding (nullptr: not reported)
+  int* zero;                      // small-batch launch: n ints cleared for the tower launch behind it (SnvFwdArgs::tile_count), or nullptr
 };
 
 // training-mode first layer of ONE tower (snv_stage1.hip: first_train_kernel)
@@ -117,6 +120,11 @@ struct SnvFwdArgs {
   // its fc logits go to xlogit) and then {1, 1} (mid tower with its own, larger tile; reads xlogit and does the head).
   int tw_first, tw_last;
   float* xlogit;                  // [n][SNV_MAXCLASS] large-tower logits between the two launches of the split mode
+  // Tower-parallel launch (phase 0, tw {0, 1}, small batches): grid = 2 workgroups per tile, one per tower; both publish their
+  // logits (xlogit / xlogit2) and count up tile_count[tile] (zero before the launch); the second one to arrive runs the head.
+  int par;
+  float* xlogit2;                 // [n][SNV_MAXCLASS] mid-tower logits
+  int* tile_count;                // [tiles]
   // Stage range of this launch.  phase 0: everything.  phase 1: first conv stage only (entry + 4 residual convs + max-pool
   // 2 + BN), the pooled tile goes to s3[tower].  phase 2: the two short stages (6 convs), global max, fc (+ head), reading
   // s3[tower] - with a tile of many more positions, so that the short stages run full-width layers.

@@ -179,7 +179,23 @@ __global__ __launch_bounds__(LOC_THREADS) void snv_local_mlp_mfma(LocalDev L, co
   float* H1 = A3 + (size_t)J3 * 256;       // [LM_TP][s1]
   float* XH = H1 + LM_TP * d.s1;           // [LM_TP][sx]: embeddings, later the second hidden layer
   float* EM = XH + LM_TP * d.sx;           // the embedding table [emb_rows][5]
-  for (int i = threadIdx.x; i < L.frag_floats / 4; i += LOC_THREADS) st4(A1 + 4 * i, ld4(L.frag + 4 * i));   // A1 | A2 | A3
+  {   // A1 | A2 | A3: eight loads in flight per thread (a one-tile call is this copy's latency: 40 dependent round trips otherwise)
+    constexpr int UN = 8;
+    const int n4 = L.frag_floats / 4;
+    for (int i0 = threadIdx.x; i0 < n4; i0 += UN * LOC_THREADS) {
+      f32x4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + u * LOC_THREADS;
+        v[u] = ld4(L.frag + 4 * (i < n4 ? i : i0));
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + u * LOC_THREADS;
+        if (i < n4) st4(A1 + 4 * i, v[u]);
+      }
+    }
+  }
   for (int i = threadIdx.x; i < L.emb_rows * 5; i += LOC_THREADS) EM[i] = L.emb[i];
   float* BI1 = EM + ((L.emb_rows * 5 + 3) & ~3);      // biases, zero-padded to whole 16-feature blocks
   float* BI2 = BI1 + d.K2p;

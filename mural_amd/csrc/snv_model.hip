@@ -14,6 +14,7 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream);
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream);
+bool stage1_small_batch(int64_t n);
 
 namespace {
 
@@ -480,6 +481,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     Stage1Args s = s1;
     s.n = cn;
     s.x0 = w.x0;
+    s.zero = small ? reinterpret_cast<int*>(w.s3[1]) : nullptr;
     if (packed) { s.pos = s1.pos + c0; s.strand = s1.strand + c0; }
     else s.codes = s1.codes + c0 * m->shape.distal_len;
     if (int rc = launch_snv_stage1(s, packed, m->s1_lds_bytes, stream)) return rc;
@@ -491,6 +493,11 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       t.n = cn;
       t.x0 = w.x0;
       t.xlogit = w.xlogit;
+      if (small) {   // one workgroup per (site, tower): the split launches' s3 scratch carries the mid logits and the arrival counters
+        t.par = 1;
+        t.xlogit2 = w.s3[0];
+        t.tile_count = reinterpret_cast<int*>(w.s3[1]);
+      }
       t.local_logits = w.local_logits + c0 * nc;
       t.out = out + c0 * nc;
       t.taps = c0 == 0 ? taps : nullptr;
@@ -528,10 +535,17 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
     MURAL_REQUIRE(cat_x, "cat_x is NULL");
     if (int rc = launch_snv_local(m->local, cat_x, n, w.local_logits, stream)) return rc;
   }
-  if (int rc = launch_dense_to_symbols(distal_x, n, sh.distal_len, w.symbols, status, stream)) return rc;
+  // a small batch is one launch per stage: its first-stage kernel classifies the dense columns itself
+  const bool direct = stage1_small_batch(n);
+  if (!direct)
+    if (int rc = launch_dense_to_symbols(distal_x, n, sh.distal_len, w.symbols, status, stream)) return rc;
   if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * m->args.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * m->args.nbuf);
   Stage1Args s1 = m->s1;
   s1.codes = w.symbols;
+  if (direct) {
+    s1.dense = distal_x;
+    s1.status = status;
+  }
   return run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, status, stream);
 }
 

@@ -12,6 +12,7 @@
 // itself, so four waves per SIMD hide each other's LDS latency.  Bound: LDS reads (256 KB of table rows per site).
 #include <cstdlib>
 
+#include "dense_symbol.h"
 #include "snv.h"
 
 namespace mural {
@@ -214,6 +215,8 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_site_kernel(const Stage
     *reinterpret_cast<f32x4*>(lutM + i) = s1_ld4(args.lut[1] + i);
   }
   const int Lwin = args.Lwin;
+  if (args.zero != nullptr && blockIdx.x == 0)
+    for (int64_t i = tid; i < args.n; i += S1_THREADS) args.zero[i] = 0;
   for (int64_t row = blockIdx.x; row < args.n; row += gridDim.x) {
     __syncthreads();                         // previous site's readers are done (first pass: nothing to wait for but the LUT writers)
     if (SRC == 1) {
@@ -229,6 +232,29 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_site_kernel(const Stage
         if (neg) sym = sym_complement(sym);
         cb[j + 1] = (uint8_t)sym;
       }
+    } else if (SRC == 2) {                   // the dense window itself: 4 channel loads per column, up to 2 columns per thread in flight
+      const float* src = args.dense + (size_t)row * 4 * Lwin;
+      if (tid == 0) {
+        cb[0] = SYM_PAD;
+        cb[Lwin + 1] = SYM_PAD;
+      }
+      bool bad = false;
+      for (int j0 = tid; j0 < Lwin; j0 += 2 * S1_THREADS) {
+        const int j1 = j0 + S1_THREADS;
+        const int j1c = j1 < Lwin ? j1 : j0;
+        float v[2][4];
+#pragma unroll
+        for (int ch = 0; ch < 4; ++ch) {
+          v[0][ch] = src[(size_t)ch * Lwin + j0];
+          v[1][ch] = src[(size_t)ch * Lwin + j1c];
+        }
+        int s0 = dense_symbol(v[0][0], v[0][1], v[0][2], v[0][3]);
+        int s1 = dense_symbol(v[1][0], v[1][1], v[1][2], v[1][3]);
+        bad |= (s0 < 0) | (s1 < 0);
+        cb[j0 + 1] = (uint8_t)(s0 < 0 ? SYM_N : s0);
+        if (j1 < Lwin) cb[j1 + 1] = (uint8_t)(s1 < 0 ? SYM_N : s1);
+      }
+      if (bad && args.status != nullptr) atomicOr(args.status, (int)MURAL_E_ENCODING);
     } else {
       const uint8_t* src = args.codes + row * Lwin;
       for (int jj = tid; jj < Lwin + 2; jj += S1_THREADS) {
@@ -491,13 +517,19 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
   return MURAL_OK;
 }
 
+bool stage1_small_batch(int64_t n) { return n <= 256 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH"); }
+
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream) {
   if (a.n == 0) return MURAL_OK;
+  MURAL_REQUIRE(a.dense == nullptr || (!packed && stage1_small_batch(a.n)), "stage 1: the dense source is the small-batch kernel's");
   static DynLdsOnce big_lds;
-  if (int rc = big_lds.ensure(&snv_stage1_kernel<0>, &snv_stage1_kernel<1>, &snv_stage1_site_kernel<0>, &snv_stage1_site_kernel<1>))
+  if (int rc = big_lds.ensure(&snv_stage1_kernel<0>, &snv_stage1_kernel<1>, &snv_stage1_site_kernel<0>, &snv_stage1_site_kernel<1>,
+                              &snv_stage1_site_kernel<2>))
     return rc;
-  if (a.n <= 256 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH")) {     // latency-bound call: one workgroup per site
-    if (packed) hipLaunchKernelGGL(snv_stage1_site_kernel<1>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
+  if (stage1_small_batch(a.n)) {     // latency-bound call: one workgroup per site
+    if (!packed && a.dense != nullptr)
+      hipLaunchKernelGGL(snv_stage1_site_kernel<2>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
+    else if (packed) hipLaunchKernelGGL(snv_stage1_site_kernel<1>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
     else hipLaunchKernelGGL(snv_stage1_site_kernel<0>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
     MURAL_HIP_CHECK(hipGetLastError());
     return MURAL_OK;
