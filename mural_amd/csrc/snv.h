@@ -63,6 +63,8 @@ struct LocalDev {
   int cols, emb_rows, in1, h1, h2, n_class;
 };
 
+struct LocalMfmaDims { int K1p, K2p, K3p, n1b, n2b, s1, sx, dbg; };   // LDS layout of snv_local_mlp_mfma (snv_local_mfma.h)
+
 struct Stage1Tower { int L1, col0, L2, pk, ps, pp; };
 
 struct Stage1Args {               // snv_stage1_kernel: window decode + first conv layer + maxpool1
@@ -77,6 +79,12 @@ struct Stage1Args {               // snv_stage1_kernel: window decode + first co
   float* x0;                      // [n][x0_cols][32] pooled first-layer activations (large columns, then mid)
   const float* dense;             // small-batch dense entry: [n][4][Lwin] one-hot / IUPAC fractions read directly (codes unused), or nullptr
   int32_t* status;                // dense: MURAL_E_ENCODING is or-ed in for a column that is no valid encoding (nullptr: not reported)
+  // small-batch launch, Network2: one extra workgroup (blockIdx n) runs the local branch (snv_local_mfma.h) beside the site workgroups
+  int loc_on;
+  LocalDev loc;
+  LocalMfmaDims loc_d;
+  const int64_t* loc_cat;         // [n][loc.cols] k-mer ids
+  float* loc_out;                 // [n][n_class] logits
   int* zero;                      // small-batch launch: n ints cleared for the tower launch behind it (SnvFwdArgs::tile_count), or nullptr
 };
 
@@ -152,4 +160,8 @@ struct MuralSnvModel {
   size_t lds_bytes;               // dynamic LDS of the tower kernel
   mural::Stage1Args s1;           // stage-1 kernel arguments (input/output fields filled per call)
   size_t s1_lds_bytes;
+  // Network2, small batches: the local branch rides in the first-stage launch (Stage1Args::loc_on) when its MFMA kernel applies
+  bool loc_fused;
+  mural::LocalMfmaDims loc_d;
+  size_t loc_lds;
 };

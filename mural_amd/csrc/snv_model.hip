@@ -15,6 +15,7 @@ int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStr
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream);
 bool stage1_small_batch(int64_t n);
+bool local_mfma_plan(const LocalDev& L, LocalMfmaDims* d, size_t* lds_bytes);
 
 namespace {
 
@@ -433,6 +434,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     L.frag = m->blob + loff.frag; L.frag_floats = (int)loff.frag_floats;
     L.cols = sh.local_cols; L.emb_rows = sh.emb_rows; L.in1 = 5 * sh.local_cols; L.h1 = sh.hidden1; L.h2 = sh.hidden2;
     L.n_class = sh.n_class;
+    m->loc_fused = has_towers && local_mfma_plan(L, &m->loc_d, &m->loc_lds) && !getenv("MURAL_DEBUG_NO_LOCAL_FUSE");
   }
   *out = m;
   return MURAL_OK;
@@ -484,7 +486,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     s.zero = small ? reinterpret_cast<int*>(w.s3[1]) : nullptr;
     if (packed) { s.pos = s1.pos + c0; s.strand = s1.strand + c0; }
     else s.codes = s1.codes + c0 * m->shape.distal_len;
-    if (int rc = launch_snv_stage1(s, packed, m->s1_lds_bytes, stream)) return rc;
+    if (int rc = launch_snv_stage1(s, packed, s.loc_on ? std::max(m->s1_lds_bytes, m->loc_lds) : m->s1_lds_bytes, stream)) return rc;
     const bool split = m->split && taps == nullptr && !small;   // the debug dump wants both towers in one tile geometry
     for (int part = 0; part < (split ? 4 : 1); ++part) {
       SnvFwdArgs t = split ? m->args_split[part] : (small ? m->args_small : a);
@@ -511,6 +513,16 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
   return MURAL_OK;
 }
 
+// Network2 at small batch sizes: the local branch is one more workgroup of the first-stage launch instead of a launch of its own
+static bool local_rides(const MuralSnvModel* m, int64_t n) { return m->shape.model_no == 2 && m->loc_fused && stage1_small_batch(n); }
+static void ride_local(const MuralSnvModel* m, Stage1Args* s1, const int64_t* cat, float* logits) {
+  s1->loc_on = 1;
+  s1->loc = m->local;
+  s1->loc_d = m->loc_d;
+  s1->loc_cat = cat;
+  s1->loc_out = logits;
+}
+
 static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n, float* out,
                               void* workspace, size_t ws_bytes, int32_t* status, float* taps, size_t taps_floats,
                               void* stream_) {
@@ -533,7 +545,8 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
   MURAL_REQUIRE(distal_x, "distal_x is NULL");
   if (sh.model_no == 2) {
     MURAL_REQUIRE(cat_x, "cat_x is NULL");
-    if (int rc = launch_snv_local(m->local, cat_x, n, w.local_logits, stream)) return rc;
+    if (!local_rides(m, n))
+      if (int rc = launch_snv_local(m->local, cat_x, n, w.local_logits, stream)) return rc;
   }
   // a small batch is one launch per stage: its first-stage kernel classifies the dense columns itself
   const bool direct = stage1_small_batch(n);
@@ -546,6 +559,7 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
     s1.dense = distal_x;
     s1.status = status;
   }
+  if (local_rides(m, n)) ride_local(m, &s1, cat_x, w.local_logits);
   return run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, status, stream);
 }
 
@@ -587,10 +601,12 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
                   sh.emb_rows);
     if (int rc = mural_encode_kmer(g, pos, strand, n, local_radius, local_order, 0, w.cat, stream_)) return rc;
     float* dst = sh.model_no == 0 ? out : w.local_logits;
-    if (int rc = launch_snv_local(m->local, w.cat, n, dst, stream)) return rc;
+    if (!local_rides(m, n))
+      if (int rc = launch_snv_local(m->local, w.cat, n, dst, stream)) return rc;
     if (sh.model_no == 0) return MURAL_OK;
   }
   Stage1Args s1 = m->s1;
+  if (local_rides(m, n)) ride_local(m, &s1, w.cat, w.local_logits);
   s1.genome = *g;
   s1.pos = pos;
   s1.strand = strand;

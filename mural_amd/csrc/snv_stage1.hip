@@ -14,6 +14,7 @@
 
 #include "dense_symbol.h"
 #include "snv.h"
+#include "snv_local_mfma.h"
 
 namespace mural {
 
@@ -205,6 +206,10 @@ template <int SRC>
 __global__ __launch_bounds__(S1_THREADS) void snv_stage1_site_kernel(const Stage1Args args) {
   extern __shared__ __attribute__((aligned(16))) float s1mem[];
   const int tid = threadIdx.x;
+  if (args.loc_on && (int64_t)blockIdx.x == args.n) {   // the extra workgroup: local branch of the whole (small) batch, 4 of the 16 waves
+    if (tid < LOC_THREADS) local_mlp_mfma_body(args.loc, args.loc_cat, args.n, args.loc_out, args.loc_d, s1mem, 0, 1);
+    return;
+  }
   float* lutL = s1mem;
   float* lutM = s1mem + SNV_LUTBLK;
   uint8_t* cb = reinterpret_cast<uint8_t*>(s1mem + 2 * SNV_LUTBLK);
@@ -522,15 +527,17 @@ bool stage1_small_batch(int64_t n) { return n <= 256 && !getenv("MURAL_DEBUG_NO_
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream) {
   if (a.n == 0) return MURAL_OK;
   MURAL_REQUIRE(a.dense == nullptr || (!packed && stage1_small_batch(a.n)), "stage 1: the dense source is the small-batch kernel's");
+  MURAL_REQUIRE(!a.loc_on || stage1_small_batch(a.n), "stage 1: the local-branch workgroup is the small-batch kernel's");
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&snv_stage1_kernel<0>, &snv_stage1_kernel<1>, &snv_stage1_site_kernel<0>, &snv_stage1_site_kernel<1>,
                               &snv_stage1_site_kernel<2>))
     return rc;
-  if (stage1_small_batch(a.n)) {     // latency-bound call: one workgroup per site
+  if (stage1_small_batch(a.n)) {     // latency-bound call: one workgroup per site (+ one for the local branch)
+    const unsigned grid = (unsigned)a.n + (a.loc_on ? 1u : 0u);
     if (!packed && a.dense != nullptr)
-      hipLaunchKernelGGL(snv_stage1_site_kernel<2>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
-    else if (packed) hipLaunchKernelGGL(snv_stage1_site_kernel<1>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
-    else hipLaunchKernelGGL(snv_stage1_site_kernel<0>, dim3((unsigned)a.n), dim3(S1_THREADS), lds_bytes, stream, a);
+      hipLaunchKernelGGL(snv_stage1_site_kernel<2>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
+    else if (packed) hipLaunchKernelGGL(snv_stage1_site_kernel<1>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
+    else hipLaunchKernelGGL(snv_stage1_site_kernel<0>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
     MURAL_HIP_CHECK(hipGetLastError());
     return MURAL_OK;
   }

@@ -442,3 +442,51 @@ def test_local_branch_other_widths_on_both_kernels(h1, h2, r, nc, monkeypatch):
         got_valu = model((cont.cuda(), torch.from_numpy(cat).cuda()), x.cuda()).cpu().numpy()
     assert_probs_close(got_valu, want, 0, "valu")
     assert_probs_close(got_mfma, want, 0, "mfma")
+
+
+# ------------------------------------------------------------------------------------------------ small-batch launches
+@pytest.mark.parametrize("name", SNV_FORWARD)
+def test_throughput_kernels_on_golden_batches(name, monkeypatch):
+    """Calls of up to 256 sites take the latency-shaped launches (one workgroup per (site, tower), dense window and local branch
+    inside the first-stage launch); the golden batches are small, so the throughput-shaped launches are forced on them here."""
+    monkeypatch.setenv("MURAL_DEBUG_NO_SMALL_BATCH", "1")
+    test_forward_dense_matches_reference(name)
+
+
+@pytest.mark.parametrize("n_sites", [1, 16, 255, 256])
+def test_small_batch_launches_equal_throughput_launches(n_sites, monkeypatch):
+    """Same sites through both launch shapes, dense and packed entry, both strands, IUPAC codes and a chromosome edge: the
+    per-site arithmetic is the same, so the results agree to the last bits."""
+    from mural_amd.data import PackedGenome
+    fx = U.load("snv_synth_S_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    model = model.cuda().eval()
+    r, R = int(fx["hp"][0]), int(fx["hp"][2])
+    rng = np.random.default_rng(n_sites)
+    raw = rng.choice(np.frombuffer(b"ACGTNRY", np.uint8), size=20_000, p=[.245, .245, .245, .245, .01, .005, .005])
+    seq = raw.tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = rng.integers(0, len(seq), size=n_sites)
+    pos[0] = 3
+    strand = rng.integers(0, 2, size=n_sites).astype(np.uint8)
+    sym = ["-" if s else "+" for s in strand]
+    cat = torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, r, 3)).cuda()
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R)).cuda()
+    cont = torch.zeros(n_sites, 1, dtype=torch.float64, device="cuda")
+    genome = PackedGenome.from_sequence(seq, "cuda")
+
+    def both():
+        with torch.no_grad():
+            d = model((cont, cat), x).cpu().numpy()
+            p = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r,
+                                     local_order=3).cpu().numpy()
+        return d, p
+
+    d_small, p_small = both()
+    monkeypatch.setenv("MURAL_DEBUG_NO_SMALL_BATCH", "1")
+    d_big, p_big = both()
+    assert np.isfinite(d_small).all() and np.isfinite(p_small).all()
+    assert np.abs(d_small - d_big).max() <= 2e-6 and np.abs(p_small - p_big).max() <= 2e-6
+    assert np.abs(d_small - p_small).max() <= 2e-6
