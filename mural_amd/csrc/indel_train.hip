@@ -3,9 +3,11 @@
 // input- and weight-gradient kernels, and the SiLU / Softplus / ReLU element-wise pair.  BatchNorm (batch statistics),
 // Linear, Dropout and the global max come from train_ops.hip.  Tensors are [B][C][L] fp32, weights in torch's
 // [Cout][Cin][K] layout.  Direct convolutions on the vector ALU: at 4..48 channels the layers are HBM / latency bound.
+#include <cstdlib>
 #include <cstring>
 
 #include "conv1d.h"
+#include "mfma_tile.h"
 
 namespace mural {
 namespace {
@@ -66,36 +68,45 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __r
 // upsampled by `up`; part[chunk][co][Cin * K] = sum of dy (bias gradient).  Workgroup = (chunk, group of 4 output channels).
 // With E = Cin * K <= 256 entries the 256 threads form 256 / E slices that split the 64 positions of a tile between them
 // (summed through LDS at the end); with more entries a thread owns two of them and all 64 positions.
-constexpr int WG_CO = 4, WG_TL = 64, WG_E = 2, WG_CHUNKS = 1024;
+constexpr int WG_CHUNKS = 1024;
 
+// CO output channels per workgroup (4 / 8 / 16), tiles of WG_TL positions (64 / 128 / 256), WG_EP = 4 entries per thread: a tile's
+// input span is staged once for all CO channels, and the CO gradients of a position -- 16-byte LDS reads that return 1 KB per wave
+// whatever the lanes ask for -- serve four entries each.  (With one entry per thread the launch ran at the LDS return bandwidth,
+// 4x below the FMA rate.)  The threads form slices = 256 / ceil(E / 4) groups that split the positions of a tile between them;
+// the slices are summed through LDS at the end.
+constexpr int WG_EP = 4;
+
+template <int CO, int WG_TL>
 __global__ __launch_bounds__(IT_THREADS) void conv_wgrad_kernel(const float* __restrict__ dy, const float* __restrict__ x,
                                                                 float* __restrict__ part, int B, int Cin, int Lin, int Cout,
                                                                 int Lout, int K, int stride, int pad, int up, int tiles_per_row,
                                                                 int64_t tiles, int chunks) {
-  extern __shared__ float lds[];
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int span = (WG_TL - 1) * stride + K, spanp = span | 1;
-  float* xs = lds;                               // [Cin][spanp]; reused for the slice reduction at the end
-  float* ds = lds + (size_t)Cin * spanp;         // [WG_CO][WG_TL]
-  const int chunk = blockIdx.x, co0 = blockIdx.y * WG_CO;
+  float* ds = lds;                               // [WG_TL][CO]
+  float* xs = lds + CO * WG_TL;                  // [Cin][spanp]; reused for the slice reduction at the end
+  const int chunk = blockIdx.x, co0 = blockIdx.y * CO;
   const int entries = Cin * K;
-  const int slices = entries <= IT_THREADS ? IT_THREADS / entries : 1;
-  float acc[WG_E][WG_CO];
+  const int eq = (entries + WG_EP - 1) / WG_EP;  // threads per slice
+  const int slices = IT_THREADS / eq;
+  const int sl = threadIdx.x / eq, q0 = threadIdx.x - sl * eq;
+  const bool active = sl < slices;
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[WG_EP][CO / 2];                        // channel pairs: one v_pk_fma_f32 per pair, entry and position
+  int xo[WG_EP];
 #pragma unroll
-  for (int e = 0; e < WG_E; ++e)
+  for (int j = 0; j < WG_EP; ++j) {
 #pragma unroll
-    for (int g = 0; g < WG_CO; ++g) acc[e][g] = 0.f;
-  float bacc = 0.f;
-  int eidx[WG_E], eci[WG_E], ek[WG_E];
-  const int sl = slices > 1 ? threadIdx.x / entries : 0;
-#pragma unroll
-  for (int e = 0; e < WG_E; ++e) {
-    int idx;
-    if (slices > 1) idx = (e == 0 && sl < slices) ? (int)threadIdx.x - sl * entries : -1;
-    else idx = (int)threadIdx.x + e * IT_THREADS < entries ? (int)threadIdx.x + e * IT_THREADS : -1;
-    eidx[e] = idx;
-    eci[e] = idx >= 0 ? idx / K : -1;
-    ek[e] = idx >= 0 ? idx % K : 0;
+    for (int g = 0; g < CO / 2; ++g) acc[j][g] = f32x2{0.f, 0.f};
+    const int e = WG_EP * q0 + j;
+    const int ec = e < entries ? e : entries - 1;  // (a padding entry recomputes the last one; it is not written)
+    xo[j] = (ec / K) * spanp + ec % K;
   }
+  constexpr int DV = CO * WG_TL / IT_THREADS;      // gradient values per thread and tile
+  float bsum[DV];                                  // bias gradient: this thread's share of the dy values it stages
+#pragma unroll
+  for (int q = 0; q < DV; ++q) bsum[q] = 0.f;
   const int Lup = Lin * up;
   for (int64_t tile = chunk; tile < tiles; tile += chunks) {
     const int b = (int)(tile / tiles_per_row), lo0 = (int)(tile % tiles_per_row) * WG_TL;
@@ -103,10 +114,16 @@ __global__ __launch_bounds__(IT_THREADS) void conv_wgrad_kernel(const float* __r
     const float* xb = x + (size_t)b * Cin * Lin;
     const int base = lo0 * stride - pad;
     {
-      const int i = threadIdx.x;                     // WG_CO * WG_TL == IT_THREADS: one gradient value per thread, requested first
-      const int g = i / WG_TL, t = i - g * WG_TL;
-      const int lo = lo0 + t, co = co0 + g;
-      const float dv = (lo < Lout && co < Cout) ? dy[((size_t)b * Cout + co) * Lout + lo] : 0.f;
+      float dv[DV];                                  // requested first: position-major over the threads (coalesced along lo)
+#pragma unroll
+      for (int q = 0; q < DV; ++q) {
+        const int i = threadIdx.x + q * IT_THREADS;
+        const int g = i / WG_TL, t = i - g * WG_TL;
+        const int lo = lo0 + t, co = co0 + g;
+        const bool ok = lo < Lout && co < Cout;
+        dv[q] = dy[ok ? ((size_t)b * Cout + co) * Lout + lo : 0];
+        if (!ok) dv[q] = 0.f;
+      }
       constexpr int UN = 4;                          // input loads of a thread in flight (a round per load = a global round trip)
       for (int i0 = threadIdx.x; i0 < Cin * span; i0 += IT_THREADS * UN) {
         float v[UN];
@@ -128,53 +145,70 @@ __global__ __launch_bounds__(IT_THREADS) void conv_wgrad_kernel(const float* __r
           }
         }
       }
-      ds[i] = dv;
-    }
-    __syncthreads();
 #pragma unroll
-    for (int e = 0; e < WG_E; ++e) {
-      if (eci[e] < 0) continue;
-      const float* xr = xs + eci[e] * spanp + ek[e];
-      for (int t = sl; t < WG_TL; t += slices) {
-        const float xv = xr[t * stride];
-#pragma unroll
-        for (int g = 0; g < WG_CO; ++g) acc[e][g] = fmaf(ds[g * WG_TL + t], xv, acc[e][g]);
+      for (int q = 0; q < DV; ++q) {
+        const int i = threadIdx.x + q * IT_THREADS;
+        const int g = i / WG_TL, t = i - g * WG_TL;
+        ds[t * CO + g] = dv[q];
+        bsum[q] += dv[q];
       }
     }
-    if (threadIdx.x >= IT_THREADS - WG_CO) {       // the last threads are the least loaded ones
-      const int g = threadIdx.x - (IT_THREADS - WG_CO);
-      float sm = 0.f;
-      for (int t = 0; t < WG_TL; ++t) sm += ds[g * WG_TL + t];
-      bacc += sm;
+    __syncthreads();
+    if (active) {
+      for (int t = sl; t < WG_TL; t += slices) {
+        f32x2 xv[WG_EP];
+#pragma unroll
+        for (int j = 0; j < WG_EP; ++j) {
+          const float v = xs[xo[j] + t * stride];
+          xv[j] = f32x2{v, v};
+        }
+#pragma unroll
+        for (int g4 = 0; g4 < CO / 4; ++g4) {
+          const f32x4 d = *reinterpret_cast<const f32x4*>(ds + t * CO + 4 * g4);
+          const f32x2 d0 = {d.x, d.y}, d1 = {d.z, d.w};
+#pragma unroll
+          for (int j = 0; j < WG_EP; ++j) {
+            acc[j][2 * g4 + 0] = __builtin_elementwise_fma(d0, xv[j], acc[j][2 * g4 + 0]);
+            acc[j][2 * g4 + 1] = __builtin_elementwise_fma(d1, xv[j], acc[j][2 * g4 + 1]);
+          }
+        }
+      }
     }
   }
   const int rowlen = entries + 1;
-  if (slices > 1) {
-    __syncthreads();
-    if (eidx[0] >= 0)
+  // slice reduction, four channels per round: xs holds [slice][entry][4]
 #pragma unroll
-      for (int g = 0; g < WG_CO; ++g) xs[(sl * entries + eidx[0]) * WG_CO + g] = acc[0][g];
+  for (int g4 = 0; g4 < CO / 4; ++g4) {
     __syncthreads();
-    if (sl == 0 && eidx[0] >= 0) {
+    if (active) {
 #pragma unroll
-      for (int g = 0; g < WG_CO; ++g) {
-        float sm = 0.f;
-        for (int q = 0; q < slices; ++q) sm += xs[(q * entries + eidx[0]) * WG_CO + g];
-        if (co0 + g < Cout) part[((size_t)chunk * Cout + co0 + g) * rowlen + eidx[0]] = sm;
+      for (int j = 0; j < WG_EP; ++j) {
+        const int e = WG_EP * q0 + j;
+        if (e < entries)
+          *reinterpret_cast<f32x4*>(xs + ((size_t)sl * entries + e) * 4) =
+              f32x4{acc[j][2 * g4][0], acc[j][2 * g4][1], acc[j][2 * g4 + 1][0], acc[j][2 * g4 + 1][1]};
       }
     }
-  } else {
-#pragma unroll
-    for (int e = 0; e < WG_E; ++e) {
-      if (eidx[e] < 0) continue;
-#pragma unroll
-      for (int g = 0; g < WG_CO; ++g)
-        if (co0 + g < Cout) part[((size_t)chunk * Cout + co0 + g) * rowlen + eidx[e]] = acc[e][g];
+    __syncthreads();
+    for (int o = threadIdx.x; o < entries * 4; o += IT_THREADS) {
+      const int e = o >> 2, c = o & 3;
+      float sm = 0.f;
+      for (int q = 0; q < slices; ++q) sm += xs[((size_t)q * entries + e) * 4 + c];
+      const int co = co0 + 4 * g4 + c;
+      if (co < Cout) part[((size_t)chunk * Cout + co) * rowlen + e] = sm;
     }
   }
-  if (threadIdx.x >= IT_THREADS - WG_CO) {
-    const int g = threadIdx.x - (IT_THREADS - WG_CO);
-    if (co0 + g < Cout) part[((size_t)chunk * Cout + co0 + g) * rowlen + entries] = bacc;
+  // thread i staged channel i / WG_TL + q * (IT_THREADS / WG_TL) as its q-th value: gather the per-thread sums per channel
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < DV; ++q) ds[q * IT_THREADS + threadIdx.x] = bsum[q];
+  __syncthreads();
+  if (threadIdx.x < CO) {
+    constexpr int R = IT_THREADS / WG_TL;          // channels per round of IT_THREADS values
+    const int g = threadIdx.x, q = g / R, t0 = (g % R) * WG_TL;
+    float sm = 0.f;
+    for (int t = 0; t < WG_TL; ++t) sm += ds[q * IT_THREADS + t0 + t];
+    if (co0 + g < Cout) part[((size_t)chunk * Cout + co0 + g) * rowlen + entries] = sm;
   }
 }
 
@@ -261,7 +295,7 @@ extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* 
   const int Lout = mural_op_convg_out_length(Lin, K, stride, pad, up);
   MURAL_REQUIRE(Lout >= 1, "convg_bwd: bad geometry");
   MURAL_REQUIRE(dy && x && W && dW && part, "convg_bwd: null pointer");
-  MURAL_REQUIRE(Cin * K <= WG_E * IT_THREADS, "convg_bwd: Cin * K = %d exceeds %d", Cin * K, WG_E * IT_THREADS);
+  MURAL_REQUIRE(Cin * K <= 4 * IT_THREADS, "convg_bwd: Cin * K = %d exceeds %d", Cin * K, 4 * IT_THREADS);
   hipStream_t st = (hipStream_t)stream;
   if (dx) {
     const int64_t rows = B * Lin;
@@ -275,17 +309,40 @@ extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* 
       hipLaunchKernelGGL(conv_dgrad_kernel<8>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad, up);
     MURAL_HIP_CHECK(hipGetLastError());
   }
-  const int tiles_per_row = (Lout + WG_TL - 1) / WG_TL;
+  const int entries = Cin * K;
+  const int co = Cout % 16 == 0 ? 16 : (Cout % 8 == 0 ? 8 : 4);
+  // tile length: fewest visits per row, a visit priced as one latency + its share of FMAs; the tile must leave 5 workgroups per CU
+  int tl = 64;
+  size_t lds = 0;
+  {
+    double best = 0.0;
+    for (int cand = 256; cand >= 64; cand >>= 1) {
+      size_t fl = (size_t)Cin * (((cand - 1) * stride + K) | 1);
+      if (fl < (size_t)IT_THREADS * WG_EP * 4) fl = (size_t)IT_THREADS * WG_EP * 4;      // slice reduction scratch: [slices][entries][4]
+      const size_t bytes = (fl + (size_t)co * cand) * sizeof(float);
+      if (cand > 64 && bytes > 32 * 1024) continue;
+      const double cost = (double)((Lout + cand - 1) / cand) * (1.0 + cand / 256.0);
+      if (lds == 0 || cost < best) { best = cost; tl = cand; lds = bytes; }
+    }
+  }
+  MURAL_REQUIRE(lds <= 64 * 1024, "convg_bwd: input tile of %zu bytes exceeds 64 KB of LDS", lds);
+  const int tiles_per_row = (Lout + tl - 1) / tl;
   const int64_t tiles = B * tiles_per_row;
   const int chunks = (int)(tiles < WG_CHUNKS ? tiles : WG_CHUNKS);
-  const int entries = Cin * K;
   MURAL_REQUIRE(part_floats >= (size_t)chunks * Cout * (entries + 1), "convg_bwd: scratch too small");
-  size_t lds_floats = (size_t)Cin * (((WG_TL - 1) * stride + K) | 1);
-  if (lds_floats < (size_t)IT_THREADS * WG_CO) lds_floats = (size_t)IT_THREADS * WG_CO;      // slice reduction scratch
-  const size_t lds = (lds_floats + WG_CO * WG_TL) * sizeof(float);
-  MURAL_REQUIRE(lds <= 64 * 1024, "convg_bwd: input tile of %zu bytes exceeds 64 KB of LDS", lds);
-  hipLaunchKernelGGL(conv_wgrad_kernel, dim3(chunks, (Cout + WG_CO - 1) / WG_CO), dim3(IT_THREADS), lds, st, dy, x, part, (int)B, Cin,
-                     Lin, Cout, Lout, K, stride, pad, up, tiles_per_row, tiles, chunks);
+  const dim3 wgrid(chunks, (Cout + co - 1) / co);
+#define MURAL_WGRAD(CO_, TL_)                                                                                                        \
+  hipLaunchKernelGGL((conv_wgrad_kernel<CO_, TL_>), wgrid, dim3(IT_THREADS), lds, st, dy, x, part, (int)B, Cin, Lin, Cout, Lout, K, \
+                     stride, pad, up, tiles_per_row, tiles, chunks)
+#define MURAL_WGRAD_TL(CO_)                \
+  if (tl == 256) MURAL_WGRAD(CO_, 256);    \
+  else if (tl == 128) MURAL_WGRAD(CO_, 128); \
+  else MURAL_WGRAD(CO_, 64)
+  if (co == 16) { MURAL_WGRAD_TL(16); }
+  else if (co == 8) { MURAL_WGRAD_TL(8); }
+  else { MURAL_WGRAD_TL(4); }
+#undef MURAL_WGRAD_TL
+#undef MURAL_WGRAD
   MURAL_HIP_CHECK(hipGetLastError());
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((Cout * (entries + 1) + 3) / 4), dim3(IT_THREADS), 0, st, part, chunks, Cout,
                      entries, dW, db);

@@ -40,8 +40,10 @@ torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
     loss = step()
+t_host = (time.perf_counter() - t0) / steps
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+print("host enqueue %.2f ms/step (the device drains the queue in %.2f ms/step)" % (t_host * 1e3, dt * 1e3))
 # forward 113.4 MFLOP/position; backward = input + weight gradients of every conv ~ 2x (the first conv has no input gradient)
 print("UNet_Small train step B=%d L=8000: %.1f ms/step = %.1f positions/s; loss %.3f; %.1f TFLOP/s algorithmic (3 x 113.4 MFLOP/pos)"
       % (B, dt * 1e3, B / dt, loss.item(), B / dt * 3 * 113.4e6 / 1e12))
