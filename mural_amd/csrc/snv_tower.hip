@@ -123,36 +123,38 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   const int64_t n_tiles = (args.n + P - 1) / P;
   // Tower-parallel launch (small batches): workgroup 2t runs the large tower of tile t, workgroup 2t + 1 its mid tower, and
   // whichever of the two finishes last runs the head -- the latency of a call is ONE tower, not the sum of both.
-  const bool tpar = PHASE == 0 && args.par != 0;
-  const int tw_first = tpar ? (int)(blockIdx.x & 1u) : args.tw_first;
-  const int tw_last = tpar ? tw_first : args.tw_last;
-  const int64_t tile0 = tpar ? (int64_t)(blockIdx.x >> 1) : (int64_t)blockIdx.x;
-  const int64_t tile_step = tpar ? (int64_t)(gridDim.x >> 1) : (int64_t)gridDim.x;
+  // (PHASE 3 = the stages of PHASE 0 in this launch shape.  The other phases must compile to exactly what they were: the
+  // first-stage kernel sits at 254 of 256 VGPRs, and naming these values in locals was enough to make it spill 84 of them.)
+  constexpr bool TPAR = PHASE == 3;
+#define TW_FIRST (TPAR ? (int)(blockIdx.x & 1u) : args.tw_first)
+#define TW_LAST (TPAR ? (int)(blockIdx.x & 1u) : args.tw_last)
+#define TILE0 (TPAR ? (int64_t)(blockIdx.x >> 1) : (int64_t)blockIdx.x)
+#define TILE_STEP (TPAR ? (gridDim.x >> 1) : gridDim.x)
 
   // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator
   // layout, one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
   f32x4 xres[SNV_NB2MAX];
   X0Plan xplan;
   if (PHASE == 1) {
-    xplan = x0_plan(args, tw_first, cgp, n16);
-    request_x0_planned(args, xplan, xres, tile0, tw_first, n_tiles, chv);
+    xplan = x0_plan(args, TW_FIRST, cgp, n16);
+    request_x0_planned(args, xplan, xres, TILE0, TW_FIRST, n_tiles, chv);
   } else if (PHASE != 2) {
-    request_x0(args, xres, tile0, tw_first, n_tiles, cgp, n16, chv);
+    request_x0(args, xres, TILE0, TW_FIRST, n_tiles, cgp, n16, chv);
   }
   const bool do_head = args.tw_last == 1 && PHASE != 1;
   // a first-stage launch runs one tower and one stage: its lane addressing / validity mask is tile-invariant
-  const StageAddr sa_first = stage_setup(args.geom[tw_first], 0, P, n16, kk, mb, cgp);
+  const StageAddr sa_first = stage_setup(args.geom[TW_FIRST], 0, P, n16, kk, mb, cgp);
   // a short-stage launch runs one tower through stages 1 and 2: both lane maps are tile-invariant as well
   StageAddr sa_s1 = sa_first, sa_s2 = sa_first;
   if (PHASE == 2) {
-    sa_s1 = stage_setup(args.geom[tw_first], 1, P, n16, kk, mb, cgp);
-    sa_s2 = stage_setup(args.geom[tw_first], 2, P, n16, kk, mb, cgp);
+    sa_s1 = stage_setup(args.geom[TW_FIRST], 1, P, n16, kk, mb, cgp);
+    sa_s2 = stage_setup(args.geom[TW_FIRST], 2, P, n16, kk, mb, cgp);
   }
 
   float a_cur[SNV_KSTEPS];
-  for (int64_t tile = tile0; tile < n_tiles; tile += tile_step) {
+  for (int64_t tile = TILE0; tile < n_tiles; tile += TILE_STEP) {
     const int64_t row0 = tile * P;
-    if (do_head && !tpar && tid < P * args.n_class) {   // local-branch logits of this tile -> LDS (third logit vector)
+    if (do_head && !TPAR && tid < P * args.n_class) {   // local-branch logits of this tile -> LDS (third logit vector)
       const int p = tid / args.n_class, k = tid - p * args.n_class;
       float v = 0.f;
       if (args.has_local && row0 + p < args.n) v = args.local_logits[(row0 + p) * args.n_class + k];
@@ -164,21 +166,21 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       }
     }
 
-    for (int tw_i = tw_first; tw_i <= tw_last; ++tw_i) {
+    for (int tw_i = TW_FIRST; tw_i <= TW_LAST; ++tw_i) {
       const TowerGeom& g = args.geom[tw_i];
       const TowerDev& tw = args.tw[tw_i];
       const float* tpar = par + tw_i * par_stride;
 
       // weights of the first conv: issued now, consumed after the entry barrier.  A stage-split launch runs one tower, so
       // from its second tile on they are already there: the last layer of a tile prefetches the first layer's fragments.
-      if (PHASE == 0 || tile == tile0) {
+      if (PHASE == 0 || PHASE == 3 || tile == TILE0) {
         const float* wf = tw.wfrag + (size_t)(PHASE == 2 ? 4 : 0) * SNV_WFRAG + (size_t)mb * SNV_KSTEPS * 64 + lane;
 #pragma unroll
         for (int s = 0; s < SNV_KSTEPS; ++s) a_cur[s] = wf[s * 64];
       }
 
       // -------------------------------------------------------------- entry: BN(ReLU(x0)) -> bufA, x0 stays in xres
-      StageAddr sa = (PHASE == 1 || tw_i == tw_first) ? sa_first : stage_setup(g, 0, P, n16, kk, mb, cgp);
+      StageAddr sa = (PHASE == 1 || tw_i == TW_FIRST) ? sa_first : stage_setup(g, 0, P, n16, kk, mb, cgp);
       if (PHASE != 2) {
         const f32x4 es = ld4(tpar + EX_RB1_ENTRY * 32 + chv), et = ld4(tpar + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv);
         char* A = reinterpret_cast<char*>(bufA);
@@ -218,7 +220,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         } else if (layer == 4 || layer == 9) {
           // a first-stage launch ends with this pooling: the residual registers are dead, so the next tile's stage-1
           // activations are requested now and their HBM latency hides under the pooling instead of stalling the next entry
-          if (PHASE == 1) request_x0_planned(args, xplan, xres, tile + tile_step, tw_i, n_tiles, chv);
+          if (PHASE == 1) request_x0_planned(args, xplan, xres, tile + TILE_STEP, tw_i, n_tiles, chv);
           // max-pool (raw y in bufA) + BN (no ReLU) -> bufB in the next stage's geometry
           const int si = st - 1;  // input stage
           const int Lin = g.L[si], Lout = g.L[st], ScI = g.Sc[si], ScO = g.Sc[st];
@@ -316,7 +318,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       // -------------------------------------------------------------- global max per (position, channel)
       // (the residual registers are dead after the last conv: request the next tower's stage-1 activations now)
       if (PHASE != 2)
-        request_x0(args, xres, tw_i < tw_last ? tile : tile + tile_step, tw_i < tw_last ? tw_i + 1 : tw_first, n_tiles,
+        request_x0(args, xres, tw_i < TW_LAST ? tile : tile + TILE_STEP, tw_i < TW_LAST ? tw_i + 1 : TW_FIRST, n_tiles,
                    cgp, n16, chv);
       {
         const int L4 = g.L[2], Sc4 = g.Sc[2];
@@ -340,9 +342,9 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
 
     if (PHASE == 1) continue;
     // ------------------------------------------------------------------ BN+Linear per tower (BN folded on the host)
-    for (int t = tid; t < (tw_last - tw_first + 1) * P * args.n_class; t += SNV_THREADS) {
+    for (int t = tid; t < (TW_LAST - TW_FIRST + 1) * P * args.n_class; t += SNV_THREADS) {
       const int k = t % args.n_class;
-      const int tp = tw_first * P + t / args.n_class;  // tower * P + p
+      const int tp = TW_FIRST * P + t / args.n_class;  // tower * P + p
       const int tw_i = tp / P;
       const float* w = par + tw_i * par_stride + 2 * EX_COUNT * SNV_C + k * SNV_C;
       const float* f = feat + tp * SNV_C;
@@ -360,16 +362,16 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
     lds_barrier();
     SNV_STAMP(25);   // fc
 
-    if (tpar) {
+    if (TPAR) {
       // publish this tower's logits; the second workgroup of the tile to get here gathers both and runs the head
-      float* mine = tw_first == 0 ? args.xlogit : args.xlogit2;
+      float* mine = TW_FIRST == 0 ? args.xlogit : args.xlogit2;
       if (tid < P * args.n_class) {
         const int p = tid / args.n_class, k = tid - p * args.n_class;
-        if (row0 + p < args.n) mine[(row0 + p) * SNV_MAXCLASS + k] = logit[(tw_first * P + p) * SNV_MAXCLASS + k];
+        if (row0 + p < args.n) mine[(row0 + p) * SNV_MAXCLASS + k] = logit[(TW_FIRST * P + p) * SNV_MAXCLASS + k];
       }
       __threadfence();
       __syncthreads();
-      float* flag = feat + (1 - tw_first) * P * SNV_C;   // the other tower's slot of feat is unused by this workgroup
+      float* flag = feat + (1 - TW_FIRST) * P * SNV_C;   // the other tower's slot of feat is unused by this workgroup
       if (tid == 0) {
         const int old = atomicAdd(&args.tile_count[tile], 1);
         __threadfence();
@@ -437,6 +439,11 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   }
 }
 
+#undef TW_FIRST
+#undef TW_LAST
+#undef TILE0
+#undef TILE_STEP
+
 // ---------------------------------------------------------------------------------------------
 // host launch (+ optional per-launch HIP-event timing of this kernel for bench.py's roofline line)
 // ---------------------------------------------------------------------------------------------
@@ -483,7 +490,7 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
     if (a.phase == 1 && v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
   }
   static DynLdsOnce big_lds;
-  if (int rc = big_lds.ensure(&snv_towers_fused<0>, &snv_towers_fused<1>, &snv_towers_fused<2>)) return rc;
+  if (int rc = big_lds.ensure(&snv_towers_fused<0>, &snv_towers_fused<1>, &snv_towers_fused<2>, &snv_towers_fused<3>)) return rc;
   hipEvent_t e0 = nullptr, e1 = nullptr;
   if (g_prof.on) {
     while (g_prof.ev.size() < g_prof.used + 2) {
@@ -496,7 +503,8 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
     g_prof.used += 2;
     MURAL_HIP_CHECK(hipEventRecord(e0, stream));
   }
-  if (a.phase == 1) hipLaunchKernelGGL(snv_towers_fused<1>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
+  if (a.par) hipLaunchKernelGGL(snv_towers_fused<3>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
+  else if (a.phase == 1) hipLaunchKernelGGL(snv_towers_fused<1>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
   else if (a.phase == 2) hipLaunchKernelGGL(snv_towers_fused<2>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
   else hipLaunchKernelGGL(snv_towers_fused<0>, dim3(grid), dim3(SNV_THREADS), lds_bytes, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());

@@ -1,4 +1,4 @@
-"""Whole-step hipGraph replay of the SNV training step.
+"""Whole-step hipGraph replay of the training step (``GraphedTrainStep``: SNV models, ``GraphedIndelTrainStep``: UNet_Small).
 
 The eager step (MuRaL/training.py:424-436: forward, CE-sum loss, zero_grad, backward, clip_grad_norm_, optimizer.step) is
 about 300 kernel launches behind ~4 ms of Python; once the kernels are fast the host is the bottleneck.  ``GraphedTrainStep``
@@ -10,6 +10,9 @@ Differences from a plain loop, all of them the usual graph-capture contract:
   * dropout masks: the host-drawn seeds are baked into the graph, a device-resident counter advanced inside the graph is
     added to them, so every replay draws new masks (``train_ops.set_device_seed``);
   * the encoding check of ``distal_x`` (ValueError on a non-MuRaL column) is read back after the replay, one step late.
+
+The INDEL step (MuRaL/training.py:404-450 over model_indel.py:151-176) is ~500 small launches behind 7-11 ms of Python autograd
+glue, depending on the host; its replay is bound by the device alone.
 """
 import torch
 
@@ -18,9 +21,13 @@ from .model import train_ops as T
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, criterion, cont_x, cat_x, distal_x, y, max_norm=10.0, warmup=3):
+        self.cont, self.cat = (None if t is None else t.clone() for t in (cont_x, cat_x))
+        self._capture(model, optimizer, criterion, distal_x, y, max_norm, warmup)
+
+    def _capture(self, model, optimizer, criterion, distal_x, y, max_norm, warmup):
         dev = distal_x.device
         self.model, self.opt, self.crit, self.max_norm = model, optimizer, criterion, max_norm
-        self.cont, self.cat, self.x, self.y = (t.clone() for t in (cont_x, cat_x, distal_x, y))
+        self.x, self.y = distal_x.clone(), y.clone()
         self.seed = torch.zeros(1, dtype=torch.int64, device=dev)
         self.loss = None
         self._status = []
@@ -47,18 +54,24 @@ class GraphedTrainStep:
 
     def _eager_step(self):
         self.seed += 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF       # new dropout masks every step (odd 63-bit increment)
-        out = self.model((self.cont, self.cat), self.x)
+        out = self._forward()
         self.loss = self.crit(out, self.y)
         self.opt.zero_grad(set_to_none=False)
         self.loss.backward()
         torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
         self.opt.step()
 
+    def _forward(self):
+        return self.model((self.cont, self.cat), self.x)
+
     def __call__(self, cont_x, cat_x, distal_x, y):
         """Run one training step on this batch; returns the (device) loss tensor of the step."""
-        self._check()
         self.cont.copy_(cont_x, non_blocking=True)
         self.cat.copy_(cat_x, non_blocking=True)
+        return self._replay(distal_x, y)
+
+    def _replay(self, distal_x, y):
+        self._check()
         self.x.copy_(distal_x, non_blocking=True)
         self.y.copy_(y, non_blocking=True)
         self.graph.replay()
@@ -84,6 +97,19 @@ class GraphedTrainStep:
         """Wait for the last replay and raise its deferred input check, if any."""
         torch.cuda.synchronize()
         self._check()
+
+
+class GraphedIndelTrainStep(GraphedTrainStep):
+    """The same for ``UNet_Small`` (one input tensor): ``step = GraphedIndelTrainStep(model, opt, crit, x, y); loss = step(x, y)``."""
+
+    def __init__(self, model, optimizer, criterion, x, y, max_norm=10.0, warmup=3):
+        self._capture(model, optimizer, criterion, x, y, max_norm, warmup)
+
+    def _forward(self):
+        return self.model(self.x)
+
+    def __call__(self, x, y):
+        return self._replay(x, y)
 
 
 def clip_grad_norm_(model, max_norm):

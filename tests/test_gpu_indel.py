@@ -168,6 +168,44 @@ def test_train_mode_updates_and_eval_after_training():
     assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
+def test_graphed_indel_train_step_matches_eager():
+    """hipGraph replay of the whole UNet_Small step (mural_amd.train.GraphedIndelTrainStep) == the eager step: same loss and
+    parameters after the same batches (dropout off, plain SGD: see test_gpu_train.test_graphed_train_step_matches_eager), BatchNorm
+    counters advanced by the replays, and the eval-mode program picks up the replayed weights."""
+    from mural_amd.train import GraphedIndelTrainStep
+    fx = U.load("indel_train_rev.npz")
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    x, y = U.onehot(fx["codes"]).cuda(), torch.from_numpy(fx["y"]).cuda()
+    crit = torch.nn.CrossEntropyLoss(reduction="sum")
+
+    def make():
+        model = product_from(fx)
+        model.load_state_dict(U.indel_state_for(fx, orc), strict=True)
+        model = model.cuda().train()
+        model.out_fc[1].p = 0.0
+        return model, torch.optim.SGD(model.parameters(), lr=1e-3, momentum=0.9)
+
+    eager, opt_e = make()
+    for _ in range(3 + 2):     # GraphedIndelTrainStep: 3 eager warm-up steps + 2 replays
+        _, loss = _train_step(eager, x, y)
+        torch.nn.utils.clip_grad_norm_(eager.parameters(), 10)
+        opt_e.step()
+    graphed, opt_g = make()
+    step = GraphedIndelTrainStep(graphed, opt_g, crit, x, y)
+    for _ in range(2):
+        loss_g = step(x, y)
+    step.finish()
+    assert abs(loss_g.item() - loss.item()) <= 1e-3 * abs(loss.item())
+    for (k, p), (_, q) in zip(eager.named_parameters(), graphed.named_parameters()):
+        assert float((p.detach() - q.detach()).abs().max()) <= 2e-4 * (float(p.detach().abs().max()) + 1e-3), k
+    assert int(graphed.conv[1].num_batches_tracked) == int(eager.conv[1].num_batches_tracked)
+    graphed.eval()
+    eager.eval()
+    with torch.no_grad():
+        a, b = graphed(x).cpu().numpy(), eager(x).cpu().numpy()
+    assert np.abs(a - b).max() <= 1e-4 * max(1.0, np.abs(b).max())
+
+
 def test_generic_conv1d_kernels_match_torch_fp64():
     """Both engines of the generic Conv1d behind the U-Net (vector ALU, csrc/conv1d.hip; MFMA implicit GEMM, csrc/conv1d_mfma.hip)
     against torch in float64 over the layer geometries of UNet_Small: strides 4 / 5 / 2, upsampling 2 / 5, k = 7 / 5 / 1,
