@@ -412,6 +412,20 @@ size_t mural_op_convg_bwd_scratch(int32_t Cin, int32_t Cout, int32_t K);        
 int mural_op_convg_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                        int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
                        size_t part_floats, void* stream);
+/* The U-Net's unit in one call per direction: z = act(BatchNorm1d(Conv1d(upsample_up(x)))) [+ res1] [+ res2] in training mode
+ * (reference MuRaL/model/model_indel.py:6-19, :117-123 under model.train(): nn.Conv1d -> nn.BatchNorm1d [-> nn.SiLU / nn.ReLU] and the
+ * residual adds around them).  act: 0 none, 1 ReLU, 2 SiLU, 3 Softplus.  y0 [B][Cout][Lout] receives the conv output and state
+ * [4][Cout] = scale | shift | mean | invstd (both saved for the backward); acc: zeroed [MURAL_BN_SLOTS][2][Cout] doubles; running
+ * statistics updated in place like nn.BatchNorm1d (momentum, unbiased variance).  The backward takes dz (the residuals' gradients are
+ * dz itself), a fresh zeroed acc, a scratch dy0 [B][Cout][Lout] and the part scratch of mural_op_convg_bwd. */
+int mural_op_convg_bn_fwd(const float* x, const float* W, const float* bias, float* wt, float* y0, int64_t B, int32_t Cin,
+                          int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, const float* gamma,
+                          const float* beta, float eps, float momentum, float* running_mean, float* running_var, double* acc,
+                          float* state, int32_t act, const float* res1, const float* res2, float* z, void* stream);
+int mural_op_convg_bn_bwd(const float* dz, const float* x, const float* W, const float* y0, const float* state, const float* gamma,
+                          int64_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up,
+                          int32_t act, double* acc, float* dy0, float* dx, float* dW, float* db, float* dgamma, float* dbeta,
+                          float* part, size_t part_floats, void* stream);
 /* kind: 1 ReLU, 2 SiLU, 3 Softplus (beta 1, threshold 20); backward takes the forward INPUT x */
 int mural_op_act_fwd(const float* x, int64_t n, int32_t kind, float* y, void* stream);
 int mural_op_act_bwd(const float* dy, const float* x, int64_t n, int32_t kind, float* dx, void* stream);

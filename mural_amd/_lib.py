@@ -104,6 +104,10 @@ PROTOTYPES = {
     "mural_op_convg_fwd": (C.c_int, [VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP]),
     "mural_op_convg_bwd_scratch": (C.c_size_t, [I32, I32, I32]),
     "mural_op_convg_bwd": (C.c_int, [VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, C.c_size_t, VP]),
+    "mural_op_convg_bn_fwd": (C.c_int, [VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP,
+                                        VP, I32, VP, VP, VP, VP]),
+    "mural_op_convg_bn_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP,
+                                        C.c_size_t, VP]),
     "mural_op_act_fwd": (C.c_int, [VP, I64, I32, VP, VP]),
     "mural_op_act_bwd": (C.c_int, [VP, VP, I64, I32, VP, VP]),
     "mural_op_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]),

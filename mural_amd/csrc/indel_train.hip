@@ -253,6 +253,128 @@ __global__ __launch_bounds__(IT_THREADS) void act_bwd_kernel(const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < n; i += step) dx[i] = dy[i] * act_d(x[i], kind);
 }
 
+// ------------------------------------------------------------------------------------------------ conv -> BatchNorm -> act
+// The U-Net's unit is Conv1d -> BatchNorm1d (batch statistics) [-> SiLU / ReLU] [+ residuals] (model_indel.py:6-19, :117-123): one
+// launch finalises the statistics (every workgroup derives scale / shift of all <= 96 channels from the batch sums, workgroup 0
+// also writes the state and the running statistics), applies BatchNorm and the activation and adds the residuals; the backward
+// re-derives the activation's slope from the saved conv output, so the BatchNorm output is never stored.
+constexpr int CB_SLOTS = MURAL_BN_SLOTS;
+
+__device__ __forceinline__ double cb_slot_sum(const double* __restrict__ acc, int C, int which, int c) {
+  double t = 0.0;
+  for (int k = 0; k < CB_SLOTS; ++k) t += acc[((size_t)k * 2 + which) * C + c];
+  return t;
+}
+
+// z = act(scale * y + shift) [+ res1] [+ res2];  state = scale | shift | mean | invstd ([4][C])
+__global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* __restrict__ y, int64_t total, int C, int L,
+                                                                   const double* __restrict__ acc, double n,
+                                                                   const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                   float eps, float momentum, float* __restrict__ running_mean,
+                                                                   float* __restrict__ running_var, float* __restrict__ state, int act,
+                                                                   const float* __restrict__ res1, const float* __restrict__ res2,
+                                                                   float* __restrict__ z) {
+  extern __shared__ float cst[];      // [C][2] scale, shift
+  for (int c = threadIdx.x; c < C; c += IT_THREADS) {
+    const double mean = cb_slot_sum(acc, C, 0, c) / n;
+    double var = cb_slot_sum(acc, C, 1, c) / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)eps);
+    const float sc = (float)(gamma[c] * invstd), sh = (float)(beta[c] - mean * gamma[c] * invstd);
+    cst[2 * c] = sc;
+    cst[2 * c + 1] = sh;
+    if (blockIdx.x == 0) {
+      state[c] = sc;
+      state[C + c] = sh;
+      state[2 * C + c] = (float)mean;
+      state[3 * C + c] = (float)invstd;
+      if (running_mean) {
+        const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+        running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+        running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+      }
+    }
+  }
+  __syncthreads();
+  const int64_t step = (int64_t)gridDim.x * IT_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < total; i += step) {
+    const int c = (int)((i / L) % C);
+    float v = fmaf(cst[2 * c], y[i], cst[2 * c + 1]);
+    if (act) v = act_f(v, act);
+    if (res1) v += res1[i];
+    if (res2) v += res2[i];
+    z[i] = v;
+  }
+}
+
+// sums over (B, L) of g = dz * act'(u) and g * xhat per channel, u = scale * y + shift, xhat = (y - mean) * invstd
+__global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_reduce_kernel(const float* __restrict__ dz, const float* __restrict__ y, int B,
+                                                                        int C, int L, const float* __restrict__ state, int act,
+                                                                        double* __restrict__ acc) {
+  const int c = blockIdx.x;
+  const float sc = state[c], sh = state[C + c], mu = state[2 * C + c], is = state[3 * C + c];
+  double a = 0.0, bq = 0.0;
+  const int64_t per = (int64_t)B * L;
+  for (int64_t i = (int64_t)blockIdx.y * IT_THREADS + threadIdx.x; i < per; i += (int64_t)gridDim.y * IT_THREADS) {
+    const int64_t b = i / L;
+    const int l = (int)(i - b * L);
+    const size_t o = (size_t)(b * C + c) * L + l;
+    const float v = y[o];
+    float g = dz[o];
+    if (act) g *= act_d(fmaf(sc, v, sh), act);
+    a += g;
+    bq += (double)g * ((v - mu) * is);
+  }
+  __shared__ double sh2[2][IT_THREADS];
+  sh2[0][threadIdx.x] = a;
+  sh2[1][threadIdx.x] = bq;
+  __syncthreads();
+  for (int off = IT_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      sh2[0][threadIdx.x] += sh2[0][threadIdx.x + off];
+      sh2[1][threadIdx.x] += sh2[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {   // accumulator copy by workgroup: same-address atomics serialise in L2
+    double* slot = acc + (size_t)(blockIdx.y % CB_SLOTS) * 2 * C;
+    atomicAdd(&slot[c], sh2[0][0]);
+    atomicAdd(&slot[C + c], sh2[1][0]);
+  }
+}
+
+// dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)); workgroup 0 also writes dgamma = sum(g * xhat), dbeta = sum(g)
+__global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
+                                                                       int64_t total, int C, int L, const float* __restrict__ state,
+                                                                       const float* __restrict__ gamma, const double* __restrict__ acc,
+                                                                       double n, int act, float* __restrict__ dy,
+                                                                       float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  extern __shared__ float cst[];      // [C][6]: gamma * invstd, mean(g), mean(g * xhat), mean, scale, shift
+  for (int c = threadIdx.x; c < C; c += IT_THREADS) {
+    const double s1 = cb_slot_sum(acc, C, 0, c), s2 = cb_slot_sum(acc, C, 1, c);
+    cst[6 * c + 0] = gamma[c] * state[3 * C + c];
+    cst[6 * c + 1] = (float)(s1 / n);
+    cst[6 * c + 2] = (float)(s2 / n);
+    cst[6 * c + 3] = state[2 * C + c];
+    cst[6 * c + 4] = state[c];
+    cst[6 * c + 5] = state[C + c];
+    if (blockIdx.x == 0) {
+      dgamma[c] = (float)s2;
+      dbeta[c] = (float)s1;
+    }
+  }
+  __syncthreads();
+  const int64_t step = (int64_t)gridDim.x * IT_THREADS;
+  for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < total; i += step) {
+    const int c = (int)((i / L) % C);
+    const float v = y[i];
+    float g = dz[i];
+    if (act) g *= act_d(fmaf(cst[6 * c + 4], v, cst[6 * c + 5]), act);
+    const float xh = (v - cst[6 * c + 3]) * state[3 * C + c];
+    dy[i] = cst[6 * c + 0] * (g - cst[6 * c + 1] - xh * cst[6 * c + 2]);
+  }
+}
+
 int out_length(int Lin, int K, int stride, int pad, int up) { return (Lin * up + 2 * pad - K) / stride + 1; }
 
 }  // namespace
@@ -366,4 +488,49 @@ extern "C" int mural_op_act_bwd(const float* dy, const float* x, int64_t n, int3
   hipLaunchKernelGGL(act_bwd_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(IT_THREADS), 0, (hipStream_t)stream, dy, x, n, kind, dx);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
+}
+
+// z = act(BatchNorm(Conv1d(upsample_up(x)))) [+ res1] [+ res2] with batch statistics, running statistics updated in place (momentum
+// like nn.BatchNorm1d).  y0 receives the conv output (saved for the backward), state [4][Cout] = scale | shift | mean | invstd,
+// acc = zeroed accumulator block [MURAL_BN_SLOTS][2][Cout] of doubles, wt = scratch of Cout * Cin * K floats.
+extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float* bias, float* wt, float* y0, int64_t B, int32_t Cin,
+                                     int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, const float* gamma,
+                                     const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                     double* acc, float* state, int32_t act, const float* res1, const float* res2, float* z,
+                                     void* stream) {
+  MURAL_REQUIRE(act >= 0 && act <= 3, "convg_bn_fwd: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
+  MURAL_REQUIRE(gamma && beta && acc && state && z && y0, "convg_bn_fwd: null pointer");
+  if (int rc = mural_op_convg_fwd(x, W, bias, wt, y0, B, Cin, Lin, Cout, K, stride, pad, up, stream)) return rc;
+  if (B == 0) return MURAL_OK;
+  const int Lout = out_length(Lin, K, stride, pad, up);
+  if (int rc = mural_op_bn_stats(y0, B, Cout, Lout, 0, acc, stream)) return rc;
+  const int64_t total = B * Cout * Lout;
+  int64_t g = (total + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
+  hipLaunchKernelGGL(bn_post_apply_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(IT_THREADS), (size_t)Cout * 2 * sizeof(float),
+                     (hipStream_t)stream, y0, total, Cout, Lout, acc, (double)(B * Lout), gamma, beta, eps, momentum, running_mean,
+                     running_var, state, act, res1, res2, z);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+// backward of the same unit from dz (the gradient of z; the residuals' gradients are dz itself): dgamma, dbeta, then the conv's dx
+// (optional), dW, db (optional).  acc = zeroed accumulator block, dy0 = scratch [B][Cout][Lout], part as for mural_op_convg_bwd.
+extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const float* W, const float* y0, const float* state,
+                                     const float* gamma, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride,
+                                     int32_t pad, int32_t up, int32_t act, double* acc, float* dy0, float* dx, float* dW, float* db,
+                                     float* dgamma, float* dbeta, float* part, size_t part_floats, void* stream) {
+  MURAL_REQUIRE(act >= 0 && act <= 3, "convg_bn_bwd: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
+  MURAL_REQUIRE(B >= 1 && dz && y0 && state && gamma && acc && dy0 && dgamma && dbeta, "convg_bn_bwd: null pointer / empty batch");
+  const int Lout = mural_op_convg_out_length(Lin, K, stride, pad, up);
+  MURAL_REQUIRE(Lout >= 1, "convg_bn_bwd: bad geometry");
+  hipStream_t st = (hipStream_t)stream;
+  const int64_t per = B * Lout, total = per * Cout;
+  int gy = (int)((per + IT_THREADS * 8 - 1) / (IT_THREADS * 8));
+  gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
+  hipLaunchKernelGGL(bn_post_bwd_reduce_kernel, dim3(Cout, gy), dim3(IT_THREADS), 0, st, dz, y0, (int)B, Cout, Lout, state, act, acc);
+  int64_t g = (total + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
+  hipLaunchKernelGGL(bn_post_bwd_apply_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(IT_THREADS), (size_t)Cout * 6 * sizeof(float), st,
+                     dz, y0, total, Cout, Lout, state, gamma, acc, (double)per, act, dy0, dgamma, dbeta);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return mural_op_convg_bwd(dy0, x, W, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
 }

@@ -109,6 +109,59 @@ class Act(torch.autograd.Function):
         return dx, None
 
 
+class ConvBn(torch.autograd.Function):
+    """z = act(BatchNorm1d(Conv1d(Upsample(up)(x)))) [+ res1] [+ res2] in training mode: the unit of the U-Net (model_indel.py:6-19,
+    :117-123) as ONE autograd node and one library call per direction (``mural_op_convg_bn_fwd`` / ``_bwd``).  The BatchNorm output
+    is not stored: the backward re-derives the activation's slope from the saved conv output."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, gamma, beta, bn, stride, pad, up, act, res1, res2):
+        x = x.contiguous()
+        B, Cin, Lin = x.shape
+        Cout, _, K = weight.shape
+        dev = x.device
+        Lout = int(_lib.lib().mural_op_convg_out_length(Lin, K, stride, pad, up))
+        if Lout < 1:
+            raise ValueError(f"Conv1d: kernel {K} / padding {pad} do not fit an input of length {Lin * up}")
+        y0 = torch.empty((B, Cout, Lout), dtype=torch.float32, device=dev)
+        z = torch.empty_like(y0)
+        wt = torch.empty(weight.numel(), dtype=torch.float32, device=dev)
+        state = torch.empty((4, Cout), dtype=torch.float32, device=dev)
+        for r in (res1, res2):
+            if r is not None and (r.shape != y0.shape or not r.is_contiguous() or r.dtype is not torch.float32):
+                raise ValueError("ConvBn: a residual must be a contiguous float32 tensor of the output's shape")
+        T._call("mural_op_convg_bn_fwd", x, T._f32(weight), None if bias is None else T._f32(bias), wt, y0, B, Cin, Lin, Cout, K, stride,
+                pad, up, T._f32(gamma), T._f32(beta), T.EPS, T.MOMENTUM, bn.running_mean, bn.running_var, T._bn_acc(Cout, dev), state,
+                act, res1, res2, z, T._stream(x))
+        T._bn_tick(bn)
+        ctx.save_for_backward(x, weight, y0, state, gamma)
+        ctx.geom = (stride, pad, up, act, bias is not None, res1 is not None, res2 is not None)
+        return z
+
+    @staticmethod
+    def backward(ctx, dz):
+        x, weight, y0, state, gamma = ctx.saved_tensors
+        stride, pad, up, act, has_bias, has_r1, has_r2 = ctx.geom
+        dz = dz.contiguous()
+        B, Cin, Lin = x.shape
+        Cout, _, K = weight.shape
+        dev = x.device
+        dx = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        dW = torch.empty_like(weight)
+        db = torch.empty(Cout, dtype=torch.float32, device=dev) if has_bias else None
+        dgb = torch.empty((2, Cout), dtype=torch.float32, device=dev)
+        dy0 = torch.empty_like(y0)
+        part = _bwd_scratch(dev, int(_lib.lib().mural_op_convg_bwd_scratch(Cin, Cout, K)))
+        T._call("mural_op_convg_bn_bwd", dz, x, T._f32(weight), y0, state, T._f32(gamma), B, Cin, Lin, Cout, K, stride, pad, up, act,
+                T._bn_acc(Cout, dev), dy0, dx, dW, db, dgb[0], dgb[1], part, part.numel(), T._stream(x))
+        return dx, dW, db, dgb[0], dgb[1], None, None, None, None, None, dz if has_r1 else None, dz if has_r2 else None
+
+
+def _cba(x, conv, bn, act=0, up=1, res1=None, res2=None):
+    return ConvBn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn, int(conv.stride[0]), int(conv.padding[0]), int(up), act,
+                        res1, res2)
+
+
 def _conv(x, conv, up=1):
     return Conv.apply(x, conv.weight, conv.bias, int(conv.stride[0]), int(conv.padding[0]), int(up))
 
@@ -117,29 +170,28 @@ def _bn(x, bn):
     return BatchNorm.apply(x, bn.weight, bn.bias, bn, False)
 
 
-def _conv_block(x, cb):
-    """x + BN(Conv1x1(SiLU(BN(Conv5(x)))))   (model_indel.py:6-19)"""
+def _conv_block(x, cb, skip=None):
+    """[skip +] x + BN(Conv1x1(SiLU(BN(Conv5(x)))))   (model_indel.py:6-19; the decoder adds the encoder's skip tensor, :168-170)"""
     seq = cb.conv
-    h = _bn(_conv(x, seq[0]), seq[1])
-    h = Act.apply(h, ACT_SILU)
-    return x + _bn(_conv(h, seq[3]), seq[4])
+    h = _cba(x, seq[0], seq[1], ACT_SILU)
+    return _cba(h, seq[3], seq[4], 0, res1=x, res2=skip)
 
 
 def unet_forward_train(model, x):
     """``UNet_Small.forward`` (model_indel.py:151-176) in training mode."""
     out = x
     if model.use_reverse:
-        sym = lambda t: _bn(_conv(t, model.conv[0]), model.conv[1])          # noqa: E731
+        sym = lambda t: _cba(t, model.conv[0], model.conv[1])                # noqa: E731
         out = sym(out) + sym(out.flip([1, 2])).flip([2])
     encodings = []
     for lconv, conv in zip(model.uplblocks, model.upblocks):
-        out = _conv_block(_bn(_conv(out, lconv[0]), lconv[1]), conv[0])
+        out = _conv_block(_cba(out, lconv[0], lconv[1]), conv[0])
         encodings.append(out)
     for enc, lconv, conv in zip(reversed(encodings[:-1]), model.downlblocks, model.downblocks):
         up = int(lconv[0].scale_factor)
-        out = enc + _conv_block(_bn(_conv(out, lconv[1], up), lconv[2]), conv[0])
+        out = _conv_block(_cba(out, lconv[1], lconv[2], up=up), conv[0], skip=enc)   # = enc + (x + BN(...)): same sum, same order
     oc = model.out_conv
-    out = Act.apply(_bn(_conv(out, oc[0]), oc[1]), ACT_RELU)
+    out = _cba(out, oc[0], oc[1], ACT_RELU)
     out = Act.apply(_conv(out, oc[3]), ACT_SOFTPLUS)
     feat = T.MaxPool.apply(out, None, None, None)
     fc = model.out_fc

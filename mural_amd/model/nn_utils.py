@@ -106,6 +106,8 @@ def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, 
     the GPU idle, so consecutive loader batches are concatenated until `fuse_rows` rows are waiting and evaluated by ONE
     forward.  Results are unchanged: rows keep their order, eval-mode outputs do not depend on the batch they are computed in,
     and the loss is the sum of the per-batch criterion values (taken on the slices when the criterion does not sum)."""
+    from .._host import freeze_host_heap
+    freeze_host_heap()
     device = torch.device(device)
     model.to(device)
     model.eval()

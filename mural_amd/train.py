@@ -18,6 +18,8 @@ import torch
 
 from .model import train_ops as T
 
+from ._host import freeze_host_heap  # noqa: E402,F401  (re-exported: train_epoch's loop and the benches call it)
+
 
 class GraphedTrainStep:
     def __init__(self, model, optimizer, criterion, cont_x, cat_x, distal_x, y, max_norm=10.0, warmup=3):
@@ -169,6 +171,7 @@ def train_epoch(model, batches, criterion, optimizer, scheduler, config, device,
     """One epoch of training.py:392-450 over an iterable of ``(y, cont_x, cat_x, distal_x)`` batches (the order
     ``generate_data_batches`` yields them).  Returns the summed loss."""
     model.train()
+    freeze_host_heap()
     if epoch > 0 and config["lr_scheduler"] == "StepLR2":
         for g in optimizer.param_groups:
             g["lr"] = config["restart_lr"]

@@ -23,6 +23,9 @@ with torch.no_grad():
     for i in range(100):
         co, ca, xx = calls[i % 64]
         model((co, ca), xx)
+    if "--freeze" in sys.argv:
+        from mural_amd._host import freeze_host_heap
+        freeze_host_heap()
     torch.cuda.synchronize()
     n = 3000
     t0 = time.perf_counter()

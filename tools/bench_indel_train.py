@@ -36,6 +36,8 @@ def step():
 
 for _ in range(3):
     step()
+from mural_amd.train import freeze_host_heap  # noqa: E402
+freeze_host_heap()        # as mural_amd.train.train_epoch does
 torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(steps):
