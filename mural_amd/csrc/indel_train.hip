@@ -419,7 +419,21 @@ extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* 
   MURAL_REQUIRE(dy && x && W && dW && part, "convg_bwd: null pointer");
   MURAL_REQUIRE(Cin * K <= 4 * IT_THREADS, "convg_bwd: Cin * K = %d exceeds %d", Cin * K, 4 * IT_THREADS);
   hipStream_t st = (hipStream_t)stream;
-  if (dx) {
+  if (dx && stride == 1 && up == 1 && Cin % 4 == 0) {
+    // a stride-1 conv's input gradient is the conv of dy with the transposed, tap-flipped weights: the forward engines (MFMA on short
+    // rows / deep reductions, packed FMAs otherwise) take it; the deep levels' rows of 8..80 positions left the direct kernel below
+    // with a handful of workgroups (30-80 us per launch).  The flipped weights borrow the weight gradient's scratch, which is
+    // written after this launch on the same stream.
+    MURAL_REQUIRE(part_floats >= (size_t)Cout * Cin * K, "convg_bwd: scratch too small");
+    if (int rc = mural_op_relayout(W, part, Cout, Cin, K, 1, stream)) return rc;
+    Conv1dArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.in = dy; a.wt = part; a.bias = nullptr; a.out = dx;
+    a.B = (int)B; a.Cin = Cout; a.Lin = Lout; a.Cout = Cin; a.Lout = Lin;
+    a.K = K; a.stride = 1; a.pad = K - 1 - pad; a.up = 1;
+    a.act = ACT_NONE;
+    if (int rc = launch_conv1d(a, st)) return rc;
+  } else if (dx) {
     const int64_t rows = B * Lin;
     const bool small = Cin <= 4;
     const int cg = small ? 4 : 8;
