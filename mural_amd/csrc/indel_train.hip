@@ -63,6 +63,88 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __r
     if (ci0 + c < Cin) dx[((size_t)b * Cin + ci0 + c) * Lin + j] = acc[c];
 }
 
+// The same gradient for the U-Net's strided (stride 4 / 5 / 2, up 1) and upsampled (stride 1, up 2 / 5 / 4) layers with the taps of a
+// position gathered first.  stride 1: the `up` positions that read x[j] and the K taps collapse to M = K + up - 1 distinct gradient
+// columns lo = j * up + m' + pad - (K - 1), m' < M, each with the SUM of the taps that reach it (built in LDS); up 1: the taps with
+// k = (j + pad) mod stride, + stride, ... reach lo = (j + pad - k) / stride.  Either way a position has at most DG_NT (column, weight
+// row) pairs: the loads of four output channels x all pairs are in flight together, Cout / 4 dependent rounds instead of the
+// up * K * Cout / 8 of the kernel above (210 -> 12 for the 40 -> 48-channel level).
+constexpr int DG_NT = 12, DG_COB = 4;
+
+template <int CG>
+__global__ __launch_bounds__(IT_THREADS) void conv_dgrad_gather_kernel(const float* __restrict__ dy, const float* __restrict__ W,
+                                                                       float* __restrict__ dx, int64_t rows /* B * Lin */, int Cin,
+                                                                       int Lin, int Cout, int Lout, int K, int stride, int pad, int up) {
+  extern __shared__ float wl[];                   // [Cout][T][CG]: T = K + up - 1 summed taps (stride 1) or the K taps (up 1)
+  const int ci0 = blockIdx.y * CG;
+  const bool summed = stride == 1;
+  const int T = summed ? K + up - 1 : K;
+  for (int i = threadIdx.x; i < Cout * T * CG; i += IT_THREADS) {
+    const int c = i % CG, r = i / CG, t = r % T, co = r / T;
+    float v = 0.f;
+    if (ci0 + c < Cin) {
+      const float* w = W + ((size_t)co * Cin + ci0 + c) * K;
+      if (summed) {
+        const int k0 = K - 1 - t > 0 ? K - 1 - t : 0, k1 = K - 2 - t + up < K - 1 ? K - 2 - t + up : K - 1;
+        for (int k = k0; k <= k1; ++k) v += w[k];
+      } else {
+        v = w[t];
+      }
+    }
+    wl[i] = v;
+  }
+  __syncthreads();
+  const int64_t row = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x;
+  if (row >= rows) return;
+  const int b = (int)(row / Lin), j = (int)(row - (int64_t)b * Lin);
+  int lo[DG_NT], wi[DG_NT];                       // gradient column (-1: none) and weight row of every pair
+  if (summed) {
+    const int base = j * up + pad - (K - 1);
+#pragma unroll
+    for (int t = 0; t < DG_NT; ++t) {
+      const int l = base + t;
+      lo[t] = (t < T && l >= 0 && l < Lout) ? l : -1;
+      wi[t] = t < T ? t : 0;
+    }
+  } else {
+    const int r = (j + pad) % stride, top = (j + pad - r) / stride;
+#pragma unroll
+    for (int t = 0; t < DG_NT; ++t) {
+      const int k = r + t * stride, l = top - t;
+      lo[t] = (k < K && l >= 0 && l < Lout) ? l : -1;
+      wi[t] = k < K ? k : 0;
+    }
+  }
+  float acc[CG];
+#pragma unroll
+  for (int c = 0; c < CG; ++c) acc[c] = 0.f;
+  const float* dyb = dy + (size_t)b * Cout * Lout;
+  for (int co0 = 0; co0 < Cout; co0 += DG_COB) {
+    float g[DG_COB][DG_NT];
+#pragma unroll
+    for (int q = 0; q < DG_COB; ++q)
+#pragma unroll
+      for (int t = 0; t < DG_NT; ++t) {
+        const bool ok = lo[t] >= 0 && co0 + q < Cout;
+        g[q][t] = dyb[ok ? (size_t)(co0 + q) * Lout + lo[t] : 0];
+        if (!ok) g[q][t] = 0.f;
+      }
+#pragma unroll
+    for (int q = 0; q < DG_COB; ++q) {
+      const int co = co0 + q < Cout ? co0 + q : 0;
+#pragma unroll
+      for (int t = 0; t < DG_NT; ++t) {
+        const float* w = wl + ((size_t)co * T + wi[t]) * CG;
+#pragma unroll
+        for (int c = 0; c < CG; ++c) acc[c] = fmaf(g[q][t], w[c], acc[c]);
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < CG; ++c)
+    if (ci0 + c < Cin) dx[((size_t)b * Cin + ci0 + c) * Lin + j] = acc[c];
+}
+
 // ------------------------------------------------------------------------------------------------ weight gradient
 // part[chunk][co][ci * K + k] = sum over the chunk's (b, lo) of dy[b][co][lo] * xu[b][ci][lo * stride - pad + k], xu = x
 // upsampled by `up`; part[chunk][co][Cin * K] = sum of dy (bias gradient).  Workgroup = (chunk, group of 4 output channels).
@@ -433,6 +515,14 @@ extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* 
     a.K = K; a.stride = 1; a.pad = K - 1 - pad; a.up = 1;
     a.act = ACT_NONE;
     if (int rc = launch_conv1d(a, st)) return rc;
+  } else if (dx && Cin > 4 && (stride == 1 || up == 1) && (stride == 1 ? K + up - 1 : (K + stride - 1) / stride) <= DG_NT &&
+             (size_t)Cout * (stride == 1 ? K + up - 1 : K) * 8 * sizeof(float) <= 64 * 1024) {
+    const int64_t rows = B * Lin;
+    const dim3 grid((unsigned)((rows + IT_THREADS - 1) / IT_THREADS), (Cin + 7) / 8);
+    const size_t lds = (size_t)Cout * (stride == 1 ? K + up - 1 : K) * 8 * sizeof(float);
+    hipLaunchKernelGGL(conv_dgrad_gather_kernel<8>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad,
+                       up);
+    MURAL_HIP_CHECK(hipGetLastError());
   } else if (dx) {
     const int64_t rows = B * Lin;
     const bool small = Cin <= 4;

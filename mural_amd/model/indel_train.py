@@ -179,6 +179,14 @@ def _conv_block(x, cb, skip=None):
 
 def unet_forward_train(model, x):
     """``UNet_Small.forward`` (model_indel.py:151-176) in training mode."""
+    try:
+        return _unet_forward_train(model, x)
+    except BaseException:
+        T._bn_touched.clear()          # a failed forward must not leave its BatchNorm counter ticks to the next one
+        raise
+
+
+def _unet_forward_train(model, x):
     out = x
     if model.use_reverse:
         sym = lambda t: _cba(t, model.conv[0], model.conv[1])                # noqa: E731
