@@ -67,11 +67,10 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __r
 // position gathered first.  stride 1: the `up` positions that read x[j] and the K taps collapse to M = K + up - 1 distinct gradient
 // columns lo = j * up + m' + pad - (K - 1), m' < M, each with the SUM of the taps that reach it (built in LDS); up 1: the taps with
 // k = (j + pad) mod stride, + stride, ... reach lo = (j + pad - k) / stride.  Either way a position has at most DG_NT (column, weight
-// row) pairs: the loads of four output channels x all pairs are in flight together, Cout / 4 dependent rounds instead of the
-// up * K * Cout / 8 of the kernel above (210 -> 12 for the 40 -> 48-channel level).
-constexpr int DG_NT = 12, DG_COB = 4;
-
-template <int CG>
+// row) pairs (2 at stride 4 / 5, 4 at stride 2, 8 / 10 / 11 at up 2 / 4 / 5): the loads of DG_COB output channels x all pairs are in
+// flight together (32 - 48 per thread), Cout / DG_COB dependent rounds instead of the up * K * Cout / 8 of the kernel above
+// (210 -> 12 for the 40 -> 48-channel level).
+template <int CG, int DG_NT, int DG_COB>
 __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_gather_kernel(const float* __restrict__ dy, const float* __restrict__ W,
                                                                        float* __restrict__ dx, int64_t rows /* B * Lin */, int Cin,
                                                                        int Lin, int Cout, int Lout, int K, int stride, int pad, int up) {
@@ -515,13 +514,20 @@ extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* 
     a.K = K; a.stride = 1; a.pad = K - 1 - pad; a.up = 1;
     a.act = ACT_NONE;
     if (int rc = launch_conv1d(a, st)) return rc;
-  } else if (dx && Cin > 4 && (stride == 1 || up == 1) && (stride == 1 ? K + up - 1 : (K + stride - 1) / stride) <= DG_NT &&
+  } else if (dx && Cin > 4 && (stride == 1 || up == 1) && (stride == 1 ? K + up - 1 : (K + stride - 1) / stride) <= 12 &&
              (size_t)Cout * (stride == 1 ? K + up - 1 : K) * 8 * sizeof(float) <= 64 * 1024) {
     const int64_t rows = B * Lin;
+    const int nt = stride == 1 ? K + up - 1 : (K + stride - 1) / stride;      // (column, weight row) pairs per position
     const dim3 grid((unsigned)((rows + IT_THREADS - 1) / IT_THREADS), (Cin + 7) / 8);
     const size_t lds = (size_t)Cout * (stride == 1 ? K + up - 1 : K) * 8 * sizeof(float);
-    hipLaunchKernelGGL(conv_dgrad_gather_kernel<8>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad,
-                       up);
+#define MURAL_DGRAD(NT_, COB_)                                                                                                        \
+  hipLaunchKernelGGL((conv_dgrad_gather_kernel<8, NT_, COB_>), grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, \
+                     stride, pad, up)
+    if (nt <= 2) MURAL_DGRAD(2, 16);
+    else if (nt <= 4) MURAL_DGRAD(4, 8);
+    else if (nt <= 8) MURAL_DGRAD(8, 4);
+    else MURAL_DGRAD(12, 4);
+#undef MURAL_DGRAD
     MURAL_HIP_CHECK(hipGetLastError());
   } else if (dx) {
     const int64_t rows = B * Lin;
