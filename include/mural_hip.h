@@ -425,7 +425,19 @@ int mural_op_convg_bn_fwd(const float* x, const float* W, const float* bias, flo
 int mural_op_convg_bn_bwd(const float* dz, const float* x, const float* W, const float* y0, const float* state, const float* gamma,
                           int64_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up,
                           int32_t act, double* acc, float* dy0, float* dx, float* dW, float* db, float* dgamma, float* dbeta,
-                          float* part, size_t part_floats, void* stream);
+                          float* part, size_t part_floats, const float* wt_dgrad, void* stream);
+/* The weight layouts the conv kernels read -- forward [Cin][K][Cout], input gradient [Cout][K flipped][Cin] (stride-1 layers) -- for
+ * every conv of a model in ONE launch per training step.  jobs: DEVICE array sorted by start (running sum of Cout * Cin * K).
+ * mural_op_convg_fwd / _bn_fwd take W == NULL when wt already holds the forward layout; mural_op_convg_bn_bwd takes the prepared
+ * input-gradient layout as wt_dgrad (NULL: derived from W inside the call). */
+typedef struct MuralRelayoutJob {
+  const float* W;        /* [Cout][Cin][K] (torch layout) */
+  float* wt_fwd;         /* [Cin][K][Cout] */
+  float* wt_dgrad;       /* [Cout][K][Cin], taps flipped; NULL: not needed */
+  int32_t Cout, Cin, K, reserved;
+  int64_t start;
+} MuralRelayoutJob;
+int mural_op_relayout_multi(const MuralRelayoutJob* jobs, int32_t n_jobs, int64_t total, void* stream);
 /* kind: 1 ReLU, 2 SiLU, 3 Softplus (beta 1, threshold 20); backward takes the forward INPUT x */
 int mural_op_act_fwd(const float* x, int64_t n, int32_t kind, float* y, void* stream);
 int mural_op_act_bwd(const float* dy, const float* x, int64_t n, int32_t kind, float* dx, void* stream);

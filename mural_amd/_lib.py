@@ -63,6 +63,11 @@ class MuralIndelParams(C.Structure):
                 ("out2", MuralAffine), ("fc_bn", MuralBN), ("fc", MuralAffine)]
 
 
+class MuralRelayoutJob(C.Structure):
+    _fields_ = [("W", C.c_void_p), ("wt_fwd", C.c_void_p), ("wt_dgrad", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32),
+                ("K", C.c_int32), ("reserved", C.c_int32), ("start", C.c_int64)]
+
+
 class MuralSnvShape(C.Structure):
     _fields_ = [("model_no", C.c_int32), ("n_class", C.c_int32), ("local_cols", C.c_int32), ("emb_rows", C.c_int32),
                 ("hidden1", C.c_int32), ("hidden2", C.c_int32), ("channels", C.c_int32), ("ksize", C.c_int32),
@@ -107,7 +112,8 @@ PROTOTYPES = {
     "mural_op_convg_bn_fwd": (C.c_int, [VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, VP, VP, C.c_float, C.c_float, VP, VP, VP,
                                         VP, I32, VP, VP, VP, VP]),
     "mural_op_convg_bn_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP,
-                                        C.c_size_t, VP]),
+                                        C.c_size_t, VP, VP]),
+    "mural_op_relayout_multi": (C.c_int, [VP, I32, I64, VP]),
     "mural_op_act_fwd": (C.c_int, [VP, I64, I32, VP, VP]),
     "mural_op_act_bwd": (C.c_int, [VP, VP, I64, I32, VP, VP]),
     "mural_op_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]),

@@ -334,6 +334,27 @@ __global__ __launch_bounds__(IT_THREADS) void act_bwd_kernel(const float* __rest
   for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < n; i += step) dx[i] = dy[i] * act_d(x[i], kind);
 }
 
+// ------------------------------------------------------------------------------------------------ weight layouts of a whole model
+// One launch per training step instead of one (forward) + one (input gradient) per layer: element i of the concatenated weights
+// finds its job by binary search and is written in the forward layout [Cin][K][Cout] and, where asked for, the input-gradient
+// layout [Cout][K flipped][Cin].
+__global__ __launch_bounds__(IT_THREADS) void relayout_multi_kernel(const MuralRelayoutJob* __restrict__ jobs, int n, int64_t total) {
+  const int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (jobs[mid].start <= i) lo = mid;
+    else hi = mid - 1;
+  }
+  const MuralRelayoutJob j = jobs[lo];
+  const int e = (int)(i - j.start);
+  const int co = e / (j.Cin * j.K), r = e - co * j.Cin * j.K, ci = r / j.K, k = r - ci * j.K;
+  const float v = j.W[e];
+  j.wt_fwd[((size_t)ci * j.K + k) * j.Cout + co] = v;
+  if (j.wt_dgrad) j.wt_dgrad[((size_t)co * j.K + (j.K - 1 - k)) * j.Cin + ci] = v;
+}
+
 // ------------------------------------------------------------------------------------------------ conv -> BatchNorm -> act
 // The U-Net's unit is Conv1d -> BatchNorm1d (batch statistics) [-> SiLU / ReLU] [+ residuals] (model_indel.py:6-19, :117-123): one
 // launch finalises the statistics (every workgroup derives scale / shift of all <= 96 channels from the batch sums, workgroup 0
@@ -474,9 +495,11 @@ extern "C" int mural_op_convg_fwd(const float* x, const float* W, const float* b
   MURAL_REQUIRE(B >= 0 && Cin >= 1 && Cout >= 1 && Lin >= 1, "convg_fwd: bad sizes");
   MURAL_REQUIRE(mural_op_convg_out_length(Lin, K, stride, pad, up) >= 1, "convg_fwd: bad geometry");
   if (B == 0) return MURAL_OK;
-  MURAL_REQUIRE(x && W && wt && y, "convg_fwd: null pointer");
-  int rc = mural_op_relayout(W, wt, Cout, Cin, K, 0, stream);
-  if (rc != MURAL_OK) return rc;
+  MURAL_REQUIRE(x && wt && y, "convg_fwd: null pointer");
+  if (W != nullptr) {       // W == NULL: wt already holds the forward layout (mural_op_relayout_multi)
+    int rc = mural_op_relayout(W, wt, Cout, Cin, K, 0, stream);
+    if (rc != MURAL_OK) return rc;
+  }
   Conv1dArgs a;
   std::memset(&a, 0, sizeof(a));
   a.in = x; a.wt = wt; a.bias = bias; a.out = y;
@@ -491,9 +514,20 @@ extern "C" size_t mural_op_convg_bwd_scratch(int32_t Cin, int32_t Cout, int32_t 
   return (size_t)WG_CHUNKS * Cout * ((size_t)Cin * K + 1);
 }
 
+static int convg_bwd_impl(const float* dy, const float* x, const float* W, const float* wt_dgrad, int64_t B, int32_t Cin, int32_t Lin,
+                          int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
+                          size_t part_floats, void* stream);
+
 extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                                   int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
                                   size_t part_floats, void* stream) {
+  return convg_bwd_impl(dy, x, W, nullptr, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
+}
+
+// wt_dgrad (optional): the input-gradient layout of W prepared by mural_op_relayout_multi
+static int convg_bwd_impl(const float* dy, const float* x, const float* W, const float* wt_dgrad, int64_t B, int32_t Cin, int32_t Lin,
+                          int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
+                          size_t part_floats, void* stream) {
   MURAL_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && Lin >= 1, "convg_bwd: bad sizes");
   const int Lout = mural_op_convg_out_length(Lin, K, stride, pad, up);
   MURAL_REQUIRE(Lout >= 1, "convg_bwd: bad geometry");
@@ -505,11 +539,14 @@ extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* 
     // rows / deep reductions, packed FMAs otherwise) take it; the deep levels' rows of 8..80 positions left the direct kernel below
     // with a handful of workgroups (30-80 us per launch).  The flipped weights borrow the weight gradient's scratch, which is
     // written after this launch on the same stream.
-    MURAL_REQUIRE(part_floats >= (size_t)Cout * Cin * K, "convg_bwd: scratch too small");
-    if (int rc = mural_op_relayout(W, part, Cout, Cin, K, 1, stream)) return rc;
+    if (!wt_dgrad) {
+      MURAL_REQUIRE(part_floats >= (size_t)Cout * Cin * K, "convg_bwd: scratch too small");
+      if (int rc = mural_op_relayout(W, part, Cout, Cin, K, 1, stream)) return rc;
+      wt_dgrad = part;
+    }
     Conv1dArgs a;
     std::memset(&a, 0, sizeof(a));
-    a.in = dy; a.wt = part; a.bias = nullptr; a.out = dx;
+    a.in = dy; a.wt = wt_dgrad; a.bias = nullptr; a.out = dx;
     a.B = (int)B; a.Cin = Cout; a.Lin = Lout; a.Cout = Cin; a.Lout = Lin;
     a.K = K; a.stride = 1; a.pad = K - 1 - pad; a.up = 1;
     a.act = ACT_NONE;
@@ -628,7 +665,7 @@ extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float
 extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const float* W, const float* y0, const float* state,
                                      const float* gamma, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride,
                                      int32_t pad, int32_t up, int32_t act, double* acc, float* dy0, float* dx, float* dW, float* db,
-                                     float* dgamma, float* dbeta, float* part, size_t part_floats, void* stream) {
+                                     float* dgamma, float* dbeta, float* part, size_t part_floats, const float* wt_dgrad, void* stream) {
   MURAL_REQUIRE(act >= 0 && act <= 3, "convg_bn_bwd: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
   MURAL_REQUIRE(B >= 1 && dz && y0 && state && gamma && acc && dy0 && dgamma && dbeta, "convg_bn_bwd: null pointer / empty batch");
   const int Lout = mural_op_convg_out_length(Lin, K, stride, pad, up);
@@ -642,5 +679,15 @@ extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const floa
   hipLaunchKernelGGL(bn_post_bwd_apply_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(IT_THREADS), (size_t)Cout * 6 * sizeof(float), st,
                      dz, y0, total, Cout, Lout, state, gamma, acc, (double)per, act, dy0, dgamma, dbeta);
   MURAL_HIP_CHECK(hipGetLastError());
-  return mural_op_convg_bwd(dy0, x, W, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
+  return convg_bwd_impl(dy0, x, W, wt_dgrad, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
+}
+
+// every conv weight of a model into its forward (and, where wt_dgrad is set, input-gradient) layout in one launch; jobs: device
+// array sorted by `start` (the running sum of Cout * Cin * K), total = the sum over all jobs
+extern "C" int mural_op_relayout_multi(const MuralRelayoutJob* jobs, int32_t n_jobs, int64_t total, void* stream) {
+  MURAL_REQUIRE(jobs && n_jobs >= 1 && total >= 1, "relayout_multi: empty job list");
+  hipLaunchKernelGGL(relayout_multi_kernel, dim3((unsigned)((total + IT_THREADS - 1) / IT_THREADS)), dim3(IT_THREADS), 0,
+                     (hipStream_t)stream, jobs, n_jobs, total);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
 }

@@ -115,7 +115,7 @@ class ConvBn(torch.autograd.Function):
     is not stored: the backward re-derives the activation's slope from the saved conv output."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, gamma, beta, bn, stride, pad, up, act, res1, res2):
+    def forward(ctx, x, weight, bias, gamma, beta, bn, stride, pad, up, act, res1, res2, wt_fwd=None, wt_dgrad=None):
         x = x.contiguous()
         B, Cin, Lin = x.shape
         Cout, _, K = weight.shape
@@ -125,17 +125,21 @@ class ConvBn(torch.autograd.Function):
             raise ValueError(f"Conv1d: kernel {K} / padding {pad} do not fit an input of length {Lin * up}")
         y0 = torch.empty((B, Cout, Lout), dtype=torch.float32, device=dev)
         z = torch.empty_like(y0)
-        wt = torch.empty(weight.numel(), dtype=torch.float32, device=dev)
+        # wt_fwd / wt_dgrad: this step's layouts of `weight` from the model-wide relayout launch (_WeightLayouts); without them the
+        # calls derive the layouts themselves
+        wt = wt_fwd if wt_fwd is not None else torch.empty(weight.numel(), dtype=torch.float32, device=dev)
         state = torch.empty((4, Cout), dtype=torch.float32, device=dev)
         for r in (res1, res2):
             if r is not None and (r.shape != y0.shape or not r.is_contiguous() or r.dtype is not torch.float32):
                 raise ValueError("ConvBn: a residual must be a contiguous float32 tensor of the output's shape")
-        T._call("mural_op_convg_bn_fwd", x, T._f32(weight), None if bias is None else T._f32(bias), wt, y0, B, Cin, Lin, Cout, K, stride,
+        T._call("mural_op_convg_bn_fwd", x, None if wt_fwd is not None else T._f32(weight), None if bias is None else T._f32(bias), wt, y0,
+                B, Cin, Lin, Cout, K, stride,
                 pad, up, T._f32(gamma), T._f32(beta), T.EPS, T.MOMENTUM, bn.running_mean, bn.running_var, T._bn_acc(Cout, dev), state,
                 act, res1, res2, z, T._stream(x))
         T._bn_tick(bn)
         ctx.save_for_backward(x, weight, y0, state, gamma)
         ctx.geom = (stride, pad, up, act, bias is not None, res1 is not None, res2 is not None)
+        ctx.wt_dgrad = wt_dgrad        # not a saved tensor: a scratch view that the next step's relayout launch rewrites
         return z
 
     @staticmethod
@@ -153,13 +157,63 @@ class ConvBn(torch.autograd.Function):
         dy0 = torch.empty_like(y0)
         part = _bwd_scratch(dev, int(_lib.lib().mural_op_convg_bwd_scratch(Cin, Cout, K)))
         T._call("mural_op_convg_bn_bwd", dz, x, T._f32(weight), y0, state, T._f32(gamma), B, Cin, Lin, Cout, K, stride, pad, up, act,
-                T._bn_acc(Cout, dev), dy0, dx, dW, db, dgb[0], dgb[1], part, part.numel(), T._stream(x))
-        return dx, dW, db, dgb[0], dgb[1], None, None, None, None, None, dz if has_r1 else None, dz if has_r2 else None
+                T._bn_acc(Cout, dev), dy0, dx, dW, db, dgb[0], dgb[1], part, part.numel(), ctx.wt_dgrad, T._stream(x))
+        return dx, dW, db, dgb[0], dgb[1], None, None, None, None, None, dz if has_r1 else None, dz if has_r2 else None, None, None
 
 
-def _cba(x, conv, bn, act=0, up=1, res1=None, res2=None):
+class _WeightLayouts:
+    """This step's kernel layouts of every Conv1d weight of a model -- forward [Cin][K][Cout] and, for stride-1 layers, the input
+    gradient's [Cout][K flipped][Cin] -- written by ONE launch per step (``mural_op_relayout_multi``) instead of one or two per
+    layer.  The job table lives on the device and is rebuilt when a weight's storage moves."""
+
+    def __init__(self, model):
+        self.convs = [m for m in model.modules() if isinstance(m, torch.nn.Conv1d)]
+        self.key = None
+
+    def _build(self, dev):
+        total = sum(c.weight.numel() for c in self.convs)
+        n_dg = sum(c.weight.numel() for c in self.convs if int(c.stride[0]) == 1)
+        self.buf = torch.empty(total + n_dg, dtype=torch.float32, device=dev)
+        jobs = (_lib.MuralRelayoutJob * len(self.convs))()
+        self.views = {}
+        off_f, off_d, start = 0, total, 0
+        for j, c in enumerate(self.convs):
+            w = c.weight
+            n = w.numel()
+            if w.dtype is not torch.float32 or not w.is_contiguous():
+                raise RuntimeError("the HIP training step needs contiguous float32 conv weights")
+            fwd = self.buf[off_f:off_f + n]
+            dg = self.buf[off_d:off_d + n] if int(c.stride[0]) == 1 else None
+            jobs[j].W, jobs[j].wt_fwd, jobs[j].wt_dgrad = w.data_ptr(), fwd.data_ptr(), (dg.data_ptr() if dg is not None else None)
+            jobs[j].Cout, jobs[j].Cin, jobs[j].K, jobs[j].start = w.shape[0], w.shape[1], w.shape[2], start
+            self.views[id(c)] = (fwd, dg)
+            off_f += n
+            off_d += n if dg is not None else 0
+            start += n
+        raw = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8)
+        self.jobs_dev = raw.to(dev)
+        self.n, self.total = len(self.convs), total
+
+    def refresh(self, dev, stream):
+        key = (dev, tuple(c.weight.data_ptr() for c in self.convs))
+        if key != self.key:
+            self._build(dev)
+            self.key = key
+        T._call("mural_op_relayout_multi", self.jobs_dev, self.n, self.total, stream)
+        return self.views
+
+
+def _layouts(model, x):
+    lay = getattr(model, "_train_weight_layouts", None)
+    if lay is None:
+        lay = model._train_weight_layouts = _WeightLayouts(model)
+    return lay.refresh(x.device, T._stream(x))
+
+
+def _cba(x, conv, bn, act=0, up=1, res1=None, res2=None, wl=None):
+    fwd, dg = wl[id(conv)] if wl is not None else (None, None)
     return ConvBn.apply(x, conv.weight, conv.bias, bn.weight, bn.bias, bn, int(conv.stride[0]), int(conv.padding[0]), int(up), act,
-                        res1, res2)
+                        res1, res2, fwd, dg if int(up) == 1 else None)
 
 
 def _conv(x, conv, up=1):
@@ -170,11 +224,11 @@ def _bn(x, bn):
     return BatchNorm.apply(x, bn.weight, bn.bias, bn, False)
 
 
-def _conv_block(x, cb, skip=None):
+def _conv_block(x, cb, skip=None, wl=None):
     """[skip +] x + BN(Conv1x1(SiLU(BN(Conv5(x)))))   (model_indel.py:6-19; the decoder adds the encoder's skip tensor, :168-170)"""
     seq = cb.conv
-    h = _cba(x, seq[0], seq[1], ACT_SILU)
-    return _cba(h, seq[3], seq[4], 0, res1=x, res2=skip)
+    h = _cba(x, seq[0], seq[1], ACT_SILU, wl=wl)
+    return _cba(h, seq[3], seq[4], 0, res1=x, res2=skip, wl=wl)
 
 
 def unet_forward_train(model, x):
@@ -188,18 +242,19 @@ def unet_forward_train(model, x):
 
 def _unet_forward_train(model, x):
     out = x
+    wl = _layouts(model, x)
     if model.use_reverse:
-        sym = lambda t: _cba(t, model.conv[0], model.conv[1])                # noqa: E731
+        sym = lambda t: _cba(t, model.conv[0], model.conv[1], wl=wl)         # noqa: E731
         out = sym(out) + sym(out.flip([1, 2])).flip([2])
     encodings = []
     for lconv, conv in zip(model.uplblocks, model.upblocks):
-        out = _conv_block(_cba(out, lconv[0], lconv[1]), conv[0])
+        out = _conv_block(_cba(out, lconv[0], lconv[1], wl=wl), conv[0], wl=wl)
         encodings.append(out)
     for enc, lconv, conv in zip(reversed(encodings[:-1]), model.downlblocks, model.downblocks):
         up = int(lconv[0].scale_factor)
-        out = _conv_block(_cba(out, lconv[1], lconv[2], up=up), conv[0], skip=enc)   # = enc + (x + BN(...)): same sum, same order
+        out = _conv_block(_cba(out, lconv[1], lconv[2], up=up, wl=wl), conv[0], skip=enc, wl=wl)   # = enc + (x + BN(...)): same sum, same order
     oc = model.out_conv
-    out = _cba(out, oc[0], oc[1], ACT_RELU)
+    out = _cba(out, oc[0], oc[1], ACT_RELU, wl=wl)
     out = Act.apply(_conv(out, oc[3]), ACT_SOFTPLUS)
     feat = T.MaxPool.apply(out, None, None, None)
     fc = model.out_fc
