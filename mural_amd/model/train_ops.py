@@ -86,11 +86,16 @@ def flush_bn_ticks():
     flush_input_checks()
     if _bn_touched:
         with torch.no_grad():
-            if len({id(t) for t in _bn_touched}) == len(_bn_touched):
-                torch._foreach_add_(_bn_touched, 1)
-            else:                         # a BatchNorm applied more than once per forward (UNet_Small's strand-symmetry conv)
-                for t in _bn_touched:
-                    t.add_(1)
+            count, first = {}, {}
+            for t in _bn_touched:
+                count[id(t)] = count.get(id(t), 0) + 1
+                first.setdefault(id(t), t)
+            once = [first[k] for k, c in count.items() if c == 1]
+            if once:
+                torch._foreach_add_(once, 1)
+            for k, c in count.items():    # a BatchNorm applied more than once per forward (UNet_Small's strand-symmetry conv)
+                if c > 1:
+                    first[k].add_(c)
         _bn_touched.clear()
 
 
