@@ -65,12 +65,17 @@ class UNet_Small(nn.Module):
         self._plist = None
 
     def train(self, mode=True):
-        self.invalidate_folded()
+        if bool(mode) != self.training:     # a real transition; model.eval() on a model in eval mode keeps the folded copy
+            self.invalidate_folded()
         return super().train(mode)
 
     def _apply(self, fn, *args, **kwargs):
-        self.invalidate_folded()
-        return super()._apply(fn, *args, **kwargs)
+        sig = lambda: tuple((t.data_ptr(), t.dtype, t.device) for t in list(self.parameters()) + list(self.buffers()))   # noqa: E731
+        before = sig()
+        out = super()._apply(fn, *args, **kwargs)
+        if sig() != before:                 # .to() / .cuda() that moved or cast something (a no-op .to(device) does not)
+            self.invalidate_folded()
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         self.invalidate_folded()

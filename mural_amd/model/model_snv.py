@@ -164,13 +164,20 @@ class _HipSnvBase(nn.Module):
         self._ws_rows = [0, 0]
 
     def train(self, mode=True):
-        self.invalidate_folded()
+        if bool(mode) != self.training:     # a real transition; model.eval() on a model in eval mode keeps the folded copy
+            self.invalidate_folded()
         return super().train(mode)
 
+    def _storage_signature(self):
+        return tuple((t.data_ptr(), t.dtype, t.device) for t in list(self.parameters()) + list(self.buffers()))
+
     def _apply(self, fn, *args, **kwargs):
-        self.invalidate_folded()
-        self._train_layout = None           # tensor objects / storages may be replaced
-        return super()._apply(fn, *args, **kwargs)
+        before = self._storage_signature()
+        out = super()._apply(fn, *args, **kwargs)
+        if self._storage_signature() != before:    # .to() / .cuda() that moved or cast something (a no-op .to(device) does not)
+            self.invalidate_folded()
+            self._train_layout = None              # tensor objects / storages were replaced
+        return out
 
     def load_state_dict(self, *args, **kwargs):
         self.invalidate_folded()
