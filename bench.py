@@ -401,8 +401,8 @@ def workload_variants(device, model, genome):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out["model_predict_m_batch16_loader"] = {"bases_per_s": n_rows / dt, "rows": n_rows,
-                                                 "note": "HOST tensors in 16-row batches: 32 KB of fp32 one-hot per site packed into a pinned "
-                                                         "buffer and copied over PCIe inside the timed region (that copy is the bound)"}
+                                                 "note": "HOST tensors in 16-row batches: 32 KB of fp32 one-hot per site copied over PCIe batch by "
+                                                         "batch inside the timed region and concatenated on the device"}
         dev_loader = [tuple(t.to(device) for t in b) for b in loader]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
