@@ -139,6 +139,59 @@ def test_train_general_conv_against_torch():
             assert (got.cpu() - want).abs().max() <= 1e-4 * max(1.0, float(want.abs().max())), (case, name)
 
 
+def test_conv_bn_unit_against_torch():
+    """The U-Net's training unit as one autograd node (indel_train.ConvBn: Conv1d -> batch-statistics BatchNorm -> act -> residual
+    adds, ``mural_op_convg_bn_fwd / _bwd``) against the same chain of torch modules in float64: outputs, every gradient (input,
+    conv weight / bias, BatchNorm weight / bias, both residuals) and the running statistics, over strides, upsampling factors, the
+    three activations and batches that do not fill a tile."""
+    from mural_amd.model.indel_train import ConvBn
+    rng = torch.Generator().manual_seed(11)
+    cases = [(3, 8, 16, 5, 1, 2, 1, 300, 2, True), (2, 16, 8, 1, 1, 0, 1, 257, 0, True), (2, 8, 16, 7, 4, 3, 1, 403, 0, False),
+             (4, 40, 48, 7, 2, 3, 1, 16, 1, False), (3, 48, 40, 7, 1, 3, 2, 8, 0, False), (2, 16, 8, 7, 1, 3, 4, 50, 0, True),
+             (5, 24, 48, 5, 1, 2, 1, 80, 2, False), (2, 32, 24, 7, 1, 3, 5, 16, 0, True)]
+    for B, Cin, Cout, K, stride, pad, up, L, act, with_res in cases:
+        x = torch.randn((B, Cin, L), generator=rng)
+        conv = torch.nn.Conv1d(Cin, Cout, K, stride=stride, padding=pad)
+        bn = torch.nn.BatchNorm1d(Cout)
+        with torch.no_grad():
+            conv.weight.copy_(torch.randn(conv.weight.shape, generator=rng) / (Cin * K) ** 0.5)
+            conv.bias.copy_(torch.randn(Cout, generator=rng))
+            bn.weight.copy_(1 + 0.3 * torch.randn(Cout, generator=rng))
+            bn.bias.copy_(0.3 * torch.randn(Cout, generator=rng))
+        ref_c, ref_b = torch.nn.Conv1d(Cin, Cout, K, stride=stride, padding=pad).double(), torch.nn.BatchNorm1d(Cout).double()
+        ref_c.load_state_dict({k: v.double() for k, v in conv.state_dict().items()})
+        ref_b.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+        xr = x.double().requires_grad_()
+        xu = xr.repeat_interleave(up, dim=2) if up > 1 else xr
+        u = ref_b(ref_c(xu))
+        zr = [u, torch.relu(u), torch.nn.functional.silu(u)][act]
+        r1 = torch.randn(zr.shape, generator=rng) if with_res else None
+        r2 = torch.randn(zr.shape, generator=rng) if with_res else None
+        r1r = r1.double().requires_grad_() if with_res else None
+        r2r = r2.double().requires_grad_() if with_res else None
+        if with_res:
+            zr = zr + r1r + r2r
+        g = torch.randn(zr.shape, generator=rng)
+        zr.backward(g.double())
+        conv, bn = conv.cuda().train(), bn.cuda().train()
+        xd = x.cuda().requires_grad_()
+        r1d = r1.cuda().requires_grad_() if with_res else None
+        r2d = r2.cuda().requires_grad_() if with_res else None
+        zd = ConvBn.apply(xd, conv.weight, conv.bias, bn.weight, bn.bias, bn, stride, pad, up, act, r1d, r2d)
+        zd.backward(g.cuda())
+        case = (B, Cin, Cout, K, stride, pad, up, L, act, with_res)
+        close = lambda got, want, tol: float((got.detach().cpu().double() - want.detach()).abs().max()) <= tol * max(1.0, float(want.abs().max()))   # noqa: E731
+        assert close(zd, zr, 2e-5), case
+        assert close(xd.grad, xr.grad, 1e-4), (case, "dx")
+        assert close(conv.weight.grad, ref_c.weight.grad, 1e-4), (case, "dW")
+        assert close(bn.weight.grad, ref_b.weight.grad, 1e-4) and close(bn.bias.grad, ref_b.bias.grad, 1e-4), (case, "BatchNorm")
+        # (the conv bias in front of a batch-statistics BatchNorm has a mathematically zero gradient: only its scale is checked)
+        assert float(conv.bias.grad.abs().max()) <= 1e-3 * max(1.0, float(ref_c.weight.grad.abs().max())), (case, "db")
+        if with_res:
+            assert close(r1d.grad, r1r.grad, 1e-6) and close(r2d.grad, r2r.grad, 1e-6), (case, "residuals")
+        assert close(bn.running_mean, ref_b.running_mean, 1e-5) and close(bn.running_var, ref_b.running_var, 1e-5), (case, "running")
+
+
 def test_train_mode_updates_and_eval_after_training():
     """A few Adam steps in training mode lower the loss, BatchNorm counters advance like nn.BatchNorm1d (the strand-symmetry
     BatchNorm twice per forward), and the eval-mode fused program picks up the updated weights."""
