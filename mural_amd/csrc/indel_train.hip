@@ -362,15 +362,17 @@ __global__ __launch_bounds__(IT_THREADS) void relayout_multi_kernel(const MuralR
 // re-derives the activation's slope from the saved conv output, so the BatchNorm output is never stored.
 constexpr int CB_SLOTS = MURAL_BN_SLOTS;
 
-__device__ __forceinline__ double cb_slot_sum(const double* __restrict__ acc, int C, int which, int c) {
+// nslots: the accumulator copies the producer's workgroups actually used (its grid.y, at most CB_SLOTS; the others are still zero) --
+// a short tensor's finalisation is this loop's latency, 64 dependent loads per channel when it walks all of them
+__device__ __forceinline__ double cb_slot_sum(const double* __restrict__ acc, int C, int which, int c, int nslots) {
   double t = 0.0;
-  for (int k = 0; k < CB_SLOTS; ++k) t += acc[((size_t)k * 2 + which) * C + c];
+  for (int k = 0; k < nslots; ++k) t += acc[((size_t)k * 2 + which) * C + c];
   return t;
 }
 
 // z = act(scale * y + shift) [+ res1] [+ res2];  state = scale | shift | mean | invstd ([4][C])
 __global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* __restrict__ y, int64_t total, int C, int L,
-                                                                   const double* __restrict__ acc, double n,
+                                                                   const double* __restrict__ acc, int nslots, double n,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                    float eps, float momentum, float* __restrict__ running_mean,
                                                                    float* __restrict__ running_var, float* __restrict__ state, int act,
@@ -378,8 +380,8 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* 
                                                                    float* __restrict__ z) {
   extern __shared__ float cst[];      // [C][2] scale, shift
   for (int c = threadIdx.x; c < C; c += IT_THREADS) {
-    const double mean = cb_slot_sum(acc, C, 0, c) / n;
-    double var = cb_slot_sum(acc, C, 1, c) / n - mean * mean;
+    const double mean = cb_slot_sum(acc, C, 0, c, nslots) / n;
+    double var = cb_slot_sum(acc, C, 1, c, nslots) / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const float sc = (float)(gamma[c] * invstd), sh = (float)(beta[c] - mean * gamma[c] * invstd);
@@ -449,11 +451,11 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_reduce_kernel(const fl
 __global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_apply_kernel(const float* __restrict__ dz, const float* __restrict__ y,
                                                                        int64_t total, int C, int L, const float* __restrict__ state,
                                                                        const float* __restrict__ gamma, const double* __restrict__ acc,
-                                                                       double n, int act, float* __restrict__ dy,
+                                                                       int nslots, double n, int act, float* __restrict__ dy,
                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
   extern __shared__ float cst[];      // [C][6]: gamma * invstd, mean(g), mean(g * xhat), mean, scale, shift
   for (int c = threadIdx.x; c < C; c += IT_THREADS) {
-    const double s1 = cb_slot_sum(acc, C, 0, c), s2 = cb_slot_sum(acc, C, 1, c);
+    const double s1 = cb_slot_sum(acc, C, 0, c, nslots), s2 = cb_slot_sum(acc, C, 1, c, nslots);
     cst[6 * c + 0] = gamma[c] * state[3 * C + c];
     cst[6 * c + 1] = (float)(s1 / n);
     cst[6 * c + 2] = (float)(s2 / n);
@@ -652,9 +654,11 @@ extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float
   const int Lout = out_length(Lin, K, stride, pad, up);
   if (int rc = mural_op_bn_stats(y0, B, Cout, Lout, 0, acc, stream)) return rc;
   const int64_t total = B * Cout * Lout;
+  int64_t gy = (B * Lout + 256 * 8 - 1) / (256 * 8);        // grid.y of mural_op_bn_stats: workgroup y adds into copy y % CB_SLOTS
+  const int nslots = (int)(gy < 1 ? 1 : (gy > CB_SLOTS ? CB_SLOTS : gy));
   int64_t g = (total + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
   hipLaunchKernelGGL(bn_post_apply_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(IT_THREADS), (size_t)Cout * 2 * sizeof(float),
-                     (hipStream_t)stream, y0, total, Cout, Lout, acc, (double)(B * Lout), gamma, beta, eps, momentum, running_mean,
+                     (hipStream_t)stream, y0, total, Cout, Lout, acc, nslots, (double)(B * Lout), gamma, beta, eps, momentum, running_mean,
                      running_var, state, act, res1, res2, z);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
@@ -677,7 +681,7 @@ extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const floa
   hipLaunchKernelGGL(bn_post_bwd_reduce_kernel, dim3(Cout, gy), dim3(IT_THREADS), 0, st, dz, y0, (int)B, Cout, Lout, state, act, acc);
   int64_t g = (total + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
   hipLaunchKernelGGL(bn_post_bwd_apply_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(IT_THREADS), (size_t)Cout * 6 * sizeof(float), st,
-                     dz, y0, total, Cout, Lout, state, gamma, acc, (double)per, act, dy0, dgamma, dbeta);
+                     dz, y0, total, Cout, Lout, state, gamma, acc, gy > CB_SLOTS ? CB_SLOTS : gy, (double)per, act, dy0, dgamma, dbeta);
   MURAL_HIP_CHECK(hipGetLastError());
   return convg_bwd_impl(dy0, x, W, wt_dgrad, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
 }
