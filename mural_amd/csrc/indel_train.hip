@@ -362,12 +362,31 @@ __global__ __launch_bounds__(IT_THREADS) void relayout_multi_kernel(const MuralR
 // re-derives the activation's slope from the saved conv output, so the BatchNorm output is never stored.
 constexpr int CB_SLOTS = MURAL_BN_SLOTS;
 
-// nslots: the accumulator copies the producer's workgroups actually used (its grid.y, at most CB_SLOTS; the others are still zero) --
-// a short tensor's finalisation is this loop's latency, 64 dependent loads per channel when it walks all of them
-__device__ __forceinline__ double cb_slot_sum(const double* __restrict__ acc, int C, int which, int c, int nslots) {
-  double t = 0.0;
-  for (int k = 0; k < nslots; ++k) t += acc[((size_t)k * 2 + which) * C + c];
-  return t;
+// The two batch sums of every channel into LDS (sums[0][c], sums[1][c]), by the whole workgroup: 32 lanes per channel read one
+// accumulator copy each and reduce by shuffles, 8 channels per pass.  nslots: the copies the producer's workgroups actually used
+// (its grid.y, at most CB_SLOTS; the others are still zero).  Every workgroup of the consumers below starts with this; one thread
+// per channel walking 2 x 32 copies made it 6-12 us of latency per workgroup (0.6 ms of a 6 ms step).
+constexpr int CB_MAXC = 128;
+__device__ __forceinline__ void cb_slot_sums(const double* __restrict__ acc, int C, int nslots, double (*sums)[CB_MAXC]) {
+  const int k = threadIdx.x & 31;
+  for (int base = 0; base < C; base += IT_THREADS / 32) {
+    const int c = base + (threadIdx.x >> 5);
+    double s1 = 0.0, s2 = 0.0;
+    if (c < C && k < nslots) {
+      s1 = acc[((size_t)k * 2 + 0) * C + c];
+      s2 = acc[((size_t)k * 2 + 1) * C + c];
+    }
+#pragma unroll
+    for (int off = 16; off > 0; off >>= 1) {
+      s1 += __shfl_xor(s1, off, 64);
+      s2 += __shfl_xor(s2, off, 64);
+    }
+    if (k == 0 && c < C) {
+      sums[0][c] = s1;
+      sums[1][c] = s2;
+    }
+  }
+  __syncthreads();
 }
 
 // z = act(scale * y + shift) [+ res1] [+ res2];  state = scale | shift | mean | invstd ([4][C])
@@ -379,9 +398,11 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* 
                                                                    const float* __restrict__ res1, const float* __restrict__ res2,
                                                                    float* __restrict__ z) {
   extern __shared__ float cst[];      // [C][2] scale, shift
+  __shared__ double sums[2][CB_MAXC];
+  cb_slot_sums(acc, C, nslots, sums);
   for (int c = threadIdx.x; c < C; c += IT_THREADS) {
-    const double mean = cb_slot_sum(acc, C, 0, c, nslots) / n;
-    double var = cb_slot_sum(acc, C, 1, c, nslots) / n - mean * mean;
+    const double mean = sums[0][c] / n;
+    double var = sums[1][c] / n - mean * mean;
     if (var < 0.0) var = 0.0;
     const double invstd = 1.0 / sqrt(var + (double)eps);
     const float sc = (float)(gamma[c] * invstd), sh = (float)(beta[c] - mean * gamma[c] * invstd);
@@ -454,8 +475,10 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_apply_kernel(const flo
                                                                        int nslots, double n, int act, float* __restrict__ dy,
                                                                        float* __restrict__ dgamma, float* __restrict__ dbeta) {
   extern __shared__ float cst[];      // [C][6]: gamma * invstd, mean(g), mean(g * xhat), mean, scale, shift
+  __shared__ double sums[2][CB_MAXC];
+  cb_slot_sums(acc, C, nslots, sums);
   for (int c = threadIdx.x; c < C; c += IT_THREADS) {
-    const double s1 = cb_slot_sum(acc, C, 0, c, nslots), s2 = cb_slot_sum(acc, C, 1, c, nslots);
+    const double s1 = sums[0][c], s2 = sums[1][c];
     cst[6 * c + 0] = gamma[c] * state[3 * C + c];
     cst[6 * c + 1] = (float)(s1 / n);
     cst[6 * c + 2] = (float)(s2 / n);
@@ -649,6 +672,7 @@ extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float
                                      void* stream) {
   MURAL_REQUIRE(act >= 0 && act <= 3, "convg_bn_fwd: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
   MURAL_REQUIRE(gamma && beta && acc && state && z && y0, "convg_bn_fwd: null pointer");
+  MURAL_REQUIRE(Cout <= CB_MAXC, "convg_bn_fwd: at most %d output channels (got %d)", CB_MAXC, Cout);
   if (int rc = mural_op_convg_fwd(x, W, bias, wt, y0, B, Cin, Lin, Cout, K, stride, pad, up, stream)) return rc;
   if (B == 0) return MURAL_OK;
   const int Lout = out_length(Lin, K, stride, pad, up);
@@ -672,6 +696,7 @@ extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const floa
                                      float* dgamma, float* dbeta, float* part, size_t part_floats, const float* wt_dgrad, void* stream) {
   MURAL_REQUIRE(act >= 0 && act <= 3, "convg_bn_bwd: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
   MURAL_REQUIRE(B >= 1 && dz && y0 && state && gamma && acc && dy0 && dgamma && dbeta, "convg_bn_bwd: null pointer / empty batch");
+  MURAL_REQUIRE(Cout <= CB_MAXC, "convg_bn_bwd: at most %d output channels (got %d)", CB_MAXC, Cout);
   const int Lout = mural_op_convg_out_length(Lin, K, stride, pad, up);
   MURAL_REQUIRE(Lout >= 1, "convg_bn_bwd: bad geometry");
   hipStream_t st = (hipStream_t)stream;
