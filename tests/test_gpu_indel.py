@@ -192,6 +192,44 @@ def test_conv_bn_unit_against_torch():
         assert close(bn.running_mean, ref_b.running_mean, 1e-5) and close(bn.running_var, ref_b.running_var, 1e-5), (case, "running")
 
 
+def test_train_step_does_not_read_unwritten_scratch(monkeypatch):
+    """Every buffer the training step allocates with torch.empty / empty_like (conv outputs, BatchNorm states, gradients, layouts,
+    partial sums) must be completely written before a kernel reads it: the same step with those allocations pre-filled with NaN
+    gives the same loss and gradients."""
+    from mural_amd.model import indel_train as IT
+    fx = U.load("indel_train_rev.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc), strict=True)
+    model = model.cuda().train()
+    model.out_fc[1].p = 0.0
+    x, y = U.onehot(fx["codes"]).cuda(), torch.from_numpy(fx["y"]).cuda()
+    _, loss0 = _train_step(model, x, y)
+    ref = {k: p.grad.clone() for k, p in model.named_parameters()}
+
+    class NanTorch:
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def empty(*a, **k):
+            t = torch.empty(*a, **k)
+            return t.fill_(float("nan")) if t.is_floating_point() else t
+
+        @staticmethod
+        def empty_like(*a, **k):
+            t = torch.empty_like(*a, **k)
+            return t.fill_(float("nan")) if t.is_floating_point() else t
+
+    monkeypatch.setattr(IT, "torch", NanTorch())
+    monkeypatch.setattr(IT, "_scratch", {})
+    _, loss1 = _train_step(model, x, y)
+    assert abs(loss1.item() - loss0.item()) <= 1e-5 * abs(loss0.item())
+    for k, p in model.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * (float(ref[k].abs().max()) + 1e-3), k
+
+
 def test_train_mode_updates_and_eval_after_training():
     """A few Adam steps in training mode lower the loss, BatchNorm counters advance like nn.BatchNorm1d (the strand-symmetry
     BatchNorm twice per forward), and the eval-mode fused program picks up the updated weights."""
