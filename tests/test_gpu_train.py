@@ -435,3 +435,38 @@ def test_flat_clip_grad_norm_matches_torch():
     ref_total = torch.sqrt(sum((p.grad.double() ** 2).sum() for p in model.parameters() if p.numel()))
     total = clip_grad_norm_(model, 1e9)
     assert abs(float(total) - float(ref_total)) <= 1e-5 * float(ref_total)
+
+
+def test_train_step_does_not_read_unwritten_workspace(monkeypatch):
+    """The composed training step keeps its activations, arg-max bytes, gradient tables and partial sums in ONE workspace from
+    torch.empty: the same step with that workspace (and the gradient buffer's padding) pre-filled with 0xFF bytes gives the same
+    loss and gradients."""
+    from mural_amd.model import train_step as TS
+    from tests.test_gpu_snv import _PoisonedTorch
+    fx = U.load("snv_train_T.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    model = model.cuda().train()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"].astype(np.int64)).cuda()
+    cont = torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda")
+    crit = nn.CrossEntropyLoss(reduction="sum")
+
+    def step():
+        loss = crit(model((cont, cat), x), y)
+        model.zero_grad()
+        loss.backward()
+        return loss.item(), {k: p.grad.clone() for k, p in model.named_parameters() if p.numel()}
+
+    l0, g0 = step()
+    monkeypatch.setattr(TS, "torch", _PoisonedTorch())
+    l1, g1 = step()
+    assert abs(l1 - l0) <= 1e-5 * abs(l0)
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        assert float((g1[k] - g0[k]).abs().max()) <= 2e-4 * (float(g0[k].abs().max()) + 1e-2), k
