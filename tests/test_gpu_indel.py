@@ -65,6 +65,24 @@ def test_batch_larger_than_chunk_and_packed_path():
     assert np.abs(got - want).max() <= 1e-4 * max(1.0, np.abs(want).max())
 
 
+def test_forward_does_not_read_unwritten_workspace(monkeypatch):
+    """The eval-mode forward's workspace (two chunks in flight) with 0xFF-poisoned allocations: same scores."""
+    from mural_amd.model import model_indel as MI
+    from tests.test_gpu_snv import _PoisonedTorch
+    fx = U.load("indel_synth_small.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc))
+    model = model.cuda().eval()
+    x = U.onehot(np.random.default_rng(5).integers(0, 4, size=(700, fx["codes"].shape[1])).astype(np.uint8)).cuda()
+    with torch.no_grad():
+        want = model(x).cpu().numpy()
+        monkeypatch.setattr(MI, "torch", _PoisonedTorch())
+        model._ws = None
+        got = model(x).cpu().numpy()
+    assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
+
+
 def test_incompatible_length_is_rejected():
     fx = U.load("indel_synth_small.npz")
     model = product_from(fx).cuda().eval()

@@ -108,3 +108,25 @@ def test_reuse_chunks_long_spans_and_falls_back():
         b = small.forward_packed_reuse(genome, tp[:500], ts[:500], local_radius=5, local_order=3)
     assert torch.equal(a, b)
     assert model.forward_packed_reuse(genome, tp[:0], ts[:0], local_radius=7, local_order=3).shape == (0, 4)
+
+
+def test_reuse_does_not_read_unwritten_workspace(monkeypatch):
+    """The reuse path's workspace (per-base rows, pooled tiles, edge columns, site maps) with 0xFF-poisoned allocations: same result."""
+    from mural_amd.data import PackedGenome
+    from mural_amd.model import model_snv as MS
+    from tests.test_gpu_snv import _PoisonedTorch
+    model, _ = _pair(10, 1000, 2)
+    rng = np.random.default_rng(77)
+    n = 30_000
+    genome = PackedGenome.from_sequence(_genome(rng, n), "cuda")
+    pos = np.r_[np.arange(0, 900), np.arange(12000, 15000), np.arange(n - 500, n), rng.integers(0, n, size=200)]
+    strand = (np.arange(len(pos)) % 2).astype(np.uint8)
+    tp, ts = torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda()
+    with torch.no_grad():
+        want = model.forward_packed_reuse(genome, tp, ts, local_radius=10, local_order=3).cpu().numpy()
+        monkeypatch.setattr(MS, "torch", _PoisonedTorch())
+        model._ws = None
+        model._ws_rows = [0, 0]
+        got = model.forward_packed_reuse(genome, tp, ts, local_radius=10, local_order=3).cpu().numpy()
+    assert np.isfinite(got).all()
+    assert np.abs(got - want).max() <= 2e-6
