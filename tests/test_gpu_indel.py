@@ -248,6 +248,57 @@ def test_train_step_does_not_read_unwritten_scratch(monkeypatch):
         assert float((p.grad - ref[k]).abs().max()) <= 1e-4 * (float(ref[k].abs().max()) + 1e-3), k
 
 
+def test_train_step_writes_stay_inside_their_buffers(monkeypatch):
+    """Every tensor the training step allocates is carved out of one arena with 4 KB guard zones (0xAB) around it: after a forward +
+    backward every guard byte is intact -- no kernel of the step writes outside the buffer it was given."""
+    from mural_amd.model import indel_train as IT
+    fx = U.load("indel_train_rev.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc), strict=True)
+    model = model.cuda().train()
+    x, y = U.onehot(fx["codes"]).cuda(), torch.from_numpy(fx["y"]).cuda()
+    guard = 4096
+    arena = torch.full((1 << 30,), 0xAB, dtype=torch.uint8, device="cuda")
+    allocs, top = [], [0]
+
+    def carve(shape, dtype):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        nbytes = n * torch.empty(0, dtype=dtype).element_size()
+        off = (top[0] + guard + 511) // 512 * 512
+        assert off + nbytes + guard <= arena.numel(), "test arena too small"
+        allocs.append((off, nbytes, tuple(shape)))
+        top[0] = off + nbytes
+        return arena[off:off + nbytes].view(dtype).view(tuple(int(d) for d in shape))
+
+    class GuardTorch:
+        def __getattr__(self, k):
+            return getattr(torch, k)
+
+        @staticmethod
+        def empty(*a, **k):
+            shape = a[0] if len(a) == 1 and isinstance(a[0], (tuple, list, torch.Size)) else a
+            return carve((shape,) if isinstance(shape, int) else tuple(shape), k.get("dtype", torch.float32))
+
+        @staticmethod
+        def empty_like(t, **k):
+            return carve(tuple(t.shape), t.dtype)
+
+    monkeypatch.setattr(IT, "torch", GuardTorch())
+    monkeypatch.setattr(IT, "_scratch", {})
+    _train_step(model, x, y)
+    torch.cuda.synchronize()
+    host = arena[:top[0] + guard].cpu()
+    assert len(allocs) > 200
+    end = 0
+    for off, nbytes, shape in allocs:
+        assert bool((host[end:off] == 0xAB).all()), f"a kernel wrote outside its buffer next to a tensor of shape {shape}"
+        end = off + nbytes
+    assert bool((host[end:end + guard] == 0xAB).all())
+
+
 def test_train_mode_updates_and_eval_after_training():
     """A few Adam steps in training mode lower the loss, BatchNorm counters advance like nn.BatchNorm1d (the strand-symmetry
     BatchNorm twice per forward), and the eval-mode fused program picks up the updated weights."""
