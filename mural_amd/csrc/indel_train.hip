@@ -502,6 +502,118 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_apply_kernel(const flo
   }
 }
 
+// Short tensors (the deep U-Net levels: B * L <= CB_ONEPASS elements per channel): one workgroup per channel does both passes of a
+// direction -- sums, then the map -- so the batch-sum launch, its atomics and the accumulator block drop out.  A thread keeps its
+// CB_OP_PER elements in registers between the passes.
+constexpr int CB_OP_PER = 8, CB_ONEPASS = IT_THREADS * CB_OP_PER;
+
+__device__ __forceinline__ void cb_block_sum2(double& a, double& b, double (*sh)[IT_THREADS]) {
+  sh[0][threadIdx.x] = a;
+  sh[1][threadIdx.x] = b;
+  __syncthreads();
+  for (int off = IT_THREADS / 2; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) {
+      sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
+      sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
+    }
+    __syncthreads();
+  }
+  a = sh[0][0];
+  b = sh[1][0];
+}
+
+__global__ __launch_bounds__(IT_THREADS) void bn_post_onepass_fwd_kernel(const float* __restrict__ y, int B, int C, int L,
+                                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                                         float eps, float momentum, float* __restrict__ running_mean,
+                                                                         float* __restrict__ running_var, float* __restrict__ state, int act,
+                                                                         const float* __restrict__ res1, const float* __restrict__ res2,
+                                                                         float* __restrict__ z) {
+  __shared__ double sh[2][IT_THREADS];
+  const int c = blockIdx.x, per = B * L;
+  float v[CB_OP_PER];
+  size_t o[CB_OP_PER];
+  double s = 0.0, q = 0.0;
+#pragma unroll
+  for (int j = 0; j < CB_OP_PER; ++j) {            // all of a thread's loads in flight together
+    const int i = threadIdx.x + j * IT_THREADS;
+    const int b = i / L, l = i - b * L;
+    o[j] = ((size_t)b * C + c) * L + l;
+    v[j] = i < per ? y[o[j]] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < CB_OP_PER; ++j) {
+    s += v[j];
+    q += (double)v[j] * v[j];
+  }
+  cb_block_sum2(s, q, sh);
+  const double n = (double)per, mean = s / n;
+  double var = q / n - mean * mean;
+  if (var < 0.0) var = 0.0;
+  const double invstd = 1.0 / sqrt(var + (double)eps);
+  const float sc = (float)(gamma[c] * invstd), sft = (float)(beta[c] - mean * gamma[c] * invstd);
+  if (threadIdx.x == 0) {
+    state[c] = sc;
+    state[C + c] = sft;
+    state[2 * C + c] = (float)mean;
+    state[3 * C + c] = (float)invstd;
+    if (running_mean) {
+      const double unbiased = n > 1.0 ? var * n / (n - 1.0) : var;
+      running_mean[c] = (float)((1.0 - momentum) * running_mean[c] + momentum * mean);
+      running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < CB_OP_PER; ++j) {
+    const int i = threadIdx.x + j * IT_THREADS;
+    if (i < per) {
+      float r = fmaf(sc, v[j], sft);
+      if (act) r = act_f(r, act);
+      if (res1) r += res1[o[j]];
+      if (res2) r += res2[o[j]];
+      z[o[j]] = r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(IT_THREADS) void bn_post_onepass_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y, int B,
+                                                                         int C, int L, const float* __restrict__ state,
+                                                                         const float* __restrict__ gamma, int act, float* __restrict__ dy,
+                                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  __shared__ double sh[2][IT_THREADS];
+  const int c = blockIdx.x, per = B * L;
+  const float sc = state[c], sft = state[C + c], mu = state[2 * C + c], is = state[3 * C + c];
+  float g[CB_OP_PER], xh[CB_OP_PER];
+  size_t o[CB_OP_PER];
+  double a = 0.0, bq = 0.0;
+#pragma unroll
+  for (int j = 0; j < CB_OP_PER; ++j) {
+    const int i = threadIdx.x + j * IT_THREADS;
+    const int b = i / L, l = i - b * L;
+    o[j] = ((size_t)b * C + c) * L + l;
+    const bool ok = i < per;
+    const float v = ok ? y[o[j]] : 0.f;
+    g[j] = ok ? dz[o[j]] : 0.f;
+    if (act) g[j] *= act_d(fmaf(sc, v, sft), act);
+    xh[j] = ok ? (v - mu) * is : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < CB_OP_PER; ++j) {
+    a += g[j];
+    bq += (double)g[j] * xh[j];
+  }
+  cb_block_sum2(a, bq, sh);
+  if (threadIdx.x == 0) {
+    dgamma[c] = (float)bq;
+    dbeta[c] = (float)a;
+  }
+  const float k0 = gamma[c] * is, m1 = (float)(a / per), m2 = (float)(bq / per);
+#pragma unroll
+  for (int j = 0; j < CB_OP_PER; ++j) {
+    const int i = threadIdx.x + j * IT_THREADS;
+    if (i < per) dy[o[j]] = k0 * (g[j] - m1 - xh[j] * m2);
+  }
+}
+
 int out_length(int Lin, int K, int stride, int pad, int up) { return (Lin * up + 2 * pad - K) / stride + 1; }
 
 }  // namespace
@@ -676,6 +788,12 @@ extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float
   if (int rc = mural_op_convg_fwd(x, W, bias, wt, y0, B, Cin, Lin, Cout, K, stride, pad, up, stream)) return rc;
   if (B == 0) return MURAL_OK;
   const int Lout = out_length(Lin, K, stride, pad, up);
+  if (B * Lout <= CB_ONEPASS) {       // short tensor: sums and map in one launch, one workgroup per channel
+    hipLaunchKernelGGL(bn_post_onepass_fwd_kernel, dim3(Cout), dim3(IT_THREADS), 0, (hipStream_t)stream, y0, (int)B, Cout, Lout, gamma, beta,
+                       eps, momentum, running_mean, running_var, state, act, res1, res2, z);
+    MURAL_HIP_CHECK(hipGetLastError());
+    return MURAL_OK;
+  }
   if (int rc = mural_op_bn_stats(y0, B, Cout, Lout, 0, acc, stream)) return rc;
   const int64_t total = B * Cout * Lout;
   int64_t gy = (B * Lout + 256 * 8 - 1) / (256 * 8);        // grid.y of mural_op_bn_stats: workgroup y adds into copy y % CB_SLOTS
@@ -701,12 +819,18 @@ extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const floa
   MURAL_REQUIRE(Lout >= 1, "convg_bn_bwd: bad geometry");
   hipStream_t st = (hipStream_t)stream;
   const int64_t per = B * Lout, total = per * Cout;
-  int gy = (int)((per + IT_THREADS * 8 - 1) / (IT_THREADS * 8));
-  gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
-  hipLaunchKernelGGL(bn_post_bwd_reduce_kernel, dim3(Cout, gy), dim3(IT_THREADS), 0, st, dz, y0, (int)B, Cout, Lout, state, act, acc);
-  int64_t g = (total + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
-  hipLaunchKernelGGL(bn_post_bwd_apply_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(IT_THREADS), (size_t)Cout * 6 * sizeof(float), st,
-                     dz, y0, total, Cout, Lout, state, gamma, acc, gy > CB_SLOTS ? CB_SLOTS : gy, (double)per, act, dy0, dgamma, dbeta);
+  if (per <= CB_ONEPASS) {            // short tensor: sums and map in one launch, one workgroup per channel
+    hipLaunchKernelGGL(bn_post_onepass_bwd_kernel, dim3(Cout), dim3(IT_THREADS), 0, st, dz, y0, (int)B, Cout, Lout, state, gamma, act, dy0,
+                       dgamma, dbeta);
+  } else {
+    int gy = (int)((per + IT_THREADS * 8 - 1) / (IT_THREADS * 8));
+    gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
+    hipLaunchKernelGGL(bn_post_bwd_reduce_kernel, dim3(Cout, gy), dim3(IT_THREADS), 0, st, dz, y0, (int)B, Cout, Lout, state, act, acc);
+    int64_t g = (total + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
+    hipLaunchKernelGGL(bn_post_bwd_apply_kernel, dim3((unsigned)(g > 2048 ? 2048 : g)), dim3(IT_THREADS), (size_t)Cout * 6 * sizeof(float),
+                       st, dz, y0, total, Cout, Lout, state, gamma, acc, gy > CB_SLOTS ? CB_SLOTS : gy, (double)per, act, dy0, dgamma,
+                       dbeta);
+  }
   MURAL_HIP_CHECK(hipGetLastError());
   return convg_bwd_impl(dy0, x, W, wt_dgrad, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
 }
