@@ -549,3 +549,50 @@ def test_forward_does_not_read_unwritten_workspace(n_sites, monkeypatch):
     d1, p1 = both()
     assert np.isfinite(d1).all() and np.isfinite(p1).all()
     assert np.abs(d1 - d0).max() <= 2e-6 and np.abs(p1 - p0).max() <= 2e-6
+
+
+@pytest.mark.parametrize("n_sites", [16, 200, 700])
+def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch):
+    """MURAL_DEBUG_WS_GUARD puts 4 KB of unused bytes behind every region of the forward's workspace (k-mer ids, symbols, pooled
+    rows, logits, hand-over tiles / arrival counters): with the workspace poisoned before the call, every guard byte is still the
+    poison afterwards -- no kernel of either launch shape writes outside the region it was given (dense and packed entry)."""
+    import ctypes as C
+    from mural_amd import _lib
+    from mural_amd.data import PackedGenome
+    from mural_amd.model import model_snv as MS
+    guard = 4096
+    monkeypatch.setenv("MURAL_DEBUG_WS_GUARD", str(guard))
+    monkeypatch.setattr(MS, "torch", _PoisonedTorch())
+    fx = U.load("snv_synth_S_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    model = model.cuda().eval()
+    r, R = int(fx["hp"][0]), int(fx["hp"][2])
+    rng = np.random.default_rng(n_sites)
+    seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=20_000, p=[.247, .247, .247, .247, .012]).tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = rng.integers(0, len(seq), size=n_sites)
+    strand = rng.integers(0, 2, size=n_sites).astype(np.uint8)
+    sym = ["-" if s else "+" for s in strand]
+    cat = torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, r, 3)).cuda()
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R)).cuda()
+    cont = torch.zeros(n_sites, 1, dtype=torch.float64, device="cuda")
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    for dense in (1, 0):
+        model._ws = None
+        model._ws_rows = [0, 0]
+        with torch.no_grad():
+            if dense:
+                out = model((cont, cat), x)
+            else:
+                out = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r, local_order=3)
+        assert torch.isfinite(out).all()
+        layout = (C.c_size_t * 16)()
+        n_regions = _lib.lib().mural_snv_debug_ws_layout(model._handle, n_sites, dense, layout)
+        assert n_regions == 7
+        ws = model._ws.cpu().numpy()
+        for i in range(n_regions):
+            off, size = layout[2 * i], layout[2 * i + 1]
+            zone = ws[off + size:off + size + guard]
+            assert len(zone) == guard and (zone == 255).all(), f"region {i} (dense={dense}): a kernel wrote behind its {size} bytes"
