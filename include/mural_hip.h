@@ -164,9 +164,11 @@ int mural_snv_debug_taps(const MuralSnvModel* m, const int64_t* cat_x, const flo
 /* geometry of the fused kernel for this model: fills out[0..15] =
  * {P, NBUF_floats, L2_large, L3_large, L4_large, L2_mid, L3_mid, L4_mid, n_tap_slots, ...}          */
 int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* out16);
-/* validation: (offset, bytes) pairs of the workspace regions of a forward over n sites (7 regions; layout holds 16 size_t); with
- * MURAL_DEBUG_WS_GUARD=<bytes> in the environment every region is followed by that many unused bytes */
-int mural_snv_debug_ws_layout(const MuralSnvModel* m, int64_t n, int32_t dense, size_t* layout);
+/* validation: (offset, bytes) pairs of the regions of the calling thread's latest workspace carve (mural_snv_forward_* /
+ * mural_snv_forward_packed_reuse and their *_workspace_bytes queries); returns the number of pairs.  With
+ * MURAL_DEBUG_WS_GUARD=<bytes> in the environment every region is followed by that many unused bytes, so that a test can poison a
+ * workspace, run a call and check that nothing was written outside the regions. */
+int mural_debug_last_ws_layout(size_t* out_pairs, int32_t max_pairs);
 
 /* ------------------------------------------------------------------------------------------------
  * INDEL model (UNet_Small, MuRaL/model/model_indel.py:21-176), eval mode.  Parameters are HOST pointers in the

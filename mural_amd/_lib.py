@@ -114,7 +114,7 @@ PROTOTYPES = {
     "mural_op_convg_bn_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP,
                                         C.c_size_t, VP, VP]),
     "mural_op_relayout_multi": (C.c_int, [VP, I32, I64, VP]),
-    "mural_snv_debug_ws_layout": (C.c_int, [VP, I64, I32, VP]),
+    "mural_debug_last_ws_layout": (C.c_int, [VP, I32]),
     "mural_op_act_fwd": (C.c_int, [VP, I64, I32, VP, VP]),
     "mural_op_act_bwd": (C.c_int, [VP, VP, I64, I32, VP, VP]),
     "mural_op_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]),

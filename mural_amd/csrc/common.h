@@ -13,6 +13,12 @@
 namespace mural {
 
 void set_error(const char* fmt, ...);
+// Validation of the workspace carvers (tests only): MURAL_DEBUG_WS_GUARD=<bytes> in the environment puts that many unused bytes behind
+// every region a carver hands out, and the regions of the calling thread's latest carve are kept for mural_debug_last_ws_layout, so
+// that a test can poison a workspace, run a call and see that nothing was written outside the regions.
+size_t ws_guard_bytes();
+void ws_layout_reset();
+void ws_layout_add(size_t off, size_t bytes);
 
 #define MURAL_HIP_CHECK(expr)                                                                      \
   do {                                                                                             \

@@ -18,6 +18,20 @@ void set_error(const char* fmt, ...) {
 
 const char* last_error_cstr() { return g_err.c_str(); }
 
+static thread_local std::vector<size_t> g_ws_layout;
+
+size_t ws_guard_bytes() {
+  const char* e = getenv("MURAL_DEBUG_WS_GUARD");
+  return e ? (size_t)atol(e) : 0;
+}
+void ws_layout_reset() { g_ws_layout.clear(); }
+void ws_layout_add(size_t off, size_t bytes) {
+  if (g_ws_layout.size() < 256) {
+    g_ws_layout.push_back(off);
+    g_ws_layout.push_back(bytes);
+  }
+}
+
 // one thread per (row, column): order-k index over the strand-oriented window
 __global__ void encode_kmer_kernel(MuralGenome g, const int64_t* __restrict__ pos, const uint8_t* __restrict__ strand,
                                    int64_t n, int off, int width, int order, int ncol, int64_t* __restrict__ out) {
@@ -167,4 +181,13 @@ extern "C" int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, con
                      width, out);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
+}
+
+// (offset, bytes) pairs of the regions of the calling thread's latest workspace carve (forward / reuse entry points and their
+// *_workspace_bytes queries); returns the number of pairs written (at most max_pairs)
+extern "C" int mural_debug_last_ws_layout(size_t* out, int32_t max_pairs) {
+  const int n = (int)(mural::g_ws_layout.size() / 2);
+  const int m = n < max_pairs ? n : max_pairs;
+  for (int i = 0; i < 2 * m; ++i) out[i] = mural::g_ws_layout[i];
+  return m;
 }

@@ -263,24 +263,13 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; float* s3[2]; };
 
-// MURAL_DEBUG_WS_GUARD=<bytes> (validation only, read per call): that many unused bytes behind every region, so that a test can
-// poison the workspace, run a forward and see that no kernel wrote outside its region (mural_snv_debug_ws_layout)
-size_t ws_guard() {
-  const char* e = getenv("MURAL_DEBUG_WS_GUARD");
-  return e ? (size_t)atol(e) : 0;
-}
-
-size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w, size_t* layout = nullptr) {
+size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
   size_t off = 0;
-  const size_t guard = ws_guard();
-  int region = 0;
+  const size_t guard = ws_guard_bytes();      // 0 outside the validation tests (common.h)
+  ws_layout_reset();
   auto take = [&](size_t bytes) {
     size_t o = off;
-    if (layout) {
-      layout[2 * region] = o;
-      layout[2 * region + 1] = bytes;
-    }
-    ++region;
+    ws_layout_add(o, bytes);
     off = align_up(off + bytes + guard, 256);
     return o;
   };
@@ -463,15 +452,6 @@ extern "C" void mural_snv_model_destroy(MuralSnvModel* m) {
 extern "C" size_t mural_snv_workspace_bytes(const MuralSnvModel* m, int64_t n, int32_t dense) {
   if (!m || n <= 0) return 256;
   return carve(m, n, dense != 0, nullptr, nullptr);
-}
-
-// (offset, bytes) of the workspace regions of a forward over n sites, in the order local logits | k-mer ids | symbols | pooled
-// first-layer rows | large-tower logits | hand-over tiles (large, mid); returns the number of regions
-extern "C" int mural_snv_debug_ws_layout(const MuralSnvModel* m, int64_t n, int32_t dense, size_t* layout /* [2 * 8] */) {
-  if (!m || !layout || n <= 0) return 0;
-  std::memset(layout, 0, 16 * sizeof(size_t));
-  carve(m, n, dense != 0, nullptr, nullptr, layout);
-  return 7;
 }
 
 extern "C" int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* o) {

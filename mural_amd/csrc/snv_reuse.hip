@@ -469,9 +469,12 @@ struct ReuseWs {
 size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands, void* base, ReuseWs* w) {
   const int64_t nb = std::min<int64_t>(span, RU_CHUNK_SPAN) + m->shape.distal_len;
   size_t off = 0;
+  const size_t guard = ws_guard_bytes();      // 0 outside the validation tests (common.h)
+  ws_layout_reset();
   auto take = [&](size_t bytes) {
     size_t o = off;
-    off = align_up(off + bytes, 256);
+    ws_layout_add(o, bytes);
+    off = align_up(off + bytes + guard, 256);
     return o;
   };
   size_t o_rows[2][11];

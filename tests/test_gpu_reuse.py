@@ -130,3 +130,33 @@ def test_reuse_does_not_read_unwritten_workspace(monkeypatch):
         got = model.forward_packed_reuse(genome, tp, ts, local_radius=10, local_order=3).cpu().numpy()
     assert np.isfinite(got).all()
     assert np.abs(got - want).max() <= 2e-6
+
+
+def test_reuse_writes_stay_inside_their_workspace_regions(monkeypatch):
+    """The reuse path's workspace with 4 KB of poisoned guard bytes behind every region (per-base rows of both strands, k-mer ids,
+    logits, hand-over tiles): every guard byte survives the call."""
+    import ctypes as C
+    from mural_amd import _lib
+    from mural_amd.data import PackedGenome
+    from mural_amd.model import model_snv as MS
+    from tests.test_gpu_snv import _PoisonedTorch
+    guard = 4096
+    monkeypatch.setenv("MURAL_DEBUG_WS_GUARD", str(guard))
+    monkeypatch.setattr(MS, "torch", _PoisonedTorch())
+    model, _ = _pair(10, 1000, 2)
+    rng = np.random.default_rng(78)
+    n = 30_000
+    genome = PackedGenome.from_sequence(_genome(rng, n), "cuda")
+    pos = np.r_[np.arange(0, 900), np.arange(12000, 15000), np.arange(n - 500, n), rng.integers(0, n, size=200)]
+    strand = (np.arange(len(pos)) % 2).astype(np.uint8)
+    with torch.no_grad():
+        out = model.forward_packed_reuse(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=10, local_order=3)
+    assert torch.isfinite(out).all()
+    layout = (C.c_size_t * 128)()
+    n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 64)
+    assert n_regions >= 20
+    ws = model._ws.cpu().numpy()
+    for i in range(n_regions):
+        off, size = layout[2 * i], layout[2 * i + 1]
+        zone = ws[off + size:off + size + guard]
+        assert len(zone) == guard and (zone == 255).all(), f"region {i}: a kernel wrote behind its {size} bytes"

@@ -554,7 +554,8 @@ def test_forward_does_not_read_unwritten_workspace(n_sites, monkeypatch):
 @pytest.mark.parametrize("n_sites", [16, 200, 700])
 def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch):
     """MURAL_DEBUG_WS_GUARD puts 4 KB of unused bytes behind every region of the forward's workspace (k-mer ids, symbols, pooled
-    rows, logits, hand-over tiles / arrival counters): with the workspace poisoned before the call, every guard byte is still the
+    rows, logits, hand-over tiles / arrival counters; ``mural_debug_last_ws_layout`` lists them): with the workspace poisoned before the
+    call, every guard byte is still the
     poison afterwards -- no kernel of either launch shape writes outside the region it was given (dense and packed entry)."""
     import ctypes as C
     from mural_amd import _lib
@@ -588,8 +589,8 @@ def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch
             else:
                 out = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r, local_order=3)
         assert torch.isfinite(out).all()
-        layout = (C.c_size_t * 16)()
-        n_regions = _lib.lib().mural_snv_debug_ws_layout(model._handle, n_sites, dense, layout)
+        layout = (C.c_size_t * 64)()
+        n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 32)      # the carve of the call just made (this thread's latest)
         assert n_regions == 7
         ws = model._ws.cpu().numpy()
         for i in range(n_regions):
