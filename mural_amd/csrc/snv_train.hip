@@ -54,10 +54,12 @@ constexpr size_t ACC_DOUBLES_32 = (size_t)MURAL_BN_SLOTS * 2 * TR_C;
 struct Arena {            // bump allocator over the caller's workspace; base == nullptr: dry run that only measures
   char* base;
   size_t off = 0;
-  explicit Arena(void* b) : base(static_cast<char*>(b)) {}
+  size_t guard;           // validation only (MURAL_DEBUG_WS_GUARD, common.h): unused bytes behind every region
+  explicit Arena(void* b) : base(static_cast<char*>(b)), guard(ws_guard_bytes()) { ws_layout_reset(); }
   void* take(size_t bytes) {
     const size_t o = off;
-    off = (off + bytes + 255) & ~size_t(255);
+    if (bytes) ws_layout_add(o, bytes);
+    off = (off + bytes + (bytes ? guard : 0) + 255) & ~size_t(255);
     return base ? base + o : nullptr;
   }
   float* f(size_t n) { return static_cast<float*>(take(n * 4)); }
@@ -185,6 +187,8 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
   // ---- accumulators
   const size_t acc0 = A.off;
   char* acc_base = static_cast<char*>(A.take(0));
+  const size_t guard_outside = A.guard;
+  A.guard = 0;            // the accumulator blocks are one range, cleared by one memset per step
   if (towers) {
     for (int t = 0; t < 2; ++t) {
       TowerBufs& b = P->tw[t];
@@ -205,6 +209,8 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
   }
   P->acc_begin = reinterpret_cast<double*>(acc_base);
   P->acc_bytes = A.off - acc0;
+  A.guard = guard_outside;
+  A.off += A.guard;       // (behind the accumulator range as a whole)
   // ---- backward temporaries
   for (int i = 0; i < 4; ++i) P->g[i] = A.f(max_act);
   if (towers)

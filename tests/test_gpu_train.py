@@ -470,3 +470,54 @@ def test_train_step_does_not_read_unwritten_workspace(monkeypatch):
     for k in g0:
         assert torch.isfinite(g1[k]).all(), k
         assert float((g1[k] - g0[k]).abs().max()) <= 2e-4 * (float(g0[k].abs().max()) + 1e-2), k
+
+
+def test_train_step_writes_stay_inside_their_workspace_regions(monkeypatch):
+    """The composed training step's workspace with 4 KB of poisoned guard bytes behind every region (activations, arg-max bytes,
+    BatchNorm states, gradient tables, partial sums; the accumulator blocks count as one region): every guard byte survives a
+    forward + backward."""
+    import ctypes as C
+    from mural_amd import _lib
+    from mural_amd.model import train_step as TS
+    from tests.test_gpu_snv import _PoisonedTorch
+    guard = 4096
+    monkeypatch.setenv("MURAL_DEBUG_WS_GUARD", str(guard))
+    fx = U.load("snv_train_T.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    model = model.cuda().train()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"].astype(np.int64)).cuda()
+    cont = torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda")
+    kept = []
+
+    class Keep(_PoisonedTorch):
+        @staticmethod
+        def empty(*a, **k):
+            t = _PoisonedTorch.empty(*a, **k)
+            if t.dtype is torch.uint8:
+                kept.append(t)
+            return t
+
+    monkeypatch.setattr(TS, "torch", Keep())
+    loss = nn.CrossEntropyLoss(reduction="sum")(model((cont, cat), x), y)
+    model.zero_grad()
+    loss.backward()
+    torch.cuda.synchronize()
+    assert torch.isfinite(loss) and len(kept) == 1
+    layout = (C.c_size_t * 512)()
+    n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 256)
+    assert n_regions > 60
+    ws = kept[0].cpu().numpy()
+    acc_like = 0
+    for i in range(n_regions):
+        off, size = layout[2 * i], layout[2 * i + 1]
+        nxt = layout[2 * i + 2] if i + 1 < n_regions else len(ws)
+        if nxt - (off + size) < guard:          # inside the accumulator range: no guard between its blocks
+            acc_like += 1
+            continue
+        zone = ws[off + size:off + size + guard]
+        assert (zone == 255).all(), f"region {i}: a kernel wrote behind its {size} bytes"
+    assert acc_like < n_regions // 2
