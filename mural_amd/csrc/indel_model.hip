@@ -226,11 +226,14 @@ extern "C" void mural_indel_model_destroy(MuralIndelModel* m) {
   delete m;
 }
 
+constexpr size_t INDEL_WS_REGIONS = INDEL_LEVELS + 6;   // S | E[levels] | T1 | T2 | H | SP | M
+
 extern "C" size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n) {
   if (!m || n <= 0) return 256;
   // two chunks in flight (one per stream, see mural_indel_forward_dense) once there is more than one
   const size_t lanes = n > INDEL_CHUNK ? 2 : 1;
-  return lanes * (size_t)std::min<int64_t>(n, INDEL_CHUNK) * m->per_pos_floats * 4 + 4096;
+  // (+ the validation guard behind each of a lane's INDEL_WS_REGIONS regions: 0 outside the tests, common.h)
+  return lanes * ((size_t)std::min<int64_t>(n, INDEL_CHUNK) * m->per_pos_floats * 4 + INDEL_WS_REGIONS * ws_guard_bytes()) + 4096;
 }
 
 static int run_conv(const MuralIndelModel* m, const FoldedConv& f, const float* in, int B, int Lin, float* out, int Lout,
@@ -326,9 +329,18 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     const int B = (int)std::min<int64_t>(INDEL_CHUNK, n - c0);
     const int lane = (int)(chunk_no % lanes);
     hipStream_t stream = lane == 0 ? main_stream : ss->side;
-    float* p = static_cast<float*>(workspace) + (size_t)lane * INDEL_CHUNK * m->per_pos_floats;
+    const size_t guard_floats = ws_guard_bytes() / 4;
+    float* p = static_cast<float*>(workspace) + (size_t)lane * (INDEL_CHUNK * m->per_pos_floats + INDEL_WS_REGIONS * guard_floats);
+    if (chunk_no < lanes) {
+      if (chunk_no == 0) ws_layout_reset();
+    }
     rc_all = [&]() -> int {
-    auto take = [&](size_t per_pos) { float* r = p; p += per_pos * (size_t)B; return r; };
+    auto take = [&](size_t per_pos) {
+      float* r = p;
+      if (chunk_no < lanes) ws_layout_add((size_t)(r - static_cast<float*>(workspace)) * 4, per_pos * (size_t)B * 4);
+      p += per_pos * (size_t)B + guard_floats;
+      return r;
+    };
     float* S = take((size_t)4 * Lx);
     float* E[INDEL_LEVELS];
     for (int i = 0; i < INDEL_LEVELS; ++i) E[i] = take((size_t)m->ch[i] * m->len[i]);

@@ -83,6 +83,35 @@ def test_forward_does_not_read_unwritten_workspace(monkeypatch):
     assert np.isfinite(got).all() and np.abs(got - want).max() <= 1e-6 * max(1.0, np.abs(want).max())
 
 
+def test_forward_writes_stay_inside_their_workspace_regions(monkeypatch):
+    """The eval-mode forward's workspace (both lanes) with 4 KB of poisoned guard bytes behind every region: all survive the call."""
+    import ctypes as C
+    from mural_amd import _lib
+    from mural_amd.model import model_indel as MI
+    from tests.test_gpu_snv import _PoisonedTorch
+    guard = 4096
+    monkeypatch.setenv("MURAL_DEBUG_WS_GUARD", str(guard))
+    monkeypatch.setattr(MI, "torch", _PoisonedTorch())
+    fx = U.load("indel_synth_small.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc))
+    model = model.cuda().eval()
+    x = U.onehot(np.random.default_rng(6).integers(0, 4, size=(2500, fx["codes"].shape[1])).astype(np.uint8)).cuda()
+    model._ws = None
+    with torch.no_grad():
+        out = model(x)
+    assert torch.isfinite(out).all()
+    layout = (C.c_size_t * 128)()
+    n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 64)
+    assert n_regions >= 16          # two lanes
+    ws = model._ws.cpu().numpy()
+    for i in range(n_regions):
+        off, size = layout[2 * i], layout[2 * i + 1]
+        zone = ws[off + size:off + size + guard]
+        assert len(zone) == guard and (zone == 255).all(), f"region {i}: a kernel wrote behind its {size} bytes"
+
+
 def test_incompatible_length_is_rejected():
     fx = U.load("indel_synth_small.npz")
     model = product_from(fx).cuda().eval()
