@@ -421,6 +421,27 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* 
     }
   }
   __syncthreads();
+  if ((L & 3) == 0 && total < (int64_t(1) << 31)) {
+    // four consecutive positions of a row per thread: 16-byte accesses and one pair of 32-bit divisions per four elements (two
+    // 64-bit divisions per element made this map ALU-bound)
+    const uint32_t nq = (uint32_t)(total >> 2), qstep = gridDim.x * IT_THREADS;
+    for (uint32_t q = blockIdx.x * IT_THREADS + threadIdx.x; q < nq; q += qstep) {
+      const uint32_t e = q << 2;
+      const int c = (int)((e / (uint32_t)L) % (uint32_t)C);
+      const float sc = cst[2 * c], sh = cst[2 * c + 1];
+      const f32x4 yv = ld4(y + e);
+      f32x4 r;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        r[t] = fmaf(sc, yv[t], sh);
+        if (act) r[t] = act_f(r[t], act);
+      }
+      if (res1) r += ld4(res1 + e);
+      if (res2) r += ld4(res2 + e);
+      st4(z + e, r);
+    }
+    return;
+  }
   const int64_t step = (int64_t)gridDim.x * IT_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < total; i += step) {
     const int c = (int)((i / L) % C);
@@ -440,15 +461,31 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_reduce_kernel(const fl
   const float sc = state[c], sh = state[C + c], mu = state[2 * C + c], is = state[3 * C + c];
   double a = 0.0, bq = 0.0;
   const int64_t per = (int64_t)B * L;
-  for (int64_t i = (int64_t)blockIdx.y * IT_THREADS + threadIdx.x; i < per; i += (int64_t)gridDim.y * IT_THREADS) {
-    const int64_t b = i / L;
-    const int l = (int)(i - b * L);
-    const size_t o = (size_t)(b * C + c) * L + l;
-    const float v = y[o];
-    float g = dz[o];
-    if (act) g *= act_d(fmaf(sc, v, sh), act);
-    a += g;
-    bq += (double)g * ((v - mu) * is);
+  if ((L & 3) == 0 && per * C < (int64_t(1) << 31)) {   // four positions per thread, 32-bit index math
+    const uint32_t nq = (uint32_t)(per >> 2), qstep = gridDim.y * IT_THREADS;
+    for (uint32_t q = blockIdx.y * IT_THREADS + threadIdx.x; q < nq; q += qstep) {
+      const uint32_t e = q << 2, b = e / (uint32_t)L, l = e - b * (uint32_t)L;
+      const uint32_t o = (b * (uint32_t)C + (uint32_t)c) * (uint32_t)L + l;
+      const f32x4 yv = ld4(y + o), gz = ld4(dz + o);
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float g = gz[t];
+        if (act) g *= act_d(fmaf(sc, yv[t], sh), act);
+        a += g;
+        bq += (double)g * ((yv[t] - mu) * is);
+      }
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.y * IT_THREADS + threadIdx.x; i < per; i += (int64_t)gridDim.y * IT_THREADS) {
+      const int64_t b = i / L;
+      const int l = (int)(i - b * L);
+      const size_t o = (size_t)(b * C + c) * L + l;
+      const float v = y[o];
+      float g = dz[o];
+      if (act) g *= act_d(fmaf(sc, v, sh), act);
+      a += g;
+      bq += (double)g * ((v - mu) * is);
+    }
   }
   __shared__ double sh2[2][IT_THREADS];
   sh2[0][threadIdx.x] = a;
@@ -491,6 +528,25 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_apply_kernel(const flo
     }
   }
   __syncthreads();
+  if ((L & 3) == 0 && total < (int64_t(1) << 31)) {   // (as in bn_post_apply_kernel)
+    const uint32_t nq = (uint32_t)(total >> 2), qstep = gridDim.x * IT_THREADS;
+    for (uint32_t q = blockIdx.x * IT_THREADS + threadIdx.x; q < nq; q += qstep) {
+      const uint32_t e = q << 2;
+      const int c = (int)((e / (uint32_t)L) % (uint32_t)C);
+      const float k0 = cst[6 * c + 0], m1 = cst[6 * c + 1], m2 = cst[6 * c + 2], mu = cst[6 * c + 3], sc = cst[6 * c + 4],
+                  sh = cst[6 * c + 5], is = state[3 * C + c];
+      const f32x4 yv = ld4(y + e), gz = ld4(dz + e);
+      f32x4 r;
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float g = gz[t];
+        if (act) g *= act_d(fmaf(sc, yv[t], sh), act);
+        r[t] = k0 * (g - m1 - (yv[t] - mu) * is * m2);
+      }
+      st4(dy + e, r);
+    }
+    return;
+  }
   const int64_t step = (int64_t)gridDim.x * IT_THREADS;
   for (int64_t i = (int64_t)blockIdx.x * IT_THREADS + threadIdx.x; i < total; i += step) {
     const int c = (int)((i / L) % C);
