@@ -43,13 +43,30 @@ __global__ __launch_bounds__(256) void bn_stats_kernel(const float* __restrict__
   const int c = blockIdx.x;
   double s = 0.0, q = 0.0;
   const int64_t per = (int64_t)B * L;
-  for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.y * blockDim.x) {
-    const int64_t b = i / L;
-    const int l = (int)(i - b * L);
-    float v = x[(b * C + c) * L + l];
-    if (relu) v = fmaxf(v, 0.f);
-    s += v;
-    q += (double)v * v;
+  if ((L & 3) == 0 && per * C < (int64_t(1) << 31)) {
+    // four consecutive positions per thread: 16-byte loads and 32-bit index math (a 64-bit division per element made the pass
+    // ALU-bound on the long rows of the U-Net's first levels)
+    const uint32_t nq = (uint32_t)(per >> 2), qstep = gridDim.y * blockDim.x;
+    for (uint32_t qi = blockIdx.y * blockDim.x + threadIdx.x; qi < nq; qi += qstep) {
+      const uint32_t e = qi << 2, b = e / (uint32_t)L, l = e - b * (uint32_t)L;
+      const float4 v4 = *reinterpret_cast<const float4*>(x + (size_t)(b * (uint32_t)C + (uint32_t)c) * L + l);
+      const float vv[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const float v = relu ? fmaxf(vv[t], 0.f) : vv[t];
+        s += v;
+        q += (double)v * v;
+      }
+    }
+  } else {
+    for (int64_t i = (int64_t)blockIdx.y * blockDim.x + threadIdx.x; i < per; i += (int64_t)gridDim.y * blockDim.x) {
+      const int64_t b = i / L;
+      const int l = (int)(i - b * L);
+      float v = x[(b * C + c) * L + l];
+      if (relu) v = fmaxf(v, 0.f);
+      s += v;
+      q += (double)v * v;
+    }
   }
   __shared__ double sh[2][256];
   sh[0][threadIdx.x] = s;
