@@ -296,7 +296,7 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
     # one training configuration of the same model: batch 128 (the reference's default), CE(sum) + clip + Adam.  The step is ~500
     # small launches behind Python autograd glue: the eager loop runs at the speed of the host's Python (7-11 ms on this pool's
     # boxes), mural_amd.train.GraphedIndelTrainStep replays the same step as one HIP graph and is bound by the device alone.
-    from mural_amd.train import GraphedIndelTrainStep
+    from mural_amd.train import GraphedIndelTrainStep, clip_grad_norm_
     tb = 128
     model.train()
     crit = torch.nn.CrossEntropyLoss(reduction="sum")
@@ -308,7 +308,7 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
         loss = crit(model(x), y)
         opt.zero_grad()
         loss.backward()
-        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, error_if_nonfinite=False)
+        clip_grad_norm_(model, 10)            # mural_amd.train: the launches of torch.nn.utils.clip_grad_norm_ over a cached parameter list
         opt.step()
 
     for _ in range(3):

@@ -131,7 +131,21 @@ def clip_grad_norm_(model, max_norm):
             total = torch.linalg.vector_norm(flat, 2.0)
             flat.mul_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
             return total
-    return torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=max_norm, error_if_nonfinite=False)
+    # separate gradient tensors (UNet_Small, the per-layer SNV paths): torch's own sequence of launches -- per-tensor norms by one
+    # foreach call, the norm of those, one foreach multiply -- without walking the module tree and regrouping ~150 tensors every
+    # step (0.3 of the 0.8 ms that call costs on the host; the parameter list is cached on the model)
+    plist = getattr(model, "_clip_plist", None)
+    if plist is None:
+        plist = model._clip_plist = [p for p in model.parameters()]
+    grads = [p.grad for p in plist if p.grad is not None]
+    if not grads:
+        return torch.zeros((), device=plist[0].device if plist else "cpu")
+    dev, dt = grads[0].device, grads[0].dtype
+    if any(g.device != dev or g.dtype != dt for g in grads):
+        return torch.nn.utils.clip_grad_norm_(plist, max_norm=max_norm, error_if_nonfinite=False)
+    total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads, 2.0)), 2.0)
+    torch._foreach_mul_(grads, torch.clamp(max_norm / (total + 1e-6), max=1.0))
+    return total
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -328,6 +328,32 @@ def test_train_step_writes_stay_inside_their_buffers(monkeypatch):
     assert bool((host[end:end + guard] == 0xAB).all())
 
 
+def test_clip_grad_norm_on_separate_gradient_tensors_matches_torch():
+    """mural_amd.train.clip_grad_norm_ on a model whose gradients are separate tensors (UNet_Small) == torch.nn.utils.clip_grad_norm_:
+    same total norm, same clipped gradients, and no clipping below the bound."""
+    from mural_amd.train import clip_grad_norm_
+    fx = U.load("indel_train_rev.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc), strict=True)
+    model = model.cuda().train()
+    model.out_fc[1].p = 0.0
+    x, y = U.onehot(fx["codes"]).cuda(), torch.from_numpy(fx["y"]).cuda()
+    _train_step(model, x, y)
+    g0 = [p.grad.clone() for p in model.parameters()]
+    for bound in (1e-3, 1e9):
+        for p, g in zip(model.parameters(), g0):
+            p.grad = g.clone()
+        want = torch.nn.utils.clip_grad_norm_(model.parameters(), bound)
+        ref = [p.grad.clone() for p in model.parameters()]
+        for p, g in zip(model.parameters(), g0):
+            p.grad = g.clone()
+        got = clip_grad_norm_(model, bound)
+        assert abs(float(got) - float(want)) <= 1e-6 * float(want)
+        for p, r in zip(model.parameters(), ref):
+            assert torch.equal(p.grad, r)
+
+
 def test_train_mode_updates_and_eval_after_training():
     """A few Adam steps in training mode lower the loss, BatchNorm counters advance like nn.BatchNorm1d (the strand-symmetry
     BatchNorm twice per forward), and the eval-mode fused program picks up the updated weights."""

@@ -10,6 +10,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mural_amd.model import model_choice, weights_init  # noqa: E402
+from mural_amd.train import clip_grad_norm_  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
@@ -29,7 +30,7 @@ def step():
     loss = crit(model(x), y)
     opt.zero_grad()
     loss.backward()
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, error_if_nonfinite=False)
+    clip_grad_norm_(model, 10)
     opt.step()
     return loss
 

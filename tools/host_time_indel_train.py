@@ -9,6 +9,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from mural_amd.model import model_choice, weights_init  # noqa: E402
+from mural_amd.train import clip_grad_norm_  # noqa: E402
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 and sys.argv[1].isdigit() else 16
 cfg = dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=[1, 4, 5, 5, 5, 2], use_reverse=True)
@@ -40,7 +41,7 @@ def step():
     t = lap("zero_grad", t)
     loss.backward()
     t = lap("backward", t)
-    torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=10, error_if_nonfinite=False)
+    clip_grad_norm_(model, 10)
     t = lap("clip", t)
     opt.step()
     lap("optimizer", t)
