@@ -1,0 +1,52 @@
+"""The prediction paths have no floating-point atomics and no order-dependent reductions: the same call twice gives the same bits.
+(A difference would point at a race -- two lanes of a forward sharing scratch, a hand-over read before it was published.)"""
+import numpy as np
+import pytest
+import torch
+
+from tests import _util as U
+
+pytestmark = pytest.mark.gpu
+
+
+def _snv():
+    from tests.test_gpu_snv import product_from_hp
+    fx = U.load("snv_synth_S_net2.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"])
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    return model.cuda().eval(), int(fx["hp"][0]), int(fx["hp"][2])
+
+
+@pytest.mark.parametrize("n_sites", [40, 3000])
+def test_snv_forwards_are_bitwise_repeatable(n_sites):
+    from mural_amd.data import PackedGenome
+    model, r, R = _snv()
+    rng = np.random.default_rng(n_sites)
+    seq = rng.choice(np.frombuffer(b"ACGTNRY", np.uint8), size=40_000, p=[.245, .245, .245, .245, .01, .005, .005]).tobytes().decode()
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    pos = torch.from_numpy(np.sort(rng.integers(0, len(seq), size=n_sites))).cuda()
+    strand = torch.from_numpy(rng.integers(0, 2, size=n_sites).astype(np.uint8)).cuda()
+    x = genome.encode_onehot(pos, strand, R)
+    cat = genome.encode_kmer(pos, strand, r, 3)
+    cont = torch.zeros(n_sites, 1, dtype=torch.float64, device="cuda")
+    with torch.no_grad():
+        runs = [(model((cont, cat), x), model.forward_packed(genome, pos, strand, local_radius=r, local_order=3),
+                 model.forward_packed_reuse(genome, pos, strand, local_radius=r, local_order=3)) for _ in range(3)]
+    for later in runs[1:]:
+        for a, b in zip(runs[0], later):
+            assert torch.equal(a, b)
+
+
+def test_indel_forward_is_bitwise_repeatable_across_both_lanes():
+    from tests.test_gpu_indel import product_from
+    fx = U.load("indel_synth_small.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc))
+    model = model.cuda().eval()
+    x = U.onehot(np.random.default_rng(9).integers(0, 4, size=(5000, fx["codes"].shape[1])).astype(np.uint8)).cuda()
+    with torch.no_grad():
+        a, b, c = model(x), model(x), model(x)
+        rows = torch.cat([model(x[:2048]), model(x[2048:4096]), model(x[4096:])])      # the same chunks, one lane at a time
+    assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, rows)
