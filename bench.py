@@ -433,6 +433,124 @@ def dense_reuse(device, model, genome, sites, steps):
                     "and strand, per site only the window-edge columns and the short stages (csrc/snv_reuse.hip)"}
 
 
+_DUP_KEYS = {".layer.1.": ".bn1.", ".layer.2.": ".conv1.", ".layer.4.": ".bn2.", ".layer.5.": ".conv2."}
+
+
+def shipped_snv_model(device, name="snv_pretrained_human_AT.npz"):
+    """Network2 with the shipped Homo_sapiens/SNV/AT weights (they travel inside the parity fixture tests/golden/<name>, which stores
+    every tensor once: the ResBlock's double-registered keys are expanded here); (model, local_radius, distal_radius)."""
+    from mural_amd.model import model_choice
+    fx = np.load(os.path.join(ROOT, "tests", "golden", name))
+    r, order, R, h1, h2, ch, k, n_class = [int(v) for v in fx["hp"][:8]]
+    cfg = dict(local_radius=r, local_order=order, local_hidden1_size=h1, local_hidden2_size=h2, distal_radius=R, emb_dropout=0.1,
+               local_dropout=0.1, CNN_kernel_size=k, CNN_out_channels=ch, distal_fc_dropout=0.25)
+    common = dict(emb_dims=[(4 ** order + 1, 2)] * (2 * r + 1 - (order - 1)), n_cont=0, n_class=n_class, distal_order=1, in_channels=4)
+    model = model_choice(2, cfg, common, "snv")
+    sd = {}
+    for key in model.state_dict():
+        src = key
+        for a, b in _DUP_KEYS.items():
+            src = src.replace(a, b)
+        sd[key] = torch.from_numpy(np.asarray(fx["w::" + src]))
+    model.load_state_dict(sd)
+    return model.to(device).eval(), r, order, R
+
+
+def synth_config5_files(workdir, device, n_chrom=3, chrom_len=7_000_000, seed=7):
+    """Synthetic inputs of the file-to-file run: a FASTA of `n_chrom` i.i.d. uniform ACGT chromosomes (60-column lines) and the BED of
+    an AT-model site list -- every A as a '+' site, every T as a '-' site (one focal base after strand complement, as the reference
+    requires), labels 0..3.  Generated on the device (random draws, site selection, and the BED text through the library's own row
+    formatter in its BED6 layout), because the host side of a 20 M-line text file is minutes of numpy.  Returns (fasta, bed, rows)."""
+    from mural_amd import _lib
+    from mural_amd.predict import _name_table, _tsv_struct
+    lib = _lib.lib()
+    fa, bed = os.path.join(workdir, "genome.fa"), os.path.join(workdir, "sites.bed")
+    gen = torch.Generator(device=device).manual_seed(seed)
+    lut = torch.tensor(list(b"ACGT"), dtype=torch.uint8, device=device)
+    rows = 0
+    piece = 1 << 21
+    with open(fa, "wb") as f, open(bed, "wb") as b:
+        for c in range(n_chrom):
+            name = "chr%d" % (c + 1)
+            codes = torch.randint(0, 4, (chrom_len,), device=device, generator=gen)
+            seq = lut[codes]
+            whole = chrom_len // 60 * 60
+            lines = torch.cat([seq[:whole].view(-1, 60), torch.full((whole // 60, 1), 10, dtype=torch.uint8, device=device)], dim=1)
+            f.write(b">" + name.encode() + b"\n")
+            f.write(lines.cpu().numpy().tobytes())
+            if whole < chrom_len:
+                f.write(seq[whole:].cpu().numpy().tobytes() + b"\n")
+            pos = torch.nonzero((codes == 0) | (codes == 3)).flatten()
+            strand = (codes[pos] == 3).to(torch.uint8)
+            u = torch.rand(pos.shape[0], device=device, generator=gen)
+            label = ((u < 0.03).to(torch.float32) * (1 + (u * 1e4).to(torch.int64) % 3).to(torch.float32)).contiguous()
+            end = pos + 1
+            names = _name_table([name])
+            t = _tsv_struct(names, 1, None, 0, 0, 0, 0, None, False, 0, 0, None, 0)
+            t.layout = 1
+            bound = int(lib.mural_tsv_row_bound(C.byref(t)))
+            text = torch.empty(piece * bound, dtype=torch.uint8, device=device)
+            count = torch.zeros(1, dtype=torch.int64, device=device)
+            ws = torch.empty(int(lib.mural_tsv_format_workspace_bytes(piece)) + 256, dtype=torch.uint8, device=device)
+            for r0 in range(0, pos.shape[0], piece):
+                m = min(piece, pos.shape[0] - r0)
+                t.start, t.end = pos[r0:].data_ptr(), end[r0:].data_ptr()
+                t.strand, t.label, t.n = strand[r0:].data_ptr(), label[r0:].data_ptr(), m
+                _lib.check(lib.mural_tsv_format_device(C.byref(t), text.data_ptr(), text.numel(), count.data_ptr(), ws.data_ptr(), ws.numel(),
+                                                      _lib.current_stream_ptr(device)))
+                b.write(text[:int(count.item())].cpu().numpy().tobytes())
+            rows += int(pos.shape[0])
+    return fa, bed, rows
+
+
+def config5_e2e(device, n_chrom=3, chrom_len=14_000_000):
+    """BASELINE.json configs[4] at N = 1, file to file: FASTA + BED -> sorted '%.4g' prediction table (run_predict.py:188-239) through
+    mural_amd.predict.predict_bed_sharded with the shipped Homo_sapiens/SNV/AT weights: C++ BED reader / row order / FASTA packer,
+    device-side column ordering, cross-position reuse kernels on the dense site list, focal-base check kernel, device sort + row
+    formatter, writer thread.  Everything between the two file names is inside the timed region; `split` gives the host wall-clock of
+    each stage of the driving thread and the busy times of the packer / writer threads that run beside it."""
+    import tempfile
+    from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
+    model, r, order, R = shipped_snv_model(device)
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) else None
+    with tempfile.TemporaryDirectory(prefix="mural_c5_", dir=shm) as work:
+        t0 = time.perf_counter()
+        fa, bed, rows = synth_config5_files(work, device, n_chrom, chrom_len)
+        t_gen = time.perf_counter() - t0
+        out = os.path.join(work, "pred.tsv")
+        sizes = {"fasta_bytes": os.path.getsize(fa), "bed_bytes": os.path.getsize(bed)}
+
+        def run(reuse, path):
+            split = {}
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fwd = HipShardForward(model, fa, r, order, device=device, reuse=reuse)
+            split["fasta_scan"] = time.perf_counter() - t0
+            sink = TsvSink(path)
+            n = predict_bed_sharded(fwd, bed, sink=sink, collect=False, timings=split)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert n == rows
+            split.update({"pack_thread_busy": fwd.seconds["pack"], "pack_wait": fwd.seconds["pack_wait"]})
+            split.update({"sink_" + k: v for k, v in sink.seconds.items()})
+            split.update({"writer_thread_" + k: v for k, v in sink.writer_seconds().items()})
+            return dt, split, fwd.reuse_sites
+
+        run(True, out)                                    # warm-up: kernels, allocator pools, page cache of the inputs
+        dt, split, reused = run(True, out)
+        table_bytes = os.path.getsize(out)
+        with open(out, "rb") as fh:
+            head = fh.read(400).split(b"\n")[:3]
+        dt_pw, split_pw, _ = run(False, out)
+    return {"rows_per_s": rows / dt, "rows": rows, "seconds": dt, "chromosomes": n_chrom, "bases_per_chromosome": chrom_len,
+            "sites_through_reuse_kernels": reused, "table_bytes": table_bytes, **sizes, "split_seconds": split,
+            "per_window_kernels": {"rows_per_s": rows / dt_pw, "seconds": dt_pw, "split_seconds": split_pw},
+            "weights": "Homo_sapiens/SNV/AT (shipped checkpoint, via tests/golden/snv_pretrained_human_AT.npz)",
+            "input_generation_seconds_untimed": t_gen, "table_head": [h.decode() for h in head],
+            "note": "FASTA + BED -> sorted '%.4g' TSV, one process, one GPU; second of two identical runs (inputs and output in "
+                    + ("/dev/shm" if shm else "the temp directory") + "); every A ('+') and T ('-') of 3 random chromosomes is a site"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -565,6 +683,7 @@ def main():
                 r["speedup_vs_per_window"] = r["bases_per_s"] / line["value"]
                 return r
             leg("dense_reuse", reuse_leg)
+            leg("config5_e2e", lambda: config5_e2e(device))
             leg("train", lambda: train_steps_per_s(device, genome))
             leg("indel", lambda: indel_positions_per_s(device, genome))
         if world == 1 and not args.no_cpu_baseline:

@@ -377,6 +377,48 @@ int mural_bed_segment_order(const int32_t* chrom_id, const int64_t* start, const
                             int64_t central_bp, int64_t* order, int64_t* group, int64_t* n_groups);
 
 /* ---------------------------------------------------------------------------------------------------------------
+ * The prediction table (MuRaL/scripts/run_predict.py:230-238: sort_values(['chrom', 'start']) + to_csv(sep='\t',
+ * float_format='%.4g', index=False)) formatted at kernel speed.  One text row per site:
+ *     chrom \t start \t end \t strand \t mut_type \t prob0 ... \t prob{k-1} \n
+ * integers as decimals, mut_type = int64(label) like numpy's astype, probabilities as Python's '%.4g' (byte-identical:
+ * exact round-half-even on the binary value; NaN -> empty field = pandas' na_rep).  Rows are emitted in the order
+ * perm[0..n) (NULL = input order): the caller sorts, the formatter writes.  The header line is the caller's.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct {
+  const char* chrom_names;   /* HOST: n_chroms x name_stride chars, NUL-terminated (also for the device call)      */
+  int32_t n_chroms, name_stride;
+  const int32_t* chrom_id;   /* [n] index into chrom_names, NULL = every row is chromosome 0                        */
+  const int64_t* start;      /* [n] */
+  const int64_t* end;        /* [n] */
+  const uint8_t* strand;     /* [n] 0 '+', 1 '-' */
+  const float* label;        /* [n] BED score column (class label) */
+  const void* prob;          /* [n][prob_stride] float or double, the first n_class entries of a row are written    */
+  int32_t prob_f64, n_class;
+  int64_t prob_stride;
+  const int64_t* perm;       /* [n] output row i = input row perm[i]; NULL = identity                               */
+  int64_t n;
+  int32_t layout;            /* 0: the prediction table row above; 1: the six-column BED row bed_reader consumes
+                                (chrom start end . label strand; prob is not read) -- synthetic inputs are written with it */
+  int32_t reserved;
+} MuralTsvRows;
+/* upper bound of one formatted row in bytes (text buffers hold n * bound), -1 on a bad table                        */
+int64_t mural_tsv_row_bound(const MuralTsvRows* t);
+size_t mural_tsv_format_workspace_bytes(int64_t n);
+/* column pointers, out, n_bytes (int64) and ws are DEVICE addresses; three launches on `stream`, no synchronisation:
+ * the text lands in out[0 .. *n_bytes)                                                                             */
+int mural_tsv_format_device(const MuralTsvRows* t, char* out, int64_t cap, int64_t* n_bytes, void* ws, size_t ws_bytes,
+                            void* stream);
+/* the same formatter on `threads` host threads (0 = up to 16) for tables in host memory                            */
+int mural_tsv_format_host(const MuralTsvRows* t, char* out, int64_t cap, int64_t* n_bytes, int32_t threads);
+/* '%.4g' of one value into out12 (NUL-terminated); returns the length                                              */
+int mural_tsv_format_g4(double v, char* out12);
+/* The reference's "different bases" check (MuRaL/data/preprocessing.py:479-484) on a gathered shard: rows is a device
+ * (n, row_stride) float / double matrix whose column `col` holds the strand-complemented focal base, group the
+ * non-decreasing bed_reader group id per row; bit 0 of *status (device int32) is set when two rows of one group differ. */
+int mural_focal_group_check(const void* rows, int32_t rows_f64, int64_t row_stride, int64_t col, const int64_t* group,
+                            int64_t n, int32_t* status, void* stream);
+
+/* ---------------------------------------------------------------------------------------------------------------
  * Validation-epoch analytics (device-side segmented reductions into float64 tables; the correlation / Newton algebra
  * on the tables is host work).  Replaces the pandas group-bys and per-row loops of MuRaL/evaluation/evaluation.py:
  * freq_kmer_comp_multi (:48-67), corr_calc_sub (:124-193), Evaluator.evaluate_regional_score (:544-587), ECELoss /

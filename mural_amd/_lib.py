@@ -68,6 +68,13 @@ class MuralRelayoutJob(C.Structure):
                 ("K", C.c_int32), ("reserved", C.c_int32), ("start", C.c_int64)]
 
 
+class MuralTsvRows(C.Structure):
+    _fields_ = [("chrom_names", C.c_char_p), ("n_chroms", C.c_int32), ("name_stride", C.c_int32), ("chrom_id", C.c_void_p),
+                ("start", C.c_void_p), ("end", C.c_void_p), ("strand", C.c_void_p), ("label", C.c_void_p), ("prob", C.c_void_p),
+                ("prob_f64", C.c_int32), ("n_class", C.c_int32), ("prob_stride", C.c_int64), ("perm", C.c_void_p), ("n", C.c_int64),
+                ("layout", C.c_int32), ("reserved", C.c_int32)]
+
+
 class MuralSnvShape(C.Structure):
     _fields_ = [("model_no", C.c_int32), ("n_class", C.c_int32), ("local_cols", C.c_int32), ("emb_rows", C.c_int32),
                 ("hidden1", C.c_int32), ("hidden2", C.c_int32), ("channels", C.c_int32), ("ksize", C.c_int32),
@@ -100,6 +107,12 @@ PROTOTYPES = {
     "mural_fasta_pack": (C.c_int, [C.c_char_p, I64, I64, VP, VP, VP, VP, I64, VP]),
     "mural_bed_read": (C.c_int, [C.c_char_p, I64, VP, VP, VP, VP, VP, I32, I32, VP, VP, VP]),
     "mural_bed_segment_order": (C.c_int, [VP, VP, VP, I64, I64, VP, VP, VP]),
+    "mural_tsv_row_bound": (C.c_int64, [C.POINTER(MuralTsvRows)]),
+    "mural_tsv_format_workspace_bytes": (C.c_size_t, [I64]),
+    "mural_tsv_format_device": (C.c_int, [C.POINTER(MuralTsvRows), VP, I64, VP, VP, C.c_size_t, VP]),
+    "mural_tsv_format_host": (C.c_int, [C.POINTER(MuralTsvRows), VP, I64, VP, I32]),
+    "mural_tsv_format_g4": (C.c_int, [C.c_double, VP]),
+    "mural_focal_group_check": (C.c_int, [VP, I32, I64, I64, VP, I64, VP, VP]),
     "mural_eval_kmer_keys": (C.c_int, [VP, I64, I32, I32, I32, I32, I64, I64, VP, VP, VP]),
     "mural_eval_window_keys": (C.c_int, [VP, VP, I64, I64, VP, I32, VP, VP, VP]),
     "mural_eval_group_obs_pred": (C.c_int, [VP, VP, VP, I32, I64, I32, I32, VP, VP, VP]),

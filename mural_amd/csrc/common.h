@@ -6,6 +6,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <mutex>
 #include <string>
 
 #include "../../include/mural_hip.h"
@@ -79,13 +80,19 @@ struct FastDiv {
 struct SideStream {
   hipStream_t side = nullptr, side2 = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr, join2_ev = nullptr;
-  int init() {
-    if (side) return MURAL_OK;
+  // One set of streams / events per device: a caller holds `mu` from its fork to its join (SideStreamHold), so two host threads that
+  // drive the same device cannot cross-wire each other's fork / join events.  (The enqueue between fork and join is host work of a
+  // few hundred microseconds; the device side stays concurrent.)
+  std::mutex mu;
+  bool ready = false;
+  int init() {          // called with `mu` held
+    if (ready) return MURAL_OK;
     MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
     MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&join2_ev, hipEventDisableTiming));
+    ready = true;
     return MURAL_OK;
   }
   int fork(hipStream_t main, bool both = false) {
@@ -105,15 +112,24 @@ struct SideStream {
   }
 };
 
-inline int side_stream(SideStream** out) {
-  static SideStream per_device[64];
-  int dev = 0;
-  MURAL_HIP_CHECK(hipGetDevice(&dev));
-  MURAL_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
-  if (int rc = per_device[dev].init()) return rc;
-  *out = &per_device[dev];
-  return MURAL_OK;
-}
+SideStream* side_stream_slot(int dev);      // encode.hip: ONE table for the whole library (not one per translation unit)
+
+// Exclusive use of the current device's side streams for the lifetime of the object (fork .. join of one library call).
+struct SideStreamHold {
+  SideStream* ss = nullptr;
+  std::unique_lock<std::mutex> lock;
+  int acquire() {
+    int dev = 0;
+    MURAL_HIP_CHECK(hipGetDevice(&dev));
+    MURAL_REQUIRE(dev >= 0 && dev < 64, "device index %d out of range", dev);
+    SideStream* s = side_stream_slot(dev);
+    lock = std::unique_lock<std::mutex>(s->mu);
+    if (int rc = s->init()) return rc;
+    ss = s;
+    return MURAL_OK;
+  }
+  SideStream* operator->() const { return ss; }
+};
 
 // ---------------------------------------------------------------------------------------------
 // packed genome access

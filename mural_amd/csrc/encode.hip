@@ -32,6 +32,11 @@ void ws_layout_add(size_t off, size_t bytes) {
   }
 }
 
+SideStream* side_stream_slot(int dev) {
+  static SideStream per_device[64];
+  return &per_device[dev];
+}
+
 // one thread per (row, column): order-k index over the strand-oriented window
 __global__ void encode_kmer_kernel(MuralGenome g, const int64_t* __restrict__ pos, const uint8_t* __restrict__ strand,
                                    int64_t n, int off, int width, int order, int ncol, int64_t* __restrict__ out) {

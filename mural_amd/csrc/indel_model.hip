@@ -318,9 +318,9 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
   // leave most of the chip idle: even chunks run on the caller's stream, odd ones on a side stream with their own half of the
   // workspace, so the small kernels of one chunk fill the gaps of the other.
   const int lanes = n > INDEL_CHUNK ? 2 : 1;
-  SideStream* ss = nullptr;
+  SideStreamHold ss;      // holds the device's side streams until this call has joined them again
   if (lanes == 2) {
-    if (int rc = side_stream(&ss)) return rc;
+    if (int rc = ss.acquire()) return rc;
     if (int rc = ss->fork(main_stream)) return rc;
   }
   int rc_all = MURAL_OK;

@@ -11,8 +11,10 @@
 
 #include <cctype>
 #include <cstdlib>
+#include <algorithm>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -168,6 +170,141 @@ extern "C" int mural_fasta_pack(const char* path, int64_t offset, int64_t length
 // Read a BED file with the reference's six columns (chrom, start, end, name, score = class label, strand).  Chromosome
 // names are interned in order of first appearance: chrom_id indexes `chrom_names` (n_chrom_cap x name_cap).  Call with
 // cap = 0 to count rows and chromosomes first.  Header / track / comment lines are skipped like pybedtools does.
+// The file is cut into byte ranges at line boundaries and parsed by up to 16 host threads (MURAL_HOST_THREADS overrides): a
+// whole-genome site list is gigabytes of text, and one core parses ~150 MB/s.
+namespace {
+
+struct BedChunk {
+  const char* lo = nullptr;
+  const char* hi = nullptr;
+  int64_t first_line = 0, rows = 0, row0 = 0, lines = 0;
+  std::vector<std::string> chroms;     // local interning, order of first appearance inside the chunk
+  std::vector<int32_t> remap;          // local id -> global id
+  std::string error;
+};
+
+inline bool bed_skip_line(const char* p, size_t len) {
+  return len == 0 || *p == '#' || (len >= 5 && !std::strncmp(p, "track", 5)) || (len >= 7 && !std::strncmp(p, "browser", 7));
+}
+
+// decimal integer spanning exactly [f, f + len); the common all-digit case without strtoll
+inline bool parse_i64_field(const char* f, size_t len, long long* out) {
+  if (len == 0) return false;
+  if (len <= 18) {
+    long long v = 0;
+    size_t i = 0;
+    for (; i < len; ++i) {
+      const unsigned d = (unsigned)(f[i] - '0');
+      if (d > 9) break;
+      v = v * 10 + d;
+    }
+    if (i == len) {
+      *out = v;
+      return true;
+    }
+  }
+  char* stop = nullptr;
+  *out = std::strtoll(f, &stop, 10);
+  return stop == f + len;
+}
+
+inline bool parse_score_field(const char* f, size_t len, float* out) {
+  if (len == 1 && (unsigned)(f[0] - '0') <= 9) {      // class labels are single digits
+    *out = (float)(f[0] - '0');
+    return true;
+  }
+  char* stop = nullptr;
+  *out = std::strtof(f, &stop);
+  return stop == f + len && len > 0;
+}
+
+// pass 1 (fill = false): count rows and lines; pass 2: parse into the arrays at row0
+void bed_parse_chunk(BedChunk& c, const char* path, bool fill, int32_t* chrom_id, int64_t* start, int64_t* end_, float* score,
+                     uint8_t* strand) {
+  const char* p = c.lo;
+  int64_t n = 0, line_no = c.first_line;
+  int last = -1;
+  while (p < c.hi) {
+    const char* e = line_end(p, c.hi);
+    ++line_no;
+    const char* le = e;
+    while (le > p && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;
+    const size_t len = (size_t)(le - p);
+    if (!bed_skip_line(p, len)) {
+      if (fill) {
+        const char* fld[6];
+        size_t flen[6];
+        int nf = 0;
+        const char* q = p;
+        while (q <= le && nf < 6) {
+          const char* t = static_cast<const char*>(std::memchr(q, '\t', (size_t)(le - q)));
+          if (!t) t = le;
+          fld[nf] = q;
+          flen[nf] = (size_t)(t - q);
+          ++nf;
+          q = t + 1;
+        }
+        char msg[512];
+        if (nf < 6) {
+          std::snprintf(msg, sizeof(msg), "%s:%lld: expected 6 tab-separated BED columns (chrom start end name score strand), got %d", path,
+                        (long long)line_no, nf);
+          c.error = msg;
+          return;
+        }
+        long long s = 0, t2 = 0;
+        float sc = 0.f;
+        const bool ok = parse_i64_field(fld[1], flen[1], &s) && parse_i64_field(fld[2], flen[2], &t2) &&
+                        parse_score_field(fld[4], flen[4], &sc) && flen[5] == 1 && (fld[5][0] == '+' || fld[5][0] == '-');
+        if (!ok || s < 0 || t2 < s) {
+          std::snprintf(msg, sizeof(msg), "%s:%lld: malformed BED row", path, (long long)line_no);
+          c.error = msg;
+          return;
+        }
+        int cid = -1;
+        if (last >= 0 && c.chroms[(size_t)last].size() == flen[0] && !std::memcmp(c.chroms[(size_t)last].data(), fld[0], flen[0])) cid = last;
+        for (int k = 0; cid < 0 && k < (int)c.chroms.size(); ++k)
+          if (c.chroms[(size_t)k].size() == flen[0] && !std::memcmp(c.chroms[(size_t)k].data(), fld[0], flen[0])) cid = k;
+        if (cid < 0) {
+          cid = (int)c.chroms.size();
+          c.chroms.emplace_back(fld[0], flen[0]);
+        }
+        last = cid;
+        const int64_t r = c.row0 + n;
+        chrom_id[r] = cid;
+        start[r] = s;
+        end_[r] = t2;
+        score[r] = sc;
+        strand[r] = fld[5][0] == '-' ? 1 : 0;
+      }
+      ++n;
+    }
+    p = e < c.hi ? e + 1 : c.hi;
+  }
+  c.rows = n;
+  c.lines = line_no - c.first_line;
+}
+
+int host_threads() {
+  if (const char* e = std::getenv("MURAL_HOST_THREADS")) {
+    const int v = std::atoi(e);
+    if (v >= 1) return std::min(v, 256);
+  }
+  return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
+template <typename Fn>
+void run_parallel(int T, Fn fn) {
+  if (T == 1) {
+    fn(0);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; ++k) th.emplace_back(fn, k);
+  for (auto& x : th) x.join();
+}
+
+}  // namespace
+
 extern "C" int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, int64_t* start, int64_t* end_, float* score,
                               uint8_t* strand, int32_t n_chrom_cap, int32_t name_cap, char* chrom_names, int64_t* n_rows,
                               int32_t* n_chroms) {
@@ -177,72 +314,97 @@ extern "C" int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, 
     set_error("cannot open BED file %s", path);
     return MURAL_E_INVALID;
   }
-  std::vector<std::string> chroms;
-  const char* p = f.data;
   const char* end = f.data + f.size;
-  int64_t n = 0, line_no = 0;
-  while (p < end) {
-    const char* e = line_end(p, end);
-    ++line_no;
-    const char* le = e;
-    while (le > p && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;
-    const size_t len = (size_t)(le - p);
-    const bool skip = len == 0 || *p == '#' || (len >= 5 && !std::strncmp(p, "track", 5)) || (len >= 7 && !std::strncmp(p, "browser", 7));
-    if (!skip) {
-      const char* fld[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-      size_t flen[6] = {0, 0, 0, 0, 0, 0};
-      int nf = 0;
-      const char* q = p;
-      while (q <= le && nf < 6) {
-        const char* t = q;
-        while (t < le && *t != '\t') ++t;
-        fld[nf] = q;
-        flen[nf] = (size_t)(t - q);
-        ++nf;
-        q = t + 1;
-      }
-      if (nf < 6) {
-        set_error("%s:%lld: expected 6 tab-separated BED columns (chrom start end name score strand), got %d", path,
-                  (long long)line_no, nf);
-        return MURAL_E_INVALID;
-      }
-      char* stop = nullptr;
-      const long long s = std::strtoll(fld[1], &stop, 10);
-      const bool s_ok = stop == fld[1] + flen[1] && flen[1] > 0;
-      const long long t2 = std::strtoll(fld[2], &stop, 10);
-      const bool e_ok = stop == fld[2] + flen[2] && flen[2] > 0;
-      const float sc = std::strtof(fld[4], &stop);
-      const bool c_ok = stop == fld[4] + flen[4] && flen[4] > 0;
-      const bool st_ok = flen[5] == 1 && (fld[5][0] == '+' || fld[5][0] == '-');
-      if (!s_ok || !e_ok || !c_ok || !st_ok || s < 0 || t2 < s) {
-        set_error("%s:%lld: malformed BED row", path, (long long)line_no);
-        return MURAL_E_INVALID;
-      }
-      const std::string name(fld[0], flen[0]);
-      int cid = -1;
-      if (!chroms.empty() && chroms.back() == name) cid = (int)chroms.size() - 1;   // sorted files: same as the previous row
-      for (int k = 0; cid < 0 && k < (int)chroms.size(); ++k)
-        if (chroms[k] == name) cid = k;
-      if (cid < 0) {
-        cid = (int)chroms.size();
-        chroms.push_back(name);
-      }
-      if (n < cap) {
-        if (chrom_id) chrom_id[n] = cid;
-        if (start) start[n] = s;
-        if (end_) end_[n] = t2;
-        if (score) score[n] = sc;
-        if (strand) strand[n] = fld[5][0] == '-' ? 1 : 0;
-      }
-      ++n;
+  const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), f.size / (4u << 20) + 1));
+  std::vector<BedChunk> ch((size_t)T);
+  const char* p = f.data;
+  for (int k = 0; k < T; ++k) {
+    ch[(size_t)k].lo = p;
+    const char* cut = k + 1 == T ? end : f.data + f.size * (size_t)(k + 1) / (size_t)T;
+    if (cut < p) cut = p;
+    if (cut < end) {
+      const char* e = line_end(cut, end);
+      cut = e < end ? e + 1 : end;
     }
-    p = e < end ? e + 1 : end;
+    ch[(size_t)k].hi = cut;
+    p = cut;
+  }
+  // pass 1: rows per chunk (newline scan), so that every chunk knows where its rows go
+  run_parallel(T, [&](int k) { bed_parse_chunk(ch[(size_t)k], path, false, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  int64_t n = 0, line0 = 0;
+  for (auto& c : ch) {
+    c.row0 = n;
+    c.first_line = line0;
+    n += c.rows;
+    line0 += c.lines;
   }
   *n_rows = n;
+  const bool fill = cap >= n && n > 0 && chrom_id && start && end_ && score && strand;
+  if (!fill) {
+    // counting call: only the chromosome names are still needed -- first fields only, no arrays
+    run_parallel(T, [&](int k) {
+      BedChunk& c = ch[(size_t)k];
+      const char* q = c.lo;
+      int last = -1;
+      while (q < c.hi) {
+        const char* e = line_end(q, c.hi);
+        const char* le = e;
+        while (le > q && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;
+        const size_t len = (size_t)(le - q);
+        if (!bed_skip_line(q, len)) {
+          const char* t = static_cast<const char*>(std::memchr(q, '\t', len));
+          const size_t fl = t ? (size_t)(t - q) : len;
+          int cid = -1;
+          if (last >= 0 && c.chroms[(size_t)last].size() == fl && !std::memcmp(c.chroms[(size_t)last].data(), q, fl)) cid = last;
+          for (int j = 0; cid < 0 && j < (int)c.chroms.size(); ++j)
+            if (c.chroms[(size_t)j].size() == fl && !std::memcmp(c.chroms[(size_t)j].data(), q, fl)) cid = j;
+          if (cid < 0) {
+            cid = (int)c.chroms.size();
+            c.chroms.emplace_back(q, fl);
+          }
+          last = cid;
+        }
+        q = e < c.hi ? e + 1 : c.hi;
+      }
+    });
+    std::vector<std::string> chroms;
+    for (auto& c : ch)
+      for (auto& name : c.chroms)
+        if (std::find(chroms.begin(), chroms.end(), name) == chroms.end()) chroms.push_back(name);
+    *n_chroms = (int32_t)chroms.size();
+    return MURAL_OK;
+  }
+  run_parallel(T, [&](int k) { bed_parse_chunk(ch[(size_t)k], path, true, chrom_id, start, end_, score, strand); });
+  for (auto& c : ch)
+    if (!c.error.empty()) {
+      set_error("%s", c.error.c_str());
+      return MURAL_E_INVALID;
+    }
+  // global interning in file order (chunks are in file order, local lists in order of first appearance), then the id remap
+  std::vector<std::string> chroms;
+  for (auto& c : ch) {
+    c.remap.resize(c.chroms.size());
+    for (size_t k = 0; k < c.chroms.size(); ++k) {
+      auto it = std::find(chroms.begin(), chroms.end(), c.chroms[k]);
+      if (it == chroms.end()) {
+        c.remap[k] = (int32_t)chroms.size();
+        chroms.push_back(c.chroms[k]);
+      } else {
+        c.remap[k] = (int32_t)(it - chroms.begin());
+      }
+    }
+  }
+  run_parallel(T, [&](int k) {
+    BedChunk& c = ch[(size_t)k];
+    bool identity = true;
+    for (size_t j = 0; j < c.remap.size(); ++j) identity = identity && c.remap[j] == (int32_t)j;
+    if (identity) return;
+    for (int64_t r = c.row0; r < c.row0 + c.rows; ++r) chrom_id[r] = c.remap[(size_t)chrom_id[r]];
+  });
   *n_chroms = (int32_t)chroms.size();
   if (chrom_names)
     for (int k = 0; k < (int)chroms.size() && k < n_chrom_cap; ++k) {
-      std::strncpy(chrom_names + (int64_t)k * name_cap, chroms[k].c_str(), (size_t)name_cap - 1);
+      std::strncpy(chrom_names + (int64_t)k * name_cap, chroms[(size_t)k].c_str(), (size_t)name_cap - 1);
       chrom_names[(int64_t)k * name_cap + name_cap - 1] = '\0';
     }
   return MURAL_OK;

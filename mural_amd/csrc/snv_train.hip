@@ -485,8 +485,8 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   } else if (int rc = mural_op_dense_to_symbols(distal_x, B, shape->distal_len, P.sym, status, stream)) {
     return rc;
   }
-  SideStream* ss;
-  if (int rc = side_stream(&ss)) return rc;
+  SideStreamHold ss;      // holds the device's side streams until this call has joined them again
+  if (int rc = ss.acquire()) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
   // three streams: large tower (caller's) | mid tower | local branch.  The large tower is the critical path, so it is enqueued
   // first: the ~70 launches of the other two would otherwise hold its first kernel back by their enqueue time
@@ -519,8 +519,8 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   if (m == 0) return local_b(c, cat_x, dout, dropout_p, seeds, seed_dev);
   if (int rc = mural_op_head_bwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, dout, B, nc, m == 2 ? P.dlogit[0] : nullptr,
                                  P.dlogit[1], P.dlogit[2], stream)) return rc;
-  SideStream* ss;
-  if (int rc = side_stream(&ss)) return rc;
+  SideStreamHold ss;      // holds the device's side streams until this call has joined them again
+  if (int rc = ss.acquire()) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
   int rc_large = tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);   // critical path first
   c.stream = ss->side;

@@ -182,21 +182,7 @@ def poisson_calibrate(prob):
 
 
 def write_predictions(res, path, poisson=False, dirichlet_weights=None):
-    """The prediction table of run_predict.py:217-239: optional Dirichlet calibration (``calibration.load_dirichlet_weights``
-    of the model's ``model.fdiri_cal.pkl``), optional Poisson calibration, then columns chrom, start, end, strand, mut_type,
-    prob0.., rows sorted by (chrom, start), tab-separated, floats as '%.4g'.  `res` is the dict returned by ``predict_bed``."""
-    import pandas as pd
-    prob = np.asarray(res["prob"])
-    if dirichlet_weights is not None:
-        from ..calibration import dirichlet_calibrate
-        prob = dirichlet_calibrate(prob, dirichlet_weights)
-    if poisson:
-        prob = poisson_calibrate(prob)
-    names = ["prob%d" % i for i in range(prob.shape[1])]
-    df = pd.concat((pd.DataFrame({"chrom": res["chrom"], "start": res["start"], "end": res["end"], "strand": res["strand"]}),
-                    pd.DataFrame({"mut_type": np.asarray(res["label"]).astype(np.int64)}), pd.DataFrame(prob, columns=names)),
-                   axis=1)
-    df.sort_values(["chrom", "start"], inplace=True)
-    df.reset_index(drop=True, inplace=True)
-    df.to_csv(path, sep="\t", float_format="%.4g", index=False)
-    return df
+    """The prediction table of run_predict.py:217-239 (see ``mural_amd.predict.write_predictions``, which formats it with the C++ row
+    formatter of csrc/tsv.hip, byte-identical to the reference's pandas writer)."""
+    from ..predict import write_predictions as impl
+    return impl(res, path, poisson, dirichlet_weights)

@@ -83,7 +83,8 @@ class UNet_Small(nn.Module):
 
     def _state_key(self):
         if getattr(self, "_plist", None) is None:
-            self._plist = list(self.parameters())
+            # parameters and the BatchNorm running statistics (num_batches_tracked does not enter the eval-mode arithmetic)
+            self._plist = list(self.parameters()) + [b for b in self.buffers() if b.is_floating_point()]
         return tuple([(t.data_ptr(), t._version) for t in self._plist])
 
     def _params(self, keep):

@@ -137,6 +137,7 @@ class _HipSnvBase(nn.Module):
     """Shared machinery: handle cache keyed on parameter versions, workspace, launches."""
 
     model_no = -1
+    REUSE_MIN_SITES = 1024      # forward_packed_reuse with a density rule: smaller chunks take the per-window kernels
 
     def _hip_init(self):
         self._handle = None
@@ -185,10 +186,12 @@ class _HipSnvBase(nn.Module):
         return super().load_state_dict(*args, **kwargs)
 
     def _state_key(self):
-        # in-place updates through torch bump _version; storage swaps go through _apply / load_state_dict (hooked above)
+        # in-place updates through torch bump _version (parameters and BatchNorm buffers alike); `p.data = other` keeps the version
+        # but changes data_ptr; storage moves through .to() go through _apply / load_state_dict (hooked above) as well
         if self._plist is None:
-            self._plist = list(self.parameters())
-        return [t._version for t in self._plist]
+            # num_batches_tracked (the only integer buffers) does not enter the eval-mode arithmetic
+            self._plist = list(self.parameters()) + [b for b in self.buffers() if b.is_floating_point()]
+        return [(t.data_ptr(), t._version) for t in self._plist]
 
     def _get_handle(self):
         """Folded device copy of the parameters; must be called under ``torch.cuda.device(model device)``."""
@@ -284,6 +287,14 @@ class _HipSnvBase(nn.Module):
 
     # -- dense entry (drop-in forward) ------------------------------------------------------------------------
     def _forward_dense(self, cat_x, distal_x, taps=None):
+        """Eval-mode ``model(local_input, distal_input)``.
+
+        ENCODING ERRORS ARE REPORTED LATE.  A `distal_input` column that is not a MuRaL one-hot / IUPAC-fraction encoding cannot be
+        evaluated by the sequence kernels.  The call that holds it does not raise: its output rows are NaN, a sticky device word is
+        set, and every later dense call on this model also returns NaN until the host has seen the word -- without blocking at the
+        start of a later forward, or at once through ``model.check_encoding(wait=True)`` -- and raised ``ValueError``.  Loops that
+        consume outputs without a later forward must end with ``check_encoding(wait=True)`` (``model_predict_m`` does); NaN
+        in an output always means "check_encoding will raise", never a silent wrong value."""
         self._check_eval()
         dev = self._device()
         if dev.type != "cuda":
@@ -349,11 +360,16 @@ class _HipSnvBase(nn.Module):
                                                           ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
         return out
 
-    def forward_packed_reuse(self, genome, pos, strand, local_radius=None, local_order=3):
+    def forward_packed_reuse(self, genome, pos, strand, local_radius=None, local_order=3, min_density=0.0, batch_sites=1 << 20,
+                             return_reuse_count=False):
         """``forward_packed`` with cross-position reuse (csrc/snv_reuse.hip): for site lists that are dense along a chromosome the
         first conv stage of both towers is evaluated once per base and strand instead of once per window; per site only the
         pooled columns next to its window edges are recomputed.  Same rows, same order, probabilities equal to the per-window
-        path within rounding (GPU tests: 1e-5).  Falls back to ``forward_packed`` for models the reuse kernels do not cover."""
+        path within rounding (GPU tests: 1e-5).  Falls back to ``forward_packed`` (in batches of `batch_sites`) for models the
+        reuse kernels do not cover and for chunks of the position axis with fewer than `min_density` sites per base, where the
+        per-base rows cost more than they save (with a positive `min_density` a chunk also needs REUSE_MIN_SITES sites: below that the
+        fixed launches of the row kernels dominate).  With `return_reuse_count` the result is ``(out, sites that took the reuse
+        kernels)``."""
         self._check_eval()
         dev = self._device()
         pos = _lib.require_cuda(pos, "pos").to(torch.int64).contiguous()
@@ -362,12 +378,23 @@ class _HipSnvBase(nn.Module):
         lib = _lib.lib()
         if local_radius is None:
             local_radius = (getattr(self, "no_of_cat", 1) + local_order - 2) // 2
+        done = lambda out, used: (out, used) if return_reuse_count else out      # noqa: E731
+
+        def per_window(p, st, dst=None):
+            parts = [self.forward_packed(genome, p[r0:r0 + batch_sites], st[r0:r0 + batch_sites], local_radius, local_order)
+                     for r0 in range(0, max(p.shape[0], 1), batch_sites)]
+            res = parts[0] if len(parts) == 1 else torch.cat(parts)
+            if dst is None:
+                return res
+            dst.copy_(res)
+            return dst
+
         if self.model_no == 0 or n == 0 or not self._fused_ok():
-            return self.forward_packed(genome, pos, strand, local_radius, local_order)
+            return done(per_window(pos, strand), 0)
         with torch.cuda.device(dev):
             handle = self._get_handle()
             if not lib.mural_snv_reuse_supported(handle):
-                return self.forward_packed(genome, pos, strand, local_radius, local_order)
+                return done(per_window(pos, strand), 0)
             out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
             span = int(lib.mural_snv_reuse_chunk_span())
             g = genome.as_struct(dev)
@@ -387,22 +414,33 @@ class _HipSnvBase(nn.Module):
                                                               self._ws.data_ptr(), self._ws.numel(), stream))
 
             strands = (1 if s_min == 0 else 0) | (2 if s_max != 0 else 0)
+            used = 0
             if p_max - p_min + 1 <= span:              # the common case: one chunk, rows of both strands resident, sites in any order
+                if min_density > 0 and (n < min_density * (p_max - p_min + 1) or n < self.REUSE_MIN_SITES):
+                    return done(per_window(pos, strand, out), 0)
                 run(pos, strand, p_min, p_max, strands, out)
+                used = n
             else:                                      # long spans: sort once, one call per chunk of the position axis
                 p_sorted, perm = torch.sort(pos)
                 s_sorted = strand[perm].contiguous()
-                edges = torch.arange(p_min, p_max + span, span, device=dev, dtype=torch.int64)     # chunk k: [edges[k], edges[k+1])
+                # chunk k: [edges[k], edges[k+1]); the last edge lies strictly behind p_max (also when p_max - p_min is a multiple
+                # of span), so that the half-open chunks cover every site
+                edges = torch.arange(p_min, p_max + span + 1, span, device=dev, dtype=torch.int64)
                 cuts = torch.searchsorted(p_sorted, edges).tolist()
+                res_sorted = torch.empty_like(out)
                 for k in range(len(cuts) - 1):
                     lo, hi = cuts[k], cuts[k + 1]
                     if hi == lo:
                         continue
                     c_lo = p_min + k * span
-                    res = torch.empty((hi - lo, self.n_class), dtype=torch.float32, device=dev)
-                    run(p_sorted[lo:hi], s_sorted[lo:hi], c_lo, min(c_lo + span - 1, p_max), strands, res)
-                    out.index_copy_(0, perm[lo:hi], res)
-        return out
+                    c_hi = min(c_lo + span - 1, p_max)
+                    if min_density > 0 and (hi - lo < min_density * (c_hi - c_lo + 1) or hi - lo < self.REUSE_MIN_SITES):
+                        per_window(p_sorted[lo:hi], s_sorted[lo:hi], res_sorted[lo:hi])
+                        continue
+                    run(p_sorted[lo:hi], s_sorted[lo:hi], c_lo, c_hi, strands, res_sorted[lo:hi])
+                    used += hi - lo
+                out.index_copy_(0, perm, res_sorted)
+        return done(out, used)
 
     def tap_layout(self):
         arr = (C.c_int32 * 16)()
@@ -475,8 +513,11 @@ class Network0(nn.Module):
     def forward_packed(self, genome, pos, strand, local_radius=None, local_order=3):
         return self.model.forward_packed(genome, pos, strand, local_radius, local_order)
 
-    def forward_packed_reuse(self, genome, pos, strand, local_radius=None, local_order=3):
-        return self.model.forward_packed(genome, pos, strand, local_radius, local_order)     # no conv towers: nothing to share
+    def forward_packed_reuse(self, genome, pos, strand, local_radius=None, local_order=3, min_density=0.0, batch_sites=1 << 20,
+                             return_reuse_count=False):
+        # no conv towers: nothing to share
+        return self.model.forward_packed_reuse(genome, pos, strand, local_radius, local_order, min_density, batch_sites,
+                                               return_reuse_count)
 
 
 class Network1(_HipSnvBase):

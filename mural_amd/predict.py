@@ -1,13 +1,21 @@
 """Sharded genome-wide prediction: one process per GPU, sites split into contiguous blocks, ONE RCCL all_gather of the
-per-rank log-probabilities per call (the reference itself is single-process and only advises to
+per-rank probabilities per call (the reference itself is single-process and only advises to
 split the BED file by hand, MuRaL/commands/predict.py:134-137).
 
 The host logic (block partition, padded all_gather, trimming back to the reference's row order) is backend-agnostic
-and covered by world_size-2 gloo tests on CPU; the compute function is the HIP model's ``forward_packed``.
+and covered by world_size-2 gloo tests on CPU; the compute function is the HIP model's ``forward_packed`` /
+``forward_packed_reuse``; the prediction table is formatted by ``csrc/tsv.hip`` (device kernel or host threads).
 """
+import ctypes as C
+import queue
+import threading
+import time
+
 import numpy as np
 import torch
 import torch.distributed as dist
+
+from . import _lib
 
 
 def shard_bounds(n, rank, world):
@@ -33,6 +41,8 @@ def all_gather_rows(local, n_total, group=None):
     padded[: local.shape[0]] = local
     gathered = torch.empty((world * per, width), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(gathered, padded, group=group)
+    if n_total == world * per:
+        return gathered
     out = torch.empty((n_total, width), dtype=local.dtype, device=local.device)
     for r in range(world):
         lo, hi = shard_bounds(n_total, r, world)
@@ -72,24 +82,33 @@ class ShardedPredictor:
 # to split a big BED by hand and run several `predict` processes (MuRaL/commands/predict.py:134-137) around the loop of
 # MuRaL/scripts/run_predict.py:188-239.
 #
-#   * rows are processed in bed_reader order (preprocessing.py:39-106), one SHARD = one run of rows on the same chromosome;
-#   * per shard only that chromosome is packed and resident in HBM (<= 70 MB for a human chromosome), and it is dropped
-#     before the next one is loaded (per-chromosome streaming);
-#   * rank i evaluates the contiguous block shard_bounds(rows of the shard, i, world): only its own block of sites is ever
-#     uploaded to its device;
-#   * ONE all_gather per shard returns (rows, n_class + 1) fp32: the probabilities and the strand-complemented focal base
-#     that the reference's per-(segment, strand) consistency check needs (preprocessing.py:479-484, always run by
-#     prepare_local_data :400 with local_order=1) -- groups may straddle rank boundaries, so the check runs on the gathered
-#     shard, before the next shard starts;
-#   * a sink on rank 0 (e.g. TsvSink) consumes each gathered shard; nothing of size N lives on a device.
+#   * rows keep their bed_reader order (preprocessing.py:39-106); one SHARD = all rows of one chromosome (its runs in that
+#     order, concatenated), and the shards are processed in ascending chromosome NAME order -- the order of the final
+#     sort_values(['chrom', 'start']) -- so the table can be streamed out shard by shard;
+#   * per shard only that chromosome is packed and resident in HBM (<= 70 MB for a human chromosome); the next chromosome is
+#     packed on a host thread while this one is computed, and every chromosome is packed exactly once;
+#   * rank i evaluates the contiguous block shard_bounds(rows of the shard, i, world), through the cross-position reuse kernels
+#     where the block's sites are dense along the chromosome and through the per-window kernels elsewhere;
+#   * ONE all_gather per shard returns (rows, n_class + 1): the probabilities and the strand-complemented focal base that the
+#     reference's per-(segment, strand) consistency check needs (preprocessing.py:479-484, always run by prepare_local_data
+#     :400 with local_order=1) -- groups may straddle rank boundaries, so the check (a streaming kernel) runs on the gathered
+#     shard; its verdict is read one shard late, so no rank waits for it;
+#   * rank 0 hands the gathered shard to a sink; TsvSink sorts it by start on the device, formats the text rows on the device
+#     (csrc/tsv.hip) and leaves the copy to the host and the write() to a writer thread: no rank waits for the writer unless
+#     all of its text buffers are full.
+# With a host-memory forward (gloo ranks, CPU tests) the same driver runs on numpy arrays and the host formatter.
 # ------------------------------------------------------------------------------------------------------------------
 def shard_runs(chrom_id):
-    """[(lo, hi)] runs of equal chromosome id in a row sequence (the shards of predict_bed_sharded)."""
+    """[(lo, hi)] runs of equal chromosome id in a row sequence."""
     chrom_id = np.asarray(chrom_id)
     if len(chrom_id) == 0:
         return []
     cut = np.r_[0, np.nonzero(chrom_id[1:] != chrom_id[:-1])[0] + 1, len(chrom_id)]
     return list(zip(cut[:-1].tolist(), cut[1:].tolist()))
+
+
+_FOCAL_MSG = ("The positions in input BED file have different bases (A/T and C/G mixed)! The ref_genome or "
+              "input BED file could be wrong.")
 
 
 def check_focal_groups(focal, group):
@@ -101,156 +120,621 @@ def check_focal_groups(focal, group):
     first = np.r_[True, group[1:] != group[:-1]]
     ref = focal[np.maximum.accumulate(np.where(first, np.arange(len(focal)), 0))]
     if (focal != ref).any():
-        raise ValueError("The positions in input BED file have different bases (A/T and C/G mixed)! The ref_genome or "
-                         "input BED file could be wrong.")
+        raise ValueError(_FOCAL_MSG)
 
 
 class HipShardForward:
-    """Default compute of predict_bed_sharded: packs the shard's chromosome from the FASTA file (C++ packer), keeps exactly one
-    chromosome resident, runs the fused packed-genome forward in batches and returns softmax probabilities with the focal
-    base appended as the last column."""
+    """Default compute of predict_bed_sharded: packs the shard's chromosome from the FASTA file (C++ packer; the next one on a
+    host thread while this one is computed), keeps exactly one chromosome resident, runs the fused packed-genome forward and
+    returns softmax probabilities with the focal base appended as the last column."""
+
+    REUSE_MIN_DENSITY = 0.1        # sites per base of a chunk's span above which the cross-position reuse path pays (DESIGN.md 3c)
 
     def __init__(self, model, fasta_path, local_radius, local_order=3, distal_radius=None, device="cuda", batch_sites=1 << 20,
-                 model_type="snv", dirichlet_weights=None, poisson=False, scale_factor=None):
+                 model_type="snv", dirichlet_weights=None, poisson=False, scale_factor=None, reuse=True):
         """`dirichlet_weights` / `poisson` / `scale_factor`: apply the post-head calibration chain of run_predict.py:217-225
         (and scripts/scaling.py) on the device, fused behind the head (calibration.calibrate_device); the shard then carries
-        float64 calibrated probabilities and the sink must not calibrate again."""
+        float64 calibrated probabilities and the sink must not calibrate again.  `reuse`: let dense blocks of sites take the
+        cross-position reuse kernels (same probabilities within rounding, tests/test_gpu_reuse.py)."""
         from .data import ingest
         self.calibration = dict(dirichlet_weights=dirichlet_weights, poisson=poisson, scale_factor=scale_factor)
         self.calibrated = dirichlet_weights is not None or bool(poisson) or bool(scale_factor)
         self._ingest = ingest
         self.model = model.to(device).eval()
         self.fasta_path, self.device = fasta_path, torch.device(device)
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
         self.local_radius, self.local_order, self.distal_radius = local_radius, local_order, distal_radius
-        self.batch_sites, self.model_type = batch_sites, model_type
+        self.batch_sites, self.model_type, self.reuse = batch_sites, model_type, bool(reuse) and model_type == "snv"
         self.records = {r.name: r for r in ingest.scan_fasta(fasta_path)}
         self._resident = (None, None)
+        self._prefetch = None          # (chrom, thread, result box)
+        self.seconds = {"pack_wait": 0.0, "pack": 0.0}
+        self.reuse_sites = 0           # sites that went through the reuse kernels (diagnostics / tests)
+
+    # -- chromosome residency ---------------------------------------------------------------------------------------------
+    def _pack(self, chrom, box):
+        t0 = time.perf_counter()
+        try:
+            box["packed"] = self._ingest.pack_fasta_record(self.fasta_path, self.records[chrom])
+        except Exception as e:      # noqa: BLE001  (re-raised by the consumer)
+            box["error"] = e
+        box["seconds"] = time.perf_counter() - t0
+
+    def prefetch(self, chrom):
+        """Start packing `chrom` on a host thread (the C++ packer releases the GIL); genome(chrom) picks the result up."""
+        if chrom is None or chrom not in self.records or self._resident[0] == chrom:
+            return
+        if self._prefetch is not None and self._prefetch[0] == chrom:
+            return
+        box = {}
+        th = threading.Thread(target=self._pack, args=(chrom, box), daemon=True)
+        th.start()
+        self._prefetch = (chrom, th, box)
 
     def genome(self, chrom):
         if self._resident[0] != chrom:
             self._resident = (None, None)              # drop the previous chromosome before the next one is uploaded
             if chrom not in self.records:
                 raise KeyError(chrom)                  # the reference's seq_records[chrom] lookup
-            packed, mask, n, amb = self._ingest.pack_fasta_record(self.fasta_path, self.records[chrom])
+            t0 = time.perf_counter()
+            if self._prefetch is not None and self._prefetch[0] == chrom:
+                _, th, box = self._prefetch
+                th.join()
+                self._prefetch = None
+            else:
+                box = {}
+                self._pack(chrom, box)
+            self.seconds["pack_wait"] += time.perf_counter() - t0
+            self.seconds["pack"] += box.get("seconds", 0.0)
+            if "error" in box:
+                raise box["error"]
+            packed, mask, n, amb = box["packed"]
             from .data.genome import PackedGenome
             self._resident = (chrom, PackedGenome(packed, mask, n, self.device, amb))
         return self._resident[1]
 
+    # -- compute ----------------------------------------------------------------------------------------------------------
+    def _to_device(self, a, dtype):
+        if isinstance(a, torch.Tensor):
+            return a.to(self.device, dtype)
+        return torch.from_numpy(np.ascontiguousarray(a)).to(self.device, dtype)
+
     @torch.no_grad()
     def __call__(self, chrom, pos, strand):
+        """(rows, n_class + 1) for this rank's block of the chromosome's sites (numpy arrays or tensors, any device)."""
         g = self.genome(chrom)
-        n = len(pos)
-        out = torch.empty((n, self.model.n_class + 1), dtype=torch.float64 if self.calibrated else torch.float32,
-                          device=self.device)
-        for r0 in range(0, n, self.batch_sites):
-            p = torch.from_numpy(pos[r0:r0 + self.batch_sites]).to(self.device)
-            st = torch.from_numpy(strand[r0:r0 + self.batch_sites]).to(self.device)
-            if self.model_type == "snv":
-                logp = self.model.forward_packed(g, p, st, local_radius=self.local_radius, local_order=self.local_order)
-                out[r0:r0 + len(p), -1] = g.encode_kmer(p, st, 1, 1)[:, 1].to(torch.float32)   # complemented focal base 0..4
-            else:
-                logp = self.model.forward_packed(g, p, st, self.distal_radius)
-                out[r0:r0 + len(p), -1] = 0.0
-            if self.calibrated:
-                from .calibration import calibrate_device
-                out[r0:r0 + len(p), :-1] = calibrate_device(logp, **self.calibration)
-            else:
-                out[r0:r0 + len(p), :-1] = torch.softmax(logp, dim=1)
+        pos, strand = self._to_device(pos, torch.int64), self._to_device(strand, torch.uint8)
+        n = pos.shape[0]
+        k = self.model.n_class
+        out = torch.empty((n, k + 1), dtype=torch.float64 if self.calibrated else torch.float32, device=self.device)
+        with torch.cuda.device(self.device):
+            if self.model_type == "snv" and self.reuse and n > 0:
+                logp, used = self.model.forward_packed_reuse(g, pos, strand, local_radius=self.local_radius, local_order=self.local_order,
+                                                             min_density=self.REUSE_MIN_DENSITY, batch_sites=self.batch_sites,
+                                                             return_reuse_count=True)
+                self.reuse_sites += used
+                self._finish(out, 0, logp, g, pos, strand)
+                return out
+            for r0 in range(0, n, self.batch_sites):
+                p, st = pos[r0:r0 + self.batch_sites], strand[r0:r0 + self.batch_sites]
+                if self.model_type == "snv":
+                    logp = self.model.forward_packed(g, p, st, local_radius=self.local_radius, local_order=self.local_order)
+                else:
+                    logp = self.model.forward_packed(g, p, st, self.distal_radius)
+                self._finish(out, r0, logp, g, p, st)
         return out
+
+    def _finish(self, out, r0, logp, g, p, st):
+        m = logp.shape[0]
+        if self.model_type == "snv":
+            out[r0:r0 + m, -1] = g.encode_kmer(p, st, 1, 1)[:, 1].to(out.dtype)     # complemented focal base 0..4
+        else:
+            out[r0:r0 + m, -1] = 0.0
+        if self.calibrated:
+            from .calibration import calibrate_device
+            out[r0:r0 + m, :-1] = calibrate_device(logp, **self.calibration)
+        else:
+            out[r0:r0 + m, :-1] = torch.softmax(logp, dim=1)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the prediction table
+# ------------------------------------------------------------------------------------------------------------------
+_NAME_STRIDE = 256
+
+
+def _name_table(names):
+    buf = C.create_string_buffer(max(len(names), 1) * _NAME_STRIDE)
+    for i, nm in enumerate(names):
+        raw = str(nm).encode()
+        if len(raw) >= _NAME_STRIDE:
+            raise ValueError(f"chromosome name longer than {_NAME_STRIDE - 1} bytes: {nm!r}")
+        buf[i * _NAME_STRIDE:i * _NAME_STRIDE + len(raw)] = raw
+    return buf
+
+
+def _tsv_struct(names_buf, n_names, chrom_id, start, end, strand, label, prob, prob_f64, n_class, prob_stride, perm, n):
+    t = _lib.MuralTsvRows()
+    t.chrom_names, t.n_chroms, t.name_stride = C.cast(names_buf, C.c_char_p), max(n_names, 1), _NAME_STRIDE
+    t.chrom_id, t.start, t.end, t.strand, t.label, t.prob, t.perm = chrom_id, start, end, strand, label, prob, perm
+    t.prob_f64, t.n_class, t.prob_stride, t.n = int(prob_f64), int(n_class), int(prob_stride), int(n)
+    return t
+
+
+def format_rows_host(names, chrom_id, start, end, strand, label, prob, perm=None, threads=0):
+    """Text of the prediction-table rows (no header) for host arrays, formatted by the C++ row formatter (csrc/tsv.hip): bytes.
+    `names`: list of chromosome names, `chrom_id` indexes it (None = every row is names[0]); `strand` uint8 (1 = '-');
+    `perm`: output row i = input row perm[i]."""
+    n = len(start)
+    prob = np.asarray(prob)
+    if prob.dtype not in (np.float32, np.float64):
+        prob = prob.astype(np.float64)
+    if prob.ndim != 2:
+        prob = prob.reshape(n, -1)
+    prob = np.ascontiguousarray(prob)
+    cols = dict(start=np.ascontiguousarray(start, np.int64), end=np.ascontiguousarray(end, np.int64),
+                strand=np.ascontiguousarray(strand, np.uint8), label=np.ascontiguousarray(label, np.float32))
+    cid = None if chrom_id is None else np.ascontiguousarray(chrom_id, np.int32)
+    pm = None if perm is None else np.ascontiguousarray(perm, np.int64)
+    names_buf = _name_table(names)
+    ptr = lambda a: None if a is None else a.ctypes.data     # noqa: E731
+    t = _tsv_struct(names_buf, len(names), ptr(cid), ptr(cols["start"]), ptr(cols["end"]), ptr(cols["strand"]), ptr(cols["label"]),
+                    ptr(prob) if prob.size else None, prob.dtype == np.float64, prob.shape[1], prob.shape[1], ptr(pm), n)
+    lib = _lib.lib()
+    bound = int(lib.mural_tsv_row_bound(C.byref(t)))
+    if bound < 0:
+        _lib.check(_lib.MURAL_E_INVALID)
+    out = np.empty(max(n * bound, 1), np.uint8)
+    nbytes = C.c_int64(0)
+    _lib.check(lib.mural_tsv_format_host(C.byref(t), out.ctypes.data, out.size, C.byref(nbytes), int(threads)))
+    return out[:nbytes.value].tobytes()
+
+
+def _header(n_class):
+    return ("\t".join(["chrom", "start", "end", "strand", "mut_type"] + ["prob%d" % i for i in range(n_class)]) + "\n").encode()
+
+
+class _TextWriter(threading.Thread):
+    """Writer thread of the device path: waits for a piece's format kernels, copies its text to pinned host memory on its own
+    stream and write()s it; returns the device buffer to the pool.  One thread, pieces in order."""
+
+    def __init__(self, fh, device, n_buffers, cap):
+        super().__init__(daemon=True)
+        self.fh, self.device = fh, device
+        self.jobs, self.free = queue.Queue(), queue.Queue()
+        self.text = [torch.empty(cap, dtype=torch.uint8, device=device) for _ in range(n_buffers)]
+        self.count = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(n_buffers)]
+        for i in range(n_buffers):
+            self.free.put(i)
+        self.host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+        self.host_count = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.error = None
+        self.seconds = {"wait_device": 0.0, "copy": 0.0, "write": 0.0}
+        self.bytes = 0
+
+    def run(self):
+        stream = torch.cuda.Stream(self.device)
+        while True:
+            job = self.jobs.get()
+            if job is None:
+                return
+            idx, event = job
+            try:
+                if self.error is None:
+                    t0 = time.perf_counter()
+                    event.synchronize()
+                    t1 = time.perf_counter()
+                    with torch.cuda.stream(stream):
+                        self.host_count.copy_(self.count[idx], non_blocking=True)
+                        stream.synchronize()
+                        nb = int(self.host_count[0])
+                        self.host[:nb].copy_(self.text[idx][:nb], non_blocking=True)
+                        stream.synchronize()
+                    t2 = time.perf_counter()
+                    self.fh.write(memoryview(self.host.numpy())[:nb])
+                    t3 = time.perf_counter()
+                    self.seconds["wait_device"] += t1 - t0
+                    self.seconds["copy"] += t2 - t1
+                    self.seconds["write"] += t3 - t2
+                    self.bytes += nb
+            except Exception as e:      # noqa: BLE001  (surfaced by the sink)
+                self.error = e
+            finally:
+                self.free.put(idx)
 
 
 class TsvSink:
     """Rank-0 consumer of gathered shards: the prediction table of run_predict.py:217-239 (optional Dirichlet / Poisson
-    calibration, columns chrom start end strand mut_type prob0.., rows sorted by (chrom, start), '%.4g').  Shards whose
-    chromosomes arrive in ascending name order are sorted by start and appended immediately (nothing of size N is kept);
-    otherwise the rows are buffered and sorted at close()."""
+    calibration, columns chrom start end strand mut_type prob0.., rows sorted by (chrom, start), '%.4g'), byte-identical to the
+    reference's pandas writer.
 
-    def __init__(self, path, poisson=False, dirichlet_weights=None):
-        self.path, self.poisson, self.dirichlet_weights = path, poisson, dirichlet_weights
-        self._buffer, self._streaming, self._last, self._wrote_header = [], True, None, False
-        open(path, "w").close()
+    A shard is a dict with the rows of ONE chromosome: ``chrom`` (name, or an array whose first entry is the name), ``start``,
+    ``end``, ``strand`` (uint8 1 = '-', or '+' / '-' strings), ``label``, ``prob`` (n, k) -- numpy arrays, or torch tensors on a
+    HIP device (then the stable sort by start, the calibration, the formatting and the copy-out all run on that device and a
+    writer thread does the file I/O).  Shards whose chromosomes arrive in ascending name order -- what predict_bed_sharded
+    produces -- are streamed out at once; any other arrival order is handled by spooling the raw rows and merging at close().
+    Nothing is ever parsed back as numbers: chromosome names like '01' or '10' stay strings."""
 
-    def _frame(self, shard):
-        import pandas as pd
-        prob = np.asarray(shard["prob"])
+    PIECE_ROWS = 1 << 20
+
+    def __init__(self, path, poisson=False, dirichlet_weights=None, host_threads=0):
+        self.path, self.poisson, self.dirichlet_weights = str(path), poisson, dirichlet_weights
+        self.host_threads = host_threads
+        self._fh = open(self.path, "wb")
+        self._wrote_header = False
+        self._last = None              # name of the last streamed chromosome
+        self._spool = []               # out-of-order shards as host arrays
+        self._writer = None
+        self._ws = None
+        self.rows = 0
+        self.seconds = {"sort_format_enqueue": 0.0, "wait_buffer": 0.0, "host_format": 0.0, "host_write": 0.0}
+        self._writer_totals = {"wait_device": 0.0, "copy": 0.0, "write": 0.0, "bytes": 0}
+
+    # -- helpers ----------------------------------------------------------------------------------------------------------
+    @staticmethod
+    def _name(shard):
+        c = shard["chrom"]
+        if isinstance(c, str):
+            return c
+        return str(c[0]) if len(c) else None
+
+    @staticmethod
+    def _strand_u8(s):
+        if isinstance(s, torch.Tensor):
+            return s
+        s = np.asarray(s)
+        return s if s.dtype == np.uint8 else (s == "-").astype(np.uint8)
+
+    def _ensure_header(self, n_class):
+        if not self._wrote_header:
+            self._flush_writer()
+            self._fh.write(_header(n_class))
+            self._wrote_header = True
+
+    def _flush_writer(self):
+        """Wait until the writer thread has written everything handed to it (the file position is then ours)."""
+        w = self._writer
+        if w is not None:
+            held = [w.free.get() for _ in range(len(w.text))]
+            for i in held:
+                w.free.put(i)
+            if w.error is not None:
+                raise w.error
+
+    def _host_prob(self, prob):
+        prob = np.asarray(prob)
         if self.dirichlet_weights is not None:
             from .calibration import dirichlet_calibrate
             prob = dirichlet_calibrate(prob, self.dirichlet_weights)
         if self.poisson:
             from .data.ingest import poisson_calibrate
             prob = poisson_calibrate(prob)
-        cols = {"chrom": shard["chrom"], "start": shard["start"], "end": shard["end"], "strand": shard["strand"],
-                "mut_type": np.asarray(shard["label"]).astype(np.int64)}
-        cols.update({"prob%d" % i: prob[:, i] for i in range(prob.shape[1])})
-        return pd.DataFrame(cols)
+        return prob
 
-    def _write(self, df):
-        df.to_csv(self.path, sep="\t", float_format="%.4g", index=False, mode="a", header=not self._wrote_header)
-        self._wrote_header = True
+    # -- streaming --------------------------------------------------------------------------------------------------------
+    def _stream_host(self, name, shard):
+        t0 = time.perf_counter()
+        prob = self._host_prob(shard["prob"])
+        start = np.asarray(shard["start"])
+        perm = np.argsort(start, kind="stable")
+        text = format_rows_host([name], None, start, shard["end"], self._strand_u8(shard["strand"]), shard["label"], prob, perm,
+                                self.host_threads)
+        t1 = time.perf_counter()
+        self._ensure_header(prob.shape[1] if prob.ndim == 2 else 0)
+        self._flush_writer()
+        self._fh.write(text)
+        self.seconds["host_format"] += t1 - t0
+        self.seconds["host_write"] += time.perf_counter() - t1
+
+    def _stream_device(self, name, shard):
+        t0 = time.perf_counter()
+        prob = shard["prob"]
+        dev = prob.device
+        n, k = prob.shape[0], int(shard.get("n_class", prob.shape[1]))
+        lib = _lib.lib()
+        with torch.cuda.device(dev):
+            if self.dirichlet_weights is not None or self.poisson:
+                from .calibration import calibrate_device
+                prob = calibrate_device(prob[:, :k].contiguous() if prob.stride(0) != k else prob, dirichlet_weights=self.dirichlet_weights,
+                                        poisson=self.poisson, input_is_prob=True)
+            if prob.dtype not in (torch.float32, torch.float64):
+                prob = prob.to(torch.float32)
+            if prob.stride(1) != 1:
+                prob = prob.contiguous()
+            to = lambda a, dt: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, dt).contiguous()   # noqa: E731
+            start, end = to(shard["start"], torch.int64), to(shard["end"], torch.int64)
+            strand, label = to(self._strand_u8(shard["strand"]), torch.uint8), to(shard["label"], torch.float32)
+            perm = torch.sort(start, stable=True).indices
+            names_buf = _name_table([name])
+            t = _tsv_struct(names_buf, 1, None, start.data_ptr(), end.data_ptr(), strand.data_ptr(), label.data_ptr(), prob.data_ptr(),
+                            prob.dtype == torch.float64, k, prob.stride(0), None, 0)
+            bound = int(lib.mural_tsv_row_bound(C.byref(t)))
+            piece = self.PIECE_ROWS
+            self._ensure_header(k)
+            if self._writer is None or self._writer.device != dev or self._writer.text[0].numel() < piece * bound:
+                self._close_writer()
+                self._writer = _TextWriter(self._fh, dev, 3, piece * (bound + 24))     # slack: a longer chromosome name reuses it
+                self._writer.start()
+                self._ws = torch.empty(int(lib.mural_tsv_format_workspace_bytes(piece)) + _NAME_STRIDE, dtype=torch.uint8, device=dev)
+            w = self._writer
+            stream = _lib.current_stream_ptr(dev)
+            for r0 in range(0, n, piece):
+                m = min(piece, n - r0)
+                tw = time.perf_counter()
+                idx = w.free.get()                         # back-pressure: all text buffers are with the writer
+                self.seconds["wait_buffer"] += time.perf_counter() - tw
+                if w.error is not None:
+                    w.free.put(idx)
+                    raise w.error
+                t.perm, t.n = perm[r0:r0 + m].data_ptr(), m
+                _lib.check(lib.mural_tsv_format_device(C.byref(t), w.text[idx].data_ptr(), w.text[idx].numel(), w.count[idx].data_ptr(),
+                                                      self._ws.data_ptr(), self._ws.numel(), stream))
+                ev = torch.cuda.Event()
+                ev.record()
+                w.jobs.put((idx, ev))
+            # the tensors of this shard must outlive the kernels just enqueued: the caching allocator keeps their memory on this
+            # stream, so later allocations of the same stream cannot overwrite them before the kernels ran
+        self.seconds["sort_format_enqueue"] += time.perf_counter() - t0
 
     def __call__(self, shard):
-        name = str(shard["chrom"][0]) if len(shard["chrom"]) else None
-        if self._streaming and name is not None and (self._last is None or name > self._last):
+        name = self._name(shard)
+        n = len(shard["start"])
+        if name is None or n == 0:
+            return
+        self.rows += n
+        on_device = isinstance(shard["prob"], torch.Tensor) and shard["prob"].is_cuda
+        if not self._spool and (self._last is None or name > self._last):
             self._last = name
-            df = self._frame(shard)
-            df.sort_values(["start"], inplace=True, kind="stable")
-            self._write(df)
-        else:
-            self._streaming = False
-            self._buffer.append(self._frame(shard))
+            if on_device:
+                self._stream_device(name, shard)
+            else:
+                if isinstance(shard["prob"], torch.Tensor):
+                    shard = dict(shard, prob=shard["prob"].numpy())
+                self._stream_host(name, shard)
+            return
+        cpu = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)     # noqa: E731
+        k = int(shard.get("n_class", shard["prob"].shape[1]))
+        self._spool.append({"name": name, "start": cpu(shard["start"]), "end": cpu(shard["end"]),
+                            "strand": cpu(self._strand_u8(shard["strand"])), "label": cpu(shard["label"]),
+                            "prob": self._host_prob(cpu(shard["prob"])[:, :k])})
+
+    # -- close ------------------------------------------------------------------------------------------------------------
+    def _close_writer(self):
+        if self._writer is not None:
+            self._writer.jobs.put(None)
+            self._writer.join()
+            err = self._writer.error
+            for key, v in dict(self._writer.seconds, bytes=self._writer.bytes).items():
+                self._writer_totals[key] += v
+            self._writer = None
+            if err is not None:
+                raise err
+
+    def writer_seconds(self):
+        """Busy seconds of the writer thread(s) by phase and the bytes they wrote (complete after close())."""
+        out = dict(self._writer_totals)
+        if self._writer is not None:
+            for key, v in dict(self._writer.seconds, bytes=self._writer.bytes).items():
+                out[key] += v
+        return out
 
     def close(self):
-        import pandas as pd
-        if self._buffer:
-            if self._wrote_header:                   # some shards were already streamed out: merge them back in
-                self._buffer.insert(0, pd.read_csv(self.path, sep="\t"))
-                open(self.path, "w").close()
-                self._wrote_header = False
-            df = pd.concat(self._buffer, ignore_index=True)
-            df.sort_values(["chrom", "start"], inplace=True, kind="stable")
-            self._write(df)
-            self._buffer = []
-        elif not self._wrote_header:
-            self._write(self._frame({"chrom": np.zeros(0, object), "start": np.zeros(0, np.int64), "end": np.zeros(0, np.int64),
-                                     "strand": np.zeros(0, object), "label": np.zeros(0), "prob": np.zeros((0, 0))}))
+        self._close_writer()
+        if not self._spool:
+            if not self._wrote_header:
+                self._fh.write(_header(0))
+            self._fh.close()
+            return
+        # Out-of-order arrival: merge the spooled rows with what was already streamed.  Streamed rows are text already; per
+        # chromosome they are merged line-wise by their start field (they arrived first, so they win ties), never re-parsed as
+        # numbers.
+        self._fh.flush()
+        self._fh.close()
+        with open(self.path, "rb") as fh:
+            blob = fh.read()
+        head_len = blob.index(b"\n") + 1 if self._wrote_header else 0
+        k = self._spool[0]["prob"].shape[1]
+        body = blob[head_len:]
+        lines_by_chrom = {}
+        if body:
+            for line in body.split(b"\n")[:-1]:
+                lines_by_chrom.setdefault(line.split(b"\t", 1)[0].decode(), []).append(line)
+        spooled = {}
+        for sh in self._spool:
+            spooled.setdefault(sh["name"], []).append(sh)
+        with open(self.path, "wb") as out:
+            out.write(_header(k))
+            for name in sorted(set(lines_by_chrom) | set(spooled)):
+                old = lines_by_chrom.get(name, [])
+                new_lines = []
+                if name in spooled:
+                    parts = spooled[name]
+                    cat = lambda key: np.concatenate([p[key] for p in parts])     # noqa: E731
+                    text = format_rows_host([name], None, cat("start"), cat("end"), cat("strand"), cat("label"), cat("prob"), None,
+                                            self.host_threads)
+                    new_lines = text.split(b"\n")[:-1]
+                lines = old + new_lines
+                starts = np.array([int(ln.split(b"\t", 2)[1]) for ln in lines], np.int64)
+                for i in np.argsort(starts, kind="stable"):
+                    out.write(lines[i] + b"\n")
+        self._spool = []
 
 
-def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="snv", group=None, sink=None, collect=True):
+def write_predictions(res, path, poisson=False, dirichlet_weights=None):
+    """The prediction table of run_predict.py:217-239 from the dict returned by ``predict_bed`` / ``predict_bed_sharded``: optional
+    Dirichlet calibration (``calibration.load_dirichlet_weights`` of the model's ``model.fdiri_cal.pkl``), optional Poisson
+    calibration, then columns chrom, start, end, strand, mut_type, prob0.., rows sorted by (chrom, start) like pandas'
+    sort_values (stable), tab-separated, floats as '%.4g' -- byte-identical to the reference's pandas writer, formatted by the
+    C++ row formatter.  Returns the number of rows."""
+    prob = np.asarray(res["prob"])
+    if dirichlet_weights is not None:
+        from .calibration import dirichlet_calibrate
+        prob = dirichlet_calibrate(prob, dirichlet_weights)
+    if poisson:
+        from .data.ingest import poisson_calibrate
+        prob = poisson_calibrate(prob)
+    chrom = np.asarray(res["chrom"], dtype=object)
+    n = len(chrom)
+    names = sorted(set(chrom.tolist()))
+    rank = {nm: i for i, nm in enumerate(names)}
+    cid = np.fromiter((rank[c] for c in chrom), np.int32, n)
+    start = np.asarray(res["start"], np.int64)
+    perm = np.lexsort((start, cid))                     # stable, like pandas' multi-column sort_values
+    strand = np.asarray(res["strand"])
+    strand = strand if strand.dtype == np.uint8 else (strand == "-").astype(np.uint8)
+    k = prob.shape[1] if prob.ndim == 2 else 0
+    with open(path, "wb") as fh:
+        fh.write(_header(k))
+        if n:
+            fh.write(format_rows_host(names, cid, start, res["end"], strand, np.asarray(res["label"], np.float32), prob, perm))
+    return n
+
+
+def _device_of(forward):
+    dev = getattr(forward, "device", None)
+    if dev is not None and torch.device(dev).type == "cuda":
+        return torch.device(dev)
+    return None
+
+
+def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="snv", group=None, sink=None, collect=True, timings=None):
     """Sharded file-level prediction.  `forward(chrom_name, pos, strand) -> (rows, n_class + 1)` tensor (probabilities + focal
-    base; see HipShardForward) is called once per shard with THIS rank's block of the shard's sites.  Every rank takes part in
-    one all_gather per shard; `sink(shard_dict)` is called on rank 0 with the gathered shard (keys chrom, start, end, strand,
-    label, prob, order).  With `collect` the function also returns those arrays for ALL rows (bed_reader order) on every rank --
-    leave it off for genome-scale inputs and let the sink stream them out.  Returns the dict (or row count if not collecting)."""
+    base; see HipShardForward) is called once per shard (= chromosome, in ascending name order) with THIS rank's block of the
+    shard's sites in bed_reader order.  Every rank takes part in one all_gather per shard; `sink(shard_dict)` is called on rank 0
+    with the gathered shard (keys chrom, start, end, strand, label, prob, n_class, order; device tensors when `forward` has a HIP
+    ``device`` attribute, numpy arrays otherwise).  With `collect` the function also returns those arrays for ALL rows in
+    bed_reader order on every rank -- leave it off for genome-scale inputs and let the sink stream them out.  Returns the dict
+    (or the row count if not collecting).  `timings`: optional dict that receives the wall-clock split of this call."""
     from .data import ingest
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
+    T = {} if timings is None else timings
+    clock = time.perf_counter
+    t0 = clock()
     sites = ingest.read_bed(bed_path)
+    T["bed_read"] = clock() - t0
+    t0 = clock()
     order, grp = ingest.bed_order(sites, segment_center)
-    cid, start, strand = sites.chrom_id[order], sites.start[order], sites.strand[order]
-    names = np.asarray(sites.chrom_names, dtype=object)
-    kept = []
-    for lo, hi in shard_runs(cid):
-        chrom = sites.chrom_names[cid[lo]]
-        b0, b1 = shard_bounds(hi - lo, rank, world)
-        local = forward(chrom, start[lo + b0:lo + b1], strand[lo + b0:lo + b1])
+    T["bed_order"] = clock() - t0
+    n_all = len(order)
+    dev = _device_of(forward)
+    t0 = clock()
+    if dev is not None:
+        # every column once to the device in FILE order; the bed_reader order is applied there (gathers at HBM speed)
+        up = lambda a: torch.from_numpy(a).to(dev)                                            # noqa: E731
+        order_d = up(order)
+        cid_o = up(sites.chrom_id)[order_d]
+        cut = torch.nonzero(cid_o[1:] != cid_o[:-1]).flatten().cpu().numpy() + 1 if n_all else np.zeros(0, np.int64)
+        bounds = np.r_[0, cut, n_all] if n_all else np.zeros(1, np.int64)
+        run_ids = cid_o[torch.from_numpy(bounds[:-1]).to(dev)].cpu().numpy() if n_all else np.zeros(0, np.int32)
+        start_o, strand_o = up(sites.start)[order_d], up(sites.strand)[order_d]
+        need_meta = collect or (rank == 0 and sink is not None)
+        if need_meta:
+            end_o, label_o = up(sites.end)[order_d], up(sites.score)[order_d]
+        grp_o = up(grp) if model_type == "snv" else None
+        del cid_o
+    else:
+        cid_h = sites.chrom_id[order]
+        runs = shard_runs(cid_h)
+        bounds = np.array([lo for lo, _ in runs] + [n_all], np.int64)
+        run_ids = np.array([cid_h[lo] for lo, _ in runs], np.int32)
+        start_o, strand_o = sites.start[order], sites.strand[order]
+        end_o, label_o = sites.end[order], sites.score[order]
+        grp_o = grp
+    T["order_columns"] = clock() - t0
+    by_id = {}
+    for i, c in enumerate(run_ids.tolist()):
+        by_id.setdefault(c, []).append((int(bounds[i]), int(bounds[i + 1])))
+    shards = [(sites.chrom_names[c], by_id[c]) for c in sorted(by_id, key=lambda c: sites.chrom_names[c])]
+
+    def take(col, runs):
+        if len(runs) == 1:
+            return col[runs[0][0]:runs[0][1]]
+        parts = [col[lo:hi] for lo, hi in runs]
+        return torch.cat(parts) if isinstance(col, torch.Tensor) else np.concatenate(parts)
+
+    kept, pending_check = [], None
+    T.update({"compute_enqueue": 0.0, "gather": 0.0, "sink": 0.0, "focal_wait": 0.0})
+
+    def finish_check(pc):
+        if pc is None:
+            return
+        t = clock()
+        ev, host = pc
+        ev.synchronize()
+        T["focal_wait"] += clock() - t
+        if int(host[0]) != 0:
+            raise ValueError(_FOCAL_MSG)
+
+    for si, (chrom, runs) in enumerate(shards):
+        n = sum(hi - lo for lo, hi in runs)
+        b0, b1 = shard_bounds(n, rank, world)
+        pos_s, strand_s = take(start_o, runs), take(strand_o, runs)
+        if hasattr(forward, "prefetch") and si + 1 < len(shards):
+            forward.prefetch(shards[si + 1][0])
+        t0 = clock()
+        local = forward(chrom, pos_s[b0:b1], strand_s[b0:b1])
+        T["compute_enqueue"] += clock() - t0
         if local.shape[0] != b1 - b0:
             raise RuntimeError("forward returned a wrong number of rows")
-        full = all_gather_rows(local, hi - lo, group).cpu().numpy()
-        if model_type == "snv":
-            check_focal_groups(full[:, -1].astype(np.int64), grp[lo:hi])
-        shard = {"chrom": names[cid[lo:hi]], "start": start[lo:hi], "end": sites.end[order[lo:hi]],
-                 "strand": np.where(strand[lo:hi] == 1, "-", "+"), "label": sites.score[order[lo:hi]], "prob": full[:, :-1],
-                 "order": order[lo:hi]}
+        t0 = clock()
+        full = all_gather_rows(local, n, group)
+        T["gather"] += clock() - t0
+        k = full.shape[1] - 1
+        if dev is not None:
+            if model_type == "snv":
+                status = torch.zeros(1, dtype=torch.int32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(_lib.lib().mural_focal_group_check(full.data_ptr(), int(full.dtype == torch.float64), full.stride(0), k,
+                                                                 take(grp_o, runs).contiguous().data_ptr(), n, status.data_ptr(),
+                                                                 _lib.current_stream_ptr(dev)))
+                    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    host.copy_(status, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                finish_check(pending_check)            # the verdict of the PREVIOUS shard: never waits for work just enqueued
+                pending_check = (ev, host)
+            shard = None
+            if need_meta:
+                shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
+                         "prob": full, "n_class": k}
+        else:
+            full = full.cpu().numpy() if isinstance(full, torch.Tensor) else np.asarray(full)
+            if model_type == "snv":
+                check_focal_groups(full[:, -1].astype(np.int64), take(grp_o, runs))
+            shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
+                     "prob": full[:, :-1], "n_class": k}
         if sink is not None and rank == 0:
+            t0 = clock()
             sink(shard)
+            T["sink"] += clock() - t0
         if collect:
-            kept.append(shard)
+            cpu = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)     # noqa: E731
+            kept.append((runs, {"start": cpu(shard["start"]), "end": cpu(shard["end"]), "strand": cpu(shard["strand"]),
+                                "label": cpu(shard["label"]), "prob": cpu(shard["prob"])[:, :k], "chrom": chrom}))
+    finish_check(pending_check)
     if sink is not None and rank == 0 and hasattr(sink, "close"):
+        t0 = clock()
         sink.close()
+        T["sink_close"] = clock() - t0
     if not collect:
-        return len(order)
+        return n_all
     if not kept:
         return {"chrom": np.zeros(0, object), "start": np.zeros(0, np.int64), "end": np.zeros(0, np.int64),
                 "strand": np.zeros(0, object), "label": np.zeros(0, np.float32), "prob": np.zeros((0, 0), np.float32),
                 "order": np.zeros(0, np.int64)}
-    return {k: np.concatenate([sh[k] for sh in kept]) for k in kept[0]}
+    k = kept[0][1]["prob"].shape[1]
+    out = {"chrom": np.empty(n_all, object), "start": np.empty(n_all, np.int64), "end": np.empty(n_all, np.int64),
+           "strand": np.empty(n_all, object), "label": np.empty(n_all, np.float32),
+           "prob": np.empty((n_all, k), kept[0][1]["prob"].dtype), "order": order}
+    for runs, sh in kept:
+        o = 0
+        for lo, hi in runs:
+            m = hi - lo
+            out["chrom"][lo:hi] = sh["chrom"]
+            out["start"][lo:hi], out["end"][lo:hi] = sh["start"][o:o + m], sh["end"][o:o + m]
+            out["strand"][lo:hi] = np.where(sh["strand"][o:o + m] == 1, "-", "+")
+            out["label"][lo:hi], out["prob"][lo:hi] = sh["label"][o:o + m], sh["prob"][o:o + m]
+            o += m
+    return out

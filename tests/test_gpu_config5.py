@@ -168,3 +168,76 @@ def test_sharded_driver_with_device_calibration_writes_the_same_table(tmp_path):
     assert len(ta) == len(tb) == len(sites) + 2
     diff = sum(x != y for x, y in zip(ta, tb))
     assert diff <= len(sites) // 100        # '%.4g' of float64 values that differ in the 7th digit: a rare rounding flip at most
+
+
+def test_sharded_driver_takes_the_reuse_path_on_dense_sites_and_matches_oracle(tmp_path):
+    """dense site lists go through the cross-position reuse kernels inside the sharded file-level driver (device
+    columns, device sort, device-formatted table); probabilities against the oracle, table against the single-process writer.  The
+    BED interleaves its chromosomes, so one of them arrives as two runs, and a third chromosome is sparse (per-window kernels)."""
+    from mural_amd.data.ingest import write_predictions
+    from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
+    model, orc, r, R = _models(HUMAN[0])
+    rng = np.random.default_rng(61)
+    seqs = {"chr2": _genome(rng, 12_000), "chr10": _genome(rng, 9000), "chrS": _genome(rng, 30_000, iupac=False)}
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">{k}\n" + "\n".join(s[i:i + 70] for i in range(0, len(s), 70)) + "\n" for k, s in seqs.items()))
+
+    def at_sites(name, lo, hi, every=1):
+        arr = np.frombuffer(seqs[name].encode(), np.uint8)
+        return [(name, int(p), "+" if arr[p] == ord("A") else "-") for p in range(lo, hi, every) if arr[p] in (ord("A"), ord("T"))]
+
+    a, b, c = at_sites("chr2", 0, 6000), at_sites("chr10", 0, 9000), at_sites("chr2", 6000, 12_000)
+    sparse = at_sites("chrS", 0, 30_000, every=41)
+    rows = a + b + c + sparse                              # chr2 comes back after chr10: two runs of one chromosome
+    bed = tmp_path / "s.bed"
+    bed.write_text("".join(f"{ch}\t{p}\t{p + 1}\t.\t{i % 4}\t{st}\n" for i, (ch, p, st) in enumerate(rows)))
+    fwd = HipShardForward(model, fa, local_radius=r, local_order=3)
+    out = tmp_path / "pred.tsv"
+    timings = {}
+    res = predict_bed_sharded(fwd, bed, segment_center=2500, sink=TsvSink(out), timings=timings)
+    assert fwd.reuse_sites == len(a) + len(b) + len(c)      # the dense chromosomes; chrS (1 site per ~80 bases) went per-window
+    assert len(res["start"]) == len(rows) and {"bed_read", "compute_enqueue", "sink"} <= set(timings)
+    sub = rng.choice(len(rows), size=400, replace=False)
+    for name, s in seqs.items():
+        sel = sub[res["chrom"][sub] == name]
+        want = _oracle_probs(orc, s, res["start"][sel], res["strand"][sel] == "-", r, R)
+        assert np.abs(res["prob"][sel] - want).max() <= PROB_TOL, name
+    # per-window driver on the same files: same rows, same order
+    plain = predict_bed_sharded(HipShardForward(model, fa, local_radius=r, local_order=3, reuse=False), bed, segment_center=2500)
+    assert np.array_equal(plain["start"], res["start"]) and np.array_equal(plain["chrom"], res["chrom"])
+    assert np.abs(plain["prob"] - res["prob"]).max() <= PROB_TOL
+    want_path = tmp_path / "want.tsv"
+    write_predictions(res, want_path)
+    assert open(out, "rb").read() == open(want_path, "rb").read()
+    # a site whose base disagrees with its group is still caught (device check, verdict read one shard late)
+    arr = np.frombuffer(seqs["chr10"].encode(), np.uint8)
+    p_bad = int(np.nonzero(arr == ord("C"))[0][40])            # a C posing as a '+' site in the middle of chr10's A sites
+    k_ins = next(i for i, (_, p, _) in enumerate(b) if p > p_bad)
+    bad_rows = a + b[:k_ins] + [("chr10", p_bad, "+")] + b[k_ins:] + c + sparse
+    bad_bed = tmp_path / "bad.bed"
+    bad_bed.write_text("".join(f"{ch}\t{p}\t{p + 1}\t.\t0\t{st}\n" for ch, p, st in bad_rows))
+    with pytest.raises(ValueError, match="different bases"):
+        predict_bed_sharded(HipShardForward(model, fa, local_radius=r, local_order=3), bad_bed, segment_center=2500, collect=False)
+
+
+def test_zero_row_rank_blocks_through_the_real_forward(tmp_path):
+    """A rank whose block of a shard is empty (more ranks than rows) calls the real forward with zero sites: both entries return
+    (0, n_class) / (0, n_class + 1) without touching the device queue in a way that breaks the next call."""
+    from mural_amd.data import PackedGenome
+    from mural_amd.predict import HipShardForward
+    model, orc, r, R = _models(HUMAN[0])
+    rng = np.random.default_rng(62)
+    seq = _genome(rng, 6000, iupac=False)
+    g = PackedGenome.from_sequence(seq, "cuda")
+    z = torch.zeros(0, dtype=torch.int64, device="cuda")
+    zs = torch.zeros(0, dtype=torch.uint8, device="cuda")
+    with torch.no_grad():
+        assert model.forward_packed(g, z, zs, local_radius=r, local_order=3).shape == (0, 4)
+        assert model.forward_packed_reuse(g, z, zs, local_radius=r, local_order=3).shape == (0, 4)
+    fa = tmp_path / "g.fa"
+    fa.write_text(">c\n" + seq + "\n")
+    fwd = HipShardForward(model, fa, local_radius=r, local_order=3)
+    assert fwd("c", np.zeros(0, np.int64), np.zeros(0, np.uint8)).shape == (0, 5)
+    pos = np.arange(1000, 1300)
+    got = fwd("c", pos, np.zeros(300, np.uint8))[:, :4].cpu().numpy()
+    assert np.abs(got - _oracle_probs(orc, seq, pos, np.zeros(300, bool), r, R)).max() <= PROB_TOL

@@ -79,7 +79,9 @@ def test_train_evaluate_save_reload_predict(tmp_path):
     again, cfg = nn_utils.load_model(ckpt)
     res2 = ingest.predict_bed(again, fa, bed, cfg["local_radius"], cfg["local_order"], segment_center=cfg["segment_center"])
     assert np.array_equal(res2["prob"], res["prob"])
-    table = ingest.write_predictions(res2, tmp_path / "pred.tsv", dirichlet_weights=load_dirichlet_weights(ckpt + ".fdiri_cal.pkl"))
+    assert ingest.write_predictions(res2, tmp_path / "pred.tsv", dirichlet_weights=load_dirichlet_weights(ckpt + ".fdiri_cal.pkl")) == len(rows)
+    import pandas as pd
+    table = pd.read_csv(tmp_path / "pred.tsv", sep="\t")
     assert list(table.columns[:5]) == ["chrom", "start", "end", "strand", "mut_type"] and len(table) == len(rows)
     assert table["start"].is_monotonic_increasing
     # the same through the command-line helper
@@ -126,5 +128,7 @@ def test_indel_train_from_files_and_predict(tmp_path):
     model.eval()
     res = ingest.predict_bed(model, fa, bed, 4, 3, distal_radius=R, segment_center=4000, model_type="indel")
     assert res["prob"].shape == (48, n_class) and np.allclose(res["prob"].sum(axis=1), 1.0, atol=1e-5)
-    table = ingest.write_predictions(res, tmp_path / "indel.tsv", poisson=True)
+    import pandas as pd
+    assert ingest.write_predictions(res, tmp_path / "indel.tsv", poisson=True) == 48
+    table = pd.read_csv(tmp_path / "indel.tsv", sep="\t")
     assert len(table) == 48 and np.isfinite(table[["prob0", "prob1", "prob2"]].to_numpy()).all()

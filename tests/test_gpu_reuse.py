@@ -160,3 +160,35 @@ def test_reuse_writes_stay_inside_their_workspace_regions(monkeypatch):
         off, size = layout[2 * i], layout[2 * i + 1]
         zone = ws[off + size:off + size + guard]
         assert len(zone) == guard and (zone == 255).all(), f"region {i}: a kernel wrote behind its {size} bytes"
+
+
+def test_reuse_span_multiple_keeps_last_site_and_density_fallback():
+    """with p_max - p_min an exact multiple of the chunk span the site at p_max fell outside every half-open chunk and
+    its row stayed uninitialised.  Also: chunks below `min_density` take the per-window kernels, rows keep their order."""
+    from mural_amd import _lib
+    from mural_amd.data import PackedGenome
+    model, _ = _pair(7, 1000, seed=304)
+    span = int(_lib.lib().mural_snv_reuse_chunk_span())
+    rng = np.random.default_rng(79)
+    n = 2 * span + 10_000
+    codes = rng.integers(0, 4, size=n).astype(np.uint8)
+    genome = PackedGenome.from_sequence(np.frombuffer(b"ACGT", np.uint8)[codes].tobytes().decode(), "cuda")
+    p0 = 3000
+    pos = np.r_[np.arange(p0, p0 + 3000), np.arange(p0 + span - 1500, p0 + span + 1500), np.arange(p0 + 2 * span - 2000, p0 + 2 * span + 1)]
+    assert (pos.max() - pos.min()) % span == 0
+    strand = (rng.integers(0, 2, size=len(pos))).astype(np.uint8)
+    perm = rng.permutation(len(pos))
+    tp, ts = torch.from_numpy(pos[perm]).cuda(), torch.from_numpy(strand[perm]).cuda()
+    with torch.no_grad():
+        want = model.forward_packed(genome, tp, ts, local_radius=7, local_order=3)
+        got, used = model.forward_packed_reuse(genome, tp, ts, local_radius=7, local_order=3, return_reuse_count=True)
+        assert used == len(pos)
+        assert torch.isfinite(got).all()
+        assert float((got.double().exp() - want.double().exp()).abs().max()) <= PROB_TOL
+        # every chunk holds ~3000 sites on a 2 M-base span: below any sensible density -> per-window kernels, bitwise the same rows
+        sparse, used = model.forward_packed_reuse(genome, tp, ts, local_radius=7, local_order=3, min_density=0.1, batch_sites=1000,
+                                                  return_reuse_count=True)
+        assert used == 0 and torch.equal(sparse, want)
+        # single-chunk form of the same rule
+        few = model.forward_packed_reuse(genome, tp[:50], ts[:50], local_radius=7, local_order=3, min_density=0.1)
+        assert torch.equal(few, model.forward_packed(genome, tp[:50], ts[:50], local_radius=7, local_order=3))
