@@ -41,6 +41,7 @@ struct TowerDev {                 // all device pointers into one blob
   const float* taps;              // [3][16][32]
   const float* bias0;             // [32] first-layer conv bias
   const float* wfrag;             // [10][SNV_WFRAG]
+  const float* wfrag4;            // [10][SNV_WFRAG] the same, [mblock][kstep / 4][lane][4]: one 16-byte load = four k-steps of a lane
   const float* bias;              // [10][32]
   const float* post_s;            // [10][32] BN scale applied to relu(layer output) for the next conv
   const float* post_t;            // [10][32]
@@ -138,6 +139,10 @@ struct SnvFwdArgs {
   // s3[tower] - with a tile of many more positions, so that the short stages run full-width layers.
   int phase;
   float* s3[2];                   // [n][L3][32] per tower: input of the second conv stage, in the layout of x0
+  // Wave-private launch (snv_tower_wave.hip; stage-split launches of the throughput path): P counts the sites of ONE WAVE, nbuf
+  // the floats of one wave's image, geom is laid out for P sites per wave.
+  int wave;
+  int stagger;                    // wave-private launch: late start of every second workgroup of a CU, in units of 8128 cycles
 };
 
 }  // namespace mural

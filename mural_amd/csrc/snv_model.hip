@@ -12,6 +12,7 @@
 namespace mural {
 int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_bytes, hipStream_t stream);
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream);
+size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int tower, int phase);   // snv_tower_wave.hip
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
 int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream);
 bool stage1_small_batch(int64_t n);
@@ -59,7 +60,7 @@ void pack_wfrag(const float* W, float* dst) {
       }
 }
 
-struct TowerOff { size_t lut, taps, bias0, wfrag, bias, post_s, post_t, ex_s, ex_t, fc_w, fc_b; };
+struct TowerOff { size_t lut, taps, bias0, wfrag, wfrag4, bias, post_s, post_t, ex_s, ex_t, fc_w, fc_b; };
 
 int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& o) {
   const int C = SNV_C;
@@ -75,6 +76,7 @@ int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& 
   o.taps = o.lut + SNV_LUT;
   o.bias0 = o.taps + SNV_TAPS;
   o.wfrag = B.alloc((size_t)SNV_NLAYER * SNV_WFRAG);
+  o.wfrag4 = B.alloc((size_t)SNV_NLAYER * SNV_WFRAG);
   o.bias = B.alloc(SNV_NLAYER * C);
   o.post_s = B.alloc(SNV_NLAYER * C);
   o.post_t = B.alloc(SNV_NLAYER * C);
@@ -118,6 +120,14 @@ int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& 
   double s[SNV_C], t[SNV_C];
   for (int l = 0; l < SNV_NLAYER; ++l) {
     pack_wfrag(convs[l]->weight, &B.host[o.wfrag + (size_t)l * SNV_WFRAG]);
+    // the same fragments with four consecutive k-steps of a lane side by side (one 16-byte load per lane brings them):
+    // wfrag4[((mb * 6 + g) * 64 + lane) * 4 + j] = wfrag[(mb * 24 + 4 g + j) * 64 + lane]   (snv_tower_wave.hip)
+    for (int mb = 0; mb < 2; ++mb)
+      for (int g4 = 0; g4 < SNV_KSTEPS / 4; ++g4)
+        for (int lane = 0; lane < 64; ++lane)
+          for (int j = 0; j < 4; ++j)
+            B.host[o.wfrag4 + (size_t)l * SNV_WFRAG + ((size_t)(mb * (SNV_KSTEPS / 4) + g4) * 64 + lane) * 4 + j] =
+                B.host[o.wfrag + (size_t)l * SNV_WFRAG + (size_t)(mb * SNV_KSTEPS + 4 * g4 + j) * 64 + lane];
     for (int c = 0; c < C; ++c) B.host[o.bias + l * C + c] = convs[l]->bias[c];
     if (post[l]) {
       bn_affine(*post[l], C, sh.bn_eps, s, t);
@@ -370,6 +380,23 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
               }
             }
             plan_geometry(m->args_split[q], sh.distal_len, Pq, sh.n_class, towers, phase);
+            // Wave-private form of this launch (snv_tower_wave.hip): the most sites per wave that keep a wave within its nine
+            // blocks and two four-wave workgroups on a CU.  MURAL_DEBUG_TOWER_WAVE = bit mask of the launches that may take it
+            // (default: all four); 0 keeps the workgroup-tile kernel everywhere (A/B runs).
+            int wave_mask = 15;
+            if (const char* e = getenv("MURAL_DEBUG_TOWER_WAVE")) wave_mask = atoi(e);
+            if ((wave_mask >> q) & 1) {
+              for (int cand = 31; cand >= 1; --cand) {
+                SnvFwdArgs tmp;
+                std::memset(&tmp, 0, sizeof(tmp));
+                const size_t need = plan_wave_geometry(tmp, sh.distal_len, cand, sh.n_class, q & 1, phase);
+                if (need && need <= kLdsTwoPerCu) {
+                  m->args_split[q] = tmp;
+                  m->lds_split[q] = need;
+                  break;
+                }
+              }
+            }
           }
           m->split = ok;
         }
@@ -411,7 +438,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     for (int tw = 0; tw < 2; ++tw) {
       TowerDev& d = m->args.tw[tw];
       const TowerOff& o = toff[tw];
-      d.lut = m->blob + o.lut; d.taps = m->blob + o.taps; d.bias0 = m->blob + o.bias0; d.wfrag = m->blob + o.wfrag;
+      d.lut = m->blob + o.lut; d.taps = m->blob + o.taps; d.bias0 = m->blob + o.bias0; d.wfrag = m->blob + o.wfrag; d.wfrag4 = m->blob + o.wfrag4;
       d.bias = m->blob + o.bias; d.post_s = m->blob + o.post_s; d.post_t = m->blob + o.post_t;
       d.ex_s = m->blob + o.ex_s; d.ex_t = m->blob + o.ex_t; d.fc_w = m->blob + o.fc_w; d.fc_b = m->blob + o.fc_b;
     }
@@ -465,7 +492,7 @@ extern "C" int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* o) {
   return MURAL_OK;
 }
 
-extern "C" const char* mural_snv_kernel_name(void) { return "snv_towers_fused"; }
+extern "C" const char* mural_snv_kernel_name(void) { return "snv_tower_wave"; }
 
 namespace mural { int profile_begin(); int profile_end(double*, int64_t*); }
 extern "C" int mural_profile_begin(void) { return mural::profile_begin(); }

@@ -476,9 +476,28 @@ int profile_end(double* total_ms, int64_t* launches) {
   return MURAL_OK;
 }
 
+int launch_snv_tower_wave(const SnvFwdArgs& a, size_t lds_bytes, hipStream_t stream);   // snv_tower_wave.hip
+
 int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_bytes, hipStream_t stream) {
   const int64_t n_tiles = (a.n + a.P - 1) / a.P;
   if (n_tiles == 0) return MURAL_OK;
+  if (a.wave) {      // wave-private form of a stage-split launch: same per-launch timing hooks
+    hipEvent_t w0 = nullptr, w1 = nullptr;
+    if (g_prof.on) {
+      while (g_prof.ev.size() < g_prof.used + 2) {
+        hipEvent_t e;
+        MURAL_HIP_CHECK(hipEventCreate(&e));
+        g_prof.ev.push_back(e);
+      }
+      w0 = g_prof.ev[g_prof.used];
+      w1 = g_prof.ev[g_prof.used + 1];
+      g_prof.used += 2;
+      MURAL_HIP_CHECK(hipEventRecord(w0, stream));
+    }
+    if (int rc = launch_snv_tower_wave(a, lds_bytes, stream)) return rc;
+    if (w1) MURAL_HIP_CHECK(hipEventRecord(w1, stream));
+    return MURAL_OK;
+  }
   int grid = (int)(n_tiles < 2048 ? n_tiles : 2048);
   if (a.par) grid = (int)(2 * n_tiles);   // small batches only (run_towers): one workgroup per (tile, tower)
   if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) {   // diagnostic: e.g. 256 = one workgroup per CU (tools/phase_stamps.py)

@@ -1,0 +1,698 @@
+// Wave-private form of the SNV tower kernel for the throughput launches (gfx950 / CDNA4).
+//
+// Reference semantics: MuRaL/model/model_snv.py:473-513 (tower part of Network2.forward), :794-812 (ResBlock), :515-523 (head) --
+// the same layers, layer roles, fragments, k order and epilogue arithmetic as snv_towers_fused (snv_tower.hip), which stays the
+// kernel of the latency-shaped small calls and of the debug dumps.  What changes is who owns what:
+//
+//   * a WAVE owns whole sites: all 32 output channels (both 16-row M-blocks) of every column of its own Pw sites.  A layer's
+//     output feeds only the same wave's next layer, so there is NO workgroup barrier between layers (snv_towers_fused pays
+//     one per layer: ~1.5 k cycles of barrier + pipeline fill against 6.5 k cycles of MFMAs); the waves of a CU drift apart
+//     and one wave's entry / pooling / head phases run under the other wave's MFMAs on the same SIMD.
+//   * both M-blocks share every B operand: one ds_read_b128 feeds 8 MFMAs instead of 4, and the two M-blocks ARE the two
+//     independent accumulator chains the 40-cycle dependent latency of v_mfma_f32_16x16x4_f32 asks for.
+//   * the layer runs IN PLACE on one LDS image per wave: a wave's LDS operations execute in order, block b's output columns
+//     16b+1 .. 16b+16 are written after the tap-0 operands of block b+1 (the only later read that touches them) were read.
+//     One image of <= 146 columns x 128 B = 18.7 KB per wave: four waves per workgroup, two workgroups per CU.
+//   * weight fragments: 48 VGPRs per layer (both M-blocks), single-buffered -- the next layer's fragments are requested into
+//     the registers of each tap group right after the LAST block's MFMAs of that group were issued (>= 500 cycles before their
+//     first use, against ~200 cycles of L2-hit latency).
+//
+// Launches (per chunk of <= 131072 sites, like the workgroup-tile form): (large | mid) x (first conv stage | short stages + fc
+// (+ head)), with Pw = 1 | 2 sites per wave in the first conv stage (136 / 137 columns = 9 blocks) and 6 | 5 in the short stages.
+#include <cstdlib>
+#include <type_traits>
+
+#include "snv_tower_conv.h"
+
+namespace mural {
+
+constexpr int TW_NBW = 9;            // 16-column blocks a wave owns at most
+constexpr uint32_t TW_BLK = 2048u;   // bytes between consecutive blocks of the image (16 columns x 128 B; the swizzle key has period 16)
+
+struct WaveAddr {
+  uint32_t rd[6];    // byte offset of B-operand chunk (tap t, half h) for block 0: rd[2t+h]
+  uint32_t wr[2];    // byte offset of this lane's output chunk of M-block 0 / 1 for block 0
+  uint32_t vmask;    // bit b: this lane's column of block b carries data (not separator / padding)
+};
+
+__device__ __forceinline__ WaveAddr wave_setup(const TowerGeom& g, int st, int Pw, int n16, int kk) {
+  WaveAddr a;
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) a.rd[2 * t + h] = 4u * (uint32_t)lds_off(n16 + t, 4 * h + kk);
+  a.wr[0] = 4u * (uint32_t)lds_off(n16 + 1, kk);
+  a.wr[1] = 4u * (uint32_t)lds_off(n16 + 1, 4 + kk);
+  a.vmask = 0;
+#pragma unroll
+  for (int b = 0; b < TW_NBW; ++b) a.vmask |= col_is_data(n16 + 16 * b, g.dSc[st], g.Sc[st], g.L[st], Pw) ? (1u << b) : 0u;
+  return a;
+}
+
+// 16 bytes at (wave-uniform base + 32-bit lane offset) through a raw buffer descriptor: four SGPRs + one VGPR per load -- no 64-bit
+// lane pointers for the compiler to precompute and spill (the flat form kept nine of them in scratch and drained vmcnt per load)
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
+// four k-steps (4 g .. 4 g + 3) of both M-blocks' fragments: two 16-byte loads per lane; w4 = layer base of wfrag4 + 4 * lane
+// (wf = descriptor of the tower's wfrag4 table, layer_bytes = byte offset of the layer in it: scalar; lane16 = 16 * lane)
+struct FragSrc {
+  __amdgpu_buffer_rsrc_t wf;
+  uint32_t layer_bytes;      // wave-uniform; ~0u: no request
+  uint32_t lane16;
+};
+__device__ __forceinline__ void load_frag4(float (&a0)[SNV_KSTEPS], float (&a1)[SNV_KSTEPS], const FragSrc& w4, int g) {
+  const f32x4 u = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w4.wf, w4.lane16, w4.layer_bytes + 1024u * g, 0));
+  const f32x4 v = __builtin_bit_cast(
+      f32x4, __builtin_amdgcn_raw_buffer_load_b128(w4.wf, w4.lane16, w4.layer_bytes + 1024u * (SNV_KSTEPS / 4 + g), 0));
+  a0[4 * g] = u.x;
+  a0[4 * g + 1] = u.y;
+  a0[4 * g + 2] = u.z;
+  a0[4 * g + 3] = u.w;
+  a1[4 * g] = v.x;
+  a1[4 * g + 1] = v.y;
+  a1[4 * g + 2] = v.z;
+  a1[4 * g + 3] = v.w;
+}
+
+// One slot of a block's epilogue (see epilogue() in snv_tower_conv.h: the same arithmetic, cut into eight pieces so that each piece
+// can sit behind one pair of MFMAs of the NEXT block): slots 0-3 build o = ps * max(acc, lo) + pt, 4-5 update the residual stream,
+// 6 masks separator / padding columns, 7 stores the 16-byte chunk.
+template <int R, bool FINAL>
+__device__ __forceinline__ void epi_slot(const LayerK& k, const f32x4& acc, f32x4& xr, f32x4& o, bool valid, const f32x4& ps,
+                                         const f32x4& pt, char* img, uint32_t off) {
+  if constexpr (R == 0) {
+    o.x = fmaxf(acc.x, k.lo);
+    o.y = fmaxf(acc.y, k.lo);
+  } else if constexpr (R == 1) {
+    o.z = fmaxf(acc.z, k.lo);
+    o.w = fmaxf(acc.w, k.lo);
+  } else if constexpr (R == 2) {
+    o.x = fmaf(ps.x, o.x, pt.x);
+    o.y = fmaf(ps.y, o.y, pt.y);
+  } else if constexpr (R == 3) {
+    o.z = fmaf(ps.z, o.z, pt.z);
+    o.w = fmaf(ps.w, o.w, pt.w);
+  } else if constexpr (R == 4) {
+    if constexpr (!FINAL) {      // the last layer of a launch: the residual registers are dead (and may already hold prefetched data)
+      xr.x = fmaf(acc.x, k.ku, xr.x * k.kx);
+      xr.y = fmaf(acc.y, k.ku, xr.y * k.kx);
+    }
+  } else if constexpr (R == 5) {
+    if constexpr (!FINAL) {
+      xr.z = fmaf(acc.z, k.ku, xr.z * k.kx);
+      xr.w = fmaf(acc.w, k.ku, xr.w * k.kx);
+    }
+  } else if constexpr (R == 6) {
+    o = valid ? o : splat(0.f);
+  } else {
+    lds_st4(img, off, o);
+  }
+}
+
+// One conv tap (8 k-steps) of a block for both M-blocks -- the two accumulator chains alternate, pair by pair -- with slot (pair
+// index) of the PREVIOUS block's epilogue for M-block `EM` behind every pair.  A scheduling barrier closes every pair: the
+// backend's own grouping serialises each chain (8 dependent MFMAs in a row: 40 instead of 32 cycles each).
+template <int T, bool EPI, bool FINAL>
+__device__ __forceinline__ void mfma_tap_epi(const float (&a0)[SNV_KSTEPS], const float (&a1)[SNV_KSTEPS], const f32x4 (&bv)[2], f32x4& acc0,
+                                             f32x4& acc1, const LayerK& k, const f32x4& pa, f32x4& xr, f32x4& o, bool valid, const f32x4& ps,
+                                             const f32x4& pt, char* img, uint32_t off) {
+#define MURAL_TAP_PAIR(I)                                                                                       \
+  acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[8 * T + (I)], bv[(I) >> 2][(I) & 3], acc0, 0, 0, 0);          \
+  acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[8 * T + (I)], bv[(I) >> 2][(I) & 3], acc1, 0, 0, 0);          \
+  if constexpr (EPI) epi_slot<(I), FINAL>(k, pa, xr, o, valid, ps, pt, img, off);                               \
+  __builtin_amdgcn_sched_barrier(0);
+  MURAL_TAP_PAIR(0)
+  MURAL_TAP_PAIR(1)
+  MURAL_TAP_PAIR(2)
+  MURAL_TAP_PAIR(3)
+  MURAL_TAP_PAIR(4)
+  MURAL_TAP_PAIR(5)
+  MURAL_TAP_PAIR(6)
+  MURAL_TAP_PAIR(7)
+#undef MURAL_TAP_PAIR
+}
+
+// One 32->32 k=3 conv layer of this wave, in place on `img`, NB blocks wide (compile time: straight-line code, no copies at block
+// boundaries).  wn: fragments of the layer that follows (wfrag4 layout + 4 * lane), requested into a0 / a1 tap group by tap group
+// behind the last block's MFMAs of that group.  FINAL: last layer of a launch -- the residual registers die with each block's
+// accumulator start and are not updated.
+template <int NB, bool FINAL>
+__device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, const LayerK& k, float (&a0)[SNV_KSTEPS],
+                                                float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
+                                                const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW]) {
+  static_assert(NB >= 1 && NB <= TW_NBW, "blocks per wave");
+  f32x4 X[2], Y[2], Z[2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    X[h] = lds_ld4(img, sa.rd[h]);
+    Y[h] = lds_ld4(img, sa.rd[2 + h]);
+    Z[h] = lds_ld4(img, sa.rd[4 + h]);
+  }
+  f32x4 pa0 = splat(0.f), pa1 = splat(0.f), o0 = splat(0.f), o1 = splat(0.f);
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    const bool last = b == NB - 1;
+    const int bp = b > 0 ? b - 1 : 0;
+    const bool vprev = (sa.vmask >> bp) & 1u;
+    f32x4 acc0 = acc_init(k, pb[0], xr0[b]), acc1 = acc_init(k, pb[1], xr1[b]);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_tap_epi<0, false, FINAL>(a0, a1, X, acc0, acc1, k, pa0, xr0[bp], o0, vprev, ps[0], pt[0], img, 0u);
+    // tap-0 operands of the next block: read BEFORE this block's epilogue overwrites image column 16(b+1) (in-place rule)
+    if (!last) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) X[h] = lds_ld4(img, sa.rd[h] + TW_BLK * (b + 1));
+    } else if (wn.layer_bytes != ~0u) {
+      load_frag4(a0, a1, wn, 0);
+      load_frag4(a0, a1, wn, 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // the previous block's epilogue rides behind this block's tap-1 (M-block 0) and tap-2 (M-block 1) MFMA pairs
+    if (b > 0) mfma_tap_epi<1, true, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], o0, vprev, ps[0], pt[0], img, sa.wr[0] + TW_BLK * bp);
+    else mfma_tap_epi<1, false, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], o0, vprev, ps[0], pt[0], img, 0u);
+    if (!last) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) Y[h] = lds_ld4(img, sa.rd[2 + h] + TW_BLK * (b + 1));
+    } else if (wn.layer_bytes != ~0u) {
+      load_frag4(a0, a1, wn, 2);
+      load_frag4(a0, a1, wn, 3);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (b > 0) mfma_tap_epi<2, true, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], o1, vprev, ps[1], pt[1], img, sa.wr[1] + TW_BLK * bp);
+    else mfma_tap_epi<2, false, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], o1, vprev, ps[1], pt[1], img, 0u);
+    if (!last) {
+#pragma unroll
+      for (int h = 0; h < 2; ++h) Z[h] = lds_ld4(img, sa.rd[4 + h] + TW_BLK * (b + 1));
+    } else if (wn.layer_bytes != ~0u) {
+      load_frag4(a0, a1, wn, 4);
+      load_frag4(a0, a1, wn, 5);
+    }
+    pa0 = acc0;
+    pa1 = acc1;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the last block's epilogue has no MFMAs to hide behind
+  {
+    const bool v = (sa.vmask >> (NB - 1)) & 1u;
+    f32x4 dx0 = xr0[NB - 1], dx1 = xr1[NB - 1];      // FINAL: the registers may hold prefetched data, the update goes to a dead copy
+    epilogue(k, pa0, FINAL ? dx0 : xr0[NB - 1], v, ps[0], pt[0], img, sa.wr[0] + TW_BLK * (NB - 1));
+    epilogue(k, pa1, FINAL ? dx1 : xr1[NB - 1], v, ps[1], pt[1], img, sa.wr[1] + TW_BLK * (NB - 1));
+  }
+}
+
+// the same layer for a block count known only at run time (window lengths without a specialised instantiation)
+template <bool FINAL>
+__device__ __forceinline__ void conv_layer_wave_rt(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
+                                                   float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
+                                                   const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW]) {
+  switch (nb) {
+    case 1: conv_layer_wave<1, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 2: conv_layer_wave<2, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 3: conv_layer_wave<3, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 4: conv_layer_wave<4, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 5: conv_layer_wave<5, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 6: conv_layer_wave<6, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 7: conv_layer_wave<7, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 8: conv_layer_wave<8, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    default: conv_layer_wave<9, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+  }
+}
+
+template <int NB, bool FINAL>
+__device__ __forceinline__ void conv_layer_any(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
+                                               float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
+                                               const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW]) {
+  if constexpr (NB > 0) conv_layer_wave<NB, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1);
+  else conv_layer_wave_rt<FINAL>(img, sa, nb, k, a0, a1, wn, pb, ps, pt, xr0, xr1);
+}
+
+// Stage-1 activations of unit `unit` straight into the residual registers, in MFMA accumulator layout (lane = column n16 of each
+// block, channels 4 kk .. + 3 of both M-blocks): one wave-uniform buffer descriptor per unit + a 32-bit lane offset worked out on
+// the spot (a division by multiply-high per block) -- nothing per-lane survives between units, so nothing is spilled.  Columns
+// without data (separators, padding) and rows behind the last site read as zero.
+__device__ __forceinline__ void wave_request_x0(const SnvFwdArgs& args, f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], int64_t unit,
+                                                int64_t n_units, int tw_i, int n16, int kk) {
+  const TowerGeom& g = args.geom[tw_i];
+  const int x0c = tw_i == 0 ? 0 : args.geom[0].L[0];
+  const int64_t row0 = unit * args.P;
+  const bool any = unit < n_units;
+  const __amdgpu_buffer_rsrc_t base = uniform_rsrc(args.x0 + ((size_t)(any ? row0 : 0) * args.x0_cols + x0c) * 32);
+  const int rows = any ? (int)(args.n - row0 < args.P ? args.n - row0 : args.P) : 0;      // sites of this unit that exist
+  uint32_t lane_col = (uint32_t)n16;
+  asm volatile("" : "+v"(lane_col));      // opaque: keeps the offsets below from being precomputed for the whole launch
+  if (rows == args.P) {
+    // a whole unit (all but the last): every lane loads -- lanes whose column holds no data (separators, padding) read the unit's
+    // first column instead, their values never reach a data column -- so there is no divergent control flow around the loads
+#pragma unroll
+    for (int b = 0; b < TW_NBW; ++b) {
+      if (b < g.nb[0]) {
+        const uint32_t c = 16u * b + lane_col;
+        const uint32_t u = c - 1u;
+        const uint32_t p = g.dSc[0].div(u);
+        const uint32_t j2 = u - p * (uint32_t)g.Sc[0];
+        const bool ok = c >= 1u && p < (uint32_t)rows && j2 < (uint32_t)g.L[0];
+        const uint32_t vo = (ok ? ((p * (uint32_t)args.x0_cols + j2) << 7) : 0u) + 16u * (uint32_t)kk;
+        xr0[b] = buf_ld4(base, vo);
+        xr1[b] = buf_ld4(base, vo + 64u);
+      } else {
+        xr0[b] = splat(0.f);
+        xr1[b] = splat(0.f);
+      }
+    }
+    return;
+  }
+#pragma unroll
+  for (int b = 0; b < TW_NBW; ++b) {
+    xr0[b] = splat(0.f);
+    xr1[b] = splat(0.f);
+    if (b < g.nb[0]) {
+      const uint32_t c = 16u * b + lane_col;
+      const uint32_t u = c - 1u;                        // c == 0 wraps: p becomes huge and the lane reads nothing
+      const uint32_t p = g.dSc[0].div(u);
+      const uint32_t j2 = u - p * (uint32_t)g.Sc[0];
+      if (c >= 1u && p < (uint32_t)rows && j2 < (uint32_t)g.L[0]) {
+        const uint32_t vo = ((p * (uint32_t)args.x0_cols + j2) << 7) + 16u * (uint32_t)kk;
+        xr0[b] = buf_ld4(base, vo);
+        xr1[b] = buf_ld4(base, vo + 64u);
+      }
+    }
+  }
+}
+
+// zero the image columns of stage `st` that hold no data: the separators, the padding behind the last site and the column behind
+// the last block (lanes cooperate: 8 chunks per column)
+__device__ __forceinline__ void wave_zero_gaps(float* img, const TowerGeom& g, int st, int Pw, int lane) {
+  const int Sc = g.Sc[st];
+  const int nz = 1 + Pw + (16 * g.nb[st] - g.NC[st]) + 1;
+  for (int task = lane; task < nz * 8; task += 64) {
+    const int k = task >> 3;
+    const int c = (k <= Pw) ? k * Sc : g.NC[st] + (k - Pw - 1);
+    st4(img + lds_off(c + 1, task & 7), splat(0.f));
+  }
+}
+
+// PHASE 1: first conv stage of ONE tower (entry BN/ReLU image, four ResBlock convs, max-pool 2 + BN -> s3).
+// PHASE 2: the two short stages of ONE tower (conv2, four ResBlock convs, max-pool 3 + BN, conv3), global max, fc; the mid
+//          tower's launch also runs the head.
+// NBA / NBB: 16-column blocks per wave of the launch's main stage / of the last stage (PHASE 2), fixed at compile time for the
+// shipped window length; 0 = read from the geometry at run time (other window lengths).
+// Arrival counters per CU (never reset: the workgroups resident on a CU at any time hold consecutive counts).  The two
+// workgroups of a CU are symmetric and start together, so left alone their waves run in lockstep: both in their conv layers
+// (sharing the MFMA pipe), then both in their entry / pooling phases (pipe idle).  Every second arrival therefore starts
+// `stagger` x 8 k cycles late; from then on one wave's boundary phases fall under its SIMD partner's MFMAs.
+__device__ int g_cu_arrivals[1024];
+
+__device__ __forceinline__ uint32_t cu_key() {
+  // HW_REG_HW_ID (id 4): cu_id [11:8], sh_id [12], se_id [15:13]; HW_REG_XCC_ID (id 20): xcc_id [3:0]
+  const uint32_t hw = __builtin_amdgcn_s_getreg((7 << 11) | (8 << 6) | 4);      // 8 bits from bit 8
+  const uint32_t xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);    // 4 bits from bit 0
+  return ((xcc & 7u) << 7) | (hw & 127u);
+}
+
+// diagnostic: accumulate one wave's cycles per phase into args.stamps[block][id] (only when stamps != nullptr; tools/phase_stamps.py)
+#define SNVW_STAMP(id)                                                               \
+  do {                                                                               \
+    if (args.stamps != nullptr && lane == 0 && wave == 0) {                          \
+      const unsigned long long _t = __builtin_amdgcn_s_memtime();                    \
+      args.stamps[(size_t)blockIdx.x * 32 + (PHASE == 1 ? 0 : 8) + 16 * tw_i + (id)] += _t - t_prev; \
+      t_prev = _t;                                                                   \
+    }                                                                                \
+  } while (0)
+
+template <int PHASE, int NBA, int NBB>
+__global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArgs args) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int Pw = args.P;
+  const int tw_i = args.tw_first;
+  unsigned long long t_prev = args.stamps != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+  const TowerGeom& g = args.geom[tw_i];
+  const TowerDev& tw = args.tw[tw_i];
+  // LDS: par (shared, read-only after the first barrier) | per wave: image [nbuf] | feat [Pw][32] | logit [3][Pw][16]
+  // par: ex_s[4][32] | ex_t[4][32] | fc_w[nc][32] | fc_b[16] | arrival slot[4] | lpar[6 layers][3: bias, post_s, post_t][32]
+  const int lpar0 = 2 * EX_COUNT * SNV_C + args.n_class * SNV_C + SNV_MAXCLASS + 4;
+  const int par_floats = lpar0 + 6 * 3 * SNV_C;
+  float* par = smem;
+  const int wave_floats = args.nbuf + (PHASE == 2 ? Pw * SNV_C + 3 * Pw * SNV_MAXCLASS : 0);
+  float* img = smem + par_floats + wave * wave_floats;
+  float* feat = img + args.nbuf;
+  float* logit = feat + Pw * SNV_C;
+  for (int i = tid; i < EX_COUNT * SNV_C; i += SNV_THREADS) {
+    par[i] = tw.ex_s[i];
+    par[EX_COUNT * SNV_C + i] = tw.ex_t[i];
+  }
+  for (int i = tid; i < args.n_class * SNV_C; i += SNV_THREADS) par[2 * EX_COUNT * SNV_C + i] = tw.fc_w[i];
+  if (tid < args.n_class) par[2 * EX_COUNT * SNV_C + args.n_class * SNV_C + tid] = tw.fc_b[tid];
+  {      // per-layer epilogue constants of the layers this launch runs: read from LDS at every layer start (no VMEM in the loop)
+    const int l0 = PHASE == 1 ? 0 : 4, nl = PHASE == 1 ? 4 : 6;
+    for (int i = tid; i < nl * SNV_C; i += SNV_THREADS) {
+      const int l = i >> 5, c = i & 31;
+      par[lpar0 + (l * 3 + 0) * SNV_C + c] = tw.bias[(l0 + l) * 32 + c];
+      par[lpar0 + (l * 3 + 1) * SNV_C + c] = tw.post_s[(l0 + l) * 32 + c];
+      par[lpar0 + (l * 3 + 2) * SNV_C + c] = tw.post_t[(l0 + l) * 32 + c];
+    }
+  }
+  // the two image columns no epilogue ever writes: column 0 (tap 0 of the first column) and the column behind the widest stage's
+  // last block (tap 2 of its last column) stay zero for the whole launch
+  {
+    const int st0 = PHASE == 1 ? 0 : 1;
+    if (lane < 8) st4(img + lds_off(0, lane), splat(0.f));
+    else if (lane < 16) st4(img + lds_off(16 * g.nb[st0] + 1, lane - 8), splat(0.f));
+  }
+  if (args.stagger > 0 && tid == 0) {
+    const uint32_t key = cu_key();
+    const int cnt = atomicAdd(&g_cu_arrivals[key], 1);
+    par[lpar0 - 1] = __int_as_float(cnt);
+    if (args.stamps != nullptr && PHASE == 1 && tw_i == 0) {      // diagnostic: which CU, which arrival
+      args.stamps[(size_t)blockIdx.x * 32 + 30] = key;
+      args.stamps[(size_t)blockIdx.x * 32 + 31] = (unsigned long long)cnt;
+      args.stamps[(size_t)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    }
+  }
+  __syncthreads();      // the only workgroup barrier of the kernel
+  if (args.stagger > 0 && (__float_as_int(par[lpar0 - 1]) & 1))
+    for (int i = 0; i < args.stagger; ++i) __builtin_amdgcn_s_sleep(127);
+
+  const int64_t n_units = (args.n + Pw - 1) / Pw;
+  const int64_t unit0 = (int64_t)blockIdx.x * SNV_WAVES + wave;
+  const int64_t unit_step = (int64_t)gridDim.x * SNV_WAVES;
+  char* imgb = reinterpret_cast<char*>(img);
+  const int chv0 = 4 * kk, chv1 = 16 + 4 * kk;
+
+  f32x4 xr0[TW_NBW], xr1[TW_NBW];
+  float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
+  const int first_layer = PHASE == 1 ? 0 : 4;
+  const int last_layer = PHASE == 1 ? 3 : SNV_NLAYER - 1;
+  FragSrc fsrc;
+  fsrc.wf = uniform_rsrc(tw.wfrag4);
+  fsrc.lane16 = 16u * (uint32_t)lane;
+  fsrc.layer_bytes = (uint32_t)first_layer * SNV_WFRAG * 4u;
+#pragma unroll
+  for (int g4 = 0; g4 < SNV_KSTEPS / 4; ++g4) load_frag4(a0, a1, fsrc, g4);
+  const WaveAddr sa_a = wave_setup(g, PHASE == 1 ? 0 : 1, Pw, n16, kk);
+  if (PHASE == 1) wave_request_x0(args, xr0, xr1, unit0, n_units, tw_i, n16, kk);
+  const bool do_head = PHASE == 2 && args.tw_last == 1 && args.tw_first == 1;
+
+  for (int64_t unit = unit0; unit < n_units; unit += unit_step) {
+    const int64_t row0 = unit * Pw;
+    // ------------------------------------------------------------------ entry
+    if (PHASE == 1) {
+      const f32x4 es0 = ld4(par + EX_RB1_ENTRY * 32 + chv0), et0 = ld4(par + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv0);
+      const f32x4 es1 = ld4(par + EX_RB1_ENTRY * 32 + chv1), et1 = ld4(par + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv1);
+#pragma unroll
+      for (int b = 0; b < TW_NBW; ++b)
+        if (b < g.nb[0]) {
+          const bool v = (sa_a.vmask >> b) & 1u;
+          lds_st4(imgb, sa_a.wr[0] + TW_BLK * b, v ? relu_bn(xr0[b], es0, et0) : splat(0.f));
+          lds_st4(imgb, sa_a.wr[1] + TW_BLK * b, v ? relu_bn(xr1[b], es1, et1) : splat(0.f));
+        }
+    } else {
+      // second conv stage: its input was pooled (and BN-mapped) by the first-stage launch: s3[row][column][32], the layout of x0
+#pragma unroll
+      for (int b = 0; b < TW_NBW; ++b) {
+        xr0[b] = splat(0.f);
+        xr1[b] = splat(0.f);
+      }
+      const int Lout = g.L[1], ScO = g.Sc[1];
+      const int total = Pw * Lout * 8;
+      const float* src = args.s3[tw_i] + (size_t)row0 * Lout * 32;
+      for (int t0 = 0; t0 < total; t0 += 4 * 64) {      // four 16-byte loads per lane in flight
+        f32x4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int task = t0 + 64 * u + lane;
+          const uint32_t pj = (uint32_t)task >> 3;
+          const uint32_t p = g.dL[1].div(pj);
+          v[u] = (task < total && row0 + p < args.n) ? ld4(src + (size_t)task * 4) : splat(0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int task = t0 + 64 * u + lane;
+          if (task < total) {
+            const uint32_t pj = (uint32_t)task >> 3;
+            const uint32_t p = g.dL[1].div(pj);
+            const int jo = (int)(pj - p * (uint32_t)Lout);
+            st4(img + lds_off(1 + (int)p * ScO + jo + 1, task & 7), v[u]);
+          }
+        }
+      }
+      wave_zero_gaps(img, g, 1, Pw, lane);
+      for (int t = lane; do_head && t < Pw * args.n_class; t += 64) {      // large-tower and local logits of this unit -> LDS
+        const int p = t / args.n_class, k = t - p * args.n_class;
+        const bool in = row0 + p < args.n;
+        logit[p * SNV_MAXCLASS + k] = in ? args.xlogit[(row0 + p) * SNV_MAXCLASS + k] : 0.f;
+        logit[(2 * Pw + p) * SNV_MAXCLASS + k] = (in && args.has_local) ? args.local_logits[(row0 + p) * args.n_class + k] : 0.f;
+      }
+    }
+
+    SNVW_STAMP(1);      // entry: activations landed, image written
+    // ------------------------------------------------------------------ the convs
+    // one layer of the launch's main stage; FINAL = last layer of a first-stage launch (see conv_layer_wave)
+    auto run_layer = [&](int layer, auto final_tag, const WaveAddr& sa, auto nb_tag, int nb) {
+      constexpr bool FINAL = decltype(final_tag)::value;
+      constexpr int NBX = decltype(nb_tag)::value;
+      const LayerK lk = layer_consts(layer_mode(layer));
+      const float* lp = par + lpar0 + (layer - first_layer) * 3 * SNV_C;
+      const f32x4 pb[2] = {ld4(lp + chv0), ld4(lp + chv1)};
+      const f32x4 ps[2] = {ld4(lp + SNV_C + chv0), ld4(lp + SNV_C + chv1)};
+      const f32x4 pt[2] = {ld4(lp + 2 * SNV_C + chv0), ld4(lp + 2 * SNV_C + chv1)};
+      const int ln = layer < last_layer ? layer + 1 : first_layer;      // the last layer fetches the next unit's first layer
+      FragSrc wn = fsrc;
+      wn.layer_bytes = (uint32_t)ln * SNV_WFRAG * 4u;
+      conv_layer_any<NBX, FINAL>(imgb, sa, nb, lk, a0, a1, wn, pb, ps, pt, xr0, xr1);
+    };
+    using TagA = std::integral_constant<int, NBA>;
+    using TagB = std::integral_constant<int, NBB>;
+    if (PHASE == 1) {
+      for (int layer = 0; layer < 3; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[0]);
+      SNVW_STAMP(2);      // convs but the last
+      run_layer(3, std::true_type{}, sa_a, TagA{}, g.nb[0]);
+      // the residual registers are dead: the next unit's stage-1 activations travel under the pooling (and, with the staggered
+      // start of the two workgroups of a CU, under the SIMD partner's conv layers)
+      wave_request_x0(args, xr0, xr1, unit + unit_step, n_units, tw_i, n16, kk);
+      SNVW_STAMP(3);      // last conv
+    } else {
+      for (int layer = 4; layer < 9; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[1]);
+      SNVW_STAMP(2);
+      {
+        // max-pool 3 (raw y in the image) + BN -> the last stage's geometry, in place: every output column lies at or below the
+        // first column of its own window and above the windows of all earlier outputs, and a round's reads precede its writes
+        const int Lin = g.L[1], Lout = g.L[2], ScI = g.Sc[1], ScO = g.Sc[2];
+        const int pk = g.pk[2], pst = g.ps[2], pp = g.pp[2];
+        const int total = Pw * Lout * 8;
+        const int cg = lane & 7;
+        const f32x4 pool_s = ld4(par + EX_BN_OUT * 32 + 4 * cg), pool_t = ld4(par + (EX_COUNT + EX_BN_OUT) * 32 + 4 * cg);
+        for (int task = lane; task < total; task += 64) {
+          const uint32_t pj = (uint32_t)task >> 3;
+          const uint32_t p = g.dL[2].div(pj);
+          const int jo = (int)(pj - p * (uint32_t)Lout);
+          const int jlo = jo * pst - pp;
+          const int lo = jlo < 0 ? 0 : jlo;
+          const int hi = (jlo + pk - 1) < (Lin - 1) ? (jlo + pk - 1) : (Lin - 1);
+          f32x4 m = splat(-INFINITY);
+          for (int w = 0; w < pk; ++w) {
+            int j = jlo + w;
+            j = j < lo ? lo : (j > hi ? hi : j);
+            m = max4(m, ld4(img + lds_off(1 + (int)p * ScI + j + 1, cg)));
+          }
+          m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
+                    fmaf(pool_s.w, m.w, pool_t.w)};
+          st4(img + lds_off(1 + (int)p * ScO + jo + 1, cg), m);
+        }
+        wave_zero_gaps(img, g, 2, Pw, lane);
+      }
+      const WaveAddr sa_b = wave_setup(g, 2, Pw, n16, kk);
+      SNVW_STAMP(3);      // max-pool 3
+      run_layer(9, std::true_type{}, sa_b, TagB{}, g.nb[2]);
+      SNVW_STAMP(4);      // last conv
+    }
+
+    if (PHASE == 1) {
+      // max-pool 2 (raw y in the image) + BN -> s3[row][column][32] for the short-stage launch
+      const int Lin = g.L[0], Lout = g.L[1], ScI = g.Sc[0];
+      const int pk = g.pk[1], pst = g.ps[1], pp = g.pp[1];
+      const int total = Pw * Lout * 8;
+      const int cg = lane & 7;
+      const f32x4 pool_s = ld4(par + EX_BN_MID * 32 + 4 * cg), pool_t = ld4(par + (EX_COUNT + EX_BN_MID) * 32 + 4 * cg);
+      for (int task = lane; task < total; task += 64) {
+        const uint32_t pj = (uint32_t)task >> 3;
+        const uint32_t p = g.dL[1].div(pj);
+        const int jo = (int)(pj - p * (uint32_t)Lout);
+        const int jlo = jo * pst - pp;
+        const int lo = jlo < 0 ? 0 : jlo;
+        const int hi = (jlo + pk - 1) < (Lin - 1) ? (jlo + pk - 1) : (Lin - 1);
+        f32x4 v[7];
+#pragma unroll
+        for (int w = 0; w < 7; ++w) {      // the model's pools are 7- and 3-wide: all reads in flight together
+          int j = jlo + w;
+          j = j < lo ? lo : (j > hi ? hi : j);
+          v[w] = ld4(img + lds_off(1 + (int)p * ScI + j + 1, cg));
+        }
+        f32x4 m = max4(max4(max4(v[0], v[1]), max4(v[2], v[3])), max4(max4(v[4], v[5]), v[6]));
+        for (int w = 7; w < pk; ++w) {
+          const int j = jlo + w;
+          if (j < 0 || j >= Lin) continue;
+          m = max4(m, ld4(img + lds_off(1 + (int)p * ScI + j + 1, cg)));
+        }
+        m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
+                  fmaf(pool_s.w, m.w, pool_t.w)};
+        if (row0 + p < args.n) st4(args.s3[tw_i] + ((size_t)(row0 + p) * Lout + jo) * 32 + 4 * cg, m);
+      }
+      SNVW_STAMP(4);      // max-pool 2 + store
+      continue;
+    }
+
+    // ------------------------------------------------------------------ global max per (site, channel), fc, head
+    {
+      const int L4 = g.L[2], Sc4 = g.Sc[2];
+      for (int t = lane; t < Pw * SNV_C; t += 64) {
+        const int p = t >> 5, ch = t & 31;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {      // L4 is 7 / 8 at R = 1000; short rows repeat their last column
+          const int pc = 1 + p * Sc4 + (j < L4 ? j : L4 - 1) + 1;
+          v[j] = img[lds_off(pc, ch >> 2) + (ch & 3)];
+        }
+        float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+        for (int j = 8; j < L4; ++j) m = fmaxf(m, img[lds_off(1 + p * Sc4 + j + 1, ch >> 2) + (ch & 3)]);
+        feat[t] = m;
+      }
+      const int slot = do_head ? 1 : 0;      // logit[0]: large tower, [1]: mid, [2]: local
+      for (int t = lane; t < Pw * args.n_class; t += 64) {
+        const int p = t / args.n_class, k = t - p * args.n_class;
+        const float* w = par + 2 * EX_COUNT * SNV_C + k * SNV_C;
+        const float* f = feat + p * SNV_C;
+        float acc = par[2 * EX_COUNT * SNV_C + args.n_class * SNV_C + k];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          const f32x4 wv = ld4(w + 4 * q), fv = ld4(f + 4 * q);
+          acc = fmaf(wv.x, fv.x, acc);
+          acc = fmaf(wv.y, fv.y, acc);
+          acc = fmaf(wv.z, fv.z, acc);
+          acc = fmaf(wv.w, fv.w, acc);
+        }
+        if (!do_head) {      // large tower: hand the logits to the launch that runs the mid tower and the head
+          if (row0 + p < args.n) args.xlogit[(row0 + p) * SNV_MAXCLASS + k] = acc;
+        } else {
+          logit[(slot * Pw + p) * SNV_MAXCLASS + k] = acc;
+        }
+      }
+      if (!do_head) continue;
+      // head (model_snv.py:515-523 / :284)
+      for (int t = lane; t < Pw * args.n_class; t += 64) {
+        const int nc = args.n_class;
+        const int p = t / nc, k = t - p * nc;
+        float pr[3];
+#pragma unroll 1
+        for (int v = 0; v < 3; ++v) {
+          float lg[SNV_MAXCLASS];
+#pragma unroll
+          for (int q = 0; q < SNV_MAXCLASS; ++q) lg[q] = logit[(v * Pw + p) * SNV_MAXCLASS + (q < nc ? q : 0)];
+          float mx = -INFINITY, own = 0.f;
+#pragma unroll
+          for (int q = 0; q < SNV_MAXCLASS; ++q)
+            if (q < nc) mx = fmaxf(mx, lg[q]);
+          float sum = 0.f;
+#pragma unroll
+          for (int q = 0; q < SNV_MAXCLASS; ++q)
+            if (q < nc) {
+              const float e = __expf(lg[q] - mx);
+              sum += e;
+              own = (q == k) ? e : own;
+            }
+          pr[v] = own / sum;
+        }
+        float prob = (pr[1] + pr[0]) / 2.f;
+        if (args.has_local) prob = (pr[2] + prob) / 2.f;
+        float res = __logf(fmaxf(prob, 1e-9f));
+        if (args.status != nullptr && *args.status != 0) res = __uint_as_float(0x7FC00000u);   // flagged encoding error: loud output
+        if (row0 + p < args.n) args.out[(row0 + p) * nc + k] = res;
+      }
+    }
+    SNVW_STAMP(5);      // global max, fc, head
+  }
+}
+
+// per-wave geometry: Pw sites per wave; returns the LDS bytes of a four-wave workgroup (0: does not fit a wave)
+size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int tower, int phase) {
+  static const int pools[2][3][3] = {{{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}, {{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}};
+  int maxcols = 0;
+  for (int tw = 0; tw < 2; ++tw) {
+    TowerGeom& g = a.geom[tw];
+    g.L1 = tw == 0 ? Lwin : 2 * SNV_MID_HALF + 1;
+    g.col0 = tw == 0 ? 0 : Lwin / 2 - SNV_MID_HALF;
+    int L = g.L1;
+    for (int i = 0; i < 3; ++i) {
+      g.pk[i] = pools[tw][i][0];
+      g.ps[i] = pools[tw][i][1];
+      g.pp[i] = pools[tw][i][2];
+      L = (L + 2 * g.pp[i] - g.pk[i]) / g.ps[i] + 1;
+      if (L < 1) return 0;
+      g.L[i] = L;
+      g.Sc[i] = L + 1;
+      g.NC[i] = 1 + Pw * g.Sc[i];
+      g.nb[i] = (g.NC[i] + 15) / 16;
+      g.dL[i] = FastDiv::make((uint32_t)L);
+      g.dSc[i] = FastDiv::make((uint32_t)g.Sc[i]);
+      if (tw != tower) continue;
+      if ((phase == 1 && i != 0) || (phase == 2 && i == 0)) continue;
+      if (g.nb[i] > TW_NBW) return 0;
+      maxcols = std::max(maxcols, 16 * g.nb[i] + 2);
+    }
+  }
+  if (Pw > 31) return 0;      // the x0 plan keeps the site index in five bits
+  a.P = Pw;
+  a.Lwin = Lwin;
+  a.tw_first = tower;
+  a.tw_last = tower;
+  a.phase = phase;
+  a.wave = 1;
+  a.stagger = 4;
+  if (const char* e = getenv("MURAL_DEBUG_TOWER_STAGGER")) a.stagger = atoi(e);
+  a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
+  a.nbuf = maxcols * SNV_C;
+  const size_t par = (size_t)(2 * EX_COUNT * SNV_C + n_class * SNV_C + SNV_MAXCLASS + 4 + 6 * 3 * SNV_C);
+  const size_t per_wave = (size_t)a.nbuf + (phase == 2 ? (size_t)Pw * SNV_C + 3 * (size_t)Pw * SNV_MAXCLASS : 0);
+  return (par + SNV_WAVES * per_wave) * 4;
+}
+
+int launch_snv_tower_wave(const SnvFwdArgs& a, size_t lds_bytes, hipStream_t stream) {
+  const int64_t n_units = (a.n + a.P - 1) / a.P;
+  const int64_t n_wg = (n_units + SNV_WAVES - 1) / SNV_WAVES;
+  if (n_wg == 0) return MURAL_OK;
+  // two workgroups per CU are resident: with more work than that every wave walks its units in a grid-stride loop, so the
+  // prologue (parameter staging, first fragments, first activations with their full latency) is paid once per wave
+  int resident = 512;
+  if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) resident = std::max(1, atoi(e));
+  const int grid = (int)(n_wg < resident ? n_wg : resident);
+  if (const char* e = getenv("MURAL_DEBUG_TOWER_LDS")) {      // diagnostic: inflate the LDS request (one workgroup per CU: occupancy study)
+    const size_t v = (size_t)atol(e);
+    if (v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
+  }
+  static DynLdsOnce big_lds;
+  if (int rc = big_lds.ensure(&snv_tower_wave<1, 9, 0>, &snv_tower_wave<2, 8, 4>, &snv_tower_wave<2, 8, 3>, &snv_tower_wave<1, 0, 0>,
+                              &snv_tower_wave<2, 0, 0>)) return rc;
+  const TowerGeom& g = a.geom[a.tw_first];
+  const dim3 gr(grid), bl(SNV_THREADS);
+  if (a.phase == 1) {
+    if (g.nb[0] == 9) hipLaunchKernelGGL((snv_tower_wave<1, 9, 0>), gr, bl, lds_bytes, stream, a);
+    else hipLaunchKernelGGL((snv_tower_wave<1, 0, 0>), gr, bl, lds_bytes, stream, a);
+  } else {
+    if (g.nb[1] == 8 && g.nb[2] == 4) hipLaunchKernelGGL((snv_tower_wave<2, 8, 4>), gr, bl, lds_bytes, stream, a);
+    else if (g.nb[1] == 8 && g.nb[2] == 3) hipLaunchKernelGGL((snv_tower_wave<2, 8, 3>), gr, bl, lds_bytes, stream, a);
+    else hipLaunchKernelGGL((snv_tower_wave<2, 0, 0>), gr, bl, lds_bytes, stream, a);
+  }
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural

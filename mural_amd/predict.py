@@ -50,18 +50,41 @@ def all_gather_rows(local, n_total, group=None):
     return out
 
 
-def predict_sites(forward_fn, pos, strand, group=None):
+def predict_sites(forward_fn, pos, strand, group=None, steps=1):
     """Run `forward_fn(pos_block, strand_block) -> (rows, n_class)` on this rank's block of sites and return the
     full (N, n_class) result in input order on every rank.  `pos` / `strand` hold ALL sites on every rank (they are
-    8 + 1 bytes per site; the genome and the weights are replicated)."""
+    8 + 1 bytes per site; the genome and the weights are replicated).  The block is evaluated in `steps` slices (bounded
+    workspace; the benchmark's timed steps) and ends with ONE all_gather of the whole block."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
     n = pos.shape[0]
     lo, hi = shard_bounds(n, rank, world)
-    local = forward_fn(pos[lo:hi], strand[lo:hi])
+    parts = []
+    for k in range(max(int(steps), 1)):
+        a, b = shard_bounds(hi - lo, k, max(int(steps), 1))
+        parts.append(forward_fn(pos[lo + a:lo + b], strand[lo + a:lo + b]))
+    local = parts[0] if len(parts) == 1 else torch.cat(parts)
     if local.shape[0] != hi - lo:
         raise RuntimeError("forward_fn returned a wrong number of rows")
     return all_gather_rows(local, n, group)
+
+
+def verify_gathered_rows(forward_fn, pos, strand, full, sample=4096, seed=0):
+    """Recompute a random sample of rows of a gathered result on THIS rank alone and compare: (largest absolute difference,
+    rows checked, ranks whose blocks the sample touched).  The sample is drawn over all rows, i.e. over every rank's block, so a
+    collective that scrambles, drops or pads blocks shows up here; per-site results do not depend on batch composition, so the
+    expected difference is exactly 0."""
+    world = dist.get_world_size() if dist.is_initialized() else 1
+    n = pos.shape[0]
+    if n == 0:
+        return 0.0, 0, 0
+    g = torch.Generator().manual_seed(seed)
+    idx = torch.randperm(n, generator=g)[:min(sample, n)].sort().values
+    dev_idx = idx.to(pos.device)
+    mine = forward_fn(pos[dev_idx], strand[dev_idx])
+    diff = float((mine.double() - full[dev_idx].double()).abs().max())
+    owners = {r for r in range(world) if ((idx >= shard_bounds(n, r, world)[0]) & (idx < shard_bounds(n, r, world)[1])).any()}
+    return diff, int(idx.numel()), len(owners)
 
 
 class ShardedPredictor:

@@ -32,6 +32,17 @@ def _worker(rank, world, port, n, q):
         want = fake_forward(pos, strand)
         lo, hi = shard_bounds(n, rank, world)
         ok = torch.equal(out, want) and calls[0] == hi - lo
+        # the strong-scaling shape of bench.py: the block in several timed slices, ONE gather at the end, then the sample check
+        from mural_amd.predict import verify_gathered_rows
+        calls.clear()
+        out3 = predict_sites(fake_forward, pos, strand, steps=3)
+        ok = ok and torch.equal(out3, want) and sum(calls) == hi - lo and len(calls) == 3
+        diff, rows, owners = verify_gathered_rows(fake_forward, pos, strand, out3, sample=64)
+        ok = ok and diff == 0.0 and rows == min(64, n) and (owners == world or n < 8)
+        if n > 4:                                    # a gather that swapped two blocks must not pass the check
+            bad = out3.clone()
+            bad[0], bad[n - 1] = out3[n - 1], out3[0]
+            ok = ok and verify_gathered_rows(fake_forward, pos, strand, bad, sample=n)[0] > 0
         q.put((rank, bool(ok), tuple(out.shape)))
     finally:
         dist.destroy_process_group()

@@ -23,23 +23,28 @@ for f in find("trace/**/*kernel_trace.csv"):
     with open(f) as fh:
         rows = list(csv.DictReader(fh))
     for r in rows:
-        if "snv_towers" in r.get("Kernel_Name", ""):
+        if "snv_tower" in r.get("Kernel_Name", ""):
             print("  dispatch: vgpr=%s accum_vgpr=%s sgpr=%s lds=%s scratch=%s wg=%s grid=%s" % (
                 r.get("VGPR_Count"), r.get("Accum_VGPR_Count"), r.get("SGPR_Count"), r.get("LDS_Block_Size"),
                 r.get("Scratch_Size"), r.get("Workgroup_Size"), r.get("Grid_Size")))
             break
-print("== PMC (per dispatch of snv_towers_fused, averaged) ==")
+print("== PMC (per dispatch of the tower kernel, averaged; then per template instance) ==")
 for tag in ("pmcA", "pmcB", "pmcF", "pmcW"):
     for f in find(tag + "/**/*counter_collection.csv"):
         acc, cnt = defaultdict(float), defaultdict(int)
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                if "snv_towers" not in r.get("Kernel_Name", ""):
+                if "snv_tower" not in r.get("Kernel_Name", ""):
                     continue
                 acc[r["Counter_Name"]] += float(r["Counter_Value"])
                 cnt[r["Counter_Name"]] += 1
-        for k in sorted(acc):
+                short = r["Kernel_Name"].split("(")[0].replace("void mural::", "")
+                acc[(short, r["Counter_Name"])] += float(r["Counter_Value"])
+                cnt[(short, r["Counter_Name"])] += 1
+        for k in sorted(k for k in acc if isinstance(k, str)):
             print("  %-28s %.6g  (n=%d)" % (k, acc[k] / max(cnt[k], 1), cnt[k]))
+        for k in sorted(k for k in acc if isinstance(k, tuple)):
+            print("    %-26s %-28s %.6g  (n=%d)" % (k[0], k[1], acc[k] / max(cnt[k], 1), cnt[k]))
 
 # machine-readable HBM traffic of the dominant kernel for bench.py's roofline.traffic
 import json
@@ -49,7 +54,7 @@ for tag in ("pmcF", "pmcW"):
         acc, cnt = defaultdict(float), defaultdict(int)
         with open(f) as fh:
             for r in csv.DictReader(fh):
-                if "snv_towers" in r.get("Kernel_Name", ""):
+                if "snv_tower" in r.get("Kernel_Name", ""):
                     acc[r["Counter_Name"]] += float(r["Counter_Value"]); cnt[r["Counter_Name"]] += 1
         for k in acc:
             vals[k] = acc[k] / max(cnt[k], 1)
@@ -60,7 +65,7 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     # FETCH_SIZE / WRITE_SIZE are in KiB; gfx950 FETCH_SIZE reads 1/2 of a wide coalesced stream (MI355X_MICROARCH.md)
     per_site = (2.0 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024.0 / sites
     with open(os.path.join(root, "hbm_traffic.json"), "w") as fh:
-        json.dump({"kernel": "snv_towers_fused", "fetch_size_kib_per_launch": vals["FETCH_SIZE"],
+        json.dump({"kernel": "snv_tower_wave", "fetch_size_kib_per_launch": vals["FETCH_SIZE"],
                    "write_size_kib_per_launch": vals["WRITE_SIZE"], "sites_per_launch": sites,
                    "launches_per_chunk": 4,
                    "hbm_bytes_per_site": per_site,
