@@ -138,14 +138,34 @@ __device__ __forceinline__ void mfma_tap_epi(const float (&a0)[SNV_KSTEPS], cons
 #undef MURAL_TAP_PAIR
 }
 
+// Request of the NEXT unit's stage-1 activations (first-stage launches): wave-uniform descriptor of that unit's first row and the
+// scalars of the lane-offset formula.  on == false: nothing is requested inside the layer.
+struct XReq {
+  __amdgpu_buffer_rsrc_t base;
+  FastDiv dSc;
+  uint32_t Sc, L, rows, x0_cols, lane_col, kk16;
+  bool on;
+};
+// byte offset of this lane's 16 bytes of block b (M-block 0; M-block 1 sits 64 bytes further); lanes whose column holds no
+// data read the unit's first column (their values never reach a data column)
+__device__ __forceinline__ uint32_t xreq_offset(const XReq& x, int b) {
+  const uint32_t c = 16u * b + x.lane_col;
+  const uint32_t u = c - 1u;
+  const uint32_t p = x.dSc.div(u);
+  const uint32_t j2 = u - p * x.Sc;
+  const bool ok = c >= 1u && p < x.rows && j2 < x.L;
+  return (ok ? ((p * x.x0_cols + j2) << 7) : 0u) + x.kk16;
+}
+
 // One 32->32 k=3 conv layer of this wave, in place on `img`, NB blocks wide (compile time: straight-line code, no copies at block
 // boundaries).  wn: fragments of the layer that follows (wfrag4 layout + 4 * lane), requested into a0 / a1 tap group by tap group
 // behind the last block's MFMAs of that group.  FINAL: last layer of a launch -- the residual registers die with each block's
-// accumulator start and are not updated.
-template <int NB, bool FINAL>
+// accumulator start and are not updated; with xq.on block b's registers at once receive the next unit's stage-1 activations,
+// which then travel under the rest of the layer and the pooling instead of stalling the next entry.
+template <int NB, bool FINAL, bool USEX = true>
 __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, const LayerK& k, float (&a0)[SNV_KSTEPS],
                                                 float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
-                                                const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW]) {
+                                                const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
   static_assert(NB >= 1 && NB <= TW_NBW, "blocks per wave");
   f32x4 X[2], Y[2], Z[2];
 #pragma unroll
@@ -161,8 +181,16 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
     const bool last = b == NB - 1;
     const int bp = b > 0 ? b - 1 : 0;
     const bool vprev = (sa.vmask >> bp) & 1u;
-    f32x4 acc0 = acc_init(k, pb[0], xr0[b]), acc1 = acc_init(k, pb[1], xr1[b]);
+    // USEX == false: a layer whose accumulators start from the bias alone (kr == 0) must not touch the residual registers --
+    // in the short-stage launches they already hold the next unit's input tile
+    f32x4 acc0 = USEX ? acc_init(k, pb[0], xr0[b]) : pb[0], acc1 = USEX ? acc_init(k, pb[1], xr1[b]) : pb[1];
     __builtin_amdgcn_sched_barrier(0);
+    if (FINAL && xq.on) {
+      const uint32_t vo = xreq_offset(xq, b);
+      xr0[b] = buf_ld4(xq.base, vo);
+      xr1[b] = buf_ld4(xq.base, vo + 64u);
+      __builtin_amdgcn_sched_barrier(0);
+    }
     mfma_tap_epi<0, false, FINAL>(a0, a1, X, acc0, acc1, k, pa0, xr0[bp], o0, vprev, ps[0], pt[0], img, 0u);
     // tap-0 operands of the next block: read BEFORE this block's epilogue overwrites image column 16(b+1) (in-place rule)
     if (!last) {
@@ -207,29 +235,29 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
 }
 
 // the same layer for a block count known only at run time (window lengths without a specialised instantiation)
-template <bool FINAL>
+template <bool FINAL, bool USEX>
 __device__ __forceinline__ void conv_layer_wave_rt(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
                                                    float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
-                                                   const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW]) {
+                                                   const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
   switch (nb) {
-    case 1: conv_layer_wave<1, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    case 2: conv_layer_wave<2, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    case 3: conv_layer_wave<3, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    case 4: conv_layer_wave<4, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    case 5: conv_layer_wave<5, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    case 6: conv_layer_wave<6, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    case 7: conv_layer_wave<7, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    case 8: conv_layer_wave<8, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
-    default: conv_layer_wave<9, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1); break;
+    case 1: conv_layer_wave<1, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 2: conv_layer_wave<2, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 3: conv_layer_wave<3, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 4: conv_layer_wave<4, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 5: conv_layer_wave<5, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 6: conv_layer_wave<6, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 7: conv_layer_wave<7, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 8: conv_layer_wave<8, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    default: conv_layer_wave<9, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
   }
 }
 
-template <int NB, bool FINAL>
+template <int NB, bool FINAL, bool USEX>
 __device__ __forceinline__ void conv_layer_any(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
                                                float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
-                                               const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW]) {
-  if constexpr (NB > 0) conv_layer_wave<NB, FINAL>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1);
-  else conv_layer_wave_rt<FINAL>(img, sa, nb, k, a0, a1, wn, pb, ps, pt, xr0, xr1);
+                                               const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
+  if constexpr (NB > 0) conv_layer_wave<NB, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
+  else conv_layer_wave_rt<FINAL, USEX>(img, sa, nb, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
 }
 
 // Stage-1 activations of unit `unit` straight into the residual registers, in MFMA accumulator layout (lane = column n16 of each
@@ -401,6 +429,17 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
   const WaveAddr sa_a = wave_setup(g, PHASE == 1 ? 0 : 1, Pw, n16, kk);
   if (PHASE == 1) wave_request_x0(args, xr0, xr1, unit0, n_units, tw_i, n16, kk);
   const bool do_head = PHASE == 2 && args.tw_last == 1 && args.tw_first == 1;
+  bool tile_ready = false;      // PHASE 2: the residual registers hold this unit's input tile (requested during the previous unit)
+  XReq xoff;
+  xoff.base = uniform_rsrc(args.x0);
+  xoff.dSc = g.dSc[0];
+  xoff.Sc = (uint32_t)g.Sc[0];
+  xoff.L = (uint32_t)g.L[0];
+  xoff.rows = (uint32_t)Pw;
+  xoff.x0_cols = (uint32_t)args.x0_cols;
+  xoff.lane_col = (uint32_t)n16;
+  xoff.kk16 = 16u * (uint32_t)kk;
+  xoff.on = false;
 
   for (int64_t unit = unit0; unit < n_units; unit += unit_step) {
     const int64_t row0 = unit * Pw;
@@ -416,33 +455,28 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
           lds_st4(imgb, sa_a.wr[1] + TW_BLK * b, v ? relu_bn(xr1[b], es1, et1) : splat(0.f));
         }
     } else {
-      // second conv stage: its input was pooled (and BN-mapped) by the first-stage launch: s3[row][column][32], the layout of x0
-#pragma unroll
-      for (int b = 0; b < TW_NBW; ++b) {
-        xr0[b] = splat(0.f);
-        xr1[b] = splat(0.f);
-      }
+      // second conv stage: its input was pooled (and BN-mapped) by the first-stage launch: s3[row][column][32], the layout of x0.
+      // Task t = (site, column, 16-byte chunk) in memory order; lane l takes tasks l, l + 64, ...: coalesced 1 KB per load.
       const int Lout = g.L[1], ScO = g.Sc[1];
       const int total = Pw * Lout * 8;
-      const float* src = args.s3[tw_i] + (size_t)row0 * Lout * 32;
-      for (int t0 = 0; t0 < total; t0 += 4 * 64) {      // four 16-byte loads per lane in flight
-        f32x4 v[4];
+      if (!tile_ready) {      // first unit of the wave, or a ragged unit: guarded loads
+        const float* src = args.s3[tw_i] + (size_t)row0 * Lout * 32;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int task = t0 + 64 * u + lane;
+        for (int u = 0; u < 2 * TW_NBW; ++u) {
+          const int task = 64 * u + lane;
+          const uint32_t p = g.dL[1].div((uint32_t)task >> 3);
+          const f32x4 v = (task < total && row0 + p < args.n) ? ld4(src + (size_t)task * 4) : splat(0.f);
+          if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2 * TW_NBW; ++u) {
+        const int task = 64 * u + lane;
+        if (task < total) {
           const uint32_t pj = (uint32_t)task >> 3;
           const uint32_t p = g.dL[1].div(pj);
-          v[u] = (task < total && row0 + p < args.n) ? ld4(src + (size_t)task * 4) : splat(0.f);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const int task = t0 + 64 * u + lane;
-          if (task < total) {
-            const uint32_t pj = (uint32_t)task >> 3;
-            const uint32_t p = g.dL[1].div(pj);
-            const int jo = (int)(pj - p * (uint32_t)Lout);
-            st4(img + lds_off(1 + (int)p * ScO + jo + 1, task & 7), v[u]);
-          }
+          const int jo = (int)(pj - p * (uint32_t)Lout);
+          st4(img + lds_off(1 + (int)p * ScO + jo + 1, task & 7), u < TW_NBW ? xr0[u] : xr1[u - TW_NBW]);
         }
       }
       wave_zero_gaps(img, g, 1, Pw, lane);
@@ -457,9 +491,10 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
     SNVW_STAMP(1);      // entry: activations landed, image written
     // ------------------------------------------------------------------ the convs
     // one layer of the launch's main stage; FINAL = last layer of a first-stage launch (see conv_layer_wave)
-    auto run_layer = [&](int layer, auto final_tag, const WaveAddr& sa, auto nb_tag, int nb) {
+    auto run_layer = [&](int layer, auto final_tag, const WaveAddr& sa, auto nb_tag, int nb, const XReq& xq) {
       constexpr bool FINAL = decltype(final_tag)::value;
       constexpr int NBX = decltype(nb_tag)::value;
+      constexpr bool USEX = !(PHASE == 2 && FINAL);      // conv3 starts from its bias (MODE_FINAL: kr == 0)
       const LayerK lk = layer_consts(layer_mode(layer));
       const float* lp = par + lpar0 + (layer - first_layer) * 3 * SNV_C;
       const f32x4 pb[2] = {ld4(lp + chv0), ld4(lp + chv1)};
@@ -468,21 +503,49 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       const int ln = layer < last_layer ? layer + 1 : first_layer;      // the last layer fetches the next unit's first layer
       FragSrc wn = fsrc;
       wn.layer_bytes = (uint32_t)ln * SNV_WFRAG * 4u;
-      conv_layer_any<NBX, FINAL>(imgb, sa, nb, lk, a0, a1, wn, pb, ps, pt, xr0, xr1);
+      conv_layer_any<NBX, FINAL, USEX>(imgb, sa, nb, lk, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
     };
     using TagA = std::integral_constant<int, NBA>;
     using TagB = std::integral_constant<int, NBB>;
     if (PHASE == 1) {
-      for (int layer = 0; layer < 3; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[0]);
+      for (int layer = 0; layer < 3; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[0], xoff);
       SNVW_STAMP(2);      // convs but the last
-      run_layer(3, std::true_type{}, sa_a, TagA{}, g.nb[0]);
-      // the residual registers are dead: the next unit's stage-1 activations travel under the pooling (and, with the staggered
-      // start of the two workgroups of a CU, under the SIMD partner's conv layers)
-      wave_request_x0(args, xr0, xr1, unit + unit_step, n_units, tw_i, n16, kk);
+      // last layer: block by block the dying residual registers take the next unit's stage-1 activations (a whole next unit;
+      // a ragged or missing one is requested the guarded way behind the layer)
+      const int64_t nu = unit + unit_step;
+      XReq xq = xoff;
+      xq.on = nu < n_units && (nu + 1) * Pw <= args.n;
+      if (xq.on) {
+        const int x0c = tw_i == 0 ? 0 : args.geom[0].L[0];
+        xq.base = uniform_rsrc(args.x0 + ((size_t)nu * Pw * args.x0_cols + x0c) * 32);
+        uint32_t lc = (uint32_t)n16;
+        asm volatile("" : "+v"(lc));      // opaque: the lane offsets are worked out block by block, not kept for the launch
+        xq.lane_col = lc;
+      }
+      run_layer(3, std::true_type{}, sa_a, TagA{}, g.nb[0], xq);
+      if (!xq.on) wave_request_x0(args, xr0, xr1, nu, n_units, tw_i, n16, kk);
       SNVW_STAMP(3);      // last conv
     } else {
-      for (int layer = 4; layer < 9; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[1]);
+      for (int layer = 4; layer < 9; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[1], xoff);
       SNVW_STAMP(2);
+      {
+        // the residual registers are dead from here on: the next unit's input tile travels in them under the pooling, the last
+        // conv, the global max and the head (a whole next unit; a ragged one is loaded the guarded way at its entry)
+        const int64_t nu = unit + unit_step;
+        tile_ready = nu < n_units && (nu + 1) * Pw <= args.n;
+        if (tile_ready) {
+          const int total = Pw * g.L[1] * 8;
+          const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(args.s3[tw_i] + (size_t)nu * Pw * g.L[1] * 32);
+#pragma unroll
+          for (int u = 0; u < 2 * TW_NBW; ++u) {
+            if (64 * u < total) {      // wave-uniform; lanes behind the last task of the last round read the tile's first bytes
+              const int task = 64 * u + lane;
+              const f32x4 v = buf_ld4(rs, task < total ? 16u * (uint32_t)task : 0u);
+              if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
+            }
+          }
+        }
+      }
       {
         // max-pool 3 (raw y in the image) + BN -> the last stage's geometry, in place: every output column lies at or below the
         // first column of its own window and above the windows of all earlier outputs, and a round's reads precede its writes
@@ -512,7 +575,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       }
       const WaveAddr sa_b = wave_setup(g, 2, Pw, n16, kk);
       SNVW_STAMP(3);      // max-pool 3
-      run_layer(9, std::true_type{}, sa_b, TagB{}, g.nb[2]);
+      run_layer(9, std::true_type{}, sa_b, TagB{}, g.nb[2], xoff);
       SNVW_STAMP(4);      // last conv
     }
 
@@ -656,7 +719,7 @@ size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int towe
   a.tw_last = tower;
   a.phase = phase;
   a.wave = 1;
-  a.stagger = 4;
+  a.stagger = 0;      // measured: no effect (the waves of a CU do not run in lockstep); kept as a diagnostic
   if (const char* e = getenv("MURAL_DEBUG_TOWER_STAGGER")) a.stagger = atoi(e);
   a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
   a.nbuf = maxcols * SNV_C;

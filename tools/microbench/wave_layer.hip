@@ -37,7 +37,9 @@ __global__ __launch_bounds__(256, 2) void klayer(const float* wfrag, float* out,
     fs.wf = uniform_rsrc(wfrag);
     fs.lane16 = 16u * lane;
     fs.layer_bytes = MODE == 0 ? 0u : ~0u;
-    conv_layer_wave<NB, false>(reinterpret_cast<char*>(img), sa, lk, a0, a1, fs, pb, ps, pt, xr0, xr1);
+    XReq xq;
+    xq.on = false;
+    conv_layer_wave<NB, false>(reinterpret_cast<char*>(img), sa, lk, a0, a1, fs, pb, ps, pt, xr0, xr1, xq);
   }
   float s = 0.f;
   for (int b = 0; b < NB; ++b) s += xr0[b].x + xr1[b].y;
