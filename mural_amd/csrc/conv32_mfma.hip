@@ -837,9 +837,13 @@ int train_reduce_parts(const float* const* part, const int* nrow, float* const* 
     PartJobs jobs;
     std::memset(&jobs, 0, sizeof(jobs));
     const int n = njobs - j0 < PR_MAXJOBS ? njobs - j0 : PR_MAXJOBS;
+    // validation only (tests/test_gpu_train.py): MURAL_DEBUG_DROP_PART_ROW=<job> leaves the last partial row of that job out of
+    // its sum -- the fault the parity tests of the training step must be able to see
+    int drop_job = -1;
+    if (const char* e = getenv("MURAL_DEBUG_DROP_PART_ROW")) drop_job = atoi(e);
     for (int j = 0; j < n; ++j) {
       jobs.part[j] = part[j0 + j];
-      jobs.nrow[j] = nrow[j0 + j];
+      jobs.nrow[j] = nrow[j0 + j] - ((j0 + j == drop_job && nrow[j0 + j] > 1) ? 1 : 0);
       jobs.dW[j] = dW[j0 + j];
       jobs.db[j] = db[j0 + j];
     }

@@ -434,3 +434,36 @@ def test_generic_conv1d_kernels_match_torch_fp64():
     out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
     assert "worst" in out.stdout
+
+
+@pytest.mark.parametrize("L", [16000, 64000])
+def test_long_windows_match_oracle(L):
+    """The reference advertises INDEL inputs of up to 64 kb (CHANGELOG:13): the human-insertion geometry at L = 16000 and 64000
+    (synthetic weights, use_reverse) through the dense and the packed entry against the oracle."""
+    from mural_amd.data import PackedGenome
+    from mural_amd.model import model_choice
+    from oracle import encode_ref, indel_ref, synth
+    down = [1, 4, 5, 5, 5, 2]
+    orc = indel_ref.build(n_class=8, channels=8, ksize=7, down_list=down, use_reverse=True)
+    sd = synth.synth_state_dict(orc.state_dict(), 640 + L // 1000)
+    orc.load_state_dict(sd)
+    orc.eval()
+    model = model_choice(0, dict(CNN_out_channels=8, CNN_kernel_size=7, down_list=down, use_reverse=True), dict(n_class=8), "indel")
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    rng = np.random.default_rng(L)
+    n = 3 * L
+    seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=n, p=[.248, .248, .248, .248, .008]).tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = np.array([0, L // 3, n // 2, n - 1, n - L // 2])
+    strand = np.array([0, 1, 0, 1, 1], np.uint8)
+    sym = ["-" if v else "+" for v in strand]
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, L // 2, "indel"))
+    assert x.shape == (5, 4, L)
+    with torch.no_grad():
+        want = orc(x).numpy()
+        dense = model(x.cuda()).cpu().numpy()
+        genome = PackedGenome.from_sequence(seq, "cuda")
+        packed = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), L // 2).cpu().numpy()
+    tol = 1e-4 * max(1.0, np.abs(want).max())
+    assert np.abs(dense - want).max() <= tol and np.abs(packed - want).max() <= tol

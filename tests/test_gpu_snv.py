@@ -597,3 +597,39 @@ def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch
             off, size = layout[2 * i], layout[2 * i + 1]
             zone = ws[off + size:off + size + guard]
             assert len(zone) == guard and (zone == 255).all(), f"region {i} (dense={dense}): a kernel wrote behind its {size} bytes"
+
+
+@pytest.mark.parametrize("R,model_no", [(2000, 2), (4000, 2), (4000, 1)])
+def test_long_windows_match_oracle(R, model_no):
+    """Windows beyond the shipped radius (the reference advertises inputs of up to 64 kb, CHANGELOG:13): R = 2000 and R = 4000 are
+    beyond the LDS-resident kernels and take the per-layer HIP path (model/generic_eval.py).  Packed and
+    dense entry against the oracle fed by the oracle encoders, both strands, chromosome ends."""
+    from mural_amd.data import PackedGenome
+    r = 7
+    rng = np.random.default_rng(R + model_no)
+    n = 40_000
+    raw = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=n, p=[.248, .248, .248, .248, .008])
+    seq = raw.tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = rng.integers(0, n, size=24)
+    pos[:4] = [0, 5, n - 1, n // 2]
+    strand = rng.integers(0, 2, size=len(pos)).astype(np.uint8)
+    sym = ["-" if s else "+" for s in strand]
+    orc = snv_ref.build(model_no, local_radius=r, distal_radius=R)
+    sd = synth.synth_state_dict(orc.state_dict(), 5 + R)
+    orc.load_state_dict(sd)
+    orc.eval()
+    model, _ = product_from_hp(np.array([r, 3, R, 150, 75, 32, 3, 4, model_no]))
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    cat = torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, r, 3))
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R))
+    with torch.no_grad():
+        want = orc((torch.zeros(len(pos), 1, dtype=torch.float64), cat), x).numpy()
+        genome = PackedGenome.from_sequence(seq, "cuda")
+        got = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r,
+                                   local_order=3).cpu().numpy()
+        dense = model((torch.zeros(len(pos), 1, dtype=torch.float64).cuda(), cat.cuda()), x.cuda()).cpu().numpy()
+    assert not model._fused_ok()      # both lengths are beyond the LDS-resident kernels (stage-1 window / tower tile): per-layer path
+    assert_probs_close(got, want, model_no, f"packed R={R}")
+    assert_probs_close(dense, want, model_no, f"dense R={R}")
