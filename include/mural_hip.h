@@ -205,6 +205,12 @@ size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n);
  * out: dev float [n][n_class] positive Softplus scores (callers apply softmax, run_predict.py:214).      */
 int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
                               void* workspace, size_t workspace_bytes, void* stream);
+/* The same for sites of a packed genome: replaces seq_ohe_encoder (MuRaL/data/preprocessing.py:756-816; indel window
+ * [pos - R + 1, pos + R], :564-566) + UNet_Small.forward.  The window is decoded inside the first level's kernel and the
+ * strand-symmetrising input conv (model_indel.py:29-32, :154-155) is evaluated there per symbol, so the one-hot window never
+ * exists in HBM.  pos: dev int64 [n], strand: dev uint8 [n] (1 = '-'); the model's length must be 2 * R.                    */
+int mural_indel_forward_packed(const MuralIndelModel* m, const MuralGenome* genome, const int64_t* pos, const uint8_t* strand,
+                               int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Training-mode building blocks (MuRaL/training.py:404-450 over model_snv.py:439-525): forward with

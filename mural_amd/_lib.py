@@ -182,6 +182,8 @@ PROTOTYPES = {
     "mural_indel_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
     "mural_indel_forward_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t,
                                             C.c_void_p]),
+    "mural_indel_forward_packed": (C.c_int, [C.c_void_p, C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                                             C.c_void_p, C.c_size_t, C.c_void_p]),
     "mural_snv_kernel_name": (C.c_char_p, []),
     "mural_debug_set_stamps": (C.c_int, [C.c_void_p]),
     "mural_profile_begin": (C.c_int, []),

@@ -61,6 +61,18 @@ struct ConvBlockArgs {
   const float* f_b;
   int Cf, Lf, f_up;
   const float* f_pw;     // optional (f_up == 4): polyphase front weights [4 phases][Cf][3][C] (taps summed per source column)
+  // optional source of the front input (first encoder level, Cf == 4, f_up == 1): instead of reading f_in, the workgroup decodes its
+  // span of the window from the packed genome (site g_pos[b], strand g_strand[b], window origin g_off) and evaluates the layer in
+  // front of the U-Net -- the strand-symmetrising Conv1d(4, 4, k) + BN of model_indel.py:29-32 / :154-155, folded into ONE conv
+  // on the host, or the identity when the model has none -- per symbol from a table: symtab[15 symbols][sym_taps][4] (+ sym_bias[4]
+  // on columns inside the window).  Neither the one-hot window nor the layer's output ever exist in HBM.
+  MuralGenome genome;
+  const int64_t* g_pos;
+  const uint8_t* g_strand;
+  int g_off;
+  const float* symtab;
+  const float* sym_bias;
+  int sym_taps;
   const float* ta_w;
   const float* ta_b;
   const float* tb_w;

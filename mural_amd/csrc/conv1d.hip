@@ -251,6 +251,40 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
     const int span = (l0 + 256) / up - r0 + 1;               // real columns staged per channel
     const float* fsrc = a.f_in + (size_t)b * a.Cf * a.Lf;
     constexpr int UN = 5;                                    // 16 x 67 (decoder) and 4 x 262 (encoder) floats = 5 per thread
+    if (a.symtab != nullptr) {
+      // front input from the packed genome (Cf == 4, up == 1): symbols of columns r0 - h .. r0 + span - 1 + h (h = sym_taps / 2)
+      // into LDS bytes (strand-oriented: '-' rows read the window backwards and complemented), then per staged column the
+      // sym_taps table rows of its neighbourhood; columns outside [0, Lf) hold the zero padding of the front conv, symbols
+      // outside it the zero padding of the table layer
+      uint8_t* symb = reinterpret_cast<uint8_t*>(tile);      // the block-input tile is written only after the front
+      const int h = a.sym_taps >> 1;
+      const int nsym = span + 2 * h;
+      const int64_t ws = a.g_pos[b] + a.g_off;
+      const bool neg = a.g_strand[b] != 0;
+      for (int i = tid; i < nsym; i += 256) {
+        const int j = r0 - h + i;                            // window column
+        uint32_t sy = SYM_PAD;
+        if (j >= 0 && j < a.Lf) {
+          sy = genome_sym_iupac(a.genome, neg ? ws + (a.Lf - 1 - j) : ws + j);
+          if (neg) sy = sym_complement(sy);
+        }
+        symb[i] = (uint8_t)sy;
+      }
+      __syncthreads();
+      for (int i = tid; i < 4 * span; i += 256) {
+        const int ci = i / span, rr = i - ci * span;
+        const int r = r0 + rr;
+        float v = 0.f;
+        if (r >= 0 && r < a.Lf) {
+          v = a.sym_bias[ci];
+          for (int k = 0; k < a.sym_taps; ++k) {
+            const uint32_t sy = symb[rr + k];
+            if (sy != SYM_PAD) v += a.symtab[(sy * a.sym_taps + k) * 4 + ci];
+          }
+        }
+        fin[i] = v;
+      }
+    } else
     for (int i0 = tid; i0 < a.Cf * span; i0 += 256 * UN) {
       float v[UN];
 #pragma unroll
@@ -443,16 +477,19 @@ static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.L == 0) return MURAL_OK;
   MURAL_REQUIRE(convblock_supported(a.C), "convblock: %d channels not instantiated", a.C);
-  if (a.f_in) {
+  if (a.symtab) MURAL_REQUIRE(a.Cf == 4 && a.f_up == 1 && a.C == 8 && a.sym_taps >= 1 && (a.sym_taps & 1) && a.sym_taps <= 15 && a.sym_bias &&
+                              a.g_pos && a.g_strand, "convblock: the genome-fed front serves the 4-channel input of the first level");
+  if (a.f_in || a.symtab) {
     MURAL_REQUIRE(a.f_w && a.f_b && a.f_up >= 1 && a.Lf * a.f_up == a.L, "convblock: bad front geometry");
     MURAL_REQUIRE(a.Cf * (262 / a.f_up + 3) <= CB_FRONT_FLOATS, "convblock: front input tile does not fit");
     MURAL_REQUIRE(!a.f_pw || a.f_up == 4, "convblock: the polyphase front serves an upsampling factor of 4");
   }
   if (a.tail_max) MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
   if (convblock_mfma_supported(a)) return launch_convblock_mfma(a, stream);
-  if (a.tail_max && a.f_in) launch_convblock_t<true, true>(a, stream);
+  const bool front = a.f_in != nullptr || a.symtab != nullptr;
+  if (a.tail_max && front) launch_convblock_t<true, true>(a, stream);
   else if (a.tail_max) launch_convblock_t<true, false>(a, stream);
-  else if (a.f_in) launch_convblock_t<false, true>(a, stream);
+  else if (front) launch_convblock_t<false, true>(a, stream);
   else launch_convblock_t<false, false>(a, stream);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;

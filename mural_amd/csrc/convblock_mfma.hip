@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void convblock_mfma_kernel(const ConvBlockArgs
 }  // namespace
 
 bool convblock_mfma_supported(const ConvBlockArgs& a) {
-  return (a.C == 16 || a.C == 24) && !a.f_in && !a.tail_max && !getenv("MURAL_DEBUG_CONVBLOCK_VALU");
+  return (a.C == 16 || a.C == 24) && !a.f_in && !a.symtab && !a.tail_max && !getenv("MURAL_DEBUG_CONVBLOCK_VALU");
 }
 
 int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream) {

@@ -72,6 +72,10 @@ struct MuralIndelModel {
   FoldedConv dn_lp[INDEL_LEVELS - 1];     // polyphase form of dn_l (conv of the upsampled tensor), K = 0: not built
   int dn_lp_pad[INDEL_LEVELS - 1];
   size_t front_pw;                        // level-0 decoder front in the block kernel's polyphase layout [4][Cf][3][C]; 0: not built
+  // the layer in front of the U-Net per input symbol (ConvBlockArgs::symtab): [15][sym_taps][4] + bias [4]; the folded
+  // strand-symmetrising conv with use_reverse (sym_taps = its kernel size), the one-hot columns themselves otherwise (sym_taps = 1)
+  size_t symtab, sym_bias;
+  int sym_taps;
   size_t fc_w, fc_b;     // [n_class][C0] with the BN folded, [n_class]
   float* blob;
   size_t blob_floats;
@@ -193,8 +197,31 @@ extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const Mura
       B.host[m->fc_b + k] = (float)b;
     }
   }
-  // activation scratch per position: S | E_0..E_5 | T1 | T2 | H | SP | M
-  size_t per = (size_t)4 * sh.length;
+  {
+    // symbol table of the input layer: column value of channel c for symbol s = 1 / |set(s)| if c is in the symbol's base set
+    // (preprocessing.py:758-772: one-hot, pairs 0.5, triples 1/3, N 0.25)
+    static const uint8_t kSet[15] = {1, 2, 4, 8, 15, 5, 10, 3, 6, 9, 12, 14, 13, 11, 7};   // A C G T N R Y M S W K B D H V (bit c = base c)
+    const int taps = sh.use_reverse ? K : 1;
+    m->sym_taps = taps;
+    m->symtab = B.alloc((size_t)15 * taps * 4);
+    m->sym_bias = B.alloc(4);
+    for (int sy = 0; sy < 15; ++sy) {
+      const int members = __builtin_popcount(kSet[sy]);
+      const float v = members == 1 ? 1.0f : members == 2 ? 0.5f : members == 3 ? (float)(1.0 / 3.0) : 0.25f;
+      for (int k = 0; k < taps; ++k)
+        for (int o = 0; o < 4; ++o) {
+          double acc = 0.0;
+          for (int c = 0; c < 4; ++c) {
+            if (!((kSet[sy] >> c) & 1)) continue;
+            acc += sh.use_reverse ? (double)v * B.host[m->sym.w + ((size_t)c * K + k) * 4 + o] : (c == o ? (double)v : 0.0);
+          }
+          B.host[m->symtab + ((size_t)sy * taps + k) * 4 + o] = (float)acc;
+        }
+    }
+    for (int o = 0; o < 4; ++o) B.host[m->sym_bias + o] = sh.use_reverse ? B.host[m->sym.b + o] : 0.f;
+  }
+  // activation scratch per position: S | E_0..E_5 | T1 | T2 | H | SP | M | X (one-hot window of the packed entry's fallback)
+  size_t per = (size_t)4 * sh.length + (size_t)4 * sh.length;
   for (int i = 0; i < INDEL_LEVELS; ++i) per += (size_t)m->ch[i] * m->len[i];
   const size_t big = (size_t)m->ch[0] * m->len[0];
   size_t tmax = 0, hmax = 0;
@@ -226,7 +253,7 @@ extern "C" void mural_indel_model_destroy(MuralIndelModel* m) {
   delete m;
 }
 
-constexpr size_t INDEL_WS_REGIONS = INDEL_LEVELS + 6;   // S | E[levels] | T1 | T2 | H | SP | M
+constexpr size_t INDEL_WS_REGIONS = INDEL_LEVELS + 7;   // S | E[levels] | T1 | T2 | H | SP | M | X
 
 extern "C" size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n) {
   if (!m || n <= 0) return 256;
@@ -276,9 +303,16 @@ static bool front_fusable(const FoldedConv& ff, int up, int C) {
   return C == 8 && ff.K == 7 && ff.Cout == C && up >= 1 && ff.Cin * (262 / up + 3) <= 2048;
 }
 
+struct GenomeSrc {      // packed-genome source of the first level's front input (ConvBlockArgs::symtab)
+  const MuralGenome* g = nullptr;
+  const int64_t* pos = nullptr;
+  const uint8_t* strand = nullptr;
+  int off = 0;
+};
+
 static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
                      float* H, float* out, const float* skip, hipStream_t stream, float* tail_max = nullptr,
-                     const FoldedConv* ff = nullptr, const float* fin = nullptr, int up = 1) {
+                     const FoldedConv* ff = nullptr, const float* fin = nullptr, int up = 1, const GenomeSrc* gs = nullptr) {
   if (block_fusable(f5, f1, L)) {
     ConvBlockArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -287,6 +321,10 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
     if (ff) {
       a.f_in = fin; a.f_w = m->blob + ff->w; a.f_b = m->blob + ff->b; a.Cf = ff->Cin; a.Lf = L / up; a.f_up = up;
       if (up == 4 && m->front_pw && ff == &m->dn_l[INDEL_LEVELS - 2]) a.f_pw = m->blob + m->front_pw;
+      if (gs && gs->g) {
+        a.genome = *gs->g; a.g_pos = gs->pos; a.g_strand = gs->strand; a.g_off = gs->off;
+        a.symtab = m->blob + m->symtab; a.sym_bias = m->blob + m->sym_bias; a.sym_taps = m->sym_taps;
+      }
     }
     if (tail_max) {   // out_conv (1x1, BN, ReLU, 1x1, Softplus) + max over positions ride on the last decoder block
       a.ta_w = m->blob + m->out1.w; a.ta_b = m->blob + m->out1.b; a.tb_w = m->blob + m->out2.w; a.tb_b = m->blob + m->out2.b;
@@ -299,14 +337,17 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
   return run_conv(m, f1, H, B, L, out, L, 1, 1, ACT_NONE, x, skip, stream);
 }
 
-// Replaces UNet_Small.forward(distal_input) (model_indel.py:151-176): distal_x dev float [n][4][length] -> out
-// dev float [n][n_class] (positive Softplus scores; callers apply softmax / cross-entropy, run_predict.py:214).
-extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
-                                         void* workspace, size_t workspace_bytes, void* stream_) {
+extern "C" int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n, int32_t radius,
+                                   int32_t indel, float* out, void* stream);
+
+// distal_x != nullptr: dense entry; otherwise the windows come from the packed genome (genome, pos, strand; window
+// [pos - radius + 1, pos + radius], preprocessing.py:564-566)
+static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, const MuralGenome* genome, const int64_t* pos,
+                              const uint8_t* strand, int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
   MURAL_REQUIRE(m, "model handle is NULL");
   MURAL_REQUIRE(n >= 0, "negative batch");
   if (n == 0) return MURAL_OK;
-  MURAL_REQUIRE(distal_x && out, "distal_x/out is NULL");
+  MURAL_REQUIRE((distal_x || (genome && pos && strand)) && out, "input/out is NULL");
   if (!workspace || workspace_bytes < mural_indel_workspace_bytes(m, n)) {
     set_error("workspace too small: need %zu bytes, got %zu", mural_indel_workspace_bytes(m, n), workspace_bytes);
     return MURAL_E_WORKSPACE;
@@ -355,18 +396,33 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
     float* SP = take((size_t)C0 * m->len[0]);
     int mparts = 1;
     float* M = take((size_t)C0 * convblock_tiles(m->len[0], true));
-    const float* x = distal_x + (size_t)c0 * 4 * Lx;
+    float* X = take((size_t)4 * Lx);
     int rc = MURAL_OK;
+    // packed entry: the first level's block kernel decodes its span of the window and evaluates the input layer per symbol
+    // (ConvBlockArgs::symtab) when that kernel applies; otherwise the window is materialised first
+    GenomeSrc gs;
+    const bool first_fused = sh.down[0] == 1 && block_fusable(m->up5[0], m->up1[0], m->len[0]) && front_fusable(m->up_l[0], 1, m->ch[0]);
+    const float* x = nullptr;
+    if (distal_x) {
+      x = distal_x + (size_t)c0 * 4 * Lx;
+    } else if (first_fused && !getenv("MURAL_DEBUG_INDEL_NO_GENOME_FRONT")) {
+      gs.g = genome; gs.pos = pos + c0; gs.strand = strand + c0; gs.off = -(Lx / 2) + 1;
+    } else {
+      if ((rc = mural_encode_onehot(genome, pos + c0, strand + c0, B, Lx / 2, 1, X, stream))) return rc;
+      x = X;
+    }
     const float* cur = x;
     int Lcur = Lx;
-    if (sh.use_reverse) {
+    if (sh.use_reverse && !gs.g) {
       if ((rc = run_conv(m, m->sym, cur, B, Lcur, S, Lcur, 1, 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
       cur = S;
     }
     for (int i = 0; i < INDEL_LEVELS; ++i) {     // encoder: strided conv+BN, then ConvBlock (x + BN(1x1(SiLU(BN(k5)))))
       const int Li = m->len[i];
       if (sh.down[i] == 1 && block_fusable(m->up5[i], m->up1[i], Li) && front_fusable(m->up_l[i], 1, m->ch[i])) {
-        if ((rc = run_block(m, m->up5[i], m->up1[i], nullptr, B, Li, H, E[i], nullptr, stream, nullptr, &m->up_l[i], cur, 1))) return rc;
+        if ((rc = run_block(m, m->up5[i], m->up1[i], nullptr, B, Li, H, E[i], nullptr, stream, nullptr, &m->up_l[i], cur, 1,
+                            i == 0 ? &gs : nullptr)))
+          return rc;
       } else {
         if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
         if ((rc = run_block(m, m->up5[i], m->up1[i], T1, B, Li, H, E[i], nullptr, stream))) return rc;
@@ -413,4 +469,26 @@ extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* 
   if (lanes == 2)
     if (int rc = ss->join(main_stream)) return rc;     // also on an error: the side stream must not stay forked
   return rc_all;
+}
+
+// Replaces UNet_Small.forward(distal_input) (model_indel.py:151-176): distal_x dev float [n][4][length] -> out
+// dev float [n][n_class] (positive Softplus scores; callers apply softmax / cross-entropy, run_predict.py:214).
+extern "C" int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
+                                         void* workspace, size_t workspace_bytes, void* stream_) {
+  MURAL_REQUIRE(n <= 0 || distal_x, "distal_x is NULL");
+  return indel_forward_impl(m, distal_x, nullptr, nullptr, nullptr, n, out, workspace, workspace_bytes, stream_);
+}
+
+// The same from the packed genome: replaces seq_ohe_encoder (MuRaL/data/preprocessing.py:756-816, indel window :564-566) +
+// UNet_Small.forward for the sites (pos, strand).  With the shipped geometry (down_list[0] == 1, 8 channels) the window is decoded
+// inside the first level's kernel and the strand-symmetrising input conv is evaluated there per symbol: neither the one-hot
+// window (128 KB per position at L = 8000) nor that conv's output exist in HBM.  The model's `length` must be even (2 * radius).
+extern "C" int mural_indel_forward_packed(const MuralIndelModel* m, const MuralGenome* genome, const int64_t* pos, const uint8_t* strand,
+                                          int64_t n, float* out, void* workspace, size_t workspace_bytes, void* stream_) {
+  MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(genome && genome->packed2 && genome->nmask, "genome pointers must not be NULL");
+  MURAL_REQUIRE(genome->n_amb == 0 || (genome->amb_pos && genome->amb_sym), "genome: n_amb > 0 needs amb_pos and amb_sym");
+  MURAL_REQUIRE((m->shape.length & 1) == 0, "the indel window is 2 * distal_radius wide: model length %d is odd", m->shape.length);
+  MURAL_REQUIRE(n <= 0 || (pos && strand), "pos/strand is NULL");
+  return indel_forward_impl(m, nullptr, genome, pos, strand, n, out, workspace, workspace_bytes, stream_);
 }

@@ -158,9 +158,29 @@ class UNet_Small(nn.Module):
         return out
 
     def forward_packed(self, genome, pos, strand, distal_radius):
-        """Scores for sites of a PackedGenome: windows are decoded on the GPU (indel window: [start-R+1, start+R])."""
-        x = genome.encode_onehot(pos, strand, distal_radius, "indel")
-        return self.forward(x)
+        """Scores for sites of a PackedGenome (indel window: [start-R+1, start+R]).  Eval mode: ONE library call
+        (``mural_indel_forward_packed``) -- the window is decoded inside the first level's kernel, the one-hot tensor never exists;
+        training mode encodes the windows and takes the differentiable path."""
+        if self.training:
+            return self.forward(genome.encode_onehot(pos, strand, distal_radius, "indel"))
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("mural_amd models run on a HIP device only: call model.to('cuda') first")
+        pos = _lib.require_cuda(torch.as_tensor(pos, device=dev), "pos").to(torch.int64).contiguous()
+        strand = _lib.require_cuda(torch.as_tensor(strand, device=dev), "strand").to(torch.uint8).contiguous()
+        if pos.shape != strand.shape or pos.dim() != 1:
+            raise ValueError("pos and strand must be 1-D and of equal length")
+        n, length = pos.shape[0], 2 * int(distal_radius)
+        with torch.cuda.device(dev):
+            handle = self._get_handle(length)
+            out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
+            need = int(_lib.lib().mural_indel_workspace_bytes(handle, max(n, 1)))
+            if self._ws is None or self._ws.numel() < need or self._ws.device != dev:
+                self._ws = torch.empty(need, dtype=torch.uint8, device=dev)
+            g = genome.as_struct(dev)
+            _lib.check(_lib.lib().mural_indel_forward_packed(handle, C.byref(g), pos.data_ptr(), strand.data_ptr(), n, out.data_ptr(),
+                                                            self._ws.data_ptr(), self._ws.numel(), _lib.current_stream_ptr(dev)))
+        return out
 
     def reverse_input(self, distal_input):
         return distal_input.flip([1, 2])

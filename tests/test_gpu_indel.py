@@ -467,3 +467,45 @@ def test_long_windows_match_oracle(L):
         packed = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), L // 2).cpu().numpy()
     tol = 1e-4 * max(1.0, np.abs(want).max())
     assert np.abs(dense - want).max() <= tol and np.abs(packed - want).max() <= tol
+
+
+@pytest.mark.parametrize("name", ["indel_pretrained_human_insertion.npz", "indel_synth_small.npz", "indel_synth_c2.npz",
+                                  "indel_pretrained_arabidopsis_insertion.npz"])
+def test_packed_entry_decodes_inside_the_first_level(name, monkeypatch):
+    """mural_indel_forward_packed: the window is decoded from the packed genome inside the first level's kernel and the input layer
+    (strand-symmetrising conv, or none) is evaluated per symbol -- against the oracle fed by the oracle encoder, with N runs, all
+    IUPAC codes, both strands and windows that hang over both chromosome ends; the materialising fallback gives the same scores."""
+    from mural_amd.data import PackedGenome
+    from oracle import encode_ref
+    fx = U.load(name)
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    sd = U.indel_state_for(fx, orc)
+    model.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    model = model.cuda().eval()
+    orc.eval()
+    R = int(fx["hp"][0])
+    rng = np.random.default_rng(R)
+    n = 6 * R + 1000
+    alphabet, p = b"ACGTNRYMSWKBDHV", [.2455] * 4 + [.008] + [.001] * 10
+    raw = rng.choice(np.frombuffer(alphabet, np.uint8), size=n, p=np.array(p) / sum(p))
+    raw[n // 2:n // 2 + 40] = ord("N")
+    seq = raw.tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = np.r_[[0, 3, R - 1, n - 1, n - R, n // 2 + 7], rng.integers(0, n, size=26)]
+    strand = (np.arange(len(pos)) % 2).astype(np.uint8)
+    sym = ["-" if v else "+" for v in strand]
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R, "indel"))
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    tp, ts = torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda()
+    with torch.no_grad():
+        want = orc(x).numpy()
+        got = model.forward_packed(genome, tp, ts, R).cpu().numpy()
+        monkeypatch.setenv("MURAL_DEBUG_INDEL_NO_GENOME_FRONT", "1")
+        slow = model.forward_packed(genome, tp, ts, R).cpu().numpy()
+        dense = model(genome.encode_onehot(tp, ts, R, "indel")).cpu().numpy()
+    tol = 1e-4 * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+    assert np.abs(slow - want).max() <= tol and np.array_equal(slow, dense)
+    assert model.forward_packed(genome, tp[:0], ts[:0], R).shape == (0, model.n_class)
