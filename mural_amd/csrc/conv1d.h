@@ -86,6 +86,10 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream);
 bool convblock_mfma_supported(const ConvBlockArgs& a);
 int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream);
 
+// fp32-MFMA version of the 8-channel blocks WITH a front (first encoder level / last decoder level, convblock8_mfma.hip)
+bool convblock8_mfma_supported(const ConvBlockArgs& a);
+int launch_convblock8_mfma(const ConvBlockArgs& a, hipStream_t stream);
+
 // y[b][c] = max_l x[b][c][l]
 int launch_rowmax(const float* x, int64_t rows, int L, float* y, hipStream_t stream);
 

@@ -257,6 +257,9 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
       // sym_taps table rows of its neighbourhood; columns outside [0, Lf) hold the zero padding of the front conv, symbols
       // outside it the zero padding of the table layer
       uint8_t* symb = reinterpret_cast<uint8_t*>(tile);      // the block-input tile is written only after the front
+      float* stab = tile + 128;                              // [15][sym_taps][4] table + bias[4], behind the symbol bytes
+      for (int i = tid; i < 15 * a.sym_taps * 4; i += 256) stab[i] = a.symtab[i];
+      if (tid < 4) stab[15 * 15 * 4 + tid] = a.sym_bias[tid];
       const int h = a.sym_taps >> 1;
       const int nsym = span + 2 * h;
       const int64_t ws = a.g_pos[b] + a.g_off;
@@ -276,10 +279,10 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
         const int r = r0 + rr;
         float v = 0.f;
         if (r >= 0 && r < a.Lf) {
-          v = a.sym_bias[ci];
+          v = stab[15 * 15 * 4 + ci];
           for (int k = 0; k < a.sym_taps; ++k) {
             const uint32_t sy = symb[rr + k];
-            if (sy != SYM_PAD) v += a.symtab[(sy * a.sym_taps + k) * 4 + ci];
+            if (sy != SYM_PAD) v += stab[(sy * a.sym_taps + k) * 4 + ci];
           }
         }
         fin[i] = v;
@@ -486,6 +489,7 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   }
   if (a.tail_max) MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
   if (convblock_mfma_supported(a)) return launch_convblock_mfma(a, stream);
+  if (convblock8_mfma_supported(a)) return launch_convblock8_mfma(a, stream);
   const bool front = a.f_in != nullptr || a.symtab != nullptr;
   if (a.tail_max && front) launch_convblock_t<true, true>(a, stream);
   else if (a.tail_max) launch_convblock_t<true, false>(a, stream);

@@ -29,3 +29,21 @@ with torch.no_grad():
     dt = (time.perf_counter() - t0) / 5
 print("UNet_Small insertion L=8000: %.1f positions/s (%.2f ms per %d), %.1f TFLOP/s algorithmic (113.4 MFLOP/pos)"
       % (B / dt, dt * 1e3, B, B / dt * 113.4e6 / 1e12))
+
+# the packed entry (window decode + input conv inside the first level's kernel)
+from mural_amd.data import PackedGenome  # noqa: E402
+rng = np.random.default_rng(0)
+seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=2_000_000)].tobytes().decode()
+genome = PackedGenome.from_sequence(seq, "cuda")
+idx = torch.arange(B, device="cuda", dtype=torch.int64)
+pos, strand = idx * 47 + 4000, (idx & 1).to(torch.uint8)
+with torch.no_grad():
+    for _ in range(2):
+        model.forward_packed(genome, pos, strand, 4000)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        model.forward_packed(genome, pos, strand, 4000)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / 5
+print("packed entry: %.1f positions/s (%.2f ms per %d), %.1f TFLOP/s algorithmic" % (B / dt, dt * 1e3, B, B / dt * 113.4e6 / 1e12))
