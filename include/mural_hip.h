@@ -491,6 +491,19 @@ typedef struct MuralRelayoutJob {
   int64_t start;
 } MuralRelayoutJob;
 int mural_op_relayout_multi(const MuralRelayoutJob* jobs, int32_t n_jobs, int64_t total, void* stream);
+/* The INDEL training step as one call per direction (reference: UNet_Small.forward under model.train(),
+ * MuRaL/model/model_indel.py:151-176, inside the step of MuRaL/training.py:424-436).  params / grads: DEVICE pointers in the
+ * state_dict naming (MuralIndelParams); the forward updates the BatchNorms' running statistics in place (the strand-symmetrising
+ * layer's twice, in the reference's order) and leaves everything the backward needs in the workspace; the backward writes every
+ * parameter gradient (fully, no accumulation).  x: dev float [B][4][length]; out / dout: dev float [B][n_class].  dropout_p, seed,
+ * seed_dev: out_fc's Dropout (see mural_op_dropout).  mural_indel_train_workspace_bytes: 0 on a bad shape.                      */
+size_t mural_indel_train_workspace_bytes(const MuralIndelShape* shape, int64_t B);
+int mural_indel_train_forward(const MuralIndelShape* shape, const MuralIndelParams* params, const float* x, int64_t B,
+                              float dropout_p, uint64_t seed, const uint64_t* seed_dev, float momentum, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
+int mural_indel_train_backward(const MuralIndelShape* shape, const MuralIndelParams* params, const MuralIndelParams* grads,
+                               const float* x, const float* dout, int64_t B, float dropout_p, uint64_t seed,
+                               const uint64_t* seed_dev, void* workspace, size_t workspace_bytes, void* stream);
 /* kind: 1 ReLU, 2 SiLU, 3 Softplus (beta 1, threshold 20); backward takes the forward INPUT x */
 int mural_op_act_fwd(const float* x, int64_t n, int32_t kind, float* y, void* stream);
 int mural_op_act_bwd(const float* dy, const float* x, int64_t n, int32_t kind, float* dx, void* stream);

@@ -184,6 +184,11 @@ PROTOTYPES = {
                                             C.c_void_p]),
     "mural_indel_forward_packed": (C.c_int, [C.c_void_p, C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                                              C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mural_indel_train_workspace_bytes": (C.c_size_t, [C.POINTER(MuralIndelShape), I64]),
+    "mural_indel_train_forward": (C.c_int, [C.POINTER(MuralIndelShape), C.POINTER(MuralIndelParams), VP, I64, C.c_float, C.c_uint64, VP,
+                                            C.c_float, VP, VP, C.c_size_t, VP]),
+    "mural_indel_train_backward": (C.c_int, [C.POINTER(MuralIndelShape), C.POINTER(MuralIndelParams), C.POINTER(MuralIndelParams), VP, VP,
+                                             I64, C.c_float, C.c_uint64, VP, VP, C.c_size_t, VP]),
     "mural_snv_kernel_name": (C.c_char_p, []),
     "mural_debug_set_stamps": (C.c_int, [C.c_void_p]),
     "mural_profile_begin": (C.c_int, []),

@@ -26,7 +26,7 @@ size_t ws_guard_bytes() {
 }
 void ws_layout_reset() { g_ws_layout.clear(); }
 void ws_layout_add(size_t off, size_t bytes) {
-  if (g_ws_layout.size() < 256) {
+  if (g_ws_layout.size() < 4096) {
     g_ws_layout.push_back(off);
     g_ws_layout.push_back(bytes);
   }

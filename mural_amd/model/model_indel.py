@@ -63,6 +63,7 @@ class UNet_Small(nn.Module):
     def invalidate_folded(self):
         self._release()
         self._plist = None
+        self._train_layout = None      # tensor objects / storages may have been replaced
 
     def train(self, mode=True):
         if bool(mode) != self.training:     # a real transition; model.eval() on a model in eval mode keeps the folded copy
@@ -142,10 +143,14 @@ class UNet_Small(nn.Module):
         x = _lib.require_cuda(distal_input, "distal_input").to(torch.float32).contiguous()
         if x.dim() != 3 or x.shape[1] != 4:
             raise ValueError(f"distal_input must be (B, 4, L), got {tuple(x.shape)}")
-        if self.training:       # batch-statistics BatchNorm + dropout, differentiable (model/indel_train.py)
-            from .indel_train import unet_forward_train
+        if self.training:       # batch-statistics BatchNorm + dropout, differentiable: one C call per direction
+            import os
             with torch.cuda.device(dev):
-                return unet_forward_train(self, x)
+                if os.environ.get("MURAL_INDEL_TRAIN_PER_UNIT"):      # the per-unit autograd composition (model/indel_train.py)
+                    from .indel_train import unet_forward_train
+                    return unet_forward_train(self, x)
+                from . import indel_train_step
+                return indel_train_step.run(self, x)
         n, length = x.shape[0], x.shape[2]
         with torch.cuda.device(dev):
             handle = self._get_handle(length)

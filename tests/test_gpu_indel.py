@@ -242,8 +242,10 @@ def test_conv_bn_unit_against_torch():
 def test_train_step_does_not_read_unwritten_scratch(monkeypatch):
     """Every buffer the training step allocates with torch.empty / empty_like (conv outputs, BatchNorm states, gradients, layouts,
     partial sums) must be completely written before a kernel reads it: the same step with those allocations pre-filled with NaN
-    gives the same loss and gradients."""
+    gives the same loss and gradients.  (The per-unit autograd composition of model/indel_train.py, which the generic SNV towers
+    share; the one-call step has its own workspace tests below.)"""
     from mural_amd.model import indel_train as IT
+    monkeypatch.setenv("MURAL_INDEL_TRAIN_PER_UNIT", "1")
     fx = U.load("indel_train_rev.npz")
     model = product_from(fx)
     orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
@@ -279,8 +281,9 @@ def test_train_step_does_not_read_unwritten_scratch(monkeypatch):
 
 def test_train_step_writes_stay_inside_their_buffers(monkeypatch):
     """Every tensor the training step allocates is carved out of one arena with 4 KB guard zones (0xAB) around it: after a forward +
-    backward every guard byte is intact -- no kernel of the step writes outside the buffer it was given."""
+    backward every guard byte is intact -- no kernel of the step writes outside the buffer it was given.  (Per-unit composition.)"""
     from mural_amd.model import indel_train as IT
+    monkeypatch.setenv("MURAL_INDEL_TRAIN_PER_UNIT", "1")
     fx = U.load("indel_train_rev.npz")
     model = product_from(fx)
     orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
@@ -328,10 +331,11 @@ def test_train_step_writes_stay_inside_their_buffers(monkeypatch):
     assert bool((host[end:end + guard] == 0xAB).all())
 
 
-def test_clip_grad_norm_on_separate_gradient_tensors_matches_torch():
-    """mural_amd.train.clip_grad_norm_ on a model whose gradients are separate tensors (UNet_Small) == torch.nn.utils.clip_grad_norm_:
-    same total norm, same clipped gradients, and no clipping below the bound."""
+def test_clip_grad_norm_on_separate_gradient_tensors_matches_torch(monkeypatch):
+    """mural_amd.train.clip_grad_norm_ on a model whose gradients are separate tensors (UNet_Small on the per-unit composition) ==
+    torch.nn.utils.clip_grad_norm_: same total norm, same clipped gradients, and no clipping below the bound."""
     from mural_amd.train import clip_grad_norm_
+    monkeypatch.setenv("MURAL_INDEL_TRAIN_PER_UNIT", "1")
     fx = U.load("indel_train_rev.npz")
     model = product_from(fx)
     orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
@@ -509,3 +513,76 @@ def test_packed_entry_decodes_inside_the_first_level(name, monkeypatch):
     assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
     assert np.abs(slow - want).max() <= tol and np.array_equal(slow, dense)
     assert model.forward_packed(genome, tp[:0], ts[:0], R).shape == (0, model.n_class)
+
+
+@pytest.mark.parametrize("tag", ["rev", "norev"])
+def test_one_call_train_step_equals_per_unit_composition_and_keeps_to_its_workspace(tag, monkeypatch):
+    """mural_indel_train_forward / _backward (csrc/indel_train_step.hip, one C call per direction) against the per-unit autograd
+    composition of the same kernels: same scores, loss, gradients and running statistics (G14 pins both to the reference); then the
+    same step with its workspace and flat gradient buffer pre-filled with 0xFF bytes (nothing is read before it is written) and with
+    4 KB guard zones behind every workspace region (no kernel writes outside the region it was given)."""
+    import ctypes as C
+    from mural_amd import _lib
+    from mural_amd.model import indel_train_step as ITS
+    from tests.test_gpu_snv import _PoisonedTorch
+    fx = U.load(f"indel_train_{tag}.npz")
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    sd = U.indel_state_for(fx, orc)
+    x, y = U.onehot(fx["codes"]).cuda(), torch.from_numpy(fx["y"]).cuda()
+
+    def fresh():
+        m = product_from(fx)
+        m.load_state_dict(sd, strict=True)
+        m = m.cuda().train()
+        m.out_fc[1].p = 0.0
+        return m
+
+    monkeypatch.setenv("MURAL_INDEL_TRAIN_PER_UNIT", "1")
+    ref = fresh()
+    preds0, loss0 = _train_step(ref, x, y)
+    monkeypatch.delenv("MURAL_INDEL_TRAIN_PER_UNIT")
+    model = fresh()
+    preds1, loss1 = _train_step(model, x, y)
+    assert model._train_layout.last_flat is not None                      # the one-call backward ran
+    assert float((preds1 - preds0).abs().max()) <= 1e-6 * max(1.0, float(preds0.abs().max()))
+    assert abs(loss1.item() - loss0.item()) <= 1e-6 * abs(loss0.item())
+    for (k, p), q in zip(model.named_parameters(), ref.parameters()):
+        assert float((p.grad - q.grad).abs().max()) <= 2e-5 * (float(q.grad.abs().max()) + 1e-3), k
+    for (k, b), c in zip(model.named_buffers(), ref.buffers()):
+        assert float((b.double() - c.double()).abs().max()) <= 1e-6 * max(1.0, float(c.double().abs().max())), k
+    grads = {k: p.grad.clone() for k, p in model.named_parameters()}
+    # poisoned allocations
+    monkeypatch.setattr(ITS, "torch", _PoisonedTorch())
+    model2 = fresh()
+    _, loss2 = _train_step(model2, x, y)
+    assert abs(loss2.item() - loss1.item()) <= 1e-6 * abs(loss1.item())
+    for k, p in model2.named_parameters():
+        assert torch.isfinite(p.grad).all(), k
+        assert float((p.grad - grads[k]).abs().max()) <= 1e-5 * (float(grads[k].abs().max()) + 1e-3), k
+    # guard zones behind every workspace region
+    guard = 4096
+    monkeypatch.setenv("MURAL_DEBUG_WS_GUARD", str(guard))
+    kept = []
+    real_empty = torch.empty
+
+    class Keep(_PoisonedTorch):
+        @staticmethod
+        def empty(*a, **k):
+            t = _PoisonedTorch.empty(*a, **k)
+            if t.dtype is torch.uint8:
+                kept.append(t)
+            return t
+
+    monkeypatch.setattr(ITS, "torch", Keep())
+    model3 = fresh()
+    _train_step(model3, x, y)
+    torch.cuda.synchronize()
+    layout = (C.c_size_t * 1024)()
+    n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 512)
+    assert n_regions >= 100 and kept
+    ws = kept[-1].cpu().numpy()
+    for i in range(n_regions):
+        off, size = layout[2 * i], layout[2 * i + 1]
+        zone = ws[off + size:off + size + guard]
+        assert len(zone) == guard and (zone == 255).all(), f"region {i}: a kernel wrote behind its {size} bytes"
+    del real_empty
