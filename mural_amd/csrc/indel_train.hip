@@ -310,6 +310,56 @@ __global__ __launch_bounds__(IT_THREADS) void conv_wgrad_reduce_kernel(const flo
   else if (db) db[co] = (float)s;
 }
 
+// The same for up to WD_MAXJOBS layers in ONE launch (blockIdx.y = layer): the composed training step (indel_train_step.hip) gives
+// every layer its own partial-row region and reduces them all at the end of its backward instead of once per layer.
+constexpr int WD_MAXJOBS = 48;
+struct WgradJob { const float* part; float* dW; float* db; int chunks, Cout, entries, pad; };
+struct WgradJobs { WgradJob j[WD_MAXJOBS]; };
+__global__ __launch_bounds__(IT_THREADS) void conv_wgrad_reduce_multi_kernel(const WgradJobs jobs) {
+  const WgradJob jb = jobs.j[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int rowlen = jb.entries + 1;
+  const int total = jb.Cout * rowlen;
+  for (int i = blockIdx.x * (IT_THREADS / 64) + (threadIdx.x >> 6); i < total; i += gridDim.x * (IT_THREADS / 64)) {
+    double s = 0.0;
+    for (int c = lane; c < jb.chunks; c += 64) s += (double)jb.part[(size_t)c * total + i];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+    if (lane == 0) {
+      const int co = i / rowlen, r = i - co * rowlen;
+      if (r < jb.entries) jb.dW[(size_t)co * jb.entries + r] = (float)s;
+      else if (jb.db) jb.db[co] = (float)s;
+    }
+  }
+}
+
+struct WgradDefer {
+  bool on = false;
+  int n = 0;
+  WgradJobs jobs;
+};
+static thread_local WgradDefer g_wgrad_defer;
+
+}  // namespace
+// begin collecting (the caller guarantees distinct `part` regions per layer until the flush); flush launches the one reduction
+void wgrad_defer_begin() {
+  g_wgrad_defer.on = true;
+  g_wgrad_defer.n = 0;
+}
+int wgrad_defer_flush(hipStream_t st) {
+  WgradDefer& d = g_wgrad_defer;
+  d.on = false;
+  if (d.n == 0) return MURAL_OK;
+  int most = 0;
+  for (int k = 0; k < d.n; ++k) most = std::max(most, d.jobs.j[k].Cout * (d.jobs.j[k].entries + 1));
+  const int gx = std::min((most + 3) / 4, 256);
+  hipLaunchKernelGGL(conv_wgrad_reduce_multi_kernel, dim3(gx, d.n), dim3(IT_THREADS), 0, st, d.jobs);
+  d.n = 0;
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+namespace {
+
 // ------------------------------------------------------------------------------------------------ activations
 // kind: 1 ReLU, 2 SiLU, 3 Softplus (beta 1, linear above 20, like torch.nn.Softplus)
 __device__ __forceinline__ float act_f(float v, int kind) {
@@ -806,6 +856,10 @@ static int convg_bwd_impl(const float* dy, const float* x, const float* W, const
 #undef MURAL_WGRAD_TL
 #undef MURAL_WGRAD
   MURAL_HIP_CHECK(hipGetLastError());
+  if (g_wgrad_defer.on && g_wgrad_defer.n < WD_MAXJOBS) {      // reduced with every other layer's rows by wgrad_defer_flush
+    g_wgrad_defer.jobs.j[g_wgrad_defer.n++] = WgradJob{part, dW, db, chunks, Cout, entries, 0};
+    return MURAL_OK;
+  }
   hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((Cout * (entries + 1) + 3) / 4), dim3(IT_THREADS), 0, st, part, chunks, Cout,
                      entries, dW, db);
   MURAL_HIP_CHECK(hipGetLastError());

@@ -15,6 +15,11 @@
 
 using namespace mural;
 
+namespace mural {
+void wgrad_defer_begin();                 // indel_train.hip: collect the weight-gradient partial rows of the layers that follow ...
+int wgrad_defer_flush(hipStream_t st);    // ... and reduce them all in one launch
+}
+
 namespace {
 
 constexpr int IL = 6;      // U-Net levels
@@ -88,6 +93,8 @@ struct Unit {
   float *y0, *z, *state;
   double *acc_f, *acc_b;
   float *wt_fwd, *wt_dgrad;             // this step's kernel layouts of W
+  float* part;                          // this unit's weight-gradient partial rows (reduced at the end of the backward)
+  size_t part_floats;
   int job;                              // index into the relayout job table
 };
 
@@ -260,8 +267,11 @@ int make_plan(const MuralIndelShape& sh, const MuralIndelParams* p, const MuralI
     P.gh[i] = A.f(2 * n);
     dy0max = std::max(dy0max, 2 * n);
   }
-  for (Unit& u : P.u) partmax = std::max(partmax, mural_op_convg_bwd_scratch(u.Cin, u.Cout, u.K));
-  partmax = std::max(partmax, mural_op_convg_bwd_scratch(P.C[0], P.C[0], 1));
+  for (Unit& u : P.u) {
+    u.part_floats = mural_op_convg_bwd_scratch(u.Cin, u.Cout, u.K);
+    u.part = A.f(u.part_floats);
+  }
+  partmax = mural_op_convg_bwd_scratch(P.C[0], P.C[0], 1);
   P.dy0 = A.f(dy0max);
   P.part = A.f(partmax);
   P.part_floats = partmax;
@@ -280,7 +290,7 @@ int unit_fwd(const Plan& P, Unit& u, const float* x, const float* res1, const fl
 // dW / db / dgamma / dbeta of the unit go to its gradient slots (or to alternative destinations), dx optional
 int unit_bwd(const Plan& P, const Unit& u, const float* x, const float* dz, float* dx, float* gW, float* gb, float* gga, float* gbe, hipStream_t st) {
   return mural_op_convg_bn_bwd(dz, x, u.W, u.y0, u.state, u.gamma, P.B, u.Cin, u.Lin, u.Cout, u.K, u.stride, u.pad, u.up, u.act, u.acc_b, P.dy0, dx,
-                               gW, u.bias ? gb : nullptr, gga, gbe, P.part, P.part_floats, u.up == 1 ? u.wt_dgrad : nullptr, st);
+                               gW, u.bias ? gb : nullptr, gga, gbe, u.part, u.part_floats, u.up == 1 ? u.wt_dgrad : nullptr, st);
 }
 
 int relayout_all(const Plan& P, const MuralIndelParams& p, hipStream_t st) {
@@ -410,6 +420,14 @@ extern "C" int mural_indel_train_backward(const MuralIndelShape* shape, const Mu
   MURAL_HIP_CHECK(hipMemsetAsync(P.acc_b, 0, P.acc_b_bytes, st));
   const int C0 = P.C[0], L0 = P.L[0];
   const int64_t n0 = (int64_t)P.B * C0 * L0;
+  // every conv layer leaves its weight-gradient partial rows in its own region; ONE launch reduces them all (before the two
+  // strand-symmetry terms are summed).  The guard object ends the collection on every exit path.
+  struct DeferGuard {
+    hipStream_t st;
+    bool flushed = false;
+    ~DeferGuard() { if (!flushed) (void)wgrad_defer_flush(st); }
+  } defer{st};
+  wgrad_defer_begin();
   // ---- the forward's tensor links (make_plan lays the units out; the inputs / residuals are re-derived, not stored)
   size_t ui = P.rev ? 2 : 0;
   const float* h = P.rev ? P.s2f : x;
@@ -502,6 +520,8 @@ extern "C" int mural_indel_train_backward(const MuralIndelShape* shape, const Mu
       if (int rc = flip(dh0, nullptr, dflip, P.B, 4, P.Lx, 0, st)) return rc;
       float *tW = P.tmpW, *tb = P.tmpW + ((nW + 3) & ~3), *tg = tb + 4, *tbe = tg + 4;
       if (int rc = unit_bwd(P, s_b, P.xf, dflip, nullptr, tW, tb, tg, tbe, st)) return rc;
+      defer.flushed = true;
+      if (int rc = wgrad_defer_flush(st)) return rc;
       if (int rc = add2(s_a.gW, tW, s_a.gW, nW, st)) return rc;
       if (int rc = add2(s_a.gbias, tb, s_a.gbias, 4, st)) return rc;
       if (int rc = add2(s_a.ggamma, tg, s_a.ggamma, 4, st)) return rc;
@@ -509,6 +529,10 @@ extern "C" int mural_indel_train_backward(const MuralIndelShape* shape, const Mu
     } else {
       if (int rc = unit_bwd(P, ua, unit_in[a], s1, nullptr, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
     }
+  }
+  if (!defer.flushed) {
+    defer.flushed = true;
+    return wgrad_defer_flush(st);
   }
   return MURAL_OK;
 }
