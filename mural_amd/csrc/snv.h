@@ -142,6 +142,10 @@ struct SnvFwdArgs {
   // Wave-private launch (snv_tower_wave.hip; stage-split launches of the throughput path): P counts the sites of ONE WAVE, nbuf
   // the floats of one wave's image, geom is laid out for P sites per wave.
   int wave;
+  // wave-private launch: units are handed out through this counter (zero before the launch) instead of a fixed stride -- the two
+  // waves that share a SIMD do not run at the same speed (the older wave slot wins the issue arbitration), so with equal shares
+  // the favoured half of the waves is done at 0.72 of the launch and the rest finishes alone; nullptr: fixed stride
+  int* unit_counter;
   int stagger;                    // wave-private launch: late start of every second workgroup of a CU, in units of 8128 cycles
 };
 

@@ -271,7 +271,7 @@ constexpr size_t kLdsMax = 160 * 1024;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; float* s3[2]; };
+struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; float* s3[2]; int* counters; };
 
 size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
   size_t off = 0;
@@ -290,6 +290,7 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
   const size_t o_xl = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * SNV_MAXCLASS * 4);
   const size_t o_s3l = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
   const size_t o_s3m = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
+  const size_t o_cnt = take(64);      // unit counters of the four wave-private launches of a chunk (SnvFwdArgs::unit_counter)
   if (w) {
     char* b = static_cast<char*>(base);
     w->local_logits = reinterpret_cast<float*>(b + o_ll);
@@ -299,6 +300,7 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
     w->xlogit = reinterpret_cast<float*>(b + o_xl);
     w->s3[0] = reinterpret_cast<float*>(b + o_s3l);
     w->s3[1] = reinterpret_cast<float*>(b + o_s3m);
+    w->counters = reinterpret_cast<int*>(b + o_cnt);
   }
   return off;
 }
@@ -518,6 +520,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     else s.codes = s1.codes + c0 * m->shape.distal_len;
     if (int rc = launch_snv_stage1(s, packed, s.loc_on ? std::max(m->s1_lds_bytes, m->loc_lds) : m->s1_lds_bytes, stream)) return rc;
     const bool split = m->split && taps == nullptr && !small;   // the debug dump wants both towers in one tile geometry
+    if (split) MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
     for (int part = 0; part < (split ? 4 : 1); ++part) {
       SnvFwdArgs t = split ? m->args_split[part] : (small ? m->args_small : a);
       t.s3[0] = w.s3[0];
@@ -536,6 +539,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       t.tap_stride = a.nbuf;
       t.stamps = packed ? g_stamps : nullptr;
       t.status = status;
+      t.unit_counter = split && t.wave ? w.counters + part : nullptr;
       const size_t lds = split ? m->lds_split[part] : (small ? m->lds_small : m->lds_bytes);
       if (int rc = launch_snv_towers(m, t, lds, stream)) return rc;
     }

@@ -464,6 +464,7 @@ struct ReuseWs {
   float* local_logits;
   float* xlogit;
   float* s3[2];
+  int* counters;
 };
 
 size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands, void* base, ReuseWs* w) {
@@ -486,6 +487,7 @@ size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands,
   const size_t o_xl = take((size_t)ns * SNV_MAXCLASS * 4);
   const size_t o_s3l = take((size_t)ns * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
   const size_t o_s3m = take((size_t)ns * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
+  const size_t o_cnt = take(64);      // unit counters of the wave-private launches (SnvFwdArgs::unit_counter)
   if (w) {
     char* b = static_cast<char*>(base);
     for (int st = 0; st < 2; ++st)
@@ -495,6 +497,7 @@ size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands,
     w->xlogit = reinterpret_cast<float*>(b + o_xl);
     w->s3[0] = reinterpret_cast<float*>(b + o_s3l);
     w->s3[1] = reinterpret_cast<float*>(b + o_s3m);
+    w->counters = reinterpret_cast<int*>(b + o_cnt);
   }
   return off;
 }
@@ -695,6 +698,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       hipLaunchKernelGGL(snv_edge_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, 2048)), dim3(SNV_THREADS), lds_edge, stream, e);
       MURAL_HIP_CHECK(hipGetLastError());
     }
+    MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
     for (int part = 2; part < 4; ++part) {
       SnvFwdArgs t = m->args_split[part];
       t.s3[0] = w.s3[0];
@@ -708,6 +712,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       t.tap_stride = 0;
       t.stamps = nullptr;
       t.status = nullptr;
+      t.unit_counter = t.wave ? w.counters + part : nullptr;
       if (int rc = launch_snv_towers(m, t, m->lds_split[part], stream)) return rc;
     }
   }

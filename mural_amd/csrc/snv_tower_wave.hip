@@ -27,16 +27,19 @@
 namespace mural {
 
 constexpr int TW_NBW = 9;            // 16-column blocks a wave owns at most
+constexpr int TW_DUMP = 128;          // floats per wave behind its LDS regions: 32 16-byte dump slots (lane & 31)
 constexpr uint32_t TW_BLK = 2048u;   // bytes between consecutive blocks of the image (16 columns x 128 B; the swizzle key has period 16)
 
 struct WaveAddr {
   uint32_t rd[6];    // byte offset of B-operand chunk (tap t, half h) for block 0: rd[2t+h]
   uint32_t wr[2];    // byte offset of this lane's output chunk of M-block 0 / 1 for block 0
   uint32_t vmask;    // bit b: this lane's column of block b carries data (not separator / padding)
+  uint32_t dump;     // byte offset (from the image) of this lane's dump slot: where the lanes of gap columns store (TW_DUMP)
 };
 
-__device__ __forceinline__ WaveAddr wave_setup(const TowerGeom& g, int st, int Pw, int n16, int kk) {
+__device__ __forceinline__ WaveAddr wave_setup(const TowerGeom& g, int st, int Pw, int n16, int kk, uint32_t dump0) {
   WaveAddr a;
+  a.dump = dump0 + 16u * (uint32_t)((16 * kk + n16) & 31);
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
@@ -80,52 +83,47 @@ __device__ __forceinline__ void load_frag4(float (&a0)[SNV_KSTEPS], float (&a1)[
   a1[4 * g + 3] = v.w;
 }
 
-// One slot of a block's epilogue (see epilogue() in snv_tower_conv.h: the same arithmetic, cut into eight pieces so that each piece
-// can sit behind one pair of MFMAs of the NEXT block): slots 0-3 build o = ps * max(acc, lo) + pt, 4-5 update the residual stream,
-// 6 masks separator / padding columns, 7 stores the 16-byte chunk.
-template <int R, bool FINAL>
-__device__ __forceinline__ void epi_slot(const LayerK& k, const f32x4& acc, f32x4& xr, f32x4& o, bool valid, const f32x4& ps,
-                                         const f32x4& pt, char* img, uint32_t off) {
-  if constexpr (R == 0) {
-    o.x = fmaxf(acc.x, k.lo);
-    o.y = fmaxf(acc.y, k.lo);
-  } else if constexpr (R == 1) {
-    o.z = fmaxf(acc.z, k.lo);
-    o.w = fmaxf(acc.w, k.lo);
-  } else if constexpr (R == 2) {
-    o.x = fmaf(ps.x, o.x, pt.x);
-    o.y = fmaf(ps.y, o.y, pt.y);
-  } else if constexpr (R == 3) {
-    o.z = fmaf(ps.z, o.z, pt.z);
-    o.w = fmaf(ps.w, o.w, pt.w);
-  } else if constexpr (R == 4) {
-    if constexpr (!FINAL) {      // the last layer of a launch: the residual registers are dead (and may already hold prefetched data)
-      xr.x = fmaf(acc.x, k.ku, xr.x * k.kx);
-      xr.y = fmaf(acc.y, k.ku, xr.y * k.kx);
-    }
-  } else if constexpr (R == 5) {
-    if constexpr (!FINAL) {
-      xr.z = fmaf(acc.z, k.ku, xr.z * k.kx);
-      xr.w = fmaf(acc.w, k.ku, xr.w * k.kx);
-    }
-  } else if constexpr (R == 6) {
-    o = valid ? o : splat(0.f);
-  } else {
-    lds_st4(img, off, o);
+// One conv tap (8 k-steps) of a block for both M-blocks -- the two accumulator chains alternate, pair by pair -- with the PREVIOUS
+// block's epilogue of one M-block (epi_burst) behind the first pair.  A scheduling barrier closes every pair: the
+// backend's own grouping serialises each chain (8 dependent MFMAs in a row: 40 instead of 32 cycles each).
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// The whole epilogue of one M-block of a block as ONE burst of vector instructions (measured, tools/microbench/mfma_valu.hip: vector
+// ALU work does not run beside this wave's or its SIMD partner's MFMAs -- every v_* instruction costs 2.5 - 5 cycles of MFMA issue and
+// every switch MFMA -> VALU -> MFMA a further 8 - 16 -- so the epilogue is as few instructions in as few groups as it can be):
+// packed fp32 forms for the BatchNorm map and the residual update, separator / padding lanes masked at the store.  Same roundings as epilogue() in snv_tower_conv.h.
+template <bool FINAL>
+__device__ __forceinline__ void epi_burst(const LayerK& k, const f32x4& acc, f32x4& xr, const f32x4& ps, const f32x4& pt, char* img,
+                                          uint32_t off, bool valid, uint32_t dump) {
+  f32x2 o01 = {fmaxf(acc.x, k.lo), fmaxf(acc.y, k.lo)}, o23 = {fmaxf(acc.z, k.lo), fmaxf(acc.w, k.lo)};
+  o01 = __builtin_elementwise_fma(f32x2{ps.x, ps.y}, o01, f32x2{pt.x, pt.y});
+  o23 = __builtin_elementwise_fma(f32x2{ps.z, ps.w}, o23, f32x2{pt.z, pt.w});
+  if constexpr (!FINAL) {      // the last layer of a launch: the residual registers are dead (and may already hold prefetched data)
+    const f32x2 ku = {k.ku, k.ku}, kx = {k.kx, k.kx};
+    const f32x2 x01 = __builtin_elementwise_fma(f32x2{acc.x, acc.y}, ku, f32x2{xr.x, xr.y} * kx);
+    const f32x2 x23 = __builtin_elementwise_fma(f32x2{acc.z, acc.w}, ku, f32x2{xr.z, xr.w} * kx);
+    xr = f32x4{x01.x, x01.y, x23.x, x23.y};
   }
+  // separator / padding columns are zero when a stage starts and stay zero: their lanes store into the wave's dump slots instead
+  // (one select on the address instead of four on the values; no branch)
+  lds_st4(img, valid ? off : dump, f32x4{o01.x, o01.y, o23.x, o23.y});
 }
 
-// One conv tap (8 k-steps) of a block for both M-blocks -- the two accumulator chains alternate, pair by pair -- with slot (pair
-// index) of the PREVIOUS block's epilogue for M-block `EM` behind every pair.  A scheduling barrier closes every pair: the
-// backend's own grouping serialises each chain (8 dependent MFMAs in a row: 40 instead of 32 cycles each).
+__device__ __forceinline__ f32x4 acc_init_pk(const LayerK& k, const f32x4& pb, const f32x4& xr) {
+  const f32x2 kr = {k.kr, k.kr};
+  const f32x2 a01 = __builtin_elementwise_fma(f32x2{xr.x, xr.y}, kr, f32x2{pb.x, pb.y});
+  const f32x2 a23 = __builtin_elementwise_fma(f32x2{xr.z, xr.w}, kr, f32x2{pb.z, pb.w});
+  return f32x4{a01.x, a01.y, a23.x, a23.y};
+}
+
 template <int T, bool EPI, bool FINAL>
 __device__ __forceinline__ void mfma_tap_epi(const float (&a0)[SNV_KSTEPS], const float (&a1)[SNV_KSTEPS], const f32x4 (&bv)[2], f32x4& acc0,
-                                             f32x4& acc1, const LayerK& k, const f32x4& pa, f32x4& xr, f32x4& o, bool valid, const f32x4& ps,
-                                             const f32x4& pt, char* img, uint32_t off) {
+                                             f32x4& acc1, const LayerK& k, const f32x4& pa, f32x4& xr, const f32x4& ps,
+                                             const f32x4& pt, char* img, uint32_t off, bool valid, uint32_t dump) {
 #define MURAL_TAP_PAIR(I)                                                                                       \
   acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[8 * T + (I)], bv[(I) >> 2][(I) & 3], acc0, 0, 0, 0);          \
   acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[8 * T + (I)], bv[(I) >> 2][(I) & 3], acc1, 0, 0, 0);          \
-  if constexpr (EPI) epi_slot<(I), FINAL>(k, pa, xr, o, valid, ps, pt, img, off);                               \
+  if constexpr (EPI && (I) == 0) epi_burst<FINAL>(k, pa, xr, ps, pt, img, off, valid, dump);                    \
   __builtin_amdgcn_sched_barrier(0);
   MURAL_TAP_PAIR(0)
   MURAL_TAP_PAIR(1)
@@ -174,7 +172,7 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
     Y[h] = lds_ld4(img, sa.rd[2 + h]);
     Z[h] = lds_ld4(img, sa.rd[4 + h]);
   }
-  f32x4 pa0 = splat(0.f), pa1 = splat(0.f), o0 = splat(0.f), o1 = splat(0.f);
+  f32x4 pa0 = splat(0.f), pa1 = splat(0.f);
   __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
   for (int b = 0; b < NB; ++b) {
@@ -183,7 +181,7 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
     const bool vprev = (sa.vmask >> bp) & 1u;
     // USEX == false: a layer whose accumulators start from the bias alone (kr == 0) must not touch the residual registers --
     // in the short-stage launches they already hold the next unit's input tile
-    f32x4 acc0 = USEX ? acc_init(k, pb[0], xr0[b]) : pb[0], acc1 = USEX ? acc_init(k, pb[1], xr1[b]) : pb[1];
+    f32x4 acc0 = USEX ? acc_init_pk(k, pb[0], xr0[b]) : pb[0], acc1 = USEX ? acc_init_pk(k, pb[1], xr1[b]) : pb[1];
     __builtin_amdgcn_sched_barrier(0);
     if (FINAL && xq.on) {
       const uint32_t vo = xreq_offset(xq, b);
@@ -191,7 +189,7 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
       xr1[b] = buf_ld4(xq.base, vo + 64u);
       __builtin_amdgcn_sched_barrier(0);
     }
-    mfma_tap_epi<0, false, FINAL>(a0, a1, X, acc0, acc1, k, pa0, xr0[bp], o0, vprev, ps[0], pt[0], img, 0u);
+    mfma_tap_epi<0, false, FINAL>(a0, a1, X, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, 0u, true, 0u);
     // tap-0 operands of the next block: read BEFORE this block's epilogue overwrites image column 16(b+1) (in-place rule)
     if (!last) {
 #pragma unroll
@@ -202,8 +200,8 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
     }
     __builtin_amdgcn_sched_barrier(0);
     // the previous block's epilogue rides behind this block's tap-1 (M-block 0) and tap-2 (M-block 1) MFMA pairs
-    if (b > 0) mfma_tap_epi<1, true, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], o0, vprev, ps[0], pt[0], img, sa.wr[0] + TW_BLK * bp);
-    else mfma_tap_epi<1, false, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], o0, vprev, ps[0], pt[0], img, 0u);
+    if (b > 0) mfma_tap_epi<1, true, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, sa.wr[0] + TW_BLK * bp, vprev, sa.dump);
+    else mfma_tap_epi<1, false, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, 0u, true, 0u);
     if (!last) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) Y[h] = lds_ld4(img, sa.rd[2 + h] + TW_BLK * (b + 1));
@@ -212,8 +210,8 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
       load_frag4(a0, a1, wn, 3);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (b > 0) mfma_tap_epi<2, true, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], o1, vprev, ps[1], pt[1], img, sa.wr[1] + TW_BLK * bp);
-    else mfma_tap_epi<2, false, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], o1, vprev, ps[1], pt[1], img, 0u);
+    if (b > 0) mfma_tap_epi<2, true, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], ps[1], pt[1], img, sa.wr[1] + TW_BLK * bp, vprev, sa.dump);
+    else mfma_tap_epi<2, false, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], ps[1], pt[1], img, 0u, true, 0u);
     if (!last) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) Z[h] = lds_ld4(img, sa.rd[4 + h] + TW_BLK * (b + 1));
@@ -227,10 +225,10 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
   }
   // the last block's epilogue has no MFMAs to hide behind
   {
-    const bool v = (sa.vmask >> (NB - 1)) & 1u;
     f32x4 dx0 = xr0[NB - 1], dx1 = xr1[NB - 1];      // FINAL: the registers may hold prefetched data, the update goes to a dead copy
-    epilogue(k, pa0, FINAL ? dx0 : xr0[NB - 1], v, ps[0], pt[0], img, sa.wr[0] + TW_BLK * (NB - 1));
-    epilogue(k, pa1, FINAL ? dx1 : xr1[NB - 1], v, ps[1], pt[1], img, sa.wr[1] + TW_BLK * (NB - 1));
+    const bool v = (sa.vmask >> (NB - 1)) & 1u;
+    epi_burst<FINAL>(k, pa0, FINAL ? dx0 : xr0[NB - 1], ps[0], pt[0], img, sa.wr[0] + TW_BLK * (NB - 1), v, sa.dump);
+    epi_burst<FINAL>(k, pa1, FINAL ? dx1 : xr1[NB - 1], ps[1], pt[1], img, sa.wr[1] + TW_BLK * (NB - 1), v, sa.dump);
   }
 }
 
@@ -363,14 +361,24 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
   const int Pw = args.P;
   const int tw_i = args.tw_first;
   unsigned long long t_prev = args.stamps != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
+  // diagnostic: wall-clock (100 MHz) start / end of every wave of the last launch of each (phase, tower), rows 1024.. of the stamp buffer
+  if (args.stamps != nullptr && lane == 0) {
+    unsigned long long* row = args.stamps + (size_t)(1024 + 2 * blockIdx.x + (wave >> 1)) * 32;
+    row[((PHASE - 1) * 2 + tw_i) * 4 + 2 * (wave & 1)] = __builtin_amdgcn_s_memrealtime();
+    if (PHASE == 1 && tw_i == 0) {
+      row[16 + 2 * (wave & 1)] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_ID
+      row[17 + 2 * (wave & 1)] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // XCC_ID
+    }
+  }
   const TowerGeom& g = args.geom[tw_i];
   const TowerDev& tw = args.tw[tw_i];
-  // LDS: par (shared, read-only after the first barrier) | per wave: image [nbuf] | feat [Pw][32] | logit [3][Pw][16]
+  // LDS: par (shared, read-only after the first barrier) | per wave: image [nbuf] | feat [Pw][32] | logit [3][Pw][16] | dump [TW_DUMP]
   // par: ex_s[4][32] | ex_t[4][32] | fc_w[nc][32] | fc_b[16] | arrival slot[4] | lpar[6 layers][3: bias, post_s, post_t][32]
   const int lpar0 = 2 * EX_COUNT * SNV_C + args.n_class * SNV_C + SNV_MAXCLASS + 4;
   const int par_floats = lpar0 + 6 * 3 * SNV_C;
   float* par = smem;
-  const int wave_floats = args.nbuf + (PHASE == 2 ? Pw * SNV_C + 3 * Pw * SNV_MAXCLASS : 0);
+  const int wave_floats = args.nbuf + (PHASE == 2 ? Pw * SNV_C + 3 * Pw * SNV_MAXCLASS : 0) + TW_DUMP;
+  const uint32_t dump0 = 4u * (uint32_t)(wave_floats - TW_DUMP);      // dump slots: the last TW_DUMP floats of the wave's region
   float* img = smem + par_floats + wave * wave_floats;
   float* feat = img + args.nbuf;
   float* logit = feat + Pw * SNV_C;
@@ -411,8 +419,19 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
     for (int i = 0; i < args.stagger; ++i) __builtin_amdgcn_s_sleep(127);
 
   const int64_t n_units = (args.n + Pw - 1) / Pw;
-  const int64_t unit0 = (int64_t)blockIdx.x * SNV_WAVES + wave;
+  // Units come from a counter (args.unit_counter, zero at launch) when there is one: the two waves of a SIMD do not share it evenly
+  // (the older wave slot wins the arbitration: with a fixed stride half the waves are done at 0.72 of the launch and their partners
+  // finish alone).  The ticket of the unit after the next one is requested a whole unit ahead, so its round trip is never waited for;
+  // which wave computes a unit does not change a bit of the unit's result.
+  const bool dyn = args.unit_counter != nullptr;
   const int64_t unit_step = (int64_t)gridDim.x * SNV_WAVES;
+  int ticket = 0;
+  int64_t unit0 = (int64_t)blockIdx.x * SNV_WAVES + wave;
+  if (dyn) {
+    if (lane == 0) ticket = atomicAdd(args.unit_counter, 1);
+    unit0 = __builtin_amdgcn_readfirstlane(ticket);
+    if (lane == 0) ticket = atomicAdd(args.unit_counter, 1);
+  }
   char* imgb = reinterpret_cast<char*>(img);
   const int chv0 = 4 * kk, chv1 = 16 + 4 * kk;
 
@@ -426,7 +445,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
   fsrc.layer_bytes = (uint32_t)first_layer * SNV_WFRAG * 4u;
 #pragma unroll
   for (int g4 = 0; g4 < SNV_KSTEPS / 4; ++g4) load_frag4(a0, a1, fsrc, g4);
-  const WaveAddr sa_a = wave_setup(g, PHASE == 1 ? 0 : 1, Pw, n16, kk);
+  const WaveAddr sa_a = wave_setup(g, PHASE == 1 ? 0 : 1, Pw, n16, kk, dump0);
   if (PHASE == 1) wave_request_x0(args, xr0, xr1, unit0, n_units, tw_i, n16, kk);
   const bool do_head = PHASE == 2 && args.tw_last == 1 && args.tw_first == 1;
   bool tile_ready = false;      // PHASE 2: the residual registers hold this unit's input tile (requested during the previous unit)
@@ -441,8 +460,14 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
   xoff.kk16 = 16u * (uint32_t)kk;
   xoff.on = false;
 
-  for (int64_t unit = unit0; unit < n_units; unit += unit_step) {
+  for (int64_t unit = unit0, next_unit = 0; unit < n_units; unit = next_unit) {
     const int64_t row0 = unit * Pw;
+    if (dyn) {
+      next_unit = __builtin_amdgcn_readfirstlane(ticket);
+      if (lane == 0) ticket = atomicAdd(args.unit_counter, 1);
+    } else {
+      next_unit = unit + unit_step;
+    }
     // ------------------------------------------------------------------ entry
     if (PHASE == 1) {
       const f32x4 es0 = ld4(par + EX_RB1_ENTRY * 32 + chv0), et0 = ld4(par + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv0);
@@ -512,7 +537,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       SNVW_STAMP(2);      // convs but the last
       // last layer: block by block the dying residual registers take the next unit's stage-1 activations (a whole next unit;
       // a ragged or missing one is requested the guarded way behind the layer)
-      const int64_t nu = unit + unit_step;
+      const int64_t nu = next_unit;
       XReq xq = xoff;
       xq.on = nu < n_units && (nu + 1) * Pw <= args.n;
       if (xq.on) {
@@ -531,7 +556,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       {
         // the residual registers are dead from here on: the next unit's input tile travels in them under the pooling, the last
         // conv, the global max and the head (a whole next unit; a ragged one is loaded the guarded way at its entry)
-        const int64_t nu = unit + unit_step;
+        const int64_t nu = next_unit;
         tile_ready = nu < n_units && (nu + 1) * Pw <= args.n;
         if (tile_ready) {
           const int total = Pw * g.L[1] * 8;
@@ -573,7 +598,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
         }
         wave_zero_gaps(img, g, 2, Pw, lane);
       }
-      const WaveAddr sa_b = wave_setup(g, 2, Pw, n16, kk);
+      const WaveAddr sa_b = wave_setup(g, 2, Pw, n16, kk, dump0);
       SNVW_STAMP(3);      // max-pool 3
       run_layer(9, std::true_type{}, sa_b, TagB{}, g.nb[2], xoff);
       SNVW_STAMP(4);      // last conv
@@ -683,6 +708,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
     }
     SNVW_STAMP(5);      // global max, fc, head
   }
+  if (args.stamps != nullptr && lane == 0)
+    args.stamps[(size_t)(1024 + 2 * blockIdx.x + (wave >> 1)) * 32 + ((PHASE - 1) * 2 + tw_i) * 4 + 2 * (wave & 1) + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
 // per-wave geometry: Pw sites per wave; returns the LDS bytes of a four-wave workgroup (0: does not fit a wave)
@@ -724,7 +751,7 @@ size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int towe
   a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
   a.nbuf = maxcols * SNV_C;
   const size_t par = (size_t)(2 * EX_COUNT * SNV_C + n_class * SNV_C + SNV_MAXCLASS + 4 + 6 * 3 * SNV_C);
-  const size_t per_wave = (size_t)a.nbuf + (phase == 2 ? (size_t)Pw * SNV_C + 3 * (size_t)Pw * SNV_MAXCLASS : 0);
+  const size_t per_wave = (size_t)a.nbuf + (phase == 2 ? (size_t)Pw * SNV_C + 3 * (size_t)Pw * SNV_MAXCLASS : 0) + TW_DUMP;
   return (par + SNV_WAVES * per_wave) * 4;
 }
 

@@ -591,7 +591,7 @@ def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch
         assert torch.isfinite(out).all()
         layout = (C.c_size_t * 64)()
         n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 32)      # the carve of the call just made (this thread's latest)
-        assert n_regions == 7
+        assert n_regions == 8
         ws = model._ws.cpu().numpy()
         for i in range(n_regions):
             off, size = layout[2 * i], layout[2 * i + 1]

@@ -16,19 +16,23 @@ model = model_choice(0, cfg, dict(n_class=8), "indel")
 model.apply(weights_init)
 model = model.cuda().eval()
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+MODE = sys.argv[2] if len(sys.argv) > 2 else "both"      # dense | packed | both
 codes = torch.randint(0, 4, (B, 8000), device="cuda")
 x = torch.nn.functional.one_hot(codes, 4).permute(0, 2, 1).float().contiguous()
 with torch.no_grad():
-    for _ in range(2):
+    for _ in range(2 if MODE != "packed" else 0):
         model(x)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(5 if MODE != "packed" else 0):
         model(x)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
-print("UNet_Small insertion L=8000: %.1f positions/s (%.2f ms per %d), %.1f TFLOP/s algorithmic (113.4 MFLOP/pos)"
-      % (B / dt, dt * 1e3, B, B / dt * 113.4e6 / 1e12))
+if MODE != "packed":
+    print("UNet_Small insertion L=8000: %.1f positions/s (%.2f ms per %d), %.1f TFLOP/s algorithmic (113.4 MFLOP/pos)"
+          % (B / dt, dt * 1e3, B, B / dt * 113.4e6 / 1e12))
+if MODE == "dense":
+    sys.exit(0)
 
 # the packed entry (window decode + input conv inside the first level's kernel)
 from mural_amd.data import PackedGenome  # noqa: E402
