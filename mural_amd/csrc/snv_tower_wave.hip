@@ -109,6 +109,12 @@ __device__ __forceinline__ void epi_burst(const LayerK& k, const f32x4& acc, f32
   lds_st4(img, valid ? off : dump, f32x4{o01.x, o01.y, o23.x, o23.y});
 }
 
+__device__ __forceinline__ f32x4 relu_bn_pk(const f32x4& v, const f32x4& s, const f32x4& t) {
+  const f32x2 o01 = __builtin_elementwise_fma(f32x2{s.x, s.y}, f32x2{fmaxf(v.x, 0.f), fmaxf(v.y, 0.f)}, f32x2{t.x, t.y});
+  const f32x2 o23 = __builtin_elementwise_fma(f32x2{s.z, s.w}, f32x2{fmaxf(v.z, 0.f), fmaxf(v.w, 0.f)}, f32x2{t.z, t.w});
+  return f32x4{o01.x, o01.y, o23.x, o23.y};
+}
+
 __device__ __forceinline__ f32x4 acc_init_pk(const LayerK& k, const f32x4& pb, const f32x4& xr) {
   const f32x2 kr = {k.kr, k.kr};
   const f32x2 a01 = __builtin_elementwise_fma(f32x2{xr.x, xr.y}, kr, f32x2{pb.x, pb.y});
@@ -403,6 +409,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
     const int st0 = PHASE == 1 ? 0 : 1;
     if (lane < 8) st4(img + lds_off(0, lane), splat(0.f));
     else if (lane < 16) st4(img + lds_off(16 * g.nb[st0] + 1, lane - 8), splat(0.f));
+    if (PHASE == 1) wave_zero_gaps(img, g, 0, Pw, lane);      // once: no layer of this launch stores into a gap column
   }
   if (args.stagger > 0 && tid == 0) {
     const uint32_t key = cu_key();
@@ -472,12 +479,13 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
     if (PHASE == 1) {
       const f32x4 es0 = ld4(par + EX_RB1_ENTRY * 32 + chv0), et0 = ld4(par + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv0);
       const f32x4 es1 = ld4(par + EX_RB1_ENTRY * 32 + chv1), et1 = ld4(par + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv1);
+      // the gap columns were zeroed when the kernel started and nothing stores into them (their lanes aim at the dump slots)
 #pragma unroll
       for (int b = 0; b < TW_NBW; ++b)
-        if (b < g.nb[0]) {
+        if (b < (NBA > 0 ? NBA : g.nb[0])) {
           const bool v = (sa_a.vmask >> b) & 1u;
-          lds_st4(imgb, sa_a.wr[0] + TW_BLK * b, v ? relu_bn(xr0[b], es0, et0) : splat(0.f));
-          lds_st4(imgb, sa_a.wr[1] + TW_BLK * b, v ? relu_bn(xr1[b], es1, et1) : splat(0.f));
+          lds_st4(imgb, v ? sa_a.wr[0] + TW_BLK * b : sa_a.dump, relu_bn_pk(xr0[b], es0, et0));
+          lds_st4(imgb, v ? sa_a.wr[1] + TW_BLK * b : sa_a.dump, relu_bn_pk(xr1[b], es1, et1));
         }
     } else {
       // second conv stage: its input was pooled (and BN-mapped) by the first-stage launch: s3[row][column][32], the layout of x0.
