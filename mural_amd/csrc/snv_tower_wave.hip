@@ -26,6 +26,9 @@
 
 namespace mural {
 
+template <int M>
+using ModeTag = std::integral_constant<int, M>;
+constexpr int MODE_GENERIC = -1;      // epilogue role from the run-time LayerK (layers that share one code body)
 constexpr int TW_NBW = 9;            // 16-column blocks a wave owns at most
 constexpr int TW_DUMP = 128;          // floats per wave behind its LDS regions: 32 16-byte dump slots (lane & 31)
 constexpr uint32_t TW_BLK = 2048u;   // bytes between consecutive blocks of the image (16 columns x 128 B; the swizzle key has period 16)
@@ -92,17 +95,32 @@ using f32x2 = __attribute__((ext_vector_type(2))) float;
 // ALU work does not run beside this wave's or its SIMD partner's MFMAs -- every v_* instruction costs 2.5 - 5 cycles of MFMA issue and
 // every switch MFMA -> VALU -> MFMA a further 8 - 16 -- so the epilogue is as few instructions in as few groups as it can be):
 // packed fp32 forms for the BatchNorm map and the residual update, separator / padding lanes masked at the store.  Same roundings as epilogue() in snv_tower_conv.h.
-template <bool FINAL>
+// MODE (layer_mode, compile time): the role of the layer decides which pieces exist at all -- a raw layer (MODE_RES_LAST) stores its
+// accumulators as they are (ps = 1, pt = 0, lo = -inf), only MODE_RES_FIRST / MODE_ENTRY touch the residual stream.
+template <bool FINAL, int MODE>
 __device__ __forceinline__ void epi_burst(const LayerK& k, const f32x4& acc, f32x4& xr, const f32x4& ps, const f32x4& pt, char* img,
                                           uint32_t off, bool valid, uint32_t dump) {
-  f32x2 o01 = {fmaxf(acc.x, k.lo), fmaxf(acc.y, k.lo)}, o23 = {fmaxf(acc.z, k.lo), fmaxf(acc.w, k.lo)};
-  o01 = __builtin_elementwise_fma(f32x2{ps.x, ps.y}, o01, f32x2{pt.x, pt.y});
-  o23 = __builtin_elementwise_fma(f32x2{ps.z, ps.w}, o23, f32x2{pt.z, pt.w});
+  f32x2 o01 = {acc.x, acc.y}, o23 = {acc.z, acc.w};
+  if constexpr (MODE == MODE_GENERIC) {      // role from the run-time constants (kx == 1: every layer but the entry conv)
+    o01 = __builtin_elementwise_fma(f32x2{ps.x, ps.y}, f32x2{fmaxf(acc.x, k.lo), fmaxf(acc.y, k.lo)}, f32x2{pt.x, pt.y});
+    o23 = __builtin_elementwise_fma(f32x2{ps.z, ps.w}, f32x2{fmaxf(acc.z, k.lo), fmaxf(acc.w, k.lo)}, f32x2{pt.z, pt.w});
+  } else if constexpr (MODE != MODE_RES_LAST) {
+    o01 = f32x2{fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f)};
+    o23 = f32x2{fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f)};
+    if constexpr (MODE != MODE_FINAL) {      // conv3 is raw behind its ReLU
+      o01 = __builtin_elementwise_fma(f32x2{ps.x, ps.y}, o01, f32x2{pt.x, pt.y});
+      o23 = __builtin_elementwise_fma(f32x2{ps.z, ps.w}, o23, f32x2{pt.z, pt.w});
+    }
+  }
   if constexpr (!FINAL) {      // the last layer of a launch: the residual registers are dead (and may already hold prefetched data)
-    const f32x2 ku = {k.ku, k.ku}, kx = {k.kx, k.kx};
-    const f32x2 x01 = __builtin_elementwise_fma(f32x2{acc.x, acc.y}, ku, f32x2{xr.x, xr.y} * kx);
-    const f32x2 x23 = __builtin_elementwise_fma(f32x2{acc.z, acc.w}, ku, f32x2{xr.z, xr.w} * kx);
-    xr = f32x4{x01.x, x01.y, x23.x, x23.y};
+    if constexpr (MODE == MODE_GENERIC) {
+      const f32x2 ku = {k.ku, k.ku};
+      const f32x2 x01 = __builtin_elementwise_fma(f32x2{acc.x, acc.y}, ku, f32x2{xr.x, xr.y});
+      const f32x2 x23 = __builtin_elementwise_fma(f32x2{acc.z, acc.w}, ku, f32x2{xr.z, xr.w});
+      xr = f32x4{x01.x, x01.y, x23.x, x23.y};
+    }
+    if constexpr (MODE == MODE_RES_FIRST) xr += acc;      // z = x1 + x0 keeps the outer skip (model_snv.py:477-479)
+    if constexpr (MODE == MODE_ENTRY) xr = acc;
   }
   // separator / padding columns are zero when a stage starts and stay zero: their lanes store into the wave's dump slots instead
   // (one select on the address instead of four on the values; no branch)
@@ -115,21 +133,28 @@ __device__ __forceinline__ f32x4 relu_bn_pk(const f32x4& v, const f32x4& s, cons
   return f32x4{o01.x, o01.y, o23.x, o23.y};
 }
 
+template <int MODE>
 __device__ __forceinline__ f32x4 acc_init_pk(const LayerK& k, const f32x4& pb, const f32x4& xr) {
-  const f32x2 kr = {k.kr, k.kr};
-  const f32x2 a01 = __builtin_elementwise_fma(f32x2{xr.x, xr.y}, kr, f32x2{pb.x, pb.y});
-  const f32x2 a23 = __builtin_elementwise_fma(f32x2{xr.z, xr.w}, kr, f32x2{pb.z, pb.w});
-  return f32x4{a01.x, a01.y, a23.x, a23.y};
+  if constexpr (MODE == MODE_GENERIC) {
+    const f32x2 kr = {k.kr, k.kr};
+    const f32x2 a01 = __builtin_elementwise_fma(f32x2{xr.x, xr.y}, kr, f32x2{pb.x, pb.y});
+    const f32x2 a23 = __builtin_elementwise_fma(f32x2{xr.z, xr.w}, kr, f32x2{pb.z, pb.w});
+    return f32x4{a01.x, a01.y, a23.x, a23.y};
+  } else if constexpr (MODE == MODE_RES_FIRST || MODE == MODE_RES_LAST) {
+    return pb + xr;      // accumulator starts from bias + residual
+  } else {
+    return pb;
+  }
 }
 
-template <int T, bool EPI, bool FINAL>
+template <int T, bool EPI, bool FINAL, int MODE>
 __device__ __forceinline__ void mfma_tap_epi(const float (&a0)[SNV_KSTEPS], const float (&a1)[SNV_KSTEPS], const f32x4 (&bv)[2], f32x4& acc0,
                                              f32x4& acc1, const LayerK& k, const f32x4& pa, f32x4& xr, const f32x4& ps,
                                              const f32x4& pt, char* img, uint32_t off, bool valid, uint32_t dump) {
 #define MURAL_TAP_PAIR(I)                                                                                       \
   acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[8 * T + (I)], bv[(I) >> 2][(I) & 3], acc0, 0, 0, 0);          \
   acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[8 * T + (I)], bv[(I) >> 2][(I) & 3], acc1, 0, 0, 0);          \
-  if constexpr (EPI && (I) == 0) epi_burst<FINAL>(k, pa, xr, ps, pt, img, off, valid, dump);                    \
+  if constexpr (EPI && (I) == 0) epi_burst<FINAL, MODE>(k, pa, xr, ps, pt, img, off, valid, dump);              \
   __builtin_amdgcn_sched_barrier(0);
   MURAL_TAP_PAIR(0)
   MURAL_TAP_PAIR(1)
@@ -166,7 +191,7 @@ __device__ __forceinline__ uint32_t xreq_offset(const XReq& x, int b) {
 // behind the last block's MFMAs of that group.  FINAL: last layer of a launch -- the residual registers die with each block's
 // accumulator start and are not updated; with xq.on block b's registers at once receive the next unit's stage-1 activations,
 // which then travel under the rest of the layer and the pooling instead of stalling the next entry.
-template <int NB, bool FINAL, bool USEX = true>
+template <int NB, bool FINAL, bool USEX, int MODE>
 __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, const LayerK& k, float (&a0)[SNV_KSTEPS],
                                                 float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
                                                 const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
@@ -187,7 +212,7 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
     const bool vprev = (sa.vmask >> bp) & 1u;
     // USEX == false: a layer whose accumulators start from the bias alone (kr == 0) must not touch the residual registers --
     // in the short-stage launches they already hold the next unit's input tile
-    f32x4 acc0 = USEX ? acc_init_pk(k, pb[0], xr0[b]) : pb[0], acc1 = USEX ? acc_init_pk(k, pb[1], xr1[b]) : pb[1];
+    f32x4 acc0 = USEX ? acc_init_pk<MODE>(k, pb[0], xr0[b]) : pb[0], acc1 = USEX ? acc_init_pk<MODE>(k, pb[1], xr1[b]) : pb[1];
     __builtin_amdgcn_sched_barrier(0);
     if (FINAL && xq.on) {
       const uint32_t vo = xreq_offset(xq, b);
@@ -195,7 +220,7 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
       xr1[b] = buf_ld4(xq.base, vo + 64u);
       __builtin_amdgcn_sched_barrier(0);
     }
-    mfma_tap_epi<0, false, FINAL>(a0, a1, X, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, 0u, true, 0u);
+    mfma_tap_epi<0, false, FINAL, MODE>(a0, a1, X, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, 0u, true, 0u);
     // tap-0 operands of the next block: read BEFORE this block's epilogue overwrites image column 16(b+1) (in-place rule)
     if (!last) {
 #pragma unroll
@@ -206,8 +231,8 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
     }
     __builtin_amdgcn_sched_barrier(0);
     // the previous block's epilogue rides behind this block's tap-1 (M-block 0) and tap-2 (M-block 1) MFMA pairs
-    if (b > 0) mfma_tap_epi<1, true, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, sa.wr[0] + TW_BLK * bp, vprev, sa.dump);
-    else mfma_tap_epi<1, false, FINAL>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, 0u, true, 0u);
+    if (b > 0) mfma_tap_epi<1, true, FINAL, MODE>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, sa.wr[0] + TW_BLK * bp, vprev, sa.dump);
+    else mfma_tap_epi<1, false, FINAL, MODE>(a0, a1, Y, acc0, acc1, k, pa0, xr0[bp], ps[0], pt[0], img, 0u, true, 0u);
     if (!last) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) Y[h] = lds_ld4(img, sa.rd[2 + h] + TW_BLK * (b + 1));
@@ -216,8 +241,8 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
       load_frag4(a0, a1, wn, 3);
     }
     __builtin_amdgcn_sched_barrier(0);
-    if (b > 0) mfma_tap_epi<2, true, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], ps[1], pt[1], img, sa.wr[1] + TW_BLK * bp, vprev, sa.dump);
-    else mfma_tap_epi<2, false, FINAL>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], ps[1], pt[1], img, 0u, true, 0u);
+    if (b > 0) mfma_tap_epi<2, true, FINAL, MODE>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], ps[1], pt[1], img, sa.wr[1] + TW_BLK * bp, vprev, sa.dump);
+    else mfma_tap_epi<2, false, FINAL, MODE>(a0, a1, Z, acc0, acc1, k, pa1, xr1[bp], ps[1], pt[1], img, 0u, true, 0u);
     if (!last) {
 #pragma unroll
       for (int h = 0; h < 2; ++h) Z[h] = lds_ld4(img, sa.rd[4 + h] + TW_BLK * (b + 1));
@@ -233,35 +258,35 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
   {
     f32x4 dx0 = xr0[NB - 1], dx1 = xr1[NB - 1];      // FINAL: the registers may hold prefetched data, the update goes to a dead copy
     const bool v = (sa.vmask >> (NB - 1)) & 1u;
-    epi_burst<FINAL>(k, pa0, FINAL ? dx0 : xr0[NB - 1], ps[0], pt[0], img, sa.wr[0] + TW_BLK * (NB - 1), v, sa.dump);
-    epi_burst<FINAL>(k, pa1, FINAL ? dx1 : xr1[NB - 1], ps[1], pt[1], img, sa.wr[1] + TW_BLK * (NB - 1), v, sa.dump);
+    epi_burst<FINAL, MODE>(k, pa0, FINAL ? dx0 : xr0[NB - 1], ps[0], pt[0], img, sa.wr[0] + TW_BLK * (NB - 1), v, sa.dump);
+    epi_burst<FINAL, MODE>(k, pa1, FINAL ? dx1 : xr1[NB - 1], ps[1], pt[1], img, sa.wr[1] + TW_BLK * (NB - 1), v, sa.dump);
   }
 }
 
 // the same layer for a block count known only at run time (window lengths without a specialised instantiation)
-template <bool FINAL, bool USEX>
+template <bool FINAL, bool USEX, int MODE>
 __device__ __forceinline__ void conv_layer_wave_rt(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
                                                    float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
                                                    const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
   switch (nb) {
-    case 1: conv_layer_wave<1, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 2: conv_layer_wave<2, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 3: conv_layer_wave<3, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 4: conv_layer_wave<4, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 5: conv_layer_wave<5, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 6: conv_layer_wave<6, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 7: conv_layer_wave<7, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 8: conv_layer_wave<8, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    default: conv_layer_wave<9, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 1: conv_layer_wave<1, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 2: conv_layer_wave<2, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 3: conv_layer_wave<3, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 4: conv_layer_wave<4, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 5: conv_layer_wave<5, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 6: conv_layer_wave<6, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 7: conv_layer_wave<7, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    case 8: conv_layer_wave<8, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
+    default: conv_layer_wave<9, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
   }
 }
 
-template <int NB, bool FINAL, bool USEX>
+template <int NB, bool FINAL, bool USEX, int MODE>
 __device__ __forceinline__ void conv_layer_any(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
                                                float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
                                                const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
-  if constexpr (NB > 0) conv_layer_wave<NB, FINAL, USEX>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
-  else conv_layer_wave_rt<FINAL, USEX>(img, sa, nb, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
+  if constexpr (NB > 0) conv_layer_wave<NB, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
+  else conv_layer_wave_rt<FINAL, USEX, MODE>(img, sa, nb, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
 }
 
 // Stage-1 activations of unit `unit` straight into the residual registers, in MFMA accumulator layout (lane = column n16 of each
@@ -524,24 +549,27 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
     SNVW_STAMP(1);      // entry: activations landed, image written
     // ------------------------------------------------------------------ the convs
     // one layer of the launch's main stage; FINAL = last layer of a first-stage launch (see conv_layer_wave)
-    auto run_layer = [&](int layer, auto final_tag, const WaveAddr& sa, auto nb_tag, int nb, const XReq& xq) {
+    auto run_layer = [&](int layer, auto mode_tag, auto final_tag, const WaveAddr& sa, auto nb_tag, int nb, const XReq& xq) {
+      constexpr int MODE = decltype(mode_tag)::value;      // MODE_GENERIC: the layers of a loop share one body (role from LayerK)
       constexpr bool FINAL = decltype(final_tag)::value;
       constexpr int NBX = decltype(nb_tag)::value;
       constexpr bool USEX = !(PHASE == 2 && FINAL);      // conv3 starts from its bias (MODE_FINAL: kr == 0)
       const LayerK lk = layer_consts(layer_mode(layer));
-      const float* lp = par + lpar0 + (layer - first_layer) * 3 * SNV_C;
+      int lofs = lpar0 + (layer - first_layer) * 3 * SNV_C;
+      asm volatile("" : "+s"(lofs));      // opaque: these loads are unit-invariant for the layers outside a loop, and hoisted out
+      const float* lp = par + lofs;       // of the unit loop they would hold 24 registers per layer for the whole launch
       const f32x4 pb[2] = {ld4(lp + chv0), ld4(lp + chv1)};
       const f32x4 ps[2] = {ld4(lp + SNV_C + chv0), ld4(lp + SNV_C + chv1)};
       const f32x4 pt[2] = {ld4(lp + 2 * SNV_C + chv0), ld4(lp + 2 * SNV_C + chv1)};
       const int ln = layer < last_layer ? layer + 1 : first_layer;      // the last layer fetches the next unit's first layer
       FragSrc wn = fsrc;
       wn.layer_bytes = (uint32_t)ln * SNV_WFRAG * 4u;
-      conv_layer_any<NBX, FINAL, USEX>(imgb, sa, nb, lk, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
+      conv_layer_any<NBX, FINAL, USEX, MODE>(imgb, sa, nb, lk, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
     };
     using TagA = std::integral_constant<int, NBA>;
     using TagB = std::integral_constant<int, NBB>;
     if (PHASE == 1) {
-      for (int layer = 0; layer < 3; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[0], xoff);
+      for (int layer = 0; layer < 3; ++layer) run_layer(layer, ModeTag<MODE_GENERIC>{}, std::false_type{}, sa_a, TagA{}, g.nb[0], xoff);
       SNVW_STAMP(2);      // convs but the last
       // last layer: block by block the dying residual registers take the next unit's stage-1 activations (a whole next unit;
       // a ragged or missing one is requested the guarded way behind the layer)
@@ -555,11 +583,12 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
         asm volatile("" : "+v"(lc));      // opaque: the lane offsets are worked out block by block, not kept for the launch
         xq.lane_col = lc;
       }
-      run_layer(3, std::true_type{}, sa_a, TagA{}, g.nb[0], xq);
+      run_layer(3, ModeTag<MODE_RES_LAST>{}, std::true_type{}, sa_a, TagA{}, g.nb[0], xq);
       if (!xq.on) wave_request_x0(args, xr0, xr1, nu, n_units, tw_i, n16, kk);
       SNVW_STAMP(3);      // last conv
     } else {
-      for (int layer = 4; layer < 9; ++layer) run_layer(layer, std::false_type{}, sa_a, TagA{}, g.nb[1], xoff);
+      run_layer(4, ModeTag<MODE_ENTRY>{}, std::false_type{}, sa_a, TagA{}, g.nb[1], xoff);      // the one layer with kx == 0
+      for (int layer = 5; layer < 9; ++layer) run_layer(layer, ModeTag<MODE_GENERIC>{}, std::false_type{}, sa_a, TagA{}, g.nb[1], xoff);
       SNVW_STAMP(2);
       {
         // the residual registers are dead from here on: the next unit's input tile travels in them under the pooling, the last
@@ -608,7 +637,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       }
       const WaveAddr sa_b = wave_setup(g, 2, Pw, n16, kk, dump0);
       SNVW_STAMP(3);      // max-pool 3
-      run_layer(9, std::true_type{}, sa_b, TagB{}, g.nb[2], xoff);
+      run_layer(9, ModeTag<MODE_FINAL>{}, std::true_type{}, sa_b, TagB{}, g.nb[2], xoff);
       SNVW_STAMP(4);      // last conv
     }
 
