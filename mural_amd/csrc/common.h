@@ -63,8 +63,8 @@ constexpr int N_SYM = 16;
 // exact unsigned division by a runtime constant: valid while n * d < 2^32
 struct FastDiv {
   uint32_t d, m;
-  __host__ __device__ static FastDiv make(uint32_t d) {
-    FastDiv f;
+  __host__ __device__ static constexpr FastDiv make(uint32_t d) {
+    FastDiv f{};
     f.d = d;
     f.m = (uint32_t)((0x100000000ull / d) + 1ull);
     return f;

@@ -28,6 +28,30 @@ namespace mural {
 
 template <int M>
 using ModeTag = std::integral_constant<int, M>;
+// geometry of one tower for a window of Lwin columns with Pw sites per wave (the arithmetic of plan_wave_geometry); L[i] < 1: no fit
+__host__ __device__ constexpr TowerGeom wave_tower_geom(int tw, int Lwin, int Pw) {
+  constexpr int pools[2][3][3] = {{{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}, {{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}};
+  TowerGeom g{};
+  g.L1 = tw == 0 ? Lwin : 2 * SNV_MID_HALF + 1;
+  g.col0 = tw == 0 ? 0 : Lwin / 2 - SNV_MID_HALF;
+  int L = g.L1;
+  for (int i = 0; i < 3; ++i) {
+    g.pk[i] = pools[tw][i][0];
+    g.ps[i] = pools[tw][i][1];
+    g.pp[i] = pools[tw][i][2];
+    L = (L + 2 * g.pp[i] - g.pk[i]) / g.ps[i] + 1;
+    g.L[i] = L;
+    if (L < 1) return g;
+    g.Sc[i] = L + 1;
+    g.NC[i] = 1 + Pw * g.Sc[i];
+    g.nb[i] = (g.NC[i] + 15) / 16;
+    g.dL[i] = FastDiv::make((uint32_t)L);
+    g.dSc[i] = FastDiv::make((uint32_t)g.Sc[i]);
+  }
+  return g;
+}
+constexpr int SHIP_LWIN = 2001;      // distal_radius 1000: the window the specialised instantiations are compiled for
+
 constexpr int MODE_GENERIC = -1;      // epilogue role from the run-time LayerK (layers that share one code body)
 constexpr int TW_NBW = 9;            // 16-column blocks a wave owns at most
 constexpr int TW_DUMP = 128;          // floats per wave behind its LDS regions: 32 16-byte dump slots (lane & 31)
@@ -293,17 +317,15 @@ __device__ __forceinline__ void conv_layer_any(char* img, const WaveAddr& sa, in
 // block, channels 4 kk .. + 3 of both M-blocks): one wave-uniform buffer descriptor per unit + a 32-bit lane offset worked out on
 // the spot (a division by multiply-high per block) -- nothing per-lane survives between units, so nothing is spilled.  Columns
 // without data (separators, padding) and rows behind the last site read as zero.
-__device__ __forceinline__ void wave_request_x0(const SnvFwdArgs& args, f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], int64_t unit,
-                                                int64_t n_units, int tw_i, int n16, int kk) {
-  const TowerGeom& g = args.geom[tw_i];
-  const int x0c = tw_i == 0 ? 0 : args.geom[0].L[0];
-  const int64_t row0 = unit * args.P;
+__device__ __forceinline__ void wave_request_x0(const SnvFwdArgs& args, const TowerGeom& g, int Pw, int x0_cols, int x0c,
+                                                f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], int64_t unit, int64_t n_units, int n16, int kk) {
+  const int64_t row0 = unit * Pw;
   const bool any = unit < n_units;
-  const __amdgpu_buffer_rsrc_t base = uniform_rsrc(args.x0 + ((size_t)(any ? row0 : 0) * args.x0_cols + x0c) * 32);
-  const int rows = any ? (int)(args.n - row0 < args.P ? args.n - row0 : args.P) : 0;      // sites of this unit that exist
+  const __amdgpu_buffer_rsrc_t base = uniform_rsrc(args.x0 + ((size_t)(any ? row0 : 0) * x0_cols + x0c) * 32);
+  const int rows = any ? (int)(args.n - row0 < Pw ? args.n - row0 : Pw) : 0;      // sites of this unit that exist
   uint32_t lane_col = (uint32_t)n16;
   asm volatile("" : "+v"(lane_col));      // opaque: keeps the offsets below from being precomputed for the whole launch
-  if (rows == args.P) {
+  if (rows == Pw) {
     // a whole unit (all but the last): every lane loads -- lanes whose column holds no data (separators, padding) read the unit's
     // first column instead, their values never reach a data column -- so there is no divergent control flow around the loads
 #pragma unroll
@@ -314,7 +336,7 @@ __device__ __forceinline__ void wave_request_x0(const SnvFwdArgs& args, f32x4 (&
         const uint32_t p = g.dSc[0].div(u);
         const uint32_t j2 = u - p * (uint32_t)g.Sc[0];
         const bool ok = c >= 1u && p < (uint32_t)rows && j2 < (uint32_t)g.L[0];
-        const uint32_t vo = (ok ? ((p * (uint32_t)args.x0_cols + j2) << 7) : 0u) + 16u * (uint32_t)kk;
+        const uint32_t vo = (ok ? ((p * (uint32_t)x0_cols + j2) << 7) : 0u) + 16u * (uint32_t)kk;
         xr0[b] = buf_ld4(base, vo);
         xr1[b] = buf_ld4(base, vo + 64u);
       } else {
@@ -334,7 +356,7 @@ __device__ __forceinline__ void wave_request_x0(const SnvFwdArgs& args, f32x4 (&
       const uint32_t p = g.dSc[0].div(u);
       const uint32_t j2 = u - p * (uint32_t)g.Sc[0];
       if (c >= 1u && p < (uint32_t)rows && j2 < (uint32_t)g.L[0]) {
-        const uint32_t vo = ((p * (uint32_t)args.x0_cols + j2) << 7) + 16u * (uint32_t)kk;
+        const uint32_t vo = ((p * (uint32_t)x0_cols + j2) << 7) + 16u * (uint32_t)kk;
         xr0[b] = buf_ld4(base, vo);
         xr1[b] = buf_ld4(base, vo + 64u);
       }
@@ -382,15 +404,19 @@ __device__ __forceinline__ uint32_t cu_key() {
     }                                                                                \
   } while (0)
 
-template <int PHASE, int NBA, int NBB>
+// TWC / PWC: tower and sites per wave of an instantiation compiled for the shipped window (SHIP_LWIN): the whole geometry is a
+// compile-time constant there -- no divisions by run-time constants, no geometry words fetched from the kernel arguments inside the
+// unit loop (with ~100 SGPRs live the backend re-reads them with s_load + wait at every use); TWC < 0: geometry from the arguments.
+template <int PHASE, int NBA, int NBB, int TWC = -1, int PWC = 0>
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArgs args) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kk = lane >> 4;
-  const int Pw = args.P;
-  const int tw_i = args.tw_first;
+  constexpr bool SHIP = TWC >= 0;
+  const int Pw = SHIP ? PWC : args.P;
+  const int tw_i = SHIP ? TWC : args.tw_first;
   unsigned long long t_prev = args.stamps != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
   // diagnostic: wall-clock (100 MHz) start / end of every wave of the last launch of each (phase, tower), rows 1024.. of the stamp buffer
   if (args.stamps != nullptr && lane == 0) {
@@ -401,8 +427,14 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       row[17 + 2 * (wave & 1)] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // XCC_ID
     }
   }
-  const TowerGeom& g = args.geom[tw_i];
+  constexpr TowerGeom g_ship = wave_tower_geom(SHIP ? TWC : 0, SHIP_LWIN, SHIP ? PWC : 1);
+  const TowerGeom& g_arg = args.geom[SHIP ? 0 : tw_i];
+  const TowerGeom& g = SHIP ? g_ship : g_arg;
   const TowerDev& tw = args.tw[tw_i];
+  // stage-1 activations: [site][x0_cols][32], the large tower's columns first
+  const int L0_large = SHIP ? wave_tower_geom(0, SHIP_LWIN, 1).L[0] : args.geom[0].L[0];
+  const int x0_cols = SHIP ? wave_tower_geom(0, SHIP_LWIN, 1).L[0] + wave_tower_geom(1, SHIP_LWIN, 1).L[0] : args.x0_cols;
+  const int x0c = tw_i == 0 ? 0 : L0_large;
   // LDS: par (shared, read-only after the first barrier) | per wave: image [nbuf] | feat [Pw][32] | logit [3][Pw][16] | dump [TW_DUMP]
   // par: ex_s[4][32] | ex_t[4][32] | fc_w[nc][32] | fc_b[16] | arrival slot[4] | lpar[6 layers][3: bias, post_s, post_t][32]
   const int lpar0 = 2 * EX_COUNT * SNV_C + args.n_class * SNV_C + SNV_MAXCLASS + 4;
@@ -478,7 +510,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
 #pragma unroll
   for (int g4 = 0; g4 < SNV_KSTEPS / 4; ++g4) load_frag4(a0, a1, fsrc, g4);
   const WaveAddr sa_a = wave_setup(g, PHASE == 1 ? 0 : 1, Pw, n16, kk, dump0);
-  if (PHASE == 1) wave_request_x0(args, xr0, xr1, unit0, n_units, tw_i, n16, kk);
+  if (PHASE == 1) wave_request_x0(args, g, Pw, x0_cols, x0c, xr0, xr1, unit0, n_units, n16, kk);
   const bool do_head = PHASE == 2 && args.tw_last == 1 && args.tw_first == 1;
   bool tile_ready = false;      // PHASE 2: the residual registers hold this unit's input tile (requested during the previous unit)
   XReq xoff;
@@ -487,7 +519,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
   xoff.Sc = (uint32_t)g.Sc[0];
   xoff.L = (uint32_t)g.L[0];
   xoff.rows = (uint32_t)Pw;
-  xoff.x0_cols = (uint32_t)args.x0_cols;
+  xoff.x0_cols = (uint32_t)x0_cols;
   xoff.lane_col = (uint32_t)n16;
   xoff.kk16 = 16u * (uint32_t)kk;
   xoff.on = false;
@@ -577,14 +609,13 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       XReq xq = xoff;
       xq.on = nu < n_units && (nu + 1) * Pw <= args.n;
       if (xq.on) {
-        const int x0c = tw_i == 0 ? 0 : args.geom[0].L[0];
-        xq.base = uniform_rsrc(args.x0 + ((size_t)nu * Pw * args.x0_cols + x0c) * 32);
+        xq.base = uniform_rsrc(args.x0 + ((size_t)nu * Pw * x0_cols + x0c) * 32);
         uint32_t lc = (uint32_t)n16;
         asm volatile("" : "+v"(lc));      // opaque: the lane offsets are worked out block by block, not kept for the launch
         xq.lane_col = lc;
       }
       run_layer(3, ModeTag<MODE_RES_LAST>{}, std::true_type{}, sa_a, TagA{}, g.nb[0], xq);
-      if (!xq.on) wave_request_x0(args, xr0, xr1, nu, n_units, tw_i, n16, kk);
+      if (!xq.on) wave_request_x0(args, g, Pw, x0_cols, x0c, xr0, xr1, nu, n_units, n16, kk);
       SNVW_STAMP(3);      // last conv
     } else {
       run_layer(4, ModeTag<MODE_ENTRY>{}, std::false_type{}, sa_a, TagA{}, g.nb[1], xoff);      // the one layer with kx == 0
@@ -751,28 +782,16 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
 
 // per-wave geometry: Pw sites per wave; returns the LDS bytes of a four-wave workgroup (0: does not fit a wave)
 size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int tower, int phase) {
-  static const int pools[2][3][3] = {{{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}, {{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}};
   int maxcols = 0;
   for (int tw = 0; tw < 2; ++tw) {
-    TowerGeom& g = a.geom[tw];
-    g.L1 = tw == 0 ? Lwin : 2 * SNV_MID_HALF + 1;
-    g.col0 = tw == 0 ? 0 : Lwin / 2 - SNV_MID_HALF;
-    int L = g.L1;
+    a.geom[tw] = wave_tower_geom(tw, Lwin, Pw);
+    const TowerGeom& g = a.geom[tw];
     for (int i = 0; i < 3; ++i) {
-      g.pk[i] = pools[tw][i][0];
-      g.ps[i] = pools[tw][i][1];
-      g.pp[i] = pools[tw][i][2];
-      L = (L + 2 * g.pp[i] - g.pk[i]) / g.ps[i] + 1;
-      if (L < 1) return 0;
-      g.L[i] = L;
-      g.Sc[i] = L + 1;
-      g.NC[i] = 1 + Pw * g.Sc[i];
-      g.nb[i] = (g.NC[i] + 15) / 16;
-      g.dL[i] = FastDiv::make((uint32_t)L);
-      g.dSc[i] = FastDiv::make((uint32_t)g.Sc[i]);
+      if (g.L[i] < 1) return 0;
       if (tw != tower) continue;
       if ((phase == 1 && i != 0) || (phase == 2 && i == 0)) continue;
       if (g.nb[i] > TW_NBW) return 0;
+      if (phase == 1 && g.nb[i] != TW_NBW) return 0;      // the first-stage kernel is compiled for nine blocks per wave only
       maxcols = std::max(maxcols, 16 * g.nb[i] + 2);
     }
   }
@@ -806,16 +825,28 @@ int launch_snv_tower_wave(const SnvFwdArgs& a, size_t lds_bytes, hipStream_t str
     if (v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
   }
   static DynLdsOnce big_lds;
-  if (int rc = big_lds.ensure(&snv_tower_wave<1, 9, 0>, &snv_tower_wave<2, 8, 4>, &snv_tower_wave<2, 8, 3>, &snv_tower_wave<1, 0, 0>,
-                              &snv_tower_wave<2, 0, 0>)) return rc;
-  const TowerGeom& g = a.geom[a.tw_first];
+  if (int rc = big_lds.ensure(&snv_tower_wave<1, 9, 0, 0, 1>, &snv_tower_wave<1, 9, 0, 1, 2>, &snv_tower_wave<2, 8, 4, 0, 6>,
+                              &snv_tower_wave<2, 8, 3, 1, 5>, &snv_tower_wave<1, 9, 0>, &snv_tower_wave<2, 0, 0>)) return rc;
+  // the instantiations compiled for the shipped window: the launch's geometry must be exactly theirs
+  const int t = a.tw_first;
+  const int ship_pw = a.phase == 1 ? (t == 0 ? 1 : 2) : (t == 0 ? 6 : 5);
+  bool ship = a.Lwin == SHIP_LWIN && a.P == ship_pw && !getenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM");
+  if (ship) {
+    const TowerGeom want = wave_tower_geom(t, SHIP_LWIN, ship_pw), other = wave_tower_geom(0, SHIP_LWIN, 1);
+    const TowerGeom& have = a.geom[t];
+    for (int i = 0; i < 3; ++i)
+      ship = ship && have.L[i] == want.L[i] && have.Sc[i] == want.Sc[i] && have.NC[i] == want.NC[i] && have.nb[i] == want.nb[i] &&
+             have.pk[i] == want.pk[i] && have.ps[i] == want.ps[i] && have.pp[i] == want.pp[i];
+    ship = ship && a.geom[0].L[0] == other.L[0] && a.x0_cols == other.L[0] + wave_tower_geom(1, SHIP_LWIN, 1).L[0];
+  }
   const dim3 gr(grid), bl(SNV_THREADS);
   if (a.phase == 1) {
-    if (g.nb[0] == 9) hipLaunchKernelGGL((snv_tower_wave<1, 9, 0>), gr, bl, lds_bytes, stream, a);
-    else hipLaunchKernelGGL((snv_tower_wave<1, 0, 0>), gr, bl, lds_bytes, stream, a);
+    if (ship && t == 0) hipLaunchKernelGGL((snv_tower_wave<1, 9, 0, 0, 1>), gr, bl, lds_bytes, stream, a);
+    else if (ship) hipLaunchKernelGGL((snv_tower_wave<1, 9, 0, 1, 2>), gr, bl, lds_bytes, stream, a);
+    else hipLaunchKernelGGL((snv_tower_wave<1, 9, 0>), gr, bl, lds_bytes, stream, a);      // plan_wave_geometry: nine blocks
   } else {
-    if (g.nb[1] == 8 && g.nb[2] == 4) hipLaunchKernelGGL((snv_tower_wave<2, 8, 4>), gr, bl, lds_bytes, stream, a);
-    else if (g.nb[1] == 8 && g.nb[2] == 3) hipLaunchKernelGGL((snv_tower_wave<2, 8, 3>), gr, bl, lds_bytes, stream, a);
+    if (ship && t == 0) hipLaunchKernelGGL((snv_tower_wave<2, 8, 4, 0, 6>), gr, bl, lds_bytes, stream, a);
+    else if (ship) hipLaunchKernelGGL((snv_tower_wave<2, 8, 3, 1, 5>), gr, bl, lds_bytes, stream, a);
     else hipLaunchKernelGGL((snv_tower_wave<2, 0, 0>), gr, bl, lds_bytes, stream, a);
   }
   MURAL_HIP_CHECK(hipGetLastError());

@@ -29,7 +29,7 @@ with torch.no_grad():
     _lib.check(_lib.lib().mural_debug_set_stamps(None))
 s = stamps.view(2048, 32).double().cpu()[:512]
 mean = s.mean(dim=0)
-names = {1: "entry", 2: "convs", 3: "last conv", 4: "pool2+store", 9: "s3 entry", 10: "convs", 11: "pool3", 12: "last conv", 13: "gmax/fc/head"}
+names = {1: "entry", 2: "convs", 3: "last conv", 4: "pool2+store", 9: "s3 entry", 10: "convs", 11: "pool3", 12: "last conv", 13: "gmax/fc/head", 14: "s3 tile -> image", 15: "zero gaps"}
 for tw, nm in ((0, "large"), (1, "mid")):
     for base, ph in ((0, "first stage"), (8, "short stages")):
         seg = mean[16 * tw + base:16 * tw + base + 8]
