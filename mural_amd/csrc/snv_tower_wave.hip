@@ -629,11 +629,17 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
         if (tile_ready) {
           const int total = Pw * g.L[1] * 8;
           const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(args.s3[tw_i] + (size_t)nu * Pw * g.L[1] * 32);
+          // ONE (opaque) lane offset + a scalar offset per round: per-round lane offsets are unit-invariant, get hoisted out of the
+          // unit loop, spilled, and reloaded in front of every load with a full vmcnt drain
+          uint32_t lane16 = 16u * (uint32_t)lane;
+          asm volatile("" : "+v"(lane16));
 #pragma unroll
           for (int u = 0; u < 2 * TW_NBW; ++u) {
-            if (64 * u < total) {      // wave-uniform; lanes behind the last task of the last round read the tile's first bytes
-              const int task = 64 * u + lane;
-              const f32x4 v = buf_ld4(rs, task < total ? 16u * (uint32_t)task : 0u);
+            if (64 * (u + 1) <= total) {      // whole round (wave-uniform)
+              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 1024u * (uint32_t)u, 0));
+              if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
+            } else if (64 * u < total) {      // last, partial round: lanes behind the last task read the tile's first bytes
+              const f32x4 v = buf_ld4(rs, 64 * u + lane < total ? lane16 + 1024u * (uint32_t)u : 0u);
               if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
             }
           }
