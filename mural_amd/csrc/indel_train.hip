@@ -315,21 +315,41 @@ __global__ __launch_bounds__(IT_THREADS) void conv_wgrad_reduce_kernel(const flo
 constexpr int WD_MAXJOBS = 48;
 struct WgradJob { const float* part; float* dW; float* db; int chunks, Cout, entries, pad; };
 struct WgradJobs { WgradJob j[WD_MAXJOBS]; };
+// Threads run along the elements of a partial row (coalesced 256-byte reads per wave), the four waves of a workgroup take every
+// fourth chunk with four independent double accumulators each and meet in LDS in a fixed order (bitwise reproducible).  (One wave
+// per element with its lanes striding over the chunks read one 4-byte word per cache line: 256 us for the 35 layers of the step.)
 __global__ __launch_bounds__(IT_THREADS) void conv_wgrad_reduce_multi_kernel(const WgradJobs jobs) {
+  static_assert(IT_THREADS == 256, "four waves per workgroup");
   const WgradJob jb = jobs.j[blockIdx.y];
-  const int lane = threadIdx.x & 63;
   const int rowlen = jb.entries + 1;
   const int total = jb.Cout * rowlen;
-  for (int i = blockIdx.x * (IT_THREADS / 64) + (threadIdx.x >> 6); i < total; i += gridDim.x * (IT_THREADS / 64)) {
-    double s = 0.0;
-    for (int c = lane; c < jb.chunks; c += 64) s += (double)jb.part[(size_t)c * total + i];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-    if (lane == 0) {
+  __shared__ double sm[4][64];
+  const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+  for (int i0 = blockIdx.x * 64; i0 < total; i0 += gridDim.x * 64) {
+    const int i = i0 + e;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (i < total) {
+      const float* p = jb.part + i;
+      int c = sl;
+      for (; c + 12 < jb.chunks; c += 16) {
+        const float v0 = p[(size_t)c * total], v1 = p[(size_t)(c + 4) * total], v2 = p[(size_t)(c + 8) * total],
+                    v3 = p[(size_t)(c + 12) * total];
+        s0 += (double)v0;
+        s1 += (double)v1;
+        s2 += (double)v2;
+        s3 += (double)v3;
+      }
+      for (; c < jb.chunks; c += 4) s0 += (double)p[(size_t)c * total];
+    }
+    sm[sl][e] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (sl == 0 && i < total) {
+      const double s = (sm[0][e] + sm[1][e]) + (sm[2][e] + sm[3][e]);
       const int co = i / rowlen, r = i - co * rowlen;
       if (r < jb.entries) jb.dW[(size_t)co * jb.entries + r] = (float)s;
       else if (jb.db) jb.db[co] = (float)s;
     }
+    __syncthreads();
   }
 }
 
@@ -352,7 +372,7 @@ int wgrad_defer_flush(hipStream_t st) {
   if (d.n == 0) return MURAL_OK;
   int most = 0;
   for (int k = 0; k < d.n; ++k) most = std::max(most, d.jobs.j[k].Cout * (d.jobs.j[k].entries + 1));
-  const int gx = std::min((most + 3) / 4, 256);
+  const int gx = std::min((most + 63) / 64, 64);
   hipLaunchKernelGGL(conv_wgrad_reduce_multi_kernel, dim3(gx, d.n), dim3(IT_THREADS), 0, st, d.jobs);
   d.n = 0;
   MURAL_HIP_CHECK(hipGetLastError());
