@@ -241,7 +241,7 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
                    "genome inside the timed loop; steps_per_s = %d steps without a host sync in between" % steps,
            "roofline": {"flop_per_step": FLOP_TRAIN_PER_SITE * B, "achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS,
                         "frac_mfma": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r02_train_step")
+    fact = profile_fact("r03_train_step")
     if fact:
         gbs = fact["hbm_bytes_per_step"] / t / 1e12
         out["roofline"].update({"bound": "hbm", "hbm_bytes_per_step": fact["hbm_bytes_per_step"], "achieved_TBs": gbs, "peak_TBs": PEAK_HBM_TBS,
@@ -294,7 +294,7 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
            "note": "window decode from the packed genome inside the timed region; 113.4 MFLOP/position",
            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r02_indel_forward")
+    fact = profile_fact("r03_indel_forward")
     if fact:
         tbs = fact["hbm_bytes_per_position"] * n / dt / 1e12
         out["roofline"].update({"hbm_bytes_per_position": fact["hbm_bytes_per_position"], "achieved_TBs": tbs, "frac_hbm": tbs / PEAK_HBM_TBS,
@@ -697,6 +697,7 @@ def main():
         if fact:
             traffic = fact["hbm_bytes_per_site"] * sites_per_launch
             traffic_source = "profiles/hbm_traffic.json: " + fact.get("note", "")
+        pmc = (profile_fact("r03_predict_pmc") or {}).get("all_launches", {})
         line = {
             "metric": "predicted bases/s (SNV local=10/distal=1000, 4-class, predict)",
             "value": bases / elapsed, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -714,6 +715,9 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
                          "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
+                         # from the committed PMC passes (profiles/r03_predict_pmc.json), not measured in this run:
+                         "profiled_mfma_pipe_busy": pmc.get("mfma_pipe_busy"), "profiled_held_clock_ghz": pmc.get("held_clock_ghz"),
+                         "profiled_valu_per_mfma": pmc.get("valu_insts_per_mfma_excl_mfma"),
                          "note": "four launches per chunk of <= 131072 sites: (large | mid tower) x (first conv stage | the two short "
                                  "stages + fc + head); sites_per_launch / flop_per_launch / traffic are per-launch averages. "
                                  "Algorithmic FLOP of the layers this kernel evaluates (6,353,408 per site: every 32->32 "

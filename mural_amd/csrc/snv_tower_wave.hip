@@ -817,7 +817,8 @@ size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int towe
   return (par + SNV_WAVES * per_wave) * 4;
 }
 
-int launch_snv_tower_wave(const SnvFwdArgs& a, size_t lds_bytes, hipStream_t stream) {
+int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t stream) {
+  SnvFwdArgs a = a_in;
   const int64_t n_units = (a.n + a.P - 1) / a.P;
   const int64_t n_wg = (n_units + SNV_WAVES - 1) / SNV_WAVES;
   if (n_wg == 0) return MURAL_OK;
@@ -826,6 +827,9 @@ int launch_snv_tower_wave(const SnvFwdArgs& a, size_t lds_bytes, hipStream_t str
   int resident = 512;
   if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) resident = std::max(1, atoi(e));
   const int grid = (int)(n_wg < resident ? n_wg : resident);
+  // units through the counter only when every wave has several to take: a wave holds two tickets at a time (this unit + the next),
+  // so with about one unit per wave half of the waves would find nothing to do; short launches keep the fixed stride
+  if (n_units < 4 * (int64_t)grid * SNV_WAVES || getenv("MURAL_DEBUG_TOWER_STATIC_UNITS")) a.unit_counter = nullptr;
   if (const char* e = getenv("MURAL_DEBUG_TOWER_LDS")) {      // diagnostic: inflate the LDS request (one workgroup per CU: occupancy study)
     const size_t v = (size_t)atol(e);
     if (v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
