@@ -287,30 +287,14 @@ __device__ __forceinline__ void conv_layer_wave(char* img, const WaveAddr& sa, c
   }
 }
 
-// the same layer for a block count known only at run time (window lengths without a specialised instantiation)
-template <bool FINAL, bool USEX, int MODE>
-__device__ __forceinline__ void conv_layer_wave_rt(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
-                                                   float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
-                                                   const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
-  switch (nb) {
-    case 1: conv_layer_wave<1, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 2: conv_layer_wave<2, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 3: conv_layer_wave<3, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 4: conv_layer_wave<4, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 5: conv_layer_wave<5, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 6: conv_layer_wave<6, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 7: conv_layer_wave<7, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    case 8: conv_layer_wave<8, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-    default: conv_layer_wave<9, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq); break;
-  }
-}
-
 template <int NB, bool FINAL, bool USEX, int MODE>
 __device__ __forceinline__ void conv_layer_any(char* img, const WaveAddr& sa, int nb, const LayerK& k, float (&a0)[SNV_KSTEPS],
                                                float (&a1)[SNV_KSTEPS], const FragSrc& wn, const f32x4 (&pb)[2], const f32x4 (&ps)[2],
                                                const f32x4 (&pt)[2], f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], const XReq& xq) {
+  // block counts are compile-time constants (plan_wave_geometry only admits geometries with an instance); NB == 0 marks the
+  // stage a launch phase does not have (its call sits in a branch that phase never takes)
+  (void)nb;
   if constexpr (NB > 0) conv_layer_wave<NB, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
-  else conv_layer_wave_rt<FINAL, USEX, MODE>(img, sa, nb, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
 }
 
 // Stage-1 activations of unit `unit` straight into the residual registers, in MFMA accumulator layout (lane = column n16 of each
@@ -380,7 +364,7 @@ __device__ __forceinline__ void wave_zero_gaps(float* img, const TowerGeom& g, i
 // PHASE 2: the two short stages of ONE tower (conv2, four ResBlock convs, max-pool 3 + BN, conv3), global max, fc; the mid
 //          tower's launch also runs the head.
 // NBA / NBB: 16-column blocks per wave of the launch's main stage / of the last stage (PHASE 2), fixed at compile time for the
-// shipped window length; 0 = read from the geometry at run time (other window lengths).
+// instances plan_wave_geometry admits (0: the launch phase has no such stage).
 // Arrival counters per CU (never reset: the workgroups resident on a CU at any time hold consecutive counts).  The two
 // workgroups of a CU are symmetric and start together, so left alone their waves run in lockstep: both in their conv layers
 // (sharing the MFMA pipe), then both in their entry / pooling phases (pipe idle).  Every second arrival therefore starts
@@ -802,6 +786,10 @@ size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int towe
     }
   }
   if (Pw > 31) return 0;      // the x0 plan keeps the site index in five bits
+  // the short-stage kernel exists only with the shipped window's geometry at compile time (a run-time-geometry instance -- a switch
+  // over nine block counts x three layer roles -- compiled with ~750 spilled VGPRs and its results once depended on unrelated
+  // code motion): other windows keep the workgroup-tile kernel for their short stages
+  if (phase == 2 && !(Lwin == SHIP_LWIN && Pw == (tower == 0 ? 6 : 5))) return 0;
   a.P = Pw;
   a.Lwin = Lwin;
   a.tw_first = tower;
@@ -836,7 +824,7 @@ int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t 
   }
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&snv_tower_wave<1, 9, 0, 0, 1>, &snv_tower_wave<1, 9, 0, 1, 2>, &snv_tower_wave<2, 8, 4, 0, 6>,
-                              &snv_tower_wave<2, 8, 3, 1, 5>, &snv_tower_wave<1, 9, 0>, &snv_tower_wave<2, 0, 0>)) return rc;
+                              &snv_tower_wave<2, 8, 3, 1, 5>, &snv_tower_wave<1, 9, 0>)) return rc;
   // the instantiations compiled for the shipped window: the launch's geometry must be exactly theirs
   const int t = a.tw_first;
   const int ship_pw = a.phase == 1 ? (t == 0 ? 1 : 2) : (t == 0 ? 6 : 5);
@@ -857,7 +845,10 @@ int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t 
   } else {
     if (ship && t == 0) hipLaunchKernelGGL((snv_tower_wave<2, 8, 4, 0, 6>), gr, bl, lds_bytes, stream, a);
     else if (ship) hipLaunchKernelGGL((snv_tower_wave<2, 8, 3, 1, 5>), gr, bl, lds_bytes, stream, a);
-    else hipLaunchKernelGGL((snv_tower_wave<2, 0, 0>), gr, bl, lds_bytes, stream, a);
+    else {
+      set_error("internal: short-stage wave launch without the shipped geometry");
+      return MURAL_E_INVALID;
+    }
   }
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
