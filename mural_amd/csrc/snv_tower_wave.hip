@@ -543,9 +543,14 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
           if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
         }
       }
+      // the destinations are unit-invariant: left to the backend they are worked out once per launch, 15 registers of which half
+      // get spilled and come back one scratch load + full vmcnt drain per store (5 us per unit); an opaque lane index keeps the
+      // dozen instructions per round inside the loop
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
 #pragma unroll
       for (int u = 0; u < 2 * TW_NBW; ++u) {
-        const int task = 64 * u + lane;
+        const int task = 64 * u + lane_o;
         if (task < total) {
           const uint32_t pj = (uint32_t)task >> 3;
           const uint32_t p = g.dL[1].div(pj);
@@ -828,7 +833,9 @@ int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t 
   // the instantiations compiled for the shipped window: the launch's geometry must be exactly theirs
   const int t = a.tw_first;
   const int ship_pw = a.phase == 1 ? (t == 0 ? 1 : 2) : (t == 0 ? 6 : 5);
-  bool ship = a.Lwin == SHIP_LWIN && a.P == ship_pw && !getenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM");
+  // MURAL_DEBUG_TOWER_RUNTIME_GEOM: A/B switch of the tests -- the first-stage launches through the instance that reads its geometry
+  // from the arguments (bitwise the same results)
+  bool ship = a.Lwin == SHIP_LWIN && a.P == ship_pw && !(a.phase == 1 && getenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM"));
   if (ship) {
     const TowerGeom want = wave_tower_geom(t, SHIP_LWIN, ship_pw), other = wave_tower_geom(0, SHIP_LWIN, 1);
     const TowerGeom& have = a.geom[t];

@@ -50,3 +50,37 @@ def test_indel_forward_is_bitwise_repeatable_across_both_lanes():
         a, b, c = model(x), model(x), model(x)
         rows = torch.cat([model(x[:2048]), model(x[2048:4096]), model(x[4096:])])      # the same chunks, one lane at a time
     assert torch.equal(a, b) and torch.equal(a, c) and torch.equal(a, rows)
+
+
+def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
+    """The wave-private tower kernel hands units to waves through a counter and runs instances with the window geometry at compile
+    time: neither may change a bit of the result.  Same sites with (a) tickets, (b) the fixed stride, (c) the first-stage instance
+    that reads its geometry from the arguments; 300 k sites = two chunks, several units per wave in every launch."""
+    import bench
+    from mural_amd.data import PackedGenome
+    dev = torch.device("cuda", 0)
+    codes = bench.synthetic_genome(400_000 + 2 * bench.DISTAL_RADIUS)
+    packed, mask = bench.pack2(codes)
+    genome = PackedGenome(packed, mask, len(codes), dev)
+    model = bench.build_model(dev)
+    n = 300_000
+    idx = torch.arange(n, device=dev, dtype=torch.int64)
+    pos, strand = idx + bench.DISTAL_RADIUS, (idx % 3 == 0).to(torch.uint8)
+
+    def run():
+        with torch.no_grad():
+            out = model.forward_packed(genome, pos, strand, local_radius=bench.LOCAL_RADIUS, local_order=bench.LOCAL_ORDER)
+        torch.cuda.synchronize()
+        return out
+
+    base = run()
+    assert torch.isfinite(base).all()
+    monkeypatch.setenv("MURAL_DEBUG_TOWER_STATIC_UNITS", "1")
+    static = run()
+    monkeypatch.delenv("MURAL_DEBUG_TOWER_STATIC_UNITS")
+    monkeypatch.setenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM", "1")
+    runtime_geom = run()
+    monkeypatch.delenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM")
+    assert torch.equal(base, static)
+    assert torch.equal(base, runtime_geom)
+    assert torch.equal(base, run())
