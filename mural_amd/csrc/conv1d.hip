@@ -26,6 +26,7 @@ __device__ __forceinline__ float apply_act(float v, int act) {
 }
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int COG, int KT, bool WIDE>   // KT: compile-time tap count (0 = runtime a.K)
 // WIDE = false: workgroup = 64 output positions, the 4 waves share the output-channel groups;
@@ -274,18 +275,23 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
         symb[i] = (uint8_t)sy;
       }
       __syncthreads();
-      for (int i = tid; i < 4 * span; i += 256) {
-        const int ci = i / span, rr = i - ci * span;
+      // a thread owns a staged column and all four channels of it: one symbol read and one 16-byte table read per tap (the same
+      // sums in the same order as one thread per (channel, column), a quarter of the instructions -- this kernel is bound by
+      // vector-instruction issue, PMC: SQ_ACTIVE_INST_VALU 0.97)
+      for (int rr = tid; rr < span; rr += 256) {
         const int r = r0 + rr;
-        float v = 0.f;
+        f32x4 v = f32x4{0.f, 0.f, 0.f, 0.f};
         if (r >= 0 && r < a.Lf) {
-          v = stab[15 * 15 * 4 + ci];
+          v = *reinterpret_cast<const f32x4*>(stab + 15 * 15 * 4);
           for (int k = 0; k < a.sym_taps; ++k) {
             const uint32_t sy = symb[rr + k];
-            if (sy != SYM_PAD) v += stab[(sy * a.sym_taps + k) * 4 + ci];
+            if (sy != SYM_PAD) v += *reinterpret_cast<const f32x4*>(stab + (sy * a.sym_taps + k) * 4);
           }
         }
-        fin[i] = v;
+        fin[rr] = v.x;
+        fin[span + rr] = v.y;
+        fin[2 * span + rr] = v.z;
+        fin[3 * span + rr] = v.w;
       }
     } else
     for (int i0 = tid; i0 < a.Cf * span; i0 += 256 * UN) {
@@ -340,10 +346,18 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
 #pragma unroll
       for (int c = 0; c < C / 2; ++c) t[c] = f32x2{f_b[2 * c], f_b[2 * c + 1]};
       int ridx[7];
+      if (up == 1) {                                         // first encoder level: no upsampling, no division
 #pragma unroll
-      for (int k = 0; k < 7; ++k) {
-        const int v = l - 3 + k;                             // virtual input index of tap k, >= v0
-        ridx[k] = (v >= 0 ? v / up : r0) - r0;               // v < 0 only if r0 < 0: column 0 then holds a zero
+        for (int k = 0; k < 7; ++k) {
+          const int v = l - 3 + k;
+          ridx[k] = (v >= 0 ? v : r0) - r0;
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < 7; ++k) {
+          const int v = l - 3 + k;                           // virtual input index of tap k, >= v0
+          ridx[k] = (v >= 0 ? v / up : r0) - r0;             // v < 0 only if r0 < 0: column 0 then holds a zero
+        }
       }
 #pragma unroll 1
       for (int ci = 0; ci < a.Cf; ++ci) {
