@@ -459,10 +459,13 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
     for (int c = 0; c < C / 2; ++c) u[c] = __builtin_elementwise_fma(r2, f32x2{tb_w[j * C + 2 * c], tb_w[j * C + 2 * c + 1]}, u[c]);
   }
   __syncthreads();                               // hs is free again: [4 waves][C] wave maxima
+  // Softplus is non-decreasing, so the maximum over positions of Softplus(u) is Softplus(maximum of u): the workgroup reduces
+  // the raw values and C threads apply the activation once (it is ~30 vector instructions with its log1p, and this kernel is
+  // bound by vector-instruction issue: 8 of them per lane were a sixth of the kernel)
 #pragma unroll
   for (int c = 0; c < C; ++c) {
-    float sp = apply_act((c & 1) ? u[c >> 1].y : u[c >> 1].x, ACT_SOFTPLUS);
-    if (!live) sp = 0.f;                       // Softplus > 0: 0 is the identity of the maximum
+    float sp = (c & 1) ? u[c >> 1].y : u[c >> 1].x;
+    if (!live) sp = -INFINITY;                 // identity of the maximum (every workgroup has a live lane)
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) sp = fmaxf(sp, __shfl_xor(sp, off));
     if ((tid & 63) == 0) hs[(tid >> 6) * C + c] = sp;
@@ -470,7 +473,7 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
   __syncthreads();
   if (tid < C)
     a.tail_max[((size_t)b * gridDim.x + blockIdx.x) * C + tid] =
-        fmaxf(fmaxf(hs[tid], hs[C + tid]), fmaxf(hs[2 * C + tid], hs[3 * C + tid]));
+        apply_act(fmaxf(fmaxf(hs[tid], hs[C + tid]), fmaxf(hs[2 * C + tid], hs[3 * C + tid])), ACT_SOFTPLUS);
 }
 
 bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24; }   // LDS: tile + 2C x 256 floats
