@@ -149,6 +149,42 @@ struct SnvFwdArgs {
   int stagger;                    // wave-private launch: late start of every second workgroup of a CU, in units of 8128 cycles
 };
 
+// ---- cross-position reuse (snv_reuse.hip, snv_tower_wave.hip): the edge tile of a site
+constexpr int RU_EC = 9;                 // pooled columns per window side fed to the edge pyramid (9 -> 5 valid after 4 convs)
+constexpr int RU_EV = 5;                 // window-specific columns per side after the four convs
+constexpr int RU_L = 2 * RU_EC;          // data columns per site in the edge tile
+constexpr int RU_SC = RU_L + 1;          // + zero separator
+
+struct EdgeArgs {
+  TowerGeom ge;             // stage 0 = the edge tile: L = 18, Sc = 19
+  TowerDev tw;
+  int P;
+  int nbuf;                 // floats per LDS buffer
+  int64_t n;                // sites of this launch
+  const int64_t* pos;       // genome positions of the sites
+  const uint8_t* strand;    // 0 '+', 1 '-' per site: selects the row set
+  int64_t glen;             // chromosome length
+  int64_t t0[2], nb;        // rows per strand: oriented coordinate of row 0; row count
+  int woff;                 // oriented offset of the tower's first input column from the site (-R large, -100 mid)
+  int L1;                   // conv columns of the tower input (2R+1 / 201)
+  int L2, L3;               // columns after maxpool1 / maxpool2
+  int D;                    // stride of maxpool1 on the base axis (15 / 3)
+  int pk2, ps2, pp2;        // maxpool2
+  int u_lo, u_hi;           // pooled columns whose window lies inside the shared rows (gathered from S)
+  int right_pad;            // the last pooled column contains the right zero-padded conv column (large at R = 1000: yes)
+  const float* F[2];        // per strand: shared pooled first-layer rows
+  const float* El[2];       // first pooled column of a window starting at row b
+  const float* Er[2];       // last pooled column of a window ending at row b (used when right_pad)
+  const float* R[2];        // shared first-conv-stage output rows (raw)
+  const float* S[2];        // shared maxpool2 + BN rows
+  float* s3;                // [n][L3][32] out
+};
+
+// wave-private form of the edge kernel (snv_tower_wave.hip): EW_P sites per wave = nine 16-column blocks, like the first-stage launches
+constexpr int EW_P = 7;
+size_t edge_wave_lds_bytes();
+int launch_snv_edge_wave(const EdgeArgs& e, int* unit_counter, hipStream_t stream);
+
 }  // namespace mural
 
 struct MuralSnvModel {

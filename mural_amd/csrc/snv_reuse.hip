@@ -32,10 +32,6 @@ int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* ou
 
 namespace {
 
-constexpr int RU_EC = 9;                 // pooled columns per window side fed to the edge pyramid (9 -> 5 valid after 4 convs)
-constexpr int RU_EV = 5;                 // window-specific columns per side after the four convs
-constexpr int RU_L = 2 * RU_EC;          // data columns per site in the edge tile
-constexpr int RU_SC = RU_L + 1;          // + zero separator
 constexpr int64_t RU_CHUNK_SPAN = 1 << 21;   // bases per row chunk (11 row arrays x 128 B x span = 2.9 GB)
 
 // --------------------------------------------------------------------------------------------------------------- kernel A
@@ -236,31 +232,6 @@ __global__ __launch_bounds__(256) void reuse_rows_pool_kernel(const float* __res
 }
 
 // --------------------------------------------------------------------------------------------------------------- kernel E
-struct EdgeArgs {
-  TowerGeom ge;             // stage 0 = the edge tile: L = 18, Sc = 19
-  TowerDev tw;
-  int P;
-  int nbuf;                 // floats per LDS buffer
-  int64_t n;                // sites of this launch
-  const int64_t* pos;       // genome positions of the sites
-  const uint8_t* strand;    // 0 '+', 1 '-' per site: selects the row set
-  int64_t glen;             // chromosome length
-  int64_t t0[2], nb;        // rows per strand: oriented coordinate of row 0; row count
-  int woff;                 // oriented offset of the tower's first input column from the site (-R large, -100 mid)
-  int L1;                   // conv columns of the tower input (2R+1 / 201)
-  int L2, L3;               // columns after maxpool1 / maxpool2
-  int D;                    // stride of maxpool1 on the base axis (15 / 3)
-  int pk2, ps2, pp2;        // maxpool2
-  int u_lo, u_hi;           // pooled columns whose window lies inside the shared rows (gathered from S)
-  int right_pad;            // the last pooled column contains the right zero-padded conv column (large at R = 1000: yes)
-  const float* F[2];        // per strand: shared pooled first-layer rows
-  const float* El[2];       // first pooled column of a window starting at row b
-  const float* Er[2];       // last pooled column of a window ending at row b (used when right_pad)
-  const float* R[2];        // shared first-conv-stage output rows (raw)
-  const float* S[2];        // shared maxpool2 + BN rows
-  float* s3;                // [n][L3][32] out
-};
-
 // stage-2 column of edge-tile column j (0 .. 17): the 9 leftmost, then the 9 rightmost
 __device__ __forceinline__ int edge_q(int j, int L2) { return j < RU_EC ? j : L2 - RU_L + j; }
 
@@ -647,6 +618,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
 
   static DynLdsOnce edge_lds;
   if (int rc = edge_lds.ensure(&snv_edge_kernel)) return rc;
+  const bool edge_wave = !getenv("MURAL_DEBUG_EDGE_TILE");
   for (int64_t s0 = 0; s0 < n; s0 += SNV_CHUNK) {
     const int64_t sn = std::min<int64_t>(SNV_CHUNK, n - s0);
     if (sh.model_no == 2) {
@@ -658,6 +630,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       if (int rc = mural_encode_kmer(g, pos + s0, strand + s0, sn, local_radius, local_order, 0, w.cat, stream_)) return rc;
       if (int rc = launch_snv_local(m->local, w.cat, sn, w.local_logits, stream)) return rc;
     }
+    MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));      // unit counters of this chunk's four wave-private launches
     for (int t = 0; t < 2; ++t) {
       const TowerGeom& gg = m->args.geom[t];
       EdgeArgs e{};
@@ -694,11 +667,14 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
         e.S[neg] = Srows[neg][t];
       }
       e.s3 = w.s3[t];
-      const int64_t n_tiles = (sn + P - 1) / P;
-      hipLaunchKernelGGL(snv_edge_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, 2048)), dim3(SNV_THREADS), lds_edge, stream, e);
-      MURAL_HIP_CHECK(hipGetLastError());
+      if (edge_wave) {      // wave-private form (snv_tower_wave.hip); MURAL_DEBUG_EDGE_TILE=1 keeps the workgroup-tile kernel (A/B runs)
+        if (int rc = launch_snv_edge_wave(e, w.counters + t, stream)) return rc;
+      } else {
+        const int64_t n_tiles = (sn + P - 1) / P;
+        hipLaunchKernelGGL(snv_edge_kernel, dim3((unsigned)std::min<int64_t>(n_tiles, 2048)), dim3(SNV_THREADS), lds_edge, stream, e);
+        MURAL_HIP_CHECK(hipGetLastError());
+      }
     }
-    MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
     for (int part = 2; part < 4; ++part) {
       SnvFwdArgs t = m->args_split[part];
       t.s3[0] = w.s3[0];

@@ -775,6 +775,278 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
     args.stamps[(size_t)(1024 + 2 * blockIdx.x + (wave >> 1)) * 32 + ((PHASE - 1) * 2 + tw_i) * 4 + 2 * (wave & 1) + 1] = __builtin_amdgcn_s_memrealtime();
 }
 
+// ====================================================================================================================
+// Edge tiles of the cross-position reuse path (snv_reuse.hip) in the wave-private form: a wave owns
+// EW_P = 7 sites x (9 + 9 edge columns + separator) = 134 columns = the nine blocks of a first-stage launch, runs the four
+// ResBlock convs on them with the layer code above (same fragments, k order, epilogue forms -- the per-window kernel's own
+// operation sequence), and pools: interior windows are gathered from the shared rows S, the windows that touch the edge
+// pyramids read the wave's image (+ R rows when mixed).  Replaces the workgroup-tile snv_edge_kernel (two LDS buffers, a
+// workgroup barrier per layer) for the shipped layer shape.
+// ====================================================================================================================
+constexpr int EW_NB = 9;
+constexpr int EW_WST = 32;      // floats per wave behind the image: window starts of this unit and of the next one (2 x 8 int64)
+
+__device__ __forceinline__ int64_t edge_wave_wstart(const EdgeArgs& args, int64_t row) {
+  if (row >= args.n) return -1;
+  const int64_t gp = args.pos[row];
+  const int neg = args.strand[row] != 0;
+  const int64_t t = neg ? args.glen - 1 - gp : gp;
+  const int64_t w = t + args.woff - args.t0[neg];
+  if (w < 0 || w + args.L1 > args.nb || args.F[neg] == nullptr) return -1;   // the caller's bounds / strand mask were wrong
+  return w | ((int64_t)neg << 62);
+}
+
+// raw x0 of the lane's edge columns of one unit, in accumulator layout (both M-blocks): gathers from the shared rows.  The (site,
+// column) of a lane's column in block b is launch-invariant; it is worked out here from an opaque lane index so that nothing per
+// block is kept (and spilled) across the unit loop.
+__device__ __forceinline__ void edge_wave_request(const EdgeArgs& args, const int64_t* wst, f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW],
+                                                  int n16_in, int kk) {
+  int n16 = n16_in;
+  asm volatile("" : "+v"(n16));
+  const float* safe = args.F[0] != nullptr ? args.F[0] : args.F[1];
+#pragma unroll
+  for (int b = 0; b < EW_NB; ++b) {
+    const uint32_t c = 16u * b + (uint32_t)n16;
+    const uint32_t u = c - 1u;
+    const uint32_t p = u / (uint32_t)RU_SC;      // c == 0 wraps: p is huge and the lane reads nothing
+    const uint32_t j = u - p * (uint32_t)RU_SC;
+    const bool col = c >= 1u && p < (uint32_t)EW_P && j < (uint32_t)RU_L;
+    const int q = (int)j < RU_EC ? (int)j : args.L2 - RU_L + (int)j;
+    const int64_t ws = wst[col ? p : 0];
+    const bool ok = col && ws >= 0;
+    const int set = (int)((ws >> 62) & 1);
+    const int64_t w = ws & ((1ll << 62) - 1);
+    const float* src = args.F[set] + (size_t)(w + (int64_t)args.D * q) * 32;
+    if (q == 0) src = args.El[set] + (size_t)w * 32;
+    else if (q == args.L2 - 1 && args.right_pad) src = args.Er[set] + (size_t)(w + args.L1 - 1) * 32;
+    if (!ok) src = safe;
+    const f32x4 v0 = ld4(src + 4 * kk), v1 = ld4(src + 16 + 4 * kk);
+    xr0[b] = ok ? v0 : splat(0.f);
+    xr1[b] = ok ? v1 : splat(0.f);
+  }
+}
+
+__global__ __launch_bounds__(SNV_THREADS, 2) void snv_edge_wave(const EdgeArgs args, int* unit_counter) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
+  const TowerDev& tw = args.tw;
+  constexpr int Pw = EW_P;
+  // the edge tile's geometry: Pw sites x (RU_L data columns + separator) behind the guard column
+  TowerGeom g{};
+  g.L[0] = RU_L;
+  g.Sc[0] = RU_SC;
+  g.NC[0] = 1 + Pw * RU_SC;
+  g.nb[0] = EW_NB;
+  g.dL[0] = FastDiv::make(RU_L);
+  g.dSc[0] = FastDiv::make(RU_SC);
+  // LDS: par = ex_s[2][32] (entry, pool) | ex_t[2][32] | lpar[4 layers][3][32]; per wave: image | window starts | dump slots
+  constexpr int nbuf = (16 * EW_NB + 2) * SNV_C;
+  constexpr int lpar0 = 4 * SNV_C;
+  constexpr int par_floats = lpar0 + 4 * 3 * SNV_C;
+  constexpr int wave_floats = nbuf + EW_WST + TW_DUMP;
+  float* par = smem;
+  float* img = smem + par_floats + wave * wave_floats;
+  int64_t* wst_buf = reinterpret_cast<int64_t*>(img + nbuf);      // [2][8]
+  const uint32_t dump0 = 4u * (uint32_t)(nbuf + EW_WST);
+  if (tid < SNV_C) {
+    par[tid] = tw.ex_s[EX_RB1_ENTRY * 32 + tid];
+    par[SNV_C + tid] = tw.ex_s[EX_BN_MID * 32 + tid];
+    par[2 * SNV_C + tid] = tw.ex_t[EX_RB1_ENTRY * 32 + tid];
+    par[3 * SNV_C + tid] = tw.ex_t[EX_BN_MID * 32 + tid];
+  }
+  for (int i = tid; i < 4 * SNV_C; i += SNV_THREADS) {
+    const int l = i >> 5, c = i & 31;
+    par[lpar0 + (l * 3 + 0) * SNV_C + c] = tw.bias[l * 32 + c];
+    par[lpar0 + (l * 3 + 1) * SNV_C + c] = tw.post_s[l * 32 + c];
+    par[lpar0 + (l * 3 + 2) * SNV_C + c] = tw.post_t[l * 32 + c];
+  }
+  if (lane < 8) st4(img + lds_off(0, lane), splat(0.f));
+  else if (lane < 16) st4(img + lds_off(16 * EW_NB + 1, lane - 8), splat(0.f));
+  wave_zero_gaps(img, g, 0, Pw, lane);      // once: no layer stores into a gap column
+  __syncthreads();
+
+  const int64_t n_units = (args.n + Pw - 1) / Pw;
+  const bool dyn = unit_counter != nullptr;
+  const int64_t unit_step = (int64_t)gridDim.x * SNV_WAVES;
+  int ticket = 0;
+  int64_t unit0 = (int64_t)blockIdx.x * SNV_WAVES + wave;
+  if (dyn) {
+    if (lane == 0) ticket = atomicAdd(unit_counter, 1);
+    unit0 = __builtin_amdgcn_readfirstlane(ticket);
+    if (lane == 0) ticket = atomicAdd(unit_counter, 1);
+  }
+  char* imgb = reinterpret_cast<char*>(img);
+  const int chv0 = 4 * kk, chv1 = 16 + 4 * kk;
+  f32x4 xr0[TW_NBW], xr1[TW_NBW];
+  float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
+  FragSrc fsrc;
+  fsrc.wf = uniform_rsrc(tw.wfrag4);
+  fsrc.lane16 = 16u * (uint32_t)lane;
+  fsrc.layer_bytes = 0u;
+#pragma unroll
+  for (int g4 = 0; g4 < SNV_KSTEPS / 4; ++g4) load_frag4(a0, a1, fsrc, g4);
+  const WaveAddr sa = wave_setup(g, 0, Pw, n16, kk, dump0);
+  XReq xoff{};
+  xoff.on = false;
+  int cur = 0;
+  if (lane < 8) wst_buf[lane] = lane < Pw ? edge_wave_wstart(args, unit0 * Pw + lane) : -1;
+  edge_wave_request(args, wst_buf, xr0, xr1, n16, kk);
+  const int cg = lane & 7;
+
+  for (int64_t unit = unit0, next_unit = 0; unit < n_units; unit = next_unit) {
+    const int64_t row0 = unit * Pw;
+    if (dyn) {
+      next_unit = __builtin_amdgcn_readfirstlane(ticket);
+      if (lane == 0) ticket = atomicAdd(unit_counter, 1);
+    } else {
+      next_unit = unit + unit_step;
+    }
+    const int64_t* wst = wst_buf + 8 * cur;
+    // window starts of the next unit: the position loads hide under the convs
+    if (lane < 8) wst_buf[8 * (cur ^ 1) + lane] = (lane < Pw && next_unit < n_units) ? edge_wave_wstart(args, next_unit * Pw + lane) : -1;
+    // ---- entry: BN(ReLU(x0)) image of the edge columns; the raw values stay in the residual registers
+    {
+      const f32x4 es0 = ld4(par + chv0), et0 = ld4(par + 2 * SNV_C + chv0);
+      const f32x4 es1 = ld4(par + chv1), et1 = ld4(par + 2 * SNV_C + chv1);
+#pragma unroll
+      for (int b = 0; b < EW_NB; ++b) {
+        const bool v = (sa.vmask >> b) & 1u;
+        lds_st4(imgb, v ? sa.wr[0] + TW_BLK * b : sa.dump, relu_bn_pk(xr0[b], es0, et0));
+        lds_st4(imgb, v ? sa.wr[1] + TW_BLK * b : sa.dump, relu_bn_pk(xr1[b], es1, et1));
+      }
+    }
+    // ---- the four ResBlock convs on the edge tile
+    auto run_layer = [&](int layer, auto mode_tag, auto final_tag) {
+      constexpr int MODE = decltype(mode_tag)::value;
+      constexpr bool FINAL = decltype(final_tag)::value;
+      const LayerK lk = layer_consts(layer_mode(layer));
+      int lofs = lpar0 + layer * 3 * SNV_C;
+      asm volatile("" : "+s"(lofs));
+      const float* lp = par + lofs;
+      const f32x4 pb[2] = {ld4(lp + chv0), ld4(lp + chv1)};
+      const f32x4 ps[2] = {ld4(lp + SNV_C + chv0), ld4(lp + SNV_C + chv1)};
+      const f32x4 pt[2] = {ld4(lp + 2 * SNV_C + chv0), ld4(lp + 2 * SNV_C + chv1)};
+      FragSrc wn = fsrc;
+      wn.layer_bytes = (uint32_t)(layer < 3 ? layer + 1 : 0) * SNV_WFRAG * 4u;
+      conv_layer_any<EW_NB, FINAL, true, MODE>(imgb, sa, EW_NB, lk, a0, a1, wn, pb, ps, pt, xr0, xr1, xoff);
+    };
+    for (int layer = 0; layer < 3; ++layer) run_layer(layer, ModeTag<MODE_GENERIC>{}, std::false_type{});
+    run_layer(3, ModeTag<MODE_RES_LAST>{}, std::true_type{});
+    // the residual registers are dead: the next unit's gathers fly under the pooling
+    if (next_unit < n_units) edge_wave_request(args, wst_buf + 8 * (cur ^ 1), xr0, xr1, n16, kk);
+    // ---- maxpool2 + BN -> s3.  Interior windows (columns u_lo .. u_hi): gathers from S, four rounds in flight at a time; the few
+    //      windows that touch the edge pyramids read the image (+ R rows when mixed) and get the BN here.
+    {
+      const f32x4 pool_s = ld4(par + SNV_C + 4 * cg), pool_t = ld4(par + 3 * SNV_C + 4 * cg);
+      const int n_int = args.u_hi - args.u_lo + 1;
+      int lane_o = lane;
+      asm volatile("" : "+v"(lane_o));
+      // interior windows are a copy S -> s3: site by site (window start and destination row wave-uniform: scalar address math, one
+      // buffer descriptor each), a round = 8 pooled columns x 8 channel groups; the lane offsets of the rounds are worked out once
+      // per unit, a site costs three loads and three stores and no vector arithmetic
+      const int n_rounds = (n_int + 7) >> 3;
+      const int u_l = lane_o >> 3;
+      const uint32_t sstep = (uint32_t)(args.D * args.ps2) * 128u;      // bytes between consecutive pooled columns on the base axis
+      uint32_t so[3], dof[3];
+      bool on[3];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const int u = args.u_lo + 8 * r + u_l;
+        on[r] = r < n_rounds && u <= args.u_hi;
+        so[r] = (uint32_t)u * sstep + 16u * (uint32_t)cg;
+        dof[r] = (uint32_t)u * 128u + 16u * (uint32_t)cg;
+      }
+      const float* s_any = args.S[0] != nullptr ? args.S[0] : args.S[1];
+      for (int p = 0; p < Pw; ++p) {
+        if (row0 + p >= args.n) break;
+        const int64_t wsv = wst[p];
+        const int64_t ws = ((int64_t)__builtin_amdgcn_readfirstlane((int)(wsv >> 32)) << 32) |
+                           (int64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(wsv & 0xffffffffll));
+        const bool ok = ws >= 0;
+        const int64_t w = ws & ((1ll << 62) - 1);
+        const __amdgpu_buffer_rsrc_t srs = uniform_rsrc(ok ? args.S[(int)((ws >> 62) & 1)] + (size_t)w * 32 : s_any);
+        const __amdgpu_buffer_rsrc_t drs = uniform_rsrc(args.s3 + (size_t)(row0 + p) * args.L3 * 32);
+        f32x4 sv[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          sv[r] = splat(__uint_as_float(0x7FC00000u));
+          if (on[r] && ok) sv[r] = buf_ld4(srs, so[r]);
+        }
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+          if (on[r]) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, sv[r]), drs, dof[r], 0, 0);
+        for (int r = 3; r < n_rounds; ++r) {      // more than 24 interior columns (not in the shipped geometries)
+          const int u = args.u_lo + 8 * r + u_l;
+          if (u <= args.u_hi) {
+            const f32x4 v = ok ? buf_ld4(srs, (uint32_t)u * sstep + 16u * (uint32_t)cg) : splat(__uint_as_float(0x7FC00000u));
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), drs, (uint32_t)u * 128u + 16u * (uint32_t)cg, 0, 0);
+          }
+        }
+      }
+      const int n_edge = args.L3 - n_int;
+#pragma unroll 1
+      for (int task = lane_o; task < Pw * n_edge * 8; task += 64) {
+        const int pj = task >> 3;
+        const int p = pj / n_edge, e = pj - p * n_edge;
+        const int u = e < args.u_lo ? e : args.u_hi + 1 + (e - args.u_lo);
+        if (row0 + p >= args.n) continue;
+        const int64_t ws = wst[p];
+        f32x4 m = splat(__uint_as_float(0x7FC00000u));
+        if (ws >= 0) {
+          const int set = (int)(ws >> 62);
+          const int64_t w = ws & ((1ll << 62) - 1);
+          const int jlo = u * args.ps2 - args.pp2;
+          const int lo = jlo < 0 ? 0 : jlo;
+          const int hi = (jlo + args.pk2 - 1) < (args.L2 - 1) ? (jlo + args.pk2 - 1) : (args.L2 - 1);
+          f32x4 rv[7];
+#pragma unroll
+          for (int d = 0; d < 7; ++d) {           // the model's second pools are 7 / 3 wide: every row read in flight together
+            rv[d] = splat(-INFINITY);
+            const int q = lo + d;
+            if (q <= hi) {
+              if (q < RU_EV) rv[d] = ld4(img + lds_off(1 + p * RU_SC + q + 1, cg));
+              else if (q > args.L2 - 1 - RU_EV) rv[d] = ld4(img + lds_off(1 + p * RU_SC + (q - (args.L2 - RU_L)) + 1, cg));
+              else rv[d] = ld4(args.R[set] + (size_t)(w + (int64_t)args.D * q) * 32 + 4 * cg);
+            }
+          }
+          m = max4(max4(max4(rv[0], rv[1]), max4(rv[2], rv[3])), max4(max4(rv[4], rv[5]), rv[6]));
+          for (int q = lo + 7; q <= hi; ++q) {     // wider pools (not in the model): plain loop
+            f32x4 v;
+            if (q < RU_EV) v = ld4(img + lds_off(1 + p * RU_SC + q + 1, cg));
+            else if (q > args.L2 - 1 - RU_EV) v = ld4(img + lds_off(1 + p * RU_SC + (q - (args.L2 - RU_L)) + 1, cg));
+            else v = ld4(args.R[set] + (size_t)(w + (int64_t)args.D * q) * 32 + 4 * cg);
+            m = max4(m, v);
+          }
+          m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
+                    fmaf(pool_s.w, m.w, pool_t.w)};
+        }
+        st4(args.s3 + ((size_t)(row0 + p) * args.L3 + u) * 32 + 4 * cg, m);
+      }
+    }
+    cur ^= 1;
+  }
+}
+
+size_t edge_wave_lds_bytes() {
+  return (size_t)(4 * SNV_C + 4 * 3 * SNV_C + SNV_WAVES * ((16 * EW_NB + 2) * SNV_C + EW_WST + TW_DUMP)) * 4;
+}
+
+int launch_snv_edge_wave(const EdgeArgs& e, int* unit_counter, hipStream_t stream) {
+  const int64_t n_units = (e.n + EW_P - 1) / EW_P;
+  const int64_t n_wg = (n_units + SNV_WAVES - 1) / SNV_WAVES;
+  if (n_wg == 0) return MURAL_OK;
+  const int grid = (int)(n_wg < 512 ? n_wg : 512);
+  if (n_units < 4 * (int64_t)grid * SNV_WAVES || getenv("MURAL_DEBUG_TOWER_STATIC_UNITS")) unit_counter = nullptr;
+  static DynLdsOnce lds;
+  if (int rc = lds.ensure(&snv_edge_wave)) return rc;
+  hipLaunchKernelGGL(snv_edge_wave, dim3(grid), dim3(SNV_THREADS), edge_wave_lds_bytes(), stream, e, unit_counter);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
 // per-wave geometry: Pw sites per wave; returns the LDS bytes of a four-wave workgroup (0: does not fit a wave)
 size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int tower, int phase) {
   int maxcols = 0;
