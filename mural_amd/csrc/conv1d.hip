@@ -458,22 +458,31 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
 #pragma unroll
     for (int c = 0; c < C / 2; ++c) u[c] = __builtin_elementwise_fma(r2, f32x2{tb_w[j * C + 2 * c], tb_w[j * C + 2 * c + 1]}, u[c]);
   }
-  __syncthreads();                               // hs is free again: [4 waves][C] wave maxima
+  __syncthreads();                               // hs is free again
   // Softplus is non-decreasing, so the maximum over positions of Softplus(u) is Softplus(maximum of u): the workgroup reduces
-  // the raw values and C threads apply the activation once (it is ~30 vector instructions with its log1p, and this kernel is
-  // bound by vector-instruction issue: 8 of them per lane were a sixth of the kernel)
+  // the raw values and C threads apply the activation once.  The reduction goes through LDS (a lane parks its C values, 64
+  // threads take 32 positions of one channel each, C threads finish): a butterfly of wave shuffles is 6 x C permutes with their
+  // address arithmetic per lane, and this kernel is bound by vector-instruction issue.
+  static_assert(HP * 256 >= C * 256, "the parked values fit the SiLU buffer");
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    float sp = (c & 1) ? u[c >> 1].y : u[c >> 1].x;
-    if (!live) sp = -INFINITY;                 // identity of the maximum (every workgroup has a live lane)
+  for (int c = 0; c < C; ++c) hs[c * 256 + tid] = live ? ((c & 1) ? u[c >> 1].y : u[c >> 1].x) : -INFINITY;
+  __syncthreads();
+  float part = -INFINITY;
+  if (tid < 8 * C) {                             // (channel, 32-position slice)
+    const int c = tid >> 3, sl = tid & 7;
+    const float* row = hs + c * 256 + 32 * sl;
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) sp = fmaxf(sp, __shfl_xor(sp, off));
-    if ((tid & 63) == 0) hs[(tid >> 6) * C + c] = sp;
+    for (int i = 0; i < 32; ++i) part = fmaxf(part, row[(i + 4 * sl + (c >> 1)) & 31]);      // rotated starts: the 64 threads spread over all banks
   }
   __syncthreads();
-  if (tid < C)
-    a.tail_max[((size_t)b * gridDim.x + blockIdx.x) * C + tid] =
-        apply_act(fmaxf(fmaxf(hs[tid], hs[C + tid]), fmaxf(hs[2 * C + tid], hs[3 * C + tid])), ACT_SOFTPLUS);
+  if (tid < 8 * C) hs[tid] = part;
+  __syncthreads();
+  if (tid < C) {
+    float m = hs[8 * tid];
+#pragma unroll
+    for (int i = 1; i < 8; ++i) m = fmaxf(m, hs[8 * tid + i]);
+    a.tail_max[((size_t)b * gridDim.x + blockIdx.x) * C + tid] = apply_act(m, ACT_SOFTPLUS);
+  }
 }
 
 bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24; }   // LDS: tile + 2C x 256 floats
