@@ -212,6 +212,10 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
   constexpr int HP = C == 8 ? 8 : C2;
   __shared__ float hs[HP * 256];
   static_assert(!FRONT || HP * 256 >= CB_FRONT_FLOATS, "the front input tile borrows the SiLU buffer");
+  constexpr int PW_FLOATS = (FRONT && C == 8) ? 4 * 16 * 3 * 8 : 4;      // polyphase front weights of the four phases (Cf <= 16)
+  __shared__ __attribute__((aligned(16))) float pwS[PW_FLOATS];
+  if (FRONT && C == 8 && a.f_pw != nullptr && a.Cf * 3 * C * 4 <= PW_FLOATS)
+    for (int i = threadIdx.x; i < a.Cf * 3 * C * 4; i += 256) pwS[i] = a.f_pw[i];      // visible behind the front's first barrier
   float* fin = hs;                             // front input tile: dead before the first SiLU output is parked (a barrier in between),
                                                // and 8 KB less LDS is two more workgroups per CU to hide the scalar weight loads
   const int tid = threadIdx.x;
@@ -340,6 +344,26 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
       f32x2 t[C / 2];
 #pragma unroll
       for (int c = 0; c < C / 2; ++c) t[c] = f32x2{f_b[2 * c], f_b[2 * c + 1]};
+      if (C == 8 && a.Cf * 3 * C * 4 <= PW_FLOATS) {
+        // the phase's weights from LDS (staged once per workgroup, broadcast 16-byte reads): as scalar loads they are three
+        // waited-for round trips per 12 packed FMAs (the scalar registers hold two channels' worth at most), from LDS a dozen
+        // reads are in flight
+        const float* pwl = pwS + ph * a.Cf * 3 * C;
+#pragma unroll 4
+        for (int ci = 0; ci < a.Cf; ++ci) {
+          const float* frow = fin + ci * span + i0;
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(pwl + (ci * 3 + d) * C), w1 = *reinterpret_cast<const f32x4*>(pwl + (ci * 3 + d) * C + 4);
+            const float xv = frow[d];
+            const f32x2 x2 = {xv, xv};
+            t[0] = __builtin_elementwise_fma(x2, f32x2{w0.x, w0.y}, t[0]);
+            t[1] = __builtin_elementwise_fma(x2, f32x2{w0.z, w0.w}, t[1]);
+            t[2] = __builtin_elementwise_fma(x2, f32x2{w1.x, w1.y}, t[2]);
+            t[3] = __builtin_elementwise_fma(x2, f32x2{w1.z, w1.w}, t[3]);
+          }
+        }
+      } else {
       const float* __restrict__ pw = a.f_pw + (size_t)ph * a.Cf * 3 * C;
 #pragma unroll 2
       for (int ci = 0; ci < a.Cf; ++ci) {
@@ -352,6 +376,7 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
 #pragma unroll
           for (int c = 0; c < C / 2; ++c) t[c] = __builtin_elementwise_fma(x2, f32x2{wk[2 * c], wk[2 * c + 1]}, t[c]);
         }
+      }
       }
       const bool in = l >= 0 && l < a.L;
 #pragma unroll
