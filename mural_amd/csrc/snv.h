@@ -12,6 +12,7 @@ constexpr int SNV_WFRAG = 2 * SNV_KSTEPS * 64;   // floats per layer: [mblock][k
 constexpr int SNV_LUT = 125 * SNV_C;             // 3-mer lookup table (A,C,G,T,N)^3 x channels
 constexpr int SNV_TAPS = 3 * N_SYM * SNV_C;      // per-tap, per-symbol contributions (generic path)
 constexpr int SNV_LUTBLK = SNV_LUT + SNV_TAPS + SNV_C;   // lut | taps | bias0, contiguous in the blob
+constexpr int SNV_LUT4 = 256 * SNV_C;             // pair table (A,C,G,T)^4 x channels: max of the two 3-mer rows of adjacent columns
 constexpr int SNV_MAXCLASS = 16;
 constexpr int SNV_CHUNK = 131072;  // sites per stage-1 / tower launch sequence (bounds the x0 scratch: 3.4 GB at R=1000)
 constexpr int SNV_NB2MAX = 9;      // max 16-column blocks a wave owns in one stage (waves split M x column parity)
@@ -38,6 +39,7 @@ struct TowerGeom {
 
 struct TowerDev {                 // all device pointers into one blob
   const float* lut;               // [125][32]
+  const float* lut4;              // [256][32] max(lut[abc], lut[bcd]) over (A,C,G,T)^4 (snv_stage1_kernel)
   const float* taps;              // [3][16][32]
   const float* bias0;             // [32] first-layer conv bias
   const float* wfrag;             // [10][SNV_WFRAG]
@@ -71,6 +73,7 @@ struct Stage1Tower { int L1, col0, L2, pk, ps, pp; };
 struct Stage1Args {               // snv_stage1_kernel: window decode + first conv layer + maxpool1
   Stage1Tower tw[2];              // 0 = large, 1 = mid
   const float* lut[2];            // lut | taps | bias0 blocks of the two towers
+  const float* lut4;              // large tower: pair table [256][32] (throughput kernel, 15-wide pools), or nullptr
   int Lwin, cw, wave_bytes, x0_cols, nwords, radius;
   int64_t n;
   const uint8_t* codes;           // [n][Lwin] symbols (dense path)
@@ -205,6 +208,7 @@ struct MuralSnvModel {
   size_t lds_bytes;               // dynamic LDS of the tower kernel
   mural::Stage1Args s1;           // stage-1 kernel arguments (input/output fields filled per call)
   size_t s1_lds_bytes;
+  bool s1_pair;                   // the stage-1 kernel carries the large tower's pair table (Stage1Args::lut4)
   // Network2, small batches: the local branch rides in the first-stage launch (Stage1Args::loc_on) when its MFMA kernel applies
   bool loc_fused;
   mural::LocalMfmaDims loc_d;

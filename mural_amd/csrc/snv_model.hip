@@ -60,7 +60,7 @@ void pack_wfrag(const float* W, float* dst) {
       }
 }
 
-struct TowerOff { size_t lut, taps, bias0, wfrag, wfrag4, bias, post_s, post_t, ex_s, ex_t, fc_w, fc_b; };
+struct TowerOff { size_t lut4, lut, taps, bias0, wfrag, wfrag4, bias, post_s, post_t, ex_s, ex_t, fc_w, fc_b; };
 
 int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& o) {
   const int C = SNV_C;
@@ -75,6 +75,7 @@ int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& 
   o.lut = B.alloc(SNV_LUTBLK);          // lut | taps | bias0 in one block: the stage-1 kernel stages it with one copy
   o.taps = o.lut + SNV_LUT;
   o.bias0 = o.taps + SNV_TAPS;
+  o.lut4 = B.alloc(SNV_LUT4);
   o.wfrag = B.alloc((size_t)SNV_NLAYER * SNV_WFRAG);
   o.wfrag4 = B.alloc((size_t)SNV_NLAYER * SNV_WFRAG);
   o.bias = B.alloc(SNV_NLAYER * C);
@@ -110,6 +111,17 @@ int fold_tower(const MuralTower& T, const MuralSnvShape& sh, Blob& B, TowerOff& 
           B.host[o.lut + ((l * 25 + c * 5 + r) * C + co)] =
               (float)((double)T.conv_in.bias[co] + tap[(0 * N_SYM + l) * C + co] + tap[(1 * N_SYM + c) * C + co] +
                       tap[(2 * N_SYM + r) * C + co]);
+
+  // pair table of the stage-1 kernel: two adjacent first-layer columns share three of their four bases, and the pooled value only
+  // needs their maximum -- one 128-byte row read instead of two for windows of plain bases (exactly the maximum of the two rows)
+  for (int a4 = 0; a4 < 4; ++a4)
+    for (int b4 = 0; b4 < 4; ++b4)
+      for (int c4 = 0; c4 < 4; ++c4)
+        for (int d4 = 0; d4 < 4; ++d4)
+          for (int co = 0; co < C; ++co) {
+            const float u = B.host[o.lut + (size_t)(25 * a4 + 5 * b4 + c4) * C + co], v = B.host[o.lut + (size_t)(25 * b4 + 5 * c4 + d4) * C + co];
+            B.host[o.lut4 + (size_t)(64 * a4 + 16 * b4 + 4 * c4 + d4) * C + co] = u > v ? u : v;
+          }
 
   // ---- 32->32 convs
   const MuralAffine* convs[SNV_NLAYER] = {&T.rbs1[0].conv1, &T.rbs1[0].conv2, &T.rbs1[1].conv1, &T.rbs1[1].conv2, &T.conv_mid,
@@ -415,6 +427,10 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         s1.nwords = (sh.distal_len + 15) / 16 + 1;
         s1.radius = (sh.distal_len - 1) / 2;
         m->s1_lds_bytes = (size_t)2 * SNV_LUTBLK * 4 + (size_t)16 * s1.wave_bytes;
+        // the large tower's pair table rides along where it fits (15-wide pools: the shipped first max-pool)
+        m->s1_pair = s1.tw[0].pk == 15 && s1.tw[0].ps == 15 && m->s1_lds_bytes + (size_t)SNV_LUT4 * 4 <= kLdsMax &&
+                     !getenv("MURAL_DEBUG_NO_PAIR_TABLE");
+        if (m->s1_pair) m->s1_lds_bytes += (size_t)SNV_LUT4 * 4;
         if (m->s1_lds_bytes > kLdsMax || s1.tw[0].pk > 16 || s1.tw[1].pk > 4) {
           set_error("distal_radius %d is too long for the stage-1 kernel's LDS window", (sh.distal_len - 1) / 2);
           rc = MURAL_E_INVALID;
@@ -440,7 +456,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     for (int tw = 0; tw < 2; ++tw) {
       TowerDev& d = m->args.tw[tw];
       const TowerOff& o = toff[tw];
-      d.lut = m->blob + o.lut; d.taps = m->blob + o.taps; d.bias0 = m->blob + o.bias0; d.wfrag = m->blob + o.wfrag; d.wfrag4 = m->blob + o.wfrag4;
+      d.lut = m->blob + o.lut; d.lut4 = m->blob + o.lut4; d.taps = m->blob + o.taps; d.bias0 = m->blob + o.bias0; d.wfrag = m->blob + o.wfrag; d.wfrag4 = m->blob + o.wfrag4;
       d.bias = m->blob + o.bias; d.post_s = m->blob + o.post_s; d.post_t = m->blob + o.post_t;
       d.ex_s = m->blob + o.ex_s; d.ex_t = m->blob + o.ex_t; d.fc_w = m->blob + o.fc_w; d.fc_b = m->blob + o.fc_b;
     }
@@ -457,6 +473,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     m->args_small.n_class = sh.n_class;
     m->args_small.has_local = m->args.has_local;
     m->s1.lut[0] = m->args.tw[0].lut;
+    m->s1.lut4 = m->s1_pair ? m->args.tw[0].lut4 : nullptr;
     m->s1.lut[1] = m->args.tw[1].lut;
   }
   if (has_local) {

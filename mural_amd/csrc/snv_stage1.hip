@@ -111,6 +111,86 @@ __device__ __forceinline__ void pooled_lookup(const Stage1Tower& g, int lane, co
   }
 }
 
+// ---- pair-table form of the large tower's pooled lookup (15-wide pools).  Slot of pooled column j2 (16 bytes): two halves of
+// 8 bytes, written by two lanes -- [pair codes of window columns (0,1) (2,3) (4,5) (6,7) | flag | 3 pad] and [pair codes of
+// (8,9) (10,11) (12,13) | 3-mer index of column 14 | flag | 3 pad]; a pair code is the 4-mer of the bases under both columns
+// (64 a + 16 b + 4 c + d), valid only when every base is A/C/G/T and every column is interior: the flag is 1 otherwise and the
+// whole pooled column takes the per-column path of pooled_lookup.
+__device__ __forceinline__ void build_kpair(const Stage1Tower& g, int lane, const uint8_t* cb0, uint8_t* kw) {
+  const uint8_t* cb = cb0 + g.col0;
+  for (int t = lane; t < 2 * g.L2; t += 64) {
+    const int j2 = t >> 1, half = t & 1;
+    const int j0 = j2 * g.ps - g.pp + 8 * half;      // first window column of this half
+    const int ncol = half ? 7 : 8;                   // columns j0 .. j0 + ncol - 1; symbols cb[j0] .. cb[j0 + ncol + 1]
+    uint32_t sy[10];
+    uint32_t bad = (j0 < 1 || j0 + ncol - 1 > g.L1 - 2) ? 1u : 0u;
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      const int idx = j0 + i;                        // cb[idx] = symbol of tower column idx - 1
+      const bool in = idx >= 0 && idx <= g.L1 + 1 && i < ncol + 2;
+      sy[i] = in ? cb[idx] : 0u;
+      if (i < ncol + 2 && (!in || sy[i] > 3u)) bad = 1u;
+    }
+    uint32_t lo = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      uint32_t code;
+      if (half && q == 3) code = 25u * sy[6] + 5u * sy[7] + sy[8];                     // single column 14: 3-mer index (no N here)
+      else code = 64u * sy[2 * q] + 16u * sy[2 * q + 1] + 4u * sy[2 * q + 2] + sy[2 * q + 3];
+      lo |= (code & 0xFFu) << (8 * q);
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(kw + (size_t)j2 * 16 + 8 * half);
+    dst[0] = lo;
+    dst[1] = bad;
+  }
+}
+
+__device__ __forceinline__ void pooled_lookup_pair(const Stage1Tower& g, int lane, const float* lutS, const float* lut4S, const uint8_t* cb0,
+                                                   const uint8_t* kw, float* __restrict__ out /* [L2][32] */) {
+  const float* tapS = lutS + SNV_LUT;
+  const float* b0S = tapS + SNV_TAPS;
+  const uint8_t* cb = cb0 + g.col0;
+  const int cg = lane & 7;
+  const int total = g.L2 * 8;
+  for (int task = lane; task < total; task += 64) {
+    const int j2 = task >> 3;
+    const uint4 q = *reinterpret_cast<const uint4*>(kw + (size_t)j2 * 16);
+    f32x4 m;
+    if (((q.y | q.w) & 0xFFu) == 0u) {      // eight table rows instead of fifteen
+      m = s1_ld4(lut4S + (q.x & 0xFFu) * 32u + 4u * cg);
+      m = s1_max4(m, s1_ld4(lut4S + ((q.x >> 8) & 0xFFu) * 32u + 4u * cg));
+      m = s1_max4(m, s1_ld4(lut4S + ((q.x >> 16) & 0xFFu) * 32u + 4u * cg));
+      m = s1_max4(m, s1_ld4(lut4S + (q.x >> 24) * 32u + 4u * cg));
+      m = s1_max4(m, s1_ld4(lut4S + (q.z & 0xFFu) * 32u + 4u * cg));
+      m = s1_max4(m, s1_ld4(lut4S + ((q.z >> 8) & 0xFFu) * 32u + 4u * cg));
+      m = s1_max4(m, s1_ld4(lut4S + ((q.z >> 16) & 0xFFu) * 32u + 4u * cg));
+      m = s1_max4(m, s1_ld4(lutS + (q.z >> 24) * 32u + 4u * cg));
+    } else {                                 // a column with N / IUPAC codes, zero padding or the crop edge: column by column
+      m = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+      const int jlo = j2 * g.ps - g.pp;
+      for (int w = 0; w < g.pk; ++w) {
+        const int j = jlo + w;
+        if (j < 0 || j >= g.L1) continue;      // MaxPool1d pads with -inf
+        const uint32_t idx = kmer_index(cb, j, g.L1);
+        f32x4 v;
+        if (idx != 255u) {
+          v = s1_ld4(lutS + idx * 32u + 4u * cg);
+        } else {                               // zero padding is applied after the BN: PAD rows are exactly 0
+          const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
+          const uint32_t sc = cb[j + 1];
+          const uint32_t sr = (j == g.L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
+          v = s1_ld4(b0S + 4 * cg);
+          v += s1_ld4(tapS + (0 * N_SYM + sl) * 32 + 4 * cg);
+          v += s1_ld4(tapS + (1 * N_SYM + sc) * 32 + 4 * cg);
+          v += s1_ld4(tapS + (2 * N_SYM + sr) * 32 + 4 * cg);
+        }
+        m = s1_max4(m, v);
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + (size_t)j2 * 32 + 4 * cg) = m;   // 8 lanes write one 128-byte column
+  }
+}
+
 template <int SRC>  // 0: symbol rows in HBM (dense path), 1: packed genome
 __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args args) {
   extern __shared__ __attribute__((aligned(16))) float s1mem[];
@@ -119,7 +199,9 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* lutL = s1mem;
   float* lutM = s1mem + SNV_LUTBLK;
-  uint8_t* wbase = reinterpret_cast<uint8_t*>(s1mem + 2 * SNV_LUTBLK) + (size_t)wave * args.wave_bytes;
+  const bool pair = args.lut4 != nullptr;      // large tower through the pair table (launch_snv_stage1 sized the LDS for it)
+  float* lut4 = s1mem + 2 * SNV_LUTBLK;
+  uint8_t* wbase = reinterpret_cast<uint8_t*>(s1mem + 2 * SNV_LUTBLK + (pair ? SNV_LUT4 : 0)) + (size_t)wave * args.wave_bytes;
   uint8_t* cb = wbase;                        // [CW] symbols, PAD at both ends
   uint8_t* kwL = cb + args.cw;                // [L2 large][16]
   uint8_t* kwM = kwL + args.tw[0].L2 * 16;    // [L2 mid][4]
@@ -128,6 +210,8 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
     *reinterpret_cast<f32x4*>(lutL + i) = s1_ld4(args.lut[0] + i);
     *reinterpret_cast<f32x4*>(lutM + i) = s1_ld4(args.lut[1] + i);
   }
+  if (pair)
+    for (int i = tid * 4; i < SNV_LUT4; i += S1_THREADS * 4) *reinterpret_cast<f32x4*>(lut4 + i) = s1_ld4(args.lut4 + i);
   __syncthreads();
 
   const int Lwin = args.Lwin;
@@ -190,11 +274,13 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
       }
     }
     wave_lds_fence();
-    build_kwin<16>(args.tw[0], lane, cb, kwL);
+    if (pair) build_kpair(args.tw[0], lane, cb, kwL);
+    else build_kwin<16>(args.tw[0], lane, cb, kwL);
     build_kwin<4>(args.tw[1], lane, cb, kwM);
     wave_lds_fence();
     float* out = args.x0 + (size_t)row * args.x0_cols * 32;
-    pooled_lookup<16>(args.tw[0], lane, lutL, cb, kwL, out);
+    if (pair) pooled_lookup_pair(args.tw[0], lane, lutL, lut4, cb, kwL, out);
+    else pooled_lookup<16>(args.tw[0], lane, lutL, cb, kwL, out);
     pooled_lookup<4>(args.tw[1], lane, lutM, cb, kwM, out + (size_t)args.tw[0].L2 * 32);
     wave_lds_fence();   // the next iteration overwrites cb / kw
   }
