@@ -169,11 +169,41 @@ class HipShardForward:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.local_radius, self.local_order, self.distal_radius = local_radius, local_order, distal_radius
         self.batch_sites, self.model_type, self.reuse = batch_sites, model_type, bool(reuse) and model_type == "snv"
-        self.records = {r.name: r for r in ingest.scan_fasta(fasta_path)}
+        # the FASTA index (record offsets: one pass over the file) is built on a host thread -- the C++ scanner releases the GIL --
+        # so the driver reads the BED beside it; `records` joins
+        self._records, self._scan_error, self._early = None, None, None
+        self._scan = threading.Thread(target=self._scan_fasta, daemon=True)
+        self._scan.start()
         self._resident = (None, None)
         self._prefetch = None          # (chrom, thread, result box)
         self.seconds = {"pack_wait": 0.0, "pack": 0.0}
         self.reuse_sites = 0           # sites that went through the reuse kernels (diagnostics / tests)
+
+    def _scan_fasta(self):
+        try:
+            self._records = {r.name: r for r in self._ingest.scan_fasta(self.fasta_path)}
+        except Exception as e:      # noqa: BLE001  (re-raised by `records`)
+            self._scan_error = e
+            return
+        # shards come in ascending chromosome-name order, so the first one is most likely the smallest name of the file: pack it
+        # right away (still beside the driver's BED read); a BED without that chromosome just leaves the box unused
+        if self._records:
+            first = min(self._records)
+            box = {}
+            t0 = time.perf_counter()
+            try:
+                box["packed"] = self._ingest.pack_fasta_record(self.fasta_path, self._records[first])
+            except Exception as e:      # noqa: BLE001  (re-raised by genome())
+                box["error"] = e
+            box["seconds"] = time.perf_counter() - t0
+            self._early = (first, box)
+
+    @property
+    def records(self):
+        self._scan.join()      # a finished thread joins at once; safe from the packer thread as well
+        if self._scan_error is not None:
+            raise self._scan_error
+        return self._records
 
     # -- chromosome residency ---------------------------------------------------------------------------------------------
     def _pack(self, chrom, box):
@@ -190,6 +220,8 @@ class HipShardForward:
             return
         if self._prefetch is not None and self._prefetch[0] == chrom:
             return
+        if self._early is not None and self._early[0] == chrom:      # the scan thread already packed it
+            return
         box = {}
         th = threading.Thread(target=self._pack, args=(chrom, box), daemon=True)
         th.start()
@@ -205,6 +237,8 @@ class HipShardForward:
                 _, th, box = self._prefetch
                 th.join()
                 self._prefetch = None
+            elif self._early is not None and self._early[0] == chrom:      # packed by the scan thread (records joined it above)
+                box, self._early = self._early[1], None
             else:
                 box = {}
                 self._pack(chrom, box)
@@ -215,6 +249,7 @@ class HipShardForward:
             packed, mask, n, amb = box["packed"]
             from .data.genome import PackedGenome
             self._resident = (chrom, PackedGenome(packed, mask, n, self.device, amb))
+            self._early = None                         # an unused early pack is dropped with the first resident chromosome
         return self._resident[1]
 
     # -- compute ----------------------------------------------------------------------------------------------------------
