@@ -163,10 +163,13 @@ def cpu_baseline(model_state, codes, budget_s=8.0):
             train_step()
         t = min(train_step() for _ in range(reps))
         train[str(tb)] = {"steps_per_s": 1.0 / t, "sites_per_s": tb / t}
-    return {"value": by_batch["256"], "unit": "bases/s", "cores": best_threads, "kind": "port", "cpu_model": cpu_model_name(),
+    # two medians exist for batch 256 at the chosen thread count -- the scan's (5 repeats of one batch) and the loop's (20 fresh
+    # batches); on a shared host either can catch a slow spell (observed: 4.8 k vs 8.1 k in one run), so the baseline is the better one
+    value = max(by_batch["256"], scan[str(best_threads)])
+    return {"value": value, "unit": "bases/s", "cores": best_threads, "kind": "port", "cpu_model": cpu_model_name(),
             "host_cpus": ncpu, "threads_scan_bases_per_s_at_batch_256": scan,
             "sample": "model only (inputs pre-encoded: cat_x int64, distal_x fp32 one-hot) on windows of the same synthetic chromosome; "
-                      "value = batch 256; " + "; ".join(f"batch {b}: {v}" for b, v in samples.items()),
+                      "value = batch 256 (the better of the thread scan's median and the 20-batch loop's median); " + "; ".join(f"batch {b}: {v}" for b, v in samples.items()),
             "bases_per_s_by_batch": by_batch, "train": train,
             "train_note": "forward + backward + clip + Adam of the same restatement; batch 4096 is a single timed step"}
 
