@@ -56,4 +56,17 @@ __device__ __forceinline__ f32x4 lds_ld4(const char* base, uint32_t off) {
 }
 __device__ __forceinline__ void lds_st4(char* base, uint32_t off, f32x4 v) { *reinterpret_cast<f32x4*>(base + off) = v; }
 
+
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+
+// 16 bytes at (wave-uniform base + 32-bit lane offset) through a raw buffer descriptor: four SGPRs + one VGPR per load -- no 64-bit
+// lane pointers for the compiler to precompute and spill (the flat form kept nine of them in scratch and drained vmcnt per load)
+using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
+}
+
 }  // namespace mural

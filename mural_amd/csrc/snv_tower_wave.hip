@@ -79,16 +79,6 @@ __device__ __forceinline__ WaveAddr wave_setup(const TowerGeom& g, int st, int P
   return a;
 }
 
-// 16 bytes at (wave-uniform base + 32-bit lane offset) through a raw buffer descriptor: four SGPRs + one VGPR per load -- no 64-bit
-// lane pointers for the compiler to precompute and spill (the flat form kept nine of them in scratch and drained vmcnt per load)
-using u32x4 = __attribute__((ext_vector_type(4))) unsigned int;
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t uniform_rsrc(const void* base) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, 0x7fffffff, 0x00020000);
-}
-__device__ __forceinline__ f32x4 buf_ld4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
-  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, 0, 0));
-}
-
 // four k-steps (4 g .. 4 g + 3) of both M-blocks' fragments: two 16-byte loads per lane; w4 = layer base of wfrag4 + 4 * lane
 // (wf = descriptor of the tower's wfrag4 table, layer_bytes = byte offset of the layer in it: scalar; lane16 = 16 * lane)
 struct FragSrc {
@@ -113,7 +103,6 @@ __device__ __forceinline__ void load_frag4(float (&a0)[SNV_KSTEPS], float (&a1)[
 // One conv tap (8 k-steps) of a block for both M-blocks -- the two accumulator chains alternate, pair by pair -- with the PREVIOUS
 // block's epilogue of one M-block (epi_burst) behind the first pair.  A scheduling barrier closes every pair: the
 // backend's own grouping serialises each chain (8 dependent MFMAs in a row: 40 instead of 32 cycles each).
-using f32x2 = __attribute__((ext_vector_type(2))) float;
 
 // The whole epilogue of one M-block of a block as ONE burst of vector instructions (measured, tools/microbench/mfma_valu.hip: vector
 // ALU work does not run beside this wave's or its SIMD partner's MFMAs -- every v_* instruction costs 2.5 - 5 cycles of MFMA issue and

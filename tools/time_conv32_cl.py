@@ -1,4 +1,5 @@
-"""GPU box: time single launches of the channel-last conv kernels (csrc/conv32_cl.hip) at the training shapes."""
+"""GPU box: time single launches of the channel-last conv kernels (csrc/conv32_cl.hip; WHICH=cw: csrc/conv32_wave.hip) at the
+training shapes."""
 import ctypes as C
 import os
 import sys
@@ -13,8 +14,9 @@ from mural_amd import _lib  # noqa: E402
 lib = _lib.lib()
 dev = torch.device("cuda", 0)
 B = 4096
-tag = " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("MURAL_"))
-for L in (134, 67, 20, 7):
+CW = os.environ.get("WHICH", "cl") == "cw"
+tag = ("cw " if CW else "cl ") + " ".join(f"{k}={v}" for k, v in os.environ.items() if k.startswith("MURAL_"))
+for L in (134, 67, 20, 23, 7):
     x = torch.randn(B, L, 32, device=dev)
     dy = torch.randn(B, L, 32, device=dev)
     r1, r2 = torch.randn(B, L, 32, device=dev), torch.randn(B, L, 32, device=dev)
@@ -30,14 +32,30 @@ for L in (134, 67, 20, 7):
     st = _lib.current_stream_ptr(dev)
     _lib.check(lib.mural_debug_cl_bn_stats(x.data_ptr(), B * L, 1, acc.data_ptr(), st))
 
+    tick = torch.zeros(4096, dtype=torch.int32, device=dev)
+    TICK = os.environ.get("TICKETS", "1") == "1"
+    tk = [0]
+
+    def next_tick():
+        tk[0] += 1
+        return tick[tk[0]:].data_ptr() if TICK else None
+
     def fwd(a, b):
+        if CW:
+            return lambda: _lib.check(lib.mural_debug_cw_conv32_fwd(x.data_ptr(), B, L, 1, acc.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                                                    rm.data_ptr(), rv.data_ptr(), state.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, a, b,
+                                                                    acc_out.data_ptr(), 1, y.data_ptr(), next_tick(), st))
         return lambda: _lib.check(lib.mural_debug_cl_conv32_fwd(x.data_ptr(), B, L, 1, acc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
                                                                 rv.data_ptr(), state.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, a, b,
                                                                 acc_out.data_ptr(), 1, y.data_ptr(), st))
 
     def bwd():
-        _lib.check(lib.mural_debug_cl_conv32_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), B, L, state.data_ptr(), 1, y.data_ptr(),
-                                                 acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), st))
+        if CW:
+            _lib.check(lib.mural_debug_cw_conv32_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), B, L, state.data_ptr(), gamma.data_ptr(), 1, y.data_ptr(),
+                                                     acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), next_tick(), st))
+        else:
+            _lib.check(lib.mural_debug_cl_conv32_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), B, L, state.data_ptr(), 1, y.data_ptr(),
+                                                     acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), st))
 
     res = []
     for name, fn in (("fwd", fwd(None, None)), ("fwd+r1", fwd(r1.data_ptr(), None)), ("fwd+r1+r2", fwd(r1.data_ptr(), r2.data_ptr())), ("bwd", bwd)):
