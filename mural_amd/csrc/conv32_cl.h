@@ -9,7 +9,7 @@ namespace mural {
 
 constexpr int CL_C = 32;
 
-// the same fold of the batch sums into scale / shift / state as conv32_mfma.hip (all 256 threads, eight loads each)
+// the same fold of the batch sums into scale / shift / state as conv32_mfma.hip (256 threads, eight loads each)
 struct ClFin {
   const double* acc;
   double n;
@@ -22,7 +22,7 @@ struct ClFin {
 };
 
 __device__ __forceinline__ void cl_finalize(const ClFin& f, float* aux /* scale | beta | mean */, double* red, int tid) {
-  {
+  if (tid < 256) {      // (workgroups of 256 or 512 threads)
     const int c = tid & 31, grp = tid >> 5;
     double v[8];
 #pragma unroll

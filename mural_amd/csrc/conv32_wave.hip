@@ -2,27 +2,34 @@
 //
 // Reference semantics: nn.BatchNorm1d -> nn.Conv1d of MuRaL/model/model_snv.py:350-430 and the ResBlock of :794-812 under model.train()
 // (training.py:424), and their gradients under loss.backward() (training.py:427) -- the same math as conv32_cl.hip, which stays the
-// kernel of rows too long for a wave's image and the A/B reference (MURAL_TRAIN_CONV_CL=1).  What changes is who owns what, the recipe
-// of the prediction kernel (snv_tower_wave.hip):
+// kernel of rows too long for a wave's image, of the one layer with a ReLU behind it (conv3) and the A/B reference
+// (MURAL_TRAIN_CONV_CL=1).  What changes is who owns what, the recipe of the prediction kernel (snv_tower_wave.hip):
 //
 //   * a WAVE owns whole batch rows: a unit is P rows of L columns on a flattened column axis with zero separators (<= 9 blocks of
-//     16 columns), all 32 output channels.  There is no workgroup barrier in the unit loop; the phases of conv32_cl.hip (stage,
-//     MFMA, stream-out: strictly additive there) overlap inside the wave instead.
-//   * ONE wave per SIMD (4 per CU) with 512 registers and two LDS images each:
-//       forward : the images double-buffer the units.  While unit u runs its 48 MFMAs per block, the rows of unit u+1 (requested at
-//                 the start of unit u) arrive in registers, take ReLU + BatchNorm a few 16-byte pieces per block and are written to
-//                 the other image; outputs go to memory straight from the accumulators (lane = column, 16 bytes = 4 channels) with
-//                 the residual operands loaded two blocks ahead in the same layout; the batch sums of act(y) for the next BatchNorm
-//                 ride in the epilogue bursts.
-//       backward: the images hold dy and xhat = (act(x) - mean) * invstd.  The whole next unit (dy, x) travels in registers under
-//                 the two MFMA phases: weight gradient (dW~ += dy (x) xhat, K = columns, 8-byte operand reads) and input gradient
-//                 (the forward conv with the transposed, tap-flipped filter on the dy image; dz leaves from the accumulators).
-//                 Keeping xhat instead of BN(act(x)) in the image makes sum(dz * xhat) a read of that image in accumulator layout
-//                 (the workgroup-tile kernel re-reads x from memory for it) and costs one fix-up per partial row:
-//                     dW[co][ci][t] = gamma[ci] * dW~[co][ci][t] + beta[ci] * S_t[co],
-//                 S_t = sum of dy over the columns whose tap-t input is not zero padding (S_1 = bias gradient, S_0 / S_2 leave out
-//                 the first / last column of every row), because the zero padding is applied behind the BatchNorm.
-//   * units are tickets of an atomic counter (zero at launch), requested a unit ahead.
+//     16 columns), all 32 output channels, ONE LDS image [column][32 channels] (<= 18.7 KB).  Eight waves per CU = two per SIMD: there
+//     is no workgroup barrier in the unit loop, the waves drift apart and one wave's memory phase (request its rows, wait, ReLU +
+//     BatchNorm, write the image) runs under its SIMD partner's MFMAs.  (First form of this file: one wave per SIMD with two images
+//     and the next unit travelling in registers under the MFMAs -- 55 / 86 us per 4096 x 134 layer against 60 / 101 us of the
+//     workgroup-tile kernels: with a lone wave per SIMD every vector instruction and every MFMA -> VALU switch costs MFMA issue.)
+//   * outputs leave straight from the accumulators (lane = column, 16 bytes = 4 channels; the two M-blocks complete a 128-byte row),
+//     residual operands arrive two blocks ahead in the same layout; nothing is written back to the image.
+//   * forward: the batch sums of relu(y) for the next BatchNorm ride in the epilogue bursts.
+//   * backward: ONE image (dy) serves both gradients.
+//       input gradient : the forward conv with the transposed, tap-flipped filter; its epilogue is a store and nothing else.
+//       weight gradient: dWr[co][ci][t] += dy[col - t + 1][co] * r[col][ci], K = columns; the dy operand of the three taps comes from
+//                        the image (8-byte reads of channels 2 n16, 2 n16 + 1), r = act(x) straight from memory in operand layout
+//                        (8 bytes per lane, twelve k-steps ahead), NOT normalised: columns without data read as zero and stay zero.
+//       The BatchNorm algebra moves to the partial row of the workgroup (all of it is linear in dWr and in three vectors of dy sums):
+//           S_t[co]      = sum of dy over the columns whose tap-t partner is not zero padding = S - (first columns | 0 | last columns)
+//           dWx          = invstd[ci] * (dWr - mean[ci] * S_t[co])                  (= sum dy (x) xhat)
+//           dW           = gamma[ci] * dWx + beta[ci] * S_t[co]                     (the zero padding sits behind the BatchNorm)
+//           sum dz       = sum_{co,t} W[co][ci][t] * S_t[co]
+//           sum dz*xhat  = sum_{co,t} W[co][ci][t] * dWx[co][ci][t]                 (exact identities: dz = conv^T(dy))
+//       so the BatchNorm-backward sums cost no pass over dz and no second image.
+//   * a workgroup is four waves with <= 80 KB of LDS, so two of them -- of one launch or of two launches on different streams (the
+//     two towers) -- share a CU.  Its waves walk the workgroup's contiguous share of the units with a fixed stride: the assignment
+//     decides the order of the float sums, a fixed one keeps the step bitwise reproducible (one global ticket counter for 4096 units
+//     of 10 us also serialises in L2: measured 98 instead of 55 us per launch).
 //   * out-of-range work never branches: every global access goes through a per-unit buffer descriptor whose num_records is the
 //     bytes of the rows that exist; lanes of separator / padding columns carry an offset no descriptor covers (loads return 0,
 //     stores are dropped).
@@ -35,12 +42,15 @@ namespace mural {
 namespace {
 
 constexpr int CW_NBMAX = 9;                 // 16-column blocks per unit at most
+constexpr int CW_THREADS = 256;         // four waves; two workgroups share a CU (<= 80 KB of LDS each), possibly of two launches
+constexpr int CW_WAVES = CW_THREADS / 64;
 constexpr uint32_t CW_BLK = 2048u;          // bytes between blocks of an image (16 columns x 128 B; the swizzle key has period 16)
 constexpr uint32_t CW_OOB = 0x80000000u;    // lane offset outside every unit descriptor
-constexpr int CW_DUMP = 128;                // floats behind each image of a wave: 32 16-byte dump slots (where the lanes of staging pieces
-                                            // behind the unit store; slot + image stride is the second image's slot)
-constexpr int CW_AUX = 256;                 // floats in front of the waves' regions (BatchNorm constants, final sums)
+constexpr int CW_DUMP = 128;                // floats behind a wave's image: 32 16-byte dump slots (staging pieces behind the unit)
+constexpr int CW_AUX = 512;                 // floats in front of the waves' regions: BatchNorm constants | offset table
+constexpr int CW_AUX_TAB = 128;             // uint32[4 * CW_NBMAX][4]: memory offset of column 4 s + kk of a unit (weight gradient)
 constexpr int CW_CUS = 256;
+constexpr int CW_LA = 12;                   // k-steps the weight gradient's x operand is requested ahead
 
 struct CwGeom {
   int L, Sc, P, nb;
@@ -54,7 +64,7 @@ bool cw_geom(int64_t B, int L, CwGeom* g) {
   const int Sc = L + 1;
   const int pmax = (16 * CW_NBMAX - 1) / Sc;
   if (pmax < 1) return false;
-  int64_t p = B / (4 * CW_CUS);             // one unit per wave when the rows are short
+  int64_t p = B / (2 * CW_WAVES * CW_CUS);  // one unit per wave (eight per CU) when the rows are short
   if (p > pmax) p = pmax;
   if (p < 1) p = 1;
   g->L = L;
@@ -73,39 +83,68 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t cw_rsrc(const void* base, uint
 __device__ __forceinline__ void buf_st4(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, f32x4 v) {
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, 0, 0);
 }
+// (soff: a scalar offset inside the lane's own 128-byte row -- whether a lane is in range is decided by its lane offset alone)
+__device__ __forceinline__ void buf_st4s(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t soff, f32x4 v) {
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), r, byte_off, soff, 0);
+}
+__device__ __forceinline__ f32x4 buf_ld4s(__amdgpu_buffer_rsrc_t r, uint32_t byte_off, uint32_t soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, byte_off, soff, 0));
+}
+using u32x2 = __attribute__((ext_vector_type(2))) unsigned int;
+__device__ __forceinline__ f32x2 buf_ld2(__amdgpu_buffer_rsrc_t r, uint32_t byte_off) {
+  return __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(r, byte_off, 0, 0));
+}
 __device__ __forceinline__ f32x4 pk_fma(const f32x4& a, const f32x4& b, const f32x4& c) {
   const f32x2 lo = __builtin_elementwise_fma(f32x2{a.x, a.y}, f32x2{b.x, b.y}, f32x2{c.x, c.y});
   const f32x2 hi = __builtin_elementwise_fma(f32x2{a.z, a.w}, f32x2{b.z, b.w}, f32x2{c.z, c.w});
   return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
-// byte offset inside a unit of this lane's 16 bytes of block b in accumulator layout (column n16 of the block, channels 4 kk .. + 3
-// of M-block 0; M-block 1 sits 64 bytes further); CW_OOB for separator / padding columns
-__device__ __forceinline__ uint32_t cw_acc_offset(const CwGeom& g, int b, int n16, int kk) {
-  const uint32_t c = 16u * (uint32_t)b + (uint32_t)n16;
+// byte offset inside a unit of the 128-byte row of logical column c; CW_OOB for separator / padding columns
+__device__ __forceinline__ uint32_t cw_col_offset(const CwGeom& g, uint32_t c) {
   const uint32_t u = c - 1u;
   const uint32_t p = g.dSc.div(u);
   const uint32_t j = u - p * (uint32_t)g.Sc;
   const bool ok = c >= 1u && p < (uint32_t)g.P && j < (uint32_t)g.L;
-  return ok ? (((p * (uint32_t)g.L + j) << 7) + 16u * (uint32_t)kk) : CW_OOB;
+  return ok ? ((p * (uint32_t)g.L + j) << 7) : CW_OOB;
 }
 
 // staging slot u of a lane: piece lane + 64 u of the unit in memory order (byte offset 16 lane + 1024 u: pieces behind the unit fall
 // outside its descriptor) -> byte offset in the image
-__device__ __forceinline__ void cw_stage_slot(const CwGeom& g, int u, int lane, uint32_t dump, uint32_t* soff) {
+__device__ __forceinline__ uint32_t cw_stage_slot(const CwGeom& g, int u, int lane, uint32_t dump) {
   const uint32_t task = (uint32_t)lane + 64u * (uint32_t)u;
   const uint32_t col = task >> 3;
   const uint32_t p = g.dL.div(col);
   const uint32_t l = col - p * (uint32_t)g.L;
-  const bool ok = task < (uint32_t)g.nchunk;
-  *soff = ok ? 4u * (uint32_t)lds_off(2 + (int)(p * (uint32_t)g.Sc + l), (int)(task & 7u)) : dump;
+  return task < (uint32_t)g.nchunk ? 4u * (uint32_t)lds_off(2 + (int)(p * (uint32_t)g.Sc + l), (int)(task & 7u)) : dump;
+}
+
+// filter fragments (conv32_cl.h: cl_frags) from a copy of W [32][32][3] in LDS (rows of 96 floats at a pitch of 97: the 16 lanes of a
+// read sit 96 floats apart, i.e. in one bank): the strided gather from memory touches 64 cache lines per load and instruction
+constexpr int CW_WPITCH = 97;
+constexpr int CW_WFLOATS = CL_C * CW_WPITCH;
+__device__ __forceinline__ void cw_copy_w(const float* __restrict__ W, float* Wl, int tid) {
+  for (int i = tid; i < CL_C * CL_C * 3 / 4; i += CW_THREADS) {
+    const f32x4 v = ld4(W + 4 * i);
+    const int row = (4 * i) / 96, col = (4 * i) - 96 * row;
+    float* d = Wl + row * CW_WPITCH + col;
+    d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+  }
+}
+__device__ __forceinline__ void cw_frags_lds(const float* Wl, int dgrad, int mb, int n16, int kk, float (&a)[SNV_KSTEPS]) {
+#pragma unroll
+  for (int s = 0; s < SNV_KSTEPS; ++s) {
+    const int t = s / 8, h = (s % 8) / 4, q = s % 4;
+    const int cin = 16 * h + 4 * kk + q, cout = 16 * mb + n16;
+    a[s] = Wl[dgrad ? cin * CW_WPITCH + cout * 3 + (2 - t) : cout * CW_WPITCH + cin * 3 + t];
+  }
 }
 
 #define CW_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
 // one conv tap (8 k-steps) of a block for both M-blocks: the two accumulator chains alternate pair by pair, `burst` (vector / LDS /
-// memory instructions of the pipeline around the MFMAs) sits behind the first pair; a scheduling barrier closes every pair (left alone
-// the backend serialises each chain: 8 dependent MFMAs in a row cost 40 instead of 32 cycles each)
+// memory instructions around the MFMAs) sits behind the first pair; a scheduling barrier closes every pair (left alone the backend
+// serialises each chain: 8 dependent MFMAs in a row cost 40 instead of 32 cycles each)
 template <int T, class F>
 __device__ __forceinline__ void cw_tap(const float (&a0)[SNV_KSTEPS], const float (&a1)[SNV_KSTEPS], const f32x4 (&bv)[2], f32x4& acc0,
                                        f32x4& acc1, F&& burst) {
@@ -172,28 +211,15 @@ __device__ __forceinline__ void cw_conv_blocks(const char* img, const uint32_t (
   epi(NB - 1, 1, pa1);
 }
 
-// sums held per lane in accumulator layout (column n16, channels 16 m + 4 kk .. + 3) -> the workgroup's accumulator slot: lanes of a
-// kk group meet through shuffles, the four waves through `red` ([4 waves][NV][32] floats), NV * 32 double atomics per workgroup
-template <int NV>
-__device__ __forceinline__ void cw_acc_slot_add(const f32x4 (&v)[NV][2], double* slot, float* red, int tid) {
-  const int lane = tid & 63, wave = tid >> 6, n16 = lane & 15, kk = lane >> 4;
-#pragma unroll
-  for (int i = 0; i < NV; ++i)
-#pragma unroll
-    for (int m = 0; m < 2; ++m)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float s = v[i][m][q];
-#pragma unroll
-        for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off);
-        if (n16 == 0) red[(wave * NV + i) * CL_C + 16 * m + 4 * kk + q] = s;
-      }
-  __syncthreads();
-  if (tid < NV * CL_C) {
-    const int i = tid >> 5, c = tid & 31;
-    const float t = (red[(0 * NV + i) * CL_C + c] + red[(1 * NV + i) * CL_C + c]) + (red[(2 * NV + i) * CL_C + c] + red[(3 * NV + i) * CL_C + c]);
-    atomicAdd(&slot[i * CL_C + c], (double)t);
-  }
+// the workgroup's contiguous share of the units; its waves walk it with a fixed stride (which wave computes a unit decides the order
+// of the float sums in its partial row: a fixed assignment keeps a step bitwise reproducible)
+struct CwUnits {
+  int64_t lo, hi;
+};
+__device__ __forceinline__ void cw_units_init(CwUnits& w, int64_t n_units) {
+  const int64_t per = (n_units + gridDim.x - 1) / gridDim.x;
+  w.lo = (int64_t)blockIdx.x * per;
+  w.hi = w.lo + per < n_units ? w.lo + per : n_units;
 }
 
 // ------------------------------------------------------------------------------------------------------------ forward
@@ -210,16 +236,14 @@ struct CwFwdArgs {
   double* stat_out;       // batch sums of relu(y), relu(y)^2 for the next BatchNorm; nullptr: none
   int64_t B;
   int64_t n_units;
-  int* counter;           // unit tickets (zero at launch); nullptr: fixed stride
-  int dbg;                // timing experiments (MURAL_DEBUG_CW): 1 no next-unit loads, 2 no stores, 4 no residual loads, 8 no conv
+  int dbg;                // timing experiments (MURAL_DEBUG_CW): 1 no loads of x, 2 no stores, 4 no residual loads, 8 no conv
 };
 
 template <int NB>
-__global__ __launch_bounds__(SNV_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv32w_fwd_kernel(const CwFwdArgs a) {
+__global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int IMG_FLOATS = (16 * NB + 2) * CL_C;
-  constexpr uint32_t IMG_BYTES = (IMG_FLOATS + CW_DUMP) * 4u;   // stride between the two images: image | dump slots
-  constexpr int WAVE_FLOATS = 2 * (IMG_FLOATS + CW_DUMP);
+  constexpr int WAVE_FLOATS = IMG_FLOATS + CW_DUMP;
   constexpr int NLD = 2 * NB;                                   // staging slots per lane: 64 NLD >= pieces of the widest unit
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,12 +252,28 @@ __global__ __launch_bounds__(SNV_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
   float* aux = smem;                                            // scale | beta | mean
   float* wbase = smem + CW_AUX + wave * WAVE_FLOATS;
   char* wb = reinterpret_cast<char*>(wbase);
+  CwUnits units;
+  cw_units_init(units, a.n_units);
+  const uint32_t lane16 = 16u * (uint32_t)lane;
+  const uint32_t row_bytes = (uint32_t)g.L * 128u;
+  const size_t unit_stride = (size_t)g.P * g.L * CL_C;          // floats
+  auto unit_bytes = [&](int64_t u) -> uint32_t {               // bytes of the rows of unit u that exist
+    const int64_t rows = a.B - u * g.P;
+    return u < units.hi ? (uint32_t)(rows < g.P ? rows : g.P) * row_bytes : 0u;
+  };
+  int64_t unit = units.lo + wave;
+  cw_copy_w(a.W, smem + CW_AUX + 4096, tid);
   cl_finalize(a.fin, aux, reinterpret_cast<double*>(smem + CW_AUX), tid);      // (ends with a workgroup barrier)
   const f32x4 s4 = ld4(aux + 4 * chunk), t4 = ld4(aux + CL_C + 4 * chunk), m4 = ld4(aux + 2 * CL_C + 4 * chunk);
-  for (int i = lane; i < WAVE_FLOATS / 4; i += 64) st4(wbase + 4 * i, splat(0.f));      // gap columns stay zero for the launch
   float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
-  cl_frags(a.W, 0, 0, n16, kk, a0);
-  cl_frags(a.W, 0, 1, n16, kk, a1);
+  cw_frags_lds(smem + CW_AUX + 4096, 0, 0, n16, kk, a0);
+  cw_frags_lds(smem + CW_AUX + 4096, 0, 1, n16, kk, a1);
+  const uint32_t dump = IMG_FLOATS * 4u + 16u * (uint32_t)(lane & 31);
+  // image offsets of the staging slots: a 16-bit table [slot][lane] behind the waves' regions (18 registers per lane otherwise)
+  const uint16_t* sotab = reinterpret_cast<const uint16_t*>(smem + CW_AUX + CW_WAVES * WAVE_FLOATS) + lane;
+  for (int u = wave; u < NLD; u += CW_WAVES) const_cast<uint16_t*>(sotab)[64 * u] = (uint16_t)cw_stage_slot(g, u, lane, dump);
+  __syncthreads();                                              // the scratch of the prologue becomes the images
+  for (int i = lane; i < WAVE_FLOATS / 4; i += 64) st4(wbase + 4 * i, splat(0.f));      // gap columns stay zero for the launch
   f32x4 pb[2];
   pb[0] = a.bias ? ld4(a.bias + 4 * kk) : splat(0.f);
   pb[1] = a.bias ? ld4(a.bias + 16 + 4 * kk) : splat(0.f);
@@ -244,112 +284,89 @@ __global__ __launch_bounds__(SNV_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     for (int h = 0; h < 2; ++h) rd[2 * t + h] = 4u * (uint32_t)lds_off(n16 + t, 4 * h + kk);
   uint32_t vo[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) vo[b] = cw_acc_offset(g, b, n16, kk);
-  const uint32_t dump = IMG_FLOATS * 4u + 16u * (uint32_t)(lane & 31);
-  uint32_t so[NLD];
-#pragma unroll
-  for (int u = 0; u < NLD; ++u) cw_stage_slot(g, u, lane, dump, &so[u]);
-  const uint32_t lane16 = 16u * (uint32_t)lane;
+  for (int b = 0; b < NB; ++b) {
+    const uint32_t o = cw_col_offset(g, 16u * b + (uint32_t)n16);
+    vo[b] = o == CW_OOB ? CW_OOB : o + 16u * (uint32_t)kk;
+  }
   const float lo_pre = a.pre_relu ? 0.f : -INFINITY;
-  const uint32_t row_bytes = (uint32_t)g.L * 128u;
-  const size_t unit_stride = (size_t)g.P * g.L * CL_C;          // floats
-
-  const bool dyn = a.counter != nullptr;
-  const int64_t unit_step = (int64_t)gridDim.x * SNV_WAVES;
-  int ticket = 0;
-  int64_t unit = (int64_t)blockIdx.x * SNV_WAVES + wave;
-  if (dyn) {
-    if (lane == 0) ticket = atomicAdd(a.counter, 1);
-    unit = __builtin_amdgcn_readfirstlane(ticket);
-    if (lane == 0) ticket = atomicAdd(a.counter, 1);
-  }
-  auto unit_bytes = [&](int64_t u) -> uint32_t {               // bytes of the rows of unit u that exist
-    if (u >= a.n_units) return 0u;
-    const int64_t rows = a.B - u * g.P;
-    return (uint32_t)(rows < g.P ? rows : g.P) * row_bytes;
-  };
-  auto stage = [&](const f32x4& raw, uint32_t off) __attribute__((always_inline)) {
-    const f32x4 v = max4(raw, splat(lo_pre));
-    lds_st4(wb, off, pk_fma(s4, v - m4, t4));
-  };
-  f32x4 xin[NLD];
-  {
-    const __amdgpu_buffer_rsrc_t xd = cw_rsrc(a.x + (size_t)(unit < a.n_units ? unit : 0) * unit_stride, unit_bytes(unit));
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) xin[u] = buf_ld4(xd, lane16 + 1024u * u);
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) stage(xin[u], so[u]);
-  }
-  uint32_t cur = 0u;                                            // byte offset of the current unit's image in the wave's region
-  f32x4 sum[2][2];                                              // [act(y) | act(y)^2][M-block]
+  f32x4 sum[2][2];                                              // [relu(y) | relu(y)^2][M-block]
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
     for (int m = 0; m < 2; ++m) sum[i][m] = splat(0.f);
-  constexpr int BS = NB > 2 ? 2 : NB - 1;                       // first block that consumes staged pieces of the next unit
 
-  for (int64_t next = 0; unit < a.n_units; unit = next) {
-    if (dyn) {
-      next = __builtin_amdgcn_readfirstlane(ticket);
-      if (lane == 0) ticket = atomicAdd(a.counter, 1);
-    } else {
-      next = unit + unit_step;
-    }
+  while (unit < units.hi) {
     const uint32_t ub = unit_bytes(unit);
     const size_t ubase = (size_t)unit * unit_stride;
+    const __amdgpu_buffer_rsrc_t xd = cw_rsrc(a.x + ubase, (a.dbg & 1) ? 0u : ub);
     const __amdgpu_buffer_rsrc_t yd = cw_rsrc(a.y + ubase, (a.dbg & 2) ? 0u : ub);
     const __amdgpu_buffer_rsrc_t r1d = cw_rsrc((a.res1 ? a.res1 : a.x) + ubase, (a.res1 && !(a.dbg & 4)) ? ub : 0u);
     const __amdgpu_buffer_rsrc_t r2d = cw_rsrc((a.res2 ? a.res2 : a.x) + ubase, (a.res2 && !(a.dbg & 4)) ? ub : 0u);
-    const __amdgpu_buffer_rsrc_t nxd =
-        cw_rsrc(a.x + (size_t)(next < a.n_units ? next : 0) * unit_stride, (a.dbg & 1) ? 0u : unit_bytes(next));
+    // ---- this unit's rows: memory -> ReLU, BatchNorm -> image (the wave's previous unit is past its last operand read)
+    {      // (requesting the first unit's rows in front of the prologue keeps 72 registers live across it: spills in the block loop)
+      f32x4 xin[NLD];
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) xin[u] = buf_ld4(xd, lane16 + 1024u * u);
+#pragma unroll
+      for (int u = 0; u < NLD; ++u) {
+        const f32x4 v = max4(xin[u], splat(lo_pre));
+        lds_st4(wb, sotab[64 * u], pk_fma(s4, v - m4, t4));
+      }
+    }
     f32x4 R1[NB][2], R2[NB][2];
 #pragma unroll
     for (int b = 0; b < 2 && b < NB; ++b)
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        R1[b][m] = buf_ld4(r1d, vo[b] + 64u * m);
-        R2[b][m] = buf_ld4(r2d, vo[b] + 64u * m);
+        R1[b][m] = buf_ld4s(r1d, vo[b], 64u * m);
+        R2[b][m] = buf_ld4s(r2d, vo[b], 64u * m);
       }
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) xin[u] = buf_ld4(nxd, lane16 + 1024u * u);
-    uint32_t rdc[6];
-#pragma unroll
-    for (int i = 0; i < 6; ++i) rdc[i] = rd[i] + cur;
-    const uint32_t nxt = IMG_BYTES - cur;
     __builtin_amdgcn_sched_barrier(0);
-    if (a.dbg & 8) {
+    if (!(a.dbg & 8))
+      cw_conv_blocks<NB>(
+          wb, rd, a0, a1, pb,
+          [&](int b) __attribute__((always_inline)) {
+            if (b + 2 < NB) {
 #pragma unroll
-      for (int u = 0; u < NLD; ++u) stage(xin[u], so[u] + nxt);
-    } else
-    cw_conv_blocks<NB>(
-        wb, rdc, a0, a1, pb,
-        [&](int b) __attribute__((always_inline)) {
-          if (b + 2 < NB) {
-#pragma unroll
-            for (int m = 0; m < 2; ++m) {
-              R1[b + 2 < NB ? b + 2 : 0][m] = buf_ld4(r1d, vo[b + 2 < NB ? b + 2 : 0] + 64u * m);
-              R2[b + 2 < NB ? b + 2 : 0][m] = buf_ld4(r2d, vo[b + 2 < NB ? b + 2 : 0] + 64u * m);
+              for (int m = 0; m < 2; ++m) {
+                R1[b + 2 < NB ? b + 2 : 0][m] = buf_ld4s(r1d, vo[b + 2 < NB ? b + 2 : 0], 64u * m);
+                R2[b + 2 < NB ? b + 2 : 0][m] = buf_ld4s(r2d, vo[b + 2 < NB ? b + 2 : 0], 64u * m);
+              }
             }
-          }
-          if (b >= BS) {                                        // this block's share of the next unit's pieces -> the other image
-#pragma unroll
-            for (int u = 0; u < NLD; ++u)
-              if (BS + (u * (NB - BS)) / NLD == b) stage(xin[u], so[u] + nxt);
-          }
-        },
-        [&](int b, int m, const f32x4& acc) __attribute__((always_inline)) {
-          const f32x4 y = (acc + R1[b][m]) + R2[b][m];
-          buf_st4(yd, vo[b] + 64u * m, y);
-          const f32x4 w = max4(y, splat(0.f));
-          const f32x4 mk = splat(vo[b] < ub ? 1.f : 0.f);
-          sum[0][m] = pk_fma(w, mk, sum[0][m]);
-          sum[1][m] = pk_fma(w * w, mk, sum[1][m]);
-        });
-    cur = nxt;
+          },
+          [&](int b, int m, const f32x4& acc) __attribute__((always_inline)) {
+            const f32x4 y = (acc + R1[b][m]) + R2[b][m];
+            buf_st4s(yd, vo[b], 64u * m, y);
+            const f32x4 w = max4(y, splat(0.f));
+            const f32x4 mk = splat(vo[b] < ub ? 1.f : 0.f);
+            sum[0][m] = pk_fma(w, mk, sum[0][m]);
+            sum[1][m] = pk_fma(w * w, mk, sum[1][m]);
+          });
+    unit += CW_WAVES;
   }
   if (a.stat_out) {
+    // sums held per lane in accumulator layout (column n16, channels 16 m + 4 kk .. + 3): the lanes of a kk group meet through
+    // shuffles, the eight waves through LDS, 64 double atomics per workgroup
     __syncthreads();                                            // every wave is past its last unit: the images are dead
-    cw_acc_slot_add<2>(sum, a.stat_out + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, smem, tid);
+    float* red = smem + CW_AUX;                                 // [4 waves][2][32]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          float s = sum[i][m][q];
+#pragma unroll
+          for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off);
+          if (n16 == 0) red[(wave * 2 + i) * CL_C + 16 * m + 4 * kk + q] = s;
+        }
+    __syncthreads();
+    if (tid < 2 * CL_C) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < CW_WAVES; ++w) t += red[w * 2 * CL_C + tid];
+      atomicAdd(&a.stat_out[(size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C + tid], (double)t);
+    }
   }
 }
 
@@ -367,80 +384,77 @@ struct CwBwdArgs {
   double* stat_out;       // sum(dz), sum(dz * xhat)
   int64_t B;
   int64_t n_units;
-  int* counter;
-  int dbg;                // timing experiments (MURAL_DEBUG_CW): 16 no next-unit loads, 32 no weight gradient, 64 no input gradient, 128 no stores
+  int dbg;                // timing experiments (MURAL_DEBUG_CW): 16 no loads, 32 no weight gradient, 64 no input gradient, 128 no stores
 };
 
 template <int NB>
-__global__ __launch_bounds__(SNV_THREADS) __attribute__((amdgpu_waves_per_eu(1, 1))) void conv32w_bwd_kernel(const CwBwdArgs a) {
+__global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int IMG_FLOATS = (16 * NB + 2) * CL_C;
-  constexpr uint32_t IMG_BYTES = (IMG_FLOATS + CW_DUMP) * 4u;   // stride between the two images: image | dump slots
-  constexpr int WAVE_FLOATS = 2 * (IMG_FLOATS + CW_DUMP);
+  constexpr int WAVE_FLOATS = IMG_FLOATS + CW_DUMP;
   constexpr int NLD = 2 * NB;
+  constexpr int NKS = 4 * NB;                                   // k-steps of the weight gradient: 4 columns each
   constexpr int NW = CL_C * CL_C * 3;
+  constexpr int ROW = NW + 3 * CL_C;                            // a wave's partial tiles | sum dy | first columns | last columns
+  static_assert(CW_WAVES * WAVE_FLOATS >= 2 * ROW && CW_WAVES * WAVE_FLOATS >= 4096 + CW_WFLOATS, "the waves' regions hold two partial rows / W");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kk = lane >> 4, chunk = lane & 7;
   const CwGeom& g = a.g;
-  float* wbase = smem + CW_AUX + wave * WAVE_FLOATS;            // dy image | xhat image | dump
+  float* aux = smem;
+  float* wbase = smem + CW_AUX + wave * WAVE_FLOATS;            // dy image | dump
   char* wb = reinterpret_cast<char*>(wbase);
-  for (int i = lane; i < WAVE_FLOATS / 4; i += 64) st4(wbase + 4 * i, splat(0.f));
+  CwUnits units;
+  cw_units_init(units, a.n_units);
+  const uint32_t lane16 = 16u * (uint32_t)lane;
+  const uint32_t row_bytes = (uint32_t)g.L * 128u;
+  const size_t unit_stride = (size_t)g.P * g.L * CL_C;
+  auto unit_bytes = [&](int64_t u) -> uint32_t {               // bytes of the rows of unit u that exist
+    const int64_t rows = a.B - u * g.P;
+    return (u < units.hi && !(a.dbg & 16)) ? (uint32_t)(rows < g.P ? rows : g.P) * row_bytes : 0u;
+  };
+  int64_t unit = units.lo + wave;
+  f32x4 gin[NLD];                                               // the first unit's dy rows travel under the prologue
+  {
+    const __amdgpu_buffer_rsrc_t gd = cw_rsrc(a.dy + (size_t)(unit < units.hi ? unit : 0) * unit_stride, unit_bytes(unit));
+#pragma unroll
+    for (int u = 0; u < NLD; ++u) gin[u] = buf_ld4(gd, lane16 + 1024u * u);
+  }
+  bool first = true;
+  uint32_t* tab = reinterpret_cast<uint32_t*>(aux + CW_AUX_TAB);      // memory offset of the row of column 4 s + kk, s < NKS
+  if (tid < 4 * NKS) tab[tid] = cw_col_offset(g, (uint32_t)tid);
+  cw_copy_w(a.W, smem + CW_AUX, tid);
+  __syncthreads();
   float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
-  cl_frags(a.W, 1, 0, n16, kk, a0);
-  cl_frags(a.W, 1, 1, n16, kk, a1);
-  const f32x4 mean4 = ld4(a.state + 2 * CL_C + 4 * chunk), inv4 = ld4(a.state + 3 * CL_C + 4 * chunk);
-  uint32_t rd[6], wr[2];
+  cw_frags_lds(smem + CW_AUX, 1, 0, n16, kk, a0);
+  cw_frags_lds(smem + CW_AUX, 1, 1, n16, kk, a1);
+  const uint32_t dump = IMG_FLOATS * 4u + 16u * (uint32_t)(lane & 31);
+  // image offsets of the staging slots: a 16-bit table [slot][lane] behind the waves' regions (18 registers per lane otherwise)
+  const uint16_t* sotab = reinterpret_cast<const uint16_t*>(smem + CW_AUX + CW_WAVES * WAVE_FLOATS) + lane;
+  for (int u = wave; u < NLD; u += CW_WAVES) const_cast<uint16_t*>(sotab)[64 * u] = (uint16_t)cw_stage_slot(g, u, lane, dump);
+  __syncthreads();
+  for (int i = lane; i < WAVE_FLOATS / 4; i += 64) st4(wbase + 4 * i, splat(0.f));
+  uint32_t rd[6];
 #pragma unroll
   for (int t = 0; t < 3; ++t)
 #pragma unroll
     for (int h = 0; h < 2; ++h) rd[2 * t + h] = 4u * (uint32_t)lds_off(n16 + t, 4 * h + kk);
-#pragma unroll
-  for (int m = 0; m < 2; ++m) wr[m] = IMG_BYTES + 4u * (uint32_t)lds_off(n16 + 1, 4 * m + kk);
-  // weight gradient: k-step s = 4 q + j covers the logical columns 16 q + 4 j + kk; a lane reads channels 2 n16, 2 n16 + 1 (8 bytes)
-  // of dy at image column pc + 1 and of xhat at image columns pc + tap
+  // weight gradient: k-step s = 4 q + j covers the logical columns pc = 16 q + 4 j + kk; a lane reads channels 2 n16, 2 n16 + 1
+  // (8 bytes) of dy at logical column pc - t + 1 = image column pc - t + 2 for tap t
   uint32_t wa[4][3];
 #pragma unroll
   for (int j = 0; j < 4; ++j)
 #pragma unroll
-    for (int tp = 0; tp < 3; ++tp) wa[j][tp] = 4u * (uint32_t)(lds_off(4 * j + kk + tp, n16 >> 1) + 2 * (n16 & 1));
+    for (int tp = 0; tp < 3; ++tp) wa[j][tp] = 4u * (uint32_t)(lds_off(4 * j + kk + 2 - tp, n16 >> 1) + 2 * (n16 & 1));
   uint32_t vo[NB];
 #pragma unroll
-  for (int b = 0; b < NB; ++b) vo[b] = cw_acc_offset(g, b, n16, kk);
-  const uint32_t dump = IMG_FLOATS * 4u + 16u * (uint32_t)(lane & 31);
-  uint32_t so[NLD];
-#pragma unroll
-  for (int u = 0; u < NLD; ++u) cw_stage_slot(g, u, lane, dump, &so[u]);
-  const uint32_t lane16 = 16u * (uint32_t)lane;
+  for (int b = 0; b < NB; ++b) {
+    const uint32_t o = cw_col_offset(g, 16u * b + (uint32_t)n16);
+    vo[b] = o == CW_OOB ? CW_OOB : o + 16u * (uint32_t)kk;
+  }
+  const uint32_t tab_lane = 4u * (uint32_t)(CW_AUX_TAB + kk);   // byte address of this lane's first table entry
+  const uint32_t n16x8 = 8u * (uint32_t)n16;
   const float lo_pre = a.pre_relu ? 0.f : -INFINITY;
-  const uint32_t row_bytes = (uint32_t)g.L * 128u;
-  const size_t unit_stride = (size_t)g.P * g.L * CL_C;
-
-  const bool dyn = a.counter != nullptr;
-  const int64_t unit_step = (int64_t)gridDim.x * SNV_WAVES;
-  int ticket = 0;
-  int64_t unit = (int64_t)blockIdx.x * SNV_WAVES + wave;
-  if (dyn) {
-    if (lane == 0) ticket = atomicAdd(a.counter, 1);
-    unit = __builtin_amdgcn_readfirstlane(ticket);
-    if (lane == 0) ticket = atomicAdd(a.counter, 1);
-  }
-  auto unit_bytes = [&](int64_t u) -> uint32_t {
-    if (u >= a.n_units) return 0u;
-    const int64_t rows = a.B - u * g.P;
-    return (uint32_t)(rows < g.P ? rows : g.P) * row_bytes;
-  };
-  f32x4 gin[NLD], xin[NLD];
-  {
-    const size_t o = (size_t)(unit < a.n_units ? unit : 0) * unit_stride;
-    const uint32_t ub = unit_bytes(unit);
-    const __amdgpu_buffer_rsrc_t gd = cw_rsrc(a.dy + o, ub), xd = cw_rsrc(a.x + o, ub);
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      gin[u] = buf_ld4(gd, lane16 + 1024u * u);
-      xin[u] = buf_ld4(xd, lane16 + 1024u * u);
-    }
-  }
   f32x4 wacc[2][3][2];
 #pragma unroll
   for (int m = 0; m < 2; ++m)
@@ -448,126 +462,148 @@ __global__ __launch_bounds__(SNV_THREADS) __attribute__((amdgpu_waves_per_eu(1, 
     for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
       for (int h = 0; h < 2; ++h) wacc[m][tp][h] = splat(0.f);
-  f32x4 sum[2][2];                                              // [dz | dz * xhat][M-block]
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int m = 0; m < 2; ++m) sum[i][m] = splat(0.f);
   f32x4 bsum = splat(0.f), esum = splat(0.f);                   // staging layout: channels 4 chunk .. + 3; esum: first (lane bit 3 = 0) / last column
   const f32x4 pb[2] = {splat(0.f), splat(0.f)};
   const int edge_last = (lane >> 3) & 1;
+  const char* smc = reinterpret_cast<const char*>(smem);
 
-  for (int64_t next = 0; unit < a.n_units; unit = next) {
-    if (dyn) {
-      next = __builtin_amdgcn_readfirstlane(ticket);
-      if (lane == 0) ticket = atomicAdd(a.counter, 1);
-    } else {
-      next = unit + unit_step;
-    }
-    // ---- this unit's rows: registers -> images (dy as it is, x as xhat); the bias gradient rides along
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) {
-      bsum += gin[u];
-      lds_st4(wb, so[u], gin[u]);
-      const f32x4 v = max4(xin[u], splat(lo_pre));
-      lds_st4(wb, so[u] + IMG_BYTES, (v - mean4) * inv4);
-    }
-    // ---- the next unit's rows travel under the MFMA phases
+  while (unit < units.hi) {
+    const uint32_t ub = unit_bytes(unit);
+    const size_t ubase = (size_t)unit * unit_stride;
+    const __amdgpu_buffer_rsrc_t gd = cw_rsrc(a.dy + ubase, ub), xd = cw_rsrc(a.x + ubase, ub);
+    const __amdgpu_buffer_rsrc_t zd = cw_rsrc(a.dz + ubase, (a.dbg & 128) ? 0u : ub);
+    // ---- this unit's dy rows: memory -> image; the bias gradient rides along
     {
-      const size_t o = (size_t)(next < a.n_units ? next : 0) * unit_stride;
-      const uint32_t nb_ = (a.dbg & 16) ? 0u : unit_bytes(next);
-      const __amdgpu_buffer_rsrc_t gd = cw_rsrc(a.dy + o, nb_), xd = cw_rsrc(a.x + o, nb_);
+      if (!first) {
+#pragma unroll
+        for (int u = 0; u < NLD; ++u) gin[u] = buf_ld4(gd, lane16 + 1024u * u);
+      }
+      first = false;
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
-        gin[u] = buf_ld4(gd, lane16 + 1024u * u);
-        xin[u] = buf_ld4(xd, lane16 + 1024u * u);
+        bsum += gin[u];
+        lds_st4(wb, sotab[64 * u], gin[u]);
       }
     }
-    const uint32_t ub = unit_bytes(unit);
-    const __amdgpu_buffer_rsrc_t zd = cw_rsrc(a.dz + (size_t)unit * unit_stride, (a.dbg & 128) ? 0u : ub);
-    // ---- first / last column of every row (S_0 / S_2 of the weight-gradient fix-up)
+    // ---- act(x) of the first k-steps of the weight gradient, in operand layout (channels 2 n16, 2 n16 + 1 of column 4 s + kk)
+    f32x2 xop[NKS];
+#pragma unroll
+    for (int s = 0; s < CW_LA && s < NKS; ++s)
+      xop[s] = buf_ld2(xd, *reinterpret_cast<const uint32_t*>(smc + tab_lane + 16u * s) + n16x8);
+    // ---- first / last column of every row (S_0 / S_2 of the fix-up)
     for (int t = lane; t < g.P * 16; t += 64) {
       const int row = t >> 4;
       esum += ld4(wbase + lds_off(2 + row * g.Sc + (edge_last ? g.L - 1 : 0), chunk));
     }
     __builtin_amdgcn_sched_barrier(0);
+    // ---- input gradient: the forward conv with the transposed, tap-flipped filter on the dy image
+    if (!(a.dbg & 64))
+      cw_conv_blocks<NB>(
+          wb, rd, a0, a1, pb, [&](int) __attribute__((always_inline)) {},
+          [&](int b, int m, const f32x4& acc) __attribute__((always_inline)) { buf_st4s(zd, vo[b], 64u * m, acc); });
+    __builtin_amdgcn_sched_barrier(0);
     // ---- weight gradient
     if (!(a.dbg & 32)) {
 #pragma unroll
-      for (int q = 0; q < NB; ++q) {
+      for (int s = 0; s < NKS; ++s) {
+        const int q = s >> 2, j = s & 3;
+        if (s + CW_LA < NKS)
+          xop[s + CW_LA < NKS ? s + CW_LA : 0] =
+              buf_ld2(xd, *reinterpret_cast<const uint32_t*>(smc + tab_lane + 16u * (s + CW_LA)) + n16x8);
+        f32x2 gv[3];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const f32x2 gv = *reinterpret_cast<const f32x2*>(wb + wa[j][1] + CW_BLK * q);
-          f32x2 bv[3];
+        for (int tp = 0; tp < 3; ++tp) gv[tp] = *reinterpret_cast<const f32x2*>(wb + wa[j][tp] + CW_BLK * q);
+        const f32x2 r = {fmaxf(xop[s].x, lo_pre), fmaxf(xop[s].y, lo_pre)};
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-          for (int tp = 0; tp < 3; ++tp) bv[tp] = *reinterpret_cast<const f32x2*>(wb + IMG_BYTES + wa[j][tp] + CW_BLK * q);
+        for (int tp = 0; tp < 3; ++tp)
 #pragma unroll
-          for (int tp = 0; tp < 3; ++tp)
+          for (int h = 0; h < 2; ++h) {
+            wacc[0][tp][h] = CW_MFMA(gv[tp][0], r[h], wacc[0][tp][h]);
+            wacc[1][tp][h] = CW_MFMA(gv[tp][1], r[h], wacc[1][tp][h]);
+          }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    unit += CW_WAVES;
+  }
+  // ---- partial row of the workgroup.  The waves park their tiles and sums in two rows of LDS (two rounds of two waves), then the
+  // BatchNorm algebra of the header runs on the workgroup's sums.
+  // D[row 4 kk + r][col n16] of tile (m, tap, h) <-> dWr[co = 2 (4 kk + r) + m][ci = 2 n16 + h][tap]
+  __syncthreads();                                              // every wave is past its last unit: the images are dead
+  float* mine = smem + CW_AUX + (wave & 1) * ROW;
+  for (int round = 0; round < 2; ++round) {
+    if ((wave >> 1) == round) {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              wacc[0][tp][h] = CW_MFMA(gv[0], bv[tp][h], wacc[0][tp][h]);
-              wacc[1][tp][h] = CW_MFMA(gv[1], bv[tp][h], wacc[1][tp][h]);
+      for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int tp = 0; tp < 3; ++tp)
+#pragma unroll
+          for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              float* p = mine + ((2 * (4 * kk + r) + m) * CL_C + 2 * n16 + h) * 3 + tp;
+              *p = round ? *p + wacc[m][tp][h][r] : wacc[m][tp][h][r];
             }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v = bsum[q], e = esum[q];
+#pragma unroll
+        for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off);
+#pragma unroll
+        for (int off = 16; off < 64; off <<= 1) e += __shfl_xor(e, off);
+        if (lane < 8) {
+          float* p = mine + NW + 4 * chunk + q;
+          *p = round ? *p + v : v;
+        }
+        if (lane < 16) {
+          float* p = mine + NW + CL_C + edge_last * CL_C + 4 * chunk + q;      // first columns | last columns
+          *p = round ? *p + e : e;
         }
       }
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // ---- input gradient: the forward conv with the transposed, tap-flipped filter on the dy image
-    if (!(a.dbg & 64)) {
-      cw_conv_blocks<NB>(
-          wb, rd, a0, a1, pb, [&](int) __attribute__((always_inline)) {},
-          [&](int b, int m, const f32x4& acc) __attribute__((always_inline)) {
-            buf_st4(zd, vo[b] + 64u * m, acc);
-            const f32x4 xh = lds_ld4(wb, wr[m] + CW_BLK * b);
-            const f32x4 mk = splat(vo[b] < ub ? 1.f : 0.f);
-            sum[0][m] = pk_fma(acc, mk, sum[0][m]);
-            sum[1][m] = pk_fma(acc, xh, sum[1][m]);
-          });
+    __syncthreads();
+  }
+  float* fin = aux;                                             // sum dy | first columns | last columns of the workgroup
+  if (tid < 3 * CL_C) fin[tid] = smem[CW_AUX + NW + tid] + smem[CW_AUX + ROW + NW + tid];
+  __syncthreads();
+  // thread = (input channel ci, four output channels): 12 entries (co, tap) each
+  {
+    const int ci = tid & 31, grp = tid >> 5;                    // 8 groups x 4 output channels
+    const float mu = a.state[2 * CL_C + ci], inv = a.state[3 * CL_C + ci], gm = a.gamma[ci], bt = a.state[CL_C + ci];
+    float* dst = a.part + (size_t)blockIdx.x * (NW + CL_C);
+    float wv[4][3];
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4)
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) wv[c4][tp] = a.W[((4 * grp + c4) * CL_C + ci) * 3 + tp];
+    float sdz = 0.f, sdzx = 0.f;
+#pragma unroll
+    for (int c4 = 0; c4 < 4; ++c4) {
+      const int co = 4 * grp + c4;
+      const float S1 = fin[co], Sf = fin[CL_C + co], Sl = fin[2 * CL_C + co];
+#pragma unroll
+      for (int tp = 0; tp < 3; ++tp) {
+        const int i = (co * CL_C + ci) * 3 + tp;
+        const float dwr = smem[CW_AUX + i] + smem[CW_AUX + ROW + i];
+        const float St = S1 - (tp == 0 ? Sf : tp == 2 ? Sl : 0.f);
+        const float dwx = inv * (dwr - mu * St);
+        dst[i] = gm * dwx + bt * St;
+        sdz += wv[c4][tp] * St;
+        sdzx += wv[c4][tp] * dwx;
+      }
     }
-  }
-  // ---- BatchNorm-backward sums
-  __syncthreads();                                              // every wave is past its last unit
-  cw_acc_slot_add<2>(sum, a.stat_out + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, smem, tid);
-  // ---- partial row of the weight / bias gradient: every wave parks its tiles and edge sums in its own region
-  // D[row 4 kk + r][col n16] of tile (m, tap, h) <-> dW~[co = 2 (4 kk + r) + m][ci = 2 n16 + h][tap]
-#pragma unroll
-  for (int m = 0; m < 2; ++m)
-#pragma unroll
-    for (int tp = 0; tp < 3; ++tp)
-#pragma unroll
-      for (int h = 0; h < 2; ++h)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) wbase[((2 * (4 * kk + r) + m) * CL_C + 2 * n16 + h) * 3 + tp] = wacc[m][tp][h][r];
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    float v = bsum[q], e = esum[q];
-#pragma unroll
-    for (int off = 8; off < 64; off <<= 1) v += __shfl_xor(v, off);
-#pragma unroll
-    for (int off = 16; off < 64; off <<= 1) e += __shfl_xor(e, off);
-    if (lane < 8) wbase[NW + 4 * chunk + q] = v;
-    if (lane < 16) wbase[NW + CL_C + edge_last * CL_C + 4 * chunk + q] = e;      // S_1 - S_0 (first columns) | S_1 - S_2 (last columns)
-  }
-  __syncthreads();
-  float* fin = smem;                                            // bias gradient | first-column sums | last-column sums of the workgroup
-  if (tid < 3 * CL_C) {
-    float t = 0.f;
-#pragma unroll
-    for (int w = 0; w < SNV_WAVES; ++w) t += smem[CW_AUX + w * WAVE_FLOATS + NW + tid];
-    fin[tid] = t;
-  }
-  __syncthreads();
-  float* dst = a.part + (size_t)blockIdx.x * (NW + CL_C);
-  for (int i = tid; i < NW + CL_C; i += SNV_THREADS) {
-    if (i < NW) {
+    if (tid < CL_C) dst[NW + tid] = fin[tid];
+    __syncthreads();                                            // the partial rows were read: their LDS takes the channel sums
+    float* red = smem + CW_AUX;                                 // [8 groups][2][32]
+    red[(grp * 2 + 0) * CL_C + ci] = sdz;
+    red[(grp * 2 + 1) * CL_C + ci] = sdzx;
+    __syncthreads();
+    if (tid < 2 * CL_C) {
       float t = 0.f;
 #pragma unroll
-      for (int w = 0; w < SNV_WAVES; ++w) t += smem[CW_AUX + w * WAVE_FLOATS + i];
-      const int co = i / (3 * CL_C), rem = i - co * 3 * CL_C, ci = rem / 3, tp = rem - 3 * ci;
-      const float S = fin[co] - (tp == 0 ? fin[CL_C + co] : tp == 2 ? fin[2 * CL_C + co] : 0.f);
-      dst[i] = a.gamma[ci] * t + a.state[CL_C + ci] * S;
-    } else {
-      dst[i] = fin[i - NW];
+      for (int gI = 0; gI < 8; ++gI) t += red[gI * 2 * CL_C + tid];
+      atomicAdd(&a.stat_out[(size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C + tid], (double)t);
     }
   }
 }
@@ -578,42 +614,43 @@ int cw_debug() {
 }
 
 template <int NB>
+constexpr size_t cw_lds_bytes() {
+  return (size_t)(CW_AUX + CW_WAVES * ((16 * NB + 2) * CL_C + CW_DUMP) + NB * 64) * 4;      // aux | images | 16-bit staging offsets
+}
+
+template <int NBV>
 int cw_launch_fwd(const CwFwdArgs& a, int grid, hipStream_t stream) {
-  constexpr size_t lds = (size_t)(CW_AUX + SNV_WAVES * 2 * ((16 * NB + 2) * CL_C + CW_DUMP)) * 4;
+  constexpr int NB = NBV < 4 ? 4 : NBV;      // (the waves' regions also hold W and the scratch of the prologue)
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32w_fwd_kernel<NB>)) return rc;
-  hipLaunchKernelGGL(conv32w_fwd_kernel<NB>, dim3(grid), dim3(SNV_THREADS), lds, stream, a);
+  hipLaunchKernelGGL(conv32w_fwd_kernel<NB>, dim3(grid), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
 template <int NBV>
 int cw_launch_bwd(const CwBwdArgs& a, int grid, hipStream_t stream) {
-  constexpr int NB = NBV < 3 ? 3 : NBV;      // (a wave's region also holds its partial tiles: three blocks at least)
-  constexpr size_t lds = (size_t)(CW_AUX + SNV_WAVES * 2 * ((16 * NB + 2) * CL_C + CW_DUMP)) * 4;
-  static_assert(2 * ((16 * NB + 2) * CL_C + CW_DUMP) >= CL_C * CL_C * 3 + 3 * CL_C, "a wave's region holds its partial tiles");
+  constexpr int NB = NBV < 4 ? 4 : NBV;      // (the waves' regions also hold four partial rows and W)
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32w_bwd_kernel<NB>)) return rc;
-  hipLaunchKernelGGL(conv32w_bwd_kernel<NB>, dim3(grid), dim3(SNV_THREADS), lds, stream, a);
+  hipLaunchKernelGGL(conv32w_bwd_kernel<NB>, dim3(grid), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
 #define CW_DISPATCH(FN, NBV, ...)                 \
   switch (NBV) {                                  \
-    case 2: return FN<2>(__VA_ARGS__);            \
-    case 3: return FN<3>(__VA_ARGS__);            \
-    case 4: return FN<4>(__VA_ARGS__);            \
     case 5: return FN<5>(__VA_ARGS__);            \
     case 6: return FN<6>(__VA_ARGS__);            \
     case 7: return FN<7>(__VA_ARGS__);            \
     case 8: return FN<8>(__VA_ARGS__);            \
-    default: return FN<9>(__VA_ARGS__);           \
+    case 9: return FN<9>(__VA_ARGS__);            \
+    default: return FN<4>(__VA_ARGS__);           \
   }
 
 int cw_grid(int64_t n_units) {
-  const int64_t wgs = (n_units + SNV_WAVES - 1) / SNV_WAVES;
-  return (int)(wgs < CW_CUS ? wgs : CW_CUS);
+  const int64_t wgs = (n_units + CW_WAVES - 1) / CW_WAVES;
+  return (int)(wgs < 2 * CW_CUS ? wgs : 2 * CW_CUS);
 }
 
 }  // namespace
@@ -626,32 +663,30 @@ int cw_conv32_supported(int L) {
 
 int cw_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
                   float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias, int post_relu,
-                  const float* res1, const float* res2, double* acc_out, int out_relu, float* y, int* counter, hipStream_t stream) {
+                  const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream) {
   if (B == 0 || L == 0) return MURAL_OK;
   CwFwdArgs a;
   std::memset(&a, 0, sizeof(a));
   MURAL_REQUIRE(cw_geom(B, L, &a.g), "conv32 (wave-private): L = %d does not fit a wave's image", L);
-  if (!res1) { res1 = res2; res2 = nullptr; }
   MURAL_REQUIRE(!post_relu && (out_relu || !acc_out), "conv32 (wave-private): raw output with the batch sums of relu(y) only");
+  if (!res1) { res1 = res2; res2 = nullptr; }
   a.x = x; a.y = y; a.W = W; a.bias = bias; a.res1 = res1; a.res2 = res2; a.pre_relu = pre_relu;
   a.stat_out = acc_out;
   a.fin = ClFin{acc, (double)B * L, gamma, beta, eps, momentum, running_mean, running_var, state};
   a.B = B;
   a.n_units = (B + a.g.P - 1) / a.g.P;
-  a.counter = counter;
   a.dbg = cw_debug();
   CW_DISPATCH(cw_launch_fwd, a.g.nb, a, cw_grid(a.n_units), stream)
 }
 
 int cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, const float* gamma, int pre_relu,
-                  float* dz, double* stat_out, float* part, int* nrow, int* counter, hipStream_t stream) {
+                  float* dz, double* stat_out, float* part, int* nrow, hipStream_t stream) {
   CwBwdArgs a;
   std::memset(&a, 0, sizeof(a));
   MURAL_REQUIRE(cw_geom(B, L, &a.g), "conv32_bwd (wave-private): L = %d does not fit a wave's image", L);
   a.dy = dy; a.x = x; a.W = W; a.state = state; a.gamma = gamma; a.pre_relu = pre_relu; a.part = part; a.dz = dz; a.stat_out = stat_out;
   a.B = B;
   a.n_units = (B + a.g.P - 1) / a.g.P;
-  a.counter = counter;
   a.dbg = cw_debug();
   const int grid = cw_grid(a.n_units);
   *nrow = grid;
@@ -664,16 +699,16 @@ int cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, in
 extern "C" int mural_debug_cw_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var, float* state, const float* W,
                                          const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,
-                                         int32_t out_relu, float* y, int32_t* counter, void* stream) {
+                                         int32_t out_relu, float* y, void* stream) {
   return mural::cw_conv32_fwd(x, B, L, pre_relu, acc, gamma, beta, 1e-5f, 0.1f, running_mean, running_var, state, W, bias, post_relu, res1, res2,
-                              acc_out, out_relu, y, counter, (hipStream_t)stream);
+                              acc_out, out_relu, y, (hipStream_t)stream);
 }
 
 extern "C" int mural_debug_cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* state,
                                          const float* gamma, int32_t pre_relu, float* dz, double* stat_out, float* part, int32_t* nrow,
-                                         int32_t* counter, void* stream) {
+                                         void* stream) {
   int n = 0;
-  const int rc = mural::cw_conv32_bwd(dy, x, W, B, L, state, gamma, pre_relu, dz, stat_out, part, &n, counter, (hipStream_t)stream);
+  const int rc = mural::cw_conv32_bwd(dy, x, W, B, L, state, gamma, pre_relu, dz, stat_out, part, &n, (hipStream_t)stream);
   if (nrow) *nrow = n;
   return rc;
 }

@@ -10,6 +10,7 @@
 // nothing but these two calls, an optimiser and a loss.  Parameters are DEVICE pointers in the reference's state_dict naming
 // (the MuralSnvParams structs of the eval path, here with device addresses).
 #include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "snv.h"
@@ -24,6 +25,13 @@ int cl_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* 
 size_t cl_conv32_part_floats();
 int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, int pre_relu, float* dz,
                   double* stat_out, float* part, int* nrow, hipStream_t stream);
+// conv32_wave.hip: the same two layers with wave-private units (raw output, batch sums of relu(y))
+int cw_conv32_supported(int L);
+int cw_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
+                  float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias, int post_relu,
+                  const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream);
+int cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, const float* gamma, int pre_relu,
+                  float* dz, double* stat_out, float* part, int* nrow, hipStream_t stream);
 int cl_bn_stats(const float* x, int64_t rows, int relu, double* acc, hipStream_t stream);
 int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, const float* state, const float* gamma, const double* acc,
                     const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
@@ -234,6 +242,14 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
 
 const float EPS = 1e-5f;
 
+// which conv kernels the step runs: the wave-private ones (conv32_wave.hip) where they apply, unless MURAL_TRAIN_CONV_CL=1 asks for the
+// workgroup-tile kernels everywhere (A/B runs, parity tests of both)
+bool use_wave_conv(int L, int post_relu, bool stats, int out_relu) {
+  const char* e = getenv("MURAL_TRAIN_CONV_CL");
+  if (e && atoi(e) != 0) return false;
+  return cw_conv32_supported(L) && !post_relu && (!stats || out_relu);
+}
+
 // The two towers share nothing but the symbols, so the mid tower runs on a side stream next to the large one: its short rows
 // (67 / 23 / 8 columns) leave most of the chip idle, and the fixed cost of its ~60 launches per direction hides behind the large
 // tower's kernels (SideStream, common.h).
@@ -258,6 +274,10 @@ int bnconv_f(Ctx& c, const float* x, int L, int pre_relu, double* acc, bool have
              float* state, int post_relu, const float* r1, const float* r2, double* acc_out, int out_relu, float* y) {
   if (!have_acc)
     if (int rc = cl_bn_stats(x, (int64_t)c.P->B * L, pre_relu, acc, (hipStream_t)c.stream)) return rc;
+  if (use_wave_conv(L, post_relu, acc_out != nullptr, out_relu))
+    return cw_conv32_fwd(x, c.P->B, L, pre_relu, acc, bn.weight, bn.bias, EPS, c.momentum, const_cast<float*>(bn.running_mean),
+                         const_cast<float*>(bn.running_var), state, cv.weight, cv.bias, post_relu, r1, r2, acc_out, out_relu, y,
+                         (hipStream_t)c.stream);
   return cl_conv32_fwd(x, c.P->B, L, pre_relu, acc, bn.weight, bn.bias, EPS, c.momentum, const_cast<float*>(bn.running_mean),
                        const_cast<float*>(bn.running_var), state, cv.weight, cv.bias, post_relu, r1, r2, acc_out, out_relu, y,
                        (hipStream_t)c.stream);
@@ -335,8 +355,12 @@ int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const
              double* acc, const float* add1, const float* add2, const MuralBN& gbn, const MuralAffine& gcv, float* dz, float* dx) {
   const int j = c.njobs++;
   MURAL_REQUIRE(j < 20, "internal: more conv layers than partial-row regions");
-  if (int rc = cl_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j], (hipStream_t)c.stream))
+  if (use_wave_conv(L, 0, false, 0)) {
+    if (int rc = cw_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, bn.weight, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j],
+                               (hipStream_t)c.stream)) return rc;
+  } else if (int rc = cl_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j], (hipStream_t)c.stream)) {
     return rc;
+  }
   c.job_part[j] = c.P->part[j];
   c.job_dW[j] = const_cast<float*>(gcv.weight);
   c.job_db[j] = const_cast<float*>(gcv.bias);

@@ -13,8 +13,13 @@ from tests.test_gpu_snv import product_from_hp
 pytestmark = pytest.mark.gpu
 
 
+@pytest.mark.parametrize("conv", ["wave", "tile"])
 @pytest.mark.parametrize("tag", ["T", "S"])
-def test_train_step_matches_reference(tag):
+def test_train_step_matches_reference(tag, conv, monkeypatch):
+    # both conv kernel families of the composed step: wave-private units (csrc/conv32_wave.hip, the default) and workgroup tiles
+    # (csrc/conv32_cl.hip, MURAL_TRAIN_CONV_CL=1)
+    if conv == "tile":
+        monkeypatch.setenv("MURAL_TRAIN_CONV_CL", "1")
     fx = U.load(f"snv_train_{tag}.npz")
     model, _ = product_from_hp(fx["hp"])
     orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
@@ -244,6 +249,48 @@ def test_channel_last_conv_kernels_match_torch_fp64():
     out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "worst" in out.stdout
+
+
+def test_wave_private_conv_kernels_match_torch_fp64():
+    """The wave-private conv kernels of the composed step (csrc/conv32_wave.hip) through the same harness: forward with BatchNorm
+    finalisation, residuals and fused batch sums; backward whose BatchNorm-backward sums and weight gradient come out of the
+    partial-row algebra (dW from sums of dy (x) act(x) and three vectors of dy sums) -- unit geometries of 4 .. 9 blocks, several
+    rows per unit, ragged last units, rows of one column, the widest row a wave's image holds (142)."""
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_debug_conv32_cl.py")
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=600, env=dict(os.environ, WHICH="cw"))
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "worst" in out.stdout and "L= 142" in out.stdout
+
+
+def test_train_step_conv_gradients_are_bitwise_reproducible():
+    """Two runs of the same step (S fixture tiled to 1023 rows: many workgroups, a ragged last unit) give bit-identical losses and
+    bit-identical gradients of every 32 -> 32 conv layer, its BatchNorm and the tower heads: units are assigned to waves by index,
+    partial rows are summed in a fixed order, batch sums meet in float64.  (The first layer's gradient table and the embedding
+    gradient are float atomics in LDS: last-bit differences between runs are theirs.)"""
+    fx = U.load("snv_train_S.npz")
+    reps = 86
+    cat = torch.from_numpy(np.tile(fx["cat"], (reps, 1))[:1023]).cuda()
+    x = U.onehot(np.tile(fx["codes"], (reps, 1))[:1023]).cuda()
+    y = torch.from_numpy(np.tile(fx["y"], reps)[:1023]).cuda()
+    runs = []
+    for _ in range(2):
+        model, _m = product_from_hp(fx["hp"])
+        orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+        model.load_state_dict(U.snv_state_for(fx, orc))
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        model = model.cuda().train()
+        preds = model((torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda"), cat), x)
+        loss = nn.CrossEntropyLoss(reduction="sum")(preds, y)
+        loss.backward()
+        runs.append((loss.item(), {k: p.grad.cpu().numpy().copy() for k, p in model.named_parameters() if p.grad is not None}))
+    assert runs[0][0] == runs[1][0]
+    differ = [k for k, g in runs[0][1].items() if not np.array_equal(g, runs[1][1][k])]
+    fixed = [k for k in differ if k.startswith(("RBs", "conv2", "conv3", "distal_fc"))]
+    assert not fixed, (fixed, differ)
 
 
 @pytest.mark.parametrize("name", ["snv_synth_generic_c16k5_net2.npz", "snv_synth_generic_c24k4_net2.npz", "snv_synth_generic_c64k3_net1.npz"])

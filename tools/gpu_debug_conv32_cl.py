@@ -1,5 +1,5 @@
 """GPU box: the channel-last conv kernels of the training step (csrc/conv32_cl.hip; WHICH=cw: the wave-private kernels of
-csrc/conv32_wave.hip, with and without unit tickets) against torch ops in float64 on the CPU:
+csrc/conv32_wave.hip) against torch ops in float64 on the CPU:
 forward with BatchNorm finalisation, residuals and fused batch sums; backward with weight / bias gradient, input gradient and the
 BatchNorm-backward sums.  Prints the worst relative error per quantity; exits non-zero above 1e-4."""
 import ctypes as C
@@ -29,7 +29,9 @@ def acc_sum(acc):
 
 CASES = ((12, 20, 1), (12, 7, 0), (12, 134, 1), (32, 23, 0), (5, 67, 1), (64, 8, 1), (1100, 20, 1), (3, 1, 0), (700, 134, 1))
 if CW:
-    CASES += ((4096, 20, 1), (4099, 23, 1), (2051, 7, 0), (1500, 67, 1), (3000, 134, 1), (9, 142, 1), (2500, 33, 1))
+    # (the last four: 4 / 9 / 3 / 2 rows per unit = 6 / 5 / 7 / 8 blocks)
+    CASES += ((4096, 20, 1), (4099, 23, 1), (2051, 7, 0), (1500, 67, 1), (3000, 134, 1), (9, 142, 1), (2500, 33, 1),
+              (9000, 20, 1), (20000, 7, 0), (6500, 33, 1), (5000, 60, 1))
 for case_no, (B, L, PRE) in enumerate(CASES):
     g = torch.Generator().manual_seed(B * 1000 + L)
     x = torch.randn(B, L, 32, generator=g, dtype=torch.float64)
@@ -66,12 +68,10 @@ for case_no, (B, L, PRE) in enumerate(CASES):
     rm, rv = torch.zeros(32, device=dev), torch.ones(32, device=dev)
     acc_out = torch.zeros(32 * 2 * 32, dtype=torch.float64, device=dev)
     yd = torch.empty_like(xd)
-    tick = torch.zeros(2, dtype=torch.int32, device=dev)
-    use_tick = CW and case_no % 2 == 0
     if CW:
         _lib.check(lib.mural_debug_cw_conv32_fwd(xd.data_ptr(), B, L, PRE, acc.data_ptr(), gd.data_ptr(), betad.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                                  state.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, r1d.data_ptr(), r2d.data_ptr(), acc_out.data_ptr(),
-                                                 1, yd.data_ptr(), tick.data_ptr() if use_tick else None, st))
+                                                 1, yd.data_ptr(), st))
     else:
         _lib.check(lib.mural_debug_cl_conv32_fwd(xd.data_ptr(), B, L, PRE, acc.data_ptr(), gd.data_ptr(), betad.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                                  state.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, r1d.data_ptr(), r2d.data_ptr(), acc_out.data_ptr(),
@@ -92,8 +92,7 @@ for case_no, (B, L, PRE) in enumerate(CASES):
     nrow = C.c_int32(0)
     if CW:
         _lib.check(lib.mural_debug_cw_conv32_bwd(dyd.data_ptr(), xd.data_ptr(), Wd.data_ptr(), B, L, state.data_ptr(), gd.data_ptr(), PRE,
-                                                 dzd.data_ptr(), stat.data_ptr(), part.data_ptr(), C.byref(nrow),
-                                                 tick[1:].data_ptr() if use_tick else None, st))
+                                                 dzd.data_ptr(), stat.data_ptr(), part.data_ptr(), C.byref(nrow), st))
     else:
         _lib.check(lib.mural_debug_cl_conv32_bwd(dyd.data_ptr(), xd.data_ptr(), Wd.data_ptr(), B, L, state.data_ptr(), PRE, dzd.data_ptr(),
                                                  stat.data_ptr(), part.data_ptr(), C.byref(nrow), st))

@@ -32,19 +32,11 @@ for L in (134, 67, 20, 23, 7):
     st = _lib.current_stream_ptr(dev)
     _lib.check(lib.mural_debug_cl_bn_stats(x.data_ptr(), B * L, 1, acc.data_ptr(), st))
 
-    tick = torch.zeros(4096, dtype=torch.int32, device=dev)
-    TICK = os.environ.get("TICKETS", "1") == "1"
-    tk = [0]
-
-    def next_tick():
-        tk[0] += 1
-        return tick[tk[0]:].data_ptr() if TICK else None
-
     def fwd(a, b):
         if CW:
             return lambda: _lib.check(lib.mural_debug_cw_conv32_fwd(x.data_ptr(), B, L, 1, acc.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                                     rm.data_ptr(), rv.data_ptr(), state.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, a, b,
-                                                                    acc_out.data_ptr(), 1, y.data_ptr(), next_tick(), st))
+                                                                    acc_out.data_ptr(), 1, y.data_ptr(), st))
         return lambda: _lib.check(lib.mural_debug_cl_conv32_fwd(x.data_ptr(), B, L, 1, acc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
                                                                 rv.data_ptr(), state.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, a, b,
                                                                 acc_out.data_ptr(), 1, y.data_ptr(), st))
@@ -52,7 +44,7 @@ for L in (134, 67, 20, 23, 7):
     def bwd():
         if CW:
             _lib.check(lib.mural_debug_cw_conv32_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), B, L, state.data_ptr(), gamma.data_ptr(), 1, y.data_ptr(),
-                                                     acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), next_tick(), st))
+                                                     acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), st))
         else:
             _lib.check(lib.mural_debug_cl_conv32_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), B, L, state.data_ptr(), 1, y.data_ptr(),
                                                      acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), st))
