@@ -340,14 +340,17 @@ int mural_debug_cl_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_
 int mural_debug_cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* state,
                               int32_t pre_relu, float* dz, double* stat_out, float* part, int32_t* nrow, void* stream);
 int mural_debug_cl_bn_stats(const float* x, int64_t rows, int32_t relu, double* acc, void* stream);
-/* the same two layers on the wave-private kernels (csrc/conv32_wave.hip) */
+/* the same two layers on the wave-private kernels (csrc/conv32_wave.hip); wfrag_scratch: the 6144 floats mural_debug_cw_wfrag wrote
+ * for W (forward | input-gradient filter fragments, the per-step relayout of the composed step) or NULL: the conv gathers its
+ * fragments from a copy of W in LDS */
+int mural_debug_cw_wfrag(const float* W, float* out6144, void* stream);
 int mural_debug_cw_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float* state, const float* W,
                               const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,
-                              int32_t out_relu, float* y, void* stream);
+                              int32_t out_relu, float* y, float* wfrag_scratch, void* stream);
 int mural_debug_cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* state,
                               const float* gamma, int32_t pre_relu, float* dz, double* stat_out, float* part, int32_t* nrow,
-                              void* stream);
+                              float* wfrag_scratch, void* stream);
 
 /* Validation hook: the generic Conv1d of the INDEL path with every geometry knob (stride, nearest-neighbour upsampling `up`,
  * activation 0 none / 1 ReLU / 2 SiLU / 3 Softplus, two residuals), weights wt laid out [Cin][K][Cout]; engine 0 = vector-ALU

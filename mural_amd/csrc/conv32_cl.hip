@@ -16,6 +16,7 @@
 #include <cstring>
 
 #include "conv32_cl.h"
+#include "conv32_jobs.h"
 
 namespace mural {
 namespace {
@@ -386,36 +387,42 @@ __global__ __launch_bounds__(256) void bn_stats_cl_kernel(const float* __restric
   cl_slot_add(s1, s2, acc + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, red, threadIdx.x);
 }
 
-// dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) [+ add1 + add2]; workgroup 0 writes dgamma / dbeta
-__global__ __launch_bounds__(256) void bn_bwd_apply_cl_kernel(const float* __restrict__ dz, const float* __restrict__ x, int64_t rows,
-                                                              int relu, const float* __restrict__ state, const float* __restrict__ gamma,
-                                                              const double* __restrict__ acc, double n, const float* __restrict__ add1,
-                                                              const float* __restrict__ add2, float* __restrict__ dx,
-                                                              float* __restrict__ dgamma, float* __restrict__ dbeta) {
+// dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) [+ add1 + add2]; workgroup 0 writes dgamma / dbeta.
+// blockIdx.y = job (conv32_jobs.h: the two towers in one launch)
+struct BnApplyArgs2 { BnApplyJob j[TOWER_JOBS]; };
+__global__ __launch_bounds__(256) void bn_bwd_apply_cl_kernel(const BnApplyArgs2 aa) {
+  const BnApplyJob& a = aa.j[blockIdx.y];
+  const float* __restrict__ dz = a.dz;
+  const float* __restrict__ x = a.x;
+  const float* __restrict__ add1 = a.add1;
+  const float* __restrict__ add2 = a.add2;
+  float* __restrict__ dx = a.dx;
+  const int relu = a.relu;
+  const double n = (double)a.rows;
   __shared__ float cst[4][CL_C];      // gamma * invstd, mean(dz), mean(dz * xhat), mean
   __shared__ float inv[CL_C];
   if (threadIdx.x < CL_C) {
     const int c = threadIdx.x;
     double s1 = 0.0, s2 = 0.0;
     for (int k = 0; k < MURAL_BN_SLOTS; ++k) {
-      s1 += acc[((size_t)k * 2 + 0) * CL_C + c];
-      s2 += acc[((size_t)k * 2 + 1) * CL_C + c];
+      s1 += a.acc[((size_t)k * 2 + 0) * CL_C + c];
+      s2 += a.acc[((size_t)k * 2 + 1) * CL_C + c];
     }
-    cst[0][c] = gamma[c] * state[3 * CL_C + c];
+    cst[0][c] = a.gamma[c] * a.state[3 * CL_C + c];
     cst[1][c] = (float)(s1 / n);
     cst[2][c] = (float)(s2 / n);
-    cst[3][c] = state[2 * CL_C + c];
-    inv[c] = state[3 * CL_C + c];
+    cst[3][c] = a.state[2 * CL_C + c];
+    inv[c] = a.state[3 * CL_C + c];
     if (blockIdx.x == 0) {
-      dgamma[c] = (float)s2;
-      dbeta[c] = (float)s1;
+      a.dgamma[c] = (float)s2;
+      a.dbeta[c] = (float)s1;
     }
   }
   __syncthreads();
   const int chunk = threadIdx.x & 7;
   const f32x4 k0 = ld4(&cst[0][4 * chunk]), m1 = ld4(&cst[1][4 * chunk]), m2 = ld4(&cst[2][4 * chunk]), mu = ld4(&cst[3][4 * chunk]),
               is = ld4(&inv[4 * chunk]);
-  const int64_t total = rows * 8;
+  const int64_t total = a.rows * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const f32x4 raw = ld4(x + i * 4), d = ld4(dz + i * 4);
     const f32x4 r1 = add1 ? ld4(add1 + i * 4) : splat(0.f), r2 = add2 ? ld4(add2 + i * 4) : splat(0.f);
@@ -433,12 +440,18 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cl_kernel(const float* __res
 }
 
 // MaxPool1d(k, s, p) on [B][L][32] -> [B][Lout][32] with the arg-max column (first maximum wins); thread = (row, pooled column,
-// 4 channels)
-__global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const float* __restrict__ x, int64_t B, int L, int Lout, int k, int s, int p,
-                                                             float* __restrict__ y, int32_t* __restrict__ arg, double* __restrict__ acc) {
+// 4 channels); blockIdx.y = job
+struct PoolFwdArgs2 { PoolFwdJob j[TOWER_JOBS]; };
+__global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const PoolFwdArgs2 aa) {
+  const PoolFwdJob& a = aa.j[blockIdx.y];
+  const float* __restrict__ x = a.x;
+  float* __restrict__ y = a.y;
+  int32_t* __restrict__ arg = a.arg;
+  const int L = a.L, k = a.k, s = a.s, p = a.p;
+  const int Lout = (L + 2 * p - k) / s + 1;
   __shared__ float red[256];
   f32x4 s1 = splat(0.f), s2 = splat(0.f);     // batch sums of the pooled values for the BatchNorm behind the pool (acc != nullptr)
-  const int64_t total = B * Lout * 8;
+  const int64_t total = a.B * Lout * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int chunk = (int)(i & 7);
     const int64_t bc = i >> 3;
@@ -464,13 +477,18 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const float* __rest
     s1 += m;
     s2 += f32x4{m.x * m.x, m.y * m.y, m.z * m.z, m.w * m.w};
   }
-  if (acc) cl_slot_add(s1, s2, acc + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, red, threadIdx.x);
+  if (a.acc) cl_slot_add(s1, s2, a.acc + (size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C, red, threadIdx.x);
 }
 
 // gather backward for disjoint windows (stride >= kernel: every pool of the model): dx[b][l][c] = arg[b][lo][c] == l ? dy[b][lo][c] : 0
-__global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const float* __restrict__ dy, const int32_t* __restrict__ arg, int64_t B, int L,
-                                                             int Lout, int s, int p, float* __restrict__ dx) {
-  const int64_t total = B * L * 8;
+struct PoolBwdArgs2 { PoolBwdJob j[TOWER_JOBS]; };
+__global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const PoolBwdArgs2 aa) {
+  const PoolBwdJob& a = aa.j[blockIdx.y];
+  const float* __restrict__ dy = a.dy;
+  const int32_t* __restrict__ arg = a.arg;
+  float* __restrict__ dx = a.dx;
+  const int L = a.L, Lout = a.Lout, s = a.s, p = a.p;
+  const int64_t total = a.B * L * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int chunk = (int)(i & 7);
     const int64_t bl = i >> 3;
@@ -489,10 +507,14 @@ __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const float* __rest
   }
 }
 
-// global max over the columns of [B][L][32] -> feat [B][32] + arg-max column
-__global__ __launch_bounds__(256) void gmax_cl_kernel(const float* __restrict__ x, int64_t B, int L, float* __restrict__ feat,
-                                                      int32_t* __restrict__ arg) {
-  const int64_t total = B * 8;
+// global max over the columns of [B][L][32] -> feat [B][32] + arg-max column; relu: feat = max(0, .) -- the conv in front wrote its
+// raw output and the ReLU of conv3 (model_snv.py:386-387) is taken here (max_l relu(v) = relu(max_l v); the backward masks on v > 0)
+struct GmaxFwdArgs2 { GmaxFwdJob j[TOWER_JOBS]; };
+__global__ __launch_bounds__(256) void gmax_cl_kernel(const GmaxFwdArgs2 aa) {
+  const GmaxFwdJob& a = aa.j[blockIdx.y];
+  const float* __restrict__ x = a.x;
+  const int L = a.L;
+  const int64_t total = a.B * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int chunk = (int)(i & 7);
     const int64_t b = i >> 3;
@@ -507,27 +529,31 @@ __global__ __launch_bounds__(256) void gmax_cl_kernel(const float* __restrict__ 
           am[q] = l;
         }
     }
-    st4(feat + (size_t)b * CL_C + 4 * chunk, m);
-    int32_t* ap = arg + (size_t)b * CL_C + 4 * chunk;
+    if (a.relu) m = max4(m, splat(0.f));
+    st4(a.feat + (size_t)b * CL_C + 4 * chunk, m);
+    int32_t* ap = a.arg + (size_t)b * CL_C + 4 * chunk;
     ap[0] = am[0]; ap[1] = am[1]; ap[2] = am[2]; ap[3] = am[3];
   }
 }
 
 // backward of the global max and of the ReLU in front of it: dc3[b][l][c] = (l == arg[b][c] && c3[b][l][c] > 0) ? dfeat[b][c] : 0
-__global__ __launch_bounds__(256) void gmax_relu_bwd_cl_kernel(const float* __restrict__ dfeat, const int32_t* __restrict__ arg,
-                                                               const float* __restrict__ c3, int64_t B, int L, float* __restrict__ dx) {
-  const int64_t total = B * L * 8;
+// (c3: the conv output, raw or behind its ReLU -- the mask is the same)
+struct GmaxBwdArgs2 { GmaxBwdJob j[TOWER_JOBS]; };
+__global__ __launch_bounds__(256) void gmax_relu_bwd_cl_kernel(const GmaxBwdArgs2 aa) {
+  const GmaxBwdJob& a = aa.j[blockIdx.y];
+  const int L = a.L;
+  const int64_t total = a.B * L * 8;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int chunk = (int)(i & 7);
     const int64_t bl = i >> 3;
     const int64_t b = bl / L;
     const int l = (int)(bl - b * L);
-    const f32x4 g = ld4(dfeat + (size_t)b * CL_C + 4 * chunk), v = ld4(c3 + (size_t)bl * CL_C + 4 * chunk);
-    const int32_t* ap = arg + (size_t)b * CL_C + 4 * chunk;
+    const f32x4 g = ld4(a.dfeat + (size_t)b * CL_C + 4 * chunk), v = ld4(a.c3 + (size_t)bl * CL_C + 4 * chunk);
+    const int32_t* ap = a.arg + (size_t)b * CL_C + 4 * chunk;
     f32x4 o;
 #pragma unroll
     for (int q = 0; q < 4; ++q) o[q] = (ap[q] == l && v[q] > 0.f) ? g[q] : 0.f;
-    st4(dx + (size_t)bl * CL_C + 4 * chunk, o);
+    st4(a.dx + (size_t)bl * CL_C + 4 * chunk, o);
   }
 }
 
@@ -606,44 +632,114 @@ int cl_bn_stats(const float* x, int64_t rows, int relu, double* acc, hipStream_t
   return MURAL_OK;
 }
 
+int cl_bn_bwd_apply_jobs(const BnApplyJob* jobs, int n, hipStream_t stream) {
+  BnApplyArgs2 aa;
+  std::memset(&aa, 0, sizeof(aa));
+  int gx = 0, ny = 0;
+  for (int i = 0; i < n; ++i) {
+    if (jobs[i].rows == 0) continue;
+    aa.j[ny++] = jobs[i];
+    const int g = cl_grid(jobs[i].rows * 8, 2048);
+    gx = g > gx ? g : gx;
+  }
+  if (ny == 0) return MURAL_OK;
+  hipLaunchKernelGGL(bn_bwd_apply_cl_kernel, dim3(gx, ny), dim3(256), 0, stream, aa);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
 int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, const float* state, const float* gamma, const double* acc,
                     const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta, hipStream_t stream) {
-  if (rows == 0) return MURAL_OK;
-  hipLaunchKernelGGL(bn_bwd_apply_cl_kernel, dim3(cl_grid(rows * 8, 2048)), dim3(256), 0, stream, dz, x, rows, relu, state, gamma, acc,
-                     (double)rows, add1, add2, dx, dgamma, dbeta);
+  const BnApplyJob j{dz, x, rows, relu, state, gamma, acc, add1, add2, dx, dgamma, dbeta};
+  return cl_bn_bwd_apply_jobs(&j, 1, stream);
+}
+
+int cl_maxpool_fwd_jobs(const PoolFwdJob* jobs, int n, hipStream_t stream) {
+  PoolFwdArgs2 aa;
+  std::memset(&aa, 0, sizeof(aa));
+  int gx = 0, ny = 0;
+  for (int i = 0; i < n; ++i) {
+    const PoolFwdJob& j = jobs[i];
+    const int Lout = (j.L + 2 * j.p - j.k) / j.s + 1;
+    if (j.B * Lout == 0) continue;
+    aa.j[ny++] = j;
+    const int g = cl_grid(j.B * Lout * 8, j.acc ? 1024 : 8192);
+    gx = g > gx ? g : gx;
+  }
+  if (ny == 0) return MURAL_OK;
+  hipLaunchKernelGGL(maxpool_cl_fwd_kernel, dim3(gx, ny), dim3(256), 0, stream, aa);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
 int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, double* acc, hipStream_t stream) {
-  const int Lout = (L + 2 * p - k) / s + 1;
-  if (B * Lout == 0) return MURAL_OK;
-  hipLaunchKernelGGL(maxpool_cl_fwd_kernel, dim3(cl_grid(B * Lout * 8, acc ? 1024 : 8192)), dim3(256), 0, stream, x, B, L, Lout, k, s, p, y, arg,
-                     acc);
+  const PoolFwdJob j{x, B, L, k, s, p, y, arg, acc};
+  return cl_maxpool_fwd_jobs(&j, 1, stream);
+}
+
+int cl_maxpool_bwd_jobs(const PoolBwdJob* jobs, int n, hipStream_t stream) {
+  PoolBwdArgs2 aa;
+  std::memset(&aa, 0, sizeof(aa));
+  int gx = 0, ny = 0;
+  for (int i = 0; i < n; ++i) {
+    const PoolBwdJob& j = jobs[i];
+    MURAL_REQUIRE(j.s >= j.k, "channel-last max-pool backward serves disjoint windows (stride >= kernel)");
+    if (j.B * j.L == 0) continue;
+    aa.j[ny++] = j;
+    const int g = cl_grid(j.B * j.L * 8);
+    gx = g > gx ? g : gx;
+  }
+  if (ny == 0) return MURAL_OK;
+  hipLaunchKernelGGL(maxpool_cl_bwd_kernel, dim3(gx, ny), dim3(256), 0, stream, aa);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
 int cl_maxpool_bwd(const float* dy, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream) {
-  MURAL_REQUIRE(s >= k, "channel-last max-pool backward serves disjoint windows (stride >= kernel)");
-  if (B * L == 0) return MURAL_OK;
-  hipLaunchKernelGGL(maxpool_cl_bwd_kernel, dim3(cl_grid(B * L * 8)), dim3(256), 0, stream, dy, arg, B, L, Lout, s, p, dx);
+  const PoolBwdJob j{dy, arg, B, L, Lout, k, s, p, dx};
+  return cl_maxpool_bwd_jobs(&j, 1, stream);
+}
+
+int cl_gmax_fwd_jobs(const GmaxFwdJob* jobs, int n, hipStream_t stream) {
+  GmaxFwdArgs2 aa;
+  std::memset(&aa, 0, sizeof(aa));
+  int gx = 0, ny = 0;
+  for (int i = 0; i < n; ++i) {
+    if (jobs[i].B == 0) continue;
+    aa.j[ny++] = jobs[i];
+    const int g = cl_grid(jobs[i].B * 8);
+    gx = g > gx ? g : gx;
+  }
+  if (ny == 0) return MURAL_OK;
+  hipLaunchKernelGGL(gmax_cl_kernel, dim3(gx, ny), dim3(256), 0, stream, aa);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
 int cl_gmax_fwd(const float* x, int64_t B, int L, float* feat, int32_t* arg, hipStream_t stream) {
-  if (B == 0) return MURAL_OK;
-  hipLaunchKernelGGL(gmax_cl_kernel, dim3(cl_grid(B * 8)), dim3(256), 0, stream, x, B, L, feat, arg);
+  const GmaxFwdJob j{x, B, L, 0, feat, arg};
+  return cl_gmax_fwd_jobs(&j, 1, stream);
+}
+
+int cl_gmax_relu_bwd_jobs(const GmaxBwdJob* jobs, int n, hipStream_t stream) {
+  GmaxBwdArgs2 aa;
+  std::memset(&aa, 0, sizeof(aa));
+  int gx = 0, ny = 0;
+  for (int i = 0; i < n; ++i) {
+    if (jobs[i].B * jobs[i].L == 0) continue;
+    aa.j[ny++] = jobs[i];
+    const int g = cl_grid(jobs[i].B * jobs[i].L * 8);
+    gx = g > gx ? g : gx;
+  }
+  if (ny == 0) return MURAL_OK;
+  hipLaunchKernelGGL(gmax_relu_bwd_cl_kernel, dim3(gx, ny), dim3(256), 0, stream, aa);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
 int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t B, int L, float* dx, hipStream_t stream) {
-  if (B * L == 0) return MURAL_OK;
-  hipLaunchKernelGGL(gmax_relu_bwd_cl_kernel, dim3(cl_grid(B * L * 8)), dim3(256), 0, stream, dfeat, arg, c3, B, L, dx);
-  MURAL_HIP_CHECK(hipGetLastError());
-  return MURAL_OK;
+  const GmaxBwdJob j{dfeat, arg, c3, B, L, dx};
+  return cl_gmax_relu_bwd_jobs(&j, 1, stream);
 }
 
 }  // namespace mural

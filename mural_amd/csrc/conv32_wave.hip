@@ -37,6 +37,7 @@
 #include <cstring>
 
 #include "conv32_cl.h"
+#include "conv32_jobs.h"
 
 namespace mural {
 namespace {
@@ -140,6 +141,33 @@ __device__ __forceinline__ void cw_frags_lds(const float* Wl, int dgrad, int mb,
   }
 }
 
+// The same fragments, written once per step for all conv layers of the step by cw_wfrag_kernel: [dir: forward | input gradient]
+// [mb][g][lane][4] floats = k-steps 4 g .. 4 g + 3 of a lane side by side, so that a wave reads a layer's fragments with twelve
+// coalesced 16-byte loads per lane and the prologue of a conv launch has no LDS copy of W and no barrier for it
+constexpr int CW_WFRAG = 2 * SNV_KSTEPS * 64;      // floats per (layer, direction)
+struct CwFragJobs {
+  const float* W[24];
+  float* out;             // [n][2][CW_WFRAG]
+  int n;
+};
+__global__ __launch_bounds__(256) void cw_wfrag_kernel(const CwFragJobs jobs) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= jobs.n * 2 * CW_WFRAG) return;
+  const int q = i & 3, lane = (i >> 2) & 63, g = (i >> 8) % 6, mb = (i >> 8) / 6 % 2, dir = (i / CW_WFRAG) & 1, layer = i / (2 * CW_WFRAG);
+  const int s = 4 * g + q, t = s / 8, h = (s % 8) / 4;
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int cin = 16 * h + 4 * kk + q, cout = 16 * mb + n16;
+  jobs.out[i] = jobs.W[layer][dir ? (cin * CL_C + cout) * 3 + (2 - t) : (cout * CL_C + cin) * 3 + t];
+}
+__device__ __forceinline__ void cw_frags_global(const float* __restrict__ frag, int lane, float (&a0)[SNV_KSTEPS], float (&a1)[SNV_KSTEPS]) {
+#pragma unroll
+  for (int g = 0; g < 6; ++g) {
+    const f32x4 u = ld4(frag + (size_t)g * 256 + 4 * lane), v = ld4(frag + (size_t)(6 + g) * 256 + 4 * lane);
+    a0[4 * g] = u.x; a0[4 * g + 1] = u.y; a0[4 * g + 2] = u.z; a0[4 * g + 3] = u.w;
+    a1[4 * g] = v.x; a1[4 * g + 1] = v.y; a1[4 * g + 2] = v.z; a1[4 * g + 3] = v.w;
+  }
+}
+
 #define CW_MFMA(A, B, C) __builtin_amdgcn_mfma_f32_16x16x4f32((A), (B), (C), 0, 0, 0)
 
 // one conv tap (8 k-steps) of a block for both M-blocks: the two accumulator chains alternate pair by pair, `burst` (vector / LDS /
@@ -216,8 +244,8 @@ __device__ __forceinline__ void cw_conv_blocks(const char* img, const uint32_t (
 struct CwUnits {
   int64_t lo, hi;
 };
-__device__ __forceinline__ void cw_units_init(CwUnits& w, int64_t n_units) {
-  const int64_t per = (n_units + gridDim.x - 1) / gridDim.x;
+__device__ __forceinline__ void cw_units_init(CwUnits& w, int64_t n_units, int grid) {
+  const int64_t per = (n_units + grid - 1) / grid;
   w.lo = (int64_t)blockIdx.x * per;
   w.hi = w.lo + per < n_units ? w.lo + per : n_units;
 }
@@ -228,6 +256,7 @@ struct CwFwdArgs {
   const float* x;
   float* y;
   const float* W;
+  const float* wfrag;     // the forward fragments of W (cw_wfrag_kernel) or nullptr: gathered from a copy of W in LDS
   const float* bias;
   const float* res1;
   const float* res2;
@@ -236,12 +265,16 @@ struct CwFwdArgs {
   double* stat_out;       // batch sums of relu(y), relu(y)^2 for the next BatchNorm; nullptr: none
   int64_t B;
   int64_t n_units;
+  int grid;               // workgroups of this job (blockIdx.x beyond it: nothing to do)
   int dbg;                // timing experiments (MURAL_DEBUG_CW): 1 no loads of x, 2 no stores, 4 no residual loads, 8 no conv
 };
+struct CwFwdArgs2 { CwFwdArgs j[TOWER_JOBS]; };
 
 template <int NB>
-__global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdArgs a) {
+__global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const CwFwdArgs& a = aa.j[blockIdx.y];
+  if ((int)blockIdx.x >= a.grid) return;
   constexpr int IMG_FLOATS = (16 * NB + 2) * CL_C;
   constexpr int WAVE_FLOATS = IMG_FLOATS + CW_DUMP;
   constexpr int NLD = 2 * NB;                                   // staging slots per lane: 64 NLD >= pieces of the widest unit
@@ -253,7 +286,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
   float* wbase = smem + CW_AUX + wave * WAVE_FLOATS;
   char* wb = reinterpret_cast<char*>(wbase);
   CwUnits units;
-  cw_units_init(units, a.n_units);
+  cw_units_init(units, a.n_units, a.grid);
   const uint32_t lane16 = 16u * (uint32_t)lane;
   const uint32_t row_bytes = (uint32_t)g.L * 128u;
   const size_t unit_stride = (size_t)g.P * g.L * CL_C;          // floats
@@ -262,12 +295,15 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
     return u < units.hi ? (uint32_t)(rows < g.P ? rows : g.P) * row_bytes : 0u;
   };
   int64_t unit = units.lo + wave;
-  cw_copy_w(a.W, smem + CW_AUX + 4096, tid);
+  float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
+  if (a.wfrag) cw_frags_global(a.wfrag, lane, a0, a1);          // (in flight under the BatchNorm finalisation)
+  else cw_copy_w(a.W, smem + CW_AUX + 4096, tid);
   cl_finalize(a.fin, aux, reinterpret_cast<double*>(smem + CW_AUX), tid);      // (ends with a workgroup barrier)
   const f32x4 s4 = ld4(aux + 4 * chunk), t4 = ld4(aux + CL_C + 4 * chunk), m4 = ld4(aux + 2 * CL_C + 4 * chunk);
-  float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
-  cw_frags_lds(smem + CW_AUX + 4096, 0, 0, n16, kk, a0);
-  cw_frags_lds(smem + CW_AUX + 4096, 0, 1, n16, kk, a1);
+  if (!a.wfrag) {
+    cw_frags_lds(smem + CW_AUX + 4096, 0, 0, n16, kk, a0);
+    cw_frags_lds(smem + CW_AUX + 4096, 0, 1, n16, kk, a1);
+  }
   const uint32_t dump = IMG_FLOATS * 4u + 16u * (uint32_t)(lane & 31);
   // image offsets of the staging slots: a 16-bit table [slot][lane] behind the waves' regions (18 registers per lane otherwise)
   const uint16_t* sotab = reinterpret_cast<const uint16_t*>(smem + CW_AUX + CW_WAVES * WAVE_FLOATS) + lane;
@@ -376,6 +412,7 @@ struct CwBwdArgs {
   const float* dy;
   const float* x;
   const float* W;
+  const float* wfrag;     // the input-gradient fragments of W (cw_wfrag_kernel) or nullptr
   const float* state;     // scale | beta | mean | invstd of the BatchNorm in front of the conv
   const float* gamma;
   int pre_relu;
@@ -384,12 +421,16 @@ struct CwBwdArgs {
   double* stat_out;       // sum(dz), sum(dz * xhat)
   int64_t B;
   int64_t n_units;
+  int grid;
   int dbg;                // timing experiments (MURAL_DEBUG_CW): 16 no loads, 32 no weight gradient, 64 no input gradient, 128 no stores
 };
+struct CwBwdArgs2 { CwBwdArgs j[TOWER_JOBS]; };
 
 template <int NB>
-__global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdArgs a) {
+__global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
+  const CwBwdArgs& a = aa.j[blockIdx.y];
+  if ((int)blockIdx.x >= a.grid) return;
   constexpr int IMG_FLOATS = (16 * NB + 2) * CL_C;
   constexpr int WAVE_FLOATS = IMG_FLOATS + CW_DUMP;
   constexpr int NLD = 2 * NB;
@@ -405,7 +446,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
   float* wbase = smem + CW_AUX + wave * WAVE_FLOATS;            // dy image | dump
   char* wb = reinterpret_cast<char*>(wbase);
   CwUnits units;
-  cw_units_init(units, a.n_units);
+  cw_units_init(units, a.n_units, a.grid);
   const uint32_t lane16 = 16u * (uint32_t)lane;
   const uint32_t row_bytes = (uint32_t)g.L * 128u;
   const size_t unit_stride = (size_t)g.P * g.L * CL_C;
@@ -423,11 +464,15 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
   bool first = true;
   uint32_t* tab = reinterpret_cast<uint32_t*>(aux + CW_AUX_TAB);      // memory offset of the row of column 4 s + kk, s < NKS
   if (tid < 4 * NKS) tab[tid] = cw_col_offset(g, (uint32_t)tid);
-  cw_copy_w(a.W, smem + CW_AUX, tid);
-  __syncthreads();
   float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
-  cw_frags_lds(smem + CW_AUX, 1, 0, n16, kk, a0);
-  cw_frags_lds(smem + CW_AUX, 1, 1, n16, kk, a1);
+  if (a.wfrag) {
+    cw_frags_global(a.wfrag, lane, a0, a1);
+  } else {
+    cw_copy_w(a.W, smem + CW_AUX, tid);
+    __syncthreads();
+    cw_frags_lds(smem + CW_AUX, 1, 0, n16, kk, a0);
+    cw_frags_lds(smem + CW_AUX, 1, 1, n16, kk, a1);
+  }
   const uint32_t dump = IMG_FLOATS * 4u + 16u * (uint32_t)(lane & 31);
   // image offsets of the staging slots: a 16-bit table [slot][lane] behind the waves' regions (18 registers per lane otherwise)
   const uint16_t* sotab = reinterpret_cast<const uint16_t*>(smem + CW_AUX + CW_WAVES * WAVE_FLOATS) + lane;
@@ -619,21 +664,21 @@ constexpr size_t cw_lds_bytes() {
 }
 
 template <int NBV>
-int cw_launch_fwd(const CwFwdArgs& a, int grid, hipStream_t stream) {
+int cw_launch_fwd(const CwFwdArgs2& a, int gx, int gy, hipStream_t stream) {
   constexpr int NB = NBV < 4 ? 4 : NBV;      // (the waves' regions also hold W and the scratch of the prologue)
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32w_fwd_kernel<NB>)) return rc;
-  hipLaunchKernelGGL(conv32w_fwd_kernel<NB>, dim3(grid), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
+  hipLaunchKernelGGL(conv32w_fwd_kernel<NB>, dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
 template <int NBV>
-int cw_launch_bwd(const CwBwdArgs& a, int grid, hipStream_t stream) {
-  constexpr int NB = NBV < 4 ? 4 : NBV;      // (the waves' regions also hold four partial rows and W)
+int cw_launch_bwd(const CwBwdArgs2& a, int gx, int gy, hipStream_t stream) {
+  constexpr int NB = NBV < 4 ? 4 : NBV;      // (the waves' regions also hold two partial rows / W)
   static DynLdsOnce big_lds;
   if (int rc = big_lds.ensure(&conv32w_bwd_kernel<NB>)) return rc;
-  hipLaunchKernelGGL(conv32w_bwd_kernel<NB>, dim3(grid), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
+  hipLaunchKernelGGL(conv32w_bwd_kernel<NB>, dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
@@ -661,36 +706,84 @@ int cw_conv32_supported(int L) {
   return cw_geom(2, L, &g) ? 1 : 0;
 }
 
-int cw_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
-                  float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias, int post_relu,
-                  const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream) {
-  if (B == 0 || L == 0) return MURAL_OK;
-  CwFwdArgs a;
-  std::memset(&a, 0, sizeof(a));
-  MURAL_REQUIRE(cw_geom(B, L, &a.g), "conv32 (wave-private): L = %d does not fit a wave's image", L);
-  MURAL_REQUIRE(!post_relu && (out_relu || !acc_out), "conv32 (wave-private): raw output with the batch sums of relu(y) only");
-  if (!res1) { res1 = res2; res2 = nullptr; }
-  a.x = x; a.y = y; a.W = W; a.bias = bias; a.res1 = res1; a.res2 = res2; a.pre_relu = pre_relu;
-  a.stat_out = acc_out;
-  a.fin = ClFin{acc, (double)B * L, gamma, beta, eps, momentum, running_mean, running_var, state};
-  a.B = B;
-  a.n_units = (B + a.g.P - 1) / a.g.P;
-  a.dbg = cw_debug();
-  CW_DISPATCH(cw_launch_fwd, a.g.nb, a, cw_grid(a.n_units), stream)
+// up to TOWER_JOBS layers of the same role in one launch (blockIdx.y = job); the kernel instance is the one of the widest unit
+int cw_conv32_fwd_jobs(const ConvFwdJob* jobs, int n, float eps, float momentum, hipStream_t stream) {
+  MURAL_REQUIRE(n >= 1 && n <= TOWER_JOBS, "conv32 (wave-private): %d jobs", n);
+  CwFwdArgs2 aa;
+  std::memset(&aa, 0, sizeof(aa));
+  int nb = 0, gx = 0, ny = 0;
+  for (int i = 0; i < n; ++i) {
+    const ConvFwdJob& j = jobs[i];
+    if (j.B == 0 || j.L == 0) continue;
+    CwFwdArgs& a = aa.j[ny++];
+    MURAL_REQUIRE(cw_geom(j.B, j.L, &a.g), "conv32 (wave-private): L = %d does not fit a wave's image", j.L);
+    MURAL_REQUIRE(!j.post_relu && (j.out_relu || !j.acc_out), "conv32 (wave-private): raw output with the batch sums of relu(y) only");
+    const float* res1 = j.res1 ? j.res1 : j.res2;
+    const float* res2 = j.res1 ? j.res2 : nullptr;
+    a.x = j.x; a.y = j.y; a.W = j.W; a.wfrag = j.wfrag; a.bias = j.bias; a.res1 = res1; a.res2 = res2; a.pre_relu = j.pre_relu;
+    a.stat_out = j.acc_out;
+    a.fin = ClFin{j.acc, (double)j.B * j.L, j.gamma, j.beta, eps, momentum, j.running_mean, j.running_var, j.state};
+    a.B = j.B;
+    a.n_units = (j.B + a.g.P - 1) / a.g.P;
+    a.grid = cw_grid(a.n_units);
+    a.dbg = cw_debug();
+    nb = a.g.nb > nb ? a.g.nb : nb;
+    gx = a.grid > gx ? a.grid : gx;
+  }
+  if (ny == 0) return MURAL_OK;
+  CW_DISPATCH(cw_launch_fwd, nb, aa, gx, ny, stream)
 }
 
-int cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, const float* gamma, int pre_relu,
-                  float* dz, double* stat_out, float* part, int* nrow, hipStream_t stream) {
-  CwBwdArgs a;
-  std::memset(&a, 0, sizeof(a));
-  MURAL_REQUIRE(cw_geom(B, L, &a.g), "conv32_bwd (wave-private): L = %d does not fit a wave's image", L);
-  a.dy = dy; a.x = x; a.W = W; a.state = state; a.gamma = gamma; a.pre_relu = pre_relu; a.part = part; a.dz = dz; a.stat_out = stat_out;
-  a.B = B;
-  a.n_units = (B + a.g.P - 1) / a.g.P;
-  a.dbg = cw_debug();
-  const int grid = cw_grid(a.n_units);
-  *nrow = grid;
-  CW_DISPATCH(cw_launch_bwd, a.g.nb, a, grid, stream)
+int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream) {
+  MURAL_REQUIRE(n >= 1 && n <= TOWER_JOBS, "conv32_bwd (wave-private): %d jobs", n);
+  CwBwdArgs2 aa;
+  std::memset(&aa, 0, sizeof(aa));
+  int nb = 0, gx = 0;
+  for (int i = 0; i < n; ++i) {
+    ConvBwdJob& j = jobs[i];
+    CwBwdArgs& a = aa.j[i];
+    MURAL_REQUIRE(cw_geom(j.B, j.L, &a.g), "conv32_bwd (wave-private): L = %d does not fit a wave's image", j.L);
+    a.dy = j.dy; a.x = j.x; a.W = j.W; a.wfrag = j.wfrag; a.state = j.state; a.gamma = j.gamma; a.pre_relu = j.pre_relu; a.part = j.part; a.dz = j.dz;
+    a.stat_out = j.stat_out;
+    a.B = j.B;
+    a.n_units = (j.B + a.g.P - 1) / a.g.P;
+    a.grid = cw_grid(a.n_units);
+    a.dbg = cw_debug();
+    j.nrow = a.grid;
+    nb = a.g.nb > nb ? a.g.nb : nb;
+    gx = a.grid > gx ? a.grid : gx;
+  }
+  CW_DISPATCH(cw_launch_bwd, nb, aa, gx, n, stream)
+}
+
+// fragments of n <= 24 conv weights [32][32][3] for a whole step: out[n][2][6144 / 2] (forward | input gradient), one launch
+size_t cw_wfrag_floats() { return 2 * (size_t)CW_WFRAG; }
+int cw_wfrag_build(const float* const* W, int n, float* out, hipStream_t stream) {
+  MURAL_REQUIRE(n >= 0 && n <= 24, "conv32 fragments: %d layers", n);
+  if (n == 0) return MURAL_OK;
+  CwFragJobs jobs;
+  std::memset(&jobs, 0, sizeof(jobs));
+  for (int i = 0; i < n; ++i) jobs.W[i] = W[i];
+  jobs.out = out;
+  jobs.n = n;
+  hipLaunchKernelGGL(cw_wfrag_kernel, dim3((n * 2 * CW_WFRAG + 255) / 256), dim3(256), 0, stream, jobs);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+int cw_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
+                  float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* wfrag, const float* bias,
+                  int post_relu, const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream) {
+  const ConvFwdJob j{x, B, L, pre_relu, acc, gamma, beta, running_mean, running_var, state, W, wfrag, bias, post_relu, res1, res2, acc_out, out_relu, y};
+  return cw_conv32_fwd_jobs(&j, 1, eps, momentum, stream);
+}
+
+int cw_conv32_bwd(const float* dy, const float* x, const float* W, const float* wfrag, int64_t B, int L, const float* state, const float* gamma,
+                  int pre_relu, float* dz, double* stat_out, float* part, int* nrow, hipStream_t stream) {
+  ConvBwdJob j{dy, x, W, wfrag, B, L, state, gamma, pre_relu, dz, stat_out, part, 0};
+  const int rc = cw_conv32_bwd_jobs(&j, 1, stream);
+  *nrow = j.nrow;
+  return rc;
 }
 
 }  // namespace mural
@@ -699,16 +792,23 @@ int cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, in
 extern "C" int mural_debug_cw_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
                                          const float* beta, float* running_mean, float* running_var, float* state, const float* W,
                                          const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,
-                                         int32_t out_relu, float* y, void* stream) {
-  return mural::cw_conv32_fwd(x, B, L, pre_relu, acc, gamma, beta, 1e-5f, 0.1f, running_mean, running_var, state, W, bias, post_relu, res1, res2,
-                              acc_out, out_relu, y, (hipStream_t)stream);
+                                         int32_t out_relu, float* y, float* wfrag_scratch, void* stream) {
+  // wfrag_scratch != NULL: the 6144 floats mural_debug_cw_wfrag wrote for W (the path of the composed step), NULL: the conv gathers
+  // the fragments from a copy of W in LDS
+  return mural::cw_conv32_fwd(x, B, L, pre_relu, acc, gamma, beta, 1e-5f, 0.1f, running_mean, running_var, state, W, wfrag_scratch, bias, post_relu,
+                              res1, res2, acc_out, out_relu, y, (hipStream_t)stream);
 }
 
 extern "C" int mural_debug_cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* state,
                                          const float* gamma, int32_t pre_relu, float* dz, double* stat_out, float* part, int32_t* nrow,
-                                         void* stream) {
+                                         float* wfrag_scratch, void* stream) {
   int n = 0;
-  const int rc = mural::cw_conv32_bwd(dy, x, W, B, L, state, gamma, pre_relu, dz, stat_out, part, &n, (hipStream_t)stream);
+  const int rc = mural::cw_conv32_bwd(dy, x, W, wfrag_scratch ? wfrag_scratch + 3072 : nullptr, B, L, state, gamma, pre_relu, dz, stat_out, part, &n,
+                                      (hipStream_t)stream);
   if (nrow) *nrow = n;
   return rc;
+}
+
+extern "C" int mural_debug_cw_wfrag(const float* W, float* out6144, void* stream) {
+  return mural::cw_wfrag_build(&W, 1, out6144, (hipStream_t)stream);
 }

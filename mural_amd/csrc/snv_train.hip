@@ -14,6 +14,7 @@
 #include <cstring>
 
 #include "snv.h"
+#include "conv32_jobs.h"
 
 using namespace mural;
 
@@ -28,16 +29,18 @@ int cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, in
 // conv32_wave.hip: the same two layers with wave-private units (raw output, batch sums of relu(y))
 int cw_conv32_supported(int L);
 int cw_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* acc, const float* gamma, const float* beta, float eps,
-                  float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* bias, int post_relu,
-                  const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream);
-int cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int L, const float* state, const float* gamma, int pre_relu,
-                  float* dz, double* stat_out, float* part, int* nrow, hipStream_t stream);
+                  float momentum, float* running_mean, float* running_var, float* state, const float* W, const float* wfrag, const float* bias,
+                  int post_relu, const float* res1, const float* res2, double* acc_out, int out_relu, float* y, hipStream_t stream);
+int cw_conv32_bwd(const float* dy, const float* x, const float* W, const float* wfrag, int64_t B, int L, const float* state, const float* gamma,
+                  int pre_relu, float* dz, double* stat_out, float* part, int* nrow, hipStream_t stream);
+size_t cw_wfrag_floats();
+int cw_wfrag_build(const float* const* W, int n, float* out, hipStream_t stream);
 int cl_bn_stats(const float* x, int64_t rows, int relu, double* acc, hipStream_t stream);
 int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, const float* state, const float* gamma, const double* acc,
                     const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
 int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, double* acc, hipStream_t stream);
 int cl_maxpool_bwd(const float* dy, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream);
-int cl_gmax_fwd(const float* x, int64_t B, int L, float* feat, int32_t* arg, hipStream_t stream);
+int cl_gmax_fwd_jobs(const GmaxFwdJob* jobs, int n, hipStream_t stream);
 int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t B, int L, float* dx, hipStream_t stream);
 // train_ops.hip / snv_stage1.hip: first layer with channel-last output
 int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
@@ -123,6 +126,7 @@ struct Plan {
   float* part[24]; size_t part_floats;   // one partial-row region per conv32 layer (reduced by ONE launch at the end of the backward)
   float* dlogit[3];         // gradients of the local / mid / large logits
   float* first_scratch[2];  // per tower
+  float* wfrag;             // filter fragments of the 20 conv32 layers (forward | input gradient), written once per step by the forward
   size_t total;
 };
 
@@ -236,6 +240,7 @@ int make_plan(const MuralSnvShape& sh, int64_t B, void* ws, Plan* P) {
       P->first_scratch[t] = A.f((size_t)scr);
     }
   }
+  if (towers) P->wfrag = A.f(20 * cw_wfrag_floats());
   P->total = A.off;
   return MURAL_OK;
 }
@@ -261,6 +266,7 @@ struct Ctx {
   Plan* P;
   float momentum;
   void* stream;
+  const float* conv_w[20];    // the conv32 weights in the order of Plan::wfrag
   // weight-gradient partial rows waiting for the final reduction
   int njobs = 0;
   const float* job_part[24];
@@ -269,6 +275,25 @@ struct Ctx {
   float* job_db[24];
 };
 
+// the conv32 weights of the step in a fixed order (per tower: RBs1 convs, conv2, RBs2 convs, conv3) and their fragments in the workspace
+void conv_weight_table(Ctx& c) {
+  int n = 0;
+  for (const MuralTower* T : {&c.p->mid, &c.p->large}) {
+    for (const MuralResBlock* rb : {T->rbs1, T->rbs2}) {
+      for (int i = 0; i < 2; ++i) {
+        c.conv_w[n++] = rb[i].conv1.weight;
+        c.conv_w[n++] = rb[i].conv2.weight;
+      }
+      c.conv_w[n++] = rb == T->rbs1 ? T->conv_mid.weight : T->conv_out.weight;
+    }
+  }
+}
+const float* wfrag_of(const Ctx& c, const float* W, int dgrad) {
+  for (int i = 0; i < 20; ++i)
+    if (c.conv_w[i] == W) return c.P->wfrag + ((size_t)2 * i + dgrad) * (cw_wfrag_floats() / 2);
+  return nullptr;
+}
+
 // ---- forward of one BN -> conv32 layer
 int bnconv_f(Ctx& c, const float* x, int L, int pre_relu, double* acc, bool have_acc, const MuralBN& bn, const MuralAffine& cv,
              float* state, int post_relu, const float* r1, const float* r2, double* acc_out, int out_relu, float* y) {
@@ -276,8 +301,8 @@ int bnconv_f(Ctx& c, const float* x, int L, int pre_relu, double* acc, bool have
     if (int rc = cl_bn_stats(x, (int64_t)c.P->B * L, pre_relu, acc, (hipStream_t)c.stream)) return rc;
   if (use_wave_conv(L, post_relu, acc_out != nullptr, out_relu))
     return cw_conv32_fwd(x, c.P->B, L, pre_relu, acc, bn.weight, bn.bias, EPS, c.momentum, const_cast<float*>(bn.running_mean),
-                         const_cast<float*>(bn.running_var), state, cv.weight, cv.bias, post_relu, r1, r2, acc_out, out_relu, y,
-                         (hipStream_t)c.stream);
+                         const_cast<float*>(bn.running_var), state, cv.weight, wfrag_of(c, cv.weight, 0), cv.bias, post_relu, r1, r2, acc_out,
+                         out_relu, y, (hipStream_t)c.stream);
   return cl_conv32_fwd(x, c.P->B, L, pre_relu, acc, bn.weight, bn.bias, EPS, c.momentum, const_cast<float*>(bn.running_mean),
                        const_cast<float*>(bn.running_var), state, cv.weight, cv.bias, post_relu, r1, r2, acc_out, out_relu, y,
                        (hipStream_t)c.stream);
@@ -316,9 +341,12 @@ int tower_f(Ctx& c, int t, const MuralTower& T, float drop_p, uint64_t seed, con
                         b.x0b)) return rc;
   if (int rc = stage_f(c, T.rbs2, b.x0b, g.L[1], b.s3.acc_f[0], true, b.s3)) return rc;
   if (int rc = cl_maxpool_fwd(b.s3.t[3], B, g.L[1], g.pk[2], g.ps[2], g.pp[2], b.p3, b.arg3, b.acc_c3_f, st)) return rc;
-  if (int rc = bnconv_f(c, b.p3, g.L[2], 0, b.acc_c3_f, true, T.bn_out, T.conv_out, b.state_c3, 1, nullptr, nullptr, nullptr, 0, b.c3))
+  // conv3 writes its RAW output: its ReLU (model_snv.py:386-387) is taken by the global max behind it (max_l relu(v) = relu(max_l v),
+  // and the backward masks on v > 0 either way), so the layer runs on the same kernels as the others
+  if (int rc = bnconv_f(c, b.p3, g.L[2], 0, b.acc_c3_f, true, T.bn_out, T.conv_out, b.state_c3, 0, nullptr, nullptr, nullptr, 0, b.c3))
     return rc;
-  if (int rc = cl_gmax_fwd(b.c3, B, g.L[2], b.feat, b.argg, st)) return rc;
+  const GmaxFwdJob gj{b.c3, B, g.L[2], 1, b.feat, b.argg};
+  if (int rc = cl_gmax_fwd_jobs(&gj, 1, st)) return rc;
   // distal_fc: BatchNorm1d -> Dropout -> Linear on (B, 32)
   if (int rc = mural_op_bn_stats(b.feat, B, TR_C, 1, 0, b.acc_fc_f, c.stream)) return rc;
   if (int rc = train_bn2d_apply_dropout(b.feat, B, TR_C, 0, b.acc_fc_f, T.fc_bn.weight, T.fc_bn.bias, EPS, c.momentum,
@@ -356,8 +384,8 @@ int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const
   const int j = c.njobs++;
   MURAL_REQUIRE(j < 20, "internal: more conv layers than partial-row regions");
   if (use_wave_conv(L, 0, false, 0)) {
-    if (int rc = cw_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, bn.weight, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j],
-                               (hipStream_t)c.stream)) return rc;
+    if (int rc = cw_conv32_bwd(dy, x, cv.weight, wfrag_of(c, cv.weight, 1), c.P->B, L, state, bn.weight, pre_relu, dz, acc, c.P->part[j],
+                               &c.job_nrow[j], (hipStream_t)c.stream)) return rc;
   } else if (int rc = cl_conv32_bwd(dy, x, cv.weight, c.P->B, L, state, pre_relu, dz, acc, c.P->part[j], &c.job_nrow[j], (hipStream_t)c.stream)) {
     return rc;
   }
@@ -509,6 +537,8 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   } else if (int rc = mural_op_dense_to_symbols(distal_x, B, shape->distal_len, P.sym, status, stream)) {
     return rc;
   }
+  conv_weight_table(c);
+  if (int rc = cw_wfrag_build(c.conv_w, 20, P.wfrag, (hipStream_t)stream)) return rc;     // (weights are the same in the backward of this step)
   SideStreamHold ss;      // holds the device's side streams until this call has joined them again
   if (int rc = ss.acquire()) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
@@ -540,6 +570,7 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   }
   Ctx c{shape, params, grads, &P, 0.f, stream};
   const int m = shape->model_no, nc = shape->n_class;
+  if (m != 0) conv_weight_table(c);
   if (m == 0) return local_b(c, cat_x, dout, dropout_p, seeds, seed_dev);
   if (int rc = mural_op_head_bwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, dout, B, nc, m == 2 ? P.dlogit[0] : nullptr,
                                  P.dlogit[1], P.dlogit[2], stream)) return rc;

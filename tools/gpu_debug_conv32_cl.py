@@ -60,6 +60,9 @@ for case_no, (B, L, PRE) in enumerate(CASES):
     f32 = lambda t: t.to(torch.float32).contiguous().to(dev)
     xd, Wd, bd, gd, betad, r1d, r2d, dyd = map(f32, (x, W, bias, gamma, beta, r1, r2, dy))
     st = _lib.current_stream_ptr(dev)
+    wfs = torch.empty(6144, device=dev)      # odd cases: fragments from the per-step relayout kernel, even: gathered in LDS
+    if CW:
+        _lib.check(lib.mural_debug_cw_wfrag(Wd.data_ptr(), wfs.data_ptr(), st))
     acc = torch.zeros(32 * 2 * 32, dtype=torch.float64, device=dev)
     _lib.check(lib.mural_debug_cl_bn_stats(xd.data_ptr(), B * L, PRE, acc.data_ptr(), st))
     s = acc_sum(acc)
@@ -71,7 +74,7 @@ for case_no, (B, L, PRE) in enumerate(CASES):
     if CW:
         _lib.check(lib.mural_debug_cw_conv32_fwd(xd.data_ptr(), B, L, PRE, acc.data_ptr(), gd.data_ptr(), betad.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                                  state.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, r1d.data_ptr(), r2d.data_ptr(), acc_out.data_ptr(),
-                                                 1, yd.data_ptr(), st))
+                                                 1, yd.data_ptr(), wfs.data_ptr() if case_no % 2 else None, st))
     else:
         _lib.check(lib.mural_debug_cl_conv32_fwd(xd.data_ptr(), B, L, PRE, acc.data_ptr(), gd.data_ptr(), betad.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                                                  state.data_ptr(), Wd.data_ptr(), bd.data_ptr(), 0, r1d.data_ptr(), r2d.data_ptr(), acc_out.data_ptr(),
@@ -92,7 +95,8 @@ for case_no, (B, L, PRE) in enumerate(CASES):
     nrow = C.c_int32(0)
     if CW:
         _lib.check(lib.mural_debug_cw_conv32_bwd(dyd.data_ptr(), xd.data_ptr(), Wd.data_ptr(), B, L, state.data_ptr(), gd.data_ptr(), PRE,
-                                                 dzd.data_ptr(), stat.data_ptr(), part.data_ptr(), C.byref(nrow), st))
+                                                 dzd.data_ptr(), stat.data_ptr(), part.data_ptr(), C.byref(nrow),
+                                                 wfs.data_ptr() if case_no % 2 else None, st))
     else:
         _lib.check(lib.mural_debug_cl_conv32_bwd(dyd.data_ptr(), xd.data_ptr(), Wd.data_ptr(), B, L, state.data_ptr(), PRE, dzd.data_ptr(),
                                                  stat.data_ptr(), part.data_ptr(), C.byref(nrow), st))

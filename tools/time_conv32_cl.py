@@ -30,13 +30,17 @@ for L in (134, 67, 20, 23, 7):
     part = torch.empty(1024 * 3104, device=dev)
     nrow = C.c_int32(0)
     st = _lib.current_stream_ptr(dev)
+    wfs_t = torch.empty(6144, device=dev)
+    wfs = wfs_t.data_ptr() if os.environ.get("WFRAG", "1") == "1" else None
+    if CW:
+        _lib.check(lib.mural_debug_cw_wfrag(W.data_ptr(), wfs_t.data_ptr(), st))
     _lib.check(lib.mural_debug_cl_bn_stats(x.data_ptr(), B * L, 1, acc.data_ptr(), st))
 
     def fwd(a, b):
         if CW:
             return lambda: _lib.check(lib.mural_debug_cw_conv32_fwd(x.data_ptr(), B, L, 1, acc.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                                                     rm.data_ptr(), rv.data_ptr(), state.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, a, b,
-                                                                    acc_out.data_ptr(), 1, y.data_ptr(), st))
+                                                                    acc_out.data_ptr(), 1, y.data_ptr(), wfs, st))
         return lambda: _lib.check(lib.mural_debug_cl_conv32_fwd(x.data_ptr(), B, L, 1, acc.data_ptr(), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
                                                                 rv.data_ptr(), state.data_ptr(), W.data_ptr(), bias.data_ptr(), 0, a, b,
                                                                 acc_out.data_ptr(), 1, y.data_ptr(), st))
@@ -44,7 +48,7 @@ for L in (134, 67, 20, 23, 7):
     def bwd():
         if CW:
             _lib.check(lib.mural_debug_cw_conv32_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), B, L, state.data_ptr(), gamma.data_ptr(), 1, y.data_ptr(),
-                                                     acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), st))
+                                                     acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), wfs, st))
         else:
             _lib.check(lib.mural_debug_cl_conv32_bwd(dy.data_ptr(), x.data_ptr(), W.data_ptr(), B, L, state.data_ptr(), 1, y.data_ptr(),
                                                      acc_out.data_ptr(), part.data_ptr(), C.byref(nrow), st))
