@@ -19,6 +19,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstring>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -257,8 +258,12 @@ HD int fmt_i64(int64_t v, char* o) {
 }
 
 // numpy's float -> int64 cast (truncation; NaN and out-of-range values give INT64_MIN like the x86 conversion numpy uses)
+// (tested on the exponent bits: the library is built with -fno-honor-nans, under which a comparison-based NaN guard may be folded
+// away and the cast of a NaN is undefined -- INT64_MIN on the host, 0 on the device)
 HD int64_t label_to_i64(float f) {
-  if (!(f > -9.2233720368547758e18f && f < 9.2233720368547758e18f)) return INT64_MIN;
+  uint32_t b;
+  memcpy(&b, &f, 4);
+  if (((b >> 23) & 0xFFu) >= 127u + 63u) return INT64_MIN;      // NaN, infinities and |f| >= 2^63
   return (int64_t)f;
 }
 
@@ -402,6 +407,39 @@ extern "C" int64_t mural_tsv_row_bound(const MuralTsvRows* t) {
   return row_bound(*t, t->chrom_names);
 }
 
+// The chromosome-name table of a device format call arrives as host memory of the caller (a Python ctypes buffer that may be freed
+// right after the call returns) and is needed on the device: it is staged through pinned slots owned by the library, so the copy is
+// a true asynchronous copy (from pageable memory hipMemcpyAsync either blocks until the stream has drained or reads the buffer after
+// the caller has released it).  A slot is reused after the copy that last used it has completed.
+namespace {
+struct NameStage {
+  static constexpr int SLOTS = 8;
+  static constexpr size_t SLOT_BYTES = 16 * 1024;
+  std::mutex mu;
+  char* base = nullptr;
+  hipEvent_t ev[SLOTS] = {};
+  bool used[SLOTS] = {};
+  int next = 0;
+  // copies `bytes` of `src` into a slot and returns it (nullptr: table too large for a slot -- the caller copies synchronously)
+  int stage(const char* src, size_t bytes, hipStream_t stream, char* dst_dev) {
+    std::lock_guard<std::mutex> lock(mu);
+    if (!base) {
+      MURAL_HIP_CHECK(hipHostMalloc(reinterpret_cast<void**>(&base), SLOTS * SLOT_BYTES, hipHostMallocDefault));
+      for (int i = 0; i < SLOTS; ++i) MURAL_HIP_CHECK(hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    }
+    const int i = next;
+    next = (next + 1) % SLOTS;
+    if (used[i]) MURAL_HIP_CHECK(hipEventSynchronize(ev[i]));
+    std::memcpy(base + (size_t)i * SLOT_BYTES, src, bytes);
+    MURAL_HIP_CHECK(hipMemcpyAsync(dst_dev, base + (size_t)i * SLOT_BYTES, bytes, hipMemcpyHostToDevice, stream));
+    MURAL_HIP_CHECK(hipEventRecord(ev[i], stream));
+    used[i] = true;
+    return MURAL_OK;
+  }
+};
+NameStage g_name_stage;
+}  // namespace
+
 extern "C" size_t mural_tsv_format_workspace_bytes(int64_t n) {
   const int64_t blocks = (n + 31) / 32;      // the smallest workgroup tile is 32 rows
   return (size_t)(blocks + 1) * 8 + 4096;    // + room for the name table copy is added per call below
@@ -434,7 +472,12 @@ extern "C" int mural_tsv_format_device(const MuralTsvRows* t, char* out, int64_t
     if (int rc = g_tsv_lds.ensure(tsv_format_kernel<false>, tsv_format_kernel<true>)) return rc;
   int64_t* block_bytes = static_cast<int64_t*>(ws);
   char* names_dev = static_cast<char*>(ws) + (size_t)(nb + 1) * 8;
-  MURAL_HIP_CHECK(hipMemcpyAsync(names_dev, t->chrom_names, names_bytes, hipMemcpyHostToDevice, stream));
+  if (names_bytes <= NameStage::SLOT_BYTES) {
+    if (int rc = g_name_stage.stage(t->chrom_names, names_bytes, stream, names_dev)) return rc;
+  } else {      // (a table of more than 64 names of this stride: a synchronous copy, complete when it returns)
+    MURAL_HIP_CHECK(hipStreamSynchronize(stream));
+    MURAL_HIP_CHECK(hipMemcpy(names_dev, t->chrom_names, names_bytes, hipMemcpyHostToDevice));
+  }
   hipLaunchKernelGGL(tsv_format_kernel<false>, dim3((unsigned)nb), dim3(256), lds, stream, *t, names_dev, bound, rows, block_bytes, out);
   hipLaunchKernelGGL(tsv_scan_kernel, dim3(1), dim3(1024), 0, stream, block_bytes, nb, n_bytes);
   hipLaunchKernelGGL(tsv_format_kernel<true>, dim3((unsigned)nb), dim3(256), lds, stream, *t, names_dev, bound, rows, block_bytes, out);

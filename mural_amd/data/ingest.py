@@ -102,6 +102,8 @@ def read_bed(path):
     names = C.create_string_buffer(max(chroms, 1) * _NAME)
     _lib.check(lib.mural_bed_read(path.encode(), rows, cid.ctypes.data, start.ctypes.data, end.ctypes.data, score.ctypes.data,
                                  strand.ctypes.data, chroms, _NAME, names, C.byref(n), C.byref(nc)))
+    if n.value != rows or nc.value != chroms:      # (the file changed between the counting call and the fill call)
+        raise RuntimeError(f"{path}: counted {rows} rows / {chroms} chromosomes, then read {n.value} / {nc.value}")
     cn = [names.raw[i * _NAME:(i + 1) * _NAME].split(b"\0", 1)[0].decode() for i in range(chroms)]
     return BedSites(cn, cid, start, end, score, strand)
 

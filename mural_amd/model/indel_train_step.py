@@ -79,9 +79,16 @@ class _Layout:
 
 
 def _layout(model):
+    # the cached layout holds the parameter / buffer OBJECTS: replacing one of them (model.conv.weight = nn.Parameter(...)) must
+    # rebuild it -- compared by identity, a few dozen `is` tests per call
     lay = getattr(model, "_train_layout", None)
+    if lay is not None:
+        now = list(model.parameters()) + list(model.buffers())
+        if len(now) != len(lay.identity) or any(a is not b for a, b in zip(now, lay.identity)):
+            lay = None
     if lay is None:
         lay = model._train_layout = _Layout(model)
+        lay.identity = list(model.parameters()) + list(model.buffers())
     return lay
 
 
@@ -117,8 +124,12 @@ class ModelStep(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
         model, shape, ws = ctx.model, ctx.shape, ctx.ws
+        if ws is None:
+            raise RuntimeError("the INDEL training step keeps its saved activations for ONE backward (retain_graph=True is not supported: "
+                               "run the forward again)")
         x, drop_p, seed, seed_dev, B = ctx.args
         lay = _layout(model)
         dev = ws.device

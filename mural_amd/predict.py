@@ -7,6 +7,7 @@ and covered by world_size-2 gloo tests on CPU; the compute function is the HIP m
 ``forward_packed_reuse``; the prediction table is formatted by ``csrc/tsv.hip`` (device kernel or host threads).
 """
 import ctypes as C
+import os
 import queue
 import threading
 import time
@@ -154,12 +155,15 @@ class HipShardForward:
     REUSE_MIN_DENSITY = 0.1        # sites per base of a chunk's span above which the cross-position reuse path pays
 
     def __init__(self, model, fasta_path, local_radius, local_order=3, distal_radius=None, device="cuda", batch_sites=1 << 20,
-                 model_type="snv", dirichlet_weights=None, poisson=False, scale_factor=None, reuse=True):
+                 model_type="snv", dirichlet_weights=None, poisson=None, scale_factor=None, reuse=True):
         """`dirichlet_weights` / `poisson` / `scale_factor`: apply the post-head calibration chain of run_predict.py:217-225
         (and scripts/scaling.py) on the device, fused behind the head (calibration.calibrate_device); the shard then carries
-        float64 calibrated probabilities and the sink must not calibrate again.  `reuse`: let dense blocks of sites take the
+        float64 calibrated probabilities and the sink must not calibrate again.  `poisson=None` follows the reference's rule
+        (run_predict.py:224: `poisson_calib or model_type == 'indel'`): on for indel models, off for snv.  `reuse`: let dense blocks of sites take the
         cross-position reuse kernels (same probabilities within rounding, tests/test_gpu_reuse.py)."""
         from .data import ingest
+        if poisson is None:
+            poisson = model_type == "indel"
         self.calibration = dict(dirichlet_weights=dirichlet_weights, poisson=poisson, scale_factor=scale_factor)
         self.calibrated = dirichlet_weights is not None or bool(poisson) or bool(scale_factor)
         self._ingest = ingest
@@ -323,7 +327,7 @@ def _tsv_struct(names_buf, n_names, chrom_id, start, end, strand, label, prob, p
 def format_rows_host(names, chrom_id, start, end, strand, label, prob, perm=None, threads=0):
     """Text of the prediction-table rows (no header) for host arrays, formatted by the C++ row formatter (csrc/tsv.hip): bytes.
     `names`: list of chromosome names, `chrom_id` indexes it (None = every row is names[0]); `strand` uint8 (1 = '-');
-    `perm`: output row i = input row perm[i]."""
+    `perm`: output row i = input row perm[i] (len(perm) rows are written: a sub-range of the sorted rows in the part-file mode)."""
     n = len(start)
     prob = np.asarray(prob)
     if prob.dtype not in (np.float32, np.float64):
@@ -338,12 +342,13 @@ def format_rows_host(names, chrom_id, start, end, strand, label, prob, perm=None
     names_buf = _name_table(names)
     ptr = lambda a: None if a is None else a.ctypes.data     # noqa: E731
     t = _tsv_struct(names_buf, len(names), ptr(cid), ptr(cols["start"]), ptr(cols["end"]), ptr(cols["strand"]), ptr(cols["label"]),
-                    ptr(prob) if prob.size else None, prob.dtype == np.float64, prob.shape[1], prob.shape[1], ptr(pm), n)
+                    ptr(prob) if prob.size else None, prob.dtype == np.float64, prob.shape[1], prob.shape[1], ptr(pm),
+                    n if pm is None else len(pm))
     lib = _lib.lib()
     bound = int(lib.mural_tsv_row_bound(C.byref(t)))
     if bound < 0:
         _lib.check(_lib.MURAL_E_INVALID)
-    out = np.empty(max(n * bound, 1), np.uint8)
+    out = np.empty(max(int(t.n) * bound, 1), np.uint8)
     nbytes = C.c_int64(0)
     _lib.check(lib.mural_tsv_format_host(C.byref(t), out.ctypes.data, out.size, C.byref(nbytes), int(threads)))
     return out[:nbytes.value].tobytes()
@@ -370,6 +375,7 @@ class _TextWriter(threading.Thread):
         self.error = None
         self.seconds = {"wait_device": 0.0, "copy": 0.0, "write": 0.0}
         self.bytes = 0
+        self.shard_bytes = {}          # shard number -> bytes written for it (the part-file mode's index)
 
     def run(self):
         stream = torch.cuda.Stream(self.device)
@@ -377,7 +383,7 @@ class _TextWriter(threading.Thread):
             job = self.jobs.get()
             if job is None:
                 return
-            idx, event = job
+            idx, event, shard_no = job
             try:
                 if self.error is None:
                     t0 = time.perf_counter()
@@ -396,6 +402,7 @@ class _TextWriter(threading.Thread):
                     self.seconds["copy"] += t2 - t1
                     self.seconds["write"] += t3 - t2
                     self.bytes += nb
+                    self.shard_bytes[shard_no] = self.shard_bytes.get(shard_no, 0) + nb
             except Exception as e:      # noqa: BLE001  (surfaced by the sink)
                 self.error = e
             finally:
@@ -412,14 +419,33 @@ class TsvSink:
     HIP device (then the stable sort by start, the calibration, the formatting and the copy-out all run on that device and a
     writer thread does the file I/O).  Shards whose chromosomes arrive in ascending name order -- what predict_bed_sharded
     produces -- are streamed out at once; any other arrival order is handled by spooling the raw rows and merging at close().
-    Nothing is ever parsed back as numbers: chromosome names like '01' or '10' stay strings."""
+    Nothing is ever parsed back as numbers: chromosome names like '01' or '10' stay strings.
+
+    ``parts=True`` under torch.distributed with more than one rank: EVERY rank is a consumer.  Each rank sorts the gathered shard (the
+    all-gather of the probabilities stays the one collective of the path) and formats only ITS contiguous slice of the sorted rows --
+    on its own GPU, through its own writer thread, into its own part file ``<path>.part<rank>`` -- so sort, format, copy-out and
+    write() scale with the ranks instead of funnelling ~60 bytes of text per row through rank 0.  close() exchanges the per-shard byte
+    counts and rank 0 strings the slices together in (shard, rank) order with in-kernel file copies (os.sendfile); the table is
+    byte-identical to the single-writer one."""
 
     PIECE_ROWS = 1 << 20
 
-    def __init__(self, path, poisson=False, dirichlet_weights=None, host_threads=0):
+    def __init__(self, path, poisson=False, dirichlet_weights=None, host_threads=0, parts=False, group=None):
         self.path, self.poisson, self.dirichlet_weights = str(path), poisson, dirichlet_weights
         self.host_threads = host_threads
-        self._fh = open(self.path, "wb")
+        self.group = group
+        self._emulated = isinstance(parts, tuple)      # (rank, world) without a process group: this rank's part file only -- the
+        if self._emulated:                              # measurement of one rank's share of an N-rank run (bench.py: sink_only)
+            self.rank, self.world = int(parts[0]), int(parts[1])
+        else:
+            self.rank = dist.get_rank(group) if (parts and dist.is_initialized()) else 0
+            self.world = dist.get_world_size(group) if (parts and dist.is_initialized()) else 1
+        self.parts = self.world > 1
+        self._shard_no = -1
+        self._shard_bytes = {}         # host path of the part mode: shard number -> bytes
+        self._n_class = None
+        self._out_path = self.path + (".part%04d" % self.rank if self.parts else "")
+        self._fh = open(self._out_path, "wb")
         self._wrote_header = False
         self._last = None              # name of the last streamed chromosome
         self._spool = []               # out-of-order shards as host arrays
@@ -445,6 +471,9 @@ class TsvSink:
         return s if s.dtype == np.uint8 else (s == "-").astype(np.uint8)
 
     def _ensure_header(self, n_class):
+        self._n_class = n_class
+        if self.parts:                 # part files carry rows only; rank 0 writes the header when it strings them together
+            return
         if not self._wrote_header:
             self._flush_writer()
             self._fh.write(_header(n_class))
@@ -476,12 +505,16 @@ class TsvSink:
         prob = self._host_prob(shard["prob"])
         start = np.asarray(shard["start"])
         perm = np.argsort(start, kind="stable")
+        if self.parts:
+            s0, s1 = shard_bounds(len(perm), self.rank, self.world)
+            perm = perm[s0:s1]
         text = format_rows_host([name], None, start, shard["end"], self._strand_u8(shard["strand"]), shard["label"], prob, perm,
-                                self.host_threads)
+                                self.host_threads) if len(perm) else b""
         t1 = time.perf_counter()
         self._ensure_header(prob.shape[1] if prob.ndim == 2 else 0)
         self._flush_writer()
         self._fh.write(text)
+        self._shard_bytes[self._shard_no] = self._shard_bytes.get(self._shard_no, 0) + len(text)
         self.seconds["host_format"] += t1 - t0
         self.seconds["host_write"] += time.perf_counter() - t1
 
@@ -504,6 +537,10 @@ class TsvSink:
             start, end = to(shard["start"], torch.int64), to(shard["end"], torch.int64)
             strand, label = to(self._strand_u8(shard["strand"]), torch.uint8), to(shard["label"], torch.float32)
             perm = torch.sort(start, stable=True).indices
+            if self.parts:             # this rank's slice of the sorted rows
+                s0, s1 = shard_bounds(n, self.rank, self.world)
+                perm = perm[s0:s1].contiguous()
+                n = s1 - s0
             names_buf = _name_table([name])
             t = _tsv_struct(names_buf, 1, None, start.data_ptr(), end.data_ptr(), strand.data_ptr(), label.data_ptr(), prob.data_ptr(),
                             prob.dtype == torch.float64, k, prob.stride(0), None, 0)
@@ -530,7 +567,7 @@ class TsvSink:
                                                       self._ws.data_ptr(), self._ws.numel(), stream))
                 ev = torch.cuda.Event()
                 ev.record()
-                w.jobs.put((idx, ev))
+                w.jobs.put((idx, ev, self._shard_no))
             # the tensors of this shard must outlive the kernels just enqueued: the caching allocator keeps their memory on this
             # stream, so later allocations of the same stream cannot overwrite them before the kernels ran
         self.seconds["sort_format_enqueue"] += time.perf_counter() - t0
@@ -542,8 +579,11 @@ class TsvSink:
             return
         self.rows += n
         on_device = isinstance(shard["prob"], torch.Tensor) and shard["prob"].is_cuda
+        if self.parts and not (self._last is None or name > self._last):
+            raise ValueError("TsvSink(parts=True) takes the shards in ascending chromosome order (predict_bed_sharded's order)")
         if not self._spool and (self._last is None or name > self._last):
             self._last = name
+            self._shard_no += 1
             if on_device:
                 self._stream_device(name, shard)
             else:
@@ -577,8 +617,67 @@ class TsvSink:
                 out[key] += v
         return out
 
+    def _close_parts(self):
+        """Part mode: exchange the per-shard byte counts, rank 0 strings the slices together in (shard, rank) order."""
+        w_bytes = dict(self._shard_bytes)
+        for k, v in getattr(self, "_writer_shard_bytes", {}).items():
+            w_bytes[k] = w_bytes.get(k, 0) + v
+        mine = [int(w_bytes.get(i, 0)) for i in range(self._shard_no + 1)]
+        self._fh.flush()
+        self._fh.close()
+        if self._emulated:
+            return
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, (mine, self._n_class), group=self.group)     # (every rank closed its part before this returns)
+        if self.rank == 0:
+            n_shards = max(len(c) for c, _ in everyone)
+            k = next((nc for _, nc in everyone if nc is not None), 0)
+            t0 = time.perf_counter()
+            with open(self.path, "wb") as out:
+                out.write(_header(k))
+                out.flush()
+                fds = [os.open(self.path + ".part%04d" % r, os.O_RDONLY) for r in range(self.world)]
+                offs = [0] * self.world
+                try:
+                    for i in range(n_shards):
+                        for r in range(self.world):
+                            left = everyone[r][0][i] if i < len(everyone[r][0]) else 0
+                            while left > 0:
+                                sent = os.sendfile(out.fileno(), fds[r], offs[r], left)
+                                if sent <= 0:
+                                    raise IOError("short part file %s.part%04d" % (self.path, r))
+                                offs[r] += sent
+                                left -= sent
+                finally:
+                    for fd in fds:
+                        os.close(fd)
+            for r in range(self.world):
+                os.unlink(self.path + ".part%04d" % r)
+            self.seconds["assemble_parts"] = time.perf_counter() - t0
+        dist.barrier(group=self.group)      # the table exists when any rank returns
+
+    def abort(self):
+        """Stop the writer and remove what was written: the caller's run failed (e.g. the focal-base check of a later shard) and,
+        like the reference, leaves no table behind."""
+        try:
+            self._close_writer()
+        except Exception:      # noqa: BLE001  (the run is failing already)
+            pass
+        try:
+            self._fh.close()
+        finally:
+            if os.path.exists(self._out_path):
+                os.unlink(self._out_path)
+        self._spool = []
+
     def close(self):
+        w = self._writer
         self._close_writer()
+        if w is not None:
+            self._writer_shard_bytes = dict(w.shard_bytes)
+        if self.parts:
+            self._close_parts()
+            return
         if not self._spool:
             if not self._wrote_header:
                 self._fh.write(_header(0))
@@ -687,7 +786,8 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
         bounds = np.r_[0, cut, n_all] if n_all else np.zeros(1, np.int64)
         run_ids = cid_o[torch.from_numpy(bounds[:-1]).to(dev)].cpu().numpy() if n_all else np.zeros(0, np.int32)
         start_o, strand_o = up(sites.start)[order_d], up(sites.strand)[order_d]
-        need_meta = collect or (rank == 0 and sink is not None)
+        sink_here = sink is not None and (rank == 0 or getattr(sink, "parts", False))
+        need_meta = collect or sink_here
         if need_meta:
             end_o, label_o = up(sites.end)[order_d], up(sites.score)[order_d]
         grp_o = up(grp) if model_type == "snv" else None
@@ -725,54 +825,62 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
         if int(host[0]) != 0:
             raise ValueError(_FOCAL_MSG)
 
-    for si, (chrom, runs) in enumerate(shards):
-        n = sum(hi - lo for lo, hi in runs)
-        b0, b1 = shard_bounds(n, rank, world)
-        pos_s, strand_s = take(start_o, runs), take(strand_o, runs)
-        if hasattr(forward, "prefetch") and si + 1 < len(shards):
-            forward.prefetch(shards[si + 1][0])
-        t0 = clock()
-        local = forward(chrom, pos_s[b0:b1], strand_s[b0:b1])
-        T["compute_enqueue"] += clock() - t0
-        if local.shape[0] != b1 - b0:
-            raise RuntimeError("forward returned a wrong number of rows")
-        t0 = clock()
-        full = all_gather_rows(local, n, group)
-        T["gather"] += clock() - t0
-        k = full.shape[1] - 1
-        if dev is not None:
-            if model_type == "snv":
-                status = torch.zeros(1, dtype=torch.int32, device=dev)
-                with torch.cuda.device(dev):
-                    _lib.check(_lib.lib().mural_focal_group_check(full.data_ptr(), int(full.dtype == torch.float64), full.stride(0), k,
-                                                                 take(grp_o, runs).contiguous().data_ptr(), n, status.data_ptr(),
-                                                                 _lib.current_stream_ptr(dev)))
-                    host = torch.zeros(1, dtype=torch.int32).pin_memory()
-                    host.copy_(status, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                finish_check(pending_check)            # the verdict of the PREVIOUS shard: never waits for work just enqueued
-                pending_check = (ev, host)
-            shard = None
-            if need_meta:
-                shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
-                         "prob": full, "n_class": k}
-        else:
-            full = full.cpu().numpy() if isinstance(full, torch.Tensor) else np.asarray(full)
-            if model_type == "snv":
-                check_focal_groups(full[:, -1].astype(np.int64), take(grp_o, runs))
-            shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
-                     "prob": full[:, :-1], "n_class": k}
-        if sink is not None and rank == 0:
+    feeds_sink = sink is not None and (rank == 0 or getattr(sink, "parts", False))
+    try:
+        for si, (chrom, runs) in enumerate(shards):
+            n = sum(hi - lo for lo, hi in runs)
+            b0, b1 = shard_bounds(n, rank, world)
+            pos_s, strand_s = take(start_o, runs), take(strand_o, runs)
+            if hasattr(forward, "prefetch") and si + 1 < len(shards):
+                forward.prefetch(shards[si + 1][0])
             t0 = clock()
-            sink(shard)
-            T["sink"] += clock() - t0
-        if collect:
-            cpu = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)     # noqa: E731
-            kept.append((runs, {"start": cpu(shard["start"]), "end": cpu(shard["end"]), "strand": cpu(shard["strand"]),
-                                "label": cpu(shard["label"]), "prob": cpu(shard["prob"])[:, :k], "chrom": chrom}))
-    finish_check(pending_check)
-    if sink is not None and rank == 0 and hasattr(sink, "close"):
+            local = forward(chrom, pos_s[b0:b1], strand_s[b0:b1])
+            T["compute_enqueue"] += clock() - t0
+            if local.shape[0] != b1 - b0:
+                raise RuntimeError("forward returned a wrong number of rows")
+            t0 = clock()
+            full = all_gather_rows(local, n, group)
+            T["gather"] += clock() - t0
+            k = full.shape[1] - 1
+            if dev is not None:
+                if model_type == "snv":
+                    status = torch.zeros(1, dtype=torch.int32, device=dev)
+                    with torch.cuda.device(dev):
+                        _lib.check(_lib.lib().mural_focal_group_check(full.data_ptr(), int(full.dtype == torch.float64), full.stride(0), k,
+                                                                     take(grp_o, runs).contiguous().data_ptr(), n, status.data_ptr(),
+                                                                     _lib.current_stream_ptr(dev)))
+                        host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                        host.copy_(status, non_blocking=True)
+                        ev = torch.cuda.Event()
+                        ev.record()
+                    finish_check(pending_check)            # the verdict of the PREVIOUS shard: never waits for work just enqueued
+                    pending_check = (ev, host)
+                shard = None
+                if need_meta:
+                    shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
+                             "prob": full, "n_class": k}
+            else:
+                full = full.cpu().numpy() if isinstance(full, torch.Tensor) else np.asarray(full)
+                if model_type == "snv":
+                    check_focal_groups(full[:, -1].astype(np.int64), take(grp_o, runs))
+                shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
+                         "prob": full[:, :-1], "n_class": k}
+            if sink is not None and (rank == 0 or getattr(sink, "parts", False)):
+                t0 = clock()
+                sink(shard)
+                T["sink"] += clock() - t0
+            if collect:
+                cpu = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)     # noqa: E731
+                kept.append((runs, {"start": cpu(shard["start"]), "end": cpu(shard["end"]), "strand": cpu(shard["strand"]),
+                                    "label": cpu(shard["label"]), "prob": cpu(shard["prob"])[:, :k], "chrom": chrom}))
+        finish_check(pending_check)
+    except BaseException:
+        # the verdict of a shard's focal-base check is read one shard late, i.e. after that shard's rows went to the sink: a failing
+        # run must not leave a partial table with a valid-looking header behind (the reference exits before writing anything)
+        if feeds_sink and hasattr(sink, "abort"):
+            sink.abort()
+        raise
+    if sink is not None and (rank == 0 or getattr(sink, "parts", False)) and hasattr(sink, "close"):
         t0 = clock()
         sink.close()
         T["sink_close"] = clock() - t0

@@ -217,8 +217,9 @@ def run_ref_snv(ref, model_no, cfg, common, sd, codes, cat, train=False):
 
 def g3_pretrained(ref):
     rng = np.random.default_rng(303)
-    for tag, path, r, R, B in [("human_AT", "models/Homo_sapiens/SNV/AT", 7, 1000, 48),
-                               ("example_ckpt6", "examples/snv/models/checkpoint_6", 7, 200, 48)]:
+    # 256 windows per shipped checkpoint; windows are stored as base codes, so the files stay small
+    for tag, path, r, R, B in [("human_AT", "models/Homo_sapiens/SNV/AT", 7, 1000, 256),
+                               ("example_ckpt6", "examples/snv/models/checkpoint_6", 7, 200, 256)]:
         sd = torch.load(os.path.join(REF, path, "model"), map_location="cpu")
         cfg, common = snv_cfg(r, R)
         codes, cat = snv_inputs(rng, B, r, R)
@@ -229,8 +230,8 @@ def g3_pretrained(ref):
     # the other two shipped human SNV models (models/Homo_sapiens/SNV/README:3-16; BASELINE config 5 runs all three); their own
     # generator keeps the two fixtures above byte-stable
     rng = np.random.default_rng(3031)
-    for tag, path, r, R, B in [("human_CpG", "models/Homo_sapiens/SNV/CpG", 7, 1000, 32),
-                               ("human_nonCpG", "models/Homo_sapiens/SNV/nonCpG", 7, 1000, 32)]:
+    for tag, path, r, R, B in [("human_CpG", "models/Homo_sapiens/SNV/CpG", 7, 1000, 256),
+                               ("human_nonCpG", "models/Homo_sapiens/SNV/nonCpG", 7, 1000, 256)]:
         sd = torch.load(os.path.join(REF, path, "model"), map_location="cpu")
         cfg, common = snv_cfg(r, R)
         codes, cat = snv_inputs(rng, B, r, R)
@@ -243,7 +244,7 @@ def g3_pretrained(ref):
 def g45_synth(ref):
     rng = np.random.default_rng(404)
     # (tag, model_no, r, R, n_class, B, seed)
-    cases = [("S_net2", 2, 10, 1000, 4, 40, 11), ("T_net2", 2, 5, 100, 4, 40, 12), ("P_net2", 2, 7, 1000, 4, 24, 13),
+    cases = [("S_net2", 2, 10, 1000, 4, 64, 11), ("T_net2", 2, 5, 100, 4, 40, 12), ("P_net2", 2, 7, 1000, 4, 24, 13),
              ("S_net1", 1, 10, 1000, 4, 24, 14), ("S_net0", 0, 10, 1000, 4, 40, 15), ("R300_net2_c3", 2, 4, 300, 3, 24, 16),
              ("R128_net2", 2, 7, 128, 4, 24, 17)]
     for tag, model_no, r, R, n_class, B, seed in cases:
@@ -280,7 +281,7 @@ def g6_taps(ref):
          hp=np.array([r, 3, R, 150, 75, 32, 3, 4, 2], np.int64), **{"tap::" + k: v for k, v in taps.items()})
 
 
-def pool_margins(model, margins):
+def pool_margins(model, margins, relu_margins=None):
     """Forward hooks recording the smallest top-2 gap (relative to max(|top1|, 1)) over every max-pool window and global max.
 
     The gradient of a max is discontinuous at a tie: where two window entries sit closer than float32 round-off accumulated through
@@ -308,43 +309,93 @@ def pool_margins(model, margins):
         if gap.numel():
             margins.append(float(gap.min()))
 
+    def relu_hook(m, inp, out):
+        # a ReLU input within float32 round-off of zero is the same coin toss for the mask of its gradient: smallest |input| relative
+        # to the tensor's rms
+        x = inp[0].detach()
+        if relu_margins is not None and x.dim() == 3:
+            relu_margins.append(float(x.abs().min() / x.pow(2).mean().sqrt().clamp(min=1e-6)))
+
     hooks = [m.register_forward_hook(lambda m, i, o, f=n.startswith("maxpool1"): pool_hook(m, i, o, f))
              for n, m in model.named_modules() if isinstance(m, nn.MaxPool1d)]
+    hooks += [m.register_forward_hook(relu_hook) for m in model.modules() if isinstance(m, nn.ReLU)]
     hooks += [getattr(model, n).register_forward_hook(gmax_hook) for n in ("conv3", "conv3_2")]
     return hooks
 
 
-G7_MIN_MARGIN = 8e-6     # 4 x the largest relative difference seen between float32 implementations at the deepest pool (2e-6)
+
+
+G7_MAX_F64_DISTANCE = 5e-5     # a quarter of the 2e-4 bar of the tests
+G7_MIN_POOL_MARGIN = 8e-6      # 4 x the largest relative difference seen between float32 implementations at the deepest pool (2e-6)
+G7_MIN_RELU_MARGIN = 3e-6      # of the tensor's rms: ~5 x the round-off of a 96-term float32 dot product
 
 
 def g7_train(ref):
+    """One training step of the reference's Network2 (dropouts 0): loss, every gradient, running statistics.
+
+    Which weight seed: the gradient of a max-pool / global max is discontinuous at a tie and the gradient of a ReLU at zero; where a
+    window's two best entries, or a ReLU input and zero, sit closer than the float32 round-off accumulated in front of them, the
+    reference's own float32 backward takes one side by the accident of its summation order and a correct implementation with another
+    order the other -- one such flip moves a gradient by 1e-3 .. 1e-2 of its size.  A seed is accepted when every max-pool window
+    and every ReLU input of the forward stays clear of its threshold (G7_MIN_POOL_MARGIN, G7_MIN_RELU_MARGIN: several times the
+    round-off by which two float32 implementations differ there; a forward-only screen over the seed range) AND the reference's
+    float32 gradients sit within G7_MAX_F64_DISTANCE of a float64 evaluation of the same module on the same inputs; both margins and
+    the distance are recorded with the fixture.  T (5 / 100) and S (10 / 1000) at B = 32.  S256: the S
+    configuration at B = 256 -- with 8 x the decisions no seed of the range is flip-free; the seed closest to its float64 evaluation
+    is kept and its distance recorded: its test bounds the gradients between the flip-free fixture (2e-4) and the float64-judged
+    batch of 4096."""
+    import copy
     rng = np.random.default_rng(707)
-    # weight seed of S: 32 has a pool3_2 window whose two best entries differ by 6e-7 relative (a float32 coin toss, see pool_margins);
-    # 33.. are tried in order and the first one clear of G7_MIN_MARGIN is kept
-    for tag, r, R, B, seeds in [("T", 5, 100, 32, (31,)), ("S", 10, 1000, 12, tuple(range(33, 64)))]:
+    for tag, r, R, B, seeds in [("T", 5, 100, 32, tuple(range(31, 1031))), ("S", 10, 1000, 32, tuple(range(33, 1033))),
+                                ("S256", 10, 1000, 256, tuple(range(33, 41)))]:
         cfg, common = snv_cfg(r, R, drops=(0.0, 0.0, 0.0))
         codes, cat = snv_inputs(rng, B, r, R, with_amb=False)
         y = rng.choice(4, size=B, p=[0.85, 0.05, 0.05, 0.05]).astype(np.int64)
         x = codes_to_onehot(codes)
         crit = nn.CrossEntropyLoss(reduction="sum")
-        for seed in seeds:
+
+        def step(seed, screen=False):
             model = quiet(ref.nn_utils.model_choice, 2, cfg, common, "snv")
             sd = synth.synth_state_dict(model.state_dict(), seed)
             model.load_state_dict(sd)
             model.train()
-            margins = []
-            hooks = pool_margins(model, margins)
-            preds = quiet(model.forward, (torch.zeros(B, 1, dtype=torch.float64), torch.from_numpy(cat)), x)
+            m64 = None if screen else copy.deepcopy(model).double()
+            margins, relus = [], []
+            hooks = pool_margins(model, margins, relus)
+            with torch.set_grad_enabled(not screen):
+                preds = quiet(model.forward, (torch.zeros(B, 1, dtype=torch.float64), torch.from_numpy(cat)), x)
             for h in hooks:
                 h.remove()
-            print(f"  G7 {tag}: weight seed {seed}, smallest max-pool margin {min(margins):.2e}")
-            if min(margins) >= G7_MIN_MARGIN:
-                break
+            if screen:
+                return min(margins), min(relus)
+            loss = crit(preds, torch.from_numpy(y))
+            model.zero_grad()
+            loss.backward()
+            crit(quiet(m64.forward, (torch.zeros(B, 1, dtype=torch.float64), torch.from_numpy(cat)), x.double()), torch.from_numpy(y)).backward()
+            g64 = dict(m64.named_parameters())
+            dist = 0.0
+            for k, p in model.named_parameters():
+                if ".layer." in k or p.grad is None or p.numel() == 0:
+                    continue
+                t = g64[k].grad.numpy()
+                dist = max(dist, float(np.abs(p.grad.numpy() - t).max()) / (float(np.abs(t).max()) + 1e-2))
+            print(f"  G7 {tag}: weight seed {seed}, float32 gradients {dist:.2e} from float64, smallest max-pool margin {min(margins):.2e}, "
+                  f"smallest ReLU margin {min(relus):.2e}")
+            return model, preds, loss, (margins, relus), dist
+
+        if tag == "S256":
+            seed = min(seeds, key=lambda sd_: step(sd_)[4])
+            model, preds, loss, margins, dist = step(seed)
         else:
-            raise SystemExit("g7: no weight seed clear of max-pool near-ties")
-        loss = crit(preds, torch.from_numpy(y))
-        model.zero_grad()
-        loss.backward()
+            for seed in seeds:
+                pm, rm = step(seed, screen=True)
+                if pm < G7_MIN_POOL_MARGIN or rm < G7_MIN_RELU_MARGIN:
+                    continue
+                model, preds, loss, margins, dist = step(seed)
+                if dist <= G7_MAX_F64_DISTANCE:
+                    break
+            else:
+                raise SystemExit("g7: no weight seed clear of near-ties whose float32 gradients agree with float64")
         gnorm = torch.nn.utils.clip_grad_norm_(model.parameters(), 1e9)
         arrays = {}
         for k, p in model.named_parameters():
@@ -356,7 +407,7 @@ def g7_train(ref):
                 continue
             arrays["b::" + k] = b.numpy()
         save(f"snv_train_{tag}.npz", codes=codes, cat=cat, y=y, seed=np.array(seed), loss=np.array(loss.item()),
-             pool_margin=np.array(min(margins)),
+             pool_margin=np.array(min(margins[0])), relu_margin=np.array(min(margins[1])), f64_distance=np.array(dist),
              preds=preds.detach().numpy(), gnorm=np.array(float(gnorm)),
              hp=np.array([r, 3, R, 150, 75, 32, 3, 4, 2], np.int64), **arrays)
 

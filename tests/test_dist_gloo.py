@@ -169,3 +169,62 @@ def test_predict_bed_sharded_focal_check_and_empty(tmp_path):
     res = predict_bed_sharded(_fake_shard_forward([]), empty, sink=sink)
     assert len(res["start"]) == 0
     assert open(tmp_path / "e.tsv").read().startswith("chrom\tstart\tend\tstrand\tmut_type")
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# part-file sink: every rank sorts the gathered shard, formats ITS slice of the sorted rows and writes its own part file; rank 0
+# only strings the slices together (TsvSink(parts=True)) -- the N-rank file-to-file path without a rank-0 text funnel
+# ------------------------------------------------------------------------------------------------------------------
+def _parts_worker(rank, world, port, bed, out_path, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mural_amd.predict import TsvSink, predict_bed_sharded
+        sink = TsvSink(out_path, parts=True)
+        ok = sink.parts and sink.world == world and sink.rank == rank
+        n = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000, sink=sink, collect=False)
+        # every rank formatted about 1 / world of the rows, nobody all of them
+        ok = ok and sink.rows == n and not os.path.exists(out_path + ".part%04d" % rank)
+        q.put((rank, bool(ok), n))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("unsorted", [False, True])
+def test_part_file_sink_equals_single_writer_table(tmp_path, world, unsorted):
+    from mural_amd.data.ingest import write_predictions
+    from mural_amd.predict import predict_bed_sharded
+    bed = str(tmp_path / "s.bed")
+    rows = _write_bed(bed, unsorted=unsorted)
+    out_path = str(tmp_path / "pred.tsv")
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_parts_worker, args=(r, world, port, bed, out_path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok, _ in res), res
+    assert all(n == len(rows) for _, _, n in res)
+    solo = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000)
+    want_path = str(tmp_path / "want.tsv")
+    write_predictions(solo, want_path)
+    assert open(out_path, "rb").read() == open(want_path, "rb").read()
+    assert sorted(os.listdir(tmp_path)) == ["pred.tsv", "s.bed", "want.tsv"]      # the part files are gone
+
+
+def test_failed_run_leaves_no_table_behind(tmp_path):
+    """The focal-base verdict of a shard arrives after its rows went to the sink: the failing run removes the partial table (the
+    reference exits before it writes anything, preprocessing.py:482-484)."""
+    from mural_amd.predict import TsvSink, predict_bed_sharded
+    bed = str(tmp_path / "s.bed")
+    rows = _write_bed(bed)
+    out_path = str(tmp_path / "pred.tsv")
+    sink = TsvSink(out_path)
+    with pytest.raises(ValueError, match="different bases"):
+        predict_bed_sharded(_fake_shard_forward([], mixed_at=rows[200][1]), bed, segment_center=3000, sink=sink)
+    assert not os.path.exists(out_path)
