@@ -44,7 +44,12 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
   constexpr int TLB = WIDE ? 256 : 64;
   const int l0 = blockIdx.x * TLB;
   const int TW = ((RT > 1 ? a.Lout : TLB) - 1) * a.stride + a.K;   // input span of one row of the tile
-  const int TWp = TW | 1;                      // odd row stride: channel rows start on different banks
+  // Row pitch.  Stride 4 with seven taps (the 8 -> 16 encoder conv of the U-Net): a lane's taps are the 7 floats from 4 * position
+  // on -- two aligned 16-byte reads on a pitch of a multiple of 4 (lanes 16 bytes apart: conflict-free), where seven 4-byte reads at a
+  // lane stride of 4 floats hit 8 of the 32 banks (r04 PMC: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.64 for this launch).
+  // Otherwise an odd pitch: channel rows start on different banks.
+  const bool vec4 = KT == 7 && a.stride == 4 && RT == 1;
+  const int TWp = vec4 ? ((TW + 4) & ~3) : (TW | 1);
   const int in0 = l0 * a.stride - a.pad;       // first (virtual, upsampled) input index of the tile
   const int Lv = a.Lin * a.up;
   for (int rc = wave; rc < RT * a.Cin; rc += 4) {
@@ -99,8 +104,19 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
       const float* trow = tile + trow0 + ci * TWp + lloc * a.stride;
       if (KT) {
         float x[KT ? KT : 1];
+        bool done = false;
+        if constexpr (KT == 7) {
+          if (vec4) {
+            const f32x4 u = *reinterpret_cast<const f32x4*>(trow), v = *reinterpret_cast<const f32x4*>(trow + 4);
+            x[0] = u.x; x[1] = u.y; x[2] = u.z; x[3] = u.w;
+            x[4] = v.x; x[5] = v.y; x[6] = v.z;
+            done = true;
+          }
+        }
+        if (!done) {
 #pragma unroll
-        for (int k = 0; k < KT; ++k) x[k] = trow[k];      // all taps' LDS reads and scalar weight loads in flight together
+          for (int k = 0; k < KT; ++k) x[k] = trow[k];      // all taps' LDS reads and scalar weight loads in flight together
+        }
 #pragma unroll
         for (int k = 0; k < KT; ++k) {
           const float* __restrict__ wk = w + (size_t)(ci * KT + k) * a.Cout;   // wave-uniform address: scalar loads
@@ -168,7 +184,10 @@ int launch_conv1d_valu(const Conv1dArgs& a_in, hipStream_t stream) {
   // output channels per accumulator group: 16 halves the LDS reads per FMA (used when a wave still gets a group)
   const int cog = (a.Cout % 16 == 0) ? 16 : (a.Cout % 8 == 0 ? 8 : 4);
   const int ngroups = a.Cout / cog;
-  const size_t lds_wide = (size_t)a.Cin * ((255 * a.stride + a.K) | 1) * sizeof(float);
+  auto pitch = [&](size_t span, bool one_row) -> size_t {      // the kernel's row pitch (see there)
+    return (a.K == 7 && a.stride == 4 && one_row) ? ((span + 4) & ~(size_t)3) : (span | 1);
+  };
+  const size_t lds_wide = (size_t)a.Cin * pitch((size_t)255 * a.stride + a.K, true) * sizeof(float);
   const bool wide = ngroups < 4 && lds_wide <= 64 * 1024 && a.Lout > 64;
   a.rt = 1;
   if (!wide && a.Lout <= 32) {                       // short rows: pack batch rows into the 64 lanes of a tile
@@ -176,7 +195,7 @@ int launch_conv1d_valu(const Conv1dArgs& a_in, hipStream_t stream) {
     while (a.rt > 1 && (size_t)a.rt * a.Cin * ((((size_t)a.Lout - 1) * a.stride + a.K) | 1) * sizeof(float) > 60 * 1024) --a.rt;
   }
   const int span = (a.rt > 1 ? a.Lout - 1 : (wide ? 255 : 63)) * a.stride + a.K;
-  const size_t lds = (size_t)a.rt * a.Cin * (span | 1) * sizeof(float);
+  const size_t lds = (size_t)a.rt * a.Cin * pitch((size_t)span, a.rt == 1) * sizeof(float);
   MURAL_REQUIRE(lds <= 160 * 1024, "conv1d: input tile of %zu bytes exceeds LDS", lds);
   const int tlb = wide ? 256 : 64;
   const dim3 grid(a.rt > 1 ? 1 : (a.Lout + tlb - 1) / tlb, (a.B + a.rt - 1) / a.rt);

@@ -31,6 +31,22 @@ struct ConvFwdJob {       // y = conv32(BN(act(x))) + bias [+ res1 + res2]; Batc
   float* y;
 };
 
+// dy of a conv backward made while it is staged (conv32_wave.hip, FOLD): the BatchNorm-backward apply of the layer BEHIND the conv --
+// whose input gradient `dz` and saved input `x` sit in memory, its sums `acc` complete -- plus an optional residual gradient;
+// dgamma / dbeta of that BatchNorm are written by the launch; dy_out != nullptr: dy is also written out.  dz == nullptr: no fold.
+struct ConvBwdFold {
+  const float* dz = nullptr;
+  const float* x = nullptr;
+  const float* state = nullptr;
+  const float* gamma = nullptr;
+  const double* acc = nullptr;
+  int relu = 0;
+  float* dgamma = nullptr;
+  float* dbeta = nullptr;
+  const float* add1 = nullptr;
+  float* dy_out = nullptr;
+};
+
 struct ConvBwdJob {       // dz, BatchNorm-backward sums, partial rows of dW / db
   const float* dy;
   const float* x;
@@ -45,6 +61,7 @@ struct ConvBwdJob {       // dz, BatchNorm-backward sums, partial rows of dW / d
   double* stat_out;
   float* part;
   int nrow;               // out: partial rows written
+  ConvBwdFold fold;
 };
 
 struct BnApplyJob {       // dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) [+ add1 + add2]; dgamma / dbeta

@@ -419,14 +419,29 @@ struct CwBwdArgs {
   float* part;            // [grid][32*32*3 + 32]
   float* dz;
   double* stat_out;       // sum(dz), sum(dz * xhat)
+  // FOLD: dy is not read but made while it is staged -- the BatchNorm-backward apply of the layer BEHIND this one (whose input
+  // gradient fdz and saved input fx sit in memory, its sums facc complete): dy = a'(fx) * gamma * invstd * (fdz - mean(fdz) - xhat *
+  // mean(fdz * xhat)) [+ add1]; workgroup 0 writes that BatchNorm's dgamma / dbeta; dy_out != nullptr: dy is also written out
+  const float* fdz;
+  const float* fx;
+  const float* fstate;    // that BatchNorm's state: scale | beta | mean | invstd
+  const float* fgamma;
+  const double* facc;
+  double fn;
+  int frelu;
+  float* fdgamma;
+  float* fdbeta;
+  const float* add1;
+  float* dy_out;
   int64_t B;
   int64_t n_units;
   int grid;
   int dbg;                // timing experiments (MURAL_DEBUG_CW): 16 no loads, 32 no weight gradient, 64 no input gradient, 128 no stores
 };
 struct CwBwdArgs2 { CwBwdArgs j[TOWER_JOBS]; };
+constexpr int CW_AUX_FOLD = 288;            // float[5][32]: gamma * invstd | mean(dz) | mean(dz * xhat) | mean | invstd of the folded BatchNorm
 
-template <int NB>
+template <int NB, bool FOLD>
 __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const CwBwdArgs& a = aa.j[blockIdx.y];
@@ -455,13 +470,28 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
     return (u < units.hi && !(a.dbg & 16)) ? (uint32_t)(rows < g.P ? rows : g.P) * row_bytes : 0u;
   };
   int64_t unit = units.lo + wave;
-  f32x4 gin[NLD];                                               // the first unit's dy rows travel under the prologue
-  {
+  f32x4 gin[FOLD ? 1 : NLD];                                    // the first unit's dy rows travel under the prologue
+  if constexpr (!FOLD) {
     const __amdgpu_buffer_rsrc_t gd = cw_rsrc(a.dy + (size_t)(unit < units.hi ? unit : 0) * unit_stride, unit_bytes(unit));
 #pragma unroll
     for (int u = 0; u < NLD; ++u) gin[u] = buf_ld4(gd, lane16 + 1024u * u);
   }
   bool first = true;
+  if constexpr (FOLD) {      // constants of the folded BatchNorm-backward from its sums (32 slots), its dgamma / dbeta
+    float* fc = aux + CW_AUX_FOLD;
+    if (tid < 2 * CL_C) {
+      const int c = tid & 31, which = tid >> 5;
+      double sacc = 0.0;
+      for (int k = 0; k < MURAL_BN_SLOTS; ++k) sacc += a.facc[((size_t)k * 2 + which) * CL_C + c];
+      fc[(1 + which) * CL_C + c] = (float)(sacc / a.fn);
+      if (blockIdx.x == 0) (which ? a.fdgamma : a.fdbeta)[c] = (float)sacc;
+    } else if (tid < 3 * CL_C) {
+      const int c = tid & 31;
+      fc[c] = a.fgamma[c] * a.fstate[3 * CL_C + c];
+      fc[3 * CL_C + c] = a.fstate[2 * CL_C + c];
+      fc[4 * CL_C + c] = a.fstate[3 * CL_C + c];
+    }
+  }
   uint32_t* tab = reinterpret_cast<uint32_t*>(aux + CW_AUX_TAB);      // memory offset of the row of column 4 s + kk, s < NKS
   if (tid < 4 * NKS) tab[tid] = cw_col_offset(g, (uint32_t)tid);
   float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
@@ -515,10 +545,49 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
   while (unit < units.hi) {
     const uint32_t ub = unit_bytes(unit);
     const size_t ubase = (size_t)unit * unit_stride;
-    const __amdgpu_buffer_rsrc_t gd = cw_rsrc(a.dy + ubase, ub), xd = cw_rsrc(a.x + ubase, ub);
+    const __amdgpu_buffer_rsrc_t gd = cw_rsrc((FOLD ? a.x : a.dy) + ubase, ub), xd = cw_rsrc(a.x + ubase, ub);
     const __amdgpu_buffer_rsrc_t zd = cw_rsrc(a.dz + ubase, (a.dbg & 128) ? 0u : ub);
     // ---- this unit's dy rows: memory -> image; the bias gradient rides along
-    {
+    if constexpr (FOLD) {
+      // dy = BatchNorm-backward apply of the layer behind, six staging slots a round (18 loads in flight)
+      const float* fc = aux + CW_AUX_FOLD;
+      const f32x4 k0 = ld4(fc + 4 * chunk), m1 = ld4(fc + CL_C + 4 * chunk), m2 = ld4(fc + 2 * CL_C + 4 * chunk),
+                  mu = ld4(fc + 3 * CL_C + 4 * chunk), is = ld4(fc + 4 * CL_C + 4 * chunk);
+      const __amdgpu_buffer_rsrc_t zd2 = cw_rsrc(a.fdz + ubase, ub), xd2 = cw_rsrc(a.fx + ubase, ub);
+      const __amdgpu_buffer_rsrc_t ad = cw_rsrc((a.add1 ? a.add1 : a.fdz) + ubase, a.add1 ? ub : 0u);
+      const __amdgpu_buffer_rsrc_t od = cw_rsrc((a.dy_out ? a.dy_out : a.dz) + ubase, a.dy_out ? ub : 0u);
+      constexpr int RS = 6;
+#pragma unroll
+      for (int u0 = 0; u0 < NLD; u0 += RS) {
+        f32x4 dzn[RS], xn[RS], ad1[RS];
+#pragma unroll
+        for (int q = 0; q < RS; ++q)
+          if (u0 + q < NLD) {
+            const uint32_t go = lane16 + 1024u * (u0 + q);
+            dzn[q] = buf_ld4(zd2, go);
+            xn[q] = buf_ld4(xd2, go);
+            ad1[q] = buf_ld4(ad, go);
+          }
+#pragma unroll
+        for (int q = 0; q < RS; ++q)
+          if (u0 + q < NLD) {
+            const uint32_t go = lane16 + 1024u * (u0 + q);
+            f32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float raw = xn[q][e];
+              const float v = a.frelu ? fmaxf(raw, 0.f) : raw;
+              const float xh = (v - mu[e]) * is[e];
+              float gq = k0[e] * (dzn[q][e] - m1[e] - xh * m2[e]);
+              if (a.frelu && raw <= 0.f) gq = 0.f;
+              o[e] = go < ub ? gq + ad1[q][e] : 0.f;      // (pieces of rows that do not exist read as zero, their dy must be zero)
+            }
+            bsum += o;
+            lds_st4(wb, sotab[64 * (u0 + q)], o);
+            buf_st4(od, go, o);
+          }
+      }
+    } else {
       if (!first) {
 #pragma unroll
         for (int u = 0; u < NLD; ++u) gin[u] = buf_ld4(gd, lane16 + 1024u * u);
@@ -677,8 +746,9 @@ template <int NBV>
 int cw_launch_bwd(const CwBwdArgs2& a, int gx, int gy, hipStream_t stream) {
   constexpr int NB = NBV < 4 ? 4 : NBV;      // (the waves' regions also hold two partial rows / W)
   static DynLdsOnce big_lds;
-  if (int rc = big_lds.ensure(&conv32w_bwd_kernel<NB>)) return rc;
-  hipLaunchKernelGGL(conv32w_bwd_kernel<NB>, dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
+  if (int rc = big_lds.ensure(&conv32w_bwd_kernel<NB, false>, &conv32w_bwd_kernel<NB, true>)) return rc;
+  if (a.j[0].fdz) hipLaunchKernelGGL((conv32w_bwd_kernel<NB, true>), dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
+  else hipLaunchKernelGGL((conv32w_bwd_kernel<NB, false>), dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
@@ -745,6 +815,12 @@ int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream) {
     MURAL_REQUIRE(cw_geom(j.B, j.L, &a.g), "conv32_bwd (wave-private): L = %d does not fit a wave's image", j.L);
     a.dy = j.dy; a.x = j.x; a.W = j.W; a.wfrag = j.wfrag; a.state = j.state; a.gamma = j.gamma; a.pre_relu = j.pre_relu; a.part = j.part; a.dz = j.dz;
     a.stat_out = j.stat_out;
+    MURAL_REQUIRE((j.fold.dz != nullptr) == (jobs[0].fold.dz != nullptr), "conv32_bwd (wave-private): the jobs of a launch fold or do not fold alike");
+    MURAL_REQUIRE(j.fold.dz || j.dy, "conv32_bwd (wave-private): dy is NULL");
+    if (j.fold.dz) {
+      a.fdz = j.fold.dz; a.fx = j.fold.x; a.fstate = j.fold.state; a.fgamma = j.fold.gamma; a.facc = j.fold.acc; a.fn = (double)j.B * j.L;
+      a.frelu = j.fold.relu; a.fdgamma = j.fold.dgamma; a.fdbeta = j.fold.dbeta; a.add1 = j.fold.add1; a.dy_out = j.fold.dy_out;
+    }
     a.B = j.B;
     a.n_units = (j.B + a.g.P - 1) / a.g.P;
     a.grid = cw_grid(a.n_units);
@@ -780,7 +856,7 @@ int cw_conv32_fwd(const float* x, int64_t B, int L, int pre_relu, const double* 
 
 int cw_conv32_bwd(const float* dy, const float* x, const float* W, const float* wfrag, int64_t B, int L, const float* state, const float* gamma,
                   int pre_relu, float* dz, double* stat_out, float* part, int* nrow, hipStream_t stream) {
-  ConvBwdJob j{dy, x, W, wfrag, B, L, state, gamma, pre_relu, dz, stat_out, part, 0};
+  ConvBwdJob j{dy, x, W, wfrag, B, L, state, gamma, pre_relu, dz, stat_out, part, 0, ConvBwdFold{}};
   const int rc = cw_conv32_bwd_jobs(&j, 1, stream);
   *nrow = j.nrow;
   return rc;

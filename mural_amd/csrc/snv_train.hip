@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <utility>
 
 #include "snv.h"
 #include "conv32_jobs.h"
@@ -41,6 +42,7 @@ int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, con
 int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, double* acc, hipStream_t stream);
 int cl_maxpool_bwd(const float* dy, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream);
 int cl_gmax_fwd_jobs(const GmaxFwdJob* jobs, int n, hipStream_t stream);
+int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream);
 int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t B, int L, float* dx, hipStream_t stream);
 // train_ops.hip / snv_stage1.hip: first layer with channel-last output
 int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
@@ -397,9 +399,45 @@ int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const
 }
 
 // d_out: gradient arriving at the stage output (kept intact); d_in: receives the gradient of the stage input; tmp: 3 buffers
+// conv backward of one layer on the wave kernels with the BatchNorm-backward apply of the layer behind it folded into its staging
+int conv_b_fold(Ctx& c, const float* dy, const float* x, int L, const float* state, const MuralBN& bn, const MuralAffine& cv, double* acc,
+                const MuralAffine& gcv, float* dz, const ConvBwdFold& fold) {
+  const int j = c.njobs++;
+  MURAL_REQUIRE(j < 20, "internal: more conv layers than partial-row regions");
+  ConvBwdJob job{dy, x, cv.weight, wfrag_of(c, cv.weight, 1), c.P->B, L, state, bn.weight, 1, dz, acc, c.P->part[j], 0, fold};
+  if (int rc = cw_conv32_bwd_jobs(&job, 1, (hipStream_t)c.stream)) return rc;
+  c.job_part[j] = c.P->part[j];
+  c.job_nrow[j] = job.nrow;
+  c.job_dW[j] = const_cast<float*>(gcv.weight);
+  c.job_db[j] = const_cast<float*>(gcv.bias);
+  return MURAL_OK;
+}
+
 int stage_b(Ctx& c, const MuralResBlock* rb, const MuralResBlock* grb, const float* x_in, int L, StageBufs& s, const float* d_out,
             float* d_in, float* const* tmp) {
   float *dz = tmp[0], *ga = tmp[1], *gb = tmp[2];
+  if (use_wave_conv(L, 0, false, 0) && !getenv("MURAL_TRAIN_NO_FOLD")) {
+    // Three of the four BatchNorm-backward applies of the stage never run as passes of their own: the conv backward of the layer in
+    // front makes its dy from (dz, saved input, sums) of the layer behind while it stages it (conv32_wave.hip, FOLD) -- a read of two
+    // tensors instead of one there against a pass of two reads and a write here.  Only d x1, which two consumers need, is also
+    // written out (by the launch that makes it); the stage's input gradient keeps its own pass (it adds two residual gradients and
+    // feeds another kind of kernel).
+    float *A = dz, *Bz = ga;
+    auto gbn = [](const MuralBN& g) { return std::pair<float*, float*>(const_cast<float*>(g.weight), const_cast<float*>(g.bias)); };
+    // layer 3: y = conv(BN(relu(h2))) + x1 + x_in; dy = d_out as it is
+    if (int rc = conv_b_fold(c, d_out, s.t[2], L, s.state[3], rb[1].bn2, rb[1].conv2, s.acc_b[3], grb[1].conv2, A, ConvBwdFold{})) return rc;
+    // layer 2: dy = d h2 = apply of layer 3
+    ConvBwdFold f2{A, s.t[2], s.state[3], rb[1].bn2.weight, s.acc_b[3], 1, gbn(grb[1].bn2).first, gbn(grb[1].bn2).second, nullptr, nullptr};
+    if (int rc = conv_b_fold(c, nullptr, s.t[1], L, s.state[2], rb[1].bn1, rb[1].conv1, s.acc_b[2], grb[1].conv1, Bz, f2)) return rc;
+    // layer 1: dy = d x1 (total) = apply of layer 2 + d_out, also needed by the stage's last apply: written out
+    ConvBwdFold f1{Bz, s.t[1], s.state[2], rb[1].bn1.weight, s.acc_b[2], 1, gbn(grb[1].bn1).first, gbn(grb[1].bn1).second, d_out, gb};
+    if (int rc = conv_b_fold(c, nullptr, s.t[0], L, s.state[1], rb[0].bn2, rb[0].conv2, s.acc_b[1], grb[0].conv2, A, f1)) return rc;
+    // layer 0: dy = d h = apply of layer 1
+    ConvBwdFold f0{A, s.t[0], s.state[1], rb[0].bn2.weight, s.acc_b[1], 1, gbn(grb[0].bn2).first, gbn(grb[0].bn2).second, nullptr, nullptr};
+    if (int rc = conv_b_fold(c, nullptr, x_in, L, s.state[0], rb[0].bn1, rb[0].conv1, s.acc_b[0], grb[0].conv1, Bz, f0)) return rc;
+    return cl_bn_bwd_apply(Bz, x_in, (int64_t)c.P->B * L, 1, s.state[0], rb[0].bn1.weight, s.acc_b[0], gb, d_out, d_in,
+                           const_cast<float*>(grb[0].bn1.weight), const_cast<float*>(grb[0].bn1.bias), (hipStream_t)c.stream);
+  }
   // layer 3: y = conv(BN(relu(h2))) + x1 + x_in
   if (int rc = bnconv_b(c, d_out, s.t[2], L, 1, s.state[3], rb[1].bn2, rb[1].conv2, s.acc_b[3], nullptr, nullptr, grb[1].bn2, grb[1].conv2,
                         dz, ga)) return rc;                                       // ga = d h2

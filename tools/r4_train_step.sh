@@ -1,3 +1,5 @@
 cd $GRAFT_REPO_ROOT
-(timeout 1200 python -m pytest tests/test_gpu_train.py -q -k batch_256 2>&1 | grep -E "^E|assert" | head)
-python tools/gpu_debug_g7.py S256 2>&1 | grep -v amdgpu | sort -k6 -g | tail -3
+mkdir -p gpurun_out/r4b
+(timeout 1200 python -m pytest tests/test_gpu_train.py -q -x 2>&1 | tail -3) > gpurun_out/r4b/tests.txt
+(MURAL_TRAIN_NO_FOLD=1 python tools/time_train.py; python tools/time_train.py; python tools/time_train.py) > gpurun_out/r4b/time.txt 2>&1
+cat gpurun_out/r4b/tests.txt; grep -v amdgpu.ids gpurun_out/r4b/time.txt
