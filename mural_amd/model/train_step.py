@@ -4,7 +4,18 @@
 ``torch.autograd.Function`` whose forward and backward are one library call each -- the composition of the ~100 kernels per
 direction lives in C++ (csrc/snv_train.hip), so the host costs two ctypes transitions per step instead of one per layer.
 Serves the shipped shape (32 channels, kernel 3); other shapes train on the per-layer ops of ``train_ops.py`` / ``indel_train.py``.
+
+Gradients: the C backward writes every parameter gradient into ONE flat buffer.  By default the node then sets ``p.grad`` itself
+-- views of a buffer that lives with the model, created once -- and hands autograd nothing: routing ~150 tensors through the engine
+(one AccumulateGrad node and two view constructions per parameter) cost 1.0 ms of host time per step, as much as the whole device
+backward at batch 4096.  ``p.grad`` after ``loss.backward()`` is what the reference loop (training.py:424-436: zero_grad, backward,
+clip_grad_norm_, step) reads; an existing ``p.grad`` is accumulated into, like autograd does.  What this skips is autograd's own
+bookkeeping per parameter: tensor hooks on parameters, ``torch.autograd.grad(loss, params)`` and DistributedDataParallel's reducer
+do not see these gradients -- ``MURAL_TRAIN_AUTOGRAD_PARAMS=1`` (or ``model._autograd_params = True``) routes them through the
+engine again.
 """
+import os
+
 import ctypes as C
 
 import numpy as np
@@ -40,6 +51,8 @@ class _Layout:
         self.params_all = list(model.parameters())     # cached: walking the module tree costs ~0.2 ms per step
         self.plist = [p for p in self.params_all if p.numel()]
         self.last_flat = None                          # the flat buffer behind the .grad views of the latest backward (clip_grad_norm_)
+        self.own_flat = None                           # direct-gradient mode: the buffer and the views into it, created once
+        self.own_views = None
         index = {id(p): i for i, p in enumerate(self.plist)}
         # gradient slots: offset of each parameter in one flat float32 buffer (running statistics have none)
         offs, o = [], 0
@@ -105,9 +118,10 @@ class ModelStep(torch.autograd.Function):
     """out = model(cat_x, distal_x) in training mode; backward returns the gradient of every parameter."""
 
     @staticmethod
-    def forward(ctx, model, shape, cat_x, symbols, drops, seeds, seed_dev, *params):
+    def forward(ctx, model, shape, cat_x, symbols, drops, seeds, seed_dev, direct, *params):
         lay = _layout(model)
         dev = params[0].device
+        ctx.direct = direct
         B = (cat_x if cat_x is not None else symbols).shape[0]
         lib = _lib.lib()
         need = int(lib.mural_snv_train_workspace_bytes(C.byref(shape), B))
@@ -132,8 +146,15 @@ class ModelStep(torch.autograd.Function):
         cat_x, drops, seeds, seed_dev, B = ctx.args
         lay = _layout(model)
         dev = ws.device
-        flat = torch.zeros(lay.total, dtype=torch.float32, device=dev)    # zero padding between the slots: the norm of the buffer
-        lay.last_flat = flat                                               # is the norm of the gradients
+        direct = ctx.direct and all(p.grad is None for p in lay.plist)     # (an existing .grad is accumulated into: a fresh buffer then)
+        if direct:
+            if lay.own_flat is None or lay.own_flat.device != dev:
+                lay.own_flat = torch.zeros(lay.total, dtype=torch.float32, device=dev)
+                lay.own_views = [lay.own_flat[o:o + p.numel()].view(p.shape) for p, o in zip(lay.plist, lay.poffs)]
+            flat = lay.own_flat      # every slot is rewritten by the call below; the padding between the slots stays zero
+        else:
+            flat = torch.zeros(lay.total, dtype=torch.float32, device=dev)    # zero padding between the slots: the norm of the buffer
+        lay.last_flat = flat                                                   # is the norm of the gradients
         ps, gs = lay.params_struct(), lay.grads_struct(flat.data_ptr())
         dout = dout.contiguous()
         _lib.check(_lib.lib().mural_snv_train_backward(C.byref(shape), C.byref(ps), C.byref(gs), None if cat_x is None else cat_x.data_ptr(),
@@ -141,8 +162,20 @@ class ModelStep(torch.autograd.Function):
                                                        None if seed_dev is None else seed_dev.data_ptr(), ws.data_ptr(), ws.numel(),
                                                        _lib.current_stream_ptr(dev)))
         ctx.ws = None
+        if ctx.direct:
+            if direct:
+                for p, v in zip(lay.plist, lay.own_views):
+                    p.grad = v
+            else:
+                for p, o in zip(lay.plist, lay.poffs):
+                    g = flat[o:o + p.numel()].view(p.shape)
+                    if p.grad is None:
+                        p.grad = g
+                    else:
+                        p.grad.add_(g)
+            return (None,) * (8 + len(ctx.params))
         grads = {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(lay.plist, lay.poffs)}
-        return (None,) * 7 + tuple(grads[id(p)] if p.numel() else torch.zeros_like(p) for p in ctx.params)
+        return (None,) * 8 + tuple(grads[id(p)] if p.numel() else torch.zeros_like(p) for p in ctx.params)
 
 
 def run(model, cat_x, distal_x):
@@ -160,8 +193,15 @@ def run(model, cat_x, distal_x):
         if p > 0.0:
             seeds[i] = int(torch.randint(0, 2 ** 62, (1,)).item())
     params = _layout(model).params_all
+    # direct-gradient mode (module docstring): one parameter anchors the node in the autograd graph, the node sets every .grad itself
+    direct = (not getattr(model, "_autograd_params", False) and not os.environ.get("MURAL_TRAIN_AUTOGRAD_PARAMS")
+              and all(p.requires_grad for p in params))
     try:
-        out = ModelStep.apply(model, shape, cat_x, symbols, drops, seeds, T._device_seed, *params)
+        if direct:
+            anchor = next(p for p in params if p.numel())
+            out = ModelStep.apply(model, shape, cat_x, symbols, drops, seeds, T._device_seed, True, anchor)
+        else:
+            out = ModelStep.apply(model, shape, cat_x, symbols, drops, seeds, T._device_seed, False, *params)
         T.flush_input_checks()
     except BaseException:
         T._pending_checks.clear()                       # a failed forward must not leave its input check to the next one

@@ -58,9 +58,11 @@ class GraphedTrainStep:
         self.seed += 0x9E3779B97F4A7C15 & 0x7FFFFFFFFFFFFFFF       # new dropout masks every step (odd 63-bit increment)
         out = self._forward()
         self.loss = self.crit(out, self.y)
-        self.opt.zero_grad(set_to_none=False)
+        # gradients of the one-call HIP step are views of a buffer that lives with the model (model/train_step.py: direct-gradient
+        # mode): dropped here, set again by the backward -- same addresses every step, nothing to zero or to accumulate into
+        self.opt.zero_grad(set_to_none=True)
         self.loss.backward()
-        torch.nn.utils.clip_grad_norm_(self.model.parameters(), self.max_norm)
+        clip_grad_norm_(self.model, self.max_norm)
         self.opt.step()
 
     def _forward(self):
