@@ -250,6 +250,50 @@ __device__ __forceinline__ void cw_units_init(CwUnits& w, int64_t n_units, int g
   w.hi = w.lo + per < n_units ? w.lo + per : n_units;
 }
 
+// 32 slots x 2 sums of one channel set, summed by ONE wave without LDS: lane = (which sum, channel) loads its 32 slots (independent
+// loads, one round trip), lane c then takes the second sum from lane c + 32
+__device__ __forceinline__ void cw_wave_slot_sums(const double* __restrict__ acc, int lane, double* s1, double* s2) {
+  const int c = lane & 31, which = lane >> 5;
+  double v[MURAL_BN_SLOTS];
+#pragma unroll
+  for (int k = 0; k < MURAL_BN_SLOTS; ++k) v[k] = acc[((size_t)k * 2 + which) * CL_C + c];
+  double t[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < MURAL_BN_SLOTS; ++k) t[k & 3] += v[k];
+  const double s = (t[0] + t[1]) + (t[2] + t[3]);
+  const double o = __shfl(s, lane ^ 32);
+  *s1 = which ? o : s;
+  *s2 = which ? s : o;
+}
+
+// the BatchNorm finalisation of conv32_cl.h (cl_finalize) by the first wave of a workgroup alone -- no scratch, no barrier of its
+// own: the caller's one prologue barrier publishes aux (scale | beta | mean)
+__device__ __forceinline__ void cw_finalize_wave0(const ClFin& f, float* aux, int lane) {
+  double s1, s2;
+  cw_wave_slot_sums(f.acc, lane, &s1, &s2);
+  if (lane < CL_C) {
+    const double mean = s1 / f.n;
+    double var = s2 / f.n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const double invstd = 1.0 / sqrt(var + (double)f.eps);
+    const float sc = (float)(f.gamma[lane] * invstd);
+    aux[lane] = sc;
+    aux[CL_C + lane] = f.beta[lane];
+    aux[2 * CL_C + lane] = (float)mean;
+    if (blockIdx.x == 0) {
+      f.state[lane] = sc;
+      f.state[CL_C + lane] = f.beta[lane];
+      f.state[2 * CL_C + lane] = (float)mean;
+      f.state[3 * CL_C + lane] = (float)invstd;
+      if (f.running_mean) {
+        const double unbiased = f.n > 1.0 ? var * f.n / (f.n - 1.0) : var;
+        f.running_mean[lane] = (float)((1.0 - f.momentum) * f.running_mean[lane] + f.momentum * mean);
+        f.running_var[lane] = (float)((1.0 - f.momentum) * f.running_var[lane] + f.momentum * unbiased);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------------------------------ forward
 struct CwFwdArgs {
   CwGeom g;
@@ -295,21 +339,26 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
     return u < units.hi ? (uint32_t)(rows < g.P ? rows : g.P) * row_bytes : 0u;
   };
   int64_t unit = units.lo + wave;
+  // prologue with ONE barrier: fragment loads in flight; the first wave finalises the BatchNorm (32 slots per sum, one round trip)
+  // while every wave clears its own image and writes its share of the staging-offset table
   float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
-  if (a.wfrag) cw_frags_global(a.wfrag, lane, a0, a1);          // (in flight under the BatchNorm finalisation)
-  else cw_copy_w(a.W, smem + CW_AUX + 4096, tid);
-  cl_finalize(a.fin, aux, reinterpret_cast<double*>(smem + CW_AUX), tid);      // (ends with a workgroup barrier)
-  const f32x4 s4 = ld4(aux + 4 * chunk), t4 = ld4(aux + CL_C + 4 * chunk), m4 = ld4(aux + 2 * CL_C + 4 * chunk);
-  if (!a.wfrag) {
+  if (a.wfrag) {
+    cw_frags_global(a.wfrag, lane, a0, a1);
+  } else {      // (validation hooks without the per-step fragments: gathered from a copy of W in LDS)
+    cw_copy_w(a.W, smem + CW_AUX + 4096, tid);
+    __syncthreads();
     cw_frags_lds(smem + CW_AUX + 4096, 0, 0, n16, kk, a0);
     cw_frags_lds(smem + CW_AUX + 4096, 0, 1, n16, kk, a1);
+    __syncthreads();
   }
+  if (wave == 0) cw_finalize_wave0(a.fin, aux, lane);
+  for (int i = lane; i < WAVE_FLOATS / 4; i += 64) st4(wbase + 4 * i, splat(0.f));      // gap columns stay zero for the launch
   const uint32_t dump = IMG_FLOATS * 4u + 16u * (uint32_t)(lane & 31);
   // image offsets of the staging slots: a 16-bit table [slot][lane] behind the waves' regions (18 registers per lane otherwise)
   const uint16_t* sotab = reinterpret_cast<const uint16_t*>(smem + CW_AUX + CW_WAVES * WAVE_FLOATS) + lane;
   for (int u = wave; u < NLD; u += CW_WAVES) const_cast<uint16_t*>(sotab)[64 * u] = (uint16_t)cw_stage_slot(g, u, lane, dump);
-  __syncthreads();                                              // the scratch of the prologue becomes the images
-  for (int i = lane; i < WAVE_FLOATS / 4; i += 64) st4(wbase + 4 * i, splat(0.f));      // gap columns stay zero for the launch
+  __syncthreads();
+  const f32x4 s4 = ld4(aux + 4 * chunk), t4 = ld4(aux + CL_C + 4 * chunk), m4 = ld4(aux + 2 * CL_C + 4 * chunk);
   f32x4 pb[2];
   pb[0] = a.bias ? ld4(a.bias + 4 * kk) : splat(0.f);
   pb[1] = a.bias ? ld4(a.bias + 16 + 4 * kk) : splat(0.f);
@@ -382,7 +431,8 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
   }
   if (a.stat_out) {
     // sums held per lane in accumulator layout (column n16, channels 16 m + 4 kk .. + 3): the lanes of a kk group meet through
-    // shuffles, the eight waves through LDS, 64 double atomics per workgroup
+    // shuffles, the four waves through LDS, 64 double atomics per workgroup (one set per WAVE -- no barrier -- was tried: four times
+    // the atomics on the same 2048 addresses cost the short-row launches 4 us each)
     __syncthreads();                                            // every wave is past its last unit: the images are dead
     float* red = smem + CW_AUX;                                 // [4 waves][2][32]
 #pragma unroll
@@ -391,10 +441,10 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          float s = sum[i][m][q];
+          float v = sum[i][m][q];
 #pragma unroll
-          for (int off = 1; off < 16; off <<= 1) s += __shfl_xor(s, off);
-          if (n16 == 0) red[(wave * 2 + i) * CL_C + 16 * m + 4 * kk + q] = s;
+          for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off);
+          if (n16 == 0) red[(wave * 2 + i) * CL_C + 16 * m + 4 * kk + q] = v;
         }
     __syncthreads();
     if (tid < 2 * CL_C) {
@@ -479,17 +529,21 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
   bool first = true;
   if constexpr (FOLD) {      // constants of the folded BatchNorm-backward from its sums (32 slots), its dgamma / dbeta
     float* fc = aux + CW_AUX_FOLD;
-    if (tid < 2 * CL_C) {
-      const int c = tid & 31, which = tid >> 5;
-      double sacc = 0.0;
-      for (int k = 0; k < MURAL_BN_SLOTS; ++k) sacc += a.facc[((size_t)k * 2 + which) * CL_C + c];
-      fc[(1 + which) * CL_C + c] = (float)(sacc / a.fn);
-      if (blockIdx.x == 0) (which ? a.fdgamma : a.fdbeta)[c] = (float)sacc;
-    } else if (tid < 3 * CL_C) {
-      const int c = tid & 31;
-      fc[c] = a.fgamma[c] * a.fstate[3 * CL_C + c];
-      fc[3 * CL_C + c] = a.fstate[2 * CL_C + c];
-      fc[4 * CL_C + c] = a.fstate[3 * CL_C + c];
+    if (wave == 0) {
+      double s1, s2;
+      cw_wave_slot_sums(a.facc, lane, &s1, &s2);
+      if (lane < CL_C) {
+        fc[CL_C + lane] = (float)(s1 / a.fn);
+        fc[2 * CL_C + lane] = (float)(s2 / a.fn);
+        if (blockIdx.x == 0) {
+          a.fdbeta[lane] = (float)s1;
+          a.fdgamma[lane] = (float)s2;
+        }
+      }
+    } else if (wave == 1 && lane < CL_C) {
+      fc[lane] = a.fgamma[lane] * a.fstate[3 * CL_C + lane];
+      fc[3 * CL_C + lane] = a.fstate[2 * CL_C + lane];
+      fc[4 * CL_C + lane] = a.fstate[3 * CL_C + lane];
     }
   }
   uint32_t* tab = reinterpret_cast<uint32_t*>(aux + CW_AUX_TAB);      // memory offset of the row of column 4 s + kk, s < NKS

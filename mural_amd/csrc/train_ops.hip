@@ -617,21 +617,37 @@ __global__ __launch_bounds__(256) void first_pool_bwd_kernel(const float* __rest
     if (sd[ntab + i] != 0.f) atomicAdd(&dbias[i], sd[ntab + i]);
 }
 
-// ordered sum of the per-workgroup gradient tables of first_train_kernel<.., true>
-__global__ __launch_bounds__(256) void first_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
-                                                                float* __restrict__ red) {
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= n) return;
-  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-  int b = 0;
-  for (; b + 4 <= nblk; b += 4) {
-    a0 += part[(size_t)(b + 0) * n + i];
-    a1 += part[(size_t)(b + 1) * n + i];
-    a2 += part[(size_t)(b + 2) * n + i];
-    a3 += part[(size_t)(b + 3) * n + i];
+// ordered sum of the per-workgroup gradient tables of first_train_kernel<.., true>: 64 columns x 16 row slices per workgroup (a
+// slice walks every 16th table with 8 loads in flight, the slices meet in LDS in a fixed order) -- one thread per column summing
+// 256 tables serially was 64 dependent rounds on 22 workgroups: 46 us at the tail of the backward
+__global__ __launch_bounds__(1024) void first_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
+                                                                 float* __restrict__ red) {
+  __shared__ float sh[16][64];
+  const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
+  const int i = blockIdx.x * 64 + o;
+  float s = 0.f;
+  if (i < n) {
+    const float* p = part + i;
+    int b = slice;
+    float s0 = 0.f, s1 = 0.f;
+    for (; b + 7 * 16 < nblk; b += 8 * 16) {
+      float v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + 16 * q) * n];
+      s0 += (v[0] + v[1]) + (v[2] + v[3]);
+      s1 += (v[4] + v[5]) + (v[6] + v[7]);
+    }
+    for (; b < nblk; b += 16) s0 += p[(size_t)b * n];
+    s = s0 + s1;
   }
-  for (; b < nblk; ++b) a0 += part[(size_t)b * n + i];
-  red[i] = (a0 + a1) + (a2 + a3);
+  sh[slice][o] = s;
+  __syncthreads();
+  if (slice == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += sh[q][o];
+    red[i] = t;
+  }
 }
 
 // dW[co][ci][t] = sum_sym dTap[t][sym][co] * bnval[sym][ci];  dgamma / dbeta of the BN(4) through the BN outputs.
@@ -1160,7 +1176,7 @@ static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, 
     const int nblk = first_train_grid(B);
     float* red = scratch + (size_t)FIRST_TRAIN_MAXGRID * SNV_LUTBLK;
     if (int rc = launch_first_train(a, true, STREAM)) return rc;
-    hipLaunchKernelGGL(first_part_reduce_kernel, dim3((SNV_LUTBLK + 255) / 256), dim3(256), 0, STREAM, scratch, B ? nblk : 0,
+    hipLaunchKernelGGL(first_part_reduce_kernel, dim3((SNV_LUTBLK + 63) / 64), dim3(1024), 0, STREAM, scratch, B ? nblk : 0,
                        SNV_LUTBLK, red);
     hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), lds, STREAM, nullptr, red, tab, C, W, dW, dgamma, dbeta,
                        dbias);
