@@ -344,6 +344,8 @@ int mural_debug_cl_bn_stats(const float* x, int64_t rows, int32_t relu, double* 
  * for W (forward | input-gradient filter fragments, the per-step relayout of the composed step) or NULL: the conv gathers its
  * fragments from a copy of W in LDS */
 int mural_debug_cw_wfrag(const float* W, float* out6144, void* stream);
+/* diagnostic: per-workgroup wall-clock stamps (100 MHz) of the wave-private forward kernel's phases, uint64 [workgroups][4]; NULL: off */
+int mural_debug_cw_set_stamps(void* dev_ptr);
 int mural_debug_cw_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float* state, const float* W,
                               const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,

@@ -40,6 +40,7 @@
 #include "conv32_jobs.h"
 
 namespace mural {
+unsigned long long* g_cw_stamps = nullptr;      // diagnostic (mural_debug_cw_set_stamps)
 namespace {
 
 constexpr int CW_NBMAX = 9;                 // 16-column blocks per unit at most
@@ -311,6 +312,8 @@ struct CwFwdArgs {
   int64_t n_units;
   int grid;               // workgroups of this job (blockIdx.x beyond it: nothing to do)
   int dbg;                // timing experiments (MURAL_DEBUG_CW): 1 no loads of x, 2 no stores, 4 no residual loads, 8 no conv
+  unsigned long long* stamps;      // diagnostic (mural_debug_cw_set_stamps): [workgroup][4] wall-clock ticks (100 MHz) at entry, behind the
+                                   // prologue, behind the unit loop, at exit
 };
 struct CwFwdArgs2 { CwFwdArgs j[TOWER_JOBS]; };
 
@@ -319,6 +322,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const CwFwdArgs& a = aa.j[blockIdx.y];
   if ((int)blockIdx.x >= a.grid) return;
+  if (a.stamps && threadIdx.x == 0) a.stamps[4 * blockIdx.x + 0] = __builtin_amdgcn_s_memrealtime();
   constexpr int IMG_FLOATS = (16 * NB + 2) * CL_C;
   constexpr int WAVE_FLOATS = IMG_FLOATS + CW_DUMP;
   constexpr int NLD = 2 * NB;                                   // staging slots per lane: 64 NLD >= pieces of the widest unit
@@ -359,6 +363,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
   for (int u = wave; u < NLD; u += CW_WAVES) const_cast<uint16_t*>(sotab)[64 * u] = (uint16_t)cw_stage_slot(g, u, lane, dump);
   __syncthreads();
   const f32x4 s4 = ld4(aux + 4 * chunk), t4 = ld4(aux + CL_C + 4 * chunk), m4 = ld4(aux + 2 * CL_C + 4 * chunk);
+  if (a.stamps && tid == 0) a.stamps[4 * blockIdx.x + 1] = __builtin_amdgcn_s_memrealtime();
   f32x4 pb[2];
   pb[0] = a.bias ? ld4(a.bias + 4 * kk) : splat(0.f);
   pb[1] = a.bias ? ld4(a.bias + 16 + 4 * kk) : splat(0.f);
@@ -429,6 +434,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
           });
     unit += CW_WAVES;
   }
+  if (a.stamps && tid == 0) a.stamps[4 * blockIdx.x + 2] = __builtin_amdgcn_s_memrealtime();
   if (a.stat_out) {
     // sums held per lane in accumulator layout (column n16, channels 16 m + 4 kk .. + 3): the lanes of a kk group meet through
     // shuffles, the four waves through LDS, 64 double atomics per workgroup (one set per WAVE -- no barrier -- was tried: four times
@@ -454,6 +460,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
       atomicAdd(&a.stat_out[(size_t)(blockIdx.x % MURAL_BN_SLOTS) * 2 * CL_C + tid], (double)t);
     }
   }
+  if (a.stamps && tid == 0) a.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
 }
 
 // ------------------------------------------------------------------------------------------------------------ backward
@@ -851,6 +858,7 @@ int cw_conv32_fwd_jobs(const ConvFwdJob* jobs, int n, float eps, float momentum,
     a.n_units = (j.B + a.g.P - 1) / a.g.P;
     a.grid = cw_grid(a.n_units);
     a.dbg = cw_debug();
+    a.stamps = g_cw_stamps;
     nb = a.g.nb > nb ? a.g.nb : nb;
     gx = a.grid > gx ? a.grid : gx;
   }
@@ -941,4 +949,10 @@ extern "C" int mural_debug_cw_conv32_bwd(const float* dy, const float* x, const 
 
 extern "C" int mural_debug_cw_wfrag(const float* W, float* out6144, void* stream) {
   return mural::cw_wfrag_build(&W, 1, out6144, (hipStream_t)stream);
+}
+
+// diagnostic: per-workgroup wall-clock stamps of the forward kernel's phases (tools/phase_stamps_cw.py); NULL switches them off
+extern "C" int mural_debug_cw_set_stamps(void* dev_ptr) {
+  mural::g_cw_stamps = static_cast<unsigned long long*>(dev_ptr);
+  return MURAL_OK;
 }
