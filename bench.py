@@ -263,10 +263,11 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
                    "genome inside the timed loop; steps_per_s = %d steps without a host sync in between" % steps,
            "roofline": {"flop_per_step": FLOP_TRAIN_PER_SITE * B, "achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS,
                         "frac_mfma": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r03_train_step")
+    fact = profile_fact("r04_train_step")
     if fact:
-        gbs = fact["hbm_bytes_per_step"] / t / 1e12
-        out["roofline"].update({"bound": "hbm", "hbm_bytes_per_step": fact["hbm_bytes_per_step"], "achieved_TBs": gbs, "peak_TBs": PEAK_HBM_TBS,
+        hbm = fact.get("hbm_bytes_per_unit", fact.get("hbm_bytes_per_step"))
+        gbs = hbm / t / 1e12
+        out["roofline"].update({"bound": "hbm", "hbm_bytes_per_step": hbm, "achieved_TBs": gbs, "peak_TBs": PEAK_HBM_TBS,
                                 "frac_hbm": gbs / PEAK_HBM_TBS, "launches_per_step": fact.get("launches_per_step"),
                                 "traffic_source": fact.get("source")})
     return out
@@ -316,10 +317,11 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
            "note": "window decode from the packed genome inside the timed region; 113.4 MFLOP/position",
            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r03_indel_forward")
+    fact = profile_fact("r04_indel_forward_pmc")
     if fact:
-        tbs = fact["hbm_bytes_per_position"] * n / dt / 1e12
-        out["roofline"].update({"hbm_bytes_per_position": fact["hbm_bytes_per_position"], "achieved_TBs": tbs, "frac_hbm": tbs / PEAK_HBM_TBS,
+        per_pos = fact["hbm_bytes_per_unit"] / 2048.0      # (the profiled unit is one forward of 2048 positions)
+        tbs = per_pos * n / dt / 1e12
+        out["roofline"].update({"hbm_bytes_per_position": per_pos, "achieved_TBs": tbs, "frac_hbm": tbs / PEAK_HBM_TBS,
                                 "traffic_source": fact.get("source")})
     # one training configuration of the same model: batch 128 (the reference's default), CE(sum) + clip + Adam.  The step is ~500
     # small launches behind Python autograd glue: the eager loop runs at the speed of the host's Python (7-11 ms on this pool's
