@@ -119,3 +119,45 @@ def test_tsv_sink_with_device_shards_equals_pandas(tmp_path, calibrated, monkeyp
         a, b = got.split(b"\n"), want.split(b"\n")
         assert len(a) == len(b) and sum(x != y for x, y in zip(a, b)) <= n // 200
     assert sink.writer_seconds()["bytes"] == len(got) - len(got.split(b"\n", 1)[0]) - 1
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_part_file_slices_of_device_shards_concatenate_to_the_single_writer_table(tmp_path, world, monkeypatch):
+    """The part-file mode on the device path: rank r of `world` sorts each shard and formats only its slice of the sorted rows
+    (TsvSink(parts=(r, world)) without a process group writes just that rank's part file, with its per-shard byte counts).  The
+    slices of all ranks, strung together shard by shard in rank order behind the header -- what rank 0 does at close() under
+    torch.distributed (tests/test_dist_gloo.py runs that on the host path) -- are byte-identical to the single-writer table."""
+    monkeypatch.setattr(TsvSink, "PIECE_ROWS", 2048)
+    rng = np.random.default_rng(33)
+    n = 30_000
+    r = _random_rows(rng, n)
+    prob = rng.random((n, 4)).astype(np.float32)
+    prob /= prob.sum(1, keepdims=True)
+    names = sorted(set(r["chrom"].tolist()))
+
+    def feed(sink):
+        for nm in names:
+            sel = r["chrom"] == nm
+            rows = torch.from_numpy(np.concatenate([prob[sel], np.zeros((sel.sum(), 1), np.float32)], axis=1)).cuda()
+            sink({"chrom": nm, "start": torch.from_numpy(r["start"][sel]).cuda(), "end": torch.from_numpy(r["end"][sel]).cuda(),
+                  "strand": torch.from_numpy((r["strand"][sel] == "-").astype(np.uint8)).cuda(),
+                  "label": torch.from_numpy(r["label"][sel]).cuda(), "prob": rows, "n_class": 4})
+        sink.close()
+
+    single = TsvSink(tmp_path / "single.tsv")
+    feed(single)
+    want = (tmp_path / "single.tsv").read_bytes()
+    parts, counts = [], []
+    for rank in range(world):
+        sink = TsvSink(tmp_path / "p.tsv", parts=(rank, world))
+        feed(sink)
+        parts.append((tmp_path / ("p.tsv.part%04d" % rank)).read_bytes())
+        per_shard = dict(getattr(sink, "_writer_shard_bytes", {}))
+        counts.append([per_shard.get(i, 0) for i in range(len(names))])
+        assert sum(counts[-1]) == len(parts[-1])
+    got, offs = want.split(b"\n", 1)[0] + b"\n", [0] * world
+    for i in range(len(names)):
+        for rank in range(world):
+            got += parts[rank][offs[rank]:offs[rank] + counts[rank][i]]
+            offs[rank] += counts[rank][i]
+    assert got == want

@@ -52,3 +52,14 @@ for L in (134, 20, 7):
           "exit %.1f .. %.1f (mean phase lengths: prologue %.1f, units %.1f, epilogue %.1f)"
           % (L, per, len(s), us[:, 0].min(), us[:, 0].max(), us[:, 1].min(), us[:, 1].max(), us[:, 2].min(), us[:, 2].max(),
              us[:, 3].min(), us[:, 3].max(), (us[:, 1] - us[:, 0]).mean(), (us[:, 2] - us[:, 1]).mean(), (us[:, 3] - us[:, 2]).mean()))
+    # who finishes late?  unit-phase end by XCD (workgroup i -> XCD i % 8) and by dispatch order
+    import numpy as np
+    ids = torch.nonzero(stamps.view(512, 4)[:, 0].cpu() > 0).flatten().numpy()
+    end = us[:, 2].numpy()
+    if L == 134:
+        print("   by XCD      :", " ".join("%.1f" % end[ids % 8 == k].mean() for k in range(8)))
+        print("   by id // 64 :", " ".join("%.1f" % end[ids // 64 == k].mean() for k in range(8)))
+        print("   start by id // 64:", " ".join("%.1f" % us[:, 0].numpy()[ids // 64 == k].mean() for k in range(8)))
+        order = np.argsort(end)
+        print("   slowest ids :", ids[order[-16:]].tolist())
+        print("   fastest ids :", ids[order[:16]].tolist())
