@@ -522,13 +522,18 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       // Task t = (site, column, 16-byte chunk) in memory order; lane l takes tasks l, l + 64, ...: coalesced 1 KB per load.
       const int Lout = g.L[1], ScO = g.Sc[1];
       const int total = Pw * Lout * 8;
-      if (!tile_ready) {      // first unit of the wave, or a ragged unit: guarded loads
-        const float* src = args.s3[tw_i] + (size_t)row0 * Lout * 32;
+      if (!tile_ready) {      // first unit of the wave, or a ragged unit: loads guarded by the descriptor's range (the bytes of the
+        // unit's sites that exist: pieces behind them read as zero) -- 64-bit lane pointers were unit-invariant, got hoisted out of the
+        // unit loop and spilled (7 / 11 scratch slots of the two short-stage instances)
+        const int64_t left = args.n - row0;
+        const uint32_t bytes = (uint32_t)(left < Pw ? left : Pw) * (uint32_t)Lout * 128u;
+        const __amdgpu_buffer_rsrc_t rs =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.s3[tw_i] + (size_t)row0 * Lout * 32), 0, (int)bytes, 0x00020000);
+        uint32_t l16 = 16u * (uint32_t)lane;
+        asm volatile("" : "+v"(l16));
 #pragma unroll
         for (int u = 0; u < 2 * TW_NBW; ++u) {
-          const int task = 64 * u + lane;
-          const uint32_t p = g.dL[1].div((uint32_t)task >> 3);
-          const f32x4 v = (task < total && row0 + p < args.n) ? ld4(src + (size_t)task * 4) : splat(0.f);
+          const f32x4 v = 64 * u < total ? buf_ld4(rs, l16 + 1024u * u) : splat(0.f);
           if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
         }
       }
@@ -547,12 +552,20 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
           st4(img + lds_off(1 + (int)p * ScO + jo + 1, task & 7), u < TW_NBW ? xr0[u] : xr1[u - TW_NBW]);
         }
       }
-      wave_zero_gaps(img, g, 1, Pw, lane);
-      for (int t = lane; do_head && t < Pw * args.n_class; t += 64) {      // large-tower and local logits of this unit -> LDS
-        const int p = t / args.n_class, k = t - p * args.n_class;
-        const bool in = row0 + p < args.n;
-        logit[p * SNV_MAXCLASS + k] = in ? args.xlogit[(row0 + p) * SNV_MAXCLASS + k] : 0.f;
-        logit[(2 * Pw + p) * SNV_MAXCLASS + k] = (in && args.has_local) ? args.local_logits[(row0 + p) * args.n_class + k] : 0.f;
+      wave_zero_gaps(img, g, 1, Pw, lane_o);      // (opaque lane index: the gap addresses are unit-invariant too)
+      if (do_head) {      // large-tower and local logits of this unit -> LDS (range-guarded descriptors: no 64-bit lane pointers)
+        const int64_t left = args.n - row0;
+        const uint32_t rows = (uint32_t)(left < Pw ? left : Pw);
+        const __amdgpu_buffer_rsrc_t xl =
+            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.xlogit + (size_t)row0 * SNV_MAXCLASS), 0, (int)(rows * SNV_MAXCLASS * 4u), 0x00020000);
+        const __amdgpu_buffer_rsrc_t ll = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float*>(args.has_local ? args.local_logits + (size_t)row0 * args.n_class : args.xlogit), 0,
+            args.has_local ? (int)(rows * (uint32_t)args.n_class * 4u) : 0, 0x00020000);
+        for (int t = lane_o; t < Pw * args.n_class; t += 64) {
+          const int p = t / args.n_class, k = t - p * args.n_class;
+          logit[p * SNV_MAXCLASS + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xl, 4u * (uint32_t)(p * SNV_MAXCLASS + k), 0, 0));
+          logit[(2 * Pw + p) * SNV_MAXCLASS + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ll, 4u * (uint32_t)t, 0, 0));
+        }
       }
     }
 
@@ -629,7 +642,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
         const int Lin = g.L[1], Lout = g.L[2], ScI = g.Sc[1], ScO = g.Sc[2];
         const int pk = g.pk[2], pst = g.ps[2], pp = g.pp[2];
         const int total = Pw * Lout * 8;
-        const int cg = lane & 7;
+        int cg = lane & 7;
+        asm volatile("" : "+v"(cg));      // opaque: the two constant addresses below are unit-invariant (hoisted, spilled, reloaded per unit)
         const f32x4 pool_s = ld4(par + EX_BN_OUT * 32 + 4 * cg), pool_t = ld4(par + (EX_COUNT + EX_BN_OUT) * 32 + 4 * cg);
         for (int task = lane; task < total; task += 64) {
           const uint32_t pj = (uint32_t)task >> 3;
@@ -720,8 +734,12 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
           acc = fmaf(wv.z, fv.z, acc);
           acc = fmaf(wv.w, fv.w, acc);
         }
-        if (!do_head) {      // large tower: hand the logits to the launch that runs the mid tower and the head
-          if (row0 + p < args.n) args.xlogit[(row0 + p) * SNV_MAXCLASS + k] = acc;
+        if (!do_head) {      // large tower: hand the logits to the launch that runs the mid tower and the head (a descriptor over the
+          // rows of the unit that exist: no 64-bit lane pointer to hoist and spill, stores behind the last site are dropped)
+          const int64_t left = args.n - row0;
+          const __amdgpu_buffer_rsrc_t xo = __builtin_amdgcn_make_buffer_rsrc(
+              args.xlogit + (size_t)row0 * SNV_MAXCLASS, 0, (int)((uint32_t)(left < Pw ? left : Pw) * SNV_MAXCLASS * 4u), 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc), xo, 4u * (uint32_t)(p * SNV_MAXCLASS + k), 0, 0);
         } else {
           logit[(slot * Pw + p) * SNV_MAXCLASS + k] = acc;
         }
@@ -755,7 +773,12 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
         if (args.has_local) prob = (pr[2] + prob) / 2.f;
         float res = __logf(fmaxf(prob, 1e-9f));
         if (args.status != nullptr && *args.status != 0) res = __uint_as_float(0x7FC00000u);   // flagged encoding error: loud output
-        if (row0 + p < args.n) args.out[(row0 + p) * nc + k] = res;
+        {
+          const int64_t left = args.n - row0;
+          const __amdgpu_buffer_rsrc_t oo = __builtin_amdgcn_make_buffer_rsrc(
+              args.out + (size_t)row0 * nc, 0, (int)((uint32_t)(left < Pw ? left : Pw) * (uint32_t)nc * 4u), 0x00020000);
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res), oo, 4u * (uint32_t)t, 0, 0);
+        }
       }
     }
     SNVW_STAMP(5);      // global max, fc, head

@@ -37,9 +37,9 @@ def test_stage_split_tower_kernels_do_not_spill(phase):
 
 
 def test_wave_private_tower_kernels_stay_within_their_register_budget():
-    """First-stage instances (the bulk of the headline: 61 % of the kernel time): no spill at all, two waves per SIMD.  Short-stage
-    instances: the few spills the backend leaves sit outside the layer loops (guarded first-unit loads); more than a few dozen means a
-    hoisted per-lane table came back."""
+    """Every instance: no VGPR spill, no scratch, two waves per SIMD.  A spill here means a unit-invariant per-lane address (a hoisted
+    64-bit lane pointer or LDS table address) came back: the guarded loads and stores go through range-checked buffer descriptors and
+    the invariant lane indices are opaque for exactly that reason."""
     ks = _kernels(REPORT_WAVE)
     first = [k for k in ks if "snv_tower_wave" in k and "ILi1E" in k.split("snv_tower_wave")[1][:6]]
     short = [k for k in ks if "snv_tower_wave" in k and "ILi2E" in k.split("snv_tower_wave")[1][:6]]
@@ -49,4 +49,4 @@ def test_wave_private_tower_kernels_stay_within_their_register_budget():
         assert r["VGPRs"] <= 256 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= 2, (k, r)
     for k in short:
         r = ks[k]
-        assert r["VGPRs"] <= 256 and r["VGPRs Spill"] <= 40 and r["Occupancy"] >= 2, (k, r)
+        assert r["VGPRs"] <= 256 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= 2, (k, r)
