@@ -171,8 +171,14 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   static const bool use_mfma = !(getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 0);   // A/B switch of the tools
   // measured at 2048 rows (tools/gpu_debug_conv1d.py): the implicit GEMM wins on short rows (<= 128 columns: 2-4 x) and on long
   // rows with a deep reduction (Cin * K >= 224); long rows with few input channels are bound by the output stream and the direct
-  // kernel's 64-column tiles keep more of them in flight
-  if (use_mfma && conv1d_mfma_supported(a) && (a.Lout <= 128 || a.Cin * a.K >= 224)) return launch_conv1d_mfma(a, stream);
+  // kernel's 64-column tiles keep more of them in flight.  A small launch (a training batch of 128 rows at the U-Net's 400-column
+  // level: the direct kernel's 256-column tiles make 256 workgroups of a 70 us chain each) goes to the implicit GEMM too, and so do
+  // the upsampling convs with a medium reduction (measured on the training step, tools/r4_step_classes.py: 74 -> 22, 30 -> 17, 55 -> 42 us).
+  static const bool all_mfma = getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 2;
+  const bool small_launch = (int64_t)a.B * a.Lout <= 128 * 512 && a.Lout <= 512;
+  if (use_mfma && conv1d_mfma_supported(a) &&
+      (all_mfma || a.Lout <= 128 || a.Cin * a.K >= 224 || small_launch || (a.up > 1 && a.Cin * a.K >= 128 && (int64_t)a.B * a.Lout <= 128 * 2048)))
+    return launch_conv1d_mfma(a, stream);
   return launch_conv1d_valu(a, stream);
 }
 

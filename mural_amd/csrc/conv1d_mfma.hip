@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
   //      loop that waits for one load per round costs a global round trip per round: ~100 us on the deep levels)
   {
     const int total = g.TR * a.Cin * g.span;
-    constexpr int UN = 4;
+    constexpr int UN = 16;
     for (int i0 = tid; i0 < total; i0 += 256 * UN) {
       float x[UN];
       int dsto[UN];
@@ -137,49 +137,60 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
     bcol[j] = l;
     boff[j] = (r * a.Cin + kk) * g.span_p + l * a.stride;
   }
-  // weight fragment addresses: channel blocks past Cout re-read block 0 and are zeroed by the select below
-  int woff[MW];
-  bool wok[MW];
+  // weight fragment addresses (bytes into wt, lane part): channel blocks past Cout aim past the descriptor and read zeros
+  const __amdgpu_buffer_rsrc_t rw =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wt), 0, (int)((size_t)a.Cin * KT * g.Mrows * 4), 0x00020000);
+  uint32_t woff[MW];
 #pragma unroll
   for (int m = 0; m < MW; ++m) {
     const int co = 16 * (m_base + m_first + m) + n16;
-    wok[m] = m_first + m < mb_total && co < g.Mrows;
-    woff[m] = wok[m] ? co : n16;
+    const bool wok = m_first + m < mb_total && co < g.Mrows;
+    woff[m] = wok ? (uint32_t)(kk * KT * g.Mrows + co) * 4u : 0x80000000u;
   }
   g4 acc[MW][NBW];
 #pragma unroll
   for (int m = 0; m < MW; ++m)
 #pragma unroll
     for (int j = 0; j < NBW; ++j) acc[m][j] = g4{0.f, 0.f, 0.f, 0.f};
-  const float* wbase = wt + (size_t)kk * K * g.Mrows;
-  float an[K][MW];                                          // next step's weight fragments, in flight during this step's MFMAs
-#pragma unroll
-  for (int t = 0; t < K; ++t)
-#pragma unroll
-    for (int m = 0; m < MW; ++m) an[t][m] = wbase[(size_t)t * g.Mrows + woff[m]];
-  for (int ci0 = 0; ci0 < a.Cin; ci0 += 4) {
-    float ac[K][MW];
+  // weight fragments travel CG_PF steps (of 4 input channels) ahead of their MFMAs: a step's MFMAs are shorter than a global round
+  // trip whenever a wave owns few blocks (the deep levels: a dozen steps of <= 30 MFMAs), and one step of lead left every step
+  // waiting out most of that round trip -- 15-25 us per launch for a microsecond of arithmetic.  The wave-uniform part of the
+  // address rides in the scalar offset: one address register per channel block.
+  constexpr int CG_PF = 48 / (K * MW) >= 16 ? 16 : (48 / (K * MW) >= 2 ? 48 / (K * MW) : 2);      // about 48 registers of lead
+  static_assert((CG_PF - 1) * K * MW <= 63, "newer loads in flight at a use must fit the vmcnt range");
+  float wq[CG_PF][K][MW];
+  auto fetch = [&](float (&dst)[K][MW], int ci) {
 #pragma unroll
     for (int t = 0; t < K; ++t)
 #pragma unroll
-      for (int m = 0; m < MW; ++m) ac[t][m] = wok[m] ? an[t][m] : 0.f;
-    if (ci0 + 4 < a.Cin) {
-      const float* wnext = wbase + (size_t)(ci0 + 4) * K * g.Mrows;
+      for (int m = 0; m < MW; ++m)
+        dst[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff[m], (uint32_t)((ci * K + t) * g.Mrows) * 4u, 0));
+  };
+#pragma unroll
+  for (int p = 0; p < CG_PF; ++p)
+    if (4 * p < a.Cin) fetch(wq[p], 4 * p);
+  for (int cb = 0; cb < a.Cin; cb += 4 * CG_PF) {
+#pragma unroll
+    for (int p = 0; p < CG_PF; ++p) {
+      const int ci0 = cb + 4 * p;
+      if (ci0 >= a.Cin) break;
+      float ac[K][MW];
 #pragma unroll
       for (int t = 0; t < K; ++t)
 #pragma unroll
-        for (int m = 0; m < MW; ++m) an[t][m] = wnext[(size_t)t * g.Mrows + woff[m]];
-    }
-    const float* trow = tile + (size_t)ci0 * g.span_p;
+        for (int m = 0; m < MW; ++m) ac[t][m] = wq[p][t][m];
+      if (ci0 + 4 * CG_PF < a.Cin) fetch(wq[p], ci0 + 4 * CG_PF);
+      const float* trow = tile + (size_t)ci0 * g.span_p;
 #pragma unroll
-    for (int t = 0; t < K; ++t) {
-      float bv[NBW];
+      for (int t = 0; t < K; ++t) {
+        float bv[NBW];
 #pragma unroll
-      for (int j = 0; j < NBW; ++j) bv[j] = trow[boff[j] + t];
+        for (int j = 0; j < NBW; ++j) bv[j] = trow[boff[j] + t];
 #pragma unroll
-      for (int m = 0; m < MW; ++m)
+        for (int m = 0; m < MW; ++m)
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t][m], bv[j], acc[m][j], 0, 0, 0);
+          for (int j = 0; j < NBW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t][m], bv[j], acc[m][j], 0, 0, 0);
+      }
     }
   }
   // ---- epilogue: bias, activation, residuals, straight from the accumulators.  Plain: 16 lanes write 16 consecutive columns of
@@ -268,6 +279,8 @@ bool plan(const Conv1dArgs& a, ConvGArgs* g) {
     int tr = 64 / g->Lcols;
     if (tr < 1) tr = 1;
     while (tr > 1 && (size_t)tr * a.Cin * pad_span(g->span) * 4 > 64 * 1024) --tr;
+    // few rows: smaller tiles, more workgroups -- a launch of a few dozen workgroups is a chain of staging round trips, not arithmetic
+    while (tr > 1 && (a.B + tr - 1) / tr < 128 && (tr / 2) * g->Lcols >= 16) tr /= 2;
     g->TR = tr;
   }
   g->span_p = pad_span(g->span);
@@ -277,6 +290,13 @@ bool plan(const Conv1dArgs& a, ConvGArgs* g) {
   g->d_lout = FastDiv::make((uint32_t)g->Lcols);
   g->d_ph = FastDiv::make((uint32_t)ph);
   g->mslice = CG_MSLICE;
+  {
+    // a short problem (the deep levels: a few dozen tiles) spreads its channel blocks over more workgroups: a workgroup's MFMA chain
+    // and the launch's tail shrink with the slice, the re-staged input tile is a few KB
+    const int mb_all = (g->Mrows + 15) / 16;
+    const int64_t tiles = g->seg ? (int64_t)((g->Lcols + g->segc - 1) / g->segc) * a.B : (a.B + g->TR - 1) / g->TR;
+    while (g->mslice > 2 && tiles * ((mb_all + g->mslice - 1) / g->mslice) < 128) g->mslice = g->mslice > 3 ? 3 : 2;
+  }
   return lds_bytes(*g) <= 96 * 1024;
 }
 

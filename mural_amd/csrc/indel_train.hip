@@ -3,6 +3,7 @@
 // input- and weight-gradient kernels, and the SiLU / Softplus / ReLU element-wise pair.  BatchNorm (batch statistics),
 // Linear, Dropout and the global max come from train_ops.hip.  Tensors are [B][C][L] fp32, weights in torch's
 // [Cout][Cin][K] layout.  Direct convolutions on the vector ALU: at 4..48 channels the layers are HBM / latency bound.
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -10,6 +11,9 @@
 #include "mfma_tile.h"
 
 namespace mural {
+// conv_wgrad_mfma.hip: the weight gradient as an implicit GEMM on the matrix cores (nonzero return: shape not covered)
+int launch_conv_wgrad_mfma(const float* dy, const float* x, float* part, int64_t B, int Cin, int Lin, int Cout, int Lout, int K, int stride,
+                           int pad, int up, int max_chunks, int* chunks_out, hipStream_t st);
 namespace {
 
 constexpr int IT_THREADS = 256;
@@ -842,6 +846,21 @@ static int convg_bwd_impl(const float* dy, const float* x, const float* W, const
     MURAL_HIP_CHECK(hipGetLastError());
   }
   const int entries = Cin * K;
+  static const bool wgrad_mfma = !(getenv("MURAL_WGRAD_MFMA") && atoi(getenv("MURAL_WGRAD_MFMA")) == 0);      // A/B switch of the tools
+  if (wgrad_mfma) {
+    const int cap = (int)std::min<size_t>(WG_CHUNKS, part_floats / ((size_t)Cout * (entries + 1)));
+    int chunks = 0;
+    if (cap >= 1 && launch_conv_wgrad_mfma(dy, x, part, B, Cin, Lin, Cout, Lout, K, stride, pad, up, cap, &chunks, st) == MURAL_OK) {
+      if (g_wgrad_defer.on && g_wgrad_defer.n < WD_MAXJOBS) {
+        g_wgrad_defer.jobs.j[g_wgrad_defer.n++] = WgradJob{part, dW, db, chunks, Cout, entries, 0};
+        return MURAL_OK;
+      }
+      hipLaunchKernelGGL(conv_wgrad_reduce_kernel, dim3((Cout * (entries + 1) + 3) / 4), dim3(IT_THREADS), 0, st, part, chunks, Cout,
+                         entries, dW, db);
+      MURAL_HIP_CHECK(hipGetLastError());
+      return MURAL_OK;
+    }
+  }
   const int co = Cout % 16 == 0 ? 16 : (Cout % 8 == 0 ? 8 : 4);
   // tile length: fewest visits per row, a visit priced as one latency + its share of FMAs; the tile must leave 5 workgroups per CU
   int tl = 64;
