@@ -24,8 +24,9 @@ constexpr int IT_THREADS = 256;
 // A thread owns one (b, j) and CG input channels; weights sit in LDS as [co][k][ci] (a wave reads one address: broadcast).
 template <int CG>
 __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __restrict__ dy, const float* __restrict__ W,
-                                                                float* __restrict__ dx, int64_t rows /* B * Lin */, int Cin,
-                                                                int Lin, int Cout, int Lout, int K, int stride, int pad, int up) {
+                                                                float* dx, int64_t rows /* B * Lin */, int Cin,
+                                                                int Lin, int Cout, int Lout, int K, int stride, int pad, int up,
+                                                                const float* add /* optional, may be dx itself */) {
   extern __shared__ float wl[];                   // [Cout][K][CG]
   const int ci0 = blockIdx.y * CG;
   for (int i = threadIdx.x; i < Cout * K * CG; i += IT_THREADS) {
@@ -62,9 +63,13 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __r
       }
     }
   }
+  // (+ a gradient arriving at x through another consumer; it may live in dx itself: an element is read and written by one thread)
 #pragma unroll
   for (int c = 0; c < CG; ++c)
-    if (ci0 + c < Cin) dx[((size_t)b * Cin + ci0 + c) * Lin + j] = acc[c];
+    if (ci0 + c < Cin) {
+      const size_t o = ((size_t)b * Cin + ci0 + c) * Lin + j;
+      dx[o] = add ? acc[c] + add[o] : acc[c];
+    }
 }
 
 // The same gradient for the U-Net's strided (stride 4 / 5 / 2, up 1) and upsampled (stride 1, up 2 / 5 / 4) layers with the taps of a
@@ -76,8 +81,9 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __r
 // (210 -> 12 for the 40 -> 48-channel level).
 template <int CG, int DG_NT, int DG_COB>
 __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_gather_kernel(const float* __restrict__ dy, const float* __restrict__ W,
-                                                                       float* __restrict__ dx, int64_t rows /* B * Lin */, int Cin,
-                                                                       int Lin, int Cout, int Lout, int K, int stride, int pad, int up) {
+                                                                       float* dx, int64_t rows /* B * Lin */, int Cin,
+                                                                       int Lin, int Cout, int Lout, int K, int stride, int pad, int up,
+                                                                       const float* add /* optional, may be dx itself */) {
   extern __shared__ float wl[];                   // [Cout][T][CG]: T = K + up - 1 summed taps (stride 1) or the K taps (up 1)
   const int ci0 = blockIdx.y * CG;
   const bool summed = stride == 1;
@@ -143,9 +149,13 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_gather_kernel(const flo
       }
     }
   }
+  // (+ a gradient arriving at x through another consumer; it may live in dx itself: an element is read and written by one thread)
 #pragma unroll
   for (int c = 0; c < CG; ++c)
-    if (ci0 + c < Cin) dx[((size_t)b * Cin + ci0 + c) * Lin + j] = acc[c];
+    if (ci0 + c < Cin) {
+      const size_t o = ((size_t)b * Cin + ci0 + c) * Lin + j;
+      dx[o] = add ? acc[c] + add[o] : acc[c];
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -635,47 +645,58 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_bwd_apply_kernel(const flo
 // Short tensors (the deep U-Net levels: B * L <= CB_ONEPASS elements per channel): one workgroup per channel does both passes of a
 // direction -- sums, then the map -- so the batch-sum launch, its atomics and the accumulator block drop out.  A thread keeps its
 // CB_OP_PER elements in registers between the passes.
+// Two sizes: 256 threads x 8 elements (B * L <= 2048: the two deepest levels at a batch of 128) and 1024 threads x 12 (<= 12288: the
+// 80-column level) -- beyond that a workgroup per channel is too few workgroups for the tensor.
 constexpr int CB_OP_PER = 8, CB_ONEPASS = IT_THREADS * CB_OP_PER;
+constexpr int CB_OP2_THREADS = 1024, CB_OP2_PER = 12, CB_ONEPASS2 = CB_OP2_THREADS * CB_OP2_PER;
 
-__device__ __forceinline__ void cb_block_sum2(double& a, double& b, double (*sh)[IT_THREADS]) {
-  sh[0][threadIdx.x] = a;
-  sh[1][threadIdx.x] = b;
-  __syncthreads();
-  for (int off = IT_THREADS / 2; off > 0; off >>= 1) {
-    if ((int)threadIdx.x < off) {
-      sh[0][threadIdx.x] += sh[0][threadIdx.x + off];
-      sh[1][threadIdx.x] += sh[1][threadIdx.x + off];
-    }
-    __syncthreads();
+// block sums of (a, b): shuffles inside a wave, one LDS round across the waves (fixed order: bitwise reproducible)
+template <int THREADS>
+__device__ __forceinline__ void cb_block_sum2(double& a, double& b, double (*sh)[THREADS / 64]) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    a += __shfl_xor(a, off, 64);
+    b += __shfl_xor(b, off, 64);
   }
-  a = sh[0][0];
-  b = sh[1][0];
+  if ((threadIdx.x & 63) == 0) {
+    sh[0][threadIdx.x >> 6] = a;
+    sh[1][threadIdx.x >> 6] = b;
+  }
+  __syncthreads();
+  a = 0.0;
+  b = 0.0;
+#pragma unroll
+  for (int w = 0; w < THREADS / 64; ++w) {
+    a += sh[0][w];
+    b += sh[1][w];
+  }
 }
 
-__global__ __launch_bounds__(IT_THREADS) void bn_post_onepass_fwd_kernel(const float* __restrict__ y, int B, int C, int L,
+template <int THREADS, int PER>
+__global__ __launch_bounds__(THREADS) void bn_post_onepass_fwd_kernel(const float* __restrict__ y, int B, int C, int L,
                                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                                          float eps, float momentum, float* __restrict__ running_mean,
                                                                          float* __restrict__ running_var, float* __restrict__ state, int act,
                                                                          const float* __restrict__ res1, const float* __restrict__ res2,
                                                                          float* __restrict__ z) {
-  __shared__ double sh[2][IT_THREADS];
+  __shared__ double sh[2][THREADS / 64];
   const int c = blockIdx.x, per = B * L;
-  float v[CB_OP_PER];
-  size_t o[CB_OP_PER];
+  float v[PER];
+  uint32_t o[PER];
   double s = 0.0, q = 0.0;
 #pragma unroll
-  for (int j = 0; j < CB_OP_PER; ++j) {            // all of a thread's loads in flight together
-    const int i = threadIdx.x + j * IT_THREADS;
+  for (int j = 0; j < PER; ++j) {            // all of a thread's loads in flight together
+    const int i = (int)threadIdx.x + j * THREADS;
     const int b = i / L, l = i - b * L;
-    o[j] = ((size_t)b * C + c) * L + l;
+    o[j] = (uint32_t)((b * C + c) * L + l);
     v[j] = i < per ? y[o[j]] : 0.f;
   }
 #pragma unroll
-  for (int j = 0; j < CB_OP_PER; ++j) {
+  for (int j = 0; j < PER; ++j) {
     s += v[j];
     q += (double)v[j] * v[j];
   }
-  cb_block_sum2(s, q, sh);
+  cb_block_sum2<THREADS>(s, q, sh);
   const double n = (double)per, mean = s / n;
   double var = q / n - mean * mean;
   if (var < 0.0) var = 0.0;
@@ -693,8 +714,8 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_onepass_fwd_kernel(const f
     }
   }
 #pragma unroll
-  for (int j = 0; j < CB_OP_PER; ++j) {
-    const int i = threadIdx.x + j * IT_THREADS;
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * THREADS;
     if (i < per) {
       float r = fmaf(sc, v[j], sft);
       if (act) r = act_f(r, act);
@@ -705,21 +726,22 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_onepass_fwd_kernel(const f
   }
 }
 
-__global__ __launch_bounds__(IT_THREADS) void bn_post_onepass_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y, int B,
+template <int THREADS, int PER>
+__global__ __launch_bounds__(THREADS) void bn_post_onepass_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ y, int B,
                                                                          int C, int L, const float* __restrict__ state,
                                                                          const float* __restrict__ gamma, int act, float* __restrict__ dy,
                                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
-  __shared__ double sh[2][IT_THREADS];
+  __shared__ double sh[2][THREADS / 64];
   const int c = blockIdx.x, per = B * L;
   const float sc = state[c], sft = state[C + c], mu = state[2 * C + c], is = state[3 * C + c];
-  float g[CB_OP_PER], xh[CB_OP_PER];
-  size_t o[CB_OP_PER];
+  float g[PER], xh[PER];
+  uint32_t o[PER];
   double a = 0.0, bq = 0.0;
 #pragma unroll
-  for (int j = 0; j < CB_OP_PER; ++j) {
-    const int i = threadIdx.x + j * IT_THREADS;
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * THREADS;
     const int b = i / L, l = i - b * L;
-    o[j] = ((size_t)b * C + c) * L + l;
+    o[j] = (uint32_t)((b * C + c) * L + l);
     const bool ok = i < per;
     const float v = ok ? y[o[j]] : 0.f;
     g[j] = ok ? dz[o[j]] : 0.f;
@@ -727,19 +749,19 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_onepass_bwd_kernel(const f
     xh[j] = ok ? (v - mu) * is : 0.f;
   }
 #pragma unroll
-  for (int j = 0; j < CB_OP_PER; ++j) {
+  for (int j = 0; j < PER; ++j) {
     a += g[j];
     bq += (double)g[j] * xh[j];
   }
-  cb_block_sum2(a, bq, sh);
+  cb_block_sum2<THREADS>(a, bq, sh);
   if (threadIdx.x == 0) {
     dgamma[c] = (float)bq;
     dbeta[c] = (float)a;
   }
   const float k0 = gamma[c] * is, m1 = (float)(a / per), m2 = (float)(bq / per);
 #pragma unroll
-  for (int j = 0; j < CB_OP_PER; ++j) {
-    const int i = threadIdx.x + j * IT_THREADS;
+  for (int j = 0; j < PER; ++j) {
+    const int i = (int)threadIdx.x + j * THREADS;
     if (i < per) dy[o[j]] = k0 * (g[j] - m1 - xh[j] * m2);
   }
 }
@@ -782,19 +804,20 @@ extern "C" size_t mural_op_convg_bwd_scratch(int32_t Cin, int32_t Cout, int32_t 
 }
 
 static int convg_bwd_impl(const float* dy, const float* x, const float* W, const float* wt_dgrad, int64_t B, int32_t Cin, int32_t Lin,
-                          int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
-                          size_t part_floats, void* stream);
+                          int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, const float* dx_add, float* dW, float* db,
+                          float* part, size_t part_floats, void* stream);
 
 extern "C" int mural_op_convg_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout,
                                   int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
                                   size_t part_floats, void* stream) {
-  return convg_bwd_impl(dy, x, W, nullptr, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
+  return convg_bwd_impl(dy, x, W, nullptr, B, Cin, Lin, Cout, K, stride, pad, up, dx, nullptr, dW, db, part, part_floats, stream);
 }
 
-// wt_dgrad (optional): the input-gradient layout of W prepared by mural_op_relayout_multi
+// wt_dgrad (optional): the input-gradient layout of W prepared by mural_op_relayout_multi; dx_add (optional, may alias dx): a second
+// gradient of x (a residual / skip connection's) added while dx is written
 static int convg_bwd_impl(const float* dy, const float* x, const float* W, const float* wt_dgrad, int64_t B, int32_t Cin, int32_t Lin,
-                          int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, float* dW, float* db, float* part,
-                          size_t part_floats, void* stream) {
+                          int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, float* dx, const float* dx_add, float* dW, float* db,
+                          float* part, size_t part_floats, void* stream) {
   MURAL_REQUIRE(B >= 1 && Cin >= 1 && Cout >= 1 && Lin >= 1, "convg_bwd: bad sizes");
   const int Lout = mural_op_convg_out_length(Lin, K, stride, pad, up);
   MURAL_REQUIRE(Lout >= 1, "convg_bwd: bad geometry");
@@ -817,6 +840,7 @@ static int convg_bwd_impl(const float* dy, const float* x, const float* W, const
     a.B = (int)B; a.Cin = Cout; a.Lin = Lout; a.Cout = Cin; a.Lout = Lin;
     a.K = K; a.stride = 1; a.pad = K - 1 - pad; a.up = 1;
     a.act = ACT_NONE;
+    a.res1 = dx_add;
     if (int rc = launch_conv1d(a, st)) return rc;
   } else if (dx && Cin > 4 && (stride == 1 || up == 1) && (stride == 1 ? K + up - 1 : (K + stride - 1) / stride) <= 12 &&
              (size_t)Cout * (stride == 1 ? K + up - 1 : K) * 8 * sizeof(float) <= 64 * 1024) {
@@ -826,7 +850,7 @@ static int convg_bwd_impl(const float* dy, const float* x, const float* W, const
     const size_t lds = (size_t)Cout * (stride == 1 ? K + up - 1 : K) * 8 * sizeof(float);
 #define MURAL_DGRAD(NT_, COB_)                                                                                                        \
   hipLaunchKernelGGL((conv_dgrad_gather_kernel<8, NT_, COB_>), grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, \
-                     stride, pad, up)
+                     stride, pad, up, dx_add)
     if (nt <= 2) MURAL_DGRAD(2, 16);
     else if (nt <= 4) MURAL_DGRAD(4, 8);
     else if (nt <= 8) MURAL_DGRAD(8, 4);
@@ -840,9 +864,9 @@ static int convg_bwd_impl(const float* dy, const float* x, const float* W, const
     const dim3 grid((unsigned)((rows + IT_THREADS - 1) / IT_THREADS), (Cin + cg - 1) / cg);
     const size_t lds = (size_t)Cout * K * cg * sizeof(float);
     if (small)
-      hipLaunchKernelGGL(conv_dgrad_kernel<4>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad, up);
+      hipLaunchKernelGGL(conv_dgrad_kernel<4>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad, up, dx_add);
     else
-      hipLaunchKernelGGL(conv_dgrad_kernel<8>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad, up);
+      hipLaunchKernelGGL(conv_dgrad_kernel<8>, grid, dim3(IT_THREADS), lds, st, dy, W, dx, rows, Cin, Lin, Cout, Lout, K, stride, pad, up, dx_add);
     MURAL_HIP_CHECK(hipGetLastError());
   }
   const int entries = Cin * K;
@@ -937,9 +961,13 @@ extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float
   if (int rc = mural_op_convg_fwd(x, W, bias, wt, y0, B, Cin, Lin, Cout, K, stride, pad, up, stream)) return rc;
   if (B == 0) return MURAL_OK;
   const int Lout = out_length(Lin, K, stride, pad, up);
-  if (B * Lout <= CB_ONEPASS) {       // short tensor: sums and map in one launch, one workgroup per channel
-    hipLaunchKernelGGL(bn_post_onepass_fwd_kernel, dim3(Cout), dim3(IT_THREADS), 0, (hipStream_t)stream, y0, (int)B, Cout, Lout, gamma, beta,
-                       eps, momentum, running_mean, running_var, state, act, res1, res2, z);
+  if (B * Lout <= CB_ONEPASS2 && B * Cout * Lout < (int64_t(1) << 31)) {       // short tensor: sums and map in one launch, one workgroup per channel
+    if (B * Lout <= CB_ONEPASS)
+      hipLaunchKernelGGL((bn_post_onepass_fwd_kernel<IT_THREADS, CB_OP_PER>), dim3(Cout), dim3(IT_THREADS), 0, (hipStream_t)stream, y0, (int)B,
+                         Cout, Lout, gamma, beta, eps, momentum, running_mean, running_var, state, act, res1, res2, z);
+    else
+      hipLaunchKernelGGL((bn_post_onepass_fwd_kernel<CB_OP2_THREADS, CB_OP2_PER>), dim3(Cout), dim3(CB_OP2_THREADS), 0, (hipStream_t)stream, y0,
+                         (int)B, Cout, Lout, gamma, beta, eps, momentum, running_mean, running_var, state, act, res1, res2, z);
     MURAL_HIP_CHECK(hipGetLastError());
     return MURAL_OK;
   }
@@ -957,10 +985,25 @@ extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float
 
 // backward of the same unit from dz (the gradient of z; the residuals' gradients are dz itself): dgamma, dbeta, then the conv's dx
 // (optional), dW, db (optional).  acc = zeroed accumulator block, dy0 = scratch [B][Cout][Lout], part as for mural_op_convg_bwd.
+namespace mural {
+// mural_op_convg_bn_bwd with dx_add (optional, may alias dx): dx = the conv's input gradient + dx_add -- the composed step
+// (indel_train_step.hip) hands the gradient that reaches x through a residual or skip connection here instead of a separate add pass
+int convg_bn_bwd_add(const float* dz, const float* x, const float* W, const float* y0, const float* state, const float* gamma, int64_t B,
+                     int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, int32_t act, double* acc,
+                     float* dy0, float* dx, const float* dx_add, float* dW, float* db, float* dgamma, float* dbeta, float* part,
+                     size_t part_floats, const float* wt_dgrad, void* stream);
+}
 extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const float* W, const float* y0, const float* state,
                                      const float* gamma, int64_t B, int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride,
                                      int32_t pad, int32_t up, int32_t act, double* acc, float* dy0, float* dx, float* dW, float* db,
                                      float* dgamma, float* dbeta, float* part, size_t part_floats, const float* wt_dgrad, void* stream) {
+  return convg_bn_bwd_add(dz, x, W, y0, state, gamma, B, Cin, Lin, Cout, K, stride, pad, up, act, acc, dy0, dx, nullptr, dW, db, dgamma, dbeta,
+                          part, part_floats, wt_dgrad, stream);
+}
+int mural::convg_bn_bwd_add(const float* dz, const float* x, const float* W, const float* y0, const float* state, const float* gamma, int64_t B,
+                            int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, int32_t act,
+                            double* acc, float* dy0, float* dx, const float* dx_add, float* dW, float* db, float* dgamma, float* dbeta,
+                            float* part, size_t part_floats, const float* wt_dgrad, void* stream) {
   MURAL_REQUIRE(act >= 0 && act <= 3, "convg_bn_bwd: act must be 0 (none), 1 (ReLU), 2 (SiLU) or 3 (Softplus)");
   MURAL_REQUIRE(B >= 1 && dz && y0 && state && gamma && acc && dy0 && dgamma && dbeta, "convg_bn_bwd: null pointer / empty batch");
   MURAL_REQUIRE(Cout <= CB_MAXC, "convg_bn_bwd: at most %d output channels (got %d)", CB_MAXC, Cout);
@@ -969,8 +1012,11 @@ extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const floa
   hipStream_t st = (hipStream_t)stream;
   const int64_t per = B * Lout, total = per * Cout;
   if (per <= CB_ONEPASS) {            // short tensor: sums and map in one launch, one workgroup per channel
-    hipLaunchKernelGGL(bn_post_onepass_bwd_kernel, dim3(Cout), dim3(IT_THREADS), 0, st, dz, y0, (int)B, Cout, Lout, state, gamma, act, dy0,
-                       dgamma, dbeta);
+    hipLaunchKernelGGL((bn_post_onepass_bwd_kernel<IT_THREADS, CB_OP_PER>), dim3(Cout), dim3(IT_THREADS), 0, st, dz, y0, (int)B, Cout, Lout,
+                       state, gamma, act, dy0, dgamma, dbeta);
+  } else if (per <= CB_ONEPASS2 && total < (int64_t(1) << 31)) {
+    hipLaunchKernelGGL((bn_post_onepass_bwd_kernel<CB_OP2_THREADS, CB_OP2_PER>), dim3(Cout), dim3(CB_OP2_THREADS), 0, st, dz, y0, (int)B, Cout,
+                       Lout, state, gamma, act, dy0, dgamma, dbeta);
   } else {
     int gy = (int)((per + IT_THREADS * 8 - 1) / (IT_THREADS * 8));
     gy = gy < 1 ? 1 : (gy > 256 ? 256 : gy);
@@ -981,7 +1027,8 @@ extern "C" int mural_op_convg_bn_bwd(const float* dz, const float* x, const floa
                        dbeta);
   }
   MURAL_HIP_CHECK(hipGetLastError());
-  return convg_bwd_impl(dy0, x, W, wt_dgrad, B, Cin, Lin, Cout, K, stride, pad, up, dx, dW, db, part, part_floats, stream);
+  MURAL_REQUIRE(dx || !dx_add, "convg_bn_bwd: dx_add without dx");
+  return convg_bwd_impl(dy0, x, W, wt_dgrad, B, Cin, Lin, Cout, K, stride, pad, up, dx, dx_add, dW, db, part, part_floats, stream);
 }
 
 // every conv weight of a model into its forward (and, where wt_dgrad is set, input-gradient) layout in one launch; jobs: device

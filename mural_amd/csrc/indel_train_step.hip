@@ -18,6 +18,10 @@ using namespace mural;
 namespace mural {
 void wgrad_defer_begin();                 // indel_train.hip: collect the weight-gradient partial rows of the layers that follow ...
 int wgrad_defer_flush(hipStream_t st);    // ... and reduce them all in one launch
+int convg_bn_bwd_add(const float* dz, const float* x, const float* W, const float* y0, const float* state, const float* gamma, int64_t B,
+                     int32_t Cin, int32_t Lin, int32_t Cout, int32_t K, int32_t stride, int32_t pad, int32_t up, int32_t act, double* acc,
+                     float* dy0, float* dx, const float* dx_add, float* dW, float* db, float* dgamma, float* dbeta, float* part,
+                     size_t part_floats, const float* wt_dgrad, void* stream);      // indel_train.hip
 }
 
 namespace {
@@ -287,10 +291,19 @@ int unit_fwd(const Plan& P, Unit& u, const float* x, const float* res1, const fl
                                momentum, u.rmean, u.rvar, u.acc_f, u.state, u.act, res1, res2, u.z, st);
 }
 
-// dW / db / dgamma / dbeta of the unit go to its gradient slots (or to alternative destinations), dx optional
-int unit_bwd(const Plan& P, const Unit& u, const float* x, const float* dz, float* dx, float* gW, float* gb, float* gga, float* gbe, hipStream_t st) {
-  return mural_op_convg_bn_bwd(dz, x, u.W, u.y0, u.state, u.gamma, P.B, u.Cin, u.Lin, u.Cout, u.K, u.stride, u.pad, u.up, u.act, u.acc_b, P.dy0, dx,
-                               gW, u.bias ? gb : nullptr, gga, gbe, u.part, u.part_floats, u.up == 1 ? u.wt_dgrad : nullptr, st);
+// dW / db / dgamma / dbeta of the unit go to its gradient slots (or to alternative destinations), dx optional; dx_add (optional, may be
+// dx itself): a second gradient of the unit's input, added while dx is written
+int unit_bwd(const Plan& P, const Unit& u, const float* x, const float* dz, float* dx, const float* dx_add, float* gW, float* gb, float* gga,
+             float* gbe, hipStream_t st) {
+  return convg_bn_bwd_add(dz, x, u.W, u.y0, u.state, u.gamma, P.B, u.Cin, u.Lin, u.Cout, u.K, u.stride, u.pad, u.up, u.act, u.acc_b, P.dy0, dx,
+                          dx_add, gW, u.bias ? gb : nullptr, gga, gbe, u.part, u.part_floats, u.up == 1 ? u.wt_dgrad : nullptr, st);
+}
+
+// four short vectors += their second strand-symmetry term, one launch
+struct Add4 { float* y[4]; const float* t[4]; int n[4]; };
+__global__ void add4_kernel(const Add4 j) {
+  const int k = blockIdx.x;
+  for (int i = threadIdx.x; i < j.n[k]; i += blockDim.x) j.y[k][i] += j.t[k][i];
 }
 
 int relayout_all(const Plan& P, const MuralIndelParams& p, hipStream_t st) {
@@ -470,7 +483,7 @@ extern "C" int mural_indel_train_backward(const MuralIndelShape* shape, const Mu
   Unit& o1 = P.u[iout];
   if (int rc = mural_op_convg_bwd(t1, o1.z, p.out2.weight, P.B, C0, L0, C0, 1, 1, 0, 1, t0, const_cast<float*>(g.out2.weight),
                                   const_cast<float*>(g.out2.bias), P.part, P.part_floats, st)) return rc;          // t0 = d o1
-  if (int rc = unit_bwd(P, o1, unit_in[iout], t0, t2, o1.gW, o1.gbias, o1.ggamma, o1.gbeta, st)) return rc;         // t2 = d (decoder out)
+  if (int rc = unit_bwd(P, o1, unit_in[iout], t0, t2, nullptr, o1.gW, o1.gbias, o1.ggamma, o1.gbeta, st)) return rc;         // t2 = d (decoder out)
   // ---- decoder, last level first.  G = gradient of the level's output d_lvl = ConvBlock(u) + enc: it is the 1x1 unit's dz AND the
   // gradient of both residuals; d u = G + dx(k5 unit); the upsampling conv's dx is the next (coarser) level's G.
   float* G = t2;                      // lives in P.g[lvl][2] of the current level
@@ -480,14 +493,12 @@ extern "C" int mural_indel_train_backward(const MuralIndelShape* shape, const Mu
     const int lvl = IL - 2 - j;
     const size_t a = dec0 + 3 * (size_t)j;
     const Unit &ua = P.u[a], &u5 = P.u[a + 1], &u1 = P.u[a + 2];
-    const int64_t n = (int64_t)P.B * P.C[lvl] * P.L[lvl];
-    float *s0 = P.g[lvl][0], *s1 = P.g[lvl][1];
-    if (int rc = unit_bwd(P, u1, unit_in[a + 2], G, P.gh[lvl], u1.gW, nullptr, u1.ggamma, u1.gbeta, st)) return rc;    // gh = d hidden
-    if (int rc = unit_bwd(P, u5, unit_in[a + 1], P.gh[lvl], s0, u5.gW, nullptr, u5.ggamma, u5.gbeta, st)) return rc;   // s0 = dx of the k5 unit
-    if (int rc = add2(G, s0, s1, n, st)) return rc;                                                                   // s1 = d u
+    float* s1 = P.g[lvl][1];
+    if (int rc = unit_bwd(P, u1, unit_in[a + 2], G, P.gh[lvl], nullptr, u1.gW, nullptr, u1.ggamma, u1.gbeta, st)) return rc;    // gh = d hidden
+    if (int rc = unit_bwd(P, u5, unit_in[a + 1], P.gh[lvl], s1, G, u5.gW, nullptr, u5.ggamma, u5.gbeta, st)) return rc;        // s1 = d u = G + dx of the k5 unit
     d_enc[lvl] = G;                                                                                                   // skip gradient: G itself
     float* Gnext = P.g[lvl + 1][2];
-    if (int rc = unit_bwd(P, ua, unit_in[a], s1, Gnext, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
+    if (int rc = unit_bwd(P, ua, unit_in[a], s1, Gnext, nullptr, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
     G = Gnext;
   }
   // ---- encoder, deepest level first.  d e_5 = G (from the decoder's first unit); d e_i (i < 5) = dx of level i + 1's strided conv
@@ -496,38 +507,33 @@ extern "C" int mural_indel_train_backward(const MuralIndelShape* shape, const Mu
   for (int i = IL - 1; i >= 0; --i) {
     const size_t a = (P.rev ? 2 : 0) + 3 * (size_t)i;
     const Unit &ua = P.u[a], &u5 = P.u[a + 1], &u1 = P.u[a + 2];
-    const int64_t n = (int64_t)P.B * P.C[i] * P.L[i];
-    float *s0 = P.g[i][0], *s1 = P.g[i][1];
-    if (int rc = unit_bwd(P, u1, unit_in[a + 2], de, P.gh[i], u1.gW, nullptr, u1.ggamma, u1.gbeta, st)) return rc;
-    if (int rc = unit_bwd(P, u5, unit_in[a + 1], P.gh[i], s0, u5.gW, nullptr, u5.ggamma, u5.gbeta, st)) return rc;
-    if (int rc = add2(de, s0, s1, n, st)) return rc;                                  // s1 = d a_i
+    float* s1 = P.g[i][1];
+    if (int rc = unit_bwd(P, u1, unit_in[a + 2], de, P.gh[i], nullptr, u1.gW, nullptr, u1.ggamma, u1.gbeta, st)) return rc;
+    if (int rc = unit_bwd(P, u5, unit_in[a + 1], P.gh[i], s1, de, u5.gW, nullptr, u5.ggamma, u5.gbeta, st)) return rc;      // s1 = d a_i = de + dx of the k5 unit
     if (i > 0) {
-      float* dx = P.g[i - 1][0];
-      if (int rc = unit_bwd(P, ua, unit_in[a], s1, dx, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
-      const int64_t m = (int64_t)P.B * P.C[i - 1] * P.L[i - 1];
-      // + the decoder's skip gradient, which sits in P.g[i-1][2]: summed in place (the next iteration uses [0] / [1] as temporaries)
-      if (int rc = add2(dx, d_enc[i - 1], P.g[i - 1][2], m, st)) return rc;
+      // dx of the strided conv + the decoder's skip gradient, which sits in P.g[i-1][2]: summed in place while dx is written
+      MURAL_REQUIRE(d_enc[i - 1] == P.g[i - 1][2], "internal: skip gradient is not where the encoder expects it");
+      if (int rc = unit_bwd(P, ua, unit_in[a], s1, P.g[i - 1][2], d_enc[i - 1], ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
       de = P.g[i - 1][2];
     } else if (P.rev) {
       float* dh0 = P.gh[0];           // (B, 4, L): fits the 2C x L buffer
-      if (int rc = unit_bwd(P, ua, unit_in[a], s1, dh0, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
+      if (int rc = unit_bwd(P, ua, unit_in[a], s1, dh0, nullptr, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
       // h0 = unit0(x) + flip_L(unit1(flip_CL(x))): dz of unit 0 is d h0, dz of unit 1 is flip_L(d h0); the input needs no gradient.
       // Both are the same module: the second call's parameter gradients go to a scratch and are added to the first's.
       const Unit &s_a = P.u[0], &s_b = P.u[1];
       const int nW = 4 * 4 * s_a.K;
-      if (int rc = unit_bwd(P, s_a, x, dh0, nullptr, s_a.gW, s_a.gbias, s_a.ggamma, s_a.gbeta, st)) return rc;
+      if (int rc = unit_bwd(P, s_a, x, dh0, nullptr, nullptr, s_a.gW, s_a.gbias, s_a.ggamma, s_a.gbeta, st)) return rc;
       float* dflip = P.g[0][0];
       if (int rc = flip(dh0, nullptr, dflip, P.B, 4, P.Lx, 0, st)) return rc;
       float *tW = P.tmpW, *tb = P.tmpW + ((nW + 3) & ~3), *tg = tb + 4, *tbe = tg + 4;
-      if (int rc = unit_bwd(P, s_b, P.xf, dflip, nullptr, tW, tb, tg, tbe, st)) return rc;
+      if (int rc = unit_bwd(P, s_b, P.xf, dflip, nullptr, nullptr, tW, tb, tg, tbe, st)) return rc;
       defer.flushed = true;
       if (int rc = wgrad_defer_flush(st)) return rc;
-      if (int rc = add2(s_a.gW, tW, s_a.gW, nW, st)) return rc;
-      if (int rc = add2(s_a.gbias, tb, s_a.gbias, 4, st)) return rc;
-      if (int rc = add2(s_a.ggamma, tg, s_a.ggamma, 4, st)) return rc;
-      if (int rc = add2(s_a.gbeta, tbe, s_a.gbeta, 4, st)) return rc;
+      const Add4 j4{{s_a.gW, s_a.gbias, s_a.ggamma, s_a.gbeta}, {tW, tb, tg, tbe}, {nW, 4, 4, 4}};
+      hipLaunchKernelGGL(add4_kernel, dim3(4), dim3(128), 0, st, j4);
+      MURAL_HIP_CHECK(hipGetLastError());
     } else {
-      if (int rc = unit_bwd(P, ua, unit_in[a], s1, nullptr, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
+      if (int rc = unit_bwd(P, ua, unit_in[a], s1, nullptr, nullptr, ua.gW, ua.gbias, ua.ggamma, ua.gbeta, st)) return rc;
     }
   }
   if (!defer.flushed) {
