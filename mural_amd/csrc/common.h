@@ -72,6 +72,21 @@ struct FastDiv {
   __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : __umulhi(n, m); }
 };
 
+// exact n / d for n <= the bound the host built it for: q = (n * M) >> S with 2^S > bound * d (FastDiv's single multiply stops at
+// n * d < 2^32: a flattened (row, column) index of a long batch needs the wider product)
+struct DivWide {
+  uint32_t M, S;
+  static DivWide make(uint32_t d, uint64_t bound) {      // bound * d < 2^62, bound < 2^31
+    uint32_t S = 0;
+    while ((1ull << S) <= bound * d) ++S;
+    DivWide r;
+    r.S = S;
+    r.M = (uint32_t)(((1ull << S) + d - 1) / d);
+    return r;
+  }
+  __device__ __forceinline__ uint32_t div(uint32_t n) const { return (uint32_t)(((uint64_t)n * M) >> S); }
+};
+
 // ---------------------------------------------------------------------------------------------
 // A per-device side stream for independent work inside one library call.  Fork: the side stream waits for everything queued on
 // the caller's stream; join: the caller's stream waits for the side stream.  Both are legal inside a stream capture (the side

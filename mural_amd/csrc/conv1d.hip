@@ -174,6 +174,10 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   // kernel's 64-column tiles keep more of them in flight.  A small launch (a training batch of 128 rows at the U-Net's 400-column
   // level: the direct kernel's 256-column tiles make 256 workgroups of a 70 us chain each) goes to the implicit GEMM too, and so do
   // the upsampling convs with a medium reduction (measured on the training step, tools/r4_step_classes.py: 74 -> 22, 30 -> 17, 55 -> 42 us).
+  // long rows, few channels, several taps at stride 1: the barrier-free kernel (neither tiled kernel covers its stage / compute /
+  // store phases on these; measured on the training step: 35-53 us -> see DESIGN.md)
+  static const bool use_direct = !(getenv("MURAL_CONV1D_DIRECT") && atoi(getenv("MURAL_CONV1D_DIRECT")) == 0);
+  if (use_direct && use_mfma && (int64_t)a.B * a.Lout > 128 * 512 && a.Lout > 512 && conv1d_direct_supported(a)) return launch_conv1d_direct(a, stream);
   static const bool all_mfma = getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 2;
   const bool small_launch = (int64_t)a.B * a.Lout <= 128 * 512 && a.Lout <= 512;
   if (use_mfma && conv1d_mfma_supported(a) &&

@@ -1,0 +1,286 @@
+// Stride-1 Conv1d with 3 / 5 / 7 taps, few channels and LONG rows (the first two levels of the INDEL U-Net in training: 4..32
+// channels on rows of 8000 / 2000 columns; reference MuRaL/model/model_indel.py:6-19, :29-38 under model.train(), and the input
+// gradients of the same layers) on v_mfma_f32_16x16x4_f32 with both operands taken straight from global memory -- no LDS tile, no
+// staging loop, no workgroup barrier.  Same contract as conv1d.hip / conv1d_mfma.hip for the cases it takes (Conv1dArgs: bias,
+// activation, two residuals; no pre-op, no upsampling), launch_conv1d routes to it.
+//
+// Why: on these layers the tiled kernels are neither HBM- nor ALU-bound but latency-bound -- a workgroup stages a 2-8 KB tile with
+// per-element index arithmetic, waits, computes a microsecond of arithmetic, stores, and the chip holds too few of them to cover the
+// three phases (35-55 us per launch against 10-20 us of HBM time).
+//
+// The taps as a Toeplitz product.  A wave owns 16 consecutive output columns p0 .. p0+15 of one row.  The four k-rows of an MFMA step
+// are (input channel 2c + h, tap group g) for h, g in {0, 1}: lane (n = lane & 15, kq = 2h + g) loads ONE 16-byte quad
+//     Q = x[ci = 2c + h][p0 + n - pad + 4g .. + 3]              (4-byte aligned; neighbouring lanes overlap: served by the L1)
+// whose element j is the B operand of step j: column n of the output reads tap 4g + j of channel ci there.  The A operand of step j is
+// W[co][ci][4g + j] (zero for taps >= K: 5 taps use 5 of the 8 slots, 7 taps 7), resident in registers for the whole launch.
+// One buffer_load_dwordx4 per lane and channel pair feeds 4 x (Cout / 16) MFMAs; the wave-uniform part of every address is a scalar
+// offset, the lane part is loop-invariant.  Segments that touch a row end take per-element loads with the offsets checked (a refused
+// element aims past the descriptor and reads 0 -- the zero padding).  Loads run one group of U segments ahead of the MFMAs.
+// Output: lane (n, kq) holds rows 4 kq .. + 3 of column n: 16 lanes store 64 consecutive bytes of one channel.
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+
+#include "conv1d.h"
+#include "mfma_tile.h"
+
+namespace mural {
+namespace {
+
+constexpr uint32_t CD_OOB = 0x80000000u;
+
+struct ConvDArgs {
+  Conv1dArgs a;
+  int segs_row;            // 16-column segments per row
+  int e0, gr, ss;          // first interior segment of a row, interior groups per row, edge-loop segments per row
+  int ngroups, nslow;      // interior groups / edge-loop segments of the launch
+  uint32_t x_bytes, y_bytes;
+  DivWide dGr, dSs;
+};
+
+__device__ __forceinline__ float cd_act(float v, int act) {
+  switch (act) {
+    case ACT_RELU: return fmaxf(v, 0.f);
+    case ACT_SILU: return v * __builtin_amdgcn_rcpf(1.f + __expf(-v));
+    case ACT_SOFTPLUS: {
+      const float e = __expf(v);
+      return v > 20.f ? v : (v < -15.f ? e : __logf(1.f + e));
+    }
+    default: return v;
+  }
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t cd_rsrc(const void* base, uint32_t bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ f32x4 cd_ld4(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0));
+}
+__device__ __forceinline__ float cd_ld1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, voff, soff, 0));
+}
+__device__ __forceinline__ void cd_st1(__amdgpu_buffer_rsrc_t r, uint32_t voff, uint32_t soff, float v) {
+  __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
+}
+
+// MB: 16-channel output blocks; CP: input channel pairs; U: segments per group (register double buffer of U * CP quads);
+// RES: residual tensors are read (their loads are not even issued otherwise)
+template <int MB, int CP, int U, bool RES>
+__global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g, const float* __restrict__ wt, const float* __restrict__ bias) {
+  const Conv1dArgs& a = g.a;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, kq = lane >> 4, half = kq >> 1, tg = kq & 1;
+  const __amdgpu_buffer_rsrc_t rx = cd_rsrc(a.in, g.x_bytes), ry = cd_rsrc(a.out, g.y_bytes);
+  const __amdgpu_buffer_rsrc_t r1 = cd_rsrc(a.res1 ? a.res1 : a.out, a.res1 ? g.y_bytes : 0u);      // (0 bytes: every load refused, 0)
+  const __amdgpu_buffer_rsrc_t r2 = cd_rsrc(a.res2 ? a.res2 : a.out, a.res2 ? g.y_bytes : 0u);
+
+  // A fragments: lane (row co = 16 m + n, k-row kq = (channel half, tap group)), step j = tap 4 tg + j
+  float wr[MB][CP][4];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int c = 0; c < CP; ++c)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int co = 16 * m + n, tap = 4 * tg + j;
+        wr[m][c][j] = (co < a.Cout && tap < a.K) ? wt[((size_t)(2 * c + half) * a.K + tap) * a.Cout + co] : 0.f;
+      }
+  // output rows of this lane: co = 16 m + 4 kq + r
+  float bz[MB][4];
+  uint32_t vo[MB][4];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = 16 * m + 4 * kq + r;
+      bz[m][r] = (bias && co < a.Cout) ? bias[co] : 0.f;
+      vo[m][r] = co < a.Cout ? (uint32_t)(co * a.Lout + n) * 4u : CD_OOB;
+    }
+  const uint32_t vx = (uint32_t)(half * a.Lin + n + 4 * tg) * 4u;      // lane part of the interior quad address
+
+  // one segment from its CP quads: MFMAs (two accumulation chains per block -- even / odd channel pairs -- so that a chain's next
+  // MFMA never waits for its own result), then bias / activation / residuals / store.  sy: scalar part of the output address;
+  // tail: this lane's column lies past the end of the row
+  auto finish = [&](const f32x4 (&q)[CP], uint32_t sy, bool tail) {
+    float e1[MB][4], e2[MB][4];
+    if (RES) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const uint32_t o = tail ? CD_OOB : vo[m][r];
+          e1[m][r] = cd_ld1(r1, o, sy);
+          e2[m][r] = cd_ld1(r2, o, sy);
+        }
+    }
+    f32x4 acc[MB], acb[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) {
+      acc[m] = f32x4{bz[m][0], bz[m][1], bz[m][2], bz[m][3]};
+      acb[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < CP; c += 2)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) {
+          acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m][c][j], q[c][j], acc[m], 0, 0, 0);
+          acb[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m][c + 1][j], q[c + 1][j], acb[m], 0, 0, 0);
+        }
+    float v[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[m][r] = acc[m][r] + acb[m][r];
+    if (a.act != ACT_NONE) {      // (one wave-uniform branch per segment, nothing under it touches memory)
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m][r] = cd_act(v[m][r], a.act);
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cd_st1(ry, tail ? CD_OOB : vo[m][r], sy, RES ? v[m][r] + e1[m][r] + e2[m][r] : v[m][r]);
+  };
+
+  const int nwaves = gridDim.x * 4;
+  const int wid = blockIdx.x * 4 + w;
+  // ---------------------------------------------------------------------------------------------- interior groups
+  // (no branch around a load, a next group is always fetched -- the last one re-fetches itself -- and scheduling barriers keep the
+  // prefetch in front of the MFMAs: see conv_wgrad_mfma.hip)
+  {
+    struct Buf { f32x4 q[U][CP]; };
+    auto load = [&](Buf& t, int grp) {
+      const uint32_t b = g.dGr.div((uint32_t)grp);
+      const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr) * U) * 16u;
+      const uint32_t sx = (b * (uint32_t)(a.Cin * a.Lin) + p0 - (uint32_t)a.pad) * 4u;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < CP; ++c) t.q[u][c] = cd_ld4(rx, vx, sx + 64u * u + (uint32_t)(2 * c * a.Lin) * 4u);
+    };
+    auto compute = [&](const Buf& t, int grp) {
+      const uint32_t b = g.dGr.div((uint32_t)grp);
+      const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr) * U) * 16u;
+      const uint32_t sy = (b * (uint32_t)(a.Cout * a.Lout) + p0) * 4u;
+#pragma unroll
+      for (int u = 0; u < U; ++u) finish(t.q[u], sy + 64u * u, false);
+    };
+    int cur = wid;
+    if (cur < g.ngroups) {
+      Buf t0, t1;
+      load(t0, cur);
+      for (;;) {
+        int nx = cur + nwaves;
+        load(t1, nx < g.ngroups ? nx : cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t0, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nx;
+        if (cur >= g.ngroups) break;
+        nx = cur + nwaves;
+        load(t0, nx < g.ngroups ? nx : cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t1, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nx;
+        if (cur >= g.ngroups) break;
+      }
+    }
+  }
+  // ---------------------------------------------------------------------------------------------- edge segments
+  for (int t = wid; t < g.nslow; t += nwaves) {
+    const uint32_t b = g.dSs.div((uint32_t)t);
+    const int k = t - (int)b * g.ss;
+    const int si = k < g.e0 ? k : g.e0 + g.gr * U + (k - g.e0);      // the e0 leading segments, then those behind the interior groups
+    const int p0 = 16 * si;
+    const uint32_t sx = b * (uint32_t)(a.Cin * a.Lin) * 4u;
+    f32x4 q[CP];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pos = p0 + n - a.pad + 4 * tg + e;
+      const bool ok = (pos >= 0) & (pos < a.Lin);
+      uint32_t off = (uint32_t)(half * a.Lin + pos) * 4u;
+      asm volatile("" : "+v"(off));      // (a select, not a branch around the loads)
+      off = ok ? off : CD_OOB;
+#pragma unroll
+      for (int c = 0; c < CP; ++c) q[c][e] = cd_ld1(rx, off, sx + (uint32_t)(2 * c * a.Lin) * 4u);
+    }
+    finish(q, (b * (uint32_t)(a.Cout * a.Lout) + (uint32_t)p0) * 4u, p0 + n >= a.Lout);
+  }
+}
+
+bool direct_plan(const Conv1dArgs& a, int* mb, int* cp) {
+  if (a.stride != 1 || a.up != 1 || a.phases > 1 || a.pre_s || a.pre_t || a.pre_relu) return false;
+  if (a.K != 3 && a.K != 5 && a.K != 7) return false;
+  if (a.Cin != 4 && a.Cin != 8 && a.Cin != 16 && a.Cin != 32) return false;
+  if (a.Cout < 1 || a.Cout > 32 || (a.Cout > 16 && a.Cin > 16)) return false;
+  if (a.Cout <= 8 && a.Cin >= 16) return false;      // half of every MFMA's rows idle under a deep reduction: the vector-ALU kernel is faster (58 vs 50 us)
+  if (a.Lout != a.Lin + 2 * a.pad - a.K + 1 || a.pad < 0 || a.pad > a.K - 1) return false;
+  const uint64_t xb = (uint64_t)a.B * a.Cin * a.Lin * 4, yb = (uint64_t)a.B * a.Cout * a.Lout * 4;
+  if (xb >= (1ull << 31) || yb >= (1ull << 31)) return false;
+  *mb = (a.Cout + 15) / 16;
+  *cp = a.Cin / 2;
+  return true;
+}
+
+}  // namespace
+
+bool conv1d_direct_supported(const Conv1dArgs& a) {
+  int mb, cp;
+  return direct_plan(a, &mb, &cp);
+}
+
+int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.Lout == 0) return MURAL_OK;
+  int mb, cp;
+  MURAL_REQUIRE(direct_plan(a, &mb, &cp), "conv1d (direct MFMA): unsupported geometry");
+  ConvDArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.a = a;
+  g.segs_row = (a.Lout + 15) / 16;
+  g.x_bytes = (uint32_t)((uint64_t)a.B * a.Cin * a.Lin * 4);
+  g.y_bytes = (uint32_t)((uint64_t)a.B * a.Cout * a.Lout * 4);
+  const bool res = a.res1 != nullptr || a.res2 != nullptr;
+  int wgs = 1;
+  // interior segments of a row: p0 >= pad, the last quad (p0 + 22 - pad) inside the row, all 16 columns inside the output row
+  auto plan = [&](int U) {
+    const int e0 = (a.pad + 15) / 16;
+    const int last_in = a.Lin - 23 + a.pad >= 0 ? (a.Lin - 23 + a.pad) / 16 : -1;
+    const int last_out = a.Lout >= 16 ? (a.Lout - 16) / 16 : -1;
+    const int ir = std::max(0, std::min(last_in, last_out) - e0 + 1);
+    g.e0 = e0;
+    g.gr = ir / U;
+    if (g.gr == 0) g.e0 = 0;
+    g.ss = g.segs_row - g.gr * U;
+    g.ngroups = a.B * g.gr;
+    g.nslow = a.B * g.ss;
+    g.dGr = DivWide::make((uint32_t)std::max(1, g.gr), (uint64_t)g.ngroups + 64);
+    g.dSs = DivWide::make((uint32_t)std::max(1, g.ss), (uint64_t)g.nslow + 64);
+    const int units = g.ngroups + g.nslow;
+    wgs = std::max(1, std::min(2048, std::min((units + 3) / 4, std::max(512, (units + 31) / 32))));
+  };
+#define MURAL_CD(MB_, CP_, U_)                                                                                       \
+  do {                                                                                                              \
+    plan(U_);                                                                                                       \
+    if (res) hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, true>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);  \
+    else hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, false>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);     \
+  } while (0)
+  if (mb == 1) {
+    if (cp == 2) MURAL_CD(1, 2, 8);
+    else if (cp == 4) MURAL_CD(1, 4, 4);
+    else if (cp == 8) MURAL_CD(1, 8, 2);
+    else MURAL_CD(1, 16, 1);
+  } else {
+    if (cp == 2) MURAL_CD(2, 2, 8);
+    else if (cp == 4) MURAL_CD(2, 4, 4);
+    else MURAL_CD(2, 8, 1);
+  }
+#undef MURAL_CD
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural

@@ -986,7 +986,8 @@ extern "C" int mural_op_conv1d(const float* in, const float* wt, const float* bi
 }
 
 // validation hook (tests/test_gpu_indel.py): the generic conv with every geometry knob of Conv1dArgs, on the vector-ALU kernel
-// (engine 0), the MFMA implicit-GEMM kernel (engine 1) or the router's choice (engine 2)
+// (engine 0), the MFMA implicit-GEMM kernel (engine 1), the router's choice (engine 2), the polyphase form (3) or the barrier-free
+// long-row kernel (engine 4, conv1d_direct.hip)
 extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin, int32_t Lin,
                                   int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t up, int32_t act, const float* res1,
                                   const float* res2, int32_t engine, void* stream) {
@@ -999,6 +1000,10 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
   if (engine == 1) {
     MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA): unsupported geometry");
     return launch_conv1d_mfma(a, STREAM);
+  }
+  if (engine == 4) {
+    MURAL_REQUIRE(conv1d_direct_supported(a), "conv1d (direct MFMA): unsupported geometry");
+    return launch_conv1d_direct(a, STREAM);
   }
   if (engine == 3) {     // polyphase form of the upsampled conv: weights expanded on the host once per weight tensor (kept for repeats)
     MURAL_REQUIRE(up > 1 && stride == 1, "polyphase conv: needs up > 1, stride 1");
