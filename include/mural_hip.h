@@ -362,6 +362,10 @@ int mural_debug_conv1d(const float* in, const float* wt, const float* bias, floa
                        int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t up, int32_t act, const float* res1,
                        const float* res2, int32_t engine, void* stream);
 
+/* Diagnostic: the MFMA conv's workgroups of the following launches record 5 s_memrealtime values each (start, tile staged, MFMAs done,
+ * stores issued, stores landed) into `stamps` (device memory, 5 x workgroups entries); NULL switches it off. */
+int mural_debug_conv1d_set_stamps(unsigned long long* stamps);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

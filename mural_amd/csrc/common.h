@@ -70,6 +70,9 @@ struct FastDiv {
     return f;
   }
   __device__ __forceinline__ uint32_t div(uint32_t n) const { return d == 1 ? n : __umulhi(n, m); }
+  // the same without the branch on d == 1 (there m == 1 and the high product is 0): for code that divides per element in long
+  // unrolled sequences, where a wave-uniform branch per division costs more instruction fetch than two scalar-masked ALU ops
+  __device__ __forceinline__ uint32_t divnb(uint32_t n) const { return __umulhi(n, m) + (n & (0u - (uint32_t)(d == 1))); }
 };
 
 // exact n / d for n <= the bound the host built it for: q = (n * M) >> S with 2^S > bound * d (FastDiv's single multiply stops at

@@ -135,14 +135,25 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
       }
     }
     if (live && l < a.Lout) {
+      // the residuals of all COG channels are requested together (one branch per tensor, not one -- with a full wait behind its
+      // load -- per element)
+      const size_t o0 = ((size_t)b * a.Cout + cg * COG) * a.Lout + l;
+      float e[COG];
 #pragma unroll
-      for (int c = 0; c < COG; ++c) {
-        const size_t o = ((size_t)b * a.Cout + cg * COG + c) * a.Lout + l;
-        float v = apply_act((c & 1) ? acc[c >> 1].y : acc[c >> 1].x, a.act);
-        if (a.res1) v += a.res1[o];
-        if (a.res2) v += a.res2[o];
-        a.out[o] = v;
+      for (int c = 0; c < COG; ++c) e[c] = 0.f;
+      if (a.res1) {
+#pragma unroll
+        for (int c = 0; c < COG; ++c) e[c] = a.res1[o0 + (size_t)c * a.Lout];
       }
+      if (a.res2) {
+        float e2[COG];
+#pragma unroll
+        for (int c = 0; c < COG; ++c) e2[c] = a.res2[o0 + (size_t)c * a.Lout];
+#pragma unroll
+        for (int c = 0; c < COG; ++c) e[c] += e2[c];
+      }
+#pragma unroll
+      for (int c = 0; c < COG; ++c) a.out[o0 + (size_t)c * a.Lout] = apply_act((c & 1) ? acc[c >> 1].y : acc[c >> 1].x, a.act) + e[c];
     }
   }
 }
@@ -497,10 +508,17 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
     }
   }
   float v[C];
+  {
+    // the skip tensor's C values are requested together (one branch, not one -- with a full wait behind its load -- per channel)
+    float sk[C];
 #pragma unroll
-  for (int c = 0; c < C; ++c) {
-    v[c] = ((c & 1) ? o[c >> 1].y : o[c >> 1].x) + tile[c * TWp + toff + 2];
-    if (a.res2 && live) v[c] += a.res2[((size_t)b * C + c) * a.L + l];
+    for (int c = 0; c < C; ++c) sk[c] = 0.f;
+    if (a.res2 && live) {
+#pragma unroll
+      for (int c = 0; c < C; ++c) sk[c] = a.res2[((size_t)b * C + c) * a.L + l];
+    }
+#pragma unroll
+    for (int c = 0; c < C; ++c) v[c] = ((c & 1) ? o[c >> 1].y : o[c >> 1].x) + tile[c * TWp + toff + 2] + sk[c];
   }
   if (!TAIL) {
     if (live) {

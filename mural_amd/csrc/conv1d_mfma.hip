@@ -49,6 +49,7 @@ struct ConvGArgs {
   int ph;        // phases (1: plain)
   FastDiv d_ph;
   int mslice;    // 16-row blocks per workgroup
+  unsigned long long* stamps;      // diagnostic (tools/phase_stamps_conv1d.py): 5 s_memrealtime values per workgroup, or nullptr
 };
 
 constexpr int CG_MSLICE = 6;    // at most this many 16-row blocks per workgroup; more rows go to further workgroups along grid.z
@@ -79,29 +80,56 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
   const int l0 = g.seg ? blockIdx.x * SEG : 0;
   const int in0 = l0 * a.stride - a.pad;      // virtual (upsampled) input index of the first staged column
   const int Lv = a.Lin * a.up;
-  // ---- stage: all 256 threads over the flattened (row, channel, column) index, UN independent loads in flight per thread (a
-  //      loop that waits for one load per round costs a global round trip per round: ~100 us on the deep levels)
+  if (g.stamps && tid == 0) g.stamps[5 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 0] = __builtin_amdgcn_s_memrealtime();
+  // ---- stage: all 256 threads over the flattened (row, channel, column) index, UN loads of a thread REALLY in flight: every load
+  //      goes through a range-checked descriptor with its offset chosen by a select (a refused element -- zero padding, a row past
+  //      the batch -- aims past the descriptor and reads 0), the pre-op runs on the whole round afterwards.  (The loads used to sit
+  //      behind `if (in range)` with the pre-op inside the branch: the compiler then waits for each load inside its own branch, a
+  //      global round trip per element instead of one per round -- 2-7 us of a 10-18 us launch, tools/phase_stamps_conv1d.py.)
   {
     const int total = g.TR * a.Cin * g.span;
-    constexpr int UN = 16;
+    const __amdgpu_buffer_rsrc_t rin =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)((size_t)a.B * a.Cin * a.Lin * 4), 0x00020000);
+    const bool has_pre = a.pre_s != nullptr || a.pre_t != nullptr || a.pre_relu != 0;      // wave-uniform
+    const __amdgpu_buffer_rsrc_t rps =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pre_s ? a.pre_s : a.in), 0, a.pre_s ? a.Cin * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rpt =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.pre_t ? a.pre_t : a.in), 0, a.pre_t ? a.Cin * 4 : 0, 0x00020000);
+    constexpr int UN = 8;      // (16 cost 160 registers -- two workgroups per CU -- for the index arithmetic in flight with the loads)
     for (int i0 = tid; i0 < total; i0 += 256 * UN) {
       float x[UN];
       int dsto[UN];
+      uint32_t okmask = 0;
 #pragma unroll
       for (int u = 0; u < UN; ++u) {
         const int i = i0 + 256 * u;
-        x[u] = 0.f;                           // zero padding, applied after the pre-op like nn.Conv1d behind a BatchNorm
-        dsto[u] = -1;
-        if (i < total) {
-          const int rc = (int)g.d_span.div((uint32_t)i), j = i - rc * g.span;
-          const int r = (int)g.d_cin.div((uint32_t)rc), ci = rc - r * a.Cin;
-          const int v = in0 + j;
-          dsto[u] = rc * g.span_p + j;
-          if (b0 + r < a.B && v >= 0 && v < Lv) {
-            float xv = a.in[((size_t)(b0 + r) * a.Cin + ci) * a.Lin + (int)g.d_up.div((uint32_t)v)];
-            if (a.pre_relu) xv = fmaxf(xv, 0.f);
-            x[u] = fmaf(a.pre_s ? a.pre_s[ci] : 1.f, xv, a.pre_t ? a.pre_t[ci] : 0.f);
-          }
+        const int rc = (int)g.d_span.divnb((uint32_t)i), j = i - rc * g.span;
+        const int r = (int)g.d_cin.divnb((uint32_t)rc), ci = rc - r * a.Cin;
+        const int v = in0 + j;
+        const bool in_tile = i < total;
+        const bool ok = in_tile & (b0 + r < a.B) & (v >= 0) & (v < Lv);
+        uint32_t off = (uint32_t)(((b0 + r) * a.Cin + ci) * a.Lin + (int)g.d_up.divnb((uint32_t)(ok ? v : 0))) * 4u;
+        asm volatile("" : "+v"(off));      // (a select below, not a branch)
+        x[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rin, ok ? off : 0x80000000u, 0, 0));
+        dsto[u] = in_tile ? rc * g.span_p + j : -1;
+        okmask |= ok ? (1u << u) : 0u;
+      }
+      if (has_pre) {      // x' = pre_s * (relu?)(x) + pre_t on in-range values, zero padding stays zero
+        float ps[UN], pt[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const int i = i0 + 256 * u;
+          const int rc = (int)g.d_span.divnb((uint32_t)i);
+          const int ci = rc - (int)g.d_cin.divnb((uint32_t)rc) * a.Cin;
+          const uint32_t co = (okmask >> u) & 1u ? (uint32_t)ci * 4u : 0x80000000u;
+          ps[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rps, co, 0, 0));
+          pt[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rpt, co, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+          const float xv = a.pre_relu ? fmaxf(x[u], 0.f) : x[u];
+          const float sc = a.pre_s ? ps[u] : 1.f;
+          x[u] = (okmask >> u) & 1u ? fmaf(sc, xv, pt[u]) : 0.f;
         }
       }
 #pragma unroll
@@ -110,6 +138,7 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
     }
   }
   __syncthreads();
+  if (g.stamps && tid == 0) g.stamps[5 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 1] = __builtin_amdgcn_s_memrealtime();
   const int ncols = g.seg ? (g.Lcols - l0 < SEG ? g.Lcols - l0 : SEG) : g.TR * g.Lcols;
   constexpr int K = KT;
   // wave -> (channel-block group wm, column-block group wn)
@@ -166,59 +195,143 @@ __global__ __launch_bounds__(256) void conv1d_mfma_kernel(const ConvGArgs g, con
       for (int m = 0; m < MW; ++m)
         dst[t][m] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, woff[m], (uint32_t)((ci * K + t) * g.Mrows) * 4u, 0));
   };
+  // blocks of this wave that hold any column of the tile (a short problem's tile is 16 or 32 columns wide: three of the four column
+  // blocks of the 64-column layout, and the waves that own nothing else, would spend their MFMAs on padding -- 4 of the 6 us of the
+  // MFMA phase at 16 columns)
+  const int nv = __builtin_amdgcn_readfirstlane(min(nbw, max(0, (ncols - 16 * wn * nbw + 15) >> 4)));
+  if (nv > 0 && m_first < mb_total) {
 #pragma unroll
-  for (int p = 0; p < CG_PF; ++p)
-    if (4 * p < a.Cin) fetch(wq[p], 4 * p);
-  for (int cb = 0; cb < a.Cin; cb += 4 * CG_PF) {
+    for (int p = 0; p < CG_PF; ++p) fetch(wq[p], 4 * p < a.Cin ? 4 * p : a.Cin - 4);
+    for (int cb = 0; cb < a.Cin; cb += 4 * CG_PF) {
 #pragma unroll
-    for (int p = 0; p < CG_PF; ++p) {
-      const int ci0 = cb + 4 * p;
-      if (ci0 >= a.Cin) break;
-      float ac[K][MW];
+      for (int p = 0; p < CG_PF; ++p) {
+        const int ci0 = cb + 4 * p;
+        if (ci0 >= a.Cin) break;
+        float ac[K][MW];
 #pragma unroll
-      for (int t = 0; t < K; ++t)
+        for (int t = 0; t < K; ++t)
 #pragma unroll
-        for (int m = 0; m < MW; ++m) ac[t][m] = wq[p][t][m];
-      if (ci0 + 4 * CG_PF < a.Cin) fetch(wq[p], ci0 + 4 * CG_PF);
-      const float* trow = tile + (size_t)ci0 * g.span_p;
+          for (int m = 0; m < MW; ++m) ac[t][m] = wq[p][t][m];
+        // (always fetched, the last steps re-fetch the final one: a load under a branch makes the compiler's wait-count bookkeeping
+        // merge the two paths pessimistically -- it then waits for the whole queue at the end of every round of CG_PF steps)
+        fetch(wq[p], ci0 + 4 * CG_PF < a.Cin ? ci0 + 4 * CG_PF : a.Cin - 4);
+        const float* trow = tile + (size_t)ci0 * g.span_p;
 #pragma unroll
-      for (int t = 0; t < K; ++t) {
-        float bv[NBW];
+        for (int t = 0; t < K; ++t) {
+          float bv[NBW];
 #pragma unroll
-        for (int j = 0; j < NBW; ++j) bv[j] = trow[boff[j] + t];
+          for (int j = 0; j < NBW; ++j) bv[j] = trow[boff[j] + t];
 #pragma unroll
-        for (int m = 0; m < MW; ++m)
+          for (int j = 0; j < NBW; ++j)
+            if (j < nv) {
 #pragma unroll
-          for (int j = 0; j < NBW; ++j) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t][m], bv[j], acc[m][j], 0, 0, 0);
+              for (int m = 0; m < MW; ++m) acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ac[t][m], bv[j], acc[m][j], 0, 0, 0);
+            }
+        }
       }
     }
+  }
+  if (g.stamps && tid == 0) {
+    asm volatile("s_nop 0" ::: "memory");
+    g.stamps[5 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 2] = __builtin_amdgcn_s_memrealtime();
   }
   // ---- epilogue: bias, activation, residuals, straight from the accumulators.  Plain: 16 lanes write 16 consecutive columns of
   //      one output channel.  Polyphase: row co * ph + p of source column i is output column ph * i + p of channel co, so a lane's
   //      four rows are (mostly) four consecutive output columns.  (Measured: routing the tile through LDS to store whole 16-byte
   //      runs is no faster -- the kernel is bound by its serial stage / MFMA / store phases at 3 workgroups per CU, not by the
   //      width of the stores.)
-#pragma unroll
-  for (int j = 0; j < NBW; ++j) {
-    if (!bval[j] || b0 + brow[j] >= a.B) continue;
+  //      Every load of the epilogue -- the bias of a lane's rows, both residuals of all its elements -- is issued up front through
+  //      range-checked descriptors (an absent tensor has a descriptor of 0 bytes and reads 0; a refused element aims past it): with
+  //      `if (res1) v += res1[o]` per element the compiler put a full wait behind each of the up to 108 loads of a lane, 15-20 us
+  //      of serial round trips per workgroup on launches whose arithmetic takes one.
+  {
+    const uint32_t obytes = (uint32_t)((size_t)a.B * a.Cout * a.Lout * 4);      // (launch_conv1d_mfma refuses tensors of 2 GB and more)
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)obytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rb =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(bias ? bias : wt), 0, bias ? a.Cout * 4 : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr1 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res1 ? a.res1 : wt), 0, a.res1 ? (int)obytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rr2 =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res2 ? a.res2 : wt), 0, a.res2 ? (int)obytes : 0, 0x00020000);
+    const bool any_res = a.res1 != nullptr || a.res2 != nullptr;      // wave-uniform
+    // bias of all the lane's rows first (one round trip), then one channel block at a time: its offsets, its residual loads (all in
+    // flight together), bias / activation, its stores -- a block's 12 x 3 temporaries instead of the tile's 36 x 3 keep three
+    // workgroups per CU resident on the long rows
+    float bz[MW][4];
+    int cos[MW][4], subs[MW][4];
+    bool roks[MW][4];
 #pragma unroll
     for (int m = 0; m < MW; ++m)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int row = 16 * (m_base + m_first + m) + 4 * kk + q;
-        if (m_first + m < mb_total && row < g.Mrows) {
-          int co = row, lo = l0 + bcol[j];
-          if (g.ph > 1) {
-            co = (int)g.d_ph.div((uint32_t)row);
-            lo = lo * g.ph + (row - co * g.ph);
-          }
-          const size_t o = ((size_t)(b0 + brow[j]) * a.Cout + co) * a.Lout + lo;
-          float v = cg_act(acc[m][j][q] + (bias ? bias[co] : 0.f), a.act);
-          if (a.res1) v += a.res1[o];
-          if (a.res2) v += a.res2[o];
-          a.out[o] = v;
+        const bool rok = (m_first + m < mb_total) & (row < g.Mrows);
+        int co = row, sub = 0;
+        if (g.ph > 1) {
+          co = (int)g.d_ph.div((uint32_t)row);
+          sub = row - co * g.ph;
         }
+        cos[m][q] = co; subs[m][q] = sub; roks[m][q] = rok;
+        bz[m][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rb, rok ? (uint32_t)co * 4u : 0x80000000u, 0, 0));
       }
+#pragma unroll
+    for (int m = 0; m < MW; ++m) {
+      uint32_t off[NBW][4];
+      float e1[NBW][4], e2[NBW][4], v[NBW][4];
+#pragma unroll
+      for (int j = 0; j < NBW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool ok = roks[m][q] & bval[j] & (b0 + brow[j] < a.B);
+          const int lo = (l0 + bcol[j]) * g.ph + subs[m][q];
+          uint32_t o = (uint32_t)(((b0 + brow[j]) * a.Cout + cos[m][q]) * a.Lout + lo) * 4u;
+          asm volatile("" : "+v"(o));      // (a select below, not a branch)
+          off[j][q] = ok ? o : 0x80000000u;
+          e1[j][q] = 0.f;
+          e2[j][q] = 0.f;
+        }
+      if (any_res) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            e1[j][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr1, off[j][q], 0, 0));
+            e2[j][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rr2, off[j][q], 0, 0));
+          }
+      }
+      // bias and activation, the activation chosen once per block (a switch per element is four branches and the code of every case
+      // in the instruction stream 36 times: these launches are short enough for instruction fetch to show)
+#pragma unroll
+      for (int j = 0; j < NBW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[j][q] = acc[m][j][q] + bz[m][q];
+      if (a.act == ACT_RELU) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[j][q] = fmaxf(v[j][q], 0.f);
+      } else if (a.act == ACT_SILU) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[j][q] = cg_act(v[j][q], ACT_SILU);
+      } else if (a.act == ACT_SOFTPLUS) {
+#pragma unroll
+        for (int j = 0; j < NBW; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[j][q] = cg_act(v[j][q], ACT_SOFTPLUS);
+      }
+#pragma unroll
+      for (int j = 0; j < NBW; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[j][q] + e1[j][q] + e2[j][q]), ro, off[j][q], 0, 0);
+    }
+  }
+  if (g.stamps && tid == 0) {
+    g.stamps[5 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 3] = __builtin_amdgcn_s_memrealtime();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    g.stamps[5 * (blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z)) + 4] = __builtin_amdgcn_s_memrealtime();
   }
 }
 
@@ -268,6 +381,7 @@ bool plan(const Conv1dArgs& a, ConvGArgs* g) {
   g->Mrows = a.Cout * ph;
   g->Lcols = ph > 1 ? a.Lin : a.Lout;
   if (g->Mrows < 16 || (ph == 1 && g->Mrows > 16 * CG_MSLICE)) return false;
+  if ((uint64_t)a.B * a.Cout * a.Lout * 4 >= (1ull << 31) || (uint64_t)a.B * a.Cin * a.Lin * 4 >= (1ull << 31)) return false;      // buffer descriptors address 2 GB
   if (g->Lcols > 64) {          // longer than the 64-column tile of the row regime
     g->seg = 1;
     g->TR = 1;
@@ -296,6 +410,9 @@ bool plan(const Conv1dArgs& a, ConvGArgs* g) {
     const int mb_all = (g->Mrows + 15) / 16;
     const int64_t tiles = g->seg ? (int64_t)((g->Lcols + g->segc - 1) / g->segc) * a.B : (a.B + g->TR - 1) / g->TR;
     while (g->mslice > 2 && tiles * ((mb_all + g->mslice - 1) / g->mslice) < 128) g->mslice = g->mslice > 3 ? 3 : 2;
+    // ... and down to one block per wave while the launch stays within three workgroups per CU: a wave with one block fetches its
+    // weights a dozen steps ahead (48 registers of lead / K) and its MFMA phase stops being a chain of weight round trips
+    if (tiles * ((mb_all + 1) / 2) <= 768) g->mslice = 2;
   }
   return lds_bytes(*g) <= 96 * 1024;
 }
@@ -329,10 +446,14 @@ bool conv1d_mfma_supported(const Conv1dArgs& a) {
   return plan(a, &g);
 }
 
+static unsigned long long* g_conv1d_stamps = nullptr;
+void conv1d_mfma_set_stamps(unsigned long long* p) { g_conv1d_stamps = p; }
+
 int launch_conv1d_mfma(const Conv1dArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.Lout == 0) return MURAL_OK;
   ConvGArgs g;
   MURAL_REQUIRE(plan(a, &g), "conv1d (MFMA): unsupported geometry");
+  g.stamps = g_conv1d_stamps;
   const size_t lds = lds_bytes(g);
   const int mb_all = (g.Mrows + 15) / 16;
   ConvGFn fn = pick(mb_all, a.K, g.seg ? seg_nbw(g.Mrows, g.Lcols) : 0, g.mslice);

@@ -63,13 +63,18 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_kernel(const float* __r
       }
     }
   }
-  // (+ a gradient arriving at x through another consumer; it may live in dx itself: an element is read and written by one thread)
+  // (+ a gradient arriving at x through another consumer; it may live in dx itself: an element is read and written by one thread.
+  // Its CG values are requested together -- a load behind a per-element branch carries a full wait of its own)
+  if (add) {
+    float e[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) e[c] = ci0 + c < Cin ? add[((size_t)b * Cin + ci0 + c) * Lin + j] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] += e[c];
+  }
 #pragma unroll
   for (int c = 0; c < CG; ++c)
-    if (ci0 + c < Cin) {
-      const size_t o = ((size_t)b * Cin + ci0 + c) * Lin + j;
-      dx[o] = add ? acc[c] + add[o] : acc[c];
-    }
+    if (ci0 + c < Cin) dx[((size_t)b * Cin + ci0 + c) * Lin + j] = acc[c];
 }
 
 // The same gradient for the U-Net's strided (stride 4 / 5 / 2, up 1) and upsampled (stride 1, up 2 / 5 / 4) layers with the taps of a
@@ -149,13 +154,18 @@ __global__ __launch_bounds__(IT_THREADS) void conv_dgrad_gather_kernel(const flo
       }
     }
   }
-  // (+ a gradient arriving at x through another consumer; it may live in dx itself: an element is read and written by one thread)
+  // (+ a gradient arriving at x through another consumer; it may live in dx itself: an element is read and written by one thread.
+  // Its CG values are requested together -- a load behind a per-element branch carries a full wait of its own)
+  if (add) {
+    float e[CG];
+#pragma unroll
+    for (int c = 0; c < CG; ++c) e[c] = ci0 + c < Cin ? add[((size_t)b * Cin + ci0 + c) * Lin + j] : 0.f;
+#pragma unroll
+    for (int c = 0; c < CG; ++c) acc[c] += e[c];
+  }
 #pragma unroll
   for (int c = 0; c < CG; ++c)
-    if (ci0 + c < Cin) {
-      const size_t o = ((size_t)b * Cin + ci0 + c) * Lin + j;
-      dx[o] = add ? acc[c] + add[o] : acc[c];
-    }
+    if (ci0 + c < Cin) dx[((size_t)b * Cin + ci0 + c) * Lin + j] = acc[c];
 }
 
 // ------------------------------------------------------------------------------------------------ weight gradient
@@ -474,6 +484,8 @@ __device__ __forceinline__ void cb_slot_sums(const double* __restrict__ acc, int
 }
 
 // z = act(scale * y + shift) [+ res1] [+ res2];  state = scale | shift | mean | invstd ([4][C])
+template <int NRES>      // residual tensors read: 0, 1 (res1) or 2 (res1 and res2) -- decided at compile time: a load behind a run-time
+                         // `if (res1)` carries a full wait of its own, three serial round trips per 16 bytes instead of one
 __global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* __restrict__ y, int64_t total, int C, int L,
                                                                    const double* __restrict__ acc, int nslots, double n,
                                                                    const float* __restrict__ gamma, const float* __restrict__ beta,
@@ -514,14 +526,17 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* 
       const int c = (int)((e / (uint32_t)L) % (uint32_t)C);
       const float sc = cst[2 * c], sh = cst[2 * c + 1];
       const f32x4 yv = ld4(y + e);
+      f32x4 r1 = splat(0.f), r2 = splat(0.f);
+      if (NRES >= 1) r1 = ld4(res1 + e);
+      if (NRES >= 2) r2 = ld4(res2 + e);
       f32x4 r;
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         r[t] = fmaf(sc, yv[t], sh);
         if (act) r[t] = act_f(r[t], act);
       }
-      if (res1) r += ld4(res1 + e);
-      if (res2) r += ld4(res2 + e);
+      if (NRES >= 1) r += r1;
+      if (NRES >= 2) r += r2;
       st4(z + e, r);
     }
     return;
@@ -531,8 +546,8 @@ __global__ __launch_bounds__(IT_THREADS) void bn_post_apply_kernel(const float* 
     const int c = (int)((i / L) % C);
     float v = fmaf(cst[2 * c], y[i], cst[2 * c + 1]);
     if (act) v = act_f(v, act);
-    if (res1) v += res1[i];
-    if (res2) v += res2[i];
+    if (NRES >= 1) v += res1[i];
+    if (NRES >= 2) v += res2[i];
     z[i] = v;
   }
 }
@@ -976,9 +991,16 @@ extern "C" int mural_op_convg_bn_fwd(const float* x, const float* W, const float
   int64_t gy = (B * Lout + 256 * 8 - 1) / (256 * 8);        // grid.y of mural_op_bn_stats: workgroup y adds into copy y % CB_SLOTS
   const int nslots = (int)(gy < 1 ? 1 : (gy > CB_SLOTS ? CB_SLOTS : gy));
   int64_t g = (total + IT_THREADS * 4 - 1) / (IT_THREADS * 4);
-  hipLaunchKernelGGL(bn_post_apply_kernel, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(IT_THREADS), (size_t)Cout * 2 * sizeof(float),
-                     (hipStream_t)stream, y0, total, Cout, Lout, acc, nslots, (double)(B * Lout), gamma, beta, eps, momentum, running_mean,
-                     running_var, state, act, res1, res2, z);
+  // (a lone second residual travels as the first)
+  const float *ra = res1 ? res1 : res2, *rb = res1 ? res2 : nullptr;
+#define MURAL_BNPA(N_)                                                                                                                     \
+  hipLaunchKernelGGL(bn_post_apply_kernel<N_>, dim3((unsigned)(g > 4096 ? 4096 : g)), dim3(IT_THREADS), (size_t)Cout * 2 * sizeof(float), \
+                     (hipStream_t)stream, y0, total, Cout, Lout, acc, nslots, (double)(B * Lout), gamma, beta, eps, momentum, running_mean, \
+                     running_var, state, act, ra, rb, z)
+  if (rb) MURAL_BNPA(2);
+  else if (ra) MURAL_BNPA(1);
+  else MURAL_BNPA(0);
+#undef MURAL_BNPA
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

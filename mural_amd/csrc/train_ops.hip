@@ -985,6 +985,14 @@ extern "C" int mural_op_conv1d(const float* in, const float* wt, const float* bi
   return launch_conv1d(a, STREAM);
 }
 
+namespace mural { void conv1d_mfma_set_stamps(unsigned long long* p); }
+// diagnostic (tools/phase_stamps_conv1d.py): the MFMA conv's workgroups record 5 s_memrealtime values each (start, tile staged, MFMAs
+// done, stores issued, stores landed) into `stamps` (device, 5 x workgroups of the next launches; NULL switches it off)
+extern "C" int mural_debug_conv1d_set_stamps(unsigned long long* stamps) {
+  mural::conv1d_mfma_set_stamps(stamps);
+  return MURAL_OK;
+}
+
 // validation hook (tests/test_gpu_indel.py): the generic conv with every geometry knob of Conv1dArgs, on the vector-ALU kernel
 // (engine 0), the MFMA implicit-GEMM kernel (engine 1), the router's choice (engine 2), the polyphase form (3) or the barrier-free
 // long-row kernel (engine 4, conv1d_direct.hip)
