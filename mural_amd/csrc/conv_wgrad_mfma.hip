@@ -285,7 +285,7 @@ int launch_conv_wgrad_mfma(const float* dy, const float* x, float* part, int64_t
   else nbw = 4;
   const int gy = (nblocks + nbw - 1) / nbw;
   const bool interior = stride == 1 && up == 1 && Lout % 16 == 0;
-  const int cap = std::max(1, std::min(max_chunks, std::max(64, 1024 / gy)));
+  const int cap = std::max(1, std::min(max_chunks, std::max(64, 512 / gy)));      // (two workgroups per CU are resident; the caller reduces `chunks` rows)
   int chunks = 1;
   // interior geometry for U segments per group; then workgroups: long problems get about four groups per wave (two workgroups per CU
   // and column group are resident), short ones -- the deep levels' few thousand positions -- one unit of work per wave, because a

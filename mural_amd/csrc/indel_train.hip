@@ -728,15 +728,29 @@ __global__ __launch_bounds__(THREADS) void bn_post_onepass_fwd_kernel(const floa
       running_var[c] = (float)((1.0 - momentum) * running_var[c] + momentum * unbiased);
     }
   }
+  // the residuals of all of a thread's elements are requested together (one branch per tensor: a load behind a per-element branch
+  // carries a full wait of its own -- 2 x PER serial round trips in a launch that is one round trip long otherwise)
+  float e[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) e[j] = 0.f;
+  if (res1) {
+#pragma unroll
+    for (int j = 0; j < PER; ++j) e[j] = (int)threadIdx.x + j * THREADS < per ? res1[o[j]] : 0.f;
+  }
+  if (res2) {
+    float e2[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) e2[j] = (int)threadIdx.x + j * THREADS < per ? res2[o[j]] : 0.f;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) e[j] += e2[j];
+  }
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int i = (int)threadIdx.x + j * THREADS;
     if (i < per) {
       float r = fmaf(sc, v[j], sft);
       if (act) r = act_f(r, act);
-      if (res1) r += res1[o[j]];
-      if (res2) r += res2[o[j]];
-      z[o[j]] = r;
+      z[o[j]] = r + e[j];
     }
   }
 }
