@@ -371,7 +371,7 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
                     "graph_replay_error": graph_error, "batch": tb,
                     "positions_per_s": tb / dt,
                     "note": "forward (batch-statistics BatchNorm, dropout) + backward + clip + Adam on pre-encoded windows; eager = 20 steps "
-                            "of the plain Python loop (one C call per direction, mural_indel_train_forward / _backward: ~385 launches incl. torch's loss / clip / Adam, device-bound), "
+                            "of the plain Python loop (one C call per direction, mural_indel_train_forward / _backward: ~320 launches incl. torch's loss / clip / Adam, device-bound), "
                             "graph replay = 40 replays of the same step as one HIP graph (GraphedIndelTrainStep, inputs copied in per step: "
                             "bound by the device alone); ms_per_step is the faster of the two",
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,

@@ -440,6 +440,21 @@ def test_generic_conv1d_kernels_match_torch_fp64():
     assert "worst" in out.stdout
 
 
+def test_mfma_weight_gradient_matches_torch_fp64():
+    """The weight / bias gradient of the general Conv1d on the matrix cores (csrc/conv_wgrad_mfma.hip: interior groups with both
+    operands straight from global memory, gathered edge segments) against torch's conv gradients in float64: the U-Net's layer
+    geometries (strides 4 / 5 / 2, upsampling 2 / 4, k = 7 / 5 / 3 / 1, 4..96 channels), rows of 4..8000 columns -- rows that are
+    all edge, rows with leftover segments, ragged rows -- and batches that do not fill the last group."""
+    import os
+    import subprocess
+    import sys
+    tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_debug_wgrad.py")
+    env = {k: v for k, v in os.environ.items() if k not in ("TIME", "MURAL_WGRAD_MFMA")}
+    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+    assert "worst" in out.stdout
+
+
 @pytest.mark.parametrize("L", [16000, 64000])
 def test_long_windows_match_oracle(L):
     """The reference advertises INDEL inputs of up to 64 kb (CHANGELOG:13): the human-insertion geometry at L = 16000 and 64000

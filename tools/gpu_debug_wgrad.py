@@ -8,8 +8,10 @@ from mural_amd.model.indel_train import Conv
 cases = [(3, 4, 8, 7, 1, 3, 1, 500), (2, 8, 16, 7, 4, 3, 1, 501), (2, 32, 40, 7, 5, 3, 1, 77), (5, 40, 48, 7, 2, 3, 1, 4),
          (2, 48, 40, 7, 1, 3, 2, 9), (2, 16, 8, 7, 1, 3, 4, 130), (3, 48, 96, 5, 1, 2, 1, 70), (3, 96, 48, 1, 1, 0, 1, 70),
          (1, 4, 4, 7, 1, 3, 1, 2000), (4, 8, 16, 5, 1, 2, 1, 8000), (4, 16, 8, 1, 1, 0, 1, 8000), (3, 24, 48, 5, 1, 2, 1, 400),
-         (3, 40, 80, 5, 1, 2, 1, 80), (7, 80, 40, 1, 1, 0, 1, 16), (7, 48, 96, 5, 1, 2, 1, 4), (2, 8, 8, 1, 1, 0, 1, 8000)]
+         (3, 40, 80, 5, 1, 2, 1, 80), (7, 80, 40, 1, 1, 0, 1, 16), (7, 48, 96, 5, 1, 2, 1, 4), (2, 8, 8, 1, 1, 0, 1, 8000),
+         (5, 16, 32, 5, 1, 2, 1, 2000), (3, 4, 4, 7, 1, 3, 1, 8000), (2, 32, 16, 3, 1, 1, 1, 1040), (9, 8, 20, 5, 1, 2, 1, 48)]
 rng = torch.Generator().manual_seed(5)
+worst = 0.0
 for B, Cin, Cout, K, stride, pad, up, L in cases:
     x = torch.randn((B, Cin, L), generator=rng)
     w = torch.randn((Cout, Cin, K), generator=rng) / (Cin * K) ** 0.5
@@ -23,8 +25,13 @@ for B, Cin, Cout, K, stride, pad, up, L in cases:
     yd = Conv.apply(xd, wd, bd, stride, pad, up)
     yd.backward(g.cuda())
     rel = lambda got, want: float((got.cpu().double() - want).abs().max() / max(1.0, float(want.abs().max())))
-    print((B, Cin, Cout, K, stride, pad, up, L), "dW %.2e db %.2e" % (rel(wd.grad, wr.grad), rel(bd.grad, br.grad)), flush=True)
+    ew, eb = rel(wd.grad, wr.grad), rel(bd.grad, br.grad)
+    worst = max(worst, ew if ew == ew else 1.0, eb if eb == eb else 1.0)
+    print((B, Cin, Cout, K, stride, pad, up, L), "dW %.2e db %.2e" % (ew, eb), flush=True)
+print("worst %.2e" % worst)
 
+if worst > 2e-6:
+    sys.exit(1)
 if os.environ.get("TIME"):
     from mural_amd.model import train_ops as T
     shapes = [(128, 8, 16, 5, 1, 2, 1, 8000), (128, 16, 8, 1, 1, 0, 1, 8000), (128, 4, 8, 7, 1, 3, 1, 8000), (128, 16, 32, 5, 1, 2, 1, 2000),
