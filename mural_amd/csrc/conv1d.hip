@@ -181,18 +181,23 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   MURAL_REQUIRE(a.up >= 1 && a.stride >= 1 && a.K >= 1, "conv1d: bad geometry");
   static const bool use_mfma = !(getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 0);   // A/B switch of the tools
   // measured at 2048 rows (tools/gpu_debug_conv1d.py): the implicit GEMM wins on short rows (<= 128 columns: 2-4 x) and on long
-  // rows with a deep reduction (Cin * K >= 224); long rows with few input channels are bound by the output stream and the direct
+  // rows with a deep reduction (Cin * K >= 224 then; >= 160 since the MFMA kernel stopped waiting per element: 24 -> 32 k7 at 400 columns
+  // 144 -> 66 us); long rows with few input channels are bound by the output stream and the direct
   // kernel's 64-column tiles keep more of them in flight.  A small launch (a training batch of 128 rows at the U-Net's 400-column
   // level: the direct kernel's 256-column tiles make 256 workgroups of a 70 us chain each) goes to the implicit GEMM too, and so do
   // the upsampling convs with a medium reduction (measured on the training step, tools/r4_step_classes.py: 74 -> 22, 30 -> 17, 55 -> 42 us).
   // long rows, few channels, several taps at stride 1: the barrier-free kernel (neither tiled kernel covers its stage / compute /
   // store phases on these; measured on the training step: 35-53 us -> see DESIGN.md)
   static const bool use_direct = !(getenv("MURAL_CONV1D_DIRECT") && atoi(getenv("MURAL_CONV1D_DIRECT")) == 0);
-  if (use_direct && use_mfma && (int64_t)a.B * a.Lout > 128 * 512 && a.Lout > 512 && conv1d_direct_supported(a)) return launch_conv1d_direct(a, stream);
+  // (measured at 2048 rows too, tools/gpu_debug_conv1d.py: 16 -> 20 k7 at 517 columns 258 / 188 / 159 us valu / mfma / direct, 4 -> 32 k7
+  // at 600 columns 83 / 114 / 50; three taps fill 3 of its 8 tap slots and lose to the vector ALU)
+  if (use_direct && use_mfma && a.K >= 5 && (int64_t)a.B * a.Lout >= 32768 && a.Lout >= 64 && conv1d_direct_supported(a))
+    return launch_conv1d_direct(a, stream);
   static const bool all_mfma = getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 2;
   const bool small_launch = (int64_t)a.B * a.Lout <= 128 * 512 && a.Lout <= 512;
   if (use_mfma && conv1d_mfma_supported(a) &&
-      (all_mfma || a.Lout <= 128 || a.Cin * a.K >= 224 || small_launch || (a.up > 1 && a.Cin * a.K >= 128 && (int64_t)a.B * a.Lout <= 128 * 2048)))
+      (all_mfma || a.Lout <= 128 || a.Cin * a.K >= 160 || small_launch || (a.up > 1 && a.Cin * a.K >= 128 && (int64_t)a.B * a.Lout <= 128 * 2048) ||
+       (a.Cin * a.K >= 96 && a.Cout >= 32 && a.Lout <= 1024)))
     return launch_conv1d_mfma(a, stream);
   return launch_conv1d_valu(a, stream);
 }

@@ -731,13 +731,40 @@ __global__ void linear_bwd_x_kernel(const float* __restrict__ dy, const float* _
 }
 
 // contiguous global -> LDS copy by a 256-thread workgroup (float4 when the source is 16-byte aligned), zero fill up to `pad`
+// (eight loads of a thread in flight per round, index clamped instead of a branch around the load: the one-load-per-iteration loop
+// waited out a global round trip per 4 KB -- 30 rounds for a 120 KB weight matrix, most of the dense kernels' 30-80 us)
 __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict__ src, int n, int pad, int tid) {
+  constexpr int UN = 8;
   if ((reinterpret_cast<uintptr_t>(src) & 15) == 0) {
     const int n4 = n >> 2;
-    for (int i = tid; i < n4; i += 256) reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[i];
+    for (int i0 = tid; i0 < n4; i0 += 256 * UN) {
+      float4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        v[u] = reinterpret_cast<const float4*>(src)[i < n4 ? i : n4 - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < n4) reinterpret_cast<float4*>(dst)[i] = v[u];
+      }
+    }
     for (int i = 4 * n4 + tid; i < n; i += 256) dst[i] = src[i];
   } else {
-    for (int i = tid; i < n; i += 256) dst[i] = src[i];
+    for (int i0 = tid; i0 < n; i0 += 256 * UN) {
+      float v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        v[u] = src[i < n ? i : n - 1];
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int i = i0 + 256 * u;
+        if (i < n) dst[i] = v[u];
+      }
+    }
   }
   for (int i = n + tid; i < pad; i += 256) dst[i] = 0.f;
 }
@@ -746,7 +773,7 @@ __device__ __forceinline__ void copy_to_lds(float* dst, const float* __restrict_
 // Wm(k, n) = W[n][k] (trans = 0: forward, W is [N][K]) or W[k][n] (trans = 1: input gradient, W is [K][N]).  The whole weight
 // matrix and the x tile are copied linearly into LDS; wave w owns rows 16w..16w+15 (A fragments in registers, K <= 256) and
 // walks the 16-column output blocks: D[16 rows][16 outputs] += x[16][4] * Wm[4][16] per v_mfma_f32_16x16x4_f32.
-constexpr int LIN_MAXK = 256;
+constexpr int LIN_MAXK = 256, LIN_MAXNT = 16;
 __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restrict__ x, const float* __restrict__ W, int trans,
                                                           const float* __restrict__ bias, int64_t B, int K, int N,
                                                           float* __restrict__ y) {
@@ -769,10 +796,23 @@ __global__ __launch_bounds__(256) void linear_mfma_kernel(const float* __restric
     const int k = 4 * s + kk;
     af[s] = (s < ksteps && k < K) ? xs[(16 * wave + n16) * K + k] : 0.f;
   }
-  for (int nt = 0; 16 * nt < N; ++nt) {
+  // the bias of every output block up front (N <= 16 x LIN_MAXNT columns; a load per block inside the loop is a round trip per block)
+  float bvs[LIN_MAXNT];
+#pragma unroll
+  for (int t = 0; t < LIN_MAXNT; ++t) bvs[t] = 0.f;
+  if (bias) {
+#pragma unroll
+    for (int t = 0; t < LIN_MAXNT; ++t) {
+      const int n = 16 * t + n16;
+      bvs[t] = bias[n < N ? n : 0];
+    }
+  }
+#pragma unroll
+  for (int nt = 0; nt < LIN_MAXNT; ++nt) {
+    if (16 * nt >= N) break;
     const int n = 16 * nt + n16;
     const bool nv = n < N;
-    const float bv = (bias && nv) ? bias[n] : 0.f;
+    const float bv = nv ? bvs[nt] : 0.f;
     f32x4_t acc = {bv, bv, bv, bv};
     const float* wcol = ws + (trans ? n : n * K);
     const int kstride = trans ? N : 1;
@@ -1230,7 +1270,7 @@ int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int
 
 static bool linear_tile_fits(int K, int N, size_t* lds) {
   *lds = ((size_t)((K * N + 3) & ~3) + (size_t)64 * K) * sizeof(float);
-  return *lds <= 150 * 1024 && K <= LIN_MAXK;
+  return *lds <= 150 * 1024 && K <= LIN_MAXK && N <= 16 * LIN_MAXNT;
 }
 
 static int launch_linear_tile(const float* x, const float* W, int trans, const float* bias, int64_t B, int K, int N,

@@ -5,16 +5,49 @@
 It exists for completeness of the drop-in (any ``model_choice`` configuration evaluates); every shipped checkpoint and the
 benchmark configuration take the fused path in ``model_snv.py``.  No CPU path here either.
 """
+import weakref
+
 import torch
 
 from . import train_ops as T
 
+# Per-module caches of what an eval-mode forward derives from the parameters: the BatchNorm affines and the conv weights in the
+# kernels' [Cin][K][Cout] layout.  Keyed by the module, validated by the tensors' version counters (an optimiser step, a
+# load_state_dict or a running-statistics update bumps them) and their storage: recomputing them per call was 5 tiny launches per
+# BatchNorm and a relayout launch per conv -- most of the launches of this path.
+_affine_cache = weakref.WeakKeyDictionary()
+_wt_cache = weakref.WeakKeyDictionary()
+
+
+def _stamp(*ts):
+    return tuple((t.data_ptr(), t._version, t.device) for t in ts)
+
 
 def _affine(bn):
     """eval-mode BatchNorm as y = scale * x + shift"""
+    key = _stamp(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    hit = _affine_cache.get(bn)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
     scale = (bn.weight.detach() / torch.sqrt(bn.running_var + bn.eps)).to(torch.float32).contiguous()
     shift = (bn.bias.detach() - bn.running_mean * scale).to(torch.float32).contiguous()
+    _affine_cache[bn] = (key, scale, shift)
     return scale, shift
+
+
+def _weights(conv):
+    """(wt, bias): the conv weight re-laid-out as [Cin][K][Cout] (mural_op_relayout), cached per module"""
+    key = _stamp(conv.weight) + (() if conv.bias is None else _stamp(conv.bias))
+    hit = _wt_cache.get(conv)
+    if hit is not None and hit[0] == key:
+        return hit[1], hit[2]
+    w = T._f32(conv.weight.detach())
+    Cout, Cin, K = w.shape
+    wt = torch.empty(w.numel(), device=w.device)
+    T._call("mural_op_relayout", w, wt, Cout, Cin, K, 0, T._stream(w))
+    bias = None if conv.bias is None else T._f32(conv.bias.detach()).clone()
+    _wt_cache[conv] = (key, wt, bias)
+    return wt, bias
 
 
 def _bn(x, bn, relu):
@@ -44,6 +77,30 @@ def _conv(x, conv):
     return y
 
 
+def _bn_conv(x, bn, pre_relu, conv, post_relu=False, res1=None, res2=None):
+    """conv(BN(relu?(x))) [ReLU] [+ res1] [+ res2] in ONE launch when the conv is a stride-1 'same' conv (mural_op_conv1d applies the
+    BatchNorm affine -- after the optional ReLU, before the zero padding, like nn.Conv1d behind a BatchNorm1d -- while it stages its
+    input tile, and the residuals in its epilogue); the separate launches otherwise."""
+    Cout, Cin, K = conv.weight.shape
+    same = int(conv.stride[0]) == 1 and int(conv.dilation[0]) == 1 and int(conv.padding[0]) == (K - 1) // 2 and K % 2 == 1
+    if not (same and Cout % 4 == 0 and x.dim() == 3):
+        y = _conv(_bn(x, bn, pre_relu), conv)
+        if post_relu:
+            y = _relu(y)
+        for r in (res1, res2):
+            if r is not None:
+                y = y + r
+        return y
+    x = x.contiguous()
+    B, _, L = x.shape
+    scale, shift = _affine(bn)
+    wt, bias = _weights(conv)
+    y = torch.empty((B, Cout, L), device=x.device)
+    T._call("mural_op_conv1d", x, wt, bias, y, B, Cin, Cout, L, K, scale, shift, int(pre_relu), int(post_relu),
+            None if res1 is None else res1.contiguous(), None if res2 is None else res2.contiguous(), T._stream(x))
+    return y
+
+
 def _relu(x):
     y = torch.empty_like(x)
     T._call("mural_op_act_fwd", x, x.numel(), 1, y, T._stream(x))
@@ -70,21 +127,22 @@ def _linear(x, lin):
 
 def _res_blocks(rbs, x):
     out = x
-    for rb in rbs:                       # ResBlock (model_snv.py:794-812): x + conv2(bn2(relu(conv1(bn1(relu(x))))))
-        h = _conv(_bn(out, rb.bn1, True), rb.conv1)
-        h = _conv(_bn(h, rb.bn2, True), rb.conv2)
-        out = out + h
-    return out + x                       # the outer skip (model_snv.py:477-479)
+    n = len(rbs)
+    for i, rb in enumerate(rbs):         # ResBlock (model_snv.py:794-812): x + conv2(bn2(relu(conv1(bn1(relu(x))))))
+        h = _bn_conv(out, rb.bn1, True, rb.conv1)
+        # the block's own skip rides in the second conv's epilogue, and so does the outer skip (model_snv.py:477-479) on the last block
+        out = _bn_conv(h, rb.bn2, True, rb.conv2, res1=out, res2=x if i == n - 1 else None)
+    return out if n else x + x
 
 
 def tower(mod, sfx, x, pools):
     g = lambda n: getattr(mod, n + sfx)  # noqa: E731
-    out = _pool(_conv(_bn(x, g("conv1")[0], False), g("conv1")[1]), *pools[0])
+    out = _pool(_bn_conv(x, g("conv1")[0], False, g("conv1")[1]), *pools[0])
     out = _pool(_res_blocks(g("RBs1"), out), *pools[1])
-    out = _conv(_bn(out, g("conv2")[0], False), g("conv2")[1])
+    out = _bn_conv(out, g("conv2")[0], False, g("conv2")[1])
     out = _pool(_res_blocks(g("RBs2"), out), *pools[2])
     assert out.shape[2] >= 1, "Error: distal seq is too short for the pooling layers"
-    out = _relu(_conv(_bn(out, g("conv3")[0], False), g("conv3")[1]))
+    out = _bn_conv(out, g("conv3")[0], False, g("conv3")[1], post_relu=True)
     feat = _pool(out, out.shape[2], out.shape[2], 0).reshape(out.shape[0], out.shape[1])
     fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
     return _linear(_bn(feat, fc[0], False), fc[2])
