@@ -265,7 +265,7 @@ int mural_op_bnconv32_bwd(const float* dy, const float* x, int64_t B, int32_t L,
                           const float* add1, const float* add2, float* dW, float* db, float* dx, float* dgamma, float* dbeta,
                           void* stream);
 int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int32_t k, int32_t s, int32_t p, float* y,
-                         int32_t* arg, void* stream);
+                         int32_t* arg /* argmax positions for the backward; may be NULL (inference) */, void* stream);
 int mural_op_maxpool_bwd_needs_zero(int32_t k, int32_t s);   /* 1: dx must be zeroed by the caller (overlapping windows) */
 int mural_op_maxpool_bwd(const float* dy, const int32_t* arg, int64_t rows, int32_t L, int32_t Lout, int32_t k, int32_t s,
                          int32_t p, float* dx, void* stream);

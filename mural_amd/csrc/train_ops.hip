@@ -373,7 +373,7 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(const float* __restr
 
 // ------------------------------------------------------------------------------------------- pooling
 __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int64_t rows, int L, int Lout, int k, int s, int p,
-                                   float* __restrict__ y, int32_t* __restrict__ arg) {
+                                   float* __restrict__ y, int32_t* __restrict__ arg /* optional */) {
   const int64_t total = rows * Lout;
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / Lout;
@@ -381,14 +381,33 @@ __global__ void maxpool_fwd_kernel(const float* __restrict__ x, int64_t rows, in
     const float* xr = x + r * L;
     float m = -INFINITY;
     int am = -1;
-    for (int w = 0; w < k; ++w) {
-      const int l = lo * s - p + w;
-      if (l < 0 || l >= L) continue;
-      const float v = xr[l];
-      if (v > m || am < 0) { m = v; am = l; }    // first maximum wins, like torch
+    if (k <= 16) {
+      // the window's loads together (index clamped, validity applied afterwards): a load behind `if (in range)` carries a full wait of
+      // its own -- fifteen serial round trips per output on the towers' first pool
+      float v[16];
+      const int l0 = lo * s - p;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const int l = l0 + w;
+        const bool ok = (w < k) & (l >= 0) & (l < L);
+        v[w] = xr[ok ? l : 0];
+      }
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        const int l = l0 + w;
+        const bool ok = (w < k) & (l >= 0) & (l < L);
+        if (ok && (v[w] > m || am < 0)) { m = v[w]; am = l; }      // first maximum wins, like torch
+      }
+    } else {
+      for (int w = 0; w < k; ++w) {
+        const int l = lo * s - p + w;
+        if (l < 0 || l >= L) continue;
+        const float v = xr[l];
+        if (v > m || am < 0) { m = v; am = l; }    // first maximum wins, like torch
+      }
     }
     y[i] = m;
-    arg[i] = am;
+    if (arg) arg[i] = am;
   }
 }
 
@@ -418,7 +437,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_wide_kernel(const float* __re
     }
     if (lane == 0) {
       y[i] = m;
-      arg[i] = am == INT_MAX ? -1 : am;
+      if (arg) arg[i] = am == INT_MAX ? -1 : am;
     }
   }
 }

@@ -112,8 +112,7 @@ def _pool(x, k, s, p):
     B, Cn, L = x.shape
     Lout = (L + 2 * p - k) // s + 1
     y = torch.empty((B, Cn, Lout), device=x.device)
-    arg = torch.empty((B, Cn, Lout), dtype=torch.int32, device=x.device)
-    T._call("mural_op_maxpool_fwd", x, B * Cn, L, k, s, p, y, arg, T._stream(x))
+    T._call("mural_op_maxpool_fwd", x, B * Cn, L, k, s, p, y, None, T._stream(x))      # (no argmax: nothing is differentiated here)
     return y
 
 
