@@ -90,6 +90,7 @@ struct Stage1Args {               // snv_stage1_kernel: window decode + first co
   const int64_t* loc_cat;         // [n][loc.cols] k-mer ids
   float* loc_out;                 // [n][n_class] logits
   int* zero;                      // small-batch launch: n ints cleared for the tower launch behind it (SnvFwdArgs::tile_count), or nullptr
+  int site_mode;                  // 1: the workgroup-per-site kernel at any batch size (long windows: sixteen per-wave windows do not fit LDS)
 };
 
 // training-mode first layer of ONE tower (snv_stage1.hip: first_train_kernel)
@@ -213,4 +214,13 @@ struct MuralSnvModel {
   bool loc_fused;
   mural::LocalMfmaDims loc_d;
   size_t loc_lds;
+  // Long windows (pooled first-stage rows of the large tower longer than a wave's LDS image: distal_radius 2000, 4000, ...): the first
+  // conv stage of the large tower runs on SEGMENTS of the pooled row -- virtual rows of lw_LA (lw_nA per site, starts 0, 7 lw_nj,
+  // 14 lw_nj, ...) and lw_LB columns (one per site, start lw_SB, ending at the row's end) with 4 halo columns towards the row's
+  // interior, gathered from x0 into scratch; their pooled outputs are scattered into s3[0] and the short stages run on whole rows.
+  bool longwin;
+  int lw_nA, lw_LA, lw_LB, lw_SB, lw_nj;
+  mural::SnvFwdArgs args_lwA, args_lwB;
+  size_t lds_lwA, lds_lwB;
+  int64_t chunk;                  // sites per stage-1 / tower launch sequence (SNV_CHUNK, less for long windows)
 };

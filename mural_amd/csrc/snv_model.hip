@@ -283,7 +283,8 @@ constexpr size_t kLdsMax = 160 * 1024;
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
-struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; float* s3[2]; int* counters; };
+struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; float* s3[2]; int* counters;
+                   float *vx0A, *vx0B, *vs3A, *vs3B; };      // long windows: the segments' inputs and pooled outputs
 
 size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
   size_t off = 0;
@@ -298,11 +299,19 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
   const size_t o_ll = take((size_t)n * m->shape.n_class * 4);
   const size_t o_cat = take((size_t)n * std::max(m->shape.local_cols, 1) * 8);
   const size_t o_sym = take(dense ? (size_t)n * m->shape.distal_len : 16);
-  const size_t o_x0 = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.x0_cols, 1) * SNV_C * 4);
-  const size_t o_xl = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * SNV_MAXCLASS * 4);
-  const size_t o_s3l = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
-  const size_t o_s3m = take((size_t)std::min<int64_t>(n, SNV_CHUNK) * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
-  const size_t o_cnt = take(64);      // unit counters of the four wave-private launches of a chunk (SnvFwdArgs::unit_counter)
+  const size_t o_x0 = take((size_t)std::min<int64_t>(n, m->chunk) * std::max(m->args.x0_cols, 1) * SNV_C * 4);
+  const size_t o_xl = take((size_t)std::min<int64_t>(n, m->chunk) * SNV_MAXCLASS * 4);
+  const size_t o_s3l = take((size_t)std::min<int64_t>(n, m->chunk) * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
+  const size_t o_s3m = take((size_t)std::min<int64_t>(n, m->chunk) * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
+  const size_t o_cnt = take(64);      // unit counters of the wave-private launches of a chunk (SnvFwdArgs::unit_counter)
+  size_t o_vxa = 0, o_vxb = 0, o_vsa = 0, o_vsb = 0;
+  if (m->longwin) {
+    const size_t cn = (size_t)std::min<int64_t>(n, m->chunk);
+    o_vxa = take(cn * m->lw_nA * m->lw_LA * SNV_C * 4);
+    o_vxb = take(cn * m->lw_LB * SNV_C * 4);
+    o_vsa = take(cn * m->lw_nA * m->args_lwA.geom[0].L[1] * SNV_C * 4);
+    o_vsb = take(cn * m->args_lwB.geom[0].L[1] * SNV_C * 4);
+  }
   if (w) {
     char* b = static_cast<char*>(base);
     w->local_logits = reinterpret_cast<float*>(b + o_ll);
@@ -313,8 +322,66 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
     w->s3[0] = reinterpret_cast<float*>(b + o_s3l);
     w->s3[1] = reinterpret_cast<float*>(b + o_s3m);
     w->counters = reinterpret_cast<int*>(b + o_cnt);
+    w->vx0A = reinterpret_cast<float*>(b + o_vxa);
+    w->vx0B = reinterpret_cast<float*>(b + o_vxb);
+    w->vs3A = reinterpret_cast<float*>(b + o_vsa);
+    w->vs3B = reinterpret_cast<float*>(b + o_vsb);
   }
   return off;
+}
+
+// ---- long windows: segments of the large tower's pooled first-stage row (MuralSnvModel::longwin) -------------------------------
+// columns are 32 floats = 128 bytes: a thread moves 16 bytes, 8 threads a column
+// vx[(site * nseg + k)][c][32] = x0[site][start0 + k * step + c][32]
+__global__ void lw_gather_kernel(const float* __restrict__ x0, int64_t n, int x0_cols, int nseg, int start0, int step, int Lseg,
+                                 float* __restrict__ vx) {
+  const int64_t total = n * nseg * Lseg * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 7);
+    const int64_t col = i >> 3;
+    const int c = (int)(col % Lseg);
+    const int64_t row = col / Lseg;
+    const int k = (int)(row % nseg);
+    const int64_t site = row / nseg;
+    const float4 v = reinterpret_cast<const float4*>(x0 + ((size_t)site * x0_cols + start0 + (size_t)k * step + c) * SNV_C)[q];
+    reinterpret_cast<float4*>(vx + (size_t)col * SNV_C)[q] = v;
+  }
+}
+// s3[site][j][32] for j in [j_lo, j_hi): from segment k = (j - jbase) / nj (clamped to nseg - 1), local pooled column jl = j - k * nj
+__global__ void lw_scatter_kernel(const float* __restrict__ vs, int64_t n, int nseg, int Lp /* pooled columns of a segment */, int nj, int j_lo,
+                                  int j_hi, int jl_shift, int L3, float* __restrict__ s3) {
+  const int span = j_hi - j_lo;
+  const int64_t total = n * span * 8;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int q = (int)(i & 7);
+    const int64_t col = i >> 3;
+    const int j = j_lo + (int)(col % span);
+    const int64_t site = col / span;
+    // segment 0 owns outputs 0 .. nj (its left edge is the row's), segment k >= 1 owns k nj + 1 .. k nj + nj
+    int k = j <= nj ? 0 : (j - 1) / nj;
+    if (k > nseg - 1) k = nseg - 1;
+    const int jl = j - k * nj + jl_shift;
+    const float4 v = reinterpret_cast<const float4*>(vs + (((size_t)site * nseg + k) * Lp + jl) * SNV_C)[q];
+    reinterpret_cast<float4*>(s3 + ((size_t)site * L3 + j) * SNV_C)[q] = v;
+  }
+}
+
+// the launch-independent part of a tower geometry (what stage 1 and the workspace need)
+void fill_tower_lengths(SnvFwdArgs& a, int Lwin) {
+  static const int pools[2][3][3] = {{{15, 15, 7}, {7, 7, 3}, {3, 3, 1}}, {{3, 3, 1}, {3, 3, 1}, {3, 3, 1}}};
+  for (int tw = 0; tw < 2; ++tw) {
+    TowerGeom& g = a.geom[tw];
+    g.L1 = tw == 0 ? Lwin : 2 * SNV_MID_HALF + 1;
+    g.col0 = tw == 0 ? 0 : Lwin / 2 - SNV_MID_HALF;
+    int L = g.L1;
+    for (int i = 0; i < 3; ++i) {
+      g.pk[i] = pools[tw][i][0]; g.ps[i] = pools[tw][i][1]; g.pp[i] = pools[tw][i][2];
+      L = pool_len(L, g.pk[i], g.ps[i], g.pp[i]);
+      g.L[i] = L;
+    }
+  }
+  a.Lwin = Lwin;
+  a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
 }
 
 }  // namespace
@@ -361,10 +428,93 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class);
         if (need && need <= kLdsMax) { P = cand; lds = need; }
       }
+      // (tower, phase) launch q of the split mode: the largest workgroup tile that keeps two workgroups per CU, then the wave-private
+      // form where it applies
+      auto plan_part = [&](int q) -> bool {
+        const int towers = (q & 1) ? 2 : 1, phase = q < 2 ? 1 : 2;
+        int Pq = 0, Pmax = 32;
+        if (const char* e = getenv("MURAL_DEBUG_SPLIT_P")) {   // diagnostic: "P0,P1,P2,P3" caps the tile sizes
+          int v[4] = {32, 32, 32, 32};
+          sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
+          if (v[q] >= 1) Pmax = v[q];
+        }
+        for (int cand = Pmax; cand >= 1 && !Pq; --cand) {
+          SnvFwdArgs tmp;
+          const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, towers, phase);
+          if (need && need <= kLdsTwoPerCu) { Pq = cand; m->lds_split[q] = need; }
+        }
+        if (!Pq) return false;
+        if (phase == 2) {   // prefer a tile whose long stage splits into full block pairs for both waves (nb % 4 == 0)
+          for (int cand = Pq; cand >= Pq - 2 && cand >= 1; --cand) {
+            SnvFwdArgs tmp;
+            const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, towers, phase);
+            if (need && tmp.geom[q & 1].nb[1] % 4 == 0) { Pq = cand; m->lds_split[q] = need; break; }
+          }
+        }
+        plan_geometry(m->args_split[q], sh.distal_len, Pq, sh.n_class, towers, phase);
+        // Wave-private form of this launch (snv_tower_wave.hip): the most sites per wave that keep a wave within its nine
+        // blocks and two four-wave workgroups on a CU.  MURAL_DEBUG_TOWER_WAVE = bit mask of the launches that may take it
+        // (default: all four); 0 keeps the workgroup-tile kernel everywhere (A/B runs).
+        int wave_mask = 15;
+        if (const char* e = getenv("MURAL_DEBUG_TOWER_WAVE")) wave_mask = atoi(e);
+        if ((wave_mask >> q) & 1) {
+          for (int cand = 31; cand >= 1; --cand) {
+            SnvFwdArgs tmp;
+            std::memset(&tmp, 0, sizeof(tmp));
+            const size_t need = plan_wave_geometry(tmp, sh.distal_len, cand, sh.n_class, q & 1, phase);
+            if (need && need <= kLdsTwoPerCu) {
+              m->args_split[q] = tmp;
+              m->lds_split[q] = need;
+              break;
+            }
+          }
+        }
+        return true;
+      };
+      m->chunk = SNV_CHUNK;
+      m->longwin = false;
+      if (!getenv("MURAL_DEBUG_NO_LONGWIN")) {      // (tried first: a row of 143 .. ~270 columns also fits ONE workgroup tile per CU, slowly)
+        // Long window: the large tower's pooled first-stage row (L2 columns) does not fit a wave's image.  Its first conv stage --
+        // four k=3 convs, then a 7-wide pool -- runs on segments with 4 halo columns: lw_nA segments of 7 nj + 8 columns starting at
+        // 0, 7 nj, 14 nj, ... (a start that is a multiple of the pool stride keeps the segment's pool windows on the row's; the first
+        // pooled column of a later segment is halo and dropped) and one that ends with the row.  Everything behind -- the short stages
+        // of the large tower on whole rows, the mid tower, the head -- runs as in the split mode.
+        SnvFwdArgs probe;
+        std::memset(&probe, 0, sizeof(probe));
+        fill_tower_lengths(probe, sh.distal_len);
+        const int L2 = probe.geom[0].L[0], nj = 19, LA = 7 * nj + 8;
+        if (L2 > LA && probe.geom[0].pk[1] == 7 && probe.geom[0].ps[1] == 7 && probe.geom[0].pp[1] == 3) {
+          int nA = 0;
+          while (7 * nj * nA + LA <= L2) ++nA;
+          const int SB = 7 * ((L2 - 142 + 6) / 7), LB = L2 - SB;      // 136 .. 142 columns, start <= 7 nj nA
+          bool ok = nA >= 1 && LB >= 127 && LB <= 142 && SB <= 7 * nj * nA && SB >= 0;
+          if (ok) {
+            std::memset(&m->args_lwA, 0, sizeof(SnvFwdArgs));
+            std::memset(&m->args_lwB, 0, sizeof(SnvFwdArgs));
+            m->lds_lwA = plan_wave_geometry(m->args_lwA, 15 * (LA - 1) + 1, 1, sh.n_class, 0, 1);
+            m->lds_lwB = plan_wave_geometry(m->args_lwB, 15 * (LB - 1) + 1, 1, sh.n_class, 0, 1);
+            ok = m->lds_lwA && m->lds_lwA <= kLdsTwoPerCu && m->lds_lwB && m->lds_lwB <= kLdsTwoPerCu &&
+                 m->args_lwA.geom[0].L[0] == LA && m->args_lwB.geom[0].L[0] == LB;
+          }
+          for (int q = 1; q < 4 && ok; ++q) ok = plan_part(q);
+          if (ok) {
+            m->longwin = true;
+            m->split = true;
+            m->lw_nA = nA; m->lw_LA = LA; m->lw_LB = LB; m->lw_SB = SB; m->lw_nj = nj;
+            m->args_lwA.x0_cols = LA;
+            m->args_lwB.x0_cols = LB;
+            fill_tower_lengths(m->args, sh.distal_len);
+            m->lds_bytes = 0;
+            m->chunk = 8192;      // x0 + segment scratch: ~150 KB per site at R = 4000
+            P = -1;
+          }
+        }
+      }
       if (!P) {
         set_error("distal_radius %d is too long for the LDS-resident tower kernel", (sh.distal_len - 1) / 2);
         rc = MURAL_E_INVALID;
       } else {
+        if (P > 0) {
         plan_geometry(m->args, sh.distal_len, P, sh.n_class);
         m->lds_bytes = lds;
         // split mode: (tower, phase) pairs in their own launches, each with the largest tile that keeps two workgroups per
@@ -372,49 +522,11 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         m->split = false;
         if (lds <= kLdsTwoPerCu && !getenv("MURAL_DEBUG_NO_TOWER_SPLIT")) {
           bool ok = true;
-          for (int q = 0; q < 4 && ok; ++q) {
-            const int towers = (q & 1) ? 2 : 1, phase = q < 2 ? 1 : 2;
-            int Pq = 0, Pmax = 32;
-            if (const char* e = getenv("MURAL_DEBUG_SPLIT_P")) {   // diagnostic: "P0,P1,P2,P3" caps the tile sizes
-              int v[4] = {32, 32, 32, 32};
-              sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
-              if (v[q] >= 1) Pmax = v[q];
-            }
-            for (int cand = Pmax; cand >= 1 && !Pq; --cand) {
-              SnvFwdArgs tmp;
-              const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, towers, phase);
-              if (need && need <= kLdsTwoPerCu) { Pq = cand; m->lds_split[q] = need; }
-            }
-            if (!Pq) { ok = false; break; }
-            if (phase == 2) {   // prefer a tile whose long stage splits into full block pairs for both waves (nb % 4 == 0)
-              for (int cand = Pq; cand >= Pq - 2 && cand >= 1; --cand) {
-                SnvFwdArgs tmp;
-                const size_t need = plan_geometry(tmp, sh.distal_len, cand, sh.n_class, towers, phase);
-                if (need && tmp.geom[q & 1].nb[1] % 4 == 0) { Pq = cand; m->lds_split[q] = need; break; }
-              }
-            }
-            plan_geometry(m->args_split[q], sh.distal_len, Pq, sh.n_class, towers, phase);
-            // Wave-private form of this launch (snv_tower_wave.hip): the most sites per wave that keep a wave within its nine
-            // blocks and two four-wave workgroups on a CU.  MURAL_DEBUG_TOWER_WAVE = bit mask of the launches that may take it
-            // (default: all four); 0 keeps the workgroup-tile kernel everywhere (A/B runs).
-            int wave_mask = 15;
-            if (const char* e = getenv("MURAL_DEBUG_TOWER_WAVE")) wave_mask = atoi(e);
-            if ((wave_mask >> q) & 1) {
-              for (int cand = 31; cand >= 1; --cand) {
-                SnvFwdArgs tmp;
-                std::memset(&tmp, 0, sizeof(tmp));
-                const size_t need = plan_wave_geometry(tmp, sh.distal_len, cand, sh.n_class, q & 1, phase);
-                if (need && need <= kLdsTwoPerCu) {
-                  m->args_split[q] = tmp;
-                  m->lds_split[q] = need;
-                  break;
-                }
-              }
-            }
-          }
+          for (int q = 0; q < 4 && ok; ++q) ok = plan_part(q);
           m->split = ok;
         }
-        m->lds_small = plan_geometry(m->args_small, sh.distal_len, 1, sh.n_class);
+        }
+        m->lds_small = m->longwin ? 0 : plan_geometry(m->args_small, sh.distal_len, 1, sh.n_class);
         Stage1Args& s1 = m->s1;
         for (int tw = 0; tw < 2; ++tw) {
           const TowerGeom& g = m->args.geom[tw];
@@ -427,8 +539,12 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         s1.nwords = (sh.distal_len + 15) / 16 + 1;
         s1.radius = (sh.distal_len - 1) / 2;
         m->s1_lds_bytes = (size_t)2 * SNV_LUTBLK * 4 + (size_t)16 * s1.wave_bytes;
+        if (m->longwin) {      // one workgroup per site (snv_stage1_site_kernel): a single copy of the window and its index tables
+          s1.site_mode = 1;
+          m->s1_lds_bytes = (size_t)2 * SNV_LUTBLK * 4 + (size_t)s1.wave_bytes + 64;
+        }
         // the large tower's pair table rides along where it fits (15-wide pools: the shipped first max-pool)
-        m->s1_pair = s1.tw[0].pk == 15 && s1.tw[0].ps == 15 && m->s1_lds_bytes + (size_t)SNV_LUT4 * 4 <= kLdsMax &&
+        m->s1_pair = !s1.site_mode && s1.tw[0].pk == 15 && s1.tw[0].ps == 15 && m->s1_lds_bytes + (size_t)SNV_LUT4 * 4 <= kLdsMax &&
                      !getenv("MURAL_DEBUG_NO_PAIR_TABLE");
         if (m->s1_pair) m->s1_lds_bytes += (size_t)SNV_LUT4 * 4;
         if (m->s1_lds_bytes > kLdsMax || s1.tw[0].pk > 16 || s1.tw[1].pk > 4) {
@@ -467,6 +583,12 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
       a2.tw[1] = m->args.tw[1];
       a2.n_class = sh.n_class;
       a2.has_local = m->args.has_local;
+    }
+    for (SnvFwdArgs* a3 : {&m->args_lwA, &m->args_lwB}) {
+      a3->tw[0] = m->args.tw[0];
+      a3->tw[1] = m->args.tw[1];
+      a3->n_class = sh.n_class;
+      a3->has_local = m->args.has_local;
     }
     m->args_small.tw[0] = m->args.tw[0];
     m->args_small.tw[1] = m->args.tw[1];
@@ -527,8 +649,8 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
                       float* out, float* taps, const int32_t* status, hipStream_t stream) {
   const int nc = m->shape.n_class;
   const bool small = taps == nullptr && n <= SNV_SMALL_BATCH && m->lds_small > 0 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH");
-  for (int64_t c0 = 0; c0 < n; c0 += SNV_CHUNK) {
-    const int64_t cn = std::min<int64_t>(SNV_CHUNK, n - c0);
+  for (int64_t c0 = 0; c0 < n; c0 += m->chunk) {
+    const int64_t cn = std::min<int64_t>(m->chunk, n - c0);
     Stage1Args s = s1;
     s.n = cn;
     s.x0 = w.x0;
@@ -539,6 +661,40 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     const bool split = m->split && taps == nullptr && !small;   // the debug dump wants both towers in one tile geometry
     if (split) MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
     for (int part = 0; part < (split ? 4 : 1); ++part) {
+      if (m->longwin && part == 0) {
+        // the large tower's first conv stage on segments of the pooled row: gather (with halo) -> two wave-private launches (the
+        // lw_nA equal segments of every site, then the one that ends with the row) -> scatter of the pooled columns into s3[0]
+        const int LpA = m->args_lwA.geom[0].L[1], LpB = m->args_lwB.geom[0].L[1], L3 = m->args.geom[0].L[1], nj = m->lw_nj;
+        const int x0_cols = m->args.x0_cols;
+        auto grid_of = [](int64_t items) { return dim3((unsigned)std::min<int64_t>((items + 255) / 256, 65536)); };
+        hipLaunchKernelGGL(lw_gather_kernel, grid_of(cn * m->lw_nA * m->lw_LA * 8), dim3(256), 0, stream, w.x0, cn, x0_cols, m->lw_nA, 0,
+                           7 * nj, m->lw_LA, w.vx0A);
+        hipLaunchKernelGGL(lw_gather_kernel, grid_of(cn * m->lw_LB * 8), dim3(256), 0, stream, w.x0, cn, x0_cols, 1, m->lw_SB, 0, m->lw_LB,
+                           w.vx0B);
+        MURAL_HIP_CHECK(hipGetLastError());
+        for (int kind = 0; kind < 2; ++kind) {
+          SnvFwdArgs t = kind == 0 ? m->args_lwA : m->args_lwB;
+          t.n = kind == 0 ? cn * m->lw_nA : cn;
+          t.x0 = kind == 0 ? w.vx0A : w.vx0B;
+          t.s3[0] = kind == 0 ? w.vs3A : w.vs3B;
+          t.s3[1] = w.s3[1];
+          t.xlogit = w.xlogit;
+          t.local_logits = w.local_logits + c0 * nc;
+          t.out = out + c0 * nc;
+          t.taps = nullptr;
+          t.stamps = nullptr;
+          t.status = status;
+          t.unit_counter = w.counters + 4 + kind;
+          if (int rc = launch_snv_towers(m, t, kind == 0 ? m->lds_lwA : m->lds_lwB, stream)) return rc;
+        }
+        const int jA = m->lw_nA * nj + 1;      // outputs 0 .. nA nj come from the equal segments, the rest from the last one
+        hipLaunchKernelGGL(lw_scatter_kernel, grid_of(cn * jA * 8), dim3(256), 0, stream, w.vs3A, cn, m->lw_nA, LpA, nj, 0, jA, 0, L3, w.s3[0]);
+        if (L3 > jA)
+          hipLaunchKernelGGL(lw_scatter_kernel, grid_of(cn * (L3 - jA) * 8), dim3(256), 0, stream, w.vs3B, cn, 1, LpB, nj, jA, L3,
+                             -(m->lw_SB / 7), L3, w.s3[0]);
+        MURAL_HIP_CHECK(hipGetLastError());
+        continue;
+      }
       SnvFwdArgs t = split ? m->args_split[part] : (small ? m->args_small : a);
       t.s3[0] = w.s3[0];
       t.s3[1] = w.s3[1];
@@ -603,6 +759,7 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
   const bool direct = stage1_small_batch(n);
   if (!direct)
     if (int rc = launch_dense_to_symbols(distal_x, n, sh.distal_len, w.symbols, status, stream)) return rc;
+  if (taps) MURAL_REQUIRE(!m->longwin, "the layer dump is not available for long windows (segmented first stage)");
   if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * m->args.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * m->args.nbuf);
   Stage1Args s1 = m->s1;
   s1.codes = w.symbols;

@@ -10,6 +10,7 @@
 // Mapping: ONE WAVE PER SITE, 16 waves per workgroup sharing the two towers' tables in LDS (staged once per
 // workgroup, persistent grid).  No workgroup barrier in the site loop: a wave's LDS writes are consumed only by
 // itself, so four waves per SIMD hide each other's LDS latency.  Bound: LDS reads (256 KB of table rows per site).
+#include <algorithm>
 #include <cstdlib>
 
 #include "dense_symbol.h"
@@ -618,8 +619,9 @@ int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStr
   if (int rc = big_lds.ensure(&snv_stage1_kernel<0>, &snv_stage1_kernel<1>, &snv_stage1_site_kernel<0>, &snv_stage1_site_kernel<1>,
                               &snv_stage1_site_kernel<2>))
     return rc;
-  if (stage1_small_batch(a.n)) {     // latency-bound call: one workgroup per site (+ one for the local branch)
-    const unsigned grid = (unsigned)a.n + (a.loc_on ? 1u : 0u);
+  if (stage1_small_batch(a.n) || a.site_mode) {     // latency-bound call, or a window too long for sixteen per-wave copies: one
+                                                    // workgroup per site (+ one for the local branch of a small batch)
+    const unsigned grid = stage1_small_batch(a.n) ? (unsigned)a.n + (a.loc_on ? 1u : 0u) : (unsigned)std::min<int64_t>(a.n, 16384);
     if (!packed && a.dense != nullptr)
       hipLaunchKernelGGL(snv_stage1_site_kernel<2>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
     else if (packed) hipLaunchKernelGGL(snv_stage1_site_kernel<1>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);

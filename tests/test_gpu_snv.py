@@ -599,12 +599,17 @@ def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch
             assert len(zone) == guard and (zone == 255).all(), f"region {i} (dense={dense}): a kernel wrote behind its {size} bytes"
 
 
-@pytest.mark.parametrize("R,model_no", [(2000, 2), (4000, 2), (4000, 1)])
-def test_long_windows_match_oracle(R, model_no):
-    """Windows beyond the shipped radius (the reference advertises inputs of up to 64 kb, CHANGELOG:13): R = 2000 and R = 4000 are
-    beyond the LDS-resident kernels and take the per-layer HIP path (model/generic_eval.py).  Packed and
-    dense entry against the oracle fed by the oracle encoders, both strands, chromosome ends."""
+@pytest.mark.parametrize("R,model_no,fused", [(2000, 2, True), (4000, 2, True), (4000, 1, True), (3000, 2, True), (2000, 2, False), (4000, 1, False)])
+def test_long_windows_match_oracle(R, model_no, fused, monkeypatch):
+    """Windows beyond the shipped radius (the reference advertises inputs of up to 64 kb, CHANGELOG:13).  The pooled first-stage row of
+    the large tower (267 / 400 / 534 columns at R = 2000 / 3000 / 4000) does not fit a wave's LDS image: the fused path runs that
+    stage on segments with halo columns (MuralSnvModel::longwin, csrc/snv_model.hip) and the rest as usual; with
+    MURAL_DEBUG_NO_LONGWIN the C side refuses the shape and eval takes the per-layer HIP path (model/generic_eval.py).  Packed and
+    dense entry of both against the oracle fed by the oracle encoders, both strands, chromosome ends, a batch larger than one
+    segment launch's wave count."""
     from mural_amd.data import PackedGenome
+    if not fused:
+        monkeypatch.setenv("MURAL_DEBUG_NO_LONGWIN", "1")
     r = 7
     rng = np.random.default_rng(R + model_no)
     n = 40_000
@@ -630,6 +635,6 @@ def test_long_windows_match_oracle(R, model_no):
         got = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r,
                                    local_order=3).cpu().numpy()
         dense = model((torch.zeros(len(pos), 1, dtype=torch.float64).cuda(), cat.cuda()), x.cuda()).cpu().numpy()
-    assert not model._fused_ok()      # both lengths are beyond the LDS-resident kernels (stage-1 window / tower tile): per-layer path
+    assert model._fused_ok() == fused
     assert_probs_close(got, want, model_no, f"packed R={R}")
     assert_probs_close(dense, want, model_no, f"dense R={R}")
