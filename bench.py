@@ -442,11 +442,11 @@ def workload_variants(device, model, genome):
         out["model_predict_m_batch16_device_loader"] = {"bases_per_s": n_rows / dt, "rows": n_rows,
                                                         "note": "the same 16-row batches already on the device: fused into 8192-row launches"}
         # long windows (the reference advertises inputs of up to 64 kb, CHANGELOG:13): per-window predict at distal_radius 4000 with
-        # S-config weights.  The pooled rows (534 columns) exceed the LDS images of the fused tower kernels: this shape takes one
-        # launch per layer (model/generic_eval.py)
+        # S-config weights.  The large tower's pooled row (534 columns) exceeds a wave's LDS image: its first conv stage runs on
+        # segments with halo columns (MuralSnvModel::longwin), the rest on the fused kernels as usual
         R4 = 4000
         m4 = build_model(device, R4)
-        B4 = 512
+        B4 = 2048
         codes4 = torch.randint(0, 4, (B4, 2 * R4 + 1), device=device, generator=g)
         x4 = torch.nn.functional.one_hot(codes4, 4).permute(0, 2, 1).float().contiguous()
         c4 = codes4[:, R4 - LOCAL_RADIUS:R4 + LOCAL_RADIUS + 1]
@@ -457,8 +457,9 @@ def workload_variants(device, model, genome):
         out["long_window_R4000"] = {"bases_per_s": B4 / dt, "batch": B4, "ms_per_call": dt * 1e3, "flop_per_site": fl,
                                     "tflops": fl * B4 / dt / 1e12, "frac_of_fp32_peak": fl * B4 / dt / 1e12 / PEAK_FP32_MFMA_TFLOPS,
                                     "fused_kernels": bool(m4._fused_ok()),
-                                    "note": "distal_radius 4000 (window 8001), S-config weights_init weights, dense one-hot input of 512 "
-                                            "random windows per call; algorithmic FLOP by SURVEY 8d's rule"}
+                                    "note": "distal_radius 4000 (window 8001), S-config weights_init weights, dense one-hot input of 2048 "
+                                            "random windows per call (262 MB, classified into symbols inside the timed region); algorithmic "
+                                            "FLOP by SURVEY 8d's rule; 512 windows per call: 0.26 of the roof (launches of 128-384 workgroups)"}
         del m4, x4
     return out
 

@@ -7,7 +7,7 @@ device = torch.device("cuda", 0)
 R4 = 4000
 g = torch.Generator(device=device).manual_seed(3)
 m4 = bench.build_model(device, R4)
-B4 = 512
+B4 = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 codes4 = torch.randint(0, 4, (B4, 2 * R4 + 1), device=device, generator=g)
 x4 = torch.nn.functional.one_hot(codes4, 4).permute(0, 2, 1).float().contiguous()
 c4 = codes4[:, R4 - bench.LOCAL_RADIUS:R4 + bench.LOCAL_RADIUS + 1]
