@@ -599,6 +599,56 @@ def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch
             assert len(zone) == guard and (zone == 255).all(), f"region {i} (dense={dense}): a kernel wrote behind its {size} bytes"
 
 
+def test_long_window_writes_stay_inside_their_workspace_regions(monkeypatch):
+    """The same guard check for the segmented long-window path (R = 2000: twelve regions -- the eight of the regular forward plus the
+    segments' inputs and pooled outputs of both kinds): no gather / segment / scatter launch writes outside its region, and the
+    poisoned workspace does not leak into the result (the per-layer path on the same inputs agrees)."""
+    import ctypes as C
+    from mural_amd import _lib
+    from mural_amd.data import PackedGenome
+    from mural_amd.model import model_snv as MS
+    from mural_amd.model import generic_eval
+    guard = 4096
+    monkeypatch.setenv("MURAL_DEBUG_WS_GUARD", str(guard))
+    monkeypatch.setattr(MS, "torch", _PoisonedTorch())
+    r, R, n_sites = 7, 2000, 300
+    orc = snv_ref.build(2, local_radius=r, distal_radius=R)
+    sd = synth.synth_state_dict(orc.state_dict(), 11)
+    model, _ = product_from_hp(np.array([r, 3, R, 150, 75, 32, 3, 4, 2]))
+    model.load_state_dict(sd)
+    model = model.cuda().eval()
+    rng = np.random.default_rng(3)
+    seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=30_000, p=[.247, .247, .247, .247, .012]).tobytes().decode()
+    codes = encode_ref.seq_to_codes(seq)
+    pos = rng.integers(0, len(seq), size=n_sites)
+    strand = rng.integers(0, 2, size=n_sites).astype(np.uint8)
+    sym = ["-" if s else "+" for s in strand]
+    cat = torch.from_numpy(encode_ref.kmer_encode(codes, pos, sym, r, 3)).cuda()
+    x = torch.from_numpy(encode_ref.onehot_encode(codes, pos, sym, R)).cuda()
+    cont = torch.zeros(n_sites, 1, dtype=torch.float64, device="cuda")
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    assert model._fused_ok()
+    with torch.no_grad():
+        want = generic_eval.forward(model, cat, x, MS.POOLS_MID, MS.POOLS_LARGE).cpu().numpy()
+    for dense in (1, 0):
+        model._ws = None
+        model._ws_rows = [0, 0]
+        with torch.no_grad():
+            if dense:
+                out = model((cont, cat), x)
+            else:
+                out = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r, local_order=3)
+        assert np.abs(out.cpu().numpy() - want).max() <= 1e-4      # (log-probabilities; fp32 summation orders differ between the paths)
+        layout = (C.c_size_t * 64)()
+        n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 32)
+        assert n_regions == 12
+        ws = model._ws.cpu().numpy()
+        for i in range(n_regions):
+            off, size = layout[2 * i], layout[2 * i + 1]
+            zone = ws[off + size:off + size + guard]
+            assert len(zone) == guard and (zone == 255).all(), f"region {i} (dense={dense}): a kernel wrote behind its {size} bytes"
+
+
 @pytest.mark.parametrize("R,model_no,fused", [(2000, 2, True), (4000, 2, True), (4000, 1, True), (3000, 2, True), (2000, 2, False), (4000, 1, False)])
 def test_long_windows_match_oracle(R, model_no, fused, monkeypatch):
     """Windows beyond the shipped radius (the reference advertises inputs of up to 64 kb, CHANGELOG:13).  The pooled first-stage row of
