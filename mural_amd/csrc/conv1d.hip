@@ -52,6 +52,60 @@ __global__ __launch_bounds__(256) void conv1d_kernel(const Conv1dArgs a, const f
   const int TWp = vec4 ? ((TW + 4) & ~3) : (TW | 1);
   const int in0 = l0 * a.stride - a.pad;       // first (virtual, upsampled) input index of the tile
   const int Lv = a.Lin * a.up;
+  const size_t in_bytes = (size_t)a.B * a.Cin * a.Lin * sizeof(float);
+  if (a.up == 1 && in_bytes < (size_t(1) << 31)) {
+    // 16-byte pieces of the input rows (4-byte aligned: a strided tile starts anywhere), all of a wave's pieces of a channel row in
+    // flight together: the 4-byte form below walks a 1027-column row of the stride-4 encoder conv in 4 rounds of 4 loads -- eight
+    // serial round trips per workgroup for its two channels, most of that launch's 318 us (tools/phase notes in DESIGN.md 3.3).
+    // Pieces that cross a row end are refused here (the descriptor's offset is replaced by one past its range: zeros) and patched
+    // element by element afterwards.
+    const __amdgpu_buffer_rsrc_t rin = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.in), 0, (int)in_bytes, 0x00020000);
+    const int nq = (TW + 3) >> 2;
+    constexpr int UNQ = 5;
+    for (int rc = wave; rc < RT * a.Cin; rc += 4) {
+      const int r = RT > 1 ? rc / a.Cin : 0, ci = rc - r * a.Cin;
+      const bool row_ok = b0 + r < a.B;
+      const uint32_t soff = (uint32_t)(((row_ok ? b0 + r : 0) * a.Cin + ci) * a.Lin) * 4u;
+      const float ps = a.pre_s ? a.pre_s[ci] : 1.f, pt = a.pre_t ? a.pre_t[ci] : 0.f;
+      const bool has_pre = a.pre_s != nullptr || a.pre_t != nullptr || a.pre_relu != 0;
+      float* trow = tile + rc * TWp;
+      for (int q0 = lane; q0 < nq; q0 += 64 * UNQ) {
+        f32x4 v[UNQ];
+#pragma unroll
+        for (int u = 0; u < UNQ; ++u) {
+          const int q = q0 + 64 * u, pos = in0 + 4 * q;
+          const bool full = row_ok & (q < nq) & (pos >= 0) & (pos + 3 < Lv);
+          uint32_t off = (uint32_t)pos * 4u;
+          asm volatile("" : "+v"(off));
+          v[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rin, full ? off : 0x80000000u, soff, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < UNQ; ++u) {
+          const int q = q0 + 64 * u, pos = in0 + 4 * q;
+          if (q >= nq) continue;
+          const bool full = row_ok & (pos >= 0) & (pos + 3 < Lv);
+          if (!full && row_ok) {                          // a piece across a row end (a lane or two per row): element by element
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int pe = pos + e;
+              v[u][e] = (pe >= 0 && pe < Lv) ? a.in[(size_t)soff / 4 + pe] : 0.f;
+            }
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int j = 4 * q + e, pe = pos + e;
+            float xv = v[u][e];
+            if (has_pre) {                               // zero padding applies after the pre-op, like nn.Conv1d after a BatchNorm
+              const bool in = row_ok & (pe >= 0) & (pe < Lv);
+              if (a.pre_relu) xv = fmaxf(xv, 0.f);
+              xv = in ? fmaf(ps, xv, pt) : 0.f;
+            }
+            if (j < TW) trow[j] = xv;
+          }
+        }
+      }
+    }
+  } else
   for (int rc = wave; rc < RT * a.Cin; rc += 4) {
     const int r = RT > 1 ? rc / a.Cin : 0, ci = rc - r * a.Cin;
     const bool row_ok = b0 + r < a.B;
