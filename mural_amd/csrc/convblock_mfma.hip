@@ -24,7 +24,7 @@ constexpr int CM_PITCH = 272;      // = 16 (mod 32) floats: the 16 positions x 4
 __device__ __forceinline__ float silu_fast(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
 template <int C>
-__global__ __launch_bounds__(256) void convblock_mfma_kernel(const ConvBlockArgs a) {
+__global__ __launch_bounds__(256, 2) void convblock_mfma_kernel(const ConvBlockArgs a) {
   constexpr int C2 = 2 * C;
   constexpr int MB1 = C2 / 16;           // hidden blocks
   constexpr int CQ = C / 4;              // channel quads per tap
@@ -67,97 +67,136 @@ __global__ __launch_bounds__(256) void convblock_mfma_kernel(const ConvBlockArgs
   // persistent workgroup: the weight fragments are loaded once and serve every (row, tile) this workgroup walks
   const int tiles_per_row = (a.L + 255) / 256;
   const int64_t total_tiles = (int64_t)a.B * tiles_per_row;
+
+  // the MFMA phase of one tile: tile (LDS) -> otile (LDS)
+  auto compute_tile = [&](int l0) {
 #pragma unroll 1
-  for (int64_t tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
-  const int b = (int)(tix / tiles_per_row);
-  const int l0 = (int)(tix - (int64_t)b * tiles_per_row) * 256;
-  __syncthreads();                                    // the previous tile is consumed
-  const float* src = a.x + (size_t)b * C * a.L;
-  if ((a.L & 3) == 0) {                               // rows start 16-byte aligned: float4 pieces of the tile, origin l0 - 4
-    constexpr int Q = CM_TW / 4;
-    constexpr int UN = 4;                              // loads of a thread in flight: a round per load is a global round trip per round
-    for (int i0 = tid; i0 < C * Q; i0 += 256 * UN) {
-      f32x4 v[UN];
+    for (int pb = 0; pb < 4; ++pb) {
+      const int p = 64 * wave + 16 * pb + n16;          // tile-relative position of this lane's column
+      if (l0 + 64 * wave + 16 * pb >= a.L) break;       // wave-uniform: nothing of this block is inside the row
+      const float* xp = tile + kk * CM_PITCH + p + 2;   // x[ci = 4 cq + kk][p + t - 2] sits at xp[4 cq * pitch + t] (tile origin l0 - 4)
+      f32x4 acc1[MB1];
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int i = i0 + 256 * u;
+      for (int mb = 0; mb < MB1; ++mb) acc1[mb] = bias1[mb];
+#pragma unroll
+      for (int s = 0; s < KS1; ++s) {
+        const float bv = xp[4 * (s % CQ) * CM_PITCH + s / CQ];
+#pragma unroll
+        for (int mb = 0; mb < MB1; ++mb) acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mb][s], bv, acc1[mb], 0, 0, 0);
+      }
+      f32x4 acc2[MB2];
+#pragma unroll
+      for (int mb = 0; mb < MB2; ++mb) acc2[mb] = bias2[mb];
+#pragma unroll
+      for (int s = 0; s < KS2; ++s) {
+        const float hv = silu_fast(acc1[s >> 2][s & 3]);
+#pragma unroll
+        for (int mb = 0; mb < MB2; ++mb) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb][s], hv, acc2[mb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = 16 * mb + 4 * kk + r;
+          if (c < C) otile[c * CM_PITCH + p] = tile[c * CM_PITCH + p + 4] + acc2[mb][r];
+        }
+    }
+  };
+
+  if ((a.L & 3) == 0 && (size_t)a.B * C * a.L * 4 < (size_t(1) << 31)) {
+    // Rows start 16-byte aligned: the tile (origin l0 - 4) and the skip tensor move as float4 pieces through range-checked
+    // descriptors -- a refused piece (outside the row, past the work list) reads zeros.  SOFTWARE PIPELINE: the pieces of the NEXT
+    // tile and this tile's skip pieces are requested before this tile's MFMAs and parked in registers; they reach LDS / the output
+    // after the MFMA phase.  (One tile at a time -- request, wait, MFMAs, request the skip, wait, store -- left the matrix cores idle
+    // for two global round trips per tile, and the workgroups of a CU, all on the same schedule, idle together: 55 % busy.)
+    constexpr int Q = CM_TW / 4;
+    constexpr int NX = (C * Q + 255) / 256, NR = (C * 64 + 255) / 256;
+    const size_t tbytes = (size_t)a.B * C * a.L * 4;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)tbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res2 ? a.res2 : a.x), 0, a.res2 ? (int)tbytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)tbytes, 0x00020000);
+    auto request_x = [&](f32x4 (&xr)[NX], int64_t tix) {
+      const bool live = tix < total_tiles;
+      const int b = live ? (int)(tix / tiles_per_row) : 0;
+      const int l0 = live ? (int)(tix - (int64_t)b * tiles_per_row) * 256 : 0;
+#pragma unroll
+      for (int u = 0; u < NX; ++u) {
+        const int i = tid + 256 * u;
         const int ci = i / Q, q = i - ci * Q;
         const int l = l0 - 4 + 4 * q;
-        const bool ok = i < C * Q && l >= 0 && l < a.L;
-        v[u] = ld4(src + (ok ? (size_t)ci * a.L + l : 0));
-        if (!ok) v[u] = splat(0.f);
+        const bool ok = live & (i < C * Q) & (l >= 0) & (l < a.L);
+        uint32_t off = (uint32_t)((b * C + ci) * a.L + l) * 4u;
+        asm volatile("" : "+v"(off));
+        xr[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, ok ? off : 0x80000000u, 0, 0));
       }
+    };
+    auto park_x = [&](const f32x4 (&xr)[NX]) {
 #pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int i = i0 + 256 * u;
+      for (int u = 0; u < NX; ++u) {
+        const int i = tid + 256 * u;
         if (i < C * Q) {
           const int ci = i / Q, q = i - ci * Q;
-          st4(tile + ci * CM_PITCH + 4 * q, v[u]);
+          st4(tile + ci * CM_PITCH + 4 * q, xr[u]);
         }
       }
+    };
+    f32x4 xr[NX];
+    int64_t tix = blockIdx.x;
+    request_x(xr, tix);
+    park_x(xr);
+    __syncthreads();
+#pragma unroll 1
+    for (; tix < total_tiles; tix += gridDim.x) {
+      const int b = (int)(tix / tiles_per_row);
+      const int l0 = (int)(tix - (int64_t)b * tiles_per_row) * 256;
+      request_x(xr, tix + gridDim.x);                 // the next tile (zeros past the end of the work list)
+      f32x4 rr[NR];
+      uint32_t ooff[NR];
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {                  // this tile's skip pieces and output offsets
+        const int i = tid + 256 * u;
+        const int c = i >> 6, q = i & 63;
+        const int l = l0 + 4 * q;
+        const bool ok = (i < C * 64) & (l < a.L);
+        uint32_t off = (uint32_t)((b * C + c) * a.L + l) * 4u;
+        asm volatile("" : "+v"(off));
+        ooff[u] = ok ? off : 0x80000000u;
+        rr[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ooff[u], 0, 0));
+      }
+      __builtin_amdgcn_sched_barrier(0);              // (keep the requests in front of the MFMAs)
+      compute_tile(l0);
+      __builtin_amdgcn_sched_barrier(0);
+      __syncthreads();                                // otile complete, tile consumed
+#pragma unroll
+      for (int u = 0; u < NR; ++u) {
+        const int i = tid + 256 * u;
+        const int c = i >> 6, q = i & 63;
+        if (i < C * 64) {
+          const f32x4 v = ld4(otile + c * CM_PITCH + 4 * q) + rr[u];
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ro, ooff[u], 0, 0);
+        }
+      }
+      park_x(xr);
+      __syncthreads();                                // the next tile is in place, otile is free
     }
-  } else {
+    return;
+  }
+
+#pragma unroll 1
+  for (int64_t tix = blockIdx.x; tix < total_tiles; tix += gridDim.x) {
+    const int b = (int)(tix / tiles_per_row);
+    const int l0 = (int)(tix - (int64_t)b * tiles_per_row) * 256;
+    __syncthreads();                                    // the previous tile is consumed
+    const float* src = a.x + (size_t)b * C * a.L;
     for (int i = tid; i < C * CM_TW; i += 256) {
       const int ci = i / CM_TW, j = i - ci * CM_TW;
       const int l = l0 - 4 + j;
       tile[ci * CM_PITCH + j] = (l >= 0 && l < a.L) ? src[(size_t)ci * a.L + l] : 0.f;
     }
-  }
-  __syncthreads();
-
-#pragma unroll 1
-  for (int pb = 0; pb < 4; ++pb) {
-    const int p = 64 * wave + 16 * pb + n16;          // tile-relative position of this lane's column
-    if (l0 + 64 * wave + 16 * pb >= a.L) break;       // wave-uniform: nothing of this block is inside the row
-    const float* xp = tile + kk * CM_PITCH + p + 2;   // x[ci = 4 cq + kk][p + t - 2] sits at xp[4 cq * pitch + t] (tile origin l0 - 4)
-    f32x4 acc1[MB1];
-#pragma unroll
-    for (int mb = 0; mb < MB1; ++mb) acc1[mb] = bias1[mb];
-#pragma unroll
-    for (int s = 0; s < KS1; ++s) {
-      const float bv = xp[4 * (s % CQ) * CM_PITCH + s / CQ];
-#pragma unroll
-      for (int mb = 0; mb < MB1; ++mb) acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mb][s], bv, acc1[mb], 0, 0, 0);
-    }
-    f32x4 acc2[MB2];
-#pragma unroll
-    for (int mb = 0; mb < MB2; ++mb) acc2[mb] = bias2[mb];
-#pragma unroll
-    for (int s = 0; s < KS2; ++s) {
-      const float hv = silu_fast(acc1[s >> 2][s & 3]);
-#pragma unroll
-      for (int mb = 0; mb < MB2; ++mb) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb][s], hv, acc2[mb], 0, 0, 0);
-    }
-#pragma unroll
-    for (int mb = 0; mb < MB2; ++mb)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int c = 16 * mb + 4 * kk + r;
-        if (c < C) otile[c * CM_PITCH + p] = tile[c * CM_PITCH + p + 4] + acc2[mb][r];
-      }
-  }
-  __syncthreads();
-  if ((a.L & 3) == 0) {
-    constexpr int UN = 4;
-    for (int i0 = tid; i0 < C * 64; i0 += 256 * UN) {
-      f32x4 r[UN];
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {                   // the skip tensor's pieces first, all in flight
-        const int i = i0 + 256 * u;
-        const int c = i >> 6, q = i & 63;
-        const int l = l0 + 4 * q;
-        const bool ok = a.res2 && i < C * 64 && l < a.L;
-        r[u] = ok ? ld4(a.res2 + ((size_t)b * C + c) * a.L + l) : splat(0.f);
-      }
-#pragma unroll
-      for (int u = 0; u < UN; ++u) {
-        const int i = i0 + 256 * u;
-        const int c = i >> 6, q = i & 63;
-        const int l = l0 + 4 * q;
-        if (i < C * 64 && l < a.L) st4(a.out + ((size_t)b * C + c) * a.L + l, ld4(otile + c * CM_PITCH + 4 * q) + r[u]);
-      }
-    }
-  } else {
+    __syncthreads();
+    compute_tile(l0);
+    __syncthreads();
     for (int i = tid; i < C * 256; i += 256) {
       const int c = i >> 8, j = i & 255;
       const int l = l0 + j;
@@ -168,7 +207,6 @@ __global__ __launch_bounds__(256) void convblock_mfma_kernel(const ConvBlockArgs
         a.out[o] = v;
       }
     }
-  }
   }
 }
 
