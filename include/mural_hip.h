@@ -365,6 +365,8 @@ int mural_debug_conv1d(const float* in, const float* wt, const float* bias, floa
 /* Diagnostic: the MFMA conv's workgroups of the following launches record 5 s_memrealtime values each (start, tile staged, MFMAs done,
  * stores issued, stores landed) into `stamps` (device memory, 5 x workgroups entries); NULL switches it off. */
 int mural_debug_conv1d_set_stamps(unsigned long long* stamps);
+/* The same for the level-0 MFMA ConvBlock kernel: 8 accumulators per workgroup (phase time sums over its tiles, word 7 = tiles). */
+int mural_debug_cb8_set_stamps(unsigned long long* stamps);
 
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);

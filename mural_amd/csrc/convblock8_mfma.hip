@@ -23,6 +23,7 @@
 #include "mfma_tile.h"
 
 namespace mural {
+unsigned long long* g_cb8_stamps = nullptr;      // diagnostic (tools/phase_stamps_cb8.py): per-workgroup phase sums, or nullptr
 namespace {
 
 constexpr int C8 = 8;
@@ -40,7 +41,14 @@ template <bool DEC>
 __global__ __launch_bounds__(256) void convblock8_mfma_kernel(const ConvBlockArgs a, const float* __restrict__ f_w,
                                                               const float* __restrict__ f_b, const float* __restrict__ ta_w,
                                                               const float* __restrict__ ta_b, const float* __restrict__ tb_w,
-                                                              const float* __restrict__ tb_b) {
+                                                              const float* __restrict__ tb_b, unsigned long long* stamps) {
+  unsigned long long t_prev = stamps ? __builtin_amdgcn_s_memrealtime() : 0ull;
+#define CB8_STAMP(id)                                                          \
+  if (stamps && threadIdx.x == 0) {                                            \
+    const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();         \
+    stamps[8 * blockIdx.x + (id)] += t_now - t_prev;                           \
+    t_prev = t_now;                                                            \
+  }
   // xt: block input x, tile origin = position l0 - 4; ot: block output (block + residual), origin l0; fin: front input
   __shared__ __attribute__((aligned(16))) float xt[C8 * C8_PITCH];
   __shared__ __attribute__((aligned(16))) float ot[C8 * C8_PITCH];
@@ -82,6 +90,7 @@ __global__ __launch_bounds__(256) void convblock8_mfma_kernel(const ConvBlockArg
     const int tile_no = (int)(tix - (int64_t)b * tiles_per_row);
     const int l0 = tile_no * C8_OUT;
     __syncthreads();                                    // the previous tile is consumed
+    CB8_STAMP(0);
     if (!DEC) {
       // ------------------------------------------------------------ encoder front: x[l0 - 2 + tid], tid = 0 .. 255
       // front input columns l0 - 5 .. l0 + 256 (262 of them) at fin[ci][0 .. 261]
@@ -177,6 +186,7 @@ __global__ __launch_bounds__(256) void convblock8_mfma_kernel(const ConvBlockArg
         if (i < 16 * 67) fin[(i / 67) * C8_SPITCH + (i % 67)] = v[u];
       }
       __syncthreads();
+      CB8_STAMP(1);
       // five 16-source blocks: one per wave, and wave 0 also takes the block behind them, of which only its first column (source
       // i0 + 64 = positions l0 + 252 .. l0 + 255) is inside the tile
 #pragma unroll 1
@@ -207,6 +217,7 @@ __global__ __launch_bounds__(256) void convblock8_mfma_kernel(const ConvBlockArg
       }
     }
     __syncthreads();
+    CB8_STAMP(2);
 
     // -------------------------------------------------------------- the block: 16 position blocks, 4 per wave
 #pragma unroll 1
@@ -229,6 +240,7 @@ __global__ __launch_bounds__(256) void convblock8_mfma_kernel(const ConvBlockArg
       }
     }
     __syncthreads();
+    CB8_STAMP(3);
 
     if (!DEC) {
       // ------------------------------------------------------------ stream the tile out as 16-byte pieces (L % 4 == 0) or scalars
@@ -249,10 +261,17 @@ __global__ __launch_bounds__(256) void convblock8_mfma_kernel(const ConvBlockArg
       const int l = l0 + tid;
       const bool live = tid < C8_OUT && l < a.L;
       float v[C8];
+      {
+        // the skip tensor's 8 values together (one branch, not one -- with a full wait behind its load -- per channel)
+        float sk[C8];
 #pragma unroll
-      for (int c = 0; c < C8; ++c) {
-        v[c] = ot[c * C8_PITCH + (tid < C8_OUT ? tid : 0)];
-        if (a.res2 && live) v[c] += a.res2[((size_t)b * C8 + c) * a.L + l];
+        for (int c = 0; c < C8; ++c) sk[c] = 0.f;
+        if (a.res2 && live) {
+#pragma unroll
+          for (int c = 0; c < C8; ++c) sk[c] = a.res2[((size_t)b * C8 + c) * a.L + l];
+        }
+#pragma unroll
+        for (int c = 0; c < C8; ++c) v[c] = ot[c * C8_PITCH + (tid < C8_OUT ? tid : 0)] + sk[c];
       }
       if (a.tail_max == nullptr) {
         if (live) {
@@ -293,7 +312,10 @@ __global__ __launch_bounds__(256) void convblock8_mfma_kernel(const ConvBlockArg
               fmaxf(fmaxf(wmax[tid], wmax[C8 + tid]), fmaxf(wmax[2 * C8 + tid], wmax[3 * C8 + tid]));
       }
     }
+    CB8_STAMP(4);
+    if (stamps && threadIdx.x == 0) stamps[8 * blockIdx.x + 7] += 1;
   }
+#undef CB8_STAMP
 }
 
 }  // namespace
@@ -314,8 +336,8 @@ bool convblock8_mfma_supported(const ConvBlockArgs& a) {
 int launch_convblock8_mfma(const ConvBlockArgs& a, hipStream_t stream) {
   const int64_t tiles = (int64_t)a.B * ((a.L + C8_OUT - 1) / C8_OUT);
   const dim3 grid((unsigned)(tiles < 2048 ? tiles : 2048));
-  if (a.Cf == 16) hipLaunchKernelGGL(convblock8_mfma_kernel<true>, grid, dim3(256), 0, stream, a, a.f_w, a.f_b, a.ta_w, a.ta_b, a.tb_w, a.tb_b);
-  else hipLaunchKernelGGL(convblock8_mfma_kernel<false>, grid, dim3(256), 0, stream, a, a.f_w, a.f_b, a.ta_w, a.ta_b, a.tb_w, a.tb_b);
+  if (a.Cf == 16) hipLaunchKernelGGL(convblock8_mfma_kernel<true>, grid, dim3(256), 0, stream, a, a.f_w, a.f_b, a.ta_w, a.ta_b, a.tb_w, a.tb_b, g_cb8_stamps);
+  else hipLaunchKernelGGL(convblock8_mfma_kernel<false>, grid, dim3(256), 0, stream, a, a.f_w, a.f_b, a.ta_w, a.ta_b, a.tb_w, a.tb_b, g_cb8_stamps);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

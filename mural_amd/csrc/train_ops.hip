@@ -1044,11 +1044,17 @@ extern "C" int mural_op_conv1d(const float* in, const float* wt, const float* bi
   return launch_conv1d(a, STREAM);
 }
 
-namespace mural { void conv1d_mfma_set_stamps(unsigned long long* p); }
+namespace mural { void conv1d_mfma_set_stamps(unsigned long long* p); extern unsigned long long* g_cb8_stamps; }
 // diagnostic (tools/phase_stamps_conv1d.py): the MFMA conv's workgroups record 5 s_memrealtime values each (start, tile staged, MFMAs
 // done, stores issued, stores landed) into `stamps` (device, 5 x workgroups of the next launches; NULL switches it off)
 extern "C" int mural_debug_conv1d_set_stamps(unsigned long long* stamps) {
   mural::conv1d_mfma_set_stamps(stamps);
+  return MURAL_OK;
+}
+// the same for the level-0 MFMA ConvBlock kernel (convblock8_mfma.hip): 8 accumulators per workgroup -- the time between the phase
+// boundaries of a tile summed over its tiles (100 MHz units), word 7 = tiles walked
+extern "C" int mural_debug_cb8_set_stamps(unsigned long long* stamps) {
+  mural::g_cb8_stamps = stamps;
   return MURAL_OK;
 }
 
