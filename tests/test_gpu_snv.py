@@ -341,6 +341,23 @@ def test_packed_path_other_channel_and_kernel_sizes():
         ref = orc((torch.zeros(40, 1, dtype=torch.float64), cat.cpu()), x.cpu())
     assert torch.equal(got, want)
     assert_probs_close(got.cpu().numpy(), ref.numpy(), 2, "generic packed")
+    # the per-layer path caches the folded BatchNorm affines and the re-laid-out conv weights per module: an in-place update of a
+    # weight, of running statistics, or a load_state_dict must show in the next forward (the caches key on the tensors' versions)
+    with torch.no_grad():
+        model.conv1[1].weight.mul_(1.25)
+        model.RBs1[0].bn1.running_var.add_(0.5)
+        model.distal_fc1[0].bias.add_(0.1)
+    sd2 = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    orc.load_state_dict(sd2)
+    with torch.no_grad():
+        got2 = model((torch.zeros(40, 1, dtype=torch.float64, device="cuda"), cat), x)
+        ref2 = orc((torch.zeros(40, 1, dtype=torch.float64), cat.cpu()), x.cpu())
+    assert float((got2 - want).abs().max()) > 1e-4
+    assert_probs_close(got2.cpu().numpy(), ref2.numpy(), 2, "generic, after in-place updates")
+    model.load_state_dict(sd)
+    with torch.no_grad():
+        got3 = model((torch.zeros(40, 1, dtype=torch.float64, device="cuda"), cat), x)
+    assert torch.equal(got3, want)
 
 
 def test_train_batches_from_files_match_reference_pipeline_order(tmp_path):
