@@ -6,10 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from mural_amd import _lib
 lib = _lib.lib()
 dev = torch.device("cuda", 0)
-B = 128
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
 # (Cin, Cout, Lin, K, stride, up, bias, res)
 cases = [(40, 80, 16, 5, 1, 1, 0, 0), (80, 40, 16, 1, 1, 1, 0, 0), (32, 64, 80, 5, 1, 1, 0, 0), (64, 32, 80, 1, 1, 1, 0, 0), (32, 40, 80, 7, 5, 1, 1, 0),
-         (48, 96, 8, 5, 1, 1, 0, 0), (24, 48, 400, 5, 1, 1, 0, 0), (48, 24, 400, 1, 1, 1, 0, 1)]
+         (48, 96, 8, 5, 1, 1, 0, 0), (24, 48, 400, 5, 1, 1, 0, 0), (48, 24, 400, 1, 1, 1, 0, 1),
+         (24, 16, 400, 7, 1, 5, 1, 0), (32, 24, 80, 7, 1, 5, 1, 0)]      # (up > 1: the polyphase form, engine 3)
 for Cin, Cout, Lin, K, stride, up, has_bias, nres in cases:
     pad = (K - 1) // 2
     Lout = (Lin * up + 2 * pad - K) // stride + 1
@@ -19,11 +20,11 @@ for Cin, Cout, Lin, K, stride, up, has_bias, nres in cases:
     out = torch.empty(B, Cout, Lout, device=dev)
     res = torch.randn(B, Cout, Lout, device=dev)
     st = _lib.current_stream_ptr(dev)
-    stamps = torch.zeros(5 * 65536, dtype=torch.int64, device=dev)
+    stamps = torch.zeros(5 * 262144, dtype=torch.int64, device=dev)
 
     def run():
         _lib.check(lib.mural_debug_conv1d(x.data_ptr(), wt.data_ptr(), bias.data_ptr() if has_bias else None, out.data_ptr(), B, Cin, Lin, Cout, Lout,
-                                          K, stride, up, 0, res.data_ptr() if nres else None, None, 1, st))
+                                          K, stride, up, 0, res.data_ptr() if nres else None, None, 3 if up > 1 else 1, st))
     for _ in range(3):
         run()
     torch.cuda.synchronize()
