@@ -296,23 +296,64 @@ int launch_conv1d_valu(const Conv1dArgs& a_in, hipStream_t stream) {
 constexpr int CB_FRONT_FLOATS = 2048;          // front input tile: Cf x (262 / up + 3) floats
 constexpr int CB_FRONT_OUT = 252;              // output positions per workgroup of the front variant
 
-template <int C, bool TAIL, bool FRONT>
-__global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
+// floats of the split form's front-input region (also holds the tail's 32 partial maxima)
+__host__ __device__ inline int convblock_front_floats(int Cf, int f_up, bool front) {
+  return front ? ((Cf * (262 / f_up + 3) + 3) & ~3) : 32;
+}
+
+// MF (8 channels): everything behind the front -- the k=5 conv 8 -> 16, the 1x1 conv 16 -> 8 and the tail's two 1x1 convs -- runs on
+// v_mfma_f32_16x16x4_f32 while front, SiLU and the adds stay on the vector ALU.  fp32 MFMA and v_pk_fma_f32 have the SAME peak rate,
+// so moving the whole block to the matrix pipe gains nothing (convblock8_mfma.hip: slower); splitting it does: a SIMD's eight waves
+// are in different phases, the two pipes work side by side, and each carries about half of what the vector ALU alone carried.
+//   k=5 conv  D[16 hidden][16 positions] += W5[hidden][(tap, ci)] x[ci][pos + tap - 2], 10 k-steps, four position blocks per wave
+//             (four independent accumulators); the B operand is one ds_read_b32 per MFMA at an immediate offset.
+//   1x1 conv  blocks taken in PAIRS (b, b + 2): rows 0-7 of the output tile are the 8 channels of block b, rows 8-15 those of block
+//             b + 2 (A = [W1 0] against block b's SiLU values, then [0 W1] against block b + 2's) -- no padding rows, and the
+//             accumulator layout (lane (n, kk): rows 4 kk + q) of the conv in front IS the B layout with the k index permuted.
+//   tail      the paired layout is closed under a 1x1 conv 8 -> 8 with A = diag(W, W): 4 MFMAs per pair and conv.
+template <int C, bool TAIL, bool FRONT, bool MF>
+__global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convblock_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
                                                         const float* __restrict__ b5, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ ta_w,
                                                         const float* __restrict__ ta_b, const float* __restrict__ tb_w,
                                                         const float* __restrict__ tb_b, const float* __restrict__ f_w,
-                                                        const float* __restrict__ f_b) {
-  constexpr int C2 = 2 * C, TW = 256 + 4, TWp = TW | 1;
-  __shared__ float tile[C * TWp];
+                                                        const float* __restrict__ f_b, unsigned long long* stamps) {
+  // diagnostic (tools/phase_stamps_cb8.py, split form only): wall-clock ticks (100 MHz) of the workgroup's first thread at entry, front
+  // input staged, block input ready, SiLU done, block output ready, exit -- 8 words per workgroup
+#define CB_STAMP(id)                                                                                              \
+  if (MF && stamps && threadIdx.x == 0) {                                                                         \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+    const size_t wg_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x;                                               \
+    if (wg_ < 65536) stamps[8 * wg_ + (id)] = __builtin_amdgcn_s_memrealtime();                                    \
+    __builtin_amdgcn_sched_barrier(0);                                                                            \
+  }
+  CB_STAMP(0);
+  if (MF && stamps && threadIdx.x == 0) {      // word 7: where the workgroup runs (HW_ID: CU / SE, XCC_ID)
+    const size_t wg_ = (size_t)blockIdx.y * gridDim.x + blockIdx.x;
+    if (wg_ < 65536)
+      stamps[8 * wg_ + 7] = (unsigned long long)__builtin_amdgcn_s_getreg(4 | (0 << 6) | (31 << 11)) |          // HW_REG_HW_ID, 32 bits
+                            ((unsigned long long)__builtin_amdgcn_s_getreg(20 | (0 << 6) | (31 << 11)) << 32);  // HW_REG_XCC_ID
+  }
+  static_assert(!MF || C == 8, "the matrix-core form serves the 8-channel block: its hidden width is one 16-row MFMA tile");
+  // pitch: odd for the vector-ALU form (lane = position); = 16 (mod 32) for the matrix form, whose operand reads have the lane
+  // groups kk = 0, 1 of a half wave 1 x pitch apart
+  constexpr int C2 = 2 * C, TW = 256 + 4, TWp = MF ? 272 : (TW | 1);
+  // the vector form keeps its three arrays static; the split form carves tile | front input | polyphase weights out of ONE dynamic
+  // allocation sized by the host for what the launch uses (encoder 13 KB, decoder 19 KB instead of 22.5 KB: the LDS granule made that
+  // six workgroups per CU)
+  extern __shared__ __attribute__((aligned(16))) float cb_dyn[];
+  __shared__ float tile_s[MF ? 4 : C * TWp];
+  float* const tile = MF ? cb_dyn : tile_s;
   // SiLU outputs parked for the rolled 1x1 loop, HP of the 2C rows at a time (a lane only ever touches its own column, so the
   // passes need no barrier): at 8 channels two passes of 8 rows keep the buffer at 8 KB and the workgroup at 17 KB of LDS = 8
   // workgroups per CU, which is what hides the scalar weight loads of the inner loops
   constexpr int HP = C == 8 ? 8 : C2;
-  __shared__ float hs[HP * 256];
+  __shared__ float hs_s[MF ? 4 : HP * 256];
+  float* const hs = MF ? cb_dyn + C * TWp : hs_s;
   static_assert(!FRONT || HP * 256 >= CB_FRONT_FLOATS, "the front input tile borrows the SiLU buffer");
   constexpr int PW_FLOATS = (FRONT && C == 8) ? 4 * 16 * 3 * 8 : 4;      // polyphase front weights of the four phases (Cf <= 16)
-  __shared__ __attribute__((aligned(16))) float pwS[PW_FLOATS];
+  __shared__ __attribute__((aligned(16))) float pw_s[MF ? 4 : PW_FLOATS];
+  float* const pwS = MF ? hs + convblock_front_floats(a.Cf, a.f_up, FRONT) : pw_s;
   if (FRONT && C == 8 && a.f_pw != nullptr && a.Cf * 3 * C * 4 <= PW_FLOATS)
     for (int i = threadIdx.x; i < a.Cf * 3 * C * 4; i += 256) pwS[i] = a.f_pw[i];      // visible behind the front's first barrier
   float* fin = hs;                             // front input tile: dead before the first SiLU output is parked (a barrier in between),
@@ -430,6 +471,7 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
         if (i0 + 256 * u < a.Cf * span) fin[i0 + 256 * u] = v[u];
     }
     __syncthreads();
+    CB_STAMP(1);
     if (a.f_pw) {
       // polyphase front (f_up == 4, workgroup origin l0 a multiple of 4): position l only sees the source columns l / 4 + d,
       // d in {-1, 0, 1}, with the taps that share a column summed on the host per phase l % 4.  Wave w takes the tile entries
@@ -517,7 +559,149 @@ __global__ __launch_bounds__(256) void convblock_kernel(const ConvBlockArgs a, c
       for (int c = 0; c < C; ++c) tile[c * TWp + j] = in ? ((c & 1) ? t[c >> 1].y : t[c >> 1].x) : 0.f;
     }
   }
+  // matrix form with a front: the front fills tile entries 0 .. 255; the taps of the two dead lanes behind the last output reach entries
+  // 256 .. 257, and a dead lane's values DO meet live ones here (the paired 1x1 multiplies them by the zero half of A: 0 x NaN) -- so
+  // those entries must not be whatever the previous workgroup left in LDS
+  if (MF && FRONT && tid < 4 * C) tile[(tid >> 2) * TWp + 256 + (tid & 3)] = 0.f;
+  // matrix form: the A fragments (lane (m = lane % 16, kk = lane / 16) holds A[m][kk] of a k-step), requested behind the front (its
+  // registers are free again) and in front of its barrier
+  const int n16 = tid & 15, kk = (tid >> 4) & 3;
+  float a5[MF ? 10 : 1], a1a[MF ? 4 : 1], a1b[MF ? 4 : 1];
+  f32x4 bias5 = {0.f, 0.f, 0.f, 0.f}, bias1 = bias5;
+  if constexpr (MF) {
+#pragma unroll
+    for (int s = 0; s < 10; ++s) a5[s] = w5[((4 * (s & 1) + kk) * 5 + (s >> 1)) * C2 + n16];      // k = (tap s / 2, ci 4 (s % 2) + kk)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float w = w1[(4 * kk + q) * C + (n16 & 7)];                                            // k = (q, kk): hidden channel 4 kk + q
+      a1a[q] = n16 < 8 ? w : 0.f;
+      a1b[q] = n16 < 8 ? 0.f : w;
+    }
+    bias5 = *reinterpret_cast<const f32x4*>(b5 + 4 * kk);
+    bias1 = *reinterpret_cast<const f32x4*>(b1 + 4 * (kk & 1));
+  }
   __syncthreads();
+  CB_STAMP(2);
+  if constexpr (MF) {
+    // virtual lane t = 64 wave + 16 block + n16 plays the role the lane plays in the vector form (tile index toff(t), position l(t))
+    const int t0 = (tid & ~63) + n16;
+    auto toff_of = [&](int t) { return FRONT ? (t >= 2 ? t - 2 : 0) : t; };
+    f32x4 acc[4];
+    const float* xb[4];
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk) {
+      xb[bk] = tile + kk * TWp + toff_of(t0 + 16 * bk);
+      acc[bk] = bias5;
+    }
+#pragma unroll
+    for (int s = 0; s < 10; ++s)
+#pragma unroll
+      for (int bk = 0; bk < 4; ++bk)
+        acc[bk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5[s], xb[bk][4 * (s & 1) * TWp + (s >> 1)], acc[bk], 0, 0, 0);
+    float h[4][4];                                 // SiLU values (separate scalars: element-wise updates of the accumulator vectors in place
+                                                   // have been miscompiled before)
+    // the tail's fragments are requested here: in flight under the MFMAs, not live above them
+    float tA[TAIL ? 4 : 1], tB[TAIL ? 4 : 1];
+    f32x4 biasA = {0.f, 0.f, 0.f, 0.f}, biasB = biasA;
+    if constexpr (TAIL) {
+      const bool own = (n16 >> 3) == (kk >> 1);                                                     // diag(W, W)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float wa = ta_w[(4 * (kk & 1) + q) * C + (n16 & 7)], wb = tb_w[(4 * (kk & 1) + q) * C + (n16 & 7)];
+        tA[q] = own ? wa : 0.f;
+        tB[q] = own ? wb : 0.f;
+      }
+      biasA = *reinterpret_cast<const f32x4*>(ta_b + 4 * (kk & 1));
+      biasB = *reinterpret_cast<const f32x4*>(tb_b + 4 * (kk & 1));
+    }
+#pragma unroll
+    for (int bk = 0; bk < 4; ++bk)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) h[bk][q] = apply_act(acc[bk][q], ACT_SILU);
+    CB_STAMP(3);
+    f32x4 o[2] = {bias1, bias1};
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) o[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1a[q], h[p][q], o[p], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int p = 0; p < 2; ++p) o[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1b[q], h[p + 2][q], o[p], 0, 0, 0);
+    // lane (n16, kk) now holds channels 4 (kk % 2) + q of blocks p + 2 (kk / 2), p = 0, 1: + block input + skip
+    const int cb = 4 * (kk & 1);
+    const size_t rowbase = (size_t)b * C * a.L;
+    const uint32_t row_bytes = (uint32_t)C * (uint32_t)a.L * 4u;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res2 ? a.res2 + rowbase : w5), 0,
+                                                                        a.res2 ? (int)row_bytes : 0, 0x00020000);
+    bool live[2];
+    uint32_t goff[2];
+    float v[2][4];
+    {
+      float sk[2][4], xin[2][4];
+#pragma unroll
+      for (int p = 0; p < 2; ++p) {
+        const int t = t0 + 16 * (p + 2 * (kk >> 1));
+        const int l = FRONT ? l0 - 2 + t : l0 + t;
+        live[p] = FRONT ? ((t >= 2) & (t < 2 + CB_FRONT_OUT) & (l < a.L)) : (l < a.L);
+        uint32_t off = ((uint32_t)cb * (uint32_t)a.L + (uint32_t)l) * 4u;
+        off = live[p] ? off : 0x80000000u;
+        asm volatile("" : "+v"(off));
+        goff[p] = off;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          sk[p][q] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, (uint32_t)q * (uint32_t)a.L * 4u, 0));
+          xin[p][q] = tile[(cb + q) * TWp + toff_of(t) + 2];
+        }
+      }
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[p][q] = (o[p][q] + xin[p][q]) + sk[p][q];
+    }
+    CB_STAMP(4);
+    if constexpr (!TAIL) {
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + rowbase, 0, (int)row_bytes, 0x00020000);
+#pragma unroll
+      for (int p = 0; p < 2; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[p][q]), ro, goff[p], (uint32_t)q * (uint32_t)a.L * 4u, 0);
+      CB_STAMP(5);
+      if (stamps) {      // (diagnostic only) how long the stores take to drain
+        __builtin_amdgcn_s_waitcnt(0);
+        CB_STAMP(6);
+      }
+      return;
+    } else {
+      f32x4 ta[2] = {biasA, biasA};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) ta[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(tA[q], v[p][q], ta[p], 0, 0, 0);
+      f32x4 u[2] = {biasB, biasB};
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p = 0; p < 2; ++p) u[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(tB[q], fmaxf(ta[p][q], 0.f), u[p], 0, 0, 0);
+      // Softplus is non-decreasing: reduce the raw values (lanes of one channel: the 16 columns and the two block halves), apply once
+      float* red = hs;                             // the front input tile is dead (barrier above)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float m = fmaxf(live[0] ? u[0][q] : -INFINITY, live[1] ? u[1][q] : -INFINITY);
+#pragma unroll
+        for (int off = 1; off < 16; off <<= 1) m = fmaxf(m, __shfl_xor(m, off));
+        m = fmaxf(m, __shfl_xor(m, 32));
+        if (n16 == 0 && kk < 2) red[(tid >> 6) * C + cb + q] = m;
+      }
+      __syncthreads();
+      if (tid < C)
+        a.tail_max[((size_t)b * gridDim.x + blockIdx.x) * C + tid] =
+            apply_act(fmaxf(fmaxf(red[tid], red[C + tid]), fmaxf(red[2 * C + tid], red[3 * C + tid])), ACT_SOFTPLUS);
+      CB_STAMP(5);
+      return;
+    }
+  }
   const int toff = FRONT ? (tid >= 2 ? tid - 2 : 0) : tid;    // tile index of this lane's first k=5 tap
   const int l = FRONT ? l0 - 2 + tid : l0 + tid;
   const bool live = FRONT ? (tid >= 2 && tid < 2 + CB_FRONT_OUT && l < a.L) : (l < a.L);   // lane owns a real output
@@ -637,16 +821,32 @@ bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24; }   // LD
 
 int convblock_tiles(int L, bool front) { return front ? (L + CB_FRONT_OUT - 1) / CB_FRONT_OUT : (L + 255) / 256; }
 
+extern unsigned long long* g_cb8_stamps;      // (convblock8_mfma.hip)
+int g_convblock8_form = -1;      // validation hook (mural_debug_convblock): 0 vector-ALU form, 1 split form, -1 the environment's choice
+
 template <bool TAIL, bool FRONT>
 static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
   const dim3 grid(convblock_tiles(a.L, FRONT), a.B);
 #define MURAL_CB(CN)                                                                                                        \
-  hipLaunchKernelGGL((convblock_kernel<CN, TAIL, FRONT>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, \
-                     a.tb_w, a.tb_b, a.f_w, a.f_b)
+  hipLaunchKernelGGL((convblock_kernel<CN, TAIL, FRONT, MFV>), grid, dim3(256), MFV ? mf_lds : 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, \
+                     a.tb_w, a.tb_b, a.f_w, a.f_b, g_cb8_stamps)
+  // MURAL_CONVBLOCK8_VALU=1: the 8-channel block entirely on the vector ALU (A/B switch for the split form)
+  const size_t mf_lds = (size_t)(8 * 272 + convblock_front_floats(a.Cf, a.f_up, FRONT) + (a.f_pw ? 4 * 16 * 3 * 8 : 0)) * sizeof(float);
+  static const bool valu8_env = getenv("MURAL_CONVBLOCK8_VALU") != nullptr && getenv("MURAL_CONVBLOCK8_VALU")[0] == '1';
+  const bool valu8 = g_convblock8_form >= 0 ? g_convblock8_form == 0 : valu8_env;
   switch (a.C) {
-    case 8: MURAL_CB(8); break;
-    case 16: MURAL_CB(16); break;
-    default: MURAL_CB(24); break;
+    case 8: {
+      if (valu8) {
+        constexpr bool MFV = false;
+        MURAL_CB(8);
+      } else {
+        constexpr bool MFV = true;
+        MURAL_CB(8);
+      }
+      break;
+    }
+    case 16: { constexpr bool MFV = false; MURAL_CB(16); break; }
+    default: { constexpr bool MFV = false; MURAL_CB(24); break; }
   }
 #undef MURAL_CB
 }

@@ -1099,6 +1099,42 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
   return engine == 0 ? launch_conv1d_valu(a, STREAM) : launch_conv1d(a, STREAM);
 }
 
+// validation hook (tests/test_gpu_indel.py): one fused ConvBlock launch (conv1d.hip / convblock_mfma.hip) with its optional front
+// (k = 7 conv Cf -> C on the input upsampled f_up times), skip tensor and tail.  form: 0 the 8-channel block entirely on the vector
+// ALU, 1 its split form (convs on the matrix cores), -1 the library's choice.
+namespace mural { extern int g_convblock8_form; }
+// (validation only) every CU's whole LDS filled with NaN: what a kernel reads from LDS without having written it shows up in its results
+__global__ __launch_bounds__(256) void lds_poison_kernel(float* sink) {
+  extern __shared__ float lds_all[];
+  for (int i = threadIdx.x; i < 160 * 256; i += 256) lds_all[i] = __builtin_nanf("");
+  __syncthreads();
+  if (sink && lds_all[(threadIdx.x * 97) % (160 * 256)] == 1.f) sink[0] = 1.f;
+}
+extern "C" int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1,
+                                     const float* res2, float* out, int64_t B, int32_t Cch, int32_t L, const float* f_in,
+                                     const float* f_w, const float* f_b, int32_t Cf, int32_t f_up, const float* ta_w, const float* ta_b,
+                                     const float* tb_w, const float* tb_b, float* tail_max, int32_t form, void* stream) {
+  ConvBlockArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.w5 = w5; a.b5 = b5; a.w1 = w1; a.b1 = b1; a.res2 = res2; a.out = out;
+  a.B = (int)B; a.C = Cch; a.L = L;
+  if (f_in) {
+    MURAL_REQUIRE(f_up >= 1 && L % f_up == 0, "convblock: the front's upsampling factor must divide the row length");
+    a.f_in = f_in; a.f_w = f_w; a.f_b = f_b; a.Cf = Cf; a.f_up = f_up; a.Lf = L / f_up;
+  }
+  a.ta_w = ta_w; a.ta_b = ta_b; a.tb_w = tb_w; a.tb_b = tb_b; a.tail_max = tail_max;
+  if (form >= 0 && (form & 0x100)) {      // poison LDS first
+    form &= 0xff;
+    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, STREAM, (float*)nullptr);
+    MURAL_HIP_CHECK(hipGetLastError());
+  }
+  mural::g_convblock8_form = form;
+  const int rc = launch_convblock(a, STREAM);
+  mural::g_convblock8_form = -1;
+  return rc;
+}
+
 // Batch sums live in an accumulator block acc = double[MURAL_BN_SLOTS][2][C] (zeroed by the caller): workgroups add into
 // the copy picked by their index, readers sum the copies.  [k][0][c] = sum, [k][1][c] = sum of squares (forward) or
 // sum(dz), sum(dz * xhat) (backward).
