@@ -1,7 +1,7 @@
 // Microbenchmark (gfx950): do v_mfma_f32_16x16x4_f32 and v_pk_fma_f32 / v_fma_f32 / v_exp_f32 from DIFFERENT waves of a SIMD overlap?
 // Every workgroup has 8 waves (2 per SIMD); mode 0: all waves run the MFMA loop, 1: all run the VALU loop, 2: even waves MFMA, odd
 // waves VALU (same per-wave work as in 0 / 1 -> time = max if the pipes are independent, ~sum/2.. if they share hardware).
-// build: hipcc -O3 --offload-arch=gfx950 -o mfma_valu_overlap mfma_valu_overlap.hip
+// build: hipcc -O3 --offload-arch=gfx950 -o valu_rates valu_rates.hip
 #include <hip/hip_runtime.h>
 #include <cstdio>
 #include <cstdlib>
