@@ -357,18 +357,23 @@ int mural_debug_cw_conv32_bwd(const float* dy, const float* x, const float* W, i
 /* Validation hook: the generic Conv1d of the INDEL path with every geometry knob (stride, nearest-neighbour upsampling `up`,
  * activation 0 none / 1 ReLU / 2 SiLU / 3 Softplus, two residuals), weights wt laid out [Cin][K][Cout]; engine 0 = vector-ALU
  * kernel, 1 = MFMA implicit-GEMM kernel, 2 = the router's choice, 3 = MFMA kernel on the polyphase form of an upsampled conv,
- * 4 = the barrier-free long-row MFMA kernel (stride 1, 3 / 5 / 7 taps, <= 32 channels). */
+ * 4 = the barrier-free long-row MFMA kernel (stride 1, 3 / 5 / 7 taps, <= 32 channels); engine | 0x100 first fills every CU's LDS
+ * with NaN. */
 int mural_debug_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin, int32_t Lin,
                        int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t up, int32_t act, const float* res1,
                        const float* res2, int32_t engine, void* stream);
+
+/* Validation hook: fills the whole LDS of every CU with NaN (a 160 KB-per-workgroup kernel on `stream`).  Called in front of a product
+ * call whose result is then checked: a kernel that depends on LDS it has not written fails the comparison. */
+int mural_debug_poison_lds(void* stream);
 
 /* Validation hook: one fused ConvBlock launch of the INDEL forward (model_indel.py:6-19: x + W1 . SiLU(W5 * x + b5) + b1, BatchNorms
  * folded; w5 [C][5][2C], w1 [2C][C]) with its optional front (f_in [B][Cf][L / f_up], k = 7 conv Cf -> C with weights f_w [Cf][7][C]
  * on the input upsampled f_up times: the block input x is then produced inside the launch), skip tensor res2 and tail (max over the
  * workgroup's positions of Softplus(Wb . ReLU(Wa . out + ba) + bb), weights [Cin][Cout]; tail_max [B][tiles][C], tiles =
  * ceil(L / 256) without a front, ceil(L / 252) with one).  form: 0 = the 8-channel block entirely on the vector ALU, 1 = its split
- * form (convs on the matrix cores, front / SiLU / adds on the vector ALU), -1 = the library's choice; form | 0x100 first fills every CU's LDS with NaN (a launch that
- * reads LDS it has not written then fails the comparison). */
+ * form (convs on the matrix cores, front / SiLU / adds on the vector ALU), -1 = the library's choice; form | 0x100 (form in the low byte, 0xff = the library's choice) first
+ * fills every CU's LDS with NaN: a launch that depends on LDS it has not written then fails the comparison. */
 int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1, const float* res2,
                           float* out, int64_t B, int32_t C, int32_t L, const float* f_in, const float* f_w, const float* f_b,
                           int32_t Cf, int32_t f_up, const float* ta_w, const float* ta_b, const float* tb_w, const float* tb_b,

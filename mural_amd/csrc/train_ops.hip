@@ -1058,6 +1058,23 @@ extern "C" int mural_debug_cb8_set_stamps(unsigned long long* stamps) {
   return MURAL_OK;
 }
 
+// (validation only) every CU's whole LDS filled with NaN: what a kernel reads from LDS without having written it shows up in its results
+__global__ __launch_bounds__(256) void lds_poison_kernel(float* sink) {
+  extern __shared__ float lds_all[];
+  for (int i = threadIdx.x; i < 160 * 256; i += 256) lds_all[i] = __builtin_nanf("");
+  __syncthreads();
+  if (sink && lds_all[(threadIdx.x * 97) % (160 * 256)] == 1.f) sink[0] = 1.f;
+}
+static int poison_lds(hipStream_t stream) {
+  MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+  hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, stream, (float*)nullptr);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+// validation hook: fill every CU's LDS with NaN on `stream` (tests call it in front of a product call whose result they check: a
+// kernel whose result depends on LDS it has not written then fails its parity comparison instead of passing by the luck of the leftovers)
+extern "C" int mural_debug_poison_lds(void* stream) { return poison_lds(STREAM); }
+
 // validation hook (tests/test_gpu_indel.py): the generic conv with every geometry knob of Conv1dArgs, on the vector-ALU kernel
 // (engine 0), the MFMA implicit-GEMM kernel (engine 1), the router's choice (engine 2), the polyphase form (3) or the barrier-free
 // long-row kernel (engine 4, conv1d_direct.hip)
@@ -1070,6 +1087,10 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
   a.B = (int)B; a.Cin = Cin; a.Lin = Lin; a.Cout = Cout; a.Lout = Lout;
   a.K = K; a.stride = stride; a.pad = (K - 1) / 2; a.up = up;
   a.act = act; a.res1 = res1; a.res2 = res2;
+  if (engine & 0x100) {      // every CU's LDS filled with NaN first
+    engine &= 0xff;
+    if (int rc = poison_lds(STREAM)) return rc;
+  }
   if (engine == 1) {
     MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA): unsupported geometry");
     return launch_conv1d_mfma(a, STREAM);
@@ -1103,13 +1124,6 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
 // (k = 7 conv Cf -> C on the input upsampled f_up times), skip tensor and tail.  form: 0 the 8-channel block entirely on the vector
 // ALU, 1 its split form (convs on the matrix cores), -1 the library's choice.
 namespace mural { extern int g_convblock8_form; }
-// (validation only) every CU's whole LDS filled with NaN: what a kernel reads from LDS without having written it shows up in its results
-__global__ __launch_bounds__(256) void lds_poison_kernel(float* sink) {
-  extern __shared__ float lds_all[];
-  for (int i = threadIdx.x; i < 160 * 256; i += 256) lds_all[i] = __builtin_nanf("");
-  __syncthreads();
-  if (sink && lds_all[(threadIdx.x * 97) % (160 * 256)] == 1.f) sink[0] = 1.f;
-}
 extern "C" int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1,
                                      const float* res2, float* out, int64_t B, int32_t Cch, int32_t L, const float* f_in,
                                      const float* f_w, const float* f_b, int32_t Cf, int32_t f_up, const float* ta_w, const float* ta_b,
@@ -1123,11 +1137,9 @@ extern "C" int mural_debug_convblock(const float* x, const float* w5, const floa
     a.f_in = f_in; a.f_w = f_w; a.f_b = f_b; a.Cf = Cf; a.f_up = f_up; a.Lf = L / f_up;
   }
   a.ta_w = ta_w; a.ta_b = ta_b; a.tb_w = tb_w; a.tb_b = tb_b; a.tail_max = tail_max;
-  if (form >= 0 && (form & 0x100)) {      // poison LDS first
-    form &= 0xff;
-    MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, STREAM, (float*)nullptr);
-    MURAL_HIP_CHECK(hipGetLastError());
+  if (form >= 0 && (form & 0x100)) {      // poison LDS first; the low byte is the form (0xff: the library's choice)
+    form = (form & 0xff) == 0xff ? -1 : (form & 0xff);
+    if (int rc = poison_lds(STREAM)) return rc;
   }
   mural::g_convblock8_form = form;
   const int rc = launch_convblock(a, STREAM);

@@ -52,12 +52,12 @@ for Cin, Cout, Lin, K, stride, up, act, nres in cases:
     for engine, name in ((0, "valu"), (1, "mfma")) + (((3, "polyphase"),) if up > 1 else ()) + (((4, "direct"),) if direct else ()):
         out = torch.full((B, Cout, Lout), float("nan"), device=dev)
 
-        def run():
+        def run(eng=engine):
             _lib.check(lib.mural_debug_conv1d(xd.data_ptr(), wt.data_ptr(), bd.data_ptr(), out.data_ptr(), B, Cin, Lin, Cout, Lout, K, stride,
                                               up, act, None if rd[0] is None else rd[0].data_ptr(),
-                                              None if rd[1] is None else rd[1].data_ptr(), engine, st))
+                                              None if rd[1] is None else rd[1].data_ptr(), eng, st))
         try:
-            run()
+            run(engine | 0x100)                   # every CU's LDS filled with NaN first: no engine may depend on LDS it has not written
         except (RuntimeError, ValueError):        # geometry outside the engine (fewer than 16 GEMM rows)
             line += f"  {name} n/a"
             continue

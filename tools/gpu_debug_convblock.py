@@ -51,7 +51,7 @@ def run(form, B, C, L, front, skip, tail, seed, poison=0):
         d_wa = d_ba = d_wb = d_bb = None
     call = lambda: L_.mural_debug_convblock(ptr(d_x), ptr(d_w5), ptr(d_b5), ptr(d_w1), ptr(d_b1), ptr(d_res), ptr(out), B, C, L, ptr(d_fin),
                                             ptr(d_fw), ptr(d_fb), front[0] if front else 0, front[1] if front else 1, ptr(d_wa), ptr(d_ba),
-                                            ptr(d_wb), ptr(d_bb), ptr(tmax), form if form < 0 else form | poison, None)
+                                            ptr(d_wb), ptr(d_bb), ptr(tmax), (form if form >= 0 else 0xff) | poison if poison else form, None)
     rc = call()
     assert rc == 0, L_.mural_last_error()
     torch.cuda.synchronize()
