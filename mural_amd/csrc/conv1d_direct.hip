@@ -1,4 +1,4 @@
-// Stride-1 Conv1d with 3 / 5 / 7 taps, few channels and LONG rows (the first two levels of the INDEL U-Net in training: 4..32
+// Conv1d (stride 1, or the U-Net's strided encoder convs) with 3 / 5 / 7 taps, few channels and LONG rows (the first two levels of the INDEL U-Net: 4..32
 // channels on rows of 8000 / 2000 columns; reference MuRaL/model/model_indel.py:6-19, :29-38 under model.train(), and the input
 // gradients of the same layers) on v_mfma_f32_16x16x4_f32 with both operands taken straight from global memory -- no LDS tile, no
 // staging loop, no workgroup barrier.  Same contract as conv1d.hip / conv1d_mfma.hip for the cases it takes (Conv1dArgs: bias,
@@ -62,9 +62,9 @@ __device__ __forceinline__ void cd_st1(__amdgpu_buffer_rsrc_t r, uint32_t voff, 
   __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), r, voff, soff, 0);
 }
 
-// MB: 16-channel output blocks; CP: input channel pairs; U: segments per group (register double buffer of U * CP quads);
+// MB: 16-channel output blocks; CP: input channel pairs; U: segments per group (NBUF register buffers of U * CP quads each);
 // RES: residual tensors are read (their loads are not even issued otherwise)
-template <int MB, int CP, int U, bool RES>
+template <int MB, int CP, int U, bool RES, int NBUF>
 __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g, const float* __restrict__ wt, const float* __restrict__ bias) {
   const Conv1dArgs& a = g.a;
   const int lane = threadIdx.x & 63;
@@ -96,7 +96,8 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g
       bz[m][r] = (bias && co < a.Cout) ? bias[co] : 0.f;
       vo[m][r] = co < a.Cout ? (uint32_t)(co * a.Lout + n) * 4u : CD_OOB;
     }
-  const uint32_t vx = (uint32_t)(half * a.Lin + n + 4 * tg) * 4u;      // lane part of the interior quad address
+  const int S = a.stride;      // (strided convs: column n reads from S n -- the quads of neighbouring lanes overlap less, nothing else changes)
+  const uint32_t vx = (uint32_t)(half * a.Lin + S * n + 4 * tg) * 4u;      // lane part of the interior quad address
 
   // one segment from its CP quads: MFMAs (two accumulation chains per block -- even / odd channel pairs -- so that a chain's next
   // MFMA never waits for its own result), then bias / activation / residuals / store.  sy: scalar part of the output address;
@@ -155,11 +156,11 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g
     auto load = [&](Buf& t, int grp) {
       const uint32_t b = g.dGr.div((uint32_t)grp);
       const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr) * U) * 16u;
-      const uint32_t sx = (b * (uint32_t)(a.Cin * a.Lin) + p0 - (uint32_t)a.pad) * 4u;
+      const uint32_t sx = (b * (uint32_t)(a.Cin * a.Lin) + (uint32_t)S * p0 - (uint32_t)a.pad) * 4u;
 #pragma unroll
       for (int u = 0; u < U; ++u)
 #pragma unroll
-        for (int c = 0; c < CP; ++c) t.q[u][c] = cd_ld4(rx, vx, sx + 64u * u + (uint32_t)(2 * c * a.Lin) * 4u);
+        for (int c = 0; c < CP; ++c) t.q[u][c] = cd_ld4(rx, vx, sx + 64u * (uint32_t)(S * u) + (uint32_t)(2 * c * a.Lin) * 4u);
     };
     auto compute = [&](const Buf& t, int grp) {
       const uint32_t b = g.dGr.div((uint32_t)grp);
@@ -170,23 +171,52 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g
     };
     int cur = wid;
     if (cur < g.ngroups) {
-      Buf t0, t1;
-      load(t0, cur);
-      for (;;) {
-        int nx = cur + nwaves;
-        load(t1, nx < g.ngroups ? nx : cur);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(t0, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nx;
-        if (cur >= g.ngroups) break;
-        nx = cur + nwaves;
-        load(t0, nx < g.ngroups ? nx : cur);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(t1, cur);
-        __builtin_amdgcn_sched_barrier(0);
-        cur = nx;
-        if (cur >= g.ngroups) break;
+      if constexpr (NBUF == 2) {
+        Buf t0, t1;
+        load(t0, cur);
+        for (;;) {
+          int nx = cur + nwaves;
+          load(t1, nx < g.ngroups ? nx : cur);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(t0, cur);
+          __builtin_amdgcn_sched_barrier(0);
+          cur = nx;
+          if (cur >= g.ngroups) break;
+          nx = cur + nwaves;
+          load(t0, nx < g.ngroups ? nx : cur);
+          __builtin_amdgcn_sched_barrier(0);
+          compute(t1, cur);
+          __builtin_amdgcn_sched_barrier(0);
+          cur = nx;
+          if (cur >= g.ngroups) break;
+        }
+      } else {
+        // three buffers: the loads run TWO groups ahead (a group of the deep-reduction configurations is < 1 us of MFMAs, less than a
+        // loaded round trip to HBM; with two waves per SIMD one group of distance left the matrix pipe waiting)
+        Buf t0, t1, t2;
+        auto ahead = [&](int c) { const int x = c + 2 * nwaves; return x < g.ngroups ? x : c; };
+        load(t0, cur);
+        load(t1, cur + nwaves < g.ngroups ? cur + nwaves : cur);
+        for (;;) {
+          load(t2, ahead(cur));
+          __builtin_amdgcn_sched_barrier(0);
+          compute(t0, cur);
+          __builtin_amdgcn_sched_barrier(0);
+          cur += nwaves;
+          if (cur >= g.ngroups) break;
+          load(t0, ahead(cur));
+          __builtin_amdgcn_sched_barrier(0);
+          compute(t1, cur);
+          __builtin_amdgcn_sched_barrier(0);
+          cur += nwaves;
+          if (cur >= g.ngroups) break;
+          load(t1, ahead(cur));
+          __builtin_amdgcn_sched_barrier(0);
+          compute(t2, cur);
+          __builtin_amdgcn_sched_barrier(0);
+          cur += nwaves;
+          if (cur >= g.ngroups) break;
+        }
       }
     }
   }
@@ -200,7 +230,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g
     f32x4 q[CP];
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const int pos = p0 + n - a.pad + 4 * tg + e;
+      const int pos = S * (p0 + n) - a.pad + 4 * tg + e;
       const bool ok = (pos >= 0) & (pos < a.Lin);
       uint32_t off = (uint32_t)(half * a.Lin + pos) * 4u;
       asm volatile("" : "+v"(off));      // (a select, not a branch around the loads)
@@ -213,12 +243,12 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g
 }
 
 bool direct_plan(const Conv1dArgs& a, int* mb, int* cp) {
-  if (a.stride != 1 || a.up != 1 || a.phases > 1 || a.pre_s || a.pre_t || a.pre_relu) return false;
+  if (a.stride < 1 || a.stride > 8 || a.up != 1 || a.phases > 1 || a.pre_s || a.pre_t || a.pre_relu) return false;
   if (a.K != 3 && a.K != 5 && a.K != 7) return false;
   if (a.Cin != 4 && a.Cin != 8 && a.Cin != 16 && a.Cin != 32) return false;
   if (a.Cout < 1 || a.Cout > 32 || (a.Cout > 16 && a.Cin > 16)) return false;
   if (a.Cout <= 8 && a.Cin >= 16) return false;      // half of every MFMA's rows idle under a deep reduction: the vector-ALU kernel is faster (58 vs 50 us)
-  if (a.Lout != a.Lin + 2 * a.pad - a.K + 1 || a.pad < 0 || a.pad > a.K - 1) return false;
+  if (a.pad < 0 || a.pad > a.K - 1 || a.Lin + 2 * a.pad < a.K || a.Lout != (a.Lin + 2 * a.pad - a.K) / a.stride + 1) return false;
   const uint64_t xb = (uint64_t)a.B * a.Cin * a.Lin * 4, yb = (uint64_t)a.B * a.Cout * a.Lout * 4;
   if (xb >= (1ull << 31) || yb >= (1ull << 31)) return false;
   *mb = (a.Cout + 15) / 16;
@@ -245,10 +275,12 @@ int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream) {
   g.y_bytes = (uint32_t)((uint64_t)a.B * a.Cout * a.Lout * 4);
   const bool res = a.res1 != nullptr || a.res2 != nullptr;
   int wgs = 1;
-  // interior segments of a row: p0 >= pad, the last quad (p0 + 22 - pad) inside the row, all 16 columns inside the output row
+  // interior segments of a row: S p0 >= pad, the last quad (S (p0 + 15) + 7 - pad) inside the row, all 16 columns inside the output row
   auto plan = [&](int U) {
-    const int e0 = (a.pad + 15) / 16;
-    const int last_in = a.Lin - 23 + a.pad >= 0 ? (a.Lin - 23 + a.pad) / 16 : -1;
+    const int S = a.stride;
+    const int e0 = (a.pad + 16 * S - 1) / (16 * S);
+    const int room = a.Lin - 8 + a.pad - 15 * S;      // S p0 <= room
+    const int last_in = room >= 0 ? (room / S) / 16 : -1;
     const int last_out = a.Lout >= 16 ? (a.Lout - 16) / 16 : -1;
     const int ir = std::max(0, std::min(last_in, last_out) - e0 + 1);
     g.e0 = e0;
@@ -262,21 +294,21 @@ int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream) {
     const int units = g.ngroups + g.nslow;
     wgs = std::max(1, std::min(2048, std::min((units + 3) / 4, std::max(512, (units + 31) / 32))));
   };
-#define MURAL_CD(MB_, CP_, U_)                                                                                       \
+#define MURAL_CD(MB_, CP_, U_, NB_)                                                                                  \
   do {                                                                                                              \
     plan(U_);                                                                                                       \
-    if (res) hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, true>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);  \
-    else hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, false>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);     \
+    if (res) hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, true, NB_>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);  \
+    else hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, false, NB_>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);     \
   } while (0)
   if (mb == 1) {
-    if (cp == 2) MURAL_CD(1, 2, 8);
-    else if (cp == 4) MURAL_CD(1, 4, 4);
-    else if (cp == 8) MURAL_CD(1, 8, 2);
-    else MURAL_CD(1, 16, 1);
+    if (cp == 2) MURAL_CD(1, 2, 8, 2);
+    else if (cp == 4) MURAL_CD(1, 4, 4, 2);
+    else if (cp == 8) MURAL_CD(1, 8, 2, 2);
+    else MURAL_CD(1, 16, 1, 2);
   } else {
-    if (cp == 2) MURAL_CD(2, 2, 8);
-    else if (cp == 4) MURAL_CD(2, 4, 4);
-    else MURAL_CD(2, 8, 1);
+    if (cp == 2) MURAL_CD(2, 2, 8, 2);
+    else if (cp == 4) MURAL_CD(2, 4, 4, 2);
+    else MURAL_CD(2, 8, 1, 3);
   }
 #undef MURAL_CD
   MURAL_HIP_CHECK(hipGetLastError());
