@@ -242,6 +242,16 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g
   }
 }
 
+// workgroups of `fn` that fit the device at a time (2048 if the runtime will not say)
+int resident_workgroups(const void* fn, int threads) {
+  int per_cu = 0, dev = 0;
+  hipDeviceProp_t prop;
+  if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+      hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, threads, 0) == hipSuccess && per_cu > 0)
+    return per_cu * prop.multiProcessorCount;
+  return 2048;
+}
+
 bool direct_plan(const Conv1dArgs& a, int* mb, int* cp) {
   if (a.stride < 1 || a.stride > 8 || a.up != 1 || a.phases > 1 || a.pre_s || a.pre_t || a.pre_relu) return false;
   if (a.K != 3 && a.K != 5 && a.K != 7) return false;
@@ -297,6 +307,15 @@ int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream) {
 #define MURAL_CD(MB_, CP_, U_, NB_)                                                                                  \
   do {                                                                                                              \
     plan(U_);                                                                                                       \
+    /* persistent waves: no more workgroups than are resident at a time (a larger grid runs in rounds, the last one part empty) */ \
+    static int cap_res = 0, cap_plain = 0;                                                                          \
+    int& cap = res ? cap_res : cap_plain;                                                                           \
+    if (cap == 0) {                                                                                                 \
+      const void* fn = res ? reinterpret_cast<const void*>(conv1d_direct_kernel<MB_, CP_, U_, true, NB_>)           \
+                           : reinterpret_cast<const void*>(conv1d_direct_kernel<MB_, CP_, U_, false, NB_>);         \
+      cap = resident_workgroups(fn, 256);                                                                           \
+    }                                                                                                               \
+    if (getenv("MURAL_DIRECT_GRID_CAP") == nullptr || atoi(getenv("MURAL_DIRECT_GRID_CAP")) != 0) wgs = std::min(wgs, cap); \
     if (res) hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, true, NB_>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);  \
     else hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, false, NB_>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);     \
   } while (0)

@@ -70,10 +70,13 @@ __global__ __launch_bounds__(256, 2) void convblock_mfma_kernel(const ConvBlockA
 
   // the MFMA phase of one tile: tile (LDS) -> otile (LDS)
   auto compute_tile = [&](int l0) {
+    // the tile's 16-position blocks go round the waves (block 4 pb + wave): a partial tile -- the second one of a 400-column row holds 9
+    // blocks -- costs ceil(blocks / 4) block times, not the 4 of its fullest wave
 #pragma unroll 1
     for (int pb = 0; pb < 4; ++pb) {
-      const int p = 64 * wave + 16 * pb + n16;          // tile-relative position of this lane's column
-      if (l0 + 64 * wave + 16 * pb >= a.L) break;       // wave-uniform: nothing of this block is inside the row
+      const int blk = 4 * pb + wave;
+      if (l0 + 16 * blk >= a.L) break;                  // wave-uniform: nothing of this block (or of the wave's later ones) is inside the row
+      const int p = 16 * blk + n16;                     // tile-relative position of this lane's column
       const float* xp = tile + kk * CM_PITCH + p + 2;   // x[ci = 4 cq + kk][p + t - 2] sits at xp[4 cq * pitch + t] (tile origin l0 - 4)
       f32x4 acc1[MB1];
 #pragma unroll
@@ -84,21 +87,35 @@ __global__ __launch_bounds__(256, 2) void convblock_mfma_kernel(const ConvBlockA
 #pragma unroll
         for (int mb = 0; mb < MB1; ++mb) acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mb][s], bv, acc1[mb], 0, 0, 0);
       }
-      f32x4 acc2[MB2];
+      // SiLU of all the hidden values as ONE burst of vector instructions (every MFMA -> vector -> MFMA switch costs issue cycles on
+      // this part, tools/microbench), then GEMM 2 on two accumulator chains per output block (even / odd k-steps)
+      float hv[KS2];
 #pragma unroll
-      for (int mb = 0; mb < MB2; ++mb) acc2[mb] = bias2[mb];
+      for (int s = 0; s < KS2; ++s) hv[s] = silu_fast(acc1[s >> 2][s & 3]);
+      f32x4 acc2[MB2], acc2b[MB2];      // (one output block: its k-steps alternate between two chains; two blocks ARE two chains)
 #pragma unroll
-      for (int s = 0; s < KS2; ++s) {
-        const float hv = silu_fast(acc1[s >> 2][s & 3]);
+      for (int mb = 0; mb < MB2; ++mb) {
+        acc2[mb] = bias2[mb];
+        acc2b[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      if constexpr (MB2 == 1) {
 #pragma unroll
-        for (int mb = 0; mb < MB2; ++mb) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb][s], hv, acc2[mb], 0, 0, 0);
+        for (int s = 0; s < KS2; s += 2) {
+          acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0][s], hv[s], acc2[0], 0, 0, 0);
+          acc2b[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0][s + 1], hv[s + 1], acc2b[0], 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < KS2; ++s)
+#pragma unroll
+          for (int mb = 0; mb < MB2; ++mb) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb][s], hv[s], acc2[mb], 0, 0, 0);
       }
 #pragma unroll
       for (int mb = 0; mb < MB2; ++mb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int c = 16 * mb + 4 * kk + r;
-          if (c < C) otile[c * CM_PITCH + p] = tile[c * CM_PITCH + p + 4] + acc2[mb][r];
+          if (c < C) otile[c * CM_PITCH + p] = tile[c * CM_PITCH + p + 4] + (MB2 == 1 ? acc2[mb][r] + acc2b[mb][r] : acc2[mb][r]);
         }
     }
   };
@@ -218,7 +235,21 @@ bool convblock_mfma_supported(const ConvBlockArgs& a) {
 
 int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream) {
   const int64_t tiles = (int64_t)a.B * ((a.L + 255) / 256);
-  const dim3 grid((unsigned)(tiles < 2048 ? tiles : 2048));
+  // persistent workgroups: exactly as many as are resident at a time (a grid of 2048 on 768 resident ones runs in rounds of 768, 768,
+  // 512 -- the last round a third empty)
+  static int resident[2] = {0, 0};
+  int& res = resident[a.C == 16 ? 0 : 1];
+  if (res == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    const void* fn = a.C == 16 ? reinterpret_cast<const void*>(convblock_mfma_kernel<16>) : reinterpret_cast<const void*>(convblock_mfma_kernel<24>);
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, 256, 0) == hipSuccess && per_cu > 0)
+      res = per_cu * prop.multiProcessorCount;
+    else
+      res = 2048;
+  }
+  const dim3 grid((unsigned)(tiles < res ? tiles : res));
   if (a.C == 16) hipLaunchKernelGGL(convblock_mfma_kernel<16>, grid, dim3(256), 0, stream, a);
   else hipLaunchKernelGGL(convblock_mfma_kernel<24>, grid, dim3(256), 0, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());

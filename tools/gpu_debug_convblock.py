@@ -63,9 +63,9 @@ def run(form, B, C, L, front, skip, tail, seed, poison=0):
 if __name__ == "__main__":
     worst = 0.0
     cases = []
-    for C in (8, 16):
+    for C in (8, 16, 24):
         for form in ((0, 1) if C == 8 else (-1,)):
-            for (B, L) in ((3, 1000), (2, 252), (5, 37), (2, 8000)):
+            for (B, L) in ((3, 1000), (2, 252), (5, 37), (2, 8000), (3, 400)):
                 for front in (None, (4, 1), (16, 4)):
                     if front and L % front[1]:
                         continue
@@ -80,6 +80,17 @@ if __name__ == "__main__":
             print(c, "err %.2e" % err, "<-- BAD" if bad else "", flush=True)
     print("cases %d worst %.2e" % (len(cases), worst))
     if os.environ.get("TIME"):
+        for Cc, Lc in ((16, 2000), (24, 400)):
+            for skip in (False, True):
+                _, call = run(-1, 2048, Cc, Lc, None, skip, False, seed=1)
+                for _ in range(3):
+                    call()
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                for _ in range(20):
+                    call()
+                torch.cuda.synchronize()
+                print("C", Cc, "L", Lc, "skip", skip, "%.1f us" % ((time.perf_counter() - t) / 20 * 1e6), flush=True)
         for form in (0, 1):
             for front, skip, tail in (((4, 1), False, False), ((16, 4), True, True), (None, False, False)):
                 _, call = run(form, 2048, 8, 8000, front, skip, tail, seed=1)
