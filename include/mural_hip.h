@@ -369,15 +369,17 @@ int mural_debug_poison_lds(void* stream);
 
 /* Validation hook: one fused ConvBlock launch of the INDEL forward (model_indel.py:6-19: x + W1 . SiLU(W5 * x + b5) + b1, BatchNorms
  * folded; w5 [C][5][2C], w1 [2C][C]) with its optional front (f_in [B][Cf][L / f_up], k = 7 conv Cf -> C with weights f_w [Cf][7][C]
- * on the input upsampled f_up times: the block input x is then produced inside the launch), skip tensor res2 and tail (max over the
+ * on the input upsampled f_up times: the block input x is then produced inside the launch; f_pw, optional with f_up == 4: the same
+ * weights in polyphase form [4 phases][Cf][3 source columns][C], taps that share a source column summed), skip tensor res2 and tail (max over the
  * workgroup's positions of Softplus(Wb . ReLU(Wa . out + ba) + bb), weights [Cin][Cout]; tail_max [B][tiles][C], tiles =
- * ceil(L / 256) without a front, ceil(L / 252) with one).  form: 0 = the 8-channel block entirely on the vector ALU, 1 = its split
+ * ceil(L / 256) without a front, ceil(L / 252) with one, ceil(L / 248) for the split form with f_pw and Cf = 16; entries the launch
+ * does not write keep the caller's values).  form: 0 = the 8-channel block entirely on the vector ALU, 1 = its split
  * form (convs on the matrix cores, front / SiLU / adds on the vector ALU), -1 = the library's choice; form | 0x100 (form in the low byte, 0xff = the library's choice) first
  * fills every CU's LDS with NaN: a launch that depends on LDS it has not written then fails the comparison. */
 int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1, const float* res2,
                           float* out, int64_t B, int32_t C, int32_t L, const float* f_in, const float* f_w, const float* f_b,
-                          int32_t Cf, int32_t f_up, const float* ta_w, const float* ta_b, const float* tb_w, const float* tb_b,
-                          float* tail_max, int32_t form, void* stream);
+                          int32_t Cf, int32_t f_up, const float* f_pw, const float* ta_w, const float* ta_b, const float* tb_w,
+                          const float* tb_b, float* tail_max, int32_t form, void* stream);
 
 /* Diagnostic: the MFMA conv's workgroups of the following launches record 5 s_memrealtime values each (start, tile staged, MFMAs done,
  * stores issued, stores landed) into `stamps` (device memory, 5 x workgroups entries); NULL switches it off. */

@@ -161,7 +161,7 @@ PROTOTYPES = {
     "mural_debug_conv1d": (C.c_int, [VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP, I32, VP]),
     "mural_debug_conv1d_set_stamps": (C.c_int, [VP]),
     "mural_debug_poison_lds": (C.c_int, [VP]),
-    "mural_debug_convblock": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, I64, I32, I32, VP, VP, VP, I32, I32, VP, VP, VP, VP, VP, I32, VP]),
+    "mural_debug_convblock": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, I64, I32, I32, VP, VP, VP, I32, I32, VP, VP, VP, VP, VP, VP, I32, VP]),
     "mural_debug_cb8_set_stamps": (C.c_int, [VP]),
     "mural_last_error": (C.c_char_p, []),
     "mural_abi_version": (C.c_int, []),

@@ -83,7 +83,8 @@ struct ConvBlockArgs {
   float* tail_max;
 };
 bool convblock_supported(int C);
-int convblock_tiles(int L, bool front);   // workgroups per row = entries per row of tail_max
+int convblock_tiles(int L, bool front);   // upper bound of the workgroups per row (sizing of tail_max)
+int convblock_tiles_of(const ConvBlockArgs& a);   // workgroups per row of this launch = entries per row of its tail_max
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream);
 // fp32-MFMA version of the plain block (no front, no tail) for C = 16 / 24 (convblock_mfma.hip); launch_convblock routes to it
 bool convblock_mfma_supported(const ConvBlockArgs& a);

@@ -293,8 +293,10 @@ int launch_conv1d_valu(const Conv1dArgs& a_in, hipStream_t stream) {
 // conv fills 2C accumulators from the LDS tile (weights as scalar pairs, v_pk_fma_f32), SiLU runs on them in place, the
 // 1x1 conv contracts them to C outputs, the block input is added back from the tile.  HBM traffic: read x, write out
 // (+ read res2) instead of also writing and re-reading the 2C-channel intermediate.
+int g_convblock8_form = -1;      // validation hook (mural_debug_convblock): 0 vector-ALU form, 1 split form, -1 the environment's choice
 constexpr int CB_FRONT_FLOATS = 2048;          // front input tile: Cf x (262 / up + 3) floats
 constexpr int CB_FRONT_OUT = 252;              // output positions per workgroup of the front variant
+constexpr int CB_FRONT_OUT_POLY = 248;         // ... of the split form with the polyphase front on the matrix cores
 
 // floats of the split form's front-input region (also holds the tail's 32 partial maxima)
 __host__ __device__ inline int convblock_front_floats(int Cf, int f_up, bool front) {
@@ -354,7 +356,9 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
   constexpr int PW_FLOATS = (FRONT && C == 8) ? 4 * 16 * 3 * 8 : 4;      // polyphase front weights of the four phases (Cf <= 16)
   __shared__ __attribute__((aligned(16))) float pw_s[MF ? 4 : PW_FLOATS];
   float* const pwS = MF ? hs + convblock_front_floats(a.Cf, a.f_up, FRONT) : pw_s;
-  if (FRONT && C == 8 && a.f_pw != nullptr && a.Cf * 3 * C * 4 <= PW_FLOATS)
+  // split form, decoder: the polyphase front itself runs on the matrix cores (POLY, below) -- its weights are A fragments in registers
+  const bool POLY = MF && FRONT && a.f_pw != nullptr && a.Cf == 16 && a.f_up == 4;
+  if (FRONT && C == 8 && !POLY && a.f_pw != nullptr && a.Cf * 3 * C * 4 <= PW_FLOATS)
     for (int i = threadIdx.x; i < a.Cf * 3 * C * 4; i += 256) pwS[i] = a.f_pw[i];      // visible behind the front's first barrier
   float* fin = hs;                             // front input tile: dead before the first SiLU output is parked (a barrier in between),
                                                // and 8 KB less LDS is two more workgroups per CU to hide the scalar weight loads
@@ -363,8 +367,23 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
   // without a front a workgroup covers 256 positions (tile = positions l0-2 .. l0+257); with one it covers CB_FRONT_OUT =
   // 252: lane tid computes the block INPUT at position l0-2+tid (256 of them, no second pass for the halo) and, for
   // 2 <= tid < 254, the block OUTPUT at that same position
-  constexpr int OUTW = FRONT ? CB_FRONT_OUT : 256;
+  // (POLY: 248 outputs = 62 source columns + one of halo each side = the 64 source columns of four 16-column MFMA blocks, one per wave;
+  // the tile then starts at position l0 - 4, not l0 - 2)
+  const int OUTW = FRONT ? (POLY ? CB_FRONT_OUT_POLY : CB_FRONT_OUT) : 256;
   const int l0 = blockIdx.x * OUTW;
+  float af[MF && FRONT ? 2 : 1][MF && FRONT ? 12 : 1];      // POLY: A fragments of the front, lane (row 16 mb + n16 = 4 co + phase, kk)
+  if constexpr (MF && FRONT) {
+    if (POLY) {
+      const int n16f = threadIdx.x & 15, kkf = (threadIdx.x >> 4) & 3;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+          const int d = s >> 2, ci = 4 * (s & 3) + kkf, row = 16 * mb + n16f, co = row >> 2, ph = row & 3;
+          af[mb][s] = a.f_pw[(((size_t)ph * 16 + ci) * 3 + d) * C + co];
+        }
+    }
+  }
   if (!FRONT) {
     const float* src = a.x + (size_t)b * C * a.L;
     constexpr int UN = 4;                        // loads of a thread in flight (a round per load = a global round trip per round)
@@ -472,7 +491,38 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
     }
     __syncthreads();
     CB_STAMP(1);
-    if (a.f_pw) {
+    if (MF && POLY) {
+      if constexpr (MF) {
+        // polyphase front as a GEMM on the SOURCE columns: rows = (channel, phase) -- 32 = two M-blocks --, k = (tap d of 3, 16 input
+        // channels) = 12 k-steps, columns = this wave's 16 source columns l0 / 4 - 1 + 16 wave + n.  Lane (n, kk) ends up with the four
+        // phases = four consecutive positions of channel 4 mb + kk: one 16-byte store into the tile (origin l0 - 4).  Against the
+        // vector form: 24 MFMAs for 192 packed FMAs (the same pipe time), but 12 LDS reads per wave instead of 144 -- the 96 broadcast
+        // 16-byte weight reads alone kept the CU's one LDS pipe as busy as its SIMDs.
+        const int wvf = __builtin_amdgcn_readfirstlane(tid >> 6);
+        const int n16f = tid & 15, kkf = (tid >> 4) & 3;
+        const float* sp = fin + kkf * span + 16 * wvf + n16f;      // x[ci = 4 cq + kk][source + d - 1] = sp[4 cq span + d]
+        f32x4 accf[2] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
+#pragma unroll
+        for (int s = 0; s < 12; ++s) {
+          const float bv = sp[4 * (s & 3) * span + (s >> 2)];
+          accf[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[0][s], bv, accf[0], 0, 0, 0);
+          accf[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[1][s], bv, accf[1], 0, 0, 0);
+        }
+        const int j = 64 * wvf + 4 * n16f;                         // tile entry of phase 0 (position l0 - 4 + j)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const int co = 4 * mb + kkf;
+          const float fb = f_b[co];
+          float o4[4];
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int l = l0 - 4 + j + r;
+            o4[r] = (l >= 0 && l < a.L) ? accf[mb][r] + fb : 0.f;      // the k=5 conv zero-pads ITS input
+          }
+          *reinterpret_cast<f32x4*>(tile + co * TWp + j) = f32x4{o4[0], o4[1], o4[2], o4[3]};
+        }
+      }
+    } else if (a.f_pw) {
       // polyphase front (f_up == 4, workgroup origin l0 a multiple of 4): position l only sees the source columns l / 4 + d,
       // d in {-1, 0, 1}, with the taps that share a column summed on the host per phase l % 4.  Wave w takes the tile entries
       // j = 4 lane + w -- one phase per wave, so the phase's weights stay wave-uniform (scalar loads) -- and does 3 / 7 of the
@@ -585,7 +635,7 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
   if constexpr (MF) {
     // virtual lane t = 64 wave + 16 block + n16 plays the role the lane plays in the vector form (tile index toff(t), position l(t))
     const int t0 = (tid & ~63) + n16;
-    auto toff_of = [&](int t) { return FRONT ? (t >= 2 ? t - 2 : 0) : t; };
+    auto toff_of = [&](int t) { return (FRONT && !POLY) ? (t >= 2 ? t - 2 : 0) : t; };      // (POLY: the tile starts two positions earlier)
     f32x4 acc[4];
     const float* xb[4];
 #pragma unroll
@@ -643,7 +693,7 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
       for (int p = 0; p < 2; ++p) {
         const int t = t0 + 16 * (p + 2 * (kk >> 1));
         const int l = FRONT ? l0 - 2 + t : l0 + t;
-        live[p] = FRONT ? ((t >= 2) & (t < 2 + CB_FRONT_OUT) & (l < a.L)) : (l < a.L);
+        live[p] = FRONT ? ((t >= 2) & (t < 2 + OUTW) & (l < a.L)) : (l < a.L);
         uint32_t off = ((uint32_t)cb * (uint32_t)a.L + (uint32_t)l) * 4u;
         off = live[p] ? off : 0x80000000u;
         asm volatile("" : "+v"(off));
@@ -819,21 +869,35 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
 
 bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24; }   // LDS: tile + 2C x 256 floats
 
-int convblock_tiles(int L, bool front) { return front ? (L + CB_FRONT_OUT - 1) / CB_FRONT_OUT : (L + 255) / 256; }
+// upper bound of the workgroups per row (sizing of tail_max); the exact count of a launch: convblock_tiles_of
+int convblock_tiles(int L, bool front) { return front ? (L + CB_FRONT_OUT_POLY - 1) / CB_FRONT_OUT_POLY : (L + 255) / 256; }
 
-extern unsigned long long* g_cb8_stamps;      // (convblock8_mfma.hip)
-int g_convblock8_form = -1;      // validation hook (mural_debug_convblock): 0 vector-ALU form, 1 split form, -1 the environment's choice
+static bool convblock8_valu_form() {
+  static const bool valu8_env = getenv("MURAL_CONVBLOCK8_VALU") != nullptr && getenv("MURAL_CONVBLOCK8_VALU")[0] == '1';
+  return g_convblock8_form >= 0 ? g_convblock8_form == 0 : valu8_env;
+}
+static bool convblock_poly_mfma(const ConvBlockArgs& a) {
+  return a.C == 8 && !convblock8_valu_form() && a.f_in != nullptr && a.symtab == nullptr && a.f_pw != nullptr && a.Cf == 16 && a.f_up == 4;
+}
+// workgroups per row of THIS launch = entries per row of its tail_max
+int convblock_tiles_of(const ConvBlockArgs& a) {
+  const bool front = a.f_in != nullptr || a.symtab != nullptr;
+  if (!front) return (a.L + 255) / 256;
+  if (!convblock_mfma_supported(a) && !convblock8_mfma_supported(a) && convblock_poly_mfma(a)) return (a.L + CB_FRONT_OUT_POLY - 1) / CB_FRONT_OUT_POLY;
+  return (a.L + CB_FRONT_OUT - 1) / CB_FRONT_OUT;
+}
+
+extern unsigned long long* g_cb8_stamps;      // (convblock8_mfma.hip)      // validation hook (mural_debug_convblock): 0 vector-ALU form, 1 split form, -1 the environment's choice
 
 template <bool TAIL, bool FRONT>
 static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
-  const dim3 grid(convblock_tiles(a.L, FRONT), a.B);
+  const dim3 grid(convblock_tiles_of(a), a.B);
 #define MURAL_CB(CN)                                                                                                        \
   hipLaunchKernelGGL((convblock_kernel<CN, TAIL, FRONT, MFV>), grid, dim3(256), MFV ? mf_lds : 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, \
                      a.tb_w, a.tb_b, a.f_w, a.f_b, g_cb8_stamps)
   // MURAL_CONVBLOCK8_VALU=1: the 8-channel block entirely on the vector ALU (A/B switch for the split form)
-  const size_t mf_lds = (size_t)(8 * 272 + convblock_front_floats(a.Cf, a.f_up, FRONT) + (a.f_pw ? 4 * 16 * 3 * 8 : 0)) * sizeof(float);
-  static const bool valu8_env = getenv("MURAL_CONVBLOCK8_VALU") != nullptr && getenv("MURAL_CONVBLOCK8_VALU")[0] == '1';
-  const bool valu8 = g_convblock8_form >= 0 ? g_convblock8_form == 0 : valu8_env;
+  const size_t mf_lds = (size_t)(8 * 272 + convblock_front_floats(a.Cf, a.f_up, FRONT) + ((a.f_pw && !convblock_poly_mfma(a)) ? 4 * 16 * 3 * 8 : 0)) * sizeof(float);
+  const bool valu8 = convblock8_valu_form();
   switch (a.C) {
     case 8: {
       if (valu8) {

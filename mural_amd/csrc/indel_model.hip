@@ -312,7 +312,8 @@ struct GenomeSrc {      // packed-genome source of the first level's front input
 
 static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
                      float* H, float* out, const float* skip, hipStream_t stream, float* tail_max = nullptr,
-                     const FoldedConv* ff = nullptr, const float* fin = nullptr, int up = 1, const GenomeSrc* gs = nullptr) {
+                     const FoldedConv* ff = nullptr, const float* fin = nullptr, int up = 1, const GenomeSrc* gs = nullptr,
+                     int* tiles_out = nullptr) {
   if (block_fusable(f5, f1, L)) {
     ConvBlockArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -330,6 +331,7 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
       a.ta_w = m->blob + m->out1.w; a.ta_b = m->blob + m->out1.b; a.tb_w = m->blob + m->out2.w; a.tb_b = m->blob + m->out2.b;
       a.tail_max = tail_max;
     }
+    if (tiles_out) *tiles_out = convblock_tiles_of(a);
     return launch_convblock(a, stream);
   }
   MURAL_REQUIRE(!tail_max && !ff, "internal: front / tail fusion requested for an unfusable block");
@@ -438,14 +440,17 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
       const bool fuse_tail = lvl == 0 && block_fusable(m->dn5[j], m->dn1[j], Li);
       const int up = sh.down[lvl + 1];
       if (block_fusable(m->dn5[j], m->dn1[j], Li) && front_fusable(m->dn_l[j], up, m->ch[lvl]) && Lcur * up == Li) {
+        int tiles = 0;
         if ((rc = run_block(m, m->dn5[j], m->dn1[j], nullptr, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr, &m->dn_l[j], cur,
-                            up)))
+                            up, nullptr, &tiles)))
           return rc;
-        if (fuse_tail) mparts = convblock_tiles(Li, true);
+        if (fuse_tail) mparts = tiles;
       } else {
         if ((rc = run_upconv(m, j, cur, B, Lcur, T1, Li, up, stream))) return rc;
-        if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr))) return rc;
-        if (fuse_tail) mparts = convblock_tiles(Li, false);
+        int tiles = 0;
+        if ((rc = run_block(m, m->dn5[j], m->dn1[j], T1, B, Li, H, dec, E[lvl], stream, fuse_tail ? M : nullptr, nullptr, nullptr, 1, nullptr, &tiles)))
+          return rc;
+        if (fuse_tail) mparts = tiles;
       }
       tail_done = fuse_tail;
       cur = dec;

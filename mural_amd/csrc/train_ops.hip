@@ -1126,8 +1126,8 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
 namespace mural { extern int g_convblock8_form; }
 extern "C" int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1,
                                      const float* res2, float* out, int64_t B, int32_t Cch, int32_t L, const float* f_in,
-                                     const float* f_w, const float* f_b, int32_t Cf, int32_t f_up, const float* ta_w, const float* ta_b,
-                                     const float* tb_w, const float* tb_b, float* tail_max, int32_t form, void* stream) {
+                                     const float* f_w, const float* f_b, int32_t Cf, int32_t f_up, const float* f_pw, const float* ta_w,
+                                     const float* ta_b, const float* tb_w, const float* tb_b, float* tail_max, int32_t form, void* stream) {
   ConvBlockArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.w5 = w5; a.b5 = b5; a.w1 = w1; a.b1 = b1; a.res2 = res2; a.out = out;
@@ -1135,6 +1135,7 @@ extern "C" int mural_debug_convblock(const float* x, const float* w5, const floa
   if (f_in) {
     MURAL_REQUIRE(f_up >= 1 && L % f_up == 0, "convblock: the front's upsampling factor must divide the row length");
     a.f_in = f_in; a.f_w = f_w; a.f_b = f_b; a.Cf = Cf; a.f_up = f_up; a.Lf = L / f_up;
+    a.f_pw = f_pw;      // optional (f_up == 4): the front's polyphase weights [4][Cf][3][C]
   }
   a.ta_w = ta_w; a.ta_b = ta_b; a.tb_w = tb_w; a.tb_b = tb_b; a.tail_max = tail_max;
   if (form >= 0 && (form & 0x100)) {      // poison LDS first; the low byte is the form (0xff: the library's choice)

@@ -11,7 +11,7 @@ L_ = _lib.lib()
 ptr = lambda t: None if t is None else t.data_ptr()
 
 
-def run(form, B, C, L, front, skip, tail, seed, poison=0):
+def run(form, B, C, L, front, skip, tail, seed, poison=0, poly=False):
     g = torch.Generator().manual_seed(seed)
     rn = lambda *s: torch.randn(*s, generator=g)
     w5, b5 = rn(2 * C, C, 5) / (5 * C) ** 0.5, rn(2 * C) * 0.3            # torch layouts [out][in][k]
@@ -29,7 +29,9 @@ def run(form, B, C, L, front, skip, tail, seed, poison=0):
     want = x + F.conv1d(hid, w1.double(), b1.double())
     if skip:
         want = want + res2.double()
-    tiles = (L + 251) // 252 if front else (L + 255) // 256
+    # workgroups per row: 256 outputs each without a front, 252 with one, 248 for the split form with the polyphase front on the matrix cores
+    width = 256 if not front else (248 if (poly and front == (16, 4) and C == 8 and form != 0) else 252)
+    tiles = (L + width - 1) // width
     if tail:
         wa, ba, wb, bb = rn(C, C, 1) / C ** 0.5, rn(C) * 0.3, rn(C, C, 1) / C ** 0.5, rn(C) * 0.3
         u = F.softplus(F.conv1d(F.relu(F.conv1d(want, wa.double(), ba.double())), wb.double(), bb.double()))
@@ -44,13 +46,22 @@ def run(form, B, C, L, front, skip, tail, seed, poison=0):
     d_fb = dev(fb) if front else None
     d_res = dev(res2) if skip else None
     out = None if tail else torch.full((B, C, L), float("nan"), device="cuda")
-    tmax = torch.full((B, tiles, C), float("nan"), device="cuda") if tail else None
+    tmax = torch.full((B, tiles, C), float("-inf"), device="cuda") if tail else None
+    d_pw = None
+    if front and poly and front[1] == 4:
+        # phase p of output column 4 i + p reads source columns i - 1 + d: the taps k with floor((p - 3 + k) / 4) == d - 1 summed
+        pw = torch.zeros(4, front[0], 3, C)
+        for ph in range(4):
+            for k in range(7):
+                d = (ph - 3 + k) // 4 + 1
+                pw[ph, :, d, :] += fw[:, :, k].t()
+        d_pw = dev(pw)
     if tail:
         d_wa, d_ba, d_wb, d_bb = dev(wa[:, :, 0].t()), dev(ba), dev(wb[:, :, 0].t()), dev(bb)
     else:
         d_wa = d_ba = d_wb = d_bb = None
     call = lambda: L_.mural_debug_convblock(ptr(d_x), ptr(d_w5), ptr(d_b5), ptr(d_w1), ptr(d_b1), ptr(d_res), ptr(out), B, C, L, ptr(d_fin),
-                                            ptr(d_fw), ptr(d_fb), front[0] if front else 0, front[1] if front else 1, ptr(d_wa), ptr(d_ba),
+                                            ptr(d_fw), ptr(d_fb), front[0] if front else 0, front[1] if front else 1, ptr(d_pw), ptr(d_wa), ptr(d_ba),
                                             ptr(d_wb), ptr(d_bb), ptr(tmax), (form if form >= 0 else 0xff) | poison if poison else form, None)
     rc = call()
     assert rc == 0, L_.mural_last_error()
@@ -71,9 +82,11 @@ if __name__ == "__main__":
                         continue
                     for skip in (False, True):
                         for tail in (False, True):
-                            cases.append((form, B, C, L, front, skip, tail))
+                            cases.append((form, B, C, L, front, skip, tail, False))
+                            if front == (16, 4) and C == 8:
+                                cases.append((form, B, C, L, front, skip, tail, True))      # polyphase weights handed over
     for i, c in enumerate(cases):
-        err, _ = run(*c, seed=i, poison=0x100)
+        err, _ = run(*c[:7], seed=i, poison=0x100, poly=c[7])
         bad = not (err <= 3e-6)
         worst = max(worst, err if err == err else 1.0)
         if bad or os.environ.get("VERBOSE"):
@@ -93,7 +106,7 @@ if __name__ == "__main__":
                 print("C", Cc, "L", Lc, "skip", skip, "%.1f us" % ((time.perf_counter() - t) / 20 * 1e6), flush=True)
         for form in (0, 1):
             for front, skip, tail in (((4, 1), False, False), ((16, 4), True, True), (None, False, False)):
-                _, call = run(form, 2048, 8, 8000, front, skip, tail, seed=1)
+                _, call = run(form, 2048, 8, 8000, front, skip, tail, seed=1, poly=True)
                 for _ in range(3):
                     call()
                 torch.cuda.synchronize()
