@@ -357,7 +357,8 @@ int mural_debug_cw_conv32_bwd(const float* dy, const float* x, const float* W, i
 /* Validation hook: the generic Conv1d of the INDEL path with every geometry knob (stride, nearest-neighbour upsampling `up`,
  * activation 0 none / 1 ReLU / 2 SiLU / 3 Softplus, two residuals), weights wt laid out [Cin][K][Cout]; engine 0 = vector-ALU
  * kernel, 1 = MFMA implicit-GEMM kernel, 2 = the router's choice, 3 = MFMA kernel on the polyphase form of an upsampled conv,
- * 4 = the barrier-free long-row MFMA kernel (stride 1, 3 / 5 / 7 taps, <= 32 channels); engine | 0x100 first fills every CU's LDS
+ * 4 = the barrier-free long-row MFMA kernel (3 / 5 / 7 taps, <= 32 channels, any stride), 5 = its polyphase form for upsampled
+ * convs (24 / 32 input channels); engine | 0x100 first fills every CU's LDS
  * with NaN. */
 int mural_debug_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin, int32_t Lin,
                        int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t up, int32_t act, const float* res1,

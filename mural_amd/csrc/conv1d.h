@@ -40,6 +40,9 @@ int launch_conv1d_mfma(const Conv1dArgs& a, hipStream_t stream);
 // stride-1 convs with 3 / 5 / 7 taps, <= 32 channels on long rows, operands straight from global memory (conv1d_direct.hip)
 bool conv1d_direct_supported(const Conv1dArgs& a);
 int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream);
+// the polyphase form of an upsampling conv (Conv1dArgs::phases, three source columns per phase) on the same barrier-free scheme
+bool conv1d_direct_poly_supported(const Conv1dArgs& a);
+int launch_conv1d_direct_poly(const Conv1dArgs& a, hipStream_t stream);
 // host: weights [Cin][K][Cout] of conv_K(upsample_up(x)) -> polyphase weights [Cin][KJ][Cout * up] (Conv1dArgs::phases)
 void conv1d_phase_weights(const float* w, int Cin, int K, int Cout, int up, std::vector<float>* out, int* KJ, int* pad_out);
 

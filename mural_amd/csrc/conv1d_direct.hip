@@ -266,11 +266,209 @@ bool direct_plan(const Conv1dArgs& a, int* mb, int* cp) {
   return true;
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The polyphase form of an upsampling conv (Conv1dArgs::phases = up, K = 3 source columns per phase, rows = Cout x up) the same
+// barrier-free way, for the decoder's up-convs on the long levels.  With at most four taps ONE quad per channel holds every tap:
+// the four k-rows of an MFMA step are the channels 4 c + kq of a channel QUAD, lane (n, kq) loads
+//     Q = x[ci = 4 c + kq][p0 + n - pad .. + 3]
+// and element j < KT of it is the B operand of step (c, j) -- KT steps per channel quad, no empty tap slots.  A = W[row][ci][j]
+// (wt is [Cin][KT][rows], row = co * up + phase), resident: MB x CQ x KT registers.  A workgroup's waves take segments of 16 SOURCE
+// columns; blockIdx.y takes slices of MB row blocks (80 rows = one slice of 5 blocks; 120 rows = two of 4).  Output: row -> (co, phase),
+// column n -> output position up (p0 + n) + phase: lane (n, kq) stores its four rows as four dwords.
+struct ConvPArgs {
+  Conv1dArgs a;
+  int rows, mb_total;      // GEMM rows (Cout x phases), 16-row blocks
+  int segs_row, e0, gr, ss, ngroups, nslow;
+  uint32_t x_bytes, y_bytes;
+  DivWide dGr, dSs;
+  FastDiv dPh;
+};
+
+template <int MB, int CQ, int KT, int U>
+__global__ __launch_bounds__(256, 2) void conv1d_direct_poly_kernel(const ConvPArgs g, const float* __restrict__ wt, const float* __restrict__ bias) {
+  const Conv1dArgs& a = g.a;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const int m0 = blockIdx.y * MB;
+  const int ph = a.phases;
+  const __amdgpu_buffer_rsrc_t rx = cd_rsrc(a.in, g.x_bytes), ry = cd_rsrc(a.out, g.y_bytes);
+  float wr[MB][CQ][KT];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int j = 0; j < KT; ++j) {
+        const int row = 16 * (m0 + m) + n;
+        wr[m][c][j] = row < g.rows ? wt[((size_t)(4 * c + kq) * KT + j) * g.rows + row] : 0.f;
+      }
+  float bz[MB][4];
+  uint32_t vo[MB][4];
+#pragma unroll
+  for (int m = 0; m < MB; ++m)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = 16 * (m0 + m) + 4 * kq + r;
+      const int co = (int)g.dPh.divnb((uint32_t)row), sub = row - co * ph;
+      const bool ok = row < g.rows;
+      bz[m][r] = (bias && ok) ? bias[co] : 0.f;
+      vo[m][r] = ok ? (uint32_t)(co * a.Lout + ph * n + sub) * 4u : CD_OOB;
+    }
+  const uint32_t vx = (uint32_t)(kq * a.Lin + n) * 4u;
+
+  auto finish = [&](const f32x4 (&q)[CQ], uint32_t sy, bool tail) {
+    f32x4 acc[MB];
+#pragma unroll
+    for (int m = 0; m < MB; ++m) acc[m] = f32x4{bz[m][0], bz[m][1], bz[m][2], bz[m][3]};
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int j = 0; j < KT; ++j)
+#pragma unroll
+        for (int m = 0; m < MB; ++m) acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(wr[m][c][j], q[c][j], acc[m], 0, 0, 0);
+    float v[MB][4];
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) v[m][r] = acc[m][r];
+    if (a.act != ACT_NONE) {
+#pragma unroll
+      for (int m = 0; m < MB; ++m)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[m][r] = cd_act(v[m][r], a.act);
+    }
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cd_st1(ry, tail ? CD_OOB : vo[m][r], sy, v[m][r]);
+  };
+
+  const int nwaves = gridDim.x * 4;
+  const int wid = blockIdx.x * 4 + w;
+  {
+    struct Buf { f32x4 q[U][CQ]; };
+    auto load = [&](Buf& t, int grp) {
+      const uint32_t b = g.dGr.div((uint32_t)grp);
+      const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr) * U) * 16u;
+      const uint32_t sx = (b * (uint32_t)(a.Cin * a.Lin) + p0 - (uint32_t)a.pad) * 4u;
+#pragma unroll
+      for (int u = 0; u < U; ++u)
+#pragma unroll
+        for (int c = 0; c < CQ; ++c) t.q[u][c] = cd_ld4(rx, vx, sx + 64u * u + (uint32_t)(4 * c * a.Lin) * 4u);
+    };
+    auto compute = [&](const Buf& t, int grp) {
+      const uint32_t b = g.dGr.div((uint32_t)grp);
+      const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr) * U) * 16u;
+      const uint32_t sy = (b * (uint32_t)(a.Cout * a.Lout) + (uint32_t)ph * p0) * 4u;
+#pragma unroll
+      for (int u = 0; u < U; ++u) finish(t.q[u], sy + 64u * (uint32_t)(ph * u), false);
+    };
+    int cur = wid;
+    if (cur < g.ngroups) {
+      Buf t0, t1;
+      load(t0, cur);
+      for (;;) {
+        int nx = cur + nwaves;
+        load(t1, nx < g.ngroups ? nx : cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t0, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nx;
+        if (cur >= g.ngroups) break;
+        nx = cur + nwaves;
+        load(t0, nx < g.ngroups ? nx : cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t1, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nx;
+        if (cur >= g.ngroups) break;
+      }
+    }
+  }
+  for (int t = wid; t < g.nslow; t += nwaves) {
+    const uint32_t b = g.dSs.div((uint32_t)t);
+    const int k = t - (int)b * g.ss;
+    const int si = k < g.e0 ? k : g.e0 + g.gr * U + (k - g.e0);
+    const int p0 = 16 * si;
+    const uint32_t sx = b * (uint32_t)(a.Cin * a.Lin) * 4u;
+    f32x4 q[CQ];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int pos = p0 + n - a.pad + e;
+      const bool ok = (pos >= 0) & (pos < a.Lin);
+      uint32_t off = (uint32_t)(kq * a.Lin + pos) * 4u;
+      asm volatile("" : "+v"(off));
+      off = ok ? off : CD_OOB;
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) q[c][e] = cd_ld1(rx, off, sx + (uint32_t)(4 * c * a.Lin) * 4u);
+    }
+    finish(q, (b * (uint32_t)(a.Cout * a.Lout) + (uint32_t)(ph * p0)) * 4u, p0 + n >= a.Lin);
+  }
+}
+
+bool poly_plan(const Conv1dArgs& a, int* mb, int* cq) {
+  if (a.phases < 2 || a.phases > 8 || a.stride != 1 || a.up != 1 || a.pre_s || a.pre_t || a.pre_relu || a.res1 || a.res2) return false;
+  if (a.K != 3 || a.pad < 0 || a.pad > 2 || a.Lout != a.Lin * a.phases || a.Lin < 64) return false;
+  const int rows = a.Cout * a.phases;
+  if (a.Cin == 24 && rows <= 80) { *mb = 5; *cq = 6; }
+  else if (a.Cin == 32 && rows <= 128) { *mb = 4; *cq = 8; }
+  else return false;
+  const uint64_t xb = (uint64_t)a.B * a.Cin * a.Lin * 4, yb = (uint64_t)a.B * a.Cout * a.Lout * 4;
+  return xb < (1ull << 31) && yb < (1ull << 31);
+}
+
 }  // namespace
 
 bool conv1d_direct_supported(const Conv1dArgs& a) {
   int mb, cp;
   return direct_plan(a, &mb, &cp);
+}
+
+bool conv1d_direct_poly_supported(const Conv1dArgs& a) {
+  int mb, cq;
+  return poly_plan(a, &mb, &cq);
+}
+
+int launch_conv1d_direct_poly(const Conv1dArgs& a, hipStream_t stream) {
+  if (a.B == 0 || a.Lout == 0) return MURAL_OK;
+  int mb, cq;
+  MURAL_REQUIRE(poly_plan(a, &mb, &cq), "conv1d (direct MFMA, polyphase): unsupported geometry");
+  ConvPArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.a = a;
+  g.rows = a.Cout * a.phases;
+  g.mb_total = (g.rows + 15) / 16;
+  g.segs_row = (a.Lin + 15) / 16;
+  g.x_bytes = (uint32_t)((uint64_t)a.B * a.Cin * a.Lin * 4);
+  g.y_bytes = (uint32_t)((uint64_t)a.B * a.Cout * a.Lout * 4);
+  g.dPh = FastDiv::make((uint32_t)a.phases);
+  const int U = 1;
+  // interior segments: the first quad starts inside the row (p0 >= pad), the last one ends inside it (p0 + 15 - pad + 3 < Lin)
+  const int e0 = (a.pad + 15) / 16;
+  const int last_in = a.Lin - 19 + a.pad >= 0 ? (a.Lin - 19 + a.pad) / 16 : -1;
+  const int ir = std::max(0, last_in - e0 + 1);
+  g.e0 = e0;
+  g.gr = ir / U;
+  if (g.gr == 0) g.e0 = 0;
+  g.ss = g.segs_row - g.gr * U;
+  g.ngroups = a.B * g.gr;
+  g.nslow = a.B * g.ss;
+  g.dGr = DivWide::make((uint32_t)std::max(1, g.gr), (uint64_t)g.ngroups + 64);
+  g.dSs = DivWide::make((uint32_t)std::max(1, g.ss), (uint64_t)g.nslow + 64);
+  const int units = g.ngroups + g.nslow;
+  const int slices = (g.mb_total + mb - 1) / mb;
+  static int cap5 = 0, cap4 = 0;
+  int& cap = mb == 5 ? cap5 : cap4;
+  if (cap == 0)
+    cap = resident_workgroups(mb == 5 ? reinterpret_cast<const void*>(conv1d_direct_poly_kernel<5, 6, 3, 1>)
+                                      : reinterpret_cast<const void*>(conv1d_direct_poly_kernel<4, 8, 3, 1>), 256);
+  const int wgs = std::max(1, std::min(std::max(1, cap / slices), (units + 3) / 4));
+  if (mb == 5) hipLaunchKernelGGL((conv1d_direct_poly_kernel<5, 6, 3, 1>), dim3(wgs, slices), dim3(256), 0, stream, g, a.wt, a.bias);
+  else hipLaunchKernelGGL((conv1d_direct_poly_kernel<4, 8, 3, 1>), dim3(wgs, slices), dim3(256), 0, stream, g, a.wt, a.bias);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
 }
 
 int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream) {

@@ -284,6 +284,8 @@ static int run_upconv(const MuralIndelModel* m, int j, const float* in, int B, i
     a.B = B; a.Cin = fp.Cin; a.Lin = Lin; a.Cout = fp.Cout; a.Lout = Lout;
     a.K = fp.K; a.stride = 1; a.pad = m->dn_lp_pad[j]; a.up = 1; a.phases = up;
     a.act = ACT_NONE;
+    static const bool use_direct = !(getenv("MURAL_CONV1D_DIRECT") && atoi(getenv("MURAL_CONV1D_DIRECT")) == 0);
+    if (use_direct && (int64_t)B * Lin >= 32768 && conv1d_direct_poly_supported(a)) return launch_conv1d_direct_poly(a, stream);
     if (conv1d_mfma_supported(a)) return launch_conv1d_mfma(a, stream);
   }
   return run_conv(m, m->dn_l[j], in, B, Lin, out, Lout, 1, up, ACT_NONE, nullptr, nullptr, stream);

@@ -1099,7 +1099,7 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
     MURAL_REQUIRE(conv1d_direct_supported(a), "conv1d (direct MFMA): unsupported geometry");
     return launch_conv1d_direct(a, STREAM);
   }
-  if (engine == 3) {     // polyphase form of the upsampled conv: weights expanded on the host once per weight tensor (kept for repeats)
+  if (engine == 3 || engine == 5) {     // polyphase form of the upsampled conv: weights expanded on the host once per weight tensor (kept for repeats)
     MURAL_REQUIRE(up > 1 && stride == 1, "polyphase conv: needs up > 1, stride 1");
     static const float* last_wt = nullptr;
     static float* dw = nullptr;
@@ -1114,6 +1114,10 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
       last_wt = wt;
     }
     a.wt = dw; a.K = kj; a.pad = padj; a.up = 1; a.phases = up;
+    if (engine == 5) {
+      MURAL_REQUIRE(conv1d_direct_poly_supported(a), "conv1d (direct MFMA, polyphase): unsupported geometry");
+      return launch_conv1d_direct_poly(a, STREAM);
+    }
     MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA, polyphase): unsupported geometry");
     return launch_conv1d_mfma(a, STREAM);
   }

@@ -30,7 +30,9 @@ cases = [(8, 16, 8000, 7, 4, 1, 0, 0), (16, 24, 2000, 7, 5, 1, 0, 0), (24, 32, 4
          # strided convs on the barrier-free kernel: the encoder's down-convs and ragged variants (row ends inside a segment, rows
          # shorter than a segment's reach, stride 2 / 3 / 8, 5 taps, residuals)
          (8, 16, 8003, 7, 4, 1, 1, 0), (16, 24, 1999, 7, 5, 1, 2, 1), (8, 16, 333, 5, 2, 1, 0, 2), (4, 8, 1000, 7, 3, 1, 3, 0),
-         (8, 16, 700, 7, 8, 1, 0, 0), (16, 16, 90, 7, 5, 1, 0, 0)]
+         (8, 16, 700, 7, 8, 1, 0, 0), (16, 16, 90, 7, 5, 1, 0, 0),
+         # up-convs on the polyphase barrier-free kernel: ragged source rows, activation, 80 and 120 GEMM rows, fewer rows than a slice
+         (24, 16, 403, 7, 1, 5, 2, 0), (32, 24, 77, 7, 1, 5, 0, 0), (24, 12, 131, 7, 1, 5, 1, 0), (32, 16, 100, 7, 1, 4, 3, 0)]
 worst = 0.0
 for Cin, Cout, Lin, K, stride, up, act, nres in cases:
     B = (B0 if Lin <= 2000 or not verbose else 512) if not (verbose and Lin >= 2000 and Cin <= 32 and stride == 1 and up == 1) else 128
@@ -53,7 +55,7 @@ for Cin, Cout, Lin, K, stride, up, act, nres in cases:
     st = _lib.current_stream_ptr(dev)
     line = f"Cin {Cin:3d} Cout {Cout:3d} Lin {Lin:5d} K {K} s {stride} up {up} act {act} res {nres}:"
     direct = up == 1 and Cin in (4, 8, 16, 32) and Cout <= 32 and not (Cout > 16 and Cin > 16) and K in (3, 5, 7)
-    for engine, name in ((0, "valu"), (1, "mfma")) + (((3, "polyphase"),) if up > 1 else ()) + (((4, "direct"),) if direct else ()):
+    for engine, name in ((0, "valu"), (1, "mfma")) + (((3, "polyphase"), (5, "direct-poly")) if up > 1 else ()) + (((4, "direct"),) if direct else ()):
         out = torch.full((B, Cout, Lout), float("nan"), device=dev)
 
         def run(eng=engine):
