@@ -10,7 +10,9 @@
 //           16 mb + 4 kk + r in register r of block mb, which IS a B operand if k-step (mb, r) is defined to cover exactly those
 //           four channels (the order of the k-steps of a dot product is free) -- no shuffle, no LDS round trip.
 // Both weight matrices live in registers as A fragments for the whole workgroup lifetime (C = 24: 114 VGPRs).
+#include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "conv1d.h"
 #include "mfma_tile.h"
@@ -227,6 +229,231 @@ __global__ __launch_bounds__(256, 2) void convblock_mfma_kernel(const ConvBlockA
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------------------
+// The same block WITHOUT an LDS tile, barriers or a staging loop (the scheme of conv1d_direct.hip): a wave owns 16 consecutive
+// positions p0 .. p0 + 15 of one row; the four k-rows of an MFMA step of GEMM 1 are the channels 4 c + kq of a channel quad, lane
+// (n, kq) loads ONE 16-byte quad x[4 c + kq][p0 + n - 2 .. + 1] (taps 0 .. 3) and ONE dword x[4 c + kq][p0 + n + 2] (tap 4) per
+// quad -- five taps in five steps, no empty tap slots: the 40 (C = 16) MFMAs of the tiled form, with operands straight from global
+// memory, the next segment's loads in flight under this one's MFMAs.  Block input and skip tensor in accumulator layout (channels
+// 16 mb + 4 kq + r of column n) are four more dwords each; the result leaves as four dword stores (16 lanes = 64 bytes of a row).
+// The tiled form above was bound by its per-tile schedule (request, MFMAs, barrier, LDS -> registers -> global, barrier): 295 us per
+// 2048 x 2000 x 16 launch against 160 us of MFMA time, whatever the block order, the SiLU grouping, the grid or a start-up stagger.
+struct CbdArgs {
+  ConvBlockArgs a;
+  int segs_row, e0, gr, ss, ngroups, nslow;
+  uint32_t bytes;
+  DivWide dGr, dSs;
+};
+
+template <int C>
+__global__ __launch_bounds__(256, 2) void convblock_direct_kernel(const CbdArgs g) {
+  const ConvBlockArgs& a = g.a;
+  constexpr int C2 = 2 * C, MB1 = C2 / 16, CQ = C / 4, MB2 = (C + 15) / 16, KS2 = 4 * MB1;
+  constexpr uint32_t OOB = 0x80000000u;
+  const int lane = threadIdx.x & 63;
+  const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int n = lane & 15, kq = lane >> 4;
+  const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)g.bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs =
+      __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res2 ? a.res2 : a.x), 0, a.res2 ? (int)g.bytes : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)g.bytes, 0x00020000);
+  // A fragments: GEMM 1 step (c, j): k-row kq = channel 4 c + kq, tap j; GEMM 2 step s: hidden channel 16 (s / 4) + 4 kq + s % 4
+  float a1[MB1][CQ][5], a2[MB2][KS2];
+#pragma unroll
+  for (int mb = 0; mb < MB1; ++mb)
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) a1[mb][c][j] = a.w5[((4 * c + kq) * 5 + j) * C2 + 16 * mb + n];
+#pragma unroll
+  for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) {
+      const int h = 16 * (s >> 2) + 4 * kq + (s & 3), c = 16 * mb + n;
+      a2[mb][s] = c < C ? a.w1[h * C + c] : 0.f;
+    }
+  f32x4 bias1[MB1], bias2[MB2];
+#pragma unroll
+  for (int mb = 0; mb < MB1; ++mb) bias1[mb] = ld4(a.b5 + 16 * mb + 4 * kq);
+  uint32_t vo[MB2][4];      // lane part of the offsets of the lane's output elements (channel 16 mb + 4 kq + r, column n)
+#pragma unroll
+  for (int mb = 0; mb < MB2; ++mb) {
+    const int c0 = 16 * mb + 4 * kq;
+    bias2[mb] = f32x4{c0 + 0 < C ? a.b1[c0 + 0] : 0.f, c0 + 1 < C ? a.b1[c0 + 1] : 0.f, c0 + 2 < C ? a.b1[c0 + 2] : 0.f,
+                      c0 + 3 < C ? a.b1[c0 + 3] : 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vo[mb][r] = c0 + r < C ? (uint32_t)((c0 + r) * a.L + n) * 4u : OOB;
+  }
+  const uint32_t vq = (uint32_t)(kq * a.L + n) * 4u;      // lane part of the operand addresses (channel kq of a quad, column n)
+
+  struct Buf {
+    f32x4 q[CQ];      // taps 0 .. 3
+    float t4[CQ];     // tap 4
+    float xr[MB2][4], sk[MB2][4];
+  };
+  // MFMAs, SiLU, residuals and stores of one segment; so: scalar part of the output addresses; tail: this lane's column is past the row
+  auto finish = [&](const Buf& t, uint32_t so, bool tail) {
+    f32x4 acc1[MB1];
+#pragma unroll
+    for (int mb = 0; mb < MB1; ++mb) acc1[mb] = bias1[mb];
+#pragma unroll
+    for (int c = 0; c < CQ; ++c)
+#pragma unroll
+      for (int j = 0; j < 5; ++j) {
+        const float bv = j < 4 ? t.q[c][j < 4 ? j : 0] : t.t4[c];
+#pragma unroll
+        for (int mb = 0; mb < MB1; ++mb) acc1[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[mb][c][j], bv, acc1[mb], 0, 0, 0);
+      }
+    float hv[KS2];
+#pragma unroll
+    for (int s = 0; s < KS2; ++s) hv[s] = silu_fast(acc1[s >> 2][s & 3]);
+    f32x4 acc2[MB2], acc2b[MB2];
+#pragma unroll
+    for (int mb = 0; mb < MB2; ++mb) {
+      acc2[mb] = bias2[mb];
+      acc2b[mb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if constexpr (MB2 == 1) {
+#pragma unroll
+      for (int s = 0; s < KS2; s += 2) {
+        acc2[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0][s], hv[s], acc2[0], 0, 0, 0);
+        acc2b[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[0][s + 1], hv[s + 1], acc2b[0], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int s = 0; s < KS2; ++s)
+#pragma unroll
+        for (int mb = 0; mb < MB2; ++mb) acc2[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a2[mb][s], hv[s], acc2[mb], 0, 0, 0);
+    }
+#pragma unroll
+    for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float v = ((MB2 == 1 ? acc2[mb][r] + acc2b[mb][r] : acc2[mb][r]) + t.xr[mb][r]) + t.sk[mb][r];
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, tail ? OOB : vo[mb][r], so, 0);
+      }
+  };
+
+  const int nwaves = gridDim.x * 4;
+  const int wid = blockIdx.x * 4 + w;
+  {
+    auto load = [&](Buf& t, int grp) {
+      const uint32_t b = g.dGr.div((uint32_t)grp);
+      const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr)) * 16u;
+      const uint32_t sb = (b * (uint32_t)(C * a.L) + p0) * 4u;      // (row, first column) of the segment
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        t.q[c] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vq, sb - 8u + (uint32_t)(4 * c * a.L) * 4u, 0));
+        t.t4[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vq, sb + 8u + (uint32_t)(4 * c * a.L) * 4u, 0));
+      }
+#pragma unroll
+      for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          t.xr[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, vo[mb][r], sb, 0));
+          t.sk[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, vo[mb][r], sb, 0));
+        }
+    };
+    auto compute = [&](const Buf& t, int grp) {
+      const uint32_t b = g.dGr.div((uint32_t)grp);
+      const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr)) * 16u;
+      finish(t, (b * (uint32_t)(C * a.L) + p0) * 4u, false);
+    };
+    int cur = wid;
+    if (cur < g.ngroups) {
+      Buf t0, t1;
+      load(t0, cur);
+      for (;;) {
+        int nx = cur + nwaves;
+        load(t1, nx < g.ngroups ? nx : cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t0, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nx;
+        if (cur >= g.ngroups) break;
+        nx = cur + nwaves;
+        load(t0, nx < g.ngroups ? nx : cur);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(t1, cur);
+        __builtin_amdgcn_sched_barrier(0);
+        cur = nx;
+        if (cur >= g.ngroups) break;
+      }
+    }
+  }
+  // edge segments: every tap through a checked offset (a refused element reads 0: the zero padding)
+  for (int t = wid; t < g.nslow; t += nwaves) {
+    const uint32_t b = g.dSs.div((uint32_t)t);
+    const int k = t - (int)b * g.ss;
+    const int si = k < g.e0 ? k : g.e0 + g.gr + (k - g.e0);
+    const int p0 = 16 * si;
+    const uint32_t sr = b * (uint32_t)(C * a.L) * 4u;
+    Buf q;
+#pragma unroll
+    for (int e = 0; e < 5; ++e) {
+      const int pos = p0 + n - 2 + e;
+      const bool ok = (pos >= 0) & (pos < a.L);
+      uint32_t off = (uint32_t)(kq * a.L + pos) * 4u;
+      asm volatile("" : "+v"(off));
+      off = ok ? off : OOB;
+#pragma unroll
+      for (int c = 0; c < CQ; ++c) {
+        const float v = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, sr + (uint32_t)(4 * c * a.L) * 4u, 0));
+        if (e < 4) q.q[c][e < 4 ? e : 0] = v;
+        else q.t4[c] = v;
+      }
+    }
+    const bool tail = p0 + n >= a.L;
+#pragma unroll
+    for (int mb = 0; mb < MB2; ++mb)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        uint32_t off = vo[mb][r];
+        asm volatile("" : "+v"(off));
+        off = tail ? OOB : off;
+        q.xr[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, off, sr + (uint32_t)p0 * 4u, 0));
+        q.sk[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, off, sr + (uint32_t)p0 * 4u, 0));
+      }
+    finish(q, sr + (uint32_t)p0 * 4u, tail);
+  }
+}
+
+template <int C>
+static int launch_convblock_direct_t(const ConvBlockArgs& a, hipStream_t stream) {
+  CbdArgs g;
+  std::memset(&g, 0, sizeof(g));
+  g.a = a;
+  g.bytes = (uint32_t)((uint64_t)a.B * C * a.L * 4);
+  g.segs_row = (a.L + 15) / 16;
+  // interior segments: taps p0 - 2 .. p0 + 17 inside the row
+  const int e0 = 1;
+  const int last_in = a.L >= 34 ? (a.L - 18) / 16 : -1;
+  g.gr = std::max(0, last_in - e0 + 1);
+  g.e0 = g.gr > 0 ? e0 : 0;
+  g.ss = g.segs_row - g.gr;
+  g.ngroups = a.B * g.gr;
+  g.nslow = a.B * g.ss;
+  g.dGr = DivWide::make((uint32_t)std::max(1, g.gr), (uint64_t)g.ngroups + 64);
+  g.dSs = DivWide::make((uint32_t)std::max(1, g.ss), (uint64_t)g.nslow + 64);
+  static int cap = 0;
+  if (cap == 0) {
+    int per_cu = 0, dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess &&
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(convblock_direct_kernel<C>), 256, 0) == hipSuccess &&
+        per_cu > 0)
+      cap = per_cu * prop.multiProcessorCount;
+    else
+      cap = 512;
+  }
+  const int units = g.ngroups + g.nslow;
+  const int wgs = std::max(1, std::min(cap, (units + 3) / 4));
+  hipLaunchKernelGGL(convblock_direct_kernel<C>, dim3(wgs), dim3(256), 0, stream, g);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
 }  // namespace
 
 bool convblock_mfma_supported(const ConvBlockArgs& a) {
@@ -234,6 +461,10 @@ bool convblock_mfma_supported(const ConvBlockArgs& a) {
 }
 
 int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream) {
+  // MURAL_CONVBLOCK_DIRECT=0: the LDS-tiled form; 2: the barrier-free form whatever the size (A/B switch, validation)
+  static const int direct_mode = getenv("MURAL_CONVBLOCK_DIRECT") ? atoi(getenv("MURAL_CONVBLOCK_DIRECT")) : 1;      // 2: whatever the size
+  if (direct_mode != 0 && (uint64_t)a.B * a.C * a.L * 4 < (1ull << 31) && (direct_mode == 2 || (a.L >= 64 && (int64_t)a.B * a.L >= 32768)))
+    return a.C == 16 ? launch_convblock_direct_t<16>(a, stream) : launch_convblock_direct_t<24>(a, stream);
   const int64_t tiles = (int64_t)a.B * ((a.L + 255) / 256);
   // persistent workgroups: exactly as many as are resident at a time (a grid of 2048 on 768 resident ones runs in rounds of 768, 768,
   // 512 -- the last round a third empty)

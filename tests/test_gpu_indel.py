@@ -458,15 +458,18 @@ def test_mfma_weight_gradient_matches_torch_fp64():
 def test_fused_convblock_forms_match_torch_fp64():
     """One fused ConvBlock launch (mural_debug_convblock): plain / with the k = 7 front (upsampled or not) / skip tensor / tail, at 8
     channels in BOTH forms (vector ALU; split: the convs on the matrix cores) and at 16 channels, rows of 37..8000 columns, against
-    float64 (tools/gpu_debug_convblock.py: 132 cases, relative error <= 3e-6)."""
+    float64 (tools/gpu_debug_convblock.py: 256 cases, relative error <= 3e-6, every CU's LDS filled with NaN in front of each launch)."""
     import os
     import subprocess
     import sys
     tool = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "gpu_debug_convblock.py")
-    env = {k: v for k, v in os.environ.items() if k not in ("TIME", "VERBOSE", "MURAL_CONVBLOCK8_VALU")}
-    out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env=env)
-    assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
-    assert "worst" in out.stdout
+    env = {k: v for k, v in os.environ.items() if k not in ("TIME", "VERBOSE", "MURAL_CONVBLOCK8_VALU", "MURAL_CONVBLOCK_DIRECT")}
+    # twice: the library's routing (small launches of the 16 / 24-channel block on the LDS-tiled kernel), then its barrier-free form
+    # forced for every size (rows that are all edge segments, ragged rows)
+    for extra in ({}, {"MURAL_CONVBLOCK_DIRECT": "2"}):
+        out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env={**env, **extra})
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
+        assert "worst" in out.stdout
 
 
 @pytest.mark.parametrize("L", [16000, 64000])
