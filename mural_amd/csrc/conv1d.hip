@@ -314,7 +314,7 @@ __host__ __device__ inline int convblock_front_floats(int Cf, int f_up, bool fro
 //             accumulator layout (lane (n, kk): rows 4 kk + q) of the conv in front IS the B layout with the k index permuted.
 //   tail      the paired layout is closed under a 1x1 conv 8 -> 8 with A = diag(W, W): 4 MFMAs per pair and conv.
 template <int C, bool TAIL, bool FRONT, bool MF>
-__global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convblock_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
+__global__ __launch_bounds__(256, MF ? (FRONT ? 6 : (TAIL ? 7 : 8)) : 1) void convblock_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
                                                         const float* __restrict__ b5, const float* __restrict__ w1,
                                                         const float* __restrict__ b1, const float* __restrict__ ta_w,
                                                         const float* __restrict__ ta_b, const float* __restrict__ tb_w,
@@ -372,18 +372,6 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
   const int OUTW = FRONT ? (POLY ? CB_FRONT_OUT_POLY : CB_FRONT_OUT) : 256;
   const int l0 = blockIdx.x * OUTW;
   float af[MF && FRONT ? 2 : 1][MF && FRONT ? 12 : 1];      // POLY: A fragments of the front, lane (row 16 mb + n16 = 4 co + phase, kk)
-  if constexpr (MF && FRONT) {
-    if (POLY) {
-      const int n16f = threadIdx.x & 15, kkf = (threadIdx.x >> 4) & 3;
-#pragma unroll
-      for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-        for (int s = 0; s < 12; ++s) {
-          const int d = s >> 2, ci = 4 * (s & 3) + kkf, row = 16 * mb + n16f, co = row >> 2, ph = row & 3;
-          af[mb][s] = a.f_pw[(((size_t)ph * 16 + ci) * 3 + d) * C + co];
-        }
-    }
-  }
   if (!FRONT) {
     const float* src = a.x + (size_t)b * C * a.L;
     constexpr int UN = 4;                        // loads of a thread in flight (a round per load = a global round trip per round)
@@ -488,6 +476,19 @@ __global__ __launch_bounds__(256, MF ? ((FRONT || TAIL) ? 7 : 8) : 1) void convb
 #pragma unroll
       for (int u = 0; u < UN; ++u)
         if (i0 + 256 * u < a.Cf * span) fin[i0 + 256 * u] = v[u];
+    }
+    // (requested behind the staging loads, in front of their barrier: not live across the staging)
+    if constexpr (MF && FRONT) {
+      if (POLY) {
+        const int n16f = threadIdx.x & 15, kkf = (threadIdx.x >> 4) & 3;
+  #pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+  #pragma unroll
+          for (int s = 0; s < 12; ++s) {
+            const int d = s >> 2, ci = 4 * (s & 3) + kkf, row = 16 * mb + n16f, co = row >> 2, ph = row & 3;
+            af[mb][s] = a.f_pw[(((size_t)ph * 16 + ci) * 3 + d) * C + co];
+          }
+      }
     }
     __syncthreads();
     CB_STAMP(1);

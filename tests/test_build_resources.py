@@ -50,3 +50,37 @@ def test_wave_private_tower_kernels_stay_within_their_register_budget():
     for k in short:
         r = ks[k]
         assert r["VGPRs"] <= 256 and r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= 2, (k, r)
+
+
+def _report(name):
+    return os.path.join(ROOT, "mural_amd", "csrc", name + ".resources.txt")
+
+
+def test_split_level0_convblock_instances_keep_their_occupancy():
+    """convblock_kernel<8, TAIL, FRONT, MF = true> (conv1d.hip): no spill, no scratch, and the waves per SIMD its launch bound asks for
+    (six for the instances with a front -- at seven they spill a register into scratch --, seven or eight otherwise): the
+    fragments are requested behind the front / the staging exactly so that they are not live across them."""
+    ks = _kernels(_report("conv1d"))
+    split = [k for k in ks if "convblock_kernelILi8E" in k and k.split("convblock_kernelILi8E")[1].startswith(("Lb0ELb0ELb1E", "Lb0ELb1ELb1E", "Lb1ELb0ELb1E", "Lb1ELb1ELb1E"))]
+    assert len(split) == 4, sorted(k for k in ks if "convblock_kernel" in k)
+    for k in split:
+        r = ks[k]
+        need = 6 if k.split("convblock_kernelILi8E")[1][4:8] == "Lb1E" else 7      # (the instances with a front: six)
+        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= need, (k, r)
+
+
+def test_barrier_free_convs_and_blocks_do_not_spill():
+    """conv1d_direct_kernel / conv1d_direct_poly_kernel (every instance that is launched) and convblock_direct_kernel<16> without spills
+    at two waves per SIMD; the 24-channel block is allowed the two registers it spills today (114 weight registers)."""
+    ks = _kernels(_report("conv1d_direct"))
+    direct = [k for k in ks if "conv1d_direct" in k]
+    assert len(direct) >= 16, sorted(ks)
+    for k in direct:
+        r = ks[k]
+        assert r["VGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= 2, (k, r)
+    kb = _kernels(_report("convblock_mfma"))
+    d16 = [k for k in kb if "convblock_direct_kernelILi16E" in k]
+    d24 = [k for k in kb if "convblock_direct_kernelILi24E" in k]
+    assert len(d16) == 1 and len(d24) == 1, sorted(kb)
+    assert kb[d16[0]]["VGPRs Spill"] == 0 and kb[d16[0]]["ScratchSize"] == 0 and kb[d16[0]]["Occupancy"] >= 3, kb[d16[0]]
+    assert kb[d24[0]]["VGPRs Spill"] <= 3 and kb[d24[0]]["Occupancy"] >= 2, kb[d24[0]]
