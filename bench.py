@@ -227,11 +227,12 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
     labels = torch.from_numpy(rng.choice(4, size=total * B, p=[0.955, 0.015, 0.015, 0.015]).astype(np.int64)).to(device)
     cont = torch.zeros(B, 1, device=device)
 
-    def step(s):
+    def step(s, dense=False):
         idx = torch.arange(s * B, (s + 1) * B, device=device) % GENOME_SITES
         pos, strand = idx + DISTAL_RADIUS, (idx & 1).to(torch.uint8)
         cat = genome.encode_kmer(pos, strand, LOCAL_RADIUS, LOCAL_ORDER)
-        x = genome.encode_onehot(pos, strand, DISTAL_RADIUS)
+        # one symbol per column (the training step's own input form) or, for the side figure, the reference loader's one-hot tensor
+        x = genome.encode_onehot(pos, strand, DISTAL_RADIUS) if dense else genome.encode_symbols(pos, strand, DISTAL_RADIUS)
         loss = crit(model((cont, cat), x), labels[s * B:(s + 1) * B])
         opt.zero_grad()
         loss.backward()
@@ -255,12 +256,24 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
         step(s).item()
         times.append(time.perf_counter() - t1)
     t_sync = float(np.median(times))
+    # side figure: the same loop fed with dense one-hot windows (16 bytes per column written by the encoder and read back by the step)
+    dense_steps = min(200, steps)
+    for s in range(3):
+        step(s, dense=True)
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    for s in range(dense_steps):
+        step(s, dense=True)
+    torch.cuda.synchronize()
+    t_dense = (time.perf_counter() - t2) / dense_steps
     tflops = FLOP_TRAIN_PER_SITE * B / t / 1e12
     out = {"steps_per_s": 1.0 / t, "ms_per_step": t * 1e3, "batch": B, "sites_per_s": B / t, "steps": steps,
+           "steps_per_s_dense_input": 1.0 / t_dense, "dense_input_steps": dense_steps,
            "steps_per_s_synchronised": 1.0 / t_sync, "ms_per_step_synchronised": t_sync * 1e3, "synchronised_steps": sync_steps,
            "final_loss_per_site": float(loss.item()) / B, "optimizer": "Adam lr 1e-3", "loss": "CrossEntropy(sum), clip_grad_norm 10",
-           "note": "forward (batch-statistics BatchNorm, dropout 0.1/0.1/0.25) + backward + clip + Adam; window encode from the packed "
-                   "genome inside the timed loop; steps_per_s = %d steps without a host sync in between" % steps,
+           "note": "forward (batch-statistics BatchNorm, dropout 0.1/0.1/0.25) + backward + clip + Adam; windows encoded from the packed "
+                   "genome inside the timed loop as symbol windows (PackedGenome.encode_symbols: bit-identical to the dense one-hot "
+                   "route, tests/test_gpu_train.py); steps_per_s = %d steps without a host sync in between" % steps,
            "roofline": {"flop_per_step": FLOP_TRAIN_PER_SITE * B, "achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS,
                         "frac_mfma": tflops / PEAK_FP32_MFMA_TFLOPS}}
     fact = profile_fact("r04_train_step")

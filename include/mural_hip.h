@@ -70,6 +70,12 @@ int mural_encode_kmer(const MuralGenome* g, const int64_t* pos, const uint8_t* s
 int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
                         int32_t radius, int32_t indel, float* out, void* stream);
 
+/* The same windows as one SYMBOL per column (MURAL_SYM_*: A C G T N R Y M S W K B D H V = 0..14, strand-oriented and complemented
+ * like the one-hot columns; positions outside the record are N): what mural_op_dense_to_symbols recovers from the one-hot tensor,
+ * without the detour -- the `symbols` input of mural_snv_train_forward.  out: dev uint8 [n][2*radius + (indel?0:1)].            */
+int mural_encode_symbols(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n, int32_t radius,
+                         int32_t indel, uint8_t* out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * SNV model family (Network0 / Network1 / Network2, MuRaL/model/model_snv.py:19-525), eval mode.
  * Raw parameters are handed over as HOST pointers in the reference's state_dict naming; the library

@@ -169,6 +169,8 @@ PROTOTYPES = {
                                     C.c_int32, C.c_void_p, C.c_void_p]),
     "mural_encode_onehot": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
                                       C.c_void_p, C.c_void_p]),
+    "mural_encode_symbols": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                       C.c_void_p, C.c_void_p]),
     "mural_snv_model_create": (C.c_int, [C.POINTER(MuralSnvShape), C.POINTER(MuralSnvParams), C.POINTER(C.c_void_p)]),
     "mural_snv_model_destroy": (None, [C.c_void_p]),
     "mural_snv_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),

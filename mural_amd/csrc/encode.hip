@@ -83,6 +83,22 @@ __global__ void encode_onehot_kernel(MuralGenome g, const int64_t* __restrict__ 
   }
 }
 
+// the windows as symbols (one byte per column, strand-oriented like the one-hot form): what the sequence kernels consume -- the
+// training step's first layer works from these, so a loader that holds the packed genome need not expand 16 bytes per column first
+__global__ void encode_symbols_kernel(MuralGenome g, const int64_t* __restrict__ pos, const uint8_t* __restrict__ strand, int64_t n,
+                                      int off, int width, uint8_t* __restrict__ out) {
+  const int64_t total = n * width;
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / width;
+    const int j = (int)(i - row * width);
+    const int64_t ws = pos[row] + off;
+    const bool neg = strand[row] != 0;
+    uint32_t s = genome_sym_iupac(g, neg ? ws + (width - 1 - j) : ws + j);
+    if (neg) s = sym_complement(s);
+    out[i] = (uint8_t)s;
+  }
+}
+
 // A thread converts 4 consecutive symbols of the flattened (row, column) index: 16 independent channel loads in flight and one
 // aligned 4-byte store (the symbol buffer is linear in that index, so a group may straddle two rows).  HBM-bound: 16 B in,
 // 1 B out per column.
@@ -198,6 +214,22 @@ extern "C" int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, con
   const int grid = (int)((total + block - 1) / block < 16384 ? (total + block - 1) / block : 16384);
   hipLaunchKernelGGL(encode_onehot_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *g, pos, strand, n, off,
                      width, out);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+extern "C" int mural_encode_symbols(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n, int32_t radius,
+                                    int32_t indel, uint8_t* out, void* stream) {
+  MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
+  MURAL_REQUIRE(g->n_amb == 0 || (g->amb_pos && g->amb_sym), "genome: n_amb > 0 needs amb_pos and amb_sym");
+  int off, width;
+  if (int rc = window_geometry(radius, indel, &off, &width)) return rc;
+  if (n == 0) return MURAL_OK;
+  MURAL_REQUIRE(pos && strand && out, "pos/strand/out must not be NULL");
+  const int64_t total = n * width;
+  const int block = 256;
+  const int grid = (int)((total + block - 1) / block < 16384 ? (total + block - 1) / block : 16384);
+  hipLaunchKernelGGL(encode_symbols_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *g, pos, strand, n, off, width, out);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

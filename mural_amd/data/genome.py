@@ -42,6 +42,20 @@ def pack_sequence(seq):
     return packed, mask, n, (amb, codes[amb].astype(np.uint8))
 
 
+class SymbolWindows:
+    """Sequence windows as one symbol per column (``PackedGenome.encode_symbols``): ``sym`` is a uint8 (n, W) device tensor of
+    MURAL_SYM_* codes (0..14).  Only the encoder makes these -- the kernels index tables with the bytes unchecked."""
+
+    __slots__ = ("sym",)
+
+    def __init__(self, sym):
+        self.sym = sym
+
+    @property
+    def shape(self):
+        return self.sym.shape
+
+
 class PackedGenome:
     """One chromosome resident on a HIP device."""
 
@@ -96,6 +110,22 @@ class PackedGenome:
                                                    int(order), int(model_type == "indel"), out.data_ptr(),
                                                    _lib.current_stream_ptr(self.device)))
         return out
+
+    def encode_symbols(self, pos, strand, radius, model_type="snv"):
+        """The windows of ``encode_onehot`` as one symbol per column (uint8 (n, W), wrapped as ``SymbolWindows``): the training-mode
+        forward of the SNV models takes them in place of the dense ``distal_input`` -- its first layer works from symbols anyway, the
+        one-hot tensor (16 bytes per column) and its conversion back are skipped.  Same values as the dense route, bit for bit."""
+        if model_type not in ("snv", "indel"):
+            raise ValueError(f"model_type {model_type} not supported!")
+        pos, strand = self._prep(pos, strand)
+        width = 2 * radius + (1 if model_type == "snv" else 0)
+        out = torch.empty((pos.shape[0], width), dtype=torch.uint8, device=self.device)
+        g = self.as_struct()
+        with torch.cuda.device(self.device):
+            _lib.check(_lib.lib().mural_encode_symbols(C.byref(g), pos.data_ptr(), strand.data_ptr(), pos.shape[0], int(radius),
+                                                      int(model_type == "indel"), out.data_ptr(),
+                                                      _lib.current_stream_ptr(self.device)))
+        return SymbolWindows(out)
 
     def encode_onehot(self, pos, strand, radius, model_type="snv"):
         """float32 (n, 4, W) one-hot windows (N -> 0.25 each, other IUPAC codes -> their fractional columns), exact w.r.t.

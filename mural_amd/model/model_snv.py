@@ -520,6 +520,28 @@ class Network0(nn.Module):
                                                return_reuse_count)
 
 
+def _symbol_windows(model, distal_input):
+    """``distal_input`` handed over as ``mural_amd.data.SymbolWindows`` (PackedGenome.encode_symbols): the uint8 (B, W) tensor for the
+    training step, after the checks the dense route makes on its tensor; None for a dense tensor."""
+    from ..data.genome import SymbolWindows
+    if not isinstance(distal_input, SymbolWindows):
+        return None
+    sym = distal_input.sym
+    if sym.dim() != 2 or sym.dtype != torch.uint8:
+        raise TypeError("SymbolWindows.sym must be a uint8 (B, W) tensor")
+    assert sym.shape[1] > 200, "Error: distal seq len must be >200bp"
+    if sym.shape[1] != model.seq_len:
+        raise ValueError(f"distal_input length {sym.shape[1]} != 2*distal_radius+1 = {model.seq_len}")
+    if not model.training:
+        raise TypeError("SymbolWindows are the training step's input; for prediction from a packed genome use forward_packed")
+    if getattr(model, "in_channels", 4) != 4:
+        raise ValueError("SymbolWindows stand for the four one-hot channels")
+    from . import train_step
+    if not train_step.supported(model):
+        raise ValueError("this model configuration trains through the per-layer path, which takes the dense distal_input")
+    return _lib.require_cuda(sym, "distal_input").contiguous()
+
+
 class Network1(_HipSnvBase):
     """Expanded-only model (model_snv.py:111-287)."""
     model_no = 1
@@ -541,6 +563,11 @@ class Network1(_HipSnvBase):
         return shape, params, hp
 
     def forward(self, local_input, distal_input):
+        sym = _symbol_windows(self, distal_input)
+        if sym is not None:
+            from . import train_step
+            with torch.cuda.device(self._device()):
+                return train_step.run(self, None, sym)
         assert distal_input.shape[2] > 200, "Error: distal seq len must be >200bp"
         if distal_input.shape[2] != self.seq_len:
             raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")
@@ -584,6 +611,12 @@ class Network2(_HipSnvBase):
 
     def forward(self, local_input, distal_input, _taps=None):
         cont_data, cat_data = local_input
+        sym = _symbol_windows(self, distal_input)
+        if sym is not None:
+            from . import train_step
+            cat_data, _ = self._train_inputs(cat_data, None)
+            with torch.cuda.device(self._device()):
+                return train_step.run(self, cat_data, sym)
         assert distal_input.shape[2] > 200, "Error: distal seq len must be >200"
         if distal_input.shape[2] != self.seq_len:
             raise ValueError(f"distal_input length {distal_input.shape[2]} != 2*distal_radius+1 = {self.seq_len}")

@@ -179,11 +179,13 @@ class ModelStep(torch.autograd.Function):
 
 
 def run(model, cat_x, distal_x):
-    """Training-mode forward of `model` on (cat_x int64 (B, cols) | None, distal_x float (B, 4, L) | None)."""
+    """Training-mode forward of `model` on (cat_x int64 (B, cols) | None, distal_x float (B, 4, L) | uint8 (B, L) symbols | None)."""
     from . import train_ops as T
     shape = _make_shape(model)
     symbols = None
-    if distal_x is not None:
+    if distal_x is not None and distal_x.dtype == torch.uint8 and distal_x.dim() == 2:
+        symbols = distal_x                              # the encoder's symbols (model_snv._symbol_windows): nothing to convert or check
+    elif distal_x is not None:
         symbols = T.dense_to_symbols(distal_x)          # flags non-encodings; checked behind the launches (flush_input_checks)
     ps = [model.emb_dropout_layer.p, model.droput_layers[0].p, model.droput_layers[1].p] if model.model_no != 1 else [0.0, 0.0, 0.0]
     ps += [model.distal_fc1[1].p, model.distal_fc2[1].p] if model.model_no != 0 else [0.0, 0.0]

@@ -632,3 +632,46 @@ def test_train_step_writes_stay_inside_their_workspace_regions(monkeypatch):
         zone = ws[off + size:off + size + guard]
         assert (zone == 255).all(), f"region {i}: a kernel wrote behind its {size} bytes"
     assert acc_like < n_regions // 2
+
+
+def test_symbol_windows_route_equals_the_dense_route_bit_for_bit():
+    """PackedGenome.encode_symbols -> model(local, SymbolWindows) in training mode: the training step's first layer works from symbols,
+    the dense route only recovers them from the one-hot tensor -- outputs and BatchNorm statistics of the two routes are identical bit
+    for bit, the gradients up to the order of their atomic sums (both strands, IUPAC codes and windows that hang over the record's ends included); eval mode refuses the
+    symbol form (forward_packed is the packed entry there)."""
+    from mural_amd.data import PackedGenome, SymbolWindows
+    fx = U.load("snv_train_T.npz")
+    rng = np.random.default_rng(11)
+    seq = rng.choice(np.frombuffer(b"ACGTNRYKMSWBDHV", np.uint8), size=6000,
+                     p=[.24, .24, .24, .24] + [.04 / 11] * 11).tobytes().decode()
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    R = (product_from_hp(fx["hp"])[0].seq_len - 1) // 2
+    B = 48
+    pos = torch.from_numpy(rng.integers(0, len(seq), size=B)).cuda()
+    pos[:3] = torch.tensor([0, 5, len(seq) - 1])
+    strand = torch.from_numpy(rng.integers(0, 2, size=B).astype(np.uint8)).cuda()
+    cat = genome.encode_kmer(pos, strand, int(fx["hp"][0]), int(fx["hp"][1]))
+    dense = genome.encode_onehot(pos, strand, R)
+    syms = genome.encode_symbols(pos, strand, R)
+    assert isinstance(syms, SymbolWindows) and syms.sym.dtype == torch.uint8 and tuple(syms.shape) == (B, 2 * R + 1)
+    y = torch.from_numpy(rng.integers(0, 4, size=B)).cuda()
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    results = []
+    for x in (dense, syms):
+        model, _ = product_from_hp(fx["hp"])
+        model.load_state_dict(U.snv_state_for(fx, U.snv_oracle_from_hp(fx["hp"])))
+        model = model.cuda().train()
+        torch.manual_seed(5)                                   # the dropout seeds of the step are drawn from torch's generator
+        out = model((torch.zeros(B, 1, device="cuda"), cat), x)
+        crit(out, y).backward()
+        results.append((out.detach().clone(), [None if p.grad is None else p.grad.detach().clone() for p in model.parameters()],
+                        [b.detach().clone() for b in model.buffers()]))
+    (o1, g1, b1), (o2, g2, b2) = results
+    assert torch.equal(o1, o2)
+    assert sum(g is not None for g in g1) > 20
+    # (the first-layer and embedding gradients are sums of float atomics: equal up to their order between ANY two runs)
+    assert all((a is None and b is None) or float((a - b).abs().max()) <= 1e-5 * (float(a.abs().max()) + 1e-6) for a, b in zip(g1, g2))
+    assert all(torch.equal(a, b) for a, b in zip(b1, b2))
+    model.eval()
+    with pytest.raises(TypeError):
+        model((torch.zeros(B, 1, device="cuda"), cat), syms)
