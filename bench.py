@@ -218,18 +218,23 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
     steps without a host synchronisation in between (windows encoded from the packed genome inside the timed loop), then
     `sync_steps` individually synchronised ones (the reference reads loss.item() every step, training.py:437)."""
     import torch.nn as nn
-    from mural_amd.train import clip_grad_norm_
+    from mural_amd.train import CrossEntropySum, clip_grad_norm_
     model = build_model(device).train()
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)       # one multi-tensor launch; same update rule
-    crit = nn.CrossEntropyLoss(reduction="sum")
+    crit = CrossEntropySum()                  # nn.CrossEntropyLoss(reduction="sum") in one launch per direction (mural_amd.train)
     rng = np.random.default_rng(1)
     total = steps + warmup + sync_steps
     labels = torch.from_numpy(rng.choice(4, size=total * B, p=[0.955, 0.015, 0.015, 0.015]).astype(np.int64)).to(device)
     cont = torch.zeros(B, 1, device=device)
 
+    # the site list of every step (like the labels above: inputs resident in HBM); the windows and k-mer columns are encoded from the
+    # packed genome inside the loop
+    idx_all = torch.arange(total * B, device=device) % GENOME_SITES
+    pos_all, strand_all = idx_all + DISTAL_RADIUS, (idx_all & 1).to(torch.uint8)
+    del idx_all
+
     def step(s, dense=False):
-        idx = torch.arange(s * B, (s + 1) * B, device=device) % GENOME_SITES
-        pos, strand = idx + DISTAL_RADIUS, (idx & 1).to(torch.uint8)
+        pos, strand = pos_all[s * B:(s + 1) * B], strand_all[s * B:(s + 1) * B]
         cat = genome.encode_kmer(pos, strand, LOCAL_RADIUS, LOCAL_ORDER)
         # one symbol per column (the training step's own input form) or, for the side figure, the reference loader's one-hot tensor
         x = genome.encode_onehot(pos, strand, DISTAL_RADIUS) if dense else genome.encode_symbols(pos, strand, DISTAL_RADIUS)
@@ -339,10 +344,10 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
     # one training configuration of the same model: batch 128 (the reference's default), CE(sum) + clip + Adam.  The step is ~500
     # small launches behind Python autograd glue: the eager loop runs at the speed of the host's Python (7-11 ms on this pool's
     # boxes), mural_amd.train.GraphedIndelTrainStep replays the same step as one HIP graph and is bound by the device alone.
-    from mural_amd.train import GraphedIndelTrainStep, clip_grad_norm_
+    from mural_amd.train import CrossEntropySum, GraphedIndelTrainStep, clip_grad_norm_
     tb = 128
     model.train()
-    crit = torch.nn.CrossEntropyLoss(reduction="sum")
+    crit = CrossEntropySum()                  # nn.CrossEntropyLoss(reduction="sum") in one launch per direction
     x = genome.encode_onehot(pos[:tb], strand[:tb], 4000, "indel")
     y = (idx[:tb] % 8)
     opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)       # one multi-tensor launch; same update rule

@@ -336,6 +336,12 @@ int mural_snv_train_backward(const MuralSnvShape* shape, const MuralSnvParams* p
                              const int64_t* cat_x, const float* dout, int64_t B, const float* dropout_p, const uint64_t* seeds,
                              const uint64_t* seed_dev, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The criterion of the reference's training loops, nn.CrossEntropyLoss(reduction='sum') on the model output x [B][nc] with labels y
+ * (MuRaL/training.py:327, :425), in one launch per direction: loss[0] = -sum_i (x[i][y_i] - logsumexp(x[i])) summed in a fixed order
+ * (reproducible), prob = softmax(x) kept for the backward; dx = g[0] (prob - onehot(y)).  A label outside [0, nc) makes the loss NaN. */
+int mural_op_ce_sum_fwd(const float* x, const int64_t* y, int64_t B, int32_t nc, float* prob, float* loss, void* stream);
+int mural_op_ce_sum_bwd(const float* prob, const int64_t* y, const float* g, int64_t B, int32_t nc, float* dx, void* stream);
+
 /* Validation hooks of the parity tests: the channel-last conv kernels of the composed training step on their own.  Tensors are
  * [B][L][32]; acc blocks are double[MURAL_BN_SLOTS][2][32] (the forward reads the batch sums of act(x) from `acc` and finalises the
  * BatchNorm itself; acc_out / stat_out zeroed by the caller); part: 1024 * (32*32*3 + 32) floats of partial rows, *nrow of them written. */

@@ -1436,6 +1436,57 @@ extern "C" int mural_op_head_bwd(const float* loc, const float* mid, const float
   CHECK_LAUNCH();
 }
 
+// The criterion of the training loops (training.py: nn.CrossEntropyLoss(reduction='sum') on the model output) in two launches instead of
+// torch's four-to-six: loss = -sum_i (x[i][y_i] - logsumexp(x[i])), prob = softmax(x) kept for the backward, dx = g (prob - onehot(y)).
+// ONE workgroup: the sum is taken in a fixed order (double accumulators), the loss is reproducible.  A label outside [0, nc) makes the
+// loss NaN (torch raises a device assert there).
+__global__ __launch_bounds__(1024) void ce_sum_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ y, int64_t B, int nc,
+                                                          float* __restrict__ prob, float* __restrict__ loss) {
+  __shared__ double red[16];
+  double acc = 0.0;
+  for (int64_t i = threadIdx.x; i < B; i += 1024) {
+    const float* r = x + i * nc;
+    float m = -INFINITY;
+    for (int k = 0; k < nc; ++k) m = fmaxf(m, r[k]);
+    float s = 0.f;
+    for (int k = 0; k < nc; ++k) s += expf(r[k] - m);
+    const float lse = m + logf(s);
+    const float inv = 1.f / s;
+    for (int k = 0; k < nc; ++k) prob[i * nc + k] = expf(r[k] - m) * inv;
+    const int64_t t = y[i];
+    acc += (t >= 0 && t < nc) ? (double)(lse - r[t]) : (double)NAN;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int w = 0; w < 16; ++w) t += red[w];
+    loss[0] = (float)t;
+  }
+}
+__global__ void ce_sum_bwd_kernel(const float* __restrict__ prob, const int64_t* __restrict__ y, const float* __restrict__ g, int64_t total,
+                                  int nc, float* __restrict__ dx) {
+  const float gv = g[0];
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t row = i / nc;
+    const int k = (int)(i - row * nc);
+    dx[i] = gv * (prob[i] - (y[row] == k ? 1.f : 0.f));
+  }
+}
+extern "C" int mural_op_ce_sum_fwd(const float* x, const int64_t* y, int64_t B, int32_t nc, float* prob, float* loss, void* stream) {
+  MURAL_REQUIRE(x && y && prob && loss && nc >= 1 && B >= 0, "ce_sum_fwd: bad arguments");
+  hipLaunchKernelGGL(ce_sum_fwd_kernel, dim3(1), dim3(1024), 0, STREAM, x, y, B, nc, prob, loss);
+  CHECK_LAUNCH();
+}
+extern "C" int mural_op_ce_sum_bwd(const float* prob, const int64_t* y, const float* g, int64_t B, int32_t nc, float* dx, void* stream) {
+  MURAL_REQUIRE(prob && y && g && dx && nc >= 1 && B >= 0, "ce_sum_bwd: bad arguments");
+  if (B == 0) return MURAL_OK;
+  hipLaunchKernelGGL(ce_sum_bwd_kernel, dim3(grid_for(B * nc)), dim3(256), 0, STREAM, prob, y, g, B * nc, nc, dx);
+  CHECK_LAUNCH();
+}
+
 namespace mural {
 int train_bn2d_apply_dropout(const float* x, int64_t B, int C, int relu, const double* acc, const float* gamma, const float* beta, float eps,
                              float momentum, float* running_mean, float* running_var, float* state, float p, uint64_t seed,

@@ -116,6 +116,46 @@ class GraphedIndelTrainStep(GraphedTrainStep):
         return self._replay(x, y)
 
 
+class _CESum(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, y):
+        from . import _lib
+        B, nc = x.shape
+        prob = torch.empty_like(x)
+        loss = torch.empty((), dtype=torch.float32, device=x.device)
+        with torch.cuda.device(x.device):
+            _lib.check(_lib.lib().mural_op_ce_sum_fwd(x.data_ptr(), y.data_ptr(), B, nc, prob.data_ptr(), loss.data_ptr(),
+                                                     _lib.current_stream_ptr(x.device)))
+        ctx.save_for_backward(prob, y)
+        return loss
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import _lib
+        prob, y = ctx.saved_tensors
+        B, nc = prob.shape
+        g = g.to(torch.float32).contiguous()
+        dx = torch.empty_like(prob)
+        with torch.cuda.device(prob.device):
+            _lib.check(_lib.lib().mural_op_ce_sum_bwd(prob.data_ptr(), y.data_ptr(), g.data_ptr(), B, nc, dx.data_ptr(),
+                                                     _lib.current_stream_ptr(prob.device)))
+        return dx, None
+
+
+class CrossEntropySum(torch.nn.Module):
+    """``torch.nn.CrossEntropyLoss(reduction='sum')`` (training.py:327, the criterion of the reference's loops) as one launch per
+    direction: between the model's forward and backward torch's version is a chain of four to six dependent little launches (log-softmax,
+    gather / reduce, their backwards) with nothing else to run beside them.  Same value up to the order of the sum (fixed here: the loss
+    is reproducible), same gradient; a label outside [0, n_class) gives NaN where torch raises a device assert.  Anything but a float32
+    (B, n_class) device tensor with int64 labels of at most 65536 rows goes to torch's implementation."""
+
+    def forward(self, x, y):
+        if (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and y.dim() == 1 and y.dtype == torch.int64 and y.is_cuda
+                and x.shape[0] == y.shape[0] and 0 < x.shape[0] <= 65536):
+            return _CESum.apply(x.contiguous(), y.contiguous())
+        return torch.nn.functional.cross_entropy(x, y, reduction="sum")
+
+
 def clip_grad_norm_(model, max_norm):
     """``torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)`` (training.py:430) for a model whose gradients came out of
     the one-call HIP backward: they are views of ONE flat buffer (zero between the slots), so the total 2-norm is one reduction
