@@ -423,6 +423,45 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cl_kernel(const BnApplyArgs2
   const f32x4 k0 = ld4(&cst[0][4 * chunk]), m1 = ld4(&cst[1][4 * chunk]), m2 = ld4(&cst[2][4 * chunk]), mu = ld4(&cst[3][4 * chunk]),
               is = ld4(&inv[4 * chunk]);
   const int64_t total = a.rows * 8;
+  // Every load of an iteration is issued before the first use, the optional residual gradients through range-checked descriptors (an
+  // absent tensor has one of 0 bytes and reads 0): `add1 ? ld4(add1 + i * 4) : 0` put each of them behind a branch with a full wait.
+  // Two 16-byte pieces per lane and iteration in flight.  (Tensors of 2 GB and more keep the plain loop.)
+  const uint64_t bytes = (uint64_t)total * 16;
+  if (bytes < (1ull << 31)) {
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dz), 0, (int)bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(add1 ? add1 : x), 0, add1 ? (int)bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2d = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(add2 ? add2 : x), 0, add2 ? (int)bytes : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(dx, 0, (int)bytes, 0x00020000);
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i0 = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i0 < total; i0 += 2 * stride) {
+      f32x4 raw[2], d[2], r1[2], r2[2];
+      uint32_t off[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int64_t i = i0 + u * stride;
+        off[u] = i < total ? (uint32_t)(i * 16) : 0x80000000u;
+        raw[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off[u], 0, 0));
+        d[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rz, off[u], 0, 0));
+        r1[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r1d, off[u], 0, 0));
+        r2[u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r2d, off[u], 0, 0));
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        float o[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = relu ? fmaxf(raw[u][q], 0.f) : raw[u][q];
+          const float xh = (v - mu[q]) * is[q];
+          float gq = k0[q] * (d[u][q] - m1[q] - xh * m2[q]);
+          if (relu && raw[u][q] <= 0.f) gq = 0.f;
+          o[q] = (gq + r1[u][q]) + r2[u][q];
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, f32x4{o[0], o[1], o[2], o[3]}), ro, off[u], 0, 0);
+      }
+    }
+    return;
+  }
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const f32x4 raw = ld4(x + i * 4), d = ld4(dz + i * 4);
     const f32x4 r1 = add1 ? ld4(add1 + i * 4) : splat(0.f), r2 = add2 ? ld4(add2 + i * 4) : splat(0.f);
