@@ -491,6 +491,8 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const PoolFwdArgs2 
   __shared__ float red[256];
   f32x4 s1 = splat(0.f), s2 = splat(0.f);     // batch sums of the pooled values for the BatchNorm behind the pool (acc != nullptr)
   const int64_t total = a.B * Lout * 8;
+  const uint64_t xbytes = (uint64_t)a.B * L * CL_C * 4;
+  const __amdgpu_buffer_rsrc_t rxd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, xbytes < (1ull << 31) ? (int)xbytes : 0, 0x00020000);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
     const int chunk = (int)(i & 7);
     const int64_t bc = i >> 3;
@@ -499,16 +501,41 @@ __global__ __launch_bounds__(256) void maxpool_cl_fwd_kernel(const PoolFwdArgs2 
     const int jlo = jo * s - p;
     f32x4 m = splat(-INFINITY);
     int am[4] = {0, 0, 0, 0};
-    for (int w = 0; w < k; ++w) {
-      const int j = jlo + w;
-      if (j < 0 || j >= L) continue;
-      const f32x4 v = ld4(x + ((size_t)(b * L + j) * CL_C) + 4 * chunk);
+    if (k <= 8 && xbytes < (1ull << 31)) {
+      // the window's columns requested together (a load per tap under `if (in range)` waited for each one in turn: seven round trips
+      // per output at k = 7); a column outside the row aims past the descriptor and is masked to -inf, same comparison order
+      f32x4 v[8];
+      bool ok[8];
 #pragma unroll
-      for (int q = 0; q < 4; ++q)
-        if (v[q] > m[q]) {
-          m[q] = v[q];
-          am[q] = j;
+      for (int w = 0; w < 8; ++w) {
+        const int j = jlo + w;
+        ok[w] = (w < k) & (j >= 0) & (j < L);
+        uint32_t off = (uint32_t)(((b * L + j) * CL_C + 4 * chunk) * 4);
+        asm volatile("" : "+v"(off));
+        v[w] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rxd, ok[w] ? off : 0x80000000u, 0, 0));
+      }
+#pragma unroll
+      for (int w = 0; w < 8; ++w) {
+        const int j = jlo + w;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const bool gt = ok[w] & (v[w][q] > m[q]);
+          m[q] = gt ? v[w][q] : m[q];
+          am[q] = gt ? j : am[q];
         }
+      }
+    } else {
+      for (int w = 0; w < k; ++w) {
+        const int j = jlo + w;
+        if (j < 0 || j >= L) continue;
+        const f32x4 v = ld4(x + ((size_t)(b * L + j) * CL_C) + 4 * chunk);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if (v[q] > m[q]) {
+            m[q] = v[q];
+            am[q] = j;
+          }
+      }
     }
     st4(y + (size_t)bc * CL_C + 4 * chunk, m);
     int32_t* ap = arg + (size_t)bc * CL_C + 4 * chunk;
