@@ -223,3 +223,34 @@ def test_train_epoch_policy_matches_reference_loop():
     with pytest.raises(ValueError):
         TR.make_optimizer(dict(config, optim="LBFGS"), model.parameters())
     assert isinstance(TR.make_optimizer(dict(config, optim="AdamW2"), model.parameters()), torch.optim.AdamW)
+
+
+def test_cross_entropy_sum_takes_torch_path_off_device_and_symbol_windows_are_typed():
+    """mural_amd.train.CrossEntropySum is torch's CrossEntropyLoss(reduction='sum') for anything but a float32 device tensor (the fused
+    launch is the GPU tests' matter); SymbolWindows is what encode_symbols hands to the training forward, and a dense model call with it in
+    eval mode, or with a malformed tensor inside, is refused before anything reaches the device."""
+    import pytest
+    import torch
+    from mural_amd.train import CrossEntropySum
+    from mural_amd.data import SymbolWindows
+    from mural_amd.model import model_snv
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(37, 4, generator=g, requires_grad=True)
+    y = torch.randint(0, 4, (37,), generator=g)
+    a = CrossEntropySum()(x, y)
+    b = torch.nn.CrossEntropyLoss(reduction="sum")(x, y)
+    assert torch.equal(a, b)
+    a.backward()
+    assert x.grad is not None and torch.isfinite(x.grad).all()
+
+    class Stub:                                   # what _symbol_windows looks at
+        seq_len, training, in_channels = 201, False, 4
+    ok = SymbolWindows(torch.zeros((3, 201), dtype=torch.uint8))
+    assert tuple(ok.shape) == (3, 201)
+    assert model_snv._symbol_windows(Stub(), torch.zeros(3, 4, 201)) is None          # a dense tensor takes the dense route
+    with pytest.raises(TypeError):
+        model_snv._symbol_windows(Stub(), ok)                                          # eval mode: forward_packed is the packed entry
+    with pytest.raises(TypeError):
+        model_snv._symbol_windows(Stub(), SymbolWindows(torch.zeros((3, 201), dtype=torch.float32)))
+    with pytest.raises(ValueError):
+        model_snv._symbol_windows(Stub(), SymbolWindows(torch.zeros((3, 301), dtype=torch.uint8)))
