@@ -102,6 +102,25 @@ __device__ __forceinline__ f32x4 pk_fma(const f32x4& a, const f32x4& b, const f3
   return f32x4{lo.x, lo.y, hi.x, hi.y};
 }
 
+// Staging-slot addresses without a register per slot.  Slot u of a lane is the 16-byte piece at byte 16 lane + 1024 u of the unit; the
+// twelve-bit immediate of a buffer instruction reaches 4095, so a lane keeps ONE offset per group of four slots (16 lane + 4096 k,
+// made from an opaque copy of the lane offset inside the unit loop: a hoisted table of 18 per-slot offsets was what spilled, and
+// their reloads -- one s_waitcnt vmcnt(0) each -- serialised the unit's loads) and the slot inside the group rides in the immediate.
+template <int NLD>
+struct CwSlots {
+  uint32_t g[(NLD + 3) / 4];
+  __device__ __forceinline__ void make(uint32_t lane16) {
+    uint32_t l = lane16;
+    asm volatile("" : "+v"(l));
+#pragma unroll
+    for (int k = 0; k < (NLD + 3) / 4; ++k) g[k] = l + 4096u * k;
+  }
+  __device__ __forceinline__ uint32_t at(int u) const { return g[u >> 2] + 1024u * (uint32_t)(u & 3); }
+};
+// a loop-carried sum must be complete here: left alone the IR sinks the adds of a unit's staging to the loop latch and keeps every
+// staged value (72 registers at nine blocks) alive through both MFMA phases
+__device__ __forceinline__ void cw_pin(f32x4& v) { asm volatile("" : "+v"(v)); }
+
 // byte offset inside a unit of the 128-byte row of logical column c; CW_OOB for separator / padding columns
 __device__ __forceinline__ uint32_t cw_col_offset(const CwGeom& g, uint32_t c) {
   const uint32_t u = c - 1u;
@@ -395,8 +414,10 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_fwd_kernel(const CwFwdA
     // ---- this unit's rows: memory -> ReLU, BatchNorm -> image (the wave's previous unit is past its last operand read)
     {      // (requesting the first unit's rows in front of the prologue keeps 72 registers live across it: spills in the block loop)
       f32x4 xin[NLD];
+      CwSlots<NLD> so;
+      so.make(lane16);
 #pragma unroll
-      for (int u = 0; u < NLD; ++u) xin[u] = buf_ld4(xd, lane16 + 1024u * u);
+      for (int u = 0; u < NLD; ++u) xin[u] = buf_ld4(xd, so.at(u));
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
         const f32x4 v = max4(xin[u], splat(lo_pre));
@@ -527,13 +548,6 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
     return (u < units.hi && !(a.dbg & 16)) ? (uint32_t)(rows < g.P ? rows : g.P) * row_bytes : 0u;
   };
   int64_t unit = units.lo + wave;
-  f32x4 gin[FOLD ? 1 : NLD];                                    // the first unit's dy rows travel under the prologue
-  if constexpr (!FOLD) {
-    const __amdgpu_buffer_rsrc_t gd = cw_rsrc(a.dy + (size_t)(unit < units.hi ? unit : 0) * unit_stride, unit_bytes(unit));
-#pragma unroll
-    for (int u = 0; u < NLD; ++u) gin[u] = buf_ld4(gd, lane16 + 1024u * u);
-  }
-  bool first = true;
   if constexpr (FOLD) {      // constants of the folded BatchNorm-backward from its sums (32 slots), its dgamma / dbeta
     float* fc = aux + CW_AUX_FOLD;
     if (wave == 0) {
@@ -609,8 +623,12 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
     const __amdgpu_buffer_rsrc_t gd = cw_rsrc((FOLD ? a.x : a.dy) + ubase, ub), xd = cw_rsrc(a.x + ubase, ub);
     const __amdgpu_buffer_rsrc_t zd = cw_rsrc(a.dz + ubase, (a.dbg & 128) ? 0u : ub);
     // ---- this unit's dy rows: memory -> image; the bias gradient rides along
+    CwSlots<NLD> so;
+    so.make(lane16);
     if constexpr (FOLD) {
-      // dy = BatchNorm-backward apply of the layer behind, six staging slots a round (18 loads in flight)
+      // dy = BatchNorm-backward apply of the layer behind (its input passes a ReLU: the host requires it), six staging slots a round
+      // (18 loads in flight), branch-free: a piece that does not exist reads x = 0, which the ReLU mask turns into dy = 0 like every
+      // x <= 0 -- no range test, and max(x, 0) = x wherever the mask lets a value through
       const float* fc = aux + CW_AUX_FOLD;
       const f32x4 k0 = ld4(fc + 4 * chunk), m1 = ld4(fc + CL_C + 4 * chunk), m2 = ld4(fc + 2 * CL_C + 4 * chunk),
                   mu = ld4(fc + 3 * CL_C + 4 * chunk), is = ld4(fc + 4 * CL_C + 4 * chunk);
@@ -624,7 +642,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
 #pragma unroll
         for (int q = 0; q < RS; ++q)
           if (u0 + q < NLD) {
-            const uint32_t go = lane16 + 1024u * (u0 + q);
+            const uint32_t go = so.at(u0 + q);
             dzn[q] = buf_ld4(zd2, go);
             xn[q] = buf_ld4(xd2, go);
             ad1[q] = buf_ld4(ad, go);
@@ -632,33 +650,29 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
 #pragma unroll
         for (int q = 0; q < RS; ++q)
           if (u0 + q < NLD) {
-            const uint32_t go = lane16 + 1024u * (u0 + q);
+            const f32x4 xh = (xn[q] - mu) * is;
+            const f32x4 gq = k0 * ((dzn[q] - m1) - xh * m2);
             f32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float raw = xn[q][e];
-              const float v = a.frelu ? fmaxf(raw, 0.f) : raw;
-              const float xh = (v - mu[e]) * is[e];
-              float gq = k0[e] * (dzn[q][e] - m1[e] - xh * m2[e]);
-              if (a.frelu && raw <= 0.f) gq = 0.f;
-              o[e] = go < ub ? gq + ad1[q][e] : 0.f;      // (pieces of rows that do not exist read as zero, their dy must be zero)
-            }
+            for (int e = 0; e < 4; ++e) o[e] = xn[q][e] > 0.f ? gq[e] : 0.f;
+            o += ad1[q];
             bsum += o;
             lds_st4(wb, sotab[64 * (u0 + q)], o);
-            buf_st4(od, go, o);
+            buf_st4(od, so.at(u0 + q), o);
           }
+        cw_pin(bsum);
       }
     } else {
-      if (!first) {
+      // (the first unit's rows used to travel under the prologue in 72 registers that then stayed allocated around the loop: spills)
+      f32x4 gin[NLD];
 #pragma unroll
-        for (int u = 0; u < NLD; ++u) gin[u] = buf_ld4(gd, lane16 + 1024u * u);
-      }
-      first = false;
+      for (int u = 0; u < NLD; ++u) gin[u] = buf_ld4(gd, so.at(u));
 #pragma unroll
       for (int u = 0; u < NLD; ++u) {
         bsum += gin[u];
         lds_st4(wb, sotab[64 * u], gin[u]);
       }
+      cw_pin(bsum);
     }
     // ---- act(x) of the first k-steps of the weight gradient, in operand layout (channels 2 n16, 2 n16 + 1 of column 4 s + kk)
     f32x2 xop[NKS];
@@ -880,6 +894,7 @@ int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream) {
     MURAL_REQUIRE((j.fold.dz != nullptr) == (jobs[0].fold.dz != nullptr), "conv32_bwd (wave-private): the jobs of a launch fold or do not fold alike");
     MURAL_REQUIRE(j.fold.dz || j.dy, "conv32_bwd (wave-private): dy is NULL");
     if (j.fold.dz) {
+      MURAL_REQUIRE(j.fold.relu, "conv32_bwd (wave-private): the folded BatchNorm-backward apply is built for a ReLU in front of that BatchNorm");
       a.fdz = j.fold.dz; a.fx = j.fold.x; a.fstate = j.fold.state; a.fgamma = j.fold.gamma; a.facc = j.fold.acc; a.fn = (double)j.B * j.L;
       a.frelu = j.fold.relu; a.fdgamma = j.fold.dgamma; a.fdbeta = j.fold.dbeta; a.add1 = j.fold.add1; a.dy_out = j.fold.dy_out;
     }

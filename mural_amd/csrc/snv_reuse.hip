@@ -473,8 +473,49 @@ size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands,
   return off;
 }
 
+// edge tile: as many sites as keep <= SNV_NB2MAX blocks per wave (two workgroups per CU fit by far)
+int reuse_edge_sites() {
+  for (int cand = 15; cand >= 1; --cand) {
+    const int NC = 1 + cand * RU_SC, nbk = (NC + 15) / 16;
+    if ((nbk + 1) / 2 <= SNV_NB2MAX) return cand;
+  }
+  return 1;
+}
+
+// interior pooled-column range [u_lo, u_hi] of the second pool for a tower geometry (empty range: u_lo = L3, u_hi = L3 - 1)
+void reuse_interior(const TowerGeom& gg, int* u_lo, int* u_hi) {
+  const int pk2 = gg.pk[1], ps2 = gg.ps[1], pp2 = gg.pp[1], L2 = gg.L[0], L3 = gg.L[1];
+  int lo = (RU_EV + pp2 + ps2 - 1) / ps2;
+  int hi = (L2 - 1 - RU_EV - (pk2 - 1) + pp2) / ps2;
+  if (hi > L3 - 1) hi = L3 - 1;
+  if (hi < lo) { lo = L3; hi = L3 - 1; }
+  *u_lo = lo;
+  *u_hi = hi;
+}
+
+// Every geometry condition the reuse launches REQUIRE is evaluated here, so that a caller who asks first (HipShardForward does)
+// falls back to the per-window kernels instead of meeting an error half-way through a shard.  Long-window models
+// (MuralSnvModel::longwin: the segmented first stage) are never served: their pooled interior does not fit the edge tile.
 bool reuse_supported(const MuralSnvModel* m) {
-  return m->shape.model_no != 0 && m->split && m->args.geom[0].L[0] >= RU_L && m->args.geom[1].L[0] >= RU_L;
+  if (m->shape.model_no == 0 || !m->split || m->longwin) return false;
+  const TowerGeom& gl = m->args.geom[0];
+  const TowerGeom& gm = m->args.geom[1];
+  if (gl.L[0] < RU_L || gm.L[0] < RU_L) return false;
+  if (!(gl.pk[0] == 15 && gl.ps[0] == 15 && gl.pp[0] == 7 && gm.pk[0] == 3 && gm.ps[0] == 3 && gm.pp[0] == 1)) return false;
+  const int last_lo = gl.ps[0] * (gl.L[0] - 1) - gl.pp[0];
+  const int er_n = std::min(last_lo + gl.pk[0] - 1, gl.L1 - 1) - last_lo;
+  if (er_n < 0 || er_n > 14) return false;
+  const int P = reuse_edge_sites();
+  for (int t = 0; t < 2; ++t) {
+    const TowerGeom& gg = m->args.geom[t];
+    if (!(gg.pk[1] == 2 * gg.pp[1] + 1 && gg.ps[1] == gg.pk[1])) return false;
+    const int l_lo = gg.ps[0] * (gg.L[0] - 1) - gg.pp[0];
+    if (t == 1 && l_lo + gg.pk[0] - 1 >= gg.L1 - 1) return false;      // the mid crop's last pooled column must be interior
+    int u_lo, u_hi;
+    reuse_interior(gg, &u_lo, &u_hi);
+    if ((int64_t)P * (u_hi - u_lo + 1) * 8 > (int64_t)RU_POOL_SLOTS * SNV_THREADS) return false;
+  }
+  return true;
 }
 
 int launch_rows_conv(const RowsConvArgs& a, hipStream_t stream) {
@@ -604,12 +645,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
   }
   // ---- per batch of sites: local branch, edge kernels, short-stage launches
   const int nc = sh.n_class;
-  // edge tile: as many sites as keep <= SNV_NB2MAX blocks per wave (two workgroups per CU fit by far)
-  int P = 1;
-  for (int cand = 15; cand >= 1; --cand) {
-    const int NC = 1 + cand * RU_SC, nbk = (NC + 15) / 16;
-    if ((nbk + 1) / 2 <= SNV_NB2MAX) { P = cand; break; }
-  }
+  const int P = reuse_edge_sites();
   TowerGeom ge{};
   ge.L[0] = RU_L; ge.Sc[0] = RU_SC; ge.NC[0] = 1 + P * RU_SC; ge.nb[0] = (ge.NC[0] + 15) / 16;
   ge.dL[0] = FastDiv::make(RU_L); ge.dSc[0] = FastDiv::make(RU_SC);
@@ -654,10 +690,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       const int last_lo = gg.ps[0] * (gg.L[0] - 1) - gg.pp[0];
       e.right_pad = (last_lo + gg.pk[0] - 1 >= gg.L1 - 1) ? 1 : 0;
       MURAL_REQUIRE(t == 0 || !e.right_pad, "reuse: the mid crop's last pooled column is expected to be interior");
-      e.u_lo = (RU_EV + e.pp2 + e.ps2 - 1) / e.ps2;
-      e.u_hi = (e.L2 - 1 - RU_EV - (e.pk2 - 1) + e.pp2) / e.ps2;
-      if (e.u_hi > e.L3 - 1) e.u_hi = e.L3 - 1;
-      if (e.u_hi < e.u_lo) { e.u_lo = e.L3; e.u_hi = e.L3 - 1; }        // no interior window: every pooled column from the edge loop
+      reuse_interior(gg, &e.u_lo, &e.u_hi);        // no interior window: every pooled column from the edge loop
       MURAL_REQUIRE((int64_t)P * (e.u_hi - e.u_lo + 1) * 8 <= (int64_t)RU_POOL_SLOTS * SNV_THREADS, "reuse: pooled tile too large");
       for (int neg = 0; neg < 2; ++neg) {
         e.F[neg] = w.rows[neg][t == 0 ? 0 : 1];

@@ -23,9 +23,23 @@ def _stamp(*ts):
     return tuple((t.data_ptr(), t._version, t.device) for t in ts)
 
 
+def invalidate(model=None):
+    """Drop the cached affines / weight layouts of `model`'s modules (all caches when None).  The version stamps above see every
+    in-place update made through the tensor itself; an edit through ``.data`` (``bn.weight.data.mul_()``, ``conv.weight.data.copy_()``:
+    older init / EMA code) bumps neither the stamp nor the pointer -- the model's ``invalidate_folded()`` (called by ``train()``
+    transitions, ``load_state_dict`` and ``_apply``; public for hand edits) comes through here."""
+    if model is None:
+        _affine_cache.clear()
+        _wt_cache.clear()
+        return
+    for m in model.modules():
+        _affine_cache.pop(m, None)
+        _wt_cache.pop(m, None)
+
+
 def _affine(bn):
     """eval-mode BatchNorm as y = scale * x + shift"""
-    key = _stamp(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+    key = _stamp(bn.weight, bn.bias, bn.running_mean, bn.running_var) + (float(bn.eps),)
     hit = _affine_cache.get(bn)
     if hit is not None and hit[0] == key:
         return hit[1], hit[2]

@@ -159,10 +159,14 @@ class _HipSnvBase(nn.Module):
     # parameters or BatchNorm buffers behind torch's back: a train()/eval() transition (the training kernels and a replayed
     # HIP graph update weights and running statistics without bumping tensor versions), load_state_dict, .to()/_apply.
     def invalidate_folded(self):
-        """Force the next eval-mode forward to rebuild the folded weights (call after changing buffers by hand)."""
+        """Force the next eval-mode forward to rebuild the folded weights (call after changing parameters or buffers by hand,
+        e.g. through ``.data``, which bumps no version counter)."""
         self._handle_key = None
         self._plist = None
         self._ws_rows = [0, 0]
+        if getattr(self, "_fused", None) is False:      # the per-layer eval path keeps per-module caches of its own
+            from . import generic_eval
+            generic_eval.invalidate(self)
 
     def train(self, mode=True):
         if bool(mode) != self.training:     # a real transition; model.eval() on a model in eval mode keeps the folded copy

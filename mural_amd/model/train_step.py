@@ -12,9 +12,15 @@ backward at batch 4096.  ``p.grad`` after ``loss.backward()`` is what the refere
 clip_grad_norm_, step) reads; an existing ``p.grad`` is accumulated into, like autograd does.  What this skips is autograd's own
 bookkeeping per parameter: tensor hooks on parameters, ``torch.autograd.grad(loss, params)`` and DistributedDataParallel's reducer
 do not see these gradients -- ``MURAL_TRAIN_AUTOGRAD_PARAMS=1`` (or ``model._autograd_params = True``) routes them through the
-engine again.
+engine again.  The step falls back to that route BY ITSELF when a direct gradient could go unseen: a parameter carries a tensor hook
+or a post-accumulate-grad hook, or a process group of more than one rank is initialised (DistributedDataParallel's reducer hangs off
+the AccumulateGrad nodes this mode skips; ``north_star`` keeps training single-GPU, so nothing is lost).  ``torch.autograd.grad``
+on parameters other than the anchor fails with autograd's own "not used in the graph" error.  The ``.grad`` views of one backward
+are handed out again by the next one only while nobody else still holds them (reference count of the views): a caller who keeps
+last step's gradients for accumulation or logging gets a fresh buffer instead of having them rewritten in place.
 """
 import os
+import sys
 
 import ctypes as C
 
@@ -141,13 +147,21 @@ class ModelStep(torch.autograd.Function):
         return out
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dout):
         model, shape, ws = ctx.model, ctx.shape, ctx.ws
+        if ws is None:
+            raise RuntimeError("the SNV training step keeps its saved activations for ONE backward (retain_graph=True is not supported: "
+                               "run the forward again)")
         cat_x, drops, seeds, seed_dev, B = ctx.args
         lay = _layout(model)
         dev = ws.device
         direct = ctx.direct and all(p.grad is None for p in lay.plist)     # (an existing .grad is accumulated into: a fresh buffer then)
         if direct:
+            # views somebody still holds (last step's gradients kept across zero_grad(set_to_none=True)) are not rewritten in place:
+            # 3 = the list's reference + the loop variable + getrefcount's own argument
+            if lay.own_views is not None and any(sys.getrefcount(v) > 3 for v in lay.own_views):
+                lay.own_flat = lay.own_views = None
             if lay.own_flat is None or lay.own_flat.device != dev:
                 lay.own_flat = torch.zeros(lay.total, dtype=torch.float32, device=dev)
                 lay.own_views = [lay.own_flat[o:o + p.numel()].view(p.shape) for p, o in zip(lay.plist, lay.poffs)]
@@ -178,6 +192,16 @@ class ModelStep(torch.autograd.Function):
         return (None,) * 8 + tuple(grads[id(p)] if p.numel() else torch.zeros_like(p) for p in ctx.params)
 
 
+def _direct_is_safe(params):
+    """Direct-gradient mode only where nothing but ``p.grad`` observes the gradients (module docstring)."""
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() > 1:
+        return False
+    for p in params:
+        if not p.requires_grad or p._backward_hooks or getattr(p, "_post_accumulate_grad_hooks", None):
+            return False
+    return True
+
+
 def run(model, cat_x, distal_x):
     """Training-mode forward of `model` on (cat_x int64 (B, cols) | None, distal_x float (B, 4, L) | uint8 (B, L) symbols | None)."""
     from . import train_ops as T
@@ -197,7 +221,7 @@ def run(model, cat_x, distal_x):
     params = _layout(model).params_all
     # direct-gradient mode (module docstring): one parameter anchors the node in the autograd graph, the node sets every .grad itself
     direct = (not getattr(model, "_autograd_params", False) and not os.environ.get("MURAL_TRAIN_AUTOGRAD_PARAMS")
-              and all(p.requires_grad for p in params))
+              and _direct_is_safe(params))
     try:
         if direct:
             anchor = next(p for p in params if p.numel())

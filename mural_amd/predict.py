@@ -454,6 +454,7 @@ class TsvSink:
         self.rows = 0
         self.seconds = {"sort_format_enqueue": 0.0, "wait_buffer": 0.0, "host_format": 0.0, "host_write": 0.0}
         self._writer_totals = {"wait_device": 0.0, "copy": 0.0, "write": 0.0, "bytes": 0}
+        self._writer_shard_bytes = {}  # device path of the part mode: shard number -> bytes, over every writer thread this sink had
 
     # -- helpers ----------------------------------------------------------------------------------------------------------
     @staticmethod
@@ -577,6 +578,7 @@ class TsvSink:
         n = len(shard["start"])
         if name is None or n == 0:
             return
+        _refuse_second_calibration(shard, self.poisson, self.dirichlet_weights)
         self.rows += n
         on_device = isinstance(shard["prob"], torch.Tensor) and shard["prob"].is_cuda
         if self.parts and not (self._last is None or name > self._last):
@@ -605,6 +607,10 @@ class TsvSink:
             err = self._writer.error
             for key, v in dict(self._writer.seconds, bytes=self._writer.bytes).items():
                 self._writer_totals[key] += v
+            # per-shard byte counts of EVERY writer this sink has had (a later chromosome name longer than the writer's staging or
+            # a device change replaces the writer mid-run): the part-file assembly's index
+            for k, v in self._writer.shard_bytes.items():
+                self._writer_shard_bytes[k] = self._writer_shard_bytes.get(k, 0) + v
             self._writer = None
             if err is not None:
                 raise err
@@ -620,11 +626,14 @@ class TsvSink:
     def _close_parts(self):
         """Part mode: exchange the per-shard byte counts, rank 0 strings the slices together in (shard, rank) order."""
         w_bytes = dict(self._shard_bytes)
-        for k, v in getattr(self, "_writer_shard_bytes", {}).items():
+        for k, v in self._writer_shard_bytes.items():
             w_bytes[k] = w_bytes.get(k, 0) + v
         mine = [int(w_bytes.get(i, 0)) for i in range(self._shard_no + 1)]
         self._fh.flush()
         self._fh.close()
+        size = os.path.getsize(self._out_path)
+        if sum(mine) != size:      # an index that does not add up to the part file would mis-order or truncate the table silently
+            raise IOError("part file %s holds %d bytes, its per-shard index adds up to %d" % (self._out_path, size, sum(mine)))
         if self._emulated:
             return
         everyone = [None] * self.world
@@ -648,6 +657,10 @@ class TsvSink:
                                     raise IOError("short part file %s.part%04d" % (self.path, r))
                                 offs[r] += sent
                                 left -= sent
+                    for r in range(self.world):      # every part consumed to its last byte, or the parts stay for inspection
+                        size = os.fstat(fds[r]).st_size
+                        if offs[r] != size:
+                            raise IOError("part file %s.part%04d: assembled %d of %d bytes" % (self.path, r, offs[r], size))
                 finally:
                     for fd in fds:
                         os.close(fd)
@@ -671,10 +684,7 @@ class TsvSink:
         self._spool = []
 
     def close(self):
-        w = self._writer
         self._close_writer()
-        if w is not None:
-            self._writer_shard_bytes = dict(w.shard_bytes)
         if self.parts:
             self._close_parts()
             return
@@ -718,6 +728,16 @@ class TsvSink:
         self._spool = []
 
 
+def _refuse_second_calibration(rows, poisson, dirichlet_weights):
+    """`rows` (a shard or a collected result) says whether its probabilities went through the calibration chain on the device
+    already (HipShardForward(dirichlet_weights= / poisson= / scale_factor=); `poisson` defaults to ON there for indel models,
+    run_predict.py:224).  Calibrating such rows again would be silent and wrong."""
+    if rows is not None and rows.get("calibrated") and (poisson or dirichlet_weights is not None):
+        raise ValueError("these probabilities are calibrated already (HipShardForward applied its dirichlet_weights / poisson / "
+                         "scale_factor chain on the device; poisson defaults to on for model_type='indel'): drop poisson= / "
+                         "dirichlet_weights= here, or build the forward with poisson=False")
+
+
 def write_predictions(res, path, poisson=False, dirichlet_weights=None):
     """The prediction table of run_predict.py:217-239 from the dict returned by ``predict_bed`` / ``predict_bed_sharded``: optional
     Dirichlet calibration (``calibration.load_dirichlet_weights`` of the model's ``model.fdiri_cal.pkl``), optional Poisson
@@ -725,6 +745,7 @@ def write_predictions(res, path, poisson=False, dirichlet_weights=None):
     sort_values (stable), tab-separated, floats as '%.4g' -- byte-identical to the reference's pandas writer, formatted by the
     C++ row formatter.  Returns the number of rows."""
     prob = np.asarray(res["prob"])
+    _refuse_second_calibration(res, poisson, dirichlet_weights)
     if dirichlet_weights is not None:
         from .calibration import dirichlet_calibrate
         prob = dirichlet_calibrate(prob, dirichlet_weights)
@@ -826,6 +847,9 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
             raise ValueError(_FOCAL_MSG)
 
     feeds_sink = sink is not None and (rank == 0 or getattr(sink, "parts", False))
+    # HipShardForward with a calibration chain hands over calibrated probabilities: the flag travels with every shard (and the
+    # collected result) so that a sink / write_predictions asked to calibrate as well refuses instead of calibrating twice
+    fwd_calibrated = bool(getattr(forward, "calibrated", False))
     try:
         for si, (chrom, runs) in enumerate(shards):
             n = sum(hi - lo for lo, hi in runs)
@@ -858,13 +882,13 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
                 shard = None
                 if need_meta:
                     shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
-                             "prob": full, "n_class": k}
+                             "prob": full, "n_class": k, "calibrated": fwd_calibrated}
             else:
                 full = full.cpu().numpy() if isinstance(full, torch.Tensor) else np.asarray(full)
                 if model_type == "snv":
                     check_focal_groups(full[:, -1].astype(np.int64), take(grp_o, runs))
                 shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
-                         "prob": full[:, :-1], "n_class": k}
+                         "prob": full[:, :-1], "n_class": k, "calibrated": fwd_calibrated}
             if sink is not None and (rank == 0 or getattr(sink, "parts", False)):
                 t0 = clock()
                 sink(shard)
@@ -893,7 +917,7 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
     k = kept[0][1]["prob"].shape[1]
     out = {"chrom": np.empty(n_all, object), "start": np.empty(n_all, np.int64), "end": np.empty(n_all, np.int64),
            "strand": np.empty(n_all, object), "label": np.empty(n_all, np.float32),
-           "prob": np.empty((n_all, k), kept[0][1]["prob"].dtype), "order": order}
+           "prob": np.empty((n_all, k), kept[0][1]["prob"].dtype), "order": order, "calibrated": fwd_calibrated}
     for runs, sh in kept:
         o = 0
         for lo, hi in runs:

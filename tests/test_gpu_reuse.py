@@ -192,3 +192,34 @@ def test_reuse_span_multiple_keeps_last_site_and_density_fallback():
         # single-chunk form of the same rule
         few = model.forward_packed_reuse(genome, tp[:50], ts[:50], local_radius=7, local_order=3, min_density=0.1)
         assert torch.equal(few, model.forward_packed(genome, tp[:50], ts[:50], local_radius=7, local_order=3))
+
+
+@pytest.mark.parametrize("R", [2000, 4000])
+def test_reuse_entry_on_long_windows_falls_back_to_per_window(R):
+    """ADVICE r04 (high): long-window models (segmented first stage, MuralSnvModel::longwin) set `split`, so the reuse entry's
+    support test used to say yes and the launch then refused the pooled tile ('reuse: pooled tile too large') on every dense
+    shard.  mural_snv_reuse_supported now evaluates every geometry condition the launches require: the Python entry must fall
+    back to the per-window kernels (used == 0) with identical rows, and the C entry must refuse up front."""
+    import ctypes as C
+    from mural_amd import _lib
+    from mural_amd.data import PackedGenome
+    model, _ = _pair(7, R, seed=310 + R)
+    assert model._fused_ok()
+    lib = _lib.lib()
+    assert not lib.mural_snv_reuse_supported(model._get_handle())
+    rng = np.random.default_rng(R)
+    n = 12_000
+    genome = PackedGenome.from_sequence(_genome(rng, n, iupac=False), "cuda")
+    pos = torch.arange(100, 100 + 1500, device="cuda")                # dense: 1500 sites on 1500 bases, >= REUSE_MIN_SITES
+    strand = (pos & 1).to(torch.uint8)
+    with torch.no_grad():
+        want = model.forward_packed(genome, pos, strand, local_radius=7, local_order=3)
+        got, used = model.forward_packed_reuse(genome, pos, strand, local_radius=7, local_order=3, min_density=0.1,
+                                               return_reuse_count=True)
+    assert used == 0 and torch.equal(got, want)
+    g = genome.as_struct(pos.device)
+    out = torch.empty((pos.shape[0], 4), device="cuda")
+    ws = torch.empty(1 << 20, dtype=torch.uint8, device="cuda")
+    rc = lib.mural_snv_forward_packed_reuse(model._get_handle(), C.byref(g), pos.data_ptr(), strand.data_ptr(), pos.shape[0], 3, 100, 1599,
+                                            7, 3, out.data_ptr(), ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(pos.device))
+    assert rc != 0 and b"reuse" in lib.mural_last_error()

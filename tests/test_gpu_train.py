@@ -57,6 +57,96 @@ def test_train_step_matches_reference(tag, conv, monkeypatch):
         assert np.abs(b.cpu().numpy() - fx["b::" + k]).max() <= 2e-5, k
 
 
+@pytest.mark.parametrize("tag", ["T", "S"])
+def test_train_step_through_the_bench_composition_matches_reference(tag):
+    """the step `bench.py` times (SymbolWindows input + mural_amd.train.CrossEntropySum +
+    mural_amd.train.clip_grad_norm_ over the flat gradient buffer, training.py:424-436) against the reference's own G7 fixture --
+    loss, every gradient, the total gradient norm the clip returns, and the running statistics, at the fixture's 2e-4."""
+    from mural_amd.data import SymbolWindows
+    from mural_amd.train import CrossEntropySum, clip_grad_norm_
+    fx = U.load(f"snv_train_{tag}.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    for m in model.modules():            # the fixture was generated with every dropout rate at 0
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    model = model.cuda().train()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    codes = np.ascontiguousarray(fx["codes"]).astype(np.uint8)          # base codes 0..3 = MURAL_SYM_A..T: one symbol per column
+    x = SymbolWindows(torch.from_numpy(codes).cuda())
+    preds = model((torch.zeros(len(cat), 1, device="cuda"), cat), x)
+    assert np.abs(preds.detach().cpu().numpy() - fx["preds"]).max() <= 2e-4
+    loss = CrossEntropySum()(preds, torch.from_numpy(fx["y"]).cuda())
+    model.zero_grad()
+    loss.backward()
+    assert abs(loss.item() - float(fx["loss"])) <= 1e-4 * abs(float(fx["loss"]))
+    grads = {k: p.grad.clone() for k, p in model.named_parameters() if p.numel()}
+    gnorm = clip_grad_norm_(model, 1e9)                                 # the flat-buffer route: must take it, not torch's fallback
+    lay = model._train_layout
+    assert lay.last_flat is not None and all(p.grad.data_ptr() == lay.last_flat.data_ptr() + 4 * o for p, o in zip(lay.plist, lay.poffs))
+    assert abs(float(gnorm) - float(fx["gnorm"])) <= 2e-4 * float(fx["gnorm"])
+    worst = ("", 0.0)
+    for k, g in grads.items():
+        if ".layer." in k:
+            continue
+        want = fx["g::" + k]
+        scale = float(np.abs(want).max()) + 1e-2
+        err = float(np.abs(g.cpu().numpy() - want).max()) / scale
+        if err > worst[1]:
+            worst = (k, err)
+        assert torch.equal(g, dict(model.named_parameters())[k].grad)   # max_norm far above the norm: the clip leaves them alone
+    assert worst[1] <= 2e-4, f"gradient of {worst[0]} off by {worst[1]:.2e} (relative to its max + 1e-2)"
+    for k, b in model.named_buffers():
+        if ".layer." in k or k.endswith("num_batches_tracked") or b.numel() == 0:
+            continue
+        assert np.abs(b.cpu().numpy() - fx["b::" + k]).max() <= 2e-5, k
+    # and the clip proper: a max_norm below the norm scales every gradient by max_norm / (norm + 1e-6) (torch's rule, training.py:430)
+    g0 = {k: p.grad.clone() for k, p in model.named_parameters() if p.numel()}
+    total = clip_grad_norm_(model, float(gnorm) / 4)
+    f = float(gnorm) / 4 / (float(total) + 1e-6)
+    for k, p in model.named_parameters():
+        if p.numel():
+            assert torch.allclose(p.grad, g0[k] * f, rtol=1e-6, atol=0)
+
+
+def test_direct_gradient_mode_steps_aside_for_hooks_and_kept_gradients():
+    """the step sets p.grad itself (model/train_step.py).  A parameter hook must still fire (the step then routes the
+    gradients through autograd), gradients a caller keeps across zero_grad(set_to_none=True) must not be rewritten by the next
+    backward, and a second backward over the same graph must fail with a clear message."""
+    fx = U.load("snv_train_T.npz")
+    model, _ = product_from_hp(fx["hp"])
+    model.load_state_dict(U.snv_state_for(fx, U.snv_oracle_from_hp(fx["hp"])))
+    model = model.cuda().train()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"]).cuda()
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    cont = torch.zeros(len(cat), 1, device="cuda")
+    torch.manual_seed(3)
+    crit(model((cont, cat), x), y).backward()
+    kept = {k: p.grad for k, p in model.named_parameters() if p.numel()}           # the caller keeps last step's gradients
+    snap = {k: g.clone() for k, g in kept.items()}
+    model.zero_grad(set_to_none=True)
+    torch.manual_seed(4)
+    out = model((cont, cat), x)
+    loss = crit(out, y)
+    loss.backward(retain_graph=True)
+    assert all(torch.equal(kept[k], snap[k]) for k in kept), "the next backward rewrote gradients the caller still holds"
+    assert any(not torch.equal(p.grad, snap[k]) for k, p in model.named_parameters() if p.numel())
+    with pytest.raises(RuntimeError, match="ONE backward"):
+        loss.backward()
+    # a tensor hook on one parameter: the whole step goes through autograd's accumulation and the hook sees its gradient
+    model.zero_grad(set_to_none=True)
+    seen = []
+    w = model.conv1_2[1].weight
+    h = w.register_hook(lambda g: seen.append(g.clone()))
+    torch.manual_seed(4)
+    crit(model((cont, cat), x), y).backward()
+    h.remove()
+    assert len(seen) == 1 and torch.equal(seen[0], w.grad)
+
+
 def test_train_step_at_batch_256_matches_reference():
     """G7 at B = 256 (dropouts 0): the reference's own loss, gradients and running statistics for a batch between the flip-free
     32-row fixture (2e-4) and the float64-judged batch of 4096 (3e-2).  At 8 x the max-pool windows and ReLU inputs no weight seed

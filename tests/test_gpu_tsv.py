@@ -121,8 +121,9 @@ def test_tsv_sink_with_device_shards_equals_pandas(tmp_path, calibrated, monkeyp
     assert sink.writer_seconds()["bytes"] == len(got) - len(got.split(b"\n", 1)[0]) - 1
 
 
+@pytest.mark.parametrize("long_name", [False, True])
 @pytest.mark.parametrize("world", [2, 8])
-def test_part_file_slices_of_device_shards_concatenate_to_the_single_writer_table(tmp_path, world, monkeypatch):
+def test_part_file_slices_of_device_shards_concatenate_to_the_single_writer_table(tmp_path, world, long_name, monkeypatch):
     """The part-file mode on the device path: rank r of `world` sorts each shard and formats only its slice of the sorted rows
     (TsvSink(parts=(r, world)) without a process group writes just that rank's part file, with its per-shard byte counts).  The
     slices of all ranks, strung together shard by shard in rank order behind the header -- what rank 0 does at close() under
@@ -133,19 +134,25 @@ def test_part_file_slices_of_device_shards_concatenate_to_the_single_writer_tabl
     r = _random_rows(rng, n)
     prob = rng.random((n, 4)).astype(np.float32)
     prob /= prob.sum(1, keepdims=True)
-    names = sorted(set(r["chrom"].tolist()))
+    if long_name:      # a later chromosome name > 24 bytes longer than the staging allows replaces the writer thread
+        r["chrom"] = np.array([c if c != "chr2" else "chr2_" + "scaffold" * 8 for c in r["chrom"]], object)      # mid-run; the
+    names = sorted(set(r["chrom"].tolist()))                                          # earlier shards' byte counts must survive it
 
     def feed(sink):
+        writers = []                   # (references kept: ids stay unique)
         for nm in names:
+            writers.append(sink._writer)
             sel = r["chrom"] == nm
             rows = torch.from_numpy(np.concatenate([prob[sel], np.zeros((sel.sum(), 1), np.float32)], axis=1)).cuda()
             sink({"chrom": nm, "start": torch.from_numpy(r["start"][sel]).cuda(), "end": torch.from_numpy(r["end"][sel]).cuda(),
                   "strand": torch.from_numpy((r["strand"][sel] == "-").astype(np.uint8)).cuda(),
                   "label": torch.from_numpy(r["label"][sel]).cuda(), "prob": rows, "n_class": 4})
+        writers.append(sink._writer)
         sink.close()
+        return len({id(w) for w in writers if w is not None})
 
     single = TsvSink(tmp_path / "single.tsv")
-    feed(single)
+    assert feed(single) == (2 if long_name else 1)
     want = (tmp_path / "single.tsv").read_bytes()
     parts, counts = [], []
     for rank in range(world):

@@ -174,3 +174,24 @@ def test_tsv_sink_calibration_on_host_rows(tmp_path):
     sink.close()
     want = _pandas_table(sh["chrom"], start, start + 1, sh["strand"], sh["label"], poisson_calibrate(dirichlet_calibrate(p, w)))
     assert (tmp_path / "c.tsv").read_bytes() == want
+
+
+def test_rows_calibrated_on_the_device_are_not_calibrated_again(tmp_path):
+    """HipShardForward(model_type='indel') now applies the Poisson calibration by default and marks its shards
+    `calibrated`; a sink or write_predictions that is asked to calibrate such rows refuses (it used to calibrate twice, silently)."""
+    rng = np.random.default_rng(3)
+    r = _random_rows(rng, 50)
+    res = dict(r, calibrated=True)
+    with pytest.raises(ValueError, match="calibrated already"):
+        write_predictions(res, tmp_path / "a.tsv", poisson=True)
+    with pytest.raises(ValueError, match="calibrated already"):
+        write_predictions(res, tmp_path / "a.tsv", dirichlet_weights=np.hstack([np.eye(4), np.zeros((4, 1))]))
+    assert write_predictions(res, tmp_path / "a.tsv") == 50                      # nothing asked: written as they are
+    assert write_predictions(dict(r), tmp_path / "b.tsv", poisson=True) == 50    # uncalibrated rows: calibrated here, as before
+    sink = TsvSink(tmp_path / "c.tsv", poisson=True)
+    sel = r["chrom"] == "chr1"
+    shard = {"chrom": "chr1", "start": r["start"][sel], "end": r["end"][sel], "strand": (r["strand"][sel] == "-").astype(np.uint8),
+             "label": r["label"][sel], "prob": r["prob"][sel], "n_class": 4, "calibrated": True}
+    with pytest.raises(ValueError, match="calibrated already"):
+        sink(shard)
+    sink.abort()
