@@ -95,6 +95,22 @@ struct Stage1Args {               // snv_stage1_kernel: window decode + first co
 
 // training-mode first layer of ONE tower (snv_stage1.hip: first_train_kernel)
 constexpr int FIRST_TRAIN_MAXGRID = 256;
+// The BatchNorm-backward apply of the layer BEHIND the first layer folded into the first layer's backward (channel-last form only):
+// the pooled gradient is not read but made per element, dy = relu'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)) + add1
+// + add2 (the arithmetic of bn_bwd_apply_cl_kernel, conv32_cl.hip), from that BatchNorm's input gradient dz, its saved input x (= this
+// layer's output), its completed sums acc and up to two residual gradients; workgroup 0 writes its dgamma / dbeta.  dz == nullptr: none.
+struct FirstFold {
+  const float* dz;
+  const float* x;
+  const float* add1;
+  const float* add2;
+  const float* state;             // scale | beta | mean | invstd
+  const float* gamma;
+  const double* acc;              // [MURAL_BN_SLOTS][2][32]: sum(dz), sum(dz * xhat)
+  double n;                       // elements per channel
+  float* dgamma;
+  float* dbeta;
+};
 struct FirstTrainArgs {
   Stage1Tower tw;
   int Lwin, cw, wave_bytes;
@@ -107,7 +123,11 @@ struct FirstTrainArgs {
   float* dpart;                   // backward: [grid][SNV_LUTBLK] per-workgroup gradient tables
   int cl;                         // 1: y / dy are channel-last [B][L2][32] (the composed training step), 0: [B][32][L2]
   double* stat;                   // forward, cl only: [MURAL_BN_SLOTS][2][32] batch sums of relu(y), relu(y)^2 (nullptr: none)
+  FirstFold fold;                 // backward, cl only
+  int dbg;                        // timing experiments (MURAL_DEBUG_FIRST): 1 no LDS atomics, 2 no gradient / arg-max loads, 4 no index reads
+  unsigned long long* stamps;     // diagnostic (mural_debug_first_set_stamps): [workgroup][8] wall-clock ticks (100 MHz) of wave 0's phases
 };
+extern unsigned long long* g_first_stamps;
 int first_train_grid(int64_t B);
 bool first_train_supported(int C, int pk);
 int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream);

@@ -516,10 +516,71 @@ __device__ __forceinline__ void pooled_scatter(const Stage1Tower& g, int lane, f
   }
 }
 
+#define FT_STAMP(K) do { if (a.stamps && tid == 0) a.stamps[8 * blockIdx.x + (K)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+
+
+// The same scatter for the channel-last gradient of the composed step, one CHANNEL per lane: lane = (parity of the pooled column,
+// channel).  The 32 lanes of a half-wave add into 32 different LDS banks (table rows are 32 floats), and a wave's gradient load is 256
+// contiguous bytes.  The form above -- lane = (column, four channels) -- puts the eight columns of a wave instruction on the same
+// eight banks: eight serial read-modify-writes per bank, 75 of the launch's 100 us at batch 4096 (tools/phase_stamps_first.py).
+template <int SLOT>
+__device__ __forceinline__ void pooled_scatter_cl(const Stage1Tower& g, int lane, float* acc, const uint8_t* cb0, const uint8_t* kw,
+                                                  const float* __restrict__ dy /* [L2][32] */, const uint8_t* __restrict__ arg /* [L2][32] */,
+                                                  int dbg) {
+  float* tapA = acc + SNV_LUT;
+  float* b0A = tapA + SNV_TAPS;
+  const uint8_t* cb = cb0 + g.col0;
+  const int c = lane & 31, h = lane >> 5;
+  const int npair = (g.L2 + 1) >> 1;
+  float bsum = 0.f;
+  // the row through range-checked descriptors (a column pair behind the row reads as zero), one lane offset, the pair in the immediate
+  const __amdgpu_buffer_rsrc_t gd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(dy), 0, (dbg & 2) ? 0 : g.L2 * 128, 0x00020000);
+  const __amdgpu_buffer_rsrc_t ad = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(arg), 0, (dbg & 2) ? 0 : g.L2 * 32, 0x00020000);
+  constexpr int NT = 16;                       // column pairs in flight per lane (a row of 134 pooled columns: five round trips)
+  for (int p0 = 0; p0 < npair; p0 += NT) {
+    float gv[NT];
+    uint32_t awv[NT];
+    const uint32_t go = 4u * (uint32_t)lane + 256u * (uint32_t)p0, ao = (uint32_t)lane + 64u * (uint32_t)p0;
+    int hh = h;                                // opaque per batch: the per-pair address pieces (three per pair) are made here, not hoisted
+    asm volatile("" : "+v"(hh));               // out of the batch loop into 48 registers
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      awv[u] = __builtin_amdgcn_raw_buffer_load_b8(ad, ao + 64u * u, 0, 0);
+      gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gd, go + 256u * u, 0, 0));
+    }
+#pragma unroll
+    for (int u = 0; u < NT; ++u) {
+      const int j2 = 2 * (p0 + u) + hh;
+      if (j2 < g.L2) {
+        const float gq = gv[u];
+        const int w = (int)(awv[u] & 0xFFu);
+        const uint32_t idx = (dbg & 4) ? (uint32_t)(j2 & 63) : kw[j2 * SLOT + w];
+        bsum += gq;
+        if (dbg & 1) continue;
+        // one add on the common path; a 3-mer with a symbol outside ACGTN (idx 255) goes to the three per-tap tables instead
+        const int j = j2 * g.ps - g.pp + w;
+        const uint32_t sl = (j == 0) ? (uint32_t)SYM_PAD : cb[j];
+        const bool tab = idx != 255u;
+        atomicAdd(tab ? &acc[idx * 32u + c] : &tapA[(0 * N_SYM + sl) * 32 + c], gq);
+        if (!tab) {
+          const uint32_t sc = cb[j + 1];
+          const uint32_t sr = (j == g.L1 - 1) ? (uint32_t)SYM_PAD : cb[j + 2];
+          atomicAdd(&tapA[(1 * N_SYM + sc) * 32 + c], gq);
+          atomicAdd(&tapA[(2 * N_SYM + sr) * 32 + c], gq);
+        }
+      }
+      if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);      // (left alone the scheduler hoists all sixteen index reads: spills)
+    }
+  }
+  bsum += __shfl_xor(bsum, 32);
+  if (lane < 32) atomicAdd(&b0A[c], bsum);
+}
+
 template <int SLOT, bool BWD>
 __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrainArgs a) {
   extern __shared__ __attribute__((aligned(16))) float s1mem[];
   const int tid = threadIdx.x;
+  FT_STAMP(0);
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* blk = s1mem;                         // forward: lut | taps | bias; backward: their gradient accumulators
@@ -528,6 +589,7 @@ __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrai
   for (int i = tid * 4; i < SNV_LUTBLK; i += S1_THREADS * 4)
     *reinterpret_cast<f32x4*>(blk + i) = BWD ? f32x4{0.f, 0.f, 0.f, 0.f} : s1_ld4(a.lutblk + i);
   __syncthreads();
+  FT_STAMP(1);
   const Stage1Tower g = a.tw;
   const int Lwin = a.Lwin;
   f32x4 sum1 = f32x4{0.f, 0.f, 0.f, 0.f}, sum2 = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -546,12 +608,15 @@ __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrai
         if (jj0 + 64 * u < Lwin + 2) cb[jj0 + 64 * u] = v[u];
     }
     wave_lds_fence();
+    FT_STAMP(2);
     build_kwin<SLOT>(g, lane, cb, kw);
     wave_lds_fence();
+    FT_STAMP(3);
     const size_t o = (size_t)row * 32 * g.L2;
     if (BWD) pooled_scatter<SLOT>(g, lane, blk, cb, kw, a.dy + o, a.arg + o, a.cl);
     else pooled_lookup_train<SLOT>(g, lane, blk, cb, kw, a.y + o, a.arg + o, a.cl, sum1, sum2);
     wave_lds_fence();
+    FT_STAMP(4);
   }
   if (!BWD && a.stat) {                       // 16 waves -> 64 sums through LDS -> one double atomic per sum and workgroup
     __syncthreads();                          // every wave is done with the tables: their LDS carries the partial sums
@@ -579,10 +644,187 @@ __global__ __launch_bounds__(S1_THREADS) void first_train_kernel(const FirstTrai
   }
   if (BWD) {                                  // one partial block per workgroup; first_grad_fold_kernel sums them in order
     __syncthreads();
+    FT_STAMP(5);
     float* dst = a.dpart + (size_t)blockIdx.x * SNV_LUTBLK;
     for (int i = tid * 4; i < SNV_LUTBLK; i += S1_THREADS * 4) *reinterpret_cast<f32x4*>(dst + i) = s1_ld4(blk + i);
   }
+  FT_STAMP(6);
 }
+
+
+// ---- backward of the channel-last form (the composed training step) ---------------------------------------------------------------
+// The scatter above is bound by the LDS float atomics themselves: a ds_add_f32 wave instruction occupies the LDS pipe for ~128
+// cycles whatever its bank pattern (tools/phase_stamps_first.py with MURAL_DEBUG_FIRST: 100 -> 22 us per batch of 4096 without the
+// adds, the same 100 us with one channel per lane, i.e. conflict-free) -- 4288 adds per row is 75 us of a 100 us launch.  This kernel
+// has none on its common path.  The 3-mer table is a sum of three per-tap symbol tables (lut[l,m,r] = bias + tap0[l] + tap1[m] +
+// tap2[r]; first_param_grad_kernel folds d lut back into d taps anyway), and a tap sees one of FOUR common symbols: a lane owns one
+// channel and keeps d tap[t][A C G T] of it in twelve registers; a pooled gradient goes to the three registers its window position's
+// symbols select (compare / select / add, no memory).  Symbols outside A C G T (N, IUPAC codes, the zero padding) take an LDS atomic
+// on a shared per-tap table.  Partial tables meet per workgroup in a fixed order (bitwise reproducible; the atomics were not).
+// FOLD: the pooled gradient is made from the BatchNorm-backward apply of the layer behind (FirstFold, snv.h) instead of read: four
+// 4-byte loads per element against the one of a gradient tensor that a pass of its own (four reads, one write) would have had to make.
+constexpr int FB_ROWS = 13;                  // twelve per-tap sums + the bias gradient
+template <bool FOLD>
+__global__ __launch_bounds__(S1_THREADS) void first_bwd_cl_kernel(const FirstTrainArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s1mem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  FT_STAMP(0);
+  float* rare = s1mem;                                          // [3][N_SYM][32]
+  float* red = rare + SNV_TAPS;                                 // [S1_WAVES][FB_ROWS][32]
+  uint8_t* cb0 = reinterpret_cast<uint8_t*>(red + S1_WAVES * FB_ROWS * 32) + (size_t)wave * a.cw;
+  for (int i = tid; i < SNV_TAPS; i += S1_THREADS) rare[i] = 0.f;
+  const int c = lane & 31, h = lane >> 5;
+  float k0 = 0.f, m1 = 0.f, m2 = 0.f, mu = 0.f, is = 0.f;      // FOLD: constants of this lane's channel
+  if constexpr (FOLD) {
+    float* fc = red;                                            // [5][32], read before the partial sums take the region
+    if (tid < 32) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < MURAL_BN_SLOTS; ++k) {
+        s1 += a.fold.acc[((size_t)k * 2 + 0) * 32 + tid];
+        s2 += a.fold.acc[((size_t)k * 2 + 1) * 32 + tid];
+      }
+      fc[tid] = a.fold.gamma[tid] * a.fold.state[3 * 32 + tid];
+      fc[32 + tid] = (float)(s1 / a.fold.n);
+      fc[64 + tid] = (float)(s2 / a.fold.n);
+      fc[96 + tid] = a.fold.state[2 * 32 + tid];
+      fc[128 + tid] = a.fold.state[3 * 32 + tid];
+      if (blockIdx.x == 0) {
+        a.fold.dgamma[tid] = (float)s2;
+        a.fold.dbeta[tid] = (float)s1;
+      }
+    }
+    __syncthreads();
+    k0 = fc[c]; m1 = fc[32 + c]; m2 = fc[64 + c]; mu = fc[96 + c]; is = fc[128 + c];
+  }
+  __syncthreads();
+  FT_STAMP(1);
+  const Stage1Tower g = a.tw;
+  const int Lwin = a.Lwin;
+  const int npair = (g.L2 + 1) >> 1;
+  const uint8_t* cb = cb0 + g.col0;                             // cb[j + 1] is the symbol of tower column j
+  float acc[3][4];
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[t][q] = 0.f;
+  float bsum = 0.f;
+  for (int64_t row = (int64_t)blockIdx.x * S1_WAVES + wave; row < a.B; row += (int64_t)gridDim.x * S1_WAVES) {
+    const uint8_t* src = a.sym + row * Lwin;
+    constexpr int UN = 8;                     // byte loads in flight per lane (one wave loads the whole row)
+    for (int jj0 = lane; jj0 < Lwin + 2; jj0 += 64 * UN) {
+      uint8_t v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        const int j = jj0 + 64 * u - 1;
+        v[u] = (j >= 0 && j < Lwin) ? src[j] : (uint8_t)SYM_PAD;
+      }
+#pragma unroll
+      for (int u = 0; u < UN; ++u)
+        if (jj0 + 64 * u < Lwin + 2) cb0[jj0 + 64 * u] = v[u];
+    }
+    wave_lds_fence();
+    FT_STAMP(2);
+    const size_t o = (size_t)row * 32 * g.L2;
+    // the row through range-checked descriptors (a column pair behind the row reads as zero), one lane offset, the pair in the immediate
+    const int gbytes = g.L2 * 128;
+    const __amdgpu_buffer_rsrc_t gd = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>((FOLD ? a.fold.dz : a.dy) + o), 0, gbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ad = __builtin_amdgcn_make_buffer_rsrc(a.arg + o, 0, g.L2 * 32, 0x00020000);
+    // (an absent tensor: a descriptor of zero bytes over any valid address -- every load through it returns 0)
+    auto opt = [&](const float* p) __attribute__((always_inline)) {
+      return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p ? p + o : a.dy), 0, p ? gbytes : 0, 0x00020000);
+    };
+    const __amdgpu_buffer_rsrc_t xd = opt(FOLD ? a.fold.x : nullptr), r1d = opt(FOLD ? a.fold.add1 : nullptr), r2d = opt(FOLD ? a.fold.add2 : nullptr);
+    constexpr int NT = FOLD ? 8 : 16;         // column pairs in flight per lane (a row of 134 pooled columns: five / nine round trips)
+    for (int p0 = 0; p0 < npair; p0 += NT) {
+      float gv[NT];
+      uint32_t awv[NT];
+      const uint32_t go = 4u * (uint32_t)lane + 256u * (uint32_t)p0, ao = (uint32_t)lane + 64u * (uint32_t)p0;
+      int hh = h;                             // opaque per batch: the per-pair address pieces are made here, not hoisted out of the
+      asm volatile("" : "+v"(hh));            // batch loop into 48 registers
+      if constexpr (FOLD) {
+        float xv[NT], r1[NT], r2[NT];
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          awv[u] = __builtin_amdgcn_raw_buffer_load_b8(ad, ao + 64u * u, 0, 0);
+          gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gd, go + 256u * u, 0, 0));
+          xv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xd, go + 256u * u, 0, 0));
+          r1[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r1d, go + 256u * u, 0, 0));
+          r2[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r2d, go + 256u * u, 0, 0));
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {        // (a pair behind the row: x = 0 is masked like every x <= 0, the residuals read 0)
+          const float xh = (xv[u] - mu) * is;
+          const float gq = k0 * ((gv[u] - m1) - xh * m2);
+          gv[u] = ((xv[u] > 0.f ? gq : 0.f) + r1[u]) + r2[u];
+        }
+      } else {
+#pragma unroll
+        for (int u = 0; u < NT; ++u) {
+          awv[u] = __builtin_amdgcn_raw_buffer_load_b8(ad, ao + 64u * u, 0, 0);
+          gv[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(gd, go + 256u * u, 0, 0));
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NT; ++u) {
+        const int j2 = 2 * (p0 + u) + hh;
+        // a pair behind the row (odd row length) loaded zeros: it adds 0 at the last column's symbols -- in-range table addresses
+        const float gq = j2 < g.L2 ? gv[u] : 0.f;
+        const int j = (j2 < g.L2 ? j2 : g.L2 - 1) * g.ps - g.pp + (int)(awv[u] & 0xFFu);
+        uint32_t sy[3] = {cb[j], cb[j + 1], cb[j + 2]};
+        sy[0] = j == 0 ? (uint32_t)SYM_PAD : sy[0];
+        sy[2] = j == g.L1 - 1 ? (uint32_t)SYM_PAD : sy[2];
+        bsum += gq;
+#pragma unroll
+        for (int t = 0; t < 3; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) acc[t][q] += sy[t] == (uint32_t)q ? gq : 0.f;
+        if ((sy[0] | sy[1] | sy[2]) > 3u) {                     // rare: N / IUPAC / padding at one of the three taps
+#pragma unroll
+          for (int t = 0; t < 3; ++t)
+            if (sy[t] > 3u) atomicAdd(&rare[(t * N_SYM + sy[t]) * 32 + c], gq);
+        }
+        if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    wave_lds_fence();
+    FT_STAMP(4);
+  }
+  // the two halves of a wave meet through a shuffle, the sixteen waves through LDS in a fixed order
+#pragma unroll
+  for (int t = 0; t < 3; ++t)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float v = acc[t][q] + __shfl_xor(acc[t][q], 32);
+      if (lane < 32) red[(wave * FB_ROWS + 4 * t + q) * 32 + c] = v;
+    }
+  {
+    const float v = bsum + __shfl_xor(bsum, 32);
+    if (lane < 32) red[(wave * FB_ROWS + 12) * 32 + c] = v;
+  }
+  __syncthreads();
+  FT_STAMP(5);
+  // one partial block per workgroup in the layout of the forward's tables (lut | taps | bias): the 3-mer part stays zero
+  float* dst = a.dpart + (size_t)blockIdx.x * SNV_LUTBLK;
+  for (int i = tid * 4; i < SNV_LUT; i += S1_THREADS * 4) *reinterpret_cast<f32x4*>(dst + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int i = tid; i < SNV_TAPS + 32; i += S1_THREADS) {
+    const int t = i / (N_SYM * 32), r = i - t * N_SYM * 32, sym = r >> 5, cc = r & 31;
+    const int k = i >= SNV_TAPS ? 12 : (sym < 4 ? 4 * t + sym : -1);
+    float v = i < SNV_TAPS ? rare[i] : 0.f;
+    if (k >= 0) {
+      const int ch = i >= SNV_TAPS ? i - SNV_TAPS : cc;
+#pragma unroll
+      for (int w = 0; w < S1_WAVES; ++w) v += red[(w * FB_ROWS + k) * 32 + ch];
+    }
+    dst[SNV_LUT + i] = v;
+  }
+  FT_STAMP(6);
+}
+
+#undef FT_STAMP
+
+unsigned long long* g_first_stamps = nullptr;      // diagnostic (mural_debug_first_set_stamps)
 
 int first_train_grid(int64_t B) {
   const int64_t want = (B + S1_WAVES - 1) / S1_WAVES;
@@ -600,10 +842,25 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
   const size_t lds = (size_t)SNV_LUTBLK * 4 + (size_t)S1_WAVES * a.wave_bytes;
   MURAL_REQUIRE(lds <= 160 * 1024, "first layer: window of %d columns does not fit the LDS working set", a.Lwin);
   using KernelFn = void (*)(const FirstTrainArgs);
+  MURAL_REQUIRE(!a.fold.dz || (bwd && a.cl), "first layer: the folded BatchNorm-backward apply belongs to the channel-last backward");
+  if (bwd && a.cl && (a.fold.dz || !getenv("MURAL_DEBUG_FIRST_SCATTER"))) {      // the composed step's backward: register sums, no kmer windows in LDS
+    const size_t lds_b = (size_t)(SNV_TAPS + S1_WAVES * FB_ROWS * 32) * 4 + (size_t)S1_WAVES * a.cw;
+    MURAL_REQUIRE(lds_b <= 160 * 1024, "first layer: window of %d columns does not fit the LDS working set", a.Lwin);
+    static DynLdsOnce big_b;
+    if (int rc = big_b.ensure(&first_bwd_cl_kernel<false>, &first_bwd_cl_kernel<true>)) return rc;
+    a.stamps = g_first_stamps;
+    if (a.fold.dz) hipLaunchKernelGGL(first_bwd_cl_kernel<true>, dim3(first_train_grid(a.B)), dim3(S1_THREADS), lds_b, stream, a);
+    else hipLaunchKernelGGL(first_bwd_cl_kernel<false>, dim3(first_train_grid(a.B)), dim3(S1_THREADS), lds_b, stream, a);
+    MURAL_HIP_CHECK(hipGetLastError());
+    return MURAL_OK;
+  }
   KernelFn fn = slot == 4 ? (bwd ? first_train_kernel<4, true> : first_train_kernel<4, false>)
                           : (bwd ? first_train_kernel<16, true> : first_train_kernel<16, false>);
   static DynLdsOnce big_lds[4];                             // once per instantiation and device (never inside a graph capture)
   if (int rc = big_lds[(slot == 4 ? 0 : 2) + (bwd ? 1 : 0)].ensure(fn)) return rc;
+  a.stamps = g_first_stamps;
+  static const int dbg = getenv("MURAL_DEBUG_FIRST") ? atoi(getenv("MURAL_DEBUG_FIRST")) : 0;
+  a.dbg = dbg;
   hipLaunchKernelGGL(fn, dim3(first_train_grid(a.B)), dim3(S1_THREADS), lds, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
@@ -640,3 +897,9 @@ int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStr
 }
 
 }  // namespace mural
+
+// diagnostic: per-workgroup wall-clock stamps of the training-mode first-layer kernels' phases (tools/phase_stamps_first.py); NULL: off
+extern "C" int mural_debug_first_set_stamps(void* dev_ptr) {
+  mural::g_first_stamps = static_cast<unsigned long long*>(dev_ptr);
+  return MURAL_OK;
+}

@@ -50,7 +50,7 @@ int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1
                        unsigned long long* counts, float* tab, float* y, void* arg, double* stat, hipStream_t stream);
 int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp,
                        const float* tab, const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
-                       hipStream_t stream);
+                       const FirstFold* fold, hipStream_t stream);
 // conv32_mfma.hip
 int train_reduce_parts(const float* const* part, const int* nrow, float* const* dW, float* const* db, int njobs, hipStream_t stream);
 // train_ops.hip
@@ -413,9 +413,13 @@ int conv_b_fold(Ctx& c, const float* dy, const float* x, int L, const float* sta
   return MURAL_OK;
 }
 
+// defer != nullptr: the caller's next kernel makes the stage's input gradient itself (the first layer's backward, FirstFold) -- on the
+// folded path the stage's last BatchNorm-backward apply is then described in *defer instead of launched (defer->dz stays nullptr where
+// the apply did run and d_in holds the gradient)
 int stage_b(Ctx& c, const MuralResBlock* rb, const MuralResBlock* grb, const float* x_in, int L, StageBufs& s, const float* d_out,
-            float* d_in, float* const* tmp) {
+            float* d_in, float* const* tmp, FirstFold* defer = nullptr) {
   float *dz = tmp[0], *ga = tmp[1], *gb = tmp[2];
+  if (defer) defer->dz = nullptr;
   if (use_wave_conv(L, 0, false, 0) && !getenv("MURAL_TRAIN_NO_FOLD")) {
     // Three of the four BatchNorm-backward applies of the stage never run as passes of their own: the conv backward of the layer in
     // front makes its dy from (dz, saved input, sums) of the layer behind while it stages it (conv32_wave.hip, FOLD) -- a read of two
@@ -435,6 +439,11 @@ int stage_b(Ctx& c, const MuralResBlock* rb, const MuralResBlock* grb, const flo
     // layer 0: dy = d h = apply of layer 1
     ConvBwdFold f0{A, s.t[0], s.state[1], rb[0].bn2.weight, s.acc_b[1], 1, gbn(grb[0].bn2).first, gbn(grb[0].bn2).second, nullptr, nullptr};
     if (int rc = conv_b_fold(c, nullptr, x_in, L, s.state[0], rb[0].bn1, rb[0].conv1, s.acc_b[0], grb[0].conv1, Bz, f0)) return rc;
+    if (defer && !getenv("MURAL_TRAIN_NO_FIRST_FOLD")) {
+      *defer = FirstFold{Bz, x_in, gb, d_out, s.state[0], rb[0].bn1.weight, s.acc_b[0], (double)c.P->B * L, const_cast<float*>(grb[0].bn1.weight),
+                         const_cast<float*>(grb[0].bn1.bias)};
+      return MURAL_OK;
+    }
     return cl_bn_bwd_apply(Bz, x_in, (int64_t)c.P->B * L, 1, s.state[0], rb[0].bn1.weight, s.acc_b[0], gb, d_out, d_in,
                            const_cast<float*>(grb[0].bn1.weight), const_cast<float*>(grb[0].bn1.bias), (hipStream_t)c.stream);
   }
@@ -489,10 +498,13 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
                         g1)) return rc;                                            // g1 = d p2
   if (int rc = cl_maxpool_bwd(g1, b.arg2, B, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, st)) return rc;
   float* d_in2 = b.s2.t[3];
-  if (int rc = stage_b(c, T.rbs1, G.rbs1, b.x0, g.L[0], b.s2, g3, d_in2, tmp)) return rc;
-  return train_first_bwd_cl(d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight, P.first_scratch[t],
-                            const_cast<float*>(G.conv_in.weight), const_cast<float*>(G.conv_in.bias), const_cast<float*>(G.bn_in.weight),
-                            const_cast<float*>(G.bn_in.bias), st);
+  // the first ResBlock stage's last BatchNorm-backward apply (four reads and a write of the stage tensor) never runs as a pass of its own:
+  // the first layer's backward makes its pooled gradient from the apply's operands element by element (FirstFold, snv_stage1.hip)
+  FirstFold fold{};
+  if (int rc = stage_b(c, T.rbs1, G.rbs1, b.x0, g.L[0], b.s2, g3, d_in2, tmp, &fold)) return rc;
+  return train_first_bwd_cl(fold.dz ? nullptr : d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight,
+                            P.first_scratch[t], const_cast<float*>(G.conv_in.weight), const_cast<float*>(G.conv_in.bias),
+                            const_cast<float*>(G.bn_in.weight), const_cast<float*>(G.bn_in.bias), fold.dz ? &fold : nullptr, st);
 }
 
 int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop, const uint64_t* seeds, const uint64_t* seed_dev) {

@@ -6,6 +6,7 @@
 // Correctness-first kernels (vector ALU, atomics for cross-workgroup sums); the conv forward / input-gradient reuse the
 // generic conv1d kernel.  The Python autograd glue lives in mural_amd/model/train_ops.py.
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 #include "conv1d.h"
@@ -639,7 +640,7 @@ __global__ __launch_bounds__(256) void first_pool_bwd_kernel(const float* __rest
 // ordered sum of the per-workgroup gradient tables of first_train_kernel<.., true>: 64 columns x 16 row slices per workgroup (a
 // slice walks every 16th table with 8 loads in flight, the slices meet in LDS in a fixed order) -- one thread per column summing
 // 256 tables serially was 64 dependent rounds on 22 workgroups: 46 us at the tail of the backward
-__global__ __launch_bounds__(1024) void first_part_reduce_kernel(const float* __restrict__ part, int nblk, int n,
+__global__ __launch_bounds__(1024) void first_part_reduce_kernel(const float* __restrict__ part, int nblk, int n, int pitch,
                                                                  float* __restrict__ red) {
   __shared__ float sh[16][64];
   const int o = threadIdx.x & 63, slice = threadIdx.x >> 6;
@@ -652,11 +653,11 @@ __global__ __launch_bounds__(1024) void first_part_reduce_kernel(const float* __
     for (; b + 7 * 16 < nblk; b += 8 * 16) {
       float v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + 16 * q) * n];
+      for (int q = 0; q < 8; ++q) v[q] = p[(size_t)(b + 16 * q) * pitch];
       s0 += (v[0] + v[1]) + (v[2] + v[3]);
       s1 += (v[4] + v[5]) + (v[6] + v[7]);
     }
-    for (; b < nblk; b += 16) s0 += p[(size_t)b * n];
+    for (; b < nblk; b += 16) s0 += p[(size_t)b * pitch];
     s = s0 + s1;
   }
   sh[slice][o] = s;
@@ -676,7 +677,7 @@ __global__ __launch_bounds__(256) void first_param_grad_kernel(const float* __re
                                                                const float* __restrict__ tab, int C,
                                                                const float* __restrict__ W, float* __restrict__ dW,
                                                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                               float* __restrict__ dbias) {
+                                                               float* __restrict__ dbias, int lut_is_zero) {
   extern __shared__ float sg[];          // dtap [3][16][C] | dbn [16][4]
   float* sdt = sg;
   float* sdbn = sg + 3 * N_SYM * C;
@@ -687,7 +688,7 @@ __global__ __launch_bounds__(256) void first_param_grad_kernel(const float* __re
     float acc = dlutblk ? dlutblk[125 * C + i] : dtap[i];
     if (dlutblk) {
       const int t = i / (N_SYM * C), r = i - t * N_SYM * C, sym = r / C, co = r - sym * C;
-      if (sym < 5) {
+      if (sym < 5 && !lut_is_zero) {      // (the channel-last backward of the composed step sums per tap directly: no 3-mer part)
         for (int u = 0; u < 25; ++u) {     // the 25 table entries whose tap-t symbol is `sym`
           const int e = t == 0 ? 25 * sym + u : (t == 1 ? 25 * (u / 5) + 5 * sym + (u % 5) : 5 * u + sym);
           acc += dlutblk[e * C + co];
@@ -1287,19 +1288,22 @@ extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, i
                                   int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
                                   const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                                   unsigned long long* counts, float* tab, float* y, void* arg, void* stream) {
+  static const int cl = (getenv("MURAL_DEBUG_FIRST_CL") && C == 32) ? 1 : 0;
   return first_fwd_impl(sym, B, Lwin, col0, L1, C, pk, ps, pp, gamma, beta, W, bias, eps, momentum, running_mean, running_var, counts, tab, y,
-                        arg, 0, nullptr, stream);
+                        arg, cl, nullptr, stream);
 }
 
 static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int32_t Lwin,
                           int32_t col0, int32_t L1, int32_t C, int32_t pk, int32_t ps, int32_t pp, const float* tab,
                           const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta, int cl,
-                          void* stream) {
+                          const mural::FirstFold* fold, void* stream) {
   const int L2 = (L1 + 2 * pp - pk) / ps + 1;
   const size_t lds = (size_t)(3 * N_SYM * C + N_SYM * 4) * 4;
+  MURAL_REQUIRE(!fold || (cl && first_train_supported(C, pk)), "first layer: the folded BatchNorm-backward apply needs the channel-last table kernels");
   if (first_train_supported(C, pk)) {
     FirstTrainArgs a;
     std::memset(&a, 0, sizeof(a));
+    if (fold) a.fold = *fold;
     a.tw = Stage1Tower{L1, col0, L2, pk, ps, pp};
     a.Lwin = Lwin; a.B = B; a.sym = sym; a.dy = dy; a.arg = const_cast<uint8_t*>(static_cast<const uint8_t*>(arg));
     a.dpart = scratch;
@@ -1307,10 +1311,17 @@ static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, 
     const int nblk = first_train_grid(B);
     float* red = scratch + (size_t)FIRST_TRAIN_MAXGRID * SNV_LUTBLK;
     if (int rc = launch_first_train(a, true, STREAM)) return rc;
+    if (cl) {      // first_bwd_cl_kernel fills the per-tap and bias parts only (the 3-mer part of its blocks is zero and is not read)
+      constexpr int N = SNV_TAPS + SNV_C;
+      hipLaunchKernelGGL(first_part_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, STREAM, scratch + SNV_LUT, B ? nblk : 0, N, SNV_LUTBLK,
+                         red + SNV_LUT);
+      hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), lds, STREAM, nullptr, red, tab, C, W, dW, dgamma, dbeta, dbias, 1);
+      CHECK_LAUNCH();
+    }
     hipLaunchKernelGGL(first_part_reduce_kernel, dim3((SNV_LUTBLK + 63) / 64), dim3(1024), 0, STREAM, scratch, B ? nblk : 0,
-                       SNV_LUTBLK, red);
+                       SNV_LUTBLK, SNV_LUTBLK, red);
     hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), lds, STREAM, nullptr, red, tab, C, W, dW, dgamma, dbeta,
-                       dbias);
+                       dbias, 0);
     CHECK_LAUNCH();
   }
   MURAL_REQUIRE(!cl, "first layer: the channel-last layout is served by the table kernels only");
@@ -1321,7 +1332,7 @@ static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, 
   hipLaunchKernelGGL(first_pool_bwd_kernel, dim3(grid_for(total, 256, 1024)), dim3(256), (size_t)(3 * N_SYM * C + C) * 4, STREAM,
                      dy, static_cast<const int32_t*>(arg), sym, B, Lwin, col0, L1, C, L2, dtap, dbias);
   hipLaunchKernelGGL(first_param_grad_kernel, dim3(1), dim3(256), lds, STREAM, dtap, nullptr, tab, C, W, dW, dgamma, dbeta,
-                     dbias);
+                     dbias, 0);
   CHECK_LAUNCH();
 }
 
@@ -1329,7 +1340,10 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
                                   int32_t col0, int32_t L1, int32_t C, int32_t pk, int32_t ps, int32_t pp, const float* tab,
                                   const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
                                   void* stream) {
-  return first_bwd_impl(dy, arg, sym, B, Lwin, col0, L1, C, pk, ps, pp, tab, W, scratch, dW, dbias, dgamma, dbeta, 0, stream);
+  // (MURAL_DEBUG_FIRST_CL=1: tools/phase_stamps_first.py times the channel-last form of the composed step through this entry; the
+  // buffers have the same sizes, only the element order of dy differs)
+  static const int cl = (getenv("MURAL_DEBUG_FIRST_CL") && C == 32) ? 1 : 0;
+  return first_bwd_impl(dy, arg, sym, B, Lwin, col0, L1, C, pk, ps, pp, tab, W, scratch, dW, dbias, dgamma, dbeta, cl, nullptr, stream);
 }
 
 namespace mural {
@@ -1341,8 +1355,8 @@ int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1
 }
 int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp,
                        const float* tab, const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
-                       hipStream_t stream) {
-  return first_bwd_impl(dy, arg, sym, B, Lwin, col0, L1, 32, pk, ps, pp, tab, W, scratch, dW, dbias, dgamma, dbeta, 1, stream);
+                       const FirstFold* fold, hipStream_t stream) {
+  return first_bwd_impl(dy, arg, sym, B, Lwin, col0, L1, 32, pk, ps, pp, tab, W, scratch, dW, dbias, dgamma, dbeta, 1, fold, stream);
 }
 }  // namespace mural
 
