@@ -361,6 +361,8 @@ int mural_debug_cw_set_stamps(void* dev_ptr);
 /* the same for the training-mode first-layer kernels (csrc/snv_stage1.hip: first_train_kernel), uint64 [workgroups][8]: entry, tables
  * ready, wave 0's window in LDS, its window indices built, its row done, every wave done, exit; NULL: off */
 int mural_debug_first_set_stamps(void* dev_ptr);
+/* the same for the three backward launches of the fused local branch (csrc/snv_local_train.h), uint64 [3][256][8]; NULL: off */
+int mural_debug_lt_set_stamps(void* dev_ptr);
 int mural_debug_cw_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
                               const float* beta, float* running_mean, float* running_var, float* state, const float* W,
                               const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,

@@ -156,6 +156,7 @@ PROTOTYPES = {
     "mural_debug_cw_wfrag": (C.c_int, [VP, VP, VP]),
     "mural_debug_cw_set_stamps": (C.c_int, [VP]),
     "mural_debug_first_set_stamps": (C.c_int, [VP]),
+    "mural_debug_lt_set_stamps": (C.c_int, [VP]),
     "mural_debug_cw_conv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP, VP]),
     "mural_debug_cw_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP]),
     "mural_debug_cl_bn_stats": (C.c_int, [VP, I64, I32, VP, VP]),

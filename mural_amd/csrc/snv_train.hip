@@ -57,6 +57,16 @@ int train_reduce_parts(const float* const* part, const int* nrow, float* const* 
 int train_bn2d_apply_dropout(const float* x, int64_t B, int C, int relu, const double* acc, const float* gamma, const float* beta, float eps,
                              float momentum, float* running_mean, float* running_var, float* state, float p, uint64_t seed,
                              const uint64_t* seed_dev, float* y_bn, float* y, hipStream_t stream);
+// snv_local_train.h (train_ops.hip): the local branch in three launches per direction
+bool local_train_fused_ok(int in1, int h1, int h2, int nc);
+int local_train_fwd(const int64_t* cat, const float* E, int cols, int emb_rows, int64_t B, const int* dims, const float* const* W,
+                    const float* const* bias, const float* const* gamma, const float* const* beta, float* const* running_mean,
+                    float* const* running_var, float* const* state, double* const* acc_f, const float* drop, const uint64_t* seeds,
+                    const uint64_t* seed_dev, float eps, float momentum, float* const* xt, float* const* lin, float* logits, hipStream_t stream);
+int local_train_bwd(const int64_t* cat, int cols, int emb_rows, int64_t B, const int* dims, const float* dlogits, const float* const* W,
+                    const float* const* gamma, const float* const* state, double* const* acc_b, const float* drop, const uint64_t* seeds,
+                    const uint64_t* seed_dev, const float* const* xt, const float* const* lin, float* const* dd, float* const* g,
+                    float* const* dW, float* const* db, float* const* dgamma, float* const* dbeta, float* dE, hipStream_t stream);
 }
 
 namespace {
@@ -364,6 +374,18 @@ int local_f(Ctx& c, const int64_t* cat, const float* drop, const uint64_t* seeds
   const MuralLocal& L = c.p->local;
   LocalBufs& l = P.loc;
   const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
+  if (local_train_fused_ok(in1, h[0], h[1], P.nc)) {
+    const int dims[4] = {in1, h[0], h[1], P.nc};
+    const float* W[3] = {L.lin[0].weight, L.lin[1].weight, L.out.weight};
+    const float* bias[3] = {L.lin[0].bias, L.lin[1].bias, L.out.bias};
+    const float* gamma[2] = {L.bn[0].weight, L.bn[1].weight};
+    const float* beta[2] = {L.bn[0].bias, L.bn[1].bias};
+    float* rmean[2] = {const_cast<float*>(L.bn[0].running_mean), const_cast<float*>(L.bn[1].running_mean)};
+    float* rvar[2] = {const_cast<float*>(L.bn[0].running_var), const_cast<float*>(L.bn[1].running_var)};
+    float* xt[3] = {l.emb_do, l.dout[0], l.dout[1]};
+    return local_train_fwd(cat, L.emb, sh.local_cols, sh.emb_rows, B, dims, W, bias, gamma, beta, rmean, rvar, l.bn_state, l.acc_f, drop, seeds,
+                           seed_dev, EPS, c.momentum, xt, l.lin, l.logits, (hipStream_t)c.stream);
+  }
   if (int rc = mural_op_embedding_fwd(cat, L.emb, B, sh.local_cols, sh.emb_rows, l.emb, c.stream)) return rc;
   const float* x;
   if (int rc = dropout_f(c, l.emb, (int64_t)B * in1, drop[0], seeds[0], seed_dev, l.emb_do, &x)) return rc;
@@ -515,6 +537,22 @@ int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop,
   LocalBufs& l = P.loc;
   const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
   float *g0 = P.g_loc[0], *g1 = P.g_loc[1], *g2 = P.g_loc[2];
+  if (local_train_fused_ok(in1, h[0], h[1], P.nc)) {
+    const int dims[4] = {in1, h[0], h[1], P.nc};
+    const float* W[3] = {L.lin[0].weight, L.lin[1].weight, L.out.weight};
+    const float* gamma[2] = {L.bn[0].weight, L.bn[1].weight};
+    const float* state[2] = {l.bn_state[0], l.bn_state[1]};
+    const float* xt[3] = {l.emb_do, l.dout[0], l.dout[1]};
+    const float* lin[2] = {l.lin[0], l.lin[1]};
+    float* dd[2] = {g2, g0};                    // gradients of the BatchNorm outputs behind the dropout masks: [B][h1], [B][h2]
+    float* gl[2] = {l.bn_out[0], g1};           // gradients of the Linear outputs (for the weight gradients): [B][h1], [B][h2]
+    float* dW[3] = {const_cast<float*>(G.lin[0].weight), const_cast<float*>(G.lin[1].weight), const_cast<float*>(G.out.weight)};
+    float* db[3] = {const_cast<float*>(G.lin[0].bias), const_cast<float*>(G.lin[1].bias), const_cast<float*>(G.out.bias)};
+    float* dgamma[2] = {const_cast<float*>(G.bn[0].weight), const_cast<float*>(G.bn[1].weight)};
+    float* dbeta[2] = {const_cast<float*>(G.bn[0].bias), const_cast<float*>(G.bn[1].bias)};
+    return local_train_bwd(cat, sh.local_cols, sh.emb_rows, B, dims, dlogits, W, gamma, state, l.acc_b, drop, seeds, seed_dev, xt, lin, dd, gl,
+                           dW, db, dgamma, dbeta, const_cast<float*>(G.emb), (hipStream_t)c.stream);
+  }
   const float* x_last = l.dout[1];
   if (int rc = mural_op_linear_bwd(dlogits, x_last, L.out.weight, B, h[1], P.nc, g0, const_cast<float*>(G.out.weight),
                                    const_cast<float*>(G.out.bias), c.stream)) return rc;
@@ -594,11 +632,19 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
   // three streams: large tower (caller's) | mid tower | local branch.  The large tower is the critical path, so it is enqueued
   // first: the ~70 launches of the other two would otherwise hold its first kernel back by their enqueue time
+  static const int order = getenv("MURAL_TRAIN_ORDER") ? atoi(getenv("MURAL_TRAIN_ORDER")) : 0;      // experiment: 1 = local branch first
+  int rc_loc = MURAL_OK;
+  if (order == 1 && m == 2) {
+    c.stream = ss->side2;
+    rc_loc = local_f(c, cat_x, dropout_p, seeds, seed_dev);
+    c.stream = stream;
+  }
   int rc_large = tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
   c.stream = ss->side;
   int rc_mid = rc_large ? MURAL_OK : tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
   c.stream = ss->side2;
-  if (m == 2 && !rc_mid && !rc_large) rc_mid = local_f(c, cat_x, dropout_p, seeds, seed_dev);
+  if (order != 1 && m == 2 && !rc_mid && !rc_large) rc_mid = local_f(c, cat_x, dropout_p, seeds, seed_dev);
+  if (!rc_mid) rc_mid = rc_loc;
   c.stream = stream;
   if (int rc = ss->join((hipStream_t)stream, true)) return rc;     // also on an error: the side streams must not stay forked
   if (rc_mid) return rc_mid;
@@ -627,11 +673,19 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   SideStreamHold ss;      // holds the device's side streams until this call has joined them again
   if (int rc = ss.acquire()) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
+  static const int order = getenv("MURAL_TRAIN_ORDER") ? atoi(getenv("MURAL_TRAIN_ORDER")) : 0;      // experiment: 1 = local branch first
+  int rc_loc = MURAL_OK;
+  if (order == 1 && m == 2) {
+    c.stream = ss->side2;
+    rc_loc = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
+    c.stream = stream;
+  }
   int rc_large = tower_b(c, 1, params->large, grads->large, P.dlogit[2], dropout_p[4], seeds[4], seed_dev);   // critical path first
   c.stream = ss->side;
   int rc_mid = rc_large ? MURAL_OK : tower_b(c, 0, params->mid, grads->mid, P.dlogit[1], dropout_p[3], seeds[3], seed_dev);
   c.stream = ss->side2;
-  if (m == 2 && !rc_mid && !rc_large) rc_mid = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
+  if (order != 1 && m == 2 && !rc_mid && !rc_large) rc_mid = local_b(c, cat_x, P.dlogit[0], dropout_p, seeds, seed_dev);
+  if (!rc_mid) rc_mid = rc_loc;
   c.stream = stream;
   if (int rc = ss->join((hipStream_t)stream, true)) return rc;
   if (rc_mid) return rc_mid;

@@ -22,7 +22,7 @@ model = bench.build_model(dev).train()
 opt = torch.optim.Adam(model.parameters(), lr=1e-3, capturable=True, fused=True)
 crit = nn.CrossEntropyLoss(reduction="sum")
 rng = np.random.default_rng(1)
-steps, warmup = 200, 10
+steps, warmup = (int(sys.argv[1]) if len(sys.argv) > 1 else 200), 10
 labels = torch.from_numpy(rng.choice(4, size=(steps + warmup) * B, p=[0.955, 0.015, 0.015, 0.015])).to(dev)
 cont = torch.zeros(B, 1, device=dev)
 
