@@ -341,6 +341,10 @@ int mural_snv_train_backward(const MuralSnvShape* shape, const MuralSnvParams* p
  * (reproducible), prob = softmax(x) kept for the backward; dx = g[0] (prob - onehot(y)).  A label outside [0, nc) makes the loss NaN. */
 int mural_op_ce_sum_fwd(const float* x, const int64_t* y, int64_t B, int32_t nc, float* prob, float* loss, void* stream);
 int mural_op_ce_sum_bwd(const float* prob, const int64_t* y, const float* g, int64_t B, int32_t nc, float* dx, void* stream);
+/* torch.nn.utils.clip_grad_norm_(parameters, max_norm) of training.py:430 over one flat float32 gradient buffer of n elements (16-byte
+ * aligned; zero in the padding between the parameters' slots): total[0] = 2-norm, flat *= min(max_norm / (norm + 1e-6), 1).  scratch64:
+ * 64 doubles of device scratch.  Two launches, fixed summation order (bitwise reproducible).                                        */
+int mural_op_clip_grad_norm(float* flat, int64_t n, float max_norm, double* scratch64, float* total, void* stream);
 
 /* Validation hooks of the parity tests: the channel-last conv kernels of the composed training step on their own.  Tensors are
  * [B][L][32]; acc blocks are double[MURAL_BN_SLOTS][2][32] (the forward reads the batch sums of act(x) from `acc` and finalises the

@@ -164,6 +164,7 @@ PROTOTYPES = {
     "mural_debug_conv1d_set_stamps": (C.c_int, [VP]),
     "mural_op_ce_sum_fwd": (C.c_int, [VP, VP, I64, I32, VP, VP, VP]),
     "mural_op_ce_sum_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP]),
+    "mural_op_clip_grad_norm": (C.c_int, [VP, I64, C.c_float, VP, VP, VP]),
     "mural_debug_poison_lds": (C.c_int, [VP]),
     "mural_debug_convblock": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, I64, I32, I32, VP, VP, VP, I32, I32, VP, VP, VP, VP, VP, VP, I32, VP]),
     "mural_debug_cb8_set_stamps": (C.c_int, [VP]),

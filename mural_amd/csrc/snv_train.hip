@@ -48,6 +48,12 @@ int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, in
 int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
                        const float* W, const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                        unsigned long long* counts, float* tab, float* y, void* arg, double* stat, hipStream_t stream);
+int train_first_prepare2(const uint8_t* sym, int64_t B, int Lwin, const int* col0, const int* L1, const float* const* gamma,
+                         const float* const* beta, const float* const* W, const float* const* bias, float* const* running_mean,
+                         float* const* running_var, unsigned long long* const* counts, float* const* tab, float eps, float momentum,
+                         hipStream_t stream);
+int train_first_fwd_cl_prepared(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* tab, float* y,
+                                void* arg, double* stat, hipStream_t stream);
 int train_first_bwd_cl(const float* dy, const void* arg, const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp,
                        const float* tab, const float* W, float* scratch, float* dW, float* dbias, float* dgamma, float* dbeta,
                        const FirstFold* fold, hipStream_t stream);
@@ -285,6 +291,7 @@ struct Ctx {
   int job_nrow[24];
   float* job_dW[24];
   float* job_db[24];
+  bool first_prepared = false;   // forward: the first layers' histograms / tables are in place (train_first_prepare2)
 };
 
 // the conv32 weights of the step in a fixed order (per tower: RBs1 convs, conv2, RBs2 convs, conv3) and their fragments in the workspace
@@ -344,9 +351,14 @@ int tower_f(Ctx& c, int t, const MuralTower& T, float drop_p, uint64_t seed, con
   TowerBufs& b = P.tw[t];
   const int B = P.B;
   hipStream_t st = (hipStream_t)c.stream;
-  if (int rc = train_first_fwd_cl(P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], T.bn_in.weight, T.bn_in.bias, T.conv_in.weight,
-                                  T.conv_in.bias, EPS, c.momentum, const_cast<float*>(T.bn_in.running_mean),
-                                  const_cast<float*>(T.bn_in.running_var), b.counts, b.tab, b.x0, b.arg1, b.s2.acc_f[0], st)) return rc;
+  if (c.first_prepared) {      // histograms and tables of both towers were made in front of the fork (train_first_prepare2)
+    if (int rc = train_first_fwd_cl_prepared(P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], b.tab, b.x0, b.arg1, b.s2.acc_f[0], st))
+      return rc;
+  } else if (int rc = train_first_fwd_cl(P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], T.bn_in.weight, T.bn_in.bias,
+                                         T.conv_in.weight, T.conv_in.bias, EPS, c.momentum, const_cast<float*>(T.bn_in.running_mean),
+                                         const_cast<float*>(T.bn_in.running_var), b.counts, b.tab, b.x0, b.arg1, b.s2.acc_f[0], st)) {
+    return rc;
+  }
   if (int rc = stage_f(c, T.rbs1, b.x0, g.L[0], b.s2.acc_f[0], true, b.s2)) return rc;
   if (int rc = cl_maxpool_fwd(b.s2.t[3], B, g.L[0], g.pk[1], g.ps[1], g.pp[1], b.p2, b.arg2, b.acc_c2_f, st)) return rc;
   if (int rc = bnconv_f(c, b.p2, g.L[1], 0, b.acc_c2_f, true, T.bn_mid, T.conv_mid, b.state_c2, 0, nullptr, nullptr, b.s3.acc_f[0], 1,
@@ -627,6 +639,23 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   }
   conv_weight_table(c);
   if (int rc = cw_wfrag_build(c.conv_w, 20, P.wfrag, (hipStream_t)stream)) return rc;     // (weights are the same in the backward of this step)
+  if (!getenv("MURAL_TRAIN_FIRST_SEPARATE")) {      // both towers' symbol histograms in one launch, both table sets in one launch
+    const int col0[2] = {P.geo[1].col0, P.geo[0].col0}, L1[2] = {P.geo[1].L1, P.geo[0].L1};
+    const MuralTower* T[2] = {&params->large, &params->mid};
+    const float* gamma[2] = {T[0]->bn_in.weight, T[1]->bn_in.weight};
+    const float* beta[2] = {T[0]->bn_in.bias, T[1]->bn_in.bias};
+    const float* W[2] = {T[0]->conv_in.weight, T[1]->conv_in.weight};
+    const float* bias[2] = {T[0]->conv_in.bias, T[1]->conv_in.bias};
+    float* rmean[2] = {const_cast<float*>(T[0]->bn_in.running_mean), const_cast<float*>(T[1]->bn_in.running_mean)};
+    float* rvar[2] = {const_cast<float*>(T[0]->bn_in.running_var), const_cast<float*>(T[1]->bn_in.running_var)};
+    unsigned long long* counts[2] = {P.tw[1].counts, P.tw[0].counts};
+    float* tab[2] = {P.tw[1].tab, P.tw[0].tab};
+    if (P.geo[1].col0 == 0 && P.geo[1].L1 == P.Lwin) {
+      if (int rc = train_first_prepare2(P.sym, B, P.Lwin, col0, L1, gamma, beta, W, bias, rmean, rvar, counts, tab, EPS, momentum, (hipStream_t)stream))
+        return rc;
+      c.first_prepared = true;
+    }
+  }
   SideStreamHold ss;      // holds the device's side streams until this call has joined them again
   if (int rc = ss.acquire()) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;

@@ -509,6 +509,96 @@ __global__ __launch_bounds__(256) void sym_hist_kernel(const uint8_t* __restrict
   if (threadIdx.x < N_SYM && h[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)h[threadIdx.x]);
 }
 
+// The two towers' histograms in ONE launch for the composed step (the large tower sees every byte of the symbol buffer, the mid tower a
+// crop of every row): workgroups [0, HIST2_FLAT) walk the buffer as 16-byte pieces -- A C G T are counted with three bit tricks and a
+// population count per dword, a piece that holds any other symbol goes byte by byte through LDS atomics --, the rest count the crop with
+// wave ballots like sym_hist_kernel.  1024-thread workgroups: the final global atomics of a launch all land on the same few addresses.
+constexpr int HIST2_FLAT = 64, HIST2_CROP = 64;
+__global__ __launch_bounds__(1024) void sym_hist2_kernel(const uint8_t* __restrict__ sym, int64_t B, int Lwin, int col0, int L1,
+                                                         unsigned long long* __restrict__ counts_full, unsigned long long* __restrict__ counts_crop) {
+  __shared__ unsigned int h[N_SYM];
+  const int tid = threadIdx.x;
+  if (tid < N_SYM) h[tid] = 0;
+  __syncthreads();
+  unsigned int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+  if ((int)blockIdx.x < HIST2_FLAT) {
+    const int64_t n = B * Lwin, n16 = n >> 4;
+    const uint4* p = reinterpret_cast<const uint4*>(sym);
+    constexpr int UN = 4;
+    const int64_t stride = (int64_t)HIST2_FLAT * 1024;
+    for (int64_t i0 = (int64_t)blockIdx.x * 1024 + tid; i0 < n16; i0 += stride * UN) {
+      uint4 v[UN];
+#pragma unroll
+      for (int u = 0; u < UN; ++u) v[u] = i0 + stride * u < n16 ? p[i0 + stride * u] : make_uint4(0xFFFFFFFFu, 0, 0, 0);      // (0xFF: skipped below)
+#pragma unroll
+      for (int u = 0; u < UN; ++u) {
+        if (i0 + stride * u >= n16) continue;
+        const uint32_t w[4] = {v[u].x & 0x0F0F0F0Fu, v[u].y & 0x0F0F0F0Fu, v[u].z & 0x0F0F0F0Fu, v[u].w & 0x0F0F0F0Fu};
+        if (((w[0] | w[1] | w[2] | w[3]) & 0x0C0C0C0Cu) == 0u) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const uint32_t b0 = w[q] & 0x01010101u, b1 = (w[q] >> 1) & 0x01010101u;
+            c3 += __popc(b0 & b1);
+            c2 += __popc(b1 & ~b0);
+            c1 += __popc(b0 & ~b1);
+          }
+          c0 += 16;      // (made exact below: c0 -= c1 + c2 + c3)
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int b = 0; b < 4; ++b) atomicAdd(&h[(w[q] >> (8 * b)) & 15u], 1u);
+        }
+      }
+    }
+    if (blockIdx.x == 0 && tid == 0)
+      for (int64_t j = n16 << 4; j < n; ++j) atomicAdd(&h[sym[j] & 15], 1u);
+    c0 -= c1 + c2 + c3;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      c0 += __shfl_xor(c0, off); c1 += __shfl_xor(c1, off); c2 += __shfl_xor(c2, off); c3 += __shfl_xor(c3, off);
+    }
+  } else {
+    // a wave takes RW rows per round, every lane UN bytes of each: RW * UN byte loads in flight (a row per round was a round trip per row)
+    const int wave = tid >> 6, lane = tid & 63;
+    const int nw = HIST2_CROP * 16;
+    constexpr int UN = 4, RW = 4;
+    for (int64_t b0 = ((int64_t)(blockIdx.x - HIST2_FLAT) * 16 + wave) * RW; b0 < B; b0 += (int64_t)nw * RW) {
+      for (int j0 = 0; j0 < L1; j0 += 64 * UN) {
+        int v[RW][UN];
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            const int j = j0 + 64 * u + lane;
+            const int64_t b = b0 + r;
+            const int raw = sym[(b < B ? b : 0) * Lwin + col0 + (j < L1 ? j : 0)] & 15;      // (clamped address, unconditional load)
+            v[r][u] = (j < L1 && b < B) ? raw : -1;
+          }
+#pragma unroll
+        for (int r = 0; r < RW; ++r)
+#pragma unroll
+          for (int u = 0; u < UN; ++u) {
+            c0 += __popcll(__ballot(v[r][u] == 0));
+            c1 += __popcll(__ballot(v[r][u] == 1));
+            c2 += __popcll(__ballot(v[r][u] == 2));
+            c3 += __popcll(__ballot(v[r][u] == 3));
+            if (v[r][u] > 3) atomicAdd(&h[v[r][u]], 1u);
+          }
+      }
+    }
+  }
+  if ((tid & 63) == 0) {
+    atomicAdd(&h[0], c0);
+    atomicAdd(&h[1], c1);
+    atomicAdd(&h[2], c2);
+    atomicAdd(&h[3], c3);
+  }
+  __syncthreads();
+  unsigned long long* counts = (int)blockIdx.x < HIST2_FLAT ? counts_full : counts_crop;
+  if (tid < N_SYM && h[tid]) atomicAdd(&counts[tid], (unsigned long long)h[tid]);
+}
+
 __constant__ float kSymFrac[15][4] = {
     {1, 0, 0, 0}, {0, 1, 0, 0}, {0, 0, 1, 0}, {0, 0, 0, 1}, {.25f, .25f, .25f, .25f},
     {.5f, 0, .5f, 0}, {0, .5f, 0, .5f}, {.5f, .5f, 0, 0}, {0, .5f, .5f, 0}, {.5f, 0, 0, .5f}, {0, 0, .5f, .5f},
@@ -520,11 +610,11 @@ __host__ __device__ __forceinline__ float* first_lutblk(float* tab, int C) { ret
 // batch statistics of the one-hot tensor from the histogram -> BN output per (symbol, channel), per-tap tables
 // tab: [0..3*16*C) taps[t][sym][co] | bnval[16][4] | xhat[16][4] | mean[4] | invstd[4] | (with_lut: lut | taps | bias block
 // in the layout of the prediction path's stage-1 tables, snv.h SNV_LUTBLK)
-__global__ void first_tables_kernel(const unsigned long long* __restrict__ counts, int C, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, const float* __restrict__ W /*[C][4][3]*/,
-                                    const float* __restrict__ bias, float eps, float momentum,
-                                    float* __restrict__ running_mean, float* __restrict__ running_var,
-                                    float* __restrict__ tab, int with_lut) {
+__device__ __forceinline__ void first_tables_body(const unsigned long long* __restrict__ counts, int C, const float* __restrict__ gamma,
+                                                  const float* __restrict__ beta, const float* __restrict__ W /*[C][4][3]*/,
+                                                  const float* __restrict__ bias, float eps, float momentum,
+                                                  float* __restrict__ running_mean, float* __restrict__ running_var,
+                                                  float* __restrict__ tab, int with_lut) {
   __shared__ float bnv[N_SYM][4], xh[N_SYM][4];
   const int tid = threadIdx.x;
   float* taps = tab;
@@ -577,6 +667,31 @@ __global__ void first_tables_kernel(const unsigned long long* __restrict__ count
   }
   for (int i = tid; i < 3 * N_SYM * C; i += blockDim.x) blk[125 * C + i] = taps[i];
   for (int i = tid; i < C; i += blockDim.x) blk[125 * C + 3 * N_SYM * C + i] = bias[i];
+}
+
+__global__ void first_tables_kernel(const unsigned long long* __restrict__ counts, int C, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ W /*[C][4][3]*/,
+                                    const float* __restrict__ bias, float eps, float momentum,
+                                    float* __restrict__ running_mean, float* __restrict__ running_var,
+                                    float* __restrict__ tab, int with_lut) {
+  first_tables_body(counts, C, gamma, beta, W, bias, eps, momentum, running_mean, running_var, tab, with_lut);
+}
+
+// both towers' tables in one launch (blockIdx.x = tower)
+struct FirstTablesJob {
+  const unsigned long long* counts;
+  const float* gamma;
+  const float* beta;
+  const float* W;
+  const float* bias;
+  float* running_mean;
+  float* running_var;
+  float* tab;
+};
+struct FirstTablesJobs { FirstTablesJob j[2]; };
+__global__ void first_tables2_kernel(const FirstTablesJobs jobs, int C, float eps, float momentum) {
+  const FirstTablesJob& j = jobs.j[blockIdx.x];
+  first_tables_body(j.counts, C, j.gamma, j.beta, j.W, j.bias, eps, momentum, j.running_mean, j.running_var, j.tab, 1);
 }
 
 // conv1 (via per-tap tables) + maxpool1 with argmax: one thread per (b, co, pooled column)
@@ -1347,6 +1462,33 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
 }
 
 namespace mural {
+// The composed step's first layers: ONE histogram launch and ONE table launch for both towers (on the caller's stream, in front of the
+// fork), then train_first_fwd_cl_prepared per tower runs the lookup kernel alone.  jobs[0] = the tower that sees whole rows (col0 = 0,
+// L1 = Lwin), jobs[1] = the crop.  sym: 16-byte aligned.
+int train_first_prepare2(const uint8_t* sym, int64_t B, int Lwin, const int* col0, const int* L1, const float* const* gamma,
+                         const float* const* beta, const float* const* W, const float* const* bias, float* const* running_mean,
+                         float* const* running_var, unsigned long long* const* counts, float* const* tab, float eps, float momentum,
+                         hipStream_t stream) {
+  MURAL_REQUIRE(col0[0] == 0 && L1[0] == Lwin && (reinterpret_cast<uintptr_t>(sym) & 15) == 0, "first layers: tower 0 must see whole, aligned rows");
+  if (B == 0) return MURAL_OK;
+  hipLaunchKernelGGL(sym_hist2_kernel, dim3(HIST2_FLAT + HIST2_CROP), dim3(1024), 0, stream, sym, B, Lwin, col0[1], L1[1], counts[0], counts[1]);
+  FirstTablesJobs jobs;
+  for (int t = 0; t < 2; ++t) jobs.j[t] = FirstTablesJob{counts[t], gamma[t], beta[t], W[t], bias[t], running_mean[t], running_var[t], tab[t]};
+  hipLaunchKernelGGL(first_tables2_kernel, dim3(2), dim3(256), 0, stream, jobs, 32, eps, momentum);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+int train_first_fwd_cl_prepared(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* tab, float* y,
+                                void* arg, double* stat, hipStream_t stream) {
+  MURAL_REQUIRE(first_train_supported(32, pk), "first layer: pool window %d not supported by the table kernel", pk);
+  FirstTrainArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.tw = Stage1Tower{L1, col0, (L1 + 2 * pp - pk) / ps + 1, pk, ps, pp};
+  a.Lwin = Lwin; a.B = B; a.sym = sym; a.lutblk = first_lutblk(const_cast<float*>(tab), 32); a.y = y; a.arg = static_cast<uint8_t*>(arg);
+  a.cl = 1;
+  a.stat = stat;
+  return launch_first_train(a, false, stream);
+}
 int train_first_fwd_cl(const uint8_t* sym, int64_t B, int Lwin, int col0, int L1, int pk, int ps, int pp, const float* gamma, const float* beta,
                        const float* W, const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                        unsigned long long* counts, float* tab, float* y, void* arg, double* stat, hipStream_t stream) {
@@ -1498,6 +1640,64 @@ extern "C" int mural_op_ce_sum_bwd(const float* prob, const int64_t* y, const fl
   MURAL_REQUIRE(prob && y && g && dx && nc >= 1 && B >= 0, "ce_sum_bwd: bad arguments");
   if (B == 0) return MURAL_OK;
   hipLaunchKernelGGL(ce_sum_bwd_kernel, dim3(grid_for(B * nc)), dim3(256), 0, STREAM, prob, y, g, B * nc, nc, dx);
+  CHECK_LAUNCH();
+}
+
+// torch.nn.utils.clip_grad_norm_(params, max_norm) (training.py:430) over ONE flat gradient buffer (zero between the parameters' slots) in
+// two launches: sums of squares per workgroup (fixed order inside a workgroup and over the workgroups: reproducible), then every workgroup
+// adds the CLIP_WGS partial sums in the same order, forms coef = min(max_norm / (norm + 1e-6), 1) -- torch's rule -- and scales its share;
+// workgroup 0 writes the norm.  (torch's route: one single-workgroup reduction of 20 us and five scalar launches.)
+constexpr int CLIP_WGS = 64;
+__global__ __launch_bounds__(1024) void clip_norm_partial_kernel(const float* __restrict__ g, int64_t n, double* __restrict__ part) {
+  __shared__ double sh[16];
+  const int64_t per = ((n + CLIP_WGS - 1) / CLIP_WGS + 3) & ~(int64_t)3;
+  const int64_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  double s = 0.0;
+  for (int64_t i = lo + 4 * (int64_t)threadIdx.x; i < hi; i += 4 * 1024) {
+    if (i + 4 <= hi) {
+      const float4 v = *reinterpret_cast<const float4*>(g + i);
+      s += ((double)v.x * v.x + (double)v.y * v.y) + ((double)v.z * v.z + (double)v.w * v.w);
+    } else {
+      for (int64_t j = i; j < hi; ++j) s += (double)g[j] * g[j];
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) t += sh[w];
+    part[blockIdx.x] = t;
+  }
+}
+__global__ __launch_bounds__(1024) void clip_norm_scale_kernel(float* __restrict__ g, int64_t n, const double* __restrict__ part, float max_norm,
+                                                               float* __restrict__ total) {
+  double t = 0.0;
+#pragma unroll
+  for (int w = 0; w < CLIP_WGS; ++w) t += part[w];
+  const float norm = (float)sqrt(t);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *total = norm;
+  const float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
+  if (coef >= 1.f) return;      // (torch multiplies by 1: the same values)
+  const int64_t per = ((n + CLIP_WGS - 1) / CLIP_WGS + 3) & ~(int64_t)3;
+  const int64_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+  for (int64_t i = lo + 4 * (int64_t)threadIdx.x; i < hi; i += 4 * 1024) {
+    if (i + 4 <= hi) {
+      float4 v = *reinterpret_cast<float4*>(g + i);
+      v.x *= coef; v.y *= coef; v.z *= coef; v.w *= coef;
+      *reinterpret_cast<float4*>(g + i) = v;
+    } else {
+      for (int64_t j = i; j < hi; ++j) g[j] *= coef;
+    }
+  }
+}
+extern "C" int mural_op_clip_grad_norm(float* flat, int64_t n, float max_norm, double* scratch64, float* total, void* stream) {
+  MURAL_REQUIRE(flat && scratch64 && total && n >= 0, "clip_grad_norm: bad arguments");
+  MURAL_REQUIRE((reinterpret_cast<uintptr_t>(flat) & 15) == 0, "clip_grad_norm: the gradient buffer must be 16-byte aligned");
+  hipLaunchKernelGGL(clip_norm_partial_kernel, dim3(CLIP_WGS), dim3(1024), 0, STREAM, flat, n, scratch64);
+  hipLaunchKernelGGL(clip_norm_scale_kernel, dim3(CLIP_WGS), dim3(1024), 0, STREAM, flat, n, scratch64, max_norm, total);
   CHECK_LAUNCH();
 }
 
