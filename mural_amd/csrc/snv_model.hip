@@ -472,6 +472,10 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         return true;
       };
       m->chunk = SNV_CHUNK;
+      if (const char* e = getenv("MURAL_SNV_CHUNK")) {      // experiment: smaller chunks keep x0 in the 256 MB Infinity Cache
+        const long v = atol(e);
+        if (v >= 1024 && v <= SNV_CHUNK) m->chunk = v;
+      }
       m->longwin = false;
       if (!getenv("MURAL_DEBUG_NO_LONGWIN")) {      // (tried first: a row of 143 .. ~270 columns also fits ONE workgroup tile per CU, slowly)
         // Long window: the large tower's pooled first-stage row (L2 columns) does not fit a wave's image.  Its first conv stage --

@@ -128,7 +128,9 @@ def predict_bed(model, fasta_path, bed_path, local_radius, local_order=3, distal
     this raises ValueError).  This is the one-process case of ``mural_amd.predict.predict_bed_sharded``: chromosomes are
     streamed through the device one at a time."""
     from ..predict import HipShardForward, predict_bed_sharded
-    fwd = HipShardForward(model, fasta_path, local_radius, local_order, distal_radius, device, batch_sites, model_type)
+    # (poisson=False: this function returns the softmax itself for every model type -- the calibration chain of run_predict.py:217-225 is
+    # write_predictions' / the sink's; HipShardForward alone would apply the Poisson step to indel models by default)
+    fwd = HipShardForward(model, fasta_path, local_radius, local_order, distal_radius, device, batch_sites, model_type, poisson=False)
     return predict_bed_sharded(fwd, bed_path, segment_center, model_type)
 
 
