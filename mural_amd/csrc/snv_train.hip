@@ -63,6 +63,15 @@ int train_reduce_parts(const float* const* part, const int* nrow, float* const* 
 int train_bn2d_apply_dropout(const float* x, int64_t B, int C, int relu, const double* acc, const float* gamma, const float* beta, float eps,
                              float momentum, float* running_mean, float* running_var, float* state, float p, uint64_t seed,
                              const uint64_t* seed_dev, float* y_bn, float* y, hipStream_t stream);
+// snv_head_train.h (train_ops.hip): a tower's head in two launches per direction
+bool head_train_fused_ok(int nc);
+int head_train_fwd(const float* c3, int64_t B, int L, float* feat, int32_t* arg, double* acc, const float* gamma, const float* beta, float eps,
+                   float momentum, float* running_mean, float* running_var, float* state, float p, uint64_t seed, const uint64_t* seed_dev,
+                   float* fd, const float* W, const float* bias, int nc, float* logits, hipStream_t stream);
+int head_train_bwd(const float* dlogits, const float* W, int nc, int64_t B, int L, const float* feat, const float* state, const float* gamma,
+                   float p, uint64_t seed, const uint64_t* seed_dev, float* dd, double* acc, const int32_t* arg, const float* c3, float* dx,
+                   float* dgamma, float* dbeta, hipStream_t stream);
+int head_train_wgrad(const float* dlogits, const float* fd, int64_t B, int nc, float* dW, float* db, hipStream_t stream);
 // snv_local_train.h (train_ops.hip): the local branch in three launches per direction
 bool local_train_fused_ok(int in1, int h1, int h2, int nc);
 int local_train_fwd(const int64_t* cat, const float* E, int cols, int emb_rows, int64_t B, const int* dims, const float* const* W,
@@ -369,6 +378,10 @@ int tower_f(Ctx& c, int t, const MuralTower& T, float drop_p, uint64_t seed, con
   // and the backward masks on v > 0 either way), so the layer runs on the same kernels as the others
   if (int rc = bnconv_f(c, b.p3, g.L[2], 0, b.acc_c3_f, true, T.bn_out, T.conv_out, b.state_c3, 0, nullptr, nullptr, nullptr, 0, b.c3))
     return rc;
+  if (head_train_fused_ok(P.nc))      // global max + statistics, then BatchNorm + dropout + Linear: two launches (snv_head_train.h)
+    return head_train_fwd(b.c3, B, g.L[2], b.feat, b.argg, b.acc_fc_f, T.fc_bn.weight, T.fc_bn.bias, EPS, c.momentum,
+                          const_cast<float*>(T.fc_bn.running_mean), const_cast<float*>(T.fc_bn.running_var), b.fc_state, drop_p, seed, seed_dev,
+                          b.fd, T.fc.weight, T.fc.bias, P.nc, b.logits, st);
   const GmaxFwdJob gj{b.c3, B, g.L[2], 1, b.feat, b.argg};
   if (int rc = cl_gmax_fwd_jobs(&gj, 1, st)) return rc;
   // distal_fc: BatchNorm1d -> Dropout -> Linear on (B, 32)
@@ -509,6 +522,12 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   float* const* gs = t == 0 ? P.g_mid : P.g;
   float *g0 = gs[0], *g1 = gs[1], *g2 = gs[2], *g3 = gs[3];
   const float* fin = b.fd;
+  hipStream_t st = (hipStream_t)c.stream;
+  const bool head_fused = head_train_fused_ok(P.nc);
+  if (head_fused) {      // (the Linear's weight gradient, which nothing in the step consumes, is launched behind the tower's chain)
+    if (int rc = head_train_bwd(dlogits, T.fc.weight, P.nc, B, g.L[2], b.feat, b.fc_state, T.fc_bn.weight, drop_p, seed, seed_dev, g0, b.acc_fc_b,
+                                b.argg, b.c3, g1, const_cast<float*>(G.fc_bn.weight), const_cast<float*>(G.fc_bn.bias), st)) return rc;
+  } else {
   // Linear -> Dropout -> BatchNorm1d on (B, 32)
   if (int rc = mural_op_linear_bwd(dlogits, fin, T.fc.weight, B, TR_C, P.nc, g0, const_cast<float*>(G.fc.weight),
                                    const_cast<float*>(G.fc.bias), c.stream)) return rc;
@@ -518,8 +537,8 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
                                     nullptr, nullptr, g2, const_cast<float*>(G.fc_bn.weight), const_cast<float*>(G.fc_bn.bias), c.stream))
     return rc;                                                                      // g2 = d feat
   // global max, ReLU of conv3
-  hipStream_t st = (hipStream_t)c.stream;
   if (int rc = cl_gmax_relu_bwd(g2, b.argg, b.c3, B, g.L[2], g1, st)) return rc;
+  }
   if (int rc = bnconv_b(c, g1, b.p3, g.L[2], 0, b.state_c3, T.bn_out, T.conv_out, b.acc_c3_b, nullptr, nullptr, G.bn_out, G.conv_out, g0,
                         g2)) return rc;                                            // g2 = d p3
   if (int rc = cl_maxpool_bwd(g2, b.arg3, B, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, st)) return rc;
@@ -536,6 +555,8 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   // the first layer's backward makes its pooled gradient from the apply's operands element by element (FirstFold, snv_stage1.hip)
   FirstFold fold{};
   if (int rc = stage_b(c, T.rbs1, G.rbs1, b.x0, g.L[0], b.s2, g3, d_in2, tmp, &fold)) return rc;
+  if (head_fused)
+    if (int rc = head_train_wgrad(dlogits, fin, B, P.nc, const_cast<float*>(G.fc.weight), const_cast<float*>(G.fc.bias), st)) return rc;
   return train_first_bwd_cl(fold.dz ? nullptr : d_in2, b.arg1, P.sym, B, P.Lwin, g.col0, g.L1, g.pk[0], g.ps[0], g.pp[0], b.tab, T.conv_in.weight,
                             P.first_scratch[t], const_cast<float*>(G.conv_in.weight), const_cast<float*>(G.conv_in.bias),
                             const_cast<float*>(G.bn_in.weight), const_cast<float*>(G.bn_in.bias), fold.dz ? &fold : nullptr, st);
