@@ -281,7 +281,7 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
                    "route, tests/test_gpu_train.py); steps_per_s = %d steps without a host sync in between" % steps,
            "roofline": {"flop_per_step": FLOP_TRAIN_PER_SITE * B, "achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS,
                         "frac_mfma": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r04_train_step")
+    fact = profile_fact("r05_train_step")      # profiled on the symbol route: the loop whose rate steps_per_s is
     if fact:
         hbm = fact.get("hbm_bytes_per_unit", fact.get("hbm_bytes_per_step"))
         gbs = hbm / t / 1e12
@@ -335,7 +335,7 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
            "note": "window decode from the packed genome inside the timed region; 113.4 MFLOP/position",
            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r04_indel_forward_pmc")
+    fact = profile_fact("r05_indel_forward_pmc") or profile_fact("r04_indel_forward_pmc")
     if fact:
         per_pos = fact["hbm_bytes_per_unit"] / 2048.0      # (the profiled unit is one forward of 2048 positions)
         tbs = per_pos * n / dt / 1e12
@@ -382,18 +382,23 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
         dt_graph = (time.perf_counter() - t0) / 40
     except Exception as e:      # noqa: BLE001  (the eager number stands on its own)
         graph_error = f"{type(e).__name__}: {e}"[:300]
-    dt = min(dt_graph, dt_eager)                # both are the product's step; which one wins depends on the host's Python speed
+    dt = dt_eager                               # the loop a user of training.py gets; the graph replay of the same step stands beside it
     tf = 3 * FLOP_INDEL_PER_POS * tb / dt / 1e12
-    out["train"] = {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "mode": "graph replay" if dt_graph <= dt_eager else "eager loop",
+    out["train"] = {"steps_per_s": 1.0 / dt, "ms_per_step": dt * 1e3, "mode": "eager loop",
                     "ms_per_step_eager": dt_eager * 1e3, "ms_per_step_graph_replay": None if graph_error else dt_graph * 1e3,
                     "graph_replay_error": graph_error, "batch": tb,
                     "positions_per_s": tb / dt,
                     "note": "forward (batch-statistics BatchNorm, dropout) + backward + clip + Adam on pre-encoded windows; eager = 20 steps "
                             "of the plain Python loop (one C call per direction, mural_indel_train_forward / _backward: ~320 launches incl. torch's loss / clip / Adam, device-bound), "
                             "graph replay = 40 replays of the same step as one HIP graph (GraphedIndelTrainStep, inputs copied in per step: "
-                            "bound by the device alone); ms_per_step is the faster of the two",
+                            "bound by the device alone); ms_per_step is the EAGER loop's",
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
                                  "flop_per_step": 3 * FLOP_INDEL_PER_POS * tb}}
+    tfact = profile_fact("r05_indel_train")
+    if tfact and tfact.get("hbm_bytes_per_step"):
+        tb_s = tfact["hbm_bytes_per_step"] / dt / 1e12
+        out["train"]["roofline"].update({"hbm_bytes_per_step": tfact["hbm_bytes_per_step"], "achieved_TBs": tb_s, "frac_hbm": tb_s / PEAK_HBM_TBS,
+                                         "launches_per_step": tfact.get("launches_per_step"), "traffic_source": tfact.get("source")})
     return out
 
 
@@ -478,7 +483,32 @@ def workload_variants(device, model, genome):
                                     "note": "distal_radius 4000 (window 8001), S-config weights_init weights, dense one-hot input of 2048 "
                                             "random windows per call (262 MB, classified into symbols inside the timed region); algorithmic "
                                             "FLOP by SURVEY 8d's rule; 512 windows per call: 0.26 of the roof (launches of 128-384 workgroups)"}
-        del m4, x4
+        # the same windows through the PACKED entry (forward_packed: no one-hot tensor, no dense -> symbol pass), and longer ones
+        del x4
+        glen = 400_000
+        gcodes = torch.randint(0, 4, (glen,), generator=torch.Generator().manual_seed(7)).numpy().astype(np.uint8)
+        gp, gm = pack2(gcodes)
+        from mural_amd.data import PackedGenome
+        g4 = PackedGenome(gp, gm, glen, device)
+
+        def packed_variant(mdl, R, nwin):
+            idx = torch.arange(nwin, device=device, dtype=torch.int64)
+            pos, strand = (idx * 131) % (glen - 2 * R - 2) + R + 1, (idx & 1).to(torch.uint8)
+            dtp = timed(lambda: mdl.forward_packed(g4, pos, strand, LOCAL_RADIUS, LOCAL_ORDER), 5, 2)
+            flr = snv_flop_per_site(R)
+            return {"bases_per_s": nwin / dtp, "batch": nwin, "ms_per_call": dtp * 1e3, "flop_per_site": flr, "tflops": flr * nwin / dtp / 1e12,
+                    "frac_of_fp32_peak": flr * nwin / dtp / 1e12 / PEAK_FP32_MFMA_TFLOPS, "fused_kernels": bool(mdl._fused_ok()),
+                    "note": "windows decoded from the packed genome inside the kernels (forward_packed)"}
+        out["long_window_R4000_packed"] = packed_variant(m4, R4, 2048)
+        out["long_window_R4000_packed_512"] = packed_variant(m4, R4, 512)
+        del m4
+        for R_long, nwin in ((8000, 1024), (16000, 512)):
+            try:
+                ml = build_model(device, R_long)
+                out["long_window_R%d_packed" % R_long] = packed_variant(ml, R_long, nwin)
+                del ml
+            except Exception as e:      # noqa: BLE001  (a radius the fused kernels refuse is reported, not fatal)
+                out["long_window_R%d_packed" % R_long] = {"error": f"{type(e).__name__}: {e}"[:300]}
     return out
 
 
@@ -792,11 +822,11 @@ def main():
         # HBM bytes per launch: PMC counters need their own profiler passes, so the figure comes from the committed summary of
         # those passes over this same command (tools/profile_bench.sh -> profiles/hbm_traffic.json), scaled to this run's launches
         traffic, traffic_source = None, None
-        fact = profile_fact("hbm_traffic")
-        if fact:
-            traffic = fact["hbm_bytes_per_site"] * sites_per_launch
-            traffic_source = "profiles/hbm_traffic.json: " + fact.get("note", "")
-        pmc = (profile_fact("r03_predict_pmc") or {}).get("all_launches", {})
+        fact = profile_fact("r05_predict") or profile_fact("r04_predict")
+        if fact and fact.get("tower_hbm_bytes_per_site"):
+            traffic = fact["tower_hbm_bytes_per_site"] * sites_per_launch
+            traffic_source = "profiles/%s.json: %s" % ("r05_predict" if profile_fact("r05_predict") else "r04_predict", fact.get("source", ""))
+        pmc = (fact or {}).get("all_launches", {})
         line = {
             "metric": "predicted bases/s (SNV local=10/distal=1000, 4-class, predict)",
             "value": bases / elapsed, "unit": "bases/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -814,7 +844,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
                          "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
-                         # from the committed PMC passes (profiles/r03_predict_pmc.json), not measured in this run:
+                         # from the committed PMC passes (profiles/r05_predict.json), not measured in this run:
                          "profiled_mfma_pipe_busy": pmc.get("mfma_pipe_busy"), "profiled_held_clock_ghz": pmc.get("held_clock_ghz"),
                          "profiled_valu_per_mfma": pmc.get("valu_insts_per_mfma_excl_mfma"),
                          "note": "four launches per chunk of <= 131072 sites: (large | mid tower) x (first conv stage | the two short "
