@@ -1426,7 +1426,8 @@ static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, 
     const int nblk = first_train_grid(B);
     float* red = scratch + (size_t)FIRST_TRAIN_MAXGRID * SNV_LUTBLK;
     if (int rc = launch_first_train(a, true, STREAM)) return rc;
-    if (cl) {      // first_bwd_cl_kernel fills the per-tap and bias parts only (the 3-mer part of its blocks is zero and is not read)
+    // (MURAL_DEBUG_FIRST_SCATTER=1 without a fold keeps the LDS-atomic scatter kernel, whose blocks carry a 3-mer part: launch_first_train)
+    if (cl && (fold || !getenv("MURAL_DEBUG_FIRST_SCATTER"))) {      // first_bwd_cl_kernel fills the per-tap and bias parts only (its 3-mer part is zero, not read)
       constexpr int N = SNV_TAPS + SNV_C;
       hipLaunchKernelGGL(first_part_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, STREAM, scratch + SNV_LUT, B ? nblk : 0, N, SNV_LUTBLK,
                          red + SNV_LUT);

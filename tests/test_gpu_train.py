@@ -110,6 +110,82 @@ def test_train_step_through_the_bench_composition_matches_reference(tag):
             assert torch.allclose(p.grad, g0[k] * f, rtol=1e-6, atol=0)
 
 
+_OPS_ROUTE = {"MURAL_TRAIN_LOCAL_OPS": "1", "MURAL_TRAIN_HEAD_OPS": "1", "MURAL_TRAIN_FIRST_SEPARATE": "1", "MURAL_TRAIN_NO_FIRST_FOLD": "1",
+              "MURAL_DEBUG_FIRST_SCATTER": "1"}
+
+
+@pytest.mark.parametrize("tag", ["T", "S"])
+def test_train_step_per_op_route_matches_reference(tag, monkeypatch):
+    """The forms the round-5 fusions replaced stay in the library behind switches (A/B runs): the local branch and the towers' heads as
+    one launch per op, one histogram / table launch per tower, the stage's last BatchNorm-backward apply as a pass of its own, the
+    first layer's backward as an LDS-atomic scatter.  Both routes must meet the reference's G7 fixture."""
+    for k, v in _OPS_ROUTE.items():
+        monkeypatch.setenv(k, v)
+    fx = U.load(f"snv_train_{tag}.npz")
+    model, _ = product_from_hp(fx["hp"])
+    orc = U.snv_oracle_from_hp(fx["hp"], drops=(0.0, 0.0, 0.0))
+    model.load_state_dict(U.snv_state_for(fx, orc))
+    for m in model.modules():
+        if isinstance(m, nn.Dropout):
+            m.p = 0.0
+    model = model.cuda().train()
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    preds = model((torch.zeros(len(cat), 1, dtype=torch.float64, device="cuda"), cat), x)
+    assert np.abs(preds.detach().cpu().numpy() - fx["preds"]).max() <= 2e-4
+    loss = nn.CrossEntropyLoss(reduction="sum")(preds, torch.from_numpy(fx["y"]).cuda())
+    model.zero_grad()
+    loss.backward()
+    worst = ("", 0.0)
+    for k, p in model.named_parameters():
+        if ".layer." in k or p.numel() == 0:
+            continue
+        want = fx["g::" + k]
+        err = float(np.abs(p.grad.cpu().numpy() - want).max()) / (float(np.abs(want).max()) + 1e-2)
+        if err > worst[1]:
+            worst = (k, err)
+    assert worst[1] <= 2e-4, f"gradient of {worst[0]} off by {worst[1]:.2e} (relative to its max + 1e-2)"
+    for k, b in model.named_buffers():
+        if ".layer." in k or k.endswith("num_batches_tracked") or b.numel() == 0:
+            continue
+        assert np.abs(b.cpu().numpy() - fx["b::" + k]).max() <= 2e-5, k
+
+
+def test_fused_and_per_op_routes_agree_with_dropout_on(monkeypatch):
+    """Dropout inside the fused kernels (the local branch's three masks, the towers' distal_fc masks): the fused launches draw the masks
+    of the per-op route -- same counter-based generator, same element index, same seeds -- so with every dropout at its default rate
+    (0.1 / 0.1 / 0.25) both routes give the same outputs and the same gradients up to the order of their float sums, forward and
+    backward masks included (a mask mismatch between the directions would move gradients by tens of per cent)."""
+    fx = U.load("snv_train_S.npz")
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"]).cuda()
+    results = []
+    for ops in (False, True):
+        for k, v in _OPS_ROUTE.items():
+            if ops:
+                monkeypatch.setenv(k, v)
+            else:
+                monkeypatch.delenv(k, raising=False)
+        model, _ = product_from_hp(fx["hp"])
+        model.load_state_dict(U.snv_state_for(fx, U.snv_oracle_from_hp(fx["hp"])))
+        model = model.cuda().train()
+        assert any(m.p > 0 for m in model.modules() if isinstance(m, nn.Dropout))
+        torch.manual_seed(11)
+        out = model((torch.zeros(len(cat), 1, device="cuda"), cat), x)
+        nn.CrossEntropyLoss(reduction="sum")(out, y).backward()
+        results.append((out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.numel()},
+                        {k: b.detach().clone() for k, b in model.named_buffers() if b.is_floating_point() and b.numel()}))
+    (o1, g1, b1), (o2, g2, b2) = results
+    assert float((o1 - o2).abs().max()) <= 2e-5
+    for k in g1:
+        # (the absolute floor of the G7 tests: biases in front of a batch-statistics BatchNorm have a mathematically zero gradient)
+        scale = float(g1[k].abs().max()) + 1e-2
+        assert float((g1[k] - g2[k]).abs().max()) <= 2e-4 * scale, k
+    for k in b1:
+        assert float((b1[k] - b2[k]).abs().max()) <= 1e-5 * (float(b1[k].abs().max()) + 1e-3), k
+
+
 def test_direct_gradient_mode_steps_aside_for_hooks_and_kept_gradients():
     """the step sets p.grad itself (model/train_step.py).  A parameter hook must still fire (the step then routes the
     gradients through autograd), gradients a caller keeps across zero_grad(set_to_none=True) must not be rewritten by the next
