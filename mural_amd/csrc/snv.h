@@ -91,6 +91,7 @@ struct Stage1Args {               // snv_stage1_kernel: window decode + first co
   float* loc_out;                 // [n][n_class] logits
   int* zero;                      // small-batch launch: n ints cleared for the tower launch behind it (SnvFwdArgs::tile_count), or nullptr
   int site_mode;                  // 1: the workgroup-per-site kernel at any batch size (long windows: sixteen per-wave windows do not fit LDS)
+  int dbg_alias;                  // timing experiment (MURAL_DEBUG_S1_ALIAS): every site writes the x0 rows of site (row % 64) -- WRONG results
 };
 
 // training-mode first layer of ONE tower (snv_stage1.hip: first_train_kernel)

@@ -279,7 +279,7 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
     else build_kwin<16>(args.tw[0], lane, cb, kwL);
     build_kwin<4>(args.tw[1], lane, cb, kwM);
     wave_lds_fence();
-    float* out = args.x0 + (size_t)row * args.x0_cols * 32;
+    float* out = args.x0 + (size_t)(args.dbg_alias ? (row & 63) : row) * args.x0_cols * 32;
     if (pair) pooled_lookup_pair(args.tw[0], lane, lutL, lut4, cb, kwL, out);
     else pooled_lookup<16>(args.tw[0], lane, lutL, cb, kwL, out);
     pooled_lookup<4>(args.tw[1], lane, lutM, cb, kwM, out + (size_t)args.tw[0].L2 * 32);
@@ -888,10 +888,13 @@ int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStr
   }
   const int64_t want = (a.n + S1_WAVES - 1) / S1_WAVES;
   const int grid = (int)(want < 256 ? want : 256);   // one 16-wave workgroup per CU, persistent
+  Stage1Args b = a;
+  static const int alias = getenv("MURAL_DEBUG_S1_ALIAS") ? 1 : 0;
+  b.dbg_alias = alias;
   if (packed)
-    hipLaunchKernelGGL(snv_stage1_kernel<1>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL(snv_stage1_kernel<1>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, b);
   else
-    hipLaunchKernelGGL(snv_stage1_kernel<0>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, a);
+    hipLaunchKernelGGL(snv_stage1_kernel<0>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, b);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
