@@ -68,6 +68,9 @@ bool cw_geom(int64_t B, int L, CwGeom* g) {
   if (pmax < 1) return false;
   int64_t p = B / (2 * CW_WAVES * CW_CUS);  // one unit per wave (eight per CU) when the rows are short
   if (p > pmax) p = pmax;
+  static const int pcap = getenv("MURAL_CW_PCAP") ? atoi(getenv("MURAL_CW_PCAP")) : 0;      // experiment: rows per unit at most
+  static const int pcap_minl = getenv("MURAL_CW_PCAP_MINL") ? atoi(getenv("MURAL_CW_PCAP_MINL")) : 0;
+  if (pcap > 0 && L >= pcap_minl && p > pcap) p = pcap;
   if (p < 1) p = 1;
   g->L = L;
   g->Sc = Sc;
