@@ -186,6 +186,53 @@ def test_fused_and_per_op_routes_agree_with_dropout_on(monkeypatch):
         assert float((b1[k] - b2[k]).abs().max()) <= 1e-5 * (float(b1[k].abs().max()) + 1e-3), k
 
 
+@pytest.mark.parametrize("hp,B", [((10, 3, 1000, 150, 75, 32, 3, 4, 2), 37), ((5, 3, 100, 150, 75, 32, 3, 2, 2), 2), ((7, 3, 200, 40, 9, 32, 3, 8, 0), 53),
+                                  ((4, 2, 128, 200, 130, 32, 3, 3, 2), 19), ((10, 3, 1000, 150, 75, 32, 3, 4, 1), 21)])
+def test_fused_and_per_op_routes_agree_on_ragged_shapes(hp, B, monkeypatch):
+    """The fused launches of round 5 (local branch, towers' heads, first-layer backward with its fold, histograms) against the per-op
+    launches they replace, on shapes the fixtures do not have: batches that are no multiple of a 16-row tile (37, 53, 19, 21) and the
+    smallest batch the step takes (2), two / three / eight classes, other hidden widths and k-mer orders (Linear inputs of 40, 45, 95
+    features; reduction runs of 10, 12, 24, 33, 38, 50 steps), Network0 / 1 / 2; dropouts at their defaults, weights from the oracle's
+    initialisation.  Outputs, every gradient and every running statistic must agree up to the order of the float sums."""
+    hp = np.array(hp)
+    rng = np.random.default_rng(int(hp.sum()) + B)
+    r, order, R = int(hp[0]), int(hp[1]), int(hp[2])
+    ncol = 2 * r + 1 - (order - 1)
+    cat = torch.from_numpy(rng.integers(0, 4 ** order + 1, size=(B, ncol))).cuda()
+    codes = rng.integers(0, 4, size=(B, 2 * R + 1)).astype(np.uint8)
+    codes[rng.integers(0, B, 5), rng.integers(0, 2 * R + 1, 5)] = 4          # a few N
+    x = U.onehot(codes).cuda()
+    y = torch.from_numpy(rng.integers(0, int(hp[7]), size=B)).cuda()
+    orc = U.snv_oracle_from_hp(hp)
+    sd = {k: v.clone() for k, v in orc.state_dict().items()}
+    results = []
+    for ops in (False, True):
+        for k, v in _OPS_ROUTE.items():
+            if ops:
+                monkeypatch.setenv(k, v)
+            else:
+                monkeypatch.delenv(k, raising=False)
+        model, _ = product_from_hp(hp)
+        model.load_state_dict(sd)
+        model = model.cuda().train()
+        torch.manual_seed(23)
+        out = model((torch.zeros(B, 1, device="cuda"), cat), x)
+        nn.CrossEntropyLoss(reduction="sum")(out, y).backward()
+        results.append((out.detach().clone(), {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.numel() and p.grad is not None},
+                        {k: b.detach().clone() for k, b in model.named_buffers() if b.is_floating_point() and b.numel()}))
+    (o1, g1, b1), (o2, g2, b2) = results
+    # (a batch of two rows: batch-statistics BatchNorm over two samples amplifies float32 round-off -- both routes sit 1.9e-2 from a
+    # float64 evaluation of the same step there, tools/r5_b2check.py)
+    gtol = 5e-4 if B >= 16 else 2e-2
+    assert torch.isfinite(o1).all() and float((o1 - o2).abs().max()) <= (5e-5 if B >= 16 else 1e-3) * (float(o2.abs().max()) + 1.0)
+    assert set(g1) == set(g2) and len(g1) >= 6
+    for k in g1:
+        scale = float(g2[k].abs().max()) + 1e-2
+        assert float((g1[k] - g2[k]).abs().max()) <= gtol * scale, k
+    for k in b1:
+        assert float((b1[k] - b2[k]).abs().max()) <= 1e-5 * (float(b2[k].abs().max()) + 1e-3), k
+
+
 def test_direct_gradient_mode_steps_aside_for_hooks_and_kept_gradients():
     """the step sets p.grad itself (model/train_step.py).  A parameter hook must still fire (the step then routes the
     gradients through autograd), gradients a caller keeps across zero_grad(set_to_none=True) must not be rewritten by the next
