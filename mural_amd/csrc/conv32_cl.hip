@@ -555,8 +555,35 @@ __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const PoolBwdArgs2 
   float* __restrict__ dx = a.dx;
   const int L = a.L, Lout = a.Lout, s = a.s, p = a.p;
   const int64_t total = a.B * L * 8;
+  const bool fold = a.fdz != nullptr;
+  __shared__ float cst[5][CL_C];      // fold: gamma * invstd | mean(dz) | mean(dz * xhat) | mean | invstd of the BatchNorm behind the pool
+  if (fold) {
+    if (threadIdx.x < CL_C) {
+      const int c = threadIdx.x;
+      const double n = (double)a.B * Lout;
+      double s1 = 0.0, s2 = 0.0;
+      for (int k = 0; k < MURAL_BN_SLOTS; ++k) {
+        s1 += a.facc[((size_t)k * 2 + 0) * CL_C + c];
+        s2 += a.facc[((size_t)k * 2 + 1) * CL_C + c];
+      }
+      cst[0][c] = a.fgamma[c] * a.fstate[3 * CL_C + c];
+      cst[1][c] = (float)(s1 / n);
+      cst[2][c] = (float)(s2 / n);
+      cst[3][c] = a.fstate[2 * CL_C + c];
+      cst[4][c] = a.fstate[3 * CL_C + c];
+      if (blockIdx.x == 0) {
+        a.fdgamma[c] = (float)s2;
+        a.fdbeta[c] = (float)s1;
+      }
+    }
+    __syncthreads();
+  }
+  const int chunk0 = threadIdx.x & 7;
+  const f32x4 k0 = fold ? ld4(&cst[0][4 * chunk0]) : splat(0.f), m1 = fold ? ld4(&cst[1][4 * chunk0]) : splat(0.f),
+              m2 = fold ? ld4(&cst[2][4 * chunk0]) : splat(0.f), mu = fold ? ld4(&cst[3][4 * chunk0]) : splat(0.f),
+              is = fold ? ld4(&cst[4][4 * chunk0]) : splat(0.f);
   for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int chunk = (int)(i & 7);
+    const int chunk = (int)(i & 7);      // (== chunk0: the grid stride is a multiple of 8)
     const int64_t bl = i >> 3;
     const int64_t b = bl / L;
     const int l = (int)(bl - b * L);
@@ -564,7 +591,20 @@ __global__ __launch_bounds__(256) void maxpool_cl_bwd_kernel(const PoolBwdArgs2 
     f32x4 o = splat(0.f);
     if (jo < Lout) {
       const size_t src = ((size_t)(b * Lout + jo)) * CL_C + 4 * chunk;
-      const f32x4 g = ld4(dy + src);
+      f32x4 g;
+      if (fold) {      // bn_bwd_apply_cl_kernel's arithmetic on the pooled element
+        const f32x4 d = ld4(a.fdz + src), raw = ld4(a.fx + src);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float v = a.frelu ? fmaxf(raw[q], 0.f) : raw[q];
+          const float xh = (v - mu[q]) * is[q];
+          float gq = k0[q] * (d[q] - m1[q] - xh * m2[q]);
+          if (a.frelu && raw[q] <= 0.f) gq = 0.f;
+          g[q] = gq;
+        }
+      } else {
+        g = ld4(dy + src);
+      }
       const int32_t* ap = arg + src;
 #pragma unroll
       for (int q = 0; q < 4; ++q) o[q] = ap[q] == l ? g[q] : 0.f;
@@ -752,7 +792,7 @@ int cl_maxpool_bwd_jobs(const PoolBwdJob* jobs, int n, hipStream_t stream) {
     MURAL_REQUIRE(j.s >= j.k, "channel-last max-pool backward serves disjoint windows (stride >= kernel)");
     if (j.B * j.L == 0) continue;
     aa.j[ny++] = j;
-    const int g = cl_grid(j.B * j.L * 8);
+    const int g = cl_grid(j.B * j.L * 8, j.fdz ? 2048 : 8192);      // (a fold: every workgroup sums the BatchNorm's 32 slots first)
     gx = g > gx ? g : gx;
   }
   if (ny == 0) return MURAL_OK;
@@ -762,7 +802,18 @@ int cl_maxpool_bwd_jobs(const PoolBwdJob* jobs, int n, hipStream_t stream) {
 }
 
 int cl_maxpool_bwd(const float* dy, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream) {
-  const PoolBwdJob j{dy, arg, B, L, Lout, k, s, p, dx};
+  PoolBwdJob j{};
+  j.dy = dy; j.arg = arg; j.B = B; j.L = L; j.Lout = Lout; j.k = k; j.s = s; j.p = p; j.dx = dx;
+  return cl_maxpool_bwd_jobs(&j, 1, stream);
+}
+
+// the pool's backward with the BatchNorm-backward apply of the conv behind the pool folded in (PoolBwdJob: fold)
+int cl_maxpool_bwd_fold(const BnApplyJob& f, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream) {
+  MURAL_REQUIRE(f.dz && f.x && f.state && f.gamma && f.acc && f.dgamma && f.dbeta && !f.add1 && !f.add2 && f.rows == B * Lout,
+                "max-pool backward: bad BatchNorm fold");
+  PoolBwdJob j{};
+  j.arg = arg; j.B = B; j.L = L; j.Lout = Lout; j.k = k; j.s = s; j.p = p; j.dx = dx;
+  j.fdz = f.dz; j.fx = f.x; j.fstate = f.state; j.fgamma = f.gamma; j.facc = f.acc; j.frelu = f.relu; j.fdgamma = f.dgamma; j.fdbeta = f.dbeta;
   return cl_maxpool_bwd_jobs(&j, 1, stream);
 }
 

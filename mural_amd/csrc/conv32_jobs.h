@@ -45,6 +45,7 @@ struct ConvBwdFold {
   float* dbeta = nullptr;
   const float* add1 = nullptr;
   float* dy_out = nullptr;
+  const float* add2 = nullptr;      // a second residual gradient (the stage's outer skip): dy = apply + add1 + add2
 };
 
 struct ConvBwdJob {       // dz, BatchNorm-backward sums, partial rows of dW / db
@@ -80,7 +81,14 @@ struct BnApplyJob {       // dx = a'(x) * gamma * invstd * (dz - mean(dz) - xhat
 };
 
 struct PoolFwdJob { const float* x; int64_t B; int L, k, s, p; float* y; int32_t* arg; double* acc; };
-struct PoolBwdJob { const float* dy; const int32_t* arg; int64_t B; int L, Lout, k, s, p; float* dx; };
+// fold: dy is not read but made per element from the BatchNorm-backward apply of the conv BEHIND the pool (its input gradient dz, its
+// saved input x = the pooled tensor, its completed sums): dy = a'(x) * gamma * invstd * (dz - mean(dz) - xhat * mean(dz * xhat)); the
+// launch's workgroup 0 writes that BatchNorm's dgamma / dbeta.  fdz == nullptr: no fold.
+struct PoolBwdJob {
+  const float* dy; const int32_t* arg; int64_t B; int L, Lout, k, s, p; float* dx;
+  const float* fdz = nullptr; const float* fx = nullptr; const float* fstate = nullptr; const float* fgamma = nullptr;
+  const double* facc = nullptr; int frelu = 0; float* fdgamma = nullptr; float* fdbeta = nullptr;
+};
 struct GmaxFwdJob { const float* x; int64_t B; int L; int relu; float* feat; int32_t* arg; };
 struct GmaxBwdJob { const float* dfeat; const int32_t* arg; const float* c3; int64_t B; int L; float* dx; };
 

@@ -514,6 +514,7 @@ struct CwBwdArgs {
   float* fdbeta;
   const float* add1;
   float* dy_out;
+  const float* add2;      // ADD2 instances: a second residual gradient
   int64_t B;
   int64_t n_units;
   int grid;
@@ -522,7 +523,7 @@ struct CwBwdArgs {
 struct CwBwdArgs2 { CwBwdArgs j[TOWER_JOBS]; };
 constexpr int CW_AUX_FOLD = 288;            // float[5][32]: gamma * invstd | mean(dz) | mean(dz * xhat) | mean | invstd of the folded BatchNorm
 
-template <int NB, bool FOLD>
+template <int NB, bool FOLD, bool ADD2 = false>
 __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdArgs2 aa) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const CwBwdArgs& a = aa.j[blockIdx.y];
@@ -638,10 +639,11 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
       const __amdgpu_buffer_rsrc_t zd2 = cw_rsrc(a.fdz + ubase, ub), xd2 = cw_rsrc(a.fx + ubase, ub);
       const __amdgpu_buffer_rsrc_t ad = cw_rsrc((a.add1 ? a.add1 : a.fdz) + ubase, a.add1 ? ub : 0u);
       const __amdgpu_buffer_rsrc_t od = cw_rsrc((a.dy_out ? a.dy_out : a.dz) + ubase, a.dy_out ? ub : 0u);
-      constexpr int RS = 6;
+      const __amdgpu_buffer_rsrc_t ad2d = cw_rsrc((ADD2 ? a.add2 : a.fdz) + ubase, ADD2 ? ub : 0u);
+      constexpr int RS = ADD2 ? 4 : 6;      // (four tensors per slot with a second residual: the same 16-18 loads in flight)
 #pragma unroll
       for (int u0 = 0; u0 < NLD; u0 += RS) {
-        f32x4 dzn[RS], xn[RS], ad1[RS];
+        f32x4 dzn[RS], xn[RS], ad1[RS], ad2[ADD2 ? RS : 1];
 #pragma unroll
         for (int q = 0; q < RS; ++q)
           if (u0 + q < NLD) {
@@ -649,6 +651,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
             dzn[q] = buf_ld4(zd2, go);
             xn[q] = buf_ld4(xd2, go);
             ad1[q] = buf_ld4(ad, go);
+            if constexpr (ADD2) ad2[q] = buf_ld4(ad2d, go);
           }
 #pragma unroll
         for (int q = 0; q < RS; ++q)
@@ -659,6 +662,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = xn[q][e] > 0.f ? gq[e] : 0.f;
             o += ad1[q];
+            if constexpr (ADD2) o += ad2[q];      // (gq + add1) + add2: bn_bwd_apply_cl_kernel's order
             bsum += o;
             lds_st4(wb, sotab[64 * (u0 + q)], o);
             buf_st4(od, so.at(u0 + q), o);
@@ -824,8 +828,10 @@ template <int NBV>
 int cw_launch_bwd(const CwBwdArgs2& a, int gx, int gy, hipStream_t stream) {
   constexpr int NB = NBV < 4 ? 4 : NBV;      // (the waves' regions also hold two partial rows / W)
   static DynLdsOnce big_lds;
-  if (int rc = big_lds.ensure(&conv32w_bwd_kernel<NB, false>, &conv32w_bwd_kernel<NB, true>)) return rc;
-  if (a.j[0].fdz) hipLaunchKernelGGL((conv32w_bwd_kernel<NB, true>), dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
+  if (int rc = big_lds.ensure(&conv32w_bwd_kernel<NB, false>, &conv32w_bwd_kernel<NB, true>, &conv32w_bwd_kernel<NB, true, true>)) return rc;
+  if (a.j[0].fdz && a.j[0].add2)
+    hipLaunchKernelGGL((conv32w_bwd_kernel<NB, true, true>), dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
+  else if (a.j[0].fdz) hipLaunchKernelGGL((conv32w_bwd_kernel<NB, true>), dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
   else hipLaunchKernelGGL((conv32w_bwd_kernel<NB, false>), dim3(gx, gy), dim3(CW_THREADS), cw_lds_bytes<NB>(), stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
@@ -900,6 +906,9 @@ int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream) {
       MURAL_REQUIRE(j.fold.relu, "conv32_bwd (wave-private): the folded BatchNorm-backward apply is built for a ReLU in front of that BatchNorm");
       a.fdz = j.fold.dz; a.fx = j.fold.x; a.fstate = j.fold.state; a.fgamma = j.fold.gamma; a.facc = j.fold.acc; a.fn = (double)j.B * j.L;
       a.frelu = j.fold.relu; a.fdgamma = j.fold.dgamma; a.fdbeta = j.fold.dbeta; a.add1 = j.fold.add1; a.dy_out = j.fold.dy_out;
+      a.add2 = j.fold.add2;
+      MURAL_REQUIRE(!j.fold.add2 || j.fold.add1, "conv32_bwd (wave-private): a second residual gradient without a first");
+      MURAL_REQUIRE((j.fold.add2 != nullptr) == (jobs[0].fold.add2 != nullptr), "conv32_bwd (wave-private): the jobs of a launch fold alike");
     }
     a.B = j.B;
     a.n_units = (j.B + a.g.P - 1) / a.g.P;

@@ -41,6 +41,7 @@ int cl_bn_bwd_apply(const float* dz, const float* x, int64_t rows, int relu, con
                     const float* add1, const float* add2, float* dx, float* dgamma, float* dbeta, hipStream_t stream);
 int cl_maxpool_fwd(const float* x, int64_t B, int L, int k, int s, int p, float* y, int32_t* arg, double* acc, hipStream_t stream);
 int cl_maxpool_bwd(const float* dy, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream);
+int cl_maxpool_bwd_fold(const BnApplyJob& f, const int32_t* arg, int64_t B, int L, int Lout, int k, int s, int p, float* dx, hipStream_t stream);
 int cl_gmax_fwd_jobs(const GmaxFwdJob* jobs, int n, hipStream_t stream);
 int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream);
 int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, int64_t B, int L, float* dx, hipStream_t stream);
@@ -428,8 +429,12 @@ int local_f(Ctx& c, const int64_t* cat, const float* drop, const uint64_t* seeds
 }
 
 // ---- backward of one BN -> conv32 layer: dx (+ add1 + add2), parameter gradients to their destinations
+// defer != nullptr (wave kernels, no residual gradients): the BatchNorm-backward apply is described in *defer instead of launched -- the
+// caller's next kernel (the pool's backward) makes dx per element from (dz, x, sums); defer->dz stays nullptr where the apply did run
 int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const float* state, const MuralBN& bn, const MuralAffine& cv,
-             double* acc, const float* add1, const float* add2, const MuralBN& gbn, const MuralAffine& gcv, float* dz, float* dx) {
+             double* acc, const float* add1, const float* add2, const MuralBN& gbn, const MuralAffine& gcv, float* dz, float* dx,
+             BnApplyJob* defer = nullptr) {
+  if (defer) defer->dz = nullptr;
   const int j = c.njobs++;
   MURAL_REQUIRE(j < 20, "internal: more conv layers than partial-row regions");
   if (use_wave_conv(L, 0, false, 0)) {
@@ -441,6 +446,11 @@ int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const
   c.job_part[j] = c.P->part[j];
   c.job_dW[j] = const_cast<float*>(gcv.weight);
   c.job_db[j] = const_cast<float*>(gcv.bias);
+  if (defer && !add1 && !add2 && !getenv("MURAL_TRAIN_NO_POOL_FOLD")) {
+    *defer = BnApplyJob{dz, x, (int64_t)c.P->B * L, pre_relu, state, bn.weight, acc, nullptr, nullptr, nullptr, const_cast<float*>(gbn.weight),
+                        const_cast<float*>(gbn.bias)};
+    return MURAL_OK;
+  }
   return cl_bn_bwd_apply(dz, x, (int64_t)c.P->B * L, pre_relu, state, bn.weight, acc, add1, add2, dx, const_cast<float*>(gbn.weight),
                          const_cast<float*>(gbn.bias), (hipStream_t)c.stream);
 }
@@ -448,10 +458,10 @@ int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const
 // d_out: gradient arriving at the stage output (kept intact); d_in: receives the gradient of the stage input; tmp: 3 buffers
 // conv backward of one layer on the wave kernels with the BatchNorm-backward apply of the layer behind it folded into its staging
 int conv_b_fold(Ctx& c, const float* dy, const float* x, int L, const float* state, const MuralBN& bn, const MuralAffine& cv, double* acc,
-                const MuralAffine& gcv, float* dz, const ConvBwdFold& fold) {
+                const MuralAffine& gcv, float* dz, const ConvBwdFold& fold, int pre_relu = 1) {
   const int j = c.njobs++;
   MURAL_REQUIRE(j < 20, "internal: more conv layers than partial-row regions");
-  ConvBwdJob job{dy, x, cv.weight, wfrag_of(c, cv.weight, 1), c.P->B, L, state, bn.weight, 1, dz, acc, c.P->part[j], 0, fold};
+  ConvBwdJob job{dy, x, cv.weight, wfrag_of(c, cv.weight, 1), c.P->B, L, state, bn.weight, pre_relu, dz, acc, c.P->part[j], 0, fold};
   if (int rc = cw_conv32_bwd_jobs(&job, 1, (hipStream_t)c.stream)) return rc;
   c.job_part[j] = c.P->part[j];
   c.job_nrow[j] = job.nrow;
@@ -539,17 +549,45 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   // global max, ReLU of conv3
   if (int rc = cl_gmax_relu_bwd(g2, b.argg, b.c3, B, g.L[2], g1, st)) return rc;
   }
+  // the BatchNorm-backward applies in front of the two pools never run as passes of their own on the wave kernels: the pool's backward
+  // makes its gradient per element from (dz, pooled input, sums) (PoolBwdJob: fold)
+  const bool wave3 = use_wave_conv(g.L[2], 0, false, 0), wave2 = use_wave_conv(g.L[1], 0, false, 0);
+  BnApplyJob ap3{}, ap2{};
   if (int rc = bnconv_b(c, g1, b.p3, g.L[2], 0, b.state_c3, T.bn_out, T.conv_out, b.acc_c3_b, nullptr, nullptr, G.bn_out, G.conv_out, g0,
-                        g2)) return rc;                                            // g2 = d p3
-  if (int rc = cl_maxpool_bwd(g2, b.arg3, B, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, st)) return rc;
+                        g2, wave3 ? &ap3 : nullptr)) return rc;                    // g2 = d p3 (unless deferred)
+  if (ap3.dz) {
+    if (int rc = cl_maxpool_bwd_fold(ap3, b.arg3, B, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, st)) return rc;
+  } else if (int rc = cl_maxpool_bwd(g2, b.arg3, B, g.L[1], g.L[2], g.pk[2], g.ps[2], g.pp[2], g3, st)) {
+    return rc;
+  }
   float* tmp[3] = {g0, g1, g2};
   // second ResBlock stage: the gradient of its output sits in g3, g0..g2 are the stage's temporaries; the gradient of its input
-  // lands in the forward's copy of the stage output, which no backward reads (the pooling behind it kept its arg-max)
+  // lands in the forward's copy of the stage output, which no backward reads (the pooling behind it kept its arg-max) -- or, on the
+  // wave kernels, is never materialised: conv_mid's backward makes it while staging (FOLD with the stage's two residual gradients)
   float* d_in3 = b.s3.t[3];
-  if (int rc = stage_b(c, T.rbs2, G.rbs2, b.x0b, g.L[1], b.s3, g3, d_in3, tmp)) return rc;
-  if (int rc = bnconv_b(c, d_in3, b.p2, g.L[1], 0, b.state_c2, T.bn_mid, T.conv_mid, b.acc_c2_b, nullptr, nullptr, G.bn_mid, G.conv_mid, g0,
-                        g1)) return rc;                                            // g1 = d p2
-  if (int rc = cl_maxpool_bwd(g1, b.arg2, B, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, st)) return rc;
+  FirstFold f3{};
+  if (int rc = stage_b(c, T.rbs2, G.rbs2, b.x0b, g.L[1], b.s3, g3, d_in3, tmp, wave2 && !getenv("MURAL_TRAIN_NO_MID_FOLD") ? &f3 : nullptr)) return rc;
+  if (f3.dz) {
+    // (stage_b's temporaries: dz = tmp[0] = g0, ga = tmp[1] = g1 (= f3.dz), gb = tmp[2] = g2 (= f3.add1); g3 = f3.add2: the conv's own
+    // input gradient goes to g0, free again)
+    const ConvBwdFold fold{f3.dz, f3.x, f3.state, f3.gamma, f3.acc, 1, f3.dgamma, f3.dbeta, f3.add1, nullptr, f3.add2};
+    if (int rc = conv_b_fold(c, nullptr, b.p2, g.L[1], b.state_c2, T.bn_mid, T.conv_mid, b.acc_c2_b, G.conv_mid, g0, fold, 0)) return rc;
+    ap2 = BnApplyJob{g0, b.p2, (int64_t)B * g.L[1], 0, b.state_c2, T.bn_mid.weight, b.acc_c2_b, nullptr, nullptr, nullptr,
+                     const_cast<float*>(G.bn_mid.weight), const_cast<float*>(G.bn_mid.bias)};
+    if (getenv("MURAL_TRAIN_NO_POOL_FOLD")) {
+      if (int rc = cl_bn_bwd_apply(g0, b.p2, (int64_t)B * g.L[1], 0, b.state_c2, T.bn_mid.weight, b.acc_c2_b, nullptr, nullptr, g1,
+                                   const_cast<float*>(G.bn_mid.weight), const_cast<float*>(G.bn_mid.bias), st)) return rc;
+      ap2.dz = nullptr;
+    }
+  } else if (int rc = bnconv_b(c, d_in3, b.p2, g.L[1], 0, b.state_c2, T.bn_mid, T.conv_mid, b.acc_c2_b, nullptr, nullptr, G.bn_mid, G.conv_mid,
+                               g0, g1, wave2 ? &ap2 : nullptr)) {
+    return rc;                                                                     // g1 = d p2 (unless deferred)
+  }
+  if (ap2.dz) {
+    if (int rc = cl_maxpool_bwd_fold(ap2, b.arg2, B, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, st)) return rc;
+  } else if (int rc = cl_maxpool_bwd(g1, b.arg2, B, g.L[0], g.L[1], g.pk[1], g.ps[1], g.pp[1], g3, st)) {
+    return rc;
+  }
   float* d_in2 = b.s2.t[3];
   // the first ResBlock stage's last BatchNorm-backward apply (four reads and a write of the stage tensor) never runs as a pass of its own:
   // the first layer's backward makes its pooled gradient from the apply's operands element by element (FirstFold, snv_stage1.hip)

@@ -111,14 +111,14 @@ def test_train_step_through_the_bench_composition_matches_reference(tag):
 
 
 _OPS_ROUTE = {"MURAL_TRAIN_LOCAL_OPS": "1", "MURAL_TRAIN_HEAD_OPS": "1", "MURAL_TRAIN_FIRST_SEPARATE": "1", "MURAL_TRAIN_NO_FIRST_FOLD": "1",
-              "MURAL_DEBUG_FIRST_SCATTER": "1"}
+              "MURAL_DEBUG_FIRST_SCATTER": "1", "MURAL_TRAIN_NO_POOL_FOLD": "1", "MURAL_TRAIN_NO_MID_FOLD": "1"}
 
 
 @pytest.mark.parametrize("tag", ["T", "S"])
 def test_train_step_per_op_route_matches_reference(tag, monkeypatch):
     """The forms the round-5 fusions replaced stay in the library behind switches (A/B runs): the local branch and the towers' heads as
-    one launch per op, one histogram / table launch per tower, the stage's last BatchNorm-backward apply as a pass of its own, the
-    first layer's backward as an LDS-atomic scatter.  Both routes must meet the reference's G7 fixture."""
+    one launch per op, one histogram / table launch per tower, every stage-end and pool-side BatchNorm-backward apply as a pass of its
+    own, the first layer's backward as an LDS-atomic scatter.  Both routes must meet the reference's G7 fixture."""
     for k, v in _OPS_ROUTE.items():
         monkeypatch.setenv(k, v)
     fx = U.load(f"snv_train_{tag}.npz")
