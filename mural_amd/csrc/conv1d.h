@@ -79,6 +79,11 @@ struct ConvBlockArgs {
   const float* symtab;
   const float* sym_bias;
   int sym_taps;
+  // optional (genome source): the per-symbol layer and the k=7 front composed into ONE conv of 6 + sym_taps taps, summed per group of
+  // three taps over A C G T (indel_enc0_compose, indel_level0.hip): the persistent first-level kernel takes the launch then
+  const float* e0_t3;
+  const float* e0_t1;
+  const float* e0_bias;
   const float* ta_w;
   const float* ta_b;
   const float* tb_w;
@@ -96,6 +101,15 @@ int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream);
 // fp32-MFMA version of the 8-channel blocks WITH a front (first encoder level / last decoder level, convblock8_mfma.hip)
 bool convblock8_mfma_supported(const ConvBlockArgs& a);
 int launch_convblock8_mfma(const ConvBlockArgs& a, hipStream_t stream);
+
+// the first encoder level from the packed genome as one persistent launch with a composed, table-driven front (indel_level0.hip)
+void indel_enc0_compose(const float* fw, const float* fb, const float* symtab, const float* sym_bias, int st, std::vector<float>* t3,
+                        std::vector<float>* t1, std::vector<float>* bias);
+bool indel_enc0_supported(const ConvBlockArgs& a);
+int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream);
+// the last decoder level (polyphase front from 16 channels, + skip, with or without the out_conv tail), persistent as well
+bool indel_dec0_supported(const ConvBlockArgs& a);
+int launch_indel_dec0(const ConvBlockArgs& a, hipStream_t stream);
 
 // y[b][c] = max_l x[b][c][l]
 int launch_rowmax(const float* x, int64_t rows, int L, float* y, hipStream_t stream);

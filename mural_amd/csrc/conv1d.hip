@@ -893,9 +893,14 @@ extern unsigned long long* g_cb8_stamps;      // (convblock8_mfma.hip)      // v
 template <bool TAIL, bool FRONT>
 static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
   const dim3 grid(convblock_tiles_of(a), a.B);
+  // diagnostic (tools/phase_stamps_indel_l0.py): MURAL_DEBUG_CB_STAMP_ONLY = enc | dec stamps only the genome-fed / the tail launch
+  unsigned long long* stamps = g_cb8_stamps;
+  if (stamps)
+    if (const char* only = getenv("MURAL_DEBUG_CB_STAMP_ONLY"))
+      if ((only[0] == 'e') != (a.symtab != nullptr) || (only[0] == 'd') != (a.tail_max != nullptr)) stamps = nullptr;
 #define MURAL_CB(CN)                                                                                                        \
   hipLaunchKernelGGL((convblock_kernel<CN, TAIL, FRONT, MFV>), grid, dim3(256), MFV ? mf_lds : 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, \
-                     a.tb_w, a.tb_b, a.f_w, a.f_b, g_cb8_stamps)
+                     a.tb_w, a.tb_b, a.f_w, a.f_b, stamps)
   // MURAL_CONVBLOCK8_VALU=1: the 8-channel block entirely on the vector ALU (A/B switch for the split form)
   const size_t mf_lds = (size_t)(8 * 272 + convblock_front_floats(a.Cf, a.f_up, FRONT) + ((a.f_pw && !convblock_poly_mfma(a)) ? 4 * 16 * 3 * 8 : 0)) * sizeof(float);
   const bool valu8 = convblock8_valu_form();
@@ -929,6 +934,8 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   if (a.tail_max) MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
   if (convblock_mfma_supported(a)) return launch_convblock_mfma(a, stream);
   if (convblock8_mfma_supported(a)) return launch_convblock8_mfma(a, stream);
+  if (indel_enc0_supported(a)) return launch_indel_enc0(a, stream);
+  if (convblock_poly_mfma(a) && indel_dec0_supported(a)) return launch_indel_dec0(a, stream);
   const bool front = a.f_in != nullptr || a.symtab != nullptr;
   if (a.tail_max && front) launch_convblock_t<true, true>(a, stream);
   else if (a.tail_max) launch_convblock_t<true, false>(a, stream);

@@ -76,6 +76,7 @@ struct MuralIndelModel {
   // strand-symmetrising conv with use_reverse (sym_taps = its kernel size), the one-hot columns themselves otherwise (sym_taps = 1)
   size_t symtab, sym_bias;
   int sym_taps;
+  size_t e0_t3, e0_t1, e0_bias;   // the composed front of the first level's persistent kernel (indel_enc0_compose); e0_t3 == 0: not built
   size_t fc_w, fc_b;     // [n_class][C0] with the BN folded, [n_class]
   float* blob;
   size_t blob_floats;
@@ -219,6 +220,17 @@ extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const Mura
         }
     }
     for (int o = 0; o < 4; ++o) B.host[m->sym_bias + o] = sh.use_reverse ? B.host[m->sym.b + o] : 0.f;
+    if (sh.down[0] == 1 && C0 == 8 && K == 7) {
+      std::vector<float> t3, t1, bias;
+      indel_enc0_compose(B.host.data() + m->up_l[0].w, B.host.data() + m->up_l[0].b, B.host.data() + m->symtab, B.host.data() + m->sym_bias,
+                         taps, &t3, &t1, &bias);
+      m->e0_t3 = B.alloc(t3.size());
+      m->e0_t1 = B.alloc(t1.size());
+      m->e0_bias = B.alloc(bias.size());
+      std::copy(t3.begin(), t3.end(), B.host.begin() + m->e0_t3);
+      std::copy(t1.begin(), t1.end(), B.host.begin() + m->e0_t1);
+      std::copy(bias.begin(), bias.end(), B.host.begin() + m->e0_bias);
+    }
   }
   // activation scratch per position: S | E_0..E_5 | T1 | T2 | H | SP | M | X (one-hot window of the packed entry's fallback)
   size_t per = (size_t)4 * sh.length + (size_t)4 * sh.length;
@@ -327,6 +339,9 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
       if (gs && gs->g) {
         a.genome = *gs->g; a.g_pos = gs->pos; a.g_strand = gs->strand; a.g_off = gs->off;
         a.symtab = m->blob + m->symtab; a.sym_bias = m->blob + m->sym_bias; a.sym_taps = m->sym_taps;
+        if (m->e0_t3) {
+          a.e0_t3 = m->blob + m->e0_t3; a.e0_t1 = m->blob + m->e0_t1; a.e0_bias = m->blob + m->e0_bias;
+        }
       }
     }
     if (tail_max) {   // out_conv (1x1, BN, ReLU, 1x1, Softplus) + max over positions ride on the last decoder block

@@ -110,3 +110,17 @@ def test_wave_private_training_convs_do_not_spill():
     for k in conv:
         r = ks[k]
         assert r["VGPRs"] <= 256 and r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= 2, (k, r)
+
+
+def test_persistent_level0_indel_kernels_do_not_spill():
+    """indel_enc0_kernel<13 | 7> / indel_dec0_kernel (csrc/indel_level0.hip), the instances that are launched outside the phase-stamp
+    diagnostics: no spill, no scratch, six waves per SIMD.  A scratch reload in their tile loop is behind a full `s_waitcnt vmcnt(0)`,
+    i.e. behind the prefetch of the NEXT tile's input -- the one wait these kernels exist to remove (the first build had four spilled
+    registers and exactly that wait in the middle of its matrix phase)."""
+    ks = _kernels(_report("indel_level0"))
+    run = [k for k in ks if ("indel_enc0_kernel" in k and k.split("indel_enc0_kernel")[1].startswith(("ILi13ELb0E", "ILi7ELb0E"))) or
+           ("indel_dec0_kernel" in k and k.split("indel_dec0_kernel")[1].startswith("ILb0E"))]
+    assert len(run) == 3, sorted(ks)
+    for k in run:
+        r = ks[k]
+        assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= 6, (k, r)

@@ -466,7 +466,8 @@ def test_fused_convblock_forms_match_torch_fp64():
     env = {k: v for k, v in os.environ.items() if k not in ("TIME", "VERBOSE", "MURAL_CONVBLOCK8_VALU", "MURAL_CONVBLOCK_DIRECT")}
     # twice: the library's routing (small launches of the 16 / 24-channel block on the LDS-tiled kernel), then its barrier-free form
     # forced for every size (rows that are all edge segments, ragged rows)
-    for extra in ({}, {"MURAL_CONVBLOCK_DIRECT": "2"}):
+    # (and once with the persistent level-0 kernels of indel_level0.hip off: the split form's own polyphase / genome-fed fronts)
+    for extra in ({}, {"MURAL_CONVBLOCK_DIRECT": "2"}, {"MURAL_INDEL_DEC0": "0", "MURAL_INDEL_ENC0": "0"}):
         out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env={**env, **extra})
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
         assert "worst" in out.stdout
