@@ -46,6 +46,7 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
   constexpr int NSYM = 256 + TT - 1;         // columns a tile decodes: positions l0 - 2 - HW .. l0 + 253 + HW
   static_assert(TT == 13 || TT == 7, "composed taps");
   unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  if (STAMPS && threadIdx.x == 0) stamps[8 * blockIdx.x + 6] = t_prev;      // (absolute: when the workgroup started)
 #define E0_STAMP(id)                                                           \
   if (STAMPS && threadIdx.x == 0) {                                            \
     const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();         \
@@ -95,7 +96,7 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
     g = neg ? ws + (long long)(Lf - 1 - j) : ws + (long long)j;
     ing = inwin && g >= 0 && g < glen;
   };
-  auto request = [&](int l0, long long ws, bool neg, E0Words& p) {
+  auto request = [&](int tid, int l0, long long ws, bool neg, E0Words& p) {
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
       if (r == 1 && wave != 0) break;                       // columns 256 .. : the first wave's second round
@@ -117,12 +118,17 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
   bool neg = __builtin_amdgcn_readfirstlane((int)a.g_strand[b]) != 0;
   E0Words cur;
   cur.w[1] = cur.m[1] = 0u;
-  request(tile_no * E0_OUT, ws, neg, cur);
+  request(threadIdx.x, tile_no * E0_OUT, ws, neg, cur);
   E0_STAMP(0);
 
 #pragma unroll 1
   for (long long tix = first; tix < last; ++tix) {
     const int l0 = tile_no * E0_OUT;
+    // (the lane's indices re-derived from an opaque copy of the thread index per iteration: hoisted out of the loop, the address pieces
+    // made from them cost twenty registers -- 59 instead of 80)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63, n16 = tid & 15, kk = (tid >> 4) & 3;
     // ---------------------------------------------------------------- symbols of the tile's columns -> bit planes (+ bytes for the exact form)
 #pragma unroll
     for (int r = 0; r < 2; ++r) {
@@ -166,7 +172,7 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
         nws = uniform64(a.g_pos[nb] + a.g_off);
         nneg = __builtin_amdgcn_readfirstlane((int)a.g_strand[nb]) != 0;
       }
-      request(ntile * E0_OUT, nws, nneg, nxt);
+      request(tid, ntile * E0_OUT, nws, nneg, nxt);
     }
     // ---------------------------------------------------------------- front: x[.][l0 - 2 + tid]
     {
@@ -303,6 +309,7 @@ __global__ __launch_bounds__(256, 6) void indel_dec0_kernel(const ConvBlockArgs 
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             int tiles_per_row, long long total_tiles, unsigned long long* stamps) {
   unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  if (STAMPS && threadIdx.x == 0) stamps[8 * blockIdx.x + 6] = t_prev;
 #define D0_STAMP(id)                                                           \
   if (STAMPS && threadIdx.x == 0) {                                            \
     const unsigned long long t_now = __builtin_amdgcn_s_memrealtime();         \
@@ -603,8 +610,9 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
   const int tiles_per_row = (a.L + E0_OUT - 1) / E0_OUT;
   const long long total = (long long)a.B * tiles_per_row;
   if (total == 0) return MURAL_OK;
-  static int wg_per_cu[2] = {0, 0}, cus = 0;
-  const int v = a.sym_taps == 7 ? 0 : 1;
+  unsigned long long* const stamps = l0_stamps(true);
+  const int v = (a.sym_taps == 7 ? 0 : 1) + (stamps ? 2 : 0);      // the instance that is launched
+  static int wg_per_cu[4] = {0, 0, 0, 0}, cus = 0;
   if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -614,19 +622,24 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
   }
   if (wg_per_cu[v] == 0) {
     int n = 0;
-    if (v == 0) MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<13, false>, 256, 0));
-    else MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<7, false>, 256, 0));
-    wg_per_cu[v] = n > 0 ? n : 1;
+    switch (v) {
+      case 0: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<13, false>, 256, 0)); break;
+      case 1: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<7, false>, 256, 0)); break;
+      case 2: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<13, true>, 256, 0)); break;
+      default: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<7, true>, 256, 0)); break;
+    }
+    // measured (rocprofv3, 2048 positions): 421 us at seven workgroups per CU, 446 us at the eight its 59 registers would allow
+    wg_per_cu[v] = n > 7 ? 7 : (n > 0 ? n : 1);
   }
   static const int cap = getenv("MURAL_INDEL_ENC0_WGS") ? atoi(getenv("MURAL_INDEL_ENC0_WGS")) : 0;      // experiment: workgroups per CU
   const long long want = (long long)cus * (cap > 0 ? cap : wg_per_cu[v]);
   const dim3 grid((unsigned)(total < want ? total : want));
-  unsigned long long* const stamps = l0_stamps(true);
 #define MURAL_E0(TTV, ST) hipLaunchKernelGGL((indel_enc0_kernel<TTV, ST>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps)
-  if (stamps) {
-    if (v == 0) MURAL_E0(13, true); else MURAL_E0(7, true);
-  } else {
-    if (v == 0) MURAL_E0(13, false); else MURAL_E0(7, false);
+  switch (v) {
+    case 0: MURAL_E0(13, false); break;
+    case 1: MURAL_E0(7, false); break;
+    case 2: MURAL_E0(13, true); break;
+    default: MURAL_E0(7, true); break;
   }
 #undef MURAL_E0
   MURAL_HIP_CHECK(hipGetLastError());
@@ -643,7 +656,9 @@ int launch_indel_dec0(const ConvBlockArgs& a, hipStream_t stream) {
   const int tiles_per_row = (a.L + D0_OUT - 1) / D0_OUT;
   const long long total = (long long)a.B * tiles_per_row;
   if (total == 0) return MURAL_OK;
-  static int wg_per_cu = 0, cus = 0;
+  unsigned long long* const stamps = l0_stamps(false);
+  const int v = stamps ? 1 : 0;
+  static int wg_per_cu[2] = {0, 0}, cus = 0;
   if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -651,15 +666,15 @@ int launch_indel_dec0(const ConvBlockArgs& a, hipStream_t stream) {
     MURAL_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     cus = prop.multiProcessorCount;
   }
-  if (wg_per_cu == 0) {
+  if (wg_per_cu[v] == 0) {
     int n = 0;
-    MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_dec0_kernel<false>, 256, 0));
-    wg_per_cu = n > 0 ? n : 1;
+    if (v == 0) MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_dec0_kernel<false>, 256, 0));
+    else MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_dec0_kernel<true>, 256, 0));
+    wg_per_cu[v] = n > 0 ? n : 1;
   }
   static const int cap = getenv("MURAL_INDEL_DEC0_WGS") ? atoi(getenv("MURAL_INDEL_DEC0_WGS")) : 0;      // experiment: workgroups per CU
-  const long long want = (long long)cus * (cap > 0 ? cap : wg_per_cu);
+  const long long want = (long long)cus * (cap > 0 ? cap : wg_per_cu[v]);
   const dim3 grid((unsigned)(total < want ? total : want));
-  unsigned long long* const stamps = l0_stamps(false);
   if (stamps) hipLaunchKernelGGL(indel_dec0_kernel<true>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps);
   else hipLaunchKernelGGL(indel_dec0_kernel<false>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps);
   MURAL_HIP_CHECK(hipGetLastError());

@@ -42,6 +42,10 @@ with torch.no_grad():
             for k, n in ((1, "symbols -> planes"), (2, "front"), (3, "k=5 + SiLU"), (4, "1x1 + store")):
                 print("   %-20s %.2f us per tile" % (n, (s[:, k] / tiles).mean() * 0.01))
             print("   sum %.2f us per tile" % ((s[:, 1:5].sum(1) / tiles).mean() * 0.01))
+            tot = s[:, 0:5].sum(1) * 0.01
+            start = (s[:, 6] - s[:, 6].min()) * 0.01
+            print("   per workgroup: total min %.1f / median %.1f / max %.1f us; starts min 0 / median %.1f / max %.1f us; launch span %.1f us" %
+                  (tot.min(), tot.median(), tot.max(), start.median(), start.max(), (start + tot).max()))
             continue
         if which == "dec" and os.environ.get("MURAL_INDEL_DEC0", "1") != "0":
             tiles = s[:, 7].clamp(min=1)
@@ -49,6 +53,10 @@ with torch.no_grad():
             for k, n in ((1, "source -> LDS"), (2, "polyphase front"), (3, "k=5 + SiLU"), (4, "1x1 + skip"), (5, "tail / store")):
                 print("   %-20s %.2f us per tile" % (n, (s[:, k] / tiles).mean() * 0.01))
             print("   sum %.2f us per tile" % ((s[:, 1:6].sum(1) / tiles).mean() * 0.01))
+            tot = s[:, 0:6].sum(1) * 0.01
+            start = (s[:, 6] - s[:, 6].min()) * 0.01
+            print("   per workgroup: total min %.1f / median %.1f / max %.1f us; starts min 0 / median %.1f / max %.1f us; launch span %.1f us" %
+                  (tot.min(), tot.median(), tot.max(), start.median(), start.max(), (start + tot).max()))
             continue
         print(which, ": %d workgroups stamped, launch span %.1f us, workgroup lifetime %.2f us" %
               (len(s), (s[:, 5].max() - s[:, 0].min()) * 0.01, (s[:, 5] - s[:, 0]).mean() * 0.01))
