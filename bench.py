@@ -263,8 +263,8 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
     t_sync = float(np.median(times))
     # side figure: the same loop fed with dense one-hot windows (16 bytes per column written by the encoder and read back by the step)
     dense_steps = min(200, steps)
-    for s in range(3):
-        step(s, dense=True)
+    for s in range(min(20, steps)):      # (the 131 MB window tensors of this route settle in the caching allocator first: with three warm-up
+        step(s, dense=True)              # steps the timed loop still contained allocations, 385 vs 500-520 steps/s in its first 200 steps)
     torch.cuda.synchronize()
     t2 = time.perf_counter()
     for s in range(dense_steps):
