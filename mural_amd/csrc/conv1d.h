@@ -84,6 +84,13 @@ struct ConvBlockArgs {
   const float* e0_t3;
   const float* e0_t1;
   const float* e0_bias;
+  // optional, with the composed front: the strided conv of the NEXT level (8 -> 16 channels, k = 7, stride 4, pad 3; weights
+  // [8][7][16] + bias) is emitted by the same launch from the block's outputs while they are in LDS -- d_out [B][16][d_L],
+  // d_L = (L - 1) / 4 + 1; `out` is still written (the decoder's skip)
+  const float* d_w;
+  const float* d_b;
+  float* d_out;
+  int d_L;
   const float* ta_w;
   const float* ta_b;
   const float* tb_w;

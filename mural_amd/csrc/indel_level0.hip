@@ -29,6 +29,7 @@ extern unsigned long long* g_cb8_stamps;      // diagnostic (convblock8_mfma.hip
 namespace {
 
 constexpr int E0_OUT = 252;         // output positions per tile (= the split form's tile, so tail / tile bookkeeping is shared)
+constexpr int E0_OUT_DOWN = 248;    // ... of the form that also emits the next level's stride-4 conv (62 columns of it per tile)
 constexpr int E0_PITCH = 272;       // = 16 (mod 32) floats
 constexpr int E0_C = 8;
 
@@ -36,14 +37,19 @@ __device__ __forceinline__ float silu0(float v) { return v * __builtin_amdgcn_rc
 
 struct E0Words { uint32_t w[2], m[2]; };   // genome words of a thread's one or two columns of a tile (2-bit bases, not-ACGT mask)
 
-template <int TT, bool STAMPS>
+template <int TT, bool STAMPS, bool DOWN>
 __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             int tiles_per_row, long long total_tiles, unsigned long long* stamps) {
   constexpr int HW = (TT - 1) / 2;           // half width of the composed conv
   constexpr int ST = TT - 6;                 // taps of the per-symbol layer in front (7 or 1)
   constexpr int NG = (TT - 1) / 3;           // groups of three taps; the last tap goes alone
-  constexpr int NSYM = 256 + TT - 1;         // columns a tile decodes: positions l0 - 2 - HW .. l0 + 253 + HW
+  constexpr int NSYM = 256 + TT - 1;         // columns a tile decodes: positions l0 + XO - HW .. l0 + XO + 255 + HW
+  // DOWN: the tile also emits the next level's strided conv (8 -> 16, k = 7, stride 4, model_indel.py:39-42) of its outputs: 62 columns
+  // of it per tile need the block's outputs from three positions in front of the tile's own 248, so the tile's origin moves by four
+  constexpr int OUTW = DOWN ? E0_OUT_DOWN : E0_OUT;      // outputs stored per tile
+  constexpr int XO = DOWN ? -6 : -2;                     // tile entry p <-> position l0 + XO + p; block output o <-> position l0 + XO + 2 + o
+  constexpr int OLO = DOWN ? 4 : 0;                      // block outputs OLO .. OLO + OUTW - 1 are the tile's own
   static_assert(TT == 13 || TT == 7, "composed taps");
   unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if (STAMPS && threadIdx.x == 0) stamps[8 * blockIdx.x + 6] = t_prev;      // (absolute: when the workgroup started)
@@ -58,7 +64,7 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
   __shared__ __attribute__((aligned(16))) float t1s[4 * E0_C + E0_C];        // single-tap table | bias of the composed conv
   __shared__ __attribute__((aligned(16))) float stabS[15 * ST * 4 + 4];      // exact form: per-symbol layer | its bias
   __shared__ __attribute__((aligned(16))) float fwS[4 * 7 * E0_C + E0_C];    // exact form: k = 7 conv [ci][k][co] | its bias
-  __shared__ __attribute__((aligned(16))) float biasS[16 + E0_C];            // b5 | b1 (read per tile: eight registers less across the loop)
+  __shared__ __attribute__((aligned(16))) float biasS[16 + E0_C + 16];       // b5 | b1 | bias of the strided conv (read per tile: fewer registers across the loop)
   __shared__ uint32_t planes[3 * 12];                                        // low bit | high bit | not-ACGT, 320 columns each (+ pad)
   __shared__ uint8_t symb[320];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -80,6 +86,13 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
 #pragma unroll
   for (int q = 0; q < 4; ++q) a1w[q] = w1[(4 * kk + q) * E0_C + (n16 & 7)];
   if (tid < 16 + E0_C) biasS[tid] = tid < 16 ? b5[tid] : b1[tid - 16];
+  // DOWN: A fragments of the strided conv, k-step s = (tap s / 2, ci 4 (s % 2) + kk), weights [8][7][16]
+  float ad[DOWN ? 14 : 1];
+  if constexpr (DOWN) {
+#pragma unroll
+    for (int s = 0; s < 14; ++s) ad[s] = a.d_w[((4 * (s & 1) + kk) * 7 + (s >> 1)) * 16 + n16];
+    if (tid < 16) biasS[16 + E0_C + tid] = a.d_b[tid];
+  }
 
   const long long first = total_tiles * (long long)blockIdx.x / (long long)gridDim.x;
   const long long last = total_tiles * ((long long)blockIdx.x + 1) / (long long)gridDim.x;
@@ -91,7 +104,7 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
 
   // a column's place in the genome: window column j of row (ws, neg)
   auto column = [&](int i, int l0, long long ws, bool neg, bool& inwin, bool& ing, long long& g) {
-    const int j = l0 - 2 - HW + i;
+    const int j = l0 + XO - HW + i;
     inwin = (unsigned)j < (unsigned)Lf;
     g = neg ? ws + (long long)(Lf - 1 - j) : ws + (long long)j;
     ing = inwin && g >= 0 && g < glen;
@@ -118,12 +131,12 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
   bool neg = __builtin_amdgcn_readfirstlane((int)a.g_strand[b]) != 0;
   E0Words cur;
   cur.w[1] = cur.m[1] = 0u;
-  request(threadIdx.x, tile_no * E0_OUT, ws, neg, cur);
+  request(threadIdx.x, tile_no * OUTW, ws, neg, cur);
   E0_STAMP(0);
 
 #pragma unroll 1
   for (long long tix = first; tix < last; ++tix) {
-    const int l0 = tile_no * E0_OUT;
+    const int l0 = tile_no * OUTW;
     // (the lane's indices re-derived from an opaque copy of the thread index per iteration: hoisted out of the loop, the address pieces
     // made from them cost twenty registers -- 59 instead of 80)
     int tid = threadIdx.x;
@@ -172,11 +185,11 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
         nws = uniform64(a.g_pos[nb] + a.g_off);
         nneg = __builtin_amdgcn_readfirstlane((int)a.g_strand[nb]) != 0;
       }
-      request(tid, ntile * E0_OUT, nws, nneg, nxt);
+      request(tid, ntile * OUTW, nws, nneg, nxt);
     }
     // ---------------------------------------------------------------- front: x[.][l0 - 2 + tid]
     {
-      const int l = l0 - 2 + tid;
+      const int l = l0 + XO + tid;
       const int wd = tid >> 5;
       const uint32_t sh = (uint32_t)(tid & 31);
       const uint32_t lo = __builtin_amdgcn_alignbit(planes[wd + 1], planes[wd], sh);
@@ -268,18 +281,52 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
       // lane (n16, kk) holds channels 4 (kk % 2) + q of blocks p + 2 (kk / 2), p = 0, 1: + block input, out
       const int cb = 4 * (kk & 1);
       const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)b * E0_C * a.L, 0, (int)((uint32_t)E0_C * (uint32_t)a.L * 4u), 0x00020000);
+      float v[2][4];
 #pragma unroll
       for (int p = 0; p < 2; ++p) {
         const int ob = o0 + 16 * (p + 2 * (kk >> 1));
-        const int l = l0 + ob;
-        const bool live = ob < E0_OUT && l < a.L;
+        const int l = l0 + XO + 2 + ob;
+        const bool live = ob >= OLO && ob < OLO + OUTW && l < a.L;
         uint32_t off = ((uint32_t)cb * (uint32_t)a.L + (uint32_t)l) * 4u;
         off = live ? off : 0x80000000u;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const float v = o[p][q] + tile[(cb + q) * E0_PITCH + ob + 2];
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, off, (uint32_t)q * (uint32_t)a.L * 4u, 0);
+          v[p][q] = o[p][q] + tile[(cb + q) * E0_PITCH + ob + 2];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[p][q]), ro, off, (uint32_t)q * (uint32_t)a.L * 4u, 0);
         }
+      }
+      if constexpr (DOWN) {
+        // ------------------------------------------------------------ the next level's strided conv of this tile's outputs: the block
+        // outputs go back into the tile (entry = block output index; zero outside the row: the conv pads ITS input), then column
+        // c = 16 wave + n16 of the tile's 62 (row column l0 / 4 + c) is D[16 channels] = W[16][(tap, ci)] out[ci][4 c + 1 + tap]
+        __syncthreads();                   // every wave has read its block input
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+          const int ob = o0 + 16 * (p + 2 * (kk >> 1));
+          const int l = l0 + XO + 2 + ob;
+          const bool in = l >= 0 && l < a.L;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) tile[(cb + q) * E0_PITCH + ob] = in ? v[p][q] : 0.f;
+        }
+        __syncthreads();
+        const int c = 16 * wave + n16;
+        const float* yb = tile + kk * E0_PITCH + 4 * c + 1;
+        f32x4 dacc = ld4(biasS + 16 + E0_C + bo);
+#pragma unroll
+        for (int s = 0; s < 14; ++s) dacc = __builtin_amdgcn_mfma_f32_16x16x4f32(ad[s], yb[4 * (s & 1) * E0_PITCH + (s >> 1)], dacc, 0, 0, 0);
+        const int col = l0 / 4 + c;
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(a.d_out + (size_t)b * 16 * a.d_L, 0, (int)(16u * (uint32_t)a.d_L * 4u), 0x00020000);
+        uint32_t doff = ((uint32_t)(4 * kk) * (uint32_t)a.d_L + (uint32_t)col) * 4u;
+        doff = (c < OUTW / 4 && col < a.d_L) ? doff : 0x80000000u;
+        // (the four rows as named scalars pinned behind the MFMA chain: without the pin the four stores below came out as four
+        // stores of row 0's register, the other three overwritten by the address arithmetic -- caught by the packed-entry tests)
+        float d0 = dacc.x, d1 = dacc.y, d2 = dacc.z, d3 = dacc.w;
+        asm volatile("" : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3));
+        const uint32_t rowb = (uint32_t)a.d_L * 4u;
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, d0), rd, doff, 0u, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, d1), rd, doff, rowb, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, d2), rd, doff, 2u * rowb, 0);
+        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, d3), rd, doff, 3u * rowb, 0);
       }
     }
     E0_STAMP(4);
@@ -607,12 +654,15 @@ bool indel_enc0_supported(const ConvBlockArgs& a) {
 }
 
 int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
-  const int tiles_per_row = (a.L + E0_OUT - 1) / E0_OUT;
+  const bool down = a.d_out != nullptr;
+  if (down) MURAL_REQUIRE(a.d_w && a.d_b && (a.L & 3) == 0 && a.d_L == (a.L - 1) / 4 + 1, "level-0 launch: bad geometry of the strided conv behind it");
+  const int outw = down ? E0_OUT_DOWN : E0_OUT;
+  const int tiles_per_row = (a.L + outw - 1) / outw;
   const long long total = (long long)a.B * tiles_per_row;
   if (total == 0) return MURAL_OK;
   unsigned long long* const stamps = l0_stamps(true);
-  const int v = (a.sym_taps == 7 ? 0 : 1) + (stamps ? 2 : 0);      // the instance that is launched
-  static int wg_per_cu[4] = {0, 0, 0, 0}, cus = 0;
+  const int v = (a.sym_taps == 7 ? 0 : 1) + (stamps ? 2 : 0) + (down ? 4 : 0);      // the instance that is launched
+  static int wg_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cus = 0;
   if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -620,28 +670,32 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
     MURAL_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
     cus = prop.multiProcessorCount;
   }
+#define MURAL_E0_CASES(X) \
+  switch (v) {            \
+    case 0: X(13, false, false); break; \
+    case 1: X(7, false, false); break;  \
+    case 2: X(13, true, false); break;  \
+    case 3: X(7, true, false); break;   \
+    case 4: X(13, false, true); break;  \
+    case 5: X(7, false, true); break;   \
+    case 6: X(13, true, true); break;   \
+    default: X(7, true, true); break;   \
+  }
   if (wg_per_cu[v] == 0) {
     int n = 0;
-    switch (v) {
-      case 0: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<13, false>, 256, 0)); break;
-      case 1: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<7, false>, 256, 0)); break;
-      case 2: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<13, true>, 256, 0)); break;
-      default: MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<7, true>, 256, 0)); break;
-    }
+#define MURAL_E0_OCC(TTV, ST, DN) MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<TTV, ST, DN>, 256, 0))
+    MURAL_E0_CASES(MURAL_E0_OCC)
+#undef MURAL_E0_OCC
     // measured (rocprofv3, 2048 positions): 421 us at seven workgroups per CU, 446 us at the eight its 59 registers would allow
     wg_per_cu[v] = n > 7 ? 7 : (n > 0 ? n : 1);
   }
   static const int cap = getenv("MURAL_INDEL_ENC0_WGS") ? atoi(getenv("MURAL_INDEL_ENC0_WGS")) : 0;      // experiment: workgroups per CU
   const long long want = (long long)cus * (cap > 0 ? cap : wg_per_cu[v]);
   const dim3 grid((unsigned)(total < want ? total : want));
-#define MURAL_E0(TTV, ST) hipLaunchKernelGGL((indel_enc0_kernel<TTV, ST>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps)
-  switch (v) {
-    case 0: MURAL_E0(13, false); break;
-    case 1: MURAL_E0(7, false); break;
-    case 2: MURAL_E0(13, true); break;
-    default: MURAL_E0(7, true); break;
-  }
+#define MURAL_E0(TTV, ST, DN) hipLaunchKernelGGL((indel_enc0_kernel<TTV, ST, DN>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps)
+  MURAL_E0_CASES(MURAL_E0)
 #undef MURAL_E0
+#undef MURAL_E0_CASES
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

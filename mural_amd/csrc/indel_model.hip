@@ -327,7 +327,7 @@ struct GenomeSrc {      // packed-genome source of the first level's front input
 static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
                      float* H, float* out, const float* skip, hipStream_t stream, float* tail_max = nullptr,
                      const FoldedConv* ff = nullptr, const float* fin = nullptr, int up = 1, const GenomeSrc* gs = nullptr,
-                     int* tiles_out = nullptr) {
+                     int* tiles_out = nullptr, const FoldedConv* down = nullptr, float* down_out = nullptr, int down_L = 0) {
   if (block_fusable(f5, f1, L)) {
     ConvBlockArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -341,6 +341,9 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
         a.symtab = m->blob + m->symtab; a.sym_bias = m->blob + m->sym_bias; a.sym_taps = m->sym_taps;
         if (m->e0_t3) {
           a.e0_t3 = m->blob + m->e0_t3; a.e0_t1 = m->blob + m->e0_t1; a.e0_bias = m->blob + m->e0_bias;
+          if (down) {
+            a.d_w = m->blob + down->w; a.d_b = m->blob + down->b; a.d_out = down_out; a.d_L = down_L;
+          }
         }
       }
     }
@@ -436,14 +439,22 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
       if ((rc = run_conv(m, m->sym, cur, B, Lcur, S, Lcur, 1, 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
       cur = S;
     }
+    // the genome-fed first level also emits the second level's strided conv (8 -> 16, k = 7, stride 4) where the shapes are the
+    // persistent kernel's (indel_level0.hip); MURAL_INDEL_ENC0_DOWN=0: the conv as a launch of its own
+    static const bool down_off = (getenv("MURAL_INDEL_ENC0_DOWN") && atoi(getenv("MURAL_INDEL_ENC0_DOWN")) == 0) ||
+                                 (getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0);
+    const bool emit_down = gs.g && m->e0_t3 && !down_off && sh.down[1] == 4 && m->up_l[1].K == 7 && m->up_l[1].Cin == 8 && m->up_l[1].Cout == 16 &&
+                           (m->len[0] & 3) == 0 && m->len[1] == (m->len[0] - 1) / 4 + 1 && !getenv("MURAL_DEBUG_CONVBLOCK_VALU") &&
+                           !getenv("MURAL_CONVBLOCK8_VALU") && !getenv("MURAL_CONVBLOCK8_MFMA");
     for (int i = 0; i < INDEL_LEVELS; ++i) {     // encoder: strided conv+BN, then ConvBlock (x + BN(1x1(SiLU(BN(k5)))))
       const int Li = m->len[i];
       if (sh.down[i] == 1 && block_fusable(m->up5[i], m->up1[i], Li) && front_fusable(m->up_l[i], 1, m->ch[i])) {
         if ((rc = run_block(m, m->up5[i], m->up1[i], nullptr, B, Li, H, E[i], nullptr, stream, nullptr, &m->up_l[i], cur, 1,
-                            i == 0 ? &gs : nullptr)))
+                            i == 0 ? &gs : nullptr, nullptr, (i == 0 && emit_down) ? &m->up_l[1] : nullptr, T1, m->len[1])))
           return rc;
       } else {
-        if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
+        if (!(i == 1 && emit_down))      // (else: T1 already holds this level's strided conv)
+          if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
         if ((rc = run_block(m, m->up5[i], m->up1[i], T1, B, Li, H, E[i], nullptr, stream))) return rc;
       }
       cur = E[i];
