@@ -243,17 +243,28 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
         uint32_t word = 0, mword = 0;
         if (w >= 0 && 16 * w < glen) {
           word = args.genome.packed2[w];
-          mword = args.genome.nmask[w >> 1] >> (16u * (uint32_t)(w & 1));
+          mword = (args.genome.nmask[w >> 1] >> (16u * (uint32_t)(w & 1))) & 0xFFFFu;
         }
+        // the word's first base as a window column on the plus strand (32 bits: |16 w - ws| < 16 nwords); bases outside the chromosome
+        // read as N: their mask bits are set here, once per word (the per-base form did this in 64-bit position arithmetic, ~25 vector
+        // instructions per base; this kernel is bound by vector-instruction issue -- PMC: 2800 per site, 70 % of the issue slots)
+        const int j0 = (int)(16 * w - ws);
+        if (w < 0 || 16 * w >= glen) mword = 0xFFFFu;
+        else if (16 * w + 15 >= glen) mword |= 0xFFFFu << (uint32_t)(glen - 16 * w);
+        const uint32_t cw = neg ? ~word : word;              // complement: 3 - base in every 2-bit field
+        const int jb = neg ? Lwin - 1 - j0 - 15 : j0;        // window column of the lowest-addressed byte this word writes
+        uint8_t* dst = cb + jb + 1;
+        if (jb >= 0 && jb + 15 < Lwin && (mword & 0xFFFFu) == 0u) {
+          // every base is A C G T inside the window: one field extract and one byte store at an immediate offset per base
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-          const int64_t gpos = 16 * w + k;
-          const int64_t j64 = neg ? (ws + Lwin - 1 - gpos) : (gpos - ws);
-          if (j64 >= 0 && j64 < Lwin) {
-            uint32_t sym = (word >> (2 * k)) & 3u;
-            if (neg) sym = 3u - sym;
-            if (gpos < 0 || gpos >= glen || ((mword >> k) & 1u)) sym = SYM_N;
-            cb[(int)j64 + 1] = (uint8_t)sym;
+          for (int k = 0; k < 16; ++k) dst[neg ? 15 - k : k] = (uint8_t)((cw >> (2 * k)) & 3u);
+        } else {
+          // the window's end words, N runs, chromosome ends: the same with a range test and the mask bit per base
+#pragma unroll
+          for (int k = 0; k < 16; ++k) {
+            const int o = neg ? 15 - k : k;
+            const uint32_t sym = ((mword >> k) & 1u) ? (uint32_t)SYM_N : ((cw >> (2 * k)) & 3u);
+            if ((unsigned)(jb + o) < (unsigned)Lwin) dst[o] = (uint8_t)sym;
           }
         }
       }
