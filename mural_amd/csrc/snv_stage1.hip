@@ -67,7 +67,8 @@ __device__ __forceinline__ void pooled_lookup(const Stage1Tower& g, int lane, co
   const int cg = lane & 7;
   const int total = g.L2 * 8;
   for (int task = lane; task < total; task += nl) {
-    const int j2 = task >> 3;
+    const int jt = task >> 3;
+    const int j2 = jt == 0 ? g.L2 - 1 : jt - 1;      // (last pooled column first: both edge columns in one round, see pooled_lookup_pair)
     uint32_t d[SLOT / 4];
     if (SLOT == 16) {
       const uint4 q = *reinterpret_cast<const uint4*>(kw + (size_t)j2 * 16);
@@ -154,7 +155,10 @@ __device__ __forceinline__ void pooled_lookup_pair(const Stage1Tower& g, int lan
   const int cg = lane & 7;
   const int total = g.L2 * 8;
   for (int task = lane; task < total; task += 64) {
-    const int j2 = task >> 3;
+    // (the row's LAST pooled column first: the two columns whose windows hang over the row's ends then share a round, and the
+    // fifteen-iteration per-column path they send their wave through runs once per site instead of twice)
+    const int jt = task >> 3;
+    const int j2 = jt == 0 ? g.L2 - 1 : jt - 1;
     const uint4 q = *reinterpret_cast<const uint4*>(kw + (size_t)j2 * 16);
     f32x4 m;
     if (((q.y | q.w) & 0xFFu) == 0u) {      // eight table rows instead of fifteen
@@ -254,18 +258,15 @@ __global__ __launch_bounds__(S1_THREADS) void snv_stage1_kernel(const Stage1Args
         const uint32_t cw = neg ? ~word : word;              // complement: 3 - base in every 2-bit field
         const int jb = neg ? Lwin - 1 - j0 - 15 : j0;        // window column of the lowest-addressed byte this word writes
         uint8_t* dst = cb + jb + 1;
-        if (jb >= 0 && jb + 15 < Lwin && (mword & 0xFFFFu) == 0u) {
-          // every base is A C G T inside the window: one field extract and one byte store at an immediate offset per base
+        // (ONE form for every word: the window's two end words sit in some lane of every round, so a separate fast form for the
+        // interior words would only be executed in addition -- the wave runs both sides of a divergent branch)
+        const bool nfree = (mword & 0xFFFFu) == 0u;
 #pragma unroll
-          for (int k = 0; k < 16; ++k) dst[neg ? 15 - k : k] = (uint8_t)((cw >> (2 * k)) & 3u);
-        } else {
-          // the window's end words, N runs, chromosome ends: the same with a range test and the mask bit per base
-#pragma unroll
-          for (int k = 0; k < 16; ++k) {
-            const int o = neg ? 15 - k : k;
-            const uint32_t sym = ((mword >> k) & 1u) ? (uint32_t)SYM_N : ((cw >> (2 * k)) & 3u);
-            if ((unsigned)(jb + o) < (unsigned)Lwin) dst[o] = (uint8_t)sym;
-          }
+        for (int k = 0; k < 16; ++k) {
+          const int o = neg ? 15 - k : k;
+          uint32_t sym = (cw >> (2 * k)) & 3u;
+          if (!nfree) sym = ((mword >> k) & 1u) ? (uint32_t)SYM_N : sym;
+          if ((unsigned)(jb + o) < (unsigned)Lwin) dst[o] = (uint8_t)sym;
         }
       }
       if (args.genome.n_amb > 0) {            // IUPAC codes of the side table overwrite the N the mask produced
