@@ -345,14 +345,15 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
 // Upsample(4) + Conv1d(16 -> 8, k = 7) + BN as a polyphase GEMM on the source columns, the ConvBlock, + encoder skip, out_conv
 // (1x1, BN, ReLU, 1x1, Softplus) and the maximum over positions (model_indel.py:117-134, :136-149, :172-175), persistent like the
 // encoder kernel above: the 16 x 66 source columns of tile t + 1 and the skip values of tile t are requested before tile t's matrix
-// work; the polyphase / tail fragments live in LDS (one read per use), the block's in registers; the maximum over a row's positions
+// work; every fragment stays in registers (four waves per SIMD: the launch is bound by instruction issue, not latency; LDS only
+// stages them once per workgroup); the maximum over a row's positions
 // is carried in registers from tile to tile and leaves the workgroup once per row segment (the other tiles' slots get 0, the
 // identity of a maximum of Softplus values).  Tile geometry = convblock_kernel<8, true, true, true>'s polyphase form: 248 outputs.
 constexpr int D0_OUT = 248;         // = CB_FRONT_OUT_POLY (conv1d.hip): tail_max has one slot per such tile
 constexpr int D0_SPITCH = 68;       // source tile pitch (66 columns used)
 
 template <bool STAMPS>
-__global__ __launch_bounds__(256, 6) void indel_dec0_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
+__global__ __launch_bounds__(256, 4) void indel_dec0_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             int tiles_per_row, long long total_tiles, unsigned long long* stamps) {
   unsigned long long t_prev = STAMPS ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -400,6 +401,16 @@ __global__ __launch_bounds__(256, 6) void indel_dec0_kernel(const ConvBlockArgs 
   float a1w[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) a1w[q] = w1[(4 * kk + q) * E0_C + (n16 & 7)];
+  __syncthreads();
+  // (four waves per SIMD: this launch is bound by instruction issue, not by latency -- the fragments of the polyphase front, the k = 5
+  // conv and the tail stay in registers, 42 LDS reads per wave and tile less than at six waves per SIMD)
+  float afr[24], a5r[10], tfr[8];
+#pragma unroll
+  for (int s2 = 0; s2 < 24; ++s2) afr[s2] = afS[s2 * 64 + lane];
+#pragma unroll
+  for (int s2 = 0; s2 < 10; ++s2) a5r[s2] = a5S[s2 * 64 + lane];
+#pragma unroll
+  for (int s2 = 0; s2 < 8; ++s2) tfr[s2] = tS[s2 * 64 + lane];
 
   const long long first = total_tiles * (long long)blockIdx.x / (long long)gridDim.x;
   const long long last = total_tiles * ((long long)blockIdx.x + 1) / (long long)gridDim.x;
@@ -435,7 +446,6 @@ __global__ __launch_bounds__(256, 6) void indel_dec0_kernel(const ConvBlockArgs 
     int tid = threadIdx.x;
     asm volatile("" : "+v"(tid));
     const int lane = tid & 63, n16 = tid & 15, kk = (tid >> 4) & 3;
-    const int lane_o = lane;
     {
       const int ci = tid >> 4, rr0 = tid & 15;
 #pragma unroll
@@ -473,13 +483,12 @@ __global__ __launch_bounds__(256, 6) void indel_dec0_kernel(const ConvBlockArgs 
     // ---------------------------------------------------------------- polyphase front: this wave's 16 source columns -> 64 tile entries
     {
       const float* sp = fin + kk * D0_SPITCH + 16 * wave + n16;      // source column (i0 + 16 wave + n16) + d - 1 at sp[d]
-      const float* af = afS + lane_o;
       f32x4 accf[2] = {splat(0.f), splat(0.f)};
 #pragma unroll
       for (int s = 0; s < 12; ++s) {
         const float bv = sp[4 * (s & 3) * D0_SPITCH + (s >> 2)];
-        accf[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s * 64], bv, accf[0], 0, 0, 0);
-        accf[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[(12 + s) * 64], bv, accf[1], 0, 0, 0);
+        accf[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[s], bv, accf[0], 0, 0, 0);
+        accf[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(afr[12 + s], bv, accf[1], 0, 0, 0);
       }
       const int j = 64 * wave + 4 * n16;               // tile entry of phase 0 (position l0 - 4 + j)
 #pragma unroll
@@ -504,10 +513,9 @@ __global__ __launch_bounds__(256, 6) void indel_dec0_kernel(const ConvBlockArgs 
       asm volatile("" : "+v"(bo));
       const f32x4 bias5 = ld4(biasS + bo);
       f32x4 acc[4] = {bias5, bias5, bias5, bias5};
-      const float* a5l = a5S + lane_o;
 #pragma unroll
       for (int s = 0; s < 10; ++s) {
-        const float a5s = a5l[s * 64];
+        const float a5s = a5r[s];
 #pragma unroll
         for (int bk = 0; bk < 4; ++bk)
           acc[bk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5s, xb[4 * (s & 1) * E0_PITCH + 16 * bk + (s >> 1)], acc[bk], 0, 0, 0);
@@ -553,18 +561,17 @@ __global__ __launch_bounds__(256, 6) void indel_dec0_kernel(const ConvBlockArgs 
           for (int q = 0; q < 4; ++q) __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v[p][q]), ro, off, (uint32_t)q * (uint32_t)L * 4u, 0);
         }
       } else {
-        const float* tf = tS + lane_o;
         const f32x4 biasA = ld4(biasS + 32 + (bo & 4)), biasB = ld4(biasS + 40 + (bo & 4));
         f32x4 ta[2] = {biasA, biasA};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int p = 0; p < 2; ++p) ta[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[q * 64], v[p][q], ta[p], 0, 0, 0);
+          for (int p = 0; p < 2; ++p) ta[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(tfr[q], v[p][q], ta[p], 0, 0, 0);
         f32x4 u[2] = {biasB, biasB};
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-          for (int p = 0; p < 2; ++p) u[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(tf[(4 + q) * 64], fmaxf(ta[p][q], 0.f), u[p], 0, 0, 0);
+          for (int p = 0; p < 2; ++p) u[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(tfr[4 + q], fmaxf(ta[p][q], 0.f), u[p], 0, 0, 0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) rmax[q] = fmaxf(rmax[q], fmaxf(live[0] ? u[0][q] : -INFINITY, live[1] ? u[1][q] : -INFINITY));
         // Softplus is non-decreasing: the raw values are reduced, the activation applied once per row segment
