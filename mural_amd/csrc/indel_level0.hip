@@ -38,7 +38,7 @@ __device__ __forceinline__ float silu0(float v) { return v * __builtin_amdgcn_rc
 struct E0Words { uint32_t w[2], m[2]; };   // genome words of a thread's one or two columns of a tile (2-bit bases, not-ACGT mask)
 
 template <int TT, bool STAMPS, bool DOWN>
-__global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
+__global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             int tiles_per_row, long long total_tiles, unsigned long long* stamps) {
   constexpr int HW = (TT - 1) / 2;           // half width of the composed conv
@@ -137,10 +137,10 @@ __global__ __launch_bounds__(256, 6) void indel_enc0_kernel(const ConvBlockArgs 
 #pragma unroll 1
   for (long long tix = first; tix < last; ++tix) {
     const int l0 = tile_no * OUTW;
-    // (the lane's indices re-derived from an opaque copy of the thread index per iteration: hoisted out of the loop, the address pieces
-    // made from them cost twenty registers -- 59 instead of 80)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
+    // (the lane's address pieces are loop-invariant and the compiler keeps them in ~20 registers: 91 in all, five waves per SIMD --
+    // re-deriving them per tile from an opaque thread index fits seven waves per SIMD at 59 registers and is 3 % slower: the
+    // launch is bound by instruction issue, not by latency, so registers are cheaper than instructions)
+    const int tid = threadIdx.x;
     const int lane = tid & 63, n16 = tid & 15, kk = (tid >> 4) & 3;
     // ---------------------------------------------------------------- symbols of the tile's columns -> bit planes (+ bytes for the exact form)
 #pragma unroll
@@ -693,7 +693,6 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
 #define MURAL_E0_OCC(TTV, ST, DN) MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<TTV, ST, DN>, 256, 0))
     MURAL_E0_CASES(MURAL_E0_OCC)
 #undef MURAL_E0_OCC
-    // measured (rocprofv3, 2048 positions): 421 us at seven workgroups per CU, 446 us at the eight its 59 registers would allow
     wg_per_cu[v] = n > 7 ? 7 : (n > 0 ? n : 1);
   }
   static const int cap = getenv("MURAL_INDEL_ENC0_WGS") ? atoi(getenv("MURAL_INDEL_ENC0_WGS")) : 0;      // experiment: workgroups per CU

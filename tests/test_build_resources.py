@@ -114,7 +114,7 @@ def test_wave_private_training_convs_do_not_spill():
 
 def test_persistent_level0_indel_kernels_do_not_spill():
     """indel_enc0_kernel<13 | 7> / indel_dec0_kernel (csrc/indel_level0.hip), the instances that are launched outside the phase-stamp
-    diagnostics: no spill, no scratch, six (encoder) / four (decoder) waves per SIMD.  A scratch reload in their tile loop is behind a full `s_waitcnt vmcnt(0)`,
+    diagnostics: no spill, no scratch, at least four waves per SIMD.  A scratch reload in their tile loop is behind a full `s_waitcnt vmcnt(0)`,
     i.e. behind the prefetch of the NEXT tile's input -- the one wait these kernels exist to remove (the first build had four spilled
     registers and exactly that wait in the middle of its matrix phase)."""
     ks = _kernels(_report("indel_level0"))
@@ -123,5 +123,5 @@ def test_persistent_level0_indel_kernels_do_not_spill():
     assert len(run) == 5, sorted(ks)      # encoder: 13 / 7 composed taps x (plain | also emitting the next level's strided conv); decoder
     for k in run:
         r = ks[k]
-        need = 4 if "indel_dec0_kernel" in k else 6      # (the decoder launch keeps every fragment in registers: four waves per SIMD)
+        need = 4      # (both launches are bound by instruction issue: registers instead of re-derived addresses / LDS fragment reads)
         assert r["VGPRs Spill"] == 0 and r["SGPRs Spill"] == 0 and r["ScratchSize"] == 0 and r["Occupancy"] >= need, (k, r)
