@@ -1111,8 +1111,11 @@ __global__ void head_bwd_kernel(const float* __restrict__ loc, const float* __re
     if (!v[t]) continue;
     float mx = -INFINITY, sum = 0.f;
     for (int k = 0; k < nc; ++k) mx = fmaxf(mx, v[t][k]);
-    for (int k = 0; k < nc; ++k) sum += expf(v[t][k] - mx);
-    for (int k = 0; k < nc; ++k) s[t][k] = expf(v[t][k] - mx) / sum;
+    for (int k = 0; k < nc; ++k) {      // (each exponential once: the same values as exp / sum computed in two passes)
+      s[t][k] = expf(v[t][k] - mx);
+      sum += s[t][k];
+    }
+    for (int k = 0; k < nc; ++k) s[t][k] = s[t][k] / sum;
   }
   for (int k = 0; k < nc; ++k) {
     float p = (s[1][k] + s[0][k]) / 2.f;
@@ -1606,10 +1609,14 @@ __global__ __launch_bounds__(1024) void ce_sum_fwd_kernel(const float* __restric
     float m = -INFINITY;
     for (int k = 0; k < nc; ++k) m = fmaxf(m, r[k]);
     float s = 0.f;
-    for (int k = 0; k < nc; ++k) s += expf(r[k] - m);
+    for (int k = 0; k < nc; ++k) {      // (each exponential once: parked in prob, scaled below)
+      const float e = expf(r[k] - m);
+      prob[i * nc + k] = e;
+      s += e;
+    }
     const float lse = m + logf(s);
     const float inv = 1.f / s;
-    for (int k = 0; k < nc; ++k) prob[i * nc + k] = expf(r[k] - m) * inv;
+    for (int k = 0; k < nc; ++k) prob[i * nc + k] *= inv;
     const int64_t t = y[i];
     acc += (t >= 0 && t < nc) ? (double)(lse - r[t]) : (double)NAN;
   }
