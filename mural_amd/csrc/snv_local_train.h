@@ -327,7 +327,6 @@ __global__ __launch_bounds__(256) void lt_bwd_kernel(const LtBwd a) {
   for (int nb = wave; nb < nblk; nb += 4) {
     const int i = 16 * nb + m;
     const bool iv = i < I;
-    const int ii = iv ? i : I - 1;
     // Every load of a block goes through a range-checked descriptor with its offset chosen by a select (a refused element aims past
     // the descriptor and reads 0): `valid ? W[..] : 0` is compiled to a load behind a branch with a full wait of its own -- 38 serial
     // round trips per block ("a global load behind a branch costs a full wait").
