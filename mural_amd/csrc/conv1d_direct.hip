@@ -280,6 +280,7 @@ struct ConvPArgs {
   Conv1dArgs a;
   int rows, mb_total;      // GEMM rows (Cout x phases), 16-row blocks
   int segs_row, e0, gr, ss, ngroups, nslow;
+  int wide;                // 80 rows = 16 channels x 5 phases in one slice, Lout % 4 == 0: interior segments leave as 16-byte stores
   uint32_t x_bytes, y_bytes;
   DivWide dGr, dSs;
   FastDiv dPh;
@@ -317,8 +318,31 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_poly_kernel(const ConvPA
       vo[m][r] = ok ? (uint32_t)(co * a.Lout + ph * n + sub) * 4u : CD_OOB;
     }
   const uint32_t vx = (uint32_t)(kq * a.Lin + n) * 4u;
+  // Wide stores (MB == 5, g.wide): a segment's 16 channels x 80 consecutive positions go through a wave-private LDS image
+  // [channel][84] and leave as five 16-byte stores per lane.  As dwords a lane's four rows land at a stride of `phases` positions: 20
+  // scattered dword stores per lane, and the launch took 128 us of which 42 were those stores (86 us with them switched off).
+  constexpr bool WIDE = MB == 5;
+  constexpr int OBP = 84;
+  __shared__ __attribute__((aligned(16))) float obuf[WIDE ? 4 * 16 * OBP : 4];
+  uint32_t lw[WIDE ? MB : 1][4], lr[WIDE ? 5 : 1], gw[WIDE ? 5 : 1];
+  if constexpr (WIDE) {
+#pragma unroll
+    for (int m = 0; m < MB; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = 16 * m + 4 * kq + r;
+        const int co = row / 5, sub = row - 5 * co;
+        lw[m][r] = (uint32_t)(w * 16 * OBP + co * OBP + 5 * n + sub) * 4u;
+      }
+#pragma unroll
+    for (int u = 0; u < 5; ++u) {
+      const int Q = lane + 64 * u, co = Q / 20, t = Q - 20 * co;
+      lr[u] = (uint32_t)(w * 16 * OBP + co * OBP + 4 * t) * 4u;
+      gw[u] = (uint32_t)(co * a.Lout + 4 * t) * 4u;
+    }
+  }
 
-  auto finish = [&](const f32x4 (&q)[CQ], uint32_t sy, bool tail) {
+  auto finish = [&](const f32x4 (&q)[CQ], uint32_t sy, bool tail, bool interior = false) {
     f32x4 acc[MB];
 #pragma unroll
     for (int m = 0; m < MB; ++m) acc[m] = f32x4{bz[m][0], bz[m][1], bz[m][2], bz[m][3]};
@@ -338,6 +362,25 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_poly_kernel(const ConvPA
       for (int m = 0; m < MB; ++m)
 #pragma unroll
         for (int r = 0; r < 4; ++r) v[m][r] = cd_act(v[m][r], a.act);
+    }
+    if constexpr (WIDE) {
+      if (interior && g.wide) {      // (wave-uniform)
+        char* ob = reinterpret_cast<char*>(obuf);
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) *reinterpret_cast<float*>(ob + lw[m][r]) = v[m][r];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // this wave's own image: LDS executes a wave's accesses in order
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const f32x4 o4 = *reinterpret_cast<const f32x4*>(ob + lr[u]);
+          __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) uint32_t, o4), ry, gw[u], sy, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        return;
+      }
     }
 #pragma unroll
     for (int m = 0; m < MB; ++m)
@@ -363,7 +406,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_poly_kernel(const ConvPA
       const uint32_t p0 = (uint32_t)(g.e0 + ((uint32_t)grp - b * (uint32_t)g.gr) * U) * 16u;
       const uint32_t sy = (b * (uint32_t)(a.Cout * a.Lout) + (uint32_t)ph * p0) * 4u;
 #pragma unroll
-      for (int u = 0; u < U; ++u) finish(t.q[u], sy + 64u * (uint32_t)(ph * u), false);
+      for (int u = 0; u < U; ++u) finish(t.q[u], sy + 64u * (uint32_t)(ph * u), false, true);
     };
     int cur = wid;
     if (cur < g.ngroups) {
@@ -444,6 +487,7 @@ int launch_conv1d_direct_poly(const Conv1dArgs& a, hipStream_t stream) {
   g.x_bytes = (uint32_t)((uint64_t)a.B * a.Cin * a.Lin * 4);
   g.y_bytes = (uint32_t)((uint64_t)a.B * a.Cout * a.Lout * 4);
   g.dPh = FastDiv::make((uint32_t)a.phases);
+  g.wide = (mb == 5 && g.rows == 80 && a.phases == 5 && (a.Lout & 3) == 0 && a.act == ACT_NONE && !getenv("MURAL_DEBUG_POLY_NARROW")) ? 1 : 0;
   const int U = 1;
   // interior segments: the first quad starts inside the row (p0 >= pad), the last one ends inside it (p0 + 15 - pad + 3 < Lin)
   const int e0 = (a.pad + 15) / 16;
