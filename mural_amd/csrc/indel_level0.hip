@@ -655,7 +655,7 @@ static unsigned long long* l0_stamps(bool enc) {
 }
 
 bool indel_enc0_supported(const ConvBlockArgs& a) {
-  static const bool off = getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0;
+  const bool off = getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0;      // (read per launch: the tests switch it)
   return !off && a.C == 8 && a.symtab && a.e0_t3 && a.e0_t1 && a.e0_bias && a.Cf == 4 && a.f_up == 1 && (a.sym_taps == 7 || a.sym_taps == 1) &&
          a.tail_max == nullptr && a.res2 == nullptr && a.Lf == a.L;
 }
@@ -707,7 +707,7 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
 }
 
 bool indel_dec0_supported(const ConvBlockArgs& a) {
-  static const bool off = getenv("MURAL_INDEL_DEC0") && atoi(getenv("MURAL_INDEL_DEC0")) == 0;
+  const bool off = getenv("MURAL_INDEL_DEC0") && atoi(getenv("MURAL_INDEL_DEC0")) == 0;
   return !off && a.C == 8 && a.f_in != nullptr && a.symtab == nullptr && a.f_pw != nullptr && a.Cf == 16 && a.f_up == 4 && (a.L & 3) == 0 && a.Lf * 4 == a.L &&
          a.x == nullptr && (a.tail_max != nullptr || a.out != nullptr) && (a.tail_max == nullptr || (a.ta_w && a.ta_b && a.tb_w && a.tb_b));
 }

@@ -441,7 +441,7 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
     }
     // the genome-fed first level also emits the second level's strided conv (8 -> 16, k = 7, stride 4) where the shapes are the
     // persistent kernel's (indel_level0.hip); MURAL_INDEL_ENC0_DOWN=0: the conv as a launch of its own
-    static const bool down_off = (getenv("MURAL_INDEL_ENC0_DOWN") && atoi(getenv("MURAL_INDEL_ENC0_DOWN")) == 0) ||
+    const bool down_off = (getenv("MURAL_INDEL_ENC0_DOWN") && atoi(getenv("MURAL_INDEL_ENC0_DOWN")) == 0) ||
                                  (getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0);
     const bool emit_down = gs.g && m->e0_t3 && !down_off && sh.down[1] == 4 && m->up_l[1].K == 7 && m->up_l[1].Cin == 8 && m->up_l[1].Cout == 16 &&
                            (m->len[0] & 3) == 0 && m->len[1] == (m->len[0] - 1) / 4 + 1 && !getenv("MURAL_DEBUG_CONVBLOCK_VALU") &&

@@ -548,6 +548,44 @@ def test_packed_entry_decodes_inside_the_first_level(name, monkeypatch):
     assert model.forward_packed(genome, tp[:0], ts[:0], R).shape == (0, model.n_class)
 
 
+def test_level0_kernels_and_wide_stores_against_their_fallbacks(monkeypatch):
+    """The persistent level-0 launches (csrc/indel_level0.hip: composed 13-tap table front, strided conv of the next level emitted
+    by the same launch, decoder with the tail's maximum carried across tiles) and the polyphase up-conv's 16-byte stores through a
+    wave-private LDS image, each against the launch form it replaces, on the shipped human-insertion checkpoint at L = 8000 with N
+    runs and both strands: the wide stores move the same values (bit-identical scores); the strided conv, the table front and the
+    persistent decoder sum in another order (1e-5 relative)."""
+    from mural_amd.data import PackedGenome
+    fx = U.load("indel_pretrained_human_insertion.npz")
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    model.load_state_dict(U.indel_state_for(fx, orc))
+    model = model.cuda().eval()
+    R = int(fx["hp"][0])
+    rng = np.random.default_rng(11)
+    n = 6 * R + 1000
+    raw = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=n, p=[.2485, .2485, .2485, .2485, .006])
+    raw[n // 3:n // 3 + 30] = ord("N")
+    genome = PackedGenome.from_sequence(raw.tobytes().decode(), "cuda")
+    pos = torch.from_numpy(np.r_[[0, 5, n - 1, n // 3 + 4], rng.integers(0, n, size=28)]).cuda()
+    strand = (torch.arange(len(pos)) % 2).to(torch.uint8).cuda()
+
+    def run(**env):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        with torch.no_grad():
+            out = model.forward_packed(genome, pos, strand, R).cpu().numpy()
+        for k in env:
+            monkeypatch.delenv(k)
+        return out
+
+    base = run()
+    assert np.array_equal(base, run(MURAL_DEBUG_POLY_NARROW="1"))
+    same_values = run(MURAL_INDEL_ENC0_DOWN="0")
+    assert np.abs(base - same_values).max() <= 1e-5 * max(1.0, np.abs(base).max())      # (another conv engine sums the taps in another order)
+    old = run(MURAL_INDEL_ENC0="0", MURAL_INDEL_DEC0="0")
+    assert np.abs(base - old).max() <= 1e-5 * max(1.0, np.abs(base).max())
+
+
 @pytest.mark.parametrize("tag", ["rev", "norev"])
 def test_one_call_train_step_equals_per_unit_composition_and_keeps_to_its_workspace(tag, monkeypatch):
     """mural_indel_train_forward / _backward (csrc/indel_train_step.hip, one C call per direction) against the per-unit autograd
