@@ -117,6 +117,9 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream);
 // the last decoder level (polyphase front from 16 channels, + skip, with or without the out_conv tail), persistent as well
 bool indel_dec0_supported(const ConvBlockArgs& a);
 int launch_indel_dec0(const ConvBlockArgs& a, hipStream_t stream);
+// the 32-channel block on rows of up to 80 columns (the U-Net's fourth level): one row per workgroup pass (convblock_deep.hip)
+bool convblock_deep_supported(const ConvBlockArgs& a);
+int launch_convblock_deep(const ConvBlockArgs& a, hipStream_t stream);
 
 // y[b][c] = max_l x[b][c][l]
 int launch_rowmax(const float* x, int64_t rows, int L, float* y, hipStream_t stream);

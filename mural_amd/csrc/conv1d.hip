@@ -923,6 +923,7 @@ static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
 
 int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.L == 0) return MURAL_OK;
+  if (convblock_deep_supported(a)) return launch_convblock_deep(a, stream);      // 32 channels, rows of up to 80 columns
   MURAL_REQUIRE(convblock_supported(a.C), "convblock: %d channels not instantiated", a.C);
   if (a.symtab) MURAL_REQUIRE(a.Cf == 4 && a.f_up == 1 && a.C == 8 && a.sym_taps >= 1 && (a.sym_taps & 1) && a.sym_taps <= 15 && a.sym_bias &&
                               a.g_pos && a.g_strand, "convblock: the genome-fed front serves the 4-channel input of the first level");

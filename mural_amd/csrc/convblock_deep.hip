@@ -1,0 +1,169 @@
+// The 32-channel ConvBlock of the INDEL U-Net's fourth level (rows of 80 columns and fewer) as one launch.
+//
+// Reference: MuRaL/model/model_indel.py:6-19 (ConvBlock: x + BN(1x1(SiLU(BN(k5(x)))))), eval mode, BatchNorms folded on the host.  Same
+// contract as the other ConvBlock launches (ConvBlockArgs: x, w5 [32][5][64], b5, w1 [64][32], b1, optional skip res2, out).
+//
+// On rows this short the fused blocks of the long levels do not apply (a lane / a wave owns positions of ONE row: 80 columns are five
+// 16-column blocks), so the block ran as two launches of the tiled MFMA conv -- 53 + 38 us per 2048 rows for 26 us of MFMA time (4.0 GFLOP):
+// their staging is per-element vector work (25 - 39 vector instructions per MFMA), and every launch of the forward sits on its SIMDs'
+// issue time.  Here a workgroup takes one row at a time:
+//   k = 5 conv  D[64 hidden][80] = W5[hidden][(tap, ci)] x[ci][col + tap - 2]: wave w owns hidden rows 16 w .. 16 w + 15 for all five
+//               column blocks (five independent accumulators), its 40 A fragments stay in registers for the whole launch, the B operand
+//               is one ds_read_b32 of the row image per MFMA (shared by nobody: each wave needs every column of every channel);
+//   SiLU        on the accumulators, parked in LDS as the 1x1 conv's B operand;
+//   1x1 conv    D[32][80]: wave w owns output rows 16 (w % 2) .. + 15 of the column blocks w / 2, w / 2 + 2, w / 2 + 4 (16 fragments);
+//   epilogue    + block input (from the row image) + skip, 64 contiguous bytes per channel and block.
+// The next row's ten dwords per thread are requested right after the barrier that publishes this row's image and land during the two
+// matrix phases; two workgroups per CU (fragments + prefetch + five accumulators: no spill at 256 registers, 43 KB of LDS each).
+#include <cstdlib>
+
+#include "conv1d.h"
+#include "mfma_tile.h"
+
+namespace mural {
+namespace {
+
+constexpr int DB_C = 32, DB_H = 64;
+constexpr int DB_NB = 5;            // 16-column blocks of a row (L <= 80)
+constexpr int DB_PX = 112;          // row-image pitch, = 16 (mod 32) floats: the four channel rows of a B-operand read sit 16 banks apart
+constexpr int DB_PH = 112;
+
+__device__ __forceinline__ float silu_db(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
+
+template <int NBR>      // 16-column blocks of a row
+__global__ __launch_bounds__(256, 2) void convblock_deep32_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
+                                                                  const float* __restrict__ w1, const float* __restrict__ b1) {
+  __shared__ __attribute__((aligned(16))) float xS[DB_C * DB_PX + 4];  // entry j of a channel row = column j - 2 (zeros outside the row); + a dump slot
+  __shared__ __attribute__((aligned(16))) float hS[DB_H * DB_PH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
+  const int L = a.L;
+  constexpr int nbr = NBR;
+  // A fragments, lane (m = n16, kk): k = 5 conv, k-step s = (tap s / 8, channel quad s % 8): ci = 4 (s % 8) + kk
+  float a5[40], a1[16];
+#pragma unroll
+  for (int s = 0; s < 40; ++s) a5[s] = w5[((4 * (s & 7) + kk) * 5 + (s >> 3)) * DB_H + 16 * wave + n16];
+#pragma unroll
+  for (int s = 0; s < 16; ++s) a1[s] = w1[(4 * s + kk) * DB_C + 16 * (wave & 1) + n16];
+  const f32x4 bias5 = ld4(b5 + 16 * wave + 4 * kk), bias1 = ld4(b1 + 16 * (wave & 1) + 4 * kk);
+  // the image entries no row load writes: columns -2, -1 and L .. 16 nbr + 1 of every channel
+  for (int i = tid; i < DB_C * DB_PX; i += 256) {
+    const int j = i % DB_PX;
+    if (j < 2 || j >= L + 2) xS[i] = 0.f;
+  }
+  const uint32_t row_bytes = (uint32_t)DB_C * (uint32_t)L * 4u;
+
+  // LDS slot of each of this thread's ten dwords of a row (rows are [32][L] floats, dword i = tid + 256 u); past the row: the dump slot
+  int slot[10];
+#pragma unroll
+  for (int u = 0; u < 10; ++u) {
+    const int i = tid + 256 * u, ci = i / L;
+    slot[u] = i < DB_C * L ? ci * DB_PX + (i - ci * L) + 2 : DB_C * DB_PX;
+  }
+  float v[10];
+  auto request = [&](int64_t row) {      // (a row past the launch's last: a descriptor of no bytes, the loads return 0 and are never stored)
+    const bool in = row < a.B;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (in ? (size_t)row * DB_C * L : 0), 0,
+                                                                        in ? (int)row_bytes : 0, 0x00020000);
+#pragma unroll
+    for (int u = 0; u < 10; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4u * (uint32_t)(tid + 256 * u), 0, 0));
+  };
+  request(blockIdx.x);
+
+#pragma unroll 1
+  for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
+    // ------------------------------------------------------------------ the row -> LDS; the next row's ten dwords requested behind it
+#pragma unroll
+    for (int u = 0; u < 10; ++u) xS[slot[u]] = v[u];
+    __syncthreads();
+    request(row + gridDim.x);
+    // the skip operand of this wave's output blocks (up to twelve dwords per lane), requested before the matrix phases as well
+    const int mb = wave & 1;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res2 ? a.res2 + (size_t)row * DB_C * L : w5), 0,
+                                                                        a.res2 ? (int)row_bytes : 0, 0x00020000);
+    float sk[3][4];
+    uint32_t off[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int nb = (wave >> 1) + 2 * i, col = 16 * nb + n16;
+      off[i] = col < L ? ((uint32_t)(16 * mb + 4 * kk) * (uint32_t)L + (uint32_t)col) * 4u : 0x80000000u;      // (past the row: no access)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sk[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[i], (uint32_t)r * (uint32_t)L * 4u, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // ------------------------------------------------------------------ k = 5 conv + SiLU: this wave's 16 hidden rows, every column block
+    {
+      const float* xb = xS + kk * DB_PX + n16;
+      f32x4 acc[NBR];
+#pragma unroll
+      for (int nb = 0; nb < NBR; ++nb) acc[nb] = bias5;
+#pragma unroll
+      for (int s = 0; s < 40; ++s) {
+#pragma unroll
+        for (int nb = 0; nb < NBR; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5[s], xb[4 * (s & 7) * DB_PX + 16 * nb + (s >> 3)], acc[nb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int nb = 0; nb < NBR; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hS[(16 * wave + 4 * kk + r) * DB_PH + 16 * nb + n16] = silu_db(acc[nb][r]);
+      }
+    }
+    __syncthreads();
+    // ------------------------------------------------------------------ 1x1 conv, + block input, + skip, out
+    {
+      const float* hb = hS + kk * DB_PH + n16;
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)row * DB_C * L, 0, (int)row_bytes, 0x00020000);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int nb = (wave >> 1) + 2 * i;
+        if (nb < nbr) {      // (wave-uniform)
+          const int col = 16 * nb + n16;
+          f32x4 o = bias1;
+#pragma unroll
+          for (int s = 0; s < 16; ++s) o = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s], hb[4 * s * DB_PH + 16 * nb], o, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float v = (o[r] + xS[(16 * mb + 4 * kk + r) * DB_PX + col + 2]) + sk[i][r];
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, v), ro, off[i], (uint32_t)r * (uint32_t)L * 4u, 0);
+          }
+        }
+      }
+    }
+    __syncthreads();      // the next row's load overwrites the image
+  }
+}
+
+}  // namespace
+
+bool convblock_deep_supported(const ConvBlockArgs& a) {
+  const bool off = getenv("MURAL_INDEL_DEEP") && atoi(getenv("MURAL_INDEL_DEEP")) == 0;
+  return !off && a.C == DB_C && a.L >= 1 && a.L <= 16 * DB_NB && a.x != nullptr && a.out != nullptr && a.f_in == nullptr && a.symtab == nullptr &&
+         a.tail_max == nullptr && (uint64_t)a.C * a.L * 4 < (1ull << 31);
+}
+
+int launch_convblock_deep(const ConvBlockArgs& a, hipStream_t stream) {
+  if (a.B == 0) return MURAL_OK;
+  static int cap = 0;
+  if (cap == 0) {
+    int dev = 0, n = 0;
+    hipDeviceProp_t prop;
+    MURAL_HIP_CHECK(hipGetDevice(&dev));
+    MURAL_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, convblock_deep32_kernel<DB_NB>, 256, 0));
+    cap = prop.multiProcessorCount * (n > 0 ? n : 1);
+  }
+  const dim3 grid((unsigned)(a.B < cap ? a.B : cap));
+#define MURAL_DEEP_CASE(N) \
+  case N: hipLaunchKernelGGL(convblock_deep32_kernel<N>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+  switch ((a.L + 15) >> 4) {
+    MURAL_DEEP_CASE(1) MURAL_DEEP_CASE(2) MURAL_DEEP_CASE(3) MURAL_DEEP_CASE(4) MURAL_DEEP_CASE(5)
+    default: MURAL_REQUIRE(false, "internal: deep ConvBlock launched on rows of more than 80 columns");
+  }
+#undef MURAL_DEEP_CASE
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+}  // namespace mural

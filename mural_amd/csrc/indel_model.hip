@@ -355,6 +355,13 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
     return launch_convblock(a, stream);
   }
   MURAL_REQUIRE(!tail_max && !ff, "internal: front / tail fusion requested for an unfusable block");
+  if (f5.K == 5 && f1.K == 1 && f5.Cout == 2 * f5.Cin && f1.Cout == f5.Cin) {      // short rows: one row per workgroup pass (convblock_deep.hip)
+    ConvBlockArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.x = x; a.w5 = m->blob + f5.w; a.b5 = m->blob + f5.b; a.w1 = m->blob + f1.w; a.b1 = m->blob + f1.b;
+    a.res2 = skip; a.out = out; a.B = B; a.C = f5.Cin; a.L = L;
+    if (convblock_deep_supported(a)) return launch_convblock_deep(a, stream);
+  }
   if (int rc = run_conv(m, f5, x, B, L, H, L, 1, 1, ACT_SILU, nullptr, nullptr, stream)) return rc;
   return run_conv(m, f1, H, B, L, out, L, 1, 1, ACT_NONE, x, skip, stream);
 }

@@ -467,7 +467,8 @@ def test_fused_convblock_forms_match_torch_fp64():
     # twice: the library's routing (small launches of the 16 / 24-channel block on the LDS-tiled kernel), then its barrier-free form
     # forced for every size (rows that are all edge segments, ragged rows)
     # (and once with the persistent level-0 kernels of indel_level0.hip off: the split form's own polyphase / genome-fed fronts)
-    for extra in ({}, {"MURAL_CONVBLOCK_DIRECT": "2"}, {"MURAL_INDEL_DEC0": "0", "MURAL_INDEL_ENC0": "0"}):
+    # (and the 32-channel block on rows of 1 .. 80 columns, one row per workgroup pass: convblock_deep.hip, DEEP=1 selects those cases)
+    for extra in ({}, {"MURAL_CONVBLOCK_DIRECT": "2"}, {"MURAL_INDEL_DEC0": "0", "MURAL_INDEL_ENC0": "0"}, {"DEEP": "1"}):
         out = subprocess.run([sys.executable, tool], capture_output=True, text=True, timeout=900, env={**env, **extra})
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-2000:]
         assert "worst" in out.stdout
@@ -553,7 +554,7 @@ def test_level0_kernels_and_wide_stores_against_their_fallbacks(monkeypatch):
     by the same launch, decoder with the tail's maximum carried across tiles) and the polyphase up-conv's 16-byte stores through a
     wave-private LDS image, each against the launch form it replaces, on the shipped human-insertion checkpoint at L = 8000 with N
     runs and both strands: the wide stores move the same values (bit-identical scores); the strided conv, the table front and the
-    persistent decoder sum in another order (1e-5 relative)."""
+    persistent decoder sum in another order (1e-5 relative); so does the one-launch 32-channel block of the fourth level."""
     from mural_amd.data import PackedGenome
     fx = U.load("indel_pretrained_human_insertion.npz")
     model = product_from(fx)
@@ -584,6 +585,8 @@ def test_level0_kernels_and_wide_stores_against_their_fallbacks(monkeypatch):
     assert np.abs(base - same_values).max() <= 1e-5 * max(1.0, np.abs(base).max())      # (another conv engine sums the taps in another order)
     old = run(MURAL_INDEL_ENC0="0", MURAL_INDEL_DEC0="0")
     assert np.abs(base - old).max() <= 1e-5 * max(1.0, np.abs(base).max())
+    two_launches = run(MURAL_INDEL_DEEP="0")      # the 32-channel block of the fourth level as two tiled convs (csrc/convblock_deep.hip)
+    assert np.abs(base - two_launches).max() <= 1e-5 * max(1.0, np.abs(base).max())
 
 
 @pytest.mark.parametrize("tag", ["rev", "norev"])

@@ -85,6 +85,9 @@ if __name__ == "__main__":
                             cases.append((form, B, C, L, front, skip, tail, False))
                             if front == (16, 4) and C == 8:
                                 cases.append((form, B, C, L, front, skip, tail, True))      # polyphase weights handed over
+    if os.environ.get("DEEP"):      # the 32-channel block on short rows (convblock_deep.hip) only
+        cases = [(-1, B, 32, L, None, skip, False, False) for (B, L) in ((3, 80), (700, 80), (5, 79), (2, 64), (4, 37), (3, 16), (2, 5), (1, 1), (2000, 80))
+                 for skip in (False, True)]
     for i, c in enumerate(cases):
         err, _ = run(*c[:7], seed=i, poison=0x100, poly=c[7])
         bad = not (err <= 3e-6)
@@ -92,7 +95,18 @@ if __name__ == "__main__":
         if bad or os.environ.get("VERBOSE"):
             print(c, "err %.2e" % err, "<-- BAD" if bad else "", flush=True)
     print("cases %d worst %.2e" % (len(cases), worst))
-    if os.environ.get("TIME"):
+    if os.environ.get("TIME") and os.environ.get("DEEP"):
+        for skip in (False, True):
+            _, call = run(-1, 2048, 32, 80, None, skip, False, seed=1)
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(50):
+                call()
+            torch.cuda.synchronize()
+            print("C 32 L 80 skip", skip, "%.1f us" % ((time.perf_counter() - t) / 50 * 1e6), flush=True)
+    elif os.environ.get("TIME"):
         for Cc, Lc in ((16, 2000), (24, 400)):
             for skip in (False, True):
                 _, call = run(-1, 2048, Cc, Lc, None, skip, False, seed=1)
