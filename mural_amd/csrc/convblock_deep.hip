@@ -135,16 +135,174 @@ __global__ __launch_bounds__(256, 2) void convblock_deep32_kernel(const ConvBloc
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The two deepest levels (40 channels x 16 columns, 48 channels x 8 columns): a row is one 16-column block or half of one, so the
+// column blocks of a workgroup pass are ROWS -- NW = 2 C / 16 waves (5 / 6), wave w owns hidden rows 16 w .. 16 w + 15 of the k = 5
+// conv for the pass's NW column blocks (5 rows of 16 columns / 12 rows of 8), then the whole 1x1 conv (three 16-row blocks, the last
+// padded with zero weights) of column block w.  A channel row of the image holds the pass's rows side by side, each with its own two
+// zero columns on either side, so the taps of one row never read its neighbour.  Before: two launches of the tiled conv per block,
+// 22 + 14 us for 1 - 2 us of matrix work each.
+template <int C, int L>
+struct TinyGeo {
+  static constexpr int H = 2 * C, NW = H / 16, MB2 = (C + 15) / 16, KS5 = C * 5 / 4, KS1 = H / 4;
+  static constexpr int RPB = 16 / L, RP = NW * RPB, W = L + 4;      // rows per column block / per pass, width of a row image
+  static constexpr int PX = ((RP * W + 31) / 32) * 32 + 16;         // pitches = 16 (mod 32)
+  static constexpr int PH = ((16 * NW + 31) / 32) * 32 + 16;
+  static constexpr int PER = (RP * C * L + 64 * NW - 1) / (64 * NW); // dwords of a pass per thread
+  static_assert(C % 4 == 0 && 16 % L == 0 && H % 16 == 0, "geometry");
+};
+
+template <int C, int L, int NT = 64 * (2 * C / 16)>
+__global__ __launch_bounds__(NT, 1) void convblock_tiny_kernel(const ConvBlockArgs a, const float* __restrict__ w5,
+                                                                                  const float* __restrict__ b5, const float* __restrict__ w1,
+                                                                                  const float* __restrict__ b1) {
+  using G = TinyGeo<C, L>;
+  static_assert(NT == 64 * G::NW, "one wave per 16 hidden rows");
+  __shared__ __attribute__((aligned(16))) float xS[C * G::PX + 4];
+  __shared__ __attribute__((aligned(16))) float hS[G::H * G::PH];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int n16 = lane & 15, kk = lane >> 4;
+  constexpr uint32_t ROWB = (uint32_t)C * L * 4u;
+  float v[G::PER];
+  auto request = [&](int64_t row0) {      // rows past the batch: outside the descriptor, the loads return 0
+    const int64_t left = a.B - row0;
+    const int rows = left <= 0 ? 0 : (left < G::RP ? (int)left : G::RP);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (rows ? (size_t)row0 * C * L : 0), 0,
+                                                                        (int)(rows * ROWB), 0x00020000);
+#pragma unroll
+    for (int u = 0; u < G::PER; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4u * (uint32_t)(tid + NT * u), 0, 0));
+  };
+  request((int64_t)blockIdx.x * G::RP);
+  // k = 5 fragments in registers; the 1x1 conv's (72 per lane at 48 channels: five / six waves share four SIMDs, 256 registers each) in
+  // LDS, padded to whole 16-row blocks with zeros
+  __shared__ __attribute__((aligned(16))) float w1S[G::H * 16 * G::MB2];
+  float a5[G::KS5];
+#pragma unroll
+  for (int s = 0; s < G::KS5; ++s) a5[s] = w5[((4 * (s % (C / 4)) + kk) * 5 + s / (C / 4)) * G::H + 16 * wave + n16];
+  for (int i = tid; i < G::H * 16 * G::MB2; i += NT) {
+    const int k = i / (16 * G::MB2), c = i % (16 * G::MB2);
+    w1S[i] = c < C ? w1[k * C + c] : 0.f;
+  }
+  const f32x4 bias5 = ld4(b5 + 16 * wave + 4 * kk);
+  __shared__ __attribute__((aligned(16))) float b1S[16 * G::MB2];
+  if (tid < 16 * G::MB2) b1S[tid] = tid < C ? b1[tid] : 0.f;
+  for (int i = tid; i < C * G::PX + 4; i += NT) xS[i] = 0.f;      // (the zero columns stay; the row loads overwrite the rest each pass)
+  __syncthreads();
+  const int lane_x = (n16 / L) * G::W + n16 % L;      // this lane's column inside a column block's row images
+
+#pragma unroll 1
+  for (int64_t row0 = (int64_t)blockIdx.x * G::RP; row0 < a.B; row0 += (int64_t)gridDim.x * G::RP) {
+    {
+      // LDS slot of each of this thread's dwords of a pass (RP rows of [C][L] floats, contiguous in memory); derived per pass from an
+      // opaque thread index: twelve hoisted slots are twelve registers this kernel does not have
+      int t = tid;
+      asm volatile("" : "+v"(t));
+#pragma unroll
+      for (int u = 0; u < G::PER; ++u) {
+        const int i = t + NT * u, rr = i / (C * L), ci = (i / L) % C, col = i % L;
+        xS[i < G::RP * C * L ? ci * G::PX + rr * G::W + col + 2 : C * G::PX] = v[u];
+      }
+    }
+    __syncthreads();
+    request(row0 + (int64_t)gridDim.x * G::RP);
+    // skip operand of this wave's column block (rows row0 + RPB wave ..), every output channel block
+    const int64_t left = a.B - row0;
+    const int rows = left < G::RP ? (int)left : G::RP;
+    const __amdgpu_buffer_rsrc_t rk = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.res2 ? a.res2 + (size_t)row0 * C * L : w5), 0,
+                                                                        a.res2 ? (int)(rows * ROWB) : 0, 0x00020000);
+    const int rr = wave * G::RPB + n16 / L;            // this lane's row of the pass in the 1x1 phase
+    float sk[G::MB2][4];
+    uint32_t off[G::MB2];
+#pragma unroll
+    for (int mb = 0; mb < G::MB2; ++mb) {
+      const int c0 = 16 * mb + 4 * kk;
+      off[mb] = c0 < C ? (uint32_t)((rr * C + c0) * L + n16 % L) * 4u : 0x80000000u;      // (C % 4 == 0: a lane's four channels are in or out together)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sk[mb][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[mb], (uint32_t)r * L * 4u, 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      const float* xb = xS + kk * G::PX + lane_x;
+      f32x4 acc[G::NW];
+#pragma unroll
+      for (int nb = 0; nb < G::NW; ++nb) acc[nb] = bias5;
+#pragma unroll
+      for (int s = 0; s < G::KS5; ++s) {
+#pragma unroll
+        for (int nb = 0; nb < G::NW; ++nb)
+          acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5[s], xb[4 * (s % (C / 4)) * G::PX + nb * G::RPB * G::W + s / (C / 4)], acc[nb], 0, 0, 0);
+        if (s % 6 == 5) __builtin_amdgcn_sched_barrier(0);      // (keeps the operand reads from running a hundred registers ahead)
+      }
+#pragma unroll
+      for (int nb = 0; nb < G::NW; ++nb) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) hS[(16 * wave + 4 * kk + r) * G::PH + 16 * nb + n16] = silu_db(acc[nb][r]);
+      }
+    }
+    __syncthreads();
+    {
+      const float* hb = hS + kk * G::PH + 16 * wave + n16;
+      const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)row0 * C * L, 0, (int)(rows * ROWB), 0x00020000);
+      f32x4 o[G::MB2];
+#pragma unroll
+      for (int mb = 0; mb < G::MB2; ++mb) o[mb] = *reinterpret_cast<const f32x4*>(b1S + 16 * mb + 4 * kk);
+#pragma unroll
+      for (int s = 0; s < G::KS1; ++s) {
+        const float h = hb[4 * s * G::PH];
+#pragma unroll
+        for (int mb = 0; mb < G::MB2; ++mb)
+          o[mb] = __builtin_amdgcn_mfma_f32_16x16x4f32(w1S[(4 * s + kk) * 16 * G::MB2 + 16 * mb + n16], h, o[mb], 0, 0, 0);
+      }
+#pragma unroll
+      for (int mb = 0; mb < G::MB2; ++mb) {
+        const int c0 = 16 * mb + 4 * kk;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float xin = xS[(c0 + r < C ? c0 + r : 0) * G::PX + rr * G::W + n16 % L + 2];
+          const float val = (o[mb][r] + xin) + sk[mb][r];
+          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, val), ro, off[mb], (uint32_t)r * L * 4u, 0);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int C, int L>
+int launch_tiny(const ConvBlockArgs& a, hipStream_t stream) {
+  using G = TinyGeo<C, L>;
+  const int64_t passes = (a.B + G::RP - 1) / G::RP;
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    hipDeviceProp_t prop;
+    MURAL_HIP_CHECK(hipGetDevice(&dev));
+    MURAL_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
+    (void)n;      // (two workgroups per CU where they fit: measured slower, 36.6 vs 32.8 us at 40 channels -- the weights' traffic doubles)
+    cus = prop.multiProcessorCount;
+  }
+  const dim3 grid((unsigned)(passes < cus ? passes : cus));
+  hipLaunchKernelGGL((convblock_tiny_kernel<C, L>), grid, dim3(64 * G::NW), 0, stream, a, a.w5, a.b5, a.w1, a.b1);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
+}
+
+bool tiny_geometry(int C, int L) { return (C == 40 && L == 16) || (C == 48 && L == 8); }
+
 }  // namespace
 
 bool convblock_deep_supported(const ConvBlockArgs& a) {
   const bool off = getenv("MURAL_INDEL_DEEP") && atoi(getenv("MURAL_INDEL_DEEP")) == 0;
-  return !off && a.C == DB_C && a.L >= 1 && a.L <= 16 * DB_NB && a.x != nullptr && a.out != nullptr && a.f_in == nullptr && a.symtab == nullptr &&
+  const bool geo = (a.C == DB_C && a.L >= 1 && a.L <= 16 * DB_NB) || tiny_geometry(a.C, a.L);
+  return !off && geo && a.x != nullptr && a.out != nullptr && a.f_in == nullptr && a.symtab == nullptr &&
          a.tail_max == nullptr && (uint64_t)a.C * a.L * 4 < (1ull << 31);
 }
 
 int launch_convblock_deep(const ConvBlockArgs& a, hipStream_t stream) {
   if (a.B == 0) return MURAL_OK;
+  if (a.C == 40) return launch_tiny<40, 16>(a, stream);
+  if (a.C == 48) return launch_tiny<48, 8>(a, stream);
   static int cap = 0;
   if (cap == 0) {
     int dev = 0, n = 0;

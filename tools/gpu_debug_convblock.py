@@ -88,6 +88,9 @@ if __name__ == "__main__":
     if os.environ.get("DEEP"):      # the 32-channel block on short rows (convblock_deep.hip) only
         cases = [(-1, B, 32, L, None, skip, False, False) for (B, L) in ((3, 80), (700, 80), (5, 79), (2, 64), (4, 37), (3, 16), (2, 5), (1, 1), (2000, 80))
                  for skip in (False, True)]
+        # ... and the two deepest levels (40 channels x 16 columns, 48 x 8: a pass takes 5 / 12 rows; ragged last passes)
+        cases += [(-1, B, C, L, None, skip, False, False) for (C, L) in ((40, 16), (48, 8)) for B in (1, 3, 5, 7, 12, 13, 29, 700, 2048)
+                  for skip in (False, True)]
     for i, c in enumerate(cases):
         err, _ = run(*c[:7], seed=i, poison=0x100, poly=c[7])
         bad = not (err <= 3e-6)
@@ -106,6 +109,16 @@ if __name__ == "__main__":
                 call()
             torch.cuda.synchronize()
             print("C 32 L 80 skip", skip, "%.1f us" % ((time.perf_counter() - t) / 50 * 1e6), flush=True)
+        for Cc, Lc in ((40, 16), (48, 8)):
+            _, call = run(-1, 2048, Cc, Lc, None, True, False, seed=1)
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(50):
+                call()
+            torch.cuda.synchronize()
+            print("C", Cc, "L", Lc, "skip True %.1f us" % ((time.perf_counter() - t) / 50 * 1e6), flush=True)
     elif os.environ.get("TIME"):
         for Cc, Lc in ((16, 2000), (24, 400)):
             for skip in (False, True):
