@@ -100,6 +100,27 @@ __global__ void indel_head_kernel(const float* __restrict__ feat, int64_t n, int
   }
   out[i] = acc > 20.f ? acc : log1pf(expf(acc));
 }
+
+// The same with one wave per row (C a power of two <= 64, n_class <= 64): the row's parts x C partial maxima are one coalesced sweep
+// (lane l always meets channel l % C), the lanes of a channel fold by shuffles, lane k < n_class finishes class k.  The thread-per-
+// (row, class) form above walks 33 x 8 strided loads per thread on 64 workgroups: 37 us per 2048 rows of the shipped geometry.
+__global__ __launch_bounds__(256) void indel_head_wave_kernel(const float* __restrict__ feat, int64_t n, int parts, int C, int n_class,
+                                                              const float* __restrict__ w, const float* __restrict__ b, float* __restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= n) return;
+  const float* f = feat + row * parts * C;
+  const int total = parts * C;
+  float m = -INFINITY;
+  for (int i = lane; i < total; i += 64) m = fmaxf(m, f[i]);
+  for (int off = 32; off >= C; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));      // lanes l, l + C, l + 2 C, ...: one channel
+  float acc = lane < n_class ? b[lane] : 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float mc = __shfl(m, c, 64);
+    if (lane < n_class) acc = fmaf(w[lane * C + c], mc, acc);
+  }
+  if (lane < n_class) out[row * n_class + lane] = acc > 20.f ? acc : log1pf(expf(acc));
+}
 }  // namespace mural
 
 extern "C" int mural_indel_model_create(const MuralIndelShape* shape, const MuralIndelParams* hp, MuralIndelModel** out) {
@@ -499,6 +520,10 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
       if ((rc = launch_rowmax(sp, (int64_t)B * C0, Lcur, M, stream))) return rc;
     }
     const int64_t total = (int64_t)B * sh.n_class;
+    if (C0 <= 64 && (C0 & (C0 - 1)) == 0 && sh.n_class <= 64)
+      hipLaunchKernelGGL(indel_head_wave_kernel, dim3((unsigned)((B + 3) / 4)), dim3(256), 0, stream, M, (int64_t)B, tail_done ? mparts : 1, C0,
+                         sh.n_class, m->blob + m->fc_w, m->blob + m->fc_b, out + c0 * sh.n_class);
+    else
     hipLaunchKernelGGL(indel_head_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, stream, M, (int64_t)B,
                        tail_done ? mparts : 1, C0,
                        sh.n_class, m->blob + m->fc_w, m->blob + m->fc_b, out + c0 * sh.n_class);
