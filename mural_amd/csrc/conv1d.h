@@ -66,6 +66,7 @@ struct ConvBlockArgs {
   const float* f_w;
   const float* f_b;
   int Cf, Lf, f_up;
+  int f_stride;          // convblock_deep.hip only (0 / 1 elsewhere): the front is a STRIDED k=7 conv, L == (Lf - 1) / f_stride + 1, f_up == 1
   const float* f_pw;     // optional (f_up == 4): polyphase front weights [4 phases][Cf][3][C] (taps summed per source column)
   // optional source of the front input (first encoder level, Cf == 4, f_up == 1): instead of reading f_in, the workgroup decodes its
   // span of the window from the packed genome (site g_pos[b], strand g_strand[b], window origin g_off) and evaluates the layer in

@@ -30,11 +30,22 @@ constexpr int DB_PH = 112;
 
 __device__ __forceinline__ float silu_db(float v) { return v * __builtin_amdgcn_rcpf(1.f + __expf(-v)); }
 
-template <int NBR>      // 16-column blocks of a row
+// FRONT: the block input is not read but produced here as the level's strided k = 7 conv (Cf <= 24 channels -> 32, stride f_stride, pad 3,
+// BatchNorm folded) of the row above -- the encoder's fourth level, 24 x 400 -> 32 x 80 at stride 5: the source row (with three zero
+// columns on either side) takes the place of the hidden tile in LDS (dead before the k = 5 phase writes it), the conv is 42 k-steps
+// of the same MFMA with the operand read at a lane stride of `f_stride` floats (5: conflict-free), wave w: output rows 16 (w % 2) ..,
+// column blocks w / 2, + 2, + 4.  The next source row travels in registers (ten 16-byte pieces per thread) under the matrix phases.
+// Before: a launch of the tiled conv, 63 us per 2048 rows at 26 vector instructions per MFMA.
+constexpr int DB_FC = 24, DB_PF = 432;      // front channels (max), source-row pitch: = 16 (mod 32), >= Lf + 6
+constexpr int DB_FQ = 10;                   // 16-byte pieces of a source row per thread
+
+template <int NBR, bool FRONT>      // 16-column blocks of a row
 __global__ __launch_bounds__(256, 2) void convblock_deep32_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
-                                                                  const float* __restrict__ w1, const float* __restrict__ b1) {
+                                                                  const float* __restrict__ w1, const float* __restrict__ b1,
+                                                                  const float* __restrict__ fw, const float* __restrict__ fb) {
   __shared__ __attribute__((aligned(16))) float xS[DB_C * DB_PX + 4];  // entry j of a channel row = column j - 2 (zeros outside the row); + a dump slot
-  __shared__ __attribute__((aligned(16))) float hS[DB_H * DB_PH];
+  constexpr int HF = FRONT && DB_FC * DB_PF + 4 > DB_H * DB_PH ? DB_FC * DB_PF + 4 : DB_H * DB_PH;
+  __shared__ __attribute__((aligned(16))) float hS[HF];      // the hidden tile; FRONT: first the source row, entry j of a channel = column j - 3
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = lane & 15, kk = lane >> 4;
@@ -53,6 +64,22 @@ __global__ __launch_bounds__(256, 2) void convblock_deep32_kernel(const ConvBloc
     if (j < 2 || j >= L + 2) xS[i] = 0.f;
   }
   const uint32_t row_bytes = (uint32_t)DB_C * (uint32_t)L * 4u;
+  // front: 7 (Cf / 4) fragments, k-step s = (tap s / (Cf / 4), channel quad s % (Cf / 4)); channels past Cf: zero weights
+  const int Cf = FRONT ? a.Cf : 0, Lf = FRONT ? a.Lf : 0, fst = FRONT ? a.f_stride : 1;
+  // (in LDS, fragment-major [k-step][row block][lane]: 42 more registers beside 56 fragments, the travelling source row and five
+  // accumulators spilled 41)
+  constexpr int FKS = 7 * (DB_FC / 4);
+  __shared__ __attribute__((aligned(16))) float afS[FRONT ? FKS * 2 * 64 : 4];
+  f32x4 biasf = {0.f, 0.f, 0.f, 0.f};
+  if constexpr (FRONT) {
+    for (int i = tid; i < FKS * 2 * 64; i += 256) {
+      const int fs = i >> 7, fmb = (i >> 6) & 1, fl = i & 63, ci = 4 * (fs % (DB_FC / 4)) + (fl >> 4);
+      afS[i] = ci < Cf ? fw[(ci * 7 + fs / (DB_FC / 4)) * DB_C + 16 * fmb + (fl & 15)] : 0.f;
+    }
+    biasf = ld4(fb + 16 * (wave & 1) + 4 * kk);
+    for (int i = tid; i < DB_FC * DB_PF + 4; i += 256) hS[i] = 0.f;      // (zero columns around the source row, zero rows past Cf)
+  }
+  const uint32_t frow_bytes = (uint32_t)Cf * (uint32_t)Lf * 4u;
 
   // LDS slot of each of this thread's ten dwords of a row (rows are [32][L] floats, dword i = tid + 256 u); past the row: the dump slot
   int slot[10];
@@ -61,21 +88,51 @@ __global__ __launch_bounds__(256, 2) void convblock_deep32_kernel(const ConvBloc
     const int i = tid + 256 * u, ci = i / L;
     slot[u] = i < DB_C * L ? ci * DB_PX + (i - ci * L) + 2 : DB_C * DB_PX;
   }
-  float v[10];
+  float v[FRONT ? 1 : 10];
+  f32x4 vq[FRONT ? DB_FQ : 1];
   auto request = [&](int64_t row) {      // (a row past the launch's last: a descriptor of no bytes, the loads return 0 and are never stored)
     const bool in = row < a.B;
-    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (in ? (size_t)row * DB_C * L : 0), 0,
-                                                                        in ? (int)row_bytes : 0, 0x00020000);
+    if constexpr (FRONT) {
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.f_in) + (in ? (size_t)row * Cf * Lf : 0), 0,
+                                                                          in ? (int)frow_bytes : 0, 0x00020000);
 #pragma unroll
-    for (int u = 0; u < 10; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4u * (uint32_t)(tid + 256 * u), 0, 0));
+      for (int u = 0; u < DB_FQ; ++u) vq[u] = buf_ld4(rx, 16u * (uint32_t)(tid + 256 * u));
+    } else {
+      const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x) + (in ? (size_t)row * DB_C * L : 0), 0,
+                                                                          in ? (int)row_bytes : 0, 0x00020000);
+#pragma unroll
+      for (int u = 0; u < 10; ++u) v[u] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rx, 4u * (uint32_t)(tid + 256 * u), 0, 0));
+    }
   };
+  if constexpr (FRONT) __syncthreads();      // (the zero fill of the source-row image is complete before the first row lands in it)
   request(blockIdx.x);
 
 #pragma unroll 1
   for (int64_t row = blockIdx.x; row < a.B; row += gridDim.x) {
     // ------------------------------------------------------------------ the row -> LDS; the next row's ten dwords requested behind it
+    if constexpr (FRONT) {
+      int t = tid;      // (per row from an opaque index: ten hoisted offsets are ten registers)
+      asm volatile("" : "+v"(t));
 #pragma unroll
-    for (int u = 0; u < 10; ++u) xS[slot[u]] = v[u];
+      for (int u = 0; u < DB_FQ; ++u) {
+        const int e = 4 * (t + 256 * u);      // (Lf % 4 == 0: a piece stays inside its channel row)
+        if (e < Cf * Lf) {
+          const int ci = e / Lf, col = e - ci * Lf;
+          float* d = hS + ci * DB_PF + col + 3;
+          d[0] = vq[u][0]; d[1] = vq[u][1]; d[2] = vq[u][2]; d[3] = vq[u][3];
+        }
+      }
+      // the zero columns around the row: the previous row's hidden tile has been here (channel rows past Cf keep whatever finite
+      // values it left: their weights are zero)
+      const int gap = DB_PF - Lf;      // entries Lf + 3 .. PF - 1 and 0 .. 2 of every channel row
+      for (int i = t; i < Cf * gap; i += 256) {
+        const int ci = i / gap, j = i - ci * gap;
+        hS[ci * DB_PF + (j < 3 ? j : Lf + j)] = 0.f;
+      }
+    } else {
+#pragma unroll
+      for (int u = 0; u < 10; ++u) xS[slot[u]] = v[u];
+    }
     __syncthreads();
     request(row + gridDim.x);
     // the skip operand of this wave's output blocks (up to twelve dwords per lane), requested before the matrix phases as well
@@ -92,6 +149,30 @@ __global__ __launch_bounds__(256, 2) void convblock_deep32_kernel(const ConvBloc
       for (int r = 0; r < 4; ++r) sk[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rk, off[i], (uint32_t)r * (uint32_t)L * 4u, 0));
     }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (FRONT) {
+      // ---------------------------------------------------------------- the strided k = 7 conv of the source row -> the block's input image
+      const float* fbase = hS + kk * DB_PF + fst * n16;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int nb = (wave >> 1) + 2 * i;
+        if (nb < nbr) {      // (wave-uniform)
+          f32x4 o = biasf;
+          const float* fp = fbase + fst * 16 * nb;
+#pragma unroll
+          for (int s = 0; s < FKS; ++s)
+          {
+            o = __builtin_amdgcn_mfma_f32_16x16x4f32(afS[(2 * s + mb) * 64 + lane], fp[4 * (s % (DB_FC / 4)) * DB_PF + s / (DB_FC / 4)], o, 0, 0, 0);
+            if (s % 6 == 5) __builtin_amdgcn_sched_barrier(0);
+          }
+          const int col = 16 * nb + n16;
+          if (col < L) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) xS[(16 * mb + 4 * kk + r) * DB_PX + col + 2] = o[r];
+          }
+        }
+      }
+      __syncthreads();
+    }
     // ------------------------------------------------------------------ k = 5 conv + SiLU: this wave's 16 hidden rows, every column block
     {
       const float* xb = xS + kk * DB_PX + n16;
@@ -103,6 +184,7 @@ __global__ __launch_bounds__(256, 2) void convblock_deep32_kernel(const ConvBloc
 #pragma unroll
         for (int nb = 0; nb < NBR; ++nb)
           acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a5[s], xb[4 * (s & 7) * DB_PX + 16 * nb + (s >> 3)], acc[nb], 0, 0, 0);
+        if (FRONT && (s & 7) == 7) __builtin_amdgcn_sched_barrier(0);      // (keeps the operand reads from running dozens of registers ahead)
       }
 #pragma unroll
       for (int nb = 0; nb < NBR; ++nb) {
@@ -295,7 +377,14 @@ bool tiny_geometry(int C, int L) { return (C == 40 && L == 16) || (C == 48 && L 
 bool convblock_deep_supported(const ConvBlockArgs& a) {
   const bool off = getenv("MURAL_INDEL_DEEP") && atoi(getenv("MURAL_INDEL_DEEP")) == 0;
   const bool geo = (a.C == DB_C && a.L >= 1 && a.L <= 16 * DB_NB) || tiny_geometry(a.C, a.L);
-  return !off && geo && a.x != nullptr && a.out != nullptr && a.f_in == nullptr && a.symtab == nullptr &&
+  bool input = a.x != nullptr && a.f_in == nullptr;
+  if (a.f_in != nullptr && a.C == DB_C) {      // the strided k = 7 front (convblock_deep32_kernel<., true>)
+    const bool foff = getenv("MURAL_INDEL_DEEP_FRONT") && atoi(getenv("MURAL_INDEL_DEEP_FRONT")) == 0;
+    input = !foff && a.f_w && a.f_b && a.f_up == 1 && a.f_pw == nullptr && a.f_stride >= 1 && a.f_stride <= 8 && a.Cf >= 4 && a.Cf <= DB_FC &&
+            (a.Cf & 3) == 0 && (a.Lf & 3) == 0 && a.Lf + 6 <= DB_PF && a.Cf * a.Lf <= 4 * 256 * DB_FQ && (a.Lf - 1) / a.f_stride + 1 == a.L &&
+            a.f_stride * (16 * ((a.L + 15) / 16) - 1) + 6 < DB_PF;
+  }
+  return !off && geo && input && a.out != nullptr && a.symtab == nullptr &&
          a.tail_max == nullptr && (uint64_t)a.C * a.L * 4 < (1ull << 31);
 }
 
@@ -309,12 +398,15 @@ int launch_convblock_deep(const ConvBlockArgs& a, hipStream_t stream) {
     hipDeviceProp_t prop;
     MURAL_HIP_CHECK(hipGetDevice(&dev));
     MURAL_HIP_CHECK(hipGetDeviceProperties(&prop, dev));
-    MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, convblock_deep32_kernel<DB_NB>, 256, 0));
+    MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, convblock_deep32_kernel<DB_NB, true>, 256, 0));
     cap = prop.multiProcessorCount * (n > 0 ? n : 1);
   }
   const dim3 grid((unsigned)(a.B < cap ? a.B : cap));
-#define MURAL_DEEP_CASE(N) \
-  case N: hipLaunchKernelGGL(convblock_deep32_kernel<N>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1); break;
+#define MURAL_DEEP_CASE(N)                                                                                                            \
+  case N:                                                                                                                             \
+    if (a.f_in) hipLaunchKernelGGL((convblock_deep32_kernel<N, true>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.f_w, a.f_b);    \
+    else hipLaunchKernelGGL((convblock_deep32_kernel<N, false>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.f_w, a.f_b);          \
+    break;
   switch ((a.L + 15) >> 4) {
     MURAL_DEEP_CASE(1) MURAL_DEEP_CASE(2) MURAL_DEEP_CASE(3) MURAL_DEEP_CASE(4) MURAL_DEEP_CASE(5)
     default: MURAL_REQUIRE(false, "internal: deep ConvBlock launched on rows of more than 80 columns");

@@ -481,9 +481,21 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
                             i == 0 ? &gs : nullptr, nullptr, (i == 0 && emit_down) ? &m->up_l[1] : nullptr, T1, m->len[1])))
           return rc;
       } else {
+        // short rows of 32 channels (the fourth level): the strided k = 7 conv is the front of the block's own launch (convblock_deep.hip)
+        ConvBlockArgs da;
+        std::memset(&da, 0, sizeof(da));
+        const FoldedConv &fd = m->up_l[i], &f5 = m->up5[i], &f1 = m->up1[i];
+        da.f_in = cur; da.f_w = m->blob + fd.w; da.f_b = m->blob + fd.b; da.Cf = fd.Cin; da.Lf = Lcur; da.f_up = 1; da.f_stride = sh.down[i];
+        da.w5 = m->blob + f5.w; da.b5 = m->blob + f5.b; da.w1 = m->blob + f1.w; da.b1 = m->blob + f1.b;
+        da.out = E[i]; da.B = B; da.C = f5.Cin; da.L = Li;
+        if (i >= 2 && fd.K == 7 && fd.Cout == f5.Cin && f5.K == 5 && f1.K == 1 && f5.Cout == 2 * f5.Cin && f1.Cout == f5.Cin &&
+            convblock_deep_supported(da)) {
+          if ((rc = launch_convblock_deep(da, stream))) return rc;
+        } else {
         if (!(i == 1 && emit_down))      // (else: T1 already holds this level's strided conv)
           if ((rc = run_conv(m, m->up_l[i], cur, B, Lcur, T1, Li, sh.down[i], 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
         if ((rc = run_block(m, m->up5[i], m->up1[i], T1, B, Li, H, E[i], nullptr, stream))) return rc;
+        }
       }
       cur = E[i];
       Lcur = Li;

@@ -1244,7 +1244,7 @@ extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float*
 }
 
 // validation hook (tests/test_gpu_indel.py): one fused ConvBlock launch (conv1d.hip / convblock_mfma.hip) with its optional front
-// (k = 7 conv Cf -> C on the input upsampled f_up times), skip tensor and tail.  form: 0 the 8-channel block entirely on the vector
+// (k = 7 conv Cf -> C on the input upsampled f_up times; f_up < 0: strided by -f_up instead), skip tensor and tail.  form: 0 the 8-channel block entirely on the vector
 // ALU, 1 its split form (convs on the matrix cores), -1 the library's choice.
 namespace mural { extern int g_convblock8_form; }
 extern "C" int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1,
@@ -1255,7 +1255,9 @@ extern "C" int mural_debug_convblock(const float* x, const float* w5, const floa
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.w5 = w5; a.b5 = b5; a.w1 = w1; a.b1 = b1; a.res2 = res2; a.out = out;
   a.B = (int)B; a.C = Cch; a.L = L;
-  if (f_in) {
+  if (f_in && f_up < 0) {      // a STRIDED k = 7 front (stride -f_up, source rows of L * stride columns): convblock_deep.hip
+    a.f_in = f_in; a.f_w = f_w; a.f_b = f_b; a.Cf = Cf; a.f_up = 1; a.f_stride = -f_up; a.Lf = L * a.f_stride;
+  } else if (f_in) {
     MURAL_REQUIRE(f_up >= 1 && L % f_up == 0, "convblock: the front's upsampling factor must divide the row length");
     a.f_in = f_in; a.f_w = f_w; a.f_b = f_b; a.Cf = Cf; a.f_up = f_up; a.Lf = L / f_up;
     a.f_pw = f_pw;      // optional (f_up == 4): the front's polyphase weights [4][Cf][3][C]

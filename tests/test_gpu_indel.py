@@ -587,6 +587,8 @@ def test_level0_kernels_and_wide_stores_against_their_fallbacks(monkeypatch):
     assert np.abs(base - old).max() <= 1e-5 * max(1.0, np.abs(base).max())
     two_launches = run(MURAL_INDEL_DEEP="0")      # the 32-channel block of the fourth level as two tiled convs (csrc/convblock_deep.hip)
     assert np.abs(base - two_launches).max() <= 1e-5 * max(1.0, np.abs(base).max())
+    own_conv = run(MURAL_INDEL_DEEP_FRONT="0")    # ... with its strided conv as a launch of its own
+    assert np.abs(base - own_conv).max() <= 1e-5 * max(1.0, np.abs(base).max())
 
 
 @pytest.mark.parametrize("tag", ["rev", "norev"])

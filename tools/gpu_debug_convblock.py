@@ -16,7 +16,13 @@ def run(form, B, C, L, front, skip, tail, seed, poison=0, poly=False):
     rn = lambda *s: torch.randn(*s, generator=g)
     w5, b5 = rn(2 * C, C, 5) / (5 * C) ** 0.5, rn(2 * C) * 0.3            # torch layouts [out][in][k]
     w1, b1 = rn(C, 2 * C, 1) / (2 * C) ** 0.5, rn(C) * 0.3
-    if front:
+    if front and front[1] < 0:      # strided front (stride -front[1], source rows of L * stride columns)
+        Cf, st = front[0], -front[1]
+        fin = rn(B, Cf, L * st)
+        fw, fb = rn(C, Cf, 7) / (7 * Cf) ** 0.5, rn(C) * 0.3
+        x = F.conv1d(fin.double(), fw.double(), fb.double(), padding=3, stride=st)
+        assert x.shape[2] == L
+    elif front:
         Cf, up = front
         fin = rn(B, Cf, L // up)
         fw, fb = rn(C, Cf, 7) / (7 * Cf) ** 0.5, rn(C) * 0.3
@@ -88,6 +94,10 @@ if __name__ == "__main__":
     if os.environ.get("DEEP"):      # the 32-channel block on short rows (convblock_deep.hip) only
         cases = [(-1, B, 32, L, None, skip, False, False) for (B, L) in ((3, 80), (700, 80), (5, 79), (2, 64), (4, 37), (3, 16), (2, 5), (1, 1), (2000, 80))
                  for skip in (False, True)]
+        # ... with the level's strided k = 7 conv as the launch's front (24 x 400 -> 32 x 80 at stride 5 is the shipped geometry)
+        cases += [(-1, B, 32, L, (Cf, -st), skip, False, False) for (B, L, Cf, st) in ((3, 80, 24, 5), (600, 80, 24, 5), (5, 64, 24, 4), (2, 80, 16, 5),
+                                                                                      (4, 37, 24, 8), (3, 20, 8, 4), (7, 80, 24, 1), (2, 16, 12, 4))
+                  for skip in (False, True)]
         # ... and the two deepest levels (40 channels x 16 columns, 48 x 8: a pass takes 5 / 12 rows; ragged last passes)
         cases += [(-1, B, C, L, None, skip, False, False) for (C, L) in ((40, 16), (48, 8)) for B in (1, 3, 5, 7, 12, 13, 29, 700, 2048)
                   for skip in (False, True)]
@@ -109,6 +119,15 @@ if __name__ == "__main__":
                 call()
             torch.cuda.synchronize()
             print("C 32 L 80 skip", skip, "%.1f us" % ((time.perf_counter() - t) / 50 * 1e6), flush=True)
+        _, call = run(-1, 2048, 32, 80, (24, -5), False, False, seed=1)
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(50):
+            call()
+        torch.cuda.synchronize()
+        print("C 32 L 80 strided front 24 x 400: %.1f us" % ((time.perf_counter() - t) / 50 * 1e6), flush=True)
         for Cc, Lc in ((40, 16), (48, 8)):
             _, call = run(-1, 2048, Cc, Lc, None, True, False, seed=1)
             for _ in range(3):
