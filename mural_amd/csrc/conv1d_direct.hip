@@ -36,6 +36,7 @@ struct ConvDArgs {
   int ngroups, nslow;      // interior groups / edge-loop segments of the launch
   uint32_t x_bytes, y_bytes;
   DivWide dGr, dSs;
+  int xcd;      // xcd_wave_index (mfma_tile.h)
 };
 
 __device__ __forceinline__ float cd_act(float v, int act) {
@@ -147,7 +148,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_kernel(const ConvDArgs g
   };
 
   const int nwaves = gridDim.x * 4;
-  const int wid = blockIdx.x * 4 + w;
+  const int wid = xcd_wave_index(w, g.xcd);
   // ---------------------------------------------------------------------------------------------- interior groups
   // (no branch around a load, a next group is always fetched -- the last one re-fetches itself -- and scheduling barriers keep the
   // prefetch in front of the MFMAs: see conv_wgrad_mfma.hip)
@@ -284,6 +285,7 @@ struct ConvPArgs {
   uint32_t x_bytes, y_bytes;
   DivWide dGr, dSs;
   FastDiv dPh;
+  int xcd;      // xcd_wave_index (mfma_tile.h)
 };
 
 template <int MB, int CQ, int KT, int U>
@@ -389,7 +391,7 @@ __global__ __launch_bounds__(256, 2) void conv1d_direct_poly_kernel(const ConvPA
   };
 
   const int nwaves = gridDim.x * 4;
-  const int wid = blockIdx.x * 4 + w;
+  const int wid = xcd_wave_index(w, g.xcd);
   {
     struct Buf { f32x4 q[U][CQ]; };
     auto load = [&](Buf& t, int grp) {
@@ -498,6 +500,7 @@ int launch_conv1d_direct_poly(const Conv1dArgs& a, hipStream_t stream) {
   if (g.gr == 0) g.e0 = 0;
   g.ss = g.segs_row - g.gr * U;
   g.ngroups = a.B * g.gr;
+  g.xcd = xcd_swizzle_enabled();
   g.nslow = a.B * g.ss;
   g.dGr = DivWide::make((uint32_t)std::max(1, g.gr), (uint64_t)g.ngroups + 64);
   g.dSs = DivWide::make((uint32_t)std::max(1, g.ss), (uint64_t)g.nslow + 64);
@@ -540,6 +543,7 @@ int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream) {
     if (g.gr == 0) g.e0 = 0;
     g.ss = g.segs_row - g.gr * U;
     g.ngroups = a.B * g.gr;
+    g.xcd = xcd_swizzle_enabled();
     g.nslow = a.B * g.ss;
     g.dGr = DivWide::make((uint32_t)std::max(1, g.gr), (uint64_t)g.ngroups + 64);
     g.dSs = DivWide::make((uint32_t)std::max(1, g.ss), (uint64_t)g.nslow + 64);

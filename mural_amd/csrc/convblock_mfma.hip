@@ -244,6 +244,7 @@ struct CbdArgs {
   int segs_row, e0, gr, ss, ngroups, nslow;
   uint32_t bytes;
   DivWide dGr, dSs;
+  int xcd;      // xcd_wave_index (mfma_tile.h)
 };
 
 template <int C>
@@ -336,7 +337,7 @@ __global__ __launch_bounds__(256, 2) void convblock_direct_kernel(const CbdArgs 
   };
 
   const int nwaves = gridDim.x * 4;
-  const int wid = blockIdx.x * 4 + w;
+  const int wid = xcd_wave_index(w, g.xcd);
   {
     auto load = [&](Buf& t, int grp) {
       const uint32_t b = g.dGr.div((uint32_t)grp);
@@ -433,6 +434,7 @@ static int launch_convblock_direct_t(const ConvBlockArgs& a, hipStream_t stream)
   g.e0 = g.gr > 0 ? e0 : 0;
   g.ss = g.segs_row - g.gr;
   g.ngroups = a.B * g.gr;
+  g.xcd = xcd_swizzle_enabled();
   g.nslow = a.B * g.ss;
   g.dGr = DivWide::make((uint32_t)std::max(1, g.gr), (uint64_t)g.ngroups + 64);
   g.dSs = DivWide::make((uint32_t)std::max(1, g.ss), (uint64_t)g.nslow + 64);

@@ -1,6 +1,7 @@
 // Shared device helpers of the MFMA conv kernels: the swizzled LDS image [column][32 channels] of a flattened column
 // axis (zero separator columns between rows) and the v_mfma_f32_16x16x4_f32 operand conventions.
 #pragma once
+#include <cstdlib>
 #include "common.h"
 
 namespace mural {
@@ -16,6 +17,19 @@ __device__ __forceinline__ int lds_key(int pc) {
 }
 __device__ __forceinline__ int lds_off(int pc, int chunk) { return pc * 32 + ((chunk ^ lds_key(pc)) << 2); }
 
+// Wave index of (workgroup, wave w of 4) in launches whose waves walk consecutive 16-column segments.  Workgroups are handed to the
+// eight XCDs round-robin (workgroup b runs on XCD b % 8, each with an L2 of its own), and a 16-column segment is 64 bytes of a channel
+// row: with workgroup b on segments 4 b .. 4 b + 3 every 128-byte line is fetched by two XCDs (r05 PMC: the 16-channel INDEL block read
+// 1.8 x its input from the fabric).  Slot (b % 8) * (gridDim / 8) + b / 8 gives the waves of one XCD ONE contiguous range per sweep.
+__device__ __forceinline__ int xcd_wave_index(int w, int on) {
+  const int b = blockIdx.x, nb = gridDim.x;
+  const int slot = (on && (nb & 7) == 0) ? (b & 7) * (nb >> 3) + (b >> 3) : b;
+  return slot * 4 + w;
+}
+inline int xcd_swizzle_enabled() {      // MURAL_XCD_SWIZZLE=0: workgroup b takes slot b (A/B switch)
+  const char* e = getenv("MURAL_XCD_SWIZZLE");
+  return !(e && atoi(e) == 0);
+}
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 __device__ __forceinline__ f32x4 splat(float v) { return f32x4{v, v, v, v}; }
