@@ -581,6 +581,7 @@ def test_level0_kernels_and_wide_stores_against_their_fallbacks(monkeypatch):
 
     base = run()
     assert np.array_equal(base, run(MURAL_DEBUG_POLY_NARROW="1"))
+    assert np.array_equal(base, run(MURAL_XCD_SWIZZLE="0"))      # which workgroup takes which segments changes no value (mfma_tile.h: xcd_wave_index)
     same_values = run(MURAL_INDEL_ENC0_DOWN="0")
     assert np.abs(base - same_values).max() <= 1e-5 * max(1.0, np.abs(base).max())      # (another conv engine sums the taps in another order)
     old = run(MURAL_INDEL_ENC0="0", MURAL_INDEL_DEC0="0")
