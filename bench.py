@@ -341,6 +341,23 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
         tbs = per_pos * n / dt / 1e12
         out["roofline"].update({"hbm_bytes_per_position": per_pos, "achieved_TBs": tbs, "frac_hbm": tbs / PEAK_HBM_TBS,
                                 "traffic_source": fact.get("source")})
+    # the same model on DENSE one-hot windows (B, 4, 8000) resident in HBM -- what the reference's own loader hands to the model
+    # (the drop-in input of an unchanged predict loop): 8 calls of 4096 windows encoded outside the timed region
+    nd, cd = 32_768, 4_096
+    with torch.no_grad():
+        xd = genome.encode_onehot(pos[:cd], strand[:cd], 4000, "indel")
+        for _ in range(2):
+            model(xd)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nd // cd):
+            model(xd)
+        torch.cuda.synchronize()
+        dtd = time.perf_counter() - t0
+    out["positions_per_s_dense_input"] = nd / dtd
+    out["dense_input_note"] = ("dense (B, 4, 8000) one-hot windows resident in HBM, 8 calls of 4096: classified into symbol bytes and taken by the "
+                               "same persistent first level as the packed entry (columns that are no symbol are evaluated from their floats)")
+    del xd
     # one training configuration of the same model: batch 128 (the reference's default), CE(sum) + clip + Adam.  The step is ~500
     # small launches behind Python autograd glue: the eager loop runs at the speed of the host's Python (7-11 ms on this pool's
     # boxes), mural_amd.train.GraphedIndelTrainStep replays the same step as one HIP graph and is bound by the device alone.

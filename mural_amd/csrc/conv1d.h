@@ -80,6 +80,9 @@ struct ConvBlockArgs {
   const float* symtab;
   const float* sym_bias;
   int sym_taps;
+  // optional, instead of the genome (persistent first-level kernel only): one symbol byte per column, [B][Lf] (0 .. 14 the MuRaL symbols,
+  // 16: no symbol -- the column's floats are read from f_in [B][4][Lf], which must then be set)
+  const uint8_t* sym_in;
   // optional (genome source): the per-symbol layer and the k=7 front composed into ONE conv of 6 + sym_taps taps, summed per group of
   // three taps over A C G T (indel_enc0_compose, indel_level0.hip): the persistent first-level kernel takes the launch then
   const float* e0_t3;

@@ -926,7 +926,8 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   if (convblock_deep_supported(a)) return launch_convblock_deep(a, stream);      // 32 channels, rows of up to 80 columns
   MURAL_REQUIRE(convblock_supported(a.C), "convblock: %d channels not instantiated", a.C);
   if (a.symtab) MURAL_REQUIRE(a.Cf == 4 && a.f_up == 1 && a.C == 8 && a.sym_taps >= 1 && (a.sym_taps & 1) && a.sym_taps <= 15 && a.sym_bias &&
-                              a.g_pos && a.g_strand, "convblock: the genome-fed front serves the 4-channel input of the first level");
+                              ((a.g_pos && a.g_strand) || a.sym_in), "convblock: the genome-fed front serves the 4-channel input of the first level");
+  if (a.sym_in) MURAL_REQUIRE(a.symtab && a.f_in && indel_enc0_supported(a), "convblock: a symbol-byte source is served by the persistent first-level kernel only");
   if (a.f_in || a.symtab) {
     MURAL_REQUIRE(a.f_w && a.f_b && a.f_up >= 1 && a.Lf * a.f_up == a.L, "convblock: bad front geometry");
     MURAL_REQUIRE(a.Cf * (262 / a.f_up + 3) <= CB_FRONT_FLOATS, "convblock: front input tile does not fit");

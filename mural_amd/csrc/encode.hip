@@ -124,8 +124,10 @@ __global__ __launch_bounds__(256) void encode_symbols_kernel(MuralGenome g, cons
 // A thread converts 4 consecutive symbols of the flattened (row, column) index: 16 independent channel loads in flight and one
 // aligned 4-byte store (the symbol buffer is linear in that index, so a group may straddle two rows).  HBM-bound: 16 B in,
 // 1 B out per column.
+// bad_code < 0: a column that is no MuRaL symbol becomes N and raises the status word; otherwise it becomes bad_code, silently (the
+// INDEL first level reads such a column's floats itself: indel_level0.hip)
 __global__ __launch_bounds__(256) void dense_to_symbols_kernel(const float* __restrict__ x, int64_t n, int L,
-                                                               uint8_t* __restrict__ sym, int32_t* __restrict__ status) {
+                                                               uint8_t* __restrict__ sym, int32_t* __restrict__ status, int bad_code) {
   const int64_t total = n * L;
   const int64_t groups = (total + 3) >> 2;
   for (int64_t gidx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; gidx < groups; gidx += (int64_t)gridDim.x * blockDim.x) {
@@ -164,8 +166,8 @@ __global__ __launch_bounds__(256) void dense_to_symbols_kernel(const float* __re
     for (int e = 0; e < 4; ++e) {
       int s = dense_symbol(v[e][0], v[e][1], v[e][2], v[e][3]);
       if (s < 0) {
-        s = SYM_N;
-        bad |= i0 + e < total;
+        s = bad_code < 0 ? (int)SYM_N : bad_code;
+        bad |= bad_code < 0 && i0 + e < total;
       }
       packed |= (uint32_t)s << (8 * e);
     }
@@ -178,14 +180,14 @@ __global__ __launch_bounds__(256) void dense_to_symbols_kernel(const float* __re
   }
 }
 
-int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream) {
+int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream, int bad_code) {
   const int64_t total = n * L;
   if (total == 0) return MURAL_OK;
   MURAL_REQUIRE((reinterpret_cast<uintptr_t>(sym) & 3u) == 0, "dense_to_symbols: the symbol buffer must be 4-byte aligned");
   const int block = 256;
   const int64_t groups = (total + 3) / 4;
   const int grid = (int)((groups + block - 1) / block < 16384 ? (groups + block - 1) / block : 16384);
-  hipLaunchKernelGGL(dense_to_symbols_kernel, dim3(grid), dim3(block), 0, stream, x, n, L, sym, status);
+  hipLaunchKernelGGL(dense_to_symbols_kernel, dim3(grid), dim3(block), 0, stream, x, n, L, sym, status, bad_code);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }

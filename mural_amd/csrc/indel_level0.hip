@@ -37,7 +37,11 @@ __device__ __forceinline__ float silu0(float v) { return v * __builtin_amdgcn_rc
 
 struct E0Words { uint32_t w[2], m[2]; };   // genome words of a thread's one or two columns of a tile (2-bit bases, not-ACGT mask)
 
-template <int TT, bool STAMPS, bool DOWN>
+// BYTES: the window's symbols come from one byte per column (ConvBlockArgs::sym_in [B][Lf], the dense entry's one-hot windows
+// classified by dense_to_symbols_kernel) instead of the packed genome; a column that is no MuRaL symbol (E0_SYM_DENSE) sends its
+// neighbourhood through the exact form, which reads that column's four floats from the dense window itself (f_in [B][4][Lf]).
+constexpr uint32_t E0_SYM_DENSE = 16;
+template <int TT, bool STAMPS, bool DOWN, bool BYTES = false>
 __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs a, const float* __restrict__ w5, const float* __restrict__ b5,
                                                             const float* __restrict__ w1, const float* __restrict__ b1,
                                                             int tiles_per_row, long long total_tiles, unsigned long long* stamps) {
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
   int b = (int)(first / tiles_per_row);
   int tile_no = (int)(first - (long long)b * tiles_per_row);
   const int Lf = a.Lf;
-  const long long glen = a.genome.length;
+  const long long glen = BYTES ? (long long)a.B * a.Lf : a.genome.length;      // BYTES: "genome" = the symbol rows end to end, a row's origin = b Lf
 
   // a column's place in the genome: window column j of row (ws, neg)
   auto column = [&](int i, int l0, long long ws, bool neg, bool& inwin, bool& ing, long long& g) {
@@ -117,8 +121,13 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
       long long g;
       column(tid + 256 * r, l0, ws, neg, inwin, ing, g);
       const long long gi = ing ? g : 0;
-      p.w[r] = a.genome.packed2[gi >> 4];
-      p.m[r] = a.genome.nmask[gi >> 5];
+      if constexpr (BYTES) {
+        p.w[r] = a.sym_in[gi];
+        p.m[r] = 0u;
+      } else {
+        p.w[r] = a.genome.packed2[gi >> 4];
+        p.m[r] = a.genome.nmask[gi >> 5];
+      }
     }
   };
 
@@ -127,8 +136,8 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
     const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
     return (long long)(((unsigned long long)hi << 32) | lo);
   };
-  long long ws = uniform64(a.g_pos[b] + a.g_off);
-  bool neg = __builtin_amdgcn_readfirstlane((int)a.g_strand[b]) != 0;
+  long long ws = BYTES ? (long long)b * Lf : uniform64(a.g_pos[b] + a.g_off);
+  bool neg = BYTES ? false : __builtin_amdgcn_readfirstlane((int)a.g_strand[b]) != 0;
   E0Words cur;
   cur.w[1] = cur.m[1] = 0u;
   request(threadIdx.x, tile_no * OUTW, ws, neg, cur);
@@ -150,11 +159,16 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
       bool inwin, ing;
       long long g;
       column(i, l0, ws, neg, inwin, ing, g);
-      const bool masked = ((cur.m[r] >> (uint32_t)(g & 31)) & 1u) != 0u;
-      uint32_t sy = (cur.w[r] >> (2u * (uint32_t)(g & 15))) & 3u;
-      sy = (ing && !masked) ? sy : (uint32_t)SYM_N;
-      if (ing && masked && a.genome.n_amb > 0) sy = genome_sym_iupac(a.genome, g);      // ambiguity codes: the sparse side table
-      if (neg) sy = sym_complement(sy);
+      uint32_t sy;
+      if constexpr (BYTES) {
+        sy = cur.w[r];      // (every column of the window has its byte: ing == inwin)
+      } else {
+        const bool masked = ((cur.m[r] >> (uint32_t)(g & 31)) & 1u) != 0u;
+        sy = (cur.w[r] >> (2u * (uint32_t)(g & 15))) & 3u;
+        sy = (ing && !masked) ? sy : (uint32_t)SYM_N;
+        if (ing && masked && a.genome.n_amb > 0) sy = genome_sym_iupac(a.genome, g);      // ambiguity codes: the sparse side table
+        if (neg) sy = sym_complement(sy);
+      }
       sy = (inwin && i < NSYM) ? sy : (uint32_t)SYM_PAD;
       const unsigned long long blo = __ballot((sy & 1u) != 0u), bhi = __ballot((sy & 2u) != 0u), bna = __ballot(sy >= 4u);
       symb[i] = (uint8_t)sy;
@@ -182,8 +196,8 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
     nxt.w[0] = nxt.m[0] = nxt.w[1] = nxt.m[1] = 0u;
     if (tix + 1 < last) {
       if (nb != b) {
-        nws = uniform64(a.g_pos[nb] + a.g_off);
-        nneg = __builtin_amdgcn_readfirstlane((int)a.g_strand[nb]) != 0;
+        nws = BYTES ? (long long)nb * Lf : uniform64(a.g_pos[nb] + a.g_off);
+        nneg = BYTES ? false : __builtin_amdgcn_readfirstlane((int)a.g_strand[nb]) != 0;
       }
       request(tid, ntile * OUTW, nws, nneg, nxt);
     }
@@ -217,10 +231,23 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
           const int j = l + k2 - 3;
           if ((unsigned)j >= (unsigned)Lf) continue;
           f32x4 S = ld4(stabS + 15 * ST * 4);
+          if constexpr (BYTES) {
+#pragma unroll 1
+            for (int k = 0; k < ST; ++k) {      // (rolled: this instance's slow path also reads the dense window; unrolled it spilled 49 registers)
+              const uint32_t sy = symb[tid + k2 + k];
+              if (sy == E0_SYM_DENSE) {         // no symbol: the layer is linear in the column's four floats
+                const int jc = l0 + XO - HW + tid + k2 + k;
+                const float* dv = a.f_in + (size_t)b * 4 * Lf + jc;
+#pragma unroll 1
+                for (int ci = 0; ci < 4; ++ci) S += splat(dv[(size_t)ci * Lf]) * ld4(stabS + (ci * ST + k) * 4);
+              } else if (sy != SYM_PAD) S += ld4(stabS + ((int)sy * ST + k) * 4);
+            }
+          } else {
 #pragma unroll
           for (int k = 0; k < ST; ++k) {
             const uint32_t sy = symb[tid + k2 + k];
             if (sy != SYM_PAD) S += ld4(stabS + ((int)sy * ST + k) * 4);
+          }
           }
 #pragma unroll
           for (int ci = 0; ci < 4; ++ci) {
@@ -656,6 +683,7 @@ static unsigned long long* l0_stamps(bool enc) {
 
 bool indel_enc0_supported(const ConvBlockArgs& a) {
   const bool off = getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0;      // (read per launch: the tests switch it)
+  if (a.sym_in && !(a.f_in && (int64_t)a.B * a.Lf < (int64_t(1) << 40))) return false;      // (byte source: the dense window backs it)
   return !off && a.C == 8 && a.symtab && a.e0_t3 && a.e0_t1 && a.e0_bias && a.Cf == 4 && a.f_up == 1 && (a.sym_taps == 7 || a.sym_taps == 1) &&
          a.tail_max == nullptr && a.res2 == nullptr && a.Lf == a.L;
 }
@@ -667,9 +695,11 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
   const int tiles_per_row = (a.L + outw - 1) / outw;
   const long long total = (long long)a.B * tiles_per_row;
   if (total == 0) return MURAL_OK;
-  unsigned long long* const stamps = l0_stamps(true);
-  const int v = (a.sym_taps == 7 ? 0 : 1) + (stamps ? 2 : 0) + (down ? 4 : 0);      // the instance that is launched
-  static int wg_per_cu[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cus = 0;
+  unsigned long long* stamps = l0_stamps(true);
+  const bool bytes = a.sym_in != nullptr;
+  if (bytes) stamps = nullptr;      // (the byte-source instances carry no phase stamps)
+  const int v = (a.sym_taps == 7 ? 0 : 1) + (stamps ? 2 : 0) + (down ? 4 : 0) + (bytes ? 8 : 0);      // the instance that is launched
+  static int wg_per_cu[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, cus = 0;
   if (cus == 0) {
     int dev = 0;
     hipDeviceProp_t prop;
@@ -686,11 +716,15 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
     case 4: X(13, false, true); break;  \
     case 5: X(7, false, true); break;   \
     case 6: X(13, true, true); break;   \
-    default: X(7, true, true); break;   \
+    case 7: X(7, true, true); break;    \
+    case 8: X(13, false, false, true); break; \
+    case 9: X(7, false, false, true); break;  \
+    case 12: X(13, false, true, true); break; \
+    default: X(7, false, true, true); break;  \
   }
   if (wg_per_cu[v] == 0) {
     int n = 0;
-#define MURAL_E0_OCC(TTV, ST, DN) MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<TTV, ST, DN>, 256, 0))
+#define MURAL_E0_OCC(...) MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_enc0_kernel<__VA_ARGS__>, 256, 0))
     MURAL_E0_CASES(MURAL_E0_OCC)
 #undef MURAL_E0_OCC
     wg_per_cu[v] = n > 7 ? 7 : (n > 0 ? n : 1);
@@ -698,7 +732,7 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
   static const int cap = getenv("MURAL_INDEL_ENC0_WGS") ? atoi(getenv("MURAL_INDEL_ENC0_WGS")) : 0;      // experiment: workgroups per CU
   const long long want = (long long)cus * (cap > 0 ? cap : wg_per_cu[v]);
   const dim3 grid((unsigned)(total < want ? total : want));
-#define MURAL_E0(TTV, ST, DN) hipLaunchKernelGGL((indel_enc0_kernel<TTV, ST, DN>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps)
+#define MURAL_E0(...) hipLaunchKernelGGL((indel_enc0_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps)
   MURAL_E0_CASES(MURAL_E0)
 #undef MURAL_E0
 #undef MURAL_E0_CASES

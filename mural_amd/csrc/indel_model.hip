@@ -343,6 +343,7 @@ struct GenomeSrc {      // packed-genome source of the first level's front input
   const int64_t* pos = nullptr;
   const uint8_t* strand = nullptr;
   int off = 0;
+  const uint8_t* sym = nullptr;      // or: one symbol byte per column of the dense windows (ConvBlockArgs::sym_in; the front input is the dense tensor)
 };
 
 static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const FoldedConv& f1, const float* x, int B, int L,
@@ -357,8 +358,9 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
     if (ff) {
       a.f_in = fin; a.f_w = m->blob + ff->w; a.f_b = m->blob + ff->b; a.Cf = ff->Cin; a.Lf = L / up; a.f_up = up;
       if (up == 4 && m->front_pw && ff == &m->dn_l[INDEL_LEVELS - 2]) a.f_pw = m->blob + m->front_pw;
-      if (gs && gs->g) {
-        a.genome = *gs->g; a.g_pos = gs->pos; a.g_strand = gs->strand; a.g_off = gs->off;
+      if (gs && (gs->g || gs->sym)) {
+        if (gs->g) { a.genome = *gs->g; a.g_pos = gs->pos; a.g_strand = gs->strand; a.g_off = gs->off; }
+        a.sym_in = gs->sym;
         a.symtab = m->blob + m->symtab; a.sym_bias = m->blob + m->sym_bias; a.sym_taps = m->sym_taps;
         if (m->e0_t3) {
           a.e0_t3 = m->blob + m->e0_t3; a.e0_t1 = m->blob + m->e0_t1; a.e0_bias = m->blob + m->e0_bias;
@@ -389,6 +391,7 @@ static int run_block(const MuralIndelModel* m, const FoldedConv& f5, const Folde
 
 extern "C" int mural_encode_onehot(const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n, int32_t radius,
                                    int32_t indel, float* out, void* stream);
+namespace mural { int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream, int bad_code = -1); }
 
 // distal_x != nullptr: dense entry; otherwise the windows come from the packed genome (genome, pos, strand; window
 // [pos - radius + 1, pos + radius], preprocessing.py:564-566)
@@ -455,6 +458,16 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
     const float* x = nullptr;
     if (distal_x) {
       x = distal_x + (size_t)c0 * 4 * Lx;
+      // dense one-hot windows (what the reference's loader yields): classified into one symbol byte per column and taken by the same
+      // persistent table-driven first level as the packed entry; columns that are no MuRaL symbol are evaluated from their floats there
+      // (MURAL_INDEL_DENSE_SYMBOLS=0: the input layer and the first level as launches of their own on the dense tensor)
+      const bool sym_off = (getenv("MURAL_INDEL_DENSE_SYMBOLS") && atoi(getenv("MURAL_INDEL_DENSE_SYMBOLS")) == 0) ||
+                           (getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0) || getenv("MURAL_DEBUG_CONVBLOCK_VALU") ||
+                           getenv("MURAL_CONVBLOCK8_VALU") || getenv("MURAL_CONVBLOCK8_MFMA");
+      if (first_fused && m->e0_t3 && (Lx & 3) == 0 && !sym_off) {
+        if ((rc = launch_dense_to_symbols(x, B, Lx, reinterpret_cast<uint8_t*>(X), nullptr, stream, 16))) return rc;
+        gs.sym = reinterpret_cast<const uint8_t*>(X);
+      }
     } else if (first_fused && !getenv("MURAL_DEBUG_INDEL_NO_GENOME_FRONT")) {
       gs.g = genome; gs.pos = pos + c0; gs.strand = strand + c0; gs.off = -(Lx / 2) + 1;
     } else {
@@ -463,7 +476,7 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
     }
     const float* cur = x;
     int Lcur = Lx;
-    if (sh.use_reverse && !gs.g) {
+    if (sh.use_reverse && !gs.g && !gs.sym) {
       if ((rc = run_conv(m, m->sym, cur, B, Lcur, S, Lcur, 1, 1, ACT_NONE, nullptr, nullptr, stream))) return rc;
       cur = S;
     }
@@ -471,7 +484,7 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
     // persistent kernel's (indel_level0.hip); MURAL_INDEL_ENC0_DOWN=0: the conv as a launch of its own
     const bool down_off = (getenv("MURAL_INDEL_ENC0_DOWN") && atoi(getenv("MURAL_INDEL_ENC0_DOWN")) == 0) ||
                                  (getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0);
-    const bool emit_down = gs.g && m->e0_t3 && !down_off && sh.down[1] == 4 && m->up_l[1].K == 7 && m->up_l[1].Cin == 8 && m->up_l[1].Cout == 16 &&
+    const bool emit_down = (gs.g || gs.sym) && m->e0_t3 && !down_off && sh.down[1] == 4 && m->up_l[1].K == 7 && m->up_l[1].Cin == 8 && m->up_l[1].Cout == 16 &&
                            (m->len[0] & 3) == 0 && m->len[1] == (m->len[0] - 1) / 4 + 1 && !getenv("MURAL_DEBUG_CONVBLOCK_VALU") &&
                            !getenv("MURAL_CONVBLOCK8_VALU") && !getenv("MURAL_CONVBLOCK8_MFMA");
     for (int i = 0; i < INDEL_LEVELS; ++i) {     // encoder: strided conv+BN, then ConvBlock (x + BN(1x1(SiLU(BN(k5)))))

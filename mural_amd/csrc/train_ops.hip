@@ -1734,7 +1734,7 @@ int train_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3,
 #include "snv_local_train.h"      // the local branch of the composed training step in three launches per direction
 #include "snv_head_train.h"       // a tower's head in two launches per direction
 
-namespace mural { int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream); }
+namespace mural { int launch_dense_to_symbols(const float* x, int64_t n, int L, uint8_t* sym, int32_t* status, hipStream_t stream, int bad_code = -1); }
 // dense (n,4,L) MuRaL encoding -> 1 symbol per column (status: see mural_snv_forward_dense)
 extern "C" int mural_op_dense_to_symbols(const float* x, int64_t n, int32_t L, uint8_t* sym, int32_t* status, void* stream) {
   return mural::launch_dense_to_symbols(x, n, L, sym, status, STREAM);

@@ -120,7 +120,8 @@ def test_persistent_level0_indel_kernels_do_not_spill():
     ks = _kernels(_report("indel_level0"))
     run = [k for k in ks if ("indel_enc0_kernel" in k and k.split("indel_enc0_kernel")[1].startswith(("ILi13ELb0E", "ILi7ELb0E"))) or
            ("indel_dec0_kernel" in k and k.split("indel_dec0_kernel")[1].startswith("ILb0E"))]
-    assert len(run) == 5, sorted(ks)      # encoder: 13 / 7 composed taps x (plain | also emitting the next level's strided conv); decoder
+    # encoder: 13 / 7 composed taps x (plain | also emitting the next level's strided conv) x (packed genome | symbol bytes); decoder
+    assert len(run) == 9, sorted(ks)
     for k in run:
         r = ks[k]
         need = 4      # (both launches are bound by instruction issue: registers instead of re-derived addresses / LDS fragment reads)

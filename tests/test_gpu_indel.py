@@ -542,10 +542,19 @@ def test_packed_entry_decodes_inside_the_first_level(name, monkeypatch):
         got = model.forward_packed(genome, tp, ts, R).cpu().numpy()
         monkeypatch.setenv("MURAL_DEBUG_INDEL_NO_GENOME_FRONT", "1")
         slow = model.forward_packed(genome, tp, ts, R).cpu().numpy()
-        dense = model(genome.encode_onehot(tp, ts, R, "indel")).cpu().numpy()
+        onehot = genome.encode_onehot(tp, ts, R, "indel")
+        dense = model(onehot).cpu().numpy()
+        monkeypatch.setenv("MURAL_INDEL_DENSE_SYMBOLS", "0")
+        dense_own = model(onehot).cpu().numpy()
     tol = 1e-4 * max(1.0, np.abs(want).max())
     assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
-    assert np.abs(slow - want).max() <= tol and np.array_equal(slow, dense)
+    # the dense entry classifies the one-hot windows into symbol bytes and feeds the same first-level kernel: the same symbols, the same
+    # arithmetic as the packed entry (where that kernel serves the geometry); with the switch off it is the materialising fallback's path
+    assert np.abs(slow - want).max() <= tol and np.array_equal(slow, dense_own)
+    assert np.abs(dense - want).max() <= tol
+    _, C_, k_, _, _ = [int(v) for v in fx["hp"]]
+    if int(fx["down"][0]) == 1 and C_ == 8 and k_ == 7 and (2 * R) % 4 == 0:      # (the geometry csrc/indel_level0.hip serves)
+        assert np.array_equal(dense, got)
     assert model.forward_packed(genome, tp[:0], ts[:0], R).shape == (0, model.n_class)
 
 
@@ -590,6 +599,47 @@ def test_level0_kernels_and_wide_stores_against_their_fallbacks(monkeypatch):
     assert np.abs(base - two_launches).max() <= 1e-5 * max(1.0, np.abs(base).max())
     own_conv = run(MURAL_INDEL_DEEP_FRONT="0")    # ... with its strided conv as a launch of its own
     assert np.abs(base - own_conv).max() <= 1e-5 * max(1.0, np.abs(base).max())
+
+
+@pytest.mark.parametrize("name", ["indel_pretrained_human_insertion.npz", "indel_synth_small.npz"])
+def test_dense_entry_with_columns_that_are_no_symbol(name, monkeypatch):
+    """mural_indel_forward_dense takes ANY float tensor: one-hot / IUPAC-fraction columns travel as symbol bytes through the persistent
+    table-driven first level, a column that is no MuRaL symbol (here: random floats, scaled one-hot columns, all-zero columns, isolated
+    and in runs, at both window ends) is evaluated from its floats inside that launch -- against the oracle and against the
+    launch-per-layer path on the dense tensor."""
+    from oracle import encode_ref
+    fx = U.load(name)
+    model = product_from(fx)
+    orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
+    sd = U.indel_state_for(fx, orc)
+    model.load_state_dict(sd)
+    orc.load_state_dict(sd)
+    model = model.cuda().eval()
+    orc.eval()
+    R = int(fx["hp"][0])
+    rng = np.random.default_rng(5 + R)
+    n = 4 * R + 500
+    raw = rng.choice(np.frombuffer(b"ACGTNRY", np.uint8), size=n, p=[.24, .24, .24, .24, .02, .01, .01])
+    codes = encode_ref.seq_to_codes(raw.tobytes().decode())
+    pos = np.r_[[0, n - 1, n // 2], rng.integers(0, n, size=9)]
+    sym = ["-" if i % 2 else "+" for i in range(len(pos))]
+    x = encode_ref.onehot_encode(codes, pos, sym, R, "indel").copy()
+    L = x.shape[2]
+    x[0, :, 0] = rng.standard_normal(4)                      # first column
+    x[1, :, L - 1] = rng.standard_normal(4)                  # last column
+    x[2, :, 100:140] = rng.standard_normal((4, 40))          # a run
+    x[3, :, rng.integers(0, L, size=60)] *= 0.7              # scaled one-hot columns, scattered
+    x[4, :, L // 2 - 3:L // 2 + 3] = 0.0                     # all-zero columns
+    x[5] = rng.standard_normal((4, L)).astype(np.float32)    # a window without a single symbol
+    xt = torch.from_numpy(x.astype(np.float32))
+    with torch.no_grad():
+        want = orc(xt).numpy()
+        got = model(xt.cuda()).cpu().numpy()
+        monkeypatch.setenv("MURAL_INDEL_DENSE_SYMBOLS", "0")
+        own = model(xt.cuda()).cpu().numpy()
+    tol = 1e-4 * max(1.0, np.abs(want).max())
+    assert np.abs(got - want).max() <= tol, np.abs(got - want).max()
+    assert np.abs(got - own).max() <= 1e-5 * max(1.0, np.abs(own).max())
 
 
 @pytest.mark.parametrize("tag", ["rev", "norev"])
