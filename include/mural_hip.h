@@ -397,7 +397,9 @@ int mural_debug_poison_lds(void* stream);
  * ceil(L / 256) without a front, ceil(L / 252) with one, ceil(L / 248) for the split form with f_pw and Cf = 16; entries the launch
  * does not write keep the caller's values).  form: 0 = the 8-channel block entirely on the vector ALU, 1 = its split
  * form (convs on the matrix cores, front / SiLU / adds on the vector ALU), -1 = the library's choice; form | 0x100 (form in the low byte, 0xff = the library's choice) first
- * fills every CU's LDS with NaN: a launch that depends on LDS it has not written then fails the comparison. */
+ * fills every CU's LDS with NaN: a launch that depends on LDS it has not written then fails the comparison.
+ * C = 32 with L <= 80, C = 40 with L = 16 and C = 48 with L = 8 are the one-launch blocks of the three deepest INDEL levels
+ * (csrc/convblock_deep.hip; no tail); with C = 32, f_up = -s asks for a STRIDED k = 7 front instead (stride s, f_in [B][Cf][L * s]). */
 int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1, const float* res2,
                           float* out, int64_t B, int32_t C, int32_t L, const float* f_in, const float* f_w, const float* f_b,
                           int32_t Cf, int32_t f_up, const float* f_pw, const float* ta_w, const float* ta_b, const float* tb_w,
