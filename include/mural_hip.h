@@ -208,7 +208,9 @@ int  mural_indel_model_create(const MuralIndelShape* shape, const MuralIndelPara
 void mural_indel_model_destroy(MuralIndelModel* m);
 size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n);
 /* Replaces UNet_Small.forward(distal_input) (model_indel.py:151-176).  distal_x: dev float [n][4][length];
- * out: dev float [n][n_class] positive Softplus scores (callers apply softmax, run_predict.py:214).      */
+ * out: dev float [n][n_class] positive Softplus scores (callers apply softmax, run_predict.py:214).  Any float tensor is accepted;
+ * columns that are one-hot / IUPAC-fraction columns of the reference's encoder (preprocessing.py:756-816) travel as one symbol byte
+ * each through the table-driven first level of the packed entry (same scores bit for bit), the others are evaluated from their floats. */
 int mural_indel_forward_dense(const MuralIndelModel* m, const float* distal_x, int64_t n, float* out,
                               void* workspace, size_t workspace_bytes, void* stream);
 /* The same for sites of a packed genome: replaces seq_ohe_encoder (MuRaL/data/preprocessing.py:756-816; indel window
