@@ -1042,6 +1042,11 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_edge_wave(const EdgeArgs a
   }
 }
 
+static bool tower_dynamic_units() {
+  const char* e = getenv("MURAL_TOWER_DYNAMIC_UNITS");
+  return e && atoi(e) != 0 && !getenv("MURAL_DEBUG_TOWER_STATIC_UNITS");
+}
+
 size_t edge_wave_lds_bytes() {
   return (size_t)(4 * SNV_C + 4 * 3 * SNV_C + SNV_WAVES * ((16 * EW_NB + 2) * SNV_C + EW_WST + TW_DUMP)) * 4;
 }
@@ -1051,7 +1056,7 @@ int launch_snv_edge_wave(const EdgeArgs& e, int* unit_counter, hipStream_t strea
   const int64_t n_wg = (n_units + SNV_WAVES - 1) / SNV_WAVES;
   if (n_wg == 0) return MURAL_OK;
   const int grid = (int)(n_wg < 512 ? n_wg : 512);
-  if (n_units < 4 * (int64_t)grid * SNV_WAVES || getenv("MURAL_DEBUG_TOWER_STATIC_UNITS")) unit_counter = nullptr;
+  if (n_units < 4 * (int64_t)grid * SNV_WAVES || !tower_dynamic_units()) unit_counter = nullptr;
   static DynLdsOnce lds;
   if (int rc = lds.ensure(&snv_edge_wave)) return rc;
   hipLaunchKernelGGL(snv_edge_wave, dim3(grid), dim3(SNV_THREADS), edge_wave_lds_bytes(), stream, e, unit_counter);
@@ -1104,9 +1109,12 @@ int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t 
   int resident = 512;
   if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) resident = std::max(1, atoi(e));
   const int grid = (int)(n_wg < resident ? n_wg : resident);
-  // units through the counter only when every wave has several to take: a wave holds two tickets at a time (this unit + the next),
-  // so with about one unit per wave half of the waves would find nothing to do; short launches keep the fixed stride
-  if (n_units < 4 * (int64_t)grid * SNV_WAVES || getenv("MURAL_DEBUG_TOWER_STATIC_UNITS")) a.unit_counter = nullptr;
+  // Units at a fixed stride (wave w: units w, w + waves, ...).  The ticket counter (MURAL_TOWER_DYNAMIC_UNITS=1: a returning atomic per
+  // unit, requested a unit ahead) was the default until the end of round 5 and is 2 - 5 % SLOWER on every batch size measured
+  // (500 k sites: 16.52 vs 16.85 M bases/s, 0.753 vs 0.770 of the roof; 77 777 sites: 15.77 vs 16.61 M): the units cost the same, so
+  // the fixed stride has no tail to repair, and the counter's waves end a unit apart (64 +- 1 units each).  With the counter, units
+  // go through it only when every wave has several to take.
+  if (n_units < 4 * (int64_t)grid * SNV_WAVES || !tower_dynamic_units()) a.unit_counter = nullptr;
   if (const char* e = getenv("MURAL_DEBUG_TOWER_LDS")) {      // diagnostic: inflate the LDS request (one workgroup per CU: occupancy study)
     const size_t v = (size_t)atol(e);
     if (v > lds_bytes && v <= 160 * 1024) lds_bytes = v;

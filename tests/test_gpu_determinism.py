@@ -75,9 +75,9 @@ def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
 
     base = run()
     assert torch.isfinite(base).all()
-    monkeypatch.setenv("MURAL_DEBUG_TOWER_STATIC_UNITS", "1")
+    monkeypatch.setenv("MURAL_TOWER_DYNAMIC_UNITS", "1")      # units through the ticket counter instead of the fixed stride (the default)
     static = run()
-    monkeypatch.delenv("MURAL_DEBUG_TOWER_STATIC_UNITS")
+    monkeypatch.delenv("MURAL_TOWER_DYNAMIC_UNITS")
     monkeypatch.setenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM", "1")
     runtime_geom = run()
     monkeypatch.delenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM")
