@@ -831,8 +831,8 @@ def main():
     if rank == 0:
         bases = GENOME_SITES if strong else args.steps * B * world
         kernel_ms = k_ms.value / max(k_n.value, 1)
-        # the library launches the kernel four times per chunk of <= 131072 sites ((tower, stage-phase) pairs, each with its own tile
-        # size): sites_per_launch is the per-launch SHARE of the sites, so that FLOP_TOWERS x sites_per_launch / avg_launch_ms
+        # the library launches the kernel once per (tower, stage-phase) pair -- the first stages per chunk of <= 131072 sites, the short
+        # stages per four chunks -- each with its own tile size: sites_per_launch is the per-launch SHARE of the sites, so that FLOP_TOWERS x sites_per_launch / avg_launch_ms
         # = (all tower FLOP of the timed region) / (all tower-kernel time of the timed region)
         sites_per_launch = ((bhi - blo) if strong else args.steps * B) / max(k_n.value, 1)
         achieved = FLOP_TOWERS * sites_per_launch / (kernel_ms * 1e-3) / 1e12 if kernel_ms > 0 else 0.0

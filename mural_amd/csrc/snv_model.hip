@@ -286,6 +286,15 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x0; float* xlogit; float* s3[2]; int* counters;
                    float *vx0A, *vx0B, *vs3A, *vs3B; };      // long windows: the segments' inputs and pooled outputs
 
+// Sites whose short-stage launches are deferred into ONE launch per tower (run_towers): with the units at a fixed stride a launch takes
+// ceil(units / 2048 waves) unit-times, and a 131 072-site chunk gives the short stages 10.67 / 12.8 units per wave (3 % / 1.5 % of
+// tail); four chunks' worth are 42.7 / 51.2.  Long windows and models without the split launches keep one chunk.
+constexpr int SNV_SUPER = 4;
+int64_t super_chunk_sites(const MuralSnvModel* m) {
+  const bool off = getenv("MURAL_SNV_DEFER_SHORT") && atoi(getenv("MURAL_SNV_DEFER_SHORT")) == 0;
+  return (m->split && !m->longwin && !off) ? SNV_SUPER * m->chunk : m->chunk;
+}
+
 size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
   size_t off = 0;
   const size_t guard = ws_guard_bytes();      // 0 outside the validation tests (common.h)
@@ -300,9 +309,11 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
   const size_t o_cat = take((size_t)n * std::max(m->shape.local_cols, 1) * 8);
   const size_t o_sym = take(dense ? (size_t)n * m->shape.distal_len : 16);
   const size_t o_x0 = take((size_t)std::min<int64_t>(n, m->chunk) * std::max(m->args.x0_cols, 1) * SNV_C * 4);
-  const size_t o_xl = take((size_t)std::min<int64_t>(n, m->chunk) * SNV_MAXCLASS * 4);
-  const size_t o_s3l = take((size_t)std::min<int64_t>(n, m->chunk) * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
-  const size_t o_s3m = take((size_t)std::min<int64_t>(n, m->chunk) * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
+  // (the short-stage launches run once per SUPER-chunk of up to SNV_SUPER chunks: their inputs and the mid logits are kept that long)
+  const int64_t s3_sites = std::min<int64_t>(n, super_chunk_sites(m));
+  const size_t o_xl = take((size_t)s3_sites * SNV_MAXCLASS * 4);
+  const size_t o_s3l = take((size_t)s3_sites * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
+  const size_t o_s3m = take((size_t)s3_sites * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
   const size_t o_cnt = take(64);      // unit counters of the wave-private launches of a chunk (SnvFwdArgs::unit_counter)
   size_t o_vxa = 0, o_vxb = 0, o_vsa = 0, o_vsb = 0;
   if (m->longwin) {
@@ -653,8 +664,16 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
                       float* out, float* taps, const int32_t* status, hipStream_t stream) {
   const int nc = m->shape.n_class;
   const bool small = taps == nullptr && n <= SNV_SMALL_BATCH && m->lds_small > 0 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH");
-  for (int64_t c0 = 0; c0 < n; c0 += m->chunk) {
-    const int64_t cn = std::min<int64_t>(m->chunk, n - c0);
+  // the short-stage launches of up to SNV_SUPER chunks as ONE launch per tower (super_chunk_sites): the chunks' first-stage launches leave
+  // their pooled rows side by side in s3
+  const bool defer = m->split && taps == nullptr && !small && !m->longwin && super_chunk_sites(m) > m->chunk && n > m->chunk;
+  const int64_t super = defer ? super_chunk_sites(m) : m->chunk;
+  const size_t s3l_site = (size_t)std::max(m->args.geom[0].L[1], 1) * SNV_C, s3m_site = (size_t)std::max(m->args.geom[1].L[1], 1) * SNV_C;
+  for (int64_t sc0 = 0; sc0 < n; sc0 += super) {
+  const int64_t sn = std::min<int64_t>(super, n - sc0);
+  for (int64_t c0 = sc0; c0 < sc0 + sn; c0 += m->chunk) {
+    const int64_t cn = std::min<int64_t>(m->chunk, sc0 + sn - c0);
+    const int64_t rel = defer ? c0 - sc0 : 0;      // this chunk's place in the super-chunk's s3 / xlogit
     Stage1Args s = s1;
     s.n = cn;
     s.x0 = w.x0;
@@ -664,7 +683,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     if (int rc = launch_snv_stage1(s, packed, s.loc_on ? std::max(m->s1_lds_bytes, m->loc_lds) : m->s1_lds_bytes, stream)) return rc;
     const bool split = m->split && taps == nullptr && !small;   // the debug dump wants both towers in one tile geometry
     if (split) MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
-    for (int part = 0; part < (split ? 4 : 1); ++part) {
+    for (int part = 0; part < (split ? (defer ? 2 : 4) : 1); ++part) {
       if (m->longwin && part == 0) {
         // the large tower's first conv stage on segments of the pooled row: gather (with halo) -> two wave-private launches (the
         // lw_nA equal segments of every site, then the one that ends with the row) -> scatter of the pooled columns into s3[0]
@@ -700,11 +719,11 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
         continue;
       }
       SnvFwdArgs t = split ? m->args_split[part] : (small ? m->args_small : a);
-      t.s3[0] = w.s3[0];
-      t.s3[1] = w.s3[1];
+      t.s3[0] = w.s3[0] + (size_t)rel * s3l_site;
+      t.s3[1] = w.s3[1] + (size_t)rel * s3m_site;
       t.n = cn;
       t.x0 = w.x0;
-      t.xlogit = w.xlogit;
+      t.xlogit = w.xlogit + (size_t)rel * SNV_MAXCLASS;
       if (small) {   // one workgroup per (site, tower): the split launches' s3 scratch carries the mid logits and the arrival counters
         t.par = 1;
         t.xlogit2 = w.s3[0];
@@ -720,6 +739,25 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       const size_t lds = split ? m->lds_split[part] : (small ? m->lds_small : m->lds_bytes);
       if (int rc = launch_snv_towers(m, t, lds, stream)) return rc;
     }
+  }
+  if (defer) {
+    for (int part = 2; part < 4; ++part) {
+      SnvFwdArgs t = m->args_split[part];
+      t.s3[0] = w.s3[0];
+      t.s3[1] = w.s3[1];
+      t.n = sn;
+      t.x0 = w.x0;
+      t.xlogit = w.xlogit;
+      t.local_logits = w.local_logits + sc0 * nc;
+      t.out = out + sc0 * nc;
+      t.taps = nullptr;
+      t.tap_stride = a.nbuf;
+      t.stamps = packed ? g_stamps : nullptr;
+      t.status = status;
+      t.unit_counter = t.wave ? w.counters + part : nullptr;
+      if (int rc = launch_snv_towers(m, t, m->lds_split[part], stream)) return rc;
+    }
+  }
   }
   return MURAL_OK;
 }

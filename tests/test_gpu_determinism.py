@@ -53,9 +53,11 @@ def test_indel_forward_is_bitwise_repeatable_across_both_lanes():
 
 
 def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
-    """The wave-private tower kernel hands units to waves through a counter and runs instances with the window geometry at compile
-    time: neither may change a bit of the result.  Same sites with (a) tickets, (b) the fixed stride, (c) the first-stage instance
-    that reads its geometry from the arguments; 300 k sites = two chunks, several units per wave in every launch."""
+    """The wave-private tower kernel hands units to waves at a fixed stride (or, behind a switch, through a counter), runs instances
+    with the window geometry at compile time and runs the short stages of up to four chunks as one launch per tower: none of it may
+    change a bit of the result.  Same sites with (a) the fixed stride, (b) tickets, (c) the first-stage instance that reads its
+    geometry from the arguments, (d) the short-stage launches per chunk; 300 k sites = three chunks, several units per wave in
+    every launch."""
     import bench
     from mural_amd.data import PackedGenome
     dev = torch.device("cuda", 0)
@@ -81,6 +83,10 @@ def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
     monkeypatch.setenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM", "1")
     runtime_geom = run()
     monkeypatch.delenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM")
+    monkeypatch.setenv("MURAL_SNV_DEFER_SHORT", "0")      # the short-stage launches per chunk instead of once per four chunks
+    per_chunk = run()
+    monkeypatch.delenv("MURAL_SNV_DEFER_SHORT")
     assert torch.equal(base, static)
     assert torch.equal(base, runtime_geom)
+    assert torch.equal(base, per_chunk)
     assert torch.equal(base, run())
