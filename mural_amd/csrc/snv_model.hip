@@ -682,7 +682,9 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     else s.codes = s1.codes + c0 * m->shape.distal_len;
     if (int rc = launch_snv_stage1(s, packed, s.loc_on ? std::max(m->s1_lds_bytes, m->loc_lds) : m->s1_lds_bytes, stream)) return rc;
     const bool split = m->split && taps == nullptr && !small;   // the debug dump wants both towers in one tile geometry
-    if (split) MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
+    // (the unit counters are read only with MURAL_TOWER_DYNAMIC_UNITS=1: the fill is a 4 us launch per chunk otherwise wasted)
+    if (split && getenv("MURAL_TOWER_DYNAMIC_UNITS") && atoi(getenv("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
+      MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
     for (int part = 0; part < (split ? (defer ? 2 : 4) : 1); ++part) {
       if (m->longwin && part == 0) {
         // the large tower's first conv stage on segments of the pooled row: gather (with halo) -> two wave-private launches (the

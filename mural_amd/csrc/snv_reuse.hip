@@ -666,7 +666,8 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       if (int rc = mural_encode_kmer(g, pos + s0, strand + s0, sn, local_radius, local_order, 0, w.cat, stream_)) return rc;
       if (int rc = launch_snv_local(m->local, w.cat, sn, w.local_logits, stream)) return rc;
     }
-    MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));      // unit counters of this chunk's four wave-private launches
+    if (getenv("MURAL_TOWER_DYNAMIC_UNITS") && atoi(getenv("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
+      MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));      // unit counters of this chunk's four wave-private launches (read with that switch only)
     for (int t = 0; t < 2; ++t) {
       const TowerGeom& gg = m->args.geom[t];
       EdgeArgs e{};
