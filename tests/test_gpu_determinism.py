@@ -61,7 +61,7 @@ def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
     import bench
     from mural_amd.data import PackedGenome
     dev = torch.device("cuda", 0)
-    codes = bench.synthetic_genome(400_000 + 2 * bench.DISTAL_RADIUS)
+    codes = bench.synthetic_genome(540_000 + 2 * bench.DISTAL_RADIUS)
     packed, mask = bench.pack2(codes)
     genome = PackedGenome(packed, mask, len(codes), dev)
     model = bench.build_model(dev)
@@ -90,3 +90,12 @@ def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
     assert torch.equal(base, runtime_geom)
     assert torch.equal(base, per_chunk)
     assert torch.equal(base, run())
+    # more than four chunks (two short-stage launches per tower), and a last chunk of a single site
+    for n2 in (4 * 131072 + 5000, 131072 + 1):
+        idx = torch.arange(n2, device=dev, dtype=torch.int64)
+        pos, strand = idx + bench.DISTAL_RADIUS, (idx % 3 == 0).to(torch.uint8)
+        deferred = run()
+        monkeypatch.setenv("MURAL_SNV_DEFER_SHORT", "0")
+        per_chunk = run()
+        monkeypatch.delenv("MURAL_SNV_DEFER_SHORT")
+        assert torch.equal(deferred, per_chunk) and torch.equal(deferred[:131072], base[:131072])
