@@ -438,6 +438,12 @@ struct ReuseWs {
   int* counters;
 };
 
+constexpr int RU_SUPER = 4;
+int64_t reuse_super_sites() {
+  const bool off = getenv("MURAL_SNV_DEFER_SHORT") && atoi(getenv("MURAL_SNV_DEFER_SHORT")) == 0;
+  return off ? (int64_t)SNV_CHUNK : (int64_t)RU_SUPER * SNV_CHUNK;
+}
+
 size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands, void* base, ReuseWs* w) {
   const int64_t nb = std::min<int64_t>(span, RU_CHUNK_SPAN) + m->shape.distal_len;
   size_t off = 0;
@@ -452,7 +458,8 @@ size_t carve_reuse(const MuralSnvModel* m, int64_t n, int64_t span, int strands,
   size_t o_rows[2][11];
   for (int st = 0; st < 2; ++st)
     for (int i = 0; i < 11; ++i) o_rows[st][i] = ((strands >> st) & 1) ? take((size_t)nb * 32 * 4) : 0;
-  const int64_t ns = std::min<int64_t>(std::max<int64_t>(n, 1), SNV_CHUNK);
+  // (the short-stage launches run once per RU_SUPER chunks, as in the per-window path: snv_model.hip, super_chunk_sites)
+  const int64_t ns = std::min<int64_t>(std::max<int64_t>(n, 1), reuse_super_sites());
   const size_t o_cat = take((size_t)ns * std::max(m->shape.local_cols, 1) * 8);
   const size_t o_ll = take((size_t)ns * m->shape.n_class * 4);
   const size_t o_xl = take((size_t)ns * SNV_MAXCLASS * 4);
@@ -655,8 +662,13 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
   static DynLdsOnce edge_lds;
   if (int rc = edge_lds.ensure(&snv_edge_kernel)) return rc;
   const bool edge_wave = !getenv("MURAL_DEBUG_EDGE_TILE");
-  for (int64_t s0 = 0; s0 < n; s0 += SNV_CHUNK) {
-    const int64_t sn = std::min<int64_t>(SNV_CHUNK, n - s0);
+  const int64_t super = reuse_super_sites();
+  const size_t s3_site[2] = {(size_t)std::max(m->args.geom[0].L[1], 1) * SNV_C, (size_t)std::max(m->args.geom[1].L[1], 1) * SNV_C};
+  for (int64_t u0 = 0; u0 < n; u0 += super) {
+  const int64_t un = std::min<int64_t>(super, n - u0);
+  for (int64_t s0 = u0; s0 < u0 + un; s0 += SNV_CHUNK) {
+    const int64_t sn = std::min<int64_t>(SNV_CHUNK, u0 + un - s0);
+    const int64_t rel = s0 - u0;      // this chunk's place in the super-chunk's s3 / logits
     if (sh.model_no == 2) {
       const int ncol = 2 * local_radius + 1 - (local_order - 1);
       MURAL_REQUIRE(ncol == sh.local_cols, "local_radius/local_order give %d k-mer columns, model has %d", ncol, sh.local_cols);
@@ -664,7 +676,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       for (int i = 0; i < local_order; ++i) sentinel *= 4;
       MURAL_REQUIRE(sentinel + 1 == sh.emb_rows, "local_order %d does not match the embedding table (%d rows)", local_order, sh.emb_rows);
       if (int rc = mural_encode_kmer(g, pos + s0, strand + s0, sn, local_radius, local_order, 0, w.cat, stream_)) return rc;
-      if (int rc = launch_snv_local(m->local, w.cat, sn, w.local_logits, stream)) return rc;
+      if (int rc = launch_snv_local(m->local, w.cat, sn, w.local_logits + rel * nc, stream)) return rc;
     }
     if (getenv("MURAL_TOWER_DYNAMIC_UNITS") && atoi(getenv("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
       MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));      // unit counters of this chunk's four wave-private launches (read with that switch only)
@@ -700,7 +712,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
         e.R[neg] = Rrows[neg][t];
         e.S[neg] = Srows[neg][t];
       }
-      e.s3 = w.s3[t];
+      e.s3 = w.s3[t] + (size_t)rel * s3_site[t];
       if (edge_wave) {      // wave-private form (snv_tower_wave.hip); MURAL_DEBUG_EDGE_TILE=1 keeps the workgroup-tile kernel (A/B runs)
         if (int rc = launch_snv_edge_wave(e, w.counters + t, stream)) return rc;
       } else {
@@ -709,15 +721,16 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
         MURAL_HIP_CHECK(hipGetLastError());
       }
     }
-    for (int part = 2; part < 4; ++part) {
+  }
+    for (int part = 2; part < 4; ++part) {      // the short stages and the head: one launch per tower for the whole super-chunk
       SnvFwdArgs t = m->args_split[part];
       t.s3[0] = w.s3[0];
       t.s3[1] = w.s3[1];
-      t.n = sn;
+      t.n = un;
       t.x0 = nullptr;
       t.xlogit = w.xlogit;
       t.local_logits = w.local_logits;
-      t.out = out + s0 * nc;
+      t.out = out + u0 * nc;
       t.taps = nullptr;
       t.tap_stride = 0;
       t.stamps = nullptr;
