@@ -104,6 +104,12 @@ __global__ __launch_bounds__(LOC_THREADS) void snv_local_mlp_mfma(LocalDev L, co
   local_mlp_mfma_body(L, cat, n, out, d, lsm, (int)blockIdx.x, (int)gridDim.x);
 }
 
+__global__ __launch_bounds__(LOC_THREADS, 2) void snv_local_mlp_reg(LocalDev L, const int64_t* __restrict__ cat, int64_t n,
+                                                                    float* __restrict__ out, LocalMfmaDims d) {
+  extern __shared__ __attribute__((aligned(16))) float lsm[];
+  local_mlp_reg_body(L, cat, n, out, d, lsm, (int)blockIdx.x, (int)gridDim.x);
+}
+
 bool local_mfma_plan(const LocalDev& L, LocalMfmaDims* dp, size_t* lds_bytes) {
   LocalMfmaDims d;
   d.K1p = (L.in1 + 15) & ~15;
@@ -130,6 +136,16 @@ int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* ou
     LocalMfmaDims d;
     size_t lds = 0;
     if (local_mfma_plan(L, &d, &lds)) {
+      // the shipped dimensions: fragments in registers, two workgroups per CU (snv_local_mfma.h; MURAL_LOCAL_REG=0: fragments in LDS)
+      const bool reg_off = getenv("MURAL_LOCAL_REG") && atoi(getenv("MURAL_LOCAL_REG")) == 0;
+      if (!reg_off && d.K1p == 16 * LR_J1 && d.n1b == LR_N1B && d.K2p == 16 * LR_J2 && d.n2b == LR_N2B && d.K3p == 16 * LR_J3 && !d.dbg) {
+        const size_t lds_reg = ((size_t)LM_TP * (d.s1 + d.sx) + (size_t)((L.emb_rows * 5 + 3) & ~3) + d.K2p + d.K3p + 16) * sizeof(float);
+        const int64_t n_tiles = (n + LM_TP - 1) / LM_TP;
+        const int grid = (int)(n_tiles < 512 ? n_tiles : 512);
+        hipLaunchKernelGGL(snv_local_mlp_reg, dim3(grid), dim3(LOC_THREADS), lds_reg, stream, L, cat, n, out, d);
+        MURAL_HIP_CHECK(hipGetLastError());
+        return MURAL_OK;
+      }
       static DynLdsOnce big_lds;
       if (int rc = big_lds.ensure(&snv_local_mlp_mfma)) return rc;
       const int64_t n_tiles = (n + LM_TP - 1) / LM_TP;

@@ -56,8 +56,8 @@ def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
     """The wave-private tower kernel hands units to waves at a fixed stride (or, behind a switch, through a counter), runs instances
     with the window geometry at compile time and runs the short stages of up to four chunks as one launch per tower: none of it may
     change a bit of the result.  Same sites with (a) the fixed stride, (b) tickets, (c) the first-stage instance that reads its
-    geometry from the arguments, (d) the short-stage launches per chunk; 300 k sites = three chunks, several units per wave in
-    every launch."""
+    geometry from the arguments, (d) the short-stage launches per chunk, (e) the local branch's fragments in LDS; 300 k sites = three
+    chunks, several units per wave in every launch."""
     import bench
     from mural_amd.data import PackedGenome
     dev = torch.device("cuda", 0)
@@ -86,6 +86,10 @@ def test_tower_kernel_variants_agree_bit_for_bit(monkeypatch):
     monkeypatch.setenv("MURAL_SNV_DEFER_SHORT", "0")      # the short-stage launches per chunk instead of once per four chunks
     per_chunk = run()
     monkeypatch.delenv("MURAL_SNV_DEFER_SHORT")
+    monkeypatch.setenv("MURAL_LOCAL_REG", "0")            # the local branch's weight fragments in LDS instead of registers
+    local_lds = run()
+    monkeypatch.delenv("MURAL_LOCAL_REG")
+    assert torch.equal(base, local_lds)
     assert torch.equal(base, static)
     assert torch.equal(base, runtime_geom)
     assert torch.equal(base, per_chunk)
