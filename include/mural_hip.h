@@ -443,6 +443,17 @@ int mural_fasta_pack(const char* path, int64_t offset, int64_t length, uint32_t*
 int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, int64_t* start, int64_t* end, float* score,
                    uint8_t* strand, int32_t n_chrom_cap, int32_t name_cap, char* chrom_names, int64_t* n_rows,
                    int32_t* n_chroms);
+/* Rank-local streaming ingest for N-rank prediction -- replaces the reference's "one BedTool per process, split big inputs by hand"
+ * (MuRaL/scripts/run_predict.py:107, MuRaL/commands/predict.py:134-137).  mural_bed_index_scan lists the PIECES (<= piece_rows
+ * consecutive rows of one chromosome: name, byte range, rows, start of the first row) among the lines that start in
+ * [byte_lo, byte_hi); byte_lo = byte_hi = 0 only reports file_bytes (the inflated size of a gzip file).  n_pieces may exceed cap.
+ * mural_bed_parse_range parses rows skip_rows .. skip_rows + n_rows - 1 of the rows in [byte_lo, byte_hi) (all on `chrom`).
+ * Every ingest entry point reads gzip files too (inflated once per process; pybedtools / gzip.open in the reference).            */
+int mural_bed_index_scan(const char* path, int64_t byte_lo, int64_t byte_hi, int64_t piece_rows, int32_t name_cap, int64_t cap,
+                         char* names, int64_t* piece_lo, int64_t* piece_hi, int64_t* piece_rows_out, int64_t* piece_first_start,
+                         int64_t* n_pieces, int64_t* file_bytes);
+int mural_bed_parse_range(const char* path, int64_t byte_lo, int64_t byte_hi, int64_t skip_rows, int64_t n_rows, const char* chrom,
+                          int64_t* start, int64_t* end, float* score, uint8_t* strand);
 /* order[k] = input row of output row k in bed_reader order (+ rows, then - rows of every central_bp-wide segment)    */
 int mural_bed_segment_order(const int32_t* chrom_id, const int64_t* start, const uint8_t* strand, int64_t n,
                             int64_t central_bp, int64_t* order, int64_t* group, int64_t* n_groups);

@@ -60,17 +60,27 @@ struct CwGeom {
   FastDiv dL, dSc;
 };
 
+// Workgroup slots a launch asks for.  A CU holds two of these workgroups whatever launch they belong to, and the step's two towers
+// run on two streams: a launch that takes all 512 slots only time-shares the chip with its neighbour, and every workgroup pays a
+// prologue (fragments, BatchNorm finalisation) and an epilogue (batch sums / the partial row) for one unit per wave.  Rows short
+// enough to share a unit (P >= 2) ask for ONE slot per CU -- four rows per wave in the short stages, two units per wave in the mid
+// tower's first stage -- and leave the other to the other tower; rows that need a unit each keep both (two units per wave at batch
+// 4096).  Same-box A/B of the whole step, batch 4096: 498 -> 528 steps/s (tools/r6_train_slots.sh; MURAL_CW_FULL_GRID=1 is the old
+// rule).  The choice changes the order of the float sums, not their reproducibility.
+int cw_slots(int L) {
+  static const bool full = getenv("MURAL_CW_FULL_GRID") && atoi(getenv("MURAL_CW_FULL_GRID")) != 0;
+  const int pmax = (16 * CW_NBMAX - 1) / (L + 1);
+  return (full || pmax < 2) ? 2 * CW_CUS : CW_CUS;
+}
+
 bool cw_geom(int64_t B, int L, CwGeom* g) {
   std::memset(g, 0, sizeof(*g));
   if (L < 1) return false;
   const int Sc = L + 1;
   const int pmax = (16 * CW_NBMAX - 1) / Sc;
   if (pmax < 1) return false;
-  int64_t p = B / (2 * CW_WAVES * CW_CUS);  // one unit per wave (eight per CU) when the rows are short
+  int64_t p = B / (CW_WAVES * cw_slots(L));  // one unit per wave when the rows are short
   if (p > pmax) p = pmax;
-  static const int pcap = getenv("MURAL_CW_PCAP") ? atoi(getenv("MURAL_CW_PCAP")) : 0;      // experiment: rows per unit at most
-  static const int pcap_minl = getenv("MURAL_CW_PCAP_MINL") ? atoi(getenv("MURAL_CW_PCAP_MINL")) : 0;
-  if (pcap > 0 && L >= pcap_minl && p > pcap) p = pcap;
   if (p < 1) p = 1;
   g->L = L;
   g->Sc = Sc;
@@ -847,9 +857,10 @@ int cw_launch_bwd(const CwBwdArgs2& a, int gx, int gy, hipStream_t stream) {
     default: return FN<4>(__VA_ARGS__);           \
   }
 
-int cw_grid(int64_t n_units) {
+int cw_grid(int64_t n_units, int L) {
   const int64_t wgs = (n_units + CW_WAVES - 1) / CW_WAVES;
-  return (int)(wgs < 2 * CW_CUS ? wgs : 2 * CW_CUS);
+  const int slots = cw_slots(L);
+  return (int)(wgs < slots ? wgs : slots);
 }
 
 }  // namespace
@@ -879,7 +890,7 @@ int cw_conv32_fwd_jobs(const ConvFwdJob* jobs, int n, float eps, float momentum,
     a.fin = ClFin{j.acc, (double)j.B * j.L, j.gamma, j.beta, eps, momentum, j.running_mean, j.running_var, j.state};
     a.B = j.B;
     a.n_units = (j.B + a.g.P - 1) / a.g.P;
-    a.grid = cw_grid(a.n_units);
+    a.grid = cw_grid(a.n_units, j.L);
     a.dbg = cw_debug();
     a.stamps = g_cw_stamps;
     nb = a.g.nb > nb ? a.g.nb : nb;
@@ -912,7 +923,7 @@ int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream) {
     }
     a.B = j.B;
     a.n_units = (j.B + a.g.P - 1) / a.g.P;
-    a.grid = cw_grid(a.n_units);
+    a.grid = cw_grid(a.n_units, j.L);
     a.dbg = cw_debug();
     j.nrow = a.grid;
     nb = a.g.nb > nb ? a.g.nb : nb;

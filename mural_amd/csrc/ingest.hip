@@ -3,16 +3,22 @@
 //   SeqIO.to_dict(SeqIO.parse(ref_genome, 'fasta'))      MuRaL/data/preprocessing.py:836
 //   bed_reader                                            MuRaL/data/preprocessing.py:39-106
 //   the base maps of seq_digit_encoder / seq_ohe_encoder  MuRaL/data/preprocessing.py:655-666, :762-772
+// Inputs may be gzip files (the reference's own prediction example feeds data/testing.bed.gz through pybedtools, which reads .gz
+// transparently, MuRaL/scripts/run_predict.py:107): a file that starts with the gzip magic is inflated ONCE per process (zlib, every
+// member of a multi-member / bgzip file) into an unlinked temporary file and every entry point below maps that copy.
 // No device code here: the arrays produced feed mural_encode_* / mural_snv_forward_packed (include/mural_hip.h).
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <cctype>
 #include <cstdlib>
 #include <algorithm>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -21,13 +27,12 @@
 
 namespace {
 
-struct MappedFile {
+// the bytes of one file, read-only: a mapping of the file itself or -- for a gzip file -- of its inflated copy
+struct TextMap {
   const char* data = nullptr;
   size_t size = 0;
   int fd = -1;
-  bool open(const char* path) {
-    fd = ::open(path, O_RDONLY);
-    if (fd < 0) return false;
+  bool map_fd() {
     struct stat st;
     if (fstat(fd, &st) != 0) return false;
     size = (size_t)st.st_size;
@@ -35,12 +40,165 @@ struct MappedFile {
     void* p = mmap(nullptr, size, PROT_READ, MAP_PRIVATE, fd, 0);
     if (p == MAP_FAILED) return false;
     data = static_cast<const char*>(p);
-    madvise(p, size, MADV_SEQUENTIAL);
     return true;
   }
-  ~MappedFile() {
+  ~TextMap() {
     if (data) munmap(const_cast<char*>(data), size);
     if (fd >= 0) ::close(fd);
+  }
+};
+
+// inflate every gzip member of `src` into an unlinked temporary file ($TMPDIR, /tmp; anonymous memory if neither is writable)
+int inflate_to_tmpfile(const TextMap& src, std::string* err) {
+  int out = -1;
+  const char* dirs[2] = {std::getenv("TMPDIR"), "/tmp"};
+  for (const char* d : dirs) {
+    if (!d || !*d) continue;
+    std::string tmpl = std::string(d) + "/mural_gz_XXXXXX";
+    out = mkstemp(&tmpl[0]);
+    if (out >= 0) {
+      unlink(tmpl.c_str());
+      break;
+    }
+  }
+  if (out < 0) out = memfd_create("mural_gz", 0);
+  if (out < 0) {
+    *err = "cannot create a temporary file for the inflated copy";
+    return -1;
+  }
+  z_stream zs;
+  std::memset(&zs, 0, sizeof(zs));
+  if (inflateInit2(&zs, 15 + 16) != Z_OK) {
+    *err = "zlib: inflateInit2 failed";
+    ::close(out);
+    return -1;
+  }
+  std::vector<unsigned char> buf(4u << 20);
+  const unsigned char* in = reinterpret_cast<const unsigned char*>(src.data);
+  size_t left = src.size;
+  bool ok = true, member_open = false;
+  while (ok && left > 0) {
+    if (!member_open) {      // between members: zero padding is legal behind the last one
+      size_t z = 0;
+      while (z < left && in[z] == 0) ++z;
+      if (z == left) break;
+      in += z;
+      left -= z;
+      member_open = true;
+    }
+    const size_t feed = std::min<size_t>(left, 1u << 30);
+    zs.next_in = const_cast<unsigned char*>(in);
+    zs.avail_in = (uInt)feed;
+    int rc = Z_OK;
+    do {
+      zs.next_out = buf.data();
+      zs.avail_out = (uInt)buf.size();
+      rc = inflate(&zs, Z_NO_FLUSH);
+      if (rc != Z_OK && rc != Z_STREAM_END && rc != Z_BUF_ERROR) {
+        *err = std::string("zlib: ") + (zs.msg ? zs.msg : "corrupt gzip stream");
+        ok = false;
+        break;
+      }
+      const size_t have = buf.size() - zs.avail_out;
+      size_t off = 0;
+      while (off < have) {
+        const ssize_t w = ::write(out, buf.data() + off, have - off);
+        if (w <= 0) {
+          *err = "cannot write the inflated copy (temporary directory full?)";
+          ok = false;
+          break;
+        }
+        off += (size_t)w;
+      }
+    } while (ok && rc != Z_STREAM_END && (zs.avail_out == 0 || zs.avail_in > 0));
+    const size_t used = feed - zs.avail_in;
+    in += used;
+    left -= used;
+    if (ok && rc == Z_STREAM_END) {
+      member_open = false;
+      inflateReset(&zs);
+    } else if (ok && used == 0 && rc == Z_BUF_ERROR) {
+      *err = "zlib: truncated gzip stream";
+      ok = false;
+    }
+  }
+  if (ok && member_open) {
+    *err = "zlib: truncated gzip stream";
+    ok = false;
+  }
+  inflateEnd(&zs);
+  if (!ok) {
+    ::close(out);
+    return -1;
+  }
+  return out;
+}
+
+// inflated copies are kept per process (a FASTA record is packed by one call per record: re-inflating a genome per call would
+// cost seconds each); an entry is dropped when the file changes or when four newer ones exist
+struct GzEntry {
+  std::string path;
+  dev_t dev;
+  ino_t ino;
+  off_t size;
+  struct timespec mtime;
+  std::shared_ptr<TextMap> text;
+};
+std::mutex g_gz_mutex;
+std::vector<GzEntry> g_gz_cache;
+
+// nullptr + *err on failure
+std::shared_ptr<TextMap> open_text(const char* path, std::string* err) {
+  auto raw = std::make_shared<TextMap>();
+  raw->fd = ::open(path, O_RDONLY);
+  struct stat st;
+  if (raw->fd < 0 || fstat(raw->fd, &st) != 0 || !raw->map_fd()) {
+    *err = "cannot open";
+    return nullptr;
+  }
+  const bool gz = raw->size >= 2 && (unsigned char)raw->data[0] == 0x1f && (unsigned char)raw->data[1] == 0x8b;
+  if (!gz) {
+    if (raw->data) madvise(const_cast<char*>(raw->data), raw->size, MADV_SEQUENTIAL);
+    return raw;
+  }
+  std::lock_guard<std::mutex> lock(g_gz_mutex);
+  for (size_t i = 0; i < g_gz_cache.size(); ++i) {
+    GzEntry& e = g_gz_cache[i];
+    if (e.dev == st.st_dev && e.ino == st.st_ino) {
+      if (e.size == st.st_size && e.mtime.tv_sec == st.st_mtim.tv_sec && e.mtime.tv_nsec == st.st_mtim.tv_nsec) {
+        GzEntry hit = e;
+        g_gz_cache.erase(g_gz_cache.begin() + (long)i);
+        g_gz_cache.push_back(hit);
+        return hit.text;
+      }
+      g_gz_cache.erase(g_gz_cache.begin() + (long)i);
+      break;
+    }
+  }
+  auto text = std::make_shared<TextMap>();
+  text->fd = inflate_to_tmpfile(*raw, err);
+  if (text->fd < 0) return nullptr;
+  if (!text->map_fd()) {
+    *err = "cannot map the inflated copy";
+    return nullptr;
+  }
+  if (g_gz_cache.size() >= 4) g_gz_cache.erase(g_gz_cache.begin());
+  g_gz_cache.push_back(GzEntry{path, st.st_dev, st.st_ino, st.st_size, st.st_mtim, text});
+  return text;
+}
+
+// the entry points' view of a file (kept alive by the shared mapping)
+struct MappedFile {
+  const char* data = nullptr;
+  size_t size = 0;
+  std::shared_ptr<TextMap> hold;
+  std::string why;
+  bool open(const char* path) {
+    hold = open_text(path, &why);
+    if (!hold) return false;
+    data = hold->data;
+    size = hold->size;
+    return true;
   }
 };
 
@@ -74,7 +232,7 @@ extern "C" int mural_fasta_scan(const char* path, int64_t n_cap, int32_t name_ca
   MURAL_REQUIRE(path && n_records, "NULL argument");
   MappedFile f;
   if (!f.open(path)) {
-    set_error("cannot open FASTA file %s", path);
+    set_error("cannot open FASTA file %s%s%s", path, f.why.empty() || f.why == "cannot open" ? "" : ": ", f.why == "cannot open" ? "" : f.why.c_str());
     return MURAL_E_INVALID;
   }
   const char* p = f.data;
@@ -124,7 +282,7 @@ extern "C" int mural_fasta_pack(const char* path, int64_t offset, int64_t length
   MURAL_REQUIRE(path && packed2 && nmask, "NULL argument");
   MappedFile f;
   if (!f.open(path)) {
-    set_error("cannot open FASTA file %s", path);
+    set_error("cannot open FASTA file %s%s%s", path, f.why.empty() || f.why == "cannot open" ? "" : ": ", f.why == "cannot open" ? "" : f.why.c_str());
     return MURAL_E_INVALID;
   }
   MURAL_REQUIRE(offset >= 0 && (size_t)offset <= f.size, "record offset outside the file");
@@ -311,7 +469,7 @@ extern "C" int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, 
   MURAL_REQUIRE(path && n_rows && n_chroms, "NULL argument");
   MappedFile f;
   if (!f.open(path)) {
-    set_error("cannot open BED file %s", path);
+    set_error("cannot open BED file %s%s%s", path, f.why.empty() || f.why == "cannot open" ? "" : ": ", f.why == "cannot open" ? "" : f.why.c_str());
     return MURAL_E_INVALID;
   }
   const char* end = f.data + f.size;
@@ -406,6 +564,232 @@ extern "C" int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, 
     for (int k = 0; k < (int)chroms.size() && k < n_chrom_cap; ++k) {
       std::strncpy(chrom_names + (int64_t)k * name_cap, chroms[(size_t)k].c_str(), (size_t)name_cap - 1);
       chrom_names[(int64_t)k * name_cap + name_cap - 1] = '\0';
+    }
+  return MURAL_OK;
+}
+
+// ---- rank-local, streaming BED ingest (whole-genome prediction on N ranks: mural_amd.predict.predict_bed_sharded) ------------------
+// The reference parses one whole BED per process and advises to split big inputs into ~1 M-site files by hand
+// (MuRaL/commands/predict.py:134-137, MuRaL/scripts/run_predict.py:107).  Here the file is INDEXED once -- every rank scans 1 / N of
+// its bytes (mural_bed_index_scan) and the ranks exchange the pieces they found -- and afterwards a rank parses only the rows of its
+// own block of a chromosome (mural_bed_parse_range): host memory is bounded by one rank's share of one chromosome.
+//
+// A piece = consecutive rows of ONE chromosome: name, byte range [lo, hi) (from the first byte of its first row to the first byte
+// behind its last row's line), row count, start of its first row.  A piece never holds more than piece_rows rows, so that row r of
+// a chromosome is found by a newline scan of at most one piece.  The scan covers the lines that START in [byte_lo, byte_hi)
+// (byte_lo is moved to the next line start unless it is one); comment / track / browser / blank lines belong to no piece.
+// Call with byte_lo = byte_hi = 0 to learn file_bytes (the inflated size of a .gz file).  n_pieces may exceed cap: call again.
+namespace {
+
+struct BedPiece {
+  std::string name;
+  int64_t lo, hi, rows, first_start;
+};
+
+void bed_index_chunk(const char* base, const char* lo, const char* hi, const char* file_end, int64_t piece_rows,
+                     std::vector<BedPiece>& out, std::string& error, const char* path) {
+  const char* p = lo;
+  BedPiece cur{std::string(), 0, 0, 0, 0};
+  auto flush = [&]() {
+    if (cur.rows) out.push_back(cur);
+    cur.rows = 0;
+  };
+  while (p < hi) {                                             // (a line that starts in front of hi is scanned to its end)
+    const char* e = line_end(p, file_end);
+    const char* le = e;
+    while (le > p && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;
+    const size_t len = (size_t)(le - p);
+    const char* next = e < file_end ? e + 1 : file_end;
+    if (!bed_skip_line(p, len)) {
+      const char* t = static_cast<const char*>(std::memchr(p, '\t', len));
+      const char* t2 = t ? static_cast<const char*>(std::memchr(t + 1, '\t', (size_t)(le - t - 1))) : nullptr;
+      long long st = 0;
+      if (!t || !t2 || !parse_i64_field(t + 1, (size_t)(t2 - t - 1), &st) || st < 0) {
+        char msg[512];
+        std::snprintf(msg, sizeof(msg), "%s: malformed BED row at byte offset %lld", path, (long long)(p - base));
+        error = msg;
+        return;
+      }
+      const size_t fl = (size_t)(t - p);
+      if (cur.rows && (cur.rows >= piece_rows || cur.name.size() != fl || std::memcmp(cur.name.data(), p, fl) != 0)) flush();
+      if (!cur.rows) {
+        cur.name.assign(p, fl);
+        cur.lo = (int64_t)(p - base);
+        cur.first_start = st;
+      }
+      ++cur.rows;
+      cur.hi = (int64_t)(next - base);
+    }
+    p = next;
+  }
+  flush();
+}
+
+// first line start at or behind `at`
+const char* align_line(const char* base, const char* at, const char* end) {
+  if (at <= base) return base;
+  if (at >= end) return end;
+  if (at[-1] == '\n') return at;
+  const char* e = line_end(at, end);
+  return e < end ? e + 1 : end;
+}
+
+}  // namespace
+
+extern "C" int mural_bed_index_scan(const char* path, int64_t byte_lo, int64_t byte_hi, int64_t piece_rows, int32_t name_cap, int64_t cap,
+                                    char* names, int64_t* p_lo, int64_t* p_hi, int64_t* p_rows, int64_t* p_first_start,
+                                    int64_t* n_pieces, int64_t* file_bytes) {
+  MURAL_REQUIRE(path && n_pieces && file_bytes, "NULL argument");
+  MURAL_REQUIRE(piece_rows >= 1 && byte_lo >= 0 && byte_hi >= byte_lo, "bad scan range");
+  MappedFile f;
+  if (!f.open(path)) {
+    set_error("cannot open BED file %s%s%s", path, f.why == "cannot open" ? "" : ": ", f.why == "cannot open" ? "" : f.why.c_str());
+    return MURAL_E_INVALID;
+  }
+  *file_bytes = (int64_t)f.size;
+  *n_pieces = 0;
+  const char* end = f.data + f.size;
+  const char* lo = align_line(f.data, f.data + std::min<size_t>((size_t)byte_lo, f.size), end);
+  const char* hi = align_line(f.data, f.data + std::min<size_t>((size_t)byte_hi, f.size), end);
+  if (lo >= hi) return MURAL_OK;
+  const size_t span = (size_t)(hi - lo);
+  const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), span / (4u << 20) + 1));
+  std::vector<std::vector<BedPiece>> found((size_t)T);
+  std::vector<std::string> errors((size_t)T);
+  std::vector<const char*> cut((size_t)T + 1);
+  cut[0] = lo;
+  for (int k = 1; k < T; ++k) cut[(size_t)k] = std::max(cut[(size_t)k - 1], align_line(f.data, lo + span * (size_t)k / (size_t)T, end));
+  cut[(size_t)T] = hi;
+  run_parallel(T, [&](int k) {
+    bed_index_chunk(f.data, cut[(size_t)k], std::min(cut[(size_t)k + 1], hi), end, piece_rows, found[(size_t)k], errors[(size_t)k], path);
+  });
+  for (auto& e : errors)
+    if (!e.empty()) {
+      set_error("%s", e.c_str());
+      return MURAL_E_INVALID;
+    }
+  int64_t n = 0;
+  for (auto& v : found)
+    for (auto& pc : v) {
+      if (n < cap) {
+        MURAL_REQUIRE(names && p_lo && p_hi && p_rows && p_first_start, "NULL output array");
+        if ((int64_t)pc.name.size() >= name_cap) {
+          set_error("%s: chromosome name longer than %d bytes", path, name_cap - 1);
+          return MURAL_E_INVALID;
+        }
+        std::memcpy(names + n * name_cap, pc.name.data(), pc.name.size());
+        names[n * name_cap + (int64_t)pc.name.size()] = '\0';
+        p_lo[n] = pc.lo; p_hi[n] = pc.hi; p_rows[n] = pc.rows; p_first_start[n] = pc.first_start;
+      }
+      ++n;
+    }
+  *n_pieces = n;
+  return MURAL_OK;
+}
+
+// Rows skip_rows .. skip_rows + n_rows - 1 of the rows that start in the bytes [byte_lo, byte_hi) (byte_lo = a line start), all of
+// chromosome `chrom`: start, end, score (class label), strand (0 '+', 1 '-').  The range is cut at line boundaries and parsed by the
+// host threads of mural_bed_read.  A row of another chromosome, a malformed row or fewer rows than asked for: MURAL_E_INVALID (the
+// file changed behind the index).
+extern "C" int mural_bed_parse_range(const char* path, int64_t byte_lo, int64_t byte_hi, int64_t skip_rows, int64_t n_rows, const char* chrom,
+                                     int64_t* start, int64_t* end_, float* score, uint8_t* strand) {
+  MURAL_REQUIRE(path && chrom, "NULL argument");
+  MURAL_REQUIRE(byte_lo >= 0 && byte_hi >= byte_lo && skip_rows >= 0 && n_rows >= 0, "bad parse range");
+  if (n_rows == 0) return MURAL_OK;
+  MURAL_REQUIRE(start && end_ && score && strand, "NULL output array");
+  MappedFile f;
+  if (!f.open(path)) {
+    set_error("cannot open BED file %s%s%s", path, f.why == "cannot open" ? "" : ": ", f.why == "cannot open" ? "" : f.why.c_str());
+    return MURAL_E_INVALID;
+  }
+  MURAL_REQUIRE((size_t)byte_hi <= f.size, "%s: parse range behind the end of the file (the file changed behind the index)", path);
+  const char* lo = f.data + byte_lo;
+  const char* hi = f.data + byte_hi;
+  const char* end = f.data + f.size;
+  MURAL_REQUIRE(byte_lo == 0 || lo[-1] == '\n', "%s: parse range does not start at a line start", path);
+  const size_t span = (size_t)(hi - lo);
+  const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), span / (4u << 20) + 1));
+  std::vector<BedChunk> ch((size_t)T);
+  const char* p = lo;
+  for (int k = 0; k < T; ++k) {
+    ch[(size_t)k].lo = p;
+    const char* c = k + 1 == T ? hi : std::max(p, std::min(hi, align_line(f.data, lo + span * (size_t)(k + 1) / (size_t)T, end)));
+    ch[(size_t)k].hi = c;
+    p = c;
+  }
+  run_parallel(T, [&](int k) { bed_parse_chunk(ch[(size_t)k], path, false, nullptr, nullptr, nullptr, nullptr, nullptr); });
+  int64_t n = 0;
+  for (auto& c : ch) {
+    c.row0 = n;
+    n += c.rows;
+  }
+  if (n < skip_rows + n_rows) {
+    set_error("%s: %lld rows in the byte range, the index announced %lld (the file changed behind the index)", path, (long long)n,
+              (long long)(skip_rows + n_rows));
+    return MURAL_E_INVALID;
+  }
+  const size_t clen = std::strlen(chrom);
+  run_parallel(T, [&](int k) {
+    BedChunk& c = ch[(size_t)k];
+    if (c.row0 + c.rows <= skip_rows || c.row0 >= skip_rows + n_rows) return;
+    const char* q = c.lo;
+    int64_t r = c.row0;
+    while (q < c.hi && r < skip_rows + n_rows) {
+      const char* e = line_end(q, c.hi);
+      const char* le = e;
+      while (le > q && (le[-1] == '\r' || le[-1] == ' ' || le[-1] == '\t')) --le;
+      const size_t len = (size_t)(le - q);
+      if (!bed_skip_line(q, len)) {
+        if (r >= skip_rows) {
+          const char* fld[6];
+          size_t flen[6];
+          int nf = 0;
+          const char* w = q;
+          while (w <= le && nf < 6) {
+            const char* t = static_cast<const char*>(std::memchr(w, '\t', (size_t)(le - w)));
+            if (!t) t = le;
+            fld[nf] = w;
+            flen[nf] = (size_t)(t - w);
+            ++nf;
+            w = t + 1;
+          }
+          long long s = 0, t2 = 0;
+          float sc = 0.f;
+          char msg[512];
+          if (nf < 6) {
+            std::snprintf(msg, sizeof(msg), "%s: expected 6 tab-separated BED columns (chrom start end name score strand), got %d at byte offset %lld",
+                          path, nf, (long long)(q - f.data));
+            c.error = msg;
+            return;
+          }
+          const bool ok = parse_i64_field(fld[1], flen[1], &s) && parse_i64_field(fld[2], flen[2], &t2) &&
+                          parse_score_field(fld[4], flen[4], &sc) && flen[5] == 1 && (fld[5][0] == '+' || fld[5][0] == '-');
+          if (!ok || s < 0 || t2 < s) {
+            std::snprintf(msg, sizeof(msg), "%s: malformed BED row at byte offset %lld", path, (long long)(q - f.data));
+            c.error = msg;
+            return;
+          }
+          if (flen[0] != clen || std::memcmp(fld[0], chrom, clen) != 0) {
+            std::snprintf(msg, sizeof(msg), "%s: row at byte offset %lld is not on chromosome %s (the file changed behind the index)", path,
+                          (long long)(q - f.data), chrom);
+            c.error = msg;
+            return;
+          }
+          const int64_t o = r - skip_rows;
+          start[o] = s;
+          end_[o] = t2;
+          score[o] = sc;
+          strand[o] = fld[5][0] == '-' ? 1 : 0;
+        }
+        ++r;
+      }
+      q = e < c.hi ? e + 1 : c.hi;
+    }
+  });
+  for (auto& c : ch)
+    if (!c.error.empty()) {
+      set_error("%s", c.error.c_str());
+      return MURAL_E_INVALID;
     }
   return MURAL_OK;
 }

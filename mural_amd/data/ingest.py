@@ -108,6 +108,124 @@ def read_bed(path):
     return BedSites(cn, cid, start, end, score, strand)
 
 
+PIECE_ROWS = 1 << 18      # rows per index piece at most: finding row r of a chromosome costs a newline scan of one piece
+
+
+def _scan_bed_pieces(path, byte_lo, byte_hi, piece_rows):
+    """([(name, byte_lo, byte_hi, rows, first_start)], file_bytes) for the rows that start in [byte_lo, byte_hi)."""
+    lib = _lib.lib()
+    cap = 1 << 12
+    while True:
+        names = C.create_string_buffer(cap * _NAME)
+        cols = [np.zeros(cap, np.int64) for _ in range(4)]
+        n, size = C.c_int64(0), C.c_int64(0)
+        _lib.check(lib.mural_bed_index_scan(path.encode(), int(byte_lo), int(byte_hi), int(piece_rows), _NAME, cap, names,
+                                           *(c.ctypes.data for c in cols), C.byref(n), C.byref(size)))
+        if n.value <= cap:
+            break
+        cap = int(n.value)
+    raw = names.raw
+    out = [(raw[i * _NAME:(i + 1) * _NAME].split(b"\0", 1)[0].decode(), int(cols[0][i]), int(cols[1][i]), int(cols[2][i]), int(cols[3][i]))
+           for i in range(n.value)]
+    return out, int(size.value)
+
+
+@dataclass
+class BedRun:
+    """Consecutive rows of one chromosome in file order (bed_reader restarts its segment grid at every such run)."""
+    name: str
+    row0: int               # file row index of the run's first row
+    rows: int
+    first_start: int        # start of the run's first row (the FILE's first run anchors its grid there, preprocessing.py:63-64)
+    pieces: list            # [(byte_lo, byte_hi, rows)]
+
+
+class BedIndex:
+    """Chromosome runs of a BED file with byte offsets: what a rank needs to parse ONLY its own block of a chromosome's rows.
+
+    The reference opens one BedTool per process over the whole file (MuRaL/scripts/run_predict.py:107) and advises to split big
+    inputs by hand (MuRaL/commands/predict.py:134-137).  ``BedIndex.build`` scans 1 / world of the file's bytes on every rank
+    (C++ host threads; first two fields of a row only) and exchanges the pieces found (a few KB: ``all_gather_object``, metadata
+    only); ``read_rows`` then parses a row range of one chromosome.  gzip files are inflated once per process."""
+
+    def __init__(self, path, pieces, file_bytes):
+        self.path, self.file_bytes = os.fspath(path), file_bytes
+        self.runs, self.chroms = [], {}
+        row = 0
+        for name, lo, hi, rows, first in pieces:
+            if self.runs and self.runs[-1].name == name:
+                self.runs[-1].pieces.append((lo, hi, rows))
+                self.runs[-1].rows += rows
+            else:
+                self.chroms.setdefault(name, []).append(len(self.runs))
+                self.runs.append(BedRun(name, row, rows, first, [(lo, hi, rows)]))
+            row += rows
+        self.rows = row
+
+    @classmethod
+    def build(cls, path, rank=0, world=1, group=None, piece_rows=None, emulate=False, seconds=None):
+        """`emulate`: no process group -- this process scans every rank's share itself and reports the time of ITS share
+        (`rank` of `world`) in seconds['index_scan'] (the measurement of one rank's share of an N-rank run)."""
+        import time
+        path = os.fspath(path)
+        piece_rows = PIECE_ROWS if piece_rows is None else piece_rows
+        _, size = _scan_bed_pieces(path, 0, 0, piece_rows)
+        cut = [size * r // world for r in range(world + 1)]
+        t0 = time.perf_counter()
+        mine, _ = _scan_bed_pieces(path, cut[rank], cut[rank + 1], piece_rows)
+        if seconds is not None:
+            seconds["index_scan"] = time.perf_counter() - t0
+        if world == 1:
+            everyone = [mine]
+        elif emulate:
+            everyone = [mine if r == rank else _scan_bed_pieces(path, cut[r], cut[r + 1], piece_rows)[0] for r in range(world)]
+        else:
+            import torch.distributed as dist
+            everyone = [None] * world
+            dist.all_gather_object(everyone, mine, group=group)
+        return cls(path, [p for part in everyone for p in part], size)
+
+    def chrom_rows(self, name):
+        return sum(self.runs[i].rows for i in self.chroms[name])
+
+    def read_rows(self, run_index, r0, r1):
+        """(start int64, end int64, score float32, strand uint8) of rows r0 .. r1 - 1 of a run."""
+        run = self.runs[run_index]
+        if not (0 <= r0 <= r1 <= run.rows):
+            raise ValueError(f"rows [{r0}, {r1}) outside a run of {run.rows} rows")
+        n = r1 - r0
+        start, end = np.zeros(n, np.int64), np.zeros(n, np.int64)
+        score, strand = np.zeros(n, np.float32), np.zeros(n, np.uint8)
+        if n:
+            cum = 0
+            first = last = None
+            for i, (_, _, rows) in enumerate(run.pieces):
+                if first is None and cum + rows > r0:
+                    first, skip = i, r0 - cum
+                if cum < r1:
+                    last = i
+                cum += rows
+            _lib.check(_lib.lib().mural_bed_parse_range(self.path.encode(), run.pieces[first][0], run.pieces[last][1], skip, n,
+                                                       run.name.encode(), start.ctypes.data, end.ctypes.data, score.ctypes.data,
+                                                       strand.ctypes.data))
+        return start, end, score, strand
+
+    def read_block(self, name, b0, b1):
+        """Rows b0 .. b1 - 1 of chromosome `name` in FILE order (its runs concatenated): (start, end, score, strand)."""
+        parts, off = [], 0
+        for i in self.chroms[name]:
+            rows = self.runs[i].rows
+            lo, hi = max(b0 - off, 0), min(b1 - off, rows)
+            if lo < hi:
+                parts.append(self.read_rows(i, lo, hi))
+            off += rows
+        if not parts:
+            return np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(0, np.float32), np.zeros(0, np.uint8)
+        if len(parts) == 1:
+            return parts[0]
+        return tuple(np.concatenate([p[k] for p in parts]) for k in range(4))
+
+
 def bed_order(sites, central_bp):
     """(order, group): bed_reader row order of `sites` (see batching.segment_order, here in C++)."""
     n = len(sites)

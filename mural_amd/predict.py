@@ -776,14 +776,270 @@ def _device_of(forward):
     return None
 
 
-def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="snv", group=None, sink=None, collect=True, timings=None):
+class _ShardTail:
+    """What happens to a gathered shard (rows of one chromosome in bed_reader order): the per-(segment, strand) focal-base check --
+    its verdict is read one shard late, so no rank waits for work just enqueued --, the sink, the collection for the caller."""
+
+    def __init__(self, forward, model_type, sink, collect, T, dev, rank):
+        self.model_type, self.sink, self.collect, self.T, self.dev = model_type, sink, collect, T, dev
+        self.feeds_sink = sink is not None and (rank == 0 or getattr(sink, "parts", False))
+        self.need_meta = collect or self.feeds_sink
+        # HipShardForward with a calibration chain hands over calibrated probabilities: the flag travels with every shard (and the
+        # collected result) so that a sink / write_predictions asked to calibrate as well refuses instead of calibrating twice
+        self.calibrated = bool(getattr(forward, "calibrated", False))
+        self.kept, self.pending = [], None
+        T.update({"compute_enqueue": 0.0, "gather": 0.0, "sink": 0.0, "focal_wait": 0.0})
+
+    def _finish_check(self):
+        pc, self.pending = self.pending, None
+        if pc is None:
+            return
+        t = time.perf_counter()
+        ev, host = pc
+        ev.synchronize()
+        self.T["focal_wait"] += time.perf_counter() - t
+        if int(host[0]) != 0:
+            raise ValueError(_FOCAL_MSG)
+
+    def __call__(self, chrom, runs, full, start, end, strand, label, grp, file_rows=None):
+        """`full`: (n, k + 1) probabilities + focal base; `grp`: non-decreasing group ids; `runs`: [(lo, hi)] positions of the shard's
+        rows in the whole input's bed_reader order; `file_rows`: file row index per row (rank-local ingest) or None."""
+        n, k = full.shape[0], full.shape[1] - 1
+        dev = self.dev
+        if dev is not None:
+            if self.model_type == "snv":
+                status = torch.zeros(1, dtype=torch.int32, device=dev)
+                with torch.cuda.device(dev):
+                    _lib.check(_lib.lib().mural_focal_group_check(full.data_ptr(), int(full.dtype == torch.float64), full.stride(0), k,
+                                                                 grp.contiguous().data_ptr(), n, status.data_ptr(),
+                                                                 _lib.current_stream_ptr(dev)))
+                    host = torch.zeros(1, dtype=torch.int32).pin_memory()
+                    host.copy_(status, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self._finish_check()               # the verdict of the PREVIOUS shard
+                self.pending = (ev, host)
+            shard = None
+            if self.need_meta:
+                shard = {"chrom": chrom, "start": start, "end": end, "strand": strand, "label": label, "prob": full, "n_class": k,
+                         "calibrated": self.calibrated}
+        else:
+            full = full.cpu().numpy() if isinstance(full, torch.Tensor) else np.asarray(full)
+            as_np = lambda a: a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a)       # noqa: E731
+            if self.model_type == "snv":
+                check_focal_groups(full[:, -1].astype(np.int64), as_np(grp))
+            shard = {"chrom": chrom, "start": as_np(start), "end": as_np(end), "strand": as_np(strand), "label": as_np(label),
+                     "prob": full[:, :-1], "n_class": k, "calibrated": self.calibrated}
+        if self.feeds_sink:
+            t0 = time.perf_counter()
+            self.sink(shard)
+            self.T["sink"] += time.perf_counter() - t0
+        if self.collect:
+            cpu = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)     # noqa: E731
+            self.kept.append((runs, {"start": cpu(shard["start"]), "end": cpu(shard["end"]), "strand": cpu(shard["strand"]),
+                                     "label": cpu(shard["label"]), "prob": cpu(shard["prob"])[:, :k], "chrom": chrom,
+                                     "file_rows": None if file_rows is None else cpu(file_rows)}))
+
+    def abort(self):
+        # the verdict of a shard's focal-base check is read one shard late, i.e. after that shard's rows went to the sink: a failing
+        # run must not leave a partial table with a valid-looking header behind (the reference exits before writing anything)
+        if self.feeds_sink and hasattr(self.sink, "abort"):
+            self.sink.abort()
+
+    def close(self):
+        self._finish_check()
+        if self.feeds_sink and hasattr(self.sink, "close"):
+            t0 = time.perf_counter()
+            self.sink.close()
+            self.T["sink_close"] = time.perf_counter() - t0
+
+    def result(self, n_all, order):
+        if not self.collect:
+            return n_all
+        if not self.kept:
+            return {"chrom": np.zeros(0, object), "start": np.zeros(0, np.int64), "end": np.zeros(0, np.int64),
+                    "strand": np.zeros(0, object), "label": np.zeros(0, np.float32), "prob": np.zeros((0, 0), np.float32),
+                    "order": np.zeros(0, np.int64)}
+        k = self.kept[0][1]["prob"].shape[1]
+        if order is None:
+            order = np.empty(n_all, np.int64)
+        out = {"chrom": np.empty(n_all, object), "start": np.empty(n_all, np.int64), "end": np.empty(n_all, np.int64),
+               "strand": np.empty(n_all, object), "label": np.empty(n_all, np.float32),
+               "prob": np.empty((n_all, k), self.kept[0][1]["prob"].dtype), "order": order, "calibrated": self.calibrated}
+        for runs, sh in self.kept:
+            o = 0
+            for lo, hi in runs:
+                m = hi - lo
+                out["chrom"][lo:hi] = sh["chrom"]
+                out["start"][lo:hi], out["end"][lo:hi] = sh["start"][o:o + m], sh["end"][o:o + m]
+                out["strand"][lo:hi] = np.where(sh["strand"][o:o + m] == 1, "-", "+")
+                out["label"][lo:hi], out["prob"][lo:hi] = sh["label"][o:o + m], sh["prob"][o:o + m]
+                if sh["file_rows"] is not None:
+                    out["order"][lo:hi] = sh["file_rows"][o:o + m]
+                o += m
+        return out
+
+
+def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="snv", group=None, sink=None, collect=True, timings=None,
+                        ingest="ranked", emulate=None):
     """Sharded file-level prediction.  `forward(chrom_name, pos, strand) -> (rows, n_class + 1)` tensor (probabilities + focal
-    base; see HipShardForward) is called once per shard (= chromosome, in ascending name order) with THIS rank's block of the
-    shard's sites in bed_reader order.  Every rank takes part in one all_gather per shard; `sink(shard_dict)` is called on rank 0
-    with the gathered shard (keys chrom, start, end, strand, label, prob, n_class, order; device tensors when `forward` has a HIP
-    ``device`` attribute, numpy arrays otherwise).  With `collect` the function also returns those arrays for ALL rows in
-    bed_reader order on every rank -- leave it off for genome-scale inputs and let the sink stream them out.  Returns the dict
-    (or the row count if not collecting).  `timings`: optional dict that receives the wall-clock split of this call."""
+    base; see HipShardForward) is called once per shard (= chromosome, in ascending name order) with THIS rank's contiguous block
+    of the shard's sites.  Every rank takes part in one all_gather per shard; `sink(shard_dict)` is called on rank 0 (every rank
+    for a part-file sink) with the gathered shard in bed_reader order (keys chrom, start, end, strand, label, prob, n_class;
+    device tensors when `forward` has a HIP ``device`` attribute, numpy arrays otherwise).  With `collect` the function also returns
+    those arrays for ALL rows in bed_reader order on every rank -- leave it off for genome-scale inputs and let the sink stream
+    them out.  Returns the dict (or the row count if not collecting).  `timings`: optional dict that receives the wall-clock split.
+
+    `ingest="ranked"` (default): the BED file is indexed once -- every rank scans 1 / world of its bytes -- and a rank parses only
+    its own block of every chromosome (``data.ingest.BedIndex``); the gathered row carries the site columns next to the
+    probabilities, so host memory per rank is bounded by its share of one chromosome.  `ingest="whole"`: every rank parses the
+    whole file (the reference's per-process BedTool, run_predict.py:107); the two produce identical results.
+    `emulate=(rank, world)`: no process group -- run ONE rank's share of a `world`-rank run (its index scan, parse, compute,
+    sort / format share with a part-file sink) and report the host seconds spent on standing in for the other ranks in
+    timings['emulation'] (bench.py: config5_e2e.rank_share)."""
+    if ingest == "whole":
+        if emulate is not None:
+            raise ValueError("emulate=(rank, world) needs ingest='ranked'")
+        return _predict_bed_whole(forward, bed_path, segment_center, model_type, group, sink, collect, timings)
+    if ingest != "ranked":
+        raise ValueError(f"ingest must be 'ranked' or 'whole', got {ingest!r}")
+    return _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, sink, collect, timings, emulate)
+
+
+def _row_layout(k, f64):
+    """Byte layout of a gathered row: start i64 | end i64 | prob k x (f64 | f32) | focal (same type) | label f32 | strand u8 | pad."""
+    e = 8 if f64 else 4
+    off_prob = 16
+    off_label = off_prob + (k + 1) * e
+    off_strand = off_label + 4
+    width = (off_strand + 1 + 7) // 8 * 8
+    return off_prob, off_label, off_strand, width
+
+
+def _pack_rows(local, start, end, strand, label):
+    """(m, W) uint8 rows of this rank's block: the forward's (m, k + 1) matrix with the site columns beside it."""
+    m, k = local.shape[0], local.shape[1] - 1
+    f64 = local.dtype == torch.float64
+    off_prob, off_label, off_strand, W = _row_layout(k, f64)
+    buf = torch.zeros((m, W), dtype=torch.uint8, device=local.device)
+    se = buf[:, 0:16].view(torch.int64)
+    se[:, 0], se[:, 1] = start, end
+    buf[:, off_prob:off_label].view(local.dtype)[:] = local
+    buf[:, off_label:off_label + 4].view(torch.float32)[:, 0] = label
+    buf[:, off_strand] = strand
+    return buf
+
+
+def _unpack_rows(full, k, dtype):
+    off_prob, off_label, off_strand, _ = _row_layout(k, dtype == torch.float64)
+    se = full[:, 0:16].view(torch.int64)
+    return (full[:, off_prob:off_label].view(dtype), se[:, 0], se[:, 1], full[:, off_strand],
+            full[:, off_label:off_label + 4].view(torch.float32)[:, 0])
+
+
+def _bed_reader_keys(start, strand, run_rows, first_run_anchor, central_bp):
+    """Sort key of bed_reader's row order (preprocessing.py:39-106) for the rows of one chromosome in FILE order: the runs restart
+    the segment grid (end0 = 1 + central_bp; the file's very first run: its first start + central_bp), a row's segment is the
+    number of times `while start > end0: end0 += central_bp` has fired so far -- a function of the running maximum of start --,
+    and a segment yields its '+' rows, then its '-' rows: key = ((run << 40 | segment) << 1) | strand, rows stably sorted by it."""
+    keys, lo = [], 0
+    for j, rows in enumerate(run_rows):
+        s = start[lo:lo + rows]
+        e0 = (first_run_anchor if (j == 0 and first_run_anchor is not None) else 1) + central_bp
+        rm = torch.cummax(s, 0).values
+        seg = torch.where(rm > e0, (rm - e0 + (central_bp - 1)) // central_bp, torch.zeros_like(rm))
+        keys.append((((j << 40) + seg) << 1) | strand[lo:lo + rows].to(torch.int64))
+        lo += rows
+    return keys[0] if len(keys) == 1 else torch.cat(keys)
+
+
+def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, sink, collect, timings, emulate):
+    from .data import ingest
+    if emulate is not None:
+        rank, world = int(emulate[0]), int(emulate[1])
+    else:
+        world = dist.get_world_size(group) if dist.is_initialized() else 1
+        rank = dist.get_rank(group) if dist.is_initialized() else 0
+    T = {} if timings is None else timings
+    clock = time.perf_counter
+    T["emulation"] = 0.0
+    t0 = clock()
+    index = ingest.BedIndex.build(bed_path, rank, world, group, emulate=emulate is not None, seconds=T)
+    T["bed_index"] = clock() - t0
+    if emulate is not None:
+        T["emulation"] += T["bed_index"] - T["index_scan"]
+    dev = _device_of(forward)
+    tdev = dev if dev is not None else torch.device("cpu")
+    tail = _ShardTail(forward, model_type, sink, collect, T, dev, rank)
+    T.update({"bed_parse": 0.0, "reorder": 0.0})
+    names = sorted(index.chroms)
+    up = lambda a: torch.from_numpy(a).to(tdev)                                           # noqa: E731
+    try:
+        for si, chrom in enumerate(names):
+            run_ids = index.chroms[chrom]
+            run_rows = [index.runs[i].rows for i in run_ids]
+            n = sum(run_rows)
+            b0, b1 = shard_bounds(n, rank, world)
+            t0 = clock()
+            start_h, end_h, label_h, strand_h = index.read_block(chrom, b0, b1)
+            T["bed_parse"] += clock() - t0
+            if hasattr(forward, "prefetch") and si + 1 < len(names):
+                forward.prefetch(names[si + 1])
+            pos_b, strand_b = up(start_h), up(strand_h)
+            t0 = clock()
+            local = forward(chrom, pos_b if dev is not None else start_h, strand_b if dev is not None else strand_h)
+            T["compute_enqueue"] += clock() - t0
+            if local.shape[0] != b1 - b0:
+                raise RuntimeError("forward returned a wrong number of rows")
+            if not isinstance(local, torch.Tensor):
+                local = torch.from_numpy(np.ascontiguousarray(local))
+            if local.dtype not in (torch.float32, torch.float64):
+                local = local.to(torch.float32)
+            k = local.shape[1] - 1
+            t0 = clock()
+            packed = _pack_rows(local, pos_b, up(end_h), strand_b, up(label_h))
+            if emulate is not None and world > 1:
+                # stand-in for the other ranks' blocks: their site columns (parsed here, outside the share) next to copies of this
+                # rank's probability rows -- the gathered shard has the size, the sort keys and the text width of the real one
+                te = clock()
+                full = torch.empty((n, packed.shape[1]), dtype=torch.uint8, device=tdev)
+                for r in range(world):
+                    lo, hi = shard_bounds(n, r, world)
+                    if r == rank or hi == lo:
+                        continue
+                    s2, e2, l2, d2 = index.read_block(chrom, lo, hi)
+                    src = local[torch.arange(hi - lo, device=tdev) % max(local.shape[0], 1)] if local.shape[0] else \
+                        torch.zeros((hi - lo, k + 1), dtype=local.dtype, device=tdev)
+                    full[lo:hi] = _pack_rows(src, up(s2), up(e2), up(d2), up(l2))
+                T["emulation"] += clock() - te
+                full[b0:b1] = packed                       # (the share's own copy: what the collective would deliver)
+            else:
+                full = all_gather_rows(packed, n, group)
+            T["gather"] += clock() - t0
+            t0 = clock()
+            prob, start, end, strand, label = _unpack_rows(full, k, local.dtype)
+            anchor = index.runs[run_ids[0]].first_start if run_ids[0] == 0 else None
+            key = _bed_reader_keys(start, strand, run_rows, anchor, int(segment_center))
+            key_o, order = torch.sort(key, stable=True)
+            full_o = prob[order]                            # (n, k + 1) probabilities + focal base in bed_reader order
+            start_o, strand_o = start[order], strand[order]
+            end_o = label_o = file_rows = None
+            if tail.need_meta:
+                end_o, label_o = end[order], label[order]
+            if collect:
+                file_rows = torch.cat([index.runs[i].row0 + torch.arange(index.runs[i].rows, device=tdev) for i in run_ids])[order]
+            T["reorder"] += clock() - t0
+            runs = [(index.runs[i].row0, index.runs[i].row0 + index.runs[i].rows) for i in run_ids]
+            tail(chrom, runs, full_o, start_o, end_o, strand_o, label_o, key_o, file_rows)
+        tail.close()
+    except BaseException:
+        tail.abort()
+        raise
+    return tail.result(index.rows, None)
+
+
+def _predict_bed_whole(forward, bed_path, segment_center, model_type, group, sink, collect, timings):
+    """Every rank parses the whole BED (see predict_bed_sharded, ingest="whole")."""
     from .data import ingest
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     rank = dist.get_rank(group) if dist.is_initialized() else 0
@@ -797,6 +1053,7 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
     T["bed_order"] = clock() - t0
     n_all = len(order)
     dev = _device_of(forward)
+    tail = _ShardTail(forward, model_type, sink, collect, T, dev, rank)
     t0 = clock()
     if dev is not None:
         # every column once to the device in FILE order; the bed_reader order is applied there (gathers at HBM speed)
@@ -807,11 +1064,10 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
         bounds = np.r_[0, cut, n_all] if n_all else np.zeros(1, np.int64)
         run_ids = cid_o[torch.from_numpy(bounds[:-1]).to(dev)].cpu().numpy() if n_all else np.zeros(0, np.int32)
         start_o, strand_o = up(sites.start)[order_d], up(sites.strand)[order_d]
-        sink_here = sink is not None and (rank == 0 or getattr(sink, "parts", False))
-        need_meta = collect or sink_here
-        if need_meta:
+        end_o = label_o = None
+        if tail.need_meta:
             end_o, label_o = up(sites.end)[order_d], up(sites.score)[order_d]
-        grp_o = up(grp) if model_type == "snv" else None
+        grp_o = up(grp)
         del cid_o
     else:
         cid_h = sites.chrom_id[order]
@@ -828,28 +1084,13 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
     shards = [(sites.chrom_names[c], by_id[c]) for c in sorted(by_id, key=lambda c: sites.chrom_names[c])]
 
     def take(col, runs):
+        if col is None:
+            return None
         if len(runs) == 1:
             return col[runs[0][0]:runs[0][1]]
         parts = [col[lo:hi] for lo, hi in runs]
         return torch.cat(parts) if isinstance(col, torch.Tensor) else np.concatenate(parts)
 
-    kept, pending_check = [], None
-    T.update({"compute_enqueue": 0.0, "gather": 0.0, "sink": 0.0, "focal_wait": 0.0})
-
-    def finish_check(pc):
-        if pc is None:
-            return
-        t = clock()
-        ev, host = pc
-        ev.synchronize()
-        T["focal_wait"] += clock() - t
-        if int(host[0]) != 0:
-            raise ValueError(_FOCAL_MSG)
-
-    feeds_sink = sink is not None and (rank == 0 or getattr(sink, "parts", False))
-    # HipShardForward with a calibration chain hands over calibrated probabilities: the flag travels with every shard (and the
-    # collected result) so that a sink / write_predictions asked to calibrate as well refuses instead of calibrating twice
-    fwd_calibrated = bool(getattr(forward, "calibrated", False))
     try:
         for si, (chrom, runs) in enumerate(shards):
             n = sum(hi - lo for lo, hi in runs)
@@ -865,66 +1106,9 @@ def predict_bed_sharded(forward, bed_path, segment_center=300000, model_type="sn
             t0 = clock()
             full = all_gather_rows(local, n, group)
             T["gather"] += clock() - t0
-            k = full.shape[1] - 1
-            if dev is not None:
-                if model_type == "snv":
-                    status = torch.zeros(1, dtype=torch.int32, device=dev)
-                    with torch.cuda.device(dev):
-                        _lib.check(_lib.lib().mural_focal_group_check(full.data_ptr(), int(full.dtype == torch.float64), full.stride(0), k,
-                                                                     take(grp_o, runs).contiguous().data_ptr(), n, status.data_ptr(),
-                                                                     _lib.current_stream_ptr(dev)))
-                        host = torch.zeros(1, dtype=torch.int32).pin_memory()
-                        host.copy_(status, non_blocking=True)
-                        ev = torch.cuda.Event()
-                        ev.record()
-                    finish_check(pending_check)            # the verdict of the PREVIOUS shard: never waits for work just enqueued
-                    pending_check = (ev, host)
-                shard = None
-                if need_meta:
-                    shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
-                             "prob": full, "n_class": k, "calibrated": fwd_calibrated}
-            else:
-                full = full.cpu().numpy() if isinstance(full, torch.Tensor) else np.asarray(full)
-                if model_type == "snv":
-                    check_focal_groups(full[:, -1].astype(np.int64), take(grp_o, runs))
-                shard = {"chrom": chrom, "start": pos_s, "end": take(end_o, runs), "strand": strand_s, "label": take(label_o, runs),
-                         "prob": full[:, :-1], "n_class": k, "calibrated": fwd_calibrated}
-            if sink is not None and (rank == 0 or getattr(sink, "parts", False)):
-                t0 = clock()
-                sink(shard)
-                T["sink"] += clock() - t0
-            if collect:
-                cpu = lambda a: a.detach().cpu().numpy() if isinstance(a, torch.Tensor) else np.asarray(a)     # noqa: E731
-                kept.append((runs, {"start": cpu(shard["start"]), "end": cpu(shard["end"]), "strand": cpu(shard["strand"]),
-                                    "label": cpu(shard["label"]), "prob": cpu(shard["prob"])[:, :k], "chrom": chrom}))
-        finish_check(pending_check)
+            tail(chrom, runs, full, pos_s, take(end_o, runs), strand_s, take(label_o, runs), take(grp_o, runs))
+        tail.close()
     except BaseException:
-        # the verdict of a shard's focal-base check is read one shard late, i.e. after that shard's rows went to the sink: a failing
-        # run must not leave a partial table with a valid-looking header behind (the reference exits before writing anything)
-        if feeds_sink and hasattr(sink, "abort"):
-            sink.abort()
+        tail.abort()
         raise
-    if sink is not None and (rank == 0 or getattr(sink, "parts", False)) and hasattr(sink, "close"):
-        t0 = clock()
-        sink.close()
-        T["sink_close"] = clock() - t0
-    if not collect:
-        return n_all
-    if not kept:
-        return {"chrom": np.zeros(0, object), "start": np.zeros(0, np.int64), "end": np.zeros(0, np.int64),
-                "strand": np.zeros(0, object), "label": np.zeros(0, np.float32), "prob": np.zeros((0, 0), np.float32),
-                "order": np.zeros(0, np.int64)}
-    k = kept[0][1]["prob"].shape[1]
-    out = {"chrom": np.empty(n_all, object), "start": np.empty(n_all, np.int64), "end": np.empty(n_all, np.int64),
-           "strand": np.empty(n_all, object), "label": np.empty(n_all, np.float32),
-           "prob": np.empty((n_all, k), kept[0][1]["prob"].dtype), "order": order, "calibrated": fwd_calibrated}
-    for runs, sh in kept:
-        o = 0
-        for lo, hi in runs:
-            m = hi - lo
-            out["chrom"][lo:hi] = sh["chrom"]
-            out["start"][lo:hi], out["end"][lo:hi] = sh["start"][o:o + m], sh["end"][o:o + m]
-            out["strand"][lo:hi] = np.where(sh["strand"][o:o + m] == 1, "-", "+")
-            out["label"][lo:hi], out["prob"][lo:hi] = sh["label"][o:o + m], sh["prob"][o:o + m]
-            o += m
-    return out
+    return tail.result(n_all, order)

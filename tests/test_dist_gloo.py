@@ -217,6 +217,80 @@ def test_part_file_sink_equals_single_writer_table(tmp_path, world, unsorted):
     assert sorted(os.listdir(tmp_path)) == ["pred.tsv", "s.bed", "want.tsv"]      # the part files are gone
 
 
+# ------------------------------------------------------------------------------------------------------------------
+# rank-local ingest (the default): every rank scans 1 / world of the BED's bytes, parses only its block of every chromosome and the
+# gathered row carries the site columns -- the table is byte-identical to the one of the whole-file ingest, plain and gzip
+# ------------------------------------------------------------------------------------------------------------------
+def _ingest_worker(rank, world, port, bed, out_path, ingest, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import numpy as np
+        from mural_amd.data import ingest as I
+        from mural_amd.predict import TsvSink, predict_bed_sharded
+        I.PIECE_ROWS = 97                                   # several pieces per chromosome and per rank
+        parsed = []
+        read_block = I.BedIndex.read_block
+        I.BedIndex.read_block = lambda self, name, b0, b1: parsed.append(b1 - b0) or read_block(self, name, b0, b1)
+        res = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000, sink=TsvSink(out_path, parts=True), ingest=ingest)
+        ok = ingest == "whole" or sum(parsed) <= len(res["start"]) // world + 8      # a rank parsed its blocks and nothing else
+        digest = float(np.sum(res["prob"].astype(np.float64) * (1 + np.arange(len(res["start"]))[:, None])))
+        q.put((rank, bool(ok), (len(res["start"]), res["order"].tolist()[:50], digest)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("gz", [False, True])
+def test_ranked_and_whole_file_ingest_give_the_same_table(tmp_path, world, gz):
+    from tests.test_ingest import _messy_bed
+    bed = str(_messy_bed(tmp_path / ("s.bed.gz" if gz else "s.bed"), gz=gz))
+    tables, results = {}, {}
+    for ingest in ("ranked", "whole"):
+        out_path = str(tmp_path / f"pred_{ingest}.tsv")
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_ingest_worker, args=(r, world, port, bed, out_path, ingest, q)) for r in range(world)]
+        for p in procs:
+            p.start()
+        res = [q.get(timeout=120) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+        assert all(ok for _, ok, _ in res), res
+        assert len({repr(r[2]) for r in res}) == 1          # every rank collected the same rows
+        results[ingest] = res[0][2]
+        tables[ingest] = open(out_path, "rb").read()
+    assert results["ranked"] == results["whole"]             # row count, bed_reader order, probabilities
+    assert tables["ranked"] == tables["whole"] and tables["ranked"].count(b"\n") == 5041 + 1
+
+
+def test_ranked_ingest_single_process_equals_whole_and_emulates_a_rank(tmp_path):
+    import numpy as np
+    from mural_amd.data import ingest as I
+    from mural_amd.predict import TsvSink, predict_bed_sharded
+    from tests.test_ingest import _messy_bed
+    bed = str(_messy_bed(tmp_path / "s.bed"))
+    old = I.PIECE_ROWS
+    I.PIECE_ROWS = 131
+    try:
+        a = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000, ingest="ranked")
+        b = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000, ingest="whole")
+        for key in ("chrom", "start", "end", "strand", "label", "prob", "order"):
+            assert np.array_equal(a[key], b[key]), key
+        # one rank's share of a 4-rank run, no process group: its own block is computed, the others are stood in for
+        calls, T = [], {}
+        sink = TsvSink(str(tmp_path / "p.tsv"), parts=(2, 4))
+        n = predict_bed_sharded(_fake_shard_forward(calls), bed, segment_center=3000, sink=sink, collect=False, emulate=(2, 4), timings=T)
+        assert n == len(a["start"]) and T["emulation"] > 0 and T["bed_parse"] > 0
+        assert sum(m for _, m in calls) in range(n // 4 - 4, n // 4 + 5)
+        with pytest.raises(ValueError, match="ranked"):
+            predict_bed_sharded(_fake_shard_forward([]), bed, ingest="whole", emulate=(0, 2))
+    finally:
+        I.PIECE_ROWS = old
+
+
 def test_failed_run_leaves_no_table_behind(tmp_path):
     """The focal-base verdict of a shard arrives after its rows went to the sink: the failing run removes the partial table (the
     reference exits before it writes anything, preprocessing.py:482-484)."""

@@ -94,6 +94,91 @@ def test_bed_reader_errors(tmp_path):
     assert len(order) == 0
 
 
+def _messy_bed(path, seed=3, gz=False):
+    """Several chromosome runs (chr2 twice), starts that jump back and forth inside a run (bed_reader's grid follows the running
+    maximum), both strands, comment / blank lines in the middle; optionally gzip with two members (a bgzip-like file)."""
+    import gzip
+    rng = np.random.default_rng(seed)
+    lines = ["# comment", "track name=x"]
+    for chrom, n in (("chr2", 2500), ("chr1", 1800), ("chr10", 1), ("chr2", 700), ("scaffold_9", 40)):
+        st = np.sort(rng.integers(0, 90000, size=n))
+        jump = rng.random(n) < 0.03
+        st = np.where(jump, rng.integers(0, 90000, size=n), st)
+        for i, s_ in enumerate(st):
+            lines.append(f"{chrom}\t{int(s_)}\t{int(s_) + 1 + int(rng.integers(0, 3))}\tsite{i}\t{int(rng.integers(0, 4))}\t{'+-'[int(rng.integers(0, 2))]}")
+            if i % 977 == 5:
+                lines += ["", "#mid comment"]
+    text = ("\n".join(lines) + "\n").encode()
+    if gz:
+        half = text.rfind(b"\n", 0, len(text) // 2) + 1
+        with open(path, "wb") as fh:
+            fh.write(gzip.compress(text[:half]) + gzip.compress(text[half:]))
+    else:
+        with open(path, "wb") as fh:
+            fh.write(text)
+    return path
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_bed_index_reads_any_block_of_a_chromosome(tmp_path, gz):
+    """BedIndex (every rank scans 1 / world of the bytes, pieces of <= piece_rows rows) + read_block == the whole-file reader, for
+    every world size, also on a multi-member gzip file."""
+    path = _messy_bed(tmp_path / ("s.bed.gz" if gz else "s.bed"), gz=gz)
+    whole = I.read_bed(path)
+    chrom_of = np.asarray(whole.chrom_names)[whole.chrom_id]
+    for world in (1, 2, 3, 8):
+        idx = I.BedIndex.build(path, rank=world - 1, world=world, emulate=True, piece_rows=211)
+        assert idx.rows == len(whole)
+        assert [r.name for r in idx.runs] == ["chr2", "chr1", "chr10", "chr2", "scaffold_9"]
+        assert idx.runs[0].first_start == whole.start[0]
+        assert [r.row0 for r in idx.runs] == [0, 2500, 4300, 4301, 5001]
+        for name in idx.chroms:
+            sel = chrom_of == name
+            n = idx.chrom_rows(name)
+            assert n == int(sel.sum())
+            for b0, b1 in {(0, n), (0, 0), (n // 3, 2 * n // 3), (max(n - 1, 0), n), (min(210, n), min(213, n)), (min(2499, n), min(2502, n))}:
+                st, en, sc, sd = idx.read_block(name, b0, b1)
+                assert np.array_equal(st, whole.start[sel][b0:b1]) and np.array_equal(en, whole.end[sel][b0:b1])
+                assert np.array_equal(sc, whole.score[sel][b0:b1]) and np.array_equal(sd, whole.strand[sel][b0:b1])
+
+
+def test_gzip_inputs_read_like_plain_ones(tmp_path, fasta):
+    import gzip
+    path, seqs = fasta
+    gzp = tmp_path / "g.fa.gz"
+    gzp.write_bytes(gzip.compress(path.read_bytes()))
+    recs, recs_gz = I.scan_fasta(path), I.scan_fasta(gzp)
+    assert [(r.name, r.length, r.offset) for r in recs] == [(r.name, r.length, r.offset) for r in recs_gz]
+    for a, b in zip(recs, recs_gz):
+        pa, pb = I.pack_fasta_record(path, a), I.pack_fasta_record(gzp, b)
+        assert np.array_equal(pa[0], pb[0]) and np.array_equal(pa[1], pb[1]) and pa[2] == pb[2]
+    plain = I.read_bed(_messy_bed(tmp_path / "s.bed"))
+    packed = I.read_bed(_messy_bed(tmp_path / "s.bed.gz", gz=True))
+    assert plain.chrom_names == packed.chrom_names
+    for col in ("chrom_id", "start", "end", "score", "strand"):
+        assert np.array_equal(getattr(plain, col), getattr(packed, col))
+    bad = tmp_path / "bad.bed.gz"
+    bad.write_bytes(gzip.compress(b"chr1\t1\t2\t.\t0\t+\n" * 1000)[:-20])      # truncated stream
+    with pytest.raises(ValueError, match="zlib"):
+        I.read_bed(bad)
+
+
+def test_ranked_ingest_errors(tmp_path):
+    bad = tmp_path / "bad.bed"
+    bad.write_text("chr1\t10\t11\t.\t0\t+\nchr1\tten\t11\t.\t0\t+\n")
+    with pytest.raises(ValueError, match="malformed"):
+        I.BedIndex.build(bad)
+    bad.write_text("chr1\t10\t11\t.\t0\t+\nchr1\t12\t13\t.\t0\n")
+    idx = I.BedIndex.build(bad)                    # the index reads two fields; the block's parse reads all six
+    with pytest.raises(ValueError, match="6 tab-separated"):
+        idx.read_block("chr1", 0, 2)
+    bad.write_text("chr1\t10\t11\t.\t0\t+\nchr1\t12\t13\t.\t0\t+\n")
+    idx = I.BedIndex.build(bad)
+    bad.write_text("chr1\t10\t11\t.\t0\t+\nchr7\t12\t13\t.\t0\t+\n")
+    with pytest.raises(ValueError, match="changed behind the index"):
+        idx.read_block("chr1", 0, 2)
+
+
 def test_poisson_calibrate_and_prediction_table_match_reference(tmp_path):
     fx = U.load("output.npz")
     got = I.poisson_calibrate(fx["prob"])
