@@ -618,6 +618,96 @@ def synth_config5_files(workdir, device, n_chrom=3, chrom_len=7_000_000, seed=7)
     return fa, bed, rows
 
 
+def _reset_peak_rss():
+    try:
+        with open("/proc/self/clear_refs", "w") as fh:
+            fh.write("5")
+        return True
+    except OSError:
+        return False
+
+
+def _rss_kb(field="VmHWM"):
+    with open("/proc/self/status") as fh:
+        for ln in fh:
+            if ln.startswith(field + ":"):
+                return int(ln.split()[1])
+    return None
+
+
+def rank_share(model, r, order, fa, bed, rows, work, device, t_one_rank, rank=3, world=8):
+    """ONE rank's share of a `world`-rank file-to-file run, measured on this GPU (predict_bed_sharded(emulate=(rank, world)) with a
+    part-file sink): its 1 / world of the index scan, the parse of its block of every chromosome, the FASTA pack, its block's compute,
+    a gathered shard of full size (the other ranks' site columns beside copies of this rank's probabilities stand in for the
+    collective), the bed_reader reorder, the focal check and the full sort of the gathered shard, and its slice of the table.  Host
+    seconds spent standing in for the other ranks are excluded (`emulation_seconds`).  projected_speedup = t(1 rank) / t(share)."""
+    from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
+    best = None
+    for _ in range(2):
+        split = {}
+        reset = _reset_peak_rss()
+        rss0 = _rss_kb("VmRSS")
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fwd = HipShardForward(model, fa, r, order, device=device, reuse=True)
+        sink = TsvSink(os.path.join(work, "share.tsv"), parts=(rank, world))
+        n = predict_bed_sharded(fwd, bed, sink=sink, collect=False, timings=split, emulate=(rank, world))
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        assert n == rows
+        t_share = wall - split["emulation"]
+        if best is None or t_share < best["seconds"]:
+            best = {"seconds": t_share, "wall_seconds": wall, "emulation_seconds": split["emulation"],
+                    "split_seconds": {k: v for k, v in split.items() if isinstance(v, float)},
+                    "pack_thread_busy": fwd.seconds["pack"], "pack_wait": fwd.seconds["pack_wait"],
+                    "rss_before_kb": rss0, "peak_rss_kb": _rss_kb("VmHWM") if reset else None,
+                    "part_bytes": os.path.getsize(os.path.join(work, "share.tsv.part%04d" % rank))}
+        os.unlink(os.path.join(work, "share.tsv.part%04d" % rank))
+    best.update({"rank": rank, "world": world, "one_rank_seconds": t_one_rank, "projected_speedup_at_%d" % world: t_one_rank / best["seconds"],
+                 "note": "predict_bed_sharded(emulate=(%d, %d)) + TsvSink(parts=(%d, %d)); best of two; peak_rss_kb = VmHWM of this "
+                         "process over the run (reset through /proc/self/clear_refs; it includes the bench's resident genome and "
+                         "models)" % (rank, world, rank, world)})
+    return best
+
+
+def config5_chr1(device, chrom_len=248_000_000):
+    """`python bench.py --config5-chr1`: the file-to-file run on ONE chromosome of human chr1's size (every A / T a site: ~124 M rows,
+    3.3 GB of BED text), one rank's share of an 8-rank run beside the one-rank run, with the peak host RSS of each."""
+    import shutil
+    import tempfile
+    from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
+    model, r, order, R = shipped_snv_model(device)
+    need = 14 << 30
+    shm = "/dev/shm" if os.path.isdir("/dev/shm") and os.access("/dev/shm", os.W_OK) and shutil.disk_usage("/dev/shm").free > need else None
+    with tempfile.TemporaryDirectory(prefix="mural_c5_", dir=shm) as work:
+        t0 = time.perf_counter()
+        fa, bed, rows = synth_config5_files(work, device, 1, chrom_len)
+        t_gen = time.perf_counter() - t0
+        torch.cuda.empty_cache()
+        out = os.path.join(work, "pred.tsv")
+        one = None
+        for _ in range(2):
+            split = {}
+            reset = _reset_peak_rss()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            fwd = HipShardForward(model, fa, r, order, device=device, reuse=True)
+            n = predict_bed_sharded(fwd, bed, sink=TsvSink(out), collect=False, timings=split)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+            assert n == rows
+            if one is None or dt < one["seconds"]:
+                one = {"seconds": dt, "rows_per_s": rows / dt, "split_seconds": {k: v for k, v in split.items() if isinstance(v, float)},
+                       "pack_thread_busy": fwd.seconds["pack"], "peak_rss_kb": _rss_kb("VmHWM") if reset else None,
+                       "table_bytes": os.path.getsize(out)}
+        os.unlink(out)
+        share = rank_share(model, r, order, fa, bed, rows, work, device, one["seconds"])
+        sizes = {"fasta_bytes": os.path.getsize(fa), "bed_bytes": os.path.getsize(bed)}
+    return {"workload": "config5 file-to-file, one chromosome of %d bases, every A / T a site" % chrom_len, "rows": rows, **sizes,
+            "one_rank": one, "rank_share": share, "input_generation_seconds_untimed": t_gen,
+            "files_in": "/dev/shm" if shm else "the temp directory"}
+
+
 def config5_e2e(device, n_chrom=3, chrom_len=14_000_000):
     """BASELINE.json configs[4] at N = 1, file to file: FASTA + BED -> sorted '%.4g' prediction table (run_predict.py:188-239) through
     mural_amd.predict.predict_bed_sharded with the shipped Homo_sapiens/SNV/AT weights: C++ BED reader / row order / FASTA packer,
@@ -688,7 +778,8 @@ def config5_e2e(device, n_chrom=3, chrom_len=14_000_000):
 
         n_s, t_all = sink_only(False)
         _, t_8 = sink_only((3, 8))
-    return {"rows_per_s": rows / dt, "rows": rows, "seconds": dt, "chromosomes": n_chrom, "bases_per_chromosome": chrom_len,
+        share = rank_share(model, r, order, fa, bed, rows, work, device, dt)
+    return {"rows_per_s": rows / dt, "rank_share": share, "rows": rows, "seconds": dt, "chromosomes": n_chrom, "bases_per_chromosome": chrom_len,
             "sites_through_reuse_kernels": reused, "table_bytes": table_bytes, **sizes, "split_seconds": split,
             "per_window_kernels": {"rows_per_s": rows / dt_pw, "seconds": dt_pw, "split_seconds": split_pw},
             "sink_only_rows_per_s": n_s / t_all,
@@ -715,7 +806,15 @@ def main():
                          "rank walks its block in --steps slices and ONE all_gather ends the pass (SURVEY.md section 8e)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the short train-steps/s and INDEL measurements (N=1 only)")
+    ap.add_argument("--config5-chr1", action="store_true",
+                    help="instead of the bench line: the file-to-file run on one chr1-sized chromosome (one rank, and one rank's share of 8)")
     args = ap.parse_args()
+    if args.config5_chr1:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X (no HIP device visible); there is no CPU product path")
+        torch.cuda.set_device(0)
+        print(json.dumps(config5_chr1(torch.device("cuda", 0))), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))

@@ -157,10 +157,7 @@ std::shared_ptr<TextMap> open_text(const char* path, std::string* err) {
     return nullptr;
   }
   const bool gz = raw->size >= 2 && (unsigned char)raw->data[0] == 0x1f && (unsigned char)raw->data[1] == 0x8b;
-  if (!gz) {
-    if (raw->data) madvise(const_cast<char*>(raw->data), raw->size, MADV_SEQUENTIAL);
-    return raw;
-  }
+  if (!gz) return raw;      // (no MADV_SEQUENTIAL: every reader makes two passes, and pages dropped behind the first are faulted in again)
   std::lock_guard<std::mutex> lock(g_gz_mutex);
   for (size_t i = 0; i < g_gz_cache.size(); ++i) {
     GzEntry& e = g_gz_cache[i];
@@ -202,11 +199,13 @@ struct MappedFile {
   }
 };
 
-// MURAL_SYM_* of a character (either case): 0..3 = A C G T, 4 = N, 5..14 = R Y M S W K B D H V; 255 = not a nucleotide code
+// MURAL_SYM_* of a character (either case): 0..3 = A C G T, 4 = N, 5..14 = R Y M S W K B D H V; 254 = white space (isspace in the C
+// locale), 255 = not a nucleotide code
 struct BaseTable {
   uint8_t t[256];
   BaseTable() {
     std::memset(t, 255, sizeof(t));
+    for (const char* w = " \t\n\v\f\r"; *w; ++w) t[(unsigned char)*w] = 254;
     const char* alphabet = "ACGTNRYMSWKBDHV";
     for (int i = 0; alphabet[i]; ++i) {
       t[(unsigned char)alphabet[i]] = (uint8_t)i;
@@ -215,6 +214,25 @@ struct BaseTable {
   }
 };
 const BaseTable kBase;
+
+int host_threads() {
+  if (const char* e = std::getenv("MURAL_HOST_THREADS")) {
+    const int v = std::atoi(e);
+    if (v >= 1) return std::min(v, 256);
+  }
+  return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+}
+
+template <typename Fn>
+void run_parallel(int T, Fn fn) {
+  if (T == 1) {
+    fn(0);
+    return;
+  }
+  std::vector<std::thread> th;
+  for (int k = 0; k < T; ++k) th.emplace_back(fn, k);
+  for (auto& x : th) x.join();
+}
 
 inline const char* line_end(const char* p, const char* end) {
   const void* q = std::memchr(p, '\n', (size_t)(end - p));
@@ -235,39 +253,67 @@ extern "C" int mural_fasta_scan(const char* path, int64_t n_cap, int32_t name_ca
     set_error("cannot open FASTA file %s%s%s", path, f.why.empty() || f.why == "cannot open" ? "" : ": ", f.why == "cannot open" ? "" : f.why.c_str());
     return MURAL_E_INVALID;
   }
-  const char* p = f.data;
+  // A genome is gigabytes of text and every rank scans it: the file is cut into byte chunks at line starts, every host thread lists
+  // the header lines of its chunk and counts the bases in front of its first header and behind each header; the pieces add up.
+  struct Hdr { const char* line; const char* line_end; int64_t bases; };
+  struct Part { int64_t lead = 0; std::vector<Hdr> hdr; };
   const char* end = f.data + f.size;
-  int64_t n = 0, cur_len = 0;
+  const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), f.size / (8u << 20) + 1));
+  std::vector<const char*> cut((size_t)T + 1);
+  cut[0] = f.data;
+  for (int k = 1; k < T; ++k) {
+    const char* at = f.data + f.size * (size_t)k / (size_t)T;
+    if (at > f.data && at[-1] != '\n') {
+      const char* e = line_end(at, end);
+      at = e < end ? e + 1 : end;
+    }
+    cut[(size_t)k] = std::max(at, cut[(size_t)k - 1]);
+  }
+  cut[(size_t)T] = end;
+  std::vector<Part> part((size_t)T);
+  run_parallel(T, [&](int k) {
+    Part& P = part[(size_t)k];
+    int64_t* count = &P.lead;
+    const char* p = cut[(size_t)k];
+    const char* hi = cut[(size_t)k + 1];
+    while (p < hi) {
+      const char* e = line_end(p, hi);
+      if (*p == '>') {
+        P.hdr.push_back(Hdr{p, e, 0});
+        count = &P.hdr.back().bases;
+      } else {
+        int64_t n = 0;
+        for (const char* q = p; q < e; ++q) n += kBase.t[(unsigned char)*q] != 254;
+        *count += n;
+      }
+      p = e < hi ? e + 1 : hi;
+    }
+  });
+  int64_t n = 0;
   bool in_record = false;
-  while (p < end) {
-    const char* e = line_end(p, end);
-    if (*p == '>') {
-      if (in_record && n <= n_cap && lengths) lengths[n - 1] = cur_len;
+  for (auto& P : part) {
+    if (P.lead) {
+      if (!in_record) {
+        set_error("%s: sequence data before the first '>' header", path);
+        return MURAL_E_INVALID;
+      }
+      if (n <= n_cap && lengths) lengths[n - 1] += P.lead;
+    }
+    for (auto& h : P.hdr) {
       ++n;
       in_record = true;
-      cur_len = 0;
       if (n <= n_cap) {
         if (names) {
-          const char* q = p + 1;
+          const char* q = h.line + 1;
           int k = 0;
-          while (q < e && !std::isspace((unsigned char)*q) && k + 1 < name_cap) names[(n - 1) * (int64_t)name_cap + k++] = *q++;
+          while (q < h.line_end && !std::isspace((unsigned char)*q) && k + 1 < name_cap) names[(n - 1) * (int64_t)name_cap + k++] = *q++;
           names[(n - 1) * (int64_t)name_cap + k] = '\0';
         }
-        if (offsets) offsets[n - 1] = (int64_t)((e < end ? e + 1 : end) - f.data);
+        if (offsets) offsets[n - 1] = (int64_t)((h.line_end < end ? h.line_end + 1 : end) - f.data);
+        if (lengths) lengths[n - 1] = h.bases;
       }
-    } else if (in_record) {
-      for (const char* q = p; q < e; ++q)
-        if (!std::isspace((unsigned char)*q)) ++cur_len;
-    } else {
-      for (const char* q = p; q < e; ++q)
-        if (!std::isspace((unsigned char)*q)) {
-          set_error("%s: sequence data before the first '>' header", path);
-          return MURAL_E_INVALID;
-        }
     }
-    p = e < end ? e + 1 : end;
   }
-  if (in_record && n <= n_cap && lengths) lengths[n - 1] = cur_len;
   *n_records = n;
   return MURAL_OK;
 }
@@ -288,39 +334,115 @@ extern "C" int mural_fasta_pack(const char* path, int64_t offset, int64_t length
   MURAL_REQUIRE(offset >= 0 && (size_t)offset <= f.size, "record offset outside the file");
   std::memset(packed2, 0, (size_t)((length + 15) / 16) * 4);
   std::memset(nmask, 0, (size_t)((length + 31) / 32) * 4);
-  const char* p = f.data + offset;
-  const char* end = f.data + f.size;
-  int64_t i = 0, amb = 0;
-  for (; p < end && *p != '>'; ++p) {
-    const unsigned char ch = (unsigned char)*p;
-    if (std::isspace(ch)) continue;
-    const uint8_t code = kBase.t[ch];
-    if (code == 255) {
-      set_error("%s: character '%c' at base %lld is not a nucleotide code", path, ch, (long long)i);
-      return MURAL_E_INVALID;
-    }
-    if (i >= length) {
-      set_error("%s: record holds more than the %lld bases announced by the scan", path, (long long)length);
-      return MURAL_E_INVALID;
-    }
-    if (code < 4) {
-      packed2[i >> 4] |= (uint32_t)code << (2 * (i & 15));
-    } else {
-      nmask[i >> 5] |= 1u << (i & 31);
-      if (code > 4) {
-        if (amb < amb_cap) {
-          if (amb_pos) amb_pos[amb] = i;
-          if (amb_sym) amb_sym[amb] = code;
-        }
-        ++amb;
+  const char* lo = f.data + offset;
+  const char* file_end = f.data + f.size;
+  // A human chromosome is 250 MB of text and N ranks each pack it: the record's bytes are cut into chunks, pass 1 counts the bases of
+  // every chunk (its first base index) and looks for the next record's '>', pass 2 packs the chunks side by side -- a chunk owns every
+  // 32-base word that lies wholly inside its base range and ORs atomically into the two it may share with its neighbours.  Where the
+  // record ends is not known up front: the chunks cover the bytes `length` bases take at the width of the record's first line
+  // (+ slack); a record with ragged lines that runs past them is finished by a serial scan.
+  const char* cap_end = file_end;
+  if (lo < file_end) {
+    const char* nl = static_cast<const char*>(std::memchr(lo, '\n', std::min<size_t>((size_t)(file_end - lo), 1u << 20)));
+    if (nl) {
+      int64_t on_line = 0;
+      for (const char* q = lo; q < nl; ++q) on_line += kBase.t[(unsigned char)*q] != 254;
+      if (on_line > 0) {
+        const size_t est = (size_t)(length / on_line + 2) * (size_t)(nl - lo + 1) + 4096;
+        if (est < (size_t)(file_end - lo)) cap_end = lo + est;
       }
     }
-    ++i;
   }
-  if (i != length) {
-    set_error("%s: record holds %lld bases, the scan announced %lld", path, (long long)i, (long long)length);
+  const size_t span = (size_t)(cap_end - lo);
+  const int T = (int)std::max<size_t>(1, std::min<size_t>((size_t)host_threads(), span / (8u << 20) + 1));
+  std::vector<const char*> cut((size_t)T + 2);
+  for (int k = 0; k <= T; ++k) cut[(size_t)k] = lo + span * (size_t)k / (size_t)T;
+  std::vector<int64_t> first((size_t)T + 2, 0);
+  std::vector<const char*> stop((size_t)T + 1, nullptr);      // the '>' a chunk ran into
+  run_parallel(T, [&](int k) {
+    int64_t n = 0;
+    const char* p = cut[(size_t)k];
+    for (; p < cut[(size_t)k + 1] && *p != '>'; ++p) n += kBase.t[(unsigned char)*p] != 254;
+    first[(size_t)k + 1] = n;
+    if (p < cut[(size_t)k + 1]) stop[(size_t)k] = p;
+  });
+  int chunks = T;
+  for (int k = 0; k < T; ++k)
+    if (stop[(size_t)k]) {                 // the record ends inside chunk k
+      cut[(size_t)k + 1] = stop[(size_t)k];
+      chunks = k + 1;
+      break;
+    }
+  for (int k = 0; k < chunks; ++k) first[(size_t)k + 1] += first[(size_t)k];
+  if (chunks == T && !stop[(size_t)T - 1] && cap_end < file_end && first[(size_t)T] < length) {      // ragged lines: one more, serial chunk
+    const void* gt = std::memchr(cap_end, '>', (size_t)(file_end - cap_end));
+    cut[(size_t)T + 1] = gt ? static_cast<const char*>(gt) : file_end;
+    int64_t n = 0;
+    for (const char* p = cap_end; p < cut[(size_t)T + 1]; ++p) n += kBase.t[(unsigned char)*p] != 254;
+    first[(size_t)T + 1] = first[(size_t)T] + n;
+    chunks = T + 1;
+  }
+  if (first[(size_t)chunks] != length) {
+    set_error("%s: record holds %lld bases, the scan announced %lld", path, (long long)first[(size_t)chunks], (long long)length);
     return MURAL_E_INVALID;
   }
+  struct Amb { int64_t pos; uint8_t sym; };
+  std::vector<std::vector<Amb>> ambs((size_t)chunks);
+  std::vector<std::string> errors((size_t)chunks);
+  run_parallel(chunks, [&](int k) {
+    int64_t i = first[(size_t)k];
+    const int64_t i_end = first[(size_t)k + 1];
+    if (i == i_end) return;
+    const int64_t w_first = i >> 5, w_last = (i_end - 1) >> 5;       // 32-base words this chunk may share
+    uint32_t pw[2] = {0u, 0u}, mw = 0u;                                // the two packed words and the mask word of 32-base word i >> 5
+    auto flush = [&](int64_t w) {
+      if (w == w_first || w == w_last) {
+        if (pw[0]) __atomic_fetch_or(&packed2[2 * w], pw[0], __ATOMIC_RELAXED);
+        if (pw[1] && 2 * w + 1 < (length + 15) / 16) __atomic_fetch_or(&packed2[2 * w + 1], pw[1], __ATOMIC_RELAXED);
+        if (mw) __atomic_fetch_or(&nmask[w], mw, __ATOMIC_RELAXED);
+      } else {
+        packed2[2 * w] = pw[0];
+        packed2[2 * w + 1] = pw[1];
+        nmask[w] = mw;
+      }
+      pw[0] = pw[1] = mw = 0u;
+    };
+    for (const char* p = cut[(size_t)k]; p < cut[(size_t)k + 1]; ++p) {
+      const unsigned char ch = (unsigned char)*p;
+      const uint8_t code = kBase.t[ch];
+      if (code == 254) continue;
+      if (code == 255) {
+        char msg[512];
+        std::snprintf(msg, sizeof(msg), "%s: character '%c' at base %lld is not a nucleotide code", path, ch, (long long)i);
+        errors[(size_t)k] = msg;
+        return;
+      }
+      const int b = (int)(i & 31);
+      if (code < 4) {
+        pw[b >> 4] |= (uint32_t)code << (2 * (b & 15));
+      } else {
+        mw |= 1u << b;
+        if (code > 4) ambs[(size_t)k].push_back(Amb{i, code});
+      }
+      ++i;
+      if ((i & 31) == 0) flush((i - 1) >> 5);
+    }
+    if (i & 31) flush(i >> 5);
+  });
+  for (auto& e : errors)
+    if (!e.empty()) {
+      set_error("%s", e.c_str());
+      return MURAL_E_INVALID;
+    }
+  int64_t amb = 0;
+  for (auto& v : ambs)
+    for (auto& a : v) {
+      if (amb < amb_cap) {
+        if (amb_pos) amb_pos[amb] = a.pos;
+        if (amb_sym) amb_sym[amb] = a.sym;
+      }
+      ++amb;
+    }
   if (n_amb) *n_amb = amb;
   return MURAL_OK;
 }
@@ -440,25 +562,6 @@ void bed_parse_chunk(BedChunk& c, const char* path, bool fill, int32_t* chrom_id
   }
   c.rows = n;
   c.lines = line_no - c.first_line;
-}
-
-int host_threads() {
-  if (const char* e = std::getenv("MURAL_HOST_THREADS")) {
-    const int v = std::atoi(e);
-    if (v >= 1) return std::min(v, 256);
-  }
-  return (int)std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-}
-
-template <typename Fn>
-void run_parallel(int T, Fn fn) {
-  if (T == 1) {
-    fn(0);
-    return;
-  }
-  std::vector<std::thread> th;
-  for (int k = 0; k < T; ++k) th.emplace_back(fn, k);
-  for (auto& x : th) x.join();
 }
 
 }  // namespace

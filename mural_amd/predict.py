@@ -358,6 +358,16 @@ def _header(n_class):
     return ("\t".join(["chrom", "start", "end", "strand", "mut_type"] + ["prob%d" % i for i in range(n_class)]) + "\n").encode()
 
 
+_PINNED_FREE = []      # pinned staging buffers of finished writers (pinning 100 MB costs ~20 ms: a process that writes many tables pays once)
+
+
+def _pinned_staging(cap):
+    for i, t in enumerate(_PINNED_FREE):
+        if t.numel() >= cap:
+            return _PINNED_FREE.pop(i)
+    return torch.empty(cap, dtype=torch.uint8).pin_memory()
+
+
 class _TextWriter(threading.Thread):
     """Writer thread of the device path: waits for a piece's format kernels, copies its text to pinned host memory on its own
     stream and write()s it; returns the device buffer to the pool.  One thread, pieces in order."""
@@ -370,7 +380,7 @@ class _TextWriter(threading.Thread):
         self.count = [torch.zeros(1, dtype=torch.int64, device=device) for _ in range(n_buffers)]
         for i in range(n_buffers):
             self.free.put(i)
-        self.host = torch.empty(cap, dtype=torch.uint8).pin_memory()
+        self.host = _pinned_staging(cap)
         self.host_count = torch.zeros(1, dtype=torch.int64).pin_memory()
         self.error = None
         self.seconds = {"wait_device": 0.0, "copy": 0.0, "write": 0.0}
@@ -604,6 +614,8 @@ class TsvSink:
         if self._writer is not None:
             self._writer.jobs.put(None)
             self._writer.join()
+            if len(_PINNED_FREE) < 2:
+                _PINNED_FREE.append(self._writer.host)
             err = self._writer.error
             for key, v in dict(self._writer.seconds, bytes=self._writer.bytes).items():
                 self._writer_totals[key] += v
@@ -971,7 +983,7 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
     dev = _device_of(forward)
     tdev = dev if dev is not None else torch.device("cpu")
     tail = _ShardTail(forward, model_type, sink, collect, T, dev, rank)
-    T.update({"bed_parse": 0.0, "reorder": 0.0})
+    T.update({"bed_parse": 0.0, "pack_rows": 0.0, "reorder": 0.0})
     names = sorted(index.chroms)
     up = lambda a: torch.from_numpy(a).to(tdev)                                           # noqa: E731
     try:
@@ -998,6 +1010,8 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
             k = local.shape[1] - 1
             t0 = clock()
             packed = _pack_rows(local, pos_b, up(end_h), strand_b, up(label_h))
+            T["pack_rows"] += clock() - t0
+            t0 = clock()
             if emulate is not None and world > 1:
                 # stand-in for the other ranks' blocks: their site columns (parsed here, outside the share) next to copies of this
                 # rank's probability rows -- the gathered shard has the size, the sort keys and the text width of the real one

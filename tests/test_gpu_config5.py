@@ -196,7 +196,14 @@ def test_sharded_driver_takes_the_reuse_path_on_dense_sites_and_matches_oracle(t
     timings = {}
     res = predict_bed_sharded(fwd, bed, segment_center=2500, sink=TsvSink(out), timings=timings)
     assert fwd.reuse_sites == len(a) + len(b) + len(c)      # the dense chromosomes; chrS (1 site per ~80 bases) went per-window
-    assert len(res["start"]) == len(rows) and {"bed_read", "compute_enqueue", "sink"} <= set(timings)
+    assert len(res["start"]) == len(rows) and {"bed_index", "bed_parse", "compute_enqueue", "sink"} <= set(timings)
+    # the whole-file ingest (every rank parses the whole BED, the reference's one BedTool per process) gives the same rows and table
+    whole_out = tmp_path / "pred_whole.tsv"
+    whole = predict_bed_sharded(HipShardForward(model, fa, local_radius=r, local_order=3), bed, segment_center=2500, sink=TsvSink(whole_out),
+                                ingest="whole")
+    for key in ("chrom", "start", "end", "strand", "label", "prob", "order"):
+        assert np.array_equal(whole[key], res[key]), key
+    assert open(out, "rb").read() == open(whole_out, "rb").read()
     sub = rng.choice(len(rows), size=400, replace=False)
     for name, s in seqs.items():
         sel = sub[res["chrom"][sub] == name]

