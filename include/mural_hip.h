@@ -128,6 +128,10 @@ void mural_snv_model_destroy(MuralSnvModel* m);
 /* scratch the forward calls need for a batch of n rows (bytes; allocate once, reuse).
  * dense != 0: for mural_snv_forward_dense (adds n*distal_len symbol bytes); 0: for mural_snv_forward_packed */
 size_t mural_snv_workspace_bytes(const MuralSnvModel* m, int64_t n, int32_t dense);
+/* The smallest workspace the forward calls accept.  mural_snv_workspace_bytes keeps the pooled stage-3 inputs of up to four
+ * 131072-site chunks (5.5 KB per site at the default geometry: + 2.2 GB on calls of >= 524288 sites) so that the short stages run as
+ * one launch per tower (~1 % faster); with a workspace between the two sizes they run per chunk -- same results bit for bit.       */
+size_t mural_snv_workspace_bytes_min(const MuralSnvModel* m, int64_t n, int32_t dense);
 
 /* Replaces Network{0,1,2}.forward((cont_x, cat_x), distal_x) (model_snv.py:104-108, :226-287, :439-525)
  * for already-encoded tensors.  cat_x: dev int64 [n][local_cols] (ignored for model_no 1);

@@ -181,6 +181,7 @@ PROTOTYPES = {
     "mural_snv_model_create": (C.c_int, [C.POINTER(MuralSnvShape), C.POINTER(MuralSnvParams), C.POINTER(C.c_void_p)]),
     "mural_snv_model_destroy": (None, [C.c_void_p]),
     "mural_snv_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
+    "mural_snv_workspace_bytes_min": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "mural_snv_forward_dense": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
                                           C.c_size_t, C.c_void_p, C.c_void_p]),
     "mural_snv_forward_packed": (C.c_int, [C.c_void_p, C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64,

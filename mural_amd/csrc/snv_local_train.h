@@ -496,10 +496,15 @@ int lt_launch_bwd(LtBwd a, hipStream_t stream) {
 
 // does the fused form serve this shape?  (every Linear dimension within the kernels' reduction runs; MURAL_TRAIN_LOCAL_OPS=1 keeps the
 // per-op launches for A/B runs and parity tests of both)
-bool local_train_fused_ok(int in1, int h1, int h2, int nc) {
+// The bottom backward launch keeps the embedding-gradient table (emb_rows x 5 floats) and eight rows of the Linear's output in LDS:
+// tables beyond the 64 KB a launch gets without opting in (local_order >= 6: 4097 rows = 82 KB) and batches beyond the launchers'
+// 32-bit offsets take the per-op route, which has neither limit.
+bool local_train_fused_ok(int in1, int h1, int h2, int nc, int emb_rows, int64_t B) {
   const char* e = getenv("MURAL_TRAIN_LOCAL_OPS");
   if (e && atoi(e) != 0) return false;
-  return in1 <= 256 && h1 <= 256 && h2 <= 256 && nc <= 256 && in1 >= 1 && h1 >= 1 && h2 >= 1 && nc >= 1;      // (B: see the launchers)
+  const size_t bottom_lds = ((size_t)8 * (size_t)h1 + (size_t)emb_rows * 5) * 4;
+  if (bottom_lds > (size_t)64 * 1024 || B > (1 << 20)) return false;
+  return in1 <= 256 && h1 <= 256 && h2 <= 256 && nc <= 256 && in1 >= 1 && h1 >= 1 && h2 >= 1 && nc >= 1;
 }
 
 int local_train_fwd(const int64_t* cat, const float* E, int cols, int emb_rows, int64_t B, const int* dims /* in1, h1, h2, nc */,

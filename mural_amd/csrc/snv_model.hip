@@ -295,7 +295,8 @@ int64_t super_chunk_sites(const MuralSnvModel* m) {
   return (m->split && !m->longwin && !off) ? SNV_SUPER * m->chunk : m->chunk;
 }
 
-size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w) {
+// one_chunk: the layout whose short stages run per chunk (s3 / xlogit of one chunk: the smallest workspace a call accepts)
+size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspace* w, bool one_chunk = false) {
   size_t off = 0;
   const size_t guard = ws_guard_bytes();      // 0 outside the validation tests (common.h)
   ws_layout_reset();
@@ -310,7 +311,7 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
   const size_t o_sym = take(dense ? (size_t)n * m->shape.distal_len : 16);
   const size_t o_x0 = take((size_t)std::min<int64_t>(n, m->chunk) * std::max(m->args.x0_cols, 1) * SNV_C * 4);
   // (the short-stage launches run once per SUPER-chunk of up to SNV_SUPER chunks: their inputs and the mid logits are kept that long)
-  const int64_t s3_sites = std::min<int64_t>(n, super_chunk_sites(m));
+  const int64_t s3_sites = std::min<int64_t>(n, one_chunk ? m->chunk : super_chunk_sites(m));
   const size_t o_xl = take((size_t)s3_sites * SNV_MAXCLASS * 4);
   const size_t o_s3l = take((size_t)s3_sites * std::max(m->args.geom[0].L[1], 1) * SNV_C * 4);
   const size_t o_s3m = take((size_t)s3_sites * std::max(m->args.geom[1].L[1], 1) * SNV_C * 4);
@@ -637,6 +638,11 @@ extern "C" size_t mural_snv_workspace_bytes(const MuralSnvModel* m, int64_t n, i
   return carve(m, n, dense != 0, nullptr, nullptr);
 }
 
+extern "C" size_t mural_snv_workspace_bytes_min(const MuralSnvModel* m, int64_t n, int32_t dense) {
+  if (!m || n <= 0) return 256;
+  return carve(m, n, dense != 0, nullptr, nullptr, true);
+}
+
 extern "C" int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* o) {
   MURAL_REQUIRE(m && o, "NULL argument");
   std::memset(o, 0, 16 * sizeof(int32_t));
@@ -661,12 +667,12 @@ extern "C" int mural_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long
 constexpr int64_t SNV_SMALL_BATCH = 256;   // up to here a call is latency-bound: single launch with one-site tiles
 
 static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool packed, int64_t n, const Workspace& w,
-                      float* out, float* taps, const int32_t* status, hipStream_t stream) {
+                      float* out, float* taps, const int32_t* status, hipStream_t stream, bool one_chunk = false) {
   const int nc = m->shape.n_class;
   const bool small = taps == nullptr && n <= SNV_SMALL_BATCH && m->lds_small > 0 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH");
   // the short-stage launches of up to SNV_SUPER chunks as ONE launch per tower (super_chunk_sites): the chunks' first-stage launches leave
   // their pooled rows side by side in s3
-  const bool defer = m->split && taps == nullptr && !small && !m->longwin && super_chunk_sites(m) > m->chunk && n > m->chunk;
+  const bool defer = m->split && taps == nullptr && !small && !m->longwin && super_chunk_sites(m) > m->chunk && n > m->chunk && !one_chunk;
   const int64_t super = defer ? super_chunk_sites(m) : m->chunk;
   const size_t s3l_site = (size_t)std::max(m->args.geom[0].L[1], 1) * SNV_C, s3m_site = (size_t)std::max(m->args.geom[1].L[1], 1) * SNV_C;
   for (int64_t sc0 = 0; sc0 < n; sc0 += super) {
@@ -783,12 +789,15 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
   hipStream_t stream = (hipStream_t)stream_;
   const MuralSnvShape& sh = m->shape;
   MURAL_REQUIRE(out, "out is NULL");
-  if (ws_bytes < carve(m, n, true, nullptr, nullptr) || !workspace) {
-    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, true, nullptr, nullptr), ws_bytes);
+  // a workspace of mural_snv_workspace_bytes holds the pooled rows of four chunks (the short stages as one launch per tower, + 1 %); a
+  // caller short of memory may pass mural_snv_workspace_bytes_min: the short stages then run per chunk, same results bit for bit
+  const bool one_chunk = ws_bytes < carve(m, n, true, nullptr, nullptr);
+  if (ws_bytes < carve(m, n, true, nullptr, nullptr, true) || !workspace) {
+    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, true, nullptr, nullptr, true), ws_bytes);
     return MURAL_E_WORKSPACE;
   }
   Workspace w;
-  carve(m, n, true, workspace, &w);
+  carve(m, n, true, workspace, &w, one_chunk);
   if (sh.model_no == 0) {
     MURAL_REQUIRE(cat_x, "cat_x is NULL");
     return launch_snv_local(m->local, cat_x, n, out, stream);   // raw logits, model_snv.py:93
@@ -812,7 +821,7 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
     s1.status = status;
   }
   if (local_rides(m, n)) ride_local(m, &s1, cat_x, w.local_logits);
-  return run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, status, stream);
+  return run_towers(m, s1, m->args, /*packed=*/false, n, w, out, taps, status, stream, one_chunk);
 }
 
 extern "C" int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
@@ -838,12 +847,13 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
   MURAL_REQUIRE(pos && strand && out, "pos/strand/out must not be NULL");
   hipStream_t stream = (hipStream_t)stream_;
   const MuralSnvShape& sh = m->shape;
-  if (workspace_bytes < carve(m, n, false, nullptr, nullptr) || !workspace) {
-    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, false, nullptr, nullptr), workspace_bytes);
+  const bool one_chunk = workspace_bytes < carve(m, n, false, nullptr, nullptr);      // (see forward_dense_impl)
+  if (workspace_bytes < carve(m, n, false, nullptr, nullptr, true) || !workspace) {
+    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, false, nullptr, nullptr, true), workspace_bytes);
     return MURAL_E_WORKSPACE;
   }
   Workspace w;
-  carve(m, n, false, workspace, &w);
+  carve(m, n, false, workspace, &w, one_chunk);
   if (sh.model_no != 1) {
     const int ncol = 2 * local_radius + 1 - (local_order - 1);
     MURAL_REQUIRE(ncol == sh.local_cols, "local_radius/local_order give %d k-mer columns, model has %d", ncol, sh.local_cols);
@@ -862,5 +872,5 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
   s1.genome = *g;
   s1.pos = pos;
   s1.strand = strand;
-  return run_towers(m, s1, m->args, /*packed=*/true, n, w, out, nullptr, nullptr, stream);
+  return run_towers(m, s1, m->args, /*packed=*/true, n, w, out, nullptr, nullptr, stream, one_chunk);
 }

@@ -74,7 +74,7 @@ int head_train_bwd(const float* dlogits, const float* W, int nc, int64_t B, int 
                    float* dgamma, float* dbeta, hipStream_t stream);
 int head_train_wgrad(const float* dlogits, const float* fd, int64_t B, int nc, float* dW, float* db, hipStream_t stream);
 // snv_local_train.h (train_ops.hip): the local branch in three launches per direction
-bool local_train_fused_ok(int in1, int h1, int h2, int nc);
+bool local_train_fused_ok(int in1, int h1, int h2, int nc, int emb_rows, int64_t B);
 int local_train_fwd(const int64_t* cat, const float* E, int cols, int emb_rows, int64_t B, const int* dims, const float* const* W,
                     const float* const* bias, const float* const* gamma, const float* const* beta, float* const* running_mean,
                     float* const* running_var, float* const* state, double* const* acc_f, const float* drop, const uint64_t* seeds,
@@ -400,7 +400,7 @@ int local_f(Ctx& c, const int64_t* cat, const float* drop, const uint64_t* seeds
   const MuralLocal& L = c.p->local;
   LocalBufs& l = P.loc;
   const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
-  if (local_train_fused_ok(in1, h[0], h[1], P.nc)) {
+  if (local_train_fused_ok(in1, h[0], h[1], P.nc, sh.emb_rows, B)) {
     const int dims[4] = {in1, h[0], h[1], P.nc};
     const float* W[3] = {L.lin[0].weight, L.lin[1].weight, L.out.weight};
     const float* bias[3] = {L.lin[0].bias, L.lin[1].bias, L.out.bias};
@@ -608,7 +608,7 @@ int local_b(Ctx& c, const int64_t* cat, const float* dlogits, const float* drop,
   LocalBufs& l = P.loc;
   const int B = P.B, in1 = 5 * sh.local_cols, h[2] = {sh.hidden1, sh.hidden2};
   float *g0 = P.g_loc[0], *g1 = P.g_loc[1], *g2 = P.g_loc[2];
-  if (local_train_fused_ok(in1, h[0], h[1], P.nc)) {
+  if (local_train_fused_ok(in1, h[0], h[1], P.nc, sh.emb_rows, B)) {
     const int dims[4] = {in1, h[0], h[1], P.nc};
     const float* W[3] = {L.lin[0].weight, L.lin[1].weight, L.out.weight};
     const float* gamma[2] = {L.bn[0].weight, L.bn[1].weight};

@@ -1689,8 +1689,12 @@ __global__ __launch_bounds__(1024) void clip_norm_scale_kernel(float* __restrict
   for (int w = 0; w < CLIP_WGS; ++w) t += part[w];
   const float norm = (float)sqrt(t);
   if (blockIdx.x == 0 && threadIdx.x == 0) *total = norm;
-  const float coef = fminf(max_norm / (norm + 1e-6f), 1.f);
-  if (coef >= 1.f) return;      // (torch multiplies by 1: the same values)
+  // torch: grads *= clamp(max_norm / (norm + 1e-6), max = 1) -- a NaN norm (a diverged step) makes the coefficient NaN and every
+  // gradient with it, an infinite norm makes it 0 (the infinite entries become NaN): that is what makes a diverged step visible, so it is
+  // kept.  The NaN test is on the bits: this file is built with -fno-honor-nans, under which `coef >= 1` may be folded either way.
+  const float coef = max_norm / (norm + 1e-6f);
+  const bool coef_nan = (__float_as_uint(coef) & 0x7fffffffu) > 0x7f800000u;
+  if (!coef_nan && coef >= 1.f) return;      // (torch multiplies by 1: the same values)
   const int64_t per = ((n + CLIP_WGS - 1) / CLIP_WGS + 3) & ~(int64_t)3;
   const int64_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
   for (int64_t i = lo + 4 * (int64_t)threadIdx.x; i < hi; i += 4 * 1024) {

@@ -242,7 +242,13 @@ class _HipSnvBase(nn.Module):
         need = int(_lib.lib().mural_snv_workspace_bytes(self._get_handle(), n, int(dense)))
         if ws is None or ws.numel() < need or ws.device != device:
             self._ws = None
-            self._ws = ws = torch.empty(need, dtype=torch.uint8, device=device)
+            try:
+                self._ws = ws = torch.empty(need, dtype=torch.uint8, device=device)
+            except torch.OutOfMemoryError:
+                # the full size keeps four chunks of pooled rows (one short-stage launch per tower, + 1 %); the library accepts the
+                # one-chunk layout as well (include/mural_hip.h: mural_snv_workspace_bytes_min) -- same results
+                need = int(_lib.lib().mural_snv_workspace_bytes_min(self._get_handle(), n, int(dense)))
+                self._ws = ws = torch.empty(need, dtype=torch.uint8, device=device)
             self._ws_rows = [0, 0]
         self._ws_rows[int(dense)] = max(self._ws_rows[int(dense)], n)
         return ws

@@ -18,6 +18,8 @@ Fixture list:
   G8  indel_*.npz         UNet_Small shipped checkpoints + a synthetic 2-class L=4000 model
   G9  predict_m.npz       model_predict_m on 3 uneven batches
   G10 batching.npz        generate_data_batches row order incl. tail carry-over
+  G16 config1_example.npz BASELINE config 1 through the reference's own run_predict pipeline: rows of examples/snv/data/
+                          validation.sorted.bed below 400 kb, checkpoint_6 + its Dirichlet calibrator -> the '%.4g' tables
 """
 import contextlib
 import io
@@ -824,13 +826,132 @@ def g13_analytics(ref):
     save("analytics.npz", **out)
 
 
+CONFIG1_SEED, CONFIG1_LEN, CONFIG1_CUT = 20251121, 401_000, 400_000
+
+
+def config1_genome(rows):
+    """The synthetic chr2L of BASELINE config 1 (the example's data/seq.fa is not shipped): i.i.d. uniform ACGT
+    from a seeded generator with the focal bases planted -- 'A' under '+' rows, 'T' under '-' rows (examples/snv is an A/T-site model).
+    The test rebuilds the same string from the same seed and the committed rows."""
+    rng = np.random.default_rng(CONFIG1_SEED)
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=CONFIG1_LEN)].copy()
+    for r in rows:
+        seq[r.start] = ord("A") if r.strand == "+" else ord("T")
+    return seq.tobytes().decode()
+
+
+def g16_config1(ref):
+    """BASELINE config 1 end to end THROUGH THE REFERENCE'S OWN PIPELINE (MuRaL/scripts/run_predict.py:107-239): the rows of
+    examples/snv/data/validation.sorted.bed below 400 kb (a data subsample), prepare_dataset_np -> DataLoader ->
+    generate_data_batches(pred_batch_size 16) -> model_predict_m with examples/snv/models/checkpoint_6 -> softmax -> the shipped
+    model.fdiri_cal.pkl -> get_position_info -> sort_values -> to_csv('%.4g').  Stand-ins: BedTool = a list of rows, SeqIO = a
+    two-function FASTA reader (pybedtools / Bio are absent here), jax.numpy = numpy for the calibrator's predict_proba (as in G12)."""
+    import importlib
+    import pickle
+    import tempfile
+    import types
+    import pandas as pd
+    from torch.utils.data import DataLoader
+    import torch.nn.functional as F
+    prep = ref.preprocessing
+    src = os.path.join(REF, "examples", "snv", "data", "validation.sorted.bed")
+    rows = []
+    with open(src) as fh:
+        for ln in fh:
+            c, s_, e_, name, score, strand = ln.rstrip("\n").split("\t")
+            if int(s_) < CONFIG1_CUT:
+                rows.append(Row(c, int(s_), int(e_), name, score, strand))
+    seq = config1_genome(rows)
+    with open(os.path.join(REF, "examples", "snv", "models", "checkpoint_6", "model.config.pkl"), "rb") as fh:
+        config = pickle.load(fh)
+    r, order, R = int(config["local_radius"]), int(config["local_order"]), int(config["distal_radius"])
+    FakeBedT = type("FakeBedT", (prep.BedTool, FakeBed), {})
+    bed = FakeBedT.__new__(FakeBedT)
+    FakeBed.__init__(bed, rows)
+    rec = types.SimpleNamespace(id="chr2L", seq=seq)
+    saved_seqio = prep.SeqIO
+    prep.SeqIO = types.SimpleNamespace(parse=lambda handle, fmt: [rec], to_dict=lambda recs: {x.id: x for x in recs})
+    try:
+        with tempfile.NamedTemporaryFile("w", suffix=".fa") as fa:
+            fa.write(">chr2L\n" + seq + "\n")
+            fa.flush()
+            dataset = quiet(prep.prepare_dataset_np, bed, fa.name, [], [], [], int(config["segment_center"]), r, order, R, 1, seq_only=True,
+                            model_type="snv")
+        dataset.get_distal_encoding_infomation()
+    finally:
+        prep.SeqIO = saved_seqio
+    data_local = dataset.data_local.reset_index(drop=True)
+    n_class = int(config["n_class"])
+    common = {"emb_dims": config["emb_dims"], "n_cont": len(dataset.cont_cols), "n_class": n_class, "distal_order": 1, "in_channels": 4}
+    model = quiet(ref.nn_utils.model_choice, int(config["model_no"]), config, common, "snv")
+    model.load_state_dict(torch.load(os.path.join(REF, "examples", "snv", "models", "checkpoint_6", "model"), map_location="cpu"))
+    loader = DataLoader(dataset, 1, shuffle=False, pin_memory=False)
+    batches = prep.generate_data_batches(loader, 1, 16, shuffle=False)          # commands/predict.py:84-93 defaults
+    pred_y, total_loss = quiet(ref.nn_utils.model_predict_m, model, batches, nn.CrossEntropyLoss(reduction="sum"), torch.device("cpu"), n_class,
+                               distal=True, model_type="snv")
+    prob_names = ["prob%d" % i for i in range(n_class)]
+    softmax = F.softmax(pred_y, dim=1).detach().numpy()
+    y_prob = pd.DataFrame(data=softmax, columns=prob_names)
+    # the shipped calibrator through the reference's own class (numpy standing in for jax.numpy, as in g12_dirichlet)
+    saved = {k: sys.modules.get(k) for k in list(sys.modules) if k == "jax" or k.startswith("jax.") or k.startswith("dirichletcal")
+             or k == "autograd" or k.startswith("autograd.")}
+    for k in saved:
+        sys.modules.pop(k, None)
+
+    def mod(name, **kw):
+        m = types.ModuleType(name)
+        m.__path__ = []
+        for a, v in kw.items():
+            setattr(m, a, v)
+        sys.modules[name] = m
+        return m
+
+    noop = lambda f=None, **k: (lambda *a, **kw: None)      # noqa: E731
+    jax = mod("jax", numpy=np, grad=noop, hessian=noop, jit=lambda f, **k: f)
+    jax.config = mod("jax.config", config=types.SimpleNamespace(update=lambda *a, **k: None)).config
+    sys.modules["jax.numpy"] = np
+    mod("autograd", grad=noop, hessian=noop, numpy=np)
+    sys.modules["autograd.numpy"] = np
+    sys.path.insert(0, os.path.join(REF, "dirichlet_python"))
+    try:
+        importlib.import_module("dirichletcal")
+        with open(os.path.join(REF, "examples", "snv", "models", "checkpoint_6", "model.fdiri_cal.pkl"), "rb") as fh:
+            calibr = pickle.load(fh)
+        weights = np.asarray(calibr.calibrator_.weights_, dtype=np.float64)
+        prob_cal = calibr.predict_proba(y_prob.to_numpy())
+    finally:
+        sys.path.pop(0)
+        for k in [k for k in sys.modules if k == "jax" or k.startswith("jax.") or k.startswith("dirichletcal") or k == "autograd"
+                  or k.startswith("autograd.")]:
+            sys.modules.pop(k, None)
+        sys.modules.update({k: v for k, v in saved.items() if v is not None})
+    tables = {}
+    for tag, probs in (("softmax", softmax), ("calibrated", np.copy(prob_cal))):
+        y = pd.DataFrame(data=probs, columns=prob_names)
+        data_and_prob = pd.concat([data_local, y], axis=1)
+        test_pred_df = data_and_prob[["mut_type"] + prob_names]
+        chr_pos = prep.get_position_info(bed, int(config["segment_center"]))
+        pred_df = pd.concat((chr_pos, test_pred_df), axis=1)
+        pred_df.columns = ["chrom", "start", "end", "strand", "mut_type"] + prob_names
+        pred_df.sort_values(["chrom", "start"], inplace=True)
+        pred_df.reset_index(drop=True, inplace=True)
+        buf = io.StringIO()
+        pred_df.to_csv(buf, sep="\t", float_format="%.4g", index=False)
+        tables[tag] = buf.getvalue()
+    bed_text = "".join("\t".join([x.chrom, str(x.start), str(x.stop), x.name, x.score, x.strand]) + "\n" for x in rows)
+    save("config1_example.npz", bed=np.array(bed_text), table_softmax=np.array(tables["softmax"]), table_calibrated=np.array(tables["calibrated"]),
+         softmax=softmax.astype(np.float32), calibrated=np.asarray(prob_cal, np.float64), dirichlet_w=weights,
+         total_loss=np.array(float(total_loss)), genome_seed=np.array(CONFIG1_SEED), genome_len=np.array(CONFIG1_LEN),
+         hp=np.array([r, order, R, int(config["segment_center"]), n_class], np.int64))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(8)
     ref = ref_import.load()
     only = set(sys.argv[1:])
     steps = dict(g1=g1_encode, g2=g2_windowing, g3=g3_pretrained, g45=g45_synth, g6=g6_taps, g7=g7_train,
-                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet, g13=g13_analytics, g14=g14_indel_train, g15=g15_generic_shapes)
+                 g8=g8_indel, g9=g9_predict_m, g10=g10_batching, g11=g11_output, g12=g12_dirichlet, g13=g13_analytics, g14=g14_indel_train, g15=g15_generic_shapes, g16=g16_config1)
     for name, fn in steps.items():
         if only and name not in only:
             continue

@@ -248,3 +248,73 @@ def test_zero_row_rank_blocks_through_the_real_forward(tmp_path):
     pos = np.arange(1000, 1300)
     got = fwd("c", pos, np.zeros(300, np.uint8))[:, :4].cpu().numpy()
     assert np.abs(got - _oracle_probs(orc, seq, pos, np.zeros(300, bool), r, R)).max() <= PROB_TOL
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# BASELINE config 1 on the reference's example material (examples/snv/examples.sh, Example 3): the rows of
+# examples/snv/data/validation.sorted.bed below 400 kb on the seeded synthetic chr2L with planted focal bases (the example's
+# data/seq.fa is not shipped), examples/snv/models/checkpoint_6 + its model.fdiri_cal.pkl.  G16 (config1_example.npz) holds what the
+# reference's OWN pipeline wrote for them: prepare_dataset_np -> generate_data_batches -> model_predict_m -> softmax ->
+# FullDirichletCalibrator.predict_proba -> sort_values -> to_csv('%.4g') (oracle/make_golden.py: g16_config1).
+# ------------------------------------------------------------------------------------------------------------------
+def _config1_files(tmp_path, fx, gz):
+    import gzip
+    rows = [ln.split("\t") for ln in str(fx["bed"]).split("\n") if ln]
+    rng = np.random.default_rng(int(fx["genome_seed"]))
+    seq = np.frombuffer(b"ACGT", np.uint8)[rng.integers(0, 4, size=int(fx["genome_len"]))].copy()
+    for c, s_, e_, name, score, strand in rows:
+        seq[int(s_)] = ord("A") if strand == "+" else ord("T")
+    fasta_text = (">chr2L synthetic\n" + "\n".join(seq.tobytes().decode()[i:i + 60] for i in range(0, len(seq), 60)) + "\n").encode()
+    fa, bed = tmp_path / ("seq.fa.gz" if gz else "seq.fa"), tmp_path / ("validation.bed.gz" if gz else "validation.bed")
+    fa.write_bytes(gzip.compress(fasta_text) if gz else fasta_text)
+    bed.write_bytes(gzip.compress(str(fx["bed"]).encode()) if gz else str(fx["bed"]).encode())
+    return fa, bed, len(rows)
+
+
+def _table_fields(text):
+    lines = text.rstrip("\n").split("\n")
+    return lines[0], [ln.split("\t") for ln in lines[1:]]
+
+
+@pytest.mark.parametrize("gz", [False, True])
+def test_config1_example_files_to_calibrated_table(tmp_path, gz):
+    from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
+    fx = U.load("config1_example.npz")
+    model, _, r, R = _models("snv_pretrained_example_ckpt6.npz")
+    assert (r, R) == (int(fx["hp"][0]), int(fx["hp"][2]))
+    fa, bed, n = _config1_files(tmp_path, fx, gz)
+    w = fx["dirichlet_w"]
+    # (a) softmax probabilities in bed_reader order against the reference's model_predict_m + softmax
+    res = predict_bed_sharded(HipShardForward(model, fa, r, 3), bed, segment_center=int(fx["hp"][3]))
+    assert len(res["start"]) == n
+    assert np.abs(res["prob"] - fx["softmax"]).max() <= PROB_TOL
+    # (b) files -> calibrated table, calibration on the host in the sink and on the device behind the head: every field but the
+    # probabilities byte-identical to the reference's table, the probabilities within the tolerance -- a '%.4g' field may differ by a
+    # unit of its last digit where a 1e-6 difference straddles a rounding boundary, and only there
+    head_want, want = _table_fields(str(fx["table_calibrated"]))
+    for mode in ("sink", "device"):
+        out = tmp_path / f"pred_{mode}.tsv"
+        if mode == "sink":
+            predict_bed_sharded(HipShardForward(model, fa, r, 3), bed, segment_center=int(fx["hp"][3]), collect=False,
+                                sink=TsvSink(out, dirichlet_weights=w))
+        else:
+            predict_bed_sharded(HipShardForward(model, fa, r, 3, dirichlet_weights=w), bed, segment_center=int(fx["hp"][3]), collect=False,
+                                sink=TsvSink(out))
+        head, got = _table_fields(open(out).read())
+        assert head == head_want and len(got) == len(want) == n
+        flips = 0
+        for g, t in zip(got, want):
+            assert g[:5] == t[:5]
+            for a, b in zip(g[5:], t[5:]):
+                if a != b:
+                    flips += 1
+                    unit = 10.0 ** (np.floor(np.log10(max(float(b), 1e-300))) - 3)      # one unit of the 4th significant digit
+                    assert abs(float(a) - float(b)) <= 1.001 * unit, (g, t)
+        assert flips <= n * 4 // 100, flips
+    # (c) the reference's own softmax rows through this library's calibrator + sorter + '%.4g' writer: byte-identical tables
+    from mural_amd.data.ingest import write_predictions
+    fed = dict(res, prob=fx["softmax"])
+    for name, kw in (("table_softmax", {}), ("table_calibrated", {"dirichlet_weights": w})):
+        path = tmp_path / (name + ".tsv")
+        write_predictions(fed, path, **kw)
+        assert open(path).read() == str(fx[name]), name

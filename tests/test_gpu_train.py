@@ -390,6 +390,45 @@ def test_train_step_network0_network1_vs_oracle_autograd(model_no):
         assert np.abs(p.grad.cpu().numpy() - w).max() <= 2e-4 * (np.abs(w).max() + 1e-2), k
 
 
+def test_train_step_with_local_order_6_embedding_table():
+    """the reference CLI accepts any --local_order; at order 6 the embedding has 4 ** 6 + 1 = 4097 rows, whose gradient
+    table (82 KB) is beyond the LDS the fused local-branch backward gets -- the step takes the per-op launches for such shapes
+    instead of failing the launch.  Network0 and Network2 against the oracle's autograd."""
+    for model_no in (0, 2):
+        hp = np.array([7, 6, 100, 150, 75, 32, 3, 4, model_no])
+        model, _ = product_from_hp(hp)
+        orc = U.snv_oracle_from_hp(hp, drops=(0.0, 0.0, 0.0))
+        from oracle import synth
+        sd = synth.synth_state_dict(orc.state_dict(), 606)
+        orc.load_state_dict(sd)
+        model.load_state_dict(sd)
+        assert model.state_dict()["emb_layer.weight"].shape[0] == 4097
+        for m in model.modules():
+            if isinstance(m, nn.Dropout):
+                m.p = 0.0
+        model = model.cuda().train()
+        orc.train()
+        rng = np.random.default_rng(6)
+        B = 40
+        codes = rng.integers(0, 4, size=(B, 201)).astype(np.uint8)
+        cat = torch.from_numpy(rng.integers(0, 4097, size=(B, 10)).astype(np.int64))
+        cat[0, :3] = 4096                                  # the padding row is trained as well (no padding_idx, model_snv.py:322)
+        y = torch.from_numpy(rng.integers(0, 4, size=B))
+        x = U.onehot(codes)
+        crit = nn.CrossEntropyLoss(reduction="sum")
+        want = crit(orc((torch.zeros(B, 1, dtype=torch.float64), cat), x), y)
+        want.backward()
+        got = crit(model((torch.zeros(B, 1, device="cuda"), cat.cuda()), x.cuda()), y.cuda())
+        got.backward()
+        assert abs(got.item() - want.item()) <= 1e-4 * abs(want.item())
+        ref = dict(orc.named_parameters())
+        for k, p in model.named_parameters():
+            if ".layer." in k or p.numel() == 0:
+                continue
+            w = ref[k].grad.numpy()
+            assert np.abs(p.grad.cpu().numpy() - w).max() <= 2e-4 * (np.abs(w).max() + 1e-2), (model_no, k)
+
+
 def test_graphed_train_step_matches_eager():
     """hipGraph replay of the whole step (mural_amd.train.GraphedTrainStep) == the eager step: same parameters after the
     same batches (dropout off so both paths are deterministic), and a non-encoding input is reported one step late."""
@@ -754,6 +793,23 @@ def test_flat_clip_grad_norm_matches_torch():
             if p.numel():
                 # two separate backward passes: the float atomics of the first-layer gradient table land in a different order
                 assert float((p.grad - want[k]).abs().max()) <= 2e-5 * (float(want[k].abs().max()) + 1e-6), k
+    # a diverged step stays visible: an infinite gradient gives an infinite norm, coefficient 0 -- the finite gradients
+    # become 0 and the infinite one NaN, as in torch; a NaN gradient gives a NaN norm and NaN everywhere
+    for poison in (float("inf"), float("nan")):
+        torch.manual_seed(5)
+        grads()
+        victim = next(p for p in model.parameters() if p.numel() > 8)
+        victim.grad.view(-1)[3] = poison
+        want_list = [p.grad.clone() for p in model.parameters() if p.numel()]
+        total_ref = torch.linalg.vector_norm(torch.stack([g.norm() for g in want_list]))
+        coef = torch.clamp(10.0 / (total_ref + 1e-6), max=1.0)
+        want_list = [g * coef for g in want_list]
+        total = clip_grad_norm_(model, 10.0)
+        assert model._train_layout.last_flat is not None
+        assert (torch.isnan(total) and torch.isnan(total_ref)) or float(total) == float(total_ref)
+        for p, w in zip([p for p in model.parameters() if p.numel()], want_list):
+            assert torch.equal(torch.isnan(p.grad), torch.isnan(w))
+            assert torch.equal(torch.nan_to_num(p.grad), torch.nan_to_num(w))
     # a gradient that left the flat buffer: torch's path serves the call
     torch.manual_seed(5)
     grads()

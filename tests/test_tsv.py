@@ -195,3 +195,28 @@ def test_rows_calibrated_on_the_device_are_not_calibrated_again(tmp_path):
     with pytest.raises(ValueError, match="calibrated already"):
         sink(shard)
     sink.abort()
+
+
+def test_config1_reference_rows_through_calibrator_and_writer_are_byte_identical(tmp_path):
+    """G16 (BASELINE config 1 on the reference's example material, written by the reference's own run_predict pipeline): its softmax rows
+    (model_predict_m order = bed_reader order) through this library's BED reader / row order, Dirichlet map, stable (chrom, start) sort
+    and '%.4g' writer give the reference's two tables byte for byte."""
+    import os
+    from mural_amd.calibration import load_dirichlet_weights
+    from mural_amd.data import ingest as I
+    from tests import _util as U
+    fx = U.load("config1_example.npz")
+    bed = tmp_path / "validation.bed"
+    bed.write_text(str(fx["bed"]))
+    sites = I.read_bed(bed)
+    order, _ = I.bed_order(sites, int(fx["hp"][3]))
+    res = {"chrom": np.asarray(sites.chrom_names, object)[sites.chrom_id[order]], "start": sites.start[order], "end": sites.end[order],
+           "strand": np.where(sites.strand[order] == 1, "-", "+").astype(object), "label": sites.score[order], "prob": fx["softmax"]}
+    w = fx["dirichlet_w"]
+    for name, kw in (("table_softmax", {}), ("table_calibrated", {"dirichlet_weights": w})):
+        path = tmp_path / (name + ".tsv")
+        assert write_predictions(res, path, **kw) == len(order)
+        assert open(path).read() == str(fx[name]), name
+    pkl = "/root/reference/examples/snv/models/checkpoint_6/model.fdiri_cal.pkl"
+    if os.path.exists(pkl):      # (build container only: the shipped calibrator through the jax-free reader)
+        assert np.array_equal(load_dirichlet_weights(pkl), w)
