@@ -182,6 +182,15 @@ def cpu_baseline(model_state, codes, budget_s=8.0):
             train_step()
         t = min(train_step() for _ in range(reps))
         train[str(tb)] = {"steps_per_s": 1.0 / t, "sites_per_s": tb / t}
+    # SURVEY.md section 8d's second figure: the same batch with a vectorised numpy encode of its inputs inside the timed region (the
+    # oracle's encoders: k-mer ids + one-hot windows from base codes; the reference's own per-character Python encoders are ~100 x slower)
+    enc_times = []
+    for it in range(6):
+        t0 = time.perf_counter()
+        batch_inputs(100 + it, 256)
+        enc_times.append(time.perf_counter() - t0)
+    t_encode = float(np.median(enc_times[1:]))
+    with_encode = 256.0 / (256.0 / by_batch["256"] + t_encode)
     # batch 256 at the chosen thread count: the median of the medians of three repeats of the timed loop (on this shared host a single
     # loop can catch a slow spell: 4.8 k vs 8.1 k bases/s were seen in one run); the repeats are reported
     value = by_batch["256"]
@@ -190,6 +199,8 @@ def cpu_baseline(model_state, codes, budget_s=8.0):
             "sample": "model only (inputs pre-encoded: cat_x int64, distal_x fp32 one-hot) on windows of the same synthetic chromosome; "
                       "value = batch 256 (median of the medians of three repeats of the timed loop); " + "; ".join(f"batch {b}: {v}" for b, v in samples.items()),
             "bases_per_s_by_batch": by_batch, "batch_256_repeat_medians": repeats_256, "train": train,
+            "bases_per_s_with_encode": with_encode, "encode_seconds_per_256": t_encode,
+            "with_encode_note": "batch 256: model time + a vectorised numpy encode of the batch (k-mer ids, fp32 one-hot windows) from base codes",
             "train_note": "forward + backward + clip + Adam of the same restatement; batch 4096 is a single timed step"}
 
 
@@ -471,8 +482,9 @@ def workload_variants(device, model, genome):
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
         out["model_predict_m_batch16_loader"] = {"bases_per_s": n_rows / dt, "rows": n_rows,
-                                                 "note": "HOST tensors in 16-row batches: 32 KB of fp32 one-hot per site copied over PCIe batch by "
-                                                         "batch inside the timed region and concatenated on the device"}
+                                                 "note": "HOST tensors in 16-row batches (what the reference's loader yields): windows classified "
+                                                         "into one symbol byte per column by host threads (mural_host_dense_to_symbols), 2 KB per "
+                                                         "site over PCIe instead of 32 KB, 8192-row launches through mural_snv_forward_symbols"}
         dev_loader = [tuple(t.to(device) for t in b) for b in loader]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -794,7 +806,64 @@ def config5_e2e(device, n_chrom=3, chrom_len=14_000_000):
                     + ("/dev/shm" if shm else "the temp directory") + "); every A ('+') and T ('-') of 3 random chromosomes is a site"}
 
 
+_CONTRACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                  "dtype", "data", "config", "collective_check", "roofline", "cpu_baseline")
+
+
+def _dig(obj, *path):
+    for k in path:
+        if not isinstance(obj, dict) or k not in obj:
+            return None
+        obj = obj[k]
+    return obj
+
+
+def summarize(line):
+    """The secondary legs' headline numbers in one small object (the legs themselves are kilobytes each)."""
+    r3 = lambda v: None if v is None else (round(v, 3) if abs(v) < 100 else round(v, 1))      # noqa: E731
+    tr, ind, var, c5 = line.get("train"), line.get("indel"), line.get("variants"), line.get("config5_e2e")
+    out = {
+        "train_steps_per_s": {"symbol_windows": r3(_dig(tr, "steps_per_s")), "dense_input": r3(_dig(tr, "steps_per_s_dense_input")),
+                              "synchronised": r3(_dig(tr, "steps_per_s_synchronised")), "frac_mfma": r3(_dig(tr, "roofline", "frac_mfma")),
+                              "launches_per_step": _dig(tr, "roofline", "launches_per_step"),
+                              "hbm_gb_per_step": r3((_dig(tr, "roofline", "hbm_bytes_per_step") or 0) / 1e9) or None},
+        "indel_positions_per_s": {"packed": r3(_dig(ind, "positions_per_s")), "dense_input": r3(_dig(ind, "positions_per_s_dense_input")),
+                                  "frac_mfma": r3(_dig(ind, "roofline", "frac")),
+                                  "hbm_mb_per_position": r3((_dig(ind, "roofline", "hbm_bytes_per_position") or 0) / 1e6) or None,
+                                  "train_ms_per_step": r3(_dig(ind, "train", "ms_per_step"))},
+        "dense_reuse_bases_per_s": r3(_dig(line, "dense_reuse", "bases_per_s")),
+        "config5_rows_per_s": r3(_dig(c5, "rows_per_s")),
+        "config5_projected_speedup_at_8": r3(_dig(c5, "rank_share", "projected_speedup_at_8")),
+        "cpu_baseline_bases_per_s": {"model_only": r3(_dig(line, "cpu_baseline", "value")),
+                                     "with_encode": r3(_dig(line, "cpu_baseline", "bases_per_s_with_encode"))},
+    }
+    if isinstance(var, dict):
+        frac = {}
+        for name, v in var.items():
+            if isinstance(v, dict):
+                for key in ("frac_of_fp32_peak", "bases_per_s", "rows_per_s"):
+                    if key in v and isinstance(v[key], (int, float)):
+                        frac.setdefault(name, {})[key] = r3(v[key])
+        out["variants"] = frac
+    return out
+
+
+def order_line(line):
+    """The secondary legs first, the contract's keys + roofline + cpu_baseline + a compact `summary` LAST: whoever keeps only the tail of
+    this one long line keeps the headline whole."""
+    out = {k: v for k, v in line.items() if k not in _CONTRACT_KEYS}
+    out["summary"] = summarize(line)
+    for k in _CONTRACT_KEYS:
+        if k in line:
+            out[k] = line[k]
+    return out
+
+
 def main():
+    try:      # (a side-stream AccumulateGrad warning of the training leg is ~1 KB of stderr per run)
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
+    except AttributeError:
+        pass
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -991,7 +1060,7 @@ def main():
             leg("indel", lambda: indel_positions_per_s(device, genome))
         if world == 1 and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline({k: v.detach().cpu() for k, v in model.state_dict().items()}, codes))
-        print(json.dumps(line), flush=True)
+        print(json.dumps(order_line(line)), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

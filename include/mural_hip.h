@@ -142,6 +142,11 @@ size_t mural_snv_workspace_bytes_min(const MuralSnvModel* m, int64_t n, int32_t 
  * without a host round trip (the caller reads and clears the word whenever it synchronises); may be NULL. */
 int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
                             float* out, void* workspace, size_t workspace_bytes, int32_t* status, void* stream);
+/* The same forward for windows handed over as ONE SYMBOL BYTE per column (dev uint8 [n][distal_len], MURAL_SYM_* codes 0..14 as
+ * mural_op_dense_to_symbols / mural_host_dense_to_symbols / mural_encode_symbols write them; the bytes are not checked).  Workspace:
+ * mural_snv_workspace_bytes(m, n, 0).                                                                                            */
+int mural_snv_forward_symbols(const MuralSnvModel* m, const int64_t* cat_x, const uint8_t* symbols, int64_t n, float* out,
+                              void* workspace, size_t workspace_bytes, void* stream);
 
 /* Fused encode + forward straight from the packed genome: the path `mural_snv predict` takes
  * (replaces preprocessing.py:636-723 + :756-816 + model_snv.py:439-525 for n sites).
@@ -309,6 +314,13 @@ int mural_op_head_fwd(const float* loc, const float* mid, const float* lar, int6
 int mural_op_head_bwd(const float* loc, const float* mid, const float* lar, const float* dout, int64_t B, int32_t nc,
                       float* dloc, float* dmid, float* dlar, void* stream);
 int mural_op_dense_to_symbols(const float* x, int64_t n, int32_t L, uint8_t* sym, int32_t* status, void* stream);
+/* Its HOST twin for loaders that yield host tensors (the reference's predict loop copies every fp32 window to the device batch by
+ * batch, MuRaL/model/nn_utils.py:52-56): xs[b] = HOST float [rows[b]][4][L]; sym = HOST uint8 [sum rows][L], 255 for a column that is
+ * no MuRaL encoding (*n_bad counts them).  Host threads; no device work.                                                          */
+int mural_host_dense_to_symbols(const float* const* xs, const int64_t* rows, int64_t n_batches, int32_t L, uint8_t* sym,
+                                int64_t* n_bad);
+/* the small fields (y, cat_x) of the same host batches copied side by side into one (pinned) buffer: bytes[b] bytes from srcs[b]     */
+int mural_host_concat(const void* const* srcs, const int64_t* bytes, int64_t n, void* dst);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Post-head calibration of the prediction path in one pass over the (n, n_class) rows (run_predict.py:214-225):

@@ -897,6 +897,98 @@ extern "C" int mural_bed_parse_range(const char* path, int64_t byte_lo, int64_t 
   return MURAL_OK;
 }
 
+// ---- host twin of mural_op_dense_to_symbols ------------------------------------------------------------------------------------------
+// The reference's loader yields HOST tensors (y, cont_x, cat_x, distal_x) and its predict loop moves them to the device batch by batch
+// (MuRaL/model/nn_utils.py:37-76; 16 rows per batch by default, commands/predict.py:90): 32 KB of fp32 one-hot per site over PCIe.
+// model_predict_m classifies the windows on the host instead -- one symbol byte per column (MURAL_SYM_*, dense_symbol.h's rule) -- and
+// uploads 1 / 16 of the bytes.  xs[b]: HOST float [rows[b]][4][L] contiguous; sym: HOST uint8 [sum rows][L] (rows of the batches side
+// by side); *n_bad: columns that are no MuRaL encoding (they get code 255; the caller raises).  The batches are spread over the host
+// threads (MURAL_HOST_THREADS; up to 32 here: the pass streams 16 KB per output row).
+namespace {
+
+struct SymLut {
+  uint8_t t[625];
+  SymLut() {
+    std::memset(t, 255, sizeof(t));
+    const int key[15] = {1, 5, 25, 125, 468, 52, 260, 12, 60, 252, 300, 620, 604, 524, 124};      // dense_symbol.h: d0 + 5 d1 + 25 d2 + 125 d3
+    for (int i = 0; i < 15; ++i) t[key[i]] = (uint8_t)i;
+  }
+};
+const SymLut kSymLut;
+
+inline int64_t classify_window(const float* x, int L, uint8_t* out) {
+  const float third = (float)(1.0 / 3.0);
+  int64_t bad = 0;
+  constexpr int BLK = 256;
+  int32_t key[BLK];
+  for (int c0 = 0; c0 < L; c0 += BLK) {
+    const int m = L - c0 < BLK ? L - c0 : BLK;
+    for (int c = 0; c < m; ++c) key[c] = 0;
+    int mul = 1;
+    for (int r = 0; r < 4; ++r) {
+      const float* row = x + (size_t)r * L + c0;
+      for (int c = 0; c < m; ++c) {            // digit of frac_digit(): 0, 1, .5, .25, 1/3 -> 0..4; anything else poisons the key
+        const float v = row[c];
+        const int d = (v == 1.0f) * 1 + (v == 0.5f) * 2 + (v == 0.25f) * 3 + (v == third) * 4;
+        const int ok = (v == 0.0f) | (d != 0);
+        key[c] += ok ? d * mul : 100000;
+      }
+      mul *= 5;
+    }
+    for (int c = 0; c < m; ++c) {
+      const uint8_t sy = (uint32_t)key[c] < 625u ? kSymLut.t[key[c]] : (uint8_t)255;
+      out[c0 + c] = sy;
+      bad += sy == 255;
+    }
+  }
+  return bad;
+}
+
+}  // namespace
+
+extern "C" int mural_host_dense_to_symbols(const float* const* xs, const int64_t* rows, int64_t n_batches, int32_t L, uint8_t* sym,
+                                           int64_t* n_bad) {
+  MURAL_REQUIRE(n_batches >= 0 && L >= 1 && n_bad, "host dense_to_symbols: bad arguments");
+  *n_bad = 0;
+  if (n_batches == 0) return MURAL_OK;
+  MURAL_REQUIRE(xs && rows && sym, "host dense_to_symbols: NULL argument");
+  std::vector<int64_t> first((size_t)n_batches + 1, 0);
+  for (int64_t b = 0; b < n_batches; ++b) {
+    MURAL_REQUIRE(rows[b] >= 0 && (rows[b] == 0 || xs[b]), "host dense_to_symbols: batch %lld is NULL", (long long)b);
+    first[(size_t)b + 1] = first[(size_t)b] + rows[b];
+  }
+  const int64_t total = first[(size_t)n_batches];
+  int T = host_threads();
+  if (!std::getenv("MURAL_HOST_THREADS")) T = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+  T = (int)std::max<int64_t>(1, std::min<int64_t>(T, total / 256 + 1));
+  std::vector<int64_t> bad((size_t)T, 0);
+  run_parallel(T, [&](int k) {
+    // rows [lo, hi) of the concatenation: whole windows, whichever batch they sit in
+    const int64_t lo = total * k / T, hi = total * (k + 1) / T;
+    int64_t b = (int64_t)(std::upper_bound(first.begin(), first.end(), lo) - first.begin()) - 1;
+    int64_t n = 0;
+    for (int64_t r = lo; r < hi; ++r) {
+      while (r >= first[(size_t)b + 1]) ++b;
+      n += classify_window(xs[b] + (size_t)(r - first[(size_t)b]) * 4 * (size_t)L, L, sym + (size_t)r * (size_t)L);
+    }
+    bad[(size_t)k] = n;
+  });
+  for (int64_t v : bad) *n_bad += v;
+  return MURAL_OK;
+}
+
+// the small fields of the same batches (y, cat_x) side by side in one staging buffer: bytes[b] bytes from srcs[b], in order
+extern "C" int mural_host_concat(const void* const* srcs, const int64_t* bytes, int64_t n, void* dst) {
+  MURAL_REQUIRE(n >= 0 && (n == 0 || (srcs && bytes && dst)), "host concat: bad arguments");
+  char* o = static_cast<char*>(dst);
+  for (int64_t b = 0; b < n; ++b) {
+    MURAL_REQUIRE(bytes[b] >= 0 && (bytes[b] == 0 || srcs[b]), "host concat: piece %lld is NULL", (long long)b);
+    std::memcpy(o, srcs[b], (size_t)bytes[b]);
+    o += bytes[b];
+  }
+  return MURAL_OK;
+}
+
 // Row order of bed_reader (preprocessing.py:39-106) for rows in file order: sites are cut into central_bp-wide segments
 // along each chromosome (the first chromosome's grid starts at its first site, later ones at 1), and every segment
 // yields its '+' rows, then its '-' rows.  order[k] = input row of output row k; group[k] = index of the yielded group.

@@ -780,9 +780,10 @@ static void ride_local(const MuralSnvModel* m, Stage1Args* s1, const int64_t* ca
   s1->loc_out = logits;
 }
 
+// symbols != nullptr: the windows arrive as one MURAL_SYM_* byte per column (dev uint8 [n][distal_len]) instead of distal_x
 static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n, float* out,
                               void* workspace, size_t ws_bytes, int32_t* status, float* taps, size_t taps_floats,
-                              void* stream_) {
+                              void* stream_, const uint8_t* symbols = nullptr) {
   MURAL_REQUIRE(m, "model handle is NULL");
   MURAL_REQUIRE(n >= 0, "negative batch");
   if (n == 0) return MURAL_OK;
@@ -791,31 +792,32 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
   MURAL_REQUIRE(out, "out is NULL");
   // a workspace of mural_snv_workspace_bytes holds the pooled rows of four chunks (the short stages as one launch per tower, + 1 %); a
   // caller short of memory may pass mural_snv_workspace_bytes_min: the short stages then run per chunk, same results bit for bit
-  const bool one_chunk = ws_bytes < carve(m, n, true, nullptr, nullptr);
-  if (ws_bytes < carve(m, n, true, nullptr, nullptr, true) || !workspace) {
-    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, true, nullptr, nullptr, true), ws_bytes);
+  const bool own_symbols = symbols == nullptr;      // (the symbol region of the workspace is the dense entry's)
+  const bool one_chunk = ws_bytes < carve(m, n, own_symbols, nullptr, nullptr);
+  if (ws_bytes < carve(m, n, own_symbols, nullptr, nullptr, true) || !workspace) {
+    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, own_symbols, nullptr, nullptr, true), ws_bytes);
     return MURAL_E_WORKSPACE;
   }
   Workspace w;
-  carve(m, n, true, workspace, &w, one_chunk);
+  carve(m, n, own_symbols, workspace, &w, one_chunk);
   if (sh.model_no == 0) {
     MURAL_REQUIRE(cat_x, "cat_x is NULL");
     return launch_snv_local(m->local, cat_x, n, out, stream);   // raw logits, model_snv.py:93
   }
-  MURAL_REQUIRE(distal_x, "distal_x is NULL");
+  MURAL_REQUIRE(distal_x || symbols, "distal_x is NULL");
   if (sh.model_no == 2) {
     MURAL_REQUIRE(cat_x, "cat_x is NULL");
     if (!local_rides(m, n))
       if (int rc = launch_snv_local(m->local, cat_x, n, w.local_logits, stream)) return rc;
   }
   // a small batch is one launch per stage: its first-stage kernel classifies the dense columns itself
-  const bool direct = stage1_small_batch(n);
-  if (!direct)
+  const bool direct = stage1_small_batch(n) && !symbols;
+  if (!direct && !symbols)
     if (int rc = launch_dense_to_symbols(distal_x, n, sh.distal_len, w.symbols, status, stream)) return rc;
   if (taps) MURAL_REQUIRE(!m->longwin, "the layer dump is not available for long windows (segmented first stage)");
   if (taps) MURAL_REQUIRE(taps_floats >= (size_t)13 * m->args.nbuf, "taps buffer too small (need %zu floats)", (size_t)13 * m->args.nbuf);
   Stage1Args s1 = m->s1;
-  s1.codes = w.symbols;
+  s1.codes = symbols ? symbols : w.symbols;
   if (direct) {
     s1.dense = distal_x;
     s1.status = status;
@@ -827,6 +829,12 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
 extern "C" int mural_snv_forward_dense(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,
                                        float* out, void* workspace, size_t workspace_bytes, int32_t* status, void* stream) {
   return forward_dense_impl(m, cat_x, distal_x, n, out, workspace, workspace_bytes, status, nullptr, 0, stream);
+}
+
+extern "C" int mural_snv_forward_symbols(const MuralSnvModel* m, const int64_t* cat_x, const uint8_t* symbols, int64_t n, float* out,
+                                         void* workspace, size_t workspace_bytes, void* stream) {
+  MURAL_REQUIRE(m && (m->shape.model_no == 0 || symbols), "symbols is NULL");
+  return forward_dense_impl(m, cat_x, nullptr, n, out, workspace, workspace_bytes, nullptr, nullptr, 0, stream, symbols);
 }
 
 extern "C" int mural_snv_debug_taps(const MuralSnvModel* m, const int64_t* cat_x, const float* distal_x, int64_t n,

@@ -370,6 +370,34 @@ class _HipSnvBase(nn.Module):
                                                           ws.data_ptr(), ws.numel(), _lib.current_stream_ptr(dev)))
         return out
 
+    def forward_symbols(self, cat_x, symbols):
+        """Eval-mode forward for windows given as one MURAL_SYM_* byte per column (device uint8 (n, 2 * distal_radius + 1)): what
+        ``model_predict_m`` feeds after classifying a host loader's one-hot windows on the host (``mural_host_dense_to_symbols``)."""
+        self._check_eval()
+        dev = self._device()
+        if dev.type != "cuda":
+            raise RuntimeError("mural_amd models run on a HIP device only: call model.to('cuda') first")
+        if not self.symbols_entry_ok():
+            raise RuntimeError("this model configuration evaluates through the per-layer path, which takes the dense distal_input")
+        symbols = _lib.require_cuda(symbols, "symbols")
+        if symbols.dtype != torch.uint8 or symbols.dim() != 2 or symbols.shape[1] != self.seq_len:
+            raise ValueError(f"symbols must be a uint8 (n, {self.seq_len}) tensor")
+        symbols = symbols.contiguous()
+        n = symbols.shape[0]
+        cat_ptr = None
+        if self.model_no != 1:
+            cat_x = _lib.require_cuda(cat_x, "cat_x").to(torch.int64).contiguous()
+            cat_ptr = cat_x.data_ptr()
+        with _on_device(dev):
+            out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
+            ws = self._workspace(max(n, 1), dev, dense=False)
+            _lib.check(_lib.lib().mural_snv_forward_symbols(self._get_handle(), cat_ptr, symbols.data_ptr(), n, out.data_ptr(), ws.data_ptr(),
+                                                           ws.numel(), _lib.current_stream_ptr(dev)))
+        return out
+
+    def symbols_entry_ok(self):
+        return self.model_no != 0 and self._fused_ok()
+
     def forward_packed_reuse(self, genome, pos, strand, local_radius=None, local_order=3, min_density=0.0, batch_sites=1 << 20,
                              return_reuse_count=False):
         """``forward_packed`` with cross-position reuse (csrc/snv_reuse.hip): for site lists that are dense along a chromosome the

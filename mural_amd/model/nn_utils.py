@@ -84,6 +84,71 @@ def _gather_to_device(pending, k, device):
     return torch.cat(parts, dim=0).to(device)
 
 
+class _HostSymbolRoute:
+    """model_predict_m for a loader that yields HOST tensors (the reference's: nn_utils.py:52-56 copies y, cont_x, cat_x, distal_x to
+    the device batch by batch -- 32 KB of fp32 one-hot per site over PCIe).  The waiting batches' windows are classified into one
+    symbol byte per column by host threads (``mural_host_dense_to_symbols``, the host twin of the dense entry's first pass) straight
+    into one of two pinned staging buffers, 1 / 16 of the bytes cross PCIe, and the launch takes the symbols.  Columns that are no
+    MuRaL encoding raise ValueError at once (the dense entry reports them one call late)."""
+
+    _staging = {}          # (rows, L) -> pinned buffers: pinning 16 MB costs milliseconds, a predict loop is called per file
+
+    def __init__(self, model, device, fuse_rows):
+        self.model, self.device, self.L = model, device, model.seq_len
+        key = (fuse_rows, self.L)
+        self.bufs = self._staging.setdefault(key, [None, None])
+        self.small = self._staging.setdefault(("small",) + key, [None, None])
+        self.events, self.turn = [None, None], 0
+
+    @staticmethod
+    def model_ok(model, model_type, distal):
+        return model_type == "snv" and distal and getattr(model, "symbols_entry_ok", lambda: False)()
+
+    def gather(self, pending, rows):
+        """(symbols, cat_x, y) on the device for the waiting batches, or None if a batch is not what the reference's loader yields
+        (host fp32 (b, 4, L) windows, host int64 cat_x, host fp32 (b, 1) labels): the caller then takes the dense entry."""
+        import ctypes as C
+        from .. import _lib
+        L, f32, i64 = self.L, torch.float32, torch.int64
+        cols = pending[0][2].shape[1] if pending[0][2].dim() == 2 else -1
+        xp, xn, cp, cn, yp, yn = [], [], [], [], [], []
+        for y_b, _, c_b, x_b in pending:           # one pass: checks and addresses together (this loop is the route's host cost)
+            shp, n = x_b.shape, y_b.shape[0]
+            if (x_b.dtype is not f32 or len(shp) != 3 or shp[0] != n or shp[1] != 4 or shp[2] != L or x_b.is_cuda or not x_b.is_contiguous()
+                    or c_b.dtype is not i64 or c_b.shape != (n, cols) or c_b.is_cuda or not c_b.is_contiguous()
+                    or y_b.dtype is not f32 or y_b.shape != (n, 1) or y_b.is_cuda or not y_b.is_contiguous()):
+                return None
+            xp.append(x_b.data_ptr())
+            xn.append(n)
+            cp.append(c_b.data_ptr())
+            cn.append(n * 8 * cols)
+            yp.append(y_b.data_ptr())
+            yn.append(n * 4)
+        i = self.turn
+        self.turn ^= 1
+        if self.bufs[i] is None or self.bufs[i].numel() < rows * L:
+            self.bufs[i] = torch.empty(max(rows, 1) * L, dtype=torch.uint8).pin_memory()
+        need = rows * (8 * cols + 4)
+        if self.small[i] is None or self.small[i].numel() < need:
+            self.small[i] = torch.empty(need, dtype=torch.uint8).pin_memory()
+        if self.events[i] is not None:
+            self.events[i].synchronize()               # the copies out of these buffers two flushes ago
+        nb = len(pending)
+        lib, bad = _lib.lib(), C.c_int64(0)
+        sym_h, small = self.bufs[i], self.small[i]
+        _lib.check(lib.mural_host_dense_to_symbols((C.c_void_p * nb)(*xp), (C.c_int64 * nb)(*xn), nb, L, sym_h.data_ptr(), C.byref(bad)))
+        if bad.value:
+            raise ValueError(type(self.model)._ENC_MSG)
+        _lib.check(lib.mural_host_concat((C.c_void_p * nb)(*cp), (C.c_int64 * nb)(*cn), nb, small.data_ptr()))
+        _lib.check(lib.mural_host_concat((C.c_void_p * nb)(*yp), (C.c_int64 * nb)(*yn), nb, small.data_ptr() + rows * 8 * cols))
+        sym = sym_h[:rows * L].view(rows, L).to(self.device, non_blocking=True)
+        cat_x = small[:rows * 8 * cols].view(i64).view(rows, cols).to(self.device, non_blocking=True)
+        y = small[rows * 8 * cols:need].view(f32).view(rows, 1).to(self.device, non_blocking=True)
+        self.events[i] = torch.cuda.Event()
+        self.events[i].record()
+        return sym, cat_x, y
+
+
 def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, model_type="snv", fuse_rows=8192):
     """Run the model over an iterable of (y, cont_x, cat_x, distal_x) batches.
 
@@ -101,15 +166,28 @@ def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, 
     additive = getattr(criterion, "reduction", None) == "sum"
     pending, rows = [], 0
 
+    host_route, host_ok = None, _HostSymbolRoute.model_ok(model, model_type, distal)
+
     def flush():
-        nonlocal pending, rows
+        nonlocal pending, rows, host_route
         if not pending:
             return
-        y, cont_x, cat_x, distal_x = (_gather_to_device(pending, k, device) for k in range(4))
-        if model_type == "snv":
-            preds = model.forward((cont_x, cat_x), distal_x) if distal else model.forward(cont_x, cat_x)
+        staged = None
+        if host_ok and not pending[0][3].is_cuda:
+            if host_route is None:
+                host_route = _HostSymbolRoute(model, device, fuse_rows)
+            with torch.cuda.device(device):
+                staged = host_route.gather(pending, rows)
+        if staged is not None:
+            sym, cat_x, y = staged
+            with torch.cuda.device(device):
+                preds = model.forward_symbols(cat_x, sym)
         else:
-            preds = model.forward(distal_x)
+            y, cont_x, cat_x, distal_x = (_gather_to_device(pending, k, device) for k in range(4))
+            if model_type == "snv":
+                preds = model.forward((cont_x, cat_x), distal_x) if distal else model.forward(cont_x, cat_x)
+            else:
+                preds = model.forward(distal_x)
         outs.append(preds)
         target = y.long().squeeze(1)
         if additive or len(pending) == 1:

@@ -251,6 +251,28 @@ def test_model_predict_m_contract():
     assert pred.is_cuda and pred.shape == fx["pred"].shape
     assert_probs_close(pred.cpu().numpy(), fx["pred"], 2, "predict_m")
     assert abs(total - float(fx["total_loss"])) <= 1e-4 * abs(float(fx["total_loss"]))
+    # host batches took the host-classified symbol route (1 byte per column over PCIe); the same batches on the device take the dense
+    # entry: same rows bit for bit, same loss; small fuse_rows: several flushes through the two staging buffers
+    from mural_amd.model import nn_utils
+    assert nn_utils._HostSymbolRoute.model_ok(model, "snv", True)
+    taken = []
+    gather = nn_utils._HostSymbolRoute.gather
+    nn_utils._HostSymbolRoute.gather = lambda self, pending, rows: taken.append(rows) or gather(self, pending, rows)
+    try:
+        pred_h, _ = model_predict_m(model, batches, nn.CrossEntropyLoss(reduction="sum"), torch.device("cuda"), 4, True, "snv")
+    finally:
+        nn_utils._HostSymbolRoute.gather = gather
+    assert taken == [len(fx["pred"])] and torch.equal(pred_h, pred)
+    dev_batches = [tuple(t.cuda() for t in b) for b in batches]
+    pred_d, total_d = model_predict_m(model, dev_batches, nn.CrossEntropyLoss(reduction="sum"), torch.device("cuda"), 4, True, "snv")
+    assert torch.equal(pred, pred_d) and total == total_d
+    pred_s, total_s = model_predict_m(model, batches, nn.CrossEntropyLoss(reduction="sum"), torch.device("cuda"), 4, True, "snv", fuse_rows=3)
+    assert torch.equal(pred, pred_s) and abs(total - total_s) <= 1e-6 * abs(total)      # (float32 loss sums per flush)
+    # a column that is no encoding is refused at once on this route
+    bad = [tuple(t.clone() for t in b) for b in batches]
+    bad[1][3][0, 2, 5] = 0.7
+    with pytest.raises(ValueError, match="not a MuRaL"):
+        model_predict_m(model, bad, nn.CrossEntropyLoss(reduction="sum"), torch.device("cuda"), 4, True, "snv")
 
 
 def test_predict_bed_from_fasta_matches_oracle(tmp_path):

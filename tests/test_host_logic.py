@@ -254,3 +254,33 @@ def test_cross_entropy_sum_takes_torch_path_off_device_and_symbol_windows_are_ty
         model_snv._symbol_windows(Stub(), SymbolWindows(torch.zeros((3, 201), dtype=torch.float32)))
     with pytest.raises(ValueError):
         model_snv._symbol_windows(Stub(), SymbolWindows(torch.zeros((3, 301), dtype=torch.uint8)))
+
+
+def test_host_dense_to_symbols_matches_the_encoding_table():
+    """mural_host_dense_to_symbols (the host twin of the dense entry's first pass, used by model_predict_m for host loaders): every
+    MuRaL column pattern -> its symbol, anything else -> 255 and counted; batches of unequal size, windows across thread borders."""
+    import ctypes as C
+    import numpy as np
+    import torch
+    from mural_amd import _lib
+    from tests import _util as U
+    rng = np.random.default_rng(0)
+    L = 333
+    codes = rng.integers(0, 15, size=(700, L)).astype(np.uint8)
+    x = U.onehot(codes)
+    sizes = [1, 16, 300, 7, 376]
+    batches, o = [], 0
+    for n in sizes:
+        batches.append(x[o:o + n].contiguous())
+        o += n
+    ptrs = (C.c_void_p * len(batches))(*[b.data_ptr() for b in batches])
+    counts = (C.c_int64 * len(batches))(*sizes)
+    out = np.full((700, L), 77, np.uint8)
+    bad = C.c_int64(-1)
+    _lib.check(_lib.lib().mural_host_dense_to_symbols(ptrs, counts, len(batches), L, out.ctypes.data, C.byref(bad)))
+    assert bad.value == 0 and np.array_equal(out, codes)
+    batches[2][5, 1, 17] = 0.3                       # not a fraction of the encoding
+    batches[4][0, :, 0] = torch.tensor([1.0, 1.0, 0.0, 0.0])      # two ones: no symbol has that column
+    _lib.check(_lib.lib().mural_host_dense_to_symbols(ptrs, counts, len(batches), L, out.ctypes.data, C.byref(bad)))
+    assert bad.value == 2 and out[17 + 5, 17] == 255 and out[324, 0] == 255
+    assert (out != codes).sum() == 2
