@@ -132,7 +132,6 @@ PROTOTYPES = {
     "mural_op_convg_bn_bwd": (C.c_int, [VP, VP, VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP,
                                         C.c_size_t, VP, VP]),
     "mural_op_relayout_multi": (C.c_int, [VP, I32, I64, VP]),
-    "mural_debug_last_ws_layout": (C.c_int, [VP, I32]),
     "mural_op_act_fwd": (C.c_int, [VP, I64, I32, VP, VP]),
     "mural_op_act_bwd": (C.c_int, [VP, VP, I64, I32, VP, VP]),
     "mural_op_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP, VP, C.c_size_t, VP]),
@@ -156,23 +155,9 @@ PROTOTYPES = {
                                           VP, VP, C.c_size_t, VP, VP]),
     "mural_snv_train_backward": (C.c_int, [C.POINTER(MuralSnvShape), C.POINTER(MuralSnvParams), C.POINTER(MuralSnvParams), VP, VP, I64,
                                            VP, VP, VP, VP, C.c_size_t, VP]),
-    "mural_debug_cl_conv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP]),
-    "mural_debug_cl_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, I32, VP, VP, VP, VP, VP]),
-    "mural_debug_cw_wfrag": (C.c_int, [VP, VP, VP]),
-    "mural_debug_cw_set_stamps": (C.c_int, [VP]),
-    "mural_debug_first_set_stamps": (C.c_int, [VP]),
-    "mural_debug_lt_set_stamps": (C.c_int, [VP]),
-    "mural_debug_cw_conv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP, VP]),
-    "mural_debug_cw_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP]),
-    "mural_debug_cl_bn_stats": (C.c_int, [VP, I64, I32, VP, VP]),
-    "mural_debug_conv1d": (C.c_int, [VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP, I32, VP]),
-    "mural_debug_conv1d_set_stamps": (C.c_int, [VP]),
     "mural_op_ce_sum_fwd": (C.c_int, [VP, VP, I64, I32, VP, VP, VP]),
     "mural_op_ce_sum_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP]),
     "mural_op_clip_grad_norm": (C.c_int, [VP, I64, C.c_float, VP, VP, VP]),
-    "mural_debug_poison_lds": (C.c_int, [VP]),
-    "mural_debug_convblock": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, I64, I32, I32, VP, VP, VP, I32, I32, VP, VP, VP, VP, VP, VP, I32, VP]),
-    "mural_debug_cb8_set_stamps": (C.c_int, [VP]),
     "mural_last_error": (C.c_char_p, []),
     "mural_abi_version": (C.c_int, []),
     "mural_encode_kmer": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
@@ -211,24 +196,55 @@ PROTOTYPES = {
     "mural_indel_train_backward": (C.c_int, [C.POINTER(MuralIndelShape), C.POINTER(MuralIndelParams), C.POINTER(MuralIndelParams), VP, VP,
                                              I64, C.c_float, C.c_uint64, VP, VP, C.c_size_t, VP]),
     "mural_snv_kernel_name": (C.c_char_p, []),
-    "mural_debug_set_stamps": (C.c_int, [C.c_void_p]),
     "mural_profile_begin": (C.c_int, []),
     "mural_profile_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
 }
 
+# the validation hooks / diagnostics of include/mural_hip_debug.h: exported by the debug flavour only (libmural_hip_debug.so)
+DEBUG_PROTOTYPES = {
+    "mural_debug_last_ws_layout": (C.c_int, [VP, I32]),
+    "mural_debug_cl_conv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP]),
+    "mural_debug_cl_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, I32, VP, VP, VP, VP, VP]),
+    "mural_debug_cw_wfrag": (C.c_int, [VP, VP, VP]),
+    "mural_debug_cw_set_stamps": (C.c_int, [VP]),
+    "mural_debug_first_set_stamps": (C.c_int, [VP]),
+    "mural_debug_lt_set_stamps": (C.c_int, [VP]),
+    "mural_debug_cw_conv32_fwd": (C.c_int, [VP, I64, I32, I32, VP, VP, VP, VP, VP, VP, VP, VP, I32, VP, VP, VP, I32, VP, VP, VP]),
+    "mural_debug_cw_conv32_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP, I32, VP, VP, VP, VP, VP, VP]),
+    "mural_debug_cl_bn_stats": (C.c_int, [VP, I64, I32, VP, VP]),
+    "mural_debug_conv1d": (C.c_int, [VP, VP, VP, VP, I64, I32, I32, I32, I32, I32, I32, I32, I32, VP, VP, I32, VP]),
+    "mural_debug_conv1d_set_stamps": (C.c_int, [VP]),
+    "mural_debug_poison_lds": (C.c_int, [VP]),
+    "mural_debug_convblock": (C.c_int, [VP, VP, VP, VP, VP, VP, VP, I64, I32, I32, VP, VP, VP, I32, I32, VP, VP, VP, VP, VP, VP, I32, VP]),
+    "mural_debug_cb8_set_stamps": (C.c_int, [VP]),
+    "mural_debug_set_stamps": (C.c_int, [C.c_void_p]),
+    "mural_debug_list_switches": (C.c_int, [C.c_char_p, C.c_size_t]),
+}
+
 _lib = None
+DEBUG_LIB_PATH = os.path.join(_HERE, "libmural_hip_debug.so")
+
+
+def flavor():
+    """'debug' when MURAL_HIP_FLAVOR=debug is in the environment at the first call of lib(): the library with the validation hooks of
+    include/mural_hip_debug.h, the only one that honours the development switches (csrc/common.h: dev_env).  tests/conftest.py and the
+    tools set it; bench.py, __graft_entry__.smoke() and every user of the package run the product library."""
+    return "debug" if os.environ.get("MURAL_HIP_FLAVOR", "") == "debug" else "product"
 
 
 def lib():
     """Load (once) and return the shared library with typed prototypes; raises if it is not built."""
     global _lib
     if _lib is None:
-        if not os.path.exists(LIB_PATH):
+        debug = flavor() == "debug"
+        path = DEBUG_LIB_PATH if debug else LIB_PATH
+        if not os.path.exists(path):
             raise RuntimeError(
-                f"{LIB_PATH} is missing: the HIP extension has not been built. "
+                f"{path} is missing: the HIP extension has not been built. "
                 "Run `make -C mural_amd/csrc` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback.")
-        handle = C.CDLL(LIB_PATH)
-        for name, (res, args) in PROTOTYPES.items():
+        handle = C.CDLL(path)
+        protos = dict(PROTOTYPES, **DEBUG_PROTOTYPES) if debug else PROTOTYPES
+        for name, (res, args) in protos.items():
             fn = getattr(handle, name)
             fn.restype = res
             fn.argtypes = args

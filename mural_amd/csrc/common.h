@@ -13,6 +13,17 @@
 
 namespace mural {
 
+// ---- environment switches --------------------------------------------------------------------------------------------------------
+// The PRODUCT library (libmural_hip.so) reads two variables: MURAL_HOST_THREADS (host threads of the ingest passes, csrc/ingest.hip)
+// and TMPDIR (inflated copies of gzip inputs).  Every other switch is a development switch -- an A/B of two kernels, a validation
+// path, a diagnostic, or a timing experiment that produces WRONG results -- listed in ONE table (encode.hip: dev_switch_table) and
+// read through dev_env(), which answers "not set" unless the debug flavour is loaded (libmural_hip_debug.so: csrc/debug_hooks.hip sets
+// g_dev_switches).  A stray MURAL_* variable cannot change what the product library computes.
+struct DevSwitch { const char* name; const char* what; };
+const DevSwitch* dev_switch_table();      // terminated by {nullptr, nullptr}
+extern bool g_dev_switches;
+const char* dev_env(const char* name);    // getenv(name) in the debug flavour (the name must be in the table), nullptr otherwise
+
 void set_error(const char* fmt, ...);
 // Validation of the workspace carvers (tests only): MURAL_DEBUG_WS_GUARD=<bytes> in the environment puts that many unused bytes behind
 // every region a carver hands out, and the regions of the calling thread's latest carve are kept for mural_debug_last_ws_layout, so

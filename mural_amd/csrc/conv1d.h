@@ -109,9 +109,6 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream);
 bool convblock_mfma_supported(const ConvBlockArgs& a);
 int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream);
 
-// fp32-MFMA version of the 8-channel blocks WITH a front (first encoder level / last decoder level, convblock8_mfma.hip)
-bool convblock8_mfma_supported(const ConvBlockArgs& a);
-int launch_convblock8_mfma(const ConvBlockArgs& a, hipStream_t stream);
 
 // the first encoder level from the packed genome as one persistent launch with a composed, table-driven front (indel_level0.hip)
 void indel_enc0_compose(const float* fw, const float* fb, const float* symtab, const float* sym_bias, int st, std::vector<float>* t3,

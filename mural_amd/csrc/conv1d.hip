@@ -233,7 +233,7 @@ static Conv1dFn pick_kernel(int K, int cog) {
 int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   if (a.B == 0 || a.Lout == 0) return MURAL_OK;
   MURAL_REQUIRE(a.up >= 1 && a.stride >= 1 && a.K >= 1, "conv1d: bad geometry");
-  static const bool use_mfma = !(getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 0);   // A/B switch of the tools
+  static const bool use_mfma = !(dev_env("MURAL_CONV1D_MFMA") && atoi(dev_env("MURAL_CONV1D_MFMA")) == 0);   // A/B switch of the tools
   // measured at 2048 rows (tools/gpu_debug_conv1d.py): the implicit GEMM wins on short rows (<= 128 columns: 2-4 x) and on long
   // rows with a deep reduction (Cin * K >= 224 then; >= 160 since the MFMA kernel stopped waiting per element: 24 -> 32 k7 at 400 columns
   // 144 -> 66 us); long rows with few input channels are bound by the output stream and the direct
@@ -242,12 +242,12 @@ int launch_conv1d(const Conv1dArgs& a, hipStream_t stream) {
   // the upsampling convs with a medium reduction (measured on the training step, tools/r4_step_classes.py: 74 -> 22, 30 -> 17, 55 -> 42 us).
   // long rows, few channels, several taps at stride 1: the barrier-free kernel (neither tiled kernel covers its stage / compute /
   // store phases on these; measured on the training step: 35-53 us -> see DESIGN.md)
-  static const bool use_direct = !(getenv("MURAL_CONV1D_DIRECT") && atoi(getenv("MURAL_CONV1D_DIRECT")) == 0);
+  static const bool use_direct = !(dev_env("MURAL_CONV1D_DIRECT") && atoi(dev_env("MURAL_CONV1D_DIRECT")) == 0);
   // (measured at 2048 rows too, tools/gpu_debug_conv1d.py: 16 -> 20 k7 at 517 columns 258 / 188 / 159 us valu / mfma / direct, 4 -> 32 k7
   // at 600 columns 83 / 114 / 50; three taps fill 3 of its 8 tap slots and lose to the vector ALU)
   if (use_direct && use_mfma && a.K >= 5 && (int64_t)a.B * a.Lout >= 32768 && a.Lout >= 64 && conv1d_direct_supported(a))
     return launch_conv1d_direct(a, stream);
-  static const bool all_mfma = getenv("MURAL_CONV1D_MFMA") && atoi(getenv("MURAL_CONV1D_MFMA")) == 2;
+  static const bool all_mfma = dev_env("MURAL_CONV1D_MFMA") && atoi(dev_env("MURAL_CONV1D_MFMA")) == 2;
   const bool small_launch = (int64_t)a.B * a.Lout <= 128 * 512 && a.Lout <= 512;
   if (use_mfma && conv1d_mfma_supported(a) &&
       (all_mfma || a.Lout <= 128 || a.Cin * a.K >= 160 || small_launch || (a.up > 1 && a.Cin * a.K >= 128 && (int64_t)a.B * a.Lout <= 128 * 2048) ||
@@ -305,7 +305,7 @@ __host__ __device__ inline int convblock_front_floats(int Cf, int f_up, bool fro
 
 // MF (8 channels): everything behind the front -- the k=5 conv 8 -> 16, the 1x1 conv 16 -> 8 and the tail's two 1x1 convs -- runs on
 // v_mfma_f32_16x16x4_f32 while front, SiLU and the adds stay on the vector ALU.  fp32 MFMA and v_pk_fma_f32 have the SAME peak rate,
-// so moving the whole block to the matrix pipe gains nothing (convblock8_mfma.hip: slower); splitting it does: a SIMD's eight waves
+// so moving the whole block to the matrix pipe gains nothing (tried in round 3: slower, removed in round 6); splitting it does: a SIMD's eight waves
 // are in different phases, the two pipes work side by side, and each carries about half of what the vector ALU alone carried.
 //   k=5 conv  D[16 hidden][16 positions] += W5[hidden][(tap, ci)] x[ci][pos + tap - 2], 10 k-steps, four position blocks per wave
 //             (four independent accumulators); the B operand is one ds_read_b32 per MFMA at an immediate offset.
@@ -874,7 +874,7 @@ bool convblock_supported(int C) { return C == 8 || C == 16 || C == 24; }   // LD
 int convblock_tiles(int L, bool front) { return front ? (L + CB_FRONT_OUT_POLY - 1) / CB_FRONT_OUT_POLY : (L + 255) / 256; }
 
 static bool convblock8_valu_form() {
-  static const bool valu8_env = getenv("MURAL_CONVBLOCK8_VALU") != nullptr && getenv("MURAL_CONVBLOCK8_VALU")[0] == '1';
+  static const bool valu8_env = dev_env("MURAL_CONVBLOCK8_VALU") != nullptr && dev_env("MURAL_CONVBLOCK8_VALU")[0] == '1';
   return g_convblock8_form >= 0 ? g_convblock8_form == 0 : valu8_env;
 }
 static bool convblock_poly_mfma(const ConvBlockArgs& a) {
@@ -884,11 +884,11 @@ static bool convblock_poly_mfma(const ConvBlockArgs& a) {
 int convblock_tiles_of(const ConvBlockArgs& a) {
   const bool front = a.f_in != nullptr || a.symtab != nullptr;
   if (!front) return (a.L + 255) / 256;
-  if (!convblock_mfma_supported(a) && !convblock8_mfma_supported(a) && convblock_poly_mfma(a)) return (a.L + CB_FRONT_OUT_POLY - 1) / CB_FRONT_OUT_POLY;
+  if (!convblock_mfma_supported(a) && convblock_poly_mfma(a)) return (a.L + CB_FRONT_OUT_POLY - 1) / CB_FRONT_OUT_POLY;
   return (a.L + CB_FRONT_OUT - 1) / CB_FRONT_OUT;
 }
 
-extern unsigned long long* g_cb8_stamps;      // (convblock8_mfma.hip)      // validation hook (mural_debug_convblock): 0 vector-ALU form, 1 split form, -1 the environment's choice
+unsigned long long* g_cb8_stamps = nullptr;      // diagnostic (debug flavour: mural_debug_cb8_set_stamps): per-workgroup phase sums of the level-0 blocks      // validation hook (mural_debug_convblock): 0 vector-ALU form, 1 split form, -1 the environment's choice
 
 template <bool TAIL, bool FRONT>
 static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
@@ -896,7 +896,7 @@ static void launch_convblock_t(const ConvBlockArgs& a, hipStream_t stream) {
   // diagnostic (tools/phase_stamps_indel_l0.py): MURAL_DEBUG_CB_STAMP_ONLY = enc | dec stamps only the genome-fed / the tail launch
   unsigned long long* stamps = g_cb8_stamps;
   if (stamps)
-    if (const char* only = getenv("MURAL_DEBUG_CB_STAMP_ONLY"))
+    if (const char* only = dev_env("MURAL_DEBUG_CB_STAMP_ONLY"))
       if ((only[0] == 'e') != (a.symtab != nullptr) || (only[0] == 'd') != (a.tail_max != nullptr)) stamps = nullptr;
 #define MURAL_CB(CN)                                                                                                        \
   hipLaunchKernelGGL((convblock_kernel<CN, TAIL, FRONT, MFV>), grid, dim3(256), MFV ? mf_lds : 0, stream, a, a.w5, a.b5, a.w1, a.b1, a.ta_w, a.ta_b, \
@@ -935,7 +935,6 @@ int launch_convblock(const ConvBlockArgs& a, hipStream_t stream) {
   }
   if (a.tail_max) MURAL_REQUIRE(a.ta_w && a.ta_b && a.tb_w && a.tb_b, "convblock: tail weights missing");
   if (convblock_mfma_supported(a)) return launch_convblock_mfma(a, stream);
-  if (convblock8_mfma_supported(a)) return launch_convblock8_mfma(a, stream);
   if (indel_enc0_supported(a)) return launch_indel_enc0(a, stream);
   if (convblock_poly_mfma(a) && indel_dec0_supported(a)) return launch_indel_dec0(a, stream);
   const bool front = a.f_in != nullptr || a.symtab != nullptr;

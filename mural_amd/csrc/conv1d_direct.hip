@@ -489,7 +489,7 @@ int launch_conv1d_direct_poly(const Conv1dArgs& a, hipStream_t stream) {
   g.x_bytes = (uint32_t)((uint64_t)a.B * a.Cin * a.Lin * 4);
   g.y_bytes = (uint32_t)((uint64_t)a.B * a.Cout * a.Lout * 4);
   g.dPh = FastDiv::make((uint32_t)a.phases);
-  g.wide = (mb == 5 && g.rows == 80 && a.phases == 5 && (a.Lout & 3) == 0 && a.act == ACT_NONE && !getenv("MURAL_DEBUG_POLY_NARROW")) ? 1 : 0;
+  g.wide = (mb == 5 && g.rows == 80 && a.phases == 5 && (a.Lout & 3) == 0 && a.act == ACT_NONE && !dev_env("MURAL_DEBUG_POLY_NARROW")) ? 1 : 0;
   const int U = 1;
   // interior segments: the first quad starts inside the row (p0 >= pad), the last one ends inside it (p0 + 15 - pad + 3 < Lin)
   const int e0 = (a.pad + 15) / 16;
@@ -561,7 +561,7 @@ int launch_conv1d_direct(const Conv1dArgs& a, hipStream_t stream) {
                            : reinterpret_cast<const void*>(conv1d_direct_kernel<MB_, CP_, U_, false, NB_>);         \
       cap = resident_workgroups(fn, 256);                                                                           \
     }                                                                                                               \
-    if (getenv("MURAL_DIRECT_GRID_CAP") == nullptr || atoi(getenv("MURAL_DIRECT_GRID_CAP")) != 0) wgs = std::min(wgs, cap); \
+    if (dev_env("MURAL_DIRECT_GRID_CAP") == nullptr || atoi(dev_env("MURAL_DIRECT_GRID_CAP")) != 0) wgs = std::min(wgs, cap); \
     if (res) hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, true, NB_>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);  \
     else hipLaunchKernelGGL((conv1d_direct_kernel<MB_, CP_, U_, false, NB_>), dim3(wgs), dim3(256), 0, stream, g, a.wt, a.bias);     \
   } while (0)

@@ -665,7 +665,7 @@ __global__ __launch_bounds__(256) void gmax_relu_bwd_cl_kernel(const GmaxBwdArgs
 
 // phase-ablation switches of the timing tools (tools/time_conv32_cl.py), read once
 int debug_phases() {
-  static const int v = getenv("MURAL_DEBUG_CL") ? atoi(getenv("MURAL_DEBUG_CL")) : 0;
+  static const int v = dev_env("MURAL_DEBUG_CL") ? atoi(dev_env("MURAL_DEBUG_CL")) : 0;
   return v;
 }
 
@@ -860,24 +860,3 @@ int cl_gmax_relu_bwd(const float* dfeat, const int32_t* arg, const float* c3, in
 }
 
 }  // namespace mural
-
-// ---- validation hooks (tests/test_gpu_train.py, tools/gpu_debug_conv32_cl.py): the channel-last conv kernels on their own -----
-extern "C" int mural_debug_cl_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
-                                         const float* beta, float* running_mean, float* running_var, float* state, const float* W,
-                                         const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,
-                                         int32_t out_relu, float* y, void* stream) {
-  return mural::cl_conv32_fwd(x, B, L, pre_relu, acc, gamma, beta, 1e-5f, 0.1f, running_mean, running_var, state, W, bias, post_relu, res1, res2,
-                              acc_out, out_relu, y, (hipStream_t)stream);
-}
-
-extern "C" int mural_debug_cl_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* state,
-                                         int32_t pre_relu, float* dz, double* stat_out, float* part, int32_t* nrow, void* stream) {
-  int n = 0;
-  const int rc = mural::cl_conv32_bwd(dy, x, W, B, L, state, pre_relu, dz, stat_out, part, &n, (hipStream_t)stream);
-  if (nrow) *nrow = n;
-  return rc;
-}
-
-extern "C" int mural_debug_cl_bn_stats(const float* x, int64_t rows, int32_t relu, double* acc, void* stream) {
-  return mural::cl_bn_stats(x, rows, relu, acc, (hipStream_t)stream);
-}

@@ -770,7 +770,7 @@ static bool tile_geometry(int B, int L, int* R, int* Sc, int* NC, int* nb) {
   // the fp32 partial sums of the fused BatchNorm statistics: results differ in the last bits, nothing else.)
   const int balanced = (B + 1023) / 1024;
   if (B >= 1024 && r > balanced) r = balanced;
-  if (const char* e = getenv("MURAL_DEBUG_CONV32_R")) {   // debugging aid (tools/gpu_debug_train_diff.py)
+  if (const char* e = dev_env("MURAL_DEBUG_CONV32_R")) {   // debugging aid (tools/gpu_debug_train_diff.py)
     const int v = atoi(e);
     if (v >= 1 && v <= r) r = v;
   }
@@ -816,7 +816,7 @@ int train_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B,
   a.dy = dy; a.x = x; a.W = W; a.pre_s = state; a.pre_t = state + C32; a.pre_relu = pre_relu; a.mean = state + 2 * C32;
   a.invstd = state + 3 * C32;
   a.B = (int)B; a.L = L; a.part = part; a.dz = dz; a.stat_out = stat_out;
-  if (const char* e = getenv("MURAL_DEBUG_BWD32")) a.dbg = atoi(e);
+  if (const char* e = dev_env("MURAL_DEBUG_BWD32")) a.dbg = atoi(e);
   a.dL = FastDiv::make((uint32_t)L);
   a.dSc = FastDiv::make((uint32_t)a.Sc);
   const int64_t ntiles = (B + a.R - 1) / a.R;
@@ -840,7 +840,7 @@ int train_reduce_parts(const float* const* part, const int* nrow, float* const* 
     // validation only (tests/test_gpu_train.py): MURAL_DEBUG_DROP_PART_ROW=<job> leaves the last partial row of that job out of
     // its sum -- the fault the parity tests of the training step must be able to see
     int drop_job = -1;
-    if (const char* e = getenv("MURAL_DEBUG_DROP_PART_ROW")) drop_job = atoi(e);
+    if (const char* e = dev_env("MURAL_DEBUG_DROP_PART_ROW")) drop_job = atoi(e);
     for (int j = 0; j < n; ++j) {
       jobs.part[j] = part[j0 + j];
       jobs.nrow[j] = nrow[j0 + j] - ((j0 + j == drop_job && nrow[j0 + j] > 1) ? 1 : 0);
@@ -932,7 +932,7 @@ extern "C" int mural_op_conv32_bwd(const float* dy, const float* x, const float*
   MURAL_REQUIRE(dy && x && W && mean && invstd && dW && db && dz && stat_out, "conv32_bwd: NULL argument");
   a.dy = dy; a.x = x; a.W = W; a.pre_s = pre_s; a.pre_t = pre_t; a.pre_relu = pre_relu; a.mean = mean; a.invstd = invstd;
   a.B = (int)B; a.L = L; a.part = part; a.dz = dz; a.stat_out = stat_out;
-  if (const char* e = getenv("MURAL_DEBUG_BWD32")) a.dbg = atoi(e);
+  if (const char* e = dev_env("MURAL_DEBUG_BWD32")) a.dbg = atoi(e);
   a.dL = FastDiv::make((uint32_t)L);
   a.dSc = FastDiv::make((uint32_t)a.Sc);
   const int64_t ntiles = (B + a.R - 1) / a.R;

@@ -68,7 +68,7 @@ struct CwGeom {
 // 4096).  Same-box A/B of the whole step, batch 4096: 498 -> 528 steps/s (tools/r6_train_slots.sh; MURAL_CW_FULL_GRID=1 is the old
 // rule).  The choice changes the order of the float sums, not their reproducibility.
 int cw_slots(int L) {
-  static const bool full = getenv("MURAL_CW_FULL_GRID") && atoi(getenv("MURAL_CW_FULL_GRID")) != 0;
+  static const bool full = dev_env("MURAL_CW_FULL_GRID") && atoi(dev_env("MURAL_CW_FULL_GRID")) != 0;
   const int pmax = (16 * CW_NBMAX - 1) / (L + 1);
   return (full || pmax < 2) ? 2 * CW_CUS : CW_CUS;
 }
@@ -815,7 +815,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
 }
 
 int cw_debug() {
-  static const int v = getenv("MURAL_DEBUG_CW") ? atoi(getenv("MURAL_DEBUG_CW")) : 0;
+  static const int v = dev_env("MURAL_DEBUG_CW") ? atoi(dev_env("MURAL_DEBUG_CW")) : 0;
   return v;
 }
 
@@ -963,34 +963,3 @@ int cw_conv32_bwd(const float* dy, const float* x, const float* W, const float* 
 }
 
 }  // namespace mural
-
-// ---- validation hooks (tests/test_gpu_train.py, tools/gpu_debug_conv32_cl.py): the wave-private conv kernels on their own -----
-extern "C" int mural_debug_cw_conv32_fwd(const float* x, int64_t B, int32_t L, int32_t pre_relu, const double* acc, const float* gamma,
-                                         const float* beta, float* running_mean, float* running_var, float* state, const float* W,
-                                         const float* bias, int32_t post_relu, const float* res1, const float* res2, double* acc_out,
-                                         int32_t out_relu, float* y, float* wfrag_scratch, void* stream) {
-  // wfrag_scratch != NULL: the 6144 floats mural_debug_cw_wfrag wrote for W (the path of the composed step), NULL: the conv gathers
-  // the fragments from a copy of W in LDS
-  return mural::cw_conv32_fwd(x, B, L, pre_relu, acc, gamma, beta, 1e-5f, 0.1f, running_mean, running_var, state, W, wfrag_scratch, bias, post_relu,
-                              res1, res2, acc_out, out_relu, y, (hipStream_t)stream);
-}
-
-extern "C" int mural_debug_cw_conv32_bwd(const float* dy, const float* x, const float* W, int64_t B, int32_t L, const float* state,
-                                         const float* gamma, int32_t pre_relu, float* dz, double* stat_out, float* part, int32_t* nrow,
-                                         float* wfrag_scratch, void* stream) {
-  int n = 0;
-  const int rc = mural::cw_conv32_bwd(dy, x, W, wfrag_scratch ? wfrag_scratch + 3072 : nullptr, B, L, state, gamma, pre_relu, dz, stat_out, part, &n,
-                                      (hipStream_t)stream);
-  if (nrow) *nrow = n;
-  return rc;
-}
-
-extern "C" int mural_debug_cw_wfrag(const float* W, float* out6144, void* stream) {
-  return mural::cw_wfrag_build(&W, 1, out6144, (hipStream_t)stream);
-}
-
-// diagnostic: per-workgroup wall-clock stamps of the forward kernel's phases (tools/phase_stamps_cw.py); NULL switches them off
-extern "C" int mural_debug_cw_set_stamps(void* dev_ptr) {
-  mural::g_cw_stamps = static_cast<unsigned long long*>(dev_ptr);
-  return MURAL_OK;
-}

@@ -375,11 +375,11 @@ bool tiny_geometry(int C, int L) { return (C == 40 && L == 16) || (C == 48 && L 
 }  // namespace
 
 bool convblock_deep_supported(const ConvBlockArgs& a) {
-  const bool off = getenv("MURAL_INDEL_DEEP") && atoi(getenv("MURAL_INDEL_DEEP")) == 0;
+  const bool off = dev_env("MURAL_INDEL_DEEP") && atoi(dev_env("MURAL_INDEL_DEEP")) == 0;
   const bool geo = (a.C == DB_C && a.L >= 1 && a.L <= 16 * DB_NB) || tiny_geometry(a.C, a.L);
   bool input = a.x != nullptr && a.f_in == nullptr;
   if (a.f_in != nullptr && a.C == DB_C) {      // the strided k = 7 front (convblock_deep32_kernel<., true>)
-    const bool foff = getenv("MURAL_INDEL_DEEP_FRONT") && atoi(getenv("MURAL_INDEL_DEEP_FRONT")) == 0;
+    const bool foff = dev_env("MURAL_INDEL_DEEP_FRONT") && atoi(dev_env("MURAL_INDEL_DEEP_FRONT")) == 0;
     input = !foff && a.f_w && a.f_b && a.f_up == 1 && a.f_pw == nullptr && a.f_stride >= 1 && a.f_stride <= 8 && a.Cf >= 4 && a.Cf <= DB_FC &&
             (a.Cf & 3) == 0 && (a.Lf & 3) == 0 && a.Lf + 6 <= DB_PF && a.Cf * a.Lf <= 4 * 256 * DB_FQ && (a.Lf - 1) / a.f_stride + 1 == a.L &&
             a.f_stride * (16 * ((a.L + 15) / 16) - 1) + 6 < DB_PF;

@@ -459,12 +459,12 @@ static int launch_convblock_direct_t(const ConvBlockArgs& a, hipStream_t stream)
 }  // namespace
 
 bool convblock_mfma_supported(const ConvBlockArgs& a) {
-  return (a.C == 16 || a.C == 24) && !a.f_in && !a.symtab && !a.tail_max && !getenv("MURAL_DEBUG_CONVBLOCK_VALU");
+  return (a.C == 16 || a.C == 24) && !a.f_in && !a.symtab && !a.tail_max && !dev_env("MURAL_DEBUG_CONVBLOCK_VALU");
 }
 
 int launch_convblock_mfma(const ConvBlockArgs& a, hipStream_t stream) {
   // MURAL_CONVBLOCK_DIRECT=0: the LDS-tiled form; 2: the barrier-free form whatever the size (A/B switch, validation)
-  static const int direct_mode = getenv("MURAL_CONVBLOCK_DIRECT") ? atoi(getenv("MURAL_CONVBLOCK_DIRECT")) : 1;      // 2: whatever the size
+  static const int direct_mode = dev_env("MURAL_CONVBLOCK_DIRECT") ? atoi(dev_env("MURAL_CONVBLOCK_DIRECT")) : 1;      // 2: whatever the size
   if (direct_mode != 0 && (uint64_t)a.B * a.C * a.L * 4 < (1ull << 31) && (direct_mode == 2 || (a.L >= 64 && (int64_t)a.B * a.L >= 32768)))
     return a.C == 16 ? launch_convblock_direct_t<16>(a, stream) : launch_convblock_direct_t<24>(a, stream);
   const int64_t tiles = (int64_t)a.B * ((a.L + 255) / 256);

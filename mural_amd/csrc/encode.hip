@@ -1,5 +1,7 @@
 // Window encoders on the GPU: k-mer index, one-hot, and dense-tensor -> symbol classification.
 // Reference semantics: MuRaL/data/preprocessing.py:636-723 (k-mer), :756-816 (one-hot), :559-567 (windows).
+#include <cstring>
+#include <cstdlib>
 #include "common.h"
 #include "dense_symbol.h"
 
@@ -18,10 +20,84 @@ void set_error(const char* fmt, ...) {
 
 const char* last_error_cstr() { return g_err.c_str(); }
 
-static thread_local std::vector<size_t> g_ws_layout;
+bool g_dev_switches = false;
+
+const DevSwitch* dev_switch_table() {
+  static const DevSwitch table[] = {
+    {"MURAL_TOWER_DYNAMIC_UNITS", "A/B, bit-identical: SNV predict units through a global ticket counter instead of the fixed stride"},
+    {"MURAL_SNV_DEFER_SHORT", "A/B, bit-identical: =0 runs the short-stage launches per chunk (what a one-chunk workspace does by itself)"},
+    {"MURAL_LOCAL_REG", "A/B, bit-identical: =0 keeps the local MLP's weight fragments in LDS (snv_local_mlp_mfma)"},
+    {"MURAL_CW_FULL_GRID", "A/B, same sums in another order: training conv launches ask for two workgroup slots per CU whatever the row length"},
+    {"MURAL_TRAIN_CONV_CL", "A/B: the training step on the workgroup-tile conv kernels (conv32_cl.hip) instead of the wave-private ones"},
+    {"MURAL_TRAIN_NO_FOLD", "A/B: BatchNorm-backward applies of a ResBlock stage as passes of their own"},
+    {"MURAL_TRAIN_NO_FIRST_FOLD", "A/B: the first stage's last BatchNorm-backward apply as a pass of its own"},
+    {"MURAL_TRAIN_NO_MID_FOLD", "A/B: the short stage's last apply as a pass of its own"},
+    {"MURAL_TRAIN_NO_POOL_FOLD", "A/B: the applies in front of the pools as passes of their own"},
+    {"MURAL_TRAIN_LOCAL_OPS", "A/B: the local branch of the training step as per-op launches"},
+    {"MURAL_TRAIN_HEAD_OPS", "A/B: a tower's head of the training step as per-op launches"},
+    {"MURAL_TRAIN_FIRST_SEPARATE", "A/B: symbol histograms / first-layer tables per tower"},
+    {"MURAL_TRAIN_ORDER", "experiment: 1 enqueues the local branch first"},
+    {"MURAL_XCD_SWIZZLE", "A/B, bit-identical: =0 disables the XCD-aware workgroup index of the barrier-free INDEL kernels"},
+    {"MURAL_CONV1D_MFMA", "A/B: =0 keeps the generic conv on the vector ALU, =2 routes every conv to the MFMA kernel"},
+    {"MURAL_CONV1D_DIRECT", "A/B: =0 disables the barrier-free long-row conv"},
+    {"MURAL_CONVBLOCK_DIRECT", "A/B: 0 / 2 never / always the barrier-free ConvBlock"},
+    {"MURAL_CONVBLOCK8_VALU", "A/B: the 8-channel ConvBlock entirely on the vector ALU"},
+    {"MURAL_INDEL_ENC0", "A/B: =0 disables the persistent level-0 encoder launch"},
+    {"MURAL_INDEL_ENC0_DOWN", "A/B: =0 keeps the stride-4 down-conv a launch of its own"},
+    {"MURAL_INDEL_DEC0", "A/B: =0 disables the persistent level-0 decoder launch"},
+    {"MURAL_INDEL_DEEP", "A/B: =0 runs the deep levels' blocks as two launches each"},
+    {"MURAL_INDEL_DEEP_FRONT", "A/B: =0 keeps the fourth level's strided conv a launch of its own"},
+    {"MURAL_INDEL_DENSE_SYMBOLS", "A/B: =0 keeps the dense INDEL entry on the three-launch route"},
+    {"MURAL_INDEL_ENC0_WGS", "experiment: workgroups per CU of the level-0 encoder launch"},
+    {"MURAL_INDEL_DEC0_WGS", "experiment: workgroups per CU of the level-0 decoder launch"},
+    {"MURAL_DIRECT_GRID_CAP", "experiment: =0 lifts the grid cap of the barrier-free convs"},
+    {"MURAL_WGRAD_MFMA", "A/B: =0 keeps the INDEL weight gradients on the LDS-tiled vector kernel"},
+    {"MURAL_SNV_CHUNK", "experiment: sites per launch sequence of the SNV predict path"},
+    {"MURAL_DEBUG_WS_GUARD", "validation: unused bytes behind every workspace region (tests poison and check them)"},
+    {"MURAL_DEBUG_DROP_PART_ROW", "validation (fault injection): drop one partial row of a conv weight gradient"},
+    {"MURAL_DEBUG_NO_SMALL_BATCH", "validation: calls of <= 256 sites through the throughput launches"},
+    {"MURAL_DEBUG_NO_LONGWIN", "validation: long windows through the per-layer path"},
+    {"MURAL_DEBUG_NO_TOWER_SPLIT", "validation: the towers as one launch per chunk"},
+    {"MURAL_DEBUG_NO_PAIR_TABLE", "validation: first layer without the pair table"},
+    {"MURAL_DEBUG_NO_LOCAL_FUSE", "validation: the local MLP never rides in the first-stage launch"},
+    {"MURAL_DEBUG_LOCAL_VALU", "validation: the local MLP on the vector ALU"},
+    {"MURAL_DEBUG_CONVBLOCK_VALU", "validation: every ConvBlock on the vector-ALU kernel"},
+    {"MURAL_DEBUG_INDEL_NO_GENOME_FRONT", "validation: the packed INDEL entry through an explicit one-hot tensor"},
+    {"MURAL_DEBUG_TOWER_RUNTIME_GEOM", "validation, bit-identical: the first-stage tower instance that reads its geometry from the arguments"},
+    {"MURAL_DEBUG_TOWER_STATIC_UNITS", "validation: overrides MURAL_TOWER_DYNAMIC_UNITS"},
+    {"MURAL_DEBUG_EDGE_TILE", "validation: the reuse path's edge columns on the workgroup-tile kernel"},
+    {"MURAL_DEBUG_POLY_NARROW", "validation: the polyphase up-conv's dword stores"},
+    {"MURAL_DEBUG_FIRST_SCATTER", "validation: the first layer's backward through LDS atomics"},
+    {"MURAL_DEBUG_CONV32_R", "validation: forces the row tile of the tiled conv32 kernels"},
+    {"MURAL_DEBUG_S1_ALIAS", "TIMING ONLY, wrong results: every site writes the x0 rows of site (row mod 64)"},
+    {"MURAL_DEBUG_FIRST", "TIMING ONLY, wrong results: phases of the training first-layer kernels switched off"},
+    {"MURAL_DEBUG_FIRST_CL", "TIMING ONLY: changes the layout of mural_op_first_fwd / _bwd"},
+    {"MURAL_DEBUG_CW", "TIMING ONLY, wrong results: phases of the wave-private conv kernels switched off (bit mask)"},
+    {"MURAL_DEBUG_CL", "TIMING ONLY, wrong results: phases of the workgroup-tile conv kernels switched off"},
+    {"MURAL_DEBUG_BWD32", "TIMING ONLY, wrong results: phases of the tiled conv32 backward switched off"},
+    {"MURAL_DEBUG_MLP", "TIMING ONLY, wrong results: phases of the local MLP switched off"},
+    {"MURAL_DEBUG_CB_STAMP_ONLY", "diagnostic: phase stamps of one workgroup only"},
+    {"MURAL_DEBUG_SPLIT_P", "diagnostic: caps the tile sizes of the split tower launches"},
+    {"MURAL_DEBUG_TOWER_WAVE", "diagnostic: mask of the tower launches that take the wave-private kernel"},
+    {"MURAL_DEBUG_TOWER_GRID", "diagnostic: resident workgroups of the tower launches"},
+    {"MURAL_DEBUG_TOWER_LDS", "diagnostic: inflates the tower launches' LDS request"},
+    {"MURAL_DEBUG_TOWER_STAGGER", "diagnostic: staggered start of the tower workgroups"},
+    {nullptr, nullptr}};
+  return table;
+}
+
+const char* dev_env(const char* name) {
+  if (!g_dev_switches) return nullptr;
+  for (const DevSwitch* s = dev_switch_table(); s->name; ++s)
+    if (!std::strcmp(s->name, name)) return std::getenv(name);
+  std::fprintf(stderr, "libmural_hip (debug flavour): %s is read but not listed in dev_switch_table\n", name);
+  return nullptr;
+}
+
+thread_local std::vector<size_t> g_ws_layout;      // (read by the debug flavour's mural_debug_last_ws_layout)
 
 size_t ws_guard_bytes() {
-  const char* e = getenv("MURAL_DEBUG_WS_GUARD");
+  const char* e = dev_env("MURAL_DEBUG_WS_GUARD");
   return e ? (size_t)atol(e) : 0;
 }
 void ws_layout_reset() { g_ws_layout.clear(); }
@@ -256,13 +332,4 @@ extern "C" int mural_encode_symbols(const MuralGenome* g, const int64_t* pos, co
   hipLaunchKernelGGL(encode_symbols_kernel, dim3(grid), dim3(block), 0, (hipStream_t)stream, *g, pos, strand, n, off, width, out);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
-}
-
-// (offset, bytes) pairs of the regions of the calling thread's latest workspace carve (forward / reuse entry points and their
-// *_workspace_bytes queries); returns the number of pairs written (at most max_pairs)
-extern "C" int mural_debug_last_ws_layout(size_t* out, int32_t max_pairs) {
-  const int n = (int)(mural::g_ws_layout.size() / 2);
-  const int m = n < max_pairs ? n : max_pairs;
-  for (int i = 0; i < 2 * m; ++i) out[i] = mural::g_ws_layout[i];
-  return m;
 }

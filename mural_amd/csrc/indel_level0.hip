@@ -25,7 +25,7 @@
 #include "mfma_tile.h"
 
 namespace mural {
-extern unsigned long long* g_cb8_stamps;      // diagnostic (convblock8_mfma.hip): per-workgroup phase sums, or nullptr
+extern unsigned long long* g_cb8_stamps;      // diagnostic (conv1d.hip): per-workgroup phase sums, or nullptr
 namespace {
 
 constexpr int E0_OUT = 252;         // output positions per tile (= the split form's tile, so tail / tile bookkeeping is shared)
@@ -676,13 +676,13 @@ void indel_enc0_compose(const float* fw, const float* fb, const float* symtab, c
 // diagnostic (tools/phase_stamps_indel_l0.py): MURAL_DEBUG_CB_STAMP_ONLY = enc | dec stamps only that launch
 static unsigned long long* l0_stamps(bool enc) {
   if (g_cb8_stamps)
-    if (const char* only = getenv("MURAL_DEBUG_CB_STAMP_ONLY"))
+    if (const char* only = dev_env("MURAL_DEBUG_CB_STAMP_ONLY"))
       if ((only[0] == 'e') != enc) return nullptr;
   return g_cb8_stamps;
 }
 
 bool indel_enc0_supported(const ConvBlockArgs& a) {
-  const bool off = getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0;      // (read per launch: the tests switch it)
+  const bool off = dev_env("MURAL_INDEL_ENC0") && atoi(dev_env("MURAL_INDEL_ENC0")) == 0;      // (read per launch: the tests switch it)
   if (a.sym_in && !(a.f_in && (int64_t)a.B * a.Lf < (int64_t(1) << 40))) return false;      // (byte source: the dense window backs it)
   return !off && a.C == 8 && a.symtab && a.e0_t3 && a.e0_t1 && a.e0_bias && a.Cf == 4 && a.f_up == 1 && (a.sym_taps == 7 || a.sym_taps == 1) &&
          a.tail_max == nullptr && a.res2 == nullptr && a.Lf == a.L;
@@ -729,7 +729,7 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
 #undef MURAL_E0_OCC
     wg_per_cu[v] = n > 7 ? 7 : (n > 0 ? n : 1);
   }
-  static const int cap = getenv("MURAL_INDEL_ENC0_WGS") ? atoi(getenv("MURAL_INDEL_ENC0_WGS")) : 0;      // experiment: workgroups per CU
+  static const int cap = dev_env("MURAL_INDEL_ENC0_WGS") ? atoi(dev_env("MURAL_INDEL_ENC0_WGS")) : 0;      // experiment: workgroups per CU
   const long long want = (long long)cus * (cap > 0 ? cap : wg_per_cu[v]);
   const dim3 grid((unsigned)(total < want ? total : want));
 #define MURAL_E0(...) hipLaunchKernelGGL((indel_enc0_kernel<__VA_ARGS__>), grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps)
@@ -741,7 +741,7 @@ int launch_indel_enc0(const ConvBlockArgs& a, hipStream_t stream) {
 }
 
 bool indel_dec0_supported(const ConvBlockArgs& a) {
-  const bool off = getenv("MURAL_INDEL_DEC0") && atoi(getenv("MURAL_INDEL_DEC0")) == 0;
+  const bool off = dev_env("MURAL_INDEL_DEC0") && atoi(dev_env("MURAL_INDEL_DEC0")) == 0;
   return !off && a.C == 8 && a.f_in != nullptr && a.symtab == nullptr && a.f_pw != nullptr && a.Cf == 16 && a.f_up == 4 && (a.L & 3) == 0 && a.Lf * 4 == a.L &&
          a.x == nullptr && (a.tail_max != nullptr || a.out != nullptr) && (a.tail_max == nullptr || (a.ta_w && a.ta_b && a.tb_w && a.tb_b));
 }
@@ -766,7 +766,7 @@ int launch_indel_dec0(const ConvBlockArgs& a, hipStream_t stream) {
     else MURAL_HIP_CHECK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, indel_dec0_kernel<true>, 256, 0));
     wg_per_cu[v] = n > 0 ? n : 1;
   }
-  static const int cap = getenv("MURAL_INDEL_DEC0_WGS") ? atoi(getenv("MURAL_INDEL_DEC0_WGS")) : 0;      // experiment: workgroups per CU
+  static const int cap = dev_env("MURAL_INDEL_DEC0_WGS") ? atoi(dev_env("MURAL_INDEL_DEC0_WGS")) : 0;      // experiment: workgroups per CU
   const long long want = (long long)cus * (cap > 0 ? cap : wg_per_cu[v]);
   const dim3 grid((unsigned)(total < want ? total : want));
   if (stamps) hipLaunchKernelGGL(indel_dec0_kernel<true>, grid, dim3(256), 0, stream, a, a.w5, a.b5, a.w1, a.b1, tiles_per_row, total, stamps);

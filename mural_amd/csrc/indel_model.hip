@@ -317,7 +317,7 @@ static int run_upconv(const MuralIndelModel* m, int j, const float* in, int B, i
     a.B = B; a.Cin = fp.Cin; a.Lin = Lin; a.Cout = fp.Cout; a.Lout = Lout;
     a.K = fp.K; a.stride = 1; a.pad = m->dn_lp_pad[j]; a.up = 1; a.phases = up;
     a.act = ACT_NONE;
-    static const bool use_direct = !(getenv("MURAL_CONV1D_DIRECT") && atoi(getenv("MURAL_CONV1D_DIRECT")) == 0);
+    static const bool use_direct = !(dev_env("MURAL_CONV1D_DIRECT") && atoi(dev_env("MURAL_CONV1D_DIRECT")) == 0);
     if (use_direct && (int64_t)B * Lin >= 32768 && conv1d_direct_poly_supported(a)) return launch_conv1d_direct_poly(a, stream);
     if (conv1d_mfma_supported(a)) return launch_conv1d_mfma(a, stream);
   }
@@ -461,14 +461,14 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
       // dense one-hot windows (what the reference's loader yields): classified into one symbol byte per column and taken by the same
       // persistent table-driven first level as the packed entry; columns that are no MuRaL symbol are evaluated from their floats there
       // (MURAL_INDEL_DENSE_SYMBOLS=0: the input layer and the first level as launches of their own on the dense tensor)
-      const bool sym_off = (getenv("MURAL_INDEL_DENSE_SYMBOLS") && atoi(getenv("MURAL_INDEL_DENSE_SYMBOLS")) == 0) ||
-                           (getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0) || getenv("MURAL_DEBUG_CONVBLOCK_VALU") ||
-                           getenv("MURAL_CONVBLOCK8_VALU") || getenv("MURAL_CONVBLOCK8_MFMA");
+      const bool sym_off = (dev_env("MURAL_INDEL_DENSE_SYMBOLS") && atoi(dev_env("MURAL_INDEL_DENSE_SYMBOLS")) == 0) ||
+                           (dev_env("MURAL_INDEL_ENC0") && atoi(dev_env("MURAL_INDEL_ENC0")) == 0) || dev_env("MURAL_DEBUG_CONVBLOCK_VALU") ||
+                           dev_env("MURAL_CONVBLOCK8_VALU");
       if (first_fused && m->e0_t3 && (Lx & 3) == 0 && !sym_off) {
         if ((rc = launch_dense_to_symbols(x, B, Lx, reinterpret_cast<uint8_t*>(X), nullptr, stream, 16))) return rc;
         gs.sym = reinterpret_cast<const uint8_t*>(X);
       }
-    } else if (first_fused && !getenv("MURAL_DEBUG_INDEL_NO_GENOME_FRONT")) {
+    } else if (first_fused && !dev_env("MURAL_DEBUG_INDEL_NO_GENOME_FRONT")) {
       gs.g = genome; gs.pos = pos + c0; gs.strand = strand + c0; gs.off = -(Lx / 2) + 1;
     } else {
       if ((rc = mural_encode_onehot(genome, pos + c0, strand + c0, B, Lx / 2, 1, X, stream))) return rc;
@@ -482,11 +482,11 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
     }
     // the genome-fed first level also emits the second level's strided conv (8 -> 16, k = 7, stride 4) where the shapes are the
     // persistent kernel's (indel_level0.hip); MURAL_INDEL_ENC0_DOWN=0: the conv as a launch of its own
-    const bool down_off = (getenv("MURAL_INDEL_ENC0_DOWN") && atoi(getenv("MURAL_INDEL_ENC0_DOWN")) == 0) ||
-                                 (getenv("MURAL_INDEL_ENC0") && atoi(getenv("MURAL_INDEL_ENC0")) == 0);
+    const bool down_off = (dev_env("MURAL_INDEL_ENC0_DOWN") && atoi(dev_env("MURAL_INDEL_ENC0_DOWN")) == 0) ||
+                                 (dev_env("MURAL_INDEL_ENC0") && atoi(dev_env("MURAL_INDEL_ENC0")) == 0);
     const bool emit_down = (gs.g || gs.sym) && m->e0_t3 && !down_off && sh.down[1] == 4 && m->up_l[1].K == 7 && m->up_l[1].Cin == 8 && m->up_l[1].Cout == 16 &&
-                           (m->len[0] & 3) == 0 && m->len[1] == (m->len[0] - 1) / 4 + 1 && !getenv("MURAL_DEBUG_CONVBLOCK_VALU") &&
-                           !getenv("MURAL_CONVBLOCK8_VALU") && !getenv("MURAL_CONVBLOCK8_MFMA");
+                           (m->len[0] & 3) == 0 && m->len[1] == (m->len[0] - 1) / 4 + 1 && !dev_env("MURAL_DEBUG_CONVBLOCK_VALU") &&
+                           !dev_env("MURAL_CONVBLOCK8_VALU");
     for (int i = 0; i < INDEL_LEVELS; ++i) {     // encoder: strided conv+BN, then ConvBlock (x + BN(1x1(SiLU(BN(k5)))))
       const int Li = m->len[i];
       if (sh.down[i] == 1 && block_fusable(m->up5[i], m->up1[i], Li) && front_fusable(m->up_l[i], 1, m->ch[i])) {

@@ -899,7 +899,7 @@ static int convg_bwd_impl(const float* dy, const float* x, const float* W, const
     MURAL_HIP_CHECK(hipGetLastError());
   }
   const int entries = Cin * K;
-  static const bool wgrad_mfma = !(getenv("MURAL_WGRAD_MFMA") && atoi(getenv("MURAL_WGRAD_MFMA")) == 0);      // A/B switch of the tools
+  static const bool wgrad_mfma = !(dev_env("MURAL_WGRAD_MFMA") && atoi(dev_env("MURAL_WGRAD_MFMA")) == 0);      // A/B switch of the tools
   if (wgrad_mfma) {
     const int cap = (int)std::min<size_t>(WG_CHUNKS, part_floats / ((size_t)Cout * (entries + 1)));
     int chunks = 0;

@@ -27,7 +27,7 @@ __device__ __forceinline__ int xcd_wave_index(int w, int on) {
   return slot * 4 + w;
 }
 inline int xcd_swizzle_enabled() {      // MURAL_XCD_SWIZZLE=0: workgroup b takes slot b (A/B switch)
-  const char* e = getenv("MURAL_XCD_SWIZZLE");
+  const char* e = dev_env("MURAL_XCD_SWIZZLE");
   return !(e && atoi(e) == 0);
 }
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }

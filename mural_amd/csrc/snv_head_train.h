@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void hd_bwd2_kernel(const float* __restrict__ 
 }  // namespace headtrain
 
 bool head_train_fused_ok(int nc) {
-  const char* e = getenv("MURAL_TRAIN_HEAD_OPS");
+  const char* e = dev_env("MURAL_TRAIN_HEAD_OPS");
   return !(e && atoi(e) != 0) && nc >= 1 && nc <= SNV_MAXCLASS;
 }
 

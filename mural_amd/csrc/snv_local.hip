@@ -120,13 +120,13 @@ bool local_mfma_plan(const LocalDev& L, LocalMfmaDims* dp, size_t* lds_bytes) {
   auto pitch = [](int k) { return ((k + 31) & ~31) + 16; };     // = 16 (mod 32)
   d.s1 = pitch(d.K2p);
   d.sx = std::max(pitch(d.K1p), pitch(d.K3p));
-  d.dbg = getenv("MURAL_DEBUG_MLP") ? atoi(getenv("MURAL_DEBUG_MLP")) : 0;
+  d.dbg = dev_env("MURAL_DEBUG_MLP") ? atoi(dev_env("MURAL_DEBUG_MLP")) : 0;
   const size_t floats = (size_t)256 * (d.n1b * (d.K1p / 16) + d.n2b * (d.K2p / 16) + d.K3p / 16) + (size_t)LM_TP * (d.s1 + d.sx) +
                         (size_t)((L.emb_rows * 5 + 3) & ~3) + d.K2p + d.K3p + 16;
   *dp = d;
   *lds_bytes = floats * sizeof(float);
   // (the choice must not depend on the batch size: results are bitwise independent of how a site list is chunked)
-  return L.n_class <= 16 && LM_TP * L.cols <= 4 * LOC_THREADS && floats * sizeof(float) <= 160 * 1024 && !getenv("MURAL_DEBUG_LOCAL_VALU");
+  return L.n_class <= 16 && LM_TP * L.cols <= 4 * LOC_THREADS && floats * sizeof(float) <= 160 * 1024 && !dev_env("MURAL_DEBUG_LOCAL_VALU");
 }
 
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream) {
@@ -137,7 +137,7 @@ int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* ou
     size_t lds = 0;
     if (local_mfma_plan(L, &d, &lds)) {
       // the shipped dimensions: fragments in registers, two workgroups per CU (snv_local_mfma.h; MURAL_LOCAL_REG=0: fragments in LDS)
-      const bool reg_off = getenv("MURAL_LOCAL_REG") && atoi(getenv("MURAL_LOCAL_REG")) == 0;
+      const bool reg_off = dev_env("MURAL_LOCAL_REG") && atoi(dev_env("MURAL_LOCAL_REG")) == 0;
       if (!reg_off && d.K1p == 16 * LR_J1 && d.n1b == LR_N1B && d.K2p == 16 * LR_J2 && d.n2b == LR_N2B && d.K3p == 16 * LR_J3 && !d.dbg) {
         const size_t lds_reg = ((size_t)LM_TP * (d.s1 + d.sx) + (size_t)((L.emb_rows * 5 + 3) & ~3) + d.K2p + d.K3p + 16) * sizeof(float);
         const int64_t n_tiles = (n + LM_TP - 1) / LM_TP;

@@ -500,7 +500,7 @@ int lt_launch_bwd(LtBwd a, hipStream_t stream) {
 // tables beyond the 64 KB a launch gets without opting in (local_order >= 6: 4097 rows = 82 KB) and batches beyond the launchers'
 // 32-bit offsets take the per-op route, which has neither limit.
 bool local_train_fused_ok(int in1, int h1, int h2, int nc, int emb_rows, int64_t B) {
-  const char* e = getenv("MURAL_TRAIN_LOCAL_OPS");
+  const char* e = dev_env("MURAL_TRAIN_LOCAL_OPS");
   if (e && atoi(e) != 0) return false;
   const size_t bottom_lds = ((size_t)8 * (size_t)h1 + (size_t)emb_rows * 5) * 4;
   if (bottom_lds > (size_t)64 * 1024 || B > (1 << 20)) return false;
@@ -573,9 +573,3 @@ int local_train_bwd(const int64_t* cat, int cols, int emb_rows, int64_t B, const
 }
 
 }  // namespace mural
-
-// diagnostic: wall-clock stamps of the fused local branch's three backward launches (uint64 [3][256][8]); NULL: off
-extern "C" int mural_debug_lt_set_stamps(void* dev_ptr) {
-  mural::ltrain::g_lt_stamps = static_cast<unsigned long long*>(dev_ptr);
-  return MURAL_OK;
-}

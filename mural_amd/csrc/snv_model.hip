@@ -291,7 +291,7 @@ struct Workspace { float* local_logits; int64_t* cat; uint8_t* symbols; float* x
 // tail); four chunks' worth are 42.7 / 51.2.  Long windows and models without the split launches keep one chunk.
 constexpr int SNV_SUPER = 4;
 int64_t super_chunk_sites(const MuralSnvModel* m) {
-  const bool off = getenv("MURAL_SNV_DEFER_SHORT") && atoi(getenv("MURAL_SNV_DEFER_SHORT")) == 0;
+  const bool off = dev_env("MURAL_SNV_DEFER_SHORT") && atoi(dev_env("MURAL_SNV_DEFER_SHORT")) == 0;
   return (m->split && !m->longwin && !off) ? SNV_SUPER * m->chunk : m->chunk;
 }
 
@@ -445,7 +445,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
       auto plan_part = [&](int q) -> bool {
         const int towers = (q & 1) ? 2 : 1, phase = q < 2 ? 1 : 2;
         int Pq = 0, Pmax = 32;
-        if (const char* e = getenv("MURAL_DEBUG_SPLIT_P")) {   // diagnostic: "P0,P1,P2,P3" caps the tile sizes
+        if (const char* e = dev_env("MURAL_DEBUG_SPLIT_P")) {   // diagnostic: "P0,P1,P2,P3" caps the tile sizes
           int v[4] = {32, 32, 32, 32};
           sscanf(e, "%d,%d,%d,%d", &v[0], &v[1], &v[2], &v[3]);
           if (v[q] >= 1) Pmax = v[q];
@@ -468,7 +468,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         // blocks and two four-wave workgroups on a CU.  MURAL_DEBUG_TOWER_WAVE = bit mask of the launches that may take it
         // (default: all four); 0 keeps the workgroup-tile kernel everywhere (A/B runs).
         int wave_mask = 15;
-        if (const char* e = getenv("MURAL_DEBUG_TOWER_WAVE")) wave_mask = atoi(e);
+        if (const char* e = dev_env("MURAL_DEBUG_TOWER_WAVE")) wave_mask = atoi(e);
         if ((wave_mask >> q) & 1) {
           for (int cand = 31; cand >= 1; --cand) {
             SnvFwdArgs tmp;
@@ -484,12 +484,12 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         return true;
       };
       m->chunk = SNV_CHUNK;
-      if (const char* e = getenv("MURAL_SNV_CHUNK")) {      // experiment: smaller chunks keep x0 in the 256 MB Infinity Cache
+      if (const char* e = dev_env("MURAL_SNV_CHUNK")) {      // experiment: smaller chunks keep x0 in the 256 MB Infinity Cache
         const long v = atol(e);
         if (v >= 1024 && v <= SNV_CHUNK) m->chunk = v;
       }
       m->longwin = false;
-      if (!getenv("MURAL_DEBUG_NO_LONGWIN")) {      // (tried first: a row of 143 .. ~270 columns also fits ONE workgroup tile per CU, slowly)
+      if (!dev_env("MURAL_DEBUG_NO_LONGWIN")) {      // (tried first: a row of 143 .. ~270 columns also fits ONE workgroup tile per CU, slowly)
         // Long window: the large tower's pooled first-stage row (L2 columns) does not fit a wave's image.  Its first conv stage --
         // four k=3 convs, then a 7-wide pool -- runs on segments with 4 halo columns: lw_nA segments of 7 nj + 8 columns starting at
         // 0, 7 nj, 14 nj, ... (a start that is a multiple of the pool stride keeps the segment's pool windows on the row's; the first
@@ -536,7 +536,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         // split mode: (tower, phase) pairs in their own launches, each with the largest tile that keeps two workgroups per
         // CU: the mid tower and above all the short stages then run layers that are many blocks wide
         m->split = false;
-        if (lds <= kLdsTwoPerCu && !getenv("MURAL_DEBUG_NO_TOWER_SPLIT")) {
+        if (lds <= kLdsTwoPerCu && !dev_env("MURAL_DEBUG_NO_TOWER_SPLIT")) {
           bool ok = true;
           for (int q = 0; q < 4 && ok; ++q) ok = plan_part(q);
           m->split = ok;
@@ -561,7 +561,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
         }
         // the large tower's pair table rides along where it fits (15-wide pools: the shipped first max-pool)
         m->s1_pair = !s1.site_mode && s1.tw[0].pk == 15 && s1.tw[0].ps == 15 && m->s1_lds_bytes + (size_t)SNV_LUT4 * 4 <= kLdsMax &&
-                     !getenv("MURAL_DEBUG_NO_PAIR_TABLE");
+                     !dev_env("MURAL_DEBUG_NO_PAIR_TABLE");
         if (m->s1_pair) m->s1_lds_bytes += (size_t)SNV_LUT4 * 4;
         if (m->s1_lds_bytes > kLdsMax || s1.tw[0].pk > 16 || s1.tw[1].pk > 4) {
           set_error("distal_radius %d is too long for the stage-1 kernel's LDS window", (sh.distal_len - 1) / 2);
@@ -621,7 +621,7 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
     L.frag = m->blob + loff.frag; L.frag_floats = (int)loff.frag_floats;
     L.cols = sh.local_cols; L.emb_rows = sh.emb_rows; L.in1 = 5 * sh.local_cols; L.h1 = sh.hidden1; L.h2 = sh.hidden2;
     L.n_class = sh.n_class;
-    m->loc_fused = has_towers && local_mfma_plan(L, &m->loc_d, &m->loc_lds) && !getenv("MURAL_DEBUG_NO_LOCAL_FUSE");
+    m->loc_fused = has_towers && local_mfma_plan(L, &m->loc_d, &m->loc_lds) && !dev_env("MURAL_DEBUG_NO_LOCAL_FUSE");
   }
   *out = m;
   return MURAL_OK;
@@ -660,8 +660,7 @@ namespace mural { int profile_begin(); int profile_end(double*, int64_t*); }
 extern "C" int mural_profile_begin(void) { return mural::profile_begin(); }
 extern "C" int mural_profile_end(double* total_ms, int64_t* launches) { return mural::profile_end(total_ms, launches); }
 
-static unsigned long long* g_stamps = nullptr;
-extern "C" int mural_debug_set_stamps(void* dev_ptr) { g_stamps = (unsigned long long*)dev_ptr; return MURAL_OK; }
+namespace mural { unsigned long long* g_tower_stamps = nullptr; }      // diagnostic (debug flavour: mural_debug_set_stamps)
 
 // stage-1 kernel + tower kernel over chunks of SNV_CHUNK sites (the x0 scratch holds one chunk)
 constexpr int64_t SNV_SMALL_BATCH = 256;   // up to here a call is latency-bound: single launch with one-site tiles
@@ -669,7 +668,7 @@ constexpr int64_t SNV_SMALL_BATCH = 256;   // up to here a call is latency-bound
 static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool packed, int64_t n, const Workspace& w,
                       float* out, float* taps, const int32_t* status, hipStream_t stream, bool one_chunk = false) {
   const int nc = m->shape.n_class;
-  const bool small = taps == nullptr && n <= SNV_SMALL_BATCH && m->lds_small > 0 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH");
+  const bool small = taps == nullptr && n <= SNV_SMALL_BATCH && m->lds_small > 0 && !dev_env("MURAL_DEBUG_NO_SMALL_BATCH");
   // the short-stage launches of up to SNV_SUPER chunks as ONE launch per tower (super_chunk_sites): the chunks' first-stage launches leave
   // their pooled rows side by side in s3
   const bool defer = m->split && taps == nullptr && !small && !m->longwin && super_chunk_sites(m) > m->chunk && n > m->chunk && !one_chunk;
@@ -689,7 +688,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     if (int rc = launch_snv_stage1(s, packed, s.loc_on ? std::max(m->s1_lds_bytes, m->loc_lds) : m->s1_lds_bytes, stream)) return rc;
     const bool split = m->split && taps == nullptr && !small;   // the debug dump wants both towers in one tile geometry
     // (the unit counters are read only with MURAL_TOWER_DYNAMIC_UNITS=1: the fill is a 4 us launch per chunk otherwise wasted)
-    if (split && getenv("MURAL_TOWER_DYNAMIC_UNITS") && atoi(getenv("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
+    if (split && dev_env("MURAL_TOWER_DYNAMIC_UNITS") && atoi(dev_env("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
       MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
     for (int part = 0; part < (split ? (defer ? 2 : 4) : 1); ++part) {
       if (m->longwin && part == 0) {
@@ -741,7 +740,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       t.out = out + c0 * nc;
       t.taps = c0 == 0 ? taps : nullptr;
       t.tap_stride = a.nbuf;
-      t.stamps = packed ? g_stamps : nullptr;
+      t.stamps = packed ? mural::g_tower_stamps : nullptr;
       t.status = status;
       t.unit_counter = split && t.wave ? w.counters + part : nullptr;
       const size_t lds = split ? m->lds_split[part] : (small ? m->lds_small : m->lds_bytes);
@@ -760,7 +759,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       t.out = out + sc0 * nc;
       t.taps = nullptr;
       t.tap_stride = a.nbuf;
-      t.stamps = packed ? g_stamps : nullptr;
+      t.stamps = packed ? mural::g_tower_stamps : nullptr;
       t.status = status;
       t.unit_counter = t.wave ? w.counters + part : nullptr;
       if (int rc = launch_snv_towers(m, t, m->lds_split[part], stream)) return rc;

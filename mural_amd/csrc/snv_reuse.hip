@@ -440,7 +440,7 @@ struct ReuseWs {
 
 constexpr int RU_SUPER = 4;
 int64_t reuse_super_sites() {
-  const bool off = getenv("MURAL_SNV_DEFER_SHORT") && atoi(getenv("MURAL_SNV_DEFER_SHORT")) == 0;
+  const bool off = dev_env("MURAL_SNV_DEFER_SHORT") && atoi(dev_env("MURAL_SNV_DEFER_SHORT")) == 0;
   return off ? (int64_t)SNV_CHUNK : (int64_t)RU_SUPER * SNV_CHUNK;
 }
 
@@ -661,7 +661,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
 
   static DynLdsOnce edge_lds;
   if (int rc = edge_lds.ensure(&snv_edge_kernel)) return rc;
-  const bool edge_wave = !getenv("MURAL_DEBUG_EDGE_TILE");
+  const bool edge_wave = !dev_env("MURAL_DEBUG_EDGE_TILE");
   const int64_t super = reuse_super_sites();
   const size_t s3_site[2] = {(size_t)std::max(m->args.geom[0].L[1], 1) * SNV_C, (size_t)std::max(m->args.geom[1].L[1], 1) * SNV_C};
   for (int64_t u0 = 0; u0 < n; u0 += super) {
@@ -678,7 +678,7 @@ extern "C" int mural_snv_forward_packed_reuse(const MuralSnvModel* m, const Mura
       if (int rc = mural_encode_kmer(g, pos + s0, strand + s0, sn, local_radius, local_order, 0, w.cat, stream_)) return rc;
       if (int rc = launch_snv_local(m->local, w.cat, sn, w.local_logits + rel * nc, stream)) return rc;
     }
-    if (getenv("MURAL_TOWER_DYNAMIC_UNITS") && atoi(getenv("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
+    if (dev_env("MURAL_TOWER_DYNAMIC_UNITS") && atoi(dev_env("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
       MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));      // unit counters of this chunk's four wave-private launches (read with that switch only)
     for (int t = 0; t < 2; ++t) {
       const TowerGeom& gg = m->args.geom[t];

@@ -855,7 +855,7 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
   MURAL_REQUIRE(lds <= 160 * 1024, "first layer: window of %d columns does not fit the LDS working set", a.Lwin);
   using KernelFn = void (*)(const FirstTrainArgs);
   MURAL_REQUIRE(!a.fold.dz || (bwd && a.cl), "first layer: the folded BatchNorm-backward apply belongs to the channel-last backward");
-  if (bwd && a.cl && (a.fold.dz || !getenv("MURAL_DEBUG_FIRST_SCATTER"))) {      // the composed step's backward: register sums, no kmer windows in LDS
+  if (bwd && a.cl && (a.fold.dz || !dev_env("MURAL_DEBUG_FIRST_SCATTER"))) {      // the composed step's backward: register sums, no kmer windows in LDS
     const size_t lds_b = (size_t)(SNV_TAPS + S1_WAVES * FB_ROWS * 32) * 4 + (size_t)S1_WAVES * a.cw;
     MURAL_REQUIRE(lds_b <= 160 * 1024, "first layer: window of %d columns does not fit the LDS working set", a.Lwin);
     static DynLdsOnce big_b;
@@ -871,14 +871,14 @@ int launch_first_train(FirstTrainArgs a, bool bwd, hipStream_t stream) {
   static DynLdsOnce big_lds[4];                             // once per instantiation and device (never inside a graph capture)
   if (int rc = big_lds[(slot == 4 ? 0 : 2) + (bwd ? 1 : 0)].ensure(fn)) return rc;
   a.stamps = g_first_stamps;
-  static const int dbg = getenv("MURAL_DEBUG_FIRST") ? atoi(getenv("MURAL_DEBUG_FIRST")) : 0;
+  static const int dbg = dev_env("MURAL_DEBUG_FIRST") ? atoi(dev_env("MURAL_DEBUG_FIRST")) : 0;
   a.dbg = dbg;
   hipLaunchKernelGGL(fn, dim3(first_train_grid(a.B)), dim3(S1_THREADS), lds, stream, a);
   MURAL_HIP_CHECK(hipGetLastError());
   return MURAL_OK;
 }
 
-bool stage1_small_batch(int64_t n) { return n <= 256 && !getenv("MURAL_DEBUG_NO_SMALL_BATCH"); }
+bool stage1_small_batch(int64_t n) { return n <= 256 && !dev_env("MURAL_DEBUG_NO_SMALL_BATCH"); }
 
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream) {
   if (a.n == 0) return MURAL_OK;
@@ -901,7 +901,7 @@ int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStr
   const int64_t want = (a.n + S1_WAVES - 1) / S1_WAVES;
   const int grid = (int)(want < 256 ? want : 256);   // one 16-wave workgroup per CU, persistent
   Stage1Args b = a;
-  static const int alias = getenv("MURAL_DEBUG_S1_ALIAS") ? 1 : 0;
+  static const int alias = dev_env("MURAL_DEBUG_S1_ALIAS") ? 1 : 0;
   b.dbg_alias = alias;
   if (packed)
     hipLaunchKernelGGL(snv_stage1_kernel<1>, dim3(grid), dim3(S1_THREADS), lds_bytes, stream, b);
@@ -912,9 +912,3 @@ int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStr
 }
 
 }  // namespace mural
-
-// diagnostic: per-workgroup wall-clock stamps of the training-mode first-layer kernels' phases (tools/phase_stamps_first.py); NULL: off
-extern "C" int mural_debug_first_set_stamps(void* dev_ptr) {
-  mural::g_first_stamps = static_cast<unsigned long long*>(dev_ptr);
-  return MURAL_OK;
-}

@@ -500,11 +500,11 @@ int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_by
   }
   int grid = (int)(n_tiles < 2048 ? n_tiles : 2048);
   if (a.par) grid = (int)(2 * n_tiles);   // small batches only (run_towers): one workgroup per (tile, tower)
-  if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) {   // diagnostic: e.g. 256 = one workgroup per CU (tools/phase_stamps.py)
+  if (const char* e = dev_env("MURAL_DEBUG_TOWER_GRID")) {   // diagnostic: e.g. 256 = one workgroup per CU (tools/phase_stamps.py)
     const int v = atoi(e);
     if (v >= 1 && v < grid) grid = v;
   }
-  if (const char* e = getenv("MURAL_DEBUG_TOWER_LDS")) {    // diagnostic: inflate the first-stage launches' LDS request (occupancy study)
+  if (const char* e = dev_env("MURAL_DEBUG_TOWER_LDS")) {    // diagnostic: inflate the first-stage launches' LDS request (occupancy study)
     const size_t v = (size_t)atol(e);
     if (a.phase == 1 && v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
   }

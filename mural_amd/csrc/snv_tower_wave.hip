@@ -1043,8 +1043,8 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_edge_wave(const EdgeArgs a
 }
 
 static bool tower_dynamic_units() {
-  const char* e = getenv("MURAL_TOWER_DYNAMIC_UNITS");
-  return e && atoi(e) != 0 && !getenv("MURAL_DEBUG_TOWER_STATIC_UNITS");
+  const char* e = dev_env("MURAL_TOWER_DYNAMIC_UNITS");
+  return e && atoi(e) != 0 && !dev_env("MURAL_DEBUG_TOWER_STATIC_UNITS");
 }
 
 size_t edge_wave_lds_bytes() {
@@ -1091,7 +1091,7 @@ size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int towe
   a.phase = phase;
   a.wave = 1;
   a.stagger = 0;      // measured: no effect (the waves of a CU do not run in lockstep); kept as a diagnostic
-  if (const char* e = getenv("MURAL_DEBUG_TOWER_STAGGER")) a.stagger = atoi(e);
+  if (const char* e = dev_env("MURAL_DEBUG_TOWER_STAGGER")) a.stagger = atoi(e);
   a.x0_cols = a.geom[0].L[0] + a.geom[1].L[0];
   a.nbuf = maxcols * SNV_C;
   const size_t par = (size_t)(2 * EX_COUNT * SNV_C + n_class * SNV_C + SNV_MAXCLASS + 4 + 6 * 3 * SNV_C);
@@ -1107,7 +1107,7 @@ int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t 
   // two workgroups per CU are resident: with more work than that every wave walks its units in a grid-stride loop, so the
   // prologue (parameter staging, first fragments, first activations with their full latency) is paid once per wave
   int resident = 512;
-  if (const char* e = getenv("MURAL_DEBUG_TOWER_GRID")) resident = std::max(1, atoi(e));
+  if (const char* e = dev_env("MURAL_DEBUG_TOWER_GRID")) resident = std::max(1, atoi(e));
   const int grid = (int)(n_wg < resident ? n_wg : resident);
   // Units at a fixed stride (wave w: units w, w + waves, ...).  The ticket counter (MURAL_TOWER_DYNAMIC_UNITS=1: a returning atomic per
   // unit, requested a unit ahead) was the default until the end of round 5 and is 2 - 5 % SLOWER on every batch size measured
@@ -1115,7 +1115,7 @@ int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t 
   // the fixed stride has no tail to repair, and the counter's waves end a unit apart (64 +- 1 units each).  With the counter, units
   // go through it only when every wave has several to take.
   if (n_units < 4 * (int64_t)grid * SNV_WAVES || !tower_dynamic_units()) a.unit_counter = nullptr;
-  if (const char* e = getenv("MURAL_DEBUG_TOWER_LDS")) {      // diagnostic: inflate the LDS request (one workgroup per CU: occupancy study)
+  if (const char* e = dev_env("MURAL_DEBUG_TOWER_LDS")) {      // diagnostic: inflate the LDS request (one workgroup per CU: occupancy study)
     const size_t v = (size_t)atol(e);
     if (v > lds_bytes && v <= 160 * 1024) lds_bytes = v;
   }
@@ -1127,7 +1127,7 @@ int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t 
   const int ship_pw = a.phase == 1 ? (t == 0 ? 1 : 2) : (t == 0 ? 6 : 5);
   // MURAL_DEBUG_TOWER_RUNTIME_GEOM: A/B switch of the tests -- the first-stage launches through the instance that reads its geometry
   // from the arguments (bitwise the same results)
-  bool ship = a.Lwin == SHIP_LWIN && a.P == ship_pw && !(a.phase == 1 && getenv("MURAL_DEBUG_TOWER_RUNTIME_GEOM"));
+  bool ship = a.Lwin == SHIP_LWIN && a.P == ship_pw && !(a.phase == 1 && dev_env("MURAL_DEBUG_TOWER_RUNTIME_GEOM"));
   if (ship) {
     const TowerGeom want = wave_tower_geom(t, SHIP_LWIN, ship_pw), other = wave_tower_geom(0, SHIP_LWIN, 1);
     const TowerGeom& have = a.geom[t];

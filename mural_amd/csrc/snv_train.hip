@@ -278,7 +278,7 @@ const float EPS = 1e-5f;
 // which conv kernels the step runs: the wave-private ones (conv32_wave.hip) where they apply, unless MURAL_TRAIN_CONV_CL=1 asks for the
 // workgroup-tile kernels everywhere (A/B runs, parity tests of both)
 bool use_wave_conv(int L, int post_relu, bool stats, int out_relu) {
-  const char* e = getenv("MURAL_TRAIN_CONV_CL");
+  const char* e = dev_env("MURAL_TRAIN_CONV_CL");
   if (e && atoi(e) != 0) return false;
   return cw_conv32_supported(L) && !post_relu && (!stats || out_relu);
 }
@@ -446,7 +446,7 @@ int bnconv_b(Ctx& c, const float* dy, const float* x, int L, int pre_relu, const
   c.job_part[j] = c.P->part[j];
   c.job_dW[j] = const_cast<float*>(gcv.weight);
   c.job_db[j] = const_cast<float*>(gcv.bias);
-  if (defer && !add1 && !add2 && !getenv("MURAL_TRAIN_NO_POOL_FOLD")) {
+  if (defer && !add1 && !add2 && !dev_env("MURAL_TRAIN_NO_POOL_FOLD")) {
     *defer = BnApplyJob{dz, x, (int64_t)c.P->B * L, pre_relu, state, bn.weight, acc, nullptr, nullptr, nullptr, const_cast<float*>(gbn.weight),
                         const_cast<float*>(gbn.bias)};
     return MURAL_OK;
@@ -477,7 +477,7 @@ int stage_b(Ctx& c, const MuralResBlock* rb, const MuralResBlock* grb, const flo
             float* d_in, float* const* tmp, FirstFold* defer = nullptr) {
   float *dz = tmp[0], *ga = tmp[1], *gb = tmp[2];
   if (defer) defer->dz = nullptr;
-  if (use_wave_conv(L, 0, false, 0) && !getenv("MURAL_TRAIN_NO_FOLD")) {
+  if (use_wave_conv(L, 0, false, 0) && !dev_env("MURAL_TRAIN_NO_FOLD")) {
     // Three of the four BatchNorm-backward applies of the stage never run as passes of their own: the conv backward of the layer in
     // front makes its dy from (dz, saved input, sums) of the layer behind while it stages it (conv32_wave.hip, FOLD) -- a read of two
     // tensors instead of one there against a pass of two reads and a write here.  Only d x1, which two consumers need, is also
@@ -496,7 +496,7 @@ int stage_b(Ctx& c, const MuralResBlock* rb, const MuralResBlock* grb, const flo
     // layer 0: dy = d h = apply of layer 1
     ConvBwdFold f0{A, s.t[0], s.state[1], rb[0].bn2.weight, s.acc_b[1], 1, gbn(grb[0].bn2).first, gbn(grb[0].bn2).second, nullptr, nullptr};
     if (int rc = conv_b_fold(c, nullptr, x_in, L, s.state[0], rb[0].bn1, rb[0].conv1, s.acc_b[0], grb[0].conv1, Bz, f0)) return rc;
-    if (defer && !getenv("MURAL_TRAIN_NO_FIRST_FOLD")) {
+    if (defer && !dev_env("MURAL_TRAIN_NO_FIRST_FOLD")) {
       *defer = FirstFold{Bz, x_in, gb, d_out, s.state[0], rb[0].bn1.weight, s.acc_b[0], (double)c.P->B * L, const_cast<float*>(grb[0].bn1.weight),
                          const_cast<float*>(grb[0].bn1.bias)};
       return MURAL_OK;
@@ -566,7 +566,7 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
   // wave kernels, is never materialised: conv_mid's backward makes it while staging (FOLD with the stage's two residual gradients)
   float* d_in3 = b.s3.t[3];
   FirstFold f3{};
-  if (int rc = stage_b(c, T.rbs2, G.rbs2, b.x0b, g.L[1], b.s3, g3, d_in3, tmp, wave2 && !getenv("MURAL_TRAIN_NO_MID_FOLD") ? &f3 : nullptr)) return rc;
+  if (int rc = stage_b(c, T.rbs2, G.rbs2, b.x0b, g.L[1], b.s3, g3, d_in3, tmp, wave2 && !dev_env("MURAL_TRAIN_NO_MID_FOLD") ? &f3 : nullptr)) return rc;
   if (f3.dz) {
     // (stage_b's temporaries: dz = tmp[0] = g0, ga = tmp[1] = g1 (= f3.dz), gb = tmp[2] = g2 (= f3.add1); g3 = f3.add2: the conv's own
     // input gradient goes to g0, free again)
@@ -574,7 +574,7 @@ int tower_b(Ctx& c, int t, const MuralTower& T, const MuralTower& G, const float
     if (int rc = conv_b_fold(c, nullptr, b.p2, g.L[1], b.state_c2, T.bn_mid, T.conv_mid, b.acc_c2_b, G.conv_mid, g0, fold, 0)) return rc;
     ap2 = BnApplyJob{g0, b.p2, (int64_t)B * g.L[1], 0, b.state_c2, T.bn_mid.weight, b.acc_c2_b, nullptr, nullptr, nullptr,
                      const_cast<float*>(G.bn_mid.weight), const_cast<float*>(G.bn_mid.bias)};
-    if (getenv("MURAL_TRAIN_NO_POOL_FOLD")) {
+    if (dev_env("MURAL_TRAIN_NO_POOL_FOLD")) {
       if (int rc = cl_bn_bwd_apply(g0, b.p2, (int64_t)B * g.L[1], 0, b.state_c2, T.bn_mid.weight, b.acc_c2_b, nullptr, nullptr, g1,
                                    const_cast<float*>(G.bn_mid.weight), const_cast<float*>(G.bn_mid.bias), st)) return rc;
       ap2.dz = nullptr;
@@ -698,7 +698,7 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   }
   conv_weight_table(c);
   if (int rc = cw_wfrag_build(c.conv_w, 20, P.wfrag, (hipStream_t)stream)) return rc;     // (weights are the same in the backward of this step)
-  if (!getenv("MURAL_TRAIN_FIRST_SEPARATE")) {      // both towers' symbol histograms in one launch, both table sets in one launch
+  if (!dev_env("MURAL_TRAIN_FIRST_SEPARATE")) {      // both towers' symbol histograms in one launch, both table sets in one launch
     const int col0[2] = {P.geo[1].col0, P.geo[0].col0}, L1[2] = {P.geo[1].L1, P.geo[0].L1};
     const MuralTower* T[2] = {&params->large, &params->mid};
     const float* gamma[2] = {T[0]->bn_in.weight, T[1]->bn_in.weight};
@@ -720,7 +720,7 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
   // three streams: large tower (caller's) | mid tower | local branch.  The large tower is the critical path, so it is enqueued
   // first: the ~70 launches of the other two would otherwise hold its first kernel back by their enqueue time
-  static const int order = getenv("MURAL_TRAIN_ORDER") ? atoi(getenv("MURAL_TRAIN_ORDER")) : 0;      // experiment: 1 = local branch first
+  static const int order = dev_env("MURAL_TRAIN_ORDER") ? atoi(dev_env("MURAL_TRAIN_ORDER")) : 0;      // experiment: 1 = local branch first
   int rc_loc = MURAL_OK;
   if (order == 1 && m == 2) {
     c.stream = ss->side2;
@@ -761,7 +761,7 @@ extern "C" int mural_snv_train_backward(const MuralSnvShape* shape, const MuralS
   SideStreamHold ss;      // holds the device's side streams until this call has joined them again
   if (int rc = ss.acquire()) return rc;
   if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
-  static const int order = getenv("MURAL_TRAIN_ORDER") ? atoi(getenv("MURAL_TRAIN_ORDER")) : 0;      // experiment: 1 = local branch first
+  static const int order = dev_env("MURAL_TRAIN_ORDER") ? atoi(dev_env("MURAL_TRAIN_ORDER")) : 0;      // experiment: 1 = local branch first
   int rc_loc = MURAL_OK;
   if (order == 1 && m == 2) {
     c.stream = ss->side2;

@@ -1163,115 +1163,11 @@ extern "C" int mural_op_conv1d(const float* in, const float* wt, const float* bi
   return launch_conv1d(a, STREAM);
 }
 
-namespace mural { void conv1d_mfma_set_stamps(unsigned long long* p); extern unsigned long long* g_cb8_stamps; }
-// diagnostic (tools/phase_stamps_conv1d.py): the MFMA conv's workgroups record 5 s_memrealtime values each (start, tile staged, MFMAs
-// done, stores issued, stores landed) into `stamps` (device, 5 x workgroups of the next launches; NULL switches it off)
-extern "C" int mural_debug_conv1d_set_stamps(unsigned long long* stamps) {
-  mural::conv1d_mfma_set_stamps(stamps);
-  return MURAL_OK;
-}
-// the same for the level-0 MFMA ConvBlock kernel (convblock8_mfma.hip): 8 accumulators per workgroup -- the time between the phase
-// boundaries of a tile summed over its tiles (100 MHz units), word 7 = tiles walked
-extern "C" int mural_debug_cb8_set_stamps(unsigned long long* stamps) {
-  mural::g_cb8_stamps = stamps;
-  return MURAL_OK;
-}
 
-// (validation only) every CU's whole LDS filled with NaN: what a kernel reads from LDS without having written it shows up in its results
-__global__ __launch_bounds__(256) void lds_poison_kernel(float* sink) {
-  extern __shared__ float lds_all[];
-  for (int i = threadIdx.x; i < 160 * 256; i += 256) lds_all[i] = __builtin_nanf("");
-  __syncthreads();
-  if (sink && lds_all[(threadIdx.x * 97) % (160 * 256)] == 1.f) sink[0] = 1.f;
-}
-static int poison_lds(hipStream_t stream) {
-  MURAL_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void*>(lds_poison_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  hipLaunchKernelGGL(lds_poison_kernel, dim3(2048), dim3(256), 160 * 1024, stream, (float*)nullptr);
-  MURAL_HIP_CHECK(hipGetLastError());
-  return MURAL_OK;
-}
-// validation hook: fill every CU's LDS with NaN on `stream` (tests call it in front of a product call whose result they check: a
-// kernel whose result depends on LDS it has not written then fails its parity comparison instead of passing by the luck of the leftovers)
-extern "C" int mural_debug_poison_lds(void* stream) { return poison_lds(STREAM); }
-
-// validation hook (tests/test_gpu_indel.py): the generic conv with every geometry knob of Conv1dArgs, on the vector-ALU kernel
-// (engine 0), the MFMA implicit-GEMM kernel (engine 1), the router's choice (engine 2), the polyphase form (3) or the barrier-free
-// long-row kernel (engine 4, conv1d_direct.hip)
-extern "C" int mural_debug_conv1d(const float* in, const float* wt, const float* bias, float* out, int64_t B, int32_t Cin, int32_t Lin,
-                                  int32_t Cout, int32_t Lout, int32_t K, int32_t stride, int32_t up, int32_t act, const float* res1,
-                                  const float* res2, int32_t engine, void* stream) {
-  Conv1dArgs a;
-  std::memset(&a, 0, sizeof(a));
-  a.in = in; a.wt = wt; a.bias = bias; a.out = out;
-  a.B = (int)B; a.Cin = Cin; a.Lin = Lin; a.Cout = Cout; a.Lout = Lout;
-  a.K = K; a.stride = stride; a.pad = (K - 1) / 2; a.up = up;
-  a.act = act; a.res1 = res1; a.res2 = res2;
-  if (engine & 0x100) {      // every CU's LDS filled with NaN first
-    engine &= 0xff;
-    if (int rc = poison_lds(STREAM)) return rc;
-  }
-  if (engine == 1) {
-    MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA): unsupported geometry");
-    return launch_conv1d_mfma(a, STREAM);
-  }
-  if (engine == 4) {
-    MURAL_REQUIRE(conv1d_direct_supported(a), "conv1d (direct MFMA): unsupported geometry");
-    return launch_conv1d_direct(a, STREAM);
-  }
-  if (engine == 3 || engine == 5) {     // polyphase form of the upsampled conv: weights expanded on the host once per weight tensor (kept for repeats)
-    MURAL_REQUIRE(up > 1 && stride == 1, "polyphase conv: needs up > 1, stride 1");
-    static const float* last_wt = nullptr;
-    static float* dw = nullptr;
-    static int kj = 0, padj = 0;
-    if (last_wt != wt) {
-      std::vector<float> hw((size_t)Cin * K * Cout), pw;
-      MURAL_HIP_CHECK(hipMemcpy(hw.data(), wt, hw.size() * 4, hipMemcpyDeviceToHost));
-      conv1d_phase_weights(hw.data(), Cin, K, Cout, up, &pw, &kj, &padj);
-      if (dw) (void)hipFree(dw);
-      MURAL_HIP_CHECK(hipMalloc(&dw, pw.size() * 4));
-      MURAL_HIP_CHECK(hipMemcpy(dw, pw.data(), pw.size() * 4, hipMemcpyHostToDevice));
-      last_wt = wt;
-    }
-    a.wt = dw; a.K = kj; a.pad = padj; a.up = 1; a.phases = up;
-    if (engine == 5) {
-      MURAL_REQUIRE(conv1d_direct_poly_supported(a), "conv1d (direct MFMA, polyphase): unsupported geometry");
-      return launch_conv1d_direct_poly(a, STREAM);
-    }
-    MURAL_REQUIRE(conv1d_mfma_supported(a), "conv1d (MFMA, polyphase): unsupported geometry");
-    return launch_conv1d_mfma(a, STREAM);
-  }
-  return engine == 0 ? launch_conv1d_valu(a, STREAM) : launch_conv1d(a, STREAM);
-}
 
 // validation hook (tests/test_gpu_indel.py): one fused ConvBlock launch (conv1d.hip / convblock_mfma.hip) with its optional front
 // (k = 7 conv Cf -> C on the input upsampled f_up times; f_up < 0: strided by -f_up instead), skip tensor and tail.  form: 0 the 8-channel block entirely on the vector
 // ALU, 1 its split form (convs on the matrix cores), -1 the library's choice.
-namespace mural { extern int g_convblock8_form; }
-extern "C" int mural_debug_convblock(const float* x, const float* w5, const float* b5, const float* w1, const float* b1,
-                                     const float* res2, float* out, int64_t B, int32_t Cch, int32_t L, const float* f_in,
-                                     const float* f_w, const float* f_b, int32_t Cf, int32_t f_up, const float* f_pw, const float* ta_w,
-                                     const float* ta_b, const float* tb_w, const float* tb_b, float* tail_max, int32_t form, void* stream) {
-  ConvBlockArgs a;
-  std::memset(&a, 0, sizeof(a));
-  a.x = x; a.w5 = w5; a.b5 = b5; a.w1 = w1; a.b1 = b1; a.res2 = res2; a.out = out;
-  a.B = (int)B; a.C = Cch; a.L = L;
-  if (f_in && f_up < 0) {      // a STRIDED k = 7 front (stride -f_up, source rows of L * stride columns): convblock_deep.hip
-    a.f_in = f_in; a.f_w = f_w; a.f_b = f_b; a.Cf = Cf; a.f_up = 1; a.f_stride = -f_up; a.Lf = L * a.f_stride;
-  } else if (f_in) {
-    MURAL_REQUIRE(f_up >= 1 && L % f_up == 0, "convblock: the front's upsampling factor must divide the row length");
-    a.f_in = f_in; a.f_w = f_w; a.f_b = f_b; a.Cf = Cf; a.f_up = f_up; a.Lf = L / f_up;
-    a.f_pw = f_pw;      // optional (f_up == 4): the front's polyphase weights [4][Cf][3][C]
-  }
-  a.ta_w = ta_w; a.ta_b = ta_b; a.tb_w = tb_w; a.tb_b = tb_b; a.tail_max = tail_max;
-  if (form >= 0 && (form & 0x100)) {      // poison LDS first; the low byte is the form (0xff: the library's choice)
-    form = (form & 0xff) == 0xff ? -1 : (form & 0xff);
-    if (int rc = poison_lds(STREAM)) return rc;
-  }
-  mural::g_convblock8_form = form;
-  const int rc = launch_convblock(a, STREAM);
-  mural::g_convblock8_form = -1;
-  return rc;
-}
 
 // Batch sums live in an accumulator block acc = double[MURAL_BN_SLOTS][2][C] (zeroed by the caller): workgroups add into
 // the copy picked by their index, readers sum the copies.  [k][0][c] = sum, [k][1][c] = sum of squares (forward) or
@@ -1408,7 +1304,7 @@ extern "C" int mural_op_first_fwd(const uint8_t* sym, int64_t B, int32_t Lwin, i
                                   int32_t ps, int32_t pp, const float* gamma, const float* beta, const float* W,
                                   const float* bias, float eps, float momentum, float* running_mean, float* running_var,
                                   unsigned long long* counts, float* tab, float* y, void* arg, void* stream) {
-  static const int cl = (getenv("MURAL_DEBUG_FIRST_CL") && C == 32) ? 1 : 0;
+  static const int cl = (dev_env("MURAL_DEBUG_FIRST_CL") && C == 32) ? 1 : 0;
   return first_fwd_impl(sym, B, Lwin, col0, L1, C, pk, ps, pp, gamma, beta, W, bias, eps, momentum, running_mean, running_var, counts, tab, y,
                         arg, cl, nullptr, stream);
 }
@@ -1432,7 +1328,7 @@ static int first_bwd_impl(const float* dy, const void* arg, const uint8_t* sym, 
     float* red = scratch + (size_t)FIRST_TRAIN_MAXGRID * SNV_LUTBLK;
     if (int rc = launch_first_train(a, true, STREAM)) return rc;
     // (MURAL_DEBUG_FIRST_SCATTER=1 without a fold keeps the LDS-atomic scatter kernel, whose blocks carry a 3-mer part: launch_first_train)
-    if (cl && (fold || !getenv("MURAL_DEBUG_FIRST_SCATTER"))) {      // first_bwd_cl_kernel fills the per-tap and bias parts only (its 3-mer part is zero, not read)
+    if (cl && (fold || !dev_env("MURAL_DEBUG_FIRST_SCATTER"))) {      // first_bwd_cl_kernel fills the per-tap and bias parts only (its 3-mer part is zero, not read)
       constexpr int N = SNV_TAPS + SNV_C;
       hipLaunchKernelGGL(first_part_reduce_kernel, dim3((N + 63) / 64), dim3(1024), 0, STREAM, scratch + SNV_LUT, B ? nblk : 0, N, SNV_LUTBLK,
                          red + SNV_LUT);
@@ -1463,7 +1359,7 @@ extern "C" int mural_op_first_bwd(const float* dy, const void* arg, const uint8_
                                   void* stream) {
   // (MURAL_DEBUG_FIRST_CL=1: tools/phase_stamps_first.py times the channel-last form of the composed step through this entry; the
   // buffers have the same sizes, only the element order of dy differs)
-  static const int cl = (getenv("MURAL_DEBUG_FIRST_CL") && C == 32) ? 1 : 0;
+  static const int cl = (dev_env("MURAL_DEBUG_FIRST_CL") && C == 32) ? 1 : 0;
   return first_bwd_impl(dy, arg, sym, B, Lwin, col0, L1, C, pk, ps, pp, tab, W, scratch, dW, dbias, dgamma, dbeta, cl, nullptr, stream);
 }
 

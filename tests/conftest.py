@@ -7,6 +7,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+# The suite runs on the DEBUG flavour of the library (mural_amd/libmural_hip_debug.so): the very objects of libmural_hip.so plus
+# csrc/debug_hooks.hip -- the validation hooks of include/mural_hip_debug.h (LDS poisoning in front of every GPU test, the conv kernels
+# on their own, workspace guard zones) and the development switches the A/B tests flip.  The product library exports no hook and reads
+# no switch; tests/test_product_library.py checks it (exports, a stray switch is ignored, smoke + golden parity through it).
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

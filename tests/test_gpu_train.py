@@ -402,7 +402,7 @@ def test_train_step_with_local_order_6_embedding_table():
         sd = synth.synth_state_dict(orc.state_dict(), 606)
         orc.load_state_dict(sd)
         model.load_state_dict(sd)
-        assert model.state_dict()["emb_layer.weight"].shape[0] == 4097
+        assert [v.shape[0] for k, v in model.state_dict().items() if k.endswith("emb_layer.weight")] == [4097]
         for m in model.modules():
             if isinstance(m, nn.Dropout):
                 m.p = 0.0

@@ -13,17 +13,51 @@ from tests import _util as U
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_abi_library_exports_every_declared_symbol():
-    from mural_amd import _lib
-    header = open(os.path.join(ROOT, "include", "mural_hip.h")).read()
+def _declared(header_name):
+    header = open(os.path.join(ROOT, "include", header_name)).read()
     header = re.sub(r"/\*.*?\*/", "", header, flags=re.S)        # symbols named in comments are not declarations
-    declared = set(re.findall(r"\b(mural_[a-z0-9_]+)\s*\(", header))
-    assert declared, "no declarations parsed"
-    lib = ctypes.CDLL(_lib.LIB_PATH)
+    return set(re.findall(r"\b(mural_[a-z0-9_]+)\s*\(", header))
+
+
+def test_abi_library_exports_every_declared_symbol():
+    """Both flavours export every symbol of include/mural_hip.h; the product library exports NO validation hook, the debug flavour all of
+    include/mural_hip_debug.h; the ctypes prototypes cover exactly the declarations."""
+    import subprocess
+    from mural_amd import _lib
+    declared, hooks = _declared("mural_hip.h"), _declared("mural_hip_debug.h")
+    assert declared and hooks and not any(n.startswith("mural_debug_") for n in declared)
+    assert all(n.startswith("mural_debug_") for n in hooks)
+    product, debug = ctypes.CDLL(_lib.LIB_PATH), ctypes.CDLL(_lib.DEBUG_LIB_PATH)
     for name in sorted(declared):
-        assert hasattr(lib, name), f"{name} is declared in include/mural_hip.h but not exported"
+        assert hasattr(product, name), f"{name} is declared in include/mural_hip.h but not exported"
+        assert hasattr(debug, name)
+    for name in sorted(hooks):
+        assert hasattr(debug, name), f"{name} is declared in include/mural_hip_debug.h but not exported by the debug flavour"
+        assert not hasattr(product, name), f"the product library exports the validation hook {name}"
+    exported = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "mural_debug" not in exported
     assert declared == set(_lib.PROTOTYPES), declared ^ set(_lib.PROTOTYPES)
+    assert hooks == set(_lib.DEBUG_PROTOTYPES), hooks ^ set(_lib.DEBUG_PROTOTYPES)
     assert _lib.lib().mural_abi_version() >= 1
+
+
+def test_every_development_switch_is_in_the_one_table():
+    """The product library reads MURAL_HOST_THREADS and TMPDIR; every other environment switch of csrc/ goes through dev_env() and is
+    listed in dev_switch_table (one line of description each), which only the debug flavour honours."""
+    import glob
+    from mural_amd import _lib
+    assert _lib.flavor() == "debug"
+    buf = ctypes.create_string_buffer(1 << 16)
+    n = _lib.lib().mural_debug_list_switches(buf, len(buf))
+    table = dict(ln.split("\t", 1) for ln in buf.value.decode().splitlines())
+    assert len(table) == n and all(len(v) > 10 for v in table.values())
+    used, raw = set(), set()
+    for path in glob.glob(os.path.join(ROOT, "mural_amd", "csrc", "*.h*")):
+        src = open(path).read()
+        used |= set(re.findall(r'dev_env\("([A-Z_0-9]+)"\)', src))
+        raw |= set(re.findall(r'(?<![a-z_])getenv\("([A-Z_0-9]+)"\)', src))
+    assert used == set(table), used ^ set(table)
+    assert raw == {"MURAL_HOST_THREADS", "TMPDIR"}, raw
 
 
 def _cfg(r=7, R=1000, n_class=4):

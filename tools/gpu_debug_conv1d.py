@@ -2,6 +2,7 @@
 torch in float64 on the CPU, over the layer geometries of UNet_Small (strides 4 / 5 / 2, upsampling 2 / 5 / 4, k = 7 / 5 / 1,
 16..96 channels, rows of 8..2000 columns) plus ragged batches.  With MURAL_TEST_VERBOSE: microseconds per launch of both."""
 import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import sys
 import time
 

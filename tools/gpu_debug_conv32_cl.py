@@ -4,6 +4,7 @@ forward with BatchNorm finalisation, residuals and fused batch sums; backward wi
 BatchNorm-backward sums.  Prints the worst relative error per quantity; exits non-zero above 1e-4."""
 import ctypes as C
 import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import sys
 
 import torch

@@ -1,6 +1,8 @@
 """Validation: the fused ConvBlock launch (mural_debug_convblock) against torch float64 -- plain block, with the k = 7 front (upsampled
 or not), skip tensor and tail; the 8-channel block in both forms (0 vector ALU, 1 split: convs on the matrix cores).  TIME=1 adds
 timings of the two forms at the bench geometry."""
+import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import os, sys, time
 import torch
 import torch.nn.functional as F

@@ -1,5 +1,7 @@
 """Diagnostic: the MFMA weight-gradient kernel against torch's conv gradients (float64) over the U-Net's shapes, and its timing against
 the vector-ALU kernel (MURAL_WGRAD_MFMA=0 in a second process)."""
+import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

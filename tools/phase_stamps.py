@@ -1,5 +1,6 @@
 """Diagnostic (GPU box): per-phase cycle shares of wave 0 in the fused tower kernel (s_memtime stamps)."""
 import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import sys
 
 import torch

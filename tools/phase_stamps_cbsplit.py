@@ -1,6 +1,8 @@
 """Diagnostic: phase times of the split-form 8-channel ConvBlock (conv1d.hip, convblock_kernel<8, ., ., true>) at the bench geometry
 (2048 rows of 8000): per workgroup the first thread's clock at entry / front input staged / block input ready / SiLU done / block
 output ready / exit (mural_debug_cb8_set_stamps), averaged; and the number of workgroups alive at a time."""
+import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,7 @@
 """Diagnostic: where the time of a short MFMA conv launch goes (mural_debug_conv1d_set_stamps: 5 s_memrealtime values per workgroup --
 start, tile staged, MFMAs done, stores issued, stores landed; 100 MHz clock = 10 ns units)."""
+import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

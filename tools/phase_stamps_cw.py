@@ -1,6 +1,7 @@
 """GPU box: where a launch of the wave-private training conv (forward) spends its time -- per-workgroup wall-clock stamps at entry,
 behind the prologue, behind the unit loop and at exit (mural_debug_cw_set_stamps), next to the launch-to-launch time on the host."""
 import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import sys
 import time
 

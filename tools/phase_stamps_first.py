@@ -2,6 +2,7 @@
 stamps of wave 0 of every workgroup (mural_debug_first_set_stamps) at entry / tables ready / window in LDS / window indices built / row
 done / every wave done / exit, next to the launch-to-launch time, for the large (pool 15) and the mid (pool 3) tower at batch 4096."""
 import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import sys
 import time
 

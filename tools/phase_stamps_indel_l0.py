@@ -1,6 +1,8 @@
 """Diagnostic: phase times of the two level-0 launches of the INDEL forward on the packed entry (2048 positions of L = 8000): per workgroup
 the first thread's clock at entry / front input staged / block input ready / SiLU done / block output ready / exit
 (mural_debug_cb8_set_stamps; MURAL_DEBUG_CB_STAMP_ONLY picks the launch)."""
+import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import os, sys
 import numpy as np
 import torch

@@ -1,5 +1,6 @@
 """GPU box: phases of the fused local branch's backward launches inside one training step at batch 4096 (mural_debug_lt_set_stamps)."""
 import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import sys
 
 import numpy as np

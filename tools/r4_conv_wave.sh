@@ -1,3 +1,4 @@
+export MURAL_HIP_FLAVOR=debug      # development switches are honoured by the debug flavour of the library only
 cd $GRAFT_REPO_ROOT
 mkdir -p gpurun_out/r4a
 (WHICH=cw timeout 600 python tools/gpu_debug_conv32_cl.py) > gpurun_out/r4a/parity.txt 2>&1

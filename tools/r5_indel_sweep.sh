@@ -1,4 +1,5 @@
 #!/bin/bash
+export MURAL_HIP_FLAVOR=debug      # development switches are honoured by the debug flavour of the library only
 # the INDEL forward (8192 positions, packed entry) with each of its A/B switches flipped -- are the defaults still the best?
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 run() { printf "%-36s " "$*"; env "$@" timeout 200 python3 $REPO/tools/bench_indel.py 8192 packed 2>&1 | tail -1; }

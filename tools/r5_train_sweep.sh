@@ -1,4 +1,5 @@
 #!/bin/bash
+export MURAL_HIP_FLAVOR=debug      # development switches are honoured by the debug flavour of the library only
 # the SNV training step (symbol route, batch 4096) with each of the step's A/B switches flipped -- are the defaults still the best?
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 run() { printf "%-36s " "$*"; env "$@" timeout 200 python3 $REPO/tools/bench_train_sym.py 2>&1 | tail -1; }

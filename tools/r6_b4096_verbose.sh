@@ -1,3 +1,4 @@
+export MURAL_HIP_FLAVOR=debug      # development switches are honoured by the debug flavour of the library only
 cd $GRAFT_REPO_ROOT
 for v in 0 1; do
 echo "== MURAL_CW_FULL_GRID=$v"

@@ -1,4 +1,5 @@
 #!/bin/bash
+export MURAL_HIP_FLAVOR=debug      # development switches are honoured by the debug flavour of the library only
 # round 6: the SNV training step with the conv launches asking for fewer workgroup slots (so that the two towers' launches are
 # co-resident instead of time-sharing the CUs): MURAL_CW_WGS_{LARGE9,MID9,SHORT}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}

@@ -2,6 +2,7 @@
 training shapes."""
 import ctypes as C
 import os
+os.environ.setdefault("MURAL_HIP_FLAVOR", "debug")      # validation hooks / development switches: the debug flavour of the library
 import sys
 import time
 
