@@ -292,7 +292,7 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
                    "route, tests/test_gpu_train.py); steps_per_s = %d steps without a host sync in between" % steps,
            "roofline": {"flop_per_step": FLOP_TRAIN_PER_SITE * B, "achieved_TFLOPs": tflops, "peak_TFLOPs": PEAK_FP32_MFMA_TFLOPS,
                         "frac_mfma": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r05_train_step")      # profiled on the symbol route: the loop whose rate steps_per_s is
+    fact = profile_fact("r06_train_step") or profile_fact("r05_train_step")      # profiled on the symbol route: the loop whose rate steps_per_s is
     if fact:
         hbm = fact.get("hbm_bytes_per_unit", fact.get("hbm_bytes_per_step"))
         gbs = hbm / t / 1e12
@@ -346,7 +346,7 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
            "note": "window decode from the packed genome inside the timed region; 113.4 MFLOP/position",
            "roofline": {"bound": "mfma", "achieved": tflops, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                         "frac": tflops / PEAK_FP32_MFMA_TFLOPS}}
-    fact = profile_fact("r05_indel_forward_pmc") or profile_fact("r04_indel_forward_pmc")
+    fact = profile_fact("r06_indel_forward_pmc") or profile_fact("r05_indel_forward_pmc")
     if fact:
         per_pos = fact["hbm_bytes_per_unit"] / 2048.0      # (the profiled unit is one forward of 2048 positions)
         tbs = per_pos * n / dt / 1e12
@@ -422,7 +422,7 @@ def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
                             "bound by the device alone); ms_per_step is the EAGER loop's",
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s", "frac": tf / PEAK_FP32_MFMA_TFLOPS,
                                  "flop_per_step": 3 * FLOP_INDEL_PER_POS * tb}}
-    tfact = profile_fact("r05_indel_train")
+    tfact = profile_fact("r06_indel_train") or profile_fact("r05_indel_train")
     if tfact and tfact.get("hbm_bytes_per_step"):
         tb_s = tfact["hbm_bytes_per_step"] / dt / 1e12
         out["train"]["roofline"].update({"hbm_bytes_per_step": tfact["hbm_bytes_per_step"], "achieved_TBs": tb_s, "frac_hbm": tb_s / PEAK_HBM_TBS,
@@ -1007,10 +1007,10 @@ def main():
         # HBM bytes per launch: PMC counters need their own profiler passes, so the figure comes from the committed summary of
         # those passes over this same command (tools/profile_bench.sh -> profiles/hbm_traffic.json), scaled to this run's launches
         traffic, traffic_source = None, None
-        fact = profile_fact("r05_predict") or profile_fact("r04_predict")
+        fact = profile_fact("r06_predict") or profile_fact("r05_predict")
         if fact and fact.get("tower_hbm_bytes_per_site"):
             traffic = fact["tower_hbm_bytes_per_site"] * sites_per_launch
-            traffic_source = "profiles/%s.json: %s" % ("r05_predict" if profile_fact("r05_predict") else "r04_predict", fact.get("source", ""))
+            traffic_source = "profiles/%s.json: %s" % ("r06_predict" if profile_fact("r06_predict") else "r05_predict", fact.get("source", ""))
         pmc = (fact or {}).get("all_launches", {})
         line = {
             "metric": "predicted bases/s (SNV local=10/distal=1000, 4-class, predict)",
@@ -1029,7 +1029,7 @@ def main():
                          "frac": achieved / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic, "traffic_source": traffic_source,
                          "flop_per_launch": FLOP_TOWERS * sites_per_launch, "sites_per_launch": sites_per_launch,
                          "avg_launch_ms": kernel_ms, "launches": int(k_n.value),
-                         # from the committed PMC passes (profiles/r05_predict.json), not measured in this run:
+                         # from the committed PMC passes (profiles/r06_predict.json), not measured in this run:
                          "profiled_mfma_pipe_busy": pmc.get("mfma_pipe_busy"), "profiled_held_clock_ghz": pmc.get("held_clock_ghz"),
                          "profiled_valu_per_mfma": pmc.get("valu_insts_per_mfma_excl_mfma"),
                          "note": "four launches per chunk of <= 131072 sites: (large | mid tower) x (first conv stage | the two short "

@@ -95,6 +95,7 @@ class _HostSymbolRoute:
 
     def __init__(self, model, device, fuse_rows):
         self.model, self.device, self.L = model, device, model.seq_len
+        self.cap_rows = fuse_rows + 1024                  # a flush holds fuse_rows rows + what its last batch brought: pin once
         key = (fuse_rows, self.L)
         self.bufs = self._staging.setdefault(key, [None, None])
         self.small = self._staging.setdefault(("small",) + key, [None, None])
@@ -127,10 +128,10 @@ class _HostSymbolRoute:
         i = self.turn
         self.turn ^= 1
         if self.bufs[i] is None or self.bufs[i].numel() < rows * L:
-            self.bufs[i] = torch.empty(max(rows, 1) * L, dtype=torch.uint8).pin_memory()
+            self.bufs[i] = torch.empty(max(rows, self.cap_rows) * L, dtype=torch.uint8).pin_memory()
         need = rows * (8 * cols + 4)
         if self.small[i] is None or self.small[i].numel() < need:
-            self.small[i] = torch.empty(need, dtype=torch.uint8).pin_memory()
+            self.small[i] = torch.empty(max(rows, self.cap_rows) * (8 * cols + 4), dtype=torch.uint8).pin_memory()
         if self.events[i] is not None:
             self.events[i].synchronize()               # the copies out of these buffers two flushes ago
         nb = len(pending)

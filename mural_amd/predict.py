@@ -997,7 +997,9 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
             T["bed_parse"] += clock() - t0
             if hasattr(forward, "prefetch") and si + 1 < len(names):
                 forward.prefetch(names[si + 1])
-            pos_b, strand_b = up(start_h), up(strand_h)
+            # every site column goes up BEFORE the forward is enqueued: a copy from pageable host memory waits for the stream's earlier
+            # work, and behind the forward it would hold the host for the whole compute instead of letting it parse the next chromosome
+            pos_b, strand_b, end_b, label_b = up(start_h), up(strand_h), up(end_h), up(label_h)
             t0 = clock()
             local = forward(chrom, pos_b if dev is not None else start_h, strand_b if dev is not None else strand_h)
             T["compute_enqueue"] += clock() - t0
@@ -1009,12 +1011,14 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
                 local = local.to(torch.float32)
             k = local.shape[1] - 1
             t0 = clock()
-            packed = _pack_rows(local, pos_b, up(end_h), strand_b, up(label_h))
+            packed = _pack_rows(local, pos_b, end_b, strand_b, label_b)
             T["pack_rows"] += clock() - t0
             t0 = clock()
             if emulate is not None and world > 1:
                 # stand-in for the other ranks' blocks: their site columns (parsed here, outside the share) next to copies of this
                 # rank's probability rows -- the gathered shard has the size, the sort keys and the text width of the real one
+                if dev is not None:
+                    torch.cuda.synchronize(dev)            # this rank's own work is charged to the share: the stand-in must not hide it
                 te = clock()
                 full = torch.empty((n, packed.shape[1]), dtype=torch.uint8, device=tdev)
                 for r in range(world):
@@ -1025,6 +1029,8 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
                     src = local[torch.arange(hi - lo, device=tdev) % max(local.shape[0], 1)] if local.shape[0] else \
                         torch.zeros((hi - lo, k + 1), dtype=local.dtype, device=tdev)
                     full[lo:hi] = _pack_rows(src, up(s2), up(e2), up(d2), up(l2))
+                if dev is not None:
+                    torch.cuda.synchronize(dev)            # ... and its device work is excluded with it
                 T["emulation"] += clock() - te
                 full[b0:b1] = packed                       # (the share's own copy: what the collective would deliver)
             else:
