@@ -44,3 +44,14 @@ with torch.no_grad():
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 2000
     print("16-site dense calls: %.1f us per call = %.0f bases/s" % (dt * 1e6, 16 / dt))
+    for nsite in (1, 16, 64, 256):
+        co, ca, xx = cont[:nsite], cat[:nsite].contiguous(), x[:nsite].contiguous()
+        for _ in range(50):
+            model((co, ca), xx)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(1000):
+            model((co, ca), xx)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / 1000
+        print("%d-site dense calls: %.1f us per call = %.0f bases/s" % (nsite, dt * 1e6, nsite / dt))
