@@ -6,7 +6,7 @@
   * train: BASELINE.json configs[2] — S-config from scratch, batch 4096, Adam, dropouts at defaults, N timed steps;
   * indel: BASELINE.json configs[3] — UNet_Small human-insertion geometry (L=8000, 8 classes, use_reverse) from the packed genome.
 
-Prints one JSON object per variant.  Usage: python tools/bench_variants.py [dense] [b16] [train] [indel]"""
+Prints one JSON object per variant.  Usage: python tools/archive/bench_variants.py [dense] [b16] [train] [indel]"""
 import json
 import os
 import sys

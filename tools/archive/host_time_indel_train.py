@@ -1,5 +1,5 @@
 """GPU box: where the host time of the INDEL training step goes (forward / loss / backward / clip / optimizer), no device syncs
-inside the loop.  usage: python tools/host_time_indel_train.py [batch]"""
+inside the loop.  usage: python tools/archive/host_time_indel_train.py [batch]"""
 import os
 import sys
 import time

@@ -26,5 +26,5 @@ for W in train indel; do
   rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/$W/pmcF -- python3 $PROG > $OUT/${W}_pmcF.log 2>&1
   rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/$W/pmcW -- python3 $PROG > $OUT/${W}_pmcW.log 2>&1
 done
-python3 $REPO/tools/profile_r02_facts.py $OUT
+python3 $REPO/tools/archive/profile_r02_facts.py $OUT
 ls $OUT

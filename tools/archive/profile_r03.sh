@@ -31,5 +31,5 @@ for W in train indel; do
 done
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/indel_train/trace -- python3 $REPO/tools/bench_indel_train.py > $OUT/indel_train_trace.log 2>&1
 python3 $REPO/tools/kernel_times.py $OUT/indel_train/trace 30 > $OUT/r03_indel_train_rocprof_summary.txt 2>&1
-python3 $REPO/tools/profile_r03_facts.py $OUT
+python3 $REPO/tools/archive/profile_r03_facts.py $OUT
 ls $OUT

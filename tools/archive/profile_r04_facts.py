@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 output of tools/profile_r04.sh (gpurun_out/prof_r04) into per-section summaries: kernel table from the
+"""Condense the rocprofv3 output of tools/archive/profile_r04.sh (gpurun_out/prof_r04) into per-section summaries: kernel table from the
 trace, HBM traffic from the FETCH_SIZE / WRITE_SIZE passes (FETCH doubled per the gfx950 correction for 16-byte-per-lane streaming
 reads, MI355X_MICROARCH.md), and per-kernel SQ facts from the two SQ passes (MFMA pipe busy, vector / LDS instructions per MFMA,
 wait fractions, LDS bank-conflict rate).  Writes r04_<section>_rocprof_summary.txt and r04_<section>.json next to the raw output."""
@@ -106,7 +106,7 @@ for sub, (units, uname) in UNITS.items():
                             fmt(rec["wait_any"]), fmt(rec["wait_inst_any"]), fmt(rec["lds_conflict"])))
         facts["sq"] = sq
     facts["source"] = ("rocprofv3 --kernel-trace --stats, and separate --pmc passes (FETCH_SIZE; WRITE_SIZE; two SQ sets) over the command of "
-                       "tools/profile_r04.sh section '%s'; summary: profiles/r04_%s_rocprof_summary.txt" % (sub, sub))
+                       "tools/archive/profile_r04.sh section '%s'; summary: profiles/r04_%s_rocprof_summary.txt" % (sub, sub))
     open(os.path.join(root, "r04_%s_rocprof_summary.txt" % sub), "w").write("\n".join(lines) + "\n")
     json.dump(facts, open(os.path.join(root, "r04_%s.json" % sub), "w"), indent=1)
     print("\n".join(lines[:12]))

@@ -5,7 +5,7 @@
 #   indel   : tools/bench_indel.py 2048 packed              -- kernel stats, FETCH_SIZE / WRITE_SIZE, two SQ passes
 #   indel_train : tools/bench_indel_train.py                -- kernel stats, FETCH_SIZE / WRITE_SIZE, two SQ passes
 #   reuse   : tools/bench_reuse.py (WHICH=reuse)            -- kernel stats
-# Counters are collected in their own runs with --kernel-trace only.  Writes gpurun_out/prof_r05/; tools/profile_r05_facts.py condenses
+# Counters are collected in their own runs with --kernel-trace only.  Writes gpurun_out/prof_r05/; tools/archive/profile_r05_facts.py condenses
 # it into the summaries copied to profiles/.
 set -u
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
@@ -39,5 +39,5 @@ for S in $SECTIONS; do
       rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/reuse/trace -- python3 $REPO/tools/bench_reuse.py > $OUT/reuse_trace.log 2>&1 ;;
   esac
 done
-python3 $REPO/tools/profile_r05_facts.py $OUT
+python3 $REPO/tools/archive/profile_r05_facts.py $OUT
 ls $OUT

@@ -1,4 +1,4 @@
-"""Condense the rocprofv3 output of tools/profile_r05.sh (gpurun_out/prof_r05) into per-section summaries: kernel table from the
+"""Condense the rocprofv3 output of tools/archive/profile_r05.sh (gpurun_out/prof_r05) into per-section summaries: kernel table from the
 trace, HBM traffic from the FETCH_SIZE / WRITE_SIZE passes (FETCH doubled per the gfx950 correction for 16-byte-per-lane streaming
 reads, MI355X_MICROARCH.md), and per-kernel SQ facts from the two SQ passes (MFMA pipe busy, vector / LDS instructions per MFMA,
 wait fractions, LDS bank-conflict rate).  Writes the files bench.py reads and profiles/ keeps: r05_train_step{.json,_rocprof_summary.txt}, r05_predict*, r05_indel_forward* (json:
@@ -126,7 +126,7 @@ for sub, (units, uname) in UNITS.items():
                                      "valu_insts_per_mfma_excl_mfma": (valu - m) / m if m else None,
                                      "held_clock_ghz": gui / 8.0 / (dur * 1e3) if dur else None}
     facts["source"] = ("rocprofv3 --kernel-trace --stats, and separate --pmc passes (FETCH_SIZE; WRITE_SIZE; two SQ sets) over the command of "
-                       "tools/profile_r05.sh section '%s'; summary: profiles/r05_%s_rocprof_summary.txt" % (sub, {"train": "train_step", "indel": "indel_forward"}.get(sub, sub)))
+                       "tools/archive/profile_r05.sh section '%s'; summary: profiles/r05_%s_rocprof_summary.txt" % (sub, {"train": "train_step", "indel": "indel_forward"}.get(sub, sub)))
     name = {"train": "train_step", "indel": "indel_forward"}.get(sub, sub)
     open(os.path.join(root, "r05_%s_rocprof_summary.txt" % name), "w").write("\n".join(lines) + "\n")
     json.dump(facts, open(os.path.join(root, "r05_%s.json" % ("indel_forward_pmc" if sub == "indel" else name)), "w"), indent=1)

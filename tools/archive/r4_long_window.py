@@ -1,4 +1,4 @@
-"""The long-window variant of bench.py alone (distal_radius 4000, 512 windows per call): python tools/r4_long_window.py"""
+"""The long-window variant of bench.py alone (distal_radius 4000, 512 windows per call): python tools/archive/r4_long_window.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

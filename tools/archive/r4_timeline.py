@@ -1,5 +1,5 @@
 """Timeline of one steady-state step in a rocprofv3 kernel trace: start offset, duration, queue of every launch, the union of busy
-time and the idle gaps.  python tools/r4_timeline.py <trace dir> [marker] [steps back]"""
+time and the idle gaps.  python tools/archive/r4_timeline.py <trace dir> [marker] [steps back]"""
 import csv, glob, os, re, sys
 f = sorted(glob.glob(os.path.join(sys.argv[1], "**/*kernel_trace.csv"), recursive=True), key=os.path.getmtime)[-1]
 rows = list(csv.DictReader(open(f)))

@@ -1,4 +1,4 @@
-"""bench.py's SNV training leg alone (un-synchronised steps), for A/B runs: python tools/r4_train_only.py [steps]"""
+"""bench.py's SNV training leg alone (un-synchronised steps), for A/B runs: python tools/archive/r4_train_only.py [steps]"""
 import os, sys, json
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,5 +1,5 @@
 """The training step fed with dense one-hot windows (the reference loader's form) against symbol windows, alternating, with the
-per-kernel picture of the dense route's extras.  usage: python tools/r5_dense_route.py [steps]"""
+per-kernel picture of the dense route's extras.  usage: python tools/archive/r5_dense_route.py [steps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/dn_tr
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dn_tr -- python3 $REPO/tools/r5_dense_route.py 20 > /tmp/dn_tr.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/dn_tr -- python3 $REPO/tools/archive/r5_dense_route.py 20 > /tmp/dn_tr.log 2>&1
 tail -6 /tmp/dn_tr.log
 python3 - <<P
 import csv,glob,collections

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Kernel durations of the INDEL level-0 launches under rocprofv3 (a lone 2048-position forward through the packed entry), once per
-# setting of the switch named in $1 (default: MURAL_INDEL_ENC0_DOWN) -- e.g.  bash tools/r5_l0_ab.sh MURAL_INDEL_DEC0
+# setting of the switch named in $1 (default: MURAL_INDEL_ENC0_DOWN) -- e.g.  bash tools/archive/r5_l0_ab.sh MURAL_INDEL_DEC0
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 SW=${1:-MURAL_INDEL_ENC0_DOWN}

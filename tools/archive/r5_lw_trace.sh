@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 rm -rf /tmp/lw_tr
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lw_tr -- python3 $REPO/tools/r4_long_window.py ${1:-2048} > /tmp/lw_tr.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/lw_tr -- python3 $REPO/tools/archive/r4_long_window.py ${1:-2048} > /tmp/lw_tr.log 2>&1
 head -3 /tmp/lw_tr.log
 python3 - <<P
 import csv,glob,collections

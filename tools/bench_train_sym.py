@@ -1,6 +1,6 @@
 """GPU box: the SNV training step exactly as bench.py's `train` leg composes it (symbol windows from the packed genome +
 mural_amd.train.CrossEntropySum + mural_amd.train.clip_grad_norm_ + fused Adam), 13 steps at batch 4096 -- the command of the round-5
-training profile (tools/profile_r05.sh), so that hbm_bytes_per_step / launches_per_step belong to the loop whose rate is reported."""
+training profile (tools/archive/profile_r05.sh), so that hbm_bytes_per_step / launches_per_step belong to the loop whose rate is reported."""
 import os
 import sys
 import time
