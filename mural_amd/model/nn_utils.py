@@ -105,9 +105,12 @@ class _HostSymbolRoute:
     def model_ok(model, model_type, distal):
         return model_type == "snv" and distal and getattr(model, "symbols_entry_ok", lambda: False)()
 
-    def gather(self, pending, rows):
-        """(symbols, cat_x, y) on the device for the waiting batches, or None if a batch is not what the reference's loader yields
-        (host fp32 (b, 4, L) windows, host int64 cat_x, host fp32 (b, 1) labels): the caller then takes the dense entry."""
+    _pool = None           # one helper thread: the host classification of flush k runs beside the collection of flush k + 1
+
+    def begin(self, pending, rows):
+        """Start the host side of a flush: checks and addresses here, classification + packing of the small fields on the helper thread.
+        Returns a job for ``finish`` -- or None if a batch is not what the reference's loader yields (host fp32 (b, 4, L) windows, host
+        int64 cat_x, host fp32 (b, 1) labels): the caller then takes the dense entry."""
         import ctypes as C
         from .. import _lib
         L, f32, i64 = self.L, torch.float32, torch.int64
@@ -135,19 +138,40 @@ class _HostSymbolRoute:
         if self.events[i] is not None:
             self.events[i].synchronize()               # the copies out of these buffers two flushes ago
         nb = len(pending)
-        lib, bad = _lib.lib(), C.c_int64(0)
+        lib = _lib.lib()
         sym_h, small = self.bufs[i], self.small[i]
-        _lib.check(lib.mural_host_dense_to_symbols((C.c_void_p * nb)(*xp), (C.c_int64 * nb)(*xn), nb, L, sym_h.data_ptr(), C.byref(bad)))
-        if bad.value:
+        args = ((C.c_void_p * nb)(*xp), (C.c_int64 * nb)(*xn), (C.c_void_p * nb)(*cp), (C.c_int64 * nb)(*cn), (C.c_void_p * nb)(*yp),
+                (C.c_int64 * nb)(*yn))
+
+        def host_work():
+            bad = C.c_int64(0)
+            _lib.check(lib.mural_host_dense_to_symbols(args[0], args[1], nb, L, sym_h.data_ptr(), C.byref(bad)))
+            _lib.check(lib.mural_host_concat(args[2], args[3], nb, small.data_ptr()))
+            _lib.check(lib.mural_host_concat(args[4], args[5], nb, small.data_ptr() + rows * 8 * cols))
+            return bad.value
+
+        if _HostSymbolRoute._pool is None:
+            from concurrent.futures import ThreadPoolExecutor
+            _HostSymbolRoute._pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="mural-host-classify")
+        return (_HostSymbolRoute._pool.submit(host_work), i, rows, cols, pending)      # (pending: the batches stay alive until read)
+
+    def finish(self, job):
+        """(symbols, cat_x, y) on the device for a job of ``begin``."""
+        fut, i, rows, cols, _ = job
+        if fut.result():
             raise ValueError(type(self.model)._ENC_MSG)
-        _lib.check(lib.mural_host_concat((C.c_void_p * nb)(*cp), (C.c_int64 * nb)(*cn), nb, small.data_ptr()))
-        _lib.check(lib.mural_host_concat((C.c_void_p * nb)(*yp), (C.c_int64 * nb)(*yn), nb, small.data_ptr() + rows * 8 * cols))
+        L, need = self.L, rows * (8 * cols + 4)
+        sym_h, small = self.bufs[i], self.small[i]
         sym = sym_h[:rows * L].view(rows, L).to(self.device, non_blocking=True)
-        cat_x = small[:rows * 8 * cols].view(i64).view(rows, cols).to(self.device, non_blocking=True)
-        y = small[rows * 8 * cols:need].view(f32).view(rows, 1).to(self.device, non_blocking=True)
+        cat_x = small[:rows * 8 * cols].view(torch.int64).view(rows, cols).to(self.device, non_blocking=True)
+        y = small[rows * 8 * cols:need].view(torch.float32).view(rows, 1).to(self.device, non_blocking=True)
         self.events[i] = torch.cuda.Event()
         self.events[i].record()
         return sym, cat_x, y
+
+    def gather(self, pending, rows):
+        job = self.begin(pending, rows)
+        return None if job is None else self.finish(job)
 
 
 def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, model_type="snv", fuse_rows=8192):
@@ -168,46 +192,68 @@ def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, 
     pending, rows = [], 0
 
     host_route, host_ok = None, _HostSymbolRoute.model_ok(model, model_type, distal)
+    in_flight = None       # a host-route flush whose classification runs on the helper thread: (job, batches)
+
+    def account(preds, y, batches):
+        outs.append(preds)
+        target = y.long().squeeze(1)
+        if additive or len(batches) == 1:
+            loss_acc.add_(criterion(preds, target).double())
+        else:
+            o = 0
+            for b in batches:
+                n = b[0].shape[0]
+                loss_acc.add_(criterion(preds[o:o + n], target[o:o + n]).double())
+                o += n
+
+    def complete():
+        nonlocal in_flight
+        if in_flight is None:
+            return
+        job, batches = in_flight
+        in_flight = None
+        with torch.cuda.device(device):
+            sym, cat_x, y = host_route.finish(job)
+            preds = model.forward_symbols(cat_x, sym)
+        account(preds, y, batches)
 
     def flush():
-        nonlocal pending, rows, host_route
+        nonlocal pending, rows, host_route, in_flight
         if not pending:
             return
-        staged = None
+        job = None
         if host_ok and not pending[0][3].is_cuda:
             if host_route is None:
                 host_route = _HostSymbolRoute(model, device, fuse_rows)
             with torch.cuda.device(device):
-                staged = host_route.gather(pending, rows)
-        if staged is not None:
-            sym, cat_x, y = staged
-            with torch.cuda.device(device):
-                preds = model.forward_symbols(cat_x, sym)
+                job = host_route.begin(pending, rows)      # the windows are classified on a helper thread while ...
+        complete()                                         # ... the previous flush is uploaded and launched, and the next one collected
+        if job is not None:
+            in_flight = (job, pending)
         else:
             y, cont_x, cat_x, distal_x = (_gather_to_device(pending, k, device) for k in range(4))
             if model_type == "snv":
                 preds = model.forward((cont_x, cat_x), distal_x) if distal else model.forward(cont_x, cat_x)
             else:
                 preds = model.forward(distal_x)
-        outs.append(preds)
-        target = y.long().squeeze(1)
-        if additive or len(pending) == 1:
-            loss_acc.add_(criterion(preds, target).double())
-        else:
-            o = 0
-            for b in pending:
-                n = b[0].shape[0]
-                loss_acc.add_(criterion(preds[o:o + n], target[o:o + n]).double())
-                o += n
+            account(preds, y, pending)
         pending, rows = [], 0
 
     with torch.no_grad():
-        for batch in dataloader:
-            pending.append(batch)
-            rows += batch[0].shape[0]
-            if rows >= fuse_rows:
-                flush()
-        flush()
+        try:
+            for batch in dataloader:
+                pending.append(batch)
+                rows += batch[0].shape[0]
+                if rows >= fuse_rows:
+                    flush()
+            flush()
+            complete()
+        finally:
+            if in_flight is not None:      # an error on the way: do not leave the helper thread writing into staging that will be reused
+                try:
+                    in_flight[0][0].result()
+                except Exception:      # noqa: BLE001
+                    pass
     check = getattr(getattr(model, "model", model), "check_encoding", None)     # Network0 wraps its body in .model
     if check is not None:
         check(wait=True)

@@ -256,12 +256,12 @@ def test_model_predict_m_contract():
     from mural_amd.model import nn_utils
     assert nn_utils._HostSymbolRoute.model_ok(model, "snv", True)
     taken = []
-    gather = nn_utils._HostSymbolRoute.gather
-    nn_utils._HostSymbolRoute.gather = lambda self, pending, rows: taken.append(rows) or gather(self, pending, rows)
+    begin = nn_utils._HostSymbolRoute.begin
+    nn_utils._HostSymbolRoute.begin = lambda self, pending, rows: taken.append(rows) or begin(self, pending, rows)
     try:
         pred_h, _ = model_predict_m(model, batches, nn.CrossEntropyLoss(reduction="sum"), torch.device("cuda"), 4, True, "snv")
     finally:
-        nn_utils._HostSymbolRoute.gather = gather
+        nn_utils._HostSymbolRoute.begin = begin
     assert taken == [len(fx["pred"])] and torch.equal(pred_h, pred)
     dev_batches = [tuple(t.cuda() for t in b) for b in batches]
     pred_d, total_d = model_predict_m(model, dev_batches, nn.CrossEntropyLoss(reduction="sum"), torch.device("cuda"), 4, True, "snv")
