@@ -172,6 +172,10 @@ struct SnvFwdArgs {
   // the favoured half of the waves is done at 0.72 of the launch and the rest finishes alone; nullptr: fixed stride
   int* unit_counter;
   int stagger;                    // wave-private launch: late start of every second workgroup of a CU, in units of 8128 cycles
+  // Long windows (run-time-geometry first-stage instance, one site per wave): the launch's "rows" are SEGMENTS of the large tower's
+  // pooled row read in place from x0 -- row v = segment v % seg_n of site v / seg_n, starting at column seg_col0 + (v % seg_n) *
+  // seg_step of that site's x0 row.  seg_n == 0: rows are sites (column offset by tower, as always).
+  int seg_n, seg_step, seg_col0;
 };
 
 // ---- cross-position reuse (snv_reuse.hip, snv_tower_wave.hip): the edge tile of a site

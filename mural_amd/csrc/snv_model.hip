@@ -319,8 +319,8 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
   size_t o_vxa = 0, o_vxb = 0, o_vsa = 0, o_vsb = 0;
   if (m->longwin) {
     const size_t cn = (size_t)std::min<int64_t>(n, m->chunk);
-    o_vxa = take(cn * m->lw_nA * m->lw_LA * SNV_C * 4);
-    o_vxb = take(cn * m->lw_LB * SNV_C * 4);
+    (void)o_vxa;      // (until round 6 the segments were copied out of x0 with their halo: 0.6 GB per chunk of 8192 sites at R = 4000)
+    (void)o_vxb;
     o_vsa = take(cn * m->lw_nA * m->args_lwA.geom[0].L[1] * SNV_C * 4);
     o_vsb = take(cn * m->args_lwB.geom[0].L[1] * SNV_C * 4);
   }
@@ -344,21 +344,6 @@ size_t carve(const MuralSnvModel* m, int64_t n, bool dense, void* base, Workspac
 
 // ---- long windows: segments of the large tower's pooled first-stage row (MuralSnvModel::longwin) -------------------------------
 // columns are 32 floats = 128 bytes: a thread moves 16 bytes, 8 threads a column
-// vx[(site * nseg + k)][c][32] = x0[site][start0 + k * step + c][32]
-__global__ void lw_gather_kernel(const float* __restrict__ x0, int64_t n, int x0_cols, int nseg, int start0, int step, int Lseg,
-                                 float* __restrict__ vx) {
-  const int64_t total = n * nseg * Lseg * 8;
-  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i & 7);
-    const int64_t col = i >> 3;
-    const int c = (int)(col % Lseg);
-    const int64_t row = col / Lseg;
-    const int k = (int)(row % nseg);
-    const int64_t site = row / nseg;
-    const float4 v = reinterpret_cast<const float4*>(x0 + ((size_t)site * x0_cols + start0 + (size_t)k * step + c) * SNV_C)[q];
-    reinterpret_cast<float4*>(vx + (size_t)col * SNV_C)[q] = v;
-  }
-}
 // s3[site][j][32] for j in [j_lo, j_hi): from segment k = (j - jbase) / nj (clamped to nseg - 1), local pooled column jl = j - k * nj
 __global__ void lw_scatter_kernel(const float* __restrict__ vs, int64_t n, int nseg, int Lp /* pooled columns of a segment */, int nj, int j_lo,
                                   int j_hi, int jl_shift, int L3, float* __restrict__ s3) {
@@ -697,15 +682,16 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
         const int LpA = m->args_lwA.geom[0].L[1], LpB = m->args_lwB.geom[0].L[1], L3 = m->args.geom[0].L[1], nj = m->lw_nj;
         const int x0_cols = m->args.x0_cols;
         auto grid_of = [](int64_t items) { return dim3((unsigned)std::min<int64_t>((items + 255) / 256, 65536)); };
-        hipLaunchKernelGGL(lw_gather_kernel, grid_of(cn * m->lw_nA * m->lw_LA * 8), dim3(256), 0, stream, w.x0, cn, x0_cols, m->lw_nA, 0,
-                           7 * nj, m->lw_LA, w.vx0A);
-        hipLaunchKernelGGL(lw_gather_kernel, grid_of(cn * m->lw_LB * 8), dim3(256), 0, stream, w.x0, cn, x0_cols, 1, m->lw_SB, 0, m->lw_LB,
-                           w.vx0B);
-        MURAL_HIP_CHECK(hipGetLastError());
+        // (round 6: the segments are read in place from x0 -- SnvFwdArgs::seg_n -- instead of being copied out with their halo first:
+        // 2 x 70 MB per 512 windows at R = 4000 and two launches less)
         for (int kind = 0; kind < 2; ++kind) {
           SnvFwdArgs t = kind == 0 ? m->args_lwA : m->args_lwB;
           t.n = kind == 0 ? cn * m->lw_nA : cn;
-          t.x0 = kind == 0 ? w.vx0A : w.vx0B;
+          t.x0 = w.x0;
+          t.x0_cols = x0_cols;
+          t.seg_n = kind == 0 ? m->lw_nA : 1;
+          t.seg_step = kind == 0 ? 7 * nj : 0;
+          t.seg_col0 = kind == 0 ? 0 : m->lw_SB;
           t.s3[0] = kind == 0 ? w.vs3A : w.vs3B;
           t.s3[1] = w.s3[1];
           t.xlogit = w.xlogit;

@@ -286,6 +286,17 @@ __device__ __forceinline__ void conv_layer_any(char* img, const WaveAddr& sa, in
   if constexpr (NB > 0) conv_layer_wave<NB, FINAL, USEX, MODE>(img, sa, k, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
 }
 
+// first x0 column (counted over the whole buffer) of launch row `row`: a site's row at the tower's column offset -- or, for the
+// segment launches of long windows (SnvFwdArgs::seg_n, one row per wave), segment row % seg_n of site row / seg_n in place
+__device__ __forceinline__ size_t wave_x0_column(const SnvFwdArgs& args, int64_t row, int x0_cols, int x0c) {
+  if (args.seg_n > 0) {
+    const int64_t site = row / args.seg_n;
+    const int k = (int)(row - site * args.seg_n);
+    return (size_t)site * (size_t)x0_cols + (size_t)(args.seg_col0 + k * args.seg_step);
+  }
+  return (size_t)row * (size_t)x0_cols + (size_t)x0c;
+}
+
 // Stage-1 activations of unit `unit` straight into the residual registers, in MFMA accumulator layout (lane = column n16 of each
 // block, channels 4 kk .. + 3 of both M-blocks): one wave-uniform buffer descriptor per unit + a 32-bit lane offset worked out on
 // the spot (a division by multiply-high per block) -- nothing per-lane survives between units, so nothing is spilled.  Columns
@@ -294,7 +305,7 @@ __device__ __forceinline__ void wave_request_x0(const SnvFwdArgs& args, const To
                                                 f32x4 (&xr0)[TW_NBW], f32x4 (&xr1)[TW_NBW], int64_t unit, int64_t n_units, int n16, int kk) {
   const int64_t row0 = unit * Pw;
   const bool any = unit < n_units;
-  const __amdgpu_buffer_rsrc_t base = uniform_rsrc(args.x0 + ((size_t)(any ? row0 : 0) * x0_cols + x0c) * 32);
+  const __amdgpu_buffer_rsrc_t base = uniform_rsrc(args.x0 + wave_x0_column(args, any ? row0 : 0, x0_cols, x0c) * 32);
   const int rows = any ? (int)(args.n - row0 < Pw ? args.n - row0 : Pw) : 0;      // sites of this unit that exist
   uint32_t lane_col = (uint32_t)n16;
   asm volatile("" : "+v"(lane_col));      // opaque: keeps the offsets below from being precomputed for the whole launch
@@ -600,7 +611,7 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArg
       XReq xq = xoff;
       xq.on = nu < n_units && (nu + 1) * Pw <= args.n;
       if (xq.on) {
-        xq.base = uniform_rsrc(args.x0 + ((size_t)nu * Pw * x0_cols + x0c) * 32);
+        xq.base = uniform_rsrc(args.x0 + wave_x0_column(args, nu * Pw, x0_cols, x0c) * 32);
         uint32_t lc = (uint32_t)n16;
         asm volatile("" : "+v"(lc));      // opaque: the lane offsets are worked out block by block, not kept for the launch
         xq.lane_col = lc;

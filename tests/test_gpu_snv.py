@@ -639,9 +639,10 @@ def test_forward_writes_stay_inside_their_workspace_regions(n_sites, monkeypatch
 
 
 def test_long_window_writes_stay_inside_their_workspace_regions(monkeypatch):
-    """The same guard check for the segmented long-window path (R = 2000: twelve regions -- the eight of the regular forward plus the
-    segments' inputs and pooled outputs of both kinds): no gather / segment / scatter launch writes outside its region, and the
-    poisoned workspace does not leak into the result (the per-layer path on the same inputs agrees)."""
+    """The same guard check for the segmented long-window path (R = 2000: ten regions -- the eight of the regular forward plus the
+    segments' pooled outputs of both kinds; the segments themselves are read in place from x0 since round 6): no segment / scatter
+    launch writes outside its region, and the poisoned workspace does not leak into the result (the per-layer path on the same inputs
+    agrees)."""
     import ctypes as C
     from mural_amd import _lib
     from mural_amd.data import PackedGenome
@@ -680,7 +681,7 @@ def test_long_window_writes_stay_inside_their_workspace_regions(monkeypatch):
         assert np.abs(out.cpu().numpy() - want).max() <= 1e-4      # (log-probabilities; fp32 summation orders differ between the paths)
         layout = (C.c_size_t * 64)()
         n_regions = _lib.lib().mural_debug_last_ws_layout(layout, 32)
-        assert n_regions == 12
+        assert n_regions == 10
         ws = model._ws.cpu().numpy()
         for i in range(n_regions):
             off, size = layout[2 * i], layout[2 * i + 1]
