@@ -64,7 +64,10 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
     t_prev = t_now;                                                            \
   }
   __shared__ __attribute__((aligned(16))) float tile[E0_C * E0_PITCH];       // block input x, entry p = position l0 - 2 + p
-  __shared__ __attribute__((aligned(16))) float t3s[NG * 64 * E0_C];
+  // rows of the 3-mer table at a pitch of 12 floats: a lane reads 32 bytes of a random row, and at a pitch of 8 the rows start on
+  // 8 distinct bank positions (conflict rate 0.43 of the launch's LDS cycles); 12 gives 16
+  constexpr int T3P = 12;
+  __shared__ __attribute__((aligned(16))) float t3s[NG * 64 * T3P];
   __shared__ __attribute__((aligned(16))) float t1s[4 * E0_C + E0_C];        // single-tap table | bias of the composed conv
   __shared__ __attribute__((aligned(16))) float stabS[15 * ST * 4 + 4];      // exact form: per-symbol layer | its bias
   __shared__ __attribute__((aligned(16))) float fwS[4 * 7 * E0_C + E0_C];    // exact form: k = 7 conv [ci][k][co] | its bias
@@ -75,7 +78,7 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int n16 = tid & 15, kk = (tid >> 4) & 3;
 
-  for (int i = tid; i < NG * 64 * E0_C; i += 256) t3s[i] = a.e0_t3[i];
+  for (int i = tid; i < NG * 64 * E0_C; i += 256) t3s[(i >> 3) * T3P + (i & 7)] = a.e0_t3[i];
   if (tid < 5 * E0_C) t1s[tid] = tid < 4 * E0_C ? a.e0_t1[tid] : a.e0_bias[tid - 4 * E0_C];
   for (int i = tid; i < 15 * ST * 4 + 4; i += 256) stabS[i] = i < 15 * ST * 4 ? a.symtab[i] : a.sym_bias[i - 15 * ST * 4];
   if (tid < 4 * 7 * E0_C + E0_C) fwS[tid] = tid < 4 * 7 * E0_C ? a.f_w[tid] : a.f_b[tid - 4 * 7 * E0_C];
@@ -213,7 +216,7 @@ __global__ __launch_bounds__(256, 4) void indel_enc0_kernel(const ConvBlockArgs 
 #pragma unroll
       for (int g = 0; g < NG; ++g) {
         const uint32_t code = ((lo >> (3 * g)) & 7u) | (((hi >> (3 * g)) & 7u) << 3);
-        const float* r = t3s + (g * 64 + (int)code) * E0_C;
+        const float* r = t3s + (g * 64 + (int)code) * T3P;
         x0 += ld4(r);
         x1 += ld4(r + 4);
       }
