@@ -46,6 +46,7 @@ struct ConvBwdFold {
   const float* add1 = nullptr;
   float* dy_out = nullptr;
   const float* add2 = nullptr;      // a second residual gradient (the stage's outer skip): dy = apply + add1 + add2
+  int dy_out_plus_add1 = 0;         // dy_out receives dy + add1: the ONE tensor the stage's input gradient then adds (not dy and add1 apart)
 };
 
 struct ConvBwdJob {       // dz, BatchNorm-backward sums, partial rows of dW / db

@@ -524,6 +524,7 @@ struct CwBwdArgs {
   float* fdbeta;
   const float* add1;
   float* dy_out;
+  int dy_out_sum;         // dy_out = dy + add1 (ConvBwdFold::dy_out_plus_add1)
   const float* add2;      // ADD2 instances: a second residual gradient
   int64_t B;
   int64_t n_units;
@@ -675,7 +676,7 @@ __global__ __launch_bounds__(CW_THREADS, 2) void conv32w_bwd_kernel(const CwBwdA
             if constexpr (ADD2) o += ad2[q];      // (gq + add1) + add2: bn_bwd_apply_cl_kernel's order
             bsum += o;
             lds_st4(wb, sotab[64 * (u0 + q)], o);
-            buf_st4(od, so.at(u0 + q), o);
+            buf_st4(od, so.at(u0 + q), a.dy_out_sum ? o + ad1[q] : o);
           }
         cw_pin(bsum);
       }
@@ -917,6 +918,7 @@ int cw_conv32_bwd_jobs(ConvBwdJob* jobs, int n, hipStream_t stream) {
       MURAL_REQUIRE(j.fold.relu, "conv32_bwd (wave-private): the folded BatchNorm-backward apply is built for a ReLU in front of that BatchNorm");
       a.fdz = j.fold.dz; a.fx = j.fold.x; a.fstate = j.fold.state; a.fgamma = j.fold.gamma; a.facc = j.fold.acc; a.fn = (double)j.B * j.L;
       a.frelu = j.fold.relu; a.fdgamma = j.fold.dgamma; a.fdbeta = j.fold.dbeta; a.add1 = j.fold.add1; a.dy_out = j.fold.dy_out;
+      a.dy_out_sum = j.fold.dy_out_plus_add1 && j.fold.add1 && j.fold.dy_out;
       a.add2 = j.fold.add2;
       MURAL_REQUIRE(!j.fold.add2 || j.fold.add1, "conv32_bwd (wave-private): a second residual gradient without a first");
       MURAL_REQUIRE((j.fold.add2 != nullptr) == (jobs[0].fold.add2 != nullptr), "conv32_bwd (wave-private): the jobs of a launch fold alike");

@@ -490,18 +490,20 @@ int stage_b(Ctx& c, const MuralResBlock* rb, const MuralResBlock* grb, const flo
     // layer 2: dy = d h2 = apply of layer 3
     ConvBwdFold f2{A, s.t[2], s.state[3], rb[1].bn2.weight, s.acc_b[3], 1, gbn(grb[1].bn2).first, gbn(grb[1].bn2).second, nullptr, nullptr};
     if (int rc = conv_b_fold(c, nullptr, s.t[1], L, s.state[2], rb[1].bn1, rb[1].conv1, s.acc_b[2], grb[1].conv1, Bz, f2)) return rc;
-    // layer 1: dy = d x1 (total) = apply of layer 2 + d_out, also needed by the stage's last apply: written out
+    // layer 1: dy = d x1 (total) = apply of layer 2 + d_out, also needed by the stage's last apply -- which adds d_out once more (the
+    // outer skip): the launch writes gb = dy + d_out, ONE tensor for that apply to read instead of two
     ConvBwdFold f1{Bz, s.t[1], s.state[2], rb[1].bn1.weight, s.acc_b[2], 1, gbn(grb[1].bn1).first, gbn(grb[1].bn1).second, d_out, gb};
+    f1.dy_out_plus_add1 = 1;
     if (int rc = conv_b_fold(c, nullptr, s.t[0], L, s.state[1], rb[0].bn2, rb[0].conv2, s.acc_b[1], grb[0].conv2, A, f1)) return rc;
     // layer 0: dy = d h = apply of layer 1
     ConvBwdFold f0{A, s.t[0], s.state[1], rb[0].bn2.weight, s.acc_b[1], 1, gbn(grb[0].bn2).first, gbn(grb[0].bn2).second, nullptr, nullptr};
     if (int rc = conv_b_fold(c, nullptr, x_in, L, s.state[0], rb[0].bn1, rb[0].conv1, s.acc_b[0], grb[0].conv1, Bz, f0)) return rc;
     if (defer && !dev_env("MURAL_TRAIN_NO_FIRST_FOLD")) {
-      *defer = FirstFold{Bz, x_in, gb, d_out, s.state[0], rb[0].bn1.weight, s.acc_b[0], (double)c.P->B * L, const_cast<float*>(grb[0].bn1.weight),
+      *defer = FirstFold{Bz, x_in, gb, nullptr, s.state[0], rb[0].bn1.weight, s.acc_b[0], (double)c.P->B * L, const_cast<float*>(grb[0].bn1.weight),
                          const_cast<float*>(grb[0].bn1.bias)};
       return MURAL_OK;
     }
-    return cl_bn_bwd_apply(Bz, x_in, (int64_t)c.P->B * L, 1, s.state[0], rb[0].bn1.weight, s.acc_b[0], gb, d_out, d_in,
+    return cl_bn_bwd_apply(Bz, x_in, (int64_t)c.P->B * L, 1, s.state[0], rb[0].bn1.weight, s.acc_b[0], gb, nullptr, d_in,
                            const_cast<float*>(grb[0].bn1.weight), const_cast<float*>(grb[0].bn1.bias), (hipStream_t)c.stream);
   }
   // layer 3: y = conv(BN(relu(h2))) + x1 + x_in
