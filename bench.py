@@ -674,26 +674,24 @@ def rank_share(model, r, order, fa, bed, rows, work, device, t_one_rank, rank=3,
                     "pack_thread_busy": fwd.seconds["pack"], "pack_wait": fwd.seconds["pack_wait"],
                     "rss_before_kb": rss0, "peak_rss_kb": _rss_kb("VmHWM") if reset else None,
                     "part_bytes": os.path.getsize(os.path.join(work, "share.tsv.part%04d" % rank))}
-            # what stringing the parts into ONE table file costs rank 0 at the end (TsvSink._close_parts: in-kernel copies of every part,
-            # serial -- writes to one file do not scale): this part copied once, times `world`
+            # what placing this rank's slices into the ONE table file costs at the end (TsvSink._close_parts: every rank copies its own
+            # slices through a shared mapping of the table, side by side): this part copied to its place in a file of the table's size
             part = os.path.join(work, "share.tsv.part%04d" % rank)
+            dst = os.path.join(work, "assembled.tsv")
+            with open(dst, "wb") as fh:
+                fh.truncate(best["part_bytes"] * world)
             t0 = time.perf_counter()
-            with open(os.path.join(work, "assembled.tsv"), "wb") as dst, open(part, "rb") as src:
-                left, off = best["part_bytes"], 0
-                while left > 0:
-                    sent = os.sendfile(dst.fileno(), src.fileno(), off, left)
-                    off += sent
-                    left -= sent
-            best["assemble_one_table_seconds_estimate"] = (time.perf_counter() - t0) * world
-            os.unlink(os.path.join(work, "assembled.tsv"))
+            TsvSink._copy_slices(dst, part, [(0, best["part_bytes"] * rank, best["part_bytes"])])
+            best["assemble_seconds_per_rank"] = time.perf_counter() - t0
+            os.unlink(dst)
         os.unlink(os.path.join(work, "share.tsv.part%04d" % rank))
     best.update({"rank": rank, "world": world, "one_rank_seconds": t_one_rank, "projected_speedup_at_%d" % world: t_one_rank / best["seconds"],
-                 "projected_speedup_with_one_table_file": t_one_rank / (best["seconds"] + best["assemble_one_table_seconds_estimate"]),
+                 "projected_speedup_with_one_table_file": t_one_rank / (best["seconds"] + best["assemble_seconds_per_rank"]),
                  "note": "predict_bed_sharded(emulate=(%d, %d)) + TsvSink(parts=(%d, %d)); best of two; peak_rss_kb = VmHWM of this "
                          "process over the run (reset through /proc/self/clear_refs; it includes the bench's resident genome and "
                          "models); projected_speedup = one-rank seconds / share seconds with the table left as per-rank part files; "
-                         "..._with_one_table_file adds rank 0's serial copy of every part into one file (text output at ~60 bytes "
-                         "per row bounds the file-to-file run, not the prediction)" % (rank, world, rank, world)})
+                         "..._with_one_table_file adds the copy of this rank's slices into the one table file (all ranks copy side by "
+                         "side through a shared mapping)" % (rank, world, rank, world)})
     return best
 
 
