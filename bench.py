@@ -229,9 +229,12 @@ def train_steps_per_s(device, genome, B=4096, steps=1000, warmup=20, sync_steps=
     steps without a host synchronisation in between (windows encoded from the packed genome inside the timed loop), then
     `sync_steps` individually synchronised ones (the reference reads loss.item() every step, training.py:437)."""
     import torch.nn as nn
-    from mural_amd.train import CrossEntropySum, clip_grad_norm_
+    from mural_amd.train import Adam, CrossEntropySum, clip_grad_norm_
     model = build_model(device).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)       # one multi-tensor launch; same update rule
+    # mural_amd.train.Adam = torch.optim.Adam with the update as ONE launch over the flat parameter / gradient / moment buffers of the
+    # library's training step (same rule; tests/test_gpu_train.py compares the two); MURAL_BENCH_TORCH_ADAM=1: torch's fused multi-tensor step
+    opt = (torch.optim.Adam(model.parameters(), lr=1e-3, fused=True) if os.environ.get("MURAL_BENCH_TORCH_ADAM") == "1"
+           else Adam(model.parameters(), lr=1e-3))
     crit = CrossEntropySum()                  # nn.CrossEntropyLoss(reduction="sum") in one launch per direction (mural_amd.train)
     rng = np.random.default_rng(1)
     total = steps + warmup + sync_steps

@@ -359,6 +359,13 @@ int mural_op_ce_sum_bwd(const float* prob, const int64_t* y, const float* g, int
  * 64 doubles of device scratch.  Two launches, fixed summation order (bitwise reproducible).                                        */
 int mural_op_clip_grad_norm(float* flat, int64_t n, float max_norm, double* scratch64, float* total, void* stream);
 
+/* torch.optim.Adam.step() of the reference's training loops (MuRaL/training.py:346-350, :432; amsgrad and maximize off) over flat float32
+ * buffers that share ONE slot layout -- parameters, gradients, exp_avg, exp_avg_sq of every parameter at the same offsets, zero in the
+ * padding (it stays zero) -- as one elementwise launch; n = elements (a multiple of 4, buffers 16-byte aligned), step = the 1-based
+ * count of this update (bias corrections 1 - beta^step are formed on the host in double).                                             */
+int mural_op_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                       double beta2, double eps, double weight_decay, int64_t step, void* stream);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

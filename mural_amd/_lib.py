@@ -158,6 +158,7 @@ PROTOTYPES = {
     "mural_op_ce_sum_fwd": (C.c_int, [VP, VP, I64, I32, VP, VP, VP]),
     "mural_op_ce_sum_bwd": (C.c_int, [VP, VP, VP, I64, I32, VP, VP]),
     "mural_op_clip_grad_norm": (C.c_int, [VP, I64, C.c_float, VP, VP, VP]),
+    "mural_op_adam_flat": (C.c_int, [VP, VP, VP, VP, I64, C.c_double, C.c_double, C.c_double, C.c_double, C.c_double, I64, VP]),
     "mural_last_error": (C.c_char_p, []),
     "mural_abi_version": (C.c_int, []),
     "mural_encode_kmer": (C.c_int, [C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,

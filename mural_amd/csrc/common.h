@@ -106,6 +106,7 @@ struct DivWide {
 // the caller's stream; join: the caller's stream waits for the side stream.  Both are legal inside a stream capture (the side
 // stream joins the capture and leaves it at the join).
 // ---------------------------------------------------------------------------------------------
+int side_priority_mode();      // encode.hip (development switch MURAL_SIDE_PRIORITY)
 struct SideStream {
   hipStream_t side = nullptr, side2 = nullptr;
   hipEvent_t fork_ev = nullptr, join_ev = nullptr, join2_ev = nullptr;
@@ -116,8 +117,11 @@ struct SideStream {
   bool ready = false;
   int init() {          // called with `mu` held
     if (ready) return MURAL_OK;
-    MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
-    MURAL_HIP_CHECK(hipStreamCreateWithFlags(&side2, hipStreamNonBlocking));
+    int prio_lo = 0, prio_hi = 0;      // (numerically: hi <= lo; hi = served first)
+    MURAL_HIP_CHECK(hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi));
+    const int pm = side_priority_mode();
+    MURAL_HIP_CHECK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, (pm & 1) ? prio_hi : (pm & 4) ? prio_lo : 0));
+    MURAL_HIP_CHECK(hipStreamCreateWithPriority(&side2, hipStreamNonBlocking, (pm & 2) ? prio_hi : (pm & 8) ? prio_lo : 0));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&fork_ev, hipEventDisableTiming));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&join_ev, hipEventDisableTiming));
     MURAL_HIP_CHECK(hipEventCreateWithFlags(&join2_ev, hipEventDisableTiming));

@@ -6,6 +6,7 @@
 // Correctness-first kernels (vector ALU, atomics for cross-workgroup sums); the conv forward / input-gradient reuse the
 // generic conv1d kernel.  The Python autograd glue lives in mural_amd/model/train_ops.py.
 #include <climits>
+#include <cmath>
 #include <cstdlib>
 #include <cstring>
 
@@ -1498,25 +1499,70 @@ extern "C" int mural_op_head_bwd(const float* loc, const float* mid, const float
 // torch's four-to-six: loss = -sum_i (x[i][y_i] - logsumexp(x[i])), prob = softmax(x) kept for the backward, dx = g (prob - onehot(y)).
 // ONE workgroup: the sum is taken in a fixed order (double accumulators), the loss is reproducible.  A label outside [0, nc) makes the
 // loss NaN (torch raises a device assert there).
-__global__ __launch_bounds__(1024) void ce_sum_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ y, int64_t B, int nc,
+// NC > 0: the class count at compile time -- a thread's rows (B / 1024 of them, four at a time) are requested before the first one is
+// used, a row's logits stay in registers and its probabilities are stored once (the run-time form reads a logit three times and makes
+// one dependent round trip to memory per row: 17 us for 4096 x 4 logits against 6).  Same operations in the same order per row and
+// the same order of the sum: the two forms give the same bits.
+template <int NC>
+__global__ __launch_bounds__(1024) void ce_sum_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ y, int64_t B, int nc_rt,
                                                           float* __restrict__ prob, float* __restrict__ loss) {
   __shared__ double red[16];
   double acc = 0.0;
-  for (int64_t i = threadIdx.x; i < B; i += 1024) {
-    const float* r = x + i * nc;
-    float m = -INFINITY;
-    for (int k = 0; k < nc; ++k) m = fmaxf(m, r[k]);
-    float s = 0.f;
-    for (int k = 0; k < nc; ++k) {      // (each exponential once: parked in prob, scaled below)
-      const float e = expf(r[k] - m);
-      prob[i * nc + k] = e;
-      s += e;
+  if constexpr (NC > 0) {
+    constexpr int R = 4;
+    for (int64_t i0 = threadIdx.x; i0 < B; i0 += 1024 * R) {
+      float r[R][NC];
+      int64_t t[R];
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int64_t i = i0 + 1024 * u;
+        const bool ok = i < B;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) r[u][k] = ok ? x[i * NC + k] : 0.f;
+        t[u] = ok ? y[i] : 0;
+      }
+#pragma unroll
+      for (int u = 0; u < R; ++u) {
+        const int64_t i = i0 + 1024 * u;
+        if (i >= B) break;
+        float m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) m = fmaxf(m, r[u][k]);
+        float e[NC], s = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          e[k] = expf(r[u][k] - m);
+          s += e[k];
+        }
+        const float lse = m + logf(s);
+        const float inv = 1.f / s;
+        float rt = 0.f;
+#pragma unroll
+        for (int k = 0; k < NC; ++k) {
+          prob[i * NC + k] = e[k] * inv;
+          rt = t[u] == k ? r[u][k] : rt;
+        }
+        acc += (t[u] >= 0 && t[u] < NC) ? (double)(lse - rt) : __longlong_as_double(0x7ff8000000000000LL);      // (NaN by its bits: this file is built with -fno-honor-nans)
+      }
     }
-    const float lse = m + logf(s);
-    const float inv = 1.f / s;
-    for (int k = 0; k < nc; ++k) prob[i * nc + k] *= inv;
-    const int64_t t = y[i];
-    acc += (t >= 0 && t < nc) ? (double)(lse - r[t]) : (double)NAN;
+  } else {
+    const int nc = nc_rt;
+    for (int64_t i = threadIdx.x; i < B; i += 1024) {
+      const float* r = x + i * nc;
+      float m = -INFINITY;
+      for (int k = 0; k < nc; ++k) m = fmaxf(m, r[k]);
+      float s = 0.f;
+      for (int k = 0; k < nc; ++k) {      // (each exponential once: parked in prob, scaled below)
+        const float e = expf(r[k] - m);
+        prob[i * nc + k] = e;
+        s += e;
+      }
+      const float lse = m + logf(s);
+      const float inv = 1.f / s;
+      for (int k = 0; k < nc; ++k) prob[i * nc + k] *= inv;
+      const int64_t t = y[i];
+      acc += (t >= 0 && t < nc) ? (double)(lse - r[t]) : __longlong_as_double(0x7ff8000000000000LL);
+    }
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off);
@@ -1539,13 +1585,56 @@ __global__ void ce_sum_bwd_kernel(const float* __restrict__ prob, const int64_t*
 }
 extern "C" int mural_op_ce_sum_fwd(const float* x, const int64_t* y, int64_t B, int32_t nc, float* prob, float* loss, void* stream) {
   MURAL_REQUIRE(x && y && prob && loss && nc >= 1 && B >= 0, "ce_sum_fwd: bad arguments");
-  hipLaunchKernelGGL(ce_sum_fwd_kernel, dim3(1), dim3(1024), 0, STREAM, x, y, B, nc, prob, loss);
+  if (nc == 4) hipLaunchKernelGGL(ce_sum_fwd_kernel<4>, dim3(1), dim3(1024), 0, STREAM, x, y, B, nc, prob, loss);
+  else hipLaunchKernelGGL(ce_sum_fwd_kernel<0>, dim3(1), dim3(1024), 0, STREAM, x, y, B, nc, prob, loss);
   CHECK_LAUNCH();
 }
 extern "C" int mural_op_ce_sum_bwd(const float* prob, const int64_t* y, const float* g, int64_t B, int32_t nc, float* dx, void* stream) {
   MURAL_REQUIRE(prob && y && g && dx && nc >= 1 && B >= 0, "ce_sum_bwd: bad arguments");
   if (B == 0) return MURAL_OK;
   hipLaunchKernelGGL(ce_sum_bwd_kernel, dim3(grid_for(B * nc)), dim3(256), 0, STREAM, prob, y, g, B * nc, nc, dx);
+  CHECK_LAUNCH();
+}
+
+// torch.optim.Adam.step() (training.py:346-350 builds it, :432 steps it; amsgrad / maximize off) over flat buffers with ONE slot layout:
+// parameters, gradients and the two moment buffers of every parameter at the same offsets (zero in the padding: it stays zero).  One
+// elementwise launch instead of torch's multi-tensor sequence (a step-counter foreach + three launches over ~150 tensor quadruples: 40 us
+// at the end of every step with nothing beside them).  The update is torch's fused kernel's, in float:
+//   g' = g + weight_decay p;  m = m + (g' - m)(1 - beta1);  v = beta2 v + (1 - beta2) g' g';
+//   p = p - (lr / (1 - beta1^t)) m / (sqrt(v) / sqrt(1 - beta2^t) + eps)
+// (the bias corrections come from the host in double, rounded once).
+__global__ __launch_bounds__(256) void adam_flat_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                        float* __restrict__ v, int64_t n4, float w1, float beta2, float w2, float step_size,
+                                                        float bc2_sqrt, float eps, float wd) {
+  for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    float4 pv = reinterpret_cast<float4*>(p)[i], mv = reinterpret_cast<float4*>(m)[i], vv = reinterpret_cast<float4*>(v)[i];
+    const float4 gv = reinterpret_cast<const float4*>(g)[i];
+    float* pp = &pv.x; float* mp = &mv.x; float* vp = &vv.x;
+    const float* gp = &gv.x;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const float gk = gp[k] + wd * pp[k];
+      mp[k] = mp[k] + (gk - mp[k]) * w1;
+      vp[k] = beta2 * vp[k] + w2 * gk * gk;
+      const float denom = sqrtf(vp[k]) / bc2_sqrt + eps;
+      pp[k] = pp[k] - step_size * mp[k] / denom;
+    }
+    reinterpret_cast<float4*>(p)[i] = pv;
+    reinterpret_cast<float4*>(m)[i] = mv;
+    reinterpret_cast<float4*>(v)[i] = vv;
+  }
+}
+extern "C" int mural_op_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
+                                  double beta2, double eps, double weight_decay, int64_t step, void* stream) {
+  MURAL_REQUIRE(param && grad && exp_avg && exp_avg_sq && n >= 0 && (n & 3) == 0, "adam_flat: NULL buffer or a length that is no multiple of 4");
+  MURAL_REQUIRE(step >= 1 && lr >= 0 && beta1 >= 0 && beta1 < 1 && beta2 >= 0 && beta2 < 1 && eps >= 0 && weight_decay >= 0,
+                "adam_flat: step >= 1, lr >= 0, 0 <= beta < 1, eps >= 0, weight_decay >= 0");
+  MURAL_REQUIRE(((reinterpret_cast<uintptr_t>(param) | reinterpret_cast<uintptr_t>(grad) | reinterpret_cast<uintptr_t>(exp_avg) |
+                  reinterpret_cast<uintptr_t>(exp_avg_sq)) & 15) == 0, "adam_flat: buffers must be 16-byte aligned");
+  if (n == 0) return MURAL_OK;
+  const double bc1 = 1.0 - std::pow(beta1, (double)step), bc2 = 1.0 - std::pow(beta2, (double)step);
+  hipLaunchKernelGGL(adam_flat_kernel, dim3(grid_for(n / 4)), dim3(256), 0, STREAM, param, grad, exp_avg, exp_avg_sq, n / 4, (float)(1.0 - beta1),
+                     (float)beta2, (float)(1.0 - beta2), (float)(lr / bc1), (float)std::sqrt(bc2), (float)eps, (float)weight_decay);
   CHECK_LAUNCH();
 }
 

@@ -21,6 +21,7 @@ last step's gradients for accumulation or logging gets a fresh buffer instead of
 """
 import os
 import sys
+import weakref
 
 import ctypes as C
 
@@ -31,6 +32,22 @@ from .. import _lib
 
 MOMENTUM = 0.1
 _SLOTS = C.sizeof(_lib.MuralSnvParams) // 8          # the parameter struct is a flat run of pointers
+
+
+_LAYOUT_OF = {}      # id(first parameter) -> (weak reference to that parameter, weak reference to the layout): mural_amd.train.Adam finds it
+
+
+def layout_of_params(params):
+    """The layout whose parameter list is exactly `params` (any order), or None."""
+    if not params or not _LAYOUT_OF:
+        return None
+    for p in params:
+        hit = _LAYOUT_OF.get(id(p))
+        if hit is not None and hit[0]() is p:
+            lay = hit[1]()
+            if lay is not None and len(lay.plist) == len(params) and {id(q) for q in lay.plist} == {id(q) for q in params}:
+                return lay
+    return None
 
 
 class _Layout:
@@ -56,9 +73,15 @@ class _Layout:
         self.slot_tensor = [tensors[v - 1] if v else None for v in raw.tolist()]
         self.params_all = list(model.parameters())     # cached: walking the module tree costs ~0.2 ms per step
         self.plist = [p for p in self.params_all if p.numel()]
+        self.model_ref = weakref.ref(model)
+        if self.plist:
+            for k in [k for k, (r, _) in _LAYOUT_OF.items() if r() is None]:      # (entries of models that are gone)
+                del _LAYOUT_OF[k]
+            _LAYOUT_OF[id(self.plist[0])] = (weakref.ref(self.plist[0]), weakref.ref(self))
         self.last_flat = None                          # the flat buffer behind the .grad views of the latest backward (clip_grad_norm_)
         self.own_flat = None                           # direct-gradient mode: the buffer and the views into it, created once
         self.own_views = None
+        self.own_base = None                           # holder counts of own_flat / own_views when they were made (_holder_counts)
         index = {id(p): i for i, p in enumerate(self.plist)}
         # gradient slots: offset of each parameter in one flat float32 buffer (running statistics have none)
         offs, o = [], 0
@@ -158,13 +181,16 @@ class ModelStep(torch.autograd.Function):
         dev = ws.device
         direct = ctx.direct and all(p.grad is None for p in lay.plist)     # (an existing .grad is accumulated into: a fresh buffer then)
         if direct:
-            # views somebody still holds (last step's gradients kept across zero_grad(set_to_none=True)) are not rewritten in place:
-            # 3 = the list's reference + the loop variable + getrefcount's own argument
-            if lay.own_views is not None and any(sys.getrefcount(v) > 3 for v in lay.own_views):
+            # Last step's gradients that somebody still holds (kept across zero_grad(set_to_none=True)) are not rewritten in place.
+            # Three holders are looked for, each against the count recorded when the views were made: Python references to a view
+            # object, C++ references to its TensorImpl, and -- what a derived tensor (`g.view(-1)`, `g[0]`, `g.detach()`) or any
+            # other holder of the memory adds -- references to the buffer's storage.
+            if lay.own_views is not None and not _views_are_ours(lay):
                 lay.own_flat = lay.own_views = None
             if lay.own_flat is None or lay.own_flat.device != dev:
                 lay.own_flat = torch.zeros(lay.total, dtype=torch.float32, device=dev)
                 lay.own_views = [lay.own_flat[o:o + p.numel()].view(p.shape) for p, o in zip(lay.plist, lay.poffs)]
+                lay.own_base = _holder_counts(lay)
             flat = lay.own_flat      # every slot is rewritten by the call below; the padding between the slots stays zero
         else:
             flat = torch.zeros(lay.total, dtype=torch.float32, device=dev)    # zero padding between the slots: the norm of the buffer
@@ -190,6 +216,17 @@ class ModelStep(torch.autograd.Function):
             return (None,) * (8 + len(ctx.params))
         grads = {id(p): flat[o:o + p.numel()].view(p.shape) for p, o in zip(lay.plist, lay.poffs)}
         return (None,) * 8 + tuple(grads[id(p)] if p.numel() else torch.zeros_like(p) for p in ctx.params)
+
+
+def _holder_counts(lay):
+    """(references to the storage of the gradient buffer, Python + C++ references of every view into it)."""
+    storage = torch._C._storage_Use_Count(lay.own_flat.untyped_storage()._cdata)
+    return storage, [(sys.getrefcount(v), v._use_count()) for v in lay.own_views]
+
+
+def _views_are_ours(lay):
+    """Nobody but the layout holds last step's gradient views or anything derived from them (counts as at their creation)."""
+    return _holder_counts(lay) == lay.own_base
 
 
 def _direct_is_safe(params):

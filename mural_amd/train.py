@@ -197,6 +197,120 @@ def clip_grad_norm_(model, max_norm):
     return total
 
 
+class Adam(torch.optim.Adam):
+    """``torch.optim.Adam`` (the reference's default optimiser, training.py:346-350, stepped at :432) with a ONE-launch step for a model
+    whose training step runs in the library (model/train_step.py): there every gradient is a view of one flat buffer, so the
+    parameters and the two moment buffers are laid out the same way -- ``p.data`` becomes a view of one flat buffer at the first step,
+    ``state[p]['exp_avg']`` / ``['exp_avg_sq']`` are views as well -- and the update is one elementwise kernel
+    (``mural_op_adam_flat``: torch's fused update rule, bias corrections from the host) instead of torch's multi-tensor sequence (a
+    step-counter foreach + three launches over ~150 tensor quadruples, 40 us at the end of every step with nothing beside them).
+
+    Same constructor as ``torch.optim.Adam``.  Everything the one launch does not cover goes through ``torch.optim.Adam.step`` itself,
+    on the same state tensors: more than one parameter group, amsgrad / maximize / capturable / differentiable, a tensor learning rate,
+    a closure, parameters that are not exactly one HIP model's (or a model without the flat gradient buffer: UNet_Small, CPU), a gradient
+    that is not the latest backward's view.  ``state_dict`` / ``load_state_dict`` are torch's (step counters are materialised first)."""
+
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
+        params = list(params)
+        if "fused" not in kw and "foreach" not in kw:      # torch's fused implementation for the steps that fall through, where it applies
+            flat = [q for p in params for q in (p["params"] if isinstance(p, dict) else [p])]
+            kw["fused"] = bool(flat) and all(torch.is_tensor(q) and q.is_cuda and q.is_floating_point() for q in flat)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, amsgrad=amsgrad, **kw)
+        self._flat = None          # (layout, params, param buffer, exp_avg buffer, exp_avg_sq buffer) while the one-launch step applies
+        self._flat_t = 0           # updates done (the step counters of torch's state, materialised on demand)
+
+    # -- torch's state <-> the flat buffers -----------------------------------------------------------------------------------
+    def _materialise_steps(self):
+        if self._flat is None:
+            return
+        g = self.param_groups[0]
+        on_dev = bool(g.get("fused")) or bool(g.get("capturable"))
+        for p in self._flat[1]:
+            self.state[p]["step"] = (torch.full((), float(self._flat_t), dtype=torch.float32, device=p.device) if on_dev
+                                     else torch.tensor(float(self._flat_t), dtype=torch.float32))
+
+    def _leave_flat(self):
+        self._materialise_steps()
+        self._flat = None
+
+    def _enter_flat(self, lay, params):
+        dev = params[0].device
+        if any(p.dtype is not torch.float32 or p.device != dev or not p.is_cuda for p in params):
+            return False
+        have = [p for p in params if len(self.state.get(p, {}))]
+        t = 0
+        if have:
+            if len(have) != len(params):
+                return False
+            steps = torch.stack([self.state[p]["step"].detach().to(device=dev, dtype=torch.float32).reshape(()) for p in params])
+            t = float(steps[0].item())
+            if t != int(t) or not bool((steps == t).all().item()):
+                return False
+        pf, mf, vf = (torch.zeros(lay.total, dtype=torch.float32, device=dev) for _ in range(3))
+        for p, o in zip(lay.plist, lay.poffs):
+            n = p.numel()
+            slot = lambda f: f[o:o + n].view(p.shape)      # noqa: E731
+            slot(pf).copy_(p.data)
+            st = self.state[p]
+            if have:
+                slot(mf).copy_(st["exp_avg"])
+                slot(vf).copy_(st["exp_avg_sq"])
+            p.data = slot(pf)
+            st["exp_avg"], st["exp_avg_sq"] = slot(mf), slot(vf)
+        self._flat, self._flat_t = (lay, list(lay.plist), pf, mf, vf), int(t)
+        self._materialise_steps()
+        return True
+
+    def _flat_step(self):
+        if len(self.param_groups) != 1:
+            return False
+        g = self.param_groups[0]
+        if (g.get("amsgrad") or g.get("maximize") or g.get("capturable") or g.get("differentiable") or torch.is_tensor(g["lr"])
+                or g.get("decoupled_weight_decay")):
+            return False
+        if self._flat is None:
+            params = [p for p in g["params"] if p.numel()]
+            from .model.train_step import layout_of_params
+            lay = layout_of_params(params)
+            if lay is None or lay.last_flat is None or not self._enter_flat(lay, params):
+                return False
+        lay, params, pf, mf, vf = self._flat
+        flat = lay.last_flat
+        if flat is None or flat.device != pf.device or flat.numel() != pf.numel():
+            return False
+        gbase, pbase = flat.data_ptr(), pf.data_ptr()
+        for p, off in zip(params, lay.poffs):
+            gr = p.grad
+            if gr is None or gr.data_ptr() != gbase + 4 * off or p.data_ptr() != pbase + 4 * off:
+                return False
+        from . import _lib
+        b1, b2 = g["betas"]
+        self._flat_t += 1
+        with torch.cuda.device(pf.device):
+            _lib.check(_lib.lib().mural_op_adam_flat(pf.data_ptr(), gbase, mf.data_ptr(), vf.data_ptr(), pf.numel(), float(g["lr"]), float(b1),
+                                                     float(b2), float(g["eps"]), float(g["weight_decay"]), self._flat_t,
+                                                     _lib.current_stream_ptr(pf.device)))
+        model = lay.model_ref()
+        if model is not None and not model.training:      # (a step in eval mode: the kernel bumps no tensor version the folded copy watches)
+            model.invalidate_folded()
+        return True
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if closure is None and self._flat_step():
+            return None
+        self._leave_flat()
+        return super().step(closure)
+
+    def state_dict(self):
+        self._materialise_steps()
+        return super().state_dict()
+
+    def load_state_dict(self, state_dict):
+        self._flat = None            # the loaded tensors replace the views; the next step lays them out again
+        return super().load_state_dict(state_dict)
+
+
 # ------------------------------------------------------------------------------------------------------------------
 # the reference's epoch loop (MuRaL/training.py:346-450) around the HIP models: optimiser / scheduler choice and the
 # per-batch policy (skip batches of one row, clip at 10, step the scheduler every batch, restart a learning rate that decayed
@@ -208,7 +322,7 @@ def make_optimizer(config, params):
     lr, wd = config["learning_rate"], config["weight_decay"]
     name = config["optim"]
     if name == "Adam":
-        return torch.optim.Adam(params, lr=lr, weight_decay=wd)
+        return Adam(params, lr=lr, weight_decay=wd)      # torch.optim.Adam; one launch per step behind the library's training step
     if name in ("AdamW", "AdamW2"):
         return torch.optim.AdamW(params, lr=lr, weight_decay=wd, amsgrad=True)
     if name == "SGD":

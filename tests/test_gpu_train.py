@@ -259,6 +259,27 @@ def test_direct_gradient_mode_steps_aside_for_hooks_and_kept_gradients():
     assert any(not torch.equal(p.grad, snap[k]) for k, p in model.named_parameters() if p.numel())
     with pytest.raises(RuntimeError, match="ONE backward"):
         loss.backward()
+    # a DERIVED tensor (a flattened view, a row, a detach()) shares the memory without being one of the view objects:
+    # the storage's holder count sees it, and the next backward steps aside for it as well
+    from mural_amd.model import train_step as TS
+    for it, derive in enumerate((lambda g: g.view(-1), lambda g: g[0], lambda g: g.detach())):
+        w = model.conv1_2[1].weight
+        held = derive(w.grad)
+        snap_held = held.clone()
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(5 + it)      # (another dropout mask: other gradients)
+        crit(model((cont, cat), x), y).backward()
+        assert torch.equal(held, snap_held), "the next backward rewrote memory a derived tensor still holds"
+        assert not torch.equal(derive(w.grad), snap_held)
+        del held
+    # ... and with nothing held the buffer IS reused (the point of the direct mode)
+    lay = TS._layout(model)
+    model.zero_grad(set_to_none=True)
+    crit(model((cont, cat), x), y).backward()
+    ptr = lay.own_flat.data_ptr()
+    model.zero_grad(set_to_none=True)
+    crit(model((cont, cat), x), y).backward()
+    assert lay.own_flat.data_ptr() == ptr
     # a tensor hook on one parameter: the whole step goes through autograd's accumulation and the hook sees its gradient
     model.zero_grad(set_to_none=True)
     seen = []
@@ -949,13 +970,99 @@ def test_symbol_windows_route_equals_the_dense_route_bit_for_bit():
         model((torch.zeros(B, 1, device="cuda"), cat), syms)
 
 
+def test_flat_adam_matches_torch_adam_and_falls_back():
+    """mural_amd.train.Adam (one launch over the flat parameter / gradient / moment buffers of the library's training step) against
+    torch.optim.Adam(fused=True) stepping a SHADOW copy of the parameters with the very same gradients: the same weights after every
+    step (an update is lr-sized = 1e-3, a rounding of it 1e-10; the gradients are shared because a parameter whose true gradient is
+    zero -- a conv bias in front of a BatchNorm -- gets rounding noise that Adam turns into a +-lr step, in ANY two runs); the
+    one-launch path is the one that ran; a step whose gradient is not the backward's view (replaced by a clone) goes through torch's
+    own step on the same state and the next one is one launch again; the state loads into a plain torch.optim.Adam and back; weight
+    decay is the L2 form of torch.optim.Adam; eval-mode predictions see the stepped weights."""
+    from mural_amd.train import Adam, clip_grad_norm_
+    fx = U.load("snv_train_T.npz")
+    cat = torch.from_numpy(fx["cat"]).cuda()
+    x = U.onehot(fx["codes"]).cuda()
+    y = torch.from_numpy(fx["y"]).cuda()
+    cont = torch.zeros(len(cat), 1, device="cuda")
+    crit = nn.CrossEntropyLoss(reduction="sum")
+    for wd in (0.0, 1e-2):
+        model, _ = product_from_hp(fx["hp"])
+        model.load_state_dict(U.snv_state_for(fx, U.snv_oracle_from_hp(fx["hp"])))
+        model = model.cuda().train()
+        params = [p for p in model.parameters() if p.numel()]
+        shadow = [p.detach().clone().requires_grad_() for p in params]
+        names = [k for k, p in model.named_parameters() if p.numel()]
+        opt = Adam(model.parameters(), lr=1e-3, weight_decay=wd)
+        ref = torch.optim.Adam(shadow, lr=1e-3, weight_decay=wd, fused=True)
+
+        def one_step(o, r, seed, spoil=False):
+            torch.manual_seed(seed)
+            loss = crit(model((cont, cat), x), y)
+            o.zero_grad()
+            loss.backward()
+            clip_grad_norm_(model, 10)
+            if spoil:
+                w = model.conv1_2[1].weight
+                w.grad = w.grad.clone()
+            for p, q in zip(params, shadow):
+                q.grad = p.grad.detach().clone()
+            o.step()
+            r.step()
+
+        def same(what):
+            for k, a, b in zip(names, params, shadow):
+                d = float((a.detach() - b.detach()).abs().max())
+                assert d <= 2e-7, (what, wd, k, d)
+
+        for s in range(4):
+            one_step(opt, ref, 10 + s)
+            same(("flat", s))
+        assert opt._flat is not None and opt._flat_t == 4, "the one-launch step did not run"
+        base = opt._flat[2]
+        assert all(base.data_ptr() <= p.data_ptr() < base.data_ptr() + 4 * base.numel() for p in params)
+        one_step(opt, ref, 20, spoil=True)      # a gradient that is not the backward's view: torch's own step on the same state
+        assert opt._flat is None
+        same("through torch")
+        one_step(opt, ref, 21)
+        assert opt._flat is not None and opt._flat_t == 6
+        same("flat again")
+        taken = torch.optim.Adam(model.parameters(), lr=1e-3, weight_decay=wd, fused=True)      # the state is torch's
+        taken.load_state_dict(opt.state_dict())
+        assert all(float(st["step"]) == 6.0 for st in taken.state.values())
+        one_step(taken, ref, 22)
+        same("taken over by torch")
+        back = Adam(model.parameters(), lr=1e-3, weight_decay=wd)
+        back.load_state_dict(taken.state_dict())
+        one_step(back, ref, 23)
+        assert back._flat is not None and back._flat_t == 8
+        same("taken back")
+    # eval-mode predictions see the stepped weights (the kernel bumps no tensor version): a step taken while the model is in eval mode
+    torch.manual_seed(24)
+    loss = crit(model((cont, cat), x), y)
+    back.zero_grad()
+    loss.backward()
+    model.eval()
+    with torch.no_grad():
+        before = model((cont, cat), x).clone()      # (builds the folded copy of the weights)
+    back.step()
+    assert back._flat is not None and back._flat_t == 9
+    with torch.no_grad():
+        after = model((cont, cat), x)
+    twin, _ = product_from_hp(fx["hp"])
+    twin.load_state_dict({k: v.detach().clone() for k, v in model.state_dict().items()})
+    twin = twin.cuda().eval()
+    with torch.no_grad():
+        want = twin((cont, cat), x)
+    assert not torch.equal(before, after) and float((after - want).abs().max()) <= 1e-5
+
+
 def test_fused_cross_entropy_sum_matches_torch():
     """mural_amd.train.CrossEntropySum against torch.nn.CrossEntropyLoss(reduction='sum'): value within the rounding of a 4096-term
     float sum, gradient within 1e-6, bitwise reproducible, upstream gradients other than 1 honoured, rows with large logits stable;
     tensors it does not take (float64, more than 65536 rows) go to torch's implementation."""
     from mural_amd.train import CrossEntropySum
     g = torch.Generator().manual_seed(2)
-    for B, nc, scale in ((4096, 4, 1.0), (77, 8, 30.0), (1, 3, 1.0), (5000, 2, 0.1)):
+    for B, nc, scale in ((4096, 4, 1.0), (77, 8, 30.0), (1, 3, 1.0), (5000, 2, 0.1), (5001, 4, 20.0), (3, 4, 1.0)):
         x0 = (torch.randn(B, nc, generator=g) * scale).cuda()
         y = torch.randint(0, nc, (B,), generator=g).cuda()
         xa, xb = x0.clone().requires_grad_(), x0.clone().requires_grad_()

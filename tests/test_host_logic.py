@@ -318,3 +318,29 @@ def test_host_dense_to_symbols_matches_the_encoding_table():
     _lib.check(_lib.lib().mural_host_dense_to_symbols(ptrs, counts, len(batches), L, out.ctypes.data, C.byref(bad)))
     assert bad.value == 2 and out[17 + 5, 17] == 255 and out[324, 0] == 255
     assert (out != codes).sum() == 2
+
+
+def test_train_adam_is_torch_adam_off_the_hip_path():
+    """mural_amd.train.Adam on parameters that are no HIP model's (here: CPU tensors) is torch.optim.Adam itself -- same constructor,
+    bitwise the same steps, the same state_dict -- and make_optimizer hands it out for config['optim'] == 'Adam' (training.py:346-350)."""
+    import torch
+    from mural_amd.train import Adam, make_optimizer
+    torch.manual_seed(0)
+    a = torch.nn.Linear(5, 3)
+    b = torch.nn.Linear(5, 3)
+    b.load_state_dict(a.state_dict())
+    oa, ob = Adam(a.parameters(), lr=1e-2, weight_decay=1e-3), torch.optim.Adam(b.parameters(), lr=1e-2, weight_decay=1e-3)
+    for _ in range(3):
+        x = torch.randn(7, 5)
+        for m, o in ((a, oa), (b, ob)):
+            o.zero_grad()
+            m(x).square().sum().backward()
+            o.step()
+    assert all(torch.equal(p, q) for p, q in zip(a.parameters(), b.parameters()))
+    sa, sb = oa.state_dict(), ob.state_dict()
+    assert sa["param_groups"][0]["lr"] == sb["param_groups"][0]["lr"] and sa["state"].keys() == sb["state"].keys()
+    assert all(torch.equal(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"]) and float(sa["state"][k]["step"]) == 3.0 for k in sa["state"])
+    oa.load_state_dict(sb)
+    assert oa.step(lambda: torch.tensor(1.0)) == torch.tensor(1.0)      # a closure goes to torch's step as well
+    opt = make_optimizer({"optim": "Adam", "learning_rate": 1e-3, "weight_decay": 1e-5}, a.parameters())
+    assert isinstance(opt, Adam) and isinstance(opt, torch.optim.Adam)

@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 from mural_amd.data import PackedGenome  # noqa: E402
-from mural_amd.train import CrossEntropySum, clip_grad_norm_  # noqa: E402
+from mural_amd.train import Adam, CrossEntropySum, clip_grad_norm_  # noqa: E402
 
 
 def main(B=4096, steps=10, warmup=3):
@@ -21,7 +21,7 @@ def main(B=4096, steps=10, warmup=3):
     packed, mask = bench.pack2(codes)
     genome = PackedGenome(packed, mask, len(codes), dev)
     model = bench.build_model(dev).train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)
+    opt = Adam(model.parameters(), lr=1e-3)
     crit = CrossEntropySum()
     rng = np.random.default_rng(1)
     labels = torch.from_numpy(rng.choice(4, size=(steps + warmup) * B, p=[0.955, 0.015, 0.015, 0.015])).to(dev)
