@@ -134,6 +134,11 @@ struct SideStream {
     if (both) MURAL_HIP_CHECK(hipStreamWaitEvent(side2, fork_ev, 0));
     return MURAL_OK;
   }
+  int fork2(hipStream_t main) {      // the second side stream alone (an earlier point of the caller's stream than fork())
+    MURAL_HIP_CHECK(hipEventRecord(fork_ev, main));
+    MURAL_HIP_CHECK(hipStreamWaitEvent(side2, fork_ev, 0));
+    return MURAL_OK;
+  }
   int join(hipStream_t main, bool both = false) {
     MURAL_HIP_CHECK(hipEventRecord(join_ev, side));
     MURAL_HIP_CHECK(hipStreamWaitEvent(main, join_ev, 0));

@@ -37,7 +37,7 @@ const DevSwitch* dev_switch_table() {
     {"MURAL_TRAIN_LOCAL_OPS", "A/B: the local branch of the training step as per-op launches"},
     {"MURAL_TRAIN_HEAD_OPS", "A/B: a tower's head of the training step as per-op launches"},
     {"MURAL_TRAIN_FIRST_SEPARATE", "A/B: symbol histograms / first-layer tables per tower"},
-    {"MURAL_TRAIN_ORDER", "experiment: 1 enqueues the local branch first"},
+    {"MURAL_TRAIN_ORDER", "experiment: forward 2 = the local branch forked with the towers instead of in front of their prepare chain; backward 1 = the local branch enqueued first"},
     {"MURAL_XCD_SWIZZLE", "A/B, bit-identical: =0 disables the XCD-aware workgroup index of the barrier-free INDEL kernels"},
     {"MURAL_CONV1D_MFMA", "A/B: =0 keeps the generic conv on the vector ALU, =2 routes every conv to the MFMA kernel"},
     {"MURAL_CONV1D_DIRECT", "A/B: =0 disables the barrier-free long-row conv"},

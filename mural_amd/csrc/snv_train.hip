@@ -693,6 +693,19 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
     return MURAL_OK;
   }
   MURAL_REQUIRE(distal_x || symbols, "distal_x and symbols are both NULL");
+  // three streams: large tower (caller's) | mid tower | local branch.  The local branch needs nothing of what the towers wait for (symbol
+  // histograms, first-layer tables, weight fragments: ~35 us of small launches in a row), so it starts beside them
+  SideStreamHold ss;      // holds the device's side streams until this call has joined them again
+  if (int rc = ss.acquire()) return rc;
+  static const int order = dev_env("MURAL_TRAIN_ORDER") ? atoi(dev_env("MURAL_TRAIN_ORDER")) : 0;      // experiment: 2 = local branch after the fork of the towers
+  int rc_loc = MURAL_OK;
+  if (order != 2 && m == 2) {
+    if (int rc = ss->fork2((hipStream_t)stream)) return rc;
+    c.stream = ss->side2;
+    rc_loc = local_f(c, cat_x, dropout_p, seeds, seed_dev);
+    c.stream = stream;
+  }
+  auto prepare = [&]() -> int {
   if (symbols) {
     MURAL_HIP_CHECK(hipMemcpyAsync(P.sym, symbols, (size_t)B * shape->distal_len, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   } else if (int rc = mural_op_dense_to_symbols(distal_x, B, shape->distal_len, P.sym, status, stream)) {
@@ -717,26 +730,26 @@ extern "C" int mural_snv_train_forward(const MuralSnvShape* shape, const MuralSn
       c.first_prepared = true;
     }
   }
-  SideStreamHold ss;      // holds the device's side streams until this call has joined them again
-  if (int rc = ss.acquire()) return rc;
-  if (int rc = ss->fork((hipStream_t)stream, true)) return rc;
-  // three streams: large tower (caller's) | mid tower | local branch.  The large tower is the critical path, so it is enqueued
-  // first: the ~70 launches of the other two would otherwise hold its first kernel back by their enqueue time
-  static const int order = dev_env("MURAL_TRAIN_ORDER") ? atoi(dev_env("MURAL_TRAIN_ORDER")) : 0;      // experiment: 1 = local branch first
-  int rc_loc = MURAL_OK;
-  if (order == 1 && m == 2) {
+    return MURAL_OK;
+  };
+  int rc_prep = rc_loc ? MURAL_OK : prepare();
+  // The large tower is the critical path, so it is enqueued first: the ~35 launches of the mid tower would otherwise hold its first
+  // kernel back by their enqueue time
+  int rc_large = MURAL_OK, rc_mid = MURAL_OK;
+  if (!rc_prep && !rc_loc) {
+    if (int rc = ss->fork((hipStream_t)stream, order == 2)) rc_prep = rc;
+  }
+  if (!rc_prep && !rc_loc) {
+    rc_large = tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
+    c.stream = ss->side;
+    rc_mid = rc_large ? MURAL_OK : tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
     c.stream = ss->side2;
-    rc_loc = local_f(c, cat_x, dropout_p, seeds, seed_dev);
+    if (order == 2 && m == 2 && !rc_mid && !rc_large) rc_mid = local_f(c, cat_x, dropout_p, seeds, seed_dev);
     c.stream = stream;
   }
-  int rc_large = tower_f(c, 1, params->large, dropout_p[4], seeds[4], seed_dev);
-  c.stream = ss->side;
-  int rc_mid = rc_large ? MURAL_OK : tower_f(c, 0, params->mid, dropout_p[3], seeds[3], seed_dev);
-  c.stream = ss->side2;
-  if (order != 1 && m == 2 && !rc_mid && !rc_large) rc_mid = local_f(c, cat_x, dropout_p, seeds, seed_dev);
-  if (!rc_mid) rc_mid = rc_loc;
-  c.stream = stream;
   if (int rc = ss->join((hipStream_t)stream, true)) return rc;     // also on an error: the side streams must not stay forked
+  if (rc_loc) return rc_loc;
+  if (rc_prep) return rc_prep;
   if (rc_mid) return rc_mid;
   if (rc_large) return rc_large;
   return mural_op_head_fwd(m == 2 ? P.loc.logits : nullptr, P.tw[0].logits, P.tw[1].logits, B, shape->n_class, out, stream);

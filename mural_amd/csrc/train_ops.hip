@@ -1099,35 +1099,57 @@ __global__ void head_fwd_kernel(const float* __restrict__ loc, const float* __re
   }
 }
 
+// NC > 0: the class count at compile time (the shipped 4): every loop unrolls and the per-class arrays live in registers -- with a run-time
+// count they are indexed dynamically and sit in scratch memory (16 us for 4096 rows against 5).  Same operations in the same order.
+template <int NC>
 __global__ void head_bwd_kernel(const float* __restrict__ loc, const float* __restrict__ mid, const float* __restrict__ lar,
-                                const float* __restrict__ dout, int64_t B, int nc, float* __restrict__ dloc,
+                                const float* __restrict__ dout, int64_t B, int nc_rt, float* __restrict__ dloc,
                                 float* __restrict__ dmid, float* __restrict__ dlar) {
   const int64_t b = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (b >= B) return;
+  const int nc = NC > 0 ? NC : nc_rt;
+  constexpr int CAP = NC > 0 ? NC : SNV_MAXCLASS;
   const float* v[3] = {lar + b * nc, mid + b * nc, loc ? loc + b * nc : nullptr};
   float* dv[3] = {dlar + b * nc, dmid + b * nc, dloc ? dloc + b * nc : nullptr};
   const float wgt[3] = {loc ? 0.25f : 0.5f, loc ? 0.25f : 0.5f, 0.5f};
-  float s[3][SNV_MAXCLASS], dp[SNV_MAXCLASS];
+  float s[3][CAP], dp[CAP];
+#pragma unroll
   for (int t = 0; t < 3; ++t) {
     if (!v[t]) continue;
     float mx = -INFINITY, sum = 0.f;
-    for (int k = 0; k < nc; ++k) mx = fmaxf(mx, v[t][k]);
-    for (int k = 0; k < nc; ++k) {      // (each exponential once: the same values as exp / sum computed in two passes)
-      s[t][k] = expf(v[t][k] - mx);
-      sum += s[t][k];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k)
+      if (k < nc) {
+        s[t][k] = v[t][k];
+        mx = fmaxf(mx, s[t][k]);
+      }
+#pragma unroll
+    for (int k = 0; k < CAP; ++k)
+      if (k < nc) {      // (each exponential once: the same values as exp / sum computed in two passes)
+        s[t][k] = expf(s[t][k] - mx);
+        sum += s[t][k];
+      }
+#pragma unroll
+    for (int k = 0; k < CAP; ++k)
+      if (k < nc) s[t][k] = s[t][k] / sum;
+  }
+#pragma unroll
+  for (int k = 0; k < CAP; ++k)
+    if (k < nc) {
+      float p = (s[1][k] + s[0][k]) / 2.f;
+      if (v[2]) p = (s[2][k] + p) / 2.f;
+      dp[k] = p > 1e-9f ? dout[b * nc + k] / p : 0.f;      // clamp passes no gradient below its floor
     }
-    for (int k = 0; k < nc; ++k) s[t][k] = s[t][k] / sum;
-  }
-  for (int k = 0; k < nc; ++k) {
-    float p = (s[1][k] + s[0][k]) / 2.f;
-    if (v[2]) p = (s[2][k] + p) / 2.f;
-    dp[k] = p > 1e-9f ? dout[b * nc + k] / p : 0.f;      // clamp passes no gradient below its floor
-  }
+#pragma unroll
   for (int t = 0; t < 3; ++t) {
     if (!v[t]) continue;
     float dot = 0.f;
-    for (int k = 0; k < nc; ++k) dot += dp[k] * wgt[t] * s[t][k];
-    for (int k = 0; k < nc; ++k) dv[t][k] = s[t][k] * (dp[k] * wgt[t] - dot);
+#pragma unroll
+    for (int k = 0; k < CAP; ++k)
+      if (k < nc) dot += dp[k] * wgt[t] * s[t][k];
+#pragma unroll
+    for (int k = 0; k < CAP; ++k)
+      if (k < nc) dv[t][k] = s[t][k] * (dp[k] * wgt[t] - dot);
   }
 }
 
@@ -1490,8 +1512,9 @@ extern "C" int mural_op_head_bwd(const float* loc, const float* mid, const float
                                  float* dloc, float* dmid, float* dlar, void* stream) {
   MURAL_REQUIRE(nc >= 1 && nc <= SNV_MAXCLASS, "n_class out of range");
   if (B == 0) return MURAL_OK;
-  hipLaunchKernelGGL(head_bwd_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, STREAM, loc, mid, lar, dout, B, nc, dloc,
-                     dmid, dlar);
+  // (64-thread workgroups: 4096 rows then occupy 64 CUs instead of 16)
+  if (nc == 4) hipLaunchKernelGGL(head_bwd_kernel<4>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, STREAM, loc, mid, lar, dout, B, nc, dloc, dmid, dlar);
+  else hipLaunchKernelGGL(head_bwd_kernel<0>, dim3((unsigned)((B + 63) / 64)), dim3(64), 0, STREAM, loc, mid, lar, dout, B, nc, dloc, dmid, dlar);
   CHECK_LAUNCH();
 }
 
