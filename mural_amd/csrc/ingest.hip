@@ -903,46 +903,20 @@ extern "C" int mural_bed_parse_range(const char* path, int64_t byte_lo, int64_t 
 // model_predict_m classifies the windows on the host instead -- one symbol byte per column (MURAL_SYM_*, dense_symbol.h's rule) -- and
 // uploads 1 / 16 of the bytes.  xs[b]: HOST float [rows[b]][4][L] contiguous; sym: HOST uint8 [sum rows][L] (rows of the batches side
 // by side); *n_bad: columns that are no MuRaL encoding (they get code 255; the caller raises).  The batches are spread over the host
-// threads (MURAL_HOST_THREADS; up to 32 here: the pass streams 16 KB per output row).
+// threads (MURAL_HOST_THREADS; up to 64 here: the pass streams 16 KB per output row).  The column loop is host_classify.cpp's.
+namespace mural { __attribute__((visibility("hidden"))) int64_t classify_window_host(const float* x, int L, uint8_t* out, const uint8_t* lut625, const uint8_t* lut16); }
 namespace {
 
 struct SymLut {
-  uint8_t t[625];
+  uint8_t t[625], t16[16];
   SymLut() {
     std::memset(t, 255, sizeof(t));
     const int key[15] = {1, 5, 25, 125, 468, 52, 260, 12, 60, 252, 300, 620, 604, 524, 124};      // dense_symbol.h: d0 + 5 d1 + 25 d2 + 125 d3
     for (int i = 0; i < 15; ++i) t[key[i]] = (uint8_t)i;
+    for (int i = 0; i < 16; ++i) t16[i] = t[(i & 1) + 5 * ((i >> 1) & 1) + 25 * ((i >> 2) & 1) + 125 * ((i >> 3) & 1)];      // columns of 0 / 1 only
   }
 };
 const SymLut kSymLut;
-
-inline int64_t classify_window(const float* x, int L, uint8_t* out) {
-  const float third = (float)(1.0 / 3.0);
-  int64_t bad = 0;
-  constexpr int BLK = 256;
-  int32_t key[BLK];
-  for (int c0 = 0; c0 < L; c0 += BLK) {
-    const int m = L - c0 < BLK ? L - c0 : BLK;
-    for (int c = 0; c < m; ++c) key[c] = 0;
-    int mul = 1;
-    for (int r = 0; r < 4; ++r) {
-      const float* row = x + (size_t)r * L + c0;
-      for (int c = 0; c < m; ++c) {            // digit of frac_digit(): 0, 1, .5, .25, 1/3 -> 0..4; anything else poisons the key
-        const float v = row[c];
-        const int d = (v == 1.0f) * 1 + (v == 0.5f) * 2 + (v == 0.25f) * 3 + (v == third) * 4;
-        const int ok = (v == 0.0f) | (d != 0);
-        key[c] += ok ? d * mul : 100000;
-      }
-      mul *= 5;
-    }
-    for (int c = 0; c < m; ++c) {
-      const uint8_t sy = (uint32_t)key[c] < 625u ? kSymLut.t[key[c]] : (uint8_t)255;
-      out[c0 + c] = sy;
-      bad += sy == 255;
-    }
-  }
-  return bad;
-}
 
 }  // namespace
 
@@ -959,7 +933,7 @@ extern "C" int mural_host_dense_to_symbols(const float* const* xs, const int64_t
   }
   const int64_t total = first[(size_t)n_batches];
   int T = host_threads();
-  if (!std::getenv("MURAL_HOST_THREADS")) T = (int)std::min<unsigned>(32u, std::max(1u, std::thread::hardware_concurrency()));
+  if (!std::getenv("MURAL_HOST_THREADS")) T = (int)std::min<unsigned>(64u, std::max(1u, std::thread::hardware_concurrency()));
   T = (int)std::max<int64_t>(1, std::min<int64_t>(T, total / 256 + 1));
   std::vector<int64_t> bad((size_t)T, 0);
   run_parallel(T, [&](int k) {
@@ -969,7 +943,7 @@ extern "C" int mural_host_dense_to_symbols(const float* const* xs, const int64_t
     int64_t n = 0;
     for (int64_t r = lo; r < hi; ++r) {
       while (r >= first[(size_t)b + 1]) ++b;
-      n += classify_window(xs[b] + (size_t)(r - first[(size_t)b]) * 4 * (size_t)L, L, sym + (size_t)r * (size_t)L);
+      n += classify_window_host(xs[b] + (size_t)(r - first[(size_t)b]) * 4 * (size_t)L, L, sym + (size_t)r * (size_t)L, kSymLut.t, kSymLut.t16);
     }
     bad[(size_t)k] = n;
   });

@@ -318,6 +318,22 @@ def test_host_dense_to_symbols_matches_the_encoding_table():
     _lib.check(_lib.lib().mural_host_dense_to_symbols(ptrs, counts, len(batches), L, out.ctypes.data, C.byref(bad)))
     assert bad.value == 2 and out[17 + 5, 17] == 255 and out[324, 0] == 255
     assert (out != codes).sum() == 2
+    # blocks of 256 columns that hold nothing but 0.0 and 1.0 take the bit-compare path of csrc/host_classify.cpp, any other block the
+    # digit rule: A C G T windows with one run of N, a -0.0 (a zero of the rule, not of the bit compare), a column of two ones, a column of zeros
+    L2 = 777
+    codes2 = rng.integers(0, 4, size=(40, L2)).astype(np.uint8)
+    codes2[3, 300:340] = 4                                   # N: four 0.25
+    x2 = U.onehot(codes2).contiguous()
+    x2[5, 2, 600] = -0.0 if codes2[5, 600] != 2 else x2[5, 2, 600]
+    x2[7, :, 10] = torch.tensor([0.0, 1.0, 0.0, 1.0])
+    x2[8, :, 770] = 0.0
+    ptr2 = (C.c_void_p * 1)(x2.data_ptr())
+    cnt2 = (C.c_int64 * 1)(40)
+    out2 = np.full((40, L2), 77, np.uint8)
+    _lib.check(_lib.lib().mural_host_dense_to_symbols(ptr2, cnt2, 1, L2, out2.ctypes.data, C.byref(bad)))
+    want2 = codes2.copy()
+    want2[7, 10] = want2[8, 770] = 255
+    assert bad.value == 2 and np.array_equal(out2, want2)
 
 
 def test_train_adam_is_torch_adam_off_the_hip_path():
