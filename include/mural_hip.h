@@ -397,11 +397,14 @@ int mural_bed_read(const char* path, int64_t cap, int32_t* chrom_id, int64_t* st
  * (MuRaL/scripts/run_predict.py:107, MuRaL/commands/predict.py:134-137).  mural_bed_index_scan lists the PIECES (<= piece_rows
  * consecutive rows of one chromosome: name, byte range, rows, start of the first row) among the lines that start in
  * [byte_lo, byte_hi); byte_lo = byte_hi = 0 only reports file_bytes (the inflated size of a gzip file).  n_pieces may exceed cap.
+ * piece_order (may be NULL): four values per piece -- 1 if every row's (start, strand) is >= its predecessor's ('+' < '-'), i.e. the
+ * piece already is in the order of the reference's output table (run_predict.py:227) | start of its last row | strand of its first
+ * row | strand of its last row (0 '+', 1 '-', -1 no strand field).
  * mural_bed_parse_range parses rows skip_rows .. skip_rows + n_rows - 1 of the rows in [byte_lo, byte_hi) (all on `chrom`).
  * Every ingest entry point reads gzip files too (inflated once per process; pybedtools / gzip.open in the reference).            */
 int mural_bed_index_scan(const char* path, int64_t byte_lo, int64_t byte_hi, int64_t piece_rows, int32_t name_cap, int64_t cap,
                          char* names, int64_t* piece_lo, int64_t* piece_hi, int64_t* piece_rows_out, int64_t* piece_first_start,
-                         int64_t* n_pieces, int64_t* file_bytes);
+                         int64_t* piece_order, int64_t* n_pieces, int64_t* file_bytes);
 int mural_bed_parse_range(const char* path, int64_t byte_lo, int64_t byte_hi, int64_t skip_rows, int64_t n_rows, const char* chrom,
                           int64_t* start, int64_t* end, float* score, uint8_t* strand);
 /* order[k] = input row of output row k in bed_reader order (+ rows, then - rows of every central_bp-wide segment)    */

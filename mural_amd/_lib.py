@@ -110,7 +110,7 @@ PROTOTYPES = {
     "mural_host_dense_to_symbols": (C.c_int, [VP, VP, I64, I32, VP, VP]),
     "mural_host_concat": (C.c_int, [VP, VP, I64, VP]),
     "mural_snv_forward_symbols": (C.c_int, [VP, VP, VP, I64, VP, VP, C.c_size_t, VP]),
-    "mural_bed_index_scan": (C.c_int, [C.c_char_p, I64, I64, I64, I32, I64, VP, VP, VP, VP, VP, VP, VP]),
+    "mural_bed_index_scan": (C.c_int, [C.c_char_p, I64, I64, I64, I32, I64, VP, VP, VP, VP, VP, VP, VP, VP]),
     "mural_bed_parse_range": (C.c_int, [C.c_char_p, I64, I64, I64, I64, C.c_char_p, VP, VP, VP, VP]),
     "mural_tsv_row_bound": (C.c_int64, [C.POINTER(MuralTsvRows)]),
     "mural_tsv_format_workspace_bytes": (C.c_size_t, [I64]),

@@ -687,12 +687,15 @@ namespace {
 struct BedPiece {
   std::string name;
   int64_t lo, hi, rows, first_start;
+  // table order inside the piece: every row's (start, strand) is >= its predecessor's ('+' < '-') -- then the reference's output order
+  // (bed_reader's segments, '+' rows before '-' rows, stably re-sorted by start: run_predict.py:227) IS the file order
+  int64_t in_order, last_start, first_strand, last_strand;
 };
 
 void bed_index_chunk(const char* base, const char* lo, const char* hi, const char* file_end, int64_t piece_rows,
                      std::vector<BedPiece>& out, std::string& error, const char* path) {
   const char* p = lo;
-  BedPiece cur{std::string(), 0, 0, 0, 0};
+  BedPiece cur{std::string(), 0, 0, 0, 0, 1, 0, 0, 0};
   auto flush = [&]() {
     if (cur.rows) out.push_back(cur);
     cur.rows = 0;
@@ -713,13 +716,26 @@ void bed_index_chunk(const char* base, const char* lo, const char* hi, const cha
         error = msg;
         return;
       }
+      // strand = the sixth field ('+' / '-'; a row without one is reported by the parser later: here it only ends the "in order" claim)
+      int sd = -1;
+      {
+        const char* q = t2;
+        for (int k = 0; k < 3 && q; ++k) q = static_cast<const char*>(std::memchr(q + 1, '\t', (size_t)(le - q - 1)));
+        if (q && q + 1 < le && (q + 2 == le || q[2] == '\t') && (q[1] == '+' || q[1] == '-')) sd = q[1] == '-' ? 1 : 0;
+      }
       const size_t fl = (size_t)(t - p);
       if (cur.rows && (cur.rows >= piece_rows || cur.name.size() != fl || std::memcmp(cur.name.data(), p, fl) != 0)) flush();
       if (!cur.rows) {
         cur.name.assign(p, fl);
         cur.lo = (int64_t)(p - base);
         cur.first_start = st;
+        cur.first_strand = sd;
+        cur.in_order = sd >= 0;
+      } else if (sd < 0 || st < cur.last_start || (st == cur.last_start && sd < cur.last_strand)) {
+        cur.in_order = 0;
       }
+      cur.last_start = st;
+      cur.last_strand = sd;
       ++cur.rows;
       cur.hi = (int64_t)(next - base);
     }
@@ -741,7 +757,7 @@ const char* align_line(const char* base, const char* at, const char* end) {
 
 extern "C" int mural_bed_index_scan(const char* path, int64_t byte_lo, int64_t byte_hi, int64_t piece_rows, int32_t name_cap, int64_t cap,
                                     char* names, int64_t* p_lo, int64_t* p_hi, int64_t* p_rows, int64_t* p_first_start,
-                                    int64_t* n_pieces, int64_t* file_bytes) {
+                                    int64_t* p_order, int64_t* n_pieces, int64_t* file_bytes) {
   MURAL_REQUIRE(path && n_pieces && file_bytes, "NULL argument");
   MURAL_REQUIRE(piece_rows >= 1 && byte_lo >= 0 && byte_hi >= byte_lo, "bad scan range");
   MappedFile f;
@@ -783,6 +799,9 @@ extern "C" int mural_bed_index_scan(const char* path, int64_t byte_lo, int64_t b
         std::memcpy(names + n * name_cap, pc.name.data(), pc.name.size());
         names[n * name_cap + (int64_t)pc.name.size()] = '\0';
         p_lo[n] = pc.lo; p_hi[n] = pc.hi; p_rows[n] = pc.rows; p_first_start[n] = pc.first_start;
+        if (p_order) {
+          p_order[4 * n] = pc.in_order; p_order[4 * n + 1] = pc.last_start; p_order[4 * n + 2] = pc.first_strand; p_order[4 * n + 3] = pc.last_strand;
+        }
       }
       ++n;
     }

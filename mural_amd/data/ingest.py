@@ -112,20 +112,23 @@ PIECE_ROWS = 1 << 18      # rows per index piece at most: finding row r of a chr
 
 
 def _scan_bed_pieces(path, byte_lo, byte_hi, piece_rows):
-    """([(name, byte_lo, byte_hi, rows, first_start)], file_bytes) for the rows that start in [byte_lo, byte_hi)."""
+    """([(name, byte_lo, byte_hi, rows, first_start, (in_order, last_start, first_strand, last_strand))], file_bytes) for the rows that
+    start in [byte_lo, byte_hi)."""
     lib = _lib.lib()
     cap = 1 << 12
     while True:
         names = C.create_string_buffer(cap * _NAME)
         cols = [np.zeros(cap, np.int64) for _ in range(4)]
+        order = np.zeros(4 * cap, np.int64)
         n, size = C.c_int64(0), C.c_int64(0)
         _lib.check(lib.mural_bed_index_scan(path.encode(), int(byte_lo), int(byte_hi), int(piece_rows), _NAME, cap, names,
-                                           *(c.ctypes.data for c in cols), C.byref(n), C.byref(size)))
+                                           *(c.ctypes.data for c in cols), order.ctypes.data, C.byref(n), C.byref(size)))
         if n.value <= cap:
             break
         cap = int(n.value)
     raw = names.raw
-    out = [(raw[i * _NAME:(i + 1) * _NAME].split(b"\0", 1)[0].decode(), int(cols[0][i]), int(cols[1][i]), int(cols[2][i]), int(cols[3][i]))
+    out = [(raw[i * _NAME:(i + 1) * _NAME].split(b"\0", 1)[0].decode(), int(cols[0][i]), int(cols[1][i]), int(cols[2][i]), int(cols[3][i]),
+            tuple(int(v) for v in order[4 * i:4 * i + 4]))
            for i in range(n.value)]
     return out, int(size.value)
 
@@ -138,6 +141,8 @@ class BedRun:
     rows: int
     first_start: int        # start of the run's first row (the FILE's first run anchors its grid there, preprocessing.py:63-64)
     pieces: list            # [(byte_lo, byte_hi, rows)]
+    in_order: bool = False  # every row's (start, strand) >= its predecessor's ('+' < '-'): the file order IS the output table's order
+    last: tuple = (0, 0)    # (start, strand) of the run's last row
 
 
 class BedIndex:
@@ -152,13 +157,17 @@ class BedIndex:
         self.path, self.file_bytes = os.fspath(path), file_bytes
         self.runs, self.chroms = [], {}
         row = 0
-        for name, lo, hi, rows, first in pieces:
+        for name, lo, hi, rows, first, (ordered, last_start, first_strand, last_strand) in pieces:
             if self.runs and self.runs[-1].name == name:
-                self.runs[-1].pieces.append((lo, hi, rows))
-                self.runs[-1].rows += rows
+                run = self.runs[-1]
+                run.pieces.append((lo, hi, rows))
+                run.rows += rows
+                run.in_order = run.in_order and bool(ordered) and (first, first_strand) >= run.last
             else:
                 self.chroms.setdefault(name, []).append(len(self.runs))
-                self.runs.append(BedRun(name, row, rows, first, [(lo, hi, rows)]))
+                run = BedRun(name, row, rows, first, [(lo, hi, rows)], bool(ordered))
+                self.runs.append(run)
+            run.last = (last_start, last_strand)
             row += rows
         self.rows = row
 

@@ -440,6 +440,8 @@ class TsvSink:
 
     PIECE_ROWS = 1 << 20
 
+    takes_aligned_blocks = True      # a shard marked "aligned" holds this rank's own rows in the table's order (no sort, no slicing)
+
     def __init__(self, path, poisson=False, dirichlet_weights=None, host_threads=0, parts=False, group=None):
         self.path, self.poisson, self.dirichlet_weights = str(path), poisson, dirichlet_weights
         self.host_threads = host_threads
@@ -515,10 +517,13 @@ class TsvSink:
         t0 = time.perf_counter()
         prob = self._host_prob(shard["prob"])
         start = np.asarray(shard["start"])
-        perm = np.argsort(start, kind="stable")
-        if self.parts:
-            s0, s1 = shard_bounds(len(perm), self.rank, self.world)
-            perm = perm[s0:s1]
+        if shard.get("aligned"):       # this rank's own rows, already in the table's order (predict_bed_sharded: _ShardTail.aligned)
+            perm = np.arange(len(start), dtype=np.int64)
+        else:
+            perm = np.argsort(start, kind="stable")
+            if self.parts:
+                s0, s1 = shard_bounds(len(perm), self.rank, self.world)
+                perm = perm[s0:s1]
         text = format_rows_host([name], None, start, shard["end"], self._strand_u8(shard["strand"]), shard["label"], prob, perm,
                                 self.host_threads) if len(perm) else b""
         t1 = time.perf_counter()
@@ -547,11 +552,14 @@ class TsvSink:
             to = lambda a, dt: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(a))).to(dev, dt).contiguous()   # noqa: E731
             start, end = to(shard["start"], torch.int64), to(shard["end"], torch.int64)
             strand, label = to(self._strand_u8(shard["strand"]), torch.uint8), to(shard["label"], torch.float32)
-            perm = torch.sort(start, stable=True).indices
-            if self.parts:             # this rank's slice of the sorted rows
-                s0, s1 = shard_bounds(n, self.rank, self.world)
-                perm = perm[s0:s1].contiguous()
-                n = s1 - s0
+            if shard.get("aligned"):   # this rank's own rows, already in the table's order (predict_bed_sharded: _ShardTail.aligned)
+                perm = torch.arange(n, dtype=torch.int64, device=dev)
+            else:
+                perm = torch.sort(start, stable=True).indices
+                if self.parts:             # this rank's slice of the sorted rows
+                    s0, s1 = shard_bounds(n, self.rank, self.world)
+                    perm = perm[s0:s1].contiguous()
+                    n = s1 - s0
             names_buf = _name_table([name])
             t = _tsv_struct(names_buf, 1, None, start.data_ptr(), end.data_ptr(), strand.data_ptr(), label.data_ptr(), prob.data_ptr(),
                             prob.dtype == torch.float64, k, prob.stride(0), None, 0)
@@ -586,6 +594,14 @@ class TsvSink:
     def __call__(self, shard):
         name = self._name(shard)
         n = len(shard["start"])
+        if name is not None and n == 0 and shard.get("aligned") and self.parts:
+            # an aligned shard hands every rank ITS rows: a rank without any still counts the shard (the part files are strung together by
+            # shard number)
+            if not (self._last is None or name > self._last):
+                raise ValueError("TsvSink(parts=True) takes the shards in ascending chromosome order (predict_bed_sharded's order)")
+            self._last = name
+            self._shard_no += 1
+            return
         if name is None or n == 0:
             return
         _refuse_second_calibration(shard, self.poisson, self.dirichlet_weights)
@@ -822,6 +838,26 @@ def _device_of(forward):
     return None
 
 
+def _aligned_verdict(infos):
+    """The focal-base check of an aligned shard from every rank's (rows, first segment, its '+' / '-' focal base, last segment, its
+    '+' / '-' focal base, own verdict): a block's own groups were checked by its rank; a (segment, strand) group that runs over a block
+    border -- or over several blocks, some of them without a row of that strand -- must carry one base.  Raises ValueError."""
+    carry_seg, carry = None, [-1, -1]
+    for m, seg_a, fa_p, fa_m, seg_b, fb_p, fb_m, bad in (tuple(int(v) for v in row) for row in infos):
+        if bad:
+            raise ValueError(_FOCAL_MSG)
+        if m == 0:
+            continue
+        if carry_seg == seg_a:
+            for have, mine in ((carry[0], fa_p), (carry[1], fa_m)):
+                if have >= 0 and mine >= 0 and have != mine:
+                    raise ValueError(_FOCAL_MSG)
+        if seg_b != carry_seg:
+            carry_seg, carry = seg_b, [-1, -1]
+        # (seg_a == seg_b: the two triples describe the same groups)
+        carry = [fb_p if fb_p >= 0 else carry[0], fb_m if fb_m >= 0 else carry[1]]
+
+
 class _ShardTail:
     """What happens to a gathered shard (rows of one chromosome in bed_reader order): the per-(segment, strand) focal-base check --
     its verdict is read one shard late, so no rank waits for work just enqueued --, the sink, the collection for the caller."""
@@ -844,7 +880,9 @@ class _ShardTail:
         ev, host = pc
         ev.synchronize()
         self.T["focal_wait"] += time.perf_counter() - t
-        if int(host[0]) != 0:
+        if host.dim() == 2:                 # an aligned shard: the ranks' border groups (see aligned())
+            _aligned_verdict(host.numpy())
+        elif int(host[0]) != 0:
             raise ValueError(_FOCAL_MSG)
 
     def __call__(self, chrom, runs, full, start, end, strand, label, grp, file_rows=None):
@@ -885,6 +923,85 @@ class _ShardTail:
             self.kept.append((runs, {"start": cpu(shard["start"]), "end": cpu(shard["end"]), "strand": cpu(shard["strand"]),
                                      "label": cpu(shard["label"]), "prob": cpu(shard["prob"])[:, :k], "chrom": chrom,
                                      "file_rows": None if file_rows is None else cpu(file_rows)}))
+
+    # -- a chromosome whose rows already are in the table's order (BedRun.in_order) -------------------------------------------------
+    # The file order then IS the output order, this rank's block of the rows IS its slice of the table, and nothing but the focal-base
+    # check looks across blocks: a (segment, strand) group that straddles a block border must agree on both sides.  Every rank checks its
+    # own groups, the ranks exchange 7 numbers -- rows, first / last segment, focal base of the '+' and the '-' group of each (-1: none) --
+    # and every rank walks the chain (verdict read one shard late, like the gathered shards').  No all-gather of rows, no sort of n rows.
+    def aligned(self, chrom, local, start, end, strand, label, anchor, central_bp, group, world, emulated):
+        """`local`: (m, k + 1) probabilities + focal base of THIS rank's block, rows in file order; start / strand / end / label: its site columns."""
+        m, k = local.shape[0], local.shape[1] - 1
+        dev = self.dev
+        if self.model_type == "snv":
+            e0 = (anchor if anchor is not None else 1) + central_bp
+            if dev is not None:
+                seg = torch.where(start > e0, (start - e0 + (central_bp - 1)) // central_bp, torch.zeros_like(start))
+                key = (seg << 1) | strand.to(torch.int64)
+                key_o, order = torch.sort(key, stable=True)
+                focal_o = local[:, k][order].contiguous()
+                status = torch.zeros(1, dtype=torch.int32, device=dev)
+                info = torch.full((8,), -1, dtype=torch.int64, device=dev)
+                info[0] = m
+                if m:
+                    with torch.cuda.device(dev):
+                        _lib.check(_lib.lib().mural_focal_group_check(focal_o.data_ptr(), int(focal_o.dtype == torch.float64), 1, 0,
+                                                                     key_o.data_ptr(), m, status.data_ptr(), _lib.current_stream_ptr(dev)))
+                    want = torch.stack([key_o[0] & ~1, (key_o[0] & ~1) | 1, key_o[-1] & ~1, (key_o[-1] & ~1) | 1])
+                    at = torch.searchsorted(key_o, want).clamp(max=m - 1)
+                    have = key_o[at] == want
+                    foc = torch.where(have, focal_o[at].to(torch.int64), torch.full_like(at, -1))
+                    info[1], info[4] = key_o[0] >> 1, key_o[-1] >> 1
+                    info[2:4], info[5:7] = foc[0:2], foc[2:4]
+                info[7] = status[0].to(torch.int64)
+            else:
+                start_h, strand_h = np.asarray(start), np.asarray(strand)
+                seg = np.where(start_h > e0, (start_h - e0 + (central_bp - 1)) // central_bp, 0)
+                key = (seg.astype(np.int64) << 1) | strand_h.astype(np.int64)
+                order = np.argsort(key, kind="stable")
+                key_o = key[order]
+                loc_h = local.cpu().numpy() if isinstance(local, torch.Tensor) else np.asarray(local)
+                focal_o = loc_h[:, k][order].astype(np.int64)
+                info = np.full(8, -1, np.int64)
+                info[0], info[7] = m, 0
+                if m:
+                    try:
+                        check_focal_groups(focal_o, key_o)
+                    except ValueError:
+                        info[7] = 1
+                    want = np.array([key_o[0] & ~1, (key_o[0] & ~1) | 1, key_o[-1] & ~1, (key_o[-1] & ~1) | 1])
+                    at = np.minimum(np.searchsorted(key_o, want), m - 1)
+                    foc = np.where(key_o[at] == want, focal_o[at], -1)
+                    info[1], info[4] = key_o[0] >> 1, key_o[-1] >> 1
+                    info[2:4], info[5:7] = foc[0:2], foc[2:4]
+                info = torch.from_numpy(info)
+            if world > 1 and not emulated:
+                infos = [torch.empty_like(info) for _ in range(world)]
+                dist.all_gather(infos, info, group=group)
+                infos = torch.stack(infos)
+            else:
+                infos = info.reshape(1, 8)
+            if dev is not None:
+                with torch.cuda.device(dev):
+                    host = torch.zeros(infos.shape, dtype=torch.int64).pin_memory()
+                    host.copy_(infos, non_blocking=True)
+                    ev = torch.cuda.Event()
+                    ev.record()
+                self._finish_check()               # the verdict of the PREVIOUS shard
+                self.pending = (ev, host)
+            else:
+                self._finish_check()
+                _aligned_verdict(infos.numpy())
+        shard = None
+        if self.need_meta:
+            as_np = (lambda a: a) if dev is not None else (lambda a: a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a))     # noqa: E731
+            prob = local if dev is not None else (local.cpu().numpy() if isinstance(local, torch.Tensor) else np.asarray(local))[:, :k]
+            shard = {"chrom": chrom, "start": as_np(start), "end": as_np(end), "strand": as_np(strand), "label": as_np(label), "prob": prob,
+                     "n_class": k, "calibrated": self.calibrated, "aligned": True}
+        if self.feeds_sink:
+            t0 = time.perf_counter()
+            self.sink(shard)
+            self.T["sink"] += time.perf_counter() - t0
 
     def abort(self):
         # the verdict of a shard's focal-base check is read one shard late, i.e. after that shard's rows went to the sink: a failing
@@ -999,6 +1116,9 @@ def _bed_reader_keys(start, strand, run_rows, first_run_anchor, central_bp):
     return keys[0] if len(keys) == 1 else torch.cat(keys)
 
 
+_ALIGNED_BLOCKS = True      # (tests switch it off to compare the two routes of the ranked ingest)
+
+
 def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, sink, collect, timings, emulate):
     from .data import ingest
     if emulate is not None:
@@ -1018,6 +1138,10 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
     tdev = dev if dev is not None else torch.device("cpu")
     tail = _ShardTail(forward, model_type, sink, collect, T, dev, rank)
     T.update({"bed_parse": 0.0, "pack_rows": 0.0, "reorder": 0.0})
+    # aligned blocks need a consumer that takes a rank's own rows as its slice of the table: every rank's part-file sink (or the one
+    # rank there is), and nobody who wants all rows back
+    aligned_ok = (not collect and _ALIGNED_BLOCKS and (sink is None or getattr(sink, "takes_aligned_blocks", False))
+                  and (world == 1 or sink is None or getattr(sink, "parts", False)))
     names = sorted(index.chroms)
     up = lambda a: torch.from_numpy(a).to(tdev)                                           # noqa: E731
     try:
@@ -1044,6 +1168,12 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
             if local.dtype not in (torch.float32, torch.float64):
                 local = local.to(torch.float32)
             k = local.shape[1] - 1
+            if aligned_ok and len(run_ids) == 1 and index.runs[run_ids[0]].in_order:
+                # the chromosome's rows already are in the table's order: this rank's block is its slice of the table (see _ShardTail.aligned)
+                anchor = index.runs[run_ids[0]].first_start if run_ids[0] == 0 else None
+                tail.aligned(chrom, local, pos_b, end_b, strand_b, label_b, anchor, int(segment_center), group, world, emulate is not None)
+                T["aligned_shards"] = T.get("aligned_shards", 0) + 1
+                continue
             t0 = clock()
             packed = _pack_rows(local, pos_b, end_b, strand_b, label_b)
             T["pack_rows"] += clock() - t0

@@ -182,10 +182,12 @@ def _parts_worker(rank, world, port, bed, out_path, q):
         from mural_amd.predict import TsvSink, predict_bed_sharded
         sink = TsvSink(out_path, parts=True)
         ok = sink.parts and sink.world == world and sink.rank == rank
-        n = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000, sink=sink, collect=False)
-        # every rank formatted about 1 / world of the rows, nobody all of them
-        ok = ok and sink.rows == n and not os.path.exists(out_path + ".part%04d" % rank)
-        q.put((rank, bool(ok), n))
+        T = {}
+        n = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000, sink=sink, collect=False, timings=T)
+        # every rank formatted about 1 / world of the rows, nobody all of them.  A chromosome whose rows are in the table's order reaches
+        # the sink as this rank's own rows (an "aligned" shard), any other as the gathered shard
+        ok = ok and not os.path.exists(out_path + ".part%04d" % rank)
+        q.put((rank, bool(ok), (n, sink.rows, T.get("aligned_shards", 0))))
     finally:
         dist.destroy_process_group()
 
@@ -209,7 +211,12 @@ def test_part_file_sink_equals_single_writer_table(tmp_path, world, unsorted):
         p.join(timeout=60)
         assert p.exitcode == 0
     assert all(ok for _, ok, _ in res), res
-    assert all(n == len(rows) for _, _, n in res)
+    assert all(n == len(rows) for _, _, (n, _, _) in res)
+    if unsorted:      # chr1 comes as two runs: gathered by every rank; chr10 and chr2 are in order: every rank is handed its own rows
+        assert all(al == 2 and handed >= 157 for _, _, (_, handed, al) in res)
+        assert sum(handed for _, _, (_, handed, _) in res) == 157 * world + 1 + 64
+    else:
+        assert all(al == 3 for _, _, (_, _, al) in res) and sum(handed for _, _, (_, handed, _) in res) == len(rows)
     solo = predict_bed_sharded(_fake_shard_forward([]), bed, segment_center=3000)
     want_path = str(tmp_path / "want.tsv")
     write_predictions(solo, want_path)
@@ -302,3 +309,135 @@ def test_failed_run_leaves_no_table_behind(tmp_path):
     with pytest.raises(ValueError, match="different bases"):
         predict_bed_sharded(_fake_shard_forward([], mixed_at=rows[200][1]), bed, segment_center=3000, sink=sink)
     assert not os.path.exists(out_path)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# aligned shards: a chromosome whose rows already are in the table's order is never gathered -- a rank's block is its slice of the
+# table -- and only the focal-base check looks across block borders
+# ------------------------------------------------------------------------------------------------------------------
+def _ordered_bed(path, conflict=None):
+    """Rows in the table's order with everything the aligned route has to get right: both strands at one start ('+' row first), long
+    (segment, strand) groups that run over block borders, a chromosome shorter than the number of ranks, one out of order (general
+    route in the same run).  `conflict` = (chrom, row): that row's focal base differs from its group's."""
+    import numpy as np
+    rng = np.random.default_rng(11)
+    rows = []
+    for chrom, n, span in (("chrA", 400, 9000), ("chrB", 2, 100), ("chrC", 301, 2500), ("chrD", 90, 50000)):
+        pos = np.sort(rng.choice(span, size=n, replace=False))
+        for i, p in enumerate(pos):
+            rows.append((chrom, int(p), "+", 0))
+            if i % 3 == 0:
+                rows.append((chrom, int(p), "-", 1))      # the same start on the other strand: '+' first, as the table has it
+    d = [r for r in rows if r[0] == "chrD"]
+    rows = [r for r in rows if r[0] != "chrD"] + d[40:] + d[:40]      # chrD: one run, but not in order
+    with open(path, "w") as fh:
+        for c, p, st, lab in rows:
+            fh.write(f"{c}\t{p}\t{p + 1}\t.\t{lab}\t{st}\n")
+    return rows
+
+
+def _ordered_forward(conflict=None):
+    import numpy as np
+    base = _fake_shard_forward([])
+
+    def fwd(chrom, pos, strand):
+        out = base(chrom, pos, strand).numpy()
+        out[:, 4] = strand          # focal base: one per strand, so every (segment, strand) group agrees ...
+        if conflict is not None and chrom == conflict[0]:
+            out[(pos == conflict[1]) & (strand == conflict[2]), 4] = 3      # ... but for one row
+        return torch.from_numpy(out)
+    return fwd
+
+
+def _aligned_worker(rank, world, port, bed, out_path, aligned, conflict, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mural_amd import predict as P
+        from mural_amd.data import ingest as I
+        I.PIECE_ROWS = 53
+        P._ALIGNED_BLOCKS = aligned
+        T = {}
+        sink = P.TsvSink(out_path, parts=True)
+        try:
+            n = P.predict_bed_sharded(_ordered_forward(conflict), bed, segment_center=700, sink=sink, collect=False, timings=T)
+            q.put((rank, "ok", (n, sink.rows, T.get("aligned_shards", 0))))
+        except ValueError as e:
+            q.put((rank, "ValueError", str(e)))
+    finally:
+        dist.destroy_process_group()
+
+
+def _run_aligned(tmp_path, world, bed, name, aligned, conflict=None):
+    out_path = str(tmp_path / name)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_aligned_worker, args=(r, world, port, bed, out_path, aligned, conflict, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in procs)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    return out_path, res
+
+
+@pytest.mark.parametrize("world", [2, 3, 5])
+def test_aligned_shards_give_the_gathered_route_s_table(tmp_path, world):
+    from mural_amd.data.ingest import write_predictions
+    from mural_amd.predict import predict_bed_sharded
+    bed = str(tmp_path / "o.bed")
+    rows = _ordered_bed(bed)
+    a_path, a = _run_aligned(tmp_path, world, bed, "aligned.tsv", True)
+    g_path, g = _run_aligned(tmp_path, world, bed, "gathered.tsv", False)
+    assert all(kind == "ok" for _, kind, _ in a + g), (a, g)
+    assert all(al == 3 for _, _, (_, _, al) in a) and all(al == 0 for _, _, (_, _, al) in g)       # chrA, chrB, chrC; chrD is gathered
+    n_d = sum(r[0] == "chrD" for r in rows)
+    assert sum(handed for _, _, (_, handed, _) in a) == len(rows) - n_d + world * n_d            # own rows, and the gathered chrD everywhere
+    assert all(handed == len(rows) for _, _, (_, handed, _) in g)
+    solo = predict_bed_sharded(_ordered_forward(), bed, segment_center=700, ingest="whole")
+    want_path = str(tmp_path / "want.tsv")
+    write_predictions(solo, want_path)
+    want = open(want_path, "rb").read()
+    assert open(a_path, "rb").read() == want and open(g_path, "rb").read() == want and want.count(b"\n") == len(rows) + 1
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_aligned_shards_find_a_focal_base_conflict_across_block_borders(tmp_path, world):
+    """A (segment, strand) group of an aligned chromosome runs over several blocks: one odd row anywhere in it fails the run on EVERY rank,
+    whichever rank holds it -- also when it is the only row of its group inside its block."""
+    bed = str(tmp_path / "o.bed")
+    rows = _ordered_bed(bed)
+    a_rows = [r for r in rows if r[0] == "chrA"]
+    for pick in (0, len(a_rows) // world - 1, len(a_rows) // world, len(a_rows) - 1):      # first row, last of block 0, first of block 1, last row
+        c, p, st, _ = a_rows[pick]
+        out_path, res = _run_aligned(tmp_path, world, bed, "t%d.tsv" % pick, True, conflict=(c, p, 1 if st == "-" else 0))
+        assert all(kind == "ValueError" and "different bases" in msg for _, kind, msg in res), (pick, res)
+        assert not os.path.exists(out_path) and not any(f.startswith("t%d.tsv.part" % pick) for f in os.listdir(tmp_path))
+
+
+def test_aligned_verdict_walks_groups_over_block_borders():
+    """The chain logic alone: rows of (rows, first segment, its '+' / '-' base, last segment, its '+' / '-' base, own verdict) per rank."""
+    import numpy as np
+    from mural_amd.predict import _aligned_verdict
+    ok = lambda *rows: _aligned_verdict(np.array(rows, np.int64))          # noqa: E731
+
+    def bad(*rows):
+        with pytest.raises(ValueError, match="different bases"):
+            _aligned_verdict(np.array(rows, np.int64))
+
+    ok((5, 0, 1, 2, 3, 1, 2, 0), (4, 3, 1, 2, 7, 0, 3, 0))                  # segment 3 continues with the same bases; 7 is new
+    bad((5, 0, 1, 2, 3, 1, 2, 0), (4, 3, 0, 2, 7, 0, 3, 0))                 # '+' of segment 3 changes at the border
+    bad((5, 0, 1, 2, 3, 1, 2, 0), (4, 3, 1, 0, 7, 0, 3, 0))                 # '-' of segment 3 changes at the border
+    ok((5, 0, 1, 2, 3, 1, 2, 0), (4, 4, 0, 0, 7, 0, 3, 0))                  # another segment: nothing to compare
+    # the middle rank lies inside segment 3 and has '+' rows only: the '-' group is carried over it
+    ok((5, 0, 1, 2, 3, 1, 2, 0), (2, 3, 1, -1, 3, 1, -1, 0), (4, 3, 1, 2, 9, 1, 1, 0))
+    bad((5, 0, 1, 2, 3, 1, 2, 0), (2, 3, 1, -1, 3, 1, -1, 0), (4, 3, 1, 0, 9, 1, 1, 0))
+    # a rank without rows in between changes nothing
+    bad((5, 0, 1, 2, 3, 1, 2, 0), (0, -1, -1, -1, -1, -1, -1, 0), (4, 3, 0, 2, 9, 1, 1, 0))
+    ok((5, 0, 1, 2, 3, 1, 2, 0), (0, -1, -1, -1, -1, -1, -1, 0), (4, 3, 1, 2, 9, 1, 1, 0))
+    # a group first seen on a later rank of the same segment: the first rank had no '-' row of segment 3
+    ok((5, 0, 1, 2, 3, 1, -1, 0), (4, 3, 1, 2, 3, 1, 2, 0), (1, 3, -1, 2, 3, -1, 2, 0))
+    bad((5, 0, 1, 2, 3, 1, -1, 0), (4, 3, 1, 2, 3, 1, 2, 0), (1, 3, -1, 0, 3, -1, 0, 0))
+    bad((5, 0, 1, 2, 3, 1, 2, 0), (4, 5, 1, 2, 7, 0, 3, 1))                 # a rank's own verdict
