@@ -652,10 +652,12 @@ def _rss_kb(field="VmHWM"):
 
 def rank_share(model, r, order, fa, bed, rows, work, device, t_one_rank, rank=3, world=8):
     """ONE rank's share of a `world`-rank file-to-file run, measured on this GPU (predict_bed_sharded(emulate=(rank, world)) with a
-    part-file sink): its 1 / world of the index scan, the parse of its block of every chromosome, the FASTA pack, its block's compute,
-    a gathered shard of full size (the other ranks' site columns beside copies of this rank's probabilities stand in for the
-    collective), the bed_reader reorder, the focal check and the full sort of the gathered shard, and its slice of the table.  Host
-    seconds spent standing in for the other ranks are excluded (`emulation_seconds`).  projected_speedup = t(1 rank) / t(share)."""
+    part-file sink): its 1 / world of the index scan, the parse of its block of every chromosome, the FASTA pack, its block's compute
+    and -- for a chromosome whose rows already are in the table's order (`aligned_shards`; the synthetic inputs are) -- the focal-base
+    check of its own groups and its own rows formatted as its slice of the table; for any other chromosome a gathered shard of full size
+    (the other ranks' site columns beside copies of this rank's probabilities stand in for the collective), the bed_reader reorder,
+    the focal check and the full sort of the gathered shard, and its slice of the table.  Host seconds spent standing in for the other
+    ranks are excluded (`emulation_seconds`).  projected_speedup = t(1 rank) / t(share)."""
     from mural_amd.predict import HipShardForward, TsvSink, predict_bed_sharded
     best = None
     for _ in range(2):
@@ -674,6 +676,7 @@ def rank_share(model, r, order, fa, bed, rows, work, device, t_one_rank, rank=3,
         if best is None or t_share < best["seconds"]:
             best = {"seconds": t_share, "wall_seconds": wall, "emulation_seconds": split["emulation"],
                     "split_seconds": {k: v for k, v in split.items() if isinstance(v, float)},
+                    "aligned_shards": split.get("aligned_shards", 0),
                     "pack_thread_busy": fwd.seconds["pack"], "pack_wait": fwd.seconds["pack_wait"],
                     "rss_before_kb": rss0, "peak_rss_kb": _rss_kb("VmHWM") if reset else None,
                     "part_bytes": os.path.getsize(os.path.join(work, "share.tsv.part%04d" % rank))}
@@ -726,7 +729,7 @@ def config5_chr1(device, chrom_len=248_000_000):
             assert n == rows
             if one is None or dt < one["seconds"]:
                 one = {"seconds": dt, "rows_per_s": rows / dt, "split_seconds": {k: v for k, v in split.items() if isinstance(v, float)},
-                       "pack_thread_busy": fwd.seconds["pack"], "peak_rss_kb": _rss_kb("VmHWM") if reset else None,
+                       "aligned_shards": split.get("aligned_shards", 0), "pack_thread_busy": fwd.seconds["pack"], "peak_rss_kb": _rss_kb("VmHWM") if reset else None,
                        "table_bytes": os.path.getsize(out)}
         os.unlink(out)
         share = rank_share(model, r, order, fa, bed, rows, work, device, one["seconds"])
