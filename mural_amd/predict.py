@@ -594,9 +594,13 @@ class TsvSink:
     def __call__(self, shard):
         name = self._name(shard)
         n = len(shard["start"])
+        # an aligned shard hands every rank ITS rows of a chromosome, in the table's order and possibly in several parts: the parts after
+        # the first continue the shard (same name), and a rank without rows still counts the shard (the part files are strung together by
+        # shard number)
+        more = bool(shard.get("aligned")) and name is not None and name == self._last and not self._spool
         if name is not None and n == 0 and shard.get("aligned") and self.parts:
-            # an aligned shard hands every rank ITS rows: a rank without any still counts the shard (the part files are strung together by
-            # shard number)
+            if more:
+                return
             if not (self._last is None or name > self._last):
                 raise ValueError("TsvSink(parts=True) takes the shards in ascending chromosome order (predict_bed_sharded's order)")
             self._last = name
@@ -607,11 +611,12 @@ class TsvSink:
         _refuse_second_calibration(shard, self.poisson, self.dirichlet_weights)
         self.rows += n
         on_device = isinstance(shard["prob"], torch.Tensor) and shard["prob"].is_cuda
-        if self.parts and not (self._last is None or name > self._last):
+        if self.parts and not more and not (self._last is None or name > self._last):
             raise ValueError("TsvSink(parts=True) takes the shards in ascending chromosome order (predict_bed_sharded's order)")
-        if not self._spool and (self._last is None or name > self._last):
-            self._last = name
-            self._shard_no += 1
+        if more or (not self._spool and (self._last is None or name > self._last)):
+            if not more:
+                self._last = name
+                self._shard_no += 1
             if on_device:
                 self._stream_device(name, shard)
             else:
@@ -929,10 +934,14 @@ class _ShardTail:
     # check looks across blocks: a (segment, strand) group that straddles a block border must agree on both sides.  Every rank checks its
     # own groups, the ranks exchange 7 numbers -- rows, first / last segment, focal base of the '+' and the '-' group of each (-1: none) --
     # and every rank walks the chain (verdict read one shard late, like the gathered shards').  No all-gather of rows, no sort of n rows.
-    def aligned(self, chrom, local, start, end, strand, label, anchor, central_bp, group, world, emulated):
-        """`local`: (m, k + 1) probabilities + focal base of THIS rank's block, rows in file order; start / strand / end / label: its site columns."""
+    def aligned_part(self, chrom, local, start, end, strand, label, anchor, central_bp):
+        """One PART of this rank's block of an aligned chromosome (the block goes through in parts of <= _ALIGNED_PART_ROWS rows, in file
+        order: the table writer works on one part while the next is computed, and host / device memory is bounded by a part).  `local`:
+        (m, k + 1) probabilities + focal base, start / strand / end / label: the part's site columns.  Returns the part's border record
+        for ``aligned_close`` (None for models without the focal-base rule)."""
         m, k = local.shape[0], local.shape[1] - 1
         dev = self.dev
+        info = None
         if self.model_type == "snv":
             e0 = (anchor if anchor is not None else 1) + central_bp
             if dev is not None:
@@ -975,23 +984,6 @@ class _ShardTail:
                     info[1], info[4] = key_o[0] >> 1, key_o[-1] >> 1
                     info[2:4], info[5:7] = foc[0:2], foc[2:4]
                 info = torch.from_numpy(info)
-            if world > 1 and not emulated:
-                infos = [torch.empty_like(info) for _ in range(world)]
-                dist.all_gather(infos, info, group=group)
-                infos = torch.stack(infos)
-            else:
-                infos = info.reshape(1, 8)
-            if dev is not None:
-                with torch.cuda.device(dev):
-                    host = torch.zeros(infos.shape, dtype=torch.int64).pin_memory()
-                    host.copy_(infos, non_blocking=True)
-                    ev = torch.cuda.Event()
-                    ev.record()
-                self._finish_check()               # the verdict of the PREVIOUS shard
-                self.pending = (ev, host)
-            else:
-                self._finish_check()
-                _aligned_verdict(infos.numpy())
         shard = None
         if self.need_meta:
             as_np = (lambda a: a) if dev is not None else (lambda a: a.numpy() if isinstance(a, torch.Tensor) else np.asarray(a))     # noqa: E731
@@ -1002,6 +994,31 @@ class _ShardTail:
             t0 = time.perf_counter()
             self.sink(shard)
             self.T["sink"] += time.perf_counter() - t0
+        return info
+
+    def aligned_close(self, infos, group, world, emulated):
+        """The border records of this rank's parts of one aligned chromosome -> ONE small all-gather (parts x 8 numbers per rank) -> the
+        chain over (rank, part) in table order; the verdict is read one shard late (no rank waits for work just enqueued)."""
+        if self.model_type != "snv":
+            return
+        mine = torch.stack(infos)                                    # (parts, 8)
+        if world > 1 and not emulated:
+            every = [torch.empty_like(mine) for _ in range(world)]
+            dist.all_gather(every, mine, group=group)
+            every = torch.cat(every)                                 # rank-major = table order
+        else:
+            every = mine
+        if self.dev is not None:
+            with torch.cuda.device(self.dev):
+                host = torch.zeros(every.shape, dtype=torch.int64).pin_memory()
+                host.copy_(every, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record()
+            self._finish_check()               # the verdict of the PREVIOUS shard
+            self.pending = (ev, host)
+        else:
+            self._finish_check()
+            _aligned_verdict(every.numpy())
 
     def abort(self):
         # the verdict of a shard's focal-base check is read one shard late, i.e. after that shard's rows went to the sink: a failing
@@ -1117,6 +1134,7 @@ def _bed_reader_keys(start, strand, run_rows, first_run_anchor, central_bp):
 
 
 _ALIGNED_BLOCKS = True      # (tests switch it off to compare the two routes of the ranked ingest)
+_ALIGNED_PART_ROWS = 1 << 22
 
 
 def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, sink, collect, timings, emulate):
@@ -1150,30 +1168,38 @@ def _predict_bed_ranked(forward, bed_path, segment_center, model_type, group, si
             run_rows = [index.runs[i].rows for i in run_ids]
             n = sum(run_rows)
             b0, b1 = shard_bounds(n, rank, world)
-            t0 = clock()
-            start_h, end_h, label_h, strand_h = index.read_block(chrom, b0, b1)
-            T["bed_parse"] += clock() - t0
-            if hasattr(forward, "prefetch") and si + 1 < len(names):
-                forward.prefetch(names[si + 1])
-            # every site column goes up BEFORE the forward is enqueued: a copy from pageable host memory waits for the stream's earlier
-            # work, and behind the forward it would hold the host for the whole compute instead of letting it parse the next chromosome
-            pos_b, strand_b, end_b, label_b = up(start_h), up(strand_h), up(end_h), up(label_h)
-            t0 = clock()
-            local = forward(chrom, pos_b if dev is not None else start_h, strand_b if dev is not None else strand_h)
-            T["compute_enqueue"] += clock() - t0
-            if local.shape[0] != b1 - b0:
-                raise RuntimeError("forward returned a wrong number of rows")
-            if not isinstance(local, torch.Tensor):
-                local = torch.from_numpy(np.ascontiguousarray(local))
-            if local.dtype not in (torch.float32, torch.float64):
-                local = local.to(torch.float32)
-            k = local.shape[1] - 1
-            if aligned_ok and len(run_ids) == 1 and index.runs[run_ids[0]].in_order:
-                # the chromosome's rows already are in the table's order: this rank's block is its slice of the table (see _ShardTail.aligned)
-                anchor = index.runs[run_ids[0]].first_start if run_ids[0] == 0 else None
-                tail.aligned(chrom, local, pos_b, end_b, strand_b, label_b, anchor, int(segment_center), group, world, emulate is not None)
+            # a chromosome whose rows already are in the table's order: this rank's block is its slice of the table (_ShardTail.aligned_part);
+            # it goes through in parts (every rank the same number of them: the one collective of the shard carries a record per part)
+            is_aligned = aligned_ok and len(run_ids) == 1 and index.runs[run_ids[0]].in_order
+            n_parts = max(1, -(-(-(-n // world)) // _ALIGNED_PART_ROWS)) if is_aligned else 1
+            records = []
+            for part in range(n_parts):
+                p0, p1 = shard_bounds(b1 - b0, part, n_parts)
+                t0 = clock()
+                start_h, end_h, label_h, strand_h = index.read_block(chrom, b0 + p0, b0 + p1)
+                T["bed_parse"] += clock() - t0
+                if part == 0 and hasattr(forward, "prefetch") and si + 1 < len(names):
+                    forward.prefetch(names[si + 1])
+                # every site column goes up BEFORE the forward is enqueued: a copy from pageable host memory waits for the stream's earlier
+                # work, and behind the forward it would hold the host for the whole compute instead of letting it parse the next chromosome
+                pos_b, strand_b, end_b, label_b = up(start_h), up(strand_h), up(end_h), up(label_h)
+                t0 = clock()
+                local = forward(chrom, pos_b if dev is not None else start_h, strand_b if dev is not None else strand_h)
+                T["compute_enqueue"] += clock() - t0
+                if local.shape[0] != p1 - p0:
+                    raise RuntimeError("forward returned a wrong number of rows")
+                if not isinstance(local, torch.Tensor):
+                    local = torch.from_numpy(np.ascontiguousarray(local))
+                if local.dtype not in (torch.float32, torch.float64):
+                    local = local.to(torch.float32)
+                if is_aligned:
+                    anchor = index.runs[run_ids[0]].first_start if run_ids[0] == 0 else None
+                    records.append(tail.aligned_part(chrom, local, pos_b, end_b, strand_b, label_b, anchor, int(segment_center)))
+            if is_aligned:
+                tail.aligned_close(records, group, world, emulate is not None)
                 T["aligned_shards"] = T.get("aligned_shards", 0) + 1
                 continue
+            k = local.shape[1] - 1
             t0 = clock()
             packed = _pack_rows(local, pos_b, end_b, strand_b, label_b)
             T["pack_rows"] += clock() - t0

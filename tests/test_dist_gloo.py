@@ -357,6 +357,7 @@ def _aligned_worker(rank, world, port, bed, out_path, aligned, conflict, q):
         from mural_amd.data import ingest as I
         I.PIECE_ROWS = 53
         P._ALIGNED_BLOCKS = aligned
+        P._ALIGNED_PART_ROWS = 37          # a rank's block of chrA / chrC goes through in several parts (chrB: fewer rows than ranks)
         T = {}
         sink = P.TsvSink(out_path, parts=True)
         try:
@@ -415,6 +416,33 @@ def test_aligned_shards_find_a_focal_base_conflict_across_block_borders(tmp_path
         out_path, res = _run_aligned(tmp_path, world, bed, "t%d.tsv" % pick, True, conflict=(c, p, 1 if st == "-" else 0))
         assert all(kind == "ValueError" and "different bases" in msg for _, kind, msg in res), (pick, res)
         assert not os.path.exists(out_path) and not any(f.startswith("t%d.tsv.part" % pick) for f in os.listdir(tmp_path))
+
+
+def test_aligned_shards_in_parts_single_process(tmp_path):
+    """One process: the aligned route in parts of 29 rows writes the table of the gathered route, single-writer sink and collect=False;
+    a conflict in the middle of a group that runs over parts is found."""
+    from mural_amd import predict as P
+    bed = str(tmp_path / "o.bed")
+    rows = _ordered_bed(bed)
+    old = P._ALIGNED_BLOCKS, P._ALIGNED_PART_ROWS
+    try:
+        tables = {}
+        for aligned in (True, False):
+            P._ALIGNED_BLOCKS, P._ALIGNED_PART_ROWS = aligned, 29
+            T = {}
+            out = str(tmp_path / ("t%d.tsv" % aligned))
+            n = P.predict_bed_sharded(_ordered_forward(), bed, segment_center=700, sink=P.TsvSink(out), collect=False, timings=T)
+            assert n == len(rows) and T.get("aligned_shards", 0) == (3 if aligned else 0)
+            tables[aligned] = open(out, "rb").read()
+        assert tables[True] == tables[False] and tables[True].count(b"\n") == len(rows) + 1
+        P._ALIGNED_BLOCKS = True
+        c, p, st, _ = [r for r in rows if r[0] == "chrC"][150]
+        out = str(tmp_path / "bad.tsv")
+        with pytest.raises(ValueError, match="different bases"):
+            P.predict_bed_sharded(_ordered_forward((c, p, 1 if st == "-" else 0)), bed, segment_center=700, sink=P.TsvSink(out), collect=False)
+        assert not os.path.exists(out)
+    finally:
+        P._ALIGNED_BLOCKS, P._ALIGNED_PART_ROWS = old
 
 
 def test_aligned_verdict_walks_groups_over_block_borders():
