@@ -27,7 +27,7 @@ const DevSwitch* dev_switch_table() {
     {"MURAL_TOWER_DYNAMIC_UNITS", "A/B, bit-identical: SNV predict units through a global ticket counter instead of the fixed stride"},
     {"MURAL_SNV_DEFER_SHORT", "A/B, bit-identical: =0 runs the short-stage launches per chunk (what a one-chunk workspace does by itself)"},
     {"MURAL_LOCAL_REG", "A/B, bit-identical: =0 keeps the local MLP's weight fragments in LDS (snv_local_mlp_mfma)"},
-    {"MURAL_SIDE_PRIORITY", "A/B, same results: bit mask of the side streams created with the highest (1, 2) / lowest (4, 8) stream priority; default 1"},
+    {"MURAL_SIDE_PRIORITY", "A/B, same results: bit mask of the side streams created with the highest (1, 2) / lowest (4, 8) stream priority; default 0"},
     {"MURAL_CW_FULL_GRID", "A/B, same sums in another order: training conv launches ask for two workgroup slots per CU whatever the row length"},
     {"MURAL_TRAIN_CONV_CL", "A/B: the training step on the workgroup-tile conv kernels (conv32_cl.hip) instead of the wave-private ones"},
     {"MURAL_TRAIN_NO_FOLD", "A/B: BatchNorm-backward applies of a ResBlock stage as passes of their own"},
@@ -95,14 +95,14 @@ const char* dev_env(const char* name) {
   return nullptr;
 }
 
-// The first side stream (training: the mid tower's chain; INDEL forward: the odd chunks) is created with the highest stream priority:
-// the mid tower's launches ask for ONE workgroup slot per CU so that they are co-resident with the large tower's (conv32_wave.hip:
-// cw_slots) -- whichever chain ends last then runs its tail alone, and alone the large tower's two-slot launches fill the chip while the
-// mid tower's leave half of it empty.  Served first, the mid tower's chain ends first.  Measured on one box, 800 free-running steps,
-// interleaved (tools/r6_train_ab.sh): 573 / 584 / 576 / 575 steps/s without, 593 / 593 / 583 with; INDEL forward unchanged.
+// Stream priorities of the side streams: an experiment, OFF.  Serving the mid tower's chain first (its launches ask for one workgroup
+// slot per CU, so its tail alone leaves half the chip empty while the large tower's tail alone fills it) gained 2 % on the training leg
+// run alone (573 / 584 / 576 / 575 -> 593 / 593 / 583 steps/s, tools/r6_train_ab.sh) -- and HALVED it (615 -> 311 steps/s) when the
+// process had run the file-to-file prediction leg before (tools/r6_train_after.py): with more streams alive in the process the
+// prioritised queue starves the others.  Not worth a behaviour that depends on what else the process did.
 int side_priority_mode() {
   const char* e = dev_env("MURAL_SIDE_PRIORITY");
-  return e ? atoi(e) : 1;
+  return e ? atoi(e) : 0;
 }
 
 thread_local std::vector<size_t> g_ws_layout;      // (read by the debug flavour's mural_debug_last_ws_layout)
