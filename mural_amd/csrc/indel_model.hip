@@ -286,12 +286,18 @@ extern "C" void mural_indel_model_destroy(MuralIndelModel* m) {
   delete m;
 }
 
+// chunks in flight: even / odd chunks on two streams; MURAL_INDEL_LANES=3 (experiment): a third one on the second side stream
+static int indel_lanes(int64_t n) {
+  static const int want = dev_env("MURAL_INDEL_LANES") ? atoi(dev_env("MURAL_INDEL_LANES")) : 2;
+  const int64_t chunks = (n + INDEL_CHUNK - 1) / INDEL_CHUNK;
+  return (int)std::max<int64_t>(1, std::min<int64_t>(std::min(want, 3), chunks));
+}
 constexpr size_t INDEL_WS_REGIONS = INDEL_LEVELS + 7;   // S | E[levels] | T1 | T2 | H | SP | M | X
 
 extern "C" size_t mural_indel_workspace_bytes(const MuralIndelModel* m, int64_t n) {
   if (!m || n <= 0) return 256;
   // two chunks in flight (one per stream, see mural_indel_forward_dense) once there is more than one
-  const size_t lanes = n > INDEL_CHUNK ? 2 : 1;
+  const size_t lanes = (size_t)indel_lanes(n);
   // (+ the validation guard behind each of a lane's INDEL_WS_REGIONS regions: 0 outside the tests, common.h)
   return lanes * ((size_t)std::min<int64_t>(n, INDEL_CHUNK) * m->per_pos_floats * 4 + INDEL_WS_REGIONS * ws_guard_bytes()) + 4096;
 }
@@ -411,18 +417,18 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
   // Chunks are independent, and the ~45 launches of one chunk include a dozen on the deep levels (rows of 80 / 16 / 8 columns) that
   // leave most of the chip idle: even chunks run on the caller's stream, odd ones on a side stream with their own half of the
   // workspace, so the small kernels of one chunk fill the gaps of the other.
-  const int lanes = n > INDEL_CHUNK ? 2 : 1;
+  const int lanes = indel_lanes(n);
   SideStreamHold ss;      // holds the device's side streams until this call has joined them again
-  if (lanes == 2) {
+  if (lanes >= 2) {
     if (int rc = ss.acquire()) return rc;
-    if (int rc = ss->fork(main_stream)) return rc;
+    if (int rc = ss->fork(main_stream, lanes == 3)) return rc;
   }
   int rc_all = MURAL_OK;
   int64_t chunk_no = 0;
   for (int64_t c0 = 0; c0 < n && rc_all == MURAL_OK; c0 += INDEL_CHUNK, ++chunk_no) {
     const int B = (int)std::min<int64_t>(INDEL_CHUNK, n - c0);
     const int lane = (int)(chunk_no % lanes);
-    hipStream_t stream = lane == 0 ? main_stream : ss->side;
+    hipStream_t stream = lane == 0 ? main_stream : lane == 1 ? ss->side : ss->side2;
     const size_t guard_floats = ws_guard_bytes() / 4;
     float* p = static_cast<float*>(workspace) + (size_t)lane * (INDEL_CHUNK * m->per_pos_floats + INDEL_WS_REGIONS * guard_floats);
     if (chunk_no < lanes) {
@@ -556,8 +562,8 @@ static int indel_forward_impl(const MuralIndelModel* m, const float* distal_x, c
     return MURAL_OK;
     }();
   }
-  if (lanes == 2)
-    if (int rc = ss->join(main_stream)) return rc;     // also on an error: the side stream must not stay forked
+  if (lanes >= 2)
+    if (int rc = ss->join(main_stream, lanes == 3)) return rc;     // also on an error: the side stream must not stay forked
   return rc_all;
 }
 

@@ -247,13 +247,18 @@ def model_predict_m(model, dataloader, criterion, device, n_class, distal=True, 
             account(preds, y, pending)
         pending, rows = [], 0
 
+    # the first flushes are short (fuse_rows / 4, / 2, then fuse_rows): the helper thread, the copy engine and the GPU start working after
+    # a quarter of a flush's collection time instead of a whole one (a loader of two flushes' worth of rows otherwise spends half its time
+    # before anything overlaps)
+    flush_at = max(fuse_rows // 4, 1)
     with torch.no_grad():
         try:
             for batch in dataloader:
                 pending.append(batch)
                 rows += batch[0].shape[0]
-                if rows >= fuse_rows:
+                if rows >= flush_at:
                     flush()
+                    flush_at = min(2 * flush_at, fuse_rows)
             flush()
             complete()
         finally:
