@@ -227,6 +227,62 @@ def test_sharded_driver_takes_the_reuse_path_on_dense_sites_and_matches_oracle(t
         predict_bed_sharded(HipShardForward(model, fa, local_radius=r, local_order=3), bad_bed, segment_center=2500, collect=False)
 
 
+def test_aligned_chromosomes_in_parts_write_the_gathered_route_s_table(tmp_path):
+    """Round 6: a chromosome whose rows already are in the table's order is never gathered -- its rows go through in parts, each part
+    checks its own (segment, strand) groups on the device, the border records are chained.  Real forward, parts of 700 rows, several
+    segments per part and groups that run over part borders: the table is the gathered route's byte for byte, one rank's share of a
+    3-rank run writes its third of it, and a wrong base in the middle of a group that spans parts fails the run."""
+    from mural_amd import predict as P
+    model, orc, r, R = _models(HUMAN[0])
+    rng = np.random.default_rng(77)
+    seqs = {"chr3": _genome(rng, 16_000), "chr7": _genome(rng, 5000, iupac=False)}
+    fa = tmp_path / "g.fa"
+    fa.write_text("".join(f">{k}\n" + "\n".join(s[i:i + 60] for i in range(0, len(s), 60)) + "\n" for k, s in seqs.items()))
+    rows = []
+    for name, s in seqs.items():
+        arr = np.frombuffer(s.encode(), np.uint8)
+        rows += [(name, int(p), "+" if arr[p] == ord("A") else "-") for p in range(len(arr)) if arr[p] in (ord("A"), ord("T"))]
+    bed = tmp_path / "s.bed"
+    bed.write_text("".join(f"{ch}\t{p}\t{p + 1}\t.\t{i % 4}\t{st}\n" for i, (ch, p, st) in enumerate(rows)))
+    old = P._ALIGNED_BLOCKS, P._ALIGNED_PART_ROWS
+    try:
+        tables = {}
+        for aligned in (True, False):
+            P._ALIGNED_BLOCKS, P._ALIGNED_PART_ROWS = aligned, 700
+            T = {}
+            out = tmp_path / ("t%d.tsv" % aligned)
+            n = P.predict_bed_sharded(P.HipShardForward(model, fa, local_radius=r, local_order=3), bed, segment_center=900, sink=P.TsvSink(out),
+                                      collect=False, timings=T)
+            assert n == len(rows) and T.get("aligned_shards", 0) == (2 if aligned else 0)
+            tables[aligned] = open(out, "rb").read()
+        assert tables[True] == tables[False] and tables[True].count(b"\n") == len(rows) + 1
+        P._ALIGNED_BLOCKS = True
+        # rank 1 of 3 (no process group): its part file holds its block's rows of both chromosomes, in the table's order
+        share = tmp_path / "share.tsv"
+        P.predict_bed_sharded(P.HipShardForward(model, fa, local_radius=r, local_order=3), bed, segment_center=900,
+                              sink=P.TsvSink(share, parts=(1, 3)), collect=False, emulate=(1, 3))
+        lines = tables[True].split(b"\n")[1:-1]
+        by_chrom = {c: [ln for ln in lines if ln.split(b"\t")[0] == c.encode()] for c in seqs}
+        want = []
+        for c in sorted(seqs):
+            lo, hi = P.shard_bounds(len(by_chrom[c]), 1, 3)
+            want += by_chrom[c][lo:hi]
+        assert open(str(share) + ".part0001", "rb").read() == b"".join(ln + b"\n" for ln in want)
+        # a C posing as a '+' site in the middle of chr3: its group runs over several parts
+        arr = np.frombuffer(seqs["chr3"].encode(), np.uint8)
+        p_bad = int(np.nonzero(arr == ord("C"))[0][1500])
+        bad_rows = sorted([rw for rw in rows if rw[0] == "chr3"] + [("chr3", p_bad, "+")], key=lambda rw: rw[1])
+        bad = tmp_path / "bad.bed"
+        bad.write_text("".join(f"{ch}\t{p}\t{p + 1}\t.\t0\t{st}\n" for ch, p, st in bad_rows))
+        out = tmp_path / "bad.tsv"
+        with pytest.raises(ValueError, match="different bases"):
+            P.predict_bed_sharded(P.HipShardForward(model, fa, local_radius=r, local_order=3), bad, segment_center=900, sink=P.TsvSink(out),
+                                  collect=False)
+        assert not out.exists()
+    finally:
+        P._ALIGNED_BLOCKS, P._ALIGNED_PART_ROWS = old
+
+
 def test_zero_row_rank_blocks_through_the_real_forward(tmp_path):
     """A rank whose block of a shard is empty (more ranks than rows) calls the real forward with zero sites: both entries return
     (0, n_class) / (0, n_class + 1) without touching the device queue in a way that breaks the next call."""
