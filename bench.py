@@ -954,23 +954,30 @@ def main():
             return idx + DISTAL_RADIUS, (idx & 1).to(torch.uint8)
 
     sites = [step_sites(s) for s in range(total_steps)]
-    gathered = torch.empty((world * B, N_CLASS), dtype=torch.float32, device=device) if world > 1 and not strong else None
+    # weak scaling: every step ends with all ranks' rows on every rank -- the step's all-gather runs beside the next step's compute
+    # (mural_amd.predict.OverlappedGather: two buffers; tests/test_dist_gloo.py); everything is waited for inside the timed region
+    from mural_amd.predict import OverlappedGather
+    gather = OverlappedGather(B, N_CLASS, torch.float32, device) if world > 1 and not strong else None
+    gathered = None
     parts = []
 
     def one_step(s):
+        nonlocal gathered
         pos, strand = sites[s]
         out = fwd(pos, strand)
         if strong:
             if s >= args.warmup:
                 parts.append(out)
         elif world > 1:
-            dist.all_gather_into_tensor(gathered, out)
+            gathered = gather.result(gather.submit(out))
         return out
 
     full = None
     with torch.no_grad():
         for s in range(args.warmup):
             out = one_step(s)
+        if gather is not None:
+            gather.finish()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -981,6 +988,8 @@ def main():
             out = one_step(s)
         if strong:                                   # ONE collective for the whole pass: every rank ends with all 10M rows
             full = all_gather_rows(torch.cat(parts), GENOME_SITES)
+        if gather is not None:
+            gather.finish()                          # the last steps' collectives end inside the timed region
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()

@@ -469,3 +469,43 @@ def test_aligned_verdict_walks_groups_over_block_borders():
     ok((5, 0, 1, 2, 3, 1, -1, 0), (4, 3, 1, 2, 3, 1, 2, 0), (1, 3, -1, 2, 3, -1, 2, 0))
     bad((5, 0, 1, 2, 3, 1, -1, 0), (4, 3, 1, 2, 3, 1, 2, 0), (1, 3, -1, 0, 3, -1, 0, 0))
     bad((5, 0, 1, 2, 3, 1, 2, 0), (4, 5, 1, 2, 7, 0, 3, 1))                 # a rank's own verdict
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from mural_amd.predict import OverlappedGather
+        rows, width, steps = 7, 3, 6
+        og = OverlappedGather(rows, width, torch.float32, torch.device("cpu"))
+        seen = []
+        for s in range(steps):
+            local = torch.full((rows, width), float(100 * s + rank)) + torch.arange(rows)[:, None]
+            i = og.submit(local)
+            seen.append((s, i))
+        og.finish()
+        # the two buffers hold the last two steps, every rank's block in rank order
+        ok = True
+        for s, i in seen[-2:]:
+            want = torch.cat([torch.full((rows, width), float(100 * s + r)) + torch.arange(rows)[:, None] for r in range(world)])
+            ok &= bool(torch.equal(og.result(i), want))
+        ok &= [i for _, i in seen] == [0, 1, 0, 1, 0, 1]
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_overlapped_gather_double_buffers_the_step_collective(world):
+    """bench.py's weak-scaling collective: asynchronous all-gathers into two alternating buffers deliver every rank's rows in rank order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res), res
