@@ -366,6 +366,21 @@ int mural_op_clip_grad_norm(float* flat, int64_t n, float max_norm, double* scra
 int mural_op_adam_flat(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, double lr, double beta1,
                        double beta2, double eps, double weight_decay, int64_t step, void* stream);
 
+/* Long windows (distal_radius from ~15000 up to the first-stage kernel's LDS limit) whose second conv stage fits no fused kernel: the
+ * handle is FRONT-ONLY (mural_snv_tap_layout()[10] == 1; the forward entries above refuse it) and this entry runs what still is fused --
+ * window decode + first layer + pool (model_snv.py:473-476 of the large tower) and its first ResBlock stage on halo'd segments of the
+ * pooled row, 86 % of the model's arithmetic.  s3_out: dev float [n][L3][32] = the large tower's pooled second-stage input (channel-
+ * last), L3 = mural_snv_tap_layout()[3]; the caller finishes per layer (mural_amd/model/generic_eval.py).  Serves every long-window
+ * model (distal_radius >= 2000).                                                                                                    */
+int mural_snv_forward_front(const MuralSnvModel* m, const MuralGenome* genome, const int64_t* pos, const uint8_t* strand, int64_t n,
+                            int32_t local_radius, int32_t local_order, float* s3_out, void* workspace, size_t workspace_bytes, void* stream);
+/* ... and its second half where the mid tower and the head still run fused (mural_snv_tap_layout()[12] == 1; then at most
+ * mural_snv_tap_layout()[11] sites per front / finish pair, both on THE SAME workspace: the front call leaves the local branch's logits
+ * (hence its local_radius / local_order) and the mid tower's pooled row there): large_logits dev float [n][n_class] = the large
+ * tower's fc output computed by the caller from s3_out (model_snv.py:482-495) -> out dev float [n][n_class] log-probabilities.      */
+int mural_snv_forward_finish(const MuralSnvModel* m, const float* large_logits, int64_t n, float* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
+
 /* name of the dominant kernel (the fused tower kernel), for bench.py's roofline report */
 const char* mural_snv_kernel_name(void);
 

@@ -175,6 +175,9 @@ PROTOTYPES = {
                                           C.c_size_t, C.c_void_p, C.c_void_p]),
     "mural_snv_forward_packed": (C.c_int, [C.c_void_p, C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64,
                                            C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mural_snv_forward_front": (C.c_int, [C.c_void_p, C.POINTER(MuralGenome), C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                          C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "mural_snv_forward_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "mural_snv_reuse_supported": (C.c_int, [C.c_void_p]),
     "mural_snv_reuse_chunk_span": (C.c_int64, []),
     "mural_snv_reuse_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32]),

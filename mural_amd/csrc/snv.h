@@ -244,6 +244,9 @@ struct MuralSnvModel {
   // 14 lw_nj, ...) and lw_LB columns (one per site, start lw_SB, ending at the row's end) with 4 halo columns towards the row's
   // interior, gathered from x0 into scratch; their pooled outputs are scattered into s3[0] and the short stages run on whole rows.
   bool longwin;
+  bool front_only;                // long windows whose short stages do not fit the kernels either: only the segmented first stage of the large
+                                  // tower runs here (mural_snv_forward_front); the caller finishes per layer (model/generic_eval.py)
+  bool front_mid;                 // ... and the mid tower's launches + the head fit: mural_snv_forward_finish runs them fused around the caller's large-tower logits
   int lw_nA, lw_LA, lw_LB, lw_SB, lw_nj;
   mural::SnvFwdArgs args_lwA, args_lwB;
   size_t lds_lwA, lds_lwB;

@@ -497,16 +497,24 @@ extern "C" int mural_snv_model_create(const MuralSnvShape* shape, const MuralSnv
             ok = m->lds_lwA && m->lds_lwA <= kLdsTwoPerCu && m->lds_lwB && m->lds_lwB <= kLdsTwoPerCu &&
                  m->args_lwA.geom[0].L[0] == LA && m->args_lwB.geom[0].L[0] == LB;
           }
-          for (int q = 1; q < 4 && ok; ++q) ok = plan_part(q);
+          // the short stages (second / third conv stage of the large tower on whole pooled rows, the mid tower, the head) must fit
+          // their kernels too.  Where only they do not (R >= ~15000: the second-stage row is longer than two waves' nine blocks) the
+          // model is FRONT-ONLY: the segmented first stage -- 86 % of the work -- still runs here (mural_snv_forward_front hands out
+          // the pooled second-stage input) and the caller finishes per layer.
+          bool part_ok[4] = {ok, false, false, false};
+          for (int q = 1; q < 4 && ok; ++q) part_ok[q] = plan_part(q);
+          const bool short_ok = ok && part_ok[1] && part_ok[2] && part_ok[3];
           if (ok) {
             m->longwin = true;
             m->split = true;
+            m->front_only = !short_ok;
+            m->front_mid = !short_ok && part_ok[1] && part_ok[3];      // (the large tower's short stages are what does not fit)
             m->lw_nA = nA; m->lw_LA = LA; m->lw_LB = LB; m->lw_SB = SB; m->lw_nj = nj;
             m->args_lwA.x0_cols = LA;
             m->args_lwB.x0_cols = LB;
             fill_tower_lengths(m->args, sh.distal_len);
             m->lds_bytes = 0;
-            m->chunk = 8192;      // x0 + segment scratch: ~150 KB per site at R = 4000
+            m->chunk = L2 > 1100 ? 4096 : 8192;      // x0 + segment scratch: ~150 KB per site at R = 4000
             P = -1;
           }
         }
@@ -636,6 +644,9 @@ extern "C" int mural_snv_tap_layout(const MuralSnvModel* m, int32_t* o) {
   for (int i = 0; i < 3; ++i) { o[2 + i] = m->args.geom[0].L[i]; o[5 + i] = m->args.geom[1].L[i]; }
   o[8] = 13;
   o[9] = (int32_t)m->lds_bytes;
+  o[10] = m->front_only ? 1 : 0;
+  o[11] = (int32_t)m->chunk;
+  o[12] = m->front_mid ? 1 : 0;
   return MURAL_OK;
 }
 
@@ -650,8 +661,10 @@ namespace mural { unsigned long long* g_tower_stamps = nullptr; }      // diagno
 // stage-1 kernel + tower kernel over chunks of SNV_CHUNK sites (the x0 scratch holds one chunk)
 constexpr int64_t SNV_SMALL_BATCH = 256;   // up to here a call is latency-bound: single launch with one-site tiles
 
+// front_out != nullptr (front-only models): per chunk only the stage-1 kernel and the segmented first stage of the large tower run; the
+// pooled second-stage input goes to front_out [n][L[1]][32] instead of the workspace
 static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool packed, int64_t n, const Workspace& w,
-                      float* out, float* taps, const int32_t* status, hipStream_t stream, bool one_chunk = false) {
+                      float* out, float* taps, const int32_t* status, hipStream_t stream, bool one_chunk = false, float* front_out = nullptr) {
   const int nc = m->shape.n_class;
   const bool small = taps == nullptr && n <= SNV_SMALL_BATCH && m->lds_small > 0 && !dev_env("MURAL_DEBUG_NO_SMALL_BATCH");
   // the short-stage launches of up to SNV_SUPER chunks as ONE launch per tower (super_chunk_sites): the chunks' first-stage launches leave
@@ -696,7 +709,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
           t.s3[1] = w.s3[1];
           t.xlogit = w.xlogit;
           t.local_logits = w.local_logits + c0 * nc;
-          t.out = out + c0 * nc;
+          t.out = out ? out + c0 * nc : nullptr;
           t.taps = nullptr;
           t.stamps = nullptr;
           t.status = status;
@@ -704,13 +717,16 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
           if (int rc = launch_snv_towers(m, t, kind == 0 ? m->lds_lwA : m->lds_lwB, stream)) return rc;
         }
         const int jA = m->lw_nA * nj + 1;      // outputs 0 .. nA nj come from the equal segments, the rest from the last one
-        hipLaunchKernelGGL(lw_scatter_kernel, grid_of(cn * jA * 8), dim3(256), 0, stream, w.vs3A, cn, m->lw_nA, LpA, nj, 0, jA, 0, L3, w.s3[0]);
+        float* s3_dst = front_out ? front_out + (size_t)c0 * L3 * SNV_C : w.s3[0];
+        hipLaunchKernelGGL(lw_scatter_kernel, grid_of(cn * jA * 8), dim3(256), 0, stream, w.vs3A, cn, m->lw_nA, LpA, nj, 0, jA, 0, L3, s3_dst);
         if (L3 > jA)
           hipLaunchKernelGGL(lw_scatter_kernel, grid_of(cn * (L3 - jA) * 8), dim3(256), 0, stream, w.vs3B, cn, 1, LpB, nj, jA, L3,
-                             -(m->lw_SB / 7), L3, w.s3[0]);
+                             -(m->lw_SB / 7), L3, s3_dst);
         MURAL_HIP_CHECK(hipGetLastError());
+        if (front_out && !m->front_mid) break;
         continue;
       }
+      if (front_out && part > 1) break;      // (front-only models: part 1 = the mid tower's first stage into s3[1]; mural_snv_forward_finish does the rest)
       SnvFwdArgs t = split ? m->args_split[part] : (small ? m->args_small : a);
       t.s3[0] = w.s3[0] + (size_t)rel * s3l_site;
       t.s3[1] = w.s3[1] + (size_t)rel * s3m_site;
@@ -723,7 +739,7 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
         t.tile_count = reinterpret_cast<int*>(w.s3[1]);
       }
       t.local_logits = w.local_logits + c0 * nc;
-      t.out = out + c0 * nc;
+      t.out = out ? out + c0 * nc : nullptr;
       t.taps = c0 == 0 ? taps : nullptr;
       t.tap_stride = a.nbuf;
       t.stamps = packed ? mural::g_tower_stamps : nullptr;
@@ -770,6 +786,7 @@ static int forward_dense_impl(const MuralSnvModel* m, const int64_t* cat_x, cons
                               void* workspace, size_t ws_bytes, int32_t* status, float* taps, size_t taps_floats,
                               void* stream_, const uint8_t* symbols = nullptr) {
   MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(!m->front_only, "distal_radius %d: only the first conv stage of this model runs fused (mural_snv_forward_front)", (m->shape.distal_len - 1) / 2);
   MURAL_REQUIRE(n >= 0, "negative batch");
   if (n == 0) return MURAL_OK;
   hipStream_t stream = (hipStream_t)stream_;
@@ -833,6 +850,7 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
                                         const uint8_t* strand, int64_t n, int32_t local_radius, int32_t local_order,
                                         float* out, void* workspace, size_t workspace_bytes, void* stream_) {
   MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(!m->front_only, "distal_radius %d: only the first conv stage of this model runs fused (mural_snv_forward_front)", (m->shape.distal_len - 1) / 2);
   MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
   MURAL_REQUIRE(g->n_amb == 0 || (g->amb_pos && g->amb_sym), "genome: n_amb > 0 needs amb_pos and amb_sym");
   MURAL_REQUIRE(n >= 0, "negative batch");
@@ -866,4 +884,81 @@ extern "C" int mural_snv_forward_packed(const MuralSnvModel* m, const MuralGenom
   s1.pos = pos;
   s1.strand = strand;
   return run_towers(m, s1, m->args, /*packed=*/true, n, w, out, nullptr, nullptr, stream, one_chunk);
+}
+
+// Long windows whose short stages fit no kernel here (front-only models; R from ~15000 up to the stage-1 kernel's LDS limit): window
+// decode + first layer + 15-wide pool (snv_stage1_site_kernel) and the large tower's first conv stage on halo'd segments of the
+// pooled row -- 86 % of the model's arithmetic -- for the sites (pos, strand) of a packed genome.  s3_out: dev float
+// [n][L3][32], the pooled second-stage input of the large tower (RBs1 + max-pool of model_snv.py:473-481, channel-last), L3 =
+// mural_snv_tap_layout()[3].  The caller finishes per layer (mural_amd/model/generic_eval.py: conv2 .. fc of the large tower, the mid
+// tower, the local branch, the head).  Works on every long-window model (the fused ones included).
+extern "C" int mural_snv_forward_front(const MuralSnvModel* m, const MuralGenome* g, const int64_t* pos, const uint8_t* strand, int64_t n,
+                                       int32_t local_radius, int32_t local_order, float* s3_out, void* workspace, size_t workspace_bytes,
+                                       void* stream_) {
+  MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(m->longwin, "mural_snv_forward_front serves long-window models (segmented first stage) only");
+  MURAL_REQUIRE(!m->front_mid || n <= m->chunk, "mural_snv_forward_front: at most %lld sites per call (the workspace carries the mid tower to "
+                "mural_snv_forward_finish)", (long long)m->chunk);
+  MURAL_REQUIRE(g && g->packed2 && g->nmask, "genome pointers must not be NULL");
+  MURAL_REQUIRE(g->n_amb == 0 || (g->amb_pos && g->amb_sym), "genome: n_amb > 0 needs amb_pos and amb_sym");
+  MURAL_REQUIRE(n >= 0, "negative batch");
+  if (n == 0) return MURAL_OK;
+  MURAL_REQUIRE(pos && strand && s3_out, "pos/strand/s3_out must not be NULL");
+  if (workspace_bytes < carve(m, n, false, nullptr, nullptr, true) || !workspace) {
+    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, false, nullptr, nullptr, true), workspace_bytes);
+    return MURAL_E_WORKSPACE;
+  }
+  Workspace w;
+  carve(m, n, false, workspace, &w, true);
+  const MuralSnvShape& sh = m->shape;
+  if (m->front_mid && sh.model_no == 2) {      // the local branch's logits wait in the workspace for the head
+    const int ncol = 2 * local_radius + 1 - (local_order - 1);
+    MURAL_REQUIRE(ncol == sh.local_cols, "local_radius/local_order give %d k-mer columns, model has %d", ncol, sh.local_cols);
+    int64_t sentinel = 1;
+    for (int i = 0; i < local_order; ++i) sentinel *= 4;
+    MURAL_REQUIRE(sentinel + 1 == sh.emb_rows, "local_order %d does not match the embedding table (%d rows)", local_order, sh.emb_rows);
+    if (int rc = mural_encode_kmer(g, pos, strand, n, local_radius, local_order, 0, w.cat, stream_)) return rc;
+    if (int rc = launch_snv_local(m->local, w.cat, n, w.local_logits, (hipStream_t)stream_)) return rc;
+  }
+  Stage1Args s1 = m->s1;
+  s1.genome = *g;
+  s1.pos = pos;
+  s1.strand = strand;
+  return run_towers(m, s1, m->args, /*packed=*/true, n, w, nullptr, nullptr, nullptr, (hipStream_t)stream_, true, s3_out);
+}
+
+// The second half of a front-only model with a fused mid tower (mural_snv_tap_layout()[12] == 1): the mid tower's short stages and the
+// head (model_snv.py:496-513) around the large tower's logits the caller computed per layer from mural_snv_forward_front's s3_out.
+// large_logits: dev float [n][n_class] (the large tower's fc output); workspace: THE SAME buffer the front call of these n sites used
+// (it holds the mid tower's pooled row and the local branch's logits); out: dev float [n][n_class] log-probabilities.
+extern "C" int mural_snv_forward_finish(const MuralSnvModel* m, const float* large_logits, int64_t n, float* out, void* workspace,
+                                        size_t workspace_bytes, void* stream_) {
+  MURAL_REQUIRE(m, "model handle is NULL");
+  MURAL_REQUIRE(m->front_mid, "mural_snv_forward_finish serves front-only models with a fused mid tower only");
+  MURAL_REQUIRE(n >= 0 && n <= m->chunk, "mural_snv_forward_finish: 0 .. %lld sites per call", (long long)m->chunk);
+  if (n == 0) return MURAL_OK;
+  MURAL_REQUIRE(large_logits && out, "large_logits/out must not be NULL");
+  if (workspace_bytes < carve(m, n, false, nullptr, nullptr, true) || !workspace) {
+    set_error("workspace too small: need %zu bytes, got %zu", carve(m, n, false, nullptr, nullptr, true), workspace_bytes);
+    return MURAL_E_WORKSPACE;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  Workspace w;
+  carve(m, n, false, workspace, &w, true);
+  const int nc = m->shape.n_class;
+  MURAL_HIP_CHECK(hipMemcpy2DAsync(w.xlogit, SNV_MAXCLASS * 4, large_logits, (size_t)nc * 4, (size_t)nc * 4, (size_t)n, hipMemcpyDeviceToDevice, stream));
+  SnvFwdArgs t = m->args_split[3];
+  t.s3[0] = w.s3[0];
+  t.s3[1] = w.s3[1];
+  t.n = n;
+  t.x0 = w.x0;
+  t.xlogit = w.xlogit;
+  t.local_logits = w.local_logits;
+  t.out = out;
+  t.taps = nullptr;
+  t.tap_stride = m->args.nbuf;
+  t.stamps = nullptr;
+  t.status = nullptr;
+  t.unit_counter = t.wave ? w.counters + 3 : nullptr;
+  return launch_snv_towers(m, t, m->lds_split[3], stream);
 }

@@ -1259,7 +1259,7 @@ extern "C" int mural_op_maxpool_fwd(const float* x, int64_t rows, int32_t L, int
   const int Lout = (L + 2 * p - k) / s + 1;
   const int64_t total = rows * Lout;
   if (total == 0) return MURAL_OK;
-  if (k >= 256) {
+  if (k >= 64) {      // (a wave per window from one wave's width on: 28 -> 8 us for the 102-wide global max of 16 384 rows)
     const int64_t g = (total + 3) / 4;
     hipLaunchKernelGGL(maxpool_fwd_wide_kernel, dim3((unsigned)(g > 65536 ? 65536 : g)), dim3(256), 0, STREAM, x, rows, L, Lout, k, s,
                        p, y, arg);

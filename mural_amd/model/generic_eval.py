@@ -37,8 +37,21 @@ def invalidate(model=None):
         _wt_cache.pop(m, None)
 
 
+class _NoBn:
+    """Stands for a BatchNorm that was applied already (scale 1, shift 0)."""
+    _made = {}
+
+    def __init__(self, channels, device):
+        key = (int(channels), str(device))
+        if key not in self._made:
+            self._made[key] = (torch.ones(channels, device=device), torch.zeros(channels, device=device))
+        self.pair = self._made[key]
+
+
 def _affine(bn):
     """eval-mode BatchNorm as y = scale * x + shift"""
+    if isinstance(bn, _NoBn):
+        return bn.pair
     key = _stamp(bn.weight, bn.bias, bn.running_mean, bn.running_var) + (float(bn.eps),)
     hit = _affine_cache.get(bn)
     if hit is not None and hit[0] == key:
@@ -159,6 +172,29 @@ def tower(mod, sfx, x, pools):
     feat = _pool(out, out.shape[2], out.shape[2], 0).reshape(out.shape[0], out.shape[1])
     fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
     return _linear(_bn(feat, fc[0], False), fc[2])
+
+
+def tower_tail(mod, sfx, s3, pools):
+    """The tower from its second conv stage on: `s3` (B, C, L3) = conv2's BatchNorm of the pooled output of RBs1 (model_snv.py:477-483:
+    the fused kernels apply that BatchNorm when they write the pooled row), as ``mural_snv_forward_front`` hands it out for long windows."""
+    g = lambda n: getattr(mod, n + sfx)  # noqa: E731
+    out = _bn_conv(s3, _NoBn(s3.shape[1], s3.device), False, g("conv2")[1])
+    out = _pool(_res_blocks(g("RBs2"), out), *pools[2])
+    assert out.shape[2] >= 1, "Error: distal seq is too short for the pooling layers"
+    out = _bn_conv(out, g("conv3")[0], False, g("conv3")[1], post_relu=True)
+    feat = _pool(out, out.shape[2], out.shape[2], 0).reshape(out.shape[0], out.shape[1])
+    fc = mod.distal_fc1 if sfx == "" else mod.distal_fc2
+    return _linear(_bn(feat, fc[0], False), fc[2])
+
+
+def forward_from_front(mod, cat_x, mid_x, s3_large, pools_mid, pools_large):
+    """log-probabilities from the fused front of the large tower (`s3_large` (B, C, L3)), the mid tower's 201-column window `mid_x`
+    (B, 4, 201) and the k-mer ids `cat_x` (None: Network1)."""
+    with torch.no_grad():
+        mid = tower(mod, "", mid_x.to(torch.float32).contiguous(), pools_mid)
+        lar = tower_tail(mod, "_2", s3_large, pools_large)
+        loc = None if cat_x is None else local(mod, cat_x, mod.local_fc[0])
+        return head(loc, mid, lar)
 
 
 def local(mod, cat, out_layer):

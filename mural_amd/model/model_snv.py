@@ -214,15 +214,34 @@ class _HipSnvBase(nn.Module):
 
     def _fused_ok(self):
         """False when the fused kernels are not built for this shape (CNN_out_channels != 32, CNN_kernel_size != 3, a window
-        too long for LDS): the C side refuses the model and eval takes one HIP launch per layer instead."""
+        too long for LDS): the C side refuses the model and eval takes one HIP launch per layer instead.  A FRONT-ONLY handle
+        (distal_radius from ~15000: the second conv stage fits no fused kernel) counts as not fused; ``_front_ok`` tells."""
         if self._fused is None:
             try:
                 with torch.cuda.device(self._device()):
                     self._get_handle()
-                self._fused = True
+                self._fused = not self._handle_front_only()
             except ValueError:
                 self._fused = False
         return self._fused
+
+    def _handle_front_only(self):
+        lay = (C.c_int32 * 16)()
+        _lib.check(_lib.lib().mural_snv_tap_layout(self._handle, lay))
+        self._front_L3, self._front_chunk, self._front_mid = int(lay[3]), int(lay[11]), bool(lay[12])
+        return bool(lay[10])
+
+    def _front_ok(self):
+        """The handle exists but serves ``mural_snv_forward_front`` only: the packed entry then runs the large tower's segmented
+        first stage fused and finishes per layer (generic_eval.forward_from_front)."""
+        if self._fused_ok() or self.model_no == 0:
+            return False
+        try:
+            with torch.cuda.device(self._device()):
+                self._get_handle()
+                return self._handle_front_only()
+        except ValueError:
+            return False
 
     def _release(self):
         if getattr(self, "_handle", None) is not None:
@@ -354,6 +373,34 @@ class _HipSnvBase(nn.Module):
         n = pos.shape[0]
         if local_radius is None:
             local_radius = (getattr(self, "no_of_cat", 1) + local_order - 2) // 2
+        if self.model_no != 0 and self._front_ok():
+            # a window too long for the fused short stages of the large tower: stage 1 and that tower's first conv stage (86 % of the
+            # arithmetic) run fused on segments of the pooled row, its remaining ten layers per layer (generic_eval.tower_tail), and --
+            # where their launches fit -- the mid tower, the local branch and the head fused again around its logits
+            from . import generic_eval
+            lib = _lib.lib()
+            with torch.cuda.device(dev):
+                handle = self._get_handle()
+                L3, step = self._front_L3, (self._front_chunk if self._front_mid else max(n, 1))
+                g = genome.as_struct(dev)
+                stream = _lib.current_stream_ptr(dev)
+                ws = self._workspace(max(min(n, step), 1), dev, dense=False)      # (kept with the model: the finish call reads what the front call left)
+                out = torch.empty((n, self.n_class), dtype=torch.float32, device=dev)
+                for c0 in range(0, n, step):
+                    p, st = pos[c0:c0 + step], strand[c0:c0 + step]
+                    m = p.shape[0]
+                    s3 = torch.empty((m, L3, 32), dtype=torch.float32, device=dev)
+                    _lib.check(lib.mural_snv_forward_front(handle, C.byref(g), p.data_ptr(), st.data_ptr(), m, int(local_radius), int(local_order),
+                                                          s3.data_ptr(), ws.data_ptr(), ws.numel(), stream))
+                    s3 = s3.permute(0, 2, 1).contiguous()
+                    if self._front_mid:
+                        large = generic_eval.tower_tail(self, "_2", s3, POOLS_LARGE).contiguous()
+                        _lib.check(lib.mural_snv_forward_finish(handle, large.data_ptr(), m, out[c0:c0 + m].data_ptr(), ws.data_ptr(), ws.numel(),
+                                                               stream))
+                    else:
+                        cat = genome.encode_kmer(p, st, int(local_radius), int(local_order)) if self.model_no == 2 else None
+                        out[c0:c0 + m] = generic_eval.forward_from_front(self, cat, genome.encode_onehot(p, st, 100), s3, POOLS_MID, POOLS_LARGE)
+                return out
         if self.model_no != 0 and not self._fused_ok():
             from . import generic_eval
             with torch.cuda.device(dev):

@@ -689,8 +689,33 @@ def test_long_window_writes_stay_inside_their_workspace_regions(monkeypatch):
             assert len(zone) == guard and (zone == 255).all(), f"region {i} (dense={dense}): a kernel wrote behind its {size} bytes"
 
 
+def test_front_only_long_windows_in_chunks():
+    """R = 16000 (front-only handle with a fused mid tower): more sites than one front / finish pair takes (4096) go through in chunks on
+    one workspace -- every site's result is the one it gets in a call of its own block (per-site results do not depend on the batch)."""
+    from mural_amd.data import PackedGenome
+    R, r = 16000, 7
+    rng = np.random.default_rng(3)
+    seq = rng.choice(np.frombuffer(b"ACGTN", np.uint8), size=60_000, p=[.248, .248, .248, .248, .008]).tobytes().decode()
+    genome = PackedGenome.from_sequence(seq, "cuda")
+    model, _ = product_from_hp(np.array([r, 3, R, 150, 75, 32, 3, 4, 2]))
+    model.load_state_dict(synth.synth_state_dict(model.state_dict(), 11))
+    model = model.cuda().eval()
+    n = 4096 + 300
+    pos = torch.from_numpy(rng.integers(0, 60_000, size=n)).cuda()
+    strand = torch.from_numpy(rng.integers(0, 2, size=n).astype(np.uint8)).cuda()
+    with torch.no_grad():
+        whole = model.forward_packed(genome, pos, strand, local_radius=r, local_order=3)
+        assert model._front_ok() and model._front_mid and model._front_chunk == 4096
+        a = model.forward_packed(genome, pos[:1000], strand[:1000], local_radius=r, local_order=3)
+        b = model.forward_packed(genome, pos[4000:], strand[4000:], local_radius=r, local_order=3)
+    assert torch.isfinite(whole).all()
+    assert float((whole[:1000] - a).abs().max()) <= 1e-5 and float((whole[4000:] - b).abs().max()) <= 1e-5
+
+
 @pytest.mark.parametrize("R,model_no,fused", [(2000, 2, True), (4000, 2, True), (4000, 1, True), (3000, 2, True), (2000, 2, False), (4000, 1, False),
-                                              (8000, 2, True), (16000, 2, False)])      # (R = 16000: the C side keeps the per-layer path by itself)
+                                              (8000, 2, True), (16000, 2, False), (16000, 1, False)])
+# (R = 16000: a FRONT-ONLY handle -- the packed entry runs stage 1 and the large tower's segmented first stage fused and finishes per layer,
+# the dense entry stays per-layer)
 def test_long_windows_match_oracle(R, model_no, fused, monkeypatch):
     """Windows beyond the shipped radius (the reference advertises inputs of up to 64 kb, CHANGELOG:13).  The pooled first-stage row of
     the large tower (267 / 400 / 534 columns at R = 2000 / 3000 / 4000) does not fit a wave's LDS image: the fused path runs that
@@ -726,6 +751,6 @@ def test_long_windows_match_oracle(R, model_no, fused, monkeypatch):
         got = model.forward_packed(genome, torch.from_numpy(pos).cuda(), torch.from_numpy(strand).cuda(), local_radius=r,
                                    local_order=3).cpu().numpy()
         dense = model((torch.zeros(len(pos), 1, dtype=torch.float64).cuda(), cat.cuda()), x.cuda()).cpu().numpy()
-    assert model._fused_ok() == fused
+    assert model._fused_ok() == fused and model._front_ok() == (R >= 15000)
     assert_probs_close(got, want, model_no, f"packed R={R}")
     assert_probs_close(dense, want, model_no, f"dense R={R}")

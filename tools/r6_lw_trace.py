@@ -10,7 +10,7 @@ import bench  # noqa: E402
 from mural_amd.data import PackedGenome  # noqa: E402
 
 dev = torch.device("cuda", 0)
-R, n = 4000, int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+R, n = int(os.environ.get("LW_R", "4000")), int(sys.argv[1]) if len(sys.argv) > 1 else 2048
 codes = bench.synthetic_genome(2_000_000 + 2 * R)
 packed, mask = bench.pack2(codes)
 genome = PackedGenome(packed, mask, len(codes), dev)
