@@ -323,9 +323,9 @@ def indel_model_and_weights(device):
     return model.to(device), weights
 
 
-def indel_positions_per_s(device, genome, n=204_800, chunk=20_480):
+def indel_positions_per_s(device, genome, n=196_608, chunk=24_576):
     """BASELINE.json configs[3]: UNet_Small, human-insertion geometry (L=8000, 8 classes, use_reverse), 2e5 positions decoded from
-    the packed genome inside the timed region (10 calls of 20480 positions = 10 internal chunks of 2048 each, two in flight; two
+    the packed genome inside the timed region (8 calls of 24576 positions = 6 internal chunks of 4096 each, two in flight; two
     warm-up calls)."""
     model, weights = indel_model_and_weights(device)
     model.eval()

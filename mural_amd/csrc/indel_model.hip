@@ -16,7 +16,16 @@ namespace {
 
 static_assert(sizeof(MuralIndelShape) > 0, "header");
 constexpr int INDEL_LEVELS = 6;
-constexpr int INDEL_CHUNK = 2048;   // positions per pass of the layer program (1.8 MB of activation scratch each: 3.8 GB)
+// positions per pass of the layer program (1.8 MB of activation scratch each, two passes in flight: 15 GB).  4096 instead of 2048
+// (round 6): 964 -> 989 k positions/s -- half as many launches, each twice as long, and the largest tensor (4096 x 8 x 8000 floats) still
+// within the 2^31-byte reach of the barrier-free kernels' buffer offsets.  (MURAL_INDEL_CHUNK: A/B switch of the debug flavour, 256 .. 4096)
+constexpr int INDEL_CHUNK_DEFAULT = 4096;
+static int indel_chunk() {
+  const char* e = dev_env("MURAL_INDEL_CHUNK");
+  const int c = e ? atoi(e) : INDEL_CHUNK_DEFAULT;
+  return c >= 256 && c <= 4096 ? c : INDEL_CHUNK_DEFAULT;
+}
+#define INDEL_CHUNK indel_chunk()
 
 struct FoldedConv { size_t w, b; int Cin, Cout, K; };   // offsets into the blob; w laid out [Cin][K][Cout]
 

@@ -38,8 +38,9 @@ def test_forward_matches_reference(name):
     assert np.abs(sm(out.astype(np.float64)) - sm(want.astype(np.float64))).max() <= 1e-5
 
 
-def test_batch_larger_than_chunk_and_packed_path():
+def test_batch_larger_than_chunk_and_packed_path(monkeypatch):
     from mural_amd.data import PackedGenome
+    monkeypatch.setenv("MURAL_INDEL_CHUNK", "256")      # 300 positions: two chunks, one per stream (the default chunk is 4096)
     from oracle import encode_ref
     fx = U.load("indel_synth_small.npz")
     model = product_from(fx)
@@ -69,6 +70,7 @@ def test_forward_does_not_read_unwritten_workspace(monkeypatch):
     """The eval-mode forward's workspace (two chunks in flight) with 0xFF-poisoned allocations: same scores."""
     from mural_amd.model import model_indel as MI
     from tests.test_gpu_snv import _PoisonedTorch
+    monkeypatch.setenv("MURAL_INDEL_CHUNK", "512")      # 700 windows: two chunks in flight
     fx = U.load("indel_synth_small.npz")
     model = product_from(fx)
     orc = U.indel_oracle_from_hp(fx["hp"], fx["down"])
@@ -91,6 +93,7 @@ def test_forward_writes_stay_inside_their_workspace_regions(monkeypatch):
     from tests.test_gpu_snv import _PoisonedTorch
     guard = 4096
     monkeypatch.setenv("MURAL_DEBUG_WS_GUARD", str(guard))
+    monkeypatch.setenv("MURAL_INDEL_CHUNK", "2048")     # 2500 windows: both lanes
     monkeypatch.setattr(MI, "torch", _PoisonedTorch())
     fx = U.load("indel_synth_small.npz")
     model = product_from(fx)
