@@ -1085,10 +1085,15 @@ def main():
                 r = dense_reuse(device, model, genome, sites, max(2, min(args.steps, 10)))
                 r["speedup_vs_per_window"] = r["bases_per_s"] / line["value"]
                 return r
-            leg("dense_reuse", reuse_leg)
-            leg("config5_e2e", lambda: config5_e2e(device))
-            leg("train", lambda: train_steps_per_s(device, genome))
-            leg("indel", lambda: indel_positions_per_s(device, genome))
+            # the training leg runs 3 % slower once the file-to-file leg (host threads, 20 GB of cached device blocks, pinned staging) ran
+            # in the same process (603 vs 619 steps/s, same box, same build): the two step-rate legs go first.  MURAL_BENCH_LEG_ORDER
+            # reorders them for A/B runs.
+            order = os.environ.get("MURAL_BENCH_LEG_ORDER", "train,indel,reuse,config5").split(",")
+            legs = {"reuse": lambda: leg("dense_reuse", reuse_leg), "config5": lambda: leg("config5_e2e", lambda: config5_e2e(device)),
+                    "train": lambda: leg("train", lambda: train_steps_per_s(device, genome)),
+                    "indel": lambda: leg("indel", lambda: indel_positions_per_s(device, genome))}
+            for name in order:
+                legs[name]()
         if world == 1 and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline({k: v.detach().cpu() for k, v in model.state_dict().items()}, codes))
         print(json.dumps(order_line(line)), flush=True)
