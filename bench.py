@@ -1073,6 +1073,10 @@ def main():
         def leg(name, fn):
             # the secondary objects must not cost the headline its line: a failure is reported in place of the object
             try:
+                if os.environ.get("MURAL_BENCH_EMPTY_CACHE", "1") == "1":      # every leg starts from fresh device allocations
+                    import gc
+                    gc.collect()
+                    torch.cuda.empty_cache()
                 line[name] = fn()
             except Exception as e:      # noqa: BLE001
                 line[name] = {"error": f"{type(e).__name__}: {e}"[:500]}
