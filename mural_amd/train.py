@@ -297,10 +297,15 @@ class Adam(torch.optim.Adam):
 
     @torch.no_grad()
     def step(self, closure=None):
+        # (torch wraps the step of every optimizer class -- this one too -- with its step hooks: they fire around either route; the
+        # parent's step is called without ITS wrapper so that they do not fire twice)
         if closure is None and self._flat_step():
             return None
         self._leave_flat()
-        return super().step(closure)
+        parent = torch.optim.Adam.step
+        if getattr(parent, "hooked", False):
+            parent = getattr(parent, "__wrapped__", parent)
+        return parent(self, closure)
 
     def state_dict(self):
         self._materialise_steps()

@@ -358,5 +358,12 @@ def test_train_adam_is_torch_adam_off_the_hip_path():
     assert all(torch.equal(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"]) and float(sa["state"][k]["step"]) == 3.0 for k in sa["state"])
     oa.load_state_dict(sb)
     assert oa.step(lambda: torch.tensor(1.0)) == torch.tensor(1.0)      # a closure goes to torch's step as well
+    seen = []
+    h = oa.register_step_post_hook(lambda o, args, kwargs: seen.append(1))      # step hooks keep firing (they hang off torch's step)
+    oa.zero_grad()
+    a(torch.randn(2, 5)).sum().backward()
+    oa.step()
+    h.remove()
+    assert seen == [1]
     opt = make_optimizer({"optim": "Adam", "learning_rate": 1e-3, "weight_decay": 1e-5}, a.parameters())
     assert isinstance(opt, Adam) and isinstance(opt, torch.optim.Adam)
