@@ -107,6 +107,12 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
   float* logit = feat + 2 * P * SNV_C;         // [3][P][SNV_MAXCLASS]: large, mid, local
   float* par = logit + 3 * P * SNV_MAXCLASS;   // per tower: ex_s[4][32] | ex_t[4][32] | fc_w[nc][32] | fc_b[nc..]
   const int par_stride = 2 * EX_COUNT * SNV_C + args.n_class * SNV_C + SNV_MAXCLASS;
+  // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator layout (below).  The
+  // tower-parallel small-call launch asks for them HERE, in front of the parameter staging and its barrier: a 16-site call is one tile
+  // per workgroup, and its 7 us of start-up were three memory round trips in a row (parameters, barrier, activations).
+  f32x4 xres[SNV_NB2MAX];
+  if constexpr (PHASE == 3)
+    request_x0(args, xres, (int64_t)(blockIdx.x >> 1), (int)(blockIdx.x & 1u), (args.n + P - 1) / P, cgp, n16, 16 * mb + 4 * kk);
   for (int t2 = 0; t2 < 2; ++t2) {             // small per-channel parameters: resident for the whole launch
     float* d = par + t2 * par_stride;
     const TowerDev& tw = args.tw[t2];
@@ -131,14 +137,12 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
 #define TILE0 (TPAR ? (int64_t)(blockIdx.x >> 1) : (int64_t)blockIdx.x)
 #define TILE_STEP (TPAR ? (gridDim.x >> 1) : gridDim.x)
 
-  // Stage-1 activations of (tile, tower) are requested straight into the residual registers, in MFMA accumulator
-  // layout, one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
-  f32x4 xres[SNV_NB2MAX];
+  // ... one tower ahead: the HBM/L2 latency hides under the previous tower's global max / head.
   X0Plan xplan;
   if (PHASE == 1) {
     xplan = x0_plan(args, TW_FIRST, cgp, n16);
     request_x0_planned(args, xplan, xres, TILE0, TW_FIRST, n_tiles, chv);
-  } else if (PHASE != 2) {
+  } else if (PHASE != 2 && PHASE != 3) {
     request_x0(args, xres, TILE0, TW_FIRST, n_tiles, cgp, n16, chv);
   }
   const bool do_head = args.tw_last == 1 && PHASE != 1;
@@ -369,10 +373,13 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
         const int p = tid / args.n_class, k = tid - p * args.n_class;
         if (row0 + p < args.n) mine[(row0 + p) * SNV_MAXCLASS + k] = logit[(TW_FIRST * P + p) * SNV_MAXCLASS + k];
       }
-      __threadfence();
+      // (one release by the thread that counts, behind the barrier that collects every wave's stores, and one acquire by the same thread:
+      // the workgroup's other threads read the pair's logits with device-scope atomic loads.  A fence by all 256 threads on either side --
+      // each an L2 write-back / invalidate of the XCD, the pair's workgroups never share one -- cost the last arriver 8.5 us.)
       __syncthreads();
       float* flag = feat + (1 - TW_FIRST) * P * SNV_C;   // the other tower's slot of feat is unused by this workgroup
       if (tid == 0) {
+        __threadfence();
         const int old = atomicAdd(&args.tile_count[tile], 1);
         __threadfence();
         flag[0] = __int_as_float(old);
@@ -381,7 +388,6 @@ __global__ __launch_bounds__(SNV_THREADS, 2) void snv_towers_fused(const SnvFwdA
       const bool last = __float_as_int(flag[0]) != 0;
       __syncthreads();   // flag is read by everyone before a later tile's global max could overwrite the slot
       if (!last) continue;
-      __threadfence();
       if (tid < P * args.n_class) {
         const int p = tid / args.n_class, k = tid - p * args.n_class;
         const bool in = row0 + p < args.n;
