@@ -745,7 +745,21 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
       t.stamps = packed ? mural::g_tower_stamps : nullptr;
       t.status = status;
       t.unit_counter = split && t.wave ? w.counters + part : nullptr;
-      const size_t lds = split ? m->lds_split[part] : (small ? m->lds_small : m->lds_bytes);
+      size_t lds = split ? m->lds_split[part] : (small ? m->lds_small : m->lds_bytes);
+      // A workgroup-tile short-stage launch (long windows) packs P sites into a tile so that two workgroups fill a CU -- and then a call of
+      // a few hundred windows is a few dozen workgroups on 256 CUs (R = 4000, 512 windows: 171 and 52).  Such a call takes the tile
+      // with the fewest sites that still gives every CU two workgroups: same arithmetic per site, a third of the serial work per workgroup.
+      if (split && !t.wave && part >= 2 && t.P > 1 && !dev_env("MURAL_DEBUG_NO_CALL_P")) {
+        const int want = (int)std::max<int64_t>(1, std::min<int64_t>(t.P, (cn + 511) / 512));
+        if (want < t.P) {
+          SnvFwdArgs t2 = t;
+          const size_t need = plan_geometry(t2, m->shape.distal_len, want, m->shape.n_class, (part & 1) ? 2 : 1, 2);
+          if (need && need <= lds) {
+            t = t2;
+            lds = need;
+          }
+        }
+      }
       if (int rc = launch_snv_towers(m, t, lds, stream)) return rc;
     }
   }
