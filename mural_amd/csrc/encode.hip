@@ -27,6 +27,7 @@ const DevSwitch* dev_switch_table() {
     {"MURAL_TOWER_DYNAMIC_UNITS", "A/B, bit-identical: SNV predict units through a global ticket counter instead of the fixed stride"},
     {"MURAL_SNV_DEFER_SHORT", "A/B, bit-identical: =0 runs the short-stage launches per chunk (what a one-chunk workspace does by itself)"},
     {"MURAL_LOCAL_REG", "A/B, bit-identical: =0 keeps the local MLP's weight fragments in LDS (snv_local_mlp_mfma)"},
+    {"MURAL_DEBUG_LW_SEPARATE", "A/B, same results: the long-window first-stage jobs (two segment kinds, mid tower) as three launches instead of one"},
     {"MURAL_DEBUG_NO_CALL_P", "A/B, same results: long-window short-stage launches keep the model's tile size for small calls too"},
     {"MURAL_INDEL_CHUNK", "A/B, same results: positions per pass of the INDEL layer program (256 .. 4096; default 2048)"},
     {"MURAL_INDEL_LANES", "A/B, same results: INDEL forward chunks in flight (1..3 streams; default 2)"},

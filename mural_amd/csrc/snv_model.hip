@@ -11,6 +11,7 @@
 
 namespace mural {
 int launch_snv_towers(const MuralSnvModel* m, const SnvFwdArgs& a, size_t lds_bytes, hipStream_t stream);
+int launch_snv_tower_wave_jobs(const SnvFwdArgs* jobs, const size_t* lds_bytes, int n, hipStream_t stream);   // snv_tower_wave.hip
 int launch_snv_stage1(const Stage1Args& a, bool packed, size_t lds_bytes, hipStream_t stream);
 size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int tower, int phase);   // snv_tower_wave.hip
 int launch_snv_local(const LocalDev& L, const int64_t* cat, int64_t n, float* out, hipStream_t stream);
@@ -688,7 +689,9 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
     // (the unit counters are read only with MURAL_TOWER_DYNAMIC_UNITS=1: the fill is a 4 us launch per chunk otherwise wasted)
     if (split && dev_env("MURAL_TOWER_DYNAMIC_UNITS") && atoi(dev_env("MURAL_TOWER_DYNAMIC_UNITS")) != 0)
       MURAL_HIP_CHECK(hipMemsetAsync(w.counters, 0, 64, stream));
+    bool lw_mid_done = false;      // (long windows: the mid tower's first stage rode in the segments' launch)
     for (int part = 0; part < (split ? (defer ? 2 : 4) : 1); ++part) {
+      if (part == 1 && lw_mid_done) continue;
       if (m->longwin && part == 0) {
         // the large tower's first conv stage on segments of the pooled row: gather (with halo) -> two wave-private launches (the
         // lw_nA equal segments of every site, then the one that ends with the row) -> scatter of the pooled columns into s3[0]
@@ -697,6 +700,12 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
         auto grid_of = [](int64_t items) { return dim3((unsigned)std::min<int64_t>((items + 255) / 256, 65536)); };
         // (round 6: the segments are read in place from x0 -- SnvFwdArgs::seg_n -- instead of being copied out with their halo first:
         // 2 x 70 MB per 512 windows at R = 4000 and two launches less)
+        // the two segment launches and the mid tower's first-stage launch are three jobs of one kernel instance: ONE launch (each launch of
+        // its own pays ~14 us of start-up next to 22 us per unit; MURAL_DEBUG_LW_SEPARATE: three launches, same results)
+        SnvFwdArgs lw_jobs[3];
+        size_t lw_lds[3];
+        const bool lw_merge = m->args_lwA.wave && m->args_lwB.wave && m->args_split[1].wave && !dev_env("MURAL_DEBUG_LW_SEPARATE") &&
+                              (!front_out || m->front_mid);
         for (int kind = 0; kind < 2; ++kind) {
           SnvFwdArgs t = kind == 0 ? m->args_lwA : m->args_lwB;
           t.n = kind == 0 ? cn * m->lw_nA : cn;
@@ -714,7 +723,31 @@ static int run_towers(const MuralSnvModel* m, Stage1Args s1, SnvFwdArgs a, bool 
           t.stamps = nullptr;
           t.status = status;
           t.unit_counter = w.counters + 4 + kind;
-          if (int rc = launch_snv_towers(m, t, kind == 0 ? m->lds_lwA : m->lds_lwB, stream)) return rc;
+          if (lw_merge) {
+            lw_jobs[kind] = t;
+            lw_lds[kind] = kind == 0 ? m->lds_lwA : m->lds_lwB;
+          } else if (int rc = launch_snv_towers(m, t, kind == 0 ? m->lds_lwA : m->lds_lwB, stream)) {
+            return rc;
+          }
+        }
+        if (lw_merge) {
+          SnvFwdArgs t = m->args_split[1];      // the mid tower's first conv stage (what part 1 of this loop launches otherwise)
+          t.s3[0] = w.s3[0];
+          t.s3[1] = w.s3[1];
+          t.n = cn;
+          t.x0 = w.x0;
+          t.xlogit = w.xlogit;
+          t.local_logits = w.local_logits + c0 * nc;
+          t.out = out ? out + c0 * nc : nullptr;
+          t.taps = nullptr;
+          t.tap_stride = a.nbuf;
+          t.stamps = nullptr;
+          t.status = status;
+          t.unit_counter = nullptr;
+          lw_jobs[2] = t;
+          lw_lds[2] = m->lds_split[1];
+          if (int rc = launch_snv_tower_wave_jobs(lw_jobs, lw_lds, 3, stream)) return rc;
+          lw_mid_done = true;
         }
         const int jA = m->lw_nA * nj + 1;      // outputs 0 .. nA nj come from the equal segments, the rest from the last one
         float* s3_dst = front_out ? front_out + (size_t)c0 * L3 * SNV_C : w.s3[0];

@@ -20,6 +20,7 @@
 // Launches (per chunk of <= 131072 sites, like the workgroup-tile form): (large | mid) x (first conv stage | short stages + fc
 // (+ head)), with Pw = 1 | 2 sites per wave in the first conv stage (136 / 137 columns = 9 blocks) and 6 | 5 in the short stages.
 #include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 #include "snv_tower_conv.h"
@@ -383,7 +384,7 @@ __device__ __forceinline__ uint32_t cu_key() {
   do {                                                                               \
     if (args.stamps != nullptr && lane == 0 && wave == 0) {                          \
       const unsigned long long _t = __builtin_amdgcn_s_memtime();                    \
-      args.stamps[(size_t)blockIdx.x * 32 + (PHASE == 1 ? 0 : 8) + 16 * tw_i + (id)] += _t - t_prev; \
+      args.stamps[(size_t)SNVW_BX * 32 + (PHASE == 1 ? 0 : 8) + 16 * tw_i + (id)] += _t - t_prev; \
       t_prev = _t;                                                                   \
     }                                                                                \
   } while (0)
@@ -393,410 +394,33 @@ __device__ __forceinline__ uint32_t cu_key() {
 // unit loop (with ~100 SGPRs live the backend re-reads them with s_load + wait at every use); TWC < 0: geometry from the arguments.
 template <int PHASE, int NBA, int NBB, int TWC = -1, int PWC = 0>
 __global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave(const SnvFwdArgs args) {
-  extern __shared__ __attribute__((aligned(16))) float smem[];
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int n16 = lane & 15, kk = lane >> 4;
-  constexpr bool SHIP = TWC >= 0;
-  const int Pw = SHIP ? PWC : args.P;
-  const int tw_i = SHIP ? TWC : args.tw_first;
-  unsigned long long t_prev = args.stamps != nullptr ? __builtin_amdgcn_s_memtime() : 0ull;
-  // diagnostic: wall-clock (100 MHz) start / end of every wave of the last launch of each (phase, tower), rows 1024.. of the stamp buffer
-  if (args.stamps != nullptr && lane == 0) {
-    unsigned long long* row = args.stamps + (size_t)(1024 + 2 * blockIdx.x + (wave >> 1)) * 32;
-    row[((PHASE - 1) * 2 + tw_i) * 4 + 2 * (wave & 1)] = __builtin_amdgcn_s_memrealtime();
-    if (PHASE == 1 && tw_i == 0) {
-      row[16 + 2 * (wave & 1)] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);       // HW_ID
-      row[17 + 2 * (wave & 1)] = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);       // XCC_ID
-    }
-  }
-  constexpr TowerGeom g_ship = wave_tower_geom(SHIP ? TWC : 0, SHIP_LWIN, SHIP ? PWC : 1);
-  const TowerGeom& g_arg = args.geom[SHIP ? 0 : tw_i];
-  const TowerGeom& g = SHIP ? g_ship : g_arg;
-  const TowerDev& tw = args.tw[tw_i];
-  // stage-1 activations: [site][x0_cols][32], the large tower's columns first
-  const int L0_large = SHIP ? wave_tower_geom(0, SHIP_LWIN, 1).L[0] : args.geom[0].L[0];
-  const int x0_cols = SHIP ? wave_tower_geom(0, SHIP_LWIN, 1).L[0] + wave_tower_geom(1, SHIP_LWIN, 1).L[0] : args.x0_cols;
-  const int x0c = tw_i == 0 ? 0 : L0_large;
-  // LDS: par (shared, read-only after the first barrier) | per wave: image [nbuf] | feat [Pw][32] | logit [3][Pw][16] | dump [TW_DUMP]
-  // par: ex_s[4][32] | ex_t[4][32] | fc_w[nc][32] | fc_b[16] | arrival slot[4] | lpar[6 layers][3: bias, post_s, post_t][32]
-  const int lpar0 = 2 * EX_COUNT * SNV_C + args.n_class * SNV_C + SNV_MAXCLASS + 4;
-  const int par_floats = lpar0 + 6 * 3 * SNV_C;
-  float* par = smem;
-  const int wave_floats = args.nbuf + (PHASE == 2 ? Pw * SNV_C + 3 * Pw * SNV_MAXCLASS : 0) + TW_DUMP;
-  const uint32_t dump0 = 4u * (uint32_t)(wave_floats - TW_DUMP);      // dump slots: the last TW_DUMP floats of the wave's region
-  float* img = smem + par_floats + wave * wave_floats;
-  float* feat = img + args.nbuf;
-  float* logit = feat + Pw * SNV_C;
-  for (int i = tid; i < EX_COUNT * SNV_C; i += SNV_THREADS) {
-    par[i] = tw.ex_s[i];
-    par[EX_COUNT * SNV_C + i] = tw.ex_t[i];
-  }
-  for (int i = tid; i < args.n_class * SNV_C; i += SNV_THREADS) par[2 * EX_COUNT * SNV_C + i] = tw.fc_w[i];
-  if (tid < args.n_class) par[2 * EX_COUNT * SNV_C + args.n_class * SNV_C + tid] = tw.fc_b[tid];
-  {      // per-layer epilogue constants of the layers this launch runs: read from LDS at every layer start (no VMEM in the loop)
-    const int l0 = PHASE == 1 ? 0 : 4, nl = PHASE == 1 ? 4 : 6;
-    for (int i = tid; i < nl * SNV_C; i += SNV_THREADS) {
-      const int l = i >> 5, c = i & 31;
-      par[lpar0 + (l * 3 + 0) * SNV_C + c] = tw.bias[(l0 + l) * 32 + c];
-      par[lpar0 + (l * 3 + 1) * SNV_C + c] = tw.post_s[(l0 + l) * 32 + c];
-      par[lpar0 + (l * 3 + 2) * SNV_C + c] = tw.post_t[(l0 + l) * 32 + c];
-    }
-  }
-  // the two image columns no epilogue ever writes: column 0 (tap 0 of the first column) and the column behind the widest stage's
-  // last block (tap 2 of its last column) stay zero for the whole launch
-  {
-    const int st0 = PHASE == 1 ? 0 : 1;
-    if (lane < 8) st4(img + lds_off(0, lane), splat(0.f));
-    else if (lane < 16) st4(img + lds_off(16 * g.nb[st0] + 1, lane - 8), splat(0.f));
-    if (PHASE == 1) wave_zero_gaps(img, g, 0, Pw, lane);      // once: no layer of this launch stores into a gap column
-  }
-  if (args.stagger > 0 && tid == 0) {
-    const uint32_t key = cu_key();
-    const int cnt = atomicAdd(&g_cu_arrivals[key], 1);
-    par[lpar0 - 1] = __int_as_float(cnt);
-    if (args.stamps != nullptr && PHASE == 1 && tw_i == 0) {      // diagnostic: which CU, which arrival
-      args.stamps[(size_t)blockIdx.x * 32 + 30] = key;
-      args.stamps[(size_t)blockIdx.x * 32 + 31] = (unsigned long long)cnt;
-      args.stamps[(size_t)blockIdx.x * 32 + 29] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-    }
-  }
-  __syncthreads();      // the only workgroup barrier of the kernel
-  if (args.stagger > 0 && (__float_as_int(par[lpar0 - 1]) & 1))
-    for (int i = 0; i < args.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-
-  const int64_t n_units = (args.n + Pw - 1) / Pw;
-  // Units come from a counter (args.unit_counter, zero at launch) when there is one: the two waves of a SIMD do not share it evenly
-  // (the older wave slot wins the arbitration: with a fixed stride half the waves are done at 0.72 of the launch and their partners
-  // finish alone).  The ticket of the unit after the next one is requested a whole unit ahead, so its round trip is never waited for;
-  // which wave computes a unit does not change a bit of the unit's result.
-  const bool dyn = args.unit_counter != nullptr;
-  const int64_t unit_step = (int64_t)gridDim.x * SNV_WAVES;
-  int ticket = 0;
-  int64_t unit0 = (int64_t)blockIdx.x * SNV_WAVES + wave;
-  if (dyn) {
-    if (lane == 0) ticket = atomicAdd(args.unit_counter, 1);
-    unit0 = __builtin_amdgcn_readfirstlane(ticket);
-    if (lane == 0) ticket = atomicAdd(args.unit_counter, 1);
-  }
-  char* imgb = reinterpret_cast<char*>(img);
-  const int chv0 = 4 * kk, chv1 = 16 + 4 * kk;
-
-  f32x4 xr0[TW_NBW], xr1[TW_NBW];
-  float a0[SNV_KSTEPS], a1[SNV_KSTEPS];
-  const int first_layer = PHASE == 1 ? 0 : 4;
-  const int last_layer = PHASE == 1 ? 3 : SNV_NLAYER - 1;
-  FragSrc fsrc;
-  fsrc.wf = uniform_rsrc(tw.wfrag4);
-  fsrc.lane16 = 16u * (uint32_t)lane;
-  fsrc.layer_bytes = (uint32_t)first_layer * SNV_WFRAG * 4u;
-#pragma unroll
-  for (int g4 = 0; g4 < SNV_KSTEPS / 4; ++g4) load_frag4(a0, a1, fsrc, g4);
-  const WaveAddr sa_a = wave_setup(g, PHASE == 1 ? 0 : 1, Pw, n16, kk, dump0);
-  if (PHASE == 1) wave_request_x0(args, g, Pw, x0_cols, x0c, xr0, xr1, unit0, n_units, n16, kk);
-  const bool do_head = PHASE == 2 && args.tw_last == 1 && args.tw_first == 1;
-  bool tile_ready = false;      // PHASE 2: the residual registers hold this unit's input tile (requested during the previous unit)
-  XReq xoff;
-  xoff.base = uniform_rsrc(args.x0);
-  xoff.dSc = g.dSc[0];
-  xoff.Sc = (uint32_t)g.Sc[0];
-  xoff.L = (uint32_t)g.L[0];
-  xoff.rows = (uint32_t)Pw;
-  xoff.x0_cols = (uint32_t)x0_cols;
-  xoff.lane_col = (uint32_t)n16;
-  xoff.kk16 = 16u * (uint32_t)kk;
-  xoff.on = false;
-
-  for (int64_t unit = unit0, next_unit = 0; unit < n_units; unit = next_unit) {
-    const int64_t row0 = unit * Pw;
-    if (dyn) {
-      next_unit = __builtin_amdgcn_readfirstlane(ticket);
-      if (lane == 0) ticket = atomicAdd(args.unit_counter, 1);
-    } else {
-      next_unit = unit + unit_step;
-    }
-    // ------------------------------------------------------------------ entry
-    if (PHASE == 1) {
-      const f32x4 es0 = ld4(par + EX_RB1_ENTRY * 32 + chv0), et0 = ld4(par + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv0);
-      const f32x4 es1 = ld4(par + EX_RB1_ENTRY * 32 + chv1), et1 = ld4(par + (EX_COUNT + EX_RB1_ENTRY) * 32 + chv1);
-      // the gap columns were zeroed when the kernel started and nothing stores into them (their lanes aim at the dump slots)
-#pragma unroll
-      for (int b = 0; b < TW_NBW; ++b)
-        if (b < (NBA > 0 ? NBA : g.nb[0])) {
-          const bool v = (sa_a.vmask >> b) & 1u;
-          lds_st4(imgb, v ? sa_a.wr[0] + TW_BLK * b : sa_a.dump, relu_bn_pk(xr0[b], es0, et0));
-          lds_st4(imgb, v ? sa_a.wr[1] + TW_BLK * b : sa_a.dump, relu_bn_pk(xr1[b], es1, et1));
-        }
-    } else {
-      // second conv stage: its input was pooled (and BN-mapped) by the first-stage launch: s3[row][column][32], the layout of x0.
-      // Task t = (site, column, 16-byte chunk) in memory order; lane l takes tasks l, l + 64, ...: coalesced 1 KB per load.
-      const int Lout = g.L[1], ScO = g.Sc[1];
-      const int total = Pw * Lout * 8;
-      if (!tile_ready) {      // first unit of the wave, or a ragged unit: loads guarded by the descriptor's range (the bytes of the
-        // unit's sites that exist: pieces behind them read as zero) -- 64-bit lane pointers were unit-invariant, got hoisted out of the
-        // unit loop and spilled (7 / 11 scratch slots of the two short-stage instances)
-        const int64_t left = args.n - row0;
-        const uint32_t bytes = (uint32_t)(left < Pw ? left : Pw) * (uint32_t)Lout * 128u;
-        const __amdgpu_buffer_rsrc_t rs =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.s3[tw_i] + (size_t)row0 * Lout * 32), 0, (int)bytes, 0x00020000);
-        uint32_t l16 = 16u * (uint32_t)lane;
-        asm volatile("" : "+v"(l16));
-#pragma unroll
-        for (int u = 0; u < 2 * TW_NBW; ++u) {
-          const f32x4 v = 64 * u < total ? buf_ld4(rs, l16 + 1024u * u) : splat(0.f);
-          if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
-        }
-      }
-      // the destinations are unit-invariant: left to the backend they are worked out once per launch, 15 registers of which half
-      // get spilled and come back one scratch load + full vmcnt drain per store (5 us per unit); an opaque lane index keeps the
-      // dozen instructions per round inside the loop
-      int lane_o = lane;
-      asm volatile("" : "+v"(lane_o));
-#pragma unroll
-      for (int u = 0; u < 2 * TW_NBW; ++u) {
-        const int task = 64 * u + lane_o;
-        if (task < total) {
-          const uint32_t pj = (uint32_t)task >> 3;
-          const uint32_t p = g.dL[1].div(pj);
-          const int jo = (int)(pj - p * (uint32_t)Lout);
-          st4(img + lds_off(1 + (int)p * ScO + jo + 1, task & 7), u < TW_NBW ? xr0[u] : xr1[u - TW_NBW]);
-        }
-      }
-      wave_zero_gaps(img, g, 1, Pw, lane_o);      // (opaque lane index: the gap addresses are unit-invariant too)
-      if (do_head) {      // large-tower and local logits of this unit -> LDS (range-guarded descriptors: no 64-bit lane pointers)
-        const int64_t left = args.n - row0;
-        const uint32_t rows = (uint32_t)(left < Pw ? left : Pw);
-        const __amdgpu_buffer_rsrc_t xl =
-            __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.xlogit + (size_t)row0 * SNV_MAXCLASS), 0, (int)(rows * SNV_MAXCLASS * 4u), 0x00020000);
-        const __amdgpu_buffer_rsrc_t ll = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<float*>(args.has_local ? args.local_logits + (size_t)row0 * args.n_class : args.xlogit), 0,
-            args.has_local ? (int)(rows * (uint32_t)args.n_class * 4u) : 0, 0x00020000);
-        for (int t = lane_o; t < Pw * args.n_class; t += 64) {
-          const int p = t / args.n_class, k = t - p * args.n_class;
-          logit[p * SNV_MAXCLASS + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xl, 4u * (uint32_t)(p * SNV_MAXCLASS + k), 0, 0));
-          logit[(2 * Pw + p) * SNV_MAXCLASS + k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ll, 4u * (uint32_t)t, 0, 0));
-        }
-      }
-    }
-
-    SNVW_STAMP(1);      // entry: activations landed, image written
-    // ------------------------------------------------------------------ the convs
-    // one layer of the launch's main stage; FINAL = last layer of a first-stage launch (see conv_layer_wave)
-    auto run_layer = [&](int layer, auto mode_tag, auto final_tag, const WaveAddr& sa, auto nb_tag, int nb, const XReq& xq) {
-      constexpr int MODE = decltype(mode_tag)::value;      // MODE_GENERIC: the layers of a loop share one body (role from LayerK)
-      constexpr bool FINAL = decltype(final_tag)::value;
-      constexpr int NBX = decltype(nb_tag)::value;
-      constexpr bool USEX = !(PHASE == 2 && FINAL);      // conv3 starts from its bias (MODE_FINAL: kr == 0)
-      const LayerK lk = layer_consts(layer_mode(layer));
-      int lofs = lpar0 + (layer - first_layer) * 3 * SNV_C;
-      asm volatile("" : "+s"(lofs));      // opaque: these loads are unit-invariant for the layers outside a loop, and hoisted out
-      const float* lp = par + lofs;       // of the unit loop they would hold 24 registers per layer for the whole launch
-      const f32x4 pb[2] = {ld4(lp + chv0), ld4(lp + chv1)};
-      const f32x4 ps[2] = {ld4(lp + SNV_C + chv0), ld4(lp + SNV_C + chv1)};
-      const f32x4 pt[2] = {ld4(lp + 2 * SNV_C + chv0), ld4(lp + 2 * SNV_C + chv1)};
-      const int ln = layer < last_layer ? layer + 1 : first_layer;      // the last layer fetches the next unit's first layer
-      FragSrc wn = fsrc;
-      wn.layer_bytes = (uint32_t)ln * SNV_WFRAG * 4u;
-      conv_layer_any<NBX, FINAL, USEX, MODE>(imgb, sa, nb, lk, a0, a1, wn, pb, ps, pt, xr0, xr1, xq);
-    };
-    using TagA = std::integral_constant<int, NBA>;
-    using TagB = std::integral_constant<int, NBB>;
-    if (PHASE == 1) {
-      for (int layer = 0; layer < 3; ++layer) run_layer(layer, ModeTag<MODE_GENERIC>{}, std::false_type{}, sa_a, TagA{}, g.nb[0], xoff);
-      SNVW_STAMP(2);      // convs but the last
-      // last layer: block by block the dying residual registers take the next unit's stage-1 activations (a whole next unit;
-      // a ragged or missing one is requested the guarded way behind the layer)
-      const int64_t nu = next_unit;
-      XReq xq = xoff;
-      xq.on = nu < n_units && (nu + 1) * Pw <= args.n;
-      if (xq.on) {
-        xq.base = uniform_rsrc(args.x0 + wave_x0_column(args, nu * Pw, x0_cols, x0c) * 32);
-        uint32_t lc = (uint32_t)n16;
-        asm volatile("" : "+v"(lc));      // opaque: the lane offsets are worked out block by block, not kept for the launch
-        xq.lane_col = lc;
-      }
-      run_layer(3, ModeTag<MODE_RES_LAST>{}, std::true_type{}, sa_a, TagA{}, g.nb[0], xq);
-      if (!xq.on) wave_request_x0(args, g, Pw, x0_cols, x0c, xr0, xr1, nu, n_units, n16, kk);
-      SNVW_STAMP(3);      // last conv
-    } else {
-      run_layer(4, ModeTag<MODE_ENTRY>{}, std::false_type{}, sa_a, TagA{}, g.nb[1], xoff);      // the one layer with kx == 0
-      for (int layer = 5; layer < 9; ++layer) run_layer(layer, ModeTag<MODE_GENERIC>{}, std::false_type{}, sa_a, TagA{}, g.nb[1], xoff);
-      SNVW_STAMP(2);
-      {
-        // the residual registers are dead from here on: the next unit's input tile travels in them under the pooling, the last
-        // conv, the global max and the head (a whole next unit; a ragged one is loaded the guarded way at its entry)
-        const int64_t nu = next_unit;
-        tile_ready = nu < n_units && (nu + 1) * Pw <= args.n;
-        if (tile_ready) {
-          const int total = Pw * g.L[1] * 8;
-          const __amdgpu_buffer_rsrc_t rs = uniform_rsrc(args.s3[tw_i] + (size_t)nu * Pw * g.L[1] * 32);
-          // ONE (opaque) lane offset + a scalar offset per round: per-round lane offsets are unit-invariant, get hoisted out of the
-          // unit loop, spilled, and reloaded in front of every load with a full vmcnt drain
-          uint32_t lane16 = 16u * (uint32_t)lane;
-          asm volatile("" : "+v"(lane16));
-#pragma unroll
-          for (int u = 0; u < 2 * TW_NBW; ++u) {
-            if (64 * (u + 1) <= total) {      // whole round (wave-uniform)
-              const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane16, 1024u * (uint32_t)u, 0));
-              if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
-            } else if (64 * u < total) {      // last, partial round: lanes behind the last task read the tile's first bytes
-              const f32x4 v = buf_ld4(rs, 64 * u + lane < total ? lane16 + 1024u * (uint32_t)u : 0u);
-              if (u < TW_NBW) xr0[u] = v; else xr1[u - TW_NBW] = v;
-            }
-          }
-        }
-      }
-      {
-        // max-pool 3 (raw y in the image) + BN -> the last stage's geometry, in place: every output column lies at or below the
-        // first column of its own window and above the windows of all earlier outputs, and a round's reads precede its writes
-        const int Lin = g.L[1], Lout = g.L[2], ScI = g.Sc[1], ScO = g.Sc[2];
-        const int pk = g.pk[2], pst = g.ps[2], pp = g.pp[2];
-        const int total = Pw * Lout * 8;
-        int cg = lane & 7;
-        asm volatile("" : "+v"(cg));      // opaque: the two constant addresses below are unit-invariant (hoisted, spilled, reloaded per unit)
-        const f32x4 pool_s = ld4(par + EX_BN_OUT * 32 + 4 * cg), pool_t = ld4(par + (EX_COUNT + EX_BN_OUT) * 32 + 4 * cg);
-        for (int task = lane; task < total; task += 64) {
-          const uint32_t pj = (uint32_t)task >> 3;
-          const uint32_t p = g.dL[2].div(pj);
-          const int jo = (int)(pj - p * (uint32_t)Lout);
-          const int jlo = jo * pst - pp;
-          const int lo = jlo < 0 ? 0 : jlo;
-          const int hi = (jlo + pk - 1) < (Lin - 1) ? (jlo + pk - 1) : (Lin - 1);
-          f32x4 m = splat(-INFINITY);
-          for (int w = 0; w < pk; ++w) {
-            int j = jlo + w;
-            j = j < lo ? lo : (j > hi ? hi : j);
-            m = max4(m, ld4(img + lds_off(1 + (int)p * ScI + j + 1, cg)));
-          }
-          m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
-                    fmaf(pool_s.w, m.w, pool_t.w)};
-          st4(img + lds_off(1 + (int)p * ScO + jo + 1, cg), m);
-        }
-        wave_zero_gaps(img, g, 2, Pw, lane);
-      }
-      const WaveAddr sa_b = wave_setup(g, 2, Pw, n16, kk, dump0);
-      SNVW_STAMP(3);      // max-pool 3
-      run_layer(9, ModeTag<MODE_FINAL>{}, std::true_type{}, sa_b, TagB{}, g.nb[2], xoff);
-      SNVW_STAMP(4);      // last conv
-    }
-
-    if (PHASE == 1) {
-      // max-pool 2 (raw y in the image) + BN -> s3[row][column][32] for the short-stage launch
-      const int Lin = g.L[0], Lout = g.L[1], ScI = g.Sc[0];
-      const int pk = g.pk[1], pst = g.ps[1], pp = g.pp[1];
-      const int total = Pw * Lout * 8;
-      const int cg = lane & 7;
-      const f32x4 pool_s = ld4(par + EX_BN_MID * 32 + 4 * cg), pool_t = ld4(par + (EX_COUNT + EX_BN_MID) * 32 + 4 * cg);
-      for (int task = lane; task < total; task += 64) {
-        const uint32_t pj = (uint32_t)task >> 3;
-        const uint32_t p = g.dL[1].div(pj);
-        const int jo = (int)(pj - p * (uint32_t)Lout);
-        const int jlo = jo * pst - pp;
-        const int lo = jlo < 0 ? 0 : jlo;
-        const int hi = (jlo + pk - 1) < (Lin - 1) ? (jlo + pk - 1) : (Lin - 1);
-        f32x4 v[7];
-#pragma unroll
-        for (int w = 0; w < 7; ++w) {      // the model's pools are 7- and 3-wide: all reads in flight together
-          int j = jlo + w;
-          j = j < lo ? lo : (j > hi ? hi : j);
-          v[w] = ld4(img + lds_off(1 + (int)p * ScI + j + 1, cg));
-        }
-        f32x4 m = max4(max4(max4(v[0], v[1]), max4(v[2], v[3])), max4(max4(v[4], v[5]), v[6]));
-        for (int w = 7; w < pk; ++w) {
-          const int j = jlo + w;
-          if (j < 0 || j >= Lin) continue;
-          m = max4(m, ld4(img + lds_off(1 + (int)p * ScI + j + 1, cg)));
-        }
-        m = f32x4{fmaf(pool_s.x, m.x, pool_t.x), fmaf(pool_s.y, m.y, pool_t.y), fmaf(pool_s.z, m.z, pool_t.z),
-                  fmaf(pool_s.w, m.w, pool_t.w)};
-        if (row0 + p < args.n) st4(args.s3[tw_i] + ((size_t)(row0 + p) * Lout + jo) * 32 + 4 * cg, m);
-      }
-      SNVW_STAMP(4);      // max-pool 2 + store
-      continue;
-    }
-
-    // ------------------------------------------------------------------ global max per (site, channel), fc, head
-    {
-      const int L4 = g.L[2], Sc4 = g.Sc[2];
-      for (int t = lane; t < Pw * SNV_C; t += 64) {
-        const int p = t >> 5, ch = t & 31;
-        float v[8];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {      // L4 is 7 / 8 at R = 1000; short rows repeat their last column
-          const int pc = 1 + p * Sc4 + (j < L4 ? j : L4 - 1) + 1;
-          v[j] = img[lds_off(pc, ch >> 2) + (ch & 3)];
-        }
-        float m = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-        for (int j = 8; j < L4; ++j) m = fmaxf(m, img[lds_off(1 + p * Sc4 + j + 1, ch >> 2) + (ch & 3)]);
-        feat[t] = m;
-      }
-      const int slot = do_head ? 1 : 0;      // logit[0]: large tower, [1]: mid, [2]: local
-      for (int t = lane; t < Pw * args.n_class; t += 64) {
-        const int p = t / args.n_class, k = t - p * args.n_class;
-        const float* w = par + 2 * EX_COUNT * SNV_C + k * SNV_C;
-        const float* f = feat + p * SNV_C;
-        float acc = par[2 * EX_COUNT * SNV_C + args.n_class * SNV_C + k];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          const f32x4 wv = ld4(w + 4 * q), fv = ld4(f + 4 * q);
-          acc = fmaf(wv.x, fv.x, acc);
-          acc = fmaf(wv.y, fv.y, acc);
-          acc = fmaf(wv.z, fv.z, acc);
-          acc = fmaf(wv.w, fv.w, acc);
-        }
-        if (!do_head) {      // large tower: hand the logits to the launch that runs the mid tower and the head (a descriptor over the
-          // rows of the unit that exist: no 64-bit lane pointer to hoist and spill, stores behind the last site are dropped)
-          const int64_t left = args.n - row0;
-          const __amdgpu_buffer_rsrc_t xo = __builtin_amdgcn_make_buffer_rsrc(
-              args.xlogit + (size_t)row0 * SNV_MAXCLASS, 0, (int)((uint32_t)(left < Pw ? left : Pw) * SNV_MAXCLASS * 4u), 0x00020000);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, acc), xo, 4u * (uint32_t)(p * SNV_MAXCLASS + k), 0, 0);
-        } else {
-          logit[(slot * Pw + p) * SNV_MAXCLASS + k] = acc;
-        }
-      }
-      if (!do_head) continue;
-      // head (model_snv.py:515-523 / :284)
-      for (int t = lane; t < Pw * args.n_class; t += 64) {
-        const int nc = args.n_class;
-        const int p = t / nc, k = t - p * nc;
-        float pr[3];
-#pragma unroll 1
-        for (int v = 0; v < 3; ++v) {
-          float lg[SNV_MAXCLASS];
-#pragma unroll
-          for (int q = 0; q < SNV_MAXCLASS; ++q) lg[q] = logit[(v * Pw + p) * SNV_MAXCLASS + (q < nc ? q : 0)];
-          float mx = -INFINITY, own = 0.f;
-#pragma unroll
-          for (int q = 0; q < SNV_MAXCLASS; ++q)
-            if (q < nc) mx = fmaxf(mx, lg[q]);
-          float sum = 0.f;
-#pragma unroll
-          for (int q = 0; q < SNV_MAXCLASS; ++q)
-            if (q < nc) {
-              const float e = __expf(lg[q] - mx);
-              sum += e;
-              own = (q == k) ? e : own;
-            }
-          pr[v] = own / sum;
-        }
-        float prob = (pr[1] + pr[0]) / 2.f;
-        if (args.has_local) prob = (pr[2] + prob) / 2.f;
-        float res = __logf(fmaxf(prob, 1e-9f));
-        if (args.status != nullptr && *args.status != 0) res = __uint_as_float(0x7FC00000u);   // flagged encoding error: loud output
-        {
-          const int64_t left = args.n - row0;
-          const __amdgpu_buffer_rsrc_t oo = __builtin_amdgcn_make_buffer_rsrc(
-              args.out + (size_t)row0 * nc, 0, (int)((uint32_t)(left < Pw ? left : Pw) * (uint32_t)nc * 4u), 0x00020000);
-          __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(uint32_t, res), oo, 4u * (uint32_t)t, 0, 0);
-        }
-      }
-    }
-    SNVW_STAMP(5);      // global max, fc, head
-  }
-  if (args.stamps != nullptr && lane == 0)
-    args.stamps[(size_t)(1024 + 2 * blockIdx.x + (wave >> 1)) * 32 + ((PHASE - 1) * 2 + tw_i) * 4 + 2 * (wave & 1) + 1] = __builtin_amdgcn_s_memrealtime();
+#define SNVW_BX blockIdx.x
+#define SNVW_GX gridDim.x
+#include "snv_tower_wave_body.inc"
 }
+#undef SNVW_BX
+#undef SNVW_GX
+
+// Up to three first-stage jobs of ONE instance in one launch (blockIdx.y = job; a workgroup beyond its job's grid leaves at once): the
+// long-window path's three launches of this stage -- the large tower's equal segments, its last segment, the mid tower -- each paid
+// ~14 us of start-up for 22 us of work per unit at a few hundred windows per call.  Same body, the job's own workgroup count as the stride.
+struct SnvFwdJobs {
+  SnvFwdArgs j[3];
+  int grid[3];
+};
+static_assert(sizeof(SnvFwdJobs) <= 4096, "kernel arguments: 4 KB");
+#define SNVW_BX bx_job
+#define SNVW_GX gx_job
+template <int PHASE, int NBA, int NBB, int TWC = -1, int PWC = 0>
+__global__ __launch_bounds__(SNV_THREADS, 2) void snv_tower_wave_jobs(const SnvFwdJobs jobs) {
+  const SnvFwdArgs& args = jobs.j[blockIdx.y];
+  const unsigned gx_job = (unsigned)jobs.grid[blockIdx.y];
+  const unsigned bx_job = blockIdx.x;
+  if (bx_job >= gx_job) return;
+#include "snv_tower_wave_body.inc"
+}
+#undef SNVW_BX
+#undef SNVW_GX
 
 // ====================================================================================================================
 // Edge tiles of the cross-position reuse path (snv_reuse.hip) in the wave-private form: a wave owns
@@ -1108,6 +732,42 @@ size_t plan_wave_geometry(SnvFwdArgs& a, int Lwin, int Pw, int n_class, int towe
   const size_t par = (size_t)(2 * EX_COUNT * SNV_C + n_class * SNV_C + SNV_MAXCLASS + 4 + 6 * 3 * SNV_C);
   const size_t per_wave = (size_t)a.nbuf + (phase == 2 ? (size_t)Pw * SNV_C + 3 * (size_t)Pw * SNV_MAXCLASS : 0) + TW_DUMP;
   return (par + SNV_WAVES * per_wave) * 4;
+}
+
+// n <= 3 first-stage launches of the run-time-geometry instance as ONE launch (snv_tower_wave_jobs); a job without units is dropped
+int launch_snv_tower_wave_jobs(const SnvFwdArgs* jobs_in, const size_t* lds_bytes, int n, hipStream_t stream) {
+  MURAL_REQUIRE(n >= 1 && n <= 3, "wave-private tower launch: %d jobs", n);
+  SnvFwdJobs jobs;
+  std::memset(&jobs, 0, sizeof(jobs));
+  int gx = 0, ny = 0;
+  size_t lds = 0;
+  int64_t wg_of[3] = {0, 0, 0};
+  for (int i = 0; i < n; ++i) {
+    const SnvFwdArgs& a = jobs_in[i];
+    MURAL_REQUIRE(a.phase == 1 && a.Lwin != SHIP_LWIN, "wave-private tower jobs: first-stage launches of the run-time-geometry instance only");
+    const int64_t n_units = (a.n + a.P - 1) / a.P;
+    const int64_t n_wg = (n_units + SNV_WAVES - 1) / SNV_WAVES;
+    if (n_wg == 0) continue;
+    jobs.j[ny] = a;
+    jobs.j[ny].unit_counter = nullptr;      // units at a fixed stride
+    wg_of[ny] = n_wg;
+    lds = lds_bytes[i] > lds ? lds_bytes[i] : lds;
+    ++ny;
+  }
+  if (ny == 0) return MURAL_OK;
+  // every job gets what a launch of its own would: up to 512 workgroups (two per CU are resident; the hardware hands the later jobs'
+  // workgroups the slots the earlier ones free).  Sharing 512 workgroups between the jobs in proportion to their units -- every wave
+  // the same number of units, nothing waiting for a slot -- measured SLOWER (0.56 -> 0.48 at 2048 windows): the jobs' units do not cost
+  // the same, and a fixed split cannot even that out.
+  for (int i = 0; i < ny; ++i) {
+    jobs.grid[i] = (int)(wg_of[i] < 512 ? wg_of[i] : 512);
+    gx = jobs.grid[i] > gx ? jobs.grid[i] : gx;
+  }
+  static DynLdsOnce big_lds;
+  if (int rc = big_lds.ensure(&snv_tower_wave_jobs<1, 9, 0>)) return rc;
+  hipLaunchKernelGGL((snv_tower_wave_jobs<1, 9, 0>), dim3(gx, ny), dim3(SNV_THREADS), lds, stream, jobs);
+  MURAL_HIP_CHECK(hipGetLastError());
+  return MURAL_OK;
 }
 
 int launch_snv_tower_wave(const SnvFwdArgs& a_in, size_t lds_bytes, hipStream_t stream) {
